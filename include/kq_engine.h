@@ -1,0 +1,277 @@
+/*
+ * kq_engine.h — C ABI of the MI355X-native admission / flavor-assignment engine.
+ *
+ * This is the drop-in boundary for ONE path of kubernetes-sigs/kueue: the decision logic of a
+ * scheduling cycle, i.e. what `(*Scheduler).schedule` (pkg/scheduler/scheduler.go:308-386)
+ * computes between `cache.Snapshot()` (step 2) and the side effects of step 5/6:
+ *
+ *   nominate            scheduler.go:665   -> getAssignments :821 -> flavorassigner.Assign
+ *                                             (flavorassigner.go:696) + preemption.GetTargets
+ *                                             (preemption/preemption.go:132)
+ *   makeIterator        scheduler.go:1080  (classical :1110 / fair sharing fair_sharing_iterator.go:39)
+ *   processEntry        scheduler.go:392   (fits :771, AddUsage, overlap skip, DeferredFit ...)
+ *
+ * The reference has no FFI seam (it builds with CGO_ENABLED=0, Makefile:69); the seam is cut here.
+ * Everything crossing the boundary is plain C: pointers + sizes, caller-owned SoA arrays, no
+ * callbacks, no pointers retained after a call returns (cgo pointer-passing rules). The Go-side
+ * binding a maintainer would add is shown in INTEGRATION.md and shim/go/.
+ *
+ * Conventions
+ *   - return 0 on success, negative KQ_E* otherwise; on any error the caller runs the stock Go
+ *     path for that cycle.
+ *   - single caller thread per engine (the scheduler goroutine, runtime.LockOSThread).
+ *   - quantities are int64 in the reference's canonical units (milli-CPU, bytes, counts);
+ *     INT64_MAX is resources.Unlimited (pkg/resources/amount.go:46-60).
+ *   - node index space: ClusterQueues are nodes [0, n_cq), Cohorts are nodes [n_cq, n_cq+n_cohort).
+ *     Both ranges are in CANONICAL ORDER = ascending name (SURVEY.md §8c determinism contract).
+ *   - flavor-resource index fr = flavor * n_resource + resource  (pkg/resources/resource.go:29).
+ */
+#ifndef KQ_ENGINE_H
+#define KQ_ENGINE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KQ_ABI_VERSION 1
+
+/* ---- error codes ---------------------------------------------------------------------------- */
+#define KQ_OK             0
+#define KQ_EINVAL        (-1)  /* malformed input (bad index, cycle in cohort tree, ...)        */
+#define KQ_ENOMEM        (-2)
+#define KQ_EDEVICE       (-3)  /* HIP error; kq_strerror() carries the hipGetErrorString        */
+#define KQ_EUNSUPPORTED  (-4)  /* input uses a feature the device path does not implement       */
+#define KQ_ECAPACITY     (-5)  /* caller-provided output buffer too small (targets)             */
+#define KQ_ENODEVICE     (-6)  /* no HIP device / extension not usable                          */
+
+/* ---- quantities ----------------------------------------------------------------------------- */
+#define KQ_UNLIMITED   INT64_MAX  /* resources.Unlimited, amount.go:56                           */
+#define KQ_NIL_LIMIT   (-1)       /* nil BorrowingLimit / LendingLimit (resource.go:26-33)       */
+
+/* ---- quota_flags[node*n_fr+fr] -------------------------------------------------------------- */
+#define KQ_QF_QUOTA    0x1  /* fr is a key of resourceNode.Quotas        (resource_node.go:33)  */
+#define KQ_QF_SUBTREE  0x2  /* fr is a key of resourceNode.SubtreeQuota  (resource_node.go:38)  */
+
+/* ---- per-ClusterQueue policy word (clusterqueue_snapshot.go:53-66) -------------------------- */
+/* bits 0-1  Preemption.WithinClusterQueue : 0 Never 1 LowerPriority 2 LowerOrNewerEqualPriority */
+/* bits 2-3  Preemption.ReclaimWithinCohort: 0 Never 1 LowerPriority 2 LowerOrNewerEqualPriority 3 Any */
+/* bit  4    Preemption.BorrowWithinCohort.Policy : 0 Never(or nil) 1 LowerPriority              */
+/* bit  5    BorrowWithinCohort.MaxPriorityThreshold != nil (value in cq_borrow_prio_threshold)  */
+/* bit  6    FlavorFungibility.WhenCanBorrow  : 0 MayStopSearch(=Borrow) 1 TryNextFlavor         */
+/* bit  7    FlavorFungibility.WhenCanPreempt : 0 MayStopSearch(=Preempt) 1 TryNextFlavor        */
+/* bits 8-9  FlavorFungibility.Preference : 0 nil 1 BorrowingOverPreemption 2 PreemptionOverBorrowing */
+/* bit  10   QueueingStrategy : 0 BestEffortFIFO 1 StrictFIFO                                    */
+#define KQ_POL_WITHIN_CQ(p)        ((p) & 0x3u)
+#define KQ_POL_RECLAIM(p)          (((p) >> 2) & 0x3u)
+#define KQ_POL_BORROW_WITHIN(p)    (((p) >> 4) & 0x1u)
+#define KQ_POL_HAS_THRESHOLD(p)    (((p) >> 5) & 0x1u)
+#define KQ_POL_BORROW_TRYNEXT(p)   (((p) >> 6) & 0x1u)
+#define KQ_POL_PREEMPT_TRYNEXT(p)  (((p) >> 7) & 0x1u)
+#define KQ_POL_PREFERENCE(p)       (((p) >> 8) & 0x3u)
+#define KQ_POL_STRICT_FIFO(p)      (((p) >> 10) & 0x1u)
+#define KQ_POLICY_NEVER 0
+#define KQ_POLICY_LOWER_PRIORITY 1
+#define KQ_POLICY_LOWER_OR_NEWER_EQUAL 2
+#define KQ_POLICY_ANY 3
+#define KQ_PREF_NONE 0
+#define KQ_PREF_BORROWING_OVER_PREEMPTION 1
+#define KQ_PREF_PREEMPTION_OVER_BORROWING 2
+
+/* ---- feature gates (pkg/features/kube_features.go:612-910); KQ_GATES_DEFAULT = upstream ----- */
+#define KQ_GATE_FLAVOR_FUNGIBILITY            (1u << 0)
+#define KQ_GATE_PRESERVE_SCAN_PROGRESS        (1u << 1)  /* FlavorFungibilityPreserveScanProgress */
+#define KQ_GATE_PARTIAL_ADMISSION             (1u << 2)
+#define KQ_GATE_PRIORITY_SORTING_IN_COHORT    (1u << 3)  /* PrioritySortingWithinCohort           */
+#define KQ_GATE_FS_PREEMPT_WITHIN_NOMINAL     (1u << 4)  /* FairSharingPreemptWithinNominal       */
+#define KQ_GATE_FS_PRIORITIZE_NON_BORROWING   (1u << 5)  /* FairSharingPrioritizeNonBorrowing     */
+#define KQ_GATE_RECOMPUTE_ON_OVERLAP          (1u << 6)  /* RecomputeAssignmentUponPreemptionTargetsOverlap */
+#define KQ_GATE_PRIORITIZE_PREEMPTORS         (1u << 7)  /* PrioritizePreemptorWorkloads (off)    */
+#define KQ_GATE_QUOTA_CHECK_STRATEGY          (1u << 8)
+#define KQ_GATES_DEFAULT (KQ_GATE_FLAVOR_FUNGIBILITY | KQ_GATE_PRESERVE_SCAN_PROGRESS |            \
+                          KQ_GATE_PARTIAL_ADMISSION | KQ_GATE_PRIORITY_SORTING_IN_COHORT |         \
+                          KQ_GATE_FS_PREEMPT_WITHIN_NOMINAL | KQ_GATE_FS_PRIORITIZE_NON_BORROWING |\
+                          KQ_GATE_RECOMPUTE_ON_OVERLAP | KQ_GATE_QUOTA_CHECK_STRATEGY)
+
+/* fair-sharing preemption strategies (apis/config/v1beta2; preemption.go:363-379) */
+#define KQ_FS_LESS_THAN_OR_EQUAL_TO_FINAL_SHARE 0  /* rule S2-a */
+#define KQ_FS_LESS_THAN_INITIAL_SHARE           1  /* rule S2-b */
+
+/* configapi.QuotaCheckStrategy */
+#define KQ_QUOTA_CHECK_BLOCK_UNDECLARED  0
+#define KQ_QUOTA_CHECK_IGNORE_UNDECLARED 1
+
+/* Engine configuration = what cmd/kueue/main.go:675-688 passes as scheduler.With* options. */
+typedef struct kq_config {
+  int32_t  abi_version;        /* KQ_ABI_VERSION */
+  int32_t  device;             /* HIP device ordinal */
+  uint32_t gates;              /* KQ_GATE_* ; use KQ_GATES_DEFAULT */
+  int32_t  fair_sharing;       /* fairsharing.Enabled(cfg.FairSharing) */
+  int32_t  n_fs_strategies;    /* 0 => default [S2-a, S2-b] (preemption.go:364-366) */
+  int32_t  fs_strategies[2];
+  int32_t  quota_check_strategy;
+} kq_config;
+
+/* ---- snapshot: what cache.Snapshot() returns (pkg/cache/scheduler/snapshot.go:171), flattened - */
+typedef struct kq_snapshot {
+  int32_t n_cq, n_cohort, n_flavor, n_resource;
+  int32_t pods_resource;            /* index of corev1.ResourcePods in the resource dictionary, -1 if absent */
+  const int32_t* resource_order;    /* [n_resource] rank of each resource under SliceRequests order:
+                                       FNV-1a64(name), then name (pkg/resources/slice_requests.go:35-60) */
+  /* hierarchy (pkg/cache/hierarchy): N = n_cq + n_cohort nodes */
+  const int32_t* parent;            /* [N] node index of the parent Cohort, -1 = none */
+  const int32_t* child_cohort_off;  /* [n_cohort+1] CSR into child_cohort */
+  const int32_t* child_cohort;      /* node ids, ascending name */
+  const int32_t* child_cq_off;      /* [n_cohort+1] CSR into child_cq */
+  const int32_t* child_cq;          /* node ids (= cq index), ascending name */
+  const double*  fair_weight;       /* [N] ClusterQueueSnapshot.FairWeight / CohortSnapshot.FairWeight */
+  /* resourceNode planes, [N * n_fr], n_fr = n_flavor*n_resource (resource_node.go:30-45) */
+  const int64_t* nominal;           /* Quotas[fr].Nominal */
+  const int64_t* borrow_limit;      /* Quotas[fr].BorrowingLimit or KQ_NIL_LIMIT */
+  const int64_t* lend_limit;        /* Quotas[fr].LendingLimit   or KQ_NIL_LIMIT */
+  const int64_t* subtree_quota;     /* SubtreeQuota[fr] */
+  const int64_t* usage;             /* Usage[fr] */
+  const uint8_t* quota_flags;       /* KQ_QF_* */
+  /* per ClusterQueue */
+  const int32_t* cq_rg_off;         /* [n_cq+1] CSR: resource groups of a CQ (ResourceGroups order) */
+  const int32_t* rg_flavor_off;     /* [n_rg+1]  CSR: rg.Flavors in declared order */
+  const int32_t* rg_flavor;         /* flavor indices */
+  const int32_t* rg_res_off;        /* [n_rg+1]  CSR: rg.CoveredResources */
+  const int32_t* rg_res;            /* resource indices */
+  const uint32_t* cq_policy;        /* [n_cq] policy word above */
+  const int32_t* cq_borrow_prio_threshold; /* [n_cq] BorrowWithinCohort.MaxPriorityThreshold */
+  const int64_t* cq_generation;     /* [n_cq] AllocatableResourceGeneration */
+  /* admitted workloads = union of ClusterQueueSnapshot.Workloads, rows grouped by CQ */
+  int32_t n_adm;
+  const int32_t* cq_adm_off;        /* [n_cq+1] rows of CQ c are [cq_adm_off[c], cq_adm_off[c+1]) */
+  const int64_t* adm_priority;      /* priority.EffectivePriority (util/priority/priority.go:77) */
+  const int64_t* adm_queue_ts;      /* Ordering.GetQueueOrderTimestamp, ns (workload.go:1182) */
+  const int64_t* adm_reserve_ts;    /* quotaReservationTime, ns; "now" if absent (common/ordering.go:94) */
+  const uint32_t* adm_uid_rank;     /* rank of Obj.UID under Go bytewise string order (ordering.go:77) */
+  const uint8_t* adm_flags;         /* bit0: workloadevict.IsEvicted */
+  const int32_t* adm_use_off;       /* [n_adm+1] CSR: Info.Usage().Quota.Assigned (workload.go:447) */
+  const int32_t* adm_use_fr;        /* fr index; an entry exists for every (resource -> assigned flavor),
+                                       zero quantities included (WorkloadUsesResources, candidate_generator.go:54) */
+  const int64_t* adm_use_qty;
+} kq_snapshot;
+
+#define KQ_ADM_EVICTED 0x1
+
+/* ---- heads: queues.Heads() (pkg/cache/queue/manager.go:903) after nominate's gatekeeping ------ */
+#define KQ_HEAD_HAS_QUOTA_RESERVATION 0x1  /* workload.HasQuotaReservation (second pass)          */
+#define KQ_HEAD_IS_PREEMPTOR          0x2  /* Head.IsPreemptor                                    */
+#define KQ_HEAD_HAS_LAST_ASSIGNMENT   0x4  /* Info.LastAssignment != nil                          */
+
+typedef struct kq_heads {
+  int32_t n;                        /* number of heads; canonical order = as given (CQ name asc) */
+  int64_t cycle;                    /* Scheduler.schedulingCycle (scheduler.go:97,309) */
+  const int32_t* cq;                /* [n] ClusterQueue index */
+  const int64_t* priority;          /* [n] EffectivePriority */
+  const int64_t* queue_ts;          /* [n] GetQueueOrderTimestamp, ns */
+  const uint32_t* flags;            /* [n] KQ_HEAD_* */
+  const int32_t* ps_off;            /* [n+1] CSR: podsets of a head (Info.TotalRequests, workload.go:245) */
+  /* per podset (n_ps = ps_off[n]) */
+  const int32_t* ps_count;          /* PodSetResources.Count */
+  const int32_t* ps_min_count;      /* PodSet.MinCount, -1 = nil (partial admission) */
+  const int32_t* ps_req_off;        /* [n_ps+1] CSR: PodSetResources.Requests */
+  const int32_t* req_res;           /* resource index */
+  const int64_t* req_qty;           /* total quantity for the whole podset (per-pod x count) */
+  const uint64_t* ps_flavor_ok;     /* [n_ps * n_fwords] bit f = checkFlavorForPodSets passes for flavor f
+                                       (taints / node affinity / TAS match, flavorassigner.go:1212-1261);
+                                       n_fwords = (n_flavor+63)/64 */
+  const int32_t* ps_last_tried;     /* [n_ps * n_resource] LastAssignment.LastTriedFlavorIdx[ps][res],
+                                       -1 = absent (workload.go:226-238) */
+  const int64_t* last_generation;   /* [n] LastAssignment.ClusterQueueGeneration */
+  const int64_t* last_cycle;        /* [n] LastAssignment.SchedulingCycle */
+  const uint64_t* last_hash;        /* [n] LastAssignment.SchedulingHash (0 = unknown) */
+  const uint64_t* hash;             /* [n] Info.SchedulingHash (0 = unknown) */
+} kq_heads;
+
+/* ---- decisions -------------------------------------------------------------------------------- */
+/* flavorassigner.FlavorAssignmentMode (flavorassigner.go:453-472) */
+#define KQ_MODE_NOFIT        0
+#define KQ_MODE_PREEMPT      1
+#define KQ_MODE_DEFERRED_FIT 2
+#define KQ_MODE_FIT          3
+/* entryStatus (scheduler.go:617-630) */
+#define KQ_ST_NOT_NOMINATED  0
+#define KQ_ST_NOMINATED      1
+#define KQ_ST_SKIPPED        2
+#define KQ_ST_ASSUMED        5
+/* qcache.RequeueReason (cluster_queue.go:54-65) */
+#define KQ_RQ_GENERIC                  0
+#define KQ_RQ_FAILED_AFTER_NOMINATION  1
+#define KQ_RQ_PENDING_PREEMPTION       4
+#define KQ_RQ_NOFIT                    7
+#define KQ_RQ_PREEMPTION_NO_CANDIDATES 8
+/* what the Go side has to do for this entry */
+#define KQ_ACT_NONE     0  /* requeueAndUpdate only */
+#define KQ_ACT_ADMIT    1  /* Scheduler.admit (scheduler.go:991) */
+#define KQ_ACT_PREEMPT  2  /* Scheduler.issuePreemptions (scheduler.go:563) on targets */
+/* why an entry was skipped (inadmissibleMsg selector, scheduler.go:470-481) */
+#define KQ_SKIP_NONE            0
+#define KQ_SKIP_OVERLAP         1  /* "Workload has overlapping preemption targets with another workload" */
+#define KQ_SKIP_NO_LONGER_FITS  2  /* "Workload no longer fits after processing another workload" */
+/* preemption reasons (apis/kueue/v1beta2 workload_types.go; hierarchical_preemption.go:46-58) */
+#define KQ_REASON_IN_CLUSTER_QUEUE               0
+#define KQ_REASON_IN_COHORT_RECLAMATION          1
+#define KQ_REASON_IN_COHORT_FAIR_SHARING         2
+#define KQ_REASON_IN_COHORT_RECLAIM_WHILE_BORROWING 3
+
+typedef struct kq_decisions {
+  /* per head [n] */
+  uint8_t* status;          /* KQ_ST_*   */
+  uint8_t* action;          /* KQ_ACT_*  */
+  uint8_t* nominated_mode;  /* Assignment.RepresentativeMode() after nominate */
+  uint8_t* mode;            /* RepresentativeMode() when processEntry decided (may be DeferredFit) */
+  uint8_t* requeue_reason;  /* KQ_RQ_* as passed to queues.RequeueWorkload */
+  uint8_t* skip;            /* KQ_SKIP_* */
+  int32_t* borrowing;       /* Assignment.Borrowing */
+  int32_t* order;           /* position in the entry iterator (0-based) */
+  /* per (podset, resource) [n_ps * n_resource] */
+  int32_t* flavor;          /* assigned flavor index, -1 = none */
+  uint8_t* res_mode;        /* FlavorAssignment.Mode */
+  int32_t* tried_idx;       /* FlavorAssignment.TriedFlavorIdx -> next LastAssignment */
+  /* per podset [n_ps] */
+  int32_t* ps_count;        /* PodSetAssignment.Count (differs from input under partial admission) */
+  /* preemption targets, CSR over heads */
+  int32_t* tgt_off;         /* [n+1] */
+  int32_t  tgt_cap;         /* capacity of tgt_adm / tgt_reason */
+  int32_t* tgt_adm;         /* admitted-workload row */
+  uint8_t* tgt_reason;      /* KQ_REASON_* */
+} kq_decisions;
+
+typedef struct kq_engine kq_engine;
+
+/* scheduler.New (scheduler.go:182): build an engine bound to one HIP device. */
+int  kq_engine_create(const kq_config* cfg, kq_engine** out);
+void kq_engine_destroy(kq_engine* e);
+
+/* cache.Snapshot (snapshot.go:171): upload a full snapshot into HBM. The engine copies; the
+ * caller may free its arrays on return. */
+int  kq_snapshot_put(kq_engine* e, const kq_snapshot* s);
+
+/* One scheduling cycle: nominate + iterator + processEntry (scheduler.go:308-386, steps 3-5).
+ * Synchronous. `out` arrays are caller-allocated, sized from `h`. The uploaded snapshot is left
+ * unchanged (the reference mutates a per-cycle copy). */
+int  kq_cycle_run(kq_engine* e, const kq_heads* h, kq_decisions* out);
+
+/* Device time (ms, hipEvent) of the kernels of the last kq_cycle_run, and its algorithmic bytes. */
+int  kq_last_cycle_stats(kq_engine* e, double* kernel_ms, int64_t* algorithmic_bytes);
+
+/* Recompute SubtreeQuota of every node and Usage of every Cohort from Quotas + CQ usage, as
+ * updateCohortResourceNode / accumulateFromChild do (resource_node.go:183-230). Operates on the
+ * uploaded snapshot; results readable through kq_snapshot_read_planes. */
+int  kq_snapshot_derive(kq_engine* e);
+int  kq_snapshot_read_planes(kq_engine* e, int64_t* subtree_quota, int64_t* usage, uint8_t* quota_flags);
+
+const char* kq_strerror(int code);
+const char* kq_last_error(kq_engine* e);
+int  kq_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KQ_ENGINE_H */

@@ -1,0 +1,579 @@
+"""Host-side mirror of the reference types that feed the scheduling cycle, and their flattening
+into the SoA boundary of include/kq_engine.h.
+
+Names follow the reference (ClusterQueue, Cohort, ResourceFlavor, FlavorQuotas, Workload, PodSet,
+Admission ...), so parity tests read like the reference's own table tests
+(pkg/util/testing/v1beta2/wrappers.go builders; pkg/scheduler/*_test.go).  Everything here is
+host logic that the Go side does *before* the boundary: quantity -> int64 conversion
+(pkg/resources/amount.go:76, pkg/workload/workload.go:684-722), canonical (name-sorted) index
+assignment, and CSR/plane packing.  No decision logic lives here.
+"""
+from __future__ import annotations
+
+import dataclasses
+from dataclasses import dataclass, field
+from fractions import Fraction
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _ffi as F
+
+MAXI64 = (1 << 63) - 1
+MINI64 = -(1 << 63)
+
+# ----------------------------------------------------------------------------------------------
+# resource.Quantity parsing (k8s.io/apimachinery/pkg/api/resource) — only what tests/generators need
+# ----------------------------------------------------------------------------------------------
+_SUFFIX = {
+    "": Fraction(1), "m": Fraction(1, 1000), "k": Fraction(10**3), "M": Fraction(10**6), "G": Fraction(10**9),
+    "T": Fraction(10**12), "P": Fraction(10**15), "E": Fraction(10**18),
+    "Ki": Fraction(2**10), "Mi": Fraction(2**20), "Gi": Fraction(2**30), "Ti": Fraction(2**40),
+    "Pi": Fraction(2**50), "Ei": Fraction(2**60),
+}
+
+
+def parse_quantity(q) -> Fraction:
+    if isinstance(q, (int, np.integer)):
+        return Fraction(int(q))
+    s = str(q).strip()
+    for suf in ("Ki", "Mi", "Gi", "Ti", "Pi", "Ei", "m", "k", "M", "G", "T", "P", "E"):
+        if s.endswith(suf) and not (suf == "E" and ("e" in s[:-1] or s[:-1] == "")):
+            return Fraction(s[: -len(suf)]) * _SUFFIX[suf]
+    if "e" in s or "E" in s:
+        mant, exp = s.replace("E", "e").split("e")
+        return Fraction(mant) * Fraction(10) ** int(exp)
+    return Fraction(s)
+
+
+def _ceil(fr: Fraction) -> int:
+    return -((-fr.numerator) // fr.denominator)
+
+
+def amount_from_quantity(resource: str, q) -> int:
+    """resources.AmountFromQuantity (pkg/resources/amount.go:76-88): quota-side conversion."""
+    v = parse_quantity(q)
+    if resource == "cpu":
+        if v >= Fraction(MAXI64 // 1000):
+            return MAXI64
+        return _ceil(v * 1000)
+    if v >= MAXI64:
+        return MAXI64
+    return _ceil(v)
+
+
+def resource_value(resource: str, q) -> int:
+    """resources.ResourceValue (pkg/resources/requests.go:146-151): request-side, clamped."""
+    v = parse_quantity(q)
+    x = _ceil(v * 1000) if resource == "cpu" else _ceil(v)
+    return max(MINI64, min(MAXI64, x))
+
+
+def fnv1a64(name: str) -> int:
+    """hash/fnv New64a, as hashResourceName (pkg/resources/slice_requests.go:35-43)."""
+    h = 0xCBF29CE484222325
+    for b in name.encode():
+        h ^= b
+        h = (h * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def sat(x: int) -> int:
+    return max(MINI64, min(MAXI64, x))
+
+
+# ----------------------------------------------------------------------------------------------
+# API-shaped objects
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class ResourceQuota:
+    """kueue.ResourceQuota / schdcache.ResourceQuota (pkg/cache/scheduler/resource.go:26)."""
+    nominal: int
+    borrowing_limit: Optional[int] = None
+    lending_limit: Optional[int] = None
+
+
+@dataclass
+class FlavorQuotas:
+    name: str
+    resources: Dict[str, ResourceQuota] = field(default_factory=dict)
+
+    def Resource(self, name: str, nominal="0", borrowing_limit="", lending_limit="") -> "FlavorQuotas":
+        """MakeFlavorQuotas(f).Resource(name, nominal, borrowingLimit, lendingLimit) ("" = nil)."""
+        self.resources[name] = ResourceQuota(
+            amount_from_quantity(name, nominal),
+            None if borrowing_limit in ("", None) else amount_from_quantity(name, borrowing_limit),
+            None if lending_limit in ("", None) else amount_from_quantity(name, lending_limit),
+        )
+        return self
+
+
+@dataclass
+class ResourceGroup:
+    flavors: List[FlavorQuotas]
+
+    @property
+    def covered_resources(self) -> List[str]:
+        seen: List[str] = []
+        for f in self.flavors:
+            for r in f.resources:
+                if r not in seen:
+                    seen.append(r)
+        return seen
+
+
+POLICY = {"Never": 0, "": 0, None: 0, "LowerPriority": 1, "LowerOrNewerEqualPriority": 2, "Any": 3}
+FUNG = {"MayStopSearch": 0, "Borrow": 0, "Preempt": 0, "": None, None: None, "TryNextFlavor": 1}
+PREF = {None: 0, "": 0, "BorrowingOverPreemption": 1, "PreemptionOverBorrowing": 2}
+
+
+@dataclass
+class ClusterQueue:
+    name: str
+    cohort: Optional[str] = None
+    resource_groups: List[ResourceGroup] = field(default_factory=list)
+    within_cluster_queue: str = "Never"
+    reclaim_within_cohort: str = "Never"
+    borrow_within_cohort: str = "Never"
+    max_priority_threshold: Optional[int] = None
+    when_can_borrow: str = "MayStopSearch"
+    when_can_preempt: str = "TryNextFlavor"
+    preference: Optional[str] = None
+    queueing_strategy: str = "BestEffortFIFO"
+    fair_weight: float = 1.0
+    generation: int = 0
+    extra_usage: Dict[Tuple[str, str], int] = field(default_factory=dict)  # snapshot cq.AddUsage(...) in tests
+
+    def policy_word(self) -> int:
+        p = POLICY[self.within_cluster_queue] | (POLICY[self.reclaim_within_cohort] << 2)
+        if self.borrow_within_cohort not in ("Never", "", None):
+            p |= 1 << 4
+        if self.max_priority_threshold is not None:
+            p |= 1 << 5
+        wb = FUNG[self.when_can_borrow]
+        wp = FUNG[self.when_can_preempt]
+        p |= (0 if wb is None else wb) << 6
+        p |= (1 if wp is None else wp) << 7
+        p |= PREF[self.preference] << 8
+        if self.queueing_strategy == "StrictFIFO":
+            p |= 1 << 10
+        return p
+
+
+@dataclass
+class Cohort:
+    name: str
+    parent: Optional[str] = None
+    resource_groups: List[ResourceGroup] = field(default_factory=list)
+    fair_weight: float = 1.0
+
+
+@dataclass
+class PodSet:
+    name: str = "main"
+    count: int = 1
+    min_count: Optional[int] = None
+    requests: Dict[str, int] = field(default_factory=dict)  # TOTAL for the podset (per-pod x count)
+    # admitted workloads: resource -> flavor (PodSetResources.Flavors, workload.go:291)
+    flavors: Dict[str, str] = field(default_factory=dict)
+    # pending workloads: flavors for which checkFlavorForPodSets fails (taints / affinity), host-evaluated
+    excluded_flavors: List[str] = field(default_factory=list)
+
+    def Request(self, resource: str, per_pod) -> "PodSet":
+        self.requests[resource] = sat(resource_value(resource, per_pod) * self.count) if self.count else 0
+        return self
+
+
+@dataclass
+class LastAssignment:
+    """workload.AssignmentClusterQueueState (workload.go:115-127)."""
+    last_tried_flavor_idx: List[Dict[str, int]] = field(default_factory=list)
+    cluster_queue_generation: int = 0
+    scheduling_cycle: int = 0
+    scheduling_hash: int = 0
+
+
+@dataclass
+class Workload:
+    name: str
+    cluster_queue: str = ""
+    priority: int = 0
+    creation_ts: int = 0          # GetQueueOrderTimestamp in ns
+    pod_sets: List[PodSet] = field(default_factory=list)
+    uid: Optional[str] = None
+    # admitted side
+    reserve_ts: Optional[int] = None   # QuotaReserved.LastTransitionTime ns; None -> "now"
+    evicted: bool = False
+    # pending side
+    has_quota_reservation: bool = False
+    is_preemptor: bool = False
+    last_assignment: Optional[LastAssignment] = None
+    scheduling_hash: int = 0
+
+    @property
+    def UID(self) -> str:
+        return self.uid if self.uid is not None else self.name
+
+
+# ----------------------------------------------------------------------------------------------
+# Snapshot: the flattened quota tree + admitted set
+# ----------------------------------------------------------------------------------------------
+class Snapshot:
+    """Flat image of schdcache.Snapshot (pkg/cache/scheduler/snapshot.go:53).
+
+    Index assignment is the canonical order of the determinism contract: ClusterQueues, Cohorts,
+    flavors and resources are each sorted by name.
+    """
+
+    def __init__(self, cluster_queues: Sequence[ClusterQueue], cohorts: Sequence[Cohort] = (),
+                 admitted: Sequence[Workload] = (), now_ns: int = 0,
+                 extra_flavors: Sequence[str] = (), extra_resources: Sequence[str] = ()):
+        self.cluster_queues = sorted(cluster_queues, key=lambda c: c.name)
+        cohort_by_name: Dict[str, Cohort] = {c.name: c for c in cohorts}
+        # implicit cohorts (referenced but not defined), as hierarchy.Manager does (manager.go:75-110)
+        pending = [c.cohort for c in self.cluster_queues if c.cohort] + [c.parent for c in cohorts if c.parent]
+        while pending:
+            n = pending.pop()
+            if n not in cohort_by_name:
+                cohort_by_name[n] = Cohort(n)
+            p = cohort_by_name[n].parent
+            if p and p not in cohort_by_name:
+                pending.append(p)
+        self.cohorts = sorted(cohort_by_name.values(), key=lambda c: c.name)
+        self.cq_index = {c.name: i for i, c in enumerate(self.cluster_queues)}
+        nq = len(self.cluster_queues)
+        self.cohort_index = {c.name: nq + i for i, c in enumerate(self.cohorts)}
+        self.n_cq, self.n_cohort = nq, len(self.cohorts)
+        N = nq + self.n_cohort
+
+        flavors, resources = set(extra_flavors), set(extra_resources)
+        for owner in list(self.cluster_queues) + list(self.cohorts):
+            for rg in owner.resource_groups:
+                for fq in rg.flavors:
+                    flavors.add(fq.name)
+                    resources.update(fq.resources)
+        for w in admitted:
+            for ps in w.pod_sets:
+                flavors.update(ps.flavors.values())
+                resources.update(ps.flavors)
+                resources.update(ps.requests)
+        for cq in self.cluster_queues:
+            for (f, r) in cq.extra_usage:
+                flavors.add(f); resources.add(r)
+        self.flavors = sorted(flavors)
+        self.resources = sorted(resources)
+        self.flavor_index = {f: i for i, f in enumerate(self.flavors)}
+        self.resource_index = {r: i for i, r in enumerate(self.resources)}
+        nF, nR = len(self.flavors), len(self.resources)
+        self.n_flavor, self.n_resource, self.n_fr = nF, nR, nF * nR
+        nfr = self.n_fr
+        order = sorted(self.resources, key=lambda r: (fnv1a64(r), r))
+        rank = {r: i for i, r in enumerate(order)}
+
+        a: Dict[str, np.ndarray] = {}
+        a["resource_order"] = np.array([rank[r] for r in self.resources], dtype=np.int32)
+        parent = np.full(N, -1, dtype=np.int32)
+        for i, c in enumerate(self.cluster_queues):
+            if c.cohort:
+                parent[i] = self.cohort_index[c.cohort]
+        for i, c in enumerate(self.cohorts):
+            if c.parent:
+                parent[nq + i] = self.cohort_index[c.parent]
+        a["parent"] = parent
+        # cycle check (hierarchy.HasCycle, cycle.go:32)
+        for n in range(N):
+            seen, x = set(), n
+            while x >= 0:
+                if x in seen:
+                    raise ValueError("cohort cycle")
+                seen.add(x); x = int(parent[x])
+        cc_off, cc, cq_off, cqs = [0], [], [0], []
+        for i in range(self.n_cohort):
+            node = nq + i
+            cc += [j for j in range(nq, N) if parent[j] == node]
+            cc_off.append(len(cc))
+            cqs += [j for j in range(nq) if parent[j] == node]
+            cq_off.append(len(cqs))
+        a["child_cohort_off"] = np.array(cc_off, dtype=np.int32)
+        a["child_cohort"] = np.array(cc, dtype=np.int32)
+        a["child_cq_off"] = np.array(cq_off, dtype=np.int32)
+        a["child_cq"] = np.array(cqs, dtype=np.int32)
+        a["fair_weight"] = np.array([c.fair_weight for c in self.cluster_queues] + [c.fair_weight for c in self.cohorts], dtype=np.float64)
+
+        nominal = np.zeros(N * nfr, dtype=np.int64)
+        bl = np.full(N * nfr, F.KQ_NIL_LIMIT, dtype=np.int64)
+        ll = np.full(N * nfr, F.KQ_NIL_LIMIT, dtype=np.int64)
+        flags = np.zeros(N * nfr, dtype=np.uint8)
+        rg_off, rgf_off, rgf, rgr_off, rgr = [0], [0], [], [0], []
+        for ni, owner in enumerate(list(self.cluster_queues) + list(self.cohorts)):
+            for rg in owner.resource_groups:
+                for fq in rg.flavors:
+                    for r, q in fq.resources.items():
+                        k = ni * nfr + self.flavor_index[fq.name] * nR + self.resource_index[r]
+                        nominal[k] = q.nominal
+                        if q.borrowing_limit is not None:
+                            bl[k] = q.borrowing_limit
+                        if q.lending_limit is not None:
+                            ll[k] = q.lending_limit
+                        flags[k] |= F.KQ_QF_QUOTA
+                if ni < nq:
+                    rgf += [self.flavor_index[fq.name] for fq in rg.flavors]
+                    rgf_off.append(len(rgf))
+                    rgr += [self.resource_index[r] for r in rg.covered_resources]
+                    rgr_off.append(len(rgr))
+            if ni < nq:
+                rg_off.append(len(rgf_off) - 1)
+        a["nominal"], a["borrow_limit"], a["lend_limit"], a["quota_flags"] = nominal, bl, ll, flags
+        a["cq_rg_off"] = np.array(rg_off, dtype=np.int32)
+        a["rg_flavor_off"] = np.array(rgf_off, dtype=np.int32)
+        a["rg_flavor"] = np.array(rgf, dtype=np.int32)
+        a["rg_res_off"] = np.array(rgr_off, dtype=np.int32)
+        a["rg_res"] = np.array(rgr, dtype=np.int32)
+        a["cq_policy"] = np.array([c.policy_word() for c in self.cluster_queues], dtype=np.uint32)
+        a["cq_borrow_prio_threshold"] = np.array([c.max_priority_threshold or 0 for c in self.cluster_queues], dtype=np.int32)
+        a["cq_generation"] = np.array([c.generation for c in self.cluster_queues], dtype=np.int64)
+
+        # admitted workloads grouped by CQ (rows inside a CQ: by name, any order is valid)
+        adm = sorted(admitted, key=lambda w: (self.cq_index[w.cluster_queue], w.name))
+        self.admitted = adm
+        self.adm_index = {w.name: i for i, w in enumerate(adm)}
+        uid_sorted = sorted(range(len(adm)), key=lambda i: adm[i].UID.encode())
+        uid_rank = np.zeros(len(adm), dtype=np.uint32)
+        for rnk, i in enumerate(uid_sorted):
+            uid_rank[i] = rnk
+        cq_adm_off = np.zeros(nq + 1, dtype=np.int32)
+        for w in adm:
+            cq_adm_off[self.cq_index[w.cluster_queue] + 1] += 1
+        a["cq_adm_off"] = np.cumsum(cq_adm_off).astype(np.int32)
+        a["adm_priority"] = np.array([w.priority for w in adm], dtype=np.int64)
+        a["adm_queue_ts"] = np.array([w.creation_ts for w in adm], dtype=np.int64)
+        a["adm_reserve_ts"] = np.array([now_ns if w.reserve_ts is None else w.reserve_ts for w in adm], dtype=np.int64)
+        a["adm_uid_rank"] = uid_rank
+        a["adm_flags"] = np.array([F.ADM_EVICTED if w.evicted else 0 for w in adm], dtype=np.uint8)
+        use_off, use_fr, use_qty = [0], [], []
+        usage = np.zeros(N * nfr, dtype=np.int64)
+        usage_py = [0] * (nq * nfr)
+        for w in adm:
+            ci = self.cq_index[w.cluster_queue]
+            for ps in w.pod_sets:
+                for r, fl in ps.flavors.items():
+                    fr = self.flavor_index[fl] * nR + self.resource_index[r]
+                    q = ps.requests.get(r, 0)
+                    use_fr.append(fr); use_qty.append(q)
+                    usage_py[ci * nfr + fr] = sat(usage_py[ci * nfr + fr] + q)
+            use_off.append(len(use_fr))
+        for ci, c in enumerate(self.cluster_queues):
+            for (f, r), q in c.extra_usage.items():
+                fr = self.flavor_index[f] * nR + self.resource_index[r]
+                usage_py[ci * nfr + fr] = sat(usage_py[ci * nfr + fr] + q)
+        usage[: nq * nfr] = np.array(usage_py, dtype=np.int64) if usage_py else 0
+        a["adm_use_off"] = np.array(use_off, dtype=np.int32)
+        a["adm_use_fr"] = np.array(use_fr, dtype=np.int32)
+        a["adm_use_qty"] = np.array(use_qty, dtype=np.int64)
+        a["usage"] = usage
+        a["subtree_quota"] = np.zeros(N * nfr, dtype=np.int64)
+        self.arrays = a
+        self.n_adm = len(adm)
+        self.pods_resource = self.resource_index.get("pods", -1)
+        self.derived = False
+        self._struct = None
+
+    # -- helpers -------------------------------------------------------------------------------
+    @property
+    def N(self) -> int:
+        return self.n_cq + self.n_cohort
+
+    def fr(self, flavor: str, resource: str) -> int:
+        return self.flavor_index[flavor] * self.n_resource + self.resource_index[resource]
+
+    def fr_name(self, fr: int) -> Tuple[str, str]:
+        return self.flavors[fr // self.n_resource], self.resources[fr % self.n_resource]
+
+    def node(self, name: str) -> int:
+        return self.cq_index[name] if name in self.cq_index else self.cohort_index[name]
+
+    def set_derived(self, subtree_quota: np.ndarray, usage: np.ndarray, flags: np.ndarray):
+        """Install SubtreeQuota / cohort Usage computed by kq_snapshot_derive (or the oracle in tests)."""
+        self.arrays["subtree_quota"] = np.ascontiguousarray(subtree_quota, dtype=np.int64)
+        self.arrays["usage"] = np.ascontiguousarray(usage, dtype=np.int64)
+        self.arrays["quota_flags"] = np.ascontiguousarray(flags, dtype=np.uint8)
+        self.derived = True
+        self._struct = None
+
+    def struct(self) -> F.kq_snapshot:
+        if self._struct is None:
+            s = F.kq_snapshot()
+            F.fill_struct(s, self.arrays, dict(
+                n_cq=self.n_cq, n_cohort=self.n_cohort, n_flavor=self.n_flavor, n_resource=self.n_resource,
+                pods_resource=self.pods_resource, n_adm=self.n_adm))
+            self._struct = s
+        return self._struct
+
+    def plane(self, name: str) -> np.ndarray:
+        return self.arrays[name].reshape(self.N, self.n_fr)
+
+
+class Heads:
+    """Flat image of []qcache.Head (pkg/cache/queue/manager.go:903) for one cycle."""
+
+    def __init__(self, snap: Snapshot, workloads: Sequence[Workload], cycle: int = 1):
+        self.snap = snap
+        self.workloads = list(workloads)
+        n = len(self.workloads)
+        nR, nF = snap.n_resource, snap.n_flavor
+        nw = (nF + 63) // 64
+        a: Dict[str, np.ndarray] = {}
+        a["cq"] = np.array([snap.cq_index[w.cluster_queue] for w in self.workloads], dtype=np.int32)
+        a["priority"] = np.array([w.priority for w in self.workloads], dtype=np.int64)
+        a["queue_ts"] = np.array([w.creation_ts for w in self.workloads], dtype=np.int64)
+        flags = []
+        for w in self.workloads:
+            f = 0
+            if w.has_quota_reservation:
+                f |= F.HEAD_HAS_QUOTA_RESERVATION
+            if w.is_preemptor:
+                f |= F.HEAD_IS_PREEMPTOR
+            if w.last_assignment is not None:
+                f |= F.HEAD_HAS_LAST_ASSIGNMENT
+            flags.append(f)
+        a["flags"] = np.array(flags, dtype=np.uint32)
+        ps_off, ps_count, ps_min, req_off, req_res, req_qty = [0], [], [], [0], [], []
+        ok_rows, lt_rows = [], []
+        for w in self.workloads:
+            for pi, ps in enumerate(w.pod_sets):
+                ps_count.append(ps.count)
+                ps_min.append(-1 if ps.min_count is None else ps.min_count)
+                for r, q in ps.requests.items():
+                    if r not in snap.resource_index:
+                        raise KeyError(f"resource {r} not in snapshot dictionary; pass extra_resources")
+                    req_res.append(snap.resource_index[r]); req_qty.append(q)
+                req_off.append(len(req_res))
+                words = [0] * nw
+                for fi, fname in enumerate(snap.flavors):
+                    if fname not in ps.excluded_flavors:
+                        words[fi // 64] |= 1 << (fi % 64)
+                ok_rows.append(words)
+                lt = [-1] * nR
+                la = w.last_assignment
+                if la is not None and pi < len(la.last_tried_flavor_idx):
+                    for r, idx in la.last_tried_flavor_idx[pi].items():
+                        lt[snap.resource_index[r]] = idx
+                lt_rows.append(lt)
+            ps_off.append(len(ps_count))
+        a["ps_off"] = np.array(ps_off, dtype=np.int32)
+        a["ps_count"] = np.array(ps_count, dtype=np.int32)
+        a["ps_min_count"] = np.array(ps_min, dtype=np.int32)
+        a["ps_req_off"] = np.array(req_off, dtype=np.int32)
+        a["req_res"] = np.array(req_res, dtype=np.int32)
+        a["req_qty"] = np.array(req_qty, dtype=np.int64)
+        a["ps_flavor_ok"] = np.array(ok_rows, dtype=np.uint64).reshape(-1)
+        a["ps_last_tried"] = np.array(lt_rows, dtype=np.int32).reshape(-1)
+        la_get = lambda w, k: getattr(w.last_assignment, k) if w.last_assignment is not None else 0
+        a["last_generation"] = np.array([la_get(w, "cluster_queue_generation") for w in self.workloads], dtype=np.int64)
+        a["last_cycle"] = np.array([la_get(w, "scheduling_cycle") for w in self.workloads], dtype=np.int64)
+        a["last_hash"] = np.array([la_get(w, "scheduling_hash") for w in self.workloads], dtype=np.uint64)
+        a["hash"] = np.array([w.scheduling_hash for w in self.workloads], dtype=np.uint64)
+        self.arrays = a
+        self.n = n
+        self.n_ps = len(ps_count)
+        self.cycle = cycle
+        self._struct = None
+
+    @classmethod
+    def from_arrays(cls, snap: Snapshot, arrays: Dict[str, np.ndarray], cycle: int = 1) -> "Heads":
+        """Build directly from SoA arrays (synthetic populations; no per-workload python objects)."""
+        self = cls.__new__(cls)
+        self.snap, self.workloads = snap, None
+        self.arrays = {k: np.ascontiguousarray(v) for k, v in arrays.items()}
+        self.n = int(len(arrays["cq"]))
+        self.n_ps = int(arrays["ps_off"][-1])
+        self.cycle = cycle
+        self._struct = None
+        return self
+
+    def struct(self) -> F.kq_heads:
+        if self._struct is None:
+            h = F.kq_heads()
+            F.fill_struct(h, self.arrays, dict(n=self.n, cycle=self.cycle))
+            self._struct = h
+        return self._struct
+
+
+class Decisions:
+    """Caller-allocated kq_decisions buffers + decoded views."""
+
+    def __init__(self, heads: Heads, tgt_cap: Optional[int] = None):
+        snap = heads.snap
+        n, nps, nR = heads.n, heads.n_ps, snap.n_resource
+        cap = tgt_cap if tgt_cap is not None else max(16, snap.n_adm)
+        self.heads, self.snap = heads, snap
+        self.a = dict(
+            status=np.zeros(n, np.uint8), action=np.zeros(n, np.uint8), nominated_mode=np.zeros(n, np.uint8),
+            mode=np.zeros(n, np.uint8), requeue_reason=np.zeros(n, np.uint8), skip=np.zeros(n, np.uint8),
+            borrowing=np.zeros(n, np.int32), order=np.zeros(n, np.int32),
+            flavor=np.full(nps * nR, -1, np.int32), res_mode=np.zeros(nps * nR, np.uint8),
+            tried_idx=np.full(nps * nR, -1, np.int32), ps_count=np.zeros(nps, np.int32),
+            tgt_off=np.zeros(n + 1, np.int32), tgt_adm=np.zeros(cap, np.int32), tgt_reason=np.zeros(cap, np.uint8),
+        )
+        self._struct = F.kq_decisions()
+        F.fill_struct(self._struct, self.a, dict(tgt_cap=cap))
+
+    def struct(self) -> F.kq_decisions:
+        return self._struct
+
+    def targets(self, i: int) -> List[Tuple[int, int]]:
+        o = self.a["tgt_off"]
+        return [(int(self.a["tgt_adm"][k]), int(self.a["tgt_reason"][k])) for k in range(o[i], o[i + 1])]
+
+    def target_names(self, i: int) -> set:
+        return {f"{self.snap.admitted[r].name}:{F.REASONS[why]}" for r, why in self.targets(i)}
+
+    def flavors_of(self, i: int) -> List[Dict[str, Tuple[str, str, int]]]:
+        """Per podset: resource -> (flavor name, mode name, triedFlavorIdx)."""
+        h, snap = self.heads, self.snap
+        nR = snap.n_resource
+        out = []
+        for p in range(h.arrays["ps_off"][i], h.arrays["ps_off"][i + 1]):
+            d = {}
+            for r in range(nR):
+                fl = int(self.a["flavor"][p * nR + r])
+                if fl >= 0:
+                    d[snap.resources[r]] = (snap.flavors[fl], F.MODE_NAMES[int(self.a["res_mode"][p * nR + r])], int(self.a["tried_idx"][p * nR + r]))
+            out.append(d)
+        return out
+
+    def equal(self, other: "Decisions") -> List[str]:
+        """Field-by-field comparison; returns the names of differing arrays (bit-exact parity)."""
+        bad = []
+        for k, v in self.a.items():
+            w = other.a[k]
+            if k in ("tgt_adm", "tgt_reason"):
+                m = int(self.a["tgt_off"][-1])
+                if int(other.a["tgt_off"][-1]) != m or not np.array_equal(v[:m], w[:m]):
+                    bad.append(k)
+            elif not np.array_equal(v, w):
+                bad.append(k)
+        return bad
+
+
+def make_config(fair_sharing: bool = False, gates: Optional[int] = None, fs_strategies: Sequence[int] = (),
+                device: int = 0, quota_check_strategy: int = 0) -> F.kq_config:
+    cfg = F.kq_config()
+    cfg.abi_version = F.KQ_ABI_VERSION
+    cfg.device = device
+    cfg.gates = F.KQ_GATES_DEFAULT if gates is None else gates
+    cfg.fair_sharing = 1 if fair_sharing else 0
+    cfg.n_fs_strategies = len(fs_strategies)
+    for i, s in enumerate(fs_strategies[:2]):
+        cfg.fs_strategies[i] = s
+    cfg.quota_check_strategy = quota_check_strategy
+    return cfg
+
+
+def gates_with(overrides: Dict[str, bool]) -> int:
+    """features.SetFeatureGateDuringTest equivalent."""
+    g = F.KQ_GATES_DEFAULT
+    for name, on in overrides.items():
+        bit = F.GATE_BY_NAME[name]
+        g = (g | bit) if on else (g & ~bit)
+    return g

@@ -1,0 +1,1618 @@
+// kq_oracle.cpp — CPU ORACLE for the kq_engine hot path.
+//
+// *** TEST INFRASTRUCTURE ONLY. ***  This file is a single-threaded C++ restatement of the
+// reference's Go algorithm (kubernetes-sigs/kueue, /root/reference) for the scheduling-cycle
+// decision path. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+// it. The product path (kueue_amd/csrc) never links, loads or calls anything in this directory.
+//
+// Parity status: PINNED BY TRANSCRIPTION — the Go reference cannot be built here (no Go
+// toolchain); this restatement is checked against golden vectors transcribed from the
+// reference's own unit tests (tests/golden/*.json, see tests/golden/README.md for file:line).
+//
+// Each function cites the reference file:line it follows (paths relative to /root/reference/pkg).
+// Determinism contract: Go map iteration / unstable sorts are replaced by the
+// canonical orders stated next to each use.
+#include "../include/kq_engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <map>
+#include <set>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace kqo {
+
+static const int64_t I64MAX = std::numeric_limits<int64_t>::max();
+static const int64_t I64MIN = std::numeric_limits<int64_t>::min();
+
+// ---- util/math/math.go:27,39 -------------------------------------------------------------------
+static inline int64_t SaturatingAdd(int64_t a, int64_t b) {
+  if (b > 0 && a > I64MAX - b) return I64MAX;
+  if (b < 0 && a < I64MIN - b) return I64MIN;
+  return a + b;
+}
+static inline int64_t SaturatingSub(int64_t a, int64_t b) {
+  if (b < 0 && a > I64MAX + b) return I64MAX;
+  if (b > 0 && a < I64MIN + b) return I64MIN;
+  return a - b;
+}
+// util/math/math.go:89-107
+static inline int64_t SaturatingMul(int64_t a, int64_t b) {
+  if (a == 0 || b == 0) return 0;
+  if ((a == -1 && b == I64MIN) || (b == -1 && a == I64MIN)) return I64MAX;
+  int64_t res = (int64_t)((uint64_t)a * (uint64_t)b);
+  if (res / b != a) return ((a < 0) == (b < 0)) ? I64MAX : I64MIN;
+  return res;
+}
+
+// ---- resources/amount.go:46-205 ------------------------------------------------------------------
+struct Amount {
+  int64_t v = 0;
+  Amount() = default;
+  explicit Amount(int64_t x) : v(x) {}
+  bool isUnlimited() const { return v == I64MAX; }
+  Amount Add(Amount b) const {  // :114
+    if (isUnlimited() || b.isUnlimited()) return Amount(I64MAX);
+    return Amount(SaturatingAdd(v, b.v));
+  }
+  Amount AddInt64(int64_t x) const {  // :122
+    if (isUnlimited()) return *this;
+    return Amount(SaturatingAdd(v, x));
+  }
+  Amount Sub(Amount b) const {  // :133
+    if (isUnlimited() && b.isUnlimited()) return Amount(0);
+    if (isUnlimited()) return Amount(I64MAX);
+    if (b.isUnlimited()) return Amount(I64MIN);
+    return Amount(SaturatingSub(v, b.v));
+  }
+  int Cmp(Amount b) const {  // :156
+    if (isUnlimited() && b.isUnlimited()) return 0;
+    if (isUnlimited()) return 1;
+    if (b.isUnlimited()) return -1;
+    return v < b.v ? -1 : (v > b.v ? 1 : 0);
+  }
+  int CmpInt64(int64_t x) const {  // :174
+    if (isUnlimited()) return 1;
+    return v < x ? -1 : (v > x ? 1 : 0);
+  }
+};
+static inline Amount MinAmount(Amount a, Amount b) { return a.Cmp(b) < 0 ? a : b; }  // :189
+static inline Amount MaxAmount(Amount a, Amount b) { return a.Cmp(b) > 0 ? a : b; }  // :197
+
+// FlavorResourceQuantities (resources/resource.go): map[FlavorResource]Amount. Canonical iteration
+// order = ascending fr index.
+typedef std::map<int, Amount> FRQ;
+static inline Amount frq_get(const FRQ& m, int fr) {
+  auto it = m.find(fr);
+  return it == m.end() ? Amount(0) : it->second;
+}
+
+// ---- modes ---------------------------------------------------------------------------------------
+enum { NoFit = 0, Preempt = 1, DeferredFit = 2, Fit = 3 };                     // flavorassigner.go:457
+enum { pmNoFit = 0, pmNoCandidates = 1, pmPreempt = 2, pmReclaim = 3, pmFit = 4 };  // :523-531
+enum { ppNoCandidates = 0, ppPreempt = 1, ppReclaim = 2 };                     // common/types.go:23
+struct GranularMode {
+  int pm;
+  int64_t borrow;
+};
+static const int64_t MAXINT = I64MAX;  // math.MaxInt on 64-bit
+
+// ---- bytes accounting (SURVEY §8d "algorithmic bytes") ------------------------------------------
+struct Stats {
+  int64_t cells = 0;         // fitsResourceQuota evaluations
+  int64_t cell_bytes = 0;    // 40*(D+1) per cell
+  int64_t head_io_bytes = 0; // requests in + assignment out + usage out
+  int64_t entry_bytes = 0;   // fits re-check + addUsage
+  int64_t victim_bytes = 0;  // candidate scan + simulated removals
+  int64_t drs_bytes = 0;
+  int64_t total() const { return cell_bytes + head_io_bytes + entry_bytes + victim_bytes + drs_bytes; }
+};
+
+// ---- the snapshot as the scheduler sees it -------------------------------------------------------
+struct Snap {
+  kq_config cfg;
+  const kq_snapshot* s;
+  int nq, nc, N, nF, nR, nfr;
+  std::vector<int64_t> usage;    // mutable Usage planes (the per-cycle copy, snapshot.go:171)
+  std::vector<uint8_t> removed;  // admitted row deleted from cq.Workloads (snapshot.go:62)
+  std::vector<int> adm_cq;
+  std::vector<int> depth;        // #ancestors
+  Stats st;
+
+  Snap(const kq_config& c, const kq_snapshot* sn) : cfg(c), s(sn) {
+    nq = s->n_cq; nc = s->n_cohort; N = nq + nc; nF = s->n_flavor; nR = s->n_resource; nfr = nF * nR;
+    usage.assign(s->usage, s->usage + (size_t)N * nfr);
+    removed.assign(s->n_adm, 0);
+    adm_cq.assign(s->n_adm, -1);
+    for (int c2 = 0; c2 < nq; c2++)
+      for (int r = s->cq_adm_off[c2]; r < s->cq_adm_off[c2 + 1]; r++) adm_cq[r] = c2;
+    depth.assign(N, 0);
+    for (int n = 0; n < N; n++) { int d = 0; for (int a = s->parent[n]; a >= 0; a = s->parent[a]) d++; depth[n] = d; }
+  }
+  bool gate(uint32_t g) const { return (cfg.gates & g) != 0; }
+  bool isCQ(int n) const { return n < nq; }
+  bool HasParent(int n) const { return s->parent[n] >= 0; }
+  int Parent(int n) const { return s->parent[n]; }
+  int Root(int n) const { while (s->parent[n] >= 0) n = s->parent[n]; return n; }
+  size_t ix(int n, int fr) const { return (size_t)n * nfr + fr; }
+  Amount Nominal(int n, int fr) const { return Amount(s->nominal[ix(n, fr)]); }
+  bool hasBL(int n, int fr) const { return s->borrow_limit[ix(n, fr)] != KQ_NIL_LIMIT; }
+  bool hasLL(int n, int fr) const { return s->lend_limit[ix(n, fr)] != KQ_NIL_LIMIT; }
+  Amount BL(int n, int fr) const { return Amount(s->borrow_limit[ix(n, fr)]); }
+  Amount LL(int n, int fr) const { return Amount(s->lend_limit[ix(n, fr)]); }
+  Amount SubtreeQuota(int n, int fr) const { return Amount(s->subtree_quota[ix(n, fr)]); }
+  Amount Usage(int n, int fr) const { return Amount(usage[ix(n, fr)]); }
+  void setUsage(int n, int fr, Amount a) { usage[ix(n, fr)] = a.v; }
+  bool inSubtreeQuota(int n, int fr) const { return s->quota_flags[ix(n, fr)] & KQ_QF_SUBTREE; }
+  uint32_t policy(int cq) const { return s->cq_policy[cq]; }
+
+  // resource_node.go:67-72
+  Amount localQuota(int n, int fr) const {
+    if (hasLL(n, fr)) return MaxAmount(Amount(0), SubtreeQuota(n, fr).Sub(LL(n, fr)));
+    return Amount(0);
+  }
+  // resource_node.go:92-95
+  Amount LocalAvailable(int n, int fr) const {
+    return MaxAmount(Amount(0), localQuota(n, fr).Sub(Usage(n, fr)));
+  }
+  // resource_node.go:106-122
+  Amount available(int n, int fr) const {
+    if (!HasParent(n)) return SubtreeQuota(n, fr).Sub(Usage(n, fr));
+    Amount parentAvailable = available(Parent(n), fr);
+    if (hasBL(n, fr)) {
+      Amount lq = localQuota(n, fr);
+      Amount storedInParent = SubtreeQuota(n, fr).Sub(lq);
+      Amount usedInParent = MaxAmount(Amount(0), Usage(n, fr).Sub(lq));
+      Amount withMaxFromParent = storedInParent.Sub(usedInParent).Add(BL(n, fr));
+      parentAvailable = MinAmount(withMaxFromParent, parentAvailable);
+    }
+    return LocalAvailable(n, fr).Add(parentAvailable);
+  }
+  // resource_node.go:129-140
+  Amount potentialAvailable(int n, int fr) const {
+    if (!HasParent(n)) return SubtreeQuota(n, fr);
+    Amount avail = localQuota(n, fr).Add(potentialAvailable(Parent(n), fr));
+    if (hasBL(n, fr)) {
+      Amount maxWithBorrowing = SubtreeQuota(n, fr).Add(BL(n, fr));
+      avail = MinAmount(maxWithBorrowing, avail);
+    }
+    return avail;
+  }
+  // resource_node.go:144-152
+  void addUsage(int n, int fr, Amount val) {
+    Amount localAvailable = LocalAvailable(n, fr);
+    setUsage(n, fr, Usage(n, fr).Add(val));
+    if (HasParent(n) && val.Cmp(localAvailable) > 0) addUsage(Parent(n), fr, val.Sub(localAvailable));
+  }
+  // resource_node.go:156-165
+  void removeUsage(int n, int fr, Amount val) {
+    Amount usageStoredInParent = Usage(n, fr).Sub(localQuota(n, fr));
+    setUsage(n, fr, Usage(n, fr).Sub(val));
+    if (usageStoredInParent.CmpInt64(0) <= 0 || !HasParent(n)) return;
+    removeUsage(Parent(n), fr, MinAmount(val, usageStoredInParent));
+  }
+  // clusterqueue_snapshot.go:107-119 (TAS part out of scope here)
+  void AddUsage(int cq, const FRQ& u) { for (auto& kv : u) addUsage(cq, kv.first, kv.second); }
+  void RemoveUsage(int cq, const FRQ& u) { for (auto& kv : u) removeUsage(cq, kv.first, kv.second); }
+  // clusterqueue_snapshot.go:167
+  Amount Available(int cq, int fr) const { return MaxAmount(Amount(0), available(cq, fr)); }
+  Amount PotentialAvailable(int cq, int fr) const { return potentialAvailable(cq, fr); }
+  // clusterqueue_snapshot.go:155-161 / cohort_snapshot.go:90
+  bool BorrowingWith(int n, int fr, Amount val) const {
+    if (isCQ(n)) return Nominal(n, fr).Cmp(Usage(n, fr).Add(val)) < 0;
+    return SubtreeQuota(n, fr).Cmp(Usage(n, fr).Add(val)) < 0;
+  }
+  bool Borrowing(int cq, int fr) const { return BorrowingWith(cq, fr, Amount(0)); }
+  // clusterqueue_snapshot.go:134-141 (quota part)
+  bool Fits(int cq, const FRQ& u) const {
+    for (auto& kv : u) if (Available(cq, kv.first).Cmp(kv.second) < 0) return false;
+    return true;
+  }
+  // resource_node.go:233-243
+  bool QuantitiesFitInQuota(int n, const FRQ& requests, FRQ* remaining) const {
+    bool fits = true;
+    remaining->clear();
+    for (auto& kv : requests) {
+      if (SubtreeQuota(n, kv.first).Cmp(Usage(n, kv.first).Add(kv.second)) < 0) fits = false;
+      (*remaining)[kv.first] = MaxAmount(Amount(0), kv.second.Sub(LocalAvailable(n, kv.first)));
+    }
+    return fits;
+  }
+  // resource_node.go:247-254
+  bool IsWithinNominalInResources(int n, const std::set<int>& frs) const {
+    for (int fr : frs) if (SubtreeQuota(n, fr).Cmp(Usage(n, fr)) < 0) return false;
+    return true;
+  }
+  // hierarchy/cohort.go:44-50 — canonical (name-sorted) children
+  int nChildCohorts(int cohort) const { int k = cohort - nq; return s->child_cohort_off[k + 1] - s->child_cohort_off[k]; }
+  int childCohort(int cohort, int i) const { return s->child_cohort[s->child_cohort_off[cohort - nq] + i]; }
+  int nChildCQs(int cohort) const { int k = cohort - nq; return s->child_cq_off[k + 1] - s->child_cq_off[k]; }
+  int childCQ(int cohort, int i) const { return s->child_cq[s->child_cq_off[cohort - nq] + i]; }
+  // classical/hierarchical_preemption.go:209-215
+  int getNodeHeight(int cohort) const {
+    int maxHeight = std::min(nChildCohorts(cohort) + nChildCQs(cohort), 1);
+    for (int i = 0; i < nChildCohorts(cohort); i++) maxHeight = std::max(maxHeight, getNodeHeight(childCohort(cohort, i)) + 1);
+    return maxHeight;
+  }
+  // classical/hierarchical_preemption.go:221-234
+  std::pair<int, bool> FindHeightOfLowestSubtreeThatFits(int c, int fr, Amount val) const {
+    if (!BorrowingWith(c, fr, val) || !HasParent(c)) return {0, HasParent(c)};
+    Amount remaining = val.Sub(LocalAvailable(c, fr));
+    for (int t = Parent(c); t >= 0; t = Parent(t)) {
+      if (!BorrowingWith(t, fr, remaining)) return {getNodeHeight(t), HasParent(t)};
+      remaining = remaining.Sub(LocalAvailable(t, fr));
+    }
+    return {getNodeHeight(Root(c)), false};
+  }
+  // cohort_snapshot.go:50-58: ChildCQs first, then recurse into child cohorts
+  void SubtreeClusterQueues(int cohort, std::vector<int>* out) const {
+    for (int i = 0; i < nChildCQs(cohort); i++) out->push_back(childCQ(cohort, i));
+    for (int i = 0; i < nChildCohorts(cohort); i++) SubtreeClusterQueues(childCohort(cohort, i), out);
+  }
+  // workload.go:447 Info.Usage().Quota.Assigned for an admitted row
+  FRQ admUsage(int row) const {
+    FRQ u;
+    for (int k = s->adm_use_off[row]; k < s->adm_use_off[row + 1]; k++) {
+      int fr = s->adm_use_fr[k];
+      u[fr] = frq_get(u, fr).AddInt64(s->adm_use_qty[k]);
+    }
+    return u;
+  }
+  // snapshot.go:60-74
+  void RemoveWorkload(int row) { removed[row] = 1; RemoveUsage(adm_cq[row], admUsage(row)); st.victim_bytes += 16 * (depth[adm_cq[row]] + 1) * (s->adm_use_off[row + 1] - s->adm_use_off[row]); }
+  void AddWorkload(int row) { removed[row] = 0; AddUsage(adm_cq[row], admUsage(row)); st.victim_bytes += 16 * (depth[adm_cq[row]] + 1) * (s->adm_use_off[row + 1] - s->adm_use_off[row]); }
+  // resourcegroups.RGByResource (util/resourcegroups/resourcegroups.go:62)
+  int RGByResource(int cq, int res) const {
+    for (int g = s->cq_rg_off[cq]; g < s->cq_rg_off[cq + 1]; g++)
+      for (int k = s->rg_res_off[g]; k < s->rg_res_off[g + 1]; k++)
+        if (s->rg_res[k] == res) return g;
+    return -1;
+  }
+  bool rgCovers(int g, int res) const {
+    for (int k = s->rg_res_off[g]; k < s->rg_res_off[g + 1]; k++) if (s->rg_res[k] == res) return true;
+    return false;
+  }
+};
+
+// ---- fair sharing: cache/scheduler/fair_sharing.go --------------------------------------------------
+struct DRS {
+  double fairWeight = 1.0;
+  double unweightedRatio = 0;
+  int dominantResource = -1;  // "" == -1
+  bool borrowing = false;
+  std::vector<int> borrowedFRs;
+  bool IsZero() const { return unweightedRatio == 0; }               // :66
+  bool IsBorrowing() const { return borrowing; }                      // :72
+  bool isWeightZero() const { return fairWeight == 0; }               // :88
+  bool zeroWeightBorrows() const { return isWeightZero() && !IsZero(); }  // :145
+  double PreciseWeightedShare() const {                               // :92
+    if (IsZero()) return 0.0;
+    if (isWeightZero()) return std::numeric_limits<double>::infinity();
+    return unweightedRatio / fairWeight;
+  }
+  bool IsBorrowingOn(const FRQ& requested) const {                    // :78
+    for (int fr : borrowedFRs) if (frq_get(requested, fr).CmpInt64(0) > 0) return true;
+    return false;
+  }
+};
+static inline DRS NegativeDRS() { DRS d; d.unweightedRatio = -1; d.fairWeight = 1.0; return d; }  // :58
+// Go cmp.Compare for float64 (NaN < everything, NaN == NaN)
+static inline int cmpFloat(double a, double b) {
+  bool an = std::isnan(a), bn = std::isnan(b);
+  if (an && bn) return 0;
+  if (an) return -1;
+  if (bn) return 1;
+  return a < b ? -1 : (a > b ? 1 : 0);
+}
+// fair_sharing.go:112-123
+static inline int CompareDRS(const DRS& a, const DRS& b) {
+  if (a.zeroWeightBorrows() && b.zeroWeightBorrows()) return cmpFloat(a.unweightedRatio, b.unweightedRatio);
+  if (a.zeroWeightBorrows()) return 1;
+  if (b.zeroWeightBorrows()) return -1;
+  return cmpFloat(a.PreciseWeightedShare(), b.PreciseWeightedShare());
+}
+// resource names are compared alphabetically for the dominant-resource tie-break (:176); the
+// boundary does not carry names, so the snapshot's resource dictionary must be name-sorted
+// (index order == alphabetical order). kueue_amd/api.py guarantees it.
+// fair_sharing.go:186-200
+static std::vector<Amount> calculateLendable(Snap& sn, int node) {
+  int root = sn.Root(node);
+  std::vector<Amount> lendable(sn.nR, Amount(0));
+  for (int fr = 0; fr < sn.nfr; fr++) {
+    if (!sn.inSubtreeQuota(root, fr)) continue;
+    int res = fr % sn.nR;
+    lendable[res] = lendable[res].Add(sn.potentialAvailable(node, fr));
+  }
+  return lendable;
+}
+// fair_sharing.go:149-182 (wlReq is always nil on the path; the tests pass one)
+static DRS dominantResourceShare(Snap& sn, int node, const FRQ* wlReq = nullptr) {
+  DRS drs;
+  drs.fairWeight = sn.s->fair_weight[node];
+  if (!sn.HasParent(node)) return drs;
+  std::map<int, Amount> borrowing;  // resource -> amount
+  std::vector<int> borrowedFRs;
+  int frcount = 0;
+  for (int fr = 0; fr < sn.nfr; fr++) {
+    if (!sn.inSubtreeQuota(node, fr)) continue;
+    frcount++;
+    Amount amountBorrowed = (wlReq ? frq_get(*wlReq, fr) : Amount(0)).Add(sn.Usage(node, fr)).Sub(sn.SubtreeQuota(node, fr));
+    if (amountBorrowed.CmpInt64(0) > 0) {
+      int res = fr % sn.nR;
+      borrowing[res] = (borrowing.count(res) ? borrowing[res] : Amount(0)).Add(amountBorrowed);
+      borrowedFRs.push_back(fr);
+    }
+  }
+  sn.st.drs_bytes += (int64_t)frcount * 24;
+  if (borrowing.empty()) return drs;
+  drs.borrowing = true;
+  drs.borrowedFRs = borrowedFRs;
+  std::vector<Amount> lendable = calculateLendable(sn, sn.Parent(node));
+  sn.st.drs_bytes += (int64_t)frcount * 40 * (sn.depth[node] + 1);
+  for (auto& kv : borrowing) {  // ascending resource index == alphabetical
+    Amount lr = lendable[kv.first];
+    if (lr.CmpInt64(0) > 0) {
+      double ratio = (double)kv.second.v * 1000.0 / (double)lr.v;
+      if (ratio > drs.unweightedRatio || (ratio == drs.unweightedRatio && kv.first < drs.dominantResource)) {
+        drs.unweightedRatio = ratio;
+        drs.dominantResource = kv.first;
+      }
+    }
+  }
+  return drs;
+}
+
+// ---- the pending workload (workload.Info + qcache.Head) --------------------------------------------
+struct PodSetReq {
+  int count, min_count;
+  std::vector<std::pair<int, int64_t>> req;  // (resource, qty) in given order
+};
+struct Head {
+  int idx, cq;
+  int64_t priority, queue_ts;
+  uint32_t flags;
+  std::vector<PodSetReq> ps;
+  int ps_base;                     // global podset index of ps[0]
+  bool has_last;                   // LastAssignment != nil
+  std::vector<std::vector<int>> last_tried;  // [ps][res], -1 absent
+  // NominationMapping (workload.go:262): [ps][res] -> flavor, empty when unset
+  std::vector<std::map<int, int>> nomination;
+  bool CanBePartiallyAdmitted() const {  // workload.go:636
+    for (auto& p : ps) if (p.min_count >= 0 && p.count > p.min_count) return true;
+    return false;
+  }
+};
+
+struct FlavorAssignment { int flavor = -1; int mode = NoFit; int tried = 0; int borrow = 0; };
+struct PodSetAssignment {
+  std::map<int, FlavorAssignment> flavors;  // resource -> assignment (ResourceAssignment)
+  int nreasons = 0;                          // len(Status.reasons)
+  bool err = false;
+  int count = 0;
+  std::vector<std::pair<int, int64_t>> requests;  // effective requests (incl. injected pods)
+  // flavorassigner.go:386-404
+  int RepresentativeMode() const {
+    if (!err && nreasons == 0) return Fit;
+    if (err) return NoFit;
+    if (flavors.empty()) return NoFit;
+    int mode = Fit;
+    for (auto& kv : flavors) if (kv.second.mode < mode) mode = kv.second.mode;
+    return mode;
+  }
+};
+struct Assignment {
+  std::vector<PodSetAssignment> PodSets;
+  int Borrowing = 0;
+  FRQ Usage;  // Usage.Quota.Assigned
+  int rep = -1;
+  // flavorassigner.go:211-229
+  int RepresentativeMode() {
+    if (PodSets.empty()) return NoFit;
+    if (rep >= 0) return rep;
+    int mode = Fit;
+    for (auto& ps : PodSets) mode = std::min(mode, ps.RepresentativeMode());
+    rep = mode;
+    return mode;
+  }
+  // flavorassigner.go:109-114
+  void SetRepresentativeMode(int mode) {
+    rep = mode;
+    for (auto& ps : PodSets) for (auto& kv : ps.flavors) kv.second.mode = mode;
+  }
+};
+
+struct Target { int row; int reason; };
+
+typedef std::function<std::pair<int, int>(int cq, const Head& wl, int fr, Amount quantity)> OracleFn;
+
+// ---- flavor fungibility helpers ----------------------------------------------------------------------
+// flavorassigner.go:536-576
+static bool isPreferred(GranularMode a, GranularMode b, uint32_t pol) {
+  if (a.pm == pmNoFit) return false;
+  if (b.pm == pmNoFit) return true;
+  bool aNo = a.pm == pmNoCandidates, bNo = b.pm == pmNoCandidates;
+  if (aNo != bNo) return !aNo;
+  auto borrowingOverPreemption = [&]() {
+    if (a.pm != b.pm) return a.pm > b.pm;
+    return a.borrow < b.borrow;
+  };
+  auto preemptionOverBorrowing = [&]() {
+    if (a.borrow != b.borrow) return a.borrow < b.borrow;
+    return a.pm > b.pm;
+  };
+  switch (KQ_POL_PREFERENCE(pol)) {
+    case KQ_PREF_BORROWING_OVER_PREEMPTION: return borrowingOverPreemption();
+    case KQ_PREF_PREEMPTION_OVER_BORROWING: return preemptionOverBorrowing();
+  }
+  return borrowingOverPreemption();
+}
+// flavorassigner.go:1263-1282
+static bool shouldTryNextFlavor(GranularMode m, uint32_t pol) {
+  if (m.pm == pmNoFit || m.pm == pmNoCandidates) return true;
+  if ((m.pm == pmPreempt || m.pm == pmReclaim) && KQ_POL_PREEMPT_TRYNEXT(pol)) return true;
+  if (m.borrow != 0 && KQ_POL_BORROW_TRYNEXT(pol)) return true;
+  return false;
+}
+static int flavorAssignmentMode(int pm) {  // flavorassigner.go:604-619
+  switch (pm) { case pmNoFit: return NoFit; case pmFit: return Fit; default: return Preempt; }
+}
+
+// ---- FlavorAssigner (flavorassigner.go:644-1384) -----------------------------------------------------
+struct FlavorAssigner {
+  Snap& sn;
+  const kq_heads* H;
+  const Head& wl;
+  int cq;
+  bool enableFairSharing;
+  OracleFn oracle;
+
+  bool flavorOk(int psGlobal, int flavor) const {
+    int nw = (sn.nF + 63) / 64;
+    return (H->ps_flavor_ok[(size_t)psGlobal * nw + flavor / 64] >> (flavor % 64)) & 1;
+  }
+  // flavorassigner.go:1386-1389
+  bool canPreemptWhileBorrowing() const {
+    uint32_t p = sn.policy(cq);
+    return KQ_POL_BORROW_WITHIN(p) != 0 || (enableFairSharing && KQ_POL_RECLAIM(p) != KQ_POLICY_NEVER);
+  }
+  // workload.go:226-238
+  int NextFlavorToTry(int ps, int res) const {
+    if (!sn.gate(KQ_GATE_FLAVOR_FUNGIBILITY)) return 0;
+    if (!wl.has_last || ps >= (int)wl.last_tried.size()) return 0;
+    int idx = wl.last_tried[ps][res];
+    if (idx < 0) return 0;  // absent, or stored -1 -> 0 either way
+    return idx + 1;
+  }
+  // flavorassigner.go:1334-1384 ; returns (preemptionMode, borrow, hasStatus)
+  struct FitRes { int pm; int borrow; bool status; };
+  FitRes fitsResourceQuota(int fr, Amount assumedUsage, int64_t requestUsage) {
+    sn.st.cells++;
+    sn.st.cell_bytes += 40 * (sn.depth[cq] + 1);
+    Amount available = sn.Available(cq, fr);
+    Amount maxCapacity = sn.PotentialAvailable(cq, fr);
+    Amount val = assumedUsage.AddInt64(requestUsage);
+    if (val.Cmp(maxCapacity) > 0) return {pmNoFit, 0, true};
+    auto hb = sn.FindHeightOfLowestSubtreeThatFits(cq, fr, val);
+    int borrow = hb.first;
+    bool mayReclaimInHierarchy = hb.second;
+    if (val.Cmp(available) <= 0) return {pmFit, borrow, false};
+    if (sn.Nominal(cq, fr).Cmp(val) >= 0 || mayReclaimInHierarchy || canPreemptWhileBorrowing()) {
+      auto r = oracle(cq, wl, fr, val);
+      int mode;
+      switch (r.first) { case ppNoCandidates: mode = pmNoCandidates; break; case ppPreempt: mode = pmPreempt; break; default: mode = pmReclaim; }
+      return {mode, r.second, true};
+    }
+    return {pmNoFit, borrow, true};
+  }
+  // flavorassigner.go:1408-1414 / :1422-1430
+  bool shouldRespectNominationMapping() const {
+    bool any = false;
+    for (auto& m : wl.nomination) if (!m.empty()) any = true;
+    return any && sn.gate(KQ_GATE_RECOMPUTE_ON_OVERLAP);
+  }
+  // flavorassigner.go:1065-1210 ; psIDs == {psi} (no TAS podset groups on this path)
+  // returns assignments (empty => nil), nreasons; *statusNil true when Go returns a nil status
+  std::map<int, FlavorAssignment> findFlavorForPodSets(int psi, const std::vector<std::pair<int, int64_t>>& requests,
+                                                       int resName, const FRQ& assignmentUsage, int* nreasons, bool* statusNil) {
+    *nreasons = 0; *statusNil = false;
+    int g = sn.RGByResource(cq, resName);
+    if (g < 0) { *nreasons = 1; return {}; }
+    std::vector<std::pair<int, int64_t>> filtered;  // filterRequestedResources :1391
+    for (auto& rq : requests) if (sn.rgCovers(g, rq.first)) filtered.push_back(rq);
+    std::map<int, FlavorAssignment> bestAssignment;
+    bool haveBest = false;
+    GranularMode bestMode = {pmNoFit, MAXINT};
+    int f0 = sn.s->rg_flavor_off[g], nflv = sn.s->rg_flavor_off[g + 1] - f0;
+    uint32_t pol = sn.policy(cq);
+    int attemptedFlavorIdx = -1;
+    int idx = NextFlavorToTry(psi, resName);
+    bool respectNom = shouldRespectNominationMapping();
+    for (; idx < nflv; idx++) {
+      attemptedFlavorIdx = idx;
+      int fName = sn.s->rg_flavor[f0 + idx];
+      if (respectNom) {  // shouldSkipBasedOnNominationMapping :1422
+        auto it = wl.nomination[psi].find(resName);
+        bool keep = it != wl.nomination[psi].end() && it->second == fName;
+        if (!keep) { (*nreasons)++; continue; }
+      }
+      if (!flavorOk(wl.ps_base + psi, fName)) { (*nreasons)++; continue; }  // checkFlavorForPodSets :1212 (host-evaluated)
+      std::map<int, FlavorAssignment> assignments;
+      GranularMode representativeMode = {pmFit, 0};
+      for (auto& rq : filtered) {
+        int fr = fName * sn.nR + rq.first;
+        FitRes r = fitsResourceQuota(fr, frq_get(assignmentUsage, fr), rq.second);
+        if (r.status) (*nreasons)++;
+        GranularMode mode = {r.pm, r.borrow};
+        if (isPreferred(representativeMode, mode, pol)) representativeMode = mode;
+        if (representativeMode.pm == pmNoFit) continue;  // closure "return" :1161
+        FlavorAssignment fa; fa.flavor = fName; fa.mode = flavorAssignmentMode(r.pm); fa.borrow = r.borrow;
+        assignments[rq.first] = fa;
+      }
+      if (sn.gate(KQ_GATE_FLAVOR_FUNGIBILITY)) {
+        if (!shouldTryNextFlavor(representativeMode, pol)) {
+          bestAssignment = assignments; haveBest = true; bestMode = representativeMode;
+          break;
+        }
+        if (isPreferred(representativeMode, bestMode, pol)) { bestAssignment = assignments; haveBest = true; bestMode = representativeMode; }
+      } else if (representativeMode.pm > bestMode.pm) {
+        bestAssignment = assignments; haveBest = true; bestMode = representativeMode;
+        if (bestMode.pm == pmFit) { *statusNil = true; return bestAssignment; }
+      }
+    }
+    if (sn.gate(KQ_GATE_FLAVOR_FUNGIBILITY)) {
+      for (auto& kv : bestAssignment) kv.second.tried = (attemptedFlavorIdx == nflv - 1) ? -1 : attemptedFlavorIdx;
+      if (bestMode.pm == pmFit) { *statusNil = true; return bestAssignment; }
+    }
+    (void)haveBest;
+    return bestAssignment;
+  }
+
+  // flavorassigner.go:708-908 (TAS branches excluded: out of scope for this path)
+  Assignment assignFlavors(const std::vector<int>* counts) {
+    Assignment a;
+    int P = (int)wl.ps.size();
+    std::vector<PodSetReq> requests(P);
+    for (int i = 0; i < P; i++) {
+      requests[i] = wl.ps[i];
+      if (counts && !counts->empty()) {  // ScaledTo workload.go:317-340
+        int nc2 = (*counts)[i];
+        if (wl.ps[i].count != 0 && wl.ps[i].count != nc2) {
+          for (auto& rq : requests[i].req) {
+            rq.second = rq.second / (int64_t)wl.ps[i].count;          // Divide slice_requests.go:192
+            rq.second = SaturatingMul(rq.second, (int64_t)nc2);       // Mul
+          }
+          requests[i].count = nc2;
+        }
+      }
+    }
+    for (int i = 0; i < P; i++) {
+      PodSetReq& podSet = requests[i];
+      if (sn.s->pods_resource >= 0 && sn.RGByResource(cq, sn.s->pods_resource) >= 0) {  // :743-749
+        bool found = false;
+        for (auto& rq : podSet.req) if (rq.first == sn.s->pods_resource) { rq.second = podSet.count; found = true; }
+        if (!found) podSet.req.push_back({sn.s->pods_resource, (int64_t)podSet.count});
+      }
+      // Requests.Iter order: FNV-1a64(name), name (slice_requests.go:54-60)
+      std::stable_sort(podSet.req.begin(), podSet.req.end(), [&](const std::pair<int, int64_t>& x, const std::pair<int, int64_t>& y) {
+        return sn.s->resource_order[x.first] < sn.s->resource_order[y.first];
+      });
+      sn.st.head_io_bytes += (int64_t)podSet.req.size() * 8;
+      PodSetAssignment psa;
+      psa.count = podSet.count;
+      psa.requests = podSet.req;
+      std::map<int, FlavorAssignment> groupFlavors;
+      bool groupNil = false;
+      int groupReasons = 0;
+      for (auto& rq : podSet.req) {
+        int resName = rq.first; int64_t quantity = rq.second;
+        if (sn.RGByResource(cq, resName) < 0) {  // :809-817
+          if (quantity == 0) continue;
+          if (sn.gate(KQ_GATE_QUOTA_CHECK_STRATEGY) && sn.cfg.quota_check_strategy == KQ_QUOTA_CHECK_IGNORE_UNDECLARED) continue;
+        }
+        if (groupFlavors.count(resName)) continue;  // :819
+        int nre; bool statusNil;
+        auto flavors = findFlavorForPodSets(i, podSet.req, resName, a.Usage, &nre, &statusNil);
+        if (flavors.empty() && !podSet.req.empty()) {  // :826
+          groupFlavors.clear(); groupNil = true; groupReasons = nre;
+          break;
+        }
+        for (auto& kv : flavors) groupFlavors[kv.first] = kv.second;
+        if (!statusNil) groupReasons += nre;
+      }
+      // resolvePodSetFlavors :921-947 — keep flavors for resources this podset requests
+      if (!groupNil && !podSet.req.empty()) {
+        for (auto& kv : groupFlavors) {
+          bool req = false;
+          for (auto& rq : podSet.req) if (rq.first == kv.first) req = true;
+          if (req) psa.flavors[kv.first] = kv.second;
+        }
+      }
+      psa.nreasons = groupReasons;
+      // Assignment.append :1017-1041
+      for (auto& kv : psa.flavors) {
+        if (kv.second.borrow > a.Borrowing) a.Borrowing = kv.second.borrow;
+        int fr = kv.second.flavor * sn.nR + kv.first;
+        int64_t requestAmount = 0;
+        for (auto& rq : podSet.req) if (rq.first == kv.first) requestAmount = rq.second;
+        a.Usage[fr] = frq_get(a.Usage, fr).AddInt64(requestAmount);
+      }
+      sn.st.head_io_bytes += (int64_t)podSet.req.size() * 8 + (int64_t)psa.flavors.size() * 16;
+      bool failed = !podSet.req.empty() && psa.flavors.empty();
+      a.PodSets.push_back(psa);
+      a.rep = -1;
+      if (failed) return a;  // atLeastOnePodsAssignmentFailed :848-853
+    }
+    return a;
+  }
+};
+
+// ---- preemption (scheduler/preemption/*.go) ---------------------------------------------------------
+struct PreemptionCtx {
+  const Head* preemptor;
+  int preemptorCQ;
+  FRQ workloadUsage;
+  std::set<int> frsNeedPreemption;
+};
+
+struct Preemptor {
+  Snap& sn;
+  bool enableFairSharing;
+  std::vector<int> fsStrategies;
+
+  Preemptor(Snap& s) : sn(s) {
+    enableFairSharing = s.cfg.fair_sharing != 0;
+    if (s.cfg.n_fs_strategies <= 0) fsStrategies = {KQ_FS_LESS_THAN_OR_EQUAL_TO_FINAL_SHARE, KQ_FS_LESS_THAN_INITIAL_SHARE};  // preemption.go:364-366
+    else for (int i = 0; i < s.cfg.n_fs_strategies && i < 2; i++) fsStrategies.push_back(s.cfg.fs_strategies[i]);
+  }
+
+  // candidate_generator.go:54-63
+  bool WorkloadUsesResources(int row, const std::set<int>& frs) const {
+    for (int k = sn.s->adm_use_off[row]; k < sn.s->adm_use_off[row + 1]; k++) if (frs.count(sn.s->adm_use_fr[k])) return true;
+    return false;
+  }
+  // common/preemption_policy.go:27-42
+  bool SatisfiesPreemptionPolicy(const Head& preemptor, int row, int policy) const {
+    int64_t pp = preemptor.priority, cp = sn.s->adm_priority[row];
+    bool lowerPriority = pp > cp;
+    if (policy == KQ_POLICY_LOWER_PRIORITY) return lowerPriority;
+    if (policy == KQ_POLICY_LOWER_OR_NEWER_EQUAL) {
+      bool newerEqual = (pp == cp) && preemptor.queue_ts < sn.s->adm_queue_ts[row];
+      return lowerPriority || newerEqual;
+    }
+    return policy == KQ_POLICY_ANY;
+  }
+  // common/ordering.go:42-83 (AFS branch off: out of scope)
+  int CandidatesOrdering(int a, int b, int cq) const {
+    bool ea = sn.s->adm_flags[a] & KQ_ADM_EVICTED, eb = sn.s->adm_flags[b] & KQ_ADM_EVICTED;
+    if (ea != eb) return ea ? -1 : 1;
+    bool aIn = sn.adm_cq[a] == cq, bIn = sn.adm_cq[b] == cq;
+    if (bIn != aIn) return bIn ? -1 : 1;  // CompareBool(b==cq, a==cq)
+    int64_t pa = sn.s->adm_priority[a], pb = sn.s->adm_priority[b];
+    if (pa != pb) return pa < pb ? -1 : 1;
+    int64_t ta = sn.s->adm_reserve_ts[a], tb = sn.s->adm_reserve_ts[b];
+    if (ta != tb) return tb < ta ? -1 : 1;  // quotaReservationTime(b).Compare(a)
+    uint32_t ua = sn.s->adm_uid_rank[a], ub = sn.s->adm_uid_rank[b];
+    return ua < ub ? -1 : (ua > ub ? 1 : 0);
+  }
+  void sortCandidates(std::vector<int>& v, int cq) const {
+    std::sort(v.begin(), v.end(), [&](int a, int b) { return CandidatesOrdering(a, b, cq) < 0; });
+  }
+
+  // ---------- classical ----------
+  enum { vNever = 0, vWithinCQ, vHierarchicalReclaim, vReclaimWithoutBorrowing, vReclaimWhileBorrowing };
+  struct candidateElem { int wl; int lca; int variant; };
+  static int variantReason(int v) {  // hierarchical_preemption.go:46-58
+    switch (v) {
+      case vWithinCQ: return KQ_REASON_IN_CLUSTER_QUEUE;
+      case vHierarchicalReclaim: return KQ_REASON_IN_COHORT_RECLAMATION;
+      case vReclaimWhileBorrowing: return KQ_REASON_IN_COHORT_RECLAIM_WHILE_BORROWING;
+      default: return KQ_REASON_IN_COHORT_RECLAMATION;
+    }
+  }
+  // hierarchical_preemption.go:71-77
+  bool IsBorrowingWithinCohortForbidden(int cq) const { return KQ_POL_BORROW_WITHIN(sn.policy(cq)) == 0; }
+  // hierarchical_preemption.go:115-123
+  bool isAboveBorrowingThreshold(int64_t cand, int64_t incoming, int cq) const {
+    if (cand >= incoming) return true;
+    if (!KQ_POL_HAS_THRESHOLD(sn.policy(cq))) return false;
+    return cand > (int64_t)sn.s->cq_borrow_prio_threshold[cq];
+  }
+  // hierarchical_preemption.go:81-113
+  int classifyPreemptionVariant(const PreemptionCtx& ctx, int row, bool haveHierarchicalAdvantage) const {
+    if (!WorkloadUsesResources(row, ctx.frsNeedPreemption)) return vNever;
+    uint32_t p = sn.policy(ctx.preemptorCQ);
+    bool same = sn.adm_cq[row] == ctx.preemptorCQ;
+    int policy = same ? KQ_POL_WITHIN_CQ(p) : KQ_POL_RECLAIM(p);
+    if (!SatisfiesPreemptionPolicy(*ctx.preemptor, row, policy)) return vNever;
+    if (same) return vWithinCQ;
+    if (haveHierarchicalAdvantage) return vHierarchicalReclaim;
+    if (IsBorrowingWithinCohortForbidden(ctx.preemptorCQ)) return vReclaimWithoutBorrowing;
+    if (isAboveBorrowingThreshold(sn.s->adm_priority[row], ctx.preemptor->priority, ctx.preemptorCQ)) return vReclaimWithoutBorrowing;
+    return vReclaimWhileBorrowing;
+  }
+  // hierarchical_preemption.go:132-147 ; cq.Workloads iteration -> canonical row order (lists are sorted after)
+  void getCandidatesFromCQ(int cq, int lca, const PreemptionCtx& ctx, bool adv, std::vector<candidateElem>* out) {
+    for (int row = sn.s->cq_adm_off[cq]; row < sn.s->cq_adm_off[cq + 1]; row++) {
+      if (sn.removed[row]) continue;
+      sn.st.victim_bytes += 32 + 12 * (sn.s->adm_use_off[row + 1] - sn.s->adm_use_off[row]);
+      int v = classifyPreemptionVariant(ctx, row, adv);
+      if (v == vNever) continue;
+      out->push_back({row, lca, v});
+    }
+  }
+  // hierarchical_preemption.go:179-207
+  void collectCandidatesInSubtree(const PreemptionCtx& ctx, int currentCohort, int subtreeRoot, int skipSubtree, bool adv, std::vector<candidateElem>* result) {
+    for (int i = 0; i < sn.nChildCohorts(currentCohort); i++) {
+      int childCohort = sn.childCohort(currentCohort, i);
+      if (childCohort == skipSubtree) continue;
+      if (sn.IsWithinNominalInResources(childCohort, ctx.frsNeedPreemption)) continue;
+      collectCandidatesInSubtree(ctx, childCohort, subtreeRoot, skipSubtree, adv, result);
+    }
+    for (int i = 0; i < sn.nChildCQs(currentCohort); i++) {
+      int childCq = sn.childCQ(currentCohort, i);
+      if (childCq == ctx.preemptorCQ) continue;
+      if (!sn.IsWithinNominalInResources(childCq, ctx.frsNeedPreemption)) getCandidatesFromCQ(childCq, subtreeRoot, ctx, adv, result);
+    }
+  }
+  // hierarchical_preemption.go:149-175
+  void collectCandidatesForHierarchicalReclaim(const PreemptionCtx& ctx, std::vector<candidateElem>* hierarchy, std::vector<candidateElem>* priorityC) {
+    int cq = ctx.preemptorCQ;
+    if (!sn.HasParent(cq) || KQ_POL_RECLAIM(sn.policy(cq)) == KQ_POLICY_NEVER) return;
+    int previousSubtreeRoot = -1;
+    FRQ remainingRequests, next;
+    bool hasHierarchicalAdvantage = sn.QuantitiesFitInQuota(cq, ctx.workloadUsage, &remainingRequests);
+    for (int currentSubtreeRoot = sn.Parent(cq); currentSubtreeRoot >= 0; currentSubtreeRoot = sn.Parent(currentSubtreeRoot)) {
+      std::vector<candidateElem>* list = hasHierarchicalAdvantage ? hierarchy : priorityC;
+      collectCandidatesInSubtree(ctx, currentSubtreeRoot, currentSubtreeRoot, previousSubtreeRoot, hasHierarchicalAdvantage, list);
+      bool fits = sn.QuantitiesFitInQuota(currentSubtreeRoot, remainingRequests, &next);
+      remainingRequests = next;
+      hasHierarchicalAdvantage = hasHierarchicalAdvantage || fits;
+      previousSubtreeRoot = currentSubtreeRoot;
+    }
+  }
+  // candidate_generator.go:136-158
+  bool candidateIsValid(const PreemptionCtx& ctx, const candidateElem& c, bool borrow) const {
+    int ccq = sn.adm_cq[c.wl];
+    if (ctx.preemptorCQ == ccq) return true;
+    if (borrow && c.variant == vReclaimWithoutBorrowing) return false;
+    if (sn.IsWithinNominalInResources(ccq, ctx.frsNeedPreemption)) return false;
+    for (int node = sn.Parent(ccq); node >= 0; node = sn.Parent(node)) {
+      if (node == c.lca) break;
+      if (sn.IsWithinNominalInResources(node, ctx.frsNeedPreemption)) return false;
+    }
+    return true;
+  }
+  // preemption.go:669-686 (TAS part out of scope)
+  bool workloadFits(const PreemptionCtx& ctx, bool allowBorrowing) {
+    for (auto& kv : ctx.workloadUsage) {
+      sn.st.victim_bytes += 40 * (sn.depth[ctx.preemptorCQ] + 1);
+      if (!allowBorrowing && sn.BorrowingWith(ctx.preemptorCQ, kv.first, kv.second)) return false;
+      if (kv.second.Cmp(sn.Available(ctx.preemptorCQ, kv.first)) > 0) return false;
+    }
+    return true;
+  }
+  // preemption.go:341-354
+  std::vector<Target> fillBackWorkloads(const PreemptionCtx& ctx, std::vector<Target> targets, bool allowBorrowing) {
+    for (int i = (int)targets.size() - 2; i >= 0; i--) {
+      sn.AddWorkload(targets[i].row);
+      if (workloadFits(ctx, allowBorrowing)) {
+        targets[i] = targets.back();
+        targets.pop_back();
+      } else {
+        sn.RemoveWorkload(targets[i].row);
+      }
+    }
+    return targets;
+  }
+  void restoreSnapshot(const std::vector<Target>& targets) { for (auto& t : targets) sn.AddWorkload(t.row); }  // :356
+  // preemption.go:700-707
+  bool queueUnderNominalInResourcesNeedingPreemption(const PreemptionCtx& ctx) const {
+    for (int fr : ctx.frsNeedPreemption) if (sn.Nominal(ctx.preemptorCQ, fr).Cmp(sn.Usage(ctx.preemptorCQ, fr)) <= 0) return false;
+    return true;
+  }
+  // preemption.go:714-721
+  bool queueWithinNominalInResourcesNeedingPreemption(const PreemptionCtx& ctx) const {
+    for (int fr : ctx.frsNeedPreemption) if (sn.Borrowing(ctx.preemptorCQ, fr)) return false;
+    return true;
+  }
+  // preemption.go:284-339 + candidate_generator.go:78-121
+  std::vector<Target> classicalPreemptions(const PreemptionCtx& ctx) {
+    std::vector<candidateElem> sameQueue, hierarchy, priorityC;
+    if (KQ_POL_WITHIN_CQ(sn.policy(ctx.preemptorCQ)) != KQ_POLICY_NEVER) getCandidatesFromCQ(ctx.preemptorCQ, -1, ctx, false, &sameQueue);
+    collectCandidatesForHierarchicalReclaim(ctx, &hierarchy, &priorityC);
+    auto sortL = [&](std::vector<candidateElem>& v) {
+      std::sort(v.begin(), v.end(), [&](const candidateElem& a, const candidateElem& b) { return CandidatesOrdering(a.wl, b.wl, ctx.preemptorCQ) < 0; });
+    };
+    sortL(sameQueue); sortL(priorityC); sortL(hierarchy);
+    auto split = [&](const std::vector<candidateElem>& v, std::vector<candidateElem>* ev, std::vector<candidateElem>* nev) {
+      size_t k = 0;
+      while (k < v.size() && (sn.s->adm_flags[v[k].wl] & KQ_ADM_EVICTED)) k++;
+      ev->assign(v.begin(), v.begin() + k); nev->assign(v.begin() + k, v.end());
+    };
+    std::vector<candidateElem> eh, nh, ep, np, es, ns, all;
+    split(hierarchy, &eh, &nh); split(priorityC, &ep, &np); split(sameQueue, &es, &ns);
+    for (auto* l : {&eh, &ep, &es, &nh, &np, &ns}) all.insert(all.end(), l->begin(), l->end());
+    bool NoCandidateFromOtherQueues = hierarchy.empty() && priorityC.empty();
+    bool NoCandidateForHierarchicalReclaim = hierarchy.empty();
+    bool forbidden = IsBorrowingWithinCohortForbidden(ctx.preemptorCQ);
+    std::vector<bool> attempts;
+    if (NoCandidateFromOtherQueues || (forbidden && !queueUnderNominalInResourcesNeedingPreemption(ctx))) attempts = {true};
+    else if (forbidden && NoCandidateForHierarchicalReclaim) attempts = {false, true};
+    else attempts = {true, false};
+    for (bool borrowing : attempts) {
+      std::vector<Target> targets;
+      for (size_t runIndex = 0; runIndex < all.size(); runIndex++) {
+        const candidateElem& c = all[runIndex];
+        if (!candidateIsValid(ctx, c, borrowing)) continue;
+        sn.RemoveWorkload(c.wl);
+        targets.push_back({c.wl, variantReason(c.variant)});
+        if (workloadFits(ctx, borrowing)) {
+          targets = fillBackWorkloads(ctx, targets, borrowing);
+          restoreSnapshot(targets);
+          return targets;
+        }
+      }
+      restoreSnapshot(targets);
+    }
+    return {};
+  }
+
+  // ---------- fair sharing (preemption.go:381-631, fairsharing/*.go) ----------
+  struct Ordering {  // fairsharing/ordering.go:46-90
+    int preemptorCq;
+    std::set<int> preemptorAncestors;
+    std::map<int, std::vector<int>> clusterQueueToTarget;  // cq -> rows (in given order)
+    std::set<int> prunedClusterQueues, prunedCohorts;
+    bool hasWorkload(int cq) const { auto it = clusterQueueToTarget.find(cq); return it != clusterQueueToTarget.end() && !it->second.empty(); }
+    int PopWorkload(int cq) { auto& v = clusterQueueToTarget[cq]; int h = v.front(); v.erase(v.begin()); return h; }
+  };
+  Ordering MakeClusterQueueOrdering(int cq, const std::vector<int>& candidates) {
+    Ordering t; t.preemptorCq = cq;
+    for (int a = sn.Parent(cq); a >= 0; a = sn.Parent(a)) t.preemptorAncestors.insert(a);
+    for (int row : candidates) t.clusterQueueToTarget[sn.adm_cq[row]].push_back(row);
+    return t;
+  }
+  // fairsharing/ordering.go:144-226 ; returns target cq or -1
+  int nextTarget(Ordering& t, int cohort) {
+    int highestCq = -1; DRS highestCqDrs = NegativeDRS();
+    for (int i = 0; i < sn.nChildCQs(cohort); i++) {
+      int cq = sn.childCQ(cohort, i);
+      if (t.prunedClusterQueues.count(cq)) continue;
+      DRS drs = dominantResourceShare(sn, cq);
+      if ((!drs.IsBorrowing() && cq != t.preemptorCq) || !t.hasWorkload(cq)) {
+        t.prunedClusterQueues.insert(cq);
+      } else if (CompareDRS(drs, highestCqDrs) == 0) {
+        int newCandWl = t.clusterQueueToTarget[cq][0];
+        int currentCandWl = t.clusterQueueToTarget[highestCq][0];
+        if (CandidatesOrdering(newCandWl, currentCandWl, t.preemptorCq) < 0) highestCq = cq;
+      } else if (CompareDRS(drs, highestCqDrs) == 1) {
+        highestCqDrs = drs; highestCq = cq;
+      }
+    }
+    int highestCohort = -1; DRS highestCohortDrs = NegativeDRS();
+    for (int i = 0; i < sn.nChildCohorts(cohort); i++) {
+      int ch = sn.childCohort(cohort, i);
+      if (t.prunedCohorts.count(ch)) continue;
+      DRS drs = dominantResourceShare(sn, ch);
+      if (!drs.IsBorrowing() && !t.preemptorAncestors.count(ch)) t.prunedCohorts.insert(ch);
+      else if (CompareDRS(drs, highestCohortDrs) >= 0) { highestCohortDrs = drs; highestCohort = ch; }
+    }
+    if (highestCohort < 0 && highestCq < 0) { t.prunedCohorts.insert(cohort); return -1; }
+    if (CompareDRS(highestCohortDrs, highestCqDrs) >= 0) return nextTarget(t, highestCohort);
+    return highestCq;
+  }
+  // least_common_ancestor.go:27-58 ; returns nodes (almostLCA of preemptor, of target)
+  std::pair<int, int> getAlmostLCAs(const Ordering& t, int targetCq) const {
+    int lca = -1;
+    for (int a = sn.Parent(targetCq); a >= 0; a = sn.Parent(a)) if (t.preemptorAncestors.count(a)) { lca = a; break; }
+    auto almost = [&](int cq) { int aLca = cq; for (int a = sn.Parent(cq); a >= 0; a = sn.Parent(a)) { if (a == lca) return aLca; aLca = a; } return aLca; };
+    return {almost(t.preemptorCq), almost(targetCq)};
+  }
+  static bool strategyPass(int strategy, const DRS& preemptorNew, const DRS& targetOld, const DRS& targetNew) {  // strategy.go:41,46
+    if (strategy == KQ_FS_LESS_THAN_OR_EQUAL_TO_FINAL_SHARE) return CompareDRS(preemptorNew, targetNew) <= 0;
+    return CompareDRS(preemptorNew, targetOld) < 0;
+  }
+  // preemption.go:690-695
+  bool workloadFitsForFairSharing(const PreemptionCtx& ctx) {
+    sn.RemoveUsage(ctx.preemptorCQ, ctx.workloadUsage);
+    bool res = workloadFits(ctx, true);
+    sn.AddUsage(ctx.preemptorCQ, ctx.workloadUsage);
+    return res;
+  }
+  // The Iter() protocol of ordering.go:92-127 folded into a "next" call. Returns target cq or -1 when done.
+  int orderingNext(Ordering& t) {
+    if (!sn.HasParent(t.preemptorCq)) {
+      if (!t.prunedClusterQueues.count(t.preemptorCq) && t.hasWorkload(t.preemptorCq)) return t.preemptorCq;
+      return -1;
+    }
+    int root = sn.Root(t.preemptorCq);
+    while (!t.prunedCohorts.count(root)) {
+      int target = nextTarget(t, root);
+      if (target < 0) continue;
+      return target;
+    }
+    return -1;
+  }
+  // preemption.go:384-470
+  bool runFirstFsStrategy(const PreemptionCtx& ctx, const std::vector<int>& candidates, int strategy, std::vector<Target>* targets, std::vector<int>* retryCandidates) {
+    Ordering ordering = MakeClusterQueueOrdering(ctx.preemptorCQ, candidates);
+    bool preemptorWithinNominal = sn.gate(KQ_GATE_FS_PREEMPT_WITHIN_NOMINAL) && queueWithinNominalInResourcesNeedingPreemption(ctx);
+    for (int candCQ = orderingNext(ordering); candCQ >= 0; candCQ = orderingNext(ordering)) {
+      if (candCQ == ctx.preemptorCQ) {  // InClusterQueuePreemption
+        int candWl = ordering.PopWorkload(candCQ);
+        sn.RemoveWorkload(candWl);
+        targets->push_back({candWl, KQ_REASON_IN_CLUSTER_QUEUE});
+        if (workloadFitsForFairSharing(ctx)) return true;
+        continue;
+      }
+      if (preemptorWithinNominal) {
+        int candWl = ordering.PopWorkload(candCQ);
+        sn.RemoveWorkload(candWl);
+        targets->push_back({candWl, KQ_REASON_IN_COHORT_RECLAMATION});
+        if (workloadFitsForFairSharing(ctx)) return true;
+        continue;
+      }
+      auto al = getAlmostLCAs(ordering, candCQ);
+      DRS preemptorNewShare = dominantResourceShare(sn, al.first), targetOldShare = dominantResourceShare(sn, al.second);
+      // fsStrategyUnsatisfiable :494-497
+      if (std::isinf(preemptorNewShare.PreciseWeightedShare()) && preemptorNewShare.PreciseWeightedShare() > 0 &&
+          !(std::isinf(targetOldShare.PreciseWeightedShare()) && targetOldShare.PreciseWeightedShare() > 0)) {
+        while (ordering.hasWorkload(candCQ)) retryCandidates->push_back(ordering.PopWorkload(candCQ));
+        continue;
+      }
+      while (ordering.hasWorkload(candCQ)) {
+        int candWl = ordering.PopWorkload(candCQ);
+        // ComputeTargetShareAfterRemoval target.go:67-73
+        FRQ u = sn.admUsage(candWl);
+        sn.RemoveUsage(candCQ, u);
+        DRS targetNewShare = dominantResourceShare(sn, getAlmostLCAs(ordering, candCQ).second);
+        sn.AddUsage(candCQ, u);
+        if (strategyPass(strategy, preemptorNewShare, targetOldShare, targetNewShare)) {
+          sn.RemoveWorkload(candWl);
+          targets->push_back({candWl, KQ_REASON_IN_COHORT_FAIR_SHARING});
+          if (workloadFitsForFairSharing(ctx)) return true;
+          break;
+        } else {
+          retryCandidates->push_back(candWl);
+        }
+      }
+    }
+    return false;
+  }
+  // preemption.go:501-534
+  bool runSecondFsStrategy(const std::vector<int>& retryCandidates, const PreemptionCtx& ctx, std::vector<Target>* targets) {
+    Ordering ordering = MakeClusterQueueOrdering(ctx.preemptorCQ, retryCandidates);
+    for (int candCQ = orderingNext(ordering); candCQ >= 0; candCQ = orderingNext(ordering)) {
+      auto al = getAlmostLCAs(ordering, candCQ);
+      DRS preemptorNewShare = dominantResourceShare(sn, al.first), targetOldShare = dominantResourceShare(sn, al.second);
+      bool passed = CompareDRS(preemptorNewShare, targetOldShare) < 0;
+      int candWl = ordering.PopWorkload(candCQ);
+      if (passed) {
+        sn.RemoveWorkload(candWl);
+        targets->push_back({candWl, KQ_REASON_IN_COHORT_FAIR_SHARING});
+        if (workloadFitsForFairSharing(ctx)) return true;
+      }
+      ordering.prunedClusterQueues.insert(candCQ);  // DropQueue
+    }
+    return false;
+  }
+  // preemption.go:633-667
+  std::vector<int> findCandidates(const PreemptionCtx& ctx) {
+    std::vector<int> candidates;
+    int cq = ctx.preemptorCQ; uint32_t p = sn.policy(cq);
+    auto forPolicy = [&](int c, int policy) {  // findCandidatesForPolicy :599-627
+      for (int row = sn.s->cq_adm_off[c]; row < sn.s->cq_adm_off[c + 1]; row++) {
+        if (sn.removed[row]) continue;
+        sn.st.victim_bytes += 32 + 12 * (sn.s->adm_use_off[row + 1] - sn.s->adm_use_off[row]);
+        if (!SatisfiesPreemptionPolicy(*ctx.preemptor, row, policy)) continue;
+        if (!WorkloadUsesResources(row, ctx.frsNeedPreemption)) continue;
+        candidates.push_back(row);
+      }
+    };
+    if (KQ_POL_WITHIN_CQ(p) != KQ_POLICY_NEVER) forPolicy(cq, KQ_POL_WITHIN_CQ(p));
+    if (sn.HasParent(cq) && KQ_POL_RECLAIM(p) != KQ_POLICY_NEVER) {
+      std::vector<int> cqs; sn.SubtreeClusterQueues(sn.Root(cq), &cqs);
+      for (int cohortCQ : cqs) {
+        bool borrowing = false;  // cqIsBorrowing :657-667
+        if (sn.HasParent(cohortCQ)) for (int fr : ctx.frsNeedPreemption) if (sn.Borrowing(cohortCQ, fr)) { borrowing = true; break; }
+        if (cq == cohortCQ || !borrowing) continue;
+        forPolicy(cohortCQ, KQ_POL_RECLAIM(p));
+      }
+    }
+    return candidates;
+  }
+  // preemption.go:536-597
+  std::vector<Target> fairPreemptions(const PreemptionCtx& ctx) {
+    std::vector<int> candidates = findCandidates(ctx);
+    if (candidates.empty()) return {};
+    sortCandidates(candidates, ctx.preemptorCQ);
+    sn.AddUsage(ctx.preemptorCQ, ctx.workloadUsage);  // SimulateUsageAddition :557
+    std::vector<Target> targets; std::vector<int> retry;
+    bool fits = runFirstFsStrategy(ctx, candidates, fsStrategies[0], &targets, &retry);
+    if (!fits && fsStrategies.size() > 1) fits = runSecondFsStrategy(retry, ctx, &targets);
+    sn.RemoveUsage(ctx.preemptorCQ, ctx.workloadUsage);  // revertSimulation
+    if (!fits) { restoreSnapshot(targets); return {}; }
+    targets = fillBackWorkloads(ctx, targets, true);
+    restoreSnapshot(targets);
+    return targets;
+  }
+  // preemption.go:157-162
+  std::vector<Target> getTargets(const PreemptionCtx& ctx) {
+    if (enableFairSharing) return fairPreemptions(ctx);
+    return classicalPreemptions(ctx);
+  }
+  // preemption_oracle.go:43-85
+  std::pair<int, int> SimulatePreemption(int cq, const Head& wl, int fr, Amount quantity) {
+    PreemptionCtx ctx; ctx.preemptor = &wl; ctx.preemptorCQ = wl.cq; ctx.frsNeedPreemption = {fr}; ctx.workloadUsage[fr] = quantity;
+    std::vector<Target> candidates = getTargets(ctx);
+    if (candidates.empty()) return {ppNoCandidates, sn.FindHeightOfLowestSubtreeThatFits(cq, fr, quantity).first};
+    // SimulateWorkloadUsageRemoval snapshot.go:80-100
+    for (auto& c : candidates) sn.RemoveUsage(sn.adm_cq[c.row], sn.admUsage(c.row));
+    int borrowAfter = sn.FindHeightOfLowestSubtreeThatFits(cq, fr, quantity).first;
+    for (auto& c : candidates) sn.AddUsage(sn.adm_cq[c.row], sn.admUsage(c.row));
+    for (auto& c : candidates) if (sn.adm_cq[c.row] == cq) return {ppPreempt, borrowAfter};
+    return {ppReclaim, borrowAfter};
+  }
+  // Assignment.TotalRequestsFor flavorassigner.go:267-296 (no workload slices)
+  FRQ TotalRequestsFor(const Head& wl, Assignment& a) const {
+    FRQ usage;
+    for (size_t i = 0; i < wl.ps.size(); i++) {
+      const PodSetReq& ps = wl.ps[i];
+      int newCount = a.PodSets[i].count;
+      for (auto rq : ps.req) {
+        int64_t q = rq.second;
+        if (ps.count != 0 && ps.count != newCount) { q = q / (int64_t)ps.count; q = SaturatingMul(q, (int64_t)newCount); }
+        if (q == 0) continue;
+        auto it = a.PodSets[i].flavors.find(rq.first);
+        if (it == a.PodSets[i].flavors.end()) continue;  // IgnoreUndeclared path; BlockUndeclared never gets here with a Preempt assignment
+        int fr = it->second.flavor * sn.nR + rq.first;
+        usage[fr] = frq_get(usage, fr).AddInt64(q);
+      }
+    }
+    return usage;
+  }
+  // preemption.go:132-155 + flavorResourcesNeedPreemption :586-597
+  std::vector<Target> GetTargets(const Head& wl, Assignment& a) {
+    PreemptionCtx ctx; ctx.preemptor = &wl; ctx.preemptorCQ = wl.cq;
+    for (auto& ps : a.PodSets) for (auto& kv : ps.flavors) if (kv.second.mode == Preempt) ctx.frsNeedPreemption.insert(kv.second.flavor * sn.nR + kv.first);
+    ctx.workloadUsage = TotalRequestsFor(wl, a);
+    return getTargets(ctx);
+  }
+};
+
+// ---- scheduler (scheduler/scheduler.go) -----------------------------------------------------------
+struct Entry {
+  Head head;
+  Assignment assignment;
+  std::vector<Target> preemptionTargets;
+  int status = KQ_ST_NOT_NOMINATED;
+  int requeueReason = KQ_RQ_GENERIC;
+  int skip = KQ_SKIP_NONE;
+  int action = KQ_ACT_NONE;
+  int nominatedMode = NoFit;
+  int finalMode = NoFit;
+  int order = -1;
+};
+
+struct Scheduler {
+  Snap& sn;
+  const kq_heads* H;
+  Preemptor preemptor;
+  int64_t schedulingCycle;
+  OracleFn stubOracle;  // tests only (flavorassigner_test.go:159-176)
+
+  Scheduler(Snap& s, const kq_heads* h) : sn(s), H(h), preemptor(s), schedulingCycle(h->cycle) {}
+
+  Head loadHead(int i) const {
+    Head h; h.idx = i; h.cq = H->cq[i]; h.priority = H->priority[i]; h.queue_ts = H->queue_ts[i]; h.flags = H->flags[i];
+    h.ps_base = H->ps_off[i];
+    h.has_last = (h.flags & KQ_HEAD_HAS_LAST_ASSIGNMENT) != 0;
+    for (int p = H->ps_off[i]; p < H->ps_off[i + 1]; p++) {
+      PodSetReq ps; ps.count = H->ps_count[p]; ps.min_count = H->ps_min_count ? H->ps_min_count[p] : -1;
+      for (int k = H->ps_req_off[p]; k < H->ps_req_off[p + 1]; k++) ps.req.push_back({H->req_res[k], H->req_qty[k]});
+      h.ps.push_back(ps);
+      std::vector<int> lt(sn.nR, -1);
+      if (H->ps_last_tried) for (int r = 0; r < sn.nR; r++) lt[r] = H->ps_last_tried[(size_t)p * sn.nR + r];
+      h.last_tried.push_back(lt);
+    }
+    h.nomination.assign(h.ps.size(), {});
+    return h;
+  }
+  // scheduler.go:840-856
+  bool lastAssignmentOutdated(const Head& h) const {
+    int i = h.idx;
+    if (sn.gate(KQ_GATE_PRESERVE_SCAN_PROGRESS)) {
+      uint64_t lh = H->last_hash ? H->last_hash[i] : 0, ch = H->hash ? H->hash[i] : 0;
+      if (!(lh == 0 || ch == 0 || lh == ch)) return true;  // MatchesSchedulingShape workload.go:204
+      if (schedulingCycle - (H->last_cycle ? H->last_cycle[i] : 0) <= 1) return false;
+    }
+    return sn.s->cq_generation[h.cq] > (H->last_generation ? H->last_generation[i] : 0);
+  }
+  OracleFn makeOracle() {
+    if (stubOracle) return stubOracle;
+    return [this](int cq, const Head& wl, int fr, Amount q) { return preemptor.SimulatePreemption(cq, wl, fr, q); };
+  }
+  // scheduler.go:880-924
+  void getInitialAssignments(Head& wl, Assignment* outA, std::vector<Target>* outT) {
+    FlavorAssigner fa{sn, H, wl, wl.cq, sn.cfg.fair_sharing != 0, makeOracle()};
+    Assignment full = fa.assignFlavors(nullptr);
+    int arm = full.RepresentativeMode();
+    if (arm == Fit) { *outA = full; outT->clear(); return; }
+    if (arm == Preempt) {
+      std::vector<Target> t = preemptor.GetTargets(wl, full);
+      if (!t.empty()) { *outA = full; *outT = t; return; }
+    }
+    if (sn.gate(KQ_GATE_PARTIAL_ADMISSION) && wl.CanBePartiallyAdmitted()) {
+      // PodSetReducer podset_reducer.go:28-86 ; sort.Search = smallest i in [0,n) with f(i) true
+      int P = (int)wl.ps.size();
+      std::vector<int> fullCounts(P), deltas(P); int totalDelta = 0;
+      for (int i = 0; i < P; i++) { fullCounts[i] = wl.ps[i].count; int mc = wl.ps[i].min_count >= 0 ? wl.ps[i].min_count : wl.ps[i].count; deltas[i] = wl.ps[i].count - mc; totalDelta += deltas[i]; }
+      if (totalDelta != 0) {
+        int lastGoodIdx = 0; bool haveLast = false; Assignment lastA; std::vector<Target> lastT;
+        auto fits = [&](int si) {
+          std::vector<int> current(P);
+          for (int i = 0; i < P; i++) current[i] = fullCounts[i] - (int)((int64_t)deltas[i] * (int64_t)si / (int64_t)totalDelta);
+          Assignment a = fa.assignFlavors(&current);
+          int mode = a.RepresentativeMode();
+          if (mode == Fit) { lastGoodIdx = si; lastA = a; lastT.clear(); haveLast = true; return true; }
+          if (mode == Preempt) {
+            std::vector<Target> t = preemptor.GetTargets(wl, a);
+            if (!t.empty()) { lastGoodIdx = si; lastA = a; lastT = t; haveLast = true; return true; }
+          }
+          return false;
+        };
+        int lo = 0, hi = totalDelta + 1;  // sort.Search(n=totalDelta+1)
+        while (lo < hi) { int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1); if (!fits(mid)) lo = mid + 1; else hi = mid; }
+        if (haveLast && lo == lastGoodIdx) { *outA = lastA; *outT = lastT; return; }
+      }
+    }
+    *outA = full; outT->clear();
+  }
+  // scheduler.go:821-838 + recordAssignment :281-286
+  void getAssignments(Entry& e) {
+    if (e.head.has_last && lastAssignmentOutdated(e.head)) e.head.has_last = false;
+    getInitialAssignments(e.head, &e.assignment, &e.preemptionTargets);
+    // recordAssignment: LastAssignment = &assignment.LastState
+    e.head.has_last = true;
+    for (size_t p = 0; p < e.head.ps.size(); p++) {
+      std::vector<int> lt(sn.nR, -1);
+      if (p < e.assignment.PodSets.size()) for (auto& kv : e.assignment.PodSets[p].flavors) lt[kv.first] = kv.second.tried;
+      e.head.last_tried[p] = lt;
+    }
+    if (e.assignment.PodSets.size() < e.head.ps.size()) e.head.last_tried.resize(e.assignment.PodSets.size());
+  }
+  // scheduler.go:647 assignmentUsage -> netUsage :785-794
+  FRQ assignmentUsage(const Entry& e) const {
+    if (e.head.flags & KQ_HEAD_HAS_QUOTA_RESERVATION) return {};
+    return e.assignment.Usage;
+  }
+  // scheduler.go:771-777 ; canonical removal order = ascending admitted row
+  bool fits(int cq, const FRQ& usage, const std::set<int>& preempted, const std::vector<Target>& newTargets) {
+    std::set<int> merged = preempted;
+    for (auto& t : newTargets) merged.insert(t.row);
+    for (int row : merged) sn.RemoveUsage(sn.adm_cq[row], sn.admUsage(row));
+    sn.st.entry_bytes += (int64_t)usage.size() * 40 * (sn.depth[cq] + 1);
+    bool ok = sn.Fits(cq, usage);
+    for (int row : merged) sn.AddUsage(sn.adm_cq[row], sn.admUsage(row));
+    return ok;
+  }
+  static bool hasAny(const std::set<int>& p, const std::vector<Target>& t) { for (auto& x : t) if (p.count(x.row)) return true; return false; }
+  // scheduler.go:707-769
+  bool updateAssignmentIfNeeded(Entry& e, int cq, const std::set<int>& preempted, FRQ* usageOut) {
+    FRQ usage = assignmentUsage(e);
+    bool fitsCheck = fits(cq, usage, preempted, e.preemptionTargets);
+    bool needsOverlapRecompute = hasAny(preempted, e.preemptionTargets) && sn.gate(KQ_GATE_RECOMPUTE_ON_OVERLAP);
+    if (!needsOverlapRecompute) { *usageOut = usage; return fitsCheck; }
+    std::vector<int> victims(preempted.begin(), preempted.end());
+    for (int row : victims) sn.RemoveWorkload(row);  // SimulateWorkloadRemoval snapshot.go:105-114
+    e.head.has_last = false;
+    // readResourceToFlavorMapping :651-660
+    e.head.nomination.assign(e.head.ps.size(), {});
+    for (size_t p = 0; p < e.assignment.PodSets.size(); p++) for (auto& kv : e.assignment.PodSets[p].flavors) e.head.nomination[p][kv.first] = kv.second.flavor;
+    getAssignments(e);
+    for (int row : victims) sn.AddWorkload(row);
+    if (e.assignment.RepresentativeMode() == Fit) e.assignment.SetRepresentativeMode(DeferredFit);
+    usage = assignmentUsage(e);
+    fitsCheck = fits(cq, usage, preempted, e.preemptionTargets);
+    e.head.nomination.assign(e.head.ps.size(), {});
+    *usageOut = usage;
+    return fitsCheck;
+  }
+  // scheduler.go:796-814
+  FRQ quotaResourcesToReserve(Entry& e, int cq) {
+    if (e.assignment.RepresentativeMode() != Preempt) return e.assignment.Usage;
+    FRQ reserved;
+    for (auto& kv : e.assignment.Usage) {
+      int fr = kv.first; Amount usage = kv.second;
+      if (e.assignment.Borrowing > 0) {
+        if (!sn.hasBL(cq, fr)) reserved[fr] = usage;
+        else reserved[fr] = MinAmount(usage, sn.Nominal(cq, fr).Add(sn.BL(cq, fr)).Sub(sn.Usage(cq, fr)));
+      } else {
+        reserved[fr] = MaxAmount(Amount(0), MinAmount(usage, sn.Nominal(cq, fr).Sub(sn.Usage(cq, fr))));
+      }
+    }
+    return reserved;
+  }
+  // scheduler.go:392-523
+  void processEntry(Entry& e, std::set<int>& preemptedWorkloads) {
+    int cq = e.head.cq;
+    FRQ usage;
+    bool fitsOk = updateAssignmentIfNeeded(e, cq, preemptedWorkloads, &usage);
+    int mode = e.assignment.RepresentativeMode();
+    e.finalMode = mode;
+    if (mode == NoFit) { e.requeueReason = KQ_RQ_NOFIT; return; }
+    if (mode == Preempt) {
+      if (e.preemptionTargets.empty()) {
+        e.requeueReason = KQ_RQ_PREEMPTION_NO_CANDIDATES;
+        // reserveCapacityForUnreclaimablePreempt :538-543 ; CanAlwaysReclaim policy.go:27
+        bool canAlwaysReclaim = KQ_POL_RECLAIM(sn.policy(cq)) == KQ_POLICY_ANY;
+        if (!canAlwaysReclaim || (sn.gate(KQ_GATE_PRIORITIZE_PREEMPTORS) && (e.head.flags & KQ_HEAD_IS_PREEMPTOR))) {
+          FRQ r = (e.head.flags & KQ_HEAD_HAS_QUOTA_RESERVATION) ? FRQ() : quotaResourcesToReserve(e, cq);  // resourcesToReserve :780 via netUsage
+          sn.AddUsage(cq, r);
+          sn.st.entry_bytes += (int64_t)r.size() * 8 * (sn.depth[cq] + 1);
+        }
+        return;
+      }
+    }
+    if (mode == DeferredFit) {
+      e.requeueReason = KQ_RQ_PENDING_PREEMPTION;
+      e.head.has_last = false;
+      sn.AddUsage(cq, usage);
+      return;
+    }
+    if (hasAny(preemptedWorkloads, e.preemptionTargets)) { e.status = KQ_ST_SKIPPED; e.skip = KQ_SKIP_OVERLAP; return; }
+    if (!fitsOk) { e.status = KQ_ST_SKIPPED; e.skip = KQ_SKIP_NO_LONGER_FITS; return; }
+    for (auto& t : e.preemptionTargets) preemptedWorkloads.insert(t.row);
+    sn.AddUsage(cq, usage);
+    sn.st.entry_bytes += (int64_t)usage.size() * 8 * (sn.depth[cq] + 1);
+    if (mode == Preempt) {
+      // issuePreemptions :563 -> markPreemptionOutcome :291 (all evictions assumed to succeed)
+      e.action = KQ_ACT_PREEMPT;
+      e.requeueReason = KQ_RQ_PENDING_PREEMPTION;
+      return;
+    }
+    e.status = KQ_ST_ASSUMED;  // markNominated + admit -> assumeWorkload -> markAssumed
+    e.action = KQ_ACT_ADMIT;
+  }
+
+  // scheduler.go:1110-1163 ; unstable sort w/ ties -> canonical: stable sort
+  std::vector<int> classicalOrder(std::vector<Entry>& entries) {
+    std::vector<int> ord(entries.size());
+    for (size_t i = 0; i < ord.size(); i++) ord[i] = (int)i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) {
+      Entry &a = entries[x], &b = entries[y];
+      bool aq = a.head.flags & KQ_HEAD_HAS_QUOTA_RESERVATION, bq = b.head.flags & KQ_HEAD_HAS_QUOTA_RESERVATION;
+      if (aq != bq) return aq;
+      if (sn.gate(KQ_GATE_PRIORITIZE_PREEMPTORS)) {
+        bool ap = a.head.flags & KQ_HEAD_IS_PREEMPTOR, bp = b.head.flags & KQ_HEAD_IS_PREEMPTOR;
+        if (ap != bp) return ap;
+      }
+      if (a.assignment.Borrowing != b.assignment.Borrowing) return a.assignment.Borrowing < b.assignment.Borrowing;
+      if (sn.gate(KQ_GATE_PRIORITY_SORTING_IN_COHORT) && a.head.priority != b.head.priority) return a.head.priority > b.head.priority;
+      return a.head.queue_ts < b.head.queue_ts;
+    });
+    return ord;
+  }
+
+  // ---- fair sharing iterator: fair_sharing_iterator.go ----
+  struct DrsKey { int cohort; int entry; bool operator<(const DrsKey& o) const { return cohort != o.cohort ? cohort < o.cohort : entry < o.entry; } };
+  std::map<DrsKey, DRS> drsValues;
+  std::map<int, FRQ> requestedFRs;
+  // fair_sharing_iterator.go:227-263
+  void computeDRS(int rootCohort, std::vector<Entry>& entries, const std::map<int, int>& cqToEntry) {
+    drsValues.clear(); requestedFRs.clear();
+    std::vector<int> cqs; sn.SubtreeClusterQueues(rootCohort, &cqs);
+    for (int cq : cqs) {
+      auto it = cqToEntry.find(cq);
+      if (it == cqToEntry.end()) continue;
+      Entry& e = entries[it->second];
+      FRQ usage = assignmentUsage(e);
+      sn.AddUsage(cq, usage);
+      if (sn.gate(KQ_GATE_FS_PRIORITIZE_NON_BORROWING)) requestedFRs[it->second] = usage;
+      DRS d = dominantResourceShare(sn, cq);
+      for (int anc = sn.Parent(cq); anc >= 0; anc = sn.Parent(anc)) {
+        drsValues[{anc, it->second}] = d;
+        d = dominantResourceShare(sn, anc);
+      }
+      sn.RemoveUsage(cq, usage);
+    }
+  }
+  // fair_sharing_iterator.go:176-221
+  bool less(std::vector<Entry>& entries, int a, int b, int parentCohort) {
+    Entry &ea = entries[a], &eb = entries[b];
+    if (sn.gate(KQ_GATE_PRIORITIZE_PREEMPTORS)) {
+      bool ap = ea.head.flags & KQ_HEAD_IS_PREEMPTOR, bp = eb.head.flags & KQ_HEAD_IS_PREEMPTOR;
+      if (ap != bp) return ap;
+    }
+    DRS aDrs = drsValues.count({parentCohort, a}) ? drsValues[{parentCohort, a}] : DRS{0, 0, -1, false, {}};
+    DRS bDrs = drsValues.count({parentCohort, b}) ? drsValues[{parentCohort, b}] : DRS{0, 0, -1, false, {}};
+    if (sn.gate(KQ_GATE_FS_PRIORITIZE_NON_BORROWING)) {
+      bool aB = aDrs.IsBorrowingOn(requestedFRs[a]), bB = bDrs.IsBorrowingOn(requestedFRs[b]);
+      if (aB != bB) return !aB;
+    }
+    int c = CompareDRS(aDrs, bDrs);
+    if (c != 0) return c == -1;
+    if (sn.gate(KQ_GATE_PRIORITY_SORTING_IN_COHORT) && ea.head.priority != eb.head.priority) return ea.head.priority > eb.head.priority;
+    return ea.head.queue_ts < eb.head.queue_ts;
+  }
+  // fair_sharing_iterator.go:125-163 ; returns entry index or -1
+  int runTournament(int cohort, std::vector<Entry>& entries, const std::map<int, int>& cqToEntry) {
+    std::vector<int> candidates;
+    for (int i = 0; i < sn.nChildCohorts(cohort); i++) { int c = runTournament(sn.childCohort(cohort, i), entries, cqToEntry); if (c >= 0) candidates.push_back(c); }
+    for (int i = 0; i < sn.nChildCQs(cohort); i++) { auto it = cqToEntry.find(sn.childCQ(cohort, i)); if (it != cqToEntry.end()) candidates.push_back(it->second); }
+    if (candidates.empty()) return -1;
+    int best = candidates[0];
+    for (size_t k = 1; k < candidates.size(); k++) if (less(entries, candidates[k], best, cohort)) best = candidates[k];
+    return best;
+  }
+  // fair_sharing_iterator.go:47-119 ; getCq: canonical = lowest CQ index remaining
+  std::vector<int> fairOrder(std::vector<Entry>& entries) {
+    std::map<int, int> cqToEntry;
+    for (size_t i = 0; i < entries.size(); i++) cqToEntry[entries[i].head.cq] = (int)i;  // later entry of same CQ overwrites (:58-60)
+    std::vector<int> ord;
+    while (!cqToEntry.empty()) {
+      int cq = cqToEntry.begin()->first;
+      if (!sn.HasParent(cq)) { ord.push_back(cqToEntry[cq]); cqToEntry.erase(cq); continue; }
+      int root = sn.Root(cq);
+      computeDRS(root, entries, cqToEntry);
+      int w = runTournament(root, entries, cqToEntry);
+      ord.push_back(w);
+      cqToEntry.erase(entries[w].head.cq);
+    }
+    return ord;
+  }
+
+  // scheduler.go:308-386 steps 3-5
+  void schedule(std::vector<Entry>& entries) {
+    entries.clear();
+    for (int i = 0; i < H->n; i++) {  // nominate :665-705 (gatekeeping branches are host-side)
+      Entry e; e.head = loadHead(i);
+      getAssignments(e);
+      e.nominatedMode = e.assignment.RepresentativeMode();
+      entries.push_back(std::move(e));
+    }
+    std::vector<int> ord = sn.cfg.fair_sharing ? fairOrder(entries) : classicalOrder(entries);
+    std::set<int> preemptedWorkloads;
+    int pos = 0;
+    for (int i : ord) { entries[i].order = pos++; processEntry(entries[i], preemptedWorkloads); }
+    // entries dropped by the fair-sharing map (duplicate CQ) are never processed; finalMode = nominated
+    for (auto& e : entries) if (e.order < 0) e.finalMode = e.nominatedMode;
+  }
+};
+
+// resource_node.go:183-230 updateCohortResourceNode / accumulateFromChild
+static void deriveCohort(const kq_snapshot* s, int nq, int nfr, int cohort, std::vector<int64_t>& sq, std::vector<int64_t>& us, std::vector<uint8_t>& fl) {
+  int k = cohort - nq;
+  auto ix = [&](int n, int fr) { return (size_t)n * nfr + fr; };
+  for (int fr = 0; fr < nfr; fr++) {
+    sq[ix(cohort, fr)] = 0; us[ix(cohort, fr)] = 0; fl[ix(cohort, fr)] &= ~KQ_QF_SUBTREE;
+    if (fl[ix(cohort, fr)] & KQ_QF_QUOTA) { sq[ix(cohort, fr)] = s->nominal[ix(cohort, fr)]; fl[ix(cohort, fr)] |= KQ_QF_SUBTREE; }
+  }
+  auto localQuota = [&](int n, int fr) {
+    int64_t ll = s->lend_limit[ix(n, fr)];
+    if (ll != KQ_NIL_LIMIT) return MaxAmount(Amount(0), Amount(sq[ix(n, fr)]).Sub(Amount(ll)));
+    return Amount(0);
+  };
+  auto accumulate = [&](int child) {
+    for (int fr = 0; fr < nfr; fr++) {
+      if (fl[ix(child, fr)] & KQ_QF_SUBTREE) {
+        Amount delta = Amount(sq[ix(child, fr)]).Sub(localQuota(child, fr));
+        sq[ix(cohort, fr)] = Amount(sq[ix(cohort, fr)]).Add(delta).v;
+        fl[ix(cohort, fr)] |= KQ_QF_SUBTREE;
+      }
+      // Usage map keys: every fr with a usage entry; a zero entry contributes max(0, 0-lq)=0
+      Amount d = MaxAmount(Amount(0), Amount(us[ix(child, fr)]).Sub(localQuota(child, fr)));
+      us[ix(cohort, fr)] = Amount(us[ix(cohort, fr)]).Add(d).v;
+    }
+  };
+  for (int i = s->child_cohort_off[k]; i < s->child_cohort_off[k + 1]; i++) { deriveCohort(s, nq, nfr, s->child_cohort[i], sq, us, fl); accumulate(s->child_cohort[i]); }
+  for (int i = s->child_cq_off[k]; i < s->child_cq_off[k + 1]; i++) {
+    int cq = s->child_cq[i];
+    for (int fr = 0; fr < nfr; fr++) {  // updateClusterQueueResourceNode :167-173
+      fl[ix(cq, fr)] &= ~KQ_QF_SUBTREE; sq[ix(cq, fr)] = 0;
+      if (fl[ix(cq, fr)] & KQ_QF_QUOTA) { sq[ix(cq, fr)] = s->nominal[ix(cq, fr)]; fl[ix(cq, fr)] |= KQ_QF_SUBTREE; }
+    }
+    accumulate(cq);
+  }
+}
+
+}  // namespace kqo
+
+// =================================== C entry points (tests / cpu_baseline) ==========================
+using namespace kqo;
+
+static void writeDecisions(Snap& sn, const kq_heads* h, std::vector<Entry>& entries, kq_decisions* out, int* rc) {
+  int nR = sn.nR;
+  int ntgt = 0;
+  for (int i = 0; i < h->n; i++) {
+    Entry& e = entries[i];
+    if (out->status) out->status[i] = (uint8_t)e.status;
+    if (out->action) out->action[i] = (uint8_t)e.action;
+    if (out->nominated_mode) out->nominated_mode[i] = (uint8_t)e.nominatedMode;
+    if (out->mode) out->mode[i] = (uint8_t)e.finalMode;
+    if (out->requeue_reason) {
+      int rq = e.requeueReason;
+      if (e.status != KQ_ST_NOT_NOMINATED && e.status != KQ_ST_ASSUMED && rq == KQ_RQ_GENERIC) rq = KQ_RQ_FAILED_AFTER_NOMINATION;  // scheduler.go:1167-1170
+      out->requeue_reason[i] = (uint8_t)rq;
+    }
+    if (out->skip) out->skip[i] = (uint8_t)e.skip;
+    if (out->borrowing) out->borrowing[i] = e.assignment.Borrowing;
+    if (out->order) out->order[i] = e.order;
+    for (int p = h->ps_off[i]; p < h->ps_off[i + 1]; p++) {
+      int lp = p - h->ps_off[i];
+      for (int r = 0; r < nR; r++) {
+        size_t k = (size_t)p * nR + r;
+        if (out->flavor) out->flavor[k] = -1;
+        if (out->res_mode) out->res_mode[k] = NoFit;
+        if (out->tried_idx) out->tried_idx[k] = -1;
+      }
+      if (out->ps_count) out->ps_count[p] = h->ps_count[p];
+      if (lp < (int)e.assignment.PodSets.size()) {
+        PodSetAssignment& psa = e.assignment.PodSets[lp];
+        if (out->ps_count) out->ps_count[p] = psa.count;
+        for (auto& kv : psa.flavors) {
+          size_t k = (size_t)p * nR + kv.first;
+          if (out->flavor) out->flavor[k] = kv.second.flavor;
+          if (out->res_mode) out->res_mode[k] = (uint8_t)kv.second.mode;
+          if (out->tried_idx) out->tried_idx[k] = kv.second.tried;
+        }
+      }
+    }
+    if (out->tgt_off) out->tgt_off[i] = ntgt;
+    // canonical target order inside an entry: ascending admitted row (the reference tests compare sets)
+    std::vector<Target> ts = e.preemptionTargets;
+    std::sort(ts.begin(), ts.end(), [](const Target& a, const Target& b) { return a.row < b.row; });
+    for (auto& t : ts) {
+      if (ntgt >= out->tgt_cap) { *rc = KQ_ECAPACITY; continue; }
+      if (out->tgt_adm) out->tgt_adm[ntgt] = t.row;
+      if (out->tgt_reason) out->tgt_reason[ntgt] = (uint8_t)t.reason;
+      ntgt++;
+    }
+  }
+  if (out->tgt_off) out->tgt_off[h->n] = ntgt;
+}
+
+extern "C" {
+
+// One scheduling cycle on the CPU. stats[0..5] (optional): cells, cell_bytes, head_io, entry, victim, drs
+int kqo_cycle_run(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, kq_decisions* out, int64_t* stats, int64_t* usage_after) {
+  Snap sn(*cfg, s);
+  Scheduler sch(sn, h);
+  std::vector<Entry> entries;
+  sch.schedule(entries);
+  int rc = KQ_OK;
+  writeDecisions(sn, h, entries, out, &rc);
+  if (stats) { stats[0] = sn.st.cells; stats[1] = sn.st.cell_bytes; stats[2] = sn.st.head_io_bytes; stats[3] = sn.st.entry_bytes; stats[4] = sn.st.victim_bytes; stats[5] = sn.st.drs_bytes; }
+  if (usage_after) memcpy(usage_after, sn.usage.data(), sn.usage.size() * sizeof(int64_t));
+  return rc;
+}
+
+// FlavorAssigner.Assign for head `hi` with an optional STUB preemption oracle, as
+// TestAssignFlavors drives it (flavorassigner_test.go:159-176,3641-3652): stub_fr[k] ->
+// (stub_poss[k], stub_borrow[k]); any other fr -> (Preempt, 0). n_stub < 0 selects the real oracle.
+// counts: optional per-podset counts (partial admission).
+int kqo_assign(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, int hi, const int32_t* counts,
+               int n_stub, const int32_t* stub_fr, const int32_t* stub_poss, const int32_t* stub_borrow,
+               int32_t* flavor, uint8_t* res_mode, int32_t* tried_idx, int32_t* res_borrow,
+               int32_t* rep_mode, int32_t* borrowing, int64_t* usage_fr /* [n_fr] dense, 0 if absent */, int32_t* ps_nreasons) {
+  Snap sn(*cfg, s);
+  Scheduler sch(sn, h);
+  Head wl = sch.loadHead(hi);
+  OracleFn orc;
+  if (n_stub >= 0) {
+    orc = [=](int, const Head&, int fr, Amount) -> std::pair<int, int> {
+      for (int k = 0; k < n_stub; k++) if (stub_fr[k] == fr) return {stub_poss[k], stub_borrow[k]};
+      return {ppPreempt, 0};
+    };
+  } else {
+    orc = sch.makeOracle();
+  }
+  FlavorAssigner fa{sn, h, wl, wl.cq, cfg->fair_sharing != 0, orc};
+  std::vector<int> cv;
+  if (counts) cv.assign(counts, counts + wl.ps.size());
+  Assignment a = fa.assignFlavors(counts ? &cv : nullptr);
+  int P = (int)wl.ps.size();
+  for (int p = 0; p < P; p++) {
+    for (int r = 0; r < sn.nR; r++) { size_t k = (size_t)p * sn.nR + r; flavor[k] = -1; res_mode[k] = NoFit; tried_idx[k] = -1; if (res_borrow) res_borrow[k] = 0; }
+    if (ps_nreasons) ps_nreasons[p] = 0;
+    if (p < (int)a.PodSets.size()) {
+      if (ps_nreasons) ps_nreasons[p] = a.PodSets[p].nreasons;
+      for (auto& kv : a.PodSets[p].flavors) { size_t k = (size_t)p * sn.nR + kv.first; flavor[k] = kv.second.flavor; res_mode[k] = (uint8_t)kv.second.mode; tried_idx[k] = kv.second.tried; if (res_borrow) res_borrow[k] = kv.second.borrow; }
+    }
+  }
+  *rep_mode = a.RepresentativeMode();
+  *borrowing = a.Borrowing;
+  if (usage_fr) { for (int fr = 0; fr < sn.nfr; fr++) usage_fr[fr] = 0; for (auto& kv : a.Usage) usage_fr[kv.first] = kv.second.v; }
+  return KQ_OK;
+}
+
+// Preemptor.GetTargets for head `hi` given an explicit assignment (flavor + mode per (podset,resource)),
+// as TestPreemption drives it (preemption_test.go:4093-4170). Checks the snapshot is restored exactly.
+int kqo_get_targets(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, int hi,
+                    const int32_t* flavor, const uint8_t* res_mode, int32_t cap, int32_t* tgt_adm, uint8_t* tgt_reason, int32_t* n_out) {
+  Snap sn(*cfg, s);
+  Scheduler sch(sn, h);
+  Head wl = sch.loadHead(hi);
+  Assignment a;
+  for (size_t p = 0; p < wl.ps.size(); p++) {
+    PodSetAssignment psa; psa.count = wl.ps[p].count; psa.nreasons = 1;
+    for (int r = 0; r < sn.nR; r++) { size_t k = p * sn.nR + r; if (flavor[k] >= 0) { FlavorAssignment f; f.flavor = flavor[k]; f.mode = res_mode[k]; psa.flavors[r] = f; } }
+    a.PodSets.push_back(psa);
+  }
+  std::vector<int64_t> before = sn.usage;
+  std::vector<Target> t = sch.preemptor.GetTargets(wl, a);
+  if (before != sn.usage) return KQ_EINVAL;  // snapshot-restoration invariant (preemption_test.go:4172)
+  for (auto x : sn.removed) if (x) return KQ_EINVAL;
+  std::sort(t.begin(), t.end(), [](const Target& x, const Target& y) { return x.row < y.row; });
+  *n_out = (int)t.size();
+  for (size_t i = 0; i < t.size() && (int)i < cap; i++) { tgt_adm[i] = t[i].row; tgt_reason[i] = (uint8_t)t[i].reason; }
+  return (int)t.size() > cap ? KQ_ECAPACITY : KQ_OK;
+}
+
+// Recompute SubtreeQuota (all nodes), cohort Usage and the SUBTREE flag from Quotas + CQ usage.
+int kqo_derive(const kq_snapshot* s, int64_t* subtree_quota, int64_t* usage, uint8_t* quota_flags) {
+  int nq = s->n_cq, N = nq + s->n_cohort, nfr = s->n_flavor * s->n_resource;
+  std::vector<int64_t> sq((size_t)N * nfr, 0), us(s->usage, s->usage + (size_t)N * nfr);
+  std::vector<uint8_t> fl(s->quota_flags, s->quota_flags + (size_t)N * nfr);
+  for (int cq = 0; cq < nq; cq++) for (int fr = 0; fr < nfr; fr++) {  // parentless CQs too
+    size_t k = (size_t)cq * nfr + fr;
+    fl[k] &= ~KQ_QF_SUBTREE; sq[k] = 0;
+    if (fl[k] & KQ_QF_QUOTA) { sq[k] = s->nominal[k]; fl[k] |= KQ_QF_SUBTREE; }
+  }
+  for (int c = nq; c < N; c++) if (s->parent[c] < 0) deriveCohort(s, nq, nfr, c, sq, us, fl);
+  memcpy(subtree_quota, sq.data(), sq.size() * 8);
+  memcpy(usage, us.data(), us.size() * 8);
+  memcpy(quota_flags, fl.data(), fl.size());
+  return KQ_OK;
+}
+
+// Quota math probes: what[0]=Available what[1]=PotentialAvailable what[2]=LocalAvailable
+// what[3]=borrow height for `val` what[4]=mayReclaim
+int kqo_quota_probe(const kq_config* cfg, const kq_snapshot* s, int cq, int fr, int64_t val, int64_t* what) {
+  Snap sn(*cfg, s);
+  what[0] = sn.Available(cq, fr).v; what[1] = sn.PotentialAvailable(cq, fr).v; what[2] = sn.LocalAvailable(cq, fr).v;
+  auto hb = sn.FindHeightOfLowestSubtreeThatFits(cq, fr, Amount(val));
+  what[3] = hb.first; what[4] = hb.second;
+  return KQ_OK;
+}
+
+// Apply a sequence of AddWorkload(+row) / RemoveWorkload(-(row+1)) to the snapshot and return usage.
+int kqo_apply_ops(const kq_config* cfg, const kq_snapshot* s, int n_ops, const int32_t* ops, int64_t* usage_out) {
+  Snap sn(*cfg, s);
+  for (int i = 0; i < n_ops; i++) { if (ops[i] >= 0) sn.AddWorkload(ops[i]); else sn.RemoveWorkload(-ops[i] - 1); }
+  memcpy(usage_out, sn.usage.data(), sn.usage.size() * 8);
+  return KQ_OK;
+}
+
+// dominantResourceShare(node): ratio (unweighted), weighted precise share, rounded share
+// (roundedWeightedShare fair_sharing.go:133-141), dominant resource, borrowing flag.
+int kqo_drs(const kq_config* cfg, const kq_snapshot* s, int node, const int64_t* wl_req /* [n_fr] or NULL */, double* unweighted, double* precise, int64_t* rounded, int32_t* dominant, int32_t* borrowing) {
+  Snap sn(*cfg, s);
+  FRQ req;
+  if (wl_req) for (int fr = 0; fr < sn.nfr; fr++) if (wl_req[fr] != 0) req[fr] = Amount(wl_req[fr]);
+  DRS d = dominantResourceShare(sn, node, wl_req ? &req : nullptr);
+  *unweighted = d.unweightedRatio; *precise = d.PreciseWeightedShare();
+  *rounded = d.zeroWeightBorrows() ? I64MAX : (int64_t)std::ceil(d.PreciseWeightedShare());
+  *dominant = d.dominantResource; *borrowing = d.borrowing;
+  return KQ_OK;
+}
+
+// calculateLendable(node) per resource
+int kqo_lendable(const kq_config* cfg, const kq_snapshot* s, int node, int64_t* out) {
+  Snap sn(*cfg, s);
+  auto l = calculateLendable(sn, node);
+  for (int r = 0; r < sn.nR; r++) out[r] = l[r].v;
+  return KQ_OK;
+}
+
+int kqo_is_preferred(int a_pm, int64_t a_borrow, int b_pm, int64_t b_borrow, uint32_t policy) {
+  return isPreferred({a_pm, a_borrow}, {b_pm, b_borrow}, policy) ? 1 : 0;
+}
+
+}  // extern "C"
