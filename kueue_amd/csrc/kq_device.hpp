@@ -1,0 +1,1243 @@
+// kq_device.hpp — wave-cooperative device logic of the admission engine (gfx950, wave64).
+//
+// Execution model: ONE WAVEFRONT PER PENDING HEAD (nominate) / PER ROOT-COHORT TREE (process).
+// Inside a wave, control flow is uniform; lanes fan out over
+//   * (flavor x resource) cells of a resource group   -> fitsResourceQuota for every cell at once,
+//   * admitted workloads in candidate-rank order      -> classification + ballot, in-order drain,
+//   * flavor-resource "slots" of one workload's usage -> addUsage / removeUsage / Available per slot.
+// Everything a Go pointer/map walk does in the reference is a bounded loop over flat arrays here:
+// CQ->root paths are precomputed (kq_prep.hpp), quota planes are dense [node][flavor*nR+resource].
+//
+// Reference semantics followed (paths under /root/reference/pkg):
+//   cache/scheduler/resource_node.go         localQuota :67  LocalAvailable :92  available :106
+//                                            potentialAvailable :129  addUsage :144  removeUsage :156
+//   scheduler/flavorassigner/flavorassigner.go   assignFlavors :708  findFlavorForPodSets :1065
+//                                            fitsResourceQuota :1334  isPreferred :536  shouldTryNextFlavor :1263
+//   scheduler/preemption/preemption.go       classicalPreemptions :284  fillBackWorkloads :341  workloadFits :669
+//   scheduler/preemption/classical/*.go      candidate classes / order / validity
+//   scheduler/preemption/preemption_oracle.go SimulatePreemption :43
+//   scheduler/scheduler.go                   getInitialAssignments :880  processEntry :392  fits :771
+//
+// The same source is compiled by g++ with -DKQ_HOST_EMU into a 1-lane emulation that ONLY the CPU
+// test-suite loads (tests/emu): it checks the uniform control logic against the oracle without a
+// GPU. It is not a fallback: the product library contains no host implementation of these paths.
+#pragma once
+#include <cstdint>
+
+#include "../../include/kq_engine.h"
+#include "kq_prep.hpp"
+
+#ifdef KQ_HOST_EMU
+#define KQ_DEV static inline
+#define KQ_MDEV inline
+namespace kq {
+constexpr int WAVE = 1;
+KQ_DEV int lane_id() { return 0; }
+KQ_DEV uint64_t wballot(bool p) { return p ? 1ull : 0ull; }
+template <class T> KQ_DEV T wbcast(T v, int) { return v; }
+KQ_DEV void wsync() {}
+KQ_DEV int ffs64(uint64_t m) { return __builtin_ctzll(m); }
+KQ_DEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
+KQ_DEV int atomic_add_i32(int* p, int v) { int o = *p; *p += v; return o; }
+KQ_DEV void atomic_add_i64(long long* p, long long v) { *p += v; }
+}  // namespace kq
+#else
+#include <hip/hip_runtime.h>
+#define KQ_DEV __device__ __forceinline__
+#define KQ_MDEV __device__ __forceinline__
+namespace kq {
+constexpr int WAVE = 64;
+KQ_DEV int lane_id() { return (int)(threadIdx.x & 63); }
+KQ_DEV uint64_t wballot(bool p) { return __ballot(p); }
+KQ_DEV int wbcast(int v, int src) { return __shfl(v, src, 64); }
+KQ_DEV int64_t wbcast(int64_t v, int src) { return (int64_t)__shfl((long long)v, src, 64); }
+// one wave per workgroup: __syncthreads() is the wave-level fence for LDS and global scratch
+KQ_DEV void wsync() { __syncthreads(); }
+KQ_DEV int ffs64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }
+KQ_DEV int popc64(uint64_t m) { return __popcll((unsigned long long)m); }
+KQ_DEV int atomic_add_i32(int* p, int v) { return atomicAdd(p, v); }
+KQ_DEV void atomic_add_i64(long long* p, long long v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
+}  // namespace kq
+#endif
+
+namespace kq {
+
+// ------------------------------------------------------------------------------------------------
+// device-visible images
+// ------------------------------------------------------------------------------------------------
+struct DSnap {
+  int nq, nc, N, nF, nR, nfr, pods_res, n_adm, n_tree, nfw;
+  const int32_t* resource_order;
+  const int32_t* parent;
+  const int64_t *nominal, *bl, *ll, *sq;
+  const uint8_t* qflags;
+  const int32_t *cq_rg_off, *rg_flavor_off, *rg_flavor, *rg_res_off, *rg_res;
+  const uint32_t* cq_policy;
+  const int32_t* cq_thr;
+  const int64_t* cq_gen;
+  const int32_t* cq_adm_off;
+  const int64_t *adm_prio, *adm_qts;
+  const uint8_t* adm_flags;
+  const int32_t *adm_use_off, *adm_use_fr;
+  const int64_t* adm_use_qty;
+  // prep
+  const int32_t *path, *plen, *tree_of, *node_local, *node_height, *adm_cq, *cq_local;
+  const int32_t *tree_node_off, *tree_nodes, *tree_cq_off, *tree_cqs, *tree_row_off, *tree_rows;
+};
+
+struct DCfg {
+  uint32_t gates;
+  int fair_sharing;
+  int quota_check_strategy;
+  int64_t cycle;
+};
+
+struct DHeads {
+  int n;
+  const int32_t* cq;
+  const int64_t *priority, *queue_ts;
+  const uint32_t* flags;
+  const int32_t *ps_off, *ps_count, *ps_min_count, *ps_req_off, *req_res;
+  const int64_t* req_qty;
+  const uint64_t* ps_flavor_ok;
+  const int32_t* ps_last_tried;
+  const int64_t *last_generation, *last_cycle;
+  const uint64_t *last_hash, *hash;
+};
+
+// decisions (same layout as kq_decisions) + per-head internals carried from nominate to process
+struct DOut {
+  uint8_t *status, *action, *nominated_mode, *mode, *requeue_reason, *skip;
+  int32_t *borrowing, *order;
+  int32_t* flavor;
+  uint8_t* res_mode;
+  int32_t* tried_idx;
+  int32_t* ps_count;
+  // internals
+  int32_t* use_n;     // [H]
+  int32_t* use_fr;    // [H*KQ_MAXU]
+  int64_t* use_qty;   // [H*KQ_MAXU]
+  int32_t* tgt_pos;   // [H] offset into the target pool
+  int32_t* tgt_n;     // [H]
+  int32_t* pool_row;  // [pool_cap]
+  uint8_t* pool_reason;
+  int32_t pool_cap;
+  int32_t* pool_count;  // [1] atomic
+  int32_t* error;       // [1] first device-side error (KQ_E*)
+  long long* stat_bytes;  // [1] algorithmic bytes, accumulated by lane 0
+};
+
+// per-wave-slot scratch in HBM (L2-resident working sets of one victim search)
+struct DScratch {
+  int64_t* w;        // [slots][max_tree_nodes * slot_cap] private usage of the simulated tree
+  uint8_t* cqinfo;   // [slots][max_tree_cqs]  0 = not collected, 1+level = collected under path[level]
+  uint8_t* cls;      // [slots][max_tree_rows] candidate class per rank position
+  int32_t* tgt_row;  // [slots][tgt_cap]
+  uint8_t* tgt_reason;
+  int32_t max_tree_nodes, max_tree_cqs, max_tree_rows, slot_cap, tgt_cap;
+};
+
+struct K {  // everything a kernel needs
+  DSnap S;
+  DCfg C;
+  DHeads H;
+  DOut O;
+  DScratch X;
+  const int64_t* usage;      // cycle-start usage (nominate reads this)
+  int64_t* usage_work;       // process: snapshot usage as mutated by the cycle
+  int64_t* usage_np;         // process: usage_work minus every workload preempted so far this cycle
+  uint8_t* preempted;        // [n_adm] PreemptedWorkloads membership (preempted_workloads.go:26)
+  const int32_t* order_idx;  // [H] entry index at iterator position i
+};
+
+// ------------------------------------------------------------------------------------------------
+// resources.Amount (pkg/resources/amount.go) on raw int64; INT64_MAX == Unlimited.
+// Amount.Cmp == plain signed compare because Unlimited is the maximum value.
+// ------------------------------------------------------------------------------------------------
+constexpr int64_t I64MAX = INT64_MAX;
+constexpr int64_t I64MIN = INT64_MIN;
+KQ_DEV int64_t sat_add(int64_t a, int64_t b) {
+  if (b > 0 && a > I64MAX - b) return I64MAX;
+  if (b < 0 && a < I64MIN - b) return I64MIN;
+  return a + b;
+}
+KQ_DEV int64_t sat_sub(int64_t a, int64_t b) {
+  if (b < 0 && a > I64MAX + b) return I64MAX;
+  if (b > 0 && a < I64MIN + b) return I64MIN;
+  return a - b;
+}
+KQ_DEV int64_t sat_mul(int64_t a, int64_t b) {
+  if (a == 0 || b == 0) return 0;
+  if ((a == -1 && b == I64MIN) || (b == -1 && a == I64MIN)) return I64MAX;
+  int64_t res = (int64_t)((uint64_t)a * (uint64_t)b);
+  if (res / b != a) return ((a < 0) == (b < 0)) ? I64MAX : I64MIN;
+  return res;
+}
+KQ_DEV int64_t a_add(int64_t a, int64_t b) { return (a == I64MAX || b == I64MAX) ? I64MAX : sat_add(a, b); }
+KQ_DEV int64_t a_addi(int64_t a, int64_t v) { return a == I64MAX ? a : sat_add(a, v); }
+KQ_DEV int64_t a_sub(int64_t a, int64_t b) {
+  if (a == I64MAX && b == I64MAX) return 0;
+  if (a == I64MAX) return I64MAX;
+  if (b == I64MAX) return I64MIN;
+  return sat_sub(a, b);
+}
+KQ_DEV int64_t i64max(int64_t a, int64_t b) { return a > b ? a : b; }
+KQ_DEV int64_t i64min(int64_t a, int64_t b) { return a < b ? a : b; }
+
+// modes (flavorassigner.go:453-472, :510-533; common/types.go:23)
+enum { M_NOFIT = 0, M_PREEMPT = 1, M_DEFERRED = 2, M_FIT = 3 };
+enum { PM_NOFIT = 0, PM_NOCAND = 1, PM_PREEMPT = 2, PM_RECLAIM = 3, PM_FIT = 4, PM_NEEDS = 5, PM_SKIP = 6 };
+// candidate variants (classical/hierarchical_preemption.go:32-44)
+enum { V_NEVER = 0, V_WITHIN_CQ = 1, V_HIER = 2, V_RECLAIM_NO_BORROW = 3, V_RECLAIM_BORROW = 4 };
+
+KQ_DEV bool gate(const K& k, uint32_t g) { return (k.C.gates & g) != 0; }
+KQ_DEV size_t ix(const DSnap& S, int n, int fr) { return (size_t)n * S.nfr + fr; }
+
+// resource_node.go:67-72
+KQ_DEV int64_t local_quota(const DSnap& S, int n, int fr) {
+  int64_t ll = S.ll[ix(S, n, fr)];
+  if (ll != KQ_NIL_LIMIT) return i64max(0, a_sub(S.sq[ix(S, n, fr)], ll));
+  return 0;
+}
+
+// Usage accessors: G = global plane, W = private per-search copy restricted to slots
+struct UG {
+  const DSnap* S; const int64_t* u; int fr;
+  KQ_MDEV int64_t get(int n) const { return u[(size_t)n * S->nfr + fr]; }
+};
+struct UW {
+  const DSnap* S; int64_t* w; int ns; int slot;
+  KQ_MDEV int64_t get(int n) const { return w[(size_t)S->node_local[n] * ns + slot]; }
+  KQ_MDEV void set(int n, int64_t v) const { w[(size_t)S->node_local[n] * ns + slot] = v; }
+};
+struct UGW {  // writable global plane
+  const DSnap* S; int64_t* u; int fr;
+  KQ_MDEV int64_t get(int n) const { return u[(size_t)n * S->nfr + fr]; }
+  KQ_MDEV void set(int n, int64_t v) const { u[(size_t)n * S->nfr + fr] = v; }
+};
+
+// resource_node.go:106-122, root-first iteration over the precomputed path
+template <class U> KQ_DEV int64_t available_of(const DSnap& S, const int32_t* path, int plen, int fr, const U& u) {
+  int n = path[plen - 1];
+  int64_t a = a_sub(S.sq[ix(S, n, fr)], u.get(n));
+  for (int i = plen - 2; i >= 0; i--) {
+    n = path[i];
+    int64_t lq = local_quota(S, n, fr), uu = u.get(n);
+    int64_t blv = S.bl[ix(S, n, fr)];
+    if (blv != KQ_NIL_LIMIT) {
+      int64_t stored = a_sub(S.sq[ix(S, n, fr)], lq);
+      int64_t used = i64max(0, a_sub(uu, lq));
+      a = i64min(a_add(a_sub(stored, used), blv), a);
+    }
+    a = a_add(i64max(0, a_sub(lq, uu)), a);
+  }
+  return a;
+}
+// resource_node.go:129-140
+KQ_DEV int64_t potential_of(const DSnap& S, const int32_t* path, int plen, int fr) {
+  int n = path[plen - 1];
+  int64_t a = S.sq[ix(S, n, fr)];
+  for (int i = plen - 2; i >= 0; i--) {
+    n = path[i];
+    a = a_add(local_quota(S, n, fr), a);
+    int64_t blv = S.bl[ix(S, n, fr)];
+    if (blv != KQ_NIL_LIMIT) a = i64min(a_add(S.sq[ix(S, n, fr)], blv), a);
+  }
+  return a;
+}
+// clusterqueue_snapshot.go:155-161 / cohort_snapshot.go:90 ; i == 0 is the CQ itself
+template <class U> KQ_DEV bool borrowing_with(const DSnap& S, int n, bool is_cq, int fr, int64_t val, const U& u) {
+  int64_t q = is_cq ? S.nominal[ix(S, n, fr)] : S.sq[ix(S, n, fr)];
+  return q < a_add(u.get(n), val);
+}
+// classical/hierarchical_preemption.go:221-234 ; returns height, *may_reclaim
+template <class U> KQ_DEV int find_height(const DSnap& S, const int32_t* path, int plen, int fr, int64_t val, const U& u, bool* may_reclaim) {
+  int c = path[0];
+  bool has_parent = plen > 1;
+  if (!borrowing_with(S, c, true, fr, val, u) || !has_parent) { *may_reclaim = has_parent; return 0; }
+  int64_t remaining = a_sub(val, i64max(0, a_sub(local_quota(S, c, fr), u.get(c))));
+  for (int i = 1; i < plen; i++) {
+    int t = path[i];
+    if (!borrowing_with(S, t, false, fr, remaining, u)) { *may_reclaim = i < plen - 1; return S.node_height[t]; }
+    remaining = a_sub(remaining, i64max(0, a_sub(local_quota(S, t, fr), u.get(t))));
+  }
+  *may_reclaim = false;
+  return S.node_height[path[plen - 1]];
+}
+// resource_node.go:144-152 (iterative)
+template <class U> KQ_DEV void add_usage(const DSnap& S, const int32_t* path, int plen, int fr, int64_t val, const U& u) {
+  for (int i = 0; i < plen; i++) {
+    int n = path[i];
+    int64_t uu = u.get(n);
+    int64_t la = i64max(0, a_sub(local_quota(S, n, fr), uu));
+    u.set(n, a_add(uu, val));
+    if (i + 1 < plen && val > la) val = a_sub(val, la); else break;
+  }
+}
+// resource_node.go:156-165 (iterative)
+template <class U> KQ_DEV void remove_usage(const DSnap& S, const int32_t* path, int plen, int fr, int64_t val, const U& u) {
+  for (int i = 0; i < plen; i++) {
+    int n = path[i];
+    int64_t uu = u.get(n);
+    int64_t stored = a_sub(uu, local_quota(S, n, fr));
+    u.set(n, a_sub(uu, val));
+    if (stored <= 0 || i + 1 >= plen) break;
+    val = i64min(val, stored);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-wave scratch (LDS on the device)
+// ------------------------------------------------------------------------------------------------
+constexpr int CELLS = 64;  // cells evaluated per pass (one lane each on gfx950)
+struct Wave {
+  // current head
+  int h, cq, plen, ps_base, nps;
+  int64_t prio, ts;
+  uint32_t hflags, pol;
+  int has_last;
+  int32_t path[KQ_MAXD];
+  // effective requests of the podset being assigned (flavorassigner.go:742-749), Requests.Iter order
+  int nreq;
+  int32_t req_res[KQ_MAXREQ];
+  int64_t req_qty[KQ_MAXREQ];
+  uint8_t req_done[KQ_MAXREQ];   // resource already has a flavor from its resource group (:819)
+  int32_t req_flavor[KQ_MAXREQ], req_borrow[KQ_MAXREQ], req_tried[KQ_MAXREQ];
+  uint8_t req_mode[KQ_MAXREQ];
+  // Assignment.Usage.Quota.Assigned (:1017-1041) + per-entry flags
+  int nuse;
+  int32_t use_fr[KQ_MAXU];
+  int64_t use_qty[KQ_MAXU];
+  uint8_t use_mode[KQ_MAXU];     // FlavorAssignment.Mode of the (podset,resource) that produced it
+  int borrowing, rep_mode;
+  // filtered requests of the resource group under scan
+  int nf;
+  int32_t f_res[KQ_MAXREQ];
+  int64_t f_qty[KQ_MAXREQ];
+  uint8_t f_slot[KQ_MAXREQ];     // index into req_*
+  // cell results of one pass
+  uint8_t cell_pm[CELLS];
+  int32_t cell_borrow[CELLS];
+  int64_t cell_val[CELLS];
+  // best flavor so far
+  int32_t best_mode[KQ_MAXREQ], best_borrow[KQ_MAXREQ];
+  int32_t cur_mode[KQ_MAXREQ], cur_borrow[KQ_MAXREQ];
+  // victim search
+  int ns;                         // slots
+  int32_t s_fr[KQ_MAXU];
+  int64_t s_qty[KQ_MAXU];         // workloadUsage quantity (0 if slot is need-only)
+  uint8_t s_inu[KQ_MAXU], s_need[KQ_MAXU];
+  uint8_t adv_at[KQ_MAXD];        // hasHierarchicalAdvantage when collecting under path[level]
+  int ntgt;
+  int counts[KQ_MAXPS];           // partial admission counts under test
+  int64_t bytes;                  // algorithmic bytes (lane 0 meaningful)
+};
+
+KQ_DEV void set_error(const K& k, int code) {
+  if (lane_id() == 0 && *k.O.error == 0) *k.O.error = code;
+}
+
+// ------------------------------------------------------------------------------------------------
+// flavor fungibility ordering (flavorassigner.go:536-576) as a sortable key:
+// isPreferred(a,b) <=> pref_key(a) > pref_key(b)
+// ------------------------------------------------------------------------------------------------
+KQ_DEV int64_t pref_key(int pm, int64_t borrow, uint32_t pol) {
+  if (pm == PM_NOFIT) return -1;
+  int64_t cls = (pm == PM_NOCAND) ? 0 : 1;
+  int64_t nb = (int64_t)0x3fffffff - i64min(borrow, 0x3fffffff);  // lower borrow => larger
+  if (KQ_POL_PREFERENCE(pol) == KQ_PREF_PREEMPTION_OVER_BORROWING) return (cls << 40) | (nb << 8) | (int64_t)pm;
+  return (cls << 40) | ((int64_t)pm << 32) | nb;
+}
+// flavorassigner.go:1263-1282
+KQ_DEV bool should_try_next(int pm, int64_t borrow, uint32_t pol) {
+  if (pm == PM_NOFIT || pm == PM_NOCAND) return true;
+  if ((pm == PM_PREEMPT || pm == PM_RECLAIM) && KQ_POL_PREEMPT_TRYNEXT(pol)) return true;
+  if (borrow != 0 && KQ_POL_BORROW_TRYNEXT(pol)) return true;
+  return false;
+}
+KQ_DEV int fa_mode(int pm) { return pm == PM_NOFIT ? M_NOFIT : (pm == PM_FIT ? M_FIT : M_PREEMPT); }
+
+// resourcegroups.RGByResource (util/resourcegroups/resourcegroups.go:62)
+KQ_DEV int rg_by_resource(const DSnap& S, int cq, int res) {
+  for (int g = S.cq_rg_off[cq]; g < S.cq_rg_off[cq + 1]; g++)
+    for (int i = S.rg_res_off[g]; i < S.rg_res_off[g + 1]; i++)
+      if (S.rg_res[i] == res) return g;
+  return -1;
+}
+KQ_DEV bool rg_covers(const DSnap& S, int g, int res) {
+  for (int i = S.rg_res_off[g]; i < S.rg_res_off[g + 1]; i++) if (S.rg_res[i] == res) return true;
+  return false;
+}
+KQ_DEV int64_t assumed_usage(const Wave& w, int fr) {
+  for (int i = 0; i < w.nuse; i++) if (w.use_fr[i] == fr) return w.use_qty[i];
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// classical victim search (preemption.go:284-339) on a private, slot-restricted copy of the tree
+// ------------------------------------------------------------------------------------------------
+struct Search {
+  const K* k;
+  Wave* w;
+  int slot;                 // wave slot -> scratch rows
+  const int64_t* usage;     // state the search starts from
+  const uint8_t* removed;   // rows deleted from cq.Workloads (NULL = none)
+  int64_t* W;               // private usage [local_node][ns]
+  uint8_t* cqinfo;
+  uint8_t* cls;
+  int32_t* trow;
+  uint8_t* treason;
+  int tree, row0, nrows;
+};
+
+KQ_DEV bool row_removed(const Search& s, int row) { return s.removed && s.removed[row]; }
+
+// SubtreeQuota >= Usage on every fr needing preemption (resource_node.go:247-254), private state
+KQ_DEV bool within_nominal_w(const Search& s, int n) {
+  const DSnap& S = s.k->S; const Wave& w = *s.w;
+  for (int u = 0; u < w.ns; u++) {
+    if (!w.s_need[u]) continue;
+    if (S.sq[ix(S, n, w.s_fr[u])] < s.W[(size_t)S.node_local[n] * w.ns + u]) return false;
+  }
+  return true;
+}
+KQ_DEV bool within_nominal_g(const Search& s, int n) {
+  const DSnap& S = s.k->S; const Wave& w = *s.w;
+  for (int u = 0; u < w.ns; u++) {
+    if (!w.s_need[u]) continue;
+    if (S.sq[ix(S, n, w.s_fr[u])] < s.usage[ix(S, n, w.s_fr[u])]) return false;
+  }
+  return true;
+}
+// level of node on the preemptor path, or -1
+KQ_DEV int path_level(const Wave& w, int n) {
+  for (int i = 1; i < w.plen; i++) if (w.path[i] == n) return i;
+  return -1;
+}
+// common/preemption_policy.go:27-42
+KQ_DEV bool satisfies_policy(const K& k, const Wave& w, int row, int policy) {
+  int64_t cp = k.S.adm_prio[row];
+  bool lower = w.prio > cp;
+  if (policy == KQ_POLICY_LOWER_PRIORITY) return lower;
+  if (policy == KQ_POLICY_LOWER_OR_NEWER_EQUAL) return lower || (w.prio == cp && w.ts < k.S.adm_qts[row]);
+  return policy == KQ_POLICY_ANY;
+}
+// candidate_generator.go:54-63 restricted to the need slots
+KQ_DEV bool uses_need(const K& k, const Wave& w, int row) {
+  for (int e = k.S.adm_use_off[row]; e < k.S.adm_use_off[row + 1]; e++) {
+    int fr = k.S.adm_use_fr[e];
+    for (int u = 0; u < w.ns; u++) if (w.s_need[u] && w.s_fr[u] == fr) return true;
+  }
+  return false;
+}
+// hierarchical_preemption.go:81-113 ; returns (variant) and list id (0 hierarchy, 1 priority, 2 same queue)
+KQ_DEV int classify_row(const Search& s, int row, int* list) {
+  const K& k = *s.k; const Wave& w = *s.w; const DSnap& S = k.S;
+  if (row_removed(s, row)) return V_NEVER;
+  int c = S.adm_cq[row];
+  bool same = c == w.cq;
+  int level = 0;
+  if (same) {
+    if (KQ_POL_WITHIN_CQ(w.pol) == KQ_POLICY_NEVER) return V_NEVER;
+  } else {
+    uint8_t info = s.cqinfo[S.cq_local[c]];
+    if (info == 0) return V_NEVER;
+    level = info - 1;
+  }
+  if (!uses_need(k, w, row)) return V_NEVER;
+  int policy = same ? KQ_POL_WITHIN_CQ(w.pol) : KQ_POL_RECLAIM(w.pol);
+  if (!satisfies_policy(k, w, row, policy)) return V_NEVER;
+  if (same) { *list = 2; return V_WITHIN_CQ; }
+  if (w.adv_at[level]) { *list = 0; return V_HIER; }
+  *list = 1;
+  if (KQ_POL_BORROW_WITHIN(w.pol) == 0) return V_RECLAIM_NO_BORROW;           // IsBorrowingWithinCohortForbidden :71
+  int64_t cp = S.adm_prio[row];                                                // isAboveBorrowingThreshold :115
+  if (cp >= w.prio) return V_RECLAIM_NO_BORROW;
+  if (KQ_POL_HAS_THRESHOLD(w.pol) && cp > (int64_t)S.cq_thr[w.cq]) return V_RECLAIM_NO_BORROW;
+  return V_RECLAIM_BORROW;
+}
+KQ_DEV int variant_reason(int v) {  // hierarchical_preemption.go:46-58
+  switch (v) {
+    case V_WITHIN_CQ: return KQ_REASON_IN_CLUSTER_QUEUE;
+    case V_RECLAIM_BORROW: return KQ_REASON_IN_COHORT_RECLAIM_WHILE_BORROWING;
+    default: return KQ_REASON_IN_COHORT_RECLAMATION;
+  }
+}
+
+// snapshot.RemoveWorkload / AddWorkload (snapshot.go:60-74) on the private state: one lane per slot
+KQ_DEV void w_apply_row(const Search& s, int row, bool add) {
+  const DSnap& S = s.k->S; const Wave& w = *s.w;
+  int c = S.adm_cq[row];
+  const int32_t* cpath = S.path + (size_t)c * KQ_MAXD;
+  int cplen = S.plen[c];
+  for (int u = lane_id(); u < w.ns; u += WAVE) {
+    int fr = w.s_fr[u];
+    for (int e = S.adm_use_off[row]; e < S.adm_use_off[row + 1]; e++) {
+      if (S.adm_use_fr[e] != fr) continue;
+      UW uw{&S, s.W, w.ns, u};
+      if (add) add_usage(S, cpath, cplen, fr, S.adm_use_qty[e], uw); else remove_usage(S, cpath, cplen, fr, S.adm_use_qty[e], uw);
+    }
+  }
+  wsync();
+  if (lane_id() == 0) s.w->bytes += 16 * (int64_t)cplen * (S.adm_use_off[row + 1] - S.adm_use_off[row]);
+}
+// preemption.go:669-686 on the private state (quota part)
+KQ_DEV bool w_fits(const Search& s, bool allow_borrowing) {
+  const DSnap& S = s.k->S; Wave& w = *s.w;
+  bool bad = false;
+  for (int u = lane_id(); u < w.ns; u += WAVE) {
+    if (!w.s_inu[u]) continue;
+    UW uw{&S, s.W, w.ns, u};
+    int fr = w.s_fr[u];
+    int64_t v = w.s_qty[u];
+    if (!allow_borrowing && borrowing_with(S, w.cq, true, fr, v, uw)) bad = true;
+    else if (v > i64max(0, available_of(S, w.path, w.plen, fr, uw))) bad = true;
+  }
+  if (lane_id() == 0) w.bytes += 40 * (int64_t)w.plen * w.ns;
+  return wballot(bad) == 0;
+}
+// candidate_generator.go:136-158
+KQ_DEV bool candidate_valid(const Search& s, int row, int variant, bool borrow) {
+  const DSnap& S = s.k->S; const Wave& w = *s.w;
+  int c = S.adm_cq[row];
+  if (c == w.cq) return true;
+  if (borrow && variant == V_RECLAIM_NO_BORROW) return false;
+  if (within_nominal_w(s, c)) return false;
+  int lca = w.path[s.cqinfo[S.cq_local[c]] - 1];
+  for (int n = S.parent[c]; n >= 0 && n != lca; n = S.parent[n]) if (within_nominal_w(s, n)) return false;
+  return true;
+}
+
+// Runs the classical search for the slots prepared in w (s_fr/s_qty/s_inu/s_need).
+// On return w->ntgt targets are in s.trow/s.treason and the private state has exactly those removed.
+KQ_DEV void classical_search(Search& s) {
+  const K& k = *s.k; Wave& w = *s.w; const DSnap& S = k.S;
+  const int lane = lane_id();
+  w.ntgt = 0;
+  bool same_on = KQ_POL_WITHIN_CQ(w.pol) != KQ_POLICY_NEVER;
+  bool other_on = w.plen > 1 && KQ_POL_RECLAIM(w.pol) != KQ_POLICY_NEVER;
+  if (!same_on && !other_on) return;
+  s.tree = S.tree_of[w.cq];
+  s.row0 = S.tree_row_off[s.tree];
+  s.nrows = S.tree_row_off[s.tree + 1] - s.row0;
+  if (s.nrows == 0) return;
+  const int n0 = S.tree_node_off[s.tree], nn = S.tree_node_off[s.tree + 1] - n0;
+  // private copy of the tree's usage for the slots
+  for (int i = lane; i < nn * w.ns; i += WAVE) {
+    int ln = i / w.ns, u = i % w.ns;
+    s.W[i] = s.usage[ix(S, S.tree_nodes[n0 + ln], w.s_fr[u])];
+  }
+  // hasHierarchicalAdvantage per ancestor level (hierarchical_preemption.go:149-175), one lane per slot
+  {
+    bool adv;
+    {
+      bool nf = false;
+      for (int u = lane; u < w.ns; u += WAVE)
+        if (w.s_inu[u] && S.sq[ix(S, w.cq, w.s_fr[u])] < a_add(s.usage[ix(S, w.cq, w.s_fr[u])], w.s_qty[u])) nf = true;
+      adv = wballot(nf) == 0;
+    }
+    // remaining requests per slot live in registers of lane (u % WAVE); ns <= KQ_MAXU so iterate slots serially per lane
+    int64_t rem[(KQ_MAXU + WAVE - 1) / WAVE];
+    for (int j = 0, u = lane; u < w.ns; u += WAVE, j++) {
+      UG ug{&S, s.usage, w.s_fr[u]};
+      rem[j] = w.s_inu[u] ? i64max(0, a_sub(w.s_qty[u], i64max(0, a_sub(local_quota(S, w.cq, w.s_fr[u]), ug.get(w.cq))))) : 0;
+    }
+    for (int l = 1; l < w.plen; l++) {
+      if (lane == 0) w.adv_at[l] = adv ? 1 : 0;
+      int a = w.path[l];
+      bool nf = false;
+      for (int j = 0, u = lane; u < w.ns; u += WAVE, j++) {
+        if (!w.s_inu[u]) continue;
+        int fr = w.s_fr[u];
+        int64_t uu = s.usage[ix(S, a, fr)];
+        if (S.sq[ix(S, a, fr)] < a_add(uu, rem[j])) nf = true;
+        rem[j] = i64max(0, a_sub(rem[j], i64max(0, a_sub(local_quota(S, a, fr), uu))));
+      }
+      bool fits = wballot(nf) == 0;
+      adv = adv || fits;
+    }
+  }
+  // which CQs of the tree are collected, and under which path level (collectCandidatesInSubtree :179-207)
+  {
+    const int q0 = S.tree_cq_off[s.tree], nqs = S.tree_cq_off[s.tree + 1] - q0;
+    for (int i = lane; i < nqs; i += WAVE) {
+      int c = S.tree_cqs[q0 + i];
+      uint8_t info = 0;
+      if (other_on && c != w.cq && !within_nominal_g(s, c)) {
+        bool ok = true;
+        int n = S.parent[c], lvl = -1;
+        while (n >= 0) {
+          lvl = path_level(w, n);
+          if (lvl >= 0) break;
+          if (within_nominal_g(s, n)) { ok = false; break; }
+          n = S.parent[n];
+        }
+        if (ok && lvl >= 1) info = (uint8_t)(lvl + 1);
+      }
+      s.cqinfo[i] = info;
+    }
+  }
+  wsync();
+  // classify every admitted row of the tree once; class byte = 1 + list + 3*evicted + 8*variant
+  int cnt[6] = {0, 0, 0, 0, 0, 0};
+  for (int base = 0; base < s.nrows; base += WAVE) {
+    int i = base + lane;
+    uint8_t cb = 0;
+    if (i < s.nrows) {
+      int row = S.tree_rows[s.row0 + i], list = 0;
+      int v = classify_row(s, row, &list);
+      if (v != V_NEVER) {
+        int ev = (S.adm_flags[row] & KQ_ADM_EVICTED) ? 0 : 1;  // evicted first
+        cb = (uint8_t)(1 + (ev * 3 + list) + 8 * v);
+      }
+      s.cls[i] = cb;
+    }
+    for (int p = 0; p < 6; p++) cnt[p] += popc64(wballot(cb != 0 && ((cb - 1) & 7) == p));
+  }
+  if (lane == 0) w.bytes += (int64_t)s.nrows * 44;
+  wsync();
+  bool no_hier = cnt[0] + cnt[3] == 0, no_other = no_hier && (cnt[1] + cnt[4] == 0);
+  if (cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4] + cnt[5] == 0) return;
+  bool forbidden = KQ_POL_BORROW_WITHIN(w.pol) == 0;
+  bool under_nominal;  // queueUnderNominalInResourcesNeedingPreemption preemption.go:700-707
+  {
+    bool nb = false;
+    for (int u = lane; u < w.ns; u += WAVE)
+      if (w.s_need[u] && S.nominal[ix(S, w.cq, w.s_fr[u])] <= s.usage[ix(S, w.cq, w.s_fr[u])]) nb = true;
+    under_nominal = wballot(nb) == 0;
+  }
+  int nattempt; bool attempts[2];
+  if (no_other || (forbidden && !under_nominal)) { nattempt = 1; attempts[0] = true; attempts[1] = true; }
+  else if (forbidden && no_hier) { nattempt = 2; attempts[0] = false; attempts[1] = true; }
+  else { nattempt = 2; attempts[0] = true; attempts[1] = false; }
+  for (int at = 0; at < nattempt; at++) {
+    bool borrowing = attempts[at];
+    int nt = 0;
+    for (int p = 0; p < 6; p++) {
+      if (cnt[p] == 0) continue;
+      for (int base = 0; base < s.nrows; base += WAVE) {
+        int i = base + lane;
+        uint8_t cb = i < s.nrows ? s.cls[i] : 0;
+        uint64_t m = wballot(cb != 0 && ((cb - 1) & 7) == p);
+        while (m) {
+          int b = ffs64(m);
+          m &= m - 1;
+          int pos = base + b;
+          int row = S.tree_rows[s.row0 + pos];
+          int variant = s.cls[pos] >> 3;
+          if (!candidate_valid(s, row, variant, borrowing)) continue;
+          w_apply_row(s, row, false);
+          if (nt >= k.X.tgt_cap) { set_error(k, KQ_ECAPACITY); w.ntgt = 0; return; }
+          if (lane == 0) { s.trow[nt] = row; s.treason[nt] = (uint8_t)variant_reason(variant); }
+          nt++;
+          wsync();
+          if (w_fits(s, borrowing)) {
+            // fillBackWorkloads preemption.go:341-354
+            for (int t = nt - 2; t >= 0; t--) {
+              int r = s.trow[t];
+              w_apply_row(s, r, true);
+              if (w_fits(s, borrowing)) {
+                if (lane == 0) { s.trow[t] = s.trow[nt - 1]; s.treason[t] = s.treason[nt - 1]; }
+                nt--;
+                wsync();
+              } else {
+                w_apply_row(s, r, false);
+              }
+            }
+            w.ntgt = nt;
+            return;
+          }
+        }
+      }
+    }
+    // restoreSnapshot :356
+    for (int t = 0; t < nt; t++) w_apply_row(s, s.trow[t], true);
+  }
+  w.ntgt = 0;
+}
+
+KQ_DEV Search make_search(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed) {
+  Search s;
+  s.k = &k; s.w = &w; s.slot = slot; s.usage = usage; s.removed = removed;
+  s.W = k.X.w + (size_t)slot * k.X.max_tree_nodes * k.X.slot_cap;
+  s.cqinfo = k.X.cqinfo + (size_t)slot * k.X.max_tree_cqs;
+  s.cls = k.X.cls + (size_t)slot * k.X.max_tree_rows;
+  s.trow = k.X.tgt_row + (size_t)slot * k.X.tgt_cap;
+  s.treason = k.X.tgt_reason + (size_t)slot * k.X.tgt_cap;
+  s.tree = 0; s.row0 = 0; s.nrows = 0;
+  return s;
+}
+
+// PreemptionOracle.SimulatePreemption (preemption_oracle.go:43-85) for one flavor-resource
+KQ_DEV void simulate_preemption(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed,
+                                int fr, int64_t val, int base_borrow, int* pm, int* borrow) {
+  if (k.C.fair_sharing) { set_error(k, KQ_EUNSUPPORTED); *pm = PM_NOCAND; *borrow = base_borrow; return; }
+  if (lane_id() == 0) { w.ns = 1; w.s_fr[0] = fr; w.s_qty[0] = val; w.s_inu[0] = 1; w.s_need[0] = 1; }
+  wsync();
+  Search s = make_search(k, w, slot, usage, removed);
+  classical_search(s);
+  wsync();
+  if (w.ntgt == 0) { *pm = PM_NOCAND; *borrow = base_borrow; return; }
+  bool any_same = false;
+  for (int t = 0; t < w.ntgt; t++) if (k.S.adm_cq[s.trow[t]] == w.cq) any_same = true;
+  UW uw{&k.S, s.W, 1, 0};
+  bool mr;
+  *borrow = find_height(k.S, w.path, w.plen, fr, val, uw, &mr);
+  *pm = any_same ? PM_PREEMPT : PM_RECLAIM;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FlavorAssigner.assignFlavors (flavorassigner.go:708-908, TAS branches excluded)
+// `counts` != NULL : partial admission probe (ScaledTo workload.go:317-340)
+// `nominate_map`   : respect NominationMapping = current O.flavor (recompute on overlap)
+// ------------------------------------------------------------------------------------------------
+KQ_DEV int next_flavor_to_try(const K& k, const Wave& w, int ps_global, int res) {  // workload.go:226-238
+  if (!gate(k, KQ_GATE_FLAVOR_FUNGIBILITY)) return 0;
+  if (!w.has_last) return 0;
+  int idx = k.H.ps_last_tried[(size_t)ps_global * k.S.nR + res];
+  return idx < 0 ? 0 : idx + 1;
+}
+KQ_DEV bool can_preempt_while_borrowing(const K& k, const Wave& w) {  // flavorassigner.go:1386-1389
+  return KQ_POL_BORROW_WITHIN(w.pol) != 0 || (k.C.fair_sharing && KQ_POL_RECLAIM(w.pol) != KQ_POLICY_NEVER);
+}
+
+KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed,
+                           const int* counts, bool nominate_map) {
+  const DSnap& S = k.S; const DHeads& H = k.H; const DOut& O = k.O;
+  const int lane = lane_id();
+  const int nR = S.nR;
+  if (lane == 0) { w.nuse = 0; w.borrowing = 0; w.rep_mode = M_FIT; }
+  wsync();
+  int rep = M_FIT;
+  bool any_ps = false;
+  const bool pods_cov = S.pods_res >= 0 && rg_by_resource(S, w.cq, S.pods_res) >= 0;
+  for (int pi = 0; pi < w.nps; pi++) {
+    const int psg = w.ps_base + pi;
+    any_ps = true;
+    // ---- effective requests -------------------------------------------------------------
+    int count = H.ps_count[psg];
+    int new_count = counts ? counts[pi] : count;
+    bool scale = counts && count != 0 && count != new_count;
+    if (lane == 0) {
+      int n = 0;
+      bool have_pods = false;
+      for (int e = H.ps_req_off[psg]; e < H.ps_req_off[psg + 1]; e++) {
+        if (n >= KQ_MAXREQ) { *O.error = KQ_EUNSUPPORTED; break; }
+        int64_t q = H.req_qty[e];
+        if (scale) q = sat_mul(q / (int64_t)count, (int64_t)new_count);
+        int r = H.req_res[e];
+        if (pods_cov && r == S.pods_res) { q = scale ? new_count : count; have_pods = true; }
+        w.req_res[n] = r; w.req_qty[n] = q; n++;
+      }
+      if (pods_cov && !have_pods) {
+        if (n >= KQ_MAXREQ) *O.error = KQ_EUNSUPPORTED;
+        else { w.req_res[n] = S.pods_res; w.req_qty[n] = scale ? new_count : count; n++; }
+      }
+      // Requests.Iter order (slice_requests.go:54-60): insertion sort by resource_order
+      for (int a = 1; a < n; a++) {
+        int r = w.req_res[a]; int64_t q = w.req_qty[a]; int b = a - 1;
+        while (b >= 0 && S.resource_order[w.req_res[b]] > S.resource_order[r]) { w.req_res[b + 1] = w.req_res[b]; w.req_qty[b + 1] = w.req_qty[b]; b--; }
+        w.req_res[b + 1] = r; w.req_qty[b + 1] = q;
+      }
+      w.nreq = n;
+      for (int a = 0; a < n; a++) w.req_done[a] = 0;
+      w.bytes += (int64_t)n * 8;
+    }
+    wsync();
+    // nomination mapping snapshot for this podset (flavor per resource before we overwrite O.flavor)
+    int32_t nom_flavor[KQ_MAXREQ];
+    if (nominate_map) for (int a = 0; a < w.nreq; a++) nom_flavor[a] = O.flavor[(size_t)psg * nR + w.req_res[a]];
+    // clear the podset's output rows
+    for (int r = lane; r < nR; r += WAVE) { O.flavor[(size_t)psg * nR + r] = -1; O.res_mode[(size_t)psg * nR + r] = M_NOFIT; O.tried_idx[(size_t)psg * nR + r] = -1; }
+    if (lane == 0) O.ps_count[psg] = scale ? new_count : count;
+    wsync();
+    bool group_failed = false;
+    int ps_reasons = 0, ps_nflavors = 0, ps_mode = M_FIT;
+    for (int a = 0; a < w.nreq && !group_failed; a++) {
+      const int res_name = w.req_res[a];
+      const int g = rg_by_resource(S, w.cq, res_name);
+      if (g < 0) {  // flavorassigner.go:809-817
+        if (w.req_qty[a] == 0) continue;
+        if (gate(k, KQ_GATE_QUOTA_CHECK_STRATEGY) && k.C.quota_check_strategy == KQ_QUOTA_CHECK_IGNORE_UNDECLARED) continue;
+        group_failed = true; ps_reasons = 1;  // "resource unavailable in ClusterQueue" :1080
+        break;
+      }
+      if (w.req_done[a]) continue;  // :819
+      // ---- findFlavorForPodSets :1065-1210 ---------------------------------------------
+      if (lane == 0) {
+        int nf = 0;
+        for (int b = 0; b < w.nreq; b++) if (rg_covers(S, g, w.req_res[b])) { w.f_res[nf] = w.req_res[b]; w.f_qty[nf] = w.req_qty[b]; w.f_slot[nf] = (uint8_t)b; nf++; }
+        w.nf = nf;
+      }
+      wsync();
+      const int nf = w.nf;
+      const int f0 = S.rg_flavor_off[g], nflv = S.rg_flavor_off[g + 1] - f0;
+      const int fpp = CELLS / nf;  // flavors per pass (nf <= KQ_MAXREQ <= CELLS)
+      int best = -1; int64_t best_key = -1;   // worstGranularMode
+      int best_pm = PM_NOFIT;
+      int attempted = -1;
+      int reasons = 0;
+      bool stop = false;
+      int idx0 = next_flavor_to_try(k, w, psg, res_name);
+      const int plen = w.plen;
+      for (int cs = idx0; cs < nflv && !stop; cs += fpp) {
+        const int nfl = (nflv - cs) < fpp ? (nflv - cs) : fpp;
+        // ---- all (flavor, resource) cells of this pass at once: fitsResourceQuota :1334-1384
+        for (int c = lane; c < nfl * nf; c += WAVE) {
+          int j = cs + c / nf, kk = c % nf;
+          int f = S.rg_flavor[f0 + j];
+          bool ok = (H.ps_flavor_ok[(size_t)psg * S.nfw + (f >> 6)] >> (f & 63)) & 1;  // checkFlavorForPodSets :1212 (host-evaluated)
+          if (nominate_map && nom_flavor[a] != f) ok = false;                              // shouldSkipBasedOnNominationMapping :1422
+          uint8_t pm = PM_SKIP; int32_t borrow = 0; int64_t val = 0;
+          if (ok) {
+            int fr = f * nR + w.f_res[kk];
+            UG ug{&S, usage, fr};
+            int64_t avail = i64max(0, available_of(S, w.path, plen, fr, ug));
+            int64_t maxcap = potential_of(S, w.path, plen, fr);
+            val = a_addi(assumed_usage(w, fr), w.f_qty[kk]);
+            if (val > maxcap) { pm = PM_NOFIT; borrow = 0; }
+            else {
+              bool may_reclaim;
+              borrow = find_height(S, w.path, plen, fr, val, ug, &may_reclaim);
+              if (val <= avail) pm = PM_FIT;
+              else if (S.nominal[ix(S, w.cq, fr)] >= val || may_reclaim || can_preempt_while_borrowing(k, w)) pm = PM_NEEDS;
+              else pm = PM_NOFIT | 0x80;  // noFit with a "insufficient unused quota" reason and borrow kept
+            }
+          }
+          w.cell_pm[c] = pm; w.cell_borrow[c] = borrow; w.cell_val[c] = val;
+        }
+        if (lane == 0) w.bytes += (int64_t)nfl * nf * 40 * plen;
+        wsync();
+        // ---- ordered scan of the pass (uniform) ------------------------------------------
+        for (int jj = 0; jj < nfl && !stop; jj++) {
+          const int j = cs + jj;
+          attempted = j;
+          if (w.cell_pm[jj * nf] == PM_SKIP) { reasons++; continue; }
+          const int f = S.rg_flavor[f0 + j];
+          int rep_pm = PM_FIT; int64_t rep_borrow = 0; int64_t rep_key = pref_key(PM_FIT, 0, w.pol);
+          for (int kk = 0; kk < nf; kk++) {
+            int c = jj * nf + kk;
+            int pm = w.cell_pm[c] & 0x7f; int borrow = w.cell_borrow[c];
+            bool had_status = (w.cell_pm[c] & 0x80) || pm == PM_NOFIT || pm == PM_NEEDS;
+            if (rep_pm == PM_NOFIT) { if (had_status) reasons++; continue; }  // oracle result unused past a noFit (:1161)
+            if (pm == PM_NEEDS) {
+              int opm, ob;
+              simulate_preemption(k, w, slot, usage, removed, f * nR + w.f_res[kk], w.cell_val[c], borrow, &opm, &ob);
+              pm = opm; borrow = ob;
+            }
+            if (had_status) reasons++;
+            int64_t key = pref_key(pm, borrow, w.pol);
+            if (rep_key > key) { rep_pm = pm; rep_borrow = borrow; rep_key = key; }   // isPreferred(rep, mode) -> rep = mode
+            if (rep_pm == PM_NOFIT) continue;
+            if (lane == 0) { w.cur_mode[kk] = fa_mode(pm); w.cur_borrow[kk] = borrow; }
+          }
+          wsync();
+          bool take = false;
+          if (gate(k, KQ_GATE_FLAVOR_FUNGIBILITY)) {
+            if (!should_try_next(rep_pm, rep_borrow, w.pol)) { take = true; stop = true; }
+            else if (rep_key > best_key) take = true;
+          } else if (rep_pm > best_pm) {
+            take = true;
+            if (rep_pm == PM_FIT) stop = true;
+          }
+          if (take) {
+            best = j; best_key = rep_key; best_pm = rep_pm;
+            if (lane == 0) for (int kk = 0; kk < nf; kk++) { w.best_mode[kk] = w.cur_mode[kk]; w.best_borrow[kk] = w.cur_borrow[kk]; }
+            wsync();
+          }
+        }
+      }
+      int tried = -1;
+      if (gate(k, KQ_GATE_FLAVOR_FUNGIBILITY)) tried = (attempted == nflv - 1) ? -1 : attempted;
+      else tried = 0;
+      bool status_nil = best >= 0 && best_pm == PM_FIT;
+      if (best < 0) {  // len(flavors)==0 && requests.Len()>0  (:826)
+        group_failed = true; ps_reasons = reasons;
+        break;
+      }
+      // record groupFlavors[res] for every covered requested resource (maps.Copy :831)
+      if (lane == 0) {
+        int f = S.rg_flavor[f0 + best];
+        for (int kk = 0; kk < nf; kk++) {
+          int a2 = w.f_slot[kk];
+          w.req_done[a2] = 1; w.req_flavor[a2] = f; w.req_mode[a2] = (uint8_t)w.best_mode[kk];
+          w.req_borrow[a2] = w.best_borrow[kk]; w.req_tried[a2] = tried;
+        }
+      }
+      wsync();
+      for (int kk = 0; kk < nf; kk++) { ps_nflavors++; if (w.best_mode[kk] < ps_mode) ps_mode = w.best_mode[kk]; }
+      if (!status_nil) ps_reasons += reasons;
+    }
+    // PodSetAssignment.RepresentativeMode :386-404 ; Assignment.append :1017-1041
+    int pmode;
+    if (group_failed) {
+      // groupFlavors = nil: the podset keeps no flavor and contributes no usage
+      pmode = ps_reasons == 0 ? M_FIT : M_NOFIT;
+    } else {
+      pmode = ps_reasons == 0 ? M_FIT : (ps_nflavors == 0 ? M_NOFIT : ps_mode);
+      if (lane == 0) {
+        for (int a = 0; a < w.nreq; a++) {
+          if (!w.req_done[a]) continue;
+          size_t o = (size_t)psg * nR + w.req_res[a];
+          O.flavor[o] = w.req_flavor[a]; O.res_mode[o] = w.req_mode[a]; O.tried_idx[o] = w.req_tried[a];
+          if (w.req_borrow[a] > w.borrowing) w.borrowing = w.req_borrow[a];
+          int fr = w.req_flavor[a] * nR + w.req_res[a];
+          int e = -1;
+          for (int i = 0; i < w.nuse; i++) if (w.use_fr[i] == fr) e = i;
+          if (e < 0) {
+            if (w.nuse >= KQ_MAXU) { *O.error = KQ_EUNSUPPORTED; continue; }
+            e = w.nuse++; w.use_fr[e] = fr; w.use_qty[e] = 0; w.use_mode[e] = M_FIT;
+          }
+          w.use_qty[e] = a_addi(w.use_qty[e], w.req_qty[a]);
+          if (w.req_mode[a] < w.use_mode[e]) w.use_mode[e] = w.req_mode[a];
+        }
+        w.bytes += (int64_t)w.nreq * 24;
+      }
+      wsync();
+    }
+    if (pmode < rep) rep = pmode;
+    if (group_failed && w.nreq > 0) {  // atLeastOnePodsAssignmentFailed :848-853: later podsets are never assigned
+      for (int i = lane + (pi + 1) * nR; i < w.nps * nR; i += WAVE) {
+        size_t o = (size_t)w.ps_base * nR + i;
+        O.flavor[o] = -1; O.res_mode[o] = M_NOFIT; O.tried_idx[o] = -1;
+      }
+      for (int q = pi + 1 + lane; q < w.nps; q += WAVE) O.ps_count[w.ps_base + q] = H.ps_count[w.ps_base + q];
+      wsync();
+      break;
+    }
+  }
+  if (!any_ps) rep = M_NOFIT;  // RepresentativeMode with no podsets :212-215
+  if (lane == 0) w.rep_mode = rep;
+  wsync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Preemptor.GetTargets (preemption.go:132-155): slots = flavor-resources of the assignment;
+// need = flavorResourcesNeedPreemption (:586-597); quantities = Assignment.TotalRequestsFor
+// (flavorassigner.go:267-296: original requests scaled to the assigned count, zero quantities and
+// the injected "pods" pseudo-resource excluded).
+// ------------------------------------------------------------------------------------------------
+KQ_DEV void prepare_target_slots(const K& k, Wave& w) {
+  const DSnap& S = k.S; const DHeads& H = k.H; const DOut& O = k.O;
+  if (lane_id() == 0) {
+    w.ns = w.nuse;
+    for (int e = 0; e < w.nuse; e++) { w.s_fr[e] = w.use_fr[e]; w.s_need[e] = w.use_mode[e] == M_PREEMPT; w.s_qty[e] = 0; w.s_inu[e] = 0; }
+    for (int pi = 0; pi < w.nps; pi++) {
+      int psg = w.ps_base + pi;
+      int count = H.ps_count[psg], newc = O.ps_count[psg];
+      for (int e = H.ps_req_off[psg]; e < H.ps_req_off[psg + 1]; e++) {
+        int64_t q = H.req_qty[e];
+        if (count != 0 && count != newc) q = sat_mul(q / (int64_t)count, (int64_t)newc);
+        if (q == 0) continue;
+        int res = H.req_res[e];
+        int fl = O.flavor[(size_t)psg * S.nR + res];
+        if (fl < 0) continue;
+        int fr = fl * S.nR + res;
+        for (int u = 0; u < w.ns; u++) if (w.s_fr[u] == fr) { w.s_qty[u] = a_addi(w.s_qty[u], q); w.s_inu[u] = 1; }
+      }
+    }
+  }
+  wsync();
+}
+
+KQ_DEV Search get_targets(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed) {
+  Search s = make_search(k, w, slot, usage, removed);
+  if (k.C.fair_sharing) { set_error(k, KQ_EUNSUPPORTED); w.ntgt = 0; return s; }
+  prepare_target_slots(k, w);
+  classical_search(s);
+  wsync();
+  return s;
+}
+
+// scheduler.go:840-856
+KQ_DEV bool last_assignment_outdated(const K& k, int h, int cq) {
+  if (gate(k, KQ_GATE_PRESERVE_SCAN_PROGRESS)) {
+    uint64_t lh = k.H.last_hash[h], ch = k.H.hash[h];
+    if (!(lh == 0 || ch == 0 || lh == ch)) return true;
+    if (k.C.cycle - k.H.last_cycle[h] <= 1) return false;
+  }
+  return k.S.cq_gen[cq] > k.H.last_generation[h];
+}
+
+KQ_DEV void load_head(const K& k, Wave& w, int h) {
+  const DSnap& S = k.S; const DHeads& H = k.H;
+  if (lane_id() == 0) {
+    w.h = h; w.cq = H.cq[h]; w.prio = H.priority[h]; w.ts = H.queue_ts[h]; w.hflags = H.flags[h];
+    w.pol = S.cq_policy[w.cq];
+    w.ps_base = H.ps_off[h]; w.nps = H.ps_off[h + 1] - H.ps_off[h];
+    w.plen = S.plen[w.cq];
+    for (int i = 0; i < KQ_MAXD; i++) w.path[i] = S.path[(size_t)w.cq * KQ_MAXD + i];
+    w.has_last = (w.hflags & KQ_HEAD_HAS_LAST_ASSIGNMENT) ? 1 : 0;
+    w.bytes = 0;
+    if (w.nps > KQ_MAXPS) *k.O.error = KQ_EUNSUPPORTED;
+  }
+  wsync();
+}
+
+// Scheduler.getAssignments + getInitialAssignments (scheduler.go:821-924). Leaves the chosen
+// assignment in O.flavor/res_mode/tried_idx/ps_count + w.use_*/w.rep_mode/w.borrowing and its targets in the
+// returned Search (w.ntgt rows).
+KQ_DEV Search get_assignments(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed, bool nominate_map) {
+  const DHeads& H = k.H;
+  Search s = make_search(k, w, slot, usage, removed);
+  assign_flavors(k, w, slot, usage, removed, nullptr, nominate_map);
+  w.ntgt = 0;
+  int arm = w.rep_mode;
+  if (arm == M_FIT) return s;
+  if (arm == M_PREEMPT) {
+    s = get_targets(k, w, slot, usage, removed);
+    if (w.ntgt > 0) return s;
+  }
+  // PartialAdmission: PodSetReducer.Search (podset_reducer.go:28-86)
+  bool can_partial = false;
+  int total_delta = 0;
+  if (gate(k, KQ_GATE_PARTIAL_ADMISSION) && w.nps <= KQ_MAXPS)
+    for (int pi = 0; pi < w.nps; pi++) {
+      int c = H.ps_count[w.ps_base + pi], mc = H.ps_min_count[w.ps_base + pi];
+      if (mc >= 0 && c > mc) { can_partial = true; total_delta += c - mc; }
+    }
+  if (!can_partial || total_delta == 0) { w.ntgt = 0; return s; }
+  int lo = 0, hi = total_delta + 1, good = -1, last_probe = -1;
+  auto probe = [&](int si) -> bool {
+    if (lane_id() == 0)
+      for (int pi = 0; pi < w.nps; pi++) {
+        int c = H.ps_count[w.ps_base + pi], mc = H.ps_min_count[w.ps_base + pi];
+        int d = (mc >= 0 && c > mc) ? c - mc : 0;
+        w.counts[pi] = c - (int)((int64_t)d * (int64_t)si / (int64_t)total_delta);
+      }
+    wsync();
+    assign_flavors(k, w, slot, usage, removed, w.counts, nominate_map);
+    w.ntgt = 0;
+    last_probe = si;
+    if (w.rep_mode == M_FIT) return true;
+    if (w.rep_mode == M_PREEMPT) { s = get_targets(k, w, slot, usage, removed); return w.ntgt > 0; }
+    return false;
+  };
+  while (lo < hi) {  // sort.Search
+    int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+    if (!probe(mid)) lo = mid + 1; else { hi = mid; good = mid; }
+  }
+  if (good >= 0 && lo == good) {
+    if (last_probe != good) probe(good);  // regenerate the outputs of the accepted probe
+    return s;
+  }
+  // no reduced count works: the full assignment, no targets (scheduler.go:923)
+  assign_flavors(k, w, slot, usage, removed, nullptr, nominate_map);
+  w.ntgt = 0;
+  return s;
+}
+
+// publish the head's assignment internals for the process kernel
+KQ_DEV void publish_assignment(const K& k, Wave& w, const Search& s, int h) {
+  const DOut& O = k.O;
+  int pos = 0;
+  if (lane_id() == 0) {
+    O.use_n[h] = w.nuse;
+    for (int e = 0; e < w.nuse; e++) { O.use_fr[(size_t)h * KQ_MAXU + e] = w.use_fr[e]; O.use_qty[(size_t)h * KQ_MAXU + e] = w.use_qty[e]; }
+    O.borrowing[h] = w.borrowing;
+    pos = w.ntgt > 0 ? atomic_add_i32(O.pool_count, w.ntgt) : 0;
+    if (pos + w.ntgt > O.pool_cap) { if (*O.error == 0) *O.error = KQ_ECAPACITY; O.tgt_pos[h] = 0; O.tgt_n[h] = 0; }
+    else { O.tgt_pos[h] = pos; O.tgt_n[h] = w.ntgt; }
+    w.counts[0] = pos;  // broadcast through LDS
+  }
+  wsync();
+  pos = w.counts[0];
+  if (pos + w.ntgt <= O.pool_cap)
+    for (int t = lane_id(); t < w.ntgt; t += WAVE) { O.pool_row[pos + t] = s.trow[t]; O.pool_reason[pos + t] = s.treason[t]; }
+  wsync();
+}
+
+// nominate (scheduler.go:665-705) for one head
+KQ_DEV void nominate_head(const K& k, Wave& w, int h, int slot) {
+  load_head(k, w, h);
+  if (w.has_last && last_assignment_outdated(k, h, w.cq)) { if (lane_id() == 0) w.has_last = 0; }
+  wsync();
+  Search s = get_assignments(k, w, slot, k.usage, nullptr, false);
+  publish_assignment(k, w, s, h);
+  if (lane_id() == 0) {
+    k.O.nominated_mode[h] = (uint8_t)w.rep_mode;
+    k.O.mode[h] = (uint8_t)w.rep_mode;
+    k.O.status[h] = KQ_ST_NOT_NOMINATED; k.O.action[h] = KQ_ACT_NONE; k.O.requeue_reason[h] = KQ_RQ_GENERIC; k.O.skip[h] = KQ_SKIP_NONE;
+    k.O.order[h] = -1;
+    atomic_add_i64(k.O.stat_bytes, (long long)w.bytes);
+  }
+  wsync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// processEntry (scheduler.go:392-523) — sequential inside one root-cohort tree
+// ------------------------------------------------------------------------------------------------
+// apply / revert the removal of a target row on usage_np, restricted to the entry's own flavor-resources
+KQ_DEV void np_apply_row_restricted(const K& k, Wave& w, int row, bool add) {
+  const DSnap& S = k.S;
+  int c = S.adm_cq[row];
+  const int32_t* cpath = S.path + (size_t)c * KQ_MAXD;
+  int cplen = S.plen[c];
+  for (int u = lane_id(); u < w.nuse; u += WAVE) {
+    int fr = w.use_fr[u];
+    UGW g{&S, k.usage_np, fr};
+    for (int e = S.adm_use_off[row]; e < S.adm_use_off[row + 1]; e++) {
+      if (S.adm_use_fr[e] != fr) continue;
+      if (add) add_usage(S, cpath, cplen, fr, S.adm_use_qty[e], g); else remove_usage(S, cpath, cplen, fr, S.adm_use_qty[e], g);
+    }
+  }
+  wsync();
+}
+// scheduler.fits (scheduler.go:771-777) against usage_np (= snapshot minus PreemptedWorkloads)
+KQ_DEV bool entry_fits(const K& k, Wave& w, const int32_t* trows, int nt, bool quota_usage) {
+  const DSnap& S = k.S;
+  if (!quota_usage || w.nuse == 0) return true;
+  for (int t = 0; t < nt; t++) if (!k.preempted[trows[t]]) np_apply_row_restricted(k, w, trows[t], false);
+  bool bad = false;
+  for (int u = lane_id(); u < w.nuse; u += WAVE) {
+    UG g{&S, k.usage_np, w.use_fr[u]};
+    if (i64max(0, available_of(S, w.path, w.plen, w.use_fr[u], g)) < w.use_qty[u]) bad = true;
+  }
+  bool ok = wballot(bad) == 0;
+  wsync();
+  for (int t = nt - 1; t >= 0; t--) if (!k.preempted[trows[t]]) np_apply_row_restricted(k, w, trows[t], true);
+  if (lane_id() == 0) w.bytes += (int64_t)w.nuse * 40 * w.plen;
+  return ok;
+}
+// cq.AddUsage on both planes (clusterqueue_snapshot.go:107)
+KQ_DEV void entry_add_usage(const K& k, Wave& w, const int64_t* qty) {
+  const DSnap& S = k.S;
+  for (int u = lane_id(); u < w.nuse; u += WAVE) {
+    int fr = w.use_fr[u];
+    UGW a{&S, k.usage_work, fr}, b{&S, k.usage_np, fr};
+    add_usage(S, w.path, w.plen, fr, qty[u], a);
+    add_usage(S, w.path, w.plen, fr, qty[u], b);
+  }
+  if (lane_id() == 0) w.bytes += (int64_t)w.nuse * 8 * w.plen;
+  wsync();
+}
+
+KQ_DEV void process_entry(const K& k, Wave& w, int e, int pos, int slot) {
+  const DSnap& S = k.S; const DOut& O = k.O;
+  const int lane = lane_id();
+  load_head(k, w, e);
+  if (lane == 0) {
+    w.nuse = O.use_n[e];
+    for (int u = 0; u < w.nuse; u++) { w.use_fr[u] = O.use_fr[(size_t)e * KQ_MAXU + u]; w.use_qty[u] = O.use_qty[(size_t)e * KQ_MAXU + u]; }
+    w.borrowing = O.borrowing[e];
+    w.rep_mode = O.nominated_mode[e];
+    O.order[e] = pos;
+  }
+  wsync();
+  const bool quota_usage = !(w.hflags & KQ_HEAD_HAS_QUOTA_RESERVATION);  // netUsage scheduler.go:785-794
+  const int32_t* trows = O.pool_row + O.tgt_pos[e];
+  int nt = O.tgt_n[e];
+  auto has_any = [&]() { bool a = false; for (int t = 0; t < nt; t++) if (k.preempted[trows[t]]) a = true; return a; };
+  // updateAssignmentIfNeeded :707-769
+  bool fits_ok = entry_fits(k, w, trows, nt, quota_usage);
+  int mode = w.rep_mode;
+  if (has_any() && gate(k, KQ_GATE_RECOMPUTE_ON_OVERLAP)) {
+    // SimulateWorkloadRemoval(victimsOfOtherPreemptions) == evaluate on usage_np with those rows deleted
+    if (lane == 0) w.has_last = 0;
+    wsync();
+    Search s = get_assignments(k, w, slot, k.usage_np, k.preempted, true);
+    publish_assignment(k, w, s, e);
+    trows = O.pool_row + O.tgt_pos[e];
+    nt = O.tgt_n[e];
+    mode = w.rep_mode;
+    if (mode == M_FIT) {  // SetRepresentativeMode(DeferredFit) flavorassigner.go:109-114
+      mode = M_DEFERRED;
+      for (int i = lane; i < w.nps * S.nR; i += WAVE) {
+        size_t o = (size_t)w.ps_base * S.nR + i;
+        if (O.flavor[o] >= 0) O.res_mode[o] = M_DEFERRED;
+      }
+    }
+    wsync();
+    fits_ok = entry_fits(k, w, trows, nt, quota_usage);
+  }
+  int status = KQ_ST_NOT_NOMINATED, action = KQ_ACT_NONE, rq = KQ_RQ_GENERIC, skip = KQ_SKIP_NONE;
+  bool done = false;
+  if (mode == M_NOFIT) { rq = KQ_RQ_NOFIT; done = true; }
+  if (!done && mode == M_PREEMPT && nt == 0) {
+    rq = KQ_RQ_PREEMPTION_NO_CANDIDATES;
+    // reserveCapacityForUnreclaimablePreempt :538-543 ; quotaResourcesToReserve :796-814
+    bool can_always_reclaim = KQ_POL_RECLAIM(w.pol) == KQ_POLICY_ANY;
+    if ((!can_always_reclaim || (gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS) && (w.hflags & KQ_HEAD_IS_PREEMPTOR))) && quota_usage) {
+      if (lane == 0)
+        for (int u = 0; u < w.nuse; u++) {
+          int fr = w.use_fr[u];
+          int64_t usage = w.use_qty[u], nominal = S.nominal[ix(S, w.cq, fr)], cur = k.usage_work[ix(S, w.cq, fr)], blv = S.bl[ix(S, w.cq, fr)];
+          int64_t r;
+          if (w.borrowing > 0) r = blv == KQ_NIL_LIMIT ? usage : i64min(usage, a_sub(a_add(nominal, blv), cur));
+          else r = i64max(0, i64min(usage, a_sub(nominal, cur)));
+          w.s_qty[u] = r;
+        }
+      wsync();
+      entry_add_usage(k, w, w.s_qty);
+    }
+    done = true;
+  }
+  if (!done && mode == M_DEFERRED) {
+    rq = KQ_RQ_PENDING_PREEMPTION;
+    if (quota_usage) entry_add_usage(k, w, w.use_qty);
+    done = true;
+  }
+  if (!done && has_any()) { status = KQ_ST_SKIPPED; skip = KQ_SKIP_OVERLAP; done = true; }
+  if (!done && !fits_ok) { status = KQ_ST_SKIPPED; skip = KQ_SKIP_NO_LONGER_FITS; done = true; }
+  if (!done) {
+    // preemptedWorkloads.Insert(targets): rows leave usage_np for the rest of the cycle
+    for (int t = 0; t < nt; t++) {
+      int row = trows[t];
+      if (lane == 0 && !k.preempted[row]) {
+        k.preempted[row] = 1;
+        int c = S.adm_cq[row];
+        for (int en = S.adm_use_off[row]; en < S.adm_use_off[row + 1]; en++) {
+          UGW g{&S, k.usage_np, S.adm_use_fr[en]};
+          remove_usage(S, S.path + (size_t)c * KQ_MAXD, S.plen[c], S.adm_use_fr[en], S.adm_use_qty[en], g);
+        }
+      }
+      wsync();
+    }
+    if (quota_usage) entry_add_usage(k, w, w.use_qty);
+    if (mode == M_PREEMPT) { action = KQ_ACT_PREEMPT; rq = KQ_RQ_PENDING_PREEMPTION; }
+    else { status = KQ_ST_ASSUMED; action = KQ_ACT_ADMIT; }
+  }
+  if (lane == 0) {
+    if (status != KQ_ST_NOT_NOMINATED && status != KQ_ST_ASSUMED && rq == KQ_RQ_GENERIC) rq = KQ_RQ_FAILED_AFTER_NOMINATION;  // scheduler.go:1167-1170
+    O.status[e] = (uint8_t)status; O.action[e] = (uint8_t)action; O.requeue_reason[e] = (uint8_t)rq; O.skip[e] = (uint8_t)skip;
+    O.mode[e] = (uint8_t)mode;
+    atomic_add_i64(O.stat_bytes, (long long)w.bytes);
+  }
+  wsync();
+}
+
+// one wave per root-cohort tree: drain the tree's entries in iterator order
+KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot) {
+  const int n = k.H.n;
+  for (int base = 0; base < n; base += WAVE) {
+    int i = base + lane_id();
+    bool mine = false;
+    if (i < n) mine = k.S.tree_of[k.H.cq[k.order_idx[i]]] == tree;
+    uint64_t m = wballot(mine);
+    while (m) {
+      int b = ffs64(m);
+      m &= m - 1;
+      process_entry(k, w, k.order_idx[base + b], base + b, slot);
+    }
+  }
+}
+
+// classical entry order (scheduler.go:1110-1163): a precedes b
+KQ_DEV bool entry_before(const K& k, int a, int b) {
+  bool aq = k.H.flags[a] & KQ_HEAD_HAS_QUOTA_RESERVATION, bq = k.H.flags[b] & KQ_HEAD_HAS_QUOTA_RESERVATION;
+  if (aq != bq) return aq;
+  if (gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS)) {
+    bool ap = k.H.flags[a] & KQ_HEAD_IS_PREEMPTOR, bp = k.H.flags[b] & KQ_HEAD_IS_PREEMPTOR;
+    if (ap != bp) return ap;
+  }
+  int ab = k.O.borrowing[a], bb = k.O.borrowing[b];
+  if (ab != bb) return ab < bb;
+  if (gate(k, KQ_GATE_PRIORITY_SORTING_IN_COHORT)) {
+    int64_t pa = k.H.priority[a], pb = k.H.priority[b];
+    if (pa != pb) return pa > pb;
+  }
+  int64_t ta = k.H.queue_ts[a], tb = k.H.queue_ts[b];
+  if (ta != tb) return ta < tb;
+  return a < b;  // canonical stable order
+}
+}  // namespace kq

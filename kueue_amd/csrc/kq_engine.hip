@@ -1,0 +1,192 @@
+// kq_engine.hip — gfx950 kernels + the C-ABI entry points of include/kq_engine.h.
+//
+// Launch geometry (MI355X: 256 CUs x 4 SIMD-32, wave64, 8 XCDs with private L2):
+//   k_nominate : 1 wave (64 threads) per workgroup, grid-stride over heads; up to 4096 resident waves.
+//                A head's CQ->root path rows (5 planes x (D+1) x FR) are the hot data; consecutive heads
+//                are consecutive ClusterQueues (canonical name order) i.e. siblings in the cohort tree, so
+//                workgroup w -> XCD w%8 keeps a cohort's ancestor rows hot in 8 L2s at once (read-only
+//                sharing across XCDs is safe: the planes are not written during nominate).
+//   k_order    : rank of every entry by pairwise compare (H <= a few thousand per cycle at reference
+//                semantics: <= 1 head per ClusterQueue).
+//   k_process  : 1 wave per root-cohort tree; entries of one tree are sequentially dependent
+//                (scheduler.go:486 cq.AddUsage changes what later entries see).
+// No MFMA anywhere: saturating int64 compares/adds over gathered quota rows -> HBM/L2-bound.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "kq_host.hpp"
+
+using namespace kq;
+
+__global__ __launch_bounds__(64) void k_nominate(K k, int slots) {
+  __shared__ Wave w;
+  const int slot = blockIdx.x;
+  for (int h = slot; h < k.H.n; h += slots) nominate_head(k, w, h, slot);
+}
+
+__global__ __launch_bounds__(256) void k_order(K k, int32_t* order_idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k.H.n) return;
+  int rank = 0;
+  for (int j = 0; j < k.H.n; j++) rank += (j != i && entry_before(k, j, i)) ? 1 : 0;
+  order_idx[rank] = i;
+}
+
+__global__ __launch_bounds__(64) void k_process(K k) {
+  __shared__ Wave w;
+  process_tree(k, w, blockIdx.x, blockIdx.x);
+}
+
+namespace kq {
+struct HipBackend {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int device = 0;
+  int n_cu = 256;
+  hipError_t err = hipSuccess;
+  std::string msg;
+
+  void chk(hipError_t e, const char* what) {
+    if (e != hipSuccess && err == hipSuccess) { err = e; msg = std::string(what) + ": " + hipGetErrorString(e); }
+  }
+  int init(int dev) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) { msg = "no HIP device available"; return KQ_ENODEVICE; }
+    if (dev < 0 || dev >= count) { msg = "device ordinal out of range"; return KQ_EINVAL; }
+    device = dev;
+    chk(hipSetDevice(dev), "hipSetDevice");
+    hipDeviceProp_t prop;
+    chk(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties");
+    if (err == hipSuccess) n_cu = prop.multiProcessorCount;
+    chk(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+    chk(hipEventCreate(&ev0), "hipEventCreate");
+    chk(hipEventCreate(&ev1), "hipEventCreate");
+    return err == hipSuccess ? KQ_OK : KQ_EDEVICE;
+  }
+  void destroy() {
+    if (ev0) hipEventDestroy(ev0);
+    if (ev1) hipEventDestroy(ev1);
+    if (stream) hipStreamDestroy(stream);
+  }
+  void* alloc(size_t n) { void* p = nullptr; chk(hipMalloc(&p, n), "hipMalloc"); return p; }
+  void free(void* p) { hipFree(p); }
+  void h2d(void* d, const void* h, size_t n) { chk(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, stream), "h2d"); }
+  void d2h(void* h, const void* d, size_t n) { chk(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream), "d2h"); }
+  void d2d(void* d, const void* s, size_t n) { chk(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, stream), "d2d"); }
+  void memset(void* d, int v, size_t n) { chk(hipMemsetAsync(d, v, n, stream), "memset"); }
+  int sync() {
+    chk(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    if (err != hipSuccess) { hipError_t e = err; (void)e; err = hipSuccess; (void)hipGetLastError(); return KQ_EDEVICE; }
+    return KQ_OK;
+  }
+  const char* error() { return msg.c_str(); }
+  int max_slots() { return n_cu * 16; }  // 16 one-wave workgroups per CU (4 per SIMD)
+  void timer_start() { chk(hipEventRecord(ev0, stream), "hipEventRecord"); }
+  void timer_stop() { chk(hipEventRecord(ev1, stream), "hipEventRecord"); }
+  double timer_ms() { float ms = 0; chk(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime"); return ms; }
+  void launch_nominate(const K& k, int slots) {
+    hipLaunchKernelGGL(k_nominate, dim3(slots), dim3(64), 0, stream, k, slots);
+    chk(hipGetLastError(), "k_nominate");
+  }
+  void launch_order(const K& k, int32_t* order_idx) {
+    hipLaunchKernelGGL(k_order, dim3((k.H.n + 255) / 256), dim3(256), 0, stream, k, order_idx);
+    chk(hipGetLastError(), "k_order");
+  }
+  void launch_process(const K& k, int n_tree) {
+    hipLaunchKernelGGL(k_process, dim3(n_tree), dim3(64), 0, stream, k);
+    chk(hipGetLastError(), "k_process");
+  }
+};
+}  // namespace kq
+
+struct kq_engine {
+  EngineT<HipBackend> e;
+};
+
+extern "C" {
+
+int kq_abi_version(void) { return KQ_ABI_VERSION; }
+
+const char* kq_strerror(int code) {
+  switch (code) {
+    case KQ_OK: return "ok";
+    case KQ_EINVAL: return "invalid argument";
+    case KQ_ENOMEM: return "out of memory";
+    case KQ_EDEVICE: return "HIP error";
+    case KQ_EUNSUPPORTED: return "input not supported by the device path";
+    case KQ_ECAPACITY: return "output buffer too small";
+    case KQ_ENODEVICE: return "no HIP device";
+    default: return "unknown error";
+  }
+}
+
+int kq_engine_create(const kq_config* cfg, kq_engine** out) {
+  if (!cfg || !out) return KQ_EINVAL;
+  if (cfg->abi_version != KQ_ABI_VERSION) return KQ_EINVAL;
+  kq_engine* en = new (std::nothrow) kq_engine();
+  if (!en) return KQ_ENOMEM;
+  en->e.cfg = *cfg;
+  int rc = en->e.be.init(cfg->device);
+  if (rc != KQ_OK) { fprintf(stderr, "kq_engine_create: %s\n", en->e.be.msg.c_str()); delete en; return rc; }
+  *out = en;
+  return KQ_OK;
+}
+
+void kq_engine_destroy(kq_engine* en) {
+  if (!en) return;
+  hipSetDevice(en->e.be.device);
+  en->e.free_snapshot();
+  HipBackend be = en->e.be;
+  delete en;
+  be.destroy();
+}
+
+int kq_snapshot_put(kq_engine* en, const kq_snapshot* s) {
+  if (!en || !s) return KQ_EINVAL;
+  hipSetDevice(en->e.be.device);
+  return en->e.snapshot_put(s);
+}
+
+int kq_cycle_run(kq_engine* en, const kq_heads* h, kq_decisions* out) {
+  if (!en || !h || !out) return KQ_EINVAL;
+  hipSetDevice(en->e.be.device);
+  return en->e.cycle_run(h, out);
+}
+
+int kq_last_cycle_stats(kq_engine* en, double* kernel_ms, int64_t* algorithmic_bytes) {
+  if (!en) return KQ_EINVAL;
+  if (kernel_ms) *kernel_ms = en->e.last_kernel_ms;
+  if (algorithmic_bytes) *algorithmic_bytes = en->e.last_bytes;
+  return KQ_OK;
+}
+
+int kq_snapshot_derive(kq_engine* en) {
+  if (!en) return KQ_EINVAL;
+  en->e.last_error = "kq_snapshot_derive: not implemented yet";
+  return KQ_EUNSUPPORTED;
+}
+
+int kq_snapshot_read_planes(kq_engine* en, int64_t* subtree_quota, int64_t* usage, uint8_t* quota_flags) {
+  if (!en || !en->e.have_snapshot) return KQ_EINVAL;
+  hipSetDevice(en->e.be.device);
+  size_t n = (size_t)en->e.prep.N * en->e.prep.nfr;
+  if (subtree_quota) en->e.be.d2h(subtree_quota, en->e.d_sq, n * 8);
+  if (usage) en->e.be.d2h(usage, en->e.d_usage, n * 8);
+  if (quota_flags) en->e.be.d2h(quota_flags, en->e.d_qflags, n);
+  return en->e.be.sync();
+}
+
+const char* kq_last_error(kq_engine* en) { return en ? en->e.last_error.c_str() : "null engine"; }
+
+// test hook (not part of the drop-in boundary): snapshot usage as left by the last cycle
+int kq_debug_read_usage_work(kq_engine* en, int64_t* out) {
+  if (!en) return KQ_EINVAL;
+  hipSetDevice(en->e.be.device);
+  return en->e.read_usage_work(out);
+}
+
+}  // extern "C"

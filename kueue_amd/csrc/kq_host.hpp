@@ -1,0 +1,285 @@
+// kq_host.hpp — host orchestration of the engine behind the C ABI (include/kq_engine.h).
+//
+// Templated on a Backend that owns "device" memory and launches the three phases of a cycle:
+//   nominate  (one wave per head)        scheduler.go:665   nominate
+//   order     (rank by pairwise compare) scheduler.go:1110  makeClassicalIterator
+//   process   (one wave per root tree)   scheduler.go:392   processEntry, sequential inside a tree
+// HipBackend (kq_engine.hip) is the product. EmuBackend (tests/emu) runs the same kernels as plain
+// loops with a 1-lane wave so the CPU suite can check the control logic; it is never shipped.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kq_device.hpp"
+
+namespace kq {
+
+template <class B> struct EngineT {
+  B be;
+  kq_config cfg{};
+  std::string last_error;
+  Prep prep;
+  bool have_snapshot = false;
+  DSnap S{};
+  int64_t* d_usage = nullptr;       // cycle-start usage plane (mutable by derive)
+  int64_t* d_sq = nullptr;          // subtree quota (mutable by derive)
+  uint8_t* d_qflags = nullptr;
+  std::vector<void*> snap_allocs;
+  // cycle buffers (grow-only)
+  struct Buf { void* p = nullptr; size_t cap = 0; };
+  std::vector<Buf*> all_bufs;
+  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc;
+  Buf hb[24];  // head arrays
+  Buf ob[24];  // output arrays
+  double last_kernel_ms = 0;
+  int64_t last_bytes = 0;
+
+  int fail(int code, const std::string& msg) { last_error = msg; return code; }
+
+  template <class T> T* upload(const T* host, size_t n) {
+    T* d = (T*)be.alloc(std::max<size_t>(n, 1) * sizeof(T));
+    if (n) be.h2d(d, host, n * sizeof(T));
+    snap_allocs.push_back(d);
+    return d;
+  }
+  template <class T> T* grow(Buf& b, size_t n) {
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    if (bytes > b.cap) {
+      if (b.p) be.free(b.p);
+      size_t cap = bytes + bytes / 4;
+      b.p = be.alloc(cap);
+      b.cap = cap;
+    }
+    return (T*)b.p;
+  }
+  void free_snapshot() {
+    for (void* p : snap_allocs) be.free(p);
+    snap_allocs.clear();
+    have_snapshot = false;
+  }
+  ~EngineT() {
+    free_snapshot();
+    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc}) if (b->p) be.free(b->p);
+    for (auto& b : hb) if (b.p) be.free(b.p);
+    for (auto& b : ob) if (b.p) be.free(b.p);
+  }
+
+  // cache.Snapshot -> HBM (snapshot.go:171)
+  int snapshot_put(const kq_snapshot* s) {
+    free_snapshot();
+    int rc = build_prep(s, prep);
+    if (rc != KQ_OK) return fail(rc, prep.err);
+    const size_t N = prep.N, nfr = prep.nfr, nq = prep.nq;
+    S = DSnap{};
+    S.nq = prep.nq; S.nc = prep.nc; S.N = prep.N; S.nF = prep.nF; S.nR = prep.nR; S.nfr = prep.nfr;
+    S.pods_res = s->pods_resource; S.n_adm = prep.n_adm; S.n_tree = prep.n_tree; S.nfw = (prep.nF + 63) / 64;
+    S.resource_order = upload(s->resource_order, prep.nR);
+    S.parent = upload(s->parent, N);
+    S.nominal = upload(s->nominal, N * nfr);
+    S.bl = upload(s->borrow_limit, N * nfr);
+    S.ll = upload(s->lend_limit, N * nfr);
+    d_sq = upload(s->subtree_quota, N * nfr); S.sq = d_sq;
+    d_usage = upload(s->usage, N * nfr);
+    d_qflags = upload(s->quota_flags, N * nfr); S.qflags = d_qflags;
+    S.cq_rg_off = upload(s->cq_rg_off, nq + 1);
+    S.rg_flavor_off = upload(s->rg_flavor_off, prep.n_rg + 1);
+    S.rg_flavor = upload(s->rg_flavor, s->rg_flavor_off[prep.n_rg]);
+    S.rg_res_off = upload(s->rg_res_off, prep.n_rg + 1);
+    S.rg_res = upload(s->rg_res, s->rg_res_off[prep.n_rg]);
+    S.cq_policy = upload(s->cq_policy, nq);
+    S.cq_thr = upload(s->cq_borrow_prio_threshold, nq);
+    S.cq_gen = upload(s->cq_generation, nq);
+    S.cq_adm_off = upload(s->cq_adm_off, nq + 1);
+    S.adm_prio = upload(s->adm_priority, prep.n_adm);
+    S.adm_qts = upload(s->adm_queue_ts, prep.n_adm);
+    S.adm_flags = upload(s->adm_flags, prep.n_adm);
+    S.adm_use_off = upload(s->adm_use_off, prep.n_adm + 1);
+    S.adm_use_fr = upload(s->adm_use_fr, s->adm_use_off[prep.n_adm]);
+    S.adm_use_qty = upload(s->adm_use_qty, s->adm_use_off[prep.n_adm]);
+    S.path = upload(prep.path.data(), prep.path.size());
+    S.plen = upload(prep.plen.data(), prep.plen.size());
+    S.tree_of = upload(prep.tree_of.data(), prep.tree_of.size());
+    S.node_local = upload(prep.node_local.data(), prep.node_local.size());
+    S.node_height = upload(prep.node_height.data(), prep.node_height.size());
+    S.adm_cq = upload(prep.adm_cq.data(), prep.adm_cq.size());
+    S.cq_local = upload(prep.cq_local.data(), prep.cq_local.size());
+    S.tree_node_off = upload(prep.tree_node_off.data(), prep.tree_node_off.size());
+    S.tree_nodes = upload(prep.tree_nodes.data(), prep.tree_nodes.size());
+    S.tree_cq_off = upload(prep.tree_cq_off.data(), prep.tree_cq_off.size());
+    S.tree_cqs = upload(prep.tree_cqs.data(), prep.tree_cqs.size());
+    S.tree_row_off = upload(prep.tree_row_off.data(), prep.tree_row_off.size());
+    S.tree_rows = upload(prep.tree_rows.data(), prep.tree_rows.size());
+    rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    have_snapshot = true;
+    return KQ_OK;
+  }
+
+  int validate_heads(const kq_heads* h, int* slot_cap) {
+    if (h->n < 0) return fail(KQ_EINVAL, "negative head count");
+    int cap = 1;
+    for (int i = 0; i < h->n; i++) {
+      if (h->cq[i] < 0 || h->cq[i] >= prep.nq) return fail(KQ_EINVAL, "head cq out of range");
+      int nps = h->ps_off[i + 1] - h->ps_off[i];
+      if (nps < 0) return fail(KQ_EINVAL, "ps_off not monotone");
+      if (nps > KQ_MAXPS) return fail(KQ_EUNSUPPORTED, "more podsets than KQ_MAXPS");
+      int slots = 0;
+      for (int p = h->ps_off[i]; p < h->ps_off[i + 1]; p++) {
+        int nreq = h->ps_req_off[p + 1] - h->ps_req_off[p];
+        if (nreq < 0) return fail(KQ_EINVAL, "ps_req_off not monotone");
+        if (nreq + 1 > KQ_MAXREQ) return fail(KQ_EUNSUPPORTED, "more resources per podset than KQ_MAXREQ");
+        for (int e = h->ps_req_off[p]; e < h->ps_req_off[p + 1]; e++)
+          if (h->req_res[e] < 0 || h->req_res[e] >= prep.nR) return fail(KQ_EINVAL, "req_res out of range");
+        slots += nreq + 1;
+      }
+      if (slots > KQ_MAXU) return fail(KQ_EUNSUPPORTED, "more usage entries than KQ_MAXU");
+      cap = std::max(cap, slots);
+    }
+    *slot_cap = cap;
+    return KQ_OK;
+  }
+
+  template <class T> const T* up_head(int i, const T* host, size_t n) {
+    T* d = grow<T>(hb[i], n);
+    if (n) be.h2d(d, host, n * sizeof(T));
+    return d;
+  }
+
+  int cycle_run(const kq_heads* h, kq_decisions* out) {
+    if (!have_snapshot) return fail(KQ_EINVAL, "kq_cycle_run before kq_snapshot_put");
+    if (cfg.fair_sharing) return fail(KQ_EUNSUPPORTED, "fair sharing is not implemented on the device path yet");
+    int slot_cap = 1;
+    int rc = validate_heads(h, &slot_cap);
+    if (rc != KQ_OK) return rc;
+    const int n = h->n;
+    if (out->tgt_off) out->tgt_off[0] = 0;
+    if (n == 0) {
+      last_kernel_ms = 0; last_bytes = 0;
+      be.d2d(grow<int64_t>(b_usage_work, (size_t)prep.N * prep.nfr), d_usage, (size_t)prep.N * prep.nfr * sizeof(int64_t));
+      return be.sync();
+    }
+    const size_t nps = h->ps_off[n], nreqs = h->ps_req_off[nps], nR = prep.nR, nfw = (prep.nF + 63) / 64;
+    const size_t Nfr = (size_t)prep.N * prep.nfr;
+    K k{};
+    k.S = S;
+    k.C.gates = cfg.gates; k.C.fair_sharing = cfg.fair_sharing; k.C.quota_check_strategy = cfg.quota_check_strategy; k.C.cycle = h->cycle;
+    std::vector<int64_t> zeros64(n, 0);
+    std::vector<uint64_t> zerosu64(n, 0);
+    std::vector<int32_t> minus1(nps * nR, -1), minus1ps(nps, -1);
+    k.H.n = n;
+    k.H.cq = up_head(0, h->cq, n);
+    k.H.priority = up_head(1, h->priority, n);
+    k.H.queue_ts = up_head(2, h->queue_ts, n);
+    k.H.flags = up_head(3, h->flags, n);
+    k.H.ps_off = up_head(4, h->ps_off, n + 1);
+    k.H.ps_count = up_head(5, h->ps_count, nps);
+    k.H.ps_min_count = up_head(6, h->ps_min_count ? h->ps_min_count : minus1ps.data(), nps);
+    k.H.ps_req_off = up_head(7, h->ps_req_off, nps + 1);
+    k.H.req_res = up_head(8, h->req_res, nreqs);
+    k.H.req_qty = up_head(9, h->req_qty, nreqs);
+    k.H.ps_flavor_ok = up_head(10, h->ps_flavor_ok, nps * nfw);
+    k.H.ps_last_tried = up_head(11, h->ps_last_tried ? h->ps_last_tried : minus1.data(), nps * nR);
+    k.H.last_generation = up_head(12, h->last_generation ? h->last_generation : zeros64.data(), n);
+    k.H.last_cycle = up_head(13, h->last_cycle ? h->last_cycle : zeros64.data(), n);
+    k.H.last_hash = up_head(14, h->last_hash ? h->last_hash : zerosu64.data(), n);
+    k.H.hash = up_head(15, h->hash ? h->hash : zerosu64.data(), n);
+    // outputs
+    const int pool_cap = std::max(out->tgt_cap, 1);
+    DOut& O = k.O;
+    O.status = grow<uint8_t>(ob[0], n); O.action = grow<uint8_t>(ob[1], n); O.nominated_mode = grow<uint8_t>(ob[2], n);
+    O.mode = grow<uint8_t>(ob[3], n); O.requeue_reason = grow<uint8_t>(ob[4], n); O.skip = grow<uint8_t>(ob[5], n);
+    O.borrowing = grow<int32_t>(ob[6], n); O.order = grow<int32_t>(ob[7], n);
+    O.flavor = grow<int32_t>(ob[8], nps * nR); O.res_mode = grow<uint8_t>(ob[9], nps * nR); O.tried_idx = grow<int32_t>(ob[10], nps * nR);
+    O.ps_count = grow<int32_t>(ob[11], nps);
+    O.use_n = grow<int32_t>(ob[12], n); O.use_fr = grow<int32_t>(ob[13], (size_t)n * KQ_MAXU); O.use_qty = grow<int64_t>(ob[14], (size_t)n * KQ_MAXU);
+    O.tgt_pos = grow<int32_t>(ob[15], n); O.tgt_n = grow<int32_t>(ob[16], n);
+    // recomputation on overlap appends a second target segment per head: size the pool for both
+    O.pool_cap = pool_cap * 2;
+    O.pool_row = grow<int32_t>(ob[17], O.pool_cap); O.pool_reason = grow<uint8_t>(ob[18], O.pool_cap);
+    int64_t* misc = grow<int64_t>(b_misc, 4);
+    be.memset(misc, 0, 4 * sizeof(int64_t));
+    O.pool_count = (int32_t*)misc; O.error = (int32_t*)misc + 1; O.stat_bytes = (long long*)(misc + 1);
+    // nominated flavors start empty (a head's rows are rewritten by assign_flavors)
+    be.memset(O.flavor, 0xff, nps * nR * sizeof(int32_t));
+    // scratch: one slot per resident wave
+    const int slots_nom = std::min(n, be.max_slots());
+    const int slots = std::max(slots_nom, prep.n_tree);
+    DScratch& X = k.X;
+    X.max_tree_nodes = prep.max_tree_nodes; X.max_tree_cqs = std::max(prep.max_tree_cqs, 1); X.max_tree_rows = std::max(prep.max_tree_rows, 1);
+    X.slot_cap = slot_cap; X.tgt_cap = std::max(prep.max_tree_rows, 1);
+    X.w = grow<int64_t>(b_w, (size_t)slots * X.max_tree_nodes * X.slot_cap);
+    X.cqinfo = grow<uint8_t>(b_cqinfo, (size_t)slots * X.max_tree_cqs);
+    X.cls = grow<uint8_t>(b_cls, (size_t)slots * X.max_tree_rows);
+    X.tgt_row = grow<int32_t>(b_tgt_row, (size_t)slots * X.tgt_cap);
+    X.tgt_reason = grow<uint8_t>(b_tgt_reason, (size_t)slots * X.tgt_cap);
+    k.usage = d_usage;
+    k.usage_work = grow<int64_t>(b_usage_work, Nfr);
+    k.usage_np = grow<int64_t>(b_usage_np, Nfr);
+    k.preempted = grow<uint8_t>(b_preempted, std::max(prep.n_adm, 1));
+    int32_t* order_idx = grow<int32_t>(b_order, n);
+    k.order_idx = order_idx;
+    be.d2d(k.usage_work, d_usage, Nfr * sizeof(int64_t));
+    be.d2d(k.usage_np, d_usage, Nfr * sizeof(int64_t));
+    be.memset(k.preempted, 0, std::max(prep.n_adm, 1));
+
+    be.timer_start();
+    be.launch_nominate(k, slots_nom);
+    be.launch_order(k, order_idx);
+    be.launch_process(k, prep.n_tree);
+    be.timer_stop();
+
+    // decisions back
+    if (out->status) be.d2h(out->status, O.status, n);
+    if (out->action) be.d2h(out->action, O.action, n);
+    if (out->nominated_mode) be.d2h(out->nominated_mode, O.nominated_mode, n);
+    if (out->mode) be.d2h(out->mode, O.mode, n);
+    if (out->requeue_reason) be.d2h(out->requeue_reason, O.requeue_reason, n);
+    if (out->skip) be.d2h(out->skip, O.skip, n);
+    if (out->borrowing) be.d2h(out->borrowing, O.borrowing, n * sizeof(int32_t));
+    if (out->order) be.d2h(out->order, O.order, n * sizeof(int32_t));
+    if (out->flavor) be.d2h(out->flavor, O.flavor, nps * nR * sizeof(int32_t));
+    if (out->res_mode) be.d2h(out->res_mode, O.res_mode, nps * nR);
+    if (out->tried_idx) be.d2h(out->tried_idx, O.tried_idx, nps * nR * sizeof(int32_t));
+    if (out->ps_count) be.d2h(out->ps_count, O.ps_count, nps * sizeof(int32_t));
+    std::vector<int32_t> tpos(n), tn(n);
+    be.d2h(tpos.data(), O.tgt_pos, n * sizeof(int32_t));
+    be.d2h(tn.data(), O.tgt_n, n * sizeof(int32_t));
+    int64_t miscs[4];
+    be.d2h(miscs, misc, sizeof(miscs));
+    rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    int32_t pool_used = ((int32_t*)miscs)[0], dev_err = ((int32_t*)miscs)[1];
+    last_bytes = miscs[1];
+    last_kernel_ms = be.timer_ms();
+    if (dev_err != 0) return fail(dev_err, "device-side error (capacity or unsupported input)");
+    // targets CSR: canonical order inside an entry = ascending admitted row
+    std::vector<int32_t> prow(std::max(pool_used, 1));
+    std::vector<uint8_t> preason(std::max(pool_used, 1));
+    if (pool_used > 0) { be.d2h(prow.data(), O.pool_row, (size_t)pool_used * sizeof(int32_t)); be.d2h(preason.data(), O.pool_reason, pool_used); rc = be.sync(); if (rc != KQ_OK) return fail(rc, be.error()); }
+    int tot = 0;
+    for (int i = 0; i < n; i++) {
+      if (out->tgt_off) out->tgt_off[i] = tot;
+      std::vector<std::pair<int32_t, uint8_t>> ts;
+      for (int t = 0; t < tn[i]; t++) ts.push_back({prow[tpos[i] + t], preason[tpos[i] + t]});
+      std::sort(ts.begin(), ts.end());
+      for (auto& t : ts) {
+        if (tot >= out->tgt_cap) return fail(KQ_ECAPACITY, "tgt_cap too small");
+        if (out->tgt_adm) out->tgt_adm[tot] = t.first;
+        if (out->tgt_reason) out->tgt_reason[tot] = t.second;
+        tot++;
+      }
+    }
+    if (out->tgt_off) out->tgt_off[n] = tot;
+    return KQ_OK;
+  }
+
+  int read_usage_work(int64_t* out) {  // tests: snapshot usage after the cycle
+    be.d2h(out, b_usage_work.p, (size_t)prep.N * prep.nfr * sizeof(int64_t));
+    return be.sync();
+  }
+};
+
+}  // namespace kq

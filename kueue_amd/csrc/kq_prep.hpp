@@ -1,0 +1,133 @@
+// kq_prep.hpp — host-side preparation of the HBM-resident snapshot image.
+//
+// Runs once per kq_snapshot_put (pure C++, no device code): validates the flat snapshot and builds
+// the static index structures the kernels need so that nothing on the device ever chases a
+// pointer or recurses:
+//   depth / root / tree partition      hierarchy walk        (pkg/cache/hierarchy/cohort.go)
+//   node_height                        getNodeHeight          (classical/hierarchical_preemption.go:209-215)
+//   tree_rows (rank order)             CandidatesOrdering's static part: priority asc, quota
+//                                      reservation time desc, UID asc (common/ordering.go:66-81)
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/kq_engine.h"
+
+namespace kq {
+
+constexpr int KQ_MAXD = 8;      // max nodes on a CQ->root path (CQ + 7 cohort levels)
+constexpr int KQ_MAXREQ = 16;   // max resources requested by one podset (incl. injected "pods")
+constexpr int KQ_MAXU = 32;     // max (flavor,resource) entries in one assignment's usage
+constexpr int KQ_MAXPS = 8;     // max podsets per workload handled on device
+
+struct Prep {
+  int nq = 0, nc = 0, N = 0, nF = 0, nR = 0, nfr = 0, n_adm = 0, n_rg = 0;
+  std::vector<int32_t> depth, root, tree_of, node_local, node_height;
+  std::vector<int32_t> path;         // [nq * KQ_MAXD] cq, parent, ..., root ; -1 padded
+  std::vector<int32_t> plen;         // [nq]
+  int n_tree = 0;
+  std::vector<int32_t> tree_node_off, tree_nodes;  // nodes of a tree (CQs first, then cohorts)
+  std::vector<int32_t> tree_cq_off, tree_cqs;      // CQs of a tree
+  std::vector<int32_t> cq_local;                   // [nq] index of the CQ inside tree_cqs of its tree
+  std::vector<int32_t> tree_row_off, tree_rows;    // admitted rows of a tree, in static candidate rank order
+  std::vector<int32_t> adm_cq;                     // [n_adm]
+  int max_tree_nodes = 0, max_tree_cqs = 0, max_tree_rows = 0;
+  std::string err;
+};
+
+inline int build_prep(const kq_snapshot* s, Prep& p) {
+  p.nq = s->n_cq; p.nc = s->n_cohort; p.N = p.nq + p.nc; p.nF = s->n_flavor; p.nR = s->n_resource;
+  p.nfr = p.nF * p.nR; p.n_adm = s->n_adm;
+  const int N = p.N, nq = p.nq;
+  if (p.nq < 0 || p.nc < 0 || p.nF <= 0 || p.nR <= 0) { p.err = "bad dimensions"; return KQ_EINVAL; }
+  p.n_rg = s->cq_rg_off[nq];
+  p.depth.assign(N, 0); p.root.assign(N, 0);
+  for (int n = 0; n < N; n++) {
+    int d = 0, a = n;
+    while (s->parent[a] >= 0) {
+      a = s->parent[a];
+      if (a < nq || a >= N) { p.err = "parent must be a cohort node"; return KQ_EINVAL; }
+      if (++d > N) { p.err = "cycle in cohort tree"; return KQ_EINVAL; }
+    }
+    p.depth[n] = d; p.root[n] = a;
+  }
+  p.path.assign((size_t)nq * KQ_MAXD, -1); p.plen.assign(nq, 0);
+  for (int c = 0; c < nq; c++) {
+    if (p.depth[c] + 1 > KQ_MAXD) { p.err = "cohort tree deeper than KQ_MAXD"; return KQ_EUNSUPPORTED; }
+    int k = 0;
+    for (int a = c; a >= 0; a = s->parent[a]) p.path[(size_t)c * KQ_MAXD + k++] = a;
+    p.plen[c] = k;
+  }
+  // trees = connected components by root; order trees by ascending root index
+  std::vector<int32_t> roots;
+  for (int n = 0; n < N; n++) if (p.root[n] == n) roots.push_back(n);
+  p.n_tree = (int)roots.size();
+  std::vector<int32_t> tree_of_root(N, -1);
+  for (int t = 0; t < p.n_tree; t++) tree_of_root[roots[t]] = t;
+  p.tree_of.assign(N, 0);
+  for (int n = 0; n < N; n++) p.tree_of[n] = tree_of_root[p.root[n]];
+  p.tree_node_off.assign(p.n_tree + 1, 0); p.tree_cq_off.assign(p.n_tree + 1, 0); p.tree_row_off.assign(p.n_tree + 1, 0);
+  for (int n = 0; n < N; n++) p.tree_node_off[p.tree_of[n] + 1]++;
+  for (int c = 0; c < nq; c++) p.tree_cq_off[p.tree_of[c] + 1]++;
+  for (int t = 0; t < p.n_tree; t++) { p.tree_node_off[t + 1] += p.tree_node_off[t]; p.tree_cq_off[t + 1] += p.tree_cq_off[t]; }
+  p.tree_nodes.assign(N, 0); p.tree_cqs.assign(nq, 0); p.node_local.assign(N, 0); p.cq_local.assign(nq, 0);
+  {
+    std::vector<int32_t> fill(p.tree_node_off.begin(), p.tree_node_off.end() - 1);
+    for (int n = 0; n < N; n++) { int t = p.tree_of[n]; p.node_local[n] = fill[t] - p.tree_node_off[t]; p.tree_nodes[fill[t]++] = n; }
+    std::vector<int32_t> fq(p.tree_cq_off.begin(), p.tree_cq_off.end() - 1);
+    for (int c = 0; c < nq; c++) { int t = p.tree_of[c]; p.cq_local[c] = fq[t] - p.tree_cq_off[t]; p.tree_cqs[fq[t]++] = c; }
+  }
+  // node heights, children before parents: process cohorts by decreasing depth
+  p.node_height.assign(N, 0);
+  {
+    std::vector<int32_t> order;
+    for (int n = nq; n < N; n++) order.push_back(n);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return p.depth[a] > p.depth[b]; });
+    for (int n : order) {
+      int k = n - nq;
+      int ncc = s->child_cohort_off[k + 1] - s->child_cohort_off[k], ncq = s->child_cq_off[k + 1] - s->child_cq_off[k];
+      int h = std::min(ncc + ncq, 1);
+      for (int i = s->child_cohort_off[k]; i < s->child_cohort_off[k + 1]; i++) h = std::max(h, p.node_height[s->child_cohort[i]] + 1);
+      p.node_height[n] = h;
+    }
+  }
+  // admitted rows
+  p.adm_cq.assign(p.n_adm, -1);
+  for (int c = 0; c < nq; c++) {
+    if (s->cq_adm_off[c] > s->cq_adm_off[c + 1]) { p.err = "cq_adm_off not monotone"; return KQ_EINVAL; }
+    for (int r = s->cq_adm_off[c]; r < s->cq_adm_off[c + 1]; r++) p.adm_cq[r] = c;
+  }
+  for (int r = 0; r < p.n_adm; r++) {
+    if (p.adm_cq[r] < 0) { p.err = "admitted row outside cq_adm_off"; return KQ_EINVAL; }
+    p.tree_row_off[p.tree_of[p.adm_cq[r]] + 1]++;
+  }
+  for (int t = 0; t < p.n_tree; t++) p.tree_row_off[t + 1] += p.tree_row_off[t];
+  p.tree_rows.assign(p.n_adm, 0);
+  {
+    std::vector<int32_t> fr(p.tree_row_off.begin(), p.tree_row_off.end() - 1);
+    for (int r = 0; r < p.n_adm; r++) p.tree_rows[fr[p.tree_of[p.adm_cq[r]]]++] = r;
+    for (int t = 0; t < p.n_tree; t++)
+      std::sort(p.tree_rows.begin() + p.tree_row_off[t], p.tree_rows.begin() + p.tree_row_off[t + 1], [&](int a, int b) {
+        if (s->adm_priority[a] != s->adm_priority[b]) return s->adm_priority[a] < s->adm_priority[b];
+        if (s->adm_reserve_ts[a] != s->adm_reserve_ts[b]) return s->adm_reserve_ts[a] > s->adm_reserve_ts[b];
+        if (s->adm_uid_rank[a] != s->adm_uid_rank[b]) return s->adm_uid_rank[a] < s->adm_uid_rank[b];
+        return a < b;
+      });
+  }
+  for (int t = 0; t < p.n_tree; t++) {
+    p.max_tree_nodes = std::max(p.max_tree_nodes, p.tree_node_off[t + 1] - p.tree_node_off[t]);
+    p.max_tree_cqs = std::max(p.max_tree_cqs, p.tree_cq_off[t + 1] - p.tree_cq_off[t]);
+    p.max_tree_rows = std::max(p.max_tree_rows, p.tree_row_off[t + 1] - p.tree_row_off[t]);
+  }
+  // index validation
+  for (int g = 0; g < p.n_rg; g++) {
+    for (int k = s->rg_flavor_off[g]; k < s->rg_flavor_off[g + 1]; k++) if (s->rg_flavor[k] < 0 || s->rg_flavor[k] >= p.nF) { p.err = "rg_flavor out of range"; return KQ_EINVAL; }
+    for (int k = s->rg_res_off[g]; k < s->rg_res_off[g + 1]; k++) if (s->rg_res[k] < 0 || s->rg_res[k] >= p.nR) { p.err = "rg_res out of range"; return KQ_EINVAL; }
+  }
+  for (int k = 0; k < s->adm_use_off[p.n_adm]; k++) if (s->adm_use_fr[k] < 0 || s->adm_use_fr[k] >= p.nfr) { p.err = "adm_use_fr out of range"; return KQ_EINVAL; }
+  return KQ_OK;
+}
+
+}  // namespace kq

@@ -1,0 +1,85 @@
+"""Host-side mirror of the reference's scheduler entry points over the C ABI.
+
+`Scheduler` follows pkg/scheduler/scheduler.go: `New(...)` binds configuration (scheduler.go:182,
+options :143-180), `schedule(heads, snapshot)` is one cycle (:308) whose decision part runs on the
+MI355X through kq_snapshot_put + kq_cycle_run.  There is no CPU implementation behind this class:
+if the HIP library or a device is missing it raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _ffi as F
+from .api import Decisions, Heads, Snapshot, make_config
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"kq_engine error {code} ({F.KQ_ERRORS.get(code, '?')}): {msg}")
+        self.code = code
+
+
+class Engine:
+    """Thin RAII wrapper of kq_engine*."""
+
+    def __init__(self, cfg: Optional[F.kq_config] = None):
+        self._lib = F.load_engine()
+        self.cfg = cfg if cfg is not None else make_config()
+        self._h = C.c_void_p()
+        rc = self._lib.kq_engine_create(C.byref(self.cfg), C.byref(self._h))
+        if rc != 0:
+            raise EngineError(rc, self._lib.kq_strerror(rc).decode())
+        self.snap: Optional[Snapshot] = None
+
+    def close(self):
+        if self._h:
+            self._lib.kq_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise EngineError(rc, self._lib.kq_last_error(self._h).decode())
+
+    def put(self, snap: Snapshot):
+        self._check(self._lib.kq_snapshot_put(self._h, C.byref(snap.struct())))
+        self.snap = snap
+
+    def run(self, heads: Heads, tgt_cap: Optional[int] = None, out: Optional[Decisions] = None) -> Decisions:
+        d = out if out is not None else Decisions(heads, tgt_cap=tgt_cap)
+        self._check(self._lib.kq_cycle_run(self._h, C.byref(heads.struct()), C.byref(d.struct())))
+        ms, by = C.c_double(), C.c_int64()
+        self._lib.kq_last_cycle_stats(self._h, C.byref(ms), C.byref(by))
+        d.kernel_ms, d.bytes = ms.value, by.value
+        return d
+
+    def usage_after(self) -> np.ndarray:
+        """Snapshot usage as mutated by the last cycle (test hook)."""
+        u = np.zeros(self.snap.N * self.snap.n_fr, np.int64)
+        self._lib.kq_debug_read_usage_work.argtypes = [C.c_void_p, F.i64p]
+        self._check(self._lib.kq_debug_read_usage_work(self._h, F.ptr(u)))
+        return u
+
+
+class Scheduler:
+    """scheduler.New(queues, cache, client, recorder, opts...) -> *Scheduler (scheduler.go:182)."""
+
+    def __init__(self, fair_sharing: bool = False, gates: Optional[int] = None, fs_strategies=(), device: int = 0):
+        self.cfg = make_config(fair_sharing=fair_sharing, gates=gates, fs_strategies=fs_strategies, device=device)
+        self.engine = Engine(self.cfg)
+        self.scheduling_cycle = 0
+
+    def schedule(self, heads_workloads, snapshot: Snapshot) -> Decisions:
+        """One cycle (scheduler.go:308): steps 3-5 run on the device, side effects stay with the caller."""
+        self.scheduling_cycle += 1
+        self.engine.put(snapshot)
+        heads = heads_workloads if isinstance(heads_workloads, Heads) else Heads(snapshot, heads_workloads, cycle=self.scheduling_cycle)
+        return self.engine.run(heads)

@@ -1,0 +1,57 @@
+// kq_emu.cpp — TEST-ONLY build of the engine's device logic with a 1-lane "wave" on the CPU.
+//
+// Compiles kueue_amd/csrc/kq_device.hpp + kq_host.hpp with -DKQ_HOST_EMU so that the CPU test
+// suite (-m "not gpu") can check the engine's control logic (flavor scan, victim search, entry
+// processing, host orchestration, buffer sizing) against the oracle without a GPU. It exports
+// kqe_* symbols, lives under tests/, and is never loaded by the kueue_amd package: the product
+// path has no CPU implementation and fails loudly without the HIP library.
+#define KQ_HOST_EMU 1
+#include <cstdlib>
+#include <cstring>
+
+#include "../../kueue_amd/csrc/kq_host.hpp"
+
+namespace kq {
+struct EmuBackend {
+  void* alloc(size_t n) { return calloc(n, 1); }
+  void free(void* p) { ::free(p); }
+  void h2d(void* d, const void* h, size_t n) { memcpy(d, h, n); }
+  void d2h(void* h, const void* d, size_t n) { memcpy(h, d, n); }
+  void d2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+  void memset(void* d, int v, size_t n) { ::memset(d, v, n); }
+  int sync() { return KQ_OK; }
+  const char* error() { return ""; }
+  int max_slots() { return 7; }  // small on purpose: exercises the grid-stride loop over heads
+  void timer_start() {}
+  void timer_stop() {}
+  double timer_ms() { return 0; }
+  void launch_nominate(const K& k, int slots) {
+    for (int slot = 0; slot < slots; slot++) {
+      Wave w{};
+      for (int h = slot; h < k.H.n; h += slots) nominate_head(k, w, h, slot);
+    }
+  }
+  void launch_order(const K& k, int32_t* order_idx) {
+    for (int i = 0; i < k.H.n; i++) {
+      int rank = 0;
+      for (int j = 0; j < k.H.n; j++) if (j != i && entry_before(k, j, i)) rank++;
+      order_idx[rank] = i;
+    }
+  }
+  void launch_process(const K& k, int n_tree) {
+    for (int t = 0; t < n_tree; t++) { Wave w{}; process_tree(k, w, t, t); }
+  }
+};
+}  // namespace kq
+
+typedef kq::EngineT<kq::EmuBackend> EmuEngine;
+
+extern "C" {
+int kqe_engine_create(const kq_config* cfg, void** out) { auto* e = new EmuEngine(); e->cfg = *cfg; *out = e; return KQ_OK; }
+void kqe_engine_destroy(void* e) { delete (EmuEngine*)e; }
+int kqe_snapshot_put(void* e, const kq_snapshot* s) { return ((EmuEngine*)e)->snapshot_put(s); }
+int kqe_cycle_run(void* e, const kq_heads* h, kq_decisions* out) { return ((EmuEngine*)e)->cycle_run(h, out); }
+int kqe_read_usage(void* e, int64_t* out) { return ((EmuEngine*)e)->read_usage_work(out); }
+int kqe_last_bytes(void* e, int64_t* out) { *out = ((EmuEngine*)e)->last_bytes; return KQ_OK; }
+const char* kqe_last_error(void* e) { return ((EmuEngine*)e)->last_error.c_str(); }
+}
