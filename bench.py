@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""bench.py — admission-decisions/sec of the scheduling-cycle hot path on MI355X.
+
+A "step" is ONE scheduling cycle (scheduler.go:308 steps 3-5: nominate + iterator + processEntry)
+over one batch of heads (<= 1 head per ClusterQueue, manager.go:922) of the synthetic population
+named in `config.workload`; the snapshot and every head batch are resident in HBM before the timed
+region starts (kq_heads_put), decisions are read back to the host every cycle.
+
+  python bench.py --gpus 1 --steps 100 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: the population is N independent root-cohort trees (one cfg-sized tree per rank, seed+rank);
+quota, usage bubbling and preemption candidates never leave a root tree (resource_node.go:144-165,
+preemption.go:642), so ranks share nothing on the data path ("scaling": "weak", no collective).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4c"],
+                    help="cfg3 = BASELINE.json configs[2] (100k pending, 1k CQ, 16 flavors, 3-level cohorts); "
+                         "cfg4c = configs[3] population under classical preemption")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from kueue_amd.api import Decisions, make_config
+    from kueue_amd.engine import Engine
+    from kueue_amd.population import BASE_SEED, generate
+
+    cfgn = {"cfg2": 2, "cfg3": 3, "cfg4c": 4}[args.workload]
+    pop = generate(cfgn, seed=BASE_SEED + 1000 * rank)
+    snap = pop.snapshot
+    per_cq = int((pop.cq_w_off[1:] - pop.cq_w_off[:-1]).max())
+    kcfg = make_config(fair_sharing=False, device=local_rank)
+    eng = Engine(kcfg)
+    eng.put(snap)
+    n_batches = min(per_cq, args.steps + args.warmup)
+    batches = [pop.heads_for_cycle(c, cycle=c + 1) for c in range(n_batches)]
+    lib, h = eng._lib, eng._h
+    import ctypes as C
+    for b, hb in enumerate(batches):
+        eng._check(lib.kq_heads_put(h, C.byref(hb.struct()), b))
+    outs = [Decisions(hb, tgt_cap=max(4096, snap.n_adm)) for hb in batches]
+    phase_ms = np.zeros(3, np.float64)
+    phase_by = np.zeros(2, np.int64)
+
+    def run_cycle(i):
+        b = i % n_batches
+        rc = lib.kq_cycle_run_resident(h, b, C.byref(outs[b].struct()))
+        if rc != 0:
+            eng._check(rc)
+        return batches[b].n
+
+    for i in range(args.warmup):
+        run_cycle(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    cyc_ms, dec = [], 0
+    nom_ms = ord_ms = proc_ms = 0.0
+    nom_by = proc_by = 0
+    from kueue_amd import _ffi as F
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        t1 = time.perf_counter()
+        dec += run_cycle(args.warmup + i)
+        cyc_ms.append((time.perf_counter() - t1) * 1e3)
+        lib.kq_last_cycle_phases(h, F.ptr(phase_ms), F.ptr(phase_by))
+        nom_ms += phase_ms[0]; ord_ms += phase_ms[1]; proc_ms += phase_ms[2]
+        nom_by += int(phase_by[0]); proc_by += int(phase_by[1])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed, float(dec)], dtype=torch.float64, device="cuda")
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed_all, dec_all = float(tmax[0]), float(tsum[1])
+    else:
+        elapsed_all, dec_all = elapsed, float(dec)
+
+    if rank == 0:
+        # dominant kernel of the cycle by accumulated device time
+        kernels = {"k_nominate": (nom_ms, nom_by), "k_process": (proc_ms, proc_by)}
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        dms, dby = kernels[dom]
+        achieved = (dby / args.steps) / (dms / args.steps * 1e-3) / 1e9 if dms > 0 else 0.0
+        peak = 8000.0  # GB/s, HBM3E spec (MI355X_MICROARCH.md)
+        out = {
+            "metric": "admission-decisions/sec + p99 schedule-cycle ms @ 100k pending, 1k CQ",
+            "value": dec_all / elapsed_all,
+            "unit": "decisions/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_all / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {snap.n_cq} ClusterQueues, {snap.n_cohort} cohorts, {snap.n_flavor} flavors x "
+                                   f"{snap.n_resource} resources, {snap.n_adm} admitted, {pop.n_pending} pending per GPU; "
+                                   f"one cycle = {batches[0].n} heads", "heads_per_cycle": batches[0].n,
+                       "pending_per_gpu": pop.n_pending, "sharding": "root cohort per GPU, no collective"},
+            "p50_cycle_ms": float(np.percentile(cyc_ms, 50)),
+            "p99_cycle_ms": float(np.percentile(cyc_ms, 99)),
+            "kernel_ms_per_cycle": {"k_nominate": nom_ms / args.steps, "k_order": ord_ms / args.steps, "k_process": proc_ms / args.steps},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+                         "algorithmic_bytes_per_launch": dby / args.steps, "traffic": None},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pop, kcfg, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pop, kcfg, budget_s):
+    """The oracle (single thread, like the reference's one scheduling goroutine, scheduler.go:226) on the
+    first cycles of the same population on this box's host cores. Checker code timed as a baseline only."""
+    from oracle import kqo
+    snap = pop.snapshot
+    t0 = time.perf_counter()
+    dec, cycles, cpu_t = 0, 0, 0.0
+    while time.perf_counter() - t0 < budget_s and cycles < 100:
+        hb = pop.heads_for_cycle(cycles, cycle=cycles + 1)
+        t1 = time.perf_counter()
+        kqo.cycle_run(kcfg, snap, hb)
+        dt = time.perf_counter() - t1
+        cpu_t += dt
+        dec += hb.n
+        cycles += 1
+        if cycles == 1:
+            first = dt
+    # only oracle time counts (head batch construction excluded)
+    return {"value": dec / max(cpu_t, 1e-9), "unit": "decisions/s", "cores": 1, "kind": "port",
+            "sample": f"first {cycles} cycles ({dec} decisions) of the same population, C++ restatement of the Go path, "
+                      f"host nproc={os.cpu_count()}", "first_cycle_ms": first * 1e3}
+
+
+if __name__ == "__main__":
+    main()

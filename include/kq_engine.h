@@ -258,6 +258,16 @@ int  kq_snapshot_put(kq_engine* e, const kq_snapshot* s);
  * unchanged (the reference mutates a per-cycle copy). */
 int  kq_cycle_run(kq_engine* e, const kq_heads* h, kq_decisions* out);
 
+/* Device-resident heads ("pending side on device"): upload a batch of heads once
+ * (pkg/cache/queue/manager.go:903 Heads, pre-digested workload.Info records, workload.go:245) and run
+ * cycles on it without any host->device input traffic. `batch` is a small caller-chosen id. */
+int  kq_heads_put(kq_engine* e, const kq_heads* h, int32_t batch);
+int  kq_cycle_run_resident(kq_engine* e, int32_t batch, kq_decisions* out);
+
+/* Per-kernel device time of the last cycle, HIP events on the engine's stream:
+ * phase_ms[0] nominate, [1] order, [2] process; phase_bytes[0] nominate, [1] process (algorithmic bytes). */
+int  kq_last_cycle_phases(kq_engine* e, double* phase_ms, int64_t* phase_bytes);
+
 /* Device time (ms, hipEvent) of the kernels of the last kq_cycle_run, and its algorithmic bytes. */
 int  kq_last_cycle_stats(kq_engine* e, double* kernel_ms, int64_t* algorithmic_bytes);
 

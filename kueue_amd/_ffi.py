@@ -203,6 +203,12 @@ def load_engine():
     lib.kq_snapshot_put.restype = C.c_int
     lib.kq_cycle_run.argtypes = [C.c_void_p, C.POINTER(kq_heads), C.POINTER(kq_decisions)]
     lib.kq_cycle_run.restype = C.c_int
+    lib.kq_heads_put.argtypes = [C.c_void_p, C.POINTER(kq_heads), C.c_int32]
+    lib.kq_heads_put.restype = C.c_int
+    lib.kq_cycle_run_resident.argtypes = [C.c_void_p, C.c_int32, C.POINTER(kq_decisions)]
+    lib.kq_cycle_run_resident.restype = C.c_int
+    lib.kq_last_cycle_phases.argtypes = [C.c_void_p, f64p, i64p]
+    lib.kq_last_cycle_phases.restype = C.c_int
     lib.kq_last_cycle_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.kq_last_cycle_stats.restype = C.c_int
     lib.kq_snapshot_derive.argtypes = [C.c_void_p]
@@ -223,4 +229,5 @@ def load_engine():
 ABI_SYMBOLS = [
     "kq_engine_create", "kq_engine_destroy", "kq_snapshot_put", "kq_cycle_run", "kq_last_cycle_stats",
     "kq_snapshot_derive", "kq_snapshot_read_planes", "kq_strerror", "kq_last_error", "kq_abi_version",
+    "kq_heads_put", "kq_cycle_run_resident", "kq_last_cycle_phases",
 ]

@@ -400,6 +400,62 @@ class Snapshot:
         self.derived = True
         self._struct = None
 
+    def derive(self) -> "Snapshot":
+        """SubtreeQuota of every node + Usage of every Cohort from Quotas and CQ usage.
+
+        Host mirror of what the Go cache maintains before cache.Snapshot() ever runs:
+        updateCohortResourceNode / accumulateFromChild (pkg/cache/scheduler/resource_node.go:183-230),
+        with resources.Amount semantics (amount.go:114-145). Exact python-int arithmetic.
+        """
+        N, nq, nfr = self.N, self.n_cq, self.n_fr
+        a = self.arrays
+        nominal = a["nominal"].tolist(); ll = a["lend_limit"].tolist()
+        flags = a["quota_flags"].tolist(); usage = a["usage"].tolist()
+        sq = [0] * (N * nfr)
+        parent = a["parent"].tolist()
+        U = MAXI64
+
+        def add(x, y):
+            return U if (x == U or y == U) else sat(x + y)
+
+        def sub(x, y):
+            if x == U and y == U:
+                return 0
+            if x == U:
+                return U
+            if y == U:
+                return MINI64
+            return sat(x - y)
+
+        depth = [0] * N
+        for n in range(N):
+            d, x = 0, n
+            while parent[x] >= 0:
+                x = parent[x]; d += 1
+            depth[n] = d
+        for n in range(N):
+            for fr in range(nfr):
+                k = n * nfr + fr
+                flags[k] &= ~F.KQ_QF_SUBTREE
+                if n >= nq:
+                    usage[k] = 0
+                if flags[k] & F.KQ_QF_QUOTA:
+                    sq[k] = nominal[k]; flags[k] |= F.KQ_QF_SUBTREE
+        # children before parents; children of one cohort in canonical order (cohorts then CQs)
+        order = sorted(range(N), key=lambda n: (-depth[n], 0 if n >= nq else 1, n))
+        for n in order:
+            p = parent[n]
+            if p < 0:
+                continue
+            for fr in range(nfr):
+                k, kp = n * nfr + fr, p * nfr + fr
+                lq = max(0, sub(sq[k], ll[k])) if ll[k] != F.KQ_NIL_LIMIT else 0
+                if flags[k] & F.KQ_QF_SUBTREE:
+                    sq[kp] = add(sq[kp], sub(sq[k], lq)); flags[kp] |= F.KQ_QF_SUBTREE
+                usage[kp] = add(usage[kp], max(0, sub(usage[k], lq)))
+        self.set_derived(np.array(sq, dtype=np.int64), np.array(usage, dtype=np.int64), np.array(flags, dtype=np.uint8))
+        return self
+
     def struct(self) -> F.kq_snapshot:
         if self._struct is None:
             s = F.kq_snapshot()

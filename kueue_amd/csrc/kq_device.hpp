@@ -40,6 +40,7 @@ KQ_DEV int ffs64(uint64_t m) { return __builtin_ctzll(m); }
 KQ_DEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
 KQ_DEV int atomic_add_i32(int* p, int v) { int o = *p; *p += v; return o; }
 KQ_DEV void atomic_add_i64(long long* p, long long v) { *p += v; }
+KQ_DEV int64_t wsum_i64(int64_t v) { return v; }
 }  // namespace kq
 #else
 #include <hip/hip_runtime.h>
@@ -57,6 +58,10 @@ KQ_DEV int ffs64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }
 KQ_DEV int popc64(uint64_t m) { return __popcll((unsigned long long)m); }
 KQ_DEV int atomic_add_i32(int* p, int v) { return atomicAdd(p, v); }
 KQ_DEV void atomic_add_i64(long long* p, long long v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
+KQ_DEV int64_t wsum_i64(int64_t v) {
+  for (int o = 32; o > 0; o >>= 1) v += (int64_t)__shfl_xor((long long)v, o, 64);
+  return v;
+}
 }  // namespace kq
 #endif
 
@@ -431,7 +436,7 @@ KQ_DEV bool uses_need(const K& k, const Wave& w, int row) {
   return false;
 }
 // hierarchical_preemption.go:81-113 ; returns (variant) and list id (0 hierarchy, 1 priority, 2 same queue)
-KQ_DEV int classify_row(const Search& s, int row, int* list) {
+KQ_DEV int classify_row(const Search& s, int row, int* list, int* bytes) {
   const K& k = *s.k; const Wave& w = *s.w; const DSnap& S = k.S;
   if (row_removed(s, row)) return V_NEVER;
   int c = S.adm_cq[row];
@@ -444,6 +449,7 @@ KQ_DEV int classify_row(const Search& s, int row, int* list) {
     if (info == 0) return V_NEVER;
     level = info - 1;
   }
+  *bytes += 32 + 12 * (S.adm_use_off[row + 1] - S.adm_use_off[row]);  // candidate record + its usage entries
   if (!uses_need(k, w, row)) return V_NEVER;
   int policy = same ? KQ_POL_WITHIN_CQ(w.pol) : KQ_POL_RECLAIM(w.pol);
   if (!satisfies_policy(k, w, row, policy)) return V_NEVER;
@@ -493,7 +499,7 @@ KQ_DEV bool w_fits(const Search& s, bool allow_borrowing) {
     if (!allow_borrowing && borrowing_with(S, w.cq, true, fr, v, uw)) bad = true;
     else if (v > i64max(0, available_of(S, w.path, w.plen, fr, uw))) bad = true;
   }
-  if (lane_id() == 0) w.bytes += 40 * (int64_t)w.plen * w.ns;
+  if (lane_id() == 0) { int nu = 0; for (int u = 0; u < w.ns; u++) nu += w.s_inu[u] ? 1 : 0; w.bytes += 40 * (int64_t)w.plen * nu; }
   return wballot(bad) == 0;
 }
 // candidate_generator.go:136-158
@@ -580,12 +586,13 @@ KQ_DEV void classical_search(Search& s) {
   wsync();
   // classify every admitted row of the tree once; class byte = 1 + list + 3*evicted + 8*variant
   int cnt[6] = {0, 0, 0, 0, 0, 0};
+  int cbytes = 0;
   for (int base = 0; base < s.nrows; base += WAVE) {
     int i = base + lane;
     uint8_t cb = 0;
     if (i < s.nrows) {
       int row = S.tree_rows[s.row0 + i], list = 0;
-      int v = classify_row(s, row, &list);
+      int v = classify_row(s, row, &list, &cbytes);
       if (v != V_NEVER) {
         int ev = (S.adm_flags[row] & KQ_ADM_EVICTED) ? 0 : 1;  // evicted first
         cb = (uint8_t)(1 + (ev * 3 + list) + 8 * v);
@@ -594,7 +601,10 @@ KQ_DEV void classical_search(Search& s) {
     }
     for (int p = 0; p < 6; p++) cnt[p] += popc64(wballot(cb != 0 && ((cb - 1) & 7) == p));
   }
-  if (lane == 0) w.bytes += (int64_t)s.nrows * 44;
+  {
+    int64_t tot = wsum_i64((int64_t)cbytes);
+    if (lane == 0) w.bytes += tot;
+  }
   wsync();
   bool no_hier = cnt[0] + cnt[3] == 0, no_other = no_hier && (cnt[1] + cnt[4] == 0);
   if (cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4] + cnt[5] == 0) return;
@@ -645,6 +655,13 @@ KQ_DEV void classical_search(Search& s) {
               }
             }
             w.ntgt = nt;
+            // the reference now re-adds the targets (restoreSnapshot :356); the private copy is simply
+            // dropped here, but those writes are part of the algorithm's traffic
+            if (lane == 0)
+              for (int t = 0; t < nt; t++) {
+                int r = s.trow[t];
+                w.bytes += 16 * (int64_t)S.plen[S.adm_cq[r]] * (S.adm_use_off[r + 1] - S.adm_use_off[r]);
+              }
             return;
           }
         }
@@ -741,7 +758,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
       }
       w.nreq = n;
       for (int a = 0; a < n; a++) w.req_done[a] = 0;
-      w.bytes += (int64_t)n * 8;
+      w.bytes += (int64_t)n * 16;  // requests in + requests echoed in the PodSetAssignment
     }
     wsync();
     // nomination mapping snapshot for this podset (flavor per resource before we overwrite O.flavor)
@@ -806,7 +823,6 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
           }
           w.cell_pm[c] = pm; w.cell_borrow[c] = borrow; w.cell_val[c] = val;
         }
-        if (lane == 0) w.bytes += (int64_t)nfl * nf * 40 * plen;
         wsync();
         // ---- ordered scan of the pass (uniform) ------------------------------------------
         for (int jj = 0; jj < nfl && !stop; jj++) {
@@ -814,6 +830,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
           attempted = j;
           if (w.cell_pm[jj * nf] == PM_SKIP) { reasons++; continue; }
           const int f = S.rg_flavor[f0 + j];
+          if (lane == 0) w.bytes += (int64_t)nf * 40 * plen;  // nf fitsResourceQuota calls, (D+1) x 5 planes x 8 B each
           int rep_pm = PM_FIT; int64_t rep_borrow = 0; int64_t rep_key = pref_key(PM_FIT, 0, w.pol);
           for (int kk = 0; kk < nf; kk++) {
             int c = jj * nf + kk;
@@ -891,7 +908,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
           w.use_qty[e] = a_addi(w.use_qty[e], w.req_qty[a]);
           if (w.req_mode[a] < w.use_mode[e]) w.use_mode[e] = w.req_mode[a];
         }
-        w.bytes += (int64_t)w.nreq * 24;
+        for (int a = 0; a < w.nreq; a++) if (w.req_done[a]) w.bytes += 16;  // (flavor, mode, borrow, tried) out
       }
       wsync();
     }
@@ -1017,13 +1034,19 @@ KQ_DEV Search get_assignments(const K& k, Wave& w, int slot, const int64_t* usag
     int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
     if (!probe(mid)) lo = mid + 1; else { hi = mid; good = mid; }
   }
+  // Re-running an assignment to regenerate its outputs is an artefact of keeping one output slot per
+  // head; the reference keeps the value. It is not algorithmic traffic: restore the byte counter.
+  const int64_t bytes_before = w.bytes;
   if (good >= 0 && lo == good) {
     if (last_probe != good) probe(good);  // regenerate the outputs of the accepted probe
-    return s;
+  } else {
+    // no reduced count works: the full assignment, no targets (scheduler.go:923)
+    assign_flavors(k, w, slot, usage, removed, nullptr, nominate_map);
+    w.ntgt = 0;
   }
-  // no reduced count works: the full assignment, no targets (scheduler.go:923)
-  assign_flavors(k, w, slot, usage, removed, nullptr, nominate_map);
-  w.ntgt = 0;
+  wsync();
+  if (lane_id() == 0) w.bytes = bytes_before;
+  wsync();
   return s;
 }
 

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) void k_process(K k) {
 namespace kq {
 struct HipBackend {
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int device = 0;
   int n_cu = 256;
   hipError_t err = hipSuccess;
@@ -63,17 +63,15 @@ struct HipBackend {
     chk(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties");
     if (err == hipSuccess) n_cu = prop.multiProcessorCount;
     chk(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
-    chk(hipEventCreate(&ev0), "hipEventCreate");
-    chk(hipEventCreate(&ev1), "hipEventCreate");
+    for (auto& e2 : ev) chk(hipEventCreate(&e2), "hipEventCreate");
     return err == hipSuccess ? KQ_OK : KQ_EDEVICE;
   }
   void destroy() {
-    if (ev0) hipEventDestroy(ev0);
-    if (ev1) hipEventDestroy(ev1);
-    if (stream) hipStreamDestroy(stream);
+    for (auto& e2 : ev) if (e2) (void)hipEventDestroy(e2);
+    if (stream) (void)hipStreamDestroy(stream);
   }
   void* alloc(size_t n) { void* p = nullptr; chk(hipMalloc(&p, n), "hipMalloc"); return p; }
-  void free(void* p) { hipFree(p); }
+  void free(void* p) { (void)hipFree(p); }
   void h2d(void* d, const void* h, size_t n) { chk(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, stream), "h2d"); }
   void d2h(void* h, const void* d, size_t n) { chk(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream), "d2h"); }
   void d2d(void* d, const void* s, size_t n) { chk(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, stream), "d2d"); }
@@ -85,9 +83,9 @@ struct HipBackend {
   }
   const char* error() { return msg.c_str(); }
   int max_slots() { return n_cu * 16; }  // 16 one-wave workgroups per CU (4 per SIMD)
-  void timer_start() { chk(hipEventRecord(ev0, stream), "hipEventRecord"); }
-  void timer_stop() { chk(hipEventRecord(ev1, stream), "hipEventRecord"); }
-  double timer_ms() { float ms = 0; chk(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime"); return ms; }
+  // HIP events on the engine's own stream bracket each kernel (live per-kernel duration)
+  void timer_mark(int i) { chk(hipEventRecord(ev[i], stream), "hipEventRecord"); }
+  double timer_ms(int a, int b) { float ms = 0; chk(hipEventElapsedTime(&ms, ev[a], ev[b]), "hipEventElapsedTime"); return ms; }
   void launch_nominate(const K& k, int slots) {
     hipLaunchKernelGGL(k_nominate, dim3(slots), dim3(64), 0, stream, k, slots);
     chk(hipGetLastError(), "k_nominate");
@@ -138,7 +136,7 @@ int kq_engine_create(const kq_config* cfg, kq_engine** out) {
 
 void kq_engine_destroy(kq_engine* en) {
   if (!en) return;
-  hipSetDevice(en->e.be.device);
+  (void)hipSetDevice(en->e.be.device);
   en->e.free_snapshot();
   HipBackend be = en->e.be;
   delete en;
@@ -147,14 +145,33 @@ void kq_engine_destroy(kq_engine* en) {
 
 int kq_snapshot_put(kq_engine* en, const kq_snapshot* s) {
   if (!en || !s) return KQ_EINVAL;
-  hipSetDevice(en->e.be.device);
+  (void)hipSetDevice(en->e.be.device);
   return en->e.snapshot_put(s);
 }
 
 int kq_cycle_run(kq_engine* en, const kq_heads* h, kq_decisions* out) {
   if (!en || !h || !out) return KQ_EINVAL;
-  hipSetDevice(en->e.be.device);
+  (void)hipSetDevice(en->e.be.device);
   return en->e.cycle_run(h, out);
+}
+
+int kq_heads_put(kq_engine* en, const kq_heads* h, int32_t batch) {
+  if (!en || !h || batch < 0) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.heads_put(h, batch + 1);
+}
+
+int kq_cycle_run_resident(kq_engine* en, int32_t batch, kq_decisions* out) {
+  if (!en || !out || batch < 0) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.cycle_exec(batch + 1, out);
+}
+
+int kq_last_cycle_phases(kq_engine* en, double* phase_ms, int64_t* phase_bytes) {
+  if (!en) return KQ_EINVAL;
+  if (phase_ms) for (int p = 0; p < 3; p++) phase_ms[p] = en->e.last_phase_ms[p];
+  if (phase_bytes) { phase_bytes[0] = en->e.last_phase_bytes[0]; phase_bytes[1] = en->e.last_phase_bytes[1]; }
+  return KQ_OK;
 }
 
 int kq_last_cycle_stats(kq_engine* en, double* kernel_ms, int64_t* algorithmic_bytes) {
@@ -172,7 +189,7 @@ int kq_snapshot_derive(kq_engine* en) {
 
 int kq_snapshot_read_planes(kq_engine* en, int64_t* subtree_quota, int64_t* usage, uint8_t* quota_flags) {
   if (!en || !en->e.have_snapshot) return KQ_EINVAL;
-  hipSetDevice(en->e.be.device);
+  (void)hipSetDevice(en->e.be.device);
   size_t n = (size_t)en->e.prep.N * en->e.prep.nfr;
   if (subtree_quota) en->e.be.d2h(subtree_quota, en->e.d_sq, n * 8);
   if (usage) en->e.be.d2h(usage, en->e.d_usage, n * 8);
@@ -185,7 +202,7 @@ const char* kq_last_error(kq_engine* en) { return en ? en->e.last_error.c_str() 
 // test hook (not part of the drop-in boundary): snapshot usage as left by the last cycle
 int kq_debug_read_usage_work(kq_engine* en, int64_t* out) {
   if (!en) return KQ_EINVAL;
-  hipSetDevice(en->e.be.device);
+  (void)hipSetDevice(en->e.be.device);
   return en->e.read_usage_work(out);
 }
 

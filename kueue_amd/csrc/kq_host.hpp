@@ -32,10 +32,13 @@ template <class B> struct EngineT {
   struct Buf { void* p = nullptr; size_t cap = 0; };
   std::vector<Buf*> all_bufs;
   Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc;
-  Buf hb[24];  // head arrays
+  struct HeadBatch { Buf hb[16]; DHeads H{}; int n = 0; size_t nps = 0; int slot_cap = 1; int64_t cycle = 0; bool valid = false; };
+  std::vector<HeadBatch> batches;  // [0] = transient batch of kq_cycle_run, [1+b] = resident batch b
   Buf ob[24];  // output arrays
   double last_kernel_ms = 0;
+  double last_phase_ms[3] = {0, 0, 0};
   int64_t last_bytes = 0;
+  int64_t last_phase_bytes[2] = {0, 0};
 
   int fail(int code, const std::string& msg) { last_error = msg; return code; }
 
@@ -63,7 +66,7 @@ template <class B> struct EngineT {
   ~EngineT() {
     free_snapshot();
     for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc}) if (b->p) be.free(b->p);
-    for (auto& b : hb) if (b.p) be.free(b.p);
+    for (auto& hbch : batches) for (auto& b : hbch.hb) if (b.p) be.free(b.p);
     for (auto& b : ob) if (b.p) be.free(b.p);
   }
 
@@ -142,50 +145,78 @@ template <class B> struct EngineT {
     return KQ_OK;
   }
 
-  template <class T> const T* up_head(int i, const T* host, size_t n) {
-    T* d = grow<T>(hb[i], n);
+  template <class T> const T* up_head(HeadBatch& hbch, int i, const T* host, size_t n) {
+    T* d = grow<T>(hbch.hb[i], n);
     if (n) be.h2d(d, host, n * sizeof(T));
     return d;
   }
 
-  int cycle_run(const kq_heads* h, kq_decisions* out) {
-    if (!have_snapshot) return fail(KQ_EINVAL, "kq_cycle_run before kq_snapshot_put");
-    if (cfg.fair_sharing) return fail(KQ_EUNSUPPORTED, "fair sharing is not implemented on the device path yet");
+  // Make one batch of heads resident in HBM. slot 0 is the transient batch of kq_cycle_run.
+  int heads_put(const kq_heads* h, int slot) {
+    if (!have_snapshot) return fail(KQ_EINVAL, "heads before kq_snapshot_put");
+    if (slot < 0 || slot > 4096) return fail(KQ_EINVAL, "bad batch id");
     int slot_cap = 1;
     int rc = validate_heads(h, &slot_cap);
     if (rc != KQ_OK) return rc;
+    if ((int)batches.size() <= slot) batches.resize(slot + 1);
+    HeadBatch& hbch = batches[slot];
     const int n = h->n;
+    hbch.n = n; hbch.slot_cap = slot_cap; hbch.cycle = h->cycle; hbch.valid = true;
+    hbch.nps = n ? h->ps_off[n] : 0;
+    if (n == 0) return KQ_OK;
+    const size_t nps = hbch.nps, nreqs = h->ps_req_off[nps], nR = prep.nR, nfw = (prep.nF + 63) / 64;
+    std::vector<int64_t> zeros64(n, 0);
+    std::vector<uint64_t> zerosu64(n, 0);
+    std::vector<int32_t> minus1(nps * nR, -1), minus1ps(nps, -1);
+    DHeads& H = hbch.H;
+    H.n = n;
+    H.cq = up_head(hbch, 0, h->cq, n);
+    H.priority = up_head(hbch, 1, h->priority, n);
+    H.queue_ts = up_head(hbch, 2, h->queue_ts, n);
+    H.flags = up_head(hbch, 3, h->flags, n);
+    H.ps_off = up_head(hbch, 4, h->ps_off, n + 1);
+    H.ps_count = up_head(hbch, 5, h->ps_count, nps);
+    H.ps_min_count = up_head(hbch, 6, h->ps_min_count ? h->ps_min_count : minus1ps.data(), nps);
+    H.ps_req_off = up_head(hbch, 7, h->ps_req_off, nps + 1);
+    H.req_res = up_head(hbch, 8, h->req_res, nreqs);
+    H.req_qty = up_head(hbch, 9, h->req_qty, nreqs);
+    H.ps_flavor_ok = up_head(hbch, 10, h->ps_flavor_ok, nps * nfw);
+    H.ps_last_tried = up_head(hbch, 11, h->ps_last_tried ? h->ps_last_tried : minus1.data(), nps * nR);
+    H.last_generation = up_head(hbch, 12, h->last_generation ? h->last_generation : zeros64.data(), n);
+    H.last_cycle = up_head(hbch, 13, h->last_cycle ? h->last_cycle : zeros64.data(), n);
+    H.last_hash = up_head(hbch, 14, h->last_hash ? h->last_hash : zerosu64.data(), n);
+    H.hash = up_head(hbch, 15, h->hash ? h->hash : zerosu64.data(), n);
+    rc = be.sync();  // host staging vectors go out of scope
+    if (rc != KQ_OK) return fail(rc, be.error());
+    return KQ_OK;
+  }
+
+  int cycle_run(const kq_heads* h, kq_decisions* out) {
+    int rc = heads_put(h, 0);
+    if (rc != KQ_OK) return rc;
+    return cycle_exec(0, out);
+  }
+
+  int cycle_exec(int slot, kq_decisions* out) {
+    if (!have_snapshot) return fail(KQ_EINVAL, "kq_cycle_run before kq_snapshot_put");
+    if (cfg.fair_sharing) return fail(KQ_EUNSUPPORTED, "fair sharing is not implemented on the device path yet");
+    if (slot < 0 || slot >= (int)batches.size() || !batches[slot].valid) return fail(KQ_EINVAL, "unknown head batch");
+    HeadBatch& hbch = batches[slot];
+    const int n = hbch.n;
+    const int slot_cap = hbch.slot_cap;
+    int rc = KQ_OK;
     if (out->tgt_off) out->tgt_off[0] = 0;
     if (n == 0) {
       last_kernel_ms = 0; last_bytes = 0;
       be.d2d(grow<int64_t>(b_usage_work, (size_t)prep.N * prep.nfr), d_usage, (size_t)prep.N * prep.nfr * sizeof(int64_t));
       return be.sync();
     }
-    const size_t nps = h->ps_off[n], nreqs = h->ps_req_off[nps], nR = prep.nR, nfw = (prep.nF + 63) / 64;
+    const size_t nps = hbch.nps, nR = prep.nR;
     const size_t Nfr = (size_t)prep.N * prep.nfr;
     K k{};
     k.S = S;
-    k.C.gates = cfg.gates; k.C.fair_sharing = cfg.fair_sharing; k.C.quota_check_strategy = cfg.quota_check_strategy; k.C.cycle = h->cycle;
-    std::vector<int64_t> zeros64(n, 0);
-    std::vector<uint64_t> zerosu64(n, 0);
-    std::vector<int32_t> minus1(nps * nR, -1), minus1ps(nps, -1);
-    k.H.n = n;
-    k.H.cq = up_head(0, h->cq, n);
-    k.H.priority = up_head(1, h->priority, n);
-    k.H.queue_ts = up_head(2, h->queue_ts, n);
-    k.H.flags = up_head(3, h->flags, n);
-    k.H.ps_off = up_head(4, h->ps_off, n + 1);
-    k.H.ps_count = up_head(5, h->ps_count, nps);
-    k.H.ps_min_count = up_head(6, h->ps_min_count ? h->ps_min_count : minus1ps.data(), nps);
-    k.H.ps_req_off = up_head(7, h->ps_req_off, nps + 1);
-    k.H.req_res = up_head(8, h->req_res, nreqs);
-    k.H.req_qty = up_head(9, h->req_qty, nreqs);
-    k.H.ps_flavor_ok = up_head(10, h->ps_flavor_ok, nps * nfw);
-    k.H.ps_last_tried = up_head(11, h->ps_last_tried ? h->ps_last_tried : minus1.data(), nps * nR);
-    k.H.last_generation = up_head(12, h->last_generation ? h->last_generation : zeros64.data(), n);
-    k.H.last_cycle = up_head(13, h->last_cycle ? h->last_cycle : zeros64.data(), n);
-    k.H.last_hash = up_head(14, h->last_hash ? h->last_hash : zerosu64.data(), n);
-    k.H.hash = up_head(15, h->hash ? h->hash : zerosu64.data(), n);
+    k.C.gates = cfg.gates; k.C.fair_sharing = cfg.fair_sharing; k.C.quota_check_strategy = cfg.quota_check_strategy; k.C.cycle = hbch.cycle;
+    k.H = hbch.H;
     // outputs
     const int pool_cap = std::max(out->tgt_cap, 1);
     DOut& O = k.O;
@@ -201,7 +232,7 @@ template <class B> struct EngineT {
     O.pool_row = grow<int32_t>(ob[17], O.pool_cap); O.pool_reason = grow<uint8_t>(ob[18], O.pool_cap);
     int64_t* misc = grow<int64_t>(b_misc, 4);
     be.memset(misc, 0, 4 * sizeof(int64_t));
-    O.pool_count = (int32_t*)misc; O.error = (int32_t*)misc + 1; O.stat_bytes = (long long*)(misc + 1);
+    O.pool_count = (int32_t*)misc; O.error = (int32_t*)misc + 1; O.stat_bytes = (long long*)(misc + 1);  // [1]=nominate bytes, [2]=process bytes
     // nominated flavors start empty (a head's rows are rewritten by assign_flavors)
     be.memset(O.flavor, 0xff, nps * nR * sizeof(int32_t));
     // scratch: one slot per resident wave
@@ -225,11 +256,14 @@ template <class B> struct EngineT {
     be.d2d(k.usage_np, d_usage, Nfr * sizeof(int64_t));
     be.memset(k.preempted, 0, std::max(prep.n_adm, 1));
 
-    be.timer_start();
+    be.timer_mark(0);
     be.launch_nominate(k, slots_nom);
+    be.timer_mark(1);
     be.launch_order(k, order_idx);
+    be.timer_mark(2);
+    k.O.stat_bytes = (long long*)(misc + 2);
     be.launch_process(k, prep.n_tree);
-    be.timer_stop();
+    be.timer_mark(3);
 
     // decisions back
     if (out->status) be.d2h(out->status, O.status, n);
@@ -252,8 +286,10 @@ template <class B> struct EngineT {
     rc = be.sync();
     if (rc != KQ_OK) return fail(rc, be.error());
     int32_t pool_used = ((int32_t*)miscs)[0], dev_err = ((int32_t*)miscs)[1];
-    last_bytes = miscs[1];
-    last_kernel_ms = be.timer_ms();
+    last_phase_bytes[0] = miscs[1]; last_phase_bytes[1] = miscs[2];
+    last_bytes = miscs[1] + miscs[2];
+    for (int p = 0; p < 3; p++) last_phase_ms[p] = be.timer_ms(p, p + 1);
+    last_kernel_ms = be.timer_ms(0, 3);
     if (dev_err != 0) return fail(dev_err, "device-side error (capacity or unsupported input)");
     // targets CSR: canonical order inside an entry = ascending admitted row
     std::vector<int32_t> prow(std::max(pool_used, 1));

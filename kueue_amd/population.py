@@ -1,0 +1,236 @@
+"""Seeded synthetic populations for the BASELINE.json configurations.
+
+Shapes follow the reference's scalability harness (test/performance/scheduler/configs/*/generator.yaml:
+small/medium/large workload classes, cohorts x ClusterQueues) scaled to the north-star sizes.
+Everything is emitted directly in the flat boundary schema (api.Snapshot / api.Heads).
+
+  cfg 1  100 wl,   4 CQ,    2 flavors, no cohort, StrictFIFO                       (CPU plumbing)
+  cfg 2  10k wl,   128 CQ,  8 flavors, flat cohort, BestEffortFIFO, no preemption
+  cfg 3  100k wl,  1000 CQ, 16 flavors, 3-level cohorts, borrowing + lending limits
+  cfg 4  cfg 3 + preemption policies (+ fair sharing weights; run with fair_sharing=True once the
+         device path implements it; "cfg3p" = cfg 4's policies under classical preemption)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List
+
+import numpy as np
+
+from .api import (ClusterQueue, Cohort, FlavorQuotas, Heads, PodSet, ResourceGroup, ResourceQuota, Snapshot, Workload)
+
+GI = 1 << 30
+MAXI64 = (1 << 63) - 1
+BASE_SEED = 20260921
+
+
+@dataclass
+class Population:
+    name: str
+    snapshot: Snapshot
+    # pending side: per-CQ FIFO of pre-digested workloads, SoA over all W workloads
+    w_cq: np.ndarray        # [W] CQ index, sorted by CQ then queue order
+    w_prio: np.ndarray
+    w_ts: np.ndarray
+    w_nps: np.ndarray       # podsets per workload
+    ps_count: np.ndarray    # [n_ps]
+    ps_req: np.ndarray      # [n_ps, 3] cpu milli, memory bytes, gpu  (totals for the podset)
+    cq_w_off: np.ndarray    # [n_cq+1]
+    fair_sharing: bool = False
+
+    @property
+    def n_pending(self) -> int:
+        return int(len(self.w_cq))
+
+    def heads_for_cycle(self, c: int, cycle: int = 1) -> Heads:
+        """Heads of cycle c = the c-th workload of every ClusterQueue queue (<= 1 head per CQ,
+        pkg/cache/queue/manager.go:922), CQ-name order."""
+        snap = self.snapshot
+        idx = self.cq_w_off[:-1] + c
+        idx = idx[idx < self.cq_w_off[1:]]
+        return self._heads(idx, cycle)
+
+    def all_heads(self, cycle: int = 1) -> Heads:
+        """Every pending workload as one batch ("nominate-all-pending")."""
+        return self._heads(np.arange(self.n_pending), cycle)
+
+    def _heads(self, idx: np.ndarray, cycle: int) -> Heads:
+        snap = self.snapshot
+        nR, nF = snap.n_resource, snap.n_flavor
+        ps_first = np.concatenate([[0], np.cumsum(self.w_nps)])[:-1]
+        nps = self.w_nps[idx]
+        ps_off = np.concatenate([[0], np.cumsum(nps)]).astype(np.int32)
+        ps_idx = np.concatenate([np.arange(ps_first[i], ps_first[i] + self.w_nps[i]) for i in idx]) if len(idx) else np.zeros(0, np.int64)
+        res_ids = [snap.resource_index[r] for r in ("cpu", "memory", "example.com/gpu") if r in snap.resource_index]
+        nreq = len(res_ids)
+        n_ps = len(ps_idx)
+        a: Dict[str, np.ndarray] = dict(
+            cq=self.w_cq[idx].astype(np.int32), priority=self.w_prio[idx].astype(np.int64), queue_ts=self.w_ts[idx].astype(np.int64),
+            flags=np.zeros(len(idx), np.uint32), ps_off=ps_off,
+            ps_count=self.ps_count[ps_idx].astype(np.int32), ps_min_count=np.full(n_ps, -1, np.int32),
+            ps_req_off=(np.arange(n_ps + 1) * nreq).astype(np.int32),
+            req_res=np.tile(np.array(res_ids, np.int32), n_ps),
+            req_qty=self.ps_req[ps_idx][:, :nreq].reshape(-1).astype(np.int64),
+            ps_flavor_ok=np.full(n_ps * ((nF + 63) // 64), (1 << 64) - 1, np.uint64),
+            ps_last_tried=np.full(n_ps * nR, -1, np.int32),
+            last_generation=np.zeros(len(idx), np.int64), last_cycle=np.zeros(len(idx), np.int64),
+            last_hash=np.zeros(len(idx), np.uint64), hash=np.zeros(len(idx), np.uint64),
+        )
+        return Heads.from_arrays(snap, a, cycle=cycle)
+
+
+def _quota(rng, unit, lo, hi, limits: bool, unlimited_p: float):
+    nominal = int(rng.integers(lo, hi + 1)) * unit
+    if unlimited_p and rng.random() < unlimited_p:
+        nominal = MAXI64
+    bl = ll = None
+    if nominal == MAXI64:
+        # an Unlimited cell keeps a finite lending limit, otherwise one cell makes the whole tree unconstrained
+        ll = int(rng.integers(0, hi + 1)) * unit
+    if limits and nominal != MAXI64:
+        if rng.random() < 0.5:
+            bl = int(rng.integers(0, nominal // unit + 1)) * unit
+        if rng.random() < 0.5:
+            ll = int(rng.integers(0, nominal // unit + 1)) * unit
+    return ResourceQuota(nominal, bl, ll)
+
+
+def generate(cfg: int, seed: int = BASE_SEED, n_cq: int = None, per_cq: int = None, preemption: bool = None,
+             fair_sharing: bool = False) -> Population:
+    """Build population `cfg` (1..4). n_cq / per_cq override the sizes for parity-sized variants."""
+    rng = np.random.default_rng(seed + cfg)
+    if cfg == 1:
+        nq, F, res, per, shape, strategy = 4, 2, ["cpu"], 25, "none", "StrictFIFO"
+    elif cfg == 2:
+        nq, F, res, per, shape, strategy = 128, 8, ["cpu", "memory"], 78, "flat", "BestEffortFIFO"
+    elif cfg in (3, 4):
+        nq, F, res, per, shape, strategy = 1000, 16, ["cpu", "memory", "example.com/gpu", "pods"], 100, "deep", "BestEffortFIFO"
+    else:
+        raise ValueError(cfg)
+    if n_cq is not None:
+        nq = n_cq
+    if per_cq is not None:
+        per = per_cq
+    if preemption is None:
+        preemption = cfg == 4
+    flavors = [f"flavor-{i:02d}" for i in range(F)]
+    units = {"cpu": 1000, "memory": GI, "example.com/gpu": 1, "pods": 1}
+    ranges = {"cpu": (8, 64), "memory": (32, 256), "example.com/gpu": (0, 8), "pods": (50, 500)}
+    cohorts: List[Cohort] = []
+    cq_parent: List[str] = []
+    if shape == "flat":
+        cohorts = [Cohort("cohort")]
+        cq_parent = ["cohort"] * nq
+    elif shape == "deep":
+        n_leaf = max(1, nq // 10)
+        n_mid = max(1, n_leaf // 10)
+        cohorts.append(Cohort("root"))
+        for m in range(n_mid):
+            cohorts.append(Cohort(f"mid-{m:03d}", "root"))
+        for l in range(n_leaf):
+            cohorts.append(Cohort(f"leaf-{l:04d}", f"mid-{(l * n_mid) // n_leaf:03d}"))
+        cq_parent = [f"leaf-{(i * n_leaf) // nq:04d}" for i in range(nq)]
+    cqs: List[ClusterQueue] = []
+    for i in range(nq):
+        fqs = []
+        for f in flavors:
+            fq = FlavorQuotas(f)
+            for r in res:
+                lo, hi = ranges[r]
+                if cfg == 2:
+                    q = _quota(rng, units[r], lo, hi, False, 0.0)
+                    if i % 2 == 0:
+                        q.borrowing_limit = 2 * q.nominal
+                else:
+                    q = _quota(rng, units[r], lo, hi, cfg >= 3, 0.01 if cfg >= 3 else 0.0)
+                fq.resources[r] = q
+            fqs.append(fq)
+        cq = ClusterQueue(f"cq-{i:05d}", cohort=cq_parent[i] if cq_parent else None, resource_groups=[ResourceGroup(fqs)],
+                          queueing_strategy=strategy)
+        if cfg >= 3:
+            cq.when_can_borrow = "TryNextFlavor" if rng.random() < 0.5 else "MayStopSearch"
+        if preemption:
+            cq.within_cluster_queue = "LowerPriority"
+            cq.reclaim_within_cohort = "Any"
+            if rng.random() < 0.5:
+                cq.borrow_within_cohort = "LowerPriority"
+                cq.max_priority_threshold = 1
+            cq.fair_weight = float(rng.choice([0.0, 0.5, 1.0, 2.0], p=[0.02, 0.28, 0.4, 0.3]))
+        cqs.append(cq)
+    if shape == "deep":
+        # mid cohorts own extra nominal (10% of their children's sum) on flavors 0-3
+        by_mid: Dict[str, List[ClusterQueue]] = {}
+        leaf_parent = {c.name: c.parent for c in cohorts if c.name.startswith("leaf-")}
+        for cq in cqs:
+            by_mid.setdefault(leaf_parent[cq.cohort], []).append(cq)
+        for c in cohorts:
+            if c.name.startswith("mid-") and c.name in by_mid:
+                fqs = []
+                for f in flavors[:4]:
+                    fq = FlavorQuotas(f)
+                    for r in res:
+                        tot = sum(q.resource_groups[0].flavors[flavors.index(f)].resources[r].nominal for q in by_mid[c.name]
+                                  if q.resource_groups[0].flavors[flavors.index(f)].resources[r].nominal != MAXI64)
+                        fq.resources[r] = ResourceQuota((tot // 10 // units[r]) * units[r])
+                    fqs.append(fq)
+                c.resource_groups = [ResourceGroup(fqs)]
+    # admitted set: every flavor of every CQ is filled to fill_f x nominal by k workloads, so that the
+    # pending heads meet real contention (fit / borrow / nofit / preempt mixes) instead of empty flavors.
+    #   cfg 2: 4 workloads on flavor 0 at 50 %          cfg 3: A = 20/CQ, fill_f ~ U(0.6, 1.1)
+    #   cfg 4: A = 40/CQ, fill_f ~ U(0.9, 1.5) (aggregate ~120 % => borrowing CQs and victims)
+    admitted: List[Workload] = []
+    t = 0
+    for i, cq in enumerate(cqs):
+        for fi, f in enumerate(flavors):
+            if cfg == 1:
+                k, lo_f, hi_f = 0, 0.0, 0.0
+            elif cfg == 2:
+                k, lo_f, hi_f = (4 if fi == 0 else 0), 0.5, 0.5
+            elif cfg == 3:
+                k, lo_f, hi_f = (2 if fi < 4 else 1), 0.9, 1.25
+            else:
+                k, lo_f, hi_f = (3 if fi < 8 else 2), 1.0, 1.5
+            if k == 0:
+                continue
+            fq = cq.resource_groups[0].flavors[fi]
+            fill_f = rng.uniform(lo_f, hi_f)
+            for j in range(k):
+                ps = PodSet("main", count=int(rng.integers(1, 5)))
+                for r in res:
+                    nom = fq.resources[r].nominal
+                    if nom == MAXI64:
+                        nom = ranges[r][1] * units[r]
+                    ps.requests[r] = ps.count if r == "pods" else int(nom * fill_f / k / units[r]) * units[r]
+                    ps.flavors[r] = f
+                t += 1
+                admitted.append(Workload(f"{cq.name}-adm-{fi:02d}-{j}", cq.name, priority=int(rng.integers(0, 8 if preemption else 4)),
+                                         creation_ts=t, pod_sets=[ps], reserve_ts=1_000_000 + t, uid=f"{t:09d}"))
+    snap = Snapshot(cqs, cohorts, admitted, now_ns=10_000_000)
+    snap.derive()
+    # pending workloads: classes after configs/baseline/generator.yaml:15-35 (small 70% / medium 20% / large 10%)
+    W = nq * per
+    w_cq = np.repeat(np.arange(nq), per)
+    if cfg == 1:
+        cls = rng.choice(3, size=W, p=[0.7, 0.2, 0.1])
+        cpu = np.array([1000, 5000, 20000])[cls]
+        prio = np.array([50, 100, 200])[cls]
+        w_nps = np.ones(W, np.int64)
+    else:
+        cpu = rng.choice([1000, 2000, 4000, 8000, 16000], size=W)
+        prio = rng.integers(0, 8 if preemption else 4, size=W)
+        w_nps = np.where(rng.random(W) < 0.1, 2, 1)
+    n_ps = int(w_nps.sum())
+    ps_owner = np.repeat(np.arange(W), w_nps)
+    ps_count = rng.integers(1, 5, size=n_ps)
+    ps_cpu = cpu[ps_owner]
+    ps_req = np.stack([ps_cpu, ps_cpu // 1000 * 4 * GI, (rng.random(n_ps) < 0.3) * rng.integers(0, 3, size=n_ps)], axis=1).astype(np.int64)
+    # per-CQ queue order = heap order (priority desc, timestamp asc; cluster_queue.go:844)
+    ts = np.arange(W, dtype=np.int64) * 1000 + 5_000_000
+    rng.shuffle(ts)
+    order = np.lexsort((ts, -prio, w_cq))
+    first_ps = np.concatenate([[0], np.cumsum(w_nps)])[:-1]
+    ps_order = np.concatenate([np.arange(first_ps[i], first_ps[i] + w_nps[i]) for i in order])
+    cq_w_off = np.concatenate([[0], np.cumsum(np.bincount(w_cq, minlength=nq))]).astype(np.int64)
+    return Population(name=f"cfg{cfg}", snapshot=snap, w_cq=w_cq[order], w_prio=prio[order].astype(np.int64), w_ts=ts[order],
+                      w_nps=w_nps[order], ps_count=ps_count[ps_order], ps_req=ps_req[ps_order], cq_w_off=cq_w_off,
+                      fair_sharing=fair_sharing)

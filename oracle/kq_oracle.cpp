@@ -111,7 +111,10 @@ struct Stats {
   int64_t entry_bytes = 0;   // fits re-check + addUsage
   int64_t victim_bytes = 0;  // candidate scan + simulated removals
   int64_t drs_bytes = 0;
-  int64_t total() const { return cell_bytes + head_io_bytes + entry_bytes + victim_bytes + drs_bytes; }
+  // victim/drs bytes of SimulatePreemption calls whose result the reference discards (the flavor was
+  // already noFit, flavorassigner.go:1161): the engine does not run those searches at all.
+  int64_t discarded_bytes = 0;
+  int64_t total() const { return cell_bytes + head_io_bytes + entry_bytes + victim_bytes + drs_bytes - discarded_bytes; }
 };
 
 // ---- the snapshot as the scheduler sees it -------------------------------------------------------
@@ -546,7 +549,10 @@ struct FlavorAssigner {
       GranularMode representativeMode = {pmFit, 0};
       for (auto& rq : filtered) {
         int fr = fName * sn.nR + rq.first;
+        const bool discarded = representativeMode.pm == pmNoFit;
+        const int64_t vb0 = sn.st.victim_bytes + sn.st.drs_bytes;
         FitRes r = fitsResourceQuota(fr, frq_get(assignmentUsage, fr), rq.second);
+        if (discarded) sn.st.discarded_bytes += sn.st.victim_bytes + sn.st.drs_bytes - vb0;
         if (r.status) (*nreasons)++;
         GranularMode mode = {r.pm, r.borrow};
         if (isPreferred(representativeMode, mode, pol)) representativeMode = mode;
@@ -790,8 +796,8 @@ struct Preemptor {
   }
   // preemption.go:669-686 (TAS part out of scope)
   bool workloadFits(const PreemptionCtx& ctx, bool allowBorrowing) {
+    sn.st.victim_bytes += 40 * (int64_t)(sn.depth[ctx.preemptorCQ] + 1) * (int64_t)ctx.workloadUsage.size();
     for (auto& kv : ctx.workloadUsage) {
-      sn.st.victim_bytes += 40 * (sn.depth[ctx.preemptorCQ] + 1);
       if (!allowBorrowing && sn.BorrowingWith(ctx.preemptorCQ, kv.first, kv.second)) return false;
       if (kv.second.Cmp(sn.Available(ctx.preemptorCQ, kv.first)) > 0) return false;
     }
@@ -1210,13 +1216,19 @@ struct Scheduler {
     bool needsOverlapRecompute = hasAny(preempted, e.preemptionTargets) && sn.gate(KQ_GATE_RECOMPUTE_ON_OVERLAP);
     if (!needsOverlapRecompute) { *usageOut = usage; return fitsCheck; }
     std::vector<int> victims(preempted.begin(), preempted.end());
+    // The engine keeps a second usage plane without the cycle's victims instead of removing and
+    // re-adding them here, so this traffic is excluded from the comparable byte count.
+    int64_t vb0 = sn.st.victim_bytes;
     for (int row : victims) sn.RemoveWorkload(row);  // SimulateWorkloadRemoval snapshot.go:105-114
+    sn.st.discarded_bytes += sn.st.victim_bytes - vb0;
     e.head.has_last = false;
     // readResourceToFlavorMapping :651-660
     e.head.nomination.assign(e.head.ps.size(), {});
     for (size_t p = 0; p < e.assignment.PodSets.size(); p++) for (auto& kv : e.assignment.PodSets[p].flavors) e.head.nomination[p][kv.first] = kv.second.flavor;
     getAssignments(e);
+    vb0 = sn.st.victim_bytes;
     for (int row : victims) sn.AddWorkload(row);
+    sn.st.discarded_bytes += sn.st.victim_bytes - vb0;
     if (e.assignment.RepresentativeMode() == Fit) e.assignment.SetRepresentativeMode(DeferredFit);
     usage = assignmentUsage(e);
     fitsCheck = fits(cq, usage, preempted, e.preemptionTargets);
@@ -1264,6 +1276,7 @@ struct Scheduler {
       e.requeueReason = KQ_RQ_PENDING_PREEMPTION;
       e.head.has_last = false;
       sn.AddUsage(cq, usage);
+      sn.st.entry_bytes += (int64_t)usage.size() * 8 * (sn.depth[cq] + 1);
       return;
     }
     if (hasAny(preemptedWorkloads, e.preemptionTargets)) { e.status = KQ_ST_SKIPPED; e.skip = KQ_SKIP_OVERLAP; return; }
@@ -1480,7 +1493,7 @@ static void writeDecisions(Snap& sn, const kq_heads* h, std::vector<Entry>& entr
 
 extern "C" {
 
-// One scheduling cycle on the CPU. stats[0..5] (optional): cells, cell_bytes, head_io, entry, victim, drs
+// One scheduling cycle on the CPU. stats[0..6] (optional): cells, cell_bytes, head_io, entry, victim, drs, discarded
 int kqo_cycle_run(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, kq_decisions* out, int64_t* stats, int64_t* usage_after) {
   Snap sn(*cfg, s);
   Scheduler sch(sn, h);
@@ -1488,7 +1501,7 @@ int kqo_cycle_run(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h,
   sch.schedule(entries);
   int rc = KQ_OK;
   writeDecisions(sn, h, entries, out, &rc);
-  if (stats) { stats[0] = sn.st.cells; stats[1] = sn.st.cell_bytes; stats[2] = sn.st.head_io_bytes; stats[3] = sn.st.entry_bytes; stats[4] = sn.st.victim_bytes; stats[5] = sn.st.drs_bytes; }
+  if (stats) { stats[0] = sn.st.cells; stats[1] = sn.st.cell_bytes; stats[2] = sn.st.head_io_bytes; stats[3] = sn.st.entry_bytes; stats[4] = sn.st.victim_bytes; stats[5] = sn.st.drs_bytes; stats[6] = sn.st.discarded_bytes; }
   if (usage_after) memcpy(usage_after, sn.usage.data(), sn.usage.size() * sizeof(int64_t));
   return rc;
 }

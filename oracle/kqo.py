@@ -51,13 +51,14 @@ def derive(snap: Snapshot) -> Snapshot:
 
 def cycle_run(cfg: F.kq_config, snap: Snapshot, heads: Heads, want_usage: bool = False):
     d = Decisions(heads)
-    stats = np.zeros(6, np.int64)
+    stats = np.zeros(7, np.int64)
     usage = np.zeros(snap.N * snap.n_fr, np.int64) if want_usage else None
     rc = lib().kqo_cycle_run(C.byref(cfg), C.byref(snap.struct()), C.byref(heads.struct()), C.byref(d.struct()),
                              F.ptr(stats), F.ptr(usage) if want_usage else None)
     assert rc == 0, rc
     d.stats = dict(cells=int(stats[0]), cell_bytes=int(stats[1]), head_io_bytes=int(stats[2]), entry_bytes=int(stats[3]),
-                   victim_bytes=int(stats[4]), drs_bytes=int(stats[5]), total=int(stats[1:].sum()))
+                   victim_bytes=int(stats[4]), drs_bytes=int(stats[5]), discarded_bytes=int(stats[6]),
+                   total=int(stats[1:6].sum() - stats[6]))
     d.usage_after = usage
     return d
 

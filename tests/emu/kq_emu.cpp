@@ -22,9 +22,8 @@ struct EmuBackend {
   int sync() { return KQ_OK; }
   const char* error() { return ""; }
   int max_slots() { return 7; }  // small on purpose: exercises the grid-stride loop over heads
-  void timer_start() {}
-  void timer_stop() {}
-  double timer_ms() { return 0; }
+  void timer_mark(int) {}
+  double timer_ms(int, int) { return 0; }
   void launch_nominate(const K& k, int slots) {
     for (int slot = 0; slot < slots; slot++) {
       Wave w{};
@@ -53,5 +52,6 @@ int kqe_snapshot_put(void* e, const kq_snapshot* s) { return ((EmuEngine*)e)->sn
 int kqe_cycle_run(void* e, const kq_heads* h, kq_decisions* out) { return ((EmuEngine*)e)->cycle_run(h, out); }
 int kqe_read_usage(void* e, int64_t* out) { return ((EmuEngine*)e)->read_usage_work(out); }
 int kqe_last_bytes(void* e, int64_t* out) { *out = ((EmuEngine*)e)->last_bytes; return KQ_OK; }
+int kqe_phase_bytes(void* e, int64_t* out) { out[0] = ((EmuEngine*)e)->last_phase_bytes[0]; out[1] = ((EmuEngine*)e)->last_phase_bytes[1]; return KQ_OK; }
 const char* kqe_last_error(void* e) { return ((EmuEngine*)e)->last_error.c_str(); }
 }

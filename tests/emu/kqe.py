@@ -49,4 +49,7 @@ class EmuEngine:
         b = C.c_int64()
         lib().kqe_last_bytes(self.h, C.byref(b))
         d.bytes = b.value
+        pb = np.zeros(2, np.int64)
+        lib().kqe_phase_bytes(self.h, F.ptr(pb))
+        d.phase_bytes = pb.tolist()
         return d

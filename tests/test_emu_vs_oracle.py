@@ -27,3 +27,5 @@ def test_classical_random(oracle, seed):
     bad = want.equal(got)
     assert not bad, (bad, {k: (want.a[k].tolist(), got.a[k].tolist()) for k in bad})
     assert np.array_equal(want.usage_after, got.usage_after)
+    # the engine's algorithmic-byte counter must equal the oracle's for the same decisions
+    assert got.bytes == want.stats["total"], (got.bytes, want.stats)
