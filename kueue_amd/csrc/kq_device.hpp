@@ -36,6 +36,7 @@ KQ_DEV int lane_id() { return 0; }
 KQ_DEV uint64_t wballot(bool p) { return p ? 1ull : 0ull; }
 template <class T> KQ_DEV T wbcast(T v, int) { return v; }
 KQ_DEV void wsync() {}
+KQ_DEV void wsync_lds() {}
 KQ_DEV int ffs64(uint64_t m) { return __builtin_ctzll(m); }
 KQ_DEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
 KQ_DEV int atomic_add_i32(int* p, int v) { int o = *p; *p += v; return o; }
@@ -54,6 +55,9 @@ KQ_DEV int wbcast(int v, int src) { return __shfl(v, src, 64); }
 KQ_DEV int64_t wbcast(int64_t v, int src) { return (int64_t)__shfl((long long)v, src, 64); }
 // one wave per workgroup: __syncthreads() is the wave-level fence for LDS and global scratch
 KQ_DEV void wsync() { __syncthreads(); }
+// LDS-only visibility inside the single wave of a workgroup: the LDS pipeline is in order per wave, so only
+// the compiler must be kept from reordering / caching; no wait for outstanding global memory traffic.
+KQ_DEV void wsync_lds() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 KQ_DEV int ffs64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }
 KQ_DEV int popc64(uint64_t m) { return __popcll((unsigned long long)m); }
 KQ_DEV int atomic_add_i32(int* p, int v) { return atomicAdd(p, v); }
@@ -139,6 +143,7 @@ struct DScratch {
   uint8_t* cls;      // [slots][max_tree_rows] candidate class per rank position
   int32_t* tgt_row;  // [slots][tgt_cap]
   uint8_t* tgt_reason;
+  int32_t* nom;      // [slots][KQ_MAXPS * nR] NominationMapping of the entry being recomputed (workload.go:262)
   int32_t max_tree_nodes, max_tree_cqs, max_tree_rows, slot_cap, tgt_cap;
 };
 
@@ -153,6 +158,7 @@ struct K {  // everything a kernel needs
   int64_t* usage_np;         // process: usage_work minus every workload preempted so far this cycle
   uint8_t* preempted;        // [n_adm] PreemptedWorkloads membership (preempted_workloads.go:26)
   const int32_t* order_idx;  // [H] entry index at iterator position i
+  long long* prof;           // [32] optional segment cycle counters (KQ_PROF builds)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -219,6 +225,17 @@ struct UGW {  // writable global plane
   const DSnap* S; int64_t* u; int fr;
   KQ_MDEV int64_t get(int n) const { return u[(size_t)n * S->nfr + fr]; }
   KQ_MDEV void set(int n, int64_t v) const { u[(size_t)n * S->nfr + fr] = v; }
+};
+
+// process kernel: usage plane with the tree's cohort rows served from LDS (plane 0 = work, 1 = np)
+struct UP {
+  const DSnap* S; int64_t* g; int64_t* lds; int on, ncq, ncoh, plane, fr;
+  KQ_MDEV int64_t* cell(int n) const {
+    if (on && n >= S->nq) return lds + ((size_t)plane * ncoh + (S->node_local[n] - ncq)) * S->nfr + fr;
+    return g + (size_t)n * S->nfr + fr;
+  }
+  KQ_MDEV int64_t get(int n) const { return *cell(n); }
+  KQ_MDEV void set(int n, int64_t v) const { *cell(n) = v; }
 };
 
 // resource_node.go:106-122, root-first iteration over the precomputed path
@@ -335,8 +352,25 @@ struct Wave {
   uint8_t adv_at[KQ_MAXD];        // hasHierarchicalAdvantage when collecting under path[level]
   int ntgt;
   int counts[KQ_MAXPS];           // partial admission counts under test
+  // process kernel: the tree's cohort rows of usage_work / usage_np live in LDS for the whole cycle
+  int pc_on, pc_ncq, pc_ncoh;     // cache enabled, #CQs of the tree (node_local offset of cohorts), #cohorts
+  int64_t* pc_lds;                // [2][pc_ncoh][nfr] : plane 0 = usage_work, plane 1 = usage_np
+  int32_t path_coh[KQ_MAXD];      // cohort-local index of path[i] (i >= 1)
+  int32_t win_e[64], win_pos[64]; // this tree's entries inside the current 64-wide window of the order
+  // gathered cells of the entry under process: c = u * plen + i
+  int64_t g_lq[CELLS], g_sq[CELLS], g_bl[CELLS], g_uw[CELLS], g_un[CELLS];
+  uint8_t g_dirty[CELLS];
   int64_t bytes;                  // algorithmic bytes (lane 0 meaningful)
 };
+
+// optional in-kernel segment timing (build with -DKQ_PROF): cycles accumulated per segment id
+#if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
+#define KQ_T0() long long _t0 = clock64()
+#define KQ_TS(k, id) do { long long _t1 = clock64(); if (lane_id() == 0) atomic_add_i64((long long*)(k).prof + (id), _t1 - _t0); _t0 = _t1; } while (0)
+#else
+#define KQ_T0() do {} while (0)
+#define KQ_TS(k, id) do {} while (0)
+#endif
 
 KQ_DEV void set_error(const K& k, int code) {
   if (lane_id() == 0 && *k.O.error == 0) *k.O.error = code;
@@ -763,7 +797,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
     wsync();
     // nomination mapping snapshot for this podset (flavor per resource before we overwrite O.flavor)
     int32_t nom_flavor[KQ_MAXREQ];
-    if (nominate_map) for (int a = 0; a < w.nreq; a++) nom_flavor[a] = O.flavor[(size_t)psg * nR + w.req_res[a]];
+    if (nominate_map) for (int a = 0; a < w.nreq; a++) nom_flavor[a] = k.X.nom[((size_t)slot * KQ_MAXPS + pi) * nR + w.req_res[a]];
     // clear the podset's output rows
     for (int r = lane; r < nR; r += WAVE) { O.flavor[(size_t)psg * nR + r] = -1; O.res_mode[(size_t)psg * nR + r] = M_NOFIT; O.tried_idx[(size_t)psg * nR + r] = -1; }
     if (lane == 0) O.ps_count[psg] = scale ? new_count : count;
@@ -1090,6 +1124,35 @@ KQ_DEV void nominate_head(const K& k, Wave& w, int h, int slot) {
 // ------------------------------------------------------------------------------------------------
 // processEntry (scheduler.go:392-523) — sequential inside one root-cohort tree
 // ------------------------------------------------------------------------------------------------
+KQ_DEV UP up_plane(const K& k, const Wave& w, int plane, int fr) {
+  return UP{&k.S, plane == 0 ? k.usage_work : k.usage_np, w.pc_lds, w.pc_on, w.pc_ncq, w.pc_ncoh, plane, fr};
+}
+// LDS <-> HBM for the tree's cohort rows (both planes)
+KQ_DEV void pc_load(const K& k, Wave& w, int tree) {
+  const DSnap& S = k.S;
+  if (!w.pc_on) return;
+  const int n0 = S.tree_node_off[tree] + w.pc_ncq;
+  const int total = w.pc_ncoh * S.nfr;
+  for (int i = lane_id(); i < total; i += WAVE) {
+    int node = S.tree_nodes[n0 + i / S.nfr], fr = i % S.nfr;
+    w.pc_lds[i] = k.usage_work[ix(S, node, fr)];
+    w.pc_lds[(size_t)total + i] = k.usage_np[ix(S, node, fr)];
+  }
+  wsync();
+}
+KQ_DEV void pc_flush(const K& k, Wave& w, int tree) {
+  const DSnap& S = k.S;
+  if (!w.pc_on) return;
+  const int n0 = S.tree_node_off[tree] + w.pc_ncq;
+  const int total = w.pc_ncoh * S.nfr;
+  for (int i = lane_id(); i < total; i += WAVE) {
+    int node = S.tree_nodes[n0 + i / S.nfr], fr = i % S.nfr;
+    k.usage_work[ix(S, node, fr)] = w.pc_lds[i];
+    k.usage_np[ix(S, node, fr)] = w.pc_lds[(size_t)total + i];
+  }
+  wsync();
+}
+
 // apply / revert the removal of a target row on usage_np, restricted to the entry's own flavor-resources
 KQ_DEV void np_apply_row_restricted(const K& k, Wave& w, int row, bool add) {
   const DSnap& S = k.S;
@@ -1098,7 +1161,7 @@ KQ_DEV void np_apply_row_restricted(const K& k, Wave& w, int row, bool add) {
   int cplen = S.plen[c];
   for (int u = lane_id(); u < w.nuse; u += WAVE) {
     int fr = w.use_fr[u];
-    UGW g{&S, k.usage_np, fr};
+    UP g = up_plane(k, w, 1, fr);
     for (int e = S.adm_use_off[row]; e < S.adm_use_off[row + 1]; e++) {
       if (S.adm_use_fr[e] != fr) continue;
       if (add) add_usage(S, cpath, cplen, fr, S.adm_use_qty[e], g); else remove_usage(S, cpath, cplen, fr, S.adm_use_qty[e], g);
@@ -1113,7 +1176,7 @@ KQ_DEV bool entry_fits(const K& k, Wave& w, const int32_t* trows, int nt, bool q
   for (int t = 0; t < nt; t++) if (!k.preempted[trows[t]]) np_apply_row_restricted(k, w, trows[t], false);
   bool bad = false;
   for (int u = lane_id(); u < w.nuse; u += WAVE) {
-    UG g{&S, k.usage_np, w.use_fr[u]};
+    UP g = up_plane(k, w, 1, w.use_fr[u]);
     if (i64max(0, available_of(S, w.path, w.plen, w.use_fr[u], g)) < w.use_qty[u]) bad = true;
   }
   bool ok = wballot(bad) == 0;
@@ -1127,7 +1190,7 @@ KQ_DEV void entry_add_usage(const K& k, Wave& w, const int64_t* qty) {
   const DSnap& S = k.S;
   for (int u = lane_id(); u < w.nuse; u += WAVE) {
     int fr = w.use_fr[u];
-    UGW a{&S, k.usage_work, fr}, b{&S, k.usage_np, fr};
+    UP a = up_plane(k, w, 0, fr), b = up_plane(k, w, 1, fr);
     add_usage(S, w.path, w.plen, fr, qty[u], a);
     add_usage(S, w.path, w.plen, fr, qty[u], b);
   }
@@ -1135,28 +1198,154 @@ KQ_DEV void entry_add_usage(const K& k, Wave& w, const int64_t* qty) {
   wsync();
 }
 
-KQ_DEV void process_entry(const K& k, Wave& w, int e, int pos, int slot) {
+// quotaResourcesToReserve (scheduler.go:796-814) for a Preempt-mode entry without targets
+KQ_DEV int64_t reserve_amount(int64_t usage, int64_t nominal, int64_t blv, int64_t cur, int borrowing) {
+  if (borrowing > 0) return blv == KQ_NIL_LIMIT ? usage : i64min(usage, a_sub(a_add(nominal, blv), cur));
+  return i64max(0, i64min(usage, a_sub(nominal, cur)));
+}
+
+KQ_DEV void write_entry_result(const K& k, Wave& w, int e, int status, int action, int rq, int skip, int mode) {
+  const DOut& O = k.O;
+  if (lane_id() == 0) {
+    if (status != KQ_ST_NOT_NOMINATED && status != KQ_ST_ASSUMED && rq == KQ_RQ_GENERIC) rq = KQ_RQ_FAILED_AFTER_NOMINATION;  // scheduler.go:1167-1170
+    O.status[e] = (uint8_t)status; O.action[e] = (uint8_t)action; O.requeue_reason[e] = (uint8_t)rq; O.skip[e] = (uint8_t)skip;
+    O.mode[e] = (uint8_t)mode;
+  }
+}
+
+// Entries without preemption targets (the bulk of every cycle): every (slot, path level) cell the entry
+// can touch is gathered in ONE parallel round trip (cohort levels from LDS, the CQ level from HBM),
+// fits / AddUsage run on the gathered copy in LDS, dirty cells are scattered back.
+KQ_DEV void process_entry_fast(const K& k, Wave& w, int e) {
+  const DSnap& S = k.S;
+  const int lane = lane_id();
+  KQ_T0();
+  const bool quota_usage = !(w.hflags & KQ_HEAD_HAS_QUOTA_RESERVATION);
+  const int mode = w.rep_mode;
+  const int plen = w.plen, nuse = quota_usage ? w.nuse : 0, ncell = nuse * plen;
+  // the reference runs scheduler.fits before looking at the mode (updateAssignmentIfNeeded :713-714)
+  if (lane == 0 && nuse > 0) w.bytes += (int64_t)nuse * 40 * plen;
+  if (mode == M_NOFIT) { write_entry_result(k, w, e, KQ_ST_NOT_NOMINATED, KQ_ACT_NONE, KQ_RQ_NOFIT, KQ_SKIP_NONE, mode); return; }
+  const int total = w.pc_ncoh * S.nfr;
+  for (int c = lane; c < ncell; c += WAVE) {
+    int u = c / plen, i = c % plen, n = w.path[i], fr = w.use_fr[u];
+    size_t o = ix(S, n, fr);
+    int64_t sqv = S.sq[o], llv = S.ll[o];
+    w.g_sq[c] = sqv; w.g_bl[c] = S.bl[o];
+    w.g_lq[c] = llv != KQ_NIL_LIMIT ? i64max(0, a_sub(sqv, llv)) : 0;
+    if (i > 0 && w.pc_on) {
+      size_t l = (size_t)w.path_coh[i] * S.nfr + fr;
+      w.g_uw[c] = w.pc_lds[l]; w.g_un[c] = w.pc_lds[(size_t)total + l];
+    } else {
+      w.g_uw[c] = k.usage_work[o]; w.g_un[c] = k.usage_np[o];
+    }
+    w.g_dirty[c] = 0;
+  }
+  wsync();
+  KQ_TS(k, 4);
+  // scheduler.fits on usage_np (no targets): Available(cq, fr) >= qty for every flavor-resource
+  bool bad = false;
+  for (int u = lane; u < nuse; u += WAVE) {
+    const int b = u * plen;
+    int64_t a = a_sub(w.g_sq[b + plen - 1], w.g_un[b + plen - 1]);
+    for (int i = plen - 2; i >= 0; i--) {
+      int64_t lq = w.g_lq[b + i], uu = w.g_un[b + i], blv = w.g_bl[b + i];
+      if (blv != KQ_NIL_LIMIT) a = i64min(a_add(a_sub(a_sub(w.g_sq[b + i], lq), i64max(0, a_sub(uu, lq))), blv), a);
+      a = a_add(i64max(0, a_sub(lq, uu)), a);
+    }
+    if (i64max(0, a) < w.use_qty[u]) bad = true;
+  }
+  const bool fits_ok = wballot(bad) == 0;
+  KQ_TS(k, 5);
+  int status = KQ_ST_NOT_NOMINATED, action = KQ_ACT_NONE, rq = KQ_RQ_GENERIC, skip = KQ_SKIP_NONE;
+  bool add = false, reserve = false;
+  if (mode == M_PREEMPT) {  // no targets: reserveCapacityForUnreclaimablePreempt :538-543
+    rq = KQ_RQ_PREEMPTION_NO_CANDIDATES;
+    bool can_always_reclaim = KQ_POL_RECLAIM(w.pol) == KQ_POLICY_ANY;
+    reserve = add = !can_always_reclaim || (gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS) && (w.hflags & KQ_HEAD_IS_PREEMPTOR));
+  } else if (!fits_ok) {
+    status = KQ_ST_SKIPPED; skip = KQ_SKIP_NO_LONGER_FITS;
+  } else {
+    add = true; status = KQ_ST_ASSUMED; action = KQ_ACT_ADMIT;
+  }
+  if (add && nuse > 0) {
+    for (int u = lane; u < nuse; u += WAVE) {
+      const int b = u * plen;
+      int64_t val = w.use_qty[u];
+      if (reserve) val = reserve_amount(val, S.nominal[ix(S, w.cq, w.use_fr[u])], w.g_bl[b], w.g_uw[b], w.borrowing);
+      int64_t v = val;  // resource_node.go:144-152 on both planes
+      for (int i = 0; i < plen; i++) {
+        int64_t uu = w.g_uw[b + i], la = i64max(0, a_sub(w.g_lq[b + i], uu));
+        w.g_uw[b + i] = a_add(uu, v); w.g_dirty[b + i] |= 1;
+        if (i + 1 < plen && v > la) v = a_sub(v, la); else break;
+      }
+      v = val;
+      for (int i = 0; i < plen; i++) {
+        int64_t uu = w.g_un[b + i], la = i64max(0, a_sub(w.g_lq[b + i], uu));
+        w.g_un[b + i] = a_add(uu, v); w.g_dirty[b + i] |= 2;
+        if (i + 1 < plen && v > la) v = a_sub(v, la); else break;
+      }
+    }
+    if (lane == 0) w.bytes += (int64_t)nuse * 8 * plen;
+    wsync();
+    for (int c = lane; c < ncell; c += WAVE) {
+      uint8_t d = w.g_dirty[c];
+      if (!d) continue;
+      int u = c / plen, i = c % plen, fr = w.use_fr[u];
+      if (i > 0 && w.pc_on) {
+        size_t l = (size_t)w.path_coh[i] * S.nfr + fr;
+        if (d & 1) w.pc_lds[l] = w.g_uw[c];
+        if (d & 2) w.pc_lds[(size_t)total + l] = w.g_un[c];
+      } else {
+        size_t o = ix(S, w.path[i], fr);
+        if (d & 1) k.usage_work[o] = w.g_uw[c];
+        if (d & 2) k.usage_np[o] = w.g_un[c];
+      }
+    }
+  }
+  KQ_TS(k, 6);
+  write_entry_result(k, w, e, status, action, rq, skip, mode);
+  KQ_TS(k, 7);
+}
+
+KQ_DEV void process_entry(const K& k, Wave& w, int e, int pos, int slot, int tree) {
   const DSnap& S = k.S; const DOut& O = k.O;
   const int lane = lane_id();
+  KQ_T0();
   load_head(k, w, e);
+  KQ_TS(k, 0);
   if (lane == 0) {
     w.nuse = O.use_n[e];
     for (int u = 0; u < w.nuse; u++) { w.use_fr[u] = O.use_fr[(size_t)e * KQ_MAXU + u]; w.use_qty[u] = O.use_qty[(size_t)e * KQ_MAXU + u]; }
     w.borrowing = O.borrowing[e];
     w.rep_mode = O.nominated_mode[e];
     O.order[e] = pos;
+    for (int i = 1; i < w.plen; i++) w.path_coh[i] = S.node_local[w.path[i]] - w.pc_ncq;
   }
   wsync();
+  KQ_TS(k, 1);
+  int nt = O.tgt_n[e];
+  if (nt == 0 && w.nuse * w.plen <= CELLS) {
+    process_entry_fast(k, w, e);
+    KQ_TS(k, 2);
+    if (lane == 0) atomic_add_i64(O.stat_bytes, (long long)w.bytes);
+    wsync();
+    KQ_TS(k, 3);
+    return;
+  }
   const bool quota_usage = !(w.hflags & KQ_HEAD_HAS_QUOTA_RESERVATION);  // netUsage scheduler.go:785-794
   const int32_t* trows = O.pool_row + O.tgt_pos[e];
-  int nt = O.tgt_n[e];
   auto has_any = [&]() { bool a = false; for (int t = 0; t < nt; t++) if (k.preempted[trows[t]]) a = true; return a; };
   // updateAssignmentIfNeeded :707-769
   bool fits_ok = entry_fits(k, w, trows, nt, quota_usage);
   int mode = w.rep_mode;
   if (has_any() && gate(k, KQ_GATE_RECOMPUTE_ON_OVERLAP)) {
-    // SimulateWorkloadRemoval(victimsOfOtherPreemptions) == evaluate on usage_np with those rows deleted
+    // SimulateWorkloadRemoval(victimsOfOtherPreemptions) == evaluate on usage_np with those rows deleted.
+    // The generic nominate code reads HBM planes: publish the LDS-resident cohort rows first.
+    pc_flush(k, w, tree);
     if (lane == 0) w.has_last = 0;
+    // e.NominationMapping = e.readResourceToFlavorMapping() (scheduler.go:734): fixed for the whole recomputation
+    for (int i = lane; i < w.nps * S.nR; i += WAVE) k.X.nom[(size_t)slot * KQ_MAXPS * S.nR + i] = O.flavor[(size_t)w.ps_base * S.nR + i];
     wsync();
     Search s = get_assignments(k, w, slot, k.usage_np, k.preempted, true);
     publish_assignment(k, w, s, e);
@@ -1184,11 +1373,7 @@ KQ_DEV void process_entry(const K& k, Wave& w, int e, int pos, int slot) {
       if (lane == 0)
         for (int u = 0; u < w.nuse; u++) {
           int fr = w.use_fr[u];
-          int64_t usage = w.use_qty[u], nominal = S.nominal[ix(S, w.cq, fr)], cur = k.usage_work[ix(S, w.cq, fr)], blv = S.bl[ix(S, w.cq, fr)];
-          int64_t r;
-          if (w.borrowing > 0) r = blv == KQ_NIL_LIMIT ? usage : i64min(usage, a_sub(a_add(nominal, blv), cur));
-          else r = i64max(0, i64min(usage, a_sub(nominal, cur)));
-          w.s_qty[u] = r;
+          w.s_qty[u] = reserve_amount(w.use_qty[u], S.nominal[ix(S, w.cq, fr)], S.bl[ix(S, w.cq, fr)], k.usage_work[ix(S, w.cq, fr)], w.borrowing);
         }
       wsync();
       entry_add_usage(k, w, w.s_qty);
@@ -1210,7 +1395,7 @@ KQ_DEV void process_entry(const K& k, Wave& w, int e, int pos, int slot) {
         k.preempted[row] = 1;
         int c = S.adm_cq[row];
         for (int en = S.adm_use_off[row]; en < S.adm_use_off[row + 1]; en++) {
-          UGW g{&S, k.usage_np, S.adm_use_fr[en]};
+          UP g = up_plane(k, w, 1, S.adm_use_fr[en]);
           remove_usage(S, S.path + (size_t)c * KQ_MAXD, S.plen[c], S.adm_use_fr[en], S.adm_use_qty[en], g);
         }
       }
@@ -1220,29 +1405,246 @@ KQ_DEV void process_entry(const K& k, Wave& w, int e, int pos, int slot) {
     if (mode == M_PREEMPT) { action = KQ_ACT_PREEMPT; rq = KQ_RQ_PENDING_PREEMPTION; }
     else { status = KQ_ST_ASSUMED; action = KQ_ACT_ADMIT; }
   }
-  if (lane == 0) {
-    if (status != KQ_ST_NOT_NOMINATED && status != KQ_ST_ASSUMED && rq == KQ_RQ_GENERIC) rq = KQ_RQ_FAILED_AFTER_NOMINATION;  // scheduler.go:1167-1170
-    O.status[e] = (uint8_t)status; O.action[e] = (uint8_t)action; O.requeue_reason[e] = (uint8_t)rq; O.skip[e] = (uint8_t)skip;
-    O.mode[e] = (uint8_t)mode;
-    atomic_add_i64(O.stat_bytes, (long long)w.bytes);
+  write_entry_result(k, w, e, status, action, rq, skip, mode);
+  if (lane == 0) atomic_add_i64(O.stat_bytes, (long long)w.bytes);
+  wsync();
+}
+
+// ---- chunked fast path --------------------------------------------------------------------------
+// A lone wave is latency-bound: every dependent HBM/L2 access costs ~1-2k cycles and nothing hides it.
+// So entries are handled CH at a time: (1) all lanes prefetch the CH entries' records and the static
+// quota constants of every (slot, path level) cell they can touch into LDS (latency paid once per
+// chunk, in parallel), (2) a serial core walks the chunk touching only LDS (cohort rows are resident
+// there for the whole kernel), (3) results are written back in parallel.
+constexpr int FU = 8;    // max flavor-resources of an entry on the fast path
+constexpr int FD = 4;    // max path length (CQ + 3 cohort levels) on the fast path
+constexpr int CH = 32;   // entries per chunk
+struct PRec {
+  int32_t e, pos, cq, plen, nuse, borrowing, mode, slow;
+  uint32_t pol, flags;
+  int32_t coh[FD];
+  int32_t fr[FU];
+  int64_t qty[FU], nominal[FU], uw0[FU], un0[FU];
+  int64_t lq[FU][FD], sqv[FU][FD], bl[FU][FD];
+  uint8_t status, action, rq, skip, omode, dirty, pad[2];  // dirty: CQ-level usage cells changed
+};
+
+KQ_DEV void chunk_prefetch(const K& k, Wave& w, PRec* rec, const int32_t* ent, const int32_t* entpos, int nch) {
+  const DSnap& S = k.S; const DOut& O = k.O; const DHeads& H = k.H;
+  const int lane = lane_id();
+  for (int j = lane; j < nch; j += WAVE) {
+    PRec& r = rec[j];
+    const int e = ent[j];
+    r.e = e; r.pos = entpos[j];
+    const int cq = H.cq[e];
+    r.cq = cq; r.flags = H.flags[e]; r.pol = S.cq_policy[cq];
+    r.plen = S.plen[cq]; r.borrowing = O.borrowing[e]; r.mode = O.nominated_mode[e];
+    const int nuse = (r.flags & KQ_HEAD_HAS_QUOTA_RESERVATION) ? 0 : O.use_n[e];  // netUsage scheduler.go:785-794
+    r.nuse = nuse;
+    int slow = (O.tgt_n[e] != 0 || nuse > FU || r.plen > FD || (r.plen > 1 && !w.pc_on)) ? 1 : 0;
+    if (!slow) {
+      for (int i = 1; i < r.plen; i++) r.coh[i] = S.node_local[S.path[(size_t)cq * KQ_MAXD + i]] - w.pc_ncq;
+      for (int u = 0; u < nuse; u++) { r.fr[u] = O.use_fr[(size_t)e * KQ_MAXU + u]; r.qty[u] = O.use_qty[(size_t)e * KQ_MAXU + u]; }
+    }
+    r.slow = slow; r.dirty = 0;
+  }
+  wsync();
+  // a ClusterQueue seen twice in one chunk would read a stale CQ-level cell: second one takes the slow path
+  for (int j = lane; j < nch; j += WAVE) {
+    bool dup = false;
+    for (int q = 0; q < j; q++) if (rec[q].cq == rec[j].cq) dup = true;
+    if (dup) rec[j].slow = 1;
+  }
+  wsync();
+  for (int idx = lane; idx < nch * FU * FD; idx += WAVE) {
+    const int j = idx / (FU * FD), u = (idx / FD) % FU, i = idx % FD;
+    PRec& r = rec[j];
+    if (r.slow || u >= r.nuse || i >= r.plen) continue;
+    const int n = S.path[(size_t)r.cq * KQ_MAXD + i], fr = r.fr[u];
+    const size_t o = ix(S, n, fr);
+    const int64_t sqv = S.sq[o], llv = S.ll[o];
+    r.sqv[u][i] = sqv; r.bl[u][i] = S.bl[o];
+    r.lq[u][i] = llv != KQ_NIL_LIMIT ? i64max(0, a_sub(sqv, llv)) : 0;
+    if (i == 0) { r.nominal[u] = S.nominal[o]; r.uw0[u] = k.usage_work[o]; r.un0[u] = k.usage_np[o]; }
   }
   wsync();
 }
 
-// one wave per root-cohort tree: drain the tree's entries in iterator order
-KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot) {
+// CQ-level cells of the chunk's first n entries that added usage go back to HBM, one lane per (entry, slot)
+KQ_DEV void chunk_scatter(const K& k, PRec* rec, int n) {
+  const DSnap& S = k.S;
+  for (int idx = lane_id(); idx < n * FU; idx += WAVE) {
+    PRec& r = rec[idx / FU];
+    const int u = idx % FU;
+    if (r.slow || !r.dirty || u >= r.nuse) continue;
+    const size_t o = ix(S, r.cq, r.fr[u]);
+    k.usage_work[o] = r.uw0[u]; k.usage_np[o] = r.un0[u];
+  }
+  wsync();
+  // written back exactly once: a later generic-path entry may update the same ClusterQueue's cells in HBM
+  for (int q = lane_id(); q < n; q += WAVE) rec[q].dirty = 0;
+  wsync();
+}
+
+// serial core for one fast entry: lanes = flavor-resource slots; only LDS is touched, except the CQ-level
+// cells that are written through to HBM.
+KQ_DEV void chunk_entry_fast(const K& k, Wave& w, PRec& r, int64_t* bytes) {
+  const DSnap& S = k.S;
+  const int lane = lane_id();
+  const int plen = r.plen, nuse = r.nuse, mode = r.mode;
+  const int total = w.pc_ncoh * S.nfr;
+  if (nuse > 0) *bytes += (int64_t)nuse * 40 * plen;  // scheduler.fits runs before the mode is looked at
+  if (mode == M_NOFIT) { r.status = KQ_ST_NOT_NOMINATED; r.action = KQ_ACT_NONE; r.rq = KQ_RQ_NOFIT; r.skip = KQ_SKIP_NONE; r.omode = (uint8_t)mode; return; }
+  int64_t un[FD], uw[FD], lq[FD], sq[FD], blv[FD];
+  auto load_slot = [&](int u, int fr) {
+    #pragma unroll
+    for (int i = 0; i < FD; i++) {
+      if (i < plen) {
+        lq[i] = r.lq[u][i]; sq[i] = r.sqv[u][i]; blv[i] = r.bl[u][i];
+        if (i == 0) { uw[0] = r.uw0[u]; un[0] = r.un0[u]; }
+        else { size_t l = (size_t)r.coh[i] * S.nfr + fr; uw[i] = w.pc_lds[l]; un[i] = w.pc_lds[(size_t)total + l]; }
+      }
+    }
+  };
+  bool bad = false;
+  for (int u = lane; u < nuse; u += WAVE) {  // one pass on the device (nuse <= FU < 64)
+    const int fr = r.fr[u];
+    load_slot(u, fr);
+    // Available(cq, fr) on usage_np, root first (resource_node.go:106-122)
+    int64_t a = 0;
+    #pragma unroll
+    for (int i = FD - 1; i >= 0; i--) {
+      if (i >= plen) continue;
+      if (i == plen - 1) { a = a_sub(sq[i], un[i]); continue; }
+      if (blv[i] != KQ_NIL_LIMIT) a = i64min(a_add(a_sub(a_sub(sq[i], lq[i]), i64max(0, a_sub(un[i], lq[i]))), blv[i]), a);
+      a = a_add(i64max(0, a_sub(lq[i], un[i])), a);
+    }
+    if (i64max(0, a) < r.qty[u]) bad = true;
+  }
+  const bool fits_ok = wballot(bad) == 0;
+  int status = KQ_ST_NOT_NOMINATED, action = KQ_ACT_NONE, rq = KQ_RQ_GENERIC, skip = KQ_SKIP_NONE;
+  bool add = false, reserve = false;
+  if (mode == M_PREEMPT) {  // no targets: reserveCapacityForUnreclaimablePreempt scheduler.go:538-543
+    rq = KQ_RQ_PREEMPTION_NO_CANDIDATES;
+    bool can_always_reclaim = KQ_POL_RECLAIM(r.pol) == KQ_POLICY_ANY;
+    reserve = add = !can_always_reclaim || (gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS) && (r.flags & KQ_HEAD_IS_PREEMPTOR));
+  } else if (!fits_ok) {
+    status = KQ_ST_SKIPPED; skip = KQ_SKIP_NO_LONGER_FITS;
+  } else {
+    add = true; status = KQ_ST_ASSUMED; action = KQ_ACT_ADMIT;
+  }
+  if (add && nuse > 0) {
+    *bytes += (int64_t)nuse * 8 * plen;
+    for (int u = lane; u < nuse; u += WAVE) {
+      const int fr = r.fr[u];
+      load_slot(u, fr);
+      int64_t val = reserve ? reserve_amount(r.qty[u], r.nominal[u], blv[0], uw[0], r.borrowing) : r.qty[u];
+      int64_t v = val;  // addUsage resource_node.go:144-152 on usage_work
+      bool go = true;
+      #pragma unroll
+      for (int i = 0; i < FD; i++) {
+        if (i < plen && go) {
+          int64_t la = i64max(0, a_sub(lq[i], uw[i]));
+          int64_t nu = a_add(uw[i], v);
+          if (i == 0) r.uw0[u] = nu; else w.pc_lds[(size_t)r.coh[i] * S.nfr + fr] = nu;
+          if (i + 1 < plen && v > la) v = a_sub(v, la); else go = false;
+        }
+      }
+      v = val; go = true;  // ... and on usage_np
+      #pragma unroll
+      for (int i = 0; i < FD; i++) {
+        if (i < plen && go) {
+          int64_t la = i64max(0, a_sub(lq[i], un[i]));
+          int64_t nu = a_add(un[i], v);
+          if (i == 0) r.un0[u] = nu; else w.pc_lds[(size_t)total + (size_t)r.coh[i] * S.nfr + fr] = nu;
+          if (i + 1 < plen && v > la) v = a_sub(v, la); else go = false;
+        }
+      }
+    }
+    if (lane == 0) r.dirty = 1;
+    wsync_lds();  // cohort rows in LDS must be visible to the next entry's lanes
+  }
+  if (status != KQ_ST_NOT_NOMINATED && status != KQ_ST_ASSUMED && rq == KQ_RQ_GENERIC) rq = KQ_RQ_FAILED_AFTER_NOMINATION;  // scheduler.go:1167-1170
+  if (lane == 0) { r.status = (uint8_t)status; r.action = (uint8_t)action; r.rq = (uint8_t)rq; r.skip = (uint8_t)skip; r.omode = (uint8_t)mode; }
+}
+
+// one wave per root-cohort tree: drain the tree's entries in iterator order.
+// lds layout: [2 planes of the tree's cohort rows][CH records]; too small for the rows => they stay in HBM.
+KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, size_t lds_bytes) {
+  const DSnap& S = k.S; const DOut& O = k.O;
   const int n = k.H.n;
-  for (int base = 0; base < n; base += WAVE) {
-    int i = base + lane_id();
-    bool mine = false;
-    if (i < n) mine = k.S.tree_of[k.H.cq[k.order_idx[i]]] == tree;
-    uint64_t m = wballot(mine);
-    while (m) {
-      int b = ffs64(m);
-      m &= m - 1;
-      process_entry(k, w, k.order_idx[base + b], base + b, slot);
+  const int lane = lane_id();
+  const size_t rec_bytes = sizeof(PRec) * CH;
+  if (lane == 0) {
+    w.pc_ncq = S.tree_cq_off[tree + 1] - S.tree_cq_off[tree];
+    w.pc_ncoh = (S.tree_node_off[tree + 1] - S.tree_node_off[tree]) - w.pc_ncq;
+    w.pc_lds = lds;
+    w.pc_on = (w.pc_ncoh > 0 && lds_bytes >= rec_bytes && (size_t)w.pc_ncoh * S.nfr * 16 <= lds_bytes - rec_bytes) ? 1 : 0;
+  }
+  wsync();
+  const bool chunked = lds_bytes >= rec_bytes;
+  PRec* rec = (PRec*)((unsigned char*)lds + (lds_bytes - (chunked ? rec_bytes : 0)));
+  bool loaded = false;
+  int64_t bytes = 0;
+  constexpr int WIN = 64;  // entries of the global order examined per window (independent of the wave width)
+  for (int base = 0; base < n; base += WIN) {
+    // compact this window's entries of the tree (in order) into LDS lists
+    int nwin = 0;
+    for (int off = 0; off < WIN; off += WAVE) {
+      const int i = base + off + lane;
+      bool mine = false;
+      int e = 0;
+      if (i < n) { e = k.order_idx[i]; mine = S.tree_of[k.H.cq[e]] == tree; }
+      const uint64_t m = wballot(mine);
+      const int my = nwin + popc64(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+      if (mine) { w.win_e[my] = e; w.win_pos[my] = i; }
+      nwin += popc64(m);
+    }
+    if (nwin == 0) continue;
+    wsync();
+    if (!loaded) { KQ_T0(); pc_load(k, w, tree); loaded = true; KQ_TS(k, 8); }
+    if (!chunked) {
+      for (int q = 0; q < nwin; q++) process_entry(k, w, w.win_e[q], w.win_pos[q], slot, tree);
+      continue;
+    }
+    int done = 0;
+    while (done < nwin) {
+      const int nch = (nwin - done) < CH ? (nwin - done) : CH;
+      KQ_T0();
+      chunk_prefetch(k, w, rec, w.win_e + done, w.win_pos + done, nch);
+      KQ_TS(k, 10);
+      int j = 0;
+      for (; j < nch; j++) {
+        PRec& r = rec[j];
+        if (r.slow) {
+          // generic path (targets / recompute / oversize). It reads and writes HBM for CQ-level cells, so the
+          // CQ-level values prefetched for the rest of the chunk may be stale afterwards: restart after it.
+          chunk_scatter(k, rec, j);  // earlier fast entries' CQ-level cells must be in HBM first
+          wsync();
+          process_entry(k, w, r.e, r.pos, slot, tree);
+          if (lane == 0) r.slow = 2;
+          wsync();
+          j++;
+          break;
+        }
+        chunk_entry_fast(k, w, r, &bytes);
+      }
+      KQ_TS(k, 11);
+      wsync();
+      for (int q = lane; q < j; q += WAVE) {
+        const PRec& r = rec[q];
+        if (r.slow) continue;  // the generic path wrote its own result
+        O.status[r.e] = r.status; O.action[r.e] = r.action; O.requeue_reason[r.e] = r.rq; O.skip[r.e] = r.skip; O.mode[r.e] = r.omode;
+        O.order[r.e] = r.pos;
+      }
+      chunk_scatter(k, rec, j);
+      wsync();
+      KQ_TS(k, 12);
+      done += j;
     }
   }
+  if (lane == 0 && bytes) atomic_add_i64(O.stat_bytes, (long long)bytes);
+  if (loaded) { KQ_T0(); pc_flush(k, w, tree); KQ_TS(k, 9); }
 }
 
 // classical entry order (scheduler.go:1110-1163): a precedes b

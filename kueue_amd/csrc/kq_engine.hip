@@ -27,17 +27,46 @@ __global__ __launch_bounds__(64) void k_nominate(K k, int slots) {
   for (int h = slot; h < k.H.n; h += slots) nominate_head(k, w, h, slot);
 }
 
+// Entry order (scheduler.go:1110-1163): rank = number of entries that precede. Keys are staged through
+// LDS in tiles so every thread compares against 256 keys per global round trip.
+struct OrderKey { int64_t prio, ts; int32_t borrow; uint32_t flags; };
 __global__ __launch_bounds__(256) void k_order(K k, int32_t* order_idx) {
+  __shared__ OrderKey tile[256];
+  const int n = k.H.n;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= k.H.n) return;
+  OrderKey me{0, 0, 0, 0};
+  if (i < n) me = OrderKey{k.H.priority[i], k.H.queue_ts[i], k.O.borrowing[i], k.H.flags[i]};
+  const bool pre = gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS), psort = gate(k, KQ_GATE_PRIORITY_SORTING_IN_COHORT);
   int rank = 0;
-  for (int j = 0; j < k.H.n; j++) rank += (j != i && entry_before(k, j, i)) ? 1 : 0;
-  order_idx[rank] = i;
+  for (int base = 0; base < n; base += 256) {
+    int j = base + threadIdx.x;
+    if (j < n) tile[threadIdx.x] = OrderKey{k.H.priority[j], k.H.queue_ts[j], k.O.borrowing[j], k.H.flags[j]};
+    __syncthreads();
+    const int m = (n - base) < 256 ? (n - base) : 256;
+    if (i < n)
+      for (int t = 0; t < m; t++) {
+        const OrderKey o = tile[t];
+        const int jj = base + t;
+        bool before;  // does entry jj precede entry i ?  (same predicate as kq::entry_before)
+        bool oq = o.flags & KQ_HEAD_HAS_QUOTA_RESERVATION, mq = me.flags & KQ_HEAD_HAS_QUOTA_RESERVATION;
+        bool op = o.flags & KQ_HEAD_IS_PREEMPTOR, mp = me.flags & KQ_HEAD_IS_PREEMPTOR;
+        if (oq != mq) before = oq;
+        else if (pre && op != mp) before = op;
+        else if (o.borrow != me.borrow) before = o.borrow < me.borrow;
+        else if (psort && o.prio != me.prio) before = o.prio > me.prio;
+        else if (o.ts != me.ts) before = o.ts < me.ts;
+        else before = jj < i;
+        rank += (jj != i && before) ? 1 : 0;
+      }
+    __syncthreads();
+  }
+  if (i < n) order_idx[rank] = i;
 }
 
-__global__ __launch_bounds__(64) void k_process(K k) {
+__global__ __launch_bounds__(64) void k_process(K k, unsigned lds_bytes) {
   __shared__ Wave w;
-  process_tree(k, w, blockIdx.x, blockIdx.x);
+  extern __shared__ __align__(16) unsigned char dyn_lds[];
+  process_tree(k, w, blockIdx.x, blockIdx.x, (int64_t*)dyn_lds, lds_bytes);
 }
 
 namespace kq {
@@ -94,10 +123,18 @@ struct HipBackend {
     hipLaunchKernelGGL(k_order, dim3((k.H.n + 255) / 256), dim3(256), 0, stream, k, order_idx);
     chk(hipGetLastError(), "k_order");
   }
-  void launch_process(const K& k, int n_tree) {
-    hipLaunchKernelGGL(k_process, dim3(n_tree), dim3(64), 0, stream, k);
+  // dynamic LDS = [cohort rows (2 planes) of the largest tree, if they fit][CH prefetched entry records]
+  void launch_process(const K& k, int n_tree, size_t cohort_rows_bytes) {
+    const size_t rec = sizeof(PRec) * CH, budget = 160 * 1024 - 8 * 1024;
+    size_t lds = rec + (cohort_rows_bytes + rec <= budget ? cohort_rows_bytes : 0);
+    if (lds > 48 * 1024 && lds != lds_attr) {
+      chk(hipFuncSetAttribute((const void*)k_process, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
+      lds_attr = lds;
+    }
+    hipLaunchKernelGGL(k_process, dim3(n_tree), dim3(64), lds, stream, k, (unsigned)lds);
     chk(hipGetLastError(), "k_process");
   }
+  size_t lds_attr = 0;
 };
 }  // namespace kq
 
@@ -198,6 +235,13 @@ int kq_snapshot_read_planes(kq_engine* en, int64_t* subtree_quota, int64_t* usag
 }
 
 const char* kq_last_error(kq_engine* en) { return en ? en->e.last_error.c_str() : "null engine"; }
+
+// profiling hook (KQ_PROF builds): 32 segment cycle counters accumulated since the last reset
+int kq_debug_prof(kq_engine* en, int64_t* out, int reset) {
+  if (!en) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.prof_read(out, reset != 0);
+}
 
 // test hook (not part of the drop-in boundary): snapshot usage as left by the last cycle
 int kq_debug_read_usage_work(kq_engine* en, int64_t* out) {

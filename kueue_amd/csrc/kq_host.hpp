@@ -31,7 +31,7 @@ template <class B> struct EngineT {
   // cycle buffers (grow-only)
   struct Buf { void* p = nullptr; size_t cap = 0; };
   std::vector<Buf*> all_bufs;
-  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc;
+  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom;
   struct HeadBatch { Buf hb[16]; DHeads H{}; int n = 0; size_t nps = 0; int slot_cap = 1; int64_t cycle = 0; bool valid = false; };
   std::vector<HeadBatch> batches;  // [0] = transient batch of kq_cycle_run, [1+b] = resident batch b
   Buf ob[24];  // output arrays
@@ -65,7 +65,7 @@ template <class B> struct EngineT {
   }
   ~EngineT() {
     free_snapshot();
-    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc}) if (b->p) be.free(b->p);
+    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom}) if (b->p) be.free(b->p);
     for (auto& hbch : batches) for (auto& b : hbch.hb) if (b.p) be.free(b.p);
     for (auto& b : ob) if (b.p) be.free(b.p);
   }
@@ -246,10 +246,12 @@ template <class B> struct EngineT {
     X.cls = grow<uint8_t>(b_cls, (size_t)slots * X.max_tree_rows);
     X.tgt_row = grow<int32_t>(b_tgt_row, (size_t)slots * X.tgt_cap);
     X.tgt_reason = grow<uint8_t>(b_tgt_reason, (size_t)slots * X.tgt_cap);
+    X.nom = grow<int32_t>(b_nom, (size_t)slots * KQ_MAXPS * nR);
     k.usage = d_usage;
     k.usage_work = grow<int64_t>(b_usage_work, Nfr);
     k.usage_np = grow<int64_t>(b_usage_np, Nfr);
     k.preempted = grow<uint8_t>(b_preempted, std::max(prep.n_adm, 1));
+    k.prof = (long long*)grow<int64_t>(b_prof, 32);
     int32_t* order_idx = grow<int32_t>(b_order, n);
     k.order_idx = order_idx;
     be.d2d(k.usage_work, d_usage, Nfr * sizeof(int64_t));
@@ -262,7 +264,7 @@ template <class B> struct EngineT {
     be.launch_order(k, order_idx);
     be.timer_mark(2);
     k.O.stat_bytes = (long long*)(misc + 2);
-    be.launch_process(k, prep.n_tree);
+    be.launch_process(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16);
     be.timer_mark(3);
 
     // decisions back
@@ -312,6 +314,13 @@ template <class B> struct EngineT {
     return KQ_OK;
   }
 
+  int prof_read(int64_t* out, bool reset) {
+    if (!b_prof.p) { for (int i = 0; i < 32; i++) out[i] = 0; return KQ_OK; }
+    be.d2h(out, b_prof.p, 32 * sizeof(int64_t));
+    int rc = be.sync();
+    if (reset) be.memset(b_prof.p, 0, 32 * sizeof(int64_t));
+    return rc;
+  }
   int read_usage_work(int64_t* out) {  // tests: snapshot usage after the cycle
     be.d2h(out, b_usage_work.p, (size_t)prep.N * prep.nfr * sizeof(int64_t));
     return be.sync();

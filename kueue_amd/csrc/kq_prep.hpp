@@ -33,7 +33,7 @@ struct Prep {
   std::vector<int32_t> cq_local;                   // [nq] index of the CQ inside tree_cqs of its tree
   std::vector<int32_t> tree_row_off, tree_rows;    // admitted rows of a tree, in static candidate rank order
   std::vector<int32_t> adm_cq;                     // [n_adm]
-  int max_tree_nodes = 0, max_tree_cqs = 0, max_tree_rows = 0;
+  int max_tree_nodes = 0, max_tree_cqs = 0, max_tree_rows = 0, max_tree_cohorts = 0;
   std::string err;
 };
 
@@ -72,6 +72,7 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
   for (int n = 0; n < N; n++) p.tree_node_off[p.tree_of[n] + 1]++;
   for (int c = 0; c < nq; c++) p.tree_cq_off[p.tree_of[c] + 1]++;
   for (int t = 0; t < p.n_tree; t++) { p.tree_node_off[t + 1] += p.tree_node_off[t]; p.tree_cq_off[t + 1] += p.tree_cq_off[t]; }
+  p.max_tree_nodes = p.max_tree_cqs = p.max_tree_rows = p.max_tree_cohorts = 0;
   p.tree_nodes.assign(N, 0); p.tree_cqs.assign(nq, 0); p.node_local.assign(N, 0); p.cq_local.assign(nq, 0);
   {
     std::vector<int32_t> fill(p.tree_node_off.begin(), p.tree_node_off.end() - 1);
@@ -120,6 +121,7 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
     p.max_tree_nodes = std::max(p.max_tree_nodes, p.tree_node_off[t + 1] - p.tree_node_off[t]);
     p.max_tree_cqs = std::max(p.max_tree_cqs, p.tree_cq_off[t + 1] - p.tree_cq_off[t]);
     p.max_tree_rows = std::max(p.max_tree_rows, p.tree_row_off[t + 1] - p.tree_row_off[t]);
+    p.max_tree_cohorts = std::max(p.max_tree_cohorts, (p.tree_node_off[t + 1] - p.tree_node_off[t]) - (p.tree_cq_off[t + 1] - p.tree_cq_off[t]));
   }
   // index validation
   for (int g = 0; g < p.n_rg; g++) {

@@ -21,6 +21,7 @@ struct EmuBackend {
   void memset(void* d, int v, size_t n) { ::memset(d, v, n); }
   int sync() { return KQ_OK; }
   const char* error() { return ""; }
+  int rot = 0;
   int max_slots() { return 7; }  // small on purpose: exercises the grid-stride loop over heads
   void timer_mark(int) {}
   double timer_ms(int, int) { return 0; }
@@ -37,8 +38,13 @@ struct EmuBackend {
       order_idx[rank] = i;
     }
   }
-  void launch_process(const K& k, int n_tree) {
-    for (int t = 0; t < n_tree; t++) { Wave w{}; process_tree(k, w, t, t); }
+  void launch_process(const K& k, int n_tree, size_t) {
+    // alternate between an LDS-sized cache and none so both code paths are exercised
+    // rotate LDS budgets so the chunked/LDS-resident, chunked/HBM-rows and unchunked paths are all exercised
+    std::vector<int64_t> lds(160 * 1024 / 8);
+    const size_t budgets[3] = {lds.size() * 8, sizeof(PRec) * CH + 64, 0};
+    for (int t = 0; t < n_tree; t++) { Wave w{}; process_tree(k, w, t, t, lds.data(), budgets[(t + rot) % 3]); }
+    rot++;
   }
 };
 }  // namespace kq

@@ -97,6 +97,13 @@ def random_case(seed, fair=False, preemption=True, max_cq=6, partial=False):
                 last_tried_flavor_idx=[{r: rnd.randint(-1, max(0, n_flavors - 2)) for r in ps.requests if r in RES} for ps in pods],
                 cluster_queue_generation=rnd.randint(0, 3), scheduling_cycle=rnd.randint(0, 5), scheduling_hash=rnd.choice([0, 7, 9]))
         pending.append(w)
+        if not fair and rnd.random() < 0.12:
+            # a second head on the same ClusterQueue (second-pass workloads come on top of one head per CQ,
+            # pkg/cache/queue/manager.go:923)
+            import copy
+            w2 = copy.deepcopy(w)
+            w2.name = f"{cq.name}-pend2"; w2.priority = rnd.randint(-1, 4); w2.creation_ts = rnd.randint(0, 60); w2.last_assignment = None
+            pending.append(w2)
     snap = Snapshot(cqs, cohorts, admitted, now_ns=1000, extra_resources=["uncovered.io/x"])
     heads = Heads(snap, pending, cycle=rnd.randint(1, 6))
     gates = {}

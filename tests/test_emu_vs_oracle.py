@@ -19,7 +19,7 @@ def run_both(oracle, cfg, snap, heads):
     return want, got
 
 
-@pytest.mark.parametrize("seed", range(300))
+@pytest.mark.parametrize("seed", range(600))
 def test_classical_random(oracle, seed):
     cfg, snap, heads = random_case(seed, fair=False, preemption=True, partial=(seed % 3 == 0))
     want, got = run_both(oracle, cfg, snap, heads)

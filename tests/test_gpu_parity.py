@@ -13,7 +13,7 @@ def engine_mod():
     return engine
 
 
-@pytest.mark.parametrize("block", range(10))
+@pytest.mark.parametrize("block", range(15))
 def test_random_cycles_bit_exact(oracle, engine_mod, block):
     for seed in range(block * 40, block * 40 + 40):
         cfg, snap, heads = random_case(seed, fair=False, preemption=True, partial=(seed % 3 == 0))

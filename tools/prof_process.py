@@ -1,0 +1,25 @@
+"""In-kernel segment timing of k_process (needs libkq_engine_prof.so built with -DKQ_PROF)."""
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from kueue_amd import _ffi as F
+F.ENGINE_LIB = os.path.join(F.HERE, "libkq_engine_prof.so")
+from kueue_amd.engine import Engine
+from kueue_amd.api import make_config
+from kueue_amd.population import generate
+pop = generate(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
+eng = Engine(make_config()); eng.put(pop.snapshot)
+lib = eng._lib
+lib.kq_debug_prof.argtypes = [C.c_void_p, F.i64p, C.c_int]
+prof = np.zeros(32, np.int64)
+for c in range(3):
+    eng.run(pop.heads_for_cycle(c))
+lib.kq_debug_prof(eng._h, F.ptr(prof), 1)
+n = 0
+for c in range(3, 13):
+    h = pop.heads_for_cycle(c); d = eng.run(h); n += h.n
+lib.kq_debug_prof(eng._h, F.ptr(prof), 1)
+names = {8: "pc_load", 9: "pc_flush", 10: "chunk_prefetch", 11: "chunk serial core", 12: "chunk write results", 0: "slow: load_head", 1: "slow: use list"}
+for i, nm in names.items():
+    print(f"{nm:28s} {prof[i]/n:10.1f} cycles/entry   total {prof[i]}")
+print("kernel ms last cycle", d.kernel_ms)
