@@ -30,6 +30,7 @@
 #ifdef KQ_HOST_EMU
 #define KQ_DEV static inline
 #define KQ_MDEV inline
+#define KQ_NOINLINE static
 namespace kq {
 constexpr int WAVE = 1;
 KQ_DEV int lane_id() { return 0; }
@@ -47,6 +48,7 @@ KQ_DEV int64_t wsum_i64(int64_t v) { return v; }
 #include <hip/hip_runtime.h>
 #define KQ_DEV __device__ __forceinline__
 #define KQ_MDEV __device__ __forceinline__
+#define KQ_NOINLINE __device__ __noinline__
 namespace kq {
 constexpr int WAVE = 64;
 KQ_DEV int lane_id() { return (int)(threadIdx.x & 63); }
@@ -1128,27 +1130,27 @@ KQ_DEV UP up_plane(const K& k, const Wave& w, int plane, int fr) {
   return UP{&k.S, plane == 0 ? k.usage_work : k.usage_np, w.pc_lds, w.pc_on, w.pc_ncq, w.pc_ncoh, plane, fr};
 }
 // LDS <-> HBM for the tree's cohort rows (both planes)
-KQ_DEV void pc_load(const K& k, Wave& w, int tree) {
+KQ_DEV void pc_load(const K& k, Wave& w, int64_t* pcl, int tree) {
   const DSnap& S = k.S;
   if (!w.pc_on) return;
   const int n0 = S.tree_node_off[tree] + w.pc_ncq;
   const int total = w.pc_ncoh * S.nfr;
   for (int i = lane_id(); i < total; i += WAVE) {
     int node = S.tree_nodes[n0 + i / S.nfr], fr = i % S.nfr;
-    w.pc_lds[i] = k.usage_work[ix(S, node, fr)];
-    w.pc_lds[(size_t)total + i] = k.usage_np[ix(S, node, fr)];
+    pcl[i] = k.usage_work[ix(S, node, fr)];
+    pcl[(size_t)total + i] = k.usage_np[ix(S, node, fr)];
   }
   wsync();
 }
-KQ_DEV void pc_flush(const K& k, Wave& w, int tree) {
+KQ_DEV void pc_flush(const K& k, Wave& w, int64_t* pcl, int tree) {
   const DSnap& S = k.S;
   if (!w.pc_on) return;
   const int n0 = S.tree_node_off[tree] + w.pc_ncq;
   const int total = w.pc_ncoh * S.nfr;
   for (int i = lane_id(); i < total; i += WAVE) {
     int node = S.tree_nodes[n0 + i / S.nfr], fr = i % S.nfr;
-    k.usage_work[ix(S, node, fr)] = w.pc_lds[i];
-    k.usage_np[ix(S, node, fr)] = w.pc_lds[(size_t)total + i];
+    k.usage_work[ix(S, node, fr)] = pcl[i];
+    k.usage_np[ix(S, node, fr)] = pcl[(size_t)total + i];
   }
   wsync();
 }
@@ -1308,7 +1310,10 @@ KQ_DEV void process_entry_fast(const K& k, Wave& w, int e) {
   KQ_TS(k, 7);
 }
 
-KQ_DEV void process_entry(const K& k, Wave& w, int e, int pos, int slot, int tree) {
+// Generic path (preemption targets, overlap recomputation, oversize entries). Deliberately NOT inlined: it
+// drags in the whole nominate machinery, and inlining it into the hot loop of k_process bloats the kernel
+// past the instruction cache and forces SGPR spills in the serial core.
+KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, int tree) {
   const DSnap& S = k.S; const DOut& O = k.O;
   const int lane = lane_id();
   KQ_T0();
@@ -1342,7 +1347,7 @@ KQ_DEV void process_entry(const K& k, Wave& w, int e, int pos, int slot, int tre
   if (has_any() && gate(k, KQ_GATE_RECOMPUTE_ON_OVERLAP)) {
     // SimulateWorkloadRemoval(victimsOfOtherPreemptions) == evaluate on usage_np with those rows deleted.
     // The generic nominate code reads HBM planes: publish the LDS-resident cohort rows first.
-    pc_flush(k, w, tree);
+    pc_flush(k, w, w.pc_lds, tree);
     if (lane == 0) w.has_last = 0;
     // e.NominationMapping = e.readResourceToFlavorMapping() (scheduler.go:734): fixed for the whole recomputation
     for (int i = lane; i < w.nps * S.nR; i += WAVE) k.X.nom[(size_t)slot * KQ_MAXPS * S.nR + i] = O.flavor[(size_t)w.ps_base * S.nR + i];
@@ -1486,86 +1491,128 @@ KQ_DEV void chunk_scatter(const K& k, PRec* rec, int n) {
   wsync();
 }
 
-// serial core for one fast entry: lanes = flavor-resource slots; only LDS is touched, except the CQ-level
-// cells that are written through to HBM.
-KQ_DEV void chunk_entry_fast(const K& k, Wave& w, PRec& r, int64_t* bytes) {
-  const DSnap& S = k.S;
-  const int lane = lane_id();
-  const int plen = r.plen, nuse = r.nuse, mode = r.mode;
-  const int total = w.pc_ncoh * S.nfr;
-  if (nuse > 0) *bytes += (int64_t)nuse * 40 * plen;  // scheduler.fits runs before the mode is looked at
-  if (mode == M_NOFIT) { r.status = KQ_ST_NOT_NOMINATED; r.action = KQ_ACT_NONE; r.rq = KQ_RQ_NOFIT; r.skip = KQ_SKIP_NONE; r.omode = (uint8_t)mode; return; }
-  int64_t un[FD], uw[FD], lq[FD], sq[FD], blv[FD];
-  auto load_slot = [&](int u, int fr) {
-    #pragma unroll
-    for (int i = 0; i < FD; i++) {
-      if (i < plen) {
-        lq[i] = r.lq[u][i]; sq[i] = r.sqv[u][i]; blv[i] = r.bl[u][i];
-        if (i == 0) { uw[0] = r.uw0[u]; un[0] = r.un0[u]; }
-        else { size_t l = (size_t)r.coh[i] * S.nfr + fr; uw[i] = w.pc_lds[l]; un[i] = w.pc_lds[(size_t)total + l]; }
-      }
-    }
-  };
-  bool bad = false;
-  for (int u = lane; u < nuse; u += WAVE) {  // one pass on the device (nuse <= FU < 64)
-    const int fr = r.fr[u];
-    load_slot(u, fr);
-    // Available(cq, fr) on usage_np, root first (resource_node.go:106-122)
-    int64_t a = 0;
-    #pragma unroll
-    for (int i = FD - 1; i >= 0; i--) {
-      if (i >= plen) continue;
-      if (i == plen - 1) { a = a_sub(sq[i], un[i]); continue; }
-      if (blv[i] != KQ_NIL_LIMIT) a = i64min(a_add(a_sub(a_sub(sq[i], lq[i]), i64max(0, a_sub(un[i], lq[i]))), blv[i]), a);
-      a = a_add(i64max(0, a_sub(lq[i], un[i])), a);
-    }
-    if (i64max(0, a) < r.qty[u]) bad = true;
+// ---- serial core ------------------------------------------------------------------------------------
+// One lane per flavor-resource slot, everything in registers, straight-line code specialised on the path
+// length. It only handles the PLAIN case: every operand (quota constants, both usage planes, the request) is
+// a bounded non-negative quantity < 2^56, so the saturation / Unlimited branches of resources.Amount
+// (amount.go:114-145) cannot trigger and plain 64-bit add/sub/min/max are bit-identical to them. Anything
+// else (Unlimited quota cells, over-large values) returns false and takes the generic exact path.
+constexpr int64_t PLAIN_LIMIT = (int64_t)1 << 56;
+
+template <int PLEN> struct SlotState { int64_t un[PLEN], uw[PLEN], lq[PLEN], sq[PLEN], bl[PLEN], qty, nominal; int cidx[PLEN]; };
+
+// `pcl` is the LDS base of the cohort rows, passed down explicitly (NOT re-read from Wave::pc_lds) so that after
+// inlining the compiler still knows the address space and emits ds_* instead of flat_* in the serial core.
+template <int PLEN> KQ_DEV void slot_load(const K& k, const Wave& w, const int64_t* pcl, const PRec& r, int u, SlotState<PLEN>& x) {
+  const int nfr = k.S.nfr, total = w.pc_ncoh * nfr, fr = r.fr[u];
+  x.qty = r.qty[u]; x.nominal = r.nominal[u];
+  #pragma unroll
+  for (int i = 0; i < PLEN; i++) {
+    x.lq[i] = r.lq[u][i]; x.sq[i] = r.sqv[u][i]; x.bl[i] = r.bl[u][i];
+    x.cidx[i] = i == 0 ? 0 : r.coh[i] * nfr + fr;
   }
+  x.uw[0] = r.uw0[u]; x.un[0] = r.un0[u];
+  #pragma unroll
+  for (int i = 1; i < PLEN; i++) { x.uw[i] = pcl[x.cidx[i]]; x.un[i] = pcl[total + x.cidx[i]]; }
+}
+
+template <bool PLAIN> KQ_DEV int64_t q_add(int64_t a, int64_t b) { if (PLAIN) return a + b; return a_add(a, b); }
+template <bool PLAIN> KQ_DEV int64_t q_sub(int64_t a, int64_t b) { if (PLAIN) return a - b; return a_sub(a, b); }
+
+// PLAIN = true : returns false (and does nothing) when some operand is not plain.
+// PLAIN = false: exact resources.Amount arithmetic, always succeeds.
+template <int PLEN, bool PLAIN> KQ_DEV bool core_run(const K& k, Wave& w, int64_t* pcl, PRec& r, int64_t* bytes) {
+  const int lane = lane_id();
+  const int nuse = r.nuse, mode = r.mode;
+  const int total = w.pc_ncoh * k.S.nfr;
+  SlotState<PLEN> x;
+  bool notplain = false, bad = false;
+  // one pass on the device (nuse <= FU < 64 lanes); the 1-lane emulation walks the slots one by one
+  for (int u = lane; u < nuse; u += WAVE) {
+    slot_load<PLEN>(k, w, pcl, r, u, x);
+    uint64_t big = (uint64_t)x.qty | (uint64_t)x.nominal;
+    #pragma unroll
+    for (int i = 0; i < PLEN; i++) big |= (uint64_t)x.un[i] | (uint64_t)x.uw[i] | (uint64_t)x.lq[i] | (uint64_t)x.sq[i] | (x.bl[i] == KQ_NIL_LIMIT ? 0ull : (uint64_t)x.bl[i]);
+    if (PLAIN && big >= (uint64_t)PLAIN_LIMIT) { notplain = true; continue; }  // negatives and Unlimited land here too
+    // scheduler.fits: Available(cq, fr) on usage_np, root first (resource_node.go:106-122)
+    int64_t a = q_sub<PLAIN>(x.sq[PLEN - 1], x.un[PLEN - 1]);
+    #pragma unroll
+    for (int i = PLEN - 2; i >= 0; i--) {
+      const int64_t wm = q_add<PLAIN>(q_sub<PLAIN>(q_sub<PLAIN>(x.sq[i], x.lq[i]), i64max(0, q_sub<PLAIN>(x.un[i], x.lq[i]))), x.bl[i]);
+      a = (x.bl[i] != KQ_NIL_LIMIT && wm < a) ? wm : a;
+      a = q_add<PLAIN>(i64max(0, q_sub<PLAIN>(x.lq[i], x.un[i])), a);
+    }
+    if (i64max(0, a) < x.qty) bad = true;
+  }
+  if (PLAIN && wballot(notplain) != 0) return false;
   const bool fits_ok = wballot(bad) == 0;
   int status = KQ_ST_NOT_NOMINATED, action = KQ_ACT_NONE, rq = KQ_RQ_GENERIC, skip = KQ_SKIP_NONE;
   bool add = false, reserve = false;
   if (mode == M_PREEMPT) {  // no targets: reserveCapacityForUnreclaimablePreempt scheduler.go:538-543
     rq = KQ_RQ_PREEMPTION_NO_CANDIDATES;
-    bool can_always_reclaim = KQ_POL_RECLAIM(r.pol) == KQ_POLICY_ANY;
+    const bool can_always_reclaim = KQ_POL_RECLAIM(r.pol) == KQ_POLICY_ANY;
     reserve = add = !can_always_reclaim || (gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS) && (r.flags & KQ_HEAD_IS_PREEMPTOR));
   } else if (!fits_ok) {
-    status = KQ_ST_SKIPPED; skip = KQ_SKIP_NO_LONGER_FITS;
+    status = KQ_ST_SKIPPED; skip = KQ_SKIP_NO_LONGER_FITS; rq = KQ_RQ_FAILED_AFTER_NOMINATION;  // scheduler.go:1167-1170
   } else {
     add = true; status = KQ_ST_ASSUMED; action = KQ_ACT_ADMIT;
   }
-  if (add && nuse > 0) {
-    *bytes += (int64_t)nuse * 8 * plen;
+  if (add) {
+    *bytes += (int64_t)nuse * 8 * PLEN;
     for (int u = lane; u < nuse; u += WAVE) {
-      const int fr = r.fr[u];
-      load_slot(u, fr);
-      int64_t val = reserve ? reserve_amount(r.qty[u], r.nominal[u], blv[0], uw[0], r.borrowing) : r.qty[u];
-      int64_t v = val;  // addUsage resource_node.go:144-152 on usage_work
+      if (WAVE < FU) slot_load<PLEN>(k, w, pcl, r, u, x);  // device: registers of the first pass are still live
+      int64_t val = x.qty;
+      if (reserve) {  // quotaResourcesToReserve scheduler.go:796-814
+        if (r.borrowing > 0) val = x.bl[0] == KQ_NIL_LIMIT ? x.qty : i64min(x.qty, q_sub<PLAIN>(q_add<PLAIN>(x.nominal, x.bl[0]), x.uw[0]));
+        else val = i64max(0, i64min(x.qty, q_sub<PLAIN>(x.nominal, x.uw[0])));
+      }
+      // addUsage resource_node.go:144-152 on usage_work, then on usage_np
+      int64_t v = val;
       bool go = true;
       #pragma unroll
-      for (int i = 0; i < FD; i++) {
-        if (i < plen && go) {
-          int64_t la = i64max(0, a_sub(lq[i], uw[i]));
-          int64_t nu = a_add(uw[i], v);
-          if (i == 0) r.uw0[u] = nu; else w.pc_lds[(size_t)r.coh[i] * S.nfr + fr] = nu;
-          if (i + 1 < plen && v > la) v = a_sub(v, la); else go = false;
-        }
+      for (int i = 0; i < PLEN; i++) {
+        const int64_t la = i64max(0, q_sub<PLAIN>(x.lq[i], x.uw[i]));
+        if (go) { if (i == 0) r.uw0[u] = q_add<PLAIN>(x.uw[0], v); else pcl[x.cidx[i]] = q_add<PLAIN>(x.uw[i], v); }
+        go = go && (i + 1 < PLEN) && v > la;
+        v = q_sub<PLAIN>(v, la);
       }
-      v = val; go = true;  // ... and on usage_np
+      v = val; go = true;
       #pragma unroll
-      for (int i = 0; i < FD; i++) {
-        if (i < plen && go) {
-          int64_t la = i64max(0, a_sub(lq[i], un[i]));
-          int64_t nu = a_add(un[i], v);
-          if (i == 0) r.un0[u] = nu; else w.pc_lds[(size_t)total + (size_t)r.coh[i] * S.nfr + fr] = nu;
-          if (i + 1 < plen && v > la) v = a_sub(v, la); else go = false;
-        }
+      for (int i = 0; i < PLEN; i++) {
+        const int64_t la = i64max(0, q_sub<PLAIN>(x.lq[i], x.un[i]));
+        if (go) { if (i == 0) r.un0[u] = q_add<PLAIN>(x.un[0], v); else pcl[total + x.cidx[i]] = q_add<PLAIN>(x.un[i], v); }
+        go = go && (i + 1 < PLEN) && v > la;
+        v = q_sub<PLAIN>(v, la);
       }
     }
     if (lane == 0) r.dirty = 1;
     wsync_lds();  // cohort rows in LDS must be visible to the next entry's lanes
   }
-  if (status != KQ_ST_NOT_NOMINATED && status != KQ_ST_ASSUMED && rq == KQ_RQ_GENERIC) rq = KQ_RQ_FAILED_AFTER_NOMINATION;  // scheduler.go:1167-1170
   if (lane == 0) { r.status = (uint8_t)status; r.action = (uint8_t)action; r.rq = (uint8_t)rq; r.skip = (uint8_t)skip; r.omode = (uint8_t)mode; }
+  return true;
+}
+
+// serial core dispatch for one fast entry; false => the entry needs the generic exact path
+KQ_DEV bool chunk_entry_fast(const K& k, Wave& w, int64_t* pcl, PRec& r, int64_t* bytes) {
+  const int plen = r.plen, nuse = r.nuse, mode = r.mode;
+  if (mode == M_NOFIT || nuse == 0) {
+    // scheduler.fits still runs before the mode is looked at (updateAssignmentIfNeeded :713-714)
+    if (nuse > 0) *bytes += (int64_t)nuse * 40 * plen;
+    int status = KQ_ST_NOT_NOMINATED, action = KQ_ACT_NONE, rq = KQ_RQ_GENERIC;
+    if (mode == M_NOFIT) rq = KQ_RQ_NOFIT;
+    else if (mode == M_PREEMPT) rq = KQ_RQ_PREEMPTION_NO_CANDIDATES;
+    else { status = KQ_ST_ASSUMED; action = KQ_ACT_ADMIT; }  // no quota usage: fits trivially
+    if (lane_id() == 0) { r.status = (uint8_t)status; r.action = (uint8_t)action; r.rq = (uint8_t)rq; r.skip = KQ_SKIP_NONE; r.omode = (uint8_t)mode; }
+    return true;
+  }
+  switch (plen) {
+    case 1: if (!core_run<1, true>(k, w, pcl, r, bytes)) core_run<1, false>(k, w, pcl, r, bytes); break;
+    case 2: if (!core_run<2, true>(k, w, pcl, r, bytes)) core_run<2, false>(k, w, pcl, r, bytes); break;
+    case 3: if (!core_run<3, true>(k, w, pcl, r, bytes)) core_run<3, false>(k, w, pcl, r, bytes); break;
+    default: if (!core_run<4, true>(k, w, pcl, r, bytes)) core_run<4, false>(k, w, pcl, r, bytes); break;
+  }
+  *bytes += (int64_t)nuse * 40 * plen;
+  return true;
 }
 
 // one wave per root-cohort tree: drain the tree's entries in iterator order.
@@ -1602,7 +1649,7 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
     }
     if (nwin == 0) continue;
     wsync();
-    if (!loaded) { KQ_T0(); pc_load(k, w, tree); loaded = true; KQ_TS(k, 8); }
+    if (!loaded) { KQ_T0(); pc_load(k, w, lds, tree); loaded = true; KQ_TS(k, 8); }
     if (!chunked) {
       for (int q = 0; q < nwin; q++) process_entry(k, w, w.win_e[q], w.win_pos[q], slot, tree);
       continue;
@@ -1627,7 +1674,16 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
           j++;
           break;
         }
-        chunk_entry_fast(k, w, r, &bytes);
+        if (!chunk_entry_fast(k, w, lds, r, &bytes)) {
+          // not a PLAIN entry (Unlimited / over-large operands): exact generic path, then restart the chunk
+          chunk_scatter(k, rec, j);
+          wsync();
+          process_entry(k, w, r.e, r.pos, slot, tree);
+          if (lane == 0) r.slow = 2;
+          wsync();
+          j++;
+          break;
+        }
       }
       KQ_TS(k, 11);
       wsync();
@@ -1644,7 +1700,7 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
     }
   }
   if (lane == 0 && bytes) atomic_add_i64(O.stat_bytes, (long long)bytes);
-  if (loaded) { KQ_T0(); pc_flush(k, w, tree); KQ_TS(k, 9); }
+  if (loaded) { KQ_T0(); pc_flush(k, w, lds, tree); KQ_TS(k, 9); }
 }
 
 // classical entry order (scheduler.go:1110-1163): a precedes b

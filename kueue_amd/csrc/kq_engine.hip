@@ -21,49 +21,57 @@
 
 using namespace kq;
 
-__global__ __launch_bounds__(64) void k_nominate(K k, int slots) {
+// Kernels take the argument block K by pointer (it lives in HBM and is read through the scalar cache):
+// passing ~700 B by value makes the compiler spill it to scratch as soon as any non-inlined device
+// function takes a reference to it, which put scratch loads into the serial core of k_process.
+__global__ __launch_bounds__(64) void k_nominate(const K* __restrict__ kp, int slots) {
+  const K& k = *kp;
   __shared__ Wave w;
   const int slot = blockIdx.x;
   for (int h = slot; h < k.H.n; h += slots) nominate_head(k, w, h, slot);
 }
 
-// Entry order (scheduler.go:1110-1163): rank = number of entries that precede. Keys are staged through
-// LDS in tiles so every thread compares against 256 keys per global round trip.
+// Entry order (scheduler.go:1110-1163): rank(i) = number of entries that precede i. 2-D grid: block (bi, bj)
+// compares 256 entries i against a 256-key tile j staged in LDS and adds its partial count to rank[i];
+// k_order_scatter then writes order_idx[rank[i]] = i. H^2/65536 blocks keep more CUs busy than H/256.
 struct OrderKey { int64_t prio, ts; int32_t borrow; uint32_t flags; };
-__global__ __launch_bounds__(256) void k_order(K k, int32_t* order_idx) {
+__global__ __launch_bounds__(256) void k_order(const K* __restrict__ kp, int32_t* rank) {
+  const K& k = *kp;
   __shared__ OrderKey tile[256];
   const int n = k.H.n;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  OrderKey me{0, 0, 0, 0};
-  if (i < n) me = OrderKey{k.H.priority[i], k.H.queue_ts[i], k.O.borrowing[i], k.H.flags[i]};
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int base = blockIdx.y * 256;
+  const int j = base + threadIdx.x;
+  if (j < n) tile[threadIdx.x] = OrderKey{k.H.priority[j], k.H.queue_ts[j], k.O.borrowing[j], k.H.flags[j]};
+  __syncthreads();
+  if (i >= n) return;
+  const OrderKey me{k.H.priority[i], k.H.queue_ts[i], k.O.borrowing[i], k.H.flags[i]};
   const bool pre = gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS), psort = gate(k, KQ_GATE_PRIORITY_SORTING_IN_COHORT);
-  int rank = 0;
-  for (int base = 0; base < n; base += 256) {
-    int j = base + threadIdx.x;
-    if (j < n) tile[threadIdx.x] = OrderKey{k.H.priority[j], k.H.queue_ts[j], k.O.borrowing[j], k.H.flags[j]};
-    __syncthreads();
-    const int m = (n - base) < 256 ? (n - base) : 256;
-    if (i < n)
-      for (int t = 0; t < m; t++) {
-        const OrderKey o = tile[t];
-        const int jj = base + t;
-        bool before;  // does entry jj precede entry i ?  (same predicate as kq::entry_before)
-        bool oq = o.flags & KQ_HEAD_HAS_QUOTA_RESERVATION, mq = me.flags & KQ_HEAD_HAS_QUOTA_RESERVATION;
-        bool op = o.flags & KQ_HEAD_IS_PREEMPTOR, mp = me.flags & KQ_HEAD_IS_PREEMPTOR;
-        if (oq != mq) before = oq;
-        else if (pre && op != mp) before = op;
-        else if (o.borrow != me.borrow) before = o.borrow < me.borrow;
-        else if (psort && o.prio != me.prio) before = o.prio > me.prio;
-        else if (o.ts != me.ts) before = o.ts < me.ts;
-        else before = jj < i;
-        rank += (jj != i && before) ? 1 : 0;
-      }
-    __syncthreads();
+  const bool mq = me.flags & KQ_HEAD_HAS_QUOTA_RESERVATION, mp = me.flags & KQ_HEAD_IS_PREEMPTOR;
+  const int m = (n - base) < 256 ? (n - base) : 256;
+  int cnt = 0;
+  for (int t = 0; t < m; t++) {
+    const OrderKey o = tile[t];
+    const int jj = base + t;
+    bool before;  // does entry jj precede entry i ?  (same predicate as kq::entry_before)
+    const bool oq = o.flags & KQ_HEAD_HAS_QUOTA_RESERVATION, op = o.flags & KQ_HEAD_IS_PREEMPTOR;
+    if (oq != mq) before = oq;
+    else if (pre && op != mp) before = op;
+    else if (o.borrow != me.borrow) before = o.borrow < me.borrow;
+    else if (psort && o.prio != me.prio) before = o.prio > me.prio;
+    else if (o.ts != me.ts) before = o.ts < me.ts;
+    else before = jj < i;
+    cnt += (jj != i && before) ? 1 : 0;
   }
-  if (i < n) order_idx[rank] = i;
+  if (cnt) atomicAdd(&rank[i], cnt);
+}
+__global__ __launch_bounds__(256) void k_order_scatter(int n, const int32_t* rank, int32_t* order_idx) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) order_idx[rank[i]] = i;
 }
 
-__global__ __launch_bounds__(64) void k_process(K k, unsigned lds_bytes) {
+__global__ __launch_bounds__(64) void k_process(const K* __restrict__ kp, unsigned lds_bytes) {
+  const K& k = *kp;
   __shared__ Wave w;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
   process_tree(k, w, blockIdx.x, blockIdx.x, (int64_t*)dyn_lds, lds_bytes);
@@ -97,6 +105,7 @@ struct HipBackend {
   }
   void destroy() {
     for (auto& e2 : ev) if (e2) (void)hipEventDestroy(e2);
+    for (auto& d : dk) if (d) (void)hipFree(d);
     if (stream) (void)hipStreamDestroy(stream);
   }
   void* alloc(size_t n) { void* p = nullptr; chk(hipMalloc(&p, n), "hipMalloc"); return p; }
@@ -115,12 +124,23 @@ struct HipBackend {
   // HIP events on the engine's own stream bracket each kernel (live per-kernel duration)
   void timer_mark(int i) { chk(hipEventRecord(ev[i], stream), "hipEventRecord"); }
   double timer_ms(int a, int b) { float ms = 0; chk(hipEventElapsedTime(&ms, ev[a], ev[b]), "hipEventElapsedTime"); return ms; }
+  K* dk[2] = {nullptr, nullptr};   // device copies of the argument block (nominate/order, process)
+  K hk[2];                         // host staging must outlive the async copy
+  const K* put_k(const K& k, int which) {
+    if (!dk[which]) chk(hipMalloc((void**)&dk[which], sizeof(K)), "hipMalloc K");
+    hk[which] = k;
+    chk(hipMemcpyAsync(dk[which], &hk[which], sizeof(K), hipMemcpyHostToDevice, stream), "memcpy K");
+    return dk[which];
+  }
   void launch_nominate(const K& k, int slots) {
-    hipLaunchKernelGGL(k_nominate, dim3(slots), dim3(64), 0, stream, k, slots);
+    hipLaunchKernelGGL(k_nominate, dim3(slots), dim3(64), 0, stream, put_k(k, 0), slots);
     chk(hipGetLastError(), "k_nominate");
   }
-  void launch_order(const K& k, int32_t* order_idx) {
-    hipLaunchKernelGGL(k_order, dim3((k.H.n + 255) / 256), dim3(256), 0, stream, k, order_idx);
+  void launch_order(const K& k, int32_t* order_idx, int32_t* rank) {
+    const int nb = (k.H.n + 255) / 256;
+    chk(hipMemsetAsync(rank, 0, (size_t)k.H.n * sizeof(int32_t), stream), "memset rank");
+    hipLaunchKernelGGL(k_order, dim3(nb, nb), dim3(256), 0, stream, (const K*)dk[0], rank);
+    hipLaunchKernelGGL(k_order_scatter, dim3(nb), dim3(256), 0, stream, k.H.n, (const int32_t*)rank, order_idx);
     chk(hipGetLastError(), "k_order");
   }
   // dynamic LDS = [cohort rows (2 planes) of the largest tree, if they fit][CH prefetched entry records]
@@ -131,7 +151,7 @@ struct HipBackend {
       chk(hipFuncSetAttribute((const void*)k_process, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
       lds_attr = lds;
     }
-    hipLaunchKernelGGL(k_process, dim3(n_tree), dim3(64), lds, stream, k, (unsigned)lds);
+    hipLaunchKernelGGL(k_process, dim3(n_tree), dim3(64), lds, stream, put_k(k, 1), (unsigned)lds);
     chk(hipGetLastError(), "k_process");
   }
   size_t lds_attr = 0;

@@ -31,7 +31,7 @@ template <class B> struct EngineT {
   // cycle buffers (grow-only)
   struct Buf { void* p = nullptr; size_t cap = 0; };
   std::vector<Buf*> all_bufs;
-  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom;
+  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank;
   struct HeadBatch { Buf hb[16]; DHeads H{}; int n = 0; size_t nps = 0; int slot_cap = 1; int64_t cycle = 0; bool valid = false; };
   std::vector<HeadBatch> batches;  // [0] = transient batch of kq_cycle_run, [1+b] = resident batch b
   Buf ob[24];  // output arrays
@@ -65,7 +65,7 @@ template <class B> struct EngineT {
   }
   ~EngineT() {
     free_snapshot();
-    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom}) if (b->p) be.free(b->p);
+    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank}) if (b->p) be.free(b->p);
     for (auto& hbch : batches) for (auto& b : hbch.hb) if (b.p) be.free(b.p);
     for (auto& b : ob) if (b.p) be.free(b.p);
   }
@@ -261,7 +261,7 @@ template <class B> struct EngineT {
     be.timer_mark(0);
     be.launch_nominate(k, slots_nom);
     be.timer_mark(1);
-    be.launch_order(k, order_idx);
+    be.launch_order(k, order_idx, grow<int32_t>(b_rank, n));
     be.timer_mark(2);
     k.O.stat_bytes = (long long*)(misc + 2);
     be.launch_process(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16);

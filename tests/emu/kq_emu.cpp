@@ -31,7 +31,7 @@ struct EmuBackend {
       for (int h = slot; h < k.H.n; h += slots) nominate_head(k, w, h, slot);
     }
   }
-  void launch_order(const K& k, int32_t* order_idx) {
+  void launch_order(const K& k, int32_t* order_idx, int32_t*) {
     for (int i = 0; i < k.H.n; i++) {
       int rank = 0;
       for (int j = 0; j < k.H.n; j++) if (j != i && entry_before(k, j, i)) rank++;

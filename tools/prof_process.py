@@ -19,7 +19,7 @@ n = 0
 for c in range(3, 13):
     h = pop.heads_for_cycle(c); d = eng.run(h); n += h.n
 lib.kq_debug_prof(eng._h, F.ptr(prof), 1)
-names = {8: "pc_load", 9: "pc_flush", 10: "chunk_prefetch", 11: "chunk serial core", 12: "chunk write results", 0: "slow: load_head", 1: "slow: use list"}
+names = {8: "pc_load", 9: "pc_flush", 10: "chunk_prefetch", 11: "chunk serial core",  12: "chunk write results", 0: "slow: load_head", 1: "slow: use list"}
 for i, nm in names.items():
     print(f"{nm:28s} {prof[i]/n:10.1f} cycles/entry   total {prof[i]}")
 print("kernel ms last cycle", d.kernel_ms)
