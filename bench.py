@@ -67,7 +67,7 @@ def main():
     import ctypes as C
     for b, hb in enumerate(batches):
         eng._check(lib.kq_heads_put(h, C.byref(hb.struct()), b))
-    outs = [Decisions(hb, tgt_cap=max(4096, snap.n_adm)) for hb in batches]
+    outs = [Decisions(hb, tgt_cap=max(4096, 4 * snap.n_adm)) for hb in batches]
     phase_ms = np.zeros(3, np.float64)
     phase_by = np.zeros(2, np.int64)
 

@@ -110,6 +110,8 @@ struct HipBackend {
   }
   void* alloc(size_t n) { void* p = nullptr; chk(hipMalloc(&p, n), "hipMalloc"); return p; }
   void free(void* p) { (void)hipFree(p); }
+  void* alloc_host(size_t n) { void* p = nullptr; chk(hipHostMalloc(&p, n, hipHostMallocDefault), "hipHostMalloc"); return p; }
+  void free_host(void* p) { (void)hipHostFree(p); }
   void h2d(void* d, const void* h, size_t n) { chk(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, stream), "h2d"); }
   void d2h(void* h, const void* d, size_t n) { chk(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream), "d2h"); }
   void d2d(void* d, const void* s, size_t n) { chk(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, stream), "d2d"); }

@@ -35,6 +35,8 @@ template <class B> struct EngineT {
   struct HeadBatch { Buf hb[16]; DHeads H{}; int n = 0; size_t nps = 0; int slot_cap = 1; int64_t cycle = 0; bool valid = false; };
   std::vector<HeadBatch> batches;  // [0] = transient batch of kq_cycle_run, [1+b] = resident batch b
   Buf ob[24];  // output arrays
+  uint8_t* hstage = nullptr;  // pinned host staging for the packed decisions
+  size_t hstage_cap = 0;
   double last_kernel_ms = 0;
   double last_phase_ms[3] = {0, 0, 0};
   int64_t last_bytes = 0;
@@ -65,6 +67,7 @@ template <class B> struct EngineT {
   }
   ~EngineT() {
     free_snapshot();
+    if (hstage) be.free_host(hstage);
     for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank}) if (b->p) be.free(b->p);
     for (auto& hbch : batches) for (auto& b : hbch.hb) if (b.p) be.free(b.p);
     for (auto& b : ob) if (b.p) be.free(b.p);
@@ -220,17 +223,26 @@ template <class B> struct EngineT {
     // outputs
     const int pool_cap = std::max(out->tgt_cap, 1);
     DOut& O = k.O;
-    O.status = grow<uint8_t>(ob[0], n); O.action = grow<uint8_t>(ob[1], n); O.nominated_mode = grow<uint8_t>(ob[2], n);
-    O.mode = grow<uint8_t>(ob[3], n); O.requeue_reason = grow<uint8_t>(ob[4], n); O.skip = grow<uint8_t>(ob[5], n);
-    O.borrowing = grow<int32_t>(ob[6], n); O.order = grow<int32_t>(ob[7], n);
-    O.flavor = grow<int32_t>(ob[8], nps * nR); O.res_mode = grow<uint8_t>(ob[9], nps * nR); O.tried_idx = grow<int32_t>(ob[10], nps * nR);
-    O.ps_count = grow<int32_t>(ob[11], nps);
+    // every array that goes back to the host lives in ONE packed device region -> a single D2H per cycle
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 15) & ~(size_t)15; return o; };
+    const size_t o_status = carve(n), o_action = carve(n), o_nmode = carve(n), o_mode = carve(n), o_rq = carve(n), o_skip = carve(n);
+    const size_t o_borrow = carve((size_t)n * 4), o_order = carve((size_t)n * 4);
+    const size_t o_flavor = carve(nps * nR * 4), o_rmode = carve(nps * nR), o_tried = carve(nps * nR * 4), o_pscount = carve(nps * 4);
+    const size_t o_tpos = carve((size_t)n * 4), o_tn = carve((size_t)n * 4), o_misc = carve(4 * sizeof(int64_t));
+    const size_t pack_bytes = off;
+    uint8_t* pack = grow<uint8_t>(ob[0], pack_bytes);
+    O.status = pack + o_status; O.action = pack + o_action; O.nominated_mode = pack + o_nmode; O.mode = pack + o_mode;
+    O.requeue_reason = pack + o_rq; O.skip = pack + o_skip;
+    O.borrowing = (int32_t*)(pack + o_borrow); O.order = (int32_t*)(pack + o_order);
+    O.flavor = (int32_t*)(pack + o_flavor); O.res_mode = pack + o_rmode; O.tried_idx = (int32_t*)(pack + o_tried);
+    O.ps_count = (int32_t*)(pack + o_pscount);
     O.use_n = grow<int32_t>(ob[12], n); O.use_fr = grow<int32_t>(ob[13], (size_t)n * KQ_MAXU); O.use_qty = grow<int64_t>(ob[14], (size_t)n * KQ_MAXU);
-    O.tgt_pos = grow<int32_t>(ob[15], n); O.tgt_n = grow<int32_t>(ob[16], n);
+    O.tgt_pos = (int32_t*)(pack + o_tpos); O.tgt_n = (int32_t*)(pack + o_tn);
     // recomputation on overlap appends a second target segment per head: size the pool for both
     O.pool_cap = pool_cap * 2;
     O.pool_row = grow<int32_t>(ob[17], O.pool_cap); O.pool_reason = grow<uint8_t>(ob[18], O.pool_cap);
-    int64_t* misc = grow<int64_t>(b_misc, 4);
+    int64_t* misc = (int64_t*)(pack + o_misc);
     be.memset(misc, 0, 4 * sizeof(int64_t));
     O.pool_count = (int32_t*)misc; O.error = (int32_t*)misc + 1; O.stat_bytes = (long long*)(misc + 1);  // [1]=nominate bytes, [2]=process bytes
     // nominated flavors start empty (a head's rows are rewritten by assign_flavors)
@@ -267,26 +279,27 @@ template <class B> struct EngineT {
     be.launch_process(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16);
     be.timer_mark(3);
 
-    // decisions back
-    if (out->status) be.d2h(out->status, O.status, n);
-    if (out->action) be.d2h(out->action, O.action, n);
-    if (out->nominated_mode) be.d2h(out->nominated_mode, O.nominated_mode, n);
-    if (out->mode) be.d2h(out->mode, O.mode, n);
-    if (out->requeue_reason) be.d2h(out->requeue_reason, O.requeue_reason, n);
-    if (out->skip) be.d2h(out->skip, O.skip, n);
-    if (out->borrowing) be.d2h(out->borrowing, O.borrowing, n * sizeof(int32_t));
-    if (out->order) be.d2h(out->order, O.order, n * sizeof(int32_t));
-    if (out->flavor) be.d2h(out->flavor, O.flavor, nps * nR * sizeof(int32_t));
-    if (out->res_mode) be.d2h(out->res_mode, O.res_mode, nps * nR);
-    if (out->tried_idx) be.d2h(out->tried_idx, O.tried_idx, nps * nR * sizeof(int32_t));
-    if (out->ps_count) be.d2h(out->ps_count, O.ps_count, nps * sizeof(int32_t));
-    std::vector<int32_t> tpos(n), tn(n);
-    be.d2h(tpos.data(), O.tgt_pos, n * sizeof(int32_t));
-    be.d2h(tn.data(), O.tgt_n, n * sizeof(int32_t));
-    int64_t miscs[4];
-    be.d2h(miscs, misc, sizeof(miscs));
+    // decisions back: one D2H of the packed region into host staging, then plain memcpy to the caller's arrays
+    if (hstage_cap < pack_bytes) { if (hstage) be.free_host(hstage); hstage_cap = pack_bytes + pack_bytes / 4; hstage = (uint8_t*)be.alloc_host(hstage_cap); }
+    be.d2h(hstage, pack, pack_bytes);
     rc = be.sync();
     if (rc != KQ_OK) return fail(rc, be.error());
+    if (out->status) memcpy(out->status, hstage + o_status, n);
+    if (out->action) memcpy(out->action, hstage + o_action, n);
+    if (out->nominated_mode) memcpy(out->nominated_mode, hstage + o_nmode, n);
+    if (out->mode) memcpy(out->mode, hstage + o_mode, n);
+    if (out->requeue_reason) memcpy(out->requeue_reason, hstage + o_rq, n);
+    if (out->skip) memcpy(out->skip, hstage + o_skip, n);
+    if (out->borrowing) memcpy(out->borrowing, hstage + o_borrow, (size_t)n * 4);
+    if (out->order) memcpy(out->order, hstage + o_order, (size_t)n * 4);
+    if (out->flavor) memcpy(out->flavor, hstage + o_flavor, nps * nR * 4);
+    if (out->res_mode) memcpy(out->res_mode, hstage + o_rmode, nps * nR);
+    if (out->tried_idx) memcpy(out->tried_idx, hstage + o_tried, nps * nR * 4);
+    if (out->ps_count) memcpy(out->ps_count, hstage + o_pscount, nps * 4);
+    const int32_t* tpos = (const int32_t*)(hstage + o_tpos);
+    const int32_t* tn = (const int32_t*)(hstage + o_tn);
+    int64_t miscs[4];
+    memcpy(miscs, hstage + o_misc, sizeof(miscs));
     int32_t pool_used = ((int32_t*)miscs)[0], dev_err = ((int32_t*)miscs)[1];
     last_phase_bytes[0] = miscs[1]; last_phase_bytes[1] = miscs[2];
     last_bytes = miscs[1] + miscs[2];
@@ -298,6 +311,10 @@ template <class B> struct EngineT {
     std::vector<uint8_t> preason(std::max(pool_used, 1));
     if (pool_used > 0) { be.d2h(prow.data(), O.pool_row, (size_t)pool_used * sizeof(int32_t)); be.d2h(preason.data(), O.pool_reason, pool_used); rc = be.sync(); if (rc != KQ_OK) return fail(rc, be.error()); }
     int tot = 0;
+    if (pool_used == 0) {  // no preemption anywhere in this cycle
+      if (out->tgt_off) memset(out->tgt_off, 0, (size_t)(n + 1) * sizeof(int32_t));
+      return KQ_OK;
+    }
     for (int i = 0; i < n; i++) {
       if (out->tgt_off) out->tgt_off[i] = tot;
       std::vector<std::pair<int32_t, uint8_t>> ts;

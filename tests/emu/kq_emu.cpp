@@ -15,6 +15,8 @@ namespace kq {
 struct EmuBackend {
   void* alloc(size_t n) { return calloc(n, 1); }
   void free(void* p) { ::free(p); }
+  void* alloc_host(size_t n) { return calloc(n, 1); }
+  void free_host(void* p) { ::free(p); }
   void h2d(void* d, const void* h, size_t n) { memcpy(d, h, n); }
   void d2h(void* h, const void* d, size_t n) { memcpy(h, d, n); }
   void d2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
