@@ -59,6 +59,9 @@ def _cq(d: dict) -> ClusterQueue:
     for k, q in (d.get("usage") or {}).items():
         f, r = _split_fr(k)
         cq.extra_usage[(f, r)] = amount_from_quantity(r, q)
+    for k, q in (d.get("usageRaw") or {}).items():  # already canonical int64 (milli-CPU / bytes)
+        f, r = _split_fr(k)
+        cq.extra_usage[(f, r)] = int(q)
     return cq
 
 
