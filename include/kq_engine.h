@@ -64,6 +64,9 @@ extern "C" {
 /* bit  7    FlavorFungibility.WhenCanPreempt : 0 MayStopSearch(=Preempt) 1 TryNextFlavor        */
 /* bits 8-9  FlavorFungibility.Preference : 0 nil 1 BorrowingOverPreemption 2 PreemptionOverBorrowing */
 /* bit  10   QueueingStrategy : 0 BestEffortFIFO 1 StrictFIFO                                    */
+/* bit  11   ReclaimWithinCohort is the EMPTY string (object built without API defaulting, as the
+             reference's unit tests do): behaves as Never everywhere except canPreemptWhileBorrowing,
+             which tests `!= PreemptionPolicyNever` (flavorassigner.go:1386-1389)                  */
 #define KQ_POL_WITHIN_CQ(p)        ((p) & 0x3u)
 #define KQ_POL_RECLAIM(p)          (((p) >> 2) & 0x3u)
 #define KQ_POL_BORROW_WITHIN(p)    (((p) >> 4) & 0x1u)
@@ -72,6 +75,7 @@ extern "C" {
 #define KQ_POL_PREEMPT_TRYNEXT(p)  (((p) >> 7) & 0x1u)
 #define KQ_POL_PREFERENCE(p)       (((p) >> 8) & 0x3u)
 #define KQ_POL_STRICT_FIFO(p)      (((p) >> 10) & 0x1u)
+#define KQ_POL_RECLAIM_UNSET(p)    (((p) >> 11) & 0x1u)
 #define KQ_POLICY_NEVER 0
 #define KQ_POLICY_LOWER_PRIORITY 1
 #define KQ_POLICY_LOWER_OR_NEWER_EQUAL 2

@@ -157,6 +157,8 @@ class ClusterQueue:
         p |= PREF[self.preference] << 8
         if self.queueing_strategy == "StrictFIFO":
             p |= 1 << 10
+        if self.reclaim_within_cohort == "":  # object built without API defaulting (reference unit tests)
+            p |= 1 << 11
         return p
 
 

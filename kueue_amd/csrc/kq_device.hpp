@@ -751,7 +751,7 @@ KQ_DEV int next_flavor_to_try(const K& k, const Wave& w, int ps_global, int res)
   return idx < 0 ? 0 : idx + 1;
 }
 KQ_DEV bool can_preempt_while_borrowing(const K& k, const Wave& w) {  // flavorassigner.go:1386-1389
-  return KQ_POL_BORROW_WITHIN(w.pol) != 0 || (k.C.fair_sharing && KQ_POL_RECLAIM(w.pol) != KQ_POLICY_NEVER);
+  return KQ_POL_BORROW_WITHIN(w.pol) != 0 || (k.C.fair_sharing && (KQ_POL_RECLAIM(w.pol) != KQ_POLICY_NEVER || KQ_POL_RECLAIM_UNSET(w.pol)));
 }
 
 KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed,

@@ -482,7 +482,7 @@ struct FlavorAssigner {
   // flavorassigner.go:1386-1389
   bool canPreemptWhileBorrowing() const {
     uint32_t p = sn.policy(cq);
-    return KQ_POL_BORROW_WITHIN(p) != 0 || (enableFairSharing && KQ_POL_RECLAIM(p) != KQ_POLICY_NEVER);
+    return KQ_POL_BORROW_WITHIN(p) != 0 || (enableFairSharing && (KQ_POL_RECLAIM(p) != KQ_POLICY_NEVER || KQ_POL_RECLAIM_UNSET(p)));
   }
   // workload.go:226-238
   int NextFlavorToTry(int ps, int res) const {

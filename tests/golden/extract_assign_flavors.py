@@ -132,8 +132,10 @@ def parse_cq(text):
         mm = re.search(r"MaxPriorityThreshold:\s*(?:ptr\.To\[int32\]|ptr\.To|new)\((?:int32\()?(-?\d+)", body)
         if mm:
             pre["maxPriorityThreshold"] = int(mm.group(1))
-    if pre:
-        cq["preemption"] = pre
+    # no API defaulting in the reference's unit tests: an absent ReclaimWithinCohort is "" (not "Never"),
+    # which canPreemptWhileBorrowing distinguishes under fair sharing (flavorassigner.go:1386-1389)
+    pre.setdefault("reclaimWithinCohort", "")
+    cq["preemption"] = pre
     m = re.search(r'FairWeight\(resource\.MustParse\("([^"]+)"\)\)', text)
     if m:
         cq["fairWeight"] = float(m.group(1))
