@@ -1,0 +1,53 @@
+"""The C-ABI library must load and export every symbol include/kq_engine.h declares (no compute, no GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from kueue_amd import _ffi as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "kq_engine.h")).read()
+    return sorted(set(re.findall(r"\b(kq_[a-z_]+)\s*\(", hdr)))
+
+
+def test_header_and_ffi_list_agree():
+    assert declared_symbols() == sorted(F.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(F.ENGINE_LIB):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(F.ENGINE_LIB)
+    for sym in declared_symbols():
+        assert hasattr(lib, sym), sym
+    lib.kq_abi_version.restype = ctypes.c_int
+    assert lib.kq_abi_version() == F.KQ_ABI_VERSION
+    lib.kq_strerror.restype = ctypes.c_char_p
+    assert lib.kq_strerror(-4) == b"input not supported by the device path"
+
+
+def test_engine_fails_loudly_without_a_device():
+    """No CPU fallback: creating an engine without a HIP device must raise, never silently compute."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from kueue_amd.engine import Engine, EngineError
+    with pytest.raises(EngineError) as ei:
+        Engine()
+    assert ei.value.code == -6  # KQ_ENODEVICE
+
+
+def test_product_package_never_imports_oracle_or_emulation():
+    pkg = os.path.join(ROOT, "kueue_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "kqo" not in txt, f
+                assert "tests.emu" not in txt and "libkq_emu" not in txt and "libkq_oracle" not in txt, f
