@@ -134,13 +134,25 @@ def main():
             "p99_cycle_ms": float(np.percentile(cyc_ms, 99)),
             "kernel_ms_per_cycle": {"k_nominate": nom_ms / args.steps, "k_order": ord_ms / args.steps, "k_process": proc_ms / args.steps},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                         "algorithmic_bytes_per_launch": dby / args.steps, "traffic": None},
+                         "algorithmic_bytes_per_launch": dby / args.steps, "traffic": pmc_traffic(args.workload, dom)},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pop, kcfg, args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate
+    --pmc runs of this same command; profiles/r01c_cfg3_rocprof_summary.txt). Counters cannot be collected from inside
+    the timed run, so this is the last committed measurement for the same workload, or null."""
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["traffic_bytes_per_launch"].get(kernel)
+    except Exception:
+        return None
 
 
 def cpu_baseline(pop, kcfg, budget_s):
