@@ -94,6 +94,13 @@ struct DSnap {
   // prep
   const int32_t *path, *plen, *tree_of, *node_local, *node_height, *adm_cq, *cq_local;
   const int32_t *tree_node_off, *tree_nodes, *tree_cq_off, *tree_cqs, *tree_row_off, *tree_rows;
+  // fair sharing
+  const int64_t* lendable;   // [N * nR] calculateLendable(parent(node)) per resource (static)
+  const int32_t* top_of;     // [N] ancestor-or-self that is a child of the root
+  const double* fair_weight; // [N]
+  const int32_t *child_cohort_off, *child_cohort, *child_cq_off, *child_cq, *depth;
+  const int64_t* adm_rts;
+  const uint32_t* adm_uid;
 };
 
 struct DCfg {

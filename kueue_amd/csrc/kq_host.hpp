@@ -118,6 +118,16 @@ template <class B> struct EngineT {
     S.tree_cqs = upload(prep.tree_cqs.data(), prep.tree_cqs.size());
     S.tree_row_off = upload(prep.tree_row_off.data(), prep.tree_row_off.size());
     S.tree_rows = upload(prep.tree_rows.data(), prep.tree_rows.size());
+    S.lendable = upload(prep.lendable.data(), prep.lendable.size());
+    S.top_of = upload(prep.top_of.data(), prep.top_of.size());
+    S.fair_weight = upload(s->fair_weight, N);
+    S.child_cohort_off = upload(s->child_cohort_off, prep.nc + 1);
+    S.child_cohort = upload(s->child_cohort, s->child_cohort_off[prep.nc]);
+    S.child_cq_off = upload(s->child_cq_off, prep.nc + 1);
+    S.child_cq = upload(s->child_cq, s->child_cq_off[prep.nc]);
+    S.depth = upload(prep.depth.data(), prep.depth.size());
+    S.adm_rts = upload(s->adm_reserve_ts, prep.n_adm);
+    S.adm_uid = upload(s->adm_uid_rank, prep.n_adm);
     rc = be.sync();
     if (rc != KQ_OK) return fail(rc, be.error());
     have_snapshot = true;

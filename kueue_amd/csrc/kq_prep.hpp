@@ -33,6 +33,10 @@ struct Prep {
   std::vector<int32_t> cq_local;                   // [nq] index of the CQ inside tree_cqs of its tree
   std::vector<int32_t> tree_row_off, tree_rows;    // admitted rows of a tree, in static candidate rank order
   std::vector<int32_t> adm_cq;                     // [n_adm]
+  // fair sharing: calculateLendable(parent(node)) per resource (fair_sharing.go:186-200). It only reads quotas
+  // (potentialAvailable ignores usage), so it is a per-snapshot constant. [N * nR]; 0 for root nodes.
+  std::vector<int64_t> lendable;
+  std::vector<int32_t> top_of;                     // [N] the ancestor-or-self that is a child of the root (-1 for roots)
   int max_tree_nodes = 0, max_tree_cqs = 0, max_tree_rows = 0, max_tree_cohorts = 0;
   std::string err;
 };
@@ -122,6 +126,55 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
     p.max_tree_cqs = std::max(p.max_tree_cqs, p.tree_cq_off[t + 1] - p.tree_cq_off[t]);
     p.max_tree_rows = std::max(p.max_tree_rows, p.tree_row_off[t + 1] - p.tree_row_off[t]);
     p.max_tree_cohorts = std::max(p.max_tree_cohorts, (p.tree_node_off[t + 1] - p.tree_node_off[t]) - (p.tree_cq_off[t + 1] - p.tree_cq_off[t]));
+  }
+  // ---- fair sharing constants -----------------------------------------------------------------------
+  {
+    const int64_t U = INT64_MAX;
+    auto a_add = [&](int64_t a, int64_t b) -> int64_t {
+      if (a == U || b == U) return U;
+      if (b > 0 && a > U - b) return U;
+      if (b < 0 && a < INT64_MIN - b) return INT64_MIN;
+      return a + b;
+    };
+    auto a_sub = [&](int64_t a, int64_t b) -> int64_t {
+      if (a == U && b == U) return 0;
+      if (a == U) return U;
+      if (b == U) return INT64_MIN;
+      if (b < 0 && a > U + b) return U;
+      if (b > 0 && a < INT64_MIN + b) return INT64_MIN;
+      return a - b;
+    };
+    const size_t nfr = p.nfr;
+    // potentialAvailable(node, fr) for every node, parents before children (resource_node.go:129-140)
+    std::vector<int32_t> by_depth(N);
+    for (int n = 0; n < N; n++) by_depth[n] = n;
+    std::sort(by_depth.begin(), by_depth.end(), [&](int a, int b) { return p.depth[a] < p.depth[b]; });
+    std::vector<int64_t> pot((size_t)N * nfr, 0);
+    for (int n : by_depth)
+      for (size_t fr = 0; fr < nfr; fr++) {
+        size_t o = (size_t)n * nfr + fr;
+        if (s->parent[n] < 0) { pot[o] = s->subtree_quota[o]; continue; }
+        int64_t lq = 0;
+        if (s->lend_limit[o] != KQ_NIL_LIMIT) lq = std::max<int64_t>(0, a_sub(s->subtree_quota[o], s->lend_limit[o]));
+        int64_t avail = a_add(lq, pot[(size_t)s->parent[n] * nfr + fr]);
+        if (s->borrow_limit[o] != KQ_NIL_LIMIT) avail = std::min(a_add(s->subtree_quota[o], s->borrow_limit[o]), avail);
+        pot[o] = avail;
+      }
+    p.lendable.assign((size_t)N * p.nR, 0);
+    p.top_of.assign(N, -1);
+    for (int n = 0; n < N; n++) {
+      int par = s->parent[n];
+      if (par < 0) continue;
+      int top = n;
+      while (s->parent[s->parent[top]] >= 0) top = s->parent[top];
+      p.top_of[n] = top;
+      const int root = p.root[n];
+      for (size_t fr = 0; fr < nfr; fr++) {
+        if (!(s->quota_flags[(size_t)root * nfr + fr] & KQ_QF_SUBTREE)) continue;  // keys of root.SubtreeQuota
+        size_t r = fr % p.nR;
+        p.lendable[(size_t)n * p.nR + r] = a_add(p.lendable[(size_t)n * p.nR + r], pot[(size_t)par * nfr + fr]);
+      }
+    }
   }
   // index validation
   for (int g = 0; g < p.n_rg; g++) {

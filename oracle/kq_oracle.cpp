@@ -1364,21 +1364,26 @@ struct Scheduler {
     for (size_t k = 1; k < candidates.size(); k++) if (less(entries, candidates[k], best, cohort)) best = candidates[k];
     return best;
   }
-  // fair_sharing_iterator.go:47-119 ; getCq: canonical = lowest CQ index remaining
-  std::vector<int> fairOrder(std::vector<Entry>& entries) {
+  // fair_sharing_iterator.go:47-119 ; getCq: canonical = lowest CQ index remaining.
+  // pop() reads the snapshot as mutated by the entries processed so far (scheduler.go:358-359 calls
+  // processEntry between pops), so iteration and processing are interleaved here exactly like there.
+  void fairIterate(std::vector<Entry>& entries, std::set<int>& preemptedWorkloads) {
     std::map<int, int> cqToEntry;
     for (size_t i = 0; i < entries.size(); i++) cqToEntry[entries[i].head.cq] = (int)i;  // later entry of same CQ overwrites (:58-60)
-    std::vector<int> ord;
+    int pos = 0;
     while (!cqToEntry.empty()) {
       int cq = cqToEntry.begin()->first;
-      if (!sn.HasParent(cq)) { ord.push_back(cqToEntry[cq]); cqToEntry.erase(cq); continue; }
-      int root = sn.Root(cq);
-      computeDRS(root, entries, cqToEntry);
-      int w = runTournament(root, entries, cqToEntry);
-      ord.push_back(w);
+      int w;
+      if (!sn.HasParent(cq)) { w = cqToEntry[cq]; }
+      else {
+        int root = sn.Root(cq);
+        computeDRS(root, entries, cqToEntry);
+        w = runTournament(root, entries, cqToEntry);
+      }
       cqToEntry.erase(entries[w].head.cq);
+      entries[w].order = pos++;
+      processEntry(entries[w], preemptedWorkloads);
     }
-    return ord;
   }
 
   // scheduler.go:308-386 steps 3-5
@@ -1390,10 +1395,14 @@ struct Scheduler {
       e.nominatedMode = e.assignment.RepresentativeMode();
       entries.push_back(std::move(e));
     }
-    std::vector<int> ord = sn.cfg.fair_sharing ? fairOrder(entries) : classicalOrder(entries);
     std::set<int> preemptedWorkloads;
-    int pos = 0;
-    for (int i : ord) { entries[i].order = pos++; processEntry(entries[i], preemptedWorkloads); }
+    if (sn.cfg.fair_sharing) {
+      fairIterate(entries, preemptedWorkloads);
+    } else {
+      std::vector<int> ord = classicalOrder(entries);
+      int pos = 0;
+      for (int i : ord) { entries[i].order = pos++; processEntry(entries[i], preemptedWorkloads); }
+    }
     // entries dropped by the fair-sharing map (duplicate CQ) are never processed; finalMode = nominated
     for (auto& e : entries) if (e.order < 0) e.finalMode = e.nominatedMode;
   }
