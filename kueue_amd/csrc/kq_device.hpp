@@ -41,6 +41,7 @@ KQ_DEV void wsync_lds() {}
 KQ_DEV int ffs64(uint64_t m) { return __builtin_ctzll(m); }
 KQ_DEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
 KQ_DEV int atomic_add_i32(int* p, int v) { int o = *p; *p += v; return o; }
+KQ_DEV void atomic_max_i32(int* p, int v) { if (v > *p) *p = v; }
 KQ_DEV void atomic_add_i64(long long* p, long long v) { *p += v; }
 KQ_DEV int64_t wsum_i64(int64_t v) { return v; }
 }  // namespace kq
@@ -55,6 +56,7 @@ KQ_DEV int lane_id() { return (int)(threadIdx.x & 63); }
 KQ_DEV uint64_t wballot(bool p) { return __ballot(p); }
 KQ_DEV int wbcast(int v, int src) { return __shfl(v, src, 64); }
 KQ_DEV int64_t wbcast(int64_t v, int src) { return (int64_t)__shfl((long long)v, src, 64); }
+KQ_DEV double wbcast(double v, int src) { return __longlong_as_double(__shfl(__double_as_longlong(v), src, 64)); }
 // one wave per workgroup: __syncthreads() is the wave-level fence for LDS and global scratch
 KQ_DEV void wsync() { __syncthreads(); }
 // LDS-only visibility inside the single wave of a workgroup: the LDS pipeline is in order per wave, so only
@@ -63,6 +65,7 @@ KQ_DEV void wsync_lds() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 KQ_DEV int ffs64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }
 KQ_DEV int popc64(uint64_t m) { return __popcll((unsigned long long)m); }
 KQ_DEV int atomic_add_i32(int* p, int v) { return atomicAdd(p, v); }
+KQ_DEV void atomic_max_i32(int* p, int v) { atomicMax(p, v); }
 KQ_DEV void atomic_add_i64(long long* p, long long v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
 KQ_DEV int64_t wsum_i64(int64_t v) {
   for (int o = 32; o > 0; o >>= 1) v += (int64_t)__shfl_xor((long long)v, o, 64);
@@ -97,6 +100,7 @@ struct DSnap {
   // fair sharing
   const int64_t* lendable;   // [N * nR] calculateLendable(parent(node)) per resource (static)
   const int32_t* top_of;     // [N] ancestor-or-self that is a child of the root
+  const int32_t* rank_pos;   // [n_adm] position of the row in its tree's rank-ordered tree_rows segment
   const double* fair_weight; // [N]
   const int32_t *child_cohort_off, *child_cohort, *child_cq_off, *child_cq, *depth;
   const int64_t* adm_rts;
@@ -106,6 +110,7 @@ struct DSnap {
 struct DCfg {
   uint32_t gates;
   int fair_sharing;
+  int n_fs, fs[2];           // fair-sharing preemption strategies (preemption.go:364-366)
   int quota_check_strategy;
   int64_t cycle;
 };
@@ -153,6 +158,18 @@ struct DScratch {
   int32_t* tgt_row;  // [slots][tgt_cap]
   uint8_t* tgt_reason;
   int32_t* nom;      // [slots][KQ_MAXPS * nR] NominationMapping of the entry being recomputed (workload.go:262)
+  // fair sharing: per-CQ candidate queues of the TargetClusterQueueOrdering (fairsharing/ordering.go:46)
+  int32_t* qcnt;     // [slots][max_tree_cqs] remaining candidates of the CQ
+  uint32_t* qhead;   // [slots][max_tree_cqs] key of the first remaining candidate (evicted bit | rank position)
+  uint8_t* cohp;     // [slots][max_tree_nodes] prunedCohorts
+  // fair-sharing iterator (fair_sharing_iterator.go): per tree slot
+  int32_t* cq_ent;   // [slots][max_tree_cqs] cqToEntry: the head still to schedule for the CQ, -1 = none
+  double* fs_ratio;  // [slots][max_tree_cqs * KQ_MAXD] drsValues: DRS of path[level] with the entry admitted
+  double* fs_weight;
+  uint8_t* fs_bon;   // IsBorrowingOn(requestedFRs)
+  int32_t* fs_win;   // [slots][max_tree_nodes] tournament winner per cohort
+  int32_t* fs_seq;   // [slots][max_tree_cqs] the tree's pop sequence
+  int32_t* fs_key;   // [H] merge key: smallest CQ index at or after the entry in its tree's sequence
   int32_t max_tree_nodes, max_tree_cqs, max_tree_rows, slot_cap, tgt_cap;
 };
 
@@ -436,6 +453,7 @@ struct Search {
   int32_t* trow;
   uint8_t* treason;
   int tree, row0, nrows;
+  int32_t* qcnt; uint32_t* qhead; uint8_t* cohp;  // fair sharing only
 };
 
 KQ_DEV bool row_removed(const Search& s, int row) { return s.removed && s.removed[row]; }
@@ -716,6 +734,425 @@ KQ_DEV void classical_search(Search& s) {
   w.ntgt = 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// fair sharing: DominantResourceShare (cache/scheduler/fair_sharing.go)
+// ------------------------------------------------------------------------------------------------
+struct DRSv { double ratio, weight; int borrowing, borrow_on; };
+KQ_DEV DRSv drs_negative() { DRSv d; d.ratio = -1.0; d.weight = 1.0; d.borrowing = 0; d.borrow_on = 0; return d; }  // :58
+// PreciseWeightedShare :92
+KQ_DEV double drs_pws(const DRSv& d) {
+  if (d.ratio == 0) return 0.0;
+  if (d.weight == 0) return __builtin_inf();
+  return d.ratio / d.weight;
+}
+KQ_DEV bool drs_zwb(const DRSv& d) { return d.weight == 0 && d.ratio != 0; }  // zeroWeightBorrows :145
+KQ_DEV int cmp_f64(double a, double b) {  // Go cmp.Compare
+  bool an = a != a, bn = b != b;
+  if (an && bn) return 0;
+  if (an) return -1;
+  if (bn) return 1;
+  return a < b ? -1 : (a > b ? 1 : 0);
+}
+KQ_DEV int compare_drs(const DRSv& a, const DRSv& b) {  // :112-123
+  if (drs_zwb(a) && drs_zwb(b)) return cmp_f64(a.ratio, b.ratio);
+  if (drs_zwb(a)) return 1;
+  if (drs_zwb(b)) return -1;
+  return cmp_f64(drs_pws(a), drs_pws(b));
+}
+KQ_DEV bool drs_pos_inf(const DRSv& d) { double v = drs_pws(d); return v == __builtin_inf(); }
+// dominantResourceShare :149-182 for `node` on usage plane `pl` (pl.get(node, fr)). calculateLendable(parent) is
+// the per-snapshot constant S.lendable. rq_*: the entry's requested flavor-resources (IsBorrowingOn :78), or n = 0.
+// Runs per lane: lanes may evaluate different nodes.
+template <class PL> KQ_DEV DRSv drs_of(const DSnap& S, int node, const PL& pl, int64_t* bytes,
+                                        const int32_t* rq_fr, const int64_t* rq_qty, int rq_n) {
+  DRSv d; d.ratio = 0; d.weight = S.fair_weight[node]; d.borrowing = 0; d.borrow_on = 0;
+  if (S.parent[node] < 0) return d;
+  const int nR = S.nR, nF = S.nfr / S.nR;
+  int frcount = 0;
+  for (int r = 0; r < nR; r++) {
+    int64_t sum = 0; bool any = false;
+    for (int f = 0; f < nF; f++) {
+      int fr = f * nR + r;
+      size_t o = ix(S, node, fr);
+      if (!(S.qflags[o] & KQ_QF_SUBTREE)) continue;
+      frcount++;
+      int64_t b = a_sub(pl.get(node, fr), S.sq[o]);
+      if (b > 0) {
+        sum = any ? a_add(sum, b) : b; any = true;
+        for (int q = 0; q < rq_n; q++) if (rq_fr[q] == fr && rq_qty[q] > 0) d.borrow_on = 1;
+      }
+    }
+    if (any) {
+      d.borrowing = 1;
+      int64_t lr = S.lendable[(size_t)node * nR + r];
+      if (lr > 0) {
+        double ratio = (double)sum * 1000.0 / (double)lr;
+        if (ratio > d.ratio) d.ratio = ratio;  // ascending resource index == alphabetical, ties keep the first (:176)
+      }
+    }
+  }
+  *bytes += (int64_t)frcount * 24 + (d.borrowing ? (int64_t)frcount * 40 * (S.depth[node] + 1) : 0);
+  return d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fair-sharing victim search (preemption.go:381-631, fairsharing/ordering.go, strategy.go, target.go)
+// The private state covers every flavor-resource of every node of the tree: DRS reads all of them.
+// ------------------------------------------------------------------------------------------------
+struct UF {  // one flavor-resource column of the private plane
+  const DSnap* S; int64_t* w; int fr;
+  KQ_MDEV int64_t get(int n) const { return w[(size_t)S->node_local[n] * S->nfr + fr]; }
+  KQ_MDEV void set(int n, int64_t v) const { w[(size_t)S->node_local[n] * S->nfr + fr] = v; }
+};
+struct PF {  // the whole private plane
+  const DSnap* S; const int64_t* w;
+  KQ_MDEV int64_t get(int n, int fr) const { return w[(size_t)S->node_local[n] * S->nfr + fr]; }
+};
+struct PG {  // a global plane
+  const DSnap* S; const int64_t* u;
+  KQ_MDEV int64_t get(int n, int fr) const { return u[(size_t)n * S->nfr + fr]; }
+};
+
+// snapshot.RemoveWorkload / AddWorkload or plain Remove/AddUsage of the row's usage: one lane per usage entry
+KQ_DEV void f_apply_row(const Search& s, int row, bool add, bool count) {
+  const DSnap& S = s.k->S;
+  int c = S.adm_cq[row];
+  const int32_t* cpath = S.path + (size_t)c * KQ_MAXD;
+  int cplen = S.plen[c];
+  const int e0 = S.adm_use_off[row], e1 = S.adm_use_off[row + 1];
+  for (int e = e0 + lane_id(); e < e1; e += WAVE) {
+    int fr = S.adm_use_fr[e];
+    bool first = true;
+    for (int p = e0; p < e; p++) if (S.adm_use_fr[p] == fr) first = false;
+    if (!first) continue;  // a repeated flavor-resource is applied by the lane of its first entry, in order
+    UF uf{&S, s.W, fr};
+    for (int p = e; p < e1; p++) {
+      if (S.adm_use_fr[p] != fr) continue;
+      if (add) add_usage(S, cpath, cplen, fr, S.adm_use_qty[p], uf); else remove_usage(S, cpath, cplen, fr, S.adm_use_qty[p], uf);
+    }
+  }
+  wsync();
+  if (count && lane_id() == 0) s.w->bytes += 16 * (int64_t)cplen * (e1 - e0);
+}
+// cq.SimulateUsageAddition(workloadUsage) / its revert (preemption.go:557, :690-695)
+KQ_DEV void f_apply_preemptor(const Search& s, bool add) {
+  const DSnap& S = s.k->S; const Wave& w = *s.w;
+  for (int u = lane_id(); u < w.ns; u += WAVE) {
+    if (!w.s_inu[u]) continue;
+    UF uf{&S, s.W, w.s_fr[u]};
+    if (add) add_usage(S, w.path, w.plen, w.s_fr[u], w.s_qty[u], uf); else remove_usage(S, w.path, w.plen, w.s_fr[u], w.s_qty[u], uf);
+  }
+  wsync();
+}
+// workloadFits(ctx, allowBorrowing=true) preemption.go:669-686
+KQ_DEV bool f_fits(const Search& s) {
+  const DSnap& S = s.k->S; Wave& w = *s.w;
+  bool bad = false;
+  for (int u = lane_id(); u < w.ns; u += WAVE) {
+    if (!w.s_inu[u]) continue;
+    UF uf{&S, s.W, w.s_fr[u]};
+    if (w.s_qty[u] > i64max(0, available_of(S, w.path, w.plen, w.s_fr[u], uf))) bad = true;
+  }
+  if (lane_id() == 0) { int nu = 0; for (int u = 0; u < w.ns; u++) nu += w.s_inu[u] ? 1 : 0; w.bytes += 40 * (int64_t)w.plen * nu; }
+  return wballot(bad) == 0;
+}
+KQ_DEV bool f_fits_fs(const Search& s) {  // workloadFitsForFairSharing :690-695
+  f_apply_preemptor(s, false);
+  bool r = f_fits(s);
+  f_apply_preemptor(s, true);
+  return r;
+}
+KQ_DEV uint32_t f_row_key(const DSnap& S, int row) {
+  return ((S.adm_flags[row] & KQ_ADM_EVICTED) ? 0u : 0x80000000u) | (uint32_t)S.rank_pos[row];
+}
+// CandidatesOrdering (common/ordering.go:42-83) of the queue heads of two CQs, as a sortable key
+KQ_DEV uint64_t f_head_key(const Search& s, int c) {
+  uint32_t k32 = s.qhead[s.k->S.cq_local[c]];
+  return ((uint64_t)(k32 >> 31) << 33) | ((uint64_t)(c == s.w->cq ? 1 : 0) << 32) | (uint64_t)(k32 & 0x7fffffffu);
+}
+// recount / re-head the queue of tree-local CQ `i` over rows flagged `flag` (all lanes compute the same)
+KQ_DEV void f_rescan(const Search& s, int i, uint8_t flag) {
+  const DSnap& S = s.k->S;
+  int c = S.tree_cqs[S.tree_cq_off[s.tree] + i];
+  uint32_t head = 0xffffffffu; int cnt = 0;
+  for (int row = S.cq_adm_off[c]; row < S.cq_adm_off[c + 1]; row++)
+    if (s.cls[S.rank_pos[row]] == flag) { cnt++; uint32_t key = f_row_key(S, row); if (key < head) head = key; }
+  if (lane_id() == 0) { s.qcnt[i] = cnt; s.qhead[i] = head; }
+  wsync();
+}
+// PopWorkload (ordering.go:84-90): the popped row's flag becomes `newflag`
+KQ_DEV int f_pop(const Search& s, int c, uint8_t flag, uint8_t newflag) {
+  const DSnap& S = s.k->S;
+  int i = S.cq_local[c];
+  int pos = (int)(s.qhead[i] & 0x7fffffffu);
+  int row = S.tree_rows[s.row0 + pos];
+  wsync();
+  if (lane_id() == 0) s.cls[pos] = newflag;
+  wsync();
+  f_rescan(s, i, flag);
+  return row;
+}
+// nextTarget (ordering.go:144-226), tail recursion unrolled; returns the target CQ or -1
+KQ_DEV int f_next_target(const Search& s, int root) {
+  const K& k = *s.k; Wave& w = *s.w; const DSnap& S = k.S;
+  const int lane = lane_id();
+  PF pf{&S, s.W};
+  int cohort = root;
+  int64_t lb = 0;
+  int result = -1;
+  for (;;) {
+    int best_cq = -1; DRSv best = drs_negative();
+    const int kc0 = S.child_cq_off[cohort - S.nq], nkc = S.child_cq_off[cohort - S.nq + 1] - kc0;
+    for (int base = 0; base < nkc; base += WAVE) {
+      int j = base + lane;
+      int c = j < nkc ? S.child_cq[kc0 + j] : -1;
+      DRSv d = drs_negative();
+      bool elig = false;
+      if (c >= 0 && !s.cqinfo[S.cq_local[c]]) {
+        d = drs_of(S, c, pf, &lb, nullptr, nullptr, 0);
+        if ((!d.borrowing && c != w.cq) || s.qcnt[S.cq_local[c]] == 0) s.cqinfo[S.cq_local[c]] = 1;
+        else elig = true;
+      }
+      uint64_t m = wballot(elig);
+      while (m) {
+        int b = ffs64(m);
+        m &= m - 1;
+        DRSv db; db.ratio = wbcast(d.ratio, b); db.weight = wbcast(d.weight, b); db.borrowing = 1; db.borrow_on = 0;
+        int cb = wbcast(c, b);
+        int cmp = compare_drs(db, best);
+        if (cmp == 0) { if (f_head_key(s, cb) < f_head_key(s, best_cq)) best_cq = cb; }
+        else if (cmp == 1) { best = db; best_cq = cb; }
+      }
+    }
+    int best_co = -1; DRSv bestco = drs_negative();
+    const int kh0 = S.child_cohort_off[cohort - S.nq], nkh = S.child_cohort_off[cohort - S.nq + 1] - kh0;
+    for (int base = 0; base < nkh; base += WAVE) {
+      int j = base + lane;
+      int ch = j < nkh ? S.child_cohort[kh0 + j] : -1;
+      DRSv d = drs_negative();
+      bool elig = false;
+      if (ch >= 0 && !s.cohp[S.node_local[ch]]) {
+        d = drs_of(S, ch, pf, &lb, nullptr, nullptr, 0);
+        if (!d.borrowing && path_level(w, ch) < 0) s.cohp[S.node_local[ch]] = 1;
+        else elig = true;
+      }
+      uint64_t m = wballot(elig);
+      while (m) {
+        int b = ffs64(m);
+        m &= m - 1;
+        DRSv db; db.ratio = wbcast(d.ratio, b); db.weight = wbcast(d.weight, b); db.borrowing = 1; db.borrow_on = 0;
+        int hb = wbcast(ch, b);
+        if (compare_drs(db, bestco) >= 0) { bestco = db; best_co = hb; }
+      }
+    }
+    wsync();
+    if (best_co < 0 && best_cq < 0) {
+      if (lane == 0) s.cohp[S.node_local[cohort]] = 1;
+      wsync();
+      result = -1;
+      break;
+    }
+    if (compare_drs(bestco, best) >= 0) { cohort = best_co; continue; }
+    result = best_cq;
+    break;
+  }
+  int64_t tot = wsum_i64(lb);
+  if (lane == 0) w.bytes += tot;
+  return result;
+}
+// TargetClusterQueueOrdering.Iter (ordering.go:92-127) as a "next" call
+KQ_DEV int f_ordering_next(const Search& s) {
+  const DSnap& S = s.k->S; const Wave& w = *s.w;
+  if (w.plen <= 1) {
+    int i = S.cq_local[w.cq];
+    if (!s.cqinfo[i] && s.qcnt[i] > 0) return w.cq;
+    return -1;
+  }
+  int root = w.path[w.plen - 1];
+  while (!s.cohp[S.node_local[root]]) {
+    int t = f_next_target(s, root);
+    if (t >= 0) return t;
+  }
+  return -1;
+}
+// getAlmostLCAs (least_common_ancestor.go:27-58): nodes just below the LCA on the preemptor's and the target's path
+KQ_DEV void f_almost_lcas(const Search& s, int target, int* ap, int* at) {
+  const DSnap& S = s.k->S; const Wave& w = *s.w;
+  const int32_t* tp = S.path + (size_t)target * KQ_MAXD;
+  int tpl = S.plen[target];
+  *ap = w.cq; *at = target;
+  for (int j = 1; j < tpl; j++) {
+    int l = path_level(w, tp[j]);
+    if (l >= 1) { *ap = w.path[l - 1]; *at = tp[j - 1]; return; }
+  }
+  *ap = w.path[w.plen - 1]; *at = tp[tpl - 1];
+}
+KQ_DEV bool f_push_target(Search& s, int* nt, int row, int reason) {
+  if (*nt >= s.k->X.tgt_cap) { set_error(*s.k, KQ_ECAPACITY); return false; }
+  if (lane_id() == 0) { s.trow[*nt] = row; s.treason[*nt] = (uint8_t)reason; }
+  (*nt)++;
+  wsync();
+  return true;
+}
+KQ_DEV DRSv f_drs_uniform(const Search& s, int node) {
+  PF pf{&s.k->S, s.W};
+  int64_t lb = 0;
+  DRSv d = drs_of(s.k->S, node, pf, &lb, nullptr, nullptr, 0);
+  if (lane_id() == 0) s.w->bytes += lb;
+  return d;
+}
+// fairPreemptions (preemption.go:536-597). On return w->ntgt targets are in s.trow/s.treason and the private
+// state has exactly those removed.
+KQ_DEV void fair_search(Search& s) {
+  const K& k = *s.k; Wave& w = *s.w; const DSnap& S = k.S;
+  const int lane = lane_id();
+  w.ntgt = 0;
+  bool same_on = KQ_POL_WITHIN_CQ(w.pol) != KQ_POLICY_NEVER;
+  bool other_on = w.plen > 1 && KQ_POL_RECLAIM(w.pol) != KQ_POLICY_NEVER;
+  if (!same_on && !other_on) return;
+  s.tree = S.tree_of[w.cq];
+  s.row0 = S.tree_row_off[s.tree];
+  s.nrows = S.tree_row_off[s.tree + 1] - s.row0;
+  if (s.nrows == 0) return;
+  const int n0 = S.tree_node_off[s.tree], nn = S.tree_node_off[s.tree + 1] - n0;
+  const int q0 = S.tree_cq_off[s.tree], nqs = S.tree_cq_off[s.tree + 1] - q0;
+  const int nfr = S.nfr;
+  for (int i = lane; i < nn * nfr; i += WAVE) s.W[i] = s.usage[ix(S, S.tree_nodes[n0 + i / nfr], i % nfr)];
+  for (int i = lane; i < s.nrows; i += WAVE) s.cls[i] = 0;
+  for (int i = lane; i < nn; i += WAVE) s.cohp[i] = 0;
+  wsync();
+  // findCandidates (:633-667): one lane per CQ of the tree
+  int ncand = 0;
+  {
+    int cbytes = 0;
+    for (int base = 0; base < nqs; base += WAVE) {
+      int i = base + lane;
+      int cnt = 0; uint32_t head = 0xffffffffu;
+      if (i < nqs) {
+        int c = S.tree_cqs[q0 + i];
+        bool take;
+        if (c == w.cq) take = same_on;
+        else {
+          take = false;
+          if (other_on)
+            for (int u = 0; u < w.ns; u++)  // cqIsBorrowing :657-667
+              if (w.s_need[u] && S.nominal[ix(S, c, w.s_fr[u])] < s.usage[ix(S, c, w.s_fr[u])]) take = true;
+        }
+        int policy = c == w.cq ? KQ_POL_WITHIN_CQ(w.pol) : KQ_POL_RECLAIM(w.pol);
+        if (take)
+          for (int row = S.cq_adm_off[c]; row < S.cq_adm_off[c + 1]; row++) {
+            if (row_removed(s, row)) continue;
+            cbytes += 32 + 12 * (S.adm_use_off[row + 1] - S.adm_use_off[row]);
+            if (!satisfies_policy(k, w, row, policy)) continue;
+            if (!uses_need(k, w, row)) continue;
+            s.cls[S.rank_pos[row]] = 1;
+            cnt++;
+            uint32_t key = f_row_key(S, row);
+            if (key < head) head = key;
+          }
+        s.qcnt[i] = cnt; s.qhead[i] = head; s.cqinfo[i] = 0;
+      }
+      ncand += popc64(wballot(cnt > 0));
+    }
+    int64_t tot = wsum_i64((int64_t)cbytes);
+    if (lane == 0) w.bytes += tot;
+  }
+  wsync();
+  if (ncand == 0) return;
+  f_apply_preemptor(s, true);  // SimulateUsageAddition :557
+  int nt = 0;
+  bool fits = false;
+  const int strategy0 = k.C.n_fs > 0 ? k.C.fs[0] : KQ_FS_LESS_THAN_OR_EQUAL_TO_FINAL_SHARE;
+  const bool have_second = k.C.n_fs > 0 ? k.C.n_fs > 1 : true;
+  // ---- runFirstFsStrategy :384-470 ----
+  {
+    bool within_nominal = false;
+    if (gate(k, KQ_GATE_FS_PREEMPT_WITHIN_NOMINAL)) {  // queueWithinNominalInResourcesNeedingPreemption :714-721
+      within_nominal = true;
+      for (int u = 0; u < w.ns; u++)
+        if (w.s_need[u]) { UF uf{&S, s.W, w.s_fr[u]}; if (S.nominal[ix(S, w.cq, w.s_fr[u])] < uf.get(w.cq)) within_nominal = false; }
+    }
+    for (int cand = f_ordering_next(s); cand >= 0 && !fits; cand = fits ? -1 : f_ordering_next(s)) {
+      if (cand == w.cq || within_nominal) {
+        int row = f_pop(s, cand, 1, 0);
+        f_apply_row(s, row, false, true);
+        if (!f_push_target(s, &nt, row, cand == w.cq ? KQ_REASON_IN_CLUSTER_QUEUE : KQ_REASON_IN_COHORT_RECLAMATION)) { w.ntgt = 0; return; }
+        if (f_fits_fs(s)) fits = true;
+        continue;
+      }
+      int ap, at;
+      f_almost_lcas(s, cand, &ap, &at);
+      DRSv pn = f_drs_uniform(s, ap), to = f_drs_uniform(s, at);
+      const int li = S.cq_local[cand];
+      if (drs_pos_inf(pn) && !drs_pos_inf(to)) {  // fsStrategyUnsatisfiable :494-497
+        while (s.qcnt[li] > 0) f_pop(s, cand, 1, 2);
+        continue;
+      }
+      while (s.qcnt[li] > 0) {
+        int row = f_pop(s, cand, 1, 0);
+        // ComputeTargetShareAfterRemoval target.go:67-73
+        f_apply_row(s, row, false, false);
+        DRSv tn = f_drs_uniform(s, at);
+        f_apply_row(s, row, true, false);
+        bool pass = strategy0 == KQ_FS_LESS_THAN_OR_EQUAL_TO_FINAL_SHARE ? compare_drs(pn, tn) <= 0 : compare_drs(pn, to) < 0;  // strategy.go:41,46
+        if (pass) {
+          f_apply_row(s, row, false, true);
+          if (!f_push_target(s, &nt, row, KQ_REASON_IN_COHORT_FAIR_SHARING)) { w.ntgt = 0; return; }
+          if (f_fits_fs(s)) fits = true;
+          break;
+        }
+        if (lane == 0) s.cls[S.rank_pos[row]] = 2;  // retryCandidates
+        wsync();
+      }
+    }
+  }
+  // ---- runSecondFsStrategy :501-534 ----
+  if (!fits && have_second) {
+    for (int i = lane; i < nn; i += WAVE) s.cohp[i] = 0;
+    for (int i = lane; i < nqs; i += WAVE) s.cqinfo[i] = 0;
+    wsync();
+    for (int i = 0; i < nqs; i++) f_rescan(s, i, 2);
+    for (int cand = f_ordering_next(s); cand >= 0 && !fits; cand = fits ? -1 : f_ordering_next(s)) {
+      int ap, at;
+      f_almost_lcas(s, cand, &ap, &at);
+      DRSv pn = f_drs_uniform(s, ap), to = f_drs_uniform(s, at);
+      bool passed = compare_drs(pn, to) < 0;
+      int row = f_pop(s, cand, 2, 0);
+      if (passed) {
+        f_apply_row(s, row, false, true);
+        if (!f_push_target(s, &nt, row, KQ_REASON_IN_COHORT_FAIR_SHARING)) { w.ntgt = 0; return; }
+        if (f_fits_fs(s)) fits = true;
+      }
+      if (lane == 0) s.cqinfo[S.cq_local[cand]] = 1;  // DropQueue
+      wsync();
+    }
+  }
+  f_apply_preemptor(s, false);  // revertSimulation
+  if (!fits) {
+    if (lane == 0)
+      for (int t = 0; t < nt; t++) { int r = s.trow[t]; w.bytes += 16 * (int64_t)S.plen[S.adm_cq[r]] * (S.adm_use_off[r + 1] - S.adm_use_off[r]); }
+    // restoreSnapshot :356 — the private copy is dropped, but callers read it: put the rows back
+    for (int t = 0; t < nt; t++) f_apply_row(s, s.trow[t], true, false);
+    w.ntgt = 0;
+    return;
+  }
+  // fillBackWorkloads :341-354 with allowBorrowing = true
+  for (int t = nt - 2; t >= 0; t--) {
+    int r = s.trow[t];
+    f_apply_row(s, r, true, true);
+    if (f_fits(s)) {
+      if (lane == 0) { s.trow[t] = s.trow[nt - 1]; s.treason[t] = s.treason[nt - 1]; }
+      nt--;
+      wsync();
+    } else {
+      f_apply_row(s, r, false, true);
+    }
+  }
+  w.ntgt = nt;
+  if (lane == 0)
+    for (int t = 0; t < nt; t++) { int r = s.trow[t]; w.bytes += 16 * (int64_t)S.plen[S.adm_cq[r]] * (S.adm_use_off[r + 1] - S.adm_use_off[r]); }
+}
+
 KQ_DEV Search make_search(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed) {
   Search s;
   s.k = &k; s.w = &w; s.slot = slot; s.usage = usage; s.removed = removed;
@@ -725,24 +1162,26 @@ KQ_DEV Search make_search(const K& k, Wave& w, int slot, const int64_t* usage, c
   s.trow = k.X.tgt_row + (size_t)slot * k.X.tgt_cap;
   s.treason = k.X.tgt_reason + (size_t)slot * k.X.tgt_cap;
   s.tree = 0; s.row0 = 0; s.nrows = 0;
+  s.qcnt = k.X.qcnt ? k.X.qcnt + (size_t)slot * k.X.max_tree_cqs : nullptr;
+  s.qhead = k.X.qhead ? k.X.qhead + (size_t)slot * k.X.max_tree_cqs : nullptr;
+  s.cohp = k.X.cohp ? k.X.cohp + (size_t)slot * k.X.max_tree_nodes : nullptr;
   return s;
 }
 
 // PreemptionOracle.SimulatePreemption (preemption_oracle.go:43-85) for one flavor-resource
 KQ_DEV void simulate_preemption(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed,
                                 int fr, int64_t val, int base_borrow, int* pm, int* borrow) {
-  if (k.C.fair_sharing) { set_error(k, KQ_EUNSUPPORTED); *pm = PM_NOCAND; *borrow = base_borrow; return; }
   if (lane_id() == 0) { w.ns = 1; w.s_fr[0] = fr; w.s_qty[0] = val; w.s_inu[0] = 1; w.s_need[0] = 1; }
   wsync();
   Search s = make_search(k, w, slot, usage, removed);
-  classical_search(s);
+  if (k.C.fair_sharing) fair_search(s); else classical_search(s);
   wsync();
   if (w.ntgt == 0) { *pm = PM_NOCAND; *borrow = base_borrow; return; }
   bool any_same = false;
   for (int t = 0; t < w.ntgt; t++) if (k.S.adm_cq[s.trow[t]] == w.cq) any_same = true;
-  UW uw{&k.S, s.W, 1, 0};
   bool mr;
-  *borrow = find_height(k.S, w.path, w.plen, fr, val, uw, &mr);
+  if (k.C.fair_sharing) { UF uf{&k.S, s.W, fr}; *borrow = find_height(k.S, w.path, w.plen, fr, val, uf, &mr); }
+  else { UW uw{&k.S, s.W, 1, 0}; *borrow = find_height(k.S, w.path, w.plen, fr, val, uw, &mr); }
   *pm = any_same ? PM_PREEMPT : PM_RECLAIM;
 }
 
@@ -1002,9 +1441,8 @@ KQ_DEV void prepare_target_slots(const K& k, Wave& w) {
 
 KQ_DEV Search get_targets(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed) {
   Search s = make_search(k, w, slot, usage, removed);
-  if (k.C.fair_sharing) { set_error(k, KQ_EUNSUPPORTED); w.ntgt = 0; return s; }
   prepare_target_slots(k, w);
-  classical_search(s);
+  if (k.C.fair_sharing) fair_search(s); else classical_search(s);
   wsync();
   return s;
 }
@@ -1708,6 +2146,164 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
   }
   if (lane == 0 && bytes) atomic_add_i64(O.stat_bytes, (long long)bytes);
   if (loaded) { KQ_T0(); pc_flush(k, w, lds, tree); KQ_TS(k, 9); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fair-sharing iterator (fair_sharing_iterator.go) — per root-cohort tree: pop = computeDRS + runTournament,
+// then processEntry on the winner; the next pop sees the usage that entry added (scheduler.go:358-359).
+// ------------------------------------------------------------------------------------------------
+// usage_work with one entry's assignment usage added at its CQ (SimulateUsageAddition :251), evaluated
+// functionally so that lanes can look at different entries at once: the amount reaching path[level] is
+// what AddUsage would have bubbled there (resource_node.go:144-152).
+struct PE {
+  const K* k; const Wave* w; const int32_t* path; int level; const int32_t* ufr; const int64_t* uqty; int nu;
+  KQ_MDEV int64_t get(int node, int fr) const {
+    const DSnap& S = k->S;
+    int64_t base = up_plane(*k, *w, 0, fr).get(node);
+    for (int q = 0; q < nu; q++) {
+      if (ufr[q] != fr) continue;
+      int64_t delta = uqty[q];
+      bool reach = true;
+      for (int l = 0; l < level; l++) {
+        int n = path[l];
+        int64_t la = i64max(0, a_sub(local_quota(S, n, fr), up_plane(*k, *w, 0, fr).get(n)));
+        if (delta > la) delta = a_sub(delta, la); else { reach = false; break; }
+      }
+      if (reach) base = a_add(base, delta);
+    }
+    return base;
+  }
+};
+// entryComparer.less (fair_sharing_iterator.go:176-221): entry a wins over entry b inside parentCohort
+KQ_DEV bool fs_less(const K& k, int slot, int a, int b, int cohort) {
+  const DSnap& S = k.S; const DHeads& H = k.H;
+  if (gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS)) {
+    bool ap = H.flags[a] & KQ_HEAD_IS_PREEMPTOR, bp = H.flags[b] & KQ_HEAD_IS_PREEMPTOR;
+    if (ap != bp) return ap;
+  }
+  const int ca = H.cq[a], cb = H.cq[b];
+  const size_t base = (size_t)slot * k.X.max_tree_cqs;
+  const size_t ia = (base + S.cq_local[ca]) * KQ_MAXD + (S.depth[ca] - S.depth[cohort] - 1);
+  const size_t ib = (base + S.cq_local[cb]) * KQ_MAXD + (S.depth[cb] - S.depth[cohort] - 1);
+  if (gate(k, KQ_GATE_FS_PRIORITIZE_NON_BORROWING)) {
+    bool aB = k.X.fs_bon[ia], bB = k.X.fs_bon[ib];
+    if (aB != bB) return !aB;
+  }
+  DRSv da, db;
+  da.ratio = k.X.fs_ratio[ia]; da.weight = k.X.fs_weight[ia]; da.borrowing = 0; da.borrow_on = 0;
+  db.ratio = k.X.fs_ratio[ib]; db.weight = k.X.fs_weight[ib]; db.borrowing = 0; db.borrow_on = 0;
+  int c = compare_drs(da, db);
+  if (c != 0) return c == -1;
+  if (gate(k, KQ_GATE_PRIORITY_SORTING_IN_COHORT) && H.priority[a] != H.priority[b]) return H.priority[a] > H.priority[b];
+  return H.queue_ts[a] < H.queue_ts[b];
+}
+KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* lds, size_t lds_bytes) {
+  const DSnap& S = k.S; const DOut& O = k.O; const DHeads& H = k.H;
+  const int lane = lane_id();
+  const int q0 = S.tree_cq_off[tree], nqs = S.tree_cq_off[tree + 1] - q0;
+  const int n0 = S.tree_node_off[tree], nn = S.tree_node_off[tree + 1] - n0;
+  int32_t* cq_ent = k.X.cq_ent + (size_t)slot * k.X.max_tree_cqs;
+  int32_t* win = k.X.fs_win + (size_t)slot * k.X.max_tree_nodes;
+  int32_t* seq = k.X.fs_seq + (size_t)slot * k.X.max_tree_cqs;
+  double* fr_ratio = k.X.fs_ratio + (size_t)slot * k.X.max_tree_cqs * KQ_MAXD;
+  double* fr_weight = k.X.fs_weight + (size_t)slot * k.X.max_tree_cqs * KQ_MAXD;
+  uint8_t* fr_bon = k.X.fs_bon + (size_t)slot * k.X.max_tree_cqs * KQ_MAXD;
+  if (lane == 0) {
+    w.pc_ncq = nqs;
+    w.pc_ncoh = nn - nqs;
+    w.pc_lds = lds;
+    w.pc_on = (w.pc_ncoh > 0 && (size_t)w.pc_ncoh * S.nfr * 16 <= lds_bytes) ? 1 : 0;
+  }
+  for (int i = lane; i < nqs; i += WAVE) cq_ent[i] = -1;
+  wsync();
+  // cqToEntry: the last head of a CQ wins (:58-60)
+  for (int h = lane; h < H.n; h += WAVE) {
+    int c = H.cq[h];
+    if (S.tree_of[c] == tree) atomic_max_i32(&cq_ent[S.cq_local[c]], h);
+  }
+  wsync();
+  int remaining = 0;
+  for (int base = 0; base < nqs; base += WAVE) { int i = base + lane; remaining += popc64(wballot(i < nqs && cq_ent[i] >= 0)); }
+  if (remaining == 0) return;
+  pc_load(k, w, lds, tree);
+  const bool lone = nn == 1;  // ClusterQueue without Cohort (:71-78)
+  const int root = lone ? -1 : S.path[(size_t)S.tree_cqs[q0] * KQ_MAXD + S.plen[S.tree_cqs[q0]] - 1];
+  const bool want_bon = gate(k, KQ_GATE_FS_PRIORITIZE_NON_BORROWING);
+  int lpos = 0;
+  while (remaining > 0) {
+    int e;
+    if (lone) {
+      e = cq_ent[0];
+    } else {
+      // computeDRS (:227-263): one lane per ClusterQueue that still has an entry
+      int64_t lb = 0;
+      for (int i = lane; i < nqs; i += WAVE) {
+        int en = cq_ent[i];
+        if (en < 0) continue;
+        int c = S.tree_cqs[q0 + i];
+        const int32_t* path = S.path + (size_t)c * KQ_MAXD;
+        int plen = S.plen[c];
+        PE pe{&k, &w, path, 0, O.use_fr + (size_t)en * KQ_MAXU, O.use_qty + (size_t)en * KQ_MAXU,
+              (H.flags[en] & KQ_HEAD_HAS_QUOTA_RESERVATION) ? 0 : O.use_n[en]};  // netUsage scheduler.go:785-794
+        for (int l = 0; l + 1 < plen; l++) {
+          pe.level = l;
+          DRSv d = drs_of(S, path[l], pe, &lb, pe.ufr, pe.uqty, want_bon ? pe.nu : 0);
+          fr_ratio[(size_t)i * KQ_MAXD + l] = d.ratio; fr_weight[(size_t)i * KQ_MAXD + l] = d.weight; fr_bon[(size_t)i * KQ_MAXD + l] = (uint8_t)d.borrow_on;
+        }
+      }
+      {
+        int64_t tot = wsum_i64(lb);
+        if (lane == 0 && tot) atomic_add_i64(O.stat_bytes, (long long)tot);
+      }
+      wsync();
+      // runTournament (:125-163), bottom-up by depth: one lane per cohort
+      for (int d = KQ_MAXD - 1; d >= 0; d--) {
+        for (int i = nqs + lane; i < nn; i += WAVE) {
+          int x = S.tree_nodes[n0 + i];
+          if (S.depth[x] != d) continue;
+          int best = -1;
+          for (int j = S.child_cohort_off[x - S.nq]; j < S.child_cohort_off[x - S.nq + 1]; j++) {
+            int cnd = win[S.node_local[S.child_cohort[j]]];
+            if (cnd < 0) continue;
+            if (best < 0 || fs_less(k, slot, cnd, best, x)) best = cnd;
+          }
+          for (int j = S.child_cq_off[x - S.nq]; j < S.child_cq_off[x - S.nq + 1]; j++) {
+            int cnd = cq_ent[S.cq_local[S.child_cq[j]]];
+            if (cnd < 0) continue;
+            if (best < 0 || fs_less(k, slot, cnd, best, x)) best = cnd;
+          }
+          win[S.node_local[x]] = best;
+        }
+        wsync();
+      }
+      e = win[S.node_local[root]];
+    }
+    wsync();
+    if (lane == 0) { cq_ent[S.cq_local[H.cq[e]]] = -1; seq[lpos] = e; }
+    wsync();
+    process_entry(k, w, e, lpos, slot, tree);
+    lpos++;
+    remaining--;
+  }
+  // merge key of the canonical getCq (lowest CQ index still in the map): the tree pops until
+  // that CQ's own entry has been returned, so an entry is emitted in the turn of the smallest CQ at or after it.
+  if (lane == 0) {
+    int run = 0x7fffffff;
+    for (int j = lpos - 1; j >= 0; j--) { int e = seq[j]; int c = H.cq[e]; if (c < run) run = c; k.X.fs_key[e] = run; }
+  }
+  wsync();
+  pc_flush(k, w, lds, tree);
+}
+// global iteration position of a fair-sharing entry: rank of (merge key, position in the tree's sequence)
+KQ_DEV int fair_rank(const K& k, int e, int f_begin, int f_end) {
+  const int ke = k.X.fs_key[e], pe = k.O.order[e];
+  int r = 0;
+  for (int f = f_begin; f < f_end; f++) {
+    int kf = k.X.fs_key[f];
+    if (kf < 0) continue;
+    if (kf < ke || (kf == ke && k.O.order[f] < pe)) r++;
+  }
+  return r;
 }
 
 // classical entry order (scheduler.go:1110-1163): a precedes b

@@ -77,6 +77,30 @@ __global__ __launch_bounds__(64) void k_process(const K* __restrict__ kp, unsign
   process_tree(k, w, blockIdx.x, blockIdx.x, (int64_t*)dyn_lds, lds_bytes);
 }
 
+// Fair sharing: the iterator pops interleave with processEntry (scheduler.go:358), so ordering and processing
+// are one kernel: one wave per root-cohort tree; the tree's cohort usage rows stay in LDS.
+__global__ __launch_bounds__(64) void k_process_fair(const K* __restrict__ kp, unsigned lds_bytes) {
+  const K& k = *kp;
+  __shared__ Wave w;
+  extern __shared__ __align__(16) unsigned char dyn_lds[];
+  process_tree_fair(k, w, blockIdx.x, blockIdx.x, (int64_t*)dyn_lds, lds_bytes);
+}
+// global iteration positions from the per-tree sequences (kq::fair_rank): 2-D grid like k_order
+__global__ __launch_bounds__(256) void k_fair_rank(const K* __restrict__ kp, int32_t* rank) {
+  const K& k = *kp;
+  const int n = k.H.n;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || k.X.fs_key[i] < 0) return;
+  const int base = blockIdx.y * 256;
+  const int cnt = fair_rank(k, i, base, (base + 256) < n ? (base + 256) : n);
+  if (cnt) atomicAdd(&rank[i], cnt);
+}
+__global__ __launch_bounds__(256) void k_fair_rank_apply(const K* __restrict__ kp, const int32_t* rank) {
+  const K& k = *kp;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < k.H.n && k.X.fs_key[i] >= 0) k.O.order[i] = rank[i];
+}
+
 namespace kq {
 struct HipBackend {
   hipStream_t stream = nullptr;
@@ -156,7 +180,22 @@ struct HipBackend {
     hipLaunchKernelGGL(k_process, dim3(n_tree), dim3(64), lds, stream, put_k(k, 1), (unsigned)lds);
     chk(hipGetLastError(), "k_process");
   }
-  size_t lds_attr = 0;
+  size_t lds_attr = 0, lds_attr_fair = 0;
+  void launch_process_fair(const K& k, int n_tree, size_t cohort_rows_bytes, int32_t* rank) {
+    const size_t budget = 160 * 1024 - 8 * 1024;
+    size_t lds = cohort_rows_bytes <= budget ? cohort_rows_bytes : 0;
+    if (lds > 48 * 1024 && lds != lds_attr_fair) {
+      chk(hipFuncSetAttribute((const void*)k_process_fair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
+      lds_attr_fair = lds;
+    }
+    const K* d = put_k(k, 1);
+    hipLaunchKernelGGL(k_process_fair, dim3(n_tree), dim3(64), lds, stream, d, (unsigned)lds);
+    const int nb = (k.H.n + 255) / 256;
+    chk(hipMemsetAsync(rank, 0, (size_t)k.H.n * sizeof(int32_t), stream), "memset rank");
+    hipLaunchKernelGGL(k_fair_rank, dim3(nb, nb), dim3(256), 0, stream, d, rank);
+    hipLaunchKernelGGL(k_fair_rank_apply, dim3(nb), dim3(256), 0, stream, d, (const int32_t*)rank);
+    chk(hipGetLastError(), "k_process_fair");
+  }
 };
 }  // namespace kq
 

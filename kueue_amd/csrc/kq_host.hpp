@@ -31,7 +31,7 @@ template <class B> struct EngineT {
   // cycle buffers (grow-only)
   struct Buf { void* p = nullptr; size_t cap = 0; };
   std::vector<Buf*> all_bufs;
-  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank;
+  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_fs[10];
   struct HeadBatch { Buf hb[16]; DHeads H{}; int n = 0; size_t nps = 0; int slot_cap = 1; int64_t cycle = 0; bool valid = false; };
   std::vector<HeadBatch> batches;  // [0] = transient batch of kq_cycle_run, [1+b] = resident batch b
   Buf ob[24];  // output arrays
@@ -69,6 +69,7 @@ template <class B> struct EngineT {
     free_snapshot();
     if (hstage) be.free_host(hstage);
     for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank}) if (b->p) be.free(b->p);
+    for (auto& b : b_fs) if (b.p) be.free(b.p);
     for (auto& hbch : batches) for (auto& b : hbch.hb) if (b.p) be.free(b.p);
     for (auto& b : ob) if (b.p) be.free(b.p);
   }
@@ -119,6 +120,7 @@ template <class B> struct EngineT {
     S.tree_row_off = upload(prep.tree_row_off.data(), prep.tree_row_off.size());
     S.tree_rows = upload(prep.tree_rows.data(), prep.tree_rows.size());
     S.lendable = upload(prep.lendable.data(), prep.lendable.size());
+    S.rank_pos = upload(prep.rank_pos.data(), prep.rank_pos.size());
     S.top_of = upload(prep.top_of.data(), prep.top_of.size());
     S.fair_weight = upload(s->fair_weight, N);
     S.child_cohort_off = upload(s->child_cohort_off, prep.nc + 1);
@@ -212,7 +214,6 @@ template <class B> struct EngineT {
 
   int cycle_exec(int slot, kq_decisions* out) {
     if (!have_snapshot) return fail(KQ_EINVAL, "kq_cycle_run before kq_snapshot_put");
-    if (cfg.fair_sharing) return fail(KQ_EUNSUPPORTED, "fair sharing is not implemented on the device path yet");
     if (slot < 0 || slot >= (int)batches.size() || !batches[slot].valid) return fail(KQ_EINVAL, "unknown head batch");
     HeadBatch& hbch = batches[slot];
     const int n = hbch.n;
@@ -228,6 +229,7 @@ template <class B> struct EngineT {
     const size_t Nfr = (size_t)prep.N * prep.nfr;
     K k{};
     k.S = S;
+    k.C.n_fs = std::min(std::max(cfg.n_fs_strategies, 0), 2); k.C.fs[0] = cfg.fs_strategies[0]; k.C.fs[1] = cfg.fs_strategies[1];
     k.C.gates = cfg.gates; k.C.fair_sharing = cfg.fair_sharing; k.C.quota_check_strategy = cfg.quota_check_strategy; k.C.cycle = hbch.cycle;
     k.H = hbch.H;
     // outputs
@@ -262,13 +264,22 @@ template <class B> struct EngineT {
     const int slots = std::max(slots_nom, prep.n_tree);
     DScratch& X = k.X;
     X.max_tree_nodes = prep.max_tree_nodes; X.max_tree_cqs = std::max(prep.max_tree_cqs, 1); X.max_tree_rows = std::max(prep.max_tree_rows, 1);
-    X.slot_cap = slot_cap; X.tgt_cap = std::max(prep.max_tree_rows, 1);
+    // fair sharing: the private state of a victim search covers every flavor-resource (DRS reads them all)
+    X.slot_cap = cfg.fair_sharing ? std::max<int>(slot_cap, (int)prep.nfr) : slot_cap; X.tgt_cap = std::max(prep.max_tree_rows, 1);
     X.w = grow<int64_t>(b_w, (size_t)slots * X.max_tree_nodes * X.slot_cap);
     X.cqinfo = grow<uint8_t>(b_cqinfo, (size_t)slots * X.max_tree_cqs);
     X.cls = grow<uint8_t>(b_cls, (size_t)slots * X.max_tree_rows);
     X.tgt_row = grow<int32_t>(b_tgt_row, (size_t)slots * X.tgt_cap);
     X.tgt_reason = grow<uint8_t>(b_tgt_reason, (size_t)slots * X.tgt_cap);
     X.nom = grow<int32_t>(b_nom, (size_t)slots * KQ_MAXPS * nR);
+    if (cfg.fair_sharing) {
+      const size_t tq = (size_t)slots * X.max_tree_cqs, tn = (size_t)slots * X.max_tree_nodes;
+      X.qcnt = grow<int32_t>(b_fs[0], tq); X.qhead = grow<uint32_t>(b_fs[1], tq); X.cohp = grow<uint8_t>(b_fs[2], tn);
+      X.cq_ent = grow<int32_t>(b_fs[3], tq); X.fs_ratio = grow<double>(b_fs[4], tq * KQ_MAXD); X.fs_weight = grow<double>(b_fs[5], tq * KQ_MAXD);
+      X.fs_bon = grow<uint8_t>(b_fs[6], tq * KQ_MAXD); X.fs_win = grow<int32_t>(b_fs[7], tn); X.fs_seq = grow<int32_t>(b_fs[8], tq);
+      X.fs_key = grow<int32_t>(b_fs[9], n);
+      be.memset(X.fs_key, 0xff, (size_t)n * sizeof(int32_t));
+    }
     k.usage = d_usage;
     k.usage_work = grow<int64_t>(b_usage_work, Nfr);
     k.usage_np = grow<int64_t>(b_usage_np, Nfr);
@@ -283,10 +294,12 @@ template <class B> struct EngineT {
     be.timer_mark(0);
     be.launch_nominate(k, slots_nom);
     be.timer_mark(1);
-    be.launch_order(k, order_idx, grow<int32_t>(b_rank, n));
+    int32_t* rank = grow<int32_t>(b_rank, n);
+    if (!cfg.fair_sharing) be.launch_order(k, order_idx, rank);
     be.timer_mark(2);
     k.O.stat_bytes = (long long*)(misc + 2);
-    be.launch_process(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16);
+    if (cfg.fair_sharing) be.launch_process_fair(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16, rank);
+    else be.launch_process(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16);
     be.timer_mark(3);
 
     // decisions back: one D2H of the packed region into host staging, then plain memcpy to the caller's arrays

@@ -36,6 +36,7 @@ struct Prep {
   // fair sharing: calculateLendable(parent(node)) per resource (fair_sharing.go:186-200). It only reads quotas
   // (potentialAvailable ignores usage), so it is a per-snapshot constant. [N * nR]; 0 for root nodes.
   std::vector<int64_t> lendable;
+  std::vector<int32_t> rank_pos;                   // [n_adm] position of the row inside its tree's tree_rows segment
   std::vector<int32_t> top_of;                     // [N] the ancestor-or-self that is a child of the root (-1 for roots)
   int max_tree_nodes = 0, max_tree_cqs = 0, max_tree_rows = 0, max_tree_cohorts = 0;
   std::string err;
@@ -121,6 +122,9 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
         return a < b;
       });
   }
+  p.rank_pos.assign(p.n_adm, 0);
+  for (int t = 0; t < p.n_tree; t++)
+    for (int i = p.tree_row_off[t]; i < p.tree_row_off[t + 1]; i++) p.rank_pos[p.tree_rows[i]] = i - p.tree_row_off[t];
   for (int t = 0; t < p.n_tree; t++) {
     p.max_tree_nodes = std::max(p.max_tree_nodes, p.tree_node_off[t + 1] - p.tree_node_off[t]);
     p.max_tree_cqs = std::max(p.max_tree_cqs, p.tree_cq_off[t + 1] - p.tree_cq_off[t]);

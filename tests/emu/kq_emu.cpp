@@ -48,6 +48,14 @@ struct EmuBackend {
     for (int t = 0; t < n_tree; t++) { Wave w{}; process_tree(k, w, t, t, lds.data(), budgets[(t + rot) % 3]); }
     rot++;
   }
+  void launch_process_fair(const K& k, int n_tree, size_t, int32_t* rank) {
+    std::vector<int64_t> lds(160 * 1024 / 8);
+    const size_t budgets[2] = {lds.size() * 8, 0};
+    for (int t = 0; t < n_tree; t++) { Wave w{}; process_tree_fair(k, w, t, t, lds.data(), budgets[(t + rot) % 2]); }
+    rot++;
+    for (int i = 0; i < k.H.n; i++) rank[i] = k.X.fs_key[i] >= 0 ? fair_rank(k, i, 0, k.H.n) : 0;
+    for (int i = 0; i < k.H.n; i++) if (k.X.fs_key[i] >= 0) k.O.order[i] = rank[i];
+  }
 };
 }  // namespace kq
 

@@ -9,7 +9,7 @@ POL_WCQ = ["Never", "LowerPriority", "LowerOrNewerEqualPriority"]
 POL_RWC = ["Never", "LowerPriority", "LowerOrNewerEqualPriority", "Any"]
 
 
-def random_case(seed, fair=False, preemption=True, max_cq=6, partial=False):
+def random_case(seed, fair=False, preemption=True, max_cq=6, partial=False, fair_dups=False):
     rnd = random.Random(seed)
     n_flavors = rnd.randint(1, 4)
     flavors = [f"f{i}" for i in range(n_flavors)]
@@ -97,7 +97,7 @@ def random_case(seed, fair=False, preemption=True, max_cq=6, partial=False):
                 last_tried_flavor_idx=[{r: rnd.randint(-1, max(0, n_flavors - 2)) for r in ps.requests if r in RES} for ps in pods],
                 cluster_queue_generation=rnd.randint(0, 3), scheduling_cycle=rnd.randint(0, 5), scheduling_hash=rnd.choice([0, 7, 9]))
         pending.append(w)
-        if not fair and rnd.random() < 0.12:
+        if (not fair or fair_dups) and rnd.random() < 0.12:
             # a second head on the same ClusterQueue (second-pass workloads come on top of one head per CQ,
             # pkg/cache/queue/manager.go:923)
             import copy
@@ -115,7 +115,16 @@ def random_case(seed, fair=False, preemption=True, max_cq=6, partial=False):
         gates["RecomputeAssignmentUponPreemptionTargetsOverlap"] = False
     if rnd.random() < 0.1:
         gates["FlavorFungibilityPreserveScanProgress"] = False
-    cfg = make_config(fair_sharing=fair, gates=gates_with(gates))
+    fs = ()
+    if fair and fair_dups:  # second generation of fair cases: gate and strategy variations on top
+        if rnd.random() < 0.2:
+            gates["FairSharingPreemptWithinNominal"] = False
+        if rnd.random() < 0.2:
+            gates["FairSharingPrioritizeNonBorrowing"] = False
+        if rnd.random() < 0.2:
+            gates["PrioritizePreemptorWorkloads"] = False
+        fs = rnd.choice([(), (), (0,), (1,), (1, 0), (0, 1)])
+    cfg = make_config(fair_sharing=fair, gates=gates_with(gates), fs_strategies=fs)
     return cfg, snap, heads
 
 

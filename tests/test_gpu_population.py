@@ -13,6 +13,8 @@ CASES = [
     ("cfg2-full", dict(cfg=2), [0, 3, 40]),
     ("cfg3-full", dict(cfg=3), [0, 7, 99]),                       # 1000 CQ, 1111 nodes, 20k admitted, 100k pending
     ("cfg4c-300cq", dict(cfg=4, n_cq=300, per_cq=4), [0, 2]),     # classical preemption + DeferredFit + overlap recompute
+    ("cfg4f-100cq", dict(cfg=4, n_cq=100, per_cq=4, fair_sharing=True), [0, 1]),  # fair sharing + fair preemption (oracle: ~12 s/cycle)
+    ("cfg3f-300cq", dict(cfg=3, n_cq=300, per_cq=4, fair_sharing=True), [0, 1]),  # fair-sharing iterator, admission-heavy
 ]
 
 
@@ -20,7 +22,7 @@ CASES = [
 def test_population_cycles_bit_exact(oracle, name, kw, cycles):
     from kueue_amd.engine import Engine
     pop = generate(**kw)
-    cfg = make_config()
+    cfg = make_config(fair_sharing=bool(kw.get("fair_sharing")))
     eng = Engine(cfg)
     try:
         eng.put(pop.snapshot)
