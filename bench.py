@@ -32,9 +32,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4c"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4c", "cfg3f", "cfg4f"],
                     help="cfg3 = BASELINE.json configs[2] (100k pending, 1k CQ, 16 flavors, 3-level cohorts); "
-                         "cfg4c = configs[3] population under classical preemption")
+                         "cfg4c = configs[3] population under classical preemption; cfg4f = configs[3] as quoted "
+                         "(fair sharing + preemption); cfg3f = configs[2] population under fair sharing")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -54,11 +55,12 @@ def main():
     from kueue_amd.engine import Engine
     from kueue_amd.population import BASE_SEED, generate
 
-    cfgn = {"cfg2": 2, "cfg3": 3, "cfg4c": 4}[args.workload]
-    pop = generate(cfgn, seed=BASE_SEED + 1000 * rank)
+    cfgn = {"cfg2": 2, "cfg3": 3, "cfg4c": 4, "cfg3f": 3, "cfg4f": 4}[args.workload]
+    fair = args.workload.endswith("f")
+    pop = generate(cfgn, seed=BASE_SEED + 1000 * rank, fair_sharing=fair)
     snap = pop.snapshot
     per_cq = int((pop.cq_w_off[1:] - pop.cq_w_off[:-1]).max())
-    kcfg = make_config(fair_sharing=False, device=local_rank)
+    kcfg = make_config(fair_sharing=fair, device=local_rank)
     eng = Engine(kcfg)
     eng.put(snap)
     n_batches = min(per_cq, args.steps + args.warmup)
@@ -67,7 +69,8 @@ def main():
     import ctypes as C
     for b, hb in enumerate(batches):
         eng._check(lib.kq_heads_put(h, C.byref(hb.struct()), b))
-    outs = [Decisions(hb, tgt_cap=max(4096, 4 * snap.n_adm)) for hb in batches]
+    # fair-sharing preemption names hundreds of victims per preemptor (every borrowing CQ gives back): size for it
+    outs = [Decisions(hb, tgt_cap=max(4096, (32 if fair else 4) * snap.n_adm)) for hb in batches]
     phase_ms = np.zeros(3, np.float64)
     phase_by = np.zeros(2, np.int64)
 
@@ -162,8 +165,17 @@ def cpu_baseline(pop, kcfg, budget_s):
     snap = pop.snapshot
     t0 = time.perf_counter()
     dec, cycles, cpu_t = 0, 0, 0.0
+    # fair sharing + preemption: one full 1000-head cycle takes the CPU tens of minutes (every SimulatePreemption
+    # walks the DRS tournament of the whole tree), so the bounded sample is an evenly spaced subset of the heads
+    limit = 0
+    if kcfg.fair_sharing and pop.preemption:
+        limit = 4
+        t1 = time.perf_counter()
+        kqo.cycle_run(kcfg, snap, pop.heads_for_cycle(0, cycle=1, limit=limit))
+        per_head = (time.perf_counter() - t1) / limit
+        limit = int(max(4, min(1000, budget_s / max(per_head, 1e-6))))
     while time.perf_counter() - t0 < budget_s and cycles < 100:
-        hb = pop.heads_for_cycle(cycles, cycle=cycles + 1)
+        hb = pop.heads_for_cycle(cycles, cycle=cycles + 1, limit=limit)
         t1 = time.perf_counter()
         kqo.cycle_run(kcfg, snap, hb)
         dt = time.perf_counter() - t1
@@ -174,7 +186,7 @@ def cpu_baseline(pop, kcfg, budget_s):
             first = dt
     # only oracle time counts (head batch construction excluded)
     return {"value": dec / max(cpu_t, 1e-9), "unit": "decisions/s", "cores": 1, "kind": "port",
-            "sample": f"first {cycles} cycles ({dec} decisions) of the same population, C++ restatement of the Go path, "
+            "sample": f"first {cycles} cycles ({dec} decisions{', ' + str(limit) + ' evenly spaced heads per cycle' if limit else ''}) of the same population, C++ restatement of the Go path, "
                       f"host nproc={os.cpu_count()}", "first_cycle_ms": first * 1e3}
 
 

@@ -563,7 +563,7 @@ class Decisions:
     def __init__(self, heads: Heads, tgt_cap: Optional[int] = None):
         snap = heads.snap
         n, nps, nR = heads.n, heads.n_ps, snap.n_resource
-        cap = tgt_cap if tgt_cap is not None else max(16, snap.n_adm)
+        cap = tgt_cap if tgt_cap is not None else max(16, snap.n_adm * max(1, min(heads.n, 8)))  # every head may name most rows
         self.heads, self.snap = heads, snap
         self.a = dict(
             status=np.zeros(n, np.uint8), action=np.zeros(n, np.uint8), nominated_mode=np.zeros(n, np.uint8),

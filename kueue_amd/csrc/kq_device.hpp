@@ -38,6 +38,8 @@ KQ_DEV uint64_t wballot(bool p) { return p ? 1ull : 0ull; }
 template <class T> KQ_DEV T wbcast(T v, int) { return v; }
 KQ_DEV void wsync() {}
 KQ_DEV void wsync_lds() {}
+KQ_DEV void bsync() {}
+KQ_DEV uint64_t wmin_u64(uint64_t v) { return v; }
 KQ_DEV int ffs64(uint64_t m) { return __builtin_ctzll(m); }
 KQ_DEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
 KQ_DEV int atomic_add_i32(int* p, int v) { int o = *p; *p += v; return o; }
@@ -57,8 +59,17 @@ KQ_DEV uint64_t wballot(bool p) { return __ballot(p); }
 KQ_DEV int wbcast(int v, int src) { return __shfl(v, src, 64); }
 KQ_DEV int64_t wbcast(int64_t v, int src) { return (int64_t)__shfl((long long)v, src, 64); }
 KQ_DEV double wbcast(double v, int src) { return __longlong_as_double(__shfl(__double_as_longlong(v), src, 64)); }
-// one wave per workgroup: __syncthreads() is the wave-level fence for LDS and global scratch
-KQ_DEV void wsync() { __syncthreads(); }
+// Wave-level sync: the serial logic of every kernel runs inside ONE wave, whose lanes execute in lockstep, so
+// making one lane's LDS / global-scratch writes visible to the others only needs the outstanding memory
+// operations drained (workgroup-scope fence = s_waitcnt; the CU's L1 is shared, no invalidate) and the compiler
+// kept from moving accesses across. No s_barrier: workgroups may hold helper waves that are not in this code.
+KQ_DEV void wsync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+// all waves of the workgroup (phase boundaries of the multi-wave fair-sharing kernel)
+KQ_DEV void bsync() { __syncthreads(); }
+KQ_DEV uint64_t wmin_u64(uint64_t v) {
+  for (int o = 32; o > 0; o >>= 1) { uint64_t t = (uint64_t)__shfl_xor((unsigned long long)v, o, 64); v = t < v ? t : v; }
+  return v;
+}
 // LDS-only visibility inside the single wave of a workgroup: the LDS pipeline is in order per wave, so only
 // the compiler must be kept from reordering / caching; no wait for outstanding global memory traffic.
 KQ_DEV void wsync_lds() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
@@ -101,6 +112,7 @@ struct DSnap {
   const int64_t* lendable;   // [N * nR] calculateLendable(parent(node)) per resource (static)
   const int32_t* top_of;     // [N] ancestor-or-self that is a child of the root
   const int32_t* rank_pos;   // [n_adm] position of the row in its tree's rank-ordered tree_rows segment
+  const int32_t* frcount;    // [N] flavor-resources with a SubtreeQuota entry
   const double* fair_weight; // [N]
   const int32_t *child_cohort_off, *child_cohort, *child_cq_off, *child_cq, *depth;
   const int64_t* adm_rts;
@@ -111,6 +123,7 @@ struct DCfg {
   uint32_t gates;
   int fair_sharing;
   int n_fs, fs[2];           // fair-sharing preemption strategies (preemption.go:364-366)
+  int fs_plain;              // all amounts small: per-node borrowed sums are exact in plain int64 (no saturation)
   int quota_check_strategy;
   int64_t cycle;
 };
@@ -162,6 +175,8 @@ struct DScratch {
   int32_t* qcnt;     // [slots][max_tree_cqs] remaining candidates of the CQ
   uint32_t* qhead;   // [slots][max_tree_cqs] key of the first remaining candidate (evicted bit | rank position)
   uint8_t* cohp;     // [slots][max_tree_nodes] prunedCohorts
+  int64_t* psum;     // [slots][max_tree_nodes * nR] borrowed sums of the search's private state (C.fs_plain)
+  int32_t* ppos;     // [slots][max_tree_nodes]
   // fair-sharing iterator (fair_sharing_iterator.go): per tree slot
   int32_t* cq_ent;   // [slots][max_tree_cqs] cqToEntry: the head still to schedule for the CQ, -1 = none
   double* fs_ratio;  // [slots][max_tree_cqs * KQ_MAXD] drsValues: DRS of path[level] with the entry admitted
@@ -170,6 +185,15 @@ struct DScratch {
   int32_t* fs_win;   // [slots][max_tree_nodes] tournament winner per cohort
   int32_t* fs_seq;   // [slots][max_tree_cqs] the tree's pop sequence
   int32_t* fs_key;   // [H] merge key: smallest CQ index at or after the entry in its tree's sequence
+  uint8_t* fs_stale; // [slots][max_tree_cqs] lowest path level whose cached DRS is out of date (255 = none)
+  int32_t* fs_cost;  // [slots][max_tree_cqs * KQ_MAXD] algorithmic bytes of the cached DRS evaluation
+  long long* fs_sum; // [slots] sum of fs_cost over the entries still in the map
+  int32_t* fs_ctl;   // [slots][4] leader -> helpers: remaining, last popped CQ, usage changed
+  // per-node borrowed amount per resource = sum over flavors of max(0, usage - subtreeQuota), and the number of
+  // borrowed flavor-resources: DRS (fair_sharing.go:149-182) is a function of these. bu_* : cycle-start plane
+  // (k.usage), bs_* : the work plane as processEntry mutates it.
+  int64_t *bu_sum, *bs_sum;  // [N * nR]
+  int32_t *bu_pos, *bs_pos;  // [N]
   int32_t max_tree_nodes, max_tree_cqs, max_tree_rows, slot_cap, tgt_cap;
 };
 
@@ -387,6 +411,12 @@ struct Wave {
   int64_t g_lq[CELLS], g_sq[CELLS], g_bl[CELLS], g_uw[CELLS], g_un[CELLS];
   uint8_t g_dirty[CELLS];
   int64_t bytes;                  // algorithmic bytes (lane 0 meaningful)
+  int usage_dirty;                // set when processEntry added usage to the snapshot plane (fair-sharing DRS cache)
+  // A NEGATIVE amount was added to the snapshot (quotaResourcesToReserve has no max(0, .) on its borrowing
+  // branch, scheduler.go:806): cohort usage no longer equals what its children store in it, removals stop being
+  // order-independent, and usage_np cannot be maintained incrementally any more. From then on the tree's
+  // usage_np is rebuilt from usage_work before every use, removing rows in the reference's canonical order.
+  int np_broken;
 };
 
 // optional in-kernel segment timing (build with -DKQ_PROF): cycles accumulated per segment id
@@ -454,6 +484,7 @@ struct Search {
   uint8_t* treason;
   int tree, row0, nrows;
   int32_t* qcnt; uint32_t* qhead; uint8_t* cohp;  // fair sharing only
+  int64_t* psum; int32_t* ppos;                   // fair sharing with C.fs_plain, else NULL
 };
 
 KQ_DEV bool row_removed(const Search& s, int row) { return s.removed && s.removed[row]; }
@@ -795,14 +826,52 @@ template <class PL> KQ_DEV DRSv drs_of(const DSnap& S, int node, const PL& pl, i
   return d;
 }
 
+// borrowed sums of one node from a plane (all flavor-resources of resource r), plain int64 (C.fs_plain)
+template <class PL> KQ_DEV void node_sums(const DSnap& S, int node, const PL& pl, int r, int64_t* sum, int* pos) {
+  const int nR = S.nR, nF = S.nfr / S.nR;
+  int64_t s = 0; int p = 0;
+  for (int f = 0; f < nF; f++) {
+    int fr = f * nR + r;
+    size_t o = ix(S, node, fr);
+    if (!(S.qflags[o] & KQ_QF_SUBTREE)) continue;
+    int64_t b = a_sub(pl.get(node, fr), S.sq[o]);
+    if (b > 0) { s += b; p++; }
+  }
+  *sum = s; *pos = p;
+}
+KQ_DEV DRSv drs_from_sums(const DSnap& S, int node, const int64_t* sum, int pos, int64_t* bytes) {
+  DRSv d; d.ratio = 0; d.weight = S.fair_weight[node]; d.borrowing = pos > 0; d.borrow_on = 0;
+  for (int r = 0; r < S.nR; r++) {
+    if (sum[r] <= 0) continue;
+    int64_t lr = S.lendable[(size_t)node * S.nR + r];
+    if (lr > 0) { double ratio = (double)sum[r] * 1000.0 / (double)lr; if (ratio > d.ratio) d.ratio = ratio; }
+  }
+  const int frcount = S.frcount[node];
+  *bytes += (int64_t)frcount * 24 + (d.borrowing ? (int64_t)frcount * 40 * (S.depth[node] + 1) : 0);
+  return d;
+}
 // ------------------------------------------------------------------------------------------------
 // fair-sharing victim search (preemption.go:381-631, fairsharing/ordering.go, strategy.go, target.go)
 // The private state covers every flavor-resource of every node of the tree: DRS reads all of them.
 // ------------------------------------------------------------------------------------------------
-struct UF {  // one flavor-resource column of the private plane
-  const DSnap* S; int64_t* w; int fr;
+struct UF {  // one flavor-resource column of the private plane; keeps the node's borrowed sums current
+  const DSnap* S; int64_t* w; int fr; int64_t* psum; int32_t* ppos;
   KQ_MDEV int64_t get(int n) const { return w[(size_t)S->node_local[n] * S->nfr + fr]; }
-  KQ_MDEV void set(int n, int64_t v) const { w[(size_t)S->node_local[n] * S->nfr + fr] = v; }
+  KQ_MDEV void set(int n, int64_t v) const {
+    const int li = S->node_local[n];
+    int64_t* cell = w + (size_t)li * S->nfr + fr;
+    if (psum) {
+      const size_t o = (size_t)n * S->nfr + fr;
+      if (S->qflags[o] & KQ_QF_SUBTREE) {
+        const int64_t sqv = S->sq[o];
+        const int64_t ob = i64max(0, a_sub(*cell, sqv)), nb = i64max(0, a_sub(v, sqv));
+        if (nb != ob) atomic_add_i64((long long*)&psum[(size_t)li * S->nR + fr % S->nR], (long long)(nb - ob));
+        const int dp = (nb > 0 ? 1 : 0) - (ob > 0 ? 1 : 0);
+        if (dp) atomic_add_i32(&ppos[li], dp);
+      }
+    }
+    *cell = v;
+  }
 };
 struct PF {  // the whole private plane
   const DSnap* S; const int64_t* w;
@@ -825,7 +894,7 @@ KQ_DEV void f_apply_row(const Search& s, int row, bool add, bool count) {
     bool first = true;
     for (int p = e0; p < e; p++) if (S.adm_use_fr[p] == fr) first = false;
     if (!first) continue;  // a repeated flavor-resource is applied by the lane of its first entry, in order
-    UF uf{&S, s.W, fr};
+    UF uf{&S, s.W, fr, s.psum, s.ppos};
     for (int p = e; p < e1; p++) {
       if (S.adm_use_fr[p] != fr) continue;
       if (add) add_usage(S, cpath, cplen, fr, S.adm_use_qty[p], uf); else remove_usage(S, cpath, cplen, fr, S.adm_use_qty[p], uf);
@@ -839,7 +908,7 @@ KQ_DEV void f_apply_preemptor(const Search& s, bool add) {
   const DSnap& S = s.k->S; const Wave& w = *s.w;
   for (int u = lane_id(); u < w.ns; u += WAVE) {
     if (!w.s_inu[u]) continue;
-    UF uf{&S, s.W, w.s_fr[u]};
+    UF uf{&S, s.W, w.s_fr[u], s.psum, s.ppos};
     if (add) add_usage(S, w.path, w.plen, w.s_fr[u], w.s_qty[u], uf); else remove_usage(S, w.path, w.plen, w.s_fr[u], w.s_qty[u], uf);
   }
   wsync();
@@ -850,7 +919,7 @@ KQ_DEV bool f_fits(const Search& s) {
   bool bad = false;
   for (int u = lane_id(); u < w.ns; u += WAVE) {
     if (!w.s_inu[u]) continue;
-    UF uf{&S, s.W, w.s_fr[u]};
+    UF uf{&S, s.W, w.s_fr[u], s.psum, s.ppos};
     if (w.s_qty[u] > i64max(0, available_of(S, w.path, w.plen, w.s_fr[u], uf))) bad = true;
   }
   if (lane_id() == 0) { int nu = 0; for (int u = 0; u < w.ns; u++) nu += w.s_inu[u] ? 1 : 0; w.bytes += 40 * (int64_t)w.plen * nu; }
@@ -892,11 +961,22 @@ KQ_DEV int f_pop(const Search& s, int c, uint8_t flag, uint8_t newflag) {
   f_rescan(s, i, flag);
   return row;
 }
+KQ_DEV DRSv f_drs(const Search& s, int node, int64_t* lb) {
+  const DSnap& S = s.k->S;
+  if (s.psum) { const int li = S.node_local[node]; return drs_from_sums(S, node, s.psum + (size_t)li * S.nR, s.ppos[li], lb); }
+  PF pf{&S, s.W};
+  return drs_of(S, node, pf, lb, nullptr, nullptr, 0);
+}
+KQ_DEV DRSv f_drs_uniform(const Search& s, int node) {
+  int64_t lb = 0;
+  DRSv d = f_drs(s, node, &lb);
+  if (lane_id() == 0) s.w->bytes += lb;
+  return d;
+}
 // nextTarget (ordering.go:144-226), tail recursion unrolled; returns the target CQ or -1
 KQ_DEV int f_next_target(const Search& s, int root) {
   const K& k = *s.k; Wave& w = *s.w; const DSnap& S = k.S;
   const int lane = lane_id();
-  PF pf{&S, s.W};
   int cohort = root;
   int64_t lb = 0;
   int result = -1;
@@ -909,7 +989,7 @@ KQ_DEV int f_next_target(const Search& s, int root) {
       DRSv d = drs_negative();
       bool elig = false;
       if (c >= 0 && !s.cqinfo[S.cq_local[c]]) {
-        d = drs_of(S, c, pf, &lb, nullptr, nullptr, 0);
+        d = f_drs(s, c, &lb);
         if ((!d.borrowing && c != w.cq) || s.qcnt[S.cq_local[c]] == 0) s.cqinfo[S.cq_local[c]] = 1;
         else elig = true;
       }
@@ -932,7 +1012,7 @@ KQ_DEV int f_next_target(const Search& s, int root) {
       DRSv d = drs_negative();
       bool elig = false;
       if (ch >= 0 && !s.cohp[S.node_local[ch]]) {
-        d = drs_of(S, ch, pf, &lb, nullptr, nullptr, 0);
+        d = f_drs(s, ch, &lb);
         if (!d.borrowing && path_level(w, ch) < 0) s.cohp[S.node_local[ch]] = 1;
         else elig = true;
       }
@@ -994,13 +1074,6 @@ KQ_DEV bool f_push_target(Search& s, int* nt, int row, int reason) {
   wsync();
   return true;
 }
-KQ_DEV DRSv f_drs_uniform(const Search& s, int node) {
-  PF pf{&s.k->S, s.W};
-  int64_t lb = 0;
-  DRSv d = drs_of(s.k->S, node, pf, &lb, nullptr, nullptr, 0);
-  if (lane_id() == 0) s.w->bytes += lb;
-  return d;
-}
 // fairPreemptions (preemption.go:536-597). On return w->ntgt targets are in s.trow/s.treason and the private
 // state has exactly those removed.
 KQ_DEV void fair_search(Search& s) {
@@ -1018,6 +1091,19 @@ KQ_DEV void fair_search(Search& s) {
   const int q0 = S.tree_cq_off[s.tree], nqs = S.tree_cq_off[s.tree + 1] - q0;
   const int nfr = S.nfr;
   for (int i = lane; i < nn * nfr; i += WAVE) s.W[i] = s.usage[ix(S, S.tree_nodes[n0 + i / nfr], i % nfr)];
+  if (s.psum) {
+    if (s.usage == k.usage) {  // cycle-start plane: k_fs_sums already reduced it
+      for (int i = lane; i < nn * S.nR; i += WAVE) s.psum[i] = k.X.bu_sum[(size_t)S.tree_nodes[n0 + i / S.nR] * S.nR + i % S.nR];
+      for (int i = lane; i < nn; i += WAVE) s.ppos[i] = k.X.bu_pos[S.tree_nodes[n0 + i]];
+    } else {
+      PG pg{&S, s.usage};
+      for (int i = lane; i < nn; i += WAVE) {
+        int tot = 0;
+        for (int r = 0; r < S.nR; r++) { int64_t sm; int ps; node_sums(S, S.tree_nodes[n0 + i], pg, r, &sm, &ps); s.psum[(size_t)i * S.nR + r] = sm; tot += ps; }
+        s.ppos[i] = tot;
+      }
+    }
+  }
   for (int i = lane; i < s.nrows; i += WAVE) s.cls[i] = 0;
   for (int i = lane; i < nn; i += WAVE) s.cohp[i] = 0;
   wsync();
@@ -1070,7 +1156,7 @@ KQ_DEV void fair_search(Search& s) {
     if (gate(k, KQ_GATE_FS_PREEMPT_WITHIN_NOMINAL)) {  // queueWithinNominalInResourcesNeedingPreemption :714-721
       within_nominal = true;
       for (int u = 0; u < w.ns; u++)
-        if (w.s_need[u]) { UF uf{&S, s.W, w.s_fr[u]}; if (S.nominal[ix(S, w.cq, w.s_fr[u])] < uf.get(w.cq)) within_nominal = false; }
+        if (w.s_need[u]) { UF uf{&S, s.W, w.s_fr[u], s.psum, s.ppos}; if (S.nominal[ix(S, w.cq, w.s_fr[u])] < uf.get(w.cq)) within_nominal = false; }
     }
     for (int cand = f_ordering_next(s); cand >= 0 && !fits; cand = fits ? -1 : f_ordering_next(s)) {
       if (cand == w.cq || within_nominal) {
@@ -1165,6 +1251,8 @@ KQ_DEV Search make_search(const K& k, Wave& w, int slot, const int64_t* usage, c
   s.qcnt = k.X.qcnt ? k.X.qcnt + (size_t)slot * k.X.max_tree_cqs : nullptr;
   s.qhead = k.X.qhead ? k.X.qhead + (size_t)slot * k.X.max_tree_cqs : nullptr;
   s.cohp = k.X.cohp ? k.X.cohp + (size_t)slot * k.X.max_tree_nodes : nullptr;
+  s.psum = (k.C.fs_plain && k.X.psum) ? k.X.psum + (size_t)slot * k.X.max_tree_nodes * k.S.nR : nullptr;
+  s.ppos = (k.C.fs_plain && k.X.ppos) ? k.X.ppos + (size_t)slot * k.X.max_tree_nodes : nullptr;
   return s;
 }
 
@@ -1180,7 +1268,7 @@ KQ_DEV void simulate_preemption(const K& k, Wave& w, int slot, const int64_t* us
   bool any_same = false;
   for (int t = 0; t < w.ntgt; t++) if (k.S.adm_cq[s.trow[t]] == w.cq) any_same = true;
   bool mr;
-  if (k.C.fair_sharing) { UF uf{&k.S, s.W, fr}; *borrow = find_height(k.S, w.path, w.plen, fr, val, uf, &mr); }
+  if (k.C.fair_sharing) { UF uf{&k.S, s.W, fr, nullptr, nullptr}; *borrow = find_height(k.S, w.path, w.plen, fr, val, uf, &mr); }
   else { UW uw{&k.S, s.W, 1, 0}; *borrow = find_height(k.S, w.path, w.plen, fr, val, uw, &mr); }
   *pm = any_same ? PM_PREEMPT : PM_RECLAIM;
 }
@@ -1616,10 +1704,52 @@ KQ_DEV void np_apply_row_restricted(const K& k, Wave& w, int row, bool add) {
   }
   wsync();
 }
+// usage_np := usage_work with every row marked in k.preempted removed, ascending row (SimulateWorkloadUsageRemoval
+// snapshot.go:80-100 over the canonical order). One lane per flavor-resource column; columns are independent.
+KQ_DEV void np_rebuild(const K& k, Wave& w, int tree) {
+  const DSnap& S = k.S;
+  const int n0 = S.tree_node_off[tree], nn = S.tree_node_off[tree + 1] - n0;
+  const int q0 = S.tree_cq_off[tree], nqs = S.tree_cq_off[tree + 1] - q0;
+  for (int i = lane_id(); i < nn * S.nfr; i += WAVE) {
+    const int node = S.tree_nodes[n0 + i / S.nfr], fr = i % S.nfr;
+    up_plane(k, w, 1, fr).set(node, up_plane(k, w, 0, fr).get(node));
+  }
+  wsync();
+  for (int fr = lane_id(); fr < S.nfr; fr += WAVE) {
+    UP g = up_plane(k, w, 1, fr);
+    for (int qi = 0; qi < nqs; qi++) {
+      const int c = S.tree_cqs[q0 + qi];
+      for (int row = S.cq_adm_off[c]; row < S.cq_adm_off[c + 1]; row++) {
+        if (!k.preempted[row]) continue;
+        for (int e = S.adm_use_off[row]; e < S.adm_use_off[row + 1]; e++)
+          if (S.adm_use_fr[e] == fr) remove_usage(S, S.path + (size_t)c * KQ_MAXD, S.plen[c], fr, S.adm_use_qty[e], g);
+      }
+    }
+  }
+  wsync();
+}
 // scheduler.fits (scheduler.go:771-777) against usage_np (= snapshot minus PreemptedWorkloads)
-KQ_DEV bool entry_fits(const K& k, Wave& w, const int32_t* trows, int nt, bool quota_usage) {
+KQ_DEV bool entry_fits(const K& k, Wave& w, const int32_t* trows, int nt, bool quota_usage, int tree) {
   const DSnap& S = k.S;
   if (!quota_usage || w.nuse == 0) return true;
+  if (w.np_broken) {
+    // exact order of the reference: preempted and new targets leave the snapshot together, ascending row
+    if (lane_id() == 0) for (int t = 0; t < nt; t++) if (!k.preempted[trows[t]]) k.preempted[trows[t]] = 2;
+    wsync();
+    np_rebuild(k, w, tree);
+    bool bad = false;
+    for (int u = lane_id(); u < w.nuse; u += WAVE) {
+      UP g = up_plane(k, w, 1, w.use_fr[u]);
+      if (i64max(0, available_of(S, w.path, w.plen, w.use_fr[u], g)) < w.use_qty[u]) bad = true;
+    }
+    const bool ok = wballot(bad) == 0;
+    wsync();
+    if (lane_id() == 0) for (int t = 0; t < nt; t++) if (k.preempted[trows[t]] == 2) k.preempted[trows[t]] = 0;
+    wsync();
+    np_rebuild(k, w, tree);
+    if (lane_id() == 0) w.bytes += (int64_t)w.nuse * 40 * w.plen;
+    return ok;
+  }
   for (int t = 0; t < nt; t++) if (!k.preempted[trows[t]]) np_apply_row_restricted(k, w, trows[t], false);
   bool bad = false;
   for (int u = lane_id(); u < w.nuse; u += WAVE) {
@@ -1641,7 +1771,7 @@ KQ_DEV void entry_add_usage(const K& k, Wave& w, const int64_t* qty) {
     add_usage(S, w.path, w.plen, fr, qty[u], a);
     add_usage(S, w.path, w.plen, fr, qty[u], b);
   }
-  if (lane_id() == 0) w.bytes += (int64_t)w.nuse * 8 * w.plen;
+  if (lane_id() == 0) { w.bytes += (int64_t)w.nuse * 8 * w.plen; w.usage_dirty = 1; }
   wsync();
 }
 
@@ -1720,6 +1850,7 @@ KQ_DEV void process_entry_fast(const K& k, Wave& w, int e) {
       const int b = u * plen;
       int64_t val = w.use_qty[u];
       if (reserve) val = reserve_amount(val, S.nominal[ix(S, w.cq, w.use_fr[u])], w.g_bl[b], w.g_uw[b], w.borrowing);
+      if (val < 0) w.np_broken = 1;
       int64_t v = val;  // resource_node.go:144-152 on both planes
       for (int i = 0; i < plen; i++) {
         int64_t uu = w.g_uw[b + i], la = i64max(0, a_sub(w.g_lq[b + i], uu));
@@ -1733,7 +1864,7 @@ KQ_DEV void process_entry_fast(const K& k, Wave& w, int e) {
         if (i + 1 < plen && v > la) v = a_sub(v, la); else break;
       }
     }
-    if (lane == 0) w.bytes += (int64_t)nuse * 8 * plen;
+    if (lane == 0) { w.bytes += (int64_t)nuse * 8 * plen; w.usage_dirty = 1; }
     wsync();
     for (int c = lane; c < ncell; c += WAVE) {
       uint8_t d = w.g_dirty[c];
@@ -1775,7 +1906,7 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
   wsync();
   KQ_TS(k, 1);
   int nt = O.tgt_n[e];
-  if (nt == 0 && w.nuse * w.plen <= CELLS) {
+  if (nt == 0 && w.nuse * w.plen <= CELLS && !w.np_broken) {
     process_entry_fast(k, w, e);
     KQ_TS(k, 2);
     if (lane == 0) atomic_add_i64(O.stat_bytes, (long long)w.bytes);
@@ -1787,11 +1918,12 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
   const int32_t* trows = O.pool_row + O.tgt_pos[e];
   auto has_any = [&]() { bool a = false; for (int t = 0; t < nt; t++) if (k.preempted[trows[t]]) a = true; return a; };
   // updateAssignmentIfNeeded :707-769
-  bool fits_ok = entry_fits(k, w, trows, nt, quota_usage);
+  bool fits_ok = entry_fits(k, w, trows, nt, quota_usage, tree);
   int mode = w.rep_mode;
   if (has_any() && gate(k, KQ_GATE_RECOMPUTE_ON_OVERLAP)) {
     // SimulateWorkloadRemoval(victimsOfOtherPreemptions) == evaluate on usage_np with those rows deleted.
     // The generic nominate code reads HBM planes: publish the LDS-resident cohort rows first.
+    if (w.np_broken) np_rebuild(k, w, tree);
     pc_flush(k, w, w.pc_lds, tree);
     if (lane == 0) w.has_last = 0;
     // e.NominationMapping = e.readResourceToFlavorMapping() (scheduler.go:734): fixed for the whole recomputation
@@ -1810,7 +1942,7 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
       }
     }
     wsync();
-    fits_ok = entry_fits(k, w, trows, nt, quota_usage);
+    fits_ok = entry_fits(k, w, trows, nt, quota_usage, tree);
   }
   int status = KQ_ST_NOT_NOMINATED, action = KQ_ACT_NONE, rq = KQ_RQ_GENERIC, skip = KQ_SKIP_NONE;
   bool done = false;
@@ -1824,6 +1956,7 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
         for (int u = 0; u < w.nuse; u++) {
           int fr = w.use_fr[u];
           w.s_qty[u] = reserve_amount(w.use_qty[u], S.nominal[ix(S, w.cq, fr)], S.bl[ix(S, w.cq, fr)], k.usage_work[ix(S, w.cq, fr)], w.borrowing);
+          if (w.s_qty[u] < 0) w.np_broken = 1;
         }
       wsync();
       entry_add_usage(k, w, w.s_qty);
@@ -2010,6 +2143,7 @@ template <int PLEN, bool PLAIN> KQ_DEV bool core_run(const K& k, Wave& w, int64_
       if (reserve) {  // quotaResourcesToReserve scheduler.go:796-814
         if (r.borrowing > 0) val = x.bl[0] == KQ_NIL_LIMIT ? x.qty : i64min(x.qty, q_sub<PLAIN>(q_add<PLAIN>(x.nominal, x.bl[0]), x.uw[0]));
         else val = i64max(0, i64min(x.qty, q_sub<PLAIN>(x.nominal, x.uw[0])));
+        if (val < 0) w.np_broken = 1;
       }
       // addUsage resource_node.go:144-152 on usage_work, then on usage_np
       int64_t v = val;
@@ -2072,6 +2206,7 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
     w.pc_ncoh = (S.tree_node_off[tree + 1] - S.tree_node_off[tree]) - w.pc_ncq;
     w.pc_lds = lds;
     w.pc_on = (w.pc_ncoh > 0 && lds_bytes >= rec_bytes && (size_t)w.pc_ncoh * S.nfr * 16 <= lds_bytes - rec_bytes) ? 1 : 0;
+    w.np_broken = 0;
   }
   wsync();
   const bool chunked = lds_bytes >= rec_bytes;
@@ -2108,8 +2243,8 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
       int j = 0;
       for (; j < nch; j++) {
         PRec& r = rec[j];
-        if (r.slow) {
-          // generic path (targets / recompute / oversize). It reads and writes HBM for CQ-level cells, so the
+        if (r.slow || w.np_broken) {
+          // generic path (targets / recompute / oversize / usage_np no longer incremental). It reads and writes HBM for CQ-level cells, so the
           // CQ-level values prefetched for the rest of the chunk may be stale afterwards: restart after it.
           chunk_scatter(k, rec, j);  // earlier fast entries' CQ-level cells must be in HBM first
           wsync();
@@ -2174,32 +2309,114 @@ struct PE {
     return base;
   }
 };
-// entryComparer.less (fair_sharing_iterator.go:176-221): entry a wins over entry b inside parentCohort
-KQ_DEV bool fs_less(const K& k, int slot, int a, int b, int cohort) {
-  const DSnap& S = k.S; const DHeads& H = k.H;
-  if (gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS)) {
-    bool ap = H.flags[a] & KQ_HEAD_IS_PREEMPTOR, bp = H.flags[b] & KQ_HEAD_IS_PREEMPTOR;
-    if (ap != bp) return ap;
+struct PW { const K* k; const Wave* w; KQ_MDEV int64_t get(int node, int fr) const { return up_plane(*k, *w, 0, fr).get(node); } };
+// DRS of path[level] with the entry's usage added, from the node's borrowed sums: only the entry's own
+// flavor-resources can differ from the cached sums. Exact when C.fs_plain (no saturating step can trigger).
+KQ_DEV DRSv drs_entry_level(const K& k, const Wave& w, const int32_t* path, int level, const int32_t* ufr, const int64_t* uqty, int nu,
+                            bool want_bon, int64_t* bytes) {
+  const DSnap& S = k.S;
+  const int n = path[level], nR = S.nR;
+  int64_t sum[KQ_MAXR];
+  #pragma unroll
+  for (int r = 0; r < KQ_MAXR; r++) sum[r] = r < nR ? k.X.bs_sum[(size_t)n * nR + r] : 0;
+  int pos = k.X.bs_pos[n];
+  int bon = 0;
+  for (int q = 0; q < nu; q++) {
+    const int fr = ufr[q];
+    const size_t o = ix(S, n, fr);
+    if (!(S.qflags[o] & KQ_QF_SUBTREE)) continue;
+    int64_t delta = uqty[q];
+    for (int l = 0; l < level; l++) {  // what AddUsage bubbles up to this level (resource_node.go:144-152)
+      int m = path[l];
+      int64_t la = i64max(0, a_sub(local_quota(S, m, fr), up_plane(k, w, 0, fr).get(m)));
+      if (delta > la) delta = a_sub(delta, la); else { delta = 0; break; }
+    }
+    const int64_t u = up_plane(k, w, 0, fr).get(n), sqv = S.sq[o];
+    const int64_t ob = i64max(0, a_sub(u, sqv)), nb = i64max(0, a_sub(a_add(u, delta), sqv));
+    const int r = fr % nR;
+    #pragma unroll
+    for (int rr = 0; rr < KQ_MAXR; rr++) if (rr == r) sum[rr] += nb - ob;
+    pos += (nb > 0 ? 1 : 0) - (ob > 0 ? 1 : 0);
+    if (want_bon && nb > 0 && uqty[q] > 0) bon = 1;
   }
-  const int ca = H.cq[a], cb = H.cq[b];
-  const size_t base = (size_t)slot * k.X.max_tree_cqs;
-  const size_t ia = (base + S.cq_local[ca]) * KQ_MAXD + (S.depth[ca] - S.depth[cohort] - 1);
-  const size_t ib = (base + S.cq_local[cb]) * KQ_MAXD + (S.depth[cb] - S.depth[cohort] - 1);
-  if (gate(k, KQ_GATE_FS_PRIORITIZE_NON_BORROWING)) {
-    bool aB = k.X.fs_bon[ia], bB = k.X.fs_bon[ib];
-    if (aB != bB) return !aB;
-  }
-  DRSv da, db;
-  da.ratio = k.X.fs_ratio[ia]; da.weight = k.X.fs_weight[ia]; da.borrowing = 0; da.borrow_on = 0;
-  db.ratio = k.X.fs_ratio[ib]; db.weight = k.X.fs_weight[ib]; db.borrowing = 0; db.borrow_on = 0;
-  int c = compare_drs(da, db);
-  if (c != 0) return c == -1;
-  if (gate(k, KQ_GATE_PRIORITY_SORTING_IN_COHORT) && H.priority[a] != H.priority[b]) return H.priority[a] > H.priority[b];
-  return H.queue_ts[a] < H.queue_ts[b];
+  DRSv d = drs_from_sums(S, n, sum, pos, bytes);
+  d.borrow_on = bon;
+  return d;
 }
-KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* lds, size_t lds_bytes) {
+// entryComparer.less (fair_sharing_iterator.go:176-221) as a lexicographic key: a wins over b inside
+// parentCohort <=> key(a) < key(b); ties keep the earlier tournament candidate.
+//   k1: [PrioritizePreemptors] non-preemptor, [FairSharingPrioritizeNonBorrowing] borrowing on a requested
+//       flavor-resource, zero-weight-but-borrowing (CompareDRS :112-123 puts those above everything else)
+//   k2: the share CompareDRS compares (the raw ratio between two zero-weight borrowers, else PreciseWeightedShare);
+//       both are >= 0, so the IEEE bit pattern orders them
+//   k3: [PrioritySortingWithinCohort] priority descending ; k4: queue-order timestamp ascending
+struct FsKey { uint64_t k1, k2, k3, k4; };
+KQ_DEV bool fskey_less(const FsKey& a, const FsKey& b) {
+  if (a.k1 != b.k1) return a.k1 < b.k1;
+  if (a.k2 != b.k2) return a.k2 < b.k2;
+  if (a.k3 != b.k3) return a.k3 < b.k3;
+  return a.k4 < b.k4;
+}
+KQ_DEV uint64_t f64_bits(double v) {
+  union { double d; uint64_t u; } x;
+  x.d = v;
+  return x.u;
+}
+KQ_DEV FsKey fs_key(const K& k, int slot, int en, int cohort) {
+  const DSnap& S = k.S; const DHeads& H = k.H;
+  const int c = H.cq[en];
+  const size_t i = ((size_t)slot * k.X.max_tree_cqs + S.cq_local[c]) * KQ_MAXD + (S.depth[c] - S.depth[cohort] - 1);
+  DRSv d; d.ratio = k.X.fs_ratio[i]; d.weight = k.X.fs_weight[i]; d.borrowing = 0; d.borrow_on = 0;
+  const bool zwb = drs_zwb(d);
+  FsKey key;
+  key.k1 = (gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS) && !(H.flags[en] & KQ_HEAD_IS_PREEMPTOR) ? 4u : 0u) |
+           (gate(k, KQ_GATE_FS_PRIORITIZE_NON_BORROWING) && k.X.fs_bon[i] ? 2u : 0u) | (zwb ? 1u : 0u);
+  key.k2 = f64_bits(zwb ? d.ratio : drs_pws(d));
+  key.k3 = gate(k, KQ_GATE_PRIORITY_SORTING_IN_COHORT) ? ~((uint64_t)H.priority[en] ^ 0x8000000000000000ull) : 0;
+  key.k4 = (uint64_t)H.queue_ts[en] ^ 0x8000000000000000ull;
+  return key;
+}
+// runTournament for ONE cohort (fair_sharing_iterator.go:125-163): candidates = the winners of the child
+// cohorts, then the entries of the child ClusterQueues; one lane per candidate, wave arg-min on the key.
+KQ_DEV int tournament_cohort(const K& k, int slot, int x, const int32_t* win, const int32_t* cq_ent) {
+  const DSnap& S = k.S;
+  const int lane = lane_id();
+  const int h0 = S.child_cohort_off[x - S.nq], nh = S.child_cohort_off[x - S.nq + 1] - h0;
+  const int c0 = S.child_cq_off[x - S.nq], ncq = S.child_cq_off[x - S.nq + 1] - c0;
+  int best = -1;
+  FsKey bk; bk.k1 = bk.k2 = bk.k3 = bk.k4 = 0;
+  for (int base = 0; base < nh + ncq; base += WAVE) {
+    const int j = base + lane;
+    int cnd = -1;
+    if (j < nh) cnd = win[S.node_local[S.child_cohort[h0 + j]]];
+    else if (j < nh + ncq) cnd = cq_ent[S.cq_local[S.child_cq[c0 + j - nh]]];
+    bool in = cnd >= 0;
+    FsKey key; key.k1 = key.k2 = key.k3 = key.k4 = 0;
+    if (in) key = fs_key(k, slot, cnd, x);
+    if (wballot(in) == 0) continue;
+    uint64_t mn;
+    mn = wmin_u64(in ? key.k1 : ~0ull); in = in && key.k1 == mn;
+    mn = wmin_u64(in ? key.k2 : ~0ull); in = in && key.k2 == mn;
+    mn = wmin_u64(in ? key.k3 : ~0ull); in = in && key.k3 == mn;
+    mn = wmin_u64(in ? key.k4 : ~0ull); in = in && key.k4 == mn;
+    const int b = ffs64(wballot(in));  // ties keep the first candidate
+    FsKey wk;
+    wk.k1 = (uint64_t)wbcast((int64_t)key.k1, b); wk.k2 = (uint64_t)wbcast((int64_t)key.k2, b);
+    wk.k3 = (uint64_t)wbcast((int64_t)key.k3, b); wk.k4 = (uint64_t)wbcast((int64_t)key.k4, b);
+    const int wc = wbcast(cnd, b);
+    if (best < 0 || fskey_less(wk, bk)) { best = wc; bk = wk; }  // an earlier chunk's winner keeps ties
+  }
+  return best;
+}
+// One workgroup per root-cohort tree. Wave 0 ("leader") runs the serial part — tournament on the path of the
+// last popped entry, processEntry on the winner — and every wave of the workgroup takes part in computeDRS.
+// computeDRS is incremental: DRS(path[l] of entry i, with i admitted) only reads usage rows of path[0..l], so it
+// is recomputed only for levels at or above the lowest ancestor shared with the entry processEntry just changed;
+// the algorithmic-byte counter is still charged for every (entry, level) the reference evaluates on each pop.
+KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* lds, size_t lds_bytes, int tid, int nthreads) {
   const DSnap& S = k.S; const DOut& O = k.O; const DHeads& H = k.H;
   const int lane = lane_id();
+  const bool leader = tid < WAVE;
   const int q0 = S.tree_cq_off[tree], nqs = S.tree_cq_off[tree + 1] - q0;
   const int n0 = S.tree_node_off[tree], nn = S.tree_node_off[tree + 1] - n0;
   int32_t* cq_ent = k.X.cq_ent + (size_t)slot * k.X.max_tree_cqs;
@@ -2208,83 +2425,156 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
   double* fr_ratio = k.X.fs_ratio + (size_t)slot * k.X.max_tree_cqs * KQ_MAXD;
   double* fr_weight = k.X.fs_weight + (size_t)slot * k.X.max_tree_cqs * KQ_MAXD;
   uint8_t* fr_bon = k.X.fs_bon + (size_t)slot * k.X.max_tree_cqs * KQ_MAXD;
-  if (lane == 0) {
+  uint8_t* stale = k.X.fs_stale + (size_t)slot * k.X.max_tree_cqs;
+  int32_t* cost = k.X.fs_cost + (size_t)slot * k.X.max_tree_cqs * KQ_MAXD;
+  long long* sum = k.X.fs_sum + slot;
+  int32_t* ctl = k.X.fs_ctl + (size_t)slot * 4;
+  if (tid == 0) {
     w.pc_ncq = nqs;
     w.pc_ncoh = nn - nqs;
     w.pc_lds = lds;
     w.pc_on = (w.pc_ncoh > 0 && (size_t)w.pc_ncoh * S.nfr * 16 <= lds_bytes) ? 1 : 0;
+    *sum = 0; ctl[0] = 0; ctl[1] = -1; ctl[2] = 0;
+    w.np_broken = 0;
   }
-  for (int i = lane; i < nqs; i += WAVE) cq_ent[i] = -1;
-  wsync();
+  for (int i = tid; i < nqs; i += nthreads) { cq_ent[i] = -1; stale[i] = 0; }
+  for (int i = tid; i < nqs * KQ_MAXD; i += nthreads) cost[i] = 0;
+  for (int i = tid; i < nn; i += nthreads) win[i] = -1;
+  bsync();
   // cqToEntry: the last head of a CQ wins (:58-60)
-  for (int h = lane; h < H.n; h += WAVE) {
+  for (int h = tid; h < H.n; h += nthreads) {
     int c = H.cq[h];
     if (S.tree_of[c] == tree) atomic_max_i32(&cq_ent[S.cq_local[c]], h);
   }
-  wsync();
-  int remaining = 0;
-  for (int base = 0; base < nqs; base += WAVE) { int i = base + lane; remaining += popc64(wballot(i < nqs && cq_ent[i] >= 0)); }
-  if (remaining == 0) return;
-  pc_load(k, w, lds, tree);
-  const bool lone = nn == 1;  // ClusterQueue without Cohort (:71-78)
-  const int root = lone ? -1 : S.path[(size_t)S.tree_cqs[q0] * KQ_MAXD + S.plen[S.tree_cqs[q0]] - 1];
+  bsync();
+  if (leader) {
+    int remaining = 0;
+    for (int base = 0; base < nqs; base += WAVE) { int i = base + lane; remaining += popc64(wballot(i < nqs && cq_ent[i] >= 0)); }
+    if (lane == 0) ctl[0] = remaining;
+    if (remaining > 0) pc_load(k, w, lds, tree);
+    wsync();
+  }
+  bsync();
+  if (ctl[0] == 0) return;
+  if (nn == 1) {  // ClusterQueue without Cohort: its workload is simply returned (:71-78)
+    if (leader) {
+      int e = cq_ent[0];
+      process_entry(k, w, e, 0, slot, tree);
+      if (lane == 0) k.X.fs_key[e] = H.cq[e];
+      wsync();
+      pc_flush(k, w, lds, tree);
+    }
+    return;
+  }
+  const int root = S.path[(size_t)S.tree_cqs[q0] * KQ_MAXD + S.plen[S.tree_cqs[q0]] - 1];
   const bool want_bon = gate(k, KQ_GATE_FS_PRIORITIZE_NON_BORROWING);
   int lpos = 0;
-  while (remaining > 0) {
-    int e;
-    if (lone) {
-      e = cq_ent[0];
-    } else {
-      // computeDRS (:227-263): one lane per ClusterQueue that still has an entry
-      int64_t lb = 0;
-      for (int i = lane; i < nqs; i += WAVE) {
-        int en = cq_ent[i];
+  bool first = true;
+  for (;;) {
+    // ---- computeDRS (:227-263), all waves: one thread per ClusterQueue that still has an entry ----
+    KQ_T0();
+    {
+      const int xc = ctl[1];
+      const bool changed = ctl[2] != 0;
+      int64_t delta = 0;
+      for (int i = tid; i < nqs; i += nthreads) {
+        const int en = cq_ent[i];
         if (en < 0) continue;
-        int c = S.tree_cqs[q0 + i];
+        const int c = S.tree_cqs[q0 + i];
         const int32_t* path = S.path + (size_t)c * KQ_MAXD;
-        int plen = S.plen[c];
+        const int plen = S.plen[c];
+        int from = stale[i];
+        if (changed) {  // lowest level of this path that is also on the popped entry's path
+          const int32_t* xp = S.path + (size_t)xc * KQ_MAXD;
+          const int xl = S.plen[xc];
+          int t = 0;
+          while (t < plen - 1 && t < xl - 1 && path[plen - 1 - t - 1] == xp[xl - 1 - t - 1]) t++;
+          const int lvl = plen - 1 - t;
+          if (lvl < from) from = lvl;
+        }
+        if (from + 1 >= plen) { if (from != 255) stale[i] = 255; continue; }
         PE pe{&k, &w, path, 0, O.use_fr + (size_t)en * KQ_MAXU, O.use_qty + (size_t)en * KQ_MAXU,
               (H.flags[en] & KQ_HEAD_HAS_QUOTA_RESERVATION) ? 0 : O.use_n[en]};  // netUsage scheduler.go:785-794
-        for (int l = 0; l + 1 < plen; l++) {
+        for (int l = from; l + 1 < plen; l++) {
           pe.level = l;
-          DRSv d = drs_of(S, path[l], pe, &lb, pe.ufr, pe.uqty, want_bon ? pe.nu : 0);
-          fr_ratio[(size_t)i * KQ_MAXD + l] = d.ratio; fr_weight[(size_t)i * KQ_MAXD + l] = d.weight; fr_bon[(size_t)i * KQ_MAXD + l] = (uint8_t)d.borrow_on;
+          int64_t lb = 0;
+          DRSv d = k.C.fs_plain ? drs_entry_level(k, w, path, l, pe.ufr, pe.uqty, pe.nu, want_bon, &lb)
+                                : drs_of(S, path[l], pe, &lb, pe.ufr, pe.uqty, want_bon ? pe.nu : 0);
+          const size_t o = (size_t)i * KQ_MAXD + l;
+          fr_ratio[o] = d.ratio; fr_weight[o] = d.weight; fr_bon[o] = (uint8_t)d.borrow_on;
+          delta += lb - cost[o];
+          cost[o] = (int32_t)lb;
+        }
+        stale[i] = 255;
+      }
+      const int64_t tot = wsum_i64(delta);
+      if (lane == 0 && tot) atomic_add_i64(sum, (long long)tot);
+    }
+    if (leader) KQ_TS(k, 16);
+    bsync();
+    if (leader) KQ_TS(k, 17);
+    // ---- leader: tournament, pop, processEntry ----
+    if (leader) {
+      if (first) {
+        for (int d = KQ_MAXD - 1; d >= 0; d--)
+          for (int i = nqs; i < nn; i++) {
+            const int x = S.tree_nodes[n0 + i];
+            if (S.depth[x] != d) continue;
+            const int b = tournament_cohort(k, slot, x, win, cq_ent);
+            if (lane == 0) win[i] = b;
+            wsync();
+          }
+      } else {
+        const int xc = ctl[1];
+        for (int l = 1; l < S.plen[xc]; l++) {  // only the cohorts that nominated the popped entry can change
+          const int x = S.path[(size_t)xc * KQ_MAXD + l];
+          const int b = tournament_cohort(k, slot, x, win, cq_ent);
+          if (lane == 0) win[S.node_local[x]] = b;
+          wsync();
         }
       }
-      {
-        int64_t tot = wsum_i64(lb);
-        if (lane == 0 && tot) atomic_add_i64(O.stat_bytes, (long long)tot);
+      KQ_TS(k, 18);
+      const int e = win[S.node_local[root]];
+      const int ec = H.cq[e], ei = S.cq_local[ec];
+      if (lane == 0) {
+        atomic_add_i64(O.stat_bytes, *sum);  // the reference evaluates every remaining (entry, level) on every pop
+        long long mine = 0;
+        for (int l = 0; l + 1 < S.plen[ec]; l++) mine += cost[(size_t)ei * KQ_MAXD + l];
+        *sum -= mine;
+        cq_ent[ei] = -1; seq[lpos] = e;
+        w.usage_dirty = 0;
       }
       wsync();
-      // runTournament (:125-163), bottom-up by depth: one lane per cohort
-      for (int d = KQ_MAXD - 1; d >= 0; d--) {
-        for (int i = nqs + lane; i < nn; i += WAVE) {
-          int x = S.tree_nodes[n0 + i];
-          if (S.depth[x] != d) continue;
-          int best = -1;
-          for (int j = S.child_cohort_off[x - S.nq]; j < S.child_cohort_off[x - S.nq + 1]; j++) {
-            int cnd = win[S.node_local[S.child_cohort[j]]];
-            if (cnd < 0) continue;
-            if (best < 0 || fs_less(k, slot, cnd, best, x)) best = cnd;
-          }
-          for (int j = S.child_cq_off[x - S.nq]; j < S.child_cq_off[x - S.nq + 1]; j++) {
-            int cnd = cq_ent[S.cq_local[S.child_cq[j]]];
-            if (cnd < 0) continue;
-            if (best < 0 || fs_less(k, slot, cnd, best, x)) best = cnd;
-          }
-          win[S.node_local[x]] = best;
+      KQ_TS(k, 19);
+      process_entry(k, w, e, lpos, slot, tree);
+      KQ_TS(k, 20);
+      if (k.C.fs_plain && w.usage_dirty) {  // the rows of the popped entry's path changed: refresh their sums
+        const int pl = S.plen[ec];
+        PW pw{&k, &w};
+        for (int j = lane; j < pl * S.nR; j += WAVE) {
+          const int nd = S.path[(size_t)ec * KQ_MAXD + j / S.nR], r = j % S.nR;
+          int64_t sm; int ps;
+          node_sums(S, nd, pw, r, &sm, &ps);
+          k.X.bs_sum[(size_t)nd * S.nR + r] = sm;
+          w.cell_borrow[j] = ps;
+        }
+        wsync();
+        for (int j = lane; j < pl; j += WAVE) {
+          int ps = 0;
+          for (int r = 0; r < S.nR; r++) ps += w.cell_borrow[j * S.nR + r];
+          k.X.bs_pos[S.path[(size_t)ec * KQ_MAXD + j]] = ps;
         }
         wsync();
       }
-      e = win[S.node_local[root]];
+      lpos++;
+      if (lane == 0) { ctl[0] -= 1; ctl[1] = ec; ctl[2] = w.usage_dirty; }
+      wsync();
     }
-    wsync();
-    if (lane == 0) { cq_ent[S.cq_local[H.cq[e]]] = -1; seq[lpos] = e; }
-    wsync();
-    process_entry(k, w, e, lpos, slot, tree);
-    lpos++;
-    remaining--;
+    bsync();
+    if (ctl[0] == 0) break;
+    first = false;
   }
+  if (!leader) return;
   // merge key of the canonical getCq (lowest CQ index still in the map): the tree pops until
   // that CQ's own entry has been returned, so an entry is emitted in the turn of the smallest CQ at or after it.
   if (lane == 0) {
@@ -2293,6 +2583,20 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
   }
   wsync();
   pc_flush(k, w, lds, tree);
+}
+// cycle-start borrowed sums (k_fs_sums): the count of borrowed cells of (node, r) is parked in bs_pos scratch
+// layout [N*nR] is not available, so bu_pos is produced by a second pass over the node's resources
+KQ_DEV void fs_sums_cell(const K& k, int node, int r) {
+  PG pg{&k.S, k.usage};
+  int64_t sm; int ps;
+  node_sums(k.S, node, pg, r, &sm, &ps);
+  k.X.bu_sum[(size_t)node * k.S.nR + r] = sm;
+}
+KQ_DEV void fs_pos_node(const K& k, int node) {
+  PG pg{&k.S, k.usage};
+  int tot = 0;
+  for (int r = 0; r < k.S.nR; r++) { int64_t sm; int ps; node_sums(k.S, node, pg, r, &sm, &ps); tot += ps; }
+  k.X.bu_pos[node] = tot;
 }
 // global iteration position of a fair-sharing entry: rank of (merge key, position in the tree's sequence)
 KQ_DEV int fair_rank(const K& k, int e, int f_begin, int f_end) {

@@ -79,11 +79,12 @@ __global__ __launch_bounds__(64) void k_process(const K* __restrict__ kp, unsign
 
 // Fair sharing: the iterator pops interleave with processEntry (scheduler.go:358), so ordering and processing
 // are one kernel: one wave per root-cohort tree; the tree's cohort usage rows stay in LDS.
-__global__ __launch_bounds__(64) void k_process_fair(const K* __restrict__ kp, unsigned lds_bytes) {
+constexpr int FAIR_THREADS = 512;  // wave 0 leads, all 8 waves recompute DRS values between pops
+__global__ __launch_bounds__(FAIR_THREADS) void k_process_fair(const K* __restrict__ kp, unsigned lds_bytes) {
   const K& k = *kp;
   __shared__ Wave w;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
-  process_tree_fair(k, w, blockIdx.x, blockIdx.x, (int64_t*)dyn_lds, lds_bytes);
+  process_tree_fair(k, w, blockIdx.x, blockIdx.x, (int64_t*)dyn_lds, lds_bytes, (int)threadIdx.x, FAIR_THREADS);
 }
 // global iteration positions from the per-tree sequences (kq::fair_rank): 2-D grid like k_order
 __global__ __launch_bounds__(256) void k_fair_rank(const K* __restrict__ kp, int32_t* rank) {
@@ -99,6 +100,19 @@ __global__ __launch_bounds__(256) void k_fair_rank_apply(const K* __restrict__ k
   const K& k = *kp;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < k.H.n && k.X.fs_key[i] >= 0) k.O.order[i] = rank[i];
+}
+
+// per-node borrowed sums of the cycle-start plane: one thread per (node, resource)
+__global__ __launch_bounds__(256) void k_fs_sums(const K* __restrict__ kp) {
+  const K& k = *kp;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= k.S.N * k.S.nR) return;
+  fs_sums_cell(k, i / k.S.nR, i % k.S.nR);
+}
+__global__ __launch_bounds__(256) void k_fs_pos(const K* __restrict__ kp) {
+  const K& k = *kp;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n < k.S.N) fs_pos_node(k, n);
 }
 
 namespace kq {
@@ -158,6 +172,12 @@ struct HipBackend {
     chk(hipMemcpyAsync(dk[which], &hk[which], sizeof(K), hipMemcpyHostToDevice, stream), "memcpy K");
     return dk[which];
   }
+  void launch_fs_sums(const K& k) {
+    const K* d = put_k(k, 0);
+    hipLaunchKernelGGL(k_fs_sums, dim3((k.S.N * k.S.nR + 255) / 256), dim3(256), 0, stream, d);
+    hipLaunchKernelGGL(k_fs_pos, dim3((k.S.N + 255) / 256), dim3(256), 0, stream, d);
+    chk(hipGetLastError(), "k_fs_sums");
+  }
   void launch_nominate(const K& k, int slots) {
     hipLaunchKernelGGL(k_nominate, dim3(slots), dim3(64), 0, stream, put_k(k, 0), slots);
     chk(hipGetLastError(), "k_nominate");
@@ -189,7 +209,7 @@ struct HipBackend {
       lds_attr_fair = lds;
     }
     const K* d = put_k(k, 1);
-    hipLaunchKernelGGL(k_process_fair, dim3(n_tree), dim3(64), lds, stream, d, (unsigned)lds);
+    hipLaunchKernelGGL(k_process_fair, dim3(n_tree), dim3(FAIR_THREADS), lds, stream, d, (unsigned)lds);
     const int nb = (k.H.n + 255) / 256;
     chk(hipMemsetAsync(rank, 0, (size_t)k.H.n * sizeof(int32_t), stream), "memset rank");
     hipLaunchKernelGGL(k_fair_rank, dim3(nb, nb), dim3(256), 0, stream, d, rank);
@@ -298,6 +318,8 @@ int kq_snapshot_read_planes(kq_engine* en, int64_t* subtree_quota, int64_t* usag
 const char* kq_last_error(kq_engine* en) { return en ? en->e.last_error.c_str() : "null engine"; }
 
 // profiling hook (KQ_PROF builds): 32 segment cycle counters accumulated since the last reset
+// tests: take the saturation-safe DRS loops even when the incremental sums would be exact
+int kq_debug_force_exact_drs(kq_engine* en, int on) { if (!en) return KQ_EINVAL; en->e.force_exact_drs = on != 0; return KQ_OK; }
 int kq_debug_prof(kq_engine* en, int64_t* out, int reset) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);

@@ -31,8 +31,9 @@ template <class B> struct EngineT {
   // cycle buffers (grow-only)
   struct Buf { void* p = nullptr; size_t cap = 0; };
   std::vector<Buf*> all_bufs;
-  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_fs[10];
-  struct HeadBatch { Buf hb[16]; DHeads H{}; int n = 0; size_t nps = 0; int slot_cap = 1; int64_t cycle = 0; bool valid = false; };
+  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_fs[20];
+  bool force_exact_drs = false;  // tests: take the saturation-safe DRS loops even when the sums would be exact
+  struct HeadBatch { Buf hb[16]; DHeads H{}; int n = 0; size_t nps = 0; int slot_cap = 1; int64_t cycle = 0; bool valid = false; bool plain = true; };
   std::vector<HeadBatch> batches;  // [0] = transient batch of kq_cycle_run, [1+b] = resident batch b
   Buf ob[24];  // output arrays
   uint8_t* hstage = nullptr;  // pinned host staging for the packed decisions
@@ -121,6 +122,7 @@ template <class B> struct EngineT {
     S.tree_rows = upload(prep.tree_rows.data(), prep.tree_rows.size());
     S.lendable = upload(prep.lendable.data(), prep.lendable.size());
     S.rank_pos = upload(prep.rank_pos.data(), prep.rank_pos.size());
+    S.frcount = upload(prep.frcount.data(), prep.frcount.size());
     S.top_of = upload(prep.top_of.data(), prep.top_of.size());
     S.fair_weight = upload(s->fair_weight, N);
     S.child_cohort_off = upload(s->child_cohort_off, prep.nc + 1);
@@ -136,9 +138,10 @@ template <class B> struct EngineT {
     return KQ_OK;
   }
 
-  int validate_heads(const kq_heads* h, int* slot_cap) {
+  int validate_heads(const kq_heads* h, int* slot_cap, bool* plain) {
     if (h->n < 0) return fail(KQ_EINVAL, "negative head count");
     int cap = 1;
+    *plain = true;
     for (int i = 0; i < h->n; i++) {
       if (h->cq[i] < 0 || h->cq[i] >= prep.nq) return fail(KQ_EINVAL, "head cq out of range");
       int nps = h->ps_off[i + 1] - h->ps_off[i];
@@ -150,7 +153,10 @@ template <class B> struct EngineT {
         if (nreq < 0) return fail(KQ_EINVAL, "ps_req_off not monotone");
         if (nreq + 1 > KQ_MAXREQ) return fail(KQ_EUNSUPPORTED, "more resources per podset than KQ_MAXREQ");
         for (int e = h->ps_req_off[p]; e < h->ps_req_off[p + 1]; e++)
+        {
           if (h->req_res[e] < 0 || h->req_res[e] >= prep.nR) return fail(KQ_EINVAL, "req_res out of range");
+          if (h->req_qty[e] < 0 || h->req_qty[e] >= ((int64_t)1 << 40)) *plain = false;
+        }
         slots += nreq + 1;
       }
       if (slots > KQ_MAXU) return fail(KQ_EUNSUPPORTED, "more usage entries than KQ_MAXU");
@@ -171,12 +177,13 @@ template <class B> struct EngineT {
     if (!have_snapshot) return fail(KQ_EINVAL, "heads before kq_snapshot_put");
     if (slot < 0 || slot > 4096) return fail(KQ_EINVAL, "bad batch id");
     int slot_cap = 1;
-    int rc = validate_heads(h, &slot_cap);
+    bool plain = true;
+    int rc = validate_heads(h, &slot_cap, &plain);
     if (rc != KQ_OK) return rc;
     if ((int)batches.size() <= slot) batches.resize(slot + 1);
     HeadBatch& hbch = batches[slot];
     const int n = h->n;
-    hbch.n = n; hbch.slot_cap = slot_cap; hbch.cycle = h->cycle; hbch.valid = true;
+    hbch.n = n; hbch.slot_cap = slot_cap; hbch.cycle = h->cycle; hbch.valid = true; hbch.plain = plain;
     hbch.nps = n ? h->ps_off[n] : 0;
     if (n == 0) return KQ_OK;
     const size_t nps = hbch.nps, nreqs = h->ps_req_off[nps], nR = prep.nR, nfw = (prep.nF + 63) / 64;
@@ -230,6 +237,7 @@ template <class B> struct EngineT {
     K k{};
     k.S = S;
     k.C.n_fs = std::min(std::max(cfg.n_fs_strategies, 0), 2); k.C.fs[0] = cfg.fs_strategies[0]; k.C.fs[1] = cfg.fs_strategies[1];
+    k.C.fs_plain = (prep.fs_plain && hbch.plain && prep.nR <= KQ_MAXR && !force_exact_drs) ? 1 : 0;
     k.C.gates = cfg.gates; k.C.fair_sharing = cfg.fair_sharing; k.C.quota_check_strategy = cfg.quota_check_strategy; k.C.cycle = hbch.cycle;
     k.H = hbch.H;
     // outputs
@@ -278,7 +286,13 @@ template <class B> struct EngineT {
       X.cq_ent = grow<int32_t>(b_fs[3], tq); X.fs_ratio = grow<double>(b_fs[4], tq * KQ_MAXD); X.fs_weight = grow<double>(b_fs[5], tq * KQ_MAXD);
       X.fs_bon = grow<uint8_t>(b_fs[6], tq * KQ_MAXD); X.fs_win = grow<int32_t>(b_fs[7], tn); X.fs_seq = grow<int32_t>(b_fs[8], tq);
       X.fs_key = grow<int32_t>(b_fs[9], n);
+      X.fs_stale = grow<uint8_t>(b_fs[10], tq); X.fs_cost = grow<int32_t>(b_fs[11], tq * KQ_MAXD);
+      X.fs_sum = (long long*)grow<int64_t>(b_fs[12], slots); X.fs_ctl = grow<int32_t>(b_fs[13], (size_t)slots * 4);
       be.memset(X.fs_key, 0xff, (size_t)n * sizeof(int32_t));
+      // per-node borrowed sums (the segmented reduction DRS is built from), for the cycle-start plane and the work plane
+      X.bu_sum = grow<int64_t>(b_fs[14], (size_t)prep.N * nR); X.bu_pos = grow<int32_t>(b_fs[15], prep.N);
+      X.bs_sum = grow<int64_t>(b_fs[16], (size_t)prep.N * nR); X.bs_pos = grow<int32_t>(b_fs[17], prep.N);
+      X.psum = grow<int64_t>(b_fs[18], tn * nR); X.ppos = grow<int32_t>(b_fs[19], tn);
     }
     k.usage = d_usage;
     k.usage_work = grow<int64_t>(b_usage_work, Nfr);
@@ -292,6 +306,11 @@ template <class B> struct EngineT {
     be.memset(k.preempted, 0, std::max(prep.n_adm, 1));
 
     be.timer_mark(0);
+    if (cfg.fair_sharing) {
+      be.launch_fs_sums(k);
+      be.d2d(X.bs_sum, X.bu_sum, (size_t)prep.N * nR * sizeof(int64_t));
+      be.d2d(X.bs_pos, X.bu_pos, (size_t)prep.N * sizeof(int32_t));
+    }
     be.launch_nominate(k, slots_nom);
     be.timer_mark(1);
     int32_t* rank = grow<int32_t>(b_rank, n);

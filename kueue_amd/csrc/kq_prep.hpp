@@ -21,6 +21,7 @@ constexpr int KQ_MAXD = 8;      // max nodes on a CQ->root path (CQ + 7 cohort l
 constexpr int KQ_MAXREQ = 16;   // max resources requested by one podset (incl. injected "pods")
 constexpr int KQ_MAXU = 32;     // max (flavor,resource) entries in one assignment's usage
 constexpr int KQ_MAXPS = 8;     // max podsets per workload handled on device
+constexpr int KQ_MAXR = 8;      // max resources for the incremental (sum-based) DRS; more fall back to the exact loops
 
 struct Prep {
   int nq = 0, nc = 0, N = 0, nF = 0, nR = 0, nfr = 0, n_adm = 0, n_rg = 0;
@@ -36,6 +37,8 @@ struct Prep {
   // fair sharing: calculateLendable(parent(node)) per resource (fair_sharing.go:186-200). It only reads quotas
   // (potentialAvailable ignores usage), so it is a per-snapshot constant. [N * nR]; 0 for root nodes.
   std::vector<int64_t> lendable;
+  std::vector<int32_t> frcount;                    // [N] flavor-resources with a SubtreeQuota entry (DRS iterates those)
+  bool fs_plain = true;                            // every finite amount is small enough that DRS sums cannot saturate
   std::vector<int32_t> rank_pos;                   // [n_adm] position of the row inside its tree's tree_rows segment
   std::vector<int32_t> top_of;                     // [N] the ancestor-or-self that is a child of the root (-1 for roots)
   int max_tree_nodes = 0, max_tree_cqs = 0, max_tree_rows = 0, max_tree_cohorts = 0;
@@ -164,6 +167,20 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
         if (s->borrow_limit[o] != KQ_NIL_LIMIT) avail = std::min(a_add(s->subtree_quota[o], s->borrow_limit[o]), avail);
         pot[o] = avail;
       }
+    p.frcount.assign(N, 0);
+    p.fs_plain = true;
+    const int64_t LIM = (int64_t)1 << 50;
+    for (int n = 0; n < N; n++)
+      for (size_t fr = 0; fr < nfr; fr++) {
+        size_t o = (size_t)n * nfr + fr;
+        if (s->quota_flags[o] & KQ_QF_SUBTREE) p.frcount[n]++;
+        auto small = [&](int64_t v) { return v > -LIM && v < LIM; };
+        if (!small(s->usage[o])) p.fs_plain = false;
+        if (s->subtree_quota[o] != U && !small(s->subtree_quota[o])) p.fs_plain = false;
+      }
+    for (int r = 0; r < p.n_adm; r++)
+      for (int e = s->adm_use_off[r]; e < s->adm_use_off[r + 1]; e++)
+        if (s->adm_use_qty[e] < 0 || s->adm_use_qty[e] >= LIM) p.fs_plain = false;
     p.lendable.assign((size_t)N * p.nR, 0);
     p.top_of.assign(N, -1);
     for (int n = 0; n < N; n++) {

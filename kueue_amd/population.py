@@ -37,17 +37,20 @@ class Population:
     ps_req: np.ndarray      # [n_ps, 3] cpu milli, memory bytes, gpu  (totals for the podset)
     cq_w_off: np.ndarray    # [n_cq+1]
     fair_sharing: bool = False
+    preemption: bool = False
 
     @property
     def n_pending(self) -> int:
         return int(len(self.w_cq))
 
-    def heads_for_cycle(self, c: int, cycle: int = 1) -> Heads:
+    def heads_for_cycle(self, c: int, cycle: int = 1, limit: int = 0) -> Heads:
         """Heads of cycle c = the c-th workload of every ClusterQueue queue (<= 1 head per CQ,
-        pkg/cache/queue/manager.go:922), CQ-name order."""
+        pkg/cache/queue/manager.go:922), CQ-name order. limit > 0: an evenly spaced sample of that batch."""
         snap = self.snapshot
         idx = self.cq_w_off[:-1] + c
         idx = idx[idx < self.cq_w_off[1:]]
+        if limit and limit < len(idx):
+            idx = idx[np.linspace(0, len(idx) - 1, limit).astype(np.int64)]
         return self._heads(idx, cycle)
 
     def all_heads(self, cycle: int = 1) -> Heads:
@@ -233,4 +236,4 @@ def generate(cfg: int, seed: int = BASE_SEED, n_cq: int = None, per_cq: int = No
     cq_w_off = np.concatenate([[0], np.cumsum(np.bincount(w_cq, minlength=nq))]).astype(np.int64)
     return Population(name=f"cfg{cfg}", snapshot=snap, w_cq=w_cq[order], w_prio=prio[order].astype(np.int64), w_ts=ts[order],
                       w_nps=w_nps[order], ps_count=ps_count[ps_order], ps_req=ps_req[ps_order], cq_w_off=cq_w_off,
-                      fair_sharing=fair_sharing)
+                      fair_sharing=fair_sharing, preemption=bool(preemption))

@@ -27,6 +27,10 @@ struct EmuBackend {
   int max_slots() { return 7; }  // small on purpose: exercises the grid-stride loop over heads
   void timer_mark(int) {}
   double timer_ms(int, int) { return 0; }
+  void launch_fs_sums(const K& k) {
+    for (int n = 0; n < k.S.N; n++) for (int r = 0; r < k.S.nR; r++) fs_sums_cell(k, n, r);
+    for (int n = 0; n < k.S.N; n++) fs_pos_node(k, n);
+  }
   void launch_nominate(const K& k, int slots) {
     for (int slot = 0; slot < slots; slot++) {
       Wave w{};
@@ -51,7 +55,7 @@ struct EmuBackend {
   void launch_process_fair(const K& k, int n_tree, size_t, int32_t* rank) {
     std::vector<int64_t> lds(160 * 1024 / 8);
     const size_t budgets[2] = {lds.size() * 8, 0};
-    for (int t = 0; t < n_tree; t++) { Wave w{}; process_tree_fair(k, w, t, t, lds.data(), budgets[(t + rot) % 2]); }
+    for (int t = 0; t < n_tree; t++) { Wave w{}; process_tree_fair(k, w, t, t, lds.data(), budgets[(t + rot) % 2], 0, 1); }
     rot++;
     for (int i = 0; i < k.H.n; i++) rank[i] = k.X.fs_key[i] >= 0 ? fair_rank(k, i, 0, k.H.n) : 0;
     for (int i = 0; i < k.H.n; i++) if (k.X.fs_key[i] >= 0) k.O.order[i] = rank[i];
@@ -65,6 +69,7 @@ extern "C" {
 int kqe_engine_create(const kq_config* cfg, void** out) { auto* e = new EmuEngine(); e->cfg = *cfg; *out = e; return KQ_OK; }
 void kqe_engine_destroy(void* e) { delete (EmuEngine*)e; }
 int kqe_snapshot_put(void* e, const kq_snapshot* s) { return ((EmuEngine*)e)->snapshot_put(s); }
+void kqe_force_exact_drs(void* e, int on) { ((EmuEngine*)e)->force_exact_drs = on != 0; }
 int kqe_cycle_run(void* e, const kq_heads* h, kq_decisions* out) { return ((EmuEngine*)e)->cycle_run(h, out); }
 int kqe_read_usage(void* e, int64_t* out) { return ((EmuEngine*)e)->read_usage_work(out); }
 int kqe_last_bytes(void* e, int64_t* out) { *out = ((EmuEngine*)e)->last_bytes; return KQ_OK; }

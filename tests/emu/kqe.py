@@ -27,6 +27,9 @@ class EmuEngine:
         self.h = C.c_void_p()
         assert lib().kqe_engine_create(C.byref(cfg), C.byref(self.h)) == 0
 
+    def force_exact_drs(self, on=True):
+        lib().kqe_force_exact_drs(self.h, 1 if on else 0)
+
     def close(self):
         if self.h:
             lib().kqe_engine_destroy(self.h)

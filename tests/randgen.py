@@ -9,7 +9,9 @@ POL_WCQ = ["Never", "LowerPriority", "LowerOrNewerEqualPriority"]
 POL_RWC = ["Never", "LowerPriority", "LowerOrNewerEqualPriority", "Any"]
 
 
-def random_case(seed, fair=False, preemption=True, max_cq=6, partial=False, fair_dups=False):
+def random_case(seed, fair=False, preemption=True, max_cq=6, partial=False, fair_dups=False, tight=False):
+    global _TIGHT
+    _TIGHT = tight
     rnd = random.Random(seed)
     n_flavors = rnd.randint(1, 4)
     flavors = [f"f{i}" for i in range(n_flavors)]
@@ -128,14 +130,19 @@ def random_case(seed, fair=False, preemption=True, max_cq=6, partial=False, fair
     return cfg, snap, heads
 
 
+_TIGHT = False
+
+
 def _fq(rnd, flavor, resources):
     fq = FlavorQuotas(flavor)
     for r in resources:
         unit = 1000 if r == "cpu" else 1
-        nominal = rnd.randint(0, 8) * unit
+        nominal = rnd.randint(0, 3 if _TIGHT else 8) * unit
         if rnd.random() < 0.03:
             nominal = (1 << 63) - 1
-        bl = rnd.choice([None, None, rnd.randint(0, 6) * unit])
+        # tight: over-committed ClusterQueues (usage above nominal + borrowingLimit), where
+        # quotaResourcesToReserve goes negative (scheduler.go:806) and removals stop commuting
+        bl = rnd.choice([None, rnd.randint(0, 2) * unit, rnd.randint(0, 2) * unit]) if _TIGHT else rnd.choice([None, None, rnd.randint(0, 6) * unit])
         ll = rnd.choice([None, None, rnd.randint(0, 6) * unit])
         fq.resources[r] = ResourceQuota(nominal, bl, ll)
     return fq

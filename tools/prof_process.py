@@ -7,8 +7,9 @@ F.ENGINE_LIB = os.path.join(F.HERE, "libkq_engine_prof.so")
 from kueue_amd.engine import Engine
 from kueue_amd.api import make_config
 from kueue_amd.population import generate
-pop = generate(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
-eng = Engine(make_config()); eng.put(pop.snapshot)
+fair = len(sys.argv) > 2 and sys.argv[2] == "fair"
+pop = generate(int(sys.argv[1]) if len(sys.argv) > 1 else 3, fair_sharing=fair)
+eng = Engine(make_config(fair_sharing=fair)); eng.put(pop.snapshot)
 lib = eng._lib
 lib.kq_debug_prof.argtypes = [C.c_void_p, F.i64p, C.c_int]
 prof = np.zeros(32, np.int64)
@@ -19,7 +20,8 @@ n = 0
 for c in range(3, 13):
     h = pop.heads_for_cycle(c); d = eng.run(h); n += h.n
 lib.kq_debug_prof(eng._h, F.ptr(prof), 1)
-names = {8: "pc_load", 9: "pc_flush", 10: "chunk_prefetch", 11: "chunk serial core",  12: "chunk write results", 0: "slow: load_head", 1: "slow: use list"}
+names = {8: "pc_load", 9: "pc_flush", 10: "chunk_prefetch", 11: "chunk serial core",  12: "chunk write results", 0: "slow: load_head", 1: "slow: use list",
+         16: "fair: computeDRS (leader wave)", 17: "fair: barrier wait", 18: "fair: tournament", 19: "fair: pop bookkeeping", 20: "fair: processEntry"}
 for i, nm in names.items():
     print(f"{nm:28s} {prof[i]/n:10.1f} cycles/entry   total {prof[i]}")
 print("kernel ms last cycle", d.kernel_ms)
