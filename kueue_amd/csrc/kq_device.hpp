@@ -45,6 +45,7 @@ KQ_DEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
 KQ_DEV int atomic_add_i32(int* p, int v) { int o = *p; *p += v; return o; }
 KQ_DEV void atomic_max_i32(int* p, int v) { if (v > *p) *p = v; }
 KQ_DEV void atomic_add_i64(long long* p, long long v) { *p += v; }
+KQ_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 KQ_DEV int64_t wsum_i64(int64_t v) { return v; }
 }  // namespace kq
 #else
@@ -78,6 +79,7 @@ KQ_DEV int popc64(uint64_t m) { return __popcll((unsigned long long)m); }
 KQ_DEV int atomic_add_i32(int* p, int v) { return atomicAdd(p, v); }
 KQ_DEV void atomic_max_i32(int* p, int v) { atomicMax(p, v); }
 KQ_DEV void atomic_add_i64(long long* p, long long v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
+KQ_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
 KQ_DEV int64_t wsum_i64(int64_t v) {
   for (int o = 32; o > 0; o >>= 1) v += (int64_t)__shfl_xor((long long)v, o, 64);
   return v;
@@ -113,6 +115,7 @@ struct DSnap {
   const int32_t* top_of;     // [N] ancestor-or-self that is a child of the root
   const int32_t* rank_pos;   // [n_adm] position of the row in its tree's rank-ordered tree_rows segment
   const int32_t* frcount;    // [N] flavor-resources with a SubtreeQuota entry
+  const int32_t* tree_rows_asc;  // admitted rows of a tree, ascending (offsets = tree_row_off)
   const double* fair_weight; // [N]
   const int32_t *child_cohort_off, *child_cohort, *child_cq_off, *child_cq, *depth;
   const int64_t* adm_rts;
@@ -179,9 +182,8 @@ struct DScratch {
   int32_t* ppos;     // [slots][max_tree_nodes]
   // fair-sharing iterator (fair_sharing_iterator.go): per tree slot
   int32_t* cq_ent;   // [slots][max_tree_cqs] cqToEntry: the head still to schedule for the CQ, -1 = none
-  double* fs_ratio;  // [slots][max_tree_cqs * KQ_MAXD] drsValues: DRS of path[level] with the entry admitted
-  double* fs_weight;
-  uint8_t* fs_bon;   // IsBorrowingOn(requestedFRs)
+  uint64_t* fs_keys; // [slots][max_tree_cqs * KQ_MAXD][4] drsValues folded into the tournament key (FsKey) of the
+                     // CQ's entry at each ancestor level
   int32_t* fs_win;   // [slots][max_tree_nodes] tournament winner per cohort
   int32_t* fs_seq;   // [slots][max_tree_cqs] the tree's pop sequence
   int32_t* fs_key;   // [H] merge key: smallest CQ index at or after the entry in its tree's sequence
@@ -412,12 +414,22 @@ struct Wave {
   uint8_t g_dirty[CELLS];
   int64_t bytes;                  // algorithmic bytes (lane 0 meaningful)
   int usage_dirty;                // set when processEntry added usage to the snapshot plane (fair-sharing DRS cache)
-  // A NEGATIVE amount was added to the snapshot (quotaResourcesToReserve has no max(0, .) on its borrowing
-  // branch, scheduler.go:806): cohort usage no longer equals what its children store in it, removals stop being
-  // order-independent, and usage_np cannot be maintained incrementally any more. From then on the tree's
-  // usage_np is rebuilt from usage_work before every use, removing rows in the reference's canonical order.
-  int np_broken;
+  // A NEGATIVE amount was added to a flavor-resource column of the snapshot (quotaResourcesToReserve has no
+  // max(0, .) on its borrowing branch, scheduler.go:806): in that column cohort usage no longer equals what the
+  // children store in it, removals stop being order-independent, and usage_np cannot be maintained incrementally.
+  // Once rows have been preempted too, such columns of usage_np are rebuilt from usage_work before every use,
+  // removing rows in the reference's canonical order (ascending row).
+  int np_broken;                  // any column broken
+  int n_pre;                      // rows preempted in this tree so far this cycle
+  uint64_t broken[4];             // column bitmap (nfr <= 256; beyond that every column counts as broken)
 };
+KQ_DEV void mark_broken(Wave& w, int fr) {
+  if (fr < 256) atomic_or_u64(&w.broken[fr >> 6], 1ull << (fr & 63));
+  w.np_broken = 1;
+}
+KQ_DEV bool col_broken(const Wave& w, int fr) { return fr >= 256 ? w.np_broken != 0 : ((w.broken[fr >> 6] >> (fr & 63)) & 1) != 0; }
+// must usage_np be rebuilt before it is read?
+KQ_DEV bool np_exact_mode(const Wave& w) { return w.np_broken && w.n_pre > 0; }
 
 // optional in-kernel segment timing (build with -DKQ_PROF): cycles accumulated per segment id
 #if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
@@ -939,14 +951,22 @@ KQ_DEV uint64_t f_head_key(const Search& s, int c) {
   uint32_t k32 = s.qhead[s.k->S.cq_local[c]];
   return ((uint64_t)(k32 >> 31) << 33) | ((uint64_t)(c == s.w->cq ? 1 : 0) << 32) | (uint64_t)(k32 & 0x7fffffffu);
 }
-// recount / re-head the queue of tree-local CQ `i` over rows flagged `flag` (all lanes compute the same)
+// recount / re-head the queue of tree-local CQ `i` over rows flagged `flag`: one lane per row, wave min
 KQ_DEV void f_rescan(const Search& s, int i, uint8_t flag) {
   const DSnap& S = s.k->S;
-  int c = S.tree_cqs[S.tree_cq_off[s.tree] + i];
-  uint32_t head = 0xffffffffu; int cnt = 0;
-  for (int row = S.cq_adm_off[c]; row < S.cq_adm_off[c + 1]; row++)
-    if (s.cls[S.rank_pos[row]] == flag) { cnt++; uint32_t key = f_row_key(S, row); if (key < head) head = key; }
-  if (lane_id() == 0) { s.qcnt[i] = cnt; s.qhead[i] = head; }
+  const int c = S.tree_cqs[S.tree_cq_off[s.tree] + i];
+  const int r0 = S.cq_adm_off[c], nr = S.cq_adm_off[c + 1] - r0;
+  uint64_t head = 0xffffffffull; int cnt = 0;
+  for (int base = 0; base < nr; base += WAVE) {
+    const int j = base + lane_id();
+    uint64_t key = 0xffffffffull;
+    bool in = false;
+    if (j < nr) { const int row = r0 + j; in = s.cls[S.rank_pos[row]] == flag; if (in) key = f_row_key(S, row); }
+    cnt += popc64(wballot(in));
+    const uint64_t mn = wmin_u64(key);
+    if (mn < head) head = mn;
+  }
+  if (lane_id() == 0) { s.qcnt[i] = cnt; s.qhead[i] = (uint32_t)head; }
   wsync();
 }
 // PopWorkload (ordering.go:84-90): the popped row's flag becomes `newflag`
@@ -1197,7 +1217,15 @@ KQ_DEV void fair_search(Search& s) {
     for (int i = lane; i < nn; i += WAVE) s.cohp[i] = 0;
     for (int i = lane; i < nqs; i += WAVE) s.cqinfo[i] = 0;
     wsync();
-    for (int i = 0; i < nqs; i++) f_rescan(s, i, 2);
+    for (int i = lane; i < nqs; i += WAVE) {  // MakeClusterQueueOrdering(retryCandidates): one lane per CQ
+      const int c = S.tree_cqs[q0 + i];
+      uint32_t head = 0xffffffffu; int cnt = 0;
+      if (s.qcnt[i] >= 0)
+        for (int row = S.cq_adm_off[c]; row < S.cq_adm_off[c + 1]; row++)
+          if (s.cls[S.rank_pos[row]] == 2) { cnt++; const uint32_t key = f_row_key(S, row); if (key < head) head = key; }
+      s.qcnt[i] = cnt; s.qhead[i] = head;
+    }
+    wsync();
     for (int cand = f_ordering_next(s); cand >= 0 && !fits; cand = fits ? -1 : f_ordering_next(s)) {
       int ap, at;
       f_almost_lcas(s, cand, &ap, &at);
@@ -1704,24 +1732,38 @@ KQ_DEV void np_apply_row_restricted(const K& k, Wave& w, int row, bool add) {
   }
   wsync();
 }
-// usage_np := usage_work with every row marked in k.preempted removed, ascending row (SimulateWorkloadUsageRemoval
-// snapshot.go:80-100 over the canonical order). One lane per flavor-resource column; columns are independent.
-KQ_DEV void np_rebuild(const K& k, Wave& w, int tree) {
+// Columns of usage_np := usage_work with every row marked in k.preempted removed, ascending row
+// (SimulateWorkloadUsageRemoval snapshot.go:80-100 over the canonical order). `use_only`: the entry's own
+// flavor-resources (w.use_fr), else every broken column. Marked rows are found with a ballot scan over the tree's
+// rows in ascending order; each selected column is owned by one lane (columns are independent).
+KQ_DEV void np_rebuild(const K& k, Wave& w, int tree, bool use_only) {
   const DSnap& S = k.S;
+  const int lane = lane_id();
   const int n0 = S.tree_node_off[tree], nn = S.tree_node_off[tree + 1] - n0;
-  const int q0 = S.tree_cq_off[tree], nqs = S.tree_cq_off[tree + 1] - q0;
-  for (int i = lane_id(); i < nn * S.nfr; i += WAVE) {
-    const int node = S.tree_nodes[n0 + i / S.nfr], fr = i % S.nfr;
-    up_plane(k, w, 1, fr).set(node, up_plane(k, w, 0, fr).get(node));
+  const int r0 = S.tree_row_off[tree], nrows = S.tree_row_off[tree + 1] - r0;
+  const int ncol = use_only ? w.nuse : S.nfr;
+  // copy the selected columns
+  for (int ci = 0; ci < ncol; ci++) {
+    const int fr = use_only ? w.use_fr[ci] : ci;
+    if (!use_only && !col_broken(w, fr)) continue;
+    UP a = up_plane(k, w, 0, fr), b = up_plane(k, w, 1, fr);
+    for (int i = lane; i < nn; i += WAVE) { const int node = S.tree_nodes[n0 + i]; b.set(node, a.get(node)); }
   }
   wsync();
-  for (int fr = lane_id(); fr < S.nfr; fr += WAVE) {
-    UP g = up_plane(k, w, 1, fr);
-    for (int qi = 0; qi < nqs; qi++) {
-      const int c = S.tree_cqs[q0 + qi];
-      for (int row = S.cq_adm_off[c]; row < S.cq_adm_off[c + 1]; row++) {
-        if (!k.preempted[row]) continue;
-        for (int e = S.adm_use_off[row]; e < S.adm_use_off[row + 1]; e++)
+  for (int base = 0; base < nrows; base += WAVE) {
+    const int i = base + lane;
+    const int row = i < nrows ? S.tree_rows_asc[r0 + i] : -1;
+    uint64_t m = wballot(row >= 0 && k.preempted[row] != 0);
+    while (m) {
+      const int bsrc = ffs64(m);
+      m &= m - 1;
+      const int prow = wbcast(row, bsrc);
+      const int c = S.adm_cq[prow];
+      for (int ci = lane; ci < ncol; ci += WAVE) {
+        const int fr = use_only ? w.use_fr[ci] : ci;
+        if (!use_only && !col_broken(w, fr)) continue;
+        UP g = up_plane(k, w, 1, fr);
+        for (int e = S.adm_use_off[prow]; e < S.adm_use_off[prow + 1]; e++)
           if (S.adm_use_fr[e] == fr) remove_usage(S, S.path + (size_t)c * KQ_MAXD, S.plen[c], fr, S.adm_use_qty[e], g);
       }
     }
@@ -1732,11 +1774,14 @@ KQ_DEV void np_rebuild(const K& k, Wave& w, int tree) {
 KQ_DEV bool entry_fits(const K& k, Wave& w, const int32_t* trows, int nt, bool quota_usage, int tree) {
   const DSnap& S = k.S;
   if (!quota_usage || w.nuse == 0) return true;
-  if (w.np_broken) {
+  bool exact = false;
+  if (w.np_broken && (w.n_pre > 0 || nt > 0))
+    for (int u = 0; u < w.nuse; u++) if (col_broken(w, w.use_fr[u])) exact = true;
+  if (exact) {
     // exact order of the reference: preempted and new targets leave the snapshot together, ascending row
     if (lane_id() == 0) for (int t = 0; t < nt; t++) if (!k.preempted[trows[t]]) k.preempted[trows[t]] = 2;
     wsync();
-    np_rebuild(k, w, tree);
+    np_rebuild(k, w, tree, true);
     bool bad = false;
     for (int u = lane_id(); u < w.nuse; u += WAVE) {
       UP g = up_plane(k, w, 1, w.use_fr[u]);
@@ -1746,7 +1791,7 @@ KQ_DEV bool entry_fits(const K& k, Wave& w, const int32_t* trows, int nt, bool q
     wsync();
     if (lane_id() == 0) for (int t = 0; t < nt; t++) if (k.preempted[trows[t]] == 2) k.preempted[trows[t]] = 0;
     wsync();
-    np_rebuild(k, w, tree);
+    np_rebuild(k, w, tree, true);
     if (lane_id() == 0) w.bytes += (int64_t)w.nuse * 40 * w.plen;
     return ok;
   }
@@ -1850,7 +1895,7 @@ KQ_DEV void process_entry_fast(const K& k, Wave& w, int e) {
       const int b = u * plen;
       int64_t val = w.use_qty[u];
       if (reserve) val = reserve_amount(val, S.nominal[ix(S, w.cq, w.use_fr[u])], w.g_bl[b], w.g_uw[b], w.borrowing);
-      if (val < 0) w.np_broken = 1;
+      if (val < 0) mark_broken(w, w.use_fr[u]);
       int64_t v = val;  // resource_node.go:144-152 on both planes
       for (int i = 0; i < plen; i++) {
         int64_t uu = w.g_uw[b + i], la = i64max(0, a_sub(w.g_lq[b + i], uu));
@@ -1906,7 +1951,7 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
   wsync();
   KQ_TS(k, 1);
   int nt = O.tgt_n[e];
-  if (nt == 0 && w.nuse * w.plen <= CELLS && !w.np_broken) {
+  if (nt == 0 && w.nuse * w.plen <= CELLS && !np_exact_mode(w)) {
     process_entry_fast(k, w, e);
     KQ_TS(k, 2);
     if (lane == 0) atomic_add_i64(O.stat_bytes, (long long)w.bytes);
@@ -1923,7 +1968,7 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
   if (has_any() && gate(k, KQ_GATE_RECOMPUTE_ON_OVERLAP)) {
     // SimulateWorkloadRemoval(victimsOfOtherPreemptions) == evaluate on usage_np with those rows deleted.
     // The generic nominate code reads HBM planes: publish the LDS-resident cohort rows first.
-    if (w.np_broken) np_rebuild(k, w, tree);
+    if (np_exact_mode(w)) np_rebuild(k, w, tree, false);
     pc_flush(k, w, w.pc_lds, tree);
     if (lane == 0) w.has_last = 0;
     // e.NominationMapping = e.readResourceToFlavorMapping() (scheduler.go:734): fixed for the whole recomputation
@@ -1956,7 +2001,7 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
         for (int u = 0; u < w.nuse; u++) {
           int fr = w.use_fr[u];
           w.s_qty[u] = reserve_amount(w.use_qty[u], S.nominal[ix(S, w.cq, fr)], S.bl[ix(S, w.cq, fr)], k.usage_work[ix(S, w.cq, fr)], w.borrowing);
-          if (w.s_qty[u] < 0) w.np_broken = 1;
+          if (w.s_qty[u] < 0) mark_broken(w, fr);
         }
       wsync();
       entry_add_usage(k, w, w.s_qty);
@@ -1976,6 +2021,7 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
       int row = trows[t];
       if (lane == 0 && !k.preempted[row]) {
         k.preempted[row] = 1;
+        w.n_pre++;
         int c = S.adm_cq[row];
         for (int en = S.adm_use_off[row]; en < S.adm_use_off[row + 1]; en++) {
           UP g = up_plane(k, w, 1, S.adm_use_fr[en]);
@@ -2143,7 +2189,7 @@ template <int PLEN, bool PLAIN> KQ_DEV bool core_run(const K& k, Wave& w, int64_
       if (reserve) {  // quotaResourcesToReserve scheduler.go:796-814
         if (r.borrowing > 0) val = x.bl[0] == KQ_NIL_LIMIT ? x.qty : i64min(x.qty, q_sub<PLAIN>(q_add<PLAIN>(x.nominal, x.bl[0]), x.uw[0]));
         else val = i64max(0, i64min(x.qty, q_sub<PLAIN>(x.nominal, x.uw[0])));
-        if (val < 0) w.np_broken = 1;
+        if (val < 0) mark_broken(w, r.fr[u]);
       }
       // addUsage resource_node.go:144-152 on usage_work, then on usage_np
       int64_t v = val;
@@ -2206,7 +2252,7 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
     w.pc_ncoh = (S.tree_node_off[tree + 1] - S.tree_node_off[tree]) - w.pc_ncq;
     w.pc_lds = lds;
     w.pc_on = (w.pc_ncoh > 0 && lds_bytes >= rec_bytes && (size_t)w.pc_ncoh * S.nfr * 16 <= lds_bytes - rec_bytes) ? 1 : 0;
-    w.np_broken = 0;
+    w.np_broken = 0; w.n_pre = 0; w.broken[0] = w.broken[1] = w.broken[2] = w.broken[3] = 0;
   }
   wsync();
   const bool chunked = lds_bytes >= rec_bytes;
@@ -2243,7 +2289,7 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
       int j = 0;
       for (; j < nch; j++) {
         PRec& r = rec[j];
-        if (r.slow || w.np_broken) {
+        if (r.slow || np_exact_mode(w)) {
           // generic path (targets / recompute / oversize / usage_np no longer incremental). It reads and writes HBM for CQ-level cells, so the
           // CQ-level values prefetched for the rest of the chunk may be stale afterwards: restart after it.
           chunk_scatter(k, rec, j);  // earlier fast entries' CQ-level cells must be in HBM first
@@ -2362,18 +2408,23 @@ KQ_DEV uint64_t f64_bits(double v) {
   x.d = v;
   return x.u;
 }
-KQ_DEV FsKey fs_key(const K& k, int slot, int en, int cohort) {
-  const DSnap& S = k.S; const DHeads& H = k.H;
-  const int c = H.cq[en];
-  const size_t i = ((size_t)slot * k.X.max_tree_cqs + S.cq_local[c]) * KQ_MAXD + (S.depth[c] - S.depth[cohort] - 1);
-  DRSv d; d.ratio = k.X.fs_ratio[i]; d.weight = k.X.fs_weight[i]; d.borrowing = 0; d.borrow_on = 0;
+KQ_DEV FsKey fs_make_key(const K& k, int en, const DRSv& d) {
+  const DHeads& H = k.H;
   const bool zwb = drs_zwb(d);
   FsKey key;
   key.k1 = (gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS) && !(H.flags[en] & KQ_HEAD_IS_PREEMPTOR) ? 4u : 0u) |
-           (gate(k, KQ_GATE_FS_PRIORITIZE_NON_BORROWING) && k.X.fs_bon[i] ? 2u : 0u) | (zwb ? 1u : 0u);
+           (gate(k, KQ_GATE_FS_PRIORITIZE_NON_BORROWING) && d.borrow_on ? 2u : 0u) | (zwb ? 1u : 0u);
   key.k2 = f64_bits(zwb ? d.ratio : drs_pws(d));
   key.k3 = gate(k, KQ_GATE_PRIORITY_SORTING_IN_COHORT) ? ~((uint64_t)H.priority[en] ^ 0x8000000000000000ull) : 0;
   key.k4 = (uint64_t)H.queue_ts[en] ^ 0x8000000000000000ull;
+  return key;
+}
+// the cached key of entry `en` for the tournament inside `cohort`
+KQ_DEV FsKey fs_key(const K& k, int slot, int en, int cohort) {
+  const DSnap& S = k.S;
+  const int c = k.H.cq[en];
+  const uint64_t* p = k.X.fs_keys + (((size_t)slot * k.X.max_tree_cqs + S.cq_local[c]) * KQ_MAXD + (S.depth[c] - S.depth[cohort] - 1)) * 4;
+  FsKey key; key.k1 = p[0]; key.k2 = p[1]; key.k3 = p[2]; key.k4 = p[3];
   return key;
 }
 // runTournament for ONE cohort (fair_sharing_iterator.go:125-163): candidates = the winners of the child
@@ -2422,9 +2473,11 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
   int32_t* cq_ent = k.X.cq_ent + (size_t)slot * k.X.max_tree_cqs;
   int32_t* win = k.X.fs_win + (size_t)slot * k.X.max_tree_nodes;
   int32_t* seq = k.X.fs_seq + (size_t)slot * k.X.max_tree_cqs;
-  double* fr_ratio = k.X.fs_ratio + (size_t)slot * k.X.max_tree_cqs * KQ_MAXD;
-  double* fr_weight = k.X.fs_weight + (size_t)slot * k.X.max_tree_cqs * KQ_MAXD;
-  uint8_t* fr_bon = k.X.fs_bon + (size_t)slot * k.X.max_tree_cqs * KQ_MAXD;
+  uint64_t* fkeys = k.X.fs_keys + (size_t)slot * k.X.max_tree_cqs * KQ_MAXD * 4;
+  // lds layout: [2 planes of the tree's cohort rows, if they fit][one prefetched entry record]
+  const bool have_rec = lds_bytes >= sizeof(PRec);
+  PRec* rec = (PRec*)((unsigned char*)lds + (lds_bytes - (have_rec ? sizeof(PRec) : 0)));
+  int64_t fast_bytes = 0;
   uint8_t* stale = k.X.fs_stale + (size_t)slot * k.X.max_tree_cqs;
   int32_t* cost = k.X.fs_cost + (size_t)slot * k.X.max_tree_cqs * KQ_MAXD;
   long long* sum = k.X.fs_sum + slot;
@@ -2433,9 +2486,9 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
     w.pc_ncq = nqs;
     w.pc_ncoh = nn - nqs;
     w.pc_lds = lds;
-    w.pc_on = (w.pc_ncoh > 0 && (size_t)w.pc_ncoh * S.nfr * 16 <= lds_bytes) ? 1 : 0;
+    w.pc_on = (w.pc_ncoh > 0 && have_rec && (size_t)w.pc_ncoh * S.nfr * 16 <= lds_bytes - sizeof(PRec)) ? 1 : 0;
     *sum = 0; ctl[0] = 0; ctl[1] = -1; ctl[2] = 0;
-    w.np_broken = 0;
+    w.np_broken = 0; w.n_pre = 0; w.broken[0] = w.broken[1] = w.broken[2] = w.broken[3] = 0; w.n_pre = 0; w.broken[0] = w.broken[1] = w.broken[2] = w.broken[3] = 0;
   }
   for (int i = tid; i < nqs; i += nthreads) { cq_ent[i] = -1; stale[i] = 0; }
   for (int i = tid; i < nqs * KQ_MAXD; i += nthreads) cost[i] = 0;
@@ -2501,7 +2554,8 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
           DRSv d = k.C.fs_plain ? drs_entry_level(k, w, path, l, pe.ufr, pe.uqty, pe.nu, want_bon, &lb)
                                 : drs_of(S, path[l], pe, &lb, pe.ufr, pe.uqty, want_bon ? pe.nu : 0);
           const size_t o = (size_t)i * KQ_MAXD + l;
-          fr_ratio[o] = d.ratio; fr_weight[o] = d.weight; fr_bon[o] = (uint8_t)d.borrow_on;
+          const FsKey key = fs_make_key(k, en, d);
+          fkeys[o * 4 + 0] = key.k1; fkeys[o * 4 + 1] = key.k2; fkeys[o * 4 + 2] = key.k3; fkeys[o * 4 + 3] = key.k4;
           delta += lb - cost[o];
           cost[o] = (int32_t)lb;
         }
@@ -2546,7 +2600,26 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
       }
       wsync();
       KQ_TS(k, 19);
-      process_entry(k, w, e, lpos, slot, tree);
+      // processEntry: the straight-line core on a prefetched record when the entry has no preemption targets
+      bool done = false;
+      if (have_rec && !np_exact_mode(w)) {
+        if (lane == 0) { w.win_e[0] = e; w.win_pos[0] = lpos; }
+        wsync();
+        chunk_prefetch(k, w, rec, w.win_e, w.win_pos, 1);
+        if (!rec->slow) {
+          chunk_entry_fast(k, w, lds, *rec, &fast_bytes);
+          wsync();
+          if (lane == 0) {
+            O.status[e] = rec->status; O.action[e] = rec->action; O.requeue_reason[e] = rec->rq; O.skip[e] = rec->skip; O.mode[e] = rec->omode;
+            O.order[e] = lpos;
+            w.usage_dirty = rec->dirty;
+          }
+          wsync();
+          chunk_scatter(k, rec, 1);
+          done = true;
+        }
+      }
+      if (!done) process_entry(k, w, e, lpos, slot, tree);
       KQ_TS(k, 20);
       if (k.C.fs_plain && w.usage_dirty) {  // the rows of the popped entry's path changed: refresh their sums
         const int pl = S.plen[ec];
@@ -2575,6 +2648,7 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
     first = false;
   }
   if (!leader) return;
+  if (lane == 0 && fast_bytes) atomic_add_i64(O.stat_bytes, (long long)fast_bytes);
   // merge key of the canonical getCq (lowest CQ index still in the map): the tree pops until
   // that CQ's own entry has been returned, so an entry is emitted in the turn of the smallest CQ at or after it.
   if (lane == 0) {

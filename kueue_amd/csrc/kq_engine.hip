@@ -203,7 +203,7 @@ struct HipBackend {
   size_t lds_attr = 0, lds_attr_fair = 0;
   void launch_process_fair(const K& k, int n_tree, size_t cohort_rows_bytes, int32_t* rank) {
     const size_t budget = 160 * 1024 - 8 * 1024;
-    size_t lds = cohort_rows_bytes <= budget ? cohort_rows_bytes : 0;
+    size_t lds = sizeof(PRec) + (cohort_rows_bytes + sizeof(PRec) <= budget ? cohort_rows_bytes : 0);
     if (lds > 48 * 1024 && lds != lds_attr_fair) {
       chk(hipFuncSetAttribute((const void*)k_process_fair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
       lds_attr_fair = lds;

@@ -123,6 +123,7 @@ template <class B> struct EngineT {
     S.lendable = upload(prep.lendable.data(), prep.lendable.size());
     S.rank_pos = upload(prep.rank_pos.data(), prep.rank_pos.size());
     S.frcount = upload(prep.frcount.data(), prep.frcount.size());
+    S.tree_rows_asc = upload(prep.tree_rows_asc.data(), prep.tree_rows_asc.size());
     S.top_of = upload(prep.top_of.data(), prep.top_of.size());
     S.fair_weight = upload(s->fair_weight, N);
     S.child_cohort_off = upload(s->child_cohort_off, prep.nc + 1);
@@ -283,8 +284,8 @@ template <class B> struct EngineT {
     if (cfg.fair_sharing) {
       const size_t tq = (size_t)slots * X.max_tree_cqs, tn = (size_t)slots * X.max_tree_nodes;
       X.qcnt = grow<int32_t>(b_fs[0], tq); X.qhead = grow<uint32_t>(b_fs[1], tq); X.cohp = grow<uint8_t>(b_fs[2], tn);
-      X.cq_ent = grow<int32_t>(b_fs[3], tq); X.fs_ratio = grow<double>(b_fs[4], tq * KQ_MAXD); X.fs_weight = grow<double>(b_fs[5], tq * KQ_MAXD);
-      X.fs_bon = grow<uint8_t>(b_fs[6], tq * KQ_MAXD); X.fs_win = grow<int32_t>(b_fs[7], tn); X.fs_seq = grow<int32_t>(b_fs[8], tq);
+      X.cq_ent = grow<int32_t>(b_fs[3], tq); X.fs_keys = (uint64_t*)grow<int64_t>(b_fs[4], tq * KQ_MAXD * 4);
+      X.fs_win = grow<int32_t>(b_fs[7], tn); X.fs_seq = grow<int32_t>(b_fs[8], tq);
       X.fs_key = grow<int32_t>(b_fs[9], n);
       X.fs_stale = grow<uint8_t>(b_fs[10], tq); X.fs_cost = grow<int32_t>(b_fs[11], tq * KQ_MAXD);
       X.fs_sum = (long long*)grow<int64_t>(b_fs[12], slots); X.fs_ctl = grow<int32_t>(b_fs[13], (size_t)slots * 4);

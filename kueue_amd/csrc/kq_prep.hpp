@@ -37,6 +37,7 @@ struct Prep {
   // fair sharing: calculateLendable(parent(node)) per resource (fair_sharing.go:186-200). It only reads quotas
   // (potentialAvailable ignores usage), so it is a per-snapshot constant. [N * nR]; 0 for root nodes.
   std::vector<int64_t> lendable;
+  std::vector<int32_t> tree_rows_asc;              // admitted rows of a tree in ascending row order (same offsets as tree_rows)
   std::vector<int32_t> frcount;                    // [N] flavor-resources with a SubtreeQuota entry (DRS iterates those)
   bool fs_plain = true;                            // every finite amount is small enough that DRS sums cannot saturate
   std::vector<int32_t> rank_pos;                   // [n_adm] position of the row inside its tree's tree_rows segment
@@ -125,6 +126,8 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
         return a < b;
       });
   }
+  p.tree_rows_asc = p.tree_rows;
+  for (int t = 0; t < p.n_tree; t++) std::sort(p.tree_rows_asc.begin() + p.tree_row_off[t], p.tree_rows_asc.begin() + p.tree_row_off[t + 1]);
   p.rank_pos.assign(p.n_adm, 0);
   for (int t = 0; t < p.n_tree; t++)
     for (int i = p.tree_row_off[t]; i < p.tree_row_off[t + 1]; i++) p.rank_pos[p.tree_rows[i]] = i - p.tree_row_off[t];

@@ -54,8 +54,8 @@ struct EmuBackend {
   }
   void launch_process_fair(const K& k, int n_tree, size_t, int32_t* rank) {
     std::vector<int64_t> lds(160 * 1024 / 8);
-    const size_t budgets[2] = {lds.size() * 8, 0};
-    for (int t = 0; t < n_tree; t++) { Wave w{}; process_tree_fair(k, w, t, t, lds.data(), budgets[(t + rot) % 2], 0, 1); }
+    const size_t budgets[3] = {lds.size() * 8, sizeof(PRec) + 64, 0};
+    for (int t = 0; t < n_tree; t++) { Wave w{}; process_tree_fair(k, w, t, t, lds.data(), budgets[(t + rot) % 3], 0, 1); }
     rot++;
     for (int i = 0; i < k.H.n; i++) rank[i] = k.X.fs_key[i] >= 0 ? fair_rank(k, i, 0, k.H.n) : 0;
     for (int i = 0; i < k.H.n; i++) if (k.X.fs_key[i] >= 0) k.O.order[i] = rank[i];

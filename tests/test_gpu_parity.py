@@ -48,3 +48,24 @@ def test_random_fair_sharing_cycles_bit_exact(oracle, engine_mod, block):
             assert got.bytes == want.stats["total"], (seed, got.bytes, want.stats)
         finally:
             eng.close()
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_overcommitted_queues_bit_exact(oracle, engine_mod, block):
+    """Negative capacity reservations (usage above nominal + borrowingLimit) with preemptions in the same tree:
+    usage_np columns are rebuilt in the reference's canonical removal order. Classical and fair sharing."""
+    for seed in range(block * 50, block * 50 + 50):
+        fair = seed % 2 == 1
+        cfg, snap, heads = random_case(50_000 + seed, fair=fair, preemption=True, partial=(seed % 5 == 0), max_cq=8, fair_dups=fair, tight=True)
+        oracle.derive(snap)
+        want = oracle.cycle_run(cfg, snap, heads, want_usage=True)
+        eng = engine_mod.Engine(cfg)
+        try:
+            eng.put(snap)
+            got = eng.run(heads, tgt_cap=max(64, snap.n_adm * 8))
+            bad = want.equal(got)
+            assert not bad, (seed, bad, {k: (want.a[k].tolist(), got.a[k].tolist()) for k in bad})
+            assert np.array_equal(want.usage_after, eng.usage_after()), seed
+            assert got.bytes == want.stats["total"], (seed, got.bytes, want.stats)
+        finally:
+            eng.close()
