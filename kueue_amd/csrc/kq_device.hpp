@@ -2684,6 +2684,39 @@ KQ_DEV int fair_rank(const K& k, int e, int f_begin, int f_end) {
   return r;
 }
 
+// ------------------------------------------------------------------------------------------------
+// snapshot derivation (resource_node.go:167-230): SubtreeQuota of every node and Usage of every Cohort from
+// the Quotas and the ClusterQueue usage. One thread per (node, flavor-resource); cohorts level by level, deepest
+// first, children in hierarchy order (child cohorts, then ClusterQueues) as accumulateFromChild is called.
+// ------------------------------------------------------------------------------------------------
+struct DDerive { int64_t* sq; int64_t* usage; uint8_t* flags; };
+KQ_DEV void derive_cq_cell(const DSnap& S, const DDerive& d, int cq, int fr) {  // updateClusterQueueResourceNode :167-173
+  const size_t o = ix(S, cq, fr);
+  uint8_t f = d.flags[o] & (uint8_t)~KQ_QF_SUBTREE;
+  int64_t q = 0;
+  if (f & KQ_QF_QUOTA) { q = S.nominal[o]; f |= KQ_QF_SUBTREE; }
+  d.sq[o] = q; d.flags[o] = f;
+}
+KQ_DEV void derive_cohort_cell(const DSnap& S, const DDerive& d, int cohort, int fr) {  // updateCohortResourceNode :183-230
+  const size_t o = ix(S, cohort, fr);
+  uint8_t f = d.flags[o] & (uint8_t)~KQ_QF_SUBTREE;
+  int64_t q = 0, u = 0;
+  if (f & KQ_QF_QUOTA) { q = S.nominal[o]; f |= KQ_QF_SUBTREE; }
+  const int kx = cohort - S.nq;
+  for (int pass = 0; pass < 2; pass++) {
+    const int32_t* off = pass == 0 ? S.child_cohort_off : S.child_cq_off;
+    const int32_t* lst = pass == 0 ? S.child_cohort : S.child_cq;
+    for (int i = off[kx]; i < off[kx + 1]; i++) {
+      const size_t co = ix(S, lst[i], fr);
+      const int64_t csq = d.sq[co], ll = S.ll[co];
+      const int64_t lq = ll != KQ_NIL_LIMIT ? i64max(0, a_sub(csq, ll)) : 0;
+      if (d.flags[co] & KQ_QF_SUBTREE) { q = a_add(q, a_sub(csq, lq)); f |= KQ_QF_SUBTREE; }
+      u = a_add(u, i64max(0, a_sub(d.usage[co], lq)));
+    }
+  }
+  d.sq[o] = q; d.usage[o] = u; d.flags[o] = f;
+}
+
 // classical entry order (scheduler.go:1110-1163): a precedes b
 KQ_DEV bool entry_before(const K& k, int a, int b) {
   bool aq = k.H.flags[a] & KQ_HEAD_HAS_QUOTA_RESERVATION, bq = k.H.flags[b] & KQ_HEAD_HAS_QUOTA_RESERVATION;

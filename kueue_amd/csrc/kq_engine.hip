@@ -115,6 +115,18 @@ __global__ __launch_bounds__(256) void k_fs_pos(const K* __restrict__ kp) {
   if (n < k.S.N) fs_pos_node(k, n);
 }
 
+// kq_snapshot_derive: ClusterQueue cells, then one launch per cohort depth (deepest first)
+__global__ __launch_bounds__(256) void k_derive_cq(DSnap S, DDerive d) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < S.nq * S.nfr) derive_cq_cell(S, d, i / S.nfr, i % S.nfr);
+}
+__global__ __launch_bounds__(256) void k_derive_level(DSnap S, DDerive d, int depth) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= S.nc * S.nfr) return;
+  const int cohort = S.nq + i / S.nfr;
+  if (S.depth[cohort] == depth) derive_cohort_cell(S, d, cohort, i % S.nfr);
+}
+
 namespace kq {
 struct HipBackend {
   hipStream_t stream = nullptr;
@@ -171,6 +183,12 @@ struct HipBackend {
     hk[which] = k;
     chk(hipMemcpyAsync(dk[which], &hk[which], sizeof(K), hipMemcpyHostToDevice, stream), "memcpy K");
     return dk[which];
+  }
+  void launch_derive(const DSnap& S, const DDerive& d, int max_depth) {
+    hipLaunchKernelGGL(k_derive_cq, dim3((S.nq * S.nfr + 255) / 256), dim3(256), 0, stream, S, d);
+    for (int dep = max_depth; dep >= 0; dep--)
+      hipLaunchKernelGGL(k_derive_level, dim3((S.nc * S.nfr + 255) / 256), dim3(256), 0, stream, S, d, dep);
+    chk(hipGetLastError(), "k_derive");
   }
   void launch_fs_sums(const K& k) {
     const K* d = put_k(k, 0);
@@ -301,8 +319,8 @@ int kq_last_cycle_stats(kq_engine* en, double* kernel_ms, int64_t* algorithmic_b
 
 int kq_snapshot_derive(kq_engine* en) {
   if (!en) return KQ_EINVAL;
-  en->e.last_error = "kq_snapshot_derive: not implemented yet";
-  return KQ_EUNSUPPORTED;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.snapshot_derive();
 }
 
 int kq_snapshot_read_planes(kq_engine* en, int64_t* subtree_quota, int64_t* usage, uint8_t* quota_flags) {

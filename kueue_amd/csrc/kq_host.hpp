@@ -139,6 +139,36 @@ template <class B> struct EngineT {
     return KQ_OK;
   }
 
+  // kq_snapshot_derive: SubtreeQuota / cohort Usage / flags recomputed on the device from the uploaded Quotas and
+  // ClusterQueue usage; the fair-sharing constants that depend on them are rebuilt from the result.
+  int snapshot_derive() {
+    if (!have_snapshot) return fail(KQ_EINVAL, "kq_snapshot_derive before kq_snapshot_put");
+    int max_depth = 0;
+    for (int n = 0; n < prep.N; n++) max_depth = std::max(max_depth, (int)prep.depth[n]);
+    DDerive d{d_sq, d_usage, d_qflags};
+    be.launch_derive(S, d, max_depth);
+    const size_t cells = (size_t)prep.N * prep.nfr;
+    std::vector<int64_t> sq(cells), us(cells);
+    std::vector<uint8_t> fl(cells);
+    be.d2h(sq.data(), d_sq, cells * 8); be.d2h(us.data(), d_usage, cells * 8); be.d2h(fl.data(), d_qflags, cells);
+    int rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    build_fair(prep, sq.data(), us.data(), fl.data());
+    S.lendable = upload(prep.lendable.data(), prep.lendable.size());
+    S.frcount = upload(prep.frcount.data(), prep.frcount.size());
+    rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    return KQ_OK;
+  }
+  int read_planes(int64_t* sq, int64_t* us, uint8_t* fl) {
+    if (!have_snapshot) return fail(KQ_EINVAL, "no snapshot");
+    const size_t cells = (size_t)prep.N * prep.nfr;
+    if (sq) be.d2h(sq, d_sq, cells * 8);
+    if (us) be.d2h(us, d_usage, cells * 8);
+    if (fl) be.d2h(fl, d_qflags, cells);
+    return be.sync();
+  }
+
   int validate_heads(const kq_heads* h, int* slot_cap, bool* plain) {
     if (h->n < 0) return fail(KQ_EINVAL, "negative head count");
     int cap = 1;

@@ -39,12 +39,79 @@ struct Prep {
   std::vector<int64_t> lendable;
   std::vector<int32_t> tree_rows_asc;              // admitted rows of a tree in ascending row order (same offsets as tree_rows)
   std::vector<int32_t> frcount;                    // [N] flavor-resources with a SubtreeQuota entry (DRS iterates those)
+  std::vector<int32_t> h_parent;                   // host copies kept for build_fair after a device derive
+  std::vector<int64_t> h_ll, h_bl;
+  bool fs_plain_adm = true;
   bool fs_plain = true;                            // every finite amount is small enough that DRS sums cannot saturate
   std::vector<int32_t> rank_pos;                   // [n_adm] position of the row inside its tree's tree_rows segment
   std::vector<int32_t> top_of;                     // [N] the ancestor-or-self that is a child of the root (-1 for roots)
   int max_tree_nodes = 0, max_tree_cqs = 0, max_tree_rows = 0, max_tree_cohorts = 0;
   std::string err;
 };
+
+// fair sharing constants from the derived planes (sq = SubtreeQuota). calculateLendable(parent(node)) per
+// resource (fair_sharing.go:186-200) only reads quotas (potentialAvailable ignores usage): a per-snapshot constant.
+static inline void build_fair(Prep& p, const int64_t* sq, const int64_t* usage, const uint8_t* flags) {
+  const int N = p.N;
+  const int64_t U = INT64_MAX;
+  auto a_add = [&](int64_t a, int64_t b) -> int64_t {
+    if (a == U || b == U) return U;
+    if (b > 0 && a > U - b) return U;
+    if (b < 0 && a < INT64_MIN - b) return INT64_MIN;
+    return a + b;
+  };
+  auto a_sub = [&](int64_t a, int64_t b) -> int64_t {
+    if (a == U && b == U) return 0;
+    if (a == U) return U;
+    if (b == U) return INT64_MIN;
+    if (b < 0 && a > U + b) return U;
+    if (b > 0 && a < INT64_MIN + b) return INT64_MIN;
+    return a - b;
+  };
+  const size_t nfr = p.nfr;
+  const int32_t* parent = p.h_parent.data();
+  // potentialAvailable(node, fr) for every node, parents before children (resource_node.go:129-140)
+  std::vector<int32_t> by_depth(N);
+  for (int n = 0; n < N; n++) by_depth[n] = n;
+  std::sort(by_depth.begin(), by_depth.end(), [&](int a, int b) { return p.depth[a] < p.depth[b]; });
+  std::vector<int64_t> pot((size_t)N * nfr, 0);
+  for (int n : by_depth)
+    for (size_t fr = 0; fr < nfr; fr++) {
+      size_t o = (size_t)n * nfr + fr;
+      if (parent[n] < 0) { pot[o] = sq[o]; continue; }
+      int64_t lq = 0;
+      if (p.h_ll[o] != KQ_NIL_LIMIT) lq = std::max<int64_t>(0, a_sub(sq[o], p.h_ll[o]));
+      int64_t avail = a_add(lq, pot[(size_t)parent[n] * nfr + fr]);
+      if (p.h_bl[o] != KQ_NIL_LIMIT) avail = std::min(a_add(sq[o], p.h_bl[o]), avail);
+      pot[o] = avail;
+    }
+  p.frcount.assign(N, 0);
+  p.fs_plain = p.fs_plain_adm;
+  const int64_t LIM = (int64_t)1 << 50;
+  for (int n = 0; n < N; n++)
+    for (size_t fr = 0; fr < nfr; fr++) {
+      size_t o = (size_t)n * nfr + fr;
+      if (flags[o] & KQ_QF_SUBTREE) p.frcount[n]++;
+      auto small = [&](int64_t v) { return v > -LIM && v < LIM; };
+      if (!small(usage[o])) p.fs_plain = false;
+      if (sq[o] != U && !small(sq[o])) p.fs_plain = false;
+    }
+  p.lendable.assign((size_t)N * p.nR, 0);
+  p.top_of.assign(N, -1);
+  for (int n = 0; n < N; n++) {
+    int par = parent[n];
+    if (par < 0) continue;
+    int top = n;
+    while (parent[parent[top]] >= 0) top = parent[top];
+    p.top_of[n] = top;
+    const int root = p.root[n];
+    for (size_t fr = 0; fr < nfr; fr++) {
+      if (!(flags[(size_t)root * nfr + fr] & KQ_QF_SUBTREE)) continue;  // keys of root.SubtreeQuota
+      size_t r = fr % p.nR;
+      p.lendable[(size_t)n * p.nR + r] = a_add(p.lendable[(size_t)n * p.nR + r], pot[(size_t)par * nfr + fr]);
+    }
+  }
+}
 
 inline int build_prep(const kq_snapshot* s, Prep& p) {
   p.nq = s->n_cq; p.nc = s->n_cohort; p.N = p.nq + p.nc; p.nF = s->n_flavor; p.nR = s->n_resource;
@@ -137,69 +204,15 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
     p.max_tree_rows = std::max(p.max_tree_rows, p.tree_row_off[t + 1] - p.tree_row_off[t]);
     p.max_tree_cohorts = std::max(p.max_tree_cohorts, (p.tree_node_off[t + 1] - p.tree_node_off[t]) - (p.tree_cq_off[t + 1] - p.tree_cq_off[t]));
   }
-  // ---- fair sharing constants -----------------------------------------------------------------------
-  {
-    const int64_t U = INT64_MAX;
-    auto a_add = [&](int64_t a, int64_t b) -> int64_t {
-      if (a == U || b == U) return U;
-      if (b > 0 && a > U - b) return U;
-      if (b < 0 && a < INT64_MIN - b) return INT64_MIN;
-      return a + b;
-    };
-    auto a_sub = [&](int64_t a, int64_t b) -> int64_t {
-      if (a == U && b == U) return 0;
-      if (a == U) return U;
-      if (b == U) return INT64_MIN;
-      if (b < 0 && a > U + b) return U;
-      if (b > 0 && a < INT64_MIN + b) return INT64_MIN;
-      return a - b;
-    };
-    const size_t nfr = p.nfr;
-    // potentialAvailable(node, fr) for every node, parents before children (resource_node.go:129-140)
-    std::vector<int32_t> by_depth(N);
-    for (int n = 0; n < N; n++) by_depth[n] = n;
-    std::sort(by_depth.begin(), by_depth.end(), [&](int a, int b) { return p.depth[a] < p.depth[b]; });
-    std::vector<int64_t> pot((size_t)N * nfr, 0);
-    for (int n : by_depth)
-      for (size_t fr = 0; fr < nfr; fr++) {
-        size_t o = (size_t)n * nfr + fr;
-        if (s->parent[n] < 0) { pot[o] = s->subtree_quota[o]; continue; }
-        int64_t lq = 0;
-        if (s->lend_limit[o] != KQ_NIL_LIMIT) lq = std::max<int64_t>(0, a_sub(s->subtree_quota[o], s->lend_limit[o]));
-        int64_t avail = a_add(lq, pot[(size_t)s->parent[n] * nfr + fr]);
-        if (s->borrow_limit[o] != KQ_NIL_LIMIT) avail = std::min(a_add(s->subtree_quota[o], s->borrow_limit[o]), avail);
-        pot[o] = avail;
-      }
-    p.frcount.assign(N, 0);
-    p.fs_plain = true;
-    const int64_t LIM = (int64_t)1 << 50;
-    for (int n = 0; n < N; n++)
-      for (size_t fr = 0; fr < nfr; fr++) {
-        size_t o = (size_t)n * nfr + fr;
-        if (s->quota_flags[o] & KQ_QF_SUBTREE) p.frcount[n]++;
-        auto small = [&](int64_t v) { return v > -LIM && v < LIM; };
-        if (!small(s->usage[o])) p.fs_plain = false;
-        if (s->subtree_quota[o] != U && !small(s->subtree_quota[o])) p.fs_plain = false;
-      }
-    for (int r = 0; r < p.n_adm; r++)
-      for (int e = s->adm_use_off[r]; e < s->adm_use_off[r + 1]; e++)
-        if (s->adm_use_qty[e] < 0 || s->adm_use_qty[e] >= LIM) p.fs_plain = false;
-    p.lendable.assign((size_t)N * p.nR, 0);
-    p.top_of.assign(N, -1);
-    for (int n = 0; n < N; n++) {
-      int par = s->parent[n];
-      if (par < 0) continue;
-      int top = n;
-      while (s->parent[s->parent[top]] >= 0) top = s->parent[top];
-      p.top_of[n] = top;
-      const int root = p.root[n];
-      for (size_t fr = 0; fr < nfr; fr++) {
-        if (!(s->quota_flags[(size_t)root * nfr + fr] & KQ_QF_SUBTREE)) continue;  // keys of root.SubtreeQuota
-        size_t r = fr % p.nR;
-        p.lendable[(size_t)n * p.nR + r] = a_add(p.lendable[(size_t)n * p.nR + r], pot[(size_t)par * nfr + fr]);
-      }
-    }
-  }
+  // ---- fair sharing constants (depend on SubtreeQuota / usage: recomputed after kq_snapshot_derive) ----
+  p.h_parent.assign(s->parent, s->parent + N);
+  p.h_ll.assign(s->lend_limit, s->lend_limit + (size_t)N * p.nfr);
+  p.h_bl.assign(s->borrow_limit, s->borrow_limit + (size_t)N * p.nfr);
+  p.fs_plain_adm = true;
+  for (int r = 0; r < p.n_adm; r++)
+    for (int e = s->adm_use_off[r]; e < s->adm_use_off[r + 1]; e++)
+      if (s->adm_use_qty[e] < 0 || s->adm_use_qty[e] >= ((int64_t)1 << 50)) p.fs_plain_adm = false;
+  build_fair(p, s->subtree_quota, s->usage, s->quota_flags);
   // index validation
   for (int g = 0; g < p.n_rg; g++) {
     for (int k = s->rg_flavor_off[g]; k < s->rg_flavor_off[g + 1]; k++) if (s->rg_flavor[k] < 0 || s->rg_flavor[k] >= p.nF) { p.err = "rg_flavor out of range"; return KQ_EINVAL; }

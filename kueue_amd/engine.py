@@ -61,6 +61,14 @@ class Engine:
         d.kernel_ms, d.bytes = ms.value, by.value
         return d
 
+    def derive(self):
+        """kq_snapshot_derive on the uploaded snapshot; returns (subtree_quota, usage, quota_flags) read back."""
+        self._check(self._lib.kq_snapshot_derive(self._h))
+        n = self.snap.N * self.snap.n_fr
+        sq, us, fl = np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.uint8)
+        self._check(self._lib.kq_snapshot_read_planes(self._h, F.ptr(sq), F.ptr(us), F.ptr(fl)))
+        return sq, us, fl
+
     def usage_after(self) -> np.ndarray:
         """Snapshot usage as mutated by the last cycle (test hook)."""
         u = np.zeros(self.snap.N * self.snap.n_fr, np.int64)

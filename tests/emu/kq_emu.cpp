@@ -27,6 +27,11 @@ struct EmuBackend {
   int max_slots() { return 7; }  // small on purpose: exercises the grid-stride loop over heads
   void timer_mark(int) {}
   double timer_ms(int, int) { return 0; }
+  void launch_derive(const DSnap& S, const DDerive& d, int max_depth) {
+    for (int i = 0; i < S.nq * S.nfr; i++) derive_cq_cell(S, d, i / S.nfr, i % S.nfr);
+    for (int dep = max_depth; dep >= 0; dep--)
+      for (int i = 0; i < S.nc * S.nfr; i++) if (S.depth[S.nq + i / S.nfr] == dep) derive_cohort_cell(S, d, S.nq + i / S.nfr, i % S.nfr);
+  }
   void launch_fs_sums(const K& k) {
     for (int n = 0; n < k.S.N; n++) for (int r = 0; r < k.S.nR; r++) fs_sums_cell(k, n, r);
     for (int n = 0; n < k.S.N; n++) fs_pos_node(k, n);
@@ -69,6 +74,8 @@ extern "C" {
 int kqe_engine_create(const kq_config* cfg, void** out) { auto* e = new EmuEngine(); e->cfg = *cfg; *out = e; return KQ_OK; }
 void kqe_engine_destroy(void* e) { delete (EmuEngine*)e; }
 int kqe_snapshot_put(void* e, const kq_snapshot* s) { return ((EmuEngine*)e)->snapshot_put(s); }
+int kqe_snapshot_derive(void* e) { return ((EmuEngine*)e)->snapshot_derive(); }
+int kqe_read_planes(void* e, int64_t* sq, int64_t* us, uint8_t* fl) { return ((EmuEngine*)e)->read_planes(sq, us, fl); }
 void kqe_force_exact_drs(void* e, int on) { ((EmuEngine*)e)->force_exact_drs = on != 0; }
 int kqe_cycle_run(void* e, const kq_heads* h, kq_decisions* out) { return ((EmuEngine*)e)->cycle_run(h, out); }
 int kqe_read_usage(void* e, int64_t* out) { return ((EmuEngine*)e)->read_usage_work(out); }

@@ -27,6 +27,13 @@ class EmuEngine:
         self.h = C.c_void_p()
         assert lib().kqe_engine_create(C.byref(cfg), C.byref(self.h)) == 0
 
+    def derive(self):
+        assert lib().kqe_snapshot_derive(self.h) == 0
+        n = self.snap.N * self.snap.n_fr
+        sq, us, fl = np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.uint8)
+        assert lib().kqe_read_planes(self.h, F.ptr(sq), F.ptr(us), F.ptr(fl)) == 0
+        return sq, us, fl
+
     def force_exact_drs(self, on=True):
         lib().kqe_force_exact_drs(self.h, 1 if on else 0)
 
