@@ -1,0 +1,101 @@
+/* kq_tas.h — C ABI for the Topology-Aware-Scheduling part of the engine (BASELINE.json configs[4]).
+ *
+ * Replaces, for one TAS ResourceFlavor, (*TASFlavorSnapshot).FindTopologyAssignmentsForFlavor
+ * (pkg/cache/scheduler/tas_flavor_snapshot.go:578) on its default path:
+ *   phase 1  fillInCounts :1800, fillLeafCounts :1899, CountInWithLimitingResource pkg/resources/requests.go:195,
+ *            fillInCountsHelper :1930 (roll-up of pod / slice / leader capacities over the topology tree)
+ *   phase 2  findLevelWithFitDomains :1336, updateCountsToMinimumGeneric :1575, consumeWithLeadersGeneric :1486,
+ *            prioritizeLeaderDomain :1533, findBestFitDomainBy :1307, sortedDomains :1770, sortedDomainsWithLeader :1731,
+ *            buildAssignment :1701
+ * plus TASFlavorSnapshot.Fits :433 and updateTASUsage :267 as kq_tas_fits / kq_tas_usage_apply.
+ * Host side (stays in Go): building the topology tree from Nodes (tas_topology_tree.go), node feasibility
+ * (taints / selectors / affinity through the scheduling simulator -> `leaf_ok` mask), level-key resolution
+ * (levelKeyWithImpliedFallback :1212 -> `level`), message formatting from (status, operands).
+ * Not covered (status KQ_TAS_UNSUPPORTED): multi-layer slice constraints (buildSliceSizeAtLevel :1123),
+ * TASBalancedPlacement, TASRespectNodeAffinityPreferred (both default-off gates), node replacement.
+ *
+ * Canonical order: the domains of every level are numbered in the lexicographic order of their levelValues
+ * (compareDomainLevelValues :1727), so every "levelValues ascending" tie-break is an integer compare.
+ */
+#ifndef KQ_TAS_H
+#define KQ_TAS_H
+#include <stdint.h>
+#include "kq_engine.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KQ_TAS_MAX_LEVELS 8
+
+/* podset topology request kinds (isRequired :1240, isUnconstrained :1244) */
+#define KQ_TAS_REQUIRED      0
+#define KQ_TAS_PREFERRED     1
+#define KQ_TAS_UNCONSTRAINED 2
+
+/* per-podset result status */
+#define KQ_TAS_OK              0
+#define KQ_TAS_NOT_FIT         1  /* notFitMessage :1997: operand a = slices that fit, b = slices requested */
+#define KQ_TAS_NO_LEVEL        2  /* "topology level not specified" / "no requested topology level" */
+#define KQ_TAS_SLICE_ABOVE     3  /* "podset slice topology ... is above the podset topology" */
+#define KQ_TAS_BAD_SLICE_SIZE  4  /* "slice topology requested, but slice size not provided" */
+#define KQ_TAS_SKIPPED         5  /* an earlier podset of the workload failed: FindTopologyAssignmentsForFlavor returns early */
+#define KQ_TAS_UNSUPPORTED     6
+
+typedef struct kq_tas_topology {
+  int32_t n_levels;               /* len(levelKeys) */
+  int32_t n_resources;
+  int32_t pods_resource;          /* index of corev1.ResourcePods (resources.OnePodRequest is added to every request) */
+  int32_t profile_mixed;          /* features.TASProfileMixed: LeastFreeCapacity for unconstrained podsets (:1468) */
+  const int32_t* level_off;       /* [n_levels+1] offsets of each level's domains in `parent` */
+  const int32_t* parent;          /* [level_off[n_levels]] index (within the level above) of the parent domain; level 0: -1 */
+  /* leaves = domains of the last level, n_leaves = level_off[n_levels] - level_off[n_levels-1] */
+  const int64_t* free_capacity;   /* [n_leaves][n_resources] allocatable minus non-TAS usage (leafCapacity.freeCapacity :88) */
+  const int64_t* tas_usage;       /* [n_leaves][n_resources] leafCapacity.tasUsage */
+} kq_tas_topology;
+
+/* FlavorTASRequests of a batch of workloads. Podsets of one workload are consecutive; they are assigned in order,
+ * each seeing the assumed usage of the previous ones (:654-656). */
+typedef struct kq_tas_requests {
+  int32_t n_workloads;
+  const int32_t* wl_off;          /* [n_workloads+1] -> podset requests */
+  const uint8_t* simulate_empty;  /* [n_workloads] WithSimulateEmpty (:555), may be NULL */
+  const int64_t* single_pod_requests; /* [n][n_resources] TASPodSetRequests.SinglePodRequests; 0 = resource not requested */
+  const int32_t* count;           /* [n] */
+  const int32_t* level;           /* [n] resolved index of levelKeyWithImpliedFallback, -1 = none / not found */
+  const uint8_t* kind;            /* [n] KQ_TAS_REQUIRED / PREFERRED / UNCONSTRAINED */
+  const int32_t* slice_size;      /* [n] 1 when slices are not requested (getSliceSizeWithSinglePodAsDefault :1259) */
+  const int32_t* slice_level;     /* [n] resolved slice level, lowest level by default (sliceLevelKeyWithDefault :1197) */
+  const int32_t* group;           /* [n] PodSetGroupName id, -1 = none; two podsets of a workload with the same id are
+                                         leader + workers (findLeaderAndWorkers :668) */
+  const uint8_t* leaf_ok;         /* [n][n_leaves] node feasibility from the simulator (FindFeasibleNodes), NULL = all leaves */
+} kq_tas_requests;
+
+typedef struct kq_tas_result {
+  int32_t* status;                /* [n] KQ_TAS_* */
+  int32_t* operand_a;             /* [n] */
+  int32_t* operand_b;             /* [n] */
+  int32_t* dom_off;               /* [n+1] CSR into dom_leaf / dom_count: the TopologyAssignment (:1701), leaves ascending */
+  int32_t* dom_leaf;
+  int32_t* dom_count;
+  int32_t  dom_cap;
+} kq_tas_result;
+
+typedef struct kq_tas kq_tas;
+
+int  kq_tas_create(int32_t device, kq_tas** out);
+void kq_tas_destroy(kq_tas*);
+int  kq_tas_topology_put(kq_tas*, const kq_tas_topology* t);
+/* FindTopologyAssignmentsForFlavor for every workload of the batch against the SAME leaf state (nominate-style). */
+int  kq_tas_find(kq_tas*, const kq_tas_requests* r, kq_tas_result* out);
+/* updateTASUsage :267 for a TopologyAssignment: tas_usage[leaf] +/-= single_pod_requests * count (+ pods: count) */
+int  kq_tas_usage_apply(kq_tas*, int32_t n_dom, const int32_t* leaf, const int32_t* count, const int64_t* single_pod_requests, int32_t add);
+/* TASFlavorSnapshot.Fits :433 */
+int  kq_tas_fits(kq_tas*, int32_t n_dom, const int32_t* leaf, const int32_t* count, const int64_t* single_pod_requests, int32_t* fits);
+int  kq_tas_read_usage(kq_tas*, int64_t* tas_usage);
+int  kq_tas_last_stats(kq_tas*, double* kernel_ms, int64_t* bytes);
+const char* kq_tas_last_error(kq_tas*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KQ_TAS_H */

@@ -1,0 +1,350 @@
+"""Host side of the Topology-Aware-Scheduling boundary (include/kq_tas.h), mirroring the reference's names.
+
+What stays on the host in the reference stays here: building the topology tree from Nodes
+(pkg/cache/scheduler/tas_topology_tree.go:75 newTopologyTree), free capacity = allocatable - non-TAS pod usage
+(tas_flavor.go / tas_non_tas_pod_cache.go), resolving level keys (tas_flavor_snapshot.go:1204-1238) and formatting
+failure messages (:1997 notFitMessage). The engine gets flat arrays: domains of every level numbered in the
+lexicographic order of their levelValues, a leaf capacity / usage table and one record per podset request.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _ffi as F
+from .api import amount_from_quantity
+
+HOSTNAME_LABEL = "kubernetes.io/hostname"
+
+KQ_TAS_REQUIRED, KQ_TAS_PREFERRED, KQ_TAS_UNCONSTRAINED = 0, 1, 2
+TAS_OK, TAS_NOT_FIT, TAS_NO_LEVEL, TAS_SLICE_ABOVE, TAS_BAD_SLICE_SIZE, TAS_SKIPPED, TAS_UNSUPPORTED = range(7)
+
+
+class kq_tas_topology(C.Structure):
+    _fields_ = [
+        ("n_levels", C.c_int32), ("n_resources", C.c_int32), ("pods_resource", C.c_int32), ("profile_mixed", C.c_int32),
+        ("level_off", F.i32p), ("parent", F.i32p),
+        ("free_capacity", F.i64p), ("tas_usage", F.i64p),
+    ]
+
+
+class kq_tas_requests(C.Structure):
+    _fields_ = [
+        ("n_workloads", C.c_int32),
+        ("wl_off", F.i32p), ("simulate_empty", F.u8p),
+        ("single_pod_requests", F.i64p), ("count", F.i32p), ("level", F.i32p), ("kind", F.u8p),
+        ("slice_size", F.i32p), ("slice_level", F.i32p), ("group", F.i32p), ("leaf_ok", F.u8p),
+    ]
+
+
+class kq_tas_result(C.Structure):
+    _fields_ = [
+        ("status", F.i32p), ("operand_a", F.i32p), ("operand_b", F.i32p),
+        ("dom_off", F.i32p), ("dom_leaf", F.i32p), ("dom_count", F.i32p), ("dom_cap", C.c_int32),
+    ]
+
+
+@dataclass
+class Node:
+    """corev1.Node as the TAS cache sees it (testingnode.MakeNode(...).Label(...).StatusAllocatable(...).Ready())."""
+    name: str
+    labels: Dict[str, str]
+    allocatable: Dict[str, object]      # quantity strings or canonical ints
+    ready: bool = True
+    unschedulable: bool = False
+
+
+@dataclass
+class TopologyRequest:
+    """kueue.PodSetTopologyRequest (apis/kueue/v1beta2): required / preferred level label, unconstrained, slices."""
+    required: Optional[str] = None
+    preferred: Optional[str] = None
+    unconstrained: bool = False
+    slice_required_topology: Optional[str] = None
+    slice_size: Optional[int] = None
+
+
+@dataclass
+class TASPodSetRequests:
+    """cache/scheduler TASPodSetRequests (tas_flavor_snapshot.go:380)."""
+    name: str
+    count: int
+    single_pod_requests: Dict[str, object]
+    topology_request: Optional[TopologyRequest] = None   # None => Implied (:8417 of the test harness / :1216)
+    group: Optional[str] = None                           # PodSetGroupName
+    leaf_ok: Optional[Sequence[bool]] = None              # node feasibility mask from the simulator, by leaf index
+
+
+class Topology:
+    """topologyTree + leaf capacities of one TAS flavor."""
+
+    def __init__(self, levels: Sequence[str], nodes: Sequence[Node], non_tas_usage: Optional[Dict[str, Dict[str, object]]] = None,
+                 resources: Optional[Sequence[str]] = None, profile_mixed: bool = True):
+        self.levels = list(levels)
+        self.profile_mixed = profile_mixed
+        L = len(self.levels)
+        self.lowest_is_node = self.levels[-1] == HOSTNAME_LABEL
+        res = set(resources or [])
+        res.add("pods")
+        for n in nodes:
+            res.update(n.allocatable)
+        for u in (non_tas_usage or {}).values():
+            res.update(u)
+        self.resources = sorted(res)
+        self.resource_index = {r: i for i, r in enumerate(self.resources)}
+        R = len(self.resources)
+        # nodes that carry every level label and are Ready / schedulable make up the tree (tas_flavor.go, tas_topology_tree.go)
+        usable = [n for n in nodes if n.ready and not n.unschedulable and all(k in n.labels for k in self.levels)]
+        paths = sorted({tuple(n.labels[k] for k in self.levels) for n in usable})
+        self.level_values: List[List[Tuple[str, ...]]] = []
+        for l in range(L):
+            self.level_values.append(sorted({p[:l + 1] for p in paths}))
+        self.index = [{v: i for i, v in enumerate(vals)} for vals in self.level_values]
+        level_off = [0]
+        parent: List[int] = []
+        for l in range(L):
+            for v in self.level_values[l]:
+                parent.append(-1 if l == 0 else self.index[l - 1][v[:-1]])
+            level_off.append(len(parent))
+        self.n_leaves = len(self.level_values[-1])
+        free = np.zeros((self.n_leaves, R), np.int64)
+        for n in usable:
+            leaf = self.index[-1][tuple(n.labels[k] for k in self.levels)]
+            for r, q in n.allocatable.items():
+                free[leaf, self.resource_index[r]] += _amount(r, q)
+        node_leaf = {n.name: self.index[-1][tuple(n.labels[k] for k in self.levels)] for n in usable}
+        for node_name, usage in (non_tas_usage or {}).items():
+            if node_name not in node_leaf:
+                continue
+            for r, q in usage.items():
+                free[node_leaf[node_name], self.resource_index[r]] -= _amount(r, q)
+        self.node_leaf = node_leaf
+        self.arrays = dict(level_off=np.array(level_off, np.int32), parent=np.array(parent, np.int32),
+                           free_capacity=free.reshape(-1).copy(), tas_usage=np.zeros(self.n_leaves * R, np.int64))
+        self._struct = None
+
+    # -- level resolution: levelKey :1222, levelKeyWithImpliedFallback :1212, sliceLevelKeyWithDefault :1197 --
+    def resolve(self, tr: TASPodSetRequests) -> Tuple[int, int, int, int]:
+        """-> (level index or -1, kind, slice_size, slice_level index or -1)"""
+        t = tr.topology_request
+        implied = t is None
+        key = None
+        slices = t is not None and t.slice_required_topology is not None
+        if t is not None:
+            if t.required is not None:
+                key = t.required
+            elif t.preferred is not None:
+                key = t.preferred
+            elif slices:
+                key = self.levels[0]
+            elif t.unconstrained:
+                key = self.levels[-1]
+        if key is None and implied:
+            key = self.levels[-1]
+        level = self.levels.index(key) if key in self.levels else -1
+        if t is not None and t.required is not None:
+            kind = KQ_TAS_REQUIRED
+        elif implied or (t is not None and (t.unconstrained or (slices and t.preferred is None))):
+            kind = KQ_TAS_UNCONSTRAINED
+        else:
+            kind = KQ_TAS_PREFERRED
+        slice_size = 1
+        slice_key = self.levels[-1]
+        if slices:
+            slice_size = t.slice_size if t.slice_size is not None else 0
+            slice_key = t.slice_required_topology
+        slice_level = self.levels.index(slice_key) if slice_key in self.levels else -1
+        return level, kind, slice_size, slice_level
+
+    def set_tas_usage(self, usage_by_leaf: Dict[int, Dict[str, int]]):
+        u = self.arrays["tas_usage"].reshape(self.n_leaves, -1)
+        u[:] = 0
+        for leaf, d in usage_by_leaf.items():
+            for r, q in d.items():
+                u[leaf, self.resource_index[r]] = q
+
+    def struct(self) -> kq_tas_topology:
+        if self._struct is None:
+            self._struct = kq_tas_topology()
+        F.fill_struct(self._struct, self.arrays, dict(n_levels=len(self.levels), n_resources=len(self.resources),
+                                                      pods_resource=self.resource_index["pods"], profile_mixed=1 if self.profile_mixed else 0))
+        return self._struct
+
+    def leaf_values(self, leaf: int) -> List[str]:
+        """TopologyDomainAssignment.Values of a leaf as buildAssignment emits them (:1701-1710)."""
+        v = self.level_values[-1][leaf]
+        return [v[-1]] if self.lowest_is_node else list(v)
+
+
+def _amount(r: str, q) -> int:
+    return int(q) if isinstance(q, (int, np.integer)) else amount_from_quantity(r, q)
+
+
+class Requests:
+    """FlavorTASRequests of a batch of workloads -> kq_tas_requests."""
+
+    def __init__(self, topo: Topology, workloads: Sequence[Sequence[TASPodSetRequests]], simulate_empty: Optional[Sequence[bool]] = None):
+        self.topo = topo
+        self.workloads = [list(w) for w in workloads]
+        R = len(topo.resources)
+        flat = [tr for w in self.workloads for tr in w]
+        n = len(flat)
+        self.n = n
+        wl_off = np.zeros(len(self.workloads) + 1, np.int32)
+        for i, w in enumerate(self.workloads):
+            wl_off[i + 1] = wl_off[i] + len(w)
+        req = np.zeros((n, R), np.int64)
+        count = np.zeros(n, np.int32); level = np.zeros(n, np.int32); kind = np.zeros(n, np.uint8)
+        ssize = np.ones(n, np.int32); slevel = np.zeros(n, np.int32); group = np.full(n, -1, np.int32)
+        any_mask = any(tr.leaf_ok is not None for tr in flat)
+        leaf_ok = np.ones((n, topo.n_leaves), np.uint8) if any_mask else None
+        gid: Dict[Tuple[int, str], int] = {}
+        i = 0
+        for wi, w in enumerate(self.workloads):
+            for tr in w:
+                for r, q in tr.single_pod_requests.items():
+                    if r not in topo.resource_index:
+                        raise KeyError(f"resource {r} is not in the topology's resource dictionary")
+                    req[i, topo.resource_index[r]] = _amount(r, q)
+                count[i] = tr.count
+                level[i], kind[i], ssize[i], slevel[i] = topo.resolve(tr)
+                if tr.group is not None:
+                    group[i] = gid.setdefault((wi, tr.group), len(gid))
+                if tr.leaf_ok is not None:
+                    leaf_ok[i] = np.asarray(tr.leaf_ok, np.uint8)
+                i += 1
+        self.arrays = dict(wl_off=wl_off, single_pod_requests=req.reshape(-1).copy(), count=count, level=level, kind=kind,
+                           slice_size=ssize, slice_level=slevel, group=group)
+        if simulate_empty is not None:
+            self.arrays["simulate_empty"] = np.asarray(simulate_empty, np.uint8)
+        if leaf_ok is not None:
+            self.arrays["leaf_ok"] = leaf_ok.reshape(-1).copy()
+        self._struct = None
+
+    def struct(self) -> kq_tas_requests:
+        if self._struct is None:
+            self._struct = kq_tas_requests()
+        F.fill_struct(self._struct, self.arrays, dict(n_workloads=len(self.workloads)))
+        return self._struct
+
+
+class Result:
+    def __init__(self, rq: Requests, dom_cap: Optional[int] = None):
+        self.rq = rq
+        n = rq.n
+        cap = dom_cap if dom_cap is not None else max(64, int(rq.arrays["count"].sum()) + n)
+        self.a = dict(status=np.zeros(n, np.int32), operand_a=np.zeros(n, np.int32), operand_b=np.zeros(n, np.int32),
+                      dom_off=np.zeros(n + 1, np.int32), dom_leaf=np.zeros(cap, np.int32), dom_count=np.zeros(cap, np.int32))
+        self._struct = kq_tas_result()
+        F.fill_struct(self._struct, self.a, dict(dom_cap=cap))
+
+    def struct(self) -> kq_tas_result:
+        return self._struct
+
+    def assignment(self, i: int) -> List[Tuple[int, int]]:
+        o = self.a["dom_off"]
+        return [(int(self.a["dom_leaf"][k]), int(self.a["dom_count"][k])) for k in range(o[i], o[i + 1])]
+
+    def equal(self, other: "Result") -> List[str]:
+        bad = []
+        for k in ("status", "operand_a", "operand_b", "dom_off"):
+            if not np.array_equal(self.a[k], other.a[k]):
+                bad.append(k)
+        nd = int(self.a["dom_off"][-1])
+        if "dom_off" not in bad:
+            for k in ("dom_leaf", "dom_count"):
+                if not np.array_equal(self.a[k][:nd], other.a[k][:nd]):
+                    bad.append(k)
+        return bad
+
+    def message(self, i: int, topology_name: str = "default") -> str:
+        """Failure reason as the reference words it (notFitMessage :1997, findTopologyAssignment :886-947)."""
+        st, a, b = int(self.a["status"][i]), int(self.a["operand_a"][i]), int(self.a["operand_b"][i])
+        if st == TAS_OK:
+            return ""
+        if st == TAS_NOT_FIT:
+            unit = "pod" if int(self.rq.arrays["slice_size"][i]) == 1 else "slice"
+            if a == 0:
+                return f'topology "{topology_name}" doesn\'t allow to fit any of {b} {unit}(s)'
+            return f'topology "{topology_name}" allows to fit only {a} out of {b} {unit}(s)'
+        return {TAS_NO_LEVEL: "no requested topology level", TAS_SLICE_ABOVE: "podset slice topology is above the podset topology",
+                TAS_BAD_SLICE_SIZE: "slice topology requested, but slice size not provided", TAS_SKIPPED: "",
+                TAS_UNSUPPORTED: "unsupported on the device path"}[st]
+
+
+_tas_lib = None
+
+
+def load_tas():
+    """The TAS entry points live in the same shared library as the cycle engine."""
+    global _tas_lib
+    if _tas_lib is None:
+        lib = F.load_engine()
+        lib.kq_tas_create.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]
+        lib.kq_tas_destroy.argtypes = [C.c_void_p]
+        lib.kq_tas_destroy.restype = None
+        lib.kq_tas_topology_put.argtypes = [C.c_void_p, C.POINTER(kq_tas_topology)]
+        lib.kq_tas_find.argtypes = [C.c_void_p, C.POINTER(kq_tas_requests), C.POINTER(kq_tas_result)]
+        lib.kq_tas_usage_apply.argtypes = [C.c_void_p, C.c_int32, F.i32p, F.i32p, F.i64p, C.c_int32]
+        lib.kq_tas_fits.argtypes = [C.c_void_p, C.c_int32, F.i32p, F.i32p, F.i64p, F.i32p]
+        lib.kq_tas_read_usage.argtypes = [C.c_void_p, F.i64p]
+        lib.kq_tas_last_stats.argtypes = [C.c_void_p, F.f64p, F.i64p]
+        lib.kq_tas_last_error.argtypes = [C.c_void_p]
+        lib.kq_tas_last_error.restype = C.c_char_p
+        _tas_lib = lib
+    return _tas_lib
+
+
+TAS_ABI_SYMBOLS = ["kq_tas_create", "kq_tas_destroy", "kq_tas_topology_put", "kq_tas_find", "kq_tas_usage_apply", "kq_tas_fits",
+                   "kq_tas_read_usage", "kq_tas_last_stats", "kq_tas_last_error"]
+
+
+class TASEngine:
+    """FindTopologyAssignmentsForFlavor on the GPU (kueue_amd/csrc/kq_tas.hip) behind include/kq_tas.h."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_tas()
+        self._h = C.c_void_p()
+        rc = self._lib.kq_tas_create(device, C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError(f"kq_tas_create failed: {F.KQ_ERRORS.get(rc, rc)}")
+        self.topo: Optional[Topology] = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"kq_tas error {F.KQ_ERRORS.get(rc, rc)}: {self._lib.kq_tas_last_error(self._h).decode()}")
+
+    def put(self, topo: Topology):
+        self._check(self._lib.kq_tas_topology_put(self._h, C.byref(topo.struct())))
+        self.topo = topo
+
+    def find(self, rq: Requests, dom_cap: Optional[int] = None) -> Result:
+        out = Result(rq, dom_cap)
+        self._check(self._lib.kq_tas_find(self._h, C.byref(rq.struct()), C.byref(out.struct())))
+        ms, by = np.zeros(1, np.float64), np.zeros(1, np.int64)
+        self._lib.kq_tas_last_stats(self._h, F.ptr(ms), F.ptr(by))
+        out.kernel_ms, out.bytes = float(ms[0]), int(by[0])
+        return out
+
+    def usage_apply(self, assignment: Sequence[Tuple[int, int]], single_pod_requests: np.ndarray, add: bool = True):
+        leaf = np.array([a for a, _ in assignment], np.int32); cnt = np.array([c for _, c in assignment], np.int32)
+        self._check(self._lib.kq_tas_usage_apply(self._h, len(leaf), F.ptr(leaf), F.ptr(cnt), F.ptr(np.ascontiguousarray(single_pod_requests, np.int64)), 1 if add else 0))
+
+    def fits(self, assignment: Sequence[Tuple[int, int]], single_pod_requests: np.ndarray) -> bool:
+        leaf = np.array([a for a, _ in assignment], np.int32); cnt = np.array([c for _, c in assignment], np.int32)
+        out = np.zeros(1, np.int32)
+        self._check(self._lib.kq_tas_fits(self._h, len(leaf), F.ptr(leaf), F.ptr(cnt), F.ptr(np.ascontiguousarray(single_pod_requests, np.int64)), F.ptr(out)))
+        return bool(out[0])
+
+    def read_usage(self) -> np.ndarray:
+        u = np.zeros(self.topo.n_leaves * len(self.topo.resources), np.int64)
+        self._check(self._lib.kq_tas_read_usage(self._h, F.ptr(u)))
+        return u
+
+    def close(self):
+        if self._h:
+            self._lib.kq_tas_destroy(self._h)
+            self._h = None

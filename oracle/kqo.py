@@ -154,3 +154,20 @@ def is_preferred(a, b, policy_word: int) -> bool:
     l = lib()
     l.kqo_is_preferred.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_uint32]
     return bool(l.kqo_is_preferred(a[0], a[1], b[0], b[1], policy_word))
+
+
+def tas_find(topo, rq, dom_cap=None):
+    """FindTopologyAssignmentsForFlavor restatement (oracle/kq_tas_oracle.cpp) -> kueue_amd.tas.Result (+ .bytes)."""
+    from kueue_amd import tas as T
+    out = T.Result(rq, dom_cap)
+    stats = np.zeros(2, np.int64)
+    rc = lib().kqo_tas_find(C.byref(topo.struct()), C.byref(rq.struct()), C.byref(out.struct()), F.ptr(stats))
+    assert rc == 0, rc
+    out.bytes = int(stats[0])
+    return out
+
+
+def tas_fits(topo, assignment, single_pod_requests) -> bool:
+    leaf = np.array([a for a, _ in assignment], np.int32); cnt = np.array([c for _, c in assignment], np.int32)
+    req = np.ascontiguousarray(single_pod_requests, np.int64)
+    return bool(lib().kqo_tas_fits(C.byref(topo.struct()), len(leaf), F.ptr(leaf), F.ptr(cnt), F.ptr(req)))

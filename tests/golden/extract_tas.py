@@ -1,0 +1,368 @@
+#!/usr/bin/env python
+"""Transcribe TestFindTopologyAssignments (pkg/cache/scheduler/tas_cache_test.go:61) into tests/golden/tas_find.yaml.
+
+Run in the build container (needs /root/reference):  python tests/golden/extract_tas.py
+Only cases that stay on the path the engine covers are kept: plain Nodes (labels + allocatable, Ready / NotReady /
+Unschedulable), level lists, podsets with Required / Preferred / Unconstrained / single-layer slices / podset groups,
+`pods` giving non-TAS usage, feature gates limited to TASProfileMixed. Cases using taints, tolerations, node selectors,
+node affinity, previous assignments, workloads with unhealthy nodes, prior usage, balanced placement, multi-layer
+topology or other gates are counted and skipped (the reason is written into the YAML header).
+"""
+import collections
+import os
+import re
+import sys
+
+import yaml
+
+SRC = "/root/reference/pkg/cache/scheduler/tas_cache_test.go"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tas_find.yaml")
+
+
+def strip_comments(s):
+    s = re.sub(r"/\*.*?\*/", "", s, flags=re.S)
+    return "\n".join(re.sub(r"(^|\s)//.*$", "", ln) for ln in s.split("\n"))
+
+
+def match_brace(s, i, open_ch="{", close_ch="}"):
+    """s[i] == open_ch -> index of the matching close, skipping string literals."""
+    depth, j, n = 0, i, len(s)
+    while j < n:
+        c = s[j]
+        if c == '"':
+            j += 1
+            while s[j] != '"':
+                j += 2 if s[j] == "\\" else 1
+        elif c == "`":
+            j = s.index("`", j + 1)
+        elif c == open_ch:
+            depth += 1
+        elif c == close_ch:
+            depth -= 1
+            if depth == 0:
+                return j
+        j += 1
+    raise ValueError("unbalanced")
+
+
+def top_level_fields(body):
+    """'name: value,' pairs at depth 0 of a composite literal body -> {name: value_text}"""
+    out, i, n = collections.OrderedDict(), 0, len(body)
+    while i < n:
+        m = re.compile(r"\s*([A-Za-z_][A-Za-z0-9_]*)\s*:\s*").match(body, i)
+        if not m:
+            break
+        name, j = m.group(1), m.end()
+        k, depth = j, 0
+        while k < n:
+            c = body[k]
+            if c == '"':
+                k += 1
+                while body[k] != '"':
+                    k += 2 if body[k] == "\\" else 1
+            elif c == "`":
+                k = body.index("`", k + 1)
+            elif c in "{([":
+                depth += 1
+            elif c in "})]":
+                depth -= 1
+            elif c == "," and depth == 0:
+                break
+            k += 1
+        out[name] = body[j:k].strip()
+        i = k + 1
+    return out
+
+
+def elements(body):
+    """comma-separated elements at depth 0"""
+    out, k, depth, start, n = [], 0, 0, 0, len(body)
+    while k < n:
+        c = body[k]
+        if c == '"':
+            k += 1
+            while body[k] != '"':
+                k += 2 if body[k] == "\\" else 1
+        elif c == "`":
+            k = body.index("`", k + 1)
+        elif c in "{([":
+            depth += 1
+        elif c in "})]":
+            depth -= 1
+        elif c == "," and depth == 0:
+            if body[start:k].strip():
+                out.append(body[start:k].strip())
+            start = k + 1
+        k += 1
+    if body[start:].strip():
+        out.append(body[start:].strip())
+    return out
+
+
+CONSTS = {"corev1.LabelHostname": "kubernetes.io/hostname", "corev1.ResourceCPU": "cpu", "corev1.ResourceMemory": "memory",
+          "corev1.ResourcePods": "pods"}
+
+
+def ident(tok):
+    tok = tok.strip()
+    m = re.fullmatch(r"string\((.*)\)", tok)
+    if m:
+        tok = m.group(1).strip()
+    if tok.startswith('"'):
+        return tok[1:-1]
+    if tok in CONSTS:
+        return CONSTS[tok]
+    raise KeyError(tok)
+
+
+class Skip(Exception):
+    pass
+
+
+def parse_nodes(text):
+    """[]corev1.Node{ *testingnode.MakeNode("..").Label(..)...Obj(), ... } -> list of dicts"""
+    nodes = []
+    for el in elements(text):
+        m = re.match(r'\*testingnode\.MakeNode\("([^"]+)"\)', el)
+        if not m:
+            raise Skip("node literal: " + el[:40])
+        node = dict(name=m.group(1), labels={}, allocatable={}, ready=False)
+        rest = el[m.end():]
+        pos = 0
+        while pos < len(rest):
+            mm = re.compile(r"\s*\.\s*([A-Za-z]+)\(").match(rest, pos)
+            if not mm:
+                break
+            meth = mm.group(1)
+            close = match_brace(rest, mm.end() - 1, "(", ")")
+            args = rest[mm.end():close]
+            pos = close + 1
+            if meth == "Label":
+                k, v = elements(args)
+                node["labels"][ident(k)] = ident(v)
+            elif meth == "StatusAllocatable":
+                inner = args[args.index("{") + 1:args.rindex("}")]
+                for k, v in top_level_fields_generic(inner):
+                    node["allocatable"][ident(k)] = re.search(r'MustParse\("([^"]+)"\)', v).group(1)
+            elif meth == "Ready":
+                node["ready"] = True
+            elif meth == "NotReady":
+                node["ready"] = False
+            elif meth == "Unschedulable":
+                node["unschedulable"] = True
+            elif meth == "Obj":
+                pass
+            else:
+                raise Skip("node method " + meth)
+        nodes.append(node)
+    return nodes
+
+
+def top_level_fields_generic(body):
+    """key: value pairs where the key may be a quoted string or a dotted identifier"""
+    out = []
+    for el in elements(body):
+        k, depth = 0, 0
+        while k < len(el):
+            c = el[k]
+            if c == '"':
+                k += 1
+                while el[k] != '"':
+                    k += 1
+            elif c in "{([":
+                depth += 1
+            elif c in "})]":
+                depth -= 1
+            elif c == ":" and depth == 0:
+                break
+            k += 1
+        out.append((el[:k].strip(), el[k + 1:].strip()))
+    return out
+
+
+def parse_strings(text, named):
+    text = text.strip()
+    if text in named:
+        return named[text]
+    inner = text[text.index("{") + 1:text.rindex("}")]
+    return [ident(e) for e in elements(inner)]
+
+
+def new_arg(v):
+    m = re.fullmatch(r"new\((.*)\)", v.strip(), flags=re.S)
+    if not m:
+        m = re.fullmatch(r"ptr\.To\((.*)\)", v.strip(), flags=re.S)
+    if not m:
+        raise Skip("pointer literal " + v[:30])
+    return m.group(1).strip()
+
+
+def parse_podset(body, named_levels):
+    f = top_level_fields(body)
+    for bad in ("tolerations", "nodeSelector", "nodeAffinity", "previousAssignment"):
+        if bad in f:
+            raise Skip(bad)
+    ps = dict(name=ident(f["podSetName"]) if "podSetName" in f else "", count=int(f.get("count", "0")))
+    ps["requests"] = {}
+    if "requests" in f:
+        inner = f["requests"][f["requests"].index("{") + 1:f["requests"].rindex("}")]
+        for k, v in top_level_fields_generic(inner):
+            ps["requests"][ident(k)] = int(v)
+    if "topologyRequest" in f and f["topologyRequest"] != "nil":
+        t = f["topologyRequest"]
+        tf = top_level_fields(t[t.index("{") + 1:t.rindex("}")])
+        tr = {}
+        for k, v in tf.items():
+            if k == "Required":
+                tr["required"] = ident(new_arg(v))
+            elif k == "Preferred":
+                tr["preferred"] = ident(new_arg(v))
+            elif k == "Unconstrained":
+                tr["unconstrained"] = new_arg(v) == "true"
+            elif k == "PodSetSliceRequiredTopology":
+                tr["sliceRequiredTopology"] = ident(new_arg(v))
+            elif k == "PodSetSliceSize":
+                tr["sliceSize"] = int(re.search(r"(-?\d+)\)?$", re.sub(r"int32\(", "", new_arg(v))).group(1))
+            else:
+                raise Skip("topologyRequest." + k)
+        ps["topologyRequest"] = tr
+    if "podSetGroupName" in f:
+        ps["group"] = ident(new_arg(f["podSetGroupName"]))
+    if "wantReason" in f:
+        w = f["wantReason"].strip()
+        if not (w.startswith('"') or w.startswith("`")):
+            raise Skip("computed wantReason")
+        ps["wantReason"] = w[1:-1].replace('\\"', '"')
+    if "wantAssignment" in f and f["wantAssignment"] != "nil":
+        w = f["wantAssignment"]
+        wf = top_level_fields(w[w.index("{") + 1:w.rindex("}")])
+        doms = []
+        dtext = wf["Domains"]
+        for el in elements(dtext[dtext.index("{") + 1:dtext.rindex("}")]):
+            df = top_level_fields(el[el.index("{") + 1:el.rindex("}")])
+            vals = df["Values"]
+            doms.append(dict(count=int(df["Count"]), values=[ident(x) for x in elements(vals[vals.index("{") + 1:vals.rindex("}")])]))
+        ps["wantAssignment"] = dict(levels=parse_strings(wf["Levels"], named_levels), domains=doms)
+    return ps
+
+
+def parse_pods(text):
+    """[]corev1.Pod{ *testingpod.MakePod(..).NodeName("x").Request(res, "q")...Obj() } -> non-TAS usage per node"""
+    usage = {}
+    for el in elements(text):
+        if not re.match(r"\*testingpod\.MakePod\(", el):
+            raise Skip("pod literal")
+        node = None
+        reqs = {}
+        phase_done = False
+        for mm in re.finditer(r"\.\s*([A-Za-z]+)\(", el):
+            meth = mm.group(1)
+            close = match_brace(el, mm.end() - 1, "(", ")")
+            args = el[mm.end():close]
+            if meth == "NodeName":
+                node = ident(args)
+            elif meth == "Request":
+                k, v = elements(args)
+                reqs[ident(k)] = ident(v)
+            elif meth == "StatusPhase":
+                if "Succeeded" in args or "Failed" in args:
+                    phase_done = True
+            elif meth in ("MakePod", "Obj", "Clone"):
+                pass
+            else:
+                raise Skip("pod method " + meth)
+        if node is None or phase_done:
+            continue
+        u = usage.setdefault(node, collections.Counter())
+        for k, v in reqs.items():
+            u[k] += v if isinstance(v, int) else 0
+            usage[node][k] = usage[node].get(k, 0)  # placeholder, replaced below
+        usage[node] = dict(usage[node])
+        usage.setdefault("__raw__", []).append((node, reqs))
+    raw = usage.pop("__raw__", [])
+    out = {}
+    for node, reqs in raw:
+        d = out.setdefault(node, {})
+        for k, v in reqs.items():
+            d.setdefault(k, []).append(v)
+        d.setdefault("pods", []).append("1")
+    return out
+
+
+def main():
+    src = strip_comments(open(SRC).read())
+    start = src.index("func TestFindTopologyAssignments(")
+    end = src.index("func TestFindTopologyAssignmentsMultiLayerReplacement(")
+    body = src[start:end]
+    for m in re.finditer(r'(\w+)\s*=\s*"([^"]+)"', body[:body.index("defaultNodes")]):
+        CONSTS[m.group(1)] = m.group(2)
+    # named node sets and level lists
+    named_nodes, named_levels = {}, {}
+    for m in re.finditer(r"\n\t(\w+) := \[\]corev1\.Node\{", body):
+        close = match_brace(body, m.end() - 1)
+        try:
+            named_nodes[m.group(1)] = parse_nodes(body[m.end():close])
+        except Skip as e:
+            named_nodes[m.group(1)] = e
+    for m in re.finditer(r"\n\t(\w+) := \[\]string\{", body):
+        close = match_brace(body, m.end() - 1)
+        named_levels[m.group(1)] = [ident(e) for e in elements(body[m.end():close])]
+    cm = re.search(r"cases := map\[string\]struct \{", body)
+    sclose = match_brace(body, cm.end() - 1)
+    open_cases = body.index("{", sclose + 1)
+    close_cases = match_brace(body, open_cases)
+    cases_text = body[open_cases + 1:close_cases]
+    cases, skipped = [], collections.Counter()
+    for el in elements(cases_text):
+        nm = re.match(r'"((?:[^"\\]|\\.)*)"\s*:\s*\{', el)
+        if not nm:
+            skipped["unparsed"] += 1
+            continue
+        name = nm.group(1)
+        f = top_level_fields(el[nm.end():el.rindex("}")])
+        try:
+            case = dict(name=name)
+            if "nodeLabels" in f:  # flavorInformation.NodeLabels: the flavor only selects nodes carrying these labels
+                nl = f["nodeLabels"]
+                case["nodeLabels"] = {ident(k): ident(v) for k, v in top_level_fields_generic(nl[nl.index("{") + 1:nl.rindex("}")])}
+            for bad in ("workload", "priorOwnUsage", "priorFlavorUsage", "aggregatedDomainUsages"):
+                if bad in f:
+                    raise Skip(bad)
+            if "featureGates" in f:
+                g = f["featureGates"]
+                gates = dict(top_level_fields_generic(g[g.index("{") + 1:g.rindex("}")]))
+                for k, v in gates.items():
+                    if k == "features.TASProfileMixed":
+                        case["profileMixed"] = v.strip() == "true"
+                    else:
+                        raise Skip("gate " + k.replace("features.", ""))
+            nodes = f.get("nodes", "").strip()
+            if nodes in named_nodes:
+                if isinstance(named_nodes[nodes], Skip):
+                    raise named_nodes[nodes]
+                case["nodes"] = named_nodes[nodes]
+            elif nodes:
+                case["nodes"] = parse_nodes(nodes[nodes.index("{") + 1:nodes.rindex("}")])
+            else:
+                case["nodes"] = []
+            case["levels"] = parse_strings(f["levels"], named_levels)
+            if "pods" in f:
+                p = f["pods"]
+                case["nonTASUsage"] = parse_pods(p[p.index("{") + 1:p.rindex("}")])
+            ps_text = f["podSets"]
+            case["podSets"] = [parse_podset(e[e.index("{") + 1:e.rindex("}")], named_levels) for e in elements(ps_text[ps_text.index("{") + 1:ps_text.rindex("}")])]
+            cases.append(case)
+        except Skip as e:
+            skipped[str(e).split(" ")[0] if str(e).startswith(("gate", "node", "pod")) else str(e)] += 1
+        except (KeyError, ValueError, AttributeError) as e:
+            skipped["parse:" + type(e).__name__] += 1
+    hdr = ("# Generated by tests/golden/extract_tas.py from pkg/cache/scheduler/tas_cache_test.go (TestFindTopologyAssignments).\n"
+           f"# {len(cases)} cases kept; skipped: {dict(skipped)}\n")
+    with open(OUT, "w") as fh:
+        fh.write(hdr)
+        yaml.safe_dump(dict(cases=cases), fh, sort_keys=False, width=160)
+    print(len(cases), "cases;", dict(skipped))
+
+
+if __name__ == "__main__":
+    main()
