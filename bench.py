@@ -32,10 +32,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4c", "cfg3f", "cfg4f"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4c", "cfg3f", "cfg4f", "cfg5"],
                     help="cfg3 = BASELINE.json configs[2] (100k pending, 1k CQ, 16 flavors, 3-level cohorts); "
                          "cfg4c = configs[3] population under classical preemption; cfg4f = configs[3] as quoted "
-                         "(fair sharing + preemption); cfg3f = configs[2] population under fair sharing")
+                         "(fair sharing + preemption); cfg3f = configs[2] population under fair sharing; cfg5 = configs[4] "
+                         "(TAS: 4096-leaf 3-tier topology, topology assignment for a batch of pending workloads)")
+    ap.add_argument("--tas-batch", type=int, default=50_000, help="cfg5: pending workloads assigned per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -51,6 +53,8 @@ def main():
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
+    if args.workload == "cfg5":
+        return bench_tas(args, torch, dist, world, rank, local_rank)
     from kueue_amd.api import Decisions, make_config
     from kueue_amd.engine import Engine
     from kueue_amd.population import BASE_SEED, generate
@@ -144,6 +148,81 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_tas(args, torch, dist, world, rank, local_rank):
+    """cfg5: one step = FindTopologyAssignmentsForFlavor for --tas-batch pending workloads against the resident leaf
+    table (the nominate-side TAS work of one cycle over every pending workload). Ranks own independent TAS flavors
+    (topology + workloads, seed + rank): leaf usage never crosses flavors, so there is no collective (weak scaling)."""
+    from kueue_amd import tas as T
+    from kueue_amd.tas_population import TAS_SEED, generate_tas
+    topo, rq = generate_tas(n_workloads=args.tas_batch, seed=TAS_SEED + 1000 * rank)
+    eng = T.TASEngine(device=local_rank)
+    eng.put(topo)
+    out = T.Result(rq, dom_cap=int(rq.arrays["count"].sum()) + rq.n)
+    import ctypes as C
+    lib, h = eng._lib, eng._h
+
+    def step():
+        rc = lib.kq_tas_find(h, C.byref(rq.struct()), C.byref(out.struct()))
+        assert rc == 0, rc
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ms = np.zeros(1, np.float64); by = np.zeros(1, np.int64)
+    kms, kby, st_ms = 0.0, 0, []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t1 = time.perf_counter()
+        step()
+        st_ms.append((time.perf_counter() - t1) * 1e3)
+        lib.kq_tas_last_stats(h, F_ptr(ms), F_ptr(by))
+        kms += float(ms[0]); kby += int(by[0])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dec = float(args.steps * rq.n)
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed, dec], dtype=torch.float64, device="cuda")
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, dec = float(tmax[0]), float(tsum[1])
+    if rank == 0:
+        achieved = (kby / args.steps) / (kms / args.steps * 1e-3) / 1e9 if kms > 0 else 0.0
+        res = {
+            "metric": "admission-decisions/sec + p99 schedule-cycle ms @ 100k pending, 1k CQ",
+            "value": dec / elapsed, "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"cfg5: TAS, {topo.n_leaves} leaves (8 blocks x 8 racks x 64 hosts), {len(topo.resources)} resources, "
+                                   f"{rq.n} pending workloads per step per GPU (1..64 pods, required/preferred/unconstrained at block or rack)",
+                       "decision": "one workload's topology assignment (phase 1 counts + roll-up + phase 2 descent)",
+                       "sharding": "TAS flavor per GPU, no collective"},
+            "p50_cycle_ms": float(np.percentile(st_ms, 50)), "p99_cycle_ms": float(np.percentile(st_ms, 99)),
+            "kernel_ms_per_cycle": {"k_tas_find": kms / args.steps},
+            "roofline": {"bound": "hbm", "kernel": "k_tas_find", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "algorithmic_bytes_per_launch": kby / args.steps, "traffic": pmc_traffic("cfg5", "k_tas_find")},
+        }
+        if not args.no_cpu_baseline:
+            from oracle import kqo
+            n_s = min(rq.n, 20000)
+            sub = T.Requests(topo, rq.workloads[:n_s])
+            t1 = time.perf_counter()
+            kqo.tas_find(topo, sub)
+            dt = time.perf_counter() - t1
+            res["cpu_baseline"] = {"value": n_s / dt, "unit": "decisions/s", "cores": 1, "kind": "port",
+                                   "sample": f"first {n_s} workloads of the same batch, C++ restatement of FindTopologyAssignmentsForFlavor, host nproc={os.cpu_count()}"}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def F_ptr(a):
+    from kueue_amd import _ffi as F
+    return F.ptr(a)
 
 
 def pmc_traffic(workload, kernel):

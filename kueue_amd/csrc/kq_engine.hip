@@ -18,6 +18,7 @@
 #include <string>
 
 #include "kq_host.hpp"
+#include "kq_tas_host.hpp"
 
 using namespace kq;
 
@@ -127,6 +128,20 @@ __global__ __launch_bounds__(256) void k_derive_level(DSnap S, DDerive d, int de
   if (S.depth[cohort] == depth) derive_cohort_cell(S, d, cohort, i % S.nfr);
 }
 
+// TAS: one wavefront per workload (FindTopologyAssignmentsForFlavor), grid-stride over the batch
+__global__ __launch_bounds__(64) void k_tas_find(const TK* __restrict__ kp, int slots) {
+  const TK& k = *kp;
+  for (int w = blockIdx.x; w < k.Q.n_wl; w += slots) t_workload(k, blockIdx.x, w);
+}
+__global__ __launch_bounds__(64) void k_tas_usage(TTopo T, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int add) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i < n) t_usage_cell(T, i, leaf, count, spr, add);
+}
+__global__ __launch_bounds__(64) void k_tas_fits(TTopo T, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t* flag) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i < n) t_fits_cell(T, i, leaf, count, spr, flag);
+}
+
 namespace kq {
 struct HipBackend {
   hipStream_t stream = nullptr;
@@ -156,6 +171,7 @@ struct HipBackend {
   void destroy() {
     for (auto& e2 : ev) if (e2) (void)hipEventDestroy(e2);
     for (auto& d : dk) if (d) (void)hipFree(d);
+    if (dtk) (void)hipFree(dtk);
     if (stream) (void)hipStreamDestroy(stream);
   }
   void* alloc(size_t n) { void* p = nullptr; chk(hipMalloc(&p, n), "hipMalloc"); return p; }
@@ -184,10 +200,28 @@ struct HipBackend {
     chk(hipMemcpyAsync(dk[which], &hk[which], sizeof(K), hipMemcpyHostToDevice, stream), "memcpy K");
     return dk[which];
   }
+  TK* dtk = nullptr;
+  TK htk;
+  void launch_tas_find(const TK& k, int slots) {
+    if (!dtk) chk(hipMalloc((void**)&dtk, sizeof(TK)), "hipMalloc TK");
+    htk = k;
+    chk(hipMemcpyAsync(dtk, &htk, sizeof(TK), hipMemcpyHostToDevice, stream), "memcpy TK");
+    hipLaunchKernelGGL(k_tas_find, dim3(slots), dim3(64), 0, stream, (const TK*)dtk, slots);
+    chk(hipGetLastError(), "k_tas_find");
+  }
+  void launch_tas_usage(const TTopo& T, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int add) {
+    hipLaunchKernelGGL(k_tas_usage, dim3((n + 63) / 64), dim3(64), 0, stream, T, n, leaf, count, spr, add);
+    chk(hipGetLastError(), "k_tas_usage");
+  }
+  void launch_tas_fits(const TTopo& T, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t* flag) {
+    hipLaunchKernelGGL(k_tas_fits, dim3((n + 63) / 64), dim3(64), 0, stream, T, n, leaf, count, spr, flag);
+    chk(hipGetLastError(), "k_tas_fits");
+  }
   void launch_derive(const DSnap& S, const DDerive& d, int max_depth) {
-    hipLaunchKernelGGL(k_derive_cq, dim3((S.nq * S.nfr + 255) / 256), dim3(256), 0, stream, S, d);
-    for (int dep = max_depth; dep >= 0; dep--)
-      hipLaunchKernelGGL(k_derive_level, dim3((S.nc * S.nfr + 255) / 256), dim3(256), 0, stream, S, d, dep);
+    if (S.nq * S.nfr > 0) hipLaunchKernelGGL(k_derive_cq, dim3((S.nq * S.nfr + 255) / 256), dim3(256), 0, stream, S, d);
+    if (S.nc * S.nfr > 0)
+      for (int dep = max_depth; dep >= 0; dep--)
+        hipLaunchKernelGGL(k_derive_level, dim3((S.nc * S.nfr + 255) / 256), dim3(256), 0, stream, S, d, dep);
     chk(hipGetLastError(), "k_derive");
   }
   void launch_fs_sums(const K& k) {
@@ -334,6 +368,41 @@ int kq_snapshot_read_planes(kq_engine* en, int64_t* subtree_quota, int64_t* usag
 }
 
 const char* kq_last_error(kq_engine* en) { return en ? en->e.last_error.c_str() : "null engine"; }
+
+// ---- include/kq_tas.h ------------------------------------------------------------------------------
+struct kq_tas { TasT<HipBackend> e; };
+int kq_tas_create(int32_t device, kq_tas** out) {
+  if (!out) return KQ_EINVAL;
+  kq_tas* t = new (std::nothrow) kq_tas();
+  if (!t) return KQ_ENOMEM;
+  int rc = t->e.be.init(device);
+  if (rc != KQ_OK) { fprintf(stderr, "kq_tas_create: %s\n", t->e.be.error()); delete t; return rc; }
+  *out = t;
+  return KQ_OK;
+}
+void kq_tas_destroy(kq_tas* t) {
+  if (!t) return;
+  (void)hipSetDevice(t->e.be.device);
+  t->e.free_topo();
+  t->e.~TasT<HipBackend>();
+  t->e.be.destroy();
+  ::operator delete(t);
+}
+int kq_tas_topology_put(kq_tas* t, const kq_tas_topology* tp) { if (!t || !tp) return KQ_EINVAL; (void)hipSetDevice(t->e.be.device); return t->e.topology_put(tp); }
+int kq_tas_find(kq_tas* t, const kq_tas_requests* r, kq_tas_result* out) { if (!t || !r || !out) return KQ_EINVAL; (void)hipSetDevice(t->e.be.device); return t->e.find(r, out); }
+int kq_tas_usage_apply(kq_tas* t, int32_t n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t add) {
+  if (!t) return KQ_EINVAL;
+  (void)hipSetDevice(t->e.be.device);
+  return t->e.usage_apply(n, leaf, count, spr, add);
+}
+int kq_tas_fits(kq_tas* t, int32_t n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t* fits) {
+  if (!t || !fits) return KQ_EINVAL;
+  (void)hipSetDevice(t->e.be.device);
+  return t->e.fits(n, leaf, count, spr, fits);
+}
+int kq_tas_read_usage(kq_tas* t, int64_t* u) { if (!t || !u) return KQ_EINVAL; (void)hipSetDevice(t->e.be.device); return t->e.read_usage(u); }
+int kq_tas_last_stats(kq_tas* t, double* ms, int64_t* bytes) { if (!t) return KQ_EINVAL; if (ms) *ms = t->e.last_ms; if (bytes) *bytes = t->e.last_bytes; return KQ_OK; }
+const char* kq_tas_last_error(kq_tas* t) { return t ? t->e.last_error.c_str() : "null engine"; }
 
 // profiling hook (KQ_PROF builds): 32 segment cycle counters accumulated since the last reset
 // tests: take the saturation-safe DRS loops even when the incremental sums would be exact

@@ -1,0 +1,704 @@
+// kq_tas_device.hpp — Topology-Aware Scheduling on gfx950: FindTopologyAssignmentsForFlavor
+// (pkg/cache/scheduler/tas_flavor_snapshot.go:578) for a batch of workloads, one wavefront per workload.
+//
+//   phase 1  fillLeafCounts :1899 / CountInWithLimitingResource (pkg/resources/requests.go:195): lanes = leaves, the leaf
+//            capacity / usage rows are read coalesced ([leaf][R] int64); fillInCountsHelper :1930: level by level,
+//            lanes = domains (children of a domain are a contiguous id range because domains are numbered in the
+//            lexicographic order of their levelValues).
+//   phase 2  the reference sorts domain slices and walks them sequentially with early exits. Here a sorted slice is a
+//            LAZY view: packed 128-bit sort keys are built once per slice (lanes = elements), elements are produced
+//            in order on demand by a wave arg-min over "key > last key" (only as many as the greedy loops consume —
+//            domains whose state is all zero can never change a decision and are left out), and the "best fit over
+//            the rest of the slice" scans (findBestFitDomainBy :1307) are wave min-reductions over the same keys.
+//
+// Everything is integer work on int32 counts / int64 capacities; bound by L2/HBM reads of the leaf table.
+// The same code compiles for the 1-lane CPU emulation used by the CPU test-suite (KQ_HOST_EMU).
+#pragma once
+#include "../../include/kq_tas.h"
+#include "kq_device.hpp"
+
+namespace kq {
+
+struct TTopo {
+  int L, R, pods, profile_mixed, D, n_leaves, leaf_base;
+  int level_off[KQ_TAS_MAX_LEVELS + 1];
+  const int32_t* child_first;  // [D] global id of the first child (children are contiguous), -1 for leaves
+  const int32_t* child_cnt;    // [D]
+  const int64_t* free_cap;     // [n_leaves][R]
+  int64_t* tas_usage;          // [n_leaves][R]
+};
+struct TReq {
+  int n_wl;
+  const int32_t* wl_off;
+  const uint8_t* sim_empty;
+  const int64_t* spr;
+  const int32_t *count, *level;
+  const uint8_t* kind;
+  const int32_t *slice_size, *slice_level, *group;
+  const uint8_t* leaf_ok;
+};
+struct TOut {
+  int32_t *status, *op_a, *op_b, *dom_pos, *dom_n;  // per podset request; dom_pos = offset into the pool
+  int32_t *pool_leaf, *pool_count;
+  int32_t pool_cap;
+  int32_t* pool_used;  // [1] atomic
+  int32_t* error;      // [1]
+  long long* bytes;    // [1]
+};
+struct TScratch {  // per wave slot
+  int32_t *pc, *sc, *pcwl, *scwl, *lc;  // [slots][D] domainState :55
+  int32_t *set, *arr, *cur, *nxt;       // [slots][n_leaves] id lists: the slice being sorted, its materialised prefix, currFitDomain x2
+  uint64_t *k0, *k1;                    // [slots][n_leaves] sort keys of `set`
+  int64_t* assumed;                     // [slots][n_leaves][R] assumedUsage of the workload (:586)
+  int32_t max_set;
+};
+struct TK { TTopo T; TReq Q; TOut O; TScratch X; };
+
+struct TState {  // per-slot pointers
+  int32_t *pc, *sc, *pcwl, *scwl, *lc, *set, *arr, *cur, *nxt;
+  uint64_t *k0, *k1;
+  int64_t* assumed;
+};
+KQ_DEV TState tas_state(const TK& k, int slot) {
+  TState s;
+  const size_t D = k.T.D, M = k.X.max_set;
+  s.pc = k.X.pc + slot * D; s.sc = k.X.sc + slot * D; s.pcwl = k.X.pcwl + slot * D; s.scwl = k.X.scwl + slot * D; s.lc = k.X.lc + slot * D;
+  s.set = k.X.set + slot * M; s.arr = k.X.arr + slot * M; s.cur = k.X.cur + slot * M; s.nxt = k.X.nxt + slot * M;
+  s.k0 = k.X.k0 + slot * M; s.k1 = k.X.k1 + slot * M;
+  s.assumed = k.X.assumed + (size_t)slot * k.T.n_leaves * k.T.R;
+  return s;
+}
+
+struct TParams {  // topologyAssignmentParameters :473 + requirements :461
+  int32_t count, leaderCount, sliceSize;
+  int requestedLevelIdx, sliceLevelIdx;
+  bool required, unconstrained, simulateEmpty, hasLeader, hasAssumed;
+  const int64_t* req;        // [R] SinglePodRequests of the workers (pods added on the fly)
+  const int64_t* leaderReq;  // [R] or NULL
+  const uint8_t* leafOk;
+};
+
+KQ_DEV bool t_lfc(const TK& k, bool unconstrained) { return unconstrained && k.T.profile_mixed; }  // useLeastFreeCapacityAlgorithm :1468
+
+// requests.go:195-232 on remaining capacity rem[] (registers of the lane)
+KQ_DEV int32_t t_count_in(const TK& k, const int64_t* req, const int64_t* rem) {
+  bool have = false;
+  int32_t result = 0;
+  for (int r = 0; r < k.T.R; r++) {
+    int64_t q = req[r] + (r == k.T.pods ? 1 : 0);  // resources.OnePodRequest :905
+    if (q == 0) continue;
+    int64_t c = rem[r] / q;
+    int32_t cnt = (int32_t)i64max(0, i64min(c, 0x7fffffff));
+    if (!have || cnt < result) { result = cnt; have = true; }
+  }
+  return have ? result : 0;
+}
+
+constexpr int KQ_TAS_MAXR = 16;
+
+// fillInCounts :1800 = fillLeafCounts for every feasible leaf + fillInCountsHelper roll-up
+KQ_DEV void t_fill_in_counts(const TK& k, const TState& s, const TParams& p) {
+  const TTopo& T = k.T;
+  const int lane = lane_id();
+  for (int d = lane; d < T.leaf_base; d += WAVE) { s.pc[d] = 0; s.sc[d] = 0; s.pcwl[d] = 0; s.scwl[d] = 0; s.lc[d] = 0; }
+  int64_t lb = 0;
+  for (int leaf = lane; leaf < T.n_leaves; leaf += WAVE) {
+    const int d = T.leaf_base + leaf;
+    int32_t pc = 0, pcwl = 0, lc = 0;
+    if (!p.leafOk || p.leafOk[leaf]) {
+      int64_t rem[KQ_TAS_MAXR];
+      for (int r = 0; r < T.R; r++) {
+        int64_t v = T.free_cap[(size_t)leaf * T.R + r];
+        if (!p.simulateEmpty) v -= T.tas_usage[(size_t)leaf * T.R + r];  // remainingCapacityForLeaf :1884
+        if (p.hasAssumed) v -= s.assumed[(size_t)leaf * T.R + r];
+        rem[r] = v;
+      }
+      pc = t_count_in(k, p.req, rem);
+      if (p.leaderReq && t_count_in(k, p.leaderReq, rem) > 0) {
+        lc = 1;
+        for (int r = 0; r < T.R; r++) rem[r] -= p.leaderReq[r] + (r == T.pods ? 1 : 0);
+      }
+      pcwl = t_count_in(k, p.req, rem);
+      lb += (int64_t)T.R * 16 + 24;
+    }
+    s.pc[d] = pc; s.pcwl[d] = pcwl; s.lc[d] = lc;
+    const bool at = T.L - 1 == p.sliceLevelIdx;
+    s.sc[d] = at ? pc / p.sliceSize : 0;
+    s.scwl[d] = at ? pcwl / p.sliceSize : 0;
+  }
+  wsync();
+  const bool leaderRequired = p.leaderCount > 0;
+  for (int level = T.L - 2; level >= 0; level--) {
+    for (int d = T.level_off[level] + lane; d < T.level_off[level + 1]; d += WAVE) {
+      int32_t childrenCapacity = 0, sliceCapacity = 0, minPodDiff = 0x7fffffff, minSliceDiff = 0x7fffffff, leaderCount = 0;
+      bool contributor = false;
+      const int c0 = T.child_first[d], cn = T.child_cnt[d];
+      for (int c = c0; c < c0 + cn; c++) {
+        const int32_t cpc = s.pc[c], cpcwl = s.pcwl[c], csc = s.sc[c], cscwl = s.scwl[c], clc = s.lc[c];
+        childrenCapacity += cpc;
+        sliceCapacity += csc;
+        if (!leaderRequired || clc > 0) {
+          contributor = true;
+          if (cpc - cpcwl < minPodDiff) minPodDiff = cpc - cpcwl;
+          if (csc - cscwl < minSliceDiff) minSliceDiff = csc - cscwl;
+        }
+        if (clc > leaderCount) leaderCount = clc;
+      }
+      int32_t pcwl = 0, scwl = 0;
+      if (contributor) { pcwl = childrenCapacity - minPodDiff; scwl = sliceCapacity - minSliceDiff; }
+      if (level == p.sliceLevelIdx) { sliceCapacity = childrenCapacity / p.sliceSize; scwl = pcwl / p.sliceSize; }
+      s.pc[d] = childrenCapacity; s.pcwl[d] = pcwl; s.lc[d] = leaderCount; s.sc[d] = sliceCapacity; s.scwl[d] = scwl;
+      lb += 24;
+    }
+    wsync();
+  }
+  const int64_t tot = wsum_i64(lb);
+  if (lane == 0) atomic_add_i64(k.O.bytes, (long long)(tot + (int64_t)T.R * 8));
+}
+
+// ---- lazily sorted slice of domains -------------------------------------------------------------------
+// A slice of domains in the order the reference would have sorted it (sortedDomains :1770, sortedDomainsWithLeader
+// :1731) or, for currFitDomain, in the order it was built. The order is a 128-bit key per element, ascending.
+enum { ORD_LIST = 0, ORD_PLAIN = 1, ORD_LEADER = 2 };
+constexpr uint64_t KQ_TAS_EXCLUDED = 1ull << 63;  // bit 63 of k0 is free: the leaderCount field is < 2^31
+struct TView {
+  int n;                 // elements of s.set
+  int order; bool lfc;
+  int mat;               // materialised prefix length (s.arr)
+  uint64_t c0, c1;       // key of the last element taken from the stream
+  bool started;
+  int skip;              // element moved to the front by prioritizeLeaderDomain (it sits in arr already), -1 none
+};
+KQ_DEV int t_dom(uint64_t k1) { return (int)(uint32_t)(k1 & 0xffffffffu); }
+KQ_DEV void t_key_of(const TState& s, int d, int pos, int order, bool lfc, uint64_t* k0, uint64_t* k1) {
+  if (order == ORD_LIST) { *k0 = 0; *k1 = ((uint64_t)(uint32_t)pos << 32) | (uint32_t)d; return; }
+  const bool wl = order == ORD_LEADER;
+  const uint32_t lcv = wl ? (uint32_t)s.lc[d] : 0u;
+  const uint32_t scv = (uint32_t)(wl ? s.scwl[d] : s.sc[d]);
+  const uint32_t pcv = (uint32_t)(wl ? s.pcwl[d] : s.pc[d]);
+  // leaderCount descending, sliceCount descending (BestFit) / ascending (LeastFreeCapacity), podCount ascending, levelValues
+  *k0 = ((uint64_t)(0x7fffffffu - lcv) << 32) | (uint64_t)(lfc ? scv : 0x7fffffffu - scv);
+  *k1 = ((uint64_t)pcv << 32) | (uint32_t)d;
+}
+KQ_DEV bool t_key_lt(uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1) { return a0 < b0 || (a0 == b0 && a1 < b1); }
+KQ_DEV bool t_all_zero(const TState& s, int d) { return (s.pc[d] | s.sc[d] | s.pcwl[d] | s.scwl[d] | s.lc[d]) == 0; }
+
+// s.set[0..n) must hold the slice. In the sorted orders, domains with an all-zero state are dropped: in every loop of
+// phase 2 they neither change a remaining count nor survive into the assignment (buildTopologyAssignmentForLevels :1690
+// drops podCount == 0), and they can never win a best-fit scan.
+KQ_DEV TView t_view(const TK& k, const TState& s, int n, int order, bool unconstrained) {
+  TView v;
+  v.n = n; v.order = order; v.lfc = t_lfc(k, unconstrained); v.mat = 0; v.c0 = 0; v.c1 = 0; v.started = false; v.skip = -1;
+  for (int i = lane_id(); i < n; i += WAVE) {
+    const int d = s.set[i];
+    uint64_t a, b;
+    t_key_of(s, d, i, order, v.lfc, &a, &b);
+    if (order != ORD_LIST && t_all_zero(s, d)) a |= KQ_TAS_EXCLUDED;  // keeps its place in the order, never produced
+    s.k0[i] = a; s.k1[i] = b;
+  }
+  wsync();
+  return v;
+}
+// wave arg-min over the elements accepted by `sel`, ranked by sel.rank (default: the slice order: the winner is
+// t_dom(*o1)); false if no element is accepted
+template <class SEL> KQ_DEV bool t_argmin(const TState& s, const TView& v, const SEL& sel, uint64_t* o0, uint64_t* o1, bool with_excluded = false) {
+  uint64_t b0 = ~0ull, b1 = ~0ull;
+  for (int i = lane_id(); i < v.n; i += WAVE) {
+    uint64_t a0 = s.k0[i];
+    const uint64_t a1 = s.k1[i];
+    if (a0 & KQ_TAS_EXCLUDED) { if (!with_excluded) continue; a0 &= ~KQ_TAS_EXCLUDED; }
+    if (!sel.take(a0, a1)) continue;
+    uint64_t x0 = a0, x1 = a1;
+    sel.rank(&x0, &x1);
+    if (t_key_lt(x0, x1, b0, b1)) { b0 = x0; b1 = x1; }
+  }
+  const uint64_t m0 = wmin_u64(b0);
+  const uint64_t m1 = wmin_u64(b0 == m0 ? b1 : ~0ull);
+  if (m0 == ~0ull && m1 == ~0ull) return false;
+  *o0 = m0; *o1 = m1;
+  return true;
+}
+// elements of the slice that have not been produced yet
+struct SelRest {
+  bool started; uint64_t c0, c1; int skip;
+  KQ_MDEV bool rest(uint64_t a0, uint64_t a1) const { return t_dom(a1) != skip && (!started || t_key_lt(c0, c1, a0, a1)); }
+  KQ_MDEV bool take(uint64_t a0, uint64_t a1) const { return rest(a0, a1); }
+  KQ_MDEV void rank(uint64_t*, uint64_t*) const {}
+};
+// domains[i]: materialise the slice up to index i; -1 past the end
+KQ_DEV int t_get(const TState& s, TView& v, int i) {
+  while (v.mat <= i) {
+    SelRest sel{v.started, v.c0, v.c1, v.skip};
+    uint64_t o0 = 0, o1 = 0;
+    if (!t_argmin(s, v, sel, &o0, &o1)) return -1;
+    const int d = t_dom(o1);
+    v.started = true; v.c0 = o0; v.c1 = o1;
+    if (lane_id() == 0) s.arr[v.mat] = d;
+    v.mat++;
+    wsync();
+  }
+  return s.arr[i];
+}
+KQ_DEV int32_t t_count_of(const TState& s, int d, int which) {  // 0 podCount, 1 podCountWithLeader, 2 sliceCount, 3 sliceCountWithLeader
+  return which == 0 ? s.pc[d] : which == 1 ? s.pcwl[d] : which == 2 ? s.sc[d] : s.scwl[d];
+}
+// findBestFitDomainBy :1307 over domains[from:] : the first (slice order) domain with the smallest count >= needed
+struct SelFitCount {  // rank = the count itself
+  const TState* s; SelRest r; int32_t needed, leaderCount, below; int which;
+  KQ_MDEV bool take(uint64_t a0, uint64_t a1) const {
+    if (!r.rest(a0, a1)) return false;
+    const int d = t_dom(a1);
+    if (s->lc[d] < leaderCount) return false;
+    const int32_t c = t_count_of(*s, d, which);
+    return c >= needed && c < below;
+  }
+  KQ_MDEV void rank(uint64_t* x0, uint64_t* x1) const { *x0 = (uint64_t)(uint32_t)t_count_of(*s, t_dom(*x1), which); *x1 &= 0xffffffffull; }
+};
+struct SelFitEq {  // the first element, in slice order, having exactly `want`
+  const TState* s; SelRest r; int32_t want, leaderCount; int which;
+  KQ_MDEV bool take(uint64_t a0, uint64_t a1) const {
+    if (!r.rest(a0, a1)) return false;
+    const int d = t_dom(a1);
+    return s->lc[d] >= leaderCount && t_count_of(*s, d, which) == want;
+  }
+  KQ_MDEV void rank(uint64_t*, uint64_t*) const {}
+};
+KQ_DEV int t_best_fit(const TState& s, TView& v, int from, int32_t needed, int which, int32_t leaderCount) {
+  const int first = t_get(s, v, from);
+  if (first < 0) return -1;
+  // the materialised part arr[from..mat) is short: walk it in order, then reduce over what the stream still holds
+  int best = -1; int32_t bestCount = 0x7fffffff;
+  for (int i = from; i < v.mat; i++) {
+    const int d = s.arr[i];
+    if (s.lc[d] < leaderCount) continue;
+    const int32_t c = t_count_of(s, d, which);
+    if (c >= needed && c < bestCount) { best = d; bestCount = c; }
+  }
+  const SelRest rest{v.started, v.c0, v.c1, v.skip};
+  SelFitCount sc{&s, rest, needed, leaderCount, bestCount, which};
+  uint64_t m0 = 0, m1 = 0;
+  if (t_argmin(s, v, sc, &m0, &m1)) {
+    SelFitEq se{&s, rest, (int32_t)m0, leaderCount, which};
+    uint64_t e0 = 0, e1 = 0;
+    if (t_argmin(s, v, se, &e0, &e1)) best = t_dom(e1);  // strictly smaller count than anything in the materialised part
+  }
+  return best >= 0 ? best : first;
+}
+KQ_DEV int t_best_fit_pods(const TState& s, TView& v, int from, int32_t count, int32_t leaderCount) {  // findBestFitDomain :1276
+  return t_best_fit(s, v, from, count, leaderCount > 0 ? 1 : 0, leaderCount);
+}
+KQ_DEV int t_best_fit_slices(const TState& s, TView& v, int from, int32_t sliceCount, int32_t leaderCount) {  // :1293
+  return t_best_fit(s, v, from, sliceCount, leaderCount > 0 ? 3 : 2, leaderCount);
+}
+
+// prioritizeLeaderDomain :1533 — the first leader-capable domain whose leader penalty fits in the slack moves to the front
+struct SelLeaderElig {
+  const TState* s; int32_t leaderCount, availableCapacity, requiredCapacity; bool slices;
+  KQ_MDEV bool take(uint64_t, uint64_t a1) const {
+    const int d = t_dom(a1);
+    if (s->lc[d] < leaderCount) return false;
+    const int32_t pen = slices ? s->sc[d] - s->scwl[d] : s->pc[d] - s->pcwl[d];
+    return availableCapacity - pen >= requiredCapacity;
+  }
+  KQ_MDEV void rank(uint64_t*, uint64_t*) const {}
+};
+KQ_DEV void t_prioritize_leader(const TK& k, const TState& s, TView& v, int32_t count, int32_t leaderCount, int32_t sliceSize, bool slicesEnabled) {
+  (void)k;
+  if (leaderCount == 0) return;
+  int64_t avail = 0;  // all-zero domains add nothing; "len(domains) < 2" cannot reorder anything either way
+  for (int i = lane_id(); i < v.n; i += WAVE) {
+    if (s.k0[i] & KQ_TAS_EXCLUDED) continue;
+    const int d = s.set[i];
+    avail += slicesEnabled ? s.sc[d] : s.pc[d];
+  }
+  const int32_t availableCapacity = (int32_t)wsum_i64(avail);
+  const int32_t requiredCapacity = slicesEnabled ? count / sliceSize : count;
+  SelLeaderElig se{&s, leaderCount, availableCapacity, requiredCapacity, slicesEnabled};
+  uint64_t f0 = 0, f1 = 0;
+  if (!t_argmin(s, v, se, &f0, &f1)) return;
+  const int f = t_dom(f1);
+  const int head = t_get(s, v, 0);
+  if (head == f) return;
+  const bool inside = v.started && !t_key_lt(v.c0, v.c1, f0, f1);  // f already sits in the materialised prefix
+  wsync();
+  if (lane_id() == 0) {
+    int pos = v.mat;
+    if (inside) { pos = 0; while (s.arr[pos] != f) pos++; }
+    for (int i = pos; i >= 1; i--) s.arr[i] = s.arr[i - 1];
+    s.arr[0] = f;
+  }
+  if (!inside) { v.mat++; v.skip = f; }
+  wsync();
+}
+
+// consumeWithLeadersGeneric :1486 ; *domain = domains[i]; returns completed
+KQ_DEV bool t_consume_with_leaders(const TK& k, const TState& s, TView& v, int i, int* domain, int32_t* remainingPrimary, int32_t* remainingLeaderCount,
+                                   bool unconstrained, int32_t sliceSize, bool slices) {
+  int d = *domain;
+  int32_t* withLeader = slices ? s.scwl : s.pcwl;
+  int32_t* primary = slices ? s.sc : s.pc;
+  if (!t_lfc(k, unconstrained) && withLeader[d] >= *remainingPrimary && s.lc[d] >= *remainingLeaderCount)
+    d = slices ? t_best_fit_slices(s, v, i, *remainingPrimary, *remainingLeaderCount) : t_best_fit_pods(s, v, i, *remainingPrimary, *remainingLeaderCount);
+  *domain = d;
+  bool completed;
+  if (withLeader[d] >= *remainingPrimary && s.lc[d] >= *remainingLeaderCount) {
+    wsync();
+    if (lane_id() == 0) { primary[d] = *remainingPrimary; s.lc[d] = *remainingLeaderCount; s.pc[d] = *remainingPrimary * sliceSize; }
+    completed = true;
+  } else {
+    int32_t wl = withLeader[d], lcv = s.lc[d];
+    if (wl > *remainingPrimary) wl = *remainingPrimary;
+    if (lcv > *remainingLeaderCount) lcv = *remainingLeaderCount;
+    wsync();
+    if (lane_id() == 0) { withLeader[d] = wl; s.lc[d] = lcv; primary[d] = wl; s.pc[d] = wl * sliceSize; }
+    *remainingLeaderCount -= lcv;
+    *remainingPrimary -= wl;
+    completed = false;
+  }
+  wsync();
+  return completed;
+}
+
+// updateCountsToMinimumGeneric :1575 over the slice s.set[0..n) in `order`; result domains appended to out[out_n..)
+// returns the new length of out, -1 on the reference's "unexpected remainingCount" path
+KQ_DEV int t_update_counts(const TK& k, const TState& s, int n, int order, int32_t count, int32_t leaderCount, int32_t sliceSize,
+                           bool unconstrained, bool slices, int32_t* out, int out_n) {
+  TView v = t_view(k, s, n, order, unconstrained);
+  t_prioritize_leader(k, s, v, count, leaderCount, sliceSize, slices);
+  int32_t remainingPrimary = slices ? count / sliceSize : count;
+  int32_t remainingLeaderCount = leaderCount;
+  const bool bestfit = !t_lfc(k, unconstrained);
+  for (int i = 0;; i++) {
+    int dom = t_get(s, v, i);
+    if (dom < 0) break;
+    if (remainingLeaderCount > 0) {
+      const bool completed = t_consume_with_leaders(k, s, v, i, &dom, &remainingPrimary, &remainingLeaderCount, unconstrained, slices ? sliceSize : 1, slices);
+      if (lane_id() == 0) out[out_n] = dom;
+      out_n++;
+      wsync();
+      if (completed) return out_n;
+      continue;
+    }
+    if (slices) {
+      if (bestfit && s.sc[dom] >= remainingPrimary) dom = t_best_fit_slices(s, v, i, remainingPrimary, 0);
+      const int32_t scv = s.sc[dom];
+      wsync();
+      if (scv >= remainingPrimary) {
+        if (lane_id() == 0) { s.lc[dom] = 0; s.pc[dom] = remainingPrimary * sliceSize; s.sc[dom] = remainingPrimary; out[out_n] = dom; }
+        out_n++;
+        wsync();
+        return out_n;
+      }
+      if (lane_id() == 0) { s.lc[dom] = 0; s.pc[dom] = scv * sliceSize; out[out_n] = dom; }
+      remainingPrimary -= scv;
+      out_n++;
+      wsync();
+      continue;
+    }
+    if (bestfit && s.pc[dom] >= remainingPrimary) dom = t_best_fit_pods(s, v, i, remainingPrimary, 0);
+    const int32_t pcv = s.pc[dom];
+    wsync();
+    if (pcv >= remainingPrimary) {
+      if (lane_id() == 0) { s.lc[dom] = 0; s.pc[dom] = remainingPrimary; out[out_n] = dom; }
+      out_n++;
+      wsync();
+      return out_n;
+    }
+    if (lane_id() == 0) { s.lc[dom] = 0; out[out_n] = dom; }
+    remainingPrimary -= pcv;
+    out_n++;
+    wsync();
+  }
+  // only all-zero domains are left: the reference walks them without effect, then either it had nothing left to place
+  // or it reports "unexpected remainingCount" and returns nil
+  return (remainingPrimary <= 0 && remainingLeaderCount <= 0) ? out_n : -1;
+}
+
+struct TFail { int status; int32_t a, b; };
+struct SelHolds {  // LeastFreeCapacity: the first domain (ascending order) that holds everything (:1364-1376)
+  const TState* s; int32_t sliceCount, leaderCount;
+  KQ_MDEV bool take(uint64_t, uint64_t a1) const {
+    const int d = t_dom(a1);
+    if (leaderCount > 0) return s->lc[d] >= leaderCount && s->scwl[d] >= sliceCount;
+    return s->sc[d] >= sliceCount;
+  }
+  KQ_MDEV void rank(uint64_t*, uint64_t*) const {}
+};
+struct SelLast {  // the last element of the slice: arg-max by complementing the key (the caller un-complements the id)
+  KQ_MDEV bool take(uint64_t, uint64_t) const { return true; }
+  KQ_MDEV void rank(uint64_t* x0, uint64_t* x1) const { *x0 = ~*x0 - 1; *x1 = ~*x1; }
+};
+struct SelAll {
+  KQ_MDEV bool take(uint64_t, uint64_t) const { return true; }
+  KQ_MDEV void rank(uint64_t*, uint64_t*) const {}
+};
+// sortedDomain[0] / sortedDomain[len-1] of the reference's slice, all-zero domains included (they only matter for
+// the numbers a failure message quotes)
+KQ_DEV int t_true_first(const TState& s, const TView& v) {
+  uint64_t a = 0, b = 0;
+  return t_argmin(s, v, SelAll{}, &a, &b, true) ? t_dom(b) : -1;
+}
+KQ_DEV int t_true_last(const TState& s, const TView& v) {
+  uint64_t a = 0, b = 0;
+  return t_argmin(s, v, SelLast{}, &a, &b, true) ? t_dom(~b) : -1;
+}
+
+// findLevelWithFitDomains :1336 ; on success the fitting domains are in s.cur[0..*nfit)
+KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* fitLevel, int* nfit) {
+  const TTopo& T = k.T;
+  const int32_t sliceCount = st.count / st.sliceSize;
+  const bool lfc = t_lfc(k, st.unconstrained);
+  for (int searchLevelIdx = st.requestedLevelIdx;; searchLevelIdx--) {
+    const int n = T.level_off[searchLevelIdx + 1] - T.level_off[searchLevelIdx];
+    if (n == 0) return TFail{KQ_TAS_NO_LEVEL, 0, 0};
+    for (int i = lane_id(); i < n; i += WAVE) s.set[i] = T.level_off[searchLevelIdx] + i;
+    wsync();
+    TView v = t_view(k, s, n, ORD_LEADER, st.unconstrained);
+    int topDomain = t_get(s, v, 0);
+    if (topDomain < 0) {
+      // every domain of the level has an all-zero state: whatever sortedDomain[0] is, it holds nothing
+      if (sliceCount == 0 && st.leaderCount == 0) {
+        if (lane_id() == 0) s.cur[0] = T.level_off[searchLevelIdx];
+        *fitLevel = searchLevelIdx; *nfit = 1;
+        wsync();
+        return TFail{KQ_TAS_OK, 0, 0};
+      }
+      if (st.required || searchLevelIdx == 0 || st.unconstrained) return TFail{KQ_TAS_NOT_FIT, 0, sliceCount};
+      continue;
+    }
+    if (!lfc && s.scwl[topDomain] >= sliceCount && s.lc[topDomain] >= st.leaderCount) topDomain = t_best_fit_slices(s, v, 0, sliceCount, st.leaderCount);
+    if (lfc) {
+      SelHolds sh{&s, sliceCount, st.leaderCount};
+      uint64_t e0 = 0, e1 = 0;
+      if (t_argmin(s, v, sh, &e0, &e1)) {
+        if (lane_id() == 0) s.cur[0] = t_dom(e1);
+        *fitLevel = searchLevelIdx; *nfit = 1;
+        wsync();
+        return TFail{KQ_TAS_OK, 0, 0};
+      }
+      if (st.required) {
+        const int last = t_true_last(s, v);
+        return TFail{KQ_TAS_NOT_FIT, last >= 0 ? s.pc[last] : 0, sliceCount};
+      }
+    }
+    if (s.scwl[topDomain] < sliceCount || s.lc[topDomain] < st.leaderCount) {
+      if (st.required) return TFail{KQ_TAS_NOT_FIT, s.sc[t_true_first(s, v)], sliceCount};
+      if (searchLevelIdx > 0 && !st.unconstrained) continue;
+      int nres = 0;
+      int32_t remainingSliceCount = sliceCount, remainingLeaderCount = st.leaderCount;
+      t_prioritize_leader(k, s, v, st.count, st.leaderCount, st.sliceSize, true);
+      int idx = 0;
+      for (; remainingLeaderCount > 0; idx++) {
+        int domain = t_get(s, v, idx);
+        if (domain < 0 || s.lc[domain] <= 0) break;
+        if (!lfc && s.scwl[domain] >= remainingSliceCount) domain = t_best_fit_slices(s, v, idx, remainingSliceCount, remainingLeaderCount);
+        if (lane_id() == 0) s.cur[nres] = domain;
+        nres++;
+        remainingLeaderCount -= s.lc[domain];
+        remainingSliceCount -= s.scwl[domain];
+      }
+      if (remainingLeaderCount > 0) return TFail{KQ_TAS_NOT_FIT, st.leaderCount - remainingLeaderCount, sliceCount};
+      wsync();
+      if (remainingSliceCount > 0) {
+        // sortedDomains(sortedDomain[idx:]): the rest of the slice re-sorted by worker capacity
+        int m = n;
+        if (idx > 0) {
+          m = 0;
+          for (int base = 0; base < n; base += WAVE) {
+            const int i = base + lane_id();
+            bool keep = false; int d = 0;
+            if (i < n) {
+              d = T.level_off[searchLevelIdx] + i;
+              keep = true;
+              for (int q = 0; q < idx; q++) if (s.arr[q] == d) keep = false;
+            }
+            const uint64_t mk = wballot(keep);
+            const int my = m + popc64(mk & ((lane_id() == 0) ? 0ull : (~0ull >> (64 - lane_id()))));
+            if (keep) s.nxt[my] = d;
+            m += popc64(mk);
+          }
+          wsync();
+          for (int i = lane_id(); i < m; i += WAVE) s.set[i] = s.nxt[i];
+          wsync();
+        }
+        TView r = t_view(k, s, m, ORD_PLAIN, st.unconstrained);
+        for (int i = 0; remainingSliceCount > 0; i++) {
+          int domain = t_get(s, r, i);
+          if (domain < 0) break;
+          if (!lfc && s.sc[domain] >= remainingSliceCount) domain = t_best_fit_slices(s, r, i, remainingSliceCount, 0);
+          if (lane_id() == 0) s.cur[nres] = domain;
+          nres++;
+          remainingSliceCount -= s.sc[domain];
+        }
+        if (remainingSliceCount > 0) return TFail{KQ_TAS_NOT_FIT, sliceCount - remainingSliceCount, sliceCount};
+      }
+      *fitLevel = searchLevelIdx; *nfit = nres;
+      wsync();
+      return TFail{KQ_TAS_OK, 0, 0};
+    }
+    if (lane_id() == 0) s.cur[0] = topDomain;
+    *fitLevel = searchLevelIdx; *nfit = 1;
+    wsync();
+    return TFail{KQ_TAS_OK, 0, 0};
+  }
+}
+
+// findTopologyAssignment :886. On success the leaves of the assignment are in s.cur[0..*nfit) with their pod / leader
+// counts in s.pc / s.lc.
+KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, int* nfit) {
+  const TTopo& T = k.T;
+  t_fill_in_counts(k, s, st);
+  int fitLevelIdx = 0, ncur = 0;
+  TFail f = t_find_level(k, s, st, &fitLevelIdx, &ncur);
+  if (f.status != KQ_TAS_OK) return f;
+  // phase 2b :1041 — currFitDomain in the order findLevelWithFitDomains built it
+  for (int i = lane_id(); i < ncur; i += WAVE) s.set[i] = s.cur[i];
+  wsync();
+  int nout = t_update_counts(k, s, ncur, ORD_LIST, st.count, st.leaderCount, st.sliceSize, st.unconstrained, true, s.nxt, 0);
+  if (nout < 0) { *nfit = 0; return TFail{KQ_TAS_OK, 0, 0}; }
+  for (int i = lane_id(); i < nout; i += WAVE) s.cur[i] = s.nxt[i];
+  wsync();
+  ncur = nout;
+  int level = fitLevelIdx;
+  const int stop = (T.L - 1) < st.sliceLevelIdx ? (T.L - 1) : st.sliceLevelIdx;
+  for (; level < stop; level++) {
+    // sortedDomains(lowerLevelDomains(currFitDomain))
+    int m = 0;
+    for (int j = 0; j < ncur; j++) {
+      const int d = s.cur[j], c0 = T.child_first[d], cn = T.child_cnt[d];
+      for (int i = lane_id(); i < cn; i += WAVE) s.set[m + i] = c0 + i;
+      m += cn;
+    }
+    wsync();
+    nout = t_update_counts(k, s, m, ORD_PLAIN, st.count, st.leaderCount, st.sliceSize, st.unconstrained, true, s.nxt, 0);
+    if (nout < 0) { *nfit = 0; return TFail{KQ_TAS_OK, 0, 0}; }
+    for (int i = lane_id(); i < nout; i += WAVE) s.cur[i] = s.nxt[i];
+    wsync();
+    ncur = nout;
+  }
+  for (; level < T.L - 1; level++) {
+    const int32_t sliceSizeOnLevel = level >= st.sliceLevelIdx ? 1 : st.sliceSize;
+    nout = 0;
+    for (int j = 0; j < ncur; j++) {
+      const int d = s.cur[j], c0 = T.child_first[d], cn = T.child_cnt[d];
+      for (int i = lane_id(); i < cn; i += WAVE) {
+        s.set[i] = c0 + i;
+        if (sliceSizeOnLevel > 1) { s.sc[c0 + i] = s.pc[c0 + i] / sliceSizeOnLevel; s.scwl[c0 + i] = s.pcwl[c0 + i] / sliceSizeOnLevel; }
+      }
+      wsync();
+      const int32_t dpc = s.pc[d], dlc = s.lc[d];
+      nout = t_update_counts(k, s, cn, ORD_PLAIN, dpc, dlc, sliceSizeOnLevel, st.unconstrained, sliceSizeOnLevel > 1, s.nxt, nout);
+      if (nout < 0) { *nfit = 0; return TFail{KQ_TAS_OK, 0, 0}; }
+    }
+    for (int i = lane_id(); i < nout; i += WAVE) s.cur[i] = s.nxt[i];
+    wsync();
+    ncur = nout;
+  }
+  *nfit = ncur;
+  return TFail{KQ_TAS_OK, 0, 0};
+}
+
+// buildAssignment :1701 for `which` (0 workers: podCount, 1 leader: leaderCount) into the pool, leaves ascending
+KQ_DEV void t_emit(const TK& k, const TState& s, int ncur, int which, int ps) {
+  const TTopo& T = k.T; const TOut& O = k.O;
+  const int lane = lane_id();
+  // how many entries, and each entry's rank among them (the lists are short: pods of one podset)
+  int total = 0;
+  for (int base = 0; base < ncur; base += WAVE) {
+    const int i = base + lane;
+    const bool in = i < ncur && (which == 0 ? s.pc[s.cur[i]] : s.lc[s.cur[i]]) > 0;
+    total += popc64(wballot(in));
+  }
+  int pos = 0;
+  if (lane == 0) {
+    pos = total > 0 ? atomic_add_i32(O.pool_used, total) : 0;
+    if (pos + total > O.pool_cap) { if (*O.error == 0) *O.error = KQ_ECAPACITY; O.dom_pos[ps] = 0; O.dom_n[ps] = 0; }
+    else { O.dom_pos[ps] = pos; O.dom_n[ps] = total; }
+    s.arr[0] = pos;  // broadcast through memory
+  }
+  wsync();
+  pos = s.arr[0];
+  wsync();
+  if (pos + total > O.pool_cap) return;
+  for (int i = lane; i < ncur; i += WAVE) {
+    const int d = s.cur[i];
+    const int32_t c = which == 0 ? s.pc[d] : s.lc[d];
+    if (c <= 0) continue;
+    int rank = 0;
+    for (int j = 0; j < ncur; j++) {
+      const int e = s.cur[j];
+      if ((which == 0 ? s.pc[e] : s.lc[e]) > 0 && e < d) rank++;
+    }
+    O.pool_leaf[pos + rank] = d - T.leaf_base;
+    O.pool_count[pos + rank] = c;
+  }
+  wsync();
+}
+
+// FindTopologyAssignmentsForFlavor :578 for workload w
+KQ_DEV void t_workload(const TK& k, int slot, int w) {
+  const TTopo& T = k.T; const TReq& Q = k.Q; const TOut& O = k.O;
+  const TState s = tas_state(k, slot);
+  const int lane = lane_id();
+  const int p0 = Q.wl_off[w], p1 = Q.wl_off[w + 1];
+  // more than one group => later groups see the usage assumed for the earlier ones (:654-656)
+  int ngroups = 0;
+  for (int p = p0; p < p1; p++) {
+    bool firstOfGroup = true;
+    if (Q.group[p] >= 0) for (int q = p0; q < p; q++) if (Q.group[q] == Q.group[p]) firstOfGroup = false;
+    if (firstOfGroup) ngroups++;
+  }
+  const bool track = ngroups > 1;
+  if (track) { for (int i = lane; i < T.n_leaves * T.R; i += WAVE) s.assumed[i] = 0; wsync(); }
+  bool failed = false, hasAssumed = false;
+  for (int p = p0; p < p1; p++) {
+    bool firstOfGroup = true;
+    if (Q.group[p] >= 0) for (int q = p0; q < p; q++) if (Q.group[q] == Q.group[p]) firstOfGroup = false;
+    if (!firstOfGroup) continue;
+    int second = -1, members = 1;
+    if (Q.group[p] >= 0) for (int q = p + 1; q < p1; q++) if (Q.group[q] == Q.group[p]) { if (second < 0) second = q; members++; }
+    auto set_all = [&](int st, int a, int b) {
+      if (lane == 0) {
+        O.status[p] = st; O.op_a[p] = a; O.op_b[p] = b; O.dom_pos[p] = 0; O.dom_n[p] = 0;
+        if (Q.group[p] >= 0) for (int q = p + 1; q < p1; q++) if (Q.group[q] == Q.group[p]) { O.status[q] = st; O.op_a[q] = a; O.op_b[q] = b; O.dom_pos[q] = 0; O.dom_n[q] = 0; }
+      }
+    };
+    if (failed) { set_all(KQ_TAS_SKIPPED, 0, 0); continue; }
+    if (members > 2) { set_all(KQ_TAS_UNSUPPORTED, 0, 0); failed = true; continue; }
+    // findLeaderAndWorkers :668
+    int workers = p, leader = -1;
+    if (second >= 0) { leader = second; if (Q.count[leader] > Q.count[workers]) { leader = p; workers = second; } }
+    TParams st;
+    st.count = Q.count[workers]; st.leaderCount = leader >= 0 ? 1 : 0; st.sliceSize = Q.slice_size[workers];
+    st.requestedLevelIdx = Q.level[workers]; st.sliceLevelIdx = Q.slice_level[workers];
+    st.required = Q.kind[workers] == KQ_TAS_REQUIRED; st.unconstrained = Q.kind[workers] == KQ_TAS_UNCONSTRAINED;
+    st.simulateEmpty = Q.sim_empty && Q.sim_empty[w]; st.hasLeader = leader >= 0; st.hasAssumed = hasAssumed;
+    st.req = Q.spr + (size_t)workers * T.R; st.leaderReq = leader >= 0 ? Q.spr + (size_t)leader * T.R : nullptr;
+    st.leafOk = Q.leaf_ok ? Q.leaf_ok + (size_t)workers * T.n_leaves : nullptr;
+    TFail f{KQ_TAS_OK, 0, 0};
+    int ncur = 0;
+    if (st.sliceSize <= 0) f = TFail{KQ_TAS_BAD_SLICE_SIZE, 0, 0};
+    else if (st.requestedLevelIdx < 0 || st.requestedLevelIdx >= T.L || st.sliceLevelIdx < 0 || st.sliceLevelIdx >= T.L) f = TFail{KQ_TAS_NO_LEVEL, 0, 0};
+    else if (st.requestedLevelIdx > st.sliceLevelIdx) f = TFail{KQ_TAS_SLICE_ABOVE, 0, 0};
+    else f = t_find_assignment(k, s, st, &ncur);
+    if (f.status != KQ_TAS_OK) { set_all(f.status, f.a, f.b); failed = true; continue; }
+    if (lane == 0) { O.status[workers] = KQ_TAS_OK; O.op_a[workers] = 0; O.op_b[workers] = 0; if (leader >= 0) { O.status[leader] = KQ_TAS_OK; O.op_a[leader] = 0; O.op_b[leader] = 0; } }
+    // addAssumedUsage :734 before the leader's copies of the counts are consumed
+    if (track) {
+      for (int i = lane; i < ncur; i += WAVE) {
+        const int d = s.cur[i], leaf = d - T.leaf_base;
+        for (int r = 0; r < T.R; r++) {
+          int64_t add = Q.spr[(size_t)workers * T.R + r] * (int64_t)s.pc[d] + (r == T.pods ? s.pc[d] : 0);
+          if (leader >= 0) add += Q.spr[(size_t)leader * T.R + r] * (int64_t)s.lc[d] + (r == T.pods ? s.lc[d] : 0);
+          s.assumed[(size_t)leaf * T.R + r] += add;
+        }
+      }
+      hasAssumed = true;
+      wsync();
+    }
+    if (leader >= 0) t_emit(k, s, ncur, 1, leader);
+    t_emit(k, s, ncur, 0, workers);
+  }
+}
+
+}  // namespace kq

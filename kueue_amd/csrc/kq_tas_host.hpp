@@ -1,0 +1,204 @@
+// kq_tas_host.hpp — host orchestration of the TAS path behind include/kq_tas.h (backend-templated like kq_host.hpp:
+// HipBackend in kq_engine.hip, the 1-lane emulation in tests/emu).
+#pragma once
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kq_tas_device.hpp"
+
+namespace kq {
+
+template <class Backend> struct TasT {
+  Backend be;
+  std::string last_error;
+  bool have_topo = false;
+  TTopo T{};
+  std::vector<void*> topo_allocs;
+  struct Buf { void* p = nullptr; size_t cap = 0; };
+  Buf bq[12], bo[8], bx[13];
+  double last_ms = 0;
+  int64_t last_bytes = 0;
+
+  int fail(int code, const std::string& m) { last_error = m; return code; }
+  template <class U> U* grow(Buf& b, size_t n) {
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(U);
+    if (b.cap < bytes) { if (b.p) be.free(b.p); b.cap = bytes + bytes / 4 + 256; b.p = be.alloc(b.cap); }
+    return (U*)b.p;
+  }
+  template <class U> U* upload(std::vector<void*>& owner, const U* host, size_t n) {
+    U* d = (U*)be.alloc(std::max<size_t>(n, 1) * sizeof(U));
+    owner.push_back(d);
+    if (n) be.h2d(d, host, n * sizeof(U));
+    return d;
+  }
+  template <class U> U* stage(Buf& b, const U* host, size_t n) {
+    U* d = grow<U>(b, n);
+    if (n) be.h2d(d, host, n * sizeof(U));
+    return d;
+  }
+  void free_topo() {
+    for (void* p : topo_allocs) be.free(p);
+    topo_allocs.clear();
+    have_topo = false;
+  }
+  ~TasT() {
+    free_topo();
+    for (auto& b : bq) if (b.p) be.free(b.p);
+    for (auto& b : bo) if (b.p) be.free(b.p);
+    for (auto& b : bx) if (b.p) be.free(b.p);
+  }
+
+  int topology_put(const kq_tas_topology* t) {
+    free_topo();
+    if (t->n_levels < 1 || t->n_levels > KQ_TAS_MAX_LEVELS) return fail(KQ_EUNSUPPORTED, "n_levels out of range");
+    if (t->n_resources < 1 || t->n_resources > KQ_TAS_MAXR) return fail(KQ_EUNSUPPORTED, "n_resources out of range");
+    T = TTopo{};
+    T.L = t->n_levels; T.R = t->n_resources; T.pods = t->pods_resource; T.profile_mixed = t->profile_mixed;
+    for (int l = 0; l <= T.L; l++) T.level_off[l] = t->level_off[l];
+    T.D = T.level_off[T.L]; T.leaf_base = T.level_off[T.L - 1]; T.n_leaves = T.D - T.leaf_base;
+    for (int l = 0; l < T.L; l++) if (T.level_off[l + 1] < T.level_off[l]) return fail(KQ_EINVAL, "level_off not monotone");
+    // children of a domain are contiguous because domains are numbered in lexicographic levelValues order
+    std::vector<int32_t> first(T.D, -1), cnt(T.D, 0);
+    for (int l = 1; l < T.L; l++) {
+      int prev = -1;
+      for (int d = T.level_off[l]; d < T.level_off[l + 1]; d++) {
+        const int par = t->parent[d];
+        if (par < 0 || par >= T.level_off[l] - T.level_off[l - 1]) return fail(KQ_EINVAL, "parent out of range");
+        if (par < prev) return fail(KQ_EINVAL, "domains of a level must be ordered by their parents (lexicographic levelValues)");
+        prev = par;
+        const int g = T.level_off[l - 1] + par;
+        if (first[g] < 0) first[g] = d;
+        cnt[g]++;
+      }
+    }
+    T.child_first = upload(topo_allocs, first.data(), first.size());
+    T.child_cnt = upload(topo_allocs, cnt.data(), cnt.size());
+    T.free_cap = upload(topo_allocs, t->free_capacity, (size_t)T.n_leaves * T.R);
+    T.tas_usage = upload(topo_allocs, t->tas_usage, (size_t)T.n_leaves * T.R);
+    int rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    have_topo = true;
+    return KQ_OK;
+  }
+
+  int find(const kq_tas_requests* r, kq_tas_result* out) {
+    if (!have_topo) return fail(KQ_EINVAL, "kq_tas_find before kq_tas_topology_put");
+    const int nw = r->n_workloads;
+    if (nw < 0) return fail(KQ_EINVAL, "negative workload count");
+    const int n = nw > 0 ? r->wl_off[nw] : 0;
+    out->dom_off[0] = 0;
+    last_ms = 0; last_bytes = 0;
+    if (n == 0) return KQ_OK;
+    for (int i = 0; i < n; i++) if (r->count[i] < 0) return fail(KQ_EINVAL, "negative pod count");
+    TK k{};
+    k.T = T;
+    TReq& Q = k.Q;
+    Q.n_wl = nw;
+    Q.wl_off = stage(bq[0], r->wl_off, (size_t)nw + 1);
+    Q.sim_empty = r->simulate_empty ? stage(bq[1], r->simulate_empty, nw) : nullptr;
+    Q.spr = stage(bq[2], r->single_pod_requests, (size_t)n * T.R);
+    Q.count = stage(bq[3], r->count, n); Q.level = stage(bq[4], r->level, n); Q.kind = stage(bq[5], r->kind, n);
+    Q.slice_size = stage(bq[6], r->slice_size, n); Q.slice_level = stage(bq[7], r->slice_level, n); Q.group = stage(bq[8], r->group, n);
+    Q.leaf_ok = r->leaf_ok ? stage(bq[9], r->leaf_ok, (size_t)n * T.n_leaves) : nullptr;
+    TOut& O = k.O;
+    // [status | op_a | op_b | dom_pos | dom_n] in one region -> one D2H
+    int32_t* pack = grow<int32_t>(bo[0], (size_t)n * 5);
+    O.status = pack; O.op_a = pack + n; O.op_b = pack + 2 * (size_t)n; O.dom_pos = pack + 3 * (size_t)n; O.dom_n = pack + 4 * (size_t)n;
+    O.pool_cap = std::max(out->dom_cap, 1);
+    O.pool_leaf = grow<int32_t>(bo[1], O.pool_cap); O.pool_count = grow<int32_t>(bo[2], O.pool_cap);
+    int64_t* misc = grow<int64_t>(bo[3], 4);
+    be.memset(misc, 0, 4 * sizeof(int64_t));
+    be.memset(pack, 0, (size_t)n * 5 * sizeof(int32_t));
+    O.pool_used = (int32_t*)misc; O.error = (int32_t*)misc + 1; O.bytes = (long long*)(misc + 1);
+    const int slots = std::min(nw, be.max_slots());
+    TScratch& X = k.X;
+    X.max_set = std::max(T.n_leaves, T.D - T.n_leaves + 1) + 1;
+    const size_t sd = (size_t)slots * T.D, sm = (size_t)slots * X.max_set;
+    X.pc = grow<int32_t>(bx[0], sd); X.sc = grow<int32_t>(bx[1], sd); X.pcwl = grow<int32_t>(bx[2], sd); X.scwl = grow<int32_t>(bx[3], sd); X.lc = grow<int32_t>(bx[4], sd);
+    X.set = grow<int32_t>(bx[5], sm); X.arr = grow<int32_t>(bx[6], sm + slots); X.cur = grow<int32_t>(bx[7], sm); X.nxt = grow<int32_t>(bx[8], sm);
+    X.k0 = (uint64_t*)grow<int64_t>(bx[9], sm); X.k1 = (uint64_t*)grow<int64_t>(bx[10], sm);
+    X.assumed = grow<int64_t>(bx[11], (size_t)slots * T.n_leaves * T.R);
+    be.timer_mark(0);
+    be.launch_tas_find(k, slots);
+    be.timer_mark(1);
+    std::vector<int32_t> hp((size_t)n * 5);
+    int64_t hm[4];
+    be.d2h(hp.data(), pack, hp.size() * sizeof(int32_t));
+    be.d2h(hm, misc, sizeof(hm));
+    int rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    last_ms = be.timer_ms(0, 1);
+    last_bytes = hm[1];
+    const int32_t used = ((int32_t*)hm)[0], derr = ((int32_t*)hm)[1];
+    if (derr != 0) return fail(derr, "device-side error (dom_cap too small)");
+    std::vector<int32_t> pl(std::max(used, 1)), pcnt(std::max(used, 1));
+    if (used > 0) { be.d2h(pl.data(), O.pool_leaf, (size_t)used * 4); be.d2h(pcnt.data(), O.pool_count, (size_t)used * 4); rc = be.sync(); if (rc != KQ_OK) return fail(rc, be.error()); }
+    int tot = 0;
+    for (int i = 0; i < n; i++) {
+      out->status[i] = hp[i]; out->operand_a[i] = hp[(size_t)n + i]; out->operand_b[i] = hp[2 * (size_t)n + i];
+      const int pos = hp[3 * (size_t)n + i], cnt = hp[4 * (size_t)n + i];
+      for (int j = 0; j < cnt; j++) {
+        if (tot >= out->dom_cap) return fail(KQ_ECAPACITY, "dom_cap too small");
+        out->dom_leaf[tot] = pl[pos + j]; out->dom_count[tot] = pcnt[pos + j]; tot++;
+      }
+      out->dom_off[i + 1] = tot;
+    }
+    return KQ_OK;
+  }
+
+  int usage_apply(int n_dom, const int32_t* leaf, const int32_t* count, const int64_t* spr, int add) {
+    if (!have_topo) return fail(KQ_EINVAL, "no topology");
+    if (n_dom <= 0) return KQ_OK;
+    for (int i = 0; i < n_dom; i++) if (leaf[i] < 0 || leaf[i] >= T.n_leaves) return fail(KQ_EINVAL, "leaf out of range");
+    const int32_t* dl = stage(bq[10], leaf, n_dom);
+    const int32_t* dc = stage(bq[11], count, n_dom);
+    const int64_t* dr = stage(bq[2], spr, T.R);
+    be.launch_tas_usage(T, n_dom, dl, dc, dr, add);
+    int rc = be.sync();
+    return rc == KQ_OK ? KQ_OK : fail(rc, be.error());
+  }
+  int fits(int n_dom, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t* out) {
+    if (!have_topo) return fail(KQ_EINVAL, "no topology");
+    *out = 1;
+    if (n_dom <= 0) return KQ_OK;
+    for (int i = 0; i < n_dom; i++) if (leaf[i] < 0 || leaf[i] >= T.n_leaves) { *out = 0; return KQ_OK; }  // domain not found (:438)
+    const int32_t* dl = stage(bq[10], leaf, n_dom);
+    const int32_t* dc = stage(bq[11], count, n_dom);
+    const int64_t* dr = stage(bq[2], spr, T.R);
+    int32_t* flag = (int32_t*)grow<int64_t>(bo[3], 4);
+    int32_t one = 1;
+    be.h2d(flag, &one, sizeof(one));
+    be.launch_tas_fits(T, n_dom, dl, dc, dr, flag);
+    be.d2h(out, flag, sizeof(int32_t));
+    int rc = be.sync();
+    return rc == KQ_OK ? KQ_OK : fail(rc, be.error());
+  }
+  int read_usage(int64_t* out) {
+    if (!have_topo) return fail(KQ_EINVAL, "no topology");
+    be.d2h(out, T.tas_usage, (size_t)T.n_leaves * T.R * sizeof(int64_t));
+    return be.sync();
+  }
+};
+
+// updateTASUsage :267 / Fits :433 : one thread per assigned domain
+KQ_DEV void t_usage_cell(const TTopo& T, int i, const int32_t* leaf, const int32_t* count, const int64_t* spr, int add) {
+  for (int r = 0; r < T.R; r++) {
+    const int64_t v = spr[r] * (int64_t)count[i] + (r == T.pods ? count[i] : 0);
+    int64_t* cell = T.tas_usage + (size_t)leaf[i] * T.R + r;
+    atomic_add_i64((long long*)cell, (long long)(add ? v : -v));
+  }
+}
+KQ_DEV void t_fits_cell(const TTopo& T, int i, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t* flag) {
+  bool have = false; int32_t result = 0;
+  for (int r = 0; r < T.R; r++) {
+    if (spr[r] == 0) continue;
+    const int64_t rem = T.free_cap[(size_t)leaf[i] * T.R + r] - T.tas_usage[(size_t)leaf[i] * T.R + r];
+    const int32_t c = (int32_t)i64max(0, i64min(rem / spr[r], 0x7fffffff));
+    if (!have || c < result) { result = c; have = true; }
+  }
+  if ((have ? result : 0) < count[i]) *flag = 0;
+}
+
+}  // namespace kq

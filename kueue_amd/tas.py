@@ -160,7 +160,7 @@ class Topology:
         return level, kind, slice_size, slice_level
 
     def set_tas_usage(self, usage_by_leaf: Dict[int, Dict[str, int]]):
-        u = self.arrays["tas_usage"].reshape(self.n_leaves, -1)
+        u = self.arrays["tas_usage"].reshape(self.n_leaves, len(self.resources))
         u[:] = 0
         for leaf, d in usage_by_leaf.items():
             for r, q in d.items():

@@ -10,6 +10,7 @@
 #include <cstring>
 
 #include "../../kueue_amd/csrc/kq_host.hpp"
+#include "../../kueue_amd/csrc/kq_tas_host.hpp"
 
 namespace kq {
 struct EmuBackend {
@@ -27,6 +28,9 @@ struct EmuBackend {
   int max_slots() { return 7; }  // small on purpose: exercises the grid-stride loop over heads
   void timer_mark(int) {}
   double timer_ms(int, int) { return 0; }
+  void launch_tas_find(const TK& k, int slots) { for (int slot = 0; slot < slots; slot++) for (int w = slot; w < k.Q.n_wl; w += slots) t_workload(k, slot, w); }
+  void launch_tas_usage(const TTopo& T, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int add) { for (int i = 0; i < n; i++) t_usage_cell(T, i, leaf, count, spr, add); }
+  void launch_tas_fits(const TTopo& T, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t* flag) { for (int i = 0; i < n; i++) t_fits_cell(T, i, leaf, count, spr, flag); }
   void launch_derive(const DSnap& S, const DDerive& d, int max_depth) {
     for (int i = 0; i < S.nq * S.nfr; i++) derive_cq_cell(S, d, i / S.nfr, i % S.nfr);
     for (int dep = max_depth; dep >= 0; dep--)
@@ -74,6 +78,16 @@ extern "C" {
 int kqe_engine_create(const kq_config* cfg, void** out) { auto* e = new EmuEngine(); e->cfg = *cfg; *out = e; return KQ_OK; }
 void kqe_engine_destroy(void* e) { delete (EmuEngine*)e; }
 int kqe_snapshot_put(void* e, const kq_snapshot* s) { return ((EmuEngine*)e)->snapshot_put(s); }
+typedef kq::TasT<kq::EmuBackend> EmuTas;
+int kqe_tas_create(void** out) { *out = new EmuTas(); return KQ_OK; }
+void kqe_tas_destroy(void* t) { delete (EmuTas*)t; }
+int kqe_tas_topology_put(void* t, const kq_tas_topology* tp) { return ((EmuTas*)t)->topology_put(tp); }
+int kqe_tas_find(void* t, const kq_tas_requests* r, kq_tas_result* out) { return ((EmuTas*)t)->find(r, out); }
+int kqe_tas_usage_apply(void* t, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int add) { return ((EmuTas*)t)->usage_apply(n, leaf, count, spr, add); }
+int kqe_tas_fits(void* t, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t* fits) { return ((EmuTas*)t)->fits(n, leaf, count, spr, fits); }
+int kqe_tas_read_usage(void* t, int64_t* u) { return ((EmuTas*)t)->read_usage(u); }
+int64_t kqe_tas_last_bytes(void* t) { return ((EmuTas*)t)->last_bytes; }
+const char* kqe_tas_last_error(void* t) { return ((EmuTas*)t)->last_error.c_str(); }
 int kqe_snapshot_derive(void* e) { return ((EmuEngine*)e)->snapshot_derive(); }
 int kqe_read_planes(void* e, int64_t* sq, int64_t* us, uint8_t* fl) { return ((EmuEngine*)e)->read_planes(sq, us, fl); }
 void kqe_force_exact_drs(void* e, int on) { ((EmuEngine*)e)->force_exact_drs = on != 0; }

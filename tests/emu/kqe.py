@@ -63,3 +63,49 @@ class EmuEngine:
         lib().kqe_phase_bytes(self.h, F.ptr(pb))
         d.phase_bytes = pb.tolist()
         return d
+
+
+class EmuTas:
+    """1-lane emulation of the TAS device code (kq_tas_device.hpp), same interface as kueue_amd.tas.TASEngine."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        assert lib().kqe_tas_create(C.byref(self.h)) == 0
+        lib().kqe_tas_last_error.restype = C.c_char_p
+        lib().kqe_tas_last_bytes.restype = C.c_int64
+        self.topo = None
+
+    def put(self, topo):
+        rc = lib().kqe_tas_topology_put(self.h, C.byref(topo.struct()))
+        assert rc == 0, (rc, lib().kqe_tas_last_error(self.h))
+        self.topo = topo
+
+    def find(self, rq, dom_cap=None):
+        from kueue_amd import tas as T
+        out = T.Result(rq, dom_cap)
+        rc = lib().kqe_tas_find(self.h, C.byref(rq.struct()), C.byref(out.struct()))
+        assert rc == 0, (rc, lib().kqe_tas_last_error(self.h))
+        out.bytes = int(lib().kqe_tas_last_bytes(self.h))
+        return out
+
+    def usage_apply(self, assignment, single_pod_requests, add=True):
+        leaf = np.array([a for a, _ in assignment], np.int32); cnt = np.array([c for _, c in assignment], np.int32)
+        req = np.ascontiguousarray(single_pod_requests, np.int64)
+        assert lib().kqe_tas_usage_apply(self.h, len(leaf), F.ptr(leaf), F.ptr(cnt), F.ptr(req), 1 if add else 0) == 0
+
+    def fits(self, assignment, single_pod_requests):
+        leaf = np.array([a for a, _ in assignment], np.int32); cnt = np.array([c for _, c in assignment], np.int32)
+        req = np.ascontiguousarray(single_pod_requests, np.int64)
+        out = np.zeros(1, np.int32)
+        assert lib().kqe_tas_fits(self.h, len(leaf), F.ptr(leaf), F.ptr(cnt), F.ptr(req), F.ptr(out)) == 0
+        return bool(out[0])
+
+    def read_usage(self):
+        u = np.zeros(self.topo.n_leaves * len(self.topo.resources), np.int64)
+        assert lib().kqe_tas_read_usage(self.h, F.ptr(u)) == 0
+        return u
+
+    def close(self):
+        if self.h:
+            lib().kqe_tas_destroy(self.h)
+            self.h = None

@@ -1,0 +1,78 @@
+"""Seeded random TAS topologies and request batches for differential tests (oracle vs engine)."""
+import random
+
+from kueue_amd import tas as T
+
+LEVELS3 = ["cloud.com/topology-block", "cloud.com/topology-rack", T.HOSTNAME_LABEL]
+
+
+def random_tas_case(seed, max_blocks=3, max_racks=4, max_hosts=6, n_workloads=12):
+    rnd = random.Random(seed)
+    shape = rnd.choice(["3host", "3host", "2host", "2rack", "1host"])
+    levels = {"3host": LEVELS3, "2host": LEVELS3[1:], "2rack": LEVELS3[:2], "1host": LEVELS3[2:]}[shape]
+    nodes = []
+    hid = 0
+    for b in range(rnd.randint(1, max_blocks)):
+        for r in range(rnd.randint(1, max_racks)):
+            for h in range(rnd.randint(1, max_hosts)):
+                hid += 1
+                alloc = {"cpu": str(rnd.randint(0, 8)), "pods": str(rnd.choice([2, 4, 10, 110]))}
+                if rnd.random() < 0.6:
+                    alloc["example.com/gpu"] = str(rnd.randint(0, 8))
+                if rnd.random() < 0.5:
+                    alloc["memory"] = f"{rnd.randint(1, 16)}Gi"
+                nodes.append(T.Node(f"n{hid}", {LEVELS3[0]: f"b{b}", LEVELS3[1]: f"r{b}-{r}", T.HOSTNAME_LABEL: f"x{hid:03d}"}, alloc,
+                                    ready=rnd.random() > 0.05))
+    topo = T.Topology(levels, nodes, resources=["cpu", "memory", "example.com/gpu"], profile_mixed=rnd.random() > 0.2)
+    # some TAS usage already on the leaves
+    use = {}
+    for leaf in range(topo.n_leaves):
+        if rnd.random() < 0.4:
+            use[leaf] = {"cpu": rnd.randint(0, 4) * 1000, "pods": rnd.randint(0, 3)}
+            if rnd.random() < 0.5:
+                use[leaf]["example.com/gpu"] = rnd.randint(0, 4)
+    topo.set_tas_usage(use)
+    workloads, sim = [], []
+    for w in range(rnd.randint(1, n_workloads)):
+        podsets = []
+        kind = rnd.choice(["single", "single", "single", "two", "group"])
+        n_ps = {"single": 1, "two": 2, "group": 2}[kind]
+        for p in range(n_ps):
+            reqs = {}
+            if rnd.random() < 0.8:
+                reqs["cpu"] = rnd.choice([0, 250, 500, 1000, 2000])
+            if rnd.random() < 0.4:
+                reqs["example.com/gpu"] = rnd.randint(0, 2)
+            if rnd.random() < 0.3:
+                reqs["memory"] = rnd.choice([1, 2]) * (1 << 30)
+            lv = rnd.choice(levels)
+            mode = rnd.choice(["required", "preferred", "unconstrained", "implied", "slice-only"])
+            tr = None
+            slice_kw = {}
+            if rnd.random() < 0.35 or mode == "slice-only":
+                li = levels.index(lv) if mode in ("required", "preferred") else 0
+                slice_kw = dict(slice_required_topology=rnd.choice(levels[li:] if rnd.random() < 0.9 else levels), slice_size=rnd.choice([1, 2, 2, 3, 4]))
+            if mode == "required":
+                tr = T.TopologyRequest(required=lv, **slice_kw)
+            elif mode == "preferred":
+                tr = T.TopologyRequest(preferred=lv, **slice_kw)
+            elif mode == "unconstrained":
+                tr = T.TopologyRequest(unconstrained=True, **slice_kw)
+            elif mode == "slice-only":
+                tr = T.TopologyRequest(**slice_kw)
+            count = rnd.choice([0, 1, 1, 2, 3, 4, 6, 8, 12, 20])
+            if slice_kw and slice_kw["slice_size"] > 0:
+                count = max(1, count // slice_kw["slice_size"]) * slice_kw["slice_size"]
+            ps = T.TASPodSetRequests(f"ps{p}", count, reqs, tr)
+            if kind == "group":
+                ps.group = "g"
+                if p == 1:
+                    ps.count = 1
+            if rnd.random() < 0.15:
+                ps.leaf_ok = [rnd.random() < 0.7 for _ in range(topo.n_leaves)]
+            podsets.append(ps)
+        if kind == "group":  # leader + workers share the topology request (PodSet grouping validation)
+            podsets[1].topology_request = podsets[0].topology_request
+        workloads.append(podsets)
+        sim.append(rnd.random() < 0.15)
+    return topo, T.Requests(topo, workloads, simulate_empty=sim)

@@ -10,13 +10,37 @@ from kueue_amd import _ffi as F
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    hdr = open(os.path.join(ROOT, "include", "kq_engine.h")).read()
+def declared_symbols(header="kq_engine.h"):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     return sorted(set(re.findall(r"\b(kq_[a-z_]+)\s*\(", hdr)))
 
 
 def test_header_and_ffi_list_agree():
     assert declared_symbols() == sorted(F.ABI_SYMBOLS)
+
+
+def test_tas_header_and_ffi_list_agree():
+    from kueue_amd import tas
+    assert declared_symbols("kq_tas.h") == sorted(tas.TAS_ABI_SYMBOLS)
+
+
+def test_library_exports_every_tas_symbol():
+    if not os.path.exists(F.ENGINE_LIB):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(F.ENGINE_LIB)
+    for sym in declared_symbols("kq_tas.h"):
+        assert hasattr(lib, sym), sym
+
+
+def test_tas_engine_fails_loudly_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from kueue_amd import tas
+    with pytest.raises(RuntimeError):
+        tas.TASEngine()
 
 
 def test_library_exports_every_declared_symbol():

@@ -1,0 +1,50 @@
+"""Differential test for the TAS path: the engine's device code (1-lane CPU emulation) vs the oracle on seeded random
+topologies: statuses, failure operands, assignments (leaf, count) and the algorithmic byte counter, bit-exact."""
+import numpy as np
+import pytest
+
+from tests.emu import kqe
+from tests.tasgen import random_tas_case
+
+
+@pytest.mark.parametrize("seed", range(500))
+def test_tas_random(oracle, seed):
+    topo, rq = random_tas_case(seed)
+    want = oracle.tas_find(topo, rq)
+    eng = kqe.EmuTas()
+    try:
+        eng.put(topo)
+        got = eng.find(rq)
+    finally:
+        eng.close()
+    bad = want.equal(got)
+    assert not bad, (bad, {k: (want.a[k].tolist(), got.a[k].tolist()) for k in bad})
+    assert got.bytes == want.bytes
+
+
+def test_usage_apply_and_fits(oracle):
+    topo, rq = random_tas_case(7)
+    eng = kqe.EmuTas()
+    try:
+        eng.put(topo)
+        out = eng.find(rq)
+        R = len(topo.resources)
+        for i in range(rq.n):
+            a = out.assignment(i)
+            if not a:
+                continue
+            spr = rq.arrays["single_pod_requests"].reshape(-1, R)[i]
+            with_pods = spr.copy(); with_pods[topo.resource_index["pods"]] += 1
+            assert eng.fits(a, with_pods) == oracle.tas_fits(topo, a, with_pods)
+            before = eng.read_usage().copy()
+            eng.usage_apply(a, spr, add=True)
+            after = eng.read_usage().reshape(-1, R)
+            exp = before.reshape(-1, R).copy()
+            for leaf, cnt in a:
+                exp[leaf] += spr * cnt
+                exp[leaf, topo.resource_index["pods"]] += cnt
+            assert np.array_equal(after, exp)
+            eng.usage_apply(a, spr, add=False)
+            assert np.array_equal(eng.read_usage(), before)
+    finally:
+        eng.close()
