@@ -39,6 +39,9 @@ def main():
                          "(TAS: 4096-leaf 3-tier topology, topology assignment for a batch of pending workloads)")
     ap.add_argument("--tas-batch", type=int, default=50_000, help="cfg5: pending workloads assigned per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--open-loop", action="store_true",
+                    help="every cycle sees the same snapshot (no kq_cycle_commit / kq_cycle_release between cycles)")
+    ap.add_argument("--hold", type=int, default=4, help="closed loop: admitted workloads finish after this many cycles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -78,11 +81,23 @@ def main():
     phase_ms = np.zeros(3, np.float64)
     phase_by = np.zeros(2, np.int64)
 
+    # a run applies the decisions between cycles. Closed loop = commit the cycle's admissions into the resident
+    # snapshot and let the workloads admitted `hold` cycles ago finish. Preemption workloads stay open-loop: evictions
+    # and the admitted-workload table behind the candidate search are host-side state the loop does not rebuild.
+    closed = not args.open_loop and not pop.preemption
+    live = [0]
+
     def run_cycle(i):
         b = i % n_batches
         rc = lib.kq_cycle_run_resident(h, b, C.byref(outs[b].struct()))
         if rc != 0:
             eng._check(rc)
+        if closed:
+            eng._check(lib.kq_cycle_commit(h, None))
+            live[0] += 1
+            if live[0] > args.hold:
+                eng._check(lib.kq_cycle_release(h, args.hold + 1))
+                live[0] -= 1
         return batches[b].n
 
     for i in range(args.warmup):
@@ -136,7 +151,8 @@ def main():
             "config": {"workload": f"{args.workload}: {snap.n_cq} ClusterQueues, {snap.n_cohort} cohorts, {snap.n_flavor} flavors x "
                                    f"{snap.n_resource} resources, {snap.n_adm} admitted, {pop.n_pending} pending per GPU; "
                                    f"one cycle = {batches[0].n} heads", "heads_per_cycle": batches[0].n,
-                       "pending_per_gpu": pop.n_pending, "sharding": "root cohort per GPU, no collective"},
+                       "pending_per_gpu": pop.n_pending, "sharding": "root cohort per GPU, no collective",
+                       "loop": (f"closed: admissions committed every cycle, finished after {args.hold} cycles" if closed else "open: static snapshot")},
             "p50_cycle_ms": float(np.percentile(cyc_ms, 50)),
             "p99_cycle_ms": float(np.percentile(cyc_ms, 99)),
             "kernel_ms_per_cycle": {"k_nominate": nom_ms / args.steps, "k_order": ord_ms / args.steps, "k_process": proc_ms / args.steps},
@@ -144,7 +160,7 @@ def main():
                          "algorithmic_bytes_per_launch": dby / args.steps, "traffic": pmc_traffic(args.workload, dom)},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pop, kcfg, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(pop, kcfg, args.cpu_seconds, closed, args.hold)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -237,7 +253,7 @@ def pmc_traffic(workload, kernel):
         return None
 
 
-def cpu_baseline(pop, kcfg, budget_s):
+def cpu_baseline(pop, kcfg, budget_s, closed=False, hold=4):
     """The oracle (single thread, like the reference's one scheduling goroutine, scheduler.go:226) on the
     first cycles of the same population on this box's host cores. Checker code timed as a baseline only."""
     from oracle import kqo
@@ -253,10 +269,22 @@ def cpu_baseline(pop, kcfg, budget_s):
         kqo.cycle_run(kcfg, snap, pop.heads_for_cycle(0, cycle=1, limit=limit))
         per_head = (time.perf_counter() - t1) / limit
         limit = int(max(4, min(1000, budget_s / max(per_head, 1e-6))))
+    import copy
+    if closed:  # same loop as the GPU leg: the snapshot's usage plane evolves
+        snap = copy.copy(snap)
+        snap.arrays = dict(snap.arrays)
+    held = []
     while time.perf_counter() - t0 < budget_s and cycles < 100:
         hb = pop.heads_for_cycle(cycles, cycle=cycles + 1, limit=limit)
         t1 = time.perf_counter()
-        kqo.cycle_run(kcfg, snap, hb)
+        if closed:
+            usage, _, triples = kqo.cycle_commit(kcfg, snap, hb)   # one schedule() + the folding of its admissions
+            snap.arrays["usage"] = usage; snap._struct = None
+            held.append(triples)
+            if len(held) > hold:
+                snap.arrays["usage"] = kqo.usage_apply(kcfg, snap, held.pop(0), add=False); snap._struct = None
+        else:
+            kqo.cycle_run(kcfg, snap, hb)
         dt = time.perf_counter() - t1
         cpu_t += dt
         dec += hb.n

@@ -268,6 +268,18 @@ int  kq_cycle_run(kq_engine* e, const kq_heads* h, kq_decisions* out);
 int  kq_heads_put(kq_engine* e, const kq_heads* h, int32_t batch);
 int  kq_cycle_run_resident(kq_engine* e, int32_t batch, kq_decisions* out);
 
+/* Closed-loop driver support ("a run" applies decisions to the snapshot between cycles).
+ * kq_cycle_commit folds the usage of every workload the LAST cycle admitted into the resident snapshot — what
+ * cache.AssumeWorkload leaves in the cache (pkg/cache/scheduler/clusterqueue.go:594 updateWorkloadUsage ->
+ * resource_node.go:144 addUsage) — and remembers it; kq_cycle_release removes, via removeUsage (:156), what the
+ * commit `age` commits ago added (age = 1: the latest), i.e. those workloads finish. Preempt-mode reservations
+ * and DeferredFit usage are per-cycle simulation state and are not committed. The admitted-workload table used for
+ * preemption candidates is not extended; callers that need it re-upload the snapshot.
+ * *n_admitted (optional) receives the number of workloads folded in. Ring depth KQ_COMMIT_RING. */
+#define KQ_COMMIT_RING 32
+int  kq_cycle_commit(kq_engine* e, int32_t* n_admitted);
+int  kq_cycle_release(kq_engine* e, int32_t age);
+
 /* Per-kernel device time of the last cycle, HIP events on the engine's stream:
  * phase_ms[0] nominate, [1] order, [2] process; phase_bytes[0] nominate, [1] process (algorithmic bytes). */
 int  kq_last_cycle_phases(kq_engine* e, double* phase_ms, int64_t* phase_bytes);

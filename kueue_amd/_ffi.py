@@ -211,6 +211,10 @@ def load_engine():
     lib.kq_last_cycle_phases.restype = C.c_int
     lib.kq_last_cycle_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.kq_last_cycle_stats.restype = C.c_int
+    lib.kq_cycle_commit.argtypes = [C.c_void_p, i32p]
+    lib.kq_cycle_commit.restype = C.c_int
+    lib.kq_cycle_release.argtypes = [C.c_void_p, C.c_int32]
+    lib.kq_cycle_release.restype = C.c_int
     lib.kq_snapshot_derive.argtypes = [C.c_void_p]
     lib.kq_snapshot_derive.restype = C.c_int
     lib.kq_snapshot_read_planes.argtypes = [C.c_void_p, i64p, i64p, u8p]
@@ -228,6 +232,6 @@ def load_engine():
 # every symbol include/kq_engine.h declares (checked by tests/test_abi.py without a GPU)
 ABI_SYMBOLS = [
     "kq_engine_create", "kq_engine_destroy", "kq_snapshot_put", "kq_cycle_run", "kq_last_cycle_stats",
-    "kq_snapshot_derive", "kq_snapshot_read_planes", "kq_strerror", "kq_last_error", "kq_abi_version",
+    "kq_cycle_commit", "kq_cycle_release", "kq_snapshot_derive", "kq_snapshot_read_planes", "kq_strerror", "kq_last_error", "kq_abi_version",
     "kq_heads_put", "kq_cycle_run_resident", "kq_last_cycle_phases",
 ]

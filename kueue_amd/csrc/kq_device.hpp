@@ -2717,6 +2717,66 @@ KQ_DEV void derive_cohort_cell(const DSnap& S, const DDerive& d, int cohort, int
   d.sq[o] = q; d.usage[o] = u; d.flags[o] = f;
 }
 
+// ------------------------------------------------------------------------------------------------
+// closed-loop support: fold admitted usage into the resident snapshot / take it out again
+// (cache side of assumeWorkload: clusterqueue.go:594 updateWorkloadUsage -> resource_node.go:144-165)
+// ------------------------------------------------------------------------------------------------
+struct DCommit {
+  int n;                  // heads of the committed cycle
+  const int32_t* cq;      // [n]
+  const int32_t* use_n;   // [n] 0 for heads that were not admitted (or hold a quota reservation already)
+  const int32_t* use_fr;  // [n * KQ_MAXU]
+  const int64_t* use_qty;
+  int64_t* usage;         // the snapshot's usage plane
+};
+// one wave per root-cohort tree; entries of a tree touch the same cohort cells, so they are applied one after another,
+// lanes = the entry's flavor-resources (independent columns)
+KQ_DEV void commit_tree(const DSnap& S, const DCommit& c, int tree, bool add) {
+  for (int h = 0; h < c.n; h++) {
+    const int nu = c.use_n[h];
+    if (nu == 0) continue;
+    const int cq = c.cq[h];
+    if (S.tree_of[cq] != tree) continue;
+    for (int u = lane_id(); u < nu; u += WAVE) {
+      const int fr = c.use_fr[(size_t)h * KQ_MAXU + u];
+      UGW g{&S, c.usage, fr};
+      if (add) add_usage(S, S.path + (size_t)cq * KQ_MAXD, S.plen[cq], fr, c.use_qty[(size_t)h * KQ_MAXU + u], g);
+      else remove_usage(S, S.path + (size_t)cq * KQ_MAXD, S.plen[cq], fr, c.use_qty[(size_t)h * KQ_MAXU + u], g);
+    }
+    wsync();
+  }
+}
+// Fast commit when the snapshot's cohort usage is consistent with its children (kq_prep usage_consistent): the
+// admissions are added at the ClusterQueue level in parallel and cohort usage is re-derived level by level —
+// addUsage / removeUsage preserve "cohort usage = sum of what the children store in it" (resource_node.go:217-230),
+// so the result is the one sequential bubbling produces.
+KQ_DEV void commit_cq_cell(const DCommit& c, const DSnap& S, int h, int u, bool add) {
+  if (u >= c.use_n[h]) return;
+  const int fr = c.use_fr[(size_t)h * KQ_MAXU + u];
+  const int64_t q = c.use_qty[(size_t)h * KQ_MAXU + u];
+  atomic_add_i64((long long*)&c.usage[(size_t)c.cq[h] * S.nfr + fr], (long long)(add ? q : -q));
+}
+KQ_DEV void derive_usage_cell(const DSnap& S, int64_t* usage, int cohort, int fr) {
+  int64_t u = 0;
+  const int kx = cohort - S.nq;
+  for (int pass = 0; pass < 2; pass++) {
+    const int32_t* off = pass == 0 ? S.child_cohort_off : S.child_cq_off;
+    const int32_t* lst = pass == 0 ? S.child_cohort : S.child_cq;
+    for (int i = off[kx]; i < off[kx + 1]; i++) {
+      const size_t co = ix(S, lst[i], fr);
+      u = a_add(u, i64max(0, a_sub(usage[co], local_quota(S, lst[i], fr))));
+    }
+  }
+  usage[ix(S, cohort, fr)] = u;
+}
+// which heads of the last cycle count: action == admit and no quota reservation held (netUsage scheduler.go:785-794)
+KQ_DEV void commit_mask_head(const K& k, int h, int32_t* use_n_out, int32_t* cq_out, int32_t* count) {
+  const bool take = k.O.action[h] == KQ_ACT_ADMIT && !(k.H.flags[h] & KQ_HEAD_HAS_QUOTA_RESERVATION);
+  use_n_out[h] = take ? k.O.use_n[h] : 0;
+  cq_out[h] = k.H.cq[h];
+  if (take) atomic_add_i32(count, 1);
+}
+
 // classical entry order (scheduler.go:1110-1163): a precedes b
 KQ_DEV bool entry_before(const K& k, int a, int b) {
   bool aq = k.H.flags[a] & KQ_HEAD_HAS_QUOTA_RESERVATION, bq = k.H.flags[b] & KQ_HEAD_HAS_QUOTA_RESERVATION;

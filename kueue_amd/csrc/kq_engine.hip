@@ -103,6 +103,23 @@ __global__ __launch_bounds__(256) void k_fair_rank_apply(const K* __restrict__ k
   if (i < k.H.n && k.X.fs_key[i] >= 0) k.O.order[i] = rank[i];
 }
 
+__global__ __launch_bounds__(256) void k_commit_mask(const K* __restrict__ kp, int32_t* use_n_out, int32_t* cq_out, int32_t* count) {
+  const K& k = *kp;
+  const int h = blockIdx.x * 256 + threadIdx.x;
+  if (h < k.H.n) commit_mask_head(k, h, use_n_out, cq_out, count);
+}
+__global__ __launch_bounds__(64) void k_commit(DSnap S, DCommit c, int add) { commit_tree(S, c, blockIdx.x, add != 0); }
+__global__ __launch_bounds__(256) void k_commit_cq(DSnap S, DCommit c, int add) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < c.n * KQ_MAXU) commit_cq_cell(c, S, i / KQ_MAXU, i % KQ_MAXU, add != 0);
+}
+__global__ __launch_bounds__(256) void k_usage_level(DSnap S, int64_t* usage, int depth) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= S.nc * S.nfr) return;
+  const int cohort = S.nq + i / S.nfr;
+  if (S.depth[cohort] == depth) derive_usage_cell(S, usage, cohort, i % S.nfr);
+}
+
 // per-node borrowed sums of the cycle-start plane: one thread per (node, resource)
 __global__ __launch_bounds__(256) void k_fs_sums(const K* __restrict__ kp) {
   const K& k = *kp;
@@ -216,6 +233,21 @@ struct HipBackend {
   void launch_tas_fits(const TTopo& T, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t* flag) {
     hipLaunchKernelGGL(k_tas_fits, dim3((n + 63) / 64), dim3(64), 0, stream, T, n, leaf, count, spr, flag);
     chk(hipGetLastError(), "k_tas_fits");
+  }
+  void launch_commit_mask(int n, int32_t* use_n_out, int32_t* cq_out, int32_t* count) {  // uses the K block of the last cycle
+    hipLaunchKernelGGL(k_commit_mask, dim3((n + 255) / 256), dim3(256), 0, stream, (const K*)dk[1], use_n_out, cq_out, count);
+    chk(hipGetLastError(), "k_commit_mask");
+  }
+  void launch_commit(const DSnap& S, const DCommit& c, bool add, bool consistent, int max_depth) {
+    if (consistent) {
+      hipLaunchKernelGGL(k_commit_cq, dim3((c.n * KQ_MAXU + 255) / 256), dim3(256), 0, stream, S, c, add ? 1 : 0);
+      if (S.nc * S.nfr > 0)
+        for (int dep = max_depth; dep >= 0; dep--)
+          hipLaunchKernelGGL(k_usage_level, dim3((S.nc * S.nfr + 255) / 256), dim3(256), 0, stream, S, c.usage, dep);
+    } else if (S.n_tree > 0) {
+      hipLaunchKernelGGL(k_commit, dim3(S.n_tree), dim3(64), 0, stream, S, c, add ? 1 : 0);
+    }
+    chk(hipGetLastError(), "k_commit");
   }
   void launch_derive(const DSnap& S, const DDerive& d, int max_depth) {
     if (S.nq * S.nfr > 0) hipLaunchKernelGGL(k_derive_cq, dim3((S.nq * S.nfr + 255) / 256), dim3(256), 0, stream, S, d);
@@ -351,6 +383,16 @@ int kq_last_cycle_stats(kq_engine* en, double* kernel_ms, int64_t* algorithmic_b
   return KQ_OK;
 }
 
+int kq_cycle_commit(kq_engine* en, int32_t* n_admitted) {
+  if (!en) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.cycle_commit(n_admitted);
+}
+int kq_cycle_release(kq_engine* en, int32_t age) {
+  if (!en) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.cycle_release(age);
+}
 int kq_snapshot_derive(kq_engine* en) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);

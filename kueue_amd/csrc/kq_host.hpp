@@ -71,6 +71,7 @@ template <class B> struct EngineT {
     if (hstage) be.free_host(hstage);
     for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank}) if (b->p) be.free(b->p);
     for (auto& b : b_fs) if (b.p) be.free(b.p);
+    for (auto& c : ring) for (Buf* b : {&c.cq, &c.use_n, &c.use_fr, &c.use_qty}) if (b->p) be.free(b->p);
     for (auto& hbch : batches) for (auto& b : hbch.hb) if (b.p) be.free(b.p);
     for (auto& b : ob) if (b.p) be.free(b.p);
   }
@@ -78,6 +79,8 @@ template <class B> struct EngineT {
   // cache.Snapshot -> HBM (snapshot.go:171)
   int snapshot_put(const kq_snapshot* s) {
     free_snapshot();
+    for (auto& c : ring) c.live = false;
+    commits = 0; last_cycle_n = -1;
     int rc = build_prep(s, prep);
     if (rc != KQ_OK) return fail(rc, prep.err);
     const size_t N = prep.N, nfr = prep.nfr, nq = prep.nq;
@@ -136,6 +139,57 @@ template <class B> struct EngineT {
     rc = be.sync();
     if (rc != KQ_OK) return fail(rc, be.error());
     have_snapshot = true;
+    return KQ_OK;
+  }
+
+  // ---- closed loop: commit the last cycle's admissions into the snapshot, release them later --------------
+  struct Committed { Buf cq, use_n, use_fr, use_qty; int n = 0; bool live = false; };
+  Committed ring[KQ_COMMIT_RING];
+  int64_t commits = 0;
+  int last_cycle_n = -1;   // heads of the last executed cycle, -1 = none / already committed
+  DOut last_O{};
+  int max_depth() const { int m = 0; for (int n = 0; n < prep.N; n++) m = std::max(m, (int)prep.depth[n]); return m; }
+  int cycle_commit(int32_t* n_admitted) {
+    if (!have_snapshot) return fail(KQ_EINVAL, "kq_cycle_commit before kq_snapshot_put");
+    if (last_cycle_n < 0) return fail(KQ_EINVAL, "kq_cycle_commit: no uncommitted cycle");
+    const int n = last_cycle_n;
+    Committed& c = ring[commits % KQ_COMMIT_RING];
+    if (c.live) return fail(KQ_ECAPACITY, "commit ring full: release older commits first");
+    c.n = n;
+    int32_t count = 0;
+    if (n > 0) {
+      int32_t* d_cq = grow<int32_t>(c.cq, n);
+      int32_t* d_un = grow<int32_t>(c.use_n, n);
+      int32_t* d_fr = grow<int32_t>(c.use_fr, (size_t)n * KQ_MAXU);
+      int64_t* d_qty = grow<int64_t>(c.use_qty, (size_t)n * KQ_MAXU);
+      int32_t* d_count = (int32_t*)grow<int64_t>(b_misc, 2);
+      be.memset(d_count, 0, 16);
+      be.launch_commit_mask(n, d_un, d_cq, d_count);
+      be.d2d(d_fr, last_O.use_fr, (size_t)n * KQ_MAXU * sizeof(int32_t));
+      be.d2d(d_qty, last_O.use_qty, (size_t)n * KQ_MAXU * sizeof(int64_t));
+      DCommit dc{n, d_cq, d_un, d_fr, d_qty, d_usage};
+      be.launch_commit(S, dc, true, prep.usage_consistent, max_depth());
+      if (n_admitted) {  // only a caller that asks for the count pays for a round trip; the stream orders the rest
+        be.d2h(&count, d_count, sizeof(count));
+        int rc = be.sync();
+        if (rc != KQ_OK) return fail(rc, be.error());
+      }
+    }
+    c.live = true;
+    commits++;
+    last_cycle_n = -1;
+    if (n_admitted) *n_admitted = count;
+    return KQ_OK;
+  }
+  int cycle_release(int age) {
+    if (age < 1 || age > KQ_COMMIT_RING || age > commits) return fail(KQ_EINVAL, "kq_cycle_release: no such commit");
+    Committed& c = ring[(commits - age) % KQ_COMMIT_RING];
+    if (!c.live) return fail(KQ_EINVAL, "kq_cycle_release: already released");
+    if (c.n > 0) {
+      DCommit dc{c.n, (const int32_t*)c.cq.p, (const int32_t*)c.use_n.p, (const int32_t*)c.use_fr.p, (const int64_t*)c.use_qty.p, d_usage};
+      be.launch_commit(S, dc, false, prep.usage_consistent, max_depth());
+    }
+    c.live = false;
     return KQ_OK;
   }
 
@@ -259,7 +313,7 @@ template <class B> struct EngineT {
     int rc = KQ_OK;
     if (out->tgt_off) out->tgt_off[0] = 0;
     if (n == 0) {
-      last_kernel_ms = 0; last_bytes = 0;
+      last_kernel_ms = 0; last_bytes = 0; last_cycle_n = 0;
       be.d2d(grow<int64_t>(b_usage_work, (size_t)prep.N * prep.nfr), d_usage, (size_t)prep.N * prep.nfr * sizeof(int64_t));
       return be.sync();
     }
@@ -351,6 +405,7 @@ template <class B> struct EngineT {
     if (cfg.fair_sharing) be.launch_process_fair(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16, rank);
     else be.launch_process(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16);
     be.timer_mark(3);
+    last_cycle_n = n; last_O = k.O;
 
     // decisions back: one D2H of the packed region into host staging, then plain memcpy to the caller's arrays
     if (hstage_cap < pack_bytes) { if (hstage) be.free_host(hstage); hstage_cap = pack_bytes + pack_bytes / 4; hstage = (uint8_t*)be.alloc_host(hstage_cap); }

@@ -42,6 +42,7 @@ struct Prep {
   std::vector<int32_t> h_parent;                   // host copies kept for build_fair after a device derive
   std::vector<int64_t> h_ll, h_bl;
   bool fs_plain_adm = true;
+  bool usage_consistent = true;                    // cohort usage == sum over children of max(0, usage - localQuota) (resource_node.go:217-230)
   bool fs_plain = true;                            // every finite amount is small enough that DRS sums cannot saturate
   std::vector<int32_t> rank_pos;                   // [n_adm] position of the row inside its tree's tree_rows segment
   std::vector<int32_t> top_of;                     // [N] the ancestor-or-self that is a child of the root (-1 for roots)
@@ -213,6 +214,44 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
     for (int e = s->adm_use_off[r]; e < s->adm_use_off[r + 1]; e++)
       if (s->adm_use_qty[e] < 0 || s->adm_use_qty[e] >= ((int64_t)1 << 50)) p.fs_plain_adm = false;
   build_fair(p, s->subtree_quota, s->usage, s->quota_flags);
+  // is the uploaded cohort usage what accumulateFromChild would have produced? (lets kq_cycle_commit re-derive it
+  // level by level instead of bubbling every admission one after another)
+  {
+    const int64_t U = INT64_MAX;
+    auto a_add = [&](int64_t x, int64_t y) -> int64_t {
+      if (x == U || y == U) return U;
+      if (y > 0 && x > U - y) return U;
+      if (y < 0 && x < INT64_MIN - y) return INT64_MIN;
+      return x + y;
+    };
+    auto a_sub = [&](int64_t x, int64_t y) -> int64_t {
+      if (x == U && y == U) return 0;
+      if (x == U) return U;
+      if (y == U) return INT64_MIN;
+      if (y < 0 && x > U + y) return U;
+      if (y > 0 && x < INT64_MIN + y) return INT64_MIN;
+      return x - y;
+    };
+    p.usage_consistent = true;
+    const size_t nfr = p.nfr;
+    for (int c = nq; c < N && p.usage_consistent; c++) {
+      const int kx = c - nq;
+      for (size_t fr = 0; fr < nfr; fr++) {
+        int64_t sum = 0;
+        for (int pass = 0; pass < 2; pass++) {
+          const int32_t* off = pass == 0 ? s->child_cohort_off : s->child_cq_off;
+          const int32_t* lst = pass == 0 ? s->child_cohort : s->child_cq;
+          for (int i = off[kx]; i < off[kx + 1]; i++) {
+            const size_t o = (size_t)lst[i] * nfr + fr;
+            const int64_t ll = s->lend_limit[o];
+            const int64_t lq = ll != KQ_NIL_LIMIT ? std::max<int64_t>(0, a_sub(s->subtree_quota[o], ll)) : 0;
+            sum = a_add(sum, std::max<int64_t>(0, a_sub(s->usage[o], lq)));
+          }
+        }
+        if (sum != s->usage[(size_t)c * nfr + fr]) { p.usage_consistent = false; break; }
+      }
+    }
+  }
   // index validation
   for (int g = 0; g < p.n_rg; g++) {
     for (int k = s->rg_flavor_off[g]; k < s->rg_flavor_off[g + 1]; k++) if (s->rg_flavor[k] < 0 || s->rg_flavor[k] >= p.nF) { p.err = "rg_flavor out of range"; return KQ_EINVAL; }

@@ -61,6 +61,22 @@ class Engine:
         d.kernel_ms, d.bytes = ms.value, by.value
         return d
 
+    def commit(self) -> int:
+        """kq_cycle_commit: fold the last cycle's admissions into the resident snapshot; returns how many."""
+        n = C.c_int32()
+        self._check(self._lib.kq_cycle_commit(self._h, C.byref(n)))
+        return n.value
+
+    def release(self, age: int = 1):
+        """kq_cycle_release: the workloads committed `age` commits ago finish."""
+        self._check(self._lib.kq_cycle_release(self._h, age))
+
+    def read_usage(self) -> np.ndarray:
+        n = self.snap.N * self.snap.n_fr
+        us = np.zeros(n, np.int64)
+        self._check(self._lib.kq_snapshot_read_planes(self._h, None, F.ptr(us), None))
+        return us
+
     def derive(self):
         """kq_snapshot_derive on the uploaded snapshot; returns (subtree_quota, usage, quota_flags) read back."""
         self._check(self._lib.kq_snapshot_derive(self._h))

@@ -1605,6 +1605,35 @@ int kqo_quota_probe(const kq_config* cfg, const kq_snapshot* s, int cq, int fr, 
 }
 
 // Apply a sequence of AddWorkload(+row) / RemoveWorkload(-(row+1)) to the snapshot and return usage.
+// Closed loop (checker for kq_cycle_commit / kq_cycle_release): run the cycle, then fold the usage of every admitted
+// workload into the snapshot's ORIGINAL usage (cache side of assumeWorkload: clusterqueue.go:594 -> resource_node.go:144).
+// The (cq, fr, qty) triples that were added come back so that a later release can be replayed with kqo_usage_apply.
+int kqo_cycle_commit(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, int64_t* usage_out, int32_t* n_admitted,
+                     int32_t cap, int32_t* t_cq, int32_t* t_fr, int64_t* t_qty, int32_t* n_triples) {
+  Snap sn(*cfg, s);
+  Scheduler sch(sn, h);
+  std::vector<Entry> entries;
+  sch.schedule(entries);
+  Snap fresh(*cfg, s);
+  int na = 0, nt = 0;
+  for (auto& e : entries) {
+    if (e.action != KQ_ACT_ADMIT) continue;
+    na++;
+    FRQ u = sch.assignmentUsage(e);
+    fresh.AddUsage(e.head.cq, u);
+    for (auto& kv : u) { if (nt >= cap) return KQ_ECAPACITY; t_cq[nt] = e.head.cq; t_fr[nt] = kv.first; t_qty[nt] = kv.second.v; nt++; }
+  }
+  memcpy(usage_out, fresh.usage.data(), fresh.usage.size() * 8);
+  *n_admitted = na; *n_triples = nt;
+  return KQ_OK;
+}
+int kqo_usage_apply(const kq_config* cfg, const kq_snapshot* s, int n, const int32_t* cq, const int32_t* fr, const int64_t* qty, int add, int64_t* usage_out) {
+  Snap sn(*cfg, s);
+  for (int i = 0; i < n; i++) { if (add) sn.addUsage(cq[i], fr[i], Amount(qty[i])); else sn.removeUsage(cq[i], fr[i], Amount(qty[i])); }
+  memcpy(usage_out, sn.usage.data(), sn.usage.size() * 8);
+  return KQ_OK;
+}
+
 int kqo_apply_ops(const kq_config* cfg, const kq_snapshot* s, int n_ops, const int32_t* ops, int64_t* usage_out) {
   Snap sn(*cfg, s);
   for (int i = 0; i < n_ops; i++) { if (ops[i] >= 0) sn.AddWorkload(ops[i]); else sn.RemoveWorkload(-ops[i] - 1); }

@@ -171,3 +171,25 @@ def tas_fits(topo, assignment, single_pod_requests) -> bool:
     leaf = np.array([a for a, _ in assignment], np.int32); cnt = np.array([c for _, c in assignment], np.int32)
     req = np.ascontiguousarray(single_pod_requests, np.int64)
     return bool(lib().kqo_tas_fits(C.byref(topo.struct()), len(leaf), F.ptr(leaf), F.ptr(cnt), F.ptr(req)))
+
+
+def cycle_commit(cfg, snap: Snapshot, heads: Heads):
+    """-> (usage plane after folding the cycle's admissions in, n_admitted, triples (cq, fr, qty) that were added)."""
+    n = snap.N * snap.n_fr
+    usage = np.zeros(n, np.int64)
+    cap = max(16, heads.n * 32)
+    tcq, tfr, tq = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.int64)
+    na, nt = C.c_int32(), C.c_int32()
+    rc = lib().kqo_cycle_commit(C.byref(cfg), C.byref(snap.struct()), C.byref(heads.struct()), F.ptr(usage), C.byref(na), cap,
+                                F.ptr(tcq), F.ptr(tfr), F.ptr(tq), C.byref(nt))
+    assert rc == 0, rc
+    return usage, na.value, (tcq[:nt.value].copy(), tfr[:nt.value].copy(), tq[:nt.value].copy())
+
+
+def usage_apply(cfg, snap: Snapshot, triples, add: bool):
+    tcq, tfr, tq = triples
+    usage = np.zeros(snap.N * snap.n_fr, np.int64)
+    pad = lambda a: a if a.size else np.zeros(1, a.dtype)
+    rc = lib().kqo_usage_apply(C.byref(cfg), C.byref(snap.struct()), len(tcq), F.ptr(pad(tcq)), F.ptr(pad(tfr)), F.ptr(pad(tq)), 1 if add else 0, F.ptr(usage))
+    assert rc == 0, rc
+    return usage

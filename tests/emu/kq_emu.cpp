@@ -31,6 +31,17 @@ struct EmuBackend {
   void launch_tas_find(const TK& k, int slots) { for (int slot = 0; slot < slots; slot++) for (int w = slot; w < k.Q.n_wl; w += slots) t_workload(k, slot, w); }
   void launch_tas_usage(const TTopo& T, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int add) { for (int i = 0; i < n; i++) t_usage_cell(T, i, leaf, count, spr, add); }
   void launch_tas_fits(const TTopo& T, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t* flag) { for (int i = 0; i < n; i++) t_fits_cell(T, i, leaf, count, spr, flag); }
+  K last_k{};
+  void launch_commit_mask(int n, int32_t* use_n_out, int32_t* cq_out, int32_t* count) { for (int h = 0; h < n; h++) commit_mask_head(last_k, h, use_n_out, cq_out, count); }
+  void launch_commit(const DSnap& S, const DCommit& c, bool add, bool consistent, int max_depth) {
+    if (consistent && (rot++ & 1)) {  // alternate between the two equivalent procedures
+      for (int i = 0; i < c.n * KQ_MAXU; i++) commit_cq_cell(c, S, i / KQ_MAXU, i % KQ_MAXU, add);
+      for (int dep = max_depth; dep >= 0; dep--)
+        for (int i = 0; i < S.nc * S.nfr; i++) if (S.depth[S.nq + i / S.nfr] == dep) derive_usage_cell(S, c.usage, S.nq + i / S.nfr, i % S.nfr);
+    } else {
+      for (int t = 0; t < S.n_tree; t++) commit_tree(S, c, t, add);
+    }
+  }
   void launch_derive(const DSnap& S, const DDerive& d, int max_depth) {
     for (int i = 0; i < S.nq * S.nfr; i++) derive_cq_cell(S, d, i / S.nfr, i % S.nfr);
     for (int dep = max_depth; dep >= 0; dep--)
@@ -60,6 +71,7 @@ struct EmuBackend {
     const size_t budgets[3] = {lds.size() * 8, sizeof(PRec) * CH + 64, 0};
     for (int t = 0; t < n_tree; t++) { Wave w{}; process_tree(k, w, t, t, lds.data(), budgets[(t + rot) % 3]); }
     rot++;
+    last_k = k;
   }
   void launch_process_fair(const K& k, int n_tree, size_t, int32_t* rank) {
     std::vector<int64_t> lds(160 * 1024 / 8);
@@ -68,6 +80,7 @@ struct EmuBackend {
     rot++;
     for (int i = 0; i < k.H.n; i++) rank[i] = k.X.fs_key[i] >= 0 ? fair_rank(k, i, 0, k.H.n) : 0;
     for (int i = 0; i < k.H.n; i++) if (k.X.fs_key[i] >= 0) k.O.order[i] = rank[i];
+    last_k = k;
   }
 };
 }  // namespace kq
@@ -88,6 +101,8 @@ int kqe_tas_fits(void* t, int n, const int32_t* leaf, const int32_t* count, cons
 int kqe_tas_read_usage(void* t, int64_t* u) { return ((EmuTas*)t)->read_usage(u); }
 int64_t kqe_tas_last_bytes(void* t) { return ((EmuTas*)t)->last_bytes; }
 const char* kqe_tas_last_error(void* t) { return ((EmuTas*)t)->last_error.c_str(); }
+int kqe_cycle_commit(void* e, int32_t* n) { return ((EmuEngine*)e)->cycle_commit(n); }
+int kqe_cycle_release(void* e, int age) { return ((EmuEngine*)e)->cycle_release(age); }
 int kqe_snapshot_derive(void* e) { return ((EmuEngine*)e)->snapshot_derive(); }
 int kqe_read_planes(void* e, int64_t* sq, int64_t* us, uint8_t* fl) { return ((EmuEngine*)e)->read_planes(sq, us, fl); }
 void kqe_force_exact_drs(void* e, int on) { ((EmuEngine*)e)->force_exact_drs = on != 0; }

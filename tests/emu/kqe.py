@@ -27,6 +27,21 @@ class EmuEngine:
         self.h = C.c_void_p()
         assert lib().kqe_engine_create(C.byref(cfg), C.byref(self.h)) == 0
 
+    def commit(self):
+        n = C.c_int32()
+        rc = lib().kqe_cycle_commit(self.h, C.byref(n))
+        assert rc == 0, (rc, lib().kqe_last_error(self.h))
+        return n.value
+
+    def release(self, age=1):
+        rc = lib().kqe_cycle_release(self.h, age)
+        assert rc == 0, (rc, lib().kqe_last_error(self.h))
+
+    def read_usage(self):
+        us = np.zeros(self.snap.N * self.snap.n_fr, np.int64)
+        assert lib().kqe_read_planes(self.h, None, F.ptr(us), None) == 0
+        return us
+
     def derive(self):
         assert lib().kqe_snapshot_derive(self.h) == 0
         n = self.snap.N * self.snap.n_fr
