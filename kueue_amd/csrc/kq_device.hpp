@@ -116,6 +116,8 @@ struct DSnap {
   const int32_t* rank_pos;   // [n_adm] position of the row in its tree's rank-ordered tree_rows segment
   const int32_t* frcount;    // [N] flavor-resources with a SubtreeQuota entry
   const int32_t* tree_rows_asc;  // admitted rows of a tree, ascending (offsets = tree_row_off)
+  const int32_t *frb_off, *frb;  // [(tree * nfr + fr)] rank positions of the rows using that flavor-resource, ascending
+  const int32_t* cq_row_bytes;   // [nq] algorithmic bytes of a ClusterQueue's candidate records
   const double* fair_weight; // [N]
   const int32_t *child_cohort_off, *child_cohort, *child_cq_off, *child_cq, *depth;
   const int64_t* adm_rts;
@@ -174,6 +176,8 @@ struct DScratch {
   int32_t* tgt_row;  // [slots][tgt_cap]
   uint8_t* tgt_reason;
   int32_t* nom;      // [slots][KQ_MAXPS * nR] NominationMapping of the entry being recomputed (workload.go:262)
+  int32_t* cand;     // [slots][max_tree_rows] rank positions of the rows that use a flavor-resource needing preemption
+  uint64_t* mark;    // [slots][ceil(max_tree_rows / 64)] bitmap used to merge the buckets of several flavor-resources
   // fair sharing: per-CQ candidate queues of the TargetClusterQueueOrdering (fairsharing/ordering.go:46)
   int32_t* qcnt;     // [slots][max_tree_cqs] remaining candidates of the CQ
   uint32_t* qhead;   // [slots][max_tree_cqs] key of the first remaining candidate (evicted bit | rank position)
@@ -211,6 +215,7 @@ struct K {  // everything a kernel needs
   uint8_t* preempted;        // [n_adm] PreemptedWorkloads membership (preempted_workloads.go:26)
   const int32_t* order_idx;  // [H] entry index at iterator position i
   long long* prof;           // [32] optional segment cycle counters (KQ_PROF builds)
+  int32_t* cq_rm_bytes;      // [nq] candidate-record bytes of the rows preempted so far this cycle (they left cq.Workloads)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -492,6 +497,7 @@ struct Search {
   int64_t* W;               // private usage [local_node][ns]
   uint8_t* cqinfo;
   uint8_t* cls;
+  int32_t* cand; uint64_t* mark;
   int32_t* trow;
   uint8_t* treason;
   int tree, row0, nrows;
@@ -553,8 +559,8 @@ KQ_DEV int classify_row(const Search& s, int row, int* list, int* bytes) {
     if (info == 0) return V_NEVER;
     level = info - 1;
   }
-  *bytes += 32 + 12 * (S.adm_use_off[row + 1] - S.adm_use_off[row]);  // candidate record + its usage entries
-  if (!uses_need(k, w, row)) return V_NEVER;
+  (void)bytes;  // candidate-record bytes are charged per collected ClusterQueue (cq_row_bytes); the row uses a needed
+                // flavor-resource by construction (it comes from that flavor-resource's bucket)
   int policy = same ? KQ_POL_WITHIN_CQ(w.pol) : KQ_POL_RECLAIM(w.pol);
   if (!satisfies_policy(k, w, row, policy)) return V_NEVER;
   if (same) { *list = 2; return V_WITHIN_CQ; }
@@ -668,6 +674,7 @@ KQ_DEV void classical_search(Search& s) {
     }
   }
   // which CQs of the tree are collected, and under which path level (collectCandidatesInSubtree :179-207)
+  int cbytes = 0;
   {
     const int q0 = S.tree_cq_off[s.tree], nqs = S.tree_cq_off[s.tree + 1] - q0;
     for (int i = lane; i < nqs; i += WAVE) {
@@ -685,29 +692,67 @@ KQ_DEV void classical_search(Search& s) {
         if (ok && lvl >= 1) info = (uint8_t)(lvl + 1);
       }
       s.cqinfo[i] = info;
+      // every row still in cq.Workloads of a collected ClusterQueue is looked at (candidate record + usage entries)
+      if (info != 0 || (c == w.cq && same_on)) cbytes += S.cq_row_bytes[c] - (s.removed ? k.cq_rm_bytes[c] : 0);
     }
-  }
-  wsync();
-  // classify every admitted row of the tree once; class byte = 1 + list + 3*evicted + 8*variant
-  int cnt[6] = {0, 0, 0, 0, 0, 0};
-  int cbytes = 0;
-  for (int base = 0; base < s.nrows; base += WAVE) {
-    int i = base + lane;
-    uint8_t cb = 0;
-    if (i < s.nrows) {
-      int row = S.tree_rows[s.row0 + i], list = 0;
-      int v = classify_row(s, row, &list, &cbytes);
-      if (v != V_NEVER) {
-        int ev = (S.adm_flags[row] & KQ_ADM_EVICTED) ? 0 : 1;  // evicted first
-        cb = (uint8_t)(1 + (ev * 3 + list) + 8 * v);
-      }
-      s.cls[i] = cb;
-    }
-    for (int p = 0; p < 6; p++) cnt[p] += popc64(wballot(cb != 0 && ((cb - 1) & 7) == p));
   }
   {
     int64_t tot = wsum_i64((int64_t)cbytes);
     if (lane == 0) w.bytes += tot;
+  }
+  wsync();
+  // candidate positions: the rows that use a flavor-resource needing preemption (WorkloadUsesResources), rank order
+  const int32_t* positions;
+  int M = 0;
+  {
+    int nneed = 0, one = -1;
+    for (int u = 0; u < w.ns; u++) if (w.s_need[u]) { nneed++; one = u; }
+    if (nneed == 1) {
+      const size_t b = (size_t)s.tree * S.nfr + w.s_fr[one];
+      positions = S.frb + S.frb_off[b];
+      M = S.frb_off[b + 1] - S.frb_off[b];
+    } else {
+      const int nwords = (s.nrows + 63) / 64;
+      for (int i = lane; i < nwords; i += WAVE) s.mark[i] = 0;
+      wsync();
+      for (int u = 0; u < w.ns; u++) {
+        if (!w.s_need[u]) continue;
+        const size_t b = (size_t)s.tree * S.nfr + w.s_fr[u];
+        for (int j = S.frb_off[b] + lane; j < S.frb_off[b + 1]; j += WAVE) { const int pos = S.frb[j]; atomic_or_u64(&s.mark[pos >> 6], 1ull << (pos & 63)); }
+      }
+      wsync();
+      for (int base = 0; base < nwords; base += WAVE) {
+        const int i = base + lane;
+        uint64_t wd = i < nwords ? s.mark[i] : 0;
+        const int c = popc64(wd);
+        w.cell_borrow[lane] = c;
+        wsync_lds();
+        int before = 0, total = 0;
+        for (int q = 0; q < WAVE; q++) { const int v = w.cell_borrow[q]; if (q < lane) before += v; total += v; }
+        int my = M + before;
+        while (wd) { const int bit = ffs64(wd); wd &= wd - 1; s.cand[my++] = i * 64 + bit; }
+        M += total;
+        wsync_lds();
+      }
+      wsync();
+      positions = s.cand;
+    }
+  }
+  // classify the candidate rows once; class byte = 1 + list + 3*evicted + 8*variant (indexed like `positions`)
+  int cnt[6] = {0, 0, 0, 0, 0, 0};
+  for (int base = 0; base < M; base += WAVE) {
+    int j = base + lane;
+    uint8_t cb = 0;
+    if (j < M) {
+      int row = S.tree_rows[s.row0 + positions[j]], list = 0, unused = 0;
+      int v = classify_row(s, row, &list, &unused);
+      if (v != V_NEVER) {
+        int ev = (S.adm_flags[row] & KQ_ADM_EVICTED) ? 0 : 1;  // evicted first
+        cb = (uint8_t)(1 + (ev * 3 + list) + 8 * v);
+      }
+      s.cls[j] = cb;
+    }
+    for (int p = 0; p < 6; p++) cnt[p] += popc64(wballot(cb != 0 && ((cb - 1) & 7) == p));
   }
   wsync();
   bool no_hier = cnt[0] + cnt[3] == 0, no_other = no_hier && (cnt[1] + cnt[4] == 0);
@@ -729,15 +774,15 @@ KQ_DEV void classical_search(Search& s) {
     int nt = 0;
     for (int p = 0; p < 6; p++) {
       if (cnt[p] == 0) continue;
-      for (int base = 0; base < s.nrows; base += WAVE) {
+      for (int base = 0; base < M; base += WAVE) {
         int i = base + lane;
-        uint8_t cb = i < s.nrows ? s.cls[i] : 0;
+        uint8_t cb = i < M ? s.cls[i] : 0;
         uint64_t m = wballot(cb != 0 && ((cb - 1) & 7) == p);
         while (m) {
           int b = ffs64(m);
           m &= m - 1;
           int pos = base + b;
-          int row = S.tree_rows[s.row0 + pos];
+          int row = S.tree_rows[s.row0 + positions[pos]];
           int variant = s.cls[pos] >> 3;
           if (!candidate_valid(s, row, variant, borrowing)) continue;
           w_apply_row(s, row, false);
@@ -1273,6 +1318,8 @@ KQ_DEV Search make_search(const K& k, Wave& w, int slot, const int64_t* usage, c
   s.W = k.X.w + (size_t)slot * k.X.max_tree_nodes * k.X.slot_cap;
   s.cqinfo = k.X.cqinfo + (size_t)slot * k.X.max_tree_cqs;
   s.cls = k.X.cls + (size_t)slot * k.X.max_tree_rows;
+  s.cand = k.X.cand + (size_t)slot * k.X.max_tree_rows;
+  s.mark = k.X.mark + (size_t)slot * ((k.X.max_tree_rows + 63) / 64);
   s.trow = k.X.tgt_row + (size_t)slot * k.X.tgt_cap;
   s.treason = k.X.tgt_reason + (size_t)slot * k.X.tgt_cap;
   s.tree = 0; s.row0 = 0; s.nrows = 0;
@@ -2022,6 +2069,7 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
       if (lane == 0 && !k.preempted[row]) {
         k.preempted[row] = 1;
         w.n_pre++;
+        k.cq_rm_bytes[S.adm_cq[row]] += 32 + 12 * (S.adm_use_off[row + 1] - S.adm_use_off[row]);
         int c = S.adm_cq[row];
         for (int en = S.adm_use_off[row]; en < S.adm_use_off[row + 1]; en++) {
           UP g = up_plane(k, w, 1, S.adm_use_fr[en]);

@@ -31,7 +31,7 @@ template <class B> struct EngineT {
   // cycle buffers (grow-only)
   struct Buf { void* p = nullptr; size_t cap = 0; };
   std::vector<Buf*> all_bufs;
-  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_fs[20];
+  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_fs[20];
   bool force_exact_drs = false;  // tests: take the saturation-safe DRS loops even when the sums would be exact
   struct HeadBatch { Buf hb[16]; DHeads H{}; int n = 0; size_t nps = 0; int slot_cap = 1; int64_t cycle = 0; bool valid = false; bool plain = true; };
   std::vector<HeadBatch> batches;  // [0] = transient batch of kq_cycle_run, [1+b] = resident batch b
@@ -69,7 +69,7 @@ template <class B> struct EngineT {
   ~EngineT() {
     free_snapshot();
     if (hstage) be.free_host(hstage);
-    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank}) if (b->p) be.free(b->p);
+    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb}) if (b->p) be.free(b->p);
     for (auto& b : b_fs) if (b.p) be.free(b.p);
     for (auto& c : ring) for (Buf* b : {&c.cq, &c.use_n, &c.use_fr, &c.use_qty}) if (b->p) be.free(b->p);
     for (auto& hbch : batches) for (auto& b : hbch.hb) if (b.p) be.free(b.p);
@@ -126,6 +126,9 @@ template <class B> struct EngineT {
     S.lendable = upload(prep.lendable.data(), prep.lendable.size());
     S.rank_pos = upload(prep.rank_pos.data(), prep.rank_pos.size());
     S.frcount = upload(prep.frcount.data(), prep.frcount.size());
+    S.frb_off = upload(prep.frb_off.data(), prep.frb_off.size());
+    S.frb = upload(prep.frb.data(), prep.frb.size());
+    S.cq_row_bytes = upload(prep.cq_row_bytes.data(), prep.cq_row_bytes.size());
     S.tree_rows_asc = upload(prep.tree_rows_asc.data(), prep.tree_rows_asc.size());
     S.top_of = upload(prep.top_of.data(), prep.top_of.size());
     S.fair_weight = upload(s->fair_weight, N);
@@ -365,6 +368,10 @@ template <class B> struct EngineT {
     X.tgt_row = grow<int32_t>(b_tgt_row, (size_t)slots * X.tgt_cap);
     X.tgt_reason = grow<uint8_t>(b_tgt_reason, (size_t)slots * X.tgt_cap);
     X.nom = grow<int32_t>(b_nom, (size_t)slots * KQ_MAXPS * nR);
+    X.cand = grow<int32_t>(b_cand, (size_t)slots * X.max_tree_rows);
+    X.mark = (uint64_t*)grow<int64_t>(b_mark, (size_t)slots * ((X.max_tree_rows + 63) / 64));
+    k.cq_rm_bytes = grow<int32_t>(b_rmb, std::max(prep.nq, 1));
+    be.memset(k.cq_rm_bytes, 0, (size_t)std::max(prep.nq, 1) * sizeof(int32_t));
     if (cfg.fair_sharing) {
       const size_t tq = (size_t)slots * X.max_tree_cqs, tn = (size_t)slots * X.max_tree_nodes;
       X.qcnt = grow<int32_t>(b_fs[0], tq); X.qhead = grow<uint32_t>(b_fs[1], tq); X.cohp = grow<uint8_t>(b_fs[2], tn);

@@ -37,6 +37,10 @@ struct Prep {
   // fair sharing: calculateLendable(parent(node)) per resource (fair_sharing.go:186-200). It only reads quotas
   // (potentialAvailable ignores usage), so it is a per-snapshot constant. [N * nR]; 0 for root nodes.
   std::vector<int64_t> lendable;
+  // victim search: per (tree, flavor-resource) the rank positions of the admitted rows that use it (WorkloadUsesResources,
+  // classical/candidate_generator.go:54), ascending = candidate order; and per ClusterQueue the algorithmic bytes of its rows
+  std::vector<int32_t> frb_off, frb;
+  std::vector<int32_t> cq_row_bytes;
   std::vector<int32_t> tree_rows_asc;              // admitted rows of a tree in ascending row order (same offsets as tree_rows)
   std::vector<int32_t> frcount;                    // [N] flavor-resources with a SubtreeQuota entry (DRS iterates those)
   std::vector<int32_t> h_parent;                   // host copies kept for build_fair after a device derive
@@ -196,6 +200,29 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
   }
   p.tree_rows_asc = p.tree_rows;
   for (int t = 0; t < p.n_tree; t++) std::sort(p.tree_rows_asc.begin() + p.tree_row_off[t], p.tree_rows_asc.begin() + p.tree_row_off[t + 1]);
+  p.frb_off.assign((size_t)p.n_tree * p.nfr + 1, 0);
+  p.cq_row_bytes.assign(nq, 0);
+  {
+    auto first_use = [&](int row, int e) { for (int q = s->adm_use_off[row]; q < e; q++) if (s->adm_use_fr[q] == s->adm_use_fr[e]) return false; return true; };
+    for (int r = 0; r < p.n_adm; r++) {
+      p.cq_row_bytes[p.adm_cq[r]] += 32 + 12 * (s->adm_use_off[r + 1] - s->adm_use_off[r]);
+      const int t = p.tree_of[p.adm_cq[r]];
+      for (int e = s->adm_use_off[r]; e < s->adm_use_off[r + 1]; e++) {
+        const int fr = s->adm_use_fr[e];
+        if (fr < 0 || fr >= p.nfr) { p.err = "adm_use_fr out of range"; return KQ_EINVAL; }
+        if (first_use(r, e)) p.frb_off[(size_t)t * p.nfr + fr + 1]++;
+      }
+    }
+    for (size_t i = 0; i + 1 < p.frb_off.size(); i++) p.frb_off[i + 1] += p.frb_off[i];
+    p.frb.assign(p.frb_off.back(), 0);
+    std::vector<int32_t> fill(p.frb_off.begin(), p.frb_off.end() - 1);
+    for (int t = 0; t < p.n_tree; t++)
+      for (int i = p.tree_row_off[t]; i < p.tree_row_off[t + 1]; i++) {  // rank order => every bucket is ascending
+        const int r = p.tree_rows[i];
+        for (int e = s->adm_use_off[r]; e < s->adm_use_off[r + 1]; e++)
+          if (first_use(r, e)) p.frb[fill[(size_t)t * p.nfr + s->adm_use_fr[e]]++] = i - p.tree_row_off[t];
+      }
+  }
   p.rank_pos.assign(p.n_adm, 0);
   for (int t = 0; t < p.n_tree; t++)
     for (int i = p.tree_row_off[t]; i < p.tree_row_off[t + 1]; i++) p.rank_pos[p.tree_rows[i]] = i - p.tree_row_off[t];
