@@ -47,6 +47,7 @@ KQ_DEV void atomic_max_i32(int* p, int v) { if (v > *p) *p = v; }
 KQ_DEV void atomic_add_i64(long long* p, long long v) { *p += v; }
 KQ_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 KQ_DEV int64_t wsum_i64(int64_t v) { return v; }
+static int g_emu_pipeline = 0;  // tests: emulate the helper waves of k_process prefetching one chunk ahead
 }  // namespace kq
 #else
 #include <hip/hip_runtime.h>
@@ -413,7 +414,8 @@ struct Wave {
   int pc_on, pc_ncq, pc_ncoh;     // cache enabled, #CQs of the tree (node_local offset of cohorts), #cohorts
   int64_t* pc_lds;                // [2][pc_ncoh][nfr] : plane 0 = usage_work, plane 1 = usage_np
   int32_t path_coh[KQ_MAXD];      // cohort-local index of path[i] (i >= 1)
-  int32_t win_e[64], win_pos[64]; // this tree's entries inside the current 64-wide window of the order
+  int32_t win_e[256], win_pos[256]; // this tree's entries inside the current window of the order
+  int nwin2[2], chunk_done, chunk_stop;  // leader -> helper waves of the process workgroup
   // gathered cells of the entry under process: c = u * plen + i
   int64_t g_lq[CELLS], g_sq[CELLS], g_bl[CELLS], g_uw[CELLS], g_un[CELLS];
   uint8_t g_dirty[CELLS];
@@ -2095,7 +2097,8 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
 // there for the whole kernel), (3) results are written back in parallel.
 constexpr int FU = 8;    // max flavor-resources of an entry on the fast path
 constexpr int FD = 4;    // max path length (CQ + 3 cohort levels) on the fast path
-constexpr int CH = 32;   // entries per chunk
+constexpr int CH = 16;   // entries per chunk; two chunk buffers live in LDS (one being processed, one being prefetched)
+constexpr int NBUF = 2;
 struct PRec {
   int32_t e, pos, cq, plen, nuse, borrowing, mode, slow;
   uint32_t pol, flags;
@@ -2106,10 +2109,15 @@ struct PRec {
   uint8_t status, action, rq, skip, omode, dirty, pad[2];  // dirty: CQ-level usage cells changed
 };
 
-KQ_DEV void chunk_prefetch(const K& k, Wave& w, PRec* rec, const int32_t* ent, const int32_t* entpos, int nch) {
+// Fills the records of one chunk. No synchronisation inside: the thread that writes a record header and the threads
+// that fetch its (slot, level) cells all start from the global inputs (head -> ClusterQueue -> path -> quota cells), so
+// any subset of the workgroup's threads can run it while wave 0 is busy with the previous chunk.
+// prev / nprev: the chunk that is still being processed — its CQ-level cells are not in HBM yet, so an entry of the same
+// ClusterQueue must not take the prefetched values (slow path).
+KQ_DEV void chunk_prefetch(const K& k, const Wave& w, PRec* rec, const PRec* prev, int nprev, const int32_t* ent, const int32_t* entpos, int nch,
+                           int tid, int nthreads) {
   const DSnap& S = k.S; const DOut& O = k.O; const DHeads& H = k.H;
-  const int lane = lane_id();
-  for (int j = lane; j < nch; j += WAVE) {
+  for (int j = tid; j < nch; j += nthreads) {
     PRec& r = rec[j];
     const int e = ent[j];
     r.e = e; r.pos = entpos[j];
@@ -2119,31 +2127,30 @@ KQ_DEV void chunk_prefetch(const K& k, Wave& w, PRec* rec, const int32_t* ent, c
     const int nuse = (r.flags & KQ_HEAD_HAS_QUOTA_RESERVATION) ? 0 : O.use_n[e];  // netUsage scheduler.go:785-794
     r.nuse = nuse;
     int slow = (O.tgt_n[e] != 0 || nuse > FU || r.plen > FD || (r.plen > 1 && !w.pc_on)) ? 1 : 0;
-    if (!slow) {
-      for (int i = 1; i < r.plen; i++) r.coh[i] = S.node_local[S.path[(size_t)cq * KQ_MAXD + i]] - w.pc_ncq;
-      for (int u = 0; u < nuse; u++) { r.fr[u] = O.use_fr[(size_t)e * KQ_MAXU + u]; r.qty[u] = O.use_qty[(size_t)e * KQ_MAXU + u]; }
-    }
+    // a ClusterQueue seen earlier in this chunk or in the chunk still in flight would read a stale CQ-level cell
+    for (int q = 0; q < j; q++) if (H.cq[ent[q]] == cq) slow = 1;
+    for (int q = 0; q < nprev; q++) if (prev[q].cq == cq) slow = 1;
+    if (!slow) for (int i = 1; i < r.plen; i++) r.coh[i] = S.node_local[S.path[(size_t)cq * KQ_MAXD + i]] - w.pc_ncq;
     r.slow = slow; r.dirty = 0;
   }
-  wsync();
-  // a ClusterQueue seen twice in one chunk would read a stale CQ-level cell: second one takes the slow path
-  for (int j = lane; j < nch; j += WAVE) {
-    bool dup = false;
-    for (int q = 0; q < j; q++) if (rec[q].cq == rec[j].cq) dup = true;
-    if (dup) rec[j].slow = 1;
-  }
-  wsync();
-  for (int idx = lane; idx < nch * FU * FD; idx += WAVE) {
+  for (int idx = tid; idx < nch * FU * FD; idx += nthreads) {
     const int j = idx / (FU * FD), u = (idx / FD) % FU, i = idx % FD;
     PRec& r = rec[j];
-    if (r.slow || u >= r.nuse || i >= r.plen) continue;
-    const int n = S.path[(size_t)r.cq * KQ_MAXD + i], fr = r.fr[u];
+    const int e = ent[j];
+    const int cq = H.cq[e];
+    const int nuse = (H.flags[e] & KQ_HEAD_HAS_QUOTA_RESERVATION) ? 0 : O.use_n[e];
+    if (u >= nuse || nuse > FU || i >= S.plen[cq] || S.plen[cq] > FD) continue;
+    const int fr = O.use_fr[(size_t)e * KQ_MAXU + u];
+    const int n = S.path[(size_t)cq * KQ_MAXD + i];
     const size_t o = ix(S, n, fr);
     const int64_t sqv = S.sq[o], llv = S.ll[o];
     r.sqv[u][i] = sqv; r.bl[u][i] = S.bl[o];
     r.lq[u][i] = llv != KQ_NIL_LIMIT ? i64max(0, a_sub(sqv, llv)) : 0;
-    if (i == 0) { r.nominal[u] = S.nominal[o]; r.uw0[u] = k.usage_work[o]; r.un0[u] = k.usage_np[o]; }
+    if (i == 0) { r.fr[u] = fr; r.qty[u] = O.use_qty[(size_t)e * KQ_MAXU + u]; r.nominal[u] = S.nominal[o]; r.uw0[u] = k.usage_work[o]; r.un0[u] = k.usage_np[o]; }
   }
+}
+KQ_DEV void chunk_prefetch_wave(const K& k, Wave& w, PRec* rec, const int32_t* ent, const int32_t* entpos, int nch) {
+  chunk_prefetch(k, w, rec, nullptr, 0, ent, entpos, nch, lane_id(), WAVE);
   wsync();
 }
 
@@ -2290,89 +2297,141 @@ KQ_DEV bool chunk_entry_fast(const K& k, Wave& w, int64_t* pcl, PRec& r, int64_t
 
 // one wave per root-cohort tree: drain the tree's entries in iterator order.
 // lds layout: [2 planes of the tree's cohort rows][CH records]; too small for the rows => they stay in HBM.
-KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, size_t lds_bytes) {
+// tid / nthreads: every wave of the workgroup helps with the parallel parts (record prefetch); wave 0 ("leader") runs the
+// serial core and the generic path. Workgroup-uniform control flow comes from LDS scalars read after a bsync().
+KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, size_t lds_bytes, int tid, int nthreads) {
   const DSnap& S = k.S; const DOut& O = k.O;
   const int n = k.H.n;
   const int lane = lane_id();
-  const size_t rec_bytes = sizeof(PRec) * CH;
-  if (lane == 0) {
+  const bool leader = tid < WAVE;
+  const size_t rec_bytes = sizeof(PRec) * CH * NBUF;
+  if (tid == 0) {
     w.pc_ncq = S.tree_cq_off[tree + 1] - S.tree_cq_off[tree];
     w.pc_ncoh = (S.tree_node_off[tree + 1] - S.tree_node_off[tree]) - w.pc_ncq;
     w.pc_lds = lds;
     w.pc_on = (w.pc_ncoh > 0 && lds_bytes >= rec_bytes && (size_t)w.pc_ncoh * S.nfr * 16 <= lds_bytes - rec_bytes) ? 1 : 0;
     w.np_broken = 0; w.n_pre = 0; w.broken[0] = w.broken[1] = w.broken[2] = w.broken[3] = 0;
+    w.nwin2[0] = w.nwin2[1] = 0; w.chunk_done = 0; w.chunk_stop = 0;
   }
-  wsync();
+  bsync();
   const bool chunked = lds_bytes >= rec_bytes;
   PRec* rec = (PRec*)((unsigned char*)lds + (lds_bytes - (chunked ? rec_bytes : 0)));
   bool loaded = false;
   int64_t bytes = 0;
-  constexpr int WIN = 64;  // entries of the global order examined per window (independent of the wave width)
-  for (int base = 0; base < n; base += WIN) {
-    // compact this window's entries of the tree (in order) into LDS lists
-    int nwin = 0;
-    for (int off = 0; off < WIN; off += WAVE) {
-      const int i = base + off + lane;
-      bool mine = false;
-      int e = 0;
-      if (i < n) { e = k.order_idx[i]; mine = S.tree_of[k.H.cq[e]] == tree; }
-      const uint64_t m = wballot(mine);
-      const int my = nwin + popc64(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-      if (mine) { w.win_e[my] = e; w.win_pos[my] = i; }
-      nwin += popc64(m);
+  constexpr int WIN = 256;  // entries of the global order examined per window (independent of the wave width)
+  for (int base = 0, par = 0; base < n; base += WIN, par ^= 1) {
+    // leader: compact this window's entries of the tree (in order) into LDS lists
+    if (leader) {
+      int nwin = 0;
+      for (int off = 0; off < WIN; off += WAVE) {
+        const int i = base + off + lane;
+        bool mine = false;
+        int e = 0;
+        if (i < n) { e = k.order_idx[i]; mine = S.tree_of[k.H.cq[e]] == tree; }
+        const uint64_t m = wballot(mine);
+        const int my = nwin + popc64(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+        if (mine) { w.win_e[my] = e; w.win_pos[my] = i; }
+        nwin += popc64(m);
+      }
+      if (lane == 0) w.nwin2[par] = nwin;
+      wsync();
     }
+    bsync();
+    const int nwin = w.nwin2[par];
     if (nwin == 0) continue;
-    wsync();
-    if (!loaded) { KQ_T0(); pc_load(k, w, lds, tree); loaded = true; KQ_TS(k, 8); }
+    if (!loaded) { if (leader) { KQ_T0(); pc_load(k, w, lds, tree); KQ_TS(k, 8); } loaded = true; }
     if (!chunked) {
-      for (int q = 0; q < nwin; q++) process_entry(k, w, w.win_e[q], w.win_pos[q], slot, tree);
+      if (leader) for (int q = 0; q < nwin; q++) process_entry(k, w, w.win_e[q], w.win_pos[q], slot, tree);
       continue;
     }
-    int done = 0;
+    // Chunks of CH entries, double buffered: while wave 0 walks chunk c (serial core), the other waves fetch the records of
+    // chunk c + 1. A chunk that stops early (generic path taken: it may touch HBM cells other records were fetched from)
+    // discards the prefetched buffer and restarts behind the entry it stopped at.
+#ifdef KQ_HOST_EMU
+    // single-threaded emulation of the pipeline: the "helper" prefetch of chunk c + 1 runs BEFORE chunk c is processed,
+    // i.e. the earliest it could ever run on the device
+    const bool helpers = nthreads > WAVE || g_emu_pipeline;
+#else
+    const bool helpers = nthreads > WAVE;
+#endif
+    int done = 0, cur = 0;
+    {
+      KQ_T0();
+      const int n0 = nwin < CH ? nwin : CH;
+      chunk_prefetch(k, w, rec, nullptr, 0, w.win_e, w.win_pos, n0, tid, nthreads);
+      bsync();
+      if (leader) KQ_TS(k, 10);
+    }
     while (done < nwin) {
       const int nch = (nwin - done) < CH ? (nwin - done) : CH;
-      KQ_T0();
-      chunk_prefetch(k, w, rec, w.win_e + done, w.win_pos + done, nch);
-      KQ_TS(k, 10);
-      int j = 0;
-      for (; j < nch; j++) {
-        PRec& r = rec[j];
-        if (r.slow || np_exact_mode(w)) {
-          // generic path (targets / recompute / oversize / usage_np no longer incremental). It reads and writes HBM for CQ-level cells, so the
-          // CQ-level values prefetched for the rest of the chunk may be stale afterwards: restart after it.
-          chunk_scatter(k, rec, j);  // earlier fast entries' CQ-level cells must be in HBM first
-          wsync();
-          process_entry(k, w, r.e, r.pos, slot, tree);
-          if (lane == 0) r.slow = 2;
-          wsync();
-          j++;
-          break;
+      const int next0 = done + nch;
+      const int nnext = (nwin - next0) < CH ? (nwin - next0) : CH;
+      PRec* rc = rec + cur * CH;
+      PRec* rn = rec + (cur ^ 1) * CH;
+#ifdef KQ_HOST_EMU
+      if (g_emu_pipeline && nnext > 0) chunk_prefetch(k, w, rn, rc, nch, w.win_e + next0, w.win_pos + next0, nnext, 0, 1);
+#endif
+      if (leader) {
+        KQ_T0();
+        int j = 0;
+        bool stopped = false;
+        for (; j < nch; j++) {
+          PRec& r = rc[j];
+          if (r.slow || np_exact_mode(w)) {
+            // generic path (targets / recompute / oversize / usage_np no longer incremental). It reads and writes HBM for
+            // CQ-level cells, so prefetched CQ-level values may be stale afterwards: stop the chunk behind it.
+            chunk_scatter(k, rc, j);  // earlier fast entries' CQ-level cells must be in HBM first
+            wsync();
+            process_entry(k, w, r.e, r.pos, slot, tree);
+            if (lane == 0) r.slow = 2;
+            wsync();
+            j++;
+            stopped = true;
+            break;
+          }
+          if (!chunk_entry_fast(k, w, lds, r, &bytes)) {
+            // not a PLAIN entry (Unlimited / over-large operands): exact generic path, then stop the chunk
+            chunk_scatter(k, rc, j);
+            wsync();
+            process_entry(k, w, r.e, r.pos, slot, tree);
+            if (lane == 0) r.slow = 2;
+            wsync();
+            j++;
+            stopped = true;
+            break;
+          }
         }
-        if (!chunk_entry_fast(k, w, lds, r, &bytes)) {
-          // not a PLAIN entry (Unlimited / over-large operands): exact generic path, then restart the chunk
-          chunk_scatter(k, rec, j);
-          wsync();
-          process_entry(k, w, r.e, r.pos, slot, tree);
-          if (lane == 0) r.slow = 2;
-          wsync();
-          j++;
-          break;
+        KQ_TS(k, 11);
+        wsync();
+        for (int q = lane; q < j; q += WAVE) {
+          const PRec& r = rc[q];
+          if (r.slow) continue;  // the generic path wrote its own result
+          O.status[r.e] = r.status; O.action[r.e] = r.action; O.requeue_reason[r.e] = r.rq; O.skip[r.e] = r.skip; O.mode[r.e] = r.omode;
+          O.order[r.e] = r.pos;
+        }
+        chunk_scatter(k, rc, j);
+        if (lane == 0) { w.chunk_done = j; w.chunk_stop = stopped ? 1 : 0; }
+        wsync();
+        KQ_TS(k, 12);
+      } else if (nnext > 0) {
+        chunk_prefetch(k, w, rn, rc, nch, w.win_e + next0, w.win_pos + next0, nnext, tid - WAVE, nthreads - WAVE);
+      }
+      bsync();
+      const int j = w.chunk_done;
+      const bool clean = j == nch && !w.chunk_stop;
+      if (clean && helpers) {
+        done = next0; cur ^= 1;  // the next chunk's records are ready
+      } else {
+        done += j;
+        if (done < nwin) {
+          const int nre = (nwin - done) < CH ? (nwin - done) : CH;
+          chunk_prefetch(k, w, rc, nullptr, 0, w.win_e + done, w.win_pos + done, nre, tid, nthreads);
+          bsync();
         }
       }
-      KQ_TS(k, 11);
-      wsync();
-      for (int q = lane; q < j; q += WAVE) {
-        const PRec& r = rec[q];
-        if (r.slow) continue;  // the generic path wrote its own result
-        O.status[r.e] = r.status; O.action[r.e] = r.action; O.requeue_reason[r.e] = r.rq; O.skip[r.e] = r.skip; O.mode[r.e] = r.omode;
-        O.order[r.e] = r.pos;
-      }
-      chunk_scatter(k, rec, j);
-      wsync();
-      KQ_TS(k, 12);
-      done += j;
     }
   }
+  if (!leader) return;
   if (lane == 0 && bytes) atomic_add_i64(O.stat_bytes, (long long)bytes);
   if (loaded) { KQ_T0(); pc_flush(k, w, lds, tree); KQ_TS(k, 9); }
 }
@@ -2653,7 +2712,7 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
       if (have_rec && !np_exact_mode(w)) {
         if (lane == 0) { w.win_e[0] = e; w.win_pos[0] = lpos; }
         wsync();
-        chunk_prefetch(k, w, rec, w.win_e, w.win_pos, 1);
+        chunk_prefetch_wave(k, w, rec, w.win_e, w.win_pos, 1);
         if (!rec->slow) {
           chunk_entry_fast(k, w, lds, *rec, &fast_bytes);
           wsync();

@@ -71,11 +71,12 @@ __global__ __launch_bounds__(256) void k_order_scatter(int n, const int32_t* ran
   if (i < n) order_idx[rank[i]] = i;
 }
 
-__global__ __launch_bounds__(64) void k_process(const K* __restrict__ kp, unsigned lds_bytes) {
+constexpr int PROCESS_THREADS = 1024;  // wave 0 runs the serial core; all 4 waves prefetch the entry records of a chunk
+__global__ __launch_bounds__(PROCESS_THREADS) void k_process(const K* __restrict__ kp, unsigned lds_bytes) {
   const K& k = *kp;
   __shared__ Wave w;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
-  process_tree(k, w, blockIdx.x, blockIdx.x, (int64_t*)dyn_lds, lds_bytes);
+  process_tree(k, w, blockIdx.x, blockIdx.x, (int64_t*)dyn_lds, lds_bytes, (int)threadIdx.x, PROCESS_THREADS);
 }
 
 // Fair sharing: the iterator pops interleave with processEntry (scheduler.go:358), so ordering and processing
@@ -275,13 +276,13 @@ struct HipBackend {
   }
   // dynamic LDS = [cohort rows (2 planes) of the largest tree, if they fit][CH prefetched entry records]
   void launch_process(const K& k, int n_tree, size_t cohort_rows_bytes) {
-    const size_t rec = sizeof(PRec) * CH, budget = 160 * 1024 - 8 * 1024;
+    const size_t rec = sizeof(PRec) * CH * NBUF, budget = 160 * 1024 - 8 * 1024;
     size_t lds = rec + (cohort_rows_bytes + rec <= budget ? cohort_rows_bytes : 0);
     if (lds > 48 * 1024 && lds != lds_attr) {
       chk(hipFuncSetAttribute((const void*)k_process, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
       lds_attr = lds;
     }
-    hipLaunchKernelGGL(k_process, dim3(n_tree), dim3(64), lds, stream, put_k(k, 1), (unsigned)lds);
+    hipLaunchKernelGGL(k_process, dim3(n_tree), dim3(PROCESS_THREADS), lds, stream, put_k(k, 1), (unsigned)lds);
     chk(hipGetLastError(), "k_process");
   }
   size_t lds_attr = 0, lds_attr_fair = 0;

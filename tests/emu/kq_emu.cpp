@@ -68,8 +68,9 @@ struct EmuBackend {
     // alternate between an LDS-sized cache and none so both code paths are exercised
     // rotate LDS budgets so the chunked/LDS-resident, chunked/HBM-rows and unchunked paths are all exercised
     std::vector<int64_t> lds(160 * 1024 / 8);
-    const size_t budgets[3] = {lds.size() * 8, sizeof(PRec) * CH + 64, 0};
-    for (int t = 0; t < n_tree; t++) { Wave w{}; process_tree(k, w, t, t, lds.data(), budgets[(t + rot) % 3]); }
+    const size_t budgets[3] = {lds.size() * 8, sizeof(PRec) * CH * NBUF + 64, 0};
+    for (int t = 0; t < n_tree; t++) { Wave w{}; g_emu_pipeline = ((t + rot) % 2); process_tree(k, w, t, t, lds.data(), budgets[(t + rot) % 3], 0, 1); }
+    g_emu_pipeline = 0;
     rot++;
     last_k = k;
   }

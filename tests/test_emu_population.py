@@ -6,11 +6,13 @@ from kueue_amd.api import make_config
 from kueue_amd.population import generate
 from tests.emu import kqe
 
+# the emulation rotates LDS budgets (period 3) and the one-chunk-ahead prefetch (period 2) per launch: 6+ cycles cover
+# every combination of the process kernel's code paths
 CASES = [
     ("cfg1", dict(cfg=1), [0, 3]),
-    ("cfg2", dict(cfg=2), [0, 9]),
-    ("cfg3-200cq", dict(cfg=3, n_cq=200, per_cq=6), [0, 5]),
-    ("cfg4c-60cq", dict(cfg=4, n_cq=60, per_cq=4), [0, 1, 3]),
+    ("cfg2", dict(cfg=2), [0, 9, 1, 2, 3, 4, 5]),
+    ("cfg3-200cq", dict(cfg=3, n_cq=200, per_cq=8), [0, 5, 1, 2, 3, 4, 6]),
+    ("cfg4c-60cq", dict(cfg=4, n_cq=60, per_cq=8), [0, 1, 3, 2, 4, 5, 6]),
 ]
 
 
