@@ -2272,6 +2272,107 @@ template <int PLEN, bool PLAIN> KQ_DEV bool core_run(const K& k, Wave& w, int64_
   return true;
 }
 
+#ifndef KQ_HOST_EMU
+// ---- quad core (device only) ------------------------------------------------------------------------------
+// The same computation with one lane per (flavor-resource slot, path level) cell: lane = slot * 4 + level, so the four
+// levels of a slot are one DPP quad. Each lane loads only its own cell and computes its own level's terms
+// (max(0, localQuota - usage), the borrowing-limit cap, LocalAvailable); the root-to-ClusterQueue recurrence of
+// `available` (resource_node.go:106-122) and the bubbling of addUsage (:144-152) become three quad_perm steps each
+// instead of a four-level dependent chain per lane. Plain operands only; anything else -> false (exact core).
+KQ_DEV int64_t dpp64_next(int64_t v) {  // value of the next lane of the quad (level + 1)
+  int lo = (int)v, hi = (int)(v >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0xF9, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0xF9, 0xf, 0xf, false);
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+KQ_DEV int64_t dpp64_prev(int64_t v) {  // value of the previous lane of the quad (level - 1)
+  int lo = (int)v, hi = (int)(v >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x90, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x90, 0xf, 0xf, false);
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+KQ_DEV int dpp32_prev(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x90, 0xf, 0xf, false); }
+KQ_DEV int64_t dpp64_lane0(int64_t v) {  // value of the quad's first lane (the ClusterQueue level)
+  int lo = (int)v, hi = (int)(v >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x00, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x00, 0xf, 0xf, false);
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+static_assert(FD == 4, "the quad core maps the path levels of a slot onto one DPP quad");
+KQ_DEV bool core_run_quad(const K& k, Wave& w, int64_t* pcl, PRec& r, int64_t* bytes) {
+  const int lane = lane_id();
+  const int plen = r.plen, nuse = r.nuse, mode = r.mode;
+  const int u = lane >> 2, i = lane & 3;
+  const bool act = u < nuse && i < plen;
+  const int total = w.pc_ncoh * k.S.nfr;
+  int64_t lq = 0, sq = 0, bl = KQ_NIL_LIMIT, un = 0, uw = 0, qty = 0, nominal = 0;
+  int cidx = 0;
+  if (act) {
+    lq = r.lq[u][i]; sq = r.sqv[u][i]; bl = r.bl[u][i];
+    if (i == 0) { uw = r.uw0[u]; un = r.un0[u]; qty = r.qty[u]; nominal = r.nominal[u]; }
+    else { cidx = r.coh[i] * k.S.nfr + r.fr[u]; uw = pcl[cidx]; un = pcl[total + cidx]; }
+  }
+  const bool hb = bl != KQ_NIL_LIMIT;
+  const uint64_t big = (uint64_t)lq | (uint64_t)sq | (uint64_t)un | (uint64_t)uw | (uint64_t)qty | (uint64_t)nominal | (hb ? (uint64_t)bl : 0ull);
+  if (wballot(act && big >= (uint64_t)PLAIN_LIMIT) != 0) return false;  // negatives and Unlimited land here too
+  // scheduler.fits: Available(cq, fr) on usage_np. Level terms in parallel, then root -> ClusterQueue in plen - 1 steps.
+  int64_t a = sq - un;  // the root lane's value; overwritten below for the other levels
+  const int64_t t = i64max(0, lq - un);
+  const int64_t wm = (sq - lq) - i64max(0, un - lq) + bl;
+  #pragma unroll
+  for (int s = 1; s < FD; s++) {
+    const int64_t up = dpp64_next(a);
+    if (i == plen - 1 - s) a = t + ((hb && wm < up) ? wm : up);
+  }
+  const bool bad = act && i == 0 && i64max(0, a) < qty;
+  const bool fits_ok = wballot(bad) == 0;
+  int status = KQ_ST_NOT_NOMINATED, action = KQ_ACT_NONE, rq = KQ_RQ_GENERIC, skip = KQ_SKIP_NONE;
+  bool add = false, reserve = false;
+  if (mode == M_PREEMPT) {  // no targets: reserveCapacityForUnreclaimablePreempt scheduler.go:538-543
+    rq = KQ_RQ_PREEMPTION_NO_CANDIDATES;
+    const bool can_always_reclaim = KQ_POL_RECLAIM(r.pol) == KQ_POLICY_ANY;
+    reserve = add = !can_always_reclaim || (gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS) && (r.flags & KQ_HEAD_IS_PREEMPTOR));
+  } else if (!fits_ok) {
+    status = KQ_ST_SKIPPED; skip = KQ_SKIP_NO_LONGER_FITS; rq = KQ_RQ_FAILED_AFTER_NOMINATION;  // scheduler.go:1167-1170
+  } else {
+    add = true; status = KQ_ST_ASSUMED; action = KQ_ACT_ADMIT;
+  }
+  if (add) {
+    *bytes += (int64_t)nuse * 8 * plen;
+    int64_t val = qty;  // meaningful in the quad's first lane
+    if (reserve) {  // quotaResourcesToReserve scheduler.go:796-814
+      if (r.borrowing > 0) val = !hb ? qty : i64min(qty, (nominal + bl) - uw);
+      else val = i64max(0, i64min(qty, nominal - uw));
+      if (act && i == 0 && val < 0) mark_broken(w, r.fr[u]);
+    }
+    val = dpp64_lane0(val);
+    // addUsage resource_node.go:144-152: level l receives what the levels below did not absorb
+    #pragma unroll
+    for (int plane = 0; plane < 2; plane++) {
+      const int64_t cur = plane == 0 ? uw : un;
+      const int64_t la = i64max(0, lq - cur);
+      int64_t v = val;
+      int go = i == 0 ? 1 : 0;
+      #pragma unroll
+      for (int s = 1; s < FD; s++) {
+        const int64_t pv = dpp64_prev(v), pla = dpp64_prev(la);
+        const int pgo = dpp32_prev(go);
+        if (i == s) { go = (pgo && pv > pla) ? 1 : 0; v = pv - pla; }
+      }
+      if (act && go) {
+        const int64_t nv = cur + v;
+        if (i == 0) { if (plane == 0) r.uw0[u] = nv; else r.un0[u] = nv; }
+        else pcl[(plane == 0 ? 0 : total) + cidx] = nv;
+      }
+    }
+    if (lane == 0) r.dirty = 1;
+    wsync_lds();  // cohort rows in LDS must be visible to the next entry's lanes
+  }
+  if (lane == 0) { r.status = (uint8_t)status; r.action = (uint8_t)action; r.rq = (uint8_t)rq; r.skip = (uint8_t)skip; r.omode = (uint8_t)mode; }
+  return true;
+}
+#endif
+
 // serial core dispatch for one fast entry; false => the entry needs the generic exact path
 KQ_DEV bool chunk_entry_fast(const K& k, Wave& w, int64_t* pcl, PRec& r, int64_t* bytes) {
   const int plen = r.plen, nuse = r.nuse, mode = r.mode;
@@ -2285,6 +2386,17 @@ KQ_DEV bool chunk_entry_fast(const K& k, Wave& w, int64_t* pcl, PRec& r, int64_t
     if (lane_id() == 0) { r.status = (uint8_t)status; r.action = (uint8_t)action; r.rq = (uint8_t)rq; r.skip = KQ_SKIP_NONE; r.omode = (uint8_t)mode; }
     return true;
   }
+#ifndef KQ_HOST_EMU
+  if (core_run_quad(k, w, pcl, r, bytes)) { *bytes += (int64_t)nuse * 40 * plen; return true; }
+  switch (plen) {  // not plain: exact Amount arithmetic, one lane per slot
+    case 1: core_run<1, false>(k, w, pcl, r, bytes); break;
+    case 2: core_run<2, false>(k, w, pcl, r, bytes); break;
+    case 3: core_run<3, false>(k, w, pcl, r, bytes); break;
+    default: core_run<4, false>(k, w, pcl, r, bytes); break;
+  }
+  *bytes += (int64_t)nuse * 40 * plen;
+  return true;
+#endif
   switch (plen) {
     case 1: if (!core_run<1, true>(k, w, pcl, r, bytes)) core_run<1, false>(k, w, pcl, r, bytes); break;
     case 2: if (!core_run<2, true>(k, w, pcl, r, bytes)) core_run<2, false>(k, w, pcl, r, bytes); break;
