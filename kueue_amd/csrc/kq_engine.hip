@@ -149,8 +149,12 @@ __global__ __launch_bounds__(256) void k_derive_level(DSnap S, DDerive d, int de
 // TAS: one wavefront per workload (FindTopologyAssignmentsForFlavor), grid-stride over the batch
 __global__ __launch_bounds__(64) void k_tas_find(const TK* __restrict__ kp, int slots) {
   const TK& k = *kp;
-  for (int w = blockIdx.x; w < k.Q.n_wl; w += slots) t_workload(k, blockIdx.x, w);
+  // workloads are sorted by request class; a slot walks a contiguous piece so that it rarely changes class
+  const int per = (k.Q.n_wl + slots - 1) / slots;
+  const int lo = blockIdx.x * per, hi = (lo + per) < k.Q.n_wl ? (lo + per) : k.Q.n_wl;
+  for (int i = lo; i < hi; i++) t_workload(k, blockIdx.x, k.C.order[i]);
 }
+__global__ __launch_bounds__(64) void k_tas_classes(const TK* __restrict__ kp) { t_class(*kp, blockIdx.x); }
 __global__ __launch_bounds__(64) void k_tas_usage(TTopo T, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int add) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i < n) t_usage_cell(T, i, leaf, count, spr, add);
@@ -220,10 +224,18 @@ struct HipBackend {
   }
   TK* dtk = nullptr;
   TK htk;
-  void launch_tas_find(const TK& k, int slots) {
+  void put_tk(const TK& k) {
     if (!dtk) chk(hipMalloc((void**)&dtk, sizeof(TK)), "hipMalloc TK");
     htk = k;
     chk(hipMemcpyAsync(dtk, &htk, sizeof(TK), hipMemcpyHostToDevice, stream), "memcpy TK");
+  }
+  void launch_tas_classes(const TK& k) {
+    put_tk(k);
+    hipLaunchKernelGGL(k_tas_classes, dim3(k.C.n), dim3(64), 0, stream, (const TK*)dtk);
+    chk(hipGetLastError(), "k_tas_classes");
+  }
+  void launch_tas_find(const TK& k, int slots) {
+    put_tk(k);
     hipLaunchKernelGGL(k_tas_find, dim3(slots), dim3(64), 0, stream, (const TK*)dtk, slots);
     chk(hipGetLastError(), "k_tas_find");
   }

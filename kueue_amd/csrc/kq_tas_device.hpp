@@ -50,15 +50,37 @@ struct TScratch {  // per wave slot
   int32_t *set, *arr, *cur, *nxt;       // [slots][n_leaves] id lists: the slice being sorted, its materialised prefix, currFitDomain x2
   uint64_t *k0, *k1;                    // [slots][n_leaves] sort keys of `set`
   int64_t* assumed;                     // [slots][n_leaves][R] assumedUsage of the workload (:586)
+  int32_t* log;                         // [slots][max_set] domains whose state phase 2 changed
+  int32_t* meta;                        // [slots][4] log length, state no longer restorable, class the state was copied from
   int32_t max_set;
 };
-struct TK { TTopo T; TReq Q; TOut O; TScratch X; };
+// Phase 1 only depends on (requests, leader requests, simulate-empty, slice size / level) — not on the pod count, the
+// requested level or required / preferred / unconstrained. Workloads with one podset group and no feasibility mask are
+// grouped into request classes on the host; phase 1 runs once per class (k_tas_classes) and a workload starts phase 2
+// from its class's table. Phase 2 changes the state of the few domains it consumes: those are logged and restored.
+struct TClass {
+  int n;
+  const int32_t *workers, *leader;  // [n] representative podset requests (leader = -1: none)
+  const uint8_t* sim_empty;         // [n]
+  int32_t *pc, *sc, *pcwl, *scwl, *lc;  // [n][D]
+  long long* bytes;                 // [n] algorithmic bytes of one phase 1 of the class
+  const int32_t* wl_class;          // [n_wl] class of the workload, -1 = private phase 1
+  const int32_t* order;             // [n_wl] workloads sorted by class: a slot walks a contiguous piece
+};
+struct TK { TTopo T; TReq Q; TOut O; TScratch X; TClass C; };
 
 struct TState {  // per-slot pointers
   int32_t *pc, *sc, *pcwl, *scwl, *lc, *set, *arr, *cur, *nxt;
   uint64_t *k0, *k1;
   int64_t* assumed;
+  int32_t *log, *meta;
+  int logcap;
 };
+// lane 0 records a domain whose state it is about to change
+KQ_DEV void t_touch(const TState& s, int d) {
+  const int n = s.meta[0];
+  if (n < s.logcap) { s.log[n] = d; s.meta[0] = n + 1; } else s.meta[1] = 1;
+}
 KQ_DEV TState tas_state(const TK& k, int slot) {
   TState s;
   const size_t D = k.T.D, M = k.X.max_set;
@@ -66,6 +88,7 @@ KQ_DEV TState tas_state(const TK& k, int slot) {
   s.set = k.X.set + slot * M; s.arr = k.X.arr + slot * M; s.cur = k.X.cur + slot * M; s.nxt = k.X.nxt + slot * M;
   s.k0 = k.X.k0 + slot * M; s.k1 = k.X.k1 + slot * M;
   s.assumed = k.X.assumed + (size_t)slot * k.T.n_leaves * k.T.R;
+  s.log = k.X.log + slot * M; s.meta = k.X.meta + (size_t)slot * 4; s.logcap = (int)M;
   return s;
 }
 
@@ -97,7 +120,7 @@ KQ_DEV int32_t t_count_in(const TK& k, const int64_t* req, const int64_t* rem) {
 constexpr int KQ_TAS_MAXR = 16;
 
 // fillInCounts :1800 = fillLeafCounts for every feasible leaf + fillInCountsHelper roll-up
-KQ_DEV void t_fill_in_counts(const TK& k, const TState& s, const TParams& p) {
+KQ_DEV void t_fill_in_counts(const TK& k, const TState& s, const TParams& p, long long* bytes_out) {
   const TTopo& T = k.T;
   const int lane = lane_id();
   for (int d = lane; d < T.leaf_base; d += WAVE) { s.pc[d] = 0; s.sc[d] = 0; s.pcwl[d] = 0; s.scwl[d] = 0; s.lc[d] = 0; }
@@ -153,7 +176,7 @@ KQ_DEV void t_fill_in_counts(const TK& k, const TState& s, const TParams& p) {
     wsync();
   }
   const int64_t tot = wsum_i64(lb);
-  if (lane == 0) atomic_add_i64(k.O.bytes, (long long)(tot + (int64_t)T.R * 8));
+  if (lane == 0) atomic_add_i64(bytes_out, (long long)(tot + (int64_t)T.R * 8));
 }
 
 // ---- lazily sorted slice of domains -------------------------------------------------------------------
@@ -203,14 +226,27 @@ KQ_DEV TView t_view(const TK& k, const TState& s, int n, int order, bool unconst
 // t_dom(*o1)); false if no element is accepted
 template <class SEL> KQ_DEV bool t_argmin(const TState& s, const TView& v, const SEL& sel, uint64_t* o0, uint64_t* o1, bool with_excluded = false) {
   uint64_t b0 = ~0ull, b1 = ~0ull;
-  for (int i = lane_id(); i < v.n; i += WAVE) {
-    uint64_t a0 = s.k0[i];
-    const uint64_t a1 = s.k1[i];
-    if (a0 & KQ_TAS_EXCLUDED) { if (!with_excluded) continue; a0 &= ~KQ_TAS_EXCLUDED; }
-    if (!sel.take(a0, a1)) continue;
-    uint64_t x0 = a0, x1 = a1;
-    sel.rank(&x0, &x1);
-    if (t_key_lt(x0, x1, b0, b1)) { b0 = x0; b1 = x1; }
+  // a lone wave is latency-bound: fetch the keys of UNR strided elements before looking at any of them
+  constexpr int UNR = 8;
+  for (int base = lane_id(); base < v.n; base += WAVE * UNR) {
+    uint64_t k0v[UNR], k1v[UNR];
+    #pragma unroll
+    for (int q = 0; q < UNR; q++) {
+      const int i = base + q * WAVE;
+      k0v[q] = i < v.n ? s.k0[i] : KQ_TAS_EXCLUDED;
+      k1v[q] = i < v.n ? s.k1[i] : 0;
+    }
+    #pragma unroll
+    for (int q = 0; q < UNR; q++) {
+      if (base + q * WAVE >= v.n) continue;
+      uint64_t a0 = k0v[q];
+      const uint64_t a1 = k1v[q];
+      if (a0 & KQ_TAS_EXCLUDED) { if (!with_excluded) continue; a0 &= ~KQ_TAS_EXCLUDED; }
+      if (!sel.take(a0, a1)) continue;
+      uint64_t x0 = a0, x1 = a1;
+      sel.rank(&x0, &x1);
+      if (t_key_lt(x0, x1, b0, b1)) { b0 = x0; b1 = x1; }
+    }
   }
   const uint64_t m0 = wmin_u64(b0);
   const uint64_t m1 = wmin_u64(b0 == m0 ? b1 : ~0ull);
@@ -343,14 +379,14 @@ KQ_DEV bool t_consume_with_leaders(const TK& k, const TState& s, TView& v, int i
   bool completed;
   if (withLeader[d] >= *remainingPrimary && s.lc[d] >= *remainingLeaderCount) {
     wsync();
-    if (lane_id() == 0) { primary[d] = *remainingPrimary; s.lc[d] = *remainingLeaderCount; s.pc[d] = *remainingPrimary * sliceSize; }
+    if (lane_id() == 0) { t_touch(s, d); primary[d] = *remainingPrimary; s.lc[d] = *remainingLeaderCount; s.pc[d] = *remainingPrimary * sliceSize; }
     completed = true;
   } else {
     int32_t wl = withLeader[d], lcv = s.lc[d];
     if (wl > *remainingPrimary) wl = *remainingPrimary;
     if (lcv > *remainingLeaderCount) lcv = *remainingLeaderCount;
     wsync();
-    if (lane_id() == 0) { withLeader[d] = wl; s.lc[d] = lcv; primary[d] = wl; s.pc[d] = wl * sliceSize; }
+    if (lane_id() == 0) { t_touch(s, d); withLeader[d] = wl; s.lc[d] = lcv; primary[d] = wl; s.pc[d] = wl * sliceSize; }
     *remainingLeaderCount -= lcv;
     *remainingPrimary -= wl;
     completed = false;
@@ -384,12 +420,12 @@ KQ_DEV int t_update_counts(const TK& k, const TState& s, int n, int order, int32
       const int32_t scv = s.sc[dom];
       wsync();
       if (scv >= remainingPrimary) {
-        if (lane_id() == 0) { s.lc[dom] = 0; s.pc[dom] = remainingPrimary * sliceSize; s.sc[dom] = remainingPrimary; out[out_n] = dom; }
+        if (lane_id() == 0) { t_touch(s, dom); s.lc[dom] = 0; s.pc[dom] = remainingPrimary * sliceSize; s.sc[dom] = remainingPrimary; out[out_n] = dom; }
         out_n++;
         wsync();
         return out_n;
       }
-      if (lane_id() == 0) { s.lc[dom] = 0; s.pc[dom] = scv * sliceSize; out[out_n] = dom; }
+      if (lane_id() == 0) { t_touch(s, dom); s.lc[dom] = 0; s.pc[dom] = scv * sliceSize; out[out_n] = dom; }
       remainingPrimary -= scv;
       out_n++;
       wsync();
@@ -399,12 +435,12 @@ KQ_DEV int t_update_counts(const TK& k, const TState& s, int n, int order, int32
     const int32_t pcv = s.pc[dom];
     wsync();
     if (pcv >= remainingPrimary) {
-      if (lane_id() == 0) { s.lc[dom] = 0; s.pc[dom] = remainingPrimary; out[out_n] = dom; }
+      if (lane_id() == 0) { t_touch(s, dom); s.lc[dom] = 0; s.pc[dom] = remainingPrimary; out[out_n] = dom; }
       out_n++;
       wsync();
       return out_n;
     }
-    if (lane_id() == 0) { s.lc[dom] = 0; out[out_n] = dom; }
+    if (lane_id() == 0) { t_touch(s, dom); s.lc[dom] = 0; out[out_n] = dom; }
     remainingPrimary -= pcv;
     out_n++;
     wsync();
@@ -521,6 +557,47 @@ KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* 
           for (int i = lane_id(); i < m; i += WAVE) s.set[i] = s.nxt[i];
           wsync();
         }
+        if (lfc && idx == 0 && m > 128 && k.X.max_set >= 128) {  // 64 int64 bins live in s.nxt
+          // LeastFreeCapacity walks the slice in ascending sliceCount until the capacity adds up (:1425-1436). Every
+          // domain whose sliceCount lies below the value at which the running sum reaches the target is taken whole, in
+          // any order (none of them can hold the remainder on its own, so updateCountsToMinimumGeneric consumes each of
+          // them entirely); only the domains AT that value need the slice order. One histogram pass finds the value.
+          constexpr int NB = 64;  // sliceCount values >= NB - 1 share the last bin (its members are ordered by the view)
+          long long* bins = (long long*)s.nxt;
+          for (int b = lane_id(); b < NB; b += WAVE) bins[b] = 0;
+          wsync();
+          for (int i = lane_id(); i < m; i += WAVE) {
+            const int32_t scv = s.sc[s.set[i]];
+            if (scv > 0) atomic_add_i64(&bins[scv < NB - 1 ? scv : NB - 1], (long long)scv);
+          }
+          wsync();
+          int tb = -1;
+          int64_t cum = 0;
+          for (int b = 0; b < NB; b++) {
+            const int64_t v = bins[b];
+            if (cum + v >= (int64_t)remainingSliceCount) { tb = b; break; }
+            cum += v;
+          }
+          if (tb < 0) return TFail{KQ_TAS_NOT_FIT, (int32_t)cum, sliceCount};
+          // below the threshold -> results; at the threshold -> the slice the loop below still has to order
+          int m2 = 0;
+          for (int base = 0; base < m; base += WAVE) {
+            const int i = base + lane_id();
+            int d = 0, bin = -1;
+            if (i < m) { d = s.set[i]; const int32_t scv = s.sc[d]; bin = scv > 0 ? (scv < NB - 1 ? scv : NB - 1) : -1; }
+            const uint64_t lo = wballot(bin >= 0 && bin < tb), at = wballot(bin == tb);
+            const uint64_t below_me = (lane_id() == 0) ? 0ull : (~0ull >> (64 - lane_id()));
+            if (bin >= 0 && bin < tb) s.cur[nres + popc64(lo & below_me)] = d;
+            if (bin == tb) s.arr[m2 + popc64(at & below_me)] = d;
+            nres += popc64(lo);
+            m2 += popc64(at);
+          }
+          wsync();
+          for (int i = lane_id(); i < m2; i += WAVE) s.set[i] = s.arr[i];
+          wsync();
+          remainingSliceCount -= (int32_t)cum;
+          m = m2;
+        }
         TView r = t_view(k, s, m, ORD_PLAIN, st.unconstrained);
         for (int i = 0; remainingSliceCount > 0; i++) {
           int domain = t_get(s, r, i);
@@ -545,9 +622,9 @@ KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* 
 
 // findTopologyAssignment :886. On success the leaves of the assignment are in s.cur[0..*nfit) with their pod / leader
 // counts in s.pc / s.lc.
-KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, int* nfit) {
+KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, int* nfit, bool have_counts) {
   const TTopo& T = k.T;
-  t_fill_in_counts(k, s, st);
+  if (!have_counts) t_fill_in_counts(k, s, st, k.O.bytes);
   int fitLevelIdx = 0, ncur = 0;
   TFail f = t_find_level(k, s, st, &fitLevelIdx, &ncur);
   if (f.status != KQ_TAS_OK) return f;
@@ -583,7 +660,7 @@ KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, 
       const int d = s.cur[j], c0 = T.child_first[d], cn = T.child_cnt[d];
       for (int i = lane_id(); i < cn; i += WAVE) {
         s.set[i] = c0 + i;
-        if (sliceSizeOnLevel > 1) { s.sc[c0 + i] = s.pc[c0 + i] / sliceSizeOnLevel; s.scwl[c0 + i] = s.pcwl[c0 + i] / sliceSizeOnLevel; }
+        if (sliceSizeOnLevel > 1) { s.sc[c0 + i] = s.pc[c0 + i] / sliceSizeOnLevel; s.scwl[c0 + i] = s.pcwl[c0 + i] / sliceSizeOnLevel; s.meta[1] = 1; }
       }
       wsync();
       const int32_t dpc = s.pc[d], dlc = s.lc[d];
@@ -649,6 +726,7 @@ KQ_DEV void t_workload(const TK& k, int slot, int w) {
     if (firstOfGroup) ngroups++;
   }
   const bool track = ngroups > 1;
+  if (lane == 0) s.meta[0] = 0;
   if (track) { for (int i = lane; i < T.n_leaves * T.R; i += WAVE) s.assumed[i] = 0; wsync(); }
   bool failed = false, hasAssumed = false;
   for (int p = p0; p < p1; p++) {
@@ -680,7 +758,27 @@ KQ_DEV void t_workload(const TK& k, int slot, int w) {
     if (st.sliceSize <= 0) f = TFail{KQ_TAS_BAD_SLICE_SIZE, 0, 0};
     else if (st.requestedLevelIdx < 0 || st.requestedLevelIdx >= T.L || st.sliceLevelIdx < 0 || st.sliceLevelIdx >= T.L) f = TFail{KQ_TAS_NO_LEVEL, 0, 0};
     else if (st.requestedLevelIdx > st.sliceLevelIdx) f = TFail{KQ_TAS_SLICE_ABOVE, 0, 0};
-    else f = t_find_assignment(k, s, st, &ncur);
+    else {
+      const int cls = k.C.n > 0 ? k.C.wl_class[w] : -1;
+      bool have = false;
+      if (cls >= 0) {
+        // start from the class's phase-1 table; the slot keeps it between workloads of the same class
+        if (s.meta[2] != cls || s.meta[1]) {
+          wsync();
+          for (int d = lane; d < T.D; d += WAVE) {
+            const size_t o = (size_t)cls * T.D + d;
+            s.pc[d] = k.C.pc[o]; s.sc[d] = k.C.sc[o]; s.pcwl[d] = k.C.pcwl[o]; s.scwl[d] = k.C.scwl[o]; s.lc[d] = k.C.lc[o];
+          }
+          if (lane == 0) { s.meta[1] = 0; s.meta[2] = cls; }
+        }
+        if (lane == 0) { s.meta[0] = 0; atomic_add_i64(O.bytes, k.C.bytes[cls]); }
+        wsync();
+        have = true;
+      } else if (lane == 0) {
+        s.meta[2] = -1;
+      }
+      f = t_find_assignment(k, s, st, &ncur, have);
+    }
     if (f.status != KQ_TAS_OK) { set_all(f.status, f.a, f.b); failed = true; continue; }
     if (lane == 0) { O.status[workers] = KQ_TAS_OK; O.op_a[workers] = 0; O.op_b[workers] = 0; if (leader >= 0) { O.status[leader] = KQ_TAS_OK; O.op_a[leader] = 0; O.op_b[leader] = 0; } }
     // addAssumedUsage :734 before the leader's copies of the counts are consumed
@@ -699,6 +797,35 @@ KQ_DEV void t_workload(const TK& k, int slot, int w) {
     if (leader >= 0) t_emit(k, s, ncur, 1, leader);
     t_emit(k, s, ncur, 0, workers);
   }
+  // put the class table's values back into the domains phase 2 consumed
+  if (s.meta[2] >= 0 && !s.meta[1]) {
+    const int cls = s.meta[2], nlog = s.meta[0];
+    wsync();
+    for (int i = lane; i < nlog; i += WAVE) {
+      const int d = s.log[i];
+      const size_t o = (size_t)cls * T.D + d;
+      s.pc[d] = k.C.pc[o]; s.sc[d] = k.C.sc[o]; s.pcwl[d] = k.C.pcwl[o]; s.scwl[d] = k.C.scwl[o]; s.lc[d] = k.C.lc[o];
+    }
+    wsync();
+  }
+}
+// phase 1 of request class c into the class tables
+KQ_DEV void t_class(const TK& k, int c) {
+  const TTopo& T = k.T; const TReq& Q = k.Q;
+  TState s{};
+  s.pc = k.C.pc + (size_t)c * T.D; s.sc = k.C.sc + (size_t)c * T.D; s.pcwl = k.C.pcwl + (size_t)c * T.D;
+  s.scwl = k.C.scwl + (size_t)c * T.D; s.lc = k.C.lc + (size_t)c * T.D;
+  const int workers = k.C.workers[c], leader = k.C.leader[c];
+  TParams st{};
+  st.count = Q.count[workers]; st.leaderCount = leader >= 0 ? 1 : 0; st.sliceSize = Q.slice_size[workers];
+  st.sliceLevelIdx = Q.slice_level[workers]; st.requestedLevelIdx = Q.level[workers];
+  st.simulateEmpty = k.C.sim_empty[c] != 0; st.hasAssumed = false;
+  st.req = Q.spr + (size_t)workers * T.R; st.leaderReq = leader >= 0 ? Q.spr + (size_t)leader * T.R : nullptr;
+  st.leafOk = nullptr;
+  if (lane_id() == 0) k.C.bytes[c] = 0;
+  wsync();
+  if (st.sliceSize <= 0 || st.sliceLevelIdx < 0 || st.sliceLevelIdx >= T.L) return;  // the workloads of the class fail before phase 1
+  t_fill_in_counts(k, s, st, k.C.bytes + c);
 }
 
 }  // namespace kq

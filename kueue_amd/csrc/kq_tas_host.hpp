@@ -3,6 +3,8 @@
 #pragma once
 #include <algorithm>
 #include <cstring>
+#include <numeric>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -17,7 +19,8 @@ template <class Backend> struct TasT {
   TTopo T{};
   std::vector<void*> topo_allocs;
   struct Buf { void* p = nullptr; size_t cap = 0; };
-  Buf bq[12], bo[8], bx[13];
+  Buf bq[12], bo[8], bx[15], bc[12];
+  bool use_classes = true;  // tests can switch the shared phase 1 off
   double last_ms = 0;
   int64_t last_bytes = 0;
 
@@ -48,6 +51,7 @@ template <class Backend> struct TasT {
     for (auto& b : bq) if (b.p) be.free(b.p);
     for (auto& b : bo) if (b.p) be.free(b.p);
     for (auto& b : bx) if (b.p) be.free(b.p);
+    for (auto& b : bc) if (b.p) be.free(b.p);
   }
 
   int topology_put(const kq_tas_topology* t) {
@@ -114,13 +118,58 @@ template <class Backend> struct TasT {
     O.pool_used = (int32_t*)misc; O.error = (int32_t*)misc + 1; O.bytes = (long long*)(misc + 1);
     const int slots = std::min(nw, be.max_slots());
     TScratch& X = k.X;
-    X.max_set = std::max(T.n_leaves, T.D - T.n_leaves + 1) + 1;
+    X.max_set = (std::max(T.n_leaves, T.D - T.n_leaves + 1) + 1 + 15) & ~15;  // per-slot lists start 64-byte aligned (s.nxt doubles as int64 bins)
     const size_t sd = (size_t)slots * T.D, sm = (size_t)slots * X.max_set;
     X.pc = grow<int32_t>(bx[0], sd); X.sc = grow<int32_t>(bx[1], sd); X.pcwl = grow<int32_t>(bx[2], sd); X.scwl = grow<int32_t>(bx[3], sd); X.lc = grow<int32_t>(bx[4], sd);
     X.set = grow<int32_t>(bx[5], sm); X.arr = grow<int32_t>(bx[6], sm + slots); X.cur = grow<int32_t>(bx[7], sm); X.nxt = grow<int32_t>(bx[8], sm);
     X.k0 = (uint64_t*)grow<int64_t>(bx[9], sm); X.k1 = (uint64_t*)grow<int64_t>(bx[10], sm);
     X.assumed = grow<int64_t>(bx[11], (size_t)slots * T.n_leaves * T.R);
+    X.log = grow<int32_t>(bx[12], sm); X.meta = grow<int32_t>(bx[13], (size_t)slots * 4);
+    be.memset(X.meta, 0xff, (size_t)slots * 4 * sizeof(int32_t));
+    // request classes: workloads with one podset group and no feasibility mask share phase 1 when their requests,
+    // leader requests, simulate-empty flag and slice parameters are identical
+    std::vector<int32_t> wl_class(nw, -1), order(nw), c_workers, c_leader;
+    std::vector<uint8_t> c_sim;
+    if (use_classes && !r->leaf_ok) {
+      std::unordered_map<std::string, int> ids;
+      ids.reserve(64);
+      for (int w = 0; w < nw; w++) {
+        const int p0 = r->wl_off[w], p1 = r->wl_off[w + 1];
+        if (p1 - p0 < 1 || p1 - p0 > 2) continue;
+        if (p1 - p0 == 2 && (r->group[p0] < 0 || r->group[p0] != r->group[p0 + 1])) continue;
+        int workers = p0, leader = -1;
+        if (p1 - p0 == 2) { leader = p0 + 1; if (r->count[leader] > r->count[workers]) { leader = p0; workers = p0 + 1; } }
+        std::string key((const char*)(r->single_pod_requests + (size_t)workers * T.R), (size_t)T.R * 8);
+        if (leader >= 0) key.append((const char*)(r->single_pod_requests + (size_t)leader * T.R), (size_t)T.R * 8); else key.append("-");
+        const int32_t tail[3] = {r->slice_size[workers], r->slice_level[workers], r->simulate_empty ? (int32_t)r->simulate_empty[w] : 0};
+        key.append((const char*)tail, sizeof(tail));
+        auto it = ids.find(key);
+        if (it == ids.end()) {
+          it = ids.emplace(key, (int)c_workers.size()).first;
+          c_workers.push_back(workers); c_leader.push_back(leader); c_sim.push_back((uint8_t)tail[2]);
+        }
+        wl_class[w] = it->second;
+      }
+    }
+    {  // counting sort by class, private-phase-1 workloads (-1) last
+      const int nc = (int)c_workers.size();
+      std::vector<int> start(nc + 2, 0);
+      for (int w = 0; w < nw; w++) start[(wl_class[w] < 0 ? nc : wl_class[w]) + 1]++;
+      for (int c = 0; c <= nc; c++) start[c + 1] += start[c];
+      for (int w = 0; w < nw; w++) order[start[wl_class[w] < 0 ? nc : wl_class[w]]++] = w;
+    }
+    TClass& Cc = k.C;
+    Cc.n = (int)c_workers.size();
+    Cc.wl_class = stage(bc[0], wl_class.data(), nw);
+    Cc.order = stage(bc[1], order.data(), nw);
+    if (Cc.n > 0) {
+      Cc.workers = stage(bc[2], c_workers.data(), Cc.n); Cc.leader = stage(bc[3], c_leader.data(), Cc.n); Cc.sim_empty = stage(bc[4], c_sim.data(), Cc.n);
+      const size_t cd = (size_t)Cc.n * T.D;
+      Cc.pc = grow<int32_t>(bc[5], cd); Cc.sc = grow<int32_t>(bc[6], cd); Cc.pcwl = grow<int32_t>(bc[7], cd); Cc.scwl = grow<int32_t>(bc[8], cd); Cc.lc = grow<int32_t>(bc[9], cd);
+      Cc.bytes = (long long*)grow<int64_t>(bc[10], Cc.n);
+    }
     be.timer_mark(0);
+    if (Cc.n > 0) be.launch_tas_classes(k);
     be.launch_tas_find(k, slots);
     be.timer_mark(1);
     std::vector<int32_t> hp((size_t)n * 5);

@@ -12,7 +12,7 @@ BLOCK, RACK = "cloud.provider.com/topology-block", "cloud.provider.com/topology-
 TAS_SEED = 20260921 + 5
 
 
-def generate_tas(n_workloads: int = 50_000, seed: int = TAS_SEED, blocks: int = 8, racks: int = 8, hosts: int = 64):
+def generate_tas(n_workloads: int = 50_000, seed: int = TAS_SEED, blocks: int = 8, racks: int = 8, hosts: int = 64, kinds=(0, 1, 2)):
     rng = np.random.default_rng(seed)
     levels = [BLOCK, RACK, T.HOSTNAME_LABEL]
     nodes = []
@@ -32,7 +32,7 @@ def generate_tas(n_workloads: int = 50_000, seed: int = TAS_SEED, blocks: int = 
     use[:, ri["pods"]] = (frac * 60).astype(np.int64)
     cpu_classes = np.array([500, 1250, 2500])
     workloads = []
-    kinds = rng.integers(0, 3, size=n_workloads)            # required / preferred / unconstrained
+    kinds = np.asarray(kinds)[rng.integers(0, len(kinds), size=n_workloads)]   # required / preferred / unconstrained
     lvls = rng.integers(0, 2, size=n_workloads)              # block / rack
     counts = rng.integers(1, 65, size=n_workloads)
     cls = rng.integers(0, 3, size=n_workloads)

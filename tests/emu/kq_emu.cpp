@@ -28,7 +28,12 @@ struct EmuBackend {
   int max_slots() { return 7; }  // small on purpose: exercises the grid-stride loop over heads
   void timer_mark(int) {}
   double timer_ms(int, int) { return 0; }
-  void launch_tas_find(const TK& k, int slots) { for (int slot = 0; slot < slots; slot++) for (int w = slot; w < k.Q.n_wl; w += slots) t_workload(k, slot, w); }
+  void launch_tas_classes(const TK& k) { for (int c = 0; c < k.C.n; c++) t_class(k, c); }
+  void launch_tas_find(const TK& k, int slots) {
+    const int per = (k.Q.n_wl + slots - 1) / slots;
+    for (int slot = 0; slot < slots; slot++)
+      for (int i = slot * per; i < (slot + 1) * per && i < k.Q.n_wl; i++) t_workload(k, slot, k.C.order[i]);
+  }
   void launch_tas_usage(const TTopo& T, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int add) { for (int i = 0; i < n; i++) t_usage_cell(T, i, leaf, count, spr, add); }
   void launch_tas_fits(const TTopo& T, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t* flag) { for (int i = 0; i < n; i++) t_fits_cell(T, i, leaf, count, spr, flag); }
   K last_k{};
@@ -97,6 +102,7 @@ int kqe_tas_create(void** out) { *out = new EmuTas(); return KQ_OK; }
 void kqe_tas_destroy(void* t) { delete (EmuTas*)t; }
 int kqe_tas_topology_put(void* t, const kq_tas_topology* tp) { return ((EmuTas*)t)->topology_put(tp); }
 int kqe_tas_find(void* t, const kq_tas_requests* r, kq_tas_result* out) { return ((EmuTas*)t)->find(r, out); }
+void kqe_tas_use_classes(void* t, int on) { ((EmuTas*)t)->use_classes = on != 0; }
 int kqe_tas_usage_apply(void* t, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int add) { return ((EmuTas*)t)->usage_apply(n, leaf, count, spr, add); }
 int kqe_tas_fits(void* t, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t* fits) { return ((EmuTas*)t)->fits(n, leaf, count, spr, fits); }
 int kqe_tas_read_usage(void* t, int64_t* u) { return ((EmuTas*)t)->read_usage(u); }
