@@ -1666,4 +1666,54 @@ int kqo_is_preferred(int a_pm, int64_t a_borrow, int b_pm, int64_t b_borrow, uin
   return isPreferred({a_pm, a_borrow}, {b_pm, b_borrow}, policy) ? 1 : 0;
 }
 
+// Hooks that replay the reference's small table tests directly against the restated functions
+// (TestResourcesToReserve scheduler_test.go:8692, TestLastAssignmentOutdated :9216, TestEntryOrdering :6793,
+//  TestCandidatesOrdering preemption_test.go:4613).
+// quotaResourcesToReserve (scheduler.go:796-814) for head 0 of `h` with the given representative mode / borrowing and
+// assignment usage; reserved[] is dense over flavor-resources (entries not in the usage stay 0).
+int kqo_resources_to_reserve(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, int mode, int borrowing,
+                             int n, const int32_t* fr, const int64_t* qty, int64_t* reserved) {
+  Snap sn(*cfg, s);
+  Scheduler sch(sn, h);
+  Entry e; e.head = sch.loadHead(0);
+  e.assignment.PodSets.resize(1);
+  for (int i = 0; i < n; i++) {
+    e.assignment.Usage[fr[i]] = Amount(qty[i]);
+    FlavorAssignment fa; fa.flavor = fr[i] / sn.nR; fa.mode = mode; fa.borrow = borrowing;
+    e.assignment.PodSets[0].flavors[fr[i] % sn.nR] = fa;
+  }
+  e.assignment.Borrowing = borrowing;
+  e.assignment.SetRepresentativeMode(mode);  // the test harness sets it the same way (scheduler_test.go:8839-8850)
+  FRQ r = sch.quotaResourcesToReserve(e, e.head.cq);
+  for (int f = 0; f < sn.nfr; f++) reserved[f] = 0;
+  for (auto& kv : r) reserved[kv.first] = kv.second.v;
+  return KQ_OK;
+}
+// lastAssignmentOutdated (scheduler.go:840-856) for head 0
+int kqo_last_assignment_outdated(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h) {
+  Snap sn(*cfg, s);
+  Scheduler sch(sn, h);
+  Head hd = sch.loadHead(0);
+  return sch.lastAssignmentOutdated(hd) ? 1 : 0;
+}
+// makeClassicalIterator (scheduler.go:1110-1163): order[i] = head index at position i, given each head's Borrows()
+int kqo_entry_order(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, const int32_t* borrowing, int32_t* order) {
+  Snap sn(*cfg, s);
+  Scheduler sch(sn, h);
+  std::vector<Entry> entries(h->n);
+  for (int i = 0; i < h->n; i++) { entries[i].head = sch.loadHead(i); entries[i].assignment.Borrowing = borrowing[i]; }
+  std::vector<int> ord = sch.classicalOrder(entries);
+  for (int i = 0; i < h->n; i++) order[i] = ord[i];
+  return KQ_OK;
+}
+// CandidatesOrdering (preemption/common/ordering.go:42-83): the admitted rows `rows` sorted for a preemptor in `cq`
+int kqo_candidates_order(const kq_config* cfg, const kq_snapshot* s, int cq, int n, const int32_t* rows, int32_t* out) {
+  Snap sn(*cfg, s);
+  Preemptor p(sn);
+  std::vector<int> v(rows, rows + n);
+  p.sortCandidates(v, cq);
+  for (int i = 0; i < n; i++) out[i] = v[i];
+  return KQ_OK;
+}
+
 }  // extern "C"

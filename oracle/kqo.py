@@ -193,3 +193,33 @@ def usage_apply(cfg, snap: Snapshot, triples, add: bool):
     rc = lib().kqo_usage_apply(C.byref(cfg), C.byref(snap.struct()), len(tcq), F.ptr(pad(tcq)), F.ptr(pad(tfr)), F.ptr(pad(tq)), 1 if add else 0, F.ptr(usage))
     assert rc == 0, rc
     return usage
+
+
+def resources_to_reserve(cfg, snap: Snapshot, heads: Heads, mode: int, borrowing: int, usage: dict):
+    """quotaResourcesToReserve for head 0; usage / result: {(flavor, resource): amount}."""
+    frs = np.array([snap.fr(f, r) for (f, r) in usage], np.int32)
+    qty = np.array(list(usage.values()), np.int64)
+    out = np.zeros(snap.n_fr, np.int64)
+    pad = lambda a: a if a.size else np.zeros(1, a.dtype)
+    rc = lib().kqo_resources_to_reserve(C.byref(cfg), C.byref(snap.struct()), C.byref(heads.struct()), mode, borrowing, len(frs),
+                                        F.ptr(pad(frs)), F.ptr(pad(qty)), F.ptr(out))
+    assert rc == 0
+    return {k: int(out[snap.fr(*k)]) for k in usage}
+
+
+def last_assignment_outdated(cfg, snap: Snapshot, heads: Heads) -> bool:
+    return bool(lib().kqo_last_assignment_outdated(C.byref(cfg), C.byref(snap.struct()), C.byref(heads.struct())))
+
+
+def entry_order(cfg, snap: Snapshot, heads: Heads, borrowing):
+    b = np.asarray(borrowing, np.int32)
+    out = np.zeros(heads.n, np.int32)
+    assert lib().kqo_entry_order(C.byref(cfg), C.byref(snap.struct()), C.byref(heads.struct()), F.ptr(b), F.ptr(out)) == 0
+    return out.tolist()
+
+
+def candidates_order(cfg, snap: Snapshot, cq: str, rows):
+    r = np.asarray(rows, np.int32)
+    out = np.zeros(len(r), np.int32)
+    assert lib().kqo_candidates_order(C.byref(cfg), C.byref(snap.struct()), snap.cq_index[cq], len(r), F.ptr(r), F.ptr(out)) == 0
+    return out.tolist()

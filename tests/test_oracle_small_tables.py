@@ -1,0 +1,89 @@
+"""Small table tests of the reference replayed on the oracle's restated functions:
+TestIsPreferred, TestResourcesToReserve, TestLastAssignmentOutdated (tests/golden/small_tables.yaml, extractor committed),
+TestCandidatesOrdering, TestEntryOrdering (tests/golden/small_tables_manual.yaml, hand transcription)."""
+import pytest
+
+from kueue_amd import _ffi as F
+from kueue_amd.api import (ClusterQueue, Cohort, FlavorQuotas, Heads, LastAssignment, PodSet, ResourceGroup, Snapshot, Workload,
+                           gates_with, make_config)
+from tests.conftest import load_golden
+
+T = load_golden("small_tables.yaml")
+M = load_golden("small_tables_manual.yaml")
+PM = {"noFit": 0, "noPreemptionCandidates": 1, "preempt": 2, "reclaim": 3, "fit": 4}
+
+
+@pytest.mark.parametrize("case", T["isPreferred"], ids=lambda c: c["name"][:70])
+def test_is_preferred(oracle, case):
+    c = case["config"]
+    cq = ClusterQueue("cq", when_can_borrow=c.get("WhenCanBorrow", "MayStopSearch"), when_can_preempt=c.get("WhenCanPreempt", "TryNextFlavor"),
+                      preference=c.get("Preference"))
+    got = oracle.is_preferred((PM[case["a"]["mode"]], case["a"]["borrow"]), (PM[case["b"]["mode"]], case["b"]["borrow"]), cq.policy_word())
+    assert got == case["want"]
+
+
+def _reserve_snapshot(cq_usage):
+    # the ClusterQueue of TestResourcesToReserve (scheduler_test.go:8700-8716)
+    cq = ClusterQueue("cq", cohort="eng", queueing_strategy="StrictFIFO", resource_groups=[
+        ResourceGroup([FlavorQuotas("on-demand").Resource("memory", "100"), FlavorQuotas("spot").Resource("memory", "0", "100")]),
+        ResourceGroup([FlavorQuotas("model-a").Resource("gpu", "10", "0"), FlavorQuotas("model-b").Resource("gpu", "10", "5")])])
+    for k, v in cq_usage.items():
+        f, r = k.split("/")
+        cq.extra_usage[(f, r)] = v
+    return Snapshot([cq], [Cohort("eng")], [])
+
+
+@pytest.mark.parametrize("case", T["resourcesToReserve"], ids=lambda c: c["name"][:70])
+def test_resources_to_reserve(oracle, case):
+    snap = _reserve_snapshot(case["cqUsage"])
+    oracle.derive(snap)
+    wl = Workload("wl", "cq", pod_sets=[PodSet("main", count=1)])
+    heads = Heads(snap, [wl])
+    usage = {tuple(k.split("/")): v for k, v in case["assignmentUsage"].items()}
+    mode = {"Preempt": F.Preempt, "Fit": F.Fit, "NoFit": F.NoFit}[case["mode"]]
+    got = oracle.resources_to_reserve(make_config(), snap, heads, mode, case["borrowing"], usage)
+    assert got == {tuple(k.split("/")): v for k, v in case["wantReserved"].items()}
+
+
+@pytest.mark.parametrize("case", T["lastAssignmentOutdated"], ids=lambda c: c["name"][:70])
+def test_last_assignment_outdated(oracle, case):
+    cq = ClusterQueue("cq", resource_groups=[ResourceGroup([FlavorQuotas("f").Resource("cpu", "1")])], generation=case["cqGeneration"])
+    snap = Snapshot([cq], [], [])
+    oracle.derive(snap)
+    wl = Workload("wl", "cq", pod_sets=[PodSet("main", count=1).Request("cpu", "1")], scheduling_hash=case["hash"],
+                  last_assignment=LastAssignment(last_tried_flavor_idx=[{"cpu": 0}], cluster_queue_generation=case["last"]["generation"],
+                                                 scheduling_cycle=case["last"]["cycle"], scheduling_hash=case["last"]["hash"]))
+    heads = Heads(snap, [wl], cycle=case["cycle"])
+    cfg = make_config(gates=gates_with({"FlavorFungibilityPreserveScanProgress": case["preserveProgress"]}))
+    assert oracle.last_assignment_outdated(cfg, snap, heads) == case["want"]
+
+
+@pytest.mark.parametrize("case", M["candidatesOrdering"], ids=lambda c: c["name"][:70])
+def test_candidates_ordering(oracle, case):
+    cq_names = sorted({c["cq"] for c in case["candidates"]} | {case["preemptorCq"]})
+    rg = [ResourceGroup([FlavorQuotas("f").Resource("cpu", "10")])]
+    cqs = [ClusterQueue(n, cohort="co", resource_groups=rg) for n in cq_names]
+    now = 1_000_000_000_000
+    adm = [Workload(c["name"], c["cq"], priority=c["priority"], pod_sets=[PodSet("main", count=1, requests={"cpu": 1000}, flavors={"cpu": "f"})],
+                    reserve_ts=(now + c["reservedAt"] * 1_000_000_000) if "reservedAt" in c else None, evicted=c.get("evicted", False),
+                    uid=f"uid-{i}") for i, c in enumerate(case["candidates"])]
+    snap = Snapshot(cqs, [Cohort("co")], adm, now_ns=now)
+    oracle.derive(snap)
+    rows = [snap.adm_index[c["name"]] for c in case["candidates"]]
+    got = oracle.candidates_order(make_config(), snap, case["preemptorCq"], rows)
+    names = {snap.adm_index[c["name"]]: c["name"] for c in case["candidates"]}
+    assert [names[r] for r in got] == case["want"]
+
+
+@pytest.mark.parametrize("case", M["entryOrdering"], ids=lambda c: c["name"][:70])
+def test_entry_ordering(oracle, case):
+    rg = [ResourceGroup([FlavorQuotas("f").Resource("cpu", "100")])]
+    cqs = [ClusterQueue(f"cq{i:02d}", cohort="co", resource_groups=rg) for i in range(len(case["entries"]))]
+    snap = Snapshot(cqs, [Cohort("co")], [])
+    oracle.derive(snap)
+    wls = [Workload(e["name"], f"cq{i:02d}", priority=e["priority"], creation_ts=e["queueTs"] * 1_000_000_000,
+                    pod_sets=[PodSet("main", count=1).Request("cpu", "1")]) for i, e in enumerate(case["entries"])]
+    heads = Heads(snap, wls)
+    cfg = make_config(gates=gates_with({"PrioritySortingWithinCohort": case["prioritySorting"]}))
+    got = oracle.entry_order(cfg, snap, heads, [e["borrowing"] for e in case["entries"]])
+    assert [case["entries"][i]["name"] for i in got] == case["want"]
