@@ -22,6 +22,7 @@
 // test-suite loads (tests/emu): it checks the uniform control logic against the oracle without a
 // GPU. It is not a fallback: the product library contains no host implementation of these paths.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 
 #include "../../include/kq_engine.h"
@@ -429,10 +430,12 @@ struct Wave {
   int np_broken;                  // any column broken
   int n_pre;                      // rows preempted in this tree so far this cycle
   uint64_t broken[4];             // column bitmap (nfr <= 256; beyond that every column counts as broken)
+  int mono_break;                 // usage went DOWN since the leader last looked: "did not fit when fetched" flags are void
 };
 KQ_DEV void mark_broken(Wave& w, int fr) {
   if (fr < 256) atomic_or_u64(&w.broken[fr >> 6], 1ull << (fr & 63));
   w.np_broken = 1;
+  w.mono_break = 1;
 }
 KQ_DEV bool col_broken(const Wave& w, int fr) { return fr >= 256 ? w.np_broken != 0 : ((w.broken[fr >> 6] >> (fr & 63)) & 1) != 0; }
 // must usage_np be rebuilt before it is read?
@@ -1740,30 +1743,31 @@ KQ_DEV UP up_plane(const K& k, const Wave& w, int plane, int fr) {
   return UP{&k.S, plane == 0 ? k.usage_work : k.usage_np, w.pc_lds, w.pc_on, w.pc_ncq, w.pc_ncoh, plane, fr};
 }
 // LDS <-> HBM for the tree's cohort rows (both planes)
-KQ_DEV void pc_load(const K& k, Wave& w, int64_t* pcl, int tree) {
+// tid / nthreads: the threads sharing the copy; the caller synchronises them afterwards
+KQ_DEV void pc_load_by(const K& k, const Wave& w, int64_t* pcl, int tree, int tid, int nthreads) {
   const DSnap& S = k.S;
   if (!w.pc_on) return;
   const int n0 = S.tree_node_off[tree] + w.pc_ncq;
   const int total = w.pc_ncoh * S.nfr;
-  for (int i = lane_id(); i < total; i += WAVE) {
+  for (int i = tid; i < total; i += nthreads) {
     int node = S.tree_nodes[n0 + i / S.nfr], fr = i % S.nfr;
     pcl[i] = k.usage_work[ix(S, node, fr)];
     pcl[(size_t)total + i] = k.usage_np[ix(S, node, fr)];
   }
-  wsync();
 }
-KQ_DEV void pc_flush(const K& k, Wave& w, int64_t* pcl, int tree) {
+KQ_DEV void pc_flush_by(const K& k, const Wave& w, const int64_t* pcl, int tree, int tid, int nthreads) {
   const DSnap& S = k.S;
   if (!w.pc_on) return;
   const int n0 = S.tree_node_off[tree] + w.pc_ncq;
   const int total = w.pc_ncoh * S.nfr;
-  for (int i = lane_id(); i < total; i += WAVE) {
+  for (int i = tid; i < total; i += nthreads) {
     int node = S.tree_nodes[n0 + i / S.nfr], fr = i % S.nfr;
     k.usage_work[ix(S, node, fr)] = pcl[i];
     k.usage_np[ix(S, node, fr)] = pcl[(size_t)total + i];
   }
-  wsync();
 }
+KQ_DEV void pc_load(const K& k, Wave& w, int64_t* pcl, int tree) { pc_load_by(k, w, pcl, tree, lane_id(), WAVE); wsync(); }
+KQ_DEV void pc_flush(const K& k, Wave& w, int64_t* pcl, int tree) { pc_flush_by(k, w, pcl, tree, lane_id(), WAVE); wsync(); }
 
 // apply / revert the removal of a target row on usage_np, restricted to the entry's own flavor-resources
 KQ_DEV void np_apply_row_restricted(const K& k, Wave& w, int row, bool add) {
@@ -2099,15 +2103,26 @@ constexpr int FU = 8;    // max flavor-resources of an entry on the fast path
 constexpr int FD = 4;    // max path length (CQ + 3 cohort levels) on the fast path
 constexpr int CH = 16;   // entries per chunk; two chunk buffers live in LDS (one being processed, one being prefetched)
 constexpr int NBUF = 2;
+constexpr int64_t PLAIN_LIMIT = (int64_t)1 << 56;  // see "serial core" below
+constexpr int64_t QC_NOLIMIT = (int64_t)1 << 61;   // "no borrowing limit at this level" in PRec::ccv (sums of plain values stay below it)
 struct PRec {
   int32_t e, pos, cq, plen, nuse, borrowing, mode, slow;
   uint32_t pol, flags;
   int32_t coh[FD];
   int32_t fr[FU];
   int64_t qty[FU], nominal[FU], uw0[FU], un0[FU];
-  int64_t lq[FU][FD], sqv[FU][FD], bl[FU][FD];
-  uint8_t status, action, rq, skip, omode, dirty, pad[2];  // dirty: CQ-level usage cells changed
+  int64_t lq[FU][FD], sqv[FU][FD];
+  // quad core: Available(cq) = min over the path levels j of  sum_{k<j} max(0, lq_k - usage_k) + ccv_j - usage_j  with
+  // ccv = subtree quota (+ borrowing limit below the root; QC_NOLIMIT without one)  — see core_run_quad
+  int64_t ccv[FU][FD];
+  uint8_t status, action, rq, skip, omode, dirty, added, pad;  // dirty: CQ-level usage cells not yet in HBM; added: AddUsage ran
+  union { uint8_t b[FU]; uint64_t all; } pre;  // per slot: "already did not fit when the record was fetched" (see chunk_prefetch)
+  // quad core: where the usage_work cell of (slot, level) lives, as an int64 index from the LDS base (level 0: this record's
+  // uw0[slot]; cohort levels: the resident row), and whether one of the cell's constants is not a plain quantity
+  int32_t uoff[FU][FD];
+  uint8_t cbig[FU][FD];
 };
+static_assert(offsetof(PRec, un0) - offsetof(PRec, uw0) == FU * sizeof(int64_t), "quad core: un0[u] is FU cells after uw0[u]");
 
 // Fills the records of one chunk. No synchronisation inside: the thread that writes a record header and the threads
 // that fetch its (slot, level) cells all start from the global inputs (head -> ClusterQueue -> path -> quota cells), so
@@ -2131,7 +2146,7 @@ KQ_DEV void chunk_prefetch(const K& k, const Wave& w, PRec* rec, const PRec* pre
     for (int q = 0; q < j; q++) if (H.cq[ent[q]] == cq) slow = 1;
     for (int q = 0; q < nprev; q++) if (prev[q].cq == cq) slow = 1;
     if (!slow) for (int i = 1; i < r.plen; i++) r.coh[i] = S.node_local[S.path[(size_t)cq * KQ_MAXD + i]] - w.pc_ncq;
-    r.slow = slow; r.dirty = 0;
+    r.slow = slow; r.dirty = 0; r.added = 0;
   }
   for (int idx = tid; idx < nch * FU * FD; idx += nthreads) {
     const int j = idx / (FU * FD), u = (idx / FD) % FU, i = idx % FD;
@@ -2144,9 +2159,67 @@ KQ_DEV void chunk_prefetch(const K& k, const Wave& w, PRec* rec, const PRec* pre
     const int n = S.path[(size_t)cq * KQ_MAXD + i];
     const size_t o = ix(S, n, fr);
     const int64_t sqv = S.sq[o], llv = S.ll[o];
-    r.sqv[u][i] = sqv; r.bl[u][i] = S.bl[o];
-    r.lq[u][i] = llv != KQ_NIL_LIMIT ? i64max(0, a_sub(sqv, llv)) : 0;
-    if (i == 0) { r.fr[u] = fr; r.qty[u] = O.use_qty[(size_t)e * KQ_MAXU + u]; r.nominal[u] = S.nominal[o]; r.uw0[u] = k.usage_work[o]; r.un0[u] = k.usage_np[o]; }
+    const int64_t blv = S.bl[o], lqv = llv != KQ_NIL_LIMIT ? i64max(0, a_sub(sqv, llv)) : 0;
+    r.sqv[u][i] = sqv; r.lq[u][i] = lqv;
+    r.ccv[u][i] = i == S.plen[cq] - 1 ? sqv : (blv != KQ_NIL_LIMIT ? (int64_t)((uint64_t)sqv + (uint64_t)blv) : QC_NOLIMIT);
+    uint64_t big = (uint64_t)sqv | (uint64_t)lqv | (blv != KQ_NIL_LIMIT ? (uint64_t)blv : 0ull);
+    if (i == 0) {
+      const int64_t qty = O.use_qty[(size_t)e * KQ_MAXU + u], nominal = S.nominal[o];
+      r.fr[u] = fr; r.qty[u] = qty; r.nominal[u] = nominal; r.uw0[u] = k.usage_work[o]; r.un0[u] = k.usage_np[o];
+      big |= (uint64_t)qty | (uint64_t)nominal;
+      r.uoff[u][0] = (int32_t)(&r.uw0[u] - w.pc_lds);
+    } else {
+      r.uoff[u][i] = (S.node_local[n] - w.pc_ncq) * S.nfr + fr;
+    }
+    r.cbig[u][i] = big >= (uint64_t)PLAIN_LIMIT ? 1 : 0;
+  }
+  // Early "no longer fits" (scheduler.go:1167): between two generic-path entries the serial core only ever ADDS usage, and
+  // Available (resource_node.go:106-122) does not increase when usage grows, so a slot that does not fit against the usage
+  // visible now (cohort rows as they are in LDS at this moment, possibly while wave 0 is still adding to them; CQ-level
+  // cells from HBM) cannot fit when its turn comes. The serial core then skips the arithmetic for that entry. The core
+  // ends the chunk (and drops the records fetched ahead) whenever it subtracts: a negative reservation (:806).
+  for (int idx = tid; idx < nch * FU; idx += nthreads) {
+    const int j = idx / FU, u = idx % FU;
+    const int e = ent[j];
+    const int cq = H.cq[e];
+    const int nuse = (H.flags[e] & KQ_HEAD_HAS_QUOTA_RESERVATION) ? 0 : O.use_n[e];
+    const int plen = S.plen[cq], mode = O.nominated_mode[e];
+    bool bad = false;
+    if (u < nuse && nuse <= FU && plen <= FD && (plen == 1 || w.pc_on) && mode != M_PREEMPT && mode != M_NOFIT) {
+      const int fr = O.use_fr[(size_t)e * KQ_MAXU + u];
+      const int64_t qty = O.use_qty[(size_t)e * KQ_MAXU + u];
+      const int64_t* np_rows = w.pc_lds + (size_t)w.pc_ncoh * S.nfr;
+      // all levels' operands first (independent loads), then the root -> ClusterQueue recurrence
+      int64_t sqv[FD], lqv[FD], blv[FD], unv[FD];
+      #pragma unroll
+      for (int i = 0; i < FD; i++) {
+        sqv[i] = lqv[i] = unv[i] = 0; blv[i] = KQ_NIL_LIMIT;
+        if (i < plen) {
+          const int n = S.path[(size_t)cq * KQ_MAXD + i];
+          const size_t o = ix(S, n, fr);
+          const int64_t llv = S.ll[o];
+          sqv[i] = S.sq[o]; blv[i] = S.bl[o];
+          lqv[i] = llv != KQ_NIL_LIMIT ? i64max(0, a_sub(sqv[i], llv)) : 0;
+          unv[i] = i == 0 ? k.usage_np[o] : np_rows[(size_t)(S.node_local[n] - w.pc_ncq) * S.nfr + fr];
+        }
+      }
+      uint64_t big = (uint64_t)qty;
+      int64_t a = 0;
+      #pragma unroll
+      for (int i = FD - 1; i >= 0; i--) {
+        if (i >= plen) continue;
+        const bool hb = blv[i] != KQ_NIL_LIMIT;
+        big |= (uint64_t)sqv[i] | (uint64_t)lqv[i] | (uint64_t)unv[i] | (hb ? (uint64_t)blv[i] : 0ull);
+        if (i == plen - 1) a = sqv[i] - unv[i];
+        else {
+          const int64_t wm = (sqv[i] - lqv[i]) - i64max(0, unv[i] - lqv[i]) + blv[i];
+          a = i64max(0, lqv[i] - unv[i]) + ((hb && wm < a) ? wm : a);
+        }
+      }
+      const bool plain = big < (uint64_t)PLAIN_LIMIT;  // otherwise `a` may have wrapped: no claim
+      bad = plain && i64max(0, a) < qty;
+    }
+    rec[j].pre.b[u] = bad ? 1 : 0;
   }
 }
 KQ_DEV void chunk_prefetch_wave(const K& k, Wave& w, PRec* rec, const int32_t* ent, const int32_t* entpos, int nch) {
@@ -2176,18 +2249,55 @@ KQ_DEV void chunk_scatter(const K& k, PRec* rec, int n) {
 // a bounded non-negative quantity < 2^56, so the saturation / Unlimited branches of resources.Amount
 // (amount.go:114-145) cannot trigger and plain 64-bit add/sub/min/max are bit-identical to them. Anything
 // else (Unlimited quota cells, over-large values) returns false and takes the generic exact path.
-constexpr int64_t PLAIN_LIMIT = (int64_t)1 << 56;
+
+// Scalars the serial core needs from the kernel argument block. K lives in global memory and the compiler cannot prove the
+// core's stores do not alias it, so reading them through `k` costs a global load (+ wait) per entry; they are read once
+// per tree instead.
+struct CoreCtx { int nfr, total; bool prio_preemptors; const int64_t* bl_tab; const int32_t* path_tab; };
+KQ_DEV CoreCtx core_ctx(const K& k, const Wave& w) {
+  CoreCtx c; c.nfr = k.S.nfr; c.total = w.pc_ncoh * k.S.nfr; c.prio_preemptors = gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS);
+  c.bl_tab = k.S.bl; c.path_tab = k.S.path;
+  return c;
+}
+// algorithmic bytes of a record the serial core handled: scheduler.fits reads nuse * 40 * plen, AddUsage writes nuse * 8 * plen
+KQ_DEV int64_t rec_algo_bytes(const PRec& r) {
+  return r.nuse > 0 ? (int64_t)r.nuse * r.plen * (40 + (r.added ? 8 : 0)) : 0;
+}
+
+// What the serial core reads from a record before it touches a usage cell. None of it is written while a chunk is walked, so
+// the leader loads it one entry ahead (the loads are in flight while the previous entry's arithmetic runs).
+struct QPre {
+  int slow, plen, nuse, mode, borrowing;
+  uint32_t pol, flags;
+  uint64_t pre;
+#ifndef KQ_HOST_EMU
+  int64_t lq, ccv, qty;  // this lane's (slot, level) cell: lane = plane * 32 + slot * 4 + level
+  int uoff, cbig;
+#endif
+};
+KQ_DEV QPre rec_preload(const PRec& r) {
+  QPre q;
+  q.slow = r.slow; q.plen = r.plen; q.nuse = r.nuse; q.mode = r.mode; q.borrowing = r.borrowing; q.pol = r.pol; q.flags = r.flags;
+  q.pre = r.pre.all;
+#ifndef KQ_HOST_EMU
+  const int lane = lane_id(), u = (lane >> 2) & 7, i = lane & 3;
+  q.lq = r.lq[u][i]; q.ccv = r.ccv[u][i]; q.qty = r.qty[u];
+  q.uoff = r.uoff[u][i]; q.cbig = r.cbig[u][i];
+#endif
+  return q;
+}
 
 template <int PLEN> struct SlotState { int64_t un[PLEN], uw[PLEN], lq[PLEN], sq[PLEN], bl[PLEN], qty, nominal; int cidx[PLEN]; };
 
 // `pcl` is the LDS base of the cohort rows, passed down explicitly (NOT re-read from Wave::pc_lds) so that after
 // inlining the compiler still knows the address space and emits ds_* instead of flat_* in the serial core.
-template <int PLEN> KQ_DEV void slot_load(const K& k, const Wave& w, const int64_t* pcl, const PRec& r, int u, SlotState<PLEN>& x) {
-  const int nfr = k.S.nfr, total = w.pc_ncoh * nfr, fr = r.fr[u];
+template <int PLEN> KQ_DEV void slot_load(const CoreCtx& cc, const int64_t* pcl, const PRec& r, int u, SlotState<PLEN>& x) {
+  const int nfr = cc.nfr, total = cc.total, fr = r.fr[u];
   x.qty = r.qty[u]; x.nominal = r.nominal[u];
   #pragma unroll
   for (int i = 0; i < PLEN; i++) {
-    x.lq[i] = r.lq[u][i]; x.sq[i] = r.sqv[u][i]; x.bl[i] = r.bl[u][i];
+    x.lq[i] = r.lq[u][i]; x.sq[i] = r.sqv[u][i];
+    x.bl[i] = cc.bl_tab[(size_t)cc.path_tab[(size_t)r.cq * KQ_MAXD + i] * nfr + fr];  // not kept in the record (the quad core reads ccv)
     x.cidx[i] = i == 0 ? 0 : r.coh[i] * nfr + fr;
   }
   x.uw[0] = r.uw0[u]; x.un[0] = r.un0[u];
@@ -2200,15 +2310,15 @@ template <bool PLAIN> KQ_DEV int64_t q_sub(int64_t a, int64_t b) { if (PLAIN) re
 
 // PLAIN = true : returns false (and does nothing) when some operand is not plain.
 // PLAIN = false: exact resources.Amount arithmetic, always succeeds.
-template <int PLEN, bool PLAIN> KQ_DEV bool core_run(const K& k, Wave& w, int64_t* pcl, PRec& r, int64_t* bytes) {
+template <int PLEN, bool PLAIN> KQ_DEV bool core_run(Wave& w, int64_t* pcl, PRec& r, const CoreCtx& cc) {
   const int lane = lane_id();
   const int nuse = r.nuse, mode = r.mode;
-  const int total = w.pc_ncoh * k.S.nfr;
+  const int total = cc.total;
   SlotState<PLEN> x;
   bool notplain = false, bad = false;
   // one pass on the device (nuse <= FU < 64 lanes); the 1-lane emulation walks the slots one by one
   for (int u = lane; u < nuse; u += WAVE) {
-    slot_load<PLEN>(k, w, pcl, r, u, x);
+    slot_load<PLEN>(cc, pcl, r, u, x);
     uint64_t big = (uint64_t)x.qty | (uint64_t)x.nominal;
     #pragma unroll
     for (int i = 0; i < PLEN; i++) big |= (uint64_t)x.un[i] | (uint64_t)x.uw[i] | (uint64_t)x.lq[i] | (uint64_t)x.sq[i] | (x.bl[i] == KQ_NIL_LIMIT ? 0ull : (uint64_t)x.bl[i]);
@@ -2230,16 +2340,15 @@ template <int PLEN, bool PLAIN> KQ_DEV bool core_run(const K& k, Wave& w, int64_
   if (mode == M_PREEMPT) {  // no targets: reserveCapacityForUnreclaimablePreempt scheduler.go:538-543
     rq = KQ_RQ_PREEMPTION_NO_CANDIDATES;
     const bool can_always_reclaim = KQ_POL_RECLAIM(r.pol) == KQ_POLICY_ANY;
-    reserve = add = !can_always_reclaim || (gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS) && (r.flags & KQ_HEAD_IS_PREEMPTOR));
+    reserve = add = !can_always_reclaim || (cc.prio_preemptors && (r.flags & KQ_HEAD_IS_PREEMPTOR));
   } else if (!fits_ok) {
     status = KQ_ST_SKIPPED; skip = KQ_SKIP_NO_LONGER_FITS; rq = KQ_RQ_FAILED_AFTER_NOMINATION;  // scheduler.go:1167-1170
   } else {
     add = true; status = KQ_ST_ASSUMED; action = KQ_ACT_ADMIT;
   }
   if (add) {
-    *bytes += (int64_t)nuse * 8 * PLEN;
     for (int u = lane; u < nuse; u += WAVE) {
-      if (WAVE < FU) slot_load<PLEN>(k, w, pcl, r, u, x);  // device: registers of the first pass are still live
+      if (WAVE < FU) slot_load<PLEN>(cc, pcl, r, u, x);  // device: registers of the first pass are still live
       int64_t val = x.qty;
       if (reserve) {  // quotaResourcesToReserve scheduler.go:796-814
         if (r.borrowing > 0) val = x.bl[0] == KQ_NIL_LIMIT ? x.qty : i64min(x.qty, q_sub<PLAIN>(q_add<PLAIN>(x.nominal, x.bl[0]), x.uw[0]));
@@ -2265,7 +2374,7 @@ template <int PLEN, bool PLAIN> KQ_DEV bool core_run(const K& k, Wave& w, int64_
         v = q_sub<PLAIN>(v, la);
       }
     }
-    if (lane == 0) r.dirty = 1;
+    if (lane == 0) { r.dirty = 1; r.added = 1; }
     wsync_lds();  // cohort rows in LDS must be visible to the next entry's lanes
   }
   if (lane == 0) { r.status = (uint8_t)status; r.action = (uint8_t)action; r.rq = (uint8_t)rq; r.skip = (uint8_t)skip; r.omode = (uint8_t)mode; }
@@ -2274,98 +2383,63 @@ template <int PLEN, bool PLAIN> KQ_DEV bool core_run(const K& k, Wave& w, int64_
 
 #ifndef KQ_HOST_EMU
 // ---- quad core (device only) ------------------------------------------------------------------------------
-// The same computation with one lane per (flavor-resource slot, path level) cell: lane = slot * 4 + level, so the four
-// levels of a slot are one DPP quad. Each lane loads only its own cell and computes its own level's terms
-// (max(0, localQuota - usage), the borrowing-limit cap, LocalAvailable); the root-to-ClusterQueue recurrence of
-// `available` (resource_node.go:106-122) and the bubbling of addUsage (:144-152) become three quad_perm steps each
-// instead of a four-level dependent chain per lane. Plain operands only; anything else -> false (exact core).
-KQ_DEV int64_t dpp64_next(int64_t v) {  // value of the next lane of the quad (level + 1)
-  int lo = (int)v, hi = (int)(v >> 32);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0xF9, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0xF9, 0xf, 0xf, false);
+// One lane per (usage plane, flavor-resource slot, path level): lane = plane * 32 + slot * 4 + level, so the levels of a slot
+// are one DPP quad and both planes run the same instructions. Plain operands only (anything else -> false, exact core), which
+// lets the two recurrences of the reference be rewritten without a level-by-level chain. With u_k the usage of path level k
+// (0 = ClusterQueue), t_k = max(0, localQuota_k - u_k) and E_j = t_0 + .. + t_{j-1}:
+//  * available (resource_node.go:106-122):  a_root = sq - u,  a_k = t_k + min(a_{k+1}, (sq_k - lq_k) - max(0, u_k - lq_k) + bl_k).
+//    t_k - max(0, u_k - lq_k) = lq_k - u_k, so the second operand of the min is sq_k + bl_k - u_k - ... unrolled:
+//    Available(cq) = min_j ( E_j + ccv_j - u_j ),  ccv_j = sq_j + bl_j below the root (no limit: QC_NOLIMIT), sq_j at the root.
+//  * addUsage (:144-152): level j receives val - E_j, and only if val > E_j (level 0 always).
+// E is three independent quad_perm reads of t; the min is a two-step butterfly.
+template <int CTRL> KQ_DEV int64_t dpp64(int64_t v) {
+  const int lo = __builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(v >> 32), CTRL, 0xf, 0xf, false);
   return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
-KQ_DEV int64_t dpp64_prev(int64_t v) {  // value of the previous lane of the quad (level - 1)
-  int lo = (int)v, hi = (int)(v >> 32);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x90, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x90, 0xf, 0xf, false);
-  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
-}
-KQ_DEV int dpp32_prev(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x90, 0xf, 0xf, false); }
-KQ_DEV int64_t dpp64_lane0(int64_t v) {  // value of the quad's first lane (the ClusterQueue level)
-  int lo = (int)v, hi = (int)(v >> 32);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x00, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x00, 0xf, 0xf, false);
-  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
-}
-static_assert(FD == 4, "the quad core maps the path levels of a slot onto one DPP quad");
-KQ_DEV bool core_run_quad(const K& k, Wave& w, int64_t* pcl, PRec& r, int64_t* bytes) {
+static_assert(FD == 4 && FU == 8, "the quad core maps (plane, slot, level) onto the 64 lanes: lane = plane * 32 + slot * 4 + level");
+KQ_DEV bool core_run_quad(Wave& w, int64_t* pcl, PRec& r, const CoreCtx& cc, const QPre& q) {
   const int lane = lane_id();
-  const int plen = r.plen, nuse = r.nuse, mode = r.mode;
-  const int u = lane >> 2, i = lane & 3;
+  const int plane = lane >> 5, u = (lane >> 2) & 7, i = lane & 3;  // plane 0: usage_work, plane 1: usage_np
+  const int plen = q.plen, nuse = q.nuse, mode = q.mode;
+  const int64_t qty = q.qty;
   const bool act = u < nuse && i < plen;
-  const int total = w.pc_ncoh * k.S.nfr;
-  int64_t lq = 0, sq = 0, bl = KQ_NIL_LIMIT, un = 0, uw = 0, qty = 0, nominal = 0;
-  int cidx = 0;
-  if (act) {
-    lq = r.lq[u][i]; sq = r.sqv[u][i]; bl = r.bl[u][i];
-    if (i == 0) { uw = r.uw0[u]; un = r.un0[u]; qty = r.qty[u]; nominal = r.nominal[u]; }
-    else { cidx = r.coh[i] * k.S.nfr + r.fr[u]; uw = pcl[cidx]; un = pcl[total + cidx]; }
-  }
-  const bool hb = bl != KQ_NIL_LIMIT;
-  const uint64_t big = (uint64_t)lq | (uint64_t)sq | (uint64_t)un | (uint64_t)uw | (uint64_t)qty | (uint64_t)nominal | (hb ? (uint64_t)bl : 0ull);
-  if (wballot(act && big >= (uint64_t)PLAIN_LIMIT) != 0) return false;  // negatives and Unlimited land here too
-  // scheduler.fits: Available(cq, fr) on usage_np. Level terms in parallel, then root -> ClusterQueue in plen - 1 steps.
-  int64_t a = sq - un;  // the root lane's value; overwritten below for the other levels
-  const int64_t t = i64max(0, lq - un);
-  const int64_t wm = (sq - lq) - i64max(0, un - lq) + bl;
-  #pragma unroll
-  for (int s = 1; s < FD; s++) {
-    const int64_t up = dpp64_next(a);
-    if (i == plen - 1 - s) a = t + ((hb && wm < up) ? wm : up);
-  }
-  const bool bad = act && i == 0 && i64max(0, a) < qty;
+  // the only dependent LDS round trip: this lane's usage cell in its plane (un0 follows uw0 in the record; plane 1 of the rows is `total` further)
+  const int ua = q.uoff + (plane ? (i == 0 ? FU : cc.total) : 0);
+  const int64_t cur = act ? pcl[ua] : 0;
+  if (wballot(act && (q.cbig != 0 || (uint64_t)cur >= (uint64_t)PLAIN_LIMIT)) != 0) return false;  // negatives and Unlimited land here too
+  const int64_t t = i64max(0, q.lq - cur);
+  const int64_t t1 = dpp64<0x90>(t), t2 = dpp64<0x40>(t), t3 = dpp64<0x00>(t);  // t of level i-1, i-2, i-3 (where they exist)
+  const int64_t E = (i >= 1 ? t1 : 0) + (i >= 2 ? t2 : 0) + (i >= 3 ? t3 : 0);
+  // scheduler.fits: Available(cq, fr), meaningful in plane 1
+  int64_t a = act ? E + q.ccv - cur : QC_NOLIMIT;
+  { const int64_t o = dpp64<0xB1>(a); a = o < a ? o : a; }
+  { const int64_t o = dpp64<0x4E>(a); a = o < a ? o : a; }
+  const bool bad = act && plane == 1 && i == 0 && i64max(0, a) < qty;
   const bool fits_ok = wballot(bad) == 0;
   int status = KQ_ST_NOT_NOMINATED, action = KQ_ACT_NONE, rq = KQ_RQ_GENERIC, skip = KQ_SKIP_NONE;
   bool add = false, reserve = false;
   if (mode == M_PREEMPT) {  // no targets: reserveCapacityForUnreclaimablePreempt scheduler.go:538-543
     rq = KQ_RQ_PREEMPTION_NO_CANDIDATES;
-    const bool can_always_reclaim = KQ_POL_RECLAIM(r.pol) == KQ_POLICY_ANY;
-    reserve = add = !can_always_reclaim || (gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS) && (r.flags & KQ_HEAD_IS_PREEMPTOR));
+    const bool can_always_reclaim = KQ_POL_RECLAIM(q.pol) == KQ_POLICY_ANY;
+    reserve = add = !can_always_reclaim || (cc.prio_preemptors && (q.flags & KQ_HEAD_IS_PREEMPTOR));
   } else if (!fits_ok) {
     status = KQ_ST_SKIPPED; skip = KQ_SKIP_NO_LONGER_FITS; rq = KQ_RQ_FAILED_AFTER_NOMINATION;  // scheduler.go:1167-1170
   } else {
     add = true; status = KQ_ST_ASSUMED; action = KQ_ACT_ADMIT;
   }
   if (add) {
-    *bytes += (int64_t)nuse * 8 * plen;
-    int64_t val = qty;  // meaningful in the quad's first lane
-    if (reserve) {  // quotaResourcesToReserve scheduler.go:796-814
-      if (r.borrowing > 0) val = !hb ? qty : i64min(qty, (nominal + bl) - uw);
-      else val = i64max(0, i64min(qty, nominal - uw));
-      if (act && i == 0 && val < 0) mark_broken(w, r.fr[u]);
+    int64_t val = qty;
+    if (reserve && act) {  // quotaResourcesToReserve scheduler.go:796-814: every lane of the slot derives the same value
+      const int64_t uw0 = r.uw0[u], nominal = r.nominal[u];
+      const int64_t bl0 = cc.bl_tab[(size_t)r.cq * cc.nfr + r.fr[u]];
+      if (q.borrowing > 0) val = bl0 == KQ_NIL_LIMIT ? qty : i64min(qty, (nominal + bl0) - uw0);
+      else val = i64max(0, i64min(qty, nominal - uw0));
+      if (i == 0 && plane == 0 && val < 0) mark_broken(w, r.fr[u]);
     }
-    val = dpp64_lane0(val);
-    // addUsage resource_node.go:144-152: level l receives what the levels below did not absorb
-    #pragma unroll
-    for (int plane = 0; plane < 2; plane++) {
-      const int64_t cur = plane == 0 ? uw : un;
-      const int64_t la = i64max(0, lq - cur);
-      int64_t v = val;
-      int go = i == 0 ? 1 : 0;
-      #pragma unroll
-      for (int s = 1; s < FD; s++) {
-        const int64_t pv = dpp64_prev(v), pla = dpp64_prev(la);
-        const int pgo = dpp32_prev(go);
-        if (i == s) { go = (pgo && pv > pla) ? 1 : 0; v = pv - pla; }
-      }
-      if (act && go) {
-        const int64_t nv = cur + v;
-        if (i == 0) { if (plane == 0) r.uw0[u] = nv; else r.un0[u] = nv; }
-        else pcl[(plane == 0 ? 0 : total) + cidx] = nv;
-      }
-    }
-    if (lane == 0) r.dirty = 1;
+    // addUsage resource_node.go:144-152, both planes at once
+    if (act && (i == 0 || val > E)) pcl[ua] = cur + (val - E);
+    if (lane == 0) { r.dirty = 1; r.added = 1; }
     wsync_lds();  // cohort rows in LDS must be visible to the next entry's lanes
   }
   if (lane == 0) { r.status = (uint8_t)status; r.action = (uint8_t)action; r.rq = (uint8_t)rq; r.skip = (uint8_t)skip; r.omode = (uint8_t)mode; }
@@ -2374,11 +2448,10 @@ KQ_DEV bool core_run_quad(const K& k, Wave& w, int64_t* pcl, PRec& r, int64_t* b
 #endif
 
 // serial core dispatch for one fast entry; false => the entry needs the generic exact path
-KQ_DEV bool chunk_entry_fast(const K& k, Wave& w, int64_t* pcl, PRec& r, int64_t* bytes) {
-  const int plen = r.plen, nuse = r.nuse, mode = r.mode;
+KQ_DEV bool chunk_entry_fast(Wave& w, int64_t* pcl, PRec& r, const CoreCtx& cc, const QPre& q) {
+  const int plen = q.plen, nuse = q.nuse, mode = q.mode;
   if (mode == M_NOFIT || nuse == 0) {
-    // scheduler.fits still runs before the mode is looked at (updateAssignmentIfNeeded :713-714)
-    if (nuse > 0) *bytes += (int64_t)nuse * 40 * plen;
+    // scheduler.fits still runs before the mode is looked at (updateAssignmentIfNeeded :713-714): rec_bytes counts it
     int status = KQ_ST_NOT_NOMINATED, action = KQ_ACT_NONE, rq = KQ_RQ_GENERIC;
     if (mode == M_NOFIT) rq = KQ_RQ_NOFIT;
     else if (mode == M_PREEMPT) rq = KQ_RQ_PREEMPTION_NO_CANDIDATES;
@@ -2386,24 +2459,26 @@ KQ_DEV bool chunk_entry_fast(const K& k, Wave& w, int64_t* pcl, PRec& r, int64_t
     if (lane_id() == 0) { r.status = (uint8_t)status; r.action = (uint8_t)action; r.rq = (uint8_t)rq; r.skip = KQ_SKIP_NONE; r.omode = (uint8_t)mode; }
     return true;
   }
-#ifndef KQ_HOST_EMU
-  if (core_run_quad(k, w, pcl, r, bytes)) { *bytes += (int64_t)nuse * 40 * plen; return true; }
-  switch (plen) {  // not plain: exact Amount arithmetic, one lane per slot
-    case 1: core_run<1, false>(k, w, pcl, r, bytes); break;
-    case 2: core_run<2, false>(k, w, pcl, r, bytes); break;
-    case 3: core_run<3, false>(k, w, pcl, r, bytes); break;
-    default: core_run<4, false>(k, w, pcl, r, bytes); break;
+  if (mode != M_PREEMPT && q.pre != 0) {  // did not fit when fetched => does not fit now (scheduler.go:1167-1170)
+    if (lane_id() == 0) { r.status = KQ_ST_SKIPPED; r.action = KQ_ACT_NONE; r.rq = KQ_RQ_FAILED_AFTER_NOMINATION; r.skip = KQ_SKIP_NO_LONGER_FITS; r.omode = (uint8_t)mode; }
+    return true;
   }
-  *bytes += (int64_t)nuse * 40 * plen;
+#ifndef KQ_HOST_EMU
+  if (core_run_quad(w, pcl, r, cc, q)) return true;
+  switch (plen) {  // not plain: exact Amount arithmetic, one lane per slot
+    case 1: core_run<1, false>(w, pcl, r, cc); break;
+    case 2: core_run<2, false>(w, pcl, r, cc); break;
+    case 3: core_run<3, false>(w, pcl, r, cc); break;
+    default: core_run<4, false>(w, pcl, r, cc); break;
+  }
   return true;
 #endif
   switch (plen) {
-    case 1: if (!core_run<1, true>(k, w, pcl, r, bytes)) core_run<1, false>(k, w, pcl, r, bytes); break;
-    case 2: if (!core_run<2, true>(k, w, pcl, r, bytes)) core_run<2, false>(k, w, pcl, r, bytes); break;
-    case 3: if (!core_run<3, true>(k, w, pcl, r, bytes)) core_run<3, false>(k, w, pcl, r, bytes); break;
-    default: if (!core_run<4, true>(k, w, pcl, r, bytes)) core_run<4, false>(k, w, pcl, r, bytes); break;
+    case 1: if (!core_run<1, true>(w, pcl, r, cc)) core_run<1, false>(w, pcl, r, cc); break;
+    case 2: if (!core_run<2, true>(w, pcl, r, cc)) core_run<2, false>(w, pcl, r, cc); break;
+    case 3: if (!core_run<3, true>(w, pcl, r, cc)) core_run<3, false>(w, pcl, r, cc); break;
+    default: if (!core_run<4, true>(w, pcl, r, cc)) core_run<4, false>(w, pcl, r, cc); break;
   }
-  *bytes += (int64_t)nuse * 40 * plen;
   return true;
 }
 
@@ -2423,13 +2498,17 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
     w.pc_lds = lds;
     w.pc_on = (w.pc_ncoh > 0 && lds_bytes >= rec_bytes && (size_t)w.pc_ncoh * S.nfr * 16 <= lds_bytes - rec_bytes) ? 1 : 0;
     w.np_broken = 0; w.n_pre = 0; w.broken[0] = w.broken[1] = w.broken[2] = w.broken[3] = 0;
-    w.nwin2[0] = w.nwin2[1] = 0; w.chunk_done = 0; w.chunk_stop = 0;
+    w.nwin2[0] = w.nwin2[1] = 0; w.chunk_done = 0; w.chunk_stop = 0; w.mono_break = 0;
   }
   bsync();
+#if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
+  const long long _tree0 = clock64(), _wall0 = wall_clock64();
+#endif
+  const CoreCtx cc = core_ctx(k, w);
   const bool chunked = lds_bytes >= rec_bytes;
   PRec* rec = (PRec*)((unsigned char*)lds + (lds_bytes - (chunked ? rec_bytes : 0)));
   bool loaded = false;
-  int64_t bytes = 0;
+  int64_t bytes = 0;  // per-lane partial sum (the result pass below adds what its records cost)
   constexpr int WIN = 256;  // entries of the global order examined per window (independent of the wave width)
   for (int base = 0, par = 0; base < n; base += WIN, par ^= 1) {
     // leader: compact this window's entries of the tree (in order) into LDS lists
@@ -2451,7 +2530,10 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
     bsync();
     const int nwin = w.nwin2[par];
     if (nwin == 0) continue;
-    if (!loaded) { if (leader) { KQ_T0(); pc_load(k, w, lds, tree); KQ_TS(k, 8); } loaded = true; }
+    if (!loaded) {  // the whole workgroup copies the rows in; the record prefetch below already reads them
+      KQ_T0(); pc_load_by(k, w, lds, tree, tid, nthreads); bsync(); if (leader) KQ_TS(k, 8);
+      loaded = true;
+    }
     if (!chunked) {
       if (leader) for (int q = 0; q < nwin; q++) process_entry(k, w, w.win_e[q], w.win_pos[q], slot, tree);
       continue;
@@ -2487,9 +2569,12 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
         KQ_T0();
         int j = 0;
         bool stopped = false;
+        const bool had_preemptions = w.n_pre > 0;  // only the generic path changes it, and that ends the chunk
+        QPre q = rec_preload(rc[0]);
         for (; j < nch; j++) {
           PRec& r = rc[j];
-          if (r.slow || np_exact_mode(w)) {
+          const QPre qn = rec_preload(rc[j + 1 < nch ? j + 1 : j]);  // in flight during this entry's arithmetic
+          if (q.slow || (had_preemptions && np_exact_mode(w))) {
             // generic path (targets / recompute / oversize / usage_np no longer incremental). It reads and writes HBM for
             // CQ-level cells, so prefetched CQ-level values may be stale afterwards: stop the chunk behind it.
             chunk_scatter(k, rc, j);  // earlier fast entries' CQ-level cells must be in HBM first
@@ -2501,7 +2586,18 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
             stopped = true;
             break;
           }
-          if (!chunk_entry_fast(k, w, lds, r, &bytes)) {
+#if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
+          const long long _e0 = clock64();
+          const bool _ok = chunk_entry_fast(w, lds, r, cc, q);
+          {
+            const long long _e1 = clock64();
+            const int cls = (q.mode != M_PREEMPT && q.pre != 0) ? 0 : (r.added ? 2 : 1);  // screened / core, no add / core, add
+            if (lane == 0) { atomic_add_i64((long long*)k.prof + 21 + cls, _e1 - _e0); atomic_add_i64((long long*)k.prof + 24 + cls, 1); }
+          }
+          if (!_ok) {
+#else
+          if (!chunk_entry_fast(w, lds, r, cc, q)) {
+#endif
             // not a PLAIN entry (Unlimited / over-large operands): exact generic path, then stop the chunk
             chunk_scatter(k, rc, j);
             wsync();
@@ -2512,14 +2608,29 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
             stopped = true;
             break;
           }
+          if (q.mode == M_PREEMPT && w.mono_break) {
+            // a negative reservation (scheduler.go:806) lowered usage: the records fetched so far were screened against
+            // more usage than there is now; fetch the rest again
+            j++;
+            stopped = true;
+            break;
+          }
+          q = qn;
         }
+        if (stopped) { wsync(); if (lane == 0) w.mono_break = 0; }
         KQ_TS(k, 11);
         wsync();
-        for (int q = lane; q < j; q += WAVE) {
-          const PRec& r = rc[q];
-          if (r.slow) continue;  // the generic path wrote its own result
-          O.status[r.e] = r.status; O.action[r.e] = r.action; O.requeue_reason[r.e] = r.rq; O.skip[r.e] = r.skip; O.mode[r.e] = r.omode;
-          O.order[r.e] = r.pos;
+        {
+          // output pointers into locals first: read through `O` between the stores they would be reloaded from HBM one by one
+          uint8_t* const o_status = O.status; uint8_t* const o_action = O.action; uint8_t* const o_rq = O.requeue_reason;
+          uint8_t* const o_skip = O.skip; uint8_t* const o_mode = O.mode; int32_t* const o_order = O.order;
+          for (int q = lane; q < j; q += WAVE) {
+            const PRec& r = rc[q];
+            if (r.slow) continue;  // the generic path wrote its own result
+            o_status[r.e] = r.status; o_action[r.e] = r.action; o_rq[r.e] = r.rq; o_skip[r.e] = r.skip; o_mode[r.e] = r.omode;
+            o_order[r.e] = r.pos;
+            bytes += rec_algo_bytes(r);
+          }
         }
         chunk_scatter(k, rc, j);
         if (lane == 0) { w.chunk_done = j; w.chunk_stop = stopped ? 1 : 0; }
@@ -2528,7 +2639,7 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
       } else if (nnext > 0) {
         chunk_prefetch(k, w, rn, rc, nch, w.win_e + next0, w.win_pos + next0, nnext, tid - WAVE, nthreads - WAVE);
       }
-      bsync();
+      { KQ_T0(); bsync(); if (leader) KQ_TS(k, 13); }
       const int j = w.chunk_done;
       const bool clean = j == nch && !w.chunk_stop;
       if (clean && helpers) {
@@ -2536,16 +2647,22 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
       } else {
         done += j;
         if (done < nwin) {
+          KQ_T0();
           const int nre = (nwin - done) < CH ? (nwin - done) : CH;
           chunk_prefetch(k, w, rc, nullptr, 0, w.win_e + done, w.win_pos + done, nre, tid, nthreads);
           bsync();
+          if (leader) { KQ_TS(k, 27); KQ_TS(k, 28); }
         }
       }
     }
   }
+  if (loaded) { KQ_T0(); pc_flush_by(k, w, lds, tree, tid, nthreads); if (leader) KQ_TS(k, 9); }  // after the loop's last bsync
   if (!leader) return;
+#if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
+  if (lane == 0) { atomic_add_i64((long long*)k.prof + 14, clock64() - _tree0); atomic_add_i64((long long*)k.prof + 29, wall_clock64() - _wall0); }
+#endif
+  bytes = wsum_i64(bytes);
   if (lane == 0 && bytes) atomic_add_i64(O.stat_bytes, (long long)bytes);
-  if (loaded) { KQ_T0(); pc_flush(k, w, lds, tree); KQ_TS(k, 9); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2713,6 +2830,7 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
   for (int i = tid; i < nqs * KQ_MAXD; i += nthreads) cost[i] = 0;
   for (int i = tid; i < nn; i += nthreads) win[i] = -1;
   bsync();
+  const CoreCtx cc = core_ctx(k, w);
   // cqToEntry: the last head of a CQ wins (:58-60)
   for (int h = tid; h < H.n; h += nthreads) {
     int c = H.cq[h];
@@ -2826,8 +2944,9 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
         wsync();
         chunk_prefetch_wave(k, w, rec, w.win_e, w.win_pos, 1);
         if (!rec->slow) {
-          chunk_entry_fast(k, w, lds, *rec, &fast_bytes);
+          chunk_entry_fast(w, lds, *rec, cc, rec_preload(*rec));
           wsync();
+          fast_bytes += rec_algo_bytes(*rec);
           if (lane == 0) {
             O.status[e] = rec->status; O.action[e] = rec->action; O.requeue_reason[e] = rec->rq; O.skip[e] = rec->skip; O.mode[e] = rec->omode;
             O.order[e] = lpos;

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_order_scatter(int n, const int32_t* ran
   if (i < n) order_idx[rank[i]] = i;
 }
 
-constexpr int PROCESS_THREADS = 1024;  // wave 0 runs the serial core; all 4 waves prefetch the entry records of a chunk
+constexpr int PROCESS_THREADS = 256;   // wave 0 runs the serial core; all 4 waves prefetch the entry records of a chunk
 __global__ __launch_bounds__(PROCESS_THREADS) void k_process(const K* __restrict__ kp, unsigned lds_bytes) {
   const K& k = *kp;
   __shared__ Wave w;
