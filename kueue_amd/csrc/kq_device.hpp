@@ -132,6 +132,7 @@ struct DCfg {
   int n_fs, fs[2];           // fair-sharing preemption strategies (preemption.go:364-366)
   int fs_plain;              // all amounts small: per-node borrowed sums are exact in plain int64 (no saturation)
   int quota_check_strategy;
+  int dbg_variant;           // timing experiments only (KQ_DEBUG_VARIANT; results are wrong when non-zero)
   int64_t cycle;
 };
 
@@ -218,6 +219,8 @@ struct K {  // everything a kernel needs
   const int32_t* order_idx;  // [H] entry index at iterator position i
   long long* prof;           // [32] optional segment cycle counters (KQ_PROF builds)
   int32_t* cq_rm_bytes;      // [nq] candidate-record bytes of the rows preempted so far this cycle (they left cq.Workloads)
+  uint8_t* cq_dirty;         // [nq] a ClusterQueue-level usage cell of this CQ was written in HBM during this cycle's k_process
+  struct PRec* grec;         // [H] per-head entry records, static part (rec_fill_static); k_process copies them into LDS
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -288,13 +291,13 @@ struct UGW {  // writable global plane
 
 // process kernel: usage plane with the tree's cohort rows served from LDS (plane 0 = work, 1 = np)
 struct UP {
-  const DSnap* S; int64_t* g; int64_t* lds; int on, ncq, ncoh, plane, fr;
+  const DSnap* S; int64_t* g; int64_t* lds; int on, ncq, ncoh, plane, fr; uint8_t* dirty;
   KQ_MDEV int64_t* cell(int n) const {
     if (on && n >= S->nq) return lds + ((size_t)plane * ncoh + (S->node_local[n] - ncq)) * S->nfr + fr;
     return g + (size_t)n * S->nfr + fr;
   }
   KQ_MDEV int64_t get(int n) const { return *cell(n); }
-  KQ_MDEV void set(int n, int64_t v) const { *cell(n) = v; }
+  KQ_MDEV void set(int n, int64_t v) const { *cell(n) = v; if (dirty && n < S->nq) dirty[n] = 1; }  // see K::cq_dirty
 };
 
 // resource_node.go:106-122, root-first iteration over the precomputed path
@@ -415,7 +418,8 @@ struct Wave {
   int pc_on, pc_ncq, pc_ncoh;     // cache enabled, #CQs of the tree (node_local offset of cohorts), #cohorts
   int64_t* pc_lds;                // [2][pc_ncoh][nfr] : plane 0 = usage_work, plane 1 = usage_np
   int32_t path_coh[KQ_MAXD];      // cohort-local index of path[i] (i >= 1)
-  int32_t win_e[256], win_pos[256]; // this tree's entries inside the current window of the order
+  int32_t win_e[256], win_cq[256]; // this tree's entries inside the current window of the order, and their ClusterQueues
+  uint8_t win_off[256];           // ... and their positions in the order, relative to the window base
   int nwin2[2], chunk_done, chunk_stop;  // leader -> helper waves of the process workgroup
   // gathered cells of the entry under process: c = u * plen + i
   int64_t g_lq[CELLS], g_sq[CELLS], g_bl[CELLS], g_uw[CELLS], g_un[CELLS];
@@ -448,6 +452,11 @@ KQ_DEV bool np_exact_mode(const Wave& w) { return w.np_broken && w.n_pre > 0; }
 #else
 #define KQ_T0() do {} while (0)
 #define KQ_TS(k, id) do {} while (0)
+#endif
+#if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
+#define KQ_STAMP(i) do { const long long _n = clock64(); tacc[i] += _n - *tlast; *tlast = _n; } while (0)
+#else
+#define KQ_STAMP(i) do {} while (0)
 #endif
 
 KQ_DEV void set_error(const K& k, int code) {
@@ -1740,7 +1749,7 @@ KQ_DEV void nominate_head(const K& k, Wave& w, int h, int slot) {
 // processEntry (scheduler.go:392-523) — sequential inside one root-cohort tree
 // ------------------------------------------------------------------------------------------------
 KQ_DEV UP up_plane(const K& k, const Wave& w, int plane, int fr) {
-  return UP{&k.S, plane == 0 ? k.usage_work : k.usage_np, w.pc_lds, w.pc_on, w.pc_ncq, w.pc_ncoh, plane, fr};
+  return UP{&k.S, plane == 0 ? k.usage_work : k.usage_np, w.pc_lds, w.pc_on, w.pc_ncq, w.pc_ncoh, plane, fr, k.cq_dirty};
 }
 // LDS <-> HBM for the tree's cohort rows (both planes)
 // tid / nthreads: the threads sharing the copy; the caller synchronises them afterwards
@@ -1976,6 +1985,7 @@ KQ_DEV void process_entry_fast(const K& k, Wave& w, int e) {
         size_t o = ix(S, w.path[i], fr);
         if (d & 1) k.usage_work[o] = w.g_uw[c];
         if (d & 2) k.usage_np[o] = w.g_un[c];
+        if (w.path[i] < S.nq) k.cq_dirty[w.path[i]] = 1;
       }
     }
   }
@@ -2105,143 +2115,198 @@ constexpr int CH = 16;   // entries per chunk; two chunk buffers live in LDS (on
 constexpr int NBUF = 2;
 constexpr int64_t PLAIN_LIMIT = (int64_t)1 << 56;  // see "serial core" below
 constexpr int64_t QC_NOLIMIT = (int64_t)1 << 61;   // "no borrowing limit at this level" in PRec::ccv (sums of plain values stay below it)
-struct PRec {
-  int32_t e, pos, cq, plen, nuse, borrowing, mode, slow;
+struct alignas(16) PRec {
+  // ---- static part: a function of the head's nomination and the quota constants only. Written once per cycle for every head
+  // (rec_fill_static, after k_nominate), copied into LDS by the prefetch of k_process.
+  int32_t e, cq, plen, nuse, borrowing, mode, slow_static, pad0;
   uint32_t pol, flags;
-  int32_t coh[FD];
+  int32_t pad1[2];
   int32_t fr[FU];
-  int64_t qty[FU], nominal[FU], uw0[FU], un0[FU];
+  int64_t qty[FU], nominal[FU];
   int64_t lq[FU][FD], sqv[FU][FD];
   // quad core: Available(cq) = min over the path levels j of  sum_{k<j} max(0, lq_k - usage_k) + ccv_j - usage_j  with
   // ccv = subtree quota (+ borrowing limit below the root; QC_NOLIMIT without one)  — see core_run_quad
   int64_t ccv[FU][FD];
-  uint8_t status, action, rq, skip, omode, dirty, added, pad;  // dirty: CQ-level usage cells not yet in HBM; added: AddUsage ran
-  union { uint8_t b[FU]; uint64_t all; } pre;  // per slot: "already did not fit when the record was fetched" (see chunk_prefetch)
-  // quad core: where the usage_work cell of (slot, level) lives, as an int64 index from the LDS base (level 0: this record's
-  // uw0[slot]; cohort levels: the resident row), and whether one of the cell's constants is not a plain quantity
+  // cohort levels (i >= 1): index of the (node, flavor-resource) cell inside a plane of the tree's resident rows
   int32_t uoff[FU][FD];
-  uint8_t cbig[FU][FD];
+  uint8_t cbig[FU][FD];    // one of the cell's constants is not a plain quantity
+  // the ClusterQueue-level usage cells, both planes, AS THEY WERE AT THE START OF THE CYCLE (the serial core updates the LDS
+  // copy). Valid for an entry as long as K::cq_dirty of its ClusterQueue is clear; otherwise the entry takes the generic path.
+  int64_t uw0[FU], un0[FU];
+  // ---- dynamic part: written by the prefetch (pos .. pre) and by the serial core (the rest)
+  int32_t pos, slow;
+  union { uint8_t b[FU]; uint64_t all; } pre;  // per slot: "already did not fit when the record was fetched" (see chunk_prefetch)
+  uint8_t status, action, rq, skip, omode, dirty, added, pad;  // dirty: CQ-level usage cells not yet in HBM; added: AddUsage ran
 };
+constexpr size_t PREC_STATIC = offsetof(PRec, pos);
+static_assert(offsetof(PRec, status) % 4 == 0 && offsetof(PRec, action) == offsetof(PRec, status) + 1 && offsetof(PRec, rq) == offsetof(PRec, status) + 2 &&
+              offsetof(PRec, skip) == offsetof(PRec, status) + 3, "core_fit_quad writes status/action/rq/skip as one word");
+static_assert(PREC_STATIC % 16 == 0 && sizeof(PRec) % 16 == 0, "the static part is copied 16 bytes at a time");
 static_assert(offsetof(PRec, un0) - offsetof(PRec, uw0) == FU * sizeof(int64_t), "quad core: un0[u] is FU cells after uw0[u]");
 
-// Fills the records of one chunk. No synchronisation inside: the thread that writes a record header and the threads
-// that fetch its (slot, level) cells all start from the global inputs (head -> ClusterQueue -> path -> quota cells), so
-// any subset of the workgroup's threads can run it while wave 0 is busy with the previous chunk.
-// prev / nprev: the chunk that is still being processed — its CQ-level cells are not in HBM yet, so an entry of the same
-// ClusterQueue must not take the prefetched values (slow path).
-KQ_DEV void chunk_prefetch(const K& k, const Wave& w, PRec* rec, const PRec* prev, int nprev, const int32_t* ent, const int32_t* entpos, int nch,
-                           int tid, int nthreads) {
+// Static part of head e's record, one call per (slot, level) cell c = u * FD + i; the call with c == 0 also writes the header.
+// Runs for every head between k_nominate and k_process (k_records), so that the prefetch inside k_process is two dependent
+// memory round trips (entry -> record, record -> ClusterQueue usage cells) instead of walking head -> ClusterQueue -> path ->
+// quota cells for every chunk while the serial core waits.
+KQ_DEV void rec_fill_static(const K& k, int e, int c) {
   const DSnap& S = k.S; const DOut& O = k.O; const DHeads& H = k.H;
-  for (int j = tid; j < nch; j += nthreads) {
-    PRec& r = rec[j];
-    const int e = ent[j];
-    r.e = e; r.pos = entpos[j];
-    const int cq = H.cq[e];
-    r.cq = cq; r.flags = H.flags[e]; r.pol = S.cq_policy[cq];
-    r.plen = S.plen[cq]; r.borrowing = O.borrowing[e]; r.mode = O.nominated_mode[e];
-    const int nuse = (r.flags & KQ_HEAD_HAS_QUOTA_RESERVATION) ? 0 : O.use_n[e];  // netUsage scheduler.go:785-794
-    r.nuse = nuse;
-    int slow = (O.tgt_n[e] != 0 || nuse > FU || r.plen > FD || (r.plen > 1 && !w.pc_on)) ? 1 : 0;
-    // a ClusterQueue seen earlier in this chunk or in the chunk still in flight would read a stale CQ-level cell
-    for (int q = 0; q < j; q++) if (H.cq[ent[q]] == cq) slow = 1;
-    for (int q = 0; q < nprev; q++) if (prev[q].cq == cq) slow = 1;
-    if (!slow) for (int i = 1; i < r.plen; i++) r.coh[i] = S.node_local[S.path[(size_t)cq * KQ_MAXD + i]] - w.pc_ncq;
-    r.slow = slow; r.dirty = 0; r.added = 0;
+  PRec& r = k.grec[e];
+  const int u = c / FD, i = c % FD;
+  const int cq = H.cq[e];
+  const uint32_t flags = H.flags[e];
+  const int plen = S.plen[cq];
+  const int nuse = (flags & KQ_HEAD_HAS_QUOTA_RESERVATION) ? 0 : O.use_n[e];  // netUsage scheduler.go:785-794
+  if (c == 0) {
+    r.e = e; r.cq = cq; r.flags = flags; r.pol = S.cq_policy[cq];
+    r.plen = plen; r.borrowing = O.borrowing[e]; r.mode = O.nominated_mode[e]; r.nuse = nuse;
+    r.slow_static = (O.tgt_n[e] != 0 || nuse > FU || plen > FD) ? 1 : 0;
+    k.cq_dirty[cq] = 0;
   }
-  for (int idx = tid; idx < nch * FU * FD; idx += nthreads) {
-    const int j = idx / (FU * FD), u = (idx / FD) % FU, i = idx % FD;
-    PRec& r = rec[j];
-    const int e = ent[j];
-    const int cq = H.cq[e];
-    const int nuse = (H.flags[e] & KQ_HEAD_HAS_QUOTA_RESERVATION) ? 0 : O.use_n[e];
-    if (u >= nuse || nuse > FU || i >= S.plen[cq] || S.plen[cq] > FD) continue;
-    const int fr = O.use_fr[(size_t)e * KQ_MAXU + u];
-    const int n = S.path[(size_t)cq * KQ_MAXD + i];
-    const size_t o = ix(S, n, fr);
-    const int64_t sqv = S.sq[o], llv = S.ll[o];
-    const int64_t blv = S.bl[o], lqv = llv != KQ_NIL_LIMIT ? i64max(0, a_sub(sqv, llv)) : 0;
-    r.sqv[u][i] = sqv; r.lq[u][i] = lqv;
-    r.ccv[u][i] = i == S.plen[cq] - 1 ? sqv : (blv != KQ_NIL_LIMIT ? (int64_t)((uint64_t)sqv + (uint64_t)blv) : QC_NOLIMIT);
-    uint64_t big = (uint64_t)sqv | (uint64_t)lqv | (blv != KQ_NIL_LIMIT ? (uint64_t)blv : 0ull);
-    if (i == 0) {
-      const int64_t qty = O.use_qty[(size_t)e * KQ_MAXU + u], nominal = S.nominal[o];
-      r.fr[u] = fr; r.qty[u] = qty; r.nominal[u] = nominal; r.uw0[u] = k.usage_work[o]; r.un0[u] = k.usage_np[o];
-      big |= (uint64_t)qty | (uint64_t)nominal;
-      r.uoff[u][0] = (int32_t)(&r.uw0[u] - w.pc_lds);
-    } else {
-      r.uoff[u][i] = (S.node_local[n] - w.pc_ncq) * S.nfr + fr;
-    }
-    r.cbig[u][i] = big >= (uint64_t)PLAIN_LIMIT ? 1 : 0;
+  if (u >= nuse || nuse > FU || i >= plen || plen > FD) return;
+  const int fr = O.use_fr[(size_t)e * KQ_MAXU + u];
+  const int n = S.path[(size_t)cq * KQ_MAXD + i];
+  const size_t o = ix(S, n, fr);
+  const int64_t sqv = S.sq[o], llv = S.ll[o];
+  const int64_t blv = S.bl[o], lqv = llv != KQ_NIL_LIMIT ? i64max(0, a_sub(sqv, llv)) : 0;
+  r.sqv[u][i] = sqv; r.lq[u][i] = lqv;
+  r.ccv[u][i] = i == plen - 1 ? sqv : (blv != KQ_NIL_LIMIT ? (int64_t)((uint64_t)sqv + (uint64_t)blv) : QC_NOLIMIT);
+  uint64_t big = (uint64_t)sqv | (uint64_t)lqv | (blv != KQ_NIL_LIMIT ? (uint64_t)blv : 0ull);
+  if (i == 0) {
+    const int64_t qty = O.use_qty[(size_t)e * KQ_MAXU + u], nominal = S.nominal[o];
+    r.fr[u] = fr; r.qty[u] = qty; r.nominal[u] = nominal;
+    big |= (uint64_t)qty | (uint64_t)nominal;
+    r.uoff[u][0] = 0;
+    r.uw0[u] = r.un0[u] = k.usage[o];  // both work planes start the cycle as copies of the snapshot's usage
+  } else {
+    const int tree = S.tree_of[cq];
+    const int ncq = S.tree_cq_off[tree + 1] - S.tree_cq_off[tree];
+    r.uoff[u][i] = (S.node_local[n] - ncq) * S.nfr + fr;
   }
-  // Early "no longer fits" (scheduler.go:1167): between two generic-path entries the serial core only ever ADDS usage, and
-  // Available (resource_node.go:106-122) does not increase when usage grows, so a slot that does not fit against the usage
-  // visible now (cohort rows as they are in LDS at this moment, possibly while wave 0 is still adding to them; CQ-level
-  // cells from HBM) cannot fit when its turn comes. The serial core then skips the arithmetic for that entry. The core
-  // ends the chunk (and drops the records fetched ahead) whenever it subtracts: a negative reservation (:806).
-  for (int idx = tid; idx < nch * FU; idx += nthreads) {
-    const int j = idx / FU, u = idx % FU;
-    const int e = ent[j];
-    const int cq = H.cq[e];
-    const int nuse = (H.flags[e] & KQ_HEAD_HAS_QUOTA_RESERVATION) ? 0 : O.use_n[e];
-    const int plen = S.plen[cq], mode = O.nominated_mode[e];
-    bool bad = false;
-    if (u < nuse && nuse <= FU && plen <= FD && (plen == 1 || w.pc_on) && mode != M_PREEMPT && mode != M_NOFIT) {
-      const int fr = O.use_fr[(size_t)e * KQ_MAXU + u];
-      const int64_t qty = O.use_qty[(size_t)e * KQ_MAXU + u];
-      const int64_t* np_rows = w.pc_lds + (size_t)w.pc_ncoh * S.nfr;
-      // all levels' operands first (independent loads), then the root -> ClusterQueue recurrence
-      int64_t sqv[FD], lqv[FD], blv[FD], unv[FD];
-      #pragma unroll
-      for (int i = 0; i < FD; i++) {
-        sqv[i] = lqv[i] = unv[i] = 0; blv[i] = KQ_NIL_LIMIT;
-        if (i < plen) {
-          const int n = S.path[(size_t)cq * KQ_MAXD + i];
-          const size_t o = ix(S, n, fr);
-          const int64_t llv = S.ll[o];
-          sqv[i] = S.sq[o]; blv[i] = S.bl[o];
-          lqv[i] = llv != KQ_NIL_LIMIT ? i64max(0, a_sub(sqv[i], llv)) : 0;
-          unv[i] = i == 0 ? k.usage_np[o] : np_rows[(size_t)(S.node_local[n] - w.pc_ncq) * S.nfr + fr];
-        }
-      }
-      uint64_t big = (uint64_t)qty;
-      int64_t a = 0;
-      #pragma unroll
-      for (int i = FD - 1; i >= 0; i--) {
-        if (i >= plen) continue;
-        const bool hb = blv[i] != KQ_NIL_LIMIT;
-        big |= (uint64_t)sqv[i] | (uint64_t)lqv[i] | (uint64_t)unv[i] | (hb ? (uint64_t)blv[i] : 0ull);
-        if (i == plen - 1) a = sqv[i] - unv[i];
-        else {
-          const int64_t wm = (sqv[i] - lqv[i]) - i64max(0, unv[i] - lqv[i]) + blv[i];
-          a = i64max(0, lqv[i] - unv[i]) + ((hb && wm < a) ? wm : a);
-        }
-      }
-      const bool plain = big < (uint64_t)PLAIN_LIMIT;  // otherwise `a` may have wrapped: no claim
-      bad = plain && i64max(0, a) < qty;
+  r.cbig[u][i] = big >= (uint64_t)PLAIN_LIMIT ? 1 : 0;
+}
+
+// Fills the LDS records of one chunk from the static records, in three independent parts. No synchronisation inside: every
+// thread starts from the entry list and the global records, never from what another thread of this call wrote, so any subset
+// of the workgroup's threads can run it while wave 0 is busy with the previous chunk — and the three parts can run on
+// different waves at the same time (chunk_prefetch): what matters is the LATENCY of one call (the serial core waits for it at
+// the end of every chunk), i.e. the number of dependent memory round trips, not the amount of work.
+typedef uint32_t V16 __attribute__((vector_size(16)));  // a native 16-byte vector: arrays of it stay in registers
+// (1) static parts: 16 bytes per thread and step; all loads of a thread are issued before its first store
+KQ_DEV void prefetch_copy(const K& k, PRec* rec, const int32_t* ent, int nch, int t, int nt) {
+  constexpr int W16 = (int)(PREC_STATIC / 16), STAGE = 20;  // 16 records over one wave: 16 * 79 / 64 = 19.75 words per lane
+  const PRec* grec = k.grec;
+  const int total = nch * W16;
+  for (int base = t; base < total; base += nt * STAGE) {
+    V16 tmp[STAGE];
+    #pragma unroll
+    for (int m = 0; m < STAGE; m++) {  // unconditional (index clamped): the loads stay independent and `tmp` stays in registers
+      const int idx = base + m * nt < total ? base + m * nt : total - 1;
+      tmp[m] = ((const V16*)&grec[ent[idx / W16]])[idx % W16];
     }
-    rec[j].pre.b[u] = bad ? 1 : 0;
+    #pragma unroll
+    for (int m = 0; m < STAGE; m++) {
+      const int idx = base + m * nt;
+      if (idx < total) ((V16*)&rec[idx / W16])[idx % W16] = tmp[m];
+    }
   }
 }
-KQ_DEV void chunk_prefetch_wave(const K& k, Wave& w, PRec* rec, const int32_t* ent, const int32_t* entpos, int nch) {
-  chunk_prefetch(k, w, rec, nullptr, 0, ent, entpos, nch, lane_id(), WAVE);
+// the entries of a chunk: indices into the heads, their ClusterQueues, their positions in the order (base + offset)
+struct EntList { const int32_t* e; const int32_t* cq; const uint8_t* off; int posbase; };
+// (2) per (record, slot): the slot's early "no longer fits" (scheduler.go:1167); the lane of slot 0 also decides whether the
+// entry may use the serial core at all (position, slow flag).
+// Screening: between two generic-path entries the serial core only ever ADDS usage, and Available (resource_node.go:106-122)
+// does not increase when usage grows, so a slot that does not fit against the usage visible now (cohort rows as they are in
+// LDS at this moment, possibly while wave 0 is still adding to them; the ClusterQueue's own cells as recorded at the start of
+// the cycle, only used while K::cq_dirty says nothing wrote them) cannot fit when its turn comes. The serial core then skips
+// the arithmetic for that entry. The core ends the chunk (and drops the records fetched ahead) whenever it subtracts: a
+// negative reservation (:806). Same closed form as core_run_quad.
+// One global round trip (the record's fields and the dirty flag), then LDS reads.
+// prevcq / nprev: the ClusterQueues of the chunk that is still being processed — its CQ-level cells are neither in HBM nor
+// flagged dirty yet, so an entry of the same ClusterQueue takes the generic path; same for an earlier entry of this chunk.
+KQ_DEV void prefetch_cells(const K& k, const Wave& w, PRec* rec, const EntList& L, int nch, const int32_t* prevcq, int nprev, int t, int nt) {
+  const DSnap& S = k.S;
+  const PRec* grec = k.grec;
+  const int64_t* np_rows = w.pc_lds + (size_t)w.pc_ncoh * S.nfr;
+  const bool rows = w.pc_on != 0;
+  for (int idx = t; idx < nch * FU; idx += nt) {
+    const int j = idx / FU, u = idx % FU;
+    PRec& r = rec[j];
+    const PRec& g = grec[L.e[j]];
+    const int cq = L.cq[j];
+    // everything from the record and the flag first: independent loads
+    const int nuse = g.nuse, plen = g.plen, mode = g.mode, slow_static = g.slow_static;
+    const int dirty = k.cq_dirty[cq];
+    const int64_t qty = g.qty[u], un0 = g.un0[u];
+    int64_t ccv[FD], lq[FD]; int uoff[FD]; uint8_t cbig[FD];
+    #pragma unroll
+    for (int i = 0; i < FD; i++) { ccv[i] = g.ccv[u][i]; lq[i] = g.lq[u][i]; uoff[i] = g.uoff[u][i]; cbig[i] = g.cbig[u][i]; }
+    const bool on = u < nuse && nuse <= FU && plen <= FD;
+    const bool screen = on && (plen == 1 || rows) && mode != M_PREEMPT && mode != M_NOFIT;
+    int64_t un[FD];
+    un[0] = un0;
+    #pragma unroll
+    for (int i = 1; i < FD; i++) un[i] = (screen && i < plen) ? np_rows[uoff[i]] : 0;
+    if (u == 0) {
+      int slow = (slow_static || dirty || (plen > 1 && !rows)) ? 1 : 0;
+      for (int q = 0; q < j; q++) if (L.cq[q] == cq) slow = 1;
+      for (int q = 0; q < nprev; q++) if (prevcq[q] == cq) slow = 1;
+      r.pos = L.posbase + L.off[j]; r.slow = slow; r.dirty = 0; r.added = 0;
+    }
+    bool bad = false;
+    if (screen) {
+      int64_t E = 0, a = QC_NOLIMIT;
+      bool plain = (uint64_t)qty < (uint64_t)PLAIN_LIMIT;
+      #pragma unroll
+      for (int i = 0; i < FD; i++) {
+        if (i >= plen) continue;
+        plain = plain && cbig[i] == 0 && (uint64_t)un[i] < (uint64_t)PLAIN_LIMIT;
+        const int64_t x = (int64_t)((uint64_t)E + (uint64_t)ccv[i] - (uint64_t)un[i]);  // garbage (never UB) when not plain
+        a = x < a ? x : a;
+        E = (int64_t)((uint64_t)E + (uint64_t)i64max(0, (int64_t)((uint64_t)lq[i] - (uint64_t)un[i])));
+      }
+      bad = plain && i64max(0, a) < qty;  // not plain: the sums could have wrapped, no claim
+    }
+    r.pre.b[u] = bad ? 1 : 0;
+  }
+}
+KQ_DEV void chunk_prefetch(const K& k, const Wave& w, PRec* rec, const EntList& L, int nch, const int32_t* prevcq, int nprev, int tid, int nthreads) {
+  if (nthreads >= 3 * WAVE && nthreads % WAVE == 0) {
+    // two waves on the per-slot tasks (one task per lane), the rest on the copy: one global round trip each
+    constexpr int NCELL = 2 * WAVE;
+    if (tid < NCELL) prefetch_cells(k, w, rec, L, nch, prevcq, nprev, tid, NCELL);
+    else prefetch_copy(k, rec, L.e, nch, tid - NCELL, nthreads - NCELL);
+    return;
+  }
+  prefetch_copy(k, rec, L.e, nch, tid, nthreads);
+  prefetch_cells(k, w, rec, L, nch, prevcq, nprev, tid, nthreads);
+}
+KQ_DEV void chunk_prefetch_wave(const K& k, Wave& w, PRec* rec, const EntList& L, int nch) {
+  chunk_prefetch(k, w, rec, L, nch, nullptr, 0, lane_id(), WAVE);
   wsync();
 }
 
 // CQ-level cells of the chunk's first n entries that added usage go back to HBM, one lane per (entry, slot)
-KQ_DEV void chunk_scatter(const K& k, PRec* rec, int n) {
-  const DSnap& S = k.S;
+// Pointers the per-chunk write-out needs, read from the argument block once per tree: read through `k` where they are used
+// they cost a global round trip per chunk (the compiler must assume the stores in between may have changed the block).
+struct ProcPtrs { uint8_t *status, *action, *rq, *skip, *mode; int32_t* order; int64_t *uw, *un; uint8_t* dirty; int nfr; };
+KQ_DEV ProcPtrs proc_ptrs(const K& k) {
+  return ProcPtrs{k.O.status, k.O.action, k.O.requeue_reason, k.O.skip, k.O.mode, k.O.order, k.usage_work, k.usage_np, k.cq_dirty, k.S.nfr};
+}
+KQ_DEV void chunk_scatter(const ProcPtrs& P, PRec* rec, int n) {
   for (int idx = lane_id(); idx < n * FU; idx += WAVE) {
     PRec& r = rec[idx / FU];
     const int u = idx % FU;
     if (r.slow || !r.dirty || u >= r.nuse) continue;
-    const size_t o = ix(S, r.cq, r.fr[u]);
-    k.usage_work[o] = r.uw0[u]; k.usage_np[o] = r.un0[u];
+    const size_t o = (size_t)r.cq * P.nfr + r.fr[u];
+    P.uw[o] = r.uw0[u]; P.un[o] = r.un0[u];
+    P.dirty[r.cq] = 1;
   }
   wsync();
   // written back exactly once: a later generic-path entry may update the same ClusterQueue's cells in HBM
   for (int q = lane_id(); q < n; q += WAVE) rec[q].dirty = 0;
   wsync();
 }
+KQ_DEV void chunk_scatter(const K& k, PRec* rec, int n) { chunk_scatter(proc_ptrs(k), rec, n); }
 
 // ---- serial core ------------------------------------------------------------------------------------
 // One lane per flavor-resource slot, everything in registers, straight-line code specialised on the path
@@ -2253,10 +2318,10 @@ KQ_DEV void chunk_scatter(const K& k, PRec* rec, int n) {
 // Scalars the serial core needs from the kernel argument block. K lives in global memory and the compiler cannot prove the
 // core's stores do not alias it, so reading them through `k` costs a global load (+ wait) per entry; they are read once
 // per tree instead.
-struct CoreCtx { int nfr, total; bool prio_preemptors; const int64_t* bl_tab; const int32_t* path_tab; };
+struct CoreCtx { int nfr, total, dbg; bool prio_preemptors; const int64_t* bl_tab; const int32_t* path_tab; };
 KQ_DEV CoreCtx core_ctx(const K& k, const Wave& w) {
   CoreCtx c; c.nfr = k.S.nfr; c.total = w.pc_ncoh * k.S.nfr; c.prio_preemptors = gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS);
-  c.bl_tab = k.S.bl; c.path_tab = k.S.path;
+  c.bl_tab = k.S.bl; c.path_tab = k.S.path; c.dbg = k.C.dbg_variant;
   return c;
 }
 // algorithmic bytes of a record the serial core handled: scheduler.fits reads nuse * 40 * plen, AddUsage writes nuse * 8 * plen
@@ -2298,7 +2363,7 @@ template <int PLEN> KQ_DEV void slot_load(const CoreCtx& cc, const int64_t* pcl,
   for (int i = 0; i < PLEN; i++) {
     x.lq[i] = r.lq[u][i]; x.sq[i] = r.sqv[u][i];
     x.bl[i] = cc.bl_tab[(size_t)cc.path_tab[(size_t)r.cq * KQ_MAXD + i] * nfr + fr];  // not kept in the record (the quad core reads ccv)
-    x.cidx[i] = i == 0 ? 0 : r.coh[i] * nfr + fr;
+    x.cidx[i] = i == 0 ? 0 : r.uoff[u][i];
   }
   x.uw[0] = r.uw0[u]; x.un[0] = r.un0[u];
   #pragma unroll
@@ -2405,7 +2470,7 @@ KQ_DEV bool core_run_quad(Wave& w, int64_t* pcl, PRec& r, const CoreCtx& cc, con
   const int64_t qty = q.qty;
   const bool act = u < nuse && i < plen;
   // the only dependent LDS round trip: this lane's usage cell in its plane (un0 follows uw0 in the record; plane 1 of the rows is `total` further)
-  const int ua = q.uoff + (plane ? (i == 0 ? FU : cc.total) : 0);
+  const int ua = i == 0 ? (int)(&r.uw0[u] - pcl) + (plane ? FU : 0) : q.uoff + (plane ? cc.total : 0);
   const int64_t cur = act ? pcl[ua] : 0;
   if (wballot(act && (q.cbig != 0 || (uint64_t)cur >= (uint64_t)PLAIN_LIMIT)) != 0) return false;  // negatives and Unlimited land here too
   const int64_t t = i64max(0, q.lq - cur);
@@ -2428,7 +2493,7 @@ KQ_DEV bool core_run_quad(Wave& w, int64_t* pcl, PRec& r, const CoreCtx& cc, con
   } else {
     add = true; status = KQ_ST_ASSUMED; action = KQ_ACT_ADMIT;
   }
-  if (add) {
+  if (add && cc.dbg != 2) {
     int64_t val = qty;
     if (reserve && act) {  // quotaResourcesToReserve scheduler.go:796-814: every lane of the slot derives the same value
       const int64_t uw0 = r.uw0[u], nominal = r.nominal[u];
@@ -2445,6 +2510,65 @@ KQ_DEV bool core_run_quad(Wave& w, int64_t* pcl, PRec& r, const CoreCtx& cc, con
   if (lane == 0) { r.status = (uint8_t)status; r.action = (uint8_t)action; r.rq = (uint8_t)rq; r.skip = (uint8_t)skip; r.omode = (uint8_t)mode; }
   return true;
 }
+// The serial loop over the Fit-class records of a chunk, as a function of its own: inside process_tree the loop shares
+// registers with everything that kernel inlines, and the shuffling between entries (accumulator-register and lane spills) cost
+// more than the arithmetic. Here the live state is a work mask, one record's lane constants and the next one's.
+// Visits the set bits of `work` in ascending order while they are not in `special`; returns the mask that is left — its
+// lowest bit, if any, is a record this loop cannot handle (generic path, reservation, or operands that are not plain).
+#define KQ_LDS __attribute__((address_space(3)))
+KQ_DEV uint64_t uniform_u64(uint64_t v) {  // the same in every lane: keep it in scalar registers
+  return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)v) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32;
+}
+__device__ __noinline__ uint64_t fit_run(int64_t* pcl_generic, PRec* rc_generic, uint64_t work_v, uint64_t special_v, int total_v) {
+  uint64_t work = uniform_u64(work_v);
+  const uint64_t special = uniform_u64(special_v);
+  const int total = __builtin_amdgcn_readfirstlane(total_v);
+  KQ_LDS int64_t* const pcl = (KQ_LDS int64_t*)pcl_generic;
+  KQ_LDS PRec* const rc = (KQ_LDS PRec*)rc_generic;
+  const int lane = lane_id();
+  const int plane = lane >> 5, u = (lane >> 2) & 7, i = lane & 3;  // plane 0: usage_work, plane 1: usage_np
+  struct LC { int plen, nuse, mode, uoff, cbig; int64_t lq, ccv, qty; };
+  auto load = [&](int j) {
+    KQ_LDS PRec& r = rc[j];
+    LC x;
+    x.plen = r.plen; x.nuse = r.nuse; x.mode = r.mode; x.uoff = r.uoff[u][i]; x.cbig = r.cbig[u][i];
+    x.lq = r.lq[u][i]; x.ccv = r.ccv[u][i]; x.qty = r.qty[u];
+    return x;
+  };
+  if (!work || ((special >> ffs64(work)) & 1)) return work;
+  LC q = load(ffs64(work));
+  for (;;) {
+    const int cj = ffs64(work);
+    const uint64_t rest = work & (work - 1);
+    const bool more = rest != 0 && !((special >> ffs64(rest)) & 1);
+    const LC qn = load(more ? ffs64(rest) : cj);  // in flight during this record's arithmetic
+    KQ_LDS PRec& r = rc[cj];
+    const bool act = u < q.nuse && i < q.plen;
+    // this lane's usage cell in its plane: un0 follows uw0 in the record; plane 1 of the resident rows is `total` further
+    KQ_LDS int64_t* const cell = i == 0 ? &r.uw0[u] + (plane ? FU : 0) : pcl + q.uoff + (plane ? total : 0);
+    const int64_t cur = act ? *cell : 0;
+    if (__builtin_expect(wballot(act && (q.cbig != 0 || (uint64_t)cur >= (uint64_t)PLAIN_LIMIT)) != 0, 0)) return work;
+    const int64_t t = i64max(0, q.lq - cur);
+    const int64_t t1 = dpp64<0x90>(t), t2 = dpp64<0x40>(t), t3 = dpp64<0x00>(t);
+    const int64_t E = (i >= 1 ? t1 : 0) + (i >= 2 ? t2 : 0) + (i >= 3 ? t3 : 0);
+    int64_t a = act ? E + q.ccv - cur : QC_NOLIMIT;
+    { const int64_t o = dpp64<0xB1>(a); a = o < a ? o : a; }
+    { const int64_t o = dpp64<0x4E>(a); a = o < a ? o : a; }
+    const bool fits_ok = wballot(act && plane == 1 && i == 0 && i64max(0, a) < q.qty) == 0;
+    // addUsage on both planes when it fits (scheduler.go:1167-1175), predicated
+    if (fits_ok && act && (i == 0 || q.qty > E)) *cell = cur + (q.qty - E);
+    if (lane == 0) {
+      const uint32_t res = fits_ok ? ((uint32_t)KQ_ST_ASSUMED | (uint32_t)KQ_ACT_ADMIT << 8 | (uint32_t)KQ_RQ_GENERIC << 16 | (uint32_t)KQ_SKIP_NONE << 24)
+                                   : ((uint32_t)KQ_ST_SKIPPED | (uint32_t)KQ_ACT_NONE << 8 | (uint32_t)KQ_RQ_FAILED_AFTER_NOMINATION << 16 | (uint32_t)KQ_SKIP_NO_LONGER_FITS << 24);
+      *(KQ_LDS uint32_t*)&r.status = res;
+      r.omode = (uint8_t)q.mode; r.dirty = fits_ok ? 1 : 0; r.added = fits_ok ? 1 : 0;
+    }
+    wsync_lds();  // cohort rows in LDS must be visible to the next record's lanes
+    work = rest;
+    if (!more) return work;
+    q = qn;
+  }
+}
 #endif
 
 // serial core dispatch for one fast entry; false => the entry needs the generic exact path
@@ -2459,7 +2583,7 @@ KQ_DEV bool chunk_entry_fast(Wave& w, int64_t* pcl, PRec& r, const CoreCtx& cc, 
     if (lane_id() == 0) { r.status = (uint8_t)status; r.action = (uint8_t)action; r.rq = (uint8_t)rq; r.skip = KQ_SKIP_NONE; r.omode = (uint8_t)mode; }
     return true;
   }
-  if (mode != M_PREEMPT && q.pre != 0) {  // did not fit when fetched => does not fit now (scheduler.go:1167-1170)
+  if ((mode != M_PREEMPT && q.pre != 0) || cc.dbg == 1) {  // did not fit when fetched => does not fit now (scheduler.go:1167-1170)
     if (lane_id() == 0) { r.status = KQ_ST_SKIPPED; r.action = KQ_ACT_NONE; r.rq = KQ_RQ_FAILED_AFTER_NOMINATION; r.skip = KQ_SKIP_NO_LONGER_FITS; r.omode = (uint8_t)mode; }
     return true;
   }
@@ -2505,6 +2629,7 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
   const long long _tree0 = clock64(), _wall0 = wall_clock64();
 #endif
   const CoreCtx cc = core_ctx(k, w);
+  const ProcPtrs P = proc_ptrs(k);
   const bool chunked = lds_bytes >= rec_bytes;
   PRec* rec = (PRec*)((unsigned char*)lds + (lds_bytes - (chunked ? rec_bytes : 0)));
   bool loaded = false;
@@ -2517,11 +2642,11 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
       for (int off = 0; off < WIN; off += WAVE) {
         const int i = base + off + lane;
         bool mine = false;
-        int e = 0;
-        if (i < n) { e = k.order_idx[i]; mine = S.tree_of[k.H.cq[e]] == tree; }
+        int e = 0, ecq = 0;
+        if (i < n) { e = k.order_idx[i]; ecq = k.H.cq[e]; mine = S.tree_of[ecq] == tree; }
         const uint64_t m = wballot(mine);
         const int my = nwin + popc64(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-        if (mine) { w.win_e[my] = e; w.win_pos[my] = i; }
+        if (mine) { w.win_e[my] = e; w.win_cq[my] = ecq; w.win_off[my] = (uint8_t)(off + lane); }
         nwin += popc64(m);
       }
       if (lane == 0) w.nwin2[par] = nwin;
@@ -2535,7 +2660,7 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
       loaded = true;
     }
     if (!chunked) {
-      if (leader) for (int q = 0; q < nwin; q++) process_entry(k, w, w.win_e[q], w.win_pos[q], slot, tree);
+      if (leader) for (int q = 0; q < nwin; q++) process_entry(k, w, w.win_e[q], base + w.win_off[q], slot, tree);
       continue;
     }
     // Chunks of CH entries, double buffered: while wave 0 walks chunk c (serial core), the other waves fetch the records of
@@ -2552,7 +2677,7 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
     {
       KQ_T0();
       const int n0 = nwin < CH ? nwin : CH;
-      chunk_prefetch(k, w, rec, nullptr, 0, w.win_e, w.win_pos, n0, tid, nthreads);
+      chunk_prefetch(k, w, rec, EntList{w.win_e, w.win_cq, w.win_off, base}, n0, nullptr, 0, tid, nthreads);
       bsync();
       if (leader) KQ_TS(k, 10);
     }
@@ -2563,81 +2688,85 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
       PRec* rc = rec + cur * CH;
       PRec* rn = rec + (cur ^ 1) * CH;
 #ifdef KQ_HOST_EMU
-      if (g_emu_pipeline && nnext > 0) chunk_prefetch(k, w, rn, rc, nch, w.win_e + next0, w.win_pos + next0, nnext, 0, 1);
+      if (g_emu_pipeline && nnext > 0) chunk_prefetch(k, w, rn, EntList{w.win_e + next0, w.win_cq + next0, w.win_off + next0, base}, nnext, w.win_cq + done, nch, 0, 1);
 #endif
       if (leader) {
         KQ_T0();
         int j = 0;
         bool stopped = false;
-        const bool had_preemptions = w.n_pre > 0;  // only the generic path changes it, and that ends the chunk
-        QPre q = rec_preload(rc[0]);
-        for (; j < nch; j++) {
-          PRec& r = rc[j];
-          const QPre qn = rec_preload(rc[j + 1 < nch ? j + 1 : j]);  // in flight during this entry's arithmetic
-          if (q.slow || (had_preemptions && np_exact_mode(w))) {
+        // Classify the chunk's records first (one lane per record). Records that need no arithmetic — nothing to reserve, or
+        // screened at fetch time — get their result here, in parallel; the serial loop below only visits the others.
+        const bool exact_now = np_exact_mode(w);  // can only switch on inside the chunk through mark_broken => mono_break => stop
+        uint64_t work = 0, slowm = 0, resm = 0;
+        for (int b = 0; b < nch; b += WAVE) {
+          const int jj = b + lane;
+          int cls = 0;  // 0: done here, 1: generic path, 2: serial core (Fit), 3: serial core (reservation for a preemptor)
+          if (jj < nch) {
+            PRec& r = rc[jj];
+            const int mode = r.mode, nuse = r.nuse;
+            if (r.slow || exact_now) cls = 1;
+            else if (mode == M_NOFIT || nuse == 0) {
+              // scheduler.fits still runs before the mode is looked at (updateAssignmentIfNeeded :713-714): rec_algo_bytes counts it
+              int status = KQ_ST_NOT_NOMINATED, action = KQ_ACT_NONE, rq = KQ_RQ_GENERIC;
+              if (mode == M_NOFIT) rq = KQ_RQ_NOFIT;
+              else if (mode == M_PREEMPT) rq = KQ_RQ_PREEMPTION_NO_CANDIDATES;
+              else { status = KQ_ST_ASSUMED; action = KQ_ACT_ADMIT; }  // no quota usage: fits trivially
+              r.status = (uint8_t)status; r.action = (uint8_t)action; r.rq = (uint8_t)rq; r.skip = KQ_SKIP_NONE; r.omode = (uint8_t)mode;
+            } else if ((mode != M_PREEMPT && r.pre.all != 0) || cc.dbg == 1) {  // did not fit when fetched => does not fit now (:1167-1170)
+              r.status = KQ_ST_SKIPPED; r.action = KQ_ACT_NONE; r.rq = KQ_RQ_FAILED_AFTER_NOMINATION; r.skip = KQ_SKIP_NO_LONGER_FITS; r.omode = (uint8_t)mode;
+            } else cls = mode == M_PREEMPT ? 3 : 2;
+          }
+          work |= wballot(cls != 0) << b; slowm |= wballot(cls == 1) << b; resm |= wballot(cls == 3) << b;
+        }
+        wsync_lds();
+        j = nch;
+        while (work) {
+#ifndef KQ_HOST_EMU
+          work = fit_run(lds, rc, work, slowm | resm, cc.total);  // the Fit-class records up to the next special one
+          if (!work) break;
+#endif
+          const int cj = ffs64(work);
+          work &= work - 1;
+          PRec& r = rc[cj];
+          bool generic = ((slowm >> cj) & 1) != 0;
+          // reservation for a preemptor, or a Fit-class record fit_run handed back (operands not plain): the general core
+          if (!generic) generic = !chunk_entry_fast(w, lds, r, cc, rec_preload(r));  // (the exact core always succeeds today)
+          if (generic) {
             // generic path (targets / recompute / oversize / usage_np no longer incremental). It reads and writes HBM for
             // CQ-level cells, so prefetched CQ-level values may be stale afterwards: stop the chunk behind it.
-            chunk_scatter(k, rc, j);  // earlier fast entries' CQ-level cells must be in HBM first
+            chunk_scatter(P, rc, cj);  // earlier fast entries' CQ-level cells must be in HBM first
             wsync();
             process_entry(k, w, r.e, r.pos, slot, tree);
             if (lane == 0) r.slow = 2;
             wsync();
-            j++;
+            j = cj + 1;
             stopped = true;
             break;
           }
-#if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
-          const long long _e0 = clock64();
-          const bool _ok = chunk_entry_fast(w, lds, r, cc, q);
-          {
-            const long long _e1 = clock64();
-            const int cls = (q.mode != M_PREEMPT && q.pre != 0) ? 0 : (r.added ? 2 : 1);  // screened / core, no add / core, add
-            if (lane == 0) { atomic_add_i64((long long*)k.prof + 21 + cls, _e1 - _e0); atomic_add_i64((long long*)k.prof + 24 + cls, 1); }
-          }
-          if (!_ok) {
-#else
-          if (!chunk_entry_fast(w, lds, r, cc, q)) {
-#endif
-            // not a PLAIN entry (Unlimited / over-large operands): exact generic path, then stop the chunk
-            chunk_scatter(k, rc, j);
-            wsync();
-            process_entry(k, w, r.e, r.pos, slot, tree);
-            if (lane == 0) r.slow = 2;
-            wsync();
-            j++;
-            stopped = true;
-            break;
-          }
-          if (q.mode == M_PREEMPT && w.mono_break) {
+          if (((resm >> cj) & 1) && w.mono_break) {
             // a negative reservation (scheduler.go:806) lowered usage: the records fetched so far were screened against
             // more usage than there is now; fetch the rest again
-            j++;
+            j = cj + 1;
             stopped = true;
             break;
           }
-          q = qn;
         }
         if (stopped) { wsync(); if (lane == 0) w.mono_break = 0; }
         KQ_TS(k, 11);
         wsync();
-        {
-          // output pointers into locals first: read through `O` between the stores they would be reloaded from HBM one by one
-          uint8_t* const o_status = O.status; uint8_t* const o_action = O.action; uint8_t* const o_rq = O.requeue_reason;
-          uint8_t* const o_skip = O.skip; uint8_t* const o_mode = O.mode; int32_t* const o_order = O.order;
-          for (int q = lane; q < j; q += WAVE) {
-            const PRec& r = rc[q];
-            if (r.slow) continue;  // the generic path wrote its own result
-            o_status[r.e] = r.status; o_action[r.e] = r.action; o_rq[r.e] = r.rq; o_skip[r.e] = r.skip; o_mode[r.e] = r.omode;
-            o_order[r.e] = r.pos;
-            bytes += rec_algo_bytes(r);
-          }
+        for (int q = lane; q < j; q += WAVE) {
+          const PRec& r = rc[q];
+          if (r.slow) continue;  // the generic path wrote its own result
+          P.status[r.e] = r.status; P.action[r.e] = r.action; P.rq[r.e] = r.rq; P.skip[r.e] = r.skip; P.mode[r.e] = r.omode;
+          P.order[r.e] = r.pos;
+          bytes += rec_algo_bytes(r);
         }
-        chunk_scatter(k, rc, j);
+        chunk_scatter(P, rc, j);
         if (lane == 0) { w.chunk_done = j; w.chunk_stop = stopped ? 1 : 0; }
         wsync();
         KQ_TS(k, 12);
       } else if (nnext > 0) {
-        chunk_prefetch(k, w, rn, rc, nch, w.win_e + next0, w.win_pos + next0, nnext, tid - WAVE, nthreads - WAVE);
+        chunk_prefetch(k, w, rn, EntList{w.win_e + next0, w.win_cq + next0, w.win_off + next0, base}, nnext, w.win_cq + done, nch, tid - WAVE, nthreads - WAVE);
       }
       { KQ_T0(); bsync(); if (leader) KQ_TS(k, 13); }
       const int j = w.chunk_done;
@@ -2649,7 +2778,7 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
         if (done < nwin) {
           KQ_T0();
           const int nre = (nwin - done) < CH ? (nwin - done) : CH;
-          chunk_prefetch(k, w, rc, nullptr, 0, w.win_e + done, w.win_pos + done, nre, tid, nthreads);
+          chunk_prefetch(k, w, rc, EntList{w.win_e + done, w.win_cq + done, w.win_off + done, base}, nre, nullptr, 0, tid, nthreads);
           bsync();
           if (leader) { KQ_TS(k, 27); KQ_TS(k, 28); }
         }
@@ -2940,9 +3069,9 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
       // processEntry: the straight-line core on a prefetched record when the entry has no preemption targets
       bool done = false;
       if (have_rec && !np_exact_mode(w)) {
-        if (lane == 0) { w.win_e[0] = e; w.win_pos[0] = lpos; }
+        if (lane == 0) { w.win_e[0] = e; w.win_cq[0] = ec; w.win_off[0] = 0; }
         wsync();
-        chunk_prefetch_wave(k, w, rec, w.win_e, w.win_pos, 1);
+        chunk_prefetch_wave(k, w, rec, EntList{w.win_e, w.win_cq, w.win_off, lpos}, 1);
         if (!rec->slow) {
           chunk_entry_fast(w, lds, *rec, cc, rec_preload(*rec));
           wsync();

@@ -71,6 +71,13 @@ __global__ __launch_bounds__(256) void k_order_scatter(int n, const int32_t* ran
   if (i < n) order_idx[rank[i]] = i;
 }
 
+// static part of every head's entry record (kq::rec_fill_static): one thread per (head, flavor-resource slot, path level)
+__global__ __launch_bounds__(256) void k_records(const K* __restrict__ kp) {
+  const K& k = *kp;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < k.H.n * FU * FD) rec_fill_static(k, idx / (FU * FD), idx % (FU * FD));
+}
+
 constexpr int PROCESS_THREADS = 256;   // wave 0 runs the serial core; all 4 waves prefetch the entry records of a chunk
 __global__ __launch_bounds__(PROCESS_THREADS) void k_process(const K* __restrict__ kp, unsigned lds_bytes) {
   const K& k = *kp;
@@ -278,6 +285,11 @@ struct HipBackend {
   void launch_nominate(const K& k, int slots) {
     hipLaunchKernelGGL(k_nominate, dim3(slots), dim3(64), 0, stream, put_k(k, 0), slots);
     chk(hipGetLastError(), "k_nominate");
+  }
+  void launch_records(const K& k) {
+    if (k.H.n == 0) return;
+    hipLaunchKernelGGL(k_records, dim3((k.H.n * FU * FD + 255) / 256), dim3(256), 0, stream, (const K*)dk[0]);
+    chk(hipGetLastError(), "k_records");
   }
   void launch_order(const K& k, int32_t* order_idx, int32_t* rank) {
     const int nb = (k.H.n + 255) / 256;

@@ -7,6 +7,7 @@
 // HipBackend (kq_engine.hip) is the product. EmuBackend (tests/emu) runs the same kernels as plain
 // loops with a 1-lane wave so the CPU suite can check the control logic; it is never shipped.
 #pragma once
+#include <cstdlib>
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -31,7 +32,7 @@ template <class B> struct EngineT {
   // cycle buffers (grow-only)
   struct Buf { void* p = nullptr; size_t cap = 0; };
   std::vector<Buf*> all_bufs;
-  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_fs[20];
+  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_grec, b_cqd, b_fs[20];
   bool force_exact_drs = false;  // tests: take the saturation-safe DRS loops even when the sums would be exact
   struct HeadBatch { Buf hb[16]; DHeads H{}; int n = 0; size_t nps = 0; int slot_cap = 1; int64_t cycle = 0; bool valid = false; bool plain = true; };
   std::vector<HeadBatch> batches;  // [0] = transient batch of kq_cycle_run, [1+b] = resident batch b
@@ -69,7 +70,7 @@ template <class B> struct EngineT {
   ~EngineT() {
     free_snapshot();
     if (hstage) be.free_host(hstage);
-    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb}) if (b->p) be.free(b->p);
+    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb, &b_grec, &b_cqd}) if (b->p) be.free(b->p);
     for (auto& b : b_fs) if (b.p) be.free(b.p);
     for (auto& c : ring) for (Buf* b : {&c.cq, &c.use_n, &c.use_fr, &c.use_qty}) if (b->p) be.free(b->p);
     for (auto& hbch : batches) for (auto& b : hbch.hb) if (b.p) be.free(b.p);
@@ -325,6 +326,7 @@ template <class B> struct EngineT {
     K k{};
     k.S = S;
     k.C.n_fs = std::min(std::max(cfg.n_fs_strategies, 0), 2); k.C.fs[0] = cfg.fs_strategies[0]; k.C.fs[1] = cfg.fs_strategies[1];
+    { const char* dv = getenv("KQ_DEBUG_VARIANT"); k.C.dbg_variant = dv ? atoi(dv) : 0; }
     k.C.fs_plain = (prep.fs_plain && hbch.plain && prep.nR <= KQ_MAXR && !force_exact_drs) ? 1 : 0;
     k.C.gates = cfg.gates; k.C.fair_sharing = cfg.fair_sharing; k.C.quota_check_strategy = cfg.quota_check_strategy; k.C.cycle = hbch.cycle;
     k.H = hbch.H;
@@ -391,6 +393,8 @@ template <class B> struct EngineT {
     k.usage_np = grow<int64_t>(b_usage_np, Nfr);
     k.preempted = grow<uint8_t>(b_preempted, std::max(prep.n_adm, 1));
     k.prof = (long long*)grow<int64_t>(b_prof, 32);
+    k.grec = grow<PRec>(b_grec, n);
+    k.cq_dirty = grow<uint8_t>(b_cqd, std::max(prep.nq, 1));  // cleared per head by k_records
     int32_t* order_idx = grow<int32_t>(b_order, n);
     k.order_idx = order_idx;
     be.d2d(k.usage_work, d_usage, Nfr * sizeof(int64_t));
@@ -404,6 +408,7 @@ template <class B> struct EngineT {
       be.d2d(X.bs_pos, X.bu_pos, (size_t)prep.N * sizeof(int32_t));
     }
     be.launch_nominate(k, slots_nom);
+    be.launch_records(k);  // entry records (static part) for k_process; charged to the nominate interval
     be.timer_mark(1);
     int32_t* rank = grow<int32_t>(b_rank, n);
     if (!cfg.fair_sharing) be.launch_order(k, order_idx, rank);

@@ -62,6 +62,9 @@ struct EmuBackend {
       for (int h = slot; h < k.H.n; h += slots) nominate_head(k, w, h, slot);
     }
   }
+  void launch_records(const K& k) {
+    for (int e = 0; e < k.H.n; e++) for (int c = 0; c < FU * FD; c++) rec_fill_static(k, e, c);
+  }
   void launch_order(const K& k, int32_t* order_idx, int32_t*) {
     for (int i = 0; i < k.H.n; i++) {
       int rank = 0;

@@ -27,5 +27,7 @@ for i, nm in names.items():
     print(f"{nm:28s} {prof[i]/n:10.1f} cycles/entry   total {prof[i]}")
 for i, nm in ((24, "screened"), (25, "core, no add"), (26, "core, add")):
     print(f"entries {nm:14s} {prof[i]/n:6.3f} of all, {prof[i-3]/max(1, prof[i]):8.1f} cycles each")
+nw = max(1, prof[21])
+print(f"worked entries per cycle {prof[21]/10:.0f}; cycles per worked entry: loop top->core start (preload issue) {prof[16]/nw:.0f}, usage load + plain ballot {prof[17]/nw:.0f}, fits {prof[18]/nw:.0f}, add + results + sync {prof[19]/nw:.0f}, loop back {prof[20]/nw:.0f}")
 print(f"clock64 / wall_clock64 = {prof[14]/max(1,prof[29]):.2f}  (wall clock is 100 MHz => core clock {prof[14]/max(1,prof[29])*0.1:.2f} GHz); tree wall time {prof[29]/10/100:.1f} us per cycle")
 print("kernel ms last cycle", d.kernel_ms)
