@@ -132,7 +132,7 @@ struct DCfg {
   int n_fs, fs[2];           // fair-sharing preemption strategies (preemption.go:364-366)
   int fs_plain;              // all amounts small: per-node borrowed sums are exact in plain int64 (no saturation)
   int quota_check_strategy;
-  int dbg_variant;           // timing experiments only (KQ_DEBUG_VARIANT; results are wrong when non-zero)
+  int dbg_variant;           // KQ_PROF builds only: timing experiments (KQ_DEBUG_VARIANT; results are wrong when non-zero)
   int64_t cycle;
 };
 
@@ -452,11 +452,6 @@ KQ_DEV bool np_exact_mode(const Wave& w) { return w.np_broken && w.n_pre > 0; }
 #else
 #define KQ_T0() do {} while (0)
 #define KQ_TS(k, id) do {} while (0)
-#endif
-#if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
-#define KQ_STAMP(i) do { const long long _n = clock64(); tacc[i] += _n - *tlast; *tlast = _n; } while (0)
-#else
-#define KQ_STAMP(i) do {} while (0)
 #endif
 
 KQ_DEV void set_error(const K& k, int code) {
@@ -2321,7 +2316,12 @@ KQ_DEV void chunk_scatter(const K& k, PRec* rec, int n) { chunk_scatter(proc_ptr
 struct CoreCtx { int nfr, total, dbg; bool prio_preemptors; const int64_t* bl_tab; const int32_t* path_tab; };
 KQ_DEV CoreCtx core_ctx(const K& k, const Wave& w) {
   CoreCtx c; c.nfr = k.S.nfr; c.total = w.pc_ncoh * k.S.nfr; c.prio_preemptors = gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS);
-  c.bl_tab = k.S.bl; c.path_tab = k.S.path; c.dbg = k.C.dbg_variant;
+  c.bl_tab = k.S.bl; c.path_tab = k.S.path;
+#ifdef KQ_PROF
+  c.dbg = k.C.dbg_variant;  // timing experiments (tools/prof_process.py): results are wrong when non-zero
+#else
+  c.dbg = 0;
+#endif
   return c;
 }
 // algorithmic bytes of a record the serial core handled: scheduler.fits reads nuse * 40 * plen, AddUsage writes nuse * 8 * plen

@@ -326,7 +326,10 @@ template <class B> struct EngineT {
     K k{};
     k.S = S;
     k.C.n_fs = std::min(std::max(cfg.n_fs_strategies, 0), 2); k.C.fs[0] = cfg.fs_strategies[0]; k.C.fs[1] = cfg.fs_strategies[1];
+    k.C.dbg_variant = 0;
+#ifdef KQ_PROF
     { const char* dv = getenv("KQ_DEBUG_VARIANT"); k.C.dbg_variant = dv ? atoi(dv) : 0; }
+#endif
     k.C.fs_plain = (prep.fs_plain && hbch.plain && prep.nR <= KQ_MAXR && !force_exact_drs) ? 1 : 0;
     k.C.gates = cfg.gates; k.C.fair_sharing = cfg.fair_sharing; k.C.quota_check_strategy = cfg.quota_check_strategy; k.C.cycle = hbch.cycle;
     k.H = hbch.H;

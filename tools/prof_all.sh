@@ -3,8 +3,8 @@
 set -x
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-for W in cfg3 cfg5; do
-  if [ $W = cfg3 ]; then CMD="python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline"; else CMD="python $R/bench.py --workload cfg5 --steps 5 --warmup 1 --no-cpu-baseline"; fi
+for W in ${@:-cfg3 cfg5}; do
+  if [ $W = cfg3 ]; then CMD="python $R/bench.py --no-cpu-baseline"; else CMD="python $R/bench.py --workload cfg5 --steps 5 --warmup 1 --no-cpu-baseline"; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/p_${W}_stats -- $CMD > $R/gpurun_out/p_${W}_stats.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/p_${W}_fetch -- $CMD > $R/gpurun_out/p_${W}_fetch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/p_${W}_write -- $CMD > $R/gpurun_out/p_${W}_write.log 2>&1

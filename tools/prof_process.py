@@ -21,13 +21,9 @@ for c in range(3, 13):
     h = pop.heads_for_cycle(c); d = eng.run(h); n += h.n
 lib.kq_debug_prof(eng._h, F.ptr(prof), 1)
 names = {8: "pc_load", 9: "pc_flush", 10: "chunk_prefetch", 11: "chunk serial core",  12: "chunk write results", 13: "leader waits for helpers", 14: "leader: whole tree", 27: "re-prefetch after a stopped chunk",
-         21: "core: screened entries", 22: "core: no add", 23: "core: add", 0: "slow: load_head", 1: "slow: use list",
+         0: "slow: load_head", 1: "slow: use list",
          16: "fair: computeDRS (leader wave)", 17: "fair: barrier wait", 18: "fair: tournament", 19: "fair: pop bookkeeping", 20: "fair: processEntry"}
 for i, nm in names.items():
     print(f"{nm:28s} {prof[i]/n:10.1f} cycles/entry   total {prof[i]}")
-for i, nm in ((24, "screened"), (25, "core, no add"), (26, "core, add")):
-    print(f"entries {nm:14s} {prof[i]/n:6.3f} of all, {prof[i-3]/max(1, prof[i]):8.1f} cycles each")
-nw = max(1, prof[21])
-print(f"worked entries per cycle {prof[21]/10:.0f}; cycles per worked entry: loop top->core start (preload issue) {prof[16]/nw:.0f}, usage load + plain ballot {prof[17]/nw:.0f}, fits {prof[18]/nw:.0f}, add + results + sync {prof[19]/nw:.0f}, loop back {prof[20]/nw:.0f}")
 print(f"clock64 / wall_clock64 = {prof[14]/max(1,prof[29]):.2f}  (wall clock is 100 MHz => core clock {prof[14]/max(1,prof[29])*0.1:.2f} GHz); tree wall time {prof[29]/10/100:.1f} us per cycle")
 print("kernel ms last cycle", d.kernel_ms)
