@@ -3188,6 +3188,13 @@ KQ_DEV void derive_cohort_cell(const DSnap& S, const DDerive& d, int cohort, int
 // closed-loop support: fold admitted usage into the resident snapshot / take it out again
 // (cache side of assumeWorkload: clusterqueue.go:594 updateWorkloadUsage -> resource_node.go:144-165)
 // ------------------------------------------------------------------------------------------------
+// Start-of-cycle housekeeping as ONE launch: fills and device-to-device copies of 4-byte words (k_prep).
+struct DPrepOp { void* dst; const void* src; uint32_t words; uint32_t fill; };  // src == nullptr: fill
+struct DPrep { int n; DPrepOp op[10]; };
+KQ_DEV void prep_word(const DPrep& p, int o, uint32_t i) {
+  const DPrepOp& x = p.op[o];
+  ((uint32_t*)x.dst)[i] = x.src ? ((const uint32_t*)x.src)[i] : x.fill;
+}
 struct DCommit {
   int n;                  // heads of the committed cycle
   const int32_t* cq;      // [n]
@@ -3242,6 +3249,11 @@ KQ_DEV void commit_mask_head(const K& k, int h, int32_t* use_n_out, int32_t* cq_
   use_n_out[h] = take ? k.O.use_n[h] : 0;
   cq_out[h] = k.H.cq[h];
   if (take) atomic_add_i32(count, 1);
+}
+// one call per (head, slot): keeps the cycle's usage rows for a later release (the cycle's own buffers are reused)
+KQ_DEV void commit_keep_cell(const K& k, int i, int32_t* use_n_out, int32_t* cq_out, int32_t* fr_out, int64_t* qty_out, int32_t* count) {
+  fr_out[i] = k.O.use_fr[i]; qty_out[i] = k.O.use_qty[i];
+  if (i % KQ_MAXU == 0) commit_mask_head(k, i / KQ_MAXU, use_n_out, cq_out, count);
 }
 
 // classical entry order (scheduler.go:1110-1163): a precedes b

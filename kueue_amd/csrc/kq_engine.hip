@@ -111,10 +111,27 @@ __global__ __launch_bounds__(256) void k_fair_rank_apply(const K* __restrict__ k
   if (i < k.H.n && k.X.fs_key[i] >= 0) k.O.order[i] = rank[i];
 }
 
-__global__ __launch_bounds__(256) void k_commit_mask(const K* __restrict__ kp, int32_t* use_n_out, int32_t* cq_out, int32_t* count) {
+__global__ __launch_bounds__(256) void k_commit_mask(const K* __restrict__ kp, int32_t* use_n_out, int32_t* cq_out, int32_t* fr_out, int64_t* qty_out, int32_t* count) {
   const K& k = *kp;
-  const int h = blockIdx.x * 256 + threadIdx.x;
-  if (h < k.H.n) commit_mask_head(k, h, use_n_out, cq_out, count);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < k.H.n * KQ_MAXU) commit_keep_cell(k, i, use_n_out, cq_out, fr_out, qty_out, count);
+}
+// start-of-cycle fills and copies in one launch (kq::DPrep): blockIdx.y = operation
+__global__ __launch_bounds__(256) void k_prep(DPrep p) {
+  const int o = blockIdx.y;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < p.op[o].words; i += gridDim.x * 256) prep_word(p, o, i);
+}
+// cohort usage re-derived from the ClusterQueue cells, every level in one launch (one workgroup; small populations)
+__global__ __launch_bounds__(1024) void k_usage_levels(DSnap S, int64_t* usage, int max_depth) {
+  const int cells = S.nc * S.nfr;
+  for (int dep = max_depth; dep >= 0; dep--) {
+    for (int i = threadIdx.x; i < cells; i += 1024) {
+      const int cohort = S.nq + i / S.nfr;
+      if (S.depth[cohort] == dep) derive_usage_cell(S, usage, cohort, i % S.nfr);
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
 }
 __global__ __launch_bounds__(64) void k_commit(DSnap S, DCommit c, int add) { commit_tree(S, c, blockIdx.x, add != 0); }
 __global__ __launch_bounds__(256) void k_commit_cq(DSnap S, DCommit c, int add) {
@@ -254,20 +271,34 @@ struct HipBackend {
     hipLaunchKernelGGL(k_tas_fits, dim3((n + 63) / 64), dim3(64), 0, stream, T, n, leaf, count, spr, flag);
     chk(hipGetLastError(), "k_tas_fits");
   }
-  void launch_commit_mask(int n, int32_t* use_n_out, int32_t* cq_out, int32_t* count) {  // uses the K block of the last cycle
-    hipLaunchKernelGGL(k_commit_mask, dim3((n + 255) / 256), dim3(256), 0, stream, (const K*)dk[1], use_n_out, cq_out, count);
+  void launch_commit_mask(int n, int32_t* use_n_out, int32_t* cq_out, int32_t* fr_out, int64_t* qty_out, int32_t* count) {  // uses the K block of the last cycle
+    hipLaunchKernelGGL(k_commit_mask, dim3((n * KQ_MAXU + 255) / 256), dim3(256), 0, stream, (const K*)dk[1], use_n_out, cq_out, fr_out, qty_out, count);
     chk(hipGetLastError(), "k_commit_mask");
   }
-  void launch_commit(const DSnap& S, const DCommit& c, bool add, bool consistent, int max_depth) {
-    if (consistent) {
-      hipLaunchKernelGGL(k_commit_cq, dim3((c.n * KQ_MAXU + 255) / 256), dim3(256), 0, stream, S, c, add ? 1 : 0);
-      if (S.nc * S.nfr > 0)
-        for (int dep = max_depth; dep >= 0; dep--)
-          hipLaunchKernelGGL(k_usage_level, dim3((S.nc * S.nfr + 255) / 256), dim3(256), 0, stream, S, c.usage, dep);
-    } else if (S.n_tree > 0) {
-      hipLaunchKernelGGL(k_commit, dim3(S.n_tree), dim3(64), 0, stream, S, c, add ? 1 : 0);
-    }
+  // ClusterQueue-level cells only; the cohort levels follow from them (launch_usage_levels, deferred by the host)
+  void launch_commit_cells(const DSnap& S, const DCommit& c, bool add) {
+    hipLaunchKernelGGL(k_commit_cq, dim3((c.n * KQ_MAXU + 255) / 256), dim3(256), 0, stream, S, c, add ? 1 : 0);
+    chk(hipGetLastError(), "k_commit_cq");
+  }
+  void launch_commit_trees(const DSnap& S, const DCommit& c, bool add) {
+    if (S.n_tree > 0) hipLaunchKernelGGL(k_commit, dim3(S.n_tree), dim3(64), 0, stream, S, c, add ? 1 : 0);
     chk(hipGetLastError(), "k_commit");
+  }
+  void launch_usage_levels(const DSnap& S, int64_t* usage, int max_depth) {
+    const int cells = S.nc * S.nfr;
+    if (cells == 0) return;
+    if (cells <= 32768) hipLaunchKernelGGL(k_usage_levels, dim3(1), dim3(1024), 0, stream, S, usage, max_depth);
+    else for (int dep = max_depth; dep >= 0; dep--)
+      hipLaunchKernelGGL(k_usage_level, dim3((cells + 255) / 256), dim3(256), 0, stream, S, usage, dep);
+    chk(hipGetLastError(), "k_usage_level");
+  }
+  void launch_prep(const DPrep& p) {
+    uint32_t mx = 0;
+    for (int o = 0; o < p.n; o++) mx = std::max(mx, p.op[o].words);
+    if (p.n == 0 || mx == 0) return;
+    const unsigned gx = std::min<unsigned>((mx + 1023) / 1024, 256);
+    hipLaunchKernelGGL(k_prep, dim3(gx, p.n), dim3(256), 0, stream, p);
+    chk(hipGetLastError(), "k_prep");
   }
   void launch_derive(const DSnap& S, const DDerive& d, int max_depth) {
     if (S.nq * S.nfr > 0) hipLaunchKernelGGL(k_derive_cq, dim3((S.nq * S.nfr + 255) / 256), dim3(256), 0, stream, S, d);
@@ -293,7 +324,6 @@ struct HipBackend {
   }
   void launch_order(const K& k, int32_t* order_idx, int32_t* rank) {
     const int nb = (k.H.n + 255) / 256;
-    chk(hipMemsetAsync(rank, 0, (size_t)k.H.n * sizeof(int32_t), stream), "memset rank");
     hipLaunchKernelGGL(k_order, dim3(nb, nb), dim3(256), 0, stream, (const K*)dk[0], rank);
     hipLaunchKernelGGL(k_order_scatter, dim3(nb), dim3(256), 0, stream, k.H.n, (const int32_t*)rank, order_idx);
     chk(hipGetLastError(), "k_order");
@@ -427,11 +457,7 @@ int kq_snapshot_derive(kq_engine* en) {
 int kq_snapshot_read_planes(kq_engine* en, int64_t* subtree_quota, int64_t* usage, uint8_t* quota_flags) {
   if (!en || !en->e.have_snapshot) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  size_t n = (size_t)en->e.prep.N * en->e.prep.nfr;
-  if (subtree_quota) en->e.be.d2h(subtree_quota, en->e.d_sq, n * 8);
-  if (usage) en->e.be.d2h(usage, en->e.d_usage, n * 8);
-  if (quota_flags) en->e.be.d2h(quota_flags, en->e.d_qflags, n);
-  return en->e.be.sync();
+  return en->e.read_planes(subtree_quota, usage, quota_flags);  // (re-derives the cohort levels first if commits are pending)
 }
 
 const char* kq_last_error(kq_engine* en) { return en ? en->e.last_error.c_str() : "null engine"; }

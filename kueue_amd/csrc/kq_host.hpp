@@ -94,7 +94,7 @@ template <class B> struct EngineT {
     S.bl = upload(s->borrow_limit, N * nfr);
     S.ll = upload(s->lend_limit, N * nfr);
     d_sq = upload(s->subtree_quota, N * nfr); S.sq = d_sq;
-    d_usage = upload(s->usage, N * nfr);
+    d_usage = upload(s->usage, N * nfr); levels_stale = false;
     d_qflags = upload(s->quota_flags, N * nfr); S.qflags = d_qflags;
     S.cq_rg_off = upload(s->cq_rg_off, nq + 1);
     S.rg_flavor_off = upload(s->rg_flavor_off, prep.n_rg + 1);
@@ -153,6 +153,18 @@ template <class B> struct EngineT {
   int last_cycle_n = -1;   // heads of the last executed cycle, -1 = none / already committed
   DOut last_O{};
   int max_depth() const { int m = 0; for (int n = 0; n < prep.N; n++) m = std::max(m, (int)prep.depth[n]); return m; }
+  // Folding usage rows into the resident snapshot. When the snapshot satisfies "cohort usage = sum of what the children store
+  // in it" only the ClusterQueue cells are touched here; the cohort levels are re-derived from them once, right before the
+  // next reader (flush_levels) — a commit and a release between two cycles cost one re-derivation, not two.
+  bool levels_stale = false;
+  void apply_commit(const DCommit& dc, bool add) {
+    if (prep.usage_consistent) { be.launch_commit_cells(S, dc, add); levels_stale = true; }
+    else be.launch_commit_trees(S, dc, add);
+  }
+  void flush_levels() {
+    if (levels_stale) be.launch_usage_levels(S, d_usage, max_depth());
+    levels_stale = false;
+  }
   int cycle_commit(int32_t* n_admitted) {
     if (!have_snapshot) return fail(KQ_EINVAL, "kq_cycle_commit before kq_snapshot_put");
     if (last_cycle_n < 0) return fail(KQ_EINVAL, "kq_cycle_commit: no uncommitted cycle");
@@ -167,12 +179,10 @@ template <class B> struct EngineT {
       int32_t* d_fr = grow<int32_t>(c.use_fr, (size_t)n * KQ_MAXU);
       int64_t* d_qty = grow<int64_t>(c.use_qty, (size_t)n * KQ_MAXU);
       int32_t* d_count = (int32_t*)grow<int64_t>(b_misc, 2);
-      be.memset(d_count, 0, 16);
-      be.launch_commit_mask(n, d_un, d_cq, d_count);
-      be.d2d(d_fr, last_O.use_fr, (size_t)n * KQ_MAXU * sizeof(int32_t));
-      be.d2d(d_qty, last_O.use_qty, (size_t)n * KQ_MAXU * sizeof(int64_t));
+      if (n_admitted) be.memset(d_count, 0, 16);  // the count is only read back on request
+      be.launch_commit_mask(n, d_un, d_cq, d_fr, d_qty, d_count);  // also keeps the cycle's usage rows for the release
       DCommit dc{n, d_cq, d_un, d_fr, d_qty, d_usage};
-      be.launch_commit(S, dc, true, prep.usage_consistent, max_depth());
+      apply_commit(dc, true);
       if (n_admitted) {  // only a caller that asks for the count pays for a round trip; the stream orders the rest
         be.d2h(&count, d_count, sizeof(count));
         int rc = be.sync();
@@ -191,7 +201,7 @@ template <class B> struct EngineT {
     if (!c.live) return fail(KQ_EINVAL, "kq_cycle_release: already released");
     if (c.n > 0) {
       DCommit dc{c.n, (const int32_t*)c.cq.p, (const int32_t*)c.use_n.p, (const int32_t*)c.use_fr.p, (const int64_t*)c.use_qty.p, d_usage};
-      be.launch_commit(S, dc, false, prep.usage_consistent, max_depth());
+      apply_commit(dc, false);
     }
     c.live = false;
     return KQ_OK;
@@ -204,7 +214,7 @@ template <class B> struct EngineT {
     int max_depth = 0;
     for (int n = 0; n < prep.N; n++) max_depth = std::max(max_depth, (int)prep.depth[n]);
     DDerive d{d_sq, d_usage, d_qflags};
-    be.launch_derive(S, d, max_depth);
+    be.launch_derive(S, d, max_depth); levels_stale = false;  // cohort usage is recomputed from the ClusterQueue cells here
     const size_t cells = (size_t)prep.N * prep.nfr;
     std::vector<int64_t> sq(cells), us(cells);
     std::vector<uint8_t> fl(cells);
@@ -221,6 +231,7 @@ template <class B> struct EngineT {
   int read_planes(int64_t* sq, int64_t* us, uint8_t* fl) {
     if (!have_snapshot) return fail(KQ_EINVAL, "no snapshot");
     const size_t cells = (size_t)prep.N * prep.nfr;
+    flush_levels();
     if (sq) be.d2h(sq, d_sq, cells * 8);
     if (us) be.d2h(us, d_usage, cells * 8);
     if (fl) be.d2h(fl, d_qflags, cells);
@@ -318,6 +329,7 @@ template <class B> struct EngineT {
     if (out->tgt_off) out->tgt_off[0] = 0;
     if (n == 0) {
       last_kernel_ms = 0; last_bytes = 0; last_cycle_n = 0;
+      flush_levels();
       be.d2d(grow<int64_t>(b_usage_work, (size_t)prep.N * prep.nfr), d_usage, (size_t)prep.N * prep.nfr * sizeof(int64_t));
       return be.sync();
     }
@@ -356,10 +368,13 @@ template <class B> struct EngineT {
     O.pool_cap = pool_cap * 2;
     O.pool_row = grow<int32_t>(ob[17], O.pool_cap); O.pool_reason = grow<uint8_t>(ob[18], O.pool_cap);
     int64_t* misc = (int64_t*)(pack + o_misc);
-    be.memset(misc, 0, 4 * sizeof(int64_t));
+    DPrep pp{};  // the fills and copies every cycle starts with, gathered into one launch (be.launch_prep below)
+    auto prep_fill = [&](void* dst, size_t words, uint32_t v) { if (words) pp.op[pp.n++] = DPrepOp{dst, nullptr, (uint32_t)words, v}; };
+    auto prep_copy = [&](void* dst, const void* src, size_t words) { if (words) pp.op[pp.n++] = DPrepOp{dst, src, (uint32_t)words, 0}; };
+    prep_fill(misc, 8, 0);
     O.pool_count = (int32_t*)misc; O.error = (int32_t*)misc + 1; O.stat_bytes = (long long*)(misc + 1);  // [1]=nominate bytes, [2]=process bytes
     // nominated flavors start empty (a head's rows are rewritten by assign_flavors)
-    be.memset(O.flavor, 0xff, nps * nR * sizeof(int32_t));
+    prep_fill(O.flavor, nps * nR, 0xffffffffu);
     // scratch: one slot per resident wave
     const int slots_nom = std::min(n, be.max_slots());
     const int slots = std::max(slots_nom, prep.n_tree);
@@ -376,7 +391,7 @@ template <class B> struct EngineT {
     X.cand = grow<int32_t>(b_cand, (size_t)slots * X.max_tree_rows);
     X.mark = (uint64_t*)grow<int64_t>(b_mark, (size_t)slots * ((X.max_tree_rows + 63) / 64));
     k.cq_rm_bytes = grow<int32_t>(b_rmb, std::max(prep.nq, 1));
-    be.memset(k.cq_rm_bytes, 0, (size_t)std::max(prep.nq, 1) * sizeof(int32_t));
+    prep_fill(k.cq_rm_bytes, (size_t)std::max(prep.nq, 1), 0);
     if (cfg.fair_sharing) {
       const size_t tq = (size_t)slots * X.max_tree_cqs, tn = (size_t)slots * X.max_tree_nodes;
       X.qcnt = grow<int32_t>(b_fs[0], tq); X.qhead = grow<uint32_t>(b_fs[1], tq); X.cohp = grow<uint8_t>(b_fs[2], tn);
@@ -385,7 +400,7 @@ template <class B> struct EngineT {
       X.fs_key = grow<int32_t>(b_fs[9], n);
       X.fs_stale = grow<uint8_t>(b_fs[10], tq); X.fs_cost = grow<int32_t>(b_fs[11], tq * KQ_MAXD);
       X.fs_sum = (long long*)grow<int64_t>(b_fs[12], slots); X.fs_ctl = grow<int32_t>(b_fs[13], (size_t)slots * 4);
-      be.memset(X.fs_key, 0xff, (size_t)n * sizeof(int32_t));
+      prep_fill(X.fs_key, (size_t)n, 0xffffffffu);
       // per-node borrowed sums (the segmented reduction DRS is built from), for the cycle-start plane and the work plane
       X.bu_sum = grow<int64_t>(b_fs[14], (size_t)prep.N * nR); X.bu_pos = grow<int32_t>(b_fs[15], prep.N);
       X.bs_sum = grow<int64_t>(b_fs[16], (size_t)prep.N * nR); X.bs_pos = grow<int32_t>(b_fs[17], prep.N);
@@ -394,15 +409,19 @@ template <class B> struct EngineT {
     k.usage = d_usage;
     k.usage_work = grow<int64_t>(b_usage_work, Nfr);
     k.usage_np = grow<int64_t>(b_usage_np, Nfr);
-    k.preempted = grow<uint8_t>(b_preempted, std::max(prep.n_adm, 1));
+    k.preempted = grow<uint8_t>(b_preempted, ((size_t)std::max(prep.n_adm, 1) + 3) & ~(size_t)3);
     k.prof = (long long*)grow<int64_t>(b_prof, 32);
     k.grec = grow<PRec>(b_grec, n);
     k.cq_dirty = grow<uint8_t>(b_cqd, std::max(prep.nq, 1));  // cleared per head by k_records
     int32_t* order_idx = grow<int32_t>(b_order, n);
     k.order_idx = order_idx;
-    be.d2d(k.usage_work, d_usage, Nfr * sizeof(int64_t));
-    be.d2d(k.usage_np, d_usage, Nfr * sizeof(int64_t));
-    be.memset(k.preempted, 0, std::max(prep.n_adm, 1));
+    int32_t* rank = grow<int32_t>(b_rank, n);
+    flush_levels();  // commits / releases since the last cycle: cohort usage re-derived before anything reads it
+    prep_copy(k.usage_work, d_usage, Nfr * 2);
+    prep_copy(k.usage_np, d_usage, Nfr * 2);
+    prep_fill(k.preempted, ((size_t)std::max(prep.n_adm, 1) + 3) / 4, 0);
+    if (!cfg.fair_sharing) prep_fill(rank, (size_t)n, 0);  // k_order accumulates into it
+    be.launch_prep(pp);
 
     be.timer_mark(0);
     if (cfg.fair_sharing) {
@@ -413,7 +432,6 @@ template <class B> struct EngineT {
     be.launch_nominate(k, slots_nom);
     be.launch_records(k);  // entry records (static part) for k_process; charged to the nominate interval
     be.timer_mark(1);
-    int32_t* rank = grow<int32_t>(b_rank, n);
     if (!cfg.fair_sharing) be.launch_order(k, order_idx, rank);
     be.timer_mark(2);
     k.O.stat_bytes = (long long*)(misc + 2);

@@ -37,16 +37,21 @@ struct EmuBackend {
   void launch_tas_usage(const TTopo& T, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int add) { for (int i = 0; i < n; i++) t_usage_cell(T, i, leaf, count, spr, add); }
   void launch_tas_fits(const TTopo& T, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t* flag) { for (int i = 0; i < n; i++) t_fits_cell(T, i, leaf, count, spr, flag); }
   K last_k{};
-  void launch_commit_mask(int n, int32_t* use_n_out, int32_t* cq_out, int32_t* count) { for (int h = 0; h < n; h++) commit_mask_head(last_k, h, use_n_out, cq_out, count); }
-  void launch_commit(const DSnap& S, const DCommit& c, bool add, bool consistent, int max_depth) {
-    if (consistent && (rot++ & 1)) {  // alternate between the two equivalent procedures
-      for (int i = 0; i < c.n * KQ_MAXU; i++) commit_cq_cell(c, S, i / KQ_MAXU, i % KQ_MAXU, add);
-      for (int dep = max_depth; dep >= 0; dep--)
-        for (int i = 0; i < S.nc * S.nfr; i++) if (S.depth[S.nq + i / S.nfr] == dep) derive_usage_cell(S, c.usage, S.nq + i / S.nfr, i % S.nfr);
-    } else {
-      for (int t = 0; t < S.n_tree; t++) commit_tree(S, c, t, add);
-    }
+  void launch_commit_mask(int n, int32_t* use_n_out, int32_t* cq_out, int32_t* fr_out, int64_t* qty_out, int32_t* count) {
+    for (int i = 0; i < n * KQ_MAXU; i++) commit_keep_cell(last_k, i, use_n_out, cq_out, fr_out, qty_out, count);
   }
+  void launch_commit_cells(const DSnap& S, const DCommit& c, bool add) {
+    // alternate between the two procedures: both leave the ClusterQueue cells right (the second one also updates the cohorts,
+    // which the deferred re-derivation overwrites)
+    if (rot++ & 1) for (int i = 0; i < c.n * KQ_MAXU; i++) commit_cq_cell(c, S, i / KQ_MAXU, i % KQ_MAXU, add);
+    else for (int t = 0; t < S.n_tree; t++) commit_tree(S, c, t, add);
+  }
+  void launch_commit_trees(const DSnap& S, const DCommit& c, bool add) { for (int t = 0; t < S.n_tree; t++) commit_tree(S, c, t, add); }
+  void launch_usage_levels(const DSnap& S, int64_t* usage, int max_depth) {
+    for (int dep = max_depth; dep >= 0; dep--)
+      for (int i = 0; i < S.nc * S.nfr; i++) if (S.depth[S.nq + i / S.nfr] == dep) derive_usage_cell(S, usage, S.nq + i / S.nfr, i % S.nfr);
+  }
+  void launch_prep(const DPrep& p) { for (int o = 0; o < p.n; o++) for (uint32_t i = 0; i < p.op[o].words; i++) prep_word(p, o, i); }
   void launch_derive(const DSnap& S, const DDerive& d, int max_depth) {
     for (int i = 0; i < S.nq * S.nfr; i++) derive_cq_cell(S, d, i / S.nfr, i % S.nfr);
     for (int dep = max_depth; dep >= 0; dep--)
