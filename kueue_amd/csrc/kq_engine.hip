@@ -33,36 +33,41 @@ __global__ __launch_bounds__(64) void k_nominate(const K* __restrict__ kp, int s
 }
 
 // Entry order (scheduler.go:1110-1163): rank(i) = number of entries that precede i. 2-D grid: block (bi, bj)
-// compares 256 entries i against a 256-key tile j staged in LDS and adds its partial count to rank[i];
-// k_order_scatter then writes order_idx[rank[i]] = i. H^2/65536 blocks keep more CUs busy than H/256.
-struct OrderKey { int64_t prio, ts; int32_t borrow; uint32_t flags; };
+// compares 256 entries i against a 64-key tile j staged in LDS and adds its partial count to rank[i];
+// k_order_scatter then writes order_idx[rank[i]] = i. H^2/16384 blocks keep more CUs busy than H/256.
+// The predicate of kq::entry_before as a lexicographic compare of three unsigned words (then the index), so that the inner
+// loop has no divergent branches: a = [no quota reservation | not a preemptor (gate) | borrowing level], b = priority
+// descending (gate), c = queue timestamp ascending.
+struct OrderKey { uint64_t a, b, c; };
+constexpr int ORDER_TILE = 64;
+__device__ __forceinline__ OrderKey order_key(const K& k, int h, bool pre, bool psort) {
+  const uint32_t fl = k.H.flags[h];
+  OrderKey o;
+  o.a = ((fl & KQ_HEAD_HAS_QUOTA_RESERVATION) ? 0ull : 1ull << 63) | ((pre && !(fl & KQ_HEAD_IS_PREEMPTOR)) ? 1ull << 62 : 0ull) |
+        (uint64_t)((uint32_t)k.O.borrowing[h] ^ 0x80000000u);
+  o.b = psort ? ~((uint64_t)k.H.priority[h] ^ 0x8000000000000000ull) : 0ull;
+  o.c = (uint64_t)k.H.queue_ts[h] ^ 0x8000000000000000ull;
+  return o;
+}
 __global__ __launch_bounds__(256) void k_order(const K* __restrict__ kp, int32_t* rank) {
   const K& k = *kp;
-  __shared__ OrderKey tile[256];
+  __shared__ OrderKey tile[ORDER_TILE];
   const int n = k.H.n;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const int base = blockIdx.y * 256;
-  const int j = base + threadIdx.x;
-  if (j < n) tile[threadIdx.x] = OrderKey{k.H.priority[j], k.H.queue_ts[j], k.O.borrowing[j], k.H.flags[j]};
+  const int base = blockIdx.y * ORDER_TILE;
+  const bool pre = gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS), psort = gate(k, KQ_GATE_PRIORITY_SORTING_IN_COHORT);
+  if ((int)threadIdx.x < ORDER_TILE && base + (int)threadIdx.x < n) tile[threadIdx.x] = order_key(k, base + threadIdx.x, pre, psort);
   __syncthreads();
   if (i >= n) return;
-  const OrderKey me{k.H.priority[i], k.H.queue_ts[i], k.O.borrowing[i], k.H.flags[i]};
-  const bool pre = gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS), psort = gate(k, KQ_GATE_PRIORITY_SORTING_IN_COHORT);
-  const bool mq = me.flags & KQ_HEAD_HAS_QUOTA_RESERVATION, mp = me.flags & KQ_HEAD_IS_PREEMPTOR;
-  const int m = (n - base) < 256 ? (n - base) : 256;
+  const OrderKey me = order_key(k, i, pre, psort);
+  const int m = (n - base) < ORDER_TILE ? (n - base) : ORDER_TILE;
   int cnt = 0;
   for (int t = 0; t < m; t++) {
     const OrderKey o = tile[t];
     const int jj = base + t;
-    bool before;  // does entry jj precede entry i ?  (same predicate as kq::entry_before)
-    const bool oq = o.flags & KQ_HEAD_HAS_QUOTA_RESERVATION, op = o.flags & KQ_HEAD_IS_PREEMPTOR;
-    if (oq != mq) before = oq;
-    else if (pre && op != mp) before = op;
-    else if (o.borrow != me.borrow) before = o.borrow < me.borrow;
-    else if (psort && o.prio != me.prio) before = o.prio > me.prio;
-    else if (o.ts != me.ts) before = o.ts < me.ts;
-    else before = jj < i;
-    cnt += (jj != i && before) ? 1 : 0;
+    // does entry jj precede entry i ?
+    const bool before = o.a < me.a || (o.a == me.a && (o.b < me.b || (o.b == me.b && (o.c < me.c || (o.c == me.c && jj < i)))));
+    cnt += before ? 1 : 0;
   }
   if (cnt) atomicAdd(&rank[i], cnt);
 }
@@ -324,7 +329,7 @@ struct HipBackend {
   }
   void launch_order(const K& k, int32_t* order_idx, int32_t* rank) {
     const int nb = (k.H.n + 255) / 256;
-    hipLaunchKernelGGL(k_order, dim3(nb, nb), dim3(256), 0, stream, (const K*)dk[0], rank);
+    hipLaunchKernelGGL(k_order, dim3(nb, (k.H.n + ORDER_TILE - 1) / ORDER_TILE), dim3(256), 0, stream, (const K*)dk[0], rank);
     hipLaunchKernelGGL(k_order_scatter, dim3(nb), dim3(256), 0, stream, k.H.n, (const int32_t*)rank, order_idx);
     chk(hipGetLastError(), "k_order");
   }
