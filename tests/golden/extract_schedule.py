@@ -142,6 +142,39 @@ def workloads_in(text):
     return out
 
 
+def inline_func_vars(text):
+    """`additionalClusterQueues: func() []kueue.ClusterQueue { rg := ...; preemption := ...; cq1 := *Make...(rg)...; return ... }()`
+    -> the same text with the local variables substituted into the MakeClusterQueue chains that use them."""
+    if not re.match(r"\s*func\(\)", text):
+        return text
+    lines = text.split("\n")
+    vars_, i = {}, 0
+    while i < len(lines):
+        m = re.match(r"^\s*(\w+) := (.*)$", lines[i])
+        if not m:
+            i += 1
+            continue
+        expr = m.group(2)
+        while expr.count("(") != expr.count(")") or expr.count("{") != expr.count("}"):
+            i += 1
+            expr += "\n" + lines[i]
+        vars_[m.group(1)] = expr.lstrip("*")
+        i += 1
+    cq_exprs = {}
+    for name, expr in vars_.items():
+        if "MakeClusterQueue" not in expr:
+            continue
+        for other, oexpr in vars_.items():
+            if "MakeClusterQueue" not in oexpr:
+                expr = re.sub(r"\b(ResourceGroup|Preemption)\(" + re.escape(other) + r"\)", lambda mm: mm.group(1) + "(" + oexpr + ")", expr)
+        cq_exprs[name] = expr
+    m = re.search(r"return \[\]kueue\.ClusterQueue\{([^}]*)\}", text)
+    order = [n.strip() for n in m.group(1).split(",") if n.strip()] if m else list(cq_exprs)
+    if not cq_exprs or any(n not in cq_exprs for n in order):
+        return text
+    return "[]kueue.ClusterQueue{\n" + ",\n".join("*" + cq_exprs[n] for n in order) + ",\n}"
+
+
 def parse_lqs(text):
     out = {}
     for m in re.finditer(r'MakeLocalQueue\("([^"]+)",\s*"([^"]+)"\)\.\s*ClusterQueue\("([^"]+)"\)', text):
@@ -199,6 +232,7 @@ def extract(fname, func, cases, skipped):
             cqs = [dict(c) for c in default_cqs]
             acq = field(block, "additionalClusterQueues")
             if acq:
+                acq = inline_func_vars(acq)
                 p = acq.index("{")
                 items = list_items(acq[p + 1: match_brace(acq, p)], "MakeClusterQueue")
                 for t in items:
