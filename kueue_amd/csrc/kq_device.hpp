@@ -348,6 +348,65 @@ template <class U> KQ_DEV int find_height(const DSnap& S, const int32_t* path, i
   *may_reclaim = false;
   return S.node_height[path[plen - 1]];
 }
+// The three root-path walks of one fitsResourceQuota cell (available_of, potential_of, find_height) read the same
+// (node, flavor-resource) cells; for short paths they are gathered once — every load issued before the first use — and the
+// three quantities are computed from registers with the same operations in the same order as the functions above.
+constexpr int GP_MAX = 4;
+struct GPath { int64_t sq[GP_MAX], lq[GP_MAX], bl[GP_MAX], us[GP_MAX]; int32_t hgt[GP_MAX]; int64_t nominal0; };
+KQ_DEV void gpath_load(const DSnap& S, const int32_t* path, int plen, int fr, const int64_t* usage, GPath& g) {
+  int64_t ll[GP_MAX];
+  #pragma unroll
+  for (int i = 0; i < GP_MAX; i++) {
+    const int n = path[i < plen ? i : 0];  // clamped: the loads stay unconditional
+    const size_t o = ix(S, n, fr);
+    g.sq[i] = S.sq[o]; ll[i] = S.ll[o]; g.bl[i] = S.bl[o]; g.us[i] = usage[o]; g.hgt[i] = S.node_height[n];
+  }
+  g.nominal0 = S.nominal[ix(S, path[0], fr)];
+  #pragma unroll
+  for (int i = 0; i < GP_MAX; i++) g.lq[i] = ll[i] != KQ_NIL_LIMIT ? i64max(0, a_sub(g.sq[i], ll[i])) : 0;  // local_quota
+}
+KQ_DEV int64_t gpath_available(const GPath& g, int plen) {  // = available_of
+  int64_t a = 0;
+  #pragma unroll
+  for (int i = GP_MAX - 1; i >= 0; i--) {
+    if (i >= plen) continue;
+    if (i == plen - 1) { a = a_sub(g.sq[i], g.us[i]); continue; }
+    if (g.bl[i] != KQ_NIL_LIMIT) {
+      const int64_t stored = a_sub(g.sq[i], g.lq[i]);
+      const int64_t used = i64max(0, a_sub(g.us[i], g.lq[i]));
+      a = i64min(a_add(a_sub(stored, used), g.bl[i]), a);
+    }
+    a = a_add(i64max(0, a_sub(g.lq[i], g.us[i])), a);
+  }
+  return a;
+}
+KQ_DEV int64_t gpath_potential(const GPath& g, int plen) {  // = potential_of
+  int64_t a = 0;
+  #pragma unroll
+  for (int i = GP_MAX - 1; i >= 0; i--) {
+    if (i >= plen) continue;
+    if (i == plen - 1) { a = g.sq[i]; continue; }
+    a = a_add(g.lq[i], a);
+    if (g.bl[i] != KQ_NIL_LIMIT) a = i64min(a_add(g.sq[i], g.bl[i]), a);
+  }
+  return a;
+}
+KQ_DEV int gpath_height(const GPath& g, int plen, int64_t val, bool* may_reclaim) {  // = find_height
+  const bool has_parent = plen > 1;
+  if (!(g.nominal0 < a_add(g.us[0], val)) || !has_parent) { *may_reclaim = has_parent; return 0; }
+  int64_t remaining = a_sub(val, i64max(0, a_sub(g.lq[0], g.us[0])));
+  int height = 0;
+  bool found = false, mr = false;
+  #pragma unroll
+  for (int i = 1; i < GP_MAX; i++) {
+    if (i >= plen || found) continue;
+    if (!(g.sq[i] < a_add(g.us[i], remaining))) { found = true; mr = i < plen - 1; height = g.hgt[i]; continue; }
+    remaining = a_sub(remaining, i64max(0, a_sub(g.lq[i], g.us[i])));
+  }
+  if (!found) { mr = false; height = g.hgt[plen - 1]; }
+  *may_reclaim = mr;
+  return height;
+}
 // resource_node.go:144-152 (iterative)
 template <class U> KQ_DEV void add_usage(const DSnap& S, const int32_t* path, int plen, int fr, int64_t val, const U& u) {
   for (int i = 0; i < plen; i++) {
@@ -1462,16 +1521,29 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
           uint8_t pm = PM_SKIP; int32_t borrow = 0; int64_t val = 0;
           if (ok) {
             int fr = f * nR + w.f_res[kk];
-            UG ug{&S, usage, fr};
-            int64_t avail = i64max(0, available_of(S, w.path, plen, fr, ug));
-            int64_t maxcap = potential_of(S, w.path, plen, fr);
             val = a_addi(assumed_usage(w, fr), w.f_qty[kk]);
+            int64_t avail, maxcap, nominal;
+            bool may_reclaim = false;
+            int height = 0;
+            if (plen <= GP_MAX) {
+              GPath g;
+              gpath_load(S, w.path, plen, fr, usage, g);
+              avail = i64max(0, gpath_available(g, plen));
+              maxcap = gpath_potential(g, plen);
+              nominal = g.nominal0;
+              if (!(val > maxcap)) height = gpath_height(g, plen, val, &may_reclaim);
+            } else {
+              UG ug{&S, usage, fr};
+              avail = i64max(0, available_of(S, w.path, plen, fr, ug));
+              maxcap = potential_of(S, w.path, plen, fr);
+              nominal = S.nominal[ix(S, w.cq, fr)];
+              if (!(val > maxcap)) height = find_height(S, w.path, plen, fr, val, ug, &may_reclaim);
+            }
             if (val > maxcap) { pm = PM_NOFIT; borrow = 0; }
             else {
-              bool may_reclaim;
-              borrow = find_height(S, w.path, plen, fr, val, ug, &may_reclaim);
+              borrow = height;
               if (val <= avail) pm = PM_FIT;
-              else if (S.nominal[ix(S, w.cq, fr)] >= val || may_reclaim || can_preempt_while_borrowing(k, w)) pm = PM_NEEDS;
+              else if (nominal >= val || may_reclaim || can_preempt_while_borrowing(k, w)) pm = PM_NEEDS;
               else pm = PM_NOFIT | 0x80;  // noFit with a "insufficient unused quota" reason and borrow kept
             }
           }
