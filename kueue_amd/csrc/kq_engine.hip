@@ -6,10 +6,14 @@
 //                are consecutive ClusterQueues (canonical name order) i.e. siblings in the cohort tree, so
 //                workgroup w -> XCD w%8 keeps a cohort's ancestor rows hot in 8 L2s at once (read-only
 //                sharing across XCDs is safe: the planes are not written during nominate).
-//   k_order    : rank of every entry by pairwise compare (H <= a few thousand per cycle at reference
-//                semantics: <= 1 head per ClusterQueue).
-//   k_process  : 1 wave per root-cohort tree; entries of one tree are sequentially dependent
-//                (scheduler.go:486 cq.AddUsage changes what later entries see).
+//   k_prep     : the fills and device-to-device copies a cycle starts with, one launch (blockIdx.y = operation).
+//   k_records  : 1 thread per (head, flavor-resource slot, path level): the static part of the entry records k_process
+//                copies into LDS.
+//   k_order    : rank of every entry by pairwise compare of three-word keys (H <= a few thousand per cycle at reference
+//                semantics: <= 1 head per ClusterQueue); 256 entries x 64-key tiles per workgroup.
+//   k_process  : 1 workgroup of 4 waves per root-cohort tree; entries of one tree are sequentially dependent
+//                (scheduler.go:486 cq.AddUsage changes what later entries see): wave 0 walks them, waves 1-3 fetch and
+//                screen the records of the next chunk.
 // No MFMA anywhere: saturating int64 compares/adds over gathered quota rows -> HBM/L2-bound.
 #include <hip/hip_runtime.h>
 
