@@ -159,7 +159,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                          "algorithmic_bytes_per_launch": dby / args.steps, "traffic": pmc_traffic(args.workload, dom)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is a single-GPU-run figure (rank 0, N = 1)
             out["cpu_baseline"] = cpu_baseline(pop, kcfg, args.cpu_seconds, closed, args.hold)
         print(json.dumps(out))
     if world > 1:
@@ -224,7 +224,7 @@ def bench_tas(args, torch, dist, world, rank, local_rank):
                          "note": "algorithmic bytes = phase 1 of every workload as the reference runs it; the kernel runs phase 1 once "
                                  "per request class and shares the table, so measured traffic is below the algorithmic figure"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is a single-GPU-run figure (rank 0, N = 1)
             from oracle import kqo
             n_s = min(rq.n, 20000)
             sub = T.Requests(topo, rq.workloads[:n_s])
