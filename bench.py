@@ -161,6 +161,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is a single-GPU-run figure (rank 0, N = 1)
             out["cpu_baseline"] = cpu_baseline(pop, kcfg, args.cpu_seconds, closed, args.hold)
+        else:
+            out["cpu_baseline"] = None
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -233,6 +235,8 @@ def bench_tas(args, torch, dist, world, rank, local_rank):
             dt = time.perf_counter() - t1
             res["cpu_baseline"] = {"value": n_s / dt, "unit": "decisions/s", "cores": 1, "kind": "port",
                                    "sample": f"first {n_s} workloads of the same batch, C++ restatement of FindTopologyAssignmentsForFlavor, host nproc={os.cpu_count()}"}
+        else:
+            res["cpu_baseline"] = None
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
