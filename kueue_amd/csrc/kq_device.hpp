@@ -1797,6 +1797,9 @@ KQ_DEV void publish_assignment(const K& k, Wave& w, const Search& s, int h) {
 
 // nominate (scheduler.go:665-705) for one head
 KQ_DEV void nominate_head(const K& k, Wave& w, int h, int slot) {
+#if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
+  const long long _h0 = clock64();
+#endif
   load_head(k, w, h);
   if (w.has_last && last_assignment_outdated(k, h, w.cq)) { if (lane_id() == 0) w.has_last = 0; }
   wsync();
@@ -1808,6 +1811,14 @@ KQ_DEV void nominate_head(const K& k, Wave& w, int h, int slot) {
     k.O.status[h] = KQ_ST_NOT_NOMINATED; k.O.action[h] = KQ_ACT_NONE; k.O.requeue_reason[h] = KQ_RQ_GENERIC; k.O.skip[h] = KQ_SKIP_NONE;
     k.O.order[h] = -1;
     atomic_add_i64(k.O.stat_bytes, (long long)w.bytes);
+#if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
+    // per-head latency by outcome: the kernel lasts as long as its slowest head
+    const long long dt = clock64() - _h0;
+    const int cls = w.rep_mode == M_FIT ? 0 : (w.rep_mode == M_PREEMPT ? 1 : 2);
+    atomic_add_i64((long long*)k.prof + 21 + cls, dt);
+    atomic_add_i64((long long*)k.prof + 24 + cls, 1);
+    atomicMax((unsigned long long*)k.prof + 30, (unsigned long long)dt);
+#endif
   }
   wsync();
 }

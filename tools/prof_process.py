@@ -25,5 +25,9 @@ names = {8: "pc_load", 9: "pc_flush", 10: "chunk_prefetch", 11: "chunk serial co
          16: "fair: computeDRS (leader wave)", 17: "fair: barrier wait", 18: "fair: tournament", 19: "fair: pop bookkeeping", 20: "fair: processEntry"}
 for i, nm in names.items():
     print(f"{nm:28s} {prof[i]/n:10.1f} cycles/entry   total {prof[i]}")
+for i, nm in enumerate(("Fit", "Preempt", "NoFit")):
+    c = max(1, prof[24 + i])
+    print(f"k_nominate heads with mode {nm:8s}: {prof[24 + i] / 10:7.1f} per cycle, {prof[21 + i] / c:10.0f} cycles each ({prof[21 + i] / c / 2400:.1f} us)")
+print(f"k_nominate slowest head of the measured cycles: {prof[30]} cycles ({prof[30] / 2400:.1f} us)")
 print(f"clock64 / wall_clock64 = {prof[14]/max(1,prof[29]):.2f}  (wall clock is 100 MHz => core clock {prof[14]/max(1,prof[29])*0.1:.2f} GHz); tree wall time {prof[29]/10/100:.1f} us per cycle")
 print("kernel ms last cycle", d.kernel_ms)
