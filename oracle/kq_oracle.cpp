@@ -1106,6 +1106,28 @@ struct Entry {
   int order = -1;
 };
 
+// PodSetReducer (podset_reducer.go:28-86): Search finds the largest counts between PodSets[*].Count and *MinimumCount that
+// pass fits(); sort.Search(totalDelta + 1, f) = smallest i in [0, n) with f(i) true, n if none. The last call of fits might
+// not be a successful one, hence lastGoodIdx. fits(counts) records its own result when it returns true.
+template <class F> static bool podSetReducerSearch(const std::vector<int>& fullCounts, const std::vector<int>& minCounts, F fits) {
+  const int P = (int)fullCounts.size();
+  std::vector<int> deltas(P);
+  int totalDelta = 0;
+  for (int i = 0; i < P; i++) { deltas[i] = fullCounts[i] - (minCounts[i] >= 0 ? minCounts[i] : fullCounts[i]); totalDelta += deltas[i]; }  // ptr.Deref(MinCount, Count)
+  if (totalDelta == 0) return false;
+  int lastGoodIdx = 0;
+  std::vector<int> current(P);
+  auto f = [&](int si) {
+    for (int i = 0; i < P; i++) current[i] = fullCounts[i] - (int)((int64_t)deltas[i] * (int64_t)si / (int64_t)totalDelta);  // fillPodSetSizesForSearchIndex
+    const bool ok = fits(current);
+    if (ok) lastGoodIdx = si;
+    return ok;
+  };
+  int lo = 0, hi = totalDelta + 1;
+  while (lo < hi) { const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1); if (!f(mid)) lo = mid + 1; else hi = mid; }
+  return lo == lastGoodIdx;
+}
+
 struct Scheduler {
   Snap& sn;
   const kq_heads* H;
@@ -1155,28 +1177,21 @@ struct Scheduler {
       if (!t.empty()) { *outA = full; *outT = t; return; }
     }
     if (sn.gate(KQ_GATE_PARTIAL_ADMISSION) && wl.CanBePartiallyAdmitted()) {
-      // PodSetReducer podset_reducer.go:28-86 ; sort.Search = smallest i in [0,n) with f(i) true
       int P = (int)wl.ps.size();
-      std::vector<int> fullCounts(P), deltas(P); int totalDelta = 0;
-      for (int i = 0; i < P; i++) { fullCounts[i] = wl.ps[i].count; int mc = wl.ps[i].min_count >= 0 ? wl.ps[i].min_count : wl.ps[i].count; deltas[i] = wl.ps[i].count - mc; totalDelta += deltas[i]; }
-      if (totalDelta != 0) {
-        int lastGoodIdx = 0; bool haveLast = false; Assignment lastA; std::vector<Target> lastT;
-        auto fits = [&](int si) {
-          std::vector<int> current(P);
-          for (int i = 0; i < P; i++) current[i] = fullCounts[i] - (int)((int64_t)deltas[i] * (int64_t)si / (int64_t)totalDelta);
-          Assignment a = fa.assignFlavors(&current);
-          int mode = a.RepresentativeMode();
-          if (mode == Fit) { lastGoodIdx = si; lastA = a; lastT.clear(); haveLast = true; return true; }
-          if (mode == Preempt) {
-            std::vector<Target> t = preemptor.GetTargets(wl, a);
-            if (!t.empty()) { lastGoodIdx = si; lastA = a; lastT = t; haveLast = true; return true; }
-          }
-          return false;
-        };
-        int lo = 0, hi = totalDelta + 1;  // sort.Search(n=totalDelta+1)
-        while (lo < hi) { int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1); if (!fits(mid)) lo = mid + 1; else hi = mid; }
-        if (haveLast && lo == lastGoodIdx) { *outA = lastA; *outT = lastT; return; }
-      }
+      std::vector<int> fullCounts(P), minCounts(P);
+      for (int i = 0; i < P; i++) { fullCounts[i] = wl.ps[i].count; minCounts[i] = wl.ps[i].min_count; }
+      Assignment lastA; std::vector<Target> lastT;
+      bool found = podSetReducerSearch(fullCounts, minCounts, [&](const std::vector<int>& current) {
+        Assignment a = fa.assignFlavors(&current);
+        int mode = a.RepresentativeMode();
+        if (mode == Fit) { lastA = a; lastT.clear(); return true; }
+        if (mode == Preempt) {
+          std::vector<Target> t = preemptor.GetTargets(wl, a);
+          if (!t.empty()) { lastA = a; lastT = t; return true; }
+        }
+        return false;
+      });
+      if (found) { *outA = lastA; *outT = lastT; return; }
     }
     *outA = full; outT->clear();
   }
@@ -1716,4 +1731,17 @@ int kqo_candidates_order(const kq_config* cfg, const kq_snapshot* s, int cq, int
   return KQ_OK;
 }
 
+// PodSetReducer.Search with the predicate of the reference's TestSearch (podset_reducer_test.go:127-134): sum(counts) <= limit
+int kqo_podset_reducer_search(int32_t n, const int32_t* counts, const int32_t* min_counts, int32_t count_limit, int32_t* out_count, int32_t* out_found) {
+  std::vector<int> full(counts, counts + n), mins(min_counts, min_counts + n);
+  int64_t last = 0;
+  const bool found = podSetReducerSearch(full, mins, [&](const std::vector<int>& cur) {
+    int64_t total = 0;
+    for (int v : cur) total += v;
+    if (total <= count_limit) { last = total; return true; }
+    return false;
+  });
+  *out_count = (int32_t)last; *out_found = found ? 1 : 0;
+  return 0;
+}
 }  // extern "C"

@@ -156,6 +156,18 @@ def is_preferred(a, b, policy_word: int) -> bool:
     return bool(l.kqo_is_preferred(a[0], a[1], b[0], b[1], policy_word))
 
 
+def podset_reducer_search(counts, min_counts, count_limit):
+    """PodSetReducer.Search (podset_reducer.go:56-86) with the predicate of the reference's TestSearch: sum(counts) <= limit.
+    min_counts: -1 = no MinimumCount. Returns (count, found)."""
+    l = lib()
+    c = np.asarray(counts, np.int32); m = np.asarray(min_counts, np.int32)
+    oc = C.c_int32(); of = C.c_int32()
+    l.kqo_podset_reducer_search.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    rc = l.kqo_podset_reducer_search(len(c), c.ctypes.data, m.ctypes.data, int(count_limit), C.byref(oc), C.byref(of))
+    assert rc == 0, rc
+    return oc.value, bool(of.value)
+
+
 def tas_find(topo, rq, dom_cap=None):
     """FindTopologyAssignmentsForFlavor restatement (oracle/kq_tas_oracle.cpp) -> kueue_amd.tas.Result (+ .bytes)."""
     from kueue_amd import tas as T

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Transcribe three small table tests of the reference into tests/golden/small_tables.yaml:
+"""Transcribe four small table tests of the reference into tests/golden/small_tables.yaml:
+  TestSearch (PodSetReducer) pkg/scheduler/flavorassigner/podset_reducer_test.go:27
   TestIsPreferred            pkg/scheduler/flavorassigner/flavorassigner_test.go:4184
   TestResourcesToReserve     pkg/scheduler/scheduler_test.go:8692
   TestLastAssignmentOutdated pkg/scheduler/scheduler_test.go:9216
@@ -105,11 +106,33 @@ def last_assignment_outdated():
     return out
 
 
+def podset_reducer_search():
+    body = func_body(f"{REF}/flavorassigner/podset_reducer_test.go", "TestSearch") if False else None
+    src = strip_comments(open(f"{REF}/flavorassigner/podset_reducer_test.go").read())
+    a = src.index("func TestSearch(")
+    body = src[a:]
+    m = re.search(r"cases := map\[string\]struct \{", body)
+    close = match_brace(body, m.end() - 1)
+    o = body.index("{", close + 1)
+    c = match_brace(body, o)
+    out = []
+    for el in elements(body[o + 1:c]):
+        nm = re.match(r'"((?:[^"\\]|\\.)*)"\s*:\s*\{', el)
+        f = top_level_fields(el[nm.end():el.rindex("}")])
+        podsets = []
+        for pm in re.finditer(r'MakePodSet\("[^"]+",\s*([\d_]+)\)((?:\.\s*SetMinimumCount\(([\d_]+)\))?)', f["podSets"]):
+            podsets.append(dict(count=int(pm.group(1).replace("_", "")), minCount=(int(pm.group(3).replace("_", "")) if pm.group(3) else None)))
+        out.append(dict(name=nm.group(1), podSets=podsets, countLimit=int(f["countLimit"].replace("_", "")),
+                        wantCount=int(f["wantCount"].replace("_", "")), wantFound=f["wantFound"] == "true"))
+    return out
+
+
 def main():
-    doc = dict(isPreferred=is_preferred(), resourcesToReserve=resources_to_reserve(), lastAssignmentOutdated=last_assignment_outdated())
+    doc = dict(isPreferred=is_preferred(), resourcesToReserve=resources_to_reserve(), lastAssignmentOutdated=last_assignment_outdated(),
+               podSetReducerSearch=podset_reducer_search())
     with open(OUT, "w") as fh:
-        fh.write("# Generated by tests/golden/extract_small_tables.py from the reference's TestIsPreferred, TestResourcesToReserve and\n"
-                 "# TestLastAssignmentOutdated tables.\n")
+        fh.write("# Generated by tests/golden/extract_small_tables.py from the reference's TestIsPreferred, TestResourcesToReserve,\n"
+                 "# TestLastAssignmentOutdated and TestSearch (PodSetReducer) tables.\n")
         yaml.safe_dump(doc, fh, sort_keys=False, width=160)
     print({k: len(v) for k, v in doc.items()})
 

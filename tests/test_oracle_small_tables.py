@@ -1,5 +1,6 @@
 """Small table tests of the reference replayed on the oracle's restated functions:
-TestIsPreferred, TestResourcesToReserve, TestLastAssignmentOutdated (tests/golden/small_tables.yaml, extractor committed),
+TestIsPreferred, TestResourcesToReserve, TestLastAssignmentOutdated, TestSearch of the PodSetReducer (tests/golden/small_tables.yaml,
+extractor committed),
 TestCandidatesOrdering, TestEntryOrdering (tests/golden/small_tables_manual.yaml, hand transcription)."""
 import pytest
 
@@ -87,3 +88,12 @@ def test_entry_ordering(oracle, case):
     cfg = make_config(gates=gates_with({"PrioritySortingWithinCohort": case["prioritySorting"]}))
     got = oracle.entry_order(cfg, snap, heads, [e["borrowing"] for e in case["entries"]])
     assert [case["entries"][i]["name"] for i in got] == case["want"]
+
+
+@pytest.mark.parametrize("case", T["podSetReducerSearch"], ids=lambda c: c["name"][:70])
+def test_podset_reducer_search(oracle, case):
+    """podset_reducer_test.go:27 TestSearch — the partial-admission search of getInitialAssignments (scheduler.go:906-921)."""
+    counts = [p["count"] for p in case["podSets"]]
+    mins = [-1 if p["minCount"] is None else p["minCount"] for p in case["podSets"]]
+    got_count, got_found = oracle.podset_reducer_search(counts, mins, case["countLimit"])
+    assert (got_count, got_found) == (case["wantCount"], case["wantFound"])
