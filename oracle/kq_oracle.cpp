@@ -683,15 +683,17 @@ struct Preemptor {
     return false;
   }
   // common/preemption_policy.go:27-42
-  bool SatisfiesPreemptionPolicy(const Head& preemptor, int row, int policy) const {
-    int64_t pp = preemptor.priority, cp = sn.s->adm_priority[row];
+  static bool satisfiesPreemptionPolicy(int64_t pp, int64_t pts, int64_t cp, int64_t cts, int policy) {  // effective priorities
     bool lowerPriority = pp > cp;
     if (policy == KQ_POLICY_LOWER_PRIORITY) return lowerPriority;
     if (policy == KQ_POLICY_LOWER_OR_NEWER_EQUAL) {
-      bool newerEqual = (pp == cp) && preemptor.queue_ts < sn.s->adm_queue_ts[row];
+      bool newerEqual = (pp == cp) && pts < cts;
       return lowerPriority || newerEqual;
     }
     return policy == KQ_POLICY_ANY;
+  }
+  bool SatisfiesPreemptionPolicy(const Head& preemptor, int row, int policy) const {
+    return satisfiesPreemptionPolicy(preemptor.priority, preemptor.queue_ts, sn.s->adm_priority[row], sn.s->adm_queue_ts[row], policy);
   }
   // common/ordering.go:42-83 (AFS branch off: out of scope)
   int CandidatesOrdering(int a, int b, int cq) const {
@@ -1743,5 +1745,9 @@ int kqo_podset_reducer_search(int32_t n, const int32_t* counts, const int32_t* m
   });
   *out_count = (int32_t)last; *out_found = found ? 1 : 0;
   return 0;
+}
+// SatisfiesPreemptionPolicy (preemption/common/preemption_policy.go:27-42) on effective priorities and queue-order timestamps
+int kqo_satisfies_preemption_policy(int64_t preemptor_priority, int64_t preemptor_ts, int64_t candidate_priority, int64_t candidate_ts, int32_t policy) {
+  return Preemptor::satisfiesPreemptionPolicy(preemptor_priority, preemptor_ts, candidate_priority, candidate_ts, policy) ? 1 : 0;
 }
 }  // extern "C"

@@ -156,6 +156,13 @@ def is_preferred(a, b, policy_word: int) -> bool:
     return bool(l.kqo_is_preferred(a[0], a[1], b[0], b[1], policy_word))
 
 
+def satisfies_preemption_policy(preemptor, candidate, policy: int) -> bool:
+    """SatisfiesPreemptionPolicy (preemption/common/preemption_policy.go:27-42); preemptor / candidate = (effective priority, queue-order ts)."""
+    l = lib()
+    l.kqo_satisfies_preemption_policy.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
+    return bool(l.kqo_satisfies_preemption_policy(preemptor[0], preemptor[1], candidate[0], candidate[1], policy))
+
+
 def podset_reducer_search(counts, min_counts, count_limit):
     """PodSetReducer.Search (podset_reducer.go:56-86) with the predicate of the reference's TestSearch: sum(counts) <= limit.
     min_counts: -1 = no MinimumCount. Returns (count, found)."""

@@ -97,3 +97,15 @@ def test_podset_reducer_search(oracle, case):
     mins = [-1 if p["minCount"] is None else p["minCount"] for p in case["podSets"]]
     got_count, got_found = oracle.podset_reducer_search(counts, mins, case["countLimit"])
     assert (got_count, got_found) == (case["wantCount"], case["wantFound"])
+
+
+POLICY = {"Never": 0, "LowerPriority": 1, "LowerOrNewerEqualPriority": 2, "Any": 3}
+
+
+@pytest.mark.parametrize("case", M["satisfiesPreemptionPolicy"], ids=lambda c: c["name"][:70])
+def test_satisfies_preemption_policy(oracle, case):
+    """preemption_policy_test.go:34 TestSatisfiesPreemptionPolicy on effective priorities (hand transcription, each case cites its line)."""
+    sec = 1_000_000_000
+    got = oracle.satisfies_preemption_policy((case["preemptor"][0], case["preemptor"][1] * sec), (case["candidate"][0], case["candidate"][1] * sec),
+                                             POLICY[case["policy"]])
+    assert got == case["want"]
