@@ -1733,6 +1733,27 @@ int kqo_candidates_order(const kq_config* cfg, const kq_snapshot* s, int cq, int
   return KQ_OK;
 }
 
+// TargetClusterQueueOrdering.Iter() (preemption/fairsharing/ordering.go:92-226) driven like the reference's
+// TestMakeClusterQueueOrdering (ordering_test.go:255-268): every yielded target is either dropped (DropQueue) or loses its first
+// candidate (PopWorkload), as actions[i] says (1 = drop; beyond n_actions: pop). Returns the yielded ClusterQueues in order.
+int kqo_cq_ordering(const kq_config* cfg, const kq_snapshot* s, int32_t preemptor_cq, int32_t n_cand, const int32_t* cand_rows,
+                    int32_t n_actions, const uint8_t* actions, int32_t cap, int32_t* out_cq, int32_t* out_n) {
+  Snap sn(*cfg, s);
+  Preemptor p(sn);
+  std::vector<int> cands(cand_rows, cand_rows + n_cand);
+  Preemptor::Ordering ord = p.MakeClusterQueueOrdering(preemptor_cq, cands);
+  int n = 0;
+  for (int cq = p.orderingNext(ord); cq >= 0; cq = p.orderingNext(ord)) {
+    if (n >= cap) return KQ_ECAPACITY;
+    out_cq[n] = cq;
+    if (n < n_actions && actions[n]) ord.prunedClusterQueues.insert(cq);  // DropQueue ordering.go:129-131
+    else ord.PopWorkload(cq);
+    n++;
+  }
+  *out_n = n;
+  return KQ_OK;
+}
+
 // PodSetReducer.Search with the predicate of the reference's TestSearch (podset_reducer_test.go:127-134): sum(counts) <= limit
 int kqo_podset_reducer_search(int32_t n, const int32_t* counts, const int32_t* min_counts, int32_t count_limit, int32_t* out_count, int32_t* out_found) {
   std::vector<int> full(counts, counts + n), mins(min_counts, min_counts + n);

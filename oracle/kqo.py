@@ -156,6 +156,21 @@ def is_preferred(a, b, policy_word: int) -> bool:
     return bool(l.kqo_is_preferred(a[0], a[1], b[0], b[1], policy_word))
 
 
+def cq_ordering(cfg, snap: Snapshot, preemptor_cq: str, rows, actions=()):
+    """TargetClusterQueueOrdering.Iter() (fairsharing/ordering.go:92-226); actions[i] == "drop" drops the i-th yielded queue, anything
+    else pops its first candidate. Returns the yielded ClusterQueue names."""
+    r = np.asarray(rows, np.int32)
+    a = np.asarray([1 if x == "drop" else 0 for x in actions], np.uint8)
+    out = np.zeros(64, np.int32); n = C.c_int32()
+    l = lib()
+    l.kqo_cq_ordering.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
+    rc = l.kqo_cq_ordering(C.addressof(cfg), C.addressof(snap.struct()), snap.cq_index[preemptor_cq], len(r), r.ctypes.data, len(a), a.ctypes.data, 64,
+                           out.ctypes.data, C.byref(n))
+    assert rc == 0, rc
+    names = {i: nm for nm, i in snap.cq_index.items()}
+    return [names[int(c)] for c in out[:n.value]]
+
+
 def satisfies_preemption_policy(preemptor, candidate, policy: int) -> bool:
     """SatisfiesPreemptionPolicy (preemption/common/preemption_policy.go:27-42); preemptor / candidate = (effective priority, queue-order ts)."""
     l = lib()

@@ -109,3 +109,19 @@ def test_satisfies_preemption_policy(oracle, case):
     got = oracle.satisfies_preemption_policy((case["preemptor"][0], case["preemptor"][1] * sec), (case["candidate"][0], case["candidate"][1] * sec),
                                              POLICY[case["policy"]])
     assert got == case["want"]
+
+
+@pytest.mark.parametrize("case", M["clusterQueueOrdering"], ids=lambda c: c["name"][:70])
+def test_cluster_queue_ordering(oracle, case):
+    """ordering_test.go:36 TestMakeClusterQueueOrdering: the DRS-guided descent that picks the next ClusterQueue to take a victim from."""
+    cqs = [ClusterQueue(c["name"], cohort=c.get("cohort"), resource_groups=[ResourceGroup([FlavorQuotas("default").Resource("cpu", c["cpu"])])])
+           for c in case["clusterQueues"]]
+    cohorts = [Cohort(c["name"], parent=c.get("parent")) for c in case.get("cohorts", [])]
+    now = 1_000_000_000_000
+    adm = [Workload(w["name"], w["cq"], pod_sets=[PodSet("main", count=1, flavors={"cpu": "default"}).Request("cpu", w["cpu"])], reserve_ts=now, uid=f"uid-{i}")
+           for i, w in enumerate(case["admitted"])]
+    snap = Snapshot(cqs, cohorts, adm, now_ns=now)
+    oracle.derive(snap)
+    rows = [snap.adm_index[w["name"]] for w in case["admitted"] if w["cq"] in case["candidateCqs"]]
+    got = oracle.cq_ordering(make_config(fair_sharing=True), snap, case["preemptorCq"], rows, case.get("actions", ()))
+    assert got == case["want"]
