@@ -71,6 +71,10 @@ struct Amount {
     if (b.isUnlimited()) return Amount(I64MIN);
     return Amount(SaturatingSub(v, b.v));
   }
+  Amount SubInt64(int64_t x) const {  // :147
+    if (isUnlimited()) return *this;
+    return Amount(SaturatingSub(v, x));
+  }
   int Cmp(Amount b) const {  // :156
     if (isUnlimited() && b.isUnlimited()) return 0;
     if (isUnlimited()) return 1;
@@ -1751,6 +1755,22 @@ int kqo_cq_ordering(const kq_config* cfg, const kq_snapshot* s, int32_t preempto
     n++;
   }
   *out_n = n;
+  return KQ_OK;
+}
+
+// resources.Amount arithmetic (pkg/resources/amount.go:114-186) for the reference's TestAmountArithmetic known answers.
+// op: 0 Add, 1 AddInt64, 2 Sub, 3 SubInt64, 4 Cmp, 5 CmpInt64
+int kqo_amount_op(int32_t op, int64_t a, int64_t b, int64_t* out) {
+  const Amount x(a), y(b);
+  switch (op) {
+    case 0: *out = x.Add(y).v; break;
+    case 1: *out = x.AddInt64(b).v; break;
+    case 2: *out = x.Sub(y).v; break;
+    case 3: *out = x.SubInt64(b).v; break;
+    case 4: *out = x.Cmp(y); break;
+    case 5: *out = x.CmpInt64(b); break;
+    default: return KQ_EINVAL;
+  }
   return KQ_OK;
 }
 

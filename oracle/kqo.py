@@ -156,6 +156,18 @@ def is_preferred(a, b, policy_word: int) -> bool:
     return bool(l.kqo_is_preferred(a[0], a[1], b[0], b[1], policy_word))
 
 
+AMOUNT_OPS = {"Add": 0, "AddInt64": 1, "Sub": 2, "SubInt64": 3, "Cmp": 4, "CmpInt64": 5}
+
+
+def amount_op(op: str, a: int, b: int) -> int:
+    """resources.Amount arithmetic (pkg/resources/amount.go:114-186) on raw int64 (INT64_MAX = Unlimited)."""
+    out = C.c_int64()
+    l = lib()
+    l.kqo_amount_op.argtypes = [C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
+    assert l.kqo_amount_op(AMOUNT_OPS[op], a, b, C.byref(out)) == 0
+    return out.value
+
+
 def cq_ordering(cfg, snap: Snapshot, preemptor_cq: str, rows, actions=()):
     """TargetClusterQueueOrdering.Iter() (fairsharing/ordering.go:92-226); actions[i] == "drop" drops the i-th yielded queue, anything
     else pops its first candidate. Returns the yielded ClusterQueue names."""

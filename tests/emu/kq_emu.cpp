@@ -102,6 +102,18 @@ struct EmuBackend {
 typedef kq::EngineT<kq::EmuBackend> EmuEngine;
 
 extern "C" {
+// the device's resources.Amount arithmetic (kq_device.hpp a_add / a_addi / a_sub; Cmp is a plain signed compare because Unlimited is
+// INT64_MAX) for the reference's known answers. op: 0 Add, 1 AddInt64, 2 Sub, 4 Cmp, 5 CmpInt64
+int kqe_amount_op(int32_t op, int64_t a, int64_t b, int64_t* out) {
+  switch (op) {
+    case 0: *out = kq::a_add(a, b); break;
+    case 1: *out = kq::a_addi(a, b); break;
+    case 2: *out = kq::a_sub(a, b); break;
+    case 4: case 5: *out = a < b ? -1 : (a > b ? 1 : 0); break;
+    default: return KQ_EINVAL;
+  }
+  return KQ_OK;
+}
 int kqe_engine_create(const kq_config* cfg, void** out) { auto* e = new EmuEngine(); e->cfg = *cfg; *out = e; return KQ_OK; }
 void kqe_engine_destroy(void* e) { delete (EmuEngine*)e; }
 int kqe_snapshot_put(void* e, const kq_snapshot* s) { return ((EmuEngine*)e)->snapshot_put(s); }

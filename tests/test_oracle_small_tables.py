@@ -125,3 +125,26 @@ def test_cluster_queue_ordering(oracle, case):
     rows = [snap.adm_index[w["name"]] for w in case["admitted"] if w["cq"] in case["candidateCqs"]]
     got = oracle.cq_ordering(make_config(fair_sharing=True), snap, case["preemptorCq"], rows, case.get("actions", ()))
     assert got == case["want"]
+
+
+def _i64(v):
+    if isinstance(v, int):
+        return v
+    mx, mn = 2 ** 63 - 1, -2 ** 63
+    return {"MAX": mx, "MIN": mn}.get(v) if v in ("MAX", "MIN") else mx - int(v.split("-")[1])
+
+
+@pytest.mark.parametrize("case", M["amountArithmetic"], ids=lambda c: c["name"][:70])
+def test_amount_arithmetic(oracle, case):
+    """amount_test.go:148 TestAmountArithmetic: the saturating / Unlimited-aware arithmetic every quota computation rests on —
+    on the oracle's Amount and on the engine's a_add / a_addi / a_sub (device source compiled for the CPU emulation)."""
+    import ctypes as C
+    from tests.emu import kqe
+    a, b, want = _i64(case["a"]), _i64(case["b"]), _i64(case["want"])
+    assert oracle.amount_op(case["op"], a, b) == want
+    if case["op"] != "SubInt64":  # the engine has no SubInt64 (the path never subtracts a plain integer from an Amount)
+        out = C.c_int64()
+        l = kqe.lib()
+        l.kqe_amount_op.argtypes = [C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
+        assert l.kqe_amount_op(oracle.AMOUNT_OPS[case["op"]], a, b, C.byref(out)) == 0
+        assert out.value == want
