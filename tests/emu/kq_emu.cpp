@@ -114,6 +114,13 @@ int kqe_amount_op(int32_t op, int64_t a, int64_t b, int64_t* out) {
   }
   return KQ_OK;
 }
+// the device's CountIn (kq_tas_device.hpp t_count_in) on dense [R] vectors; no pods pseudo-resource
+int kqe_tas_count_in(int32_t R, const int64_t* req, const int64_t* cap, int32_t* out) {
+  kq::TK k{};
+  k.T.R = R; k.T.pods = -1;
+  *out = kq::t_count_in(k, req, cap);
+  return KQ_OK;
+}
 int kqe_engine_create(const kq_config* cfg, void** out) { auto* e = new EmuEngine(); e->cfg = *cfg; *out = e; return KQ_OK; }
 void kqe_engine_destroy(void* e) { delete (EmuEngine*)e; }
 int kqe_snapshot_put(void* e, const kq_snapshot* s) { return ((EmuEngine*)e)->snapshot_put(s); }

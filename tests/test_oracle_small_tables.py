@@ -148,3 +148,20 @@ def test_amount_arithmetic(oracle, case):
         l.kqe_amount_op.argtypes = [C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
         assert l.kqe_amount_op(oracle.AMOUNT_OPS[case["op"]], a, b, C.byref(out)) == 0
         assert out.value == want
+
+
+@pytest.mark.parametrize("case", M["countIn"], ids=lambda c: c["name"][:70])
+def test_count_in(oracle, case):
+    """requests_test.go:31,130 TestCountIn / TestCountInWithLimitingResource: how many pods of a request fit into a capacity vector — the
+    leaf count of TAS phase 1 (tas_flavor_snapshot.go:1899) — on the oracle and on the device function (CPU emulation)."""
+    import ctypes as C
+    import numpy as np
+    from oracle import kqo
+    from tests.emu import kqe
+    req = np.asarray(case["req"], np.int64); cap = np.asarray(case["cap"], np.int64)
+    for l, fn in ((kqo.lib(), "kqo_tas_count_in"), (kqe.lib(), "kqe_tas_count_in")):
+        f = getattr(l, fn)
+        f.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+        out = C.c_int32()
+        assert f(len(req), req.ctypes.data, cap.ctypes.data, C.byref(out)) == 0
+        assert out.value == case["want"], fn
