@@ -127,12 +127,39 @@ def podset_reducer_search():
     return out
 
 
+def sorted_domains(func):
+    """TestSortedDomains / TestSortedDomainsWithLeader (pkg/cache/scheduler/tas_flavor_snapshot_test.go:884 / :601)."""
+    src = strip_comments(open("/root/reference/pkg/cache/scheduler/tas_flavor_snapshot_test.go").read())
+    a = src.index(f"func {func}(")
+    body = src[a:src.index("\nfunc ", a + 10)]
+    m = re.search(r"testCases := map\[string\]struct \{", body)
+    close = match_brace(body, m.end() - 1)
+    o = body.index("{", close + 1)
+    c = match_brace(body, o)
+    out = []
+    for el in elements(body[o + 1:c]):
+        nm = re.match(r'"((?:[^"\\]|\\.)*)"\s*:\s*\{', el)
+        f = top_level_fields(el[nm.end():el.rindex("}")])
+        doms = []
+        dl = f["domains"]
+        for d in elements(dl[dl.index("{") + 1:dl.rindex("}")]):
+            did = re.search(r'id:\s*"([^"]+)"', d).group(1)
+            lv = re.search(r'levelValues:\s*\[\]string\{"([^"]+)"\}', d).group(1)
+            st = {k: int(v) for k, v in re.findall(r"(affinityScore|sliceCount|podCount|leaderCount|sliceCountWithLeader|podCountWithLeader):\s*(\d+)", d)}
+            doms.append(dict(id=did, levelValue=lv, **st))
+        out.append(dict(name=nm.group(1), affinityGate=f.get("enableTASPreferredSchedulingAffinity", "false") == "true",
+                        unconstrained=f.get("unconstrained", "false") == "true", domains=doms,
+                        want=re.findall(r'"([^"]+)"', f["wantOrder"])))
+    return out
+
+
 def main():
-    doc = dict(isPreferred=is_preferred(), resourcesToReserve=resources_to_reserve(), lastAssignmentOutdated=last_assignment_outdated(),
+    doc = dict(sortedDomains=sorted_domains("TestSortedDomains"), sortedDomainsWithLeader=sorted_domains("TestSortedDomainsWithLeader"),
+               isPreferred=is_preferred(), resourcesToReserve=resources_to_reserve(), lastAssignmentOutdated=last_assignment_outdated(),
                podSetReducerSearch=podset_reducer_search())
     with open(OUT, "w") as fh:
         fh.write("# Generated by tests/golden/extract_small_tables.py from the reference's TestIsPreferred, TestResourcesToReserve,\n"
-                 "# TestLastAssignmentOutdated and TestSearch (PodSetReducer) tables.\n")
+                 "# TestLastAssignmentOutdated, TestSearch (PodSetReducer), TestSortedDomains and TestSortedDomainsWithLeader tables.\n")
         yaml.safe_dump(doc, fh, sort_keys=False, width=160)
     print({k: len(v) for k, v in doc.items()})
 

@@ -165,3 +165,34 @@ def test_count_in(oracle, case):
         out = C.c_int32()
         assert f(len(req), req.ctypes.data, cap.ctypes.data, C.byref(out)) == 0
         assert out.value == case["want"], fn
+
+
+def _sorted_domains(case, with_leader):
+    import ctypes as C
+    import numpy as np
+    from oracle import kqo
+    doms = case["domains"]
+    by_level = sorted(range(len(doms)), key=lambda i: doms[i]["levelValue"])  # domain index = rank of its levelValues (final tie-break)
+    idx_of = {orig: rank for rank, orig in enumerate(by_level)}
+    state = np.zeros((len(doms), 5), np.int32)
+    for orig, d in enumerate(doms):
+        state[idx_of[orig]] = [d.get("podCount", 0), d.get("sliceCount", 0), d.get("podCountWithLeader", 0), d.get("sliceCountWithLeader", 0), d.get("leaderCount", 0)]
+    order_in = np.asarray([idx_of[i] for i in range(len(doms))], np.int32)
+    out = np.zeros(len(doms), np.int32)
+    l = kqo.lib()
+    l.kqo_tas_sorted_domains.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    # the reference test runs with the default (Mixed) profile: unconstrained => LeastFreeCapacity (tas_flavor_snapshot.go:1468)
+    assert l.kqo_tas_sorted_domains(len(doms), state.ctypes.data, order_in.ctypes.data, int(case["unconstrained"]), 1, int(with_leader), out.ctypes.data) == 0
+    return [doms[by_level[r]]["id"] for r in out]
+
+
+@pytest.mark.parametrize("case", [c for c in T["sortedDomains"] if not c["affinityGate"]], ids=lambda c: c["name"][:70])
+def test_tas_sorted_domains(oracle, case):
+    """tas_flavor_snapshot_test.go:884 TestSortedDomains (the TASRespectNodeAffinityPreferred cases are outside the boundary)."""
+    assert _sorted_domains(case, False) == case["want"]
+
+
+@pytest.mark.parametrize("case", [c for c in T["sortedDomainsWithLeader"] if not c["affinityGate"]], ids=lambda c: c["name"][:70])
+def test_tas_sorted_domains_with_leader(oracle, case):
+    """tas_flavor_snapshot_test.go:601 TestSortedDomainsWithLeader."""
+    assert _sorted_domains(case, True) == case["want"]
