@@ -34,11 +34,13 @@ template <class B> struct EngineT {
   std::vector<Buf*> all_bufs;
   Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_grec, b_cqd, b_fs[20];
   bool force_exact_drs = false;  // tests: take the saturation-safe DRS loops even when the sums would be exact
-  struct HeadBatch { Buf hb[16]; DHeads H{}; int n = 0; size_t nps = 0; int slot_cap = 1; int64_t cycle = 0; bool valid = false; bool plain = true; };
+  struct HeadBatch { Buf hb[1]; DHeads H{}; int n = 0; size_t nps = 0; int slot_cap = 1; int64_t cycle = 0; bool valid = false; bool plain = true; };
   std::vector<HeadBatch> batches;  // [0] = transient batch of kq_cycle_run, [1+b] = resident batch b
   Buf ob[24];  // output arrays
   uint8_t* hstage = nullptr;  // pinned host staging for the packed decisions
   size_t hstage_cap = 0;
+  uint8_t* hup = nullptr;     // pinned host staging for a batch of heads (one H2D per kq_heads_put / kq_cycle_run)
+  size_t hup_cap = 0;
   double last_kernel_ms = 0;
   double last_phase_ms[3] = {0, 0, 0};
   int64_t last_bytes = 0;
@@ -70,6 +72,7 @@ template <class B> struct EngineT {
   ~EngineT() {
     free_snapshot();
     if (hstage) be.free_host(hstage);
+    if (hup) be.free_host(hup);
     for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb, &b_grec, &b_cqd}) if (b->p) be.free(b->p);
     for (auto& b : b_fs) if (b.p) be.free(b.p);
     for (auto& c : ring) for (Buf* b : {&c.cq, &c.use_n, &c.use_fr, &c.use_qty}) if (b->p) be.free(b->p);
@@ -266,12 +269,6 @@ template <class B> struct EngineT {
     return KQ_OK;
   }
 
-  template <class T> const T* up_head(HeadBatch& hbch, int i, const T* host, size_t n) {
-    T* d = grow<T>(hbch.hb[i], n);
-    if (n) be.h2d(d, host, n * sizeof(T));
-    return d;
-  }
-
   // Make one batch of heads resident in HBM. slot 0 is the transient batch of kq_cycle_run.
   int heads_put(const kq_heads* h, int slot) {
     if (!have_snapshot) return fail(KQ_EINVAL, "heads before kq_snapshot_put");
@@ -287,28 +284,39 @@ template <class B> struct EngineT {
     hbch.nps = n ? h->ps_off[n] : 0;
     if (n == 0) return KQ_OK;
     const size_t nps = hbch.nps, nreqs = h->ps_req_off[nps], nR = prep.nR, nfw = (prep.nF + 63) / 64;
-    std::vector<int64_t> zeros64(n, 0);
-    std::vector<uint64_t> zerosu64(n, 0);
-    std::vector<int32_t> minus1(nps * nR, -1), minus1ps(nps, -1);
+    // The sixteen arrays of a batch travel as ONE packed region (16-byte aligned pieces) through a pinned staging buffer: the
+    // PCIe-inclusive entry point kq_cycle_run pays one copy per cycle instead of sixteen.
+    size_t off = 0;
+    auto place = [&](size_t bytes) { const size_t o = off; off += (bytes + 15) & ~(size_t)15; return o; };
+    const size_t o_cq = place(n * 4), o_prio = place(n * 8), o_ts = place(n * 8), o_flags = place(n * 4), o_psoff = place((n + 1) * 4);
+    const size_t o_pscnt = place(nps * 4), o_psmin = place(nps * 4), o_reqoff = place((nps + 1) * 4), o_rres = place(nreqs * 4), o_rqty = place(nreqs * 8);
+    const size_t o_fok = place(nps * nfw * 8), o_ltried = place(nps * nR * 4), o_lgen = place(n * 8), o_lcyc = place(n * 8), o_lhash = place(n * 8), o_hash = place(n * 8);
+    const size_t total = off;
+    if (hup_cap < total) { if (hup) be.free_host(hup); hup_cap = total + total / 4; hup = (uint8_t*)be.alloc_host(hup_cap); }
+    if (!hup) { hup_cap = 0; return fail(KQ_EDEVICE, "pinned staging buffer for the heads could not be allocated"); }
+    auto put = [&](size_t o, const void* src, size_t bytes) { if (bytes) memcpy(hup + o, src, bytes); };
+    auto fill = [&](size_t o, int byte, size_t bytes) { if (bytes) memset(hup + o, byte, bytes); };
+    put(o_cq, h->cq, n * 4); put(o_prio, h->priority, n * 8); put(o_ts, h->queue_ts, n * 8); put(o_flags, h->flags, n * 4);
+    put(o_psoff, h->ps_off, (n + 1) * 4); put(o_pscnt, h->ps_count, nps * 4);
+    if (h->ps_min_count) put(o_psmin, h->ps_min_count, nps * 4); else fill(o_psmin, 0xff, nps * 4);          // -1: no MinimumCount
+    put(o_reqoff, h->ps_req_off, (nps + 1) * 4); put(o_rres, h->req_res, nreqs * 4); put(o_rqty, h->req_qty, nreqs * 8);
+    put(o_fok, h->ps_flavor_ok, nps * nfw * 8);
+    if (h->ps_last_tried) put(o_ltried, h->ps_last_tried, nps * nR * 4); else fill(o_ltried, 0xff, nps * nR * 4);  // -1: nothing tried
+    if (h->last_generation) put(o_lgen, h->last_generation, n * 8); else fill(o_lgen, 0, n * 8);
+    if (h->last_cycle) put(o_lcyc, h->last_cycle, n * 8); else fill(o_lcyc, 0, n * 8);
+    if (h->last_hash) put(o_lhash, h->last_hash, n * 8); else fill(o_lhash, 0, n * 8);
+    if (h->hash) put(o_hash, h->hash, n * 8); else fill(o_hash, 0, n * 8);
+    uint8_t* d = grow<uint8_t>(hbch.hb[0], total);
+    be.h2d(d, hup, total);
     DHeads& H = hbch.H;
     H.n = n;
-    H.cq = up_head(hbch, 0, h->cq, n);
-    H.priority = up_head(hbch, 1, h->priority, n);
-    H.queue_ts = up_head(hbch, 2, h->queue_ts, n);
-    H.flags = up_head(hbch, 3, h->flags, n);
-    H.ps_off = up_head(hbch, 4, h->ps_off, n + 1);
-    H.ps_count = up_head(hbch, 5, h->ps_count, nps);
-    H.ps_min_count = up_head(hbch, 6, h->ps_min_count ? h->ps_min_count : minus1ps.data(), nps);
-    H.ps_req_off = up_head(hbch, 7, h->ps_req_off, nps + 1);
-    H.req_res = up_head(hbch, 8, h->req_res, nreqs);
-    H.req_qty = up_head(hbch, 9, h->req_qty, nreqs);
-    H.ps_flavor_ok = up_head(hbch, 10, h->ps_flavor_ok, nps * nfw);
-    H.ps_last_tried = up_head(hbch, 11, h->ps_last_tried ? h->ps_last_tried : minus1.data(), nps * nR);
-    H.last_generation = up_head(hbch, 12, h->last_generation ? h->last_generation : zeros64.data(), n);
-    H.last_cycle = up_head(hbch, 13, h->last_cycle ? h->last_cycle : zeros64.data(), n);
-    H.last_hash = up_head(hbch, 14, h->last_hash ? h->last_hash : zerosu64.data(), n);
-    H.hash = up_head(hbch, 15, h->hash ? h->hash : zerosu64.data(), n);
-    rc = be.sync();  // host staging vectors go out of scope
+    H.cq = (const int32_t*)(d + o_cq); H.priority = (const int64_t*)(d + o_prio); H.queue_ts = (const int64_t*)(d + o_ts);
+    H.flags = (const uint32_t*)(d + o_flags); H.ps_off = (const int32_t*)(d + o_psoff); H.ps_count = (const int32_t*)(d + o_pscnt);
+    H.ps_min_count = (const int32_t*)(d + o_psmin); H.ps_req_off = (const int32_t*)(d + o_reqoff); H.req_res = (const int32_t*)(d + o_rres);
+    H.req_qty = (const int64_t*)(d + o_rqty); H.ps_flavor_ok = (const uint64_t*)(d + o_fok); H.ps_last_tried = (const int32_t*)(d + o_ltried);
+    H.last_generation = (const int64_t*)(d + o_lgen); H.last_cycle = (const int64_t*)(d + o_lcyc);
+    H.last_hash = (const uint64_t*)(d + o_lhash); H.hash = (const uint64_t*)(d + o_hash);
+    rc = be.sync();  // the staging buffer is reused by the next call
     if (rc != KQ_OK) return fail(rc, be.error());
     return KQ_OK;
   }
