@@ -293,6 +293,14 @@ int  kq_last_cycle_stats(kq_engine* e, double* kernel_ms, int64_t* algorithmic_b
 int  kq_snapshot_derive(kq_engine* e);
 int  kq_snapshot_read_planes(kq_engine* e, int64_t* subtree_quota, int64_t* usage, uint8_t* quota_flags);
 
+/* Diagnostics. NOT part of the drop-in boundary (a Go binding does not need them); the parity tests use them.
+ * kq_debug_read_usage_work: the cycle's private usage plane [N * n_fr] as processEntry left it (what the reference's
+ * per-cycle Snapshot holds after schedule() returns). kq_debug_force_exact_drs: take the saturation-safe per-cell DRS loops
+ * even when the maintained sums would be exact. kq_debug_prof: 32 in-kernel segment counters (KQ_PROF builds). */
+int  kq_debug_read_usage_work(kq_engine* e, int64_t* usage_out);
+int  kq_debug_force_exact_drs(kq_engine* e, int on);
+int  kq_debug_prof(kq_engine* e, int64_t* out32, int reset);
+
 const char* kq_strerror(int code);
 const char* kq_last_error(kq_engine* e);
 int  kq_abi_version(void);

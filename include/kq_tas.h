@@ -89,7 +89,10 @@ int  kq_tas_topology_put(kq_tas*, const kq_tas_topology* t);
 int  kq_tas_find(kq_tas*, const kq_tas_requests* r, kq_tas_result* out);
 /* updateTASUsage :267 for a TopologyAssignment: tas_usage[leaf] +/-= single_pod_requests * count (+ pods: count) */
 int  kq_tas_usage_apply(kq_tas*, int32_t n_dom, const int32_t* leaf, const int32_t* count, const int64_t* single_pod_requests, int32_t add);
-/* TASFlavorSnapshot.Fits :433 */
+/* TASFlavorSnapshot.Fits :433. single_pod_requests is dense over the resource dictionary: 0 = the resource is not a key of
+ * SinglePodRequests; KQ_TAS_REQ_ZERO = it is a key with quantity zero, which CountIn counts as MaxInt32
+ * (pkg/resources/requests.go:205-207) — a pod whose requests are all zero fits, a pod without any request never does. */
+#define KQ_TAS_REQ_ZERO (-1)
 int  kq_tas_fits(kq_tas*, int32_t n_dom, const int32_t* leaf, const int32_t* count, const int64_t* single_pod_requests, int32_t* fits);
 int  kq_tas_read_usage(kq_tas*, int64_t* tas_usage);
 int  kq_tas_last_stats(kq_tas*, double* kernel_ms, int64_t* bytes);

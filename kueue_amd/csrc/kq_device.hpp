@@ -47,6 +47,7 @@ KQ_DEV int atomic_add_i32(int* p, int v) { int o = *p; *p += v; return o; }
 KQ_DEV void atomic_max_i32(int* p, int v) { if (v > *p) *p = v; }
 KQ_DEV void atomic_add_i64(long long* p, long long v) { *p += v; }
 KQ_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
+KQ_DEV int64_t atomic_cas_i64(int64_t* p, int64_t expect, int64_t v) { int64_t o = *p; if (o == expect) *p = v; return o; }
 KQ_DEV int64_t wsum_i64(int64_t v) { return v; }
 static int g_emu_pipeline = 0;  // tests: emulate the helper waves of k_process prefetching one chunk ahead
 }  // namespace kq
@@ -82,6 +83,9 @@ KQ_DEV int atomic_add_i32(int* p, int v) { return atomicAdd(p, v); }
 KQ_DEV void atomic_max_i32(int* p, int v) { atomicMax(p, v); }
 KQ_DEV void atomic_add_i64(long long* p, long long v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
 KQ_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
+KQ_DEV int64_t atomic_cas_i64(int64_t* p, int64_t expect, int64_t v) {
+  return (int64_t)atomicCAS((unsigned long long*)p, (unsigned long long)expect, (unsigned long long)v);
+}
 KQ_DEV int64_t wsum_i64(int64_t v) {
   for (int o = 32; o > 0; o >>= 1) v += (int64_t)__shfl_xor((long long)v, o, 64);
   return v;
@@ -221,7 +225,10 @@ struct K {  // everything a kernel needs
   int32_t* cq_rm_bytes;      // [nq] candidate-record bytes of the rows preempted so far this cycle (they left cq.Workloads)
   uint8_t* cq_dirty;         // [nq] a ClusterQueue-level usage cell of this CQ was written in HBM during this cycle's k_process
   struct PRec* grec;         // [H] per-head entry records, static part (rec_fill_static); k_process copies them into LDS
+  const int32_t* usage_big;  // [1] set by kq_cycle_commit / release when a ClusterQueue usage cell left the plain range (>= 2^50 or
+                             // negative): the sum-based DRS shortcuts (C.fs_plain) are off from then on
 };
+KQ_DEV bool fs_plain_now(const K& k) { return k.C.fs_plain && !(k.usage_big && *k.usage_big); }
 
 // ------------------------------------------------------------------------------------------------
 // resources.Amount (pkg/resources/amount.go) on raw int64; INT64_MAX == Unlimited.
@@ -1394,8 +1401,9 @@ KQ_DEV Search make_search(const K& k, Wave& w, int slot, const int64_t* usage, c
   s.qcnt = k.X.qcnt ? k.X.qcnt + (size_t)slot * k.X.max_tree_cqs : nullptr;
   s.qhead = k.X.qhead ? k.X.qhead + (size_t)slot * k.X.max_tree_cqs : nullptr;
   s.cohp = k.X.cohp ? k.X.cohp + (size_t)slot * k.X.max_tree_nodes : nullptr;
-  s.psum = (k.C.fs_plain && k.X.psum) ? k.X.psum + (size_t)slot * k.X.max_tree_nodes * k.S.nR : nullptr;
-  s.ppos = (k.C.fs_plain && k.X.ppos) ? k.X.ppos + (size_t)slot * k.X.max_tree_nodes : nullptr;
+  const bool plain = fs_plain_now(k);
+  s.psum = (plain && k.X.psum) ? k.X.psum + (size_t)slot * k.X.max_tree_nodes * k.S.nR : nullptr;
+  s.ppos = (plain && k.X.ppos) ? k.X.ppos + (size_t)slot * k.X.max_tree_nodes : nullptr;
   return s;
 }
 
@@ -3070,6 +3078,7 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
   }
   const int root = S.path[(size_t)S.tree_cqs[q0] * KQ_MAXD + S.plen[S.tree_cqs[q0]] - 1];
   const bool want_bon = gate(k, KQ_GATE_FS_PRIORITIZE_NON_BORROWING);
+  const bool fs_plain = fs_plain_now(k);
   int lpos = 0;
   bool first = true;
   for (;;) {
@@ -3100,7 +3109,7 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
         for (int l = from; l + 1 < plen; l++) {
           pe.level = l;
           int64_t lb = 0;
-          DRSv d = k.C.fs_plain ? drs_entry_level(k, w, path, l, pe.ufr, pe.uqty, pe.nu, want_bon, &lb)
+          DRSv d = fs_plain ? drs_entry_level(k, w, path, l, pe.ufr, pe.uqty, pe.nu, want_bon, &lb)
                                 : drs_of(S, path[l], pe, &lb, pe.ufr, pe.uqty, want_bon ? pe.nu : 0);
           const size_t o = (size_t)i * KQ_MAXD + l;
           const FsKey key = fs_make_key(k, en, d);
@@ -3171,7 +3180,7 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
       }
       if (!done) process_entry(k, w, e, lpos, slot, tree);
       KQ_TS(k, 20);
-      if (k.C.fs_plain && w.usage_dirty) {  // the rows of the popped entry's path changed: refresh their sums
+      if (fs_plain && w.usage_dirty) {  // the rows of the popped entry's path changed: refresh their sums
         const int pl = S.plen[ec];
         PW pw{&k, &w};
         for (int j = lane; j < pl * S.nR; j += WAVE) {
@@ -3285,6 +3294,7 @@ struct DCommit {
   const int32_t* use_fr;  // [n * KQ_MAXU]
   const int64_t* use_qty;
   int64_t* usage;         // the snapshot's usage plane
+  int32_t* big;           // [1] K::usage_big
 };
 // one wave per root-cohort tree; entries of a tree touch the same cohort cells, so they are applied one after another,
 // lanes = the entry's flavor-resources (independent columns)
@@ -3299,6 +3309,7 @@ KQ_DEV void commit_tree(const DSnap& S, const DCommit& c, int tree, bool add) {
       UGW g{&S, c.usage, fr};
       if (add) add_usage(S, S.path + (size_t)cq * KQ_MAXD, S.plen[cq], fr, c.use_qty[(size_t)h * KQ_MAXU + u], g);
       else remove_usage(S, S.path + (size_t)cq * KQ_MAXD, S.plen[cq], fr, c.use_qty[(size_t)h * KQ_MAXU + u], g);
+      if (c.big && (uint64_t)g.get(cq) >= ((uint64_t)1 << 50)) *c.big = 1;
     }
     wsync();
   }
@@ -3311,7 +3322,17 @@ KQ_DEV void commit_cq_cell(const DCommit& c, const DSnap& S, int h, int u, bool 
   if (u >= c.use_n[h]) return;
   const int fr = c.use_fr[(size_t)h * KQ_MAXU + u];
   const int64_t q = c.use_qty[(size_t)h * KQ_MAXU + u];
-  atomic_add_i64((long long*)&c.usage[(size_t)c.cq[h] * S.nfr + fr], (long long)(add ? q : -q));
+  // resources.Amount.Add / Sub (amount.go:114-145: saturating, Unlimited absorbing) under a compare-and-swap: admissions of one
+  // commit only add, releases only subtract, so the result does not depend on the order the heads arrive in
+  int64_t* cell = &c.usage[(size_t)c.cq[h] * S.nfr + fr];
+  int64_t old = *(volatile int64_t*)cell, nw;
+  for (;;) {
+    nw = add ? a_add(old, q) : a_sub(old, q);
+    const int64_t seen = atomic_cas_i64(cell, old, nw);
+    if (seen == old) break;
+    old = seen;
+  }
+  if (c.big && (uint64_t)nw >= ((uint64_t)1 << 50)) *c.big = 1;  // negatives land here too
 }
 KQ_DEV void derive_usage_cell(const DSnap& S, int64_t* usage, int cohort, int fr) {
   int64_t u = 0;

@@ -488,9 +488,9 @@ void kq_tas_destroy(kq_tas* t) {
   if (!t) return;
   (void)hipSetDevice(t->e.be.device);
   t->e.free_topo();
-  t->e.~TasT<HipBackend>();
-  t->e.be.destroy();
-  ::operator delete(t);
+  HipBackend be = t->e.be;  // the backend handles outlive the engine object: its destructor still frees device buffers
+  delete t;
+  be.destroy();
 }
 int kq_tas_topology_put(kq_tas* t, const kq_tas_topology* tp) { if (!t || !tp) return KQ_EINVAL; (void)hipSetDevice(t->e.be.device); return t->e.topology_put(tp); }
 int kq_tas_find(kq_tas* t, const kq_tas_requests* r, kq_tas_result* out) { if (!t || !r || !out) return KQ_EINVAL; (void)hipSetDevice(t->e.be.device); return t->e.find(r, out); }

@@ -28,6 +28,7 @@ template <class B> struct EngineT {
   int64_t* d_usage = nullptr;       // cycle-start usage plane (mutable by derive)
   int64_t* d_sq = nullptr;          // subtree quota (mutable by derive)
   uint8_t* d_qflags = nullptr;
+  int32_t* d_big = nullptr;         // K::usage_big
   std::vector<void*> snap_allocs;
   // cycle buffers (grow-only)
   struct Buf { void* p = nullptr; size_t cap = 0; };
@@ -85,6 +86,9 @@ template <class B> struct EngineT {
     free_snapshot();
     for (auto& c : ring) c.live = false;
     commits = 0; last_cycle_n = -1;
+    // Resident head batches were validated against, and carry the strides of, the snapshot they were uploaded under
+    // (cq < nq, req_res < nR, ps_flavor_ok / ps_last_tried row widths): a new snapshot voids them. kq_heads_put again.
+    for (auto& hbch : batches) hbch.valid = false;
     int rc = build_prep(s, prep);
     if (rc != KQ_OK) return fail(rc, prep.err);
     const size_t N = prep.N, nfr = prep.nfr, nq = prep.nq;
@@ -99,6 +103,7 @@ template <class B> struct EngineT {
     d_sq = upload(s->subtree_quota, N * nfr); S.sq = d_sq;
     d_usage = upload(s->usage, N * nfr); levels_stale = false;
     d_qflags = upload(s->quota_flags, N * nfr); S.qflags = d_qflags;
+    { const int32_t zero = 0; d_big = upload(&zero, 1); }
     S.cq_rg_off = upload(s->cq_rg_off, nq + 1);
     S.rg_flavor_off = upload(s->rg_flavor_off, prep.n_rg + 1);
     S.rg_flavor = upload(s->rg_flavor, s->rg_flavor_off[prep.n_rg]);
@@ -153,7 +158,8 @@ template <class B> struct EngineT {
   struct Committed { Buf cq, use_n, use_fr, use_qty; int n = 0; bool live = false; };
   Committed ring[KQ_COMMIT_RING];
   int64_t commits = 0;
-  int last_cycle_n = -1;   // heads of the last executed cycle, -1 = none / already committed
+  int last_cycle_n = -1;   // heads of the last executed cycle, -1 = none / already committed / failed
+  int last_slot = -1;      // head batch of that cycle (kq_cycle_commit reads its cq array on the device)
   DOut last_O{};
   int max_depth() const { int m = 0; for (int n = 0; n < prep.N; n++) m = std::max(m, (int)prep.depth[n]); return m; }
   // Folding usage rows into the resident snapshot. When the snapshot satisfies "cohort usage = sum of what the children store
@@ -184,7 +190,7 @@ template <class B> struct EngineT {
       int32_t* d_count = (int32_t*)grow<int64_t>(b_misc, 2);
       if (n_admitted) be.memset(d_count, 0, 16);  // the count is only read back on request
       be.launch_commit_mask(n, d_un, d_cq, d_fr, d_qty, d_count);  // also keeps the cycle's usage rows for the release
-      DCommit dc{n, d_cq, d_un, d_fr, d_qty, d_usage};
+      DCommit dc{n, d_cq, d_un, d_fr, d_qty, d_usage, d_big};
       apply_commit(dc, true);
       if (n_admitted) {  // only a caller that asks for the count pays for a round trip; the stream orders the rest
         be.d2h(&count, d_count, sizeof(count));
@@ -203,7 +209,7 @@ template <class B> struct EngineT {
     Committed& c = ring[(commits - age) % KQ_COMMIT_RING];
     if (!c.live) return fail(KQ_EINVAL, "kq_cycle_release: already released");
     if (c.n > 0) {
-      DCommit dc{c.n, (const int32_t*)c.cq.p, (const int32_t*)c.use_n.p, (const int32_t*)c.use_fr.p, (const int64_t*)c.use_qty.p, d_usage};
+      DCommit dc{c.n, (const int32_t*)c.cq.p, (const int32_t*)c.use_n.p, (const int32_t*)c.use_fr.p, (const int64_t*)c.use_qty.p, d_usage, d_big};
       apply_commit(dc, false);
     }
     c.live = false;
@@ -279,6 +285,7 @@ template <class B> struct EngineT {
     if (rc != KQ_OK) return rc;
     if ((int)batches.size() <= slot) batches.resize(slot + 1);
     HeadBatch& hbch = batches[slot];
+    if (slot == last_slot) last_cycle_n = -1;  // the uncommitted cycle's head arrays are about to be replaced (or freed)
     const int n = h->n;
     hbch.n = n; hbch.slot_cap = slot_cap; hbch.cycle = h->cycle; hbch.valid = true; hbch.plain = plain;
     hbch.nps = n ? h->ps_off[n] : 0;
@@ -414,7 +421,7 @@ template <class B> struct EngineT {
       X.bs_sum = grow<int64_t>(b_fs[16], (size_t)prep.N * nR); X.bs_pos = grow<int32_t>(b_fs[17], prep.N);
       X.psum = grow<int64_t>(b_fs[18], tn * nR); X.ppos = grow<int32_t>(b_fs[19], tn);
     }
-    k.usage = d_usage;
+    k.usage = d_usage; k.usage_big = d_big;
     k.usage_work = grow<int64_t>(b_usage_work, Nfr);
     k.usage_np = grow<int64_t>(b_usage_np, Nfr);
     k.preempted = grow<uint8_t>(b_preempted, ((size_t)std::max(prep.n_adm, 1) + 3) & ~(size_t)3);
@@ -446,7 +453,7 @@ template <class B> struct EngineT {
     if (cfg.fair_sharing) be.launch_process_fair(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16, rank);
     else be.launch_process(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16);
     be.timer_mark(3);
-    last_cycle_n = n; last_O = k.O;
+    last_cycle_n = -1;  // set on the success path only: a failed cycle must not be committable
 
     // decisions back: one D2H of the packed region into host staging, then plain memcpy to the caller's arrays
     if (hstage_cap < pack_bytes) { if (hstage) be.free_host(hstage); hstage_cap = pack_bytes + pack_bytes / 4; hstage = (uint8_t*)be.alloc_host(hstage_cap); }
@@ -482,6 +489,7 @@ template <class B> struct EngineT {
     int tot = 0;
     if (pool_used == 0) {  // no preemption anywhere in this cycle
       if (out->tgt_off) memset(out->tgt_off, 0, (size_t)(n + 1) * sizeof(int32_t));
+      last_cycle_n = n; last_O = k.O; last_slot = slot;
       return KQ_OK;
     }
     for (int i = 0; i < n; i++) {
@@ -497,6 +505,7 @@ template <class B> struct EngineT {
       }
     }
     if (out->tgt_off) out->tgt_off[n] = tot;
+    last_cycle_n = n; last_O = k.O; last_slot = slot;
     return KQ_OK;
   }
 

@@ -92,9 +92,14 @@ template <class Backend> struct TasT {
     const int nw = r->n_workloads;
     if (nw < 0) return fail(KQ_EINVAL, "negative workload count");
     const int n = nw > 0 ? r->wl_off[nw] : 0;
+    if (!out->dom_off) return fail(KQ_EINVAL, "null dom_off");
     out->dom_off[0] = 0;
     last_ms = 0; last_bytes = 0;
     if (n == 0) return KQ_OK;
+    if (!r->wl_off || !r->single_pod_requests || !r->count || !r->level || !r->kind || !r->slice_size || !r->slice_level || !r->group ||
+        !out->dom_off) return fail(KQ_EINVAL, "null array in kq_tas_requests / kq_tas_result");
+    if (r->wl_off[0] != 0) return fail(KQ_EINVAL, "wl_off[0] must be 0");
+    for (int w = 0; w < nw; w++) if (r->wl_off[w + 1] < r->wl_off[w]) return fail(KQ_EINVAL, "wl_off not monotone");
     for (int i = 0; i < n; i++) if (r->count[i] < 0) return fail(KQ_EINVAL, "negative pod count");
     TK k{};
     k.T = T;
@@ -200,6 +205,7 @@ template <class Backend> struct TasT {
   int usage_apply(int n_dom, const int32_t* leaf, const int32_t* count, const int64_t* spr, int add) {
     if (!have_topo) return fail(KQ_EINVAL, "no topology");
     if (n_dom <= 0) return KQ_OK;
+    if (!leaf || !count || !spr) return fail(KQ_EINVAL, "null array");
     for (int i = 0; i < n_dom; i++) if (leaf[i] < 0 || leaf[i] >= T.n_leaves) return fail(KQ_EINVAL, "leaf out of range");
     const int32_t* dl = stage(bq[10], leaf, n_dom);
     const int32_t* dc = stage(bq[11], count, n_dom);
@@ -212,6 +218,7 @@ template <class Backend> struct TasT {
     if (!have_topo) return fail(KQ_EINVAL, "no topology");
     *out = 1;
     if (n_dom <= 0) return KQ_OK;
+    if (!leaf || !count || !spr) return fail(KQ_EINVAL, "null array");
     for (int i = 0; i < n_dom; i++) if (leaf[i] < 0 || leaf[i] >= T.n_leaves) { *out = 0; return KQ_OK; }  // domain not found (:438)
     const int32_t* dl = stage(bq[10], leaf, n_dom);
     const int32_t* dc = stage(bq[11], count, n_dom);
@@ -234,17 +241,22 @@ template <class Backend> struct TasT {
 // updateTASUsage :267 / Fits :433 : one thread per assigned domain
 KQ_DEV void t_usage_cell(const TTopo& T, int i, const int32_t* leaf, const int32_t* count, const int64_t* spr, int add) {
   for (int r = 0; r < T.R; r++) {
-    const int64_t v = spr[r] * (int64_t)count[i] + (r == T.pods ? count[i] : 0);
+    const int64_t v = (spr[r] > 0 ? spr[r] : 0) * (int64_t)count[i] + (r == T.pods ? count[i] : 0);  // KQ_TAS_REQ_ZERO adds nothing
     int64_t* cell = T.tas_usage + (size_t)leaf[i] * T.R + r;
     atomic_add_i64((long long*)cell, (long long)(add ? v : -v));
   }
 }
 KQ_DEV void t_fits_cell(const TTopo& T, int i, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t* flag) {
+  // CountIn (pkg/resources/requests.go:195-228): a resource that is PRESENT with quantity zero (KQ_TAS_REQ_ZERO in the dense
+  // vector) counts MaxInt32; an absent one (0) is not iterated; no resource at all gives 0.
   bool have = false; int32_t result = 0;
   for (int r = 0; r < T.R; r++) {
     if (spr[r] == 0) continue;
-    const int64_t rem = T.free_cap[(size_t)leaf[i] * T.R + r] - T.tas_usage[(size_t)leaf[i] * T.R + r];
-    const int32_t c = (int32_t)i64max(0, i64min(rem / spr[r], 0x7fffffff));
+    int32_t c = 0x7fffffff;
+    if (spr[r] > 0) {
+      const int64_t rem = T.free_cap[(size_t)leaf[i] * T.R + r] - T.tas_usage[(size_t)leaf[i] * T.R + r];
+      c = (int32_t)i64max(0, i64min(rem / spr[r], 0x7fffffff));
+    }
     if (!have || c < result) { result = c; have = true; }
   }
   if ((have ? result : 0) < count[i]) *flag = 0;

@@ -61,6 +61,20 @@ class Engine:
         d.kernel_ms, d.bytes = ms.value, by.value
         return d
 
+    def heads_put(self, heads: Heads, batch: int):
+        """kq_heads_put: make a batch of heads resident in HBM under a small caller-chosen id."""
+        self._check(self._lib.kq_heads_put(self._h, C.byref(heads.struct()), batch))
+
+    def run_resident(self, batch: int, out: Decisions, check: bool = True) -> int:
+        """kq_cycle_run_resident: one cycle over a resident batch (no host->device input traffic)."""
+        rc = self._lib.kq_cycle_run_resident(self._h, batch, C.byref(out.struct()))
+        if check:
+            self._check(rc)
+        return rc
+
+    def try_commit(self) -> int:
+        return self._lib.kq_cycle_commit(self._h, None)
+
     def commit(self) -> int:
         """kq_cycle_commit: fold the last cycle's admissions into the resident snapshot; returns how many."""
         n = C.c_int32()

@@ -62,6 +62,19 @@ class EmuEngine:
         assert rc == 0, (rc, lib().kqe_last_error(self.h))
         self.snap = snap
 
+    def heads_put(self, heads, batch):
+        rc = lib().kqe_heads_put(self.h, C.byref(heads.struct()), batch)
+        assert rc == 0, (rc, lib().kqe_last_error(self.h))
+
+    def run_resident(self, batch, out, check=True):
+        rc = lib().kqe_cycle_run_resident(self.h, batch, C.byref(out.struct()))
+        if check:
+            assert rc == 0, (rc, lib().kqe_last_error(self.h))
+        return rc
+
+    def try_commit(self):
+        return lib().kqe_cycle_commit(self.h, None)
+
     def run(self, heads, want_usage=False, tgt_cap=None):
         d = Decisions(heads, tgt_cap=tgt_cap)
         rc = lib().kqe_cycle_run(self.h, C.byref(heads.struct()), C.byref(d.struct()))
