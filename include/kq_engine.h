@@ -299,6 +299,7 @@ int  kq_snapshot_read_planes(kq_engine* e, int64_t* subtree_quota, int64_t* usag
  * even when the maintained sums would be exact. kq_debug_prof: 32 in-kernel segment counters (KQ_PROF builds). */
 int  kq_debug_read_usage_work(kq_engine* e, int64_t* usage_out);
 int  kq_debug_force_exact_drs(kq_engine* e, int on);
+int  kq_debug_disable_scan_search(kq_engine* e, int on);  /* classical victim searches walk candidate by candidate */
 int  kq_debug_prof(kq_engine* e, int64_t* out32, int reset);
 
 const char* kq_strerror(int code);

@@ -24,6 +24,11 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#ifdef KQ_HOST_EMU
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+#endif
 
 #include "../../include/kq_engine.h"
 #include "kq_prep.hpp"
@@ -49,6 +54,11 @@ KQ_DEV void atomic_add_i64(long long* p, long long v) { *p += v; }
 KQ_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 KQ_DEV int64_t atomic_cas_i64(int64_t* p, int64_t expect, int64_t v) { int64_t o = *p; if (o == expect) *p = v; return o; }
 KQ_DEV int64_t wsum_i64(int64_t v) { return v; }
+KQ_DEV int64_t wprefix_incl_i64(int64_t v) { return v; }
+KQ_DEV int wprefix_incl_i32(int v) { return v; }
+KQ_DEV int64_t wshfl_i64(int64_t v, int) { return v; }
+KQ_DEV int wshfl_i32(int v, int) { return v; }
+KQ_DEV int clz64(uint64_t m) { return __builtin_clzll(m); }
 static int g_emu_pipeline = 0;  // tests: emulate the helper waves of k_process prefetching one chunk ahead
 }  // namespace kq
 #else
@@ -90,6 +100,20 @@ KQ_DEV int64_t wsum_i64(int64_t v) {
   for (int o = 32; o > 0; o >>= 1) v += (int64_t)__shfl_xor((long long)v, o, 64);
   return v;
 }
+// inclusive prefix sums over the lanes of the wave (Hillis-Steele on the cross-lane network)
+KQ_DEV int64_t wprefix_incl_i64(int64_t v) {
+  const int lane = (int)(threadIdx.x & 63);
+  for (int o = 1; o < 64; o <<= 1) { const int64_t t = (int64_t)__shfl_up((long long)v, o, 64); if (lane >= o) v += t; }
+  return v;
+}
+KQ_DEV int wprefix_incl_i32(int v) {
+  const int lane = (int)(threadIdx.x & 63);
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+  return v;
+}
+KQ_DEV int64_t wshfl_i64(int64_t v, int src) { return (int64_t)__shfl((long long)v, src, 64); }
+KQ_DEV int wshfl_i32(int v, int src) { return __shfl(v, src, 64); }
+KQ_DEV int clz64(uint64_t m) { return __clzll((long long)m); }
 }  // namespace kq
 #endif
 
@@ -128,6 +152,13 @@ struct DSnap {
   const int32_t *child_cohort_off, *child_cohort, *child_cq_off, *child_cq, *depth;
   const int64_t* adm_rts;
   const uint32_t* adm_uid;
+  // scan-formulated classical victim search (kq_cs.hpp): static per-snapshot structures built by kq_prep.hpp
+  const AdmRec* adm_rec;        // [n_adm]
+  const CsEnt* frl[CS_LEVELS];  // level orders of the buckets (offsets = frb_off)
+  const int32_t* frbr;          // admitted row of every bucket entry
+  const uint64_t* frb_sig;      // [n_tree * nfr]
+  const uint8_t* cs_ok;         // [n_tree]
+  const int32_t* tree_depth;    // [n_tree]
 };
 
 struct DCfg {
@@ -136,6 +167,7 @@ struct DCfg {
   int n_fs, fs[2];           // fair-sharing preemption strategies (preemption.go:364-366)
   int fs_plain;              // all amounts small: per-node borrowed sums are exact in plain int64 (no saturation)
   int quota_check_strategy;
+  int cs_on;                 // classical victim searches may take the scan formulation (kq_cs.hpp)
   int dbg_variant;           // KQ_PROF builds only: timing experiments (KQ_DEBUG_VARIANT; results are wrong when non-zero)
   int64_t cycle;
 };
@@ -208,6 +240,8 @@ struct DScratch {
   int64_t *bu_sum, *bs_sum;  // [N * nR]
   int32_t *bu_pos, *bs_pos;  // [N]
   int32_t max_tree_nodes, max_tree_cqs, max_tree_rows, slot_cap, tgt_cap;
+  unsigned char* cs;  // [slots][cs_bytes] arrays of a scan-formulated search when they do not fit the workgroup's LDS
+  int64_t cs_bytes;
 };
 
 struct K {  // everything a kernel needs
@@ -501,6 +535,12 @@ struct Wave {
   int n_pre;                      // rows preempted in this tree so far this cycle
   uint64_t broken[4];             // column bitmap (nfr <= 256; beyond that every column counts as broken)
   int mono_break;                 // usage went DOWN since the leader last looked: "did not fit when fetched" flags are void
+  // scan-formulated classical search (kq_cs.hpp): LDS region for its arrays (null: use DScratch::cs) and the constants of the
+  // preemptor's path per (slot, level): subtree quota, local quota, borrowing limit, usage at the start / at the stopping time
+  unsigned char* cs_lds; int cs_lds_bytes;
+  int64_t cs_sq[CS_NS][CS_LEVELS + 1], cs_lq[CS_NS][CS_LEVELS + 1], cs_bl[CS_NS][CS_LEVELS + 1], cs_u0[CS_NS][CS_LEVELS + 1], cs_uf[CS_NS][CS_LEVELS + 1];
+  int64_t cs_nom[CS_NS];
+  int32_t cs_pl[CS_LEVELS + 1];   // tree-local ids of the path nodes
 };
 KQ_DEV void mark_broken(Wave& w, int fr) {
   if (fr < 256) atomic_or_u64(&w.broken[fr >> 6], 1ull << (fr & 63));
@@ -520,6 +560,13 @@ KQ_DEV bool np_exact_mode(const Wave& w) { return w.np_broken && w.n_pre > 0; }
 #define KQ_TS(k, id) do {} while (0)
 #endif
 
+#ifdef KQ_HOST_EMU
+static long long g_cs[32];
+#define CSTAT(i, v) (g_cs[i] += (v))
+static int g_cs_check = 0, g_cs_force_off = 0;  // tests: run every scan-formulated search a second time as a walk and compare
+#else
+#define CSTAT(i, v) do {} while (0)
+#endif
 KQ_DEV void set_error(const K& k, int code) {
   if (lane_id() == 0 && *k.O.error == 0) *k.O.error = code;
 }
@@ -699,12 +746,16 @@ KQ_DEV bool candidate_valid(const Search& s, int row, int variant, bool borrow) 
   return true;
 }
 
+}  // namespace kq
+#include "kq_cs.hpp"
+namespace kq {
 // Runs the classical search for the slots prepared in w (s_fr/s_qty/s_inu/s_need).
 // On return w->ntgt targets are in s.trow/s.treason and the private state has exactly those removed.
 KQ_DEV void classical_search(Search& s) {
   const K& k = *s.k; Wave& w = *s.w; const DSnap& S = k.S;
   const int lane = lane_id();
   w.ntgt = 0;
+  CSTAT(0, 1); if (s.removed) CSTAT(10, 1);
   bool same_on = KQ_POL_WITHIN_CQ(w.pol) != KQ_POLICY_NEVER;
   bool other_on = w.plen > 1 && KQ_POL_RECLAIM(w.pol) != KQ_POLICY_NEVER;
   if (!same_on && !other_on) return;
@@ -713,11 +764,6 @@ KQ_DEV void classical_search(Search& s) {
   s.nrows = S.tree_row_off[s.tree + 1] - s.row0;
   if (s.nrows == 0) return;
   const int n0 = S.tree_node_off[s.tree], nn = S.tree_node_off[s.tree + 1] - n0;
-  // private copy of the tree's usage for the slots
-  for (int i = lane; i < nn * w.ns; i += WAVE) {
-    int ln = i / w.ns, u = i % w.ns;
-    s.W[i] = s.usage[ix(S, S.tree_nodes[n0 + ln], w.s_fr[u])];
-  }
   // hasHierarchicalAdvantage per ancestor level (hierarchical_preemption.go:149-175), one lane per slot
   {
     bool adv;
@@ -776,6 +822,47 @@ KQ_DEV void classical_search(Search& s) {
     if (lane == 0) w.bytes += tot;
   }
   wsync();
+#ifdef KQ_HOST_EMU
+  if (g_cs_check && !g_cs_force_off) {
+    const int64_t b0 = w.bytes;
+    if (cs_run(s, same_on, other_on)) {
+      const int nt1 = w.ntgt; const int64_t b1 = w.bytes;
+      std::vector<int> t1(s.trow, s.trow + nt1);
+      std::sort(t1.begin(), t1.end());
+      std::vector<int64_t> pw;
+      for (int l = 0; l < w.plen; l++) for (int u = 0; u < w.ns; u++) pw.push_back(s.W[(size_t)S.node_local[w.path[l]] * w.ns + u]);
+      g_cs_force_off = 1; w.bytes = b0;
+      cs_run_walk_again:
+      ;
+      // fall through to the walk below, compare at its end through the recursion-free trick: run it via a nested call
+      Search s2 = s;
+      w.bytes = b0 - 0;  // setup bytes are already inside b0
+      g_cs_force_off = 2;  // nested marker
+      classical_search(s2);
+      g_cs_force_off = 0;
+      std::vector<int> t2(s2.trow, s2.trow + w.ntgt);
+      std::sort(t2.begin(), t2.end());
+      bool same = nt1 == w.ntgt && t1 == t2;
+      if (same && nt1 > 0) { int q = 0; for (int l = 0; l < w.plen; l++) for (int u = 0; u < w.ns; u++) if (pw[q++] != s.W[(size_t)S.node_local[w.path[l]] * w.ns + u]) same = false; }
+      if (!same) {
+        CSTAT(22, 1);
+        fprintf(stderr, "CS MISMATCH head %d cq %d ns %d plen %d: scan ntgt %d walk ntgt %d\n", w.h, w.cq, w.ns, w.plen, nt1, w.ntgt);
+        fprintf(stderr, "  scan:"); for (int x : t1) fprintf(stderr, " %d", x); fprintf(stderr, "\n  walk:"); for (int x : t2) fprintf(stderr, " %d", x); fprintf(stderr, "\n");
+      }
+      (void)b1;
+      return;
+    }
+  }
+  if (g_cs_force_off != 0) { /* walk */ } else
+#endif
+  if (cs_run(s, same_on, other_on)) return;  // the same search as segmented scans (kq_cs.hpp); false: outside its preconditions
+  CSTAT(21, 1);
+  // private copy of the tree's usage for the slots
+  for (int i = lane; i < nn * w.ns; i += WAVE) {
+    int ln = i / w.ns, u = i % w.ns;
+    s.W[i] = s.usage[ix(S, S.tree_nodes[n0 + ln], w.s_fr[u])];
+  }
+  wsync();
   // candidate positions: the rows that use a flavor-resource needing preemption (WorkloadUsesResources), rank order
   const int32_t* positions;
   int M = 0;
@@ -830,6 +917,7 @@ KQ_DEV void classical_search(Search& s) {
     for (int p = 0; p < 6; p++) cnt[p] += popc64(wballot(cb != 0 && ((cb - 1) & 7) == p));
   }
   wsync();
+  CSTAT(1, M); CSTAT(2, cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4] + cnt[5]); CSTAT(9, w.ns);
   bool no_hier = cnt[0] + cnt[3] == 0, no_other = no_hier && (cnt[1] + cnt[4] == 0);
   if (cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4] + cnt[5] == 0) return;
   bool forbidden = KQ_POL_BORROW_WITHIN(w.pol) == 0;
@@ -847,6 +935,7 @@ KQ_DEV void classical_search(Search& s) {
   for (int at = 0; at < nattempt; at++) {
     bool borrowing = attempts[at];
     int nt = 0;
+    CSTAT(3, 1);
     for (int p = 0; p < 6; p++) {
       if (cnt[p] == 0) continue;
       for (int base = 0; base < M; base += WAVE) {
@@ -859,7 +948,9 @@ KQ_DEV void classical_search(Search& s) {
           int pos = base + b;
           int row = S.tree_rows[s.row0 + positions[pos]];
           int variant = s.cls[pos] >> 3;
+          CSTAT(4, 1);
           if (!candidate_valid(s, row, variant, borrowing)) continue;
+          CSTAT(5, 1);
           w_apply_row(s, row, false);
           if (nt >= k.X.tgt_cap) { set_error(k, KQ_ECAPACITY); w.ntgt = 0; return; }
           if (lane == 0) { s.trow[nt] = row; s.treason[nt] = (uint8_t)variant_reason(variant); }
@@ -879,6 +970,7 @@ KQ_DEV void classical_search(Search& s) {
               }
             }
             w.ntgt = nt;
+            CSTAT(6, 1); CSTAT(7, nt);
             // the reference now re-adds the targets (restoreSnapshot :356); the private copy is simply
             // dropped here, but those writes are part of the algorithm's traffic
             if (lane == 0)
@@ -1092,6 +1184,7 @@ KQ_DEV void f_rescan(const Search& s, int i, uint8_t flag) {
 // PopWorkload (ordering.go:84-90): the popped row's flag becomes `newflag`
 KQ_DEV int f_pop(const Search& s, int c, uint8_t flag, uint8_t newflag) {
   const DSnap& S = s.k->S;
+  CSTAT(13, 1);
   int i = S.cq_local[c];
   int pos = (int)(s.qhead[i] & 0x7fffffffu);
   int row = S.tree_rows[s.row0 + pos];
@@ -1117,10 +1210,12 @@ KQ_DEV DRSv f_drs_uniform(const Search& s, int node) {
 KQ_DEV int f_next_target(const Search& s, int root) {
   const K& k = *s.k; Wave& w = *s.w; const DSnap& S = k.S;
   const int lane = lane_id();
+  CSTAT(11, 1);
   int cohort = root;
   int64_t lb = 0;
   int result = -1;
   for (;;) {
+    CSTAT(12, 1);
     int best_cq = -1; DRSv best = drs_negative();
     const int kc0 = S.child_cq_off[cohort - S.nq], nkc = S.child_cq_off[cohort - S.nq + 1] - kc0;
     for (int base = 0; base < nkc; base += WAVE) {
@@ -1284,6 +1379,7 @@ KQ_DEV void fair_search(Search& s) {
     if (lane == 0) w.bytes += tot;
   }
   wsync();
+  CSTAT(14, 1); CSTAT(15, ncand);
   if (ncand == 0) return;
   f_apply_preemptor(s, true);  // SimulateUsageAddition :557
   int nt = 0;
@@ -1370,6 +1466,7 @@ KQ_DEV void fair_search(Search& s) {
     w.ntgt = 0;
     return;
   }
+  CSTAT(16, 1); CSTAT(17, nt);
   // fillBackWorkloads :341-354 with allowBorrowing = true
   for (int t = nt - 2; t >= 0; t--) {
     int r = s.trow[t];

@@ -29,9 +29,12 @@ using namespace kq;
 // Kernels take the argument block K by pointer (it lives in HBM and is read through the scalar cache):
 // passing ~700 B by value makes the compiler spill it to scratch as soon as any non-inlined device
 // function takes a reference to it, which put scratch loads into the serial core of k_process.
-__global__ __launch_bounds__(64) void k_nominate(const K* __restrict__ kp, int slots) {
+__global__ __launch_bounds__(64) void k_nominate(const K* __restrict__ kp, int slots, unsigned lds_bytes) {
   const K& k = *kp;
   __shared__ Wave w;
+  extern __shared__ __align__(16) unsigned char dyn_lds[];
+  if (threadIdx.x == 0) { w.cs_lds = lds_bytes ? dyn_lds : nullptr; w.cs_lds_bytes = (int)lds_bytes; }
+  __syncthreads();
   const int slot = blockIdx.x;
   for (int h = slot; h < k.H.n; h += slots) nominate_head(k, w, h, slot);
 }
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(PROCESS_THREADS) void k_process(const K* __restrict
   const K& k = *kp;
   __shared__ Wave w;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
+  if (threadIdx.x == 0) { w.cs_lds = nullptr; w.cs_lds_bytes = 0; }  // searches inside k_process use the HBM spill space
   process_tree(k, w, blockIdx.x, blockIdx.x, (int64_t*)dyn_lds, lds_bytes, (int)threadIdx.x, PROCESS_THREADS);
 }
 
@@ -102,6 +106,7 @@ __global__ __launch_bounds__(FAIR_THREADS) void k_process_fair(const K* __restri
   const K& k = *kp;
   __shared__ Wave w;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
+  if (threadIdx.x == 0) { w.cs_lds = nullptr; w.cs_lds_bytes = 0; }
   process_tree_fair(k, w, blockIdx.x, blockIdx.x, (int64_t*)dyn_lds, lds_bytes, (int)threadIdx.x, FAIR_THREADS);
 }
 // global iteration positions from the per-tree sequences (kq::fair_rank): 2-D grid like k_order
@@ -324,8 +329,14 @@ struct HipBackend {
     hipLaunchKernelGGL(k_fs_pos, dim3((k.S.N + 255) / 256), dim3(256), 0, stream, d);
     chk(hipGetLastError(), "k_fs_sums");
   }
-  void launch_nominate(const K& k, int slots) {
-    hipLaunchKernelGGL(k_nominate, dim3(slots), dim3(64), 0, stream, put_k(k, 0), slots);
+  size_t lds_attr_nom = 0;
+  void launch_nominate(const K& k, int slots, size_t lds) {
+    if (lds > 64 * 1024) lds = 0;  // beyond that the searches use their HBM spill space and occupancy stays up
+    if (lds > 48 * 1024 && lds != lds_attr_nom) {
+      chk(hipFuncSetAttribute((const void*)k_nominate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
+      lds_attr_nom = lds;
+    }
+    hipLaunchKernelGGL(k_nominate, dim3(slots), dim3(64), lds, stream, put_k(k, 0), slots, (unsigned)lds);
     chk(hipGetLastError(), "k_nominate");
   }
   void launch_records(const K& k) {
@@ -510,6 +521,7 @@ const char* kq_tas_last_error(kq_tas* t) { return t ? t->e.last_error.c_str() : 
 
 // profiling hook (KQ_PROF builds): 32 segment cycle counters accumulated since the last reset
 // tests: take the saturation-safe DRS loops even when the incremental sums would be exact
+int kq_debug_disable_scan_search(kq_engine* en, int on) { if (!en) return KQ_EINVAL; en->e.cs_disable = on != 0; return KQ_OK; }
 int kq_debug_force_exact_drs(kq_engine* en, int on) { if (!en) return KQ_EINVAL; en->e.force_exact_drs = on != 0; return KQ_OK; }
 int kq_debug_prof(kq_engine* en, int64_t* out, int reset) {
   if (!en) return KQ_EINVAL;

@@ -35,6 +35,8 @@ template <class B> struct EngineT {
   std::vector<Buf*> all_bufs;
   Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_grec, b_cqd, b_fs[20];
   bool force_exact_drs = false;  // tests: take the saturation-safe DRS loops even when the sums would be exact
+  bool cs_disable = false;       // tests: classical victim searches always take the candidate-by-candidate walk
+  Buf b_cs;
   struct HeadBatch { Buf hb[1]; DHeads H{}; int n = 0; size_t nps = 0; int slot_cap = 1; int64_t cycle = 0; bool valid = false; bool plain = true; };
   std::vector<HeadBatch> batches;  // [0] = transient batch of kq_cycle_run, [1+b] = resident batch b
   Buf ob[24];  // output arrays
@@ -74,7 +76,7 @@ template <class B> struct EngineT {
     free_snapshot();
     if (hstage) be.free_host(hstage);
     if (hup) be.free_host(hup);
-    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb, &b_grec, &b_cqd}) if (b->p) be.free(b->p);
+    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb, &b_grec, &b_cqd, &b_cs}) if (b->p) be.free(b->p);
     for (auto& b : b_fs) if (b.p) be.free(b.p);
     for (auto& c : ring) for (Buf* b : {&c.cq, &c.use_n, &c.use_fr, &c.use_qty}) if (b->p) be.free(b->p);
     for (auto& hbch : batches) for (auto& b : hbch.hb) if (b.p) be.free(b.p);
@@ -148,6 +150,12 @@ template <class B> struct EngineT {
     S.depth = upload(prep.depth.data(), prep.depth.size());
     S.adm_rts = upload(s->adm_reserve_ts, prep.n_adm);
     S.adm_uid = upload(s->adm_uid_rank, prep.n_adm);
+    S.adm_rec = upload(prep.adm_rec.data(), prep.adm_rec.size());
+    for (int l = 0; l < CS_LEVELS; l++) S.frl[l] = upload(prep.frl[l].data(), prep.frl[l].size());
+    S.frbr = upload(prep.frbr.data(), prep.frbr.size());
+    S.frb_sig = upload(prep.frb_sig.data(), prep.frb_sig.size());
+    S.cs_ok = upload(prep.cs_ok.data(), prep.cs_ok.size());
+    S.tree_depth = upload(prep.tree_depth.data(), prep.tree_depth.size());
     rc = be.sync();
     if (rc != KQ_OK) return fail(rc, be.error());
     have_snapshot = true;
@@ -358,6 +366,8 @@ template <class B> struct EngineT {
     { const char* dv = getenv("KQ_DEBUG_VARIANT"); k.C.dbg_variant = dv ? atoi(dv) : 0; }
 #endif
     k.C.fs_plain = (prep.fs_plain && hbch.plain && prep.nR <= KQ_MAXR && !force_exact_drs) ? 1 : 0;
+    // scan-formulated classical search: usage and admitted quantities must be plain (its prefix sums are ordinary additions)
+    k.C.cs_on = (!cfg.fair_sharing && prep.any_preemption && prep.fs_plain && !cs_disable) ? 1 : 0;
     k.C.gates = cfg.gates; k.C.fair_sharing = cfg.fair_sharing; k.C.quota_check_strategy = cfg.quota_check_strategy; k.C.cycle = hbch.cycle;
     k.H = hbch.H;
     // outputs
@@ -405,6 +415,11 @@ template <class B> struct EngineT {
     X.nom = grow<int32_t>(b_nom, (size_t)slots * KQ_MAXPS * nR);
     X.cand = grow<int32_t>(b_cand, (size_t)slots * X.max_tree_rows);
     X.mark = (uint64_t*)grow<int64_t>(b_mark, (size_t)slots * ((X.max_tree_rows + 63) / 64));
+    X.cs = nullptr; X.cs_bytes = 0;
+    if (k.C.cs_on) {  // spill space for the arrays of a search that do not fit the workgroup's LDS (worst case: CS_NS slots)
+      X.cs_bytes = (int64_t)((cs_bytes(CS_NS, prep.cs_max_bucket, prep.max_tree_nodes) + 255) & ~(size_t)255);
+      X.cs = grow<unsigned char>(b_cs, (size_t)slots * (size_t)X.cs_bytes);
+    }
     k.cq_rm_bytes = grow<int32_t>(b_rmb, std::max(prep.nq, 1));
     prep_fill(k.cq_rm_bytes, (size_t)std::max(prep.nq, 1), 0);
     if (cfg.fair_sharing) {
@@ -444,7 +459,9 @@ template <class B> struct EngineT {
       be.d2d(X.bs_sum, X.bu_sum, (size_t)prep.N * nR * sizeof(int64_t));
       be.d2d(X.bs_pos, X.bu_pos, (size_t)prep.N * sizeof(int32_t));
     }
-    be.launch_nominate(k, slots_nom);
+    // LDS of a nominate workgroup: the arrays of a one-slot search (SimulatePreemption, 37 of the 38 searches of a cfg 4 head)
+    const size_t nom_lds = k.C.cs_on ? cs_bytes(1, prep.cs_max_bucket, prep.max_tree_nodes) : 0;
+    be.launch_nominate(k, slots_nom, nom_lds);
     be.launch_records(k);  // entry records (static part) for k_process; charged to the nominate interval
     be.timer_mark(1);
     if (!cfg.fair_sharing) be.launch_order(k, order_idx, rank);

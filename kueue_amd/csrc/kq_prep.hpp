@@ -23,6 +23,27 @@ constexpr int KQ_MAXU = 32;     // max (flavor,resource) entries in one assignme
 constexpr int KQ_MAXPS = 8;     // max podsets per workload handled on device
 constexpr int KQ_MAXR = 8;      // max resources for the incremental (sum-based) DRS; more fall back to the exact loops
 
+// ---- static structures of the scan-formulated classical victim search (kq_cs.hpp) ----------------------------------
+// One record per admitted row: its usage entries folded per flavor-resource (<= CS_RFR distinct ones), the policy operands and
+// the algorithmic cost of one snapshot.RemoveWorkload / AddWorkload of the row.
+constexpr int CS_NS = 4;       // flavor-resource slots of one search on the fast path
+constexpr int CS_RFR = 4;      // distinct flavor-resources of a row on the fast path
+constexpr int CS_LEVELS = 3;   // candidate ClusterQueues may sit up to this many levels below the LCA with the preemptor's path
+struct alignas(16) AdmRec {
+  int64_t qty[CS_RFR];
+  int32_t fr[CS_RFR];          // -1 = unused
+  int64_t prio, qts;
+  int32_t cq;
+  int32_t rowbytes;            // 16 * (depth + 1) * usage entries of the row (what the oracle charges per Remove/AddWorkload)
+  uint32_t flags;              // bit0 evicted
+  int32_t pad;
+};
+// One entry of a (tree, flavor-resource) bucket in "level order" d (d = 1 .. CS_LEVELS, the depth below the root): grouped by the
+// node of depth d on the way from the row's ClusterQueue to the root (`node`, tree-local id; the ClusterQueue itself when it sits
+// at depth d; -1 when it is shallower), evicted rows first, then candidate rank — i.e. the order in which the reference's
+// candidate loop meets the rows of one subtree. jd = index of the row inside the bucket's rank order | depth of its ClusterQueue << 24.
+struct alignas(16) CsEnt { int32_t jd, node, row, gnode; };  // gnode = global node id of `node` (-1 if none)
+
 struct Prep {
   int nq = 0, nc = 0, N = 0, nF = 0, nR = 0, nfr = 0, n_adm = 0, n_rg = 0;
   std::vector<int32_t> depth, root, tree_of, node_local, node_height;
@@ -45,6 +66,14 @@ struct Prep {
   std::vector<int32_t> frcount;                    // [N] flavor-resources with a SubtreeQuota entry (DRS iterates those)
   std::vector<int32_t> h_parent;                   // host copies kept for build_fair after a device derive
   std::vector<int64_t> h_ll, h_bl;
+  std::vector<AdmRec> adm_rec;                     // [n_adm]
+  std::vector<CsEnt> frl[CS_LEVELS];               // level orders of every bucket (same offsets as frb)
+  std::vector<uint64_t> frb_sig;                   // [n_tree * nfr] hash of the bucket's row list (equal sets <=> equal buckets)
+  std::vector<uint8_t> cs_ok;                      // [n_tree] the tree's shape fits the fast search
+  std::vector<int32_t> frbr;                       // admitted row of every bucket entry (same layout as frb)
+  std::vector<int32_t> tree_depth;                 // [n_tree] deepest ClusterQueue (0 = no cohort)
+  bool any_preemption = false;                     // some ClusterQueue may preempt (within its queue or by reclaim)
+  int cs_max_bucket = 0;
   bool fs_plain_adm = true;
   bool usage_consistent = true;                    // cohort usage == sum over children of max(0, usage - localQuota) (resource_node.go:217-230)
   bool fs_plain = true;                            // every finite amount is small enough that DRS sums cannot saturate
@@ -226,6 +255,76 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
   p.rank_pos.assign(p.n_adm, 0);
   for (int t = 0; t < p.n_tree; t++)
     for (int i = p.tree_row_off[t]; i < p.tree_row_off[t + 1]; i++) p.rank_pos[p.tree_rows[i]] = i - p.tree_row_off[t];
+  // ---- scan-formulated classical search: row records, level orders of the buckets, bucket signatures ----
+  {
+    p.cs_ok.assign(p.n_tree, 1);
+    p.tree_depth.assign(p.n_tree, 0);
+    for (int c = 0; c < nq; c++) p.tree_depth[p.tree_of[c]] = std::max(p.tree_depth[p.tree_of[c]], (int32_t)p.depth[c]);
+    p.any_preemption = false;
+    for (int c = 0; c < nq; c++) if (KQ_POL_WITHIN_CQ(s->cq_policy[c]) != KQ_POLICY_NEVER || KQ_POL_RECLAIM(s->cq_policy[c]) != KQ_POLICY_NEVER) p.any_preemption = true;
+    p.frbr.assign(p.frb.size(), 0);
+    for (int t = 0; t < p.n_tree; t++)
+      for (int i = p.frb_off[(size_t)t * p.nfr]; i < p.frb_off[(size_t)(t + 1) * p.nfr]; i++) p.frbr[i] = p.tree_rows[p.tree_row_off[t] + p.frb[i]];
+    p.adm_rec.assign(p.n_adm, AdmRec{});
+    for (int c = 0; c < nq; c++) if (p.depth[c] > CS_LEVELS) p.cs_ok[p.tree_of[c]] = 0;
+    for (int r = 0; r < p.n_adm; r++) {
+      AdmRec& a = p.adm_rec[r];
+      for (int e = 0; e < CS_RFR; e++) { a.fr[e] = -1; a.qty[e] = 0; }
+      const int c = p.adm_cq[r];
+      a.prio = s->adm_priority[r]; a.qts = s->adm_queue_ts[r]; a.cq = c; a.flags = (s->adm_flags[r] & KQ_ADM_EVICTED) ? 1u : 0u;
+      a.rowbytes = 16 * (p.depth[c] + 1) * (s->adm_use_off[r + 1] - s->adm_use_off[r]);
+      int nf = 0;
+      for (int e = s->adm_use_off[r]; e < s->adm_use_off[r + 1]; e++) {
+        const int fr = s->adm_use_fr[e];
+        int k = 0;
+        while (k < nf && a.fr[k] != fr) k++;
+        if (k == nf) { if (nf == CS_RFR) { p.cs_ok[p.tree_of[c]] = 0; break; } a.fr[nf++] = fr; }
+        // plain sum (entries of a repeated flavor-resource are removed one after another by the reference; on plain amounts that
+        // is the removal of their sum). Non-plain rows switch the fast search off through fs_plain_adm.
+        a.qty[k] = (int64_t)((uint64_t)a.qty[k] + (uint64_t)s->adm_use_qty[e]);
+      }
+    }
+    p.frb_sig.assign((size_t)p.n_tree * p.nfr, 0);
+    p.cs_max_bucket = 0;
+    for (int l = 0; l < CS_LEVELS; l++) p.frl[l].assign(p.frb.size(), CsEnt{0, -1, 0, -1});
+    // (M <= 0xfff0 is checked by the search; the depth shares the word with j)
+    std::vector<int32_t> anc;  // scratch: ancestor at height l of the row's ClusterQueue
+    for (int t = 0; t < p.n_tree; t++)
+      for (int fr = 0; fr < p.nfr; fr++) {
+        const size_t b = (size_t)t * p.nfr + fr;
+        const int o = p.frb_off[b], M = p.frb_off[b + 1] - o;
+        p.cs_max_bucket = std::max(p.cs_max_bucket, M);
+        uint64_t sig = 1469598103934665603ull ^ (uint64_t)M;
+        for (int j = 0; j < M; j++) { sig ^= (uint64_t)(uint32_t)p.tree_rows[p.tree_row_off[t] + p.frb[o + j]]; sig *= 1099511628211ull; }
+        p.frb_sig[b] = sig;
+        for (int l = 0; l < CS_LEVELS; l++) {
+          anc.assign(M, -1);
+          for (int j = 0; j < M; j++) {
+            const int row = p.tree_rows[p.tree_row_off[t] + p.frb[o + j]];
+            int n = p.adm_cq[row];
+            const int dd = l + 1;  // level order l holds depth l + 1
+            if (p.depth[n] < dd) n = -1;
+            else for (int h = p.depth[n]; h > dd; h--) n = s->parent[n];
+            anc[j] = n;
+          }
+          std::vector<int32_t> idx(M);
+          for (int j = 0; j < M; j++) idx[j] = j;
+          std::stable_sort(idx.begin(), idx.end(), [&](int a, int bb) {
+            const int na = anc[a] < 0 ? INT32_MAX : anc[a], nb = anc[bb] < 0 ? INT32_MAX : anc[bb];
+            if (na != nb) return na < nb;
+            const int ra = p.tree_rows[p.tree_row_off[t] + p.frb[o + a]], rb = p.tree_rows[p.tree_row_off[t] + p.frb[o + bb]];
+            const int ea = (s->adm_flags[ra] & KQ_ADM_EVICTED) ? 0 : 1, eb = (s->adm_flags[rb] & KQ_ADM_EVICTED) ? 0 : 1;
+            if (ea != eb) return ea < eb;
+            return a < bb;
+          });
+          for (int q = 0; q < M; q++) {
+            const int j = idx[q];
+            const int row = p.tree_rows[p.tree_row_off[t] + p.frb[o + j]];
+            p.frl[l][o + q] = CsEnt{j | (p.depth[p.adm_cq[row]] << 24), anc[j] >= 0 ? p.node_local[anc[j]] : -1, row, anc[j]};
+          }
+        }
+      }
+  }
   for (int t = 0; t < p.n_tree; t++) {
     p.max_tree_nodes = std::max(p.max_tree_nodes, p.tree_node_off[t + 1] - p.tree_node_off[t]);
     p.max_tree_cqs = std::max(p.max_tree_cqs, p.tree_cq_off[t + 1] - p.tree_cq_off[t]);

@@ -61,9 +61,12 @@ struct EmuBackend {
     for (int n = 0; n < k.S.N; n++) for (int r = 0; r < k.S.nR; r++) fs_sums_cell(k, n, r);
     for (int n = 0; n < k.S.N; n++) fs_pos_node(k, n);
   }
-  void launch_nominate(const K& k, int slots) {
+  void launch_nominate(const K& k, int slots, size_t lds) {
+    std::vector<int64_t> region(lds / 8 + 8);
     for (int slot = 0; slot < slots; slot++) {
       Wave w{};
+      // alternate between "LDS" and the spill space so that both placements of the search arrays are exercised
+      if (lds && ((slot + rot) & 1)) { w.cs_lds = (unsigned char*)region.data(); w.cs_lds_bytes = (int)lds; }
       for (int h = slot; h < k.H.n; h += slots) nominate_head(k, w, h, slot);
     }
   }
@@ -121,6 +124,7 @@ int kqe_tas_count_in(int32_t R, const int64_t* req, const int64_t* cap, int32_t*
   *out = kq::t_count_in(k, req, cap);
   return KQ_OK;
 }
+void kqe_cstat(long long* out) { for (int i = 0; i < 32; i++) { out[i] = kq::g_cs[i]; kq::g_cs[i] = 0; } }
 int kqe_engine_create(const kq_config* cfg, void** out) { auto* e = new EmuEngine(); e->cfg = *cfg; *out = e; return KQ_OK; }
 void kqe_engine_destroy(void* e) { delete (EmuEngine*)e; }
 int kqe_snapshot_put(void* e, const kq_snapshot* s) { return ((EmuEngine*)e)->snapshot_put(s); }
@@ -139,6 +143,8 @@ int kqe_cycle_commit(void* e, int32_t* n) { return ((EmuEngine*)e)->cycle_commit
 int kqe_cycle_release(void* e, int age) { return ((EmuEngine*)e)->cycle_release(age); }
 int kqe_snapshot_derive(void* e) { return ((EmuEngine*)e)->snapshot_derive(); }
 int kqe_read_planes(void* e, int64_t* sq, int64_t* us, uint8_t* fl) { return ((EmuEngine*)e)->read_planes(sq, us, fl); }
+void kqe_cs_check(int on) { kq::g_cs_check = on; }
+void kqe_disable_scan_search(void* e, int on) { ((EmuEngine*)e)->cs_disable = on != 0; }
 void kqe_force_exact_drs(void* e, int on) { ((EmuEngine*)e)->force_exact_drs = on != 0; }
 int kqe_cycle_run(void* e, const kq_heads* h, kq_decisions* out) { return ((EmuEngine*)e)->cycle_run(h, out); }
 int kqe_heads_put(void* e, const kq_heads* h, int32_t batch) { return batch < 0 ? KQ_EINVAL : ((EmuEngine*)e)->heads_put(h, batch + 1); }

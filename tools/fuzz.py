@@ -101,5 +101,10 @@ def loop(seed):
 if __name__ == "__main__":
     mode, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     fn = {"cycle": cycle, "tight": lambda s: cycle(s, True), "tas": tas, "loop": loop}[mode]
+    import ctypes as C
+    if mode in ("cycle", "tight"):
+        kqe.lib().kqe_cs_check(1)  # every scan-formulated classical search is re-run as a candidate-by-candidate walk and compared
     bad = [s for s in range(lo, hi) if not fn(s)]
-    print(mode, "seeds", lo, hi, "differ:", bad)
+    st = (C.c_longlong * 32)()
+    kqe.lib().kqe_cstat(st)
+    print(mode, "seeds", lo, hi, "differ:", bad, "| classical searches: scan", st[20], "walk-only", st[21] - st[20], "scan != walk", st[22])
