@@ -29,11 +29,13 @@ namespace kq {
 
 struct CsCtx {
   const K* k; Wave* w; Search* s;
-  int ns, M, Mp, nn, n0, boff, Mt, plen, levels;
-  int64_t* W;        // [ns][nn]  private usage, slot-major
-  int64_t* dB;       // [ns][Mp]  what the candidate's removal takes out of the node one level up (level by level, in place)
+  int ns, M, Mp, nn, n0, boff, Mt, plen, levels, ufirst;
+  int64_t* W;            // [ns][nn]  private usage, slot-major
+  int64_t* dB[CS_NS];    // [Mp] per slot: what the candidate's removal takes out of the node one level up (level by level, in place)
+  int64_t *sqT, *lqT;    // [ns][nn]  SubtreeQuota / localQuota of every node of the tree for the slots; null: read the planes
   uint16_t *tord, *tinv, *rb;  // [Mp] candidate at time t / time of candidate j (0xffff = never) / AdmRec::rowbytes
   uint8_t *alive, *cls, *att;  // [Mp] still removable / class byte (classical_search) / path level the candidate's branch hangs off
+  uint8_t* cqi;          // [tree ClusterQueues] Search::cqinfo
   uint32_t needm, inum;
 };
 
@@ -42,10 +44,20 @@ static inline
 #else
 __host__ __device__ inline
 #endif
-size_t cs_bytes(int ns, int M, int nn) {
+size_t cs_bytes(int ns, int M, int nn, int nqs, bool tables) {  // everything a search with ns slots allocates
   const size_t Mp = ((size_t)M + 63) & ~(size_t)63;
-  return (size_t)ns * nn * 8 + (size_t)ns * Mp * 8 + Mp * 2 * 3 + Mp * 3 + 64;
+  return (size_t)ns * nn * 8 * (tables ? 3 : 1) + (size_t)ns * Mp * 8 + Mp * 2 * 3 + Mp * 3 + (((size_t)nqs + 15) & ~(size_t)15) + 512;
 }
+// Arrays are placed in the workgroup's LDS region in order of heat while they fit, the rest in the wave slot's HBM spill space:
+// the byte arrays and the private usage first, then the quota tables, then the per-slot quantity arrays.
+struct CsCarve {
+  unsigned char *a, *ae, *b;  // LDS cursor / end, spill cursor
+  KQ_MDEV void* take(size_t bytes, bool* in_lds = nullptr) {
+    bytes = (bytes + 15) & ~(size_t)15;
+    if (a && a + bytes <= ae) { void* p = a; a += bytes; if (in_lds) *in_lds = true; return p; }
+    void* p = b; b += bytes; if (in_lds) *in_lds = false; return p;
+  }
+};
 KQ_DEV int64_t cs_rec_qty(const AdmRec& r, int fr) {
   int64_t q = 0;
   #pragma unroll
@@ -91,10 +103,13 @@ KQ_DEV void cs_level_pass(CsCtx& c, int dd, int limit_t, bool finalize) {
   int64_t carry[CS_NS];
   #pragma unroll
   for (int u = 0; u < CS_NS; u++) carry[u] = 0;
+  // the entries are static and read front to back: the next chunk's load is in flight while this one is processed
+  CsEnt e_next = ents[lane < M ? lane : M - 1];
   for (int base = 0; base < M; base += WAVE) {
     const int q = base + lane;
     const bool in = q < M;
-    CsEnt e = ents[in ? q : M - 1];
+    const CsEnt e = e_next;
+    { const int qn = q + WAVE; e_next = ents[qn < M ? qn : M - 1]; }
     const int node_prev = wshfl_i32(e.node, lane > 0 ? lane - 1 : 0);
     const bool head = in && (lane == 0 ? e.node != carry_node : e.node != node_prev);
     const uint64_t H = wballot(head);
@@ -108,10 +123,10 @@ KQ_DEV void cs_level_pass(CsCtx& c, int dd, int limit_t, bool finalize) {
     int64_t d[CS_NS];
     {
       AdmRec r{};
-      if (enters) r = S.adm_rec[e.row];
+      if (enters && al && ns > 1) r = S.adm_rec[e.row];  // the other slots' quantities; the bucket's own one travels with the entry
       #pragma unroll
-      for (int u = 0; u < CS_NS; u++) d[u] = (u < ns && al) ? (enters ? cs_rec_qty(r, w.s_fr[u]) : c.dB[(size_t)u * c.Mp + j]) : 0;
-      if (enters && !finalize) c.rb[j] = (uint16_t)r.rowbytes;
+      for (int u = 0; u < CS_NS; u++)
+        d[u] = (u < ns && al) ? (enters ? (u == c.ufirst ? e.qty : cs_rec_qty(r, w.s_fr[u])) : c.dB[u][j]) : 0;
     }
     bool within = true;   // IsWithinNominalInResources on the state before this candidate (resource_node.go:247-254)
     int64_t ua[CS_NS], outv[CS_NS];
@@ -120,10 +135,13 @@ KQ_DEV void cs_level_pass(CsCtx& c, int dd, int limit_t, bool finalize) {
       if (u >= ns) { ua[u] = 0; outv[u] = 0; continue; }
       int64_t sqv = 0, lq = 0, u0 = 0;
       if (part) {
-        const size_t o = ix(S, e.gnode, w.s_fr[u]);
-        sqv = S.sq[o];
-        const int64_t llv = S.ll[o];
-        lq = llv != KQ_NIL_LIMIT ? i64max(0, a_sub(sqv, llv)) : 0;
+        if (c.sqT) { sqv = c.sqT[(size_t)u * c.nn + e.node]; lq = c.lqT[(size_t)u * c.nn + e.node]; }
+        else {
+          const size_t o = ix(S, e.gnode, w.s_fr[u]);
+          sqv = S.sq[o];
+          const int64_t llv = S.ll[o];
+          lq = llv != KQ_NIL_LIMIT ? i64max(0, a_sub(sqv, llv)) : 0;
+        }
         u0 = c.W[(size_t)u * c.nn + e.node];
       }
       const int64_t P = wprefix_incl_i64(d[u]);
@@ -143,14 +161,15 @@ KQ_DEV void cs_level_pass(CsCtx& c, int dd, int limit_t, bool finalize) {
     #pragma unroll
     for (int u = 0; u < CS_NS; u++) {
       if (u >= ns || !in) continue;
-      if (part) { if (al && !dead) c.dB[(size_t)u * c.Mp + j] = outv[u]; }
-      else if (enters) c.dB[(size_t)u * c.Mp + j] = d[u];  // the preemptor's own ClusterQueue: straight onto the path
+      if (part) { if (al && !dead) c.dB[u][j] = outv[u]; }
+      else if (enters) c.dB[u][j] = d[u];  // the preemptor's own ClusterQueue: straight onto the path
     }
     if (finalize) {
-      int nxt = -9;
-      if (q + 1 < M) nxt = lane == WAVE - 1 ? ents[q + 1].node : 0;
+      // the node's usage after its last counted removal: written by the last entry of the segment
       const int nsh = wshfl_i32(e.node, lane < WAVE - 1 ? lane + 1 : lane);
-      if (q + 1 < M && lane != WAVE - 1) nxt = nsh;
+      const int nfirst = wbcast(e_next.node, 0);  // first entry of the next chunk
+      int nxt = -9;
+      if (q + 1 < M) nxt = lane == WAVE - 1 ? nfirst : nsh;
       #pragma unroll
       for (int u = 0; u < CS_NS; u++) if (u < ns && part && nxt != e.node) c.W[(size_t)u * c.nn + e.node] = ua[u];
     }
@@ -180,24 +199,36 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
   }
   if (first < 0 || M == 0 || M > 0xfff0) return false;
   const int n0 = S.tree_node_off[s.tree], nn = S.tree_node_off[s.tree + 1] - n0;
-  const size_t need_bytes = cs_bytes(ns, M, nn);
-  unsigned char* mem = nullptr;
-  if (w.cs_lds && need_bytes <= (size_t)w.cs_lds_bytes) mem = w.cs_lds;
-  else if (k.X.cs && need_bytes <= (size_t)k.X.cs_bytes) mem = k.X.cs + (size_t)s.slot * k.X.cs_bytes;
-  if (!mem) return false;
+  const int q0 = S.tree_cq_off[s.tree], nqs = S.tree_cq_off[s.tree + 1] - q0;
+  if (!k.X.cs || cs_bytes(ns, M, nn, nqs, false) > (size_t)k.X.cs_bytes) return false;
   CsCtx c;
   c.k = &k; c.w = &w; c.s = &s; c.ns = ns; c.M = M; c.Mp = (M + 63) & ~63; c.nn = nn; c.n0 = n0; c.boff = boff; c.plen = plen;
   c.levels = S.tree_depth[s.tree] < CS_LEVELS ? S.tree_depth[s.tree] : CS_LEVELS;
-  c.needm = needm; c.inum = inum;
-  c.W = (int64_t*)mem; c.dB = c.W + (size_t)ns * nn;
-  c.tord = (uint16_t*)(c.dB + (size_t)ns * c.Mp); c.tinv = c.tord + c.Mp; c.rb = c.tinv + c.Mp;
-  c.alive = (uint8_t*)(c.rb + c.Mp); c.cls = c.alive + c.Mp; c.att = c.cls + c.Mp;
+  c.needm = needm; c.inum = inum; c.ufirst = first;
+  {
+    CsCarve cv{w.cs_lds, w.cs_lds ? w.cs_lds + w.cs_lds_bytes : nullptr, k.X.cs + (size_t)s.slot * k.X.cs_bytes};
+    c.alive = (uint8_t*)cv.take(c.Mp); c.cls = (uint8_t*)cv.take(c.Mp); c.att = (uint8_t*)cv.take(c.Mp);
+    c.tord = (uint16_t*)cv.take((size_t)c.Mp * 2); c.tinv = (uint16_t*)cv.take((size_t)c.Mp * 2); c.rb = (uint16_t*)cv.take((size_t)c.Mp * 2);
+    c.cqi = (uint8_t*)cv.take(nqs);
+    c.W = (int64_t*)cv.take((size_t)ns * nn * 8);
+    // the quota tables only pay off next to the arithmetic: in LDS or not at all (the planes are L2-resident anyway)
+    c.sqT = c.lqT = nullptr;
+    if (cv.a && cv.a + 2 * (((size_t)ns * nn * 8 + 15) & ~(size_t)15) <= cv.ae) { c.sqT = (int64_t*)cv.take((size_t)ns * nn * 8); c.lqT = (int64_t*)cv.take((size_t)ns * nn * 8); }
+    #pragma unroll
+    for (int u = 0; u < CS_NS; u++) c.dB[u] = u < ns ? (int64_t*)cv.take((size_t)c.Mp * 8) : nullptr;
+  }
   CSTAT(20, 1);
-  // ---- private copy of the tree's usage for the slots; constants of the preemptor's path ----
+  // ---- private copy of the tree's usage (and quotas) for the slots; constants of the preemptor's path ----
   for (int i = lane; i < nn * ns; i += WAVE) {
     const int u = i / nn, ln = i % nn;
-    c.W[i] = s.usage[ix(S, S.tree_nodes[n0 + ln], w.s_fr[u])];
+    const size_t o = ix(S, S.tree_nodes[n0 + ln], w.s_fr[u]);
+    c.W[i] = s.usage[o];
+    if (c.sqT) {
+      const int64_t sqv = S.sq[o], llv = S.ll[o];
+      c.sqT[i] = sqv; c.lqT[i] = llv != KQ_NIL_LIMIT ? i64max(0, a_sub(sqv, llv)) : 0;
+    }
   }
+  for (int i = lane; i < nqs; i += WAVE) c.cqi[i] = s.cqinfo[i];
   for (int i = lane; i < ns * plen; i += WAVE) {
     const int u = i / plen, l = i % plen, n = w.path[l];
     const size_t o = ix(S, n, w.s_fr[u]);
@@ -211,20 +242,23 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
   wsync();
   // ---- classify the bucket once (hierarchical_preemption.go:81-113); class byte = 1 + list + 3 * not-evicted + 8 * variant ----
   const int32_t* rows = S.frbr + boff;
+  const CsRec* recs = S.frec + boff;
+  const int own_cql = S.cq_local[w.cq];
   int cnt[6] = {0, 0, 0, 0, 0, 0};
+  CsRec r_next = recs[lane < M ? lane : M - 1];
   for (int base = 0; base < M; base += WAVE) {
     const int j = base + lane;
     uint8_t cb = 0, at = 0;
+    const CsRec r = r_next;
+    { const int jn = j + WAVE; r_next = recs[jn < M ? jn : M - 1]; }
     if (j < M) {
-      const int row = rows[j];
-      const AdmRec r = S.adm_rec[row];
-      const int cq = r.cq;
-      const bool same = cq == w.cq;
+      const int row = r.row;
+      const bool same = r.cql == own_cql;
       int level = 0;
       bool ok = !row_removed(s, row);
       if (ok) {
         if (same) ok = same_on;
-        else { const uint8_t info = s.cqinfo[S.cq_local[cq]]; ok = info != 0; level = info - 1; }
+        else { const uint8_t info = c.cqi[r.cql]; ok = info != 0; level = info - 1; }
       }
       if (ok) {
         const int policy = same ? KQ_POL_WITHIN_CQ(w.pol) : KQ_POL_RECLAIM(w.pol);
@@ -246,7 +280,7 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
         cb = (uint8_t)(1 + (ev * 3 + list) + 8 * v);
         at = (uint8_t)level;
       }
-      c.cls[j] = cb; c.att[j] = at;
+      c.cls[j] = cb; c.att[j] = at; c.rb[j] = (uint16_t)r.rowbytes;
     }
     for (int p = 0; p < 6; p++) cnt[p] += popc64(wballot(cb != 0 && ((cb - 1) & 7) == p));
   }
@@ -302,9 +336,8 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
         const int j = base + lane;
         if (j < M) {
           const AdmRec r = S.adm_rec[rows[j]];
-          c.rb[j] = (uint16_t)r.rowbytes;
           #pragma unroll
-          for (int u = 0; u < CS_NS; u++) if (u < ns) c.dB[(size_t)u * c.Mp + j] = cs_rec_qty(r, w.s_fr[u]);
+          for (int u = 0; u < CS_NS; u++) if (u < ns) c.dB[u][j] = cs_rec_qty(r, w.s_fr[u]);
         }
       }
       wsync();
@@ -329,7 +362,7 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
       #pragma unroll
       for (int u = 0; u < CS_NS; u++) {
         if (u >= ns) continue;
-        const int64_t d = al ? c.dB[(size_t)u * c.Mp + j] : 0;
+        const int64_t d = al ? c.dB[u][j] : 0;
         int64_t A[CS_LEVELS + 1];
         #pragma unroll
         for (int l = 0; l <= CS_LEVELS; l++) {

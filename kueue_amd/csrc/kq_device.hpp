@@ -156,6 +156,7 @@ struct DSnap {
   const AdmRec* adm_rec;        // [n_adm]
   const CsEnt* frl[CS_LEVELS];  // level orders of the buckets (offsets = frb_off)
   const int32_t* frbr;          // admitted row of every bucket entry
+  const CsRec* frec;            // rank order of every bucket (offsets = frb_off)
   const uint64_t* frb_sig;      // [n_tree * nfr]
   const uint8_t* cs_ok;         // [n_tree]
   const int32_t* tree_depth;    // [n_tree]
@@ -755,6 +756,9 @@ KQ_DEV void classical_search(Search& s) {
   const K& k = *s.k; Wave& w = *s.w; const DSnap& S = k.S;
   const int lane = lane_id();
   w.ntgt = 0;
+#ifdef KQ_HOST_EMU
+  const int64_t bytes_entry = w.bytes;
+#endif
   CSTAT(0, 1); if (s.removed) CSTAT(10, 1);
   bool same_on = KQ_POL_WITHIN_CQ(w.pol) != KQ_POLICY_NEVER;
   bool other_on = w.plen > 1 && KQ_POL_RECLAIM(w.pol) != KQ_POLICY_NEVER;
@@ -824,21 +828,17 @@ KQ_DEV void classical_search(Search& s) {
   wsync();
 #ifdef KQ_HOST_EMU
   if (g_cs_check && !g_cs_force_off) {
-    const int64_t b0 = w.bytes;
     if (cs_run(s, same_on, other_on)) {
       const int nt1 = w.ntgt; const int64_t b1 = w.bytes;
       std::vector<int> t1(s.trow, s.trow + nt1);
       std::sort(t1.begin(), t1.end());
       std::vector<int64_t> pw;
       for (int l = 0; l < w.plen; l++) for (int u = 0; u < w.ns; u++) pw.push_back(s.W[(size_t)S.node_local[w.path[l]] * w.ns + u]);
-      g_cs_force_off = 1; w.bytes = b0;
-      cs_run_walk_again:
-      ;
-      // fall through to the walk below, compare at its end through the recursion-free trick: run it via a nested call
       Search s2 = s;
-      w.bytes = b0 - 0;  // setup bytes are already inside b0
-      g_cs_force_off = 2;  // nested marker
+      w.bytes = bytes_entry;  // the nested call charges the candidate records again
+      g_cs_force_off = 2;     // nested marker: walk
       classical_search(s2);
+      if (w.bytes != b1) { CSTAT(22, 1); fprintf(stderr, "CS BYTES MISMATCH head %d: scan %lld walk %lld\n", w.h, (long long)(b1 - bytes_entry), (long long)(w.bytes - bytes_entry)); }
       g_cs_force_off = 0;
       std::vector<int> t2(s2.trow, s2.trow + w.ntgt);
       std::sort(t2.begin(), t2.end());
@@ -849,7 +849,6 @@ KQ_DEV void classical_search(Search& s) {
         fprintf(stderr, "CS MISMATCH head %d cq %d ns %d plen %d: scan ntgt %d walk ntgt %d\n", w.h, w.cq, w.ns, w.plen, nt1, w.ntgt);
         fprintf(stderr, "  scan:"); for (int x : t1) fprintf(stderr, " %d", x); fprintf(stderr, "\n  walk:"); for (int x : t2) fprintf(stderr, " %d", x); fprintf(stderr, "\n");
       }
-      (void)b1;
       return;
     }
   }
@@ -2220,8 +2219,13 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
     // e.NominationMapping = e.readResourceToFlavorMapping() (scheduler.go:734): fixed for the whole recomputation
     for (int i = lane; i < w.nps * S.nR; i += WAVE) k.X.nom[(size_t)slot * KQ_MAXPS * S.nR + i] = O.flavor[(size_t)w.ps_base * S.nR + i];
     wsync();
+    // the flushed rows are not read until the recomputation is over: their LDS serves the victim searches meanwhile (kq_cs.hpp)
+    const bool lend = w.pc_on && !k.C.fair_sharing;
+    if (lend && lane == 0) { w.cs_lds = (unsigned char*)w.pc_lds; w.cs_lds_bytes = (int)((size_t)w.pc_ncoh * S.nfr * 16); }
+    wsync();
     Search s = get_assignments(k, w, slot, k.usage_np, k.preempted, true);
     publish_assignment(k, w, s, e);
+    if (lend) { if (lane == 0) { w.cs_lds = nullptr; w.cs_lds_bytes = 0; } wsync(); pc_load(k, w, w.pc_lds, tree); }
     trows = O.pool_row + O.tgt_pos[e];
     nt = O.tgt_n[e];
     mode = w.rep_mode;

@@ -331,7 +331,6 @@ struct HipBackend {
   }
   size_t lds_attr_nom = 0;
   void launch_nominate(const K& k, int slots, size_t lds) {
-    if (lds > 64 * 1024) lds = 0;  // beyond that the searches use their HBM spill space and occupancy stays up
     if (lds > 48 * 1024 && lds != lds_attr_nom) {
       chk(hipFuncSetAttribute((const void*)k_nominate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
       lds_attr_nom = lds;

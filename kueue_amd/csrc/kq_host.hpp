@@ -153,6 +153,7 @@ template <class B> struct EngineT {
     S.adm_rec = upload(prep.adm_rec.data(), prep.adm_rec.size());
     for (int l = 0; l < CS_LEVELS; l++) S.frl[l] = upload(prep.frl[l].data(), prep.frl[l].size());
     S.frbr = upload(prep.frbr.data(), prep.frbr.size());
+    S.frec = upload(prep.frec.data(), prep.frec.size());
     S.frb_sig = upload(prep.frb_sig.data(), prep.frb_sig.size());
     S.cs_ok = upload(prep.cs_ok.data(), prep.cs_ok.size());
     S.tree_depth = upload(prep.tree_depth.data(), prep.tree_depth.size());
@@ -417,7 +418,7 @@ template <class B> struct EngineT {
     X.mark = (uint64_t*)grow<int64_t>(b_mark, (size_t)slots * ((X.max_tree_rows + 63) / 64));
     X.cs = nullptr; X.cs_bytes = 0;
     if (k.C.cs_on) {  // spill space for the arrays of a search that do not fit the workgroup's LDS (worst case: CS_NS slots)
-      X.cs_bytes = (int64_t)((cs_bytes(CS_NS, prep.cs_max_bucket, prep.max_tree_nodes) + 255) & ~(size_t)255);
+      X.cs_bytes = (int64_t)((cs_bytes(CS_NS, prep.cs_max_bucket, prep.max_tree_nodes, prep.max_tree_cqs, false) + 255) & ~(size_t)255);
       X.cs = grow<unsigned char>(b_cs, (size_t)slots * (size_t)X.cs_bytes);
     }
     k.cq_rm_bytes = grow<int32_t>(b_rmb, std::max(prep.nq, 1));
@@ -460,7 +461,12 @@ template <class B> struct EngineT {
       be.d2d(X.bs_pos, X.bu_pos, (size_t)prep.N * sizeof(int32_t));
     }
     // LDS of a nominate workgroup: the arrays of a one-slot search (SimulatePreemption, 37 of the 38 searches of a cfg 4 head)
-    const size_t nom_lds = k.C.cs_on ? cs_bytes(1, prep.cs_max_bucket, prep.max_tree_nodes) : 0;
+    // (with the quota tables when that stays within half a CU's LDS; what does not fit goes to the spill space array by array)
+    size_t nom_lds = 0;
+    if (k.C.cs_on) {
+      nom_lds = cs_bytes(1, prep.cs_max_bucket, prep.max_tree_nodes, prep.max_tree_cqs, true);
+      if (nom_lds > 78 * 1024) nom_lds = std::min<size_t>(cs_bytes(1, prep.cs_max_bucket, prep.max_tree_nodes, prep.max_tree_cqs, false), 78 * 1024);
+    }
     be.launch_nominate(k, slots_nom, nom_lds);
     be.launch_records(k);  // entry records (static part) for k_process; charged to the nominate interval
     be.timer_mark(1);

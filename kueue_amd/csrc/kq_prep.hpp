@@ -42,7 +42,10 @@ struct alignas(16) AdmRec {
 // node of depth d on the way from the row's ClusterQueue to the root (`node`, tree-local id; the ClusterQueue itself when it sits
 // at depth d; -1 when it is shallower), evicted rows first, then candidate rank — i.e. the order in which the reference's
 // candidate loop meets the rows of one subtree. jd = index of the row inside the bucket's rank order | depth of its ClusterQueue << 24.
-struct alignas(16) CsEnt { int32_t jd, node, row, gnode; };  // gnode = global node id of `node` (-1 if none)
+struct alignas(8) CsEnt { int32_t jd, node, row, gnode; int64_t qty; };  // gnode = global node id of `node` (-1 if none); qty = the
+                                                                          // row's quantity of the bucket's own flavor-resource
+// One entry of a bucket in candidate rank order: everything the classification of a candidate reads (hierarchical_preemption.go:81-113)
+struct alignas(8) CsRec { int64_t prio, qts; int32_t row, cql, rowbytes; uint32_t flags; };  // cql = index of the ClusterQueue in its tree
 
 struct Prep {
   int nq = 0, nc = 0, N = 0, nF = 0, nR = 0, nfr = 0, n_adm = 0, n_rg = 0;
@@ -68,6 +71,7 @@ struct Prep {
   std::vector<int64_t> h_ll, h_bl;
   std::vector<AdmRec> adm_rec;                     // [n_adm]
   std::vector<CsEnt> frl[CS_LEVELS];               // level orders of every bucket (same offsets as frb)
+  std::vector<CsRec> frec;                         // rank order of every bucket (same offsets as frb)
   std::vector<uint64_t> frb_sig;                   // [n_tree * nfr] hash of the bucket's row list (equal sets <=> equal buckets)
   std::vector<uint8_t> cs_ok;                      // [n_tree] the tree's shape fits the fast search
   std::vector<int32_t> frbr;                       // admitted row of every bucket entry (same layout as frb)
@@ -286,7 +290,8 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
     }
     p.frb_sig.assign((size_t)p.n_tree * p.nfr, 0);
     p.cs_max_bucket = 0;
-    for (int l = 0; l < CS_LEVELS; l++) p.frl[l].assign(p.frb.size(), CsEnt{0, -1, 0, -1});
+    for (int l = 0; l < CS_LEVELS; l++) p.frl[l].assign(p.frb.size(), CsEnt{0, -1, 0, -1, 0});
+    p.frec.assign(p.frb.size(), CsRec{});
     // (M <= 0xfff0 is checked by the search; the depth shares the word with j)
     std::vector<int32_t> anc;  // scratch: ancestor at height l of the row's ClusterQueue
     for (int t = 0; t < p.n_tree; t++)
@@ -297,6 +302,11 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
         uint64_t sig = 1469598103934665603ull ^ (uint64_t)M;
         for (int j = 0; j < M; j++) { sig ^= (uint64_t)(uint32_t)p.tree_rows[p.tree_row_off[t] + p.frb[o + j]]; sig *= 1099511628211ull; }
         p.frb_sig[b] = sig;
+        for (int j = 0; j < M; j++) {
+          const int row = p.tree_rows[p.tree_row_off[t] + p.frb[o + j]];
+          const AdmRec& a = p.adm_rec[row];
+          p.frec[o + j] = CsRec{a.prio, a.qts, row, p.cq_local[a.cq], a.rowbytes, a.flags};
+        }
         for (int l = 0; l < CS_LEVELS; l++) {
           anc.assign(M, -1);
           for (int j = 0; j < M; j++) {
@@ -320,7 +330,9 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
           for (int q = 0; q < M; q++) {
             const int j = idx[q];
             const int row = p.tree_rows[p.tree_row_off[t] + p.frb[o + j]];
-            p.frl[l][o + q] = CsEnt{j | (p.depth[p.adm_cq[row]] << 24), anc[j] >= 0 ? p.node_local[anc[j]] : -1, row, anc[j]};
+            int64_t qty = 0;
+            for (int e = 0; e < CS_RFR; e++) if (p.adm_rec[row].fr[e] == fr) qty = p.adm_rec[row].qty[e];
+            p.frl[l][o + q] = CsEnt{j | (p.depth[p.adm_cq[row]] << 24), anc[j] >= 0 ? p.node_local[anc[j]] : -1, row, anc[j], qty};
           }
         }
       }

@@ -48,7 +48,7 @@ def test_engine_matches_offline_oracle(name, cycle):
     try:
         eng.put(pop.snapshot)
         m = int(g["tgt_off"][-1])
-        got = eng.run(heads, tgt_cap=max(4096, 2 * m))
+        got = eng.run(heads, tgt_cap=max(4096, (32 if fair else 4) * pop.snapshot.n_adm))
         for k in ("status", "action", "nominated_mode", "mode", "requeue_reason", "skip", "borrowing", "order", "flavor", "res_mode",
                   "tried_idx", "ps_count", "tgt_off"):
             assert np.array_equal(got.a[k], g[k]), (name, k)
