@@ -32,17 +32,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4c", "cfg3f", "cfg4f", "cfg5"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3-batch", "cfg4c", "cfg3f", "cfg4f", "cfg5"],
                     help="cfg3 = BASELINE.json configs[2] (100k pending, 1k CQ, 16 flavors, 3-level cohorts); "
                          "cfg4c = configs[3] population under classical preemption; cfg4f = configs[3] as quoted "
                          "(fair sharing + preemption); cfg3f = configs[2] population under fair sharing; cfg5 = configs[4] "
-                         "(TAS: 4096-leaf 3-tier topology, topology assignment for a batch of pending workloads)")
+                         "(TAS: 4096-leaf 3-tier topology, topology assignment for a batch of pending workloads); cfg3-batch = every pending "
+                         "workload of cfg3 nominated in one launch (SURVEY 8d 'nominate-all-pending', kq_nominate_run_resident)")
     ap.add_argument("--tas-batch", type=int, default=50_000, help="cfg5: pending workloads assigned per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--open-loop", action="store_true",
                     help="every cycle sees the same snapshot (no kq_cycle_commit / kq_cycle_release between cycles)")
     ap.add_argument("--hold", type=int, default=4, help="closed loop: admitted workloads finish after this many cycles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-gate", action="store_true")
+    ap.add_argument("--resident-batches", action="store_true",
+                    help="cfg2 / cfg3 / cfg3f: the round-1 loop over pre-cut resident head batches (batch c = the c-th workload of every "
+                         "ClusterQueue, no requeue) instead of the pending-side loop (Heads() and requeue on the device)")
+    ap.add_argument("--full-run", type=int, default=6000, help="pending loop: cycle cap of the untimed 'until every workload had a decision' leg (0 = skip)")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive kq_cycle_run leg and the kq_snapshot_put timing")
     args = ap.parse_args()
 
     import torch
@@ -58,6 +65,10 @@ def main():
 
     if args.workload == "cfg5":
         return bench_tas(args, torch, dist, world, rank, local_rank)
+    if args.workload == "cfg3-batch":
+        return bench_batch(args, torch, dist, world, rank, local_rank)
+    if args.workload in ("cfg2", "cfg3", "cfg3f") and not args.resident_batches and not args.open_loop:
+        return bench_pending(args, torch, dist, world, rank, local_rank)
     from kueue_amd.api import Decisions, make_config
     from kueue_amd.engine import Engine
     from kueue_amd.population import BASE_SEED, generate
@@ -128,6 +139,13 @@ def main():
     else:
         elapsed_all, dec_all = elapsed, float(dec)
 
+    # ---- outside the timed region --------------------------------------------------------------------------------------
+    extra = {}
+    if rank == 0:
+        extra["parity_checked"], extra["parity"] = parity_gate(eng, pop, kcfg, batches, outs, args.warmup + args.steps, n_batches, fair)
+        if not args.no_host_leg:
+            extra["host_heads"] = host_heads_leg(eng, pop, kcfg, snap, min(args.steps, 50), closed, args.hold, fair, live[0])
+            extra["snapshot_put_ms"] = snapshot_put_cost(eng, snap)
     if rank == 0:
         # dominant kernel of the cycle by accumulated device time
         kernels = {"k_nominate": (nom_ms, nom_by), "k_process": (proc_ms, proc_by)}
@@ -159,11 +177,372 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                          "algorithmic_bytes_per_launch": dby / args.steps, "traffic": pmc_traffic(args.workload, dom)},
         }
+        out.update(extra)
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is a single-GPU-run figure (rank 0, N = 1)
             out["cpu_baseline"] = cpu_baseline(pop, kcfg, args.cpu_seconds, closed, args.hold)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def parity_gate(eng, pop, kcfg, batches, outs, next_i, n_batches, fair):
+    """One more cycle of the loop that was just timed, compared decision by decision with the oracle on the state the engine is in
+    now (resident usage plane read back). Outside the timed region; the oracle is the checker here, never the thing measured.
+    Fair sharing + preemption: the oracle needs minutes per full cycle, so the gate runs an evenly spaced sample of the heads
+    through kq_cycle_run instead of the resident batch."""
+    import copy
+    from oracle import kqo
+    from kueue_amd.api import Decisions
+    osnap = copy.copy(pop.snapshot)
+    osnap.arrays = dict(pop.snapshot.arrays)
+    osnap.arrays["usage"] = eng.read_usage(); osnap._struct = None
+    b = next_i % n_batches
+    if fair and pop.preemption:
+        hb = pop.heads_for_cycle(b, cycle=b + 1, limit=6)
+        got = eng.run(hb, tgt_cap=max(4096, 32 * pop.snapshot.n_adm))
+        what = f"{hb.n} evenly spaced heads of batch {b} through kq_cycle_run"
+    else:
+        hb = batches[b]
+        eng.run_resident(b, outs[b])
+        got = outs[b]
+        what = f"all {hb.n} heads of resident batch {b} through kq_cycle_run_resident, engine state after the timed loop"
+    want = kqo.cycle_run(kcfg, osnap, hb)
+    bad = want.equal(got)
+    return (not bad), (what if not bad else f"MISMATCH in {bad}: {what}")
+
+
+def host_heads_leg(eng, pop, kcfg, snap, cycles, closed, hold, fair, live=0):
+    """SURVEY 8d cycle time: host call -> decisions readable on the host INCLUDING the upload of the cycle's heads (kq_cycle_run:
+    one packed H2D per cycle, no resident batch). Never reported as `value`."""
+    import ctypes as C
+    from kueue_amd.api import Decisions
+    lib, h = eng._lib, eng._h
+    per_cq = int((pop.cq_w_off[1:] - pop.cq_w_off[:-1]).max())
+    n = min(cycles, per_cq, 4 if (fair and pop.preemption) else cycles)
+    hbs = [pop.heads_for_cycle(c, cycle=c + 1) for c in range(n)]
+    outs = [Decisions(hb, tgt_cap=max(4096, (32 if fair else 4) * snap.n_adm)) for hb in hbs]
+    ms, dec = [], 0  # `live`: commits of the timed loop that are still held
+    for c in range(n):
+        t1 = time.perf_counter()
+        eng._check(lib.kq_cycle_run(h, C.byref(hbs[c].struct()), C.byref(outs[c].struct())))
+        if closed:
+            eng._check(lib.kq_cycle_commit(h, None))
+            live += 1
+            if live > hold:
+                eng._check(lib.kq_cycle_release(h, hold + 1))
+                live -= 1
+        ms.append((time.perf_counter() - t1) * 1e3)
+        dec += hbs[c].n
+    return {"decisions_per_s": dec / (sum(ms) * 1e-3), "p50_cycle_ms": float(np.percentile(ms, 50)), "p99_cycle_ms": float(np.percentile(ms, 99)),
+            "cycles": n, "what": "kq_cycle_run: the cycle's heads cross PCIe every cycle (one packed H2D), decisions one packed D2H"}
+
+
+def snapshot_put_cost(eng, snap):
+    """kq_snapshot_put = what a drop-in pays when it re-uploads cache.Snapshot() (host-side prep + every plane over PCIe)."""
+    ms = []
+    for _ in range(3):
+        t1 = time.perf_counter()
+        eng.put(snap)
+        ms.append((time.perf_counter() - t1) * 1e3)
+    return float(np.median(ms))
+
+
+class PendingLoop:
+    """SURVEY 8d's run on the engine: Heads() from the device-resident pending set, one cycle, admissions committed into the resident
+    snapshot, requeue on the device, the workloads admitted `hold` cycles ago finish (which requeues the inadmissible ones)."""
+
+    def __init__(self, eng, pop, hold, tgt_cap):
+        import ctypes as C
+        from kueue_amd.api import Decisions
+        self.C, self.eng, self.hold, self.live, self.cycle = C, eng, hold, 0, 0
+        self.lib, self.h = eng._lib, eng._h
+        snap = pop.snapshot
+        self.nq = snap.n_cq
+        # decision buffers sized once for the widest cycle (<= 1 head per ClusterQueue)
+        any_heads = pop.heads_for_cycle(0)
+        self.out = Decisions(any_heads, tgt_cap=tgt_cap, n=snap.n_cq, n_ps=int(pop.w_nps.max()) * snap.n_cq)
+        self.n = C.c_int32(); self.nps = C.c_int32()
+        self.hw = np.full(snap.n_cq, -1, np.int32)
+
+    def step(self, want_heads=False):
+        C, lib, h, eng = self.C, self.lib, self.h, self.eng
+        self.cycle += 1
+        eng._check(lib.kq_pending_heads(h, self.cycle, None, C.byref(self.n), C.byref(self.nps), F_ptr(self.hw) if want_heads else None))
+        if self.n.value == 0:
+            eng._check(lib.kq_pending_apply(h))
+            return 0
+        eng._check(lib.kq_cycle_run_pending(h, C.byref(self.out.struct())))
+        eng._check(lib.kq_cycle_commit(h, None))
+        eng._check(lib.kq_pending_apply(h))
+        self.live += 1
+        if self.live > self.hold:
+            eng._check(lib.kq_cycle_release(h, self.hold + 1))
+            self.live -= 1
+        return self.n.value
+
+
+def pending_parity_gate(eng, pop, kcfg, hold, cycles):
+    """The first `cycles` cycles of the pending loop, engine and oracle side by side: Heads(), every decision, the queue states.
+    Outside the timed region; the engine is reset afterwards."""
+    import copy
+    from oracle import kqo
+    from kueue_amd.api import Decisions
+    snap = pop.snapshot
+    pending = pop.pending()
+    eng.put(snap); eng.pending_put(pending)
+    q = kqo.PendingOracle(kcfg, snap, pending)
+    osnap = copy.copy(snap); osnap.arrays = dict(snap.arrays)
+    parent = snap.arrays["parent"]; root_of = np.arange(snap.N)
+    for _ in range(8):
+        root_of = np.where(parent[root_of] >= 0, parent[root_of], root_of)
+    held, live, dec = [], 0, 0
+    try:
+        for cyc in range(1, cycles + 1):
+            n, nps, hw = eng.pending_heads(cyc)
+            hb, ohw = q.heads(cyc)
+            if not np.array_equal(hw, ohw):
+                return False, f"cycle {cyc}: Heads() differ"
+            got = eng.run_pending(Decisions(hb, tgt_cap=max(4096, snap.n_adm)))
+            want = kqo.cycle_run(kcfg, osnap, hb)
+            bad = want.equal(got)
+            if bad:
+                return False, f"cycle {cyc}: MISMATCH in {bad}"
+            dec += n
+            usage, na, triples = kqo.cycle_commit(kcfg, osnap, hb)
+            osnap.arrays["usage"] = usage; osnap._struct = None
+            eng.commit(); eng.pending_apply(); q.apply(hb, want)
+            held.append(triples); live += 1
+            if live > hold:
+                eng.release(hold + 1); live -= 1
+                done = held.pop(0)
+                osnap.arrays["usage"] = kqo.usage_apply(kcfg, osnap, done, add=False); osnap._struct = None
+                freed = np.unique(root_of[done[0]])
+                if len(freed):
+                    q.queue_inadmissible(np.nonzero(np.isin(root_of[:snap.n_cq], freed))[0])
+            if not np.array_equal(eng.pending_state()[0], q.state()):
+                return False, f"cycle {cyc}: queue states differ"
+        return True, f"first {cycles} cycles of the pending loop ({dec} decisions): Heads(), every decision field and the queue states equal the oracle's"
+    finally:
+        q.close()
+
+
+def bench_pending(args, torch, dist, world, rank, local_rank):
+    """cfg2 / cfg3 / cfg3f: the §8d run. The W pending workloads live in HBM (kq_pending_put); every step is one scheduling cycle:
+    kq_pending_heads (Pop per ClusterQueue + gather) -> kq_cycle_run_pending -> kq_cycle_commit -> kq_pending_apply (requeue policy) ->
+    kq_cycle_release (workloads admitted `hold` cycles ago finish, inadmissible workloads of their root cohort requeue)."""
+    import ctypes as C
+    from kueue_amd.api import make_config
+    from kueue_amd.engine import Engine
+    from kueue_amd.population import BASE_SEED, generate
+    from kueue_amd import _ffi as F
+    cfgn = {"cfg2": 2, "cfg3": 3, "cfg3f": 3}[args.workload]
+    fair = args.workload.endswith("f")
+    pop = generate(cfgn, seed=BASE_SEED + 1000 * rank, fair_sharing=fair)
+    snap = pop.snapshot
+    kcfg = make_config(fair_sharing=fair, device=local_rank)
+    eng = Engine(kcfg)
+    tgt_cap = max(4096, (32 if fair else 4) * snap.n_adm)
+    parity = (None, "skipped")
+    if rank == 0 and not args.no_parity_gate:
+        parity = pending_parity_gate(eng, pop, kcfg, args.hold, 6 if fair else 12)
+    pending = pop.pending()
+
+    def reset():
+        eng.put(snap)
+        eng.pending_put(pending)
+        return PendingLoop(eng, pop, args.hold, tgt_cap)
+
+    loop = reset()
+    lib, h = eng._lib, eng._h
+    phase_ms = np.zeros(3, np.float64); phase_by = np.zeros(2, np.int64)
+    for _ in range(args.warmup):
+        loop.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    cyc_ms, dec = [], 0
+    nom_ms = ord_ms = proc_ms = 0.0
+    nom_by = proc_by = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t1 = time.perf_counter()
+        dec += loop.step()
+        cyc_ms.append((time.perf_counter() - t1) * 1e3)
+        lib.kq_last_cycle_phases(h, F.ptr(phase_ms), F.ptr(phase_by))
+        nom_ms += phase_ms[0]; ord_ms += phase_ms[1]; proc_ms += phase_ms[2]
+        nom_by += int(phase_by[0]); proc_by += int(phase_by[1])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed, float(dec)], dtype=torch.float64, device="cuda")
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed_all, dec_all = float(tmax[0]), float(tsum[1])
+    else:
+        elapsed_all, dec_all = elapsed, float(dec)
+    if rank == 0:
+        kernels = {"k_nominate": (nom_ms, nom_by), "k_process": (proc_ms, proc_by)}
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        dms, dby = kernels[dom]
+        achieved = (dby / args.steps) / (dms / args.steps * 1e-3) / 1e9 if dms > 0 else 0.0
+        out = {
+            "metric": "admission-decisions/sec + p99 schedule-cycle ms @ 100k pending, 1k CQ",
+            "value": dec_all / elapsed_all, "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed_all / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {snap.n_cq} ClusterQueues, {snap.n_cohort} cohorts, {snap.n_flavor} flavors x "
+                                   f"{snap.n_resource} resources, {snap.n_adm} admitted, {pop.n_pending} pending per GPU resident in HBM; "
+                                   f"one cycle = Heads() (<= 1 head per ClusterQueue, {dec // max(args.steps, 1)} on average)",
+                       "heads_per_cycle": dec / max(args.steps, 1), "pending_per_gpu": pop.n_pending, "sharding": "root cohort per GPU, no collective",
+                       "loop": f"pending side on device: Heads() + requeue policy per cycle; admissions committed every cycle, finished after {args.hold} cycles"},
+            "p50_cycle_ms": float(np.percentile(cyc_ms, 50)), "p99_cycle_ms": float(np.percentile(cyc_ms, 99)),
+            "kernel_ms_per_cycle": {"k_nominate": nom_ms / args.steps, "k_order": ord_ms / args.steps, "k_process": proc_ms / args.steps},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "algorithmic_bytes_per_launch": dby / args.steps, "traffic": pmc_traffic(args.workload, dom)},
+            "parity_checked": parity[0], "parity": parity[1],
+        }
+        if args.full_run and world == 1:
+            # the run of SURVEY 8d, untimed region: from a fresh queue until every pending workload has had a decision
+            loop = reset()
+            decided = np.zeros(pop.n_pending, bool)
+            ms, fdec, cyc = [], 0, 0
+            while cyc < args.full_run and not decided.all():
+                t1 = time.perf_counter()
+                n = loop.step(want_heads=True)
+                ms.append((time.perf_counter() - t1) * 1e3)
+                cyc += 1
+                if n == 0:
+                    break
+                decided[loop.hw[loop.hw >= 0]] = True
+                fdec += n
+            st, counts = eng.pending_state()
+            out["full_run"] = {"cycles": cyc, "decisions": fdec, "workloads_decided": int(decided.sum()), "of": pop.n_pending,
+                               "decisions_per_s": fdec / (sum(ms) * 1e-3), "p50_cycle_ms": float(np.percentile(ms, 50)), "p99_cycle_ms": float(np.percentile(ms, 99)),
+                               "admitted": int(counts[3]), "still_active": int(counts[0]), "inadmissible": int(counts[2]),
+                               "what": "fresh queue -> cycles until every pending workload had >= 1 decision (or the cycle cap); wall time per cycle, heads read back"}
+        if not args.no_host_leg:
+            eng.put(snap)
+            out["host_heads"] = host_heads_leg(eng, pop, kcfg, snap, min(args.steps, 50), True, args.hold, fair, 0)
+            out["snapshot_put_ms"] = snapshot_put_cost(eng, snap)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline_pending(pop, kcfg, args.cpu_seconds, args.hold)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_pending(pop, kcfg, budget_s, hold):
+    """The same pending loop on the oracle (queue restatement + cycle restatement, one thread) for a bounded number of cycles."""
+    import copy
+    from oracle import kqo
+    snap = pop.snapshot
+    pending = pop.pending()
+    q = kqo.PendingOracle(kcfg, snap, pending)
+    osnap = copy.copy(snap); osnap.arrays = dict(snap.arrays)
+    held, live, dec, cpu_t, cycles = [], 0, 0, 0.0, 0
+    t0 = time.perf_counter()
+    first = 0.0
+    while time.perf_counter() - t0 < budget_s and cycles < 200:
+        t1 = time.perf_counter()
+        hb, hw = q.heads(cycles + 1)
+        t_heads = time.perf_counter() - t1   # includes building the batch in Python: not counted
+        t1 = time.perf_counter()
+        want = kqo.cycle_run(kcfg, osnap, hb)
+        usage, na, triples = kqo.cycle_commit(kcfg, osnap, hb)
+        q.apply(hb, want)
+        dt = time.perf_counter() - t1
+        osnap.arrays["usage"] = usage; osnap._struct = None
+        held.append(triples); live += 1
+        if live > hold:
+            live -= 1
+            done = held.pop(0)
+            t1 = time.perf_counter()
+            osnap.arrays["usage"] = kqo.usage_apply(kcfg, osnap, done, add=False); osnap._struct = None
+            if len(done[0]):
+                q.queue_inadmissible()
+            dt += time.perf_counter() - t1
+        cpu_t += dt; dec += hb.n; cycles += 1
+        if cycles == 1:
+            first = dt
+    q.close()
+    return {"value": dec / max(cpu_t, 1e-9), "unit": "decisions/s", "cores": 1, "kind": "port",
+            "sample": f"first {cycles} cycles ({dec} decisions) of the same pending loop, C++ restatement of the Go path (scheduling cycle + queue requeue; "
+                      f"the Python gather of the heads batch is not counted), host nproc={os.cpu_count()}", "first_cycle_ms": first * 1e3}
+
+
+def bench_batch(args, torch, dist, world, rank, local_rank):
+    """cfg3-batch: one step = Scheduler.nominate (flavorassigner.Assign + GetTargets) for EVERY pending workload of cfg 3 in one
+    k_nominate launch against the resident snapshot — the bandwidth-meaningful figure of SURVEY 8d; a 'decision' here is one
+    workload's nomination (flavor assignment per podset/resource, mode, borrowing level, targets)."""
+    import ctypes as C
+    from kueue_amd.api import Decisions, make_config
+    from kueue_amd.engine import Engine
+    from kueue_amd.population import BASE_SEED, generate
+    from kueue_amd import _ffi as F
+    pop = generate(3, seed=BASE_SEED + 1000 * rank)
+    snap = pop.snapshot
+    kcfg = make_config(device=local_rank)
+    eng = Engine(kcfg)
+    eng.put(snap)
+    heads = pop.all_heads()
+    eng.heads_put(heads, 0)
+    out = Decisions(heads, tgt_cap=4096)
+    lib, h = eng._lib, eng._h
+    phase_ms = np.zeros(3, np.float64); phase_by = np.zeros(2, np.int64)
+    for _ in range(args.warmup):
+        eng.nominate_resident(0, out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    st_ms, kms, kby = [], 0.0, 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t1 = time.perf_counter()
+        eng._check(lib.kq_nominate_run_resident(h, 0, C.byref(out.struct())))
+        st_ms.append((time.perf_counter() - t1) * 1e3)
+        lib.kq_last_cycle_phases(h, F.ptr(phase_ms), F.ptr(phase_by))
+        kms += phase_ms[0]; kby += int(phase_by[0])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dec = float(args.steps * heads.n)
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed, dec], dtype=torch.float64, device="cuda")
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, dec = float(tmax[0]), float(tsum[1])
+    if rank == 0:
+        achieved = (kby / args.steps) / (kms / args.steps * 1e-3) / 1e9 if kms > 0 else 0.0
+        res = {
+            "metric": "admission-decisions/sec + p99 schedule-cycle ms @ 100k pending, 1k CQ",
+            "value": dec / elapsed, "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"cfg3-batch: nominate-all-pending, {heads.n} heads in one launch against {snap.n_cq} ClusterQueues, {snap.n_cohort} cohorts, "
+                                   f"{snap.n_flavor} flavors x {snap.n_resource} resources, {snap.n_adm} admitted",
+                       "decision": "one workload's nomination (Scheduler.nominate: flavor assignment + targets); no iterator / processEntry",
+                       "sharding": "root cohort per GPU, no collective"},
+            "p50_cycle_ms": float(np.percentile(st_ms, 50)), "p99_cycle_ms": float(np.percentile(st_ms, 99)),
+            "kernel_ms_per_cycle": {"k_nominate": kms / args.steps},
+            "roofline": {"bound": "hbm", "kernel": "k_nominate", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "algorithmic_bytes_per_launch": kby / args.steps, "traffic": pmc_traffic("cfg3-batch", "k_nominate")},
+        }
+        from oracle import kqo
+        t1 = time.perf_counter()
+        want = kqo.nominate_run(kcfg, snap, heads, tgt_cap=4096)
+        dt = time.perf_counter() - t1
+        bad = want.equal(out)
+        res["parity_checked"] = not bad
+        res["parity"] = f"all {heads.n} nominations of the last timed launch vs the oracle" if not bad else f"MISMATCH in {bad}"
+        res["cpu_baseline"] = None if args.no_cpu_baseline else {
+            "value": heads.n / dt, "unit": "decisions/s", "cores": 1, "kind": "port",
+            "sample": f"the same {heads.n} nominations, C++ restatement of the Go path, host nproc={os.cpu_count()}"}
+        print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
 

@@ -94,10 +94,12 @@ extern "C" {
 #define KQ_GATE_RECOMPUTE_ON_OVERLAP          (1u << 6)  /* RecomputeAssignmentUponPreemptionTargetsOverlap */
 #define KQ_GATE_PRIORITIZE_PREEMPTORS         (1u << 7)  /* PrioritizePreemptorWorkloads (off)    */
 #define KQ_GATE_QUOTA_CHECK_STRATEGY          (1u << 8)
+#define KQ_GATE_SCHEDULING_EQUIVALENCE_HASHING (1u << 9) /* SchedulingEquivalenceHashing (pending side only)  */
 #define KQ_GATES_DEFAULT (KQ_GATE_FLAVOR_FUNGIBILITY | KQ_GATE_PRESERVE_SCAN_PROGRESS |            \
                           KQ_GATE_PARTIAL_ADMISSION | KQ_GATE_PRIORITY_SORTING_IN_COHORT |         \
                           KQ_GATE_FS_PREEMPT_WITHIN_NOMINAL | KQ_GATE_FS_PRIORITIZE_NON_BORROWING |\
-                          KQ_GATE_RECOMPUTE_ON_OVERLAP | KQ_GATE_QUOTA_CHECK_STRATEGY)
+                          KQ_GATE_RECOMPUTE_ON_OVERLAP | KQ_GATE_QUOTA_CHECK_STRATEGY |            \
+                          KQ_GATE_SCHEDULING_EQUIVALENCE_HASHING)
 
 /* fair-sharing preemption strategies (apis/config/v1beta2; preemption.go:363-379) */
 #define KQ_FS_LESS_THAN_OR_EQUAL_TO_FINAL_SHARE 0  /* rule S2-a */
@@ -268,6 +270,48 @@ int  kq_cycle_run(kq_engine* e, const kq_heads* h, kq_decisions* out);
 int  kq_heads_put(kq_engine* e, const kq_heads* h, int32_t batch);
 int  kq_cycle_run_resident(kq_engine* e, int32_t batch, kq_decisions* out);
 
+/* Nominate-ahead over a resident batch ("nominate-all-pending"): what Scheduler.nominate (scheduler.go:665-705)
+ * computes for every head of the batch — getAssignments :821 = flavorassigner.Assign (flavorassigner.go:696) +
+ * preemption.GetTargets (preemption.go:132) + the partial-admission search — against the resident snapshot, WITHOUT the entry
+ * iterator and processEntry. The batch may hold any number of workloads per ClusterQueue (all W pending). Fills the
+ * nomination fields of `out` (nominated_mode = mode, borrowing, flavor / res_mode / tried_idx / ps_count, targets); status is
+ * KQ_ST_NOT_NOMINATED and order -1 for every head. Nothing is committable afterwards. */
+int  kq_nominate_run_resident(kq_engine* e, int32_t batch, kq_decisions* out);
+
+/* ---- pending side on the device: pkg/cache/queue ---------------------------------------------
+ * Every pending workload of every ClusterQueue lives in HBM; Heads() (manager.go:903,922: one ClusterQueue.Pop per
+ * ClusterQueue, cluster_queue.go:657) is a segmented arg-min under baseCompareFunc (cluster_queue.go:844: sticky preemptor,
+ * priority descending, queue-order timestamp ascending, UID ascending) and the requeue policy (RequeueIfNotPresent :826,
+ * requeueIfNotPresent :550, handleInadmissibleHash :606, queueInadmissibleWorkloads inadmissible_workloads.go:149) runs on the
+ * device from the cycle's decisions, together with the LastAssignment bookkeeping of scheduler.go:248-295,459-464.
+ * Outside: RequeueState back-off, namespace selectors, second-pass queue, AdmissionFairSharing ordering. */
+#define KQ_WL_ACTIVE        0  /* in the heap                                   */
+#define KQ_WL_INFLIGHT      1  /* popped by Heads(), decision pending           */
+#define KQ_WL_INADMISSIBLE  2  /* parked in inadmissibleWorkloads               */
+#define KQ_WL_GONE          3  /* admitted (left the queue)                     */
+typedef struct kq_pending {
+  kq_heads w;                 /* n = W workloads: the pre-digested workload.Info columns of a heads batch, any order;
+                                 w.cycle is ignored */
+  const uint32_t* uid_rank;   /* [W] rank of Obj.UID (cluster_queue.go:873) */
+} kq_pending;
+/* PushOrUpdate (cluster_queue.go:379) of every workload into its ClusterQueue's heap; replaces any previous pending set. */
+int  kq_pending_put(kq_engine* e, const kq_pending* p);
+/* Heads(): pops <= 1 workload per ClusterQueue (cq_active[c] == 0: ClusterQueue skipped, manager.go:926; NULL = all active)
+ * and gathers them, in canonical head order (ClusterQueue index ascending), into the engine's resident pending batch.
+ * *n_heads / *n_podsets size the kq_decisions arrays of the cycle; head_wl (optional, [n_cq]) receives the workload of every
+ * head (index into kq_pending.w). */
+int  kq_pending_heads(kq_engine* e, int64_t cycle, const uint8_t* cq_active, int32_t* n_heads, int32_t* n_podsets, int32_t* head_wl);
+/* kq_cycle_run over the batch kq_pending_heads just built (no head crosses PCIe). */
+int  kq_cycle_run_pending(kq_engine* e, kq_decisions* out);
+/* Step 6 of schedule() (scheduler.go:362-377) for the heads of that cycle: admitted workloads leave the queue, the others go
+ * through RequeueIfNotPresent with the decision's requeue reason; their LastAssignment becomes the cycle's tried indices. */
+int  kq_pending_apply(kq_engine* e);
+/* queueInadmissibleWorkloads for the listed ClusterQueues (cq == NULL: all) — what requeueWorkloadsCohort does for the root
+ * cohorts whose quota was freed (inadmissible_workloads.go:112-175). */
+int  kq_pending_queue_inadmissible(kq_engine* e, int32_t n, const int32_t* cq);
+/* state[W] (KQ_WL_*) and counts[4] per state; both optional. */
+int  kq_pending_read_state(kq_engine* e, uint8_t* state, int32_t* counts);
+
 /* Closed-loop driver support ("a run" applies decisions to the snapshot between cycles).
  * kq_cycle_commit folds the usage of every workload the LAST cycle admitted into the resident snapshot — what
  * cache.AssumeWorkload leaves in the cache (pkg/cache/scheduler/clusterqueue.go:594 updateWorkloadUsage ->
@@ -275,7 +319,11 @@ int  kq_cycle_run_resident(kq_engine* e, int32_t batch, kq_decisions* out);
  * commit `age` commits ago added (age = 1: the latest), i.e. those workloads finish. Preempt-mode reservations
  * and DeferredFit usage are per-cycle simulation state and are not committed. The admitted-workload table used for
  * preemption candidates is not extended; callers that need it re-upload the snapshot.
- * *n_admitted (optional) receives the number of workloads folded in. Ring depth KQ_COMMIT_RING. */
+ * *n_admitted (optional) receives the number of workloads folded in. Ring depth KQ_COMMIT_RING.
+ * With a pending set resident (kq_pending_put), a release that frees quota also does what the cache's notification does in the
+ * reference (QueueAssociatedInadmissibleWorkloadsAfter -> requeueWorkloadsCohort, inadmissible_workloads.go:112-147): every ClusterQueue
+ * under the ROOT cohort of a ClusterQueue whose workloads finished runs queueInadmissibleWorkloads. A release of a commit that
+ * admitted nothing is no event and requeues nothing. */
 #define KQ_COMMIT_RING 32
 int  kq_cycle_commit(kq_engine* e, int32_t* n_admitted);
 int  kq_cycle_release(kq_engine* e, int32_t age);

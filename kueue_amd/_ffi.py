@@ -31,6 +31,7 @@ KQ_GATE_FS_PRIORITIZE_NON_BORROWING = 1 << 5
 KQ_GATE_RECOMPUTE_ON_OVERLAP = 1 << 6
 KQ_GATE_PRIORITIZE_PREEMPTORS = 1 << 7
 KQ_GATE_QUOTA_CHECK_STRATEGY = 1 << 8
+KQ_GATE_SCHEDULING_EQUIVALENCE_HASHING = 1 << 9
 KQ_GATES_DEFAULT = (
     KQ_GATE_FLAVOR_FUNGIBILITY
     | KQ_GATE_PRESERVE_SCAN_PROGRESS
@@ -40,8 +41,10 @@ KQ_GATES_DEFAULT = (
     | KQ_GATE_FS_PRIORITIZE_NON_BORROWING
     | KQ_GATE_RECOMPUTE_ON_OVERLAP
     | KQ_GATE_QUOTA_CHECK_STRATEGY
+    | KQ_GATE_SCHEDULING_EQUIVALENCE_HASHING
 )
 GATE_BY_NAME = {
+    "SchedulingEquivalenceHashing": KQ_GATE_SCHEDULING_EQUIVALENCE_HASHING,
     "FlavorFungibility": KQ_GATE_FLAVOR_FUNGIBILITY,
     "FlavorFungibilityPreserveScanProgress": KQ_GATE_PRESERVE_SCAN_PROGRESS,
     "PartialAdmission": KQ_GATE_PARTIAL_ADMISSION,
@@ -135,6 +138,13 @@ class kq_heads(C.Structure):
     ]
 
 
+class kq_pending(C.Structure):
+    _fields_ = [("w", kq_heads), ("uid_rank", u32p)]
+
+
+WL_ACTIVE, WL_INFLIGHT, WL_INADMISSIBLE, WL_GONE = 0, 1, 2, 3
+
+
 class kq_decisions(C.Structure):
     _fields_ = [
         ("status", u8p), ("action", u8p), ("nominated_mode", u8p), ("mode", u8p),
@@ -207,6 +217,16 @@ def load_engine():
     lib.kq_heads_put.restype = C.c_int
     lib.kq_cycle_run_resident.argtypes = [C.c_void_p, C.c_int32, C.POINTER(kq_decisions)]
     lib.kq_cycle_run_resident.restype = C.c_int
+    lib.kq_nominate_run_resident.argtypes = [C.c_void_p, C.c_int32, C.POINTER(kq_decisions)]
+    lib.kq_nominate_run_resident.restype = C.c_int
+    lib.kq_pending_put.argtypes = [C.c_void_p, C.POINTER(kq_pending)]
+    lib.kq_pending_heads.argtypes = [C.c_void_p, C.c_int64, u8p, i32p, i32p, i32p]
+    lib.kq_cycle_run_pending.argtypes = [C.c_void_p, C.POINTER(kq_decisions)]
+    lib.kq_pending_apply.argtypes = [C.c_void_p]
+    lib.kq_pending_queue_inadmissible.argtypes = [C.c_void_p, C.c_int32, i32p]
+    lib.kq_pending_read_state.argtypes = [C.c_void_p, u8p, i32p]
+    for f in ("kq_pending_put", "kq_pending_heads", "kq_cycle_run_pending", "kq_pending_apply", "kq_pending_queue_inadmissible", "kq_pending_read_state"):
+        getattr(lib, f).restype = C.c_int
     lib.kq_last_cycle_phases.argtypes = [C.c_void_p, f64p, i64p]
     lib.kq_last_cycle_phases.restype = C.c_int
     lib.kq_last_cycle_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -233,6 +253,7 @@ def load_engine():
 ABI_SYMBOLS = [
     "kq_engine_create", "kq_engine_destroy", "kq_snapshot_put", "kq_cycle_run", "kq_last_cycle_stats",
     "kq_cycle_commit", "kq_cycle_release", "kq_snapshot_derive", "kq_snapshot_read_planes", "kq_strerror", "kq_last_error", "kq_abi_version",
-    "kq_heads_put", "kq_cycle_run_resident", "kq_last_cycle_phases",
+    "kq_heads_put", "kq_cycle_run_resident", "kq_nominate_run_resident", "kq_last_cycle_phases",
+    "kq_pending_put", "kq_pending_heads", "kq_cycle_run_pending", "kq_pending_apply", "kq_pending_queue_inadmissible", "kq_pending_read_state",
     "kq_debug_read_usage_work", "kq_debug_force_exact_drs", "kq_debug_prof", "kq_debug_disable_scan_search",
 ]

@@ -557,12 +557,51 @@ class Heads:
         return self._struct
 
 
+class Pending:
+    """kq_pending: every pending workload of every ClusterQueue (the heaps of pkg/cache/queue), as one heads-shaped table
+    plus the UID ranks baseCompareFunc breaks ties with (cluster_queue.go:873)."""
+
+    def __init__(self, heads: Heads, uid_rank: Optional[np.ndarray] = None):
+        self.heads = heads
+        self.snap = heads.snap
+        self.n = heads.n
+        self.uid_rank = np.ascontiguousarray(uid_rank if uid_rank is not None else np.arange(heads.n), dtype=np.uint32)
+        self._struct = None
+
+    def struct(self) -> F.kq_pending:
+        if self._struct is None:
+            p = F.kq_pending()
+            F.fill_struct(p.w, self.heads.arrays, dict(n=self.heads.n, cycle=0))
+            pad = self.uid_rank if self.uid_rank.size else np.zeros(1, np.uint32)
+            self._pad = pad
+            p.uid_rank = F.ptr(pad)
+            self._struct = p
+        return self._struct
+
+    def heads_of(self, wl: np.ndarray, cycle: int) -> "Heads":
+        """The kq_heads batch of the workloads `wl` with their STATIC columns (resume state left at its initial value)."""
+        a = self.heads.arrays
+        nR, nfw = self.snap.n_resource, (self.snap.n_flavor + 63) // 64
+        ps0, ps1 = a["ps_off"][wl], a["ps_off"][wl + 1]
+        nps = ps1 - ps0
+        ps_idx = np.concatenate([np.arange(x, y) for x, y in zip(ps0, ps1)]) if len(wl) else np.zeros(0, np.int64)
+        r0, r1 = a["ps_req_off"][ps_idx], a["ps_req_off"][ps_idx + 1]
+        req_idx = np.concatenate([np.arange(x, y) for x, y in zip(r0, r1)]) if len(ps_idx) else np.zeros(0, np.int64)
+        rows = lambda name, w: a[name].reshape(-1, w)[ps_idx].reshape(-1)
+        b = dict(cq=a["cq"][wl], priority=a["priority"][wl], queue_ts=a["queue_ts"][wl], flags=a["flags"][wl].copy(),
+                 ps_off=np.concatenate([[0], np.cumsum(nps)]).astype(np.int32), ps_count=a["ps_count"][ps_idx], ps_min_count=a["ps_min_count"][ps_idx],
+                 ps_req_off=np.concatenate([[0], np.cumsum(r1 - r0)]).astype(np.int32), req_res=a["req_res"][req_idx], req_qty=a["req_qty"][req_idx],
+                 ps_flavor_ok=rows("ps_flavor_ok", nfw), ps_last_tried=rows("ps_last_tried", nR).copy(),
+                 last_generation=a["last_generation"][wl].copy(), last_cycle=a["last_cycle"][wl].copy(), last_hash=a["last_hash"][wl].copy(), hash=a["hash"][wl])
+        return Heads.from_arrays(self.snap, b, cycle=cycle)
+
+
 class Decisions:
     """Caller-allocated kq_decisions buffers + decoded views."""
 
-    def __init__(self, heads: Heads, tgt_cap: Optional[int] = None):
+    def __init__(self, heads: Heads, tgt_cap: Optional[int] = None, n: Optional[int] = None, n_ps: Optional[int] = None):
         snap = heads.snap
-        n, nps, nR = heads.n, heads.n_ps, snap.n_resource
+        n, nps, nR = (heads.n if n is None else n), (heads.n_ps if n_ps is None else n_ps), snap.n_resource
         cap = tgt_cap if tgt_cap is not None else max(16, snap.n_adm * max(1, min(heads.n, 8)))  # every head may name most rows
         self.heads, self.snap = heads, snap
         self.a = dict(

@@ -3480,3 +3480,4 @@ KQ_DEV bool entry_before(const K& k, int a, int b) {
   return a < b;  // canonical stable order
 }
 }  // namespace kq
+#include "kq_pending.hpp"

@@ -202,6 +202,26 @@ __global__ __launch_bounds__(64) void k_tas_fits(TTopo T, int n, const int32_t* 
   if (i < n) t_fits_cell(T, i, leaf, count, spr, flag);
 }
 
+// pending side on the device (kq_pending.hpp): Heads() = pop per ClusterQueue + compaction + gather; requeue from the decisions
+__global__ __launch_bounds__(64) void k_pend_pop(DPend D) { pend_pop(D, blockIdx.x); }
+constexpr int PEND_SCAN_THREADS = 1024;
+__global__ __launch_bounds__(PEND_SCAN_THREADS) void k_pend_scan(DPend D, DGather G) {
+  __shared__ int32_t scan3[3 * PEND_SCAN_THREADS];
+  pend_scan(D, G, (int)threadIdx.x, PEND_SCAN_THREADS, scan3);
+}
+__global__ __launch_bounds__(64) void k_pend_gather(DPend D, DGather G) { if ((int)blockIdx.x < D.counts[0]) pend_gather_head(D, G, blockIdx.x); }
+__global__ __launch_bounds__(64) void k_pend_apply(DPend D, DSnap S, DOut O, DHeads H, uint32_t gates, int64_t cycle) {
+  pend_apply_head(D, S, O, H, gates, cycle, blockIdx.x);
+}
+__global__ __launch_bounds__(64) void k_pend_qi(DPend D, const int32_t* list) { pend_queue_inadmissible(D, list ? list[blockIdx.x] : (int)blockIdx.x); }
+
+__global__ __launch_bounds__(256) void k_pend_release_mark(DSnap S, int32_t* tree_stamp, const int32_t* cq, const int32_t* use_n, int n, int32_t stamp) {
+  pend_release_mark(S, tree_stamp, cq, use_n, n, blockIdx.x * 256 + threadIdx.x, stamp);
+}
+__global__ __launch_bounds__(64) void k_pend_release_requeue(DPend D, DSnap S, const int32_t* tree_stamp, int32_t stamp) {
+  pend_release_requeue(D, S, tree_stamp, blockIdx.x, stamp);
+}
+
 namespace kq {
 struct HipBackend {
   hipStream_t stream = nullptr;
@@ -329,6 +349,27 @@ struct HipBackend {
     hipLaunchKernelGGL(k_fs_pos, dim3((k.S.N + 255) / 256), dim3(256), 0, stream, d);
     chk(hipGetLastError(), "k_fs_sums");
   }
+  void launch_pend_heads(const DPend& D, const DGather& G) {
+    if (D.nq == 0) return;
+    hipLaunchKernelGGL(k_pend_pop, dim3(D.nq), dim3(64), 0, stream, D);
+    hipLaunchKernelGGL(k_pend_scan, dim3(1), dim3(PEND_SCAN_THREADS), 0, stream, D, G);
+    hipLaunchKernelGGL(k_pend_gather, dim3(D.nq), dim3(64), 0, stream, D, G);
+    chk(hipGetLastError(), "k_pend_heads");
+  }
+  void launch_pend_apply(const DPend& D, const DSnap& S, const DOut& O, const DHeads& H, uint32_t gates, int64_t cycle, int n) {
+    hipLaunchKernelGGL(k_pend_apply, dim3(n), dim3(64), 0, stream, D, S, O, H, gates, cycle);
+    chk(hipGetLastError(), "k_pend_apply");
+  }
+  void launch_pend_qi(const DPend& D, const int32_t* list, int n) {
+    if (n > 0) hipLaunchKernelGGL(k_pend_qi, dim3(n), dim3(64), 0, stream, D, list);
+    chk(hipGetLastError(), "k_pend_qi");
+  }
+  void launch_pend_release(const DPend& D, const DSnap& S, int32_t* tree_stamp, const int32_t* cq, const int32_t* use_n, int n, int32_t stamp) {
+    if (n <= 0 || D.nq == 0) return;
+    hipLaunchKernelGGL(k_pend_release_mark, dim3((n + 255) / 256), dim3(256), 0, stream, S, tree_stamp, cq, use_n, n, stamp);
+    hipLaunchKernelGGL(k_pend_release_requeue, dim3(D.nq), dim3(64), 0, stream, D, S, (const int32_t*)tree_stamp, stamp);
+    chk(hipGetLastError(), "k_pend_release");
+  }
   size_t lds_attr_nom = 0;
   void launch_nominate(const K& k, int slots, size_t lds) {
     if (lds > 48 * 1024 && lds != lds_attr_nom) {
@@ -415,6 +456,7 @@ int kq_engine_create(const kq_config* cfg, kq_engine** out) {
 void kq_engine_destroy(kq_engine* en) {
   if (!en) return;
   (void)hipSetDevice(en->e.be.device);
+  en->e.pending_free();
   en->e.free_snapshot();
   HipBackend be = en->e.be;
   delete en;
@@ -443,6 +485,43 @@ int kq_cycle_run_resident(kq_engine* en, int32_t batch, kq_decisions* out) {
   if (!en || !out || batch < 0) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
   return en->e.cycle_exec(batch + 1, out);
+}
+
+int kq_nominate_run_resident(kq_engine* en, int32_t batch, kq_decisions* out) {
+  if (!en || !out || batch < 0) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.cycle_exec(batch + 1, out, true);
+}
+
+int kq_pending_put(kq_engine* en, const kq_pending* p) {
+  if (!en || !p) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.pending_put(p);
+}
+int kq_pending_heads(kq_engine* en, int64_t cycle, const uint8_t* cq_active, int32_t* n_heads, int32_t* n_podsets, int32_t* head_wl) {
+  if (!en) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.pending_heads(cycle, cq_active, n_heads, n_podsets, head_wl);
+}
+int kq_cycle_run_pending(kq_engine* en, kq_decisions* out) {
+  if (!en || !out) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.cycle_run_pending(out);
+}
+int kq_pending_apply(kq_engine* en) {
+  if (!en) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.pending_apply();
+}
+int kq_pending_queue_inadmissible(kq_engine* en, int32_t n, const int32_t* cq) {
+  if (!en) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.pending_queue_inadmissible(n, cq);
+}
+int kq_pending_read_state(kq_engine* en, uint8_t* state, int32_t* counts) {
+  if (!en) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.pending_read_state(state, counts);
 }
 
 int kq_last_cycle_phases(kq_engine* en, double* phase_ms, int64_t* phase_bytes) {

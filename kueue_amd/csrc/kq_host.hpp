@@ -51,6 +51,39 @@ template <class B> struct EngineT {
 
   int fail(int code, const std::string& msg) { last_error = msg; return code; }
 
+  // ---- pending side on the device (kq_pending.hpp) ---------------------------------------------------------------------
+  static constexpr int PEND_SLOT = 4098;  // head batch the gathered heads live in (beyond every caller-visible batch id)
+  struct Pending {
+    bool valid = false;
+    int W = 0, nq = 0, nR = 0, nF = 0, n_tree = 0, slot_cap = 1;
+    bool plain = true;
+    std::vector<void*> allocs;
+    DPend D{};
+    DGather G{};
+    int n_heads = -1;        // heads of the cycle in flight (popped, not applied yet); -1 = none
+    int n_ps = 0;
+    bool ran = false;        // kq_cycle_run_pending succeeded on those heads
+    int64_t cycle = 0;
+    DOut O{};
+    DHeads H{};
+    uint8_t* d_active = nullptr;
+    int32_t* d_list = nullptr;
+    int32_t* d_tree_stamp = nullptr;  // [n_tree] last release that freed quota in the tree
+    int32_t release_seq = 0;
+  } pend;
+  template <class T> T* pend_alloc(size_t n, const T* host = nullptr, int fill = -2) {
+    T* d = (T*)be.alloc(std::max<size_t>(n, 1) * sizeof(T));
+    if (host && n) be.h2d(d, host, n * sizeof(T));
+    else if (fill != -2) be.memset(d, fill, std::max<size_t>(n, 1) * sizeof(T));
+    pend.allocs.push_back(d);
+    return d;
+  }
+  void pending_free() {
+    for (void* p : pend.allocs) be.free(p);
+    pend = Pending{};
+    if ((int)batches.size() > PEND_SLOT) batches[PEND_SLOT].valid = false;
+  }
+
   template <class T> T* upload(const T* host, size_t n) {
     T* d = (T*)be.alloc(std::max<size_t>(n, 1) * sizeof(T));
     if (n) be.h2d(d, host, n * sizeof(T));
@@ -73,6 +106,7 @@ template <class B> struct EngineT {
     have_snapshot = false;
   }
   ~EngineT() {
+    pending_free();
     free_snapshot();
     if (hstage) be.free_host(hstage);
     if (hup) be.free_host(hup);
@@ -90,9 +124,11 @@ template <class B> struct EngineT {
     commits = 0; last_cycle_n = -1;
     // Resident head batches were validated against, and carry the strides of, the snapshot they were uploaded under
     // (cq < nq, req_res < nR, ps_flavor_ok / ps_last_tried row widths): a new snapshot voids them. kq_heads_put again.
-    for (auto& hbch : batches) hbch.valid = false;
+    for (size_t b = 0; b < batches.size(); b++) if ((int)b != PEND_SLOT) batches[b].valid = false;
     int rc = build_prep(s, prep);
     if (rc != KQ_OK) return fail(rc, prep.err);
+    // the pending store is indexed by ClusterQueue / resource / flavor: it survives a snapshot refresh with the same dictionary
+    if (pend.valid && (pend.nq != prep.nq || pend.nR != prep.nR || pend.nF != prep.nF || pend.n_tree != prep.n_tree)) pending_free();
     const size_t N = prep.N, nfr = prep.nfr, nq = prep.nq;
     S = DSnap{};
     S.nq = prep.nq; S.nc = prep.nc; S.N = prep.N; S.nF = prep.nF; S.nR = prep.nR; S.nfr = prep.nfr;
@@ -220,6 +256,8 @@ template <class B> struct EngineT {
     if (c.n > 0) {
       DCommit dc{c.n, (const int32_t*)c.cq.p, (const int32_t*)c.use_n.p, (const int32_t*)c.use_fr.p, (const int64_t*)c.use_qty.p, d_usage, d_big};
       apply_commit(dc, false);
+      // the finished workloads freed quota: inadmissible workloads of their root cohorts go back to the heaps
+      if (pend.valid && pend.nq == prep.nq) be.launch_pend_release(pend.D, S, pend.d_tree_stamp, dc.cq, dc.use_n, c.n, ++pend.release_seq);
     }
     c.live = false;
     return KQ_OK;
@@ -343,7 +381,9 @@ template <class B> struct EngineT {
     return cycle_exec(0, out);
   }
 
-  int cycle_exec(int slot, kq_decisions* out) {
+  // nominate_only: stop after k_nominate (kq_nominate_run_resident: flavor assignment + targets for every head of the batch,
+  // no iterator, no processEntry; nothing to commit afterwards)
+  int cycle_exec(int slot, kq_decisions* out, bool nominate_only = false) {
     if (!have_snapshot) return fail(KQ_EINVAL, "kq_cycle_run before kq_snapshot_put");
     if (slot < 0 || slot >= (int)batches.size() || !batches[slot].valid) return fail(KQ_EINVAL, "unknown head batch");
     HeadBatch& hbch = batches[slot];
@@ -352,7 +392,7 @@ template <class B> struct EngineT {
     int rc = KQ_OK;
     if (out->tgt_off) out->tgt_off[0] = 0;
     if (n == 0) {
-      last_kernel_ms = 0; last_bytes = 0; last_cycle_n = 0;
+      last_kernel_ms = 0; last_bytes = 0; last_cycle_n = nominate_only ? -1 : 0;
       flush_levels();
       be.d2d(grow<int64_t>(b_usage_work, (size_t)prep.N * prep.nfr), d_usage, (size_t)prep.N * prep.nfr * sizeof(int64_t));
       return be.sync();
@@ -468,12 +508,13 @@ template <class B> struct EngineT {
       if (nom_lds > 78 * 1024) nom_lds = std::min<size_t>(cs_bytes(1, prep.cs_max_bucket, prep.max_tree_nodes, prep.max_tree_cqs, false), 78 * 1024);
     }
     be.launch_nominate(k, slots_nom, nom_lds);
-    be.launch_records(k);  // entry records (static part) for k_process; charged to the nominate interval
+    if (!nominate_only) be.launch_records(k);  // entry records (static part) for k_process; charged to the nominate interval
     be.timer_mark(1);
-    if (!cfg.fair_sharing) be.launch_order(k, order_idx, rank);
+    if (!cfg.fair_sharing && !nominate_only) be.launch_order(k, order_idx, rank);
     be.timer_mark(2);
     k.O.stat_bytes = (long long*)(misc + 2);
-    if (cfg.fair_sharing) be.launch_process_fair(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16, rank);
+    if (nominate_only) {}
+    else if (cfg.fair_sharing) be.launch_process_fair(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16, rank);
     else be.launch_process(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16);
     be.timer_mark(3);
     last_cycle_n = -1;  // set on the success path only: a failed cycle must not be committable
@@ -512,7 +553,8 @@ template <class B> struct EngineT {
     int tot = 0;
     if (pool_used == 0) {  // no preemption anywhere in this cycle
       if (out->tgt_off) memset(out->tgt_off, 0, (size_t)(n + 1) * sizeof(int32_t));
-      last_cycle_n = n; last_O = k.O; last_slot = slot;
+      if (!nominate_only) { last_cycle_n = n; last_O = k.O; last_slot = slot; }
+      if (slot == PEND_SLOT && !nominate_only) { pend.O = k.O; pend.H = k.H; pend.ran = true; }
       return KQ_OK;
     }
     for (int i = 0; i < n; i++) {
@@ -528,7 +570,143 @@ template <class B> struct EngineT {
       }
     }
     if (out->tgt_off) out->tgt_off[n] = tot;
-    last_cycle_n = n; last_O = k.O; last_slot = slot;
+    if (!nominate_only) { last_cycle_n = n; last_O = k.O; last_slot = slot; }
+    if (slot == PEND_SLOT && !nominate_only) { pend.O = k.O; pend.H = k.H; pend.ran = true; }
+    return KQ_OK;
+  }
+
+  // ---- pending side: host orchestration ----------------------------------------------------------------------------
+  int pending_put(const kq_pending* p) {
+    if (!have_snapshot) return fail(KQ_EINVAL, "kq_pending_put before kq_snapshot_put");
+    const kq_heads* h = &p->w;
+    int slot_cap = 1; bool plain = true;
+    int rc = validate_heads(h, &slot_cap, &plain);
+    if (rc != KQ_OK) return rc;
+    pending_free();
+    const int W = h->n, nq = prep.nq, nR = prep.nR;
+    const size_t nfw = (prep.nF + 63) / 64;
+    const size_t nps = W ? h->ps_off[W] : 0, nreq = nps ? h->ps_req_off[nps] : 0;
+    // heap order of every ClusterQueue (baseCompareFunc cluster_queue.go:844 without the sticky term): priority descending,
+    // queue-order timestamp ascending, UID ascending — static while the workloads are pending
+    std::vector<int32_t> ord(W), cq_off(nq + 1, 0);
+    for (int w = 0; w < W; w++) { ord[w] = w; cq_off[h->cq[w] + 1]++; }
+    for (int c = 0; c < nq; c++) cq_off[c + 1] += cq_off[c];
+    std::sort(ord.begin(), ord.end(), [&](int a, int b) {
+      if (h->cq[a] != h->cq[b]) return h->cq[a] < h->cq[b];
+      if (h->priority[a] != h->priority[b]) return h->priority[a] > h->priority[b];
+      if (h->queue_ts[a] != h->queue_ts[b]) return h->queue_ts[a] < h->queue_ts[b];
+      const uint32_t ua = p->uid_rank ? p->uid_rank[a] : (uint32_t)a, ub = p->uid_rank ? p->uid_rank[b] : (uint32_t)b;
+      if (ua != ub) return ua < ub;
+      return a < b;
+    });
+    // the gathered batch holds <= 1 head per ClusterQueue: size it for the widest workload of every ClusterQueue
+    std::vector<int> mps(nq, 0), mrq(nq, 0);
+    for (int w = 0; w < W; w++) {
+      const int c = h->cq[w], a = h->ps_off[w + 1] - h->ps_off[w], b = h->ps_req_off[h->ps_off[w + 1]] - h->ps_req_off[h->ps_off[w]];
+      mps[c] = std::max(mps[c], a); mrq[c] = std::max(mrq[c], b);
+    }
+    size_t gps = 0, grq = 0;
+    for (int c = 0; c < nq; c++) { gps += mps[c]; grq += mrq[c]; }
+    Pending& P = pend;
+    P.W = W; P.nq = nq; P.nR = nR; P.nF = prep.nF; P.n_tree = prep.n_tree; P.slot_cap = slot_cap; P.plain = plain;
+    DPend& D = P.D;
+    D.W = W; D.nq = nq; D.nR = nR; D.nfw = (int)nfw;
+    DHeads& S0 = D.P;
+    S0.n = W;
+    S0.cq = pend_alloc(W, h->cq); S0.priority = pend_alloc(W, h->priority); S0.queue_ts = pend_alloc(W, h->queue_ts);
+    S0.flags = pend_alloc(W, h->flags); S0.ps_off = pend_alloc(W + 1, h->ps_off);
+    S0.ps_count = pend_alloc(nps, h->ps_count);
+    S0.ps_min_count = pend_alloc<int32_t>(nps, h->ps_min_count, 0xff);
+    S0.ps_req_off = pend_alloc(nps + 1, h->ps_req_off);
+    S0.req_res = pend_alloc(nreq, h->req_res); S0.req_qty = pend_alloc(nreq, h->req_qty);
+    S0.ps_flavor_ok = pend_alloc(nps * nfw, h->ps_flavor_ok);
+    S0.ps_last_tried = nullptr; S0.last_generation = nullptr; S0.last_cycle = nullptr; S0.last_hash = nullptr;
+    S0.hash = pend_alloc<uint64_t>(W, h->hash, 0);
+    D.uid = pend_alloc<uint32_t>(W, p->uid_rank, 0);
+    D.cq_off = pend_alloc(nq + 1, cq_off.data()); D.ord = pend_alloc(W, ord.data());
+    D.state = pend_alloc<uint8_t>(W, nullptr, 0);  // WL_ACTIVE
+    D.mflags = pend_alloc(W, h->flags);
+    D.last_tried = pend_alloc<int32_t>(nps * nR, h->ps_last_tried, 0xff);
+    D.last_gen = pend_alloc<int64_t>(W, h->last_generation, 0); D.last_cycle = pend_alloc<int64_t>(W, h->last_cycle, 0);
+    D.last_hash = pend_alloc<uint64_t>(W, h->last_hash, 0);
+    D.pw = pend_alloc<int32_t>(nq, nullptr, 0xff); D.pw_sticky = pend_alloc<uint8_t>(nq, nullptr, 0);
+    D.pop_cycle = pend_alloc<int64_t>(nq, nullptr, 0); D.qi_cycle = pend_alloc<int64_t>(nq, nullptr, 0xff);
+    D.head_wl = pend_alloc<int32_t>(nq, nullptr, 0xff); D.hd = pend_alloc<int32_t>(nq, nullptr, 0); D.hreq = pend_alloc<int32_t>(nq, nullptr, 0);
+    D.counts = pend_alloc<int32_t>(4, nullptr, 0);
+    D.cq_active = nullptr;
+    P.d_active = pend_alloc<uint8_t>(nq, nullptr, 1);
+    P.d_list = pend_alloc<int32_t>(nq, nullptr, 0);
+    P.d_tree_stamp = pend_alloc<int32_t>(std::max(prep.n_tree, 1), nullptr, 0);
+    DGather& G = P.G;
+    G.cq = pend_alloc<int32_t>(nq); G.priority = pend_alloc<int64_t>(nq); G.queue_ts = pend_alloc<int64_t>(nq); G.flags = pend_alloc<uint32_t>(nq);
+    G.ps_off = pend_alloc<int32_t>(nq + 1);
+    G.ps_count = pend_alloc<int32_t>(gps); G.ps_min_count = pend_alloc<int32_t>(gps); G.ps_req_off = pend_alloc<int32_t>(gps + 1);
+    G.req_res = pend_alloc<int32_t>(grq); G.req_qty = pend_alloc<int64_t>(grq);
+    G.ps_flavor_ok = pend_alloc<uint64_t>(gps * nfw); G.ps_last_tried = pend_alloc<int32_t>(gps * nR);
+    G.last_generation = pend_alloc<int64_t>(nq); G.last_cycle = pend_alloc<int64_t>(nq);
+    G.last_hash = pend_alloc<uint64_t>(nq); G.hash = pend_alloc<uint64_t>(nq);
+    rc = be.sync();
+    if (rc != KQ_OK) { pending_free(); return fail(rc, be.error()); }
+    P.valid = true; P.n_heads = -1; P.ran = false;
+    return KQ_OK;
+  }
+  int pending_heads(int64_t cycle, const uint8_t* cq_active, int32_t* n_heads, int32_t* n_podsets, int32_t* head_wl) {
+    if (!have_snapshot || !pend.valid) return fail(KQ_EINVAL, "kq_pending_heads before kq_pending_put");
+    if (pend.n_heads >= 0) return fail(KQ_EINVAL, "kq_pending_heads: the previous heads were not applied (kq_pending_apply)");
+    Pending& P = pend;
+    if (cq_active) { be.h2d(P.d_active, cq_active, P.nq); P.D.cq_active = P.d_active; } else P.D.cq_active = nullptr;
+    be.launch_pend_heads(P.D, P.G);
+    int32_t counts[4] = {0, 0, 0, 0};
+    be.d2h(counts, P.D.counts, sizeof(counts));
+    if (head_wl) be.d2h(head_wl, P.D.head_wl, (size_t)P.nq * sizeof(int32_t));
+    int rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    P.n_heads = counts[0]; P.n_ps = counts[1]; P.ran = false; P.cycle = cycle;
+    if ((int)batches.size() <= PEND_SLOT) batches.resize(PEND_SLOT + 1);
+    HeadBatch& hb = batches[PEND_SLOT];
+    if (last_slot == PEND_SLOT) last_cycle_n = -1;  // the previous cycle's head arrays were just overwritten
+    hb.n = P.n_heads; hb.nps = (size_t)P.n_ps; hb.slot_cap = P.slot_cap; hb.cycle = cycle; hb.valid = true; hb.plain = P.plain;
+    DHeads& H = hb.H; const DGather& G = P.G;
+    H.n = P.n_heads; H.cq = G.cq; H.priority = G.priority; H.queue_ts = G.queue_ts; H.flags = G.flags; H.ps_off = G.ps_off;
+    H.ps_count = G.ps_count; H.ps_min_count = G.ps_min_count; H.ps_req_off = G.ps_req_off; H.req_res = G.req_res; H.req_qty = G.req_qty;
+    H.ps_flavor_ok = G.ps_flavor_ok; H.ps_last_tried = G.ps_last_tried; H.last_generation = G.last_generation; H.last_cycle = G.last_cycle;
+    H.last_hash = G.last_hash; H.hash = G.hash;
+    if (n_heads) *n_heads = P.n_heads;
+    if (n_podsets) *n_podsets = P.n_ps;
+    return KQ_OK;
+  }
+  int cycle_run_pending(kq_decisions* out) {
+    if (!pend.valid || pend.n_heads < 0) return fail(KQ_EINVAL, "kq_cycle_run_pending before kq_pending_heads");
+    return cycle_exec(PEND_SLOT, out);
+  }
+  int pending_apply() {
+    if (!pend.valid || pend.n_heads < 0) return fail(KQ_EINVAL, "kq_pending_apply: no heads in flight");
+    if (pend.n_heads > 0 && !pend.ran) return fail(KQ_EINVAL, "kq_pending_apply: the cycle over these heads did not run");
+    if (pend.n_heads > 0) be.launch_pend_apply(pend.D, S, pend.O, pend.H, cfg.gates, pend.cycle, pend.n_heads);
+    pend.n_heads = -1; pend.ran = false;
+    return KQ_OK;  // stream-ordered with the next kq_pending_heads
+  }
+  int pending_queue_inadmissible(int n, const int32_t* cq) {
+    if (!pend.valid) return fail(KQ_EINVAL, "kq_pending_queue_inadmissible before kq_pending_put");
+    if (cq) {
+      if (n < 0 || n > pend.nq) return fail(KQ_EINVAL, "bad ClusterQueue list");
+      for (int i = 0; i < n; i++) if (cq[i] < 0 || cq[i] >= pend.nq) return fail(KQ_EINVAL, "ClusterQueue out of range");
+      if (n == 0) return KQ_OK;
+      be.h2d(pend.d_list, cq, (size_t)n * sizeof(int32_t));
+      be.launch_pend_qi(pend.D, pend.d_list, n);
+      return be.sync();  // the caller's list may go away
+    }
+    be.launch_pend_qi(pend.D, nullptr, pend.nq);
+    return KQ_OK;
+  }
+  int pending_read_state(uint8_t* state, int32_t* counts) {
+    if (!pend.valid) return fail(KQ_EINVAL, "kq_pending_read_state before kq_pending_put");
+    std::vector<uint8_t> st(std::max(pend.W, 1));
+    be.d2h(st.data(), pend.D.state, pend.W);
+    int rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    if (state) memcpy(state, st.data(), pend.W);
+    if (counts) { counts[0] = counts[1] = counts[2] = counts[3] = 0; for (int w = 0; w < pend.W; w++) counts[st[w] & 3]++; }
     return KQ_OK;
   }
 

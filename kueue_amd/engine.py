@@ -72,6 +72,45 @@ class Engine:
             self._check(rc)
         return rc
 
+    def nominate_resident(self, batch: int, out: Decisions) -> Decisions:
+        """kq_nominate_run_resident: Scheduler.nominate for every head of a resident batch (no iterator, no processEntry)."""
+        self._check(self._lib.kq_nominate_run_resident(self._h, batch, C.byref(out.struct())))
+        return out
+
+    # ---- pending side on the device (pkg/cache/queue) -------------------------------------------------------------
+    def pending_put(self, pending):
+        """kq_pending_put: PushOrUpdate of every pending workload."""
+        self._check(self._lib.kq_pending_put(self._h, C.byref(pending.struct())))
+        self.pending = pending
+
+    def pending_heads(self, cycle: int, cq_active: Optional[np.ndarray] = None):
+        """kq_pending_heads = queues.Heads(): -> (n_heads, n_podsets, head_wl[n_cq])."""
+        n, nps = C.c_int32(), C.c_int32()
+        hw = np.full(self.snap.n_cq, -1, np.int32)
+        act = None if cq_active is None else F.ptr(np.ascontiguousarray(cq_active, np.uint8))
+        self._check(self._lib.kq_pending_heads(self._h, cycle, act, C.byref(n), C.byref(nps), F.ptr(hw)))
+        return n.value, nps.value, hw
+
+    def run_pending(self, out: Decisions) -> Decisions:
+        self._check(self._lib.kq_cycle_run_pending(self._h, C.byref(out.struct())))
+        return out
+
+    def pending_apply(self):
+        self._check(self._lib.kq_pending_apply(self._h))
+
+    def pending_queue_inadmissible(self, cqs=None):
+        if cqs is None:
+            self._check(self._lib.kq_pending_queue_inadmissible(self._h, 0, None))
+        else:
+            a = np.ascontiguousarray(cqs, np.int32)
+            self._check(self._lib.kq_pending_queue_inadmissible(self._h, len(a), F.ptr(a) if len(a) else None))
+
+    def pending_state(self):
+        st = np.zeros(max(self.pending.n, 1), np.uint8)
+        counts = np.zeros(4, np.int32)
+        self._check(self._lib.kq_pending_read_state(self._h, F.ptr(st), F.ptr(counts)))
+        return st[:self.pending.n], counts
+
     def try_commit(self) -> int:
         return self._lib.kq_cycle_commit(self._h, None)
 

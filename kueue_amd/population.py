@@ -57,6 +57,27 @@ class Population:
         """Every pending workload as one batch ("nominate-all-pending")."""
         return self._heads(np.arange(self.n_pending), cycle)
 
+    def pending(self, hashes: bool = True):
+        """Every pending workload as the device-resident pending set (api.Pending). hashes: a SchedulingHash per workload shape
+        (priority, per-podset count and requests — what computeSchedulingHash digests, workload.go:389), so that equal-shaped workloads
+        of a ClusterQueue form equivalence classes; False leaves the hash unknown (0)."""
+        from .api import Pending
+        hb = self._heads(np.arange(self.n_pending), 1)
+        if hashes:
+            a = hb.arrays
+            h = (a["priority"].astype(np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+            ps_owner = np.repeat(np.arange(hb.n), a["ps_off"][1:] - a["ps_off"][:-1])
+            nreq = int(a["ps_req_off"][1] - a["ps_req_off"][0]) if hb.n_ps else 0
+            q = a["req_qty"].reshape(hb.n_ps, nreq).astype(np.uint64) if nreq else np.zeros((hb.n_ps, 0), np.uint64)
+            ph = a["ps_count"].astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F)
+            for r in range(nreq):
+                ph = (ph ^ (q[:, r] + np.uint64(r + 1))) * np.uint64(0x100000001B3)
+            np.add.at(h, ps_owner, ph)  # order-insensitive over podsets is enough for a synthetic shape id
+            h |= np.uint64(1)           # 0 = SchedulingHashUnknown
+            a["hash"] = h
+            hb._struct = None
+        return Pending(hb, uid_rank=np.arange(hb.n, dtype=np.uint32))
+
     def _heads(self, idx: np.ndarray, cycle: int) -> Heads:
         snap = self.snapshot
         nR, nF = snap.n_resource, snap.n_flavor

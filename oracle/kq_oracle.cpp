@@ -1408,7 +1408,7 @@ struct Scheduler {
   }
 
   // scheduler.go:308-386 steps 3-5
-  void schedule(std::vector<Entry>& entries) {
+  void schedule(std::vector<Entry>& entries, bool nominate_only = false) {
     entries.clear();
     for (int i = 0; i < H->n; i++) {  // nominate :665-705 (gatekeeping branches are host-side)
       Entry e; e.head = loadHead(i);
@@ -1416,6 +1416,7 @@ struct Scheduler {
       e.nominatedMode = e.assignment.RepresentativeMode();
       entries.push_back(std::move(e));
     }
+    if (nominate_only) { for (auto& e : entries) e.finalMode = e.nominatedMode; return; }
     std::set<int> preemptedWorkloads;
     if (sn.cfg.fair_sharing) {
       fairIterate(entries, preemptedWorkloads);
@@ -1533,6 +1534,18 @@ int kqo_cycle_run(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h,
   writeDecisions(sn, h, entries, out, &rc);
   if (stats) { stats[0] = sn.st.cells; stats[1] = sn.st.cell_bytes; stats[2] = sn.st.head_io_bytes; stats[3] = sn.st.entry_bytes; stats[4] = sn.st.victim_bytes; stats[5] = sn.st.drs_bytes; stats[6] = sn.st.discarded_bytes; }
   if (usage_after) memcpy(usage_after, sn.usage.data(), sn.usage.size() * sizeof(int64_t));
+  return rc;
+}
+
+// Scheduler.nominate (scheduler.go:665-705) for every head, nothing else: the checker of kq_nominate_run_resident.
+int kqo_nominate_run(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, kq_decisions* out, int64_t* stats) {
+  Snap sn(*cfg, s);
+  Scheduler sch(sn, h);
+  std::vector<Entry> entries;
+  sch.schedule(entries, true);
+  int rc = KQ_OK;
+  writeDecisions(sn, h, entries, out, &rc);
+  if (stats) { stats[0] = sn.st.cells; stats[1] = sn.st.cell_bytes; stats[2] = sn.st.head_io_bytes; stats[3] = sn.st.entry_bytes; stats[4] = sn.st.victim_bytes; stats[5] = sn.st.drs_bytes; stats[6] = sn.st.discarded_bytes; }
   return rc;
 }
 

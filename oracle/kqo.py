@@ -21,9 +21,7 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(HERE, "kq_oracle.cpp")
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(HERE, "..", "include", "kq_engine.h"))):
-        subprocess.check_call(["make", "-C", HERE, "-s"])
+    subprocess.check_call(["make", "-C", HERE, "-s"] + (["-B"] if force else []))  # a no-op when nothing changed
     return LIB
 
 
@@ -60,6 +58,19 @@ def cycle_run(cfg: F.kq_config, snap: Snapshot, heads: Heads, want_usage: bool =
                    victim_bytes=int(stats[4]), drs_bytes=int(stats[5]), discarded_bytes=int(stats[6]),
                    total=int(stats[1:6].sum() - stats[6]))
     d.usage_after = usage
+    return d
+
+
+def nominate_run(cfg: F.kq_config, snap: Snapshot, heads: Heads, tgt_cap=None):
+    """Scheduler.nominate (scheduler.go:665-705) for every head and nothing else."""
+    d = Decisions(heads, tgt_cap=tgt_cap)
+    stats = np.zeros(7, np.int64)
+    l = lib()
+    l.kqo_nominate_run.restype = C.c_int
+    rc = l.kqo_nominate_run(C.byref(cfg), C.byref(snap.struct()), C.byref(heads.struct()), C.byref(d.struct()), F.ptr(stats))
+    assert rc == 0, rc
+    d.stats = dict(cells=int(stats[0]), cell_bytes=int(stats[1]), head_io_bytes=int(stats[2]), victim_bytes=int(stats[4]), drs_bytes=int(stats[5]),
+                   total=int(stats[1:6].sum() - stats[6]))
     return d
 
 
@@ -269,3 +280,90 @@ def candidates_order(cfg, snap: Snapshot, cq: str, rows):
     out = np.zeros(len(r), np.int32)
     assert lib().kqo_candidates_order(C.byref(cfg), C.byref(snap.struct()), snap.cq_index[cq], len(r), F.ptr(r), F.ptr(out)) == 0
     return out.tolist()
+
+
+class PendingOracle:
+    """pkg/cache/queue restated (oracle/kq_pending_oracle.cpp): the heaps of every ClusterQueue, Heads(), the requeue policy and the
+    LastAssignment bookkeeping between cycles. The checker of the engine's kq_pending_* entry points."""
+
+    def __init__(self, cfg, snap: Snapshot, pending):
+        l = lib()
+        l.kqp_create.restype = C.c_void_p
+        l.kqp_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint32]
+        self.snap, self.pending, self.cfg = snap, pending, cfg
+        self.h = C.c_void_p(l.kqp_create(C.addressof(pending.struct()), snap.n_cq, snap.n_resource, snap.arrays["cq_policy"].ctypes.data, cfg.gates))
+        for f in ("kqp_destroy", "kqp_read_state", "kqp_workload", "kqp_set_last", "kqp_set_state", "kqp_delete"):
+            getattr(l, f).restype = None
+        self.l = l
+
+    def close(self):
+        if self.h:
+            self.l.kqp_destroy(self.h)
+            self.h = None
+
+    def heads(self, cycle: int, cq_active=None):
+        """queues.Heads() -> (Heads batch as the scheduler sees it this cycle, head_wl[n_cq])."""
+        hw = np.full(self.snap.n_cq, -1, np.int32)
+        act = None if cq_active is None else F.ptr(np.ascontiguousarray(cq_active, np.uint8))
+        self.l.kqp_heads(self.h, act, F.ptr(hw))
+        wl = hw[hw >= 0].astype(np.int64)
+        hb = self.pending.heads_of(wl, cycle)
+        a = hb.arrays
+        nR = self.snap.n_resource
+        fl = C.c_uint32(); g = C.c_int64(); cy = C.c_int64(); lh = C.c_uint64()
+        for i, w in enumerate(wl):
+            p0, p1 = int(a["ps_off"][i]), int(a["ps_off"][i + 1])
+            lt = np.zeros(max((p1 - p0) * nR, 1), np.int32)
+            fl.value = int(a["flags"][i])
+            self.l.kqp_workload(self.h, int(w), C.byref(fl), F.ptr(lt), C.byref(g), C.byref(cy), C.byref(lh))
+            a["flags"][i] = fl.value
+            a["ps_last_tried"][p0 * nR:p1 * nR] = lt[:(p1 - p0) * nR]
+            a["last_generation"][i] = g.value; a["last_cycle"][i] = cy.value; a["last_hash"][i] = lh.value
+        hb._struct = None
+        return hb, hw
+
+    def apply(self, heads: Heads, d: Decisions):
+        rc = self.l.kqp_apply(self.h, C.byref(heads.struct()), C.byref(d.struct()), F.ptr(self.snap.arrays["cq_generation"]))
+        assert rc == 0, rc
+
+    def queue_inadmissible(self, cqs=None) -> int:
+        if cqs is None:
+            return self.l.kqp_queue_inadmissible(self.h, 0, None)
+        a = np.ascontiguousarray(cqs, np.int32)
+        return self.l.kqp_queue_inadmissible(self.h, len(a), F.ptr(a) if len(a) else None)
+
+    def state(self) -> np.ndarray:
+        st = np.zeros(max(self.pending.n, 1), np.uint8)
+        self.l.kqp_read_state(self.h, F.ptr(st))
+        return st[:self.pending.n]
+
+    # single operations (transcribed unit tests)
+    def pop(self, cq: int) -> int:
+        return self.l.kqp_pop(self.h, cq)
+
+    def requeue(self, w: int, reason: int, immediate=None) -> bool:
+        return bool(self.l.kqp_requeue(self.h, w, reason, -1 if immediate is None else int(bool(immediate))))
+
+    def set_last(self, w: int, last_tried):
+        if last_tried is None:
+            self.l.kqp_set_last(self.h, w, 0, None)
+        else:
+            a = np.ascontiguousarray(last_tried, np.int32)
+            self.l.kqp_set_last(self.h, w, 1, F.ptr(a))
+
+    def set_state(self, w: int, st: int):
+        self.l.kqp_set_state(self.h, w, st)
+
+    def delete(self, w: int):
+        self.l.kqp_delete(self.h, w)
+
+    def handle_hash(self, cq: int, hash_: int) -> int:
+        self.l.kqp_handle_hash.argtypes = [C.c_void_p, C.c_int32, C.c_uint64]
+        return self.l.kqp_handle_hash(self.h, cq, hash_)
+
+    def is_sticky(self, w: int) -> bool:
+        return bool(self.l.kqp_is_sticky(self.h, w))
+
+    def has_hash(self, cq: int, hash_: int) -> bool:
+        self.l.kqp_has_hash.argtypes = [C.c_void_p, C.c_int32, C.c_uint64]
+        return bool(self.l.kqp_has_hash(self.h, cq, hash_))

@@ -61,6 +61,19 @@ struct EmuBackend {
     for (int n = 0; n < k.S.N; n++) for (int r = 0; r < k.S.nR; r++) fs_sums_cell(k, n, r);
     for (int n = 0; n < k.S.N; n++) fs_pos_node(k, n);
   }
+  void launch_pend_heads(const DPend& D, const DGather& G) {
+    for (int c = 0; c < D.nq; c++) pend_pop(D, c);
+    pend_scan(D, G, 0, 1, nullptr);
+    for (int h = 0; h < D.counts[0]; h++) pend_gather_head(D, G, h);
+  }
+  void launch_pend_apply(const DPend& D, const DSnap& S, const DOut& O, const DHeads& H, uint32_t gates, int64_t cycle, int n) {
+    for (int h = 0; h < n; h++) pend_apply_head(D, S, O, H, gates, cycle, h);
+  }
+  void launch_pend_qi(const DPend& D, const int32_t* list, int n) { for (int i = 0; i < n; i++) pend_queue_inadmissible(D, list ? list[i] : i); }
+  void launch_pend_release(const DPend& D, const DSnap& S, int32_t* tree_stamp, const int32_t* cq, const int32_t* use_n, int n, int32_t stamp) {
+    for (int i = 0; i < n; i++) pend_release_mark(S, tree_stamp, cq, use_n, n, i, stamp);
+    for (int c = 0; c < D.nq; c++) pend_release_requeue(D, S, tree_stamp, c, stamp);
+  }
   void launch_nominate(const K& k, int slots, size_t lds) {
     std::vector<int64_t> region(lds / 8 + 8);
     for (int slot = 0; slot < slots; slot++) {
@@ -149,6 +162,23 @@ void kqe_force_exact_drs(void* e, int on) { ((EmuEngine*)e)->force_exact_drs = o
 int kqe_cycle_run(void* e, const kq_heads* h, kq_decisions* out) { return ((EmuEngine*)e)->cycle_run(h, out); }
 int kqe_heads_put(void* e, const kq_heads* h, int32_t batch) { return batch < 0 ? KQ_EINVAL : ((EmuEngine*)e)->heads_put(h, batch + 1); }
 int kqe_cycle_run_resident(void* e, int32_t batch, kq_decisions* out) { return batch < 0 ? KQ_EINVAL : ((EmuEngine*)e)->cycle_exec(batch + 1, out); }
+int kqe_nominate_run_resident(void* e, int32_t batch, kq_decisions* out) { return batch < 0 ? KQ_EINVAL : ((EmuEngine*)e)->cycle_exec(batch + 1, out, true); }
+int kqe_pending_put(void* e, const kq_pending* p) { return ((EmuEngine*)e)->pending_put(p); }
+int kqe_pending_heads(void* e, int64_t cycle, const uint8_t* act, int32_t* n, int32_t* nps, int32_t* hw) { return ((EmuEngine*)e)->pending_heads(cycle, act, n, nps, hw); }
+int kqe_cycle_run_pending(void* e, kq_decisions* out) { return ((EmuEngine*)e)->cycle_run_pending(out); }
+int kqe_pending_apply(void* e) { return ((EmuEngine*)e)->pending_apply(); }
+int kqe_pending_queue_inadmissible(void* e, int32_t n, const int32_t* cq) { return ((EmuEngine*)e)->pending_queue_inadmissible(n, cq); }
+int kqe_pending_read_state(void* e, uint8_t* st, int32_t* counts) { return ((EmuEngine*)e)->pending_read_state(st, counts); }
+// Transcribed unit tests of the reference's requeue policy through the DEVICE code: the heads in flight get fabricated decisions
+// (status / action / mode / requeue reason per head, tried indices per (podset, resource)) instead of a cycle's.
+int kqe_pending_apply_fabricated(void* ep, const uint8_t* status, const uint8_t* action, const uint8_t* mode, const uint8_t* rq, const int32_t* tried) {
+  EmuEngine& e = *(EmuEngine*)ep;
+  if (!e.pend.valid || e.pend.n_heads < 0) return KQ_EINVAL;
+  kq::DOut O{};
+  O.status = (uint8_t*)status; O.action = (uint8_t*)action; O.mode = (uint8_t*)mode; O.requeue_reason = (uint8_t*)rq; O.tried_idx = (int32_t*)tried;
+  e.pend.O = O; e.pend.H = e.batches[EmuEngine::PEND_SLOT].H; e.pend.ran = true;
+  return e.pending_apply();
+}
 int kqe_read_usage(void* e, int64_t* out) { return ((EmuEngine*)e)->read_usage_work(out); }
 int kqe_last_bytes(void* e, int64_t* out) { *out = ((EmuEngine*)e)->last_bytes; return KQ_OK; }
 int kqe_phase_bytes(void* e, int64_t* out) { out[0] = ((EmuEngine*)e)->last_phase_bytes[0]; out[1] = ((EmuEngine*)e)->last_phase_bytes[1]; return KQ_OK; }

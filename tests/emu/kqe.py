@@ -72,8 +72,47 @@ class EmuEngine:
             assert rc == 0, (rc, lib().kqe_last_error(self.h))
         return rc
 
+    def nominate_resident(self, batch, out):
+        rc = lib().kqe_nominate_run_resident(self.h, batch, C.byref(out.struct()))
+        assert rc == 0, (rc, lib().kqe_last_error(self.h))
+        return out
+
     def try_commit(self):
         return lib().kqe_cycle_commit(self.h, None)
+
+    def _ok(self, rc):
+        assert rc == 0, (rc, lib().kqe_last_error(self.h))
+
+    def pending_put(self, pending):
+        self._ok(lib().kqe_pending_put(self.h, C.byref(pending.struct())))
+        self.pending = pending
+
+    def pending_heads(self, cycle, cq_active=None):
+        n, nps = C.c_int32(), C.c_int32()
+        hw = np.full(self.snap.n_cq, -1, np.int32)
+        act = None if cq_active is None else F.ptr(np.ascontiguousarray(cq_active, np.uint8))
+        self._ok(lib().kqe_pending_heads(self.h, C.c_int64(cycle), act, C.byref(n), C.byref(nps), F.ptr(hw)))
+        return n.value, nps.value, hw
+
+    def run_pending(self, out):
+        self._ok(lib().kqe_cycle_run_pending(self.h, C.byref(out.struct())))
+        return out
+
+    def pending_apply(self):
+        self._ok(lib().kqe_pending_apply(self.h))
+
+    def pending_queue_inadmissible(self, cqs=None):
+        if cqs is None:
+            self._ok(lib().kqe_pending_queue_inadmissible(self.h, 0, None))
+        else:
+            a = np.ascontiguousarray(cqs, np.int32)
+            self._ok(lib().kqe_pending_queue_inadmissible(self.h, len(a), F.ptr(a) if len(a) else None))
+
+    def pending_state(self):
+        st = np.zeros(max(self.pending.n, 1), np.uint8)
+        counts = np.zeros(4, np.int32)
+        self._ok(lib().kqe_pending_read_state(self.h, F.ptr(st), F.ptr(counts)))
+        return st[:self.pending.n], counts
 
     def run(self, heads, want_usage=False, tgt_cap=None):
         d = Decisions(heads, tgt_cap=tgt_cap)

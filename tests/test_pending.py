@@ -1,0 +1,231 @@
+"""The pending side on the device (include/kq_engine.h kq_pending_*): every pending workload resident in HBM, Heads() as
+a segmented arg-min, the requeue policy driven by the cycle's decisions.
+
+ 1. the oracle (oracle/kq_pending_oracle.cpp) replays the reference's own unit tests of pkg/cache/queue, transcribed op by op
+    (tests/golden/pending_queue.yaml);
+ 2. the RequeueIfNotPresent tables also run through the DEVICE code (1-lane emulation) with fabricated decisions;
+ 3. closed loops — Heads() -> cycle -> commit -> requeue -> finish/queueInadmissibleWorkloads — compare the engine with the oracle
+    cycle by cycle (popped workloads, every decision, queue states) until every pending workload has had a decision:
+    emulation on small populations here, the HIP engine on full cfg 3 (100 000 pending) in the GPU suite.
+"""
+import copy
+
+import numpy as np
+import pytest
+
+from kueue_amd import _ffi as F
+from kueue_amd.api import (ClusterQueue, Decisions, FlavorQuotas, Heads, Pending, PodSet, ResourceGroup, ResourceQuota, Snapshot, Workload,
+                           make_config, gates_with)
+from kueue_amd.population import generate
+from tests.conftest import load_golden
+
+REASON = {"Generic": F.RQ_GENERIC, "FailedAfterNomination": F.RQ_FAILED_AFTER_NOMINATION, "PendingPreemption": F.RQ_PENDING_PREEMPTION,
+          "NoFit": F.RQ_NOFIT, "PreemptionNoCandidates": F.RQ_PREEMPTION_NO_CANDIDATES}
+CASES = load_golden("pending_queue.yaml")["cases"]
+
+
+def _tiny(case):
+    """One ClusterQueue with the case's queueing strategy and its workloads as a pending set."""
+    fq = FlavorQuotas("f0", {"cpu": ResourceQuota(10_000), "memory": ResourceQuota(10_000)})
+    cq = ClusterQueue("cq", resource_groups=[ResourceGroup([fq])], queueing_strategy=case["strategy"])
+    snap = Snapshot([cq], [], [], now_ns=1)
+    snap.derive()
+    wls = []
+    for i, w in enumerate(case["workloads"]):
+        ps = [PodSet(f"ps{j}", count=1, requests={"cpu": 1000, "memory": 1}) for j in range(w.get("podsets", 1))]
+        x = Workload(w["name"], "cq", priority=w.get("prio", 0), creation_ts=w.get("ts", i + 1), pod_sets=ps, uid=f"{i:04d}")
+        x.scheduling_hash = w.get("hash", 0)
+        wls.append(x)
+    heads = Heads(snap, wls, cycle=0)
+    return snap, Pending(heads, uid_rank=np.arange(len(wls), dtype=np.uint32)), {w["name"]: i for i, w in enumerate(case["workloads"])}
+
+
+def _names(state, names, code):
+    inv = {i: n for n, i in names.items()}
+    return sorted(inv[i] for i in range(len(state)) if state[i] == code)
+
+
+def _check(q, names, exp, state):
+    if "active" in exp:
+        assert _names(state, names, F.WL_ACTIVE) == sorted(exp["active"])
+    if "inadmissible" in exp:
+        assert _names(state, names, F.WL_INADMISSIBLE) == sorted(exp["inadmissible"])
+    if "pending" in exp:
+        assert int(((state == F.WL_ACTIVE) | (state == F.WL_INADMISSIBLE)).sum()) == exp["pending"]
+    if q is not None:
+        if "sticky" in exp:
+            assert sorted(n for n, i in names.items() if q.is_sticky(i)) == sorted(exp["sticky"])
+        for h in exp.get("has_hash", []):
+            assert q.has_hash(0, h)
+        for h in exp.get("no_hash", []):
+            assert not q.has_hash(0, h)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_reference_queue_tables_on_oracle(oracle, case):
+    snap, pending, names = _tiny(case)
+    q = oracle.PendingOracle(make_config(), snap, pending)
+    try:
+        for w, i in zip(case["workloads"], range(len(names))):
+            if w.get("present", True) is False:
+                q.set_state(i, F.WL_INFLIGHT)  # an Info that is in no set
+        nR = snap.n_resource
+        for op in case["ops"]:
+            k = op["op"]
+            if k == "requeue":
+                i = names[op["w"]]
+                if "last" in op:
+                    lt = op["last"]
+                    if lt is not None:
+                        assert len(lt) == len(case["workloads"][i].get("podsets", 1) * [0]) * nR, "last = [podset][resource] in dictionary order"
+                    q.set_last(i, lt)
+                got = q.requeue(i, REASON[op["reason"]], op.get("immediate"))
+                if "want" in op:
+                    assert got == op["want"], op
+            elif k == "pop":
+                got = q.pop(0)
+                assert (None if got < 0 else [n for n, i in names.items() if i == got][0]) == op["want"]
+            elif k == "queue_inadmissible":
+                moved = q.queue_inadmissible([0])
+                if "want_moved" in op:
+                    assert moved == op["want_moved"]
+            elif k == "handle_hash":
+                assert q.handle_hash(0, op["hash"]) == op["want_moved"]
+            elif k == "check":
+                _check(q, names, op, q.state())
+            else:
+                raise AssertionError(k)
+        _check(q, names, case["expect"], q.state())
+    finally:
+        q.close()
+
+
+REQUEUE_CASES = [c for c in CASES if len(c["workloads"]) == 1 and c["workloads"][0].get("present", True) is False and c["ops"][0]["op"] == "requeue"
+                 and "immediate" not in c["ops"][0]]
+
+
+@pytest.mark.parametrize("case", REQUEUE_CASES, ids=[c["name"] for c in REQUEUE_CASES])
+def test_reference_requeue_tables_on_device_code(case):
+    """RequeueIfNotPresent through kq_pending.hpp (emulated): pop the single workload (it is in flight, i.e. in no set), hand the
+    apply step a fabricated decision carrying the table's requeue reason / LastAssignment, read the queue state back."""
+    import ctypes as C
+    from tests.emu import kqe
+    snap, pending, names = _tiny(case)
+    eng = kqe.EmuEngine(make_config())
+    try:
+        eng.put(snap)
+        eng.pending_put(pending)
+        n, nps, hw = eng.pending_heads(cycle=1)
+        assert n == 1 and hw[0] == 0
+        op = case["ops"][0]
+        rq = REASON[op["reason"]]
+        status = np.array([F.ST_NOMINATED if rq == F.RQ_FAILED_AFTER_NOMINATION else 0], np.uint8)
+        action = np.zeros(1, np.uint8)
+        mode = np.array([1], np.uint8)
+        tried = np.full(nps * snap.n_resource, -1, np.int32)
+        if op.get("last") is not None:
+            tried[:] = np.asarray(op["last"], np.int32)
+        rc = kqe.lib().kqe_pending_apply_fabricated(eng.h, F.ptr(status), F.ptr(action), F.ptr(mode), F.ptr(np.array([rq], np.uint8)), F.ptr(tried))
+        assert rc == 0
+        st, counts = eng.pending_state()
+        _check(None, names, case["expect"], st)
+        if "sticky" in case["expect"]:
+            # the sticky preemptor is the next head and is flagged IsPreemptor (cluster_queue.go:213)
+            n2, _, hw2 = eng.pending_heads(cycle=2)
+            assert (n2 == 1) == (st[0] == F.WL_ACTIVE)
+    finally:
+        eng.close()
+
+
+# ---- closed loops ------------------------------------------------------------------------------------------------------
+
+def closed_loop(oracle, eng_factory, pop, cfg, max_cycles, hold, hashes=True, stop_when_all_decided=True, check_state_every=1):
+    """Runs the §8d loop on the engine and on the oracle side by side; returns (cycles, decisions, workloads decided)."""
+    snap = pop.snapshot
+    pending = pop.pending(hashes=hashes)
+    eng = eng_factory(cfg)
+    q = oracle.PendingOracle(cfg, snap, pending)
+    osnap = copy.copy(snap); osnap.arrays = dict(snap.arrays)
+    decided = np.zeros(pending.n, bool)
+    held, live, dec = [], 0, 0
+    parent = snap.arrays["parent"]
+    root_of = np.arange(snap.N)
+    for _ in range(8):
+        root_of = np.where(parent[root_of] >= 0, parent[root_of], root_of)
+    try:
+        eng.put(snap)
+        eng.pending_put(pending)
+        for cyc in range(1, max_cycles + 1):
+            n, nps, hw = eng.pending_heads(cyc)
+            hb, ohw = q.heads(cyc)
+            assert np.array_equal(hw, ohw), f"cycle {cyc}: Heads() differ"
+            assert n == hb.n and nps == hb.n_ps
+            if n == 0:
+                break
+            got = eng.run_pending(Decisions(hb, tgt_cap=max(4096, snap.n_adm)))
+            want = oracle.cycle_run(cfg, osnap, hb)
+            bad = want.equal(got)
+            assert not bad, (cyc, bad)
+            decided[hw[hw >= 0]] = True
+            dec += n
+            # admissions fold into the snapshot on both sides; requeue; older admissions finish and free quota
+            usage, na, triples = oracle.cycle_commit(cfg, osnap, hb)
+            osnap.arrays["usage"] = usage; osnap._struct = None
+            assert eng.try_commit() == 0
+            eng.pending_apply()
+            q.apply(hb, want)
+            held.append(triples); live += 1
+            if live > hold:
+                # the workloads admitted `hold` cycles ago finish. kq_cycle_release also requeues the inadmissible workloads of the
+                # root cohorts whose quota was freed (QueueAssociatedInadmissibleWorkloadsAfter); the oracle side does it by hand
+                eng.release(hold + 1); live -= 1
+                done = held.pop(0)
+                osnap.arrays["usage"] = oracle.usage_apply(cfg, osnap, done, add=False); osnap._struct = None
+                freed = np.unique(root_of[done[0]])
+                if len(freed):
+                    q.queue_inadmissible(np.nonzero(np.isin(root_of[:snap.n_cq], freed))[0])
+            if cyc % check_state_every == 0:
+                st, counts = eng.pending_state()
+                assert np.array_equal(st, q.state()), f"cycle {cyc}: queue states differ"
+            if stop_when_all_decided and decided.all():
+                break
+        st, counts = eng.pending_state()
+        assert np.array_equal(st, q.state())
+        return cyc, dec, int(decided.sum()), counts
+    finally:
+        eng.close(); q.close()
+
+
+@pytest.mark.parametrize("cfgn,n_cq,per,fair", [(3, 40, 10, False), (2, 16, 12, False), (1, 4, 25, False), (3, 30, 6, True)],
+                         ids=["cfg3-besteffort", "cfg2-flat", "cfg1-strictfifo", "cfg3-fair"])
+def test_pending_closed_loop_emulated(oracle, cfgn, n_cq, per, fair):
+    from tests.emu import kqe
+    pop = generate(cfgn, n_cq=n_cq, per_cq=per, fair_sharing=fair)
+    cyc, dec, ndec, counts = closed_loop(oracle, kqe.EmuEngine, pop, make_config(fair_sharing=fair), max_cycles=60, hold=2)
+    assert dec >= ndec > 0 and counts[F.WL_GONE] > 0
+
+
+def test_pending_closed_loop_preemption_emulated(oracle):
+    """Preemptors become sticky heads (PendingPreemption) and keep their place while their victims are 'being evicted'."""
+    from tests.emu import kqe
+    pop = generate(4, n_cq=30, per_cq=5)
+    cyc, dec, ndec, counts = closed_loop(oracle, kqe.EmuEngine, pop, make_config(), max_cycles=12, hold=2, stop_when_all_decided=False)
+    assert dec > 0
+
+
+def test_pending_without_hashing_gate(oracle):
+    from tests.emu import kqe
+    pop = generate(3, n_cq=20, per_cq=8)
+    cfg = make_config(gates=gates_with({"SchedulingEquivalenceHashing": False}))
+    closed_loop(oracle, kqe.EmuEngine, pop, cfg, max_cycles=30, hold=2)
+
+
+@pytest.mark.gpu
+def test_pending_closed_loop_cfg3_full(oracle):
+    """BASELINE configs[2] as SURVEY §8d defines a run: 100 000 pending workloads resident in HBM, cycles until every one of them
+    has had a decision; Heads(), every decision and the queue states equal the oracle's in every cycle."""
+    from kueue_amd.engine import Engine
+    pop = generate(3)
+    cyc, dec, ndec, counts = closed_loop(oracle, Engine, pop, make_config(), max_cycles=400, hold=4, check_state_every=10)
+    assert ndec == pop.n_pending, (cyc, dec, ndec)
+    assert cyc >= 100
