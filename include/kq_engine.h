@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define KQ_ABI_VERSION 1
+#define KQ_ABI_VERSION 2
 
 /* ---- error codes ---------------------------------------------------------------------------- */
 #define KQ_OK             0
@@ -226,6 +226,15 @@ typedef struct kq_heads {
 #define KQ_REASON_IN_COHORT_FAIR_SHARING         2
 #define KQ_REASON_IN_COHORT_RECLAIM_WHILE_BORROWING 3
 
+/* Why a flavor was not assigned as Fit: the operands of one Status.reasons string (flavorassigner.go:349). The caller formats
+ * the text (shim/go/messages.go; kueue_amd/messages.py), so no string crosses the boundary. */
+#define KQ_RSN_EXCEEDS_MAX_CAPACITY  1  /* flavorassigner.go:1353: a = previously considered podsets requests (assumedUsage), b = current
+                                           podset request (requestUsage), c = maximum capacity (PotentialAvailable)              */
+#define KQ_RSN_INSUFFICIENT_UNUSED   2  /* :1372: a = val - Available(fr), the "more needed" amount                              */
+#define KQ_RSN_NOT_IN_NOMINATION     3  /* :1097: flavor skipped by the nomination mapping; resource = the scan's resource name   */
+#define KQ_RSN_FLAVOR_INELIGIBLE     4  /* :1105-1113: checkFlavorForPodSets failed (ps_flavor_ok bit clear); the host knows the text */
+#define KQ_RSN_RESOURCE_UNAVAILABLE  5  /* :1080: no resource group of the ClusterQueue covers `resource`                         */
+
 typedef struct kq_decisions {
   /* per head [n] */
   uint8_t* status;          /* KQ_ST_*   */
@@ -247,6 +256,17 @@ typedef struct kq_decisions {
   int32_t  tgt_cap;         /* capacity of tgt_adm / tgt_reason */
   int32_t* tgt_adm;         /* admitted-workload row */
   uint8_t* tgt_reason;      /* KQ_REASON_* */
+  /* reason records, CSR over heads, in the order the reference appends them (PodSetAssignment.Status.reasons of the assignment
+   * the entry ends the cycle with; Assignment.Message = podsets joined, flavorassigner.go:229). rsn_cap == 0: not reported. */
+  int32_t  rsn_cap;         /* capacity of the rsn_* arrays, in records */
+  int32_t* rsn_off;         /* [n+1] */
+  uint8_t* rsn_code;        /* KQ_RSN_* */
+  uint8_t* rsn_podset;      /* podset index within the head */
+  int16_t* rsn_flavor;      /* flavor index, -1 = none */
+  int16_t* rsn_resource;    /* resource index, -1 = none */
+  int64_t* rsn_a;
+  int64_t* rsn_b;
+  int64_t* rsn_c;
 } kq_decisions;
 
 typedef struct kq_engine kq_engine;

@@ -14,7 +14,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ENGINE_LIB = os.path.join(HERE, "libkq_engine.so")
 
-KQ_ABI_VERSION = 1
+KQ_ABI_VERSION = 2
 KQ_UNLIMITED = (1 << 63) - 1
 KQ_NIL_LIMIT = -1
 
@@ -153,11 +153,15 @@ class kq_decisions(C.Structure):
         ("flavor", i32p), ("res_mode", u8p), ("tried_idx", i32p),
         ("ps_count", i32p),
         ("tgt_off", i32p), ("tgt_cap", C.c_int32), ("tgt_adm", i32p), ("tgt_reason", u8p),
+        ("rsn_cap", C.c_int32), ("rsn_off", i32p), ("rsn_code", u8p), ("rsn_podset", u8p),
+        ("rsn_flavor", C.POINTER(C.c_int16)), ("rsn_resource", C.POINTER(C.c_int16)),
+        ("rsn_a", i64p), ("rsn_b", i64p), ("rsn_c", i64p),
     ]
 
 
 _NP2C = {
     np.dtype(np.int32): C.c_int32,
+    np.dtype(np.int16): C.c_int16,
     np.dtype(np.int64): C.c_int64,
     np.dtype(np.uint8): C.c_uint8,
     np.dtype(np.uint32): C.c_uint32,

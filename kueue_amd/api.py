@@ -599,7 +599,7 @@ class Pending:
 class Decisions:
     """Caller-allocated kq_decisions buffers + decoded views."""
 
-    def __init__(self, heads: Heads, tgt_cap: Optional[int] = None, n: Optional[int] = None, n_ps: Optional[int] = None):
+    def __init__(self, heads: Heads, tgt_cap: Optional[int] = None, n: Optional[int] = None, n_ps: Optional[int] = None, rsn_cap: int = 0):
         snap = heads.snap
         n, nps, nR = (heads.n if n is None else n), (heads.n_ps if n_ps is None else n_ps), snap.n_resource
         cap = tgt_cap if tgt_cap is not None else max(16, snap.n_adm * max(1, min(heads.n, 8)))  # every head may name most rows
@@ -612,8 +612,12 @@ class Decisions:
             tried_idx=np.full(nps * nR, -1, np.int32), ps_count=np.zeros(nps, np.int32),
             tgt_off=np.zeros(n + 1, np.int32), tgt_adm=np.zeros(cap, np.int32), tgt_reason=np.zeros(cap, np.uint8),
         )
+        if rsn_cap > 0:  # reason records (kueue_amd/messages.py turns them into the reference's status text)
+            self.a.update(rsn_off=np.zeros(n + 1, np.int32), rsn_code=np.zeros(rsn_cap, np.uint8), rsn_podset=np.zeros(rsn_cap, np.uint8),
+                          rsn_flavor=np.zeros(rsn_cap, np.int16), rsn_resource=np.zeros(rsn_cap, np.int16),
+                          rsn_a=np.zeros(rsn_cap, np.int64), rsn_b=np.zeros(rsn_cap, np.int64), rsn_c=np.zeros(rsn_cap, np.int64))
         self._struct = F.kq_decisions()
-        F.fill_struct(self._struct, self.a, dict(tgt_cap=cap))
+        F.fill_struct(self._struct, self.a, dict(tgt_cap=cap, rsn_cap=rsn_cap))
 
     def struct(self) -> F.kq_decisions:
         return self._struct
@@ -644,9 +648,15 @@ class Decisions:
         bad = []
         for k, v in self.a.items():
             w = other.a[k]
+            if k not in other.a:
+                continue
             if k in ("tgt_adm", "tgt_reason"):
                 m = int(self.a["tgt_off"][-1])
                 if int(other.a["tgt_off"][-1]) != m or not np.array_equal(v[:m], w[:m]):
+                    bad.append(k)
+            elif k.startswith("rsn_") and k != "rsn_off":
+                m = int(self.a["rsn_off"][-1])
+                if int(other.a["rsn_off"][-1]) != m or not np.array_equal(v[:m], w[:m]):
                     bad.append(k)
             elif not np.array_equal(v, w):
                 bad.append(k)

@@ -186,6 +186,10 @@ struct DHeads {
   const uint64_t *last_hash, *hash;
 };
 
+// One reason why a flavor was not assigned as Fit: the operands of a Status.reasons string (flavorassigner.go:349), see KQ_RSN_*.
+struct alignas(16) RsnRec { uint8_t code, podset; int16_t flavor, resource, pad; int64_t a, b, c; };
+static_assert(sizeof(RsnRec) == 32, "RsnRec is copied to the host as 32-byte records");
+
 // decisions (same layout as kq_decisions) + per-head internals carried from nominate to process
 struct DOut {
   uint8_t *status, *action, *nominated_mode, *mode, *requeue_reason, *skip;
@@ -206,6 +210,11 @@ struct DOut {
   int32_t* pool_count;  // [1] atomic
   int32_t* error;       // [1] first device-side error (KQ_E*)
   long long* stat_bytes;  // [1] algorithmic bytes, accumulated by lane 0
+  // reasons (optional: rsn_win == 0 -> not recorded): a window of rsn_win records per head, rewritten by every assign_flavors of
+  // the head, so it ends up describing the assignment the head keeps; rsn_n[h] = records used, negative = window overflowed
+  RsnRec* rsn;            // [H * rsn_win]
+  int32_t* rsn_n;         // [H]
+  int32_t rsn_win;
 };
 
 // per-wave-slot scratch in HBM (L2-resident working sets of one victim search)
@@ -504,6 +513,8 @@ struct Wave {
   uint8_t cell_pm[CELLS];
   int32_t cell_borrow[CELLS];
   int64_t cell_val[CELLS];
+  int64_t cell_aux[CELLS];        // operand of the cell's reason: maximum capacity (noFit by capacity) or val - available
+  int nrsn, rsn_ps0, rsn_g0, rsn_over;  // reason records of the assignment under construction (lane 0)
   // best flavor so far
   int32_t best_mode[KQ_MAXREQ], best_borrow[KQ_MAXREQ];
   int32_t cur_mode[KQ_MAXREQ], cur_borrow[KQ_MAXREQ];
@@ -1535,12 +1546,21 @@ KQ_DEV bool can_preempt_while_borrowing(const K& k, const Wave& w) {  // flavora
   return KQ_POL_BORROW_WITHIN(w.pol) != 0 || (k.C.fair_sharing && (KQ_POL_RECLAIM(w.pol) != KQ_POLICY_NEVER || KQ_POL_RECLAIM_UNSET(w.pol)));
 }
 
+// Status.appendf (flavorassigner.go:349): lane 0 appends one record to the head's window
+KQ_DEV void rsn_push(const K& k, Wave& w, int code, int podset, int flavor, int resource, int64_t a, int64_t b, int64_t c) {
+  if (k.O.rsn_win <= 0) return;
+  if (w.nrsn >= k.O.rsn_win) { w.rsn_over = 1; return; }
+  RsnRec r; r.code = (uint8_t)code; r.podset = (uint8_t)podset; r.flavor = (int16_t)flavor; r.resource = (int16_t)resource; r.pad = 0; r.a = a; r.b = b; r.c = c;
+  k.O.rsn[(size_t)w.h * k.O.rsn_win + w.nrsn] = r;
+  w.nrsn++;
+}
+
 KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed,
                            const int* counts, bool nominate_map) {
   const DSnap& S = k.S; const DHeads& H = k.H; const DOut& O = k.O;
   const int lane = lane_id();
   const int nR = S.nR;
-  if (lane == 0) { w.nuse = 0; w.borrowing = 0; w.rep_mode = M_FIT; }
+  if (lane == 0) { w.nuse = 0; w.borrowing = 0; w.rep_mode = M_FIT; w.nrsn = 0; w.rsn_over = 0; }
   wsync();
   int rep = M_FIT;
   bool any_ps = false;
@@ -1587,6 +1607,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
     wsync();
     bool group_failed = false;
     int ps_reasons = 0, ps_nflavors = 0, ps_mode = M_FIT;
+    if (lane == 0) w.rsn_ps0 = w.nrsn;
     for (int a = 0; a < w.nreq && !group_failed; a++) {
       const int res_name = w.req_res[a];
       const int g = rg_by_resource(S, w.cq, res_name);
@@ -1594,6 +1615,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
         if (w.req_qty[a] == 0) continue;
         if (gate(k, KQ_GATE_QUOTA_CHECK_STRATEGY) && k.C.quota_check_strategy == KQ_QUOTA_CHECK_IGNORE_UNDECLARED) continue;
         group_failed = true; ps_reasons = 1;  // "resource unavailable in ClusterQueue" :1080
+        if (lane == 0) { w.nrsn = w.rsn_ps0; rsn_push(k, w, KQ_RSN_RESOURCE_UNAVAILABLE, pi, -1, res_name, 0, 0, 0); }  // the podset's whole status (:826-829)
         break;
       }
       if (w.req_done[a]) continue;  // :819
@@ -1602,6 +1624,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
         int nf = 0;
         for (int b = 0; b < w.nreq; b++) if (rg_covers(S, g, w.req_res[b])) { w.f_res[nf] = w.req_res[b]; w.f_qty[nf] = w.req_qty[b]; w.f_slot[nf] = (uint8_t)b; nf++; }
         w.nf = nf;
+        w.rsn_g0 = w.nrsn;
       }
       wsync();
       const int nf = w.nf;
@@ -1621,8 +1644,8 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
           int j = cs + c / nf, kk = c % nf;
           int f = S.rg_flavor[f0 + j];
           bool ok = (H.ps_flavor_ok[(size_t)psg * S.nfw + (f >> 6)] >> (f & 63)) & 1;  // checkFlavorForPodSets :1212 (host-evaluated)
-          if (nominate_map && nom_flavor[a] != f) ok = false;                              // shouldSkipBasedOnNominationMapping :1422
-          uint8_t pm = PM_SKIP; int32_t borrow = 0; int64_t val = 0;
+          uint8_t pm = PM_SKIP; int32_t borrow = ok ? 0 : KQ_RSN_FLAVOR_INELIGIBLE; int64_t val = 0, aux = 0;  // a skipped cell keeps WHY in `borrow`
+          if (nominate_map && nom_flavor[a] != f) { ok = false; borrow = KQ_RSN_NOT_IN_NOMINATION; }  // shouldSkipBasedOnNominationMapping :1422 (checked first, :1096)
           if (ok) {
             int fr = f * nR + w.f_res[kk];
             val = a_addi(assumed_usage(w, fr), w.f_qty[kk]);
@@ -1643,29 +1666,39 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
               nominal = S.nominal[ix(S, w.cq, fr)];
               if (!(val > maxcap)) height = find_height(S, w.path, plen, fr, val, ug, &may_reclaim);
             }
-            if (val > maxcap) { pm = PM_NOFIT; borrow = 0; }
+            if (val > maxcap) { pm = PM_NOFIT; borrow = 0; aux = maxcap; }
             else {
               borrow = height;
+              aux = a_sub(val, avail);  // "%s more needed" :1372
               if (val <= avail) pm = PM_FIT;
               else if (nominal >= val || may_reclaim || can_preempt_while_borrowing(k, w)) pm = PM_NEEDS;
               else pm = PM_NOFIT | 0x80;  // noFit with a "insufficient unused quota" reason and borrow kept
             }
           }
-          w.cell_pm[c] = pm; w.cell_borrow[c] = borrow; w.cell_val[c] = val;
+          w.cell_pm[c] = pm; w.cell_borrow[c] = borrow; w.cell_val[c] = val; w.cell_aux[c] = aux;
         }
         wsync();
         // ---- ordered scan of the pass (uniform) ------------------------------------------
         for (int jj = 0; jj < nfl && !stop; jj++) {
           const int j = cs + jj;
           attempted = j;
-          if (w.cell_pm[jj * nf] == PM_SKIP) { reasons++; continue; }
           const int f = S.rg_flavor[f0 + j];
+          if (w.cell_pm[jj * nf] == PM_SKIP) {
+            reasons++;
+            if (lane == 0) { const int why = w.cell_borrow[jj * nf]; rsn_push(k, w, why, pi, f, why == KQ_RSN_NOT_IN_NOMINATION ? res_name : -1, 0, 0, 0); }
+            continue;
+          }
           if (lane == 0) w.bytes += (int64_t)nf * 40 * plen;  // nf fitsResourceQuota calls, (D+1) x 5 planes x 8 B each
           int rep_pm = PM_FIT; int64_t rep_borrow = 0; int64_t rep_key = pref_key(PM_FIT, 0, w.pol);
           for (int kk = 0; kk < nf; kk++) {
             int c = jj * nf + kk;
             int pm = w.cell_pm[c] & 0x7f; int borrow = w.cell_borrow[c];
             bool had_status = (w.cell_pm[c] & 0x80) || pm == PM_NOFIT || pm == PM_NEEDS;
+            if (had_status && lane == 0) {  // the string fitsResourceQuota formats (:1353-1373)
+              const int fr = f * nR + w.f_res[kk];
+              if (pm == PM_NOFIT && !(w.cell_pm[c] & 0x80)) rsn_push(k, w, KQ_RSN_EXCEEDS_MAX_CAPACITY, pi, f, w.f_res[kk], assumed_usage(w, fr), w.f_qty[kk], w.cell_aux[c]);
+              else rsn_push(k, w, KQ_RSN_INSUFFICIENT_UNUSED, pi, f, w.f_res[kk], w.cell_aux[c], 0, 0);
+            }
             if (rep_pm == PM_NOFIT) { if (had_status) reasons++; continue; }  // oracle result unused past a noFit (:1161)
             if (pm == PM_NEEDS) {
               int opm, ob;
@@ -1700,8 +1733,15 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
       bool status_nil = best >= 0 && best_pm == PM_FIT;
       if (best < 0) {  // len(flavors)==0 && requests.Len()>0  (:826)
         group_failed = true; ps_reasons = reasons;
+        if (lane == 0 && k.O.rsn_win > 0) {  // psAssignment.Status = status (:829): this group's reasons replace the podset's
+          RsnRec* win = k.O.rsn + (size_t)w.h * k.O.rsn_win;
+          const int cnt = w.nrsn - w.rsn_g0;
+          for (int q = 0; q < cnt; q++) win[w.rsn_ps0 + q] = win[w.rsn_g0 + q];
+          w.nrsn = w.rsn_ps0 + cnt;
+        }
         break;
       }
+      if (status_nil && lane == 0) w.nrsn = w.rsn_g0;  // a nil status drops the scan's reasons (:1199-1207)
       // record groupFlavors[res] for every covered requested resource (maps.Copy :831)
       if (lane == 0) {
         int f = S.rg_flavor[f0 + best];
@@ -1754,7 +1794,10 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
     }
   }
   if (!any_ps) rep = M_NOFIT;  // RepresentativeMode with no podsets :212-215
-  if (lane == 0) w.rep_mode = rep;
+  if (lane == 0) {
+    w.rep_mode = rep;
+    if (O.rsn_win > 0) O.rsn_n[w.h] = w.rsn_over ? -w.nrsn : w.nrsn;
+  }
   wsync();
 }
 

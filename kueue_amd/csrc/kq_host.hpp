@@ -37,7 +37,7 @@ template <class B> struct EngineT {
   bool force_exact_drs = false;  // tests: take the saturation-safe DRS loops even when the sums would be exact
   bool cs_disable = false;       // tests: classical victim searches always take the candidate-by-candidate walk
   Buf b_cs;
-  struct HeadBatch { Buf hb[1]; DHeads H{}; int n = 0; size_t nps = 0; int slot_cap = 1; int64_t cycle = 0; bool valid = false; bool plain = true; };
+  struct HeadBatch { Buf hb[1]; DHeads H{}; int n = 0; size_t nps = 0; int slot_cap = 1; int64_t cycle = 0; bool valid = false; bool plain = true; int max_nps = KQ_MAXPS; };
   std::vector<HeadBatch> batches;  // [0] = transient batch of kq_cycle_run, [1+b] = resident batch b
   Buf ob[24];  // output arrays
   uint8_t* hstage = nullptr;  // pinned host staging for the packed decisions
@@ -55,7 +55,7 @@ template <class B> struct EngineT {
   static constexpr int PEND_SLOT = 4098;  // head batch the gathered heads live in (beyond every caller-visible batch id)
   struct Pending {
     bool valid = false;
-    int W = 0, nq = 0, nR = 0, nF = 0, n_tree = 0, slot_cap = 1;
+    int W = 0, nq = 0, nR = 0, nF = 0, n_tree = 0, slot_cap = 1, max_nps = 1;
     bool plain = true;
     std::vector<void*> allocs;
     DPend D{};
@@ -294,15 +294,17 @@ template <class B> struct EngineT {
     return be.sync();
   }
 
-  int validate_heads(const kq_heads* h, int* slot_cap, bool* plain) {
+  int validate_heads(const kq_heads* h, int* slot_cap, bool* plain, int* max_nps = nullptr) {
     if (h->n < 0) return fail(KQ_EINVAL, "negative head count");
     int cap = 1;
+    int mnps = 1;
     *plain = true;
     for (int i = 0; i < h->n; i++) {
       if (h->cq[i] < 0 || h->cq[i] >= prep.nq) return fail(KQ_EINVAL, "head cq out of range");
       int nps = h->ps_off[i + 1] - h->ps_off[i];
       if (nps < 0) return fail(KQ_EINVAL, "ps_off not monotone");
       if (nps > KQ_MAXPS) return fail(KQ_EUNSUPPORTED, "more podsets than KQ_MAXPS");
+      mnps = std::max(mnps, nps);
       int slots = 0;
       for (int p = h->ps_off[i]; p < h->ps_off[i + 1]; p++) {
         int nreq = h->ps_req_off[p + 1] - h->ps_req_off[p];
@@ -319,6 +321,7 @@ template <class B> struct EngineT {
       cap = std::max(cap, slots);
     }
     *slot_cap = cap;
+    if (max_nps) *max_nps = mnps;
     return KQ_OK;
   }
 
@@ -326,12 +329,13 @@ template <class B> struct EngineT {
   int heads_put(const kq_heads* h, int slot) {
     if (!have_snapshot) return fail(KQ_EINVAL, "heads before kq_snapshot_put");
     if (slot < 0 || slot > 4096) return fail(KQ_EINVAL, "bad batch id");
-    int slot_cap = 1;
+    int slot_cap = 1, max_nps = 1;
     bool plain = true;
-    int rc = validate_heads(h, &slot_cap, &plain);
+    int rc = validate_heads(h, &slot_cap, &plain, &max_nps);
     if (rc != KQ_OK) return rc;
     if ((int)batches.size() <= slot) batches.resize(slot + 1);
     HeadBatch& hbch = batches[slot];
+    hbch.max_nps = max_nps;
     if (slot == last_slot) last_cycle_n = -1;  // the uncommitted cycle's head arrays are about to be replaced (or freed)
     const int n = h->n;
     hbch.n = n; hbch.slot_cap = slot_cap; hbch.cycle = h->cycle; hbch.valid = true; hbch.plain = plain;
@@ -421,6 +425,9 @@ template <class B> struct EngineT {
     const size_t o_borrow = carve((size_t)n * 4), o_order = carve((size_t)n * 4);
     const size_t o_flavor = carve(nps * nR * 4), o_rmode = carve(nps * nR), o_tried = carve(nps * nR * 4), o_pscount = carve(nps * 4);
     const size_t o_tpos = carve((size_t)n * 4), o_tn = carve((size_t)n * 4), o_misc = carve(4 * sizeof(int64_t));
+    // reason records: a window per head, sized for the longest scan any head of the batch can produce
+    const int rsn_win = out->rsn_cap > 0 ? std::min(std::max(prep.max_rsn_per_podset * hbch.max_nps, 8), 4096) : 0;
+    const size_t o_rsn = carve(rsn_win ? (size_t)n * 4 : 0);
     const size_t pack_bytes = off;
     uint8_t* pack = grow<uint8_t>(ob[0], pack_bytes);
     O.status = pack + o_status; O.action = pack + o_action; O.nominated_mode = pack + o_nmode; O.mode = pack + o_mode;
@@ -433,6 +440,8 @@ template <class B> struct EngineT {
     // recomputation on overlap appends a second target segment per head: size the pool for both
     O.pool_cap = pool_cap * 2;
     O.pool_row = grow<int32_t>(ob[17], O.pool_cap); O.pool_reason = grow<uint8_t>(ob[18], O.pool_cap);
+    O.rsn_win = rsn_win; O.rsn_n = rsn_win ? (int32_t*)(pack + o_rsn) : nullptr;
+    O.rsn = rsn_win ? grow<RsnRec>(ob[19], (size_t)n * rsn_win) : nullptr;
     int64_t* misc = (int64_t*)(pack + o_misc);
     DPrep pp{};  // the fills and copies every cycle starts with, gathered into one launch (be.launch_prep below)
     auto prep_fill = [&](void* dst, size_t words, uint32_t v) { if (words) pp.op[pp.n++] = DPrepOp{dst, nullptr, (uint32_t)words, v}; };
@@ -441,6 +450,7 @@ template <class B> struct EngineT {
     O.pool_count = (int32_t*)misc; O.error = (int32_t*)misc + 1; O.stat_bytes = (long long*)(misc + 1);  // [1]=nominate bytes, [2]=process bytes
     // nominated flavors start empty (a head's rows are rewritten by assign_flavors)
     prep_fill(O.flavor, nps * nR, 0xffffffffu);
+    if (rsn_win) prep_fill(O.rsn_n, (size_t)n, 0);
     // scratch: one slot per resident wave
     const int slots_nom = std::min(n, be.max_slots());
     const int slots = std::max(slots_nom, prep.n_tree);
@@ -541,6 +551,34 @@ template <class B> struct EngineT {
     int64_t miscs[4];
     memcpy(miscs, hstage + o_misc, sizeof(miscs));
     int32_t pool_used = ((int32_t*)miscs)[0], dev_err = ((int32_t*)miscs)[1];
+    if (rsn_win && dev_err == 0) {  // reason windows -> the caller's CSR (only the used part of every window is copied out)
+      const int32_t* rn = (const int32_t*)(hstage + o_rsn);
+      size_t used_heads = 0;
+      for (int i = 0; i < n; i++) if (rn[i] != 0) used_heads++;
+      std::vector<RsnRec> win;
+      if (used_heads) { win.resize((size_t)n * rsn_win); be.d2h(win.data(), O.rsn, win.size() * sizeof(RsnRec)); rc = be.sync(); if (rc != KQ_OK) return fail(rc, be.error()); }
+      int tot = 0;
+      for (int i = 0; i < n; i++) {
+        if (out->rsn_off) out->rsn_off[i] = tot;
+        const int cnt = rn[i] < 0 ? -rn[i] : rn[i];
+        for (int q = 0; q < cnt + (rn[i] < 0 ? 1 : 0); q++) {
+          if (tot >= out->rsn_cap) return fail(KQ_ECAPACITY, "rsn_cap too small");
+          RsnRec r{};
+          if (q < cnt) r = win[(size_t)i * rsn_win + q]; else { r.code = 255; r.flavor = -1; r.resource = -1; }  // overflow marker
+          if (out->rsn_code) out->rsn_code[tot] = r.code;
+          if (out->rsn_podset) out->rsn_podset[tot] = r.podset;
+          if (out->rsn_flavor) out->rsn_flavor[tot] = r.flavor;
+          if (out->rsn_resource) out->rsn_resource[tot] = r.resource;
+          if (out->rsn_a) out->rsn_a[tot] = r.a;
+          if (out->rsn_b) out->rsn_b[tot] = r.b;
+          if (out->rsn_c) out->rsn_c[tot] = r.c;
+          tot++;
+        }
+      }
+      if (out->rsn_off) out->rsn_off[n] = tot;
+    } else if (out->rsn_off && out->rsn_cap > 0) {
+      memset(out->rsn_off, 0, (size_t)(n + 1) * sizeof(int32_t));
+    }
     last_phase_bytes[0] = miscs[1]; last_phase_bytes[1] = miscs[2];
     last_bytes = miscs[1] + miscs[2];
     for (int p = 0; p < 3; p++) last_phase_ms[p] = be.timer_ms(p, p + 1);
@@ -579,8 +617,8 @@ template <class B> struct EngineT {
   int pending_put(const kq_pending* p) {
     if (!have_snapshot) return fail(KQ_EINVAL, "kq_pending_put before kq_snapshot_put");
     const kq_heads* h = &p->w;
-    int slot_cap = 1; bool plain = true;
-    int rc = validate_heads(h, &slot_cap, &plain);
+    int slot_cap = 1, max_nps = 1; bool plain = true;
+    int rc = validate_heads(h, &slot_cap, &plain, &max_nps);
     if (rc != KQ_OK) return rc;
     pending_free();
     const int W = h->n, nq = prep.nq, nR = prep.nR;
@@ -608,7 +646,7 @@ template <class B> struct EngineT {
     size_t gps = 0, grq = 0;
     for (int c = 0; c < nq; c++) { gps += mps[c]; grq += mrq[c]; }
     Pending& P = pend;
-    P.W = W; P.nq = nq; P.nR = nR; P.nF = prep.nF; P.n_tree = prep.n_tree; P.slot_cap = slot_cap; P.plain = plain;
+    P.W = W; P.nq = nq; P.nR = nR; P.nF = prep.nF; P.n_tree = prep.n_tree; P.slot_cap = slot_cap; P.plain = plain; P.max_nps = max_nps;
     DPend& D = P.D;
     D.W = W; D.nq = nq; D.nR = nR; D.nfw = (int)nfw;
     DHeads& S0 = D.P;
@@ -665,7 +703,7 @@ template <class B> struct EngineT {
     if ((int)batches.size() <= PEND_SLOT) batches.resize(PEND_SLOT + 1);
     HeadBatch& hb = batches[PEND_SLOT];
     if (last_slot == PEND_SLOT) last_cycle_n = -1;  // the previous cycle's head arrays were just overwritten
-    hb.n = P.n_heads; hb.nps = (size_t)P.n_ps; hb.slot_cap = P.slot_cap; hb.cycle = cycle; hb.valid = true; hb.plain = P.plain;
+    hb.n = P.n_heads; hb.nps = (size_t)P.n_ps; hb.slot_cap = P.slot_cap; hb.cycle = cycle; hb.valid = true; hb.plain = P.plain; hb.max_nps = P.max_nps;
     DHeads& H = hb.H; const DGather& G = P.G;
     H.n = P.n_heads; H.cq = G.cq; H.priority = G.priority; H.queue_ts = G.queue_ts; H.flags = G.flags; H.ps_off = G.ps_off;
     H.ps_count = G.ps_count; H.ps_min_count = G.ps_min_count; H.ps_req_off = G.ps_req_off; H.req_res = G.req_res; H.req_qty = G.req_qty;

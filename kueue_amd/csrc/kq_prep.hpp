@@ -84,6 +84,7 @@ struct Prep {
   std::vector<int32_t> rank_pos;                   // [n_adm] position of the row inside its tree's tree_rows segment
   std::vector<int32_t> top_of;                     // [N] the ancestor-or-self that is a child of the root (-1 for roots)
   int max_tree_nodes = 0, max_tree_cqs = 0, max_tree_rows = 0, max_tree_cohorts = 0;
+  int max_rsn_per_podset = 1;  // most reason records one podset's flavor scans can produce: max over ClusterQueues of sum over groups of flavors x (resources + 1)
   std::string err;
 };
 
@@ -342,6 +343,13 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
     p.max_tree_cqs = std::max(p.max_tree_cqs, p.tree_cq_off[t + 1] - p.tree_cq_off[t]);
     p.max_tree_rows = std::max(p.max_tree_rows, p.tree_row_off[t + 1] - p.tree_row_off[t]);
     p.max_tree_cohorts = std::max(p.max_tree_cohorts, (p.tree_node_off[t + 1] - p.tree_node_off[t]) - (p.tree_cq_off[t + 1] - p.tree_cq_off[t]));
+  }
+  p.max_rsn_per_podset = 1;
+  for (int c = 0; c < p.nq; c++) {
+    int tot = 1;
+    for (int g = s->cq_rg_off[c]; g < s->cq_rg_off[c + 1]; g++)
+      tot += (s->rg_flavor_off[g + 1] - s->rg_flavor_off[g]) * (s->rg_res_off[g + 1] - s->rg_res_off[g] + 1);
+    p.max_rsn_per_podset = std::max(p.max_rsn_per_podset, tot);
   }
   // ---- fair sharing constants (depend on SubtreeQuota / usage: recomputed after kq_snapshot_derive) ----
   p.h_parent.assign(s->parent, s->parent + N);

@@ -53,8 +53,8 @@ class Engine:
         self._check(self._lib.kq_snapshot_put(self._h, C.byref(snap.struct())))
         self.snap = snap
 
-    def run(self, heads: Heads, tgt_cap: Optional[int] = None, out: Optional[Decisions] = None) -> Decisions:
-        d = out if out is not None else Decisions(heads, tgt_cap=tgt_cap)
+    def run(self, heads: Heads, tgt_cap: Optional[int] = None, out: Optional[Decisions] = None, rsn_cap: int = 0) -> Decisions:
+        d = out if out is not None else Decisions(heads, tgt_cap=tgt_cap, rsn_cap=rsn_cap)
         self._check(self._lib.kq_cycle_run(self._h, C.byref(heads.struct()), C.byref(d.struct())))
         ms, by = C.c_double(), C.c_int64()
         self._lib.kq_last_cycle_stats(self._h, C.byref(ms), C.byref(by))

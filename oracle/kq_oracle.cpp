@@ -397,9 +397,12 @@ struct Head {
 };
 
 struct FlavorAssignment { int flavor = -1; int mode = NoFit; int tried = 0; int borrow = 0; };
+// one Status.reasons string as its operands (KQ_RSN_*, include/kq_engine.h): Status.appendf flavorassigner.go:349
+struct Reason { int code, flavor, resource; int64_t a, b, c; };
 struct PodSetAssignment {
   std::map<int, FlavorAssignment> flavors;  // resource -> assignment (ResourceAssignment)
   int nreasons = 0;                          // len(Status.reasons)
+  std::vector<Reason> reasons;               // Status.reasons, in append order
   bool err = false;
   int count = 0;
   std::vector<std::pair<int, int64_t>> requests;  // effective requests (incl. injected pods)
@@ -497,25 +500,27 @@ struct FlavorAssigner {
     return idx + 1;
   }
   // flavorassigner.go:1334-1384 ; returns (preemptionMode, borrow, hasStatus)
-  struct FitRes { int pm; int borrow; bool status; };
+  struct FitRes { int pm; int borrow; bool status; Reason why; };
   FitRes fitsResourceQuota(int fr, Amount assumedUsage, int64_t requestUsage) {
     sn.st.cells++;
     sn.st.cell_bytes += 40 * (sn.depth[cq] + 1);
     Amount available = sn.Available(cq, fr);
     Amount maxCapacity = sn.PotentialAvailable(cq, fr);
     Amount val = assumedUsage.AddInt64(requestUsage);
-    if (val.Cmp(maxCapacity) > 0) return {pmNoFit, 0, true};
+    const int fl = fr / sn.nR, rs = fr % sn.nR;
+    if (val.Cmp(maxCapacity) > 0) return {pmNoFit, 0, true, {KQ_RSN_EXCEEDS_MAX_CAPACITY, fl, rs, assumedUsage.v, requestUsage, maxCapacity.v}};  // :1353
     auto hb = sn.FindHeightOfLowestSubtreeThatFits(cq, fr, val);
     int borrow = hb.first;
     bool mayReclaimInHierarchy = hb.second;
-    if (val.Cmp(available) <= 0) return {pmFit, borrow, false};
+    if (val.Cmp(available) <= 0) return {pmFit, borrow, false, {}};
+    const Reason more = {KQ_RSN_INSUFFICIENT_UNUSED, fl, rs, val.Sub(available).v, 0, 0};  // :1372
     if (sn.Nominal(cq, fr).Cmp(val) >= 0 || mayReclaimInHierarchy || canPreemptWhileBorrowing()) {
       auto r = oracle(cq, wl, fr, val);
       int mode;
       switch (r.first) { case ppNoCandidates: mode = pmNoCandidates; break; case ppPreempt: mode = pmPreempt; break; default: mode = pmReclaim; }
-      return {mode, r.second, true};
+      return {mode, r.second, true, more};
     }
-    return {pmNoFit, borrow, true};
+    return {pmNoFit, borrow, true, more};
   }
   // flavorassigner.go:1408-1414 / :1422-1430
   bool shouldRespectNominationMapping() const {
@@ -526,10 +531,12 @@ struct FlavorAssigner {
   // flavorassigner.go:1065-1210 ; psIDs == {psi} (no TAS podset groups on this path)
   // returns assignments (empty => nil), nreasons; *statusNil true when Go returns a nil status
   std::map<int, FlavorAssignment> findFlavorForPodSets(int psi, const std::vector<std::pair<int, int64_t>>& requests,
-                                                       int resName, const FRQ& assignmentUsage, int* nreasons, bool* statusNil) {
+                                                       int resName, const FRQ& assignmentUsage, int* nreasons, bool* statusNil,
+                                                       std::vector<Reason>* why) {
     *nreasons = 0; *statusNil = false;
+    why->clear();
     int g = sn.RGByResource(cq, resName);
-    if (g < 0) { *nreasons = 1; return {}; }
+    if (g < 0) { *nreasons = 1; why->push_back({KQ_RSN_RESOURCE_UNAVAILABLE, -1, resName, 0, 0, 0}); return {}; }
     std::vector<std::pair<int, int64_t>> filtered;  // filterRequestedResources :1391
     for (auto& rq : requests) if (sn.rgCovers(g, rq.first)) filtered.push_back(rq);
     std::map<int, FlavorAssignment> bestAssignment;
@@ -546,9 +553,9 @@ struct FlavorAssigner {
       if (respectNom) {  // shouldSkipBasedOnNominationMapping :1422
         auto it = wl.nomination[psi].find(resName);
         bool keep = it != wl.nomination[psi].end() && it->second == fName;
-        if (!keep) { (*nreasons)++; continue; }
+        if (!keep) { (*nreasons)++; why->push_back({KQ_RSN_NOT_IN_NOMINATION, fName, resName, 0, 0, 0}); continue; }
       }
-      if (!flavorOk(wl.ps_base + psi, fName)) { (*nreasons)++; continue; }  // checkFlavorForPodSets :1212 (host-evaluated)
+      if (!flavorOk(wl.ps_base + psi, fName)) { (*nreasons)++; why->push_back({KQ_RSN_FLAVOR_INELIGIBLE, fName, -1, 0, 0, 0}); continue; }  // checkFlavorForPodSets :1212 (host-evaluated)
       std::map<int, FlavorAssignment> assignments;
       GranularMode representativeMode = {pmFit, 0};
       for (auto& rq : filtered) {
@@ -557,7 +564,7 @@ struct FlavorAssigner {
         const int64_t vb0 = sn.st.victim_bytes + sn.st.drs_bytes;
         FitRes r = fitsResourceQuota(fr, frq_get(assignmentUsage, fr), rq.second);
         if (discarded) sn.st.discarded_bytes += sn.st.victim_bytes + sn.st.drs_bytes - vb0;
-        if (r.status) (*nreasons)++;
+        if (r.status) { (*nreasons)++; why->push_back(r.why); }
         GranularMode mode = {r.pm, r.borrow};
         if (isPreferred(representativeMode, mode, pol)) representativeMode = mode;
         if (representativeMode.pm == pmNoFit) continue;  // closure "return" :1161
@@ -627,13 +634,15 @@ struct FlavorAssigner {
         }
         if (groupFlavors.count(resName)) continue;  // :819
         int nre; bool statusNil;
-        auto flavors = findFlavorForPodSets(i, podSet.req, resName, a.Usage, &nre, &statusNil);
+        std::vector<Reason> why;
+        auto flavors = findFlavorForPodSets(i, podSet.req, resName, a.Usage, &nre, &statusNil, &why);
         if (flavors.empty() && !podSet.req.empty()) {  // :826
           groupFlavors.clear(); groupNil = true; groupReasons = nre;
+          psa.reasons = why;  // psAssignment.Status = status (:829)
           break;
         }
         for (auto& kv : flavors) groupFlavors[kv.first] = kv.second;
-        if (!statusNil) groupReasons += nre;
+        if (!statusNil) { groupReasons += nre; psa.reasons.insert(psa.reasons.end(), why.begin(), why.end()); }
       }
       // resolvePodSetFlavors :921-947 — keep flavors for resources this podset requests
       if (!groupNil && !podSet.req.empty()) {
@@ -1473,7 +1482,7 @@ using namespace kqo;
 
 static void writeDecisions(Snap& sn, const kq_heads* h, std::vector<Entry>& entries, kq_decisions* out, int* rc) {
   int nR = sn.nR;
-  int ntgt = 0;
+  int ntgt = 0, nrsn = 0;
   for (int i = 0; i < h->n; i++) {
     Entry& e = entries[i];
     if (out->status) out->status[i] = (uint8_t)e.status;
@@ -1508,6 +1517,16 @@ static void writeDecisions(Snap& sn, const kq_heads* h, std::vector<Entry>& entr
         }
       }
     }
+    if (out->rsn_cap > 0 && out->rsn_off) {
+      out->rsn_off[i] = nrsn;
+      for (size_t lp = 0; lp < e.assignment.PodSets.size(); lp++)
+        for (const Reason& r : e.assignment.PodSets[lp].reasons) {
+          if (nrsn >= out->rsn_cap) { *rc = KQ_ECAPACITY; continue; }
+          out->rsn_code[nrsn] = (uint8_t)r.code; out->rsn_podset[nrsn] = (uint8_t)lp; out->rsn_flavor[nrsn] = (int16_t)r.flavor; out->rsn_resource[nrsn] = (int16_t)r.resource;
+          out->rsn_a[nrsn] = r.a; out->rsn_b[nrsn] = r.b; out->rsn_c[nrsn] = r.c;
+          nrsn++;
+        }
+    }
     if (out->tgt_off) out->tgt_off[i] = ntgt;
     // canonical target order inside an entry: ascending admitted row (the reference tests compare sets)
     std::vector<Target> ts = e.preemptionTargets;
@@ -1520,6 +1539,7 @@ static void writeDecisions(Snap& sn, const kq_heads* h, std::vector<Entry>& entr
     }
   }
   if (out->tgt_off) out->tgt_off[h->n] = ntgt;
+  if (out->rsn_cap > 0 && out->rsn_off) out->rsn_off[h->n] = nrsn;
 }
 
 extern "C" {
@@ -1556,7 +1576,8 @@ int kqo_nominate_run(const kq_config* cfg, const kq_snapshot* s, const kq_heads*
 int kqo_assign(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, int hi, const int32_t* counts,
                int n_stub, const int32_t* stub_fr, const int32_t* stub_poss, const int32_t* stub_borrow,
                int32_t* flavor, uint8_t* res_mode, int32_t* tried_idx, int32_t* res_borrow,
-               int32_t* rep_mode, int32_t* borrowing, int64_t* usage_fr /* [n_fr] dense, 0 if absent */, int32_t* ps_nreasons) {
+               int32_t* rep_mode, int32_t* borrowing, int64_t* usage_fr /* [n_fr] dense, 0 if absent */, int32_t* ps_nreasons,
+               int32_t rsn_cap, int32_t* rsn_n, int32_t* rsn_rec /* [rsn_cap][4]: podset, code, flavor, resource */, int64_t* rsn_abc /* [rsn_cap][3] */) {
   Snap sn(*cfg, s);
   Scheduler sch(sn, h);
   Head wl = sch.loadHead(hi);
@@ -1585,6 +1606,15 @@ int kqo_assign(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, in
   *rep_mode = a.RepresentativeMode();
   *borrowing = a.Borrowing;
   if (usage_fr) { for (int fr = 0; fr < sn.nfr; fr++) usage_fr[fr] = 0; for (auto& kv : a.Usage) usage_fr[kv.first] = kv.second.v; }
+  if (rsn_n) {
+    int n = 0;
+    for (size_t p = 0; p < a.PodSets.size(); p++)
+      for (const Reason& r : a.PodSets[p].reasons) {
+        if (n < rsn_cap) { rsn_rec[4 * n] = (int)p; rsn_rec[4 * n + 1] = r.code; rsn_rec[4 * n + 2] = r.flavor; rsn_rec[4 * n + 3] = r.resource; rsn_abc[3 * n] = r.a; rsn_abc[3 * n + 1] = r.b; rsn_abc[3 * n + 2] = r.c; }
+        n++;
+      }
+    *rsn_n = n;
+  }
   return KQ_OK;
 }
 

@@ -47,8 +47,8 @@ def derive(snap: Snapshot) -> Snapshot:
     return snap
 
 
-def cycle_run(cfg: F.kq_config, snap: Snapshot, heads: Heads, want_usage: bool = False):
-    d = Decisions(heads)
+def cycle_run(cfg: F.kq_config, snap: Snapshot, heads: Heads, want_usage: bool = False, rsn_cap: int = 0):
+    d = Decisions(heads, rsn_cap=rsn_cap)
     stats = np.zeros(7, np.int64)
     usage = np.zeros(snap.N * snap.n_fr, np.int64) if want_usage else None
     rc = lib().kqo_cycle_run(C.byref(cfg), C.byref(snap.struct()), C.byref(heads.struct()), C.byref(d.struct()),
@@ -74,7 +74,7 @@ def nominate_run(cfg: F.kq_config, snap: Snapshot, heads: Heads, tgt_cap=None):
     return d
 
 
-def assign(cfg, snap: Snapshot, heads: Heads, hi: int = 0, counts=None, stub=None):
+def assign(cfg, snap: Snapshot, heads: Heads, hi: int = 0, counts=None, stub=None, ineligible=None):
     """FlavorAssigner.Assign with an optional stub preemption oracle {fr: (possibility, borrow)}."""
     nR = snap.n_resource
     P = int(heads.arrays["ps_off"][hi + 1] - heads.arrays["ps_off"][hi])
@@ -90,10 +90,19 @@ def assign(cfg, snap: Snapshot, heads: Heads, hi: int = 0, counts=None, stub=Non
         sp = np.array([v[0] for v in stub.values()] or [0], np.int32)
         sb = np.array([v[1] for v in stub.values()] or [0], np.int32)
     cv = None if counts is None else np.array(counts, np.int32)
+    rcap = 4096
+    rsn_n = C.c_int32(); rsn_rec = np.zeros(rcap * 4, np.int32); rsn_abc = np.zeros(rcap * 3, np.int64)
     rc = lib().kqo_assign(C.byref(cfg), C.byref(snap.struct()), C.byref(heads.struct()), C.c_int(hi),
                           F.ptr(cv) if cv is not None else None, C.c_int(n_stub), F.ptr(sf), F.ptr(sp), F.ptr(sb),
-                          F.ptr(flavor), F.ptr(mode), F.ptr(tried), F.ptr(rb), C.byref(rep), C.byref(bor), F.ptr(usage), F.ptr(nre))
+                          F.ptr(flavor), F.ptr(mode), F.ptr(tried), F.ptr(rb), C.byref(rep), C.byref(bor), F.ptr(usage), F.ptr(nre),
+                          C.c_int32(rcap), C.byref(rsn_n), F.ptr(rsn_rec), F.ptr(rsn_abc))
     assert rc == 0, rc
+    from kueue_amd import messages as M
+    reasons = [[] for _ in range(P)]
+    for k in range(min(rsn_n.value, rcap)):
+        p_, code, fl, rs = (int(x) for x in rsn_rec[4 * k:4 * k + 4])
+        a_, b_, c_ = (int(x) for x in rsn_abc[3 * k:3 * k + 3])
+        reasons[p_].extend(M.reason_text(snap, code, fl, rs, a_, b_, c_, ineligible, p_))
     podsets = []
     for p in range(P):
         d = {}
@@ -103,7 +112,8 @@ def assign(cfg, snap: Snapshot, heads: Heads, hi: int = 0, counts=None, stub=Non
                 d[snap.resources[r]] = (snap.flavors[int(flavor[k])], F.MODE_NAMES[int(mode[k])], int(tried[k]), int(rb[k]))
         podsets.append(d)
     use = {snap.fr_name(fr): int(usage[fr]) for fr in range(snap.n_fr) if usage[fr] != 0}
-    return dict(rep_mode=F.MODE_NAMES[rep.value], borrowing=bor.value, podsets=podsets, usage=use, nreasons=[int(x) for x in nre[:P]])
+    return dict(rep_mode=F.MODE_NAMES[rep.value], borrowing=bor.value, podsets=podsets, usage=use, nreasons=[int(x) for x in nre[:P]],
+                reasons=[sorted(x) for x in reasons])
 
 
 def get_targets(cfg, snap: Snapshot, heads: Heads, hi: int, assignment):

@@ -2,13 +2,20 @@
 
 // Package kqengine binds the MI355X admission engine (include/kq_engine.h) into Kueue's scheduler.
 //
-// NOT COMPILED IN THIS REPOSITORY'S CI: the build image has no Go toolchain. This file is the reviewed
-// source a Kueue maintainer would drop under pkg/scheduler/kqengine and build with
-//   CGO_ENABLED=1 go build -tags kq_hip ./cmd/kueue
+// NOT COMPILED IN THIS REPOSITORY'S CI: the build image has no Go toolchain (`go version`: not found). These files are the
+// source a Kueue maintainer drops under pkg/scheduler/kqengine and builds with
+//
+//	CGO_ENABLED=1 go build -tags kq_hip ./cmd/kueue
+//
 // (the reference builds with CGO_ENABLED=0, Makefile:69, so the tag keeps the stock build untouched).
 //
-// Call site: (*Scheduler).schedule, pkg/scheduler/scheduler.go:340-362 — between cache.Snapshot() and the
-// requeue loop. See INTEGRATION.md for the patch.
+//	kqengine.go  the cgo binding: Engine, flat SoA buffers, pinning, RunCycle, the pending-side entry points
+//	flatten.go   *schdcache.Snapshot / []qcache.Head  ->  FlatSnapshot / FlatHeads
+//	apply.go     FlatDecisions -> entries (assignment, targets, status, requeue reason, inadmissible message)
+//	messages.go  reason records -> the strings flavorassigner.go formats (twin of kueue_amd/messages.py, which the tests run)
+//
+// Call site: (*Scheduler).schedule, pkg/scheduler/scheduler.go:340-362 — between cache.Snapshot() and the requeue loop.
+// See INTEGRATION.md for the patch.
 package kqengine
 
 /*
@@ -62,90 +69,258 @@ func New(cfg Config) (*Engine, error) {
 
 func (e *Engine) Close() { C.kq_engine_destroy(e.h); e.h = nil }
 
-// FlatSnapshot / FlatHeads / FlatDecisions are Go-side SoA buffers (plain slices) filled by flatten.go from
-// *schdcache.Snapshot and []qcache.Head. Slices are pinned for the duration of one call with runtime.Pinner
-// (Go 1.21+), which satisfies the cgo pointer-passing rules: C keeps no pointer after returning.
-type FlatSnapshot struct {
-	NCQ, NCohort, NFlavor, NResource, PodsResource int32
-	ResourceOrder, Parent                          []int32
-	ChildCohortOff, ChildCohort, ChildCQOff, ChildCQ []int32
-	FairWeight                                     []float64
-	Nominal, BorrowLimit, LendLimit, SubtreeQuota, Usage []int64
-	QuotaFlags                                     []uint8
-	CQRgOff, RgFlavorOff, RgFlavor, RgResOff, RgRes []int32
-	CQPolicy                                       []uint32
-	CQBorrowPrioThreshold                          []int32
-	CQGeneration                                   []int64
-	NAdm                                           int32
-	CQAdmOff                                       []int32
-	AdmPriority, AdmQueueTs, AdmReserveTs          []int64
-	AdmUIDRank                                     []uint32
-	AdmFlags                                       []uint8
-	AdmUseOff, AdmUseFr                            []int32
-	AdmUseQty                                      []int64
+func (e *Engine) err(what string, rc C.int) error {
+	return fmt.Errorf("%s: %s (%s)", what, C.GoString(C.kq_strerror(rc)), C.GoString(C.kq_last_error(e.h)))
 }
 
-func p32(s []int32) *C.int32_t {
-	if len(s) == 0 {
-		return nil
-	}
-	return (*C.int32_t)(unsafe.Pointer(&s[0]))
+// FlatSnapshot / FlatHeads / FlatDecisions are Go-side SoA buffers (plain slices) filled by flatten.go from
+// *schdcache.Snapshot and []qcache.Head. The C structs that carry their addresses are allocated with C.malloc (so the struct
+// itself is not Go memory) and every slice's backing array is pinned with runtime.Pinner (Go 1.21+) for the duration of
+// the call: that is what the cgo pointer-passing rules ask for a C struct holding several Go pointers. The engine keeps no
+// pointer after returning.
+type FlatSnapshot struct {
+	NCQ, NCohort, NFlavor, NResource, PodsResource     int32
+	ResourceOrder, Parent                              []int32
+	ChildCohortOff, ChildCohort, ChildCQOff, ChildCQ   []int32
+	FairWeight                                         []float64
+	Nominal, BorrowLimit, LendLimit, SubtreeQuota, Usage []int64
+	QuotaFlags                                         []uint8
+	CQRgOff, RgFlavorOff, RgFlavor, RgResOff, RgRes    []int32
+	CQPolicy                                           []uint32
+	CQBorrowPrioThreshold                              []int32
+	CQGeneration                                       []int64
+	NAdm                                               int32
+	CQAdmOff                                           []int32
+	AdmPriority, AdmQueueTs, AdmReserveTs              []int64
+	AdmUIDRank                                         []uint32
+	AdmFlags                                           []uint8
+	AdmUseOff, AdmUseFr                                []int32
+	AdmUseQty                                          []int64
+
+	// dictionaries kept on the Go side (names never cross the boundary)
+	CQNames, CohortNames, FlavorNames, ResourceNames []string
+	AdmKeys                                           []string // workload.Reference of every admitted row
 }
-func p64(s []int64) *C.int64_t {
-	if len(s) == 0 {
-		return nil
-	}
-	return (*C.int64_t)(unsafe.Pointer(&s[0]))
+
+type FlatHeads struct {
+	N                                         int32
+	Cycle                                     int64
+	CQ                                        []int32
+	Priority, QueueTs                         []int64
+	Flags                                     []uint32
+	PsOff, PsCount, PsMinCount, PsReqOff, ReqRes []int32
+	ReqQty                                    []int64
+	PsFlavorOK                                []uint64
+	PsLastTried                               []int32
+	LastGeneration, LastCycle                 []int64
+	LastHash, Hash                            []uint64
 }
-func pu8(s []uint8) *C.uint8_t {
-	if len(s) == 0 {
-		return nil
-	}
-	return (*C.uint8_t)(unsafe.Pointer(&s[0]))
+
+type FlatDecisions struct {
+	Status, Action, NominatedMode, Mode, RequeueReason, Skip []uint8
+	Borrowing, Order                                          []int32
+	Flavor                                                    []int32
+	ResMode                                                   []uint8
+	TriedIdx                                                  []int32
+	PsCount                                                   []int32
+	TgtOff, TgtAdm                                            []int32
+	TgtReason                                                 []uint8
+	RsnOff                                                    []int32
+	RsnCode, RsnPodset                                        []uint8
+	RsnFlavor, RsnResource                                    []int16
+	RsnA, RsnB, RsnC                                          []int64
 }
-func pu32(s []uint32) *C.uint32_t {
-	if len(s) == 0 {
-		return nil
-	}
-	return (*C.uint32_t)(unsafe.Pointer(&s[0]))
+
+// NewDecisions sizes the output buffers for a heads batch: per head, per (podset, resource), a target pool of tgtCap rows and
+// rsnCap reason records.
+func NewDecisions(h *FlatHeads, nResource int32, tgtCap, rsnCap int) *FlatDecisions {
+	n, nps := int(h.N), int(h.PsOff[h.N])
+	d := &FlatDecisions{}
+	d.Status, d.Action, d.NominatedMode = make([]uint8, n), make([]uint8, n), make([]uint8, n)
+	d.Mode, d.RequeueReason, d.Skip = make([]uint8, n), make([]uint8, n), make([]uint8, n)
+	d.Borrowing, d.Order = make([]int32, n), make([]int32, n)
+	d.Flavor, d.ResMode, d.TriedIdx = make([]int32, nps*int(nResource)), make([]uint8, nps*int(nResource)), make([]int32, nps*int(nResource))
+	d.PsCount = make([]int32, nps)
+	d.TgtOff, d.TgtAdm, d.TgtReason = make([]int32, n+1), make([]int32, tgtCap), make([]uint8, tgtCap)
+	d.RsnOff = make([]int32, n+1)
+	d.RsnCode, d.RsnPodset = make([]uint8, rsnCap), make([]uint8, rsnCap)
+	d.RsnFlavor, d.RsnResource = make([]int16, rsnCap), make([]int16, rsnCap)
+	d.RsnA, d.RsnB, d.RsnC = make([]int64, rsnCap), make([]int64, rsnCap), make([]int64, rsnCap)
+	return d
 }
-func pf64(s []float64) *C.double {
+
+// pin returns &s[0] as an unsafe.Pointer (nil for an empty slice) after pinning the backing array.
+func pin[T any](p *runtime.Pinner, s []T) unsafe.Pointer {
 	if len(s) == 0 {
 		return nil
 	}
-	return (*C.double)(unsafe.Pointer(&s[0]))
+	p.Pin(&s[0])
+	return unsafe.Pointer(&s[0])
 }
 
 // PutSnapshot uploads cache.Snapshot() (pkg/cache/scheduler/snapshot.go:171) to HBM.
 func (e *Engine) PutSnapshot(s *FlatSnapshot) error {
-	var pin runtime.Pinner
-	defer pin.Unpin()
-	for _, p := range []any{&s.ResourceOrder, &s.Parent, &s.Nominal, &s.Usage} {
-		_ = p // every slice's backing array is pinned in the real shim (elided: one pin.Pin(&slice[0]) per field)
-	}
-	c := C.kq_snapshot{
-		n_cq: C.int32_t(s.NCQ), n_cohort: C.int32_t(s.NCohort), n_flavor: C.int32_t(s.NFlavor), n_resource: C.int32_t(s.NResource),
-		pods_resource: C.int32_t(s.PodsResource), resource_order: p32(s.ResourceOrder), parent: p32(s.Parent),
-		child_cohort_off: p32(s.ChildCohortOff), child_cohort: p32(s.ChildCohort), child_cq_off: p32(s.ChildCQOff), child_cq: p32(s.ChildCQ),
-		fair_weight: pf64(s.FairWeight), nominal: p64(s.Nominal), borrow_limit: p64(s.BorrowLimit), lend_limit: p64(s.LendLimit),
-		subtree_quota: p64(s.SubtreeQuota), usage: p64(s.Usage), quota_flags: pu8(s.QuotaFlags),
-		cq_rg_off: p32(s.CQRgOff), rg_flavor_off: p32(s.RgFlavorOff), rg_flavor: p32(s.RgFlavor), rg_res_off: p32(s.RgResOff), rg_res: p32(s.RgRes),
-		cq_policy: pu32(s.CQPolicy), cq_borrow_prio_threshold: p32(s.CQBorrowPrioThreshold), cq_generation: p64(s.CQGeneration),
-		n_adm: C.int32_t(s.NAdm), cq_adm_off: p32(s.CQAdmOff), adm_priority: p64(s.AdmPriority), adm_queue_ts: p64(s.AdmQueueTs),
-		adm_reserve_ts: p64(s.AdmReserveTs), adm_uid_rank: pu32(s.AdmUIDRank), adm_flags: pu8(s.AdmFlags),
-		adm_use_off: p32(s.AdmUseOff), adm_use_fr: p32(s.AdmUseFr), adm_use_qty: p64(s.AdmUseQty),
-	}
-	if rc := C.kq_snapshot_put(e.h, &c); rc != 0 {
-		return fmt.Errorf("kq_snapshot_put: %s (%s)", C.GoString(C.kq_strerror(rc)), C.GoString(C.kq_last_error(e.h)))
+	var p runtime.Pinner
+	defer p.Unpin()
+	c := (*C.kq_snapshot)(C.calloc(1, C.sizeof_kq_snapshot))
+	defer C.free(unsafe.Pointer(c))
+	c.n_cq, c.n_cohort, c.n_flavor, c.n_resource = C.int32_t(s.NCQ), C.int32_t(s.NCohort), C.int32_t(s.NFlavor), C.int32_t(s.NResource)
+	c.pods_resource = C.int32_t(s.PodsResource)
+	c.resource_order = (*C.int32_t)(pin(&p, s.ResourceOrder))
+	c.parent = (*C.int32_t)(pin(&p, s.Parent))
+	c.child_cohort_off = (*C.int32_t)(pin(&p, s.ChildCohortOff))
+	c.child_cohort = (*C.int32_t)(pin(&p, s.ChildCohort))
+	c.child_cq_off = (*C.int32_t)(pin(&p, s.ChildCQOff))
+	c.child_cq = (*C.int32_t)(pin(&p, s.ChildCQ))
+	c.fair_weight = (*C.double)(pin(&p, s.FairWeight))
+	c.nominal = (*C.int64_t)(pin(&p, s.Nominal))
+	c.borrow_limit = (*C.int64_t)(pin(&p, s.BorrowLimit))
+	c.lend_limit = (*C.int64_t)(pin(&p, s.LendLimit))
+	c.subtree_quota = (*C.int64_t)(pin(&p, s.SubtreeQuota))
+	c.usage = (*C.int64_t)(pin(&p, s.Usage))
+	c.quota_flags = (*C.uint8_t)(pin(&p, s.QuotaFlags))
+	c.cq_rg_off = (*C.int32_t)(pin(&p, s.CQRgOff))
+	c.rg_flavor_off = (*C.int32_t)(pin(&p, s.RgFlavorOff))
+	c.rg_flavor = (*C.int32_t)(pin(&p, s.RgFlavor))
+	c.rg_res_off = (*C.int32_t)(pin(&p, s.RgResOff))
+	c.rg_res = (*C.int32_t)(pin(&p, s.RgRes))
+	c.cq_policy = (*C.uint32_t)(pin(&p, s.CQPolicy))
+	c.cq_borrow_prio_threshold = (*C.int32_t)(pin(&p, s.CQBorrowPrioThreshold))
+	c.cq_generation = (*C.int64_t)(pin(&p, s.CQGeneration))
+	c.n_adm = C.int32_t(s.NAdm)
+	c.cq_adm_off = (*C.int32_t)(pin(&p, s.CQAdmOff))
+	c.adm_priority = (*C.int64_t)(pin(&p, s.AdmPriority))
+	c.adm_queue_ts = (*C.int64_t)(pin(&p, s.AdmQueueTs))
+	c.adm_reserve_ts = (*C.int64_t)(pin(&p, s.AdmReserveTs))
+	c.adm_uid_rank = (*C.uint32_t)(pin(&p, s.AdmUIDRank))
+	c.adm_flags = (*C.uint8_t)(pin(&p, s.AdmFlags))
+	c.adm_use_off = (*C.int32_t)(pin(&p, s.AdmUseOff))
+	c.adm_use_fr = (*C.int32_t)(pin(&p, s.AdmUseFr))
+	c.adm_use_qty = (*C.int64_t)(pin(&p, s.AdmUseQty))
+	if rc := C.kq_snapshot_put(e.h, c); rc != 0 {
+		return e.err("kq_snapshot_put", rc)
 	}
 	return nil
 }
 
+func fillHeads(p *runtime.Pinner, c *C.kq_heads, h *FlatHeads) {
+	c.n, c.cycle = C.int32_t(h.N), C.int64_t(h.Cycle)
+	c.cq = (*C.int32_t)(pin(p, h.CQ))
+	c.priority = (*C.int64_t)(pin(p, h.Priority))
+	c.queue_ts = (*C.int64_t)(pin(p, h.QueueTs))
+	c.flags = (*C.uint32_t)(pin(p, h.Flags))
+	c.ps_off = (*C.int32_t)(pin(p, h.PsOff))
+	c.ps_count = (*C.int32_t)(pin(p, h.PsCount))
+	c.ps_min_count = (*C.int32_t)(pin(p, h.PsMinCount))
+	c.ps_req_off = (*C.int32_t)(pin(p, h.PsReqOff))
+	c.req_res = (*C.int32_t)(pin(p, h.ReqRes))
+	c.req_qty = (*C.int64_t)(pin(p, h.ReqQty))
+	c.ps_flavor_ok = (*C.uint64_t)(pin(p, h.PsFlavorOK))
+	c.ps_last_tried = (*C.int32_t)(pin(p, h.PsLastTried))
+	c.last_generation = (*C.int64_t)(pin(p, h.LastGeneration))
+	c.last_cycle = (*C.int64_t)(pin(p, h.LastCycle))
+	c.last_hash = (*C.uint64_t)(pin(p, h.LastHash))
+	c.hash = (*C.uint64_t)(pin(p, h.Hash))
+}
+
+func fillDecisions(p *runtime.Pinner, c *C.kq_decisions, d *FlatDecisions) {
+	c.status = (*C.uint8_t)(pin(p, d.Status))
+	c.action = (*C.uint8_t)(pin(p, d.Action))
+	c.nominated_mode = (*C.uint8_t)(pin(p, d.NominatedMode))
+	c.mode = (*C.uint8_t)(pin(p, d.Mode))
+	c.requeue_reason = (*C.uint8_t)(pin(p, d.RequeueReason))
+	c.skip = (*C.uint8_t)(pin(p, d.Skip))
+	c.borrowing = (*C.int32_t)(pin(p, d.Borrowing))
+	c.order = (*C.int32_t)(pin(p, d.Order))
+	c.flavor = (*C.int32_t)(pin(p, d.Flavor))
+	c.res_mode = (*C.uint8_t)(pin(p, d.ResMode))
+	c.tried_idx = (*C.int32_t)(pin(p, d.TriedIdx))
+	c.ps_count = (*C.int32_t)(pin(p, d.PsCount))
+	c.tgt_off = (*C.int32_t)(pin(p, d.TgtOff))
+	c.tgt_cap = C.int32_t(len(d.TgtAdm))
+	c.tgt_adm = (*C.int32_t)(pin(p, d.TgtAdm))
+	c.tgt_reason = (*C.uint8_t)(pin(p, d.TgtReason))
+	c.rsn_cap = C.int32_t(len(d.RsnCode))
+	c.rsn_off = (*C.int32_t)(pin(p, d.RsnOff))
+	c.rsn_code = (*C.uint8_t)(pin(p, d.RsnCode))
+	c.rsn_podset = (*C.uint8_t)(pin(p, d.RsnPodset))
+	c.rsn_flavor = (*C.int16_t)(pin(p, d.RsnFlavor))
+	c.rsn_resource = (*C.int16_t)(pin(p, d.RsnResource))
+	c.rsn_a = (*C.int64_t)(pin(p, d.RsnA))
+	c.rsn_b = (*C.int64_t)(pin(p, d.RsnB))
+	c.rsn_c = (*C.int64_t)(pin(p, d.RsnC))
+}
+
 // RunCycle = nominate + iterator + processEntry (scheduler.go:308-386 steps 3-5) on the device.
 // On ANY error the caller runs the stock Go path for this cycle (the engine is stateless across cycles).
-func (e *Engine) RunCycle(h *C.kq_heads, out *C.kq_decisions) error {
-	if rc := C.kq_cycle_run(e.h, h, out); rc != 0 {
-		return fmt.Errorf("kq_cycle_run: %s (%s)", C.GoString(C.kq_strerror(rc)), C.GoString(C.kq_last_error(e.h)))
+func (e *Engine) RunCycle(h *FlatHeads, out *FlatDecisions) error {
+	var p runtime.Pinner
+	defer p.Unpin()
+	ch := (*C.kq_heads)(C.calloc(1, C.sizeof_kq_heads))
+	defer C.free(unsafe.Pointer(ch))
+	cd := (*C.kq_decisions)(C.calloc(1, C.sizeof_kq_decisions))
+	defer C.free(unsafe.Pointer(cd))
+	fillHeads(&p, ch, h)
+	fillDecisions(&p, cd, out)
+	if rc := C.kq_cycle_run(e.h, ch, cd); rc != 0 {
+		return e.err("kq_cycle_run", rc)
+	}
+	return nil
+}
+
+// ---- pending side on the device (pkg/cache/queue): see include/kq_engine.h "pending side" -----------------------
+
+// PutPending = PushOrUpdate of every pending workload (cluster_queue.go:379). uidRank[w] = rank of Obj.UID.
+func (e *Engine) PutPending(all *FlatHeads, uidRank []uint32) error {
+	var p runtime.Pinner
+	defer p.Unpin()
+	c := (*C.kq_pending)(C.calloc(1, C.sizeof_kq_pending))
+	defer C.free(unsafe.Pointer(c))
+	fillHeads(&p, &c.w, all)
+	c.uid_rank = (*C.uint32_t)(pin(&p, uidRank))
+	if rc := C.kq_pending_put(e.h, c); rc != 0 {
+		return e.err("kq_pending_put", rc)
+	}
+	return nil
+}
+
+// Heads = queues.Heads() (manager.go:903): pops on the device; headWl[c] = index of the popped workload of ClusterQueue c or -1.
+func (e *Engine) Heads(cycle int64, cqActive []uint8, headWl []int32) (nHeads, nPodsets int32, err error) {
+	var p runtime.Pinner
+	defer p.Unpin()
+	var n, nps C.int32_t
+	if rc := C.kq_pending_heads(e.h, C.int64_t(cycle), (*C.uint8_t)(pin(&p, cqActive)), &n, &nps, (*C.int32_t)(pin(&p, headWl))); rc != 0 {
+		return 0, 0, e.err("kq_pending_heads", rc)
+	}
+	return int32(n), int32(nps), nil
+}
+
+// RunPendingCycle runs the cycle over the heads gathered by Heads; ApplyPending is step 6 of schedule() on the device.
+func (e *Engine) RunPendingCycle(out *FlatDecisions) error {
+	var p runtime.Pinner
+	defer p.Unpin()
+	cd := (*C.kq_decisions)(C.calloc(1, C.sizeof_kq_decisions))
+	defer C.free(unsafe.Pointer(cd))
+	fillDecisions(&p, cd, out)
+	if rc := C.kq_cycle_run_pending(e.h, cd); rc != 0 {
+		return e.err("kq_cycle_run_pending", rc)
+	}
+	return nil
+}
+
+func (e *Engine) ApplyPending() error {
+	if rc := C.kq_pending_apply(e.h); rc != 0 {
+		return e.err("kq_pending_apply", rc)
+	}
+	return nil
+}
+
+// QueueInadmissible = queueInadmissibleWorkloads for the listed ClusterQueues (nil: all), inadmissible_workloads.go:149.
+func (e *Engine) QueueInadmissible(cqs []int32) error {
+	var p runtime.Pinner
+	defer p.Unpin()
+	if rc := C.kq_pending_queue_inadmissible(e.h, C.int32_t(len(cqs)), (*C.int32_t)(pin(&p, cqs))); rc != 0 {
+		return e.err("kq_pending_queue_inadmissible", rc)
 	}
 	return nil
 }

@@ -114,8 +114,8 @@ class EmuEngine:
         self._ok(lib().kqe_pending_read_state(self.h, F.ptr(st), F.ptr(counts)))
         return st[:self.pending.n], counts
 
-    def run(self, heads, want_usage=False, tgt_cap=None):
-        d = Decisions(heads, tgt_cap=tgt_cap)
+    def run(self, heads, want_usage=False, tgt_cap=None, rsn_cap=0):
+        d = Decisions(heads, tgt_cap=tgt_cap, rsn_cap=rsn_cap)
         rc = lib().kqe_cycle_run(self.h, C.byref(heads.struct()), C.byref(d.struct()))
         d.rc = rc
         d.error = lib().kqe_last_error(self.h).decode()

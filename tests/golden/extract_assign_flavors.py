@@ -194,7 +194,12 @@ def parse_want(text):
                 for r in re.finditer(r'([\w\."/-]+):\s*(?:&FlavorAssignment)?\{Name:\s*"([^"]+)",\s*Mode:\s*(\w+)(?:,\s*TriedFlavorIdx:\s*(-?\d+))?\}', el[fm.end():fe]):
                     fl[res_name(r.group(1))] = [r.group(2), r.group(3), int(r.group(4) or 0)]
             cnt = re.search(r"(?m)^\s*Count:\s*(\d+)", el)
-            want["podsets"].append({"flavors": fl, "count": int(cnt.group(1)) if cnt else None})
+            ps_want = {"flavors": fl, "count": int(cnt.group(1)) if cnt else None}
+            sm = re.search(r"Status:\s*\*NewStatus\(", el)
+            if sm:  # PodSetAssignment.Status.reasons (flavorassigner.go:329-339): the strings Status.Message joins
+                se = match_brace(el, sm.end() - 1, "(", ")")
+                ps_want["status"] = [bytes(x, "utf-8").decode("unicode_escape") for x in re.findall(r'"((?:[^"\\]|\\.)*)"', el[sm.end():se])]
+            want["podsets"].append(ps_want)
             i = e + 1
     m = re.search(r"(?m)^\t{4}Borrowing:\s*(\d+)", text)
     want["borrowing"] = int(m.group(1)) if m else 0

@@ -122,6 +122,11 @@ def parse_wl(text, start):
             typ = re.search(r"Type:\s*kueue\.(\w+)", a)
             status = re.search(r"Status:\s*metav1\.Condition(\w+)", a)
             reason = re.search(r'Reason:\s*(?:kueue\.)?"?([\w\.]+)"?', a)
+            if typ and status and typ.group(1) == "WorkloadQuotaReserved" and status.group(1) == "False":
+                # the status message the scheduler patches for a head that stays pending (requeueAndUpdate scheduler.go:1189-1190)
+                mm = re.search(r'Message:\s*((?:"(?:[^"\\]|\\.)*"\s*\+?\s*)+)', a)
+                if mm:
+                    w["pendingMessage"] = "".join(bytes(x, "utf-8").decode("unicode_escape") for x in re.findall(r'"((?:[^"\\]|\\.)*)"', mm.group(1)))
             if typ and status and status.group(1) == "True":
                 if typ.group(1) == "WorkloadPreempted":
                     w["preemptedReason"] = reason.group(1).replace("Reason", "") if reason else ""
@@ -324,6 +329,10 @@ def extract(fname, func, cases, skipped):
                 for k in keys:
                     if k in expect:
                         expect[k]["left"] = "inadmissible"
+            for w in want_wls:
+                k = f"{w['ns']}/{w['name']}"
+                if "pendingMessage" in w and k in expect and not expect[k]["admitted"]:
+                    expect[k]["message"] = w["pendingMessage"]
             preempted = sorted(f"{w['ns']}/{w['name']}:{w['preemptedReason']}" for w in want_wls if "preemptedReason" in w and f"{w['ns']}/{w['name']}" in adm_keys)
             for c in cqs:
                 c.pop("_bad", None)

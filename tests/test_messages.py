@@ -1,0 +1,158 @@
+"""Reason records (kq_decisions.rsn_*, include/kq_engine.h KQ_RSN_*) and the status text regenerated from them (kueue_amd/messages.py,
+shim/go/messages.go) — VERDICT r01 "missing" 5.
+
+ * the regenerated Status.reasons of the oracle's Assign equal the strings of the reference's TestAssignFlavors table
+   (flavorassigner_test.go `Status: *NewStatus(...)`, extracted into tests/golden/assign_flavors.yaml), stub oracle and all;
+ * the regenerated inadmissible message of every pending head equals the QuotaReserved=False condition message the reference's
+   TestSchedule expects (scheduler_test.go wantWorkloads, tests/golden/schedule.yaml `message`), on the oracle AND on the engine
+   (emulation here, HIP in the GPU suite);
+ * the engine's records equal the oracle's, record by record, on random cycles;
+ * resource.Quantity canonical strings against values quoted by the reference's tests.
+"""
+import numpy as np
+import pytest
+
+from kueue_amd import _ffi as F
+from kueue_amd import messages as M
+from kueue_amd.fixtures import load_case
+from tests.conftest import load_golden
+from tests.fixture_cycles import POSS, _stub
+from tests.randgen import random_case
+
+ASG = [c for c in load_golden("assign_flavors.yaml")["cases"] if any("status" in ps for ps in c["want"].get("podsets", []))]
+SCHED = [c for c in load_golden("schedule.yaml")["cases"] if any("message" in e for e in c["expect"].values())]
+
+# checkFlavorForPodSets strings are formatted on the host (taints / affinity never cross the boundary): the text per tainted flavor
+# of the reference's tables (flavorassigner_test.go:260-283, scheduler_test.go:505-530)
+TAINT_TEXT = {"tainted": "untolerated taint {instance spot NoSchedule <nil>} in flavor tainted",
+              "spot-tainted": "untolerated taint {key val NoSchedule <nil>} in flavor spot-tainted",
+              "spot-tainted-2": "untolerated taint {key val2 NoSchedule <nil>} in flavor spot-tainted-2"}
+
+
+def _ineligible(snap):
+    return lambda ps, fl: [TAINT_TEXT[snap.flavors[fl]]]
+
+
+def test_quantity_strings():
+    # values quoted by the reference's expectations
+    assert M.quantity_string("cpu", 500) == "500m"                 # "maximum capacity (500m)" flavorassigner_test.go:3428
+    assert M.quantity_string("cpu", 1000) == "1" and M.quantity_string("cpu", 12000) == "12"
+    assert M.quantity_string("cpu", 10_000_000) == "10k"           # "(10k)" scheduler_test.go
+    assert M.quantity_string("memory", 5 << 20) == "5Mi"           # "5Mi more needed" flavorassigner_test.go:852
+    assert M.quantity_string("memory", 10 << 20) == "10Mi" and M.quantity_string("memory", 1 << 20) == "1Mi"
+    assert M.quantity_string("example.com/gpu", 4) == "4" and M.quantity_string("pods", 3) == "3"
+    assert M.quantity_string("memory", 1000) == "1k" and M.quantity_string("memory", 1536) == "1536" and M.quantity_string("memory", 2000) == "2k"
+    assert M.quantity_string("memory", 0) == "0" and M.quantity_string("cpu", 1500) == "1500m"
+    assert M.amount_string("cpu", M.UNLIMITED) == "<unlimited>"
+
+
+@pytest.mark.parametrize("case", ASG, ids=[c["name"] for c in ASG])
+def test_assign_flavors_status_strings(oracle, case):
+    """FlavorAssigner.Assign with the table's stub oracle -> Status.reasons per podset, regenerated from the operands."""
+    cfg, snap, heads = load_case(case)
+    oracle.derive(snap)
+    got = oracle.assign(cfg, snap, heads, 0, stub=_stub(snap, case), ineligible=_ineligible(snap))
+    for pi, ps in enumerate(case["want"]["podsets"]):
+        assert got["reasons"][pi] == sorted(ps.get("status", [])), (case["name"], pi)
+
+
+def _schedule_messages(oracle, run, case):
+    cfg, snap, heads = load_case(case)
+    oracle.derive(snap)
+    d = run(cfg, snap, heads)
+    out = {}
+    for i, w in enumerate(heads.workloads):
+        if int(d.a["status"][i]) == F.ST_ASSUMED:
+            continue
+        out[w.name] = M.inadmissible_message(d, i, [ps.name for ps in w.pod_sets], _ineligible(snap))
+    return out
+
+
+@pytest.mark.parametrize("case", SCHED, ids=[c["name"] for c in SCHED])
+def test_schedule_messages_oracle_and_emulation(oracle, case):
+    from tests.emu import kqe
+
+    def emu(cfg, snap, heads):
+        eng = kqe.EmuEngine(cfg)
+        try:
+            eng.put(snap)
+            return eng.run(heads, rsn_cap=4096)
+        finally:
+            eng.close()
+    want = {k: e["message"] for k, e in case["expect"].items() if "message" in e}
+    for run in (lambda c, s, h: oracle.cycle_run(c, s, h, rsn_cap=4096), emu):
+        got = _schedule_messages(oracle, run, case)
+        for k, msg in want.items():
+            assert got.get(k) == msg, (case["name"], k, got.get(k))
+
+
+@pytest.mark.gpu
+def test_schedule_messages_gpu(oracle):
+    from kueue_amd.engine import Engine
+
+    def hip(cfg, snap, heads):
+        eng = Engine(cfg)
+        try:
+            eng.put(snap)
+            return eng.run(heads, rsn_cap=4096)
+        finally:
+            eng.close()
+    n = 0
+    for case in SCHED:
+        got = _schedule_messages(oracle, hip, case)
+        for k, e in case["expect"].items():
+            if "message" in e:
+                assert got.get(k) == e["message"], (case["name"], k, got.get(k))
+                n += 1
+    assert n >= 30
+
+
+def _records_match(oracle, factory, seeds, **kw):
+    for seed in seeds:
+        cfg, snap, heads = random_case(seed, **kw)
+        oracle.derive(snap)
+        want = oracle.cycle_run(cfg, snap, heads, rsn_cap=8192)
+        eng = factory(cfg)
+        try:
+            eng.put(snap)
+            got = eng.run(heads, rsn_cap=8192)
+        finally:
+            eng.close()
+        bad = want.equal(got)
+        assert not bad, (seed, bad)
+        assert "rsn_code" in got.a
+
+
+@pytest.mark.parametrize("fair", [False, True])
+def test_reason_records_equal_the_oracle_emulated(oracle, fair):
+    from tests.emu import kqe
+    _records_match(oracle, kqe.EmuEngine, range(200), fair=fair, preemption=True, partial=True)
+
+
+@pytest.mark.gpu
+def test_reason_records_equal_the_oracle_gpu(oracle):
+    from kueue_amd.engine import Engine
+    _records_match(oracle, Engine, range(120), fair=False, preemption=True, partial=True)
+    _records_match(oracle, Engine, range(40), fair=True, preemption=True)
+
+
+def test_reason_window_overflow_is_reported(oracle):
+    """A caller buffer smaller than the records of the cycle -> KQ_ECAPACITY, like the target pool."""
+    from tests.emu import kqe
+    for seed in range(40):
+        cfg, snap, heads = random_case(seed, preemption=True)
+        oracle.derive(snap)
+        want = oracle.cycle_run(cfg, snap, heads, rsn_cap=8192)
+        n = int(want.a["rsn_off"][-1])
+        if n < 2:
+            continue
+        eng = kqe.EmuEngine(cfg)
+        try:
+            eng.put(snap)
+            d = eng.run(heads, rsn_cap=n - 1)
+            assert d.rc == -5
+            assert eng.run(heads, rsn_cap=n).rc == 0
+        finally:
+            eng.close()
+        return
+    raise AssertionError("no case with two reason records")
