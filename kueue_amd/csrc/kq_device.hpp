@@ -271,6 +271,8 @@ struct K {  // everything a kernel needs
   struct PRec* grec;         // [H] per-head entry records, static part (rec_fill_static); k_process copies them into LDS
   const int32_t* usage_big;  // [1] set by kq_cycle_commit / release when a ClusterQueue usage cell left the plain range (>= 2^50 or
                              // negative): the sum-based DRS shortcuts (C.fs_plain) are off from then on
+  int32_t* defer_list;       // [H] heads the lean nominate pass handed to the full pass
+  int32_t* defer_count;      // [1]
 };
 KQ_DEV bool fs_plain_now(const K& k) { return k.C.fs_plain && !(k.usage_big && *k.usage_big); }
 
@@ -515,6 +517,7 @@ struct Wave {
   int64_t cell_val[CELLS];
   int64_t cell_aux[CELLS];        // operand of the cell's reason: maximum capacity (noFit by capacity) or val - available
   int nrsn, rsn_ps0, rsn_g0, rsn_over;  // reason records of the assignment under construction (lane 0)
+  int defer_head;                 // lean nominate pass: this head needs the full pass (victim search / partial admission)
   // best flavor so far
   int32_t best_mode[KQ_MAXREQ], best_borrow[KQ_MAXREQ];
   int32_t cur_mode[KQ_MAXREQ], cur_borrow[KQ_MAXREQ];
@@ -1555,6 +1558,10 @@ KQ_DEV void rsn_push(const K& k, Wave& w, int code, int podset, int flavor, int 
   w.nrsn++;
 }
 
+// LEAN (k_nominate's first pass): no victim search is linked in. A cell that needs SimulatePreemption is answered in place when the
+// ClusterQueue cannot preempt at all (both searches return "no candidates" before reading anything, preemption.go:284-296 / :536-547);
+// otherwise the head is handed to the full pass (w.defer_head) and this call's outputs are dropped.
+template <bool LEAN>
 KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed,
                            const int* counts, bool nominate_map) {
   const DSnap& S = k.S; const DHeads& H = k.H; const DOut& O = k.O;
@@ -1702,7 +1709,13 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
             if (rep_pm == PM_NOFIT) { if (had_status) reasons++; continue; }  // oracle result unused past a noFit (:1161)
             if (pm == PM_NEEDS) {
               int opm, ob;
-              simulate_preemption(k, w, slot, usage, removed, f * nR + w.f_res[kk], w.cell_val[c], borrow, &opm, &ob);
+              if constexpr (LEAN) {
+                const bool can_search = KQ_POL_WITHIN_CQ(w.pol) != KQ_POLICY_NEVER || (w.plen > 1 && KQ_POL_RECLAIM(w.pol) != KQ_POLICY_NEVER);
+                if (can_search) { if (lane == 0) w.defer_head = 1; wsync(); return; }
+                opm = PM_NOCAND; ob = borrow;  // simulate_preemption with an empty target set
+              } else {
+                simulate_preemption(k, w, slot, usage, removed, f * nR + w.f_res[kk], w.cell_val[c], borrow, &opm, &ob);
+              }
               pm = opm; borrow = ob;
             }
             if (had_status) reasons++;
@@ -1869,7 +1882,7 @@ KQ_DEV void load_head(const K& k, Wave& w, int h) {
 KQ_DEV Search get_assignments(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed, bool nominate_map) {
   const DHeads& H = k.H;
   Search s = make_search(k, w, slot, usage, removed);
-  assign_flavors(k, w, slot, usage, removed, nullptr, nominate_map);
+  assign_flavors<false>(k, w, slot, usage, removed, nullptr, nominate_map);
   w.ntgt = 0;
   int arm = w.rep_mode;
   if (arm == M_FIT) return s;
@@ -1895,7 +1908,7 @@ KQ_DEV Search get_assignments(const K& k, Wave& w, int slot, const int64_t* usag
         w.counts[pi] = c - (int)((int64_t)d * (int64_t)si / (int64_t)total_delta);
       }
     wsync();
-    assign_flavors(k, w, slot, usage, removed, w.counts, nominate_map);
+    assign_flavors<false>(k, w, slot, usage, removed, w.counts, nominate_map);
     w.ntgt = 0;
     last_probe = si;
     if (w.rep_mode == M_FIT) return true;
@@ -1913,7 +1926,7 @@ KQ_DEV Search get_assignments(const K& k, Wave& w, int slot, const int64_t* usag
     if (last_probe != good) probe(good);  // regenerate the outputs of the accepted probe
   } else {
     // no reduced count works: the full assignment, no targets (scheduler.go:923)
-    assign_flavors(k, w, slot, usage, removed, nullptr, nominate_map);
+    assign_flavors<false>(k, w, slot, usage, removed, nullptr, nominate_map);
     w.ntgt = 0;
   }
   wsync();
@@ -1939,6 +1952,50 @@ KQ_DEV void publish_assignment(const K& k, Wave& w, const Search& s, int h) {
   pos = w.counts[0];
   if (pos + w.ntgt <= O.pool_cap)
     for (int t = lane_id(); t < w.ntgt; t += WAVE) { O.pool_row[pos + t] = s.trow[t]; O.pool_reason[pos + t] = s.treason[t]; }
+  wsync();
+}
+
+// outputs of a nominated head that k_process / the host read (everything but the assignment rows assign_flavors wrote itself)
+KQ_DEV void nominate_finish(const K& k, Wave& w, int h) {
+  if (lane_id() == 0) {
+    k.O.nominated_mode[h] = (uint8_t)w.rep_mode;
+    k.O.mode[h] = (uint8_t)w.rep_mode;
+    k.O.status[h] = KQ_ST_NOT_NOMINATED; k.O.action[h] = KQ_ACT_NONE; k.O.requeue_reason[h] = KQ_RQ_GENERIC; k.O.skip[h] = KQ_SKIP_NONE;
+    k.O.order[h] = -1;
+    atomic_add_i64(k.O.stat_bytes, (long long)w.bytes);
+  }
+}
+// First pass of nominate: every head whose assignment needs neither a victim search nor the partial-admission search — the bulk
+// of every cycle — is finished here by a kernel that contains nothing else; the others are appended to k.defer_list for the full
+// pass (k_nominate). Same results: a deferred head is recomputed from scratch.
+KQ_DEV void nominate_head_lean(const K& k, Wave& w, int h) {
+  load_head(k, w, h);
+  if (lane_id() == 0) { if (w.has_last && last_assignment_outdated(k, h, w.cq)) w.has_last = 0; w.defer_head = 0; }
+  wsync();
+  assign_flavors<true>(k, w, 0, k.usage, nullptr, nullptr, false);
+  bool defer = w.defer_head != 0;
+  if (!defer && w.rep_mode != M_FIT) {
+    // getInitialAssignments (scheduler.go:880-924) past the first Assign: Preempt asks GetTargets, then the partial-admission search
+    const bool can_search = KQ_POL_WITHIN_CQ(w.pol) != KQ_POLICY_NEVER || (w.plen > 1 && KQ_POL_RECLAIM(w.pol) != KQ_POLICY_NEVER);
+    if (w.rep_mode == M_PREEMPT && can_search) defer = true;
+    if (!defer && gate(k, KQ_GATE_PARTIAL_ADMISSION))
+      for (int pi = 0; pi < w.nps; pi++) {
+        const int c = k.H.ps_count[w.ps_base + pi], mc = k.H.ps_min_count[w.ps_base + pi];
+        if (mc >= 0 && c > mc) defer = true;
+      }
+  }
+  if (defer) {
+    if (lane_id() == 0) { const int pos = atomic_add_i32(k.defer_count, 1); k.defer_list[pos] = h; }
+    wsync();
+    return;
+  }
+  if (lane_id() == 0) {
+    k.O.use_n[h] = w.nuse;
+    for (int e = 0; e < w.nuse; e++) { k.O.use_fr[(size_t)h * KQ_MAXU + e] = w.use_fr[e]; k.O.use_qty[(size_t)h * KQ_MAXU + e] = w.use_qty[e]; }
+    k.O.borrowing[h] = w.borrowing;
+    k.O.tgt_pos[h] = 0; k.O.tgt_n[h] = 0;
+  }
+  nominate_finish(k, w, h);
   wsync();
 }
 
@@ -3426,7 +3483,7 @@ KQ_DEV void derive_cohort_cell(const DSnap& S, const DDerive& d, int cohort, int
 // ------------------------------------------------------------------------------------------------
 // Start-of-cycle housekeeping as ONE launch: fills and device-to-device copies of 4-byte words (k_prep).
 struct DPrepOp { void* dst; const void* src; uint32_t words; uint32_t fill; };  // src == nullptr: fill
-struct DPrep { int n; DPrepOp op[10]; };
+struct DPrep { int n; DPrepOp op[12]; };
 KQ_DEV void prep_word(const DPrep& p, int o, uint32_t i) {
   const DPrepOp& x = p.op[o];
   ((uint32_t*)x.dst)[i] = x.src ? ((const uint32_t*)x.src)[i] : x.fill;

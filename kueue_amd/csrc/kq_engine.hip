@@ -29,6 +29,14 @@ using namespace kq;
 // Kernels take the argument block K by pointer (it lives in HBM and is read through the scalar cache):
 // passing ~700 B by value makes the compiler spill it to scratch as soon as any non-inlined device
 // function takes a reference to it, which put scratch loads into the serial core of k_process.
+// First pass over every head: flavor assignment without any victim-search / partial-admission machinery linked in (the common
+// case by far); heads that need more are appended to K::defer_list.
+__global__ __launch_bounds__(64) void k_nominate_lean(const K* __restrict__ kp, int slots) {
+  const K& k = *kp;
+  __shared__ Wave w;
+  for (int h = blockIdx.x; h < k.H.n; h += slots) nominate_head_lean(k, w, h);
+}
+// Full pass (victim searches, GetTargets, partial admission) over the heads the first pass deferred.
 __global__ __launch_bounds__(64) void k_nominate(const K* __restrict__ kp, int slots, unsigned lds_bytes) {
   const K& k = *kp;
   __shared__ Wave w;
@@ -36,7 +44,8 @@ __global__ __launch_bounds__(64) void k_nominate(const K* __restrict__ kp, int s
   if (threadIdx.x == 0) { w.cs_lds = lds_bytes ? dyn_lds : nullptr; w.cs_lds_bytes = (int)lds_bytes; }
   __syncthreads();
   const int slot = blockIdx.x;
-  for (int h = slot; h < k.H.n; h += slots) nominate_head(k, w, h, slot);
+  const int nd = *k.defer_count;
+  for (int i = slot; i < nd; i += slots) nominate_head(k, w, k.defer_list[i], slot);
 }
 
 // Entry order (scheduler.go:1110-1163): rank(i) = number of entries that precede i. 2-D grid: block (bi, bj)
@@ -376,7 +385,9 @@ struct HipBackend {
       chk(hipFuncSetAttribute((const void*)k_nominate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
       lds_attr_nom = lds;
     }
-    hipLaunchKernelGGL(k_nominate, dim3(slots), dim3(64), lds, stream, put_k(k, 0), slots, (unsigned)lds);
+    const K* d = put_k(k, 0);
+    hipLaunchKernelGGL(k_nominate_lean, dim3(slots), dim3(64), 0, stream, d, slots);
+    hipLaunchKernelGGL(k_nominate, dim3(slots), dim3(64), lds, stream, d, slots, (unsigned)lds);
     chk(hipGetLastError(), "k_nominate");
   }
   void launch_records(const K& k) {

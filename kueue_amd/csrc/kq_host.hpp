@@ -33,7 +33,7 @@ template <class B> struct EngineT {
   // cycle buffers (grow-only)
   struct Buf { void* p = nullptr; size_t cap = 0; };
   std::vector<Buf*> all_bufs;
-  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_grec, b_cqd, b_fs[20];
+  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_grec, b_cqd, b_defer, b_fs[20];
   bool force_exact_drs = false;  // tests: take the saturation-safe DRS loops even when the sums would be exact
   bool cs_disable = false;       // tests: classical victim searches always take the candidate-by-candidate walk
   Buf b_cs;
@@ -110,7 +110,7 @@ template <class B> struct EngineT {
     free_snapshot();
     if (hstage) be.free_host(hstage);
     if (hup) be.free_host(hup);
-    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb, &b_grec, &b_cqd, &b_cs}) if (b->p) be.free(b->p);
+    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb, &b_grec, &b_cqd, &b_cs, &b_defer}) if (b->p) be.free(b->p);
     for (auto& b : b_fs) if (b.p) be.free(b.p);
     for (auto& c : ring) for (Buf* b : {&c.cq, &c.use_n, &c.use_fr, &c.use_qty}) if (b->p) be.free(b->p);
     for (auto& hbch : batches) for (auto& b : hbch.hb) if (b.p) be.free(b.p);
@@ -494,6 +494,8 @@ template <class B> struct EngineT {
     k.prof = (long long*)grow<int64_t>(b_prof, 32);
     k.grec = grow<PRec>(b_grec, n);
     k.cq_dirty = grow<uint8_t>(b_cqd, std::max(prep.nq, 1));  // cleared per head by k_records
+    k.defer_list = grow<int32_t>(b_defer, (size_t)n + 1); k.defer_count = k.defer_list + n;
+    prep_fill(k.defer_count, 1, 0);
     int32_t* order_idx = grow<int32_t>(b_order, n);
     k.order_idx = order_idx;
     int32_t* rank = grow<int32_t>(b_rank, n);

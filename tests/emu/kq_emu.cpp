@@ -24,7 +24,7 @@ struct EmuBackend {
   void memset(void* d, int v, size_t n) { ::memset(d, v, n); }
   int sync() { return KQ_OK; }
   const char* error() { return ""; }
-  int rot = 0;
+  int rot = 0, nom_rot = 0;
   int max_slots() { return 7; }  // small on purpose: exercises the grid-stride loop over heads
   void timer_mark(int) {}
   double timer_ms(int, int) { return 0; }
@@ -76,11 +76,16 @@ struct EmuBackend {
   }
   void launch_nominate(const K& k, int slots, size_t lds) {
     std::vector<int64_t> region(lds / 8 + 8);
+    // every other launch skips the lean first pass, so that the full pass also sees the heads the lean one would have finished
+    const bool lean = (nom_rot++ & 1) == 0;
+    if (lean) { for (int slot = 0; slot < slots; slot++) { Wave w{}; for (int h = slot; h < k.H.n; h += slots) nominate_head_lean(k, w, h); } }
+    else { for (int h = 0; h < k.H.n; h++) k.defer_list[h] = h; *k.defer_count = k.H.n; }
+    const int nd = *k.defer_count;
     for (int slot = 0; slot < slots; slot++) {
       Wave w{};
       // alternate between "LDS" and the spill space so that both placements of the search arrays are exercised
       if (lds && ((slot + rot) & 1)) { w.cs_lds = (unsigned char*)region.data(); w.cs_lds_bytes = (int)lds; }
-      for (int h = slot; h < k.H.n; h += slots) nominate_head(k, w, h, slot);
+      for (int i = slot; i < nd; i += slots) nominate_head(k, w, k.defer_list[i], slot);
     }
   }
   void launch_records(const K& k) {

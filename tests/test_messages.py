@@ -156,3 +156,30 @@ def test_reason_window_overflow_is_reported(oracle):
             eng.close()
         return
     raise AssertionError("no case with two reason records")
+
+
+def test_eighteen_podsets(oracle):
+    """The API's limit (apis/kueue/v1beta2/workload_types.go:36 MaxItems=18) is inside the device path (KQ_MAXPS = 18, KQ_MAXU = 96)."""
+    from kueue_amd.api import (ClusterQueue, Cohort, FlavorQuotas, Heads, PodSet, ResourceGroup, ResourceQuota, Snapshot, Workload, make_config)
+    from tests.emu import kqe
+    fqs = [FlavorQuotas(f"f{i}", {"cpu": ResourceQuota(20_000, 5_000), "memory": ResourceQuota(64 << 30), "example.com/gpu": ResourceQuota(8), "pods": ResourceQuota(100)})
+           for i in range(3)]
+    cqs = [ClusterQueue(f"cq{i}", cohort="root", resource_groups=[ResourceGroup(fqs)]) for i in range(2)]
+    snap = Snapshot(cqs, [Cohort("root")], [], now_ns=1)
+    snap.derive()
+    wls = []
+    for i in range(2):
+        ps = [PodSet(f"ps{j:02d}", count=1 + j % 3, requests={"cpu": 500 * (1 + j % 4), "memory": (1 + j % 5) << 28, "example.com/gpu": j % 2}) for j in range(18)]
+        wls.append(Workload(f"w{i}", f"cq{i}", priority=i, creation_ts=i + 1, pod_sets=ps, uid=f"{i}"))
+    heads = Heads(snap, wls, cycle=1)
+    cfg = make_config()
+    want = oracle.cycle_run(cfg, snap, heads, rsn_cap=4096)
+    eng = kqe.EmuEngine(cfg)
+    try:
+        eng.put(snap)
+        got = eng.run(heads, rsn_cap=4096)
+        assert got.rc == 0, got.error
+        assert not want.equal(got)
+        assert (got.a["flavor"].reshape(36, -1) >= 0).any(axis=1).all()
+    finally:
+        eng.close()
