@@ -348,6 +348,24 @@ int  kq_pending_read_state(kq_engine* e, uint8_t* state, int32_t* counts);
 int  kq_cycle_commit(kq_engine* e, int32_t* n_admitted);
 int  kq_cycle_release(kq_engine* e, int32_t age);
 
+/* ---- one root cohort tree split across GPUs -------------------------------------------------
+ * Shards of one root tree (unions of the root's child subtrees) share only the ROOT's usage row: usage bubbles along the path
+ * (resource_node.go:144-165). Every rank runs the cycle over the heads of ITS ClusterQueues against the same cycle-start
+ * snapshot; then
+ *   kq_cycle_certificate  usage_delta_dev[N * n_fr] (a buffer in the engine's device memory: the RCCL send buffer) = what this
+ *                         rank's cycle added to every usage cell; root_margin[n_tree * n_fr] (host) = for every flavor-resource the
+ *                         smallest slack an admitted entry of this rank had in the root term of Available (resource_node.go:106-122);
+ *                         flags[n_tree] (host) != 0: some entry changed usage outside the certificate (preemption targets,
+ *                         recomputation, non-plain amounts, negative reservation, fair sharing).
+ *   all-reduce(sum, int64) of the deltas over the ranks. If on every rank, for every flavor-resource, the root usage the OTHER
+ *   ranks added is within that rank's slack and no flag is set, every decision is the one the unsharded cycle takes (an admitted
+ *   entry still fits with the others' usage in front of it; a rejected one stays rejected because Available only shrinks). Otherwise
+ *   the ranks run the whole cycle redundantly (kq_cycle_run over all heads).
+ *   kq_snapshot_usage_add folds the reduced ClusterQueue-level delta ([n_cq * n_fr], device memory) into the resident snapshot
+ *   (sign +1) — or takes it out again when those workloads finish (sign -1); cohort usage follows from it. */
+int  kq_cycle_certificate(kq_engine* e, int64_t* usage_delta_dev, int64_t* root_margin, int32_t* flags);
+int  kq_snapshot_usage_add(kq_engine* e, const int64_t* delta_dev, int32_t sign);
+
 /* Per-kernel device time of the last cycle, HIP events on the engine's stream:
  * phase_ms[0] nominate, [1] order, [2] process; phase_bytes[0] nominate, [1] process (algorithmic bytes). */
 int  kq_last_cycle_phases(kq_engine* e, double* phase_ms, int64_t* phase_bytes);

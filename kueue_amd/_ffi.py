@@ -231,6 +231,10 @@ def load_engine():
     lib.kq_pending_read_state.argtypes = [C.c_void_p, u8p, i32p]
     for f in ("kq_pending_put", "kq_pending_heads", "kq_cycle_run_pending", "kq_pending_apply", "kq_pending_queue_inadmissible", "kq_pending_read_state"):
         getattr(lib, f).restype = C.c_int
+    lib.kq_cycle_certificate.argtypes = [C.c_void_p, C.c_void_p, i64p, i32p]
+    lib.kq_cycle_certificate.restype = C.c_int
+    lib.kq_snapshot_usage_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    lib.kq_snapshot_usage_add.restype = C.c_int
     lib.kq_last_cycle_phases.argtypes = [C.c_void_p, f64p, i64p]
     lib.kq_last_cycle_phases.restype = C.c_int
     lib.kq_last_cycle_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -258,6 +262,7 @@ ABI_SYMBOLS = [
     "kq_engine_create", "kq_engine_destroy", "kq_snapshot_put", "kq_cycle_run", "kq_last_cycle_stats",
     "kq_cycle_commit", "kq_cycle_release", "kq_snapshot_derive", "kq_snapshot_read_planes", "kq_strerror", "kq_last_error", "kq_abi_version",
     "kq_heads_put", "kq_cycle_run_resident", "kq_nominate_run_resident", "kq_last_cycle_phases",
+    "kq_cycle_certificate", "kq_snapshot_usage_add",
     "kq_pending_put", "kq_pending_heads", "kq_cycle_run_pending", "kq_pending_apply", "kq_pending_queue_inadmissible", "kq_pending_read_state",
     "kq_debug_read_usage_work", "kq_debug_force_exact_drs", "kq_debug_prof", "kq_debug_disable_scan_search",
 ]

@@ -556,6 +556,27 @@ class Heads:
             self._struct = h
         return self._struct
 
+    def subset(self, idx, cycle: Optional[int] = None) -> "Heads":
+        """The batch made of heads `idx` (in that order): every per-head, per-podset and per-request array gathered."""
+        a = self.arrays
+        idx = np.asarray(idx, np.int64)
+        nR, nfw = self.snap.n_resource, (self.snap.n_flavor + 63) // 64
+        ps0, ps1 = a["ps_off"][idx], a["ps_off"][idx + 1]
+        nps = ps1 - ps0
+        ps_idx = np.concatenate([np.arange(x, y) for x, y in zip(ps0, ps1)]).astype(np.int64) if len(idx) else np.zeros(0, np.int64)
+        r0, r1 = a["ps_req_off"][ps_idx], a["ps_req_off"][ps_idx + 1]
+        req_idx = np.concatenate([np.arange(x, y) for x, y in zip(r0, r1)]).astype(np.int64) if len(ps_idx) else np.zeros(0, np.int64)
+        rows = lambda name, w: a[name].reshape(-1, w)[ps_idx].reshape(-1)
+        b = dict(cq=a["cq"][idx], priority=a["priority"][idx], queue_ts=a["queue_ts"][idx], flags=a["flags"][idx].copy(),
+                 ps_off=np.concatenate([[0], np.cumsum(nps)]).astype(np.int32), ps_count=a["ps_count"][ps_idx], ps_min_count=a["ps_min_count"][ps_idx],
+                 ps_req_off=np.concatenate([[0], np.cumsum(r1 - r0)]).astype(np.int32), req_res=a["req_res"][req_idx], req_qty=a["req_qty"][req_idx],
+                 ps_flavor_ok=rows("ps_flavor_ok", nfw), ps_last_tried=rows("ps_last_tried", nR).copy(),
+                 last_generation=a["last_generation"][idx].copy(), last_cycle=a["last_cycle"][idx].copy(), last_hash=a["last_hash"][idx].copy(), hash=a["hash"][idx])
+        h = Heads.from_arrays(self.snap, b, cycle=self.cycle if cycle is None else cycle)
+        if self.workloads is not None:
+            h.workloads = [self.workloads[int(i)] for i in idx]
+        return h
+
 
 class Pending:
     """kq_pending: every pending workload of every ClusterQueue (the heaps of pkg/cache/queue), as one heads-shaped table
@@ -580,20 +601,7 @@ class Pending:
 
     def heads_of(self, wl: np.ndarray, cycle: int) -> "Heads":
         """The kq_heads batch of the workloads `wl` with their STATIC columns (resume state left at its initial value)."""
-        a = self.heads.arrays
-        nR, nfw = self.snap.n_resource, (self.snap.n_flavor + 63) // 64
-        ps0, ps1 = a["ps_off"][wl], a["ps_off"][wl + 1]
-        nps = ps1 - ps0
-        ps_idx = np.concatenate([np.arange(x, y) for x, y in zip(ps0, ps1)]) if len(wl) else np.zeros(0, np.int64)
-        r0, r1 = a["ps_req_off"][ps_idx], a["ps_req_off"][ps_idx + 1]
-        req_idx = np.concatenate([np.arange(x, y) for x, y in zip(r0, r1)]) if len(ps_idx) else np.zeros(0, np.int64)
-        rows = lambda name, w: a[name].reshape(-1, w)[ps_idx].reshape(-1)
-        b = dict(cq=a["cq"][wl], priority=a["priority"][wl], queue_ts=a["queue_ts"][wl], flags=a["flags"][wl].copy(),
-                 ps_off=np.concatenate([[0], np.cumsum(nps)]).astype(np.int32), ps_count=a["ps_count"][ps_idx], ps_min_count=a["ps_min_count"][ps_idx],
-                 ps_req_off=np.concatenate([[0], np.cumsum(r1 - r0)]).astype(np.int32), req_res=a["req_res"][req_idx], req_qty=a["req_qty"][req_idx],
-                 ps_flavor_ok=rows("ps_flavor_ok", nfw), ps_last_tried=rows("ps_last_tried", nR).copy(),
-                 last_generation=a["last_generation"][wl].copy(), last_cycle=a["last_cycle"][wl].copy(), last_hash=a["last_hash"][wl].copy(), hash=a["hash"][wl])
-        return Heads.from_arrays(self.snap, b, cycle=cycle)
+        return self.heads.subset(wl, cycle)
 
 
 class Decisions:

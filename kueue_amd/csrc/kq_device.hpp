@@ -273,6 +273,13 @@ struct K {  // everything a kernel needs
                              // negative): the sum-based DRS shortcuts (C.fs_plain) are off from then on
   int32_t* defer_list;       // [H] heads the lean nominate pass handed to the full pass
   int32_t* defer_count;      // [1]
+  // Exactness certificate of a cycle run on a SHARD of a root tree (kueue_amd/sharding.py): for every flavor-resource
+  // the smallest slack any admitted entry had at the ROOT level of Available (root term of resource_node.go:106-122 minus the
+  // request). The root is the only node shards of one tree share; if the usage all other shards add to it stays within this slack,
+  // every decision of this shard is the one the unsharded cycle takes. cert_flags: an entry changed usage on a path the slack
+  // does not cover (preemption targets, recomputation, non-plain operands, negative reservation, fair sharing).
+  long long* root_margin;    // [n_tree * nfr], start = CERT_INF
+  int32_t* cert_flags;       // [n_tree]
 };
 KQ_DEV bool fs_plain_now(const K& k) { return k.C.fs_plain && !(k.usage_big && *k.usage_big); }
 
@@ -309,6 +316,30 @@ KQ_DEV int64_t a_sub(int64_t a, int64_t b) {
 }
 KQ_DEV int64_t i64max(int64_t a, int64_t b) { return a > b ? a : b; }
 KQ_DEV int64_t i64min(int64_t a, int64_t b) { return a < b ? a : b; }
+
+// ---- sharding certificate helpers (K::root_margin) ----
+constexpr long long CERT_INF = 0x7f7f7f7f7f7f7f7fll;  // k_prep fills 32-bit words
+constexpr int64_t CERT_PLAIN = (int64_t)1 << 56;       // = PLAIN_LIMIT: slack arithmetic is only exact on plain operands
+KQ_DEV void cert_min(long long* cell, long long v) {
+#ifdef KQ_HOST_EMU
+  if (v < *cell) *cell = v;
+#else
+  atomicMin(cell, v);
+#endif
+}
+// Slack of the root term with resources.Amount arithmetic (Unlimited absorbing, saturating): operands that are not plain. An
+// Unlimited term anywhere below or at the root means the root never binds for this entry: no constraint. Negative operands (an
+// over-subtracted usage cell) are outside what the argument covers: *bad.
+KQ_DEV void cert_margin_exact(long long* cell, const int64_t* lq, const int64_t* un, int64_t sq_root, int plen, int64_t qty, int32_t* bad) {
+  int64_t e = 0;
+  for (int i = 0; i < plen; i++) if (un[i] < 0 || lq[i] < 0) { if (bad) *bad = 1; return; }
+  if (sq_root < 0 || qty < 0) { if (bad) *bad = 1; return; }
+  for (int i = 0; i < plen - 1; i++) e = a_add(e, i64max(0, a_sub(lq[i], un[i])));
+  const int64_t term = a_add(e, a_sub(sq_root, un[plen - 1]));
+  if (term == I64MAX) return;
+  cert_min(cell, (long long)a_sub(term, qty));
+}
+KQ_DEV void cert_unverifiable(const K& k, int tree) { if (k.cert_flags && lane_id() == 0) k.cert_flags[tree] = 1; }
 
 // modes (flavorassigner.go:453-472, :510-533; common/types.go:23)
 enum { M_NOFIT = 0, M_PREEMPT = 1, M_DEFERRED = 2, M_FIT = 3 };
@@ -511,11 +542,12 @@ struct Wave {
   int32_t f_res[KQ_MAXREQ];
   int64_t f_qty[KQ_MAXREQ];
   uint8_t f_slot[KQ_MAXREQ];     // index into req_*
-  // cell results of one pass
-  uint8_t cell_pm[CELLS];
-  int32_t cell_borrow[CELLS];
-  int64_t cell_val[CELLS];
-  int64_t cell_aux[CELLS];        // operand of the cell's reason: maximum capacity (noFit by capacity) or val - available
+  // cell results of one pass of assign_flavors. They share their LDS with the gathered cells of process_entry_fast (g_* below): that
+  // function is a leaf that never runs inside an assign_flavors pass, and the workgroup's LDS is full at cfg 3 (cohort rows of both
+  // planes + two record buffers + this struct = 160 KB)
+  union { int64_t cell_val[CELLS]; int64_t g_sq[CELLS]; };
+  union { int64_t cell_aux[CELLS]; int64_t g_lq[CELLS]; };  // cell_aux: operand of the cell's reason (maximum capacity, or val - available)
+  union { struct { int32_t cell_borrow[CELLS]; uint8_t cell_pm[CELLS]; }; int64_t g_bl[CELLS]; };
   int nrsn, rsn_ps0, rsn_g0, rsn_over;  // reason records of the assignment under construction (lane 0)
   int defer_head;                 // lean nominate pass: this head needs the full pass (victim search / partial admission)
   // best flavor so far
@@ -537,7 +569,7 @@ struct Wave {
   uint8_t win_off[256];           // ... and their positions in the order, relative to the window base
   int nwin2[2], chunk_done, chunk_stop;  // leader -> helper waves of the process workgroup
   // gathered cells of the entry under process: c = u * plen + i
-  int64_t g_lq[CELLS], g_sq[CELLS], g_bl[CELLS], g_uw[CELLS], g_un[CELLS];
+  int64_t g_uw[CELLS], g_un[CELLS];  // g_lq / g_sq / g_bl: see the unions above
   uint8_t g_dirty[CELLS];
   int64_t bytes;                  // algorithmic bytes (lane 0 meaningful)
   int usage_dirty;                // set when processEntry added usage to the snapshot plane (fair-sharing DRS cache)
@@ -2239,7 +2271,10 @@ KQ_DEV void process_entry_fast(const K& k, Wave& w, int e) {
       const int b = u * plen;
       int64_t val = w.use_qty[u];
       if (reserve) val = reserve_amount(val, S.nominal[ix(S, w.cq, w.use_fr[u])], w.g_bl[b], w.g_uw[b], w.borrowing);
-      if (val < 0) mark_broken(w, w.use_fr[u]);
+      if (val < 0) { mark_broken(w, w.use_fr[u]); if (k.cert_flags) k.cert_flags[S.tree_of[w.cq]] = 1; }
+      if (!reserve && plen > 1 && k.root_margin)  // certificate: slack of the root term of Available (see K::root_margin)
+        cert_margin_exact(k.root_margin + (size_t)S.tree_of[w.cq] * S.nfr + w.use_fr[u], &w.g_lq[b], &w.g_un[b], w.g_sq[b + plen - 1], plen, val,
+                          k.cert_flags + S.tree_of[w.cq]);
       int64_t v = val;  // resource_node.go:144-152 on both planes
       for (int i = 0; i < plen; i++) {
         int64_t uu = w.g_uw[b + i], la = i64max(0, a_sub(w.g_lq[b + i], uu));
@@ -2305,6 +2340,9 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
     return;
   }
   const bool quota_usage = !(w.hflags & KQ_HEAD_HAS_QUOTA_RESERVATION);  // netUsage scheduler.go:785-794
+  // the generic path (targets, recomputation, oversize entries, exact np mode) is outside the sharding certificate unless it ends
+  // up changing nothing
+  if (w.rep_mode != M_NOFIT) cert_unverifiable(k, tree);
   const int32_t* trows = O.pool_row + O.tgt_pos[e];
   auto has_any = [&]() { bool a = false; for (int t = 0; t < nt; t++) if (k.preempted[trows[t]]) a = true; return a; };
   // updateAssignmentIfNeeded :707-769
@@ -2605,10 +2643,11 @@ KQ_DEV void chunk_scatter(const K& k, PRec* rec, int n) { chunk_scatter(proc_ptr
 // Scalars the serial core needs from the kernel argument block. K lives in global memory and the compiler cannot prove the
 // core's stores do not alias it, so reading them through `k` costs a global load (+ wait) per entry; they are read once
 // per tree instead.
-struct CoreCtx { int nfr, total, dbg; bool prio_preemptors; const int64_t* bl_tab; const int32_t* path_tab; };
-KQ_DEV CoreCtx core_ctx(const K& k, const Wave& w) {
+struct CoreCtx { int nfr, total, dbg; bool prio_preemptors; const int64_t* bl_tab; const int32_t* path_tab; long long* margin; int32_t* cert_flag; };
+KQ_DEV CoreCtx core_ctx(const K& k, const Wave& w, int tree) {
   CoreCtx c; c.nfr = k.S.nfr; c.total = w.pc_ncoh * k.S.nfr; c.prio_preemptors = gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS);
   c.bl_tab = k.S.bl; c.path_tab = k.S.path;
+  c.margin = k.root_margin ? k.root_margin + (size_t)tree * k.S.nfr : nullptr; c.cert_flag = k.cert_flags ? k.cert_flags + tree : nullptr;
 #ifdef KQ_PROF
   c.dbg = k.C.dbg_variant;  // timing experiments (tools/prof_process.py): results are wrong when non-zero
 #else
@@ -2707,10 +2746,11 @@ template <int PLEN, bool PLAIN> KQ_DEV bool core_run(Wave& w, int64_t* pcl, PRec
     for (int u = lane; u < nuse; u += WAVE) {
       if (WAVE < FU) slot_load<PLEN>(cc, pcl, r, u, x);  // device: registers of the first pass are still live
       int64_t val = x.qty;
+      if (!reserve && PLEN > 1 && cc.margin) cert_margin_exact(cc.margin + r.fr[u], x.lq, x.un, x.sq[PLEN - 1], PLEN, val, cc.cert_flag);  // K::root_margin
       if (reserve) {  // quotaResourcesToReserve scheduler.go:796-814
         if (r.borrowing > 0) val = x.bl[0] == KQ_NIL_LIMIT ? x.qty : i64min(x.qty, q_sub<PLAIN>(q_add<PLAIN>(x.nominal, x.bl[0]), x.uw[0]));
         else val = i64max(0, i64min(x.qty, q_sub<PLAIN>(x.nominal, x.uw[0])));
-        if (val < 0) mark_broken(w, r.fr[u]);
+        if (val < 0) { mark_broken(w, r.fr[u]); if (cc.cert_flag) *cc.cert_flag = 1; }
       }
       // addUsage resource_node.go:144-152 on usage_work, then on usage_np
       int64_t v = val;
@@ -2794,6 +2834,8 @@ KQ_DEV bool core_run_quad(Wave& w, int64_t* pcl, PRec& r, const CoreCtx& cc, con
       else val = i64max(0, i64min(qty, nominal - uw0));
       if (i == 0 && plane == 0 && val < 0) mark_broken(w, r.fr[u]);
     }
+    if (!reserve && cc.margin && act && plane == 1 && plen > 1 && i == plen - 1) cert_min(cc.margin + r.fr[u], (E + q.ccv - cur) - qty);  // K::root_margin
+    if (reserve && val < 0 && cc.cert_flag && act && i == 0 && plane == 0) *cc.cert_flag = 1;
     // addUsage resource_node.go:144-152, both planes at once
     if (act && (i == 0 || val > E)) pcl[ua] = cur + (val - E);
     if (lane == 0) { r.dirty = 1; r.added = 1; }
@@ -2811,7 +2853,7 @@ KQ_DEV bool core_run_quad(Wave& w, int64_t* pcl, PRec& r, const CoreCtx& cc, con
 KQ_DEV uint64_t uniform_u64(uint64_t v) {  // the same in every lane: keep it in scalar registers
   return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)v) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32;
 }
-__device__ __noinline__ uint64_t fit_run(int64_t* pcl_generic, PRec* rc_generic, uint64_t work_v, uint64_t special_v, int total_v) {
+__device__ __noinline__ uint64_t fit_run(int64_t* pcl_generic, PRec* rc_generic, uint64_t work_v, uint64_t special_v, int total_v, long long* margin) {
   uint64_t work = uniform_u64(work_v);
   const uint64_t special = uniform_u64(special_v);
   const int total = __builtin_amdgcn_readfirstlane(total_v);
@@ -2819,11 +2861,11 @@ __device__ __noinline__ uint64_t fit_run(int64_t* pcl_generic, PRec* rc_generic,
   KQ_LDS PRec* const rc = (KQ_LDS PRec*)rc_generic;
   const int lane = lane_id();
   const int plane = lane >> 5, u = (lane >> 2) & 7, i = lane & 3;  // plane 0: usage_work, plane 1: usage_np
-  struct LC { int plen, nuse, mode, uoff, cbig; int64_t lq, ccv, qty; };
+  struct LC { int plen, nuse, mode, uoff, cbig, fr; int64_t lq, ccv, qty; };
   auto load = [&](int j) {
     KQ_LDS PRec& r = rc[j];
     LC x;
-    x.plen = r.plen; x.nuse = r.nuse; x.mode = r.mode; x.uoff = r.uoff[u][i]; x.cbig = r.cbig[u][i];
+    x.plen = r.plen; x.nuse = r.nuse; x.mode = r.mode; x.uoff = r.uoff[u][i]; x.cbig = r.cbig[u][i]; x.fr = r.fr[u];
     x.lq = r.lq[u][i]; x.ccv = r.ccv[u][i]; x.qty = r.qty[u];
     return x;
   };
@@ -2847,6 +2889,8 @@ __device__ __noinline__ uint64_t fit_run(int64_t* pcl_generic, PRec* rc_generic,
     { const int64_t o = dpp64<0xB1>(a); a = o < a ? o : a; }
     { const int64_t o = dpp64<0x4E>(a); a = o < a ? o : a; }
     const bool fits_ok = wballot(act && plane == 1 && i == 0 && i64max(0, a) < q.qty) == 0;
+    // sharding certificate: the slack of the root term (K::root_margin); a fire-and-forget atomic, nothing waits for it
+    if (margin && fits_ok && act && plane == 1 && q.plen > 1 && i == q.plen - 1) atomicMin(margin + q.fr, (long long)((E + q.ccv - cur) - q.qty));
     // addUsage on both planes when it fits (scheduler.go:1167-1175), predicated
     if (fits_ok && act && (i == 0 || q.qty > E)) *cell = cur + (q.qty - E);
     if (lane == 0) {
@@ -2920,7 +2964,7 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
 #if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
   const long long _tree0 = clock64(), _wall0 = wall_clock64();
 #endif
-  const CoreCtx cc = core_ctx(k, w);
+  const CoreCtx cc = core_ctx(k, w, tree);
   const ProcPtrs P = proc_ptrs(k);
   const bool chunked = lds_bytes >= rec_bytes;
   PRec* rec = (PRec*)((unsigned char*)lds + (lds_bytes - (chunked ? rec_bytes : 0)));
@@ -3014,7 +3058,7 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
         j = nch;
         while (work) {
 #ifndef KQ_HOST_EMU
-          work = fit_run(lds, rc, work, slowm | resm, cc.total);  // the Fit-class records up to the next special one
+          work = fit_run(lds, rc, work, slowm | resm, cc.total, cc.margin);  // the Fit-class records up to the next special one
           if (!work) break;
 #endif
           const int cj = ffs64(work);
@@ -3251,7 +3295,8 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
   for (int i = tid; i < nqs * KQ_MAXD; i += nthreads) cost[i] = 0;
   for (int i = tid; i < nn; i += nthreads) win[i] = -1;
   bsync();
-  const CoreCtx cc = core_ctx(k, w);
+  const CoreCtx cc = core_ctx(k, w, tree);
+  cert_unverifiable(k, tree);  // the DRS tournament compares ClusterQueues of every subtree: a shard of the tree cannot run it alone
   // cqToEntry: the last head of a CQ wins (:58-60)
   for (int h = tid; h < H.n; h += nthreads) {
     int c = H.cq[h];
@@ -3547,6 +3592,16 @@ KQ_DEV void derive_usage_cell(const DSnap& S, int64_t* usage, int cohort, int fr
     }
   }
   usage[ix(S, cohort, fr)] = u;
+}
+// sharded single-root cycles (kueue_amd/sharding.py): what the cycle added to every usage cell, and folding an all-reduced
+// ClusterQueue-level delta into the resident snapshot
+KQ_DEV void usage_delta_cell(int64_t* out, const int64_t* work, const int64_t* start, size_t i) { out[i] = work[i] - start[i]; }
+KQ_DEV void usage_add_cell(int64_t* usage, const int64_t* delta, size_t i, int sign, int32_t* big) {
+  const int64_t d = delta[i];
+  if (d == 0) return;
+  const int64_t v = sign > 0 ? a_add(usage[i], d) : a_sub(usage[i], d);
+  usage[i] = v;
+  if (big && (uint64_t)v >= ((uint64_t)1 << 50)) *big = 1;
 }
 // which heads of the last cycle count: action == admit and no quota reservation held (netUsage scheduler.go:785-794)
 KQ_DEV void commit_mask_head(const K& k, int h, int32_t* use_n_out, int32_t* cq_out, int32_t* count) {

@@ -231,6 +231,15 @@ __global__ __launch_bounds__(64) void k_pend_release_requeue(DPend D, DSnap S, c
   pend_release_requeue(D, S, tree_stamp, blockIdx.x, stamp);
 }
 
+__global__ __launch_bounds__(256) void k_usage_delta(int64_t* out, const int64_t* work, const int64_t* start, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) usage_delta_cell(out, work, start, i);
+}
+__global__ __launch_bounds__(256) void k_usage_add(int64_t* usage, const int64_t* delta, size_t n, int sign, int32_t* big) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) usage_add_cell(usage, delta, i, sign, big);
+}
+
 namespace kq {
 struct HipBackend {
   hipStream_t stream = nullptr;
@@ -379,6 +388,14 @@ struct HipBackend {
     hipLaunchKernelGGL(k_pend_release_requeue, dim3(D.nq), dim3(64), 0, stream, D, S, (const int32_t*)tree_stamp, stamp);
     chk(hipGetLastError(), "k_pend_release");
   }
+  void launch_usage_delta(int64_t* out, const int64_t* work, const int64_t* start, size_t n) {
+    if (n) hipLaunchKernelGGL(k_usage_delta, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out, work, start, n);
+    chk(hipGetLastError(), "k_usage_delta");
+  }
+  void launch_usage_add(int64_t* usage, const int64_t* delta, size_t n, int sign, int32_t* big) {
+    if (n) hipLaunchKernelGGL(k_usage_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, usage, delta, n, sign, big);
+    chk(hipGetLastError(), "k_usage_add");
+  }
   size_t lds_attr_nom = 0;
   void launch_nominate(const K& k, int slots, size_t lds) {
     if (lds > 48 * 1024 && lds != lds_attr_nom) {
@@ -403,7 +420,8 @@ struct HipBackend {
   }
   // dynamic LDS = [cohort rows (2 planes) of the largest tree, if they fit][CH prefetched entry records]
   void launch_process(const K& k, int n_tree, size_t cohort_rows_bytes) {
-    const size_t rec = sizeof(PRec) * CH * NBUF, budget = 160 * 1024 - 8 * 1024;
+    // 160 KB per CU: the kernel's static LDS (Wave) + [cohort rows of both planes, if they fit] + two record buffers
+    const size_t rec = sizeof(PRec) * CH * NBUF, budget = 160 * 1024 - sizeof(Wave) - 256;
     size_t lds = rec + (cohort_rows_bytes + rec <= budget ? cohort_rows_bytes : 0);
     if (lds > 48 * 1024 && lds != lds_attr) {
       chk(hipFuncSetAttribute((const void*)k_process, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
@@ -414,7 +432,7 @@ struct HipBackend {
   }
   size_t lds_attr = 0, lds_attr_fair = 0;
   void launch_process_fair(const K& k, int n_tree, size_t cohort_rows_bytes, int32_t* rank) {
-    const size_t budget = 160 * 1024 - 8 * 1024;
+    const size_t budget = 160 * 1024 - sizeof(Wave) - 256;
     size_t lds = sizeof(PRec) + (cohort_rows_bytes + sizeof(PRec) <= budget ? cohort_rows_bytes : 0);
     if (lds > 48 * 1024 && lds != lds_attr_fair) {
       chk(hipFuncSetAttribute((const void*)k_process_fair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
@@ -533,6 +551,17 @@ int kq_pending_read_state(kq_engine* en, uint8_t* state, int32_t* counts) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
   return en->e.pending_read_state(state, counts);
+}
+
+int kq_cycle_certificate(kq_engine* en, int64_t* usage_delta_dev, int64_t* root_margin, int32_t* flags) {
+  if (!en) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.cycle_certificate(usage_delta_dev, root_margin, flags);
+}
+int kq_snapshot_usage_add(kq_engine* en, const int64_t* delta_dev, int32_t sign) {
+  if (!en || !delta_dev) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.snapshot_usage_add(delta_dev, sign);
 }
 
 int kq_last_cycle_phases(kq_engine* en, double* phase_ms, int64_t* phase_bytes) {

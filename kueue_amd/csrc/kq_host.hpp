@@ -33,7 +33,7 @@ template <class B> struct EngineT {
   // cycle buffers (grow-only)
   struct Buf { void* p = nullptr; size_t cap = 0; };
   std::vector<Buf*> all_bufs;
-  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_grec, b_cqd, b_defer, b_fs[20];
+  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_grec, b_cqd, b_defer, b_cert, b_fs[20];
   bool force_exact_drs = false;  // tests: take the saturation-safe DRS loops even when the sums would be exact
   bool cs_disable = false;       // tests: classical victim searches always take the candidate-by-candidate walk
   Buf b_cs;
@@ -110,7 +110,7 @@ template <class B> struct EngineT {
     free_snapshot();
     if (hstage) be.free_host(hstage);
     if (hup) be.free_host(hup);
-    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb, &b_grec, &b_cqd, &b_cs, &b_defer}) if (b->p) be.free(b->p);
+    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb, &b_grec, &b_cqd, &b_cs, &b_defer, &b_cert}) if (b->p) be.free(b->p);
     for (auto& b : b_fs) if (b.p) be.free(b.p);
     for (auto& c : ring) for (Buf* b : {&c.cq, &c.use_n, &c.use_fr, &c.use_qty}) if (b->p) be.free(b->p);
     for (auto& hbch : batches) for (auto& b : hbch.hb) if (b.p) be.free(b.p);
@@ -496,6 +496,13 @@ template <class B> struct EngineT {
     k.cq_dirty = grow<uint8_t>(b_cqd, std::max(prep.nq, 1));  // cleared per head by k_records
     k.defer_list = grow<int32_t>(b_defer, (size_t)n + 1); k.defer_count = k.defer_list + n;
     prep_fill(k.defer_count, 1, 0);
+    {  // sharding certificate (K::root_margin): one slack per (tree, flavor-resource), one flag per tree
+      const size_t cells = (size_t)std::max(prep.n_tree, 1) * prep.nfr;
+      k.root_margin = (long long*)grow<int64_t>(b_cert, cells + (std::max(prep.n_tree, 1) + 1) / 2);
+      k.cert_flags = (int32_t*)(k.root_margin + cells);
+      prep_fill(k.root_margin, cells * 2, 0x7f7f7f7fu);
+      prep_fill(k.cert_flags, (size_t)std::max(prep.n_tree, 1), 0);
+    }
     int32_t* order_idx = grow<int32_t>(b_order, n);
     k.order_idx = order_idx;
     int32_t* rank = grow<int32_t>(b_rank, n);
@@ -748,6 +755,29 @@ template <class B> struct EngineT {
     if (state) memcpy(state, st.data(), pend.W);
     if (counts) { counts[0] = counts[1] = counts[2] = counts[3] = 0; for (int w = 0; w < pend.W; w++) counts[st[w] & 3]++; }
     return KQ_OK;
+  }
+
+  // ---- sharded single-root cycles ------------------------------------------------------------------------------------
+  // After a cycle: what it added to every usage cell (device buffer of the caller, [N * nfr]) and the certificate of K::root_margin.
+  int cycle_certificate(int64_t* delta_dev, int64_t* margin, int32_t* flags) {
+    if (!have_snapshot || !b_usage_work.p || !b_cert.p) return fail(KQ_EINVAL, "kq_cycle_certificate before a cycle");
+    const size_t cells = (size_t)prep.N * prep.nfr;
+    if (delta_dev) be.launch_usage_delta(delta_dev, (const int64_t*)b_usage_work.p, d_usage, cells);
+    const size_t mc = (size_t)std::max(prep.n_tree, 1) * prep.nfr;
+    if (margin) be.d2h(margin, b_cert.p, mc * sizeof(int64_t));
+    if (flags) be.d2h(flags, (const int64_t*)b_cert.p + mc, (size_t)std::max(prep.n_tree, 1) * sizeof(int32_t));
+    int rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    return KQ_OK;
+  }
+  // usage[ClusterQueue cells] += sign * delta (device buffer, [n_cq * nfr]); cohort levels follow from them (flush_levels).
+  int snapshot_usage_add(const int64_t* delta_dev, int sign) {
+    if (!have_snapshot) return fail(KQ_EINVAL, "kq_snapshot_usage_add before kq_snapshot_put");
+    if (!prep.usage_consistent) return fail(KQ_EUNSUPPORTED, "the snapshot's cohort usage is not derived from its children: deltas cannot be folded at the ClusterQueue level");
+    be.launch_usage_add(d_usage, delta_dev, (size_t)prep.nq * prep.nfr, sign, d_big);
+    levels_stale = true;
+    last_cycle_n = -1;
+    return be.sync();  // the caller's buffer may be reused
   }
 
   int prof_read(int64_t* out, bool reset) {

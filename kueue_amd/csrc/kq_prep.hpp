@@ -19,7 +19,7 @@ namespace kq {
 
 constexpr int KQ_MAXD = 8;      // max nodes on a CQ->root path (CQ + 7 cohort levels)
 constexpr int KQ_MAXREQ = 16;   // max resources requested by one podset (incl. injected "pods")
-constexpr int KQ_MAXU = 96;     // max (flavor,resource) entries in one assignment's usage (18 podsets x (4 resources + pods))
+constexpr int KQ_MAXU = 56;     // max (flavor,resource) entries in one assignment's usage (18 podsets x (2 resources + pods))
 constexpr int KQ_MAXPS = 18;    // max podsets per workload = the API limit (apis/kueue/v1beta2/workload_types.go:36 MaxItems=18)
 constexpr int KQ_MAXR = 8;      // max resources for the incremental (sum-based) DRS; more fall back to the exact loops
 

@@ -111,6 +111,19 @@ class Engine:
         self._check(self._lib.kq_pending_read_state(self._h, F.ptr(st), F.ptr(counts)))
         return st[:self.pending.n], counts
 
+    # ---- one root tree split across ranks (kueue_amd/sharding.py) ---------------------------------------------------------
+    def certificate(self, delta_dev_ptr: int):
+        """kq_cycle_certificate: the cycle's usage delta into a device buffer; -> (root_margin [n_tree * n_fr], flags [n_tree])."""
+        n_tree = int((self.snap.arrays["parent"] < 0).sum())
+        margin = np.zeros(max(n_tree, 1) * self.snap.n_fr, np.int64)
+        flags = np.zeros(max(n_tree, 1), np.int32)
+        self._check(self._lib.kq_cycle_certificate(self._h, C.c_void_p(delta_dev_ptr), F.ptr(margin), F.ptr(flags)))
+        return margin, flags
+
+    def usage_add(self, delta_dev_ptr: int, sign: int):
+        """kq_snapshot_usage_add: fold an (all-reduced) ClusterQueue-level usage delta into the resident snapshot."""
+        self._check(self._lib.kq_snapshot_usage_add(self._h, C.c_void_p(delta_dev_ptr), sign))
+
     def try_commit(self) -> int:
         return self._lib.kq_cycle_commit(self._h, None)
 

@@ -120,8 +120,9 @@ def _quota(rng, unit, lo, hi, limits: bool, unlimited_p: float):
 
 
 def generate(cfg: int, seed: int = BASE_SEED, n_cq: int = None, per_cq: int = None, preemption: bool = None,
-             fair_sharing: bool = False) -> Population:
-    """Build population `cfg` (1..4). n_cq / per_cq override the sizes for parity-sized variants."""
+             fair_sharing: bool = False, fill: float = 1.0) -> Population:
+    """Build population `cfg` (1..4). n_cq / per_cq override the sizes for parity-sized variants; fill scales how full the admitted
+    set leaves every flavor (1.0 = the BASELINE populations; < 1 leaves headroom at the root cohort)."""
     rng = np.random.default_rng(seed + cfg)
     if cfg == 1:
         nq, F, res, per, shape, strategy = 4, 2, ["cpu"], 25, "none", "StrictFIFO"
@@ -217,7 +218,7 @@ def generate(cfg: int, seed: int = BASE_SEED, n_cq: int = None, per_cq: int = No
             if k == 0:
                 continue
             fq = cq.resource_groups[0].flavors[fi]
-            fill_f = rng.uniform(lo_f, hi_f)
+            fill_f = rng.uniform(lo_f, hi_f) * fill
             for j in range(k):
                 ps = PodSet("main", count=int(rng.integers(1, 5)))
                 for r in res:

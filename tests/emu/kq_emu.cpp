@@ -74,6 +74,8 @@ struct EmuBackend {
     for (int i = 0; i < n; i++) pend_release_mark(S, tree_stamp, cq, use_n, n, i, stamp);
     for (int c = 0; c < D.nq; c++) pend_release_requeue(D, S, tree_stamp, c, stamp);
   }
+  void launch_usage_delta(int64_t* out, const int64_t* work, const int64_t* start, size_t n) { for (size_t i = 0; i < n; i++) usage_delta_cell(out, work, start, i); }
+  void launch_usage_add(int64_t* usage, const int64_t* delta, size_t n, int sign, int32_t* big) { for (size_t i = 0; i < n; i++) usage_add_cell(usage, delta, i, sign, big); }
   void launch_nominate(const K& k, int slots, size_t lds) {
     std::vector<int64_t> region(lds / 8 + 8);
     // every other launch skips the lean first pass, so that the full pass also sees the heads the lean one would have finished
@@ -184,6 +186,10 @@ int kqe_pending_apply_fabricated(void* ep, const uint8_t* status, const uint8_t*
   e.pend.O = O; e.pend.H = e.batches[EmuEngine::PEND_SLOT].H; e.pend.ran = true;
   return e.pending_apply();
 }
+int kqe_cycle_certificate(void* e, int64_t* delta, int64_t* margin, int32_t* flags) { return ((EmuEngine*)e)->cycle_certificate(delta, margin, flags); }
+int kqe_snapshot_usage_add(void* e, const int64_t* delta, int32_t sign) { return ((EmuEngine*)e)->snapshot_usage_add(delta, sign); }
+// LDS budget of k_process (kq_engine.hip launch_process): static Wave + record buffers
+void kqe_lds_sizes(int64_t* out) { out[0] = (int64_t)sizeof(kq::Wave); out[1] = (int64_t)(sizeof(kq::PRec) * kq::CH * kq::NBUF); }
 int kqe_read_usage(void* e, int64_t* out) { return ((EmuEngine*)e)->read_usage_work(out); }
 int kqe_last_bytes(void* e, int64_t* out) { *out = ((EmuEngine*)e)->last_bytes; return KQ_OK; }
 int kqe_phase_bytes(void* e, int64_t* out) { out[0] = ((EmuEngine*)e)->last_phase_bytes[0]; out[1] = ((EmuEngine*)e)->last_phase_bytes[1]; return KQ_OK; }

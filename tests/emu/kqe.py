@@ -80,6 +80,16 @@ class EmuEngine:
     def try_commit(self):
         return lib().kqe_cycle_commit(self.h, None)
 
+    def certificate(self, delta_ptr):
+        n_tree = int((self.snap.arrays["parent"] < 0).sum())
+        margin = np.zeros(max(n_tree, 1) * self.snap.n_fr, np.int64)
+        flags = np.zeros(max(n_tree, 1), np.int32)
+        self._ok(lib().kqe_cycle_certificate(self.h, C.c_void_p(delta_ptr), F.ptr(margin), F.ptr(flags)))
+        return margin, flags
+
+    def usage_add(self, delta_ptr, sign):
+        self._ok(lib().kqe_snapshot_usage_add(self.h, C.c_void_p(delta_ptr), C.c_int32(sign)))
+
     def _ok(self, rc):
         assert rc == 0, (rc, lib().kqe_last_error(self.h))
 

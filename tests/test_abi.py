@@ -75,3 +75,17 @@ def test_product_package_never_imports_oracle_or_emulation():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "kqo" not in txt, f
                 assert "tests.emu" not in txt and "libkq_emu" not in txt and "libkq_oracle" not in txt, f
+
+
+def test_process_kernel_lds_budget_holds_cfg3():
+    """k_process keeps the cohort rows of BOTH usage planes of the tree in LDS (kq_engine.hip launch_process): at BASELINE configs[2]
+    (111 cohorts x 64 flavor-resources) that only fits the CU's 160 KB if the kernel's static LDS (struct Wave) stays small. A
+    field added to Wave without looking breaks the launch on the device, not the CPU suite — hence this check."""
+    import ctypes as C
+    import numpy as np
+    from tests.emu import kqe
+    out = np.zeros(2, np.int64)
+    kqe.lib().kqe_lds_sizes(out.ctypes.data_as(C.POINTER(C.c_int64)))
+    wave, rec = int(out[0]), int(out[1])
+    rows = 111 * 64 * 16
+    assert rows + rec <= 160 * 1024 - wave - 256, (wave, rec, rows)

@@ -159,7 +159,8 @@ def test_reason_window_overflow_is_reported(oracle):
 
 
 def test_eighteen_podsets(oracle):
-    """The API's limit (apis/kueue/v1beta2/workload_types.go:36 MaxItems=18) is inside the device path (KQ_MAXPS = 18, KQ_MAXU = 96)."""
+    """The API's limit (apis/kueue/v1beta2/workload_types.go:36 MaxItems=18) is inside the device path: KQ_MAXPS = 18; KQ_MAXU = 56
+    usage entries = 18 podsets x (2 resources + pods)."""
     from kueue_amd.api import (ClusterQueue, Cohort, FlavorQuotas, Heads, PodSet, ResourceGroup, ResourceQuota, Snapshot, Workload, make_config)
     from tests.emu import kqe
     fqs = [FlavorQuotas(f"f{i}", {"cpu": ResourceQuota(20_000, 5_000), "memory": ResourceQuota(64 << 30), "example.com/gpu": ResourceQuota(8), "pods": ResourceQuota(100)})
@@ -169,7 +170,7 @@ def test_eighteen_podsets(oracle):
     snap.derive()
     wls = []
     for i in range(2):
-        ps = [PodSet(f"ps{j:02d}", count=1 + j % 3, requests={"cpu": 500 * (1 + j % 4), "memory": (1 + j % 5) << 28, "example.com/gpu": j % 2}) for j in range(18)]
+        ps = [PodSet(f"ps{j:02d}", count=1 + j % 3, requests={"cpu": 500 * (1 + j % 4), "memory": (1 + j % 5) << 28}) for j in range(18)]
         wls.append(Workload(f"w{i}", f"cq{i}", priority=i, creation_ts=i + 1, pod_sets=ps, uid=f"{i}"))
     heads = Heads(snap, wls, cycle=1)
     cfg = make_config()
