@@ -279,6 +279,18 @@ void kq_engine_destroy(kq_engine* e);
  * caller may free its arrays on return. */
 int  kq_snapshot_put(kq_engine* e, const kq_snapshot* s);
 
+/* Incremental snapshot: the next cycle's cache.Snapshot() when the quota tree, the policies and the dictionaries are
+ * the ones of the last kq_snapshot_put and only usage and / or the admitted set moved — what clusterQueue.updateWorkloadUsage
+ * (pkg/cache/scheduler/clusterqueue.go:594) and updateCohortResourceNode (resource_node.go:190) change between two cycles.
+ * `s` is a complete kq_snapshot image as for kq_snapshot_put; only the parts named by `what` are read (plus sizes and `parent`,
+ * which must match). KQ_PATCH_USAGE: the usage plane [N * n_fr] replaces the resident one (0.57 MB at cfg 3, nothing rebuilt).
+ * KQ_PATCH_ADMITTED: the admitted-workload table (cq_adm_off, adm_*) replaces the resident one and the engine's candidate
+ * structures are rebuilt from it; implies KQ_PATCH_USAGE. Resident head batches and the pending set stay valid; folded commits
+ * (kq_cycle_commit) are forgotten: the new plane is the truth. */
+#define KQ_PATCH_USAGE     0x1u
+#define KQ_PATCH_ADMITTED  0x2u
+int  kq_snapshot_patch(kq_engine* e, const kq_snapshot* s, uint32_t what);
+
 /* One scheduling cycle: nominate + iterator + processEntry (scheduler.go:308-386, steps 3-5).
  * Synchronous. `out` arrays are caller-allocated, sized from `h`. The uploaded snapshot is left
  * unchanged (the reference mutates a per-cycle copy). */

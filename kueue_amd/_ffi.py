@@ -143,6 +143,7 @@ class kq_pending(C.Structure):
 
 
 WL_ACTIVE, WL_INFLIGHT, WL_INADMISSIBLE, WL_GONE = 0, 1, 2, 3
+PATCH_USAGE, PATCH_ADMITTED = 1, 2
 
 
 class kq_decisions(C.Structure):
@@ -231,6 +232,8 @@ def load_engine():
     lib.kq_pending_read_state.argtypes = [C.c_void_p, u8p, i32p]
     for f in ("kq_pending_put", "kq_pending_heads", "kq_cycle_run_pending", "kq_pending_apply", "kq_pending_queue_inadmissible", "kq_pending_read_state"):
         getattr(lib, f).restype = C.c_int
+    lib.kq_snapshot_patch.argtypes = [C.c_void_p, C.POINTER(kq_snapshot), C.c_uint32]
+    lib.kq_snapshot_patch.restype = C.c_int
     lib.kq_cycle_certificate.argtypes = [C.c_void_p, C.c_void_p, i64p, i32p]
     lib.kq_cycle_certificate.restype = C.c_int
     lib.kq_snapshot_usage_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
@@ -262,7 +265,7 @@ ABI_SYMBOLS = [
     "kq_engine_create", "kq_engine_destroy", "kq_snapshot_put", "kq_cycle_run", "kq_last_cycle_stats",
     "kq_cycle_commit", "kq_cycle_release", "kq_snapshot_derive", "kq_snapshot_read_planes", "kq_strerror", "kq_last_error", "kq_abi_version",
     "kq_heads_put", "kq_cycle_run_resident", "kq_nominate_run_resident", "kq_last_cycle_phases",
-    "kq_cycle_certificate", "kq_snapshot_usage_add",
+    "kq_cycle_certificate", "kq_snapshot_usage_add", "kq_snapshot_patch",
     "kq_pending_put", "kq_pending_heads", "kq_cycle_run_pending", "kq_pending_apply", "kq_pending_queue_inadmissible", "kq_pending_read_state",
     "kq_debug_read_usage_work", "kq_debug_force_exact_drs", "kq_debug_prof", "kq_debug_disable_scan_search",
 ]

@@ -470,6 +470,31 @@ class Snapshot:
     def plane(self, name: str) -> np.ndarray:
         return self.arrays[name].reshape(self.N, self.n_fr)
 
+    def with_rows(self, keep: np.ndarray, usage: Optional[np.ndarray] = None) -> "Snapshot":
+        """The same quota tree with only the admitted rows `keep` (ascending row indices) left — e.g. after preemptions were carried out
+        or workloads finished — and, optionally, another usage plane. The image kq_snapshot_patch(KQ_PATCH_ADMITTED) takes."""
+        import copy
+        keep = np.asarray(keep, np.int64)
+        t = copy.copy(self)
+        a = dict(self.arrays)
+        old_cq = np.repeat(np.arange(self.n_cq), np.diff(self.arrays["cq_adm_off"]))
+        a["cq_adm_off"] = np.concatenate([[0], np.cumsum(np.bincount(old_cq[keep], minlength=self.n_cq))]).astype(np.int32)
+        for k in ("adm_priority", "adm_queue_ts", "adm_reserve_ts", "adm_uid_rank", "adm_flags"):
+            a[k] = np.ascontiguousarray(self.arrays[k][keep])
+        u0, u1 = self.arrays["adm_use_off"][keep], self.arrays["adm_use_off"][keep + 1]
+        idx = np.concatenate([np.arange(x, y) for x, y in zip(u0, u1)]).astype(np.int64) if len(keep) else np.zeros(0, np.int64)
+        a["adm_use_off"] = np.concatenate([[0], np.cumsum(u1 - u0)]).astype(np.int32)
+        a["adm_use_fr"] = np.ascontiguousarray(self.arrays["adm_use_fr"][idx]); a["adm_use_qty"] = np.ascontiguousarray(self.arrays["adm_use_qty"][idx])
+        if usage is not None:
+            a["usage"] = np.ascontiguousarray(usage, np.int64).reshape(-1)
+        t.arrays = a
+        t.admitted = [self.admitted[int(i)] for i in keep] if getattr(self, "admitted", None) is not None else None
+        if t.admitted is not None:
+            t.adm_index = {w.name: i for i, w in enumerate(t.admitted)}
+        t.n_adm = int(len(keep))
+        t._struct = None
+        return t
+
 
 class Heads:
     """Flat image of []qcache.Head (pkg/cache/queue/manager.go:903) for one cycle."""

@@ -498,6 +498,12 @@ int kq_snapshot_put(kq_engine* en, const kq_snapshot* s) {
   return en->e.snapshot_put(s);
 }
 
+int kq_snapshot_patch(kq_engine* en, const kq_snapshot* s, uint32_t what) {
+  if (!en || !s) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.snapshot_patch(s, what);
+}
+
 int kq_cycle_run(kq_engine* en, const kq_heads* h, kq_decisions* out) {
   if (!en || !h || !out) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);

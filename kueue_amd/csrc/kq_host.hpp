@@ -199,6 +199,56 @@ template <class B> struct EngineT {
     return KQ_OK;
   }
 
+  // kq_snapshot_patch: the snapshot of the next cycle when only usage and / or the admitted set moved — what
+  // clusterQueue.updateWorkloadUsage (pkg/cache/scheduler/clusterqueue.go:594) and updateCohortResourceNode (resource_node.go:190)
+  // change between two cache.Snapshot() calls. The quota tree, policies and dictionaries must be the ones of the last
+  // kq_snapshot_put (checked where cheap); resident head batches and the pending set stay valid.
+  template <class T> void reupload(const T*& field, const T* host, size_t n) {
+    for (size_t i = 0; i < snap_allocs.size(); i++) if (snap_allocs[i] == (const void*)field) { be.free(snap_allocs[i]); snap_allocs.erase(snap_allocs.begin() + i); break; }
+    field = upload(host, n);
+  }
+  int snapshot_patch(const kq_snapshot* s, uint32_t what) {
+    if (!have_snapshot) return fail(KQ_EINVAL, "kq_snapshot_patch before kq_snapshot_put");
+    if (s->n_cq != prep.nq || s->n_cohort != prep.nc || s->n_flavor != prep.nF || s->n_resource != prep.nR)
+      return fail(KQ_EINVAL, "kq_snapshot_patch: dictionary sizes differ from the uploaded snapshot");
+    if (memcmp(s->parent, prep.h_parent.data(), (size_t)prep.N * sizeof(int32_t)) != 0) return fail(KQ_EINVAL, "kq_snapshot_patch: the cohort tree changed");
+    const size_t Nfr = (size_t)prep.N * prep.nfr;
+    for (auto& c : ring) c.live = false;   // commits folded into the old plane are part of the new one by construction
+    commits = 0; last_cycle_n = -1;
+    if (what & KQ_PATCH_ADMITTED) {
+      // the admitted-row structures (candidate rank order, flavor-resource buckets, level orders, row records) are rebuilt on the
+      // host and replace the resident ones; quota planes, the tree and the resource groups are not touched
+      Prep np;
+      int rc = build_prep(s, np);
+      if (rc != KQ_OK) return fail(rc, np.err);
+      prep = std::move(np);
+      S.n_adm = prep.n_adm;
+      reupload(S.cq_adm_off, s->cq_adm_off, (size_t)prep.nq + 1);
+      reupload(S.adm_prio, s->adm_priority, (size_t)prep.n_adm); reupload(S.adm_qts, s->adm_queue_ts, (size_t)prep.n_adm);
+      reupload(S.adm_flags, s->adm_flags, (size_t)prep.n_adm); reupload(S.adm_use_off, s->adm_use_off, (size_t)prep.n_adm + 1);
+      reupload(S.adm_use_fr, s->adm_use_fr, (size_t)s->adm_use_off[prep.n_adm]); reupload(S.adm_use_qty, s->adm_use_qty, (size_t)s->adm_use_off[prep.n_adm]);
+      reupload(S.adm_rts, s->adm_reserve_ts, (size_t)prep.n_adm); reupload(S.adm_uid, s->adm_uid_rank, (size_t)prep.n_adm);
+      reupload(S.adm_cq, prep.adm_cq.data(), prep.adm_cq.size());
+      reupload(S.tree_row_off, prep.tree_row_off.data(), prep.tree_row_off.size()); reupload(S.tree_rows, prep.tree_rows.data(), prep.tree_rows.size());
+      reupload(S.tree_rows_asc, prep.tree_rows_asc.data(), prep.tree_rows_asc.size());
+      reupload(S.rank_pos, prep.rank_pos.data(), prep.rank_pos.size());
+      reupload(S.frb_off, prep.frb_off.data(), prep.frb_off.size()); reupload(S.frb, prep.frb.data(), prep.frb.size());
+      reupload(S.cq_row_bytes, prep.cq_row_bytes.data(), prep.cq_row_bytes.size());
+      reupload(S.adm_rec, prep.adm_rec.data(), prep.adm_rec.size());
+      for (int l = 0; l < CS_LEVELS; l++) reupload(S.frl[l], prep.frl[l].data(), prep.frl[l].size());
+      reupload(S.frbr, prep.frbr.data(), prep.frbr.size()); reupload(S.frec, prep.frec.data(), prep.frec.size());
+      reupload(S.frb_sig, prep.frb_sig.data(), prep.frb_sig.size()); reupload(S.cs_ok, prep.cs_ok.data(), prep.cs_ok.size());
+      what |= KQ_PATCH_USAGE;  // build_prep re-derived usage_consistent / fs_plain from s->usage: the plane must match
+    } else if (what & KQ_PATCH_USAGE) {
+      // usage-dependent flags of the prep: "cohort usage == what the children store in it" and the plain range of the amounts
+      check_usage(s, prep);
+    }
+    if (what & KQ_PATCH_USAGE) { be.h2d(d_usage, s->usage, Nfr * sizeof(int64_t)); levels_stale = false; const int32_t zero = 0; be.h2d(d_big, &zero, sizeof(zero)); }
+    int rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    return KQ_OK;
+  }
+
   // ---- closed loop: commit the last cycle's admissions into the snapshot, release them later --------------
   struct Committed { Buf cq, use_n, use_fr, use_qty; int n = 0; bool live = false; };
   Committed ring[KQ_COMMIT_RING];

@@ -152,6 +152,49 @@ static inline void build_fair(Prep& p, const int64_t* sq, const int64_t* usage, 
   }
 }
 
+// The two properties of the usage plane the engine's shortcuts rely on, re-checked when only usage changes (kq_snapshot_patch):
+// cohort usage == sum over children of max(0, usage - localQuota) (resource_node.go:217-230), and every finite amount small enough
+// that the per-node borrowed sums of the DRS cannot saturate.
+inline void check_usage(const kq_snapshot* s, Prep& p) {
+  const int64_t U = INT64_MAX;
+  auto a_add = [&](int64_t x, int64_t y) -> int64_t {
+    if (x == U || y == U) return U;
+    if (y > 0 && x > U - y) return U;
+    if (y < 0 && x < INT64_MIN - y) return INT64_MIN;
+    return x + y;
+  };
+  auto a_sub = [&](int64_t x, int64_t y) -> int64_t {
+    if (x == U && y == U) return 0;
+    if (x == U) return U;
+    if (y == U) return INT64_MIN;
+    if (y < 0 && x > U + y) return U;
+    if (y > 0 && x < INT64_MIN + y) return INT64_MIN;
+    return x - y;
+  };
+  const int N = p.N, nq = p.nq;
+  const size_t nfr = p.nfr;
+  p.usage_consistent = true;
+  for (int c = nq; c < N && p.usage_consistent; c++) {
+    const int kx = c - nq;
+    for (size_t fr = 0; fr < nfr; fr++) {
+      int64_t sum = 0;
+      for (int pass = 0; pass < 2; pass++) {
+        const int32_t* off = pass == 0 ? s->child_cohort_off : s->child_cq_off;
+        const int32_t* lst = pass == 0 ? s->child_cohort : s->child_cq;
+        for (int i = off[kx]; i < off[kx + 1]; i++) {
+          const size_t o = (size_t)lst[i] * nfr + fr;
+          const int64_t ll = s->lend_limit[o];
+          const int64_t lq = ll != KQ_NIL_LIMIT ? std::max<int64_t>(0, a_sub(s->subtree_quota[o], ll)) : 0;
+          sum = a_add(sum, std::max<int64_t>(0, a_sub(s->usage[o], lq)));
+        }
+      }
+      if (sum != s->usage[(size_t)c * nfr + fr]) { p.usage_consistent = false; break; }
+    }
+  }
+  const int64_t LIM = (int64_t)1 << 50;
+  for (size_t i = 0; i < (size_t)N * nfr && p.fs_plain; i++) if (s->usage[i] < 0 || (s->usage[i] >= LIM && s->usage[i] != U)) p.fs_plain = false;
+}
+
 inline int build_prep(const kq_snapshot* s, Prep& p) {
   p.nq = s->n_cq; p.nc = s->n_cohort; p.N = p.nq + p.nc; p.nF = s->n_flavor; p.nR = s->n_resource;
   p.nfr = p.nF * p.nR; p.n_adm = s->n_adm;

@@ -53,6 +53,11 @@ class Engine:
         self._check(self._lib.kq_snapshot_put(self._h, C.byref(snap.struct())))
         self.snap = snap
 
+    def patch(self, snap: Snapshot, what: int):
+        """kq_snapshot_patch: the next cycle's snapshot when only usage (F.PATCH_USAGE) and / or the admitted set (F.PATCH_ADMITTED) moved."""
+        self._check(self._lib.kq_snapshot_patch(self._h, C.byref(snap.struct()), what))
+        self.snap = snap
+
     def run(self, heads: Heads, tgt_cap: Optional[int] = None, out: Optional[Decisions] = None, rsn_cap: int = 0) -> Decisions:
         d = out if out is not None else Decisions(heads, tgt_cap=tgt_cap, rsn_cap=rsn_cap)
         self._check(self._lib.kq_cycle_run(self._h, C.byref(heads.struct()), C.byref(d.struct())))

@@ -150,7 +150,8 @@ class SplitRoot:
         self._sync()
         mine = self.delta.clone()
         total = self.delta.clone()
-        dist.all_reduce(total, op=dist.ReduceOp.SUM)                      # <- the data-path collective
+        if self.world > 1:
+            dist.all_reduce(total, op=dist.ReduceOp.SUM)                  # <- the data-path collective
         ok = int(flags.sum() == 0)
         if ok:
             slack = margin.reshape(-1, self.nfr)
@@ -158,14 +159,21 @@ class SplitRoot:
                 others = (total[r * self.nfr:(r + 1) * self.nfr] - mine[r * self.nfr:(r + 1) * self.nfr]).cpu().numpy()
                 if not (others <= slack[t]).all():
                     ok = 0
-        verdict = torch.tensor([ok], dtype=torch.int32, device=self.device)
-        dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
-        exact = bool(int(verdict.item()))
+        if self.world > 1:
+            verdict = torch.tensor([ok], dtype=torch.int32, device=self.device)
+            dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+            exact = bool(int(verdict.item()))
+        else:
+            exact = bool(ok)
         self.stats["cycles"] += 1
         if exact:
             self.stats["exact"] += 1
             parts = [None] * self.world
-            dist.all_gather_object(parts, (own, {k: v for k, v in d_own.a.items()}, hb.arrays["ps_off"]))
+            mine_part = (own, {k: v for k, v in d_own.a.items()}, hb.arrays["ps_off"])
+            if self.world > 1:
+                dist.all_gather_object(parts, mine_part)
+            else:
+                parts = [mine_part]
             merged = Decisions(heads_all, tgt_cap=tgt_cap)
             nR = self.snap.n_resource
             tgts = {}

@@ -147,6 +147,7 @@ int kqe_tas_count_in(int32_t R, const int64_t* req, const int64_t* cap, int32_t*
 void kqe_cstat(long long* out) { for (int i = 0; i < 32; i++) { out[i] = kq::g_cs[i]; kq::g_cs[i] = 0; } }
 int kqe_engine_create(const kq_config* cfg, void** out) { auto* e = new EmuEngine(); e->cfg = *cfg; *out = e; return KQ_OK; }
 void kqe_engine_destroy(void* e) { delete (EmuEngine*)e; }
+int kqe_snapshot_patch(void* e, const kq_snapshot* s, uint32_t what) { return ((EmuEngine*)e)->snapshot_patch(s, what); }
 int kqe_snapshot_put(void* e, const kq_snapshot* s) { return ((EmuEngine*)e)->snapshot_put(s); }
 typedef kq::TasT<kq::EmuBackend> EmuTas;
 int kqe_tas_create(void** out) { *out = new EmuTas(); return KQ_OK; }

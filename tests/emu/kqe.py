@@ -62,6 +62,11 @@ class EmuEngine:
         assert rc == 0, (rc, lib().kqe_last_error(self.h))
         self.snap = snap
 
+    def patch(self, snap, what):
+        rc = lib().kqe_snapshot_patch(self.h, C.byref(snap.struct()), C.c_uint32(what))
+        assert rc == 0, (rc, lib().kqe_last_error(self.h))
+        self.snap = snap
+
     def heads_put(self, heads, batch):
         rc = lib().kqe_heads_put(self.h, C.byref(heads.struct()), batch)
         assert rc == 0, (rc, lib().kqe_last_error(self.h))
