@@ -244,13 +244,19 @@ def host_heads_leg(eng, pop, kcfg, snap, cycles, closed, hold, fair, live=0):
 
 
 def snapshot_put_cost(eng, snap):
-    """kq_snapshot_put = what a drop-in pays when it re-uploads cache.Snapshot() (host-side prep + every plane over PCIe)."""
-    ms = []
-    for _ in range(3):
-        t1 = time.perf_counter()
-        eng.put(snap)
-        ms.append((time.perf_counter() - t1) * 1e3)
-    return float(np.median(ms))
+    """kq_snapshot_put = what a drop-in pays when it re-uploads cache.Snapshot() (host-side prep + every plane over PCIe), and
+    kq_snapshot_patch = what it pays when only usage / the admitted set moved since the last cycle."""
+    from kueue_amd import _ffi as F
+
+    def med(fn):
+        ms = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            fn()
+            ms.append((time.perf_counter() - t1) * 1e3)
+        return float(np.median(ms))
+    return {"put": med(lambda: eng.put(snap)), "patch_usage": med(lambda: eng.patch(snap, F.PATCH_USAGE)),
+            "patch_admitted": med(lambda: eng.patch(snap, F.PATCH_ADMITTED))}
 
 
 class PendingLoop:
