@@ -160,6 +160,8 @@ struct DSnap {
   const uint64_t* frb_sig;      // [n_tree * nfr]
   const uint8_t* cs_ok;         // [n_tree]
   const int32_t* tree_depth;    // [n_tree]
+  const int8_t* cq_res_rg;      // [nq * nR] resource group of the ClusterQueue covering the resource (index inside the ClusterQueue's
+                                // groups, -1 = none): resourcegroups.RGByResource as one load instead of a walk of two CSR levels
 };
 
 struct DCfg {
@@ -487,7 +489,13 @@ KQ_DEV int gpath_height(const GPath& g, int plen, int64_t val, bool* may_reclaim
     if (!(g.sq[i] < a_add(g.us[i], remaining))) { found = true; mr = i < plen - 1; height = g.hgt[i]; continue; }
     remaining = a_sub(remaining, i64max(0, a_sub(g.lq[i], g.us[i])));
   }
-  if (!found) { mr = false; height = g.hgt[plen - 1]; }
+  if (!found) {
+    mr = false;
+    // g.hgt[plen - 1] without a run-time index: a dynamically indexed member sends the WHOLE struct to scratch (7 x 16-byte stores per
+    // lane and cell pass: 93 % of k_nominate's HBM write traffic before this, profiles/r02g_cfg3-batch_rocprof_summary.txt)
+    #pragma unroll
+    for (int i = 0; i < GP_MAX; i++) if (i == plen - 1) height = g.hgt[i];
+  }
   *may_reclaim = mr;
   return height;
 }
@@ -529,6 +537,7 @@ struct Wave {
   int32_t req_res[KQ_MAXREQ];
   int64_t req_qty[KQ_MAXREQ];
   uint8_t req_done[KQ_MAXREQ];   // resource already has a flavor from its resource group (:819)
+  int8_t req_rg[KQ_MAXREQ];      // resource group (index inside the ClusterQueue's groups) covering the request, -1 = none
   int32_t req_flavor[KQ_MAXREQ], req_borrow[KQ_MAXREQ], req_tried[KQ_MAXREQ];
   uint8_t req_mode[KQ_MAXREQ];
   // Assignment.Usage.Quota.Assigned (:1017-1041) + per-entry flags
@@ -640,14 +649,8 @@ KQ_DEV int fa_mode(int pm) { return pm == PM_NOFIT ? M_NOFIT : (pm == PM_FIT ? M
 
 // resourcegroups.RGByResource (util/resourcegroups/resourcegroups.go:62)
 KQ_DEV int rg_by_resource(const DSnap& S, int cq, int res) {
-  for (int g = S.cq_rg_off[cq]; g < S.cq_rg_off[cq + 1]; g++)
-    for (int i = S.rg_res_off[g]; i < S.rg_res_off[g + 1]; i++)
-      if (S.rg_res[i] == res) return g;
-  return -1;
-}
-KQ_DEV bool rg_covers(const DSnap& S, int g, int res) {
-  for (int i = S.rg_res_off[g]; i < S.rg_res_off[g + 1]; i++) if (S.rg_res[i] == res) return true;
-  return false;
+  const int l = S.cq_res_rg[(size_t)cq * S.nR + res];
+  return l < 0 ? -1 : S.cq_rg_off[cq] + l;
 }
 KQ_DEV int64_t assumed_usage(const Wave& w, int fr) {
   for (int i = 0; i < w.nuse; i++) if (w.use_fr[i] == fr) return w.use_qty[i];
@@ -1611,35 +1614,54 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
     int count = H.ps_count[psg];
     int new_count = counts ? counts[pi] : count;
     bool scale = counts && count != 0 && count != new_count;
+    // one lane per request: the loads of a podset's requests and of their resource groups are one round trip each (they were a
+    // dependent chain on lane 0: ~8 of the ~25 round trips a head cost)
+    const int e0 = H.ps_req_off[psg], ne_raw = H.ps_req_off[psg + 1] - e0;
+    const int ne = ne_raw < KQ_MAXREQ ? ne_raw : KQ_MAXREQ;
+    if (ne_raw > KQ_MAXREQ && lane == 0) *O.error = KQ_EUNSUPPORTED;
+    bool is_pods = false;
+    for (int a = lane; a < ne; a += WAVE) {
+      int64_t q = H.req_qty[e0 + a];
+      if (scale) q = sat_mul(q / (int64_t)count, (int64_t)new_count);
+      const int r = H.req_res[e0 + a];
+      if (pods_cov && r == S.pods_res) { q = scale ? new_count : count; is_pods = true; }
+      w.req_res[a] = r; w.req_qty[a] = q;
+    }
+    const bool have_pods = wballot(is_pods) != 0;
+    wsync();
     if (lane == 0) {
-      int n = 0;
-      bool have_pods = false;
-      for (int e = H.ps_req_off[psg]; e < H.ps_req_off[psg + 1]; e++) {
-        if (n >= KQ_MAXREQ) { *O.error = KQ_EUNSUPPORTED; break; }
-        int64_t q = H.req_qty[e];
-        if (scale) q = sat_mul(q / (int64_t)count, (int64_t)new_count);
-        int r = H.req_res[e];
-        if (pods_cov && r == S.pods_res) { q = scale ? new_count : count; have_pods = true; }
-        w.req_res[n] = r; w.req_qty[n] = q; n++;
-      }
+      int n = ne;
       if (pods_cov && !have_pods) {
         if (n >= KQ_MAXREQ) *O.error = KQ_EUNSUPPORTED;
         else { w.req_res[n] = S.pods_res; w.req_qty[n] = scale ? new_count : count; n++; }
       }
-      // Requests.Iter order (slice_requests.go:54-60): insertion sort by resource_order
-      for (int a = 1; a < n; a++) {
+      w.nreq = n;
+    }
+    wsync();
+    {  // Requests.Iter order (slice_requests.go:54-60)
+      const int n = w.nreq;
+#ifdef KQ_HOST_EMU
+      for (int a = 1; a < n; a++) {  // 1-lane emulation: insertion sort by resource_order
         int r = w.req_res[a]; int64_t q = w.req_qty[a]; int b = a - 1;
         while (b >= 0 && S.resource_order[w.req_res[b]] > S.resource_order[r]) { w.req_res[b + 1] = w.req_res[b]; w.req_qty[b + 1] = w.req_qty[b]; b--; }
         w.req_res[b + 1] = r; w.req_qty[b + 1] = q;
       }
-      w.nreq = n;
-      for (int a = 0; a < n; a++) w.req_done[a] = 0;
-      w.bytes += (int64_t)n * 16;  // requests in + requests echoed in the PodSetAssignment
+      for (int a = 0; a < n; a++) { w.req_done[a] = 0; w.req_rg[a] = S.cq_res_rg[(size_t)w.cq * nR + w.req_res[a]]; }
+#else
+      // device: one lane per request (n <= KQ_MAXREQ < 64): rank by pairwise compare, then a scatter — no serial loop, one round trip
+      int r = 0, ord = 0, rank = 0; int64_t q = 0;
+      if (lane < n) { r = w.req_res[lane]; q = w.req_qty[lane]; ord = S.resource_order[r]; }
+      for (int b = 0; b < n; b++) {
+        const int ob = wshfl_i32(ord, b);
+        if (lane < n && (ob < ord || (ob == ord && b < lane))) rank++;
+      }
+      wsync();
+      if (lane < n) { w.req_res[rank] = r; w.req_qty[rank] = q; w.req_done[rank] = 0; w.req_rg[rank] = S.cq_res_rg[(size_t)w.cq * nR + r]; }
+#endif
+      if (lane == 0) w.bytes += (int64_t)n * 16;  // requests in + requests echoed in the PodSetAssignment
     }
     wsync();
-    // nomination mapping snapshot for this podset (flavor per resource before we overwrite O.flavor)
-    int32_t nom_flavor[KQ_MAXREQ];
-    if (nominate_map) for (int a = 0; a < w.nreq; a++) nom_flavor[a] = k.X.nom[((size_t)slot * KQ_MAXPS + pi) * nR + w.req_res[a]];
+    // (the nomination mapping of a recomputation, X.nom, was taken before O.flavor is overwritten: process_entry)
     // clear the podset's output rows
     for (int r = lane; r < nR; r += WAVE) { O.flavor[(size_t)psg * nR + r] = -1; O.res_mode[(size_t)psg * nR + r] = M_NOFIT; O.tried_idx[(size_t)psg * nR + r] = -1; }
     if (lane == 0) O.ps_count[psg] = scale ? new_count : count;
@@ -1649,7 +1671,8 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
     if (lane == 0) w.rsn_ps0 = w.nrsn;
     for (int a = 0; a < w.nreq && !group_failed; a++) {
       const int res_name = w.req_res[a];
-      const int g = rg_by_resource(S, w.cq, res_name);
+      const int gl = w.req_rg[a];
+      const int g = gl < 0 ? -1 : S.cq_rg_off[w.cq] + gl;
       if (g < 0) {  // flavorassigner.go:809-817
         if (w.req_qty[a] == 0) continue;
         if (gate(k, KQ_GATE_QUOTA_CHECK_STRATEGY) && k.C.quota_check_strategy == KQ_QUOTA_CHECK_IGNORE_UNDECLARED) continue;
@@ -1661,7 +1684,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
       // ---- findFlavorForPodSets :1065-1210 ---------------------------------------------
       if (lane == 0) {
         int nf = 0;
-        for (int b = 0; b < w.nreq; b++) if (rg_covers(S, g, w.req_res[b])) { w.f_res[nf] = w.req_res[b]; w.f_qty[nf] = w.req_qty[b]; w.f_slot[nf] = (uint8_t)b; nf++; }
+        for (int b = 0; b < w.nreq; b++) if (w.req_rg[b] == gl) { w.f_res[nf] = w.req_res[b]; w.f_qty[nf] = w.req_qty[b]; w.f_slot[nf] = (uint8_t)b; nf++; }
         w.nf = nf;
         w.rsn_g0 = w.nrsn;
       }
@@ -1684,7 +1707,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
           int f = S.rg_flavor[f0 + j];
           bool ok = (H.ps_flavor_ok[(size_t)psg * S.nfw + (f >> 6)] >> (f & 63)) & 1;  // checkFlavorForPodSets :1212 (host-evaluated)
           uint8_t pm = PM_SKIP; int32_t borrow = ok ? 0 : KQ_RSN_FLAVOR_INELIGIBLE; int64_t val = 0, aux = 0;  // a skipped cell keeps WHY in `borrow`
-          if (nominate_map && nom_flavor[a] != f) { ok = false; borrow = KQ_RSN_NOT_IN_NOMINATION; }  // shouldSkipBasedOnNominationMapping :1422 (checked first, :1096)
+          if (nominate_map && k.X.nom[((size_t)slot * KQ_MAXPS + pi) * nR + res_name] != f) { ok = false; borrow = KQ_RSN_NOT_IN_NOMINATION; }  // shouldSkipBasedOnNominationMapping :1422 (checked first, :1096)
           if (ok) {
             int fr = f * nR + w.f_res[kk];
             val = a_addi(assumed_usage(w, fr), w.f_qty[kk]);

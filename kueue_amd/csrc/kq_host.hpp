@@ -193,6 +193,7 @@ template <class B> struct EngineT {
     S.frb_sig = upload(prep.frb_sig.data(), prep.frb_sig.size());
     S.cs_ok = upload(prep.cs_ok.data(), prep.cs_ok.size());
     S.tree_depth = upload(prep.tree_depth.data(), prep.tree_depth.size());
+    S.cq_res_rg = upload(prep.cq_res_rg.data(), prep.cq_res_rg.size());
     rc = be.sync();
     if (rc != KQ_OK) return fail(rc, be.error());
     have_snapshot = true;

@@ -84,6 +84,7 @@ struct Prep {
   std::vector<int32_t> rank_pos;                   // [n_adm] position of the row inside its tree's tree_rows segment
   std::vector<int32_t> top_of;                     // [N] the ancestor-or-self that is a child of the root (-1 for roots)
   int max_tree_nodes = 0, max_tree_cqs = 0, max_tree_rows = 0, max_tree_cohorts = 0;
+  std::vector<int8_t> cq_res_rg;                   // [nq * nR] RGByResource: index of the covering group inside the ClusterQueue's groups, -1 = none
   int max_rsn_per_podset = 1;  // most reason records one podset's flavor scans can produce: max over ClusterQueues of sum over groups of flavors x (resources + 1)
   std::string err;
 };
@@ -386,6 +387,13 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
     p.max_tree_cqs = std::max(p.max_tree_cqs, p.tree_cq_off[t + 1] - p.tree_cq_off[t]);
     p.max_tree_rows = std::max(p.max_tree_rows, p.tree_row_off[t + 1] - p.tree_row_off[t]);
     p.max_tree_cohorts = std::max(p.max_tree_cohorts, (p.tree_node_off[t + 1] - p.tree_node_off[t]) - (p.tree_cq_off[t + 1] - p.tree_cq_off[t]));
+  }
+  p.cq_res_rg.assign((size_t)p.nq * p.nR, -1);
+  for (int c = 0; c < p.nq; c++) {
+    if (s->cq_rg_off[c + 1] - s->cq_rg_off[c] > 127) { p.err = "more than 127 resource groups in a ClusterQueue"; return KQ_EUNSUPPORTED; }
+    for (int g = s->cq_rg_off[c + 1] - 1; g >= s->cq_rg_off[c]; g--)  // the first group covering a resource wins (util/resourcegroups/resourcegroups.go:62)
+      for (int i = s->rg_res_off[g]; i < s->rg_res_off[g + 1]; i++)
+        if (s->rg_res[i] >= 0 && s->rg_res[i] < p.nR) p.cq_res_rg[(size_t)c * p.nR + s->rg_res[i]] = (int8_t)(g - s->cq_rg_off[c]);
   }
   p.max_rsn_per_podset = 1;
   for (int c = 0; c < p.nq; c++) {

@@ -39,12 +39,13 @@ def pmc(path):
 
 def main(tag, workload, kernels):
     out = os.path.join(ROOT, "profiles")
-    base = os.path.join(ROOT, "gpurun_out")
+    base = os.environ.get("KQ_PROF_BASE", os.path.join(ROOT, "gpurun_out"))
     stats = one(f"{base}/p_{workload}_stats/**/*_kernel_stats.csv")
     shutil.copy(stats, os.path.join(out, f"{tag}_{workload}_kernel_stats.csv"))
     fetch = pmc(one(f"{base}/p_{workload}_fetch/**/*_counter_collection.csv"))
     write = pmc(one(f"{base}/p_{workload}_write/**/*_counter_collection.csv"))
-    cmd = {"cfg3": "python bench.py --no-cpu-baseline   (the default bench: workload cfg3, closed loop, 100 steps + 5 warm-up, 1 x MI355X)",
+    cmd = {"cfg3": "python bench.py --no-cpu-baseline --no-parity-gate --full-run 0 --no-host-leg   (the default bench: workload cfg3, pending loop, 100 steps + 5 warm-up, 1 x MI355X)",
+           "cfg3-batch": "python bench.py --workload cfg3-batch --steps 10 --warmup 1 --no-cpu-baseline   (nominate-all-pending, 100 000 heads per launch, 1 x MI355X)",
            "cfg5": "python bench.py --workload cfg5 --steps 5 --warmup 1 --no-cpu-baseline   (1 x MI355X)"}.get(workload, workload)
     lines = [f"# rocprofv3 --kernel-trace --stats --output-format csv -- {cmd}"]
     lines += [l.rstrip("\n") for l in open(stats)]
