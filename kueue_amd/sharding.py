@@ -136,6 +136,30 @@ class SplitRoot:
             import torch
             torch.cuda.synchronize()
 
+    def plan(self, heads_all):
+        """Index arrays of one heads batch (cached per batch object): every rank's heads, their podsets and (podset, resource) cells
+        inside the batch's arrays, and this rank's sub-batch. Computed once per batch, not per cycle."""
+        import numpy as np
+        key = id(heads_all)
+        if getattr(self, "_plans", None) is None:
+            self._plans = {}
+        if key in self._plans:
+            return self._plans[key]
+        a = heads_all.arrays
+        nR = self.snap.n_resource
+        owner = self.owner[a["cq"]]
+        nps = np.diff(a["ps_off"])
+        ps_owner = np.repeat(owner, nps)
+        per_rank = []
+        for r in range(self.world):
+            idx = np.nonzero(owner == r)[0]
+            ps_idx = np.nonzero(ps_owner == r)[0]
+            cell_idx = (ps_idx[:, None] * nR + np.arange(nR)[None, :]).reshape(-1)
+            per_rank.append((idx, ps_idx, cell_idx))
+        pl = dict(per_rank=per_rank, hb=heads_all.subset(per_rank[self.rank][0]))
+        self._plans[key] = pl
+        return pl
+
     def cycle(self, heads_all, tgt_cap=None):
         """-> (Decisions over heads_all, merged on every rank; exact: bool). The resident snapshot of every rank ends up with the
         cycle's admissions folded in; the ClusterQueue-level delta that was folded is returned as .last_delta (for a later release)."""
@@ -143,8 +167,8 @@ class SplitRoot:
         import torch
         from .api import Decisions
         dist = self.dist
-        own = np.nonzero(self.owner[heads_all.arrays["cq"]] == self.rank)[0]
-        hb = heads_all.subset(own)
+        pl = self.plan(heads_all)
+        hb = pl["hb"]
         d_own = self.eng.run(hb, tgt_cap=tgt_cap)
         margin, flags = self.eng.certificate(self.delta.data_ptr())
         self._sync()
@@ -168,32 +192,31 @@ class SplitRoot:
         self.stats["cycles"] += 1
         if exact:
             self.stats["exact"] += 1
+            m = int(d_own.a["tgt_off"][-1])
+            mine_part = {k: (v[:m] if k in ("tgt_adm", "tgt_reason") else v) for k, v in d_own.a.items()}
             parts = [None] * self.world
-            mine_part = (own, {k: v for k, v in d_own.a.items()}, hb.arrays["ps_off"])
             if self.world > 1:
                 dist.all_gather_object(parts, mine_part)
             else:
                 parts = [mine_part]
             merged = Decisions(heads_all, tgt_cap=tgt_cap)
-            nR = self.snap.n_resource
-            tgts = {}
-            for idx, a, ps_off in parts:
+            tn = np.zeros(heads_all.n, np.int64)
+            for (idx, ps_idx, cell_idx), a in zip(pl["per_rank"], parts):
                 for k in ("status", "action", "nominated_mode", "mode", "requeue_reason", "skip", "borrowing"):
                     merged.a[k][idx] = a[k]
-                for j, h in enumerate(idx):
-                    g0, g1 = int(heads_all.arrays["ps_off"][h]), int(heads_all.arrays["ps_off"][h + 1])
-                    l0, l1 = int(ps_off[j]), int(ps_off[j + 1])
-                    merged.a["ps_count"][g0:g1] = a["ps_count"][l0:l1]
-                    for k in ("flavor", "res_mode", "tried_idx"):
-                        merged.a[k][g0 * nR:g1 * nR] = a[k][l0 * nR:l1 * nR]
-                    tgts[int(h)] = (a["tgt_adm"][a["tgt_off"][j]:a["tgt_off"][j + 1]], a["tgt_reason"][a["tgt_off"][j]:a["tgt_off"][j + 1]])
-            t = 0
-            for h in range(heads_all.n):
-                merged.a["tgt_off"][h] = t
-                rows, why = tgts.get(h, ((), ()))
-                merged.a["tgt_adm"][t:t + len(rows)] = rows; merged.a["tgt_reason"][t:t + len(rows)] = why
-                t += len(rows)
-            merged.a["tgt_off"][heads_all.n] = t
+                merged.a["ps_count"][ps_idx] = a["ps_count"]
+                for k in ("flavor", "res_mode", "tried_idx"):
+                    merged.a[k][cell_idx] = a[k]
+                tn[idx] = np.diff(a["tgt_off"])
+            off = np.concatenate([[0], np.cumsum(tn)])
+            merged.a["tgt_off"][:] = off
+            if off[-1] > 0:   # targets CSR: every head's rows land at its global offset
+                for (idx, _, _), a in zip(pl["per_rank"], parts):
+                    cnt = np.diff(a["tgt_off"])
+                    if cnt.sum() == 0:
+                        continue
+                    dst = np.repeat(off[idx], cnt) + (np.arange(int(cnt.sum())) - np.repeat(a["tgt_off"][:-1], cnt))
+                    merged.a["tgt_adm"][dst] = a["tgt_adm"][:int(cnt.sum())]; merged.a["tgt_reason"][dst] = a["tgt_reason"][:int(cnt.sum())]
             merged.a["order"][:] = classical_order(heads_all, merged.a["borrowing"], self.cfg.gates)
             fold = total[:self.nq * self.nfr].contiguous()
         else:
