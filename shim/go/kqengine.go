@@ -158,47 +158,65 @@ func pin[T any](p *runtime.Pinner, s []T) unsafe.Pointer {
 	return unsafe.Pointer(&s[0])
 }
 
+func fillSnapshot(p *runtime.Pinner, c *C.kq_snapshot, s *FlatSnapshot) {
+	c.n_cq, c.n_cohort, c.n_flavor, c.n_resource = C.int32_t(s.NCQ), C.int32_t(s.NCohort), C.int32_t(s.NFlavor), C.int32_t(s.NResource)
+	c.pods_resource = C.int32_t(s.PodsResource)
+	c.resource_order = (*C.int32_t)(pin(p, s.ResourceOrder))
+	c.parent = (*C.int32_t)(pin(p, s.Parent))
+	c.child_cohort_off = (*C.int32_t)(pin(p, s.ChildCohortOff))
+	c.child_cohort = (*C.int32_t)(pin(p, s.ChildCohort))
+	c.child_cq_off = (*C.int32_t)(pin(p, s.ChildCQOff))
+	c.child_cq = (*C.int32_t)(pin(p, s.ChildCQ))
+	c.fair_weight = (*C.double)(pin(p, s.FairWeight))
+	c.nominal = (*C.int64_t)(pin(p, s.Nominal))
+	c.borrow_limit = (*C.int64_t)(pin(p, s.BorrowLimit))
+	c.lend_limit = (*C.int64_t)(pin(p, s.LendLimit))
+	c.subtree_quota = (*C.int64_t)(pin(p, s.SubtreeQuota))
+	c.usage = (*C.int64_t)(pin(p, s.Usage))
+	c.quota_flags = (*C.uint8_t)(pin(p, s.QuotaFlags))
+	c.cq_rg_off = (*C.int32_t)(pin(p, s.CQRgOff))
+	c.rg_flavor_off = (*C.int32_t)(pin(p, s.RgFlavorOff))
+	c.rg_flavor = (*C.int32_t)(pin(p, s.RgFlavor))
+	c.rg_res_off = (*C.int32_t)(pin(p, s.RgResOff))
+	c.rg_res = (*C.int32_t)(pin(p, s.RgRes))
+	c.cq_policy = (*C.uint32_t)(pin(p, s.CQPolicy))
+	c.cq_borrow_prio_threshold = (*C.int32_t)(pin(p, s.CQBorrowPrioThreshold))
+	c.cq_generation = (*C.int64_t)(pin(p, s.CQGeneration))
+	c.n_adm = C.int32_t(s.NAdm)
+	c.cq_adm_off = (*C.int32_t)(pin(p, s.CQAdmOff))
+	c.adm_priority = (*C.int64_t)(pin(p, s.AdmPriority))
+	c.adm_queue_ts = (*C.int64_t)(pin(p, s.AdmQueueTs))
+	c.adm_reserve_ts = (*C.int64_t)(pin(p, s.AdmReserveTs))
+	c.adm_uid_rank = (*C.uint32_t)(pin(p, s.AdmUIDRank))
+	c.adm_flags = (*C.uint8_t)(pin(p, s.AdmFlags))
+	c.adm_use_off = (*C.int32_t)(pin(p, s.AdmUseOff))
+	c.adm_use_fr = (*C.int32_t)(pin(p, s.AdmUseFr))
+	c.adm_use_qty = (*C.int64_t)(pin(p, s.AdmUseQty))
+}
+
 // PutSnapshot uploads cache.Snapshot() (pkg/cache/scheduler/snapshot.go:171) to HBM.
 func (e *Engine) PutSnapshot(s *FlatSnapshot) error {
 	var p runtime.Pinner
 	defer p.Unpin()
 	c := (*C.kq_snapshot)(C.calloc(1, C.sizeof_kq_snapshot))
 	defer C.free(unsafe.Pointer(c))
-	c.n_cq, c.n_cohort, c.n_flavor, c.n_resource = C.int32_t(s.NCQ), C.int32_t(s.NCohort), C.int32_t(s.NFlavor), C.int32_t(s.NResource)
-	c.pods_resource = C.int32_t(s.PodsResource)
-	c.resource_order = (*C.int32_t)(pin(&p, s.ResourceOrder))
-	c.parent = (*C.int32_t)(pin(&p, s.Parent))
-	c.child_cohort_off = (*C.int32_t)(pin(&p, s.ChildCohortOff))
-	c.child_cohort = (*C.int32_t)(pin(&p, s.ChildCohort))
-	c.child_cq_off = (*C.int32_t)(pin(&p, s.ChildCQOff))
-	c.child_cq = (*C.int32_t)(pin(&p, s.ChildCQ))
-	c.fair_weight = (*C.double)(pin(&p, s.FairWeight))
-	c.nominal = (*C.int64_t)(pin(&p, s.Nominal))
-	c.borrow_limit = (*C.int64_t)(pin(&p, s.BorrowLimit))
-	c.lend_limit = (*C.int64_t)(pin(&p, s.LendLimit))
-	c.subtree_quota = (*C.int64_t)(pin(&p, s.SubtreeQuota))
-	c.usage = (*C.int64_t)(pin(&p, s.Usage))
-	c.quota_flags = (*C.uint8_t)(pin(&p, s.QuotaFlags))
-	c.cq_rg_off = (*C.int32_t)(pin(&p, s.CQRgOff))
-	c.rg_flavor_off = (*C.int32_t)(pin(&p, s.RgFlavorOff))
-	c.rg_flavor = (*C.int32_t)(pin(&p, s.RgFlavor))
-	c.rg_res_off = (*C.int32_t)(pin(&p, s.RgResOff))
-	c.rg_res = (*C.int32_t)(pin(&p, s.RgRes))
-	c.cq_policy = (*C.uint32_t)(pin(&p, s.CQPolicy))
-	c.cq_borrow_prio_threshold = (*C.int32_t)(pin(&p, s.CQBorrowPrioThreshold))
-	c.cq_generation = (*C.int64_t)(pin(&p, s.CQGeneration))
-	c.n_adm = C.int32_t(s.NAdm)
-	c.cq_adm_off = (*C.int32_t)(pin(&p, s.CQAdmOff))
-	c.adm_priority = (*C.int64_t)(pin(&p, s.AdmPriority))
-	c.adm_queue_ts = (*C.int64_t)(pin(&p, s.AdmQueueTs))
-	c.adm_reserve_ts = (*C.int64_t)(pin(&p, s.AdmReserveTs))
-	c.adm_uid_rank = (*C.uint32_t)(pin(&p, s.AdmUIDRank))
-	c.adm_flags = (*C.uint8_t)(pin(&p, s.AdmFlags))
-	c.adm_use_off = (*C.int32_t)(pin(&p, s.AdmUseOff))
-	c.adm_use_fr = (*C.int32_t)(pin(&p, s.AdmUseFr))
-	c.adm_use_qty = (*C.int64_t)(pin(&p, s.AdmUseQty))
+	fillSnapshot(&p, c, s)
 	if rc := C.kq_snapshot_put(e.h, c); rc != 0 {
 		return e.err("kq_snapshot_put", rc)
+	}
+	return nil
+}
+
+// PatchSnapshot is the next cycle's snapshot when only usage (KQ_PATCH_USAGE = 1) and / or the admitted set (KQ_PATCH_ADMITTED = 2)
+// moved since the last PutSnapshot: what clusterQueue.updateWorkloadUsage (clusterqueue.go:594) changes between two cycles.
+func (e *Engine) PatchSnapshot(s *FlatSnapshot, what uint32) error {
+	var p runtime.Pinner
+	defer p.Unpin()
+	c := (*C.kq_snapshot)(C.calloc(1, C.sizeof_kq_snapshot))
+	defer C.free(unsafe.Pointer(c))
+	fillSnapshot(&p, c, s)
+	if rc := C.kq_snapshot_patch(e.h, c, C.uint32_t(what)); rc != 0 {
+		return e.err("kq_snapshot_patch", rc)
 	}
 	return nil
 }
