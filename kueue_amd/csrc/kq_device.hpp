@@ -1532,6 +1532,18 @@ KQ_DEV void fair_search(Search& s) {
     for (int t = 0; t < nt; t++) { int r = s.trow[t]; w.bytes += 16 * (int64_t)S.plen[S.adm_cq[r]] * (S.adm_use_off[r + 1] - S.adm_use_off[r]); }
 }
 
+// LDS bytes the small state of one FAIR victim search wants: the per-node borrowed sums the DRS is computed from (psum, ppos: every
+// pop of the TargetClusterQueueOrdering updates them with atomics and reads them back), the per-ClusterQueue candidate-queue heads and
+// the pruning maps. The big private usage plane W and the per-row class bytes stay in HBM scratch: they are touched sparsely.
+KQ_MDEV size_t fair_lds_bytes(int nn, int nqs, int nR) {
+  size_t b = (size_t)nn * nR * 8;              // psum
+  b += ((size_t)nn * 4 + 7) & ~(size_t)7;       // ppos
+  b += ((size_t)nqs * 4 + 7) & ~(size_t)7;      // qcnt
+  b += ((size_t)nqs * 4 + 7) & ~(size_t)7;      // qhead
+  b += ((size_t)nqs + 7) & ~(size_t)7;          // cqinfo
+  b += ((size_t)nn + 7) & ~(size_t)7;           // cohp
+  return b;
+}
 KQ_DEV Search make_search(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed) {
   Search s;
   s.k = &k; s.w = &w; s.slot = slot; s.usage = usage; s.removed = removed;
@@ -1549,6 +1561,21 @@ KQ_DEV Search make_search(const K& k, Wave& w, int slot, const int64_t* usage, c
   const bool plain = fs_plain_now(k);
   s.psum = (plain && k.X.psum) ? k.X.psum + (size_t)slot * k.X.max_tree_nodes * k.S.nR : nullptr;
   s.ppos = (plain && k.X.ppos) ? k.X.ppos + (size_t)slot * k.X.max_tree_nodes : nullptr;
+  // fair sharing: the search's small, hot state in the workgroup's LDS when the launch provided enough of it (k_nominate's dynamic
+  // LDS; in k_process_fair the flushed cohort rows lend theirs for the time of a recomputation)
+  if (k.C.fair_sharing && w.cs_lds && k.X.qcnt &&
+      (size_t)w.cs_lds_bytes >= fair_lds_bytes(k.X.max_tree_nodes, k.X.max_tree_cqs, k.S.nR)) {
+    const int nn = k.X.max_tree_nodes, nqs = k.X.max_tree_cqs;
+    unsigned char* p = w.cs_lds;
+    auto carve = [&](size_t bytes) { unsigned char* q = p; p += (bytes + 7) & ~(size_t)7; return q; };
+    int64_t* lp = (int64_t*)carve((size_t)nn * k.S.nR * 8);
+    int32_t* lpp = (int32_t*)carve((size_t)nn * 4);
+    if (s.psum) { s.psum = lp; s.ppos = lpp; }
+    s.qcnt = (int32_t*)carve((size_t)nqs * 4);
+    s.qhead = (uint32_t*)carve((size_t)nqs * 4);
+    s.cqinfo = (uint8_t*)carve((size_t)nqs);
+    s.cohp = (uint8_t*)carve((size_t)nn);
+  }
   return s;
 }
 
@@ -2381,7 +2408,7 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
     for (int i = lane; i < w.nps * S.nR; i += WAVE) k.X.nom[(size_t)slot * KQ_MAXPS * S.nR + i] = O.flavor[(size_t)w.ps_base * S.nR + i];
     wsync();
     // the flushed rows are not read until the recomputation is over: their LDS serves the victim searches meanwhile (kq_cs.hpp)
-    const bool lend = w.pc_on && !k.C.fair_sharing;
+    const bool lend = w.pc_on != 0;  // classical: the scan search's arrays; fair sharing: the search's small state (make_search)
     if (lend && lane == 0) { w.cs_lds = (unsigned char*)w.pc_lds; w.cs_lds_bytes = (int)((size_t)w.pc_ncoh * S.nfr * 16); }
     wsync();
     Search s = get_assignments(k, w, slot, k.usage_np, k.preempted, true);
