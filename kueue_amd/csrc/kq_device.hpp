@@ -1535,7 +1535,12 @@ KQ_DEV void fair_search(Search& s) {
 // LDS bytes the small state of one FAIR victim search wants: the per-node borrowed sums the DRS is computed from (psum, ppos: every
 // pop of the TargetClusterQueueOrdering updates them with atomics and reads them back), the per-ClusterQueue candidate-queue heads and
 // the pruning maps. The big private usage plane W and the per-row class bytes stay in HBM scratch: they are touched sparsely.
-KQ_MDEV size_t fair_lds_bytes(int nn, int nqs, int nR) {
+#ifdef KQ_HOST_EMU
+static inline
+#else
+__host__ __device__ inline
+#endif
+size_t fair_lds_bytes(int nn, int nqs, int nR) {
   size_t b = (size_t)nn * nR * 8;              // psum
   b += ((size_t)nn * 4 + 7) & ~(size_t)7;       // ppos
   b += ((size_t)nqs * 4 + 7) & ~(size_t)7;      // qcnt
