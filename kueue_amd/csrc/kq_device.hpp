@@ -2406,8 +2406,10 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
   if (has_any() && gate(k, KQ_GATE_RECOMPUTE_ON_OVERLAP)) {
     // SimulateWorkloadRemoval(victimsOfOtherPreemptions) == evaluate on usage_np with those rows deleted.
     // The generic nominate code reads HBM planes: publish the LDS-resident cohort rows first.
+    KQ_TS(k, 4);  // (KQ_PROF) everything of this entry before the recomputation
     if (np_exact_mode(w)) np_rebuild(k, w, tree, false);
     pc_flush(k, w, w.pc_lds, tree);
+    KQ_TS(k, 5);  // flush of the LDS-resident cohort rows
     if (lane == 0) w.has_last = 0;
     // e.NominationMapping = e.readResourceToFlavorMapping() (scheduler.go:734): fixed for the whole recomputation
     for (int i = lane; i < w.nps * S.nR; i += WAVE) k.X.nom[(size_t)slot * KQ_MAXPS * S.nR + i] = O.flavor[(size_t)w.ps_base * S.nR + i];
@@ -2418,7 +2420,9 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
     wsync();
     Search s = get_assignments(k, w, slot, k.usage_np, k.preempted, true);
     publish_assignment(k, w, s, e);
+    KQ_TS(k, 6);  // the recomputation itself
     if (lend) { if (lane == 0) { w.cs_lds = nullptr; w.cs_lds_bytes = 0; } wsync(); pc_load(k, w, w.pc_lds, tree); }
+    KQ_TS(k, 7);  // reload of the rows
     trows = O.pool_row + O.tgt_pos[e];
     nt = O.tgt_n[e];
     mode = w.rep_mode;

@@ -573,10 +573,9 @@ template <class B> struct EngineT {
     // LDS of a nominate workgroup: the arrays of a one-slot search (SimulatePreemption, 37 of the 38 searches of a cfg 4 head)
     // (with the quota tables when that stays within half a CU's LDS; what does not fit goes to the spill space array by array)
     size_t nom_lds = 0;
-    if (cfg.fair_sharing && prep.any_preemption) {  // fair victim searches keep their small hot state in LDS (make_search)
-      const size_t need = fair_lds_bytes(prep.max_tree_nodes, std::max(prep.max_tree_cqs, 1), prep.nR);
-      if (need <= 72 * 1024) nom_lds = need;
-    }
+    // (fair victim searches: giving k_nominate dynamic LDS for the search's small state — make_search can place it there — was measured
+    // at cfg 4f and lost: 50 KB per workgroup leaves 2 resident waves per CU instead of 16 and the pass went from 6.1 to 9.4 s,
+    // profiles/r02i_bench_cfg4f_lds_state.json. Only k_process_fair, which has the LDS anyway, uses the placement.)
     if (k.C.cs_on) {
       nom_lds = cs_bytes(1, prep.cs_max_bucket, prep.max_tree_nodes, prep.max_tree_cqs, true);
       if (nom_lds > 78 * 1024) nom_lds = std::min<size_t>(cs_bytes(1, prep.cs_max_bucket, prep.max_tree_nodes, prep.max_tree_cqs, false), 78 * 1024);

@@ -4,7 +4,7 @@ import pytest
 from tests import fixture_cycles as FC
 from tests.conftest import load_golden
 
-PRE = load_golden("preemption.yaml")["cases"]
+PRE = load_golden("preemption.yaml")["cases"] + load_golden("preemption_manual.yaml")["cases"]
 FAIR = load_golden("preemption_fair.yaml")["cases"]
 ASG = load_golden("assign_flavors.yaml")["cases"] + load_golden("assign_flavors_hierarchical.yaml")["cases"] + load_golden("assign_flavors_reclaim.yaml")["cases"]
 
