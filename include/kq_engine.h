@@ -325,6 +325,14 @@ typedef struct kq_pending {
   kq_heads w;                 /* n = W workloads: the pre-digested workload.Info columns of a heads batch, any order;
                                  w.cycle is ignored */
   const uint32_t* uid_rank;   /* [W] rank of Obj.UID (cluster_queue.go:873) */
+  /* AdmissionFairSharing ordering (queueOrderingFunc cluster_queue.go:880-904): in a ClusterQueue whose AdmissionScope is
+   * UsageBasedAdmissionFairSharing the heap compares the LocalQueues' fair-sharing usage first (lower first, Go cmp.Compare on
+   * float64), then baseCompareFunc. lq[w] = index of the workload's LocalQueue, -1 = ordering by baseCompareFunc only (the
+   * ClusterQueue has no AFS). NULL / n_lq = 0: no AFS anywhere. The usage values (afs.CalculateUsage: consumed + pending penalty,
+   * resource weights, LocalQueue weight - pkg/util/admissionfairsharing/admission_fair_sharing.go:86) are the host's:
+   * kq_pending_set_lq_usage before Heads(). */
+  int32_t n_lq;
+  const int32_t* lq;          /* [W] or NULL */
 } kq_pending;
 /* PushOrUpdate (cluster_queue.go:379) of every workload into its ClusterQueue's heap; replaces any previous pending set. */
 int  kq_pending_put(kq_engine* e, const kq_pending* p);
@@ -338,6 +346,8 @@ int  kq_cycle_run_pending(kq_engine* e, kq_decisions* out);
 /* Step 6 of schedule() (scheduler.go:362-377) for the heads of that cycle: admitted workloads leave the queue, the others go
  * through RequeueIfNotPresent with the decision's requeue reason; their LastAssignment becomes the cycle's tried indices. */
 int  kq_pending_apply(kq_engine* e);
+/* ComputeLocalQueueFSUsage of every LocalQueue (workload.go:492) as the ledger stands now; read by the next kq_pending_heads. */
+int  kq_pending_set_lq_usage(kq_engine* e, int32_t n_lq, const double* usage);
 /* queueInadmissibleWorkloads for the listed ClusterQueues (cq == NULL: all) — what requeueWorkloadsCohort does for the root
  * cohorts whose quota was freed (inadmissible_workloads.go:112-175). */
 int  kq_pending_queue_inadmissible(kq_engine* e, int32_t n, const int32_t* cq);

@@ -607,11 +607,14 @@ class Pending:
     """kq_pending: every pending workload of every ClusterQueue (the heaps of pkg/cache/queue), as one heads-shaped table
     plus the UID ranks baseCompareFunc breaks ties with (cluster_queue.go:873)."""
 
-    def __init__(self, heads: Heads, uid_rank: Optional[np.ndarray] = None):
+    def __init__(self, heads: Heads, uid_rank: Optional[np.ndarray] = None, lq: Optional[np.ndarray] = None, n_lq: int = 0):
         self.heads = heads
         self.snap = heads.snap
         self.n = heads.n
         self.uid_rank = np.ascontiguousarray(uid_rank if uid_rank is not None else np.arange(heads.n), dtype=np.uint32)
+        # AdmissionFairSharing: LocalQueue of every workload (-1: its ClusterQueue orders by baseCompareFunc only)
+        self.lq = None if lq is None else np.ascontiguousarray(lq, dtype=np.int32)
+        self.n_lq = int(n_lq)
         self._struct = None
 
     def struct(self) -> F.kq_pending:
@@ -621,6 +624,9 @@ class Pending:
             pad = self.uid_rank if self.uid_rank.size else np.zeros(1, np.uint32)
             self._pad = pad
             p.uid_rank = F.ptr(pad)
+            p.n_lq = self.n_lq if self.lq is not None else 0
+            if self.lq is not None and self.lq.size:
+                p.lq = F.ptr(self.lq)
             self._struct = p
         return self._struct
 

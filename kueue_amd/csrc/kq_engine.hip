@@ -548,6 +548,11 @@ int kq_pending_apply(kq_engine* en) {
   (void)hipSetDevice(en->e.be.device);
   return en->e.pending_apply();
 }
+int kq_pending_set_lq_usage(kq_engine* en, int32_t n_lq, const double* usage) {
+  if (!en) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.pending_set_lq_usage(n_lq, usage);
+}
 int kq_pending_queue_inadmissible(kq_engine* en, int32_t n, const int32_t* cq) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);

@@ -69,6 +69,8 @@ template <class B> struct EngineT {
     uint8_t* d_active = nullptr;
     int32_t* d_list = nullptr;
     int32_t* d_tree_stamp = nullptr;  // [n_tree] last release that freed quota in the tree
+    double* d_lq_usage = nullptr;     // [n_lq] AdmissionFairSharing usage of every LocalQueue
+    int n_lq = 0;
     int32_t release_seq = 0;
   } pend;
   template <class T> T* pend_alloc(size_t n, const T* host = nullptr, int fill = -2) {
@@ -735,6 +737,13 @@ template <class B> struct EngineT {
     D.head_wl = pend_alloc<int32_t>(nq, nullptr, 0xff); D.hd = pend_alloc<int32_t>(nq, nullptr, 0); D.hreq = pend_alloc<int32_t>(nq, nullptr, 0);
     D.counts = pend_alloc<int32_t>(4, nullptr, 0);
     D.cq_active = nullptr;
+    D.lq = nullptr; D.lq_usage = nullptr; P.n_lq = 0;
+    if (p->lq && p->n_lq > 0) {
+      for (int w = 0; w < W; w++) if (p->lq[w] < -1 || p->lq[w] >= p->n_lq) { pending_free(); return fail(KQ_EINVAL, "kq_pending: LocalQueue index out of range"); }
+      D.lq = pend_alloc(W, p->lq);
+      P.d_lq_usage = pend_alloc<double>(p->n_lq, nullptr, 0);
+      D.lq_usage = P.d_lq_usage; P.n_lq = p->n_lq;
+    }
     P.d_active = pend_alloc<uint8_t>(nq, nullptr, 1);
     P.d_list = pend_alloc<int32_t>(nq, nullptr, 0);
     P.d_tree_stamp = pend_alloc<int32_t>(std::max(prep.n_tree, 1), nullptr, 0);
@@ -786,6 +795,13 @@ template <class B> struct EngineT {
     if (pend.n_heads > 0) be.launch_pend_apply(pend.D, S, pend.O, pend.H, cfg.gates, pend.cycle, pend.n_heads);
     pend.n_heads = -1; pend.ran = false;
     return KQ_OK;  // stream-ordered with the next kq_pending_heads
+  }
+  int pending_set_lq_usage(int n_lq, const double* usage) {
+    if (!pend.valid) return fail(KQ_EINVAL, "kq_pending_set_lq_usage before kq_pending_put");
+    if (n_lq != pend.n_lq || (n_lq > 0 && !usage)) return fail(KQ_EINVAL, "kq_pending_set_lq_usage: LocalQueue count differs from kq_pending_put");
+    if (n_lq == 0) return KQ_OK;
+    be.h2d(pend.d_lq_usage, usage, (size_t)n_lq * sizeof(double));
+    return be.sync();  // the caller's array may go away
   }
   int pending_queue_inadmissible(int n, const int32_t* cq) {
     if (!pend.valid) return fail(KQ_EINVAL, "kq_pending_queue_inadmissible before kq_pending_put");

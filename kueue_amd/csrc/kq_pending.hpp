@@ -45,7 +45,23 @@ struct DPend {
   int32_t* hreq;             // [n_heads] first request of head h in the gathered batch
   int32_t* counts;           // [4] n_heads, n_podsets, n_requests
   const uint8_t* cq_active;  // [nq] or null: statusChecker.ClusterQueueActive (manager.go:926)
+  // AdmissionFairSharing ordering (queueOrderingFunc cluster_queue.go:880): LocalQueue of every workload (-1: none) and the
+  // LocalQueues' fair-sharing usage (host-evaluated afs.CalculateUsage); lq == null: baseCompareFunc everywhere
+  const int32_t* lq;         // [W] or null
+  const double* lq_usage;    // [n_lq]
 };
+// Go cmp.Compare(float64) as a sortable 64-bit key: NaN sorts before everything, then -Inf .. +Inf (-0 == +0)
+KQ_DEV uint64_t afs_key(double v) {
+  if (v != v) return 0;
+  if (v == 0) v = 0;  // -0 -> +0
+  uint64_t b;
+#ifdef KQ_HOST_EMU
+  memcpy(&b, &v, 8);
+#else
+  b = (uint64_t)__double_as_longlong(v);
+#endif
+  return ((b >> 63) ? ~b : (b | 0x8000000000000000ull)) + 1;  // + 1 keeps 0 for NaN (the largest key, +Inf, does not overflow)
+}
 
 // the gathered batch (same arrays as a kq_heads upload), written by pend_gather_head
 struct DGather {
@@ -61,7 +77,7 @@ KQ_DEV void pend_pop(const DPend& D, int c) {
   int head = -1;
   const int pw = D.pw[c];
   if (pw >= 0 && D.pw_sticky[c] && D.state[pw] == WL_ACTIVE) head = pw;  // stickyMatches sorts first (:848-856)
-  if (head < 0) {
+  if (head < 0 && !D.lq) {
     const int o0 = D.cq_off[c], o1 = D.cq_off[c + 1];
     for (int base = o0; base < o1 && head < 0; base += WAVE) {
       const int j = base + lane;
@@ -69,6 +85,24 @@ KQ_DEV void pend_pop(const DPend& D, int c) {
       const uint64_t m = wballot(w >= 0 && D.state[w] == WL_ACTIVE);
       if (m) head = wbcast(w, ffs64(m));
     }
+  }
+  if (head < 0 && D.lq) {
+    // queueOrderingFunc: LocalQueue usage first, then the static base order = the position in the sorted segment. A wave arg-min
+    // over (usage key, position): 64 positions per step.
+    const int o0 = D.cq_off[c], o1 = D.cq_off[c + 1];
+    uint64_t best_k = ~0ull; int best_pos = 0x7fffffff;
+    for (int base = o0; base < o1; base += WAVE) {
+      const int j = base + lane;
+      const int w = j < o1 ? D.ord[j] : -1;
+      if (w >= 0 && D.state[w] == WL_ACTIVE) {
+        const int l = D.lq[w];
+        const uint64_t kk = l >= 0 ? afs_key(D.lq_usage[l]) : afs_key(0.0);
+        if (kk < best_k || (kk == best_k && j < best_pos)) { best_k = kk; best_pos = j; }
+      }
+    }
+    const uint64_t mk = wmin_u64(best_k);
+    const uint64_t mp = wmin_u64(best_k == mk ? (uint64_t)(uint32_t)best_pos : ~0ull);
+    if (mk != ~0ull && (int)mp != 0x7fffffff) head = D.ord[(int)mp];
   }
   if (lane == 0) {
     D.pop_cycle[c] += 1;  // :670, also when the heap is empty

@@ -103,6 +103,11 @@ class Engine:
     def pending_apply(self):
         self._check(self._lib.kq_pending_apply(self._h))
 
+    def pending_set_lq_usage(self, usage):
+        """kq_pending_set_lq_usage: the LocalQueues' fair-sharing usage (afs.CalculateUsage, host-evaluated) for the next Heads()."""
+        u = np.ascontiguousarray(usage, np.float64)
+        self._check(self._lib.kq_pending_set_lq_usage(self._h, len(u), F.ptr(u)))
+
     def pending_queue_inadmissible(self, cqs=None):
         if cqs is None:
             self._check(self._lib.kq_pending_queue_inadmissible(self._h, 0, None))

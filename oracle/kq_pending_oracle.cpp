@@ -28,6 +28,7 @@ struct WL {
   // LastAssignment (workload.AssignmentClusterQueueState, workload.go:115-135)
   bool has_last; std::vector<int32_t> last_tried; int64_t last_gen, last_cycle; uint64_t last_hash;
   int ps0, nps;
+  int lq;  // LocalQueue index, -1 = the ClusterQueue orders by baseCompareFunc only
 };
 
 struct CQ {
@@ -43,11 +44,25 @@ struct Queue {
   std::vector<WL> wl;
   std::vector<CQ> cqs;
   std::vector<int> head_wl;          // heads of the cycle in flight, per ClusterQueue
+  std::vector<double> lq_usage;      // ComputeLocalQueueFSUsage per LocalQueue (workload.go:492), host-evaluated
+  // Go cmp.Compare on float64: NaN < everything, -0 == +0
+  static int cmpF(double a, double b) {
+    const bool an = a != a, bn = b != b;
+    if (an && bn) return 0;
+    if (an) return -1;
+    if (bn) return 1;
+    return a < b ? -1 : (a > b ? 1 : 0);
+  }
 
   // baseCompareFunc cluster_queue.go:844-876 : a before b
   bool before(const CQ& c, int a, int b) const {
     const bool as = c.pw_sticky && c.pw == a, bs = c.pw_sticky && c.pw == b;
     if (as != bs) return as;
+    if (!lq_usage.empty()) {  // queueOrderingFunc cluster_queue.go:880-904 (enableAdmissionFs)
+      const double ua = wl[a].lq >= 0 ? lq_usage[wl[a].lq] : 0.0, ub = wl[b].lq >= 0 ? lq_usage[wl[b].lq] : 0.0;
+      const int c3 = cmpF(ua, ub);
+      if (c3 != 0) return c3 < 0;
+    }
     if (wl[a].prio != wl[b].prio) return wl[a].prio > wl[b].prio;
     if (wl[a].ts != wl[b].ts) return wl[a].ts < wl[b].ts;
     if (wl[a].uid != wl[b].uid) return wl[a].uid < wl[b].uid;
@@ -142,9 +157,11 @@ void* kqp_create(const kq_pending* p, int32_t n_cq, int32_t n_resource, const ui
     if (h.ps_last_tried) for (size_t i = 0; i < x.last_tried.size(); i++) x.last_tried[i] = h.ps_last_tried[(size_t)x.ps0 * n_resource + i];
     x.last_gen = h.last_generation ? h.last_generation[w] : 0; x.last_cycle = h.last_cycle ? h.last_cycle[w] : 0;
     x.last_hash = h.last_hash ? h.last_hash[w] : 0;
+    x.lq = (p->lq && p->n_lq > 0) ? p->lq[w] : -1;
     q->cqs[x.cq].members.push_back(w);
   }
   q->head_wl.assign(n_cq, -1);
+  if (p->lq && p->n_lq > 0) q->lq_usage.assign(p->n_lq, 0.0);
   return q;
 }
 void kqp_destroy(void* q) { delete (Queue*)q; }
@@ -205,6 +222,7 @@ int kqp_queue_inadmissible(void* qp, int32_t n, const int32_t* cq) {
   else for (int i = 0; i < n; i++) moved += q.queueInadmissibleWorkloads(cq[i]);
   return moved;
 }
+void kqp_set_lq_usage(void* qp, int32_t n, const double* usage) { Queue& q = *(Queue*)qp; for (int i = 0; i < n && i < (int)q.lq_usage.size(); i++) q.lq_usage[i] = usage[i]; }
 void kqp_read_state(void* qp, uint8_t* state) { Queue& q = *(Queue*)qp; for (size_t w = 0; w < q.wl.size(); w++) state[w] = (uint8_t)q.wl[w].state; }
 
 // ---- single operations, for the transcribed unit tests of the reference ----

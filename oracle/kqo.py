@@ -336,6 +336,11 @@ class PendingOracle:
         rc = self.l.kqp_apply(self.h, C.byref(heads.struct()), C.byref(d.struct()), F.ptr(self.snap.arrays["cq_generation"]))
         assert rc == 0, rc
 
+    def set_lq_usage(self, usage):
+        u = np.ascontiguousarray(usage, np.float64)
+        self.l.kqp_set_lq_usage.restype = None
+        self.l.kqp_set_lq_usage(self.h, len(u), F.ptr(u))
+
     def queue_inadmissible(self, cqs=None) -> int:
         if cqs is None:
             return self.l.kqp_queue_inadmissible(self.h, 0, None)

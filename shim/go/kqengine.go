@@ -289,15 +289,30 @@ func (e *Engine) RunCycle(h *FlatHeads, out *FlatDecisions) error {
 // ---- pending side on the device (pkg/cache/queue): see include/kq_engine.h "pending side" -----------------------
 
 // PutPending = PushOrUpdate of every pending workload (cluster_queue.go:379). uidRank[w] = rank of Obj.UID.
-func (e *Engine) PutPending(all *FlatHeads, uidRank []uint32) error {
+// lq (optional, AdmissionFairSharing): index of the workload's LocalQueue in [0,nLQ) or -1 (queueOrderingFunc cluster_queue.go:880).
+func (e *Engine) PutPending(all *FlatHeads, uidRank []uint32, nLQ int32, lq []int32) error {
 	var p runtime.Pinner
 	defer p.Unpin()
 	c := (*C.kq_pending)(C.calloc(1, C.sizeof_kq_pending))
 	defer C.free(unsafe.Pointer(c))
 	fillHeads(&p, &c.w, all)
 	c.uid_rank = (*C.uint32_t)(pin(&p, uidRank))
+	if len(lq) > 0 {
+		c.n_lq = C.int32_t(nLQ)
+		c.lq = (*C.int32_t)(pin(&p, lq))
+	}
 	if rc := C.kq_pending_put(e.h, c); rc != 0 {
 		return e.err("kq_pending_put", rc)
+	}
+	return nil
+}
+
+// SetLQUsage hands over afs.CalculateUsage of every LocalQueue (admission_fair_sharing.go:86) before Heads.
+func (e *Engine) SetLQUsage(usage []float64) error {
+	var p runtime.Pinner
+	defer p.Unpin()
+	if rc := C.kq_pending_set_lq_usage(e.h, C.int32_t(len(usage)), (*C.double)(pin(&p, usage))); rc != 0 {
+		return e.err("kq_pending_set_lq_usage", rc)
 	}
 	return nil
 }

@@ -175,6 +175,7 @@ int kqe_pending_put(void* e, const kq_pending* p) { return ((EmuEngine*)e)->pend
 int kqe_pending_heads(void* e, int64_t cycle, const uint8_t* act, int32_t* n, int32_t* nps, int32_t* hw) { return ((EmuEngine*)e)->pending_heads(cycle, act, n, nps, hw); }
 int kqe_cycle_run_pending(void* e, kq_decisions* out) { return ((EmuEngine*)e)->cycle_run_pending(out); }
 int kqe_pending_apply(void* e) { return ((EmuEngine*)e)->pending_apply(); }
+int kqe_pending_set_lq_usage(void* e, int32_t n, const double* u) { return ((EmuEngine*)e)->pending_set_lq_usage(n, u); }
 int kqe_pending_queue_inadmissible(void* e, int32_t n, const int32_t* cq) { return ((EmuEngine*)e)->pending_queue_inadmissible(n, cq); }
 int kqe_pending_read_state(void* e, uint8_t* st, int32_t* counts) { return ((EmuEngine*)e)->pending_read_state(st, counts); }
 // Transcribed unit tests of the reference's requeue policy through the DEVICE code: the heads in flight get fabricated decisions

@@ -116,6 +116,10 @@ class EmuEngine:
     def pending_apply(self):
         self._ok(lib().kqe_pending_apply(self.h))
 
+    def pending_set_lq_usage(self, usage):
+        u = np.ascontiguousarray(usage, np.float64)
+        self._ok(lib().kqe_pending_set_lq_usage(self.h, C.c_int32(len(u)), F.ptr(u)))
+
     def pending_queue_inadmissible(self, cqs=None):
         if cqs is None:
             self._ok(lib().kqe_pending_queue_inadmissible(self.h, 0, None))

@@ -229,3 +229,97 @@ def test_pending_closed_loop_cfg3_full(oracle):
     pop = generate(3)
     cyc, dec, ndec, counts = closed_loop(oracle, Engine, pop, make_config(), max_cycles=160, hold=4, check_state_every=10)
     assert cyc == 160 and dec > 150_000 and ndec > 15_000, (cyc, dec, ndec)
+
+
+# ---- AdmissionFairSharing ordering (queueOrderingFunc cluster_queue.go:880-904) ---------------------------------------------------
+
+# TestFsAdmission (cluster_queue_test.go:1708-1878), transcribed by hand: (LocalQueue weights, AFS resource weights, consumed resources
+# per LocalQueue, workloads (name, LocalQueue, priority), the workload Pop must return). cpu in cores, as Quantity.AsApproximateFloat64.
+FS_ADMISSION = [
+    ("workloads are ordered by LQ usage, instead of priorities :1723", {"lqA": 1, "lqB": 1}, None, {"lqA": {"cpu": 2}, "lqB": {"cpu": 1}},
+     [("wlA-high", "lqA", 2), ("wlB-low", "lqB", 1)], "wlB-low"),
+    ("ordered by LQ usage with respect to resource weights :1749", {"lqA": 1, "lqB": 1}, {"cpu": 0, "gpu": 1},
+     {"lqA": {"cpu": 1, "gpu": 10}, "lqB": {"cpu": 1000, "gpu": 1}}, [("wlA-high", "lqA", 2), ("wlB-low", "lqB", 1)], "wlB-low"),
+    ("ordered by LQ usage with respect to LQs' fair sharing weights :1780", {"lqA": 1, "lqB": 2}, None, {"lqA": {"cpu": 10}, "lqB": {"cpu": 6}},
+     [("wlA-high", "lqA", 2), ("wlB-low", "lqB", 1)], "wlB-low"),
+    ("workloads with the same LQ usage are ordered by priority :1806", {"lqA": 1}, None, {"lqA": {"cpu": 10}},
+     [("wlA-low", "lqA", 1), ("wlA-high", "lqA", 2)], "wlA-high"),
+    ("workloads with NoFairSharing CQ are ordered by priority :1826", None, None, {}, [("wlA-low", "lqA", 1), ("wlA-high", "lqA", 2)], "wlA-high"),
+]
+
+
+@pytest.mark.parametrize("case", FS_ADMISSION, ids=[c[0] for c in FS_ADMISSION])
+def test_fs_admission_table(oracle, case):
+    """Oracle and device code (emulated) pop what the reference's TestFsAdmission expects; the usage numbers come from the host-side
+    twin of afs.CalculateUsage."""
+    from kueue_amd import afs
+    from tests.emu import kqe
+    name, lq_w, res_w, consumed, wls, want = case
+    snap, _, _ = _tiny({"strategy": "BestEffortFIFO", "workloads": [{"name": n, "prio": p} for n, _, p in wls]})
+    heads = Heads(snap, [Workload(n, "cq", priority=p, creation_ts=1, pod_sets=[PodSet("main", 1, requests={"cpu": 1000})], uid=n) for n, _, p in wls], cycle=0)
+    lqs = sorted(lq_w) if lq_w else []
+    lq_idx = np.array([lqs.index(l) if lq_w else -1 for _, l, _ in wls], np.int32)
+    pending = Pending(heads, uid_rank=np.arange(len(wls), dtype=np.uint32), lq=lq_idx if lq_w else None, n_lq=len(lqs))
+    usage = [afs.calculate_usage(consumed.get(l, {}), None, lq_w[l], res_w) for l in lqs]
+    cfg = make_config()
+    q = oracle.PendingOracle(cfg, snap, pending)
+    eng = kqe.EmuEngine(cfg)
+    try:
+        if lqs:
+            q.set_lq_usage(usage)
+        assert wls[q.pop(0)][0] == want
+        eng.put(snap); eng.pending_put(pending)
+        if lqs:
+            eng.pending_set_lq_usage(usage)
+        n, _, hw = eng.pending_heads(1)
+        assert n == 1 and wls[int(hw[0])][0] == want
+    finally:
+        q.close(); eng.close()
+
+
+def _afs_loop(oracle, eng_factory, n_cq, per, cycles, seed):
+    """Closed loop with AdmissionFairSharing ordering: every workload belongs to one of a few LocalQueues of its ClusterQueue, the
+    LocalQueues' usage changes every cycle (as the ledger's would), Heads() must follow it on both sides."""
+    rnd = np.random.default_rng(seed)
+    pop = generate(3, n_cq=n_cq, per_cq=per)
+    pend0 = pop.pending()
+    cqs = pend0.heads.arrays["cq"]
+    lq = (cqs * 3 + rnd.integers(0, 3, size=pend0.n)).astype(np.int32)
+    lq[cqs % 4 == 0] = -1                      # a quarter of the ClusterQueues have no AdmissionScope
+    n_lq = 3 * n_cq
+    pending = Pending(pend0.heads, uid_rank=pend0.uid_rank, lq=lq, n_lq=n_lq)
+    cfg = make_config()
+    snap = pop.snapshot
+    eng = eng_factory(cfg); q = oracle.PendingOracle(cfg, snap, pending)
+    try:
+        eng.put(snap); eng.pending_put(pending)
+        osnap = copy.copy(snap); osnap.arrays = dict(snap.arrays)
+        for cyc in range(1, cycles + 1):
+            usage = rnd.choice([0.0, 0.5, 1.0, 2.5, 2.5, np.inf, np.nan], size=n_lq) * rnd.choice([1.0, -1.0], size=n_lq, p=[0.9, 0.1])
+            eng.pending_set_lq_usage(usage); q.set_lq_usage(usage)
+            n, nps, hw = eng.pending_heads(cyc)
+            hb, ohw = q.heads(cyc)
+            assert np.array_equal(hw, ohw), cyc
+            if n == 0:
+                break
+            got = eng.run_pending(Decisions(hb, tgt_cap=4096))
+            want = oracle.cycle_run(cfg, osnap, hb)
+            assert not want.equal(got)
+            usage_plane, na, triples = oracle.cycle_commit(cfg, osnap, hb)
+            osnap.arrays["usage"] = usage_plane; osnap._struct = None
+            assert eng.try_commit() == 0
+            eng.pending_apply(); q.apply(hb, want)
+            assert np.array_equal(eng.pending_state()[0], q.state()), cyc
+    finally:
+        eng.close(); q.close()
+
+
+def test_afs_ordering_closed_loop_emulated(oracle):
+    from tests.emu import kqe
+    _afs_loop(oracle, kqe.EmuEngine, n_cq=24, per=8, cycles=10, seed=5)
+
+
+@pytest.mark.gpu
+def test_afs_ordering_closed_loop_gpu(oracle):
+    from kueue_amd.engine import Engine
+    _afs_loop(oracle, Engine, n_cq=200, per=30, cycles=12, seed=6)
