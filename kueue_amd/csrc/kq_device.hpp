@@ -54,6 +54,7 @@ KQ_DEV void atomic_add_i64(long long* p, long long v) { *p += v; }
 KQ_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 KQ_DEV int64_t atomic_cas_i64(int64_t* p, int64_t expect, int64_t v) { int64_t o = *p; if (o == expect) *p = v; return o; }
 KQ_DEV int64_t wsum_i64(int64_t v) { return v; }
+KQ_DEV int wbcast_u(int v, int) { return v; }
 KQ_DEV int64_t wprefix_incl_i64(int64_t v) { return v; }
 KQ_DEV int wprefix_incl_i32(int v) { return v; }
 KQ_DEV int64_t wshfl_i64(int64_t v, int) { return v; }
@@ -80,9 +81,26 @@ KQ_DEV double wbcast(double v, int src) { return __longlong_as_double(__shfl(__d
 KQ_DEV void wsync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 // all waves of the workgroup (phase boundaries of the multi-wave fair-sharing kernel)
 KQ_DEV void bsync() { __syncthreads(); }
+// Wave reductions on the DPP network (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: every lane of a 16-lane row ends up
+// with the row's result; the four rows are combined on the scalar unit). ~5x shorter than a __shfl_xor butterfly, whose every
+// step is a ds_bpermute round trip. All 64 lanes must be active (uniform control flow), as for the shuffles they replace.
+template <int CTRL> KQ_DEV uint64_t dpp_u64(uint64_t v) {
+  const int lo = __builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(v >> 32), (int)(v >> 32), CTRL, 0xf, 0xf, false);
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+KQ_DEV uint64_t readlane_u64(uint64_t v, int l) {
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
 KQ_DEV uint64_t wmin_u64(uint64_t v) {
-  for (int o = 32; o > 0; o >>= 1) { uint64_t t = (uint64_t)__shfl_xor((unsigned long long)v, o, 64); v = t < v ? t : v; }
-  return v;
+  uint64_t t;
+  t = dpp_u64<0xB1>(v); v = t < v ? t : v;
+  t = dpp_u64<0x4E>(v); v = t < v ? t : v;
+  t = dpp_u64<0x141>(v); v = t < v ? t : v;
+  t = dpp_u64<0x140>(v); v = t < v ? t : v;
+  const uint64_t r0 = readlane_u64(v, 0), r1 = readlane_u64(v, 16), r2 = readlane_u64(v, 32), r3 = readlane_u64(v, 48);
+  const uint64_t a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+  return a < b ? a : b;
 }
 // LDS-only visibility inside the single wave of a workgroup: the LDS pipeline is in order per wave, so only
 // the compiler must be kept from reordering / caching; no wait for outstanding global memory traffic.
@@ -96,10 +114,16 @@ KQ_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { atomicOr((unsigned long lon
 KQ_DEV int64_t atomic_cas_i64(int64_t* p, int64_t expect, int64_t v) {
   return (int64_t)atomicCAS((unsigned long long*)p, (unsigned long long)expect, (unsigned long long)v);
 }
-KQ_DEV int64_t wsum_i64(int64_t v) {
-  for (int o = 32; o > 0; o >>= 1) v += (int64_t)__shfl_xor((long long)v, o, 64);
-  return v;
+KQ_DEV int64_t wsum_i64(int64_t x) {
+  uint64_t v = (uint64_t)x;
+  v += dpp_u64<0xB1>(v);
+  v += dpp_u64<0x4E>(v);
+  v += dpp_u64<0x141>(v);
+  v += dpp_u64<0x140>(v);
+  return (int64_t)(readlane_u64(v, 0) + readlane_u64(v, 16) + readlane_u64(v, 32) + readlane_u64(v, 48));
 }
+// broadcast from a lane that is the same for the whole wave (no LDS crossbar round trip)
+KQ_DEV int wbcast_u(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
 // inclusive prefix sums over the lanes of the wave (Hillis-Steele on the cross-lane network)
 KQ_DEV int64_t wprefix_incl_i64(int64_t v) {
   const int lane = (int)(threadIdx.x & 63);
@@ -160,6 +184,15 @@ struct DSnap {
   const uint64_t* frb_sig;      // [n_tree * nfr]
   const uint8_t* cs_ok;         // [n_tree]
   const int32_t* tree_depth;    // [n_tree]
+  // LDS-resident fair-sharing victim search (kq_fs.hpp): candidates in position order and the tree's constants in tree-node order
+  const FsScan* fs_scan;        // [n_adm] (offsets = tree_row_off)
+  const FsApply* fs_apply;      // [n_adm]
+  const int32_t* fs_posoff;     // [nq + n_tree] per tree at tree_cq_off[t] + t
+  const uint8_t* fs_ok;         // [n_tree]
+  const int16_t *fs_kid, *fs_koff, *fs_knc, *fs_knh, *fs_c0, *fs_c1;  // [N] at tree_node_off[t] + local id
+  const int64_t *fs_lq, *fs_sqb;  // [N * nfr]
+  const int64_t* fs_lend;       // [N * nR]
+  const double* fs_weight;      // [N]
   const int8_t* cq_res_rg;      // [nq * nR] resource group of the ClusterQueue covering the resource (index inside the ClusterQueue's
                                 // groups, -1 = none): resourcegroups.RGByResource as one load instead of a walk of two CSR levels
 };
@@ -171,6 +204,7 @@ struct DCfg {
   int fs_plain;              // all amounts small: per-node borrowed sums are exact in plain int64 (no saturation)
   int quota_check_strategy;
   int cs_on;                 // classical victim searches may take the scan formulation (kq_cs.hpp)
+  int fs_on;                 // fair-sharing victim searches may take the LDS-resident formulation (kq_fs.hpp)
   int dbg_variant;           // KQ_PROF builds only: timing experiments (KQ_DEBUG_VARIANT; results are wrong when non-zero)
   int64_t cycle;
 };
@@ -267,7 +301,7 @@ struct K {  // everything a kernel needs
   int64_t* usage_np;         // process: usage_work minus every workload preempted so far this cycle
   uint8_t* preempted;        // [n_adm] PreemptedWorkloads membership (preempted_workloads.go:26)
   const int32_t* order_idx;  // [H] entry index at iterator position i
-  long long* prof;           // [32] optional segment cycle counters (KQ_PROF builds)
+  long long* prof;           // [64] optional segment cycle counters (KQ_PROF builds)
   int32_t* cq_rm_bytes;      // [nq] candidate-record bytes of the rows preempted so far this cycle (they left cq.Workloads)
   uint8_t* cq_dirty;         // [nq] a ClusterQueue-level usage cell of this CQ was written in HBM during this cycle's k_process
   struct PRec* grec;         // [H] per-head entry records, static part (rec_fill_static); k_process copies them into LDS
@@ -594,6 +628,7 @@ struct Wave {
   // scan-formulated classical search (kq_cs.hpp): LDS region for its arrays (null: use DScratch::cs) and the constants of the
   // preemptor's path per (slot, level): subtree quota, local quota, borrowing limit, usage at the start / at the stopping time
   unsigned char* cs_lds; int cs_lds_bytes;
+  int pc_region_bytes;            // process kernels: bytes of the workgroup's dynamic LDS a recomputation's searches may borrow
   int64_t cs_sq[CS_NS][CS_LEVELS + 1], cs_lq[CS_NS][CS_LEVELS + 1], cs_bl[CS_NS][CS_LEVELS + 1], cs_u0[CS_NS][CS_LEVELS + 1], cs_uf[CS_NS][CS_LEVELS + 1];
   int64_t cs_nom[CS_NS];
   int32_t cs_pl[CS_LEVELS + 1];   // tree-local ids of the path nodes
@@ -611,7 +646,11 @@ KQ_DEV bool np_exact_mode(const Wave& w) { return w.np_broken && w.n_pre > 0; }
 #if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
 #define KQ_T0() long long _t0 = clock64()
 #define KQ_TS(k, id) do { long long _t1 = clock64(); if (lane_id() == 0) atomic_add_i64((long long*)(k).prof + (id), _t1 - _t0); _t0 = _t1; } while (0)
+#define KQ_A0() long long _a0 = clock64()
+#define KQ_AS(k, id) do { long long _a1 = clock64(); if (lane_id() == 0) atomic_add_i64((long long*)(k).prof + (id), _a1 - _a0); } while (0)
 #else
+#define KQ_A0() do {} while (0)
+#define KQ_AS(k, id) do {} while (0)
 #define KQ_T0() do {} while (0)
 #define KQ_TS(k, id) do {} while (0)
 #endif
@@ -1157,6 +1196,7 @@ struct PG {  // a global plane
 // snapshot.RemoveWorkload / AddWorkload or plain Remove/AddUsage of the row's usage: one lane per usage entry
 KQ_DEV void f_apply_row(const Search& s, int row, bool add, bool count) {
   const DSnap& S = s.k->S;
+  KQ_A0();
   int c = S.adm_cq[row];
   const int32_t* cpath = S.path + (size_t)c * KQ_MAXD;
   int cplen = S.plen[c];
@@ -1174,6 +1214,7 @@ KQ_DEV void f_apply_row(const Search& s, int row, bool add, bool count) {
   }
   wsync();
   if (count && lane_id() == 0) s.w->bytes += 16 * (int64_t)cplen * (e1 - e0);
+  KQ_AS(*s.k, 49);
 }
 // cq.SimulateUsageAddition(workloadUsage) / its revert (preemption.go:557, :690-695)
 KQ_DEV void f_apply_preemptor(const Search& s, bool add) {
@@ -1198,9 +1239,11 @@ KQ_DEV bool f_fits(const Search& s) {
   return wballot(bad) == 0;
 }
 KQ_DEV bool f_fits_fs(const Search& s) {  // workloadFitsForFairSharing :690-695
+  KQ_A0();
   f_apply_preemptor(s, false);
   bool r = f_fits(s);
   f_apply_preemptor(s, true);
+  KQ_AS(*s.k, 50);
   return r;
 }
 KQ_DEV uint32_t f_row_key(const DSnap& S, int row) {
@@ -1233,6 +1276,7 @@ KQ_DEV void f_rescan(const Search& s, int i, uint8_t flag) {
 KQ_DEV int f_pop(const Search& s, int c, uint8_t flag, uint8_t newflag) {
   const DSnap& S = s.k->S;
   CSTAT(13, 1);
+  KQ_A0();
   int i = S.cq_local[c];
   int pos = (int)(s.qhead[i] & 0x7fffffffu);
   int row = S.tree_rows[s.row0 + pos];
@@ -1240,6 +1284,7 @@ KQ_DEV int f_pop(const Search& s, int c, uint8_t flag, uint8_t newflag) {
   if (lane_id() == 0) s.cls[pos] = newflag;
   wsync();
   f_rescan(s, i, flag);
+  KQ_AS(*s.k, 48);
   return row;
 }
 KQ_DEV DRSv f_drs(const Search& s, int node, int64_t* lb) {
@@ -1326,6 +1371,7 @@ KQ_DEV int f_next_target(const Search& s, int root) {
 // TargetClusterQueueOrdering.Iter (ordering.go:92-127) as a "next" call
 KQ_DEV int f_ordering_next(const Search& s) {
   const DSnap& S = s.k->S; const Wave& w = *s.w;
+  KQ_A0();
   if (w.plen <= 1) {
     int i = S.cq_local[w.cq];
     if (!s.cqinfo[i] && s.qcnt[i] > 0) return w.cq;
@@ -1334,8 +1380,9 @@ KQ_DEV int f_ordering_next(const Search& s) {
   int root = w.path[w.plen - 1];
   while (!s.cohp[S.node_local[root]]) {
     int t = f_next_target(s, root);
-    if (t >= 0) return t;
+    if (t >= 0) { KQ_AS(*s.k, 47); return t; }
   }
+  KQ_AS(*s.k, 47);
   return -1;
 }
 // getAlmostLCAs (least_common_ancestor.go:27-58): nodes just below the LCA on the preemptor's and the target's path
@@ -1357,9 +1404,42 @@ KQ_DEV bool f_push_target(Search& s, int* nt, int row, int reason) {
   wsync();
   return true;
 }
+}  // namespace kq
+#include "kq_fs.hpp"
+namespace kq {
+#ifdef KQ_HOST_EMU
+static int g_fs_check = 0, g_fs_force_off = 0;  // tests: run every LDS-formulated fair search a second time as the walk and compare
+#endif
+KQ_DEV void fair_search_walk(Search& s);
 // fairPreemptions (preemption.go:536-597). On return w->ntgt targets are in s.trow/s.treason and the private
-// state has exactly those removed.
+// state has exactly those removed (where callers read it: the preemptor's path).
 KQ_DEV void fair_search(Search& s) {
+#ifdef KQ_HOST_EMU
+  if (g_fs_force_off) { fair_search_walk(s); return; }
+  Wave& w = *s.w;
+  const int64_t bytes_entry = w.bytes;
+  if (!fair_search_lds(s)) { fair_search_walk(s); return; }
+  CSTAT(23, 1);
+  if (g_fs_check) {
+    const DSnap& S = s.k->S;
+    const int nt1 = w.ntgt;
+    const int64_t b1 = w.bytes;
+    std::vector<int32_t> tr(s.trow, s.trow + nt1);
+    std::vector<uint8_t> rs(s.treason, s.treason + nt1);
+    std::vector<int64_t> pw;
+    for (int l = 0; l < w.plen; l++) for (int u = 0; u < w.ns; u++) pw.push_back(s.W[(size_t)S.node_local[w.path[l]] * S.nfr + w.s_fr[u]]);
+    w.bytes = bytes_entry;
+    fair_search_walk(s);
+    bool same = nt1 == w.ntgt && b1 == w.bytes;
+    for (int t = 0; same && t < nt1; t++) if (tr[t] != s.trow[t] || rs[t] != s.treason[t]) same = false;
+    if (same && nt1 > 0) { int q = 0; for (int l = 0; l < w.plen; l++) for (int u = 0; u < w.ns; u++) { const int64_t v = s.W[(size_t)S.node_local[w.path[l]] * S.nfr + w.s_fr[u]]; if (w.s_inu[u] && pw[q] != v) same = false; q++; } }
+    if (!same) { CSTAT(24, 1); fprintf(stderr, "FS MISMATCH head %d: lds %d targets %lld bytes, walk %d targets %lld bytes\n", w.h, nt1, (long long)(b1 - bytes_entry), w.ntgt, (long long)(w.bytes - bytes_entry)); }
+  }
+#else
+  if (!fair_search_lds(s)) fair_search_walk(s);
+#endif
+}
+KQ_DEV void fair_search_walk(Search& s) {
   const K& k = *s.k; Wave& w = *s.w; const DSnap& S = k.S;
   const int lane = lane_id();
   w.ntgt = 0;
@@ -1373,7 +1453,9 @@ KQ_DEV void fair_search(Search& s) {
   const int n0 = S.tree_node_off[s.tree], nn = S.tree_node_off[s.tree + 1] - n0;
   const int q0 = S.tree_cq_off[s.tree], nqs = S.tree_cq_off[s.tree + 1] - q0;
   const int nfr = S.nfr;
+  KQ_T0();
   for (int i = lane; i < nn * nfr; i += WAVE) s.W[i] = s.usage[ix(S, S.tree_nodes[n0 + i / nfr], i % nfr)];
+  KQ_TS(k, 40);  // fair search: private copy of the plane
   if (s.psum) {
     if (s.usage == k.usage) {  // cycle-start plane: k_fs_sums already reduced it
       for (int i = lane; i < nn * S.nR; i += WAVE) s.psum[i] = k.X.bu_sum[(size_t)S.tree_nodes[n0 + i / S.nR] * S.nR + i % S.nR];
@@ -1390,6 +1472,7 @@ KQ_DEV void fair_search(Search& s) {
   for (int i = lane; i < s.nrows; i += WAVE) s.cls[i] = 0;
   for (int i = lane; i < nn; i += WAVE) s.cohp[i] = 0;
   wsync();
+  KQ_TS(k, 41);  // fair search: borrowed sums + clears
   // findCandidates (:633-667): one lane per CQ of the tree
   int ncand = 0;
   {
@@ -1428,6 +1511,7 @@ KQ_DEV void fair_search(Search& s) {
   }
   wsync();
   CSTAT(14, 1); CSTAT(15, ncand);
+  KQ_TS(k, 42);  // fair search: findCandidates
   if (ncand == 0) return;
   f_apply_preemptor(s, true);  // SimulateUsageAddition :557
   int nt = 0;
@@ -1476,6 +1560,7 @@ KQ_DEV void fair_search(Search& s) {
       }
     }
   }
+  KQ_TS(k, 43);  // fair search: first strategy
   // ---- runSecondFsStrategy :501-534 ----
   if (!fits && have_second) {
     for (int i = lane; i < nn; i += WAVE) s.cohp[i] = 0;
@@ -1506,12 +1591,14 @@ KQ_DEV void fair_search(Search& s) {
     }
   }
   f_apply_preemptor(s, false);  // revertSimulation
+  KQ_TS(k, 44);  // fair search: second strategy
   if (!fits) {
     if (lane == 0)
       for (int t = 0; t < nt; t++) { int r = s.trow[t]; w.bytes += 16 * (int64_t)S.plen[S.adm_cq[r]] * (S.adm_use_off[r + 1] - S.adm_use_off[r]); }
     // restoreSnapshot :356 — the private copy is dropped, but callers read it: put the rows back
     for (int t = 0; t < nt; t++) f_apply_row(s, s.trow[t], true, false);
     w.ntgt = 0;
+    KQ_TS(k, 45);  // fair search: restore after a failed search
     return;
   }
   CSTAT(16, 1); CSTAT(17, nt);
@@ -1530,6 +1617,7 @@ KQ_DEV void fair_search(Search& s) {
   w.ntgt = nt;
   if (lane == 0)
     for (int t = 0; t < nt; t++) { int r = s.trow[t]; w.bytes += 16 * (int64_t)S.plen[S.adm_cq[r]] * (S.adm_use_off[r + 1] - S.adm_use_off[r]); }
+  KQ_TS(k, 46);  // fair search: fillBackWorkloads
 }
 
 // LDS bytes the small state of one FAIR victim search wants: the per-node borrowed sums the DRS is computed from (psum, ppos: every
@@ -2402,6 +2490,7 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
   auto has_any = [&]() { bool a = false; for (int t = 0; t < nt; t++) if (k.preempted[trows[t]]) a = true; return a; };
   // updateAssignmentIfNeeded :707-769
   bool fits_ok = entry_fits(k, w, trows, nt, quota_usage, tree);
+  KQ_TS(k, 34);  // generic path: first fits
   int mode = w.rep_mode;
   if (has_any() && gate(k, KQ_GATE_RECOMPUTE_ON_OVERLAP)) {
     // SimulateWorkloadRemoval(victimsOfOtherPreemptions) == evaluate on usage_np with those rows deleted.
@@ -2415,8 +2504,8 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
     for (int i = lane; i < w.nps * S.nR; i += WAVE) k.X.nom[(size_t)slot * KQ_MAXPS * S.nR + i] = O.flavor[(size_t)w.ps_base * S.nR + i];
     wsync();
     // the flushed rows are not read until the recomputation is over: their LDS serves the victim searches meanwhile (kq_cs.hpp)
-    const bool lend = w.pc_on != 0;  // classical: the scan search's arrays; fair sharing: the search's small state (make_search)
-    if (lend && lane == 0) { w.cs_lds = (unsigned char*)w.pc_lds; w.cs_lds_bytes = (int)((size_t)w.pc_ncoh * S.nfr * 16); }
+    const bool lend = w.pc_region_bytes > 0;  // classical: the scan search's arrays (kq_cs.hpp); fair sharing: the search's state (kq_fs.hpp)
+    if (lend && lane == 0) { w.cs_lds = (unsigned char*)w.pc_lds; w.cs_lds_bytes = w.pc_region_bytes; }
     wsync();
     Search s = get_assignments(k, w, slot, k.usage_np, k.preempted, true);
     publish_assignment(k, w, s, e);
@@ -2435,6 +2524,7 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
     }
     wsync();
     fits_ok = entry_fits(k, w, trows, nt, quota_usage, tree);
+    KQ_TS(k, 32);  // fits after the recomputation
   }
   int status = KQ_ST_NOT_NOMINATED, action = KQ_ACT_NONE, rq = KQ_RQ_GENERIC, skip = KQ_SKIP_NONE;
   bool done = false;
@@ -2485,6 +2575,7 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
   write_entry_result(k, w, e, status, action, rq, skip, mode);
   if (lane == 0) atomic_add_i64(O.stat_bytes, (long long)w.bytes);
   wsync();
+  KQ_TS(k, 33);  // generic path: everything after the (optional) recomputation
 }
 
 // ---- chunked fast path --------------------------------------------------------------------------
@@ -3016,6 +3107,7 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
     w.pc_ncoh = (S.tree_node_off[tree + 1] - S.tree_node_off[tree]) - w.pc_ncq;
     w.pc_lds = lds;
     w.pc_on = (w.pc_ncoh > 0 && lds_bytes >= rec_bytes && (size_t)w.pc_ncoh * S.nfr * 16 <= lds_bytes - rec_bytes) ? 1 : 0;
+    w.pc_region_bytes = w.pc_on ? (int)((size_t)w.pc_ncoh * S.nfr * 16) : 0;
     w.np_broken = 0; w.n_pre = 0; w.broken[0] = w.broken[1] = w.broken[2] = w.broken[3] = 0;
     w.nwin2[0] = w.nwin2[1] = 0; w.chunk_done = 0; w.chunk_stop = 0; w.mono_break = 0;
   }
@@ -3347,6 +3439,7 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
     w.pc_ncoh = nn - nqs;
     w.pc_lds = lds;
     w.pc_on = (w.pc_ncoh > 0 && have_rec && (size_t)w.pc_ncoh * S.nfr * 16 <= lds_bytes - sizeof(PRec)) ? 1 : 0;
+    w.pc_region_bytes = have_rec ? (int)(lds_bytes - sizeof(PRec)) : 0;  // the rows (if resident) are flushed before a recomputation borrows the region
     *sum = 0; ctl[0] = 0; ctl[1] = -1; ctl[2] = 0;
     w.np_broken = 0; w.n_pre = 0; w.broken[0] = w.broken[1] = w.broken[2] = w.broken[3] = 0; w.n_pre = 0; w.broken[0] = w.broken[1] = w.broken[2] = w.broken[3] = 0;
   }

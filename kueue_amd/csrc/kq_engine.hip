@@ -287,6 +287,7 @@ struct HipBackend {
   }
   const char* error() { return msg.c_str(); }
   int max_slots() { return n_cu * 16; }  // 16 one-wave workgroups per CU (4 per SIMD)
+  size_t lds_budget() { return 160 * 1024 - sizeof(Wave) - 256; }  // dynamic LDS a workgroup can get next to its static Wave
   // HIP events on the engine's own stream bracket each kernel (live per-kernel duration)
   void timer_mark(int i) { chk(hipEventRecord(ev[i], stream), "hipEventRecord"); }
   double timer_ms(int a, int b) { float ms = 0; chk(hipEventElapsedTime(&ms, ev[a], ev[b]), "hipEventElapsedTime"); return ms; }
@@ -431,9 +432,12 @@ struct HipBackend {
     chk(hipGetLastError(), "k_process");
   }
   size_t lds_attr = 0, lds_attr_fair = 0;
-  void launch_process_fair(const K& k, int n_tree, size_t cohort_rows_bytes, int32_t* rank) {
+  void launch_process_fair(const K& k, int n_tree, size_t cohort_rows_bytes, size_t search_bytes, int32_t* rank) {
+    // [cohort rows of both planes, if they fit | the state of a recomputation's victim search (kq_fs.hpp), which borrows the region][one record]
     const size_t budget = 160 * 1024 - sizeof(Wave) - 256;
-    size_t lds = sizeof(PRec) + (cohort_rows_bytes + sizeof(PRec) <= budget ? cohort_rows_bytes : 0);
+    size_t region = cohort_rows_bytes + sizeof(PRec) <= budget ? cohort_rows_bytes : 0;
+    region = std::max(region, std::min(search_bytes, budget - sizeof(PRec)));
+    size_t lds = sizeof(PRec) + region;
     if (lds > 48 * 1024 && lds != lds_attr_fair) {
       chk(hipFuncSetAttribute((const void*)k_process_fair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
       lds_attr_fair = lds;
@@ -648,9 +652,9 @@ int kq_tas_read_usage(kq_tas* t, int64_t* u) { if (!t || !u) return KQ_EINVAL; (
 int kq_tas_last_stats(kq_tas* t, double* ms, int64_t* bytes) { if (!t) return KQ_EINVAL; if (ms) *ms = t->e.last_ms; if (bytes) *bytes = t->e.last_bytes; return KQ_OK; }
 const char* kq_tas_last_error(kq_tas* t) { return t ? t->e.last_error.c_str() : "null engine"; }
 
-// profiling hook (KQ_PROF builds): 32 segment cycle counters accumulated since the last reset
+// profiling hook (KQ_PROF builds): 64 segment cycle counters accumulated since the last reset
 // tests: take the saturation-safe DRS loops even when the incremental sums would be exact
-int kq_debug_disable_scan_search(kq_engine* en, int on) { if (!en) return KQ_EINVAL; en->e.cs_disable = on != 0; return KQ_OK; }
+int kq_debug_disable_scan_search(kq_engine* en, int on) { if (!en) return KQ_EINVAL; en->e.cs_disable = on != 0; en->e.fs_disable = on != 0; return KQ_OK; }
 int kq_debug_force_exact_drs(kq_engine* en, int on) { if (!en) return KQ_EINVAL; en->e.force_exact_drs = on != 0; return KQ_OK; }
 int kq_debug_prof(kq_engine* en, int64_t* out, int reset) {
   if (!en) return KQ_EINVAL;

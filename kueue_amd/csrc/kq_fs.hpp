@@ -1,0 +1,811 @@
+// kq_fs.hpp — the fair-sharing victim search (preemption.go:381-631) with its whole working state in the workgroup's LDS.
+//
+// fair_search (kq_device.hpp) keeps a private copy of the tree's usage plane in HBM scratch and walks it with one dependent
+// global access after the other: at cfg 4f (one tree of 1111 nodes, 40 000 admitted rows, ~2400 pops per search) a pop costs
+// ~50 000 cycles, 60 % of it in snapshot.RemoveWorkload / AddWorkload chains (profiles/r02k_prof_fair_1000.txt). Here:
+//
+//  * DRS only reads the per-node borrowed sums (psum[node][resource], count of borrowed cells): they live in LDS together with
+//    the CACHED share of every node (dval: the quantity CompareDRS orders by), refreshed for the <= 4 nodes of a row's path
+//    after every usage change. A tournament level of nextTarget (ordering.go:144-226) is then one LDS read per child and a
+//    wave arg-max instead of nR fp64 divisions per child and a serial fold.
+//  * Candidate queues are bitmaps over a static "position order" (kq_prep.hpp FsScan/FsApply: candidates grouped by
+//    ClusterQueue, inside a ClusterQueue in pop order): class 1 = candidates, class 2 = retryCandidates. PopWorkload is a
+//    find-first-set, findCandidates a ballot per 64 positions; nothing is rescanned.
+//  * Usage cells: the columns (flavor-resources) of the flavors the preemptor needs are cached in LDS for all nodes — with
+//    one flavor per admitted workload those are the only cells a search writes. Other columns fall back to the private HBM
+//    plane, copied lazily the first time a row touches one.
+//  * A row's Remove/AddWorkload gathers every constant it needs (localQuota / SubtreeQuota of the <= 4 flavor-resources x
+//    <= 4 path levels, lendable and weight of the path nodes) in ONE round of independent loads from tables in tree-node
+//    order; the chain of removeUsage / addUsage (resource_node.go:144-165) then runs on registers and LDS.
+//
+// Same sequence of operations as fair_search, hence the same targets, the same private state where callers read it, and the
+// same algorithmic byte count (an "evaluation" of a cached share is charged what computing it costs the reference). Trees or
+// searches outside the preconditions (deeper than FS_LV levels, rows with more than CS_RFR flavor-resources, non-plain
+// amounts, more than FS_PCN preemptor cells) return false and fair_search runs. Bit-exact: tests run both and compare.
+#pragma once
+
+namespace kq {
+
+constexpr int FS_PCN = 64;      // (in-use slot, level) cells of the preemptor's context
+constexpr int FS_NCMAX = 16;    // usage columns cached per search
+constexpr int FS_RC = CS_RFR * FS_LV;
+
+struct Fs {
+  const K* k; Wave* w; Search* s;
+  int nn, nqs, ncoh, nR, nfr, n0, q0, row0, nrows, mw, nc, npc, wli, plen;
+  bool wcopied;
+  // state
+  int64_t* psum; double* dval; int32_t* ppos; uint8_t* nflag; uint64_t *m1, *m2, *mq; int8_t* colslot; int64_t** colp;
+  // static tables of the tree
+  int32_t* posoff; int16_t *kid, *koff, *knc, *knh, *c0, *c1;
+  // context of the row being applied / of the preemptor
+  int64_t **rc_ptr, *rc_lq, *rc_sqb, *rc_lend; double* rc_wt;
+  int64_t* td; int32_t* tp; double* tx; uint64_t* tout;   // staging of one row operation: borrowed-amount deltas / borrowed-cell count deltas per (flavor-resource, level), share terms per (level, resource), result
+  int64_t **pc_ptr, *pc_lq, *pc_sq, *pc_sqb, *pc_bl, *pc_lend; double* pc_wt; int32_t* pc_u;
+  int32_t* tpos;
+};
+struct FsRow { int64_t qty[CS_RFR]; int fr[CS_RFR]; int lp[FS_LV]; int plen, row, cbytes, rowbytes; uint32_t hkey; };
+
+#ifdef KQ_HOST_EMU
+static inline
+#else
+__host__ __device__ inline
+#endif
+size_t fs_bytes(int nn, int nqs, int nR, int nfr, int mw, int ncols) {
+  auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
+  const int ncoh = nn - nqs;
+  size_t b = 0;
+  b += al(FS_RC * 8) * 3 + al(FS_LV * KQ_MAXR * 8) + al(FS_LV * 8);                               // row context
+  b += al(FS_RC * 8) + al(FS_RC * 4) + al(FS_LV * KQ_MAXR * 8) + al(4 * 8);                        // staging of a row operation
+  b += al(FS_PCN * 8) * 5 + al(FS_PCN * 4) + al(FS_LV * KQ_MAXR * 8) + al(FS_LV * 8);              // preemptor context
+  b += al(FS_NCMAX * 8);                                                                            // column pointers
+  b += al(nn) + al((size_t)nn * 8) + al((size_t)nn * 4) + al((size_t)nn * 2) * 3;                  // nflag dval ppos c0 c1 kid
+  b += al((size_t)(ncoh > 0 ? ncoh : 1) * 2) * 3 + al((size_t)(nqs + 1) * 4) + al(nfr);            // koff knc knh posoff colslot
+  b += al((size_t)nn * nR * 8) + al((size_t)mw * 8) * 2;                                           // psum m1 m2
+  b += al((size_t)nn * 8) * (size_t)ncols;
+  return b + 256;
+}
+
+KQ_DEV uint64_t fs_bits(double v) { union { double d; uint64_t u; } x; x.d = v; return x.u; }
+// total order of Go's cmp.Compare on float64 (NaN lowest, -0 == +0) as an unsigned key
+KQ_DEV uint64_t fs_okey(double v) {
+  if (v != v) return 0;
+  if (v == 0) v = 0.0;
+  const uint64_t u = fs_bits(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+// CompareDRS (fair_sharing.go:112-123) on (zero-weight-borrows, key of ratio / PreciseWeightedShare)
+KQ_DEV int fs_cmp(int za, uint64_t ka, int zb, uint64_t kb) {
+  if (za != zb) return za ? 1 : -1;
+  return ka < kb ? -1 : (ka > kb ? 1 : 0);
+}
+KQ_DEV uint64_t wmax_u64(uint64_t v) { return ~wmin_u64(~v); }
+template <class T> KQ_DEV T fs_sel4(const T* a, int i) { T v = a[0]; if (i == 1) v = a[1]; if (i == 2) v = a[2]; if (i == 3) v = a[3]; return v; }
+
+// first set position of bitmap m inside [a, b), -1 if none
+KQ_DEV int fs_first(const uint64_t* m, int a, int b) {
+  if (a >= b) return -1;
+  const int wa = a >> 6, wb = (b - 1) >> 6;
+  for (int wi = wa; wi <= wb; wi++) {
+    uint64_t x = m[wi];
+    if (wi == wa) x &= ~0ull << (a & 63);
+    if (wi == wb) { const int e = (b - 1) & 63; if (e < 63) x &= (2ull << e) - 1; }
+    if (x) return wi * 64 + ffs64(x);
+  }
+  return -1;
+}
+// nflag: 1 pruned (prunedClusterQueues / prunedCohorts), 2 zero weight but borrowing, 4 the ClusterQueue contributes candidates,
+//        8 the ClusterQueue's queue of the class under iteration is not empty
+KQ_DEV bool fs_cq_has(const Fs& f, int li) { return (f.nflag[li] & 8) != 0; }
+KQ_DEV void fs_has_update(const Fs& f, int li) {  // one lane
+  const bool has = fs_first(f.mq, f.posoff[li], f.posoff[li + 1]) >= 0;
+  f.nflag[li] = (uint8_t)((f.nflag[li] & ~8) | (has ? 8 : 0));
+}
+
+KQ_DEV int64_t* fs_cellp(const Fs& f, int li, int fr) {
+  const int sl = f.colslot[fr];
+  return sl >= 0 ? f.colp[sl] + li : f.s->W + (size_t)li * f.nfr + fr;
+}
+// the private HBM plane serves the columns that are not cached: copied from the search's starting state on first use
+KQ_DEV void fs_ensure_w(Fs& f) {
+  if (f.wcopied) return;
+  const DSnap& S = f.k->S;
+  for (int i = lane_id(); i < f.nn * f.nfr; i += WAVE) f.s->W[i] = f.s->usage[ix(S, S.tree_nodes[f.n0 + i / f.nfr], i % f.nfr)];
+  wsync();
+  f.wcopied = true;
+}
+
+// cached share of node li from its borrowed sums: dominantResourceShare :149-182 + PreciseWeightedShare :92
+KQ_DEV void fs_refresh(const Fs& f, int li, const int64_t* lend, double weight) {
+  double ratio = 0;
+  for (int r = 0; r < f.nR; r++) {
+    const int64_t sum = f.psum[(size_t)li * f.nR + r];
+    if (sum <= 0) continue;
+    const int64_t lr = lend[r];
+    if (lr > 0) { const double x = (double)sum * 1000.0 / (double)lr; if (x > ratio) ratio = x; }
+  }
+  const bool zwb = weight == 0 && ratio != 0;
+  double v = ratio;
+  if (!zwb) v = ratio == 0 ? 0.0 : (weight == 0 ? __builtin_inf() : ratio / weight);
+  f.dval[li] = v;
+  f.nflag[li] = (uint8_t)((f.nflag[li] & ~2) | (zwb ? 2 : 0));
+}
+KQ_DEV int64_t fs_cost(const Fs& f, int li) { return (int64_t)f.c0[li] + (f.ppos[li] > 0 ? (int64_t)f.c1[li] : 0); }
+KQ_DEV bool fs_pos_inf(const Fs& f, int li) { return (f.nflag[li] & 2) || f.dval[li] == __builtin_inf(); }
+
+// ---- the row under Remove/AddWorkload ---------------------------------------------------------------------------------------
+KQ_DEV FsRow fs_row_load(const Fs& f, int p) {
+  const DSnap& S = f.k->S;
+  const FsScan sc = S.fs_scan[(size_t)f.row0 + p];
+  const FsApply ap = S.fs_apply[(size_t)f.row0 + p];
+  FsRow r;
+  #pragma unroll
+  for (int e = 0; e < CS_RFR; e++) { r.qty[e] = ap.qty[e]; r.fr[e] = sc.fr[e]; }
+  #pragma unroll
+  for (int l = 0; l < FS_LV; l++) r.lp[l] = ap.lp[l];
+  r.plen = ap.plen; r.row = sc.row; r.cbytes = sc.cbytes; r.hkey = ap.hkey;
+  r.rowbytes = 16 * ap.plen * ((sc.cbytes - 32) / 12);
+  return r;
+}
+// constants of every (flavor-resource, level) cell of the row and of its path nodes: one round of independent loads
+KQ_DEV void fs_row_ctx(Fs& f, const FsRow& r) {
+  const DSnap& S = f.k->S;
+  bool miss = false;
+  #pragma unroll
+  for (int e = 0; e < CS_RFR; e++) if (r.fr[e] >= 0 && f.colslot[r.fr[e]] < 0) miss = true;
+  if (miss) fs_ensure_w(f);
+  for (int c = lane_id(); c < FS_RC; c += WAVE) {
+    const int u = c / FS_LV, i = c % FS_LV;
+    const int fr = fs_sel4(r.fr, u), li = fs_sel4(r.lp, i);
+    if (fr < 0 || i >= r.plen) continue;
+    const size_t o = (size_t)(f.n0 + li) * f.nfr + fr;
+    f.rc_lq[c] = S.fs_lq[o]; f.rc_sqb[c] = S.fs_sqb[o];
+    f.rc_ptr[c] = fs_cellp(f, li, fr);
+  }
+  for (int j = lane_id(); j < r.plen * f.nR; j += WAVE) {
+    const int i = j / f.nR, rr = j % f.nR;
+    f.rc_lend[i * KQ_MAXR + rr] = S.fs_lend[(size_t)(f.n0 + fs_sel4(r.lp, i)) * f.nR + rr];
+  }
+  for (int i = lane_id(); i < r.plen; i += WAVE) f.rc_wt[i] = S.fs_weight[f.n0 + fs_sel4(r.lp, i)];
+  wsync();
+}
+// one usage chain on gathered cells: removeUsage (resource_node.go:156-165) / addUsage (:144-152) of `val` along `plen` levels.
+// Outputs per level: the new value, what the node's borrowed amount (max(0, usage - SubtreeQuota)) and its count of borrowed
+// cells change by. `write`: store the new values.
+struct FsChainOut { int64_t d[FS_LV]; int dp[FS_LV]; };
+KQ_DEV FsChainOut fs_chain(int64_t** ptr, const int64_t* lq, const int64_t* sqb, int plen, int64_t val, bool add, bool write) {
+  int64_t v[FS_LV], nv[FS_LV];
+  bool t[FS_LV];
+  #pragma unroll
+  for (int i = 0; i < FS_LV; i++) { v[i] = 0; nv[i] = 0; t[i] = false; if (i < plen) v[i] = *ptr[i]; }
+  bool go = true;
+  #pragma unroll
+  for (int i = 0; i < FS_LV; i++) {
+    if (!go || i >= plen) continue;
+    const int64_t uu = v[i];
+    t[i] = true;
+    if (add) {
+      const int64_t la = i64max(0, a_sub(lq[i], uu));
+      nv[i] = a_add(uu, val);
+      if (i + 1 < plen && val > la) val = a_sub(val, la); else go = false;
+    } else {
+      const int64_t stored = a_sub(uu, lq[i]);
+      nv[i] = a_sub(uu, val);
+      if (stored <= 0 || i + 1 >= plen) go = false; else val = i64min(val, stored);
+    }
+  }
+  FsChainOut o;
+  #pragma unroll
+  for (int i = 0; i < FS_LV; i++) {
+    o.d[i] = 0; o.dp[i] = 0;
+    if (!t[i]) continue;
+    const int64_t ob = i64max(0, a_sub(v[i], sqb[i])), nb = i64max(0, a_sub(nv[i], sqb[i]));
+    o.d[i] = nb - ob;
+    o.dp[i] = (nb > 0 ? 1 : 0) - (ob > 0 ? 1 : 0);
+    if (write) *ptr[i] = nv[i];
+  }
+  return o;
+}
+// The borrowed sums / cached shares of `plen` path nodes after the per-chain deltas staged in f.td / f.tp (nch chains, chain u
+// belongs to resource res(u)): one lane per (level, resource) adds the deltas and evaluates the share term, one lane per level
+// folds the terms (dominantResourceShare :149-182). commit = false: nothing is stored, only the share of node `at` is returned
+// (ComputeTargetShareAfterRemoval target.go:67-73 without touching the state). Returns z | borrowing << 1 of `at`, *key = its key.
+template <class RES>
+KQ_DEV int fs_nodes_update(const Fs& f, const int* lp, int plen, const int64_t* lend, const double* wt, int nch, const RES& res, bool commit, int at, uint64_t* key) {
+  const int lane = lane_id();
+  for (int j = lane; j < plen * f.nR; j += WAVE) {
+    const int i = j / f.nR, rr = j % f.nR, li = fs_sel4(lp, i);
+    int64_t d = 0;
+    for (int u = 0; u < nch; u++) if (res(u) == rr) d += f.td[u * FS_LV + i];
+    const int64_t sum = f.psum[(size_t)li * f.nR + rr] + d;
+    if (commit && d != 0) f.psum[(size_t)li * f.nR + rr] = sum;
+    double x = 0;
+    if (sum > 0) { const int64_t lr = lend[i * KQ_MAXR + rr]; if (lr > 0) x = (double)sum * 1000.0 / (double)lr; }
+    f.tx[i * KQ_MAXR + rr] = x;
+  }
+  wsync_lds();
+  for (int i = lane; i < plen; i += WAVE) {
+    const int li = fs_sel4(lp, i);
+    int dp = 0;
+    for (int u = 0; u < nch; u++) dp += f.tp[u * FS_LV + i];
+    const int np = f.ppos[li] + dp;
+    double ratio = 0;
+    for (int r = 0; r < f.nR; r++) { const double x = f.tx[i * KQ_MAXR + r]; if (x > ratio) ratio = x; }
+    const double weight = wt[i];
+    const bool zwb = weight == 0 && ratio != 0;
+    double v = ratio;
+    if (!zwb) v = ratio == 0 ? 0.0 : (weight == 0 ? __builtin_inf() : ratio / weight);
+    if (commit) {
+      if (dp) f.ppos[li] = np;
+      f.dval[li] = v;
+      f.nflag[li] = (uint8_t)((f.nflag[li] & ~2) | (zwb ? 2 : 0));
+    }
+    if (li == at) { f.tout[0] = fs_okey(v); f.tout[1] = (uint64_t)((zwb ? 1 : 0) | (np > 0 ? 2 : 0)); }
+  }
+  wsync_lds();
+  if (at >= 0) { *key = f.tout[0]; return (int)f.tout[1]; }
+  return 0;
+}
+struct FsRowRes { const FsRow* r; int nR; KQ_MDEV int operator()(int u) const { const int fr = fs_sel4(r->fr, u); return fr < 0 ? -1 : fr % nR; } };
+// snapshot.RemoveWorkload / AddWorkload of the row whose context is loaded. commit = false evaluates the share of node `at`
+// after the operation without changing anything.
+KQ_DEV int fs_row_apply(const Fs& f, const FsRow& r, bool add, bool commit, bool count, int at = -1, uint64_t* key = nullptr) {
+  for (int u = lane_id(); u < CS_RFR; u += WAVE) {
+    const int fr = fs_sel4(r.fr, u);
+    FsChainOut o;
+    #pragma unroll
+    for (int i = 0; i < FS_LV; i++) { o.d[i] = 0; o.dp[i] = 0; }
+    if (fr >= 0) o = fs_chain(f.rc_ptr + u * FS_LV, f.rc_lq + u * FS_LV, f.rc_sqb + u * FS_LV, r.plen, fs_sel4(r.qty, u), add, commit);
+    #pragma unroll
+    for (int i = 0; i < FS_LV; i++) { f.td[u * FS_LV + i] = o.d[i]; f.tp[u * FS_LV + i] = o.dp[i]; }
+  }
+  wsync();
+  const int z = fs_nodes_update(f, r.lp, r.plen, f.rc_lend, f.rc_wt, CS_RFR, FsRowRes{&r, f.nR}, commit, at, key);
+  if (count && lane_id() == 0) f.w->bytes += r.rowbytes;
+  return z;
+}
+
+// ---- the preemptor ----------------------------------------------------------------------------------------------------------
+KQ_DEV void fs_pc_setup(Fs& f) {
+  const K& k = *f.k; Wave& w = *f.w; const DSnap& S = k.S;
+  if (lane_id() == 0) { int n = 0; for (int u = 0; u < w.ns; u++) if (w.s_inu[u]) f.pc_u[n++] = u; }
+  wsync();
+  bool miss = false;
+  for (int j = 0; j < f.npc; j++) if (f.colslot[w.s_fr[f.pc_u[j]]] < 0) miss = true;
+  if (miss) fs_ensure_w(f);
+  for (int c = lane_id(); c < f.npc * FS_LV; c += WAVE) {
+    const int j = c / FS_LV, i = c % FS_LV;
+    if (i >= f.plen) continue;
+    const int fr = w.s_fr[f.pc_u[j]], n = w.path[i], li = w.cs_pl[i];
+    const size_t o = ix(S, n, fr);
+    f.pc_lq[c] = local_quota(S, n, fr); f.pc_sq[c] = S.sq[o]; f.pc_bl[c] = S.bl[o];
+    f.pc_sqb[c] = (S.qflags[o] & KQ_QF_SUBTREE) ? S.sq[o] : INT64_MAX;
+    f.pc_ptr[c] = fs_cellp(f, li, fr);
+  }
+  for (int j = lane_id(); j < f.plen * f.nR; j += WAVE) f.pc_lend[(j / f.nR) * KQ_MAXR + j % f.nR] = S.fs_lend[(size_t)(f.n0 + w.cs_pl[j / f.nR]) * f.nR + j % f.nR];
+  for (int i = lane_id(); i < f.plen; i += WAVE) f.pc_wt[i] = S.fs_weight[f.n0 + w.cs_pl[i]];
+  wsync();
+}
+// cq.SimulateUsageAddition(workloadUsage) / its revert (preemption.go:557, :690-695)
+struct FsPcRes { const Fs* f; KQ_MDEV int operator()(int j) const { return f->w->s_fr[f->pc_u[j]] % f->nR; } };
+KQ_DEV void fs_pc_apply(const Fs& f, bool add) {
+  const Wave& w = *f.w;
+  int lp[FS_LV];
+  #pragma unroll
+  for (int i = 0; i < FS_LV; i++) lp[i] = w.cs_pl[i];
+  // FS_RC staging cells serve CS_RFR chains at a time
+  for (int base = 0; base < f.npc; base += CS_RFR) {
+    const int nch = f.npc - base < CS_RFR ? f.npc - base : CS_RFR;
+    for (int q = lane_id(); q < CS_RFR; q += WAVE) {
+      FsChainOut o;
+      #pragma unroll
+      for (int i = 0; i < FS_LV; i++) { o.d[i] = 0; o.dp[i] = 0; }
+      const int j = base + q;
+      if (q < nch) o = fs_chain(f.pc_ptr + j * FS_LV, f.pc_lq + j * FS_LV, f.pc_sqb + j * FS_LV, f.plen, w.s_qty[f.pc_u[j]], add, true);
+      #pragma unroll
+      for (int i = 0; i < FS_LV; i++) { f.td[q * FS_LV + i] = o.d[i]; f.tp[q * FS_LV + i] = o.dp[i]; }
+    }
+    wsync();
+    const Fs* fp = &f;
+    auto res = [fp, base](int q) { return fp->w->s_fr[fp->pc_u[base + q]] % fp->nR; };
+    fs_nodes_update(f, lp, f.plen, f.pc_lend, f.pc_wt, nch, res, true, -1, nullptr);
+  }
+}
+// Available (resource_node.go:106-122) of one in-use slot from its gathered path cells
+KQ_DEV int64_t fs_avail(const int64_t* v, const int64_t* lq, const int64_t* sq, const int64_t* bl, int plen) {
+  int64_t a = 0;
+  #pragma unroll
+  for (int i = FS_LV - 1; i >= 0; i--) {
+    if (i >= plen) continue;
+    if (i == plen - 1) { a = a_sub(sq[i], v[i]); continue; }
+    if (bl[i] != KQ_NIL_LIMIT) a = i64min(a_add(a_sub(a_sub(sq[i], lq[i]), i64max(0, a_sub(v[i], lq[i]))), bl[i]), a);
+    a = a_add(i64max(0, a_sub(lq[i], v[i])), a);
+  }
+  return a;
+}
+// workloadFits(allowBorrowing = true) preemption.go:669-686. without_own: workloadFitsForFairSharing :690-695 — the reference
+// removes the preemptor's simulated usage, tests, and adds it again; on plain amounts addUsage(removeUsage(x)) == x level by
+// level (what removeUsage passes up, min(val, usage - localQuota), is exactly what addUsage passes up afterwards), so the
+// removal is evaluated on registers and nothing is written.
+KQ_DEV bool fs_fits(const Fs& f, bool without_own) {
+  Wave& w = *f.w;
+  bool bad = false;
+  for (int j = lane_id(); j < f.npc; j += WAVE) {
+    int64_t v[FS_LV];
+    #pragma unroll
+    for (int i = 0; i < FS_LV; i++) { v[i] = 0; if (i < f.plen) v[i] = *f.pc_ptr[j * FS_LV + i]; }
+    const int64_t qty = w.s_qty[f.pc_u[j]];
+    if (without_own) {
+      int64_t val = qty;
+      bool go = true;
+      #pragma unroll
+      for (int i = 0; i < FS_LV; i++) {
+        if (!go || i >= f.plen) continue;
+        const int64_t stored = a_sub(v[i], f.pc_lq[j * FS_LV + i]);
+        v[i] = a_sub(v[i], val);
+        if (stored <= 0 || i + 1 >= f.plen) go = false; else val = i64min(val, stored);
+      }
+    }
+    if (qty > i64max(0, fs_avail(v, f.pc_lq + j * FS_LV, f.pc_sq + j * FS_LV, f.pc_bl + j * FS_LV, f.plen))) bad = true;
+  }
+  if (lane_id() == 0) w.bytes += 40 * (int64_t)f.plen * f.npc;
+  return wballot(bad) == 0;
+}
+KQ_DEV bool fs_fits_fs(const Fs& f) { return fs_fits(f, true); }
+
+// ---- TargetClusterQueueOrdering ---------------------------------------------------------------------------------------------
+// CandidatesOrdering of the queue heads of two ClusterQueues (common/ordering.go:42-83), as in f_head_key
+KQ_DEV uint64_t fs_head_key(const Fs& f, int li) {
+  const int p = fs_first(f.mq, f.posoff[li], f.posoff[li + 1]);
+  const uint32_t k32 = p >= 0 ? f.k->S.fs_apply[(size_t)f.row0 + p].hkey : 0xffffffffu;
+  return ((uint64_t)(k32 >> 31) << 33) | ((uint64_t)(li == f.wli ? 1 : 0) << 32) | (uint64_t)(k32 & 0x7fffffffu);
+}
+// nextTarget (ordering.go:144-226) from the tree-local cohort `root`; the target ClusterQueue (tree-local) or -1
+KQ_DEV int fs_next_target(const Fs& f, int root) {
+  Wave& w = *f.w;
+  const int lane = lane_id();
+  CSTAT(11, 1);
+  int cohort = root;
+  int64_t lb = 0;
+  int result = -1;
+  const uint64_t NEGK = fs_okey(-1.0);
+  for (;;) {
+    CSTAT(12, 1);
+    const int xc = cohort - f.nqs;
+    const int k0 = f.koff[xc], nkc = f.knc[xc], nkh = f.knh[xc];
+    int best_cq = -1, bz = 0; uint64_t bk = NEGK;
+    for (int base = 0; base < nkc; base += WAVE) {
+      const int j = base + lane;
+      const int c = j < nkc ? f.kid[k0 + j] : -1;
+      bool elig = false; int z = 0; uint64_t key = 0;
+      if (c >= 0 && !(f.nflag[c] & 1)) {
+        lb += fs_cost(f, c);
+        if ((f.ppos[c] <= 0 && c != f.wli) || !fs_cq_has(f, c)) f.nflag[c] |= 1;
+        else { elig = true; z = (f.nflag[c] & 2) ? 1 : 0; key = fs_okey(f.dval[c]); }
+      }
+      uint64_t m = wballot(elig);
+      if (!m) continue;
+      const uint64_t mz = wballot(elig && z);
+      if (mz) m = mz;
+      const bool in = ((m >> lane) & 1) != 0;
+      const uint64_t mx = wmax_u64(in ? key : 0);
+      uint64_t tie = wballot(in && key == mx);
+      if (tie & (tie - 1)) {  // equal shares: the ClusterQueue whose head candidate comes first
+        const bool it = ((tie >> lane) & 1) != 0;
+        const uint64_t hk = it ? fs_head_key(f, c) : ~0ull;
+        const uint64_t mn = wmin_u64(hk);
+        tie = wballot(it && hk == mn);
+      }
+      const int b = ffs64(tie);
+      const int cb = wbcast_u(c, b);
+      const int zb = mz ? 1 : 0;
+      const int cmp = fs_cmp(zb, mx, bz, bk);
+      if (cmp > 0 || (cmp == 0 && best_cq >= 0 && fs_head_key(f, cb) < fs_head_key(f, best_cq))) { best_cq = cb; bz = zb; bk = mx; }
+    }
+    int best_co = -1, hz = 0; uint64_t hk2 = NEGK;
+    for (int base = 0; base < nkh; base += WAVE) {
+      const int j = base + lane;
+      const int ch = j < nkh ? f.kid[k0 + nkc + j] : -1;
+      bool elig = false; int z = 0; uint64_t key = 0;
+      if (ch >= 0 && !(f.nflag[ch] & 1)) {
+        lb += fs_cost(f, ch);
+        bool onpath = false;
+        for (int i = 1; i < f.plen; i++) if (w.cs_pl[i] == ch) onpath = true;
+        if (f.ppos[ch] <= 0 && !onpath) f.nflag[ch] |= 1;
+        else { elig = true; z = (f.nflag[ch] & 2) ? 1 : 0; key = fs_okey(f.dval[ch]); }
+      }
+      uint64_t m = wballot(elig);
+      if (!m) continue;
+      const uint64_t mz = wballot(elig && z);
+      if (mz) m = mz;
+      const bool in = ((m >> lane) & 1) != 0;
+      const uint64_t mx = wmax_u64(in ? key : 0);
+      const uint64_t tie = wballot(in && key == mx);
+      const int b = 63 - clz64(tie);  // `>=` in the reference's fold: the last of equal cohorts wins
+      const int hb = wbcast_u(ch, b);
+      const int zb = mz ? 1 : 0;
+      if (fs_cmp(zb, mx, hz, hk2) >= 0) { best_co = hb; hz = zb; hk2 = mx; }
+    }
+    wsync();
+    if (best_co < 0 && best_cq < 0) {
+      if (lane == 0) f.nflag[cohort] |= 1;
+      wsync();
+      result = -1;
+      break;
+    }
+    if (fs_cmp(hz, hk2, bz, bk) >= 0) { cohort = best_co; continue; }
+    result = best_cq;
+    break;
+  }
+  const int64_t tot = wsum_i64(lb);
+  if (lane == 0) w.bytes += tot;
+  return result;
+}
+// TargetClusterQueueOrdering.Iter (ordering.go:92-127) as a "next" call
+KQ_DEV int fs_ordering_next(const Fs& f) {
+  KQ_A0();
+  if (f.plen <= 1) {
+    KQ_AS(*f.k, 47);
+    if (!(f.nflag[f.wli] & 1) && fs_cq_has(f, f.wli)) return f.wli;
+    return -1;
+  }
+  const int root = f.w->cs_pl[f.plen - 1];
+  while (!(f.nflag[root] & 1)) {
+    const int t = fs_next_target(f, root);
+    if (t >= 0) { KQ_AS(*f.k, 47); return t; }
+  }
+  KQ_AS(*f.k, 47);
+  return -1;
+}
+// PopWorkload (ordering.go:84-90) from class bitmap `from`; `to`: the class the row moves to (null: none). Returns the position.
+KQ_DEV int fs_pop(const Fs& f, int li, uint64_t* from, uint64_t* to) {
+  CSTAT(13, 1);
+  const int p = fs_first(from, f.posoff[li], f.posoff[li + 1]);
+  wsync();
+  if (lane_id() == 0) { from[p >> 6] &= ~(1ull << (p & 63)); if (to) to[p >> 6] |= 1ull << (p & 63); fs_has_update(f, li); }
+  wsync();
+  return p;
+}
+KQ_DEV bool fs_push_target(Fs& f, int* nt, int row, int p, int reason) {
+  Search& s = *f.s;
+  if (*nt >= f.k->X.tgt_cap) { set_error(*f.k, KQ_ECAPACITY); return false; }
+  if (lane_id() == 0) { s.trow[*nt] = row; s.treason[*nt] = (uint8_t)reason; f.tpos[*nt] = p; }
+  (*nt)++;
+  wsync();
+  return true;
+}
+
+// ---- set-up -----------------------------------------------------------------------------------------------------------------
+KQ_DEV bool fs_setup(Search& s, Fs& f) {
+  const K& k = *s.k; Wave& w = *s.w; const DSnap& S = k.S;
+  const int lane = lane_id();
+  if (!k.C.fair_sharing || !k.C.fs_on || !S.fs_ok || !fs_plain_now(k) || w.plen > FS_LV || S.nR > KQ_MAXR) return false;
+  const int tree = S.tree_of[w.cq];
+  if (!S.fs_ok[tree]) return false;
+  f.k = &k; f.w = &w; f.s = &s;
+  f.n0 = S.tree_node_off[tree]; f.nn = S.tree_node_off[tree + 1] - f.n0;
+  f.q0 = S.tree_cq_off[tree]; f.nqs = S.tree_cq_off[tree + 1] - f.q0;
+  f.ncoh = f.nn - f.nqs; f.nR = S.nR; f.nfr = S.nfr;
+  f.row0 = S.tree_row_off[tree]; f.nrows = S.tree_row_off[tree + 1] - f.row0;
+  f.mw = (f.nrows + 63) / 64 + 1;
+  f.plen = w.plen; f.wli = S.cq_local[w.cq];
+  f.wcopied = false;
+  int npc = 0;
+  for (int u = 0; u < w.ns; u++) npc += w.s_inu[u] ? 1 : 0;
+  if (npc * FS_LV > FS_PCN) return false;
+  f.npc = npc;
+  // columns: every resource of the flavors the preemptor needs, then of the flavors it uses
+  int colfr[FS_NCMAX];
+  int nc = 0;
+  for (int pass = 0; pass < 2; pass++)
+    for (int u = 0; u < w.ns; u++) {
+      if (pass == 0 ? !w.s_need[u] : (w.s_need[u] || !w.s_inu[u])) continue;
+      const int fl = w.s_fr[u] / S.nR;
+      for (int r = 0; r < S.nR; r++) {
+        const int fr = fl * S.nR + r;
+        bool have = false;
+        #pragma unroll
+        for (int q = 0; q < FS_NCMAX; q++) if (q < nc && colfr[q] == fr) have = true;
+        if (have || nc >= FS_NCMAX) continue;
+        #pragma unroll
+        for (int q = 0; q < FS_NCMAX; q++) if (q == nc) colfr[q] = fr;
+        nc++;
+      }
+    }
+  f.nc = nc;
+  const size_t need = fs_bytes(f.nn, f.nqs, f.nR, f.nfr, f.mw, nc);
+  unsigned char* spill = k.X.cs ? k.X.cs + (size_t)s.slot * (size_t)k.X.cs_bytes : nullptr;
+  const bool all_lds = w.cs_lds && (size_t)w.cs_lds_bytes >= need;
+  if (!all_lds && (!spill || (size_t)k.X.cs_bytes < need)) return false;
+  CsCarve cv{w.cs_lds, w.cs_lds ? w.cs_lds + w.cs_lds_bytes : nullptr, spill};
+  f.rc_ptr = (int64_t**)cv.take(FS_RC * 8); f.rc_lq = (int64_t*)cv.take(FS_RC * 8); f.rc_sqb = (int64_t*)cv.take(FS_RC * 8);
+  f.rc_lend = (int64_t*)cv.take(FS_LV * KQ_MAXR * 8); f.rc_wt = (double*)cv.take(FS_LV * 8);
+  f.td = (int64_t*)cv.take(FS_RC * 8); f.tp = (int32_t*)cv.take(FS_RC * 4); f.tx = (double*)cv.take(FS_LV * KQ_MAXR * 8); f.tout = (uint64_t*)cv.take(4 * 8);
+  f.pc_ptr = (int64_t**)cv.take(FS_PCN * 8); f.pc_lq = (int64_t*)cv.take(FS_PCN * 8); f.pc_sq = (int64_t*)cv.take(FS_PCN * 8);
+  f.pc_sqb = (int64_t*)cv.take(FS_PCN * 8); f.pc_bl = (int64_t*)cv.take(FS_PCN * 8); f.pc_u = (int32_t*)cv.take(FS_PCN * 4);
+  f.pc_lend = (int64_t*)cv.take(FS_LV * KQ_MAXR * 8); f.pc_wt = (double*)cv.take(FS_LV * 8);
+  f.colp = (int64_t**)cv.take(FS_NCMAX * 8);
+  f.nflag = (uint8_t*)cv.take(f.nn); f.dval = (double*)cv.take((size_t)f.nn * 8); f.ppos = (int32_t*)cv.take((size_t)f.nn * 4);
+  f.c0 = (int16_t*)cv.take((size_t)f.nn * 2); f.c1 = (int16_t*)cv.take((size_t)f.nn * 2); f.kid = (int16_t*)cv.take((size_t)f.nn * 2);
+  const size_t nco = (size_t)(f.ncoh > 0 ? f.ncoh : 1);
+  f.koff = (int16_t*)cv.take(nco * 2); f.knc = (int16_t*)cv.take(nco * 2); f.knh = (int16_t*)cv.take(nco * 2);
+  f.posoff = (int32_t*)cv.take((size_t)(f.nqs + 1) * 4); f.colslot = (int8_t*)cv.take(f.nfr);
+  f.psum = (int64_t*)cv.take((size_t)f.nn * f.nR * 8);
+  f.m1 = (uint64_t*)cv.take((size_t)f.mw * 8); f.m2 = (uint64_t*)cv.take((size_t)f.mw * 8);
+  f.mq = f.m1;
+  f.tpos = s.cand;
+  for (int i = lane; i < f.nfr; i += WAVE) f.colslot[i] = -1;
+  wsync();
+  #pragma unroll
+  for (int q = 0; q < FS_NCMAX; q++) {
+    if (q >= nc) continue;
+    int64_t* cp = (int64_t*)cv.take((size_t)f.nn * 8);
+    if (lane == 0) { f.colp[q] = cp; f.colslot[colfr[q]] = (int8_t)q; }
+  }
+  // tree-local ids of the preemptor's path
+  if (lane == 0) for (int i = 0; i < w.plen; i++) w.cs_pl[i] = S.node_local[w.path[i]];
+  wsync();
+  return true;
+}
+// state of the search = the plane it starts from
+KQ_DEV void fs_init(Fs& f) {
+  const K& k = *f.k; const DSnap& S = k.S; Search& s = *f.s;
+  const int lane = lane_id();
+  for (int i = lane; i < f.nn; i += WAVE) {
+    f.nflag[i] = 0;
+    f.c0[i] = S.fs_c0[f.n0 + i]; f.c1[i] = S.fs_c1[f.n0 + i]; f.kid[i] = S.fs_kid[f.n0 + i];
+    if (i >= f.nqs) { f.koff[i - f.nqs] = S.fs_koff[f.n0 + i]; f.knc[i - f.nqs] = S.fs_knc[f.n0 + i]; f.knh[i - f.nqs] = S.fs_knh[f.n0 + i]; }
+  }
+  for (int i = lane; i <= f.nqs; i += WAVE) f.posoff[i] = S.fs_posoff[(size_t)f.q0 + s.tree + i];
+  for (int i = lane; i < f.mw; i += WAVE) { f.m1[i] = 0; f.m2[i] = 0; }
+  for (int q = 0; q < f.nc; q++) {
+    int64_t* cp = f.colp[q];
+    int fr = 0;
+    for (int x = 0; x < f.nfr; x++) if (f.colslot[x] == q) fr = x;
+    for (int i = lane; i < f.nn; i += WAVE) cp[i] = s.usage[ix(S, S.tree_nodes[f.n0 + i], fr)];
+  }
+  if (s.usage == k.usage) {  // cycle-start plane: k_fs_sums already reduced it
+    for (int i = lane; i < f.nn * f.nR; i += WAVE) f.psum[i] = k.X.bu_sum[(size_t)S.tree_nodes[f.n0 + i / f.nR] * f.nR + i % f.nR];
+    for (int i = lane; i < f.nn; i += WAVE) f.ppos[i] = k.X.bu_pos[S.tree_nodes[f.n0 + i]];
+  } else {
+    for (int i = lane; i < f.nn * f.nR; i += WAVE) f.psum[i] = 0;
+    for (int i = lane; i < f.nn; i += WAVE) f.ppos[i] = 0;
+    wsync();
+    for (int i = lane; i < f.nn * f.nfr; i += WAVE) {
+      const int li = i / f.nfr, fr = i % f.nfr;
+      const int64_t b = a_sub(s.usage[ix(S, S.tree_nodes[f.n0 + li], fr)], S.fs_sqb[(size_t)(f.n0 + li) * f.nfr + fr]);
+      if (b > 0) { atomic_add_i64((long long*)&f.psum[(size_t)li * f.nR + fr % f.nR], (long long)b); atomic_add_i32(&f.ppos[li], 1); }
+    }
+  }
+  wsync();
+  for (int i = lane; i < f.nn; i += WAVE) fs_refresh(f, i, S.fs_lend + (size_t)(f.n0 + i) * f.nR, S.fs_weight[f.n0 + i]);
+  wsync();
+}
+
+// fairPreemptions (preemption.go:536-597): same contract as fair_search. false: preconditions not met, nothing was done.
+KQ_DEV bool fair_search_lds(Search& s) {
+  const K& k = *s.k; Wave& w = *s.w; const DSnap& S = k.S;
+  const int lane = lane_id();
+  const bool same_on = KQ_POL_WITHIN_CQ(w.pol) != KQ_POLICY_NEVER;
+  const bool other_on = w.plen > 1 && KQ_POL_RECLAIM(w.pol) != KQ_POLICY_NEVER;
+  if (!same_on && !other_on) { w.ntgt = 0; return true; }
+  s.tree = S.tree_of[w.cq];
+  s.row0 = S.tree_row_off[s.tree];
+  s.nrows = S.tree_row_off[s.tree + 1] - s.row0;
+  if (s.nrows == 0) { w.ntgt = 0; return true; }
+  Fs f;
+  if (!fs_setup(s, f)) return false;
+  w.ntgt = 0;
+  KQ_T0();
+  fs_init(f);
+  KQ_TS(k, 41);
+  // ---- findCandidates (:633-667) ----
+  for (int i = lane; i < f.nqs; i += WAVE) {  // does the ClusterQueue contribute candidates?
+    const int c = S.tree_cqs[f.q0 + i];
+    bool take;
+    if (i == f.wli) take = same_on;
+    else {
+      take = false;
+      if (other_on)
+        for (int u = 0; u < w.ns; u++)  // cqIsBorrowing :657-667
+          if (w.s_need[u] && S.nominal[ix(S, c, w.s_fr[u])] < s.usage[ix(S, c, w.s_fr[u])]) take = true;
+    }
+    if (take) f.nflag[i] |= 4;
+  }
+  wsync();
+  {
+    int64_t cbytes = 0;
+    const int policy_same = KQ_POL_WITHIN_CQ(w.pol), policy_other = KQ_POL_RECLAIM(w.pol);
+    for (int base = 0; base < f.nrows; base += 64) {
+      uint64_t word = 0;
+      for (int sub = 0; sub < 64; sub += WAVE) {  // one ballot per 64 positions (the emulation has one lane)
+        const int p = base + sub + lane;
+        bool bit = false;
+        if (p < f.nrows) {
+          const FsScan sc = S.fs_scan[(size_t)f.row0 + p];
+          if ((f.nflag[sc.cql] & 4) && !row_removed(s, sc.row)) {
+            cbytes += sc.cbytes;
+            const int policy = sc.cql == f.wli ? policy_same : policy_other;
+            const bool lower = w.prio > sc.prio;
+            bool ok = policy == KQ_POLICY_ANY;
+            if (policy == KQ_POLICY_LOWER_PRIORITY) ok = lower;
+            if (policy == KQ_POLICY_LOWER_OR_NEWER_EQUAL) ok = lower || (w.prio == sc.prio && w.ts < sc.qts);
+            bool uses = false;
+            #pragma unroll
+            for (int e = 0; e < CS_RFR; e++)
+              for (int u = 0; u < w.ns; u++) if (sc.fr[e] >= 0 && w.s_need[u] && w.s_fr[u] == sc.fr[e]) uses = true;
+            bit = ok && uses;
+          }
+        }
+        word |= wballot(bit) << sub;
+      }
+      if (lane == 0) f.m1[base >> 6] = word;
+    }
+    const int64_t tot = wsum_i64(cbytes);
+    if (lane == 0) w.bytes += tot;
+  }
+  wsync();
+  int ncand = 0;
+  for (int i = lane; i < f.nqs; i += WAVE) fs_has_update(f, i);
+  wsync();
+  for (int base = 0; base < f.nqs; base += WAVE) { const int i = base + lane; ncand += popc64(wballot(i < f.nqs && fs_cq_has(f, i))); }
+  CSTAT(14, 1); CSTAT(15, ncand);
+  KQ_TS(k, 42);
+  if (ncand == 0) return true;
+  fs_pc_setup(f);
+  fs_pc_apply(f, true);  // SimulateUsageAddition :557
+  int nt = 0;
+  int64_t tbytes = 0;  // what the final bookkeeping of the targets is charged (16 B per level and usage entry)
+  bool fits = false;
+  const int strategy0 = k.C.n_fs > 0 ? k.C.fs[0] : KQ_FS_LESS_THAN_OR_EQUAL_TO_FINAL_SHARE;
+  const bool have_second = k.C.n_fs > 0 ? k.C.n_fs > 1 : true;
+  // ---- runFirstFsStrategy :384-470 ----
+  {
+    bool within_nominal = false;
+    if (gate(k, KQ_GATE_FS_PREEMPT_WITHIN_NOMINAL)) {  // queueWithinNominalInResourcesNeedingPreemption :714-721
+      within_nominal = true;
+      for (int u = 0; u < w.ns; u++)
+        if (w.s_need[u] && S.nominal[ix(S, w.cq, w.s_fr[u])] < *fs_cellp(f, f.wli, w.s_fr[u])) within_nominal = false;
+    }
+    for (int cand = fs_ordering_next(f); cand >= 0 && !fits; cand = fits ? -1 : fs_ordering_next(f)) {
+      if (cand == f.wli || within_nominal) {
+        const int p = fs_pop(f, cand, f.m1, nullptr);
+        const FsRow r = fs_row_load(f, p);
+        fs_row_ctx(f, r);
+        fs_row_apply(f, r, false, true, true);
+        if (!fs_push_target(f, &nt, r.row, p, cand == f.wli ? KQ_REASON_IN_CLUSTER_QUEUE : KQ_REASON_IN_COHORT_RECLAMATION)) { w.ntgt = 0; return true; }
+        tbytes += r.rowbytes;
+        if (fs_fits_fs(f)) fits = true;
+        continue;
+      }
+      // getAlmostLCAs (least_common_ancestor.go:27-58) from the path of the ClusterQueue's first candidate record
+      int p = fs_first(f.m1, f.posoff[cand], f.posoff[cand + 1]);
+      FsRow r = fs_row_load(f, p);
+      int ap = f.wli, at = cand;
+      {
+        bool found = false;
+        #pragma unroll
+        for (int j = 1; j < FS_LV; j++) {
+          if (found || j >= r.plen) continue;
+          int l = -1;
+          for (int i = 1; i < f.plen; i++) if (w.cs_pl[i] == r.lp[j]) l = i;
+          if (l >= 1) { ap = w.cs_pl[l - 1]; at = r.lp[j - 1]; found = true; }
+        }
+        if (!found) { ap = w.cs_pl[f.plen - 1]; at = fs_sel4(r.lp, r.plen - 1); }
+      }
+      const int pz = (f.nflag[ap] & 2) ? 1 : 0, tz = (f.nflag[at] & 2) ? 1 : 0;
+      const uint64_t pk = fs_okey(f.dval[ap]), tk = fs_okey(f.dval[at]);
+      if (lane == 0) w.bytes += fs_cost(f, ap) + fs_cost(f, at);
+      if (fs_pos_inf(f, ap) && !fs_pos_inf(f, at)) {  // fsStrategyUnsatisfiable :494-497: the whole queue goes to retryCandidates
+        const int a = f.posoff[cand], b = f.posoff[cand + 1];
+        wsync();
+        for (int wi = (a >> 6) + lane; wi <= ((b - 1) >> 6); wi += WAVE) {
+          uint64_t mask = ~0ull;
+          if (wi == (a >> 6)) mask &= ~0ull << (a & 63);
+          if (wi == ((b - 1) >> 6)) { const int e = (b - 1) & 63; if (e < 63) mask &= (2ull << e) - 1; }
+          const uint64_t mv = f.m1[wi] & mask;
+          CSTAT(13, popc64(mv));
+          f.m2[wi] |= mv; f.m1[wi] &= ~mask;
+        }
+        if (lane == 0) f.nflag[cand] &= ~8;
+        wsync();
+        continue;
+      }
+      bool first = true;
+      while (fs_cq_has(f, cand)) {
+        p = fs_pop(f, cand, f.m1, nullptr);
+        if (!first) r = fs_row_load(f, p);
+        first = false;
+        fs_row_ctx(f, r);
+        // ComputeTargetShareAfterRemoval target.go:67-73: RemoveWorkload, share of the target's side, AddWorkload. The state after
+        // the pair is the state before it (plain amounts, see fs_fits), so the removal is only evaluated.
+        uint64_t nk = 0;
+        const int zb = fs_row_apply(f, r, false, false, false, at, &nk);
+        const int nz = zb & 1;
+        if (lane == 0) w.bytes += (int64_t)f.c0[at] + ((zb & 2) ? (int64_t)f.c1[at] : 0);
+        const bool pass = strategy0 == KQ_FS_LESS_THAN_OR_EQUAL_TO_FINAL_SHARE ? fs_cmp(pz, pk, nz, nk) <= 0 : fs_cmp(pz, pk, tz, tk) < 0;  // strategy.go:41,46
+        if (pass) {
+          fs_row_apply(f, r, false, true, true);
+          if (!fs_push_target(f, &nt, r.row, p, KQ_REASON_IN_COHORT_FAIR_SHARING)) { w.ntgt = 0; return true; }
+          tbytes += r.rowbytes;
+          if (fs_fits_fs(f)) fits = true;
+          break;
+        }
+        if (lane == 0) f.m2[p >> 6] |= 1ull << (p & 63);  // retryCandidates
+        wsync();
+      }
+    }
+  }
+  KQ_TS(k, 43);
+  // ---- runSecondFsStrategy :501-534 ----
+  if (!fits && have_second) {
+    f.mq = f.m2;
+    for (int i = lane; i < f.nn; i += WAVE) { f.nflag[i] &= ~1; if (i < f.nqs) fs_has_update(f, i); }
+    wsync();
+    for (int cand = fs_ordering_next(f); cand >= 0 && !fits; cand = fits ? -1 : fs_ordering_next(f)) {
+      const int p = fs_pop(f, cand, f.m2, nullptr);
+      const FsRow r = fs_row_load(f, p);
+      int ap = f.wli, at = cand;
+      {
+        bool found = false;
+        #pragma unroll
+        for (int j = 1; j < FS_LV; j++) {
+          if (found || j >= r.plen) continue;
+          int l = -1;
+          for (int i = 1; i < f.plen; i++) if (w.cs_pl[i] == r.lp[j]) l = i;
+          if (l >= 1) { ap = w.cs_pl[l - 1]; at = r.lp[j - 1]; found = true; }
+        }
+        if (!found) { ap = w.cs_pl[f.plen - 1]; at = fs_sel4(r.lp, r.plen - 1); }
+      }
+      const bool passed = fs_cmp((f.nflag[ap] & 2) ? 1 : 0, fs_okey(f.dval[ap]), (f.nflag[at] & 2) ? 1 : 0, fs_okey(f.dval[at])) < 0;
+      if (lane == 0) w.bytes += fs_cost(f, ap) + fs_cost(f, at);
+      if (passed) {
+        fs_row_ctx(f, r);
+        fs_row_apply(f, r, false, true, true);
+        if (!fs_push_target(f, &nt, r.row, p, KQ_REASON_IN_COHORT_FAIR_SHARING)) { w.ntgt = 0; return true; }
+        tbytes += r.rowbytes;
+        if (fs_fits_fs(f)) fits = true;
+      }
+      if (lane == 0) f.nflag[cand] |= 1;  // DropQueue
+      wsync();
+    }
+  }
+  fs_pc_apply(f, false);  // revertSimulation
+  KQ_TS(k, 44);
+  if (!fits) {
+    if (lane == 0) w.bytes += tbytes;
+    // restoreSnapshot :356 — the private copy is dropped, but callers read it: put the rows back
+    for (int t = 0; t < nt; t++) { const FsRow r = fs_row_load(f, f.tpos[t]); fs_row_ctx(f, r); fs_row_apply(f, r, true, true, false); }
+    w.ntgt = 0;
+    KQ_TS(k, 45);
+  } else {
+    CSTAT(16, 1); CSTAT(17, nt);
+    // fillBackWorkloads :341-354 with allowBorrowing = true
+    for (int t = nt - 2; t >= 0; t--) {
+      const FsRow r = fs_row_load(f, f.tpos[t]);
+      fs_row_ctx(f, r);
+      fs_row_apply(f, r, true, true, true);
+      if (fs_fits(f, false)) {
+        if (lane == 0) { s.trow[t] = s.trow[nt - 1]; s.treason[t] = s.treason[nt - 1]; f.tpos[t] = f.tpos[nt - 1]; }
+        nt--;
+        tbytes -= r.rowbytes;
+        wsync();
+      } else {
+        fs_row_apply(f, r, false, true, true);
+      }
+    }
+    w.ntgt = nt;
+    if (lane == 0) w.bytes += tbytes;
+    KQ_TS(k, 46);
+  }
+  // callers read the private plane on the preemptor's path (find_height in simulate_preemption)
+  for (int c = lane; c < f.npc * FS_LV; c += WAVE) {
+    const int j = c / FS_LV, i = c % FS_LV;
+    if (i >= f.plen) continue;
+    s.W[(size_t)w.cs_pl[i] * f.nfr + w.s_fr[f.pc_u[j]]] = *f.pc_ptr[c];
+  }
+  wsync();
+  return true;
+}
+
+}  // namespace kq

@@ -36,6 +36,7 @@ template <class B> struct EngineT {
   Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_grec, b_cqd, b_defer, b_cert, b_fs[20];
   bool force_exact_drs = false;  // tests: take the saturation-safe DRS loops even when the sums would be exact
   bool cs_disable = false;       // tests: classical victim searches always take the candidate-by-candidate walk
+  bool fs_disable = false;       // tests: fair-sharing victim searches always take the walk
   Buf b_cs;
   struct HeadBatch { Buf hb[1]; DHeads H{}; int n = 0; size_t nps = 0; int slot_cap = 1; int64_t cycle = 0; bool valid = false; bool plain = true; int max_nps = KQ_MAXPS; };
   std::vector<HeadBatch> batches;  // [0] = transient batch of kq_cycle_run, [1+b] = resident batch b
@@ -194,6 +195,9 @@ template <class B> struct EngineT {
     S.frec = upload(prep.frec.data(), prep.frec.size());
     S.frb_sig = upload(prep.frb_sig.data(), prep.frb_sig.size());
     S.cs_ok = upload(prep.cs_ok.data(), prep.cs_ok.size());
+    upload_fs_rows(); upload_fs_quota();
+    S.fs_kid = upload(prep.fs_kid.data(), prep.fs_kid.size()); S.fs_koff = upload(prep.fs_koff.data(), prep.fs_koff.size());
+    S.fs_knc = upload(prep.fs_knc.data(), prep.fs_knc.size()); S.fs_knh = upload(prep.fs_knh.data(), prep.fs_knh.size());
     S.tree_depth = upload(prep.tree_depth.data(), prep.tree_depth.size());
     S.cq_res_rg = upload(prep.cq_res_rg.data(), prep.cq_res_rg.size());
     rc = be.sync();
@@ -209,6 +213,17 @@ template <class B> struct EngineT {
   template <class T> void reupload(const T*& field, const T* host, size_t n) {
     for (size_t i = 0; i < snap_allocs.size(); i++) if (snap_allocs[i] == (const void*)field) { be.free(snap_allocs[i]); snap_allocs.erase(snap_allocs.begin() + i); break; }
     field = upload(host, n);
+  }
+  // static structures of the LDS-resident fair victim search: the part that follows the admitted set / the part that follows the quotas
+  void upload_fs_rows() {
+    reupload(S.fs_scan, prep.fs_scan.data(), prep.fs_scan.size()); reupload(S.fs_apply, prep.fs_apply.data(), prep.fs_apply.size());
+    reupload(S.fs_posoff, prep.fs_posoff.data(), prep.fs_posoff.size());
+  }
+  void upload_fs_quota() {
+    reupload(S.fs_ok, prep.fs_ok.data(), prep.fs_ok.size());
+    reupload(S.fs_c0, prep.fs_c0.data(), prep.fs_c0.size()); reupload(S.fs_c1, prep.fs_c1.data(), prep.fs_c1.size());
+    reupload(S.fs_lq, prep.fs_lq.data(), prep.fs_lq.size()); reupload(S.fs_sqb, prep.fs_sqb.data(), prep.fs_sqb.size());
+    reupload(S.fs_lend, prep.fs_lend.data(), prep.fs_lend.size()); reupload(S.fs_weight, prep.fs_weight.data(), prep.fs_weight.size());
   }
   int snapshot_patch(const kq_snapshot* s, uint32_t what) {
     if (!have_snapshot) return fail(KQ_EINVAL, "kq_snapshot_patch before kq_snapshot_put");
@@ -241,6 +256,7 @@ template <class B> struct EngineT {
       for (int l = 0; l < CS_LEVELS; l++) reupload(S.frl[l], prep.frl[l].data(), prep.frl[l].size());
       reupload(S.frbr, prep.frbr.data(), prep.frbr.size()); reupload(S.frec, prep.frec.data(), prep.frec.size());
       reupload(S.frb_sig, prep.frb_sig.data(), prep.frb_sig.size()); reupload(S.cs_ok, prep.cs_ok.data(), prep.cs_ok.size());
+      upload_fs_rows(); reupload(S.fs_ok, prep.fs_ok.data(), prep.fs_ok.size());  // the quota-derived tables stay (like S.lendable)
       what |= KQ_PATCH_USAGE;  // build_prep re-derived usage_consistent / fs_plain from s->usage: the plane must match
     } else if (what & KQ_PATCH_USAGE) {
       // usage-dependent flags of the prep: "cohort usage == what the children store in it" and the plain range of the amounts
@@ -333,6 +349,7 @@ template <class B> struct EngineT {
     build_fair(prep, sq.data(), us.data(), fl.data());
     S.lendable = upload(prep.lendable.data(), prep.lendable.size());
     S.frcount = upload(prep.frcount.data(), prep.frcount.size());
+    upload_fs_quota();
     rc = be.sync();
     if (rc != KQ_OK) return fail(rc, be.error());
     return KQ_OK;
@@ -466,6 +483,7 @@ template <class B> struct EngineT {
     k.C.fs_plain = (prep.fs_plain && hbch.plain && prep.nR <= KQ_MAXR && !force_exact_drs) ? 1 : 0;
     // scan-formulated classical search: usage and admitted quantities must be plain (its prefix sums are ordinary additions)
     k.C.cs_on = (!cfg.fair_sharing && prep.any_preemption && prep.fs_plain && !cs_disable) ? 1 : 0;
+    k.C.fs_on = (cfg.fair_sharing && prep.any_preemption && prep.fs_plain && !fs_disable) ? 1 : 0;
     k.C.gates = cfg.gates; k.C.fair_sharing = cfg.fair_sharing; k.C.quota_check_strategy = cfg.quota_check_strategy; k.C.cycle = hbch.cycle;
     k.H = hbch.H;
     // outputs
@@ -524,6 +542,11 @@ template <class B> struct EngineT {
       X.cs_bytes = (int64_t)((cs_bytes(CS_NS, prep.cs_max_bucket, prep.max_tree_nodes, prep.max_tree_cqs, false) + 255) & ~(size_t)255);
       X.cs = grow<unsigned char>(b_cs, (size_t)slots * (size_t)X.cs_bytes);
     }
+    const bool fs_lds = k.C.fs_on != 0;  // kq_fs.hpp may run
+    if (fs_lds) {  // the same spill space serves the state of an LDS-formulated fair search that does not (all) fit the LDS
+      X.cs_bytes = (int64_t)((fs_bytes(prep.max_tree_nodes, prep.max_tree_cqs, nR, (int)prep.nfr, prep.max_tree_mw, FS_NCMAX) + 255) & ~(size_t)255);
+      X.cs = grow<unsigned char>(b_cs, (size_t)slots * (size_t)X.cs_bytes);
+    }
     k.cq_rm_bytes = grow<int32_t>(b_rmb, std::max(prep.nq, 1));
     prep_fill(k.cq_rm_bytes, (size_t)std::max(prep.nq, 1), 0);
     if (cfg.fair_sharing) {
@@ -544,7 +567,7 @@ template <class B> struct EngineT {
     k.usage_work = grow<int64_t>(b_usage_work, Nfr);
     k.usage_np = grow<int64_t>(b_usage_np, Nfr);
     k.preempted = grow<uint8_t>(b_preempted, ((size_t)std::max(prep.n_adm, 1) + 3) & ~(size_t)3);
-    k.prof = (long long*)grow<int64_t>(b_prof, 32);
+    k.prof = (long long*)grow<int64_t>(b_prof, 64);
     k.grec = grow<PRec>(b_grec, n);
     k.cq_dirty = grow<uint8_t>(b_cqd, std::max(prep.nq, 1));  // cleared per head by k_records
     k.defer_list = grow<int32_t>(b_defer, (size_t)n + 1); k.defer_count = k.defer_list + n;
@@ -582,6 +605,10 @@ template <class B> struct EngineT {
       nom_lds = cs_bytes(1, prep.cs_max_bucket, prep.max_tree_nodes, prep.max_tree_cqs, true);
       if (nom_lds > 78 * 1024) nom_lds = std::min<size_t>(cs_bytes(1, prep.cs_max_bucket, prep.max_tree_nodes, prep.max_tree_cqs, false), 78 * 1024);
     }
+    // fair sharing: the whole state of a victim search (kq_fs.hpp) in LDS — one search per CU, but a pop costs LDS round trips
+    // instead of ~30 dependent HBM/L2 accesses. A one-slot search caches the nR columns of its flavor.
+    const size_t fs_want = fs_lds ? fs_bytes(prep.max_tree_nodes, prep.max_tree_cqs, nR, (int)prep.nfr, prep.max_tree_mw, 2 * nR) : 0;
+    if (fs_lds) nom_lds = std::min<size_t>(fs_want, be.lds_budget());
     be.launch_nominate(k, slots_nom, nom_lds);
     if (!nominate_only) be.launch_records(k);  // entry records (static part) for k_process; charged to the nominate interval
     be.timer_mark(1);
@@ -589,7 +616,7 @@ template <class B> struct EngineT {
     be.timer_mark(2);
     k.O.stat_bytes = (long long*)(misc + 2);
     if (nominate_only) {}
-    else if (cfg.fair_sharing) be.launch_process_fair(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16, rank);
+    else if (cfg.fair_sharing) be.launch_process_fair(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16, fs_want, rank);
     else be.launch_process(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16);
     be.timer_mark(3);
     last_cycle_n = -1;  // set on the success path only: a failed cycle must not be committable
@@ -851,10 +878,10 @@ template <class B> struct EngineT {
   }
 
   int prof_read(int64_t* out, bool reset) {
-    if (!b_prof.p) { for (int i = 0; i < 32; i++) out[i] = 0; return KQ_OK; }
-    be.d2h(out, b_prof.p, 32 * sizeof(int64_t));
+    if (!b_prof.p) { for (int i = 0; i < 64; i++) out[i] = 0; return KQ_OK; }
+    be.d2h(out, b_prof.p, 64 * sizeof(int64_t));
     int rc = be.sync();
-    if (reset) be.memset(b_prof.p, 0, 32 * sizeof(int64_t));
+    if (reset) be.memset(b_prof.p, 0, 64 * sizeof(int64_t));
     return rc;
   }
   int read_usage_work(int64_t* out) {  // tests: snapshot usage after the cycle

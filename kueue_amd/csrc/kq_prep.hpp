@@ -47,6 +47,16 @@ struct alignas(8) CsEnt { int32_t jd, node, row, gnode; int64_t qty; };  // gnod
 // One entry of a bucket in candidate rank order: everything the classification of a candidate reads (hierarchical_preemption.go:81-113)
 struct alignas(8) CsRec { int64_t prio, qts; int32_t row, cql, rowbytes; uint32_t flags; };  // cql = index of the ClusterQueue in its tree
 
+// ---- static structures of the LDS-resident fair-sharing victim search (kq_fs.hpp) ---------------------------------
+// The candidates of a tree in "position order": grouped by ClusterQueue (tree-local index ascending), inside a ClusterQueue in the
+// order the TargetClusterQueueOrdering pops them (evicted first, then candidate rank, fairsharing/ordering.go:84-90 +
+// common/ordering.go:42-83). A search's candidate classes are bitmaps over these positions. Two records per position: what the
+// candidate scan reads, and what a pop / a snapshot.RemoveWorkload of the row reads (tree-local path of its ClusterQueue included).
+constexpr int FS_LV = 4;       // path levels (ClusterQueue + 3 cohort levels) of a tree the LDS search handles
+struct alignas(16) FsScan { int64_t prio, qts; int16_t fr[CS_RFR]; int32_t row; int16_t cql; uint16_t cbytes; };
+struct alignas(16) FsApply { int64_t qty[CS_RFR]; int16_t lp[FS_LV]; uint32_t hkey; int32_t cq; int32_t plen; int32_t pad[3]; };
+static_assert(sizeof(FsScan) == 32 && sizeof(FsApply) == 64, "FsScan / FsApply are read as 32 / 64 byte records");
+
 struct Prep {
   int nq = 0, nc = 0, N = 0, nF = 0, nR = 0, nfr = 0, n_adm = 0, n_rg = 0;
   std::vector<int32_t> depth, root, tree_of, node_local, node_height;
@@ -85,6 +95,18 @@ struct Prep {
   std::vector<int32_t> top_of;                     // [N] the ancestor-or-self that is a child of the root (-1 for roots)
   int max_tree_nodes = 0, max_tree_cqs = 0, max_tree_rows = 0, max_tree_cohorts = 0;
   std::vector<int8_t> cq_res_rg;                   // [nq * nR] RGByResource: index of the covering group inside the ClusterQueue's groups, -1 = none
+  // kq_fs.hpp: per tree position (same offsets as tree_rows)
+  std::vector<FsScan> fs_scan;
+  std::vector<FsApply> fs_apply;
+  std::vector<int32_t> fs_posoff;                  // [nq + n_tree] per tree (offset tree_cq_off[t] + t): nqs + 1 position offsets of its ClusterQueues
+  std::vector<uint8_t> fs_ok;                      // [n_tree] the tree fits the LDS search (depth, rows with few flavor-resources, index ranges)
+  // kq_fs.hpp: tables in tree-node order (index tree_node_off[t] + tree-local node id), so that the search never needs global ids
+  std::vector<int16_t> fs_kid, fs_koff, fs_knc, fs_knh;  // children (tree-local ids; ClusterQueue children first) of every cohort
+  std::vector<int16_t> fs_c0, fs_c1;               // algorithmic bytes of one DRS evaluation of the node: always / more when it borrows
+  std::vector<int64_t> fs_lq, fs_sqb, fs_lend;     // [N * nfr] localQuota, SubtreeQuota (INT64_MAX where the node has no entry); [N * nR] lendable
+  std::vector<double> fs_weight;                   // [N]
+  std::vector<double> h_weight;                    // host copy of fair_weight for build_fair after a device derive
+  int max_tree_mw = 1;                             // words of a candidate bitmap of the largest tree
   int max_rsn_per_podset = 1;  // most reason records one podset's flavor scans can produce: max over ClusterQueues of sum over groups of flavors x (resources + 1)
   std::string err;
 };
@@ -150,6 +172,21 @@ static inline void build_fair(Prep& p, const int64_t* sq, const int64_t* usage, 
       size_t r = fr % p.nR;
       p.lendable[(size_t)n * p.nR + r] = a_add(p.lendable[(size_t)n * p.nR + r], pot[(size_t)par * nfr + fr]);
     }
+  }
+  // kq_fs.hpp: the same constants in tree-node order
+  p.fs_lq.assign((size_t)N * nfr, 0); p.fs_sqb.assign((size_t)N * nfr, U); p.fs_lend.assign((size_t)N * p.nR, 0);
+  p.fs_weight.assign(N, 1.0); p.fs_c0.assign(N, 0); p.fs_c1.assign(N, 0);
+  for (int tp = 0; tp < N; tp++) {
+    const int n = p.tree_nodes[tp];
+    for (size_t fr = 0; fr < nfr; fr++) {
+      const size_t o = (size_t)n * nfr + fr, d = (size_t)tp * nfr + fr;
+      if (p.h_ll[o] != KQ_NIL_LIMIT) p.fs_lq[d] = std::max<int64_t>(0, a_sub(sq[o], p.h_ll[o]));
+      if (flags[o] & KQ_QF_SUBTREE) p.fs_sqb[d] = sq[o];
+    }
+    for (int r = 0; r < p.nR; r++) p.fs_lend[(size_t)tp * p.nR + r] = p.lendable[(size_t)n * p.nR + r];
+    if (!p.h_weight.empty()) p.fs_weight[tp] = p.h_weight[n];
+    const int64_t c0 = (int64_t)p.frcount[n] * 24, c1 = (int64_t)p.frcount[n] * 40 * (p.depth[n] + 1);
+    if (c0 > 32767 || c1 > 32767) { for (auto& f : p.fs_ok) f = 0; } else { p.fs_c0[tp] = (int16_t)c0; p.fs_c1[tp] = (int16_t)c1; }
   }
 }
 
@@ -315,6 +352,7 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
     for (int t = 0; t < p.n_tree; t++)
       for (int i = p.frb_off[(size_t)t * p.nfr]; i < p.frb_off[(size_t)(t + 1) * p.nfr]; i++) p.frbr[i] = p.tree_rows[p.tree_row_off[t] + p.frb[i]];
     p.adm_rec.assign(p.n_adm, AdmRec{});
+    p.fs_ok.assign(p.n_tree, 1);
     for (int c = 0; c < nq; c++) if (p.depth[c] > CS_LEVELS) p.cs_ok[p.tree_of[c]] = 0;
     for (int r = 0; r < p.n_adm; r++) {
       AdmRec& a = p.adm_rec[r];
@@ -331,6 +369,62 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
         // plain sum (entries of a repeated flavor-resource are removed one after another by the reference; on plain amounts that
         // is the removal of their sum). Non-plain rows switch the fast search off through fs_plain_adm.
         a.qty[k] = (int64_t)((uint64_t)a.qty[k] + (uint64_t)s->adm_use_qty[e]);
+      }
+      if (nf == CS_RFR) {  // did the row have more distinct flavor-resources than a record holds?
+        for (int e = s->adm_use_off[r]; e < s->adm_use_off[r + 1]; e++) {
+          bool in = false;
+          for (int q = 0; q < CS_RFR; q++) if (a.fr[q] == s->adm_use_fr[e]) in = true;
+          if (!in) p.fs_ok[p.tree_of[c]] = 0;
+        }
+      }
+    }
+    // ---- kq_fs.hpp: candidates in position order, children lists in tree-node order ----
+    for (int c = 0; c < nq; c++) if (p.depth[c] + 1 > FS_LV) p.fs_ok[p.tree_of[c]] = 0;
+    if (p.nfr > 32767) for (auto& f : p.fs_ok) f = 0;
+    p.fs_scan.assign(p.n_adm, FsScan{}); p.fs_apply.assign(p.n_adm, FsApply{});
+    p.fs_posoff.assign((size_t)nq + p.n_tree, 0);
+    p.max_tree_mw = 1;
+    for (int t = 0; t < p.n_tree; t++) {
+      const int q0 = p.tree_cq_off[t], nqs = p.tree_cq_off[t + 1] - q0, r0 = p.tree_row_off[t];
+      const int nn = p.tree_node_off[t + 1] - p.tree_node_off[t];
+      if (nn > 32767) p.fs_ok[t] = 0;
+      p.max_tree_mw = std::max(p.max_tree_mw, (p.tree_row_off[t + 1] - r0 + 63) / 64 + 1);
+      int pos = 0;
+      std::vector<int32_t> rows;
+      for (int i = 0; i < nqs; i++) {
+        const int c = p.tree_cqs[q0 + i];
+        p.fs_posoff[(size_t)q0 + t + i] = pos;
+        rows.assign(0, 0);
+        for (int r = s->cq_adm_off[c]; r < s->cq_adm_off[c + 1]; r++) rows.push_back(r);
+        auto hkey = [&](int r) { return ((s->adm_flags[r] & KQ_ADM_EVICTED) ? 0u : 0x80000000u) | (uint32_t)p.rank_pos[r]; };
+        std::sort(rows.begin(), rows.end(), [&](int a, int b) { return hkey(a) < hkey(b); });
+        for (int r : rows) {
+          const AdmRec& a = p.adm_rec[r];
+          FsScan& sc = p.fs_scan[(size_t)r0 + pos];
+          FsApply& ap = p.fs_apply[(size_t)r0 + pos];
+          sc.prio = a.prio; sc.qts = a.qts; sc.row = r; sc.cql = (int16_t)i;
+          sc.cbytes = (uint16_t)(32 + 12 * (s->adm_use_off[r + 1] - s->adm_use_off[r]));
+          for (int e = 0; e < CS_RFR; e++) { sc.fr[e] = (int16_t)a.fr[e]; ap.qty[e] = a.qty[e]; }
+          for (int l = 0; l < FS_LV; l++) ap.lp[l] = l < p.plen[c] ? (int16_t)p.node_local[p.path[(size_t)c * KQ_MAXD + l]] : (int16_t)-1;
+          ap.hkey = hkey(r); ap.cq = c; ap.plen = p.plen[c];
+          pos++;
+        }
+      }
+      p.fs_posoff[(size_t)q0 + t + nqs] = pos;
+    }
+    p.fs_kid.assign(N, -1); p.fs_koff.assign(N, 0); p.fs_knc.assign(N, 0); p.fs_knh.assign(N, 0);
+    for (int t = 0; t < p.n_tree; t++) {
+      const int n0 = p.tree_node_off[t], nn = p.tree_node_off[t + 1] - n0;
+      int fill = 0;
+      for (int li = 0; li < nn; li++) {
+        const int n = p.tree_nodes[n0 + li];
+        if (n < nq) continue;
+        const int kx = n - nq;
+        p.fs_koff[n0 + li] = (int16_t)fill;
+        p.fs_knc[n0 + li] = (int16_t)(s->child_cq_off[kx + 1] - s->child_cq_off[kx]);
+        p.fs_knh[n0 + li] = (int16_t)(s->child_cohort_off[kx + 1] - s->child_cohort_off[kx]);
+        for (int i = s->child_cq_off[kx]; i < s->child_cq_off[kx + 1] && fill < nn; i++) p.fs_kid[n0 + fill++] = (int16_t)p.node_local[s->child_cq[i]];
+        for (int i = s->child_cohort_off[kx]; i < s->child_cohort_off[kx + 1] && fill < nn; i++) p.fs_kid[n0 + fill++] = (int16_t)p.node_local[s->child_cohort[i]];
       }
     }
     p.frb_sig.assign((size_t)p.n_tree * p.nfr, 0);
@@ -410,6 +504,7 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
   for (int r = 0; r < p.n_adm; r++)
     for (int e = s->adm_use_off[r]; e < s->adm_use_off[r + 1]; e++)
       if (s->adm_use_qty[e] < 0 || s->adm_use_qty[e] >= ((int64_t)1 << 50)) p.fs_plain_adm = false;
+  if (s->fair_weight) p.h_weight.assign(s->fair_weight, s->fair_weight + N); else p.h_weight.clear();
   build_fair(p, s->subtree_quota, s->usage, s->quota_flags);
   // is the uploaded cohort usage what accumulateFromChild would have produced? (lets kq_cycle_commit re-derive it
   // level by level instead of bubbling every admission one after another)

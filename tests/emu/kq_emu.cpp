@@ -26,6 +26,7 @@ struct EmuBackend {
   const char* error() { return ""; }
   int rot = 0, nom_rot = 0;
   int max_slots() { return 7; }  // small on purpose: exercises the grid-stride loop over heads
+  size_t lds_budget() { return 150 * 1024; }
   void timer_mark(int) {}
   double timer_ms(int, int) { return 0; }
   void launch_tas_classes(const TK& k) { for (int c = 0; c < k.C.n; c++) t_class(k, c); }
@@ -110,9 +111,10 @@ struct EmuBackend {
     rot++;
     last_k = k;
   }
-  void launch_process_fair(const K& k, int n_tree, size_t, int32_t* rank) {
+  void launch_process_fair(const K& k, int n_tree, size_t, size_t, int32_t* rank) {
     std::vector<int64_t> lds(160 * 1024 / 8);
-    const size_t budgets[3] = {lds.size() * 8, sizeof(PRec) + 64, 0};
+    // (a recomputation's victim search borrows the region: whole state in "LDS" / almost none of it / no region at all)
+    const size_t budgets[3] = {lds.size() * 8, sizeof(PRec) + 2048, 0};
     for (int t = 0; t < n_tree; t++) { Wave w{}; process_tree_fair(k, w, t, t, lds.data(), budgets[(t + rot) % 3], 0, 1); }
     rot++;
     for (int i = 0; i < k.H.n; i++) rank[i] = k.X.fs_key[i] >= 0 ? fair_rank(k, i, 0, k.H.n) : 0;
@@ -165,7 +167,8 @@ int kqe_cycle_release(void* e, int age) { return ((EmuEngine*)e)->cycle_release(
 int kqe_snapshot_derive(void* e) { return ((EmuEngine*)e)->snapshot_derive(); }
 int kqe_read_planes(void* e, int64_t* sq, int64_t* us, uint8_t* fl) { return ((EmuEngine*)e)->read_planes(sq, us, fl); }
 void kqe_cs_check(int on) { kq::g_cs_check = on; }
-void kqe_disable_scan_search(void* e, int on) { ((EmuEngine*)e)->cs_disable = on != 0; }
+void kqe_disable_scan_search(void* e, int on) { ((EmuEngine*)e)->cs_disable = on != 0; ((EmuEngine*)e)->fs_disable = on != 0; }
+void kqe_fs_check(int on) { kq::g_fs_check = on; }
 void kqe_force_exact_drs(void* e, int on) { ((EmuEngine*)e)->force_exact_drs = on != 0; }
 int kqe_cycle_run(void* e, const kq_heads* h, kq_decisions* out) { return ((EmuEngine*)e)->cycle_run(h, out); }
 int kqe_heads_put(void* e, const kq_heads* h, int32_t batch) { return batch < 0 ? KQ_EINVAL : ((EmuEngine*)e)->heads_put(h, batch + 1); }
