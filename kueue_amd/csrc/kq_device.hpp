@@ -55,6 +55,16 @@ KQ_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 KQ_DEV int64_t atomic_cas_i64(int64_t* p, int64_t expect, int64_t v) { int64_t o = *p; if (o == expect) *p = v; return o; }
 KQ_DEV int64_t wsum_i64(int64_t v) { return v; }
 KQ_DEV int wbcast_u(int v, int) { return v; }
+// device-wide (agent scope) synchronisation between workgroups: the emulation is one thread
+KQ_DEV uint64_t ag_load_u64(const uint64_t* p) { return *p; }
+KQ_DEV void ag_store_u64(uint64_t* p, uint64_t v) { *p = v; }
+KQ_DEV uint32_t ag_load_u32(const uint32_t* p) { return *p; }
+KQ_DEV bool ag_cas_u64(uint64_t* p, uint64_t expect, uint64_t v) { if (*p != expect) return false; *p = v; return true; }
+KQ_DEV void ag_add_u32(uint32_t* p, uint32_t v) { *p += v; }
+KQ_DEV void ag_release() {}
+KQ_DEV void ag_acquire() {}
+KQ_DEV void ag_pause() {}
+KQ_DEV int wuniform_i32(int v) { return v; }
 KQ_DEV int64_t wprefix_incl_i64(int64_t v) { return v; }
 KQ_DEV int wprefix_incl_i32(int v) { return v; }
 KQ_DEV int64_t wshfl_i64(int64_t v, int) { return v; }
@@ -124,6 +134,19 @@ KQ_DEV int64_t wsum_i64(int64_t x) {
 }
 // broadcast from a lane that is the same for the whole wave (no LDS crossbar round trip)
 KQ_DEV int wbcast_u(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+// device-wide (agent scope) synchronisation between workgroups (helper workgroups of k_process_fair): relaxed loads / stores that
+// bypass the non-coherent caches, fences that publish / pick up everything else
+KQ_DEV uint64_t ag_load_u64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+KQ_DEV void ag_store_u64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+KQ_DEV uint32_t ag_load_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+KQ_DEV bool ag_cas_u64(uint64_t* p, uint64_t expect, uint64_t v) {
+  return __hip_atomic_compare_exchange_strong(p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+KQ_DEV void ag_add_u32(uint32_t* p, uint32_t v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+KQ_DEV void ag_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+KQ_DEV void ag_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+KQ_DEV void ag_pause() { __builtin_amdgcn_s_sleep(8); }
+KQ_DEV int wuniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // inclusive prefix sums over the lanes of the wave (Hillis-Steele on the cross-lane network)
 KQ_DEV int64_t wprefix_incl_i64(int64_t v) {
   const int lane = (int)(threadIdx.x & 63);
@@ -142,6 +165,8 @@ KQ_DEV int clz64(uint64_t m) { return __clzll((long long)m); }
 #endif
 
 namespace kq {
+
+constexpr int CELLS = 64;  // cells evaluated per pass (one lane each on gfx950)
 
 // ------------------------------------------------------------------------------------------------
 // device-visible images
@@ -189,8 +214,8 @@ struct DSnap {
   const FsApply* fs_apply;      // [n_adm]
   const int32_t* fs_posoff;     // [nq + n_tree] per tree at tree_cq_off[t] + t
   const uint8_t* fs_ok;         // [n_tree]
-  const int16_t *fs_kid, *fs_koff, *fs_knc, *fs_knh, *fs_c0, *fs_c1;  // [N] at tree_node_off[t] + local id
-  const int64_t *fs_lq, *fs_sqb;  // [N * nfr]
+  const int16_t *fs_kid, *fs_koff, *fs_knc, *fs_knh, *fs_c0, *fs_c1, *fs_par;  // [N] at tree_node_off[t] + local id
+  const FsQ* fs_q;              // [N * nfr]
   const int64_t* fs_lend;       // [N * nR]
   const double* fs_weight;      // [N]
   const int8_t* cq_res_rg;      // [nq * nR] resource group of the ClusterQueue covering the resource (index inside the ClusterQueue's
@@ -290,6 +315,22 @@ struct DScratch {
   int64_t cs_bytes;
 };
 
+// Helper workgroups of k_process_fair: the victim searches of one flavor scan of a recomputation (PreemptionOracle.SimulatePreemption
+// for every flavor-resource cell that needs one, flavorassigner.go:1375-1384) are independent given the snapshot state. The
+// leader of a tree posts them as a batch; idle workgroups (and the leader itself) take them one by one.
+struct HelpTask { int32_t fr, base_borrow; int64_t val; };
+struct HelpRes { int32_t pm, borrow; int64_t bytes; };
+struct HelpBox {
+  uint64_t hdr;      // batch sequence << 32 | tasks (0 tasks = closed)
+  uint64_t next;     // batch sequence << 32 | next task to hand out
+  uint32_t done;     // tasks of the batch finished
+  uint32_t seq;      // leader only
+  int32_t entry;     // the head being recomputed
+  int32_t pad;
+  HelpTask task[CELLS];
+  HelpRes res[CELLS];
+};
+
 struct K {  // everything a kernel needs
   DSnap S;
   DCfg C;
@@ -316,6 +357,9 @@ struct K {  // everything a kernel needs
   // does not cover (preemption targets, recomputation, non-plain operands, negative reservation, fair sharing).
   long long* root_margin;    // [n_tree * nfr], start = CERT_INF
   int32_t* cert_flags;       // [n_tree]
+  HelpBox* help;             // [n_tree] or null: no helper workgroups in this launch
+  uint32_t* help_quit;       // [1] trees whose leader has finished
+  int help_trees;            // n_tree of the launch (helper workgroups are the blocks after them)
 };
 KQ_DEV bool fs_plain_now(const K& k) { return k.C.fs_plain && !(k.usage_big && *k.usage_big); }
 
@@ -558,7 +602,6 @@ template <class U> KQ_DEV void remove_usage(const DSnap& S, const int32_t* path,
 // ------------------------------------------------------------------------------------------------
 // per-wave scratch (LDS on the device)
 // ------------------------------------------------------------------------------------------------
-constexpr int CELLS = 64;  // cells evaluated per pass (one lane each on gfx950)
 struct Wave {
   // current head
   int h, cq, plen, ps_base, nps;
@@ -613,7 +656,7 @@ struct Wave {
   int nwin2[2], chunk_done, chunk_stop;  // leader -> helper waves of the process workgroup
   // gathered cells of the entry under process: c = u * plen + i
   int64_t g_uw[CELLS], g_un[CELLS];  // g_lq / g_sq / g_bl: see the unions above
-  uint8_t g_dirty[CELLS];
+  union { uint8_t g_dirty[CELLS]; uint8_t cell_task[CELLS]; };  // cell_task (assign_flavors inside a recomputation): task index of a cell whose simulation was posted to K::help, 0xff = none
   int64_t bytes;                  // algorithmic bytes (lane 0 meaningful)
   int usage_dirty;                // set when processEntry added usage to the snapshot plane (fair-sharing DRS cache)
   // A NEGATIVE amount was added to a flavor-resource column of the snapshot (quotaResourcesToReserve has no
@@ -628,6 +671,10 @@ struct Wave {
   // scan-formulated classical search (kq_cs.hpp): LDS region for its arrays (null: use DScratch::cs) and the constants of the
   // preemptor's path per (slot, level): subtree quota, local quota, borrowing limit, usage at the start / at the stopping time
   unsigned char* cs_lds; int cs_lds_bytes;
+#if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
+  long long pacc[16];             // (KQ_PROF) segment cycles of the search in flight
+#endif
+  int help_on, help_tree, help_nt; // recomputation searches of this tree go through K::help
   int pc_region_bytes;            // process kernels: bytes of the workgroup's dynamic LDS a recomputation's searches may borrow
   int64_t cs_sq[CS_NS][CS_LEVELS + 1], cs_lq[CS_NS][CS_LEVELS + 1], cs_bl[CS_NS][CS_LEVELS + 1], cs_u0[CS_NS][CS_LEVELS + 1], cs_uf[CS_NS][CS_LEVELS + 1];
   int64_t cs_nom[CS_NS];
@@ -648,9 +695,16 @@ KQ_DEV bool np_exact_mode(const Wave& w) { return w.np_broken && w.n_pre > 0; }
 #define KQ_TS(k, id) do { long long _t1 = clock64(); if (lane_id() == 0) atomic_add_i64((long long*)(k).prof + (id), _t1 - _t0); _t0 = _t1; } while (0)
 #define KQ_A0() long long _a0 = clock64()
 #define KQ_AS(k, id) do { long long _a1 = clock64(); if (lane_id() == 0) atomic_add_i64((long long*)(k).prof + (id), _a1 - _a0); } while (0)
+// accumulate in the wave's LDS (no global atomic for the next fence to wait on); flushed with KQ_LFLUSH
+#define KQ_LS(w, id) do { long long _a1 = clock64(); if (lane_id() == 0) (w).pacc[id] += _a1 - _a0; _a0 = _a1; } while (0)
+#define KQ_LZERO(w) do { if (lane_id() == 0) for (int _i = 0; _i < 16; _i++) (w).pacc[_i] = 0; } while (0)
+#define KQ_LFLUSH(k, w, base) do { if (lane_id() == 0) for (int _i = 0; _i < 16; _i++) { atomic_add_i64((long long*)(k).prof + (base) + _i, (w).pacc[_i]); (w).pacc[_i] = 0; } } while (0)
 #else
 #define KQ_A0() do {} while (0)
 #define KQ_AS(k, id) do {} while (0)
+#define KQ_LS(w, id) do {} while (0)
+#define KQ_LFLUSH(k, w, base) do {} while (0)
+#define KQ_LZERO(w) do {} while (0)
 #define KQ_T0() do {} while (0)
 #define KQ_TS(k, id) do {} while (0)
 #endif
@@ -1689,6 +1743,107 @@ KQ_DEV void simulate_preemption(const K& k, Wave& w, int slot, const int64_t* us
   *pm = any_same ? PM_PREEMPT : PM_RECLAIM;
 }
 
+// ---- helper workgroups (K::help): a batch of SimulatePreemption calls run by whoever is idle ------------------------------------
+KQ_DEV void load_head(const K& k, Wave& w, int h);
+KQ_DEV uint64_t wuniform_u64(uint64_t v) { return ((uint64_t)(uint32_t)wuniform_i32((int)(v >> 32)) << 32) | (uint32_t)wuniform_i32((int)v); }
+// one task of a batch on wave w, which holds the head of the batch (load_head): a pure function of (head, cell, planes)
+KQ_DEV void help_run_task(const K& k, Wave& w, int slot, HelpBox* box, int idx) {
+  const int64_t b0 = w.bytes;
+  const HelpTask t = box->task[idx];
+  int pm = 0, borrow = 0;
+  simulate_preemption(k, w, slot, k.usage_np, k.preempted, t.fr, t.val, t.base_borrow, &pm, &borrow);
+  wsync();
+  if (lane_id() == 0) { box->res[idx].pm = pm; box->res[idx].borrow = borrow; box->res[idx].bytes = w.bytes - b0; w.bytes = b0; }
+  wsync();
+}
+// take the next task of batch `seq`, -1 = none left (or the batch is over)
+KQ_DEV int help_grab(HelpBox* box, uint32_t seq, int nt) {
+  int idx = -1;
+  if (lane_id() == 0) {
+    uint64_t old = ag_load_u64(&box->next);
+    while ((uint32_t)(old >> 32) == seq && (int)(old & 0xffffffffu) < nt) {
+      if (ag_cas_u64(&box->next, old, old + 1)) { idx = (int)(old & 0xffffffffu); break; }
+      old = ag_load_u64(&box->next);
+    }
+  }
+  return wuniform_i32(idx);
+}
+// leader: post box->task[0..nt), work on it too, return when every result is in box->res
+KQ_DEV void help_exec(const K& k, Wave& w, int slot, HelpBox* box, int nt) {
+  const int lane = lane_id();
+  uint32_t seq = 0;
+  if (lane == 0) {
+    seq = ++box->seq;
+    box->entry = w.h;
+    box->done = 0;
+    ag_store_u64(&box->next, (uint64_t)seq << 32);
+  }
+  seq = (uint32_t)wuniform_i32((int)seq);
+  wsync();
+  ag_release();
+  if (lane == 0) ag_store_u64(&box->hdr, ((uint64_t)seq << 32) | (uint32_t)nt);
+  for (;;) {
+    const int idx = help_grab(box, seq, nt);
+    if (idx < 0) break;
+#ifdef KQ_HOST_EMU
+    if (idx & 1) {  // what a helper workgroup does: a fresh wave, its own scratch slot, the head reloaded
+      Wave hw{};
+      hw.cs_lds = nullptr; hw.cs_lds_bytes = 0;
+      load_head(k, hw, box->entry);
+      help_run_task(k, hw, k.help_trees, box, idx);
+      box->done += 1;
+      continue;
+    }
+#endif
+    help_run_task(k, w, slot, box, idx);
+    ag_release();
+    if (lane == 0) ag_add_u32(&box->done, 1);
+  }
+  int spins = 0;
+  for (;;) {
+    uint32_t d = 0;
+    if (lane == 0) d = ag_load_u32(&box->done);
+    if ((uint32_t)wuniform_i32((int)d) >= (uint32_t)nt) break;
+    ag_pause();
+    if (++spins > (1 << 26)) { set_error(k, KQ_EDEVICE); break; }  // a helper died: fail the cycle instead of hanging the device
+  }
+  ag_acquire();
+  if (lane == 0) ag_store_u64(&box->hdr, (uint64_t)seq << 32);  // closed
+  wsync();
+}
+// helper workgroup: until every tree's leader has finished
+KQ_DEV void helper_main(const K& k, Wave& w, int slot) {
+  const int lane = lane_id();
+  for (;;) {
+    uint32_t q = 0;
+    if (lane == 0) q = ag_load_u32(k.help_quit);
+    if ((uint32_t)wuniform_i32((int)q) >= (uint32_t)k.help_trees) break;
+    bool worked = false;
+    for (int t = 0; t < k.help_trees && !worked; t++) {
+      HelpBox* box = k.help + t;
+      uint64_t hdr = 0;
+      if (lane == 0) hdr = ag_load_u64(&box->hdr);
+      hdr = wuniform_u64(hdr);
+      const int nt = (int)(hdr & 0xffffffffu);
+      if (nt == 0) continue;
+      const int idx = help_grab(box, (uint32_t)(hdr >> 32), nt);
+      if (idx < 0) continue;
+      ag_acquire();
+      int e = 0;
+      if (lane == 0) e = box->entry;
+      e = wuniform_i32(e);
+      load_head(k, w, e);
+      if (lane == 0) w.bytes = 0;
+      wsync();
+      help_run_task(k, w, slot, box, idx);
+      ag_release();
+      if (lane == 0) ag_add_u32(&box->done, 1);
+      worked = true;
+    }
+    if (!worked) ag_pause();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // FlavorAssigner.assignFlavors (flavorassigner.go:708-908, TAS branches excluded)
 // `counts` != NULL : partial admission probe (ScaledTo workload.go:317-340)
@@ -1860,6 +2015,30 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
           w.cell_pm[c] = pm; w.cell_borrow[c] = borrow; w.cell_val[c] = val; w.cell_aux[c] = aux;
         }
         wsync();
+        // ---- recomputation inside k_process_fair: every cell of the pass that needs a SimulatePreemption is posted as one batch ----
+        bool batched = false;
+        HelpBox* hbox = nullptr;
+        if constexpr (!LEAN) {
+          if (w.help_on && nominate_map && k.help) {
+            hbox = k.help + w.help_tree;
+            if (lane == 0) {
+              int nt = 0;
+              for (int jj = 0; jj < nfl; jj++)
+                for (int kk = 0; kk < nf; kk++) {
+                  const int c = jj * nf + kk;
+                  w.cell_task[c] = 0xff;
+                  if (w.cell_pm[jj * nf] == PM_SKIP) continue;
+                  if ((w.cell_pm[c] & 0x7f) == PM_NEEDS) {
+                    hbox->task[nt] = HelpTask{S.rg_flavor[f0 + cs + jj] * nR + w.f_res[kk], w.cell_borrow[c], w.cell_val[c]};
+                    w.cell_task[c] = (uint8_t)nt++;
+                  }
+                }
+              w.help_nt = nt;
+            }
+            wsync();
+            if (w.help_nt > 1) { CSTAT(25, 1); CSTAT(26, w.help_nt); help_exec(k, w, slot, hbox, w.help_nt); batched = true; }
+          }
+        }
         // ---- ordered scan of the pass (uniform) ------------------------------------------
         for (int jj = 0; jj < nfl && !stop; jj++) {
           const int j = cs + jj;
@@ -1889,7 +2068,13 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
                 if (can_search) { if (lane == 0) w.defer_head = 1; wsync(); return; }
                 opm = PM_NOCAND; ob = borrow;  // simulate_preemption with an empty target set
               } else {
-                simulate_preemption(k, w, slot, usage, removed, f * nR + w.f_res[kk], w.cell_val[c], borrow, &opm, &ob);
+                if (batched && w.cell_task[c] != 0xff) {  // the batch evaluated it; only a consumed result is charged
+                  const HelpRes hr = hbox->res[w.cell_task[c]];
+                  opm = hr.pm; ob = hr.borrow;
+                  if (lane == 0) w.bytes += hr.bytes;
+                } else {
+                  simulate_preemption(k, w, slot, usage, removed, f * nR + w.f_res[kk], w.cell_val[c], borrow, &opm, &ob);
+                }
               }
               pm = opm; borrow = ob;
             }
@@ -3440,6 +3625,7 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
     w.pc_lds = lds;
     w.pc_on = (w.pc_ncoh > 0 && have_rec && (size_t)w.pc_ncoh * S.nfr * 16 <= lds_bytes - sizeof(PRec)) ? 1 : 0;
     w.pc_region_bytes = have_rec ? (int)(lds_bytes - sizeof(PRec)) : 0;  // the rows (if resident) are flushed before a recomputation borrows the region
+    w.help_on = k.help ? 1 : 0; w.help_tree = tree;
     *sum = 0; ctl[0] = 0; ctl[1] = -1; ctl[2] = 0;
     w.np_broken = 0; w.n_pre = 0; w.broken[0] = w.broken[1] = w.broken[2] = w.broken[3] = 0; w.n_pre = 0; w.broken[0] = w.broken[1] = w.broken[2] = w.broken[3] = 0;
   }
@@ -3680,7 +3866,7 @@ KQ_DEV void derive_cohort_cell(const DSnap& S, const DDerive& d, int cohort, int
 // ------------------------------------------------------------------------------------------------
 // Start-of-cycle housekeeping as ONE launch: fills and device-to-device copies of 4-byte words (k_prep).
 struct DPrepOp { void* dst; const void* src; uint32_t words; uint32_t fill; };  // src == nullptr: fill
-struct DPrep { int n; DPrepOp op[12]; };
+struct DPrep { int n; DPrepOp op[16]; };
 KQ_DEV void prep_word(const DPrep& p, int o, uint32_t i) {
   const DPrepOp& x = p.op[o];
   ((uint32_t*)x.dst)[i] = x.src ? ((const uint32_t*)x.src)[i] : x.fill;

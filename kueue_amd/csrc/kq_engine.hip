@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(64) void k_nominate(const K* __restrict__ kp, int s
   const K& k = *kp;
   __shared__ Wave w;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
-  if (threadIdx.x == 0) { w.cs_lds = lds_bytes ? dyn_lds : nullptr; w.cs_lds_bytes = (int)lds_bytes; }
+  if (threadIdx.x == 0) { w.cs_lds = lds_bytes ? dyn_lds : nullptr; w.cs_lds_bytes = (int)lds_bytes; w.help_on = 0; }
   __syncthreads();
   const int slot = blockIdx.x;
   const int nd = *k.defer_count;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(PROCESS_THREADS) void k_process(const K* __restrict
   const K& k = *kp;
   __shared__ Wave w;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
-  if (threadIdx.x == 0) { w.cs_lds = nullptr; w.cs_lds_bytes = 0; }  // searches inside k_process use the HBM spill space
+  if (threadIdx.x == 0) { w.cs_lds = nullptr; w.cs_lds_bytes = 0; w.help_on = 0; }  // searches inside k_process use the HBM spill space
   process_tree(k, w, blockIdx.x, blockIdx.x, (int64_t*)dyn_lds, lds_bytes, (int)threadIdx.x, PROCESS_THREADS);
 }
 
@@ -115,8 +116,16 @@ __global__ __launch_bounds__(FAIR_THREADS) void k_process_fair(const K* __restri
   const K& k = *kp;
   __shared__ Wave w;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
-  if (threadIdx.x == 0) { w.cs_lds = nullptr; w.cs_lds_bytes = 0; }
+  if (k.help && (int)blockIdx.x >= k.help_trees) {  // helper workgroup: one wave takes victim searches the leaders post (K::help)
+    if (threadIdx.x >= 64) return;
+    if (threadIdx.x == 0) { w.cs_lds = dyn_lds; w.cs_lds_bytes = (int)lds_bytes; w.help_on = 0; w.bytes = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    helper_main(k, w, blockIdx.x);
+    return;
+  }
+  if (threadIdx.x == 0) { w.cs_lds = nullptr; w.cs_lds_bytes = 0; w.help_on = 0; }
   process_tree_fair(k, w, blockIdx.x, blockIdx.x, (int64_t*)dyn_lds, lds_bytes, (int)threadIdx.x, FAIR_THREADS);
+  if (k.help && threadIdx.x == 0) { ag_release(); ag_add_u32(k.help_quit, 1); }  // this tree needs no more help
 }
 // global iteration positions from the per-tree sequences (kq::fair_rank): 2-D grid like k_order
 __global__ __launch_bounds__(256) void k_fair_rank(const K* __restrict__ kp, int32_t* rank) {
@@ -432,6 +441,14 @@ struct HipBackend {
     chk(hipGetLastError(), "k_process");
   }
   size_t lds_attr = 0, lds_attr_fair = 0;
+  // helper workgroups of k_process_fair (K::help). Off unless KQ_HELP_BLOCKS asks for some: a recomputation under its nomination
+  // mapping only simulates the nominated flavor (2-3 searches per batch at cfg 4f), which is too little to share.
+  int help_blocks(int n_tree) {
+    const char* e = getenv("KQ_HELP_BLOCKS");
+    const int want = e ? atoi(e) : 0;
+    const int free_cu = n_cu - n_tree;
+    return want > 0 && free_cu >= 8 ? std::min(free_cu, want) : 0;  // helpers must not crowd out leaders
+  }
   void launch_process_fair(const K& k, int n_tree, size_t cohort_rows_bytes, size_t search_bytes, int32_t* rank) {
     // [cohort rows of both planes, if they fit | the state of a recomputation's victim search (kq_fs.hpp), which borrows the region][one record]
     const size_t budget = 160 * 1024 - sizeof(Wave) - 256;
@@ -443,7 +460,8 @@ struct HipBackend {
       lds_attr_fair = lds;
     }
     const K* d = put_k(k, 1);
-    hipLaunchKernelGGL(k_process_fair, dim3(n_tree), dim3(FAIR_THREADS), lds, stream, d, (unsigned)lds);
+    const int nblk = n_tree + (k.help ? help_blocks(n_tree) : 0);
+    hipLaunchKernelGGL(k_process_fair, dim3(nblk), dim3(FAIR_THREADS), lds, stream, d, (unsigned)lds);
     const int nb = (k.H.n + 255) / 256;
     chk(hipMemsetAsync(rank, 0, (size_t)k.H.n * sizeof(int32_t), stream), "memset rank");
     hipLaunchKernelGGL(k_fair_rank, dim3(nb, nb), dim3(256), 0, stream, d, rank);

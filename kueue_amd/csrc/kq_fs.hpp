@@ -32,19 +32,21 @@ constexpr int FS_RC = CS_RFR * FS_LV;
 
 struct Fs {
   const K* k; Wave* w; Search* s;
-  int nn, nqs, ncoh, nR, nfr, n0, q0, row0, nrows, mw, nc, npc, wli, plen;
+  int nn, nqs, ncoh, nR, nfr, n0, q0, row0, nrows, mw, nc, npc, wli, plen, tree;
   bool wcopied;
   // state
-  int64_t* psum; double* dval; int32_t* ppos; uint8_t* nflag; uint64_t *m1, *m2, *mq; int8_t* colslot; int64_t** colp;
+  int64_t* psum; double* dval; int32_t* ppos; uint8_t* nflag; uint64_t *m1, *m2, *mq; int8_t* colslot; int64_t* col;
   // static tables of the tree
-  int32_t* posoff; int16_t *kid, *koff, *knc, *knh, *c0, *c1;
+  int32_t* posoff; int16_t *kid, *koff, *knc, *knh, *c0, *c1, *par; int8_t* plv;   // plv: level of the node on the preemptor's path, -1 = not on it
   // context of the row being applied / of the preemptor
-  int64_t **rc_ptr, *rc_lq, *rc_sqb, *rc_lend; double* rc_wt;
+  int32_t* rc_ptr; int64_t *rc_lq, *rc_sqb, *rc_lend; double* rc_wt;   // rc_ptr / pc_ptr: cell codes, see fs_cell
   int64_t* td; int32_t* tp; double* tx; uint64_t* tout;   // staging of one row operation: borrowed-amount deltas / borrowed-cell count deltas per (flavor-resource, level), share terms per (level, resource), result
-  int64_t **pc_ptr, *pc_lq, *pc_sq, *pc_sqb, *pc_bl, *pc_lend; double* pc_wt; int32_t* pc_u;
+  int32_t* pc_ptr; int64_t *pc_lq, *pc_sq, *pc_sqb, *pc_bl, *pc_lend; double* pc_wt; int32_t* pc_u;
   int32_t* tpos;
+  // fields of the Search (it lives in the caller's frame)
+  int64_t* W; const int64_t* usage; const uint8_t* removed; int32_t* trow; uint8_t* treason;
 };
-struct FsRow { int64_t qty[CS_RFR]; int fr[CS_RFR]; int lp[FS_LV]; int plen, row, cbytes, rowbytes; uint32_t hkey; };
+struct FsRow { int64_t qty[CS_RFR]; int fr[CS_RFR]; int res[CS_RFR]; int lp[FS_LV]; int plen, row, cbytes, rowbytes; uint32_t hkey; };
 
 #ifdef KQ_HOST_EMU
 static inline
@@ -59,13 +61,20 @@ size_t fs_bytes(int nn, int nqs, int nR, int nfr, int mw, int ncols) {
   b += al(FS_RC * 8) + al(FS_RC * 4) + al(FS_LV * KQ_MAXR * 8) + al(4 * 8);                        // staging of a row operation
   b += al(FS_PCN * 8) * 5 + al(FS_PCN * 4) + al(FS_LV * KQ_MAXR * 8) + al(FS_LV * 8);              // preemptor context
   b += al(FS_NCMAX * 8);                                                                            // column pointers
-  b += al(nn) + al((size_t)nn * 8) + al((size_t)nn * 4) + al((size_t)nn * 2) * 3;                  // nflag dval ppos c0 c1 kid
+  b += al(nn) * 2 + al((size_t)nn * 8) + al((size_t)nn * 4) + al((size_t)nn * 2) * 4;              // nflag plv dval ppos c0 c1 kid par
   b += al((size_t)(ncoh > 0 ? ncoh : 1) * 2) * 3 + al((size_t)(nqs + 1) * 4) + al(nfr);            // koff knc knh posoff colslot
   b += al((size_t)nn * nR * 8) + al((size_t)mw * 8) * 2;                                           // psum m1 m2
   b += al((size_t)nn * 8) * (size_t)ncols;
   return b + 256;
 }
 
+// Under C.fs_plain every finite amount is below 2^50; "unlimited" constants are clipped to 2^60 when they are gathered, so that
+// the chains below run on plain int64 arithmetic: a clipped value stays far above every finite one through the <= FS_LV
+// additions / subtractions of a chain, hence every comparison and every finite result equals what resources.Amount's
+// saturating operations (a_add / a_sub) give — at a tenth of the instructions (a wave64 VALU instruction costs 4 cycles
+// whatever the number of active lanes, and these chains are nothing but 64-bit VALU work).
+constexpr int64_t FS_CAP = (int64_t)1 << 60;
+KQ_DEV int64_t fs_cap(int64_t v) { return v > FS_CAP ? FS_CAP : v; }
 KQ_DEV uint64_t fs_bits(double v) { union { double d; uint64_t u; } x; x.d = v; return x.u; }
 // total order of Go's cmp.Compare on float64 (NaN lowest, -0 == +0) as an unsigned key
 KQ_DEV uint64_t fs_okey(double v) {
@@ -102,15 +111,19 @@ KQ_DEV void fs_has_update(const Fs& f, int li) {  // one lane
   f.nflag[li] = (uint8_t)((f.nflag[li] & ~8) | (has ? 8 : 0));
 }
 
-KQ_DEV int64_t* fs_cellp(const Fs& f, int li, int fr) {
+// A usage cell of the private state is addressed by a code: >= 0 an index into the cached columns (LDS), < 0 the complement of
+// an index into the private HBM plane.
+KQ_DEV int fs_cell(const Fs& f, int li, int fr) {
   const int sl = f.colslot[fr];
-  return sl >= 0 ? f.colp[sl] + li : f.s->W + (size_t)li * f.nfr + fr;
+  return sl >= 0 ? sl * f.nn + li : ~(li * f.nfr + fr);
 }
+KQ_DEV int64_t fs_ld(const Fs& f, int code) { return code >= 0 ? f.col[code] : f.W[~code]; }
+KQ_DEV void fs_st(const Fs& f, int code, int64_t v) { if (code >= 0) f.col[code] = v; else f.W[~code] = v; }
 // the private HBM plane serves the columns that are not cached: copied from the search's starting state on first use
 KQ_DEV void fs_ensure_w(Fs& f) {
   if (f.wcopied) return;
   const DSnap& S = f.k->S;
-  for (int i = lane_id(); i < f.nn * f.nfr; i += WAVE) f.s->W[i] = f.s->usage[ix(S, S.tree_nodes[f.n0 + i / f.nfr], i % f.nfr)];
+  for (int i = lane_id(); i < f.nn * f.nfr; i += WAVE) f.W[i] = f.usage[ix(S, S.tree_nodes[f.n0 + i / f.nfr], i % f.nfr)];
   wsync();
   f.wcopied = true;
 }
@@ -133,18 +146,33 @@ KQ_DEV void fs_refresh(const Fs& f, int li, const int64_t* lend, double weight) 
 KQ_DEV int64_t fs_cost(const Fs& f, int li) { return (int64_t)f.c0[li] + (f.ppos[li] > 0 ? (int64_t)f.c1[li] : 0); }
 KQ_DEV bool fs_pos_inf(const Fs& f, int li) { return (f.nflag[li] & 2) || f.dval[li] == __builtin_inf(); }
 
+// the candidate scan streams the whole tree once per search: keep it from evicting the records the pops re-read (L2 is 4 MB per XCD)
+KQ_DEV FsScan fs_scan_load(const FsScan* p) {
+#if defined(KQ_HOST_EMU) || !defined(__HIP_DEVICE_COMPILE__)
+  return *p;
+#else
+  typedef long long v2 __attribute__((ext_vector_type(2)));
+  const v2* q = (const v2*)p;
+  const v2 a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1);
+  FsScan r;
+  r.prio = a.x; r.qts = a.y;
+  const uint64_t w0 = (uint64_t)b.x, w1 = (uint64_t)b.y;
+  r.fr[0] = (int16_t)w0; r.fr[1] = (int16_t)(w0 >> 16); r.fr[2] = (int16_t)(w0 >> 32); r.fr[3] = (int16_t)(w0 >> 48);
+  r.row = (int32_t)w1; r.cql = (int16_t)(w1 >> 32); r.cbytes = (uint16_t)(w1 >> 48);
+  return r;
+#endif
+}
 // ---- the row under Remove/AddWorkload ---------------------------------------------------------------------------------------
 KQ_DEV FsRow fs_row_load(const Fs& f, int p) {
   const DSnap& S = f.k->S;
-  const FsScan sc = S.fs_scan[(size_t)f.row0 + p];
   const FsApply ap = S.fs_apply[(size_t)f.row0 + p];
   FsRow r;
   #pragma unroll
-  for (int e = 0; e < CS_RFR; e++) { r.qty[e] = ap.qty[e]; r.fr[e] = sc.fr[e]; }
+  for (int e = 0; e < CS_RFR; e++) { r.qty[e] = ap.qty[e]; r.fr[e] = ap.fr[e]; r.res[e] = ap.fr[e] >= 0 ? (int)ap.res[e] : -1; }
   #pragma unroll
   for (int l = 0; l < FS_LV; l++) r.lp[l] = ap.lp[l];
-  r.plen = ap.plen; r.row = sc.row; r.cbytes = sc.cbytes; r.hkey = ap.hkey;
-  r.rowbytes = 16 * ap.plen * ((sc.cbytes - 32) / 12);
+  r.plen = ap.plen; r.row = ap.row; r.cbytes = ap.cbytes; r.hkey = ap.hkey;
+  r.rowbytes = 16 * (int)ap.plen * (((int)ap.cbytes - 32) / 12);
   return r;
 }
 // constants of every (flavor-resource, level) cell of the row and of its path nodes: one round of independent loads
@@ -158,13 +186,14 @@ KQ_DEV void fs_row_ctx(Fs& f, const FsRow& r) {
     const int u = c / FS_LV, i = c % FS_LV;
     const int fr = fs_sel4(r.fr, u), li = fs_sel4(r.lp, i);
     if (fr < 0 || i >= r.plen) continue;
-    const size_t o = (size_t)(f.n0 + li) * f.nfr + fr;
-    f.rc_lq[c] = S.fs_lq[o]; f.rc_sqb[c] = S.fs_sqb[o];
-    f.rc_ptr[c] = fs_cellp(f, li, fr);
+    const FsQ q = S.fs_q[(size_t)(f.n0 + li) * f.nfr + fr];
+    f.rc_lq[c] = fs_cap(q.lq); f.rc_sqb[c] = fs_cap(q.sqb);
+    f.rc_ptr[c] = fs_cell(f, li, fr);
   }
-  for (int j = lane_id(); j < r.plen * f.nR; j += WAVE) {
-    const int i = j / f.nR, rr = j % f.nR;
-    f.rc_lend[i * KQ_MAXR + rr] = S.fs_lend[(size_t)(f.n0 + fs_sel4(r.lp, i)) * f.nR + rr];
+  for (int j = lane_id(); j < FS_LV * KQ_MAXR; j += WAVE) {
+    const int i = j / KQ_MAXR, rr = j % KQ_MAXR;
+    if (i >= r.plen || rr >= f.nR) continue;
+    f.rc_lend[j] = S.fs_lend[(size_t)(f.n0 + fs_sel4(r.lp, i)) * f.nR + rr];
   }
   for (int i = lane_id(); i < r.plen; i += WAVE) f.rc_wt[i] = S.fs_weight[f.n0 + fs_sel4(r.lp, i)];
   wsync();
@@ -173,11 +202,11 @@ KQ_DEV void fs_row_ctx(Fs& f, const FsRow& r) {
 // Outputs per level: the new value, what the node's borrowed amount (max(0, usage - SubtreeQuota)) and its count of borrowed
 // cells change by. `write`: store the new values.
 struct FsChainOut { int64_t d[FS_LV]; int dp[FS_LV]; };
-KQ_DEV FsChainOut fs_chain(int64_t** ptr, const int64_t* lq, const int64_t* sqb, int plen, int64_t val, bool add, bool write) {
+KQ_DEV FsChainOut fs_chain(const Fs& f, const int32_t* ptr, const int64_t* lq, const int64_t* sqb, int plen, int64_t val, bool add, bool write) {
   int64_t v[FS_LV], nv[FS_LV];
   bool t[FS_LV];
   #pragma unroll
-  for (int i = 0; i < FS_LV; i++) { v[i] = 0; nv[i] = 0; t[i] = false; if (i < plen) v[i] = *ptr[i]; }
+  for (int i = 0; i < FS_LV; i++) { v[i] = 0; nv[i] = 0; t[i] = false; if (i < plen) v[i] = fs_ld(f, ptr[i]); }
   bool go = true;
   #pragma unroll
   for (int i = 0; i < FS_LV; i++) {
@@ -185,12 +214,12 @@ KQ_DEV FsChainOut fs_chain(int64_t** ptr, const int64_t* lq, const int64_t* sqb,
     const int64_t uu = v[i];
     t[i] = true;
     if (add) {
-      const int64_t la = i64max(0, a_sub(lq[i], uu));
-      nv[i] = a_add(uu, val);
-      if (i + 1 < plen && val > la) val = a_sub(val, la); else go = false;
+      const int64_t la = i64max(0, lq[i] - uu);
+      nv[i] = uu + val;
+      if (i + 1 < plen && val > la) val = val - la; else go = false;
     } else {
-      const int64_t stored = a_sub(uu, lq[i]);
-      nv[i] = a_sub(uu, val);
+      const int64_t stored = uu - lq[i];
+      nv[i] = uu - val;
       if (stored <= 0 || i + 1 >= plen) go = false; else val = i64min(val, stored);
     }
   }
@@ -199,10 +228,10 @@ KQ_DEV FsChainOut fs_chain(int64_t** ptr, const int64_t* lq, const int64_t* sqb,
   for (int i = 0; i < FS_LV; i++) {
     o.d[i] = 0; o.dp[i] = 0;
     if (!t[i]) continue;
-    const int64_t ob = i64max(0, a_sub(v[i], sqb[i])), nb = i64max(0, a_sub(nv[i], sqb[i]));
+    const int64_t ob = i64max(0, v[i] - sqb[i]), nb = i64max(0, nv[i] - sqb[i]);
     o.d[i] = nb - ob;
     o.dp[i] = (nb > 0 ? 1 : 0) - (ob > 0 ? 1 : 0);
-    if (write) *ptr[i] = nv[i];
+    if (write) fs_st(f, ptr[i], nv[i]);
   }
   return o;
 }
@@ -213,8 +242,10 @@ KQ_DEV FsChainOut fs_chain(int64_t** ptr, const int64_t* lq, const int64_t* sqb,
 template <class RES>
 KQ_DEV int fs_nodes_update(const Fs& f, const int* lp, int plen, const int64_t* lend, const double* wt, int nch, const RES& res, bool commit, int at, uint64_t* key) {
   const int lane = lane_id();
-  for (int j = lane; j < plen * f.nR; j += WAVE) {
-    const int i = j / f.nR, rr = j % f.nR, li = fs_sel4(lp, i);
+  for (int j = lane; j < FS_LV * KQ_MAXR; j += WAVE) {
+    const int i = j / KQ_MAXR, rr = j % KQ_MAXR;
+    if (i >= plen || rr >= f.nR) continue;
+    const int li = fs_sel4(lp, i);
     int64_t d = 0;
     for (int u = 0; u < nch; u++) if (res(u) == rr) d += f.td[u * FS_LV + i];
     const int64_t sum = f.psum[(size_t)li * f.nR + rr] + d;
@@ -246,7 +277,7 @@ KQ_DEV int fs_nodes_update(const Fs& f, const int* lp, int plen, const int64_t* 
   if (at >= 0) { *key = f.tout[0]; return (int)f.tout[1]; }
   return 0;
 }
-struct FsRowRes { const FsRow* r; int nR; KQ_MDEV int operator()(int u) const { const int fr = fs_sel4(r->fr, u); return fr < 0 ? -1 : fr % nR; } };
+struct FsRowRes { int r0, r1, r2, r3; KQ_MDEV int operator()(int u) const { return u == 0 ? r0 : (u == 1 ? r1 : (u == 2 ? r2 : r3)); } };
 // snapshot.RemoveWorkload / AddWorkload of the row whose context is loaded. commit = false evaluates the share of node `at`
 // after the operation without changing anything.
 KQ_DEV int fs_row_apply(const Fs& f, const FsRow& r, bool add, bool commit, bool count, int at = -1, uint64_t* key = nullptr) {
@@ -255,12 +286,12 @@ KQ_DEV int fs_row_apply(const Fs& f, const FsRow& r, bool add, bool commit, bool
     FsChainOut o;
     #pragma unroll
     for (int i = 0; i < FS_LV; i++) { o.d[i] = 0; o.dp[i] = 0; }
-    if (fr >= 0) o = fs_chain(f.rc_ptr + u * FS_LV, f.rc_lq + u * FS_LV, f.rc_sqb + u * FS_LV, r.plen, fs_sel4(r.qty, u), add, commit);
+    if (fr >= 0) o = fs_chain(f, f.rc_ptr + u * FS_LV, f.rc_lq + u * FS_LV, f.rc_sqb + u * FS_LV, r.plen, fs_sel4(r.qty, u), add, commit);
     #pragma unroll
     for (int i = 0; i < FS_LV; i++) { f.td[u * FS_LV + i] = o.d[i]; f.tp[u * FS_LV + i] = o.dp[i]; }
   }
   wsync();
-  const int z = fs_nodes_update(f, r.lp, r.plen, f.rc_lend, f.rc_wt, CS_RFR, FsRowRes{&r, f.nR}, commit, at, key);
+  const int z = fs_nodes_update(f, r.lp, r.plen, f.rc_lend, f.rc_wt, CS_RFR, FsRowRes{r.res[0], r.res[1], r.res[2], r.res[3]}, commit, at, key);
   if (count && lane_id() == 0) f.w->bytes += r.rowbytes;
   return z;
 }
@@ -278,16 +309,18 @@ KQ_DEV void fs_pc_setup(Fs& f) {
     if (i >= f.plen) continue;
     const int fr = w.s_fr[f.pc_u[j]], n = w.path[i], li = w.cs_pl[i];
     const size_t o = ix(S, n, fr);
-    f.pc_lq[c] = local_quota(S, n, fr); f.pc_sq[c] = S.sq[o]; f.pc_bl[c] = S.bl[o];
-    f.pc_sqb[c] = (S.qflags[o] & KQ_QF_SUBTREE) ? S.sq[o] : INT64_MAX;
-    f.pc_ptr[c] = fs_cellp(f, li, fr);
+    f.pc_lq[c] = fs_cap(local_quota(S, n, fr)); f.pc_sq[c] = fs_cap(S.sq[o]); f.pc_bl[c] = S.bl[o] == KQ_NIL_LIMIT ? KQ_NIL_LIMIT : fs_cap(S.bl[o]);
+    f.pc_sqb[c] = (S.qflags[o] & KQ_QF_SUBTREE) ? fs_cap(S.sq[o]) : FS_CAP;
+    f.pc_ptr[c] = fs_cell(f, li, fr);
   }
-  for (int j = lane_id(); j < f.plen * f.nR; j += WAVE) f.pc_lend[(j / f.nR) * KQ_MAXR + j % f.nR] = S.fs_lend[(size_t)(f.n0 + w.cs_pl[j / f.nR]) * f.nR + j % f.nR];
+  for (int j = lane_id(); j < FS_LV * KQ_MAXR; j += WAVE) {
+    const int i = j / KQ_MAXR, rr = j % KQ_MAXR;
+    if (i < f.plen && rr < f.nR) f.pc_lend[j] = S.fs_lend[(size_t)(f.n0 + w.cs_pl[i]) * f.nR + rr];
+  }
   for (int i = lane_id(); i < f.plen; i += WAVE) f.pc_wt[i] = S.fs_weight[f.n0 + w.cs_pl[i]];
   wsync();
 }
 // cq.SimulateUsageAddition(workloadUsage) / its revert (preemption.go:557, :690-695)
-struct FsPcRes { const Fs* f; KQ_MDEV int operator()(int j) const { return f->w->s_fr[f->pc_u[j]] % f->nR; } };
 KQ_DEV void fs_pc_apply(const Fs& f, bool add) {
   const Wave& w = *f.w;
   int lp[FS_LV];
@@ -301,14 +334,15 @@ KQ_DEV void fs_pc_apply(const Fs& f, bool add) {
       #pragma unroll
       for (int i = 0; i < FS_LV; i++) { o.d[i] = 0; o.dp[i] = 0; }
       const int j = base + q;
-      if (q < nch) o = fs_chain(f.pc_ptr + j * FS_LV, f.pc_lq + j * FS_LV, f.pc_sqb + j * FS_LV, f.plen, w.s_qty[f.pc_u[j]], add, true);
+      if (q < nch) o = fs_chain(f, f.pc_ptr + j * FS_LV, f.pc_lq + j * FS_LV, f.pc_sqb + j * FS_LV, f.plen, w.s_qty[f.pc_u[j]], add, true);
       #pragma unroll
       for (int i = 0; i < FS_LV; i++) { f.td[q * FS_LV + i] = o.d[i]; f.tp[q * FS_LV + i] = o.dp[i]; }
     }
     wsync();
-    const Fs* fp = &f;
-    auto res = [fp, base](int q) { return fp->w->s_fr[fp->pc_u[base + q]] % fp->nR; };
-    fs_nodes_update(f, lp, f.plen, f.pc_lend, f.pc_wt, nch, res, true, -1, nullptr);
+    int rs[CS_RFR];
+    #pragma unroll
+    for (int q = 0; q < CS_RFR; q++) rs[q] = q < nch ? w.s_fr[f.pc_u[base + q]] % f.nR : -1;
+    fs_nodes_update(f, lp, f.plen, f.pc_lend, f.pc_wt, nch, FsRowRes{rs[0], rs[1], rs[2], rs[3]}, true, -1, nullptr);
   }
 }
 // Available (resource_node.go:106-122) of one in-use slot from its gathered path cells
@@ -317,9 +351,9 @@ KQ_DEV int64_t fs_avail(const int64_t* v, const int64_t* lq, const int64_t* sq, 
   #pragma unroll
   for (int i = FS_LV - 1; i >= 0; i--) {
     if (i >= plen) continue;
-    if (i == plen - 1) { a = a_sub(sq[i], v[i]); continue; }
-    if (bl[i] != KQ_NIL_LIMIT) a = i64min(a_add(a_sub(a_sub(sq[i], lq[i]), i64max(0, a_sub(v[i], lq[i]))), bl[i]), a);
-    a = a_add(i64max(0, a_sub(lq[i], v[i])), a);
+    if (i == plen - 1) { a = sq[i] - v[i]; continue; }
+    if (bl[i] != KQ_NIL_LIMIT) a = i64min((sq[i] - lq[i]) - i64max(0, v[i] - lq[i]) + bl[i], a);
+    a = i64max(0, lq[i] - v[i]) + a;
   }
   return a;
 }
@@ -333,7 +367,7 @@ KQ_DEV bool fs_fits(const Fs& f, bool without_own) {
   for (int j = lane_id(); j < f.npc; j += WAVE) {
     int64_t v[FS_LV];
     #pragma unroll
-    for (int i = 0; i < FS_LV; i++) { v[i] = 0; if (i < f.plen) v[i] = *f.pc_ptr[j * FS_LV + i]; }
+    for (int i = 0; i < FS_LV; i++) { v[i] = 0; if (i < f.plen) v[i] = fs_ld(f, f.pc_ptr[j * FS_LV + i]); }
     const int64_t qty = w.s_qty[f.pc_u[j]];
     if (without_own) {
       int64_t val = qty;
@@ -341,8 +375,8 @@ KQ_DEV bool fs_fits(const Fs& f, bool without_own) {
       #pragma unroll
       for (int i = 0; i < FS_LV; i++) {
         if (!go || i >= f.plen) continue;
-        const int64_t stored = a_sub(v[i], f.pc_lq[j * FS_LV + i]);
-        v[i] = a_sub(v[i], val);
+        const int64_t stored = v[i] - f.pc_lq[j * FS_LV + i];
+        v[i] = v[i] - val;
         if (stored <= 0 || i + 1 >= f.plen) go = false; else val = i64min(val, stored);
       }
     }
@@ -409,9 +443,7 @@ KQ_DEV int fs_next_target(const Fs& f, int root) {
       bool elig = false; int z = 0; uint64_t key = 0;
       if (ch >= 0 && !(f.nflag[ch] & 1)) {
         lb += fs_cost(f, ch);
-        bool onpath = false;
-        for (int i = 1; i < f.plen; i++) if (w.cs_pl[i] == ch) onpath = true;
-        if (f.ppos[ch] <= 0 && !onpath) f.nflag[ch] |= 1;
+        if (f.ppos[ch] <= 0 && f.plv[ch] < 1) f.nflag[ch] |= 1;
         else { elig = true; z = (f.nflag[ch] & 2) ? 1 : 0; key = fs_okey(f.dval[ch]); }
       }
       uint64_t m = wballot(elig);
@@ -443,35 +475,37 @@ KQ_DEV int fs_next_target(const Fs& f, int root) {
 }
 // TargetClusterQueueOrdering.Iter (ordering.go:92-127) as a "next" call
 KQ_DEV int fs_ordering_next(const Fs& f) {
-  KQ_A0();
   if (f.plen <= 1) {
-    KQ_AS(*f.k, 47);
     if (!(f.nflag[f.wli] & 1) && fs_cq_has(f, f.wli)) return f.wli;
     return -1;
   }
   const int root = f.w->cs_pl[f.plen - 1];
   while (!(f.nflag[root] & 1)) {
     const int t = fs_next_target(f, root);
-    if (t >= 0) { KQ_AS(*f.k, 47); return t; }
+    if (t >= 0) return t;
   }
-  KQ_AS(*f.k, 47);
   return -1;
 }
 // PopWorkload (ordering.go:84-90) from class bitmap `from`; `to`: the class the row moves to (null: none). Returns the position.
 KQ_DEV int fs_pop(const Fs& f, int li, uint64_t* from, uint64_t* to) {
   CSTAT(13, 1);
-  const int p = fs_first(from, f.posoff[li], f.posoff[li + 1]);
-  wsync();
-  if (lane_id() == 0) { from[p >> 6] &= ~(1ull << (p & 63)); if (to) to[p >> 6] |= 1ull << (p & 63); fs_has_update(f, li); }
-  wsync();
+  int p = 0;
+  if (lane_id() == 0) {  // one lane finds the head, removes it and looks whether anything is left behind it
+    const int b = f.posoff[li + 1];
+    p = fs_first(from, f.posoff[li], b);
+    from[p >> 6] &= ~(1ull << (p & 63));
+    if (to) to[p >> 6] |= 1ull << (p & 63);
+    const bool has = fs_first(from, p + 1, b) >= 0;
+    f.nflag[li] = (uint8_t)((f.nflag[li] & ~8) | (has ? 8 : 0));
+  }
+  p = wuniform_i32(p);
+  wsync_lds();
   return p;
 }
 KQ_DEV bool fs_push_target(Fs& f, int* nt, int row, int p, int reason) {
-  Search& s = *f.s;
   if (*nt >= f.k->X.tgt_cap) { set_error(*f.k, KQ_ECAPACITY); return false; }
-  if (lane_id() == 0) { s.trow[*nt] = row; s.treason[*nt] = (uint8_t)reason; f.tpos[*nt] = p; }
+  if (lane_id() == 0) { f.trow[*nt] = row; f.treason[*nt] = (uint8_t)reason; f.tpos[*nt] = p; }  // read back after later fences only
   (*nt)++;
-  wsync();
   return true;
 }
 
@@ -488,7 +522,7 @@ KQ_DEV bool fs_setup(Search& s, Fs& f) {
   f.ncoh = f.nn - f.nqs; f.nR = S.nR; f.nfr = S.nfr;
   f.row0 = S.tree_row_off[tree]; f.nrows = S.tree_row_off[tree + 1] - f.row0;
   f.mw = (f.nrows + 63) / 64 + 1;
-  f.plen = w.plen; f.wli = S.cq_local[w.cq];
+  f.plen = w.plen; f.wli = S.cq_local[w.cq]; f.tree = tree;
   f.wcopied = false;
   int npc = 0;
   for (int u = 0; u < w.ns; u++) npc += w.s_inu[u] ? 1 : 0;
@@ -516,17 +550,21 @@ KQ_DEV bool fs_setup(Search& s, Fs& f) {
   const size_t need = fs_bytes(f.nn, f.nqs, f.nR, f.nfr, f.mw, nc);
   unsigned char* spill = k.X.cs ? k.X.cs + (size_t)s.slot * (size_t)k.X.cs_bytes : nullptr;
   const bool all_lds = w.cs_lds && (size_t)w.cs_lds_bytes >= need;
-  if (!all_lds && (!spill || (size_t)k.X.cs_bytes < need)) return false;
+#ifdef KQ_HOST_EMU
+  if (!all_lds && (!spill || (size_t)k.X.cs_bytes < need)) return false;  // the emulation also places (part of) the state in the spill space
+#else
+  if (!all_lds) return false;  // on the device the formulation only pays with the whole state in LDS
+#endif
   CsCarve cv{w.cs_lds, w.cs_lds ? w.cs_lds + w.cs_lds_bytes : nullptr, spill};
-  f.rc_ptr = (int64_t**)cv.take(FS_RC * 8); f.rc_lq = (int64_t*)cv.take(FS_RC * 8); f.rc_sqb = (int64_t*)cv.take(FS_RC * 8);
+  f.rc_ptr = (int32_t*)cv.take(FS_RC * 8); f.rc_lq = (int64_t*)cv.take(FS_RC * 8); f.rc_sqb = (int64_t*)cv.take(FS_RC * 8);
   f.rc_lend = (int64_t*)cv.take(FS_LV * KQ_MAXR * 8); f.rc_wt = (double*)cv.take(FS_LV * 8);
   f.td = (int64_t*)cv.take(FS_RC * 8); f.tp = (int32_t*)cv.take(FS_RC * 4); f.tx = (double*)cv.take(FS_LV * KQ_MAXR * 8); f.tout = (uint64_t*)cv.take(4 * 8);
-  f.pc_ptr = (int64_t**)cv.take(FS_PCN * 8); f.pc_lq = (int64_t*)cv.take(FS_PCN * 8); f.pc_sq = (int64_t*)cv.take(FS_PCN * 8);
+  f.pc_ptr = (int32_t*)cv.take(FS_PCN * 8); f.pc_lq = (int64_t*)cv.take(FS_PCN * 8); f.pc_sq = (int64_t*)cv.take(FS_PCN * 8);
   f.pc_sqb = (int64_t*)cv.take(FS_PCN * 8); f.pc_bl = (int64_t*)cv.take(FS_PCN * 8); f.pc_u = (int32_t*)cv.take(FS_PCN * 4);
   f.pc_lend = (int64_t*)cv.take(FS_LV * KQ_MAXR * 8); f.pc_wt = (double*)cv.take(FS_LV * 8);
-  f.colp = (int64_t**)cv.take(FS_NCMAX * 8);
+  (void)cv.take(FS_NCMAX * 8);
   f.nflag = (uint8_t*)cv.take(f.nn); f.dval = (double*)cv.take((size_t)f.nn * 8); f.ppos = (int32_t*)cv.take((size_t)f.nn * 4);
-  f.c0 = (int16_t*)cv.take((size_t)f.nn * 2); f.c1 = (int16_t*)cv.take((size_t)f.nn * 2); f.kid = (int16_t*)cv.take((size_t)f.nn * 2);
+  f.c0 = (int16_t*)cv.take((size_t)f.nn * 2); f.c1 = (int16_t*)cv.take((size_t)f.nn * 2); f.kid = (int16_t*)cv.take((size_t)f.nn * 2); f.par = (int16_t*)cv.take((size_t)f.nn * 2); f.plv = (int8_t*)cv.take(f.nn);
   const size_t nco = (size_t)(f.ncoh > 0 ? f.ncoh : 1);
   f.koff = (int16_t*)cv.take(nco * 2); f.knc = (int16_t*)cv.take(nco * 2); f.knh = (int16_t*)cv.take(nco * 2);
   f.posoff = (int32_t*)cv.take((size_t)(f.nqs + 1) * 4); f.colslot = (int8_t*)cv.take(f.nfr);
@@ -534,13 +572,23 @@ KQ_DEV bool fs_setup(Search& s, Fs& f) {
   f.m1 = (uint64_t*)cv.take((size_t)f.mw * 8); f.m2 = (uint64_t*)cv.take((size_t)f.mw * 8);
   f.mq = f.m1;
   f.tpos = s.cand;
+  f.W = s.W; f.usage = s.usage; f.removed = s.removed; f.trow = s.trow; f.treason = s.treason;
+  f.col = (int64_t*)cv.take((size_t)f.nn * 8 * (size_t)(nc > 0 ? nc : 1));
+#if !defined(KQ_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
+  // every array sits in the workgroup's LDS (checked above): tell the compiler, so that the accesses are ds_* instead of flat_*
+  #define FS_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))
+  FS_LDS(f.psum); FS_LDS(f.dval); FS_LDS(f.ppos); FS_LDS(f.nflag); FS_LDS(f.m1); FS_LDS(f.m2); FS_LDS(f.mq); FS_LDS(f.colslot); FS_LDS(f.col);
+  FS_LDS(f.posoff); FS_LDS(f.kid); FS_LDS(f.koff); FS_LDS(f.knc); FS_LDS(f.knh); FS_LDS(f.c0); FS_LDS(f.c1); FS_LDS(f.par); FS_LDS(f.plv);
+  FS_LDS(f.rc_ptr); FS_LDS(f.rc_lq); FS_LDS(f.rc_sqb); FS_LDS(f.rc_lend); FS_LDS(f.rc_wt); FS_LDS(f.td); FS_LDS(f.tp); FS_LDS(f.tx); FS_LDS(f.tout);
+  FS_LDS(f.pc_ptr); FS_LDS(f.pc_lq); FS_LDS(f.pc_sq); FS_LDS(f.pc_sqb); FS_LDS(f.pc_bl); FS_LDS(f.pc_lend); FS_LDS(f.pc_wt); FS_LDS(f.pc_u);
+  #undef FS_LDS
+#endif
   for (int i = lane; i < f.nfr; i += WAVE) f.colslot[i] = -1;
   wsync();
   #pragma unroll
   for (int q = 0; q < FS_NCMAX; q++) {
     if (q >= nc) continue;
-    int64_t* cp = (int64_t*)cv.take((size_t)f.nn * 8);
-    if (lane == 0) { f.colp[q] = cp; f.colslot[colfr[q]] = (int8_t)q; }
+    if (lane == 0) f.colslot[colfr[q]] = (int8_t)q;
   }
   // tree-local ids of the preemptor's path
   if (lane == 0) for (int i = 0; i < w.plen; i++) w.cs_pl[i] = S.node_local[w.path[i]];
@@ -549,22 +597,22 @@ KQ_DEV bool fs_setup(Search& s, Fs& f) {
 }
 // state of the search = the plane it starts from
 KQ_DEV void fs_init(Fs& f) {
-  const K& k = *f.k; const DSnap& S = k.S; Search& s = *f.s;
+  const K& k = *f.k; const DSnap& S = k.S;
   const int lane = lane_id();
   for (int i = lane; i < f.nn; i += WAVE) {
-    f.nflag[i] = 0;
-    f.c0[i] = S.fs_c0[f.n0 + i]; f.c1[i] = S.fs_c1[f.n0 + i]; f.kid[i] = S.fs_kid[f.n0 + i];
+    f.nflag[i] = 0; f.plv[i] = -1;
+    f.c0[i] = S.fs_c0[f.n0 + i]; f.c1[i] = S.fs_c1[f.n0 + i]; f.kid[i] = S.fs_kid[f.n0 + i]; f.par[i] = S.fs_par[f.n0 + i];
     if (i >= f.nqs) { f.koff[i - f.nqs] = S.fs_koff[f.n0 + i]; f.knc[i - f.nqs] = S.fs_knc[f.n0 + i]; f.knh[i - f.nqs] = S.fs_knh[f.n0 + i]; }
   }
-  for (int i = lane; i <= f.nqs; i += WAVE) f.posoff[i] = S.fs_posoff[(size_t)f.q0 + s.tree + i];
+  for (int i = lane; i <= f.nqs; i += WAVE) f.posoff[i] = S.fs_posoff[(size_t)f.q0 + f.tree + i];
   for (int i = lane; i < f.mw; i += WAVE) { f.m1[i] = 0; f.m2[i] = 0; }
   for (int q = 0; q < f.nc; q++) {
-    int64_t* cp = f.colp[q];
+    int64_t* cp = f.col + (size_t)q * f.nn;
     int fr = 0;
     for (int x = 0; x < f.nfr; x++) if (f.colslot[x] == q) fr = x;
-    for (int i = lane; i < f.nn; i += WAVE) cp[i] = s.usage[ix(S, S.tree_nodes[f.n0 + i], fr)];
+    for (int i = lane; i < f.nn; i += WAVE) cp[i] = f.usage[ix(S, S.tree_nodes[f.n0 + i], fr)];
   }
-  if (s.usage == k.usage) {  // cycle-start plane: k_fs_sums already reduced it
+  if (f.usage == k.usage) {  // cycle-start plane: k_fs_sums already reduced it
     for (int i = lane; i < f.nn * f.nR; i += WAVE) f.psum[i] = k.X.bu_sum[(size_t)S.tree_nodes[f.n0 + i / f.nR] * f.nR + i % f.nR];
     for (int i = lane; i < f.nn; i += WAVE) f.ppos[i] = k.X.bu_pos[S.tree_nodes[f.n0 + i]];
   } else {
@@ -573,7 +621,7 @@ KQ_DEV void fs_init(Fs& f) {
     wsync();
     for (int i = lane; i < f.nn * f.nfr; i += WAVE) {
       const int li = i / f.nfr, fr = i % f.nfr;
-      const int64_t b = a_sub(s.usage[ix(S, S.tree_nodes[f.n0 + li], fr)], S.fs_sqb[(size_t)(f.n0 + li) * f.nfr + fr]);
+      const int64_t b = a_sub(f.usage[ix(S, S.tree_nodes[f.n0 + li], fr)], S.fs_q[(size_t)(f.n0 + li) * f.nfr + fr].sqb);
       if (b > 0) { atomic_add_i64((long long*)&f.psum[(size_t)li * f.nR + fr % f.nR], (long long)b); atomic_add_i32(&f.ppos[li], 1); }
     }
   }
@@ -582,8 +630,21 @@ KQ_DEV void fs_init(Fs& f) {
   wsync();
 }
 
+// getAlmostLCAs (least_common_ancestor.go:27-58): the nodes just below the lowest common ancestor on the preemptor's and on the
+// target ClusterQueue's path (tree-local ids), from the tree's parent table
+KQ_DEV void fs_lcas(const Fs& f, int cand, int* ap, int* at) {
+  const Wave& w = *f.w;
+  int prev = cand, cur = f.par[cand];
+  for (int j = 1; j < FS_LV && cur >= 0; j++) {
+    const int l = f.plv[cur];
+    if (l >= 1) { *ap = w.cs_pl[l - 1]; *at = prev; return; }
+    prev = cur; cur = f.par[cur];
+  }
+  *ap = w.cs_pl[f.plen - 1]; *at = prev;
+}
+
 // fairPreemptions (preemption.go:536-597): same contract as fair_search. false: preconditions not met, nothing was done.
-KQ_DEV bool fair_search_lds(Search& s) {
+KQ_NOINLINE bool fair_search_lds(Search& s) {
   const K& k = *s.k; Wave& w = *s.w; const DSnap& S = k.S;
   const int lane = lane_id();
   const bool same_on = KQ_POL_WITHIN_CQ(w.pol) != KQ_POLICY_NEVER;
@@ -597,6 +658,7 @@ KQ_DEV bool fair_search_lds(Search& s) {
   if (!fs_setup(s, f)) return false;
   w.ntgt = 0;
   KQ_T0();
+  KQ_LZERO(w);
   fs_init(f);
   KQ_TS(k, 41);
   // ---- findCandidates (:633-667) ----
@@ -608,7 +670,7 @@ KQ_DEV bool fair_search_lds(Search& s) {
       take = false;
       if (other_on)
         for (int u = 0; u < w.ns; u++)  // cqIsBorrowing :657-667
-          if (w.s_need[u] && S.nominal[ix(S, c, w.s_fr[u])] < s.usage[ix(S, c, w.s_fr[u])]) take = true;
+          if (w.s_need[u] && S.nominal[ix(S, c, w.s_fr[u])] < f.usage[ix(S, c, w.s_fr[u])]) take = true;
     }
     if (take) f.nflag[i] |= 4;
   }
@@ -622,8 +684,8 @@ KQ_DEV bool fair_search_lds(Search& s) {
         const int p = base + sub + lane;
         bool bit = false;
         if (p < f.nrows) {
-          const FsScan sc = S.fs_scan[(size_t)f.row0 + p];
-          if ((f.nflag[sc.cql] & 4) && !row_removed(s, sc.row)) {
+          const FsScan sc = fs_scan_load(S.fs_scan + (size_t)f.row0 + p);
+          if ((f.nflag[sc.cql] & 4) && !(f.removed && f.removed[sc.row])) {
             cbytes += sc.cbytes;
             const int policy = sc.cql == f.wli ? policy_same : policy_other;
             const bool lower = w.prio > sc.prio;
@@ -665,9 +727,13 @@ KQ_DEV bool fair_search_lds(Search& s) {
     if (gate(k, KQ_GATE_FS_PREEMPT_WITHIN_NOMINAL)) {  // queueWithinNominalInResourcesNeedingPreemption :714-721
       within_nominal = true;
       for (int u = 0; u < w.ns; u++)
-        if (w.s_need[u] && S.nominal[ix(S, w.cq, w.s_fr[u])] < *fs_cellp(f, f.wli, w.s_fr[u])) within_nominal = false;
+        if (w.s_need[u] && S.nominal[ix(S, w.cq, w.s_fr[u])] < fs_ld(f, fs_cell(f, f.wli, w.s_fr[u]))) within_nominal = false;
     }
-    for (int cand = fs_ordering_next(f); cand >= 0 && !fits; cand = fits ? -1 : fs_ordering_next(f)) {
+    while (!fits) {
+      KQ_A0();
+      const int cand = fs_ordering_next(f);
+      KQ_LS(w, 0);
+      if (cand < 0) break;
       if (cand == f.wli || within_nominal) {
         const int p = fs_pop(f, cand, f.m1, nullptr);
         const FsRow r = fs_row_load(f, p);
@@ -678,21 +744,8 @@ KQ_DEV bool fair_search_lds(Search& s) {
         if (fs_fits_fs(f)) fits = true;
         continue;
       }
-      // getAlmostLCAs (least_common_ancestor.go:27-58) from the path of the ClusterQueue's first candidate record
-      int p = fs_first(f.m1, f.posoff[cand], f.posoff[cand + 1]);
-      FsRow r = fs_row_load(f, p);
       int ap = f.wli, at = cand;
-      {
-        bool found = false;
-        #pragma unroll
-        for (int j = 1; j < FS_LV; j++) {
-          if (found || j >= r.plen) continue;
-          int l = -1;
-          for (int i = 1; i < f.plen; i++) if (w.cs_pl[i] == r.lp[j]) l = i;
-          if (l >= 1) { ap = w.cs_pl[l - 1]; at = r.lp[j - 1]; found = true; }
-        }
-        if (!found) { ap = w.cs_pl[f.plen - 1]; at = fs_sel4(r.lp, r.plen - 1); }
-      }
+      fs_lcas(f, cand, &ap, &at);
       const int pz = (f.nflag[ap] & 2) ? 1 : 0, tz = (f.nflag[at] & 2) ? 1 : 0;
       const uint64_t pk = fs_okey(f.dval[ap]), tk = fs_okey(f.dval[at]);
       if (lane == 0) w.bytes += fs_cost(f, ap) + fs_cost(f, at);
@@ -711,24 +764,28 @@ KQ_DEV bool fair_search_lds(Search& s) {
         wsync();
         continue;
       }
-      bool first = true;
+      KQ_LS(w, 7);
       while (fs_cq_has(f, cand)) {
-        p = fs_pop(f, cand, f.m1, nullptr);
-        if (!first) r = fs_row_load(f, p);
-        first = false;
+        const int p = fs_pop(f, cand, f.m1, nullptr);
+        KQ_LS(w, 1);
+        const FsRow r = fs_row_load(f, p);
         fs_row_ctx(f, r);
+        KQ_LS(w, 2);
         // ComputeTargetShareAfterRemoval target.go:67-73: RemoveWorkload, share of the target's side, AddWorkload. The state after
         // the pair is the state before it (plain amounts, see fs_fits), so the removal is only evaluated.
         uint64_t nk = 0;
         const int zb = fs_row_apply(f, r, false, false, false, at, &nk);
+        KQ_LS(w, 3);
         const int nz = zb & 1;
         if (lane == 0) w.bytes += (int64_t)f.c0[at] + ((zb & 2) ? (int64_t)f.c1[at] : 0);
         const bool pass = strategy0 == KQ_FS_LESS_THAN_OR_EQUAL_TO_FINAL_SHARE ? fs_cmp(pz, pk, nz, nk) <= 0 : fs_cmp(pz, pk, tz, tk) < 0;  // strategy.go:41,46
         if (pass) {
           fs_row_apply(f, r, false, true, true);
+          KQ_LS(w, 4);
           if (!fs_push_target(f, &nt, r.row, p, KQ_REASON_IN_COHORT_FAIR_SHARING)) { w.ntgt = 0; return true; }
           tbytes += r.rowbytes;
           if (fs_fits_fs(f)) fits = true;
+          KQ_LS(w, 6);
           break;
         }
         if (lane == 0) f.m2[p >> 6] |= 1ull << (p & 63);  // retryCandidates
@@ -742,24 +799,16 @@ KQ_DEV bool fair_search_lds(Search& s) {
     f.mq = f.m2;
     for (int i = lane; i < f.nn; i += WAVE) { f.nflag[i] &= ~1; if (i < f.nqs) fs_has_update(f, i); }
     wsync();
-    for (int cand = fs_ordering_next(f); cand >= 0 && !fits; cand = fits ? -1 : fs_ordering_next(f)) {
-      const int p = fs_pop(f, cand, f.m2, nullptr);
-      const FsRow r = fs_row_load(f, p);
+    while (!fits) {
+      const int cand = fs_ordering_next(f);
+      if (cand < 0) break;
       int ap = f.wli, at = cand;
-      {
-        bool found = false;
-        #pragma unroll
-        for (int j = 1; j < FS_LV; j++) {
-          if (found || j >= r.plen) continue;
-          int l = -1;
-          for (int i = 1; i < f.plen; i++) if (w.cs_pl[i] == r.lp[j]) l = i;
-          if (l >= 1) { ap = w.cs_pl[l - 1]; at = r.lp[j - 1]; found = true; }
-        }
-        if (!found) { ap = w.cs_pl[f.plen - 1]; at = fs_sel4(r.lp, r.plen - 1); }
-      }
+      fs_lcas(f, cand, &ap, &at);
       const bool passed = fs_cmp((f.nflag[ap] & 2) ? 1 : 0, fs_okey(f.dval[ap]), (f.nflag[at] & 2) ? 1 : 0, fs_okey(f.dval[at])) < 0;
       if (lane == 0) w.bytes += fs_cost(f, ap) + fs_cost(f, at);
+      const int p = fs_pop(f, cand, f.m2, nullptr);
       if (passed) {
+        const FsRow r = fs_row_load(f, p);
         fs_row_ctx(f, r);
         fs_row_apply(f, r, false, true, true);
         if (!fs_push_target(f, &nt, r.row, p, KQ_REASON_IN_COHORT_FAIR_SHARING)) { w.ntgt = 0; return true; }
@@ -786,7 +835,7 @@ KQ_DEV bool fair_search_lds(Search& s) {
       fs_row_ctx(f, r);
       fs_row_apply(f, r, true, true, true);
       if (fs_fits(f, false)) {
-        if (lane == 0) { s.trow[t] = s.trow[nt - 1]; s.treason[t] = s.treason[nt - 1]; f.tpos[t] = f.tpos[nt - 1]; }
+        if (lane == 0) { f.trow[t] = f.trow[nt - 1]; f.treason[t] = f.treason[nt - 1]; f.tpos[t] = f.tpos[nt - 1]; }
         nt--;
         tbytes -= r.rowbytes;
         wsync();
@@ -798,11 +847,12 @@ KQ_DEV bool fair_search_lds(Search& s) {
     if (lane == 0) w.bytes += tbytes;
     KQ_TS(k, 46);
   }
+  KQ_LFLUSH(k, w, 47);
   // callers read the private plane on the preemptor's path (find_height in simulate_preemption)
   for (int c = lane; c < f.npc * FS_LV; c += WAVE) {
     const int j = c / FS_LV, i = c % FS_LV;
     if (i >= f.plen) continue;
-    s.W[(size_t)w.cs_pl[i] * f.nfr + w.s_fr[f.pc_u[j]]] = *f.pc_ptr[c];
+    f.W[(size_t)w.cs_pl[i] * f.nfr + w.s_fr[f.pc_u[j]]] = fs_ld(f, f.pc_ptr[c]);
   }
   wsync();
   return true;

@@ -33,10 +33,11 @@ template <class B> struct EngineT {
   // cycle buffers (grow-only)
   struct Buf { void* p = nullptr; size_t cap = 0; };
   std::vector<Buf*> all_bufs;
-  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_grec, b_cqd, b_defer, b_cert, b_fs[20];
+  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_grec, b_cqd, b_defer, b_cert, b_help, b_fs[20];
   bool force_exact_drs = false;  // tests: take the saturation-safe DRS loops even when the sums would be exact
   bool cs_disable = false;       // tests: classical victim searches always take the candidate-by-candidate walk
   bool fs_disable = false;       // tests: fair-sharing victim searches always take the walk
+  bool help_disable = false;     // tests: no helper workgroups
   Buf b_cs;
   struct HeadBatch { Buf hb[1]; DHeads H{}; int n = 0; size_t nps = 0; int slot_cap = 1; int64_t cycle = 0; bool valid = false; bool plain = true; int max_nps = KQ_MAXPS; };
   std::vector<HeadBatch> batches;  // [0] = transient batch of kq_cycle_run, [1+b] = resident batch b
@@ -113,7 +114,7 @@ template <class B> struct EngineT {
     free_snapshot();
     if (hstage) be.free_host(hstage);
     if (hup) be.free_host(hup);
-    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb, &b_grec, &b_cqd, &b_cs, &b_defer, &b_cert}) if (b->p) be.free(b->p);
+    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb, &b_grec, &b_cqd, &b_cs, &b_defer, &b_cert, &b_help}) if (b->p) be.free(b->p);
     for (auto& b : b_fs) if (b.p) be.free(b.p);
     for (auto& c : ring) for (Buf* b : {&c.cq, &c.use_n, &c.use_fr, &c.use_qty}) if (b->p) be.free(b->p);
     for (auto& hbch : batches) for (auto& b : hbch.hb) if (b.p) be.free(b.p);
@@ -198,6 +199,7 @@ template <class B> struct EngineT {
     upload_fs_rows(); upload_fs_quota();
     S.fs_kid = upload(prep.fs_kid.data(), prep.fs_kid.size()); S.fs_koff = upload(prep.fs_koff.data(), prep.fs_koff.size());
     S.fs_knc = upload(prep.fs_knc.data(), prep.fs_knc.size()); S.fs_knh = upload(prep.fs_knh.data(), prep.fs_knh.size());
+    S.fs_par = upload(prep.fs_par.data(), prep.fs_par.size());
     S.tree_depth = upload(prep.tree_depth.data(), prep.tree_depth.size());
     S.cq_res_rg = upload(prep.cq_res_rg.data(), prep.cq_res_rg.size());
     rc = be.sync();
@@ -222,7 +224,7 @@ template <class B> struct EngineT {
   void upload_fs_quota() {
     reupload(S.fs_ok, prep.fs_ok.data(), prep.fs_ok.size());
     reupload(S.fs_c0, prep.fs_c0.data(), prep.fs_c0.size()); reupload(S.fs_c1, prep.fs_c1.data(), prep.fs_c1.size());
-    reupload(S.fs_lq, prep.fs_lq.data(), prep.fs_lq.size()); reupload(S.fs_sqb, prep.fs_sqb.data(), prep.fs_sqb.size());
+    reupload(S.fs_q, prep.fs_q.data(), prep.fs_q.size());
     reupload(S.fs_lend, prep.fs_lend.data(), prep.fs_lend.size()); reupload(S.fs_weight, prep.fs_weight.data(), prep.fs_weight.size());
   }
   int snapshot_patch(const kq_snapshot* s, uint32_t what) {
@@ -524,7 +526,10 @@ template <class B> struct EngineT {
     if (rsn_win) prep_fill(O.rsn_n, (size_t)n, 0);
     // scratch: one slot per resident wave
     const int slots_nom = std::min(n, be.max_slots());
-    const int slots = std::max(slots_nom, prep.n_tree);
+    // fair sharing: helper workgroups of k_process_fair (K::help) take the victim searches of a recomputation; each needs a scratch slot
+    const bool want_help = cfg.fair_sharing && prep.any_preemption && prep.fs_plain && !fs_disable && !nominate_only && !help_disable;
+    const int n_help = want_help ? be.help_blocks(prep.n_tree) : 0;
+    const int slots = std::max(slots_nom, prep.n_tree + n_help);
     DScratch& X = k.X;
     X.max_tree_nodes = prep.max_tree_nodes; X.max_tree_cqs = std::max(prep.max_tree_cqs, 1); X.max_tree_rows = std::max(prep.max_tree_rows, 1);
     // fair sharing: the private state of a victim search covers every flavor-resource (DRS reads them all)
@@ -572,6 +577,12 @@ template <class B> struct EngineT {
     k.cq_dirty = grow<uint8_t>(b_cqd, std::max(prep.nq, 1));  // cleared per head by k_records
     k.defer_list = grow<int32_t>(b_defer, (size_t)n + 1); k.defer_count = k.defer_list + n;
     prep_fill(k.defer_count, 1, 0);
+    k.help = nullptr; k.help_quit = nullptr; k.help_trees = 0;
+    HelpBox* d_help = nullptr;
+    if (n_help > 0) {  // one box per tree + the quit counter behind them, zeroed every cycle
+      d_help = grow<HelpBox>(b_help, (size_t)prep.n_tree + 1);
+      prep_fill(d_help, ((size_t)prep.n_tree + 1) * sizeof(HelpBox) / 4, 0);
+    }
     {  // sharding certificate (K::root_margin): one slack per (tree, flavor-resource), one flag per tree
       const size_t cells = (size_t)std::max(prep.n_tree, 1) * prep.nfr;
       k.root_margin = (long long*)grow<int64_t>(b_cert, cells + (std::max(prep.n_tree, 1) + 1) / 2);
@@ -616,7 +627,10 @@ template <class B> struct EngineT {
     be.timer_mark(2);
     k.O.stat_bytes = (long long*)(misc + 2);
     if (nominate_only) {}
-    else if (cfg.fair_sharing) be.launch_process_fair(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16, fs_want, rank);
+    else if (cfg.fair_sharing) {
+      if (n_help > 0) { k.help = d_help; k.help_quit = (uint32_t*)(d_help + prep.n_tree); k.help_trees = prep.n_tree; }
+      be.launch_process_fair(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16, fs_want, rank);
+    }
     else be.launch_process(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16);
     be.timer_mark(3);
     last_cycle_n = -1;  // set on the success path only: a failed cycle must not be committable

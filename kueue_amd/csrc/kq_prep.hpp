@@ -54,8 +54,9 @@ struct alignas(8) CsRec { int64_t prio, qts; int32_t row, cql, rowbytes; uint32_
 // candidate scan reads, and what a pop / a snapshot.RemoveWorkload of the row reads (tree-local path of its ClusterQueue included).
 constexpr int FS_LV = 4;       // path levels (ClusterQueue + 3 cohort levels) of a tree the LDS search handles
 struct alignas(16) FsScan { int64_t prio, qts; int16_t fr[CS_RFR]; int32_t row; int16_t cql; uint16_t cbytes; };
-struct alignas(16) FsApply { int64_t qty[CS_RFR]; int16_t lp[FS_LV]; uint32_t hkey; int32_t cq; int32_t plen; int32_t pad[3]; };
-static_assert(sizeof(FsScan) == 32 && sizeof(FsApply) == 64, "FsScan / FsApply are read as 32 / 64 byte records");
+struct alignas(16) FsApply { int64_t qty[CS_RFR]; int16_t lp[FS_LV]; int16_t fr[CS_RFR]; int32_t row; uint32_t hkey; uint16_t cbytes; uint8_t plen; uint8_t res[CS_RFR]; uint8_t pad; };
+struct alignas(16) FsQ { int64_t lq, sqb; };  // localQuota, SubtreeQuota (INT64_MAX where the node has no entry) of one (node, flavor-resource)
+static_assert(sizeof(FsScan) == 32 && sizeof(FsApply) == 64 && sizeof(FsQ) == 16, "FsScan / FsApply / FsQ are read as 32 / 64 / 16 byte records");
 
 struct Prep {
   int nq = 0, nc = 0, N = 0, nF = 0, nR = 0, nfr = 0, n_adm = 0, n_rg = 0;
@@ -101,9 +102,11 @@ struct Prep {
   std::vector<int32_t> fs_posoff;                  // [nq + n_tree] per tree (offset tree_cq_off[t] + t): nqs + 1 position offsets of its ClusterQueues
   std::vector<uint8_t> fs_ok;                      // [n_tree] the tree fits the LDS search (depth, rows with few flavor-resources, index ranges)
   // kq_fs.hpp: tables in tree-node order (index tree_node_off[t] + tree-local node id), so that the search never needs global ids
+  std::vector<int16_t> fs_par;                     // tree-local parent of every node, -1 for the root
   std::vector<int16_t> fs_kid, fs_koff, fs_knc, fs_knh;  // children (tree-local ids; ClusterQueue children first) of every cohort
   std::vector<int16_t> fs_c0, fs_c1;               // algorithmic bytes of one DRS evaluation of the node: always / more when it borrows
-  std::vector<int64_t> fs_lq, fs_sqb, fs_lend;     // [N * nfr] localQuota, SubtreeQuota (INT64_MAX where the node has no entry); [N * nR] lendable
+  std::vector<FsQ> fs_q;                           // [N * nfr]
+  std::vector<int64_t> fs_lend;                    // [N * nR] lendable
   std::vector<double> fs_weight;                   // [N]
   std::vector<double> h_weight;                    // host copy of fair_weight for build_fair after a device derive
   int max_tree_mw = 1;                             // words of a candidate bitmap of the largest tree
@@ -174,14 +177,14 @@ static inline void build_fair(Prep& p, const int64_t* sq, const int64_t* usage, 
     }
   }
   // kq_fs.hpp: the same constants in tree-node order
-  p.fs_lq.assign((size_t)N * nfr, 0); p.fs_sqb.assign((size_t)N * nfr, U); p.fs_lend.assign((size_t)N * p.nR, 0);
+  p.fs_q.assign((size_t)N * nfr, FsQ{0, U}); p.fs_lend.assign((size_t)N * p.nR, 0);
   p.fs_weight.assign(N, 1.0); p.fs_c0.assign(N, 0); p.fs_c1.assign(N, 0);
   for (int tp = 0; tp < N; tp++) {
     const int n = p.tree_nodes[tp];
     for (size_t fr = 0; fr < nfr; fr++) {
       const size_t o = (size_t)n * nfr + fr, d = (size_t)tp * nfr + fr;
-      if (p.h_ll[o] != KQ_NIL_LIMIT) p.fs_lq[d] = std::max<int64_t>(0, a_sub(sq[o], p.h_ll[o]));
-      if (flags[o] & KQ_QF_SUBTREE) p.fs_sqb[d] = sq[o];
+      if (p.h_ll[o] != KQ_NIL_LIMIT) p.fs_q[d].lq = std::max<int64_t>(0, a_sub(sq[o], p.h_ll[o]));
+      if (flags[o] & KQ_QF_SUBTREE) p.fs_q[d].sqb = sq[o];
     }
     for (int r = 0; r < p.nR; r++) p.fs_lend[(size_t)tp * p.nR + r] = p.lendable[(size_t)n * p.nR + r];
     if (!p.h_weight.empty()) p.fs_weight[tp] = p.h_weight[n];
@@ -404,15 +407,16 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
           FsApply& ap = p.fs_apply[(size_t)r0 + pos];
           sc.prio = a.prio; sc.qts = a.qts; sc.row = r; sc.cql = (int16_t)i;
           sc.cbytes = (uint16_t)(32 + 12 * (s->adm_use_off[r + 1] - s->adm_use_off[r]));
-          for (int e = 0; e < CS_RFR; e++) { sc.fr[e] = (int16_t)a.fr[e]; ap.qty[e] = a.qty[e]; }
+          for (int e = 0; e < CS_RFR; e++) { sc.fr[e] = ap.fr[e] = (int16_t)a.fr[e]; ap.qty[e] = a.qty[e]; ap.res[e] = (uint8_t)(a.fr[e] >= 0 ? a.fr[e] % p.nR : 255); }
           for (int l = 0; l < FS_LV; l++) ap.lp[l] = l < p.plen[c] ? (int16_t)p.node_local[p.path[(size_t)c * KQ_MAXD + l]] : (int16_t)-1;
-          ap.hkey = hkey(r); ap.cq = c; ap.plen = p.plen[c];
+          ap.hkey = hkey(r); ap.row = r; ap.cbytes = sc.cbytes; ap.plen = (uint8_t)std::min(p.plen[c], 255);
           pos++;
         }
       }
       p.fs_posoff[(size_t)q0 + t + nqs] = pos;
     }
-    p.fs_kid.assign(N, -1); p.fs_koff.assign(N, 0); p.fs_knc.assign(N, 0); p.fs_knh.assign(N, 0);
+    p.fs_kid.assign(N, -1); p.fs_koff.assign(N, 0); p.fs_knc.assign(N, 0); p.fs_knh.assign(N, 0); p.fs_par.assign(N, -1);
+    for (int tp = 0; tp < N; tp++) { const int n = p.tree_nodes[tp]; if (s->parent[n] >= 0) p.fs_par[tp] = (int16_t)p.node_local[s->parent[n]]; }
     for (int t = 0; t < p.n_tree; t++) {
       const int n0 = p.tree_node_off[t], nn = p.tree_node_off[t + 1] - n0;
       int fill = 0;

@@ -27,6 +27,7 @@ struct EmuBackend {
   int rot = 0, nom_rot = 0;
   int max_slots() { return 7; }  // small on purpose: exercises the grid-stride loop over heads
   size_t lds_budget() { return 150 * 1024; }
+  int help_blocks(int) { return 1; }  // no helper runs in the emulation, but the leader runs every other task the way one would
   void timer_mark(int) {}
   double timer_ms(int, int) { return 0; }
   void launch_tas_classes(const TK& k) { for (int c = 0; c < k.C.n; c++) t_class(k, c); }

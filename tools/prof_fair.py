@@ -23,7 +23,9 @@ names = {0: "generic: load_head", 1: "generic: use list", 34: "generic: first fi
          7: "recompute: row reload", 32: "recompute: fits after", 33: "generic: tail (insert targets, add usage)", 2: "fast entry", 3: "fast entry: stat",
          16: "fair: computeDRS (leader wave)", 17: "fair: barrier wait", 18: "fair: tournament", 19: "fair: pop bookkeeping", 20: "fair: processEntry",
          40: "search: private plane copy", 41: "search: sums + clears", 42: "search: findCandidates", 43: "search: first strategy", 44: "search: second strategy",
-         45: "search: restore (no fit)", 46: "search: fillBack", 47: "  of which ordering.next", 48: "  of which pop + rescan", 49: "  of which apply_row (all)", 50: "  of which fits_fs",
+         45: "search: restore (no fit)", 46: "search: fillBack", 47: "  lds search: ordering.next", 48: "  lds search: pop", 49: "  lds search: row load + context", 50: "  lds search: share after removal (virtual)",
+         51: "  lds search: RemoveWorkload commit", 52: "  lds search: push target", 53: "  lds search: fits", 54: "  lds search: LCAs + shares of both sides",
+         55: "    virtual apply: read row", 56: "    virtual apply: chains", 57: "    virtual apply: fence", 58: "    virtual apply: node update",
          21: "nominate heads Fit (sum cycles)", 22: "nominate heads Preempt (sum cycles)", 23: "nominate heads NoFit (sum cycles)", 24: "n Fit", 25: "n Preempt", 26: "n NoFit", 30: "slowest head"}
 print(f"n_cq {ncq} heads {h.n} wall {dt:.3f}s kernel_ms {d.kernel_ms}")
 for i, nm in names.items():
