@@ -214,6 +214,7 @@ struct DSnap {
   const FsApply* fs_apply;      // [n_adm]
   const int32_t* fs_posoff;     // [nq + n_tree] per tree at tree_cq_off[t] + t
   const uint8_t* fs_ok;         // [n_tree]
+  const uint8_t* rec_ok;        // [n_tree] AdmRec describes every row of the tree completely
   const int16_t *fs_kid, *fs_koff, *fs_knc, *fs_knh, *fs_c0, *fs_c1, *fs_par;  // [N] at tree_node_off[t] + local id
   const FsQ* fs_q;              // [N * nfr]
   const int64_t* fs_lend;       // [N * nR]
@@ -2436,6 +2437,108 @@ KQ_DEV void np_apply_row_restricted(const K& k, Wave& w, int row, bool add) {
   }
   wsync();
 }
+// The same for a list of target rows, in list order (add = false) or in reverse (add = true: the revert). restricted: only the
+// entry's own flavor-resources (entry_fits), else every flavor-resource of the rows (PreemptedWorkloads.Insert). When the tree's
+// row records are complete and the amounts plain, the records of 64 targets are loaded at once (one lane each) and handed to the
+// chain lanes through the scalar unit: per target there is then one round of cell / quota loads instead of six dependent ones,
+// and no fence — a flavor-resource column is always handled by the same lane, in program order.
+KQ_DEV void np_apply_targets(const K& k, Wave& w, const int32_t* trows, int nt, bool add, bool restricted, int tree) {
+  const DSnap& S = k.S;
+  const int lane = lane_id();
+  if (!(fs_plain_now(k) && S.rec_ok && S.rec_ok[tree])) {
+    if (restricted) {
+      for (int q = 0; q < nt; q++) { const int t = add ? nt - 1 - q : q; if (!k.preempted[trows[t]]) np_apply_row_restricted(k, w, trows[t], add); }
+    } else {
+      for (int t = 0; t < nt; t++) {
+        const int row = trows[t];
+        if (lane == 0 && k.preempted[row] == 1) {
+          const int c = S.adm_cq[row];
+          for (int en = S.adm_use_off[row]; en < S.adm_use_off[row + 1]; en++) {
+            UP g = up_plane(k, w, 1, S.adm_use_fr[en]);
+            remove_usage(S, S.path + (size_t)c * KQ_MAXD, S.plen[c], S.adm_use_fr[en], S.adm_use_qty[en], g);
+          }
+        }
+        wsync();
+      }
+    }
+    return;
+  }
+  for (int base = 0; base < nt; base += WAVE) {
+    const int cnt = nt - base < WAVE ? nt - base : WAVE;
+    int row = -1, skip = 1, plen = 0, pn[4] = {0, 0, 0, 0}, rf[CS_RFR];
+    int64_t rq[CS_RFR];
+    #pragma unroll
+    for (int e = 0; e < CS_RFR; e++) { rf[e] = -1; rq[e] = 0; }
+    if (lane < cnt) {
+      row = trows[add ? nt - 1 - (base + lane) : base + lane];
+      skip = restricted ? (k.preempted[row] != 0) : (k.preempted[row] != 1);  // Insert: rows this entry just marked (1); rows marked 3 were in the set already
+      const AdmRec a = S.adm_rec[row];
+      plen = S.plen[a.cq];
+      #pragma unroll
+      for (int e = 0; e < CS_RFR; e++) { rf[e] = a.fr[e]; rq[e] = a.qty[e]; }
+      #pragma unroll
+      for (int i = 0; i < 4; i++) if (i < plen) pn[i] = S.path[(size_t)a.cq * KQ_MAXD + i];
+    }
+    for (int jj = 0; jj < cnt; jj++) {
+      if (wbcast_u(skip, jj)) continue;
+      const int pl = wbcast_u(plen, jj);
+      if (pl > 4) {  // deeper than the gathered path: the row walk
+        const int rw = wbcast_u(row, jj);
+        if (restricted) np_apply_row_restricted(k, w, rw, add);
+        else {
+          if (lane == 0) {
+            const int c = S.adm_cq[rw];
+            for (int en = S.adm_use_off[rw]; en < S.adm_use_off[rw + 1]; en++) { UP g = up_plane(k, w, 1, S.adm_use_fr[en]); remove_usage(S, S.path + (size_t)c * KQ_MAXD, S.plen[c], S.adm_use_fr[en], S.adm_use_qty[en], g); }
+          }
+          wsync();
+        }
+        continue;
+      }
+      int n[4], f[CS_RFR];
+      int64_t q[CS_RFR];
+      #pragma unroll
+      for (int i = 0; i < 4; i++) n[i] = wbcast_u(pn[i], jj);
+      #pragma unroll
+      for (int e = 0; e < CS_RFR; e++) { f[e] = wbcast_u(rf[e], jj); q[e] = (int64_t)(((uint64_t)(uint32_t)wbcast_u((int)(rq[e] >> 32), jj) << 32) | (uint32_t)wbcast_u((int)rq[e], jj)); }
+      const int nl = restricted ? w.nuse : CS_RFR;
+      for (int u = lane; u < nl; u += WAVE) {
+        int fr; int64_t val = 0; bool hit = false;
+        if (restricted) {
+          fr = w.use_fr[u];
+          #pragma unroll
+          for (int e = 0; e < CS_RFR; e++) if (f[e] == fr) { val = q[e]; hit = true; }
+        } else {
+          fr = f[0]; val = q[0];
+          if (u == 1) { fr = f[1]; val = q[1]; }
+          if (u == 2) { fr = f[2]; val = q[2]; }
+          if (u == 3) { fr = f[3]; val = q[3]; }
+          hit = fr >= 0;
+        }
+        if (!hit) continue;
+        UP g = up_plane(k, w, 1, fr);
+        int64_t v[4], lq[4];
+        #pragma unroll
+        for (int i = 0; i < 4; i++) { v[i] = 0; lq[i] = 0; if (i < pl) { v[i] = g.get(n[i]); lq[i] = local_quota(S, n[i], fr); } }
+        bool go = true;
+        #pragma unroll
+        for (int i = 0; i < 4; i++) {  // addUsage / removeUsage resource_node.go:144-165
+          if (!go || i >= pl) continue;
+          const int64_t uu = v[i];
+          if (add) {
+            const int64_t la = i64max(0, a_sub(lq[i], uu));
+            g.set(n[i], a_add(uu, val));
+            if (i + 1 < pl && val > la) val = a_sub(val, la); else go = false;
+          } else {
+            const int64_t stored = a_sub(uu, lq[i]);
+            g.set(n[i], a_sub(uu, val));
+            if (stored <= 0 || i + 1 >= pl) go = false; else val = i64min(val, stored);
+          }
+        }
+      }
+    }
+  }
+  wsync();
+}
 // Columns of usage_np := usage_work with every row marked in k.preempted removed, ascending row
 // (SimulateWorkloadUsageRemoval snapshot.go:80-100 over the canonical order). `use_only`: the entry's own
 // flavor-resources (w.use_fr), else every broken column. Marked rows are found with a ballot scan over the tree's
@@ -2499,7 +2602,7 @@ KQ_DEV bool entry_fits(const K& k, Wave& w, const int32_t* trows, int nt, bool q
     if (lane_id() == 0) w.bytes += (int64_t)w.nuse * 40 * w.plen;
     return ok;
   }
-  for (int t = 0; t < nt; t++) if (!k.preempted[trows[t]]) np_apply_row_restricted(k, w, trows[t], false);
+  np_apply_targets(k, w, trows, nt, false, true, tree);
   bool bad = false;
   for (int u = lane_id(); u < w.nuse; u += WAVE) {
     UP g = up_plane(k, w, 1, w.use_fr[u]);
@@ -2507,7 +2610,7 @@ KQ_DEV bool entry_fits(const K& k, Wave& w, const int32_t* trows, int nt, bool q
   }
   bool ok = wballot(bad) == 0;
   wsync();
-  for (int t = nt - 1; t >= 0; t--) if (!k.preempted[trows[t]]) np_apply_row_restricted(k, w, trows[t], true);
+  np_apply_targets(k, w, trows, nt, true, true, tree);
   if (lane_id() == 0) w.bytes += (int64_t)w.nuse * 40 * w.plen;
   return ok;
 }
@@ -2739,18 +2842,25 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
   if (!done && !fits_ok) { status = KQ_ST_SKIPPED; skip = KQ_SKIP_NO_LONGER_FITS; done = true; }
   if (!done) {
     // preemptedWorkloads.Insert(targets): rows leave usage_np for the rest of the cycle
-    for (int t = 0; t < nt; t++) {
-      int row = trows[t];
-      if (lane == 0 && !k.preempted[row]) {
-        k.preempted[row] = 1;
-        w.n_pre++;
-        k.cq_rm_bytes[S.adm_cq[row]] += 32 + 12 * (S.adm_use_off[row + 1] - S.adm_use_off[row]);
-        int c = S.adm_cq[row];
-        for (int en = S.adm_use_off[row]; en < S.adm_use_off[row + 1]; en++) {
-          UP g = up_plane(k, w, 1, S.adm_use_fr[en]);
-          remove_usage(S, S.path + (size_t)c * KQ_MAXD, S.plen[c], S.adm_use_fr[en], S.adm_use_qty[en], g);
+    {  // rows already in the set are marked 3 for the time of the removal pass, new ones 1
+      int fresh = 0;
+      for (int base = 0; base < nt; base += WAVE) {
+        const int t = base + lane;
+        bool isnew = false;
+        if (t < nt) {
+          const int row = trows[t];
+          if (!k.preempted[row]) {
+            isnew = true;
+            k.preempted[row] = 1;
+            atomic_add_i32(&k.cq_rm_bytes[S.adm_cq[row]], 32 + 12 * (S.adm_use_off[row + 1] - S.adm_use_off[row]));
+          } else if (k.preempted[row] == 1) k.preempted[row] = 3;
         }
+        fresh += popc64(wballot(isnew));
       }
+      if (lane == 0) w.n_pre += fresh;
+      wsync();
+      np_apply_targets(k, w, trows, nt, false, false, tree);
+      for (int t = lane; t < nt; t += WAVE) if (k.preempted[trows[t]] == 3) k.preempted[trows[t]] = 1;
       wsync();
     }
     if (quota_usage) entry_add_usage(k, w, w.use_qty);

@@ -604,6 +604,8 @@ KQ_DEV void fs_init(Fs& f) {
     f.c0[i] = S.fs_c0[f.n0 + i]; f.c1[i] = S.fs_c1[f.n0 + i]; f.kid[i] = S.fs_kid[f.n0 + i]; f.par[i] = S.fs_par[f.n0 + i];
     if (i >= f.nqs) { f.koff[i - f.nqs] = S.fs_koff[f.n0 + i]; f.knc[i - f.nqs] = S.fs_knc[f.n0 + i]; f.knh[i - f.nqs] = S.fs_knh[f.n0 + i]; }
   }
+  wsync();
+  for (int i = lane; i < f.plen; i += WAVE) f.plv[f.w->cs_pl[i]] = (int8_t)i;
   for (int i = lane; i <= f.nqs; i += WAVE) f.posoff[i] = S.fs_posoff[(size_t)f.q0 + f.tree + i];
   for (int i = lane; i < f.mw; i += WAVE) { f.m1[i] = 0; f.m2[i] = 0; }
   for (int q = 0; q < f.nc; q++) {

@@ -218,6 +218,7 @@ template <class B> struct EngineT {
   }
   // static structures of the LDS-resident fair victim search: the part that follows the admitted set / the part that follows the quotas
   void upload_fs_rows() {
+    reupload(S.rec_ok, prep.rec_ok.data(), prep.rec_ok.size());
     reupload(S.fs_scan, prep.fs_scan.data(), prep.fs_scan.size()); reupload(S.fs_apply, prep.fs_apply.data(), prep.fs_apply.size());
     reupload(S.fs_posoff, prep.fs_posoff.data(), prep.fs_posoff.size());
   }

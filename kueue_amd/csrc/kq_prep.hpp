@@ -100,6 +100,7 @@ struct Prep {
   std::vector<FsScan> fs_scan;
   std::vector<FsApply> fs_apply;
   std::vector<int32_t> fs_posoff;                  // [nq + n_tree] per tree (offset tree_cq_off[t] + t): nqs + 1 position offsets of its ClusterQueues
+  std::vector<uint8_t> rec_ok;                     // [n_tree] every admitted row of the tree has at most CS_RFR distinct flavor-resources: AdmRec describes it completely
   std::vector<uint8_t> fs_ok;                      // [n_tree] the tree fits the LDS search (depth, rows with few flavor-resources, index ranges)
   // kq_fs.hpp: tables in tree-node order (index tree_node_off[t] + tree-local node id), so that the search never needs global ids
   std::vector<int16_t> fs_par;                     // tree-local parent of every node, -1 for the root
@@ -355,7 +356,7 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
     for (int t = 0; t < p.n_tree; t++)
       for (int i = p.frb_off[(size_t)t * p.nfr]; i < p.frb_off[(size_t)(t + 1) * p.nfr]; i++) p.frbr[i] = p.tree_rows[p.tree_row_off[t] + p.frb[i]];
     p.adm_rec.assign(p.n_adm, AdmRec{});
-    p.fs_ok.assign(p.n_tree, 1);
+    p.fs_ok.assign(p.n_tree, 1); p.rec_ok.assign(p.n_tree, 1);
     for (int c = 0; c < nq; c++) if (p.depth[c] > CS_LEVELS) p.cs_ok[p.tree_of[c]] = 0;
     for (int r = 0; r < p.n_adm; r++) {
       AdmRec& a = p.adm_rec[r];
@@ -377,7 +378,7 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
         for (int e = s->adm_use_off[r]; e < s->adm_use_off[r + 1]; e++) {
           bool in = false;
           for (int q = 0; q < CS_RFR; q++) if (a.fr[q] == s->adm_use_fr[e]) in = true;
-          if (!in) p.fs_ok[p.tree_of[c]] = 0;
+          if (!in) { p.fs_ok[p.tree_of[c]] = 0; p.rec_ok[p.tree_of[c]] = 0; }
         }
       }
     }
