@@ -110,7 +110,7 @@ KQ_DEV void cs_level_pass(CsCtx& c, int dd, int limit_t, bool finalize) {
     const bool in = q < M;
     const CsEnt e = e_next;
     { const int qn = q + WAVE; e_next = ents[qn < M ? qn : M - 1]; }
-    const int node_prev = wshfl_i32(e.node, lane > 0 ? lane - 1 : 0);
+    const int node_prev = wshift_up_i32(e.node);
     const bool head = in && (lane == 0 ? e.node != carry_node : e.node != node_prev);
     const uint64_t H = wballot(head);
     const uint64_t below = H & (lane == 63 ? ~0ull : ((2ull << lane) - 1));
@@ -153,9 +153,9 @@ KQ_DEV void cs_level_pass(CsCtx& c, int dd, int limit_t, bool finalize) {
       ua[u] = a_sub(u0, inc);
       if (((c.needm >> u) & 1) && sqv < ub) within = false;
       outv[u] = cs_B(ub, lq) - cs_B(ua[u], lq);
-      carry[u] = wbcast(inc, WAVE - 1);
+      carry[u] = wbcast_u(inc, WAVE - 1);
     }
-    carry_node = wbcast(e.node, WAVE - 1);
+    carry_node = wbcast_u(e.node, WAVE - 1);
     const bool dead = part && within;
     if (!finalize && dead && in && c.alive[j]) c.alive[j] = 0;
     #pragma unroll
@@ -166,8 +166,8 @@ KQ_DEV void cs_level_pass(CsCtx& c, int dd, int limit_t, bool finalize) {
     }
     if (finalize) {
       // the node's usage after its last counted removal: written by the last entry of the segment
-      const int nsh = wshfl_i32(e.node, lane < WAVE - 1 ? lane + 1 : lane);
-      const int nfirst = wbcast(e_next.node, 0);  // first entry of the next chunk
+      const int nsh = wshift_down_i32(e.node);
+      const int nfirst = wbcast_u(e_next.node, 0);  // first entry of the next chunk
       int nxt = -9;
       if (q + 1 < M) nxt = lane == WAVE - 1 ? nfirst : nsh;
       #pragma unroll
@@ -370,7 +370,7 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
           if (l >= plen || wballot(al && L == l) == 0) continue;
           const int64_t P = wprefix_incl_i64(L == l ? d : 0);
           A[l] = cA[u][l] + P;
-          cA[u][l] = wbcast(A[l], WAVE - 1);
+          cA[u][l] = wbcast_u(A[l], WAVE - 1);
         }
         PathU uv;
         uv.v[0] = a_sub(w.cs_u0[u][0], A[0]);
@@ -385,13 +385,13 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
       }
       const int na = cN + wprefix_incl_i32(al ? 1 : 0);
       const int64_t rbs = cRB + wprefix_incl_i64(al ? (int64_t)c.rb[j] : 0);
-      cN = wbcast(na, WAVE - 1); cRB = wbcast(rbs, WAVE - 1);
+      cN = wbcast_u(na, WAVE - 1); cRB = wbcast_u(rbs, WAVE - 1);
       const uint64_t fm = wballot(fit);
       if (fm) {
         const int b = ffs64(fm);
         tstar = base + b;
-        nt = wbcast(na, b);
-        rb_removed = wbcast(rbs, b);
+        nt = wbcast_u(na, b);
+        rb_removed = wbcast_u(rbs, b);
         #pragma unroll
         for (int u = 0; u < CS_NS; u++) {
           #pragma unroll

@@ -55,6 +55,7 @@ KQ_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 KQ_DEV int64_t atomic_cas_i64(int64_t* p, int64_t expect, int64_t v) { int64_t o = *p; if (o == expect) *p = v; return o; }
 KQ_DEV int64_t wsum_i64(int64_t v) { return v; }
 KQ_DEV int wbcast_u(int v, int) { return v; }
+KQ_DEV int64_t wbcast_u(int64_t v, int) { return v; }
 // device-wide (agent scope) synchronisation between workgroups: the emulation is one thread
 KQ_DEV uint64_t ag_load_u64(const uint64_t* p) { return *p; }
 KQ_DEV void ag_store_u64(uint64_t* p, uint64_t v) { *p = v; }
@@ -68,6 +69,8 @@ KQ_DEV int wuniform_i32(int v) { return v; }
 KQ_DEV int64_t wprefix_incl_i64(int64_t v) { return v; }
 KQ_DEV int wprefix_incl_i32(int v) { return v; }
 KQ_DEV int64_t wshfl_i64(int64_t v, int) { return v; }
+KQ_DEV int wshift_up_i32(int v) { return v; }
+KQ_DEV int wshift_down_i32(int v) { return v; }
 KQ_DEV int wshfl_i32(int v, int) { return v; }
 KQ_DEV int clz64(uint64_t m) { return __builtin_clzll(m); }
 static int g_emu_pipeline = 0;  // tests: emulate the helper waves of k_process prefetching one chunk ahead
@@ -134,6 +137,10 @@ KQ_DEV int64_t wsum_i64(int64_t x) {
 }
 // broadcast from a lane that is the same for the whole wave (no LDS crossbar round trip)
 KQ_DEV int wbcast_u(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+KQ_DEV int64_t wbcast_u(int64_t v, int src) {
+  const int l = __builtin_amdgcn_readfirstlane(src);
+  return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, l));
+}
 // device-wide (agent scope) synchronisation between workgroups (helper workgroups of k_process_fair): relaxed loads / stores that
 // bypass the non-coherent caches, fences that publish / pick up everything else
 KQ_DEV uint64_t ag_load_u64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -147,17 +154,37 @@ KQ_DEV void ag_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
 KQ_DEV void ag_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 KQ_DEV void ag_pause() { __builtin_amdgcn_s_sleep(8); }
 KQ_DEV int wuniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
-// inclusive prefix sums over the lanes of the wave (Hillis-Steele on the cross-lane network)
-KQ_DEV int64_t wprefix_incl_i64(int64_t v) {
-  const int lane = (int)(threadIdx.x & 63);
-  for (int o = 1; o < 64; o <<= 1) { const int64_t t = (int64_t)__shfl_up((long long)v, o, 64); if (lane >= o) v += t; }
-  return v;
+// inclusive prefix sums over the lanes of the wave on the DPP network: Hillis-Steele inside each 16-lane row (row_shr 1, 2, 4, 8,
+// lanes without a source add 0), then the row totals travel with row_bcast:15 (rows 1 and 3 take lane 15 of the row before) and
+// row_bcast:31 (rows 2 and 3 take lane 31). 6 steps of two v_mov_dpp + one 64-bit add instead of 6 x 2 ds_bpermute round trips:
+// the scan-formulated victim search is made of these.
+template <int CTRL, int ROWMASK> KQ_DEV uint64_t dpp0_u64(uint64_t v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, ROWMASK, 0xf, false);
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+KQ_DEV int64_t wprefix_incl_i64(int64_t x) {
+  uint64_t v = (uint64_t)x;
+  v += dpp0_u64<0x111, 0xf>(v);
+  v += dpp0_u64<0x112, 0xf>(v);
+  v += dpp0_u64<0x114, 0xf>(v);
+  v += dpp0_u64<0x118, 0xf>(v);
+  v += dpp0_u64<0x142, 0xa>(v);
+  v += dpp0_u64<0x143, 0xc>(v);
+  return (int64_t)v;
 }
 KQ_DEV int wprefix_incl_i32(int v) {
-  const int lane = (int)(threadIdx.x & 63);
-  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
   return v;
 }
+// the value of the lane before / after (lane 0 / lane 63 keep their own): one DPP move across the whole wave
+KQ_DEV int wshift_up_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+KQ_DEV int wshift_down_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
 KQ_DEV int64_t wshfl_i64(int64_t v, int src) { return (int64_t)__shfl((long long)v, src, 64); }
 KQ_DEV int wshfl_i32(int v, int src) { return __shfl(v, src, 64); }
 KQ_DEV int clz64(uint64_t m) { return __clzll((long long)m); }
@@ -3699,9 +3726,9 @@ KQ_DEV int tournament_cohort(const K& k, int slot, int x, const int32_t* win, co
     mn = wmin_u64(in ? key.k4 : ~0ull); in = in && key.k4 == mn;
     const int b = ffs64(wballot(in));  // ties keep the first candidate
     FsKey wk;
-    wk.k1 = (uint64_t)wbcast((int64_t)key.k1, b); wk.k2 = (uint64_t)wbcast((int64_t)key.k2, b);
-    wk.k3 = (uint64_t)wbcast((int64_t)key.k3, b); wk.k4 = (uint64_t)wbcast((int64_t)key.k4, b);
-    const int wc = wbcast(cnd, b);
+    wk.k1 = (uint64_t)wbcast_u((int64_t)key.k1, b); wk.k2 = (uint64_t)wbcast_u((int64_t)key.k2, b);
+    wk.k3 = (uint64_t)wbcast_u((int64_t)key.k3, b); wk.k4 = (uint64_t)wbcast_u((int64_t)key.k4, b);
+    const int wc = wbcast_u(cnd, b);
     if (best < 0 || fskey_less(wk, bk)) { best = wc; bk = wk; }  // an earlier chunk's winner keeps ties
   }
   return best;
