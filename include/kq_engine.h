@@ -351,6 +351,16 @@ int  kq_pending_set_lq_usage(kq_engine* e, int32_t n_lq, const double* usage);
 /* queueInadmissibleWorkloads for the listed ClusterQueues (cq == NULL: all) — what requeueWorkloadsCohort does for the root
  * cohorts whose quota was freed (inadmissible_workloads.go:112-175). */
 int  kq_pending_queue_inadmissible(kq_engine* e, int32_t n, const int32_t* cq);
+/* PushOrUpdate (cluster_queue.go:379-428) of workloads that were not pending before: they are APPENDED to the resident set — the
+ * first one gets index *first_index (= the previous count), existing indices do not move — and merged into the heap order of their
+ * ClusterQueues. A new workload starts in the heap, or among the inadmissible when its ClusterQueue is BestEffortFIFO, its
+ * scheduling hash is known and its equivalence class was bulk-moved since the ClusterQueue's last queueInadmissibleWorkloads
+ * (:419-425, hashToBulkMoveReason). `more` has the layout of kq_pending_put's argument (LocalQueue indices iff the set has them).
+ * Not between kq_pending_heads and kq_pending_apply. */
+int  kq_pending_add(kq_engine* e, const kq_pending* more, int32_t* first_index);
+/* ClusterQueue.Delete (cluster_queue.go:488-512): the workloads leave the pending set (deleted, finished, admitted by another
+ * scheduler). Not between kq_pending_heads and kq_pending_apply. */
+int  kq_pending_delete(kq_engine* e, int32_t n, const int32_t* wl);
 /* state[W] (KQ_WL_*) and counts[4] per state; both optional. */
 int  kq_pending_read_state(kq_engine* e, uint8_t* state, int32_t* counts);
 

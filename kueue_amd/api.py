@@ -630,6 +630,20 @@ class Pending:
             self._struct = p
         return self._struct
 
+    def extended(self, more: "Pending") -> "Pending":
+        """The table after kq_pending_add(more): `more`'s workloads appended (indices of the existing ones do not move)."""
+        a, b = self.heads.arrays, more.heads.arrays
+        cat = lambda k: np.concatenate([a[k], b[k]])
+        off = lambda k: np.concatenate([a[k], b[k][1:] + a[k][-1]]).astype(np.int32)
+        arr = {k: cat(k) for k in ("cq", "priority", "queue_ts", "flags", "ps_count", "ps_min_count", "req_res", "req_qty", "ps_flavor_ok",
+                                   "ps_last_tried", "last_generation", "last_cycle", "last_hash", "hash")}
+        arr["ps_off"] = off("ps_off"); arr["ps_req_off"] = off("ps_req_off")
+        h = Heads.from_arrays(self.snap, arr, cycle=self.heads.cycle)
+        if self.heads.workloads is not None and more.heads.workloads is not None:
+            h.workloads = list(self.heads.workloads) + list(more.heads.workloads)
+        lq = None if self.lq is None else np.concatenate([self.lq, more.lq])
+        return Pending(h, uid_rank=np.concatenate([self.uid_rank, more.uid_rank]), lq=lq, n_lq=self.n_lq)
+
     def heads_of(self, wl: np.ndarray, cycle: int) -> "Heads":
         """The kq_heads batch of the workloads `wl` with their STATIC columns (resume state left at its initial value)."""
         return self.heads.subset(wl, cycle)

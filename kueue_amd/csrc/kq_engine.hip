@@ -231,6 +231,8 @@ __global__ __launch_bounds__(64) void k_pend_gather(DPend D, DGather G) { if ((i
 __global__ __launch_bounds__(64) void k_pend_apply(DPend D, DSnap S, DOut O, DHeads H, uint32_t gates, int64_t cycle) {
   pend_apply_head(D, S, O, H, gates, cycle, blockIdx.x);
 }
+__global__ __launch_bounds__(64) void k_pend_add_fix(DPend D, DSnap S, int first) { pend_add_fix(D, S, first + (int)blockIdx.x); }
+__global__ __launch_bounds__(256) void k_pend_delete(DPend D, const int32_t* list, int n) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) pend_delete(D, list, i); }
 __global__ __launch_bounds__(64) void k_pend_qi(DPend D, const int32_t* list) { pend_queue_inadmissible(D, list ? list[blockIdx.x] : (int)blockIdx.x); }
 
 __global__ __launch_bounds__(256) void k_pend_release_mark(DSnap S, int32_t* tree_stamp, const int32_t* cq, const int32_t* use_n, int n, int32_t stamp) {
@@ -387,6 +389,14 @@ struct HipBackend {
   void launch_pend_apply(const DPend& D, const DSnap& S, const DOut& O, const DHeads& H, uint32_t gates, int64_t cycle, int n) {
     hipLaunchKernelGGL(k_pend_apply, dim3(n), dim3(64), 0, stream, D, S, O, H, gates, cycle);
     chk(hipGetLastError(), "k_pend_apply");
+  }
+  void launch_pend_add_fix(const DPend& D, const DSnap& S, int first, int n) {
+    if (n > 0) hipLaunchKernelGGL(k_pend_add_fix, dim3(n), dim3(64), 0, stream, D, S, first);
+    chk(hipGetLastError(), "k_pend_add_fix");
+  }
+  void launch_pend_delete(const DPend& D, const int32_t* list, int n) {
+    if (n > 0) hipLaunchKernelGGL(k_pend_delete, dim3((n + 255) / 256), dim3(256), 0, stream, D, list, n);
+    chk(hipGetLastError(), "k_pend_delete");
   }
   void launch_pend_qi(const DPend& D, const int32_t* list, int n) {
     if (n > 0) hipLaunchKernelGGL(k_pend_qi, dim3(n), dim3(64), 0, stream, D, list);
@@ -574,6 +584,14 @@ int kq_pending_set_lq_usage(kq_engine* en, int32_t n_lq, const double* usage) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
   return en->e.pending_set_lq_usage(n_lq, usage);
+}
+int kq_pending_add(kq_engine* en, const kq_pending* more, int32_t* first_index) {
+  if (!en || !more) return KQ_EINVAL;
+  return en->e.pending_add(more, first_index);
+}
+int kq_pending_delete(kq_engine* en, int32_t n, const int32_t* wl) {
+  if (!en || (n > 0 && !wl)) return KQ_EINVAL;
+  return en->e.pending_delete(n, wl);
 }
 int kq_pending_queue_inadmissible(kq_engine* en, int32_t n, const int32_t* cq) {
   if (!en) return KQ_EINVAL;

@@ -74,7 +74,62 @@ template <class B> struct EngineT {
     double* d_lq_usage = nullptr;     // [n_lq] AdmissionFairSharing usage of every LocalQueue
     int n_lq = 0;
     int32_t release_seq = 0;
+    // host mirror of what kq_pending_add needs to merge new workloads into the heap orders and to size the gathered batch
+    std::vector<int32_t> h_cq; std::vector<int64_t> h_prio, h_ts; std::vector<uint32_t> h_uid;
+    std::vector<int> mps, mrq;       // widest workload of every ClusterQueue (podsets / requests)
+    size_t nps_total = 0, nreq_total = 0;
   } pend;
+  // grow a resident array of the pending set by `add_n` elements (tail from the host, or a fill byte)
+  template <class T> void pend_regrow(T*& d, size_t old_n, size_t add_n, const T* tail, int fill = -2) {
+    T* nd = (T*)be.alloc(std::max<size_t>(old_n + add_n, 1) * sizeof(T));
+    if (old_n) be.d2d(nd, d, old_n * sizeof(T));
+    if (add_n) { if (tail) be.h2d(nd + old_n, tail, add_n * sizeof(T)); else if (fill != -2) be.memset(nd + old_n, fill, add_n * sizeof(T)); }
+    for (size_t i = 0; i < pend.allocs.size(); i++) if (pend.allocs[i] == (void*)d) { be.free(pend.allocs[i]); pend.allocs.erase(pend.allocs.begin() + i); break; }
+    pend.allocs.push_back(nd);
+    d = nd;
+  }
+  template <class T> void pend_regrow(const T*& d, size_t old_n, size_t add_n, const T* tail, int fill = -2) {
+    T* m = const_cast<T*>(d);
+    pend_regrow(m, old_n, add_n, tail, fill);
+    d = m;
+  }
+  void pend_release_ptr(const void* d) {
+    for (size_t i = 0; i < pend.allocs.size(); i++) if (pend.allocs[i] == d) { be.free(pend.allocs[i]); pend.allocs.erase(pend.allocs.begin() + i); break; }
+  }
+  // heap order of every ClusterQueue from the host mirror (baseCompareFunc cluster_queue.go:844 without the sticky term)
+  void pend_sort(std::vector<int32_t>& ord, std::vector<int32_t>& cq_off) {
+    const Pending& P = pend;
+    const int W = (int)P.h_cq.size(), nq = prep.nq;
+    ord.resize(W); cq_off.assign(nq + 1, 0);
+    for (int w = 0; w < W; w++) { ord[w] = w; cq_off[P.h_cq[w] + 1]++; }
+    for (int c = 0; c < nq; c++) cq_off[c + 1] += cq_off[c];
+    std::sort(ord.begin(), ord.end(), [&](int a, int b) {
+      if (P.h_cq[a] != P.h_cq[b]) return P.h_cq[a] < P.h_cq[b];
+      if (P.h_prio[a] != P.h_prio[b]) return P.h_prio[a] > P.h_prio[b];
+      if (P.h_ts[a] != P.h_ts[b]) return P.h_ts[a] < P.h_ts[b];
+      if (P.h_uid[a] != P.h_uid[b]) return P.h_uid[a] < P.h_uid[b];
+      return a < b;
+    });
+  }
+  void pend_alloc_gather() {  // the gathered batch holds <= 1 head per ClusterQueue: sized for the widest workload of every ClusterQueue
+    Pending& P = pend;
+    const int nq = prep.nq, nR = prep.nR;
+    const size_t nfw = (prep.nF + 63) / 64;
+    size_t gps = 0, grq = 0;
+    for (int c = 0; c < nq; c++) { gps += P.mps[c]; grq += P.mrq[c]; }
+    DGather& G = P.G;
+    for (const void* q : {(const void*)G.cq, (const void*)G.priority, (const void*)G.queue_ts, (const void*)G.flags, (const void*)G.ps_off, (const void*)G.ps_count,
+                          (const void*)G.ps_min_count, (const void*)G.ps_req_off, (const void*)G.req_res, (const void*)G.req_qty, (const void*)G.ps_flavor_ok,
+                          (const void*)G.ps_last_tried, (const void*)G.last_generation, (const void*)G.last_cycle, (const void*)G.last_hash, (const void*)G.hash})
+      if (q) pend_release_ptr(q);
+    G.cq = pend_alloc<int32_t>(nq); G.priority = pend_alloc<int64_t>(nq); G.queue_ts = pend_alloc<int64_t>(nq); G.flags = pend_alloc<uint32_t>(nq);
+    G.ps_off = pend_alloc<int32_t>(nq + 1);
+    G.ps_count = pend_alloc<int32_t>(gps); G.ps_min_count = pend_alloc<int32_t>(gps); G.ps_req_off = pend_alloc<int32_t>(gps + 1);
+    G.req_res = pend_alloc<int32_t>(grq); G.req_qty = pend_alloc<int64_t>(grq);
+    G.ps_flavor_ok = pend_alloc<uint64_t>(gps * nfw); G.ps_last_tried = pend_alloc<int32_t>(gps * nR);
+    G.last_generation = pend_alloc<int64_t>(nq); G.last_cycle = pend_alloc<int64_t>(nq);
+    G.last_hash = pend_alloc<uint64_t>(nq); G.hash = pend_alloc<uint64_t>(nq);
+  }
   template <class T> T* pend_alloc(size_t n, const T* host = nullptr, int fill = -2) {
     T* d = (T*)be.alloc(std::max<size_t>(n, 1) * sizeof(T));
     if (host && n) be.h2d(d, host, n * sizeof(T));
@@ -731,28 +786,20 @@ template <class B> struct EngineT {
     const int W = h->n, nq = prep.nq, nR = prep.nR;
     const size_t nfw = (prep.nF + 63) / 64;
     const size_t nps = W ? h->ps_off[W] : 0, nreq = nps ? h->ps_req_off[nps] : 0;
+    Pending& P = pend;
+    P.h_cq.assign(h->cq, h->cq + W); P.h_prio.assign(h->priority, h->priority + W); P.h_ts.assign(h->queue_ts, h->queue_ts + W);
+    P.h_uid.resize(W);
+    for (int w = 0; w < W; w++) P.h_uid[w] = p->uid_rank ? p->uid_rank[w] : (uint32_t)w;
     // heap order of every ClusterQueue (baseCompareFunc cluster_queue.go:844 without the sticky term): priority descending,
     // queue-order timestamp ascending, UID ascending — static while the workloads are pending
-    std::vector<int32_t> ord(W), cq_off(nq + 1, 0);
-    for (int w = 0; w < W; w++) { ord[w] = w; cq_off[h->cq[w] + 1]++; }
-    for (int c = 0; c < nq; c++) cq_off[c + 1] += cq_off[c];
-    std::sort(ord.begin(), ord.end(), [&](int a, int b) {
-      if (h->cq[a] != h->cq[b]) return h->cq[a] < h->cq[b];
-      if (h->priority[a] != h->priority[b]) return h->priority[a] > h->priority[b];
-      if (h->queue_ts[a] != h->queue_ts[b]) return h->queue_ts[a] < h->queue_ts[b];
-      const uint32_t ua = p->uid_rank ? p->uid_rank[a] : (uint32_t)a, ub = p->uid_rank ? p->uid_rank[b] : (uint32_t)b;
-      if (ua != ub) return ua < ub;
-      return a < b;
-    });
-    // the gathered batch holds <= 1 head per ClusterQueue: size it for the widest workload of every ClusterQueue
-    std::vector<int> mps(nq, 0), mrq(nq, 0);
+    std::vector<int32_t> ord, cq_off;
+    pend_sort(ord, cq_off);
+    P.mps.assign(nq, 0); P.mrq.assign(nq, 0);
     for (int w = 0; w < W; w++) {
       const int c = h->cq[w], a = h->ps_off[w + 1] - h->ps_off[w], b = h->ps_req_off[h->ps_off[w + 1]] - h->ps_req_off[h->ps_off[w]];
-      mps[c] = std::max(mps[c], a); mrq[c] = std::max(mrq[c], b);
+      P.mps[c] = std::max(P.mps[c], a); P.mrq[c] = std::max(P.mrq[c], b);
     }
-    size_t gps = 0, grq = 0;
-    for (int c = 0; c < nq; c++) { gps += mps[c]; grq += mrq[c]; }
-    Pending& P = pend;
+    P.nps_total = nps; P.nreq_total = nreq;
     P.W = W; P.nq = nq; P.nR = nR; P.nF = prep.nF; P.n_tree = prep.n_tree; P.slot_cap = slot_cap; P.plain = plain; P.max_nps = max_nps;
     DPend& D = P.D;
     D.W = W; D.nq = nq; D.nR = nR; D.nfw = (int)nfw;
@@ -767,9 +814,10 @@ template <class B> struct EngineT {
     S0.ps_flavor_ok = pend_alloc(nps * nfw, h->ps_flavor_ok);
     S0.ps_last_tried = nullptr; S0.last_generation = nullptr; S0.last_cycle = nullptr; S0.last_hash = nullptr;
     S0.hash = pend_alloc<uint64_t>(W, h->hash, 0);
-    D.uid = pend_alloc<uint32_t>(W, p->uid_rank, 0);
+    D.uid = pend_alloc<uint32_t>(W, P.h_uid.data());
     D.cq_off = pend_alloc(nq + 1, cq_off.data()); D.ord = pend_alloc(W, ord.data());
     D.state = pend_alloc<uint8_t>(W, nullptr, 0);  // WL_ACTIVE
+    D.bulk = pend_alloc<uint8_t>(W, nullptr, 0);
     D.mflags = pend_alloc(W, h->flags);
     D.last_tried = pend_alloc<int32_t>(nps * nR, h->ps_last_tried, 0xff);
     D.last_gen = pend_alloc<int64_t>(W, h->last_generation, 0); D.last_cycle = pend_alloc<int64_t>(W, h->last_cycle, 0);
@@ -789,14 +837,8 @@ template <class B> struct EngineT {
     P.d_active = pend_alloc<uint8_t>(nq, nullptr, 1);
     P.d_list = pend_alloc<int32_t>(nq, nullptr, 0);
     P.d_tree_stamp = pend_alloc<int32_t>(std::max(prep.n_tree, 1), nullptr, 0);
-    DGather& G = P.G;
-    G.cq = pend_alloc<int32_t>(nq); G.priority = pend_alloc<int64_t>(nq); G.queue_ts = pend_alloc<int64_t>(nq); G.flags = pend_alloc<uint32_t>(nq);
-    G.ps_off = pend_alloc<int32_t>(nq + 1);
-    G.ps_count = pend_alloc<int32_t>(gps); G.ps_min_count = pend_alloc<int32_t>(gps); G.ps_req_off = pend_alloc<int32_t>(gps + 1);
-    G.req_res = pend_alloc<int32_t>(grq); G.req_qty = pend_alloc<int64_t>(grq);
-    G.ps_flavor_ok = pend_alloc<uint64_t>(gps * nfw); G.ps_last_tried = pend_alloc<int32_t>(gps * nR);
-    G.last_generation = pend_alloc<int64_t>(nq); G.last_cycle = pend_alloc<int64_t>(nq);
-    G.last_hash = pend_alloc<uint64_t>(nq); G.hash = pend_alloc<uint64_t>(nq);
+    P.G = DGather{};
+    pend_alloc_gather();
     rc = be.sync();
     if (rc != KQ_OK) { pending_free(); return fail(rc, be.error()); }
     P.valid = true; P.n_heads = -1; P.ran = false;
@@ -844,6 +886,75 @@ template <class B> struct EngineT {
     if (n_lq == 0) return KQ_OK;
     be.h2d(pend.d_lq_usage, usage, (size_t)n_lq * sizeof(double));
     return be.sync();  // the caller's array may go away
+  }
+  // PushOrUpdate of new workloads (cluster_queue.go:379): appended, merged into the heap orders, resident state carried over
+  int pending_add(const kq_pending* p, int32_t* first_index) {
+    if (!have_snapshot || !pend.valid) return fail(KQ_EINVAL, "kq_pending_add before kq_pending_put");
+    if (pend.n_heads >= 0) return fail(KQ_EINVAL, "kq_pending_add between kq_pending_heads and kq_pending_apply");
+    const kq_heads* h = &p->w;
+    int slot_cap = 1, max_nps = 1; bool plain = true;
+    int rc = validate_heads(h, &slot_cap, &plain, &max_nps);
+    if (rc != KQ_OK) return rc;
+    Pending& P = pend;
+    const int n = h->n, W0 = P.W, nq = prep.nq, nR = prep.nR;
+    if (first_index) *first_index = W0;
+    if (n == 0) return KQ_OK;
+    if ((P.n_lq > 0) != (p->lq != nullptr && p->n_lq > 0) || (P.n_lq > 0 && p->n_lq != P.n_lq)) return fail(KQ_EINVAL, "kq_pending_add: LocalQueue indices must match kq_pending_put");
+    if (P.n_lq > 0) for (int w = 0; w < n; w++) if (p->lq[w] < -1 || p->lq[w] >= P.n_lq) return fail(KQ_EINVAL, "kq_pending: LocalQueue index out of range");
+    const size_t nfw = (prep.nF + 63) / 64;
+    const size_t aps = (size_t)h->ps_off[n], arq = aps ? (size_t)h->ps_req_off[aps] : 0;
+    const size_t nps0 = P.nps_total, nrq0 = P.nreq_total;
+    DPend& D = P.D;
+    DHeads& S0 = D.P;
+    pend_regrow(S0.cq, W0, n, h->cq); pend_regrow(S0.priority, W0, n, h->priority); pend_regrow(S0.queue_ts, W0, n, h->queue_ts);
+    pend_regrow(S0.flags, W0, n, h->flags);
+    { std::vector<int32_t> t(n); for (int i = 0; i < n; i++) t[i] = (int32_t)(nps0 + h->ps_off[i + 1]); pend_regrow(S0.ps_off, (size_t)W0 + 1, n, t.data()); }
+    pend_regrow(S0.ps_count, nps0, aps, h->ps_count);
+    pend_regrow(S0.ps_min_count, nps0, aps, h->ps_min_count, 0xff);
+    { std::vector<int32_t> t(aps); for (size_t i = 0; i < aps; i++) t[i] = (int32_t)(nrq0 + h->ps_req_off[i + 1]); pend_regrow(S0.ps_req_off, nps0 + 1, aps, t.data()); }
+    pend_regrow(S0.req_res, nrq0, arq, h->req_res); pend_regrow(S0.req_qty, nrq0, arq, h->req_qty);
+    pend_regrow(S0.ps_flavor_ok, nps0 * nfw, aps * nfw, h->ps_flavor_ok);
+    pend_regrow(S0.hash, W0, n, h->hash, 0);
+    std::vector<uint32_t> uid(n);
+    for (int w = 0; w < n; w++) uid[w] = p->uid_rank ? p->uid_rank[w] : (uint32_t)(W0 + w);
+    pend_regrow(D.uid, W0, n, uid.data());
+    pend_regrow(D.state, W0, n, (const uint8_t*)nullptr, 0); pend_regrow(D.bulk, W0, n, (const uint8_t*)nullptr, 0);
+    pend_regrow(D.mflags, W0, n, h->flags);
+    pend_regrow(D.last_tried, nps0 * nR, aps * nR, h->ps_last_tried, 0xff);
+    pend_regrow(D.last_gen, W0, n, h->last_generation, 0); pend_regrow(D.last_cycle, W0, n, h->last_cycle, 0);
+    pend_regrow(D.last_hash, W0, n, h->last_hash, 0);
+    if (P.n_lq > 0) pend_regrow(D.lq, W0, n, p->lq);
+    P.h_cq.insert(P.h_cq.end(), h->cq, h->cq + n); P.h_prio.insert(P.h_prio.end(), h->priority, h->priority + n);
+    P.h_ts.insert(P.h_ts.end(), h->queue_ts, h->queue_ts + n); P.h_uid.insert(P.h_uid.end(), uid.begin(), uid.end());
+    for (int w = 0; w < n; w++) {
+      const int c = h->cq[w], a = h->ps_off[w + 1] - h->ps_off[w], b = h->ps_req_off[h->ps_off[w + 1]] - h->ps_req_off[h->ps_off[w]];
+      P.mps[c] = std::max(P.mps[c], a); P.mrq[c] = std::max(P.mrq[c], b);
+    }
+    P.W = W0 + n; D.W = P.W; S0.n = P.W;
+    P.nps_total = nps0 + aps; P.nreq_total = nrq0 + arq;
+    P.slot_cap = std::max(P.slot_cap, slot_cap); P.plain = P.plain && plain; P.max_nps = std::max(P.max_nps, max_nps);
+    std::vector<int32_t> ord, cq_off;
+    pend_sort(ord, cq_off);
+    pend_release_ptr(D.ord); pend_release_ptr(D.cq_off);
+    D.cq_off = pend_alloc(nq + 1, cq_off.data()); D.ord = pend_alloc(P.W, ord.data());
+    pend_alloc_gather();
+    be.launch_pend_add_fix(D, S, W0, n);
+    rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    return KQ_OK;
+  }
+  int pending_delete(int n, const int32_t* wl) {
+    if (!pend.valid) return fail(KQ_EINVAL, "kq_pending_delete before kq_pending_put");
+    if (pend.n_heads >= 0) return fail(KQ_EINVAL, "kq_pending_delete between kq_pending_heads and kq_pending_apply");
+    if (n <= 0) return KQ_OK;
+    for (int i = 0; i < n; i++) if (wl[i] < 0 || wl[i] >= pend.W) return fail(KQ_EINVAL, "kq_pending_delete: workload out of range");
+    int32_t* d = (int32_t*)be.alloc((size_t)n * sizeof(int32_t));
+    be.h2d(d, wl, (size_t)n * sizeof(int32_t));
+    be.launch_pend_delete(pend.D, d, n);
+    int rc = be.sync();
+    be.free(d);
+    if (rc != KQ_OK) return fail(rc, be.error());
+    return KQ_OK;
   }
   int pending_queue_inadmissible(int n, const int32_t* cq) {
     if (!pend.valid) return fail(KQ_EINVAL, "kq_pending_queue_inadmissible before kq_pending_put");

@@ -32,6 +32,8 @@ struct DPend {
   const int32_t* ord;        // [W]
   // mutable queue state
   uint8_t* state;            // [W] WL_*
+  uint8_t* bulk;             // [W] the workload's requeue bulk-moved its equivalence class (its hash is in hashToBulkMoveReason,
+                             //     cluster_queue.go:169-172) since the ClusterQueue's last queueInadmissibleWorkloads
   uint32_t* mflags;          // [W] KQ_HEAD_* (HAS_LAST_ASSIGNMENT evolves with the cycles)
   int32_t* last_tried;       // [n_ps_total * nR] LastAssignment.LastTriedFlavorIdx
   int64_t *last_gen, *last_cycle;
@@ -212,6 +214,7 @@ KQ_DEV void pend_apply_head(const DPend& D, const DSnap& S, const DOut& O, const
   // :592-597 bulk move of the equivalence class (handleInadmissibleHash :606-621; BestEffortFIFO only)
   const uint64_t hash = D.P.hash[w];
   if ((gates & KQ_GATE_SCHEDULING_EQUIVALENCE_HASHING) && hash != 0 && !strict && (rq == KQ_RQ_NOFIT || rq == KQ_RQ_PREEMPTION_NO_CANDIDATES)) {
+    if (lane == 0) D.bulk[w] = 1;  // c.hashToBulkMoveReason[hash] = reason :610
     for (int j = D.cq_off[c] + lane; j < D.cq_off[c + 1]; j += WAVE) {
       const int w2 = D.ord[j];
       if (w2 != w && D.state[w2] == WL_ACTIVE && D.P.hash[w2] == hash) D.state[w2] = WL_INADMISSIBLE;
@@ -226,7 +229,29 @@ KQ_DEV void pend_queue_inadmissible(const DPend& D, int c) {
   for (int j = D.cq_off[c] + lane; j < D.cq_off[c + 1]; j += WAVE) {
     const int w = D.ord[j];
     if (D.state[w] == WL_INADMISSIBLE) D.state[w] = WL_ACTIVE;
+    D.bulk[w] = 0;  // c.hashToBulkMoveReason = make(...) inadmissible_workloads.go:158
   }
+}
+// PushOrUpdate of a workload that was just appended (cluster_queue.go:419-425): BestEffortFIFO, hash known, class already bulk-moved
+// => it joins the inadmissible workloads instead of the heap. One wave per new workload.
+KQ_DEV void pend_add_fix(const DPend& D, const DSnap& S, int w) {
+  const int lane = lane_id();
+  const int c = D.P.cq[w];
+  const uint64_t hash = D.P.hash[w];
+  if (hash == 0 || KQ_POL_STRICT_FIFO(S.cq_policy[c]) != 0) return;
+  bool hit = false;
+  for (int j = D.cq_off[c] + lane; j < D.cq_off[c + 1]; j += WAVE) {
+    const int w2 = D.ord[j];
+    if (w2 != w && D.bulk[w2] && D.P.hash[w2] == hash) hit = true;
+  }
+  if (wballot(hit) != 0 && lane == 0) D.state[w] = WL_INADMISSIBLE;
+}
+// ClusterQueue.Delete :488-512 — one thread per workload
+KQ_DEV void pend_delete(const DPend& D, const int32_t* list, int i) {
+  const int w = list[i];
+  const int c = D.P.cq[w];
+  D.state[w] = WL_GONE;
+  if (D.pw[c] == w) { D.pw[c] = -1; D.pw_sticky[c] = 0; }
 }
 
 // Workloads finishing free quota: the cache notifies the queues, which move the inadmissible workloads of the whole ROOT cohort of

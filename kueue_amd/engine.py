@@ -103,6 +103,19 @@ class Engine:
     def pending_apply(self):
         self._check(self._lib.kq_pending_apply(self._h))
 
+    def pending_add(self, more) -> int:
+        """kq_pending_add: PushOrUpdate of workloads that were not pending before; returns the index of the first one."""
+        first = C.c_int32()
+        self._check(self._lib.kq_pending_add(self._h, C.byref(more.struct()), C.byref(first)))
+        self.pending = self.pending.extended(more)
+        return first.value
+
+    def pending_delete(self, wl):
+        """kq_pending_delete: ClusterQueue.Delete of pending workloads."""
+        a = np.ascontiguousarray(wl, np.int32)
+        if len(a):
+            self._check(self._lib.kq_pending_delete(self._h, len(a), F.ptr(a)))
+
     def pending_set_lq_usage(self, usage):
         """kq_pending_set_lq_usage: the LocalQueues' fair-sharing usage (afs.CalculateUsage, host-evaluated) for the next Heads()."""
         u = np.ascontiguousarray(usage, np.float64)

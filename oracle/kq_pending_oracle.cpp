@@ -166,6 +166,33 @@ void* kqp_create(const kq_pending* p, int32_t n_cq, int32_t n_resource, const ui
 }
 void kqp_destroy(void* q) { delete (Queue*)q; }
 
+// PushOrUpdate (cluster_queue.go:379-428) of workloads that were not pending before; returns the index of the first one.
+// A new workload goes to the heap unless its ClusterQueue is BestEffortFIFO, its hash is known and the class was bulk-moved (:419-425).
+int kqp_add(void* qp, const kq_pending* p) {
+  Queue& q = *(Queue*)qp;
+  const kq_heads& h = p->w;
+  const int first = (int)q.wl.size();
+  int ps_base = 0;
+  for (const WL& x : q.wl) ps_base = std::max(ps_base, x.ps0 + x.nps);
+  for (int i = 0; i < h.n; i++) {
+    WL x;
+    x.cq = h.cq[i]; x.prio = h.priority[i]; x.ts = h.queue_ts[i]; x.uid = p->uid_rank ? p->uid_rank[i] : (uint32_t)(first + i);
+    x.hash = h.hash ? h.hash[i] : 0;
+    x.ps0 = ps_base + h.ps_off[i]; x.nps = h.ps_off[i + 1] - h.ps_off[i];
+    x.has_last = (h.flags[i] & KQ_HEAD_HAS_LAST_ASSIGNMENT) != 0;
+    x.last_tried.assign((size_t)x.nps * q.nR, -1);
+    if (h.ps_last_tried) for (size_t j = 0; j < x.last_tried.size(); j++) x.last_tried[j] = h.ps_last_tried[(size_t)h.ps_off[i] * q.nR + j];
+    x.last_gen = h.last_generation ? h.last_generation[i] : 0; x.last_cycle = h.last_cycle ? h.last_cycle[i] : 0;
+    x.last_hash = h.last_hash ? h.last_hash[i] : 0;
+    x.lq = (p->lq && p->n_lq > 0) ? p->lq[i] : -1;
+    CQ& c = q.cqs[x.cq];
+    x.state = (!c.strict && x.hash != 0 && c.hashToBulkMoveReason.count(x.hash)) ? KQ_WL_INADMISSIBLE : KQ_WL_ACTIVE;
+    q.wl.push_back(x);
+    c.members.push_back(first + i);
+  }
+  return first;
+}
+
 // manager.heads :922-947 in canonical ClusterQueue order. head_wl[n_cq]: popped workload or -1; returns the number of heads.
 // For every head also: its flags / LastAssignment as the scheduler will see them (the caller builds the kq_heads batch).
 int kqp_heads(void* qp, const uint8_t* cq_active, int32_t* head_wl) {
@@ -238,6 +265,7 @@ void kqp_set_last(void* qp, int32_t w, int32_t has_last, const int32_t* last_tri
 }
 void kqp_set_state(void* qp, int32_t w, int32_t state) { ((Queue*)qp)->wl[w].state = state; }
 void kqp_delete(void* qp, int32_t w) { ((Queue*)qp)->Delete(w); }
+void kqp_delete_list(void* qp, int32_t n, const int32_t* wl) { for (int i = 0; i < n; i++) ((Queue*)qp)->Delete(wl[i]); }
 int kqp_handle_hash(void* qp, int32_t cq, uint64_t hash) { Queue& q = *(Queue*)qp; return hash ? q.handleInadmissibleHash(q.cqs[cq], hash) : 0; }
 int kqp_is_sticky(void* qp, int32_t w) { Queue& q = *(Queue*)qp; const CQ& c = q.cqs[q.wl[w].cq]; return c.pw == w && c.pw_sticky; }
 int kqp_has_hash(void* qp, int32_t cq, uint64_t hash) { return ((Queue*)qp)->cqs[cq].hashToBulkMoveReason.count(hash) ? 1 : 0; }

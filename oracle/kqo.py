@@ -336,6 +336,18 @@ class PendingOracle:
         rc = self.l.kqp_apply(self.h, C.byref(heads.struct()), C.byref(d.struct()), F.ptr(self.snap.arrays["cq_generation"]))
         assert rc == 0, rc
 
+    def add(self, more) -> int:
+        """PushOrUpdate of new workloads; `self.pending` becomes the extended table."""
+        first = self.l.kqp_add(self.h, C.byref(more.struct()))
+        self.pending = self.pending.extended(more)
+        return first
+
+    def delete_many(self, wl):
+        a = np.ascontiguousarray(wl, np.int32)
+        self.l.kqp_delete_list.restype = None
+        if len(a):
+            self.l.kqp_delete_list(self.h, len(a), F.ptr(a))
+
     def set_lq_usage(self, usage):
         u = np.ascontiguousarray(usage, np.float64)
         self.l.kqp_set_lq_usage.restype = None

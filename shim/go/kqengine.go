@@ -307,6 +307,39 @@ func (e *Engine) PutPending(all *FlatHeads, uidRank []uint32, nLQ int32, lq []in
 	return nil
 }
 
+// AddPending = PushOrUpdate (cluster_queue.go:379) of workloads that were not pending before; returns the index of the first one
+// (existing indices do not move). lq as in PutPending.
+func (e *Engine) AddPending(more *FlatHeads, uidRank []uint32, nLQ int32, lq []int32) (int32, error) {
+	var p runtime.Pinner
+	defer p.Unpin()
+	c := (*C.kq_pending)(C.calloc(1, C.sizeof_kq_pending))
+	defer C.free(unsafe.Pointer(c))
+	fillHeads(&p, &c.w, more)
+	c.uid_rank = (*C.uint32_t)(pin(&p, uidRank))
+	if len(lq) > 0 {
+		c.n_lq = C.int32_t(nLQ)
+		c.lq = (*C.int32_t)(pin(&p, lq))
+	}
+	var first C.int32_t
+	if rc := C.kq_pending_add(e.h, c, &first); rc != 0 {
+		return 0, e.err("kq_pending_add", rc)
+	}
+	return int32(first), nil
+}
+
+// DeletePending = ClusterQueue.Delete (cluster_queue.go:488) of pending workloads (deleted, finished, admitted elsewhere).
+func (e *Engine) DeletePending(wl []int32) error {
+	if len(wl) == 0 {
+		return nil
+	}
+	var p runtime.Pinner
+	defer p.Unpin()
+	if rc := C.kq_pending_delete(e.h, C.int32_t(len(wl)), (*C.int32_t)(pin(&p, wl))); rc != 0 {
+		return e.err("kq_pending_delete", rc)
+	}
+	return nil
+}
+
 // SetLQUsage hands over afs.CalculateUsage of every LocalQueue (admission_fair_sharing.go:86) before Heads.
 func (e *Engine) SetLQUsage(usage []float64) error {
 	var p runtime.Pinner

@@ -116,6 +116,17 @@ class EmuEngine:
     def pending_apply(self):
         self._ok(lib().kqe_pending_apply(self.h))
 
+    def pending_add(self, more) -> int:
+        first = C.c_int32()
+        self._ok(lib().kqe_pending_add(self.h, C.byref(more.struct()), C.byref(first)))
+        self.pending = self.pending.extended(more)
+        return first.value
+
+    def pending_delete(self, wl):
+        a = np.ascontiguousarray(wl, np.int32)
+        if len(a):
+            self._ok(lib().kqe_pending_delete(self.h, C.c_int32(len(a)), F.ptr(a)))
+
     def pending_set_lq_usage(self, usage):
         u = np.ascontiguousarray(usage, np.float64)
         self._ok(lib().kqe_pending_set_lq_usage(self.h, C.c_int32(len(u)), F.ptr(u)))

@@ -323,3 +323,116 @@ def test_afs_ordering_closed_loop_emulated(oracle):
 def test_afs_ordering_closed_loop_gpu(oracle):
     from kueue_amd.engine import Engine
     _afs_loop(oracle, Engine, n_cq=200, per=30, cycles=12, seed=6)
+
+
+# ---- arrivals and deletions between cycles (PushOrUpdate cluster_queue.go:379, Delete :488) ---------------------------------------
+
+def _arrivals_loop(oracle, eng_factory, pop, cfg, cycles, seed, start_frac=0.4):
+    """Half of the population is resident at the start; every cycle a few more workloads arrive (kq_pending_add) and a few pending
+    ones are deleted (kq_pending_delete). Heads(), every decision and the queue states equal the oracle's in every cycle."""
+    rng = np.random.default_rng(seed)
+    full = pop.pending()
+    perm = rng.permutation(full.n)
+    n0 = max(1, int(full.n * start_frac))
+    sub = lambda idx: Pending(full.heads.subset(np.asarray(idx, np.int64)), uid_rank=full.uid_rank[np.asarray(idx, np.int64)])
+    resident = sub(np.sort(perm[:n0]))
+    rest = list(perm[n0:])
+    snap = pop.snapshot
+    eng = eng_factory(cfg); q = oracle.PendingOracle(cfg, snap, resident)
+    added = deleted = inadm_on_arrival = 0
+    try:
+        eng.put(snap); eng.pending_put(resident)
+        osnap = copy.copy(snap); osnap.arrays = dict(snap.arrays)
+        for cyc in range(1, cycles + 1):
+            k = int(rng.integers(0, 7))
+            if rest and k:
+                batch, rest = rest[:k], rest[k:]
+                more = sub(batch)
+                f1 = eng.pending_add(more); f2 = q.add(more)
+                assert f1 == f2
+                added += len(batch)
+                st = q.state()
+                inadm_on_arrival += int((st[f2:f2 + len(batch)] == F.WL_INADMISSIBLE).sum())
+            st = q.state()
+            alive = np.nonzero(st != F.WL_GONE)[0]
+            if len(alive) and cyc % 2 == 0:
+                d = rng.choice(alive, size=min(2, len(alive)), replace=False)
+                eng.pending_delete(d); q.delete_many(d)
+                deleted += len(d)
+            assert np.array_equal(eng.pending_state()[0], q.state()), f"cycle {cyc}: states differ after add / delete"
+            n, nps, hw = eng.pending_heads(cyc)
+            hb, ohw = q.heads(cyc)
+            assert np.array_equal(hw, ohw), f"cycle {cyc}: Heads() differ"
+            if n == 0:
+                eng.pending_apply()  # closes the (empty) cycle
+                continue
+            got = eng.run_pending(Decisions(hb, tgt_cap=max(4096, snap.n_adm)))
+            want = oracle.cycle_run(cfg, osnap, hb)
+            assert not want.equal(got), (cyc, want.equal(got))
+            usage, na, triples = oracle.cycle_commit(cfg, osnap, hb)
+            osnap.arrays["usage"] = usage; osnap._struct = None
+            assert eng.try_commit() == 0
+            eng.pending_apply(); q.apply(hb, want)
+            if cyc % 5 == 0:
+                eng.pending_queue_inadmissible(); q.queue_inadmissible()
+            assert np.array_equal(eng.pending_state()[0], q.state()), f"cycle {cyc}: states differ"
+        return added, deleted, inadm_on_arrival
+    finally:
+        eng.close(); q.close()
+
+
+@pytest.mark.parametrize("cfgn,n_cq,per", [(3, 24, 10), (2, 12, 14), (1, 4, 20)], ids=["cfg3", "cfg2", "cfg1-strict"])
+def test_pending_arrivals_and_deletions_emulated(oracle, cfgn, n_cq, per):
+    from tests.emu import kqe
+    pop = generate(cfgn, n_cq=n_cq, per_cq=per)
+    added, deleted, _ = _arrivals_loop(oracle, kqe.EmuEngine, pop, make_config(), cycles=30, seed=cfgn)
+    assert added > 20 and deleted > 10
+
+
+def test_new_workload_of_a_bulk_moved_class_arrives_inadmissible(oracle):
+    """cluster_queue.go:419-425: BestEffortFIFO, hash known, class already bulk-moved to the inadmissible workloads => PushOrUpdate puts the
+    new workload there too; after queueInadmissibleWorkloads (hashToBulkMoveReason cleared) an equal workload goes to the heap.
+    Oracle and device code (emulated, fabricated NoFit decision) side by side."""
+    from tests.emu import kqe
+    snap, _, _ = _tiny({"strategy": "BestEffortFIFO", "workloads": [{"name": "a", "prio": 1}]})
+
+    def pend(names, rank0):
+        h = Heads(snap, [Workload(n, "cq", priority=1, creation_ts=10 + rank0 + i, pod_sets=[PodSet("main", 1, requests={"cpu": 1000})], uid=n)
+                         for i, n in enumerate(names)], cycle=0)
+        h.arrays["hash"][:] = 77
+        h._struct = None
+        return Pending(h, uid_rank=np.arange(rank0, rank0 + len(names), dtype=np.uint32))
+    cfg = make_config()
+    first = pend(["a", "b"], 0)
+    q = oracle.PendingOracle(cfg, snap, first)
+    eng = kqe.EmuEngine(cfg)
+    try:
+        eng.put(snap); eng.pending_put(first)
+        # "a" is popped and comes back NoFit: its class (hash 77) is bulk-moved, "b" with it
+        assert q.pop(0) == 0
+        q.requeue(0, F.RQ_NOFIT)
+        n, nps, hw = eng.pending_heads(1)
+        assert n == 1 and hw[0] == 0
+        tried = np.full(nps * snap.n_resource, -1, np.int32)
+        rc = kqe.lib().kqe_pending_apply_fabricated(eng.h, F.ptr(np.zeros(1, np.uint8)), F.ptr(np.zeros(1, np.uint8)), F.ptr(np.zeros(1, np.uint8)),
+                                                    F.ptr(np.array([F.RQ_NOFIT], np.uint8)), F.ptr(tried))
+        assert rc == 0
+        assert list(q.state()) == [F.WL_INADMISSIBLE, F.WL_INADMISSIBLE] == list(eng.pending_state()[0])
+        more = pend(["c"], 10)
+        f1, f2 = eng.pending_add(more), q.add(more)
+        assert f1 == f2 == 2
+        assert q.state()[2] == F.WL_INADMISSIBLE and eng.pending_state()[0][2] == F.WL_INADMISSIBLE
+        q.queue_inadmissible(); eng.pending_queue_inadmissible()
+        more2 = pend(["d"], 20)
+        f3 = q.add(more2); assert eng.pending_add(more2) == f3
+        assert list(q.state()) == [F.WL_ACTIVE] * 4 == list(eng.pending_state()[0])
+    finally:
+        eng.close(); q.close()
+
+
+@pytest.mark.gpu
+def test_pending_arrivals_and_deletions_gpu(oracle):
+    from kueue_amd.engine import Engine
+    pop = generate(3, n_cq=200, per_cq=20)
+    added, deleted, _ = _arrivals_loop(oracle, Engine, pop, make_config(), cycles=40, seed=9)
+    assert added > 50 and deleted > 20

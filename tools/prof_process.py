@@ -12,7 +12,7 @@ pop = generate(int(sys.argv[1]) if len(sys.argv) > 1 else 3, fair_sharing=fair)
 eng = Engine(make_config(fair_sharing=fair)); eng.put(pop.snapshot)
 lib = eng._lib
 lib.kq_debug_prof.argtypes = [C.c_void_p, F.i64p, C.c_int]
-prof = np.zeros(32, np.int64)
+prof = np.zeros(64, np.int64)
 for c in range(3):
     eng.run(pop.heads_for_cycle(c))
 lib.kq_debug_prof(eng._h, F.ptr(prof), 1)
