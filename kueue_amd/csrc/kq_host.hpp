@@ -908,10 +908,14 @@ template <class B> struct EngineT {
     DHeads& S0 = D.P;
     pend_regrow(S0.cq, W0, n, h->cq); pend_regrow(S0.priority, W0, n, h->priority); pend_regrow(S0.queue_ts, W0, n, h->queue_ts);
     pend_regrow(S0.flags, W0, n, h->flags);
-    { std::vector<int32_t> t(n); for (int i = 0; i < n; i++) t[i] = (int32_t)(nps0 + h->ps_off[i + 1]); pend_regrow(S0.ps_off, (size_t)W0 + 1, n, t.data()); }
+    // (the temporaries below are read by asynchronous copies: they live until the be.sync() at the end)
+    std::vector<int32_t> t_ps(n), t_rq(aps);
+    for (int i = 0; i < n; i++) t_ps[i] = (int32_t)(nps0 + h->ps_off[i + 1]);
+    pend_regrow(S0.ps_off, (size_t)W0 + 1, n, t_ps.data());
     pend_regrow(S0.ps_count, nps0, aps, h->ps_count);
     pend_regrow(S0.ps_min_count, nps0, aps, h->ps_min_count, 0xff);
-    { std::vector<int32_t> t(aps); for (size_t i = 0; i < aps; i++) t[i] = (int32_t)(nrq0 + h->ps_req_off[i + 1]); pend_regrow(S0.ps_req_off, nps0 + 1, aps, t.data()); }
+    for (size_t i = 0; i < aps; i++) t_rq[i] = (int32_t)(nrq0 + h->ps_req_off[i + 1]);
+    pend_regrow(S0.ps_req_off, nps0 + 1, aps, t_rq.data());
     pend_regrow(S0.req_res, nrq0, arq, h->req_res); pend_regrow(S0.req_qty, nrq0, arq, h->req_qty);
     pend_regrow(S0.ps_flavor_ok, nps0 * nfw, aps * nfw, h->ps_flavor_ok);
     pend_regrow(S0.hash, W0, n, h->hash, 0);

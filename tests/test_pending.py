@@ -434,5 +434,5 @@ def test_new_workload_of_a_bulk_moved_class_arrives_inadmissible(oracle):
 def test_pending_arrivals_and_deletions_gpu(oracle):
     from kueue_amd.engine import Engine
     pop = generate(3, n_cq=200, per_cq=20)
-    added, deleted, _ = _arrivals_loop(oracle, Engine, pop, make_config(), cycles=40, seed=9)
+    added, deleted, _ = _arrivals_loop(oracle, Engine, pop, make_config(), cycles=30, seed=9)  # (no releases here: stay inside the commit ring)
     assert added > 50 and deleted > 20
