@@ -333,7 +333,14 @@ typedef struct kq_pending {
    * kq_pending_set_lq_usage before Heads(). */
   int32_t n_lq;
   const int32_t* lq;          /* [W] or NULL */
+  /* Back-off after a PodsReady timeout (backoffWaitingTimeExpired cluster_queue.go:474-485): per workload RequeueState.RequeueAt in
+   * ns, KQ_REQUEUE_NONE when there is none, KQ_REQUEUE_BLOCKED while the Requeued condition is False. A workload whose back-off has
+   * not expired (against kq_pending_set_clock) waits among the inadmissible workloads (:414, :568, inadmissible_workloads.go:167).
+   * NULL: no workload is backing off. */
+  const int64_t* requeue_at;  /* [W] or NULL */
 } kq_pending;
+#define KQ_REQUEUE_NONE    INT64_MIN
+#define KQ_REQUEUE_BLOCKED INT64_MAX
 /* PushOrUpdate (cluster_queue.go:379) of every workload into its ClusterQueue's heap; replaces any previous pending set. */
 int  kq_pending_put(kq_engine* e, const kq_pending* p);
 /* Heads(): pops <= 1 workload per ClusterQueue (cq_active[c] == 0: ClusterQueue skipped, manager.go:926; NULL = all active)
@@ -361,6 +368,12 @@ int  kq_pending_add(kq_engine* e, const kq_pending* more, int32_t* first_index);
 /* ClusterQueue.Delete (cluster_queue.go:488-512): the workloads leave the pending set (deleted, finished, admitted by another
  * scheduler). Not between kq_pending_heads and kq_pending_apply. */
 int  kq_pending_delete(kq_engine* e, int32_t n, const int32_t* wl);
+/* c.clock.Now() of the queues for every later call (ns; 0 until set). */
+int  kq_pending_set_clock(kq_engine* e, int64_t now_ns);
+/* The workload controller changed RequeueState / the Requeued condition of pending workloads: PushOrUpdate of an existing workload
+ * whose conditions changed (cluster_queue.go:391-428). An inadmissible workload leaves the inadmissible set unless its back-off has
+ * still not expired or its equivalence class is bulk-moved; a workload in the heap stays there. */
+int  kq_pending_set_requeue_at(kq_engine* e, int32_t n, const int32_t* wl, const int64_t* requeue_at);
 /* state[W] (KQ_WL_*) and counts[4] per state; both optional. */
 int  kq_pending_read_state(kq_engine* e, uint8_t* state, int32_t* counts);
 

@@ -139,9 +139,10 @@ class kq_heads(C.Structure):
 
 
 class kq_pending(C.Structure):
-    _fields_ = [("w", kq_heads), ("uid_rank", u32p), ("n_lq", C.c_int32), ("lq", i32p)]
+    _fields_ = [("w", kq_heads), ("uid_rank", u32p), ("n_lq", C.c_int32), ("lq", i32p), ("requeue_at", i64p)]
 
 
+REQUEUE_NONE, REQUEUE_BLOCKED = -(1 << 63), (1 << 63) - 1
 WL_ACTIVE, WL_INFLIGHT, WL_INADMISSIBLE, WL_GONE = 0, 1, 2, 3
 PATCH_USAGE, PATCH_ADMITTED = 1, 2
 
@@ -231,6 +232,10 @@ def load_engine():
     lib.kq_pending_queue_inadmissible.argtypes = [C.c_void_p, C.c_int32, i32p]
     lib.kq_pending_add.argtypes = [C.c_void_p, C.POINTER(kq_pending), i32p]
     lib.kq_pending_add.restype = C.c_int
+    lib.kq_pending_set_clock.argtypes = [C.c_void_p, C.c_int64]
+    lib.kq_pending_set_clock.restype = C.c_int
+    lib.kq_pending_set_requeue_at.argtypes = [C.c_void_p, C.c_int32, i32p, i64p]
+    lib.kq_pending_set_requeue_at.restype = C.c_int
     lib.kq_pending_delete.argtypes = [C.c_void_p, C.c_int32, i32p]
     lib.kq_pending_delete.restype = C.c_int
     lib.kq_pending_set_lq_usage.argtypes = [C.c_void_p, C.c_int32, f64p]
@@ -272,6 +277,6 @@ ABI_SYMBOLS = [
     "kq_cycle_commit", "kq_cycle_release", "kq_snapshot_derive", "kq_snapshot_read_planes", "kq_strerror", "kq_last_error", "kq_abi_version",
     "kq_heads_put", "kq_cycle_run_resident", "kq_nominate_run_resident", "kq_last_cycle_phases",
     "kq_cycle_certificate", "kq_snapshot_usage_add", "kq_snapshot_patch",
-    "kq_pending_set_lq_usage", "kq_pending_add", "kq_pending_delete", "kq_pending_put", "kq_pending_heads", "kq_cycle_run_pending", "kq_pending_apply", "kq_pending_queue_inadmissible", "kq_pending_read_state",
+    "kq_pending_set_lq_usage", "kq_pending_add", "kq_pending_delete", "kq_pending_set_clock", "kq_pending_set_requeue_at", "kq_pending_put", "kq_pending_heads", "kq_cycle_run_pending", "kq_pending_apply", "kq_pending_queue_inadmissible", "kq_pending_read_state",
     "kq_debug_read_usage_work", "kq_debug_force_exact_drs", "kq_debug_prof", "kq_debug_disable_scan_search",
 ]

@@ -607,8 +607,11 @@ class Pending:
     """kq_pending: every pending workload of every ClusterQueue (the heaps of pkg/cache/queue), as one heads-shaped table
     plus the UID ranks baseCompareFunc breaks ties with (cluster_queue.go:873)."""
 
-    def __init__(self, heads: Heads, uid_rank: Optional[np.ndarray] = None, lq: Optional[np.ndarray] = None, n_lq: int = 0):
+    def __init__(self, heads: Heads, uid_rank: Optional[np.ndarray] = None, lq: Optional[np.ndarray] = None, n_lq: int = 0,
+                 requeue_at: Optional[np.ndarray] = None):
         self.heads = heads
+        # RequeueState.RequeueAt per workload in ns (F.REQUEUE_NONE / F.REQUEUE_BLOCKED), None: nobody backs off
+        self.requeue_at = None if requeue_at is None else np.ascontiguousarray(requeue_at, dtype=np.int64)
         self.snap = heads.snap
         self.n = heads.n
         self.uid_rank = np.ascontiguousarray(uid_rank if uid_rank is not None else np.arange(heads.n), dtype=np.uint32)
@@ -627,6 +630,8 @@ class Pending:
             p.n_lq = self.n_lq if self.lq is not None else 0
             if self.lq is not None and self.lq.size:
                 p.lq = F.ptr(self.lq)
+            if self.requeue_at is not None and self.requeue_at.size:
+                p.requeue_at = F.ptr(self.requeue_at)
             self._struct = p
         return self._struct
 
@@ -642,7 +647,12 @@ class Pending:
         if self.heads.workloads is not None and more.heads.workloads is not None:
             h.workloads = list(self.heads.workloads) + list(more.heads.workloads)
         lq = None if self.lq is None else np.concatenate([self.lq, more.lq])
-        return Pending(h, uid_rank=np.concatenate([self.uid_rank, more.uid_rank]), lq=lq, n_lq=self.n_lq)
+        ra = None
+        if self.requeue_at is not None or more.requeue_at is not None:
+            none = lambda n: np.full(n, F.REQUEUE_NONE, np.int64)
+            ra = np.concatenate([self.requeue_at if self.requeue_at is not None else none(self.n),
+                                 more.requeue_at if more.requeue_at is not None else none(more.n)])
+        return Pending(h, uid_rank=np.concatenate([self.uid_rank, more.uid_rank]), lq=lq, n_lq=self.n_lq, requeue_at=ra)
 
     def heads_of(self, wl: np.ndarray, cycle: int) -> "Heads":
         """The kq_heads batch of the workloads `wl` with their STATIC columns (resume state left at its initial value)."""

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(64) void k_pend_apply(DPend D, DSnap S, DOut O, DHe
   pend_apply_head(D, S, O, H, gates, cycle, blockIdx.x);
 }
 __global__ __launch_bounds__(64) void k_pend_add_fix(DPend D, DSnap S, int first) { pend_add_fix(D, S, first + (int)blockIdx.x); }
+__global__ __launch_bounds__(64) void k_pend_requeue_at(DPend D, DSnap S, const int32_t* list, const int64_t* at) { pend_requeue_at(D, S, list, at, blockIdx.x); }
 __global__ __launch_bounds__(256) void k_pend_delete(DPend D, const int32_t* list, int n) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) pend_delete(D, list, i); }
 __global__ __launch_bounds__(64) void k_pend_qi(DPend D, const int32_t* list) { pend_queue_inadmissible(D, list ? list[blockIdx.x] : (int)blockIdx.x); }
 
@@ -393,6 +394,10 @@ struct HipBackend {
   void launch_pend_add_fix(const DPend& D, const DSnap& S, int first, int n) {
     if (n > 0) hipLaunchKernelGGL(k_pend_add_fix, dim3(n), dim3(64), 0, stream, D, S, first);
     chk(hipGetLastError(), "k_pend_add_fix");
+  }
+  void launch_pend_requeue_at(const DPend& D, const DSnap& S, const int32_t* list, const int64_t* at, int n) {
+    if (n > 0) hipLaunchKernelGGL(k_pend_requeue_at, dim3(n), dim3(64), 0, stream, D, S, list, at);
+    chk(hipGetLastError(), "k_pend_requeue_at");
   }
   void launch_pend_delete(const DPend& D, const int32_t* list, int n) {
     if (n > 0) hipLaunchKernelGGL(k_pend_delete, dim3((n + 255) / 256), dim3(256), 0, stream, D, list, n);
@@ -588,6 +593,11 @@ int kq_pending_set_lq_usage(kq_engine* en, int32_t n_lq, const double* usage) {
 int kq_pending_add(kq_engine* en, const kq_pending* more, int32_t* first_index) {
   if (!en || !more) return KQ_EINVAL;
   return en->e.pending_add(more, first_index);
+}
+int kq_pending_set_clock(kq_engine* en, int64_t now_ns) { if (!en) return KQ_EINVAL; return en->e.pending_set_clock(now_ns); }
+int kq_pending_set_requeue_at(kq_engine* en, int32_t n, const int32_t* wl, const int64_t* at) {
+  if (!en || (n > 0 && (!wl || !at))) return KQ_EINVAL;
+  return en->e.pending_set_requeue_at(n, wl, at);
 }
 int kq_pending_delete(kq_engine* en, int32_t n, const int32_t* wl) {
   if (!en || (n > 0 && !wl)) return KQ_EINVAL;

@@ -74,6 +74,7 @@ template <class B> struct EngineT {
     double* d_lq_usage = nullptr;     // [n_lq] AdmissionFairSharing usage of every LocalQueue
     int n_lq = 0;
     int32_t release_seq = 0;
+    int64_t now = 0;          // the queues' clock (kq_pending_set_clock)
     // host mirror of what kq_pending_add needs to merge new workloads into the heap orders and to size the gathered batch
     std::vector<int32_t> h_cq; std::vector<int64_t> h_prio, h_ts; std::vector<uint32_t> h_uid;
     std::vector<int> mps, mrq;       // widest workload of every ClusterQueue (podsets / requests)
@@ -139,7 +140,9 @@ template <class B> struct EngineT {
   }
   void pending_free() {
     for (void* p : pend.allocs) be.free(p);
+    const int64_t now = pend.now;
     pend = Pending{};
+    pend.now = now;
     if ((int)batches.size() > PEND_SLOT) batches[PEND_SLOT].valid = false;
   }
 
@@ -834,11 +837,14 @@ template <class B> struct EngineT {
       P.d_lq_usage = pend_alloc<double>(p->n_lq, nullptr, 0);
       D.lq_usage = P.d_lq_usage; P.n_lq = p->n_lq;
     }
+    D.requeue_at = nullptr; D.now = P.now;
+    if (p->requeue_at) D.requeue_at = pend_alloc<int64_t>(W, p->requeue_at);
     P.d_active = pend_alloc<uint8_t>(nq, nullptr, 1);
     P.d_list = pend_alloc<int32_t>(nq, nullptr, 0);
     P.d_tree_stamp = pend_alloc<int32_t>(std::max(prep.n_tree, 1), nullptr, 0);
     P.G = DGather{};
     pend_alloc_gather();
+    if (D.requeue_at && W > 0) be.launch_pend_add_fix(D, S, 0, W);  // workloads still backing off start among the inadmissible ones (:414)
     rc = be.sync();
     if (rc != KQ_OK) { pending_free(); return fail(rc, be.error()); }
     P.valid = true; P.n_heads = -1; P.ran = false;
@@ -927,6 +933,15 @@ template <class B> struct EngineT {
     pend_regrow(D.last_tried, nps0 * nR, aps * nR, h->ps_last_tried, 0xff);
     pend_regrow(D.last_gen, W0, n, h->last_generation, 0); pend_regrow(D.last_cycle, W0, n, h->last_cycle, 0);
     pend_regrow(D.last_hash, W0, n, h->last_hash, 0);
+    std::vector<int64_t> t_at;
+    t_at.reserve((size_t)W0 + (size_t)n);  // no reallocation while the copies below are in flight
+    if (D.requeue_at || p->requeue_at) {
+      if (!D.requeue_at) { t_at.assign((size_t)W0, KQ_REQUEUE_NONE); D.requeue_at = pend_alloc<int64_t>(W0, t_at.data()); }
+      std::vector<int64_t> tail((size_t)n, KQ_REQUEUE_NONE);
+      if (p->requeue_at) tail.assign(p->requeue_at, p->requeue_at + n);
+      t_at.insert(t_at.end(), tail.begin(), tail.end());  // (kept alive until the sync below)
+      pend_regrow(D.requeue_at, W0, n, t_at.data() + (t_at.size() - (size_t)n));
+    }
     if (P.n_lq > 0) pend_regrow(D.lq, W0, n, p->lq);
     P.h_cq.insert(P.h_cq.end(), h->cq, h->cq + n); P.h_prio.insert(P.h_prio.end(), h->priority, h->priority + n);
     P.h_ts.insert(P.h_ts.end(), h->queue_ts, h->queue_ts + n); P.h_uid.insert(P.h_uid.end(), uid.begin(), uid.end());
@@ -944,6 +959,24 @@ template <class B> struct EngineT {
     pend_alloc_gather();
     be.launch_pend_add_fix(D, S, W0, n);
     rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    return KQ_OK;
+  }
+  int pending_set_clock(int64_t now) { pend.now = now; pend.D.now = now; return KQ_OK; }
+  int pending_set_requeue_at(int n, const int32_t* wl, const int64_t* at) {
+    if (!have_snapshot || !pend.valid) return fail(KQ_EINVAL, "kq_pending_set_requeue_at before kq_pending_put");
+    if (pend.n_heads >= 0) return fail(KQ_EINVAL, "kq_pending_set_requeue_at between kq_pending_heads and kq_pending_apply");
+    if (n <= 0) return KQ_OK;
+    for (int i = 0; i < n; i++) if (wl[i] < 0 || wl[i] >= pend.W) return fail(KQ_EINVAL, "kq_pending_set_requeue_at: workload out of range");
+    DPend& D = pend.D;
+    std::vector<int64_t> none;
+    if (!D.requeue_at) { none.assign((size_t)pend.W, KQ_REQUEUE_NONE); D.requeue_at = pend_alloc<int64_t>(pend.W, none.data()); }
+    int32_t* dl = (int32_t*)be.alloc((size_t)n * sizeof(int32_t));
+    int64_t* da = (int64_t*)be.alloc((size_t)n * sizeof(int64_t));
+    be.h2d(dl, wl, (size_t)n * sizeof(int32_t)); be.h2d(da, at, (size_t)n * sizeof(int64_t));
+    be.launch_pend_requeue_at(D, S, dl, da, n);
+    int rc = be.sync();
+    be.free(dl); be.free(da);
     if (rc != KQ_OK) return fail(rc, be.error());
     return KQ_OK;
   }

@@ -51,7 +51,17 @@ struct DPend {
   // LocalQueues' fair-sharing usage (host-evaluated afs.CalculateUsage); lq == null: baseCompareFunc everywhere
   const int32_t* lq;         // [W] or null
   const double* lq_usage;    // [n_lq]
+  // back-off (backoffWaitingTimeExpired cluster_queue.go:474): RequeueAt per workload (null: nobody backs off) and the queues' clock
+  int64_t* requeue_at;       // [W] or null
+  int64_t now;
 };
+KQ_DEV bool pend_backoff_expired(const DPend& D, int w) {
+  if (!D.requeue_at) return true;
+  const int64_t at = D.requeue_at[w];
+  if (at == KQ_REQUEUE_NONE) return true;
+  if (at == KQ_REQUEUE_BLOCKED) return false;   // Requeued condition False :475
+  return D.now >= at;                           // Now().After(at) || Now().Equal(at) :483
+}
 // Go cmp.Compare(float64) as a sortable 64-bit key: NaN sorts before everything, then -Inf .. +Inf (-0 == +0)
 KQ_DEV uint64_t afs_key(double v) {
   if (v != v) return 0;
@@ -208,8 +218,8 @@ KQ_DEV void pend_apply_head(const DPend& D, const DSnap& S, const DOut& O, const
   }
   // RequeueIfNotPresent :826-841
   const bool immediate = strict ? true : (rq == KQ_RQ_FAILED_AFTER_NOMINATION || rq == KQ_RQ_PENDING_PREEMPTION);
-  // requeueIfNotPresent :568-575 (backoffWaitingTimeExpired: no RequeueState at this boundary)
-  if (immediate || D.qi_cycle[c] >= D.pop_cycle[c] || pending_flavors) { if (lane == 0) D.state[w] = WL_ACTIVE; return; }
+  // requeueIfNotPresent :568-575
+  if (pend_backoff_expired(D, w) && (immediate || D.qi_cycle[c] >= D.pop_cycle[c] || pending_flavors)) { if (lane == 0) D.state[w] = WL_ACTIVE; return; }
   if (lane == 0) D.state[w] = WL_INADMISSIBLE;  // :585
   // :592-597 bulk move of the equivalence class (handleInadmissibleHash :606-621; BestEffortFIFO only)
   const uint64_t hash = D.P.hash[w];
@@ -228,7 +238,7 @@ KQ_DEV void pend_queue_inadmissible(const DPend& D, int c) {
   if (lane == 0) D.qi_cycle[c] = D.pop_cycle[c];
   for (int j = D.cq_off[c] + lane; j < D.cq_off[c + 1]; j += WAVE) {
     const int w = D.ord[j];
-    if (D.state[w] == WL_INADMISSIBLE) D.state[w] = WL_ACTIVE;
+    if (D.state[w] == WL_INADMISSIBLE && pend_backoff_expired(D, w)) D.state[w] = WL_ACTIVE;  // :167: a workload still backing off stays
     D.bulk[w] = 0;  // c.hashToBulkMoveReason = make(...) inadmissible_workloads.go:158
   }
 }
@@ -237,14 +247,26 @@ KQ_DEV void pend_queue_inadmissible(const DPend& D, int c) {
 KQ_DEV void pend_add_fix(const DPend& D, const DSnap& S, int w) {
   const int lane = lane_id();
   const int c = D.P.cq[w];
+  if (!pend_backoff_expired(D, w)) { if (lane == 0) D.state[w] = WL_INADMISSIBLE; return; }  // :414
   const uint64_t hash = D.P.hash[w];
   if (hash == 0 || KQ_POL_STRICT_FIFO(S.cq_policy[c]) != 0) return;
   bool hit = false;
   for (int j = D.cq_off[c] + lane; j < D.cq_off[c + 1]; j += WAVE) {
     const int w2 = D.ord[j];
-    if (w2 != w && D.bulk[w2] && D.P.hash[w2] == hash) hit = true;
+    if (D.bulk[w2] && D.P.hash[w2] == hash) hit = true;
   }
   if (wballot(hit) != 0 && lane == 0) D.state[w] = WL_INADMISSIBLE;
+}
+// PushOrUpdate of a pending workload whose RequeueState / Requeued condition changed (cluster_queue.go:391-428): one wave per workload
+KQ_DEV void pend_requeue_at(const DPend& D, const DSnap& S, const int32_t* list, const int64_t* at, int i) {
+  const int lane = lane_id();
+  const int w = list[i];
+  if (lane == 0) D.requeue_at[w] = at[i];
+  wsync();
+  if (D.state[w] != WL_INADMISSIBLE) return;   // in flight: RequeueWorkload places it (:388); in the heap: stays (:414 needs GetActive == nil)
+  if (lane == 0) D.state[w] = WL_ACTIVE;       // conditions changed => leaves the inadmissible set (:405) ...
+  wsync();
+  pend_add_fix(D, S, w);                       // ... unless it still backs off or its class is bulk-moved
 }
 // ClusterQueue.Delete :488-512 — one thread per workload
 KQ_DEV void pend_delete(const DPend& D, const int32_t* list, int i) {

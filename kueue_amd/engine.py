@@ -110,6 +110,14 @@ class Engine:
         self.pending = self.pending.extended(more)
         return first.value
 
+    def pending_set_clock(self, now_ns: int):
+        self._check(self._lib.kq_pending_set_clock(self._h, C.c_int64(int(now_ns))))
+
+    def pending_set_requeue_at(self, wl, at):
+        a = np.ascontiguousarray(wl, np.int32); b = np.ascontiguousarray(at, np.int64)
+        if len(a):
+            self._check(self._lib.kq_pending_set_requeue_at(self._h, C.c_int32(len(a)), F.ptr(a), F.ptr(b)))
+
     def pending_delete(self, wl):
         """kq_pending_delete: ClusterQueue.Delete of pending workloads."""
         a = np.ascontiguousarray(wl, np.int32)

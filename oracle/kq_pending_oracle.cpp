@@ -29,6 +29,7 @@ struct WL {
   bool has_last; std::vector<int32_t> last_tried; int64_t last_gen, last_cycle; uint64_t last_hash;
   int ps0, nps;
   int lq;  // LocalQueue index, -1 = the ClusterQueue orders by baseCompareFunc only
+  int64_t requeue_at = KQ_REQUEUE_NONE;  // RequeueState.RequeueAt (ns); KQ_REQUEUE_BLOCKED while the Requeued condition is False
 };
 
 struct CQ {
@@ -45,6 +46,13 @@ struct Queue {
   std::vector<CQ> cqs;
   std::vector<int> head_wl;          // heads of the cycle in flight, per ClusterQueue
   std::vector<double> lq_usage;      // ComputeLocalQueueFSUsage per LocalQueue (workload.go:492), host-evaluated
+  int64_t now = 0;                   // c.clock.Now()
+  // backoffWaitingTimeExpired cluster_queue.go:474-485
+  bool backoffExpired(const WL& x) const {
+    if (x.requeue_at == KQ_REQUEUE_BLOCKED) return false;
+    if (x.requeue_at == KQ_REQUEUE_NONE) return true;
+    return now >= x.requeue_at;
+  }
   // Go cmp.Compare on float64: NaN < everything, -0 == +0
   static int cmpF(double a, double b) {
     const bool an = a != a, bn = b != b;
@@ -96,7 +104,7 @@ struct Queue {
     WL& x = wl[w]; CQ& c = cqs[x.cq];
     if (reason == KQ_RQ_PENDING_PREEMPTION) { c.pw = w; c.pw_sticky = !c.strict; }  // :558-563
     const bool inadm = x.state == KQ_WL_INADMISSIBLE;
-    if (immediate || c.queueInadmissibleCycle >= c.popCycle || PendingFlavors(x)) {  // :568-575
+    if (backoffExpired(x) && (immediate || c.queueInadmissibleCycle >= c.popCycle || PendingFlavors(x))) {  // :568-575
       if (x.state == KQ_WL_ACTIVE) return false;  // PushActiveIfNotPresent
       x.state = KQ_WL_ACTIVE;
       return true;
@@ -128,8 +136,15 @@ struct Queue {
     c.queueInadmissibleCycle = c.popCycle;
     c.hashToBulkMoveReason.clear();
     int moved = 0;
-    for (int w : c.members) if (wl[w].state == KQ_WL_INADMISSIBLE) { wl[w].state = KQ_WL_ACTIVE; moved++; }
+    for (int w : c.members) if (wl[w].state == KQ_WL_INADMISSIBLE && backoffExpired(wl[w])) { wl[w].state = KQ_WL_ACTIVE; moved++; }  // :167
     return moved;
+  }
+  // PushOrUpdate :379-428 of workload w with its present columns: where does it go?
+  void place(int w) {
+    WL& x = wl[w]; CQ& c = cqs[x.cq];
+    if (!backoffExpired(x)) { x.state = KQ_WL_INADMISSIBLE; return; }                                               // :414
+    if (!c.strict && x.hash != 0 && c.hashToBulkMoveReason.count(x.hash)) { x.state = KQ_WL_INADMISSIBLE; return; }  // :419-425
+    x.state = KQ_WL_ACTIVE;
   }
 };
 
@@ -158,7 +173,9 @@ void* kqp_create(const kq_pending* p, int32_t n_cq, int32_t n_resource, const ui
     x.last_gen = h.last_generation ? h.last_generation[w] : 0; x.last_cycle = h.last_cycle ? h.last_cycle[w] : 0;
     x.last_hash = h.last_hash ? h.last_hash[w] : 0;
     x.lq = (p->lq && p->n_lq > 0) ? p->lq[w] : -1;
+    x.requeue_at = p->requeue_at ? p->requeue_at[w] : KQ_REQUEUE_NONE;
     q->cqs[x.cq].members.push_back(w);
+    q->place(w);
   }
   q->head_wl.assign(n_cq, -1);
   if (p->lq && p->n_lq > 0) q->lq_usage.assign(p->n_lq, 0.0);
@@ -185,10 +202,11 @@ int kqp_add(void* qp, const kq_pending* p) {
     x.last_gen = h.last_generation ? h.last_generation[i] : 0; x.last_cycle = h.last_cycle ? h.last_cycle[i] : 0;
     x.last_hash = h.last_hash ? h.last_hash[i] : 0;
     x.lq = (p->lq && p->n_lq > 0) ? p->lq[i] : -1;
-    CQ& c = q.cqs[x.cq];
-    x.state = (!c.strict && x.hash != 0 && c.hashToBulkMoveReason.count(x.hash)) ? KQ_WL_INADMISSIBLE : KQ_WL_ACTIVE;
+    x.requeue_at = p->requeue_at ? p->requeue_at[i] : KQ_REQUEUE_NONE;
+    x.state = KQ_WL_ACTIVE;
     q.wl.push_back(x);
-    c.members.push_back(first + i);
+    q.cqs[x.cq].members.push_back(first + i);
+    q.place(first + i);
   }
   return first;
 }
@@ -265,6 +283,17 @@ void kqp_set_last(void* qp, int32_t w, int32_t has_last, const int32_t* last_tri
 }
 void kqp_set_state(void* qp, int32_t w, int32_t state) { ((Queue*)qp)->wl[w].state = state; }
 void kqp_delete(void* qp, int32_t w) { ((Queue*)qp)->Delete(w); }
+void kqp_set_clock(void* qp, int64_t now) { ((Queue*)qp)->now = now; }
+// the controller changed RequeueState / the Requeued condition: PushOrUpdate of an existing workload whose conditions changed (:391-428)
+void kqp_set_requeue_at(void* qp, int32_t n, const int32_t* wl, const int64_t* at) {
+  Queue& q = *(Queue*)qp;
+  for (int i = 0; i < n; i++) {
+    WL& x = q.wl[wl[i]];
+    x.requeue_at = at[i];
+    if (x.state != KQ_WL_INADMISSIBLE) continue;  // in flight: skipped (:388); in the heap: PushOrUpdateActive
+    q.place(wl[i]);
+  }
+}
 void kqp_delete_list(void* qp, int32_t n, const int32_t* wl) { for (int i = 0; i < n; i++) ((Queue*)qp)->Delete(wl[i]); }
 int kqp_handle_hash(void* qp, int32_t cq, uint64_t hash) { Queue& q = *(Queue*)qp; return hash ? q.handleInadmissibleHash(q.cqs[cq], hash) : 0; }
 int kqp_is_sticky(void* qp, int32_t w) { Queue& q = *(Queue*)qp; const CQ& c = q.cqs[q.wl[w].cq]; return c.pw == w && c.pw_sticky; }

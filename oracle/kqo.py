@@ -342,6 +342,16 @@ class PendingOracle:
         self.pending = self.pending.extended(more)
         return first
 
+    def set_clock(self, now_ns: int):
+        self.l.kqp_set_clock.restype = None
+        self.l.kqp_set_clock(self.h, C.c_int64(int(now_ns)))
+
+    def set_requeue_at(self, wl, at):
+        a = np.ascontiguousarray(wl, np.int32); b = np.ascontiguousarray(at, np.int64)
+        self.l.kqp_set_requeue_at.restype = None
+        if len(a):
+            self.l.kqp_set_requeue_at(self.h, len(a), F.ptr(a), F.ptr(b))
+
     def delete_many(self, wl):
         a = np.ascontiguousarray(wl, np.int32)
         self.l.kqp_delete_list.restype = None

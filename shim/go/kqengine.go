@@ -290,7 +290,8 @@ func (e *Engine) RunCycle(h *FlatHeads, out *FlatDecisions) error {
 
 // PutPending = PushOrUpdate of every pending workload (cluster_queue.go:379). uidRank[w] = rank of Obj.UID.
 // lq (optional, AdmissionFairSharing): index of the workload's LocalQueue in [0,nLQ) or -1 (queueOrderingFunc cluster_queue.go:880).
-func (e *Engine) PutPending(all *FlatHeads, uidRank []uint32, nLQ int32, lq []int32) error {
+// requeueAt (optional): RequeueState.RequeueAt per workload in ns, RequeueNone / RequeueBlocked (backoffWaitingTimeExpired :474).
+func (e *Engine) PutPending(all *FlatHeads, uidRank []uint32, nLQ int32, lq []int32, requeueAt []int64) error {
 	var p runtime.Pinner
 	defer p.Unpin()
 	c := (*C.kq_pending)(C.calloc(1, C.sizeof_kq_pending))
@@ -301,6 +302,9 @@ func (e *Engine) PutPending(all *FlatHeads, uidRank []uint32, nLQ int32, lq []in
 		c.n_lq = C.int32_t(nLQ)
 		c.lq = (*C.int32_t)(pin(&p, lq))
 	}
+	if len(requeueAt) > 0 {
+		c.requeue_at = (*C.int64_t)(pin(&p, requeueAt))
+	}
 	if rc := C.kq_pending_put(e.h, c); rc != 0 {
 		return e.err("kq_pending_put", rc)
 	}
@@ -309,7 +313,7 @@ func (e *Engine) PutPending(all *FlatHeads, uidRank []uint32, nLQ int32, lq []in
 
 // AddPending = PushOrUpdate (cluster_queue.go:379) of workloads that were not pending before; returns the index of the first one
 // (existing indices do not move). lq as in PutPending.
-func (e *Engine) AddPending(more *FlatHeads, uidRank []uint32, nLQ int32, lq []int32) (int32, error) {
+func (e *Engine) AddPending(more *FlatHeads, uidRank []uint32, nLQ int32, lq []int32, requeueAt []int64) (int32, error) {
 	var p runtime.Pinner
 	defer p.Unpin()
 	c := (*C.kq_pending)(C.calloc(1, C.sizeof_kq_pending))
@@ -320,11 +324,40 @@ func (e *Engine) AddPending(more *FlatHeads, uidRank []uint32, nLQ int32, lq []i
 		c.n_lq = C.int32_t(nLQ)
 		c.lq = (*C.int32_t)(pin(&p, lq))
 	}
+	if len(requeueAt) > 0 {
+		c.requeue_at = (*C.int64_t)(pin(&p, requeueAt))
+	}
 	var first C.int32_t
 	if rc := C.kq_pending_add(e.h, c, &first); rc != 0 {
 		return 0, e.err("kq_pending_add", rc)
 	}
 	return int32(first), nil
+}
+
+const (
+	RequeueNone    = int64(-1 << 63) // no RequeueState.RequeueAt
+	RequeueBlocked = int64(1<<63 - 1) // the Requeued condition is False
+)
+
+// SetClock = c.clock.Now() of the queues for the calls that follow.
+func (e *Engine) SetClock(nowNs int64) error {
+	if rc := C.kq_pending_set_clock(e.h, C.int64_t(nowNs)); rc != 0 {
+		return e.err("kq_pending_set_clock", rc)
+	}
+	return nil
+}
+
+// SetRequeueAt = PushOrUpdate of pending workloads whose RequeueState / Requeued condition changed (cluster_queue.go:391-428).
+func (e *Engine) SetRequeueAt(wl []int32, at []int64) error {
+	if len(wl) == 0 {
+		return nil
+	}
+	var p runtime.Pinner
+	defer p.Unpin()
+	if rc := C.kq_pending_set_requeue_at(e.h, C.int32_t(len(wl)), (*C.int32_t)(pin(&p, wl)), (*C.int64_t)(pin(&p, at))); rc != 0 {
+		return e.err("kq_pending_set_requeue_at", rc)
+	}
+	return nil
 }
 
 // DeletePending = ClusterQueue.Delete (cluster_queue.go:488) of pending workloads (deleted, finished, admitted elsewhere).

@@ -72,6 +72,7 @@ struct EmuBackend {
     for (int h = 0; h < n; h++) pend_apply_head(D, S, O, H, gates, cycle, h);
   }
   void launch_pend_add_fix(const DPend& D, const DSnap& S, int first, int n) { for (int i = 0; i < n; i++) pend_add_fix(D, S, first + i); }
+  void launch_pend_requeue_at(const DPend& D, const DSnap& S, const int32_t* list, const int64_t* at, int n) { for (int i = 0; i < n; i++) pend_requeue_at(D, S, list, at, i); }
   void launch_pend_delete(const DPend& D, const int32_t* list, int n) { for (int i = 0; i < n; i++) pend_delete(D, list, i); }
   void launch_pend_qi(const DPend& D, const int32_t* list, int n) { for (int i = 0; i < n; i++) pend_queue_inadmissible(D, list ? list[i] : i); }
   void launch_pend_release(const DPend& D, const DSnap& S, int32_t* tree_stamp, const int32_t* cq, const int32_t* use_n, int n, int32_t stamp) {
@@ -183,6 +184,8 @@ int kqe_cycle_run_pending(void* e, kq_decisions* out) { return ((EmuEngine*)e)->
 int kqe_pending_apply(void* e) { return ((EmuEngine*)e)->pending_apply(); }
 int kqe_pending_set_lq_usage(void* e, int32_t n, const double* u) { return ((EmuEngine*)e)->pending_set_lq_usage(n, u); }
 int kqe_pending_add(void* e, const kq_pending* more, int32_t* first) { return ((EmuEngine*)e)->pending_add(more, first); }
+int kqe_pending_set_clock(void* e, int64_t now) { return ((EmuEngine*)e)->pending_set_clock(now); }
+int kqe_pending_set_requeue_at(void* e, int32_t n, const int32_t* wl, const int64_t* at) { return ((EmuEngine*)e)->pending_set_requeue_at(n, wl, at); }
 int kqe_pending_delete(void* e, int32_t n, const int32_t* wl) { return ((EmuEngine*)e)->pending_delete(n, wl); }
 int kqe_pending_queue_inadmissible(void* e, int32_t n, const int32_t* cq) { return ((EmuEngine*)e)->pending_queue_inadmissible(n, cq); }
 int kqe_pending_read_state(void* e, uint8_t* st, int32_t* counts) { return ((EmuEngine*)e)->pending_read_state(st, counts); }

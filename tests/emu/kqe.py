@@ -122,6 +122,14 @@ class EmuEngine:
         self.pending = self.pending.extended(more)
         return first.value
 
+    def pending_set_clock(self, now_ns: int):
+        self._ok(lib().kqe_pending_set_clock(self.h, C.c_int64(int(now_ns))))
+
+    def pending_set_requeue_at(self, wl, at):
+        a = np.ascontiguousarray(wl, np.int32); b = np.ascontiguousarray(at, np.int64)
+        if len(a):
+            self._ok(lib().kqe_pending_set_requeue_at(self.h, C.c_int32(len(a)), F.ptr(a), F.ptr(b)))
+
     def pending_delete(self, wl):
         a = np.ascontiguousarray(wl, np.int32)
         if len(a):

@@ -436,3 +436,119 @@ def test_pending_arrivals_and_deletions_gpu(oracle):
     pop = generate(3, n_cq=200, per_cq=20)
     added, deleted, _ = _arrivals_loop(oracle, Engine, pop, make_config(), cycles=30, seed=9)  # (no releases here: stay inside the commit ring)
     assert added > 50 and deleted > 20
+
+
+# ---- back-off after a PodsReady timeout (backoffWaitingTimeExpired cluster_queue.go:474) --------------------------------------------
+
+NOW = 1_000_000_000_000
+MIN = 60_000_000_000
+# Test_PushOrUpdate (cluster_queue_test.go:69-175) and TestBackoffWaitingTimeExpired (:1321-1378), transcribed by hand:
+# (name, RequeueAt as the boundary carries it, does the pushed workload land in the heap?)
+BACKOFF = [
+    ("workload doesn't have re-queue state :85", F.REQUEUE_NONE, True),
+    ("workload is still under the backoff waiting time :89 (Requeued=False)", F.REQUEUE_BLOCKED, False),
+    ("should wait for Requeued=true after backoff waiting time before push to heap :116", F.REQUEUE_BLOCKED, False),
+    ("should push workload to heap after Requeued=true :142", F.REQUEUE_NONE, True),
+    ("requeueState without requeueAt :1343", F.REQUEUE_NONE, True),
+    ("now already has exceeded requeueAt :1347", NOW - MIN, True),
+    ("now hasn't yet exceeded requeueAt :1357", NOW + MIN, False),
+    ("now equals requeueAt (Equal, :484)", NOW, True),
+]
+
+
+@pytest.mark.parametrize("case", BACKOFF, ids=[c[0] for c in BACKOFF])
+def test_backoff_push_tables(oracle, case):
+    from tests.emu import kqe
+    name, at, in_heap = case
+    snap, _, _ = _tiny({"strategy": "BestEffortFIFO", "workloads": [{"name": "workload-1", "prio": 1}]})
+    h = Heads(snap, [Workload("workload-1", "cq", priority=1, creation_ts=1, pod_sets=[PodSet("main", 1, requests={"cpu": 1000})], uid="u")], cycle=0)
+    pending = Pending(h, uid_rank=np.zeros(1, np.uint32), requeue_at=np.array([at], np.int64))
+    cfg = make_config()
+    q = oracle.PendingOracle.__new__(oracle.PendingOracle)
+    eng = kqe.EmuEngine(cfg)
+    try:
+        eng.put(snap)
+        eng.pending_set_clock(NOW)
+        eng.pending_put(pending)
+        # the oracle's clock must be set before its PushOrUpdate: create it empty and add
+        empty = Pending(h.subset(np.zeros(0, np.int64)), uid_rank=np.zeros(0, np.uint32), requeue_at=np.zeros(0, np.int64))
+        q.__init__(cfg, snap, empty)
+        q.set_clock(NOW)
+        q.add(pending)
+        want = F.WL_ACTIVE if in_heap else F.WL_INADMISSIBLE
+        assert q.state()[0] == want and eng.pending_state()[0][0] == want
+        # a minute and a second later the back-off is over; queueInadmissibleWorkloads (:167) lets only expired workloads back
+        eng.pending_set_clock(NOW + MIN + 1_000_000_000); q.set_clock(NOW + MIN + 1_000_000_000)
+        eng.pending_queue_inadmissible(); q.queue_inadmissible()
+        later = F.WL_INADMISSIBLE if at == F.REQUEUE_BLOCKED else F.WL_ACTIVE
+        assert q.state()[0] == later and eng.pending_state()[0][0] == later
+        # the controller sets Requeued=True: the workload leaves the inadmissible set
+        eng.pending_set_requeue_at([0], [F.REQUEUE_NONE]); q.set_requeue_at([0], [F.REQUEUE_NONE])
+        assert q.state()[0] == F.WL_ACTIVE and eng.pending_state()[0][0] == F.WL_ACTIVE
+    finally:
+        eng.close(); q.close()
+
+
+def _backoff_loop(oracle, eng_factory, pop, cfg, cycles, seed):
+    """Closed loop in which a third of the workloads carry a back-off (some expired, some not, some blocked), the clock advances
+    every cycle, the controller lifts blocks now and then, and cohorts requeue their inadmissible workloads."""
+    rng = np.random.default_rng(seed)
+    base = pop.pending()
+    W = base.n
+    at = np.full(W, F.REQUEUE_NONE, np.int64)
+    pick = rng.random(W) < 0.35
+    at[pick] = NOW + rng.integers(-3, 12, size=int(pick.sum())) * MIN
+    at[rng.random(W) < 0.05] = F.REQUEUE_BLOCKED
+    pending = Pending(base.heads, uid_rank=base.uid_rank, requeue_at=at)
+    snap = pop.snapshot
+    eng = eng_factory(cfg)
+    q = oracle.PendingOracle.__new__(oracle.PendingOracle)
+    try:
+        eng.put(snap); eng.pending_set_clock(NOW); eng.pending_put(pending)
+        empty = Pending(base.heads.subset(np.zeros(0, np.int64)), uid_rank=np.zeros(0, np.uint32), requeue_at=np.zeros(0, np.int64))
+        q.__init__(cfg, snap, empty); q.set_clock(NOW); q.add(pending)
+        assert np.array_equal(eng.pending_state()[0], q.state())
+        waiting0 = int((q.state() == F.WL_INADMISSIBLE).sum())
+        osnap = copy.copy(snap); osnap.arrays = dict(snap.arrays)
+        for cyc in range(1, cycles + 1):
+            now = NOW + cyc * MIN
+            eng.pending_set_clock(now); q.set_clock(now)
+            if cyc % 3 == 0:
+                blocked = np.nonzero(pending.requeue_at == F.REQUEUE_BLOCKED)[0]
+                if len(blocked):
+                    lift = rng.choice(blocked, size=min(3, len(blocked)), replace=False)
+                    pending.requeue_at[lift] = F.REQUEUE_NONE
+                    eng.pending_set_requeue_at(lift, np.full(len(lift), F.REQUEUE_NONE, np.int64)); q.set_requeue_at(lift, np.full(len(lift), F.REQUEUE_NONE, np.int64))
+            if cyc % 2 == 0:
+                eng.pending_queue_inadmissible(); q.queue_inadmissible()
+            assert np.array_equal(eng.pending_state()[0], q.state()), f"cycle {cyc}: states differ before Heads()"
+            n, nps, hw = eng.pending_heads(cyc)
+            hb, ohw = q.heads(cyc)
+            assert np.array_equal(hw, ohw), f"cycle {cyc}: Heads() differ"
+            if n == 0:
+                eng.pending_apply()
+                continue
+            got = eng.run_pending(Decisions(hb, tgt_cap=max(4096, snap.n_adm)))
+            want = oracle.cycle_run(cfg, osnap, hb)
+            assert not want.equal(got), (cyc, want.equal(got))
+            usage, na, triples = oracle.cycle_commit(cfg, osnap, hb)
+            osnap.arrays["usage"] = usage; osnap._struct = None
+            assert eng.try_commit() == 0
+            eng.pending_apply(); q.apply(hb, want)
+            assert np.array_equal(eng.pending_state()[0], q.state()), f"cycle {cyc}: states differ"
+        return waiting0
+    finally:
+        eng.close(); q.close()
+
+
+def test_backoff_closed_loop_emulated(oracle):
+    from tests.emu import kqe
+    pop = generate(3, n_cq=24, per_cq=10)
+    assert _backoff_loop(oracle, kqe.EmuEngine, pop, make_config(), cycles=24, seed=4) > 20
+
+
+@pytest.mark.gpu
+def test_backoff_closed_loop_gpu(oracle):
+    from kueue_amd.engine import Engine
+    pop = generate(3, n_cq=200, per_cq=20)
+    assert _backoff_loop(oracle, Engine, pop, make_config(), cycles=28, seed=5) > 200
