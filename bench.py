@@ -259,6 +259,26 @@ def snapshot_put_cost(eng, snap):
             "patch_admitted": med(lambda: eng.patch(snap, F.PATCH_ADMITTED))}
 
 
+def pending_cost(eng, pop):
+    """What the device-resident pending side costs a drop-in between cycles: kq_pending_put of the whole set (host sort + every column
+    over PCIe), kq_pending_add of 1000 arrivals into the resident set, kq_pending_delete of 1000 workloads."""
+    from kueue_amd.api import Pending
+    full = pop.pending()
+
+    def t(fn):
+        t1 = time.perf_counter()
+        fn()
+        return (time.perf_counter() - t1) * 1e3
+    put = float(np.median([t(lambda: eng.pending_put(full)) for _ in range(3)]))
+    idx = np.arange(0, full.n, max(1, full.n // 1000))[:1000]
+    more = Pending(full.heads.subset(idx), uid_rank=(full.uid_rank[idx] + np.uint32(full.n)))
+    add = []
+    for _ in range(3):
+        add.append(t(lambda: eng.pending_add(more)))
+    dele = t(lambda: eng.pending_delete(idx.astype(np.int32)))
+    return {"put": put, "add_1000": float(np.median(add)), "delete_1000": dele, "resident": int(full.n)}
+
+
 class PendingLoop:
     """SURVEY 8d's run on the engine: Heads() from the device-resident pending set, one cycle, admissions committed into the resident
     snapshot, requeue on the device, the workloads admitted `hold` cycles ago finish (which requeues the inadmissible ones)."""
@@ -437,6 +457,7 @@ def bench_pending(args, torch, dist, world, rank, local_rank):
             eng.put(snap)
             out["host_heads"] = host_heads_leg(eng, pop, kcfg, snap, min(args.steps, 50), True, args.hold, fair, 0)
             out["snapshot_put_ms"] = snapshot_put_cost(eng, snap)
+            out["pending_ms"] = pending_cost(eng, pop)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_pending(pop, kcfg, args.cpu_seconds, args.hold)
         else:
