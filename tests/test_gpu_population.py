@@ -54,3 +54,24 @@ def test_all_pending_batch_nominate(oracle):
             assert np.array_equal(want.a[k], got.a[k]), k
     finally:
         eng.close()
+
+
+def test_fair_preemption_with_helper_workgroups(oracle, monkeypatch):
+    """KQ_HELP_BLOCKS: the SimulatePreemption calls of a recomputation inside k_process_fair are posted as a batch and taken by helper
+    workgroups (K::help, kq_device.hpp help_exec / helper_main). Off by default; whoever runs a task, the cycle is the oracle's."""
+    from kueue_amd.engine import Engine
+    monkeypatch.setenv("KQ_HELP_BLOCKS", "24")
+    pop = generate(4, n_cq=100, per_cq=4, fair_sharing=True)
+    cfg = make_config(fair_sharing=True)
+    eng = Engine(cfg)
+    try:
+        eng.put(pop.snapshot)
+        for c in (0, 1):
+            heads = pop.heads_for_cycle(c, cycle=c + 1)
+            want = oracle.cycle_run(cfg, pop.snapshot, heads, want_usage=True)
+            got = eng.run(heads, tgt_cap=max(4096, pop.snapshot.n_adm))
+            assert not want.equal(got), (c, want.equal(got))
+            assert np.array_equal(want.usage_after, eng.usage_after()), c
+            assert got.bytes == want.stats["total"], c
+    finally:
+        eng.close()
