@@ -187,6 +187,7 @@ template <class B> struct EngineT {
     // Resident head batches were validated against, and carry the strides of, the snapshot they were uploaded under
     // (cq < nq, req_res < nR, ps_flavor_ok / ps_last_tried row widths): a new snapshot voids them. kq_heads_put again.
     for (size_t b = 0; b < batches.size(); b++) if ((int)b != PEND_SLOT) batches[b].valid = false;
+    prep.want_fs = cfg.fair_sharing != 0;
     int rc = build_prep(s, prep);
     if (rc != KQ_OK) return fail(rc, prep.err);
     // the pending store is indexed by ClusterQueue / resource / flavor: it survives a snapshot refresh with the same dictionary
@@ -298,6 +299,7 @@ template <class B> struct EngineT {
       // the admitted-row structures (candidate rank order, flavor-resource buckets, level orders, row records) are rebuilt on the
       // host and replace the resident ones; quota planes, the tree and the resource groups are not touched
       Prep np;
+      np.want_fs = cfg.fair_sharing != 0;
       int rc = build_prep(s, np);
       if (rc != KQ_OK) return fail(rc, np.err);
       prep = std::move(np);

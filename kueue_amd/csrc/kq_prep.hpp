@@ -111,6 +111,7 @@ struct Prep {
   std::vector<double> fs_weight;                   // [N]
   std::vector<double> h_weight;                    // host copy of fair_weight for build_fair after a device derive
   int max_tree_mw = 1;                             // words of a candidate bitmap of the largest tree
+  bool want_fs = true;                             // build the kq_fs.hpp structures (the engine clears it when fair sharing is off)
   int max_rsn_per_podset = 1;  // most reason records one podset's flavor scans can produce: max over ClusterQueues of sum over groups of flavors x (resources + 1)
   std::string err;
 };
@@ -178,6 +179,7 @@ static inline void build_fair(Prep& p, const int64_t* sq, const int64_t* usage, 
     }
   }
   // kq_fs.hpp: the same constants in tree-node order
+  if (!p.want_fs) { p.fs_q.clear(); p.fs_lend.clear(); p.fs_weight.clear(); p.fs_c0.clear(); p.fs_c1.clear(); return; }
   p.fs_q.assign((size_t)N * nfr, FsQ{0, U}); p.fs_lend.assign((size_t)N * p.nR, 0);
   p.fs_weight.assign(N, 1.0); p.fs_c0.assign(N, 0); p.fs_c1.assign(N, 0);
   for (int tp = 0; tp < N; tp++) {
@@ -385,10 +387,11 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
     // ---- kq_fs.hpp: candidates in position order, children lists in tree-node order ----
     for (int c = 0; c < nq; c++) if (p.depth[c] + 1 > FS_LV) p.fs_ok[p.tree_of[c]] = 0;
     if (p.nfr > 32767) for (auto& f : p.fs_ok) f = 0;
-    p.fs_scan.assign(p.n_adm, FsScan{}); p.fs_apply.assign(p.n_adm, FsApply{});
+    if (!p.want_fs) for (auto& f : p.fs_ok) f = 0;
+    p.fs_scan.assign(p.want_fs ? p.n_adm : 0, FsScan{}); p.fs_apply.assign(p.want_fs ? p.n_adm : 0, FsApply{});
     p.fs_posoff.assign((size_t)nq + p.n_tree, 0);
     p.max_tree_mw = 1;
-    for (int t = 0; t < p.n_tree; t++) {
+    for (int t = 0; t < p.n_tree && p.want_fs; t++) {
       const int q0 = p.tree_cq_off[t], nqs = p.tree_cq_off[t + 1] - q0, r0 = p.tree_row_off[t];
       const int nn = p.tree_node_off[t + 1] - p.tree_node_off[t];
       if (nn > 32767) p.fs_ok[t] = 0;
