@@ -78,15 +78,27 @@ template <class B> struct EngineT {
     // host mirror of what kq_pending_add needs to merge new workloads into the heap orders and to size the gathered batch
     std::vector<int32_t> h_cq; std::vector<int64_t> h_prio, h_ts; std::vector<uint32_t> h_uid;
     std::vector<int> mps, mrq;       // widest workload of every ClusterQueue (podsets / requests)
+    std::vector<int32_t> h_ord;      // the heap orders as uploaded
+    size_t gps = 0, grq = 0;         // podset / request rows of the gathered batch as allocated
     size_t nps_total = 0, nreq_total = 0;
   } pend;
-  // grow a resident array of the pending set by `add_n` elements (tail from the host, or a fill byte)
+  // grow a resident array of the pending set by `add_n` elements (tail from the host, or a fill byte). Arrays are reallocated with
+  // head room, so that a stream of small arrivals mostly costs the copy of its own rows.
+  std::vector<std::pair<const void*, size_t>> pend_caps;  // capacity in bytes of the arrays pend_regrow allocated
+  size_t pend_cap_of(const void* d) const { for (auto& c : pend_caps) if (c.first == d) return c.second; return 0; }
   template <class T> void pend_regrow(T*& d, size_t old_n, size_t add_n, const T* tail, int fill = -2) {
-    T* nd = (T*)be.alloc(std::max<size_t>(old_n + add_n, 1) * sizeof(T));
-    if (old_n) be.d2d(nd, d, old_n * sizeof(T));
+    const size_t need = std::max<size_t>(old_n + add_n, 1) * sizeof(T);
+    T* nd = d;
+    if (need > pend_cap_of(d)) {
+      const size_t cap = need + need / 4 + 65536;
+      nd = (T*)be.alloc(cap);
+      if (old_n) be.d2d(nd, d, old_n * sizeof(T));
+      for (size_t i = 0; i < pend.allocs.size(); i++) if (pend.allocs[i] == (void*)d) { be.free(pend.allocs[i]); pend.allocs.erase(pend.allocs.begin() + i); break; }
+      for (size_t i = 0; i < pend_caps.size(); i++) if (pend_caps[i].first == (const void*)d) { pend_caps.erase(pend_caps.begin() + i); break; }
+      pend.allocs.push_back(nd);
+      pend_caps.emplace_back((const void*)nd, cap);
+    }
     if (add_n) { if (tail) be.h2d(nd + old_n, tail, add_n * sizeof(T)); else if (fill != -2) be.memset(nd + old_n, fill, add_n * sizeof(T)); }
-    for (size_t i = 0; i < pend.allocs.size(); i++) if (pend.allocs[i] == (void*)d) { be.free(pend.allocs[i]); pend.allocs.erase(pend.allocs.begin() + i); break; }
-    pend.allocs.push_back(nd);
     d = nd;
   }
   template <class T> void pend_regrow(const T*& d, size_t old_n, size_t add_n, const T* tail, int fill = -2) {
@@ -96,6 +108,7 @@ template <class B> struct EngineT {
   }
   void pend_release_ptr(const void* d) {
     for (size_t i = 0; i < pend.allocs.size(); i++) if (pend.allocs[i] == d) { be.free(pend.allocs[i]); pend.allocs.erase(pend.allocs.begin() + i); break; }
+    for (size_t i = 0; i < pend_caps.size(); i++) if (pend_caps[i].first == d) { pend_caps.erase(pend_caps.begin() + i); break; }
   }
   // heap order of every ClusterQueue from the host mirror (baseCompareFunc cluster_queue.go:844 without the sticky term)
   void pend_sort(std::vector<int32_t>& ord, std::vector<int32_t>& cq_off) {
@@ -118,6 +131,8 @@ template <class B> struct EngineT {
     const size_t nfw = (prep.nF + 63) / 64;
     size_t gps = 0, grq = 0;
     for (int c = 0; c < nq; c++) { gps += P.mps[c]; grq += P.mrq[c]; }
+    gps += gps / 8 + 16; grq += grq / 8 + 64;  // head room: arrivals seldom widen a ClusterQueue's widest workload
+    P.gps = gps; P.grq = grq;
     DGather& G = P.G;
     for (const void* q : {(const void*)G.cq, (const void*)G.priority, (const void*)G.queue_ts, (const void*)G.flags, (const void*)G.ps_off, (const void*)G.ps_count,
                           (const void*)G.ps_min_count, (const void*)G.ps_req_off, (const void*)G.req_res, (const void*)G.req_qty, (const void*)G.ps_flavor_ok,
@@ -143,6 +158,7 @@ template <class B> struct EngineT {
     const int64_t now = pend.now;
     pend = Pending{};
     pend.now = now;
+    pend_caps.clear();
     if ((int)batches.size() > PEND_SLOT) batches[PEND_SLOT].valid = false;
   }
 
@@ -799,6 +815,7 @@ template <class B> struct EngineT {
     // queue-order timestamp ascending, UID ascending — static while the workloads are pending
     std::vector<int32_t> ord, cq_off;
     pend_sort(ord, cq_off);
+    P.h_ord = ord;
     P.mps.assign(nq, 0); P.mrq.assign(nq, 0);
     for (int w = 0; w < W; w++) {
       const int c = h->cq[w], a = h->ps_off[w + 1] - h->ps_off[w], b = h->ps_req_off[h->ps_off[w + 1]] - h->ps_req_off[h->ps_off[w]];
@@ -954,11 +971,30 @@ template <class B> struct EngineT {
     P.W = W0 + n; D.W = P.W; S0.n = P.W;
     P.nps_total = nps0 + aps; P.nreq_total = nrq0 + arq;
     P.slot_cap = std::max(P.slot_cap, slot_cap); P.plain = P.plain && plain; P.max_nps = std::max(P.max_nps, max_nps);
-    std::vector<int32_t> ord, cq_off;
-    pend_sort(ord, cq_off);
-    pend_release_ptr(D.ord); pend_release_ptr(D.cq_off);
-    D.cq_off = pend_alloc(nq + 1, cq_off.data()); D.ord = pend_alloc(P.W, ord.data());
-    pend_alloc_gather();
+    // merge the (sorted) arrivals into the resident heap orders: O(W + n log n) instead of sorting everything again
+    std::vector<int32_t> ord(P.W), cq_off(nq + 1, 0), fresh(n);
+    {
+      auto before = [&](int a, int b) {
+        if (P.h_cq[a] != P.h_cq[b]) return P.h_cq[a] < P.h_cq[b];
+        if (P.h_prio[a] != P.h_prio[b]) return P.h_prio[a] > P.h_prio[b];
+        if (P.h_ts[a] != P.h_ts[b]) return P.h_ts[a] < P.h_ts[b];
+        if (P.h_uid[a] != P.h_uid[b]) return P.h_uid[a] < P.h_uid[b];
+        return a < b;
+      };
+      for (int i = 0; i < n; i++) fresh[i] = W0 + i;
+      std::sort(fresh.begin(), fresh.end(), before);
+      std::merge(P.h_ord.begin(), P.h_ord.end(), fresh.begin(), fresh.end(), ord.begin(), before);
+      for (int w = 0; w < P.W; w++) cq_off[P.h_cq[w] + 1]++;
+      for (int c = 0; c < nq; c++) cq_off[c + 1] += cq_off[c];
+      P.h_ord = ord;
+    }
+    { const int32_t* oc = D.cq_off; be.h2d(const_cast<int32_t*>(oc), cq_off.data(), (size_t)(nq + 1) * sizeof(int32_t)); }
+    pend_regrow(D.ord, 0, (size_t)P.W, ord.data());  // (old_n = 0: the whole order is rewritten; reallocated only beyond its head room)
+    {
+      size_t gps = 0, grq = 0;
+      for (int c = 0; c < nq; c++) { gps += P.mps[c]; grq += P.mrq[c]; }
+      if (gps > P.gps || grq > P.grq) pend_alloc_gather();
+    }
     be.launch_pend_add_fix(D, S, W0, n);
     rc = be.sync();
     if (rc != KQ_OK) return fail(rc, be.error());
