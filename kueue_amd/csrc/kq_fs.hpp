@@ -527,6 +527,8 @@ KQ_DEV bool fs_setup(Search& s, Fs& f) {
   int npc = 0;
   for (int u = 0; u < w.ns; u++) npc += w.s_inu[u] ? 1 : 0;
   if (npc * FS_LV > FS_PCN) return false;
+  // the chains run on plain int64 (FS_CAP): the preemptor's own quantities must be plain too (the snapshot's are: C.fs_plain)
+  for (int u = 0; u < w.ns; u++) if (w.s_qty[u] < 0 || w.s_qty[u] >= ((int64_t)1 << 50)) return false;
   f.npc = npc;
   // columns: every resource of the flavors the preemptor needs, then of the flavors it uses
   int colfr[FS_NCMAX];
