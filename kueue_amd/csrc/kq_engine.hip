@@ -456,13 +456,15 @@ struct HipBackend {
     chk(hipGetLastError(), "k_process");
   }
   size_t lds_attr = 0, lds_attr_fair = 0;
-  // helper workgroups of k_process_fair (K::help). Off unless KQ_HELP_BLOCKS asks for some: a recomputation under its nomination
-  // mapping only simulates the nominated flavor (2-3 searches per batch at cfg 4f), which is too little to share.
+  // helper workgroups of k_process_fair (K::help): KQ_HELP_BLOCKS of them, none by default. A recomputation under its nomination
+  // mapping only simulates the nominated flavor (2-3 searches per batch at cfg 4f): measured 14.8 s against 15.3 s per cycle with 16
+  // helpers — kept as an experiment (GPU tests run it), not worth being on. They only exist while every tree's leader workgroup is
+  // resident as well (free CUs), and they leave when the last leader is done.
   int help_blocks(int n_tree) {
     const char* e = getenv("KQ_HELP_BLOCKS");
     const int want = e ? atoi(e) : 0;
     const int free_cu = n_cu - n_tree;
-    return want > 0 && free_cu >= 8 ? std::min(free_cu, want) : 0;  // helpers must not crowd out leaders
+    return want > 0 && free_cu >= 8 ? std::min(free_cu, want) : 0;
   }
   void launch_process_fair(const K& k, int n_tree, size_t cohort_rows_bytes, size_t search_bytes, int32_t* rank) {
     // [cohort rows of both planes, if they fit | the state of a recomputation's victim search (kq_fs.hpp), which borrows the region][one record]

@@ -69,3 +69,25 @@ def test_overcommitted_queues_bit_exact(oracle, engine_mod, block):
             assert got.bytes == want.stats["total"], (seed, got.bytes, want.stats)
         finally:
             eng.close()
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_random_fair_sharing_cycles_with_helper_workgroups(oracle, engine_mod, block, monkeypatch):
+    """The same with K::help on (KQ_HELP_BLOCKS): several trees per cycle, every tree's leader posts its recomputation batches to the
+    same pool of helper workgroups."""
+    monkeypatch.setenv("KQ_HELP_BLOCKS", "12")
+    for seed in range(block * 40, block * 40 + 40):
+        cfg, snap, heads = random_case(20_000 + seed, fair=True, preemption=True, partial=(seed % 4 == 0),
+                                       max_cq=6 + (seed % 3) * 5, fair_dups=True)
+        oracle.derive(snap)
+        want = oracle.cycle_run(cfg, snap, heads, want_usage=True)
+        eng = engine_mod.Engine(cfg)
+        try:
+            eng.put(snap)
+            got = eng.run(heads)
+            bad = want.equal(got)
+            assert not bad, (seed, bad)
+            assert np.array_equal(want.usage_after, eng.usage_after()), seed
+            assert got.bytes == want.stats["total"], (seed, got.bytes, want.stats)
+        finally:
+            eng.close()
