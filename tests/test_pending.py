@@ -552,3 +552,88 @@ def test_backoff_closed_loop_gpu(oracle):
     from kueue_amd.engine import Engine
     pop = generate(3, n_cq=200, per_cq=20)
     assert _backoff_loop(oracle, Engine, pop, make_config(), cycles=28, seed=5) > 200
+
+
+# ---- the reference's own tests of PushOrUpdate / Delete on the new entry points, transcribed by hand --------------------------------
+
+def _one_cq(strategy="BestEffortFIFO"):
+    snap, _, _ = _tiny({"strategy": strategy, "workloads": [{"name": "seed", "prio": 1}]})
+    return snap
+
+
+def _mk_pending(snap, names, hashes, rank0=0, at=None):
+    h = Heads(snap, [Workload(n, "cq", priority=1, creation_ts=100 + rank0 + i, pod_sets=[PodSet("main", 1, requests={"cpu": 1000})], uid=n)
+                     for i, n in enumerate(names)], cycle=0)
+    h.arrays["hash"][:] = np.asarray(hashes, np.uint64)
+    h._struct = None
+    return Pending(h, uid_rank=np.arange(rank0, rank0 + len(names), dtype=np.uint32), requeue_at=at)
+
+
+@pytest.mark.parametrize("push_hash,want", [(11, F.WL_INADMISSIBLE), (22, F.WL_ACTIVE)],
+                         ids=["workload with blocked hash goes to inadmissible :1962", "workload with non-blocked hash goes to heap :1968"])
+def test_push_or_update_respects_inadmissible_hashes(oracle, push_hash, want):
+    """TestPushOrUpdateRespectsInadmissibleHashes (cluster_queue_test.go:1955-2000): hashToBulkMoveReason = {"blocked"} (here: recorded
+    the way the reference records it, by a NoFit requeue of a workload of that class), then PushOrUpdate of a workload."""
+    from tests.emu import kqe
+    snap = _one_cq()
+    cfg = make_config()
+    first = _mk_pending(snap, ["blocker"], [11])
+    q = oracle.PendingOracle(cfg, snap, first)
+    eng = kqe.EmuEngine(cfg)
+    try:
+        eng.put(snap); eng.pending_put(first)
+        assert q.pop(0) == 0
+        q.requeue(0, F.RQ_NOFIT)
+        n, nps, hw = eng.pending_heads(1)
+        rc = kqe.lib().kqe_pending_apply_fabricated(eng.h, F.ptr(np.zeros(1, np.uint8)), F.ptr(np.zeros(1, np.uint8)), F.ptr(np.zeros(1, np.uint8)),
+                                                    F.ptr(np.array([F.RQ_NOFIT], np.uint8)), F.ptr(np.full(nps * snap.n_resource, -1, np.int32)))
+        assert rc == 0
+        more = _mk_pending(snap, ["wl"], [push_hash], rank0=5)
+        i1, i2 = eng.pending_add(more), q.add(more)
+        assert i1 == i2 == 1
+        assert q.state()[1] == want and eng.pending_state()[0][1] == want
+    finally:
+        eng.close(); q.close()
+
+
+def test_strict_fifo_ignores_recorded_hashes(oracle):
+    """cluster_queue.go:419: the rule only applies to BestEffortFIFO (StrictFIFO preserves strict ordering)."""
+    from tests.emu import kqe
+    snap = _one_cq("StrictFIFO")
+    cfg = make_config()
+    first = _mk_pending(snap, ["a"], [11])
+    q = oracle.PendingOracle(cfg, snap, first)
+    eng = kqe.EmuEngine(cfg)
+    try:
+        eng.put(snap); eng.pending_put(first)
+        more = _mk_pending(snap, ["b"], [11], rank0=3)
+        eng.pending_add(more); q.add(more)
+        assert list(q.state()) == [F.WL_ACTIVE, F.WL_ACTIVE] == list(eng.pending_state()[0])
+    finally:
+        eng.close(); q.close()
+
+
+def test_delete_and_inflight_update(oracle):
+    """Test_Delete (cluster_queue_test.go:312-332): two workloads, delete one, delete the other -> empty.
+    TestPushOrUpdateSkipsInflightWorkload (:221-250): an update that arrives while the workload is in flight places it nowhere."""
+    from tests.emu import kqe
+    snap = _one_cq()
+    cfg = make_config()
+    both = _mk_pending(snap, ["workload-1", "workload-2"], [0, 0], at=np.full(2, F.REQUEUE_NONE, np.int64))
+    q = oracle.PendingOracle(cfg, snap, both)
+    eng = kqe.EmuEngine(cfg)
+    try:
+        eng.put(snap); eng.pending_put(both)
+        eng.pending_delete([0]); q.delete_many([0])
+        assert list(q.state()) == [F.WL_GONE, F.WL_ACTIVE] == list(eng.pending_state()[0])
+        # the other one is popped (in flight); the controller's update must not place it (:388)
+        assert q.pop(0) == 1
+        n, _, hw = eng.pending_heads(1)
+        assert n == 1 and hw[0] == 1
+        q.set_requeue_at([1], [F.REQUEUE_NONE])
+        assert q.state()[1] == F.WL_INFLIGHT
+        # (the engine refuses updates between Heads() and apply: the host applies them after the cycle — same outcome)
+        with pytest.raises(AssertionError):
+            eng.pending_set_requeue_at([1], [F.REQUEUE_NONE])
+    finally:
+        eng.close(); q.close()
