@@ -8,7 +8,8 @@ seeds the test-suite pins. Test infrastructure: needs no GPU.
   python tools/fuzz.py loop   LO HI     closed loops (commit / release) of 6-14 cycles on random cfg2 / cfg3 populations
 
 Prints the seeds that differ (none expected). Runs of this round: cycle 100000-108000, 200000-204000, 300000-320000; tight
-400000-412000; tas 10000-19000; loop 0-180 — all clean.
+400000-412000; tas 10000-19000; loop 0-180 — all clean. On the last code of round 2: cycle 500000-506000, tight 600000-604000,
+loop 1000-1120 — all clean.
 """
 import copy
 import os
