@@ -1,0 +1,54 @@
+/* kq_cycle_tas.h — the TAS side input / output of a scheduling cycle, as the ORACLE consumes it. TEST INFRASTRUCTURE.
+ *
+ * Topology-Aware Scheduling inside the cycle (flavorassigner.go:864-903, scheduler.go:707-769 needsTASRecompute, :941-985
+ * updateAssignmentForTAS, preemption.go:669-684 workloadFits, clusterqueue_snapshot.go:107-149 AddUsage / RemoveUsage / Fits) is
+ * restated by oracle/kq_oracle.cpp (kqo_cycle_run_tas) ahead of the engine: this struct is the boundary the engine's cycle will
+ * take next to kq_snapshot / kq_heads (it is laid out like include/kq_tas.h's batch entry points, so the flatten code is shared).
+ * Host side, as for include/kq_tas.h: topology trees, node feasibility (leaf_ok), level-key resolution per TAS flavor,
+ * checkPodSetAndFlavorMatchForTAS (tas_flavorassigner.go:164 -> folded into kq_heads.ps_flavor_ok like taints and affinity).
+ */
+#ifndef KQ_CYCLE_TAS_H
+#define KQ_CYCLE_TAS_H
+#include <stdint.h>
+#include "../include/kq_tas.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KQ_PS_TAS_EXPLICIT 1u   /* workload.IsExplicitlyRequestingTAS(podSet) */
+
+typedef struct kq_cycle_tas {
+  int32_t n_tas;                    /* TAS ResourceFlavors with a cached topology (ClusterQueueSnapshot.TASFlavors, snapshot.go:260) */
+  const int32_t* tas_flavor;        /* [n_tas] index in the snapshot's flavor dictionary; ascending by flavor NAME (slices.Sorted,
+                                       clusterqueue_snapshot.go:220) */
+  const kq_tas_topology* topo;      /* [n_tas] all over ONE resource dictionary (n_resources, pods_resource equal) */
+  const uint8_t* cq_tas_only;       /* [n_cq] clusterQueue.isTASOnly clusterqueue.go:746 */
+  /* admitted workloads: workload.TASUsage() as TopologyDomainRequests, CSR over the snapshot's admitted rows */
+  const int32_t* adm_off;           /* [n_adm+1] */
+  const int32_t* adm_tas;           /* [..] index into tas_flavor */
+  const int32_t* adm_leaf;          /* [..] */
+  const int32_t* adm_count;         /* [..] */
+  const int64_t* adm_req;           /* [..][n_resources] SinglePodRequests, dense (0 = absent) */
+  /* pending heads: one record per podset of kq_heads (global podset index) */
+  const uint8_t* ps_flags;          /* [n_ps] KQ_PS_TAS_EXPLICIT */
+  const uint8_t* ps_kind;           /* [n_ps] KQ_TAS_REQUIRED / PREFERRED / UNCONSTRAINED (implied requests: UNCONSTRAINED) */
+  const int32_t* ps_level;          /* [n_ps][n_tas] levelKeyWithImpliedFallback :1212 resolved against each TAS flavor, -1 = absent */
+  const int32_t* ps_slice_size;     /* [n_ps] */
+  const int32_t* ps_slice_level;    /* [n_ps][n_tas] */
+  const int32_t* ps_group;          /* [n_ps] PodSetGroupName id, -1 = none */
+  const int64_t* ps_req;            /* [n_ps][n_resources] SinglePodRequests from the pod spec (tas_flavorassigner.go:116) */
+} kq_cycle_tas;
+
+typedef struct kq_cycle_tas_out {
+  int32_t* ps_tas;                  /* [n_ps] index into tas_flavor of the podset's TopologyAssignment, -1 = none */
+  int32_t* dom_off;                 /* [n_ps+1] */
+  int32_t* dom_leaf;
+  int32_t* dom_count;
+  int32_t  dom_cap;
+  int64_t* tas_usage_after;         /* optional: [n_tas][n_leaves][n_resources] concatenated, leaf usage after the cycle */
+} kq_cycle_tas_out;
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -26,6 +26,9 @@
 #include <utility>
 #include <vector>
 
+#include "kq_cycle_tas.h"
+#include "kq_tas_oracle.hpp"
+
 namespace kqo {
 
 static const int64_t I64MAX = std::numeric_limits<int64_t>::max();
@@ -131,6 +134,29 @@ struct Snap {
   std::vector<int> adm_cq;
   std::vector<int> depth;        // #ancestors
   Stats st;
+  // Topology-Aware Scheduling (optional): one TASFlavorSnapshot per TAS flavor, shared by the ClusterQueues (snapshot.go:260)
+  const kq_cycle_tas* T = nullptr;
+  std::vector<tas::Snapshot*> tasS;
+  std::vector<int> tasOfFlavor;  // flavor -> index into T->tas_flavor, -1 = not a TAS flavor
+  int tasR = 0;
+  bool tasUnsupported = false;
+  int64_t tasFinds = 0, tasRecomputes = 0;
+  void attachTAS(const kq_cycle_tas* t) {
+    T = t;
+    tasOfFlavor.assign(nF, -1);
+    for (int i = 0; i < t->n_tas; i++) { tasS.push_back(tas::snapshot_new(&t->topo[i])); tasOfFlavor[t->tas_flavor[i]] = i; tasR = t->topo[i].n_resources; }
+  }
+  ~Snap() { for (auto* x : tasS) tas::snapshot_free(x); }
+  Snap(const Snap&) = delete;
+  // workload.Usage().TAS of an admitted row applied to the flavor snapshots (clusterqueue_snapshot.go:121-134)
+  void tasRow(int row, bool add) {
+    if (!T) return;
+    for (int k = T->adm_off[row]; k < T->adm_off[row + 1]; k++)
+      tas::usage_apply(*tasS[T->adm_tas[k]], T->adm_leaf[k], T->adm_count[k], T->adm_req + (size_t)k * tasR, add);
+  }
+  // Snapshot.SimulateWorkloadUsageRemoval (snapshot.go:80-97) of one admitted row, and its revert
+  void RemoveRowUsage(int row) { RemoveUsage(adm_cq[row], admUsage(row)); tasRow(row, false); }
+  void AddRowUsage(int row) { AddUsage(adm_cq[row], admUsage(row)); tasRow(row, true); }
 
   Snap(const kq_config& c, const kq_snapshot* sn) : cfg(c), s(sn) {
     nq = s->n_cq; nc = s->n_cohort; N = nq + nc; nF = s->n_flavor; nR = s->n_resource; nfr = nF * nR;
@@ -272,8 +298,8 @@ struct Snap {
     return u;
   }
   // snapshot.go:60-74
-  void RemoveWorkload(int row) { removed[row] = 1; RemoveUsage(adm_cq[row], admUsage(row)); st.victim_bytes += 16 * (depth[adm_cq[row]] + 1) * (s->adm_use_off[row + 1] - s->adm_use_off[row]); }
-  void AddWorkload(int row) { removed[row] = 0; AddUsage(adm_cq[row], admUsage(row)); st.victim_bytes += 16 * (depth[adm_cq[row]] + 1) * (s->adm_use_off[row + 1] - s->adm_use_off[row]); }
+  void RemoveWorkload(int row) { removed[row] = 1; tasRow(row, false); RemoveUsage(adm_cq[row], admUsage(row)); st.victim_bytes += 16 * (depth[adm_cq[row]] + 1) * (s->adm_use_off[row + 1] - s->adm_use_off[row]); }
+  void AddWorkload(int row) { removed[row] = 0; tasRow(row, true); AddUsage(adm_cq[row], admUsage(row)); st.victim_bytes += 16 * (depth[adm_cq[row]] + 1) * (s->adm_use_off[row + 1] - s->adm_use_off[row]); }
   // resourcegroups.RGByResource (util/resourcegroups/resourcegroups.go:62)
   int RGByResource(int cq, int res) const {
     for (int g = s->cq_rg_off[cq]; g < s->cq_rg_off[cq + 1]; g++)
@@ -406,6 +432,10 @@ struct PodSetAssignment {
   bool err = false;
   int count = 0;
   std::vector<std::pair<int, int64_t>> requests;  // effective requests (incl. injected pods)
+  // TopologyAssignment (flavorassigner.go:379): (leaf, count) on TAS flavor tasIdx
+  bool hasTopo = false;
+  int tasIdx = -1;
+  tas::Assignment topo;
   // flavorassigner.go:386-404
   int RepresentativeMode() const {
     if (!err && nreasons == 0) return Fit;
@@ -416,10 +446,12 @@ struct PodSetAssignment {
     return mode;
   }
 };
+struct TasDomainUse { int tas, leaf; int32_t count; int ps; };  // workload.TopologyDomainRequests; SinglePodRequests = the podset's
 struct Assignment {
   std::vector<PodSetAssignment> PodSets;
   int Borrowing = 0;
   FRQ Usage;  // Usage.Quota.Assigned
+  std::vector<TasDomainUse> UsageTAS;  // Usage.TAS
   int rep = -1;
   // flavorassigner.go:211-229
   int RepresentativeMode() {
@@ -438,6 +470,116 @@ struct Assignment {
 };
 
 struct Target { int row; int reason; };
+
+// ---- Topology-Aware Scheduling inside the cycle -------------------------------------------------------
+// WorkloadTASRequests (clusterqueue_snapshot.go:202): TAS flavor -> podset indices, in podset order
+typedef std::map<int, std::vector<int>> TasRequests;
+struct TasFailure { bool failed = false; int ps = -1, tas = -1, status = 0; int32_t a = 0, b = 0; };
+struct TasResult {
+  std::map<int, std::pair<int, tas::PodSetResult>> byPodSet;  // ps -> (tas flavor, result)   (TASAssignmentsResult :409)
+  // TASAssignmentsResult.Failure :411 ranges over a Go map; FindTopologyAssignmentsForFlavor stops at a flavor's first failing
+  // podset, so there is one candidate per TAS flavor. Canonical choice here: the lowest TAS flavor (name order).
+  TasFailure Failure() const {
+    TasFailure f;
+    for (auto& kv : byPodSet) {
+      const tas::PodSetResult& r = kv.second.second;
+      if (r.status == KQ_TAS_OK || r.status == KQ_TAS_SKIPPED) continue;
+      if (!f.failed || kv.second.first < f.tas) { f.failed = true; f.ps = kv.first; f.tas = kv.second.first; f.status = r.status; f.a = r.a; f.b = r.b; }
+    }
+    return f;
+  }
+};
+#define KQ_RSN_TAS_FAILURE 200  /* oracle-only reason code: the FailureReason string of a TAS placement (operands: status, a, b) */
+
+// tas_flavorassigner.go:37-83 (+ podSetTopologyRequest :92, onlyTASFlavor :142). MultiKueue / ProvisioningRequest delays, elastic
+// slices and unhealthy-node replacement are outside the boundary (the host keeps such workloads on the Go path).
+static TasRequests WorkloadsTopologyRequests(Snap& sn, const Head& wl, Assignment& a) {
+  TasRequests out;
+  if (!sn.T) return out;
+  for (size_t p = 0; p < wl.ps.size(); p++) {
+    const bool explicitReq = (sn.T->ps_flags[wl.ps_base + p] & KQ_PS_TAS_EXPLICIT) != 0;
+    const bool implied = !explicitReq && sn.T->cq_tas_only[wl.cq];  // isTASImplied :225
+    if (!explicitReq && !implied) continue;                        // isTASRequested :231
+    if (p >= a.PodSets.size()) continue;
+    PodSetAssignment& psa = a.PodSets[p];
+    if (psa.err) continue;
+    if (psa.count == 0) continue;
+    if (psa.hasTopo) continue;
+    std::set<int> flavors;  // onlyTASFlavor
+    for (auto& kv : psa.flavors) if (sn.tasOfFlavor[kv.second.flavor] >= 0) flavors.insert(sn.tasOfFlavor[kv.second.flavor]);
+    if (flavors.size() != 1) { psa.err = true; a.rep = -1; continue; }  // ErrNoTASFlavorAssigned / MultipleTASFlavorsAssignedError -> psError :290
+    out[*flavors.begin()].push_back((int)p);
+  }
+  return out;
+}
+
+// ClusterQueueSnapshot.FindTopologyAssignmentsForWorkload clusterqueue_snapshot.go:204-237. TASHandleOverlappingFlavors
+// (aggregatedDomainUsages across flavors that share hostname leaves) is not restated: one TAS flavor per workload, else *unsupported.
+static TasResult FindTopologyAssignmentsForWorkload(Snap& sn, const Head& wl, const Assignment& a, const TasRequests& reqs, bool simulateEmpty, bool* unsupported) {
+  TasResult out;
+  if (reqs.size() > 1 && unsupported) *unsupported = true;
+  for (auto& kv : reqs) {
+    const int t = kv.first;
+    const std::vector<int>& pss = kv.second;
+    const int n = (int)pss.size(), R = sn.tasR, nt = sn.T->n_tas;
+    std::vector<int32_t> wl_off = {0, n}, count(n), level(n), slice_size(n), slice_level(n), group(n);
+    std::vector<uint8_t> kind(n);
+    std::vector<int64_t> req((size_t)n * R);
+    for (int i = 0; i < n; i++) {
+      const int g = wl.ps_base + pss[i];
+      count[i] = a.PodSets[pss[i]].count;
+      level[i] = sn.T->ps_level[(size_t)g * nt + t];
+      slice_size[i] = sn.T->ps_slice_size[g];
+      slice_level[i] = sn.T->ps_slice_level[(size_t)g * nt + t];
+      group[i] = sn.T->ps_group[g];
+      kind[i] = sn.T->ps_kind[g];
+      for (int r = 0; r < R; r++) req[(size_t)i * R + r] = sn.T->ps_req[(size_t)g * R + r];
+    }
+    kq_tas_requests rq;
+    memset(&rq, 0, sizeof rq);
+    rq.n_workloads = 1; rq.wl_off = wl_off.data(); rq.single_pod_requests = req.data(); rq.count = count.data(); rq.level = level.data();
+    rq.kind = kind.data(); rq.slice_size = slice_size.data(); rq.slice_level = slice_level.data(); rq.group = group.data();
+    std::vector<tas::PodSetResult> res;
+    tas::find_workload(*sn.tasS[t], &rq, 0, n, simulateEmpty, &res);
+    sn.tasFinds++;
+    for (int i = 0; i < n; i++) out.byPodSet[pss[i]] = {t, res[i]};
+  }
+  return out;
+}
+
+// Assignment.ComputeTASNetUsage flavorassigner.go:106-155 (no previous admission: pending workloads only)
+static void ComputeTASNetUsage(Assignment& a) {
+  a.UsageTAS.clear();
+  for (size_t p = 0; p < a.PodSets.size(); p++) {
+    const PodSetAssignment& psa = a.PodSets[p];
+    if (!psa.hasTopo) continue;
+    for (auto& dc : psa.topo) if (dc.second > 0) a.UsageTAS.push_back({psa.tasIdx, dc.first, dc.second, (int)p});
+  }
+}
+// Assignment.UpdateForTASResult flavorassigner.go:87-96
+static void UpdateForTASResult(Assignment& a, const TasResult& result) {
+  for (auto& kv : result.byPodSet) {
+    PodSetAssignment& psa = a.PodSets[kv.first];
+    const tas::PodSetResult& r = kv.second.second;
+    psa.hasTopo = r.status == KQ_TAS_OK;  // TopologyAssignment = psResult.TopologyAssignment (nil on failure)
+    psa.tasIdx = kv.second.first;
+    psa.topo = r.status == KQ_TAS_OK ? r.domains : tas::Assignment();
+  }
+  ComputeTASNetUsage(a);
+}
+// Assignment.updateMode flavorassigner.go:192-198
+static void updateModePS(Assignment& a, int ps, int mode) {
+  for (auto& kv : a.PodSets[ps].flavors) kv.second.mode = mode;
+  a.rep = mode;
+}
+// Usage.TAS applied to / checked against the flavor snapshots (clusterqueue_snapshot.go:121-149)
+static void tasUsageApply(Snap& sn, const Head& wl, const std::vector<TasDomainUse>& u, bool add) {
+  for (auto& d : u) tas::usage_apply(*sn.tasS[d.tas], d.leaf, d.count, sn.T->ps_req + (size_t)(wl.ps_base + d.ps) * sn.tasR, add);
+}
+static bool tasUsageFits(Snap& sn, const Head& wl, const std::vector<TasDomainUse>& u) {
+  for (auto& d : u) if (!tas::fits_domain(*sn.tasS[d.tas], d.leaf, d.count, sn.T->ps_req + (size_t)(wl.ps_base + d.ps) * sn.tasR)) return false;
+  return true;
+}
 
 typedef std::function<std::pair<int, int>(int cq, const Head& wl, int fr, Amount quantity)> OracleFn;
 
@@ -667,7 +809,32 @@ struct FlavorAssigner {
       a.rep = -1;
       if (failed) return a;  // atLeastOnePodsAssignmentFailed :848-853
     }
+    if (a.RepresentativeMode() == NoFit) return a;  // :857-862
+    if (sn.T) assignTAS(a);
     return a;
+  }
+
+  // flavorassigner.go:864-903
+  void assignTAS(Assignment& assignment) {
+    TasRequests tasRequests = WorkloadsTopologyRequests(sn, wl, assignment);
+    if (assignment.RepresentativeMode() == Fit) {
+      TasResult result = FindTopologyAssignmentsForWorkload(sn, wl, assignment, tasRequests, false, &sn.tasUnsupported);
+      TasFailure failure = result.Failure();
+      if (failure.failed) {
+        PodSetAssignment& psa = assignment.PodSets[failure.ps];
+        psa.nreasons++;  // psAssignment.reason(failure.Reason)
+        psa.reasons.push_back({KQ_RSN_TAS_FAILURE, sn.T->tas_flavor[failure.tas], -1, failure.status, failure.a, failure.b});
+        updateModePS(assignment, failure.ps, Preempt);
+      } else {
+        UpdateForTASResult(assignment, result);
+      }
+    }
+    if (assignment.RepresentativeMode() == Preempt) {
+      TasResult result = FindTopologyAssignmentsForWorkload(sn, wl, assignment, tasRequests, true, &sn.tasUnsupported);
+      TasFailure failure = result.Failure();
+      if (failure.failed) updateModePS(assignment, failure.ps, NoFit);
+      else for (auto& kv : tasRequests) for (int ps : kv.second) updateModePS(assignment, ps, Preempt);  // updateModeForTASRequests :200
+    }
   }
 };
 
@@ -677,6 +844,8 @@ struct PreemptionCtx {
   int preemptorCQ;
   FRQ workloadUsage;
   std::set<int> frsNeedPreemption;
+  TasRequests tasRequests;             // preemption.go:135-138
+  const Assignment* assignment = nullptr;
 };
 
 struct Preemptor {
@@ -809,14 +978,15 @@ struct Preemptor {
     }
     return true;
   }
-  // preemption.go:669-686 (TAS part out of scope)
+  // preemption.go:669-686
   bool workloadFits(const PreemptionCtx& ctx, bool allowBorrowing) {
     sn.st.victim_bytes += 40 * (int64_t)(sn.depth[ctx.preemptorCQ] + 1) * (int64_t)ctx.workloadUsage.size();
     for (auto& kv : ctx.workloadUsage) {
       if (!allowBorrowing && sn.BorrowingWith(ctx.preemptorCQ, kv.first, kv.second)) return false;
       if (kv.second.Cmp(sn.Available(ctx.preemptorCQ, kv.first)) > 0) return false;
     }
-    return true;
+    if (ctx.tasRequests.empty()) return true;
+    return !FindTopologyAssignmentsForWorkload(sn, *ctx.preemptor, *ctx.assignment, ctx.tasRequests, false, &sn.tasUnsupported).Failure().failed;
   }
   // preemption.go:341-354
   std::vector<Target> fillBackWorkloads(const PreemptionCtx& ctx, std::vector<Target> targets, bool allowBorrowing) {
@@ -1074,9 +1244,9 @@ struct Preemptor {
     std::vector<Target> candidates = getTargets(ctx);
     if (candidates.empty()) return {ppNoCandidates, sn.FindHeightOfLowestSubtreeThatFits(cq, fr, quantity).first};
     // SimulateWorkloadUsageRemoval snapshot.go:80-100
-    for (auto& c : candidates) sn.RemoveUsage(sn.adm_cq[c.row], sn.admUsage(c.row));
+    for (auto& c : candidates) sn.RemoveRowUsage(c.row);
     int borrowAfter = sn.FindHeightOfLowestSubtreeThatFits(cq, fr, quantity).first;
-    for (auto& c : candidates) sn.AddUsage(sn.adm_cq[c.row], sn.admUsage(c.row));
+    for (auto& c : candidates) sn.AddRowUsage(c.row);
     for (auto& c : candidates) if (sn.adm_cq[c.row] == cq) return {ppPreempt, borrowAfter};
     return {ppReclaim, borrowAfter};
   }
@@ -1103,6 +1273,7 @@ struct Preemptor {
     PreemptionCtx ctx; ctx.preemptor = &wl; ctx.preemptorCQ = wl.cq;
     for (auto& ps : a.PodSets) for (auto& kv : ps.flavors) if (kv.second.mode == Preempt) ctx.frsNeedPreemption.insert(kv.second.flavor * sn.nR + kv.first);
     ctx.workloadUsage = TotalRequestsFor(wl, a);
+    if (sn.T) { ctx.tasRequests = WorkloadsTopologyRequests(sn, wl, a); ctx.assignment = &a; }
     return getTargets(ctx);
   }
 };
@@ -1214,6 +1385,7 @@ struct Scheduler {
   void getAssignments(Entry& e) {
     if (e.head.has_last && lastAssignmentOutdated(e.head)) e.head.has_last = false;
     getInitialAssignments(e.head, &e.assignment, &e.preemptionTargets);
+    if (sn.T) updateAssignmentForTAS(e.head, e.assignment, e.preemptionTargets);
     // recordAssignment: LastAssignment = &assignment.LastState
     e.head.has_last = true;
     for (size_t p = 0; p < e.head.ps.size(); p++) {
@@ -1223,28 +1395,60 @@ struct Scheduler {
     }
     if (e.assignment.PodSets.size() < e.head.ps.size()) e.head.last_tried.resize(e.assignment.PodSets.size());
   }
+  // scheduler.go:941-985
+  void updateAssignmentForTAS(const Head& wl, Assignment& assignment, const std::vector<Target>& targets) {
+    if (assignment.RepresentativeMode() != Preempt) return;
+    bool anyExplicit = false;
+    for (size_t p = 0; p < wl.ps.size(); p++) if (sn.T->ps_flags[wl.ps_base + p] & KQ_PS_TAS_EXPLICIT) anyExplicit = true;
+    if (!anyExplicit && !sn.T->cq_tas_only[wl.cq]) return;
+    TasRequests tasRequests = WorkloadsTopologyRequests(sn, wl, assignment);
+    TasResult tasResult;
+    if (!targets.empty()) {
+      for (auto& t : targets) sn.RemoveRowUsage(t.row);  // SimulateWorkloadUsageRemoval
+      tasResult = FindTopologyAssignmentsForWorkload(sn, wl, assignment, tasRequests, false, &sn.tasUnsupported);
+      for (auto& t : targets) sn.AddRowUsage(t.row);
+    } else {
+      tasResult = FindTopologyAssignmentsForWorkload(sn, wl, assignment, tasRequests, true, &sn.tasUnsupported);
+    }
+    UpdateForTASResult(assignment, tasResult);
+  }
   // scheduler.go:647 assignmentUsage -> netUsage :785-794
   FRQ assignmentUsage(const Entry& e) const {
     if (e.head.flags & KQ_HEAD_HAS_QUOTA_RESERVATION) return {};
     return e.assignment.Usage;
   }
   // scheduler.go:771-777 ; canonical removal order = ascending admitted row
-  bool fits(int cq, const FRQ& usage, const std::set<int>& preempted, const std::vector<Target>& newTargets) {
+  enum { FitsCheckOk = 0, FitsCheckNoQuota = 1, FitsCheckNoTAS = 2 };  // clusterqueue_snapshot.go:42-51
+  int fitsCheck(const Entry& e, int cq, const FRQ& usage, const std::set<int>& preempted, const std::vector<Target>& newTargets) {
     std::set<int> merged = preempted;
     for (auto& t : newTargets) merged.insert(t.row);
-    for (int row : merged) sn.RemoveUsage(sn.adm_cq[row], sn.admUsage(row));
+    for (int row : merged) sn.RemoveRowUsage(row);
     sn.st.entry_bytes += (int64_t)usage.size() * 40 * (sn.depth[cq] + 1);
-    bool ok = sn.Fits(cq, usage);
-    for (int row : merged) sn.AddUsage(sn.adm_cq[row], sn.admUsage(row));
-    return ok;
+    int res = sn.Fits(cq, usage) ? FitsCheckOk : FitsCheckNoQuota;  // ClusterQueueSnapshot.Fits :136-150
+    if (res == FitsCheckOk && sn.T && !tasUsageFits(sn, e.head, e.assignment.UsageTAS)) res = FitsCheckNoTAS;
+    for (int row : merged) sn.AddRowUsage(row);
+    return res;
   }
   static bool hasAny(const std::set<int>& p, const std::vector<Target>& t) { for (auto& x : t) if (p.count(x.row)) return true; return false; }
   // scheduler.go:707-769
   bool updateAssignmentIfNeeded(Entry& e, int cq, const std::set<int>& preempted, FRQ* usageOut) {
     FRQ usage = assignmentUsage(e);
-    bool fitsCheck = fits(cq, usage, preempted, e.preemptionTargets);
+    int fc = fitsCheck(e, cq, usage, preempted, e.preemptionTargets);
+    const bool needsTASRecompute = fc == FitsCheckNoTAS;  // TASRecomputeAssignmentWithinSchedulingCycle: default on
     bool needsOverlapRecompute = hasAny(preempted, e.preemptionTargets) && sn.gate(KQ_GATE_RECOMPUTE_ON_OVERLAP);
-    if (!needsOverlapRecompute) { *usageOut = usage; return fitsCheck; }
+    if (!needsOverlapRecompute && !needsTASRecompute) { *usageOut = usage; return fc == FitsCheckOk; }
+    if (!needsOverlapRecompute) {  // case needsTASRecompute :728
+      sn.tasRecomputes++;
+      e.head.has_last = false;
+      e.head.nomination.assign(e.head.ps.size(), {});
+      for (size_t p = 0; p < e.assignment.PodSets.size(); p++) for (auto& kv : e.assignment.PodSets[p].flavors) e.head.nomination[p][kv.first] = kv.second.flavor;
+      getAssignments(e);
+      usage = assignmentUsage(e);
+      fc = fitsCheck(e, cq, usage, preempted, e.preemptionTargets);
+      e.head.nomination.assign(e.head.ps.size(), {});
+      *usageOut = usage;
+      return fc == FitsCheckOk;
+    }
     std::vector<int> victims(preempted.begin(), preempted.end());
     // The engine keeps a second usage plane without the cycle's victims instead of removing and
     // re-adding them here, so this traffic is excluded from the comparable byte count.
@@ -1261,10 +1465,10 @@ struct Scheduler {
     sn.st.discarded_bytes += sn.st.victim_bytes - vb0;
     if (e.assignment.RepresentativeMode() == Fit) e.assignment.SetRepresentativeMode(DeferredFit);
     usage = assignmentUsage(e);
-    fitsCheck = fits(cq, usage, preempted, e.preemptionTargets);
+    fc = fitsCheck(e, cq, usage, preempted, e.preemptionTargets);
     e.head.nomination.assign(e.head.ps.size(), {});
     *usageOut = usage;
-    return fitsCheck;
+    return fc == FitsCheckOk;
   }
   // scheduler.go:796-814
   FRQ quotaResourcesToReserve(Entry& e, int cq) {
@@ -1297,6 +1501,7 @@ struct Scheduler {
         if (!canAlwaysReclaim || (sn.gate(KQ_GATE_PRIORITIZE_PREEMPTORS) && (e.head.flags & KQ_HEAD_IS_PREEMPTOR))) {
           FRQ r = (e.head.flags & KQ_HEAD_HAS_QUOTA_RESERVATION) ? FRQ() : quotaResourcesToReserve(e, cq);  // resourcesToReserve :780 via netUsage
           sn.AddUsage(cq, r);
+          if (sn.T) tasUsageApply(sn, e.head, e.assignment.UsageTAS, true);  // resourcesToReserve -> netUsage :785-794 carries Usage.TAS
           sn.st.entry_bytes += (int64_t)r.size() * 8 * (sn.depth[cq] + 1);
         }
         return;
@@ -1306,6 +1511,7 @@ struct Scheduler {
       e.requeueReason = KQ_RQ_PENDING_PREEMPTION;
       e.head.has_last = false;
       sn.AddUsage(cq, usage);
+      if (sn.T) tasUsageApply(sn, e.head, e.assignment.UsageTAS, true);
       sn.st.entry_bytes += (int64_t)usage.size() * 8 * (sn.depth[cq] + 1);
       return;
     }
@@ -1313,6 +1519,7 @@ struct Scheduler {
     if (!fitsOk) { e.status = KQ_ST_SKIPPED; e.skip = KQ_SKIP_NO_LONGER_FITS; return; }
     for (auto& t : e.preemptionTargets) preemptedWorkloads.insert(t.row);
     sn.AddUsage(cq, usage);
+    if (sn.T) tasUsageApply(sn, e.head, e.assignment.UsageTAS, true);
     sn.st.entry_bytes += (int64_t)usage.size() * 8 * (sn.depth[cq] + 1);
     if (mode == Preempt) {
       // issuePreemptions :563 -> markPreemptionOutcome :291 (all evictions assumed to succeed)
@@ -1554,6 +1761,46 @@ int kqo_cycle_run(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h,
   writeDecisions(sn, h, entries, out, &rc);
   if (stats) { stats[0] = sn.st.cells; stats[1] = sn.st.cell_bytes; stats[2] = sn.st.head_io_bytes; stats[3] = sn.st.entry_bytes; stats[4] = sn.st.victim_bytes; stats[5] = sn.st.drs_bytes; stats[6] = sn.st.discarded_bytes; }
   if (usage_after) memcpy(usage_after, sn.usage.data(), sn.usage.size() * sizeof(int64_t));
+  return rc;
+}
+
+// One scheduling cycle with Topology-Aware Scheduling inside it (oracle/kq_cycle_tas.h). tstats[0..2] (optional): TAS placements
+// computed, TAS recomputations inside processEntry, 1 when the cycle met a case outside the restated path.
+int kqo_cycle_run_tas(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, const kq_cycle_tas* t, kq_decisions* out, kq_cycle_tas_out* tout,
+                      int64_t* tstats) {
+  Snap sn(*cfg, s);
+  sn.attachTAS(t);
+  Scheduler sch(sn, h);
+  std::vector<Entry> entries;
+  sch.schedule(entries);
+  int rc = KQ_OK;
+  for (auto& e : entries) for (auto& ps : e.assignment.PodSets) ps.reasons.erase(std::remove_if(ps.reasons.begin(), ps.reasons.end(), [](const Reason& r) { return r.code == KQ_RSN_TAS_FAILURE; }), ps.reasons.end());
+  writeDecisions(sn, h, entries, out, &rc);
+  int nd = 0;
+  tout->dom_off[0] = 0;
+  for (int i = 0; i < h->n; i++) {
+    Entry& e = entries[i];
+    for (int p = h->ps_off[i]; p < h->ps_off[i + 1]; p++) {
+      const int lp = p - h->ps_off[i];
+      tout->ps_tas[p] = -1;
+      if (lp < (int)e.assignment.PodSets.size() && e.assignment.PodSets[lp].hasTopo) {
+        const PodSetAssignment& psa = e.assignment.PodSets[lp];
+        tout->ps_tas[p] = psa.tasIdx;
+        for (auto& dc : psa.topo) {
+          if (nd >= tout->dom_cap) { rc = KQ_ECAPACITY; break; }
+          tout->dom_leaf[nd] = dc.first; tout->dom_count[nd] = dc.second; nd++;
+        }
+      }
+      tout->dom_off[p + 1] = nd;
+    }
+  }
+  if (tout->tas_usage_after) {
+    // the leaf usage after the cycle = the input usage + every Usage.TAS the cycle added: replay on a fresh copy is not needed,
+    // the flavor snapshots carry it; exported through a find-independent accessor
+    size_t o = 0;
+    for (int i = 0; i < t->n_tas; i++) o += tas::snapshot_export_usage(*sn.tasS[i], tout->tas_usage_after + o);
+  }
+  if (tstats) { tstats[0] = sn.tasFinds; tstats[1] = sn.tasRecomputes; tstats[2] = sn.tasUnsupported ? 1 : 0; }
   return rc;
 }
 
