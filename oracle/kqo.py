@@ -234,6 +234,22 @@ def tas_find(topo, rq, dom_cap=None):
     return out
 
 
+def cycle_run_tas(cfg: F.kq_config, snap: Snapshot, heads: Heads, ct, tgt_cap=None):
+    """One scheduling cycle with Topology-Aware Scheduling inside it (oracle/kq_cycle_tas.h; ct = kueue_amd.tas_cycle.CycleTAS).
+    -> (Decisions, CycleTASOut); Decisions.tas_stats = {finds, recomputes, unsupported}."""
+    from kueue_amd.tas_cycle import CycleTASOut
+    d = Decisions(heads, tgt_cap=tgt_cap)
+    out = CycleTASOut(ct)
+    ts = np.zeros(3, np.int64)
+    l = lib()
+    l.kqo_cycle_run_tas.restype = C.c_int
+    rc = l.kqo_cycle_run_tas(C.byref(cfg), C.byref(snap.struct()), C.byref(heads.struct()), C.byref(ct.struct()), C.byref(d.struct()),
+                             C.byref(out.struct()), F.ptr(ts))
+    assert rc == 0, rc
+    d.tas_stats = dict(finds=int(ts[0]), recomputes=int(ts[1]), unsupported=bool(ts[2]))
+    return d, out
+
+
 def tas_fits(topo, assignment, single_pod_requests) -> bool:
     leaf = np.array([a for a, _ in assignment], np.int32); cnt = np.array([c for _, c in assignment], np.int32)
     req = np.ascontiguousarray(single_pod_requests, np.int64)
