@@ -21,7 +21,8 @@ typedef struct kq_cycle_tas {
   int32_t n_tas;                    /* TAS ResourceFlavors with a cached topology (ClusterQueueSnapshot.TASFlavors, snapshot.go:260) */
   const int32_t* tas_flavor;        /* [n_tas] index in the snapshot's flavor dictionary; ascending by flavor NAME (slices.Sorted,
                                        clusterqueue_snapshot.go:220) */
-  const kq_tas_topology* topo;      /* [n_tas] all over ONE resource dictionary (n_resources, pods_resource equal) */
+  const kq_tas_topology* topo;      /* [n_tas] all over ONE resource dictionary (n_resources, pods_resource equal); tas_usage holds only
+                                       usage that belongs to no admitted row below (the rows' usage is added from the CSR) */
   const uint8_t* cq_tas_only;       /* [n_cq] clusterQueue.isTASOnly clusterqueue.go:746 */
   /* admitted workloads: workload.TASUsage() as TopologyDomainRequests, CSR over the snapshot's admitted rows */
   const int32_t* adm_off;           /* [n_adm+1] */

@@ -145,6 +145,10 @@ struct Snap {
     T = t;
     tasOfFlavor.assign(nF, -1);
     for (int i = 0; i < t->n_tas; i++) { tasS.push_back(tas::snapshot_new(&t->topo[i])); tasOfFlavor[t->tas_flavor[i]] = i; tasR = t->topo[i].n_resources; }
+    // topo[i].tas_usage is the usage NOT attributable to an admitted row of the snapshot; the rows' own usage comes through the CSR
+    // so that removing a row (preemption simulation) takes exactly what adding it put there (tas_flavor.go: the cache adds
+    // workload.TASUsage() of every admitted workload when it builds the flavor snapshot)
+    for (int row = 0; row < s->n_adm; row++) tasRow(row, true);
   }
   ~Snap() { for (auto* x : tasS) tas::snapshot_free(x); }
   Snap(const Snap&) = delete;

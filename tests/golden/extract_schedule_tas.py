@@ -1,0 +1,446 @@
+#!/usr/bin/env python
+"""Transcribes the whole-cycle TAS tables of pkg/scheduler/scheduler_tas_test.go — TestScheduleForTAS (:58),
+TestScheduleForTASPreemption (:4121), TestScheduleForTASCohorts (:5950) — into tests/golden/schedule_tas.yaml.
+
+  python tests/golden/extract_schedule_tas.py      # needs /root/reference (this container only)
+
+A Go case = Nodes, Topologies, ResourceFlavors, ClusterQueues (+ Cohorts), Workloads (admitted ones carry a TopologyAssignment, the
+others are pending in a LocalQueue) and, after exactly ONE Scheduler.schedule(): wantNewAssignments (flavors + TopologyAssignment of
+every new admission), wantLeft / wantInadmissibleLeft. The fixture keeps the inputs, the heads (one per ClusterQueue: priority desc,
+creation asc) and the expected per-head outcome. Cases needing machinery outside the boundary (admission checks / delayed topology,
+unhealthy-node replacement, taints / tolerations / node selectors / affinity, non-TAS pods, workload slices, podset groups, balanced
+placement, multi-layer slices, resource transformations, gates) are skipped and counted in the YAML header.
+"""
+import collections
+import os
+import re
+import sys
+
+import yaml
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from extract_assign_flavors import match_brace, parse_cq, res_name  # noqa: E402
+from extract_preemption import NOW, chain, parse_cohort, parse_time, split_top  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = "/root/reference/pkg/scheduler/scheduler_tas_test.go"
+HOST = "kubernetes.io/hostname"
+
+
+class Skip(Exception):
+    pass
+
+
+def field(block, name, tabs=3):
+    m = re.search(r"(?m)^\t{%d}%s:\s*" % (tabs, re.escape(name)), block)
+    if not m:
+        return None
+    i = m.end()
+    # value runs to the top-level comma
+    depth, j, n = 0, i, len(block)
+    while j < n:
+        c = block[j]
+        if c == '"':
+            j += 1
+            while block[j] != '"':
+                j += 2 if block[j] == "\\" else 1
+        elif c in "({[":
+            depth += 1
+        elif c in ")}]":
+            depth -= 1
+        elif c == "," and depth == 0:
+            break
+        j += 1
+    return block[i:j]
+
+
+def strip_comments(src):
+    src = "\n".join("" if l.strip().startswith("//") else l for l in src.split("\n"))
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return re.sub(r"(?m)\s//[^\"\n]*$", "", src)
+
+
+def func_body(src, name):
+    start = src.index("func %s(" % name)
+    b = src.index("{", src.index(")", start))
+    return src[b + 1: match_brace(src, b)], src[:b + 1].count("\n")
+
+
+def symbols(body):
+    """top-level `name := expr` / const name = "..." of a test function, before its table"""
+    sym = {}
+    for m in re.finditer(r'(?m)^\t\t?(\w+)\s*=\s*"([^"]*)"$', body):
+        sym[m.group(1)] = '"%s"' % m.group(2)
+    lines = body.split("\n")
+    i = 0
+    while i < len(lines):
+        m = re.match(r"^\t(\w+) := (.*)$", lines[i])
+        if not m or m.group(1) in ("cases", "testCases"):
+            i += 1
+            continue
+        expr = m.group(2)
+        while expr.count("(") != expr.count(")") or expr.count("{") != expr.count("}") or expr.rstrip().endswith("."):
+            i += 1
+            expr += "\n" + lines[i]
+        sym[m.group(1)] = expr
+        i += 1
+    return sym
+
+
+def label(tok, sym):
+    tok = tok.strip()
+    if tok == "corev1.LabelHostname":
+        return HOST
+    if tok in sym:
+        return sym[tok].strip('"')
+    m = re.match(r'^"([^"]*)"$', tok)
+    if m:
+        return m.group(1)
+    raise Skip("label token " + tok)
+
+
+def resolve(expr, sym, depth=0):
+    """substitute a bare identifier (optionally `*x`, `x.DeepCopy()`, `*x.DeepCopy()`, `x.Obj()`) by its definition"""
+    e = expr.strip()
+    m = re.match(r"^\*?(\w+)(?:\.DeepCopy\(\))?(?:\.\s*Obj\(\))?$", e)
+    if m and m.group(1) in sym and depth < 6:
+        return resolve(sym[m.group(1)], sym, depth + 1)
+    return e
+
+
+def items_of(expr, sym):
+    """elements of a `[]T{...}` literal (or of a variable holding one), each resolved"""
+    e = resolve(expr, sym)
+    if "{" not in e:
+        raise Skip("not a literal: " + e[:40])
+    p = e.index("{")
+    return [resolve(t, sym) for t in split_top(e[p + 1: match_brace(e, p)]) if t.strip()]
+
+
+def parse_node(text, sym):
+    calls, _ = chain(text, text.index("MakeNode"))
+    n = {"name": calls[0][1].strip().strip('"'), "labels": {}, "allocatable": {}, "ready": False}
+    for m, a in calls[1:]:
+        if m == "Label":
+            k, v = split_top(a)
+            n["labels"][label(k, sym)] = label(v, sym)
+        elif m == "StatusAllocatable":
+            for r, q in re.findall(r'([\w\.]+|"[^"]+"):\s*resource\.MustParse\("([^"]+)"\)', a):
+                n["allocatable"][res_name(r) if not r.startswith('"') else r.strip('"')] = q
+        elif m == "Ready":
+            n["ready"] = True
+        elif m == "NotReady":
+            n["ready"] = False
+        elif m == "Unschedulable":
+            n["unschedulable"] = True
+        elif m in ("Obj", "DeepCopy", "Clone"):
+            pass
+        else:
+            raise Skip("Node." + m)
+    return n
+
+
+def parse_topology(text, sym):
+    m = re.search(r'MakeDefaultOneLevelTopology\("([^"]+)"\)', text)
+    if m:
+        return m.group(1), [HOST]
+    calls, _ = chain(text, text.index("MakeTopology"))
+    name = calls[0][1].strip().strip('"')
+    levels = []
+    for mm, a in calls[1:]:
+        if mm == "Levels":
+            levels = [label(x, sym) for x in split_top(a)]
+        elif mm != "Obj":
+            raise Skip("Topology." + mm)
+    return name, levels
+
+
+def parse_flavor(text, sym):
+    calls, _ = chain(text, text.index("MakeResourceFlavor"))
+    f = {"name": calls[0][1].strip().strip('"'), "nodeLabels": {}}
+    for m, a in calls[1:]:
+        if m == "NodeLabel":
+            k, v = split_top(a)
+            f["nodeLabels"][label(k, sym)] = label(v, sym)
+        elif m == "TopologyName":
+            f["topologyName"] = a.strip().strip('"')
+        elif m != "Obj":
+            raise Skip("ResourceFlavor." + m)
+    return f
+
+
+def parse_topology_assignment(a, sym):
+    """MakeTopologyAssignment(levels).Domain(MakeTopologyDomainAssignment([]string{...}, n).Obj())... -> [[values], count]"""
+    doms = []
+    for m in re.finditer(r"MakeTopologyDomainAssignment\(\[\]string\{([^}]*)\},\s*(\d+)\)", a):
+        doms.append([[label(x, sym) for x in split_top(m.group(1)) if x.strip()], int(m.group(2))])
+    return {"domains": doms}
+
+
+def parse_admission(args, sym):
+    calls, _ = chain(args, args.index("MakeAdmission"))
+    cq = split_top(calls[0][1])[0].strip().strip('"')
+    podsets = []
+    for name, a in calls[1:]:
+        if name == "PodSets":
+            for psa in split_top(a):
+                pc, _ = chain(psa, psa.index("MakePodSetAssignment"))
+                ps = {"name": pc[0][1].strip().strip('"').replace("kueue.DefaultPodSetName", "main"), "usage": {}, "flavors": {}, "count": 1}
+                for n2, a2 in pc[1:]:
+                    if n2 == "Assignment":
+                        r, f, q = [x.strip() for x in split_top(a2)]
+                        ps["flavors"][res_name(r)] = f.strip('"'); ps["usage"][res_name(r)] = q.strip('"')
+                    elif n2 in ("Count", "AssignmentPodCount"):
+                        ps["count"] = int(a2)
+                    elif n2 == "TopologyAssignment":
+                        ps["topologyAssignment"] = parse_topology_assignment(a2, sym)
+                    elif n2 == "Obj":
+                        pass
+                    else:
+                        raise Skip("PodSetAssignment." + n2)
+                podsets.append(ps)
+        elif name != "Obj":
+            raise Skip("Admission." + name)
+    return cq, podsets
+
+
+PS_OK = {"MakePodSet", "Request", "Obj", "Image", "RequiredTopologyRequest", "PreferredTopologyRequest", "UnconstrainedTopologyRequest",
+         "SliceRequiredTopologyRequest", "SliceSizeTopologyRequest", "Limit"}
+
+
+def parse_podsets(args, sym):
+    out = []
+    for t in split_top(args):
+        if "MakePodSet" not in t:
+            raise Skip("PodSets without MakePodSet")
+        pc, _ = chain(t, t.index("MakePodSet"))
+        n, c = split_top(pc[0][1])
+        ps = {"name": n.strip().strip('"').replace("kueue.DefaultPodSetName", "main"), "count": int(c), "requests": {}}
+        tr = {}
+        for m, a in pc[1:]:
+            if m not in PS_OK:
+                raise Skip("PodSet." + m)
+            if m == "Request":
+                r, q = split_top(a)
+                ps["requests"][res_name(r) if not r.strip().startswith('"') else r.strip().strip('"')] = q.strip().strip('"')
+            elif m == "RequiredTopologyRequest":
+                tr["required"] = label(a, sym)
+            elif m == "PreferredTopologyRequest":
+                tr["preferred"] = label(a, sym)
+            elif m == "UnconstrainedTopologyRequest":
+                tr["unconstrained"] = True
+            elif m == "SliceRequiredTopologyRequest":
+                tr["sliceRequiredTopology"] = label(a, sym)
+            elif m == "SliceSizeTopologyRequest":
+                tr["sliceSize"] = int(a)
+        if tr:
+            ps["topologyRequest"] = tr
+        out.append(ps)
+    return out
+
+
+WL_OK = {"MakeWorkload", "Queue", "Priority", "Creation", "Request", "PodSets", "ReserveQuota", "ReserveQuotaAt", "Admission", "Condition",
+         "ResourceRequests", "SchedulingStatsEviction", "Obj", "UID", "JobUID", "Generation", "Clone", "AdmittedAt", "Admitted", "PastAdmittedTime",
+         "ResourceVersion", "Label", "Labels", "Finalizers"}
+
+
+def parse_wl(text, start, sym):
+    calls, end = chain(text, start)
+    name, ns = [x.strip().strip('"') for x in split_top(calls[0][1])]
+    w = {"name": name, "ns": ns, "priority": 0, "created": 0, "podsets": None}
+    for m, a in calls[1:]:
+        if m not in WL_OK:
+            raise Skip("Workload." + m)
+        if m == "Queue":
+            w["queue"] = a.strip().strip('"')
+        elif m == "Priority":
+            w["priority"] = int(a)
+        elif m == "Creation":
+            w["created"] = parse_time(a)
+        elif m == "PodSets":
+            w["podsets"] = parse_podsets(a, sym)
+        elif m == "Request":
+            raise Skip("Workload.Request shorthand")
+        elif m in ("ReserveQuota", "ReserveQuotaAt"):
+            parts = split_top(a)
+            w["cq"], w["admission"] = parse_admission(parts[0], sym)
+            w["reservedAt"] = parse_time(parts[1]) if len(parts) > 1 else NOW
+        elif m == "Condition":
+            typ = re.search(r"Type:\s*kueue\.(\w+)", a)
+            status = re.search(r"Status:\s*metav1\.Condition(\w+)", a)
+            if typ and status and status.group(1) == "True" and typ.group(1) == "WorkloadEvicted":
+                w["evicted"] = True
+            if typ and status and status.group(1) == "True" and typ.group(1) == "WorkloadPreempted":
+                w["preempted"] = True
+    if w["podsets"] is None:
+        raise Skip("workload without PodSets")
+    return w, end
+
+
+def workloads_in(text, sym):
+    out, i = [], 0
+    for m in re.finditer(r"utiltestingapi\.MakeWorkload\(", text):
+        if m.start() < i:
+            continue
+        w, i = parse_wl(text, m.start() + len("utiltestingapi."), sym)
+        out.append(w)
+    return out
+
+
+def parse_keymap(text):
+    out = {}
+    if not text:
+        return out
+    for m in re.finditer(r'"([^"]+)":\s*\{([^}]*)\}', text):
+        out[m.group(1)] = re.findall(r'"([^"]+)"', m.group(2))
+    return out
+
+
+BAD = r"AdmissionCheck|Toleration|NodeSelector|Taint|PreemptionGate|WorkloadSlice|Annotation|UnhealthyNode|DelayedTopologyRequest|PodSetGroup|" \
+      r"resourceTransformations|patchStatusErr|RequiredDuringScheduling|PreferredDuringScheduling|PodSetUpdate|StopPolicy|SliceRequiredTopologyConstraint|" \
+      r"MinimumCount|SetMinimumCount|MakePod\("
+
+
+def lqs_of(body):
+    out = {}
+    for m in re.finditer(r'MakeLocalQueue\("([^"]+)",\s*"([^"]+)"\)\.\s*ClusterQueue\("([^"]+)"\)', body):
+        out[(m.group(2), m.group(1))] = m.group(3)
+    return out
+
+
+def extract(src, func, cases, skipped):
+    body, line0 = func_body(src, func)
+    sym = symbols(body)
+    lqs = lqs_of(body)
+    tm = re.search(r"(?m)^\tcases := map\[string\](?:struct \{|tasScheduleTestCase\{)", body)
+    p = body.index("{", tm.start())
+    if "struct {" in tm.group(0):
+        p = body.index("{", match_brace(body, p) + 1)
+    table = body[p + 1: match_brace(body, p)]
+    for m in re.finditer(r'(?m)^\t\t"((?:[^"\\]|\\.)*)":\s*\{', table):
+        j = match_brace(table, m.end() - 1)
+        block = table[m.end():j]
+        name = m.group(1)
+        line = line0 + body[:p + 1 + m.start()].count("\n") + 1
+        try:
+            if re.search(BAD, block):
+                raise Skip("outside the boundary (" + re.search(BAD, block).group(0) + ")")
+            gates = {}
+            fg = field(block, "featureGates")
+            if fg:
+                for g, v in re.findall(r"features\.(\w+):\s*(true|false)", fg):
+                    gates[g] = v == "true"
+                allowed = {"TASProfileMixed": True, "TASRecomputeAssignmentWithinSchedulingCycle": True, "VectorizedResourceRequests": None,
+                           "TASCachingRemainingResources": None, "TASCacheNodeMatchResults": None}
+                for g, v in gates.items():
+                    if g not in allowed or (allowed[g] is not None and allowed[g] != v):
+                        raise Skip("gate " + g)
+            def listf(fname):
+                f = field(block, fname)
+                return items_of(f, sym) if f else []
+            for t in listf("nodes") + listf("clusterQueues") + listf("resourceFlavors"):
+                if re.search(BAD, t):
+                    raise Skip("outside the boundary (" + re.search(BAD, t).group(0) + ")")
+            nodes = [parse_node(t, sym) for t in listf("nodes")]
+            topologies = dict(parse_topology(t, sym) for t in listf("topologies"))
+            flavors = [parse_flavor(t, sym) for t in listf("resourceFlavors")]
+            cqs = []
+            for t in listf("clusterQueues"):
+                c = parse_cq(t)
+                if "StrictFIFO" in t:
+                    c["strategy"] = "StrictFIFO"
+                cqs.append(c)
+            cohorts = [parse_cohort(t) for t in listf("cohorts")]
+            wf = field(block, "workloads") or ""
+            wls = workloads_in(wf, sym)
+            cq_names = {c["name"] for c in cqs}
+            admitted, pending = [], []
+            pod_requests = {}
+            for w in wls:
+                key = f"{w['ns']}/{w['name']}"
+                if "cq" in w:
+                    if w["cq"] not in cq_names:
+                        raise Skip("admitted into an unknown ClusterQueue")
+                    d = {"name": key, "cq": w["cq"], "priority": w["priority"], "created": w["created"], "reservedAt": w.get("reservedAt", NOW),
+                         "evicted": bool(w.get("evicted")), "podsets": []}
+                    spec = {ps["name"]: ps for ps in w["podsets"]}
+                    for ps in w["admission"]:
+                        e = {"count": ps["count"], "totalRequests": ps["usage"], "flavors": ps["flavors"]}
+                        if "topologyAssignment" in ps:
+                            e["topologyAssignment"] = ps["topologyAssignment"]
+                            e["podRequests"] = spec[ps["name"]]["requests"] if ps["name"] in spec else {}
+                        d["podsets"].append(e)
+                    admitted.append(d)
+                else:
+                    cq = lqs.get((w["ns"], w.get("queue", "")))
+                    if cq is None or cq not in cq_names:
+                        raise Skip("pending workload in a missing LocalQueue/ClusterQueue")
+                    pending.append({"name": key, "cq": cq, "priority": w["priority"], "created": w["created"], "podsets": w["podsets"]})
+            heads, rest = [], []
+            for cq in sorted({p_["cq"] for p_ in pending}):
+                q = sorted([p_ for p_ in pending if p_["cq"] == cq], key=lambda p_: (-p_["priority"], p_["created"]))
+                if len(q) > 1 and (-q[0]["priority"], q[0]["created"]) == (-q[1]["priority"], q[1]["created"]):
+                    raise Skip("head order decided by UID / name tie-break")
+                heads.append(q[0]); rest += q[1:]
+            want_adm = {}
+            wa = field(block, "wantNewAssignments")
+            if wa and "{" in wa:
+                p0 = wa.index("{")
+                for ent in split_top(wa[p0 + 1: match_brace(wa, p0)]):
+                    km = re.match(r'\s*"([^"]+)":\s*', ent)
+                    if not km:
+                        continue
+                    cq, pss = parse_admission(ent[km.end():], sym)
+                    want_adm[km.group(1)] = {"cq": cq, "podsets": pss}
+            expect = {}
+            for h in heads:
+                if h["name"] in want_adm:
+                    expect[h["name"]] = {"admitted": True, "podsets": [
+                        {"flavors": ps["flavors"], "count": ps["count"], **({"topologyAssignment": ps["topologyAssignment"]} if "topologyAssignment" in ps else {})}
+                        for ps in want_adm[h["name"]]["podsets"]]}
+                else:
+                    expect[h["name"]] = {"admitted": False}
+            for k in want_adm:
+                if k not in expect:
+                    raise Skip("admission of a workload that is not a head")
+            left = parse_keymap(field(block, "wantLeft"))
+            inadm = parse_keymap(field(block, "wantInadmissibleLeft"))
+            for keys in left.values():
+                for k in keys:
+                    if k in expect:
+                        expect[k]["left"] = "active"
+            for keys in inadm.values():
+                for k in keys:
+                    if k in expect:
+                        expect[k]["left"] = "inadmissible"
+            want_wls = workloads_in(field(block, "wantWorkloads") or "", sym)
+            preempted = sorted(f"{w['ns']}/{w['name']}" for w in want_wls if w.get("preempted"))
+            case = {"name": name, "ref": f"pkg/scheduler/scheduler_tas_test.go:{line}", "func": func, "now": NOW, "nodes": nodes,
+                    "topologies": topologies, "resourceFlavors": flavors, "clusterQueues": cqs, "cohorts": cohorts, "admitted": admitted,
+                    "pending": heads, "notHeads": [r["name"] for r in rest], "expect": expect}
+            if want_wls:
+                case["wantPreempted"] = preempted
+            if gates:
+                case["gatesGo"] = gates
+            cases.append(case)
+        except Skip as e:
+            skipped[str(e)] += 1
+        except (ValueError, KeyError, IndexError, AttributeError) as e:
+            skipped["parse:" + type(e).__name__] += 1
+
+
+def main():
+    src = strip_comments(open(SRC).read())
+    cases, skipped = [], collections.Counter()
+    for func in ("TestScheduleForTAS", "TestScheduleForTASPreemption", "TestScheduleForTASCohorts"):
+        extract(src, func, cases, skipped)
+    out = os.path.join(HERE, "schedule_tas.yaml")
+    with open(out, "w") as f:
+        f.write("# GENERATED by tests/golden/extract_schedule_tas.py from /root/reference/pkg/scheduler/scheduler_tas_test.go\n")
+        f.write("# %d cases kept; skipped: %s\n" % (len(cases), dict(skipped)))
+        yaml.safe_dump({"cases": cases}, f, sort_keys=False, width=160)
+    print(len(cases), "cases;", dict(skipped))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,57 @@
+"""Topology-Aware Scheduling INSIDE the scheduling cycle: the oracle (oracle/kq_oracle.cpp kqo_cycle_run_tas) against the whole-cycle
+tables of pkg/scheduler/scheduler_tas_test.go (TestScheduleForTAS :58, TestScheduleForTASPreemption :4121, TestScheduleForTASCohorts
+:5950) transcribed by tests/golden/extract_schedule_tas.py: exactly one Scheduler.schedule() per case. Checked per head: admitted or
+not, flavors, pod counts and the TopologyAssignment (domain values + counts) of the admission, requeue class, preempted set.
+The engine does not run this path yet: this pins the checker ahead of the device code."""
+import pytest
+
+from kueue_amd import _ffi as F
+from kueue_amd.tas_cycle import load_tas_case
+from tests.conftest import load_golden
+
+IMMEDIATE = {F.RQ_FAILED_AFTER_NOMINATION, F.RQ_PENDING_PREEMPTION}
+CASES = load_golden("schedule_tas.yaml")["cases"]
+
+
+def check_case(oracle, case):
+    cfg, snap, heads, ct = load_tas_case(case)
+    oracle.derive(snap)
+    d, out = oracle.cycle_run_tas(cfg, snap, heads, ct, tgt_cap=max(16, snap.n_adm))
+    assert not d.tas_stats["unsupported"], "the case left the restated path"
+    strict = {c["name"]: c.get("strategy") == "StrictFIFO" for c in case["clusterQueues"]}
+    preempted = set()
+    for i, w in enumerate(heads.workloads):
+        exp = case["expect"][w.name]
+        act = int(d.a["action"][i])
+        if exp["admitted"]:
+            assert act == F.ACT_ADMIT, (w.name, "expected admission", {k: v[i] for k, v in d.a.items() if len(v) == heads.n})
+            got = d.flavors_of(i)
+            for pi, ps in enumerate(exp["podsets"]):
+                assert {r: v[0] for r, v in got[pi].items()} == ps["flavors"], (w.name, got, ps)
+                assert int(d.a["ps_count"][heads.arrays["ps_off"][i] + pi]) == ps["count"], (w.name, pi)
+                ta = out.topology_assignment(i, pi)
+                if "topologyAssignment" in ps:
+                    assert ta is not None, (w.name, pi, "no TopologyAssignment")
+                    want = sorted((tuple(v), c) for v, c in ps["topologyAssignment"]["domains"])
+                    assert sorted((tuple(v), c) for v, c in ta[1]) == want, (w.name, pi, ta, want)
+                else:
+                    assert ta is None, (w.name, pi, ta)
+        else:
+            assert act != F.ACT_ADMIT, (w.name, "unexpected admission", out.topology_assignment(i, 0))
+            rq = int(d.a["requeue_reason"][i])
+            # requeueIfNotPresent cluster_queue.go:568-575: immediate, or LastAssignment.PendingFlavors() (workload.go:211)
+            pending_flavors = any(v[2] != -1 for ps in d.flavors_of(i) for v in ps.values())
+            active = strict[w.cluster_queue] or rq in IMMEDIATE or pending_flavors
+            if exp.get("left") == "inadmissible":
+                assert not active, (w.name, rq)
+            elif exp.get("left") == "active":
+                assert active, (w.name, rq)
+        if act == F.ACT_PREEMPT:
+            preempted |= {t.split(":")[0] for t in d.target_names(i)}
+    if "wantPreempted" in case:
+        assert sorted(preempted) == case["wantPreempted"], (sorted(preempted), case["wantPreempted"])
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"][:80])
+def test_schedule_tas(oracle, case):
+    check_case(oracle, case)
