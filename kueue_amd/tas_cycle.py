@@ -22,11 +22,12 @@ from .api import Heads, Snapshot, amount_from_quantity
 from .tas import KQ_TAS_UNCONSTRAINED, Node, TASPodSetRequests, Topology, TopologyRequest, kq_tas_topology
 
 PS_TAS_EXPLICIT = 1
+CT_NO_RECOMPUTE = 1
 
 
 class kq_cycle_tas(C.Structure):
     _fields_ = [
-        ("n_tas", C.c_int32), ("tas_flavor", F.i32p), ("topo", C.POINTER(kq_tas_topology)), ("cq_tas_only", F.u8p),
+        ("flags", C.c_uint32), ("n_tas", C.c_int32), ("tas_flavor", F.i32p), ("topo", C.POINTER(kq_tas_topology)), ("cq_tas_only", F.u8p),
         ("adm_off", F.i32p), ("adm_tas", F.i32p), ("adm_leaf", F.i32p), ("adm_count", F.i32p), ("adm_req", F.i64p),
         ("ps_flags", F.u8p), ("ps_kind", F.u8p), ("ps_level", F.i32p), ("ps_slice_size", F.i32p), ("ps_slice_level", F.i32p),
         ("ps_group", F.i32p), ("ps_req", F.i64p),
@@ -119,7 +120,7 @@ class CycleTAS:
     """kq_cycle_tas for one (Snapshot, Heads)."""
 
     def __init__(self, snap: Snapshot, heads: Heads, topologies: Dict[str, Topology], pod_tas: Dict[Tuple[str, int], PodSetTAS],
-                 admitted_tas: Optional[Dict[str, List[AdmittedTAS]]] = None):
+                 admitted_tas: Optional[Dict[str, List[AdmittedTAS]]] = None, recompute: bool = True):
         self.snap, self.heads = snap, heads
         names = sorted(topologies)                       # slices.Sorted(maps.Keys(...)) clusterqueue_snapshot.go:220
         self.names = names
@@ -174,7 +175,7 @@ class CycleTAS:
                     group[g] = gid.setdefault((w.name, pt.group), len(gid))
                 for r, q in pt.single_pod_requests.items():
                     v = _amount(r, q)
-                    if v != 0:
+                    if v != 0 and nt:
                         req[g, rix[r]] = v
                 g += 1
         a.update(ps_flags=flags, ps_kind=kind, ps_level=level.reshape(-1).copy(), ps_slice_size=ssize, ps_slice_level=slevel.reshape(-1).copy(),
@@ -185,7 +186,7 @@ class CycleTAS:
             st = t.struct()
             C.memmove(C.byref(self._topo_arr, i * C.sizeof(kq_tas_topology)), C.byref(st), C.sizeof(kq_tas_topology))
         self._struct = kq_cycle_tas()
-        F.fill_struct(self._struct, a, dict(n_tas=nt))
+        F.fill_struct(self._struct, a, dict(n_tas=nt, flags=0 if recompute else CT_NO_RECOMPUTE))
         self._struct.topo = C.cast(self._topo_arr, C.POINTER(kq_tas_topology))
 
     def struct(self) -> kq_cycle_tas:
@@ -261,8 +262,10 @@ def load_tas_case(case: dict, cycle: int = 1):
     for w in case.get("pending", []) + case.get("admitted", []):
         for ps in w.get("podsets", []):
             extra.update((ps.get("requests") or {}).keys())
+    non_tas = {node: {r: (sum(_amount(r, q) for q in qs) if isinstance(qs, (list, tuple)) else _amount(r, qs)) for r, qs in d.items()}
+               for node, d in (case.get("nonTASUsage") or {}).items()}
     topologies = build_topologies(list(flavors.values()), {k: list(v) for k, v in (case.get("topologies") or {}).items()}, nodes,
-                                  case.get("nonTASUsage"), sorted(extra))
+                                  non_tas, sorted(extra))
     cqs = {c["name"]: _cq(c) for c in case.get("clusterQueues", [])}
 
     def req_of(ps):
@@ -294,4 +297,5 @@ def load_tas_case(case: dict, cycle: int = 1):
     case.setdefault("flavors", [])
     case["flavors"] = sorted(set(case["flavors"]) | set(flavors))
     cfg, snap, heads = load_case(case, cycle)
-    return cfg, snap, heads, CycleTAS(snap, heads, topologies, pod_tas, admitted_tas)
+    recompute = bool((case.get("gatesGo") or {}).get("TASRecomputeAssignmentWithinSchedulingCycle", True))
+    return cfg, snap, heads, CycleTAS(snap, heads, topologies, pod_tas, admitted_tas, recompute=recompute)

@@ -17,7 +17,10 @@ extern "C" {
 
 #define KQ_PS_TAS_EXPLICIT 1u   /* workload.IsExplicitlyRequestingTAS(podSet) */
 
+#define KQ_CT_NO_RECOMPUTE 1u    /* features.TASRecomputeAssignmentWithinSchedulingCycle off (default on) */
+
 typedef struct kq_cycle_tas {
+  uint32_t flags;                   /* KQ_CT_* */
   int32_t n_tas;                    /* TAS ResourceFlavors with a cached topology (ClusterQueueSnapshot.TASFlavors, snapshot.go:260) */
   const int32_t* tas_flavor;        /* [n_tas] index in the snapshot's flavor dictionary; ascending by flavor NAME (slices.Sorted,
                                        clusterqueue_snapshot.go:220) */

@@ -1438,7 +1438,7 @@ struct Scheduler {
   bool updateAssignmentIfNeeded(Entry& e, int cq, const std::set<int>& preempted, FRQ* usageOut) {
     FRQ usage = assignmentUsage(e);
     int fc = fitsCheck(e, cq, usage, preempted, e.preemptionTargets);
-    const bool needsTASRecompute = fc == FitsCheckNoTAS;  // TASRecomputeAssignmentWithinSchedulingCycle: default on
+    const bool needsTASRecompute = fc == FitsCheckNoTAS && !(sn.T->flags & KQ_CT_NO_RECOMPUTE);  // TASRecomputeAssignmentWithinSchedulingCycle
     bool needsOverlapRecompute = hasAny(preempted, e.preemptionTargets) && sn.gate(KQ_GATE_RECOMPUTE_ON_OVERLAP);
     if (!needsOverlapRecompute && !needsTASRecompute) { *usageOut = usage; return fc == FitsCheckOk; }
     if (!needsOverlapRecompute) {  // case needsTASRecompute :728

@@ -140,6 +140,31 @@ def parse_node(text, sym):
     return n
 
 
+def parse_pods(items):
+    """[]corev1.Pod -> non-TAS usage {node: {resource: [quantities]}} (tas_non_tas_pod_cache.go: scheduled, not terminated pods)"""
+    out = {}
+    for text in items:
+        calls, _ = chain(text, text.index("MakePod"))
+        node, reqs, done = None, {}, False
+        for m, a in calls[1:]:
+            if m == "NodeName":
+                node = a.strip().strip('"')
+            elif m == "Request":
+                r, q = split_top(a)
+                reqs[res_name(r)] = q.strip().strip('"')
+            elif m == "StatusPhase":
+                done = "Succeeded" in a or "Failed" in a
+            elif m not in ("Obj", "Clone"):
+                raise Skip("Pod." + m)
+        if node is None or done:
+            continue
+        d = out.setdefault(node, {})
+        for r, q in reqs.items():
+            d.setdefault(r, []).append(q)
+        d.setdefault("pods", []).append("1")
+    return out
+
+
 def parse_topology(text, sym):
     m = re.search(r'MakeDefaultOneLevelTopology\("([^"]+)"\)', text)
     if m:
@@ -298,7 +323,7 @@ def parse_keymap(text):
 
 BAD = r"AdmissionCheck|Toleration|NodeSelector|Taint|PreemptionGate|WorkloadSlice|Annotation|UnhealthyNode|DelayedTopologyRequest|PodSetGroup|" \
       r"resourceTransformations|patchStatusErr|RequiredDuringScheduling|PreferredDuringScheduling|PodSetUpdate|StopPolicy|SliceRequiredTopologyConstraint|" \
-      r"MinimumCount|SetMinimumCount|MakePod\("
+      r"MinimumCount|SetMinimumCount"
 
 
 def lqs_of(body):
@@ -330,7 +355,7 @@ def extract(src, func, cases, skipped):
             if fg:
                 for g, v in re.findall(r"features\.(\w+):\s*(true|false)", fg):
                     gates[g] = v == "true"
-                allowed = {"TASProfileMixed": True, "TASRecomputeAssignmentWithinSchedulingCycle": True, "VectorizedResourceRequests": None,
+                allowed = {"TASProfileMixed": True, "TASRecomputeAssignmentWithinSchedulingCycle": None, "VectorizedResourceRequests": None,
                            "TASCachingRemainingResources": None, "TASCacheNodeMatchResults": None}
                 for g, v in gates.items():
                     if g not in allowed or (allowed[g] is not None and allowed[g] != v):
@@ -351,6 +376,7 @@ def extract(src, func, cases, skipped):
                     c["strategy"] = "StrictFIFO"
                 cqs.append(c)
             cohorts = [parse_cohort(t) for t in listf("cohorts")]
+            non_tas = parse_pods(listf("pods"))
             wf = field(block, "workloads") or ""
             wls = workloads_in(wf, sym)
             cq_names = {c["name"] for c in cqs}
@@ -418,6 +444,8 @@ def extract(src, func, cases, skipped):
             case = {"name": name, "ref": f"pkg/scheduler/scheduler_tas_test.go:{line}", "func": func, "now": NOW, "nodes": nodes,
                     "topologies": topologies, "resourceFlavors": flavors, "clusterQueues": cqs, "cohorts": cohorts, "admitted": admitted,
                     "pending": heads, "notHeads": [r["name"] for r in rest], "expect": expect}
+            if non_tas:
+                case["nonTASUsage"] = non_tas
             if want_wls:
                 case["wantPreempted"] = preempted
             if gates:

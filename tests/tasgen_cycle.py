@@ -1,0 +1,67 @@
+"""Seeded random TAS sides on top of tests/randgen.py populations: some flavors become TAS flavors over random node trees, pending
+podsets get random topology requests, a few admitted workloads get a TopologyAssignment. Used for property tests of the TAS cycle."""
+import random
+
+from kueue_amd.api import Heads
+from kueue_amd.tas import Node, TopologyRequest
+from kueue_amd.tas_cycle import AdmittedTAS, CycleTAS, PodSetTAS, ResourceFlavor, build_topologies, excluded_flavors_for_tas
+from tests.randgen import random_case
+
+BLOCK, RACK, HOST = "cloud.com/topology-block", "cloud.com/topology-rack", "kubernetes.io/hostname"
+
+
+def random_tas_cycle_case(seed, roomy=False, **kw):
+    cfg, snap, heads = random_case(seed, **kw)
+    rnd = random.Random(seed * 7919 + 13)
+    levels = rnd.choice([[HOST], [RACK, HOST], [BLOCK, RACK, HOST], [BLOCK, RACK]])
+    nodes = []
+    for b in range(rnd.randint(1, 2)):
+        for r in range(rnd.randint(1, 3)):
+            for h in range(rnd.randint(1, 3)):
+                big = 10 ** 6 if roomy else 1
+                nodes.append(Node(f"b{b}-r{r}-x{h}", {BLOCK: f"b{b}", RACK: f"r{r}", HOST: f"b{b}-r{r}-x{h}", "pool": rnd.choice(["a", "b"])},
+                                  {"cpu": rnd.randint(1, 8) * 1000 * big, "memory": rnd.randint(1, 8) * big, "example.com/gpu": rnd.randint(0, 4) * big,
+                                   "pods": rnd.randint(2, 12) * big}))
+    flavors = []
+    for f in snap.flavors:
+        if rnd.random() < 0.6:
+            flavors.append(ResourceFlavor(f, {"pool": rnd.choice(["a", "b"])} if rnd.random() < 0.4 else {}, "topo"))
+        else:
+            flavors.append(ResourceFlavor(f))
+    fl = {f.name: f for f in flavors}
+    topologies = build_topologies(flavors, {"topo": levels}, nodes, None, ["cpu", "memory", "example.com/gpu", "uncovered.io/x"])
+    cqs = {c.name: c for c in snap.cluster_queues}
+    pod_tas = {}
+    pending = heads.workloads
+    for w in pending:
+        for pi, ps in enumerate(w.pod_sets):
+            tr = None
+            k = rnd.random()
+            if k < 0.25:
+                tr = TopologyRequest(required=rnd.choice(levels))
+            elif k < 0.45:
+                tr = TopologyRequest(preferred=rnd.choice(levels))
+            elif k < 0.6:
+                tr = TopologyRequest(unconstrained=True)
+            elif k < 0.7 and ps.count > 1:
+                tr = TopologyRequest(required=levels[0], slice_required_topology=levels[-1], slice_size=rnd.choice([s for s in (1, 2, 3) if ps.count % s == 0]))
+            per_pod = {r: (q // ps.count if ps.count else 0) for r, q in ps.requests.items() if r != "pods"}
+            pt = PodSetTAS(tr, None, per_pod)
+            pod_tas[(w.name, pi)] = pt
+            ex = excluded_flavors_for_tas(cqs[w.cluster_queue], [r for r in ps.requests if r != "pods" or True], pt, topologies, fl)
+            ps.excluded_flavors = sorted(set(ps.excluded_flavors) | set(ex))
+    heads = Heads(snap, pending, cycle=heads.cycle)
+    admitted_tas = {}
+    for w in snap.admitted:
+        for ps in w.pod_sets:
+            tf = [f for f in set(ps.flavors.values()) if f in topologies]
+            if len(tf) != 1 or rnd.random() < 0.3 or ps.count <= 0:
+                continue
+            topo = topologies[tf[0]]
+            if topo.n_leaves == 0:
+                continue
+            leaf = rnd.randrange(topo.n_leaves)
+            per_pod = {r: q // ps.count for r, q in ps.requests.items() if r != "pods" and q // ps.count > 0}
+            admitted_tas.setdefault(w.name, []).append(AdmittedTAS(tf[0], [(tuple(topo.leaf_values(leaf)), ps.count)], per_pod))
+    ct = CycleTAS(snap, heads, topologies, pod_tas, admitted_tas, recompute=rnd.random() < 0.85)
+    return cfg, snap, heads, ct, pod_tas
