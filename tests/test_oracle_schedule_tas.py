@@ -55,3 +55,45 @@ def check_case(oracle, case):
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"][:80])
 def test_schedule_tas(oracle, case):
     check_case(oracle, case)
+
+
+HOST = "kubernetes.io/hostname"
+
+
+def test_multiple_tas_flavors_in_one_podset_is_nofit(oracle):
+    """TestAssignFlavors "multiple TAS flavors assigned to different resources in the same PodSet leads to NoFit"
+    (flavorassigner_test.go:3443): cpu lands on tas-a, memory on tas-b, onlyTASFlavor fails -> psError -> NoFit, flavors kept as Fit."""
+    node = dict(name="x1", labels={HOST: "x1"}, allocatable={"cpu": "10", "memory": "10Gi", "pods": "10"})
+    case = dict(
+        nodes=[node], topologies={"tas-topo-a": [HOST], "tas-topo-b": [HOST]},
+        resourceFlavors=[dict(name="tas-a", topologyName="tas-topo-a"), dict(name="tas-b", topologyName="tas-topo-b")],
+        clusterQueues=[dict(name="test-clusterqueue", resourceGroups=[[dict(flavor="tas-a", resources={"cpu": ["10", "", ""]})],
+                                                                      [dict(flavor="tas-b", resources={"memory": ["10Mi", "", ""]})]])],
+        pending=[dict(name="ns/wl", cq="test-clusterqueue", podsets=[dict(name="main", count=1, requests={"cpu": "1", "memory": "1Mi"},
+                                                                           topologyRequest={"required": HOST})])])
+    cfg, snap, heads, ct = load_tas_case(case)
+    oracle.derive(snap)
+    d, out = oracle.cycle_run_tas(cfg, snap, heads, ct)
+    assert F.MODE_NAMES[int(d.a["nominated_mode"][0])] == "NoFit" and int(d.a["action"][0]) == F.ACT_NONE
+    assert {r: (v[0], v[1], v[2]) for r, v in d.flavors_of(0)[0].items()} == {"cpu": ("tas-a", "Fit", -1), "memory": ("tas-b", "Fit", -1)}
+    assert out.topology_assignment(0, 0) is None
+
+
+def test_fit_on_quota_but_fragmented_topology_turns_into_preempt_then_nofit(oracle):
+    """flavorassigner.go:866-903 step by step on one node of 1 cpu: a 1-cpu pod fits; with the node full of an admitted pod the Fit
+    becomes Preempt (TAS failure reason), the simulate-empty placement succeeds, and without a preemption policy the head stays
+    pending with no targets; a 2-cpu pod does not fit even on the empty topology -> NoFit."""
+    node = dict(name="x1", labels={HOST: "x1"}, allocatable={"cpu": "1", "pods": "10"})
+    base = dict(nodes=[node], topologies={"t": [HOST]}, resourceFlavors=[dict(name="tas", topologyName="t")],
+                clusterQueues=[dict(name="cq", resourceGroups=[[dict(flavor="tas", resources={"cpu": ["50", "", ""]})]])])
+    pend = lambda cpu: [dict(name="ns/new", cq="cq", podsets=[dict(name="one", count=1, requests={"cpu": cpu}, topologyRequest={"required": HOST})])]
+    adm = [dict(name="ns/old", cq="cq", podsets=[dict(count=1, totalRequests={"cpu": "1"}, flavors={"cpu": "tas"}, podRequests={"cpu": "1"},
+                                                       topologyAssignment={"domains": [[["x1"], 1]]})])]
+    for admitted, cpu, want_mode, want_ta in (([], "1", "Fit", [(["x1"], 1)]), (adm, "1", "Preempt", [(["x1"], 1)]), ([], "2", "NoFit", None)):
+        cfg, snap, heads, ct = load_tas_case(dict(base, admitted=admitted, pending=pend(cpu)))
+        oracle.derive(snap)
+        d, out = oracle.cycle_run_tas(cfg, snap, heads, ct)
+        assert F.MODE_NAMES[int(d.a["nominated_mode"][0])] == want_mode, (cpu, d.a["nominated_mode"])
+        ta = out.topology_assignment(0, 0)
+        assert (ta[1] if ta else None) == want_ta, (cpu, ta)
+        assert (int(d.a["action"][0]) == F.ACT_ADMIT) == (want_mode == "Fit")
