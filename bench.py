@@ -32,13 +32,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3-batch", "cfg3-split", "cfg4c", "cfg3f", "cfg4f", "cfg5"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3-batch", "cfg3-split", "cfg4c", "cfg3f", "cfg4f", "cfg5", "cfg5-split"],
                     help="cfg3 = BASELINE.json configs[2] (100k pending, 1k CQ, 16 flavors, 3-level cohorts); "
                          "cfg4c = configs[3] population under classical preemption; cfg4f = configs[3] as quoted "
                          "(fair sharing + preemption); cfg3f = configs[2] population under fair sharing; cfg5 = configs[4] "
                          "(TAS: 4096-leaf 3-tier topology, topology assignment for a batch of pending workloads); cfg3-batch = every pending "
                          "workload of cfg3 nominated in one launch (SURVEY 8d 'nominate-all-pending', kq_nominate_run_resident)")
     ap.add_argument("--tas-batch", type=int, default=50_000, help="cfg5: pending workloads assigned per step")
+    ap.add_argument("--tas-cycle", type=int, default=1000, help="cfg5-split: pending workloads of one cycle (one head per ClusterQueue at 1k CQ)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--open-loop", action="store_true",
                     help="every cycle sees the same snapshot (no kq_cycle_commit / kq_cycle_release between cycles)")
@@ -67,6 +68,8 @@ def main():
 
     if args.workload == "cfg5":
         return bench_tas(args, torch, dist, world, rank, local_rank)
+    if args.workload == "cfg5-split":
+        return bench_tas_split(args, torch, dist, world, rank, local_rank)
     if args.workload == "cfg3-batch":
         return bench_batch(args, torch, dist, world, rank, local_rank)
     if args.workload == "cfg3-split":
@@ -665,6 +668,96 @@ def bench_batch(args, torch, dist, world, rank, local_rank):
             "value": heads.n / dt, "unit": "decisions/s", "cores": 1, "kind": "port",
             "sample": f"the same {heads.n} nominations, C++ restatement of the Go path, host nproc={os.cpu_count()}"}
         print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_tas_split(args, torch, dist, world, rank, local_rank):
+    """cfg5-split: ONE TAS flavor (cfg 5 topology) shared by all ranks — STRONG scaling: every cycle's batch of --tas-cycle pending
+    workloads is the same at every N; the leaf state is replicated, rank r places the entries r, r+N, ... of the entry order
+    (kq_tas_find), the ranks all-reduce their leaf-usage planes (RCCL, int64 sum), admit what the overflow certificate lets through as
+    a whole and walk the contended workloads in entry order (kq_tas_admit) — kueue_amd/sharding.py SplitTAS. One step = one cycle:
+    placements + admitted set + usage folded in on every rank; a cycle's admissions are released --hold cycles later."""
+    from kueue_amd import tas as T
+    from kueue_amd.sharding import SplitTAS
+    from kueue_amd.tas_population import TAS_SEED, generate_tas
+    per = args.tas_cycle
+    n_batches = min(8, args.steps + args.warmup)
+    topo, rq_all = generate_tas(n_workloads=per * n_batches, seed=TAS_SEED)
+    batches = [rq_all.subset(np.arange(c * per, (c + 1) * per)) for c in range(n_batches)]
+    eng = T.TASEngine(device=local_rank)
+    eng.put(topo)
+    dev = f"cuda:{local_rank}"
+    sp = SplitTAS(eng, topo, dist, rank, world, device=dev)
+    R = len(topo.resources)
+    held = []
+
+    def step(i):
+        rq = batches[i % n_batches]
+        merged, adm = sp.cycle(rq)
+        # what the cycle added (for the release --hold cycles later): Usage.TAS of the admitted workloads
+        plane = torch.zeros(topo.n_leaves * R, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        eng.usage_delta(rq, merged, plane.data_ptr(), wl_sel=adm)
+        held.append(plane)
+        if len(held) > args.hold:
+            eng.usage_add(held.pop(0).data_ptr(), -1)
+        return adm
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    sp.stats = dict(cycles=0, exact=0, contended=0, walked=0)
+    cyc_ms, dec, n_adm = [], 0, 0
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        t1 = time.perf_counter()
+        adm = step(args.warmup + i)
+        cyc_ms.append((time.perf_counter() - t1) * 1e3)
+        dec += per; n_adm += int(adm.sum())
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    verified = None
+    if rank == 0 and not args.no_parity_gate:   # outside the timed region: a single engine replays the loop, end state must agree
+        ref = T.TASEngine(device=local_rank)
+        ref.put(topo)
+        h2 = []
+        for i in range(args.warmup + args.steps):
+            rq = batches[i % n_batches]
+            res = ref.find(rq)
+            adm = ref.admit(rq, res)
+            plane = torch.zeros(topo.n_leaves * R, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            # the walk already added the usage; the plane is only kept for the release
+            ref.usage_delta(rq, res, plane.data_ptr(), wl_sel=adm)
+            h2.append(plane)
+            if len(h2) > args.hold:
+                ref.usage_add(h2.pop(0).data_ptr(), -1)
+        verified = bool(np.array_equal(ref.read_usage(), eng.read_usage()))
+        ref.close()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "admission-decisions/sec + p99 schedule-cycle ms @ 100k pending, 1k CQ",
+            "value": dec / elapsed, "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"cfg5-split: ONE TAS flavor, {topo.n_leaves} leaves, {per} pending workloads per cycle (placement + entry-order admission), "
+                                   f"leaf state replicated, entries sharded round-robin, all-reduce of leaf-usage planes",
+                       "decision": "one workload's topology assignment + its admission in entry order",
+                       "sharding": "SplitTAS: kq_tas_find on the shard, RCCL all-reduce(sum,int64) of [leaves x resources] planes, overflow certificate, contended walk"},
+            "p50_cycle_ms": float(np.percentile(cyc_ms, 50)), "p99_cycle_ms": float(np.percentile(cyc_ms, 99)),
+            "admitted_per_cycle": n_adm / max(args.steps, 1), "split_stats": sp.stats,
+            "end_state_equals_single_engine": verified,
+            "roofline": None, "cpu_baseline": None,
+        }))
+    eng.close()
     if world > 1:
         dist.destroy_process_group()
 

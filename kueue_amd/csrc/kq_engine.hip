@@ -220,6 +220,22 @@ __global__ __launch_bounds__(64) void k_tas_fits(TTopo T, int n, const int32_t* 
   if (i < n) t_fits_cell(T, i, leaf, count, spr, flag);
 }
 
+// batch admission in entry order: one wavefront (the entries of a TAS flavor are sequentially dependent through the leaf usage)
+__global__ __launch_bounds__(64) void k_tas_admit(TTopo T, TAdmit A) { t_admit_seq(T, A); }
+__global__ __launch_bounds__(256) void k_tas_delta(TTopo T, int n, const uint8_t* sel, const int32_t* dom_off, const int32_t* dom_leaf, const int32_t* dom_count,
+                                                   const int64_t* spr, int64_t* plane) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p < n) t_delta_cell(T, p, sel, dom_off, dom_leaf, dom_count, spr, plane);
+}
+__global__ __launch_bounds__(256) void k_tas_plane_add(TTopo T, const int64_t* plane, int sign) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < (size_t)T.n_leaves * T.R) t_plane_add_cell(T, i, plane, sign);
+}
+__global__ __launch_bounds__(256) void k_tas_overflow(TTopo T, const int64_t* plane, uint8_t* over, int32_t* n_over) {
+  const int leaf = blockIdx.x * 256 + threadIdx.x;
+  if (leaf < T.n_leaves) t_overflow_cell(T, leaf, plane, over, n_over);
+}
+
 // pending side on the device (kq_pending.hpp): Heads() = pop per ClusterQueue + compaction + gather; requeue from the decisions
 __global__ __launch_bounds__(64) void k_pend_pop(DPend D) { pend_pop(D, blockIdx.x); }
 constexpr int PEND_SCAN_THREADS = 1024;
@@ -335,6 +351,23 @@ struct HipBackend {
   void launch_tas_fits(const TTopo& T, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t* flag) {
     hipLaunchKernelGGL(k_tas_fits, dim3((n + 63) / 64), dim3(64), 0, stream, T, n, leaf, count, spr, flag);
     chk(hipGetLastError(), "k_tas_fits");
+  }
+  void launch_tas_admit(const TTopo& T, const TAdmit& A) {
+    hipLaunchKernelGGL(k_tas_admit, dim3(1), dim3(64), 0, stream, T, A);
+    chk(hipGetLastError(), "k_tas_admit");
+  }
+  void launch_tas_delta(const TTopo& T, int n, const uint8_t* sel, const int32_t* dom_off, const int32_t* dom_leaf, const int32_t* dom_count, const int64_t* spr, int64_t* plane) {
+    hipLaunchKernelGGL(k_tas_delta, dim3((n + 255) / 256), dim3(256), 0, stream, T, n, sel, dom_off, dom_leaf, dom_count, spr, plane);
+    chk(hipGetLastError(), "k_tas_delta");
+  }
+  void launch_tas_plane_add(const TTopo& T, const int64_t* plane, int sign) {
+    const size_t n = (size_t)T.n_leaves * T.R;
+    hipLaunchKernelGGL(k_tas_plane_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, T, plane, sign);
+    chk(hipGetLastError(), "k_tas_plane_add");
+  }
+  void launch_tas_overflow(const TTopo& T, const int64_t* plane, uint8_t* over, int32_t* n_over) {
+    hipLaunchKernelGGL(k_tas_overflow, dim3((T.n_leaves + 255) / 256), dim3(256), 0, stream, T, plane, over, n_over);
+    chk(hipGetLastError(), "k_tas_overflow");
   }
   void launch_commit_mask(int n, int32_t* use_n_out, int32_t* cq_out, int32_t* fr_out, int64_t* qty_out, int32_t* count) {  // uses the K block of the last cycle
     hipLaunchKernelGGL(k_commit_mask, dim3((n * KQ_MAXU + 255) / 256), dim3(256), 0, stream, (const K*)dk[1], use_n_out, cq_out, fr_out, qty_out, count);
@@ -695,6 +728,22 @@ int kq_tas_fits(kq_tas* t, int32_t n, const int32_t* leaf, const int32_t* count,
   if (!t || !fits) return KQ_EINVAL;
   (void)hipSetDevice(t->e.be.device);
   return t->e.fits(n, leaf, count, spr, fits);
+}
+int kq_tas_admit(kq_tas* t, const kq_tas_requests* r, const kq_tas_result* res, const int32_t* order, int32_t n_order, uint8_t* admitted, int32_t* n_admitted) {
+  if (!t || !r || !res) return KQ_EINVAL;
+  (void)hipSetDevice(t->e.be.device);
+  return t->e.admit(r, res, order, n_order, admitted, n_admitted);
+}
+int kq_tas_usage_delta(kq_tas* t, const kq_tas_requests* r, const kq_tas_result* res, const uint8_t* wl_sel, int64_t* plane_dev) {
+  if (!t || !r || !res) return KQ_EINVAL;
+  (void)hipSetDevice(t->e.be.device);
+  return t->e.usage_delta(r, res, wl_sel, plane_dev);
+}
+int kq_tas_usage_add(kq_tas* t, const int64_t* plane_dev, int32_t sign) { if (!t) return KQ_EINVAL; (void)hipSetDevice(t->e.be.device); return t->e.usage_add(plane_dev, sign); }
+int kq_tas_overflow(kq_tas* t, const int64_t* plane_dev, uint8_t* leaf_over, int32_t* n_over) {
+  if (!t) return KQ_EINVAL;
+  (void)hipSetDevice(t->e.be.device);
+  return t->e.overflow(plane_dev, leaf_over, n_over);
 }
 int kq_tas_read_usage(kq_tas* t, int64_t* u) { if (!t || !u) return KQ_EINVAL; (void)hipSetDevice(t->e.be.device); return t->e.read_usage(u); }
 int kq_tas_last_stats(kq_tas* t, double* ms, int64_t* bytes) { if (!t) return KQ_EINVAL; if (ms) *ms = t->e.last_ms; if (bytes) *bytes = t->e.last_bytes; return KQ_OK; }

@@ -12,6 +12,19 @@
 
 namespace kq {
 
+// argument block of k_tas_admit (t_admit_seq below)
+struct TAdmit {
+  int n_order;
+  const int32_t* order;      // workload indices in entry order, nullptr = 0 .. n_order-1
+  const int32_t* wl_off;     // [n_wl+1]
+  const int32_t* status;     // [n_ps] KQ_TAS_*
+  const int32_t* dom_off;    // [n_ps+1]
+  const int32_t *dom_leaf, *dom_count;
+  const int64_t* spr;        // [n_ps][R]
+  uint8_t* admitted;         // [n_wl]
+  int32_t* n_admitted;       // [1]
+};
+
 template <class Backend> struct TasT {
   Backend be;
   std::string last_error;
@@ -52,6 +65,7 @@ template <class Backend> struct TasT {
     for (auto& b : bo) if (b.p) be.free(b.p);
     for (auto& b : bx) if (b.p) be.free(b.p);
     for (auto& b : bc) if (b.p) be.free(b.p);
+    for (auto& b : ba) if (b.p) be.free(b.p);
   }
 
   int topology_put(const kq_tas_topology* t) {
@@ -231,6 +245,101 @@ template <class Backend> struct TasT {
     int rc = be.sync();
     return rc == KQ_OK ? KQ_OK : fail(rc, be.error());
   }
+  // ---- batch admission + the split of one TAS flavor across GPUs (include/kq_tas.h, second half) ----
+  Buf ba[10];
+  int check_batch(const kq_tas_requests* r, const kq_tas_result* res, int* n_ps) {
+    if (!have_topo) return fail(KQ_EINVAL, "no topology");
+    if (!r || !res || r->n_workloads < 0) return fail(KQ_EINVAL, "null / negative batch");
+    const int nw = r->n_workloads, n = nw > 0 ? r->wl_off[nw] : 0;
+    *n_ps = n;
+    if (n == 0) return KQ_OK;
+    if (!r->wl_off || !r->single_pod_requests || !res->status || !res->dom_off || !res->dom_leaf || !res->dom_count) return fail(KQ_EINVAL, "null array in the batch");
+    if (r->wl_off[0] != 0 || res->dom_off[0] != 0) return fail(KQ_EINVAL, "offsets must start at 0");
+    for (int w = 0; w < nw; w++) if (r->wl_off[w + 1] < r->wl_off[w]) return fail(KQ_EINVAL, "wl_off not monotone");
+    for (int p = 0; p < n; p++) if (res->dom_off[p + 1] < res->dom_off[p]) return fail(KQ_EINVAL, "dom_off not monotone");
+    for (int d = 0; d < res->dom_off[n]; d++)
+      if (res->dom_leaf[d] < 0 || res->dom_leaf[d] >= T.n_leaves || res->dom_count[d] < 0) return fail(KQ_EINVAL, "assigned domain out of range");
+    return KQ_OK;
+  }
+  int admit(const kq_tas_requests* r, const kq_tas_result* res, const int32_t* order, int n_order, uint8_t* admitted, int32_t* n_admitted) {
+    int n = 0;
+    int rc = check_batch(r, res, &n);
+    if (rc != KQ_OK) return rc;
+    const int nw = r->n_workloads;
+    if (!admitted) return fail(KQ_EINVAL, "null admitted");
+    if (!order) n_order = nw;
+    if (n_order < 0) return fail(KQ_EINVAL, "negative order length");
+    if (order) for (int i = 0; i < n_order; i++) if (order[i] < 0 || order[i] >= nw) return fail(KQ_EINVAL, "order entry out of range");
+    if (n_admitted) *n_admitted = 0;
+    if (nw == 0) return KQ_OK;
+    TAdmit A{};
+    A.n_order = n_order;
+    A.order = order ? stage(ba[0], order, n_order) : nullptr;
+    A.wl_off = stage(ba[1], r->wl_off, (size_t)nw + 1);
+    A.status = stage(ba[2], res->status, n);
+    A.dom_off = stage(ba[3], res->dom_off, (size_t)n + 1);
+    const int nd = res->dom_off[n];
+    A.dom_leaf = stage(ba[4], res->dom_leaf, nd); A.dom_count = stage(ba[5], res->dom_count, nd);
+    A.spr = stage(ba[6], r->single_pod_requests, (size_t)n * T.R);
+    A.admitted = grow<uint8_t>(ba[7], nw);
+    be.memset(A.admitted, 0, nw);
+    A.n_admitted = (int32_t*)grow<int64_t>(ba[8], 2);
+    be.memset(A.n_admitted, 0, 8);
+    be.timer_mark(0);
+    be.launch_tas_admit(T, A);
+    be.timer_mark(1);
+    be.d2h(admitted, A.admitted, nw);
+    int32_t na = 0;
+    be.d2h(&na, A.n_admitted, sizeof(na));
+    rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    last_ms = be.timer_ms(0, 1);
+    if (n_admitted) *n_admitted = na;
+    return KQ_OK;
+  }
+  int usage_delta(const kq_tas_requests* r, const kq_tas_result* res, const uint8_t* wl_sel, int64_t* plane_dev) {
+    int n = 0;
+    int rc = check_batch(r, res, &n);
+    if (rc != KQ_OK) return rc;
+    if (!plane_dev) return fail(KQ_EINVAL, "null plane");
+    be.memset(plane_dev, 0, (size_t)T.n_leaves * T.R * sizeof(int64_t));
+    if (n > 0) {
+      std::vector<uint8_t> sel(n, 0);  // a workload contributes when it is selected and every podset holds an assignment
+      for (int w = 0; w < r->n_workloads; w++) {
+        bool ok = !wl_sel || wl_sel[w];
+        for (int p = r->wl_off[w]; p < r->wl_off[w + 1] && ok; p++) ok = res->status[p] == KQ_TAS_OK;
+        if (ok) for (int p = r->wl_off[w]; p < r->wl_off[w + 1]; p++) sel[p] = 1;
+      }
+      const int nd = res->dom_off[n];
+      const uint8_t* dsel = stage(ba[0], sel.data(), n);
+      const int32_t* doff = stage(ba[3], res->dom_off, (size_t)n + 1);
+      const int32_t* dl = stage(ba[4], res->dom_leaf, nd);
+      const int32_t* dc = stage(ba[5], res->dom_count, nd);
+      const int64_t* spr = stage(ba[6], r->single_pod_requests, (size_t)n * T.R);
+      be.launch_tas_delta(T, n, dsel, doff, dl, dc, spr, plane_dev);
+    }
+    rc = be.sync();  // sel / the staging sources are free to go
+    return rc == KQ_OK ? KQ_OK : fail(rc, be.error());
+  }
+  int usage_add(const int64_t* plane_dev, int sign) {
+    if (!have_topo) return fail(KQ_EINVAL, "no topology");
+    if (!plane_dev) return fail(KQ_EINVAL, "null plane");
+    be.launch_tas_plane_add(T, plane_dev, sign);
+    int rc = be.sync();
+    return rc == KQ_OK ? KQ_OK : fail(rc, be.error());
+  }
+  int overflow(const int64_t* plane_dev, uint8_t* leaf_over, int32_t* n_over) {
+    if (!have_topo) return fail(KQ_EINVAL, "no topology");
+    if (!n_over) return fail(KQ_EINVAL, "null n_over");
+    uint8_t* dov = grow<uint8_t>(ba[7], T.n_leaves);
+    int32_t* dn = (int32_t*)grow<int64_t>(ba[8], 2);
+    be.memset(dn, 0, 8);
+    be.launch_tas_overflow(T, plane_dev, dov, dn);
+    if (leaf_over) be.d2h(leaf_over, dov, T.n_leaves);
+    be.d2h(n_over, dn, sizeof(int32_t));
+    int rc = be.sync();
+    return rc == KQ_OK ? KQ_OK : fail(rc, be.error());
+  }
   int read_usage(int64_t* out) {
     if (!have_topo) return fail(KQ_EINVAL, "no topology");
     be.d2h(out, T.tas_usage, (size_t)T.n_leaves * T.R * sizeof(int64_t));
@@ -260,6 +369,89 @@ KQ_DEV void t_fits_cell(const TTopo& T, int i, const int32_t* leaf, const int32_
     if (!have || c < result) { result = c; have = true; }
   }
   if ((have ? result : 0) < count[i]) *flag = 0;
+}
+
+
+// ---- admission of a batch's TopologyAssignments (scheduler.go:392-523 processEntry, its TAS side) and the pieces of the cross-GPU
+// ---- split of one TAS flavor (kueue_amd/sharding.py SplitTAS): delta plane, plane add, overflow map ------------------------------
+// TASFlavorSnapshot.Fits :433 for one TopologyDomainRequests against the usage as it is NOW (agent-scope loads: the usage cells are
+// updated with L2 atomics by this wave between two workloads, the CU's vector L1 must not answer)
+KQ_DEV bool t_fits_dom_now(const TTopo& T, int leaf, int32_t count, const int64_t* spr) {
+  bool have = false; int32_t result = 0;
+  for (int r = 0; r < T.R; r++) {
+    if (spr[r] == 0) continue;
+    int32_t c = 0x7fffffff;
+    if (spr[r] > 0) {
+      const int64_t used = (int64_t)ag_load_u64((const uint64_t*)(T.tas_usage + (size_t)leaf * T.R + r));
+      const int64_t rem = T.free_cap[(size_t)leaf * T.R + r] - used;
+      c = (int32_t)i64max(0, i64min(rem / spr[r], 0x7fffffff));
+    }
+    if (!have || c < result) { result = c; have = true; }
+  }
+  return (have ? result : 0) >= count;
+}
+// One wavefront walks the workloads in entry order: a workload is admitted when every podset holds an assignment and every
+// (podset, domain) of its Usage.TAS fits (clusterqueue_snapshot.go:136-149: each TopologyDomainRequests is checked on its own against
+// the snapshot, the workload's own domains do not accumulate), and its usage is added before the next entry looks
+// (ClusterQueueSnapshot.AddUsage :107 -> updateTASUsage :267). Lanes = the workload's domains.
+KQ_DEV void t_admit_seq(const TTopo& T, const TAdmit& A) {
+  const int lane = lane_id();
+  int n_adm = 0;
+  for (int i = 0; i < A.n_order; i++) {
+    const int w = A.order ? A.order[i] : i;
+    const int p0 = A.wl_off[w], p1 = A.wl_off[w + 1];
+    bool bad = false;
+    for (int p = p0 + lane; p < p1; p += WAVE) bad |= A.status[p] != KQ_TAS_OK;
+    const int d0 = A.dom_off[p0], d1 = A.dom_off[p1];
+    if (wballot(bad) == 0) {
+      for (int d = d0 + lane; d < d1; d += WAVE) {
+        int p = p0;
+        while (p + 1 < p1 && A.dom_off[p + 1] <= d) p++;
+        bad |= !t_fits_dom_now(T, A.dom_leaf[d], A.dom_count[d], A.spr + (size_t)p * T.R);
+      }
+    }
+    const bool ok = wballot(bad) == 0;
+    if (ok) {
+      for (int d = d0 + lane; d < d1; d += WAVE) {
+        int p = p0;
+        while (p + 1 < p1 && A.dom_off[p + 1] <= d) p++;
+        const int64_t* spr = A.spr + (size_t)p * T.R;
+        for (int r = 0; r < T.R; r++) {
+          const int64_t v = (spr[r] > 0 ? spr[r] : 0) * (int64_t)A.dom_count[d] + (r == T.pods ? A.dom_count[d] : 0);
+          if (v) atomic_add_i64((long long*)(T.tas_usage + (size_t)A.dom_leaf[d] * T.R + r), (long long)v);
+        }
+      }
+      n_adm++;
+      ag_release();   // the adds are performed before the next workload's loads are issued
+      ag_acquire();
+      wsync();
+    }
+    if (lane == 0) A.admitted[w] = ok ? 1 : 0;
+  }
+  if (lane == 0) *A.n_admitted = n_adm;
+}
+// Usage.TAS of the selected podsets summed into a plane [n_leaves][R] (one thread per podset): what a rank contributes to the
+// all-reduce of leaf-usage deltas
+KQ_DEV void t_delta_cell(const TTopo& T, int p, const uint8_t* ps_sel, const int32_t* dom_off, const int32_t* dom_leaf, const int32_t* dom_count,
+                         const int64_t* spr_all, int64_t* plane) {
+  if (!ps_sel[p]) return;
+  const int64_t* spr = spr_all + (size_t)p * T.R;
+  for (int d = dom_off[p]; d < dom_off[p + 1]; d++)
+    for (int r = 0; r < T.R; r++) {
+      const int64_t v = (spr[r] > 0 ? spr[r] : 0) * (int64_t)dom_count[d] + (r == T.pods ? dom_count[d] : 0);
+      if (v) atomic_add_i64((long long*)(plane + (size_t)dom_leaf[d] * T.R + r), (long long)v);
+    }
+}
+KQ_DEV void t_plane_add_cell(const TTopo& T, size_t i, const int64_t* plane, int sign) { T.tas_usage[i] += sign > 0 ? plane[i] : -plane[i]; }
+// leaves where tas_usage (+ plane) exceeds the free capacity in some resource
+KQ_DEV void t_overflow_cell(const TTopo& T, int leaf, const int64_t* plane, uint8_t* over, int32_t* n_over) {
+  bool o = false;
+  for (int r = 0; r < T.R; r++) {
+    const size_t i = (size_t)leaf * T.R + r;
+    o |= T.tas_usage[i] + (plane ? plane[i] : 0) > T.free_cap[i];
+  }
+  over[leaf] = o ? 1 : 0;
+  if (o) atomic_add_i32(n_over, 1);
 }
 
 }  // namespace kq

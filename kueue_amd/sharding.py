@@ -232,3 +232,112 @@ class SplitRoot:
     def release(self, fold):
         """The workloads a past cycle admitted finish: its folded delta leaves the snapshot."""
         self.eng.usage_add(fold.data_ptr(), -1)
+
+
+# ---- ONE TAS flavor split across ranks (BASELINE.json configs[4]: "RCCL all-reduce of domain-usage deltas"; SURVEY §8e) ----------
+#
+# A TAS ResourceFlavor's leaf state (free capacity, TAS usage per topology leaf) is shared by every ClusterQueue that lists the
+# flavor (pkg/cache/scheduler/snapshot.go:260), so unlike the quota trees it cannot be partitioned: it is REPLICATED on every rank and
+# the pending workloads of a cycle are sharded instead. Nomination (FindTopologyAssignmentsForFlavor, tas_flavor_snapshot.go:578) reads
+# the snapshot only, so each rank places its shard with kq_tas_find and the union is what one engine computes. Admission is the
+# entry-order walk of processEntry (scheduler.go:392-523: Fits, then AddUsage): a rank sums the Usage.TAS of its placed workloads into
+# a plane (kq_tas_usage_delta), the planes are all-reduced (sum, int64 — the data-path collective), and kq_tas_overflow marks the leaves
+# where usage + plane exceeds the free capacity. Usage only grows during the walk, so
+#   * no marked leaf  => every Fits of the walk passes whatever the order: all placed workloads are admitted, usage += plane;
+#   * otherwise a workload that touches no marked leaf is admitted for the same reason, and the workloads that do touch one
+#     ("contended": only they ever add to a marked leaf) are walked in entry order by kq_tas_admit on every rank, after the usage of
+#     the others has been folded in — on an unmarked leaf the check passes in both orders, on a marked leaf the usage they see is
+#     exactly what the single-engine walk shows them.
+# Either way the admitted set and the resident leaf usage of every rank equal a single engine's kq_tas_find + kq_tas_admit.
+class SplitTAS:
+    """One rank's side of the protocol above. `eng` is a TASEngine (HIP) or the test suite's emulated one with the topology already
+    put; `dist` is torch.distributed or None (world 1); `device` is where the exchange planes live."""
+
+    def __init__(self, eng, topo, dist, rank: int, world: int, device="cpu"):
+        import torch
+        self.eng, self.topo, self.dist, self.rank, self.world, self.device = eng, topo, dist, rank, world, device
+        self.cells = topo.n_leaves * len(topo.resources)
+        self.plane = torch.zeros(self.cells, dtype=torch.int64, device=device)
+        self.stats = dict(cycles=0, exact=0, contended=0, walked=0)
+        self._sync()
+
+    def _sync(self):
+        if self.device != "cpu":
+            import torch
+            torch.cuda.synchronize()
+
+    def _allreduce(self, t):
+        # the engine works on its own HIP stream and returns synchronised; the collective runs on torch's: fence both ways
+        if self.world > 1:
+            self._sync()
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            self._sync()
+
+    def cycle(self, rq, order=None):
+        """rq: the cycle's whole batch (kueue_amd.tas.Requests), identical on every rank; order: entry order (workload indices,
+        default 0..n-1). -> (Result over the whole batch, admitted [n_workloads] uint8), identical on every rank."""
+        import numpy as np
+        from .tas import Result
+        nw = rq.n_workloads
+        order = np.arange(nw, dtype=np.int32) if order is None else np.asarray(order, np.int32)
+        mine = order[self.rank::self.world]                      # round-robin over the entry order: balanced whatever the order is
+        sub = rq.subset(mine)
+        res = self.eng.find(sub)
+        nd = int(res.a["dom_off"][-1])
+        part = (mine, {k: (v[:nd] if k in ("dom_leaf", "dom_count") else v) for k, v in res.a.items()})
+        off = sub.arrays["wl_off"]
+        placed = np.ones(len(mine), bool)
+        # a podset whose SinglePodRequests has no key counts 0 pods into any capacity (CountIn, pkg/resources/requests.go:195-228):
+        # its domains never fit, whatever the usage — such a workload is rejected by the walk and adds nothing
+        R = len(self.topo.resources)
+        keyless = (sub.arrays["single_pod_requests"].reshape(-1, R) == 0).all(axis=1) & (np.diff(res.a["dom_off"]) > 0)
+        bad_ps = (res.a["status"] != 0) | keyless
+        if bad_ps.any():
+            placed[np.searchsorted(off, np.nonzero(bad_ps)[0], side="right") - 1] = False
+        self.eng.usage_delta(sub, res, self.plane.data_ptr(), wl_sel=placed.astype(np.uint8))
+        self._allreduce(self.plane)                                # <- the data-path collective
+        over = self.eng.overflow(self.plane.data_ptr())
+        self.stats["cycles"] += 1
+        if not over.any():
+            self.stats["exact"] += 1
+            self.eng.usage_add(self.plane.data_ptr(), +1)
+            part[1]["_placed"] = placed
+            parts = self._gather(part)
+            admitted = np.zeros(nw, np.uint8)
+            for idx, a in parts:
+                admitted[np.asarray(idx)[a["_placed"]]] = 1
+            return Result.gather(rq, [(i, {k: v for k, v in a.items() if not k.startswith("_")}) for i, a in parts]), admitted
+        # contended workloads of this rank: placed and touching a marked leaf
+        self.stats["contended"] += 1
+        dom_hit = over[res.a["dom_leaf"][:nd]].astype(np.int64)
+        ps_hit = np.add.reduceat(np.concatenate([dom_hit, [0]]), res.a["dom_off"][:-1].astype(np.int64)) if len(res.a["dom_off"]) > 1 else np.zeros(0, np.int64)
+        ps_hit = np.where(np.diff(res.a["dom_off"]) > 0, ps_hit, 0)
+        wl_hit = np.zeros(len(mine), bool)
+        hp = np.nonzero(ps_hit > 0)[0]
+        if len(hp):
+            wl_hit[np.searchsorted(off, hp, side="right") - 1] = True
+        free = placed & ~wl_hit
+        self.eng.usage_delta(sub, res, self.plane.data_ptr(), wl_sel=free.astype(np.uint8))
+        self._allreduce(self.plane)
+        self.eng.usage_add(self.plane.data_ptr(), +1)
+        part[1]["_free"] = free
+        part[1]["_hit"] = placed & wl_hit
+        parts = self._gather(part)
+        merged = Result.gather(rq, [(i, {k: v for k, v in a.items() if not k.startswith("_")}) for i, a in parts])
+        admitted = np.zeros(nw, np.uint8)
+        hit_all = np.zeros(nw, bool)
+        for idx, a in parts:
+            admitted[np.asarray(idx)[a["_free"]]] = 1
+            hit_all[np.asarray(idx)[a["_hit"]]] = True
+        walk = order[hit_all[order]]                               # the contended workloads in entry order
+        self.stats["walked"] += len(walk)
+        if len(walk):
+            admitted |= self.eng.admit(rq, merged, order=walk)     # replicated: identical on every rank
+        return merged, admitted
+
+    def _gather(self, part):
+        if self.world == 1:
+            return [part]
+        parts = [None] * self.world
+        self.dist.all_gather_object(parts, part)
+        return parts

@@ -227,8 +227,43 @@ class Requests:
     def struct(self) -> kq_tas_requests:
         if self._struct is None:
             self._struct = kq_tas_requests()
-        F.fill_struct(self._struct, self.arrays, dict(n_workloads=len(self.workloads)))
+        F.fill_struct(self._struct, self.arrays, dict(n_workloads=len(self.arrays["wl_off"]) - 1))
         return self._struct
+
+    @property
+    def n_workloads(self) -> int:
+        return len(self.arrays["wl_off"]) - 1
+
+    def ps_index(self, wl_idx: np.ndarray) -> np.ndarray:
+        """Global podset-request indices of the given workloads, in order."""
+        off = self.arrays["wl_off"]
+        cnt = (off[wl_idx + 1] - off[wl_idx]).astype(np.int64)
+        base = np.repeat(off[wl_idx].astype(np.int64), cnt)
+        within = np.arange(int(cnt.sum()), dtype=np.int64) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        return base + within
+
+    def subset(self, wl_idx) -> "Requests":
+        """The sub-batch made of the given workloads (array slicing: no re-resolution of the requests)."""
+        wl_idx = np.asarray(wl_idx, np.int64)
+        sub = Requests.__new__(Requests)
+        sub.topo = self.topo
+        sub.workloads = None
+        ps = self.ps_index(wl_idx)
+        R = len(self.topo.resources)
+        off = self.arrays["wl_off"]
+        cnt = (off[wl_idx + 1] - off[wl_idx]).astype(np.int32)
+        a = dict(wl_off=np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32),
+                 single_pod_requests=self.arrays["single_pod_requests"].reshape(-1, R)[ps].reshape(-1).copy())
+        for k in ("count", "level", "kind", "slice_size", "slice_level", "group"):
+            a[k] = self.arrays[k][ps].copy()
+        if "simulate_empty" in self.arrays:
+            a["simulate_empty"] = self.arrays["simulate_empty"][wl_idx].copy()
+        if "leaf_ok" in self.arrays:
+            a["leaf_ok"] = self.arrays["leaf_ok"].reshape(-1, self.topo.n_leaves)[ps].reshape(-1).copy()
+        sub.arrays = a
+        sub.n = len(ps)
+        sub._struct = None
+        return sub
 
 
 class Result:
@@ -243,6 +278,27 @@ class Result:
 
     def struct(self) -> kq_tas_result:
         return self._struct
+
+    @staticmethod
+    def gather(rq: Requests, parts: Sequence[Tuple[np.ndarray, Dict[str, np.ndarray]]]) -> "Result":
+        """The Result over the whole batch `rq` from per-shard results: parts = [(workload indices of the shard, its arrays)]."""
+        n = rq.n
+        nd = np.zeros(n, np.int64)
+        for wl_idx, a in parts:
+            nd[rq.ps_index(np.asarray(wl_idx, np.int64))] = np.diff(a["dom_off"])
+        off = np.concatenate([[0], np.cumsum(nd)])
+        out = Result(rq, dom_cap=max(int(off[-1]), 1))
+        out.a["dom_off"][:] = off
+        for wl_idx, a in parts:
+            ps = rq.ps_index(np.asarray(wl_idx, np.int64))
+            for k in ("status", "operand_a", "operand_b"):
+                out.a[k][ps] = a[k]
+            cnt = np.diff(a["dom_off"]).astype(np.int64)
+            tot = int(cnt.sum())
+            if tot:
+                dst = np.repeat(off[ps], cnt) + (np.arange(tot) - np.repeat(a["dom_off"][:-1].astype(np.int64), cnt))
+                out.a["dom_leaf"][dst] = a["dom_leaf"][:tot]; out.a["dom_count"][dst] = a["dom_count"][:tot]
+        return out
 
     def assignment(self, i: int) -> List[Tuple[int, int]]:
         o = self.a["dom_off"]
@@ -291,6 +347,10 @@ def load_tas():
         lib.kq_tas_usage_apply.argtypes = [C.c_void_p, C.c_int32, F.i32p, F.i32p, F.i64p, C.c_int32]
         lib.kq_tas_fits.argtypes = [C.c_void_p, C.c_int32, F.i32p, F.i32p, F.i64p, F.i32p]
         lib.kq_tas_read_usage.argtypes = [C.c_void_p, F.i64p]
+        lib.kq_tas_admit.argtypes = [C.c_void_p, C.POINTER(kq_tas_requests), C.POINTER(kq_tas_result), F.i32p, C.c_int32, F.u8p, F.i32p]
+        lib.kq_tas_usage_delta.argtypes = [C.c_void_p, C.POINTER(kq_tas_requests), C.POINTER(kq_tas_result), F.u8p, C.c_void_p]
+        lib.kq_tas_usage_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        lib.kq_tas_overflow.argtypes = [C.c_void_p, C.c_void_p, F.u8p, F.i32p]
         lib.kq_tas_last_stats.argtypes = [C.c_void_p, F.f64p, F.i64p]
         lib.kq_tas_last_error.argtypes = [C.c_void_p]
         lib.kq_tas_last_error.restype = C.c_char_p
@@ -299,7 +359,8 @@ def load_tas():
 
 
 TAS_ABI_SYMBOLS = ["kq_tas_create", "kq_tas_destroy", "kq_tas_topology_put", "kq_tas_find", "kq_tas_usage_apply", "kq_tas_fits",
-                   "kq_tas_read_usage", "kq_tas_last_stats", "kq_tas_last_error"]
+                   "kq_tas_read_usage", "kq_tas_last_stats", "kq_tas_last_error",
+                   "kq_tas_admit", "kq_tas_usage_delta", "kq_tas_usage_add", "kq_tas_overflow"]
 
 
 class TASEngine:
@@ -343,6 +404,34 @@ class TASEngine:
         u = np.zeros(self.topo.n_leaves * len(self.topo.resources), np.int64)
         self._check(self._lib.kq_tas_read_usage(self._h, F.ptr(u)))
         return u
+
+    def admit(self, rq: Requests, res: "Result", order: Optional[np.ndarray] = None) -> np.ndarray:
+        """kq_tas_admit: entry-order walk (Fits, then AddUsage) over the batch -> admitted [n_workloads] uint8."""
+        nw = len(rq.arrays["wl_off"]) - 1
+        adm = np.zeros(max(nw, 1), np.uint8); na = np.zeros(1, np.int32)
+        o = None if order is None else np.ascontiguousarray(order, np.int32)
+        self._check(self._lib.kq_tas_admit(self._h, C.byref(rq.struct()), C.byref(res.struct()), F.ptr(o) if o is not None else None,
+                                           0 if o is None else len(o), F.ptr(adm), F.ptr(na)))
+        ms = np.zeros(1, np.float64)
+        self._lib.kq_tas_last_stats(self._h, F.ptr(ms), None)
+        self.last_admit_ms = float(ms[0])
+        return adm[:nw]
+
+    def usage_delta(self, rq: Requests, res: "Result", plane_ptr: int, wl_sel: Optional[np.ndarray] = None):
+        """kq_tas_usage_delta: Usage.TAS of the placed (and selected) workloads summed into the caller's device plane."""
+        sel = None if wl_sel is None else np.ascontiguousarray(wl_sel, np.uint8)
+        self._check(self._lib.kq_tas_usage_delta(self._h, C.byref(rq.struct()), C.byref(res.struct()), F.ptr(sel) if sel is not None else None,
+                                                 C.c_void_p(plane_ptr)))
+
+    def usage_add(self, plane_ptr: int, sign: int = 1):
+        self._check(self._lib.kq_tas_usage_add(self._h, C.c_void_p(plane_ptr), sign))
+
+    def overflow(self, plane_ptr: Optional[int]) -> np.ndarray:
+        """kq_tas_overflow -> leaf_over [n_leaves] uint8 (tas_usage + plane > free_capacity in some resource)."""
+        over = np.zeros(self.topo.n_leaves, np.uint8); n = np.zeros(1, np.int32)
+        self._check(self._lib.kq_tas_overflow(self._h, C.c_void_p(plane_ptr) if plane_ptr else None, F.ptr(over), F.ptr(n)))
+        assert int(n[0]) == int(over.sum())
+        return over
 
     def close(self):
         if self._h:

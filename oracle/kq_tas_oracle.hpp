@@ -19,6 +19,7 @@ struct PodSetResult {  // tasPodSetAssignmentResult :424
   int status = KQ_TAS_OK;
   int32_t a = 0, b = 0;
   Assignment domains;
+  std::vector<int32_t> layerFit;  // KQ_TAS_NOT_FIT_LAYERS: fit slices per layer of the constraint list
 };
 
 Snapshot* snapshot_new(const kq_tas_topology* t);

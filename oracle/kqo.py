@@ -250,6 +250,20 @@ def cycle_run_tas(cfg: F.kq_config, snap: Snapshot, heads: Heads, ct, tgt_cap=No
     return d, out
 
 
+def tas_admit(topo, rq, res, order=None):
+    """Entry-order admission of a batch's TopologyAssignments (oracle/kq_tas_oracle.cpp kqo_tas_admit) -> (admitted, usage_after)."""
+    nw = len(rq.arrays["wl_off"]) - 1
+    adm = np.zeros(max(nw, 1), np.uint8)
+    usage = np.zeros(topo.n_leaves * len(topo.resources), np.int64)
+    o = None if order is None else np.ascontiguousarray(order, np.int32)
+    l = lib()
+    l.kqo_tas_admit.restype = C.c_int
+    rc = l.kqo_tas_admit(C.byref(topo.struct()), C.byref(rq.struct()), C.byref(res.struct()), F.ptr(o) if o is not None else None,
+                         C.c_int32(0 if o is None else len(o)), F.ptr(adm), F.ptr(usage))
+    assert rc == 0, rc
+    return adm[:nw], usage
+
+
 def tas_fits(topo, assignment, single_pod_requests) -> bool:
     leaf = np.array([a for a, _ in assignment], np.int32); cnt = np.array([c for _, c in assignment], np.int32)
     req = np.ascontiguousarray(single_pod_requests, np.int64)

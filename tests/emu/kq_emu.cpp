@@ -37,6 +37,12 @@ struct EmuBackend {
       for (int i = slot * per; i < (slot + 1) * per && i < k.Q.n_wl; i++) t_workload(k, slot, k.C.order[i]);
   }
   void launch_tas_usage(const TTopo& T, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int add) { for (int i = 0; i < n; i++) t_usage_cell(T, i, leaf, count, spr, add); }
+  void launch_tas_admit(const TTopo& T, const TAdmit& A) { t_admit_seq(T, A); }
+  void launch_tas_delta(const TTopo& T, int n, const uint8_t* sel, const int32_t* dom_off, const int32_t* dom_leaf, const int32_t* dom_count, const int64_t* spr, int64_t* plane) {
+    for (int p = 0; p < n; p++) t_delta_cell(T, p, sel, dom_off, dom_leaf, dom_count, spr, plane);
+  }
+  void launch_tas_plane_add(const TTopo& T, const int64_t* plane, int sign) { for (size_t i = 0; i < (size_t)T.n_leaves * T.R; i++) t_plane_add_cell(T, i, plane, sign); }
+  void launch_tas_overflow(const TTopo& T, const int64_t* plane, uint8_t* over, int32_t* n_over) { for (int l = 0; l < T.n_leaves; l++) t_overflow_cell(T, l, plane, over, n_over); }
   void launch_tas_fits(const TTopo& T, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t* flag) { for (int i = 0; i < n; i++) t_fits_cell(T, i, leaf, count, spr, flag); }
   K last_k{};
   void launch_commit_mask(int n, int32_t* use_n_out, int32_t* cq_out, int32_t* fr_out, int64_t* qty_out, int32_t* count) {
@@ -163,6 +169,10 @@ int kqe_tas_find(void* t, const kq_tas_requests* r, kq_tas_result* out) { return
 void kqe_tas_use_classes(void* t, int on) { ((EmuTas*)t)->use_classes = on != 0; }
 int kqe_tas_usage_apply(void* t, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int add) { return ((EmuTas*)t)->usage_apply(n, leaf, count, spr, add); }
 int kqe_tas_fits(void* t, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t* fits) { return ((EmuTas*)t)->fits(n, leaf, count, spr, fits); }
+int kqe_tas_admit(void* t, const kq_tas_requests* r, const kq_tas_result* res, const int32_t* order, int32_t n_order, uint8_t* admitted, int32_t* n_admitted) { return ((EmuTas*)t)->admit(r, res, order, n_order, admitted, n_admitted); }
+int kqe_tas_usage_delta(void* t, const kq_tas_requests* r, const kq_tas_result* res, const uint8_t* wl_sel, int64_t* plane) { return ((EmuTas*)t)->usage_delta(r, res, wl_sel, plane); }
+int kqe_tas_usage_add(void* t, const int64_t* plane, int32_t sign) { return ((EmuTas*)t)->usage_add(plane, sign); }
+int kqe_tas_overflow(void* t, const int64_t* plane, uint8_t* leaf_over, int32_t* n_over) { return ((EmuTas*)t)->overflow(plane, leaf_over, n_over); }
 int kqe_tas_read_usage(void* t, int64_t* u) { return ((EmuTas*)t)->read_usage(u); }
 int64_t kqe_tas_last_bytes(void* t) { return ((EmuTas*)t)->last_bytes; }
 const char* kqe_tas_last_error(void* t) { return ((EmuTas*)t)->last_error.c_str(); }

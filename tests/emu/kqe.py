@@ -210,6 +210,30 @@ class EmuTas:
         assert lib().kqe_tas_read_usage(self.h, F.ptr(u)) == 0
         return u
 
+    def admit(self, rq, res, order=None):
+        nw = len(rq.arrays["wl_off"]) - 1
+        adm = np.zeros(max(nw, 1), np.uint8); na = np.zeros(1, np.int32)
+        o = None if order is None else np.ascontiguousarray(order, np.int32)
+        rc = lib().kqe_tas_admit(self.h, C.byref(rq.struct()), C.byref(res.struct()), F.ptr(o) if o is not None else None,
+                                 C.c_int32(0 if o is None else len(o)), F.ptr(adm), F.ptr(na))
+        assert rc == 0, (rc, lib().kqe_tas_last_error(self.h))
+        assert int(na[0]) == int(adm[:nw].sum())
+        return adm[:nw]
+
+    def usage_delta(self, rq, res, plane_ptr, wl_sel=None):
+        sel = None if wl_sel is None else np.ascontiguousarray(wl_sel, np.uint8)
+        rc = lib().kqe_tas_usage_delta(self.h, C.byref(rq.struct()), C.byref(res.struct()), F.ptr(sel) if sel is not None else None, C.c_void_p(plane_ptr))
+        assert rc == 0, (rc, lib().kqe_tas_last_error(self.h))
+
+    def usage_add(self, plane_ptr, sign=1):
+        assert lib().kqe_tas_usage_add(self.h, C.c_void_p(plane_ptr), C.c_int32(sign)) == 0
+
+    def overflow(self, plane_ptr):
+        over = np.zeros(self.topo.n_leaves, np.uint8); n = np.zeros(1, np.int32)
+        assert lib().kqe_tas_overflow(self.h, C.c_void_p(plane_ptr) if plane_ptr else None, F.ptr(over), F.ptr(n)) == 0
+        assert int(n[0]) == int(over.sum())
+        return over
+
     def close(self):
         if self.h:
             lib().kqe_tas_destroy(self.h)
