@@ -36,9 +36,11 @@ struct TReq {
   const uint8_t* kind;
   const int32_t *slice_size, *slice_level, *group;
   const uint8_t* leaf_ok;
+  const int32_t *n_layers, *layer_level, *layer_size;  // TASMultiLayerTopology: NULL = single layer everywhere
 };
 struct TOut {
   int32_t *status, *op_a, *op_b, *dom_pos, *dom_n;  // per podset request; dom_pos = offset into the pool
+  int32_t* layer_fit;  // [n][KQ_TAS_MAX_LEVELS] or NULL
   int32_t *pool_leaf, *pool_count;
   int32_t pool_cap;
   int32_t* pool_used;  // [1] atomic
@@ -99,6 +101,10 @@ struct TParams {  // topologyAssignmentParameters :473 + requirements :461
   const int64_t* req;        // [R] SinglePodRequests of the workers (pods added on the fly)
   const int64_t* leaderReq;  // [R] or NULL
   const uint8_t* leafOk;
+  // TASMultiLayerTopology: sliceSizeAtLevel :474 (0 = no entry), the constraint list for multiLayerNotFitMessage :2030
+  int32_t sizeAt[KQ_TAS_MAX_LEVELS + 1];
+  int nLayers;                // len(multiLayerConstraints) :482, 0 unless sliceSizeAtLevel has an entry
+  const int32_t *layerLevel, *layerSize;
 };
 
 KQ_DEV bool t_lfc(const TK& k, bool unconstrained) { return unconstrained && k.T.profile_mixed; }  // useLeastFreeCapacityAlgorithm :1468
@@ -156,8 +162,11 @@ KQ_DEV void t_fill_in_counts(const TK& k, const TState& s, const TParams& p, lon
       int32_t childrenCapacity = 0, sliceCapacity = 0, minPodDiff = 0x7fffffff, minSliceDiff = 0x7fffffff, leaderCount = 0;
       bool contributor = false;
       const int c0 = T.child_first[d], cn = T.child_cnt[d];
+      const int32_t innerSize = p.sizeAt[level + 1];  // a child at a constrained level only contributes whole inner slices (:1950-1967)
       for (int c = c0; c < c0 + cn; c++) {
-        const int32_t cpc = s.pc[c], cpcwl = s.pcwl[c], csc = s.sc[c], cscwl = s.scwl[c], clc = s.lc[c];
+        int32_t cpc = s.pc[c], cpcwl = s.pcwl[c];
+        const int32_t csc = s.sc[c], cscwl = s.scwl[c], clc = s.lc[c];
+        if (innerSize > 0) { cpc = (cpc / innerSize) * innerSize; cpcwl = (cpcwl / innerSize) * innerSize; }
         childrenCapacity += cpc;
         sliceCapacity += csc;
         if (!leaderRequired || clc > 0) {
@@ -398,8 +407,15 @@ KQ_DEV bool t_consume_with_leaders(const TK& k, const TState& s, TView& v, int i
 // updateCountsToMinimumGeneric :1575 over the slice s.set[0..n) in `order`; result domains appended to out[out_n..)
 // returns the new length of out, -1 on the reference's "unexpected remainingCount" path
 KQ_DEV int t_update_counts(const TK& k, const TState& s, int n, int order, int32_t count, int32_t leaderCount, int32_t sliceSize,
-                           bool unconstrained, bool slices, int32_t* out, int out_n) {
+                           bool unconstrained, bool slices, int32_t* out, int out_n, int32_t recompute = 0) {
   TView v = t_view(k, s, n, order, unconstrained);
+  if (recompute > 1) {
+    // an inner slice layer (:1060-1070): the children were sorted with the slice counts phase 1 left (the keys above), only then
+    // are the counts recomputed for this layer's size
+    for (int i = lane_id(); i < n; i += WAVE) { const int d = s.set[i]; s.sc[d] = s.pc[d] / recompute; s.scwl[d] = s.pcwl[d] / recompute; }
+    if (lane_id() == 0) s.meta[1] = 1;
+    wsync();
+  }
   t_prioritize_leader(k, s, v, count, leaderCount, sliceSize, slices);
   int32_t remainingPrimary = slices ? count / sliceSize : count;
   int32_t remainingLeaderCount = leaderCount;
@@ -485,6 +501,7 @@ KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* 
   const int32_t sliceCount = st.count / st.sliceSize;
   const bool lfc = t_lfc(k, st.unconstrained);
   for (int searchLevelIdx = st.requestedLevelIdx;; searchLevelIdx--) {
+    *fitLevel = searchLevelIdx;  // also the level a KQ_TAS_NOT_FIT below refers to (notFitReason :1354)
     const int n = T.level_off[searchLevelIdx + 1] - T.level_off[searchLevelIdx];
     if (n == 0) return TFail{KQ_TAS_NO_LEVEL, 0, 0};
     for (int i = lane_id(); i < n; i += WAVE) s.set[i] = T.level_off[searchLevelIdx] + i;
@@ -620,6 +637,34 @@ KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* 
   }
 }
 
+// multiLayerNotFitMessage :2030 as operands: a = the domain of the failing level with the most slices (ties: the lower canonical
+// index = the lower domain id), b = that level; lf[i] = countSlicesInSubtree :2019 of that domain for layer i. Domains are numbered in
+// canonical order with contiguous children, so the descendants of a domain on a lower level are one index range.
+KQ_DEV TFail t_not_fit_layers(const TK& k, const TState& s, const TParams& st, int lvl, int32_t* lf0, int32_t* lf1) {
+  const TTopo& T = k.T;
+  const int lane = lane_id();
+  const int b0 = T.level_off[lvl], n = T.level_off[lvl + 1] - b0;
+  uint64_t key = ~0ull;
+  for (int i = lane; i < n; i += WAVE) {
+    const uint64_t kk = ((uint64_t)(uint32_t)(0x7fffffff - s.sc[b0 + i]) << 32) | (uint32_t)i;
+    if (kk < key) key = kk;
+  }
+  key = wmin_u64(key);
+  const int best = n > 0 ? (int)(uint32_t)(key & 0xffffffffu) : -1;
+  for (int i = 0; i < KQ_TAS_MAX_LEVELS; i++) {
+    int32_t fit = 0;
+    if (best >= 0 && i < st.nLayers && st.layerLevel[i] >= lvl) {
+      int lo = b0 + best, hi = lo + 1;
+      for (int l = lvl; l < st.layerLevel[i]; l++) { const int nlo = T.child_first[lo], nhi = T.child_first[hi - 1] + T.child_cnt[hi - 1]; lo = nlo; hi = nhi; }
+      int64_t part = 0;
+      for (int d = lo + lane; d < hi; d += WAVE) part += s.pc[d] / st.layerSize[i];
+      fit = (int32_t)wsum_i64(part);
+    }
+    if (lane == 0) { if (lf0) lf0[i] = fit; if (lf1) lf1[i] = fit; }
+  }
+  return TFail{KQ_TAS_NOT_FIT_LAYERS, best, lvl};
+}
+
 // findTopologyAssignment :886. On success the leaves of the assignment are in s.cur[0..*nfit) with their pod / leader
 // counts in s.pc / s.lc.
 KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, int* nfit, bool have_counts) {
@@ -627,6 +672,7 @@ KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, 
   if (!have_counts) t_fill_in_counts(k, s, st, k.O.bytes);
   int fitLevelIdx = 0, ncur = 0;
   TFail f = t_find_level(k, s, st, &fitLevelIdx, &ncur);
+  if (f.status == KQ_TAS_NOT_FIT && st.nLayers > 0) { *nfit = fitLevelIdx; return f; }  // the caller turns it into the per-layer form
   if (f.status != KQ_TAS_OK) return f;
   // phase 2b :1041 — currFitDomain in the order findLevelWithFitDomains built it
   for (int i = lane_id(); i < ncur; i += WAVE) s.set[i] = s.cur[i];
@@ -654,17 +700,15 @@ KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, 
     ncur = nout;
   }
   for (; level < T.L - 1; level++) {
-    const int32_t sliceSizeOnLevel = level >= st.sliceLevelIdx ? 1 : st.sliceSize;
+    int32_t sliceSizeOnLevel = st.sliceSize;
+    if (level >= st.sliceLevelIdx) sliceSizeOnLevel = st.sizeAt[level + 1] > 0 ? st.sizeAt[level + 1] : 1;  // :1049-1057
     nout = 0;
     for (int j = 0; j < ncur; j++) {
       const int d = s.cur[j], c0 = T.child_first[d], cn = T.child_cnt[d];
-      for (int i = lane_id(); i < cn; i += WAVE) {
-        s.set[i] = c0 + i;
-        if (sliceSizeOnLevel > 1) { s.sc[c0 + i] = s.pc[c0 + i] / sliceSizeOnLevel; s.scwl[c0 + i] = s.pcwl[c0 + i] / sliceSizeOnLevel; s.meta[1] = 1; }
-      }
+      for (int i = lane_id(); i < cn; i += WAVE) s.set[i] = c0 + i;
       wsync();
       const int32_t dpc = s.pc[d], dlc = s.lc[d];
-      nout = t_update_counts(k, s, cn, ORD_PLAIN, dpc, dlc, sliceSizeOnLevel, st.unconstrained, sliceSizeOnLevel > 1, s.nxt, nout);
+      nout = t_update_counts(k, s, cn, ORD_PLAIN, dpc, dlc, sliceSizeOnLevel, st.unconstrained, sliceSizeOnLevel > 1, s.nxt, nout, sliceSizeOnLevel);
       if (nout < 0) { *nfit = 0; return TFail{KQ_TAS_OK, 0, 0}; }
     }
     for (int i = lane_id(); i < nout; i += WAVE) s.cur[i] = s.nxt[i];
@@ -753,12 +797,30 @@ KQ_DEV void t_workload(const TK& k, int slot, int w) {
     st.simulateEmpty = Q.sim_empty && Q.sim_empty[w]; st.hasLeader = leader >= 0; st.hasAssumed = hasAssumed;
     st.req = Q.spr + (size_t)workers * T.R; st.leaderReq = leader >= 0 ? Q.spr + (size_t)leader * T.R : nullptr;
     st.leafOk = Q.leaf_ok ? Q.leaf_ok + (size_t)workers * T.n_leaves : nullptr;
+    for (int l = 0; l <= KQ_TAS_MAX_LEVELS; l++) st.sizeAt[l] = 0;
+    st.nLayers = 0; st.layerLevel = nullptr; st.layerSize = nullptr;
     TFail f{KQ_TAS_OK, 0, 0};
     int ncur = 0;
     if (st.sliceSize <= 0) f = TFail{KQ_TAS_BAD_SLICE_SIZE, 0, 0};
     else if (st.requestedLevelIdx < 0 || st.requestedLevelIdx >= T.L || st.sliceLevelIdx < 0 || st.sliceLevelIdx >= T.L) f = TFail{KQ_TAS_NO_LEVEL, 0, 0};
     else if (st.requestedLevelIdx > st.sliceLevelIdx) f = TFail{KQ_TAS_SLICE_ABOVE, 0, 0};
     else {
+      // buildSliceSizeAtLevel :1123 over the inner layers (layer 0 is sliceSize / sliceLevelIdx)
+      const int nl = Q.n_layers ? Q.n_layers[workers] : 0;
+      if (nl > 1) {
+        const int32_t* ll = Q.layer_level + (size_t)workers * KQ_TAS_MAX_LEVELS;
+        const int32_t* ls = Q.layer_size + (size_t)workers * KQ_TAS_MAX_LEVELS;
+        int32_t prevSize = st.sliceSize; int prevLevel = st.sliceLevelIdx;
+        for (int i = 1; i < nl && i < KQ_TAS_MAX_LEVELS && f.status == KQ_TAS_OK; i++) {
+          if (ll[i] < 0 || ll[i] >= T.L) f = TFail{KQ_TAS_BAD_LAYER, i, 0};
+          else if (ll[i] <= prevLevel) f = TFail{KQ_TAS_BAD_LAYER, i, 1};
+          else if (ls[i] <= 0 || prevSize % ls[i] != 0) f = TFail{KQ_TAS_BAD_LAYER, i, 2};
+          else { for (int l = prevLevel + 1; l <= ll[i]; l++) st.sizeAt[l] = ls[i]; prevSize = ls[i]; prevLevel = ll[i]; }
+        }
+        if (f.status == KQ_TAS_OK) { st.nLayers = nl < KQ_TAS_MAX_LEVELS ? nl : KQ_TAS_MAX_LEVELS; st.layerLevel = ll; st.layerSize = ls; }
+      }
+    }
+    if (f.status == KQ_TAS_OK) {
       const int cls = k.C.n > 0 ? k.C.wl_class[w] : -1;
       bool have = false;
       if (cls >= 0) {
@@ -778,6 +840,9 @@ KQ_DEV void t_workload(const TK& k, int slot, int w) {
         s.meta[2] = -1;
       }
       f = t_find_assignment(k, s, st, &ncur, have);
+      if (f.status == KQ_TAS_NOT_FIT && st.nLayers > 0)
+        f = t_not_fit_layers(k, s, st, ncur, O.layer_fit ? O.layer_fit + (size_t)workers * KQ_TAS_MAX_LEVELS : nullptr,
+                             O.layer_fit && leader >= 0 ? O.layer_fit + (size_t)leader * KQ_TAS_MAX_LEVELS : nullptr);
     }
     if (f.status != KQ_TAS_OK) { set_all(f.status, f.a, f.b); failed = true; continue; }
     if (lane == 0) { O.status[workers] = KQ_TAS_OK; O.op_a[workers] = 0; O.op_b[workers] = 0; if (leader >= 0) { O.status[leader] = KQ_TAS_OK; O.op_a[leader] = 0; O.op_b[leader] = 0; } }

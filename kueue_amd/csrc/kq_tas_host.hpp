@@ -32,7 +32,7 @@ template <class Backend> struct TasT {
   TTopo T{};
   std::vector<void*> topo_allocs;
   struct Buf { void* p = nullptr; size_t cap = 0; };
-  Buf bq[12], bo[8], bx[15], bc[12];
+  Buf bq[16], bo[8], bx[15], bc[12];
   bool use_classes = true;  // tests can switch the shared phase 1 off
   double last_ms = 0;
   int64_t last_bytes = 0;
@@ -125,6 +125,18 @@ template <class Backend> struct TasT {
     Q.count = stage(bq[3], r->count, n); Q.level = stage(bq[4], r->level, n); Q.kind = stage(bq[5], r->kind, n);
     Q.slice_size = stage(bq[6], r->slice_size, n); Q.slice_level = stage(bq[7], r->slice_level, n); Q.group = stage(bq[8], r->group, n);
     Q.leaf_ok = r->leaf_ok ? stage(bq[9], r->leaf_ok, (size_t)n * T.n_leaves) : nullptr;
+    // TASMultiLayerTopology: staged only when some podset carries more than one layer
+    bool layered = false;
+    if (r->n_layers) {
+      for (int i = 0; i < n; i++) {
+        if (r->n_layers[i] < 0 || r->n_layers[i] > KQ_TAS_MAX_LEVELS) return fail(KQ_EUNSUPPORTED, "n_layers out of range");
+        if (r->n_layers[i] > 1) layered = true;
+      }
+      if (layered && (!r->layer_level || !r->layer_size)) return fail(KQ_EINVAL, "n_layers without layer_level / layer_size");
+    }
+    Q.n_layers = layered ? stage(bq[12], r->n_layers, n) : nullptr;
+    Q.layer_level = layered ? stage(bq[13], r->layer_level, (size_t)n * KQ_TAS_MAX_LEVELS) : nullptr;
+    Q.layer_size = layered ? stage(bq[14], r->layer_size, (size_t)n * KQ_TAS_MAX_LEVELS) : nullptr;
     TOut& O = k.O;
     // [status | op_a | op_b | dom_pos | dom_n] in one region -> one D2H
     int32_t* pack = grow<int32_t>(bo[0], (size_t)n * 5);
@@ -135,6 +147,11 @@ template <class Backend> struct TasT {
     be.memset(misc, 0, 4 * sizeof(int64_t));
     be.memset(pack, 0, (size_t)n * 5 * sizeof(int32_t));
     O.pool_used = (int32_t*)misc; O.error = (int32_t*)misc + 1; O.bytes = (long long*)(misc + 1);
+    O.layer_fit = nullptr;
+    if (layered && out->layer_fit) {
+      O.layer_fit = grow<int32_t>(bo[4], (size_t)n * KQ_TAS_MAX_LEVELS);
+      be.memset(O.layer_fit, 0, (size_t)n * KQ_TAS_MAX_LEVELS * sizeof(int32_t));
+    }
     const int slots = std::min(nw, be.max_slots());
     TScratch& X = k.X;
     X.max_set = (std::max(T.n_leaves, T.D - T.n_leaves + 1) + 1 + 15) & ~15;  // per-slot lists start 64-byte aligned (s.nxt doubles as int64 bins)
@@ -158,6 +175,7 @@ template <class Backend> struct TasT {
         if (p1 - p0 == 2 && (r->group[p0] < 0 || r->group[p0] != r->group[p0 + 1])) continue;
         int workers = p0, leader = -1;
         if (p1 - p0 == 2) { leader = p0 + 1; if (r->count[leader] > r->count[workers]) { leader = p0; workers = p0 + 1; } }
+        if (layered && r->n_layers[workers] > 1) continue;  // inner layers change the roll-up: private phase 1
         std::string key((const char*)(r->single_pod_requests + (size_t)workers * T.R), (size_t)T.R * 8);
         if (leader >= 0) key.append((const char*)(r->single_pod_requests + (size_t)leader * T.R), (size_t)T.R * 8); else key.append("-");
         const int32_t tail[3] = {r->slice_size[workers], r->slice_level[workers], r->simulate_empty ? (int32_t)r->simulate_empty[w] : 0};
@@ -195,6 +213,10 @@ template <class Backend> struct TasT {
     int64_t hm[4];
     be.d2h(hp.data(), pack, hp.size() * sizeof(int32_t));
     be.d2h(hm, misc, sizeof(hm));
+    if (out->layer_fit) {
+      if (O.layer_fit) be.d2h(out->layer_fit, O.layer_fit, (size_t)n * KQ_TAS_MAX_LEVELS * sizeof(int32_t));
+      else std::memset(out->layer_fit, 0, (size_t)n * KQ_TAS_MAX_LEVELS * sizeof(int32_t));
+    }
     int rc = be.sync();
     if (rc != KQ_OK) return fail(rc, be.error());
     last_ms = be.timer_ms(0, 1);

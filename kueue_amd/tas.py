@@ -20,7 +20,8 @@ from .api import amount_from_quantity
 HOSTNAME_LABEL = "kubernetes.io/hostname"
 
 KQ_TAS_REQUIRED, KQ_TAS_PREFERRED, KQ_TAS_UNCONSTRAINED = 0, 1, 2
-TAS_OK, TAS_NOT_FIT, TAS_NO_LEVEL, TAS_SLICE_ABOVE, TAS_BAD_SLICE_SIZE, TAS_SKIPPED, TAS_UNSUPPORTED = range(7)
+TAS_OK, TAS_NOT_FIT, TAS_NO_LEVEL, TAS_SLICE_ABOVE, TAS_BAD_SLICE_SIZE, TAS_SKIPPED, TAS_UNSUPPORTED, TAS_NOT_FIT_LAYERS, TAS_BAD_LAYER = range(9)
+TAS_MAX_LEVELS = 8
 
 
 class kq_tas_topology(C.Structure):
@@ -37,6 +38,7 @@ class kq_tas_requests(C.Structure):
         ("wl_off", F.i32p), ("simulate_empty", F.u8p),
         ("single_pod_requests", F.i64p), ("count", F.i32p), ("level", F.i32p), ("kind", F.u8p),
         ("slice_size", F.i32p), ("slice_level", F.i32p), ("group", F.i32p), ("leaf_ok", F.u8p),
+        ("n_layers", F.i32p), ("layer_level", F.i32p), ("layer_size", F.i32p),   # TASMultiLayerTopology, NULL = single layer
     ]
 
 
@@ -44,6 +46,7 @@ class kq_tas_result(C.Structure):
     _fields_ = [
         ("status", F.i32p), ("operand_a", F.i32p), ("operand_b", F.i32p),
         ("dom_off", F.i32p), ("dom_leaf", F.i32p), ("dom_count", F.i32p), ("dom_cap", C.c_int32),
+        ("layer_fit", F.i32p),                                                   # optional, NULL = not wanted
     ]
 
 
@@ -65,6 +68,16 @@ class TopologyRequest:
     unconstrained: bool = False
     slice_required_topology: Optional[str] = None
     slice_size: Optional[int] = None
+    # PodsetSliceRequiredTopologyConstraints (TASMultiLayerTopology): [(topology key, size)], outermost first; when set it replaces
+    # the two fields above (utiltas.PodSetSliceRequiredTopologyConstraints pkg/util/tas/tas.go:141)
+    slice_constraints: Optional[Sequence[Tuple[str, int]]] = None
+
+    def constraints(self) -> List[Tuple[str, int]]:
+        if self.slice_constraints:
+            return [(k, int(v)) for k, v in self.slice_constraints]
+        if self.slice_required_topology is None:
+            return []
+        return [(self.slice_required_topology, int(self.slice_size) if self.slice_size is not None else 0)]
 
 
 @dataclass
@@ -132,7 +145,8 @@ class Topology:
         t = tr.topology_request
         implied = t is None
         key = None
-        slices = t is not None and t.slice_required_topology is not None
+        cons = t.constraints() if t is not None else []
+        slices = len(cons) > 0
         if t is not None:
             if t.required is not None:
                 key = t.required
@@ -154,10 +168,15 @@ class Topology:
         slice_size = 1
         slice_key = self.levels[-1]
         if slices:
-            slice_size = t.slice_size if t.slice_size is not None else 0
-            slice_key = t.slice_required_topology
+            slice_key, slice_size = cons[0]
         slice_level = self.levels.index(slice_key) if slice_key in self.levels else -1
         return level, kind, slice_size, slice_level
+
+    def resolve_layers(self, tr: TASPodSetRequests) -> List[Tuple[int, int]]:
+        """All layers of the podset's slice constraints as (level index or -1, size); layer 0 repeats resolve()'s slice fields."""
+        t = tr.topology_request
+        cons = t.constraints() if t is not None else []
+        return [(self.levels.index(k) if k in self.levels else -1, v) for k, v in cons]
 
     def set_tas_usage(self, usage_by_leaf: Dict[int, Dict[str, int]]):
         u = self.arrays["tas_usage"].reshape(self.n_leaves, len(self.resources))
@@ -218,6 +237,17 @@ class Requests:
                 i += 1
         self.arrays = dict(wl_off=wl_off, single_pod_requests=req.reshape(-1).copy(), count=count, level=level, kind=kind,
                            slice_size=ssize, slice_level=slevel, group=group)
+        layers = [topo.resolve_layers(tr) for tr in flat]
+        self.layer_keys = [[k for k, _ in (tr.topology_request.constraints() if tr.topology_request is not None else [])] for tr in flat]
+        if any(len(l) > 1 for l in layers):
+            nl = np.zeros(n, np.int32); ll = np.full((n, TAS_MAX_LEVELS), -1, np.int32); ls = np.zeros((n, TAS_MAX_LEVELS), np.int32)
+            for i, l in enumerate(layers):
+                if len(l) > TAS_MAX_LEVELS:
+                    raise ValueError("more slice layers than topology levels the ABI carries")
+                nl[i] = len(l)
+                for j, (lv, sz) in enumerate(l):
+                    ll[i, j] = lv; ls[i, j] = sz
+            self.arrays.update(n_layers=nl, layer_level=ll.reshape(-1).copy(), layer_size=ls.reshape(-1).copy())
         if simulate_empty is not None:
             self.arrays["simulate_empty"] = np.asarray(simulate_empty, np.uint8)
         if leaf_ok is not None:
@@ -248,6 +278,7 @@ class Requests:
         sub = Requests.__new__(Requests)
         sub.topo = self.topo
         sub.workloads = None
+        sub.layer_keys = None
         ps = self.ps_index(wl_idx)
         R = len(self.topo.resources)
         off = self.arrays["wl_off"]
@@ -258,6 +289,10 @@ class Requests:
             a[k] = self.arrays[k][ps].copy()
         if "simulate_empty" in self.arrays:
             a["simulate_empty"] = self.arrays["simulate_empty"][wl_idx].copy()
+        if "n_layers" in self.arrays:
+            a["n_layers"] = self.arrays["n_layers"][ps].copy()
+            for k in ("layer_level", "layer_size"):
+                a[k] = self.arrays[k].reshape(-1, TAS_MAX_LEVELS)[ps].reshape(-1).copy()
         if "leaf_ok" in self.arrays:
             a["leaf_ok"] = self.arrays["leaf_ok"].reshape(-1, self.topo.n_leaves)[ps].reshape(-1).copy()
         sub.arrays = a
@@ -272,7 +307,8 @@ class Result:
         n = rq.n
         cap = dom_cap if dom_cap is not None else max(64, int(rq.arrays["count"].sum()) + n)
         self.a = dict(status=np.zeros(n, np.int32), operand_a=np.zeros(n, np.int32), operand_b=np.zeros(n, np.int32),
-                      dom_off=np.zeros(n + 1, np.int32), dom_leaf=np.zeros(cap, np.int32), dom_count=np.zeros(cap, np.int32))
+                      dom_off=np.zeros(n + 1, np.int32), dom_leaf=np.zeros(cap, np.int32), dom_count=np.zeros(cap, np.int32),
+                      layer_fit=np.zeros(n * TAS_MAX_LEVELS, np.int32))
         self._struct = kq_tas_result()
         F.fill_struct(self._struct, self.a, dict(dom_cap=cap))
 
@@ -293,6 +329,8 @@ class Result:
             ps = rq.ps_index(np.asarray(wl_idx, np.int64))
             for k in ("status", "operand_a", "operand_b"):
                 out.a[k][ps] = a[k]
+            if "layer_fit" in a:
+                out.a["layer_fit"].reshape(-1, TAS_MAX_LEVELS)[ps] = a["layer_fit"].reshape(-1, TAS_MAX_LEVELS)
             cnt = np.diff(a["dom_off"]).astype(np.int64)
             tot = int(cnt.sum())
             if tot:
@@ -306,7 +344,7 @@ class Result:
 
     def equal(self, other: "Result") -> List[str]:
         bad = []
-        for k in ("status", "operand_a", "operand_b", "dom_off"):
+        for k in ("status", "operand_a", "operand_b", "dom_off", "layer_fit"):
             if not np.array_equal(self.a[k], other.a[k]):
                 bad.append(k)
         nd = int(self.a["dom_off"][-1])
@@ -315,6 +353,11 @@ class Result:
                 if not np.array_equal(self.a[k][:nd], other.a[k][:nd]):
                     bad.append(k)
         return bad
+
+    def _prev_level_key(self, i: int, layer: int) -> str:
+        # the previous layer that was accepted: its resolved level (layer 0 is the slice level)
+        lv = int(self.rq.arrays["layer_level"][i * TAS_MAX_LEVELS + layer - 1]) if layer > 1 else int(self.rq.arrays["slice_level"][i])
+        return self.rq.topo.levels[lv]
 
     def message(self, i: int, topology_name: str = "default") -> str:
         """Failure reason as the reference words it (notFitMessage :1997, findTopologyAssignment :886-947)."""
@@ -326,6 +369,28 @@ class Result:
             if a == 0:
                 return f'topology "{topology_name}" doesn\'t allow to fit any of {b} {unit}(s)'
             return f'topology "{topology_name}" allows to fit only {a} out of {b} {unit}(s)'
+        if st == TAS_NOT_FIT_LAYERS:
+            # multiLayerNotFitMessage :2030: "; fit/needed slice(s) fit on level <key>" per constraint, counted in the best domain
+            msg = f'topology "{topology_name}" doesn\'t allow to fit'
+            if a < 0:
+                return msg
+            nl = int(self.rq.arrays["n_layers"][i])
+            cnt = int(self.rq.arrays["count"][i])
+            for j in range(nl):
+                lv = int(self.rq.arrays["layer_level"][i * TAS_MAX_LEVELS + j]); sz = int(self.rq.arrays["layer_size"][i * TAS_MAX_LEVELS + j])
+                if lv < 0:
+                    continue
+                msg += f"; {int(self.a['layer_fit'][i * TAS_MAX_LEVELS + j])}/{cnt // sz} slice(s) fit on level {self.rq.topo.levels[lv]}"
+            return msg
+        if st == TAS_BAD_LAYER:
+            # buildSliceSizeAtLevel :1123
+            key = lambda j: (self.rq.layer_keys[i][j] if getattr(self.rq, "layer_keys", None) else f"#{j}")
+            sz = lambda j: int(self.rq.arrays["layer_size"][i * TAS_MAX_LEVELS + j])
+            if b == 0:
+                return f"no requested topology level for additional slice layer: {key(a)}"
+            if b == 1:
+                return f"additional slice layer topology {key(a)} must be at a lower level than {self._prev_level_key(i, a)}"
+            return f"additional slice layer size {sz(a)} must evenly divide parent layer size {sz(a - 1)}"
         return {TAS_NO_LEVEL: "no requested topology level", TAS_SLICE_ABOVE: "podset slice topology is above the podset topology",
                 TAS_BAD_SLICE_SIZE: "slice topology requested, but slice size not provided", TAS_SKIPPED: "",
                 TAS_UNSUPPORTED: "unsupported on the device path"}[st]

@@ -21,7 +21,10 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    subprocess.check_call(["make", "-C", HERE, "-s"] + (["-B"] if force else []))  # a no-op when nothing changed
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lk:          # xdist workers must not rebuild the library side by side
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-C", HERE, "-s"] + (["-B"] if force else []))  # a no-op when nothing changed
     return LIB
 
 

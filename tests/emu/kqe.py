@@ -16,7 +16,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        subprocess.check_call(["make", "-C", HERE, "-s"])
+        import fcntl
+        with open(os.path.join(HERE, ".build.lock"), "w") as lk:      # xdist workers must not rebuild the library side by side
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            subprocess.check_call(["make", "-C", HERE, "-s"])
         _lib = C.CDLL(LIB)
         _lib.kqe_last_error.restype = C.c_char_p
     return _lib

@@ -184,6 +184,9 @@ def parse_strings(text, named):
     text = text.strip()
     if text in named:
         return named[text]
+    m = re.fullmatch(r"append\((\[\]string\{.*?\}),\s*(\w+)\.\.\.\)", text, flags=re.S)
+    if m:  # append([]string{a, b}, named...)
+        return parse_strings(m.group(1), named) + list(named[m.group(2)])
     inner = text[text.index("{") + 1:text.rindex("}")]
     return [ident(e) for e in elements(inner)]
 
@@ -221,6 +224,13 @@ def parse_podset(body, named_levels):
                 tr["unconstrained"] = new_arg(v) == "true"
             elif k == "PodSetSliceRequiredTopology":
                 tr["sliceRequiredTopology"] = ident(new_arg(v))
+            elif k == "PodsetSliceRequiredTopologyConstraints":
+                inner = v[v.index("{", v.index("PodsetSliceRequiredTopologyConstraint{") ) + 1:v.rindex("}")]
+                cons = []
+                for e in elements(inner):
+                    ef = top_level_fields(e[e.index("{") + 1:e.rindex("}")])
+                    cons.append(dict(topology=ident(ef["Topology"]), size=int(ef["Size"])))
+                tr["sliceConstraints"] = cons
             elif k == "PodSetSliceSize":
                 tr["sliceSize"] = int(re.search(r"(-?\d+)\)?$", re.sub(r"int32\(", "", new_arg(v))).group(1))
             else:
@@ -334,6 +344,8 @@ def main():
                 for k, v in gates.items():
                     if k == "features.TASProfileMixed":
                         case["profileMixed"] = v.strip() == "true"
+                    elif k == "features.TASMultiLayerTopology" and v.strip() == "true":
+                        pass  # the gate only lets the job parser populate the constraint list; the algorithm honours whatever is there
                     else:
                         raise Skip("gate " + k.replace("features.", ""))
             nodes = f.get("nodes", "").strip()

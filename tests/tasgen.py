@@ -76,3 +76,75 @@ def random_tas_case(seed, max_blocks=3, max_racks=4, max_hosts=6, n_workloads=12
         workloads.append(podsets)
         sim.append(rnd.random() < 0.15)
     return topo, T.Requests(topo, workloads, simulate_empty=sim)
+
+
+LEVELS4 = ["cloud.com/datacenter"] + LEVELS3
+
+
+def random_tas_multilayer_case(seed, n_workloads=10):
+    """Topologies of 3-4 levels and podsets that mostly carry PodsetSliceRequiredTopologyConstraints with inner layers (TASMultiLayerTopology),
+    valid and invalid ones (unknown key, not below the previous layer, size that does not divide), with and without leaders."""
+    rnd = random.Random(0x3A7E5 + seed)
+    levels = rnd.choice([LEVELS4, LEVELS4, LEVELS3, LEVELS3[1:]])
+    nodes = []
+    hid = 0
+    for dc in range(rnd.randint(1, 2)):
+        for b in range(rnd.randint(1, 3)):
+            for r in range(rnd.randint(1, 3)):
+                for h in range(rnd.randint(1, 4)):
+                    hid += 1
+                    alloc = {"cpu": str(rnd.choice([0, 1, 2, 3, 4, 4, 6, 8])), "pods": str(rnd.choice([3, 10, 110]))}
+                    nodes.append(T.Node(f"n{hid}", {LEVELS4[0]: f"dc{dc}", LEVELS4[1]: f"b{dc}-{b}", LEVELS4[2]: f"r{dc}-{b}-{r}", T.HOSTNAME_LABEL: f"x{hid:03d}"},
+                                        alloc, ready=rnd.random() > 0.04))
+    topo = T.Topology(levels, nodes, resources=["cpu"], profile_mixed=rnd.random() > 0.3)
+    use = {leaf: {"cpu": rnd.randint(0, 2) * 1000, "pods": rnd.randint(0, 2)} for leaf in range(topo.n_leaves) if rnd.random() < 0.3}
+    topo.set_tas_usage(use)
+    workloads, sim = [], []
+    for w in range(rnd.randint(1, n_workloads)):
+        grouped = rnd.random() < 0.25
+        mode = rnd.choice(["required", "required", "preferred", "slice-only", "unconstrained"])
+        top = rnd.randrange(len(levels) - 1) if len(levels) > 1 else 0
+        # layers on strictly lower and lower levels, sizes dividing each other
+        first = rnd.randrange(top, len(levels))
+        lv_idx = [first]
+        while lv_idx[-1] + 1 < len(levels) and rnd.random() < 0.75:
+            lv_idx.append(rnd.randrange(lv_idx[-1] + 1, len(levels)))
+        sizes = [rnd.choice([1, 2, 3])]
+        for _ in lv_idx[1:]:
+            sizes.append(sizes[-1] * rnd.choice([1, 2, 2, 3]))
+        sizes.reverse()
+        cons = [(levels[l], s) for l, s in zip(lv_idx, sizes)]
+        flaw = rnd.random()
+        if len(cons) > 1 and flaw < 0.08:
+            cons[-1] = ("example.com/unknown", cons[-1][1])
+        elif len(cons) > 1 and flaw < 0.16:
+            cons[-1] = (cons[rnd.randrange(len(cons) - 1)][0], cons[-1][1])        # not below the previous layer
+        elif len(cons) > 1 and flaw < 0.24:
+            cons[-1] = (cons[-1][0], cons[-2][1] + 1)                                # does not divide
+        elif flaw < 0.28:
+            cons[0] = (cons[0][0], 0)                                                # slice size not provided
+        kw = dict(slice_constraints=cons)
+        if mode == "required":
+            tr = T.TopologyRequest(required=levels[top], **kw)
+        elif mode == "preferred":
+            tr = T.TopologyRequest(preferred=levels[top], **kw)
+        elif mode == "unconstrained":
+            tr = T.TopologyRequest(unconstrained=True, **kw)
+        else:
+            tr = T.TopologyRequest(**kw)
+        outer = max(1, cons[0][1])
+        count = outer * rnd.choice([1, 1, 2, 3, 4])
+        reqs = {"cpu": rnd.choice([500, 1000, 1000, 2000])}
+        podsets = [T.TASPodSetRequests("workers", count, reqs, tr)]
+        if grouped:
+            podsets[0].group = "g"
+            podsets.append(T.TASPodSetRequests("leader", 1, {"cpu": rnd.choice([500, 1000])}, tr, group="g"))
+            if rnd.random() < 0.5:
+                podsets.reverse()
+        elif rnd.random() < 0.2:   # a second, plain podset after the layered one sees its assumed usage
+            podsets.append(T.TASPodSetRequests("extra", rnd.choice([1, 2, 4]), {"cpu": 1000}, T.TopologyRequest(preferred=levels[-1])))
+        if rnd.random() < 0.1:
+            podsets[0].leaf_ok = [rnd.random() < 0.8 for _ in range(topo.n_leaves)]
+        workloads.append(podsets)
+        sim.append(rnd.random() < 0.1)
+    return topo, T.Requests(topo, workloads, simulate_empty=sim)
