@@ -105,7 +105,7 @@ CONSTS = {"corev1.LabelHostname": "kubernetes.io/hostname", "corev1.ResourceCPU"
 
 def ident(tok):
     tok = tok.strip()
-    m = re.fullmatch(r"string\((.*)\)", tok)
+    m = re.fullmatch(r"(?:string|corev1\.ResourceName|kueue\.\w+)\((.*)\)", tok)   # a conversion around a literal or constant
     if m:
         tok = m.group(1).strip()
     if tok.startswith('"'):
@@ -150,6 +150,10 @@ def parse_nodes(text):
                 node["ready"] = False
             elif meth == "Unschedulable":
                 node["unschedulable"] = True
+            elif meth == "StatusConditions":
+                cf = top_level_fields(args[args.index("{") + 1:args.rindex("}")])
+                if cf.get("Type", "").strip() == "corev1.NodeReady":      # any other condition leaves readiness alone
+                    node["ready"] = cf.get("Status", "").strip() == "corev1.ConditionTrue"
             elif meth == "Obj":
                 pass
             else:
@@ -200,6 +204,14 @@ def new_arg(v):
     return m.group(1).strip()
 
 
+def int_expr(v):
+    """an integer literal or a product of them (64 * 1024 * 1024 * 1024)"""
+    out = 1
+    for t in v.split("*"):
+        out *= int(t.strip())
+    return out
+
+
 def parse_podset(body, named_levels):
     f = top_level_fields(body)
     for bad in ("tolerations", "nodeSelector", "nodeAffinity", "previousAssignment"):
@@ -210,7 +222,7 @@ def parse_podset(body, named_levels):
     if "requests" in f:
         inner = f["requests"][f["requests"].index("{") + 1:f["requests"].rindex("}")]
         for k, v in top_level_fields_generic(inner):
-            ps["requests"][ident(k)] = int(v)
+            ps["requests"][ident(k)] = int_expr(v)
     if "topologyRequest" in f and f["topologyRequest"] != "nil":
         t = f["topologyRequest"]
         tf = top_level_fields(t[t.index("{") + 1:t.rindex("}")])
