@@ -107,6 +107,13 @@ struct TParams {  // topologyAssignmentParameters :473 + requirements :461
   const int32_t *layerLevel, *layerSize;
 };
 
+// sizeAt[l] with static indices only, so that the table stays in registers (a dynamically indexed member would put TParams into scratch)
+KQ_DEV int32_t t_size_at(const TParams& p, int l) {
+  int32_t v = 0;
+  #pragma unroll
+  for (int i = 0; i <= KQ_TAS_MAX_LEVELS; i++) if (i == l) v = p.sizeAt[i];
+  return v;
+}
 KQ_DEV bool t_lfc(const TK& k, bool unconstrained) { return unconstrained && k.T.profile_mixed; }  // useLeastFreeCapacityAlgorithm :1468
 
 // requests.go:195-232 on remaining capacity rem[] (registers of the lane)
@@ -162,7 +169,7 @@ KQ_DEV void t_fill_in_counts(const TK& k, const TState& s, const TParams& p, lon
       int32_t childrenCapacity = 0, sliceCapacity = 0, minPodDiff = 0x7fffffff, minSliceDiff = 0x7fffffff, leaderCount = 0;
       bool contributor = false;
       const int c0 = T.child_first[d], cn = T.child_cnt[d];
-      const int32_t innerSize = p.sizeAt[level + 1];  // a child at a constrained level only contributes whole inner slices (:1950-1967)
+      const int32_t innerSize = t_size_at(p, level + 1);  // a child at a constrained level only contributes whole inner slices (:1950-1967)
       for (int c = c0; c < c0 + cn; c++) {
         int32_t cpc = s.pc[c], cpcwl = s.pcwl[c];
         const int32_t csc = s.sc[c], cscwl = s.scwl[c], clc = s.lc[c];
@@ -701,7 +708,7 @@ KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, 
   }
   for (; level < T.L - 1; level++) {
     int32_t sliceSizeOnLevel = st.sliceSize;
-    if (level >= st.sliceLevelIdx) sliceSizeOnLevel = st.sizeAt[level + 1] > 0 ? st.sizeAt[level + 1] : 1;  // :1049-1057
+    if (level >= st.sliceLevelIdx) { const int32_t sz = t_size_at(st, level + 1); sliceSizeOnLevel = sz > 0 ? sz : 1; }  // :1049-1057
     nout = 0;
     for (int j = 0; j < ncur; j++) {
       const int d = s.cur[j], c0 = T.child_first[d], cn = T.child_cnt[d];
@@ -797,6 +804,7 @@ KQ_DEV void t_workload(const TK& k, int slot, int w) {
     st.simulateEmpty = Q.sim_empty && Q.sim_empty[w]; st.hasLeader = leader >= 0; st.hasAssumed = hasAssumed;
     st.req = Q.spr + (size_t)workers * T.R; st.leaderReq = leader >= 0 ? Q.spr + (size_t)leader * T.R : nullptr;
     st.leafOk = Q.leaf_ok ? Q.leaf_ok + (size_t)workers * T.n_leaves : nullptr;
+    #pragma unroll
     for (int l = 0; l <= KQ_TAS_MAX_LEVELS; l++) st.sizeAt[l] = 0;
     st.nLayers = 0; st.layerLevel = nullptr; st.layerSize = nullptr;
     TFail f{KQ_TAS_OK, 0, 0};
@@ -815,7 +823,11 @@ KQ_DEV void t_workload(const TK& k, int slot, int w) {
           if (ll[i] < 0 || ll[i] >= T.L) f = TFail{KQ_TAS_BAD_LAYER, i, 0};
           else if (ll[i] <= prevLevel) f = TFail{KQ_TAS_BAD_LAYER, i, 1};
           else if (ls[i] <= 0 || prevSize % ls[i] != 0) f = TFail{KQ_TAS_BAD_LAYER, i, 2};
-          else { for (int l = prevLevel + 1; l <= ll[i]; l++) st.sizeAt[l] = ls[i]; prevSize = ls[i]; prevLevel = ll[i]; }
+          else {
+            #pragma unroll
+            for (int l = 0; l <= KQ_TAS_MAX_LEVELS; l++) if (l > prevLevel && l <= ll[i]) st.sizeAt[l] = ls[i];
+            prevSize = ls[i]; prevLevel = ll[i];
+          }
         }
         if (f.status == KQ_TAS_OK) { st.nLayers = nl < KQ_TAS_MAX_LEVELS ? nl : KQ_TAS_MAX_LEVELS; st.layerLevel = ll; st.layerSize = ls; }
       }

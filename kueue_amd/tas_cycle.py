@@ -31,6 +31,7 @@ class kq_cycle_tas(C.Structure):
         ("adm_off", F.i32p), ("adm_tas", F.i32p), ("adm_leaf", F.i32p), ("adm_count", F.i32p), ("adm_req", F.i64p),
         ("ps_flags", F.u8p), ("ps_kind", F.u8p), ("ps_level", F.i32p), ("ps_slice_size", F.i32p), ("ps_slice_level", F.i32p),
         ("ps_group", F.i32p), ("ps_req", F.i64p),
+        ("ps_n_layers", F.i32p), ("ps_layer_level", F.i32p), ("ps_layer_size", F.i32p),   # TASMultiLayerTopology, NULL = single layer
     ]
 
 
@@ -58,7 +59,7 @@ class PodSetTAS:
     def explicit(self) -> bool:  # workload.IsExplicitlyRequestingTAS workload.go:535-541
         t = self.topology_request
         return t is not None and (t.unconstrained or t.required is not None or t.preferred is not None or
-                                  t.slice_required_topology is not None or t.slice_size is not None)
+                                  t.slice_required_topology is not None or t.slice_size is not None or bool(t.slice_constraints))
 
 
 @dataclass
@@ -159,6 +160,8 @@ class CycleTAS:
         level = np.full((max(n_ps, 1), max(nt, 1)), -1, np.int32); slevel = np.full((max(n_ps, 1), max(nt, 1)), -1, np.int32)
         ssize = np.ones(max(n_ps, 1), np.int32); group = np.full(max(n_ps, 1), -1, np.int32)
         req = np.zeros((max(n_ps, 1), R), np.int64)
+        ML = 8   # KQ_TAS_MAX_LEVELS
+        nlay = np.zeros(max(n_ps, 1), np.int32); llev = np.full((max(n_ps, 1), max(nt, 1), ML), -1, np.int32); lsz = np.zeros((max(n_ps, 1), ML), np.int32)
         g = 0
         gid: Dict[Tuple[str, str], int] = {}
         for w in heads.workloads:
@@ -169,6 +172,10 @@ class CycleTAS:
                 tr = TASPodSetRequests(name=ps.name, count=ps.count, single_pod_requests={}, topology_request=pt.topology_request if pt.explicit else None)
                 for ti, topo in enumerate(self.topos):
                     level[g, ti], kind[g], ssize[g], slevel[g, ti] = topo.resolve(tr)
+                    lay = topo.resolve_layers(tr)
+                    nlay[g] = len(lay)
+                    for j, (lv, sz) in enumerate(lay[:ML]):
+                        llev[g, ti, j] = lv; lsz[g, j] = sz
                 if not self.topos:
                     kind[g] = KQ_TAS_UNCONSTRAINED
                 if pt.group is not None:
@@ -180,6 +187,8 @@ class CycleTAS:
                 g += 1
         a.update(ps_flags=flags, ps_kind=kind, ps_level=level.reshape(-1).copy(), ps_slice_size=ssize, ps_slice_level=slevel.reshape(-1).copy(),
                  ps_group=group, ps_req=req.reshape(-1).copy())
+        if (nlay > 1).any():
+            a.update(ps_n_layers=nlay, ps_layer_level=llev.reshape(-1).copy(), ps_layer_size=lsz.reshape(-1).copy())
         self.arrays = a
         self._topo_arr = (kq_tas_topology * max(nt, 1))()
         for i, t in enumerate(self.topos):
@@ -273,7 +282,8 @@ def load_tas_case(case: dict, cycle: int = 1):
         tr = None
         if t is not None:
             tr = TopologyRequest(required=t.get("required"), preferred=t.get("preferred"), unconstrained=bool(t.get("unconstrained", False)),
-                                 slice_required_topology=t.get("sliceRequiredTopology"), slice_size=t.get("sliceSize"))
+                                 slice_required_topology=t.get("sliceRequiredTopology"), slice_size=t.get("sliceSize"),
+                                 slice_constraints=[(c["topology"], c["size"]) for c in t["sliceConstraints"]] if t.get("sliceConstraints") else None)
         return PodSetTAS(tr, ps.get("group"), dict(ps.get("requests") or {}))
 
     pod_tas: Dict[Tuple[str, int], PodSetTAS] = {}

@@ -41,6 +41,11 @@ typedef struct kq_cycle_tas {
   const int32_t* ps_slice_level;    /* [n_ps][n_tas] */
   const int32_t* ps_group;          /* [n_ps] PodSetGroupName id, -1 = none */
   const int64_t* ps_req;            /* [n_ps][n_resources] SinglePodRequests from the pod spec (tas_flavorassigner.go:116) */
+  /* TASMultiLayerTopology: utiltas.PodSetSliceRequiredTopologyConstraints of the podset, all layers, outermost first (layer 0 repeats
+   * ps_slice_size / ps_slice_level); NULL = no podset carries more than one layer. Same meaning as kq_tas_requests.n_layers / layer_*. */
+  const int32_t* ps_n_layers;       /* [n_ps] */
+  const int32_t* ps_layer_level;    /* [n_ps][n_tas][KQ_TAS_MAX_LEVELS] resolved against each TAS flavor, -1 = absent */
+  const int32_t* ps_layer_size;     /* [n_ps][KQ_TAS_MAX_LEVELS] */
 } kq_cycle_tas;
 
 typedef struct kq_cycle_tas_out {

@@ -529,8 +529,16 @@ static TasResult FindTopologyAssignmentsForWorkload(Snap& sn, const Head& wl, co
     std::vector<int32_t> wl_off = {0, n}, count(n), level(n), slice_size(n), slice_level(n), group(n);
     std::vector<uint8_t> kind(n);
     std::vector<int64_t> req((size_t)n * R);
+    std::vector<int32_t> n_layers(n, 0), layer_level((size_t)n * KQ_TAS_MAX_LEVELS, -1), layer_size((size_t)n * KQ_TAS_MAX_LEVELS, 0);
     for (int i = 0; i < n; i++) {
       const int g = wl.ps_base + pss[i];
+      if (sn.T->ps_n_layers) {
+        n_layers[i] = sn.T->ps_n_layers[g];
+        for (int j = 0; j < KQ_TAS_MAX_LEVELS; j++) {
+          layer_level[(size_t)i * KQ_TAS_MAX_LEVELS + j] = sn.T->ps_layer_level[((size_t)g * nt + t) * KQ_TAS_MAX_LEVELS + j];
+          layer_size[(size_t)i * KQ_TAS_MAX_LEVELS + j] = sn.T->ps_layer_size[(size_t)g * KQ_TAS_MAX_LEVELS + j];
+        }
+      }
       count[i] = a.PodSets[pss[i]].count;
       level[i] = sn.T->ps_level[(size_t)g * nt + t];
       slice_size[i] = sn.T->ps_slice_size[g];
@@ -543,6 +551,7 @@ static TasResult FindTopologyAssignmentsForWorkload(Snap& sn, const Head& wl, co
     memset(&rq, 0, sizeof rq);
     rq.n_workloads = 1; rq.wl_off = wl_off.data(); rq.single_pod_requests = req.data(); rq.count = count.data(); rq.level = level.data();
     rq.kind = kind.data(); rq.slice_size = slice_size.data(); rq.slice_level = slice_level.data(); rq.group = group.data();
+    if (sn.T->ps_n_layers) { rq.n_layers = n_layers.data(); rq.layer_level = layer_level.data(); rq.layer_size = layer_size.data(); }
     std::vector<tas::PodSetResult> res;
     tas::find_workload(*sn.tasS[t], &rq, 0, n, simulateEmpty, &res);
     sn.tasFinds++;

@@ -230,7 +230,7 @@ def parse_admission(args, sym):
 
 
 PS_OK = {"MakePodSet", "Request", "Obj", "Image", "RequiredTopologyRequest", "PreferredTopologyRequest", "UnconstrainedTopologyRequest",
-         "SliceRequiredTopologyRequest", "SliceSizeTopologyRequest", "Limit"}
+         "SliceRequiredTopologyRequest", "SliceSizeTopologyRequest", "SliceRequiredTopologyConstraints", "Limit"}
 
 
 def parse_podsets(args, sym):
@@ -258,6 +258,9 @@ def parse_podsets(args, sym):
                 tr["sliceRequiredTopology"] = label(a, sym)
             elif m == "SliceSizeTopologyRequest":
                 tr["sliceSize"] = int(a)
+            elif m == "SliceRequiredTopologyConstraints":
+                tr["sliceConstraints"] = [dict(topology=label(k, sym), size=int(v))
+                                          for k, v in re.findall(r"Topology:\s*([^,]+),\s*Size:\s*(\d+)", a)]
         if tr:
             ps["topologyRequest"] = tr
         out.append(ps)
@@ -322,7 +325,7 @@ def parse_keymap(text):
 
 
 BAD = r"AdmissionCheck|Toleration|NodeSelector|Taint|PreemptionGate|WorkloadSlice|Annotation|UnhealthyNode|DelayedTopologyRequest|PodSetGroup|" \
-      r"resourceTransformations|patchStatusErr|RequiredDuringScheduling|PreferredDuringScheduling|PodSetUpdate|StopPolicy|SliceRequiredTopologyConstraint|" \
+      r"resourceTransformations|patchStatusErr|RequiredDuringScheduling|PreferredDuringScheduling|PodSetUpdate|StopPolicy|" \
       r"MinimumCount|SetMinimumCount"
 
 
@@ -355,7 +358,7 @@ def extract(src, func, cases, skipped):
             if fg:
                 for g, v in re.findall(r"features\.(\w+):\s*(true|false)", fg):
                     gates[g] = v == "true"
-                allowed = {"TASProfileMixed": True, "TASRecomputeAssignmentWithinSchedulingCycle": None, "VectorizedResourceRequests": None,
+                allowed = {"TASMultiLayerTopology": True, "TASProfileMixed": True, "TASRecomputeAssignmentWithinSchedulingCycle": None, "VectorizedResourceRequests": None,
                            "TASCachingRemainingResources": None, "TASCacheNodeMatchResults": None}
                 for g, v in gates.items():
                     if g not in allowed or (allowed[g] is not None and allowed[g] != v):
