@@ -234,6 +234,8 @@ typedef struct kq_heads {
 #define KQ_RSN_NOT_IN_NOMINATION     3  /* :1097: flavor skipped by the nomination mapping; resource = the scan's resource name   */
 #define KQ_RSN_FLAVOR_INELIGIBLE     4  /* :1105-1113: checkFlavorForPodSets failed (ps_flavor_ok bit clear); the host knows the text */
 #define KQ_RSN_RESOURCE_UNAVAILABLE  5  /* :1080: no resource group of the ClusterQueue covers `resource`                         */
+#define KQ_RSN_TRUNCATED           255  /* not a reference reason: the head produced more records than its window holds; the list
+                                         * returned for that head is incomplete (flavor = resource = -1). Retry with a larger rsn_cap. */
 
 typedef struct kq_decisions {
   /* per head [n] */
@@ -427,11 +429,11 @@ int  kq_snapshot_read_planes(kq_engine* e, int64_t* subtree_quota, int64_t* usag
 /* Diagnostics. NOT part of the drop-in boundary (a Go binding does not need them); the parity tests use them.
  * kq_debug_read_usage_work: the cycle's private usage plane [N * n_fr] as processEntry left it (what the reference's
  * per-cycle Snapshot holds after schedule() returns). kq_debug_force_exact_drs: take the saturation-safe per-cell DRS loops
- * even when the maintained sums would be exact. kq_debug_prof: 32 in-kernel segment counters (KQ_PROF builds). */
+ * even when the maintained sums would be exact. kq_debug_prof: 64 in-kernel segment counters (KQ_PROF builds); `out64` must hold 64 int64. */
 int  kq_debug_read_usage_work(kq_engine* e, int64_t* usage_out);
 int  kq_debug_force_exact_drs(kq_engine* e, int on);
 int  kq_debug_disable_scan_search(kq_engine* e, int on);  /* classical victim searches walk candidate by candidate */
-int  kq_debug_prof(kq_engine* e, int64_t* out32, int reset);
+int  kq_debug_prof(kq_engine* e, int64_t* out64, int reset);
 
 const char* kq_strerror(int code);
 const char* kq_last_error(kq_engine* e);

@@ -126,6 +126,7 @@ template <class B> struct EngineT {
     });
   }
   void pend_alloc_gather() {  // the gathered batch holds <= 1 head per ClusterQueue: sized for the widest workload of every ClusterQueue
+    if (last_slot == PEND_SLOT) last_cycle_n = -1;  // kq_cycle_commit re-reads the last cycle's K block, whose H.* point into the arrays freed here
     Pending& P = pend;
     const int nq = prep.nq, nR = prep.nR;
     const size_t nfw = (prep.nF + 63) / 64;
@@ -154,6 +155,7 @@ template <class B> struct EngineT {
     return d;
   }
   void pending_free() {
+    if (last_slot == PEND_SLOT) last_cycle_n = -1;  // the uncommitted pending cycle's gathered head arrays are freed below
     for (void* p : pend.allocs) be.free(p);
     const int64_t now = pend.now;
     pend = Pending{};

@@ -88,7 +88,8 @@ KQ_DEV void pend_pop(const DPend& D, int c) {
   if (D.cq_active && !D.cq_active[c]) { if (lane == 0) D.head_wl[c] = -1; return; }  // manager.go:926: no Pop at all
   int head = -1;
   const int pw = D.pw[c];
-  if (pw >= 0 && D.pw_sticky[c] && D.state[pw] == WL_ACTIVE) head = pw;  // stickyMatches sorts first (:848-856)
+  const bool sticky = pw >= 0 && D.pw_sticky[c] && D.state[pw] == WL_ACTIVE;
+  if (sticky && !D.lq) head = pw;  // stickyMatches sorts first (:848-856)
   if (head < 0 && !D.lq) {
     const int o0 = D.cq_off[c], o1 = D.cq_off[c + 1];
     for (int base = o0; base < o1 && head < 0; base += WAVE) {
@@ -99,22 +100,24 @@ KQ_DEV void pend_pop(const DPend& D, int c) {
     }
   }
   if (head < 0 && D.lq) {
-    // queueOrderingFunc: LocalQueue usage first, then the static base order = the position in the sorted segment. A wave arg-min
-    // over (usage key, position): 64 positions per step.
+    // queueOrderingFunc (:880-904): LocalQueue usage FIRST, then baseCompareFunc = [sticky preemptor, the static base order (the
+    // position in the sorted segment)] — the sticky workload only wins among equal usage keys. A wave arg-min over
+    // (usage key, 0 for the sticky workload | 1 + position): 64 positions per step.
     const int o0 = D.cq_off[c], o1 = D.cq_off[c + 1];
-    uint64_t best_k = ~0ull; int best_pos = 0x7fffffff;
+    uint64_t best_k = ~0ull; uint32_t best_pos = 0xffffffffu;
     for (int base = o0; base < o1; base += WAVE) {
       const int j = base + lane;
       const int w = j < o1 ? D.ord[j] : -1;
       if (w >= 0 && D.state[w] == WL_ACTIVE) {
         const int l = D.lq[w];
         const uint64_t kk = l >= 0 ? afs_key(D.lq_usage[l]) : afs_key(0.0);
-        if (kk < best_k || (kk == best_k && j < best_pos)) { best_k = kk; best_pos = j; }
+        const uint32_t pk = (sticky && w == pw) ? 0u : (uint32_t)(j - o0) + 1u;
+        if (kk < best_k || (kk == best_k && pk < best_pos)) { best_k = kk; best_pos = pk; }
       }
     }
     const uint64_t mk = wmin_u64(best_k);
-    const uint64_t mp = wmin_u64(best_k == mk ? (uint64_t)(uint32_t)best_pos : ~0ull);
-    if (mk != ~0ull && (int)mp != 0x7fffffff) head = D.ord[(int)mp];
+    const uint64_t mp = wmin_u64(best_k == mk ? (uint64_t)best_pos : ~0ull);
+    if (mk != ~0ull && mp != 0xffffffffull) head = mp == 0 ? pw : D.ord[o0 + (int)mp - 1];
   }
   if (lane == 0) {
     D.pop_cycle[c] += 1;  // :670, also when the heap is empty

@@ -64,13 +64,13 @@ struct Queue {
 
   // baseCompareFunc cluster_queue.go:844-876 : a before b
   bool before(const CQ& c, int a, int b) const {
-    const bool as = c.pw_sticky && c.pw == a, bs = c.pw_sticky && c.pw == b;
-    if (as != bs) return as;
-    if (!lq_usage.empty()) {  // queueOrderingFunc cluster_queue.go:880-904 (enableAdmissionFs)
+    if (!lq_usage.empty()) {  // queueOrderingFunc cluster_queue.go:880-904 (enableAdmissionFs): usage first, baseCmp only on a tie
       const double ua = wl[a].lq >= 0 ? lq_usage[wl[a].lq] : 0.0, ub = wl[b].lq >= 0 ? lq_usage[wl[b].lq] : 0.0;
       const int c3 = cmpF(ua, ub);
       if (c3 != 0) return c3 < 0;
     }
+    const bool as = c.pw_sticky && c.pw == a, bs = c.pw_sticky && c.pw == b;  // baseCompareFunc :848-856
+    if (as != bs) return as;
     if (wl[a].prio != wl[b].prio) return wl[a].prio > wl[b].prio;
     if (wl[a].ts != wl[b].ts) return wl[a].ts < wl[b].ts;
     if (wl[a].uid != wl[b].uid) return wl[a].uid < wl[b].uid;

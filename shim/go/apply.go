@@ -50,9 +50,10 @@ type Outcome struct {
 	InadmissibleMsg string
 }
 
-// Outcomes decodes the decisions of one cycle, ordered by iterator position.
+// Outcomes decodes the decisions of one cycle, ordered by iterator position. ErrReasonsTruncated: a head's reason window
+// overflowed (KQ_RSN_TRUNCATED) — run the cycle again with a larger rsn_cap or take the stock Go path for this cycle.
 func Outcomes(f *resources.ResourceFormatter, s *FlatSnapshot, h *FlatHeads, d *FlatDecisions, podsetNames func(head int) []string,
-	inel IneligibleText, preserveScanProgress bool) []Outcome {
+	inel IneligibleText, preserveScanProgress bool) ([]Outcome, error) {
 	n, nR := int(h.N), int(s.NResource)
 	out := make([]Outcome, n)
 	for i := 0; i < n; i++ {
@@ -91,7 +92,11 @@ func Outcomes(f *resources.ResourceFormatter, s *FlatSnapshot, h *FlatHeads, d *
 		case d.Mode[i] == modeDeferredFit:
 			o.InadmissibleMsg = "Workload has overlapping preemption targets with another workload, but will fit after these preemptions complete"
 		case !o.Admit:
-			o.InadmissibleMsg = AssignmentMessage(podsetNames(i), PodSetReasons(f, s, h, d, i, inel))
+			reasons, err := PodSetReasons(f, s, h, d, i, inel)
+			if err != nil {
+				return nil, err
+			}
+			o.InadmissibleMsg = AssignmentMessage(podsetNames(i), reasons)
 		}
 		out[i] = o
 	}
@@ -109,5 +114,5 @@ func Outcomes(f *resources.ResourceFormatter, s *FlatSnapshot, h *FlatHeads, d *
 			sorted = append(sorted, out[i])
 		}
 	}
-	return sorted
+	return sorted, nil
 }

@@ -7,6 +7,7 @@ package kqengine
 // the reference's TestAssignFlavors / TestSchedule tables.
 
 import (
+	"errors"
 	"fmt"
 	"sort"
 	"strings"
@@ -57,10 +58,19 @@ func ReasonText(f *resources.ResourceFormatter, s *FlatSnapshot, code uint8, fla
 	return ""
 }
 
+// RsnTruncated = KQ_RSN_TRUNCATED (kq_engine.h): the head's reason window overflowed, its record list is incomplete.
+const RsnTruncated = 255
+
+// ErrReasonsTruncated tells the caller to run the cycle again with a larger rsn_cap (or to take the stock Go path for the head).
+var ErrReasonsTruncated = errors.New("kqengine: reason records of the head were truncated (KQ_RSN_TRUNCATED)")
+
 // PodSetReasons returns Status.reasons of every podset of head i, sorted as Status.Message sorts them (flavorassigner.go:361).
-func PodSetReasons(f *resources.ResourceFormatter, s *FlatSnapshot, h *FlatHeads, d *FlatDecisions, i int, inel IneligibleText) [][]string {
+func PodSetReasons(f *resources.ResourceFormatter, s *FlatSnapshot, h *FlatHeads, d *FlatDecisions, i int, inel IneligibleText) ([][]string, error) {
 	out := make([][]string, h.PsOff[i+1]-h.PsOff[i])
 	for k := d.RsnOff[i]; k < d.RsnOff[i+1]; k++ {
+		if d.RsnCode[k] == RsnTruncated {
+			return nil, ErrReasonsTruncated
+		}
 		ps := int(d.RsnPodset[k])
 		if d.RsnCode[k] == RsnFlavorIneligible {
 			out[ps] = append(out[ps], inel(i, ps, s.FlavorNames[d.RsnFlavor[k]])...)
@@ -71,7 +81,7 @@ func PodSetReasons(f *resources.ResourceFormatter, s *FlatSnapshot, h *FlatHeads
 	for _, r := range out {
 		sort.Strings(r)
 	}
-	return out
+	return out, nil
 }
 
 // AssignmentMessage = Assignment.Message (flavorassigner.go:229-247).

@@ -277,6 +277,40 @@ def test_fs_admission_table(oracle, case):
         q.close(); eng.close()
 
 
+@pytest.mark.parametrize("usage_after,want", [([2.0, 1.0], "wlB-high"), ([1.0, 1.0], "wlA-low")], ids=["sticky-in-higher-usage-lq", "sticky-wins-a-usage-tie"])
+def test_afs_sticky_preemptor_is_a_tie_break(oracle, usage_after, want):
+    """queueOrderingFunc (cluster_queue.go:880-904) compares LocalQueue usage FIRST and falls through to baseCompareFunc (whose first
+    term is the sticky preemptor, :848-856) only on a tie: a sticky preemptor in the LocalQueue with the higher usage does not pop."""
+    from tests.emu import kqe
+    wls = [("wlA-low", "lqA", 1), ("wlB-high", "lqB", 2)]
+    snap, _, _ = _tiny({"strategy": "BestEffortFIFO", "workloads": [{"name": n, "prio": p} for n, _, p in wls]})
+    heads = Heads(snap, [Workload(n, "cq", priority=p, creation_ts=1, pod_sets=[PodSet("main", 1, requests={"cpu": 1000})], uid=n) for n, _, p in wls], cycle=0)
+    pending = Pending(heads, uid_rank=np.arange(2, dtype=np.uint32), lq=np.array([0, 1], np.int32), n_lq=2)
+    cfg = make_config()
+    q = oracle.PendingOracle(cfg, snap, pending)
+    eng = kqe.EmuEngine(cfg)
+    try:
+        first = [0.0, 1.0]   # lqA has the lower usage: wlA-low pops although its priority is lower
+        q.set_lq_usage(first)
+        assert q.pop(0) == 0
+        assert q.requeue(0, F.RQ_PENDING_PREEMPTION) and q.is_sticky(0)
+        q.set_lq_usage(usage_after)
+        assert wls[q.pop(0)][0] == want
+        eng.put(snap); eng.pending_put(pending)
+        eng.pending_set_lq_usage(first)
+        n, nps, hw = eng.pending_heads(1)
+        assert n == 1 and hw[0] == 0
+        tried = np.full(nps * snap.n_resource, -1, np.int32)
+        rc = kqe.lib().kqe_pending_apply_fabricated(eng.h, F.ptr(np.zeros(1, np.uint8)), F.ptr(np.zeros(1, np.uint8)), F.ptr(np.array([1], np.uint8)),
+                                                   F.ptr(np.array([F.RQ_PENDING_PREEMPTION], np.uint8)), F.ptr(tried))
+        assert rc == 0
+        eng.pending_set_lq_usage(usage_after)
+        n, _, hw = eng.pending_heads(2)
+        assert n == 1 and wls[int(hw[0])][0] == want
+    finally:
+        q.close(); eng.close()
+
+
 def _afs_loop(oracle, eng_factory, n_cq, per, cycles, seed):
     """Closed loop with AdmissionFairSharing ordering: every workload belongs to one of a few LocalQueues of its ClusterQueue, the
     LocalQueues' usage changes every cycle (as the ledger's would), Heads() must follow it on both sides."""
