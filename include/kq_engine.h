@@ -434,6 +434,9 @@ int  kq_debug_read_usage_work(kq_engine* e, int64_t* usage_out);
 int  kq_debug_force_exact_drs(kq_engine* e, int on);
 int  kq_debug_disable_scan_search(kq_engine* e, int on);  /* classical victim searches walk candidate by candidate */
 int  kq_debug_prof(kq_engine* e, int64_t* out64, int reset);
+/* last cycle's speculative process rounds (kq_spec.hpp): [0] windows, [1] rounds, [2] entries they decided, [3] trees handed (partly)
+ * back to the serial kernel, [4] (entry, flavor-resource) items, [5] most rounds of one window, [6] abandoned windows, [7] truncated */
+int  kq_debug_spec_stats(kq_engine* e, int64_t* out8);
 
 const char* kq_strerror(int code);
 const char* kq_last_error(kq_engine* e);

@@ -50,6 +50,7 @@ KQ_DEV int ffs64(uint64_t m) { return __builtin_ctzll(m); }
 KQ_DEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
 KQ_DEV int atomic_add_i32(int* p, int v) { int o = *p; *p += v; return o; }
 KQ_DEV void atomic_max_i32(int* p, int v) { if (v > *p) *p = v; }
+KQ_DEV void atomic_min_i32(int* p, int v) { if (v < *p) *p = v; }
 KQ_DEV void atomic_add_i64(long long* p, long long v) { *p += v; }
 KQ_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 KQ_DEV int64_t atomic_cas_i64(int64_t* p, int64_t expect, int64_t v) { int64_t o = *p; if (o == expect) *p = v; return o; }
@@ -122,6 +123,7 @@ KQ_DEV int ffs64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }
 KQ_DEV int popc64(uint64_t m) { return __popcll((unsigned long long)m); }
 KQ_DEV int atomic_add_i32(int* p, int v) { return atomicAdd(p, v); }
 KQ_DEV void atomic_max_i32(int* p, int v) { atomicMax(p, v); }
+KQ_DEV void atomic_min_i32(int* p, int v) { atomicMin(p, v); }
 KQ_DEV void atomic_add_i64(long long* p, long long v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
 KQ_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
 KQ_DEV int64_t atomic_cas_i64(int64_t* p, int64_t expect, int64_t v) {
@@ -236,6 +238,8 @@ struct DSnap {
   const uint64_t* frb_sig;      // [n_tree * nfr]
   const uint8_t* cs_ok;         // [n_tree]
   const int32_t* tree_depth;    // [n_tree]
+  const int32_t* drank;         // [N] cohorts: rank among the cohorts of the same depth of the tree (sort keys of kq_spec.hpp)
+  const int32_t* tree_dcnt;     // [n_tree * KQ_MAXD] cohorts of the tree per depth
   // LDS-resident fair-sharing victim search (kq_fs.hpp): candidates in position order and the tree's constants in tree-node order
   const FsScan* fs_scan;        // [n_adm] (offsets = tree_row_off)
   const FsApply* fs_apply;      // [n_adm]
@@ -259,6 +263,7 @@ struct DCfg {
   int cs_on;                 // classical victim searches may take the scan formulation (kq_cs.hpp)
   int fs_on;                 // fair-sharing victim searches may take the LDS-resident formulation (kq_fs.hpp)
   int dbg_variant;           // KQ_PROF builds only: timing experiments (KQ_DEBUG_VARIANT; results are wrong when non-zero)
+  int any_preempt;           // some ClusterQueue of the snapshot may preempt (Prep::any_preemption)
   int64_t cycle;
 };
 
@@ -378,6 +383,11 @@ struct K {  // everything a kernel needs
                              // negative): the sum-based DRS shortcuts (C.fs_plain) are off from then on
   int32_t* defer_list;       // [H] heads the lean nominate pass handed to the full pass
   int32_t* defer_count;      // [1]
+  // speculative process kernel (kq_spec.hpp)
+  int32_t* cq_heads;         // [nq] heads of the batch per ClusterQueue (k_records counts them; > 1: the entries take the serial kernel)
+  int32_t* spec_resume;      // [n_tree] iterator position from which the serial kernel (process_tree) takes the tree over; >= H.n: nothing left
+  int32_t* spec_stats;       // [8] diagnostics: windows, passes, entries decided by the rounds, entries handed back, ...
+  int64_t* spec_kt;          // [workgroups of k_process_spec][SP_KT_WORDS] per-item constants of the window being solved
   // Exactness certificate of a cycle run on a SHARD of a root tree (kueue_amd/sharding.py): for every flavor-resource
   // the smallest slack any admitted entry had at the ROOT level of Available (root term of resource_node.go:106-122 minus the
   // request). The root is the only node shards of one tree share; if the usage all other shards add to it stays within this slack,
@@ -2911,6 +2921,7 @@ constexpr int FD = 4;    // max path length (CQ + 3 cohort levels) on the fast p
 constexpr int CH = 16;   // entries per chunk; two chunk buffers live in LDS (one being processed, one being prefetched)
 constexpr int NBUF = 2;
 constexpr int64_t PLAIN_LIMIT = (int64_t)1 << 56;  // see "serial core" below
+constexpr int64_t SP_SMALL = (int64_t)1 << 44;      // kq_spec.hpp: requests below it => prefix sums over <= 2^12 items stay below 2^56
 constexpr int64_t QC_NOLIMIT = (int64_t)1 << 61;   // "no borrowing limit at this level" in PRec::ccv (sums of plain values stay below it)
 struct alignas(16) PRec {
   // ---- static part: a function of the head's nomination and the quota constants only. Written once per cycle for every head
@@ -2958,6 +2969,7 @@ KQ_DEV void rec_fill_static(const K& k, int e, int c) {
     r.plen = plen; r.borrowing = O.borrowing[e]; r.mode = O.nominated_mode[e]; r.nuse = nuse;
     r.slow_static = (O.tgt_n[e] != 0 || nuse > FU || plen > FD) ? 1 : 0;
     k.cq_dirty[cq] = 0;
+    if (k.cq_heads) atomic_add_i32(&k.cq_heads[cq], 1);
   }
   if (u >= nuse || nuse > FU || i >= plen || plen > FD) return;
   const int fr = O.use_fr[(size_t)e * KQ_MAXU + u];
@@ -2968,18 +2980,25 @@ KQ_DEV void rec_fill_static(const K& k, int e, int c) {
   r.sqv[u][i] = sqv; r.lq[u][i] = lqv;
   r.ccv[u][i] = i == plen - 1 ? sqv : (blv != KQ_NIL_LIMIT ? (int64_t)((uint64_t)sqv + (uint64_t)blv) : QC_NOLIMIT);
   uint64_t big = (uint64_t)sqv | (uint64_t)lqv | (blv != KQ_NIL_LIMIT ? (uint64_t)blv : 0ull);
+  // what the speculative rounds (kq_spec.hpp) cannot take: a constant that is neither plain nor exactly Unlimited (saturating
+  // arithmetic would matter), a usage cell outside the plain range, a request too large to sum thousands of
+  auto odd = [](int64_t v) { return (uint64_t)v >= (uint64_t)PLAIN_LIMIT && v != I64MAX; };
+  const int64_t ucell = k.usage[o];
+  bool unsup = odd(sqv) || odd(lqv) || (blv != KQ_NIL_LIMIT && odd(blv)) || (uint64_t)ucell >= (uint64_t)PLAIN_LIMIT;
   if (i == 0) {
     const int64_t qty = O.use_qty[(size_t)e * KQ_MAXU + u], nominal = S.nominal[o];
     r.fr[u] = fr; r.qty[u] = qty; r.nominal[u] = nominal;
     big |= (uint64_t)qty | (uint64_t)nominal;
+    unsup = unsup || (uint64_t)qty >= (uint64_t)SP_SMALL;
     r.uoff[u][0] = 0;
-    r.uw0[u] = r.un0[u] = k.usage[o];  // both work planes start the cycle as copies of the snapshot's usage
+    r.uw0[u] = r.un0[u] = ucell;  // both work planes start the cycle as copies of the snapshot's usage
   } else {
     const int tree = S.tree_of[cq];
     const int ncq = S.tree_cq_off[tree + 1] - S.tree_cq_off[tree];
     r.uoff[u][i] = (S.node_local[n] - ncq) * S.nfr + fr;
   }
-  r.cbig[u][i] = big >= (uint64_t)PLAIN_LIMIT ? 1 : 0;
+  // bit 0: not a plain quantity (serial core -> exact Amount arithmetic); bit 1: outside what kq_spec.hpp handles
+  r.cbig[u][i] = (big >= (uint64_t)PLAIN_LIMIT ? 1 : 0) | (unsup ? 2 : 0);
 }
 
 // Fills the LDS records of one chunk from the static records, in three independent parts. No synchronisation inside: every
@@ -3056,7 +3075,7 @@ KQ_DEV void prefetch_cells(const K& k, const Wave& w, PRec* rec, const EntList& 
       #pragma unroll
       for (int i = 0; i < FD; i++) {
         if (i >= plen) continue;
-        plain = plain && cbig[i] == 0 && (uint64_t)un[i] < (uint64_t)PLAIN_LIMIT;
+        plain = plain && (cbig[i] & 1) == 0 && (uint64_t)un[i] < (uint64_t)PLAIN_LIMIT;
         const int64_t x = (int64_t)((uint64_t)E + (uint64_t)ccv[i] - (uint64_t)un[i]);  // garbage (never UB) when not plain
         a = x < a ? x : a;
         E = (int64_t)((uint64_t)E + (uint64_t)i64max(0, (int64_t)((uint64_t)lq[i] - (uint64_t)un[i])));
@@ -3150,7 +3169,7 @@ KQ_DEV QPre rec_preload(const PRec& r) {
 #ifndef KQ_HOST_EMU
   const int lane = lane_id(), u = (lane >> 2) & 7, i = lane & 3;
   q.lq = r.lq[u][i]; q.ccv = r.ccv[u][i]; q.qty = r.qty[u];
-  q.uoff = r.uoff[u][i]; q.cbig = r.cbig[u][i];
+  q.uoff = r.uoff[u][i]; q.cbig = r.cbig[u][i] & 1;
 #endif
   return q;
 }
@@ -3337,7 +3356,7 @@ __device__ __noinline__ uint64_t fit_run(int64_t* pcl_generic, PRec* rc_generic,
   auto load = [&](int j) {
     KQ_LDS PRec& r = rc[j];
     LC x;
-    x.plen = r.plen; x.nuse = r.nuse; x.mode = r.mode; x.uoff = r.uoff[u][i]; x.cbig = r.cbig[u][i]; x.fr = r.fr[u];
+    x.plen = r.plen; x.nuse = r.nuse; x.mode = r.mode; x.uoff = r.uoff[u][i]; x.cbig = r.cbig[u][i] & 1; x.fr = r.fr[u];
     x.lq = r.lq[u][i]; x.ccv = r.ccv[u][i]; x.qty = r.qty[u];
     return x;
   };
@@ -3444,7 +3463,9 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
   bool loaded = false;
   int64_t bytes = 0;  // per-lane partial sum (the result pass below adds what its records cost)
   constexpr int WIN = 256;  // entries of the global order examined per window (independent of the wave width)
-  for (int base = 0, par = 0; base < n; base += WIN, par ^= 1) {
+  // entries in front of `resume` were decided by the speculative rounds (kq_spec.hpp); their usage is in the planes already
+  const int resume = k.spec_resume ? k.spec_resume[tree] : 0;
+  for (int base = resume < n ? (resume / WIN) * WIN : n, par = 0; base < n; base += WIN, par ^= 1) {
     // leader: compact this window's entries of the tree (in order) into LDS lists
     if (leader) {
       int nwin = 0;
@@ -3452,7 +3473,7 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
         const int i = base + off + lane;
         bool mine = false;
         int e = 0, ecq = 0;
-        if (i < n) { e = k.order_idx[i]; ecq = k.H.cq[e]; mine = S.tree_of[ecq] == tree; }
+        if (i < n && i >= resume) { e = k.order_idx[i]; ecq = k.H.cq[e]; mine = S.tree_of[ecq] == tree; }
         const uint64_t m = wballot(mine);
         const int my = nwin + popc64(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
         if (mine) { w.win_e[my] = e; w.win_cq[my] = ecq; w.win_off[my] = (uint8_t)(off + lane); }
@@ -3602,6 +3623,10 @@ KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, 
   bytes = wsum_i64(bytes);
   if (lane == 0 && bytes) atomic_add_i64(O.stat_bytes, (long long)bytes);
 }
+
+}  // namespace kq
+#include "kq_spec.hpp"
+namespace kq {
 
 // ------------------------------------------------------------------------------------------------
 // fair-sharing iterator (fair_sharing_iterator.go) — per root-cohort tree: pop = computeDRS + runTournament,

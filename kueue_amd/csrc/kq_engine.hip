@@ -100,6 +100,10 @@ __global__ __launch_bounds__(256) void k_records(const K* __restrict__ kp) {
   if (idx < k.H.n * FU * FD) rec_fill_static(k, idx / (FU * FD), idx % (FU * FD));
 }
 
+// k_process_spec (speculative parallel rounds over the plain entries of a tree, kq_spec.hpp) is compiled in its own translation unit
+// (kq_spec_kernel.hip): it runs in front of k_process, which takes over at K::spec_resume[tree] (nothing left in the common case).
+namespace kq { hipError_t launch_process_spec(const K* d, int n_tree, hipStream_t stream); }
+
 constexpr int PROCESS_THREADS = 256;   // wave 0 runs the serial core; all 4 waves prefetch the entry records of a chunk
 __global__ __launch_bounds__(PROCESS_THREADS) void k_process(const K* __restrict__ kp, unsigned lds_bytes) {
   const K& k = *kp;
@@ -485,10 +489,13 @@ struct HipBackend {
       chk(hipFuncSetAttribute((const void*)k_process, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
       lds_attr = lds;
     }
-    hipLaunchKernelGGL(k_process, dim3(n_tree), dim3(PROCESS_THREADS), lds, stream, put_k(k, 1), (unsigned)lds);
+    const K* d = put_k(k, 1);
+    if (!spec_off && k.spec_kt) chk(launch_process_spec(d, n_tree, stream), "k_process_spec");
+    hipLaunchKernelGGL(k_process, dim3(n_tree), dim3(PROCESS_THREADS), lds, stream, d, (unsigned)lds);
     chk(hipGetLastError(), "k_process");
   }
   size_t lds_attr = 0, lds_attr_fair = 0;
+  bool spec_off = getenv("KQ_SPEC_OFF") != nullptr;  // KQ_SPEC_OFF: every tree goes to the serial kernel (A/B timing)
   // helper workgroups of k_process_fair (K::help): KQ_HELP_BLOCKS of them, none by default. A recomputation under its nomination
   // mapping only simulates the nominated flavor (2-3 searches per batch at cfg 4f): measured 14.8 s against 15.3 s per cycle with 16
   // helpers — kept as an experiment (GPU tests run it), not worth being on. They only exist while every tree's leader workgroup is
@@ -753,6 +760,7 @@ const char* kq_tas_last_error(kq_tas* t) { return t ? t->e.last_error.c_str() : 
 // tests: take the saturation-safe DRS loops even when the incremental sums would be exact
 int kq_debug_disable_scan_search(kq_engine* en, int on) { if (!en) return KQ_EINVAL; en->e.cs_disable = on != 0; en->e.fs_disable = on != 0; return KQ_OK; }
 int kq_debug_force_exact_drs(kq_engine* en, int on) { if (!en) return KQ_EINVAL; en->e.force_exact_drs = on != 0; return KQ_OK; }
+int kq_debug_spec_stats(kq_engine* en, int64_t* out8) { return en ? en->e.spec_stats(out8) : KQ_EINVAL; }
 int kq_debug_prof(kq_engine* en, int64_t* out, int reset) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);

@@ -33,7 +33,7 @@ template <class B> struct EngineT {
   // cycle buffers (grow-only)
   struct Buf { void* p = nullptr; size_t cap = 0; };
   std::vector<Buf*> all_bufs;
-  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_grec, b_cqd, b_defer, b_cert, b_help, b_fs[20];
+  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_grec, b_cqd, b_defer, b_cert, b_help, b_cqh, b_spkt, b_fs[20];
   bool force_exact_drs = false;  // tests: take the saturation-safe DRS loops even when the sums would be exact
   bool cs_disable = false;       // tests: classical victim searches always take the candidate-by-candidate walk
   bool fs_disable = false;       // tests: fair-sharing victim searches always take the walk
@@ -190,7 +190,7 @@ template <class B> struct EngineT {
     free_snapshot();
     if (hstage) be.free_host(hstage);
     if (hup) be.free_host(hup);
-    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb, &b_grec, &b_cqd, &b_cs, &b_defer, &b_cert, &b_help}) if (b->p) be.free(b->p);
+    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb, &b_grec, &b_cqd, &b_cs, &b_defer, &b_cert, &b_help, &b_cqh, &b_spkt}) if (b->p) be.free(b->p);
     for (auto& b : b_fs) if (b.p) be.free(b.p);
     for (auto& c : ring) for (Buf* b : {&c.cq, &c.use_n, &c.use_fr, &c.use_qty}) if (b->p) be.free(b->p);
     for (auto& hbch : batches) for (auto& b : hbch.hb) if (b.p) be.free(b.p);
@@ -278,6 +278,7 @@ template <class B> struct EngineT {
     S.fs_knc = upload(prep.fs_knc.data(), prep.fs_knc.size()); S.fs_knh = upload(prep.fs_knh.data(), prep.fs_knh.size());
     S.fs_par = upload(prep.fs_par.data(), prep.fs_par.size());
     S.tree_depth = upload(prep.tree_depth.data(), prep.tree_depth.size());
+    S.drank = upload(prep.drank.data(), prep.drank.size()); S.tree_dcnt = upload(prep.tree_dcnt.data(), prep.tree_dcnt.size());
     S.cq_res_rg = upload(prep.cq_res_rg.data(), prep.cq_res_rg.size());
     rc = be.sync();
     if (rc != KQ_OK) return fail(rc, be.error());
@@ -565,6 +566,7 @@ template <class B> struct EngineT {
     // scan-formulated classical search: usage and admitted quantities must be plain (its prefix sums are ordinary additions)
     k.C.cs_on = (!cfg.fair_sharing && prep.any_preemption && prep.fs_plain && !cs_disable) ? 1 : 0;
     k.C.fs_on = (cfg.fair_sharing && prep.any_preemption && prep.fs_plain && !fs_disable) ? 1 : 0;
+    k.C.any_preempt = prep.any_preemption ? 1 : 0;
     k.C.gates = cfg.gates; k.C.fair_sharing = cfg.fair_sharing; k.C.quota_check_strategy = cfg.quota_check_strategy; k.C.cycle = hbch.cycle;
     k.H = hbch.H;
     // outputs
@@ -655,6 +657,10 @@ template <class B> struct EngineT {
     k.grec = grow<PRec>(b_grec, n);
     k.cq_dirty = grow<uint8_t>(b_cqd, std::max(prep.nq, 1));  // cleared per head by k_records
     k.defer_list = grow<int32_t>(b_defer, (size_t)n + 1); k.defer_count = k.defer_list + n;
+    k.cq_heads = grow<int32_t>(b_cqh, (size_t)std::max(prep.nq, 1) + std::max(prep.n_tree, 1) + 8);
+    k.spec_resume = k.cq_heads + std::max(prep.nq, 1); k.spec_stats = k.spec_resume + std::max(prep.n_tree, 1);
+    prep_fill(k.cq_heads, (size_t)std::max(prep.nq, 1) + std::max(prep.n_tree, 1) + 8, 0);  // resume 0: the serial kernel takes the whole tree
+    k.spec_kt = cfg.fair_sharing ? nullptr : grow<int64_t>(b_spkt, (size_t)std::min(std::max(prep.n_tree, 1), (int)SP_SLOTS) * SP_KT_WORDS);
     prep_fill(k.defer_count, 1, 0);
     k.help = nullptr; k.help_quit = nullptr; k.help_trees = 0;
     HelpBox* d_help = nullptr;
@@ -1085,6 +1091,17 @@ template <class B> struct EngineT {
     be.d2h(out, b_prof.p, 64 * sizeof(int64_t));
     int rc = be.sync();
     if (reset) be.memset(b_prof.p, 0, 64 * sizeof(int64_t));
+    return rc;
+  }
+  // diagnostics of the last cycle's speculative rounds (K::spec_stats): windows, rounds, entries decided, trees handed (partly) back to the
+  // serial kernel, items, most rounds of one window, abandoned windows, truncated windows
+  int spec_stats(int64_t* out) {
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    if (!b_cqh.p || !have_snapshot) return KQ_OK;
+    int32_t v[8];
+    be.d2h(v, (int32_t*)b_cqh.p + std::max(prep.nq, 1) + std::max(prep.n_tree, 1), sizeof(v));
+    int rc = be.sync();
+    for (int i = 0; i < 8; i++) out[i] = v[i];
     return rc;
   }
   int read_usage_work(int64_t* out) {  // tests: snapshot usage after the cycle

@@ -87,6 +87,8 @@ struct Prep {
   std::vector<uint8_t> cs_ok;                      // [n_tree] the tree's shape fits the fast search
   std::vector<int32_t> frbr;                       // admitted row of every bucket entry (same layout as frb)
   std::vector<int32_t> tree_depth;                 // [n_tree] deepest ClusterQueue (0 = no cohort)
+  std::vector<int32_t> drank;                      // [N] cohorts: rank among the cohorts of the same depth in the tree (kq_spec.hpp sort keys); ClusterQueues: 0
+  std::vector<int32_t> tree_dcnt;                  // [n_tree * KQ_MAXD] cohorts of the tree at every depth
   bool any_preemption = false;                     // some ClusterQueue may preempt (within its queue or by reclaim)
   int cs_max_bucket = 0;
   bool fs_plain_adm = true;
@@ -282,6 +284,9 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
     std::vector<int32_t> fq(p.tree_cq_off.begin(), p.tree_cq_off.end() - 1);
     for (int c = 0; c < nq; c++) { int t = p.tree_of[c]; p.cq_local[c] = fq[t] - p.tree_cq_off[t]; p.tree_cqs[fq[t]++] = c; }
   }
+  // per tree and depth: the cohorts numbered 0.. (dense sort keys of the speculative process kernel, kq_spec.hpp)
+  p.drank.assign(N, 0); p.tree_dcnt.assign((size_t)std::max(p.n_tree, 1) * KQ_MAXD, 0);
+  for (int n = nq; n < N; n++) if (p.depth[n] < KQ_MAXD) p.drank[n] = p.tree_dcnt[(size_t)p.tree_of[n] * KQ_MAXD + p.depth[n]]++;
   // node heights, children before parents: process cohorts by decreasing depth
   p.node_height.assign(N, 0);
   {

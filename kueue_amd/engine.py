@@ -143,6 +143,12 @@ class Engine:
         return st[:self.pending.n], counts
 
     # ---- one root tree split across ranks (kueue_amd/sharding.py) ---------------------------------------------------------
+    def spec_stats(self) -> np.ndarray:
+        """kq_debug_spec_stats: [windows, rounds, entries decided, trees handed back, items, max rounds, abandoned, truncated] of the last cycle."""
+        out = np.zeros(8, np.int64)
+        self._check(self._lib.kq_debug_spec_stats(self._h, F.ptr(out)))
+        return out
+
     def certificate(self, delta_dev_ptr: int):
         """kq_cycle_certificate: the cycle's usage delta into a device buffer; -> (root_margin [n_tree * n_fr], flags [n_tree])."""
         n_tree = int((self.snap.arrays["parent"] < 0).sum())

@@ -24,7 +24,7 @@ struct EmuBackend {
   void memset(void* d, int v, size_t n) { ::memset(d, v, n); }
   int sync() { return KQ_OK; }
   const char* error() { return ""; }
-  int rot = 0, nom_rot = 0;
+  int rot = 0, nom_rot = 0, spec_rot = 0, spec_fixed = -1;
   int max_slots() { return 7; }  // small on purpose: exercises the grid-stride loop over heads
   size_t lds_budget() { return 150 * 1024; }
   int help_blocks(int) { return 1; }  // no helper runs in the emulation, but the leader runs every other task the way one would
@@ -116,6 +116,17 @@ struct EmuBackend {
     // rotate LDS budgets so the chunked/LDS-resident, chunked/HBM-rows and unchunked paths are all exercised
     std::vector<int64_t> lds(160 * 1024 / 8);
     const size_t budgets[3] = {lds.size() * 8, sizeof(PRec) * CH * NBUF + 64, 0};
+    // the speculative rounds first (kq_spec.hpp), with rotating window sizes / round limits so that multi-window trees, truncation
+    // (the undecided tail goes back to the serial kernel) and "rounds off" are all exercised; then the serial kernel from K::spec_resume
+    {
+      static SpecLds sl;
+      const int variant = spec_fixed >= 0 ? spec_fixed : spec_rot++ % 5;
+      g_spec_off = variant == 4;
+      g_spec_maxe = variant == 1 ? 3 : (variant == 2 ? 17 : SP_MAXE);
+      g_spec_maxi = variant == 1 ? 16 : (variant == 2 ? 40 : SP_MAXI);
+      g_spec_pmax = variant == 3 ? 2 : (variant == 2 ? 3 : SP_PMAX);
+      for (int t = 0; t < n_tree; t++) spec_tree(k, t, sl, k.spec_kt + (size_t)(t % SP_SLOTS) * SP_KT_WORDS, 0);
+    }
     for (int t = 0; t < n_tree; t++) { Wave w{}; g_emu_pipeline = ((t + rot) % 2); process_tree(k, w, t, t, lds.data(), budgets[(t + rot) % 3], 0, 1); }
     g_emu_pipeline = 0;
     rot++;
@@ -180,6 +191,8 @@ int kqe_cycle_commit(void* e, int32_t* n) { return ((EmuEngine*)e)->cycle_commit
 int kqe_cycle_release(void* e, int age) { return ((EmuEngine*)e)->cycle_release(age); }
 int kqe_snapshot_derive(void* e) { return ((EmuEngine*)e)->snapshot_derive(); }
 int kqe_read_planes(void* e, int64_t* sq, int64_t* us, uint8_t* fl) { return ((EmuEngine*)e)->read_planes(sq, us, fl); }
+int kqe_spec_stats(void* e, int64_t* out8) { return ((EmuEngine*)e)->spec_stats(out8); }
+void kqe_spec_variant(void* e, int v) { ((EmuEngine*)e)->be.spec_fixed = v; }  // -1: rotate
 void kqe_cs_check(int on) { kq::g_cs_check = on; }
 void kqe_disable_scan_search(void* e, int on) { ((EmuEngine*)e)->cs_disable = on != 0; ((EmuEngine*)e)->fs_disable = on != 0; }
 void kqe_fs_check(int on) { kq::g_fs_check = on; }

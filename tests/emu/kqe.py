@@ -52,6 +52,16 @@ class EmuEngine:
         assert lib().kqe_read_planes(self.h, F.ptr(sq), F.ptr(us), F.ptr(fl)) == 0
         return sq, us, fl
 
+    def spec_stats(self):
+        """[windows, rounds, entries decided, trees handed back, items, max rounds, abandoned windows, truncated windows] of the last cycle."""
+        out = np.zeros(8, np.int64)
+        assert lib().kqe_spec_stats(self.h, F.ptr(out)) == 0
+        return out
+
+    def spec_variant(self, v):
+        """-1: rotate (default); 0: full windows; 1 / 2: tiny windows; 3: two rounds, then the serial kernel; 4: rounds off."""
+        lib().kqe_spec_variant(self.h, int(v))
+
     def force_exact_drs(self, on=True):
         lib().kqe_force_exact_drs(self.h, 1 if on else 0)
 
