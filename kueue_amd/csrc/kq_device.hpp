@@ -388,6 +388,11 @@ struct K {  // everything a kernel needs
   int32_t* spec_resume;      // [n_tree] iterator position from which the serial kernel (process_tree) takes the tree over; >= H.n: nothing left
   int32_t* spec_stats;       // [8] diagnostics: windows, passes, entries decided by the rounds, entries handed back, ...
   int64_t* spec_kt;          // [workgroups of k_process_spec][SP_KT_WORDS] per-item constants of the window being solved
+  // written by k_records for every (head, slot, path level) cell / (head, slot), against the usage at the start of the cycle:
+  int64_t *spec_K, *spec_T;  // [H * FU * FD] cohort levels: K = c - usage - val + E0 (term of Available, E0 folded in), T = localQuota - usage
+  int32_t* spec_o;           // [H * FU * FD] index of the cell in a usage plane
+  int64_t *spec_push, *spec_nv;  // [H * FU] what leaves the ClusterQueue level (max(0, val - E0)); the ClusterQueue's cell after AddUsage(val)
+  struct SpecHdr* spec_hdr;  // [H] BY ITERATOR POSITION: what the rounds need to know of the entry at that position (written with the order)
   // Exactness certificate of a cycle run on a SHARD of a root tree (kueue_amd/sharding.py): for every flavor-resource
   // the smallest slack any admitted entry had at the ROOT level of Available (root term of resource_node.go:106-122 minus the
   // request). The root is the only node shards of one tree share; if the usage all other shards add to it stays within this slack,
@@ -2922,6 +2927,7 @@ constexpr int CH = 16;   // entries per chunk; two chunk buffers live in LDS (on
 constexpr int NBUF = 2;
 constexpr int64_t PLAIN_LIMIT = (int64_t)1 << 56;  // see "serial core" below
 constexpr int64_t SP_SMALL = (int64_t)1 << 44;      // kq_spec.hpp: requests below it => prefix sums over <= 2^12 items stay below 2^56
+constexpr int64_t SP_C_NOLIMIT = (int64_t)1 << 60, SP_T_INF = (int64_t)1 << 59;  // kq_spec.hpp: "this level never binds" / "everything stays local"
 constexpr int64_t QC_NOLIMIT = (int64_t)1 << 61;   // "no borrowing limit at this level" in PRec::ccv (sums of plain values stay below it)
 struct alignas(16) PRec {
   // ---- static part: a function of the head's nomination and the quota constants only. Written once per cycle for every head
@@ -2997,8 +3003,58 @@ KQ_DEV void rec_fill_static(const K& k, int e, int c) {
     const int ncq = S.tree_cq_off[tree + 1] - S.tree_cq_off[tree];
     r.uoff[u][i] = (S.node_local[n] - ncq) * S.nfr + fr;
   }
-  // bit 0: not a plain quantity (serial core -> exact Amount arithmetic); bit 1: outside what kq_spec.hpp handles
-  r.cbig[u][i] = (big >= (uint64_t)PLAIN_LIMIT ? 1 : 0) | (unsup ? 2 : 0);
+  // ---- constants of the speculative rounds (kq_spec.hpp), against the usage at the start of the cycle. Unlimited constants
+  // (resources.Amount: absorbing): with finite usage, a level whose SubtreeQuota, localQuota or borrowing limit is Unlimited never binds
+  // (its term of Available is Unlimited), and an Unlimited localQuota keeps everything local (LocalAvailable Unlimited, nothing is
+  // passed up, resource_node.go:92-152) — both are the closed form with a large constant.
+  int spf = 0;
+  if (k.spec_K) {
+    const int mode = O.nominated_mode[e];
+    const uint32_t pol = S.cq_policy[cq];
+    const size_t o0 = ix(S, cq, fr);
+    const int64_t u0 = k.usage[o0], qty = O.use_qty[(size_t)e * KQ_MAXU + u];
+    int64_t val = qty;
+    if (mode == M_PREEMPT) {  // quotaResourcesToReserve scheduler.go:796-814 (only used when the entry reserves, see sp_chunk_classify)
+      const int64_t nominal = S.nominal[o0], bl0 = S.bl[o0];
+      const bool bl_inf = bl0 == KQ_NIL_LIMIT || bl0 == I64MAX;
+      if (O.borrowing[e] > 0) {
+        if (bl_inf || nominal == I64MAX) val = qty;
+        else if ((uint64_t)nominal >= (uint64_t)PLAIN_LIMIT || (uint64_t)bl0 >= (uint64_t)PLAIN_LIMIT) unsup = true;
+        else val = i64min(qty, (nominal + bl0) - u0);
+      } else if (nominal == I64MAX) val = i64max(0, qty);
+      else if ((uint64_t)nominal >= (uint64_t)PLAIN_LIMIT) unsup = true;
+      else val = i64max(0, i64min(qty, nominal - u0));
+      (void)pol;
+    }
+    const int64_t sq0 = S.sq[o0], ll0 = S.ll[o0];
+    const int64_t lq0 = ll0 != KQ_NIL_LIMIT ? i64max(0, a_sub(sq0, ll0)) : 0;
+    const int64_t E0 = lq0 == I64MAX ? SP_T_INF : i64max(0, lq0 - u0);
+    auto limit = [&](int64_t sq_, int64_t lq_, int64_t bl_, bool root) {
+      return (sq_ == I64MAX || lq_ == I64MAX || (!root && (bl_ == KQ_NIL_LIMIT || bl_ == I64MAX))) ? SP_C_NOLIMIT : (root ? sq_ : sq_ + bl_);
+    };
+    if (!unsup) {
+      if (i == 0) {
+        k.spec_push[(size_t)e * FU + u] = i64max(0, val - E0);
+        k.spec_o[((size_t)e * FU + u) * FD] = (int32_t)o;
+        k.spec_nv[(size_t)e * FU + u] = u0 + val;
+        const int64_t c0 = limit(sqv, lqv, blv, plen == 1);
+        if (mode == M_FIT && qty > 0 && c0 - u0 < qty) spf |= 16;   // level-0 term of Available fails (static: one head per ClusterQueue)
+        if (val < 0) spf |= 32;                                       // negative reservation (scheduler.go:806)
+      } else {
+        // (a request of 0 always fits — max(0, Available) < 0 is false — whatever the cell holds: never tested)
+        const int64_t cc = (mode == M_FIT && qty <= 0) ? SP_C_NOLIMIT : limit(sqv, lqv, blv, i == plen - 1);
+        const int64_t Tv = lqv == I64MAX ? SP_T_INF : lqv - ucell;
+        const size_t ci = ((size_t)e * FU + u) * FD + i;
+        k.spec_K[ci] = cc - ucell - val + E0; k.spec_T[ci] = Tv; k.spec_o[ci] = (int32_t)o;
+        // the prefix P of a cell is >= 0: a level's term can only bind with a finite limit (and only Fit entries are tested); local
+        // quota is only left while T > 0. A depth where neither holds for any item needs no scan.
+        if (cc != SP_C_NOLIMIT && mode == M_FIT) spf |= 4;
+        if (Tv > 0) spf |= 8;
+      }
+    }
+  }
+  // bit 0: not a plain quantity (serial core -> exact Amount arithmetic); bit 1: outside what kq_spec.hpp handles; bits 2-5: see above
+  r.cbig[u][i] = (big >= (uint64_t)PLAIN_LIMIT ? 1 : 0) | (unsup ? 2 : 0) | spf;
 }
 
 // Fills the LDS records of one chunk from the static records, in three independent parts. No synchronisation inside: every

@@ -88,9 +88,12 @@ __global__ __launch_bounds__(256) void k_order(const K* __restrict__ kp, int32_t
   }
   if (cnt) atomicAdd(&rank[i], cnt);
 }
-__global__ __launch_bounds__(256) void k_order_scatter(int n, const int32_t* rank, int32_t* order_idx) {
+__global__ __launch_bounds__(256) void k_order_scatter(const K* __restrict__ kp, int n, const int32_t* rank, int32_t* order_idx) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) order_idx[rank[i]] = i;
+  if (i >= n) return;
+  const int r = rank[i];
+  order_idx[r] = i;
+  if (kp->spec_hdr) kp->spec_hdr[r] = spec_hdr_of(*kp, i);  // the rounds' view of the entry, by iterator position (kq_spec.hpp)
 }
 
 // static part of every head's entry record (kq::rec_fill_static): one thread per (head, flavor-resource slot, path level)
@@ -477,7 +480,7 @@ struct HipBackend {
   void launch_order(const K& k, int32_t* order_idx, int32_t* rank) {
     const int nb = (k.H.n + 255) / 256;
     hipLaunchKernelGGL(k_order, dim3(nb, (k.H.n + ORDER_TILE - 1) / ORDER_TILE), dim3(256), 0, stream, (const K*)dk[0], rank);
-    hipLaunchKernelGGL(k_order_scatter, dim3(nb), dim3(256), 0, stream, k.H.n, (const int32_t*)rank, order_idx);
+    hipLaunchKernelGGL(k_order_scatter, dim3(nb), dim3(256), 0, stream, (const K*)dk[0], k.H.n, (const int32_t*)rank, order_idx);
     chk(hipGetLastError(), "k_order");
   }
   // dynamic LDS = [cohort rows (2 planes) of the largest tree, if they fit][CH prefetched entry records]

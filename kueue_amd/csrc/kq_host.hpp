@@ -33,7 +33,12 @@ template <class B> struct EngineT {
   // cycle buffers (grow-only)
   struct Buf { void* p = nullptr; size_t cap = 0; };
   std::vector<Buf*> all_bufs;
-  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_grec, b_cqd, b_defer, b_cert, b_help, b_cqh, b_spkt, b_fs[20];
+  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_grec, b_cqd, b_defer, b_cert, b_help, b_cqh, b_spkt, b_spc, b_sphdr, b_fs[20];
+#ifdef KQ_HOST_EMU
+  bool spec_stats_on = true;
+#else
+  bool spec_stats_on = getenv("KQ_SPEC_STATS") != nullptr;  // kq_debug_spec_stats: a handful of global atomics per window, off by default
+#endif
   bool force_exact_drs = false;  // tests: take the saturation-safe DRS loops even when the sums would be exact
   bool cs_disable = false;       // tests: classical victim searches always take the candidate-by-candidate walk
   bool fs_disable = false;       // tests: fair-sharing victim searches always take the walk
@@ -190,7 +195,7 @@ template <class B> struct EngineT {
     free_snapshot();
     if (hstage) be.free_host(hstage);
     if (hup) be.free_host(hup);
-    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb, &b_grec, &b_cqd, &b_cs, &b_defer, &b_cert, &b_help, &b_cqh, &b_spkt}) if (b->p) be.free(b->p);
+    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb, &b_grec, &b_cqd, &b_cs, &b_defer, &b_cert, &b_help, &b_cqh, &b_spkt, &b_spc, &b_sphdr}) if (b->p) be.free(b->p);
     for (auto& b : b_fs) if (b.p) be.free(b.p);
     for (auto& c : ring) for (Buf* b : {&c.cq, &c.use_n, &c.use_fr, &c.use_qty}) if (b->p) be.free(b->p);
     for (auto& hbch : batches) for (auto& b : hbch.hb) if (b.p) be.free(b.p);
@@ -658,9 +663,15 @@ template <class B> struct EngineT {
     k.cq_dirty = grow<uint8_t>(b_cqd, std::max(prep.nq, 1));  // cleared per head by k_records
     k.defer_list = grow<int32_t>(b_defer, (size_t)n + 1); k.defer_count = k.defer_list + n;
     k.cq_heads = grow<int32_t>(b_cqh, (size_t)std::max(prep.nq, 1) + std::max(prep.n_tree, 1) + 8);
-    k.spec_resume = k.cq_heads + std::max(prep.nq, 1); k.spec_stats = k.spec_resume + std::max(prep.n_tree, 1);
+    k.spec_resume = k.cq_heads + std::max(prep.nq, 1); k.spec_stats = spec_stats_on ? k.spec_resume + std::max(prep.n_tree, 1) : nullptr;
     prep_fill(k.cq_heads, (size_t)std::max(prep.nq, 1) + std::max(prep.n_tree, 1) + 8, 0);  // resume 0: the serial kernel takes the whole tree
     k.spec_kt = cfg.fair_sharing ? nullptr : grow<int64_t>(b_spkt, (size_t)std::min(std::max(prep.n_tree, 1), (int)SP_SLOTS) * SP_KT_WORDS);
+    if (k.spec_kt) {  // per-cell constants of the rounds, written by k_records
+      const size_t cells = (size_t)n * FU * FD, slots_ = (size_t)n * FU;
+      int64_t* a = grow<int64_t>(b_spc, cells * 2 + slots_ * 2 + (cells + 1) / 2);
+      k.spec_hdr = grow<SpecHdr>(b_sphdr, (size_t)n);
+      k.spec_K = a; k.spec_T = a + cells; k.spec_push = a + 2 * cells; k.spec_nv = a + 2 * cells + slots_; k.spec_o = (int32_t*)(a + 2 * cells + 2 * slots_);
+    }
     prep_fill(k.defer_count, 1, 0);
     k.help = nullptr; k.help_quit = nullptr; k.help_trees = 0;
     HelpBox* d_help = nullptr;
@@ -1097,7 +1108,7 @@ template <class B> struct EngineT {
   // serial kernel, items, most rounds of one window, abandoned windows, truncated windows
   int spec_stats(int64_t* out) {
     for (int i = 0; i < 8; i++) out[i] = 0;
-    if (!b_cqh.p || !have_snapshot) return KQ_OK;
+    if (!b_cqh.p || !have_snapshot || !spec_stats_on) return KQ_OK;
     int32_t v[8];
     be.d2h(v, (int32_t*)b_cqh.p + std::max(prep.nq, 1) + std::max(prep.n_tree, 1), sizeof(v));
     int rc = be.sync();

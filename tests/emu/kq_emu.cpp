@@ -109,6 +109,7 @@ struct EmuBackend {
       int rank = 0;
       for (int j = 0; j < k.H.n; j++) if (j != i && entry_before(k, j, i)) rank++;
       order_idx[rank] = i;
+      if (k.spec_hdr) k.spec_hdr[rank] = spec_hdr_of(k, i);
     }
   }
   void launch_process(const K& k, int n_tree, size_t) {
