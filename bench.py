@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3-batch", "cfg3-split", "cfg4c", "cfg3f", "cfg4f", "cfg5", "cfg5-split"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3-batch", "cfg3-split", "cfg4c-split", "cfg4c", "cfg3f", "cfg4f", "cfg5", "cfg5-split"],
                     help="cfg3 = BASELINE.json configs[2] (100k pending, 1k CQ, 16 flavors, 3-level cohorts); "
                          "cfg4c = configs[3] population under classical preemption; cfg4f = configs[3] as quoted "
                          "(fair sharing + preemption); cfg3f = configs[2] population under fair sharing; cfg5 = configs[4] "
@@ -72,7 +72,7 @@ def main():
         return bench_tas_split(args, torch, dist, world, rank, local_rank)
     if args.workload == "cfg3-batch":
         return bench_batch(args, torch, dist, world, rank, local_rank)
-    if args.workload == "cfg3-split":
+    if args.workload in ("cfg3-split", "cfg4c-split"):
         return bench_split(args, torch, dist, world, rank, local_rank)
     if args.workload in ("cfg2", "cfg3", "cfg3f") and not args.resident_batches and not args.open_loop:
         return bench_pending(args, torch, dist, world, rank, local_rank)
@@ -510,90 +510,116 @@ def cpu_baseline_pending(pop, kcfg, budget_s, hold):
 
 
 def bench_split(args, torch, dist, world, rank, local_rank):
-    """cfg3-split: ONE root cohort tree (cfg 3) split across the ranks — STRONG scaling: the population and the heads of every cycle
-    are the same at every N, rank r runs the cycle over the heads of its share of the root's child subtrees, the ranks all-reduce
-    the usage deltas (RCCL) and check the exactness certificate (kueue_amd/sharding.py); a cycle whose certificate fails runs
-    replicated on every rank. Every rank ends every cycle with the same resident snapshot and the merged decisions."""
-    from kueue_amd.api import make_config
+    """cfg3-split / cfg4c-split: ONE root cohort tree shared by all ranks — STRONG scaling: the population and the heads of every cycle
+    are the same at every N. Sharded nominate, merged process (kueue_amd/sharding.py ShardedCycle): rank r nominates every world-th
+    head, one all-reduce(SUM, int64) over RCCL merges the nominations, every rank runs iterator order + processEntry on the merged
+    batch and commits. No fallback path. Heads are uploaded every cycle (the PCIe-inclusive cycle: this is the kq_cycle_run leg of
+    the default bench, sharded), so the line also carries the plain single-engine cycle of the same loop for comparison."""
+    from kueue_amd.api import Decisions, make_config
     from kueue_amd.engine import Engine
     from kueue_amd.population import BASE_SEED, generate
-    from kueue_amd.sharding import SplitRoot
-    pop = generate(3, seed=BASE_SEED, fill=args.fill)
+    from kueue_amd.sharding import ShardedCycle
+    cfgn = 4 if args.workload.startswith("cfg4c") else 3
+    pop = generate(cfgn, seed=BASE_SEED, fill=args.fill) if cfgn == 3 else generate(cfgn, seed=BASE_SEED)
     snap = pop.snapshot
     kcfg = make_config(device=local_rank)
-    eng = Engine(kcfg)
-    eng.put(snap)
+    tgt_cap = 4096 if cfgn == 3 else 4 * snap.n_adm
     per_cq = int((pop.cq_w_off[1:] - pop.cq_w_off[:-1]).max())
     n_batches = min(per_cq, args.steps + args.warmup)
     batches = [pop.heads_for_cycle(c, cycle=c + 1) for c in range(n_batches)]
-    sr = SplitRoot(eng, snap, kcfg, dist, rank, world, device=f"cuda:{local_rank}")
-    held = []
 
-    def step(i):
-        merged, exact = sr.cycle(batches[i % n_batches], tgt_cap=4096)
-        held.append(sr.last_delta)
-        if len(held) > args.hold:
-            sr.release(held.pop(0))
-        return merged
+    def loop(run, eng, steps, keep=None):
+        live, ms = 0, []
+        for i in range(steps):
+            t1 = time.perf_counter()
+            d = run(batches[i % n_batches])
+            eng.commit(); live += 1
+            if live > args.hold:
+                eng.release(args.hold + 1); live -= 1
+            ms.append((time.perf_counter() - t1) * 1e3)
+            if keep is not None:
+                keep.append({k: v.copy() for k, v in d.a.items()})
+        return ms
 
-    for i in range(args.warmup):
-        step(i)
+    eng = Engine(kcfg)
+    eng.put(snap)
+    sc = ShardedCycle(eng, dist if world > 1 else None, rank, world, device=f"cuda:{local_rank}")
+    outs = {}
+
+    def run_sharded(h):
+        o = outs.get(id(h))
+        if o is None:
+            o = outs[id(h)] = Decisions(h, tgt_cap=tgt_cap)
+        return sc.cycle(h, out=o)
+
+    total = args.warmup + args.steps
+    got = [] if (rank == 0 and not args.no_parity_gate) else None
+    loop(run_sharded, eng, args.warmup, got)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    sr.stats = dict(cycles=0, exact=0, fallback=0)
-    cyc_ms, dec = [], 0
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    # (the timed region continues the warm-up's loop: same engine state)
+    live_ms = []
+    live = min(args.warmup, args.hold)
+    for i in range(args.warmup, total):
         t1 = time.perf_counter()
-        step(args.warmup + i)
-        cyc_ms.append((time.perf_counter() - t1) * 1e3)
-        dec += batches[(args.warmup + i) % n_batches].n
+        d = run_sharded(batches[i % n_batches])
+        eng.commit(); live += 1
+        if live > args.hold:
+            eng.release(args.hold + 1); live -= 1
+        live_ms.append((time.perf_counter() - t1) * 1e3)
+        if got is not None:
+            got.append({k: v.copy() for k, v in d.a.items()})
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    dec = sum(batches[i % n_batches].n for i in range(args.warmup, total))
     if world > 1:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
-    # equality with the unsharded run (outside the timed region): a fresh single engine replays the same loop on rank 0
-    verified = None
-    if rank == 0 and not args.no_parity_gate:
-        import ctypes as C
+    verified, plain_ms = None, None
+    if rank == 0:
+        # the same loop on ONE plain engine (kq_cycle_run): the comparison figure, and — outside the timed region — the check that every
+        # decision of every cycle and the resident usage at the end equal the sharded run's
         ref = Engine(kcfg)
         ref.put(snap)
-        eng2 = Engine(kcfg)
-        eng2.put(snap)
-        # the sharded side cannot be replayed alone on one rank when world > 1; what is checked here is the loop's END STATE:
-        # the resident usage plane every rank holds now must be the one a single engine reaches through the same cycles
-        delta = torch.zeros(snap.N * snap.n_fr, dtype=torch.int64, device=f"cuda:{local_rank}")
-        h2 = []
-        for i in range(args.warmup + args.steps):
-            ref.run(batches[i % n_batches], tgt_cap=4096)
-            ref.certificate(delta.data_ptr())
-            torch.cuda.synchronize()
-            fold = delta[:snap.n_cq * snap.n_fr].clone()
-            ref.usage_add(fold.data_ptr(), +1)
-            h2.append(fold)
-            if len(h2) > args.hold:
-                old = h2.pop(0)
-                ref.usage_add(old.data_ptr(), -1)
-        verified = bool(np.array_equal(ref.read_usage(), eng.read_usage()))
-        ref.close(); eng2.close()
-    if rank == 0:
+        want = [] if got is not None else None
+        ro = {}
+
+        def run_plain(h):
+            o = ro.get(id(h))
+            if o is None:
+                o = ro[id(h)] = Decisions(h, tgt_cap=tgt_cap)
+            return ref.run(h, out=o)
+        ms = loop(run_plain, ref, total, want)
+        plain_ms = float(np.mean(ms[args.warmup:]))
+        if got is not None:
+            verified = bool(np.array_equal(ref.read_usage(), eng.read_usage()))
+            for a, b in zip(want, got):
+                m = int(a["tgt_off"][-1])
+                for k in a:
+                    ok = np.array_equal(a[k][:m], b[k][:m]) if k in ("tgt_adm", "tgt_reason") else np.array_equal(a[k], b[k])
+                    verified = verified and bool(ok)
+        ref.close()
         print(json.dumps({
             "metric": "admission-decisions/sec + p99 schedule-cycle ms @ 100k pending, 1k CQ",
             "value": dec / elapsed, "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
-            "config": {"workload": f"cfg3-split: ONE root cohort tree ({snap.n_cq} ClusterQueues, {snap.n_cohort} cohorts, {snap.n_flavor} flavors x {snap.n_resource} resources, "
-                                   f"{snap.n_adm} admitted, fill x{args.fill}) split across {world} rank(s) at the root's {int(len(np.unique(__import__('kueue_amd.sharding', fromlist=['x']).tops_of(snap))))} child subtrees; "
-                                   f"one cycle = {batches[0].n} heads", "heads_per_cycle": batches[0].n,
-                       "sharding": "mid-level cohort subtrees per rank; all-reduce(sum, int64) of the cycle's usage deltas + exactness certificate; replicated cycle when it fails",
-                       "loop": f"closed: reduced deltas folded every cycle, taken out after {args.hold} cycles"},
-            "p50_cycle_ms": float(np.percentile(cyc_ms, 50)), "p99_cycle_ms": float(np.percentile(cyc_ms, 99)),
-            "split": dict(sr.stats), "end_state_equals_single_engine": verified,
+            "config": {"workload": f"{args.workload}: ONE root cohort tree ({snap.n_cq} ClusterQueues, {snap.n_cohort} cohorts, {snap.n_flavor} flavors x {snap.n_resource} resources, "
+                                   f"{snap.n_adm} admitted{', fill x' + str(args.fill) if cfgn == 3 else ''}) shared by {world} rank(s); one cycle = {batches[0].n} heads, uploaded every cycle",
+                       "heads_per_cycle": batches[0].n,
+                       "sharding": "sharded nominate (every world-th head per rank), one all-reduce(SUM, int64) of the nominations, merged order + processEntry on every rank; no fallback path",
+                       "loop": f"closed: kq_cycle_commit every cycle, kq_cycle_release after {args.hold} cycles"},
+            "p50_cycle_ms": float(np.percentile(live_ms, 50)), "p99_cycle_ms": float(np.percentile(live_ms, 99)),
+            "split": {"cycles": args.steps, "fallback": 0, "exchange_bytes_per_cycle": int(sc.stats["words"]) * 8, "plain_single_engine_cycle_ms": plain_ms,
+                      "ratio_to_plain": (elapsed / args.steps * 1e3) / plain_ms if plain_ms else None},
+            "parity_checked": verified,
+            "parity": "every decision field of every cycle and the resident usage at the end equal a plain engine's kq_cycle_run loop" if verified is not None else "skipped",
             "roofline": None, "cpu_baseline": None}))
+    eng.close()
     if world > 1:
         dist.destroy_process_group()
 

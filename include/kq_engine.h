@@ -411,6 +411,22 @@ int  kq_cycle_release(kq_engine* e, int32_t age);
  *   kq_snapshot_usage_add folds the reduced ClusterQueue-level delta ([n_cq * n_fr], device memory) into the resident snapshot
  *   (sign +1) — or takes it out again when those workloads finish (sign -1); cohort usage follows from it. */
 int  kq_cycle_certificate(kq_engine* e, int64_t* usage_delta_dev, int64_t* root_margin, int32_t* flags);
+
+/* ---- sharded nominate, merged process --------------------------------------------------------
+ * nominate (scheduler.go:665: flavor assignment + victim search per head) only reads the cycle-start snapshot, so the heads of a
+ * cycle shard over the ranks with no exchange; processEntry (scheduler.go:392) is one dependency chain per root cohort and cheap
+ * once it runs as speculative rounds (kq_spec.hpp). Every rank holds the same snapshot and the same batch of heads:
+ *   kq_cycle_shard_words     size (int64 words) of the exchange buffer for this batch, these decision capacities and `world` ranks
+ *   kq_cycle_nominate_shard  nominate the heads with mine[h] != 0 (host array [n]; NULL: all) and write their nomination into
+ *                            xbuf_dev (device memory, e.g. the RCCL buffer). Words of the other ranks' heads are ZERO.
+ *   all-reduce(SUM, int64) of xbuf over the ranks — the one collective of the cycle — merges the shards
+ *   kq_cycle_process_merged  import the merged nomination of ALL heads, then iterator order + processEntry + decisions, exactly as
+ *                            kq_cycle_run does after its own nominate. Identical on every rank: kq_cycle_commit / _release keep the
+ *                            resident snapshots in step, no fallback path, preemption and fair sharing included.
+ * `out` carries the capacities (tgt_cap per rank, rsn_cap) in both calls and receives the decisions in the second. */
+int  kq_cycle_shard_words(kq_engine* e, const kq_heads* h, const kq_decisions* out, int32_t world, int64_t* words);
+int  kq_cycle_nominate_shard(kq_engine* e, const kq_heads* h, const uint8_t* mine, int32_t world, int32_t rank, void* xbuf_dev, kq_decisions* out);
+int  kq_cycle_process_merged(kq_engine* e, int32_t world, int32_t rank, const void* xbuf_dev, kq_decisions* out);
 int  kq_snapshot_usage_add(kq_engine* e, const int64_t* delta_dev, int32_t sign);
 
 /* Per-kernel device time of the last cycle, HIP events on the engine's stream:

@@ -276,7 +276,7 @@ ABI_SYMBOLS = [
     "kq_engine_create", "kq_engine_destroy", "kq_snapshot_put", "kq_cycle_run", "kq_last_cycle_stats",
     "kq_cycle_commit", "kq_cycle_release", "kq_snapshot_derive", "kq_snapshot_read_planes", "kq_strerror", "kq_last_error", "kq_abi_version",
     "kq_heads_put", "kq_cycle_run_resident", "kq_nominate_run_resident", "kq_last_cycle_phases",
-    "kq_cycle_certificate", "kq_snapshot_usage_add", "kq_snapshot_patch",
+    "kq_cycle_certificate", "kq_snapshot_usage_add", "kq_snapshot_patch", "kq_cycle_shard_words", "kq_cycle_nominate_shard", "kq_cycle_process_merged",
     "kq_pending_set_lq_usage", "kq_pending_add", "kq_pending_delete", "kq_pending_set_clock", "kq_pending_set_requeue_at", "kq_pending_put", "kq_pending_heads", "kq_cycle_run_pending", "kq_pending_apply", "kq_pending_queue_inadmissible", "kq_pending_read_state",
     "kq_debug_read_usage_work", "kq_debug_force_exact_drs", "kq_debug_prof", "kq_debug_spec_stats", "kq_debug_disable_scan_search",
 ]

@@ -37,6 +37,7 @@
 #define KQ_DEV static inline
 #define KQ_MDEV inline
 #define KQ_NOINLINE static
+#define KQ_HD static inline
 namespace kq {
 constexpr int WAVE = 1;
 KQ_DEV int lane_id() { return 0; }
@@ -81,6 +82,7 @@ static int g_emu_pipeline = 0;  // tests: emulate the helper waves of k_process 
 #define KQ_DEV __device__ __forceinline__
 #define KQ_MDEV __device__ __forceinline__
 #define KQ_NOINLINE __device__ __noinline__
+#define KQ_HD __host__ __device__ __forceinline__
 namespace kq {
 constexpr int WAVE = 64;
 KQ_DEV int lane_id() { return (int)(threadIdx.x & 63); }
@@ -364,6 +366,28 @@ struct HelpBox {
   HelpRes res[CELLS];
 };
 
+// Sharded nominate, replicated process (include/kq_engine.h kq_cycle_nominate_shard / kq_cycle_process_merged): every rank nominates
+// the heads it owns and writes their nomination into an exchange buffer of int64 words that is ZERO for the heads of the others, so
+// that one SUM all-reduce over the buffer merges the shards. Layout (n heads, P podsets, C = P * nR cells):
+//   [n][SH_HEAD]  nominated mode, borrowing, use_n, tgt_n << 32 | global target position, use_fr[KQ_MAXU], use_qty[KQ_MAXU]
+//   [P]           ps_count
+//   [C]           (flavor + 1) | res_mode << 24 | (tried_idx + 1) << 32
+//   [2 + world]   algorithmic bytes of the nomination, device error, pool entries used per rank
+//   [n] + [n][rsn_win][4]   reason records (only with rsn_win > 0)
+//   [world][pool_cap]       target pool segments: admitted row | reason << 32
+constexpr int SH_HEAD = 4 + 2 * KQ_MAXU;
+struct DShard {
+  const uint8_t* mine;   // [n] this engine nominates head h (null: every head)
+  int64_t* x;            // the exchange buffer (null outside the sharded calls)
+  int world, rank, pool_cap;
+};
+KQ_HD size_t shard_off_ps(int n) { return (size_t)n * SH_HEAD; }
+KQ_HD size_t shard_off_cell(int n, size_t P) { return shard_off_ps(n) + P; }
+KQ_HD size_t shard_off_misc(int n, size_t P, int nR) { return shard_off_cell(n, P) + P * nR; }
+KQ_HD size_t shard_off_rsn(int n, size_t P, int nR, int world) { return shard_off_misc(n, P, nR) + 2 + world; }
+KQ_HD size_t shard_off_pool(int n, size_t P, int nR, int world, int rsn_win) { return shard_off_rsn(n, P, nR, world) + (rsn_win ? (size_t)n * (1 + (size_t)rsn_win * 4) : 0); }
+KQ_HD size_t shard_words(int n, size_t P, int nR, int world, int rsn_win, int pool_cap) { return shard_off_pool(n, P, nR, world, rsn_win) + (size_t)world * pool_cap; }
+
 struct K {  // everything a kernel needs
   DSnap S;
   DCfg C;
@@ -393,6 +417,7 @@ struct K {  // everything a kernel needs
   int32_t* spec_o;           // [H * FU * FD] index of the cell in a usage plane
   int64_t *spec_push, *spec_nv;  // [H * FU] what leaves the ClusterQueue level (max(0, val - E0)); the ClusterQueue's cell after AddUsage(val)
   struct SpecHdr* spec_hdr;  // [H] BY ITERATOR POSITION: what the rounds need to know of the entry at that position (written with the order)
+  DShard shard;              // sharded nominate (all zero: the ordinary cycle)
   // Exactness certificate of a cycle run on a SHARD of a root tree (kueue_amd/sharding.py): for every flavor-resource
   // the smallest slack any admitted entry had at the ROOT level of Available (root term of resource_node.go:106-122 minus the
   // request). The root is the only node shards of one tree share; if the usage all other shards add to it stays within this slack,
@@ -2372,6 +2397,7 @@ KQ_DEV void nominate_finish(const K& k, Wave& w, int h) {
 // of every cycle — is finished here by a kernel that contains nothing else; the others are appended to k.defer_list for the full
 // pass (k_nominate). Same results: a deferred head is recomputed from scratch.
 KQ_DEV void nominate_head_lean(const K& k, Wave& w, int h) {
+  if (k.shard.mine && !k.shard.mine[h]) return;  // sharded nominate: another rank's head
   load_head(k, w, h);
   if (lane_id() == 0) { if (w.has_last && last_assignment_outdated(k, h, w.cq)) w.has_last = 0; w.defer_head = 0; }
   wsync();
@@ -2404,6 +2430,7 @@ KQ_DEV void nominate_head_lean(const K& k, Wave& w, int h) {
 
 // nominate (scheduler.go:665-705) for one head
 KQ_DEV void nominate_head(const K& k, Wave& w, int h, int slot) {
+  if (k.shard.mine && !k.shard.mine[h]) return;  // sharded nominate: another rank's head
 #if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
   const long long _h0 = clock64();
 #endif
@@ -4173,6 +4200,89 @@ KQ_DEV void commit_keep_cell(const K& k, int i, int32_t* use_n_out, int32_t* cq_
 }
 
 // classical entry order (scheduler.go:1110-1163): a precedes b
+// ---- sharded nominate: export of the own heads' nomination / import of the merged one (one call per head; nps_total = podsets of the batch)
+KQ_DEV void shard_export_head(const K& k, int h, size_t nps_total) {
+  const DShard& sh = k.shard; const DOut& O = k.O; const DHeads& H = k.H;
+  if (sh.mine && !sh.mine[h]) return;
+  const int n = H.n, nR = k.S.nR;
+  int64_t* x = sh.x + (size_t)h * SH_HEAD;
+  const int tn = O.tgt_n[h];
+  x[0] = O.nominated_mode[h]; x[1] = O.borrowing[h]; x[2] = O.use_n[h];
+  x[3] = (int64_t)tn << 32 | (int64_t)(uint32_t)(tn ? sh.rank * sh.pool_cap + O.tgt_pos[h] : 0);
+  const int un = O.use_n[h] < KQ_MAXU ? O.use_n[h] : KQ_MAXU;
+  for (int u = 0; u < un; u++) { x[4 + u] = O.use_fr[(size_t)h * KQ_MAXU + u]; x[4 + KQ_MAXU + u] = O.use_qty[(size_t)h * KQ_MAXU + u]; }
+  int64_t* xp = sh.x + shard_off_ps(n);
+  int64_t* xc = sh.x + shard_off_cell(n, nps_total);
+  for (int p = H.ps_off[h]; p < H.ps_off[h + 1]; p++) {
+    xp[p] = O.ps_count[p];
+    for (int r = 0; r < nR; r++) {
+      const size_t c = (size_t)p * nR + r;
+      xc[c] = (int64_t)(uint32_t)(O.flavor[c] + 1) | (int64_t)O.res_mode[c] << 24 | (int64_t)(uint32_t)(O.tried_idx[c] + 1) << 32;
+    }
+  }
+  if (O.rsn_win) {
+    int64_t* xr = sh.x + shard_off_rsn(n, nps_total, nR, sh.world);
+    xr[h] = O.rsn_n[h];
+    const int cnt = O.rsn_n[h] < 0 ? -O.rsn_n[h] : O.rsn_n[h];
+    const int64_t* src = (const int64_t*)(O.rsn + (size_t)h * O.rsn_win);
+    int64_t* dst = xr + n + (size_t)h * O.rsn_win * 4;
+    for (int q = 0; q < cnt * 4; q++) dst[q] = src[q];
+  }
+}
+KQ_DEV void shard_export_misc(const K& k, size_t nps_total, int rsn_win) {  // one thread: counters; the pool is copied by shard_export_pool
+  const DShard& sh = k.shard;
+  int64_t* xm = sh.x + shard_off_misc(k.H.n, nps_total, k.S.nR);
+  xm[0] = *k.O.stat_bytes; xm[1] = *k.O.error; xm[2 + sh.rank] = *k.O.pool_count;
+  (void)rsn_win;
+}
+KQ_DEV void shard_export_pool(const K& k, size_t nps_total, int rsn_win, int t) {
+  const DShard& sh = k.shard;
+  if (t >= *k.O.pool_count || t >= sh.pool_cap) return;
+  sh.x[shard_off_pool(k.H.n, nps_total, k.S.nR, sh.world, rsn_win) + (size_t)sh.rank * sh.pool_cap + t] = (int64_t)(uint32_t)k.O.pool_row[t] | (int64_t)k.O.pool_reason[t] << 32;
+}
+KQ_DEV void shard_import_head(const K& k, int h, size_t nps_total) {
+  const DShard& sh = k.shard; const DOut& O = k.O; const DHeads& H = k.H;
+  const int n = H.n, nR = k.S.nR;
+  const int64_t* x = sh.x + (size_t)h * SH_HEAD;
+  O.nominated_mode[h] = (uint8_t)x[0]; O.borrowing[h] = (int32_t)x[1]; O.use_n[h] = (int32_t)x[2];
+  // (what nominate_head leaves besides the nomination itself)
+  O.mode[h] = (uint8_t)x[0]; O.status[h] = KQ_ST_NOT_NOMINATED; O.action[h] = KQ_ACT_NONE; O.requeue_reason[h] = KQ_RQ_GENERIC; O.skip[h] = KQ_SKIP_NONE; O.order[h] = -1;
+  O.tgt_n[h] = (int32_t)(x[3] >> 32); O.tgt_pos[h] = (int32_t)(x[3] & 0xffffffff);
+  const int un = x[2] < KQ_MAXU ? (int)x[2] : KQ_MAXU;
+  for (int u = 0; u < un; u++) { O.use_fr[(size_t)h * KQ_MAXU + u] = (int32_t)x[4 + u]; O.use_qty[(size_t)h * KQ_MAXU + u] = x[4 + KQ_MAXU + u]; }
+  const int64_t* xp = sh.x + shard_off_ps(n);
+  const int64_t* xc = sh.x + shard_off_cell(n, nps_total);
+  for (int p = H.ps_off[h]; p < H.ps_off[h + 1]; p++) {
+    O.ps_count[p] = (int32_t)xp[p];
+    for (int r = 0; r < nR; r++) {
+      const size_t c = (size_t)p * nR + r;
+      const int64_t w = xc[c];
+      O.flavor[c] = (int32_t)(w & 0xffffff) - 1; O.res_mode[c] = (uint8_t)((w >> 24) & 0xff); O.tried_idx[c] = (int32_t)(uint32_t)(w >> 32) - 1;
+    }
+  }
+  if (O.rsn_win) {
+    const int64_t* xr = sh.x + shard_off_rsn(n, nps_total, nR, sh.world);
+    O.rsn_n[h] = (int32_t)xr[h];
+    const int cnt = O.rsn_n[h] < 0 ? -O.rsn_n[h] : O.rsn_n[h];
+    int64_t* dst = (int64_t*)(O.rsn + (size_t)h * O.rsn_win);
+    const int64_t* src = xr + n + (size_t)h * O.rsn_win * 4;
+    for (int q = 0; q < cnt * 4; q++) dst[q] = src[q];
+  }
+}
+KQ_DEV void shard_import_misc(const K& k, size_t nps_total) {
+  const DShard& sh = k.shard;
+  const int64_t* xm = sh.x + shard_off_misc(k.H.n, nps_total, k.S.nR);
+  *k.O.stat_bytes = xm[0];
+  if (xm[1] != 0) *k.O.error = KQ_EUNSUPPORTED;   // (the sum of the ranks' error words: any rank's device-side error fails the cycle)
+  *k.O.pool_count = sh.world * sh.pool_cap;        // a recomputation appends behind the imported segments
+}
+KQ_DEV void shard_import_pool(const K& k, size_t nps_total, int rsn_win, int t) {
+  const DShard& sh = k.shard;
+  if (t >= sh.world * sh.pool_cap) return;
+  const int64_t w = sh.x[shard_off_pool(k.H.n, nps_total, k.S.nR, sh.world, rsn_win) + t];
+  k.O.pool_row[t] = (int32_t)(w & 0xffffffff); k.O.pool_reason[t] = (uint8_t)(w >> 32);
+}
+
 KQ_DEV bool entry_before(const K& k, int a, int b) {
   bool aq = k.H.flags[a] & KQ_HEAD_HAS_QUOTA_RESERVATION, bq = k.H.flags[b] & KQ_HEAD_HAS_QUOTA_RESERVATION;
   if (aq != bq) return aq;

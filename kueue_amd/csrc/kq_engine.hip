@@ -266,6 +266,21 @@ __global__ __launch_bounds__(64) void k_pend_release_requeue(DPend D, DSnap S, c
   pend_release_requeue(D, S, tree_stamp, blockIdx.x, stamp);
 }
 
+// sharded nominate: export of this rank's nomination into the exchange buffer / import of the merged one (kq_device.hpp DShard)
+__global__ __launch_bounds__(256) void k_shard_export(const K* __restrict__ kp, size_t nps_total, int rsn_win) {
+  const K& k = *kp;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < k.H.n) shard_export_head(k, i, nps_total);
+  if (i == 0) shard_export_misc(k, nps_total, rsn_win);
+  shard_export_pool(k, nps_total, rsn_win, i);
+}
+__global__ __launch_bounds__(256) void k_shard_import(const K* __restrict__ kp, size_t nps_total, int rsn_win) {
+  const K& k = *kp;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < k.H.n) shard_import_head(k, i, nps_total);
+  if (i == 0) shard_import_misc(k, nps_total);
+  shard_import_pool(k, nps_total, rsn_win, i);
+}
 __global__ __launch_bounds__(256) void k_usage_delta(int64_t* out, const int64_t* work, const int64_t* start, size_t n) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) usage_delta_cell(out, work, start, i);
@@ -461,6 +476,17 @@ struct HipBackend {
     if (n) hipLaunchKernelGGL(k_usage_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, usage, delta, n, sign, big);
     chk(hipGetLastError(), "k_usage_add");
   }
+  void launch_shard_export(const K& k, size_t nps_total, int rsn_win) {
+    const int items = std::max(k.H.n, k.shard.pool_cap);
+    hipLaunchKernelGGL(k_shard_export, dim3((items + 255) / 256), dim3(256), 0, stream, (const K*)dk[0], nps_total, rsn_win);
+    chk(hipGetLastError(), "k_shard_export");
+  }
+  void launch_shard_import(const K& k, size_t nps_total, int rsn_win) {
+    const K* d = put_k(k, 0);
+    const int items = std::max(k.H.n, k.shard.world * k.shard.pool_cap);
+    hipLaunchKernelGGL(k_shard_import, dim3((items + 255) / 256), dim3(256), 0, stream, d, nps_total, rsn_win);
+    chk(hipGetLastError(), "k_shard_import");
+  }
   size_t lds_attr_nom = 0;
   void launch_nominate(const K& k, int slots, size_t lds) {
     if (lds > 48 * 1024 && lds != lds_attr_nom) {
@@ -590,6 +616,22 @@ int kq_cycle_run(kq_engine* en, const kq_heads* h, kq_decisions* out) {
   if (!en || !h || !out) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
   return en->e.cycle_run(h, out);
+}
+
+int kq_cycle_shard_words(kq_engine* en, const kq_heads* h, const kq_decisions* out, int32_t world, int64_t* words) {
+  if (!en || !h || !out || !words) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.cycle_shard_words(h, out, world, words);
+}
+int kq_cycle_nominate_shard(kq_engine* en, const kq_heads* h, const uint8_t* mine, int32_t world, int32_t rank, void* xbuf_dev, kq_decisions* out) {
+  if (!en || !h || !out) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.cycle_nominate_shard(h, mine, world, rank, xbuf_dev, out);
+}
+int kq_cycle_process_merged(kq_engine* en, int32_t world, int32_t rank, const void* xbuf_dev, kq_decisions* out) {
+  if (!en || !out || !xbuf_dev) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.cycle_process_merged(world, rank, xbuf_dev, out);
 }
 
 int kq_heads_put(kq_engine* en, const kq_heads* h, int32_t batch) {

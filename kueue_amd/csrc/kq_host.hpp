@@ -33,7 +33,7 @@ template <class B> struct EngineT {
   // cycle buffers (grow-only)
   struct Buf { void* p = nullptr; size_t cap = 0; };
   std::vector<Buf*> all_bufs;
-  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_grec, b_cqd, b_defer, b_cert, b_help, b_cqh, b_spkt, b_spc, b_sphdr, b_fs[20];
+  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_grec, b_cqd, b_defer, b_cert, b_help, b_cqh, b_spkt, b_spc, b_sphdr, b_shard, b_fs[20];
 #ifdef KQ_HOST_EMU
   bool spec_stats_on = true;
 #else
@@ -195,7 +195,7 @@ template <class B> struct EngineT {
     free_snapshot();
     if (hstage) be.free_host(hstage);
     if (hup) be.free_host(hup);
-    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb, &b_grec, &b_cqd, &b_cs, &b_defer, &b_cert, &b_help, &b_cqh, &b_spkt, &b_spc, &b_sphdr}) if (b->p) be.free(b->p);
+    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb, &b_grec, &b_cqd, &b_cs, &b_defer, &b_cert, &b_help, &b_cqh, &b_spkt, &b_spc, &b_sphdr, &b_shard}) if (b->p) be.free(b->p);
     for (auto& b : b_fs) if (b.p) be.free(b.p);
     for (auto& c : ring) for (Buf* b : {&c.cq, &c.use_n, &c.use_fr, &c.use_qty}) if (b->p) be.free(b->p);
     for (auto& hbch : batches) for (auto& b : hbch.hb) if (b.p) be.free(b.p);
@@ -536,7 +536,29 @@ template <class B> struct EngineT {
     return KQ_OK;
   }
 
+  int cycle_shard_words(const kq_heads* h, const kq_decisions* out, int world, int64_t* words) {
+    int rc = heads_put(h, 0);
+    if (rc != KQ_OK) return rc;
+    if (world < 1) return fail(KQ_EINVAL, "world < 1");
+    *words = (int64_t)shard_words_for(0, out, world);
+    return KQ_OK;
+  }
+  int cycle_nominate_shard(const kq_heads* h, const uint8_t* mine, int world, int rank, void* xbuf, kq_decisions* out) {
+    if (world < 1 || rank < 0 || rank >= world || !xbuf) return fail(KQ_EINVAL, "bad shard arguments");
+    int rc = heads_put(h, 0);
+    if (rc != KQ_OK) return rc;
+    shard_heads_ok = true;
+    ShardCall sc; sc.mode = 1; sc.mine = mine; sc.x = (int64_t*)xbuf; sc.world = world; sc.rank = rank;
+    return cycle_exec(0, out, false, sc);
+  }
+  int cycle_process_merged(int world, int rank, const void* xbuf, kq_decisions* out) {
+    if (!shard_heads_ok || batches.empty() || !batches[0].valid) return fail(KQ_EINVAL, "kq_cycle_process_merged without kq_cycle_nominate_shard");
+    ShardCall sc; sc.mode = 2; sc.x = (int64_t*)const_cast<void*>(xbuf); sc.world = world; sc.rank = rank;
+    return cycle_exec(0, out, false, sc);
+  }
+  bool shard_heads_ok = false;
   int cycle_run(const kq_heads* h, kq_decisions* out) {
+    shard_heads_ok = false;
     int rc = heads_put(h, 0);
     if (rc != KQ_OK) return rc;
     return cycle_exec(0, out);
@@ -544,7 +566,15 @@ template <class B> struct EngineT {
 
   // nominate_only: stop after k_nominate (kq_nominate_run_resident: flavor assignment + targets for every head of the batch,
   // no iterator, no processEntry; nothing to commit afterwards)
-  int cycle_exec(int slot, kq_decisions* out, bool nominate_only = false) {
+  // Sharded nominate / merged process (kq_cycle_nominate_shard, kq_cycle_process_merged): mode 1 = nominate the heads of `mine` and
+  // export them into the exchange buffer; mode 2 = import the merged buffer instead of nominating, then the rest of the cycle.
+  struct ShardCall { int mode = 0; const uint8_t* mine = nullptr; int64_t* x = nullptr; int world = 1, rank = 0; };
+  size_t shard_words_for(int slot, const kq_decisions* out, int world) {
+    const HeadBatch& hbch = batches[slot];
+    const int rsn_win = out->rsn_cap > 0 ? std::min(std::max(prep.max_rsn_per_podset * hbch.max_nps, 8), 4096) : 0;
+    return shard_words(hbch.n, hbch.nps, prep.nR, world, rsn_win, 2 * std::max(out->tgt_cap, 1));
+  }
+  int cycle_exec(int slot, kq_decisions* out, bool nominate_only = false, ShardCall sc = ShardCall{}) {
     if (!have_snapshot) return fail(KQ_EINVAL, "kq_cycle_run before kq_snapshot_put");
     if (slot < 0 || slot >= (int)batches.size() || !batches[slot].valid) return fail(KQ_EINVAL, "unknown head batch");
     HeadBatch& hbch = batches[slot];
@@ -596,8 +626,11 @@ template <class B> struct EngineT {
     O.ps_count = (int32_t*)(pack + o_pscount);
     O.use_n = grow<int32_t>(ob[12], n); O.use_fr = grow<int32_t>(ob[13], (size_t)n * KQ_MAXU); O.use_qty = grow<int64_t>(ob[14], (size_t)n * KQ_MAXU);
     O.tgt_pos = (int32_t*)(pack + o_tpos); O.tgt_n = (int32_t*)(pack + o_tn);
-    // recomputation on overlap appends a second target segment per head: size the pool for both
-    O.pool_cap = pool_cap * 2;
+    // recomputation on overlap appends a second target segment per head: size the pool for both (sharded: behind every rank's segment)
+    // sharded: a rank's nomination gets the budget the whole pool has in the ordinary cycle (2 x tgt_cap: KQ_ECAPACITY beyond it, exactly
+    // as there), the merged pool is every rank's segment plus the same room again for recomputations
+    const int seg_cap = 2 * pool_cap;
+    O.pool_cap = sc.mode == 1 ? seg_cap : (sc.mode == 2 ? seg_cap * (sc.world + 1) : pool_cap * 2);
     O.pool_row = grow<int32_t>(ob[17], O.pool_cap); O.pool_reason = grow<uint8_t>(ob[18], O.pool_cap);
     O.rsn_win = rsn_win; O.rsn_n = rsn_win ? (int32_t*)(pack + o_rsn) : nullptr;
     O.rsn = rsn_win ? grow<RsnRec>(ob[19], (size_t)n * rsn_win) : nullptr;
@@ -716,7 +749,19 @@ template <class B> struct EngineT {
     // instead of ~30 dependent HBM/L2 accesses. A one-slot search caches the nR columns of its flavor.
     const size_t fs_want = fs_lds ? fs_bytes(prep.max_tree_nodes, prep.max_tree_cqs, nR, (int)prep.nfr, prep.max_tree_mw, 2 * nR) : 0;
     if (fs_lds) nom_lds = std::min<size_t>(fs_want, be.lds_budget());
-    be.launch_nominate(k, slots_nom, nom_lds);
+    if (sc.mode) { k.shard.x = sc.x; k.shard.world = sc.world; k.shard.rank = sc.rank; k.shard.pool_cap = seg_cap; }
+    if (sc.mode == 1) {
+      k.shard.mine = nullptr;
+      if (sc.mine) { uint8_t* dm = grow<uint8_t>(b_shard, (size_t)n); be.h2d(dm, sc.mine, (size_t)n); k.shard.mine = dm; }
+      be.memset(sc.x, 0, shard_words(n, nps, (int)nR, sc.world, rsn_win, seg_cap) * sizeof(int64_t));
+    }
+    if (sc.mode == 2) be.launch_shard_import(k, nps, rsn_win);  // the merged nomination of every rank's heads
+    else be.launch_nominate(k, slots_nom, nom_lds);
+    if (sc.mode == 1) {
+      be.launch_shard_export(k, nps, rsn_win);
+      last_cycle_n = -1;
+      return be.sync();   // the caller's all-reduce reads the buffer next
+    }
     if (!nominate_only) be.launch_records(k);  // entry records (static part) for k_process; charged to the nominate interval
     be.timer_mark(1);
     if (!cfg.fair_sharing && !nominate_only) be.launch_order(k, order_idx, rank);

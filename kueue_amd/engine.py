@@ -143,6 +143,21 @@ class Engine:
         return st[:self.pending.n], counts
 
     # ---- one root tree split across ranks (kueue_amd/sharding.py) ---------------------------------------------------------
+    # ---- sharded nominate, merged process (kq_engine.h) ----
+    def shard_words(self, heads: Heads, out: Decisions, world: int) -> int:
+        w = C.c_int64()
+        self._check(self._lib.kq_cycle_shard_words(self._h, C.byref(heads.struct()), C.byref(out.struct()), C.c_int32(world), C.byref(w)))
+        return w.value
+
+    def nominate_shard(self, heads: Heads, mine: Optional[np.ndarray], world: int, rank: int, xbuf_ptr: int, out: Decisions):
+        m = None if mine is None else np.ascontiguousarray(mine, np.uint8)
+        self._check(self._lib.kq_cycle_nominate_shard(self._h, C.byref(heads.struct()), None if m is None else F.ptr(m), C.c_int32(world), C.c_int32(rank),
+                                                      C.c_void_p(xbuf_ptr), C.byref(out.struct())))
+
+    def process_merged(self, world: int, rank: int, xbuf_ptr: int, out: Decisions) -> Decisions:
+        self._check(self._lib.kq_cycle_process_merged(self._h, C.c_int32(world), C.c_int32(rank), C.c_void_p(xbuf_ptr), C.byref(out.struct())))
+        return out
+
     def spec_stats(self) -> np.ndarray:
         """kq_debug_spec_stats: [windows, rounds, entries decided, trees handed back, items, max rounds, abandoned, truncated] of the last cycle."""
         out = np.zeros(8, np.int64)

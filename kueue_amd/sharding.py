@@ -140,11 +140,10 @@ class SplitRoot:
         """Index arrays of one heads batch (cached per batch object): every rank's heads, their podsets and (podset, resource) cells
         inside the batch's arrays, and this rank's sub-batch. Computed once per batch, not per cycle."""
         import numpy as np
-        key = id(heads_all)
-        if getattr(self, "_plans", None) is None:
-            self._plans = {}
-        if key in self._plans:
-            return self._plans[key]
+        # (cached on the batch object itself: an id()-keyed table would hand a dead batch's plan to a new object at the same address)
+        pl = getattr(heads_all, "_split_plan", None)
+        if pl is not None and pl.get("world") == self.world and pl.get("rank") == self.rank:
+            return pl
         a = heads_all.arrays
         nR = self.snap.n_resource
         owner = self.owner[a["cq"]]
@@ -156,8 +155,8 @@ class SplitRoot:
             ps_idx = np.nonzero(ps_owner == r)[0]
             cell_idx = (ps_idx[:, None] * nR + np.arange(nR)[None, :]).reshape(-1)
             per_rank.append((idx, ps_idx, cell_idx))
-        pl = dict(per_rank=per_rank, hb=heads_all.subset(per_rank[self.rank][0]))
-        self._plans[key] = pl
+        pl = dict(per_rank=per_rank, hb=heads_all.subset(per_rank[self.rank][0]), world=self.world, rank=self.rank)
+        heads_all._split_plan = pl
         return pl
 
     def cycle(self, heads_all, tgt_cap=None):
@@ -232,6 +231,54 @@ class SplitRoot:
     def release(self, fold):
         """The workloads a past cycle admitted finish: its folded delta leaves the snapshot."""
         self.eng.usage_add(fold.data_ptr(), -1)
+
+
+# ---- sharded nominate, merged process: the protocol for ONE root tree that never falls back -------------------------------------
+#
+# The two halves of a cycle scale differently. nominate (scheduler.go:665-705: flavorassigner.Assign + preemption.GetTargets per head)
+# reads nothing but the cycle-start snapshot: H independent problems, and the expensive ones (victim searches: seconds per cycle at
+# BASELINE configs[3]) — it shards over the ranks with no exchange at all. processEntry (scheduler.go:392-523) is a dependency chain
+# through the shared rows of the tree (at BASELINE fill the ROOT row binds in almost every cycle: the certificate above fails 50 cycles
+# out of 50), but it is cheap: ~0.14 ms for 1000 entries as speculative rounds on one CU (kq_spec.hpp). Exchanging the root row once per
+# round of that solver would cost a collective per round (5-10 per cycle, each a launch + a latency-bound all-reduce of a few KB): more
+# than running the rounds. So every rank nominates its share of the heads, ONE all-reduce(SUM) merges the nominations (an int64 buffer
+# that is zero outside a rank's own heads, kq_device.hpp DShard: ~1 KB per head + the target pools), and every rank runs the order +
+# processEntry step on the merged batch — the same code as the single engine, so preemption targets, overlap recomputation, fair
+# sharing and DeferredFit need no special case, every rank ends the cycle with the same decisions and kq_cycle_commit / kq_cycle_release
+# keep the resident snapshots in step. Amdahl bounds the gain: (nominate / world + process) against (nominate + process).
+class ShardedCycle:
+    """One rank's side. `eng`: Engine (HIP) or the emulated engine of the test suite; `dist`: torch.distributed (nccl = RCCL, gloo on
+    CPU) or None for world 1; `device`: where the exchange buffer lives."""
+
+    def __init__(self, eng, dist, rank: int, world: int, device="cpu"):
+        self.eng, self.dist, self.rank, self.world, self.device = eng, dist, rank, world, device
+        self.buf = None
+        self.stats = dict(cycles=0, words=0)
+
+    def owner(self, heads):
+        """Heads are dealt round-robin (nominate cost per head varies by orders of magnitude between Fit heads and preemptors; consecutive
+        heads are consecutive ClusterQueues, i.e. siblings with similar cost, so the deal balances)."""
+        import numpy as np
+        return (np.arange(heads.n) % self.world).astype(np.int32)
+
+    def cycle(self, heads, tgt_cap=None, rsn_cap: int = 0, out=None):
+        import numpy as np
+        import torch
+        from .api import Decisions
+        d = out if out is not None else Decisions(heads, tgt_cap=tgt_cap, rsn_cap=rsn_cap)
+        words = self.eng.shard_words(heads, d, self.world)
+        if self.buf is None or self.buf.numel() < words:
+            self.buf = torch.zeros(words + words // 8, dtype=torch.int64, device=self.device)
+        x = self.buf[:words]
+        mine = (self.owner(heads) == self.rank).astype(np.uint8) if self.world > 1 else None
+        self.eng.nominate_shard(heads, mine, self.world, self.rank, x.data_ptr(), d)     # (synchronous: the buffer is complete on return)
+        if self.world > 1:
+            self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM)                               # <- the one collective of the cycle
+            if self.device != "cpu":
+                torch.cuda.current_stream().synchronize()
+        self.eng.process_merged(self.world, self.rank, x.data_ptr(), d)
+        self.stats["cycles"] += 1; self.stats["words"] = words
+        return d
 
 
 # ---- ONE TAS flavor split across ranks (BASELINE.json configs[4]: "RCCL all-reduce of domain-usage deltas"; SURVEY §8e) ----------

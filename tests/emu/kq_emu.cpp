@@ -101,6 +101,16 @@ struct EmuBackend {
       for (int i = slot; i < nd; i += slots) nominate_head(k, w, k.defer_list[i], slot);
     }
   }
+  void launch_shard_export(const K& k, size_t nps_total, int rsn_win) {
+    for (int h = 0; h < k.H.n; h++) shard_export_head(k, h, nps_total);
+    shard_export_misc(k, nps_total, rsn_win);
+    for (int t = 0; t < k.shard.pool_cap; t++) shard_export_pool(k, nps_total, rsn_win, t);
+  }
+  void launch_shard_import(const K& k, size_t nps_total, int rsn_win) {
+    for (int h = 0; h < k.H.n; h++) shard_import_head(k, h, nps_total);
+    shard_import_misc(k, nps_total);
+    for (int t = 0; t < k.shard.world * k.shard.pool_cap; t++) shard_import_pool(k, nps_total, rsn_win, t);
+  }
   void launch_records(const K& k) {
     for (int e = 0; e < k.H.n; e++) for (int c = 0; c < FU * FD; c++) rec_fill_static(k, e, c);
   }
@@ -199,6 +209,9 @@ void kqe_disable_scan_search(void* e, int on) { ((EmuEngine*)e)->cs_disable = on
 void kqe_fs_check(int on) { kq::g_fs_check = on; }
 void kqe_force_exact_drs(void* e, int on) { ((EmuEngine*)e)->force_exact_drs = on != 0; }
 int kqe_cycle_run(void* e, const kq_heads* h, kq_decisions* out) { return ((EmuEngine*)e)->cycle_run(h, out); }
+int kqe_cycle_shard_words(void* e, const kq_heads* h, const kq_decisions* out, int32_t world, int64_t* words) { return ((EmuEngine*)e)->cycle_shard_words(h, out, world, words); }
+int kqe_cycle_nominate_shard(void* e, const kq_heads* h, const uint8_t* mine, int32_t world, int32_t rank, void* x, kq_decisions* out) { return ((EmuEngine*)e)->cycle_nominate_shard(h, mine, world, rank, x, out); }
+int kqe_cycle_process_merged(void* e, int32_t world, int32_t rank, const void* x, kq_decisions* out) { return ((EmuEngine*)e)->cycle_process_merged(world, rank, x, out); }
 int kqe_heads_put(void* e, const kq_heads* h, int32_t batch) { return batch < 0 ? KQ_EINVAL : ((EmuEngine*)e)->heads_put(h, batch + 1); }
 int kqe_cycle_run_resident(void* e, int32_t batch, kq_decisions* out) { return batch < 0 ? KQ_EINVAL : ((EmuEngine*)e)->cycle_exec(batch + 1, out); }
 int kqe_nominate_run_resident(void* e, int32_t batch, kq_decisions* out) { return batch < 0 ? KQ_EINVAL : ((EmuEngine*)e)->cycle_exec(batch + 1, out, true); }

@@ -45,6 +45,12 @@ class EmuEngine:
         assert lib().kqe_read_planes(self.h, None, F.ptr(us), None) == 0
         return us
 
+    def read_usage_work(self):
+        """The cycle's private usage plane as processEntry left it."""
+        u = np.zeros(self.snap.N * self.snap.n_fr, np.int64)
+        lib().kqe_read_usage(self.h, F.ptr(u))
+        return u
+
     def derive(self):
         assert lib().kqe_snapshot_derive(self.h) == 0
         n = self.snap.N * self.snap.n_fr
@@ -97,6 +103,20 @@ class EmuEngine:
 
     def try_commit(self):
         return lib().kqe_cycle_commit(self.h, None)
+
+    def shard_words(self, heads, out, world):
+        w = C.c_int64()
+        self._ok(lib().kqe_cycle_shard_words(self.h, C.byref(heads.struct()), C.byref(out.struct()), C.c_int32(world), C.byref(w)))
+        return w.value
+
+    def nominate_shard(self, heads, mine, world, rank, xbuf_ptr, out):
+        m = None if mine is None else np.ascontiguousarray(mine, np.uint8)
+        self._ok(lib().kqe_cycle_nominate_shard(self.h, C.byref(heads.struct()), None if m is None else F.ptr(m), C.c_int32(world), C.c_int32(rank),
+                                                C.c_void_p(xbuf_ptr), C.byref(out.struct())))
+
+    def process_merged(self, world, rank, xbuf_ptr, out):
+        self._ok(lib().kqe_cycle_process_merged(self.h, C.c_int32(world), C.c_int32(rank), C.c_void_p(xbuf_ptr), C.byref(out.struct())))
+        return out
 
     def certificate(self, delta_ptr):
         n_tree = int((self.snap.arrays["parent"] < 0).sum())
