@@ -95,11 +95,12 @@ extern "C" {
 #define KQ_GATE_PRIORITIZE_PREEMPTORS         (1u << 7)  /* PrioritizePreemptorWorkloads (off)    */
 #define KQ_GATE_QUOTA_CHECK_STRATEGY          (1u << 8)
 #define KQ_GATE_SCHEDULING_EQUIVALENCE_HASHING (1u << 9) /* SchedulingEquivalenceHashing (pending side only)  */
+#define KQ_GATE_ELASTIC_JOBS                  (1u << 10) /* ElasticJobsViaWorkloadSlices (kq_heads.slice_*)        */
 #define KQ_GATES_DEFAULT (KQ_GATE_FLAVOR_FUNGIBILITY | KQ_GATE_PRESERVE_SCAN_PROGRESS |            \
                           KQ_GATE_PARTIAL_ADMISSION | KQ_GATE_PRIORITY_SORTING_IN_COHORT |         \
                           KQ_GATE_FS_PREEMPT_WITHIN_NOMINAL | KQ_GATE_FS_PRIORITIZE_NON_BORROWING |\
                           KQ_GATE_RECOMPUTE_ON_OVERLAP | KQ_GATE_QUOTA_CHECK_STRATEGY |            \
-                          KQ_GATE_SCHEDULING_EQUIVALENCE_HASHING)
+                          KQ_GATE_SCHEDULING_EQUIVALENCE_HASHING | KQ_GATE_ELASTIC_JOBS)
 
 /* fair-sharing preemption strategies (apis/config/v1beta2; preemption.go:363-379) */
 #define KQ_FS_LESS_THAN_OR_EQUAL_TO_FINAL_SHARE 0  /* rule S2-a */
@@ -193,6 +194,16 @@ typedef struct kq_heads {
   const int64_t* last_cycle;        /* [n] LastAssignment.SchedulingCycle */
   const uint64_t* last_hash;        /* [n] LastAssignment.SchedulingHash (0 = unknown) */
   const uint64_t* hash;             /* [n] Info.SchedulingHash (0 = unknown) */
+  /* Workload slices (ElasticJobsViaWorkloadSlices): a head that replaces an admitted slice of the same job
+   * (workloadslicing.ReplacedWorkloadSlice, scheduler.go:883: annotation lookup in queue.Workloads, same namespace — host-evaluated).
+   * All NULL: no head replaces a slice. The old slice's podsets are aligned with the head's by index (replaced.TotalRequests[psID],
+   * flavorassigner.go:1127; the host also resolves findOldPodSetRequest's lookup by podset NAME to that index). */
+  const int32_t* slice_row;         /* [n] admitted row of the replaced slice (a row of the head's ClusterQueue), -1 = none */
+  const int32_t* ps_slice_count;    /* [n_ps] replaced.TotalRequests[i].Count (Assignment.TotalRequestsFor :265) */
+  const int32_t* req_slice_flavor;  /* [n_req] flavor the old slice holds for (podset, resource) (PodSetResources.Flavors), -1 = none */
+  const int64_t* req_slice_qty;     /* [n_req] the old slice's request for (podset, resource) */
+  const int32_t* ps_slice_pods_flavor; /* [n_ps] the same two for the `pods` request the assigner injects (flavorassigner.go:743-749) */
+  const int64_t* ps_slice_pods_qty; /* [n_ps] */
 } kq_heads;
 
 /* ---- decisions -------------------------------------------------------------------------------- */
@@ -225,6 +236,9 @@ typedef struct kq_heads {
 #define KQ_REASON_IN_COHORT_RECLAMATION          1
 #define KQ_REASON_IN_COHORT_FAIR_SHARING         2
 #define KQ_REASON_IN_COHORT_RECLAIM_WHILE_BORROWING 3
+#define KQ_REASON_REPLACED_SLICE                 4  /* not a preemption: the old workload slice the head replaces. It is part of the
+                                                      * targets while the cycle runs (scheduler.go:883-899, :771-777); FindReplacedSliceTarget
+                                                      * (:492) takes it out before issuePreemptions and Scheduler.admit finishes it (:605) */
 
 /* Why a flavor was not assigned as Fit: the operands of one Status.reasons string (flavorassigner.go:349). The caller formats
  * the text (shim/go/messages.go; kueue_amd/messages.py), so no string crosses the boundary. */
@@ -234,6 +248,8 @@ typedef struct kq_heads {
 #define KQ_RSN_NOT_IN_NOMINATION     3  /* :1097: flavor skipped by the nomination mapping; resource = the scan's resource name   */
 #define KQ_RSN_FLAVOR_INELIGIBLE     4  /* :1105-1113: checkFlavorForPodSets failed (ps_flavor_ok bit clear); the host knows the text */
 #define KQ_RSN_RESOURCE_UNAVAILABLE  5  /* :1080: no resource group of the ClusterQueue covers `resource`                         */
+#define KQ_RSN_SLICE_FLAVOR_MISMATCH 6  /* :1132-1137: "could not assign %s flavor since the original workload is assigned: %s";
+                                         * flavor = the flavor tried, a = the old slice's flavor for `resource` (-1: none)          */
 #define KQ_RSN_TRUNCATED           255  /* not a reference reason: the head produced more records than its window holds; the list
                                          * returned for that head is incomplete (flavor = resource = -1). Retry with a larger rsn_cap. */
 

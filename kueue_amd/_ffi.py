@@ -32,6 +32,7 @@ KQ_GATE_RECOMPUTE_ON_OVERLAP = 1 << 6
 KQ_GATE_PRIORITIZE_PREEMPTORS = 1 << 7
 KQ_GATE_QUOTA_CHECK_STRATEGY = 1 << 8
 KQ_GATE_SCHEDULING_EQUIVALENCE_HASHING = 1 << 9
+KQ_GATE_ELASTIC_JOBS = 1 << 10
 KQ_GATES_DEFAULT = (
     KQ_GATE_FLAVOR_FUNGIBILITY
     | KQ_GATE_PRESERVE_SCAN_PROGRESS
@@ -42,6 +43,7 @@ KQ_GATES_DEFAULT = (
     | KQ_GATE_RECOMPUTE_ON_OVERLAP
     | KQ_GATE_QUOTA_CHECK_STRATEGY
     | KQ_GATE_SCHEDULING_EQUIVALENCE_HASHING
+    | KQ_GATE_ELASTIC_JOBS
 )
 GATE_BY_NAME = {
     "SchedulingEquivalenceHashing": KQ_GATE_SCHEDULING_EQUIVALENCE_HASHING,
@@ -54,6 +56,7 @@ GATE_BY_NAME = {
     "RecomputeAssignmentUponPreemptionTargetsOverlap": KQ_GATE_RECOMPUTE_ON_OVERLAP,
     "PrioritizePreemptorWorkloads": KQ_GATE_PRIORITIZE_PREEMPTORS,
     "QuotaCheckStrategy": KQ_GATE_QUOTA_CHECK_STRATEGY,
+    "ElasticJobsViaWorkloadSlices": KQ_GATE_ELASTIC_JOBS,
 }
 
 # modes / status / actions
@@ -68,6 +71,7 @@ REASONS = {
     1: "InCohortReclamation",
     2: "InCohortFairSharing",
     3: "InCohortReclaimWhileBorrowing",
+    4: "ReplacedWorkloadSlice",   # not a preemption reason: the old slice the head replaces (kq_engine.h KQ_REASON_REPLACED_SLICE)
 }
 REASON_BY_NAME = {v: k for k, v in REASONS.items()}
 
@@ -135,6 +139,8 @@ class kq_heads(C.Structure):
         ("ps_flavor_ok", u64p),
         ("ps_last_tried", i32p),
         ("last_generation", i64p), ("last_cycle", i64p), ("last_hash", u64p), ("hash", u64p),
+        ("slice_row", i32p), ("ps_slice_count", i32p), ("req_slice_flavor", i32p), ("req_slice_qty", i64p),
+        ("ps_slice_pods_flavor", i32p), ("ps_slice_pods_qty", i64p),
     ]
 
 

@@ -211,6 +211,9 @@ class Workload:
     is_preemptor: bool = False
     last_assignment: Optional[LastAssignment] = None
     scheduling_hash: int = 0
+    # ElasticJobsViaWorkloadSlices: name of the ADMITTED workload (same ClusterQueue) this one replaces (workloadslicing.ReplacedWorkloadSlice,
+    # scheduler.go:883); the old slice's podsets (count, requests, flavors) are read from that admitted workload, aligned by podset name
+    replaces: Optional[str] = None
 
     @property
     def UID(self) -> str:
@@ -556,6 +559,25 @@ class Heads:
         a["last_cycle"] = np.array([la_get(w, "scheduling_cycle") for w in self.workloads], dtype=np.int64)
         a["last_hash"] = np.array([la_get(w, "scheduling_hash") for w in self.workloads], dtype=np.uint64)
         a["hash"] = np.array([w.scheduling_hash for w in self.workloads], dtype=np.uint64)
+        if any(w.replaces for w in self.workloads):
+            # workload slices: the replaced slice's columns next to the head's own (kq_heads.slice_*)
+            srow, scnt, sfl, sq, spf, spq = [], [], [], [], [], []
+            for w in self.workloads:
+                old = snap.admitted[snap.adm_index[w.replaces]] if w.replaces else None
+                srow.append(snap.adm_index[w.replaces] if old is not None else -1)
+                for pi, ps in enumerate(w.pod_sets):
+                    ops = None
+                    if old is not None:
+                        ops = next((o for o in old.pod_sets if o.name == ps.name), None)   # findOldPodSetRequest: by podset name
+                    scnt.append(ops.count if ops else 0)
+                    for r in ps.requests:
+                        sfl.append(snap.flavor_index[ops.flavors[r]] if ops and r in ops.flavors else -1)
+                        sq.append(ops.requests.get(r, 0) if ops else 0)
+                    spf.append(snap.flavor_index[ops.flavors["pods"]] if ops and "pods" in ops.flavors else -1)
+                    spq.append((ops.requests.get("pods", ops.count) if "pods" in ops.flavors else 0) if ops else 0)
+            a["slice_row"] = np.array(srow, np.int32); a["ps_slice_count"] = np.array(scnt, np.int32)
+            a["req_slice_flavor"] = np.array(sfl, np.int32); a["req_slice_qty"] = np.array(sq, np.int64)
+            a["ps_slice_pods_flavor"] = np.array(spf, np.int32); a["ps_slice_pods_qty"] = np.array(spq, np.int64)
         self.arrays = a
         self.n = n
         self.n_ps = len(ps_count)
@@ -597,6 +619,9 @@ class Heads:
                  ps_req_off=np.concatenate([[0], np.cumsum(r1 - r0)]).astype(np.int32), req_res=a["req_res"][req_idx], req_qty=a["req_qty"][req_idx],
                  ps_flavor_ok=rows("ps_flavor_ok", nfw), ps_last_tried=rows("ps_last_tried", nR).copy(),
                  last_generation=a["last_generation"][idx].copy(), last_cycle=a["last_cycle"][idx].copy(), last_hash=a["last_hash"][idx].copy(), hash=a["hash"][idx])
+        if "slice_row" in a:  # workload slices travel with their heads
+            b.update(slice_row=a["slice_row"][idx], ps_slice_count=a["ps_slice_count"][ps_idx], req_slice_flavor=a["req_slice_flavor"][req_idx],
+                     req_slice_qty=a["req_slice_qty"][req_idx], ps_slice_pods_flavor=a["ps_slice_pods_flavor"][ps_idx], ps_slice_pods_qty=a["ps_slice_pods_qty"][ps_idx])
         h = Heads.from_arrays(self.snap, b, cycle=self.cycle if cycle is None else cycle)
         if self.workloads is not None:
             h.workloads = [self.workloads[int(i)] for i in idx]

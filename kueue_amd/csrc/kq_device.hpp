@@ -280,6 +280,11 @@ struct DHeads {
   const int32_t* ps_last_tried;
   const int64_t *last_generation, *last_cycle;
   const uint64_t *last_hash, *hash;
+  // workload slices (kq_heads.slice_*): all null when no head of the batch replaces a slice
+  const int32_t *slice_row, *ps_slice_count, *req_slice_flavor;
+  const int64_t* req_slice_qty;
+  const int32_t* ps_slice_pods_flavor;
+  const int64_t* ps_slice_pods_qty;
 };
 
 // One reason why a flavor was not assigned as Fit: the operands of a Status.reasons string (flavorassigner.go:349), see KQ_RSN_*.
@@ -683,6 +688,8 @@ struct Wave {
   int64_t req_qty[KQ_MAXREQ];
   uint8_t req_done[KQ_MAXREQ];   // resource already has a flavor from its resource group (:819)
   int8_t req_rg[KQ_MAXREQ];      // resource group (index inside the ClusterQueue's groups) covering the request, -1 = none
+  uint8_t req_src[KQ_MAXREQ];    // position of the request in the head's own list (0xff: the injected `pods`): index of its workload-slice columns
+  int slice_row;                  // admitted row of the workload slice the head replaces, -1 = none (ElasticJobsViaWorkloadSlices)
   int32_t req_flavor[KQ_MAXREQ], req_borrow[KQ_MAXREQ], req_tried[KQ_MAXREQ];
   uint8_t req_mode[KQ_MAXREQ];
   // Assignment.Usage.Quota.Assigned (:1017-1041) + per-entry flags
@@ -1939,6 +1946,17 @@ KQ_DEV void rsn_push(const K& k, Wave& w, int code, int podset, int flavor, int 
 // LEAN (k_nominate's first pass): no victim search is linked in. A cell that needs SimulatePreemption is answered in place when the
 // ClusterQueue cannot preempt at all (both searches return "no candidates" before reading anything, preemption.go:284-296 / :536-547);
 // otherwise the head is handed to the full pass (w.defer_head) and this call's outputs are dropped.
+// workload slices: the flavor / request the replaced slice holds for request slot `a` of podset psg (replaceWorkloadSlice.TotalRequests
+// [psID].Flavors / .Requests, flavorassigner.go:1127-1143)
+KQ_DEV void slice_of(const K& k, const Wave& w, int psg, int a, int* flavor, int64_t* qty) {
+  const DHeads& H = k.H;
+  const int src = w.req_src[a];
+  if (src == 0xff) { *flavor = H.ps_slice_pods_flavor ? H.ps_slice_pods_flavor[psg] : -1; *qty = H.ps_slice_pods_qty ? H.ps_slice_pods_qty[psg] : 0; return; }
+  const int e = H.ps_req_off[psg] + src;
+  *flavor = H.req_slice_flavor ? H.req_slice_flavor[e] : -1;
+  *qty = H.req_slice_qty ? H.req_slice_qty[e] : 0;
+}
+
 template <bool LEAN>
 KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed,
                            const int* counts, bool nominate_map) {
@@ -1968,7 +1986,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
       if (scale) q = sat_mul(q / (int64_t)count, (int64_t)new_count);
       const int r = H.req_res[e0 + a];
       if (pods_cov && r == S.pods_res) { q = scale ? new_count : count; is_pods = true; }
-      w.req_res[a] = r; w.req_qty[a] = q;
+      w.req_res[a] = r; w.req_qty[a] = q; w.req_src[a] = (uint8_t)a;
     }
     const bool have_pods = wballot(is_pods) != 0;
     wsync();
@@ -1976,7 +1994,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
       int n = ne;
       if (pods_cov && !have_pods) {
         if (n >= KQ_MAXREQ) *O.error = KQ_EUNSUPPORTED;
-        else { w.req_res[n] = S.pods_res; w.req_qty[n] = scale ? new_count : count; n++; }
+        else { w.req_res[n] = S.pods_res; w.req_qty[n] = scale ? new_count : count; w.req_src[n] = 0xff; n++; }
       }
       w.nreq = n;
     }
@@ -1985,21 +2003,21 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
       const int n = w.nreq;
 #ifdef KQ_HOST_EMU
       for (int a = 1; a < n; a++) {  // 1-lane emulation: insertion sort by resource_order
-        int r = w.req_res[a]; int64_t q = w.req_qty[a]; int b = a - 1;
-        while (b >= 0 && S.resource_order[w.req_res[b]] > S.resource_order[r]) { w.req_res[b + 1] = w.req_res[b]; w.req_qty[b + 1] = w.req_qty[b]; b--; }
-        w.req_res[b + 1] = r; w.req_qty[b + 1] = q;
+        int r = w.req_res[a]; int64_t q = w.req_qty[a]; uint8_t sr = w.req_src[a]; int b = a - 1;
+        while (b >= 0 && S.resource_order[w.req_res[b]] > S.resource_order[r]) { w.req_res[b + 1] = w.req_res[b]; w.req_qty[b + 1] = w.req_qty[b]; w.req_src[b + 1] = w.req_src[b]; b--; }
+        w.req_res[b + 1] = r; w.req_qty[b + 1] = q; w.req_src[b + 1] = sr;
       }
       for (int a = 0; a < n; a++) { w.req_done[a] = 0; w.req_rg[a] = S.cq_res_rg[(size_t)w.cq * nR + w.req_res[a]]; }
 #else
       // device: one lane per request (n <= KQ_MAXREQ < 64): rank by pairwise compare, then a scatter — no serial loop, one round trip
-      int r = 0, ord = 0, rank = 0; int64_t q = 0;
-      if (lane < n) { r = w.req_res[lane]; q = w.req_qty[lane]; ord = S.resource_order[r]; }
+      int r = 0, ord = 0, rank = 0, sr = 0; int64_t q = 0;
+      if (lane < n) { r = w.req_res[lane]; q = w.req_qty[lane]; sr = w.req_src[lane]; ord = S.resource_order[r]; }
       for (int b = 0; b < n; b++) {
         const int ob = wshfl_i32(ord, b);
         if (lane < n && (ob < ord || (ob == ord && b < lane))) rank++;
       }
       wsync();
-      if (lane < n) { w.req_res[rank] = r; w.req_qty[rank] = q; w.req_done[rank] = 0; w.req_rg[rank] = S.cq_res_rg[(size_t)w.cq * nR + r]; }
+      if (lane < n) { w.req_res[rank] = r; w.req_qty[rank] = q; w.req_src[rank] = (uint8_t)sr; w.req_done[rank] = 0; w.req_rg[rank] = S.cq_res_rg[(size_t)w.cq * nR + r]; }
 #endif
       if (lane == 0) w.bytes += (int64_t)n * 16;  // requests in + requests echoed in the PodSetAssignment
     }
@@ -2051,9 +2069,16 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
           bool ok = (H.ps_flavor_ok[(size_t)psg * S.nfw + (f >> 6)] >> (f & 63)) & 1;  // checkFlavorForPodSets :1212 (host-evaluated)
           uint8_t pm = PM_SKIP; int32_t borrow = ok ? 0 : KQ_RSN_FLAVOR_INELIGIBLE; int64_t val = 0, aux = 0;  // a skipped cell keeps WHY in `borrow`
           if (nominate_map && k.X.nom[((size_t)slot * KQ_MAXPS + pi) * nR + res_name] != f) { ok = false; borrow = KQ_RSN_NOT_IN_NOMINATION; }  // shouldSkipBasedOnNominationMapping :1422 (checked first, :1096)
+          bool mismatch = false;
           if (ok) {
             int fr = f * nR + w.f_res[kk];
-            val = a_addi(assumed_usage(w, fr), w.f_qty[kk]);
+            int64_t reqv = w.f_qty[kk];
+            if (w.slice_row >= 0) {  // the flavor of the slice it replaces, and only the delta (flavorassigner.go:1125-1145)
+              int sfl; int64_t sq;
+              slice_of(k, w, psg, w.f_slot[kk], &sfl, &sq);
+              if (sfl != f) mismatch = true; else reqv -= sq;   // (a mismatch leaves val unreduced: the `break` comes before the subtraction)
+            }
+            val = a_addi(assumed_usage(w, fr), reqv);
             int64_t avail, maxcap, nominal;
             bool may_reclaim = false;
             int height = 0;
@@ -2080,7 +2105,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
               else pm = PM_NOFIT | 0x80;  // noFit with a "insufficient unused quota" reason and borrow kept
             }
           }
-          w.cell_pm[c] = pm; w.cell_borrow[c] = borrow; w.cell_val[c] = val; w.cell_aux[c] = aux;
+          w.cell_pm[c] = pm | (mismatch ? 0x40 : 0); w.cell_borrow[c] = borrow; w.cell_val[c] = val; w.cell_aux[c] = aux;
         }
         wsync();
         // ---- recomputation inside k_process_fair: every cell of the pass that needs a SimulatePreemption is posted as one batch ----
@@ -2096,7 +2121,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
                   const int c = jj * nf + kk;
                   w.cell_task[c] = 0xff;
                   if (w.cell_pm[jj * nf] == PM_SKIP) continue;
-                  if ((w.cell_pm[c] & 0x7f) == PM_NEEDS) {
+                  if ((w.cell_pm[c] & 0x3f) == PM_NEEDS) {
                     hbox->task[nt] = HelpTask{S.rg_flavor[f0 + cs + jj] * nR + w.f_res[kk], w.cell_borrow[c], w.cell_val[c]};
                     w.cell_task[c] = (uint8_t)nt++;
                   }
@@ -2121,11 +2146,23 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
           int rep_pm = PM_FIT; int64_t rep_borrow = 0; int64_t rep_key = pref_key(PM_FIT, 0, w.pol);
           for (int kk = 0; kk < nf; kk++) {
             int c = jj * nf + kk;
-            int pm = w.cell_pm[c] & 0x7f; int borrow = w.cell_borrow[c];
+            int pm = w.cell_pm[c] & 0x3f; int borrow = w.cell_borrow[c];
             bool had_status = (w.cell_pm[c] & 0x80) || pm == PM_NOFIT || pm == PM_NEEDS;
+            int64_t reqv = w.f_qty[kk];
+            if (w.slice_row >= 0) {
+              int sfl; int64_t sq;
+              slice_of(k, w, psg, w.f_slot[kk], &sfl, &sq);
+              if (w.cell_pm[c] & 0x40) {
+                // the flavor is not the replaced slice's: worstGranularMode() and a reason; the closure goes on to fitsResourceQuota
+                // (its reasons are appended too) and returns at the noFit check below (flavorassigner.go:1130-1162)
+                if (lane == 0) rsn_push(k, w, KQ_RSN_SLICE_FLAVOR_MISMATCH, pi, f, w.f_res[kk], sfl, 0, 0);
+                reasons++;
+                rep_pm = PM_NOFIT; rep_borrow = 0; rep_key = -1;
+              } else reqv -= sq;
+            }
             if (had_status && lane == 0) {  // the string fitsResourceQuota formats (:1353-1373)
               const int fr = f * nR + w.f_res[kk];
-              if (pm == PM_NOFIT && !(w.cell_pm[c] & 0x80)) rsn_push(k, w, KQ_RSN_EXCEEDS_MAX_CAPACITY, pi, f, w.f_res[kk], assumed_usage(w, fr), w.f_qty[kk], w.cell_aux[c]);
+              if (pm == PM_NOFIT && !(w.cell_pm[c] & 0x80)) rsn_push(k, w, KQ_RSN_EXCEEDS_MAX_CAPACITY, pi, f, w.f_res[kk], assumed_usage(w, fr), reqv, w.cell_aux[c]);
               else rsn_push(k, w, KQ_RSN_INSUFFICIENT_UNUSED, pi, f, w.f_res[kk], w.cell_aux[c], 0, 0);
             }
             if (rep_pm == PM_NOFIT) { if (had_status) reasons++; continue; }  // oracle result unused past a noFit (:1161)
@@ -2216,7 +2253,9 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
             if (w.nuse >= KQ_MAXU) { *O.error = KQ_EUNSUPPORTED; continue; }
             e = w.nuse++; w.use_fr[e] = fr; w.use_qty[e] = 0; w.use_mode[e] = M_FIT;
           }
-          w.use_qty[e] = a_addi(w.use_qty[e], w.req_qty[a]);
+          int64_t amount = w.req_qty[a];
+          if (w.slice_row >= 0) { int sfl; int64_t sq; slice_of(k, w, psg, a, &sfl, &sq); amount -= sq; }  // Assignment.append :1028-1035
+          w.use_qty[e] = a_addi(w.use_qty[e], amount);
           if (w.req_mode[a] < w.use_mode[e]) w.use_mode[e] = w.req_mode[a];
         }
         for (int a = 0; a < w.nreq; a++) if (w.req_done[a]) w.bytes += 16;  // (flavor, mode, borrow, tried) out
@@ -2256,6 +2295,7 @@ KQ_DEV void prepare_target_slots(const K& k, Wave& w) {
     for (int pi = 0; pi < w.nps; pi++) {
       int psg = w.ps_base + pi;
       int count = H.ps_count[psg], newc = O.ps_count[psg];
+      if (w.slice_row >= 0) newc = count - (H.ps_slice_count ? H.ps_slice_count[psg] : 0);  // TotalRequestsFor :265-267
       for (int e = H.ps_req_off[psg]; e < H.ps_req_off[psg + 1]; e++) {
         int64_t q = H.req_qty[e];
         if (count != 0 && count != newc) q = sat_mul(q / (int64_t)count, (int64_t)newc);
@@ -2299,6 +2339,7 @@ KQ_DEV void load_head(const K& k, Wave& w, int h) {
     for (int i = 0; i < KQ_MAXD; i++) w.path[i] = S.path[(size_t)w.cq * KQ_MAXD + i];
     w.has_last = (w.hflags & KQ_HEAD_HAS_LAST_ASSIGNMENT) ? 1 : 0;
     w.bytes = 0;
+    w.slice_row = (H.slice_row && gate(k, KQ_GATE_ELASTIC_JOBS)) ? H.slice_row[h] : -1;
     if (w.nps > KQ_MAXPS) *k.O.error = KQ_EUNSUPPORTED;
   }
   wsync();
@@ -2307,7 +2348,7 @@ KQ_DEV void load_head(const K& k, Wave& w, int h) {
 // Scheduler.getAssignments + getInitialAssignments (scheduler.go:821-924). Leaves the chosen
 // assignment in O.flavor/res_mode/tried_idx/ps_count + w.use_*/w.rep_mode/w.borrowing and its targets in the
 // returned Search (w.ntgt rows).
-KQ_DEV Search get_assignments(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed, bool nominate_map) {
+KQ_DEV Search get_assignments_inner(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed, bool nominate_map) {
   const DHeads& H = k.H;
   Search s = make_search(k, w, slot, usage, removed);
   assign_flavors<false>(k, w, slot, usage, removed, nullptr, nominate_map);
@@ -2363,6 +2404,32 @@ KQ_DEV Search get_assignments(const K& k, Wave& w, int slot, const int64_t* usag
   return s;
 }
 
+// workloadslicing.ReplacedWorkloadSlice (scheduler.go:883-899): the slice the head replaces is a target of every assignment that comes
+// with targets at all — Fit: the slice alone; Preempt with victims (also through the PodSetReducer): the slice and the victims; Preempt
+// without victims / NoFit: nil. Appended (targets are a set; the host sorts them). If the victim search named the slice itself it is
+// listed once, under the search's reason (kq_engine.h KQ_REASON_REPLACED_SLICE).
+KQ_DEV Search get_assignments(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed, bool nominate_map) {
+  // ReplacedWorkloadSlice looks the old slice up in queue.Workloads (workloadslicing.go:371): inside an overlap recomputation
+  // (SimulateWorkloadRemoval of the other preemptions' victims, scheduler.go:726-727) a slice that was preempted is not there any more
+  // and the head is assigned like any other workload
+  const int slice_saved = w.slice_row;
+  if (slice_saved >= 0 && removed && removed[slice_saved]) { wsync(); if (lane_id() == 0) w.slice_row = -1; wsync(); }
+  Search s = get_assignments_inner(k, w, slot, usage, removed, nominate_map);
+  if (w.slice_row != slice_saved) { wsync(); if (lane_id() == 0) w.slice_row = slice_saved; wsync(); return s; }
+  if (w.slice_row >= 0 && (w.rep_mode == M_FIT || w.ntgt > 0)) {
+    if (lane_id() == 0) {
+      bool dup = false;
+      for (int t = 0; t < w.ntgt; t++) if (s.trow[t] == w.slice_row) dup = true;
+      if (!dup) {
+        if (w.ntgt >= k.X.tgt_cap) *k.O.error = KQ_ECAPACITY;
+        else { s.trow[w.ntgt] = w.slice_row; s.treason[w.ntgt] = KQ_REASON_REPLACED_SLICE; w.ntgt++; }
+      }
+    }
+    wsync();
+  }
+  return s;
+}
+
 // publish the head's assignment internals for the process kernel
 KQ_DEV void publish_assignment(const K& k, Wave& w, const Search& s, int h) {
   const DOut& O = k.O;
@@ -2402,7 +2469,7 @@ KQ_DEV void nominate_head_lean(const K& k, Wave& w, int h) {
   if (lane_id() == 0) { if (w.has_last && last_assignment_outdated(k, h, w.cq)) w.has_last = 0; w.defer_head = 0; }
   wsync();
   assign_flavors<true>(k, w, 0, k.usage, nullptr, nullptr, false);
-  bool defer = w.defer_head != 0;
+  bool defer = w.defer_head != 0 || w.slice_row >= 0;  // (a head that replaces a workload slice always has a target: the full pass publishes it)
   if (!defer && w.rep_mode != M_FIT) {
     // getInitialAssignments (scheduler.go:880-924) past the first Assign: Preempt asks GetTargets, then the partial-admission search
     const bool can_search = KQ_POL_WITHIN_CQ(w.pol) != KQ_POLICY_NEVER || (w.plen > 1 && KQ_POL_RECLAIM(w.pol) != KQ_POLICY_NEVER);

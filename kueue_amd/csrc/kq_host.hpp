@@ -477,6 +477,12 @@ template <class B> struct EngineT {
       if (slots > KQ_MAXU) return fail(KQ_EUNSUPPORTED, "more usage entries than KQ_MAXU");
       cap = std::max(cap, slots);
     }
+    if (h->slice_row)
+      for (int i = 0; i < h->n; i++) {
+        const int row = h->slice_row[i];
+        if (row < -1 || row >= prep.n_adm) return fail(KQ_EINVAL, "slice_row out of range");
+        if (row >= 0 && prep.adm_cq[row] != h->cq[i]) return fail(KQ_EINVAL, "slice_row: the replaced slice is not admitted in the head's ClusterQueue");
+      }
     *slot_cap = cap;
     if (max_nps) *max_nps = mnps;
     return KQ_OK;
@@ -506,6 +512,9 @@ template <class B> struct EngineT {
     const size_t o_cq = place(n * 4), o_prio = place(n * 8), o_ts = place(n * 8), o_flags = place(n * 4), o_psoff = place((n + 1) * 4);
     const size_t o_pscnt = place(nps * 4), o_psmin = place(nps * 4), o_reqoff = place((nps + 1) * 4), o_rres = place(nreqs * 4), o_rqty = place(nreqs * 8);
     const size_t o_fok = place(nps * nfw * 8), o_ltried = place(nps * nR * 4), o_lgen = place(n * 8), o_lcyc = place(n * 8), o_lhash = place(n * 8), o_hash = place(n * 8);
+    const bool sl = h->slice_row != nullptr;
+    const size_t o_srow = place(sl ? n * 4 : 0), o_scnt = place(sl ? nps * 4 : 0), o_sfl = place(sl ? nreqs * 4 : 0), o_sq = place(sl ? nreqs * 8 : 0),
+                 o_spf = place(sl ? nps * 4 : 0), o_spq = place(sl ? nps * 8 : 0);
     const size_t total = off;
     if (hup_cap < total) { if (hup) be.free_host(hup); hup_cap = total + total / 4; hup = (uint8_t*)be.alloc_host(hup_cap); }
     if (!hup) { hup_cap = 0; return fail(KQ_EDEVICE, "pinned staging buffer for the heads could not be allocated"); }
@@ -521,6 +530,14 @@ template <class B> struct EngineT {
     if (h->last_cycle) put(o_lcyc, h->last_cycle, n * 8); else fill(o_lcyc, 0, n * 8);
     if (h->last_hash) put(o_lhash, h->last_hash, n * 8); else fill(o_lhash, 0, n * 8);
     if (h->hash) put(o_hash, h->hash, n * 8); else fill(o_hash, 0, n * 8);
+    if (sl) {  // workload slices: absent columns read as "no flavor / nothing requested"
+      put(o_srow, h->slice_row, n * 4);
+      if (h->ps_slice_count) put(o_scnt, h->ps_slice_count, nps * 4); else fill(o_scnt, 0, nps * 4);
+      if (h->req_slice_flavor) put(o_sfl, h->req_slice_flavor, nreqs * 4); else fill(o_sfl, 0xff, nreqs * 4);
+      if (h->req_slice_qty) put(o_sq, h->req_slice_qty, nreqs * 8); else fill(o_sq, 0, nreqs * 8);
+      if (h->ps_slice_pods_flavor) put(o_spf, h->ps_slice_pods_flavor, nps * 4); else fill(o_spf, 0xff, nps * 4);
+      if (h->ps_slice_pods_qty) put(o_spq, h->ps_slice_pods_qty, nps * 8); else fill(o_spq, 0, nps * 8);
+    }
     uint8_t* d = grow<uint8_t>(hbch.hb[0], total);
     be.h2d(d, hup, total);
     DHeads& H = hbch.H;
@@ -531,6 +548,9 @@ template <class B> struct EngineT {
     H.req_qty = (const int64_t*)(d + o_rqty); H.ps_flavor_ok = (const uint64_t*)(d + o_fok); H.ps_last_tried = (const int32_t*)(d + o_ltried);
     H.last_generation = (const int64_t*)(d + o_lgen); H.last_cycle = (const int64_t*)(d + o_lcyc);
     H.last_hash = (const uint64_t*)(d + o_lhash); H.hash = (const uint64_t*)(d + o_hash);
+    H.slice_row = sl ? (const int32_t*)(d + o_srow) : nullptr; H.ps_slice_count = sl ? (const int32_t*)(d + o_scnt) : nullptr;
+    H.req_slice_flavor = sl ? (const int32_t*)(d + o_sfl) : nullptr; H.req_slice_qty = sl ? (const int64_t*)(d + o_sq) : nullptr;
+    H.ps_slice_pods_flavor = sl ? (const int32_t*)(d + o_spf) : nullptr; H.ps_slice_pods_qty = sl ? (const int64_t*)(d + o_spq) : nullptr;
     rc = be.sync();  // the staging buffer is reused by the next call
     if (rc != KQ_OK) return fail(rc, be.error());
     return KQ_OK;
@@ -867,6 +887,7 @@ template <class B> struct EngineT {
     int slot_cap = 1, max_nps = 1; bool plain = true;
     int rc = validate_heads(h, &slot_cap, &plain, &max_nps);
     if (rc != KQ_OK) return rc;
+    if (h->slice_row) return fail(KQ_EUNSUPPORTED, "workload slices in the resident pending set: use kq_cycle_run for heads that replace a slice");
     pending_free();
     const int W = h->n, nq = prep.nq, nR = prep.nR;
     const size_t nfw = (prep.nF + 63) / 64;

@@ -114,7 +114,7 @@ struct Prep {
   std::vector<double> h_weight;                    // host copy of fair_weight for build_fair after a device derive
   int max_tree_mw = 1;                             // words of a candidate bitmap of the largest tree
   bool want_fs = true;                             // build the kq_fs.hpp structures (the engine clears it when fair sharing is off)
-  int max_rsn_per_podset = 1;  // most reason records one podset's flavor scans can produce: max over ClusterQueues of sum over groups of flavors x (resources + 1)
+  int max_rsn_per_podset = 1;  // most reason records one podset's flavor scans can produce: max over ClusterQueues of sum over groups of flavors x (2 x resources + 1)
   std::string err;
 };
 
@@ -506,7 +506,7 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
   for (int c = 0; c < p.nq; c++) {
     int tot = 1;
     for (int g = s->cq_rg_off[c]; g < s->cq_rg_off[c + 1]; g++)
-      tot += (s->rg_flavor_off[g + 1] - s->rg_flavor_off[g]) * (s->rg_res_off[g + 1] - s->rg_res_off[g] + 1);
+      tot += (s->rg_flavor_off[g + 1] - s->rg_flavor_off[g]) * (2 * (s->rg_res_off[g + 1] - s->rg_res_off[g]) + 1);  // (a cell of a head that replaces a workload slice can leave two: flavor mismatch + quota)
     p.max_rsn_per_podset = std::max(p.max_rsn_per_podset, tot);
   }
   // ---- fair sharing constants (depend on SubtreeQuota / usage: recomputed after kq_snapshot_derive) ----

@@ -103,7 +103,7 @@ def _workload(d: dict) -> Workload:
         creation_ts=int(d.get("created", 0)), pod_sets=_podsets(d), uid=d.get("uid"),
         reserve_ts=d.get("reservedAt"), evicted=bool(d.get("evicted", False)),
         has_quota_reservation=bool(d.get("hasQuotaReservation", False)), is_preemptor=bool(d.get("isPreemptor", False)),
-        last_assignment=la, scheduling_hash=int(d.get("hash", 0)),
+        last_assignment=la, scheduling_hash=int(d.get("hash", 0)), replaces=d.get("replaces"),
     )
 
 

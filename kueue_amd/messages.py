@@ -23,6 +23,7 @@ RSN_INSUFFICIENT_UNUSED = 2    # a = val - available ("more needed")
 RSN_NOT_IN_NOMINATION = 3      # flavor skipped by the nomination mapping of a recomputation; resource = the scan's resource
 RSN_FLAVOR_INELIGIBLE = 4      # checkFlavorForPodSets failed on the host (ps_flavor_ok bit clear)
 RSN_RESOURCE_UNAVAILABLE = 5   # no resource group of the ClusterQueue covers the resource
+RSN_SLICE_FLAVOR_MISMATCH = 6  # workload slices: flavor = the flavor tried, a = the replaced slice's flavor for the resource
 RSN_TRUNCATED = 255
 
 UNLIMITED = (1 << 63) - 1
@@ -105,6 +106,8 @@ def reason_text(snap, code: int, flavor: int, resource: int, a: int, b: int, c: 
         return list(ineligible(podset, flavor)) if ineligible else [f"flavor {fl} is not eligible for the pod set"]
     if code == RSN_RESOURCE_UNAVAILABLE:
         return [f"resource {rs} unavailable in ClusterQueue"]
+    if code == RSN_SLICE_FLAVOR_MISMATCH:   # flavorassigner.go:1134
+        return [f"could not assign {fl} flavor since the original workload is assigned: {snap.flavors[a] if a >= 0 else ''}"]
     raise ValueError(code)
 
 

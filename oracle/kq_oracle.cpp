@@ -409,6 +409,9 @@ static DRS dominantResourceShare(Snap& sn, int node, const FRQ* wlReq = nullptr)
 struct PodSetReq {
   int count, min_count;
   std::vector<std::pair<int, int64_t>> req;  // (resource, qty) in given order
+  // the podset of the replaced workload slice at the same index (replaceWorkloadSlice.TotalRequests[psID]): Count, Flavors, Requests
+  int slice_count = 0;
+  std::map<int, std::pair<int, int64_t>> slice;  // resource -> (flavor or -1, request)
 };
 struct Head {
   int idx, cq;
@@ -416,10 +419,12 @@ struct Head {
   uint32_t flags;
   std::vector<PodSetReq> ps;
   int ps_base;                     // global podset index of ps[0]
+  int slice_row = -1;              // admitted row of the workload slice this head replaces (workloadslicing.ReplacedWorkloadSlice), -1 = none
   bool has_last;                   // LastAssignment != nil
   std::vector<std::vector<int>> last_tried;  // [ps][res], -1 absent
   // NominationMapping (workload.go:262): [ps][res] -> flavor, empty when unset
   std::vector<std::map<int, int>> nomination;
+  bool has_nomination = false;     // len(NominationMapping) > 0: readResourceToFlavorMapping makes an entry per assigned podset, even without flavors
   bool CanBePartiallyAdmitted() const {  // workload.go:636
     for (auto& p : ps) if (p.min_count >= 0 && p.count > p.min_count) return true;
     return false;
@@ -679,9 +684,9 @@ struct FlavorAssigner {
   }
   // flavorassigner.go:1408-1414 / :1422-1430
   bool shouldRespectNominationMapping() const {
-    bool any = false;
-    for (auto& m : wl.nomination) if (!m.empty()) any = true;
-    return any && sn.gate(KQ_GATE_RECOMPUTE_ON_OVERLAP);
+    // len(a.wl.NominationMapping) > 0 (flavorassigner.go:1403): the mapping has one (possibly empty) entry per podset of the nominated
+    // assignment (scheduler.go:651-660) — a podset that was nominated without any flavor then skips EVERY flavor of the recomputation
+    return wl.has_nomination && (sn.gate(KQ_GATE_RECOMPUTE_ON_OVERLAP) || (sn.T && !(sn.T->flags & KQ_CT_NO_RECOMPUTE)));
   }
   // flavorassigner.go:1065-1210 ; psIDs == {psi} (no TAS podset groups on this path)
   // returns assignments (empty => nil), nreasons; *statusNil true when Go returns a nil status
@@ -715,9 +720,18 @@ struct FlavorAssigner {
       GranularMode representativeMode = {pmFit, 0};
       for (auto& rq : filtered) {
         int fr = fName * sn.nR + rq.first;
+        int64_t val = rq.second;
+        if (wl.slice_row >= 0) {  // :1125-1145 — the same flavor as the slice it replaces, and only the delta is requested
+          auto it = wl.ps[psi].slice.find(rq.first);
+          const int originalFlavor = it == wl.ps[psi].slice.end() ? -1 : it->second.first;
+          if (originalFlavor != fName) {
+            representativeMode = {pmNoFit, MAXINT};  // worstGranularMode(); the `break` only leaves the psIDs loop: fitsResourceQuota still runs
+            (*nreasons)++; why->push_back({KQ_RSN_SLICE_FLAVOR_MISMATCH, fName, rq.first, originalFlavor, 0, 0});
+          } else val -= it->second.second;
+        }
         const bool discarded = representativeMode.pm == pmNoFit;
         const int64_t vb0 = sn.st.victim_bytes + sn.st.drs_bytes;
-        FitRes r = fitsResourceQuota(fr, frq_get(assignmentUsage, fr), rq.second);
+        FitRes r = fitsResourceQuota(fr, frq_get(assignmentUsage, fr), val);
         if (discarded) sn.st.discarded_bytes += sn.st.victim_bytes + sn.st.drs_bytes - vb0;
         if (r.status) { (*nreasons)++; why->push_back(r.why); }
         GranularMode mode = {r.pm, r.borrow};
@@ -814,6 +828,10 @@ struct FlavorAssigner {
         int fr = kv.second.flavor * sn.nR + kv.first;
         int64_t requestAmount = 0;
         for (auto& rq : podSet.req) if (rq.first == kv.first) requestAmount = rq.second;
+        if (wl.slice_row >= 0) {  // :1032-1035 findOldPodSetRequest (by podset name: the host aligned the names to indices)
+          auto it = wl.ps[i].slice.find(kv.first);
+          if (it != wl.ps[i].slice.end()) requestAmount -= it->second.second;
+        }
         a.Usage[fr] = frq_get(a.Usage, fr).AddInt64(requestAmount);
       }
       sn.st.head_io_bytes += (int64_t)podSet.req.size() * 8 + (int64_t)psa.flavors.size() * 16;
@@ -1269,6 +1287,7 @@ struct Preemptor {
     for (size_t i = 0; i < wl.ps.size(); i++) {
       const PodSetReq& ps = wl.ps[i];
       int newCount = a.PodSets[i].count;
+      if (wl.slice_row >= 0) newCount = ps.count - ps.slice_count;  // :265-267
       for (auto rq : ps.req) {
         int64_t q = rq.second;
         if (ps.count != 0 && ps.count != newCount) { q = q / (int64_t)ps.count; q = SaturatingMul(q, (int64_t)newCount); }
@@ -1343,12 +1362,20 @@ struct Scheduler {
     for (int p = H->ps_off[i]; p < H->ps_off[i + 1]; p++) {
       PodSetReq ps; ps.count = H->ps_count[p]; ps.min_count = H->ps_min_count ? H->ps_min_count[p] : -1;
       for (int k = H->ps_req_off[p]; k < H->ps_req_off[p + 1]; k++) ps.req.push_back({H->req_res[k], H->req_qty[k]});
+      if (H->slice_row && H->slice_row[i] >= 0 && sn.gate(KQ_GATE_ELASTIC_JOBS)) {
+        ps.slice_count = H->ps_slice_count ? H->ps_slice_count[p] : 0;
+        for (int k = H->ps_req_off[p]; k < H->ps_req_off[p + 1]; k++)
+          ps.slice[H->req_res[k]] = {H->req_slice_flavor ? H->req_slice_flavor[k] : -1, H->req_slice_qty ? H->req_slice_qty[k] : 0};
+        if (sn.s->pods_resource >= 0 && !ps.slice.count(sn.s->pods_resource))
+          ps.slice[sn.s->pods_resource] = {H->ps_slice_pods_flavor ? H->ps_slice_pods_flavor[p] : -1, H->ps_slice_pods_qty ? H->ps_slice_pods_qty[p] : 0};
+      }
       h.ps.push_back(ps);
       std::vector<int> lt(sn.nR, -1);
       if (H->ps_last_tried) for (int r = 0; r < sn.nR; r++) lt[r] = H->ps_last_tried[(size_t)p * sn.nR + r];
       h.last_tried.push_back(lt);
     }
     h.nomination.assign(h.ps.size(), {});
+    if (H->slice_row && sn.gate(KQ_GATE_ELASTIC_JOBS)) h.slice_row = H->slice_row[i];
     return h;
   }
   // scheduler.go:840-856
@@ -1366,14 +1393,32 @@ struct Scheduler {
     return [this](int cq, const Head& wl, int fr, Amount q) { return preemptor.SimulatePreemption(cq, wl, fr, q); };
   }
   // scheduler.go:880-924
-  void getInitialAssignments(Head& wl, Assignment* outA, std::vector<Target>* outT) {
+  void getInitialAssignments(Head& wl0, Assignment* outA, std::vector<Target>* outT) {
+    // ReplacedWorkloadSlice looks the old slice up in queue.Workloads (workloadslicing.go:371): inside an overlap recomputation
+    // (SimulateWorkloadRemoval of the other preemptions' victims, scheduler.go:726-727) a slice that was preempted is not there
+    // any more and the head is assigned like any other workload
+    Head wl = wl0;
+    if (wl.slice_row >= 0 && sn.removed[wl.slice_row]) wl.slice_row = -1;
     FlavorAssigner fa{sn, H, wl, wl.cq, sn.cfg.fair_sharing != 0, makeOracle()};
     Assignment full = fa.assignFlavors(nullptr);
     int arm = full.RepresentativeMode();
-    if (arm == Fit) { *outA = full; outT->clear(); return; }
+    // workloadslicing.ReplacedWorkloadSlice :883: the replaced slice is a target from the start (Target without a reason)
+    std::vector<Target> sliceTargets;
+    if (wl.slice_row >= 0) sliceTargets.push_back({wl.slice_row, KQ_REASON_REPLACED_SLICE});
+    // (should the victim search name the slice itself, the reference's list holds it twice and FindReplacedSliceTarget :402 takes the
+    // first entry out; here the row is listed once, under the search's reason: it is evicted either way — documented in kq_engine.h)
+    auto withSlice = [&](const std::vector<Target>& t) {
+      std::vector<Target> r;
+      bool dup = false;
+      for (auto& x : t) if (!sliceTargets.empty() && x.row == sliceTargets[0].row) dup = true;
+      if (!dup) r = sliceTargets;
+      r.insert(r.end(), t.begin(), t.end());
+      return r;
+    };
+    if (arm == Fit) { *outA = full; *outT = sliceTargets; return; }
     if (arm == Preempt) {
       std::vector<Target> t = preemptor.GetTargets(wl, full);
-      if (!t.empty()) { *outA = full; *outT = t; return; }
+      if (!t.empty()) { *outA = full; *outT = withSlice(t); return; }
     }
     if (sn.gate(KQ_GATE_PARTIAL_ADMISSION) && wl.CanBePartiallyAdmitted()) {
       int P = (int)wl.ps.size();
@@ -1390,7 +1435,7 @@ struct Scheduler {
         }
         return false;
       });
-      if (found) { *outA = lastA; *outT = lastT; return; }
+      if (found) { *outA = lastA; *outT = withSlice(lastT); return; }
     }
     *outA = full; outT->clear();
   }
@@ -1454,11 +1499,12 @@ struct Scheduler {
       sn.tasRecomputes++;
       e.head.has_last = false;
       e.head.nomination.assign(e.head.ps.size(), {});
+      e.head.has_nomination = !e.assignment.PodSets.empty();
       for (size_t p = 0; p < e.assignment.PodSets.size(); p++) for (auto& kv : e.assignment.PodSets[p].flavors) e.head.nomination[p][kv.first] = kv.second.flavor;
       getAssignments(e);
       usage = assignmentUsage(e);
       fc = fitsCheck(e, cq, usage, preempted, e.preemptionTargets);
-      e.head.nomination.assign(e.head.ps.size(), {});
+      e.head.nomination.assign(e.head.ps.size(), {}); e.head.has_nomination = false;
       *usageOut = usage;
       return fc == FitsCheckOk;
     }
@@ -1471,6 +1517,7 @@ struct Scheduler {
     e.head.has_last = false;
     // readResourceToFlavorMapping :651-660
     e.head.nomination.assign(e.head.ps.size(), {});
+    e.head.has_nomination = !e.assignment.PodSets.empty();
     for (size_t p = 0; p < e.assignment.PodSets.size(); p++) for (auto& kv : e.assignment.PodSets[p].flavors) e.head.nomination[p][kv.first] = kv.second.flavor;
     getAssignments(e);
     vb0 = sn.st.victim_bytes;
@@ -1479,7 +1526,7 @@ struct Scheduler {
     if (e.assignment.RepresentativeMode() == Fit) e.assignment.SetRepresentativeMode(DeferredFit);
     usage = assignmentUsage(e);
     fc = fitsCheck(e, cq, usage, preempted, e.preemptionTargets);
-    e.head.nomination.assign(e.head.ps.size(), {});
+    e.head.nomination.assign(e.head.ps.size(), {}); e.head.has_nomination = false;
     *usageOut = usage;
     return fc == FitsCheckOk;
   }

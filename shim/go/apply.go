@@ -24,7 +24,9 @@ const (
 var requeueReasons = map[uint8]string{0: "", 1: "FailedAfterNomination", 4: "PendingPreemption", 7: "NoFit", 8: "PreemptionNoCandidates"}
 
 var targetReasons = [...]string{kueue.InClusterQueueReason, kueue.InCohortReclamationReason, kueue.InCohortFairSharingReason,
-	kueue.InCohortReclaimWhileBorrowingReason}
+	kueue.InCohortReclaimWhileBorrowingReason,
+	kueue.WorkloadSliceReplaced} // KQ_REASON_REPLACED_SLICE: the old slice of an elastic workload (preemption.go:141-149); the preemptor
+// evicts it with workloadslicing's "Replaced to accommodate a new workload slice" instead of the preemption message
 
 // FlavorChoice is flavorassigner.FlavorAssignment as the engine reports it.
 type FlavorChoice struct {

@@ -30,6 +30,7 @@ import (
 	"sigs.k8s.io/kueue/pkg/resources"
 	"sigs.k8s.io/kueue/pkg/util/priority"
 	"sigs.k8s.io/kueue/pkg/workload"
+	"sigs.k8s.io/kueue/pkg/workloadslicing"
 	workloadevict "sigs.k8s.io/kueue/pkg/workload/evict"
 )
 
@@ -46,6 +47,8 @@ const (
 // Index is the Go-side dictionary of one flattened snapshot.
 type Index struct {
 	CQ, Cohort, Flavor, Resource map[string]int32
+	AdmRow  map[string]int32 // workload.Reference -> admitted row (workload slices: the row a head replaces)
+	AdmInfo []*workload.Info // by admitted row
 }
 
 func amount(a resources.Amount) int64 { return a.Int64() } // Unlimited == math.MaxInt64 == KQ_UNLIMITED
@@ -263,6 +266,11 @@ func Flatten(log logr.Logger, snap *schdcache.Snapshot, strategies map[kueue.Clu
 		sort.Slice(rows, func(a, b int) bool { return rows[a].key < rows[b].key })
 		for _, r := range rows {
 			wl := r.wl
+			if ix.AdmRow == nil {
+				ix.AdmRow = map[string]int32{}
+			}
+			ix.AdmRow[r.key] = int32(len(s.AdmKeys))
+			ix.AdmInfo = append(ix.AdmInfo, wl)
 			s.AdmKeys = append(s.AdmKeys, r.key)
 			s.AdmPriority = append(s.AdmPriority, priority.EffectivePriority(log, wl.Obj))
 			s.AdmQueueTs = append(s.AdmQueueTs, ordering.GetQueueOrderTimestamp(wl.Obj).UnixNano())
@@ -412,5 +420,63 @@ func FlattenHeads(log logr.Logger, s *FlatSnapshot, ix *Index, heads []*qcache.H
 		}
 		h.PsOff = append(h.PsOff, int32(len(h.PsCount)))
 	}
+	flattenSlices(s, ix, heads, h)
 	return h
+}
+
+// flattenSlices fills the kq_heads.slice_* columns: for a head that replaces an admitted workload slice
+// (workloadslicing.ReplacedWorkloadSlice, scheduler.go:883: annotation -> queue.Workloads, same namespace) the admitted row of the
+// old slice and, per podset / request of the head, what the old slice holds: Count, Flavors[res], Requests[res]
+// (replaceWorkloadSlice.TotalRequests[psID], flavorassigner.go:1127; findOldPodSetRequest :1046 looks the podset up by NAME).
+func flattenSlices(s *FlatSnapshot, ix *Index, heads []*qcache.Head, h *FlatHeads) {
+	any := false
+	rows := make([]int32, len(heads))
+	olds := make([]*workload.Info, len(heads))
+	for i, hd := range heads {
+		rows[i] = -1
+		key := workloadslicing.ReplacementForKey(hd.Info.Obj)
+		if key == nil {
+			continue
+		}
+		if row, ok := ix.AdmRow[string(*key)]; ok && ix.AdmInfo[row].ClusterQueue == hd.Info.ClusterQueue &&
+			ix.AdmInfo[row].Obj.Namespace == hd.Info.Obj.Namespace {
+			rows[i], olds[i], any = row, ix.AdmInfo[row], true
+		}
+	}
+	if !any {
+		return
+	}
+	h.SliceRow = rows
+	pods := corev1.ResourcePods
+	for i, hd := range heads {
+		for _, ps := range hd.Info.TotalRequests {
+			var ops *workload.PodSetResources
+			if olds[i] != nil {
+				for k := range olds[i].TotalRequests {
+					if olds[i].TotalRequests[k].Name == ps.Name {
+						ops = &olds[i].TotalRequests[k]
+					}
+				}
+			}
+			cnt, pf, pq := int32(0), int32(-1), int64(0)
+			if ops != nil {
+				cnt = ops.Count
+				if f, ok := ops.Flavors[pods]; ok {
+					pf, pq = ix.Flavor[string(f)], ops.Requests.ResourceValue(pods)
+				}
+			}
+			h.PsSliceCount = append(h.PsSliceCount, cnt)
+			h.PsSlicePodsFlavor, h.PsSlicePodsQty = append(h.PsSlicePodsFlavor, pf), append(h.PsSlicePodsQty, pq)
+			ps.Requests.ForEach(func(r corev1.ResourceName, _ int64) {
+				f, q := int32(-1), int64(0)
+				if ops != nil {
+					if fl, ok := ops.Flavors[r]; ok {
+						f = ix.Flavor[string(fl)]
+					}
+					q = ops.Requests.ResourceValue(r)
+				}
+				h.ReqSliceFlavor, h.ReqSliceQty = append(h.ReqSliceFlavor, f), append(h.ReqSliceQty, q)
+			})
+		}
+	}
 }

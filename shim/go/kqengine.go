@@ -114,6 +114,9 @@ type FlatHeads struct {
 	PsLastTried                               []int32
 	LastGeneration, LastCycle                 []int64
 	LastHash, Hash                            []uint64
+	// workload slices (ElasticJobsViaWorkloadSlices): nil when no head replaces a slice
+	SliceRow, PsSliceCount, ReqSliceFlavor, PsSlicePodsFlavor []int32
+	ReqSliceQty, PsSlicePodsQty                               []int64
 }
 
 type FlatDecisions struct {
@@ -239,6 +242,14 @@ func fillHeads(p *runtime.Pinner, c *C.kq_heads, h *FlatHeads) {
 	c.last_cycle = (*C.int64_t)(pin(p, h.LastCycle))
 	c.last_hash = (*C.uint64_t)(pin(p, h.LastHash))
 	c.hash = (*C.uint64_t)(pin(p, h.Hash))
+	if h.SliceRow != nil {
+		c.slice_row = (*C.int32_t)(pin(p, h.SliceRow))
+		c.ps_slice_count = (*C.int32_t)(pin(p, h.PsSliceCount))
+		c.req_slice_flavor = (*C.int32_t)(pin(p, h.ReqSliceFlavor))
+		c.req_slice_qty = (*C.int64_t)(pin(p, h.ReqSliceQty))
+		c.ps_slice_pods_flavor = (*C.int32_t)(pin(p, h.PsSlicePodsFlavor))
+		c.ps_slice_pods_qty = (*C.int64_t)(pin(p, h.PsSlicePodsQty))
+	}
 }
 
 func fillDecisions(p *runtime.Pinner, c *C.kq_decisions, d *FlatDecisions) {

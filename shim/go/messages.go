@@ -23,6 +23,7 @@ const (
 	RsnNotInNomination     = 3
 	RsnFlavorIneligible    = 4
 	RsnResourceUnavailable = 5
+	RsnSliceFlavorMismatch = 6
 )
 
 // IneligibleText returns the strings checkFlavorForPodSets (flavorassigner.go:1212-1261) produced on the host for a flavor whose
@@ -54,6 +55,12 @@ func ReasonText(f *resources.ResourceFormatter, s *FlatSnapshot, code uint8, fla
 		return fmt.Sprintf("skipping flavor %s as it is not found in the nomination mapping for resource %s", fl, rs)
 	case RsnResourceUnavailable:
 		return fmt.Sprintf("resource %s unavailable in ClusterQueue", rs)
+	case RsnSliceFlavorMismatch: // flavorassigner.go:1134; a = the replaced slice's flavor for the resource (-1: none)
+		orig := ""
+		if a >= 0 {
+			orig = s.FlavorNames[a]
+		}
+		return fmt.Sprintf("could not assign %s flavor since the original workload is assigned: %s", fl, orig)
 	}
 	return ""
 }

@@ -9,7 +9,7 @@ POL_WCQ = ["Never", "LowerPriority", "LowerOrNewerEqualPriority"]
 POL_RWC = ["Never", "LowerPriority", "LowerOrNewerEqualPriority", "Any"]
 
 
-def random_case(seed, fair=False, preemption=True, max_cq=6, partial=False, fair_dups=False, tight=False):
+def random_case(seed, fair=False, preemption=True, max_cq=6, partial=False, fair_dups=False, tight=False, slices=False):
     global _TIGHT
     _TIGHT = tight
     rnd = random.Random(seed)
@@ -98,6 +98,20 @@ def random_case(seed, fair=False, preemption=True, max_cq=6, partial=False, fair
             w.last_assignment = LastAssignment(
                 last_tried_flavor_idx=[{r: rnd.randint(-1, max(0, n_flavors - 2)) for r in ps.requests if r in RES} for ps in pods],
                 cluster_queue_generation=rnd.randint(0, 3), scheduling_cycle=rnd.randint(0, 5), scheduling_hash=rnd.choice([0, 7, 9]))
+        if slices and rnd.random() < 0.6:
+            # ElasticJobsViaWorkloadSlices: the head is the scaled-up slice of an admitted workload of its ClusterQueue (same podset name in
+            # most cases, so that the old requests / flavors line up; sometimes a different one: nothing of the old slice matches)
+            olds = [a for a in admitted if a.cluster_queue == cq.name]
+            if olds:
+                old = rnd.choice(olds)
+                w.replaces = old.name
+                if rnd.random() < 0.85:
+                    w.pod_sets[0].name = old.pod_sets[0].name
+                    if rnd.random() < 0.7:   # a real scale-up: the same resources, at least the old amounts
+                        np_ = w.pod_sets[0]
+                        np_.count = old.pod_sets[0].count + rnd.randint(0, 2)
+                        np_.requests = {r: q + rnd.choice([0, 0, 500 if r == "cpu" else 1]) * 1 for r, q in old.pod_sets[0].requests.items()}
+                        np_.min_count = None
         pending.append(w)
         if (not fair or fair_dups) and rnd.random() < 0.12:
             # a second head on the same ClusterQueue (second-pass workloads come on top of one head per CQ,

@@ -1,0 +1,145 @@
+"""Workload slices (features.ElasticJobsViaWorkloadSlices, default on): a pending workload that replaces an admitted slice of the same job.
+
+Reference: workloadslicing.ReplacedWorkloadSlice (scheduler.go:883: the old slice is a target from the start), the flavor pin and the delta
+request of findFlavorForPodSets (flavorassigner.go:1125-1145), Assignment.append's delta usage (:1028-1035), TotalRequestsFor's count
+(:261-267), FindReplacedSliceTarget (scheduler.go:492). Oracle pinned by the two slice cases of TestAssignFlavors
+(tests/golden/assign_flavors_slices.yaml, hand transcription: flavors, usage and the Status strings); the engine's device code (emulated;
+GPU twin below) against the oracle on those and on random cycles with slices."""
+import numpy as np
+import pytest
+
+from kueue_amd import _ffi as F
+from kueue_amd import messages
+from kueue_amd.fixtures import load_case
+from tests.conftest import load_golden
+from tests.randgen import random_case
+
+G = load_golden("assign_flavors_slices.yaml")
+
+
+@pytest.mark.parametrize("case", G["cases"], ids=lambda c: c["name"][:60])
+def test_assign_flavors_slices_oracle(oracle, case):
+    cfg, snap, heads = load_case(case)
+    oracle.derive(snap)
+    got = oracle.assign(cfg, snap, heads, 0)
+    want = case["want"]
+    assert got["rep_mode"] == want["repMode"], got
+    gotfl = {r: [v[0], v[1], v[2]] for r, v in (got["podsets"][0] if got["podsets"] else {}).items()}
+    assert gotfl == {r: list(v) for r, v in want["flavors"].items()}, got
+    want_usage = {tuple(k.split("/", 1)): v for k, v in want["usage"].items() if v != 0}
+    assert got["usage"] == want_usage, got
+
+
+@pytest.mark.parametrize("case", G["cases"], ids=lambda c: c["name"][:60])
+def test_assign_flavors_slices_engine(oracle, case):
+    """One cycle through the device code (emulated): equal to the oracle's cycle, the replaced slice reported as a target with
+    KQ_REASON_REPLACED_SLICE when the head is admitted, the reference's Status strings regenerated from the reason records."""
+    from tests.emu import kqe
+    cfg, snap, heads = load_case(case)
+    oracle.derive(snap)
+    want = oracle.cycle_run(cfg, snap, heads, rsn_cap=256)
+    eng = kqe.EmuEngine(cfg)
+    try:
+        eng.put(snap)
+        got = eng.run(heads, rsn_cap=256)
+    finally:
+        eng.close()
+    assert got.rc == 0, got.error
+    assert not want.equal(got), want.equal(got)
+    w = case["want"]
+    if w["repMode"] == "Fit":
+        assert got.a["action"][0] == F.ACT_ADMIT
+        assert got.targets(0) == [(snap.adm_index["old-slice"], 4)]
+    else:
+        assert got.a["action"][0] == F.ACT_NONE and got.targets(0) == []
+        assert messages.podset_reasons(got, 0)[0] == sorted(w["status"])
+
+
+@pytest.mark.parametrize("case", G["schedule"], ids=lambda c: c["name"][:60])
+def test_schedule_slice_case(oracle, case):
+    """TestSchedule's workload-slice case through the oracle and the device code (emulated): the new slice is admitted on the old slice's
+    flavor, the cycle's usage grows by the DELTA only, the old slice comes back as the one target with KQ_REASON_REPLACED_SLICE."""
+    from tests.emu import kqe
+    cfg, snap, heads = load_case(case)
+    oracle.derive(snap)
+    want = oracle.cycle_run(cfg, snap, heads, want_usage=True)
+    eng = kqe.EmuEngine(cfg)
+    try:
+        eng.put(snap)
+        got = eng.run(heads, want_usage=True)
+    finally:
+        eng.close()
+    w = case["want"]
+    for d in (want, got):
+        assert [heads.workloads[i].name for i in range(heads.n) if d.a["action"][i] == F.ACT_ADMIT] == w["admitted"]
+        assert {r: v[0] for r, v in d.flavors_of(0)[0].items()} == w["flavors"]
+        assert d.targets(0) == [(snap.adm_index[w["replaced"]], 4)]
+    assert not want.equal(got), want.equal(got)
+    assert np.array_equal(want.usage_after, got.usage_after)
+    for k, v in w["usage"].items():   # the ClusterQueue's usage after the cycle: the old slice's 10 cpu + the delta of 5
+        f, r = k.split("/", 1)
+        assert want.usage_after[snap.cq_index["sales"] * snap.n_fr + snap.fr(f, r)] == v
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_slices_random_cycles(oracle, seed):
+    """Random cycles in which most heads replace an admitted workload of their ClusterQueue (with and without preemption): decisions,
+    targets (the slice among them), usage and bytes equal the oracle's."""
+    from tests.emu import kqe
+    cfg, snap, heads = random_case(seed, fair=False, preemption=(seed % 2 == 0), partial=False, slices=True)
+    oracle.derive(snap)
+    want = oracle.cycle_run(cfg, snap, heads, want_usage=True, rsn_cap=2048)
+    eng = kqe.EmuEngine(cfg)
+    try:
+        eng.put(snap)
+        got = eng.run(heads, want_usage=True, rsn_cap=2048)
+    finally:
+        eng.close()
+    assert got.rc == 0, got.error
+    assert not want.equal(got), (seed, want.equal(got))
+    assert np.array_equal(want.usage_after, got.usage_after), seed
+    assert got.bytes == want.stats["total"], seed
+
+
+def test_slices_gate_off_ignores_the_columns(oracle):
+    """ElasticJobsViaWorkloadSlices off: ReplacedWorkloadSlice returns nil, the head is an ordinary workload."""
+    from kueue_amd.api import gates_with, make_config
+    from tests.emu import kqe
+    n_with = 0
+    for seed in range(20):
+        cfg, snap, heads = random_case(seed, fair=False, preemption=True, slices=True)
+        if "slice_row" not in heads.arrays:
+            continue
+        n_with += 1
+        cfg = make_config(gates=gates_with({"ElasticJobsViaWorkloadSlices": False}))
+        oracle.derive(snap)
+        want = oracle.cycle_run(cfg, snap, heads)
+        plain = {k: v for k, v in heads.arrays.items() if not k.startswith(("slice_", "ps_slice", "req_slice"))}
+        from kueue_amd.api import Heads
+        want2 = oracle.cycle_run(cfg, snap, Heads.from_arrays(snap, plain, cycle=heads.cycle))
+        assert not want.equal(want2)
+        eng = kqe.EmuEngine(cfg)
+        try:
+            eng.put(snap)
+            got = eng.run(heads)
+        finally:
+            eng.close()
+        assert not want.equal(got), (seed, want.equal(got))
+    assert n_with > 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(40))
+def test_slices_random_cycles_gpu(oracle, seed):
+    from kueue_amd.engine import Engine
+    cfg, snap, heads = random_case(1000 + seed, fair=False, preemption=(seed % 2 == 0), partial=False, slices=True)
+    oracle.derive(snap)
+    want = oracle.cycle_run(cfg, snap, heads, want_usage=True, rsn_cap=2048)
+    eng = Engine(cfg)
+    try:
+        eng.put(snap)
+        got = eng.run(heads, rsn_cap=2048)
+        assert not want.equal(got), (seed, want.equal(got))
+        assert np.array_equal(want.usage_after, eng.usage_after()), seed
+    finally:
+        eng.close()
