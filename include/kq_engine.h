@@ -334,7 +334,7 @@ int  kq_nominate_run_resident(kq_engine* e, int32_t batch, kq_decisions* out);
  * priority descending, queue-order timestamp ascending, UID ascending) and the requeue policy (RequeueIfNotPresent :826,
  * requeueIfNotPresent :550, handleInadmissibleHash :606, queueInadmissibleWorkloads inadmissible_workloads.go:149) runs on the
  * device from the cycle's decisions, together with the LastAssignment bookkeeping of scheduler.go:248-295,459-464.
- * Outside: RequeueState back-off, namespace selectors, second-pass queue, AdmissionFairSharing ordering. */
+ * Outside: namespace selectors, second-pass queue. */
 #define KQ_WL_ACTIVE        0  /* in the heap                                   */
 #define KQ_WL_INFLIGHT      1  /* popped by Heads(), decision pending           */
 #define KQ_WL_INADMISSIBLE  2  /* parked in inadmissibleWorkloads               */
@@ -373,6 +373,47 @@ int  kq_cycle_run_pending(kq_engine* e, kq_decisions* out);
 int  kq_pending_apply(kq_engine* e);
 /* ComputeLocalQueueFSUsage of every LocalQueue (workload.go:492) as the ledger stands now; read by the next kq_pending_heads. */
 int  kq_pending_set_lq_usage(kq_engine* e, int32_t n_lq, const double* usage);
+/* ---- AdmissionFairSharing ledger on the device (pkg/cache/queue/afs/usage_ledger.go, entry_penalties.go) --------------------
+ * With a ledger resident, the LocalQueues' fair-sharing usage that Heads() orders by is evaluated on the device from the ledger, and the
+ * scheduler's own write to it — the entry penalty pushed when a workload is assumed (scheduler.go:1064-1068 assumeWorkload ->
+ * updateEntryPenalty :1337-1355 -> AfsUsageLedger.PushPenalty entry_penalties.go:30) — happens in kq_pending_apply, so a resident loop
+ * needs no host round trip between cycles. kq_pending_set_lq_usage is refused while a ledger is resident.
+ * Amounts are EXACT: integers in units of 10^-9 of the resource's base unit (resource.Quantity has no finer precision; MulByFloat
+ * rounds to that scale, pkg/util/resource/resource.go:93-115), 128 bits as (lo, hi) two's complement words.
+ * Resource dictionary of the ledger: every resource name that can appear in a consumed list or a penalty, SORTED BY NAME
+ * (afs.CalculateUsage sums in sorted key order, admission_fair_sharing.go:86-103); n_res <= 64.
+ * One LocalQueue feeds exactly one ClusterQueue (so the <= 1 head per ClusterQueue of a cycle never share a ledger row). */
+typedef struct kq_afs_ledger {
+  int32_t n_lq, n_res;
+  const double* lq_weight;        /* [n_lq] afs.LQWeightAsFloat64; <= 0: usage is +Inf (:98-100) */
+  const double* res_weight;       /* [n_res] fsResWeights[name], 1 when the name is not listed (:92-95) */
+  /* entry.Resources (the decayed consumed history): the amount, and its AsApproximateFloat64 AS THE LEDGER HOLDS IT (a parsed "8"
+   * and a decayed 8.000000000 are different float paths, quantity.go:468-483); NULL f64: every amount is in the scale-9 form */
+  const uint64_t* consumed_lo; const int64_t* consumed_hi; const double* consumed_f64;   /* [n_lq * n_res] */
+  /* entry.pendingPenalty at upload time (penalties of workloads that are not in the pending set any more); NULL: none.
+   * present[i]: the key exists in the aggregate (a zero amount still moves the sum to scale 9) */
+  const uint64_t* penalty_lo; const int64_t* penalty_hi; const uint8_t* penalty_present; /* [n_lq * n_res] */
+  /* what PushPenalty would record for pending workload w (afs.CalculateEntryPenalty(SumTotalRequests, config),
+   * admission_fair_sharing.go:53-60; scheduler.go:1343-1348), key set as a bit mask over the ledger's resources */
+  const uint64_t* wl_penalty_lo; const int64_t* wl_penalty_hi;   /* [W * n_res] */
+  const uint64_t* wl_penalty_mask;                                /* [W] */
+} kq_afs_ledger;
+/* Installs the ledger for the resident pending set (kq_pending_put with LocalQueue indices first). Workloads appended later by
+ * kq_pending_add carry no penalty until kq_pending_afs_wl_penalty gives them one. */
+int  kq_pending_afs_put(kq_engine* e, const kq_afs_ledger* l);
+int  kq_pending_afs_wl_penalty(kq_engine* e, int32_t n, const int32_t* wl, const uint64_t* lo, const int64_t* hi, const uint64_t* mask);
+/* AfsUsageLedger.SubPenalty (entry_penalties.go:45) for pending-set workloads: rollback of a failed admission (scheduler.go:1032),
+ * deletion (workload_controller.go:1296,1475,1481). No record: nothing happens. */
+int  kq_pending_afs_sub_penalty(kq_engine* e, int32_t n, const int32_t* wl);
+/* A controller rewrote entry.Resources of LocalQueues lq[i] (LocalQueue reconciler decay, localqueue_controller.go:223; settlement
+ * workload_controller.go:1506-1528). settle_wl (optional): workload whose recorded penalty is folded in the same write —
+ * remaining, penalty := old.WithoutPenalty(wlKey); Resources = MergeResourceListKeepSum(newConsumed, penalty) — or -1. */
+int  kq_pending_afs_set_consumed(kq_engine* e, int32_t n, const int32_t* lq, const uint64_t* lo, const int64_t* hi, const double* f64,
+                                 const int32_t* settle_wl);
+/* Read back: usage[n_lq] = afs.CalculateUsage per LocalQueue as Heads() would see it now; penalty lo/hi/present [n_lq * n_res];
+ * wl_record[W]; any pointer may be NULL. */
+int  kq_pending_afs_read(kq_engine* e, double* usage, uint64_t* penalty_lo, int64_t* penalty_hi, uint8_t* penalty_present,
+                         uint64_t* consumed_lo, int64_t* consumed_hi, uint8_t* wl_record);
 /* queueInadmissibleWorkloads for the listed ClusterQueues (cq == NULL: all) — what requeueWorkloadsCohort does for the root
  * cohorts whose quota was freed (inadmissible_workloads.go:112-175). */
 int  kq_pending_queue_inadmissible(kq_engine* e, int32_t n, const int32_t* cq);

@@ -148,6 +148,13 @@ class kq_pending(C.Structure):
     _fields_ = [("w", kq_heads), ("uid_rank", u32p), ("n_lq", C.c_int32), ("lq", i32p), ("requeue_at", i64p)]
 
 
+class kq_afs_ledger(C.Structure):
+    _fields_ = [("n_lq", C.c_int32), ("n_res", C.c_int32), ("lq_weight", f64p), ("res_weight", f64p),
+                ("consumed_lo", u64p), ("consumed_hi", i64p), ("consumed_f64", f64p),
+                ("penalty_lo", u64p), ("penalty_hi", i64p), ("penalty_present", u8p),
+                ("wl_penalty_lo", u64p), ("wl_penalty_hi", i64p), ("wl_penalty_mask", u64p)]
+
+
 REQUEUE_NONE, REQUEUE_BLOCKED = -(1 << 63), (1 << 63) - 1
 WL_ACTIVE, WL_INFLIGHT, WL_INADMISSIBLE, WL_GONE = 0, 1, 2, 3
 PATCH_USAGE, PATCH_ADMITTED = 1, 2
@@ -244,6 +251,13 @@ def load_engine():
     lib.kq_pending_set_requeue_at.restype = C.c_int
     lib.kq_pending_delete.argtypes = [C.c_void_p, C.c_int32, i32p]
     lib.kq_pending_delete.restype = C.c_int
+    lib.kq_pending_afs_put.argtypes = [C.c_void_p, C.POINTER(kq_afs_ledger)]
+    lib.kq_pending_afs_wl_penalty.argtypes = [C.c_void_p, C.c_int32, i32p, u64p, i64p, u64p]
+    lib.kq_pending_afs_sub_penalty.argtypes = [C.c_void_p, C.c_int32, i32p]
+    lib.kq_pending_afs_set_consumed.argtypes = [C.c_void_p, C.c_int32, i32p, u64p, i64p, f64p, i32p]
+    lib.kq_pending_afs_read.argtypes = [C.c_void_p, f64p, u64p, i64p, u8p, u64p, i64p, u8p]
+    for f in ("kq_pending_afs_put", "kq_pending_afs_wl_penalty", "kq_pending_afs_sub_penalty", "kq_pending_afs_set_consumed", "kq_pending_afs_read"):
+        getattr(lib, f).restype = C.c_int
     lib.kq_pending_set_lq_usage.argtypes = [C.c_void_p, C.c_int32, f64p]
     lib.kq_pending_set_lq_usage.restype = C.c_int
     lib.kq_pending_read_state.argtypes = [C.c_void_p, u8p, i32p]
@@ -283,6 +297,7 @@ ABI_SYMBOLS = [
     "kq_cycle_commit", "kq_cycle_release", "kq_snapshot_derive", "kq_snapshot_read_planes", "kq_strerror", "kq_last_error", "kq_abi_version",
     "kq_heads_put", "kq_cycle_run_resident", "kq_nominate_run_resident", "kq_last_cycle_phases",
     "kq_cycle_certificate", "kq_snapshot_usage_add", "kq_snapshot_patch", "kq_cycle_shard_words", "kq_cycle_nominate_shard", "kq_cycle_process_merged",
+    "kq_pending_afs_put", "kq_pending_afs_wl_penalty", "kq_pending_afs_sub_penalty", "kq_pending_afs_set_consumed", "kq_pending_afs_read",
     "kq_pending_set_lq_usage", "kq_pending_add", "kq_pending_delete", "kq_pending_set_clock", "kq_pending_set_requeue_at", "kq_pending_put", "kq_pending_heads", "kq_cycle_run_pending", "kq_pending_apply", "kq_pending_queue_inadmissible", "kq_pending_read_state",
     "kq_debug_read_usage_work", "kq_debug_force_exact_drs", "kq_debug_prof", "kq_debug_spec_stats", "kq_debug_disable_scan_search",
 ]

@@ -257,6 +257,12 @@ __global__ __launch_bounds__(64) void k_pend_apply(DPend D, DSnap S, DOut O, DHe
 __global__ __launch_bounds__(64) void k_pend_add_fix(DPend D, DSnap S, int first) { pend_add_fix(D, S, first + (int)blockIdx.x); }
 __global__ __launch_bounds__(64) void k_pend_requeue_at(DPend D, DSnap S, const int32_t* list, const int64_t* at) { pend_requeue_at(D, S, list, at, blockIdx.x); }
 __global__ __launch_bounds__(256) void k_pend_delete(DPend D, const int32_t* list, int n) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) pend_delete(D, list, i); }
+__global__ __launch_bounds__(256) void k_afs_usage(DPend D, int init_f64) { const int l = blockIdx.x * 256 + threadIdx.x; if (l < D.A.n_lq) afs_init_lq(D.A, l, init_f64 != 0); }
+__global__ __launch_bounds__(64) void k_afs_sub(DPend D, const int32_t* list, int n) { if (threadIdx.x == 0) afs_sub_list(D, list, n); }
+__global__ __launch_bounds__(256) void k_afs_set_consumed(DPend D, const int32_t* lq, const uint64_t* lo, const int64_t* hi, const double* f64, const int32_t* settle, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) afs_set_consumed(D.A, lq, lo, hi, f64, settle, i);
+}
 __global__ __launch_bounds__(64) void k_pend_qi(DPend D, const int32_t* list) { pend_queue_inadmissible(D, list ? list[blockIdx.x] : (int)blockIdx.x); }
 
 __global__ __launch_bounds__(256) void k_pend_release_mark(DSnap S, int32_t* tree_stamp, const int32_t* cq, const int32_t* use_n, int n, int32_t stamp) {
@@ -441,6 +447,18 @@ struct HipBackend {
     hipLaunchKernelGGL(k_pend_scan, dim3(1), dim3(PEND_SCAN_THREADS), 0, stream, D, G);
     hipLaunchKernelGGL(k_pend_gather, dim3(D.nq), dim3(64), 0, stream, D, G);
     chk(hipGetLastError(), "k_pend_heads");
+  }
+  void launch_afs_usage(const DPend& D, bool init_f64) {
+    if (D.A.n_lq > 0) hipLaunchKernelGGL(k_afs_usage, dim3((D.A.n_lq + 255) / 256), dim3(256), 0, stream, D, init_f64 ? 1 : 0);
+    chk(hipGetLastError(), "k_afs_usage");
+  }
+  void launch_afs_sub(const DPend& D, const int32_t* list, int n) {
+    hipLaunchKernelGGL(k_afs_sub, dim3(1), dim3(64), 0, stream, D, list, n);
+    chk(hipGetLastError(), "k_afs_sub");
+  }
+  void launch_afs_set_consumed(const DPend& D, const int32_t* lq, const uint64_t* lo, const int64_t* hi, const double* f64, const int32_t* settle, int n) {
+    hipLaunchKernelGGL(k_afs_set_consumed, dim3((n + 255) / 256), dim3(256), 0, stream, D, lq, lo, hi, f64, settle, n);
+    chk(hipGetLastError(), "k_afs_set_consumed");
   }
   void launch_pend_apply(const DPend& D, const DSnap& S, const DOut& O, const DHeads& H, uint32_t gates, int64_t cycle, int n) {
     hipLaunchKernelGGL(k_pend_apply, dim3(n), dim3(64), 0, stream, D, S, O, H, gates, cycle);
@@ -671,6 +689,31 @@ int kq_pending_apply(kq_engine* en) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
   return en->e.pending_apply();
+}
+int kq_pending_afs_put(kq_engine* en, const kq_afs_ledger* l) {
+  if (!en || !l) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.pending_afs_put(l);
+}
+int kq_pending_afs_wl_penalty(kq_engine* en, int32_t n, const int32_t* wl, const uint64_t* lo, const int64_t* hi, const uint64_t* mask) {
+  if (!en) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.pending_afs_wl_penalty(n, wl, lo, hi, mask);
+}
+int kq_pending_afs_sub_penalty(kq_engine* en, int32_t n, const int32_t* wl) {
+  if (!en || (n > 0 && !wl)) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.pending_afs_sub_penalty(n, wl);
+}
+int kq_pending_afs_set_consumed(kq_engine* en, int32_t n, const int32_t* lq, const uint64_t* lo, const int64_t* hi, const double* f64, const int32_t* settle_wl) {
+  if (!en) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.pending_afs_set_consumed(n, lq, lo, hi, f64, settle_wl);
+}
+int kq_pending_afs_read(kq_engine* en, double* usage, uint64_t* plo, int64_t* phi, uint8_t* ppres, uint64_t* clo, int64_t* chi, uint8_t* wrec) {
+  if (!en) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.pending_afs_read(usage, plo, phi, ppres, clo, chi, wrec);
 }
 int kq_pending_set_lq_usage(kq_engine* en, int32_t n_lq, const double* usage) {
   if (!en) return KQ_EINVAL;

@@ -990,8 +990,128 @@ template <class B> struct EngineT {
     pend.n_heads = -1; pend.ran = false;
     return KQ_OK;  // stream-ordered with the next kq_pending_heads
   }
+  // ---- AdmissionFairSharing ledger (kq_pending.hpp DAfs) ----
+  int pending_afs_put(const kq_afs_ledger* l) {
+    if (!pend.valid) return fail(KQ_EINVAL, "kq_pending_afs_put before kq_pending_put");
+    if (pend.n_heads >= 0) return fail(KQ_EINVAL, "kq_pending_afs_put between kq_pending_heads and kq_pending_apply");
+    Pending& P = pend;
+    if (!l || l->n_lq != P.n_lq || P.n_lq <= 0) return fail(KQ_EINVAL, "kq_pending_afs_put: LocalQueue count differs from kq_pending_put");
+    if (l->n_res <= 0 || l->n_res > 64) return fail(KQ_EINVAL, "kq_pending_afs_put: 1..64 ledger resources");
+    if (!l->lq_weight || !l->res_weight || !l->consumed_lo || !l->consumed_hi || !l->wl_penalty_lo || !l->wl_penalty_hi || !l->wl_penalty_mask)
+      return fail(KQ_EINVAL, "kq_pending_afs_put: missing array");
+    if ((l->penalty_lo != nullptr) != (l->penalty_hi != nullptr) || (l->penalty_lo != nullptr) != (l->penalty_present != nullptr))
+      return fail(KQ_EINVAL, "kq_pending_afs_put: penalty_lo / penalty_hi / penalty_present go together");
+    const size_t cells = (size_t)l->n_lq * l->n_res, wc = (size_t)P.W * l->n_res;
+    if (l->n_res < 64) for (int w = 0; w < P.W; w++) if (l->wl_penalty_mask[w] >> l->n_res) return fail(KQ_EINVAL, "kq_pending_afs_put: penalty mask names a resource outside the ledger");
+    DAfs& A = P.D.A;
+    if (A.n_res > 0) {  // a previous ledger: its arrays go
+      const void* old[] = {A.lq_weight, A.res_weight, A.cons_lo, A.cons_hi, A.cons_f64, A.pen_lo, A.pen_hi, A.pen_present, A.wl_lo, A.wl_hi, A.wl_mask, A.wl_rec};
+      for (const void* q : old) pend_release_ptr(q);
+    }
+    A = DAfs{};
+    A.n_lq = l->n_lq; A.n_res = l->n_res;
+    A.lq_weight = pend_alloc(l->n_lq, l->lq_weight); A.res_weight = pend_alloc(l->n_res, l->res_weight);
+    A.cons_lo = pend_alloc(cells, l->consumed_lo); A.cons_hi = pend_alloc(cells, l->consumed_hi);
+    A.cons_f64 = pend_alloc<double>(cells, l->consumed_f64, 0);   // NULL: the scale-9 form, evaluated by the device below
+    A.pen_lo = pend_alloc<uint64_t>(cells, l->penalty_lo, 0); A.pen_hi = pend_alloc<int64_t>(cells, l->penalty_hi, 0);
+    A.pen_present = pend_alloc<uint8_t>(cells, l->penalty_present, 0);
+    A.wl_lo = pend_alloc(wc, l->wl_penalty_lo); A.wl_hi = pend_alloc(wc, l->wl_penalty_hi); A.wl_mask = pend_alloc((size_t)P.W, l->wl_penalty_mask);
+    A.wl_rec = pend_alloc<uint8_t>((size_t)P.W, nullptr, 0);
+    A.usage = P.d_lq_usage;
+    be.launch_afs_usage(P.D, l->consumed_f64 == nullptr);
+    int rc = be.sync();   // the caller's arrays may go away
+    if (rc != KQ_OK) { A.n_res = 0; return fail(rc, be.error()); }
+    return KQ_OK;
+  }
+  int pending_afs_guard(const char* what) {
+    if (!pend.valid || pend.D.A.n_res <= 0) return fail(KQ_EINVAL, (std::string(what) + " before kq_pending_afs_put").c_str());
+    if (pend.n_heads >= 0) return fail(KQ_EINVAL, (std::string(what) + " between kq_pending_heads and kq_pending_apply").c_str());
+    return KQ_OK;
+  }
+  template <class T> T* afs_tmp(std::vector<void*>& tmp, const T* host, size_t n) {
+    T* d = (T*)be.alloc(std::max<size_t>(n, 1) * sizeof(T));
+    if (host && n) be.h2d(d, host, n * sizeof(T));
+    tmp.push_back(d);
+    return d;
+  }
+  int afs_finish(std::vector<void*>& tmp) {
+    int rc = be.sync();
+    for (void* q : tmp) be.free(q);
+    return rc != KQ_OK ? fail(rc, be.error()) : KQ_OK;
+  }
+  int pending_afs_wl_penalty(int n, const int32_t* wl, const uint64_t* lo, const int64_t* hi, const uint64_t* mask) {
+    int rc = pending_afs_guard("kq_pending_afs_wl_penalty");
+    if (rc != KQ_OK) return rc;
+    if (n <= 0) return KQ_OK;
+    const DAfs& A = pend.D.A;
+    if (!wl || !lo || !hi || !mask) return fail(KQ_EINVAL, "kq_pending_afs_wl_penalty: missing array");
+    for (int i = 0; i < n; i++) {
+      if (wl[i] < 0 || wl[i] >= pend.W) return fail(KQ_EINVAL, "kq_pending_afs_wl_penalty: workload out of range");
+      if (A.n_res < 64 && (mask[i] >> A.n_res)) return fail(KQ_EINVAL, "kq_pending_afs_wl_penalty: penalty mask names a resource outside the ledger");
+    }
+    // a recorded penalty keeps the amount it was pushed with (penaltyRecords holds a copy): refuse to change it under a record
+    std::vector<uint8_t> rec((size_t)pend.W);
+    be.d2h(rec.data(), A.wl_rec, (size_t)pend.W);
+    rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    for (int i = 0; i < n; i++) if (rec[wl[i]]) return fail(KQ_EINVAL, "kq_pending_afs_wl_penalty: the workload has a pending penalty record");
+    for (int i = 0; i < n; i++) {
+      be.h2d(A.wl_lo + (size_t)wl[i] * A.n_res, lo + (size_t)i * A.n_res, (size_t)A.n_res * 8);
+      be.h2d(A.wl_hi + (size_t)wl[i] * A.n_res, hi + (size_t)i * A.n_res, (size_t)A.n_res * 8);
+      be.h2d(A.wl_mask + wl[i], mask + i, 8);
+    }
+    rc = be.sync();
+    return rc != KQ_OK ? fail(rc, be.error()) : KQ_OK;
+  }
+  int pending_afs_sub_penalty(int n, const int32_t* wl) {
+    int rc = pending_afs_guard("kq_pending_afs_sub_penalty");
+    if (rc != KQ_OK) return rc;
+    if (n <= 0) return KQ_OK;
+    std::vector<int32_t> seen((size_t)n);
+    for (int i = 0; i < n; i++) { if (wl[i] < 0 || wl[i] >= pend.W) return fail(KQ_EINVAL, "kq_pending_afs_sub_penalty: workload out of range"); seen[i] = wl[i]; }
+    std::vector<void*> tmp;
+    const int32_t* dl = afs_tmp(tmp, wl, (size_t)n);
+    be.launch_afs_sub(pend.D, dl, n);   // one thread, list order: two workloads of one LocalQueue must not race on its row
+    return afs_finish(tmp);
+  }
+  int pending_afs_set_consumed(int n, const int32_t* lq, const uint64_t* lo, const int64_t* hi, const double* f64, const int32_t* settle) {
+    int rc = pending_afs_guard("kq_pending_afs_set_consumed");
+    if (rc != KQ_OK) return rc;
+    if (n <= 0) return KQ_OK;
+    const DAfs& A = pend.D.A;
+    if (!lq || !lo || !hi) return fail(KQ_EINVAL, "kq_pending_afs_set_consumed: missing array");
+    std::vector<uint8_t> hit((size_t)A.n_lq, 0);
+    for (int i = 0; i < n; i++) {
+      if (lq[i] < 0 || lq[i] >= A.n_lq) return fail(KQ_EINVAL, "kq_pending_afs_set_consumed: LocalQueue out of range");
+      if (hit[lq[i]]++) return fail(KQ_EINVAL, "kq_pending_afs_set_consumed: a LocalQueue is listed twice");
+      if (settle && (settle[i] < -1 || settle[i] >= pend.W)) return fail(KQ_EINVAL, "kq_pending_afs_set_consumed: workload out of range");
+    }
+    std::vector<void*> tmp;
+    const size_t cells = (size_t)n * A.n_res;
+    const int32_t* dl = afs_tmp(tmp, lq, (size_t)n);
+    const uint64_t* dlo = afs_tmp(tmp, lo, cells); const int64_t* dhi = afs_tmp(tmp, hi, cells);
+    const double* df = f64 ? afs_tmp(tmp, f64, cells) : nullptr;
+    const int32_t* ds = settle ? afs_tmp(tmp, settle, (size_t)n) : nullptr;
+    be.launch_afs_set_consumed(pend.D, dl, dlo, dhi, df, ds, n);
+    return afs_finish(tmp);
+  }
+  int pending_afs_read(double* usage, uint64_t* plo, int64_t* phi, uint8_t* ppres, uint64_t* clo, int64_t* chi, uint8_t* wrec) {
+    if (!pend.valid || pend.D.A.n_res <= 0) return fail(KQ_EINVAL, "kq_pending_afs_read before kq_pending_afs_put");
+    const DAfs& A = pend.D.A;
+    const size_t cells = (size_t)A.n_lq * A.n_res;
+    if (usage) be.d2h(usage, A.usage, (size_t)A.n_lq * sizeof(double));
+    if (plo) be.d2h(plo, A.pen_lo, cells * 8);
+    if (phi) be.d2h(phi, A.pen_hi, cells * 8);
+    if (ppres) be.d2h(ppres, A.pen_present, cells);
+    if (clo) be.d2h(clo, A.cons_lo, cells * 8);
+    if (chi) be.d2h(chi, A.cons_hi, cells * 8);
+    if (wrec) be.d2h(wrec, A.wl_rec, (size_t)pend.W);
+    int rc = be.sync();
+    return rc != KQ_OK ? fail(rc, be.error()) : KQ_OK;
+  }
   int pending_set_lq_usage(int n_lq, const double* usage) {
     if (!pend.valid) return fail(KQ_EINVAL, "kq_pending_set_lq_usage before kq_pending_put");
+    if (pend.D.A.n_res > 0) return fail(KQ_EINVAL, "kq_pending_set_lq_usage: an AdmissionFairSharing ledger is resident (kq_pending_afs_put) — the usage is the ledger's");
     if (n_lq != pend.n_lq || (n_lq > 0 && !usage)) return fail(KQ_EINVAL, "kq_pending_set_lq_usage: LocalQueue count differs from kq_pending_put");
     if (n_lq == 0) return KQ_OK;
     be.h2d(pend.d_lq_usage, usage, (size_t)n_lq * sizeof(double));
@@ -1047,6 +1167,11 @@ template <class B> struct EngineT {
       pend_regrow(D.requeue_at, W0, n, t_at.data() + (t_at.size() - (size_t)n));
     }
     if (P.n_lq > 0) pend_regrow(D.lq, W0, n, p->lq);
+    if (D.A.n_res > 0) {  // arrivals carry no entry penalty until kq_pending_afs_wl_penalty
+      pend_regrow(D.A.wl_lo, (size_t)W0 * D.A.n_res, (size_t)n * D.A.n_res, (const uint64_t*)nullptr, 0);
+      pend_regrow(D.A.wl_hi, (size_t)W0 * D.A.n_res, (size_t)n * D.A.n_res, (const int64_t*)nullptr, 0);
+      pend_regrow(D.A.wl_mask, W0, n, (const uint64_t*)nullptr, 0); pend_regrow(D.A.wl_rec, W0, n, (const uint8_t*)nullptr, 0);
+    }
     P.h_cq.insert(P.h_cq.end(), h->cq, h->cq + n); P.h_prio.insert(P.h_prio.end(), h->priority, h->priority + n);
     P.h_ts.insert(P.h_ts.end(), h->queue_ts, h->queue_ts + n); P.h_uid.insert(P.h_uid.end(), uid.begin(), uid.end());
     for (int w = 0; w < n; w++) {

@@ -24,8 +24,21 @@ namespace kq {
 
 enum { WL_ACTIVE = KQ_WL_ACTIVE, WL_INFLIGHT = KQ_WL_INFLIGHT, WL_INADMISSIBLE = KQ_WL_INADMISSIBLE, WL_GONE = KQ_WL_GONE };
 
+// AdmissionFairSharing ledger (pkg/cache/queue/afs/usage_ledger.go:38-60): per (LocalQueue, resource) the consumed history and the
+// aggregate of the pending entry penalties, exact 128-bit integers in units of 1e-9; per workload what PushPenalty records.
+struct DAfs {
+  int n_lq, n_res;           // n_res == 0: no ledger resident (DPend::lq_usage is the host's)
+  const double *lq_weight, *res_weight;
+  uint64_t* cons_lo; int64_t* cons_hi; double* cons_f64;     // [n_lq * n_res] entry.Resources
+  uint64_t* pen_lo; int64_t* pen_hi; uint8_t* pen_present;   // [n_lq * n_res] entry.pendingPenalty
+  uint64_t* wl_lo; int64_t* wl_hi; uint64_t* wl_mask;        // [W * n_res], [W]
+  uint8_t* wl_rec;           // [W] penaltyRecords[wlKey] exists
+  double* usage;             // [n_lq] afs.CalculateUsage, rewritten by afs_usage_lq
+};
+
 struct DPend {
   int W, nq, nR, nfw;
+  DAfs A;
   DHeads P;                  // static columns of the W workloads (flags / last_* here are the values at kq_pending_put)
   const uint32_t* uid;       // [W]
   const int32_t* cq_off;     // [nq+1] heap-ordered workloads of ClusterQueue c: ord[cq_off[c] .. cq_off[c+1])
@@ -73,6 +86,132 @@ KQ_DEV uint64_t afs_key(double v) {
   b = (uint64_t)__double_as_longlong(v);
 #endif
   return ((b >> 63) ? ~b : (b | 0x8000000000000000ull)) + 1;  // + 1 keeps 0 for NaN (the largest key, +Inf, does not overflow)
+}
+
+// ---- ledger arithmetic ----------------------------------------------------------------------------------------------------
+struct I128 { uint64_t lo; int64_t hi; };
+KQ_DEV I128 i128_add(I128 a, I128 b) { I128 r; r.lo = a.lo + b.lo; r.hi = (int64_t)((uint64_t)a.hi + (uint64_t)b.hi + (r.lo < a.lo ? 1u : 0u)); return r; }
+KQ_DEV I128 i128_neg(I128 a) { I128 r; r.lo = ~a.lo + 1; r.hi = (int64_t)(~(uint64_t)a.hi + (r.lo == 0 ? 1u : 0u)); return r; }
+KQ_DEV double afs_mul(double a, double b) {
+#ifdef KQ_HOST_EMU
+  volatile double r = a * b; return r;
+#else
+  return __dmul_rn(a, b);
+#endif
+}
+KQ_DEV double afs_addd(double a, double b) {
+#ifdef KQ_HOST_EMU
+  volatile double r = a + b; return r;
+#else
+  return __dadd_rn(a, b);
+#endif
+}
+// big.NewFloat(0).SetInt(unscaled).Float64() (quantity.go:472): the integer rounded to the nearest double, ties to even
+KQ_DEV double i128_to_f64(I128 v) {
+  const bool neg = v.hi < 0;
+  if (neg) v = i128_neg(v);
+  const uint64_t hi = (uint64_t)v.hi, lo = v.lo;
+  double r;
+  if (hi == 0) {
+    if (lo < (1ull << 53)) r = (double)(int64_t)lo;
+    else {
+      const int lz = clz64(lo), sh = 11 - lz;          // keep 53 bits
+      uint64_t m = lo >> sh; const uint64_t rem = lo & ((1ull << sh) - 1), half = 1ull << (sh - 1);
+      if (rem > half || (rem == half && (m & 1))) m++;
+      r = (double)(int64_t)m;                            // exact: m <= 2^53
+      for (int i = 0; i < sh; i++) r = afs_mul(r, 2.0);  // exact scaling
+    }
+  } else {
+    const int lz = clz64(hi), bits = 128 - lz, sh = bits - 53;  // sh in 12..75
+    uint64_t m, rem_hi, rem_lo;                               // m = v >> sh; rem = v & (2^sh - 1)
+    if (sh >= 64) { m = hi >> (sh - 64); rem_hi = sh == 64 ? 0 : (hi & ((1ull << (sh - 64)) - 1)); rem_lo = lo; }
+    else { m = (hi << (64 - sh)) | (lo >> sh); rem_hi = 0; rem_lo = lo & ((1ull << sh) - 1); }
+    // half = 2^(sh-1)
+    const uint64_t half_hi = sh - 1 >= 64 ? 1ull << (sh - 65) : 0, half_lo = sh - 1 >= 64 ? 0 : 1ull << (sh - 1);
+    const bool gt = rem_hi > half_hi || (rem_hi == half_hi && rem_lo > half_lo), eq = rem_hi == half_hi && rem_lo == half_lo;
+    if (gt || (eq && (m & 1))) m++;
+    r = (double)(int64_t)m;
+    for (int i = 0; i < sh; i++) r = afs_mul(r, 2.0);
+  }
+  return neg ? -r : r;
+}
+// Quantity.AsApproximateFloat64 of an amount held at scale 9: base * math.Pow10(-9) (quantity.go:482; Pow10(-9) = 1 / 1e9)
+KQ_DEV double afs_nano_f64(I128 v) { return afs_mul(i128_to_f64(v), 1e-9); }
+
+// entry.WithoutPenalty(wlKey) (usage_ledger.go:96-120): the record's amounts leave the aggregate, zero keys are dropped
+KQ_DEV void afs_without(const DAfs& A, int l, int w) {
+  if (!A.wl_rec[w]) return;
+  A.wl_rec[w] = 0;
+  const uint64_t mask = A.wl_mask[w];
+  for (int r = 0; r < A.n_res; r++) {
+    const size_t o = (size_t)l * A.n_res + r;
+    I128 agg{A.pen_lo[o], A.pen_hi[o]};
+    if ((mask >> r) & 1) {
+      const size_t q = (size_t)w * A.n_res + r;
+      agg = i128_add(agg, i128_neg(I128{A.wl_lo[q], A.wl_hi[q]}));
+      A.pen_lo[o] = agg.lo; A.pen_hi[o] = agg.hi;
+    }
+    if (agg.lo == 0 && agg.hi == 0) A.pen_present[o] = 0;   // :113-117 (every zero key of the aggregate)
+  }
+}
+// entry.withPenalty(wlKey, penalty) (usage_ledger.go:78-90)
+KQ_DEV void afs_push(const DAfs& A, int l, int w) {
+  afs_without(A, l, w);
+  const uint64_t mask = A.wl_mask[w];
+  for (int r = 0; r < A.n_res; r++) if ((mask >> r) & 1) {
+    const size_t o = (size_t)l * A.n_res + r, q = (size_t)w * A.n_res + r;
+    const I128 agg = i128_add(I128{A.pen_lo[o], A.pen_hi[o]}, I128{A.wl_lo[q], A.wl_hi[q]});
+    A.pen_lo[o] = agg.lo; A.pen_hi[o] = agg.hi; A.pen_present[o] = 1;
+  }
+  A.wl_rec[w] = 1;
+}
+// afs.CalculateUsage(consumed, penalty, lqWeight, resWeights) (admission_fair_sharing.go:86-103) for LocalQueue l
+KQ_DEV void afs_usage_lq(const DAfs& A, int l) {
+  double usage = 0.0;
+  for (int r = 0; r < A.n_res; r++) {   // sorted key order = dictionary order
+    const size_t o = (size_t)l * A.n_res + r;
+    // MergeResourceListKeepSum: a key of both lists is Quantity.Add (infDec at scale 9 once a penalty takes part), a key of
+    // one list is copied
+    const double v = A.pen_present[o] ? afs_nano_f64(i128_add(I128{A.cons_lo[o], A.cons_hi[o]}, I128{A.pen_lo[o], A.pen_hi[o]})) : A.cons_f64[o];
+    usage = afs_addd(usage, afs_mul(A.res_weight[r], v));
+  }
+  const double lw = A.lq_weight[l];
+  const double inf = __builtin_huge_val();   // math.Inf(1) :99
+#ifdef KQ_HOST_EMU
+  A.usage[l] = lw <= 0 ? inf : usage / lw;
+#else
+  A.usage[l] = lw <= 0 ? inf : __ddiv_rn(usage, lw);
+#endif
+}
+// every LocalQueue's usage after a ledger upload (init_f64: the consumed amounts are in the scale-9 form)
+KQ_DEV void afs_init_lq(const DAfs& A, int l, bool init_f64) {
+  if (init_f64) for (int r = 0; r < A.n_res; r++) { const size_t o = (size_t)l * A.n_res + r; A.cons_f64[o] = afs_nano_f64(I128{A.cons_lo[o], A.cons_hi[o]}); }
+  afs_usage_lq(A, l);
+}
+// AfsUsageLedger.SubPenalty (entry_penalties.go:45-52) for the listed workloads, in list order
+KQ_DEV void afs_sub_list(const DPend& D, const int32_t* list, int n) {
+  for (int i = 0; i < n; i++) {
+    const int w = list[i], l = D.lq ? D.lq[w] : -1;
+    if (l < 0 || !D.A.wl_rec[w]) continue;
+    afs_without(D.A, l, w);
+    afs_usage_lq(D.A, l);
+  }
+}
+// entry.Resources of LocalQueue lq[i] rewritten by a controller; with settle[i] >= 0 that workload's record folds in the same write
+// (workload_controller.go:1519-1526: remaining, penalty := old.WithoutPenalty(wlKey); Resources = newConsumed + penalty)
+KQ_DEV void afs_set_consumed(const DAfs& A, const int32_t* lq, const uint64_t* lo, const int64_t* hi, const double* f64, const int32_t* settle, int i) {
+  const int l = lq[i];
+  const int w = settle ? settle[i] : -1;
+  uint64_t fold = 0;
+  if (w >= 0 && A.wl_rec[w]) { fold = A.wl_mask[w]; afs_without(A, l, w); }
+  for (int r = 0; r < A.n_res; r++) {
+    const size_t o = (size_t)l * A.n_res + r, q = (size_t)i * A.n_res + r;
+    I128 v{lo[q], hi[q]};
+    double f = f64 ? f64[q] : afs_nano_f64(v);
+    if ((fold >> r) & 1) { v = i128_add(v, I128{A.wl_lo[(size_t)w * A.n_res + r], A.wl_hi[(size_t)w * A.n_res + r]}); f = afs_nano_f64(v); }
+    A.cons_lo[o] = v.lo; A.cons_hi[o] = v.hi; A.cons_f64[o] = f;
+  }
+  afs_usage_lq(A, l);
 }
 
 // the gathered batch (same arrays as a kq_heads upload), written by pend_gather_head
@@ -197,7 +336,15 @@ KQ_DEV void pend_apply_head(const DPend& D, const DSnap& S, const DOut& O, const
   const int c = D.P.cq[w];
   const int status = O.status[h], action = O.action[h], mode = O.mode[h], rq = O.requeue_reason[h];
   if (status == KQ_ST_ASSUMED) {
-    if (lane == 0) { D.state[w] = WL_GONE; if (D.pw[c] == w) { D.pw[c] = -1; D.pw_sticky[c] = 0; } }
+    if (lane == 0) {
+      D.state[w] = WL_GONE; if (D.pw[c] == w) { D.pw[c] = -1; D.pw_sticky[c] = 0; }
+      // assumeWorkload -> updateEntryPenalty(add) (scheduler.go:1064-1068, :1337-1350) when shouldApplyEntryPenalty (:1318-1335):
+      // a ledger is resident, the ClusterQueue admits usage-based (the workload has a LocalQueue row), first reservation
+      if (D.A.n_res > 0 && D.lq && D.lq[w] >= 0 && !(D.P.flags[w] & KQ_HEAD_HAS_QUOTA_RESERVATION)) {
+        afs_push(D.A, D.lq[w], w);
+        afs_usage_lq(D.A, D.lq[w]);   // <= 1 head per ClusterQueue and a LocalQueue feeds one ClusterQueue: nobody else writes this row
+      }
+    }
     return;
   }
   const bool strict = KQ_POL_STRICT_FIFO(S.cq_policy[c]) != 0;

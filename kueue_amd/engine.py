@@ -129,6 +129,45 @@ class Engine:
         u = np.ascontiguousarray(usage, np.float64)
         self._check(self._lib.kq_pending_set_lq_usage(self._h, len(u), F.ptr(u)))
 
+    # ---- AdmissionFairSharing ledger on the device (kq_pending_afs_*) ----
+    def pending_afs_put(self, ledger, penalties):
+        """kq_pending_afs_put: `ledger` = kueue_amd.afs.Ledger, `penalties` = entry_penalty of every pending workload."""
+        self._afs = ledger
+        self._check(self._lib.kq_pending_afs_put(self._h, C.byref(ledger.struct(penalties))))
+
+    def pending_afs_wl_penalty(self, wl, penalties):
+        a = np.ascontiguousarray(wl, np.int32)
+        lo, hi, mask = self._afs.workload_columns(penalties)
+        if len(a):
+            self._check(self._lib.kq_pending_afs_wl_penalty(self._h, len(a), F.ptr(a), F.ptr(lo), F.ptr(hi), F.ptr(mask)))
+
+    def pending_afs_sub_penalty(self, wl):
+        a = np.ascontiguousarray(wl, np.int32)
+        if len(a):
+            self._check(self._lib.kq_pending_afs_sub_penalty(self._h, len(a), F.ptr(a)))
+
+    def pending_afs_set_consumed(self, lq, rows, f64_rows=None, settle_wl=None):
+        """rows[i] = entry.Resources of LocalQueue lq[i] as amounts per ledger resource (nano units)."""
+        a = np.ascontiguousarray(lq, np.int32)
+        lo, hi, f = self._afs.consumed_columns(rows, f64_rows)
+        st = None if settle_wl is None else np.ascontiguousarray(settle_wl, np.int32)
+        if len(a):
+            self._check(self._lib.kq_pending_afs_set_consumed(self._h, len(a), F.ptr(a), F.ptr(lo), F.ptr(hi), None if f is None else F.ptr(f),
+                                                              None if st is None else F.ptr(st)))
+
+    def pending_afs_read(self, n_workloads):
+        from kueue_amd.afs import join128
+        L = self._afs
+        cells = L.n_lq * L.n_res
+        usage = np.zeros(L.n_lq, np.float64)
+        plo, phi, pp = np.zeros(cells, np.uint64), np.zeros(cells, np.int64), np.zeros(cells, np.uint8)
+        clo, chi = np.zeros(cells, np.uint64), np.zeros(cells, np.int64)
+        rec = np.zeros(max(n_workloads, 1), np.uint8)
+        self._check(self._lib.kq_pending_afs_read(self._h, F.ptr(usage), F.ptr(plo), F.ptr(phi), F.ptr(pp), F.ptr(clo), F.ptr(chi), F.ptr(rec)))
+        pen = [join128(a, b) for a, b in zip(plo.tolist(), phi.tolist())]
+        con = [join128(a, b) for a, b in zip(clo.tolist(), chi.tolist())]
+        return dict(usage=usage, penalty=pen, present=pp, consumed=con, record=rec[:n_workloads])
+
     def pending_queue_inadmissible(self, cqs=None):
         if cqs is None:
             self._check(self._lib.kq_pending_queue_inadmissible(self._h, 0, None))

@@ -74,6 +74,11 @@ struct EmuBackend {
     pend_scan(D, G, 0, 1, nullptr);
     for (int h = 0; h < D.counts[0]; h++) pend_gather_head(D, G, h);
   }
+  void launch_afs_usage(const DPend& D, bool init_f64) { for (int l = 0; l < D.A.n_lq; l++) afs_init_lq(D.A, l, init_f64); }
+  void launch_afs_sub(const DPend& D, const int32_t* list, int n) { afs_sub_list(D, list, n); }
+  void launch_afs_set_consumed(const DPend& D, const int32_t* lq, const uint64_t* lo, const int64_t* hi, const double* f64, const int32_t* settle, int n) {
+    for (int i = 0; i < n; i++) afs_set_consumed(D.A, lq, lo, hi, f64, settle, i);
+  }
   void launch_pend_apply(const DPend& D, const DSnap& S, const DOut& O, const DHeads& H, uint32_t gates, int64_t cycle, int n) {
     for (int h = 0; h < n; h++) pend_apply_head(D, S, O, H, gates, cycle, h);
   }
@@ -219,6 +224,15 @@ int kqe_pending_put(void* e, const kq_pending* p) { return ((EmuEngine*)e)->pend
 int kqe_pending_heads(void* e, int64_t cycle, const uint8_t* act, int32_t* n, int32_t* nps, int32_t* hw) { return ((EmuEngine*)e)->pending_heads(cycle, act, n, nps, hw); }
 int kqe_cycle_run_pending(void* e, kq_decisions* out) { return ((EmuEngine*)e)->cycle_run_pending(out); }
 int kqe_pending_apply(void* e) { return ((EmuEngine*)e)->pending_apply(); }
+int kqe_pending_afs_put(void* e, const kq_afs_ledger* l) { return ((EmuEngine*)e)->pending_afs_put(l); }
+int kqe_pending_afs_wl_penalty(void* e, int32_t n, const int32_t* wl, const uint64_t* lo, const int64_t* hi, const uint64_t* mask) { return ((EmuEngine*)e)->pending_afs_wl_penalty(n, wl, lo, hi, mask); }
+int kqe_pending_afs_sub_penalty(void* e, int32_t n, const int32_t* wl) { return ((EmuEngine*)e)->pending_afs_sub_penalty(n, wl); }
+int kqe_pending_afs_set_consumed(void* e, int32_t n, const int32_t* lq, const uint64_t* lo, const int64_t* hi, const double* f64, const int32_t* settle) {
+  return ((EmuEngine*)e)->pending_afs_set_consumed(n, lq, lo, hi, f64, settle);
+}
+int kqe_pending_afs_read(void* e, double* usage, uint64_t* plo, int64_t* phi, uint8_t* pp, uint64_t* clo, int64_t* chi, uint8_t* wrec) {
+  return ((EmuEngine*)e)->pending_afs_read(usage, plo, phi, pp, clo, chi, wrec);
+}
 int kqe_pending_set_lq_usage(void* e, int32_t n, const double* u) { return ((EmuEngine*)e)->pending_set_lq_usage(n, u); }
 int kqe_pending_add(void* e, const kq_pending* more, int32_t* first) { return ((EmuEngine*)e)->pending_add(more, first); }
 int kqe_pending_set_clock(void* e, int64_t now) { return ((EmuEngine*)e)->pending_set_clock(now); }

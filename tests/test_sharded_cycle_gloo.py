@@ -135,8 +135,8 @@ def test_sharded_cycle_world1_gpu(kind):
     try:
         for c in range(4):
             heads = pop.heads_for_cycle(c, cycle=c + 1)
-            want = a.run(heads, tgt_cap=4 * pop.snapshot.n_adm, rsn_cap=4096)
-            got = sc.cycle(heads, tgt_cap=4 * pop.snapshot.n_adm, rsn_cap=4096)
+            want = a.run(heads, tgt_cap=4 * pop.snapshot.n_adm, rsn_cap=128 * heads.n)
+            got = sc.cycle(heads, tgt_cap=4 * pop.snapshot.n_adm, rsn_cap=128 * heads.n)
             assert not want.equal(got), (kind, c, want.equal(got))
             a.commit(); b.commit()
             assert np.array_equal(a.read_usage(), b.read_usage())
