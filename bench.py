@@ -43,6 +43,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--open-loop", action="store_true",
                     help="every cycle sees the same snapshot (no kq_cycle_commit / kq_cycle_release between cycles)")
+    ap.add_argument("--loop", default="pipelined", choices=["pipelined", "sync"],
+                    help="pending workloads (cfg2 / cfg3 / cfg3f): one enqueue per cycle with the decisions fetched one cycle later (kq_pending_step), or the "
+                         "call-by-call loop with two host round trips per cycle")
+    ap.add_argument("--parity-cycles", type=int, default=0, help="pending loop: cycles of the parity gate (0 = 12, 6 with fair sharing)")
     ap.add_argument("--hold", type=int, default=4, help="closed loop: admitted workloads finish after this many cycles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true")
@@ -295,9 +299,39 @@ class PendingLoop:
         self.nq = snap.n_cq
         # decision buffers sized once for the widest cycle (<= 1 head per ClusterQueue)
         any_heads = pop.heads_for_cycle(0)
-        self.out = Decisions(any_heads, tgt_cap=tgt_cap, n=snap.n_cq, n_ps=int(pop.w_nps.max()) * snap.n_cq)
+        mh, mps = eng.pending_bounds()
+        self.out = Decisions(any_heads, tgt_cap=tgt_cap, n=mh, n_ps=max(mps, int(pop.w_nps.max()) * snap.n_cq))
         self.n = C.c_int32(); self.nps = C.c_int32()
         self.hw = np.full(snap.n_cq, -1, np.int32)
+
+    # -- the same loop enqueued one cycle per call (kq_pending_step): the host runs one cycle ahead of the device and fetches the
+    #    decisions of cycle i while cycle i+1 executes; no host round trip inside a cycle
+    def issue(self, want_heads=False):
+        C, lib, h, eng = self.C, self.lib, self.h, self.eng
+        self.cycle += 1
+        self.live += 1
+        rel = 0
+        if self.live > self.hold:
+            rel = self.hold + 1; self.live -= 1
+        eng._check(lib.kq_pending_step(h, self.cycle, None, self.out.struct().tgt_cap, rel, 1 if want_heads else 0))
+        self.in_flight = getattr(self, "in_flight", 0) + 1
+
+    def wait(self, want_heads=False):
+        C, lib, h, eng = self.C, self.lib, self.h, self.eng
+        eng._check(lib.kq_pending_step_wait(h, C.byref(self.out.struct()), C.byref(self.n), C.byref(self.nps), F_ptr(self.hw) if want_heads else None))
+        self.in_flight -= 1
+        return self.n.value
+
+    def step_pipelined(self, want_heads=False):
+        """Issue the next cycle, then collect the oldest one once two are in flight -> decisions collected by this call."""
+        self.issue(want_heads)
+        return self.wait(want_heads) if self.in_flight >= 2 else 0
+
+    def drain(self, want_heads=False):
+        n = 0
+        while getattr(self, "in_flight", 0) > 0:
+            n += self.wait(want_heads)
+        return n
 
     def step(self, want_heads=False):
         C, lib, h, eng = self.C, self.lib, self.h, self.eng
@@ -331,6 +365,7 @@ def pending_parity_gate(eng, pop, kcfg, hold, cycles):
     for _ in range(8):
         root_of = np.where(parent[root_of] >= 0, parent[root_of], root_of)
     held, live, dec = [], 0, 0
+    record = []   # (heads batch, popped workloads, the oracle's decisions) per cycle: the pipelined replay below must give the same
     try:
         for cyc in range(1, cycles + 1):
             n, nps, hw = eng.pending_heads(cyc)
@@ -342,6 +377,7 @@ def pending_parity_gate(eng, pop, kcfg, hold, cycles):
             bad = want.equal(got)
             if bad:
                 return False, f"cycle {cyc}: MISMATCH in {bad}"
+            record.append((hb, ohw, want))
             dec += n
             usage, na, triples = kqo.cycle_commit(kcfg, osnap, hb)
             osnap.arrays["usage"] = usage; osnap._struct = None
@@ -356,7 +392,41 @@ def pending_parity_gate(eng, pop, kcfg, hold, cycles):
                     q.queue_inadmissible(np.nonzero(np.isin(root_of[:snap.n_cq], freed))[0])
             if not np.array_equal(eng.pending_state()[0], q.state()):
                 return False, f"cycle {cyc}: queue states differ"
-        return True, f"first {cycles} cycles of the pending loop ({dec} decisions): Heads(), every decision field and the queue states equal the oracle's"
+        final_state = q.state().copy()
+        # the same cycles through kq_pending_step / kq_pending_step_wait, two steps in flight
+        eng.put(snap); eng.pending_put(pending)
+        mh, mps = eng.pending_bounds()
+        outs = [Decisions(record[0][0], tgt_cap=max(4096, snap.n_adm), n=mh, n_ps=mps) for _ in range(2)]
+        live = issued = waited = 0
+
+        def collect():
+            nonlocal waited
+            n, nps, hw = eng.pending_step_wait(outs[waited % 2], want_heads=True)
+            hb, ohw, want = record[waited]
+            if not np.array_equal(hw, ohw) or n != hb.n:
+                return f"pipelined cycle {waited + 1}: Heads() differ"
+            bad = want.equal(outs[waited % 2].view(hb))
+            waited += 1
+            return f"pipelined cycle {waited}: MISMATCH in {bad}" if bad else None
+
+        for cyc in range(1, cycles + 1):
+            live += 1
+            rel = 0
+            if live > hold:
+                rel = hold + 1; live -= 1
+            eng.pending_step(cyc, max(4096, snap.n_adm), release_age=rel, want_heads=True); issued += 1
+            if issued - waited >= 2:
+                err = collect()
+                if err:
+                    return False, err
+        while waited < issued:
+            err = collect()
+            if err:
+                return False, err
+        if not np.array_equal(eng.pending_state()[0], final_state):
+            return False, "pipelined loop: queue states differ"
+        return True, (f"first {cycles} cycles of the pending loop ({dec} decisions), call by call and again through kq_pending_step with two steps in flight: "
+                      "Heads(), every decision field and the queue states equal the oracle's")
     finally:
         q.close()
 
@@ -379,7 +449,7 @@ def bench_pending(args, torch, dist, world, rank, local_rank):
     tgt_cap = max(4096, (32 if fair else 4) * snap.n_adm)
     parity = (None, "skipped")
     if rank == 0 and not args.no_parity_gate:
-        parity = pending_parity_gate(eng, pop, kcfg, args.hold, 6 if fair else 12)
+        parity = pending_parity_gate(eng, pop, kcfg, args.hold, args.parity_cycles or (6 if fair else 12))
     pending = pop.pending()
 
     def reset():
@@ -390,6 +460,7 @@ def bench_pending(args, torch, dist, world, rank, local_rank):
     loop = reset()
     lib, h = eng._lib, eng._h
     phase_ms = np.zeros(3, np.float64); phase_by = np.zeros(2, np.int64)
+    pipelined = args.loop == "pipelined"
     for _ in range(args.warmup):
         loop.step()
     torch.cuda.synchronize()
@@ -398,14 +469,31 @@ def bench_pending(args, torch, dist, world, rank, local_rank):
     cyc_ms, dec = [], 0
     nom_ms = ord_ms = proc_ms = 0.0
     nom_by = proc_by = 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        t1 = time.perf_counter()
-        dec += loop.step()
-        cyc_ms.append((time.perf_counter() - t1) * 1e3)
+
+    def phases():
+        nonlocal nom_ms, ord_ms, proc_ms, nom_by, proc_by
         lib.kq_last_cycle_phases(h, F.ptr(phase_ms), F.ptr(phase_by))
         nom_ms += phase_ms[0]; ord_ms += phase_ms[1]; proc_ms += phase_ms[2]
         nom_by += int(phase_by[0]); proc_by += int(phase_by[1])
+
+    t0 = time.perf_counter()
+    if pipelined:
+        # exactly `steps` cycles: each is issued once and collected once; cycle i's decisions are fetched while cycle i+1 runs
+        t1 = t0
+        for _ in range(args.steps):
+            loop.issue()
+            if loop.in_flight >= 2:
+                dec += loop.wait(); phases()
+                t2 = time.perf_counter(); cyc_ms.append((t2 - t1) * 1e3); t1 = t2
+        while loop.in_flight > 0:
+            dec += loop.wait(); phases()
+            t2 = time.perf_counter(); cyc_ms.append((t2 - t1) * 1e3); t1 = t2
+    else:
+        for _ in range(args.steps):
+            t1 = time.perf_counter()
+            dec += loop.step()
+            cyc_ms.append((time.perf_counter() - t1) * 1e3)
+            phases()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -430,7 +518,9 @@ def bench_pending(args, torch, dist, world, rank, local_rank):
                                    f"{snap.n_resource} resources, {snap.n_adm} admitted, {pop.n_pending} pending per GPU resident in HBM; "
                                    f"one cycle = Heads() (<= 1 head per ClusterQueue, {dec // max(args.steps, 1)} on average)",
                        "heads_per_cycle": dec / max(args.steps, 1), "pending_per_gpu": pop.n_pending, "sharding": "root cohort per GPU, no collective",
-                       "loop": f"pending side on device: Heads() + requeue policy per cycle; admissions committed every cycle, finished after {args.hold} cycles"},
+                       "loop": f"pending side on device: Heads() + requeue policy per cycle; admissions committed every cycle, finished after {args.hold} cycles; "
+                               + ("one enqueue per cycle (kq_pending_step), decisions of cycle i fetched while cycle i+1 runs; cycle_ms = interval between completions"
+                                  if pipelined else "kq_pending_heads / kq_cycle_run_pending / commit / apply / release, two host round trips per cycle")},
             "p50_cycle_ms": float(np.percentile(cyc_ms, 50)), "p99_cycle_ms": float(np.percentile(cyc_ms, 99)),
             "kernel_ms_per_cycle": {"k_nominate": nom_ms / args.steps, "k_order": ord_ms / args.steps, "k_process": proc_ms / args.steps},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
@@ -442,7 +532,8 @@ def bench_pending(args, torch, dist, world, rank, local_rank):
             loop = reset()
             decided = np.zeros(pop.n_pending, bool)
             ms, fdec, cyc = [], 0, 0
-            while cyc < args.full_run and not decided.all():
+            parked = np.zeros(pop.n_pending, bool)
+            while cyc < args.full_run and not (decided | parked).all():
                 t1 = time.perf_counter()
                 n = loop.step(want_heads=True)
                 ms.append((time.perf_counter() - t1) * 1e3)
@@ -451,11 +542,19 @@ def bench_pending(args, torch, dist, world, rank, local_rank):
                     break
                 decided[loop.hw[loop.hw >= 0]] = True
                 fdec += n
+                if cyc % 25 == 0:
+                    # a workload whose equivalence class was bulk-moved with a NoFit head is parked among the inadmissible workloads
+                    # without ever being a head (cluster_queue.go:592-597): the reference decides it "by class", so does the run
+                    st, _ = eng.pending_state()
+                    parked = (st == 2) & ~decided
             st, counts = eng.pending_state()
-            out["full_run"] = {"cycles": cyc, "decisions": fdec, "workloads_decided": int(decided.sum()), "of": pop.n_pending,
+            parked = (st == 2) & ~decided
+            out["full_run"] = {"cycles": cyc, "decisions": fdec, "workloads_decided": int(decided.sum()), "parked_with_their_class": int(parked.sum()),
+                               "complete": bool((decided | parked).all()), "of": pop.n_pending,
                                "decisions_per_s": fdec / (sum(ms) * 1e-3), "p50_cycle_ms": float(np.percentile(ms, 50)), "p99_cycle_ms": float(np.percentile(ms, 99)),
                                "admitted": int(counts[3]), "still_active": int(counts[0]), "inadmissible": int(counts[2]),
-                               "what": "fresh queue -> cycles until every pending workload had >= 1 decision (or the cycle cap); wall time per cycle, heads read back"}
+                               "what": "fresh queue -> cycles until every pending workload had >= 1 decision or was parked with its equivalence class "
+                                       "(handleInadmissibleHash, cluster_queue.go:606) without being a head, or the cycle cap; wall time per cycle, heads read back"}
         if not args.no_host_leg:
             eng.put(snap)
             out["host_heads"] = host_heads_leg(eng, pop, kcfg, snap, min(args.steps, 50), True, args.hold, fair, 0)

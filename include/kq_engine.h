@@ -373,6 +373,24 @@ int  kq_cycle_run_pending(kq_engine* e, kq_decisions* out);
 int  kq_pending_apply(kq_engine* e);
 /* ComputeLocalQueueFSUsage of every LocalQueue (workload.go:492) as the ledger stands now; read by the next kq_pending_heads. */
 int  kq_pending_set_lq_usage(kq_engine* e, int32_t n_lq, const double* usage);
+/* ---- the pending loop without a host round trip inside a cycle (one cycle = one enqueue) --------------------------------------
+ * kq_pending_step enqueues kq_pending_heads -> kq_cycle_run_pending -> kq_cycle_commit -> kq_pending_apply (-> kq_cycle_release(
+ * release_age) when release_age > 0) on the engine's stream and returns WITHOUT waiting: the head count never leaves the device (every
+ * array and grid is sized by the bound of kq_pending_bounds: <= 1 head per ClusterQueue, the widest workload of every ClusterQueue),
+ * and the decisions land in pinned host memory behind an event. kq_pending_step_wait blocks until the OLDEST step in flight is done
+ * and unpacks its decisions; at most two steps may be in flight, so the host enqueues cycle i+1 while the device runs cycle i
+ * (schedule()'s own side effects — the API writes of admit / requeueAndUpdate — trail the cycle in the reference as well,
+ * scheduler.go:362-377 runs them from the decisions, not the other way round).
+ * `out` of kq_pending_step_wait is sized for the bound (kq_pending_bounds); reason records are not produced on this path
+ * (out->rsn_cap is ignored: use kq_cycle_run_pending for a cycle whose messages are wanted). tgt_cap as in kq_decisions.
+ * A step whose cycle fails on the device (KQ_ECAPACITY of the target pool, ...) commits nothing and puts its heads back into their
+ * heaps; kq_pending_step_wait returns the error for that step. KQ_ECAPACITY from the unpack (out->tgt_cap too small for the target
+ * CSR) leaves the step applied on the device.
+ * Not to be mixed with kq_pending_heads / kq_pending_apply while a step is in flight. */
+int  kq_pending_bounds(kq_engine* e, int32_t* max_heads, int32_t* max_podsets);
+int  kq_pending_step(kq_engine* e, int64_t cycle, const uint8_t* cq_active, int32_t tgt_cap, int32_t release_age, int32_t want_head_wl);
+int  kq_pending_step_wait(kq_engine* e, kq_decisions* out, int32_t* n_heads, int32_t* n_podsets, int32_t* head_wl);
+
 /* ---- AdmissionFairSharing ledger on the device (pkg/cache/queue/afs/usage_ledger.go, entry_penalties.go) --------------------
  * With a ledger resident, the LocalQueues' fair-sharing usage that Heads() orders by is evaluated on the device from the ledger, and the
  * scheduler's own write to it — the entry penalty pushed when a workload is assumed (scheduler.go:1064-1068 assumeWorkload ->

@@ -710,6 +710,21 @@ class Decisions:
     def struct(self) -> F.kq_decisions:
         return self._struct
 
+    def view(self, heads: Heads) -> "Decisions":
+        """The decisions of a cycle over `heads` held in buffers sized for a bound (kq_pending_step_wait): the same fields cut to the
+        heads / podsets of that cycle, comparable with equal()."""
+        n, nps, nR = heads.n, heads.n_ps, self.snap.n_resource
+        v = Decisions.__new__(Decisions)
+        v.heads, v.snap, v._struct = heads, self.snap, None
+        per_head = ("status", "action", "nominated_mode", "mode", "requeue_reason", "skip", "borrowing", "order")
+        v.a = {k: self.a[k][:n].copy() for k in per_head}
+        for k in ("flavor", "res_mode", "tried_idx"):
+            v.a[k] = self.a[k][:nps * nR].copy()
+        v.a["ps_count"] = self.a["ps_count"][:nps].copy()
+        v.a["tgt_off"] = self.a["tgt_off"][:n + 1].copy()
+        v.a["tgt_adm"], v.a["tgt_reason"] = self.a["tgt_adm"], self.a["tgt_reason"]
+        return v
+
     def targets(self, i: int) -> List[Tuple[int, int]]:
         o = self.a["tgt_off"]
         return [(int(self.a["tgt_adm"][k]), int(self.a["tgt_reason"][k])) for k in range(o[i], o[i + 1])]

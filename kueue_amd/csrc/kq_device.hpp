@@ -270,7 +270,8 @@ struct DCfg {
 };
 
 struct DHeads {
-  int n;
+  int n;                  // head count; with n_dev set: only an upper bound (arrays and grids are sized by it)
+  const int32_t* n_dev;   // the count in device memory (the pending side's gather writes it: kq_pending_step) or null
   const int32_t* cq;
   const int64_t *priority, *queue_ts;
   const uint32_t* flags;
@@ -286,6 +287,8 @@ struct DHeads {
   const int32_t* ps_slice_pods_flavor;
   const int64_t* ps_slice_pods_qty;
 };
+
+KQ_DEV int hn(const DHeads& H) { return H.n_dev ? H.n_dev[0] : H.n; }
 
 // One reason why a flavor was not assigned as Fit: the operands of a Status.reasons string (flavorassigner.go:349), see KQ_RSN_*.
 struct alignas(16) RsnRec { uint8_t code, podset; int16_t flavor, resource, pad; int64_t a, b, c; };
@@ -3056,6 +3059,13 @@ static_assert(offsetof(PRec, un0) - offsetof(PRec, uw0) == FU * sizeof(int64_t),
 // Runs for every head between k_nominate and k_process (k_records), so that the prefetch inside k_process is two dependent
 // memory round trips (entry -> record, record -> ClusterQueue usage cells) instead of walking head -> ClusterQueue -> path ->
 // quota cells for every chunk while the serial core waits.
+// kq_pending_step: the head / podset counts the gather left on the device travel to the host inside the packed decisions (the free
+// word behind the byte counters), so the step needs no copy of its own for them. One call per cycle (k_records).
+KQ_DEV void pack_counts(const K& k) {
+  if (!k.H.n_dev) return;
+  int32_t* m = k.O.pool_count + 6;   // misc[3] of the pack: [pool_count | error][nominate bytes][process bytes][n_heads | n_podsets]
+  m[0] = k.H.n_dev[0]; m[1] = k.H.n_dev[1];
+}
 KQ_DEV void rec_fill_static(const K& k, int e, int c) {
   const DSnap& S = k.S; const DOut& O = k.O; const DHeads& H = k.H;
   PRec& r = k.grec[e];
@@ -3589,7 +3599,7 @@ KQ_DEV bool chunk_entry_fast(Wave& w, int64_t* pcl, PRec& r, const CoreCtx& cc, 
 // serial core and the generic path. Workgroup-uniform control flow comes from LDS scalars read after a bsync().
 KQ_DEV void process_tree(const K& k, Wave& w, int tree, int slot, int64_t* lds, size_t lds_bytes, int tid, int nthreads) {
   const DSnap& S = k.S; const DOut& O = k.O;
-  const int n = k.H.n;
+  const int n = hn(k.H);
   const int lane = lane_id();
   const bool leader = tid < WAVE;
   const size_t rec_bytes = sizeof(PRec) * CH * NBUF;
@@ -3948,7 +3958,7 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
   const CoreCtx cc = core_ctx(k, w, tree);
   cert_unverifiable(k, tree);  // the DRS tournament compares ClusterQueues of every subtree: a shard of the tree cannot run it alone
   // cqToEntry: the last head of a CQ wins (:58-60)
-  for (int h = tid; h < H.n; h += nthreads) {
+  for (int h = tid; h < hn(H); h += nthreads) {
     int c = H.cq[h];
     if (S.tree_of[c] == tree) atomic_max_i32(&cq_ent[S.cq_local[c]], h);
   }
@@ -4255,13 +4265,18 @@ KQ_DEV void usage_add_cell(int64_t* usage, const int64_t* delta, size_t i, int s
 }
 // which heads of the last cycle count: action == admit and no quota reservation held (netUsage scheduler.go:785-794)
 KQ_DEV void commit_mask_head(const K& k, int h, int32_t* use_n_out, int32_t* cq_out, int32_t* count) {
-  const bool take = k.O.action[h] == KQ_ACT_ADMIT && !(k.H.flags[h] & KQ_HEAD_HAS_QUOTA_RESERVATION);
+  // (a cycle that ended with a device-side error commits nothing: the asynchronous step enqueues the commit before the host has seen the flag)
+  const bool take = k.O.action[h] == KQ_ACT_ADMIT && !(k.H.flags[h] & KQ_HEAD_HAS_QUOTA_RESERVATION) && !(k.O.error && k.O.error[0] != 0);
   use_n_out[h] = take ? k.O.use_n[h] : 0;
   cq_out[h] = k.H.cq[h];
   if (take) atomic_add_i32(count, 1);
 }
 // one call per (head, slot): keeps the cycle's usage rows for a later release (the cycle's own buffers are reused)
 KQ_DEV void commit_keep_cell(const K& k, int i, int32_t* use_n_out, int32_t* cq_out, int32_t* fr_out, int64_t* qty_out, int32_t* count) {
+  if (i >= hn(k.H) * KQ_MAXU) {  // rows between the head count and the bound the arrays are sized for (kq_pending_step) commit nothing
+    if (i % KQ_MAXU == 0) use_n_out[i / KQ_MAXU] = 0;
+    return;
+  }
   fr_out[i] = k.O.use_fr[i]; qty_out[i] = k.O.use_qty[i];
   if (i % KQ_MAXU == 0) commit_mask_head(k, i / KQ_MAXU, use_n_out, cq_out, count);
 }

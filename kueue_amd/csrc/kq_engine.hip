@@ -35,7 +35,7 @@ using namespace kq;
 __global__ __launch_bounds__(64) void k_nominate_lean(const K* __restrict__ kp, int slots) {
   const K& k = *kp;
   __shared__ Wave w;
-  for (int h = blockIdx.x; h < k.H.n; h += slots) nominate_head_lean(k, w, h);
+  for (int h = blockIdx.x, n = hn(k.H); h < n; h += slots) nominate_head_lean(k, w, h);
 }
 // Full pass (victim searches, GetTargets, partial admission) over the heads the first pass deferred.
 __global__ __launch_bounds__(64) void k_nominate(const K* __restrict__ kp, int slots, unsigned lds_bytes) {
@@ -69,7 +69,7 @@ __device__ __forceinline__ OrderKey order_key(const K& k, int h, bool pre, bool 
 __global__ __launch_bounds__(256) void k_order(const K* __restrict__ kp, int32_t* rank) {
   const K& k = *kp;
   __shared__ OrderKey tile[ORDER_TILE];
-  const int n = k.H.n;
+  const int n = hn(k.H);
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int base = blockIdx.y * ORDER_TILE;
   const bool pre = gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS), psort = gate(k, KQ_GATE_PRIORITY_SORTING_IN_COHORT);
@@ -88,9 +88,12 @@ __global__ __launch_bounds__(256) void k_order(const K* __restrict__ kp, int32_t
   }
   if (cnt) atomicAdd(&rank[i], cnt);
 }
-__global__ __launch_bounds__(256) void k_order_scatter(const K* __restrict__ kp, int n, const int32_t* rank, int32_t* order_idx) {
+__global__ __launch_bounds__(256) void k_order_scatter(const K* __restrict__ kp, int n, const int32_t* rank, int32_t* order_idx, int patch_stat) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  // the process step charges its bytes to the next counter: the argument block is patched in place instead of being uploaded a second
+  // time (classical path; nothing in this kernel reads the field)
+  if (i == 0 && patch_stat) const_cast<K*>(kp)->O.stat_bytes = kp->O.stat_bytes + 1;
+  if (i >= n || i >= hn(kp->H)) return;
   const int r = rank[i];
   order_idx[r] = i;
   if (kp->spec_hdr) kp->spec_hdr[r] = spec_hdr_of(*kp, i);  // the rounds' view of the entry, by iterator position (kq_spec.hpp)
@@ -100,7 +103,8 @@ __global__ __launch_bounds__(256) void k_order_scatter(const K* __restrict__ kp,
 __global__ __launch_bounds__(256) void k_records(const K* __restrict__ kp) {
   const K& k = *kp;
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx < k.H.n * FU * FD) rec_fill_static(k, idx / (FU * FD), idx % (FU * FD));
+  if (idx == 0) pack_counts(k);
+  if (idx < hn(k.H) * FU * FD) rec_fill_static(k, idx / (FU * FD), idx % (FU * FD));
 }
 
 // k_process_spec (speculative parallel rounds over the plain entries of a tree, kq_spec.hpp) is compiled in its own translation unit
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(FAIR_THREADS) void k_process_fair(const K* __restri
 // global iteration positions from the per-tree sequences (kq::fair_rank): 2-D grid like k_order
 __global__ __launch_bounds__(256) void k_fair_rank(const K* __restrict__ kp, int32_t* rank) {
   const K& k = *kp;
-  const int n = k.H.n;
+  const int n = hn(k.H);
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n || k.X.fs_key[i] < 0) return;
   const int base = blockIdx.y * 256;
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void k_fair_rank(const K* __restrict__ kp, int
 __global__ __launch_bounds__(256) void k_fair_rank_apply(const K* __restrict__ kp, const int32_t* rank) {
   const K& k = *kp;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < k.H.n && k.X.fs_key[i] >= 0) k.O.order[i] = rank[i];
+  if (i < hn(k.H) && k.X.fs_key[i] >= 0) k.O.order[i] = rank[i];
 }
 
 __global__ __launch_bounds__(256) void k_commit_mask(const K* __restrict__ kp, int32_t* use_n_out, int32_t* cq_out, int32_t* fr_out, int64_t* qty_out, int32_t* count) {
@@ -176,6 +180,20 @@ __global__ __launch_bounds__(64) void k_commit(DSnap S, DCommit c, int add) { co
 __global__ __launch_bounds__(256) void k_commit_cq(DSnap S, DCommit c, int add) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < c.n * KQ_MAXU) commit_cq_cell(c, S, i / KQ_MAXU, i % KQ_MAXU, add != 0);
+}
+// the same for larger trees in ONE launch: the levels of a flavor-resource column only depend on that column, so a workgroup takes a
+// few columns of every cohort through all levels (barrier between levels) — 1 launch instead of max_depth + 1 (4 x ~6 us at cfg 3)
+__global__ __launch_bounds__(256) void k_usage_cols(DSnap S, int64_t* usage, int max_depth, int cols) {
+  const int col0 = blockIdx.x * cols;
+  const int ncol = (col0 + cols <= S.nfr) ? cols : S.nfr - col0;
+  for (int dep = max_depth; dep >= 0; dep--) {
+    for (int i = threadIdx.x; i < S.nc * ncol; i += 256) {
+      const int cohort = S.nq + i / ncol;
+      if (S.depth[cohort] == dep) derive_usage_cell(S, usage, cohort, col0 + i % ncol);
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
 }
 __global__ __launch_bounds__(256) void k_usage_level(DSnap S, int64_t* usage, int depth) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -299,7 +317,9 @@ __global__ __launch_bounds__(256) void k_usage_add(int64_t* usage, const int64_t
 namespace kq {
 struct HipBackend {
   hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};  // phase timers, one set per step in flight
+  hipEvent_t sev[2] = {nullptr, nullptr};   // "everything of this asynchronous step is done" (kq_pending_step_wait)
+  int stage = 0;                            // which of the two sets the calls below use
   int device = 0;
   int n_cu = 256;
   hipError_t err = hipSuccess;
@@ -319,11 +339,15 @@ struct HipBackend {
     chk(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties");
     if (err == hipSuccess) n_cu = prop.multiProcessorCount;
     chk(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
-    for (auto& e2 : ev) chk(hipEventCreate(&e2), "hipEventCreate");
+    for (auto& set : ev) for (auto& e2 : set) chk(hipEventCreate(&e2), "hipEventCreate");
+    for (auto& e2 : sev) chk(hipEventCreateWithFlags(&e2, hipEventDisableTiming), "hipEventCreate");
+    chk(hipHostMalloc((void**)&hk, 4 * sizeof(K), hipHostMallocDefault), "hipHostMalloc K");
     return err == hipSuccess ? KQ_OK : KQ_EDEVICE;
   }
   void destroy() {
-    for (auto& e2 : ev) if (e2) (void)hipEventDestroy(e2);
+    for (auto& set : ev) for (auto& e2 : set) if (e2) (void)hipEventDestroy(e2);
+    for (auto& e2 : sev) if (e2) (void)hipEventDestroy(e2);
+    if (hk) (void)hipHostFree(hk);
     for (auto& d : dk) if (d) (void)hipFree(d);
     if (dtk) (void)hipFree(dtk);
     if (stream) (void)hipStreamDestroy(stream);
@@ -345,14 +369,23 @@ struct HipBackend {
   int max_slots() { return n_cu * 16; }  // 16 one-wave workgroups per CU (4 per SIMD)
   size_t lds_budget() { return 160 * 1024 - sizeof(Wave) - 256; }  // dynamic LDS a workgroup can get next to its static Wave
   // HIP events on the engine's own stream bracket each kernel (live per-kernel duration)
-  void timer_mark(int i) { chk(hipEventRecord(ev[i], stream), "hipEventRecord"); }
-  double timer_ms(int a, int b) { float ms = 0; chk(hipEventElapsedTime(&ms, ev[a], ev[b]), "hipEventElapsedTime"); return ms; }
+  void timer_mark(int i) { chk(hipEventRecord(ev[stage][i], stream), "hipEventRecord"); }
+  double timer_ms(int a, int b) { float ms = 0; chk(hipEventElapsedTime(&ms, ev[stage][a], ev[stage][b]), "hipEventElapsedTime"); return ms; }
+  // asynchronous steps: two in flight at most, each with its own timers, K staging and completion event
+  void stage_select(int i) { stage = i & 1; }
+  void stage_mark() { chk(hipEventRecord(sev[stage], stream), "hipEventRecord"); }
+  int stage_wait() {
+    chk(hipEventSynchronize(sev[stage]), "hipEventSynchronize");
+    if (err != hipSuccess) { err = hipSuccess; (void)hipGetLastError(); return KQ_EDEVICE; }
+    return KQ_OK;
+  }
   K* dk[2] = {nullptr, nullptr};   // device copies of the argument block (nominate/order, process)
-  K hk[2];                         // host staging must outlive the async copy
+  K* hk = nullptr;                 // pinned staging [stage][which]: a pageable source would make hipMemcpyAsync wait for the stream
   const K* put_k(const K& k, int which) {
     if (!dk[which]) chk(hipMalloc((void**)&dk[which], sizeof(K)), "hipMalloc K");
-    hk[which] = k;
-    chk(hipMemcpyAsync(dk[which], &hk[which], sizeof(K), hipMemcpyHostToDevice, stream), "memcpy K");
+    K* h = hk + stage * 2 + which;
+    memcpy((void*)h, (const void*)&k, sizeof(K));
+    chk(hipMemcpyAsync(dk[which], h, sizeof(K), hipMemcpyHostToDevice, stream), "memcpy K");
     return dk[which];
   }
   TK* dtk = nullptr;
@@ -398,7 +431,7 @@ struct HipBackend {
     chk(hipGetLastError(), "k_tas_overflow");
   }
   void launch_commit_mask(int n, int32_t* use_n_out, int32_t* cq_out, int32_t* fr_out, int64_t* qty_out, int32_t* count) {  // uses the K block of the last cycle
-    hipLaunchKernelGGL(k_commit_mask, dim3((n * KQ_MAXU + 255) / 256), dim3(256), 0, stream, (const K*)dk[1], use_n_out, cq_out, fr_out, qty_out, count);
+    hipLaunchKernelGGL(k_commit_mask, dim3((n * KQ_MAXU + 255) / 256), dim3(256), 0, stream, dproc, use_n_out, cq_out, fr_out, qty_out, count);
     chk(hipGetLastError(), "k_commit_mask");
   }
   // ClusterQueue-level cells only; the cohort levels follow from them (launch_usage_levels, deferred by the host)
@@ -416,6 +449,10 @@ struct HipBackend {
     // one workgroup for all levels only while every thread has at most one cell per level; beyond that a launch per level
     // (many workgroups) is faster than the serial passes of one (measured: 75 us vs 4 x 6.5 us at 7104 cells)
     if (cells <= 1024) hipLaunchKernelGGL(k_usage_levels, dim3(1), dim3(1024), 0, stream, S, usage, max_depth);
+    else if (S.nc <= 4096) {  // one launch: a workgroup per group of columns (as many as keep one cell per thread and level)
+      const int cols = std::max(1, std::min(S.nfr, 256 / std::max(S.nc, 1)));
+      hipLaunchKernelGGL(k_usage_cols, dim3((S.nfr + cols - 1) / cols), dim3(256), 0, stream, S, usage, max_depth, cols);
+    }
     else for (int dep = max_depth; dep >= 0; dep--)
       hipLaunchKernelGGL(k_usage_level, dim3((cells + 255) / 256), dim3(256), 0, stream, S, usage, dep);
     chk(hipGetLastError(), "k_usage_level");
@@ -506,14 +543,15 @@ struct HipBackend {
     chk(hipGetLastError(), "k_shard_import");
   }
   size_t lds_attr_nom = 0;
-  void launch_nominate(const K& k, int slots, size_t lds) {
+  void launch_nominate(const K& k, int slots, size_t lds, bool full_pass) {
+    stat_patched = false;
     if (lds > 48 * 1024 && lds != lds_attr_nom) {
       chk(hipFuncSetAttribute((const void*)k_nominate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
       lds_attr_nom = lds;
     }
     const K* d = put_k(k, 0);
     hipLaunchKernelGGL(k_nominate_lean, dim3(slots), dim3(64), 0, stream, d, slots);
-    hipLaunchKernelGGL(k_nominate, dim3(slots), dim3(64), lds, stream, d, slots, (unsigned)lds);
+    if (full_pass) hipLaunchKernelGGL(k_nominate, dim3(slots), dim3(64), lds, stream, d, slots, (unsigned)lds);
     chk(hipGetLastError(), "k_nominate");
   }
   void launch_records(const K& k) {
@@ -524,7 +562,8 @@ struct HipBackend {
   void launch_order(const K& k, int32_t* order_idx, int32_t* rank) {
     const int nb = (k.H.n + 255) / 256;
     hipLaunchKernelGGL(k_order, dim3(nb, (k.H.n + ORDER_TILE - 1) / ORDER_TILE), dim3(256), 0, stream, (const K*)dk[0], rank);
-    hipLaunchKernelGGL(k_order_scatter, dim3(nb), dim3(256), 0, stream, (const K*)dk[0], k.H.n, (const int32_t*)rank, order_idx);
+    hipLaunchKernelGGL(k_order_scatter, dim3(nb), dim3(256), 0, stream, (const K*)dk[0], k.H.n, (const int32_t*)rank, order_idx, 1);
+    stat_patched = true;
     chk(hipGetLastError(), "k_order");
   }
   // dynamic LDS = [cohort rows (2 planes) of the largest tree, if they fit][CH prefetched entry records]
@@ -536,12 +575,16 @@ struct HipBackend {
       chk(hipFuncSetAttribute((const void*)k_process, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
       lds_attr = lds;
     }
-    const K* d = put_k(k, 1);
+    // after launch_order the block of the nominate step is already what the process step needs (k_order_scatter moved its byte counter)
+    const K* d = stat_patched ? (const K*)dk[0] : put_k(k, 1);
+    dproc = d; stat_patched = false;
     if (!spec_off && k.spec_kt) chk(launch_process_spec(d, n_tree, stream), "k_process_spec");
     hipLaunchKernelGGL(k_process, dim3(n_tree), dim3(PROCESS_THREADS), lds, stream, d, (unsigned)lds);
     chk(hipGetLastError(), "k_process");
   }
   size_t lds_attr = 0, lds_attr_fair = 0;
+  const K* dproc = nullptr;    // argument block of the last process launch (kq_cycle_commit reads the cycle's outputs through it)
+  bool stat_patched = false;
   bool spec_off = getenv("KQ_SPEC_OFF") != nullptr;  // KQ_SPEC_OFF: every tree goes to the serial kernel (A/B timing)
   // helper workgroups of k_process_fair (K::help): KQ_HELP_BLOCKS of them, none by default. A recomputation under its nomination
   // mapping only simulates the nominated flavor (2-3 searches per batch at cfg 4f): measured 14.8 s against 15.3 s per cycle with 16
@@ -564,6 +607,7 @@ struct HipBackend {
       lds_attr_fair = lds;
     }
     const K* d = put_k(k, 1);
+    dproc = d;
     const int nblk = n_tree + (k.help ? help_blocks(n_tree) : 0);
     hipLaunchKernelGGL(k_process_fair, dim3(nblk), dim3(FAIR_THREADS), lds, stream, d, (unsigned)lds);
     const int nb = (k.H.n + 255) / 256;
@@ -689,6 +733,20 @@ int kq_pending_apply(kq_engine* en) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
   return en->e.pending_apply();
+}
+int kq_pending_bounds(kq_engine* en, int32_t* max_heads, int32_t* max_podsets) {
+  if (!en) return KQ_EINVAL;
+  return en->e.pending_bounds(max_heads, max_podsets);
+}
+int kq_pending_step(kq_engine* en, int64_t cycle, const uint8_t* cq_active, int32_t tgt_cap, int32_t release_age, int32_t want_head_wl) {
+  if (!en) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.pending_step(cycle, cq_active, tgt_cap, release_age, want_head_wl);
+}
+int kq_pending_step_wait(kq_engine* en, kq_decisions* out, int32_t* n_heads, int32_t* n_podsets, int32_t* head_wl) {
+  if (!en) return KQ_EINVAL;
+  (void)hipSetDevice(en->e.be.device);
+  return en->e.pending_step_wait(out, n_heads, n_podsets, head_wl);
 }
 int kq_pending_afs_put(kq_engine* en, const kq_afs_ledger* l) {
   if (!en || !l) return KQ_EINVAL;

@@ -44,7 +44,7 @@ template <class B> struct EngineT {
   bool fs_disable = false;       // tests: fair-sharing victim searches always take the walk
   bool help_disable = false;     // tests: no helper workgroups
   Buf b_cs;
-  struct HeadBatch { Buf hb[1]; DHeads H{}; int n = 0; size_t nps = 0; int slot_cap = 1; int64_t cycle = 0; bool valid = false; bool plain = true; int max_nps = KQ_MAXPS; };
+  struct HeadBatch { Buf hb[1]; DHeads H{}; int n = 0; size_t nps = 0; int slot_cap = 1; int64_t cycle = 0; bool valid = false; bool plain = true; int max_nps = KQ_MAXPS; bool partial = true; };
   std::vector<HeadBatch> batches;  // [0] = transient batch of kq_cycle_run, [1+b] = resident batch b
   Buf ob[24];  // output arrays
   uint8_t* hstage = nullptr;  // pinned host staging for the packed decisions
@@ -64,6 +64,7 @@ template <class B> struct EngineT {
     bool valid = false;
     int W = 0, nq = 0, nR = 0, nF = 0, n_tree = 0, slot_cap = 1, max_nps = 1;
     bool plain = true;
+    bool partial = false;      // some pending podset may be admitted partially
     std::vector<void*> allocs;
     DPend D{};
     DGather G{};
@@ -162,6 +163,7 @@ template <class B> struct EngineT {
   void pending_free() {
     if (last_slot == PEND_SLOT) last_cycle_n = -1;  // the uncommitted pending cycle's gathered head arrays are freed below
     for (void* p : pend.allocs) be.free(p);
+    steps_issued = steps_waited = 0; steps[0].busy = steps[1].busy = false;   // steps in flight die with the set they ran on
     const int64_t now = pend.now;
     pend = Pending{};
     pend.now = now;
@@ -451,11 +453,14 @@ template <class B> struct EngineT {
     return be.sync();
   }
 
+  bool lean_only_ok = getenv("KQ_FULL_PASS_ALWAYS") == nullptr;   // (A/B switch: launch the full nominate pass in every cycle)
+  bool vh_partial = false;   // validate_heads: some podset of the batch may be admitted partially (minCount < count)
   int validate_heads(const kq_heads* h, int* slot_cap, bool* plain, int* max_nps = nullptr) {
     if (h->n < 0) return fail(KQ_EINVAL, "negative head count");
     int cap = 1;
     int mnps = 1;
     *plain = true;
+    vh_partial = false;
     for (int i = 0; i < h->n; i++) {
       if (h->cq[i] < 0 || h->cq[i] >= prep.nq) return fail(KQ_EINVAL, "head cq out of range");
       int nps = h->ps_off[i + 1] - h->ps_off[i];
@@ -466,6 +471,7 @@ template <class B> struct EngineT {
       for (int p = h->ps_off[i]; p < h->ps_off[i + 1]; p++) {
         int nreq = h->ps_req_off[p + 1] - h->ps_req_off[p];
         if (nreq < 0) return fail(KQ_EINVAL, "ps_req_off not monotone");
+        if (h->ps_min_count && h->ps_min_count[p] >= 0 && h->ps_count[p] > h->ps_min_count[p]) vh_partial = true;
         if (nreq + 1 > KQ_MAXREQ) return fail(KQ_EUNSUPPORTED, "more resources per podset than KQ_MAXREQ");
         for (int e = h->ps_req_off[p]; e < h->ps_req_off[p + 1]; e++)
         {
@@ -501,7 +507,7 @@ template <class B> struct EngineT {
     hbch.max_nps = max_nps;
     if (slot == last_slot) last_cycle_n = -1;  // the uncommitted cycle's head arrays are about to be replaced (or freed)
     const int n = h->n;
-    hbch.n = n; hbch.slot_cap = slot_cap; hbch.cycle = h->cycle; hbch.valid = true; hbch.plain = plain;
+    hbch.n = n; hbch.slot_cap = slot_cap; hbch.cycle = h->cycle; hbch.valid = true; hbch.plain = plain; hbch.partial = vh_partial;
     hbch.nps = n ? h->ps_off[n] : 0;
     if (n == 0) return KQ_OK;
     const size_t nps = hbch.nps, nreqs = h->ps_req_off[nps], nR = prep.nR, nfw = (prep.nF + 63) / 64;
@@ -594,7 +600,25 @@ template <class B> struct EngineT {
     const int rsn_win = out->rsn_cap > 0 ? std::min(std::max(prep.max_rsn_per_podset * hbch.max_nps, 8), 4096) : 0;
     return shard_words(hbch.n, hbch.nps, prep.nR, world, rsn_win, 2 * std::max(out->tgt_cap, 1));
   }
-  int cycle_exec(int slot, kq_decisions* out, bool nominate_only = false, ShardCall sc = ShardCall{}) {
+  // where every decision array lives inside the packed output region of a cycle (one D2H per cycle)
+  struct PackLayout {
+    size_t o_status = 0, o_action = 0, o_nmode = 0, o_mode = 0, o_rq = 0, o_skip = 0, o_borrow = 0, o_order = 0, o_flavor = 0, o_rmode = 0, o_tried = 0,
+           o_pscount = 0, o_tpos = 0, o_tn = 0, o_misc = 0, o_rsn = 0, pack_bytes = 0;
+    int rsn_win = 0;
+  };
+  // One asynchronous step of the pending loop in flight (kq_pending_step / kq_pending_step_wait): the packed decisions, the head
+  // count and the target pool land in pinned host memory behind an event; the host unpacks them one step later.
+  struct StepStage {
+    uint8_t* host = nullptr; size_t cap = 0;
+    bool busy = false;
+    PackLayout lay; int n_bound = 0; size_t nps_bound = 0, nR = 0; int pool_cap = 0; bool with_pool = false, with_heads = false;
+    size_t o_counts = 0, o_prow = 0, o_preason = 0, o_headwl = 0;
+    int tgt_cap = 0; int64_t cycle = 0;
+  };
+  StepStage steps[2];
+  int64_t steps_issued = 0, steps_waited = 0;
+
+  int cycle_exec(int slot, kq_decisions* out, bool nominate_only = false, ShardCall sc = ShardCall{}, StepStage* st = nullptr) {
     if (!have_snapshot) return fail(KQ_EINVAL, "kq_cycle_run before kq_snapshot_put");
     if (slot < 0 || slot >= (int)batches.size() || !batches[slot].valid) return fail(KQ_EINVAL, "unknown head batch");
     HeadBatch& hbch = batches[slot];
@@ -602,7 +626,7 @@ template <class B> struct EngineT {
     const int slot_cap = hbch.slot_cap;
     int rc = KQ_OK;
     if (out->tgt_off) out->tgt_off[0] = 0;
-    if (n == 0) {
+    if (n == 0 && !st) {
       last_kernel_ms = 0; last_bytes = 0; last_cycle_n = nominate_only ? -1 : 0;
       flush_levels();
       be.d2d(grow<int64_t>(b_usage_work, (size_t)prep.N * prep.nfr), d_usage, (size_t)prep.N * prep.nfr * sizeof(int64_t));
@@ -630,14 +654,19 @@ template <class B> struct EngineT {
     // every array that goes back to the host lives in ONE packed device region -> a single D2H per cycle
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 15) & ~(size_t)15; return o; };
-    const size_t o_status = carve(n), o_action = carve(n), o_nmode = carve(n), o_mode = carve(n), o_rq = carve(n), o_skip = carve(n);
-    const size_t o_borrow = carve((size_t)n * 4), o_order = carve((size_t)n * 4);
-    const size_t o_flavor = carve(nps * nR * 4), o_rmode = carve(nps * nR), o_tried = carve(nps * nR * 4), o_pscount = carve(nps * 4);
-    const size_t o_tpos = carve((size_t)n * 4), o_tn = carve((size_t)n * 4), o_misc = carve(4 * sizeof(int64_t));
+    PackLayout L;
+    L.o_status = carve(n); L.o_action = carve(n); L.o_nmode = carve(n); L.o_mode = carve(n); L.o_rq = carve(n); L.o_skip = carve(n);
+    L.o_borrow = carve((size_t)n * 4); L.o_order = carve((size_t)n * 4);
+    L.o_flavor = carve(nps * nR * 4); L.o_rmode = carve(nps * nR); L.o_tried = carve(nps * nR * 4); L.o_pscount = carve(nps * 4);
+    L.o_tpos = carve((size_t)n * 4); L.o_tn = carve((size_t)n * 4); L.o_misc = carve(4 * sizeof(int64_t));
+    const size_t o_status = L.o_status, o_action = L.o_action, o_nmode = L.o_nmode, o_mode = L.o_mode, o_rq = L.o_rq, o_skip = L.o_skip, o_borrow = L.o_borrow,
+                 o_order = L.o_order, o_flavor = L.o_flavor, o_rmode = L.o_rmode, o_tried = L.o_tried, o_pscount = L.o_pscount, o_tpos = L.o_tpos, o_tn = L.o_tn,
+                 o_misc = L.o_misc;
     // reason records: a window per head, sized for the longest scan any head of the batch can produce
     const int rsn_win = out->rsn_cap > 0 ? std::min(std::max(prep.max_rsn_per_podset * hbch.max_nps, 8), 4096) : 0;
-    const size_t o_rsn = carve(rsn_win ? (size_t)n * 4 : 0);
-    const size_t pack_bytes = off;
+    L.o_rsn = carve(rsn_win ? (size_t)n * 4 : 0);
+    L.pack_bytes = off; L.rsn_win = rsn_win;
+    const size_t o_rsn = L.o_rsn, pack_bytes = L.pack_bytes;
     uint8_t* pack = grow<uint8_t>(ob[0], pack_bytes);
     O.status = pack + o_status; O.action = pack + o_action; O.nominated_mode = pack + o_nmode; O.mode = pack + o_mode;
     O.requeue_reason = pack + o_rq; O.skip = pack + o_skip;
@@ -776,7 +805,12 @@ template <class B> struct EngineT {
       be.memset(sc.x, 0, shard_words(n, nps, (int)nR, sc.world, rsn_win, seg_cap) * sizeof(int64_t));
     }
     if (sc.mode == 2) be.launch_shard_import(k, nps, rsn_win);  // the merged nomination of every rank's heads
-    else be.launch_nominate(k, slots_nom, nom_lds);
+    else {
+      // the full pass (victim searches, partial admission, replaced slices) only gets heads the lean pass defers; when nothing of the
+      // kind exists in the snapshot and the batch, its launch is skipped
+      const bool full_pass = prep.any_preemption || hbch.partial || hbch.H.slice_row != nullptr || !lean_only_ok;
+      be.launch_nominate(k, slots_nom, nom_lds, full_pass);
+    }
     if (sc.mode == 1) {
       be.launch_shard_export(k, nps, rsn_win);
       last_cycle_n = -1;
@@ -796,30 +830,61 @@ template <class B> struct EngineT {
     be.timer_mark(3);
     last_cycle_n = -1;  // set on the success path only: a failed cycle must not be committable
 
+    if (st) {
+      // asynchronous step: the packed decisions, the head count the gather left on the device and (where victims can exist) the target
+      // pool go to pinned memory behind an event; nothing here waits for the device
+      st->lay = L; st->n_bound = n; st->nps_bound = nps; st->nR = nR; st->pool_cap = O.pool_cap; st->with_pool = prep.any_preemption;
+      st->tgt_cap = pool_cap; st->cycle = hbch.cycle;
+      size_t so = (pack_bytes + 15) & ~(size_t)15;
+      st->o_counts = so; so += 16;
+      st->o_prow = so; so += st->with_pool ? (((size_t)O.pool_cap * 4 + 15) & ~(size_t)15) : 0;
+      st->o_preason = so; so += st->with_pool ? (((size_t)O.pool_cap + 15) & ~(size_t)15) : 0;
+      st->o_headwl = so; so += st->with_heads ? (size_t)pend.nq * 4 : 0;
+      if (st->cap < so) { if (st->host) be.free_host(st->host); st->cap = so + so / 4; st->host = (uint8_t*)be.alloc_host(st->cap); }
+      be.d2h(st->host, pack, pack_bytes);   // (the head / podset counts ride in the pack: pack_counts)
+      if (st->with_pool) { be.d2h(st->host + st->o_prow, O.pool_row, (size_t)O.pool_cap * 4); be.d2h(st->host + st->o_preason, O.pool_reason, (size_t)O.pool_cap); }
+      if (st->with_heads) be.d2h(st->host + st->o_headwl, pend.D.head_wl, (size_t)pend.nq * 4);
+      last_O = k.O; last_slot = slot; pend.O = k.O; pend.H = k.H;
+      return KQ_OK;
+    }
     // decisions back: one D2H of the packed region into host staging, then plain memcpy to the caller's arrays
     if (hstage_cap < pack_bytes) { if (hstage) be.free_host(hstage); hstage_cap = pack_bytes + pack_bytes / 4; hstage = (uint8_t*)be.alloc_host(hstage_cap); }
     be.d2h(hstage, pack, pack_bytes);
     rc = be.sync();
     if (rc != KQ_OK) return fail(rc, be.error());
-    if (out->status) memcpy(out->status, hstage + o_status, n);
-    if (out->action) memcpy(out->action, hstage + o_action, n);
-    if (out->nominated_mode) memcpy(out->nominated_mode, hstage + o_nmode, n);
-    if (out->mode) memcpy(out->mode, hstage + o_mode, n);
-    if (out->requeue_reason) memcpy(out->requeue_reason, hstage + o_rq, n);
-    if (out->skip) memcpy(out->skip, hstage + o_skip, n);
-    if (out->borrowing) memcpy(out->borrowing, hstage + o_borrow, (size_t)n * 4);
-    if (out->order) memcpy(out->order, hstage + o_order, (size_t)n * 4);
-    if (out->flavor) memcpy(out->flavor, hstage + o_flavor, nps * nR * 4);
-    if (out->res_mode) memcpy(out->res_mode, hstage + o_rmode, nps * nR);
-    if (out->tried_idx) memcpy(out->tried_idx, hstage + o_tried, nps * nR * 4);
-    if (out->ps_count) memcpy(out->ps_count, hstage + o_pscount, nps * 4);
-    const int32_t* tpos = (const int32_t*)(hstage + o_tpos);
-    const int32_t* tn = (const int32_t*)(hstage + o_tn);
+    for (int p = 0; p < 3; p++) last_phase_ms[p] = be.timer_ms(p, p + 1);
+    last_kernel_ms = be.timer_ms(0, 3);
+    rc = cycle_unpack(L, hstage, n, nps, nR, out, k.O, nullptr, nullptr);
+    if (rc != KQ_OK) return rc;
+    if (!nominate_only) { last_cycle_n = n; last_O = k.O; last_slot = slot; }
+    if (slot == PEND_SLOT && !nominate_only) { pend.O = k.O; pend.H = k.H; pend.ran = true; }
+    return KQ_OK;
+  }
+  // The packed region of a finished cycle (host copy `stg`) -> the caller's kq_decisions. n / nps: heads and podsets of the cycle.
+  // prow / preason: the target pool when it is already on the host (asynchronous step), else it is fetched here.
+  int cycle_unpack(const PackLayout& L, const uint8_t* stg, int n, size_t nps, size_t nR, kq_decisions* out, const DOut& O, const int32_t* prow_h, const uint8_t* preason_h) {
+    int rc = KQ_OK;
+    const int rsn_win = L.rsn_win;
+    if (out->tgt_off) out->tgt_off[0] = 0;
+    if (out->status) memcpy(out->status, stg + L.o_status, n);
+    if (out->action) memcpy(out->action, stg + L.o_action, n);
+    if (out->nominated_mode) memcpy(out->nominated_mode, stg + L.o_nmode, n);
+    if (out->mode) memcpy(out->mode, stg + L.o_mode, n);
+    if (out->requeue_reason) memcpy(out->requeue_reason, stg + L.o_rq, n);
+    if (out->skip) memcpy(out->skip, stg + L.o_skip, n);
+    if (out->borrowing) memcpy(out->borrowing, stg + L.o_borrow, (size_t)n * 4);
+    if (out->order) memcpy(out->order, stg + L.o_order, (size_t)n * 4);
+    if (out->flavor) memcpy(out->flavor, stg + L.o_flavor, nps * nR * 4);
+    if (out->res_mode) memcpy(out->res_mode, stg + L.o_rmode, nps * nR);
+    if (out->tried_idx) memcpy(out->tried_idx, stg + L.o_tried, nps * nR * 4);
+    if (out->ps_count) memcpy(out->ps_count, stg + L.o_pscount, nps * 4);
+    const int32_t* tpos = (const int32_t*)(stg + L.o_tpos);
+    const int32_t* tn = (const int32_t*)(stg + L.o_tn);
     int64_t miscs[4];
-    memcpy(miscs, hstage + o_misc, sizeof(miscs));
+    memcpy(miscs, stg + L.o_misc, sizeof(miscs));
     int32_t pool_used = ((int32_t*)miscs)[0], dev_err = ((int32_t*)miscs)[1];
     if (rsn_win && dev_err == 0) {  // reason windows -> the caller's CSR (only the used part of every window is copied out)
-      const int32_t* rn = (const int32_t*)(hstage + o_rsn);
+      const int32_t* rn = (const int32_t*)(stg + L.o_rsn);
       size_t used_heads = 0;
       for (int i = 0; i < n; i++) if (rn[i] != 0) used_heads++;
       std::vector<RsnRec> win;
@@ -848,24 +913,26 @@ template <class B> struct EngineT {
     }
     last_phase_bytes[0] = miscs[1]; last_phase_bytes[1] = miscs[2];
     last_bytes = miscs[1] + miscs[2];
-    for (int p = 0; p < 3; p++) last_phase_ms[p] = be.timer_ms(p, p + 1);
-    last_kernel_ms = be.timer_ms(0, 3);
     if (dev_err != 0) return fail(dev_err, "device-side error (capacity or unsupported input)");
     // targets CSR: canonical order inside an entry = ascending admitted row
-    std::vector<int32_t> prow(std::max(pool_used, 1));
-    std::vector<uint8_t> preason(std::max(pool_used, 1));
-    if (pool_used > 0) { be.d2h(prow.data(), O.pool_row, (size_t)pool_used * sizeof(int32_t)); be.d2h(preason.data(), O.pool_reason, pool_used); rc = be.sync(); if (rc != KQ_OK) return fail(rc, be.error()); }
-    int tot = 0;
     if (pool_used == 0) {  // no preemption anywhere in this cycle
       if (out->tgt_off) memset(out->tgt_off, 0, (size_t)(n + 1) * sizeof(int32_t));
-      if (!nominate_only) { last_cycle_n = n; last_O = k.O; last_slot = slot; }
-      if (slot == PEND_SLOT && !nominate_only) { pend.O = k.O; pend.H = k.H; pend.ran = true; }
       return KQ_OK;
     }
+    std::vector<int32_t> prow;
+    std::vector<uint8_t> preason;
+    if (!prow_h) {
+      prow.resize(pool_used); preason.resize(pool_used);
+      be.d2h(prow.data(), O.pool_row, (size_t)pool_used * sizeof(int32_t)); be.d2h(preason.data(), O.pool_reason, pool_used);
+      rc = be.sync();
+      if (rc != KQ_OK) return fail(rc, be.error());
+      prow_h = prow.data(); preason_h = preason.data();
+    }
+    int tot = 0;
     for (int i = 0; i < n; i++) {
       if (out->tgt_off) out->tgt_off[i] = tot;
       std::vector<std::pair<int32_t, uint8_t>> ts;
-      for (int t = 0; t < tn[i]; t++) ts.push_back({prow[tpos[i] + t], preason[tpos[i] + t]});
+      for (int t = 0; t < tn[i]; t++) ts.push_back({prow_h[tpos[i] + t], preason_h[tpos[i] + t]});
       std::sort(ts.begin(), ts.end());
       for (auto& t : ts) {
         if (tot >= out->tgt_cap) return fail(KQ_ECAPACITY, "tgt_cap too small");
@@ -875,8 +942,6 @@ template <class B> struct EngineT {
       }
     }
     if (out->tgt_off) out->tgt_off[n] = tot;
-    if (!nominate_only) { last_cycle_n = n; last_O = k.O; last_slot = slot; }
-    if (slot == PEND_SLOT && !nominate_only) { pend.O = k.O; pend.H = k.H; pend.ran = true; }
     return KQ_OK;
   }
 
@@ -907,7 +972,7 @@ template <class B> struct EngineT {
       P.mps[c] = std::max(P.mps[c], a); P.mrq[c] = std::max(P.mrq[c], b);
     }
     P.nps_total = nps; P.nreq_total = nreq;
-    P.W = W; P.nq = nq; P.nR = nR; P.nF = prep.nF; P.n_tree = prep.n_tree; P.slot_cap = slot_cap; P.plain = plain; P.max_nps = max_nps;
+    P.W = W; P.nq = nq; P.nR = nR; P.nF = prep.nF; P.n_tree = prep.n_tree; P.slot_cap = slot_cap; P.plain = plain; P.max_nps = max_nps; P.partial = vh_partial;
     DPend& D = P.D;
     D.W = W; D.nq = nq; D.nR = nR; D.nfw = (int)nfw;
     DHeads& S0 = D.P;
@@ -957,6 +1022,7 @@ template <class B> struct EngineT {
   int pending_heads(int64_t cycle, const uint8_t* cq_active, int32_t* n_heads, int32_t* n_podsets, int32_t* head_wl) {
     if (!have_snapshot || !pend.valid) return fail(KQ_EINVAL, "kq_pending_heads before kq_pending_put");
     if (pend.n_heads >= 0) return fail(KQ_EINVAL, "kq_pending_heads: the previous heads were not applied (kq_pending_apply)");
+    if (steps_issued != steps_waited) return fail(KQ_EINVAL, "kq_pending_heads: an asynchronous step is in flight (kq_pending_step_wait first)");
     Pending& P = pend;
     if (cq_active) { be.h2d(P.d_active, cq_active, P.nq); P.D.cq_active = P.d_active; } else P.D.cq_active = nullptr;
     be.launch_pend_heads(P.D, P.G);
@@ -969,8 +1035,9 @@ template <class B> struct EngineT {
     if ((int)batches.size() <= PEND_SLOT) batches.resize(PEND_SLOT + 1);
     HeadBatch& hb = batches[PEND_SLOT];
     if (last_slot == PEND_SLOT) last_cycle_n = -1;  // the previous cycle's head arrays were just overwritten
-    hb.n = P.n_heads; hb.nps = (size_t)P.n_ps; hb.slot_cap = P.slot_cap; hb.cycle = cycle; hb.valid = true; hb.plain = P.plain; hb.max_nps = P.max_nps;
+    hb.n = P.n_heads; hb.nps = (size_t)P.n_ps; hb.slot_cap = P.slot_cap; hb.cycle = cycle; hb.valid = true; hb.plain = P.plain; hb.max_nps = P.max_nps; hb.partial = P.partial;
     DHeads& H = hb.H; const DGather& G = P.G;
+    H = DHeads{};   // (also drops the device-side count a kq_pending_step left in the slot)
     H.n = P.n_heads; H.cq = G.cq; H.priority = G.priority; H.queue_ts = G.queue_ts; H.flags = G.flags; H.ps_off = G.ps_off;
     H.ps_count = G.ps_count; H.ps_min_count = G.ps_min_count; H.ps_req_off = G.ps_req_off; H.req_res = G.req_res; H.req_qty = G.req_qty;
     H.ps_flavor_ok = G.ps_flavor_ok; H.ps_last_tried = G.ps_last_tried; H.last_generation = G.last_generation; H.last_cycle = G.last_cycle;
@@ -989,6 +1056,88 @@ template <class B> struct EngineT {
     if (pend.n_heads > 0) be.launch_pend_apply(pend.D, S, pend.O, pend.H, cfg.gates, pend.cycle, pend.n_heads);
     pend.n_heads = -1; pend.ran = false;
     return KQ_OK;  // stream-ordered with the next kq_pending_heads
+  }
+  // ---- the pending loop without a host round trip inside a cycle --------------------------------------------------------------
+  // kq_pending_step: Heads() -> the cycle -> kq_cycle_commit -> kq_pending_apply (-> kq_cycle_release) enqueued back to back; the head
+  // count stays on the device (DHeads::n_dev), arrays and grids are sized by the bound (<= 1 head per ClusterQueue, the widest
+  // workload of every ClusterQueue). The decisions are fetched by kq_pending_step_wait, up to two steps later.
+  int pending_step(int64_t cycle, const uint8_t* cq_active, int tgt_cap, int release_age, int want_head_wl) {
+    if (!have_snapshot || !pend.valid) return fail(KQ_EINVAL, "kq_pending_step before kq_pending_put");
+    if (pend.n_heads >= 0) return fail(KQ_EINVAL, "kq_pending_step: heads of kq_pending_heads are in flight (kq_pending_apply first)");
+    if (steps_issued - steps_waited >= 2) return fail(KQ_ECAPACITY, "kq_pending_step: two steps in flight, kq_pending_step_wait first");
+    if (ring[commits % KQ_COMMIT_RING].live) return fail(KQ_ECAPACITY, "commit ring full: release older commits first");
+    if (release_age != 0) {
+      if (release_age < 1 || release_age > KQ_COMMIT_RING || release_age > commits + 1) return fail(KQ_EINVAL, "kq_pending_step: no such commit to release");
+      if (release_age > 1 && !ring[(commits + 1 - release_age) % KQ_COMMIT_RING].live) return fail(KQ_EINVAL, "kq_pending_step: already released");
+    }
+    Pending& P = pend;
+    StepStage& st = steps[steps_issued & 1];
+    be.stage_select((int)(steps_issued & 1));
+    if (cq_active) { be.h2d(P.d_active, cq_active, P.nq); P.D.cq_active = P.d_active; } else P.D.cq_active = nullptr;
+    be.launch_pend_heads(P.D, P.G);
+    P.n_ps = 0; P.ran = false; P.cycle = cycle;
+    if ((int)batches.size() <= PEND_SLOT) batches.resize(PEND_SLOT + 1);
+    HeadBatch& hb = batches[PEND_SLOT];
+    last_cycle_n = -1;
+    hb.n = P.nq; hb.nps = std::max<size_t>(P.gps, 1); hb.slot_cap = P.slot_cap; hb.cycle = cycle; hb.valid = true; hb.plain = P.plain; hb.max_nps = P.max_nps; hb.partial = P.partial;
+    DHeads& H = hb.H; const DGather& G = P.G;
+    H = DHeads{};
+    H.n = P.nq; H.n_dev = P.D.counts;
+    H.cq = G.cq; H.priority = G.priority; H.queue_ts = G.queue_ts; H.flags = G.flags; H.ps_off = G.ps_off;
+    H.ps_count = G.ps_count; H.ps_min_count = G.ps_min_count; H.ps_req_off = G.ps_req_off; H.req_res = G.req_res; H.req_qty = G.req_qty;
+    H.ps_flavor_ok = G.ps_flavor_ok; H.ps_last_tried = G.ps_last_tried; H.last_generation = G.last_generation; H.last_cycle = G.last_cycle;
+    H.last_hash = G.last_hash; H.hash = G.hash;
+    st.with_heads = want_head_wl != 0;
+    kq_decisions caps{};
+    caps.tgt_cap = tgt_cap; caps.rsn_cap = 0;
+    int rc = cycle_exec(PEND_SLOT, &caps, false, ShardCall{}, &st);
+    if (rc == KQ_OK) {
+      last_cycle_n = hb.n;          // the bound: rows past the device's count commit nothing (k_commit_mask)
+      rc = cycle_commit(nullptr);   // skipped on the device when the cycle raised its error flag, like the requeue below
+    }
+    if (rc == KQ_OK) {
+      be.launch_pend_apply(P.D, S, pend.O, pend.H, cfg.gates, cycle, hb.n);
+      if (release_age > 0) rc = cycle_release(release_age);
+    }
+    hb.valid = false;               // the batch only exists on the device: kq_cycle_run_pending has nothing to run on
+    if (rc != KQ_OK) { (void)be.sync(); be.stage_select(0); return rc; }
+    be.stage_mark();
+    be.stage_select(0);
+    st.busy = true;
+    steps_issued++;
+    return KQ_OK;
+  }
+  int pending_bounds(int32_t* max_heads, int32_t* max_podsets) {
+    if (!pend.valid) return fail(KQ_EINVAL, "kq_pending_bounds before kq_pending_put");
+    if (max_heads) *max_heads = pend.nq;
+    if (max_podsets) *max_podsets = (int32_t)std::max<size_t>(pend.gps, 1);
+    return KQ_OK;
+  }
+  int pending_step_wait(kq_decisions* out, int32_t* n_heads, int32_t* n_podsets, int32_t* head_wl) {
+    if (steps_waited == steps_issued) return fail(KQ_EINVAL, "kq_pending_step_wait: no step in flight");
+    StepStage& st = steps[steps_waited & 1];
+    be.stage_select((int)(steps_waited & 1));
+    int rc = be.stage_wait();
+    st.busy = false; steps_waited++;
+    if (rc != KQ_OK) { be.stage_select(0); return fail(rc, be.error()); }
+    for (int p = 0; p < 3; p++) last_phase_ms[p] = be.timer_ms(p, p + 1);
+    last_kernel_ms = be.timer_ms(0, 3);
+    be.stage_select(0);
+    const int32_t* counts = (const int32_t*)(st.host + st.lay.o_misc) + 6;
+    const int n = counts[0]; const size_t nps = (size_t)counts[1];
+    if (n < 0 || n > st.n_bound || nps > st.nps_bound) return fail(KQ_EDEVICE, "kq_pending_step_wait: head count outside the bound the step was sized for");
+    if (n_heads) *n_heads = n;
+    if (n_podsets) *n_podsets = (int32_t)nps;
+    if (head_wl) { if (!st.with_heads) return fail(KQ_EINVAL, "kq_pending_step_wait: the step was issued without want_head_wl"); memcpy(head_wl, st.host + st.o_headwl, (size_t)pend.nq * 4); }
+    if (!out) return KQ_OK;
+    if (!st.with_pool) {  // no ClusterQueue can preempt: a target would have nowhere to be fetched from once the next step runs
+      int64_t miscs[4]; memcpy(miscs, st.host + st.lay.o_misc, sizeof(miscs));
+      if (((int32_t*)miscs)[0] != 0 && ((int32_t*)miscs)[1] == 0) return fail(KQ_EDEVICE, "kq_pending_step_wait: targets in a snapshot without preemption");
+    }
+    kq_decisions o = *out;
+    o.rsn_cap = 0; o.rsn_off = nullptr;   // reason records need the synchronous path (their windows are not staged)
+    return cycle_unpack(st.lay, st.host, n, nps, st.nR, &o, pend.O, st.with_pool ? (const int32_t*)(st.host + st.o_prow) : nullptr,
+                        st.with_pool ? st.host + st.o_preason : nullptr);
   }
   // ---- AdmissionFairSharing ledger (kq_pending.hpp DAfs) ----
   int pending_afs_put(const kq_afs_ledger* l) {
@@ -1180,7 +1329,7 @@ template <class B> struct EngineT {
     }
     P.W = W0 + n; D.W = P.W; S0.n = P.W;
     P.nps_total = nps0 + aps; P.nreq_total = nrq0 + arq;
-    P.slot_cap = std::max(P.slot_cap, slot_cap); P.plain = P.plain && plain; P.max_nps = std::max(P.max_nps, max_nps);
+    P.slot_cap = std::max(P.slot_cap, slot_cap); P.plain = P.plain && plain; P.max_nps = std::max(P.max_nps, max_nps); P.partial = P.partial || vh_partial;
     // merge the (sorted) arrivals into the resident heap orders: O(W + n log n) instead of sorting everything again
     std::vector<int32_t> ord(P.W), cq_off(nq + 1, 0), fresh(n);
     {

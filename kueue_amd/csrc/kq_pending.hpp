@@ -332,8 +332,13 @@ KQ_DEV void pend_gather_head(const DPend& D, const DGather& G, int h) {
 // the workload leaving the queue (assumeWorkload; the controller's delete, cluster_queue.go:495). One wave per head.
 KQ_DEV void pend_apply_head(const DPend& D, const DSnap& S, const DOut& O, const DHeads& H, uint32_t gates, int64_t cycle, int h) {
   const int lane = lane_id();
+  if (h >= D.counts[0]) return;   // the grid is sized by a bound when the count never left the device (kq_pending_step)
   const int w = D.hd[h];
   const int c = D.P.cq[w];
+  if (O.error && O.error[0] != 0) {  // the cycle failed on the device (capacity): its heads go back to the heap as if they had not been popped
+    if (lane == 0) D.state[w] = WL_ACTIVE;
+    return;
+  }
   const int status = O.status[h], action = O.action[h], mode = O.mode[h], rq = O.requeue_reason[h];
   if (status == KQ_ST_ASSUMED) {
     if (lane == 0) {

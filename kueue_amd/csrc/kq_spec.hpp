@@ -507,7 +507,7 @@ KQ_DEV int sp_rounds(const K& k, const SpecCtx& c, SpecLds& L, const int64_t* kt
 KQ_DEV void spec_tree(const K& k, int tree, SpecLds& L, int64_t* kt, int tid_arg) {
   const DSnap& S = k.S;
   SpecCtx c;
-  c.tree = tree; c.n = k.H.n; c.nfr = S.nfr;
+  c.tree = tree; c.n = hn(k.H); c.nfr = S.nfr;
   c.D = S.tree_depth[tree] < SP_MAXS ? S.tree_depth[tree] : SP_MAXS;
   c.maxe = SP_MAXE; c.maxi = SP_MAXI; c.pmax = SP_PMAX;
 #ifdef KQ_HOST_EMU

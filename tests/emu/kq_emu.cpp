@@ -6,6 +6,7 @@
 // kqe_* symbols, lives under tests/, and is never loaded by the kueue_amd package: the product
 // path has no CPU implementation and fails loudly without the HIP library.
 #define KQ_HOST_EMU 1
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -29,6 +30,9 @@ struct EmuBackend {
   size_t lds_budget() { return 150 * 1024; }
   int help_blocks(int) { return 1; }  // no helper runs in the emulation, but the leader runs every other task the way one would
   void timer_mark(int) {}
+  void stage_select(int) {}
+  void stage_mark() {}
+  int stage_wait() { return KQ_OK; }
   double timer_ms(int, int) { return 0; }
   void launch_tas_classes(const TK& k) { for (int c = 0; c < k.C.n; c++) t_class(k, c); }
   void launch_tas_find(const TK& k, int slots) {
@@ -92,13 +96,14 @@ struct EmuBackend {
   }
   void launch_usage_delta(int64_t* out, const int64_t* work, const int64_t* start, size_t n) { for (size_t i = 0; i < n; i++) usage_delta_cell(out, work, start, i); }
   void launch_usage_add(int64_t* usage, const int64_t* delta, size_t n, int sign, int32_t* big) { for (size_t i = 0; i < n; i++) usage_add_cell(usage, delta, i, sign, big); }
-  void launch_nominate(const K& k, int slots, size_t lds) {
+  void launch_nominate(const K& k, int slots, size_t lds, bool full_pass) {
     std::vector<int64_t> region(lds / 8 + 8);
     // every other launch skips the lean first pass, so that the full pass also sees the heads the lean one would have finished
-    const bool lean = (nom_rot++ & 1) == 0;
-    if (lean) { for (int slot = 0; slot < slots; slot++) { Wave w{}; for (int h = slot; h < k.H.n; h += slots) nominate_head_lean(k, w, h); } }
-    else { for (int h = 0; h < k.H.n; h++) k.defer_list[h] = h; *k.defer_count = k.H.n; }
+    const bool lean = !full_pass || (nom_rot++ & 1) == 0;
+    if (lean) { for (int slot = 0; slot < slots; slot++) { Wave w{}; for (int h = slot; h < hn(k.H); h += slots) nominate_head_lean(k, w, h); } }
+    else { for (int h = 0; h < hn(k.H); h++) k.defer_list[h] = h; *k.defer_count = hn(k.H); }
     const int nd = *k.defer_count;
+    if (!full_pass) { if (nd != 0) { fprintf(stderr, "kq_emu: the lean pass deferred %d heads but the host skipped the full pass\n", nd); abort(); } return; }
     for (int slot = 0; slot < slots; slot++) {
       Wave w{};
       // alternate between "LDS" and the spill space so that both placements of the search arrays are exercised
@@ -117,12 +122,13 @@ struct EmuBackend {
     for (int t = 0; t < k.shard.world * k.shard.pool_cap; t++) shard_import_pool(k, nps_total, rsn_win, t);
   }
   void launch_records(const K& k) {
-    for (int e = 0; e < k.H.n; e++) for (int c = 0; c < FU * FD; c++) rec_fill_static(k, e, c);
+    pack_counts(k);
+    for (int e = 0; e < hn(k.H); e++) for (int c = 0; c < FU * FD; c++) rec_fill_static(k, e, c);
   }
   void launch_order(const K& k, int32_t* order_idx, int32_t*) {
-    for (int i = 0; i < k.H.n; i++) {
+    for (int i = 0; i < hn(k.H); i++) {
       int rank = 0;
-      for (int j = 0; j < k.H.n; j++) if (j != i && entry_before(k, j, i)) rank++;
+      for (int j = 0; j < hn(k.H); j++) if (j != i && entry_before(k, j, i)) rank++;
       order_idx[rank] = i;
       if (k.spec_hdr) k.spec_hdr[rank] = spec_hdr_of(k, i);
     }
@@ -154,8 +160,8 @@ struct EmuBackend {
     const size_t budgets[3] = {lds.size() * 8, sizeof(PRec) + 2048, 0};
     for (int t = 0; t < n_tree; t++) { Wave w{}; process_tree_fair(k, w, t, t, lds.data(), budgets[(t + rot) % 3], 0, 1); }
     rot++;
-    for (int i = 0; i < k.H.n; i++) rank[i] = k.X.fs_key[i] >= 0 ? fair_rank(k, i, 0, k.H.n) : 0;
-    for (int i = 0; i < k.H.n; i++) if (k.X.fs_key[i] >= 0) k.O.order[i] = rank[i];
+    for (int i = 0; i < hn(k.H); i++) rank[i] = k.X.fs_key[i] >= 0 ? fair_rank(k, i, 0, hn(k.H)) : 0;
+    for (int i = 0; i < hn(k.H); i++) if (k.X.fs_key[i] >= 0) k.O.order[i] = rank[i];
     last_k = k;
   }
 };
@@ -224,6 +230,9 @@ int kqe_pending_put(void* e, const kq_pending* p) { return ((EmuEngine*)e)->pend
 int kqe_pending_heads(void* e, int64_t cycle, const uint8_t* act, int32_t* n, int32_t* nps, int32_t* hw) { return ((EmuEngine*)e)->pending_heads(cycle, act, n, nps, hw); }
 int kqe_cycle_run_pending(void* e, kq_decisions* out) { return ((EmuEngine*)e)->cycle_run_pending(out); }
 int kqe_pending_apply(void* e) { return ((EmuEngine*)e)->pending_apply(); }
+int kqe_pending_bounds(void* e, int32_t* a, int32_t* b) { return ((EmuEngine*)e)->pending_bounds(a, b); }
+int kqe_pending_step(void* e, int64_t cycle, const uint8_t* act, int32_t tgt_cap, int32_t release_age, int32_t want) { return ((EmuEngine*)e)->pending_step(cycle, act, tgt_cap, release_age, want); }
+int kqe_pending_step_wait(void* e, kq_decisions* out, int32_t* n, int32_t* nps, int32_t* hw) { return ((EmuEngine*)e)->pending_step_wait(out, n, nps, hw); }
 int kqe_pending_afs_put(void* e, const kq_afs_ledger* l) { return ((EmuEngine*)e)->pending_afs_put(l); }
 int kqe_pending_afs_wl_penalty(void* e, int32_t n, const int32_t* wl, const uint64_t* lo, const int64_t* hi, const uint64_t* mask) { return ((EmuEngine*)e)->pending_afs_wl_penalty(n, wl, lo, hi, mask); }
 int kqe_pending_afs_sub_penalty(void* e, int32_t n, const int32_t* wl) { return ((EmuEngine*)e)->pending_afs_sub_penalty(n, wl); }

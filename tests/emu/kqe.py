@@ -172,6 +172,25 @@ class EmuEngine:
         u = np.ascontiguousarray(usage, np.float64)
         self._ok(lib().kqe_pending_set_lq_usage(self.h, C.c_int32(len(u)), F.ptr(u)))
 
+    def pending_bounds(self):
+        """kq_pending_bounds: (max heads, max podsets) of a cycle over the resident pending set."""
+        a, b = C.c_int32(), C.c_int32()
+        self._ok(lib().kqe_pending_bounds(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def pending_step(self, cycle, tgt_cap, release_age=0, want_heads=False, cq_active=None):
+        """kq_pending_step: Heads() + cycle + commit + apply (+ release) enqueued, nothing waited for."""
+        act = None if cq_active is None else F.ptr(np.ascontiguousarray(cq_active, np.uint8))
+        self._ok(lib().kqe_pending_step(self.h, C.c_int64(cycle), act, C.c_int32(tgt_cap), C.c_int32(release_age), C.c_int32(1 if want_heads else 0)))
+
+    def pending_step_wait(self, out=None, want_heads=False):
+        """kq_pending_step_wait for the oldest step in flight -> (n_heads, n_podsets, head_wl or None); `out` sized for pending_bounds()."""
+        n, nps = C.c_int32(), C.c_int32()
+        hw = np.full(self.snap.n_cq, -1, np.int32) if want_heads else None
+        self._ok(lib().kqe_pending_step_wait(self.h, C.byref(out.struct()) if out is not None else None, C.byref(n), C.byref(nps),
+                                      F.ptr(hw) if want_heads else None))
+        return n.value, nps.value, hw
+
     def pending_afs_put(self, ledger, penalties):
         self._afs = ledger
         self._ok(lib().kqe_pending_afs_put(self.h, C.byref(ledger.struct(penalties))))
