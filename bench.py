@@ -280,10 +280,10 @@ def pending_cost(eng, pop):
     idx = np.arange(0, full.n, max(1, full.n // 1000))[:1000]
     more = Pending(full.heads.subset(idx), uid_rank=(full.uid_rank[idx] + np.uint32(full.n)))
     add = []
-    for _ in range(3):
+    for _ in range(7):   # (the first calls also pay the growth of the columns and of the two order buffers)
         add.append(t(lambda: eng.pending_add(more)))
     dele = t(lambda: eng.pending_delete(idx.astype(np.int32)))
-    return {"put": put, "add_1000": float(np.median(add)), "delete_1000": dele, "resident": int(full.n)}
+    return {"put": put, "add_1000": float(np.median(add)), "add_1000_first": add[0], "delete_1000": dele, "resident": int(full.n)}
 
 
 class PendingLoop:
@@ -523,8 +523,11 @@ def bench_pending(args, torch, dist, world, rank, local_rank):
                                   if pipelined else "kq_pending_heads / kq_cycle_run_pending / commit / apply / release, two host round trips per cycle")},
             "p50_cycle_ms": float(np.percentile(cyc_ms, 50)), "p99_cycle_ms": float(np.percentile(cyc_ms, 99)),
             "kernel_ms_per_cycle": {"k_nominate": nom_ms / args.steps, "k_order": ord_ms / args.steps, "k_process": proc_ms / args.steps},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "algorithmic_bytes_per_launch": dby / args.steps, "traffic": pmc_traffic(args.workload, dom)},
+            "roofline": {"bound": "hbm", "kernel": {"k_process": "k_process_fair" if fair else "k_process_spec + k_process", "k_nominate": "k_nominate_lean (+ k_nominate, k_records)"}[dom],
+                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "algorithmic_bytes_per_launch": dby / args.steps, "traffic": pmc_traffic(args.workload, dom),
+                         "what": "HIP events around the interval on the engine's stream, averaged over the timed cycles; algorithmic bytes = the reference's own "
+                                 "accounting of the cells it reads and writes (DESIGN.md section 4)"},
             "parity_checked": parity[0], "parity": parity[1],
         }
         if args.full_run and world == 1:
@@ -971,9 +974,14 @@ def pmc_traffic(workload, kernel):
     --pmc runs of this same command; profiles/r01c_cfg3_rocprof_summary.txt). Counters cannot be collected from inside
     the timed run, so this is the last committed measurement for the same workload, or null."""
     path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
+    # the intervals bench.py times hold more than one kernel: the nominate interval = the lean pass (+ the full pass, + k_records),
+    # the process interval = the speculative rounds + the serial kernel behind them
+    parts = {"k_nominate": ("k_nominate_lean", "k_nominate", "k_records"), "k_process": ("k_process_spec", "k_process")}.get(kernel, (kernel,))
     try:
         with open(path) as f:
-            return json.load(f)["traffic_bytes_per_launch"].get(kernel)
+            tab = json.load(f)["traffic_bytes_per_launch"]
+        vals = [tab[k] for k in parts if tab.get(k) is not None]
+        return float(sum(vals)) if vals else None
     except Exception:
         return None
 

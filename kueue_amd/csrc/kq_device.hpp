@@ -1966,6 +1966,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
   const DSnap& S = k.S; const DHeads& H = k.H; const DOut& O = k.O;
   const int lane = lane_id();
   const int nR = S.nR;
+  KQ_T0();
   if (lane == 0) { w.nuse = 0; w.borrowing = 0; w.rep_mode = M_FIT; w.nrsn = 0; w.rsn_over = 0; }
   wsync();
   int rep = M_FIT;
@@ -2030,6 +2031,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
     for (int r = lane; r < nR; r += WAVE) { O.flavor[(size_t)psg * nR + r] = -1; O.res_mode[(size_t)psg * nR + r] = M_NOFIT; O.tried_idx[(size_t)psg * nR + r] = -1; }
     if (lane == 0) O.ps_count[psg] = scale ? new_count : count;
     wsync();
+    if constexpr (LEAN) KQ_TS(k, 57);  // lean: requests of the podset in iterator order, output rows cleared
     bool group_failed = false;
     int ps_reasons = 0, ps_nflavors = 0, ps_mode = M_FIT;
     if (lane == 0) w.rsn_ps0 = w.nrsn;
@@ -2111,6 +2113,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
           w.cell_pm[c] = pm | (mismatch ? 0x40 : 0); w.cell_borrow[c] = borrow; w.cell_val[c] = val; w.cell_aux[c] = aux;
         }
         wsync();
+        if constexpr (LEAN) KQ_TS(k, 58);  // lean: the (flavor, resource) cells of the pass (fitsResourceQuota)
         // ---- recomputation inside k_process_fair: every cell of the pass that needs a SimulatePreemption is posted as one batch ----
         bool batched = false;
         HelpBox* hbox = nullptr;
@@ -2208,6 +2211,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
           }
         }
       }
+      if constexpr (LEAN) KQ_TS(k, 59);  // lean: the serial choice among the flavors
       int tried = -1;
       if (gate(k, KQ_GATE_FLAVOR_FUNGIBILITY)) tried = (attempted == nflv - 1) ? -1 : attempted;
       else tried = 0;
@@ -2276,6 +2280,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
       break;
     }
   }
+  if constexpr (LEAN) KQ_TS(k, 60);  // lean: usage list / outputs of the podsets
   if (!any_ps) rep = M_NOFIT;  // RepresentativeMode with no podsets :212-215
   if (lane == 0) {
     w.rep_mode = rep;
@@ -2468,10 +2473,13 @@ KQ_DEV void nominate_finish(const K& k, Wave& w, int h) {
 // pass (k_nominate). Same results: a deferred head is recomputed from scratch.
 KQ_DEV void nominate_head_lean(const K& k, Wave& w, int h) {
   if (k.shard.mine && !k.shard.mine[h]) return;  // sharded nominate: another rank's head
+  KQ_T0();
   load_head(k, w, h);
   if (lane_id() == 0) { if (w.has_last && last_assignment_outdated(k, h, w.cq)) w.has_last = 0; w.defer_head = 0; }
   wsync();
+  KQ_TS(k, 56);  // lean: load_head
   assign_flavors<true>(k, w, 0, k.usage, nullptr, nullptr, false);
+  KQ_TS(k, 61);  // lean: assign_flavors (57..60 are its parts)
   bool defer = w.defer_head != 0 || w.slice_row >= 0;  // (a head that replaces a workload slice always has a target: the full pass publishes it)
   if (!defer && w.rep_mode != M_FIT) {
     // getInitialAssignments (scheduler.go:880-924) past the first Assign: Preempt asks GetTargets, then the partial-admission search
@@ -2496,6 +2504,7 @@ KQ_DEV void nominate_head_lean(const K& k, Wave& w, int h) {
   }
   nominate_finish(k, w, h);
   wsync();
+  KQ_TS(k, 62);  // lean: publish
 }
 
 // nominate (scheduler.go:665-705) for one head
@@ -4239,6 +4248,32 @@ KQ_DEV void commit_cq_cell(const DCommit& c, const DSnap& S, int h, int u, bool 
     old = seen;
   }
   if (c.big && (uint64_t)nw >= ((uint64_t)1 << 50)) *c.big = 1;  // negatives land here too
+}
+// kq_pending_step: the commit of the cycle in ONE pass over the (head, slot) cells — what commit_keep_cell + commit_cq_cell do in two
+// launches: keep the cycle's usage rows for the later release and fold the admitted ones into the ClusterQueue cells. Same
+// arithmetic (commit_cq_cell on the kept row), so the plane is identical; only valid while the cohort levels are re-derived from
+// the ClusterQueue cells (usage_consistent).
+KQ_DEV void commit_fused_cell(const K& k, const DSnap& S, const DCommit& c, int i) {
+  int32_t* use_n_out = const_cast<int32_t*>(c.use_n); int32_t* cq_out = const_cast<int32_t*>(c.cq);
+  int32_t* fr_out = const_cast<int32_t*>(c.use_fr); int64_t* qty_out = const_cast<int64_t*>(c.use_qty);
+  const int h = i / KQ_MAXU, u = i % KQ_MAXU;
+  if (h >= hn(k.H)) { if (u == 0) use_n_out[h] = 0; return; }
+  const bool take = k.O.action[h] == KQ_ACT_ADMIT && !(k.H.flags[h] & KQ_HEAD_HAS_QUOTA_RESERVATION) && !(k.O.error && k.O.error[0] != 0);
+  const int nu = take ? k.O.use_n[h] : 0;
+  const int fr = k.O.use_fr[i]; const int64_t q = k.O.use_qty[i];
+  fr_out[i] = fr; qty_out[i] = q;
+  const int cq = k.H.cq[h];
+  if (u == 0) { use_n_out[h] = nu; cq_out[h] = cq; }
+  if (u >= nu) return;
+  int64_t* cell = &c.usage[(size_t)cq * S.nfr + fr];
+  int64_t old = *(volatile int64_t*)cell, nw;
+  for (;;) {
+    nw = a_add(old, q);
+    const int64_t seen = atomic_cas_i64(cell, old, nw);
+    if (seen == old) break;
+    old = seen;
+  }
+  if (c.big && (uint64_t)nw >= ((uint64_t)1 << 50)) *c.big = 1;
 }
 KQ_DEV void derive_usage_cell(const DSnap& S, int64_t* usage, int cohort, int fr) {
   int64_t u = 0;

@@ -272,9 +272,36 @@ __global__ __launch_bounds__(64) void k_pend_gather(DPend D, DGather G) { if ((i
 __global__ __launch_bounds__(64) void k_pend_apply(DPend D, DSnap S, DOut O, DHeads H, uint32_t gates, int64_t cycle) {
   pend_apply_head(D, S, O, H, gates, cycle, blockIdx.x);
 }
+// kq_pending_add: thread i < W0 places resident heap position i, thread W0 + r places arrival r, thread c <= nq writes the new offset of
+// ClusterQueue c — all into the second order / offsets buffers
+__global__ __launch_bounds__(256) void k_pend_merge(DPend D, const int32_t* ord_old, const int32_t* off_old, int32_t* ord_new, int32_t* off_new,
+                                                    const int32_t* fresh, const int32_t* fresh_off, int W0, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i <= D.nq) off_new[i] = off_old[i] + fresh_off[i];
+  if (i < W0) pend_merge_old(D, ord_old, ord_new, fresh, fresh_off, i);
+  else if (i < W0 + n) pend_merge_new(D, ord_old, off_old, ord_new, fresh, i - W0);
+}
 __global__ __launch_bounds__(64) void k_pend_add_fix(DPend D, DSnap S, int first) { pend_add_fix(D, S, first + (int)blockIdx.x); }
 __global__ __launch_bounds__(64) void k_pend_requeue_at(DPend D, DSnap S, const int32_t* list, const int64_t* at) { pend_requeue_at(D, S, list, at, blockIdx.x); }
 __global__ __launch_bounds__(256) void k_pend_delete(DPend D, const int32_t* list, int n) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) pend_delete(D, list, i); }
+// kq_pending_step, after the cycle: blocks [0, nb) fold the admissions into the snapshot and keep the rows for the release
+// (commit_fused_cell), blocks [nb, nb + n) run the requeue policy of one head each (wave 0 of the block) — one launch instead of three
+__global__ __launch_bounds__(256) void k_step_commit_apply(const K* __restrict__ kp, DSnap S, DCommit c, DPend D, uint32_t gates, int64_t cycle, int nb) {
+  if ((int)blockIdx.x < nb) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < c.n * KQ_MAXU) commit_fused_cell(*kp, S, c, i);
+    return;
+  }
+  if (threadIdx.x >= 64) return;
+  pend_apply_head(D, S, kp->O, kp->H, gates, cycle, (int)blockIdx.x - nb);
+}
+// ... and the release of an older commit: removeUsage of its rows + the stamp of the trees whose quota was freed, one launch
+__global__ __launch_bounds__(256) void k_step_release(DSnap S, DCommit c, int32_t* tree_stamp, int32_t stamp) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= c.n * KQ_MAXU) return;
+  commit_cq_cell(c, S, i / KQ_MAXU, i % KQ_MAXU, false);
+  if (i % KQ_MAXU == 0) pend_release_mark(S, tree_stamp, c.cq, c.use_n, c.n, i / KQ_MAXU, stamp);
+}
 __global__ __launch_bounds__(256) void k_afs_usage(DPend D, int init_f64) { const int l = blockIdx.x * 256 + threadIdx.x; if (l < D.A.n_lq) afs_init_lq(D.A, l, init_f64 != 0); }
 __global__ __launch_bounds__(64) void k_afs_sub(DPend D, const int32_t* list, int n) { if (threadIdx.x == 0) afs_sub_list(D, list, n); }
 __global__ __launch_bounds__(256) void k_afs_set_consumed(DPend D, const int32_t* lq, const uint64_t* lo, const int64_t* hi, const double* f64, const int32_t* settle, int n) {
@@ -320,6 +347,16 @@ struct HipBackend {
   hipEvent_t ev[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};  // phase timers, one set per step in flight
   hipEvent_t sev[2] = {nullptr, nullptr};   // "everything of this asynchronous step is done" (kq_pending_step_wait)
   int stage = 0;                            // which of the two sets the calls below use
+  // Asynchronous steps overlap what does not depend on each other on two side streams: the argument-block upload and the decisions'
+  // D2H on `cstream`, the re-derivation of the cohort usage levels on `ustream` (next to Heads()); events order them with `stream`.
+  hipStream_t cstream = nullptr, ustream = nullptr;
+  hipEvent_t ev_begin = nullptr, ev_usage = nullptr, ev_kup[2] = {nullptr, nullptr}, ev_cycle[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+  bool copied_pending[2] = {false, false};  // ev_copied[i] was recorded and nobody has ordered `stream` behind it yet
+  bool in_step = false;                     // between step_begin / step_end: side streams in use
+  // Measured at cfg 3 (profiles/r03h_*): 0.428 ms per cycle with the side streams against 0.416 ms with everything on the one stream — the
+  // event waits cost 8-13 us of gap each and the overlapped kernels slow each other down; so this is an experiment, off unless
+  // KQ_STEP_SIDE_STREAMS is set (the GPU suite runs it once).
+  bool side_off = getenv("KQ_STEP_SIDE_STREAMS") == nullptr;
   int device = 0;
   int n_cu = 256;
   hipError_t err = hipSuccess;
@@ -341,12 +378,20 @@ struct HipBackend {
     chk(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
     for (auto& set : ev) for (auto& e2 : set) chk(hipEventCreate(&e2), "hipEventCreate");
     for (auto& e2 : sev) chk(hipEventCreateWithFlags(&e2, hipEventDisableTiming), "hipEventCreate");
+    chk(hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking), "hipStreamCreate");
+    chk(hipStreamCreateWithFlags(&ustream, hipStreamNonBlocking), "hipStreamCreate");
+    for (hipEvent_t* e2 : {&ev_begin, &ev_usage, &ev_kup[0], &ev_kup[1], &ev_cycle[0], &ev_cycle[1], &ev_copied[0], &ev_copied[1]})
+      chk(hipEventCreateWithFlags(e2, hipEventDisableTiming), "hipEventCreate");
     chk(hipHostMalloc((void**)&hk, 4 * sizeof(K), hipHostMallocDefault), "hipHostMalloc K");
     return err == hipSuccess ? KQ_OK : KQ_EDEVICE;
   }
   void destroy() {
     for (auto& set : ev) for (auto& e2 : set) if (e2) (void)hipEventDestroy(e2);
     for (auto& e2 : sev) if (e2) (void)hipEventDestroy(e2);
+    for (hipEvent_t e2 : {ev_begin, ev_usage, ev_kup[0], ev_kup[1], ev_cycle[0], ev_cycle[1], ev_copied[0], ev_copied[1]}) if (e2) (void)hipEventDestroy(e2);
+    if (cstream) (void)hipStreamDestroy(cstream);
+    if (ustream) (void)hipStreamDestroy(ustream);
+    for (auto& d : dk2) if (d) (void)hipFree(d);
     if (hk) (void)hipHostFree(hk);
     for (auto& d : dk) if (d) (void)hipFree(d);
     if (dtk) (void)hipFree(dtk);
@@ -362,6 +407,7 @@ struct HipBackend {
   void memset(void* d, int v, size_t n) { chk(hipMemsetAsync(d, v, n, stream), "memset"); }
   int sync() {
     chk(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    if (copied_pending[0] || copied_pending[1]) { chk(hipStreamSynchronize(cstream), "hipStreamSynchronize"); copied_pending[0] = copied_pending[1] = false; }
     if (err != hipSuccess) { hipError_t e = err; (void)e; err = hipSuccess; (void)hipGetLastError(); return KQ_EDEVICE; }
     return KQ_OK;
   }
@@ -376,17 +422,62 @@ struct HipBackend {
   void stage_mark() { chk(hipEventRecord(sev[stage], stream), "hipEventRecord"); }
   int stage_wait() {
     chk(hipEventSynchronize(sev[stage]), "hipEventSynchronize");
+    if (copied_pending[stage]) { chk(hipEventSynchronize(ev_copied[stage]), "hipEventSynchronize"); copied_pending[stage] = false; }   // the decisions' copy ran on the side stream
     if (err != hipSuccess) { err = hipSuccess; (void)hipGetLastError(); return KQ_EDEVICE; }
     return KQ_OK;
   }
+  // An asynchronous step starts: whatever the previous steps' side copies still read (the packed outputs, the popped heads) must not
+  // be overwritten before they are through, and the side streams start behind everything already enqueued on `stream`.
+  void step_begin(int i) {
+    stage_select(i);
+    if (side_off) return;
+    in_step = true;
+    for (int q = 0; q < 2; q++) if (copied_pending[q]) chk(hipStreamWaitEvent(stream, ev_copied[q], 0), "hipStreamWaitEvent");
+    chk(hipEventRecord(ev_begin, stream), "hipEventRecord");
+  }
+  void step_end() { in_step = false; stage_select(0); }
+  // cohort usage levels on the side stream (they only depend on what was enqueued before the step), joined before the cycle reads them
+  void usage_levels_side(const DSnap& S, int64_t* usage, int max_depth) {
+    if (!in_step) { launch_usage_levels(S, usage, max_depth); return; }
+    chk(hipStreamWaitEvent(ustream, ev_begin, 0), "hipStreamWaitEvent");
+    hipStream_t keep = stream; stream = ustream;
+    launch_usage_levels(S, usage, max_depth);
+    stream = keep;
+    chk(hipEventRecord(ev_usage, ustream), "hipEventRecord");
+    usage_side = true;
+  }
+  bool usage_side = false;
+  void usage_join() { if (usage_side) chk(hipStreamWaitEvent(stream, ev_usage, 0), "hipStreamWaitEvent"); usage_side = false; }
+  // the step's outputs to pinned host memory on the side stream: the tail kernels of the step do not wait for the copies
+  void side_fence() {
+    if (!in_step) return;
+    chk(hipEventRecord(ev_cycle[stage], stream), "hipEventRecord");
+    chk(hipStreamWaitEvent(cstream, ev_cycle[stage], 0), "hipStreamWaitEvent");
+  }
+  void d2h_side(void* h, const void* d, size_t n) { chk(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, in_step ? cstream : stream), "d2h"); }
+  void side_done() { if (in_step) { chk(hipEventRecord(ev_copied[stage], cstream), "hipEventRecord"); copied_pending[stage] = true; } }
   K* dk[2] = {nullptr, nullptr};   // device copies of the argument block (nominate/order, process)
+  K* dk2[4] = {nullptr, nullptr, nullptr, nullptr};   // the same per step in flight [stage][which]: uploaded on the side stream ahead of time
+  const K* dcur0 = nullptr;        // the block of the nominate / order step of the cycle being enqueued
   K* hk = nullptr;                 // pinned staging [stage][which]: a pageable source would make hipMemcpyAsync wait for the stream
   const K* put_k(const K& k, int which) {
-    if (!dk[which]) chk(hipMalloc((void**)&dk[which], sizeof(K)), "hipMalloc K");
     K* h = hk + stage * 2 + which;
     memcpy((void*)h, (const void*)&k, sizeof(K));
-    chk(hipMemcpyAsync(dk[which], h, sizeof(K), hipMemcpyHostToDevice, stream), "memcpy K");
-    return dk[which];
+    K* d;
+    if (in_step) {
+      K*& dd = dk2[stage * 2 + which];
+      if (!dd) chk(hipMalloc((void**)&dd, sizeof(K)), "hipMalloc K");
+      d = dd;
+      chk(hipMemcpyAsync(d, h, sizeof(K), hipMemcpyHostToDevice, cstream), "memcpy K");
+      chk(hipEventRecord(ev_kup[stage], cstream), "hipEventRecord");
+      chk(hipStreamWaitEvent(stream, ev_kup[stage], 0), "hipStreamWaitEvent");
+    } else {
+      if (!dk[which]) chk(hipMalloc((void**)&dk[which], sizeof(K)), "hipMalloc K");
+      d = dk[which];
+      chk(hipMemcpyAsync(d, h, sizeof(K), hipMemcpyHostToDevice, stream), "memcpy K");
+    }
+    if (which == 0) dcur0 = d;
+    return d;
   }
   TK* dtk = nullptr;
   TK htk;
@@ -485,6 +576,16 @@ struct HipBackend {
     hipLaunchKernelGGL(k_pend_gather, dim3(D.nq), dim3(64), 0, stream, D, G);
     chk(hipGetLastError(), "k_pend_heads");
   }
+  void launch_step_commit_apply(const DSnap& S, const DCommit& c, const DPend& D, uint32_t gates, int64_t cycle) {
+    const int nb = (c.n * KQ_MAXU + 255) / 256;
+    hipLaunchKernelGGL(k_step_commit_apply, dim3(nb + c.n), dim3(256), 0, stream, dproc, S, c, D, gates, cycle, nb);
+    chk(hipGetLastError(), "k_step_commit_apply");
+  }
+  void launch_step_release(const DSnap& S, const DCommit& c, const DPend& D, int32_t* tree_stamp, int32_t stamp) {
+    hipLaunchKernelGGL(k_step_release, dim3((c.n * KQ_MAXU + 255) / 256), dim3(256), 0, stream, S, c, tree_stamp, stamp);
+    hipLaunchKernelGGL(k_pend_release_requeue, dim3(D.nq), dim3(64), 0, stream, D, S, (const int32_t*)tree_stamp, stamp);
+    chk(hipGetLastError(), "k_step_release");
+  }
   void launch_afs_usage(const DPend& D, bool init_f64) {
     if (D.A.n_lq > 0) hipLaunchKernelGGL(k_afs_usage, dim3((D.A.n_lq + 255) / 256), dim3(256), 0, stream, D, init_f64 ? 1 : 0);
     chk(hipGetLastError(), "k_afs_usage");
@@ -500,6 +601,12 @@ struct HipBackend {
   void launch_pend_apply(const DPend& D, const DSnap& S, const DOut& O, const DHeads& H, uint32_t gates, int64_t cycle, int n) {
     hipLaunchKernelGGL(k_pend_apply, dim3(n), dim3(64), 0, stream, D, S, O, H, gates, cycle);
     chk(hipGetLastError(), "k_pend_apply");
+  }
+  void launch_pend_merge(const DPend& D, const int32_t* ord_old, const int32_t* off_old, int32_t* ord_new, int32_t* off_new,
+                         const int32_t* fresh, const int32_t* fresh_off, int W0, int n) {
+    const int items = std::max(W0 + n, D.nq + 1);
+    hipLaunchKernelGGL(k_pend_merge, dim3((items + 255) / 256), dim3(256), 0, stream, D, ord_old, off_old, ord_new, off_new, fresh, fresh_off, W0, n);
+    chk(hipGetLastError(), "k_pend_merge");
   }
   void launch_pend_add_fix(const DPend& D, const DSnap& S, int first, int n) {
     if (n > 0) hipLaunchKernelGGL(k_pend_add_fix, dim3(n), dim3(64), 0, stream, D, S, first);
@@ -533,7 +640,7 @@ struct HipBackend {
   }
   void launch_shard_export(const K& k, size_t nps_total, int rsn_win) {
     const int items = std::max(k.H.n, k.shard.pool_cap);
-    hipLaunchKernelGGL(k_shard_export, dim3((items + 255) / 256), dim3(256), 0, stream, (const K*)dk[0], nps_total, rsn_win);
+    hipLaunchKernelGGL(k_shard_export, dim3((items + 255) / 256), dim3(256), 0, stream, dcur0, nps_total, rsn_win);
     chk(hipGetLastError(), "k_shard_export");
   }
   void launch_shard_import(const K& k, size_t nps_total, int rsn_win) {
@@ -556,13 +663,13 @@ struct HipBackend {
   }
   void launch_records(const K& k) {
     if (k.H.n == 0) return;
-    hipLaunchKernelGGL(k_records, dim3((k.H.n * FU * FD + 255) / 256), dim3(256), 0, stream, (const K*)dk[0]);
+    hipLaunchKernelGGL(k_records, dim3((k.H.n * FU * FD + 255) / 256), dim3(256), 0, stream, dcur0);
     chk(hipGetLastError(), "k_records");
   }
   void launch_order(const K& k, int32_t* order_idx, int32_t* rank) {
     const int nb = (k.H.n + 255) / 256;
-    hipLaunchKernelGGL(k_order, dim3(nb, (k.H.n + ORDER_TILE - 1) / ORDER_TILE), dim3(256), 0, stream, (const K*)dk[0], rank);
-    hipLaunchKernelGGL(k_order_scatter, dim3(nb), dim3(256), 0, stream, (const K*)dk[0], k.H.n, (const int32_t*)rank, order_idx, 1);
+    hipLaunchKernelGGL(k_order, dim3(nb, (k.H.n + ORDER_TILE - 1) / ORDER_TILE), dim3(256), 0, stream, dcur0, rank);
+    hipLaunchKernelGGL(k_order_scatter, dim3(nb), dim3(256), 0, stream, dcur0, k.H.n, (const int32_t*)rank, order_idx, 1);
     stat_patched = true;
     chk(hipGetLastError(), "k_order");
   }
@@ -576,7 +683,7 @@ struct HipBackend {
       lds_attr = lds;
     }
     // after launch_order the block of the nominate step is already what the process step needs (k_order_scatter moved its byte counter)
-    const K* d = stat_patched ? (const K*)dk[0] : put_k(k, 1);
+    const K* d = stat_patched ? dcur0 : put_k(k, 1);
     dproc = d; stat_patched = false;
     if (!spec_off && k.spec_kt) chk(launch_process_spec(d, n_tree, stream), "k_process_spec");
     hipLaunchKernelGGL(k_process, dim3(n_tree), dim3(PROCESS_THREADS), lds, stream, d, (unsigned)lds);

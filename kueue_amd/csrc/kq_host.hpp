@@ -33,7 +33,7 @@ template <class B> struct EngineT {
   // cycle buffers (grow-only)
   struct Buf { void* p = nullptr; size_t cap = 0; };
   std::vector<Buf*> all_bufs;
-  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_grec, b_cqd, b_defer, b_cert, b_help, b_cqh, b_spkt, b_spc, b_sphdr, b_shard, b_fs[20];
+  Buf b_usage_work, b_usage_np, b_preempted, b_w, b_cqinfo, b_cls, b_tgt_row, b_tgt_reason, b_order, b_misc, b_prof, b_nom, b_rank, b_cand, b_mark, b_rmb, b_grec, b_cqd, b_defer, b_cert, b_help, b_cqh, b_spkt, b_spc, b_sphdr, b_shard, b_addstage, b_fs[20];
 #ifdef KQ_HOST_EMU
   bool spec_stats_on = true;
 #else
@@ -84,7 +84,8 @@ template <class B> struct EngineT {
     // host mirror of what kq_pending_add needs to merge new workloads into the heap orders and to size the gathered batch
     std::vector<int32_t> h_cq; std::vector<int64_t> h_prio, h_ts; std::vector<uint32_t> h_uid;
     std::vector<int> mps, mrq;       // widest workload of every ClusterQueue (podsets / requests)
-    std::vector<int32_t> h_ord;      // the heap orders as uploaded
+    std::vector<int32_t> h_ord;      // the heap orders as uploaded by kq_pending_put
+    int32_t* ord_alt = nullptr; int32_t* cq_off_alt = nullptr;   // the second order / offsets buffer kq_pending_add merges into
     size_t gps = 0, grq = 0;         // podset / request rows of the gathered batch as allocated
     size_t nps_total = 0, nreq_total = 0;
   } pend;
@@ -197,7 +198,7 @@ template <class B> struct EngineT {
     free_snapshot();
     if (hstage) be.free_host(hstage);
     if (hup) be.free_host(hup);
-    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb, &b_grec, &b_cqd, &b_cs, &b_defer, &b_cert, &b_help, &b_cqh, &b_spkt, &b_spc, &b_sphdr, &b_shard}) if (b->p) be.free(b->p);
+    for (Buf* b : {&b_usage_work, &b_usage_np, &b_preempted, &b_w, &b_cqinfo, &b_cls, &b_tgt_row, &b_tgt_reason, &b_order, &b_misc, &b_prof, &b_nom, &b_rank, &b_cand, &b_mark, &b_rmb, &b_grec, &b_cqd, &b_cs, &b_defer, &b_cert, &b_help, &b_cqh, &b_spkt, &b_spc, &b_sphdr, &b_shard, &b_addstage}) if (b->p) be.free(b->p);
     for (auto& b : b_fs) if (b.p) be.free(b.p);
     for (auto& c : ring) for (Buf* b : {&c.cq, &c.use_n, &c.use_fr, &c.use_qty}) if (b->p) be.free(b->p);
     for (auto& hbch : batches) for (auto& b : hbch.hb) if (b.p) be.free(b.p);
@@ -616,10 +617,12 @@ template <class B> struct EngineT {
     int tgt_cap = 0; int64_t cycle = 0;
   };
   StepStage steps[2];
+  bool step_unfused = getenv("KQ_STEP_UNFUSED") != nullptr;   // (A/B switch: the step's commit / apply / release as the separate launches of the call-by-call API)
   int64_t steps_issued = 0, steps_waited = 0;
 
   int cycle_exec(int slot, kq_decisions* out, bool nominate_only = false, ShardCall sc = ShardCall{}, StepStage* st = nullptr) {
     if (!have_snapshot) return fail(KQ_EINVAL, "kq_cycle_run before kq_snapshot_put");
+    if (!st && steps_issued != steps_waited) return fail(KQ_EINVAL, "a kq_pending_step is in flight: its outputs share the cycle's buffers (kq_pending_step_wait first)");
     if (slot < 0 || slot >= (int)batches.size() || !batches[slot].valid) return fail(KQ_EINVAL, "unknown head batch");
     HeadBatch& hbch = batches[slot];
     const int n = hbch.n;
@@ -841,9 +844,11 @@ template <class B> struct EngineT {
       st->o_preason = so; so += st->with_pool ? (((size_t)O.pool_cap + 15) & ~(size_t)15) : 0;
       st->o_headwl = so; so += st->with_heads ? (size_t)pend.nq * 4 : 0;
       if (st->cap < so) { if (st->host) be.free_host(st->host); st->cap = so + so / 4; st->host = (uint8_t*)be.alloc_host(st->cap); }
-      be.d2h(st->host, pack, pack_bytes);   // (the head / podset counts ride in the pack: pack_counts)
-      if (st->with_pool) { be.d2h(st->host + st->o_prow, O.pool_row, (size_t)O.pool_cap * 4); be.d2h(st->host + st->o_preason, O.pool_reason, (size_t)O.pool_cap); }
-      if (st->with_heads) be.d2h(st->host + st->o_headwl, pend.D.head_wl, (size_t)pend.nq * 4);
+      be.side_fence();                           // the copies run next to the step's tail kernels, behind everything enqueued so far
+      be.d2h_side(st->host, pack, pack_bytes);   // (the head / podset counts ride in the pack: pack_counts)
+      if (st->with_pool) { be.d2h_side(st->host + st->o_prow, O.pool_row, (size_t)O.pool_cap * 4); be.d2h_side(st->host + st->o_preason, O.pool_reason, (size_t)O.pool_cap); }
+      if (st->with_heads) be.d2h_side(st->host + st->o_headwl, pend.D.head_wl, (size_t)pend.nq * 4);
+      be.side_done();
       last_O = k.O; last_slot = slot; pend.O = k.O; pend.H = k.H;
       return KQ_OK;
     }
@@ -1072,9 +1077,12 @@ template <class B> struct EngineT {
     }
     Pending& P = pend;
     StepStage& st = steps[steps_issued & 1];
-    be.stage_select((int)(steps_issued & 1));
+    be.step_begin((int)(steps_issued & 1));
+    // the cohort usage levels (stale since the previous step's commit / release) are re-derived next to Heads(), on a side stream
+    if (levels_stale) { be.usage_levels_side(S, d_usage, max_depth()); levels_stale = false; }
     if (cq_active) { be.h2d(P.d_active, cq_active, P.nq); P.D.cq_active = P.d_active; } else P.D.cq_active = nullptr;
     be.launch_pend_heads(P.D, P.G);
+    be.usage_join();
     P.n_ps = 0; P.ran = false; P.cycle = cycle;
     if ((int)batches.size() <= PEND_SLOT) batches.resize(PEND_SLOT + 1);
     HeadBatch& hb = batches[PEND_SLOT];
@@ -1091,18 +1099,37 @@ template <class B> struct EngineT {
     kq_decisions caps{};
     caps.tgt_cap = tgt_cap; caps.rsn_cap = 0;
     int rc = cycle_exec(PEND_SLOT, &caps, false, ShardCall{}, &st);
-    if (rc == KQ_OK) {
+    if (rc == KQ_OK && prep.usage_consistent && !step_unfused) {
+      // commit + requeue policy in one launch, the release of the older commit in one more (+ the requeue of the freed trees): the
+      // bookkeeping of kq_cycle_commit / kq_cycle_release, the kernels of both fused (k_step_commit_apply, k_step_release)
+      const int n = hb.n;           // the bound: rows past the device's count commit nothing
+      Committed& c = ring[commits % KQ_COMMIT_RING];
+      c.n = n;
+      DCommit dc{n, grow<int32_t>(c.cq, n), grow<int32_t>(c.use_n, n), grow<int32_t>(c.use_fr, (size_t)n * KQ_MAXU), grow<int64_t>(c.use_qty, (size_t)n * KQ_MAXU),
+                 d_usage, d_big};
+      be.launch_step_commit_apply(S, dc, P.D, cfg.gates, cycle);
+      levels_stale = true;
+      c.live = true; commits++; last_cycle_n = -1;
+      if (release_age > 0) {
+        Committed& o = ring[(commits - release_age) % KQ_COMMIT_RING];
+        if (o.n > 0) {
+          DCommit od{o.n, (const int32_t*)o.cq.p, (const int32_t*)o.use_n.p, (const int32_t*)o.use_fr.p, (const int64_t*)o.use_qty.p, d_usage, d_big};
+          be.launch_step_release(S, od, P.D, P.d_tree_stamp, ++P.release_seq);
+        }
+        o.live = false;
+      }
+    } else if (rc == KQ_OK) {
       last_cycle_n = hb.n;          // the bound: rows past the device's count commit nothing (k_commit_mask)
       rc = cycle_commit(nullptr);   // skipped on the device when the cycle raised its error flag, like the requeue below
-    }
-    if (rc == KQ_OK) {
-      be.launch_pend_apply(P.D, S, pend.O, pend.H, cfg.gates, cycle, hb.n);
-      if (release_age > 0) rc = cycle_release(release_age);
+      if (rc == KQ_OK) {
+        be.launch_pend_apply(P.D, S, pend.O, pend.H, cfg.gates, cycle, hb.n);
+        if (release_age > 0) rc = cycle_release(release_age);
+      }
     }
     hb.valid = false;               // the batch only exists on the device: kq_cycle_run_pending has nothing to run on
-    if (rc != KQ_OK) { (void)be.sync(); be.stage_select(0); return rc; }
+    if (rc != KQ_OK) { be.step_end(); (void)be.sync(); return rc; }
     be.stage_mark();
-    be.stage_select(0);
+    be.step_end();
     st.busy = true;
     steps_issued++;
     return KQ_OK;
@@ -1267,9 +1294,29 @@ template <class B> struct EngineT {
     return be.sync();  // the caller's array may go away
   }
   // PushOrUpdate of new workloads (cluster_queue.go:379): appended, merged into the heap orders, resident state carried over
+  // Arrivals travel as ONE packed upload: every column's tail is laid out in a pinned staging buffer, copied to the device once and
+  // scattered to the ends of the resident columns by k_prep (copy / fill operations of 4-byte words) — it was ~25 small uploads.
+  struct AddStage { uint8_t* host = nullptr; uint8_t* dev = nullptr; size_t off = 0, cap = 0; std::vector<DPrepOp> ops; };
+  template <class T> void add_col(AddStage& a, T*& d, size_t old_n, size_t add_n, const T* tail, int fill = -2) {
+    static_assert(sizeof(T) % 4 == 0, "staged columns are made of 4-byte words");
+    pend_regrow(d, old_n, add_n, (const T*)nullptr, -2);   // room only (the resident part moves device-to-device if it has to)
+    if (!add_n) return;
+    const size_t bytes = add_n * sizeof(T);
+    if (tail) {
+      memcpy(a.host + a.off, tail, bytes);
+      a.ops.push_back(DPrepOp{d + old_n, a.dev + a.off, (uint32_t)(bytes / 4), 0});
+      a.off += (bytes + 15) & ~(size_t)15;
+    } else if (fill != -2) a.ops.push_back(DPrepOp{d + old_n, nullptr, (uint32_t)(bytes / 4), fill == 0 ? 0u : 0xffffffffu});
+  }
+  template <class T> void add_col(AddStage& a, const T*& d, size_t old_n, size_t add_n, const T* tail, int fill = -2) {
+    T* m = const_cast<T*>(d);
+    add_col(a, m, old_n, add_n, tail, fill);
+    d = m;
+  }
   int pending_add(const kq_pending* p, int32_t* first_index) {
     if (!have_snapshot || !pend.valid) return fail(KQ_EINVAL, "kq_pending_add before kq_pending_put");
     if (pend.n_heads >= 0) return fail(KQ_EINVAL, "kq_pending_add between kq_pending_heads and kq_pending_apply");
+    if (steps_issued != steps_waited) return fail(KQ_EINVAL, "kq_pending_add: an asynchronous step is in flight (kq_pending_step_wait first)");
     const kq_heads* h = &p->w;
     int slot_cap = 1, max_nps = 1; bool plain = true;
     int rc = validate_heads(h, &slot_cap, &plain, &max_nps);
@@ -1285,77 +1332,97 @@ template <class B> struct EngineT {
     const size_t nps0 = P.nps_total, nrq0 = P.nreq_total;
     DPend& D = P.D;
     DHeads& S0 = D.P;
-    pend_regrow(S0.cq, W0, n, h->cq); pend_regrow(S0.priority, W0, n, h->priority); pend_regrow(S0.queue_ts, W0, n, h->queue_ts);
-    pend_regrow(S0.flags, W0, n, h->flags);
-    // (the temporaries below are read by asynchronous copies: they live until the be.sync() at the end)
+    AddStage a;
+    a.cap = (size_t)n * 96 + aps * (16 + 8 * nfw + 4 * (size_t)nR) + arq * 16 + (size_t)(n + nq + 2) * 8 + 64 * 16;
+    if (hup_cap < a.cap) { if (hup) be.free_host(hup); hup_cap = a.cap + a.cap / 4; hup = (uint8_t*)be.alloc_host(hup_cap); }
+    a.host = hup;
+    a.dev = grow<uint8_t>(b_addstage, a.cap);
+    add_col(a, S0.cq, W0, n, h->cq); add_col(a, S0.priority, W0, n, h->priority); add_col(a, S0.queue_ts, W0, n, h->queue_ts);
+    add_col(a, S0.flags, W0, n, h->flags);
     std::vector<int32_t> t_ps(n), t_rq(aps);
     for (int i = 0; i < n; i++) t_ps[i] = (int32_t)(nps0 + h->ps_off[i + 1]);
-    pend_regrow(S0.ps_off, (size_t)W0 + 1, n, t_ps.data());
-    pend_regrow(S0.ps_count, nps0, aps, h->ps_count);
-    pend_regrow(S0.ps_min_count, nps0, aps, h->ps_min_count, 0xff);
+    add_col(a, S0.ps_off, (size_t)W0 + 1, n, t_ps.data());
+    add_col(a, S0.ps_count, nps0, aps, h->ps_count);
+    add_col(a, S0.ps_min_count, nps0, aps, h->ps_min_count, 0xff);
     for (size_t i = 0; i < aps; i++) t_rq[i] = (int32_t)(nrq0 + h->ps_req_off[i + 1]);
-    pend_regrow(S0.ps_req_off, nps0 + 1, aps, t_rq.data());
-    pend_regrow(S0.req_res, nrq0, arq, h->req_res); pend_regrow(S0.req_qty, nrq0, arq, h->req_qty);
-    pend_regrow(S0.ps_flavor_ok, nps0 * nfw, aps * nfw, h->ps_flavor_ok);
-    pend_regrow(S0.hash, W0, n, h->hash, 0);
+    add_col(a, S0.ps_req_off, nps0 + 1, aps, t_rq.data());
+    add_col(a, S0.req_res, nrq0, arq, h->req_res); add_col(a, S0.req_qty, nrq0, arq, h->req_qty);
+    add_col(a, S0.ps_flavor_ok, nps0 * nfw, aps * nfw, h->ps_flavor_ok);
+    add_col(a, S0.hash, W0, n, h->hash, 0);
     std::vector<uint32_t> uid(n);
     for (int w = 0; w < n; w++) uid[w] = p->uid_rank ? p->uid_rank[w] : (uint32_t)(W0 + w);
-    pend_regrow(D.uid, W0, n, uid.data());
-    pend_regrow(D.state, W0, n, (const uint8_t*)nullptr, 0); pend_regrow(D.bulk, W0, n, (const uint8_t*)nullptr, 0);
-    pend_regrow(D.mflags, W0, n, h->flags);
-    pend_regrow(D.last_tried, nps0 * nR, aps * nR, h->ps_last_tried, 0xff);
-    pend_regrow(D.last_gen, W0, n, h->last_generation, 0); pend_regrow(D.last_cycle, W0, n, h->last_cycle, 0);
-    pend_regrow(D.last_hash, W0, n, h->last_hash, 0);
+    add_col(a, D.uid, W0, n, uid.data());
+    pend_regrow(D.state, W0, n, (const uint8_t*)nullptr, 0); pend_regrow(D.bulk, W0, n, (const uint8_t*)nullptr, 0);   // byte columns: memset
+    add_col(a, D.mflags, W0, n, h->flags);
+    add_col(a, D.last_tried, nps0 * nR, aps * nR, h->ps_last_tried, 0xff);
+    add_col(a, D.last_gen, W0, n, h->last_generation, 0); add_col(a, D.last_cycle, W0, n, h->last_cycle, 0);
+    add_col(a, D.last_hash, W0, n, h->last_hash, 0);
     std::vector<int64_t> t_at;
-    t_at.reserve((size_t)W0 + (size_t)n);  // no reallocation while the copies below are in flight
     if (D.requeue_at || p->requeue_at) {
-      if (!D.requeue_at) { t_at.assign((size_t)W0, KQ_REQUEUE_NONE); D.requeue_at = pend_alloc<int64_t>(W0, t_at.data()); }
+      if (!D.requeue_at) { t_at.assign((size_t)W0, KQ_REQUEUE_NONE); D.requeue_at = pend_alloc<int64_t>(W0, t_at.data()); rc = be.sync(); if (rc != KQ_OK) return fail(rc, be.error()); }
       std::vector<int64_t> tail((size_t)n, KQ_REQUEUE_NONE);
       if (p->requeue_at) tail.assign(p->requeue_at, p->requeue_at + n);
-      t_at.insert(t_at.end(), tail.begin(), tail.end());  // (kept alive until the sync below)
-      pend_regrow(D.requeue_at, W0, n, t_at.data() + (t_at.size() - (size_t)n));
+      add_col(a, D.requeue_at, W0, n, tail.data());   // (copied into the staging buffer right here)
     }
-    if (P.n_lq > 0) pend_regrow(D.lq, W0, n, p->lq);
+    if (P.n_lq > 0) add_col(a, D.lq, W0, n, p->lq);
     if (D.A.n_res > 0) {  // arrivals carry no entry penalty until kq_pending_afs_wl_penalty
-      pend_regrow(D.A.wl_lo, (size_t)W0 * D.A.n_res, (size_t)n * D.A.n_res, (const uint64_t*)nullptr, 0);
-      pend_regrow(D.A.wl_hi, (size_t)W0 * D.A.n_res, (size_t)n * D.A.n_res, (const int64_t*)nullptr, 0);
-      pend_regrow(D.A.wl_mask, W0, n, (const uint64_t*)nullptr, 0); pend_regrow(D.A.wl_rec, W0, n, (const uint8_t*)nullptr, 0);
+      add_col(a, D.A.wl_lo, (size_t)W0 * D.A.n_res, (size_t)n * D.A.n_res, (const uint64_t*)nullptr, 0);
+      add_col(a, D.A.wl_hi, (size_t)W0 * D.A.n_res, (size_t)n * D.A.n_res, (const int64_t*)nullptr, 0);
+      add_col(a, D.A.wl_mask, W0, n, (const uint64_t*)nullptr, 0); pend_regrow(D.A.wl_rec, W0, n, (const uint8_t*)nullptr, 0);
     }
-    P.h_cq.insert(P.h_cq.end(), h->cq, h->cq + n); P.h_prio.insert(P.h_prio.end(), h->priority, h->priority + n);
-    P.h_ts.insert(P.h_ts.end(), h->queue_ts, h->queue_ts + n); P.h_uid.insert(P.h_uid.end(), uid.begin(), uid.end());
     for (int w = 0; w < n; w++) {
-      const int c = h->cq[w], a = h->ps_off[w + 1] - h->ps_off[w], b = h->ps_req_off[h->ps_off[w + 1]] - h->ps_req_off[h->ps_off[w]];
-      P.mps[c] = std::max(P.mps[c], a); P.mrq[c] = std::max(P.mrq[c], b);
+      const int c = h->cq[w], x = h->ps_off[w + 1] - h->ps_off[w], b = h->ps_req_off[h->ps_off[w + 1]] - h->ps_req_off[h->ps_off[w]];
+      P.mps[c] = std::max(P.mps[c], x); P.mrq[c] = std::max(P.mrq[c], b);
     }
     P.W = W0 + n; D.W = P.W; S0.n = P.W;
     P.nps_total = nps0 + aps; P.nreq_total = nrq0 + arq;
     P.slot_cap = std::max(P.slot_cap, slot_cap); P.plain = P.plain && plain; P.max_nps = std::max(P.max_nps, max_nps); P.partial = P.partial || vh_partial;
-    // merge the (sorted) arrivals into the resident heap orders: O(W + n log n) instead of sorting everything again
-    std::vector<int32_t> ord(P.W), cq_off(nq + 1, 0), fresh(n);
+    // The heap orders are merged ON THE DEVICE (round 3; it was a host merge over all W workloads + a re-upload of the whole order):
+    // the host only sorts the n arrivals among themselves — by ClusterQueue, then baseCompareFunc's static part — and hands over that
+    // list with its per-ClusterQueue offsets; a resident workload moves back by the arrivals that sort before it, an arrival lands
+    // behind the resident workloads that sort before it (two binary searches, kq_pending.hpp pend_merge_*), into the other of two
+    // order buffers.
+    std::vector<int32_t> fresh(n), fresh_off((size_t)nq + 1, 0);
     {
-      auto before = [&](int a, int b) {
-        if (P.h_cq[a] != P.h_cq[b]) return P.h_cq[a] < P.h_cq[b];
-        if (P.h_prio[a] != P.h_prio[b]) return P.h_prio[a] > P.h_prio[b];
-        if (P.h_ts[a] != P.h_ts[b]) return P.h_ts[a] < P.h_ts[b];
-        if (P.h_uid[a] != P.h_uid[b]) return P.h_uid[a] < P.h_uid[b];
-        return a < b;
+      auto before = [&](int x, int y) {   // indices into the arrivals
+        if (h->cq[x] != h->cq[y]) return h->cq[x] < h->cq[y];
+        if (h->priority[x] != h->priority[y]) return h->priority[x] > h->priority[y];
+        if (h->queue_ts[x] != h->queue_ts[y]) return h->queue_ts[x] < h->queue_ts[y];
+        if (uid[x] != uid[y]) return uid[x] < uid[y];
+        return x < y;
       };
-      for (int i = 0; i < n; i++) fresh[i] = W0 + i;
-      std::sort(fresh.begin(), fresh.end(), before);
-      std::merge(P.h_ord.begin(), P.h_ord.end(), fresh.begin(), fresh.end(), ord.begin(), before);
-      for (int w = 0; w < P.W; w++) cq_off[P.h_cq[w] + 1]++;
-      for (int c = 0; c < nq; c++) cq_off[c + 1] += cq_off[c];
-      P.h_ord = ord;
+      std::vector<int32_t> idx(n);
+      for (int i = 0; i < n; i++) idx[i] = i;
+      std::sort(idx.begin(), idx.end(), before);
+      for (int i = 0; i < n; i++) { fresh[i] = W0 + idx[i]; fresh_off[h->cq[idx[i]] + 1]++; }
+      for (int c = 0; c < nq; c++) fresh_off[c + 1] += fresh_off[c];
     }
-    { const int32_t* oc = D.cq_off; be.h2d(const_cast<int32_t*>(oc), cq_off.data(), (size_t)(nq + 1) * sizeof(int32_t)); }
-    pend_regrow(D.ord, 0, (size_t)P.W, ord.data());  // (old_n = 0: the whole order is rewritten; reallocated only beyond its head room)
+    int32_t* d_fresh = nullptr; int32_t* d_fresh_off = nullptr;
+    {  // (two more pieces of the same staged upload; they are read by the merge, not scattered)
+      memcpy(a.host + a.off, fresh.data(), (size_t)n * 4); d_fresh = (int32_t*)(a.dev + a.off); a.off += ((size_t)n * 4 + 15) & ~(size_t)15;
+      memcpy(a.host + a.off, fresh_off.data(), (size_t)(nq + 1) * 4); d_fresh_off = (int32_t*)(a.dev + a.off); a.off += ((size_t)(nq + 1) * 4 + 15) & ~(size_t)15;
+    }
+    if (a.off > a.cap) return fail(KQ_ENOMEM, "kq_pending_add: staging buffer undersized");
+    be.h2d(a.dev, a.host, a.off);
+    for (size_t o = 0; o < a.ops.size(); o += 16) {
+      DPrep pp{};
+      for (size_t q = o; q < a.ops.size() && q < o + 16; q++) pp.op[pp.n++] = a.ops[q];
+      be.launch_prep(pp);
+    }
+    // the other order buffer / offsets buffer (allocated with head room like every resident column)
+    int32_t* ord_new = P.ord_alt; int32_t* off_new = P.cq_off_alt;
+    pend_regrow(ord_new, 0, (size_t)P.W, (const int32_t*)nullptr, -2);
+    if (!off_new) off_new = pend_alloc<int32_t>((size_t)nq + 1, nullptr, 0);
+    be.launch_pend_merge(D, D.ord, D.cq_off, ord_new, off_new, d_fresh, d_fresh_off, W0, n);
+    P.ord_alt = const_cast<int32_t*>(D.ord); P.cq_off_alt = const_cast<int32_t*>(D.cq_off);
+    D.ord = ord_new; D.cq_off = off_new;
     {
       size_t gps = 0, grq = 0;
       for (int c = 0; c < nq; c++) { gps += P.mps[c]; grq += P.mrq[c]; }
       if (gps > P.gps || grq > P.grq) pend_alloc_gather();
     }
     be.launch_pend_add_fix(D, S, W0, n);
-    rc = be.sync();
+    rc = be.sync();   // the staging buffer is reused by the next call
     if (rc != KQ_OK) return fail(rc, be.error());
     return KQ_OK;
   }

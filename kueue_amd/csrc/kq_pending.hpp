@@ -397,6 +397,35 @@ KQ_DEV void pend_queue_inadmissible(const DPend& D, int c) {
     D.bulk[w] = 0;  // c.hashToBulkMoveReason = make(...) inadmissible_workloads.go:158
   }
 }
+// ---- kq_pending_add: the arrivals merged into the heap orders on the device --------------------------------------------------------------
+// baseCompareFunc's static part (cluster_queue.go:844-878 without the sticky term) inside one ClusterQueue: does workload a sort before b?
+KQ_DEV bool pend_before(const DPend& D, int a, int b) {
+  const int64_t pa = D.P.priority[a], pb = D.P.priority[b];
+  if (pa != pb) return pa > pb;
+  const int64_t ta = D.P.queue_ts[a], tb = D.P.queue_ts[b];
+  if (ta != tb) return ta < tb;
+  const uint32_t ua = D.uid[a], ub = D.uid[b];
+  if (ua != ub) return ua < ub;
+  return a < b;
+}
+// first position in list[lo, hi) (sorted by pend_before) whose workload does NOT sort before w = how many of them precede w
+KQ_DEV int pend_rank_in(const DPend& D, const int32_t* list, int lo, int hi, int w) {
+  int a = lo, b = hi;
+  while (a < b) { const int m = (a + b) >> 1; if (pend_before(D, list[m], w)) a = m + 1; else b = m; }
+  return a - lo;
+}
+// resident workload at heap position j: it keeps its place among the resident ones and moves back by the arrivals of earlier
+// ClusterQueues (fresh_off[c]) and by those of its own ClusterQueue that sort before it
+KQ_DEV void pend_merge_old(const DPend& D, const int32_t* ord_old, int32_t* ord_new, const int32_t* fresh, const int32_t* fresh_off, int j) {
+  const int w = ord_old[j], c = D.P.cq[w];
+  ord_new[j + fresh_off[c] + pend_rank_in(D, fresh, fresh_off[c], fresh_off[c + 1], w)] = w;
+}
+// arrival r of the sorted list: behind the resident workloads of its ClusterQueue that sort before it; r itself counts the arrivals in front
+KQ_DEV void pend_merge_new(const DPend& D, const int32_t* ord_old, const int32_t* off_old, int32_t* ord_new, const int32_t* fresh, int r) {
+  const int w = fresh[r], c = D.P.cq[w];
+  ord_new[off_old[c] + pend_rank_in(D, ord_old, off_old[c], off_old[c + 1], w) + r] = w;
+}
+
 // PushOrUpdate of a workload that was just appended (cluster_queue.go:419-425): BestEffortFIFO, hash known, class already bulk-moved
 // => it joins the inadmissible workloads instead of the heap. One wave per new workload.
 KQ_DEV void pend_add_fix(const DPend& D, const DSnap& S, int w) {

@@ -31,6 +31,13 @@ struct EmuBackend {
   int help_blocks(int) { return 1; }  // no helper runs in the emulation, but the leader runs every other task the way one would
   void timer_mark(int) {}
   void stage_select(int) {}
+  void step_begin(int) {}
+  void step_end() {}
+  void usage_levels_side(const DSnap& S, int64_t* usage, int max_depth) { launch_usage_levels(S, usage, max_depth); }
+  void usage_join() {}
+  void side_fence() {}
+  void d2h_side(void* h, const void* d, size_t n) { memcpy(h, d, n); }
+  void side_done() {}
   void stage_mark() {}
   int stage_wait() { return KQ_OK; }
   double timer_ms(int, int) { return 0; }
@@ -78,6 +85,15 @@ struct EmuBackend {
     pend_scan(D, G, 0, 1, nullptr);
     for (int h = 0; h < D.counts[0]; h++) pend_gather_head(D, G, h);
   }
+  void launch_step_commit_apply(const DSnap& S, const DCommit& c, const DPend& D, uint32_t gates, int64_t cycle) {
+    for (int i = 0; i < c.n * KQ_MAXU; i++) commit_fused_cell(last_k, S, c, i);
+    for (int h = 0; h < c.n; h++) pend_apply_head(D, S, last_k.O, last_k.H, gates, cycle, h);
+  }
+  void launch_step_release(const DSnap& S, const DCommit& c, const DPend& D, int32_t* tree_stamp, int32_t stamp) {
+    for (int i = 0; i < c.n * KQ_MAXU; i++) commit_cq_cell(c, S, i / KQ_MAXU, i % KQ_MAXU, false);
+    for (int i = 0; i < c.n; i++) pend_release_mark(S, tree_stamp, c.cq, c.use_n, c.n, i, stamp);
+    for (int q = 0; q < D.nq; q++) pend_release_requeue(D, S, tree_stamp, q, stamp);
+  }
   void launch_afs_usage(const DPend& D, bool init_f64) { for (int l = 0; l < D.A.n_lq; l++) afs_init_lq(D.A, l, init_f64); }
   void launch_afs_sub(const DPend& D, const int32_t* list, int n) { afs_sub_list(D, list, n); }
   void launch_afs_set_consumed(const DPend& D, const int32_t* lq, const uint64_t* lo, const int64_t* hi, const double* f64, const int32_t* settle, int n) {
@@ -85,6 +101,12 @@ struct EmuBackend {
   }
   void launch_pend_apply(const DPend& D, const DSnap& S, const DOut& O, const DHeads& H, uint32_t gates, int64_t cycle, int n) {
     for (int h = 0; h < n; h++) pend_apply_head(D, S, O, H, gates, cycle, h);
+  }
+  void launch_pend_merge(const DPend& D, const int32_t* ord_old, const int32_t* off_old, int32_t* ord_new, int32_t* off_new,
+                         const int32_t* fresh, const int32_t* fresh_off, int W0, int n) {
+    for (int c = 0; c <= D.nq; c++) off_new[c] = off_old[c] + fresh_off[c];
+    for (int j = 0; j < W0; j++) pend_merge_old(D, ord_old, ord_new, fresh, fresh_off, j);
+    for (int r = 0; r < n; r++) pend_merge_new(D, ord_old, off_old, ord_new, fresh, r);
   }
   void launch_pend_add_fix(const DPend& D, const DSnap& S, int first, int n) { for (int i = 0; i < n; i++) pend_add_fix(D, S, first + i); }
   void launch_pend_requeue_at(const DPend& D, const DSnap& S, const int32_t* list, const int64_t* at, int n) { for (int i = 0; i < n; i++) pend_requeue_at(D, S, list, at, i); }

@@ -114,10 +114,26 @@ def test_step_loop_emulated(oracle, kind, depth):
     _loop(oracle, _emu, kind, depth, cycles=8)
 
 
+@pytest.mark.parametrize("kind", ["cfg3-120cq", "cfg4c-60cq"])
+def test_step_loop_emulated_unfused_tail(oracle, kind, monkeypatch):
+    """KQ_STEP_UNFUSED: the step's commit / requeue / release as the separate launches of the call-by-call entry points."""
+    monkeypatch.setenv("KQ_STEP_UNFUSED", "1")
+    _loop(oracle, _emu, kind, 2, cycles=8)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,kw", [("cfg3-120cq", dict(cycles=10)), ("cfg4c-60cq", dict(cycles=8)), ("cfg4f-40cq", dict(cycles=6)), ("cfg2", dict(cycles=12))])
 def test_step_loop_gpu(oracle, kind, kw):
     _loop(oracle, _hip, kind, 2, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", ["KQ_STEP_SIDE_STREAMS", "KQ_STEP_UNFUSED"])
+def test_step_loop_gpu_variants(oracle, env, monkeypatch):
+    """The measured-and-rejected variants stay correct: side streams for the upload / copies / usage levels, the unfused tail."""
+    monkeypatch.setenv(env, "1")
+    _loop(oracle, _hip, "cfg4c-60cq", 2, cycles=8)
+    _loop(oracle, _hip, "cfg3-120cq", 2, cycles=10)
 
 
 def test_step_refuses_misuse(oracle):

@@ -1,26 +1,43 @@
 #!/bin/bash
 # Measurement pass of a round on the GPU box: benches (JSON lines) + rocprofv3 kernel stats + PMC passes (FETCH_SIZE / WRITE_SIZE in
 # separate runs, never combined with other trace domains). Everything lands under gpurun_out/$1/.
-TAG=${1:-r02g}
+#   tools/prof_round.sh r03 [benches] [profiles]      (default: both)
+TAG=${1:-r03}
+WHAT="${2:-benches} ${3:-profiles}"
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-python bench.py > $O/bench_cfg3.json 2> $O/bench_cfg3.err
-python bench.py --workload cfg3-batch --steps 20 --warmup 2 > $O/bench_cfg3b.json 2> $O/bench_cfg3b.err
-python bench.py --workload cfg3-split --steps 50 > $O/bench_cfg3split.json 2> $O/bench_cfg3split.err
-python bench.py --workload cfg3-split --steps 50 --fill 0.3 > $O/bench_cfg3split_fill03.json 2> $O/bench_cfg3split_fill03.err
-python bench.py --workload cfg3f --steps 30 --full-run 0 --no-host-leg > $O/bench_cfg3f.json 2> $O/bench_cfg3f.err
-python bench.py --workload cfg4c --steps 3 --warmup 1 --cpu-seconds 5 > $O/bench_cfg4c.json 2> $O/bench_cfg4c.err
-cd /tmp && export TMPDIR=/tmp
-Q="--no-cpu-baseline --no-parity-gate --full-run 0 --no-host-leg"
-for W in cfg3 cfg3-batch; do
-  if [ $W = cfg3 ]; then CMD="python $R/bench.py $Q"; else CMD="python $R/bench.py --workload cfg3-batch --steps 10 --warmup 1 --no-cpu-baseline"; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_${W}_stats -- $CMD > $O/p_${W}_stats.log 2>&1
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/p_${W}_fetch -- $CMD > $O/p_${W}_fetch.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/p_${W}_write -- $CMD > $O/p_${W}_write.log 2>&1
-done
-cd $R
-if [ "$2" = "cfg4f" ]; then timeout 400 python bench.py --workload cfg4f --steps 1 --warmup 0 --no-cpu-baseline --no-host-leg > $O/bench_cfg4f.json 2> $O/bench_cfg4f.err; fi
-for f in $O/bench_*.json; do echo "== $f"; cut -c1-900 $f; done
-tail -n 2 $O/*.err | grep -v amdgpu.ids
+run() { name=$1; shift; timeout ${TMO:-600} python bench.py "$@" > $O/bench_$name.json 2> $O/bench_$name.err; echo "== $name"; cut -c1-700 $O/bench_$name.json; }
+if [[ $WHAT == *benches* ]]; then
+  TMO=900 run cfg3
+  run cfg3_sync --loop sync --no-cpu-baseline --full-run 0 --no-host-leg
+  run cfg2 --workload cfg2 --full-run 0
+  run cfg3f --workload cfg3f --steps 30 --full-run 0 --no-host-leg
+  run cfg3b --workload cfg3-batch --steps 20 --warmup 2
+  run cfg3split --workload cfg3-split --steps 50
+  run cfg4csplit --workload cfg4c-split --steps 3 --warmup 1
+  run cfg4c --workload cfg4c --steps 3 --warmup 1 --cpu-seconds 5
+  run cfg5 --workload cfg5 --steps 5 --warmup 1
+  run cfg5split --workload cfg5-split --steps 5 --warmup 1
+  TMO=900 run cfg4f --workload cfg4f --steps 1 --warmup 0 --cpu-seconds 5 --no-host-leg
+fi
+if [[ $WHAT == *profiles* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  Q="--no-cpu-baseline --no-parity-gate --full-run 0 --no-host-leg"
+  declare -A CMD
+  CMD[cfg3]="python $R/bench.py $Q"
+  CMD[cfg3f]="python $R/bench.py --workload cfg3f --steps 20 $Q"
+  CMD[cfg4c]="python $R/bench.py --workload cfg4c --steps 2 --warmup 1 $Q"
+  CMD[cfg4f]="python $R/bench.py --workload cfg4f --steps 1 --warmup 0 $Q"
+  CMD[cfg5]="python $R/bench.py --workload cfg5 --steps 5 --warmup 1 --no-cpu-baseline"
+  for W in ${PROF_WORKLOADS:-cfg3 cfg3f cfg4c cfg5 cfg4f}; do
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_${W}_stats -- ${CMD[$W]} > $O/p_${W}_stats.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/p_${W}_fetch -- ${CMD[$W]} > $O/p_${W}_fetch.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/p_${W}_write -- ${CMD[$W]} > $O/p_${W}_write.log 2>&1
+    echo "== profiled $W"
+  done
+  cd $R
+  python tools/cycle_timeline.py $O/p_cfg3_stats > $O/cfg3_timeline.txt 2>&1
+fi
+tail -n 2 $O/*.err 2>/dev/null | grep -v amdgpu.ids | grep -v "^$" | head -40
