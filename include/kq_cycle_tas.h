@@ -1,16 +1,25 @@
-/* kq_cycle_tas.h — the TAS side input / output of a scheduling cycle, as the ORACLE consumes it. TEST INFRASTRUCTURE.
+/* kq_cycle_tas.h — the TAS side input / output of a scheduling cycle: Topology-Aware Scheduling INSIDE kq_cycle_run.
  *
- * Topology-Aware Scheduling inside the cycle (flavorassigner.go:864-903, scheduler.go:707-769 needsTASRecompute, :941-985
- * updateAssignmentForTAS, preemption.go:669-684 workloadFits, clusterqueue_snapshot.go:107-149 AddUsage / RemoveUsage / Fits) is
- * restated by oracle/kq_oracle.cpp (kqo_cycle_run_tas) ahead of the engine: this struct is the boundary the engine's cycle will
- * take next to kq_snapshot / kq_heads (it is laid out like include/kq_tas.h's batch entry points, so the flatten code is shared).
+ * kq_cycle_run_tas replaces the same call as kq_cycle_run ((*Scheduler).schedule, pkg/scheduler/scheduler.go:226) for a cycle whose
+ * ClusterQueues list TAS ResourceFlavors. On top of kq_cycle_run it does, on the device:
+ *   - Assign's TAS step (flavorassigner.go:864-903 assignTAS; tas_flavorassigner.go:37-83 WorkloadsTopologyRequests; clusterqueue_snapshot.go:204
+ *     FindTopologyAssignmentsForWorkload -> tas_flavor_snapshot.go:578 FindTopologyAssignmentsForFlavor), normal and simulate-empty,
+ *     for every Assign of the head, also inside the partial-admission search;
+ *   - the TAS-aware workloadFits of the victim search (preemption.go:669-684): a candidate's TopologyDomainRequests leave the leaf
+ *     usage with its quota, the placement is re-run per step;
+ *   - updateAssignmentForTAS (scheduler.go:941-985), the TAS part of ClusterQueueSnapshot.Fits / AddUsage (clusterqueue_snapshot.go:107-149)
+ *     inside processEntry, and the recomputation of scheduler.go:707-769 (needsTASRecompute, features.TASRecomputeAssignmentWithinSchedulingCycle).
+ * The oracle (oracle/kq_oracle.cpp kqo_cycle_run_tas) consumes the same two structs.
  * Host side, as for include/kq_tas.h: topology trees, node feasibility (leaf_ok), level-key resolution per TAS flavor,
  * checkPodSetAndFlavorMatchForTAS (tas_flavorassigner.go:164 -> folded into kq_heads.ps_flavor_ok like taints and affinity).
+ * Outside (KQ_EUNSUPPORTED or left to the caller): fair sharing together with TAS, a workload whose podsets land on more than one TAS
+ * flavor (TASHandleOverlappingFlavors), balanced placement, node replacement, workloads that hold a previous admission (second pass).
  */
 #ifndef KQ_CYCLE_TAS_H
 #define KQ_CYCLE_TAS_H
 #include <stdint.h>
-#include "../include/kq_tas.h"
+#include "kq_engine.h"
+#include "kq_tas.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -56,6 +65,13 @@ typedef struct kq_cycle_tas_out {
   int32_t  dom_cap;
   int64_t* tas_usage_after;         /* optional: [n_tas][n_leaves][n_resources] concatenated, leaf usage after the cycle */
 } kq_cycle_tas_out;
+
+/* One scheduling cycle with TAS inside it, against the resident snapshot (kq_snapshot_put). Same contract as kq_cycle_run for `out`
+ * (decisions, targets, reasons); tout receives the TopologyAssignment of every podset that holds one (admitted or not: the nomination's)
+ * and, optionally, the leaf usage after the cycle. t->adm_* is indexed by the admitted rows of the resident snapshot, t->ps_* by the
+ * podsets of `h`. stats (optional): [0] placements computed, [1] TAS recomputations inside processEntry, [2] reserved.
+ * KQ_EUNSUPPORTED: fair sharing, or a workload with TAS requests on more than one TAS flavor. */
+int kq_cycle_run_tas(kq_engine* e, const kq_heads* h, const kq_cycle_tas* t, kq_decisions* out, kq_cycle_tas_out* tout, int64_t* stats);
 
 #ifdef __cplusplus
 }

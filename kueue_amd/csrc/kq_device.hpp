@@ -433,6 +433,7 @@ struct K {  // everything a kernel needs
   // does not cover (preemption targets, recomputation, non-plain operands, negative reservation, fair sharing).
   long long* root_margin;    // [n_tree * nfr], start = CERT_INF
   int32_t* cert_flags;       // [n_tree]
+  const struct TCyc* tc;     // Topology-Aware Scheduling inside the cycle (kq_tas_cycle.hpp; kq_cycle_run_tas), null in the ordinary cycle
   HelpBox* help;             // [n_tree] or null: no helper workgroups in this launch
   uint32_t* help_quit;       // [1] trees whose leader has finished
   int help_trees;            // n_tree of the launch (helper workgroups are the blocks after them)
@@ -678,7 +679,26 @@ template <class U> KQ_DEV void remove_usage(const DSnap& S, const int32_t* path,
 // ------------------------------------------------------------------------------------------------
 // per-wave scratch (LDS on the device)
 // ------------------------------------------------------------------------------------------------
+#ifdef KQ_TAS_CYCLE
+// TAS inside the cycle (kq_tas_cycle.hpp): the wave's view of the TopologyAssignments of the assignment under construction
+struct TAW {
+  int t, nreq;                    // WorkloadsTopologyRequests of the current flavor assignment: the TAS flavor, the podsets in request order
+  uint8_t req_ps[KQ_MAXPS];
+  int af_early;                   // assign_flavors stopped behind podset af_early - 1 (atLeastOnePodsAssignmentFailed), 0 = ran through
+  uint32_t err_mask, has_mask;    // per podset: psError; holds a TopologyAssignment
+  int32_t pos[KQ_MAXPS], n[KQ_MAXPS];  // the podset's domains in the slot's store (half 0)
+  int kept_used;
+  int plane;                      // which leaf-usage plane "the snapshot" is: 0 cycle start, 1 work, 2 work minus preempted rows
+  int srch;                       // a GetTargets walk with TAS requests is in flight: its private plane is live
+};
+#define KQ_TAS_WALK(w) ((w).ta.srch != 0)
+#else
+#define KQ_TAS_WALK(w) false
+#endif
 struct Wave {
+#ifdef KQ_TAS_CYCLE
+  TAW ta;
+#endif
   // current head
   int h, cq, plen, ps_base, nps;
   int64_t prio, ts;
@@ -802,6 +822,16 @@ KQ_DEV void set_error(const K& k, int code) {
 // flavor fungibility ordering (flavorassigner.go:536-576) as a sortable key:
 // isPreferred(a,b) <=> pref_key(a) > pref_key(b)
 // ------------------------------------------------------------------------------------------------
+#ifdef KQ_TAS_CYCLE
+KQ_DEV void tc_reset(Wave& w);
+KQ_DEV void tc_assign_tas(const K& k, Wave& w, int slot);
+KQ_DEV void tc_search_begin(const K& k, Wave& w, int slot);
+KQ_DEV void tc_search_end(Wave& w);
+KQ_DEV void tc_search_row(const K& k, const Wave& w, int slot, int row, bool add);
+KQ_DEV bool tc_search_fits(const K& k, Wave& w, int slot);
+KQ_DEV void tc_update_assignment(const K& k, Wave& w, int slot, const int32_t* trow, int nt);
+KQ_NOINLINE void tc_publish(const K& k, Wave& w, int slot);
+#endif
 KQ_DEV int64_t pref_key(int pm, int64_t borrow, uint32_t pol) {
   if (pm == PM_NOFIT) return -1;
   int64_t cls = (pm == PM_NOCAND) ? 0 : 1;
@@ -939,6 +969,9 @@ KQ_DEV void w_apply_row(const Search& s, int row, bool add) {
   }
   wsync();
   if (lane_id() == 0) s.w->bytes += 16 * (int64_t)cplen * (S.adm_use_off[row + 1] - S.adm_use_off[row]);
+#ifdef KQ_TAS_CYCLE
+  if (s.k->tc) tc_search_row(*s.k, w, s.slot, row, add);
+#endif
 }
 // preemption.go:669-686 on the private state (quota part)
 KQ_DEV bool w_fits(const Search& s, bool allow_borrowing) {
@@ -953,7 +986,12 @@ KQ_DEV bool w_fits(const Search& s, bool allow_borrowing) {
     else if (v > i64max(0, available_of(S, w.path, w.plen, fr, uw))) bad = true;
   }
   if (lane_id() == 0) { int nu = 0; for (int u = 0; u < w.ns; u++) nu += w.s_inu[u] ? 1 : 0; w.bytes += 40 * (int64_t)w.plen * nu; }
+#ifdef KQ_TAS_CYCLE
+  if (wballot(bad) != 0) return false;
+  return s.k->tc ? tc_search_fits(*s.k, w, s.slot) : true;   // preemption.go:676-684: the placement on the state without the victims so far
+#else
   return wballot(bad) == 0;
+#endif
 }
 // candidate_generator.go:136-158
 KQ_DEV bool candidate_valid(const Search& s, int row, int variant, bool borrow) {
@@ -1047,7 +1085,7 @@ KQ_DEV void classical_search(Search& s) {
   }
   wsync();
 #ifdef KQ_HOST_EMU
-  if (g_cs_check && !g_cs_force_off) {
+  if (g_cs_check && !g_cs_force_off && !KQ_TAS_WALK(w)) {
     if (cs_run(s, same_on, other_on)) {
       const int nt1 = w.ntgt; const int64_t b1 = w.bytes;
       std::vector<int> t1(s.trow, s.trow + nt1);
@@ -1074,7 +1112,7 @@ KQ_DEV void classical_search(Search& s) {
   }
   if (g_cs_force_off != 0) { /* walk */ } else
 #endif
-  if (cs_run(s, same_on, other_on)) return;  // the same search as segmented scans (kq_cs.hpp); false: outside its preconditions
+  if (!KQ_TAS_WALK(w) && cs_run(s, same_on, other_on)) return;  // the same search as segmented scans (kq_cs.hpp); false: outside its preconditions
   CSTAT(21, 1);
   // private copy of the tree's usage for the slots
   for (int i = lane; i < nn * w.ns; i += WAVE) {
@@ -1810,7 +1848,11 @@ KQ_DEV void simulate_preemption(const K& k, Wave& w, int slot, const int64_t* us
   if (lane_id() == 0) { w.ns = 1; w.s_fr[0] = fr; w.s_qty[0] = val; w.s_inu[0] = 1; w.s_need[0] = 1; }
   wsync();
   Search s = make_search(k, w, slot, usage, removed);
+#ifdef KQ_NO_FAIR
+  classical_search(s);
+#else
   if (k.C.fair_sharing) fair_search(s); else classical_search(s);
+#endif
   wsync();
   if (w.ntgt == 0) { *pm = PM_NOCAND; *borrow = base_borrow; return; }
   bool any_same = false;
@@ -1967,6 +2009,9 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
   const int lane = lane_id();
   const int nR = S.nR;
   KQ_T0();
+#ifdef KQ_TAS_CYCLE
+  if (k.tc) tc_reset(w);
+#endif
   if (lane == 0) { w.nuse = 0; w.borrowing = 0; w.rep_mode = M_FIT; w.nrsn = 0; w.rsn_over = 0; }
   wsync();
   int rep = M_FIT;
@@ -2276,6 +2321,9 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
         O.flavor[o] = -1; O.res_mode[o] = M_NOFIT; O.tried_idx[o] = -1;
       }
       for (int q = pi + 1 + lane; q < w.nps; q += WAVE) O.ps_count[w.ps_base + q] = H.ps_count[w.ps_base + q];
+#ifdef KQ_TAS_CYCLE
+      if (k.tc && lane == 0) w.ta.af_early = pi + 1;
+#endif
       wsync();
       break;
     }
@@ -2287,6 +2335,9 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
     if (O.rsn_win > 0) O.rsn_n[w.h] = w.rsn_over ? -w.nrsn : w.nrsn;
   }
   wsync();
+#ifdef KQ_TAS_CYCLE
+  if constexpr (!LEAN) if (k.tc && w.rep_mode != M_NOFIT && !w.ta.af_early) tc_assign_tas(k, w, slot);  // flavorassigner.go:857-863
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2322,8 +2373,18 @@ KQ_DEV void prepare_target_slots(const K& k, Wave& w) {
 KQ_DEV Search get_targets(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed) {
   Search s = make_search(k, w, slot, usage, removed);
   prepare_target_slots(k, w);
+#ifdef KQ_TAS_CYCLE
+  if (k.tc) tc_search_begin(k, w, slot);   // preemption.go:135-138: tasRequests of the assignment; the walk then carries the leaf usage
+#endif
+#ifdef KQ_NO_FAIR
+  classical_search(s);   // (kq_tas_cycle_kernel.hip: fair sharing is refused by the host, its searches are not compiled in)
+#else
   if (k.C.fair_sharing) fair_search(s); else classical_search(s);
+#endif
   wsync();
+#ifdef KQ_TAS_CYCLE
+  if (k.tc) tc_search_end(w);
+#endif
   return s;
 }
 
@@ -2423,7 +2484,13 @@ KQ_DEV Search get_assignments(const K& k, Wave& w, int slot, const int64_t* usag
   const int slice_saved = w.slice_row;
   if (slice_saved >= 0 && removed && removed[slice_saved]) { wsync(); if (lane_id() == 0) w.slice_row = -1; wsync(); }
   Search s = get_assignments_inner(k, w, slot, usage, removed, nominate_map);
-  if (w.slice_row != slice_saved) { wsync(); if (lane_id() == 0) w.slice_row = slice_saved; wsync(); return s; }
+  if (w.slice_row != slice_saved) {
+    wsync(); if (lane_id() == 0) w.slice_row = slice_saved; wsync();
+#ifdef KQ_TAS_CYCLE
+    if (k.tc) tc_update_assignment(k, w, slot, s.trow, w.ntgt);
+#endif
+    return s;
+  }
   if (w.slice_row >= 0 && (w.rep_mode == M_FIT || w.ntgt > 0)) {
     if (lane_id() == 0) {
       bool dup = false;
@@ -2435,6 +2502,9 @@ KQ_DEV Search get_assignments(const K& k, Wave& w, int slot, const int64_t* usag
     }
     wsync();
   }
+#ifdef KQ_TAS_CYCLE
+  if (k.tc) tc_update_assignment(k, w, slot, s.trow, w.ntgt);   // scheduler.go:941-985, behind getInitialAssignments
+#endif
   return s;
 }
 
@@ -2456,6 +2526,9 @@ KQ_DEV void publish_assignment(const K& k, Wave& w, const Search& s, int h) {
   if (pos + w.ntgt <= O.pool_cap)
     for (int t = lane_id(); t < w.ntgt; t += WAVE) { O.pool_row[pos + t] = s.trow[t]; O.pool_reason[pos + t] = s.treason[t]; }
   wsync();
+#ifdef KQ_TAS_CYCLE
+  if (k.tc) tc_publish(k, w, s.slot);
+#endif
 }
 
 // outputs of a nominated head that k_process / the host read (everything but the assignment rows assign_flavors wrote itself)

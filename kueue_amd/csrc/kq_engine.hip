@@ -110,6 +110,12 @@ __global__ __launch_bounds__(256) void k_records(const K* __restrict__ kp) {
 // k_process_spec (speculative parallel rounds over the plain entries of a tree, kq_spec.hpp) is compiled in its own translation unit
 // (kq_spec_kernel.hip): it runs in front of k_process, which takes over at K::spec_resume[tree] (nothing left in the common case).
 namespace kq { hipError_t launch_process_spec(const K* d, int n_tree, hipStream_t stream); }
+// kernels of kq_cycle_run_tas: kq_tas_cycle_kernel.hip
+namespace kq {
+hipError_t launch_tas_base_k(const TCyc* c, int n, hipStream_t stream);
+hipError_t launch_nominate_tas_k(const K* d, int slots, hipStream_t stream);
+hipError_t launch_process_tas_k(const K* d, hipStream_t stream);
+}
 
 constexpr int PROCESS_THREADS = 256;   // wave 0 runs the serial core; all 4 waves prefetch the entry records of a chunk
 __global__ __launch_bounds__(PROCESS_THREADS) void k_process(const K* __restrict__ kp, unsigned lds_bytes) {
@@ -689,6 +695,18 @@ struct HipBackend {
     hipLaunchKernelGGL(k_process, dim3(n_tree), dim3(PROCESS_THREADS), lds, stream, d, (unsigned)lds);
     chk(hipGetLastError(), "k_process");
   }
+  // kq_cycle_run_tas (kq_tas_cycle_kernel.hip)
+  void launch_tas_base(const TCyc* c, int n) { chk(launch_tas_base_k(c, n, stream), "k_tas_base"); }
+  void launch_nominate_tas(const K& k, int slots) {
+    stat_patched = false;
+    const K* d = put_k(k, 0);
+    chk(launch_nominate_tas_k(d, slots, stream), "k_nominate_tas");
+  }
+  void launch_process_tas(const K& k) {
+    const K* d = stat_patched ? dcur0 : put_k(k, 1);
+    dproc = d; stat_patched = false;
+    chk(launch_process_tas_k(d, stream), "k_process_tas");
+  }
   size_t lds_attr = 0, lds_attr_fair = 0;
   const K* dproc = nullptr;    // argument block of the last process launch (kq_cycle_commit reads the cycle's outputs through it)
   bool stat_patched = false;
@@ -913,6 +931,10 @@ int kq_cycle_certificate(kq_engine* en, int64_t* usage_delta_dev, int64_t* root_
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
   return en->e.cycle_certificate(usage_delta_dev, root_margin, flags);
+}
+int kq_cycle_run_tas(kq_engine* en, const kq_heads* h, const kq_cycle_tas* t, kq_decisions* out, kq_cycle_tas_out* tout, int64_t* stats) {
+  if (!en || !h || !out) return KQ_EINVAL;
+  return en->e.cycle_run_tas(h, t, out, tout, stats);
 }
 int kq_snapshot_usage_add(kq_engine* en, const int64_t* delta_dev, int32_t sign) {
   if (!en || !delta_dev) return KQ_EINVAL;

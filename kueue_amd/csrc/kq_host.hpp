@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "kq_device.hpp"
+#include "kq_tas_cycle.hpp"
 
 namespace kq {
 
@@ -591,6 +592,171 @@ template <class B> struct EngineT {
     return cycle_exec(0, out);
   }
 
+  // ---- Topology-Aware Scheduling inside the cycle (include/kq_cycle_tas.h, kq_tas_cycle.hpp) ------------------------------------------------
+  std::vector<Buf> tbuf;
+  size_t tnext = 0;
+  template <class T> T* tgrow(size_t n) { if (tnext >= tbuf.size()) tbuf.resize(tnext + 16); return grow<T>(tbuf[tnext++], n); }
+  template <class T> T* tstage(const T* host, size_t n) { T* d = tgrow<T>(n); if (n) be.h2d(d, host, n * sizeof(T)); return d; }
+  int cycle_run_tas(const kq_heads* h, const kq_cycle_tas* t, kq_decisions* out, kq_cycle_tas_out* tout, int64_t* stats) {
+    if (!have_snapshot) return fail(KQ_EINVAL, "kq_cycle_run_tas before kq_snapshot_put");
+    if (!t || !tout || !tout->ps_tas || !tout->dom_off) return fail(KQ_EINVAL, "null kq_cycle_tas / kq_cycle_tas_out");
+    if (cfg.fair_sharing) return fail(KQ_EUNSUPPORTED, "TAS inside a fair-sharing cycle is outside this entry point");
+    if (t->n_tas < 0) return fail(KQ_EINVAL, "negative n_tas");
+    shard_heads_ok = false;
+    int rc = heads_put(h, 0);
+    if (rc != KQ_OK) return rc;
+    const int n = batches[0].n;
+    const size_t nps = batches[0].nps;
+    if (stats) stats[0] = stats[1] = stats[2] = 0;
+    tout->dom_off[0] = 0;
+    if (t->n_tas == 0) {  // no TAS flavor in the snapshot: the ordinary cycle
+      rc = cycle_exec(0, out);
+      for (size_t p = 0; p < nps; p++) { tout->ps_tas[p] = -1; tout->dom_off[p + 1] = 0; }
+      return rc;
+    }
+    const int nt = t->n_tas, R = t->topo[0].n_resources;
+    if (R < 1 || R > KQ_TAS_MAXR) return fail(KQ_EUNSUPPORTED, "n_resources out of range");
+    if (!t->tas_flavor || !t->topo || !t->cq_tas_only || !t->adm_off || !t->ps_flags || !t->ps_kind || !t->ps_level || !t->ps_slice_size ||
+        !t->ps_slice_level || !t->ps_group || !t->ps_req) return fail(KQ_EINVAL, "null array in kq_cycle_tas");
+    tnext = 0;
+    const int slots = std::max(1, std::min(n, be.max_slots()));
+    std::vector<int32_t> tas_of(prep.nF, -1);
+    std::vector<TK> tks(nt);
+    std::vector<int64_t*> work(nt), np(nt), priv(nt);
+    int max_leaves = 1;
+    for (int i = 0; i < nt; i++) {
+      const kq_tas_topology& tp = t->topo[i];
+      if (t->tas_flavor[i] < 0 || t->tas_flavor[i] >= prep.nF) return fail(KQ_EINVAL, "tas_flavor out of range");
+      tas_of[t->tas_flavor[i]] = i;
+      if (tp.n_levels < 1 || tp.n_levels > KQ_TAS_MAX_LEVELS) return fail(KQ_EUNSUPPORTED, "n_levels out of range");
+      if (tp.n_resources != R || tp.pods_resource != t->topo[0].pods_resource) return fail(KQ_EINVAL, "every TAS topology must be built over one resource dictionary");
+      TK& tk = tks[i];
+      tk = TK{};
+      TTopo& T = tk.T;
+      T.L = tp.n_levels; T.R = R; T.pods = tp.pods_resource; T.profile_mixed = tp.profile_mixed;
+      for (int l = 0; l <= T.L; l++) T.level_off[l] = tp.level_off[l];
+      T.D = T.level_off[T.L]; T.leaf_base = T.level_off[T.L - 1]; T.n_leaves = T.D - T.leaf_base;
+      for (int l = 0; l < T.L; l++) if (T.level_off[l + 1] < T.level_off[l]) return fail(KQ_EINVAL, "level_off not monotone");
+      std::vector<int32_t> first(std::max(T.D, 1), -1), cnt(std::max(T.D, 1), 0);
+      for (int l = 1; l < T.L; l++) {
+        int prev = -1;
+        for (int d = T.level_off[l]; d < T.level_off[l + 1]; d++) {
+          const int par = tp.parent[d];
+          if (par < 0 || par >= T.level_off[l] - T.level_off[l - 1]) return fail(KQ_EINVAL, "parent out of range");
+          if (par < prev) return fail(KQ_EINVAL, "domains of a level must be ordered by their parents (lexicographic levelValues)");
+          prev = par;
+          const int g = T.level_off[l - 1] + par;
+          if (first[g] < 0) first[g] = d;
+          cnt[g]++;
+        }
+      }
+      max_leaves = std::max(max_leaves, T.n_leaves);
+      const size_t cells = (size_t)T.n_leaves * R;
+      T.child_first = tstage(first.data(), first.size()); T.child_cnt = tstage(cnt.data(), cnt.size());
+      be.sync();  // (first / cnt are locals)
+      T.free_cap = tstage(tp.free_capacity, cells);
+      T.tas_usage = tstage(tp.tas_usage, cells);
+      work[i] = tgrow<int64_t>(cells); np[i] = tgrow<int64_t>(cells); priv[i] = tgrow<int64_t>((size_t)slots * cells);
+      TScratch& X = tk.X;
+      X.max_set = (std::max(T.n_leaves, T.D - T.n_leaves + 1) + 1 + 15) & ~15;
+      const size_t sd = (size_t)slots * T.D, sm = (size_t)slots * X.max_set;
+      X.pc = tgrow<int32_t>(sd); X.sc = tgrow<int32_t>(sd); X.pcwl = tgrow<int32_t>(sd); X.scwl = tgrow<int32_t>(sd); X.lc = tgrow<int32_t>(sd);
+      X.set = tgrow<int32_t>(sm); X.arr = tgrow<int32_t>(sm + slots); X.cur = tgrow<int32_t>(sm); X.nxt = tgrow<int32_t>(sm);
+      X.k0 = (uint64_t*)tgrow<int64_t>(sm); X.k1 = (uint64_t*)tgrow<int64_t>(sm);
+      X.assumed = tgrow<int64_t>((size_t)slots * cells);
+      X.log = tgrow<int32_t>(sm); X.meta = tgrow<int32_t>((size_t)slots * 4);
+      be.memset(X.meta, 0xff, (size_t)slots * 4 * sizeof(int32_t));
+    }
+    const int n_adm = prep.n_adm;
+    const int n_ent = n_adm > 0 ? t->adm_off[n_adm] : 0;
+    if (n_ent > 0 && (!t->adm_tas || !t->adm_leaf || !t->adm_count || !t->adm_req)) return fail(KQ_EINVAL, "null admitted-row arrays in kq_cycle_tas");
+    for (int e = 0; e < n_ent; e++) {
+      if (t->adm_tas[e] < 0 || t->adm_tas[e] >= nt) return fail(KQ_EINVAL, "adm_tas out of range");
+      if (t->adm_leaf[e] < 0 || t->adm_leaf[e] >= tks[t->adm_tas[e]].T.n_leaves) return fail(KQ_EINVAL, "adm_leaf out of range");
+    }
+    TCyc c{};
+    c.flags = t->flags; c.n_tas = nt; c.R = R; c.slots = slots;
+    c.tas_of_flavor = tstage(tas_of.data(), tas_of.size());
+    c.tk = tstage(tks.data(), tks.size());
+    c.work = tstage(work.data(), work.size()); c.np = tstage(np.data(), np.size()); c.priv = tstage(priv.data(), priv.size());
+    c.cq_tas_only = tstage(t->cq_tas_only, (size_t)std::max(prep.nq, 1));
+    std::vector<int32_t> zero_off(1, 0);
+    c.adm_off = n_adm > 0 ? tstage(t->adm_off, (size_t)n_adm + 1) : tstage(zero_off.data(), 1);
+    c.adm_tas = tstage(t->adm_tas, n_ent); c.adm_leaf = tstage(t->adm_leaf, n_ent); c.adm_count = tstage(t->adm_count, n_ent);
+    c.adm_req = tstage(t->adm_req, (size_t)n_ent * R);
+    c.ps_flags = tstage(t->ps_flags, nps); c.ps_kind = tstage(t->ps_kind, nps);
+    c.ps_level = tstage(t->ps_level, nps * nt); c.ps_slice_size = tstage(t->ps_slice_size, nps); c.ps_slice_level = tstage(t->ps_slice_level, nps * nt);
+    c.ps_group = tstage(t->ps_group, nps); c.ps_req = tstage(t->ps_req, nps * R);
+    bool layered = false;
+    if (t->ps_n_layers) for (size_t p = 0; p < nps; p++) {
+      if (t->ps_n_layers[p] < 0 || t->ps_n_layers[p] > KQ_TAS_MAX_LEVELS) return fail(KQ_EUNSUPPORTED, "ps_n_layers out of range");
+      if (t->ps_n_layers[p] > 1) layered = true;
+    }
+    if (layered && (!t->ps_layer_level || !t->ps_layer_size)) return fail(KQ_EINVAL, "ps_n_layers without ps_layer_level / ps_layer_size");
+    c.ps_n_layers = layered ? tstage(t->ps_n_layers, nps) : nullptr;
+    c.ps_layer_level = layered ? tstage(t->ps_layer_level, nps * nt * KQ_TAS_MAX_LEVELS) : nullptr;
+    c.ps_layer_size = layered ? tstage(t->ps_layer_size, nps * KQ_TAS_MAX_LEVELS) : nullptr;
+    c.q_i32 = tgrow<int32_t>((size_t)slots * TQ_WORDS); c.q_u8 = tgrow<uint8_t>((size_t)slots * (TC_P + 8)); c.q_spr = tgrow<int64_t>((size_t)slots * TC_P * R);
+    // a head's TopologyAssignments hold at most min(pods, leaves) domains per podset
+    int d_cap = 1;
+    for (int i = 0; i < n; i++) {
+      int64_t tot = 0;
+      for (int p = h->ps_off[i]; p < h->ps_off[i + 1]; p++) tot += std::min<int64_t>(std::max(h->ps_count[p], 0), max_leaves);
+      d_cap = (int)std::max<int64_t>(d_cap, std::min<int64_t>(tot, (int64_t)KQ_MAXPS * max_leaves));
+    }
+    c.d_cap = d_cap;
+    c.d_leaf = tgrow<int32_t>((size_t)slots * 2 * d_cap); c.d_count = tgrow<int32_t>((size_t)slots * 2 * d_cap);
+    c.h_tas = tgrow<int32_t>(nps); c.h_pos = tgrow<int32_t>(nps); c.h_n = tgrow<int32_t>(nps);
+    be.memset(c.h_tas, 0xff, nps * 4); be.memset(c.h_pos, 0, nps * 4); be.memset(c.h_n, 0, nps * 4);
+    c.pool_cap = 2 * std::max(tout->dom_cap, 1) + d_cap;   // a recomputation inside processEntry publishes a second segment
+    c.pool_leaf = tgrow<int32_t>(c.pool_cap); c.pool_count = tgrow<int32_t>(c.pool_cap);
+    int64_t* tmisc = tgrow<int64_t>(8);
+    be.memset(tmisc, 0, 8 * sizeof(int64_t));
+    c.stats = (long long*)tmisc; c.pool_used = (int32_t*)(tmisc + 4);
+    c.tree_state = tgrow<int32_t>((size_t)std::max(prep.n_tree, 1) * 12);
+    be.memset(c.tree_state, 0, (size_t)std::max(prep.n_tree, 1) * 12 * 4);
+    TCyc* d_tc = tstage(&c, 1);
+    if (n_ent > 0) be.launch_tas_base(d_tc, n_ent);   // base plane += workload.TASUsage() of every admitted row
+    for (int i = 0; i < nt; i++) {
+      const size_t bytes = (size_t)tks[i].T.n_leaves * R * sizeof(int64_t);
+      be.d2d(work[i], tks[i].T.tas_usage, bytes); be.d2d(np[i], tks[i].T.tas_usage, bytes);
+    }
+    rc = be.sync();   // (c, tks and the pointer tables are locals)
+    if (rc != KQ_OK) return fail(rc, be.error());
+    rc = cycle_exec(0, out, false, ShardCall{}, nullptr, d_tc);
+    if (rc != KQ_OK) return rc;
+    last_cycle_n = -1;   // kq_cycle_commit does not carry leaf usage: a TAS cycle is not committable through it
+    std::vector<int32_t> ht(nps * 3);
+    int64_t hm[8];
+    be.d2h(ht.data(), c.h_tas, nps * 4); be.d2h(ht.data() + nps, c.h_pos, nps * 4); be.d2h(ht.data() + 2 * nps, c.h_n, nps * 4);
+    be.d2h(hm, tmisc, sizeof(hm));
+    rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    const int used = std::min(((int32_t*)(hm + 4))[0], c.pool_cap);
+    std::vector<int32_t> pl(std::max(used, 1)), pc(std::max(used, 1));
+    if (used > 0) { be.d2h(pl.data(), c.pool_leaf, (size_t)used * 4); be.d2h(pc.data(), c.pool_count, (size_t)used * 4); }
+    if (tout->tas_usage_after) {
+      size_t o = 0;
+      for (int i = 0; i < nt; i++) { const size_t cells = (size_t)tks[i].T.n_leaves * R; be.d2h(tout->tas_usage_after + o, work[i], cells * sizeof(int64_t)); o += cells; }
+    }
+    rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    if (stats) { stats[0] = hm[0]; stats[1] = hm[1]; stats[2] = hm[2]; }
+    int tot = 0;
+    for (size_t p = 0; p < nps; p++) {
+      const int tt = ht[p], pos = ht[nps + p], cnt = tt >= 0 ? ht[2 * nps + p] : 0;
+      tout->ps_tas[p] = tt;
+      for (int j = 0; j < cnt; j++) {
+        if (tot >= tout->dom_cap) return fail(KQ_ECAPACITY, "dom_cap too small");
+        if (tout->dom_leaf) tout->dom_leaf[tot] = pl[pos + j];
+        if (tout->dom_count) tout->dom_count[tot] = pc[pos + j];
+        tot++;
+      }
+      tout->dom_off[p + 1] = tot;
+    }
+    return KQ_OK;
+  }
+
   // nominate_only: stop after k_nominate (kq_nominate_run_resident: flavor assignment + targets for every head of the batch,
   // no iterator, no processEntry; nothing to commit afterwards)
   // Sharded nominate / merged process (kq_cycle_nominate_shard, kq_cycle_process_merged): mode 1 = nominate the heads of `mine` and
@@ -620,7 +786,7 @@ template <class B> struct EngineT {
   bool step_unfused = getenv("KQ_STEP_UNFUSED") != nullptr;   // (A/B switch: the step's commit / apply / release as the separate launches of the call-by-call API)
   int64_t steps_issued = 0, steps_waited = 0;
 
-  int cycle_exec(int slot, kq_decisions* out, bool nominate_only = false, ShardCall sc = ShardCall{}, StepStage* st = nullptr) {
+  int cycle_exec(int slot, kq_decisions* out, bool nominate_only = false, ShardCall sc = ShardCall{}, StepStage* st = nullptr, const TCyc* d_tc = nullptr) {
     if (!have_snapshot) return fail(KQ_EINVAL, "kq_cycle_run before kq_snapshot_put");
     if (!st && steps_issued != steps_waited) return fail(KQ_EINVAL, "a kq_pending_step is in flight: its outputs share the cycle's buffers (kq_pending_step_wait first)");
     if (slot < 0 || slot >= (int)batches.size() || !batches[slot].valid) return fail(KQ_EINVAL, "unknown head batch");
@@ -759,6 +925,7 @@ template <class B> struct EngineT {
     }
     prep_fill(k.defer_count, 1, 0);
     k.help = nullptr; k.help_quit = nullptr; k.help_trees = 0;
+    k.tc = d_tc;
     HelpBox* d_help = nullptr;
     if (n_help > 0) {  // one box per tree + the quit counter behind them, zeroed every cycle
       d_help = grow<HelpBox>(b_help, (size_t)prep.n_tree + 1);
@@ -812,14 +979,15 @@ template <class B> struct EngineT {
       // the full pass (victim searches, partial admission, replaced slices) only gets heads the lean pass defers; when nothing of the
       // kind exists in the snapshot and the batch, its launch is skipped
       const bool full_pass = prep.any_preemption || hbch.partial || hbch.H.slice_row != nullptr || !lean_only_ok;
-      be.launch_nominate(k, slots_nom, nom_lds, full_pass);
+      if (d_tc) be.launch_nominate_tas(k, slots_nom);   // every head through the full nominate code with the TAS hooks (kq_tas_cycle.hpp)
+      else be.launch_nominate(k, slots_nom, nom_lds, full_pass);
     }
     if (sc.mode == 1) {
       be.launch_shard_export(k, nps, rsn_win);
       last_cycle_n = -1;
       return be.sync();   // the caller's all-reduce reads the buffer next
     }
-    if (!nominate_only) be.launch_records(k);  // entry records (static part) for k_process; charged to the nominate interval
+    if (!nominate_only && !d_tc) be.launch_records(k);  // entry records (static part) for k_process; charged to the nominate interval
     be.timer_mark(1);
     if (!cfg.fair_sharing && !nominate_only) be.launch_order(k, order_idx, rank);
     be.timer_mark(2);
@@ -829,6 +997,7 @@ template <class B> struct EngineT {
       if (n_help > 0) { k.help = d_help; k.help_quit = (uint32_t*)(d_help + prep.n_tree); k.help_trees = prep.n_tree; }
       be.launch_process_fair(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16, fs_want, rank);
     }
+    else if (d_tc) be.launch_process_tas(k);   // one wave, every tree, entry order: TAS leaves are shared across root cohorts
     else be.launch_process(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16);
     be.timer_mark(3);
     last_cycle_n = -1;  // set on the success path only: a failed cycle must not be committable

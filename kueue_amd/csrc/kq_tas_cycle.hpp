@@ -1,0 +1,544 @@
+// kq_tas_cycle.hpp — Topology-Aware Scheduling INSIDE the scheduling cycle (include/kq_cycle_tas.h, kq_cycle_run_tas).
+//
+// The cycle's own code (kq_device.hpp) is compiled a second time with KQ_TAS_CYCLE defined (translation unit
+// kq_tas_cycle_kernel.hip, kernels k_nominate_tas / k_process_tas); the hooks it then calls are defined here:
+//   assign_flavors      -> tc_assign_tas          flavorassigner.go:864-903 (assignTAS)
+//   get_targets         -> tc_search_begin / tc_search_row / tc_search_fits / tc_search_end   preemption.go:135-138, :669-684
+//   get_assignments     -> tc_update_assignment   scheduler.go:941-985 (updateAssignmentForTAS)
+//   publish_assignment  -> tc_publish             the head's TopologyAssignments for processEntry and the host
+//   k_process_tas       -> process_entry_tas      scheduler.go:392-523 + :707-769 with the TAS side of Fits / AddUsage
+// The placement itself is kq_tas_device.hpp's t_workload (FindTopologyAssignmentsForFlavor :578), called in-wave on a request block
+// the wave builds from the head's current flavor assignment. The ordinary cycle's kernels do not contain any of this.
+//
+// Leaf usage of a TAS flavor ([n_leaves][R] int64) exists in three planes: `base` (cycle start: tas_usage + every admitted row's
+// TopologyDomainRequests — what nominate reads), `work` (processEntry's snapshot) and `np` (work minus the rows preempted so far this
+// cycle: what scheduler.fits and an overlap recomputation see). A victim search runs on a private copy per wave slot.
+#pragma once
+#include "../../include/kq_cycle_tas.h"
+#include "kq_tas_device.hpp"
+
+namespace kq {
+
+constexpr int TC_P = KQ_MAXPS;
+constexpr int TC_ML = KQ_TAS_MAX_LEVELS;
+// a slot's int32 request / result block (one FindTopologyAssignmentsForFlavor call in flight per wave)
+enum {
+  TQ_WLOFF = 0, TQ_COUNT = 2, TQ_LEVEL = TQ_COUNT + TC_P, TQ_SSIZE = TQ_LEVEL + TC_P, TQ_SLEVEL = TQ_SSIZE + TC_P, TQ_GROUP = TQ_SLEVEL + TC_P,
+  TQ_NLAY = TQ_GROUP + TC_P, TQ_LLEVEL = TQ_NLAY + TC_P, TQ_LSIZE = TQ_LLEVEL + TC_P * TC_ML, TQ_STATUS = TQ_LSIZE + TC_P * TC_ML,
+  TQ_OPA = TQ_STATUS + TC_P, TQ_OPB = TQ_OPA + TC_P, TQ_DPOS = TQ_OPB + TC_P, TQ_DN = TQ_DPOS + TC_P, TQ_MISC = TQ_DN + TC_P, TQ_WORDS = TQ_MISC + 8
+};
+static_assert(TQ_MISC % 2 == 0, "the misc words hold an aligned 64-bit byte counter");
+
+struct TCyc {
+  uint32_t flags;
+  int n_tas, R, slots;
+  const int32_t* tas_of_flavor;   // [nF] index into the TAS flavors, -1 = not one
+  const TK* tk;                   // [n_tas] topology + per-slot scratch (X); T.tas_usage = the base plane
+  int64_t* const* work;           // [n_tas]
+  int64_t* const* np;             // [n_tas]
+  int64_t* const* priv;           // [n_tas] [slots][n_leaves * R]
+  const uint8_t* cq_tas_only;
+  const int32_t *adm_off, *adm_tas, *adm_leaf, *adm_count;
+  const int64_t* adm_req;
+  const uint8_t *ps_flags, *ps_kind;
+  const int32_t *ps_level, *ps_slice_size, *ps_slice_level, *ps_group;
+  const int64_t* ps_req;
+  const int32_t *ps_n_layers, *ps_layer_level, *ps_layer_size;
+  int32_t* q_i32;                 // [slots][TQ_WORDS]
+  uint8_t* q_u8;                  // [slots][TC_P + 8] kind per request, simulate-empty flag
+  int64_t* q_spr;                 // [slots][TC_P][R]
+  int32_t *d_leaf, *d_count;      // [slots][2][d_cap]: half 0 = the assignment the wave keeps, half 1 = output of the find in flight
+  int d_cap;
+  int32_t *h_tas, *h_pos, *h_n;   // [n_ps] the published TopologyAssignment of every podset: TAS flavor (-1 = none), segment of the pool
+  int32_t *pool_leaf, *pool_count, *pool_used;
+  int pool_cap;
+  long long* stats;               // [4] placements, recomputations, unsupported
+  int32_t* tree_state;            // [n_tree][12] processEntry's per-tree state while one wave walks all trees in entry order
+};
+
+#ifdef KQ_TAS_CYCLE
+// ---- usage planes --------------------------------------------------------------------------------------------------------------------
+KQ_DEV int64_t* tc_plane(const TCyc& c, int t, int which, int slot) {
+  const TTopo& T = c.tk[t].T;
+  if (which == 0) return T.tas_usage;
+  if (which == 1) return c.work[t];
+  if (which == 2) return c.np[t];
+  return c.priv[t] + (size_t)slot * T.n_leaves * T.R;
+}
+// workload.TASUsage() of an admitted row applied to one plane of every TAS flavor (clusterqueue_snapshot.go:121-134). Lanes = the row's
+// domain entries; two entries of a row may name the same leaf (two podsets), hence the atomics — callers fence before reading.
+KQ_NOINLINE void tc_row_apply(const TCyc& c, int row, bool add, int which, int slot) {
+  for (int e = c.adm_off[row] + lane_id(); e < c.adm_off[row + 1]; e += WAVE) {
+    const int t = c.adm_tas[e];
+    const TTopo& T = c.tk[t].T;
+    int64_t* pl = tc_plane(c, t, which, slot);
+    const int64_t cnt = c.adm_count[e];
+    for (int r = 0; r < T.R; r++) {
+      const int64_t q = c.adm_req[(size_t)e * T.R + r];
+      const int64_t v = (q > 0 ? q : 0) * cnt + (r == T.pods ? cnt : 0);
+      if (v) atomic_add_i64((long long*)&pl[(size_t)c.adm_leaf[e] * T.R + r], (long long)(add ? v : -v));
+    }
+  }
+  wsync();
+}
+// TASFlavorSnapshot.Fits :433 for one TopologyDomainRequests on `pl` (agent-scope loads: the cells are updated with L2 atomics)
+KQ_DEV bool tc_fits_dom(const TTopo& T, const int64_t* pl, int leaf, int32_t count, const int64_t* spr) {
+  bool have = false; int32_t result = 0;
+  for (int r = 0; r < T.R; r++) {
+    if (spr[r] == 0) continue;
+    int32_t cc = 0x7fffffff;
+    if (spr[r] > 0) {
+      const int64_t used = (int64_t)ag_load_u64((const uint64_t*)(pl + (size_t)leaf * T.R + r));
+      cc = (int32_t)i64max(0, i64min((T.free_cap[(size_t)leaf * T.R + r] - used) / spr[r], 0x7fffffff));
+    }
+    if (!have || cc < result) { result = cc; have = true; }
+  }
+  return (have ? result : 0) >= count;
+}
+
+// ---- Assign's TAS step -------------------------------------------------------------------------------------------------------------------
+KQ_DEV void tc_reset(Wave& w) {
+  if (lane_id() == 0) { w.ta.t = -1; w.ta.nreq = 0; w.ta.af_early = 0; w.ta.err_mask = 0; w.ta.has_mask = 0; w.ta.kept_used = 0; w.ta.srch = 0; }
+}
+// Assignment.updateMode flavorassigner.go:192-198 for podset p; the usage entries' modes (flavorResourcesNeedPreemption reads them)
+// are re-derived from the cells: an entry is as weak as the weakest (podset, resource) behind it
+KQ_NOINLINE void tc_update_mode(const K& k, Wave& w, int p, int mode) {
+  const int nR = k.S.nR;
+  const size_t o = (size_t)(w.ps_base + p) * nR;
+  for (int r = lane_id(); r < nR; r += WAVE) if (k.O.flavor[o + r] >= 0) k.O.res_mode[o + r] = (uint8_t)mode;
+  wsync();
+  if (lane_id() == 0) {
+    w.rep_mode = mode;
+    for (int u = 0; u < w.nuse; u++) {
+      int m = M_FIT;
+      for (int q = 0; q < w.nps; q++)
+        for (int r = 0; r < nR; r++) {
+          const size_t c = (size_t)(w.ps_base + q) * nR + r;
+          if (k.O.flavor[c] >= 0 && k.O.flavor[c] * nR + r == w.use_fr[u] && k.O.res_mode[c] < m) m = k.O.res_mode[c];
+        }
+      w.use_mode[u] = (uint8_t)m;
+    }
+  }
+  wsync();
+}
+// tas_flavorassigner.go:37-83 WorkloadsTopologyRequests (+ onlyTASFlavor :142) on the head's current flavor assignment
+KQ_NOINLINE void tc_requests(const K& k, Wave& w) {
+  const TCyc& c = *k.tc;
+  if (lane_id() == 0) {
+    const int nR = k.S.nR;
+    w.ta.t = -1; w.ta.nreq = 0;
+    for (int p = 0; p < w.nps && p < TC_P; p++) {
+      const int g = w.ps_base + p;
+      const bool explicitReq = (c.ps_flags[g] & KQ_PS_TAS_EXPLICIT) != 0;
+      if (!explicitReq && !c.cq_tas_only[w.cq]) continue;                       // isTASRequested :231
+      if (w.ta.af_early && p >= w.ta.af_early) continue;                        // behind the podset Assign stopped at: not in assignment.PodSets
+      if ((w.ta.err_mask >> p) & 1) continue;
+      if (k.O.ps_count[g] == 0) continue;
+      if ((w.ta.has_mask >> p) & 1) continue;
+      int first = -1; bool many = false;
+      for (int r = 0; r < nR; r++) {
+        const int fl = k.O.flavor[(size_t)g * nR + r];
+        const int t = fl >= 0 ? c.tas_of_flavor[fl] : -1;
+        if (t < 0) continue;
+        if (first < 0) first = t; else if (t != first) many = true;
+      }
+      if (first < 0 || many) { w.ta.err_mask |= 1u << p; w.rep_mode = M_NOFIT; continue; }  // psError :290 -> RepresentativeMode NoFit
+      if (w.ta.t >= 0 && w.ta.t != first) { if (*k.O.error == 0) *k.O.error = KQ_EUNSUPPORTED; if (c.stats) c.stats[2] = 1; continue; }
+      w.ta.t = first;
+      w.ta.req_ps[w.ta.nreq++] = (uint8_t)p;
+    }
+  }
+  wsync();
+}
+struct TcFail { bool failed; int ps, status; };
+// ClusterQueueSnapshot.FindTopologyAssignmentsForWorkload clusterqueue_snapshot.go:204-237 for the requests in w.ta on plane `which`;
+// the domains land in half 1 of the slot's store. Failure = TASAssignmentsResult.Failure :411 (first failing podset).
+KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, int which) {
+  const TCyc& c = *k.tc;
+  TcFail f{false, -1, 0};
+  const int n = w.ta.nreq;
+  if (n == 0) return f;
+  const int t = w.ta.t;
+  const int lane = lane_id();
+  int32_t* qi = c.q_i32 + (size_t)slot * TQ_WORDS;
+  uint8_t* qu = c.q_u8 + (size_t)slot * (TC_P + 8);
+  int64_t* qs = c.q_spr + (size_t)slot * TC_P * c.R;
+  const bool layered = c.ps_n_layers != nullptr;
+  if (lane == 0) {
+    qi[TQ_WLOFF] = 0; qi[TQ_WLOFF + 1] = n;
+    for (int i = 0; i < n; i++) {
+      const int g = w.ps_base + w.ta.req_ps[i];
+      qi[TQ_COUNT + i] = k.O.ps_count[g];
+      qi[TQ_LEVEL + i] = c.ps_level[(size_t)g * c.n_tas + t];
+      qi[TQ_SSIZE + i] = c.ps_slice_size[g];
+      qi[TQ_SLEVEL + i] = c.ps_slice_level[(size_t)g * c.n_tas + t];
+      qi[TQ_GROUP + i] = c.ps_group[g];
+      qu[i] = c.ps_kind[g];
+      for (int r = 0; r < c.R; r++) qs[(size_t)i * c.R + r] = c.ps_req[(size_t)g * c.R + r];
+      if (layered) {
+        qi[TQ_NLAY + i] = c.ps_n_layers[g];
+        for (int j = 0; j < TC_ML; j++) {
+          qi[TQ_LLEVEL + i * TC_ML + j] = c.ps_layer_level[((size_t)g * c.n_tas + t) * TC_ML + j];
+          qi[TQ_LSIZE + i * TC_ML + j] = c.ps_layer_size[(size_t)g * TC_ML + j];
+        }
+      }
+    }
+    qu[TC_P] = simulateEmpty ? 1 : 0;
+    for (int i = 0; i < 8; i++) qi[TQ_MISC + i] = 0;
+    if (c.stats) atomic_add_i64(c.stats, 1);
+  }
+  wsync();
+  TK tk = c.tk[t];
+  tk.T.tas_usage = tc_plane(c, t, which, slot);
+  tk.Q.n_wl = 1; tk.Q.wl_off = qi + TQ_WLOFF; tk.Q.sim_empty = qu + TC_P; tk.Q.spr = qs;
+  tk.Q.count = qi + TQ_COUNT; tk.Q.level = qi + TQ_LEVEL; tk.Q.kind = qu; tk.Q.slice_size = qi + TQ_SSIZE; tk.Q.slice_level = qi + TQ_SLEVEL;
+  tk.Q.group = qi + TQ_GROUP; tk.Q.leaf_ok = nullptr;
+  tk.Q.n_layers = layered ? qi + TQ_NLAY : nullptr; tk.Q.layer_level = layered ? qi + TQ_LLEVEL : nullptr; tk.Q.layer_size = layered ? qi + TQ_LSIZE : nullptr;
+  tk.O.status = qi + TQ_STATUS; tk.O.op_a = qi + TQ_OPA; tk.O.op_b = qi + TQ_OPB; tk.O.dom_pos = qi + TQ_DPOS; tk.O.dom_n = qi + TQ_DN;
+  tk.O.layer_fit = nullptr;
+  tk.O.pool_leaf = c.d_leaf + ((size_t)slot * 2 + 1) * c.d_cap; tk.O.pool_count = c.d_count + ((size_t)slot * 2 + 1) * c.d_cap; tk.O.pool_cap = c.d_cap;
+  tk.O.pool_used = qi + TQ_MISC; tk.O.error = qi + TQ_MISC + 1; tk.O.bytes = (long long*)(qi + TQ_MISC + 2);
+  tk.C.n = 0;
+  t_workload(tk, slot, 0);
+  wsync();
+  // (the placement's own algorithmic bytes, qi[TQ_MISC + 2], are not added to the cycle's counter: SURVEY 8d's accounting of the quota
+  // cycle does not include them, and neither does the oracle's)
+  if (lane == 0 && qi[TQ_MISC + 1] != 0 && *k.O.error == 0) *k.O.error = qi[TQ_MISC + 1];
+  wsync();
+  for (int i = 0; i < n; i++) {
+    const int st = qi[TQ_STATUS + i];
+    if (st != KQ_TAS_OK && st != KQ_TAS_SKIPPED) { f.failed = true; f.ps = w.ta.req_ps[i]; f.status = st; break; }
+  }
+  return f;
+}
+// Assignment.UpdateForTASResult flavorassigner.go:87-96 with the result of the last tc_find: a podset whose placement succeeded keeps its
+// domains (copied into half 0 of the store), the others lose theirs
+KQ_NOINLINE void tc_keep_result(const K& k, Wave& w, int slot) {
+  const TCyc& c = *k.tc;
+  const int32_t* qi = c.q_i32 + (size_t)slot * TQ_WORDS;
+  const int32_t* fl = c.d_leaf + ((size_t)slot * 2 + 1) * c.d_cap; const int32_t* fc = c.d_count + ((size_t)slot * 2 + 1) * c.d_cap;
+  int32_t* kl = c.d_leaf + (size_t)slot * 2 * c.d_cap; int32_t* kc = c.d_count + (size_t)slot * 2 * c.d_cap;
+  for (int i = 0; i < w.ta.nreq; i++) {
+    const int p = w.ta.req_ps[i];
+    const bool ok = qi[TQ_STATUS + i] == KQ_TAS_OK;
+    const int pos = qi[TQ_DPOS + i], n = ok ? qi[TQ_DN + i] : 0;
+    const int at = w.ta.kept_used;
+    if (ok && at + n > c.d_cap) { set_error(k, KQ_ECAPACITY); return; }
+    for (int j = lane_id(); j < n; j += WAVE) { kl[at + j] = fl[pos + j]; kc[at + j] = fc[pos + j]; }
+    wsync();
+    if (lane_id() == 0) {
+      if (ok) { w.ta.has_mask |= 1u << p; w.ta.pos[p] = at; w.ta.n[p] = n; w.ta.kept_used = at + n; }
+      else w.ta.has_mask &= ~(1u << p);
+    }
+    wsync();
+  }
+}
+// flavorassigner.go:864-903
+KQ_DEV void tc_assign_tas(const K& k, Wave& w, int slot) {
+  tc_requests(k, w);
+  if (w.rep_mode == M_FIT) {
+    const TcFail f = tc_find(k, w, slot, false, w.ta.plane);
+    if (f.failed) tc_update_mode(k, w, f.ps, M_PREEMPT);   // (+ psAssignment.reason(failure.Reason): the message stays host-side)
+    else tc_keep_result(k, w, slot);
+  }
+  if (w.rep_mode == M_PREEMPT) {
+    const TcFail f = tc_find(k, w, slot, true, w.ta.plane);
+    if (f.failed) tc_update_mode(k, w, f.ps, M_NOFIT);
+    else for (int i = 0; i < w.ta.nreq; i++) tc_update_mode(k, w, w.ta.req_ps[i], M_PREEMPT);  // updateModeForTASRequests :200
+  }
+}
+
+// ---- GetTargets with TAS requests (preemption.go:135-138): the walk runs on a private copy of the leaf usage ---------------------
+KQ_NOINLINE void tc_copy_plane(const TCyc& c, int t, int from, int slot) {
+  const TTopo& T = c.tk[t].T;
+  const int64_t* src = tc_plane(c, t, from, slot);
+  int64_t* dst = tc_plane(c, t, 3, slot);
+  for (int i = lane_id(); i < T.n_leaves * T.R; i += WAVE) dst[i] = (int64_t)ag_load_u64((const uint64_t*)(src + i));
+  wsync();
+}
+KQ_DEV void tc_search_begin(const K& k, Wave& w, int slot) {
+  tc_requests(k, w);
+  if (w.ta.nreq == 0) return;
+  for (int t = 0; t < k.tc->n_tas; t++) tc_copy_plane(*k.tc, t, w.ta.plane, slot);
+  if (lane_id() == 0) w.ta.srch = 1;
+  wsync();
+}
+KQ_DEV void tc_search_end(Wave& w) { if (lane_id() == 0) w.ta.srch = 0; wsync(); }
+KQ_DEV void tc_search_row(const K& k, const Wave& w, int slot, int row, bool add) { if (w.ta.srch) tc_row_apply(*k.tc, row, add, 3, slot); }
+KQ_DEV bool tc_search_fits(const K& k, Wave& w, int slot) {  // preemption.go:676-684
+  if (!w.ta.srch) return true;
+  return !tc_find(k, w, slot, false, 3).failed;
+}
+
+// ---- scheduler.go:941-985 updateAssignmentForTAS ------------------------------------------------------------------------------------
+KQ_DEV void tc_update_assignment(const K& k, Wave& w, int slot, const int32_t* trow, int nt) {
+  const TCyc& c = *k.tc;
+  if (w.rep_mode != M_PREEMPT) return;
+  bool any = c.cq_tas_only[w.cq] != 0;
+  for (int p = 0; p < w.nps && !any; p++) if (c.ps_flags[w.ps_base + p] & KQ_PS_TAS_EXPLICIT) any = true;
+  if (!any) return;
+  tc_requests(k, w);
+  if (nt > 0) {
+    if (w.ta.nreq > 0) {
+      for (int t = 0; t < c.n_tas; t++) tc_copy_plane(c, t, w.ta.plane, slot);
+      for (int i = 0; i < nt; i++) tc_row_apply(c, trow[i], false, 3, slot);   // SimulateWorkloadUsageRemoval
+    }
+    tc_find(k, w, slot, false, 3);
+  } else {
+    tc_find(k, w, slot, true, w.ta.plane);
+  }
+  if (w.ta.nreq > 0) tc_keep_result(k, w, slot);
+}
+
+// the head's TopologyAssignments for processEntry and the host
+KQ_NOINLINE void tc_publish(const K& k, Wave& w, int slot) {
+  const TCyc& c = *k.tc;
+  const int32_t* kl = c.d_leaf + (size_t)slot * 2 * c.d_cap; const int32_t* kc = c.d_count + (size_t)slot * 2 * c.d_cap;
+  int total = 0;
+  for (int p = 0; p < w.nps && p < TC_P; p++) if ((w.ta.has_mask >> p) & 1) total += w.ta.n[p];
+  int base = 0;
+  if (lane_id() == 0) {
+    base = total > 0 ? atomic_add_i32(c.pool_used, total) : 0;
+    if (base + total > c.pool_cap) { if (*k.O.error == 0) *k.O.error = KQ_ECAPACITY; base = -1; }
+    w.counts[0] = base;
+  }
+  wsync();
+  base = w.counts[0];
+  wsync();
+  int at = base;
+  for (int p = 0; p < w.nps && p < TC_P; p++) {
+    const int g = w.ps_base + p;
+    const bool has = base >= 0 && ((w.ta.has_mask >> p) & 1);
+    if (lane_id() == 0) { c.h_tas[g] = has ? w.ta.t : -1; c.h_pos[g] = has ? at : 0; c.h_n[g] = has ? w.ta.n[p] : 0; }
+    if (has) {
+      for (int j = lane_id(); j < w.ta.n[p]; j += WAVE) { c.pool_leaf[at + j] = kl[w.ta.pos[p] + j]; c.pool_count[at + j] = kc[w.ta.pos[p] + j]; }
+      at += w.ta.n[p];
+    }
+  }
+  wsync();
+}
+
+// ---- processEntry ------------------------------------------------------------------------------------------------------------------------
+// Usage.TAS of entry e (Assignment.ComputeTASNetUsage flavorassigner.go:106-155, pending workloads) against / onto plane `which`:
+// every (podset, domain) on its own (clusterqueue_snapshot.go:136-149)
+KQ_DEV bool tc_entry_fits(const K& k, const Wave& w, int which) {
+  const TCyc& c = *k.tc;
+  bool bad = false;
+  for (int p = 0; p < w.nps; p++) {
+    const int g = w.ps_base + p, t = c.h_tas[g];
+    if (t < 0) continue;
+    const TTopo& T = c.tk[t].T;
+    const int64_t* pl = tc_plane(c, t, which, 0);
+    for (int j = lane_id(); j < c.h_n[g]; j += WAVE) {
+      const int32_t cnt = c.pool_count[c.h_pos[g] + j];
+      if (cnt > 0 && !tc_fits_dom(T, pl, c.pool_leaf[c.h_pos[g] + j], cnt, c.ps_req + (size_t)g * c.R)) bad = true;
+    }
+  }
+  return wballot(bad) == 0;
+}
+KQ_DEV void tc_entry_add(const K& k, const Wave& w) {  // updateTASUsage :267 on the work plane and on the one without the preempted rows
+  const TCyc& c = *k.tc;
+  for (int p = 0; p < w.nps; p++) {
+    const int g = w.ps_base + p, t = c.h_tas[g];
+    if (t < 0) continue;
+    const TTopo& T = c.tk[t].T;
+    for (int j = lane_id(); j < c.h_n[g]; j += WAVE) {
+      const int64_t cnt = c.pool_count[c.h_pos[g] + j];
+      const int leaf = c.pool_leaf[c.h_pos[g] + j];
+      if (cnt <= 0) continue;
+      for (int r = 0; r < T.R; r++) {
+        const int64_t q = c.ps_req[(size_t)g * c.R + r];
+        const int64_t v = (q > 0 ? q : 0) * cnt + (r == T.pods ? cnt : 0);
+        if (!v) continue;
+        atomic_add_i64((long long*)&c.work[t][(size_t)leaf * T.R + r], (long long)v);
+        atomic_add_i64((long long*)&c.np[t][(size_t)leaf * T.R + r], (long long)v);
+      }
+    }
+    wsync();
+  }
+}
+// scheduler.fits :771-777 -> ClusterQueueSnapshot.Fits :136-150: 0 = fits, 1 = no quota, 2 = no TAS capacity
+KQ_DEV int tc_fits_check(const K& k, Wave& w, const int32_t* trows, int nt, bool quota_usage, int tree) {
+  const TCyc& c = *k.tc;
+  if (!entry_fits(k, w, trows, nt, quota_usage, tree)) return 1;
+  bool any = false;
+  for (int p = 0; p < w.nps; p++) if (c.h_tas[w.ps_base + p] >= 0 && c.h_n[w.ps_base + p] > 0) any = true;
+  if (!any) return 0;
+  for (int i = 0; i < nt; i++) if (!k.preempted[trows[i]]) tc_row_apply(c, trows[i], false, 2, 0);
+  const bool ok = tc_entry_fits(k, w, 2);
+  for (int i = nt - 1; i >= 0; i--) if (!k.preempted[trows[i]]) tc_row_apply(c, trows[i], true, 2, 0);
+  return ok ? 0 : 2;
+}
+
+// the per-tree state of processEntry (Wave::np_broken, n_pre, broken) while ONE wave walks the entries of every tree in entry order:
+// a TAS flavor's leaves are shared by ClusterQueues of different root cohorts (snapshot.go:260), so the trees cannot run side by side
+KQ_DEV void tc_tree_switch(const K& k, Wave& w, int from, int to) {
+  int32_t* st = k.tc->tree_state;
+  if (lane_id() == 0) {
+    if (from >= 0) {
+      int32_t* a = st + (size_t)from * 12;
+      a[0] = w.np_broken; a[1] = w.n_pre;
+      for (int i = 0; i < 4; i++) { a[2 + 2 * i] = (int32_t)(w.broken[i] & 0xffffffffu); a[3 + 2 * i] = (int32_t)(w.broken[i] >> 32); }
+    }
+    const int32_t* b = st + (size_t)to * 12;
+    w.np_broken = b[0]; w.n_pre = b[1];
+    for (int i = 0; i < 4; i++) w.broken[i] = (uint64_t)(uint32_t)b[2 + 2 * i] | ((uint64_t)(uint32_t)b[3 + 2 * i] << 32);
+    w.pc_on = 0;
+    w.pc_ncq = k.S.tree_cq_off[to + 1] - k.S.tree_cq_off[to];
+    w.pc_ncoh = (k.S.tree_node_off[to + 1] - k.S.tree_node_off[to]) - w.pc_ncq;
+    w.pc_region_bytes = 0;
+  }
+  wsync();
+}
+
+// scheduler.go:392-523 for entry e at iterator position pos; the generic path of process_entry with the TAS side of
+// updateAssignmentIfNeeded (:707-769), Fits and AddUsage
+KQ_NOINLINE void process_entry_tas(const K& k, Wave& w, int e, int pos, int slot, int tree) {
+  const DSnap& S = k.S; const DOut& O = k.O; const TCyc& c = *k.tc;
+  const int lane = lane_id();
+  load_head(k, w, e);
+  auto load_nomination = [&]() {
+    if (lane == 0) {
+      w.nuse = O.use_n[e];
+      for (int u = 0; u < w.nuse; u++) { w.use_fr[u] = O.use_fr[(size_t)e * KQ_MAXU + u]; w.use_qty[u] = O.use_qty[(size_t)e * KQ_MAXU + u]; }
+      w.borrowing = O.borrowing[e];
+    }
+    wsync();
+  };
+  load_nomination();
+  if (lane == 0) {
+    w.rep_mode = O.nominated_mode[e];
+    O.order[e] = pos;
+    for (int i = 1; i < w.plen; i++) w.path_coh[i] = S.node_local[w.path[i]] - w.pc_ncq;
+  }
+  wsync();
+  int nt = O.tgt_n[e];
+  const bool quota_usage = !(w.hflags & KQ_HEAD_HAS_QUOTA_RESERVATION);
+  if (w.rep_mode != M_NOFIT) cert_unverifiable(k, tree);
+  const int32_t* trows = O.pool_row + O.tgt_pos[e];
+  auto has_any = [&]() { bool a = false; for (int t = 0; t < nt; t++) if (k.preempted[trows[t]]) a = true; return a; };
+  int fc = tc_fits_check(k, w, trows, nt, quota_usage, tree);
+  int mode = w.rep_mode;
+  const bool overlap = has_any() && gate(k, KQ_GATE_RECOMPUTE_ON_OVERLAP);
+  const bool tas_recompute = fc == 2 && !(c.flags & KQ_CT_NO_RECOMPUTE);
+  if (overlap || tas_recompute) {
+    if (overlap && np_exact_mode(w)) np_rebuild(k, w, tree, false);
+    if (!overlap && lane == 0 && c.stats) atomic_add_i64(c.stats + 1, 1);
+    if (lane == 0) { w.has_last = 0; w.ta.plane = overlap ? 2 : 1; }
+    for (int i = lane; i < w.nps * S.nR; i += WAVE) k.X.nom[(size_t)slot * KQ_MAXPS * S.nR + i] = O.flavor[(size_t)w.ps_base * S.nR + i];
+    wsync();
+    // overlap: SimulateWorkloadRemoval(victimsOfOtherPreemptions) = the planes without the preempted rows; TAS only: the snapshot as it is
+    const int64_t* plane = overlap ? k.usage_np : k.usage_work;
+    const uint8_t* removed = overlap ? k.preempted : nullptr;
+    Search s = get_assignments(k, w, slot, plane, removed, true);
+    publish_assignment(k, w, s, e);
+    trows = O.pool_row + O.tgt_pos[e];
+    nt = O.tgt_n[e];
+    mode = w.rep_mode;
+    if (overlap && mode == M_FIT) {  // SetRepresentativeMode(DeferredFit) flavorassigner.go:109-114
+      mode = M_DEFERRED;
+      for (int i = lane; i < w.nps * S.nR; i += WAVE) {
+        const size_t o = (size_t)w.ps_base * S.nR + i;
+        if (O.flavor[o] >= 0) O.res_mode[o] = M_DEFERRED;
+      }
+    }
+    wsync();
+    fc = tc_fits_check(k, w, trows, nt, quota_usage, tree);
+  }
+  const bool fits_ok = fc == 0;
+  int status = KQ_ST_NOT_NOMINATED, action = KQ_ACT_NONE, rq = KQ_RQ_GENERIC, skip = KQ_SKIP_NONE;
+  bool done = false;
+  if (mode == M_NOFIT) { rq = KQ_RQ_NOFIT; done = true; }
+  if (!done && mode == M_PREEMPT && nt == 0) {
+    rq = KQ_RQ_PREEMPTION_NO_CANDIDATES;
+    const bool can_always_reclaim = KQ_POL_RECLAIM(w.pol) == KQ_POLICY_ANY;
+    if (!can_always_reclaim || (gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS) && (w.hflags & KQ_HEAD_IS_PREEMPTOR))) {
+      if (quota_usage) {
+        if (lane == 0)
+          for (int u = 0; u < w.nuse; u++) {
+            const int fr = w.use_fr[u];
+            w.s_qty[u] = reserve_amount(w.use_qty[u], S.nominal[ix(S, w.cq, fr)], S.bl[ix(S, w.cq, fr)], k.usage_work[ix(S, w.cq, fr)], w.borrowing);
+            if (w.s_qty[u] < 0) mark_broken(w, fr);
+          }
+        wsync();
+        entry_add_usage(k, w, w.s_qty);
+      }
+      tc_entry_add(k, w);   // resourcesToReserve -> netUsage :785-794 carries Usage.TAS
+    }
+    done = true;
+  }
+  if (!done && mode == M_DEFERRED) {
+    rq = KQ_RQ_PENDING_PREEMPTION;
+    if (quota_usage) entry_add_usage(k, w, w.use_qty);
+    tc_entry_add(k, w);
+    done = true;
+  }
+  if (!done && has_any()) { status = KQ_ST_SKIPPED; skip = KQ_SKIP_OVERLAP; done = true; }
+  if (!done && !fits_ok) { status = KQ_ST_SKIPPED; skip = KQ_SKIP_NO_LONGER_FITS; done = true; }
+  if (!done) {
+    // preemptedWorkloads.Insert(targets): the rows leave the np planes (quota and leaf usage) for the rest of the cycle
+    int fresh = 0;
+    for (int base = 0; base < nt; base += WAVE) {
+      const int t = base + lane;
+      bool isnew = false;
+      if (t < nt) {
+        const int row = trows[t];
+        if (!k.preempted[row]) {
+          isnew = true;
+          k.preempted[row] = 4;   // new in this pass (np_apply_targets skips nothing below: restricted = false)
+          atomic_add_i32(&k.cq_rm_bytes[S.adm_cq[row]], 32 + 12 * (S.adm_use_off[row + 1] - S.adm_use_off[row]));
+        } else if (k.preempted[row] == 1) k.preempted[row] = 3;
+      }
+      fresh += popc64(wballot(isnew));
+    }
+    if (lane == 0) w.n_pre += fresh;
+    wsync();
+    for (int t = 0; t < nt; t++) if (k.preempted[trows[t]] == 4) tc_row_apply(c, trows[t], false, 2, 0);
+    for (int t = lane; t < nt; t += WAVE) if (k.preempted[trows[t]] == 4) k.preempted[trows[t]] = 1;
+    wsync();
+    np_apply_targets(k, w, trows, nt, false, false, tree);
+    for (int t = lane; t < nt; t += WAVE) if (k.preempted[trows[t]] == 3) k.preempted[trows[t]] = 1;
+    wsync();
+    if (quota_usage) entry_add_usage(k, w, w.use_qty);
+    tc_entry_add(k, w);
+    if (mode == M_PREEMPT) { action = KQ_ACT_PREEMPT; rq = KQ_RQ_PENDING_PREEMPTION; }
+    else { status = KQ_ST_ASSUMED; action = KQ_ACT_ADMIT; }
+  }
+  write_entry_result(k, w, e, status, action, rq, skip, mode);
+  if (lane == 0) atomic_add_i64(O.stat_bytes, (long long)w.bytes);
+  wsync();
+}
+
+// k_process_tas: one wave walks every entry in iterator order
+KQ_DEV void process_all_tas(const K& k, Wave& w, int slot) {
+  const int n = hn(k.H);
+  if (lane_id() == 0) {
+    w.pc_on = 0; w.pc_lds = nullptr; w.np_broken = 0; w.n_pre = 0; w.broken[0] = w.broken[1] = w.broken[2] = w.broken[3] = 0;
+    w.cs_lds = nullptr; w.cs_lds_bytes = 0; w.help_on = 0; w.mono_break = 0; w.ta.plane = 1; w.ta.srch = 0;
+  }
+  wsync();
+  int cur = -1;
+  for (int i = 0; i < n; i++) {
+    const int e = k.order_idx[i];
+    const int tree = k.S.tree_of[k.H.cq[e]];
+    if (tree != cur) { tc_tree_switch(k, w, cur, tree); cur = tree; }
+    process_entry_tas(k, w, e, i, slot, tree);
+  }
+}
+
+// planes at the start of a cycle: base = tas_usage + the admitted rows' usage (tas_flavor.go: the cache adds workload.TASUsage() of every
+// admitted workload when it builds the flavor snapshot); one thread per domain entry of the CSR
+KQ_DEV void tc_base_cell(const TCyc& c, int e) {
+  const int t = c.adm_tas[e];
+  const TTopo& T = c.tk[t].T;
+  const int64_t cnt = c.adm_count[e];
+  for (int r = 0; r < T.R; r++) {
+    const int64_t q = c.adm_req[(size_t)e * T.R + r];
+    const int64_t v = (q > 0 ? q : 0) * cnt + (r == T.pods ? cnt : 0);
+    if (v) atomic_add_i64((long long*)&T.tas_usage[(size_t)c.adm_leaf[e] * T.R + r], (long long)v);
+  }
+}
+
+#endif  // KQ_TAS_CYCLE
+
+}  // namespace kq

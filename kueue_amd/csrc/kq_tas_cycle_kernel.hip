@@ -1,0 +1,50 @@
+// kq_tas_cycle_kernel.hip — the kernels of kq_cycle_run_tas (include/kq_cycle_tas.h): Topology-Aware Scheduling INSIDE the scheduling
+// cycle. The cycle's device code (kq_device.hpp) is compiled here a second time with the TAS hooks switched on (KQ_TAS_CYCLE,
+// kq_tas_cycle.hpp), so that the kernels of the ordinary cycle (kq_engine.hip) carry none of it.
+//   k_tas_base      1 thread per TopologyDomainRequests entry of the admitted rows: base leaf usage = tas_usage + admitted usage
+//   k_nominate_tas  1 wave per head, grid-stride (as k_nominate): flavor assignment, the placement (FindTopologyAssignmentsForFlavor,
+//                   t_workload in-wave: lanes = leaves / domains), GetTargets with the TAS-aware workloadFits, partial admission
+//   k_process_tas   1 wave for the whole cycle: entries of every root cohort in iterator order (a TAS flavor's leaves are shared by
+//                   ClusterQueues of different root cohorts, snapshot.go:260), recomputation on overlap / on lost TAS capacity
+#define KQ_TAS_CYCLE 1
+#define KQ_NO_FAIR 1   // kq_cycle_run_tas refuses fair-sharing cycles: their victim searches stay out of these kernels
+#include <hip/hip_runtime.h>
+
+#include "kq_device.hpp"
+#include "kq_tas_cycle.hpp"
+
+using namespace kq;
+
+__global__ __launch_bounds__(256) void k_tas_base(const TCyc* __restrict__ c, int n) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < n) tc_base_cell(*c, e);
+}
+__global__ __launch_bounds__(64) void k_nominate_tas(const K* __restrict__ kp, int slots) {
+  const K& k = *kp;
+  __shared__ Wave w;
+  if (threadIdx.x == 0) { w.cs_lds = nullptr; w.cs_lds_bytes = 0; w.help_on = 0; w.ta.plane = 0; w.ta.srch = 0; }
+  __syncthreads();
+  const int slot = blockIdx.x;
+  for (int h = slot, n = hn(k.H); h < n; h += slots) nominate_head(k, w, h, slot);
+}
+__global__ __launch_bounds__(64) void k_process_tas(const K* __restrict__ kp) {
+  __shared__ Wave w;
+  process_all_tas(*kp, w, 0);
+}
+
+namespace kq {
+hipError_t launch_tas_base_k(const TCyc* c, int n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_tas_base, dim3((n + 255) / 256), dim3(256), 0, stream, c, n);
+  return hipGetLastError();
+}
+hipError_t launch_nominate_tas_k(const K* d, int slots, hipStream_t stream) {
+  if (slots <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_nominate_tas, dim3(slots), dim3(64), 0, stream, d, slots);
+  return hipGetLastError();
+}
+hipError_t launch_process_tas_k(const K* d, hipStream_t stream) {
+  hipLaunchKernelGGL(k_process_tas, dim3(1), dim3(64), 0, stream, d);
+  return hipGetLastError();
+}
+}  // namespace kq

@@ -66,6 +66,20 @@ class Engine:
         d.kernel_ms, d.bytes = ms.value, by.value
         return d
 
+    def run_tas(self, heads: Heads, ct, tgt_cap: Optional[int] = None, rsn_cap: int = 0, dom_cap: Optional[int] = None):
+        """kq_cycle_run_tas: one scheduling cycle with Topology-Aware Scheduling inside it (include/kq_cycle_tas.h; ct =
+        kueue_amd.tas_cycle.CycleTAS) -> (Decisions, CycleTASOut); Decisions.tas_stats = {finds, recomputes, unsupported}."""
+        from .tas_cycle import CycleTASOut
+        d = Decisions(heads, tgt_cap=tgt_cap, rsn_cap=rsn_cap)
+        out = CycleTASOut(ct, dom_cap=dom_cap)
+        ts = np.zeros(3, np.int64)
+        self._check(self._lib.kq_cycle_run_tas(self._h, C.byref(heads.struct()), C.byref(ct.struct()), C.byref(d.struct()), C.byref(out.struct()), F.ptr(ts)))
+        ms, by = C.c_double(), C.c_int64()
+        self._lib.kq_last_cycle_stats(self._h, C.byref(ms), C.byref(by))
+        d.kernel_ms, d.bytes = ms.value, by.value
+        d.tas_stats = dict(finds=int(ts[0]), recomputes=int(ts[1]), unsupported=bool(ts[2]))
+        return d, out
+
     def heads_put(self, heads: Heads, batch: int):
         """kq_heads_put: make a batch of heads resident in HBM under a small caller-chosen id."""
         self._check(self._lib.kq_heads_put(self._h, C.byref(heads.struct()), batch))

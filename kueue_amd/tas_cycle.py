@@ -1,5 +1,5 @@
 """Host side of Topology-Aware Scheduling INSIDE the scheduling cycle: what the Go snapshot / queue manager would flatten next to
-kq_snapshot and kq_heads (boundary: oracle/kq_cycle_tas.h, restated on the CPU by the oracle ahead of the engine).
+kq_snapshot and kq_heads (boundary: include/kq_cycle_tas.h, restated on the CPU by the oracle ahead of the engine).
 
 What stays on the host here stays on the host in the reference:
   * the TASFlavorSnapshot of every TAS ResourceFlavor (Spec.TopologyName set and the topology cached): nodes matching the flavor's
@@ -21,6 +21,7 @@ from . import _ffi as F
 from .api import Heads, Snapshot, amount_from_quantity
 from .tas import KQ_TAS_UNCONSTRAINED, Node, TASPodSetRequests, Topology, TopologyRequest, kq_tas_topology
 
+CYCLE_TAS_ABI_SYMBOLS = ["kq_cycle_run_tas"]   # include/kq_cycle_tas.h
 PS_TAS_EXPLICIT = 1
 CT_NO_RECOMPUTE = 1
 

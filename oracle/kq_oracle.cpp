@@ -26,7 +26,7 @@
 #include <utility>
 #include <vector>
 
-#include "kq_cycle_tas.h"
+#include "../include/kq_cycle_tas.h"
 #include "kq_tas_oracle.hpp"
 
 namespace kqo {
@@ -1824,7 +1824,7 @@ int kqo_cycle_run(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h,
   return rc;
 }
 
-// One scheduling cycle with Topology-Aware Scheduling inside it (oracle/kq_cycle_tas.h). tstats[0..2] (optional): TAS placements
+// One scheduling cycle with Topology-Aware Scheduling inside it (include/kq_cycle_tas.h). tstats[0..2] (optional): TAS placements
 // computed, TAS recomputations inside processEntry, 1 when the cycle met a case outside the restated path.
 int kqo_cycle_run_tas(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, const kq_cycle_tas* t, kq_decisions* out, kq_cycle_tas_out* tout,
                       int64_t* tstats) {

@@ -238,7 +238,7 @@ def tas_find(topo, rq, dom_cap=None):
 
 
 def cycle_run_tas(cfg: F.kq_config, snap: Snapshot, heads: Heads, ct, tgt_cap=None):
-    """One scheduling cycle with Topology-Aware Scheduling inside it (oracle/kq_cycle_tas.h; ct = kueue_amd.tas_cycle.CycleTAS).
+    """One scheduling cycle with Topology-Aware Scheduling inside it (include/kq_cycle_tas.h; ct = kueue_amd.tas_cycle.CycleTAS).
     -> (Decisions, CycleTASOut); Decisions.tas_stats = {finds, recomputes, unsupported}."""
     from kueue_amd.tas_cycle import CycleTASOut
     d = Decisions(heads, tgt_cap=tgt_cap)

@@ -6,6 +6,7 @@
 // kqe_* symbols, lives under tests/, and is never loaded by the kueue_amd package: the product
 // path has no CPU implementation and fails loudly without the HIP library.
 #define KQ_HOST_EMU 1
+#define KQ_TAS_CYCLE 1   // the TAS hooks of the cycle are always compiled in here (inert while K::tc is null)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -176,6 +177,12 @@ struct EmuBackend {
     rot++;
     last_k = k;
   }
+  // kq_cycle_run_tas (kq_tas_cycle.hpp)
+  void launch_tas_base(const TCyc* c, int n) { for (int e = 0; e < n; e++) tc_base_cell(*c, e); }
+  void launch_nominate_tas(const K& k, int slots) {
+    for (int slot = 0; slot < slots; slot++) { Wave w{}; for (int h = slot; h < hn(k.H); h += slots) nominate_head(k, w, h, slot); }
+  }
+  void launch_process_tas(const K& k) { Wave w{}; process_all_tas(k, w, 0); last_k = k; }
   void launch_process_fair(const K& k, int n_tree, size_t, size_t, int32_t* rank) {
     std::vector<int64_t> lds(160 * 1024 / 8);
     // (a recomputation's victim search borrows the region: whole state in "LDS" / almost none of it / no region at all)
@@ -241,6 +248,7 @@ void kqe_cs_check(int on) { kq::g_cs_check = on; }
 void kqe_disable_scan_search(void* e, int on) { ((EmuEngine*)e)->cs_disable = on != 0; ((EmuEngine*)e)->fs_disable = on != 0; }
 void kqe_fs_check(int on) { kq::g_fs_check = on; }
 void kqe_force_exact_drs(void* e, int on) { ((EmuEngine*)e)->force_exact_drs = on != 0; }
+int kqe_cycle_run_tas(void* e, const kq_heads* h, const kq_cycle_tas* t, kq_decisions* out, kq_cycle_tas_out* tout, int64_t* stats) { return ((EmuEngine*)e)->cycle_run_tas(h, t, out, tout, stats); }
 int kqe_cycle_run(void* e, const kq_heads* h, kq_decisions* out) { return ((EmuEngine*)e)->cycle_run(h, out); }
 int kqe_cycle_shard_words(void* e, const kq_heads* h, const kq_decisions* out, int32_t world, int64_t* words) { return ((EmuEngine*)e)->cycle_shard_words(h, out, world, words); }
 int kqe_cycle_nominate_shard(void* e, const kq_heads* h, const uint8_t* mine, int32_t world, int32_t rank, void* x, kq_decisions* out) { return ((EmuEngine*)e)->cycle_nominate_shard(h, mine, world, rank, x, out); }
@@ -284,7 +292,8 @@ int kqe_pending_apply_fabricated(void* ep, const uint8_t* status, const uint8_t*
 int kqe_cycle_certificate(void* e, int64_t* delta, int64_t* margin, int32_t* flags) { return ((EmuEngine*)e)->cycle_certificate(delta, margin, flags); }
 int kqe_snapshot_usage_add(void* e, const int64_t* delta, int32_t sign) { return ((EmuEngine*)e)->snapshot_usage_add(delta, sign); }
 // LDS budget of k_process (kq_engine.hip launch_process): static Wave + record buffers
-void kqe_lds_sizes(int64_t* out) { out[0] = (int64_t)sizeof(kq::Wave); out[1] = (int64_t)(sizeof(kq::PRec) * kq::CH * kq::NBUF); }
+// (the emulation's Wave also carries the TAS view of kq_cycle_run_tas's kernels, which k_process does not have)
+void kqe_lds_sizes(int64_t* out) { out[0] = (int64_t)(sizeof(kq::Wave) - sizeof(kq::TAW)); out[1] = (int64_t)(sizeof(kq::PRec) * kq::CH * kq::NBUF); }
 int kqe_read_usage(void* e, int64_t* out) { return ((EmuEngine*)e)->read_usage_work(out); }
 int kqe_last_bytes(void* e, int64_t* out) { *out = ((EmuEngine*)e)->last_bytes; return KQ_OK; }
 int kqe_phase_bytes(void* e, int64_t* out) { out[0] = ((EmuEngine*)e)->last_phase_bytes[0]; out[1] = ((EmuEngine*)e)->last_phase_bytes[1]; return KQ_OK; }

@@ -258,6 +258,29 @@ class EmuEngine:
         return d
 
 
+def _run_tas(self, heads, ct, tgt_cap=None, want_usage=False, dom_cap=None):
+    """kqe_cycle_run_tas: the cycle with TAS inside it on the emulated engine (include/kq_cycle_tas.h)."""
+    from kueue_amd.tas_cycle import CycleTASOut
+    d = Decisions(heads, tgt_cap=tgt_cap)
+    out = CycleTASOut(ct, dom_cap=dom_cap)
+    ts = np.zeros(3, np.int64)
+    rc = lib().kqe_cycle_run_tas(self.h, C.byref(heads.struct()), C.byref(ct.struct()), C.byref(d.struct()), C.byref(out.struct()), F.ptr(ts))
+    d.rc = rc
+    d.error = lib().kqe_last_error(self.h).decode()
+    if want_usage and rc == 0:
+        u = np.zeros(self.snap.N * self.snap.n_fr, np.int64)
+        lib().kqe_read_usage(self.h, F.ptr(u))
+        d.usage_after = u
+    b = C.c_int64()
+    lib().kqe_last_bytes(self.h, C.byref(b))
+    d.bytes = b.value
+    d.tas_stats = dict(finds=int(ts[0]), recomputes=int(ts[1]), unsupported=bool(ts[2]))
+    return d, out
+
+
+EmuEngine.run_tas = _run_tas
+
+
 class EmuTas:
     """1-lane emulation of the TAS device code (kq_tas_device.hpp), same interface as kueue_amd.tas.TASEngine."""
 

@@ -25,12 +25,17 @@ def test_tas_header_and_ffi_list_agree():
     assert declared_symbols("kq_tas.h") == sorted(tas.TAS_ABI_SYMBOLS)
 
 
+def test_cycle_tas_header_and_ffi_list_agree():
+    from kueue_amd import tas_cycle
+    assert declared_symbols("kq_cycle_tas.h") == sorted(tas_cycle.CYCLE_TAS_ABI_SYMBOLS)
+
+
 def test_library_exports_every_tas_symbol():
     if not os.path.exists(F.ENGINE_LIB):
         import __graft_entry__ as g
         g.build()
     lib = ctypes.CDLL(F.ENGINE_LIB)
-    for sym in declared_symbols("kq_tas.h"):
+    for sym in declared_symbols("kq_tas.h") + declared_symbols("kq_cycle_tas.h"):
         assert hasattr(lib, sym), sym
 
 

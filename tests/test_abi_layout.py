@@ -1,5 +1,5 @@
 """The ctypes mirrors of the C ABI structs against the headers themselves: size of every struct and offset of every field, taken from
-a C program compiled against include/*.h (and oracle/kq_cycle_tas.h for the cycle's TAS boundary). A field added to a header and not
+a C program compiled against include/*.h (and include/kq_cycle_tas.h for the cycle's TAS boundary). A field added to a header and not
 to its mirror makes the library read past the end of the Python-built struct — this is the check for that."""
 import ctypes as C
 import os
@@ -45,7 +45,7 @@ def test_ctypes_mirrors_match_the_headers():
 def test_every_header_field_has_a_mirror_field():
     """Field COUNT per struct, read from the header text (a mirror that merely stops early would pass the offset check)."""
     text = ""
-    for h in ("include/kq_engine.h", "include/kq_tas.h", "oracle/kq_cycle_tas.h"):
+    for h in ("include/kq_engine.h", "include/kq_tas.h", "include/kq_cycle_tas.h"):
         text += open(os.path.join(ROOT, h)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     for name, cls in STRUCTS.items():

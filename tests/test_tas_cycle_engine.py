@@ -1,0 +1,127 @@
+"""kq_cycle_run_tas — Topology-Aware Scheduling INSIDE the engine's scheduling cycle (include/kq_cycle_tas.h, kq_tas_cycle.hpp).
+ * the whole-cycle tables of pkg/scheduler/scheduler_tas_test.go (TestScheduleForTAS :58, TestScheduleForTASPreemption :4121,
+   TestScheduleForTASCohorts :5950; tests/golden/schedule_tas.yaml) through the device code: the same checks against the Go expectations
+   as tests/test_oracle_schedule_tas.py, and every decision array, TopologyAssignment and the leaf usage after the cycle equal to the oracle's;
+ * random TAS populations (tests/tasgen_cycle.py): engine == oracle on everything, with and without preemption, partial admission,
+   implied TAS (TAS-only queues), slices, podset groups;
+ * without TAS flavors the entry point is the ordinary cycle.
+CPU suite: the 1-lane emulation of the same device code (tests/emu). GPU suite (-m gpu): the HIP engine through the C ABI."""
+import numpy as np
+import pytest
+
+from kueue_amd.tas_cycle import CycleTAS, load_tas_case
+from tests.conftest import load_golden
+from tests.randgen import random_case
+from tests.tasgen_cycle import random_tas_cycle_case
+from tests.test_oracle_schedule_tas import check_case
+
+CASES = load_golden("schedule_tas.yaml")["cases"]
+
+
+def _emu(cfg):
+    from tests.emu import kqe
+    return kqe.EmuEngine(cfg)
+
+
+def _hip(cfg):
+    from kueue_amd.engine import Engine
+    return Engine(cfg)
+
+
+class _AsOracle:
+    """check_case() drives an object with the oracle's interface: derive + cycle_run_tas."""
+
+    def __init__(self, oracle, make):
+        self.oracle, self.make = oracle, make
+
+    def derive(self, snap):
+        self.oracle.derive(snap)
+
+    def cycle_run_tas(self, cfg, snap, heads, ct, tgt_cap=None):
+        eng = self.make(cfg)
+        eng.put(snap)
+        d, out = eng.run_tas(heads, ct, tgt_cap=tgt_cap)
+        assert getattr(d, "rc", 0) == 0, (getattr(d, "rc", 0), getattr(d, "error", ""))
+        eng.close()
+        return d, out
+
+
+def _same(oracle, make, cfg, snap, heads, ct, tgt_cap=None):
+    want, wout = oracle.cycle_run_tas(cfg, snap, heads, ct, tgt_cap=tgt_cap)
+    eng = make(cfg)
+    eng.put(snap)
+    got, gout = eng.run_tas(heads, ct, tgt_cap=tgt_cap)
+    eng.close()
+    if want.tas_stats["unsupported"]:
+        assert getattr(got, "rc", 0) != 0 or got.tas_stats["unsupported"], "two TAS flavors in one workload must be refused"
+        return None
+    assert getattr(got, "rc", 0) == 0, (getattr(got, "rc", 0), getattr(got, "error", ""))
+    bad = want.equal(got)
+    assert not bad, (bad, {k: (want.a[k][:12], got.a[k][:12]) for k in bad})
+    n_ps = heads.n_ps
+    assert np.array_equal(wout.a["ps_tas"][:n_ps], gout.a["ps_tas"][:n_ps]), (wout.a["ps_tas"][:n_ps], gout.a["ps_tas"][:n_ps])
+    assert np.array_equal(wout.a["dom_off"], gout.a["dom_off"]), (wout.a["dom_off"], gout.a["dom_off"])
+    m = int(wout.a["dom_off"][n_ps])
+    assert np.array_equal(wout.a["dom_leaf"][:m], gout.a["dom_leaf"][:m]) and np.array_equal(wout.a["dom_count"][:m], gout.a["dom_count"][:m])
+    assert np.array_equal(wout.a["tas_usage_after"], gout.a["tas_usage_after"])
+    assert want.tas_stats["recomputes"] == got.tas_stats["recomputes"]
+    return want
+
+
+def _golden(oracle, make, case):
+    check_case(_AsOracle(oracle, make), case)                       # the Go expectations, through the device code
+    cfg, snap, heads, ct = load_tas_case(case)
+    oracle.derive(snap)
+    _same(oracle, make, cfg, snap, heads, ct, tgt_cap=max(16, snap.n_adm))  # and everything else against the oracle
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"][:80])
+def test_schedule_tas_emulated(oracle, case):
+    _golden(oracle, _emu, case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"][:80])
+def test_schedule_tas_gpu(oracle, case):
+    _golden(oracle, _hip, case)
+
+
+def _random(oracle, make, seed):
+    cfg, snap, heads, ct, _ = random_tas_cycle_case(seed, fair=False, tight=seed % 2 == 0, preemption=seed % 3 != 0)
+    oracle.derive(snap)
+    return _same(oracle, make, cfg, snap, heads, ct, tgt_cap=max(16, snap.n_adm))
+
+
+@pytest.mark.parametrize("seed", range(300))
+def test_random_tas_cycles_emulated(oracle, seed):
+    _random(oracle, _emu, seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", range(6))
+def test_random_tas_cycles_gpu(oracle, block):
+    for seed in range(block * 50, block * 50 + 50):
+        _random(oracle, _hip, seed)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_without_tas_flavors_it_is_the_plain_cycle_emulated(oracle, seed):
+    cfg, snap, heads = random_case(seed, fair=False, tight=seed % 2 == 0)
+    oracle.derive(snap)
+    want = oracle.cycle_run(cfg, snap, heads)
+    eng = _emu(cfg)
+    eng.put(snap)
+    got, out = eng.run_tas(heads, CycleTAS(snap, heads, {}, {}), tgt_cap=want.a["tgt_adm"].size if "tgt_adm" in want.a else None)
+    eng.close()
+    assert got.rc == 0 and not want.equal(got)
+    assert (out.a["ps_tas"][:heads.n_ps] == -1).all()
+
+
+def test_fair_sharing_is_refused(oracle):
+    cfg, snap, heads, ct, _ = random_tas_cycle_case(4, fair=True, tight=False, preemption=False)
+    oracle.derive(snap)
+    eng = _emu(cfg)
+    eng.put(snap)
+    got, _ = eng.run_tas(heads, ct)
+    eng.close()
+    assert got.rc == -4   # KQ_EUNSUPPORTED
