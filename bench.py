@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3-batch", "cfg3-split", "cfg4c-split", "cfg4c", "cfg3f", "cfg4f", "cfg5", "cfg5-split"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3-batch", "cfg3-split", "cfg4c-split", "cfg4c", "cfg3f", "cfg4f", "cfg5", "cfg5-split", "cfg5-cycle"],
                     help="cfg3 = BASELINE.json configs[2] (100k pending, 1k CQ, 16 flavors, 3-level cohorts); "
                          "cfg4c = configs[3] population under classical preemption; cfg4f = configs[3] as quoted "
                          "(fair sharing + preemption); cfg3f = configs[2] population under fair sharing; cfg5 = configs[4] "
@@ -74,6 +74,8 @@ def main():
         return bench_tas(args, torch, dist, world, rank, local_rank)
     if args.workload == "cfg5-split":
         return bench_tas_split(args, torch, dist, world, rank, local_rank)
+    if args.workload == "cfg5-cycle":
+        return bench_tas_cycle(args, torch, dist, world, rank, local_rank)
     if args.workload == "cfg3-batch":
         return bench_batch(args, torch, dist, world, rank, local_rank)
     if args.workload in ("cfg3-split", "cfg4c-split"):
@@ -960,6 +962,119 @@ def bench_tas(args, torch, dist, world, rank, local_rank):
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_tas_cycle(args, torch, dist, world, rank, local_rank):
+    """cfg5-cycle: BASELINE configs[4] as whole scheduling cycles through kq_cycle_run_tas — flavor assignment, the TAS placement inside
+    Assign, the entry-order walk with the TAS side of Fits / AddUsage and the recomputation of entries whose domains an earlier entry took
+    (scheduler.go:707-769). One step = one cycle over one head per ClusterQueue (--tas-cycle ClusterQueues) against the same cycle-start
+    snapshot (open loop: every step takes the next batch of the pending workloads). The call uploads the heads and the TAS side every
+    step, so the wall-clock figure is PCIe-inclusive; kernels are timed with HIP events on the engine's stream. Ranks own independent
+    populations (seed + rank): weak scaling, no collective."""
+    from kueue_amd.api import make_config
+    from kueue_amd.engine import Engine
+    from kueue_amd.tas_population import TAS_SEED, generate_tas_cycle
+    n_cq = args.tas_cycle
+    n_pending = max(n_cq, min(args.tas_batch, n_cq * (args.steps + args.warmup)))
+    snap, topos, batch = generate_tas_cycle(n_cq=n_cq, n_pending=n_pending, seed=TAS_SEED + 1000 * rank)
+    cfg = make_config()
+    from oracle import kqo   # the checker derives the snapshot's subtree quotas host-side, as the Go cache does before Snapshot()
+    kqo.derive(snap)
+    eng = Engine(cfg)
+    eng.put(snap)
+    nb = (n_pending + n_cq - 1) // n_cq
+    batches = [batch(c) for c in range(nb)]
+    topo = topos["tas-flavor"]
+    parity = None
+    if rank == 0 and not args.no_parity_gate:
+        h0, c0 = batches[0]
+        want, wout = kqo.cycle_run_tas(cfg, snap, h0, c0)
+        got, gout = eng.run_tas(h0, c0)
+        bad = want.equal(got)
+        m = int(wout.a["dom_off"][h0.n_ps])
+        same = (not bad and np.array_equal(wout.a["ps_tas"][:h0.n_ps], gout.a["ps_tas"][:h0.n_ps]) and np.array_equal(wout.a["dom_off"], gout.a["dom_off"]) and
+                np.array_equal(wout.a["dom_leaf"][:m], gout.a["dom_leaf"][:m]) and np.array_equal(wout.a["dom_count"][:m], gout.a["dom_count"][:m]) and
+                np.array_equal(wout.a["tas_usage_after"], gout.a["tas_usage_after"]))
+        if not same:
+            raise SystemExit(f"cfg5-cycle: the engine's first cycle differs from the oracle's ({bad})")
+        parity = f"cycle 0: {h0.n} decisions, every TopologyAssignment and the leaf usage after the cycle equal the oracle's"
+    phases = np.zeros(3, np.float64)
+    import ctypes as C
+
+    def step(i):
+        h, c = batches[i % nb]
+        return eng.run_tas(h, c)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ph, st_ms, dec, admitted, finds, recomputes, by = np.zeros(3), [], 0, 0, 0, 0, 0
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        t1 = time.perf_counter()
+        d, _ = step(args.warmup + i)
+        st_ms.append((time.perf_counter() - t1) * 1e3)
+        eng._lib.kq_last_cycle_phases(eng._h, F_ptr(phases), None)
+        ph += phases
+        nh = len(d.a["action"]); dec += nh; admitted += int((d.a["action"] == 1).sum()); finds += d.tas_stats["finds"]; recomputes += d.tas_stats["recomputes"]; by += d.bytes
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    decf = float(dec)
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed, decf], dtype=torch.float64, device="cuda")
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, decf = float(tmax[0]), float(tsum[1])
+    if rank == 0:
+        names = ["k_nominate_tas", "k_order", "k_process_tas"]
+        dom = int(np.argmax(ph))
+        # algorithmic bytes of a placement = phase 1 over every leaf (16 B per resource + 24 B of counts) + the roll-up (24 B per inner domain),
+        # as kq_tas_find accounts it (DESIGN.md section 3, TAS), times the placements the cycle computed; + the quota cycle's own bytes
+        R = len(topo.resources)
+        n_dom = int(topo.arrays['level_off'][-1])
+        per_find = topo.n_leaves * (R * 16 + 24) + (n_dom - topo.n_leaves) * 24 + R * 8
+        abytes = (finds * per_find + by) / args.steps
+        kms = float(ph.sum()) / args.steps
+        achieved = abytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        res = {
+            "metric": "admission-decisions/sec + p99 schedule-cycle ms @ 100k pending, 1k CQ",
+            "value": decf / elapsed, "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"cfg5-cycle: TAS inside the scheduling cycle, {snap.n_cq} ClusterQueues in {snap.n_cohort} cohorts, one TAS flavor of {topo.n_leaves} leaves "
+                                   f"(8 blocks x 8 racks x 64 hosts, {R} resources) shared by all of them + one ordinary flavor, {n_pending} pending workloads, one head per ClusterQueue per cycle",
+                       "decision": "one head through flavor assignment, TAS placement, the entry-order walk (quota + leaf capacity) and its recomputation",
+                       "loop": "open loop: the next batch of heads every step against the same cycle-start snapshot; heads and TAS side uploaded every step",
+                       "sharding": "population per GPU, no collective"},
+            "p50_cycle_ms": float(np.percentile(st_ms, 50)), "p99_cycle_ms": float(np.percentile(st_ms, 99)),
+            "kernel_ms_per_cycle": {n: float(v) / args.steps for n, v in zip(names, ph)},
+            "per_cycle": {"admitted": admitted / args.steps, "placements": finds / args.steps, "tas_recomputations": recomputes / args.steps},
+            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "algorithmic_bytes_per_launch": abytes, "traffic": pmc_traffic("cfg5-cycle", names[dom]),
+                         "note": "all three intervals of the cycle; the placements' bytes are the reference's phase-1 accounting per FindTopologyAssignmentsForFlavor call"},
+            "parity_checked": parity is not None, "parity": parity,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            t1 = time.perf_counter()
+            nd = 0
+            for c in range(nb):
+                h, ctt = batches[c]
+                kqo.cycle_run_tas(cfg, snap, h, ctt)
+                nd += h.n
+                if time.perf_counter() - t1 > args.cpu_seconds:
+                    break
+            dt = time.perf_counter() - t1
+            res["cpu_baseline"] = {"value": nd / dt, "unit": "decisions/s", "cores": 1, "kind": "port",
+                                   "sample": f"the first {nd} heads of the same cycles, C++ restatement of the cycle with TAS (kqo_cycle_run_tas), host nproc={os.cpu_count()}"}
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    eng.close()
     if world > 1:
         dist.destroy_process_group()
 

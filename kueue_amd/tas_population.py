@@ -51,3 +51,44 @@ def generate_tas(n_workloads: int = 50_000, seed: int = TAS_SEED, blocks: int = 
             tr = T.TopologyRequest(unconstrained=True)
         workloads.append([T.TASPodSetRequests("main", int(counts[i]), reqs, tr)])
     return topo, T.Requests(topo, workloads)
+
+
+def generate_tas_cycle(n_cq: int = 1000, n_pending: int = 50_000, seed: int = TAS_SEED, cohorts: int = 10, **topo_kw):
+    """BASELINE configs[4] as whole scheduling cycles ("TAS domain fit + flavor assign"): the cfg 5 topology as ONE TAS flavor that every
+    ClusterQueue lists (its leaves are shared across the root cohorts, snapshot.go:260) next to an ordinary flavor, n_cq ClusterQueues in
+    `cohorts` flat cohorts with nominal quota for a handful of workloads each and borrowing, and n_pending workloads spread round-robin
+    over the ClusterQueues: cycle c schedules the c-th workload of every ClusterQueue (queues.Heads(): one head per ClusterQueue).
+    -> (Snapshot, topologies, batches) with batches[c] = (Heads, CycleTAS) built on demand by `batch(c)`."""
+    from .api import ClusterQueue, Cohort, FlavorQuotas, PodSet, ResourceGroup, ResourceQuota, Snapshot, Workload
+    from .tas_cycle import CycleTAS, PodSetTAS
+    topo, rq = generate_tas(n_workloads=n_pending, seed=seed, **topo_kw)
+    rng = np.random.default_rng(seed + 77)
+    res = ["cpu", "memory", "example.com/gpu"]
+    cqs = []
+    for i in range(n_cq):
+        # room for ~4 average workloads of nominal quota on the TAS flavor; the rest is borrowed from the cohort
+        fq_tas = FlavorQuotas("tas-flavor", {"cpu": ResourceQuota(200_000, None, None), "memory": ResourceQuota(800 << 30, None, None),
+                                             "example.com/gpu": ResourceQuota(16, None, None)})
+        fq_std = FlavorQuotas("zz-standard", {"cpu": ResourceQuota(50_000, None, None), "memory": ResourceQuota(200 << 30, None, None),
+                                              "example.com/gpu": ResourceQuota(0, None, None)})
+        cqs.append(ClusterQueue(f"cq-{i:04d}", cohort=f"cohort-{i % cohorts:02d}", resource_groups=[ResourceGroup([fq_tas, fq_std])]))
+    snap = Snapshot(cqs, [Cohort(f"cohort-{j:02d}") for j in range(cohorts)], [], extra_resources=["pods"])
+    topologies = {"tas-flavor": topo}
+    prio = rng.integers(0, 4, size=n_pending)
+
+    def batch(c: int):
+        wls, pod_tas = [], {}
+        for i in range(n_cq):
+            w = c * n_cq + i
+            if w >= n_pending:
+                break
+            ps = rq.workloads[w][0]
+            reqs = {r: int(q) * ps.count for r, q in ps.single_pod_requests.items()}
+            name = f"ns/wl-{w:05d}"
+            wls.append(Workload(name, f"cq-{i:04d}", priority=int(prio[w]), creation_ts=w, pod_sets=[PodSet("main", count=ps.count, requests=reqs)]))
+            pod_tas[(name, 0)] = PodSetTAS(ps.topology_request, None, dict(ps.single_pod_requests))
+        from .api import Heads
+        heads = Heads(snap, wls, cycle=c + 1)
+        return heads, CycleTAS(snap, heads, topologies, pod_tas)
+
+    return snap, topologies, batch
