@@ -690,6 +690,7 @@ struct TAW {
   int kept_used;
   int plane;                      // which leaf-usage plane "the snapshot" is: 0 cycle start, 1 work, 2 work minus preempted rows
   int srch;                       // a GetTargets walk with TAS requests is in flight: its private plane is live
+  struct TLeafJob* mail;          // k_process_tas: phase 1 of a placement is shared with the workgroup's helper waves through this LDS block
 };
 #define KQ_TAS_WALK(w) ((w).ta.srch != 0)
 #else

@@ -241,7 +241,19 @@ inline void check_usage(const kq_snapshot* s, Prep& p) {
   for (size_t i = 0; i < (size_t)N * nfr && p.fs_plain; i++) if (s->usage[i] < 0 || (s->usage[i] >= LIM && s->usage[i] != U)) p.fs_plain = false;
 }
 
+#ifdef KQ_PREP_TIMES
+}  // namespace kq
+#include <chrono>
+namespace kq {
+static double g_prep_ms[16];
+#define PT(i) do { auto _n = std::chrono::steady_clock::now(); g_prep_ms[i] += std::chrono::duration<double, std::milli>(_n - _pt).count(); _pt = _n; } while (0)
+#define PT0() auto _pt = std::chrono::steady_clock::now()
+#else
+#define PT(i) do {} while (0)
+#define PT0() do {} while (0)
+#endif
 inline int build_prep(const kq_snapshot* s, Prep& p) {
+  PT0();
   p.nq = s->n_cq; p.nc = s->n_cohort; p.N = p.nq + p.nc; p.nF = s->n_flavor; p.nR = s->n_resource;
   p.nfr = p.nF * p.nR; p.n_adm = s->n_adm;
   const int N = p.N, nq = p.nq;
@@ -301,6 +313,7 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
       p.node_height[n] = h;
     }
   }
+  PT(0);
   // admitted rows
   p.adm_cq.assign(p.n_adm, -1);
   for (int c = 0; c < nq; c++) {
@@ -324,6 +337,7 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
         return a < b;
       });
   }
+  PT(1);
   p.tree_rows_asc = p.tree_rows;
   for (int t = 0; t < p.n_tree; t++) std::sort(p.tree_rows_asc.begin() + p.tree_row_off[t], p.tree_rows_asc.begin() + p.tree_row_off[t + 1]);
   p.frb_off.assign((size_t)p.n_tree * p.nfr + 1, 0);
@@ -349,9 +363,11 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
           if (first_use(r, e)) p.frb[fill[(size_t)t * p.nfr + s->adm_use_fr[e]]++] = i - p.tree_row_off[t];
       }
   }
+  PT(2);
   p.rank_pos.assign(p.n_adm, 0);
   for (int t = 0; t < p.n_tree; t++)
     for (int i = p.tree_row_off[t]; i < p.tree_row_off[t + 1]; i++) p.rank_pos[p.tree_rows[i]] = i - p.tree_row_off[t];
+  PT(3);
   // ---- scan-formulated classical search: row records, level orders of the buckets, bucket signatures ----
   {
     p.cs_ok.assign(p.n_tree, 1);
@@ -389,6 +405,7 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
         }
       }
     }
+  PT(4);
     // ---- kq_fs.hpp: candidates in position order, children lists in tree-node order ----
     for (int c = 0; c < nq; c++) if (p.depth[c] + 1 > FS_LV) p.fs_ok[p.tree_of[c]] = 0;
     if (p.nfr > 32767) for (auto& f : p.fs_ok) f = 0;
@@ -440,12 +457,23 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
         for (int i = s->child_cohort_off[kx]; i < s->child_cohort_off[kx + 1] && fill < nn; i++) p.fs_kid[n0 + fill++] = (int16_t)p.node_local[s->child_cohort[i]];
       }
     }
+  PT(5);
     p.frb_sig.assign((size_t)p.n_tree * p.nfr, 0);
     p.cs_max_bucket = 0;
     for (int l = 0; l < CS_LEVELS; l++) p.frl[l].assign(p.frb.size(), CsEnt{0, -1, 0, -1, 0});
     p.frec.assign(p.frb.size(), CsRec{});
     // (M <= 0xfff0 is checked by the search; the depth shares the word with j)
     std::vector<int32_t> anc;  // scratch: ancestor at height l of the row's ClusterQueue
+    std::vector<int32_t> idx, keyv, cnt;
+    std::vector<int32_t> cq_anc((size_t)CS_LEVELS * std::max(nq, 1), -1);  // ancestor of a ClusterQueue at depth l + 1 (level order l), -1 = none
+    for (int l = 0; l < CS_LEVELS; l++)
+      for (int c = 0; c < nq; c++) {
+        int n = c;
+        const int dd = l + 1;
+        if (p.depth[n] < dd) n = -1;
+        else for (int h = p.depth[n]; h > dd; h--) n = s->parent[n];
+        cq_anc[(size_t)l * nq + c] = n;
+      }
     for (int t = 0; t < p.n_tree; t++)
       for (int fr = 0; fr < p.nfr; fr++) {
         const size_t b = (size_t)t * p.nfr + fr;
@@ -460,25 +488,22 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
           p.frec[o + j] = CsRec{a.prio, a.qts, row, p.cq_local[a.cq], a.rowbytes, a.flags};
         }
         for (int l = 0; l < CS_LEVELS; l++) {
-          anc.assign(M, -1);
+          anc.resize(M);
+          for (int j = 0; j < M; j++) anc[j] = cq_anc[(size_t)l * nq + p.adm_cq[p.tree_rows[p.tree_row_off[t] + p.frb[o + j]]]];
+          // order: ancestor node ascending (none last), evicted rows first, then bucket position — a stable counting sort on
+          // (ancestor, not evicted): the keys are node ids, the bucket is in rank order already (this was a comparison sort per
+          // bucket and level and 60 % of kq_snapshot_put's host time at cfg 3)
+          idx.resize(M); keyv.resize(M);
+          if (cnt.size() < 2 * ((size_t)N + 1) + 1) cnt.assign(2 * ((size_t)N + 1) + 1, 0);
           for (int j = 0; j < M; j++) {
             const int row = p.tree_rows[p.tree_row_off[t] + p.frb[o + j]];
-            int n = p.adm_cq[row];
-            const int dd = l + 1;  // level order l holds depth l + 1
-            if (p.depth[n] < dd) n = -1;
-            else for (int h = p.depth[n]; h > dd; h--) n = s->parent[n];
-            anc[j] = n;
+            const int ea = (s->adm_flags[row] & KQ_ADM_EVICTED) ? 0 : 1;
+            keyv[j] = (anc[j] < 0 ? N : anc[j]) * 2 + ea;
+            cnt[keyv[j] + 1]++;
           }
-          std::vector<int32_t> idx(M);
-          for (int j = 0; j < M; j++) idx[j] = j;
-          std::stable_sort(idx.begin(), idx.end(), [&](int a, int bb) {
-            const int na = anc[a] < 0 ? INT32_MAX : anc[a], nb = anc[bb] < 0 ? INT32_MAX : anc[bb];
-            if (na != nb) return na < nb;
-            const int ra = p.tree_rows[p.tree_row_off[t] + p.frb[o + a]], rb = p.tree_rows[p.tree_row_off[t] + p.frb[o + bb]];
-            const int ea = (s->adm_flags[ra] & KQ_ADM_EVICTED) ? 0 : 1, eb = (s->adm_flags[rb] & KQ_ADM_EVICTED) ? 0 : 1;
-            if (ea != eb) return ea < eb;
-            return a < bb;
-          });
+          for (size_t q = 1; q < cnt.size(); q++) cnt[q] += cnt[q - 1];
+          for (int j = 0; j < M; j++) idx[cnt[keyv[j]]++] = j;
+          std::fill(cnt.begin(), cnt.end(), 0);
           for (int q = 0; q < M; q++) {
             const int j = idx[q];
             const int row = p.tree_rows[p.tree_row_off[t] + p.frb[o + j]];
@@ -489,6 +514,7 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
         }
       }
   }
+  PT(6);
   for (int t = 0; t < p.n_tree; t++) {
     p.max_tree_nodes = std::max(p.max_tree_nodes, p.tree_node_off[t + 1] - p.tree_node_off[t]);
     p.max_tree_cqs = std::max(p.max_tree_cqs, p.tree_cq_off[t + 1] - p.tree_cq_off[t]);
@@ -509,6 +535,7 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
       tot += (s->rg_flavor_off[g + 1] - s->rg_flavor_off[g]) * (2 * (s->rg_res_off[g + 1] - s->rg_res_off[g]) + 1);  // (a cell of a head that replaces a workload slice can leave two: flavor mismatch + quota)
     p.max_rsn_per_podset = std::max(p.max_rsn_per_podset, tot);
   }
+  PT(7);
   // ---- fair sharing constants (depend on SubtreeQuota / usage: recomputed after kq_snapshot_derive) ----
   p.h_parent.assign(s->parent, s->parent + N);
   p.h_ll.assign(s->lend_limit, s->lend_limit + (size_t)N * p.nfr);
@@ -557,6 +584,7 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
       }
     }
   }
+  PT(8);
   // index validation
   for (int g = 0; g < p.n_rg; g++) {
     for (int k = s->rg_flavor_off[g]; k < s->rg_flavor_off[g + 1]; k++) if (s->rg_flavor[k] < 0 || s->rg_flavor[k] >= p.nF) { p.err = "rg_flavor out of range"; return KQ_EINVAL; }

@@ -89,7 +89,7 @@ KQ_DEV bool tc_fits_dom(const TTopo& T, const int64_t* pl, int leaf, int32_t cou
     int32_t cc = 0x7fffffff;
     if (spr[r] > 0) {
       const int64_t used = (int64_t)ag_load_u64((const uint64_t*)(pl + (size_t)leaf * T.R + r));
-      cc = (int32_t)i64max(0, i64min((T.free_cap[(size_t)leaf * T.R + r] - used) / spr[r], 0x7fffffff));
+      cc = (int32_t)i64max(0, i64min(t_div(T.free_cap[(size_t)leaf * T.R + r] - used, spr[r]), 0x7fffffff));
     }
     if (!have || cc < result) { result = cc; have = true; }
   }
@@ -199,8 +199,14 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
   tk.O.pool_leaf = c.d_leaf + ((size_t)slot * 2 + 1) * c.d_cap; tk.O.pool_count = c.d_count + ((size_t)slot * 2 + 1) * c.d_cap; tk.O.pool_cap = c.d_cap;
   tk.O.pool_used = qi + TQ_MISC; tk.O.error = qi + TQ_MISC + 1; tk.O.bytes = (long long*)(qi + TQ_MISC + 2);
   tk.C.n = 0;
+  tk.mail = w.ta.mail;
+  KQ_T0();
   t_workload(tk, slot, 0);
   wsync();
+  KQ_TS(k, 45);   // (timing builds) the placement; 46 = its phase 1
+#if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
+  if (lane == 0) atomic_add_i64((long long*)k.prof + 46, *(long long*)(qi + TQ_MISC + 4));
+#endif
   // (the placement's own algorithmic bytes, qi[TQ_MISC + 2], are not added to the cycle's counter: SURVEY 8d's accounting of the quota
   // cycle does not include them, and neither does the oracle's)
   if (lane == 0 && qi[TQ_MISC + 1] != 0 && *k.O.error == 0) *k.O.error = qi[TQ_MISC + 1];
@@ -417,7 +423,9 @@ KQ_NOINLINE void process_entry_tas(const K& k, Wave& w, int e, int pos, int slot
   if (w.rep_mode != M_NOFIT) cert_unverifiable(k, tree);
   const int32_t* trows = O.pool_row + O.tgt_pos[e];
   auto has_any = [&]() { bool a = false; for (int t = 0; t < nt; t++) if (k.preempted[trows[t]]) a = true; return a; };
+  KQ_T0();
   int fc = tc_fits_check(k, w, trows, nt, quota_usage, tree);
+  KQ_TS(k, 40);   // (timing builds) head + first fits
   int mode = w.rep_mode;
   const bool overlap = has_any() && gate(k, KQ_GATE_RECOMPUTE_ON_OVERLAP);
   const bool tas_recompute = fc == 2 && !(c.flags & KQ_CT_NO_RECOMPUTE);
@@ -430,7 +438,9 @@ KQ_NOINLINE void process_entry_tas(const K& k, Wave& w, int e, int pos, int slot
     // overlap: SimulateWorkloadRemoval(victimsOfOtherPreemptions) = the planes without the preempted rows; TAS only: the snapshot as it is
     const int64_t* plane = overlap ? k.usage_np : k.usage_work;
     const uint8_t* removed = overlap ? k.preempted : nullptr;
+    KQ_TS(k, 41);
     Search s = get_assignments(k, w, slot, plane, removed, true);
+    KQ_TS(k, 42);   // the recomputation (45 / 46 are inside it)
     publish_assignment(k, w, s, e);
     trows = O.pool_row + O.tgt_pos[e];
     nt = O.tgt_n[e];
@@ -444,6 +454,7 @@ KQ_NOINLINE void process_entry_tas(const K& k, Wave& w, int e, int pos, int slot
     }
     wsync();
     fc = tc_fits_check(k, w, trows, nt, quota_usage, tree);
+    KQ_TS(k, 43);   // publish + second fits
   }
   const bool fits_ok = fc == 0;
   int status = KQ_ST_NOT_NOMINATED, action = KQ_ACT_NONE, rq = KQ_RQ_GENERIC, skip = KQ_SKIP_NONE;
@@ -507,12 +518,14 @@ KQ_NOINLINE void process_entry_tas(const K& k, Wave& w, int e, int pos, int slot
   write_entry_result(k, w, e, status, action, rq, skip, mode);
   if (lane == 0) atomic_add_i64(O.stat_bytes, (long long)w.bytes);
   wsync();
+  KQ_TS(k, 44);   // usage added, result written
 }
 
 // k_process_tas: one wave walks every entry in iterator order
-KQ_DEV void process_all_tas(const K& k, Wave& w, int slot) {
+KQ_DEV void process_all_tas(const K& k, Wave& w, int slot, TLeafJob* mail) {
   const int n = hn(k.H);
   if (lane_id() == 0) {
+    w.ta.mail = mail;
     w.pc_on = 0; w.pc_lds = nullptr; w.np_broken = 0; w.n_pre = 0; w.broken[0] = w.broken[1] = w.broken[2] = w.broken[3] = 0;
     w.cs_lds = nullptr; w.cs_lds_bytes = 0; w.help_on = 0; w.mono_break = 0; w.ta.plane = 1; w.ta.srch = 0;
   }

@@ -22,14 +22,26 @@ __global__ __launch_bounds__(256) void k_tas_base(const TCyc* __restrict__ c, in
 __global__ __launch_bounds__(64) void k_nominate_tas(const K* __restrict__ kp, int slots) {
   const K& k = *kp;
   __shared__ Wave w;
-  if (threadIdx.x == 0) { w.cs_lds = nullptr; w.cs_lds_bytes = 0; w.help_on = 0; w.ta.plane = 0; w.ta.srch = 0; }
+  if (threadIdx.x == 0) { w.cs_lds = nullptr; w.cs_lds_bytes = 0; w.help_on = 0; w.ta.plane = 0; w.ta.srch = 0; w.ta.mail = nullptr; }
   __syncthreads();
   const int slot = blockIdx.x;
   for (int h = slot, n = hn(k.H); h < n; h += slots) nominate_head(k, w, h, slot);
 }
-__global__ __launch_bounds__(64) void k_process_tas(const K* __restrict__ kp) {
+// wave 0 walks the entries; waves 1..3 wait for the placements' phase-1 jobs (TLeafJob in LDS) and fill their stripes of the leaves.
+// 256 threads = one wave per SIMD: the leader keeps its 512 registers.
+constexpr int PROCESS_TAS_THREADS = 256;
+__global__ __launch_bounds__(PROCESS_TAS_THREADS) void k_process_tas(const K* __restrict__ kp) {
   __shared__ Wave w;
-  process_all_tas(*kp, w, 0);
+  __shared__ TLeafJob job;
+  if (threadIdx.x == 0) { job.cmd = 0; job.nw = PROCESS_TAS_THREADS / 64; job.bytes = 0; }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    process_all_tas(*kp, w, 0, &job);
+    if (threadIdx.x == 0) job.cmd = 2;
+    __syncthreads();
+  } else {
+    t_leaf_helper(job, (int)(threadIdx.x >> 6), PROCESS_TAS_THREADS / 64);
+  }
 }
 
 namespace kq {
@@ -44,7 +56,7 @@ hipError_t launch_nominate_tas_k(const K* d, int slots, hipStream_t stream) {
   return hipGetLastError();
 }
 hipError_t launch_process_tas_k(const K* d, hipStream_t stream) {
-  hipLaunchKernelGGL(k_process_tas, dim3(1), dim3(64), 0, stream, d);
+  hipLaunchKernelGGL(k_process_tas, dim3(1), dim3(PROCESS_TAS_THREADS), 0, stream, d);
   return hipGetLastError();
 }
 }  // namespace kq

@@ -69,7 +69,8 @@ struct TClass {
   const int32_t* wl_class;          // [n_wl] class of the workload, -1 = private phase 1
   const int32_t* order;             // [n_wl] workloads sorted by class: a slot walks a contiguous piece
 };
-struct TK { TTopo T; TReq Q; TOut O; TScratch X; TClass C; };
+struct TLeafJob;
+struct TK { TTopo T; TReq Q; TOut O; TScratch X; TClass C; TLeafJob* mail; };  // mail: phase 1 shared with the helper waves of the workgroup (null: none)
 
 struct TState {  // per-slot pointers
   int32_t *pc, *sc, *pcwl, *scwl, *lc, *set, *arr, *cur, *nxt;
@@ -116,6 +117,20 @@ KQ_DEV int32_t t_size_at(const TParams& p, int l) {
 }
 KQ_DEV bool t_lfc(const TK& k, bool unconstrained) { return unconstrained && k.T.profile_mixed; }  // useLeastFreeCapacityAlgorithm :1468
 
+// floor(a / b) as Go's int64 division gives it, for the operands CountIn meets: gfx950 has no 64-bit integer divide (the compiler
+// expands one into a ~150-instruction routine, and phase 1 does twelve per leaf: 80 % of a placement's time, profiles/r03l_prof_tas_cycle.txt),
+// but it has an IEEE fp64 divide. For 0 < a, b < 2^52 both operands are exact doubles, the correctly rounded quotient is within one
+// of the true one, and the exact integer correction below makes it exact. Anything else takes the generic division.
+KQ_DEV int64_t t_div(int64_t a, int64_t b) {
+  if (a > 0 && b > 0 && a < ((int64_t)1 << 52) && b < ((int64_t)1 << 52)) {
+    int64_t q = (int64_t)((double)a / (double)b);
+    int64_t r = a - q * b;
+    while (r < 0) { q--; r += b; }
+    while (r >= b) { q++; r -= b; }
+    return q;
+  }
+  return a / b;
+}
 // requests.go:195-232 on remaining capacity rem[] (registers of the lane)
 KQ_DEV int32_t t_count_in(const TK& k, const int64_t* req, const int64_t* rem) {
   bool have = false;
@@ -123,7 +138,7 @@ KQ_DEV int32_t t_count_in(const TK& k, const int64_t* req, const int64_t* rem) {
   for (int r = 0; r < k.T.R; r++) {
     int64_t q = req[r] + (r == k.T.pods ? 1 : 0);  // resources.OnePodRequest :905
     if (q == 0) continue;
-    int64_t c = rem[r] / q;
+    int64_t c = t_div(rem[r], q);
     int32_t cnt = (int32_t)i64max(0, i64min(c, 0x7fffffff));
     if (!have || cnt < result) { result = cnt; have = true; }
   }
@@ -132,35 +147,115 @@ KQ_DEV int32_t t_count_in(const TK& k, const int64_t* req, const int64_t* rem) {
 
 constexpr int KQ_TAS_MAXR = 16;
 
+// Phase 1 over the leaves (fillLeafCounts :1899) as a job any wave of the workgroup can take a stripe of: the leader of k_process_tas
+// posts it in LDS and its helper waves fill their stripes (t_leaf_helper); everywhere else the wave does it alone.
+struct TLeafArgs {
+  int32_t *pc, *sc, *pcwl, *scwl, *lc;
+  const int64_t *assumed, *req, *leaderReq;
+  const uint8_t* leafOk;
+  int simulateEmpty, hasAssumed, sliceLevelIdx;
+  int32_t sliceSize;
+};
+struct TLeafJob {
+  TTopo T;
+  TLeafArgs a;
+  int cmd;            // 0 idle, 1 job posted, 2 quit
+  int nw;             // waves of the workgroup sharing the job (set once by the kernel that owns the helpers)
+  long long bytes;    // helpers add their share
+};
+// leaves first, first + stride, ...: U leaves per step so that the next one's rows are in flight while the first one divides.
+// RM = 4 keeps the per-pod requests (incl. the pod itself; 0 = not requested) in registers; the general case reads them per use.
+template <int RM, int U> KQ_DEV int64_t t_leaf_counts(const TTopo& T, const TLeafArgs& a, int first, int stride) {
+  int64_t lb = 0;
+  const bool at = T.L - 1 == a.sliceLevelIdx;
+  const bool lead = a.leaderReq != nullptr;
+  auto reqv = [&](const int64_t* rq, int r) -> int64_t { return r < T.R ? rq[r] + (r == T.pods ? 1 : 0) : 0; };
+  // CountIn (requests.go:195-232): the minimum over the requested resources of floor(remaining / request), 0 when nothing is requested
+  auto count = [&](const int64_t* rq, const int64_t (&rem)[RM]) -> int32_t {
+    bool have = false;
+    int32_t result = 0;
+    #pragma unroll
+    for (int r = 0; r < RM; r++) {
+      const int64_t q = reqv(rq, r);
+      if (q == 0) continue;
+      const int32_t cnt = (int32_t)i64max(0, i64min(t_div(rem[r], q), 0x7fffffff));
+      if (!have || cnt < result) { result = cnt; have = true; }
+    }
+    return have ? result : 0;
+  };
+  for (int leaf0 = first; leaf0 < T.n_leaves; leaf0 += U * stride) {
+    int64_t rem[U][RM];
+    bool ok[U];
+    #pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int leaf = leaf0 + u * stride;
+      ok[u] = leaf < T.n_leaves && (!a.leafOk || a.leafOk[leaf]);
+      #pragma unroll
+      for (int r = 0; r < RM; r++) {
+        rem[u][r] = 0;
+        if (r < T.R && ok[u]) {
+          int64_t v = T.free_cap[(size_t)leaf * T.R + r];
+          if (!a.simulateEmpty) v -= T.tas_usage[(size_t)leaf * T.R + r];  // remainingCapacityForLeaf :1884
+          if (a.hasAssumed) v -= a.assumed[(size_t)leaf * T.R + r];
+          rem[u][r] = v;
+        }
+      }
+    }
+    #pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int leaf = leaf0 + u * stride;
+      if (leaf >= T.n_leaves) continue;
+      const int d = T.leaf_base + leaf;
+      int32_t pc = 0, pcwl = 0, lc = 0;
+      if (ok[u]) {
+        pc = count(a.req, rem[u]);
+        if (lead && count(a.leaderReq, rem[u]) > 0) {
+          lc = 1;
+          #pragma unroll
+          for (int r = 0; r < RM; r++) rem[u][r] -= reqv(a.leaderReq, r);
+        }
+        pcwl = lc ? count(a.req, rem[u]) : pc;   // without a leader on the leaf the capacity is what it was
+        lb += (int64_t)T.R * 16 + 24;
+      }
+      a.pc[d] = pc; a.pcwl[d] = pcwl; a.lc[d] = lc;
+      a.sc[d] = at ? pc / a.sliceSize : 0;
+      a.scwl[d] = at ? pcwl / a.sliceSize : 0;
+    }
+  }
+  return lb;
+}
+KQ_DEV int64_t t_leaf_counts_any(const TTopo& T, const TLeafArgs& a, int first, int stride) {
+  return T.R <= 4 ? t_leaf_counts<4, 2>(T, a, first, stride) : t_leaf_counts<KQ_TAS_MAXR, 1>(T, a, first, stride);
+}
+// helper waves of a workgroup whose wave 0 posts phase-1 jobs (k_process_tas): wave `wv` of `nw`
+KQ_DEV void t_leaf_helper(TLeafJob& job, int wv, int nw) {
+  for (;;) {
+    bsync();
+    if (job.cmd == 2) break;
+    const int64_t lb = wsum_i64(t_leaf_counts_any(job.T, job.a, wv * WAVE + lane_id(), nw * WAVE));
+    if (lane_id() == 0 && lb) atomic_add_i64(&job.bytes, (long long)lb);
+    bsync();
+  }
+}
+
 // fillInCounts :1800 = fillLeafCounts for every feasible leaf + fillInCountsHelper roll-up
 KQ_DEV void t_fill_in_counts(const TK& k, const TState& s, const TParams& p, long long* bytes_out) {
   const TTopo& T = k.T;
   const int lane = lane_id();
   for (int d = lane; d < T.leaf_base; d += WAVE) { s.pc[d] = 0; s.sc[d] = 0; s.pcwl[d] = 0; s.scwl[d] = 0; s.lc[d] = 0; }
   int64_t lb = 0;
-  for (int leaf = lane; leaf < T.n_leaves; leaf += WAVE) {
-    const int d = T.leaf_base + leaf;
-    int32_t pc = 0, pcwl = 0, lc = 0;
-    if (!p.leafOk || p.leafOk[leaf]) {
-      int64_t rem[KQ_TAS_MAXR];
-      for (int r = 0; r < T.R; r++) {
-        int64_t v = T.free_cap[(size_t)leaf * T.R + r];
-        if (!p.simulateEmpty) v -= T.tas_usage[(size_t)leaf * T.R + r];  // remainingCapacityForLeaf :1884
-        if (p.hasAssumed) v -= s.assumed[(size_t)leaf * T.R + r];
-        rem[r] = v;
-      }
-      pc = t_count_in(k, p.req, rem);
-      if (p.leaderReq && t_count_in(k, p.leaderReq, rem) > 0) {
-        lc = 1;
-        for (int r = 0; r < T.R; r++) rem[r] -= p.leaderReq[r] + (r == T.pods ? 1 : 0);
-      }
-      pcwl = t_count_in(k, p.req, rem);
-      lb += (int64_t)T.R * 16 + 24;
+  {
+    const TLeafArgs a{s.pc, s.sc, s.pcwl, s.scwl, s.lc, s.assumed, p.req, p.leaderReq, p.leafOk, p.simulateEmpty ? 1 : 0, p.hasAssumed ? 1 : 0, p.sliceLevelIdx, p.sliceSize};
+    if (k.mail) {
+      TLeafJob& j = *k.mail;
+      if (lane == 0) { j.T = T; j.a = a; j.bytes = 0; j.cmd = 1; }
+      bsync();
+      lb = t_leaf_counts_any(j.T, j.a, lane, j.nw * WAVE);
+      bsync();
+      if (lane == 0) lb += j.bytes;
+    } else {
+      lb = t_leaf_counts_any(T, a, lane, WAVE);
     }
-    s.pc[d] = pc; s.pcwl[d] = pcwl; s.lc[d] = lc;
-    const bool at = T.L - 1 == p.sliceLevelIdx;
-    s.sc[d] = at ? pc / p.sliceSize : 0;
-    s.scwl[d] = at ? pcwl / p.sliceSize : 0;
   }
   wsync();
   const bool leaderRequired = p.leaderCount > 0;
@@ -676,7 +771,13 @@ KQ_DEV TFail t_not_fit_layers(const TK& k, const TState& s, const TParams& st, i
 // counts in s.pc / s.lc.
 KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, int* nfit, bool have_counts) {
   const TTopo& T = k.T;
+#if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
+  const long long _p0 = clock64();
+#endif
   if (!have_counts) t_fill_in_counts(k, s, st, k.O.bytes);
+#if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
+  if (lane_id() == 0) k.O.bytes[1] += clock64() - _p0;   // (timing builds: cycles of phase 1, in the word behind the byte counter)
+#endif
   int fitLevelIdx = 0, ncur = 0;
   TFail f = t_find_level(k, s, st, &fitLevelIdx, &ncur);
   if (f.status == KQ_TAS_NOT_FIT && st.nLayers > 0) { *nfit = fitLevelIdx; return f; }  // the caller turns it into the per-layer form

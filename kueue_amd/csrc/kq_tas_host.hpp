@@ -386,7 +386,7 @@ KQ_DEV void t_fits_cell(const TTopo& T, int i, const int32_t* leaf, const int32_
     int32_t c = 0x7fffffff;
     if (spr[r] > 0) {
       const int64_t rem = T.free_cap[(size_t)leaf[i] * T.R + r] - T.tas_usage[(size_t)leaf[i] * T.R + r];
-      c = (int32_t)i64max(0, i64min(rem / spr[r], 0x7fffffff));
+      c = (int32_t)i64max(0, i64min(t_div(rem, spr[r]), 0x7fffffff));
     }
     if (!have || c < result) { result = c; have = true; }
   }
@@ -406,7 +406,7 @@ KQ_DEV bool t_fits_dom_now(const TTopo& T, int leaf, int32_t count, const int64_
     if (spr[r] > 0) {
       const int64_t used = (int64_t)ag_load_u64((const uint64_t*)(T.tas_usage + (size_t)leaf * T.R + r));
       const int64_t rem = T.free_cap[(size_t)leaf * T.R + r] - used;
-      c = (int32_t)i64max(0, i64min(rem / spr[r], 0x7fffffff));
+      c = (int32_t)i64max(0, i64min(t_div(rem, spr[r]), 0x7fffffff));
     }
     if (!have || c < result) { result = c; have = true; }
   }

@@ -182,7 +182,7 @@ struct EmuBackend {
   void launch_nominate_tas(const K& k, int slots) {
     for (int slot = 0; slot < slots; slot++) { Wave w{}; for (int h = slot; h < hn(k.H); h += slots) nominate_head(k, w, h, slot); }
   }
-  void launch_process_tas(const K& k) { Wave w{}; process_all_tas(k, w, 0); last_k = k; }
+  void launch_process_tas(const K& k) { Wave w{}; process_all_tas(k, w, 0, nullptr); last_k = k; }
   void launch_process_fair(const K& k, int n_tree, size_t, size_t, int32_t* rank) {
     std::vector<int64_t> lds(160 * 1024 / 8);
     // (a recomputation's victim search borrows the region: whole state in "LDS" / almost none of it / no region at all)

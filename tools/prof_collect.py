@@ -49,7 +49,8 @@ def main(tag, workload, kernels):
            "cfg3f": "python bench.py --workload cfg3f --steps 20 --no-cpu-baseline --no-parity-gate --full-run 0 --no-host-leg   (fair sharing, pending loop, 1 x MI355X)",
            "cfg4c": "python bench.py --workload cfg4c --steps 2 --warmup 1 --no-cpu-baseline --no-parity-gate --full-run 0 --no-host-leg   (classical preemption, 1000 heads per cycle, 1 x MI355X)",
            "cfg4f": "python bench.py --workload cfg4f --steps 1 --warmup 0 --no-cpu-baseline --no-parity-gate --full-run 0 --no-host-leg   (fair sharing + preemption, 1000 heads per cycle, 1 x MI355X)",
-           "cfg5": "python bench.py --workload cfg5 --steps 5 --warmup 1 --no-cpu-baseline   (1 x MI355X)"}.get(workload, workload)
+           "cfg5": "python bench.py --workload cfg5 --steps 5 --warmup 1 --no-cpu-baseline   (1 x MI355X)",
+           "cfg5-cycle": "python bench.py --workload cfg5-cycle --steps 5 --warmup 1 --no-cpu-baseline --no-parity-gate   (TAS inside the cycle, 1000 heads per cycle, 1 x MI355X)"}.get(workload, workload)
     lines = [f"# rocprofv3 --kernel-trace --stats --output-format csv -- {cmd}"]
     lines += [l.rstrip("\n") for l in open(stats)]
     lines += ["", "# PMC passes (separate runs, --kernel-trace --pmc <counter>, same command): mean per launch, unit = KB as reported by rocprofv3"]

@@ -20,6 +20,7 @@ if [[ $WHAT == *benches* ]]; then
   run cfg4c --workload cfg4c --steps 3 --warmup 1 --cpu-seconds 5
   run cfg5 --workload cfg5 --steps 5 --warmup 1
   run cfg5split --workload cfg5-split --steps 5 --warmup 1
+  run cfg5cycle --workload cfg5-cycle --steps 10 --warmup 2 --cpu-seconds 5
   TMO=900 run cfg4f --workload cfg4f --steps 1 --warmup 0 --cpu-seconds 5 --no-host-leg
 fi
 if [[ $WHAT == *profiles* ]]; then
@@ -31,6 +32,7 @@ if [[ $WHAT == *profiles* ]]; then
   CMD[cfg4c]="python $R/bench.py --workload cfg4c --steps 2 --warmup 1 $Q"
   CMD[cfg4f]="python $R/bench.py --workload cfg4f --steps 1 --warmup 0 $Q"
   CMD[cfg5]="python $R/bench.py --workload cfg5 --steps 5 --warmup 1 --no-cpu-baseline"
+  CMD[cfg5-cycle]="python $R/bench.py --workload cfg5-cycle --steps 5 --warmup 1 --no-cpu-baseline --no-parity-gate"
   for W in ${PROF_WORKLOADS:-cfg3 cfg3f cfg4c cfg5 cfg4f}; do
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_${W}_stats -- ${CMD[$W]} > $O/p_${W}_stats.log 2>&1
     timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/p_${W}_fetch -- ${CMD[$W]} > $O/p_${W}_fetch.log 2>&1

@@ -1,0 +1,28 @@
+"""In-kernel segment timing of k_process_tas (kq_cycle_run_tas; needs kueue_amd/libkq_engine_prof.so: tools/build_prof.sh, -DKQ_PROF)."""
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from kueue_amd import _ffi as F
+F.ENGINE_LIB = os.path.join(F.HERE, "libkq_engine_prof.so")
+from kueue_amd.engine import Engine
+from kueue_amd.api import make_config
+from kueue_amd.tas_population import generate_tas_cycle
+from oracle import kqo
+snap, topos, batch = generate_tas_cycle(n_cq=1000, n_pending=6000)
+kqo.derive(snap)
+eng = Engine(make_config()); eng.put(snap)
+lib = eng._lib
+lib.kq_debug_prof.argtypes = [C.c_void_p, F.i64p, C.c_int]
+prof = np.zeros(64, np.int64)
+bs = [batch(c) for c in range(6)]
+eng.run_tas(*bs[0])
+lib.kq_debug_prof(eng._h, F.ptr(prof), 1)
+n = rec = 0
+for h, ct in bs[1:]:
+    d, _ = eng.run_tas(h, ct); n += h.n; rec += d.tas_stats["recomputes"]
+lib.kq_debug_prof(eng._h, F.ptr(prof), 1)
+names = {40: "head + first fits", 41: "before the recomputation", 42: "recomputation (get_assignments)", 43: "publish + second fits", 44: "usage added, result written",
+         45: "  of which: placements (t_workload, incl. k_nominate_tas's)", 46: "  of which: phase 1 of the placements"}
+for i, nm in names.items():
+    print(f"{nm:60s} {prof[i]/n:10.1f} cycles/entry  ({prof[i]/n/2400:.2f} us at 2.4 GHz)")
+print(f"{n} entries, {rec} recomputations; kernel ms last cycle {d.kernel_ms}")
