@@ -69,7 +69,8 @@ typedef struct kq_cycle_tas_out {
 /* One scheduling cycle with TAS inside it, against the resident snapshot (kq_snapshot_put). Same contract as kq_cycle_run for `out`
  * (decisions, targets, reasons); tout receives the TopologyAssignment of every podset that holds one (admitted or not: the nomination's)
  * and, optionally, the leaf usage after the cycle. t->adm_* is indexed by the admitted rows of the resident snapshot, t->ps_* by the
- * podsets of `h`. stats (optional): [0] placements computed, [1] TAS recomputations inside processEntry, [2] reserved.
+ * podsets of `h`. stats (optional, int64[4]): [0] placements computed, [1] TAS recomputations inside processEntry, [2] 1 when the cycle met a
+ * workload outside the path (two TAS flavors), [3] placements of processEntry that started from a resident request-class table.
  * KQ_EUNSUPPORTED: fair sharing, or a workload with TAS requests on more than one TAS flavor. */
 int kq_cycle_run_tas(kq_engine* e, const kq_heads* h, const kq_cycle_tas* t, kq_decisions* out, kq_cycle_tas_out* tout, int64_t* stats);
 

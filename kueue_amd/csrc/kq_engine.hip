@@ -114,6 +114,7 @@ namespace kq { hipError_t launch_process_spec(const K* d, int n_tree, hipStream_
 namespace kq {
 hipError_t launch_tas_base_k(const TCyc* c, int n, hipStream_t stream);
 hipError_t launch_nominate_tas_k(const K* d, int slots, hipStream_t stream);
+hipError_t launch_tas_cycle_classes_k(const TCyc* c, int n, hipStream_t stream);
 hipError_t launch_process_tas_k(const K* d, hipStream_t stream);
 }
 
@@ -697,6 +698,7 @@ struct HipBackend {
   }
   // kq_cycle_run_tas (kq_tas_cycle_kernel.hip)
   void launch_tas_base(const TCyc* c, int n) { chk(launch_tas_base_k(c, n, stream), "k_tas_base"); }
+  void launch_tas_cycle_classes(const TCyc* c, int n) { chk(launch_tas_cycle_classes_k(c, n, stream), "k_tas_cycle_classes"); }
   void launch_nominate_tas(const K& k, int slots) {
     stat_patched = false;
     const K* d = put_k(k, 0);

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <unordered_map>
 
 #include "kq_device.hpp"
 #include "kq_tas_cycle.hpp"
@@ -595,6 +596,8 @@ template <class B> struct EngineT {
   // ---- Topology-Aware Scheduling inside the cycle (include/kq_cycle_tas.h, kq_tas_cycle.hpp) ------------------------------------------------
   std::vector<Buf> tbuf;
   size_t tnext = 0;
+  bool tas_classes_off = getenv("KQ_TAS_CLASSES_OFF") != nullptr;   // (A/B switch and tests: every placement of k_process_tas runs its own phase 1)
+  int tas_n_cls = 0;       // (TAS flavor, request class) pairs of the cycle being enqueued
   template <class T> T* tgrow(size_t n) { if (tnext >= tbuf.size()) tbuf.resize(tnext + 16); return grow<T>(tbuf[tnext++], n); }
   template <class T> T* tstage(const T* host, size_t n) { T* d = tgrow<T>(n); if (n) be.h2d(d, host, n * sizeof(T)); return d; }
   int cycle_run_tas(const kq_heads* h, const kq_cycle_tas* t, kq_decisions* out, kq_cycle_tas_out* tout, int64_t* stats) {
@@ -607,7 +610,7 @@ template <class B> struct EngineT {
     if (rc != KQ_OK) return rc;
     const int n = batches[0].n;
     const size_t nps = batches[0].nps;
-    if (stats) stats[0] = stats[1] = stats[2] = 0;
+    if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
     tout->dom_off[0] = 0;
     if (t->n_tas == 0) {  // no TAS flavor in the snapshot: the ordinary cycle
       rc = cycle_exec(0, out);
@@ -620,9 +623,33 @@ template <class B> struct EngineT {
         !t->ps_slice_level || !t->ps_group || !t->ps_req) return fail(KQ_EINVAL, "null array in kq_cycle_tas");
     tnext = 0;
     const int slots = std::max(1, std::min(n, be.max_slots()));
+    // request classes of the cycle's podsets (k_process_tas keeps their phase-1 tables resident, kq_tas_cycle.hpp): same per-pod requests,
+    // slice size and slice level on every TAS flavor; podset groups and inner layers stay outside
+    constexpr int TC_MAXCLS = 32;
+    std::vector<int32_t> ps_class(std::max<size_t>(nps, 1), -1), cls_rep;
+    if (!tas_classes_off) {
+      std::unordered_map<std::string, int> ids;
+      for (size_t p = 0; p < nps; p++) {
+        if (t->ps_group[p] >= 0 || (t->ps_n_layers && t->ps_n_layers[p] > 1)) continue;
+        std::string key((const char*)(t->ps_req + p * R), (size_t)R * 8);
+        key.append((const char*)&t->ps_slice_size[p], 4);
+        key.append((const char*)(t->ps_slice_level + p * nt), (size_t)nt * 4);
+        auto it = ids.find(key);
+        if (it == ids.end()) {
+          if ((int)cls_rep.size() >= TC_MAXCLS) continue;
+          it = ids.emplace(key, (int)cls_rep.size()).first;
+          cls_rep.push_back((int32_t)p);
+        }
+        ps_class[p] = it->second;
+      }
+    }
+    const int ncls = (int)cls_rep.size();
+    const int xslots = slots + ncls;
     std::vector<int32_t> tas_of(prep.nF, -1);
     std::vector<TK> tks(nt);
     std::vector<int64_t*> work(nt), np(nt), priv(nt);
+    std::vector<int32_t*> cls_tab(nt), cflag(nt), par(nt);
+    std::vector<long long*> cls_bytes(nt);
     int max_leaves = 1;
     for (int i = 0; i < nt; i++) {
       const kq_tas_topology& tp = t->topo[i];
@@ -652,20 +679,28 @@ template <class B> struct EngineT {
       }
       max_leaves = std::max(max_leaves, T.n_leaves);
       const size_t cells = (size_t)T.n_leaves * R;
+      std::vector<int32_t> parent(std::max(T.D, 1), -1);
+      for (int l = 1; l < T.L; l++) for (int d = T.level_off[l]; d < T.level_off[l + 1]; d++) parent[d] = T.level_off[l - 1] + tp.parent[d];
       T.child_first = tstage(first.data(), first.size()); T.child_cnt = tstage(cnt.data(), cnt.size());
-      be.sync();  // (first / cnt are locals)
+      par[i] = tstage(parent.data(), parent.size());
+      be.sync();  // (first / cnt / parent are locals)
+      cls_tab[i] = tgrow<int32_t>((size_t)5 * std::max(ncls, 1) * std::max(T.D, 1));
+      cls_bytes[i] = (long long*)tgrow<int64_t>(std::max(ncls, 1));
+      cflag[i] = tgrow<int32_t>((size_t)std::max(ncls, 1) * std::max(T.D, 1));
+      be.memset(cflag[i], 0, (size_t)std::max(ncls, 1) * std::max(T.D, 1) * 4);
       T.free_cap = tstage(tp.free_capacity, cells);
       T.tas_usage = tstage(tp.tas_usage, cells);
       work[i] = tgrow<int64_t>(cells); np[i] = tgrow<int64_t>(cells); priv[i] = tgrow<int64_t>((size_t)slots * cells);
       TScratch& X = tk.X;
       X.max_set = (std::max(T.n_leaves, T.D - T.n_leaves + 1) + 1 + 15) & ~15;
-      const size_t sd = (size_t)slots * T.D, sm = (size_t)slots * X.max_set;
+      // (the slots behind the wave slots hold the working copies of the request classes' phase-1 tables)
+      const size_t sd = (size_t)xslots * T.D, sm = (size_t)xslots * X.max_set;
       X.pc = tgrow<int32_t>(sd); X.sc = tgrow<int32_t>(sd); X.pcwl = tgrow<int32_t>(sd); X.scwl = tgrow<int32_t>(sd); X.lc = tgrow<int32_t>(sd);
-      X.set = tgrow<int32_t>(sm); X.arr = tgrow<int32_t>(sm + slots); X.cur = tgrow<int32_t>(sm); X.nxt = tgrow<int32_t>(sm);
+      X.set = tgrow<int32_t>(sm); X.arr = tgrow<int32_t>(sm + xslots); X.cur = tgrow<int32_t>(sm); X.nxt = tgrow<int32_t>(sm);
       X.k0 = (uint64_t*)tgrow<int64_t>(sm); X.k1 = (uint64_t*)tgrow<int64_t>(sm);
-      X.assumed = tgrow<int64_t>((size_t)slots * cells);
-      X.log = tgrow<int32_t>(sm); X.meta = tgrow<int32_t>((size_t)slots * 4);
-      be.memset(X.meta, 0xff, (size_t)slots * 4 * sizeof(int32_t));
+      X.assumed = tgrow<int64_t>((size_t)xslots * cells);
+      X.log = tgrow<int32_t>(sm); X.meta = tgrow<int32_t>((size_t)xslots * 4);
+      be.memset(X.meta, 0xff, (size_t)xslots * 4 * sizeof(int32_t));
     }
     const int n_adm = prep.n_adm;
     const int n_ent = n_adm > 0 ? t->adm_off[n_adm] : 0;
@@ -715,6 +750,26 @@ template <class B> struct EngineT {
     c.stats = (long long*)tmisc; c.pool_used = (int32_t*)(tmisc + 4);
     c.tree_state = tgrow<int32_t>((size_t)std::max(prep.n_tree, 1) * 12);
     be.memset(c.tree_state, 0, (size_t)std::max(prep.n_tree, 1) * 12 * 4);
+    // request classes
+    c.ncls = ncls;
+    c.ps_class = tstage(ps_class.data(), ps_class.size());
+    {
+      std::vector<int64_t> creq((size_t)std::max(ncls, 1) * R, 0);
+      std::vector<int32_t> css(std::max(ncls, 1), 1), csl((size_t)std::max(ncls, 1) * nt, -1);
+      for (int q = 0; q < ncls; q++) {
+        const size_t p = (size_t)cls_rep[q];
+        for (int r = 0; r < R; r++) creq[(size_t)q * R + r] = t->ps_req[p * R + r];
+        css[q] = t->ps_slice_size[p];
+        for (int i = 0; i < nt; i++) csl[(size_t)q * nt + i] = t->ps_slice_level[p * nt + i];
+      }
+      c.cls_req = tstage(creq.data(), creq.size()); c.cls_ssize = tstage(css.data(), css.size()); c.cls_slevel = tstage(csl.data(), csl.size());
+      c.cls_tab = tstage(cls_tab.data(), cls_tab.size()); c.cls_bytes = tstage(cls_bytes.data(), cls_bytes.size());
+      c.par = (const int32_t* const*)tstage(par.data(), par.size()); c.cflag = tstage(cflag.data(), cflag.size());
+      c.cls_ok = tgrow<uint8_t>((size_t)nt * std::max(ncls, 1));
+      be.memset(c.cls_ok, 0, (size_t)nt * std::max(ncls, 1));
+      be.sync();  // (locals)
+    }
+    tas_n_cls = nt * ncls;
     TCyc* d_tc = tstage(&c, 1);
     if (n_ent > 0) be.launch_tas_base(d_tc, n_ent);   // base plane += workload.TASUsage() of every admitted row
     for (int i = 0; i < nt; i++) {
@@ -741,7 +796,7 @@ template <class B> struct EngineT {
     }
     rc = be.sync();
     if (rc != KQ_OK) return fail(rc, be.error());
-    if (stats) { stats[0] = hm[0]; stats[1] = hm[1]; stats[2] = hm[2]; }
+    if (stats) { stats[0] = hm[0]; stats[1] = hm[1]; stats[2] = hm[2]; stats[3] = hm[3]; }
     int tot = 0;
     for (size_t p = 0; p < nps; p++) {
       const int tt = ht[p], pos = ht[nps + p], cnt = tt >= 0 ? ht[2 * nps + p] : 0;
@@ -997,7 +1052,7 @@ template <class B> struct EngineT {
       if (n_help > 0) { k.help = d_help; k.help_quit = (uint32_t*)(d_help + prep.n_tree); k.help_trees = prep.n_tree; }
       be.launch_process_fair(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16, fs_want, rank);
     }
-    else if (d_tc) be.launch_process_tas(k);   // one wave, every tree, entry order: TAS leaves are shared across root cohorts
+    else if (d_tc) { if (tas_n_cls > 0) be.launch_tas_cycle_classes(d_tc, tas_n_cls); be.launch_process_tas(k); }   // one wave, every tree, entry order: TAS leaves are shared across root cohorts
     else be.launch_process(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16);
     be.timer_mark(3);
     last_cycle_n = -1;  // set on the success path only: a failed cycle must not be committable

@@ -54,6 +54,19 @@ struct TCyc {
   int pool_cap;
   long long* stats;               // [4] placements, recomputations, unsupported
   int32_t* tree_state;            // [n_tree][12] processEntry's per-tree state while one wave walks all trees in entry order
+  // Request classes of k_process_tas: phase 1 of a placement depends on (per-pod requests, slice size / level) only, so the podsets of a
+  // cycle fall into a handful of classes (6 at cfg 5). Their phase-1 tables over the WORK plane are kept resident and patched after
+  // every AddUsage (an admission touches <= a few dozen leaves and their ancestors), so that a recomputation starts phase 2 directly.
+  int ncls;
+  const int32_t* ps_class;        // [n_ps] class of the podset's request, -1 = none (podset group, inner layers, table full)
+  const int64_t* cls_req;         // [ncls][R]
+  const int32_t* cls_ssize;       // [ncls]
+  const int32_t* cls_slevel;      // [ncls][n_tas]
+  int32_t* const* cls_tab;        // [n_tas] -> [5][ncls][D]: podCount, sliceCount, podCountWithLeader, sliceCountWithLeader, leaderCount
+  long long* const* cls_bytes;    // [n_tas] -> [ncls] algorithmic bytes of one phase 1 of the class
+  uint8_t* cls_ok;                // [n_tas][ncls] the class's slice parameters are valid on this flavor
+  const int32_t* const* par;      // [n_tas] -> [D] parent domain (global id), -1 at level 0
+  int32_t* const* cflag;          // [n_tas] -> [ncls][D] owner marks of the incremental update (all zero between two updates)
 };
 
 #ifdef KQ_TAS_CYCLE
@@ -94,6 +107,112 @@ KQ_DEV bool tc_fits_dom(const TTopo& T, const int64_t* pl, int leaf, int32_t cou
     if (!have || cc < result) { result = cc; have = true; }
   }
   return (have ? result : 0) >= count;
+}
+
+// ---- request classes: resident phase-1 tables over the work plane -----------------------------------------------------------------
+KQ_DEV TLeafArgs tc_class_args(const TCyc& c, int t, int cls, int32_t* tab) {
+  const size_t D = c.tk[t].T.D, n = (size_t)c.ncls * D;
+  int32_t* b = tab + (size_t)cls * D;
+  return TLeafArgs{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, nullptr, c.cls_req + (size_t)cls * c.R, nullptr, nullptr, 0, 0,
+                   c.cls_slevel[(size_t)cls * c.n_tas + t], c.cls_ssize[cls]};
+}
+// the working copy of class cls: the per-slot state arrays of slot c.slots + cls (t_workload starts phase 2 from it and puts the class
+// table's values back into the domains it consumed)
+KQ_DEV TLeafArgs tc_class_work_args(const TCyc& c, int t, int cls) {
+  const TK& tk = c.tk[t];
+  const size_t o = (size_t)(c.slots + cls) * tk.T.D;
+  return TLeafArgs{tk.X.pc + o, tk.X.sc + o, tk.X.pcwl + o, tk.X.scwl + o, tk.X.lc + o, nullptr, c.cls_req + (size_t)cls * c.R, nullptr, nullptr, 0, 0,
+                   c.cls_slevel[(size_t)cls * c.n_tas + t], c.cls_ssize[cls]};
+}
+// phase 1 of class cls on flavor t over the work plane, from scratch (one wave; before k_process_tas walks)
+KQ_DEV void tc_class_init(const TCyc& c, int t, int cls) {
+  TK tk = c.tk[t];
+  tk.T.tas_usage = c.work[t];
+  tk.mail = nullptr;
+  const int lane = lane_id();
+  const TTopo& T = tk.T;
+  const TLeafArgs a = tc_class_args(c, t, cls, c.cls_tab[t]);
+  const TLeafArgs b = tc_class_work_args(c, t, cls);
+  const bool ok = a.sliceSize > 0 && a.sliceLevelIdx >= 0 && a.sliceLevelIdx < T.L;
+  if (lane == 0) { c.cls_ok[(size_t)t * c.ncls + cls] = ok ? 1 : 0; c.cls_bytes[t][cls] = 0; }
+  if (!ok) return;
+  TState s{};
+  s.pc = a.pc; s.sc = a.sc; s.pcwl = a.pcwl; s.scwl = a.scwl; s.lc = a.lc;
+  TParams st{};
+  st.count = 1; st.leaderCount = 0; st.sliceSize = a.sliceSize; st.sliceLevelIdx = a.sliceLevelIdx; st.requestedLevelIdx = 0;
+  st.simulateEmpty = false; st.hasAssumed = false; st.req = a.req; st.leaderReq = nullptr; st.leafOk = nullptr;
+  t_fill_in_counts(tk, s, st, c.cls_bytes[t] + cls);
+  wsync();
+  for (int d = lane; d < T.D; d += WAVE) { b.pc[d] = a.pc[d]; b.sc[d] = a.sc[d]; b.pcwl[d] = a.pcwl[d]; b.scwl[d] = a.scwl[d]; b.lc[d] = a.lc[d]; }
+  int32_t* meta = tk.X.meta + (size_t)(c.slots + cls) * 4;
+  if (lane == 0) { meta[0] = 0; meta[1] = 0; meta[2] = cls; }
+  wsync();
+}
+// AddUsage changed the work plane on the leaves of entry e's TopologyAssignments: every class table (and its working copy) follows.
+// A class carries no leader and no inner layers, so in its table podCountWithLeader == podCount, sliceCountWithLeader == sliceCount,
+// leaderCount == 0 on every level, an upper domain's podCount is the SUM of its children's (fillInCountsHelper :1930 with minPodDiff 0),
+// and its sliceCount is podCount / sliceSize on the slice level, the sum of the children's above it, 0 below it. Hence deltas:
+// lanes = (class, touched leaf): the leaf's counts are recomputed from the plane (CountIn), the difference of its podCount is added to
+// every ancestor; then the slice-level ancestors (one owner lane each) turn their new podCount into a sliceCount and send that
+// difference up. Bit-identical to running phase 1 again.
+KQ_DEV void tc_class_update(const K& k, const Wave& w) {
+  const TCyc& c = *k.tc;
+  if (c.ncls == 0) return;
+  const int lane = lane_id();
+  for (int p = 0; p < w.nps; p++) {
+    const int g = w.ps_base + p, t = c.h_tas[g];
+    if (t < 0 || c.h_n[g] == 0) continue;
+    TTopo T = c.tk[t].T;
+    T.tas_usage = c.work[t];
+    const int32_t* par = c.par[t]; int32_t* flag = c.cflag[t];
+    const int n = c.h_n[g], pos = c.h_pos[g], items = n * c.ncls;
+    // A: leaves, podCount deltas up the tree (and the sliceCount deltas when the leaves are the slice level)
+    for (int i = lane; i < items; i += WAVE) {
+      const int cls = i / n, j = i % n;
+      if (!c.cls_ok[(size_t)t * c.ncls + cls]) continue;
+      const TLeafArgs a = tc_class_args(c, t, cls, c.cls_tab[t]);
+      const int leaf = c.pool_leaf[pos + j], d = T.leaf_base + leaf;
+      const int32_t old_pc = a.pc[d], old_sc = a.sc[d];
+      t_leaf_counts_any(T, a, leaf, T.n_leaves);   // exactly this leaf
+      const int32_t dpc = a.pc[d] - old_pc, dsc = a.sc[d] - old_sc;
+      for (int x = par[d]; x >= 0; x = par[x]) {
+        if (dpc) { atomic_add_i32(&a.pc[x], dpc); atomic_add_i32(&a.pcwl[x], dpc); }
+        if (dsc) { atomic_add_i32(&a.sc[x], dsc); atomic_add_i32(&a.scwl[x], dsc); }
+      }
+    }
+    wsync();
+    // B: slice level above the leaves
+    for (int i = lane; i < items; i += WAVE) {
+      const int cls = i / n, j = i % n;
+      if (!c.cls_ok[(size_t)t * c.ncls + cls]) continue;
+      const TLeafArgs a = tc_class_args(c, t, cls, c.cls_tab[t]);
+      const int sl = a.sliceLevelIdx;
+      if (sl >= T.L - 1) continue;
+      int x = T.leaf_base + c.pool_leaf[pos + j];
+      for (int l = T.L - 1; l > sl; l--) x = par[x];
+      if (atomic_add_i32(&flag[(size_t)cls * T.D + x], 1) != 0) continue;   // another lane owns this (class, domain)
+      const int32_t npc = (int32_t)ag_load_u32((const uint32_t*)&a.pc[x]);
+      const int32_t nsc = npc / a.sliceSize, dsc = nsc - a.sc[x];
+      a.sc[x] = nsc; a.scwl[x] = nsc;
+      if (dsc) for (int y = par[x]; y >= 0; y = par[y]) { atomic_add_i32(&a.sc[y], dsc); atomic_add_i32(&a.scwl[y], dsc); }
+    }
+    wsync();
+    // C: the touched chains into the working copies (and rewritten in place: what the atomics left in L2 becomes what plain loads see)
+    for (int i = lane; i < items; i += WAVE) {
+      const int cls = i / n, j = i % n;
+      if (!c.cls_ok[(size_t)t * c.ncls + cls]) continue;
+      const TLeafArgs a = tc_class_args(c, t, cls, c.cls_tab[t]);
+      const TLeafArgs b = tc_class_work_args(c, t, cls);
+      int lvl = T.L - 1;
+      for (int x = T.leaf_base + c.pool_leaf[pos + j]; x >= 0; x = par[x], lvl--) {
+        const int32_t v0 = (int32_t)ag_load_u32((const uint32_t*)&a.pc[x]), v1 = (int32_t)ag_load_u32((const uint32_t*)&a.sc[x]);
+        a.pc[x] = v0; a.pcwl[x] = v0; a.sc[x] = v1; a.scwl[x] = v1;
+        b.pc[x] = v0; b.pcwl[x] = v0; b.sc[x] = v1; b.scwl[x] = v1; b.lc[x] = 0;
+        if (lvl == a.sliceLevelIdx) flag[(size_t)cls * T.D + x] = 0;
+      }
+    }
+    wsync();
+  }
 }
 
 // ---- Assign's TAS step -------------------------------------------------------------------------------------------------------------------
@@ -158,6 +277,7 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
   TcFail f{false, -1, 0};
   const int n = w.ta.nreq;
   if (n == 0) return f;
+  KQ_T0();
   const int t = w.ta.t;
   const int lane = lane_id();
   int32_t* qi = c.q_i32 + (size_t)slot * TQ_WORDS;
@@ -200,12 +320,26 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
   tk.O.pool_used = qi + TQ_MISC; tk.O.error = qi + TQ_MISC + 1; tk.O.bytes = (long long*)(qi + TQ_MISC + 2);
   tk.C.n = 0;
   tk.mail = w.ta.mail;
-  KQ_T0();
-  t_workload(tk, slot, 0);
+  int xslot = slot;
+  if (which == 1 && !simulateEmpty && n == 1 && c.ncls > 0) {   // processEntry on the work plane: start from the class's resident phase 1
+    const int g = w.ps_base + w.ta.req_ps[0];
+    const int cls = c.ps_class[g];
+    if (cls >= 0 && c.cls_ok[(size_t)t * c.ncls + cls]) {
+      const size_t nD = (size_t)c.ncls * tk.T.D;
+      int32_t* tab = c.cls_tab[t];
+      tk.C.n = c.ncls; tk.C.wl_class = c.ps_class + g; tk.C.order = nullptr;
+      tk.C.pc = tab; tk.C.sc = tab + nD; tk.C.pcwl = tab + 2 * nD; tk.C.scwl = tab + 3 * nD; tk.C.lc = tab + 4 * nD;
+      tk.C.bytes = c.cls_bytes[t];
+      xslot = c.slots + cls;
+      if (lane == 0 && c.stats) atomic_add_i64(c.stats + 3, 1);
+    }
+  }
+  if (which != 0) KQ_TS(k, 47);   // request block + argument block of the placement
+  t_workload(tk, xslot, 0);
   wsync();
-  KQ_TS(k, 45);   // (timing builds) the placement; 46 = its phase 1
+  if (which != 0) KQ_TS(k, 45);   // (timing builds, processEntry only) the placement; 46 = its phase 1
 #if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
-  if (lane == 0) atomic_add_i64((long long*)k.prof + 46, *(long long*)(qi + TQ_MISC + 4));
+  if (lane == 0 && which != 0) atomic_add_i64((long long*)k.prof + 46, *(long long*)(qi + TQ_MISC + 4));
 #endif
   // (the placement's own algorithmic bytes, qi[TQ_MISC + 2], are not added to the cycle's counter: SURVEY 8d's accounting of the quota
   // cycle does not include them, and neither does the oracle's)
@@ -241,11 +375,15 @@ KQ_NOINLINE void tc_keep_result(const K& k, Wave& w, int slot) {
 }
 // flavorassigner.go:864-903
 KQ_DEV void tc_assign_tas(const K& k, Wave& w, int slot) {
+  KQ_T0();
   tc_requests(k, w);
+  if (w.ta.plane != 0) KQ_TS(k, 48);   // (timing builds, processEntry only) WorkloadsTopologyRequests
   if (w.rep_mode == M_FIT) {
     const TcFail f = tc_find(k, w, slot, false, w.ta.plane);
+    if (w.ta.plane != 0) KQ_TS(k, 49); // the find (47 + 45 inside it)
     if (f.failed) tc_update_mode(k, w, f.ps, M_PREEMPT);   // (+ psAssignment.reason(failure.Reason): the message stays host-side)
     else tc_keep_result(k, w, slot);
+    if (w.ta.plane != 0) KQ_TS(k, 50); // keep the result
   }
   if (w.rep_mode == M_PREEMPT) {
     const TcFail f = tc_find(k, w, slot, true, w.ta.plane);
@@ -362,6 +500,7 @@ KQ_DEV void tc_entry_add(const K& k, const Wave& w) {  // updateTASUsage :267 on
     }
     wsync();
   }
+  tc_class_update(k, w);
 }
 // scheduler.fits :771-777 -> ClusterQueueSnapshot.Fits :136-150: 0 = fits, 1 = no quota, 2 = no TAS capacity
 KQ_DEV int tc_fits_check(const K& k, Wave& w, const int32_t* trows, int nt, bool quota_usage, int tree) {

@@ -19,6 +19,10 @@ __global__ __launch_bounds__(256) void k_tas_base(const TCyc* __restrict__ c, in
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e < n) tc_base_cell(*c, e);
 }
+// phase 1 of every (TAS flavor, request class) over the work plane, one wave each, right before k_process_tas starts its walk
+__global__ __launch_bounds__(64) void k_tas_cycle_classes(const TCyc* __restrict__ c) {
+  tc_class_init(*c, (int)blockIdx.x / c->ncls, (int)blockIdx.x % c->ncls);
+}
 __global__ __launch_bounds__(64) void k_nominate_tas(const K* __restrict__ kp, int slots) {
   const K& k = *kp;
   __shared__ Wave w;
@@ -48,6 +52,11 @@ namespace kq {
 hipError_t launch_tas_base_k(const TCyc* c, int n, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_tas_base, dim3((n + 255) / 256), dim3(256), 0, stream, c, n);
+  return hipGetLastError();
+}
+hipError_t launch_tas_cycle_classes_k(const TCyc* c, int n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_tas_cycle_classes, dim3(n), dim3(64), 0, stream, c);
   return hipGetLastError();
 }
 hipError_t launch_nominate_tas_k(const K* d, int slots, hipStream_t stream) {

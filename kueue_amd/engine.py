@@ -72,12 +72,12 @@ class Engine:
         from .tas_cycle import CycleTASOut
         d = Decisions(heads, tgt_cap=tgt_cap, rsn_cap=rsn_cap)
         out = CycleTASOut(ct, dom_cap=dom_cap)
-        ts = np.zeros(3, np.int64)
+        ts = np.zeros(4, np.int64)
         self._check(self._lib.kq_cycle_run_tas(self._h, C.byref(heads.struct()), C.byref(ct.struct()), C.byref(d.struct()), C.byref(out.struct()), F.ptr(ts)))
         ms, by = C.c_double(), C.c_int64()
         self._lib.kq_last_cycle_stats(self._h, C.byref(ms), C.byref(by))
         d.kernel_ms, d.bytes = ms.value, by.value
-        d.tas_stats = dict(finds=int(ts[0]), recomputes=int(ts[1]), unsupported=bool(ts[2]))
+        d.tas_stats = dict(finds=int(ts[0]), recomputes=int(ts[1]), unsupported=bool(ts[2]), class_hits=int(ts[3]))
         return d, out
 
     def heads_put(self, heads: Heads, batch: int):

@@ -64,7 +64,7 @@ type TASCycle struct {
 type TASCycleOut struct {
 	PsTAS, DomOff, DomLeaf, DomCount []int32
 	UsageAfter                       []int64 // optional: leaf usage of every TAS flavor after the cycle, concatenated
-	Stats                            [3]int64 // placements computed, recomputations inside processEntry, reserved
+	Stats                            [4]int64 // placements computed, recomputations inside processEntry, outside-the-path flag, class-table starts
 }
 
 func NewTASCycleOut(nPodsets, domCap int, usageCells int) *TASCycleOut {

@@ -179,6 +179,7 @@ struct EmuBackend {
   }
   // kq_cycle_run_tas (kq_tas_cycle.hpp)
   void launch_tas_base(const TCyc* c, int n) { for (int e = 0; e < n; e++) tc_base_cell(*c, e); }
+  void launch_tas_cycle_classes(const TCyc* c, int n) { for (int i = 0; i < n; i++) tc_class_init(*c, i / c->ncls, i % c->ncls); }
   void launch_nominate_tas(const K& k, int slots) {
     for (int slot = 0; slot < slots; slot++) { Wave w{}; for (int h = slot; h < hn(k.H); h += slots) nominate_head(k, w, h, slot); }
   }

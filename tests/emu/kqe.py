@@ -263,7 +263,7 @@ def _run_tas(self, heads, ct, tgt_cap=None, want_usage=False, dom_cap=None):
     from kueue_amd.tas_cycle import CycleTASOut
     d = Decisions(heads, tgt_cap=tgt_cap)
     out = CycleTASOut(ct, dom_cap=dom_cap)
-    ts = np.zeros(3, np.int64)
+    ts = np.zeros(4, np.int64)
     rc = lib().kqe_cycle_run_tas(self.h, C.byref(heads.struct()), C.byref(ct.struct()), C.byref(d.struct()), C.byref(out.struct()), F.ptr(ts))
     d.rc = rc
     d.error = lib().kqe_last_error(self.h).decode()
@@ -274,7 +274,7 @@ def _run_tas(self, heads, ct, tgt_cap=None, want_usage=False, dom_cap=None):
     b = C.c_int64()
     lib().kqe_last_bytes(self.h, C.byref(b))
     d.bytes = b.value
-    d.tas_stats = dict(finds=int(ts[0]), recomputes=int(ts[1]), unsupported=bool(ts[2]))
+    d.tas_stats = dict(finds=int(ts[0]), recomputes=int(ts[1]), unsupported=bool(ts[2]), class_hits=int(ts[3]))
     return d, out
 
 

@@ -16,6 +16,7 @@ from tests.tasgen_cycle import random_tas_cycle_case
 from tests.test_oracle_schedule_tas import check_case
 
 CASES = load_golden("schedule_tas.yaml")["cases"]
+_LAST = {}
 
 
 def _emu(cfg):
@@ -70,6 +71,7 @@ def _same(oracle, make, cfg, snap, heads, ct, tgt_cap=None):
     assert np.array_equal(wout.a["dom_leaf"][:m], gout.a["dom_leaf"][:m]) and np.array_equal(wout.a["dom_count"][:m], gout.a["dom_count"][:m])
     assert np.array_equal(wout.a["tas_usage_after"], gout.a["tas_usage_after"])
     assert want.tas_stats["recomputes"] == got.tas_stats["recomputes"]
+    _LAST["class_hits"] = _LAST.get("class_hits", 0) + got.tas_stats.get("class_hits", 0)
     return want
 
 
@@ -130,3 +132,41 @@ def test_fair_sharing_is_refused(oracle):
     got, _ = eng.run_tas(heads, ct)
     eng.close()
     assert got.rc == -4   # KQ_EUNSUPPORTED
+
+
+def _population(oracle, make, n_cq, n_pending, **topo):
+    """BASELINE configs[4] as whole cycles (kueue_amd/tas_population.py generate_tas_cycle): one TAS flavor shared by every ClusterQueue, so
+    most entries lose their leaves to an earlier entry and are recomputed inside processEntry — the path of the resident request-class
+    tables (kq_tas_cycle.hpp) and of their incremental update after every AddUsage."""
+    from kueue_amd.api import make_config
+    from kueue_amd.tas_population import generate_tas_cycle
+    snap, _, batch = generate_tas_cycle(n_cq=n_cq, n_pending=n_pending, **topo)
+    cfg = make_config()
+    oracle.derive(snap)
+    rec = 0
+    for c in range((n_pending + n_cq - 1) // n_cq):
+        heads, ct = batch(c)
+        want = _same(oracle, make, cfg, snap, heads, ct)
+        rec += want.tas_stats["recomputes"]
+    return rec, _LAST.get("class_hits", 0)
+
+
+@pytest.mark.parametrize("classes_off", [False, True])
+def test_tas_cycle_population_emulated(oracle, classes_off, monkeypatch):
+    if classes_off:
+        monkeypatch.setenv("KQ_TAS_CLASSES_OFF", "1")
+    _LAST.clear()
+    rec, hits = _population(oracle, _emu, 120, 360, blocks=2, racks=4, hosts=16)
+    assert rec > 100   # the recomputation chain is what this test is about
+    assert (hits == 0) if classes_off else (hits >= rec)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("classes_off", [False, True])
+def test_tas_cycle_population_gpu(oracle, classes_off, monkeypatch):
+    if classes_off:
+        monkeypatch.setenv("KQ_TAS_CLASSES_OFF", "1")
+    _LAST.clear()
+    rec, hits = _population(oracle, _hip, 400, 800)
+    assert rec > 300
+    assert (hits == 0) if classes_off else (hits >= rec)

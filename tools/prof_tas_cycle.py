@@ -22,7 +22,8 @@ for h, ct in bs[1:]:
     d, _ = eng.run_tas(h, ct); n += h.n; rec += d.tas_stats["recomputes"]
 lib.kq_debug_prof(eng._h, F.ptr(prof), 1)
 names = {40: "head + first fits", 41: "before the recomputation", 42: "recomputation (get_assignments)", 43: "publish + second fits", 44: "usage added, result written",
-         45: "  of which: placements (t_workload, incl. k_nominate_tas's)", 46: "  of which: phase 1 of the placements"}
+         48: "  recomputation: WorkloadsTopologyRequests", 49: "  recomputation: the find (request block + placement)", 47: "    request / argument block", 45: "    placement (t_workload)",
+         46: "      phase 1 of the placement", 50: "  recomputation: keeping the result"}
 for i, nm in names.items():
     print(f"{nm:60s} {prof[i]/n:10.1f} cycles/entry  ({prof[i]/n/2400:.2f} us at 2.4 GHz)")
 print(f"{n} entries, {rec} recomputations; kernel ms last cycle {d.kernel_ms}")
