@@ -33,6 +33,9 @@ def random_tas_cycle_case(seed, roomy=False, **kw):
     cqs = {c.name: c for c in snap.cluster_queues}
     pod_tas = {}
     pending = heads.workloads
+    rg = random.Random(seed * 31 + 7)   # (its own stream: the populations of the earlier seeds stay what they were)
+    # leader + workers (PodSetGroupName): the API admits one leader pod per group, findLeaderAndWorkers :668 takes the smaller podset
+    grouped = {w.name for w in pending if len(w.pod_sets) == 2 and min(ps.count for ps in w.pod_sets) == 1 and rg.random() < 0.7}
     for w in pending:
         for pi, ps in enumerate(w.pod_sets):
             tr = None
@@ -46,7 +49,9 @@ def random_tas_cycle_case(seed, roomy=False, **kw):
             elif k < 0.7 and ps.count > 1:
                 tr = TopologyRequest(required=levels[0], slice_required_topology=levels[-1], slice_size=rnd.choice([s for s in (1, 2, 3) if ps.count % s == 0]))
             per_pod = {r: (q // ps.count if ps.count else 0) for r, q in ps.requests.items() if r != "pods"}
-            pt = PodSetTAS(tr, None, per_pod)
+            if w.name in grouped and pi == 1:   # both podsets of a group carry the same request (the reference validates that)
+                tr = pod_tas[(w.name, 0)].topology_request
+            pt = PodSetTAS(tr, "grp" if w.name in grouped else None, per_pod)
             pod_tas[(w.name, pi)] = pt
             ex = excluded_flavors_for_tas(cqs[w.cluster_queue], [r for r in ps.requests if r != "pods" or True], pt, topologies, fl)
             ps.excluded_flavors = sorted(set(ps.excluded_flavors) | set(ex))

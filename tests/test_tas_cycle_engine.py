@@ -170,3 +170,19 @@ def test_tas_cycle_population_gpu(oracle, classes_off, monkeypatch):
     rec, hits = _population(oracle, _hip, 400, 800)
     assert rec > 300
     assert (hits == 0) if classes_off else (hits >= rec)
+
+
+def test_dom_cap_too_small_is_reported(oracle):
+    """The caller's TopologyAssignment arrays are sized by dom_cap: a cycle that needs more says KQ_ECAPACITY, it does not truncate."""
+    from kueue_amd.api import make_config
+    from kueue_amd.tas_population import generate_tas_cycle
+    snap, _, batch = generate_tas_cycle(n_cq=20, n_pending=20, blocks=1, racks=2, hosts=8)
+    oracle.derive(snap)
+    heads, ct = batch(0)
+    eng = _emu(make_config())
+    eng.put(snap)
+    ok, out = eng.run_tas(heads, ct)
+    assert ok.rc == 0 and int(out.a["dom_off"][heads.n_ps]) > 1
+    bad, _ = eng.run_tas(heads, ct, dom_cap=1)
+    eng.close()
+    assert bad.rc == -5   # KQ_ECAPACITY
