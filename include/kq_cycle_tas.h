@@ -12,6 +12,7 @@
  * The oracle (oracle/kq_oracle.cpp kqo_cycle_run_tas) consumes the same two structs.
  * Host side, as for include/kq_tas.h: topology trees, node feasibility (leaf_ok), level-key resolution per TAS flavor,
  * checkPodSetAndFlavorMatchForTAS (tas_flavorassigner.go:164 -> folded into kq_heads.ps_flavor_ok like taints and affinity).
+ * A failed placement leaves a KQ_RSN_TAS_FAILURE reason record (kq_engine.h) when out->rsn_cap > 0.
  * Outside (KQ_EUNSUPPORTED or left to the caller): fair sharing together with TAS, a workload whose podsets land on more than one TAS
  * flavor (TASHandleOverlappingFlavors), balanced placement, node replacement, workloads that hold a previous admission (second pass).
  */

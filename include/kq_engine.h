@@ -250,6 +250,9 @@ typedef struct kq_heads {
 #define KQ_RSN_RESOURCE_UNAVAILABLE  5  /* :1080: no resource group of the ClusterQueue covers `resource`                         */
 #define KQ_RSN_SLICE_FLAVOR_MISMATCH 6  /* :1132-1137: "could not assign %s flavor since the original workload is assigned: %s";
                                          * flavor = the flavor tried, a = the old slice's flavor for `resource` (-1: none)          */
+#define KQ_RSN_TAS_FAILURE         200  /* kq_cycle_run_tas only (flavorassigner.go:871-877): the placement of the podset's TAS request failed on the
+                                           snapshot, psAssignment.reason(failure.Reason): flavor = the TAS flavor, a = KQ_TAS_* status, b / c = its
+                                           operands (include/kq_tas.h; notFitMessage tas_flavor_snapshot.go:1997 is regenerated from them)              */
 #define KQ_RSN_TRUNCATED           255  /* not a reference reason: the head produced more records than its window holds; the list
                                          * returned for that head is incomplete (flavor = resource = -1). Retry with a larger rsn_cap. */
 

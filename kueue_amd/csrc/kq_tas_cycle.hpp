@@ -215,6 +215,11 @@ KQ_DEV void tc_class_update(const K& k, const Wave& w) {
   }
 }
 
+KQ_DEV int tc_flavor_of(const TCyc& c, int nF, int t) {  // the ResourceFlavor of TAS flavor t (inverse of tas_of_flavor)
+  for (int f = 0; f < nF; f++) if (c.tas_of_flavor[f] == t) return f;
+  return -1;
+}
+
 // ---- Assign's TAS step -------------------------------------------------------------------------------------------------------------------
 KQ_DEV void tc_reset(Wave& w) {
   if (lane_id() == 0) { w.ta.t = -1; w.ta.nreq = 0; w.ta.af_early = 0; w.ta.err_mask = 0; w.ta.has_mask = 0; w.ta.kept_used = 0; w.ta.srch = 0; }
@@ -269,12 +274,12 @@ KQ_NOINLINE void tc_requests(const K& k, Wave& w) {
   }
   wsync();
 }
-struct TcFail { bool failed; int ps, status; };
+struct TcFail { bool failed; int ps, status; int32_t a, b; };
 // ClusterQueueSnapshot.FindTopologyAssignmentsForWorkload clusterqueue_snapshot.go:204-237 for the requests in w.ta on plane `which`;
 // the domains land in half 1 of the slot's store. Failure = TASAssignmentsResult.Failure :411 (first failing podset).
 KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, int which) {
   const TCyc& c = *k.tc;
-  TcFail f{false, -1, 0};
+  TcFail f{false, -1, 0, 0, 0};
   const int n = w.ta.nreq;
   if (n == 0) return f;
   KQ_T0();
@@ -347,7 +352,7 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
   wsync();
   for (int i = 0; i < n; i++) {
     const int st = qi[TQ_STATUS + i];
-    if (st != KQ_TAS_OK && st != KQ_TAS_SKIPPED) { f.failed = true; f.ps = w.ta.req_ps[i]; f.status = st; break; }
+    if (st != KQ_TAS_OK && st != KQ_TAS_SKIPPED) { f.failed = true; f.ps = w.ta.req_ps[i]; f.status = st; f.a = qi[TQ_OPA + i]; f.b = qi[TQ_OPB + i]; break; }
   }
   return f;
 }
@@ -381,8 +386,15 @@ KQ_DEV void tc_assign_tas(const K& k, Wave& w, int slot) {
   if (w.rep_mode == M_FIT) {
     const TcFail f = tc_find(k, w, slot, false, w.ta.plane);
     if (w.ta.plane != 0) KQ_TS(k, 49); // the find (47 + 45 inside it)
-    if (f.failed) tc_update_mode(k, w, f.ps, M_PREEMPT);   // (+ psAssignment.reason(failure.Reason): the message stays host-side)
-    else tc_keep_result(k, w, slot);
+    if (f.failed) {
+      // psAssignment.reason(failure.Reason) :875: the operands of the message (KQ_RSN_TAS_FAILURE); a Fit assignment holds no other reason
+      if (lane_id() == 0) {
+        rsn_push(k, w, KQ_RSN_TAS_FAILURE, f.ps, tc_flavor_of(*k.tc, k.S.nF, w.ta.t), -1, f.status, f.a, f.b);
+        if (k.O.rsn_win > 0) k.O.rsn_n[w.h] = w.rsn_over ? -w.nrsn : w.nrsn;
+      }
+      wsync();
+      tc_update_mode(k, w, f.ps, M_PREEMPT);
+    } else tc_keep_result(k, w, slot);
     if (w.ta.plane != 0) KQ_TS(k, 50); // keep the result
   }
   if (w.rep_mode == M_PREEMPT) {

@@ -24,6 +24,7 @@ RSN_NOT_IN_NOMINATION = 3      # flavor skipped by the nomination mapping of a r
 RSN_FLAVOR_INELIGIBLE = 4      # checkFlavorForPodSets failed on the host (ps_flavor_ok bit clear)
 RSN_RESOURCE_UNAVAILABLE = 5   # no resource group of the ClusterQueue covers the resource
 RSN_SLICE_FLAVOR_MISMATCH = 6  # workload slices: flavor = the flavor tried, a = the replaced slice's flavor for the resource
+RSN_TAS_FAILURE = 200          # kq_cycle_run_tas: the podset's TAS placement failed on the snapshot; a = KQ_TAS_* status, b / c = its operands
 RSN_TRUNCATED = 255
 
 UNLIMITED = (1 << 63) - 1
@@ -90,8 +91,25 @@ def amount_string(resource: str, a: int, binary_resources=()) -> str:
     return quantity_string(resource, a, binary_resources)
 
 
+def tas_failure_text(topology_name: str, status: int, a: int, b: int, slice_size: int = 1) -> str:
+    """TASAssignmentsResult.Failure().Reason from the operands of a KQ_RSN_TAS_FAILURE record: notFitMessage
+    (tas_flavor_snapshot.go:1997) and the fixed strings of findTopologyAssignment (:886-947). The node-exclusion statistics the
+    reference appends to the "doesn't allow to fit any" form ("Total nodes: N; excluded: ...") are not carried by the operands."""
+    from . import tas as T
+    if status == T.TAS_NOT_FIT:
+        unit = "pod" if slice_size == 1 else "slice"
+        if a == 0:
+            return f'topology "{topology_name}" doesn\'t allow to fit any of {b} {unit}(s)'
+        return f'topology "{topology_name}" allows to fit only {a} out of {b} {unit}(s)'
+    if status == T.TAS_NOT_FIT_LAYERS:
+        return f'topology "{topology_name}" doesn\'t allow to fit'
+    return {T.TAS_NO_LEVEL: "no requested topology level", T.TAS_SLICE_ABOVE: "podset slice topology is above the podset topology",
+            T.TAS_BAD_SLICE_SIZE: "slice topology requested, but slice size not provided"}.get(status, f"topology-aware placement failed (status {status})")
+
+
 def reason_text(snap, code: int, flavor: int, resource: int, a: int, b: int, c: int,
-                ineligible: Optional[Callable[[int, int], List[str]]] = None, podset: int = 0) -> List[str]:
+                ineligible: Optional[Callable[[int, int], List[str]]] = None, podset: int = 0,
+                tas: Optional[Callable[[int, int, int, int, int], str]] = None) -> List[str]:
     """One record -> the reason string(s) the reference appends to Status.reasons."""
     fl = snap.flavors[flavor] if flavor >= 0 else ""
     rs = snap.resources[resource] if resource >= 0 else ""
@@ -106,12 +124,14 @@ def reason_text(snap, code: int, flavor: int, resource: int, a: int, b: int, c: 
         return list(ineligible(podset, flavor)) if ineligible else [f"flavor {fl} is not eligible for the pod set"]
     if code == RSN_RESOURCE_UNAVAILABLE:
         return [f"resource {rs} unavailable in ClusterQueue"]
+    if code == RSN_TAS_FAILURE:   # flavorassigner.go:875; tas(podset, flavor, status, a, b): the caller knows the topology's name and the slice size
+        return [tas(podset, flavor, a, b, c) if tas else tas_failure_text(fl, a, b, c)]
     if code == RSN_SLICE_FLAVOR_MISMATCH:   # flavorassigner.go:1134
         return [f"could not assign {fl} flavor since the original workload is assigned: {snap.flavors[a] if a >= 0 else ''}"]
     raise ValueError(code)
 
 
-def podset_reasons(dec, i: int, ineligible=None) -> List[List[str]]:
+def podset_reasons(dec, i: int, ineligible=None, tas=None) -> List[List[str]]:
     """Per podset of head i: Status.reasons, sorted as Status.Message sorts them (flavorassigner.go:361)."""
     snap, heads = dec.snap, dec.heads
     nps = int(heads.arrays["ps_off"][i + 1] - heads.arrays["ps_off"][i])
@@ -123,7 +143,7 @@ def podset_reasons(dec, i: int, ineligible=None) -> List[List[str]]:
             raise OverflowError("reason window of the head overflowed: raise rsn_cap")
         ps = int(a["rsn_podset"][k])
         out[ps].extend(reason_text(snap, code, int(a["rsn_flavor"][k]), int(a["rsn_resource"][k]), int(a["rsn_a"][k]), int(a["rsn_b"][k]),
-                                   int(a["rsn_c"][k]), ineligible, ps))
+                                   int(a["rsn_c"][k]), ineligible, ps, tas))
     return [sorted(x) for x in out]
 
 

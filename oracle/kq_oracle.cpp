@@ -498,7 +498,6 @@ struct TasResult {
     return f;
   }
 };
-#define KQ_RSN_TAS_FAILURE 200  /* oracle-only reason code: the FailureReason string of a TAS placement (operands: status, a, b) */
 
 // tas_flavorassigner.go:37-83 (+ podSetTopologyRequest :92, onlyTASFlavor :142). MultiKueue / ProvisioningRequest delays, elastic
 // slices and unhealthy-node replacement are outside the boundary (the host keeps such workloads on the Go path).
@@ -1834,7 +1833,6 @@ int kqo_cycle_run_tas(const kq_config* cfg, const kq_snapshot* s, const kq_heads
   std::vector<Entry> entries;
   sch.schedule(entries);
   int rc = KQ_OK;
-  for (auto& e : entries) for (auto& ps : e.assignment.PodSets) ps.reasons.erase(std::remove_if(ps.reasons.begin(), ps.reasons.end(), [](const Reason& r) { return r.code == KQ_RSN_TAS_FAILURE; }), ps.reasons.end());
   writeDecisions(sn, h, entries, out, &rc);
   int nd = 0;
   tout->dom_off[0] = 0;

@@ -237,11 +237,11 @@ def tas_find(topo, rq, dom_cap=None):
     return out
 
 
-def cycle_run_tas(cfg: F.kq_config, snap: Snapshot, heads: Heads, ct, tgt_cap=None):
+def cycle_run_tas(cfg: F.kq_config, snap: Snapshot, heads: Heads, ct, tgt_cap=None, rsn_cap=0):
     """One scheduling cycle with Topology-Aware Scheduling inside it (include/kq_cycle_tas.h; ct = kueue_amd.tas_cycle.CycleTAS).
     -> (Decisions, CycleTASOut); Decisions.tas_stats = {finds, recomputes, unsupported}."""
     from kueue_amd.tas_cycle import CycleTASOut
-    d = Decisions(heads, tgt_cap=tgt_cap)
+    d = Decisions(heads, tgt_cap=tgt_cap, rsn_cap=rsn_cap)
     out = CycleTASOut(ct)
     ts = np.zeros(3, np.int64)
     l = lib()

@@ -55,6 +55,9 @@ func ReasonText(f *resources.ResourceFormatter, s *FlatSnapshot, code uint8, fla
 		return fmt.Sprintf("skipping flavor %s as it is not found in the nomination mapping for resource %s", fl, rs)
 	case RsnResourceUnavailable:
 		return fmt.Sprintf("resource %s unavailable in ClusterQueue", rs)
+	case RsnTASFailure: // kq_cycle_run_tas, flavorassigner.go:875: a = KQ_TAS_* status, b / c = its operands (notFitMessage tas_flavor_snapshot.go:1997);
+		// TASFailureText needs the topology's name and the podset's slice size: callers with that context use it directly
+		return TASFailureText(string(fl), int(a), int32(b), int32(c), 1)
 	case RsnSliceFlavorMismatch: // flavorassigner.go:1134; a = the replaced slice's flavor for the resource (-1: none)
 		orig := ""
 		if a >= 0 {
@@ -63,6 +66,38 @@ func ReasonText(f *resources.ResourceFormatter, s *FlatSnapshot, code uint8, fla
 		return fmt.Sprintf("could not assign %s flavor since the original workload is assigned: %s", fl, orig)
 	}
 	return ""
+}
+
+// RsnTASFailure = KQ_RSN_TAS_FAILURE (kq_engine.h).
+const RsnTASFailure = 200
+
+// TASFailureText words TASAssignmentsResult.Failure().Reason from the record's operands. The node-exclusion statistics the reference
+// appends to the "doesn't allow to fit any" form are not carried by the operands (the Go side can recompute them from its snapshot).
+func TASFailureText(topology string, status int, a, b int32, sliceSize int32) string {
+	const (
+		tasNotFit       = 1 // KQ_TAS_NOT_FIT ... (include/kq_tas.h)
+		tasNoLevel      = 2
+		tasSliceAbove   = 3
+		tasBadSliceSize = 4
+	)
+	unit := "pod"
+	if sliceSize != 1 {
+		unit = "slice"
+	}
+	switch status {
+	case tasNotFit:
+		if a == 0 {
+			return fmt.Sprintf("topology %q doesn't allow to fit any of %d %s(s)", topology, b, unit)
+		}
+		return fmt.Sprintf("topology %q allows to fit only %d out of %d %s(s)", topology, a, b, unit)
+	case tasNoLevel:
+		return "no requested topology level"
+	case tasSliceAbove:
+		return "podset slice topology is above the podset topology"
+	case tasBadSliceSize:
+		return "slice topology requested, but slice size not provided"
+	}
+	return fmt.Sprintf("topology %q doesn't allow to fit", topology)
 }
 
 // RsnTruncated = KQ_RSN_TRUNCATED (kq_engine.h): the head's reason window overflowed, its record list is incomplete.

@@ -258,10 +258,10 @@ class EmuEngine:
         return d
 
 
-def _run_tas(self, heads, ct, tgt_cap=None, want_usage=False, dom_cap=None):
+def _run_tas(self, heads, ct, tgt_cap=None, want_usage=False, dom_cap=None, rsn_cap=0):
     """kqe_cycle_run_tas: the cycle with TAS inside it on the emulated engine (include/kq_cycle_tas.h)."""
     from kueue_amd.tas_cycle import CycleTASOut
-    d = Decisions(heads, tgt_cap=tgt_cap)
+    d = Decisions(heads, tgt_cap=tgt_cap, rsn_cap=rsn_cap)
     out = CycleTASOut(ct, dom_cap=dom_cap)
     ts = np.zeros(4, np.int64)
     rc = lib().kqe_cycle_run_tas(self.h, C.byref(heads.struct()), C.byref(ct.struct()), C.byref(d.struct()), C.byref(out.struct()), F.ptr(ts))

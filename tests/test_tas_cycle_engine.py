@@ -48,11 +48,12 @@ class _AsOracle:
 
 
 def _same(oracle, make, cfg, snap, heads, ct, tgt_cap=None):
-    want, wout = oracle.cycle_run_tas(cfg, snap, heads, ct, tgt_cap=tgt_cap)
+    rsn_cap = 64 * max(heads.n_ps, 1)   # reason records too: the operands of every "why not Fit", the TAS placement's among them
+    want, wout = oracle.cycle_run_tas(cfg, snap, heads, ct, tgt_cap=tgt_cap, rsn_cap=rsn_cap)
     eng = make(cfg)
     eng.put(snap)
     try:
-        got, gout = eng.run_tas(heads, ct, tgt_cap=tgt_cap)
+        got, gout = eng.run_tas(heads, ct, tgt_cap=tgt_cap, rsn_cap=rsn_cap)
     except Exception as ex:   # the HIP engine raises on a refused cycle, the emulation returns the code
         assert want.tas_stats["unsupported"] and getattr(ex, "code", -4) == -4, ex
         return None
@@ -186,3 +187,25 @@ def test_dom_cap_too_small_is_reported(oracle):
     bad, _ = eng.run_tas(heads, ct, dom_cap=1)
     eng.close()
     assert bad.rc == -5   # KQ_ECAPACITY
+
+
+def test_tas_failure_message_of_the_reference(oracle):
+    """scheduler_tas_test.go "workload does not get scheduled as it does not fit within the node capacity": the reference's status message is
+    `couldn't assign flavors to pod set one: topology "tas-single-level" allows to fit only 1 out of 2 pod(s)` — regenerated from the
+    KQ_RSN_TAS_FAILURE record of the device code (flavorassigner.go:875; kueue_amd/messages.py tas_failure_text)."""
+    from kueue_amd import messages as M
+    case = next(c for c in CASES if c["name"] == "workload does not get scheduled as it does not fit within the node capacity")
+    cfg, snap, heads, ct = load_tas_case(case)
+    oracle.derive(snap)
+    eng = _emu(cfg)
+    eng.put(snap)
+    d, _ = eng.run_tas(heads, ct, rsn_cap=64)
+    eng.close()
+    assert d.rc == 0
+    recs = [k for k in range(int(d.a["rsn_off"][0]), int(d.a["rsn_off"][1])) if int(d.a["rsn_code"][k]) == M.RSN_TAS_FAILURE]
+    assert len(recs) == 1
+    tas = lambda ps, fl, st, a, b: M.tas_failure_text("tas-single-level", st, a, b, int(ct.arrays["ps_slice_size"][ps]))
+    names = [ps.name for ps in heads.workloads[0].pod_sets]
+    reasons = M.podset_reasons(d, 0, tas=tas)
+    msg = "; ".join(f"couldn't assign flavors to pod set {n}: " + ", ".join(r) for n, r in zip(names, reasons) if r)
+    assert msg == 'couldn\'t assign flavors to pod set one: topology "tas-single-level" allows to fit only 1 out of 2 pod(s)'
