@@ -612,14 +612,19 @@ template <class B> struct EngineT {
     const size_t nps = batches[0].nps;
     if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
     tout->dom_off[0] = 0;
-    if (t->n_tas == 0) {  // no TAS flavor in the snapshot: the ordinary cycle
+    // no TAS flavor in the snapshot and nothing asks for one: the ordinary cycle. (A podset that asks for TAS without any TAS flavor to
+    // land on still goes through WorkloadsTopologyRequests: ErrNoTASFlavorAssigned -> NoFit, tas_flavorassigner.go:60-66.)
+    bool any_request = false;
+    for (size_t p = 0; p < nps && t->ps_flags; p++) if (t->ps_flags[p] & KQ_PS_TAS_EXPLICIT) any_request = true;
+    for (int c = 0; c < prep.nq && t->cq_tas_only; c++) if (t->cq_tas_only[c]) any_request = true;
+    if (t->n_tas == 0 && !any_request) {
       rc = cycle_exec(0, out);
       for (size_t p = 0; p < nps; p++) { tout->ps_tas[p] = -1; tout->dom_off[p + 1] = 0; }
       return rc;
     }
-    const int nt = t->n_tas, R = t->topo[0].n_resources;
+    const int nt = t->n_tas, R = nt > 0 ? t->topo[0].n_resources : 1;
     if (R < 1 || R > KQ_TAS_MAXR) return fail(KQ_EUNSUPPORTED, "n_resources out of range");
-    if (!t->tas_flavor || !t->topo || !t->cq_tas_only || !t->adm_off || !t->ps_flags || !t->ps_kind || !t->ps_level || !t->ps_slice_size ||
+    if ((nt > 0 && (!t->tas_flavor || !t->topo)) || !t->cq_tas_only || !t->adm_off || !t->ps_flags || !t->ps_kind || !t->ps_level || !t->ps_slice_size ||
         !t->ps_slice_level || !t->ps_group || !t->ps_req) return fail(KQ_EINVAL, "null array in kq_cycle_tas");
     tnext = 0;
     const int slots = std::max(1, std::min(n, be.max_slots()));

@@ -15,7 +15,8 @@ package kqengine
 // What stays in Go, as in the reference: building the TASFlavorSnapshot of every TAS flavor (pkg/cache/scheduler/tas_flavor.go — nodes
 // matching the flavor's nodeLabels, free capacity, the domain tree in lexicographic levelValues order), isTASOnly (clusterqueue.go:746),
 // checkPodSetAndFlavorMatchForTAS (tas_flavorassigner.go:164, folded into FlatHeads.PsFlavorOK) and resolving every podset's level keys
-// against every TAS flavor (tas_flavor_snapshot.go:1197-1238). FlattenTAS below shows the field-by-field mapping.
+// against every TAS flavor (tas_flavor_snapshot.go:1197-1238). The flatten itself (FlattenTAS) belongs in pkg/cache/scheduler — the tree and
+// the leaf capacities of TASFlavorSnapshot are unexported — and fills TASCycle field by field as INTEGRATION.md tabulates.
 // NOT COMPILED HERE (no Go toolchain in the build image), see kqengine.go.
 
 /*
@@ -27,10 +28,15 @@ package kqengine
 import "C"
 
 import (
+	"errors"
 	"fmt"
 	"runtime"
 	"unsafe"
 )
+
+// ErrUnsupported = KQ_EUNSUPPORTED from kq_cycle_run_tas: fair sharing together with TAS, or a workload whose podsets land on two TAS
+// flavors. The caller runs this cycle on the stock Go path.
+var ErrUnsupported = errors.New("kqengine: the cycle is outside the device path (KQ_EUNSUPPORTED)")
 
 // FlatTopology is one TASFlavorSnapshot (include/kq_tas.h kq_tas_topology): domains of every level in lexicographic levelValues
 // order (utiltas.DomainID order, tas_flavor_snapshot.go:1770 sorts by it last), leaves last.
@@ -145,9 +151,21 @@ func (e *Engine) RunCycleTAS(h *FlatHeads, t *TASCycle, out *FlatDecisions, tout
 		co.tas_usage_after = (*C.int64_t)(pin(&p, tout.UsageAfter))
 	}
 	if rc := C.kq_cycle_run_tas(e.h, ch, ct, cd, co, (*C.int64_t)(unsafe.Pointer(&tout.Stats[0]))); rc != 0 {
+		if rc == C.KQ_EUNSUPPORTED {
+			return ErrUnsupported
+		}
 		return e.err("kq_cycle_run_tas", rc)
 	}
 	return nil
+}
+
+// UsageCells = length of TASCycleOut.UsageAfter: leaves x resources of every TAS flavor, concatenated.
+func (t *TASCycle) UsageCells() int {
+	n := 0
+	for i := range t.Topos {
+		n += len(t.Topos[i].TASUsage)
+	}
+	return n
 }
 
 // TopologyAssignmentOf turns a podset's (leaf, count) list back into the levels / domains of a kueue.TopologyAssignment

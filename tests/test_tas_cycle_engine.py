@@ -209,3 +209,13 @@ def test_tas_failure_message_of_the_reference(oracle):
     reasons = M.podset_reasons(d, 0, tas=tas)
     msg = "; ".join(f"couldn't assign flavors to pod set {n}: " + ", ".join(r) for n, r in zip(names, reasons) if r)
     assert msg == 'couldn\'t assign flavors to pod set one: topology "tas-single-level" allows to fit only 1 out of 2 pod(s)'
+
+
+def test_tas_request_without_any_tas_flavor(oracle):
+    """Found by the random campaign (seed 1607): a snapshot without TAS flavors but a podset that asks for TAS — WorkloadsTopologyRequests
+    still runs and turns the assignment into NoFit (ErrNoTASFlavorAssigned, tas_flavorassigner.go:60-66); the entry point must not take
+    its "no TAS flavor: ordinary cycle" shortcut then."""
+    cfg, snap, heads, ct, _ = random_tas_cycle_case(1607, fair=False, tight=False, preemption=True)
+    assert not ct.names and (ct.arrays["ps_flags"] & 1).any()
+    oracle.derive(snap)
+    _same(oracle, _emu, cfg, snap, heads, ct, tgt_cap=max(16, snap.n_adm))
