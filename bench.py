@@ -1093,7 +1093,7 @@ def pmc_traffic(workload, kernel):
     path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
     # the intervals bench.py times hold more than one kernel: the nominate interval = the lean pass (+ the full pass, + k_records),
     # the process interval = the speculative rounds + the serial kernel behind them
-    parts = {"k_nominate": ("k_nominate_lean", "k_nominate", "k_records"), "k_process": ("k_process_spec", "k_process")}.get(kernel, (kernel,))
+    parts = {"k_nominate": ("k_nominate_lean", "k_nominate", "k_records"), "k_process": ("k_process_spec", "k_process", "k_process_fair")}.get(kernel, (kernel,))
     try:
         with open(path) as f:
             tab = json.load(f)["traffic_bytes_per_launch"]
