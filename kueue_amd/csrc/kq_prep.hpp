@@ -241,19 +241,7 @@ inline void check_usage(const kq_snapshot* s, Prep& p) {
   for (size_t i = 0; i < (size_t)N * nfr && p.fs_plain; i++) if (s->usage[i] < 0 || (s->usage[i] >= LIM && s->usage[i] != U)) p.fs_plain = false;
 }
 
-#ifdef KQ_PREP_TIMES
-}  // namespace kq
-#include <chrono>
-namespace kq {
-static double g_prep_ms[16];
-#define PT(i) do { auto _n = std::chrono::steady_clock::now(); g_prep_ms[i] += std::chrono::duration<double, std::milli>(_n - _pt).count(); _pt = _n; } while (0)
-#define PT0() auto _pt = std::chrono::steady_clock::now()
-#else
-#define PT(i) do {} while (0)
-#define PT0() do {} while (0)
-#endif
 inline int build_prep(const kq_snapshot* s, Prep& p) {
-  PT0();
   p.nq = s->n_cq; p.nc = s->n_cohort; p.N = p.nq + p.nc; p.nF = s->n_flavor; p.nR = s->n_resource;
   p.nfr = p.nF * p.nR; p.n_adm = s->n_adm;
   const int N = p.N, nq = p.nq;
@@ -313,7 +301,6 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
       p.node_height[n] = h;
     }
   }
-  PT(0);
   // admitted rows
   p.adm_cq.assign(p.n_adm, -1);
   for (int c = 0; c < nq; c++) {
@@ -337,7 +324,6 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
         return a < b;
       });
   }
-  PT(1);
   p.tree_rows_asc = p.tree_rows;
   for (int t = 0; t < p.n_tree; t++) std::sort(p.tree_rows_asc.begin() + p.tree_row_off[t], p.tree_rows_asc.begin() + p.tree_row_off[t + 1]);
   p.frb_off.assign((size_t)p.n_tree * p.nfr + 1, 0);
@@ -363,11 +349,9 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
           if (first_use(r, e)) p.frb[fill[(size_t)t * p.nfr + s->adm_use_fr[e]]++] = i - p.tree_row_off[t];
       }
   }
-  PT(2);
   p.rank_pos.assign(p.n_adm, 0);
   for (int t = 0; t < p.n_tree; t++)
     for (int i = p.tree_row_off[t]; i < p.tree_row_off[t + 1]; i++) p.rank_pos[p.tree_rows[i]] = i - p.tree_row_off[t];
-  PT(3);
   // ---- scan-formulated classical search: row records, level orders of the buckets, bucket signatures ----
   {
     p.cs_ok.assign(p.n_tree, 1);
@@ -405,7 +389,6 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
         }
       }
     }
-  PT(4);
     // ---- kq_fs.hpp: candidates in position order, children lists in tree-node order ----
     for (int c = 0; c < nq; c++) if (p.depth[c] + 1 > FS_LV) p.fs_ok[p.tree_of[c]] = 0;
     if (p.nfr > 32767) for (auto& f : p.fs_ok) f = 0;
@@ -457,7 +440,6 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
         for (int i = s->child_cohort_off[kx]; i < s->child_cohort_off[kx + 1] && fill < nn; i++) p.fs_kid[n0 + fill++] = (int16_t)p.node_local[s->child_cohort[i]];
       }
     }
-  PT(5);
     p.frb_sig.assign((size_t)p.n_tree * p.nfr, 0);
     p.cs_max_bucket = 0;
     for (int l = 0; l < CS_LEVELS; l++) p.frl[l].assign(p.frb.size(), CsEnt{0, -1, 0, -1, 0});
@@ -514,7 +496,6 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
         }
       }
   }
-  PT(6);
   for (int t = 0; t < p.n_tree; t++) {
     p.max_tree_nodes = std::max(p.max_tree_nodes, p.tree_node_off[t + 1] - p.tree_node_off[t]);
     p.max_tree_cqs = std::max(p.max_tree_cqs, p.tree_cq_off[t + 1] - p.tree_cq_off[t]);
@@ -535,7 +516,6 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
       tot += (s->rg_flavor_off[g + 1] - s->rg_flavor_off[g]) * (2 * (s->rg_res_off[g + 1] - s->rg_res_off[g]) + 1);  // (a cell of a head that replaces a workload slice can leave two: flavor mismatch + quota)
     p.max_rsn_per_podset = std::max(p.max_rsn_per_podset, tot);
   }
-  PT(7);
   // ---- fair sharing constants (depend on SubtreeQuota / usage: recomputed after kq_snapshot_derive) ----
   p.h_parent.assign(s->parent, s->parent + N);
   p.h_ll.assign(s->lend_limit, s->lend_limit + (size_t)N * p.nfr);
@@ -584,7 +564,6 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
       }
     }
   }
-  PT(8);
   // index validation
   for (int g = 0; g < p.n_rg; g++) {
     for (int k = s->rg_flavor_off[g]; k < s->rg_flavor_off[g + 1]; k++) if (s->rg_flavor[k] < 0 || s->rg_flavor[k] >= p.nF) { p.err = "rg_flavor out of range"; return KQ_EINVAL; }
