@@ -982,8 +982,7 @@ def bench_tas_cycle(args, torch, dist, world, rank, local_rank):
     n_pending = max(n_cq, min(args.tas_batch, n_cq * (args.steps + args.warmup)))
     snap, topos, batch = generate_tas_cycle(n_cq=n_cq, n_pending=n_pending, seed=TAS_SEED + 1000 * rank)
     cfg = make_config()
-    from oracle import kqo   # the checker derives the snapshot's subtree quotas host-side, as the Go cache does before Snapshot()
-    kqo.derive(snap)
+    snap.derive()   # SubtreeQuota / cohort usage on the host, as the Go cache holds them before Snapshot() (kueue_amd/api.py)
     eng = Engine(cfg)
     eng.put(snap)
     nb = (n_pending + n_cq - 1) // n_cq
@@ -991,6 +990,7 @@ def bench_tas_cycle(args, torch, dist, world, rank, local_rank):
     topo = topos["tas-flavor"]
     parity = None
     if rank == 0 and not args.no_parity_gate:
+        from oracle import kqo   # the checker: parity gate here, cpu_baseline below — never inside the timed region
         h0, c0 = batches[0]
         want, wout = kqo.cycle_run_tas(cfg, snap, h0, c0)
         got, gout = eng.run_tas(h0, c0)
@@ -1062,6 +1062,7 @@ def bench_tas_cycle(args, torch, dist, world, rank, local_rank):
             "parity_checked": parity is not None, "parity": parity,
         }
         if not args.no_cpu_baseline and world == 1:
+            from oracle import kqo
             t1 = time.perf_counter()
             nd = 0
             for c in range(nb):
