@@ -1,18 +1,30 @@
 """Random TAS cycles beyond the pinned seeds: the emulated engine (tests/emu) against the oracle, kq_cycle_run_tas on every field.
-usage: python tools/fuzz_tas_cycle.py <first seed> <last seed>"""
+usage: python tools/fuzz_tas_cycle.py <first seed> <last seed> [hip]     (hip: the HIP engine through the C ABI instead of the emulation)"""
 import sys, numpy as np
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from oracle import kqo
 from tests.emu import kqe
 from tests.tasgen_cycle import random_tas_cycle_case
 lo,hi=int(sys.argv[1]),int(sys.argv[2])
+HIP = len(sys.argv) > 3 and sys.argv[3] == "hip"
+if HIP:
+    from kueue_amd.engine import Engine, EngineError
 bad=0; rec=0; fails=0; tg=0; uns=0
 for seed in range(lo,hi):
     cfg, snap, heads, ct, _ = random_tas_cycle_case(seed, fair=False, tight=seed%2==0, preemption=seed%3!=0, partial=seed%5==0)
     kqo.derive(snap)
     rc=64*max(heads.n_ps,1)
     want,wout=kqo.cycle_run_tas(cfg,snap,heads,ct,tgt_cap=max(16,snap.n_adm),rsn_cap=rc)
-    e=kqe.EmuEngine(cfg); e.put(snap); got,gout=e.run_tas(heads,ct,tgt_cap=max(16,snap.n_adm),rsn_cap=rc); e.close()
+    if HIP:
+        e=Engine(cfg); e.put(snap)
+        try:
+            got,gout=e.run_tas(heads,ct,tgt_cap=max(16,snap.n_adm),rsn_cap=rc); got.rc=0
+        except EngineError as ex:
+            assert want.tas_stats["unsupported"] and ex.code==-4, (seed, ex)
+            got=None
+        e.close()
+    else:
+        e=kqe.EmuEngine(cfg); e.put(snap); got,gout=e.run_tas(heads,ct,tgt_cap=max(16,snap.n_adm),rsn_cap=rc); e.close()
     if want.tas_stats["unsupported"]:
         uns+=1; continue
     n_ps=heads.n_ps; m=int(wout.a["dom_off"][n_ps])
