@@ -264,8 +264,53 @@ def snapshot_put_cost(eng, snap):
             fn()
             ms.append((time.perf_counter() - t1) * 1e3)
         return float(np.median(ms))
-    return {"put": med(lambda: eng.put(snap)), "patch_usage": med(lambda: eng.patch(snap, F.PATCH_USAGE)),
-            "patch_admitted": med(lambda: eng.patch(snap, F.PATCH_ADMITTED))}
+    out = {"put": med(lambda: eng.put(snap)), "patch_usage": med(lambda: eng.patch(snap, F.PATCH_USAGE)),
+           "patch_admitted": med(lambda: eng.patch(snap, F.PATCH_ADMITTED))}
+    # kq_snapshot_patch_rows: 100 rows leave, the same 100 come back (clusterqueue.go:594 one workload at a time) — the row table is
+    # compacted / extended and every derived structure rebuilt on the device; the C call alone, steady state
+    import ctypes as C
+    from kueue_amd.engine import row_patch_struct
+    a = snap.arrays
+    n = snap.n_adm
+    if n >= 200:
+        rows = np.arange(0, n, n // 100)[:100]
+        cq_of = np.repeat(np.arange(snap.n_cq), np.diff(a["cq_adm_off"]))
+        u0, u1 = a["adm_use_off"][rows], a["adm_use_off"][rows + 1]
+        idx = np.concatenate([np.arange(x, y) for x, y in zip(u0, u1)]).astype(np.int64)
+        add = dict(cq=cq_of[rows], priority=a["adm_priority"][rows], queue_ts=a["adm_queue_ts"][rows], reserve_ts=a["adm_reserve_ts"][rows],
+                   uid_rank=a["adm_uid_rank"][rows], flags=a["adm_flags"][rows], use_off=np.concatenate([[0], np.cumsum(u1 - u0)]),
+                   use_fr=a["adm_use_fr"][idx], use_qty=a["adm_use_qty"][idx])
+        eng.put(snap)
+        ms = []
+        new_index = np.zeros(n, np.int32)
+        try:
+            for _ in range(5):
+                # the rows to remove: wherever the 100 rows sit in the current table (they moved to the end of their ClusterQueue's segment)
+                cur = rows if not ms else cur_rows
+                p, keep = row_patch_struct(cur, add)
+                t1 = time.perf_counter()
+                eng._check(eng._lib.kq_snapshot_patch_rows(eng._h, C.byref(p), F_ptr(new_index)))
+                ms.append((time.perf_counter() - t1) * 1e3)
+                off = np.asarray(a["cq_adm_off"])
+                cur_rows = np.array([off[c + 1] - 1 - k for c, k in _tail_slots(cq_of[rows])], np.int32)
+            out["patch_rows_100"] = float(np.median(ms[1:]))
+        except Exception as ex:   # fair sharing: KQ_EUNSUPPORTED by design
+            out["patch_rows_100"] = None
+            out["patch_rows_note"] = str(ex)[:120]
+        eng.put(snap)
+    return out
+
+
+def _tail_slots(cqs):
+    """For rows appended to the end of their ClusterQueue's segment in the order given: (cq, distance from the segment's end) of each."""
+    from collections import Counter
+    total = Counter(cqs.tolist())
+    seen = Counter()
+    out = []
+    for c in cqs.tolist():
+        out.append((c, total[c] - 1 - seen[c]))
+        seen[c] += 1
+    return out
 
 
 def pending_cost(eng, pop):

@@ -312,6 +312,35 @@ int  kq_snapshot_put(kq_engine* e, const kq_snapshot* s);
 #define KQ_PATCH_ADMITTED  0x2u
 int  kq_snapshot_patch(kq_engine* e, const kq_snapshot* s, uint32_t what);
 
+/* The O(changes) form of KQ_PATCH_ADMITTED: what clusterQueue.updateWorkloadUsage (pkg/cache/scheduler/clusterqueue.go:594) does to
+ * cq.Workloads between two cycles — some admitted workloads left (finished, evicted and gone), some arrived (admitted by the last
+ * cycles) — handed over as the rows that left and the rows that came. The resident row table is compacted and extended ON THE DEVICE
+ * (removed rows drop out, the added rows land behind the kept rows of their ClusterQueue, in the order given) and every structure
+ * derived from it — candidate rank order per tree, flavor-resource buckets, level orders, row records — is rebuilt there by key
+ * sorts (kueue_amd/csrc/kq_rows.hpp); nothing of the admitted table crosses PCIe but the added rows. The result is byte-identical to
+ * kq_snapshot_put of the snapshot with that row table (tests/test_rows_device.py). Row indices of later calls (remove_rows,
+ * kq_decisions.tgt_adm, kq_heads.slice_row) refer to the new table: kept rows keep their order, `new_index` (optional, [n rows before
+ * the call]) receives the new index of every old row, -1 for a removed one.
+ * Usage is NOT touched: fold it with kq_cycle_commit / kq_cycle_release or KQ_PATCH_USAGE as before. add_uid_rank must be comparable
+ * with the resident rows' adm_uid_rank (any order-preserving 32-bit key of Obj.UID works; dense ranks do not survive insertions).
+ * KQ_EUNSUPPORTED (use kq_snapshot_patch): fair sharing (its position-order tables are still host-built), amounts outside the plain
+ * range, sizes beyond the sort keys' fields (2^20 rows, 2^21 nodes). */
+typedef struct kq_row_patch {
+  int32_t n_remove;
+  const int32_t* remove_rows;       /* [n_remove] distinct rows of the resident table, any order */
+  int32_t n_add;
+  const int32_t* add_cq;            /* [n_add] */
+  const int64_t* add_priority;      /* [n_add] as kq_snapshot.adm_priority ... */
+  const int64_t* add_queue_ts;
+  const int64_t* add_reserve_ts;
+  const uint32_t* add_uid_rank;
+  const uint8_t* add_flags;
+  const int32_t* add_use_off;       /* [n_add + 1] */
+  const int32_t* add_use_fr;
+  const int64_t* add_use_qty;
+} kq_row_patch;
+int  kq_snapshot_patch_rows(kq_engine* e, const kq_row_patch* p, int32_t* new_index);
+
 /* One scheduling cycle: nominate + iterator + processEntry (scheduler.go:308-386, steps 3-5).
  * Synchronous. `out` arrays are caller-allocated, sized from `h`. The uploaded snapshot is left
  * unchanged (the reference mutates a per-cycle copy). */
@@ -527,6 +556,11 @@ int  kq_snapshot_read_planes(kq_engine* e, int64_t* subtree_quota, int64_t* usag
 int  kq_debug_read_usage_work(kq_engine* e, int64_t* usage_out);
 int  kq_debug_force_exact_drs(kq_engine* e, int on);
 int  kq_debug_disable_scan_search(kq_engine* e, int on);  /* classical victim searches walk candidate by candidate */
+/* The admitted-row candidate structures (rank order per tree, flavor-resource buckets, level orders, row records ...) rebuilt on the device
+ * from the resident row table, and read back one by one (`which`: kueue_amd/csrc/kq_host.hpp read_rows; *bytes: capacity in, size out;
+ * KQ_ECAPACITY with the size when too small): tests compare the device-built structures with the host-built ones byte for byte. */
+int  kq_debug_rows_rebuild(kq_engine* e);
+int  kq_debug_read_rows(kq_engine* e, int32_t which, void* out, int64_t* bytes);
 int  kq_debug_prof(kq_engine* e, int64_t* out64, int reset);
 /* last cycle's speculative process rounds (kq_spec.hpp): [0] windows, [1] rounds, [2] entries they decided, [3] trees handed (partly)
  * back to the serial kernel, [4] (entry, flavor-resource) items, [5] most rounds of one window, [6] abandoned windows, [7] truncated */

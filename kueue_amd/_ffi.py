@@ -160,6 +160,11 @@ WL_ACTIVE, WL_INFLIGHT, WL_INADMISSIBLE, WL_GONE = 0, 1, 2, 3
 PATCH_USAGE, PATCH_ADMITTED = 1, 2
 
 
+class kq_row_patch(C.Structure):
+    _fields_ = [("n_remove", C.c_int32), ("remove_rows", i32p), ("n_add", C.c_int32), ("add_cq", i32p), ("add_priority", i64p), ("add_queue_ts", i64p),
+                ("add_reserve_ts", i64p), ("add_uid_rank", u32p), ("add_flags", u8p), ("add_use_off", i32p), ("add_use_fr", i32p), ("add_use_qty", i64p)]
+
+
 class kq_decisions(C.Structure):
     _fields_ = [
         ("status", u8p), ("action", u8p), ("nominated_mode", u8p), ("mode", u8p),
@@ -301,9 +306,10 @@ ABI_SYMBOLS = [
     "kq_engine_create", "kq_engine_destroy", "kq_snapshot_put", "kq_cycle_run", "kq_last_cycle_stats",
     "kq_cycle_commit", "kq_cycle_release", "kq_snapshot_derive", "kq_snapshot_read_planes", "kq_strerror", "kq_last_error", "kq_abi_version",
     "kq_heads_put", "kq_cycle_run_resident", "kq_nominate_run_resident", "kq_last_cycle_phases",
-    "kq_cycle_certificate", "kq_snapshot_usage_add", "kq_snapshot_patch", "kq_cycle_shard_words", "kq_cycle_nominate_shard", "kq_cycle_process_merged",
+    "kq_cycle_certificate", "kq_snapshot_usage_add", "kq_snapshot_patch", "kq_snapshot_patch_rows", "kq_cycle_shard_words", "kq_cycle_nominate_shard", "kq_cycle_process_merged",
     "kq_pending_bounds", "kq_pending_step", "kq_pending_step_wait",
     "kq_pending_afs_put", "kq_pending_afs_wl_penalty", "kq_pending_afs_sub_penalty", "kq_pending_afs_set_consumed", "kq_pending_afs_read",
     "kq_pending_set_lq_usage", "kq_pending_add", "kq_pending_delete", "kq_pending_set_clock", "kq_pending_set_requeue_at", "kq_pending_put", "kq_pending_heads", "kq_cycle_run_pending", "kq_pending_apply", "kq_pending_queue_inadmissible", "kq_pending_read_state",
     "kq_debug_read_usage_work", "kq_debug_force_exact_drs", "kq_debug_prof", "kq_debug_spec_stats", "kq_debug_disable_scan_search",
+    "kq_debug_rows_rebuild", "kq_debug_read_rows",
 ]

@@ -110,6 +110,12 @@ __global__ __launch_bounds__(256) void k_records(const K* __restrict__ kp) {
 // k_process_spec (speculative parallel rounds over the plain entries of a tree, kq_spec.hpp) is compiled in its own translation unit
 // (kq_spec_kernel.hip): it runs in front of k_process, which takes over at K::spec_resume[tree] (nothing left in the common case).
 namespace kq { hipError_t launch_process_spec(const K* d, int n_tree, hipStream_t stream); }
+// device-side rebuild of the admitted-row structures: kq_rows_kernel.hip (cell kernel + rocPRIM sort / scan)
+namespace kq {
+hipError_t rows_launch(const DRows& R, int op, int n, hipStream_t stream);
+hipError_t rows_sort_pairs(uint64_t*& key, int32_t*& val, uint64_t*& key2, int32_t*& val2, int n, int bits, hipStream_t stream);
+hipError_t rows_scan_excl(const int32_t* in, int32_t* out, int n, hipStream_t stream);
+}
 // kernels of kq_cycle_run_tas: kq_tas_cycle_kernel.hip
 namespace kq {
 hipError_t launch_tas_base_k(const TCyc* c, int n, hipStream_t stream);
@@ -696,6 +702,10 @@ struct HipBackend {
     hipLaunchKernelGGL(k_process, dim3(n_tree), dim3(PROCESS_THREADS), lds, stream, d, (unsigned)lds);
     chk(hipGetLastError(), "k_process");
   }
+  // admitted-row structures on the device (kq_rows_kernel.hip)
+  void launch_rows(const DRows& R, int op, int n) { chk(rows_launch(R, op, n, stream), "k_rows"); }
+  void sort_pairs(uint64_t*& key, int32_t*& val, uint64_t*& key2, int32_t*& val2, int n, int bits) { chk(rows_sort_pairs(key, val, key2, val2, n, bits, stream), "rows_sort_pairs"); }
+  void scan_excl(const int32_t* in, int32_t* out, int n) { chk(rows_scan_excl(in, out, n, stream), "rows_scan_excl"); }
   // kq_cycle_run_tas (kq_tas_cycle_kernel.hip)
   void launch_tas_base(const TCyc* c, int n) { chk(launch_tas_base_k(c, n, stream), "k_tas_base"); }
   void launch_tas_cycle_classes(const TCyc* c, int n) { chk(launch_tas_cycle_classes_k(c, n, stream), "k_tas_cycle_classes"); }
@@ -934,6 +944,12 @@ int kq_cycle_certificate(kq_engine* en, int64_t* usage_delta_dev, int64_t* root_
   (void)hipSetDevice(en->e.be.device);
   return en->e.cycle_certificate(usage_delta_dev, root_margin, flags);
 }
+int kq_snapshot_patch_rows(kq_engine* en, const kq_row_patch* p, int32_t* new_index) {
+  if (!en || !p) return KQ_EINVAL;
+  return en->e.snapshot_patch_rows(p, new_index);
+}
+int kq_debug_rows_rebuild(kq_engine* en) { return en ? en->e.debug_rows_rebuild() : KQ_EINVAL; }
+int kq_debug_read_rows(kq_engine* en, int32_t which, void* out, int64_t* bytes) { return (en && bytes) ? en->e.read_rows(which, out, bytes) : KQ_EINVAL; }
 int kq_cycle_run_tas(kq_engine* en, const kq_heads* h, const kq_cycle_tas* t, kq_decisions* out, kq_cycle_tas_out* tout, int64_t* stats) {
   if (!en || !h || !out) return KQ_EINVAL;
   return en->e.cycle_run_tas(h, t, out, tout, stats);

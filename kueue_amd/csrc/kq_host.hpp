@@ -17,6 +17,7 @@
 
 #include "kq_device.hpp"
 #include "kq_tas_cycle.hpp"
+#include "kq_rows.hpp"
 
 namespace kq {
 
@@ -216,8 +217,12 @@ template <class B> struct EngineT {
     // (cq < nq, req_res < nR, ps_flavor_ok / ps_last_tried row widths): a new snapshot voids them. kq_heads_put again.
     for (size_t b = 0; b < batches.size(); b++) if ((int)b != PEND_SLOT) batches[b].valid = false;
     prep.want_fs = cfg.fair_sharing != 0;
+    // the structures derived from the admitted rows are built on the device from the uploaded row table (kq_rows.hpp) unless fair
+    // sharing needs its host-built position-order tables or the sizes leave the sort keys' fields
+    prep.skip_rows = rows_device && !cfg.fair_sharing && s->n_adm < (1 << 20) && s->n_cq + s->n_cohort < (1 << 21);
     int rc = build_prep(s, prep);
     if (rc != KQ_OK) return fail(rc, prep.err);
+    if (prep.skip_rows && !rows_device_ok()) { prep.skip_rows = false; rc = build_prep(s, prep); if (rc != KQ_OK) return fail(rc, prep.err); }
     // the pending store is indexed by ClusterQueue / resource / flavor: it survives a snapshot refresh with the same dictionary
     if (pend.valid && (pend.nq != prep.nq || pend.nR != prep.nR || pend.nF != prep.nF || pend.n_tree != prep.n_tree)) pending_free();
     const size_t N = prep.N, nfr = prep.nfr, nq = prep.nq;
@@ -254,6 +259,7 @@ template <class B> struct EngineT {
     S.node_local = upload(prep.node_local.data(), prep.node_local.size());
     S.node_height = upload(prep.node_height.data(), prep.node_height.size());
     S.adm_cq = upload(prep.adm_cq.data(), prep.adm_cq.size());
+    h_adm_cq = prep.adm_cq; h_cq_adm_off.assign(s->cq_adm_off, s->cq_adm_off + prep.nq + 1);
     S.cq_local = upload(prep.cq_local.data(), prep.cq_local.size());
     S.tree_node_off = upload(prep.tree_node_off.data(), prep.tree_node_off.size());
     S.tree_nodes = upload(prep.tree_nodes.data(), prep.tree_nodes.size());
@@ -293,6 +299,7 @@ template <class B> struct EngineT {
     rc = be.sync();
     if (rc != KQ_OK) return fail(rc, be.error());
     have_snapshot = true;
+    if (prep.skip_rows) { rc = rows_rebuild(prep.n_adm); if (rc != KQ_OK) { have_snapshot = false; return rc; } }
     return KQ_OK;
   }
 
@@ -329,6 +336,7 @@ template <class B> struct EngineT {
       // host and replace the resident ones; quota planes, the tree and the resource groups are not touched
       Prep np;
       np.want_fs = cfg.fair_sharing != 0;
+      np.skip_rows = prep.skip_rows;
       int rc = build_prep(s, np);
       if (rc != KQ_OK) return fail(rc, np.err);
       prep = std::move(np);
@@ -339,6 +347,7 @@ template <class B> struct EngineT {
       reupload(S.adm_use_fr, s->adm_use_fr, (size_t)s->adm_use_off[prep.n_adm]); reupload(S.adm_use_qty, s->adm_use_qty, (size_t)s->adm_use_off[prep.n_adm]);
       reupload(S.adm_rts, s->adm_reserve_ts, (size_t)prep.n_adm); reupload(S.adm_uid, s->adm_uid_rank, (size_t)prep.n_adm);
       reupload(S.adm_cq, prep.adm_cq.data(), prep.adm_cq.size());
+      h_adm_cq = prep.adm_cq; h_cq_adm_off.assign(s->cq_adm_off, s->cq_adm_off + prep.nq + 1);
       reupload(S.tree_row_off, prep.tree_row_off.data(), prep.tree_row_off.size()); reupload(S.tree_rows, prep.tree_rows.data(), prep.tree_rows.size());
       reupload(S.tree_rows_asc, prep.tree_rows_asc.data(), prep.tree_rows_asc.size());
       reupload(S.rank_pos, prep.rank_pos.data(), prep.rank_pos.size());
@@ -349,6 +358,7 @@ template <class B> struct EngineT {
       reupload(S.frbr, prep.frbr.data(), prep.frbr.size()); reupload(S.frec, prep.frec.data(), prep.frec.size());
       reupload(S.frb_sig, prep.frb_sig.data(), prep.frb_sig.size()); reupload(S.cs_ok, prep.cs_ok.data(), prep.cs_ok.size());
       upload_fs_rows(); reupload(S.fs_ok, prep.fs_ok.data(), prep.fs_ok.size());  // the quota-derived tables stay (like S.lendable)
+      if (prep.skip_rows) { rc = be.sync(); if (rc != KQ_OK) return fail(rc, be.error()); rc = rows_rebuild(prep.n_adm); if (rc != KQ_OK) return rc; }
       what |= KQ_PATCH_USAGE;  // build_prep re-derived usage_consistent / fs_plain from s->usage: the plane must match
     } else if (what & KQ_PATCH_USAGE) {
       // usage-dependent flags of the prep: "cohort usage == what the children store in it" and the plain range of the amounts
@@ -358,6 +368,259 @@ template <class B> struct EngineT {
     int rc = be.sync();
     if (rc != KQ_OK) return fail(rc, be.error());
     return KQ_OK;
+  }
+
+  // ---- the admitted-row structures built on the device (kq_rows.hpp) ---------------------------------------------------------------------
+  Buf rb[12];
+  Buf rk2, rv2;        // second (key, value) pair of the sorts
+  Buf rs[20];          // the rebuilt structures live in grow-only buffers (a hipMalloc / hipFree pair per array and call cost more than the sorts)
+  Buf rt[2][10];       // the row table of kq_snapshot_patch_rows, double-buffered (the move reads the old table, writes the new one)
+  int rt_cur = 0;
+  // S.<field> now points into a persistent buffer: release the upload()ed array it pointed to before, if any
+  template <class T> void adopt(const T*& field, T* fresh) {
+    for (size_t i = 0; i < snap_allocs.size(); i++) if (snap_allocs[i] == (const void*)field) { be.free(snap_allocs[i]); snap_allocs.erase(snap_allocs.begin() + i); break; }
+    field = fresh;
+  }
+  bool rows_device = getenv("KQ_ROWS_HOST") == nullptr;   // (A/B switch: kq_snapshot_patch_rows rebuilds through the host path)
+  std::vector<int32_t> h_adm_cq, h_cq_adm_off;            // host mirrors the row patch needs: ClusterQueue of every row, CSR offsets
+  template <class T> void replace_dev(const T*& field, T* fresh) {
+    for (size_t i = 0; i < snap_allocs.size(); i++) if (snap_allocs[i] == (const void*)field) { be.free(snap_allocs[i]); snap_allocs.erase(snap_allocs.begin() + i); break; }
+    snap_allocs.push_back(fresh);
+    field = fresh;
+  }
+  template <class T> T* dev_new(size_t n) { return (T*)be.alloc(std::max<size_t>(n, 1) * sizeof(T)); }
+  bool rows_device_ok() const {
+    return !cfg.fair_sharing && prep.n_adm < (1 << 20) && prep.N < (1 << 21) && (int64_t)prep.n_tree * prep.nfr < (1 << 22);
+  }
+  // Rebuilds every structure derived from the admitted rows from the resident row table (S.cq_adm_off, S.adm_*): the device twin of
+  // build_prep's admitted part. n = rows, n_use = usage entries.
+  int rows_rebuild(int n) {
+    if (!rows_device_ok()) return fail(KQ_EUNSUPPORTED, "device-side row structures: fair sharing or sizes beyond the key layout");
+    const int nq = prep.nq, nfr = prep.nfr, n_tree = prep.n_tree, N = prep.N;
+    const size_t nb = (size_t)n_tree * nfr;
+    DRows R{};
+    R.n = n; R.nq = nq; R.nfr = nfr; R.n_tree = n_tree; R.N = N;
+    R.cq_adm_off = S.cq_adm_off; R.adm_use_off = S.adm_use_off; R.adm_use_fr = S.adm_use_fr; R.adm_prio = S.adm_prio; R.adm_qts = S.adm_qts;
+    R.adm_rts = S.adm_rts; R.adm_use_qty = S.adm_use_qty; R.adm_uid = S.adm_uid; R.adm_flags = S.adm_flags;
+    R.tree_of = S.tree_of; R.depth = S.depth; R.parent = S.parent; R.cq_local = S.cq_local; R.node_local = S.node_local;
+    // static part of the per-tree flags (build_prep): the tree's shape; the rows can only clear them
+    std::vector<uint8_t> cs0(std::max(n_tree, 1), 1), rec0(std::max(n_tree, 1), 1);
+    for (int c = 0; c < nq; c++) if (prep.depth[c] > CS_LEVELS) cs0[prep.tree_of[c]] = 0;
+    uint8_t* d_cs = grow<uint8_t>(rs[9], n_tree); uint8_t* d_rec = grow<uint8_t>(rs[10], n_tree);
+    be.h2d(d_cs, cs0.data(), std::max(n_tree, 1)); be.h2d(d_rec, rec0.data(), std::max(n_tree, 1));
+    R.cs_ok = d_cs; R.rec_ok = d_rec; R.fs_ok = grow<uint8_t>(rb[0], n_tree);   // (fair sharing is off here: fs_ok stays all zero, this is scratch)
+    // bits a sort key field really uses: a radix pass per 8 bits or so, so the tree / bucket / node fields are cut to their ranges
+    auto bits_of = [](int64_t maxv) { int b = 1; while (b < 63 && ((int64_t)1 << b) <= maxv) b++; return b; };
+    const int tree_bits = bits_of(std::max(n_tree - 1, 1));
+    // two pairs of (key, value) buffers: the sorts ping-pong between them
+    uint64_t* key2 = nullptr; int32_t* val2 = nullptr;
+    auto kv = [&](size_t m) {
+      R.key = (uint64_t*)grow<int64_t>(rb[1], m); R.val = grow<int32_t>(rb[2], m);
+      key2 = (uint64_t*)grow<int64_t>(rk2, m); val2 = grow<int32_t>(rv2, m);
+    };
+    kv(n);
+    R.ent_cnt = grow<int32_t>(rb[3], (size_t)n + 1); R.ent_off = grow<int32_t>(rb[4], (size_t)n + 1);
+    R.tree_cnt = grow<int32_t>(rb[5], (size_t)n_tree + 1); R.bcnt = grow<int32_t>(rb[6], nb + 1); R.scal = grow<int32_t>(rb[7], 4);
+    be.memset(R.ent_cnt, 0, ((size_t)n + 1) * 4); be.memset(R.scal, 0, 16);
+    // rows per tree from the CSR offsets (host mirror), scanned here: O(ClusterQueues)
+    std::vector<int32_t> tro((size_t)n_tree + 1, 0);
+    for (int c = 0; c < nq; c++) tro[prep.tree_of[c] + 1] += h_cq_adm_off[c + 1] - h_cq_adm_off[c];
+    for (int t = 0; t < n_tree; t++) tro[t + 1] += tro[t];
+    R.adm_cq = grow<int32_t>(rs[0], n); R.tree_row_off = grow<int32_t>(rs[1], (size_t)n_tree + 1); R.tree_rows = grow<int32_t>(rs[2], n);
+    R.tree_rows_asc = grow<int32_t>(rs[3], n); R.rank_pos = grow<int32_t>(rs[4], n); R.frb_off = grow<int32_t>(rs[5], nb + 1);
+    R.cq_row_bytes = grow<int32_t>(rs[6], nq); R.adm_rec = grow<AdmRec>(rs[7], n); R.frb_sig = (uint64_t*)grow<int64_t>(rs[8], nb);
+    be.memset(R.cq_row_bytes, 0, (size_t)std::max(nq, 1) * 4); be.memset(R.frb_sig, 0, std::max<size_t>(nb, 1) * 8);
+    be.launch_rows(R, RO_ROW_INIT, n);
+    be.sort_pairs(R.key, R.val, key2, val2, n, 32);
+    be.launch_rows(R, RO_KEY_RTS, n); be.sort_pairs(R.key, R.val, key2, val2, n, 64);
+    be.launch_rows(R, RO_KEY_PRIO, n); be.sort_pairs(R.key, R.val, key2, val2, n, 64);
+    if (n_tree > 1) { be.launch_rows(R, RO_KEY_TREE, n); be.sort_pairs(R.key, R.val, key2, val2, n, tree_bits); }
+    be.h2d(R.tree_row_off, tro.data(), tro.size() * 4);
+    be.launch_rows(R, RO_RANK, n);
+    // ascending rows per tree: the rows are in ascending order already, a stable sort by the tree alone groups them
+    be.launch_rows(R, RO_KEY_ASC, n); if (n_tree > 1) be.sort_pairs(R.key, R.val, key2, val2, n, tree_bits);
+    be.launch_rows(R, RO_ASC, n);
+    be.scan_excl(R.ent_cnt, R.ent_off, n + 1);
+    int32_t E = 0;
+    be.d2h(&E, R.ent_off + n, 4);
+    int rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    R.E = E;
+    kv(std::max(n, E));
+    R.frb = grow<int32_t>(rs[11], E); R.frbr = grow<int32_t>(rs[12], E); R.frec = grow<CsRec>(rs[13], E);
+    for (int l = 0; l < CS_LEVELS; l++) R.frl[l] = grow<CsEnt>(rs[14 + l], E);
+    be.launch_rows(R, RO_ENT_FILL, n);
+    be.sort_pairs(R.key, R.val, key2, val2, E, 32 + bits_of(std::max<int64_t>((int64_t)nb - 1, 1)));
+    be.launch_rows(R, RO_BOUNDS, E + 1);
+    be.launch_rows(R, RO_BUCKET_FILL, E);
+    be.launch_rows(R, RO_BUCKET_SIZE, (int)nb);
+    for (int l = 0; l < CS_LEVELS; l++) {
+      R.level = l;
+      be.launch_rows(R, RO_LKEY, E); be.sort_pairs(R.key, R.val, key2, val2, E, 42 + bits_of(std::max<int64_t>((int64_t)nb - 1, 1)));
+      be.launch_rows(R, RO_LFILL, E);
+    }
+    int32_t scal[4];
+    be.d2h(scal, R.scal, 16);
+    rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    prep.n_adm = n; S.n_adm = n;
+    prep.cs_max_bucket = scal[0];
+    prep.max_tree_rows = 0;
+    for (int t = 0; t < n_tree; t++) prep.max_tree_rows = std::max(prep.max_tree_rows, tro[t + 1] - tro[t]);
+    prep.tree_row_off = tro;
+    adopt(S.adm_cq, R.adm_cq); adopt(S.tree_row_off, R.tree_row_off); adopt(S.tree_rows, R.tree_rows);
+    adopt(S.tree_rows_asc, R.tree_rows_asc); adopt(S.rank_pos, R.rank_pos); adopt(S.frb_off, R.frb_off); adopt(S.frb, R.frb);
+    adopt(S.cq_row_bytes, R.cq_row_bytes); adopt(S.adm_rec, R.adm_rec); adopt(S.frbr, R.frbr); adopt(S.frec, R.frec);
+    for (int l = 0; l < CS_LEVELS; l++) adopt(S.frl[l], R.frl[l]);
+    adopt(S.frb_sig, R.frb_sig); adopt(S.cs_ok, d_cs); adopt(S.rec_ok, d_rec);
+    return KQ_OK;
+  }
+  // kq_snapshot_patch_rows (include/kq_engine.h): compaction + insertion of rows on the device, then rows_rebuild
+  int snapshot_patch_rows(const kq_row_patch* p, int32_t* new_index) {
+    if (!have_snapshot) return fail(KQ_EINVAL, "kq_snapshot_patch_rows before kq_snapshot_put");
+    if (!p || p->n_remove < 0 || p->n_add < 0) return fail(KQ_EINVAL, "bad kq_row_patch");
+    if (!rows_device || !rows_device_ok()) return fail(KQ_EUNSUPPORTED, "kq_snapshot_patch_rows: fair sharing / sizes beyond the device path (use kq_snapshot_patch)");
+    if (steps_issued != steps_waited) return fail(KQ_EINVAL, "a kq_pending_step is in flight (kq_pending_step_wait first)");
+    const int nq = prep.nq, n_old = prep.n_adm, n_rm = p->n_remove, n_add = p->n_add;
+    if ((int)h_adm_cq.size() != n_old || (int)h_cq_adm_off.size() != nq + 1) return fail(KQ_EINVAL, "host mirrors of the row table are missing");
+    if (n_rm > 0 && !p->remove_rows) return fail(KQ_EINVAL, "null remove_rows");
+    if (n_add > 0 && (!p->add_cq || !p->add_priority || !p->add_queue_ts || !p->add_reserve_ts || !p->add_uid_rank || !p->add_flags || !p->add_use_off))
+      return fail(KQ_EINVAL, "null array in kq_row_patch");
+    std::vector<int32_t> rm(p->remove_rows, p->remove_rows + n_rm);
+    std::sort(rm.begin(), rm.end());
+    for (int i = 0; i < n_rm; i++) if (rm[i] < 0 || rm[i] >= n_old || (i > 0 && rm[i] == rm[i - 1])) return fail(KQ_EINVAL, "remove_rows: out of range or repeated");
+    const int n_ause = n_add > 0 ? p->add_use_off[n_add] : 0;
+    if (n_add > 0 && p->add_use_off[0] != 0) return fail(KQ_EINVAL, "add_use_off[0] must be 0");
+    for (int i = 0; i < n_add; i++) {
+      if (p->add_cq[i] < 0 || p->add_cq[i] >= nq) return fail(KQ_EINVAL, "add_cq out of range");
+      if (p->add_use_off[i + 1] < p->add_use_off[i]) return fail(KQ_EINVAL, "add_use_off not monotone");
+    }
+    if (n_ause > 0 && (!p->add_use_fr || !p->add_use_qty)) return fail(KQ_EINVAL, "null usage entries in kq_row_patch");
+    for (int e = 0; e < n_ause; e++) {
+      if (p->add_use_fr[e] < 0 || p->add_use_fr[e] >= prep.nfr) return fail(KQ_EINVAL, "add_use_fr out of range");
+      if (p->add_use_qty[e] < 0 || p->add_use_qty[e] >= ((int64_t)1 << 50)) return fail(KQ_EUNSUPPORTED, "amount outside the plain range (kq_snapshot_patch rebuilds the flags)");
+    }
+    // new CSR offsets, the removed rows per ClusterQueue, the target of every added row: O(nq + changes) on the host
+    std::vector<int32_t> rm_off((size_t)nq + 1, 0), add_cnt(nq, 0), new_off((size_t)nq + 1, 0), target(std::max(n_add, 1));
+    for (int r : rm) rm_off[h_adm_cq[r] + 1]++;
+    for (int c = 0; c < nq; c++) rm_off[c + 1] += rm_off[c];
+    for (int i = 0; i < n_add; i++) add_cnt[p->add_cq[i]]++;
+    for (int c = 0; c < nq; c++) new_off[c + 1] = new_off[c] + (h_cq_adm_off[c + 1] - h_cq_adm_off[c]) - (rm_off[c + 1] - rm_off[c]) + add_cnt[c];
+    {
+      std::vector<int32_t> next(nq);
+      for (int c = 0; c < nq; c++) next[c] = new_off[c + 1] - add_cnt[c];
+      for (int i = 0; i < n_add; i++) target[i] = next[p->add_cq[i]]++;
+    }
+    const int n_new = new_off[nq];
+    DRows R{};
+    R.n_old = n_old; R.n_add = n_add; R.nq = nq;
+    R.old_cq_off = S.cq_adm_off; R.o_adm_cq = S.adm_cq;
+    Buf* T = rt[rt_cur ^ 1];   // the table the move writes; the resident one (rt[rt_cur], or the put's uploads) is only read
+    int32_t* d_new_off = grow<int32_t>(T[0], (size_t)nq + 1);
+    be.h2d(d_new_off, new_off.data(), ((size_t)nq + 1) * 4);
+    R.new_cq_off = d_new_off;
+    auto stage = [&](Buf& b, const void* host, size_t bytes) -> void* { void* d = grow<uint8_t>(b, bytes); if (bytes) be.h2d(d, host, bytes); return d; };
+    R.rm_off = (const int32_t*)stage(rb[8], rm_off.data(), ((size_t)nq + 1) * 4);
+    R.rm_rows = (const int32_t*)stage(rb[9], rm.data(), (size_t)n_rm * 4);
+    // the added rows in one staged region
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 15) & ~(size_t)15; return o; };
+    const size_t o_t = carve((size_t)n_add * 4), o_p = carve((size_t)n_add * 8), o_q = carve((size_t)n_add * 8), o_r = carve((size_t)n_add * 8), o_u = carve((size_t)n_add * 4),
+                 o_f = carve(n_add), o_uo = carve(((size_t)n_add + 1) * 4), o_uf = carve((size_t)n_ause * 4), o_uq = carve((size_t)n_ause * 8);
+    std::vector<uint8_t> st(std::max<size_t>(off, 16), 0);
+    if (n_add > 0) {
+      memcpy(&st[o_t], target.data(), (size_t)n_add * 4); memcpy(&st[o_p], p->add_priority, (size_t)n_add * 8); memcpy(&st[o_q], p->add_queue_ts, (size_t)n_add * 8);
+      memcpy(&st[o_r], p->add_reserve_ts, (size_t)n_add * 8); memcpy(&st[o_u], p->add_uid_rank, (size_t)n_add * 4); memcpy(&st[o_f], p->add_flags, n_add);
+      memcpy(&st[o_uo], p->add_use_off, ((size_t)n_add + 1) * 4);
+      if (n_ause > 0) { memcpy(&st[o_uf], p->add_use_fr, (size_t)n_ause * 4); memcpy(&st[o_uq], p->add_use_qty, (size_t)n_ause * 8); }
+    }
+    const uint8_t* d_st = (const uint8_t*)stage(rb[10], st.data(), st.size());
+    R.a_target = (const int32_t*)(d_st + o_t); R.a_prio = (const int64_t*)(d_st + o_p); R.a_qts = (const int64_t*)(d_st + o_q); R.a_rts = (const int64_t*)(d_st + o_r);
+    R.a_uid = (const uint32_t*)(d_st + o_u); R.a_flags = d_st + o_f; R.a_use_off = (const int32_t*)(d_st + o_uo); R.a_use_fr = (const int32_t*)(d_st + o_uf);
+    R.a_use_qty = (const int64_t*)(d_st + o_uq);
+    R.o_use_off = S.adm_use_off; R.o_use_fr = S.adm_use_fr; R.o_use_qty = S.adm_use_qty; R.o_prio = S.adm_prio; R.o_qts = S.adm_qts; R.o_rts = S.adm_rts;
+    R.o_uid = S.adm_uid; R.o_flags = S.adm_flags;
+    R.n_prio = grow<int64_t>(T[1], n_new); R.n_qts = grow<int64_t>(T[2], n_new); R.n_rts = grow<int64_t>(T[3], n_new); R.n_uid = grow<uint32_t>(T[4], n_new);
+    R.n_flags = grow<uint8_t>(T[5], n_new); R.n_use_off = grow<int32_t>(T[6], (size_t)n_new + 1);
+    R.n_ucnt = grow<int32_t>(rb[11], (size_t)n_new + 1);
+    be.memset(R.n_ucnt, 0, ((size_t)n_new + 1) * 4);
+    R.new_of_old = grow<int32_t>(rb[3], std::max(n_old, 1));   // (rb[3] = ent_cnt of the rebuild: free until then)
+    be.launch_rows(R, RO_MOVE_ROW, n_old);
+    be.launch_rows(R, RO_ADD_ROW, n_add);
+    be.scan_excl(R.n_ucnt, R.n_use_off, n_new + 1);
+    int32_t U = 0;
+    be.d2h(&U, R.n_use_off + n_new, 4);
+    std::vector<int32_t> noo(std::max(n_old, 1));
+    be.d2h(noo.data(), R.new_of_old, (size_t)n_old * 4);
+    int rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    R.n_use_fr = grow<int32_t>(T[7], U); R.n_use_qty = grow<int64_t>(T[8], U);
+    be.launch_rows(R, RO_MOVE_ENT, n_old + n_add);
+    rc = be.sync();   // (the staging vectors go out of scope below)
+    if (rc != KQ_OK) return fail(rc, be.error());
+    // the new row table becomes the resident one
+    adopt(S.cq_adm_off, d_new_off); adopt(S.adm_prio, R.n_prio); adopt(S.adm_qts, R.n_qts); adopt(S.adm_rts, R.n_rts);
+    adopt(S.adm_uid, R.n_uid); adopt(S.adm_flags, R.n_flags); adopt(S.adm_use_off, R.n_use_off);
+    adopt(S.adm_use_fr, R.n_use_fr); adopt(S.adm_use_qty, R.n_use_qty);
+    rt_cur ^= 1;
+    // host mirrors
+    std::vector<int32_t> ncq(std::max(n_new, 1));
+    for (int c = 0; c < nq; c++) for (int r = new_off[c]; r < new_off[c + 1]; r++) ncq[r] = c;
+    ncq.resize(n_new);
+    h_adm_cq.swap(ncq); h_cq_adm_off = new_off;
+    if (new_index) for (int r = 0; r < n_old; r++) new_index[r] = noo[r];
+    for (auto& c : ring) (void)c;   // (committed usage rows are keyed by ClusterQueue, not by admitted row: they stay valid)
+    last_cycle_n = -1;              // the last cycle's argument block names freed arrays
+    return rows_rebuild(n_new);
+  }
+  // test hook: the resident admitted-row structures, one by one (which: 0 adm_cq, 1 tree_row_off, 2 tree_rows, 3 tree_rows_asc, 4 rank_pos,
+  // 5 frb_off, 6 frb, 7 frbr, 8 cq_row_bytes, 9 adm_rec, 10 frec, 11-13 frl, 14 frb_sig, 15 cs_ok, 16 rec_ok, 17 cq_adm_off, 18 adm_use_off,
+  // 19 adm_use_fr, 20 adm_use_qty, 21 adm_prio, 22 adm_qts, 23 adm_rts, 24 adm_uid, 25 adm_flags). *bytes: capacity in, size out.
+  int read_rows(int which, void* out, int64_t* bytes) {
+    if (!have_snapshot) return fail(KQ_EINVAL, "no snapshot");
+    const size_t n = prep.n_adm, nb = (size_t)prep.n_tree * prep.nfr;
+    int32_t E = 0, U = 0;
+    if (nb > 0) be.d2h(&E, S.frb_off + nb, 4);
+    if (n > 0) be.d2h(&U, S.adm_use_off + n, 4);
+    int rc = be.sync();
+    if (rc != KQ_OK) return fail(rc, be.error());
+    const void* src = nullptr; size_t sz = 0;
+    switch (which) {
+      case 0: src = S.adm_cq; sz = n * 4; break;
+      case 1: src = S.tree_row_off; sz = ((size_t)prep.n_tree + 1) * 4; break;
+      case 2: src = S.tree_rows; sz = n * 4; break;
+      case 3: src = S.tree_rows_asc; sz = n * 4; break;
+      case 4: src = S.rank_pos; sz = n * 4; break;
+      case 5: src = S.frb_off; sz = (nb + 1) * 4; break;
+      case 6: src = S.frb; sz = (size_t)E * 4; break;
+      case 7: src = S.frbr; sz = (size_t)E * 4; break;
+      case 8: src = S.cq_row_bytes; sz = (size_t)prep.nq * 4; break;
+      case 9: src = S.adm_rec; sz = n * sizeof(AdmRec); break;
+      case 10: src = S.frec; sz = (size_t)E * sizeof(CsRec); break;
+      case 11: case 12: case 13: src = S.frl[which - 11]; sz = (size_t)E * sizeof(CsEnt); break;
+      case 14: src = S.frb_sig; sz = nb * 8; break;
+      case 15: src = S.cs_ok; sz = prep.n_tree; break;
+      case 16: src = S.rec_ok; sz = prep.n_tree; break;
+      case 17: src = S.cq_adm_off; sz = ((size_t)prep.nq + 1) * 4; break;
+      case 18: src = S.adm_use_off; sz = (n + 1) * 4; break;
+      case 19: src = S.adm_use_fr; sz = (size_t)U * 4; break;
+      case 20: src = S.adm_use_qty; sz = (size_t)U * 8; break;
+      case 21: src = S.adm_prio; sz = n * 8; break;
+      case 22: src = S.adm_qts; sz = n * 8; break;
+      case 23: src = S.adm_rts; sz = n * 8; break;
+      case 24: src = S.adm_uid; sz = n * 4; break;
+      case 25: src = S.adm_flags; sz = n; break;
+      default: return fail(KQ_EINVAL, "unknown structure");
+    }
+    if ((int64_t)sz > *bytes) { *bytes = (int64_t)sz; return fail(KQ_ECAPACITY, "buffer too small"); }
+    *bytes = (int64_t)sz;
+    if (sz) be.d2h(out, src, sz);
+    rc = be.sync();
+    return rc == KQ_OK ? KQ_OK : fail(rc, be.error());
+  }
+  int debug_rows_rebuild() {
+    if (!have_snapshot) return fail(KQ_EINVAL, "no snapshot");
+    return rows_rebuild(prep.n_adm);
   }
 
   // ---- closed loop: commit the last cycle's admissions into the snapshot, release them later --------------
@@ -490,7 +753,7 @@ template <class B> struct EngineT {
       for (int i = 0; i < h->n; i++) {
         const int row = h->slice_row[i];
         if (row < -1 || row >= prep.n_adm) return fail(KQ_EINVAL, "slice_row out of range");
-        if (row >= 0 && prep.adm_cq[row] != h->cq[i]) return fail(KQ_EINVAL, "slice_row: the replaced slice is not admitted in the head's ClusterQueue");
+        if (row >= 0 && h_adm_cq[row] != h->cq[i]) return fail(KQ_EINVAL, "slice_row: the replaced slice is not admitted in the head's ClusterQueue");
       }
     *slot_cap = cap;
     if (max_nps) *max_nps = mnps;

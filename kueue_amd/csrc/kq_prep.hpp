@@ -58,6 +58,15 @@ struct alignas(16) FsApply { int64_t qty[CS_RFR]; int16_t lp[FS_LV]; int16_t fr[
 struct alignas(16) FsQ { int64_t lq, sqb; };  // localQuota, SubtreeQuota (INT64_MAX where the node has no entry) of one (node, flavor-resource)
 static_assert(sizeof(FsScan) == 32 && sizeof(FsApply) == 64 && sizeof(FsQ) == 16, "FsScan / FsApply / FsQ are read as 32 / 64 / 16 byte records");
 
+// fingerprint of a bucket's row set (Prep::frb_sig): equal sets give equal values, different sets almost surely different ones
+#if defined(__HIP__) || defined(__HIPCC__)
+#define KQ_PREP_HD __host__ __device__ inline
+#else
+#define KQ_PREP_HD static inline
+#endif
+KQ_PREP_HD uint64_t frb_sig_row(int row) { uint64_t h = (uint64_t)(uint32_t)(row + 1) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; return h * 0xBF58476D1CE4E5B9ull; }
+KQ_PREP_HD uint64_t frb_sig_size(int M) { return (uint64_t)(uint32_t)M * 0xD6E8FEB86659FD93ull; }
+
 struct Prep {
   int nq = 0, nc = 0, N = 0, nF = 0, nR = 0, nfr = 0, n_adm = 0, n_rg = 0;
   std::vector<int32_t> depth, root, tree_of, node_local, node_height;
@@ -114,6 +123,7 @@ struct Prep {
   std::vector<double> h_weight;                    // host copy of fair_weight for build_fair after a device derive
   int max_tree_mw = 1;                             // words of a candidate bitmap of the largest tree
   bool want_fs = true;                             // build the kq_fs.hpp structures (the engine clears it when fair sharing is off)
+  bool skip_rows = false;                          // leave every structure derived from the admitted rows empty: the engine builds them on the device (kq_rows.hpp)
   int max_rsn_per_podset = 1;  // most reason records one podset's flavor scans can produce: max over ClusterQueues of sum over groups of flavors x (2 x resources + 1)
   std::string err;
 };
@@ -312,8 +322,8 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
     p.tree_row_off[p.tree_of[p.adm_cq[r]] + 1]++;
   }
   for (int t = 0; t < p.n_tree; t++) p.tree_row_off[t + 1] += p.tree_row_off[t];
-  p.tree_rows.assign(p.n_adm, 0);
-  {
+  p.tree_rows.assign(p.skip_rows ? 0 : p.n_adm, 0);
+  if (!p.skip_rows) {
     std::vector<int32_t> fr(p.tree_row_off.begin(), p.tree_row_off.end() - 1);
     for (int r = 0; r < p.n_adm; r++) p.tree_rows[fr[p.tree_of[p.adm_cq[r]]]++] = r;
     for (int t = 0; t < p.n_tree; t++)
@@ -325,12 +335,12 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
       });
   }
   p.tree_rows_asc = p.tree_rows;
-  for (int t = 0; t < p.n_tree; t++) std::sort(p.tree_rows_asc.begin() + p.tree_row_off[t], p.tree_rows_asc.begin() + p.tree_row_off[t + 1]);
+  for (int t = 0; t < p.n_tree && !p.skip_rows; t++) std::sort(p.tree_rows_asc.begin() + p.tree_row_off[t], p.tree_rows_asc.begin() + p.tree_row_off[t + 1]);
   p.frb_off.assign((size_t)p.n_tree * p.nfr + 1, 0);
   p.cq_row_bytes.assign(nq, 0);
   {
     auto first_use = [&](int row, int e) { for (int q = s->adm_use_off[row]; q < e; q++) if (s->adm_use_fr[q] == s->adm_use_fr[e]) return false; return true; };
-    for (int r = 0; r < p.n_adm; r++) {
+    for (int r = 0; r < p.n_adm && !p.skip_rows; r++) {
       p.cq_row_bytes[p.adm_cq[r]] += 32 + 12 * (s->adm_use_off[r + 1] - s->adm_use_off[r]);
       const int t = p.tree_of[p.adm_cq[r]];
       for (int e = s->adm_use_off[r]; e < s->adm_use_off[r + 1]; e++) {
@@ -342,15 +352,15 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
     for (size_t i = 0; i + 1 < p.frb_off.size(); i++) p.frb_off[i + 1] += p.frb_off[i];
     p.frb.assign(p.frb_off.back(), 0);
     std::vector<int32_t> fill(p.frb_off.begin(), p.frb_off.end() - 1);
-    for (int t = 0; t < p.n_tree; t++)
+    for (int t = 0; t < p.n_tree && !p.skip_rows; t++)
       for (int i = p.tree_row_off[t]; i < p.tree_row_off[t + 1]; i++) {  // rank order => every bucket is ascending
         const int r = p.tree_rows[i];
         for (int e = s->adm_use_off[r]; e < s->adm_use_off[r + 1]; e++)
           if (first_use(r, e)) p.frb[fill[(size_t)t * p.nfr + s->adm_use_fr[e]]++] = i - p.tree_row_off[t];
       }
   }
-  p.rank_pos.assign(p.n_adm, 0);
-  for (int t = 0; t < p.n_tree; t++)
+  p.rank_pos.assign(p.skip_rows ? 0 : p.n_adm, 0);
+  for (int t = 0; t < p.n_tree && !p.skip_rows; t++)
     for (int i = p.tree_row_off[t]; i < p.tree_row_off[t + 1]; i++) p.rank_pos[p.tree_rows[i]] = i - p.tree_row_off[t];
   // ---- scan-formulated classical search: row records, level orders of the buckets, bucket signatures ----
   {
@@ -362,10 +372,10 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
     p.frbr.assign(p.frb.size(), 0);
     for (int t = 0; t < p.n_tree; t++)
       for (int i = p.frb_off[(size_t)t * p.nfr]; i < p.frb_off[(size_t)(t + 1) * p.nfr]; i++) p.frbr[i] = p.tree_rows[p.tree_row_off[t] + p.frb[i]];
-    p.adm_rec.assign(p.n_adm, AdmRec{});
+    p.adm_rec.assign(p.skip_rows ? 0 : p.n_adm, AdmRec{});
     p.fs_ok.assign(p.n_tree, 1); p.rec_ok.assign(p.n_tree, 1);
     for (int c = 0; c < nq; c++) if (p.depth[c] > CS_LEVELS) p.cs_ok[p.tree_of[c]] = 0;
-    for (int r = 0; r < p.n_adm; r++) {
+    for (int r = 0; r < p.n_adm && !p.skip_rows; r++) {
       AdmRec& a = p.adm_rec[r];
       for (int e = 0; e < CS_RFR; e++) { a.fr[e] = -1; a.qty[e] = 0; }
       const int c = p.adm_cq[r];
@@ -456,13 +466,14 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
         else for (int h = p.depth[n]; h > dd; h--) n = s->parent[n];
         cq_anc[(size_t)l * nq + c] = n;
       }
-    for (int t = 0; t < p.n_tree; t++)
+    for (int t = 0; t < p.n_tree && !p.skip_rows; t++)
       for (int fr = 0; fr < p.nfr; fr++) {
         const size_t b = (size_t)t * p.nfr + fr;
         const int o = p.frb_off[b], M = p.frb_off[b + 1] - o;
         p.cs_max_bucket = std::max(p.cs_max_bucket, M);
-        uint64_t sig = 1469598103934665603ull ^ (uint64_t)M;
-        for (int j = 0; j < M; j++) { sig ^= (uint64_t)(uint32_t)p.tree_rows[p.tree_row_off[t] + p.frb[o + j]]; sig *= 1099511628211ull; }
+        // order-independent (a sum of mixed row ids + the size): the device-side rebuild (kq_rows.hpp) adds the terms with atomics
+        uint64_t sig = frb_sig_size(M);
+        for (int j = 0; j < M; j++) sig += frb_sig_row(p.tree_rows[p.tree_row_off[t] + p.frb[o + j]]);
         p.frb_sig[b] = sig;
         for (int j = 0; j < M; j++) {
           const int row = p.tree_rows[p.tree_row_off[t] + p.frb[o + j]];

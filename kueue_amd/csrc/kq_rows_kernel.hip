@@ -1,0 +1,58 @@
+// kq_rows_kernel.hip — the device-side rebuild of the admitted-row candidate structures (kq_rows.hpp): the cell kernel, and the two
+// library primitives it needs — a stable radix sort of (64-bit key, int32 value) pairs and an exclusive prefix sum — from rocPRIM.
+// Its own translation unit: the rocPRIM headers stay out of the engine's.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "kq_rows.hpp"
+
+using namespace kq;
+
+__global__ __launch_bounds__(256) void k_rows(DRows R, int op, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  rows_cell(R, op, i, i < n);
+}
+
+namespace kq {
+namespace {
+struct Scratch { void* p = nullptr; size_t cap = 0; };
+Scratch g_tmp;
+hipError_t need(Scratch& s, size_t bytes) {
+  if (bytes <= s.cap) return hipSuccess;
+  if (s.p) (void)hipFree(s.p);
+  s.cap = bytes + bytes / 4 + 256;
+  return hipMalloc(&s.p, s.cap);
+}
+}  // namespace
+
+hipError_t rows_launch(const DRows& R, int op, int n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_rows, dim3((n + 255) / 256), dim3(256), 0, stream, R, op, n);
+  return hipGetLastError();
+}
+// stable sort of (key, val) by the low `bits` bits of the key between two pairs of buffers (rocPRIM's double-buffer form: no copy
+// back); on return key / val name the pair that holds the result, key2 / val2 the other one
+hipError_t rows_sort_pairs(uint64_t*& key, int32_t*& val, uint64_t*& key2, int32_t*& val2, int n, int bits, hipStream_t stream) {
+  if (n <= 1 || bits <= 0) return hipSuccess;
+  rocprim::double_buffer<uint64_t> dk(key, key2);
+  rocprim::double_buffer<int32_t> dv(val, val2);
+  size_t bytes = 0;
+  hipError_t e;
+  if ((e = rocprim::radix_sort_pairs(nullptr, bytes, dk, dv, (unsigned)n, 0u, (unsigned)bits, stream)) != hipSuccess) return e;
+  if ((e = need(g_tmp, bytes)) != hipSuccess) return e;
+  if ((e = rocprim::radix_sort_pairs(g_tmp.p, bytes, dk, dv, (unsigned)n, 0u, (unsigned)bits, stream)) != hipSuccess) return e;
+  if (dk.current() != key) { uint64_t* t = key; key = key2; key2 = t; }
+  if (dv.current() != val) { int32_t* t = val; val = val2; val2 = t; }
+  return hipSuccess;
+}
+hipError_t rows_scan_excl(const int32_t* in, int32_t* out, int n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  size_t bytes = 0;
+  hipError_t e;
+  if ((e = rocprim::exclusive_scan(nullptr, bytes, in, out, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), stream)) != hipSuccess) return e;
+  if ((e = need(g_tmp, bytes)) != hipSuccess) return e;
+  return rocprim::exclusive_scan(g_tmp.p, bytes, in, out, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), stream);
+}
+}  // namespace kq

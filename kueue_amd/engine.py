@@ -16,6 +16,27 @@ from . import _ffi as F
 from .api import Decisions, Heads, Snapshot, make_config
 
 
+def row_patch_struct(remove_rows, add):
+    """kq_row_patch from plain arrays -> (struct, the arrays it points into)."""
+    keep = []
+    p = F.kq_row_patch()
+    rm = np.ascontiguousarray(remove_rows, np.int32)
+    keep.append(rm)
+    p.n_remove = len(rm); p.remove_rows = F.ptr(rm) if len(rm) else None
+    n_add = 0 if not add else len(add["cq"])
+    p.n_add = n_add
+    if n_add:
+        for field, key, dt in (("add_cq", "cq", np.int32), ("add_priority", "priority", np.int64), ("add_queue_ts", "queue_ts", np.int64),
+                               ("add_reserve_ts", "reserve_ts", np.int64), ("add_uid_rank", "uid_rank", np.uint32), ("add_flags", "flags", np.uint8),
+                               ("add_use_off", "use_off", np.int32), ("add_use_fr", "use_fr", np.int32), ("add_use_qty", "use_qty", np.int64)):
+            a = np.ascontiguousarray(add[key], dt)
+            if a.size == 0:
+                a = np.zeros(1, dt)
+            keep.append(a)
+            setattr(p, field, F.ptr(a))
+    return p, keep
+
+
 class EngineError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"kq_engine error {code} ({F.KQ_ERRORS.get(code, '?')}): {msg}")
@@ -57,6 +78,19 @@ class Engine:
         """kq_snapshot_patch: the next cycle's snapshot when only usage (F.PATCH_USAGE) and / or the admitted set (F.PATCH_ADMITTED) moved."""
         self._check(self._lib.kq_snapshot_patch(self._h, C.byref(snap.struct()), what))
         self.snap = snap
+
+    def patch_rows(self, remove_rows=(), add: Optional[dict] = None) -> np.ndarray:
+        """kq_snapshot_patch_rows: rows that left / rows that came (add: dict of arrays cq, priority, queue_ts, reserve_ts, uid_rank, flags,
+        use_off, use_fr, use_qty); the admitted table and everything derived from it are rebuilt on the device. -> new index of every old row."""
+        p, keep = row_patch_struct(remove_rows, add)
+        new_index = np.zeros(max(self._n_adm(), 1), np.int32)
+        self._check(self._lib.kq_snapshot_patch_rows(self._h, C.byref(p), F.ptr(new_index)))
+        return new_index
+
+    def _n_adm(self) -> int:
+        cap = C.c_int64(0)
+        self._lib.kq_debug_read_rows(self._h, C.c_int32(0), None, C.byref(cap))
+        return int(cap.value) // 4
 
     def run(self, heads: Heads, tgt_cap: Optional[int] = None, out: Optional[Decisions] = None, rsn_cap: int = 0) -> Decisions:
         d = out if out is not None else Decisions(heads, tgt_cap=tgt_cap, rsn_cap=rsn_cap)

@@ -224,6 +224,50 @@ func (e *Engine) PatchSnapshot(s *FlatSnapshot, what uint32) error {
 	return nil
 }
 
+// RowPatch = kq_row_patch: the admitted workloads that left cq.Workloads since the last call and the ones that came
+// (clusterQueue.updateWorkloadUsage, pkg/cache/scheduler/clusterqueue.go:594, one workload at a time; the Go cache calls it from
+// AddOrUpdateWorkload / DeleteWorkload, pkg/cache/scheduler/cache.go). Rows are indices into the engine's resident table: the Go side keeps
+// rowOf map[workload.Reference]int32 and renumbers it with the newIndex PatchRows returns. AddUIDRank must be comparable with the
+// resident rows' keys: use an order-preserving 32-bit prefix of Obj.UID instead of dense ranks.
+type RowPatch struct {
+	RemoveRows                            []int32
+	AddCQ                                 []int32
+	AddPriority, AddQueueTs, AddReserveTs []int64
+	AddUIDRank                            []uint32
+	AddFlags                              []uint8
+	AddUseOff, AddUseFr                   []int32
+	AddUseQty                             []int64
+}
+
+// PatchRows = kq_snapshot_patch_rows: the O(changes) form of PatchSnapshot(KQ_PATCH_ADMITTED). newIndex (len = rows before the call)
+// receives the new index of every old row, -1 for a removed one. ErrUnsupported: fair sharing or amounts outside the plain range —
+// fall back to PatchSnapshot. Usage is folded separately (CommitCycle / ReleaseCycle / PatchSnapshot(KQ_PATCH_USAGE)).
+func (e *Engine) PatchRows(p *RowPatch, newIndex []int32) error {
+	var pin_ runtime.Pinner
+	defer pin_.Unpin()
+	c := (*C.kq_row_patch)(C.calloc(1, C.sizeof_kq_row_patch))
+	defer C.free(unsafe.Pointer(c))
+	c.n_remove = C.int32_t(len(p.RemoveRows))
+	c.remove_rows = (*C.int32_t)(pin(&pin_, p.RemoveRows))
+	c.n_add = C.int32_t(len(p.AddCQ))
+	c.add_cq = (*C.int32_t)(pin(&pin_, p.AddCQ))
+	c.add_priority = (*C.int64_t)(pin(&pin_, p.AddPriority))
+	c.add_queue_ts = (*C.int64_t)(pin(&pin_, p.AddQueueTs))
+	c.add_reserve_ts = (*C.int64_t)(pin(&pin_, p.AddReserveTs))
+	c.add_uid_rank = (*C.uint32_t)(pin(&pin_, p.AddUIDRank))
+	c.add_flags = (*C.uint8_t)(pin(&pin_, p.AddFlags))
+	c.add_use_off = (*C.int32_t)(pin(&pin_, p.AddUseOff))
+	c.add_use_fr = (*C.int32_t)(pin(&pin_, p.AddUseFr))
+	c.add_use_qty = (*C.int64_t)(pin(&pin_, p.AddUseQty))
+	if rc := C.kq_snapshot_patch_rows(e.h, c, (*C.int32_t)(pin(&pin_, newIndex))); rc != 0 {
+		if rc == C.KQ_EUNSUPPORTED {
+			return ErrUnsupported
+		}
+		return e.err("kq_snapshot_patch_rows", rc)
+	}
+	return nil
+}
+
 func fillHeads(p *runtime.Pinner, c *C.kq_heads, h *FlatHeads) {
 	c.n, c.cycle = C.int32_t(h.N), C.int64_t(h.Cycle)
 	c.cq = (*C.int32_t)(pin(p, h.CQ))

@@ -177,6 +177,18 @@ struct EmuBackend {
     rot++;
     last_k = k;
   }
+  // admitted-row structures on the "device" (kq_rows.hpp)
+  void launch_rows(const DRows& R, int op, int n) { for (int i = 0; i < n; i++) rows_cell(R, op, i, true); }
+  void sort_pairs(uint64_t*& key, int32_t*& val, uint64_t*&, int32_t*&, int n, int bits) {   // (in place here; only the low `bits` bits order)
+    std::vector<int> idx(n);
+    for (int i = 0; i < n; i++) idx[i] = i;
+    const uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return (key[a] & mask) < (key[b] & mask); });
+    std::vector<uint64_t> k2(n); std::vector<int32_t> v2(n);
+    for (int i = 0; i < n; i++) { k2[i] = key[idx[i]]; v2[i] = val[idx[i]]; }
+    for (int i = 0; i < n; i++) { key[i] = k2[i]; val[i] = v2[i]; }
+  }
+  void scan_excl(const int32_t* in, int32_t* out, int n) { int32_t acc = 0; for (int i = 0; i < n; i++) { const int32_t v = in[i]; out[i] = acc; acc += v; } }
   // kq_cycle_run_tas (kq_tas_cycle.hpp)
   void launch_tas_base(const TCyc* c, int n) { for (int e = 0; e < n; e++) tc_base_cell(*c, e); }
   void launch_tas_cycle_classes(const TCyc* c, int n) { for (int i = 0; i < n; i++) tc_class_init(*c, i / c->ncls, i % c->ncls); }
@@ -239,6 +251,9 @@ int kqe_tas_overflow(void* t, const int64_t* plane, uint8_t* leaf_over, int32_t*
 int kqe_tas_read_usage(void* t, int64_t* u) { return ((EmuTas*)t)->read_usage(u); }
 int64_t kqe_tas_last_bytes(void* t) { return ((EmuTas*)t)->last_bytes; }
 const char* kqe_tas_last_error(void* t) { return ((EmuTas*)t)->last_error.c_str(); }
+int kqe_snapshot_patch_rows(void* e, const kq_row_patch* p, int32_t* new_index) { return ((EmuEngine*)e)->snapshot_patch_rows(p, new_index); }
+int kqe_debug_rows_rebuild(void* e) { return ((EmuEngine*)e)->debug_rows_rebuild(); }
+int kqe_debug_read_rows(void* e, int32_t which, void* out, int64_t* bytes) { return ((EmuEngine*)e)->read_rows(which, out, bytes); }
 int kqe_cycle_commit(void* e, int32_t* n) { return ((EmuEngine*)e)->cycle_commit(n); }
 int kqe_cycle_release(void* e, int age) { return ((EmuEngine*)e)->cycle_release(age); }
 int kqe_snapshot_derive(void* e) { return ((EmuEngine*)e)->snapshot_derive(); }

@@ -281,6 +281,20 @@ def _run_tas(self, heads, ct, tgt_cap=None, want_usage=False, dom_cap=None, rsn_
 EmuEngine.run_tas = _run_tas
 
 
+def _patch_rows(self, remove_rows=(), add=None):
+    """kqe_snapshot_patch_rows on the emulated engine -> (rc, new index of every old row)."""
+    from kueue_amd.engine import row_patch_struct
+    p, keep = row_patch_struct(remove_rows, add)
+    cap = C.c_int64(0)
+    lib().kqe_debug_read_rows(self.h, C.c_int32(0), None, C.byref(cap))
+    new_index = np.zeros(max(int(cap.value) // 4, 1), np.int32)
+    rc = lib().kqe_snapshot_patch_rows(self.h, C.byref(p), F.ptr(new_index))
+    return rc, new_index
+
+
+EmuEngine.patch_rows = _patch_rows
+
+
 class EmuTas:
     """1-lane emulation of the TAS device code (kq_tas_device.hpp), same interface as kueue_amd.tas.TASEngine."""
 
