@@ -323,8 +323,7 @@ int  kq_snapshot_patch(kq_engine* e, const kq_snapshot* s, uint32_t what);
  * the call]) receives the new index of every old row, -1 for a removed one.
  * Usage is NOT touched: fold it with kq_cycle_commit / kq_cycle_release or KQ_PATCH_USAGE as before. add_uid_rank must be comparable
  * with the resident rows' adm_uid_rank (any order-preserving 32-bit key of Obj.UID works; dense ranks do not survive insertions).
- * KQ_EUNSUPPORTED (use kq_snapshot_patch): fair sharing (its position-order tables are still host-built), amounts outside the plain
- * range, sizes beyond the sort keys' fields (2^20 rows, 2^21 nodes). */
+ * KQ_EUNSUPPORTED (use kq_snapshot_patch): amounts outside the plain range, sizes beyond the sort keys' fields (2^20 rows, 2^21 nodes). */
 typedef struct kq_row_patch {
   int32_t n_remove;
   const int32_t* remove_rows;       /* [n_remove] distinct rows of the resident table, any order */

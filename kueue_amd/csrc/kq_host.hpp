@@ -219,7 +219,7 @@ template <class B> struct EngineT {
     prep.want_fs = cfg.fair_sharing != 0;
     // the structures derived from the admitted rows are built on the device from the uploaded row table (kq_rows.hpp) unless fair
     // sharing needs its host-built position-order tables or the sizes leave the sort keys' fields
-    prep.skip_rows = rows_device && !cfg.fair_sharing && s->n_adm < (1 << 20) && s->n_cq + s->n_cohort < (1 << 21);
+    prep.skip_rows = rows_device && s->n_adm < (1 << 20) && s->n_cq + s->n_cohort < (1 << 21);
     int rc = build_prep(s, prep);
     if (rc != KQ_OK) return fail(rc, prep.err);
     if (prep.skip_rows && !rows_device_ok()) { prep.skip_rows = false; rc = build_prep(s, prep); if (rc != KQ_OK) return fail(rc, prep.err); }
@@ -373,6 +373,7 @@ template <class B> struct EngineT {
   // ---- the admitted-row structures built on the device (kq_rows.hpp) ---------------------------------------------------------------------
   Buf rb[12];
   Buf rk2, rv2;        // second (key, value) pair of the sorts
+  Buf rfs;             // resident fs_ok
   Buf rs[20];          // the rebuilt structures live in grow-only buffers (a hipMalloc / hipFree pair per array and call cost more than the sorts)
   Buf rt[2][10];       // the row table of kq_snapshot_patch_rows, double-buffered (the move reads the old table, writes the new one)
   int rt_cur = 0;
@@ -390,12 +391,12 @@ template <class B> struct EngineT {
   }
   template <class T> T* dev_new(size_t n) { return (T*)be.alloc(std::max<size_t>(n, 1) * sizeof(T)); }
   bool rows_device_ok() const {
-    return !cfg.fair_sharing && prep.n_adm < (1 << 20) && prep.N < (1 << 21) && (int64_t)prep.n_tree * prep.nfr < (1 << 22);
+    return prep.n_adm < (1 << 20) && prep.N < (1 << 21) && (int64_t)prep.n_tree * prep.nfr < (1 << 22);
   }
   // Rebuilds every structure derived from the admitted rows from the resident row table (S.cq_adm_off, S.adm_*): the device twin of
   // build_prep's admitted part. n = rows, n_use = usage entries.
   int rows_rebuild(int n) {
-    if (!rows_device_ok()) return fail(KQ_EUNSUPPORTED, "device-side row structures: fair sharing or sizes beyond the key layout");
+    if (!rows_device_ok()) return fail(KQ_EUNSUPPORTED, "device-side row structures: sizes beyond the key layout");
     const int nq = prep.nq, nfr = prep.nfr, n_tree = prep.n_tree, N = prep.N;
     const size_t nb = (size_t)n_tree * nfr;
     DRows R{};
@@ -408,7 +409,16 @@ template <class B> struct EngineT {
     for (int c = 0; c < nq; c++) if (prep.depth[c] > CS_LEVELS) cs0[prep.tree_of[c]] = 0;
     uint8_t* d_cs = grow<uint8_t>(rs[9], n_tree); uint8_t* d_rec = grow<uint8_t>(rs[10], n_tree);
     be.h2d(d_cs, cs0.data(), std::max(n_tree, 1)); be.h2d(d_rec, rec0.data(), std::max(n_tree, 1));
-    R.cs_ok = d_cs; R.rec_ok = d_rec; R.fs_ok = grow<uint8_t>(rb[0], n_tree);   // (fair sharing is off here: fs_ok stays all zero, this is scratch)
+    // fair sharing: the static part of fs_ok (tree shape, index ranges; all zero when fair sharing is off), the position offsets of every
+    // ClusterQueue inside its tree (rows per ClusterQueue: O(ClusterQueues) on the host), the bitmap words of the largest tree
+    const bool fair = cfg.fair_sharing != 0;
+    std::vector<uint8_t> fs0(std::max(n_tree, 1), fair && prep.nfr <= 32767 ? 1 : 0);
+    for (int c = 0; c < nq; c++) if (prep.depth[c] + 1 > FS_LV) fs0[prep.tree_of[c]] = 0;
+    for (int t = 0; t < n_tree; t++) if (prep.tree_node_off[t + 1] - prep.tree_node_off[t] > 32767) fs0[t] = 0;
+    uint8_t* d_fs = grow<uint8_t>(rfs, n_tree);
+    be.h2d(d_fs, fs0.data(), std::max(n_tree, 1));
+    R.cs_ok = d_cs; R.rec_ok = d_rec; R.fs_ok = d_fs;
+    R.path = S.path; R.plen = S.plen; R.nR = prep.nR;
     // bits a sort key field really uses: a radix pass per 8 bits or so, so the tree / bucket / node fields are cut to their ranges
     auto bits_of = [](int64_t maxv) { int b = 1; while (b < 63 && ((int64_t)1 << b) <= maxv) b++; return b; };
     const int tree_bits = bits_of(std::max(n_tree - 1, 1));
@@ -459,8 +469,32 @@ template <class B> struct EngineT {
       be.launch_rows(R, RO_LKEY, E); be.sort_pairs(R.key, R.val, key2, val2, E, 42 + bits_of(std::max<int64_t>((int64_t)nb - 1, 1)));
       be.launch_rows(R, RO_LFILL, E);
     }
+    std::vector<int32_t> posoff;
+    if (fair) {
+      // position order: one more sort, by (tree, ClusterQueue inside the tree, evicted first, candidate rank)
+      auto bits_of2 = [](int64_t maxv) { int b = 1; while (b < 63 && ((int64_t)1 << b) <= maxv) b++; return b; };
+      R.cq_bits = bits_of2(std::max(prep.max_tree_cqs - 1, 1));
+      R.fs_scan = grow<FsScan>(rs[17], n); R.fs_apply = grow<FsApply>(rs[18], n);
+      be.launch_rows(R, RO_KEY_FS, n);
+      be.sort_pairs(R.key, R.val, key2, val2, n, 32 + R.cq_bits + (n_tree > 1 ? tree_bits : 0));
+      be.launch_rows(R, RO_FS_FILL, n);
+      posoff.assign((size_t)nq + n_tree, 0);
+      prep.max_tree_mw = 1;
+      for (int t = 0; t < n_tree; t++) {
+        const int q0 = prep.tree_cq_off[t], nqs = prep.tree_cq_off[t + 1] - q0;
+        prep.max_tree_mw = std::max(prep.max_tree_mw, (tro[t + 1] - tro[t] + 63) / 64 + 1);
+        int pos = 0;
+        for (int i = 0; i < nqs; i++) { const int c = prep.tree_cqs[q0 + i]; posoff[(size_t)q0 + t + i] = pos; pos += h_cq_adm_off[c + 1] - h_cq_adm_off[c]; }
+        posoff[(size_t)q0 + t + nqs] = pos;
+      }
+      int32_t* d_po = grow<int32_t>(rs[19], posoff.size());
+      be.h2d(d_po, posoff.data(), posoff.size() * 4);
+      adopt(S.fs_scan, R.fs_scan); adopt(S.fs_apply, R.fs_apply); adopt(S.fs_posoff, d_po);
+    }
     int32_t scal[4];
     be.d2h(scal, R.scal, 16);
+    prep.fs_ok.assign(std::max(n_tree, 1), 0); prep.rec_ok.assign(std::max(n_tree, 1), 0);   // host copies follow (upload_fs_quota re-uploads fs_ok)
+    be.d2h(prep.fs_ok.data(), d_fs, std::max(n_tree, 1)); be.d2h(prep.rec_ok.data(), d_rec, std::max(n_tree, 1));
     rc = be.sync();
     if (rc != KQ_OK) return fail(rc, be.error());
     prep.n_adm = n; S.n_adm = n;
@@ -473,13 +507,15 @@ template <class B> struct EngineT {
     adopt(S.cq_row_bytes, R.cq_row_bytes); adopt(S.adm_rec, R.adm_rec); adopt(S.frbr, R.frbr); adopt(S.frec, R.frec);
     for (int l = 0; l < CS_LEVELS; l++) adopt(S.frl[l], R.frl[l]);
     adopt(S.frb_sig, R.frb_sig); adopt(S.cs_ok, d_cs); adopt(S.rec_ok, d_rec);
+    adopt(S.fs_ok, d_fs);
+    prep.fs_ok.resize(n_tree); prep.rec_ok.resize(n_tree);
     return KQ_OK;
   }
   // kq_snapshot_patch_rows (include/kq_engine.h): compaction + insertion of rows on the device, then rows_rebuild
   int snapshot_patch_rows(const kq_row_patch* p, int32_t* new_index) {
     if (!have_snapshot) return fail(KQ_EINVAL, "kq_snapshot_patch_rows before kq_snapshot_put");
     if (!p || p->n_remove < 0 || p->n_add < 0) return fail(KQ_EINVAL, "bad kq_row_patch");
-    if (!rows_device || !rows_device_ok()) return fail(KQ_EUNSUPPORTED, "kq_snapshot_patch_rows: fair sharing / sizes beyond the device path (use kq_snapshot_patch)");
+    if (!rows_device || !rows_device_ok()) return fail(KQ_EUNSUPPORTED, "kq_snapshot_patch_rows: sizes beyond the device path (use kq_snapshot_patch)");
     if (steps_issued != steps_waited) return fail(KQ_EINVAL, "a kq_pending_step is in flight (kq_pending_step_wait first)");
     const int nq = prep.nq, n_old = prep.n_adm, n_rm = p->n_remove, n_add = p->n_add;
     if ((int)h_adm_cq.size() != n_old || (int)h_cq_adm_off.size() != nq + 1) return fail(KQ_EINVAL, "host mirrors of the row table are missing");
@@ -610,6 +646,10 @@ template <class B> struct EngineT {
       case 23: src = S.adm_rts; sz = n * 8; break;
       case 24: src = S.adm_uid; sz = n * 4; break;
       case 25: src = S.adm_flags; sz = n; break;
+      case 26: src = S.fs_ok; sz = prep.n_tree; break;
+      case 27: src = S.fs_posoff; sz = cfg.fair_sharing ? ((size_t)prep.nq + prep.n_tree) * 4 : 0; break;
+      case 28: src = S.fs_scan; sz = cfg.fair_sharing ? n * sizeof(FsScan) : 0; break;
+      case 29: src = S.fs_apply; sz = cfg.fair_sharing ? n * sizeof(FsApply) : 0; break;
       default: return fail(KQ_EINVAL, "unknown structure");
     }
     if ((int64_t)sz > *bytes) { *bytes = (int64_t)sz; return fail(KQ_ECAPACITY, "buffer too small"); }

@@ -406,7 +406,8 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
     p.fs_scan.assign(p.want_fs ? p.n_adm : 0, FsScan{}); p.fs_apply.assign(p.want_fs ? p.n_adm : 0, FsApply{});
     p.fs_posoff.assign((size_t)nq + p.n_tree, 0);
     p.max_tree_mw = 1;
-    for (int t = 0; t < p.n_tree && p.want_fs; t++) {
+    if (p.skip_rows) { p.fs_scan.clear(); p.fs_apply.clear(); }
+    for (int t = 0; t < p.n_tree && p.want_fs && !p.skip_rows; t++) {
       const int q0 = p.tree_cq_off[t], nqs = p.tree_cq_off[t + 1] - q0, r0 = p.tree_row_off[t];
       const int nn = p.tree_node_off[t + 1] - p.tree_node_off[t];
       if (nn > 32767) p.fs_ok[t] = 0;

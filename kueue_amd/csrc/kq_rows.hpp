@@ -9,14 +9,14 @@
 //   level order  bucket entries by (bucket, ancestor at depth l + 1 or "none", evicted first, bucket position), l = 0 .. CS_LEVELS - 1
 // The sort itself is the backend's (rocPRIM radix sort on the GPU, std::stable_sort in the 1-lane emulation); everything else is the
 // cell functions below, one thread per row / entry / bucket. The results are byte-identical to build_prep's (tests/test_rows_device.py).
-// Fair sharing's position-order tables (kq_fs.hpp) are not rebuilt here: with fair sharing on, the host path stays.
+// Fair sharing's position-order tables (kq_fs.hpp: FsScan / FsApply per position) are one more sort by (tree, ClusterQueue, evicted, rank).
 #pragma once
 #include "kq_device.hpp"
 
 namespace kq {
 
 enum { RO_ROW_INIT = 0, RO_KEY_RTS, RO_KEY_PRIO, RO_KEY_TREE, RO_RANK, RO_KEY_ASC, RO_ASC, RO_ENT_FILL, RO_BOUNDS, RO_BUCKET_FILL, RO_BUCKET_SIZE,
-       RO_LKEY, RO_LFILL, RO_MOVE_ROW, RO_MOVE_ENT, RO_ADD_ROW };
+       RO_LKEY, RO_LFILL, RO_MOVE_ROW, RO_MOVE_ENT, RO_ADD_ROW, RO_KEY_FS, RO_FS_FILL };
 
 struct DRows {
   // the row table the structures are built from
@@ -43,6 +43,11 @@ struct DRows {
   uint64_t* frb_sig;
   uint8_t *cs_ok, *fs_ok, *rec_ok;
   int level;            // RO_LKEY / RO_LFILL
+  // fair sharing (kq_fs.hpp): the candidates in position order — per tree by ClusterQueue (tree-local index), inside a ClusterQueue
+  // evicted first, then candidate rank — with the two records per position the LDS search reads
+  FsScan* fs_scan; FsApply* fs_apply;
+  const int32_t *path, *plen;
+  int nR, cq_bits;
   // kq_snapshot_patch_rows: the move of the kept rows into the new table, and the added rows
   const int32_t *old_cq_off, *new_cq_off, *rm_off, *rm_rows;       // per ClusterQueue: old / new row offsets, its removed rows (ascending) as a CSR
   const int32_t *o_use_off, *o_use_fr; const int64_t *o_prio, *o_qts, *o_rts, *o_use_qty; const uint32_t* o_uid; const uint8_t* o_flags; const int32_t* o_adm_cq;
@@ -190,6 +195,25 @@ KQ_DEV void ro_lfill(const DRows& R, int q) {
   R.frl[R.level][q] = CsEnt{j | (R.depth[cq] << 24), anc >= 0 ? R.node_local[anc] : -1, row, anc, qty};
 }
 
+KQ_DEV uint32_t ro_hkey(const DRows& R, int row) { return ((R.adm_flags[row] & KQ_ADM_EVICTED) ? 0u : 0x80000000u) | (uint32_t)R.rank_pos[row]; }
+KQ_DEV void ro_key_fs(const DRows& R, int r) {
+  const int c = R.adm_cq[r];
+  R.key[r] = ((uint64_t)R.tree_of[c] << (32 + R.cq_bits)) | ((uint64_t)R.cq_local[c] << 32) | ro_hkey(R, r);
+  R.val[r] = r;
+}
+KQ_DEV void ro_fs_fill(const DRows& R, int q) {   // q = global position = tree_row_off[tree] + position inside the tree
+  const int r = R.val[q];
+  const AdmRec a = R.adm_rec[r];
+  const int c = a.cq;
+  FsScan sc{}; FsApply ap{};
+  sc.prio = a.prio; sc.qts = a.qts; sc.row = r; sc.cql = (int16_t)R.cq_local[c];
+  sc.cbytes = (uint16_t)(32 + 12 * (R.adm_use_off[r + 1] - R.adm_use_off[r]));
+  for (int e = 0; e < CS_RFR; e++) { sc.fr[e] = ap.fr[e] = (int16_t)a.fr[e]; ap.qty[e] = a.qty[e]; ap.res[e] = (uint8_t)(a.fr[e] >= 0 ? a.fr[e] % R.nR : 255); }
+  for (int l = 0; l < FS_LV; l++) ap.lp[l] = l < R.plen[c] ? (int16_t)R.node_local[R.path[(size_t)c * KQ_MAXD + l]] : (int16_t)-1;
+  ap.hkey = ro_hkey(R, r); ap.row = r; ap.cbytes = sc.cbytes; ap.plen = (uint8_t)(R.plen[c] < 255 ? R.plen[c] : 255);
+  R.fs_scan[q] = sc; R.fs_apply[q] = ap;
+}
+
 // ---- kq_snapshot_patch_rows: kept rows move to their new index, added rows land behind the kept rows of their ClusterQueue ----------------
 KQ_DEV void ro_move_row(const DRows& R, int r) {   // r = old row
   const int c = R.o_adm_cq[r];
@@ -238,6 +262,8 @@ KQ_DEV void rows_cell(const DRows& R, int op, int i, bool active) {
     case RO_MOVE_ROW: ro_move_row(R, i); break;
     case RO_MOVE_ENT: ro_move_ent(R, i); break;
     case RO_ADD_ROW: ro_add_row(R, i); break;
+    case RO_KEY_FS: ro_key_fs(R, i); break;
+    case RO_FS_FILL: ro_fs_fill(R, i); break;
     default: break;
   }
 }

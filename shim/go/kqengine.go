@@ -240,8 +240,8 @@ type RowPatch struct {
 }
 
 // PatchRows = kq_snapshot_patch_rows: the O(changes) form of PatchSnapshot(KQ_PATCH_ADMITTED). newIndex (len = rows before the call)
-// receives the new index of every old row, -1 for a removed one. ErrUnsupported: fair sharing or amounts outside the plain range —
-// fall back to PatchSnapshot. Usage is folded separately (CommitCycle / ReleaseCycle / PatchSnapshot(KQ_PATCH_USAGE)).
+// receives the new index of every old row, -1 for a removed one. ErrUnsupported: amounts outside the plain range or sizes beyond the
+// sort keys' fields — fall back to PatchSnapshot. Usage is folded separately (CommitCycle / ReleaseCycle / PatchSnapshot(KQ_PATCH_USAGE)).
 func (e *Engine) PatchRows(p *RowPatch, newIndex []int32) error {
 	var pin_ runtime.Pinner
 	defer pin_.Unpin()

@@ -10,9 +10,10 @@ import pytest
 
 from tests.randgen import random_case
 
-N_STRUCT = 26
+N_STRUCT = 30
 NAMES = ["adm_cq", "tree_row_off", "tree_rows", "tree_rows_asc", "rank_pos", "frb_off", "frb", "frbr", "cq_row_bytes", "adm_rec", "frec", "frl0", "frl1", "frl2",
-         "frb_sig", "cs_ok", "rec_ok", "cq_adm_off", "adm_use_off", "adm_use_fr", "adm_use_qty", "adm_prio", "adm_qts", "adm_rts", "adm_uid", "adm_flags"]
+         "frb_sig", "cs_ok", "rec_ok", "cq_adm_off", "adm_use_off", "adm_use_fr", "adm_use_qty", "adm_prio", "adm_qts", "adm_rts", "adm_uid", "adm_flags",
+         "fs_ok", "fs_posoff", "fs_scan", "fs_apply"]
 
 
 class _Emu:
@@ -53,9 +54,18 @@ def read_all(x):
 
 
 def check(make, cfg, snap, heads=None):
+    import os
+    os.environ["KQ_ROWS_HOST"] = "1"          # the reference: every structure built by build_prep on the host
+    try:
+        h = make(cfg)
+    finally:
+        del os.environ["KQ_ROWS_HOST"]
+    h.e.put(snap)
+    host = read_all(h)
+    h.e.close()
     x = make(cfg)
-    x.e.put(snap)
-    host = read_all(x)
+    x.e.put(snap)                              # the device build (kq_rows.hpp)
+    assert [a.tobytes() for a in read_all(x)] == [a.tobytes() for a in host], "kq_snapshot_put: device-built structures differ from build_prep's"
     want = x.run(heads, tgt_cap=max(16, snap.n_adm)) if heads is not None else None
     rc = x.rebuild_fn(x.h)
     assert rc == 0, rc
@@ -71,7 +81,7 @@ def check(make, cfg, snap, heads=None):
 
 @pytest.mark.parametrize("seed", range(150))
 def test_rows_rebuild_random_emulated(oracle, seed):
-    cfg, snap, heads = random_case(seed, fair=False, preemption=True, tight=seed % 2 == 0)
+    cfg, snap, heads = random_case(seed, fair=seed % 3 == 0, preemption=True, tight=seed % 2 == 0)
     oracle.derive(snap)
     check(_Emu, cfg, snap, heads)
 
@@ -88,7 +98,7 @@ def test_rows_rebuild_population_emulated(cfgn):
 @pytest.mark.parametrize("block", range(3))
 def test_rows_rebuild_random_gpu(oracle, block):
     for seed in range(block * 50, block * 50 + 50):
-        cfg, snap, heads = random_case(seed, fair=False, preemption=True, tight=seed % 2 == 0)
+        cfg, snap, heads = random_case(seed, fair=seed % 3 == 0, preemption=True, tight=seed % 2 == 0)
         oracle.derive(snap)
         check(_Hip, cfg, snap, heads)
 
@@ -153,7 +163,7 @@ def check_patch(make, cfg, snap, heads, rnd):
 @pytest.mark.parametrize("seed", range(150))
 def test_patch_rows_random_emulated(oracle, seed):
     import random
-    cfg, snap, heads = random_case(seed, fair=False, preemption=True, tight=seed % 2 == 0)
+    cfg, snap, heads = random_case(seed, fair=seed % 3 == 0, preemption=True, tight=seed % 2 == 0)
     oracle.derive(snap)
     check_patch(_Emu, cfg, snap, heads, random.Random(seed * 17 + 3))
 
@@ -163,7 +173,7 @@ def test_patch_rows_random_emulated(oracle, seed):
 def test_patch_rows_random_gpu(oracle, block):
     import random
     for seed in range(block * 40, block * 40 + 40):
-        cfg, snap, heads = random_case(seed, fair=False, preemption=True, tight=seed % 2 == 0)
+        cfg, snap, heads = random_case(seed, fair=seed % 3 == 0, preemption=True, tight=seed % 2 == 0)
         oracle.derive(snap)
         check_patch(_Hip, cfg, snap, heads, random.Random(seed * 17 + 3))
 
@@ -211,7 +221,7 @@ def _sequence(make, cfg, snap, rnd, steps=4):
 @pytest.mark.parametrize("seed", range(60))
 def test_patch_rows_sequence_emulated(oracle, seed):
     import random
-    cfg, snap, _ = random_case(seed, fair=False, preemption=True, tight=seed % 2 == 0)
+    cfg, snap, _ = random_case(seed, fair=seed % 3 == 0, preemption=True, tight=seed % 2 == 0)
     oracle.derive(snap)
     _sequence(_Emu, cfg, snap, random.Random(seed * 29 + 5))
 
@@ -220,7 +230,7 @@ def test_patch_rows_sequence_emulated(oracle, seed):
 def test_patch_rows_sequence_gpu(oracle):
     import random
     for seed in range(40):
-        cfg, snap, _ = random_case(seed, fair=False, preemption=True, tight=seed % 2 == 0)
+        cfg, snap, _ = random_case(seed, fair=seed % 3 == 0, preemption=True, tight=seed % 2 == 0)
         oracle.derive(snap)
         _sequence(_Hip, cfg, snap, random.Random(seed * 29 + 5))
     from kueue_amd.api import make_config
@@ -228,11 +238,18 @@ def test_patch_rows_sequence_gpu(oracle):
     _sequence(_Hip, make_config(), generate(3).snapshot, random.Random(7), steps=3)
 
 
-def test_patch_rows_is_refused_under_fair_sharing(oracle):
-    cfg, snap, _ = random_case(5, fair=True, preemption=True)
-    oracle.derive(snap)
-    x = _Emu(cfg)
-    x.e.put(snap)
-    rc, _ = x.e.patch_rows([], None)
-    x.e.close()
-    assert rc == -4   # KQ_EUNSUPPORTED: the fair search's position-order tables are host-built
+@pytest.mark.parametrize("cfgn", [1, 2])
+def test_rows_rebuild_fair_population_emulated(cfgn):
+    from kueue_amd.api import make_config
+    from kueue_amd.population import generate
+    pop = generate(cfgn, fair_sharing=True)
+    check(_Emu, make_config(fair_sharing=True), pop.snapshot)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfgn", [3, 4])
+def test_rows_rebuild_fair_population_gpu(cfgn):
+    from kueue_amd.api import make_config
+    from kueue_amd.population import generate
+    pop = generate(cfgn, fair_sharing=True)
+    check(_Hip, make_config(fair_sharing=True), pop.snapshot)
