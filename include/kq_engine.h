@@ -317,7 +317,8 @@ int  kq_snapshot_patch(kq_engine* e, const kq_snapshot* s, uint32_t what);
  * cycles) — handed over as the rows that left and the rows that came. The resident row table is compacted and extended ON THE DEVICE
  * (removed rows drop out, the added rows land behind the kept rows of their ClusterQueue, in the order given) and every structure
  * derived from it — candidate rank order per tree, flavor-resource buckets, level orders, row records — is rebuilt there by key
- * sorts (kueue_amd/csrc/kq_rows.hpp); nothing of the admitted table crosses PCIe but the added rows. The result is byte-identical to
+ * sorts (kueue_amd/csrc/kq_rows.hpp). After a cycle: add = the heads it admitted (usage = their assignment), evict_rows = the targets of
+ * its preemptions, remove_rows = the workloads that finished; nothing of the admitted table crosses PCIe but the added rows. The result is byte-identical to
  * kq_snapshot_put of the snapshot with that row table (tests/test_rows_device.py). Row indices of later calls (remove_rows,
  * kq_decisions.tgt_adm, kq_heads.slice_row) refer to the new table: kept rows keep their order, `new_index` (optional, [n rows before
  * the call]) receives the new index of every old row, -1 for a removed one.
@@ -337,6 +338,8 @@ typedef struct kq_row_patch {
   const int32_t* add_use_off;       /* [n_add + 1] */
   const int32_t* add_use_fr;
   const int64_t* add_use_qty;
+  int32_t n_evict;                  /* rows (of the resident table, not among remove_rows) that get KQ_ADM_EVICTED: the targets of the last cycle's */
+  const int32_t* evict_rows;        /* preemptions stay admitted until they terminate, marked Evicted (preemption.go IssuePreemptions)            */
 } kq_row_patch;
 int  kq_snapshot_patch_rows(kq_engine* e, const kq_row_patch* p, int32_t* new_index);
 

@@ -456,7 +456,7 @@ template <class B> struct EngineT {
     int rc = be.sync();
     if (rc != KQ_OK) return fail(rc, be.error());
     R.E = E;
-    kv(std::max(n, E));
+    kv(std::max<size_t>((size_t)n, (size_t)CS_LEVELS * E));
     R.frb = grow<int32_t>(rs[11], E); R.frbr = grow<int32_t>(rs[12], E); R.frec = grow<CsRec>(rs[13], E);
     for (int l = 0; l < CS_LEVELS; l++) R.frl[l] = grow<CsEnt>(rs[14 + l], E);
     be.launch_rows(R, RO_ENT_FILL, n);
@@ -464,11 +464,9 @@ template <class B> struct EngineT {
     be.launch_rows(R, RO_BOUNDS, E + 1);
     be.launch_rows(R, RO_BUCKET_FILL, E);
     be.launch_rows(R, RO_BUCKET_SIZE, (int)nb);
-    for (int l = 0; l < CS_LEVELS; l++) {
-      R.level = l;
-      be.launch_rows(R, RO_LKEY, E); be.sort_pairs(R.key, R.val, key2, val2, E, 42 + bits_of(std::max<int64_t>((int64_t)nb - 1, 1)));
-      be.launch_rows(R, RO_LFILL, E);
-    }
+    // the CS_LEVELS level orders of every bucket in one sort (the passes of three small sorts are launch-bound)
+    be.launch_rows(R, RO_LKEY, CS_LEVELS * E); be.sort_pairs(R.key, R.val, key2, val2, CS_LEVELS * E, 46);
+    be.launch_rows(R, RO_LFILL, CS_LEVELS * E);
     std::vector<int32_t> posoff;
     if (fair) {
       // position order: one more sort, by (tree, ClusterQueue inside the tree, evicted first, candidate rank)
@@ -514,7 +512,9 @@ template <class B> struct EngineT {
   // kq_snapshot_patch_rows (include/kq_engine.h): compaction + insertion of rows on the device, then rows_rebuild
   int snapshot_patch_rows(const kq_row_patch* p, int32_t* new_index) {
     if (!have_snapshot) return fail(KQ_EINVAL, "kq_snapshot_patch_rows before kq_snapshot_put");
-    if (!p || p->n_remove < 0 || p->n_add < 0) return fail(KQ_EINVAL, "bad kq_row_patch");
+    if (!p || p->n_remove < 0 || p->n_add < 0 || p->n_evict < 0) return fail(KQ_EINVAL, "bad kq_row_patch");
+    if (p->n_evict > 0 && !p->evict_rows) return fail(KQ_EINVAL, "null evict_rows");
+    for (int i = 0; i < p->n_evict; i++) if (p->evict_rows[i] < 0 || p->evict_rows[i] >= prep.n_adm) return fail(KQ_EINVAL, "evict_rows out of range");
     if (!rows_device || !rows_device_ok()) return fail(KQ_EUNSUPPORTED, "kq_snapshot_patch_rows: sizes beyond the device path (use kq_snapshot_patch)");
     if (steps_issued != steps_waited) return fail(KQ_EINVAL, "a kq_pending_step is in flight (kq_pending_step_wait first)");
     const int nq = prep.nq, n_old = prep.n_adm, n_rm = p->n_remove, n_add = p->n_add;
@@ -583,6 +583,10 @@ template <class B> struct EngineT {
     R.new_of_old = grow<int32_t>(rb[3], std::max(n_old, 1));   // (rb[3] = ent_cnt of the rebuild: free until then)
     be.launch_rows(R, RO_MOVE_ROW, n_old);
     be.launch_rows(R, RO_ADD_ROW, n_add);
+    if (p->n_evict > 0) {   // (two marks of one row write the same byte with the same bit: no ordering needed)
+      R.ev_rows = (const int32_t*)stage(rb[0], p->evict_rows, (size_t)p->n_evict * 4);
+      be.launch_rows(R, RO_EVICT, p->n_evict);
+    }
     be.scan_excl(R.n_ucnt, R.n_use_off, n_new + 1);
     int32_t U = 0;
     be.d2h(&U, R.n_use_off + n_new, 4);

@@ -6,7 +6,8 @@
 // level orders, row records, bucket fingerprints — is a handful of stable key sorts plus gathers:
 //   rank order   rows by (tree, priority asc, reserve time desc, uid rank asc, row asc): LSD passes uid -> ~rts -> prio -> tree
 //   buckets      (row, distinct flavor-resource) entries by (tree, flavor-resource, rank position)
-//   level order  bucket entries by (bucket, ancestor at depth l + 1 or "none", evicted first, bucket position), l = 0 .. CS_LEVELS - 1
+//   level order  bucket entries by (bucket, ancestor at depth l + 1 or "none", evicted first, bucket position), l = 0 .. CS_LEVELS - 1,
+//                all levels in one sort
 // The sort itself is the backend's (rocPRIM radix sort on the GPU, std::stable_sort in the 1-lane emulation); everything else is the
 // cell functions below, one thread per row / entry / bucket. The results are byte-identical to build_prep's (tests/test_rows_device.py).
 // Fair sharing's position-order tables (kq_fs.hpp: FsScan / FsApply per position) are one more sort by (tree, ClusterQueue, evicted, rank).
@@ -16,7 +17,7 @@
 namespace kq {
 
 enum { RO_ROW_INIT = 0, RO_KEY_RTS, RO_KEY_PRIO, RO_KEY_TREE, RO_RANK, RO_KEY_ASC, RO_ASC, RO_ENT_FILL, RO_BOUNDS, RO_BUCKET_FILL, RO_BUCKET_SIZE,
-       RO_LKEY, RO_LFILL, RO_MOVE_ROW, RO_MOVE_ENT, RO_ADD_ROW, RO_KEY_FS, RO_FS_FILL };
+       RO_LKEY, RO_LFILL, RO_MOVE_ROW, RO_MOVE_ENT, RO_ADD_ROW, RO_KEY_FS, RO_FS_FILL, RO_EVICT };
 
 struct DRows {
   // the row table the structures are built from
@@ -53,6 +54,7 @@ struct DRows {
   const int32_t *o_use_off, *o_use_fr; const int64_t *o_prio, *o_qts, *o_rts, *o_use_qty; const uint32_t* o_uid; const uint8_t* o_flags; const int32_t* o_adm_cq;
   int32_t *n_use_off, *n_use_fr, *n_ucnt; int64_t *n_prio, *n_qts, *n_rts, *n_use_qty; uint32_t* n_uid; uint8_t* n_flags;
   int32_t* new_of_old;  // [old n] new index of an old row, -1 = removed
+  const int32_t* ev_rows;   // old rows that get KQ_ADM_EVICTED
   int n_old, n_add;
   const int32_t *a_target, *a_use_off, *a_use_fr; const int64_t *a_prio, *a_qts, *a_rts, *a_use_qty; const uint32_t* a_uid; const uint8_t* a_flags;
 };
@@ -174,27 +176,30 @@ KQ_DEV int ro_bucket_of(const DRows& R, int j) {  // the bucket holding global e
   while (lo + 1 < R.n_tree * R.nfr && R.frb_off[lo + 1] <= j) lo++;
   return lo;
 }
-KQ_DEV void ro_lkey(const DRows& R, int j) {
+// all CS_LEVELS level orders in ONE sort over CS_LEVELS * E items (x = level * E + entry): key (level, bucket, ancestor, not evicted);
+// the sort is stable and the items of a level arrive in bucket-position order, so the position needs no key bits
+KQ_DEV void ro_lkey(const DRows& R, int x) {
+  const int l = x / R.E, j = x - l * R.E;
   const int row = R.frbr[j];
   const int b = ro_bucket_of(R, j);
-  const int anc = ro_anc(R, R.adm_cq[row], R.level);
+  const int anc = ro_anc(R, R.adm_cq[row], l);
   const uint64_t ev = (R.adm_flags[row] & KQ_ADM_EVICTED) ? 0 : 1;
-  R.key[j] = ((uint64_t)b << 42) | ((uint64_t)(anc < 0 ? R.N : anc) << 21) | (ev << 20) | (uint64_t)(j - R.frb_off[b]);
-  R.val[j] = j;
+  R.key[x] = ((uint64_t)l << 44) | ((uint64_t)b << 22) | ((uint64_t)(anc < 0 ? R.N : anc) << 1) | ev;
+  R.val[x] = j;
 }
-KQ_DEV void ro_lfill(const DRows& R, int q) {
-  const int src = R.val[q];
-  const int b = (int)(R.key[q] >> 42);
+KQ_DEV void ro_lfill(const DRows& R, int x) {
+  const int l = x / R.E, q = x - l * R.E;   // the items of level l occupy [l * E, (l + 1) * E) after the sort
+  const int src = R.val[x];
+  const int b = (int)((R.key[x] >> 22) & 0x3fffff);
   const int j = src - R.frb_off[b];
   const int row = R.frbr[src];
   const int cq = R.adm_cq[row];
-  const int anc = ro_anc(R, cq, R.level);
+  const int anc = ro_anc(R, cq, l);
   const int fr = b % R.nfr;
   int64_t qty = 0;
   for (int e = 0; e < CS_RFR; e++) if (R.adm_rec[row].fr[e] == fr) qty = R.adm_rec[row].qty[e];
-  R.frl[R.level][q] = CsEnt{j | (R.depth[cq] << 24), anc >= 0 ? R.node_local[anc] : -1, row, anc, qty};
+  R.frl[l][q] = CsEnt{j | (R.depth[cq] << 24), anc >= 0 ? R.node_local[anc] : -1, row, anc, qty};
 }
-
 KQ_DEV uint32_t ro_hkey(const DRows& R, int row) { return ((R.adm_flags[row] & KQ_ADM_EVICTED) ? 0u : 0x80000000u) | (uint32_t)R.rank_pos[row]; }
 KQ_DEV void ro_key_fs(const DRows& R, int r) {
   const int c = R.adm_cq[r];
@@ -230,6 +235,7 @@ KQ_DEV void ro_add_row(const DRows& R, int i) {    // i = added row: scalars and
   R.n_prio[nr] = R.a_prio[i]; R.n_qts[nr] = R.a_qts[i]; R.n_rts[nr] = R.a_rts[i]; R.n_uid[nr] = R.a_uid[i]; R.n_flags[nr] = R.a_flags[i];
   R.n_ucnt[nr] = R.a_use_off[i + 1] - R.a_use_off[i];
 }
+KQ_DEV void ro_evict(const DRows& R, int i) { const int nr = R.new_of_old[R.ev_rows[i]]; if (nr >= 0) R.n_flags[nr] |= KQ_ADM_EVICTED; }
 KQ_DEV void ro_move_ent(const DRows& R, int r) {   // r < n_old: an old row's entries; r >= n_old: added row r - n_old (n_use_off scanned)
   if (r < R.n_old) {
     const int nr = R.new_of_old[r];
@@ -264,6 +270,7 @@ KQ_DEV void rows_cell(const DRows& R, int op, int i, bool active) {
     case RO_ADD_ROW: ro_add_row(R, i); break;
     case RO_KEY_FS: ro_key_fs(R, i); break;
     case RO_FS_FILL: ro_fs_fill(R, i); break;
+    case RO_EVICT: ro_evict(R, i); break;
     default: break;
   }
 }

@@ -2,6 +2,8 @@
 // library primitives it needs — a stable radix sort of (64-bit key, int32 value) pairs and an exclusive prefix sum — from rocPRIM.
 // Its own translation unit: the rocPRIM headers stay out of the engine's.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -27,10 +29,19 @@ hipError_t need(Scratch& s, size_t bytes) {
 }
 }  // namespace
 
+// KQ_ROWS_TRACE=1: every step of the rebuild is announced on stderr and waited for (a faulting step is then the last one named)
+static bool rows_trace() { static const bool on = getenv("KQ_ROWS_TRACE") != nullptr; return on; }
+static hipError_t rows_traced(const char* what, int a, int n, hipStream_t stream, hipError_t e) {
+  if (!rows_trace()) return e;
+  fprintf(stderr, "[kq_rows] %s %d n=%d -> %s", what, a, n, hipGetErrorString(e)); fflush(stderr);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  fprintf(stderr, " / %s\n", hipGetErrorString(e)); fflush(stderr);
+  return e;
+}
 hipError_t rows_launch(const DRows& R, int op, int n, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_rows, dim3((n + 255) / 256), dim3(256), 0, stream, R, op, n);
-  return hipGetLastError();
+  return rows_traced("op", op, n, stream, hipGetLastError());
 }
 // stable sort of (key, val) by the low `bits` bits of the key between two pairs of buffers (rocPRIM's double-buffer form: no copy
 // back); on return key / val name the pair that holds the result, key2 / val2 the other one
@@ -45,7 +56,7 @@ hipError_t rows_sort_pairs(uint64_t*& key, int32_t*& val, uint64_t*& key2, int32
   if ((e = rocprim::radix_sort_pairs(g_tmp.p, bytes, dk, dv, (unsigned)n, 0u, (unsigned)bits, stream)) != hipSuccess) return e;
   if (dk.current() != key) { uint64_t* t = key; key = key2; key2 = t; }
   if (dv.current() != val) { int32_t* t = val; val = val2; val2 = t; }
-  return hipSuccess;
+  return rows_traced("sort bits", bits, n, stream, hipSuccess);
 }
 hipError_t rows_scan_excl(const int32_t* in, int32_t* out, int n, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
@@ -53,6 +64,6 @@ hipError_t rows_scan_excl(const int32_t* in, int32_t* out, int n, hipStream_t st
   hipError_t e;
   if ((e = rocprim::exclusive_scan(nullptr, bytes, in, out, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), stream)) != hipSuccess) return e;
   if ((e = need(g_tmp, bytes)) != hipSuccess) return e;
-  return rocprim::exclusive_scan(g_tmp.p, bytes, in, out, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), stream);
+  return rows_traced("scan", 0, n, stream, rocprim::exclusive_scan(g_tmp.p, bytes, in, out, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), stream));
 }
 }  // namespace kq

@@ -16,13 +16,16 @@ from . import _ffi as F
 from .api import Decisions, Heads, Snapshot, make_config
 
 
-def row_patch_struct(remove_rows, add):
+def row_patch_struct(remove_rows, add, evict_rows=()):
     """kq_row_patch from plain arrays -> (struct, the arrays it points into)."""
     keep = []
     p = F.kq_row_patch()
     rm = np.ascontiguousarray(remove_rows, np.int32)
     keep.append(rm)
     p.n_remove = len(rm); p.remove_rows = F.ptr(rm) if len(rm) else None
+    ev = np.ascontiguousarray(evict_rows, np.int32)
+    keep.append(ev)
+    p.n_evict = len(ev); p.evict_rows = F.ptr(ev) if len(ev) else None
     n_add = 0 if not add else len(add["cq"])
     p.n_add = n_add
     if n_add:
@@ -79,10 +82,10 @@ class Engine:
         self._check(self._lib.kq_snapshot_patch(self._h, C.byref(snap.struct()), what))
         self.snap = snap
 
-    def patch_rows(self, remove_rows=(), add: Optional[dict] = None) -> np.ndarray:
+    def patch_rows(self, remove_rows=(), add: Optional[dict] = None, evict_rows=()) -> np.ndarray:
         """kq_snapshot_patch_rows: rows that left / rows that came (add: dict of arrays cq, priority, queue_ts, reserve_ts, uid_rank, flags,
         use_off, use_fr, use_qty); the admitted table and everything derived from it are rebuilt on the device. -> new index of every old row."""
-        p, keep = row_patch_struct(remove_rows, add)
+        p, keep = row_patch_struct(remove_rows, add, evict_rows)
         new_index = np.zeros(max(self._n_adm(), 1), np.int32)
         self._check(self._lib.kq_snapshot_patch_rows(self._h, C.byref(p), F.ptr(new_index)))
         return new_index

@@ -237,6 +237,7 @@ type RowPatch struct {
 	AddFlags                              []uint8
 	AddUseOff, AddUseFr                   []int32
 	AddUseQty                             []int64
+	EvictRows                             []int32 // rows that get the Evicted mark: the targets of the last cycle's preemptions
 }
 
 // PatchRows = kq_snapshot_patch_rows: the O(changes) form of PatchSnapshot(KQ_PATCH_ADMITTED). newIndex (len = rows before the call)
@@ -259,6 +260,8 @@ func (e *Engine) PatchRows(p *RowPatch, newIndex []int32) error {
 	c.add_use_off = (*C.int32_t)(pin(&pin_, p.AddUseOff))
 	c.add_use_fr = (*C.int32_t)(pin(&pin_, p.AddUseFr))
 	c.add_use_qty = (*C.int64_t)(pin(&pin_, p.AddUseQty))
+	c.n_evict = C.int32_t(len(p.EvictRows))
+	c.evict_rows = (*C.int32_t)(pin(&pin_, p.EvictRows))
 	if rc := C.kq_snapshot_patch_rows(e.h, c, (*C.int32_t)(pin(&pin_, newIndex))); rc != 0 {
 		if rc == C.KQ_EUNSUPPORTED {
 			return ErrUnsupported

@@ -9,7 +9,7 @@ from kueue_amd import _ffi as F
 from kueue_amd.api import Decisions
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "libkq_emu.so")
+LIB = os.environ.get("KQE_LIB", os.path.join(HERE, "libkq_emu.so"))   # (KQE_LIB: a sanitizer build of the same source)
 _lib = None
 
 
@@ -281,10 +281,10 @@ def _run_tas(self, heads, ct, tgt_cap=None, want_usage=False, dom_cap=None, rsn_
 EmuEngine.run_tas = _run_tas
 
 
-def _patch_rows(self, remove_rows=(), add=None):
+def _patch_rows(self, remove_rows=(), add=None, evict_rows=()):
     """kqe_snapshot_patch_rows on the emulated engine -> (rc, new index of every old row)."""
     from kueue_amd.engine import row_patch_struct
-    p, keep = row_patch_struct(remove_rows, add)
+    p, keep = row_patch_struct(remove_rows, add, evict_rows)
     cap = C.c_int64(0)
     lib().kqe_debug_read_rows(self.h, C.c_int32(0), None, C.byref(cap))
     new_index = np.zeros(max(int(cap.value) // 4, 1), np.int32)

@@ -253,3 +253,109 @@ def test_rows_rebuild_fair_population_gpu(cfgn):
     from kueue_amd.population import generate
     pop = generate(cfgn, fair_sharing=True)
     check(_Hip, make_config(fair_sharing=True), pop.snapshot)
+
+
+# ---- a resident engine follows the cache through cycles with preemption ---------------------------------------------------------------
+def _edited(snap, adds, evict, usage):
+    """The snapshot after a cycle, as arrays: the admitted heads appended to their ClusterQueue's rows, Evicted marks, the new usage plane."""
+    import copy
+    a = snap.arrays
+    n = snap.n_adm
+    cq_of = np.repeat(np.arange(snap.n_cq), np.diff(a["cq_adm_off"]))
+    rows = []
+    for r in range(n):
+        e0, e1 = int(a["adm_use_off"][r]), int(a["adm_use_off"][r + 1])
+        rows.append(dict(cq=int(cq_of[r]), prio=int(a["adm_priority"][r]), qts=int(a["adm_queue_ts"][r]), rts=int(a["adm_reserve_ts"][r]), uid=int(a["adm_uid_rank"][r]),
+                         flags=int(a["adm_flags"][r]) | (1 if r in evict else 0), fr=a["adm_use_fr"][e0:e1].tolist(), qty=a["adm_use_qty"][e0:e1].tolist()))
+    table = []
+    for c in range(snap.n_cq):
+        table += [x for x in rows if x["cq"] == c] + [x for x in adds if x["cq"] == c]
+    t = copy.copy(snap)
+    b = dict(a)
+    b["cq_adm_off"] = np.concatenate([[0], np.cumsum(np.bincount([x["cq"] for x in table], minlength=snap.n_cq))]).astype(np.int32)
+    b["adm_priority"] = np.array([x["prio"] for x in table], np.int64); b["adm_queue_ts"] = np.array([x["qts"] for x in table], np.int64)
+    b["adm_reserve_ts"] = np.array([x["rts"] for x in table], np.int64); b["adm_uid_rank"] = np.array([x["uid"] for x in table], np.uint32)
+    b["adm_flags"] = np.array([x["flags"] for x in table], np.uint8)
+    b["adm_use_off"] = np.concatenate([[0], np.cumsum([len(x["fr"]) for x in table])]).astype(np.int32)
+    b["adm_use_fr"] = np.array([f for x in table for f in x["fr"]], np.int32); b["adm_use_qty"] = np.array([q for x in table for q in x["qty"]], np.int64)
+    b["usage"] = np.ascontiguousarray(usage, np.int64).reshape(-1)
+    for k in ("adm_priority", "adm_queue_ts", "adm_reserve_ts", "adm_uid_rank", "adm_flags", "adm_use_fr", "adm_use_qty"):
+        if b[k].size == 0:
+            b[k] = np.zeros(1, b[k].dtype)
+    t.arrays = b
+    t.n_adm = len(table)
+    t.admitted = None
+    t._struct = None
+    return t
+
+
+def _follow(oracle, make, seed):
+    """Cycle 1 on the resident snapshot; its admissions become rows, the targets of its preemptions get the Evicted mark, the usage is
+    committed — all on the device (kq_cycle_commit + kq_snapshot_patch_rows); then cycle 2 (the heads that stayed pending) must decide
+    exactly as on a snapshot rebuilt from scratch, and as the oracle does."""
+    from kueue_amd import _ffi as F
+    from kueue_amd.api import Heads
+    cfg, snap, heads = random_case(seed, fair=seed % 4 == 0, preemption=True, tight=True)
+    if heads.n == 0:
+        return 0
+    oracle.derive(snap)
+    cap = None   # (Decisions sizes the target arrays from the snapshot; the engine runs get the same default)
+    want1 = oracle.cycle_run(cfg, snap, heads)
+    usage1, n_adm1, (tcq, tfr, tq) = oracle.cycle_commit(cfg, snap, heads)
+    admitted = [i for i in range(heads.n) if int(want1.a["action"][i]) == F.ACT_ADMIT]
+    cqs = [int(heads.arrays["cq"][i]) for i in admitted]
+    if len(set(cqs)) != len(cqs):
+        return 0                     # (two admitted heads of one ClusterQueue: the triples cannot be told apart here)
+    evict = set()
+    for i in range(heads.n):
+        if int(want1.a["action"][i]) == F.ACT_PREEMPT:
+            evict |= {int(r) for r in want1.a["tgt_adm"][int(want1.a["tgt_off"][i]):int(want1.a["tgt_off"][i + 1])]}
+    uid0 = int(snap.arrays["adm_uid_rank"].max()) + 1 if snap.n_adm else 0
+    adds = []
+    for k, i in enumerate(admitted):
+        c = cqs[k]
+        sel = [j for j in range(len(tcq)) if int(tcq[j]) == c]
+        adds.append(dict(cq=c, prio=int(heads.arrays["priority"][i]), qts=int(heads.arrays["queue_ts"][i]), rts=10 ** 9 + k, uid=uid0 + k, flags=0,
+                         fr=[int(tfr[j]) for j in sel], qty=[int(tq[j]) for j in sel]))
+    snap1 = _edited(snap, adds, evict, usage1)
+    rest = [w for i, w in enumerate(heads.workloads) if i not in set(admitted)]
+    heads2 = Heads(snap1, rest, cycle=heads.cycle + 1)
+    # resident engine: cycle 1, commit, row patch
+    y = make(cfg)
+    y.e.put(snap)
+    got1 = y.run(heads)
+    assert not want1.equal(got1)
+    if hasattr(y.e, "commit"):
+        y.e.commit()
+    else:
+        assert y.lib.kqe_cycle_commit(y.h, None) == 0
+    add = dict(cq=[x["cq"] for x in adds], priority=[x["prio"] for x in adds], queue_ts=[x["qts"] for x in adds], reserve_ts=[x["rts"] for x in adds],
+               uid_rank=[x["uid"] for x in adds], flags=[0] * len(adds), use_off=np.concatenate([[0], np.cumsum([len(x["fr"]) for x in adds])]),
+               use_fr=[f for x in adds for f in x["fr"]], use_qty=[q for x in adds for q in x["qty"]]) if adds else None
+    r = y.e.patch_rows([], add, sorted(evict))
+    if isinstance(r, tuple):
+        assert r[0] == 0, r[0]
+    # the reference: a fresh engine on the rebuilt snapshot
+    x = make(cfg)
+    x.e.put(snap1)
+    for name, p, q in zip(NAMES, read_all(x), read_all(y)):
+        m = min(p.size, q.size)
+        assert p.size == q.size and np.array_equal(p, q), (seed, name, p.size, q.size, np.flatnonzero(p[:m] != q[:m])[:8])
+    if heads2.n:
+        want2 = oracle.cycle_run(cfg, snap1, heads2)
+        y.e.snap = snap1
+        assert not want2.equal(x.run(heads2)), (seed, "fresh engine vs oracle")
+        assert not want2.equal(y.run(heads2)), (seed, "resident engine vs oracle")
+    x.e.close(); y.e.close()
+    return len(adds) + len(evict)
+
+
+def test_resident_engine_follows_the_cache_emulated(oracle):
+    changed = sum(_follow(oracle, _Emu, seed) for seed in range(120))
+    assert changed > 100
+
+
+@pytest.mark.gpu
+def test_resident_engine_follows_the_cache_gpu(oracle):
+    changed = sum(_follow(oracle, _Hip, seed) for seed in range(80))
+    assert changed > 60
