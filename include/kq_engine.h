@@ -476,6 +476,21 @@ int  kq_pending_queue_inadmissible(kq_engine* e, int32_t n, const int32_t* cq);
  * (:419-425, hashToBulkMoveReason). `more` has the layout of kq_pending_put's argument (LocalQueue indices iff the set has them).
  * Not between kq_pending_heads and kq_pending_apply. */
 int  kq_pending_add(kq_engine* e, const kq_pending* more, int32_t* first_index);
+/* PushOrUpdate (cluster_queue.go:379-428) of workloads that ARE pending, with a new object (priority, timestamps, podsets, scheduling
+ * hash ... changed): wl[i] is replaced by the i-th workload of `more` (layout of kq_pending_add's argument, more->w.n == n, the same
+ * uid_rank as the workload it replaces). Records are variable-sized and indices append-only, so the replacement gets the index
+ * *first_index + i and wl[i] leaves the set; what the reference keys by NAME follows it:
+ *   - wl[i] in the heap: PushOrUpdateActive (:427) - the replacement is in the heap whatever its back-off or its class (:414 and
+ *     :421 only look at keys with GetActive(key) == nil);
+ *   - wl[i] inadmissible: RemoveFromInadmissible (:405), then placed like an arrival (back-off :414, bulk-moved class :419-425).
+ *     The in-place branch (:396-403, nothing that matters changed: UpdateInadmissible) needs no call at all;
+ *   - wl[i] gone: a plain arrival. In flight cannot be (:388): not between kq_pending_heads and kq_pending_apply;
+ *   - the ClusterQueue's preemptor pointer (:109 holds a name) moves to the replacement: stickyMatches (:124) still sorts it first,
+ *     IsPreemptor (:213, strict: generation) no longer holds; a replacement in another ClusterQueue clears it (Delete :506);
+ *   - AdmissionFairSharing: the replacement's entry-penalty amounts are set like an arrival's (kq_pending_afs_wl_penalty); a penalty
+ *     RECORD only exists for assumed workloads, which are no longer pending.
+ * Cost: kq_pending_add of the replacements + one small launch. */
+int  kq_pending_update(kq_engine* e, int32_t n, const int32_t* wl, const kq_pending* more, int32_t* first_index);
 /* ClusterQueue.Delete (cluster_queue.go:488-512): the workloads leave the pending set (deleted, finished, admitted by another
  * scheduler). Not between kq_pending_heads and kq_pending_apply. */
 int  kq_pending_delete(kq_engine* e, int32_t n, const int32_t* wl);

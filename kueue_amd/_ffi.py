@@ -255,6 +255,8 @@ def load_engine():
     lib.kq_pending_set_clock.restype = C.c_int
     lib.kq_pending_set_requeue_at.argtypes = [C.c_void_p, C.c_int32, i32p, i64p]
     lib.kq_pending_set_requeue_at.restype = C.c_int
+    lib.kq_pending_update.argtypes = [C.c_void_p, C.c_int32, i32p, C.POINTER(kq_pending), i32p]
+    lib.kq_pending_update.restype = C.c_int
     lib.kq_pending_delete.argtypes = [C.c_void_p, C.c_int32, i32p]
     lib.kq_pending_delete.restype = C.c_int
     lib.kq_pending_bounds.argtypes = [C.c_void_p, i32p, i32p]
@@ -310,7 +312,7 @@ ABI_SYMBOLS = [
     "kq_cycle_certificate", "kq_snapshot_usage_add", "kq_snapshot_patch", "kq_snapshot_patch_rows", "kq_cycle_shard_words", "kq_cycle_nominate_shard", "kq_cycle_process_merged",
     "kq_pending_bounds", "kq_pending_step", "kq_pending_step_wait",
     "kq_pending_afs_put", "kq_pending_afs_wl_penalty", "kq_pending_afs_sub_penalty", "kq_pending_afs_set_consumed", "kq_pending_afs_read",
-    "kq_pending_set_lq_usage", "kq_pending_add", "kq_pending_delete", "kq_pending_set_clock", "kq_pending_set_requeue_at", "kq_pending_put", "kq_pending_heads", "kq_cycle_run_pending", "kq_pending_apply", "kq_pending_queue_inadmissible", "kq_pending_read_state",
+    "kq_pending_set_lq_usage", "kq_pending_add", "kq_pending_update", "kq_pending_delete", "kq_pending_set_clock", "kq_pending_set_requeue_at", "kq_pending_put", "kq_pending_heads", "kq_cycle_run_pending", "kq_pending_apply", "kq_pending_queue_inadmissible", "kq_pending_read_state",
     "kq_debug_read_usage_work", "kq_debug_force_exact_drs", "kq_debug_prof", "kq_debug_spec_stats", "kq_debug_disable_scan_search",
     "kq_debug_rows_rebuild", "kq_debug_read_rows",
 ]

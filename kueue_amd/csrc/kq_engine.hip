@@ -296,6 +296,7 @@ __global__ __launch_bounds__(256) void k_pend_merge(DPend D, const int32_t* ord_
 }
 __global__ __launch_bounds__(64) void k_pend_add_fix(DPend D, DSnap S, int first) { pend_add_fix(D, S, first + (int)blockIdx.x); }
 __global__ __launch_bounds__(64) void k_pend_requeue_at(DPend D, DSnap S, const int32_t* list, const int64_t* at) { pend_requeue_at(D, S, list, at, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_pend_update_fix(DPend D, const int32_t* list, int first, int n) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) pend_update_fix(D, list, first, i); }
 __global__ __launch_bounds__(256) void k_pend_delete(DPend D, const int32_t* list, int n) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) pend_delete(D, list, i); }
 // kq_pending_step, after the cycle: blocks [0, nb) fold the admissions into the snapshot and keep the rows for the release
 // (commit_fused_cell), blocks [nb, nb + n) run the requeue policy of one head each (wave 0 of the block) — one launch instead of three
@@ -629,6 +630,10 @@ struct HipBackend {
     if (n > 0) hipLaunchKernelGGL(k_pend_requeue_at, dim3(n), dim3(64), 0, stream, D, S, list, at);
     chk(hipGetLastError(), "k_pend_requeue_at");
   }
+  void launch_pend_update_fix(const DPend& D, const int32_t* list, int first, int n) {
+    if (n > 0) hipLaunchKernelGGL(k_pend_update_fix, dim3((n + 255) / 256), dim3(256), 0, stream, D, list, first, n);
+    chk(hipGetLastError(), "k_pend_update_fix");
+  }
   void launch_pend_delete(const DPend& D, const int32_t* list, int n) {
     if (n > 0) hipLaunchKernelGGL(k_pend_delete, dim3((n + 255) / 256), dim3(256), 0, stream, D, list, n);
     chk(hipGetLastError(), "k_pend_delete");
@@ -918,6 +923,10 @@ int kq_pending_set_lq_usage(kq_engine* en, int32_t n_lq, const double* usage) {
 int kq_pending_add(kq_engine* en, const kq_pending* more, int32_t* first_index) {
   if (!en || !more) return KQ_EINVAL;
   return en->e.pending_add(more, first_index);
+}
+int kq_pending_update(kq_engine* en, int32_t n, const int32_t* wl, const kq_pending* more, int32_t* first_index) {
+  if (!en || !more || (n > 0 && !wl)) return KQ_EINVAL;
+  return en->e.pending_update(n, wl, more, first_index);
 }
 int kq_pending_set_clock(kq_engine* en, int64_t now_ns) { if (!en) return KQ_EINVAL; return en->e.pending_set_clock(now_ns); }
 int kq_pending_set_requeue_at(kq_engine* en, int32_t n, const int32_t* wl, const int64_t* at) {

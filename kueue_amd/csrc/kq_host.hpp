@@ -1962,6 +1962,28 @@ template <class B> struct EngineT {
     if (rc != KQ_OK) return fail(rc, be.error());
     return KQ_OK;
   }
+  // kq_pending_update (include/kq_engine.h): the replacements are appended and placed like arrivals, then the old records hand over
+  int pending_update(int n, const int32_t* wl, const kq_pending* more, int32_t* first_index) {
+    if (!have_snapshot || !pend.valid) return fail(KQ_EINVAL, "kq_pending_update before kq_pending_put");
+    if (pend.n_heads >= 0) return fail(KQ_EINVAL, "kq_pending_update between kq_pending_heads and kq_pending_apply");
+    if (!more || more->w.n != n || n < 0 || (n > 0 && !wl)) return fail(KQ_EINVAL, "kq_pending_update: one replacement per listed workload");
+    {
+      std::vector<int32_t> seen(wl, wl + n);
+      std::sort(seen.begin(), seen.end());
+      for (int i = 0; i < n; i++) if (seen[i] < 0 || seen[i] >= pend.W || (i > 0 && seen[i] == seen[i - 1])) return fail(KQ_EINVAL, "kq_pending_update: workload out of range or repeated");
+    }
+    int32_t first = pend.W;
+    int rc = pending_add(more, &first);
+    if (first_index) *first_index = first;
+    if (rc != KQ_OK || n == 0) return rc;
+    int32_t* d = (int32_t*)be.alloc((size_t)n * sizeof(int32_t));
+    be.h2d(d, wl, (size_t)n * sizeof(int32_t));
+    be.launch_pend_update_fix(pend.D, d, first, n);
+    rc = be.sync();
+    be.free(d);
+    if (rc != KQ_OK) return fail(rc, be.error());
+    return KQ_OK;
+  }
   int pending_set_clock(int64_t now) { pend.now = now; pend.D.now = now; return KQ_OK; }
   int pending_set_requeue_at(int n, const int32_t* wl, const int64_t* at) {
     if (!have_snapshot || !pend.valid) return fail(KQ_EINVAL, "kq_pending_set_requeue_at before kq_pending_put");

@@ -52,7 +52,7 @@ struct DPend {
   int64_t *last_gen, *last_cycle;
   uint64_t* last_hash;
   int32_t* pw;               // [nq] preemptorWorkload (workload id, -1 = none)
-  uint8_t* pw_sticky;        // [nq]
+  uint8_t* pw_sticky;        // [nq] bit 0: isSticky; bit 1: the workload's object changed since the pointer was set (generation differs: IsPreemptor no more, stickyMatches still)
   int64_t *pop_cycle, *qi_cycle;  // [nq] popCycle, queueInadmissibleCycle (-1 at start, cluster_queue.go:313)
   // the heads of the cycle in flight
   int32_t* head_wl;          // [nq] workload popped from ClusterQueue c, -1 = none
@@ -227,7 +227,7 @@ KQ_DEV void pend_pop(const DPend& D, int c) {
   if (D.cq_active && !D.cq_active[c]) { if (lane == 0) D.head_wl[c] = -1; return; }  // manager.go:926: no Pop at all
   int head = -1;
   const int pw = D.pw[c];
-  const bool sticky = pw >= 0 && D.pw_sticky[c] && D.state[pw] == WL_ACTIVE;
+  const bool sticky = pw >= 0 && (D.pw_sticky[c] & 1) && D.state[pw] == WL_ACTIVE;
   if (sticky && !D.lq) head = pw;  // stickyMatches sorts first (:848-856)
   if (head < 0 && !D.lq) {
     const int o0 = D.cq_off[c], o1 = D.cq_off[c + 1];
@@ -315,7 +315,7 @@ KQ_DEV void pend_gather_head(const DPend& D, const DGather& G, int h) {
   if (lane == 0) {
     G.cq[h] = c; G.priority[h] = D.P.priority[w]; G.queue_ts[h] = D.P.queue_ts[w];
     uint32_t fl = D.mflags[w] & ~(uint32_t)KQ_HEAD_IS_PREEMPTOR;
-    if (D.pw[c] == w) fl |= KQ_HEAD_IS_PREEMPTOR;  // IsPreemptor :213 (generation unchanged while pending)
+    if (D.pw[c] == w && !(D.pw_sticky[c] & 2)) fl |= KQ_HEAD_IS_PREEMPTOR;  // IsPreemptor :213 (strict: the generation the pointer was set with — kq_pending_update marks a change)
     G.flags[h] = fl;
     G.last_generation[h] = D.last_gen[w]; G.last_cycle[h] = D.last_cycle[w]; G.last_hash[h] = D.last_hash[w]; G.hash[h] = D.P.hash[w];
   }
@@ -451,6 +451,27 @@ KQ_DEV void pend_requeue_at(const DPend& D, const DSnap& S, const int32_t* list,
   if (lane == 0) D.state[w] = WL_ACTIVE;       // conditions changed => leaves the inadmissible set (:405) ...
   wsync();
   pend_add_fix(D, S, w);                       // ... unless it still backs off or its class is bulk-moved
+}
+// PushOrUpdate :379-428 of a key that IS pending, with a new object: the replacement (index first + i) was appended and placed like an
+// arrival (pend_add_fix); here the old record's part — one thread per workload:
+//   old in the heap          PushOrUpdateActive :427 — the back-off (:414) and the bulk-moved classes (:421) only count when GetActive(key) == nil
+//   old inadmissible         RemoveFromInadmissible :405, then what an arrival gets (already there)
+//   gone already             a plain arrival
+// The preemptor pointer holds a NAME (:109): it follows the key, stickyMatches (:124) still sees it, the strict match of IsPreemptor
+// (:213, generation) does not. (AdmissionFairSharing: a penalty record only exists once a workload is assumed, i.e. gone from here; the
+// replacement's entry-penalty amounts come through kq_pending_afs_wl_penalty like an arrival's.) Then the old record leaves.
+KQ_DEV void pend_update_fix(const DPend& D, const int32_t* list, int first, int i) {
+  const int old = list[i], w2 = first + i;
+  const int c = D.P.cq[old];
+  const bool same = D.P.cq[w2] == c;
+  const uint8_t st = D.state[old];
+  if (st == WL_GONE) return;
+  if (same && st == WL_ACTIVE) D.state[w2] = WL_ACTIVE;
+  if (D.pw[c] == old) {
+    if (same) { D.pw[c] = w2; D.pw_sticky[c] |= 2; }
+    else { D.pw[c] = -1; D.pw_sticky[c] = 0; }
+  }
+  D.state[old] = WL_GONE;
 }
 // ClusterQueue.Delete :488-512 — one thread per workload
 KQ_DEV void pend_delete(const DPend& D, const int32_t* list, int i) {

@@ -161,6 +161,15 @@ class Engine:
         self.pending = self.pending.extended(more)
         return first.value
 
+    def pending_update(self, wl, more) -> int:
+        """kq_pending_update: PushOrUpdate of workloads that ARE pending with a new object; wl[i] is replaced by more[i], which gets
+        the returned index + i."""
+        a = np.ascontiguousarray(wl, np.int32)
+        first = C.c_int32()
+        self._check(self._lib.kq_pending_update(self._h, C.c_int32(len(a)), F.ptr(a), C.byref(more.struct()), C.byref(first)))
+        self.pending = self.pending.extended(more)
+        return first.value
+
     def pending_set_clock(self, now_ns: int):
         self._check(self._lib.kq_pending_set_clock(self._h, C.c_int64(int(now_ns))))
 

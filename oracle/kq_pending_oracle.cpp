@@ -36,6 +36,7 @@ struct CQ {
   bool strict;                       // queueingStrategy == StrictFIFO
   std::vector<int> members;          // every workload ever pushed (heap U inadmissible U inflight U gone)
   int pw = -1; bool pw_sticky = false;  // preemptorWorkload cluster_queue.go:80-154
+  bool pw_gen_changed = false;          // the workload's object was replaced since set(): matches(strict) fails on the generation (:113-121)
   int64_t popCycle = 0, queueInadmissibleCycle = -1;  // :176-183, :313
   std::set<uint64_t> hashToBulkMoveReason;             // :169-172 (reasons themselves are status text)
 };
@@ -85,7 +86,7 @@ struct Queue {
     if (best >= 0) wl[best].state = KQ_WL_INFLIGHT;
     return best;
   }
-  bool IsPreemptor(int w) const { return cqs[wl[w].cq].pw == w; }  // :213 (generation unchanged while pending)
+  bool IsPreemptor(int w) const { const CQ& c = cqs[wl[w].cq]; return c.pw == w && !c.pw_gen_changed; }  // :213 (strict match: name and generation)
   // handleInadmissibleHash :606-621
   int handleInadmissibleHash(CQ& c, uint64_t hash) {
     if (c.strict) return 0;
@@ -102,7 +103,7 @@ struct Queue {
   // requeueIfNotPresent :550-601
   bool requeueIfNotPresent(int w, bool immediate, int reason) {
     WL& x = wl[w]; CQ& c = cqs[x.cq];
-    if (reason == KQ_RQ_PENDING_PREEMPTION) { c.pw = w; c.pw_sticky = !c.strict; }  // :558-563
+    if (reason == KQ_RQ_PENDING_PREEMPTION) { c.pw = w; c.pw_sticky = !c.strict; c.pw_gen_changed = false; }  // :558-563
     const bool inadm = x.state == KQ_WL_INADMISSIBLE;
     if (backoffExpired(x) && (immediate || c.queueInadmissibleCycle >= c.popCycle || PendingFlavors(x))) {  // :568-575
       if (x.state == KQ_WL_ACTIVE) return false;  // PushActiveIfNotPresent
@@ -128,7 +129,7 @@ struct Queue {
   void Delete(int w) {
     CQ& c = cqs[wl[w].cq];
     wl[w].state = KQ_WL_GONE;
-    if (c.pw == w) { c.pw = -1; c.pw_sticky = false; }
+    if (c.pw == w) { c.pw = -1; c.pw_sticky = false; c.pw_gen_changed = false; }
   }
   // queueInadmissibleWorkloads inadmissible_workloads.go:149-175
   int queueInadmissibleWorkloads(int ci) {
@@ -207,6 +208,30 @@ int kqp_add(void* qp, const kq_pending* p) {
     q.wl.push_back(x);
     q.cqs[x.cq].members.push_back(first + i);
     q.place(first + i);
+  }
+  return first;
+}
+
+// PushOrUpdate (cluster_queue.go:379-428) of keys that ARE pending, each with a new object (the i-th workload of `more` replaces wl[i];
+// a record is immutable here, so the replacement is a new index and the old one leaves). Returns the index of the first replacement.
+int kqp_update(void* qp, int32_t n, const int32_t* wl, const kq_pending* more) {
+  Queue& q = *(Queue*)qp;
+  std::vector<int> was(n);
+  for (int i = 0; i < n; i++) was[i] = q.wl[wl[i]].state;
+  const int first = kqp_add(qp, more);   // what a key with GetActive(key) == nil gets: back-off :414, bulk-moved class :419-425, else the heap
+  for (int i = 0; i < n; i++) {
+    const int old = wl[i], w2 = first + i;
+    if (was[i] == KQ_WL_GONE) continue;   // not pending any more: a plain arrival
+    CQ& c = q.cqs[q.wl[old].cq];
+    const bool same = q.wl[w2].cq == q.wl[old].cq;
+    // in the heap: c.workloads.GetActive(key) != nil, so neither :414 nor :421 applies -> PushOrUpdateActive :427.
+    // inadmissible: RemoveFromInadmissible :405 and on as above. (in flight :388 does not occur between cycles.)
+    if (was[i] == KQ_WL_ACTIVE && same) q.wl[w2].state = KQ_WL_ACTIVE;
+    if (c.pw == old) {
+      if (same) { c.pw = w2; c.pw_gen_changed = true; }   // the pointer is a name (:109): stickyMatches :124 still, IsPreemptor :213 not
+      else { c.pw = -1; c.pw_sticky = false; c.pw_gen_changed = false; }   // left this ClusterQueue: Delete :506
+    }
+    q.wl[old].state = KQ_WL_GONE;
   }
   return first;
 }

@@ -375,6 +375,13 @@ class PendingOracle:
         self.pending = self.pending.extended(more)
         return first
 
+    def update(self, wl, more) -> int:
+        """PushOrUpdate of pending keys with a new object (kqp_update): more[i] replaces wl[i]; returns the first replacement's index."""
+        a = np.ascontiguousarray(wl, np.int32)
+        first = self.l.kqp_update(self.h, C.c_int32(len(a)), F.ptr(a), C.byref(more.struct()))
+        self.pending = self.pending.extended(more)
+        return first
+
     def set_clock(self, now_ns: int):
         self.l.kqp_set_clock.restype = None
         self.l.kqp_set_clock(self.h, C.c_int64(int(now_ns)))

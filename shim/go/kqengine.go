@@ -392,6 +392,30 @@ func (e *Engine) AddPending(more *FlatHeads, uidRank []uint32, nLQ int32, lq []i
 	return int32(first), nil
 }
 
+// UpdatePending = PushOrUpdate (cluster_queue.go:379-428) of keys that ARE pending, each with its new object: more's i-th workload
+// replaces wl[i] (same uidRank) and gets index first+i, wl[i] leaves the set. A key that was in the heap stays in the heap (:427); an
+// inadmissible one is re-evaluated like an arrival (:405-426); the ClusterQueue's sticky preemptor pointer follows the key.
+func (e *Engine) UpdatePending(wl []int32, more *FlatHeads, uidRank []uint32, nLQ int32, lq []int32, requeueAt []int64) (int32, error) {
+	var p runtime.Pinner
+	defer p.Unpin()
+	c := (*C.kq_pending)(C.calloc(1, C.sizeof_kq_pending))
+	defer C.free(unsafe.Pointer(c))
+	fillHeads(&p, &c.w, more)
+	c.uid_rank = (*C.uint32_t)(pin(&p, uidRank))
+	if len(lq) > 0 {
+		c.n_lq = C.int32_t(nLQ)
+		c.lq = (*C.int32_t)(pin(&p, lq))
+	}
+	if len(requeueAt) > 0 {
+		c.requeue_at = (*C.int64_t)(pin(&p, requeueAt))
+	}
+	var first C.int32_t
+	if rc := C.kq_pending_update(e.h, C.int32_t(len(wl)), (*C.int32_t)(pin(&p, wl)), c, &first); rc != 0 {
+		return 0, e.err("kq_pending_update", rc)
+	}
+	return int32(first), nil
+}
+
 const (
 	RequeueNone    = int64(-1 << 63) // no RequeueState.RequeueAt
 	RequeueBlocked = int64(1<<63 - 1) // the Requeued condition is False

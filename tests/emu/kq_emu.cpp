@@ -111,6 +111,7 @@ struct EmuBackend {
   }
   void launch_pend_add_fix(const DPend& D, const DSnap& S, int first, int n) { for (int i = 0; i < n; i++) pend_add_fix(D, S, first + i); }
   void launch_pend_requeue_at(const DPend& D, const DSnap& S, const int32_t* list, const int64_t* at, int n) { for (int i = 0; i < n; i++) pend_requeue_at(D, S, list, at, i); }
+  void launch_pend_update_fix(const DPend& D, const int32_t* list, int first, int n) { for (int i = 0; i < n; i++) pend_update_fix(D, list, first, i); }
   void launch_pend_delete(const DPend& D, const int32_t* list, int n) { for (int i = 0; i < n; i++) pend_delete(D, list, i); }
   void launch_pend_qi(const DPend& D, const int32_t* list, int n) { for (int i = 0; i < n; i++) pend_queue_inadmissible(D, list ? list[i] : i); }
   void launch_pend_release(const DPend& D, const DSnap& S, int32_t* tree_stamp, const int32_t* cq, const int32_t* use_n, int n, int32_t stamp) {
@@ -290,6 +291,9 @@ int kqe_pending_afs_read(void* e, double* usage, uint64_t* plo, int64_t* phi, ui
 }
 int kqe_pending_set_lq_usage(void* e, int32_t n, const double* u) { return ((EmuEngine*)e)->pending_set_lq_usage(n, u); }
 int kqe_pending_add(void* e, const kq_pending* more, int32_t* first) { return ((EmuEngine*)e)->pending_add(more, first); }
+int kqe_pending_update(void* e, int32_t n, const int32_t* wl, const kq_pending* more, int32_t* first) { return ((EmuEngine*)e)->pending_update(n, wl, more, first); }
+// the flags of the gathered heads as the cycle will see them (IsPreemptor is decided at gather time)
+int kqe_pending_head_flags(void* ep, uint32_t* out, int32_t n) { EmuEngine& e = *(EmuEngine*)ep; for (int i = 0; i < n; i++) out[i] = e.pend.G.flags[i]; return 0; }
 int kqe_pending_set_clock(void* e, int64_t now) { return ((EmuEngine*)e)->pending_set_clock(now); }
 int kqe_pending_set_requeue_at(void* e, int32_t n, const int32_t* wl, const int64_t* at) { return ((EmuEngine*)e)->pending_set_requeue_at(n, wl, at); }
 int kqe_pending_delete(void* e, int32_t n, const int32_t* wl) { return ((EmuEngine*)e)->pending_delete(n, wl); }

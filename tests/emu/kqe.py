@@ -155,6 +155,18 @@ class EmuEngine:
         self.pending = self.pending.extended(more)
         return first.value
 
+    def pending_batch_flags(self, n):
+        out = np.zeros(max(n, 1), np.uint32)
+        self._ok(lib().kqe_pending_head_flags(self.h, F.ptr(out), C.c_int32(n)))
+        return out[:n]
+
+    def pending_update(self, wl, more) -> int:
+        a = np.ascontiguousarray(wl, np.int32)
+        first = C.c_int32()
+        self._ok(lib().kqe_pending_update(self.h, C.c_int32(len(a)), F.ptr(a), C.byref(more.struct()), C.byref(first)))
+        self.pending = self.pending.extended(more)
+        return first.value
+
     def pending_set_clock(self, now_ns: int):
         self._ok(lib().kqe_pending_set_clock(self.h, C.c_int64(int(now_ns))))
 

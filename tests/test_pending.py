@@ -361,7 +361,7 @@ def test_afs_ordering_closed_loop_gpu(oracle):
 
 # ---- arrivals and deletions between cycles (PushOrUpdate cluster_queue.go:379, Delete :488) ---------------------------------------
 
-def _arrivals_loop(oracle, eng_factory, pop, cfg, cycles, seed, start_frac=0.4):
+def _arrivals_loop(oracle, eng_factory, pop, cfg, cycles, seed, start_frac=0.4, updates=False):
     """Half of the population is resident at the start; every cycle a few more workloads arrive (kq_pending_add) and a few pending
     ones are deleted (kq_pending_delete). Heads(), every decision and the queue states equal the oracle's in every cycle."""
     rng = np.random.default_rng(seed)
@@ -373,7 +373,8 @@ def _arrivals_loop(oracle, eng_factory, pop, cfg, cycles, seed, start_frac=0.4):
     rest = list(perm[n0:])
     snap = pop.snapshot
     eng = eng_factory(cfg); q = oracle.PendingOracle(cfg, snap, resident)
-    added = deleted = inadm_on_arrival = 0
+    added = deleted = inadm_on_arrival = updated = 0
+    kinds = {"inadmissible": 0, "sticky": 0}
     try:
         eng.put(snap); eng.pending_put(resident)
         osnap = copy.copy(snap); osnap.arrays = dict(snap.arrays)
@@ -393,7 +394,25 @@ def _arrivals_loop(oracle, eng_factory, pop, cfg, cycles, seed, start_frac=0.4):
                 d = rng.choice(alive, size=min(2, len(alive)), replace=False)
                 eng.pending_delete(d); q.delete_many(d)
                 deleted += len(d)
-            assert np.array_equal(eng.pending_state()[0], q.state()), f"cycle {cyc}: states differ after add / delete"
+            st = q.state()
+            alive = np.nonzero(st != F.WL_GONE)[0]
+            if updates and len(alive) and cyc % 3 != 0:   # PushOrUpdate of pending keys with a new object (kq_pending_update)
+                u = np.sort(rng.choice(alive, size=min(int(rng.integers(1, 4)), len(alive)), replace=False))
+                cur = q.pending
+                repl = Pending(cur.heads.subset(u), uid_rank=cur.uid_rank[u])
+                a = repl.heads.arrays
+                a["priority"] = a["priority"] + rng.integers(-2, 3, len(u))
+                a["queue_ts"] = a["queue_ts"] + rng.integers(0, 2, len(u)) * 7
+                if rng.integers(0, 2):   # another class: one already seen in the same ClusterQueue, if any
+                    for i, w in enumerate(u):
+                        same = np.nonzero(cur.heads.arrays["cq"] == cur.heads.arrays["cq"][w])[0]
+                        a["hash"][i] = cur.heads.arrays["hash"][rng.choice(same)]
+                repl.heads._struct = None
+                kinds["inadmissible"] += int((st[u] == F.WL_INADMISSIBLE).sum()); kinds["sticky"] += sum(q.is_sticky(int(w)) for w in u)
+                g1 = eng.pending_update(u, repl); g2 = q.update(u, repl)
+                assert g1 == g2
+                updated += len(u)
+            assert np.array_equal(eng.pending_state()[0], q.state()), f"cycle {cyc}: states differ after add / delete / update"
             n, nps, hw = eng.pending_heads(cyc)
             hb, ohw = q.heads(cyc)
             assert np.array_equal(hw, ohw), f"cycle {cyc}: Heads() differ"
@@ -410,7 +429,7 @@ def _arrivals_loop(oracle, eng_factory, pop, cfg, cycles, seed, start_frac=0.4):
             if cyc % 5 == 0:
                 eng.pending_queue_inadmissible(); q.queue_inadmissible()
             assert np.array_equal(eng.pending_state()[0], q.state()), f"cycle {cyc}: states differ"
-        return added, deleted, inadm_on_arrival
+        return (added, deleted, kinds, updated) if updates else (added, deleted, inadm_on_arrival)
     finally:
         eng.close(); q.close()
 
@@ -421,6 +440,23 @@ def test_pending_arrivals_and_deletions_emulated(oracle, cfgn, n_cq, per):
     pop = generate(cfgn, n_cq=n_cq, per_cq=per)
     added, deleted, _ = _arrivals_loop(oracle, kqe.EmuEngine, pop, make_config(), cycles=30, seed=cfgn)
     assert added > 20 and deleted > 10
+
+
+@pytest.mark.parametrize("cfgn,n_cq,per", [(3, 24, 10), (2, 12, 14), (1, 4, 20)], ids=["cfg3", "cfg2", "cfg1-strict"])
+def test_pending_updates_emulated(oracle, cfgn, n_cq, per):
+    """The same loop with kq_pending_update in it: pending keys get a new object (priority, timestamp, class) between cycles."""
+    from tests.emu import kqe
+    pop = generate(cfgn, n_cq=n_cq, per_cq=per)
+    added, deleted, kinds, updated = _arrivals_loop(oracle, kqe.EmuEngine, pop, make_config(), cycles=30, seed=10 + cfgn, updates=True)
+    assert updated > 25 and added > 20 and (cfgn != 3 or kinds["inadmissible"] > 0)
+
+
+def test_pending_updates_with_preemption_emulated(oracle):
+    """... on a population whose heads preempt (PendingPreemption sets the sticky preemptor pointer, which an update must carry along)."""
+    from tests.emu import kqe
+    pop = generate(4, n_cq=20, per_cq=8)
+    added, deleted, kinds, updated = _arrivals_loop(oracle, kqe.EmuEngine, pop, make_config(), cycles=30, seed=5, updates=True)
+    assert updated > 20 and kinds["sticky"] > 0 and kinds["inadmissible"] > 0
 
 
 def test_new_workload_of_a_bulk_moved_class_arrives_inadmissible(oracle):
@@ -470,6 +506,17 @@ def test_pending_arrivals_and_deletions_gpu(oracle):
     pop = generate(3, n_cq=200, per_cq=20)
     added, deleted, _ = _arrivals_loop(oracle, Engine, pop, make_config(), cycles=30, seed=9)  # (no releases here: stay inside the commit ring)
     assert added > 50 and deleted > 20
+
+
+@pytest.mark.gpu
+def test_pending_updates_gpu(oracle):
+    from kueue_amd.engine import Engine
+    pop = generate(3, n_cq=200, per_cq=20)
+    added, deleted, kinds, updated = _arrivals_loop(oracle, Engine, pop, make_config(), cycles=30, seed=19, updates=True)
+    assert updated > 25 and added > 50
+    pop = generate(4, n_cq=20, per_cq=8)
+    added, deleted, kinds, updated = _arrivals_loop(oracle, Engine, pop, make_config(), cycles=30, seed=5, updates=True)
+    assert updated > 20 and kinds["sticky"] > 0 and kinds["inadmissible"] > 0
 
 
 # ---- back-off after a PodsReady timeout (backoffWaitingTimeExpired cluster_queue.go:474) --------------------------------------------
@@ -669,5 +716,96 @@ def test_delete_and_inflight_update(oracle):
         # (the engine refuses updates between Heads() and apply: the host applies them after the cycle — same outcome)
         with pytest.raises(AssertionError):
             eng.pending_set_requeue_at([1], [F.REQUEUE_NONE])
+    finally:
+        eng.close(); q.close()
+
+
+# ---- PushOrUpdate of a key that is pending, with a new object (kq_pending_update; cluster_queue.go:379-428) --------------------------------------
+def _fabricate(eng, snap, n, nps, rq):
+    from tests.emu import kqe
+    z = lambda: F.ptr(np.zeros(n, np.uint8))
+    rc = kqe.lib().kqe_pending_apply_fabricated(eng.h, z(), z(), z(), F.ptr(np.full(n, rq, np.uint8)), F.ptr(np.full(nps * snap.n_resource, -1, np.int32)))
+    assert rc == 0
+
+
+@pytest.mark.parametrize("old_state,backoff,blocked_hash,want", [
+    ("heap", False, False, F.WL_ACTIVE),            # PushOrUpdateActive :427
+    ("heap", True, False, F.WL_ACTIVE),             # :414 only looks at keys with GetActive(key) == nil
+    ("heap", False, True, F.WL_ACTIVE),             # :421 likewise
+    ("inadmissible", False, False, F.WL_ACTIVE),    # spec changed: RemoveFromInadmissible :405, then the heap
+    ("inadmissible", True, False, F.WL_INADMISSIBLE),   # ... unless it still backs off :414
+    ("inadmissible", False, True, F.WL_INADMISSIBLE),   # ... or its (new) class was bulk-moved :419-425
+], ids=["active stays active", "active ignores back-off", "active ignores bulk-moved class", "inadmissible leaves", "inadmissible backs off", "inadmissible class blocked"])
+def test_push_or_update_of_a_pending_key(oracle, old_state, backoff, blocked_hash, want):
+    """The branches of PushOrUpdate for a key that is already pending (TestPushOrUpdateRespectsInadmissibleHashes :1955 has the
+    "already active" row; the rest follows :391-427), oracle and device code side by side."""
+    from tests.emu import kqe
+    snap = _one_cq()
+    cfg = make_config()
+    none = lambda n: np.full(n, F.REQUEUE_NONE, np.int64)
+    first = _mk_pending(snap, ["blocker", "wl"], [11, 33], at=none(2))
+    q = oracle.PendingOracle(cfg, snap, first)
+    eng = kqe.EmuEngine(cfg)
+    try:
+        eng.put(snap); eng.pending_put(first)
+        q.set_clock(1000); eng.pending_set_clock(1000)
+        # "blocker" (class 11) comes back NoFit: hashToBulkMoveReason = {11}
+        assert q.pop(0) == 0
+        q.requeue(0, F.RQ_NOFIT)
+        n, nps, hw = eng.pending_heads(1)
+        assert n == 1 and hw[0] == 0
+        _fabricate(eng, snap, 1, nps, F.RQ_NOFIT)
+        if old_state == "inadmissible":   # "wl" (class 33) too, by its own NoFit round
+            assert q.pop(0) == 1
+            q.requeue(1, F.RQ_NOFIT)
+            n, nps, hw = eng.pending_heads(2)
+            assert n == 1 and hw[0] == 1
+            _fabricate(eng, snap, 1, nps, F.RQ_NOFIT)
+        assert list(q.state()) == list(eng.pending_state()[0])
+        assert q.state()[1] == (F.WL_INADMISSIBLE if old_state == "inadmissible" else F.WL_ACTIVE)
+        # the new object: another priority, maybe a class that is blocked, maybe a back-off that has not expired
+        repl = _mk_pending(snap, ["wl"], [11 if blocked_hash else 44], rank0=1, at=np.array([5000 if backoff else F.REQUEUE_NONE], np.int64))
+        repl.heads.arrays["priority"][:] = 7; repl.heads._struct = None
+        i1, i2 = eng.pending_update([1], repl), q.update([1], repl)
+        assert i1 == i2 == 2
+        assert list(q.state()) == list(eng.pending_state()[0])
+        assert q.state()[1] == F.WL_GONE and q.state()[2] == want
+    finally:
+        eng.close(); q.close()
+
+
+def test_update_keeps_the_sticky_preemptor_but_not_is_preemptor(oracle):
+    """preemptorWorkload holds a name (cluster_queue.go:109): after PushOrUpdate of that key with a new object stickyMatches (:124) still
+    sorts it first, IsPreemptor (:213, strict: generation) no longer holds."""
+    from tests.emu import kqe
+    snap = _one_cq()
+    cfg = make_config()
+    first = _mk_pending(snap, ["low", "high"], [0, 0])
+    first.heads.arrays["priority"][:] = [1, 9]; first.heads._struct = None
+    q = oracle.PendingOracle(cfg, snap, first)
+    eng = kqe.EmuEngine(cfg)
+    try:
+        eng.put(snap); eng.pending_put(first)
+        # "low" is made the sticky preemptor: pop "high" first and park it, then "low" pops and comes back PendingPreemption
+        assert q.pop(0) == 1
+        q.requeue(1, F.RQ_NOFIT)
+        n, nps, hw = eng.pending_heads(1); assert hw[0] == 1
+        _fabricate(eng, snap, 1, nps, F.RQ_NOFIT)
+        assert q.pop(0) == 0
+        q.requeue(0, F.RQ_PENDING_PREEMPTION)
+        n, nps, hw = eng.pending_heads(2); assert hw[0] == 0
+        _fabricate(eng, snap, 1, nps, F.RQ_PENDING_PREEMPTION)
+        q.queue_inadmissible(); eng.pending_queue_inadmissible()      # "high" is back in the heap: the sticky one still goes first
+        assert list(q.state()) == [F.WL_ACTIVE, F.WL_ACTIVE] == list(eng.pending_state()[0])
+        assert q.is_sticky(0)
+        repl = _mk_pending(snap, ["low"], [0], rank0=0)
+        repl.heads.arrays["priority"][:] = 2; repl.heads._struct = None
+        assert eng.pending_update([0], repl) == q.update([0], repl) == 2
+        assert q.is_sticky(2) and not q.is_sticky(0)
+        hb, ohw = q.heads(3)
+        n, nps, hw = eng.pending_heads(3)
+        assert list(hw) == list(ohw) == [2]                            # sticky: ahead of "high" (priority 9)
+        assert not (int(hb.arrays["flags"][0]) & F.HEAD_IS_PREEMPTOR)   # the generation changed
+        assert int(eng.pending_batch_flags(1)[0]) == int(hb.arrays["flags"][0])
     finally:
         eng.close(); q.close()
