@@ -825,6 +825,7 @@ KQ_DEV void set_error(const K& k, int code) {
 // ------------------------------------------------------------------------------------------------
 #ifdef KQ_TAS_CYCLE
 KQ_DEV void tc_reset(Wave& w);
+KQ_NOINLINE void tc_requests(const K& k, Wave& w);
 KQ_DEV void tc_assign_tas(const K& k, Wave& w, int slot);
 KQ_DEV void tc_search_begin(const K& k, Wave& w, int slot);
 KQ_DEV void tc_search_end(Wave& w);
@@ -2467,6 +2468,12 @@ KQ_DEV Search get_assignments_inner(const K& k, Wave& w, int slot, const int64_t
     // no reduced count works: the full assignment, no targets (scheduler.go:923)
     assign_flavors<false>(k, w, slot, usage, removed, nullptr, nominate_map);
     w.ntgt = 0;
+#ifdef KQ_TAS_CYCLE
+    // the reference returns the SAME fullAssignment object GetTargets (scheduler.go:897) already looked at: a psError that
+    // WorkloadsTopologyRequests left on one of its podsets (flavorassigner.go:290, preemption.go:135) is still there when
+    // updateAssignmentForTAS asks for its RepresentativeMode. Regenerating the outputs must not lose it.
+    if (k.tc && arm == M_PREEMPT) tc_requests(k, w);
+#endif
   }
   wsync();
   if (lane_id() == 0) w.bytes = bytes_before;

@@ -25,7 +25,7 @@ constexpr int TC_ML = KQ_TAS_MAX_LEVELS;
 enum {
   TQ_WLOFF = 0, TQ_COUNT = 2, TQ_LEVEL = TQ_COUNT + TC_P, TQ_SSIZE = TQ_LEVEL + TC_P, TQ_SLEVEL = TQ_SSIZE + TC_P, TQ_GROUP = TQ_SLEVEL + TC_P,
   TQ_NLAY = TQ_GROUP + TC_P, TQ_LLEVEL = TQ_NLAY + TC_P, TQ_LSIZE = TQ_LLEVEL + TC_P * TC_ML, TQ_STATUS = TQ_LSIZE + TC_P * TC_ML,
-  TQ_OPA = TQ_STATUS + TC_P, TQ_OPB = TQ_OPA + TC_P, TQ_DPOS = TQ_OPB + TC_P, TQ_DN = TQ_DPOS + TC_P, TQ_MISC = TQ_DN + TC_P, TQ_WORDS = TQ_MISC + 8
+  TQ_OPA = TQ_STATUS + TC_P, TQ_OPB = TQ_OPA + TC_P, TQ_DPOS = TQ_OPB + TC_P, TQ_DN = TQ_DPOS + TC_P, TQ_MISC = TQ_DN + TC_P, TQ_WORDS = TQ_MISC + 24   // misc: pool_used, error, bytes (64 bit), then the timing builds' cycle counters
 };
 static_assert(TQ_MISC % 2 == 0, "the misc words hold an aligned 64-bit byte counter");
 
@@ -309,7 +309,7 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
       }
     }
     qu[TC_P] = simulateEmpty ? 1 : 0;
-    for (int i = 0; i < 8; i++) qi[TQ_MISC + i] = 0;
+    for (int i = 0; i < 24; i++) qi[TQ_MISC + i] = 0;
     if (c.stats) atomic_add_i64(c.stats, 1);
   }
   wsync();
@@ -344,7 +344,10 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
   wsync();
   if (which != 0) KQ_TS(k, 45);   // (timing builds, processEntry only) the placement; 46 = its phase 1
 #if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
-  if (lane == 0 && which != 0) atomic_add_i64((long long*)k.prof + 46, *(long long*)(qi + TQ_MISC + 4));
+  if (lane == 0 && which != 0) {
+    atomic_add_i64((long long*)k.prof + 46, *(long long*)(qi + TQ_MISC + 4));
+    for (int j = 0; j < 8; j++) atomic_add_i64((long long*)k.prof + 51 + j, *(long long*)(qi + TQ_MISC + 6 + 2 * j));   // TPROF segments of the placement
+  }
 #endif
   // (the placement's own algorithmic bytes, qi[TQ_MISC + 2], are not added to the cycle's counter: SURVEY 8d's accounting of the quota
   // cycle does not include them, and neither does the oracle's)

@@ -95,6 +95,14 @@ KQ_DEV TState tas_state(const TK& k, int slot) {
   return s;
 }
 
+// timing builds: cycles of a placement's segments, in the words behind the byte counter (O.bytes[2 + id]); read by tc_find
+#if defined(KQ_PROF) && !defined(KQ_HOST_EMU) && defined(KQ_TAS_CYCLE)   // (the cycle's request block has the room; the batch kernel's counter is one word)
+#define TPROF0() long long _tp = clock64()
+#define TPROF(k, id) do { const long long _tq = clock64(); if (lane_id() == 0) (k).O.bytes[2 + (id)] += _tq - _tp; _tp = _tq; } while (0)
+#else
+#define TPROF0() do {} while (0)
+#define TPROF(k, id) do {} while (0)
+#endif
 struct TParams {  // topologyAssignmentParameters :473 + requirements :461
   int32_t count, leaderCount, sliceSize;
   int requestedLevelIdx, sliceLevelIdx;
@@ -439,6 +447,72 @@ KQ_DEV int t_best_fit_slices(const TState& s, TView& v, int from, int32_t sliceC
 }
 
 // prioritizeLeaderDomain :1533 — the first leader-capable domain whose leader penalty fits in the slack moves to the front
+// t_view + domains[0] + the best-fit scan from position 0 in ONE sweep over the slice. A lone wave pays a fixed latency per sweep (a
+// round trip to its scratch rows, two or three wave reductions, a fence) whatever the slice's length, and a placement used to make
+// four of them per level: the keys, the arg-min, the smallest count >= needed, its first holder (profiles/r03n_prof_tas_cycle.txt:
+// 52 us of phase 2 per recomputation, mostly that latency). Here every element's keys are built and stored for the t_get calls that
+// may follow, and two minima are kept on the way: the slice order (= domains[0]) and (count, slice order) over the elements that hold
+// `needed` with `leaderCount` leaders (= findBestFitDomainBy :1307 over domains[0:]).
+//   *first  domains[0], -1 when the slice has nothing but all-zero domains
+//   *fit    the best-fit domain among the holders, -1 when nothing holds `needed`
+// The view comes back with domains[0] materialised, exactly as after t_view + t_get(.., 0).
+KQ_DEV TView t_view_first_fit(const TK& k, const TState& s, int n, int order, bool unconstrained, int32_t needed, int which, int32_t leaderCount,
+                              int* first, int* fit) {
+  TView v;
+  v.n = n; v.order = order; v.lfc = t_lfc(k, unconstrained); v.mat = 0; v.c0 = 0; v.c1 = 0; v.started = false; v.skip = -1;
+  uint64_t b0 = ~0ull, b1 = ~0ull;               // slice order
+  uint64_t f0 = ~0ull, f1 = ~0ull, fc = ~0ull;   // (count, slice order) over the holders
+  constexpr int UNR = 4;
+  for (int base = lane_id(); base < n; base += WAVE * UNR) {
+    int dv[UNR]; int32_t pcv[UNR], scv[UNR], pwv[UNR], swv[UNR], lcv[UNR];
+    #pragma unroll
+    for (int q = 0; q < UNR; q++) { const int i = base + q * WAVE; dv[q] = i < n ? s.set[i] : -1; }
+    #pragma unroll
+    for (int q = 0; q < UNR; q++) {
+      const int d = dv[q];
+      if (d < 0) { pcv[q] = scv[q] = pwv[q] = swv[q] = lcv[q] = 0; continue; }
+      pcv[q] = s.pc[d]; scv[q] = s.sc[d]; pwv[q] = s.pcwl[d]; swv[q] = s.scwl[d]; lcv[q] = s.lc[d];
+    }
+    #pragma unroll
+    for (int q = 0; q < UNR; q++) {
+      const int i = base + q * WAVE, d = dv[q];
+      if (d < 0) continue;
+      uint64_t a, b;
+      if (order == ORD_LIST) { a = 0; b = ((uint64_t)(uint32_t)i << 32) | (uint32_t)d; }
+      else {
+        const bool wl = order == ORD_LEADER;
+        const uint32_t l = wl ? (uint32_t)lcv[q] : 0u, sc2 = (uint32_t)(wl ? swv[q] : scv[q]), pc2 = (uint32_t)(wl ? pwv[q] : pcv[q]);
+        a = ((uint64_t)(0x7fffffffu - l) << 32) | (uint64_t)(v.lfc ? sc2 : 0x7fffffffu - sc2);
+        b = ((uint64_t)pc2 << 32) | (uint32_t)d;
+      }
+      const bool zero = order != ORD_LIST && (pcv[q] | scv[q] | pwv[q] | swv[q] | lcv[q]) == 0;
+      s.k0[i] = zero ? (a | KQ_TAS_EXCLUDED) : a; s.k1[i] = b;
+      if (zero) continue;
+      if (t_key_lt(a, b, b0, b1)) { b0 = a; b1 = b; }
+      const int32_t c = which == 0 ? pcv[q] : which == 1 ? pwv[q] : which == 2 ? scv[q] : swv[q];
+      if (lcv[q] >= leaderCount && c >= needed) {
+        const uint64_t cu = (uint64_t)(uint32_t)c;
+        if (cu < fc || (cu == fc && t_key_lt(a, b, f0, f1))) { fc = cu; f0 = a; f1 = b; }
+      }
+    }
+  }
+  const uint64_t m0 = wmin_u64(b0);
+  const uint64_t m1 = wmin_u64(b0 == m0 ? b1 : ~0ull);
+  const uint64_t g = wmin_u64(fc);
+  *first = -1; *fit = -1;
+  if (g != ~0ull) {
+    const uint64_t g0 = wmin_u64(fc == g ? f0 : ~0ull);
+    const uint64_t g1 = wmin_u64(fc == g && f0 == g0 ? f1 : ~0ull);
+    *fit = t_dom(g1);
+  }
+  if (!(m0 == ~0ull && m1 == ~0ull)) {
+    *first = t_dom(m1);
+    v.started = true; v.c0 = m0; v.c1 = m1; v.mat = 1;
+    if (lane_id() == 0) s.arr[0] = *first;
+  }
+  wsync();
+  return v;
+}
 struct SelLeaderElig {
   const TState* s; int32_t leaderCount, availableCapacity, requiredCapacity; bool slices;
   KQ_MDEV bool take(uint64_t, uint64_t a1) const {
@@ -510,7 +584,12 @@ KQ_DEV bool t_consume_with_leaders(const TK& k, const TState& s, TView& v, int i
 // returns the new length of out, -1 on the reference's "unexpected remainingCount" path
 KQ_DEV int t_update_counts(const TK& k, const TState& s, int n, int order, int32_t count, int32_t leaderCount, int32_t sliceSize,
                            bool unconstrained, bool slices, int32_t* out, int out_n, int32_t recompute = 0) {
-  TView v = t_view(k, s, n, order, unconstrained);
+  const bool bestfit = !t_lfc(k, unconstrained);
+  // no leader, no inner-layer recount, BestFit: keys, domains[0] and the first best-fit scan in one sweep
+  const bool fuse = leaderCount == 0 && recompute <= 1 && bestfit;
+  int first0 = -1, fit0 = -1;
+  TView v = fuse ? t_view_first_fit(k, s, n, order, unconstrained, slices ? count / sliceSize : count, slices ? 2 : 0, 0, &first0, &fit0)
+                 : t_view(k, s, n, order, unconstrained);
   if (recompute > 1) {
     // an inner slice layer (:1060-1070): the children were sorted with the slice counts phase 1 left (the keys above), only then
     // are the counts recomputed for this layer's size
@@ -521,9 +600,9 @@ KQ_DEV int t_update_counts(const TK& k, const TState& s, int n, int order, int32
   t_prioritize_leader(k, s, v, count, leaderCount, sliceSize, slices);
   int32_t remainingPrimary = slices ? count / sliceSize : count;
   int32_t remainingLeaderCount = leaderCount;
-  const bool bestfit = !t_lfc(k, unconstrained);
   for (int i = 0;; i++) {
-    int dom = t_get(s, v, i);
+    const bool pre = fuse && i == 0;   // (remainingPrimary is still what the sweep was given)
+    int dom = pre ? first0 : t_get(s, v, i);
     if (dom < 0) break;
     if (remainingLeaderCount > 0) {
       const bool completed = t_consume_with_leaders(k, s, v, i, &dom, &remainingPrimary, &remainingLeaderCount, unconstrained, slices ? sliceSize : 1, slices);
@@ -534,7 +613,7 @@ KQ_DEV int t_update_counts(const TK& k, const TState& s, int n, int order, int32
       continue;
     }
     if (slices) {
-      if (bestfit && s.sc[dom] >= remainingPrimary) dom = t_best_fit_slices(s, v, i, remainingPrimary, 0);
+      if (bestfit && s.sc[dom] >= remainingPrimary) dom = pre ? (fit0 >= 0 ? fit0 : dom) : t_best_fit_slices(s, v, i, remainingPrimary, 0);
       const int32_t scv = s.sc[dom];
       wsync();
       if (scv >= remainingPrimary) {
@@ -549,7 +628,7 @@ KQ_DEV int t_update_counts(const TK& k, const TState& s, int n, int order, int32
       wsync();
       continue;
     }
-    if (bestfit && s.pc[dom] >= remainingPrimary) dom = t_best_fit_pods(s, v, i, remainingPrimary, 0);
+    if (bestfit && s.pc[dom] >= remainingPrimary) dom = pre ? (fit0 >= 0 ? fit0 : dom) : t_best_fit_pods(s, v, i, remainingPrimary, 0);
     const int32_t pcv = s.pc[dom];
     wsync();
     if (pcv >= remainingPrimary) {
@@ -608,8 +687,10 @@ KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* 
     if (n == 0) return TFail{KQ_TAS_NO_LEVEL, 0, 0};
     for (int i = lane_id(); i < n; i += WAVE) s.set[i] = T.level_off[searchLevelIdx] + i;
     wsync();
-    TView v = t_view(k, s, n, ORD_LEADER, st.unconstrained);
-    int topDomain = t_get(s, v, 0);
+    int fitDomain = -1, topDomain = -1;
+    TView v;
+    if (!lfc) v = t_view_first_fit(k, s, n, ORD_LEADER, st.unconstrained, sliceCount, st.leaderCount > 0 ? 3 : 2, st.leaderCount, &topDomain, &fitDomain);
+    else { v = t_view(k, s, n, ORD_LEADER, st.unconstrained); topDomain = t_get(s, v, 0); }
     if (topDomain < 0) {
       // every domain of the level has an all-zero state: whatever sortedDomain[0] is, it holds nothing
       if (sliceCount == 0 && st.leaderCount == 0) {
@@ -621,7 +702,7 @@ KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* 
       if (st.required || searchLevelIdx == 0 || st.unconstrained) return TFail{KQ_TAS_NOT_FIT, 0, sliceCount};
       continue;
     }
-    if (!lfc && s.scwl[topDomain] >= sliceCount && s.lc[topDomain] >= st.leaderCount) topDomain = t_best_fit_slices(s, v, 0, sliceCount, st.leaderCount);
+    if (!lfc && s.scwl[topDomain] >= sliceCount && s.lc[topDomain] >= st.leaderCount && fitDomain >= 0) topDomain = fitDomain;   // findBestFitDomain :1293 over the whole level
     if (lfc) {
       SelHolds sh{&s, sliceCount, st.leaderCount};
       uint64_t e0 = 0, e1 = 0;
@@ -779,7 +860,9 @@ KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, 
   if (lane_id() == 0) k.O.bytes[1] += clock64() - _p0;   // (timing builds: cycles of phase 1, in the word behind the byte counter)
 #endif
   int fitLevelIdx = 0, ncur = 0;
+  TPROF0();
   TFail f = t_find_level(k, s, st, &fitLevelIdx, &ncur);
+  TPROF(k, 0);   // findLevelWithFitDomains
   if (f.status == KQ_TAS_NOT_FIT && st.nLayers > 0) { *nfit = fitLevelIdx; return f; }  // the caller turns it into the per-layer form
   if (f.status != KQ_TAS_OK) return f;
   // phase 2b :1041 — currFitDomain in the order findLevelWithFitDomains built it
@@ -790,6 +873,7 @@ KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, 
   for (int i = lane_id(); i < nout; i += WAVE) s.cur[i] = s.nxt[i];
   wsync();
   ncur = nout;
+  TPROF(k, 1);   // the fit level's own domains
   int level = fitLevelIdx;
   const int stop = (T.L - 1) < st.sliceLevelIdx ? (T.L - 1) : st.sliceLevelIdx;
   for (; level < stop; level++) {
@@ -807,6 +891,7 @@ KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, 
     wsync();
     ncur = nout;
   }
+  TPROF(k, 2);   // levels down to the slice level
   for (; level < T.L - 1; level++) {
     int32_t sliceSizeOnLevel = st.sliceSize;
     if (level >= st.sliceLevelIdx) { const int32_t sz = t_size_at(st, level + 1); sliceSizeOnLevel = sz > 0 ? sz : 1; }  // :1049-1057
@@ -823,6 +908,7 @@ KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, 
     wsync();
     ncur = nout;
   }
+  TPROF(k, 3);   // levels below the slice level
   *nfit = ncur;
   return TFail{KQ_TAS_OK, 0, 0};
 }
@@ -878,6 +964,7 @@ KQ_DEV void t_workload(const TK& k, int slot, int w) {
     if (firstOfGroup) ngroups++;
   }
   const bool track = ngroups > 1;
+  TPROF0();
   if (lane == 0) s.meta[0] = 0;
   if (track) { for (int i = lane; i < T.n_leaves * T.R; i += WAVE) s.assumed[i] = 0; wsync(); }
   bool failed = false, hasAssumed = false;
@@ -952,7 +1039,9 @@ KQ_DEV void t_workload(const TK& k, int slot, int w) {
       } else if (lane == 0) {
         s.meta[2] = -1;
       }
+      TPROF(k, 4);   // everything of t_workload before the search
       f = t_find_assignment(k, s, st, &ncur, have);
+      TPROF(k, 5);   // t_find_assignment (0-3 are inside)
       if (f.status == KQ_TAS_NOT_FIT && st.nLayers > 0)
         f = t_not_fit_layers(k, s, st, ncur, O.layer_fit ? O.layer_fit + (size_t)workers * KQ_TAS_MAX_LEVELS : nullptr,
                              O.layer_fit && leader >= 0 ? O.layer_fit + (size_t)leader * KQ_TAS_MAX_LEVELS : nullptr);
@@ -974,6 +1063,7 @@ KQ_DEV void t_workload(const TK& k, int slot, int w) {
     }
     if (leader >= 0) t_emit(k, s, ncur, 1, leader);
     t_emit(k, s, ncur, 0, workers);
+    TPROF(k, 6);   // status words + buildAssignment
   }
   // put the class table's values back into the domains phase 2 consumed
   if (s.meta[2] >= 0 && !s.meta[1]) {
@@ -986,6 +1076,7 @@ KQ_DEV void t_workload(const TK& k, int slot, int w) {
     }
     wsync();
   }
+  TPROF(k, 7);   // the consumed domains restored from the class table
 }
 // phase 1 of request class c into the class tables
 KQ_DEV void t_class(const TK& k, int c) {

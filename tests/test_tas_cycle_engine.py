@@ -219,3 +219,20 @@ def test_tas_request_without_any_tas_flavor(oracle):
     assert not ct.names and (ct.arrays["ps_flags"] & 1).any()
     oracle.derive(snap)
     _same(oracle, _emu, cfg, snap, heads, ct, tgt_cap=max(16, snap.n_adm))
+
+
+@pytest.mark.parametrize("seed", [21190, 27235])
+def test_full_assignment_keeps_the_pserror_get_targets_left(oracle, seed):
+    """Found by the random campaign: a TAS-only ClusterQueue, a head whose full assignment is Preempt with a podset Assign stopped at
+    (no flavor, no reason), no victims, partial admission finds nothing -> getInitialAssignments returns the SAME fullAssignment that
+    GetTargets already looked at (scheduler.go:897, :923): WorkloadsTopologyRequests left a psError on the flavorless podset
+    (flavorassigner.go:290), so updateAssignmentForTAS sees NoFit and places nothing. The device code regenerates the outputs of the
+    full assignment after the search; it must carry that status along (no placement, no topology assignment)."""
+    cfg, snap, heads, ct, _ = random_tas_cycle_case(seed, fair=False, tight=seed % 2 == 0, preemption=seed % 3 != 0, partial=seed % 5 == 0)
+    oracle.derive(snap)
+    want, wout = oracle.cycle_run_tas(cfg, snap, heads, ct, tgt_cap=max(16, snap.n_adm), rsn_cap=64 * max(heads.n_ps, 1))
+    eng = _emu(cfg); eng.put(snap)
+    got, gout = eng.run_tas(heads, ct, tgt_cap=max(16, snap.n_adm), rsn_cap=64 * max(heads.n_ps, 1))
+    eng.close()
+    assert got.tas_stats["finds"] == want.tas_stats["finds"]
+    _same(oracle, _emu, cfg, snap, heads, ct, tgt_cap=max(16, snap.n_adm))
