@@ -456,17 +456,20 @@ KQ_DEV int t_best_fit_slices(const TState& s, TView& v, int from, int32_t sliceC
 //   *first  domains[0], -1 when the slice has nothing but all-zero domains
 //   *fit    the best-fit domain among the holders, -1 when nothing holds `needed`
 // The view comes back with domains[0] materialised, exactly as after t_view + t_get(.., 0).
+// id0 >= 0: the slice is the contiguous id range [id0, id0 + n) (a whole level, the children of one domain) — s.set holds the same
+// values but is not read here, so the caller needs no fence between writing it and this sweep.
 KQ_DEV TView t_view_first_fit(const TK& k, const TState& s, int n, int order, bool unconstrained, int32_t needed, int which, int32_t leaderCount,
-                              int* first, int* fit) {
+                              int* first, int* fit, int id0 = -1) {
   TView v;
   v.n = n; v.order = order; v.lfc = t_lfc(k, unconstrained); v.mat = 0; v.c0 = 0; v.c1 = 0; v.started = false; v.skip = -1;
   uint64_t b0 = ~0ull, b1 = ~0ull;               // slice order
   uint64_t f0 = ~0ull, f1 = ~0ull, fc = ~0ull;   // (count, slice order) over the holders
-  constexpr int UNR = 4;
+  // a lone wave is latency-bound: the rows of UNR strided elements are in flight before any of them is looked at
+  constexpr int UNR = 8;
   for (int base = lane_id(); base < n; base += WAVE * UNR) {
     int dv[UNR]; int32_t pcv[UNR], scv[UNR], pwv[UNR], swv[UNR], lcv[UNR];
     #pragma unroll
-    for (int q = 0; q < UNR; q++) { const int i = base + q * WAVE; dv[q] = i < n ? s.set[i] : -1; }
+    for (int q = 0; q < UNR; q++) { const int i = base + q * WAVE; dv[q] = i < n ? (id0 >= 0 ? id0 + i : s.set[i]) : -1; }
     #pragma unroll
     for (int q = 0; q < UNR; q++) {
       const int d = dv[q];
@@ -583,13 +586,26 @@ KQ_DEV bool t_consume_with_leaders(const TK& k, const TState& s, TView& v, int i
 // updateCountsToMinimumGeneric :1575 over the slice s.set[0..n) in `order`; result domains appended to out[out_n..)
 // returns the new length of out, -1 on the reference's "unexpected remainingCount" path
 KQ_DEV int t_update_counts(const TK& k, const TState& s, int n, int order, int32_t count, int32_t leaderCount, int32_t sliceSize,
-                           bool unconstrained, bool slices, int32_t* out, int out_n, int32_t recompute = 0) {
+                           bool unconstrained, bool slices, int32_t* out, int out_n, int32_t recompute = 0, int id0 = -1) {
   const bool bestfit = !t_lfc(k, unconstrained);
   // no leader, no inner-layer recount, BestFit: keys, domains[0] and the first best-fit scan in one sweep
   const bool fuse = leaderCount == 0 && recompute <= 1 && bestfit;
   int first0 = -1, fit0 = -1;
-  TView v = fuse ? t_view_first_fit(k, s, n, order, unconstrained, slices ? count / sliceSize : count, slices ? 2 : 0, 0, &first0, &fit0)
-                 : t_view(k, s, n, order, unconstrained);
+  TView v;
+  if (fuse && n == 1) {
+    // one domain: no order to establish, no reduction to make
+    const int d = id0 >= 0 ? id0 : s.set[0];
+    const int32_t need = slices ? count / sliceSize : count;
+    const bool zero = order != ORD_LIST && t_all_zero(s, d);
+    first0 = zero ? -1 : d;
+    fit0 = (!zero && (slices ? s.sc[d] : s.pc[d]) >= need) ? d : -1;
+    v.n = 1; v.order = order; v.lfc = false; v.skip = -1;
+    v.mat = zero ? 0 : 1; v.started = !zero; v.c0 = ~0ull; v.c1 = ~0ull;   // nothing left in the stream either way
+    if (zero) { if (lane_id() == 0) { s.k0[0] = KQ_TAS_EXCLUDED; s.k1[0] = (uint32_t)d; } }
+    else if (lane_id() == 0) { s.arr[0] = d; s.k0[0] = 0; s.k1[0] = (uint32_t)d; }
+    wsync();
+  } else if (fuse) v = t_view_first_fit(k, s, n, order, unconstrained, slices ? count / sliceSize : count, slices ? 2 : 0, 0, &first0, &fit0, id0);
+  else { if (id0 >= 0) wsync(); v = t_view(k, s, n, order, unconstrained); }
   if (recompute > 1) {
     // an inner slice layer (:1060-1070): the children were sorted with the slice counts phase 1 left (the keys above), only then
     // are the counts recomputed for this layer's size
@@ -686,11 +702,11 @@ KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* 
     const int n = T.level_off[searchLevelIdx + 1] - T.level_off[searchLevelIdx];
     if (n == 0) return TFail{KQ_TAS_NO_LEVEL, 0, 0};
     for (int i = lane_id(); i < n; i += WAVE) s.set[i] = T.level_off[searchLevelIdx] + i;
-    wsync();
     int fitDomain = -1, topDomain = -1;
     TView v;
-    if (!lfc) v = t_view_first_fit(k, s, n, ORD_LEADER, st.unconstrained, sliceCount, st.leaderCount > 0 ? 3 : 2, st.leaderCount, &topDomain, &fitDomain);
-    else { v = t_view(k, s, n, ORD_LEADER, st.unconstrained); topDomain = t_get(s, v, 0); }
+    if (!lfc) v = t_view_first_fit(k, s, n, ORD_LEADER, st.unconstrained, sliceCount, st.leaderCount > 0 ? 3 : 2, st.leaderCount, &topDomain, &fitDomain,
+                                   T.level_off[searchLevelIdx]);   // (its closing fence publishes s.set as well)
+    else { wsync(); v = t_view(k, s, n, ORD_LEADER, st.unconstrained); topDomain = t_get(s, v, 0); }
     if (topDomain < 0) {
       // every domain of the level has an all-zero state: whatever sortedDomain[0] is, it holds nothing
       if (sliceCount == 0 && st.leaderCount == 0) {
@@ -867,8 +883,9 @@ KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, 
   if (f.status != KQ_TAS_OK) return f;
   // phase 2b :1041 — currFitDomain in the order findLevelWithFitDomains built it
   for (int i = lane_id(); i < ncur; i += WAVE) s.set[i] = s.cur[i];
-  wsync();
-  int nout = t_update_counts(k, s, ncur, ORD_LIST, st.count, st.leaderCount, st.sliceSize, st.unconstrained, true, s.nxt, 0);
+  const int only = ncur == 1 ? s.cur[0] : -1;   // the usual case: one fitting domain, nothing to order
+  if (only < 0) wsync();
+  int nout = t_update_counts(k, s, ncur, ORD_LIST, st.count, st.leaderCount, st.sliceSize, st.unconstrained, true, s.nxt, 0, 0, only);
   if (nout < 0) { *nfit = 0; return TFail{KQ_TAS_OK, 0, 0}; }
   for (int i = lane_id(); i < nout; i += WAVE) s.cur[i] = s.nxt[i];
   wsync();
@@ -878,14 +895,15 @@ KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, 
   const int stop = (T.L - 1) < st.sliceLevelIdx ? (T.L - 1) : st.sliceLevelIdx;
   for (; level < stop; level++) {
     // sortedDomains(lowerLevelDomains(currFitDomain))
-    int m = 0;
+    int m = 0, id0 = -1;
     for (int j = 0; j < ncur; j++) {
       const int d = s.cur[j], c0 = T.child_first[d], cn = T.child_cnt[d];
       for (int i = lane_id(); i < cn; i += WAVE) s.set[m + i] = c0 + i;
+      if (ncur == 1) id0 = c0;   // the children of one domain are one id range: the sweep needs neither s.set nor a fence before it
       m += cn;
     }
-    wsync();
-    nout = t_update_counts(k, s, m, ORD_PLAIN, st.count, st.leaderCount, st.sliceSize, st.unconstrained, true, s.nxt, 0);
+    if (id0 < 0) wsync();
+    nout = t_update_counts(k, s, m, ORD_PLAIN, st.count, st.leaderCount, st.sliceSize, st.unconstrained, true, s.nxt, 0, 0, id0);
     if (nout < 0) { *nfit = 0; return TFail{KQ_TAS_OK, 0, 0}; }
     for (int i = lane_id(); i < nout; i += WAVE) s.cur[i] = s.nxt[i];
     wsync();
