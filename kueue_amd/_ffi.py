@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ENGINE_LIB = os.path.join(HERE, "libkq_engine.so")
+ENGINE_LIB = os.environ.get("KQ_ENGINE_LIB", os.path.join(HERE, "libkq_engine.so"))   # (KQ_ENGINE_LIB: an A/B or timing build of the same sources)
 
 KQ_ABI_VERSION = 2
 KQ_UNLIMITED = (1 << 63) - 1
