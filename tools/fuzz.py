@@ -9,7 +9,9 @@ seeds the test-suite pins. Test infrastructure: needs no GPU.
 
 Prints the seeds that differ (none expected). Runs of this round: cycle 100000-108000, 200000-204000, 300000-320000; tight
 400000-412000; tas 10000-19000; loop 0-180 — all clean. On the last code of round 2: cycle 500000-506000, tight 600000-604000,
-loop 1000-1120 — all clean.
+loop 1000-1120 — all clean. On the last code of round 3: cycle 700000-706000, tight 800000-804000, loop 2000-2080, tas 50000-78000
+— all clean; the TAS cycles have their own driver (tools/fuzz_tas_cycle.py: 20000-60000 on the emulation, 40000-40600 / 50000-50600 /
+60000-60300 on the MI355X; two seeds of that campaign, 21190 and 27235, found the lost psError pinned in tests/test_tas_cycle_engine.py).
 """
 import copy
 import os
