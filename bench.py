@@ -315,7 +315,7 @@ def _tail_slots(cqs):
 
 def pending_cost(eng, pop):
     """What the device-resident pending side costs a drop-in between cycles: kq_pending_put of the whole set (host sort + every column
-    over PCIe), kq_pending_add of 1000 arrivals into the resident set, kq_pending_delete of 1000 workloads."""
+    over PCIe), kq_pending_add of 1000 arrivals into the resident set, kq_pending_update of 1000 resident keys, kq_pending_delete of 1000 workloads."""
     from kueue_amd.api import Pending
     full = pop.pending()
 
@@ -331,8 +331,11 @@ def pending_cost(eng, pop):
     for _ in range(7):   # (the first calls also pay the growth of the columns and of the two order buffers)
         # the C call alone: the Python wrapper's own bookkeeping (it concatenates its host copy of every column) is not the engine's cost
         add.append(t(lambda: eng._check(eng._lib.kq_pending_add(eng._h, C.byref(ms), C.byref(first)))))
-    dele = t(lambda: eng.pending_delete(idx.astype(np.int32)))
-    return {"put": put, "add_1000": float(np.median(add)), "add_1000_first": add[0], "delete_1000": dele, "resident": int(full.n)}
+    # PushOrUpdate of 1000 keys that are pending, each with a new object (kq_pending_update): the replacements are appended, the old records hand over
+    i32 = idx.astype(np.int32)
+    upd = t(lambda: eng._check(eng._lib.kq_pending_update(eng._h, C.c_int32(len(i32)), i32.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ms), C.byref(first))))
+    dele = t(lambda: eng.pending_delete(i32))
+    return {"put": put, "add_1000": float(np.median(add)), "add_1000_first": add[0], "update_1000": upd, "delete_1000": dele, "resident": int(full.n)}
 
 
 class PendingLoop:
