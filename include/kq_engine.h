@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define KQ_ABI_VERSION 2
+#define KQ_ABI_VERSION 3
 
 /* ---- error codes ---------------------------------------------------------------------------- */
 #define KQ_OK             0
@@ -46,6 +46,13 @@ extern "C" {
 #define KQ_EUNSUPPORTED  (-4)  /* input uses a feature the device path does not implement       */
 #define KQ_ECAPACITY     (-5)  /* caller-provided output buffer too small (targets)             */
 #define KQ_ENODEVICE     (-6)  /* no HIP device / extension not usable                          */
+
+/* ---- size limits of one snapshot (checked by kq_snapshot_put before anything is allocated: larger -> KQ_EUNSUPPORTED, a negative
+ *      count -> KQ_EINVAL; no entry point aborts the calling process: C++ exceptions of the host side end at the ABI as KQ_ENOMEM /
+ *      KQ_EINVAL with kq_last_error) ----------------------------------------------------------- */
+#define KQ_MAX_ADMITTED (1 << 26)   /* admitted workloads (rows)                                   */
+#define KQ_MAX_NODES    (1 << 24)   /* ClusterQueues + Cohorts                                     */
+#define KQ_MAX_FR       (1 << 16)   /* flavors x resources; nodes x flavor-resources < 2^31        */
 
 /* ---- quantities ----------------------------------------------------------------------------- */
 #define KQ_UNLIMITED   INT64_MAX  /* resources.Unlimited, amount.go:56                           */
@@ -390,6 +397,10 @@ typedef struct kq_pending {
    * not expired (against kq_pending_set_clock) waits among the inadmissible workloads (:414, :568, inadmissible_workloads.go:167).
    * NULL: no workload is backing off. */
   const int64_t* requeue_at;  /* [W] or NULL */
+  /* kq_pending_update only ([n] or NULL): 1 = the replacement object carries the Generation the key was set with — a status-only
+   * update (ReclaimablePods, the Evicted / Requeued conditions): if the key is the ClusterQueue's preemptor, IsPreemptor
+   * (cluster_queue.go:213: name AND Obj.Generation) keeps holding. 0 / NULL: the spec changed, only stickyMatches (:124) holds. */
+  const uint8_t* same_generation;
 } kq_pending;
 #define KQ_REQUEUE_NONE    INT64_MIN
 #define KQ_REQUEUE_BLOCKED INT64_MAX
@@ -486,10 +497,14 @@ int  kq_pending_add(kq_engine* e, const kq_pending* more, int32_t* first_index);
  *     The in-place branch (:396-403, nothing that matters changed: UpdateInadmissible) needs no call at all;
  *   - wl[i] gone: a plain arrival. In flight cannot be (:388): not between kq_pending_heads and kq_pending_apply;
  *   - the ClusterQueue's preemptor pointer (:109 holds a name) moves to the replacement: stickyMatches (:124) still sorts it first,
- *     IsPreemptor (:213, strict: generation) no longer holds; a replacement in another ClusterQueue clears it (Delete :506);
+ *     IsPreemptor (:213, strict: name AND Obj.Generation) holds only if more->same_generation[i] says the generation did not change
+ *     (a status-only update); a replacement in another ClusterQueue clears it (Delete :506);
  *   - AdmissionFairSharing: the replacement's entry-penalty amounts are set like an arrival's (kq_pending_afs_wl_penalty); a penalty
  *     RECORD only exists for assumed workloads, which are no longer pending.
- * Cost: kq_pending_add of the replacements + one small launch. */
+ * Cost: kq_pending_add of the replacements + one small launch. GROWTH: the replaced records stay in every column (marked gone) and in
+ * the ClusterQueues' order segments until the next kq_pending_put; Heads(), the arrival merge and queueInadmissibleWorkloads scan a
+ * ClusterQueue's segment linearly, so a resident loop with frequent updates should re-put the pending set once the gone records
+ * (kq_pending_read_state: counts[3]) outnumber the live ones. */
 int  kq_pending_update(kq_engine* e, int32_t n, const int32_t* wl, const kq_pending* more, int32_t* first_index);
 /* ClusterQueue.Delete (cluster_queue.go:488-512): the workloads leave the pending set (deleted, finished, admitted by another
  * scheduler). Not between kq_pending_heads and kq_pending_apply. */

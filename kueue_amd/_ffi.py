@@ -14,7 +14,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ENGINE_LIB = os.environ.get("KQ_ENGINE_LIB", os.path.join(HERE, "libkq_engine.so"))   # (KQ_ENGINE_LIB: an A/B or timing build of the same sources)
 
-KQ_ABI_VERSION = 2
+KQ_ABI_VERSION = 3
 KQ_UNLIMITED = (1 << 63) - 1
 KQ_NIL_LIMIT = -1
 
@@ -80,6 +80,7 @@ HEAD_IS_PREEMPTOR = 0x2
 HEAD_HAS_LAST_ASSIGNMENT = 0x4
 ADM_EVICTED = 0x1
 
+KQ_OK, KQ_EINVAL, KQ_ENOMEM, KQ_EDEVICE, KQ_EUNSUPPORTED, KQ_ECAPACITY, KQ_ENODEVICE = 0, -1, -2, -3, -4, -5, -6
 KQ_ERRORS = {0: "OK", -1: "EINVAL", -2: "ENOMEM", -3: "EDEVICE", -4: "EUNSUPPORTED", -5: "ECAPACITY", -6: "ENODEVICE"}
 
 i32p = C.POINTER(C.c_int32)
@@ -145,7 +146,7 @@ class kq_heads(C.Structure):
 
 
 class kq_pending(C.Structure):
-    _fields_ = [("w", kq_heads), ("uid_rank", u32p), ("n_lq", C.c_int32), ("lq", i32p), ("requeue_at", i64p)]
+    _fields_ = [("w", kq_heads), ("uid_rank", u32p), ("n_lq", C.c_int32), ("lq", i32p), ("requeue_at", i64p), ("same_generation", u8p)]
 
 
 class kq_afs_ledger(C.Structure):

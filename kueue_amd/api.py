@@ -633,8 +633,10 @@ class Pending:
     plus the UID ranks baseCompareFunc breaks ties with (cluster_queue.go:873)."""
 
     def __init__(self, heads: Heads, uid_rank: Optional[np.ndarray] = None, lq: Optional[np.ndarray] = None, n_lq: int = 0,
-                 requeue_at: Optional[np.ndarray] = None):
+                 requeue_at: Optional[np.ndarray] = None, same_generation: Optional[np.ndarray] = None):
         self.heads = heads
+        # kq_pending_update only: 1 = the replacement carries the Generation the key had (status-only update, cluster_queue.go:213)
+        self.same_generation = None if same_generation is None else np.ascontiguousarray(same_generation, dtype=np.uint8)
         # RequeueState.RequeueAt per workload in ns (F.REQUEUE_NONE / F.REQUEUE_BLOCKED), None: nobody backs off
         self.requeue_at = None if requeue_at is None else np.ascontiguousarray(requeue_at, dtype=np.int64)
         self.snap = heads.snap
@@ -657,6 +659,8 @@ class Pending:
                 p.lq = F.ptr(self.lq)
             if self.requeue_at is not None and self.requeue_at.size:
                 p.requeue_at = F.ptr(self.requeue_at)
+            if self.same_generation is not None and self.same_generation.size:
+                p.same_generation = F.ptr(self.same_generation)
             self._struct = p
         return self._struct
 

@@ -52,7 +52,7 @@ KQ_DEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
 KQ_DEV int atomic_add_i32(int* p, int v) { int o = *p; *p += v; return o; }
 KQ_DEV void atomic_max_i32(int* p, int v) { if (v > *p) *p = v; }
 KQ_DEV void atomic_min_i32(int* p, int v) { if (v < *p) *p = v; }
-KQ_DEV void atomic_add_i64(long long* p, long long v) { *p += v; }
+KQ_DEV void atomic_add_i64(long long* p, long long v) { *p = (long long)((unsigned long long)*p + (unsigned long long)v); }  // wraps like the device's atomic (bucket fingerprints rely on it)
 KQ_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 KQ_DEV int64_t atomic_cas_i64(int64_t* p, int64_t expect, int64_t v) { int64_t o = *p; if (o == expect) *p = v; return o; }
 KQ_DEV int64_t wsum_i64(int64_t v) { return v; }

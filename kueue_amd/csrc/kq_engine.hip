@@ -113,8 +113,8 @@ namespace kq { hipError_t launch_process_spec(const K* d, int n_tree, hipStream_
 // device-side rebuild of the admitted-row structures: kq_rows_kernel.hip (cell kernel + rocPRIM sort / scan)
 namespace kq {
 hipError_t rows_launch(const DRows& R, int op, int n, hipStream_t stream);
-hipError_t rows_sort_pairs(uint64_t*& key, int32_t*& val, uint64_t*& key2, int32_t*& val2, int n, int bits, hipStream_t stream);
-hipError_t rows_scan_excl(const int32_t* in, int32_t* out, int n, hipStream_t stream);
+hipError_t rows_sort_pairs(RowsScratch& tmp, uint64_t*& key, int32_t*& val, uint64_t*& key2, int32_t*& val2, int n, int bits, hipStream_t stream);
+hipError_t rows_scan_excl(RowsScratch& tmp, const int32_t* in, int32_t* out, int n, hipStream_t stream);
 }
 // kernels of kq_cycle_run_tas: kq_tas_cycle_kernel.hip
 namespace kq {
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_pend_merge(DPend D, const int32_t* ord_
 }
 __global__ __launch_bounds__(64) void k_pend_add_fix(DPend D, DSnap S, int first) { pend_add_fix(D, S, first + (int)blockIdx.x); }
 __global__ __launch_bounds__(64) void k_pend_requeue_at(DPend D, DSnap S, const int32_t* list, const int64_t* at) { pend_requeue_at(D, S, list, at, blockIdx.x); }
-__global__ __launch_bounds__(256) void k_pend_update_fix(DPend D, const int32_t* list, int first, int n) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) pend_update_fix(D, list, first, i); }
+__global__ __launch_bounds__(256) void k_pend_update_fix(DPend D, const int32_t* list, const uint8_t* same_gen, int first, int n) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) pend_update_fix(D, list, same_gen, first, i); }
 __global__ __launch_bounds__(256) void k_pend_delete(DPend D, const int32_t* list, int n) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) pend_delete(D, list, i); }
 // kq_pending_step, after the cycle: blocks [0, nb) fold the admissions into the snapshot and keep the rows for the release
 // (commit_fused_cell), blocks [nb, nb + n) run the requeue policy of one head each (wave 0 of the block) — one launch instead of three
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void k_afs_usage(DPend D, int init_f64) { cons
 __global__ __launch_bounds__(64) void k_afs_sub(DPend D, const int32_t* list, int n) { if (threadIdx.x == 0) afs_sub_list(D, list, n); }
 __global__ __launch_bounds__(256) void k_afs_set_consumed(DPend D, const int32_t* lq, const uint64_t* lo, const int64_t* hi, const double* f64, const int32_t* settle, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) afs_set_consumed(D.A, lq, lo, hi, f64, settle, i);
+  if (i < n) afs_set_consumed(D.A, D.lq, lq, lo, hi, f64, settle, i);
 }
 __global__ __launch_bounds__(64) void k_pend_qi(DPend D, const int32_t* list) { pend_queue_inadmissible(D, list ? list[blockIdx.x] : (int)blockIdx.x); }
 
@@ -375,6 +375,7 @@ struct HipBackend {
   int n_cu = 256;
   hipError_t err = hipSuccess;
   std::string msg;
+  RowsScratch rows_tmp;                     // rocPRIM temporary storage of this engine's row sorts / scans (kq_rows_kernel.hip)
 
   void chk(hipError_t e, const char* what) {
     if (e != hipSuccess && err == hipSuccess) { err = e; msg = std::string(what) + ": " + hipGetErrorString(e); }
@@ -409,6 +410,7 @@ struct HipBackend {
     if (hk) (void)hipHostFree(hk);
     for (auto& d : dk) if (d) (void)hipFree(d);
     if (dtk) (void)hipFree(dtk);
+    if (rows_tmp.p) (void)hipFree(rows_tmp.p);
     if (stream) (void)hipStreamDestroy(stream);
   }
   void* alloc(size_t n) { void* p = nullptr; chk(hipMalloc(&p, n), "hipMalloc"); return p; }
@@ -630,8 +632,8 @@ struct HipBackend {
     if (n > 0) hipLaunchKernelGGL(k_pend_requeue_at, dim3(n), dim3(64), 0, stream, D, S, list, at);
     chk(hipGetLastError(), "k_pend_requeue_at");
   }
-  void launch_pend_update_fix(const DPend& D, const int32_t* list, int first, int n) {
-    if (n > 0) hipLaunchKernelGGL(k_pend_update_fix, dim3((n + 255) / 256), dim3(256), 0, stream, D, list, first, n);
+  void launch_pend_update_fix(const DPend& D, const int32_t* list, const uint8_t* same_gen, int first, int n) {
+    if (n > 0) hipLaunchKernelGGL(k_pend_update_fix, dim3((n + 255) / 256), dim3(256), 0, stream, D, list, same_gen, first, n);
     chk(hipGetLastError(), "k_pend_update_fix");
   }
   void launch_pend_delete(const DPend& D, const int32_t* list, int n) {
@@ -709,8 +711,8 @@ struct HipBackend {
   }
   // admitted-row structures on the device (kq_rows_kernel.hip)
   void launch_rows(const DRows& R, int op, int n) { chk(rows_launch(R, op, n, stream), "k_rows"); }
-  void sort_pairs(uint64_t*& key, int32_t*& val, uint64_t*& key2, int32_t*& val2, int n, int bits) { chk(rows_sort_pairs(key, val, key2, val2, n, bits, stream), "rows_sort_pairs"); }
-  void scan_excl(const int32_t* in, int32_t* out, int n) { chk(rows_scan_excl(in, out, n, stream), "rows_scan_excl"); }
+  void sort_pairs(uint64_t*& key, int32_t*& val, uint64_t*& key2, int32_t*& val2, int n, int bits) { chk(rows_sort_pairs(rows_tmp, key, val, key2, val2, n, bits, stream), "rows_sort_pairs"); }
+  void scan_excl(const int32_t* in, int32_t* out, int n) { chk(rows_scan_excl(rows_tmp, in, out, n, stream), "rows_scan_excl"); }
   // kq_cycle_run_tas (kq_tas_cycle_kernel.hip)
   void launch_tas_base(const TCyc* c, int n) { chk(launch_tas_base_k(c, n, stream), "k_tas_base"); }
   void launch_tas_cycle_classes(const TCyc* c, int n) { chk(launch_tas_cycle_classes_k(c, n, stream), "k_tas_cycle_classes"); }
@@ -764,6 +766,23 @@ struct HipBackend {
 struct kq_engine {
   EngineT<HipBackend> e;
 };
+struct kq_tas { TasT<HipBackend> e; };
+
+// No exception crosses the C ABI (include/kq_engine.h: "return 0 or a negative KQ_E*"): the host side is std::vector code, and a
+// std::bad_alloc / std::length_error escaping an extern "C" function is std::terminate in the controller process. Every entry point
+// that reaches engine code runs under KQ_TRY; the message is kept for kq_last_error / kq_tas_last_error.
+namespace {
+template <class T> int kq_fail(T* obj, int code, const char* what) noexcept {
+  try { if (obj) obj->e.last_error = std::string("exception at the C ABI: ") + what; } catch (...) {}
+  return code;
+}
+}  // namespace
+#define KQ_TRY(obj, ...)                                                                                      \
+  try { __VA_ARGS__; }                                                                                        \
+  catch (const std::bad_alloc&) { return kq_fail(obj, KQ_ENOMEM, "out of host memory"); }                     \
+  catch (const std::length_error& x) { return kq_fail(obj, KQ_ENOMEM, x.what()); }                            \
+  catch (const std::exception& x) { return kq_fail(obj, KQ_EINVAL, x.what()); }                               \
+  catch (...) { return kq_fail(obj, KQ_EINVAL, "unknown exception"); }
 
 extern "C" {
 
@@ -788,7 +807,8 @@ int kq_engine_create(const kq_config* cfg, kq_engine** out) {
   kq_engine* en = new (std::nothrow) kq_engine();
   if (!en) return KQ_ENOMEM;
   en->e.cfg = *cfg;
-  int rc = en->e.be.init(cfg->device);
+  int rc = KQ_EINVAL;
+  try { rc = en->e.be.init(cfg->device); } catch (const std::bad_alloc&) { rc = KQ_ENOMEM; } catch (...) { rc = KQ_EINVAL; }
   if (rc != KQ_OK) { fprintf(stderr, "kq_engine_create: %s\n", en->e.be.msg.c_str()); delete en; return rc; }
   *out = en;
   return KQ_OK;
@@ -796,177 +816,179 @@ int kq_engine_create(const kq_config* cfg, kq_engine** out) {
 
 void kq_engine_destroy(kq_engine* en) {
   if (!en) return;
-  (void)hipSetDevice(en->e.be.device);
-  en->e.pending_free();
-  en->e.free_snapshot();
-  HipBackend be = en->e.be;
-  delete en;
-  be.destroy();
+  try {
+    (void)hipSetDevice(en->e.be.device);
+    en->e.pending_free();
+    en->e.free_snapshot();
+    HipBackend be = en->e.be;
+    delete en;
+    be.destroy();
+  } catch (...) {}
 }
 
 int kq_snapshot_put(kq_engine* en, const kq_snapshot* s) {
   if (!en || !s) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.snapshot_put(s);
+  KQ_TRY(en, return en->e.snapshot_put(s));
 }
 
 int kq_snapshot_patch(kq_engine* en, const kq_snapshot* s, uint32_t what) {
   if (!en || !s) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.snapshot_patch(s, what);
+  KQ_TRY(en, return en->e.snapshot_patch(s, what));
 }
 
 int kq_cycle_run(kq_engine* en, const kq_heads* h, kq_decisions* out) {
   if (!en || !h || !out) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.cycle_run(h, out);
+  KQ_TRY(en, return en->e.cycle_run(h, out));
 }
 
 int kq_cycle_shard_words(kq_engine* en, const kq_heads* h, const kq_decisions* out, int32_t world, int64_t* words) {
   if (!en || !h || !out || !words) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.cycle_shard_words(h, out, world, words);
+  KQ_TRY(en, return en->e.cycle_shard_words(h, out, world, words));
 }
 int kq_cycle_nominate_shard(kq_engine* en, const kq_heads* h, const uint8_t* mine, int32_t world, int32_t rank, void* xbuf_dev, kq_decisions* out) {
   if (!en || !h || !out) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.cycle_nominate_shard(h, mine, world, rank, xbuf_dev, out);
+  KQ_TRY(en, return en->e.cycle_nominate_shard(h, mine, world, rank, xbuf_dev, out));
 }
 int kq_cycle_process_merged(kq_engine* en, int32_t world, int32_t rank, const void* xbuf_dev, kq_decisions* out) {
   if (!en || !out || !xbuf_dev) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.cycle_process_merged(world, rank, xbuf_dev, out);
+  KQ_TRY(en, return en->e.cycle_process_merged(world, rank, xbuf_dev, out));
 }
 
 int kq_heads_put(kq_engine* en, const kq_heads* h, int32_t batch) {
   if (!en || !h || batch < 0) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.heads_put(h, batch + 1);
+  KQ_TRY(en, return en->e.heads_put(h, batch + 1));
 }
 
 int kq_cycle_run_resident(kq_engine* en, int32_t batch, kq_decisions* out) {
   if (!en || !out || batch < 0) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.cycle_exec(batch + 1, out);
+  KQ_TRY(en, return en->e.cycle_exec(batch + 1, out));
 }
 
 int kq_nominate_run_resident(kq_engine* en, int32_t batch, kq_decisions* out) {
   if (!en || !out || batch < 0) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.cycle_exec(batch + 1, out, true);
+  KQ_TRY(en, return en->e.cycle_exec(batch + 1, out, true));
 }
 
 int kq_pending_put(kq_engine* en, const kq_pending* p) {
   if (!en || !p) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.pending_put(p);
+  KQ_TRY(en, return en->e.pending_put(p));
 }
 int kq_pending_heads(kq_engine* en, int64_t cycle, const uint8_t* cq_active, int32_t* n_heads, int32_t* n_podsets, int32_t* head_wl) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.pending_heads(cycle, cq_active, n_heads, n_podsets, head_wl);
+  KQ_TRY(en, return en->e.pending_heads(cycle, cq_active, n_heads, n_podsets, head_wl));
 }
 int kq_cycle_run_pending(kq_engine* en, kq_decisions* out) {
   if (!en || !out) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.cycle_run_pending(out);
+  KQ_TRY(en, return en->e.cycle_run_pending(out));
 }
 int kq_pending_apply(kq_engine* en) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.pending_apply();
+  KQ_TRY(en, return en->e.pending_apply());
 }
 int kq_pending_bounds(kq_engine* en, int32_t* max_heads, int32_t* max_podsets) {
   if (!en) return KQ_EINVAL;
-  return en->e.pending_bounds(max_heads, max_podsets);
+  KQ_TRY(en, return en->e.pending_bounds(max_heads, max_podsets));
 }
 int kq_pending_step(kq_engine* en, int64_t cycle, const uint8_t* cq_active, int32_t tgt_cap, int32_t release_age, int32_t want_head_wl) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.pending_step(cycle, cq_active, tgt_cap, release_age, want_head_wl);
+  KQ_TRY(en, return en->e.pending_step(cycle, cq_active, tgt_cap, release_age, want_head_wl));
 }
 int kq_pending_step_wait(kq_engine* en, kq_decisions* out, int32_t* n_heads, int32_t* n_podsets, int32_t* head_wl) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.pending_step_wait(out, n_heads, n_podsets, head_wl);
+  KQ_TRY(en, return en->e.pending_step_wait(out, n_heads, n_podsets, head_wl));
 }
 int kq_pending_afs_put(kq_engine* en, const kq_afs_ledger* l) {
   if (!en || !l) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.pending_afs_put(l);
+  KQ_TRY(en, return en->e.pending_afs_put(l));
 }
 int kq_pending_afs_wl_penalty(kq_engine* en, int32_t n, const int32_t* wl, const uint64_t* lo, const int64_t* hi, const uint64_t* mask) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.pending_afs_wl_penalty(n, wl, lo, hi, mask);
+  KQ_TRY(en, return en->e.pending_afs_wl_penalty(n, wl, lo, hi, mask));
 }
 int kq_pending_afs_sub_penalty(kq_engine* en, int32_t n, const int32_t* wl) {
   if (!en || (n > 0 && !wl)) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.pending_afs_sub_penalty(n, wl);
+  KQ_TRY(en, return en->e.pending_afs_sub_penalty(n, wl));
 }
 int kq_pending_afs_set_consumed(kq_engine* en, int32_t n, const int32_t* lq, const uint64_t* lo, const int64_t* hi, const double* f64, const int32_t* settle_wl) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.pending_afs_set_consumed(n, lq, lo, hi, f64, settle_wl);
+  KQ_TRY(en, return en->e.pending_afs_set_consumed(n, lq, lo, hi, f64, settle_wl));
 }
 int kq_pending_afs_read(kq_engine* en, double* usage, uint64_t* plo, int64_t* phi, uint8_t* ppres, uint64_t* clo, int64_t* chi, uint8_t* wrec) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.pending_afs_read(usage, plo, phi, ppres, clo, chi, wrec);
+  KQ_TRY(en, return en->e.pending_afs_read(usage, plo, phi, ppres, clo, chi, wrec));
 }
 int kq_pending_set_lq_usage(kq_engine* en, int32_t n_lq, const double* usage) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.pending_set_lq_usage(n_lq, usage);
+  KQ_TRY(en, return en->e.pending_set_lq_usage(n_lq, usage));
 }
 int kq_pending_add(kq_engine* en, const kq_pending* more, int32_t* first_index) {
   if (!en || !more) return KQ_EINVAL;
-  return en->e.pending_add(more, first_index);
+  KQ_TRY(en, return en->e.pending_add(more, first_index));
 }
 int kq_pending_update(kq_engine* en, int32_t n, const int32_t* wl, const kq_pending* more, int32_t* first_index) {
   if (!en || !more || (n > 0 && !wl)) return KQ_EINVAL;
-  return en->e.pending_update(n, wl, more, first_index);
+  KQ_TRY(en, return en->e.pending_update(n, wl, more, first_index));
 }
-int kq_pending_set_clock(kq_engine* en, int64_t now_ns) { if (!en) return KQ_EINVAL; return en->e.pending_set_clock(now_ns); }
+int kq_pending_set_clock(kq_engine* en, int64_t now_ns) { if (!en) return KQ_EINVAL; KQ_TRY(en, return en->e.pending_set_clock(now_ns)); }
 int kq_pending_set_requeue_at(kq_engine* en, int32_t n, const int32_t* wl, const int64_t* at) {
   if (!en || (n > 0 && (!wl || !at))) return KQ_EINVAL;
-  return en->e.pending_set_requeue_at(n, wl, at);
+  KQ_TRY(en, return en->e.pending_set_requeue_at(n, wl, at));
 }
 int kq_pending_delete(kq_engine* en, int32_t n, const int32_t* wl) {
   if (!en || (n > 0 && !wl)) return KQ_EINVAL;
-  return en->e.pending_delete(n, wl);
+  KQ_TRY(en, return en->e.pending_delete(n, wl));
 }
 int kq_pending_queue_inadmissible(kq_engine* en, int32_t n, const int32_t* cq) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.pending_queue_inadmissible(n, cq);
+  KQ_TRY(en, return en->e.pending_queue_inadmissible(n, cq));
 }
 int kq_pending_read_state(kq_engine* en, uint8_t* state, int32_t* counts) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.pending_read_state(state, counts);
+  KQ_TRY(en, return en->e.pending_read_state(state, counts));
 }
 
 int kq_cycle_certificate(kq_engine* en, int64_t* usage_delta_dev, int64_t* root_margin, int32_t* flags) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.cycle_certificate(usage_delta_dev, root_margin, flags);
+  KQ_TRY(en, return en->e.cycle_certificate(usage_delta_dev, root_margin, flags));
 }
 int kq_snapshot_patch_rows(kq_engine* en, const kq_row_patch* p, int32_t* new_index) {
   if (!en || !p) return KQ_EINVAL;
-  return en->e.snapshot_patch_rows(p, new_index);
+  KQ_TRY(en, return en->e.snapshot_patch_rows(p, new_index));
 }
-int kq_debug_rows_rebuild(kq_engine* en) { return en ? en->e.debug_rows_rebuild() : KQ_EINVAL; }
-int kq_debug_read_rows(kq_engine* en, int32_t which, void* out, int64_t* bytes) { return (en && bytes) ? en->e.read_rows(which, out, bytes) : KQ_EINVAL; }
+int kq_debug_rows_rebuild(kq_engine* en) { if (!en) return KQ_EINVAL; KQ_TRY(en, return en->e.debug_rows_rebuild()); }
+int kq_debug_read_rows(kq_engine* en, int32_t which, void* out, int64_t* bytes) { if (!en || !bytes) return KQ_EINVAL; KQ_TRY(en, return en->e.read_rows(which, out, bytes)); }
 int kq_cycle_run_tas(kq_engine* en, const kq_heads* h, const kq_cycle_tas* t, kq_decisions* out, kq_cycle_tas_out* tout, int64_t* stats) {
   if (!en || !h || !out) return KQ_EINVAL;
-  return en->e.cycle_run_tas(h, t, out, tout, stats);
+  KQ_TRY(en, return en->e.cycle_run_tas(h, t, out, tout, stats));
 }
 int kq_snapshot_usage_add(kq_engine* en, const int64_t* delta_dev, int32_t sign) {
   if (!en || !delta_dev) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.snapshot_usage_add(delta_dev, sign);
+  KQ_TRY(en, return en->e.snapshot_usage_add(delta_dev, sign));
 }
 
 int kq_last_cycle_phases(kq_engine* en, double* phase_ms, int64_t* phase_bytes) {
@@ -986,75 +1008,77 @@ int kq_last_cycle_stats(kq_engine* en, double* kernel_ms, int64_t* algorithmic_b
 int kq_cycle_commit(kq_engine* en, int32_t* n_admitted) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.cycle_commit(n_admitted);
+  KQ_TRY(en, return en->e.cycle_commit(n_admitted));
 }
 int kq_cycle_release(kq_engine* en, int32_t age) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.cycle_release(age);
+  KQ_TRY(en, return en->e.cycle_release(age));
 }
 int kq_snapshot_derive(kq_engine* en) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.snapshot_derive();
+  KQ_TRY(en, return en->e.snapshot_derive());
 }
 
 int kq_snapshot_read_planes(kq_engine* en, int64_t* subtree_quota, int64_t* usage, uint8_t* quota_flags) {
   if (!en || !en->e.have_snapshot) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.read_planes(subtree_quota, usage, quota_flags);  // (re-derives the cohort levels first if commits are pending)
+  KQ_TRY(en, return en->e.read_planes(subtree_quota, usage, quota_flags));  // (re-derives the cohort levels first if commits are pending)
 }
 
 const char* kq_last_error(kq_engine* en) { return en ? en->e.last_error.c_str() : "null engine"; }
 
 // ---- include/kq_tas.h ------------------------------------------------------------------------------
-struct kq_tas { TasT<HipBackend> e; };
 int kq_tas_create(int32_t device, kq_tas** out) {
   if (!out) return KQ_EINVAL;
   kq_tas* t = new (std::nothrow) kq_tas();
   if (!t) return KQ_ENOMEM;
-  int rc = t->e.be.init(device);
+  int rc = KQ_EINVAL;
+  try { rc = t->e.be.init(device); } catch (const std::bad_alloc&) { rc = KQ_ENOMEM; } catch (...) { rc = KQ_EINVAL; }
   if (rc != KQ_OK) { fprintf(stderr, "kq_tas_create: %s\n", t->e.be.error()); delete t; return rc; }
   *out = t;
   return KQ_OK;
 }
 void kq_tas_destroy(kq_tas* t) {
   if (!t) return;
-  (void)hipSetDevice(t->e.be.device);
-  t->e.free_topo();
-  HipBackend be = t->e.be;  // the backend handles outlive the engine object: its destructor still frees device buffers
-  delete t;
-  be.destroy();
+  try {
+    (void)hipSetDevice(t->e.be.device);
+    t->e.free_topo();
+    HipBackend be = t->e.be;  // the backend handles outlive the engine object: its destructor still frees device buffers
+    delete t;
+    be.destroy();
+  } catch (...) {}
 }
-int kq_tas_topology_put(kq_tas* t, const kq_tas_topology* tp) { if (!t || !tp) return KQ_EINVAL; (void)hipSetDevice(t->e.be.device); return t->e.topology_put(tp); }
-int kq_tas_find(kq_tas* t, const kq_tas_requests* r, kq_tas_result* out) { if (!t || !r || !out) return KQ_EINVAL; (void)hipSetDevice(t->e.be.device); return t->e.find(r, out); }
+int kq_tas_topology_put(kq_tas* t, const kq_tas_topology* tp) { if (!t || !tp) return KQ_EINVAL; (void)hipSetDevice(t->e.be.device); KQ_TRY(t, return t->e.topology_put(tp)); }
+int kq_tas_find(kq_tas* t, const kq_tas_requests* r, kq_tas_result* out) { if (!t || !r || !out) return KQ_EINVAL; (void)hipSetDevice(t->e.be.device); KQ_TRY(t, return t->e.find(r, out)); }
 int kq_tas_usage_apply(kq_tas* t, int32_t n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t add) {
   if (!t) return KQ_EINVAL;
   (void)hipSetDevice(t->e.be.device);
-  return t->e.usage_apply(n, leaf, count, spr, add);
+  KQ_TRY(t, return t->e.usage_apply(n, leaf, count, spr, add));
 }
 int kq_tas_fits(kq_tas* t, int32_t n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t* fits) {
   if (!t || !fits) return KQ_EINVAL;
   (void)hipSetDevice(t->e.be.device);
-  return t->e.fits(n, leaf, count, spr, fits);
+  KQ_TRY(t, return t->e.fits(n, leaf, count, spr, fits));
 }
 int kq_tas_admit(kq_tas* t, const kq_tas_requests* r, const kq_tas_result* res, const int32_t* order, int32_t n_order, uint8_t* admitted, int32_t* n_admitted) {
   if (!t || !r || !res) return KQ_EINVAL;
   (void)hipSetDevice(t->e.be.device);
-  return t->e.admit(r, res, order, n_order, admitted, n_admitted);
+  KQ_TRY(t, return t->e.admit(r, res, order, n_order, admitted, n_admitted));
 }
 int kq_tas_usage_delta(kq_tas* t, const kq_tas_requests* r, const kq_tas_result* res, const uint8_t* wl_sel, int64_t* plane_dev) {
   if (!t || !r || !res) return KQ_EINVAL;
   (void)hipSetDevice(t->e.be.device);
-  return t->e.usage_delta(r, res, wl_sel, plane_dev);
+  KQ_TRY(t, return t->e.usage_delta(r, res, wl_sel, plane_dev));
 }
-int kq_tas_usage_add(kq_tas* t, const int64_t* plane_dev, int32_t sign) { if (!t) return KQ_EINVAL; (void)hipSetDevice(t->e.be.device); return t->e.usage_add(plane_dev, sign); }
+int kq_tas_usage_add(kq_tas* t, const int64_t* plane_dev, int32_t sign) { if (!t) return KQ_EINVAL; (void)hipSetDevice(t->e.be.device); KQ_TRY(t, return t->e.usage_add(plane_dev, sign)); }
 int kq_tas_overflow(kq_tas* t, const int64_t* plane_dev, uint8_t* leaf_over, int32_t* n_over) {
   if (!t) return KQ_EINVAL;
   (void)hipSetDevice(t->e.be.device);
-  return t->e.overflow(plane_dev, leaf_over, n_over);
+  KQ_TRY(t, return t->e.overflow(plane_dev, leaf_over, n_over));
 }
-int kq_tas_read_usage(kq_tas* t, int64_t* u) { if (!t || !u) return KQ_EINVAL; (void)hipSetDevice(t->e.be.device); return t->e.read_usage(u); }
+int kq_tas_read_usage(kq_tas* t, int64_t* u) { if (!t || !u) return KQ_EINVAL; (void)hipSetDevice(t->e.be.device); KQ_TRY(t, return t->e.read_usage(u)); }
 int kq_tas_last_stats(kq_tas* t, double* ms, int64_t* bytes) { if (!t) return KQ_EINVAL; if (ms) *ms = t->e.last_ms; if (bytes) *bytes = t->e.last_bytes; return KQ_OK; }
 const char* kq_tas_last_error(kq_tas* t) { return t ? t->e.last_error.c_str() : "null engine"; }
 
@@ -1062,18 +1086,18 @@ const char* kq_tas_last_error(kq_tas* t) { return t ? t->e.last_error.c_str() : 
 // tests: take the saturation-safe DRS loops even when the incremental sums would be exact
 int kq_debug_disable_scan_search(kq_engine* en, int on) { if (!en) return KQ_EINVAL; en->e.cs_disable = on != 0; en->e.fs_disable = on != 0; return KQ_OK; }
 int kq_debug_force_exact_drs(kq_engine* en, int on) { if (!en) return KQ_EINVAL; en->e.force_exact_drs = on != 0; return KQ_OK; }
-int kq_debug_spec_stats(kq_engine* en, int64_t* out8) { return en ? en->e.spec_stats(out8) : KQ_EINVAL; }
+int kq_debug_spec_stats(kq_engine* en, int64_t* out8) { if (!en) return KQ_EINVAL; KQ_TRY(en, return en->e.spec_stats(out8)); }
 int kq_debug_prof(kq_engine* en, int64_t* out, int reset) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.prof_read(out, reset != 0);
+  KQ_TRY(en, return en->e.prof_read(out, reset != 0));
 }
 
 // test hook (not part of the drop-in boundary): snapshot usage as left by the last cycle
 int kq_debug_read_usage_work(kq_engine* en, int64_t* out) {
   if (!en) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);
-  return en->e.read_usage_work(out);
+  KQ_TRY(en, return en->e.read_usage_work(out));
 }
 
 }  // extern "C"

@@ -382,7 +382,7 @@ template <class B> struct EngineT {
     for (size_t i = 0; i < snap_allocs.size(); i++) if (snap_allocs[i] == (const void*)field) { be.free(snap_allocs[i]); snap_allocs.erase(snap_allocs.begin() + i); break; }
     field = fresh;
   }
-  bool rows_device = getenv("KQ_ROWS_HOST") == nullptr;   // (A/B switch: kq_snapshot_patch_rows rebuilds through the host path)
+  bool rows_device = getenv("KQ_ROWS_HOST") == nullptr;   // (A/B switch for kq_snapshot_put / kq_snapshot_patch: build_prep on the host; kq_snapshot_patch_rows has no host twin and returns KQ_EUNSUPPORTED then)
   std::vector<int32_t> h_adm_cq, h_cq_adm_off;            // host mirrors the row patch needs: ClusterQueue of every row, CSR offsets
   template <class T> void replace_dev(const T*& field, T* fresh) {
     for (size_t i = 0; i < snap_allocs.size(); i++) if (snap_allocs[i] == (const void*)field) { be.free(snap_allocs[i]); snap_allocs.erase(snap_allocs.begin() + i); break; }
@@ -548,6 +548,8 @@ template <class B> struct EngineT {
       for (int i = 0; i < n_add; i++) target[i] = next[p->add_cq[i]]++;
     }
     const int n_new = new_off[nq];
+    // the size guards look at the table AFTER the patch, before anything is moved (the old n_adm was tested)
+    if (n_new >= (1 << 20)) return fail(KQ_EUNSUPPORTED, "kq_snapshot_patch_rows: the patched table leaves the sort keys' row field (use kq_snapshot_patch)");
     DRows R{};
     R.n_old = n_old; R.n_add = n_add; R.nq = nq;
     R.old_cq_off = S.cq_adm_off; R.o_adm_cq = S.adm_cq;
@@ -611,7 +613,13 @@ template <class B> struct EngineT {
     if (new_index) for (int r = 0; r < n_old; r++) new_index[r] = noo[r];
     for (auto& c : ring) (void)c;   // (committed usage rows are keyed by ClusterQueue, not by admitted row: they stay valid)
     last_cycle_n = -1;              // the last cycle's argument block names freed arrays
-    return rows_rebuild(n_new);
+    // resident head batches that name admitted rows (slice_row) name the OLD indices: void them (kq_heads_put again)
+    for (size_t b = 0; b < batches.size(); b++) if ((int)b != PEND_SLOT && batches[b].valid && batches[b].H.slice_row) batches[b].valid = false;
+    rc = rows_rebuild(n_new);
+    // not atomic on failure: the new row table is resident but the structures derived from it are not — no cycle may run on that.
+    // The caller re-puts (kq_snapshot_put); every entry point checks have_snapshot.
+    if (rc != KQ_OK) have_snapshot = false;
+    return rc;
   }
   // test hook: the resident admitted-row structures, one by one (which: 0 adm_cq, 1 tree_row_off, 2 tree_rows, 3 tree_rows_asc, 4 rank_pos,
   // 5 frb_off, 6 frb, 7 frbr, 8 cq_row_bytes, 9 adm_rec, 10 frec, 11-13 frl, 14 frb_sig, 15 cs_ok, 16 rec_ok, 17 cq_adm_off, 18 adm_use_off,
@@ -1976,9 +1984,12 @@ template <class B> struct EngineT {
     int rc = pending_add(more, &first);
     if (first_index) *first_index = first;
     if (rc != KQ_OK || n == 0) return rc;
-    int32_t* d = (int32_t*)be.alloc((size_t)n * sizeof(int32_t));
+    // the old indices and (optionally) the "same Generation" bytes behind them, one allocation
+    const size_t lb = ((size_t)n * sizeof(int32_t) + 15) & ~(size_t)15;
+    unsigned char* d = (unsigned char*)be.alloc(lb + (size_t)n);
     be.h2d(d, wl, (size_t)n * sizeof(int32_t));
-    be.launch_pend_update_fix(pend.D, d, first, n);
+    if (more->same_generation) be.h2d(d + lb, more->same_generation, (size_t)n);
+    be.launch_pend_update_fix(pend.D, (const int32_t*)d, more->same_generation ? (const uint8_t*)(d + lb) : nullptr, first, n);
     rc = be.sync();
     be.free(d);
     if (rc != KQ_OK) return fail(rc, be.error());

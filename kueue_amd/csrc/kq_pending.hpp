@@ -199,9 +199,12 @@ KQ_DEV void afs_sub_list(const DPend& D, const int32_t* list, int n) {
 }
 // entry.Resources of LocalQueue lq[i] rewritten by a controller; with settle[i] >= 0 that workload's record folds in the same write
 // (workload_controller.go:1519-1526: remaining, penalty := old.WithoutPenalty(wlKey); Resources = newConsumed + penalty)
-KQ_DEV void afs_set_consumed(const DAfs& A, const int32_t* lq, const uint64_t* lo, const int64_t* hi, const double* f64, const int32_t* settle, int i) {
+// A settle_wl that is not a workload of LocalQueue lq[i] is ignored: the reference's penaltyRecords are per entry (usage_ledger.go:113), a
+// foreign key is simply not in that entry's map; here it would take another LocalQueue's penalty out of this row's aggregate.
+KQ_DEV void afs_set_consumed(const DAfs& A, const int32_t* wl_lq, const int32_t* lq, const uint64_t* lo, const int64_t* hi, const double* f64, const int32_t* settle, int i) {
   const int l = lq[i];
-  const int w = settle ? settle[i] : -1;
+  int w = settle ? settle[i] : -1;
+  if (w >= 0 && wl_lq && wl_lq[w] != l) w = -1;
   uint64_t fold = 0;
   if (w >= 0 && A.wl_rec[w]) { fold = A.wl_mask[w]; afs_without(A, l, w); }
   for (int r = 0; r < A.n_res; r++) {
@@ -460,7 +463,7 @@ KQ_DEV void pend_requeue_at(const DPend& D, const DSnap& S, const int32_t* list,
 // The preemptor pointer holds a NAME (:109): it follows the key, stickyMatches (:124) still sees it, the strict match of IsPreemptor
 // (:213, generation) does not. (AdmissionFairSharing: a penalty record only exists once a workload is assumed, i.e. gone from here; the
 // replacement's entry-penalty amounts come through kq_pending_afs_wl_penalty like an arrival's.) Then the old record leaves.
-KQ_DEV void pend_update_fix(const DPend& D, const int32_t* list, int first, int i) {
+KQ_DEV void pend_update_fix(const DPend& D, const int32_t* list, const uint8_t* same_gen, int first, int i) {
   const int old = list[i], w2 = first + i;
   const int c = D.P.cq[old];
   const bool same = D.P.cq[w2] == c;
@@ -468,7 +471,7 @@ KQ_DEV void pend_update_fix(const DPend& D, const int32_t* list, int first, int 
   if (st == WL_GONE) return;
   if (same && st == WL_ACTIVE) D.state[w2] = WL_ACTIVE;
   if (D.pw[c] == old) {
-    if (same) { D.pw[c] = w2; D.pw_sticky[c] |= 2; }
+    if (same) { D.pw[c] = w2; if (!(same_gen && same_gen[i])) D.pw_sticky[c] |= 2; }   // IsPreemptor :213 compares Obj.Generation
     else { D.pw[c] = -1; D.pw_sticky[c] = 0; }
   }
   D.state[old] = WL_GONE;

@@ -256,6 +256,14 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
   p.nfr = p.nF * p.nR; p.n_adm = s->n_adm;
   const int N = p.N, nq = p.nq;
   if (p.nq < 0 || p.nc < 0 || p.nF <= 0 || p.nR <= 0) { p.err = "bad dimensions"; return KQ_EINVAL; }
+  // sizes are checked before anything is sized by them: a negative or absurd count must come back as an error code, not as a
+  // std::length_error / bad_alloc out of a vector (the C ABI also catches those, kq_engine.hip KQ_TRY) or a walk off the caller's arrays
+  if (p.n_adm < 0) { p.err = "negative n_adm"; return KQ_EINVAL; }
+  if (p.n_adm > KQ_MAX_ADMITTED || (int64_t)p.nq + p.nc > KQ_MAX_NODES || (int64_t)p.nF * p.nR > KQ_MAX_FR || ((int64_t)p.nq + p.nc) * ((int64_t)p.nF * p.nR) > ((int64_t)1 << 31) - 1) {
+    p.err = "snapshot larger than the engine's index space (admitted rows / nodes / flavor-resources)"; return KQ_EUNSUPPORTED;
+  }
+  if (!s->cq_adm_off || s->cq_adm_off[0] != 0 || s->cq_adm_off[nq] != p.n_adm) { p.err = "cq_adm_off does not cover [0, n_adm)"; return KQ_EINVAL; }
+  if (p.n_adm > 0 && (!s->adm_use_off || s->adm_use_off[0] != 0)) { p.err = "adm_use_off must start at 0"; return KQ_EINVAL; }
   p.n_rg = s->cq_rg_off[nq];
   p.depth.assign(N, 0); p.root.assign(N, 0);
   for (int n = 0; n < N; n++) {
@@ -314,11 +322,12 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
   // admitted rows
   p.adm_cq.assign(p.n_adm, -1);
   for (int c = 0; c < nq; c++) {
-    if (s->cq_adm_off[c] > s->cq_adm_off[c + 1]) { p.err = "cq_adm_off not monotone"; return KQ_EINVAL; }
+    if (s->cq_adm_off[c] > s->cq_adm_off[c + 1] || s->cq_adm_off[c] < 0 || s->cq_adm_off[c + 1] > p.n_adm) { p.err = "cq_adm_off not monotone"; return KQ_EINVAL; }
     for (int r = s->cq_adm_off[c]; r < s->cq_adm_off[c + 1]; r++) p.adm_cq[r] = c;
   }
   for (int r = 0; r < p.n_adm; r++) {
     if (p.adm_cq[r] < 0) { p.err = "admitted row outside cq_adm_off"; return KQ_EINVAL; }
+    if (s->adm_use_off[r] > s->adm_use_off[r + 1]) { p.err = "adm_use_off not monotone"; return KQ_EINVAL; }
     p.tree_row_off[p.tree_of[p.adm_cq[r]] + 1]++;
   }
   for (int t = 0; t < p.n_tree; t++) p.tree_row_off[t + 1] += p.tree_row_off[t];

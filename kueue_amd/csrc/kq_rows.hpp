@@ -16,6 +16,9 @@
 
 namespace kq {
 
+// temporary storage of the backend's sort / scan primitives: one per engine (its device, its stream), grown on demand
+struct RowsScratch { void* p = nullptr; size_t cap = 0; };
+
 enum { RO_ROW_INIT = 0, RO_KEY_RTS, RO_KEY_PRIO, RO_KEY_TREE, RO_RANK, RO_KEY_ASC, RO_ASC, RO_ENT_FILL, RO_BOUNDS, RO_BUCKET_FILL, RO_BUCKET_SIZE,
        RO_LKEY, RO_LFILL, RO_MOVE_ROW, RO_MOVE_ENT, RO_ADD_ROW, RO_KEY_FS, RO_FS_FILL, RO_EVICT };
 

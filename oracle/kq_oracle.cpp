@@ -121,6 +121,8 @@ struct Stats {
   // victim/drs bytes of SimulatePreemption calls whose result the reference discards (the flavor was
   // already noFit, flavorassigner.go:1161): the engine does not run those searches at all.
   int64_t discarded_bytes = 0;
+  // probe counters (kqo_jacobi_probe): victim searches, candidates they listed, rows they removed before the fill-back, fair pops
+  int64_t searches = 0, cand_listed = 0, cand_removed = 0, fair_pops = 0;
   int64_t total() const { return cell_bytes + head_io_bytes + entry_bytes + victim_bytes + drs_bytes - discarded_bytes; }
 };
 
@@ -1059,6 +1061,7 @@ struct Preemptor {
     std::vector<candidateElem> eh, nh, ep, np, es, ns, all;
     split(hierarchy, &eh, &nh); split(priorityC, &ep, &np); split(sameQueue, &es, &ns);
     for (auto* l : {&eh, &ep, &es, &nh, &np, &ns}) all.insert(all.end(), l->begin(), l->end());
+    sn.st.searches++; sn.st.cand_listed += (int64_t)all.size();
     bool NoCandidateFromOtherQueues = hierarchy.empty() && priorityC.empty();
     bool NoCandidateForHierarchicalReclaim = hierarchy.empty();
     bool forbidden = IsBorrowingWithinCohortForbidden(ctx.preemptorCQ);
@@ -1074,6 +1077,7 @@ struct Preemptor {
         sn.RemoveWorkload(c.wl);
         targets.push_back({c.wl, variantReason(c.variant)});
         if (workloadFits(ctx, borrowing)) {
+          sn.st.cand_removed += (int64_t)targets.size();
           targets = fillBackWorkloads(ctx, targets, borrowing);
           restoreSnapshot(targets);
           return targets;
@@ -1253,11 +1257,14 @@ struct Preemptor {
     std::vector<int> candidates = findCandidates(ctx);
     if (candidates.empty()) return {};
     sortCandidates(candidates, ctx.preemptorCQ);
+    sn.st.searches++; sn.st.cand_listed += (int64_t)candidates.size();
     sn.AddUsage(ctx.preemptorCQ, ctx.workloadUsage);  // SimulateUsageAddition :557
     std::vector<Target> targets; std::vector<int> retry;
     bool fits = runFirstFsStrategy(ctx, candidates, fsStrategies[0], &targets, &retry);
     if (!fits && fsStrategies.size() > 1) fits = runSecondFsStrategy(retry, ctx, &targets);
     sn.RemoveUsage(ctx.preemptorCQ, ctx.workloadUsage);  // revertSimulation
+    sn.st.cand_removed += (int64_t)targets.size();
+    sn.st.fair_pops += (int64_t)targets.size() + (int64_t)retry.size();
     if (!fits) { restoreSnapshot(targets); return {}; }
     targets = fillBackWorkloads(ctx, targets, true);
     restoreSnapshot(targets);
@@ -1321,6 +1328,11 @@ struct Entry {
   int nominatedMode = NoFit;
   int finalMode = NoFit;
   int order = -1;
+  // what processEntry did to the state the entries share (read by kqo_jacobi_probe only): the usage it added to the ClusterQueue
+  // and whether its targets joined preemptedWorkloads; recomputed = 1 overlap recomputation, 2 TAS recomputation
+  FRQ effUsage;
+  bool effInsert = false;
+  int recomputed = 0;
 };
 
 // PodSetReducer (podset_reducer.go:28-86): Search finds the largest counts between PodSets[*].Count and *MinimumCount that
@@ -1496,6 +1508,7 @@ struct Scheduler {
     if (!needsOverlapRecompute && !needsTASRecompute) { *usageOut = usage; return fc == FitsCheckOk; }
     if (!needsOverlapRecompute) {  // case needsTASRecompute :728
       sn.tasRecomputes++;
+      e.recomputed = 2;
       e.head.has_last = false;
       e.head.nomination.assign(e.head.ps.size(), {});
       e.head.has_nomination = !e.assignment.PodSets.empty();
@@ -1507,6 +1520,7 @@ struct Scheduler {
       *usageOut = usage;
       return fc == FitsCheckOk;
     }
+    e.recomputed = 1;
     std::vector<int> victims(preempted.begin(), preempted.end());
     // The engine keeps a second usage plane without the cycle's victims instead of removing and
     // re-adding them here, so this traffic is excluded from the comparable byte count.
@@ -1560,6 +1574,7 @@ struct Scheduler {
         if (!canAlwaysReclaim || (sn.gate(KQ_GATE_PRIORITIZE_PREEMPTORS) && (e.head.flags & KQ_HEAD_IS_PREEMPTOR))) {
           FRQ r = (e.head.flags & KQ_HEAD_HAS_QUOTA_RESERVATION) ? FRQ() : quotaResourcesToReserve(e, cq);  // resourcesToReserve :780 via netUsage
           sn.AddUsage(cq, r);
+          e.effUsage = r;
           if (sn.T) tasUsageApply(sn, e.head, e.assignment.UsageTAS, true);  // resourcesToReserve -> netUsage :785-794 carries Usage.TAS
           sn.st.entry_bytes += (int64_t)r.size() * 8 * (sn.depth[cq] + 1);
         }
@@ -1570,6 +1585,7 @@ struct Scheduler {
       e.requeueReason = KQ_RQ_PENDING_PREEMPTION;
       e.head.has_last = false;
       sn.AddUsage(cq, usage);
+      e.effUsage = usage;
       if (sn.T) tasUsageApply(sn, e.head, e.assignment.UsageTAS, true);
       sn.st.entry_bytes += (int64_t)usage.size() * 8 * (sn.depth[cq] + 1);
       return;
@@ -1577,7 +1593,9 @@ struct Scheduler {
     if (hasAny(preemptedWorkloads, e.preemptionTargets)) { e.status = KQ_ST_SKIPPED; e.skip = KQ_SKIP_OVERLAP; return; }
     if (!fitsOk) { e.status = KQ_ST_SKIPPED; e.skip = KQ_SKIP_NO_LONGER_FITS; return; }
     for (auto& t : e.preemptionTargets) preemptedWorkloads.insert(t.row);
+    e.effInsert = true;
     sn.AddUsage(cq, usage);
+    e.effUsage = usage;
     if (sn.T) tasUsageApply(sn, e.head, e.assignment.UsageTAS, true);
     sn.st.entry_bytes += (int64_t)usage.size() * 8 * (sn.depth[cq] + 1);
     if (mode == Preempt) {
@@ -2138,5 +2156,142 @@ int kqo_podset_reducer_search(int32_t n, const int32_t* counts, const int32_t* m
 // SatisfiesPreemptionPolicy (preemption/common/preemption_policy.go:27-42) on effective priorities and queue-order timestamps
 int kqo_satisfies_preemption_policy(int64_t preemptor_priority, int64_t preemptor_ts, int64_t candidate_priority, int64_t candidate_ts, int32_t policy) {
   return Preemptor::satisfiesPreemptionPolicy(preemptor_priority, preemptor_ts, candidate_priority, candidate_ts, policy) ? 1 : 0;
+}
+
+// ---- measurement, not a restatement: how deep is the dependency chain of processEntry? -----------------------------------------
+// Runs the cycle's nomination once, then (a) the reference's sequential walk (scheduler.go:356-360) recording per entry what it
+// did, and (b) a JACOBI iteration over the same entries: in round r every entry is processed against the state the outcomes of
+// round r-1 leave in front of it (base usage + the usage the earlier entries added + the rows they preempted), in the order the
+// iterator yields on that state (classical: the static sort; fair sharing: the DRS tournament on the speculative state). Entry
+// 0 is exact in round 0; an entry is final once everything in front of it is final and unchanged, so the final prefix grows by
+// at least one per round and the fixed point is the sequential result. rounds[r] = {final prefix after round r, entries whose
+// outcome changed against round r-1, first changed position}. per_entry[i] = {position, nominated targets, overlap/TAS
+// recompute flag, final targets, final status, action, searches of its processEntry, candidates listed, rows removed before the
+// fill-back, round in which its outcome last changed, recompute against (cycle-start usage, true preempted set) differs? 0/1/-1}.
+struct ProbeOutcome {
+  bool valid = false;
+  int status = 0, skip = 0, finalMode = 0, action = 0, requeue = 0;
+  std::vector<int> targets;
+  FRQ effUsage; bool effInsert = false;
+  bool same(const ProbeOutcome& o) const {
+    if (valid != o.valid || status != o.status || skip != o.skip || finalMode != o.finalMode || action != o.action || requeue != o.requeue || effInsert != o.effInsert || targets != o.targets) return false;
+    if (effUsage.size() != o.effUsage.size()) return false;
+    auto a = effUsage.begin(); auto b = o.effUsage.begin();
+    for (; a != effUsage.end(); ++a, ++b) if (a->first != b->first || a->second.v != b->second.v) return false;
+    return true;
+  }
+};
+static ProbeOutcome probeOutcomeOf(const Entry& e) {
+  ProbeOutcome o; o.valid = true; o.status = e.status; o.skip = e.skip; o.finalMode = e.finalMode; o.action = e.action; o.requeue = e.requeueReason;
+  for (auto& t : e.preemptionTargets) o.targets.push_back(t.row);
+  std::sort(o.targets.begin(), o.targets.end());
+  o.effUsage = e.effUsage; o.effInsert = e.effInsert;
+  return o;
+}
+int kqo_jacobi_probe(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, int32_t max_rounds, int32_t* per_entry /* [n][12] */,
+                     int32_t* rounds /* [max_rounds][3] */, int32_t* n_rounds, int32_t* converged) {
+  Snap sn(*cfg, s);
+  Scheduler sch(sn, h);
+  std::vector<Entry> nominated;
+  sch.schedule(nominated, true);
+  const int n = h->n;
+  const bool fair = sn.cfg.fair_sharing != 0;
+  const std::vector<int64_t> baseUsage = sn.usage;
+  std::vector<int> classical;
+  if (!fair) classical = sch.classicalOrder(nominated);
+  // the iterator on the current state: classical = position in the static order; fair = getCq + computeDRS + tournament
+  auto nextEntry = [&](std::vector<Entry>& ents, std::map<int, int>& cqToEntry, int pos) -> int {
+    if (!fair) return classical[pos];
+    int cq = cqToEntry.begin()->first, w;
+    if (!sn.HasParent(cq)) w = cqToEntry[cq];
+    else { int root = sn.Root(cq); sch.computeDRS(root, ents, cqToEntry); w = sch.runTournament(root, ents, cqToEntry); }
+    cqToEntry.erase(ents[w].head.cq);
+    return w;
+  };
+  auto freshMap = [&](std::map<int, int>& m) { m.clear(); if (fair) for (int i = 0; i < n; i++) m[nominated[i].head.cq] = i; };
+  const int npos = [&] { std::map<int, int> m; freshMap(m); return fair ? (int)m.size() : n; }();
+  // (a) the sequential walk
+  std::vector<ProbeOutcome> truth(n);
+  std::vector<int> trueSeq;
+  for (int i = 0; i < n; i++) for (int k = 0; k < 12; k++) per_entry[(size_t)i * 12 + k] = -1;
+  {
+    std::vector<Entry> ents = nominated;
+    std::map<int, int> m; freshMap(m);
+    std::set<int> preempted;
+    for (int pos = 0; pos < npos; pos++) {
+      const int i = nextEntry(ents, m, pos);
+      trueSeq.push_back(i);
+      int32_t* pe = per_entry + (size_t)i * 12;
+      pe[0] = pos; pe[1] = (int)ents[i].preemptionTargets.size();
+      // (c) would the outcome be the same against {cycle-start usage, the true preempted set}? — i.e. does only the preempted
+      // set carry the dependency, or also the usage the earlier entries added
+      int differs = -1;
+      const bool overlap = Scheduler::hasAny(preempted, ents[i].preemptionTargets);
+      if (overlap) {
+        std::vector<int64_t> saveU = sn.usage;
+        sn.usage = baseUsage;
+        Entry e2 = ents[i]; std::set<int> p2 = preempted;
+        sch.processEntry(e2, p2);
+        ProbeOutcome o2 = probeOutcomeOf(e2);
+        sn.usage = saveU;
+        Entry e3 = ents[i]; std::set<int> p3 = preempted;
+        std::vector<int64_t> saveU3 = sn.usage;
+        sch.processEntry(e3, p3);
+        sn.usage = saveU3;
+        differs = o2.same(probeOutcomeOf(e3)) ? 0 : 1;
+      }
+      const int64_t s0 = sn.st.searches, c0 = sn.st.cand_listed, r0 = sn.st.cand_removed;
+      sch.processEntry(ents[i], preempted);
+      truth[i] = probeOutcomeOf(ents[i]);
+      pe[2] = ents[i].recomputed; pe[3] = (int)ents[i].preemptionTargets.size(); pe[4] = ents[i].status; pe[5] = ents[i].action;
+      pe[6] = (int)(sn.st.searches - s0); pe[7] = (int)(sn.st.cand_listed - c0); pe[8] = (int)(sn.st.cand_removed - r0);
+      pe[10] = differs;
+    }
+  }
+  // (b) Jacobi rounds
+  std::vector<ProbeOutcome> prev(n), cur(n);
+  std::vector<int> prevSeq;
+  *n_rounds = 0; *converged = 0;
+  for (int r = 0; r < max_rounds; r++) {
+    sn.usage = baseUsage;
+    std::fill(sn.removed.begin(), sn.removed.end(), 0);
+    std::vector<Entry> ents = nominated;
+    std::map<int, int> m; freshMap(m);
+    std::set<int> preempted;
+    std::vector<int> seq;
+    for (int pos = 0; pos < npos; pos++) {
+      const int i = nextEntry(ents, m, pos);
+      seq.push_back(i);
+      std::vector<int64_t> saveU = sn.usage;
+      std::set<int> p2 = preempted;
+      Entry e = nominated[i];
+      sch.processEntry(e, p2);
+      cur[i] = probeOutcomeOf(e);
+      sn.usage = saveU;
+      if (prev[i].valid) {  // the state the NEXT entries see comes from last round's outcome of this one
+        if (prev[i].effInsert) for (int row : prev[i].targets) preempted.insert(row);
+        sn.AddUsage(e.head.cq, prev[i].effUsage);
+      }
+    }
+    int changed = 0, first = npos;
+    for (int pos = 0; pos < npos; pos++) {
+      const int i = seq[pos];
+      const bool ch = (r > 0 && prevSeq[pos] != i) || !cur[i].same(prev[i]);
+      if (ch) { changed++; if (pos < first) first = pos; per_entry[(size_t)i * 12 + 9] = r; }
+    }
+    rounds[3 * r] = first >= npos ? npos : first + 1; rounds[3 * r + 1] = changed; rounds[3 * r + 2] = first;
+    *n_rounds = r + 1;
+    prev = cur; prevSeq = seq;
+    if (changed == 0) { *converged = 1; break; }
+  }
+  if (*converged) {  // the fixed point must be the sequential result
+    for (int pos = 0; pos < npos; pos++) if (prevSeq[pos] != trueSeq[pos] || !prev[trueSeq[pos]].same(truth[trueSeq[pos]])) return KQ_EINVAL;
+  } else {
+    // how much of the sequential result has the last round reached?
+    int ok = 0;
+    for (int pos = 0; pos < npos; pos++) { if (prevSeq[pos] != trueSeq[pos] || !prev[trueSeq[pos]].same(truth[trueSeq[pos]])) break; ok++; }
+    per_entry[11] = ok;
+  }
+  return KQ_OK;
 }
 }  // extern "C"

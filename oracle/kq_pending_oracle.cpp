@@ -228,7 +228,8 @@ int kqp_update(void* qp, int32_t n, const int32_t* wl, const kq_pending* more) {
     // inadmissible: RemoveFromInadmissible :405 and on as above. (in flight :388 does not occur between cycles.)
     if (was[i] == KQ_WL_ACTIVE && same) q.wl[w2].state = KQ_WL_ACTIVE;
     if (c.pw == old) {
-      if (same) { c.pw = w2; c.pw_gen_changed = true; }   // the pointer is a name (:109): stickyMatches :124 still, IsPreemptor :213 not
+      // the pointer is a name (:109): stickyMatches :124 still; IsPreemptor :213 also wants the Generation the pointer was set with
+      if (same) { c.pw = w2; if (!(more->same_generation && more->same_generation[i])) c.pw_gen_changed = true; }
       else { c.pw = -1; c.pw_sticky = false; c.pw_gen_changed = false; }   // left this ClusterQueue: Delete :506
     }
     q.wl[old].state = KQ_WL_GONE;

@@ -395,7 +395,10 @@ func (e *Engine) AddPending(more *FlatHeads, uidRank []uint32, nLQ int32, lq []i
 // UpdatePending = PushOrUpdate (cluster_queue.go:379-428) of keys that ARE pending, each with its new object: more's i-th workload
 // replaces wl[i] (same uidRank) and gets index first+i, wl[i] leaves the set. A key that was in the heap stays in the heap (:427); an
 // inadmissible one is re-evaluated like an arrival (:405-426); the ClusterQueue's sticky preemptor pointer follows the key.
-func (e *Engine) UpdatePending(wl []int32, more *FlatHeads, uidRank []uint32, nLQ int32, lq []int32, requeueAt []int64) (int32, error) {
+// sameGeneration[i] (optional): the new object's metadata.generation equals the old one's (a status-only update): IsPreemptor
+// (cluster_queue.go:213) keeps holding for the ClusterQueue's preemptor. The caller has both objects at hand in the workload
+// controller's Update handler (old.Generation == new.Generation).
+func (e *Engine) UpdatePending(wl []int32, more *FlatHeads, uidRank []uint32, nLQ int32, lq []int32, requeueAt []int64, sameGeneration []uint8) (int32, error) {
 	var p runtime.Pinner
 	defer p.Unpin()
 	c := (*C.kq_pending)(C.calloc(1, C.sizeof_kq_pending))
@@ -408,6 +411,9 @@ func (e *Engine) UpdatePending(wl []int32, more *FlatHeads, uidRank []uint32, nL
 	}
 	if len(requeueAt) > 0 {
 		c.requeue_at = (*C.int64_t)(pin(&p, requeueAt))
+	}
+	if len(sameGeneration) == len(wl) && len(wl) > 0 {
+		c.same_generation = (*C.uint8_t)(pin(&p, sameGeneration))
 	}
 	var first C.int32_t
 	if rc := C.kq_pending_update(e.h, C.int32_t(len(wl)), (*C.int32_t)(pin(&p, wl)), c, &first); rc != 0 {

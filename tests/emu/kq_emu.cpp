@@ -98,7 +98,7 @@ struct EmuBackend {
   void launch_afs_usage(const DPend& D, bool init_f64) { for (int l = 0; l < D.A.n_lq; l++) afs_init_lq(D.A, l, init_f64); }
   void launch_afs_sub(const DPend& D, const int32_t* list, int n) { afs_sub_list(D, list, n); }
   void launch_afs_set_consumed(const DPend& D, const int32_t* lq, const uint64_t* lo, const int64_t* hi, const double* f64, const int32_t* settle, int n) {
-    for (int i = 0; i < n; i++) afs_set_consumed(D.A, lq, lo, hi, f64, settle, i);
+    for (int i = 0; i < n; i++) afs_set_consumed(D.A, D.lq, lq, lo, hi, f64, settle, i);
   }
   void launch_pend_apply(const DPend& D, const DSnap& S, const DOut& O, const DHeads& H, uint32_t gates, int64_t cycle, int n) {
     for (int h = 0; h < n; h++) pend_apply_head(D, S, O, H, gates, cycle, h);
@@ -111,7 +111,7 @@ struct EmuBackend {
   }
   void launch_pend_add_fix(const DPend& D, const DSnap& S, int first, int n) { for (int i = 0; i < n; i++) pend_add_fix(D, S, first + i); }
   void launch_pend_requeue_at(const DPend& D, const DSnap& S, const int32_t* list, const int64_t* at, int n) { for (int i = 0; i < n; i++) pend_requeue_at(D, S, list, at, i); }
-  void launch_pend_update_fix(const DPend& D, const int32_t* list, int first, int n) { for (int i = 0; i < n; i++) pend_update_fix(D, list, first, i); }
+  void launch_pend_update_fix(const DPend& D, const int32_t* list, const uint8_t* same_gen, int first, int n) { for (int i = 0; i < n; i++) pend_update_fix(D, list, same_gen, first, i); }
   void launch_pend_delete(const DPend& D, const int32_t* list, int n) { for (int i = 0; i < n; i++) pend_delete(D, list, i); }
   void launch_pend_qi(const DPend& D, const int32_t* list, int n) { for (int i = 0; i < n; i++) pend_queue_inadmissible(D, list ? list[i] : i); }
   void launch_pend_release(const DPend& D, const DSnap& S, int32_t* tree_stamp, const int32_t* cq, const int32_t* use_n, int n, int32_t stamp) {

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Transcribes whole-cycle tables TestSchedule (scheduler_test.go:366) and TestScheduleForFairSharing
-(scheduler_fs_test.go:38) into YAML.
+"""Transcribes whole-cycle tables TestSchedule (scheduler_test.go:366), TestScheduleForFairSharing (scheduler_fs_test.go:38),
+TestScheduleRecomputePreemptionTargets (scheduler_recompute_preemption_test.go:59) and TestScheduleForPreserveFlavorScanProgress
+(scheduler_preserve_flavor_scan_progress_test.go:82) into YAML.
 
   python tests/golden/extract_schedule.py      # needs /root/reference (this container only)
 
@@ -232,6 +233,9 @@ def extract(fname, func, cases, skipped):
                 known = {"FlavorFungibility", "PartialAdmission", "PrioritySortingWithinCohort", "FairSharingPreemptWithinNominal",
                          "FairSharingPrioritizeNonBorrowing", "RecomputeAssignmentUponPreemptionTargetsOverlap", "PrioritizePreemptorWorkloads",
                          "FlavorFungibilityPreserveScanProgress"}
+                # the TAS gates do not touch a case without any TopologyRequest / TAS flavor (those blocks were skipped above): noted, not applied
+                ignored = {g: v for g, v in gates.items() if g in ("TopologyAwareScheduling", "TASRecomputeAssignmentWithinSchedulingCycle")}
+                gates = {g: v for g, v in gates.items() if g not in ignored}
                 if any(g not in known for g in gates):
                     raise Skip(f"feature gates {sorted(gates)}")
             cqs = [dict(c) for c in default_cqs]
@@ -253,6 +257,12 @@ def extract(fname, func, cases, skipped):
                 lqs.update(parse_lqs(alq))
             cohorts = []
             cf = field(block, "cohorts")
+            if cf and re.match(r"\s*(\w+)\(\)\s*$", cf):   # a helper of the test file returning []kueue.Cohort (defaultCohorts())
+                fn = re.match(r"\s*(\w+)\(\)", cf).group(1)
+                fm = re.search(r"(?m)^func %s\(\) \[\]kueue\.Cohort \{" % fn, src)
+                fbody = src[fm.end(): match_brace(src, fm.end() - 1)]
+                rm = re.search(r"return \[\]kueue\.Cohort\{", fbody)
+                cf = fbody[rm.start() + len("return "):]
             if cf:
                 p = cf.index("{")
                 cohorts = [parse_cohort(t) for t in list_items(cf[p + 1: match_brace(cf, p)], "MakeCohort")]
@@ -340,6 +350,8 @@ def extract(fname, func, cases, skipped):
                     "admitted": admitted, "pending": heads, "notHeads": [r["name"] for r in rest], "expect": expect, "wantPreempted": preempted}
             if gates:
                 case["gates"] = gates
+            if fg and ignored:
+                case["ignoredGates"] = ignored
             efs = field(block, "enableFairSharing")
             if efs and efs.strip() == "true":
                 case["fairSharing"] = True
@@ -351,7 +363,10 @@ def extract(fname, func, cases, skipped):
 
 
 def main():
-    for fname, func, out in (("scheduler_test.go", "TestSchedule", "schedule.yaml"), ("scheduler_fs_test.go", "TestScheduleForFairSharing", "schedule_fair.yaml")):
+    for fname, func, out in (("scheduler_test.go", "TestSchedule", "schedule.yaml"), ("scheduler_fs_test.go", "TestScheduleForFairSharing", "schedule_fair.yaml"),
+                             ("scheduler_recompute_preemption_test.go", "TestScheduleRecomputePreemptionTargets", "schedule_recompute.yaml")):
+        # (TestScheduleForPreserveFlavorScanProgress, scheduler_preserve_flavor_scan_progress_test.go:82, is a multi-cycle TAS scenario, not a
+        #  scheduleTestCase table: transcribed by hand into schedule_scan_progress_manual.yaml)
         cases, skipped = [], []
         extract(fname, func, cases, skipped)
         with open(os.path.join(HERE, out), "w") as f:

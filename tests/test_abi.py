@@ -94,3 +94,60 @@ def test_process_kernel_lds_budget_holds_cfg3():
     wave, rec = int(out[0]), int(out[1])
     rows = 111 * 64 * 16
     assert rows + rec <= 160 * 1024 - wave - 256, (wave, rec, rows)
+
+
+def _absurd_snapshots():
+    """Snapshots whose admitted-row count is negative / beyond the index space / inconsistent with cq_adm_off: the put must come back
+    with an error code — never std::terminate (a std::length_error out of vector::assign(n_adm) was the round-3 SIGABRT suspect)."""
+    import copy
+    from tests.randgen import random_case
+    out = []
+    for n_adm, want in ((-5, F.KQ_EINVAL), ((1 << 26) + 1, F.KQ_EUNSUPPORTED), (2_000_000, F.KQ_EINVAL)):
+        cfg, snap, heads = random_case(7, fair=False, preemption=True)
+        from oracle import kqo
+        kqo.derive(snap)
+        st = snap.struct()
+        st.n_adm = n_adm          # the arrays still describe the real table: cq_adm_off[nq] != n_adm
+        out.append((cfg, snap, want))
+    return out
+
+
+def test_absurd_row_counts_return_an_error_code_emulated():
+    import ctypes as C
+    from tests.emu import kqe
+    for cfg, snap, want in _absurd_snapshots():
+        eng = kqe.EmuEngine(cfg)
+        try:
+            rc = kqe.lib().kqe_snapshot_put(eng.h, C.byref(snap.struct()))
+            assert rc == want, (rc, want)
+        finally:
+            eng.close()
+
+
+@pytest.mark.gpu
+def test_absurd_row_counts_return_an_error_code_gpu():
+    import ctypes as C
+    from kueue_amd.engine import Engine
+    for cfg, snap, want in _absurd_snapshots():
+        eng = Engine(cfg)
+        try:
+            rc = eng._lib.kq_snapshot_put(eng._h, C.byref(snap.struct()))
+            assert rc == want, (rc, want, eng._lib.kq_last_error(eng._h))
+            # and the engine is still usable afterwards
+            cfg2, snap2, heads2 = __import__("tests.randgen", fromlist=["random_case"]).random_case(7, fair=False, preemption=True)
+            from oracle import kqo
+            kqo.derive(snap2)
+            eng.put(snap2)
+            assert not kqo.cycle_run(cfg2, snap2, heads2).equal(eng.run(heads2))
+        finally:
+            eng.close()
+
+
+def test_no_exception_can_cross_the_c_abi():
+    """Every extern "C" entry point that reaches engine code does so under KQ_TRY (bad_alloc -> KQ_ENOMEM, anything else -> KQ_EINVAL)."""
+    src = open(os.path.join(ROOT, "kueue_amd", "csrc", "kq_engine.hip")).read()
+    body = src[src.index('extern "C" {'):]
+    calls = re.findall(r"return (?:en|t)->e\.(?!last_|be\.device)[a-z_0-9]+\(", body)
+    guarded = re.findall(r"KQ_TRY\((?:en|t), return (?:en|t)->e\.[a-z_0-9]+\(", body)
+    assert len(calls) == len(guarded) and len(guarded) >= 50, (len(calls), len(guarded))
+    assert "g_tmp" not in open(os.path.join(ROOT, "kueue_amd", "csrc", "kq_rows_kernel.hip")).read()   # per-engine rocPRIM scratch

@@ -20,7 +20,7 @@ from tests.fixture_cycles import POSS, _stub
 from tests.randgen import random_case
 
 ASG = [c for c in load_golden("assign_flavors.yaml")["cases"] if any("status" in ps for ps in c["want"].get("podsets", []))]
-SCHED = [c for c in load_golden("schedule.yaml")["cases"] if any("message" in e for e in c["expect"].values())]
+SCHED = [c for c in load_golden("schedule.yaml")["cases"] + load_golden("schedule_recompute.yaml")["cases"] if any("message" in e for e in c["expect"].values())]
 
 # checkFlavorForPodSets strings are formatted on the host (taints / affinity never cross the boundary): the text per tainted flavor
 # of the reference's tables (flavorassigner_test.go:260-283, scheduler_test.go:505-530)

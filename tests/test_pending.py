@@ -774,9 +774,11 @@ def test_push_or_update_of_a_pending_key(oracle, old_state, backoff, blocked_has
         eng.close(); q.close()
 
 
-def test_update_keeps_the_sticky_preemptor_but_not_is_preemptor(oracle):
+@pytest.mark.parametrize("same_generation", [False, True], ids=["spec-changed", "status-only-update"])
+def test_update_keeps_the_sticky_preemptor_but_not_is_preemptor(oracle, same_generation):
     """preemptorWorkload holds a name (cluster_queue.go:109): after PushOrUpdate of that key with a new object stickyMatches (:124) still
-    sorts it first, IsPreemptor (:213, strict: generation) no longer holds."""
+    sorts it first, IsPreemptor (:213, strict: generation) no longer holds — unless the new object carries the SAME Obj.Generation (a
+    status-only update: ReclaimablePods, the Evicted / Requeued conditions), which kq_pending.same_generation tells the engine."""
     from tests.emu import kqe
     snap = _one_cq()
     cfg = make_config()
@@ -800,12 +802,15 @@ def test_update_keeps_the_sticky_preemptor_but_not_is_preemptor(oracle):
         assert q.is_sticky(0)
         repl = _mk_pending(snap, ["low"], [0], rank0=0)
         repl.heads.arrays["priority"][:] = 2; repl.heads._struct = None
+        if same_generation:
+            repl.same_generation = np.ones(1, np.uint8)
         assert eng.pending_update([0], repl) == q.update([0], repl) == 2
         assert q.is_sticky(2) and not q.is_sticky(0)
         hb, ohw = q.heads(3)
         n, nps, hw = eng.pending_heads(3)
         assert list(hw) == list(ohw) == [2]                            # sticky: ahead of "high" (priority 9)
-        assert not (int(hb.arrays["flags"][0]) & F.HEAD_IS_PREEMPTOR)   # the generation changed
+        # IsPreemptor :213 = name AND Obj.Generation: lost when the spec changed, kept by a status-only update
+        assert bool(int(hb.arrays["flags"][0]) & F.HEAD_IS_PREEMPTOR) == same_generation
         assert int(eng.pending_batch_flags(1)[0]) == int(hb.arrays["flags"][0])
     finally:
         eng.close(); q.close()
