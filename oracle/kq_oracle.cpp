@@ -123,6 +123,10 @@ struct Stats {
   int64_t discarded_bytes = 0;
   // probe counters (kqo_jacobi_probe): victim searches, candidates they listed, rows they removed before the fill-back, fair pops
   int64_t searches = 0, cand_listed = 0, cand_removed = 0, fair_pops = 0;
+  // what TestFairPreemptionSkipsUnsatisfiableTournament (preemption_fair_test.go:1194) counts through the V(4) log lines: target
+  // ClusterQueues whose candidates the first strategy simulated (one collapsed entry per ClusterQueue, preemption.go:425-470), second
+  // strategy evaluations (:512), ClusterQueues skipped by fsStrategyUnsatisfiable (:494)
+  int64_t fs_first_cq_evals = 0, fs_second_evals = 0, fs_skipped_queues = 0;
   int64_t total() const { return cell_bytes + head_io_bytes + entry_bytes + victim_bytes + drs_bytes - discarded_bytes; }
 };
 
@@ -1189,8 +1193,10 @@ struct Preemptor {
       if (std::isinf(preemptorNewShare.PreciseWeightedShare()) && preemptorNewShare.PreciseWeightedShare() > 0 &&
           !(std::isinf(targetOldShare.PreciseWeightedShare()) && targetOldShare.PreciseWeightedShare() > 0)) {
         while (ordering.hasWorkload(candCQ)) retryCandidates->push_back(ordering.PopWorkload(candCQ));
+        sn.st.fs_skipped_queues++;
         continue;
       }
+      sn.st.fs_first_cq_evals++;
       while (ordering.hasWorkload(candCQ)) {
         int candWl = ordering.PopWorkload(candCQ);
         // ComputeTargetShareAfterRemoval target.go:67-73
@@ -1217,6 +1223,7 @@ struct Preemptor {
       auto al = getAlmostLCAs(ordering, candCQ);
       DRS preemptorNewShare = dominantResourceShare(sn, al.first), targetOldShare = dominantResourceShare(sn, al.second);
       bool passed = CompareDRS(preemptorNewShare, targetOldShare) < 0;
+      sn.st.fs_second_evals++;
       int candWl = ordering.PopWorkload(candCQ);
       if (passed) {
         sn.RemoveWorkload(candWl);
@@ -1943,6 +1950,9 @@ int kqo_assign(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, in
 
 // Preemptor.GetTargets for head `hi` given an explicit assignment (flavor + mode per (podset,resource)),
 // as TestPreemption drives it (preemption_test.go:4093-4170). Checks the snapshot is restored exactly.
+static thread_local int64_t g_last_fs_counters[3] = {0, 0, 0};
+// the three log-line counters of the last kqo_get_targets on this thread (see Stats::fs_first_cq_evals)
+void kqo_last_fs_counters(int64_t* out3) { for (int i = 0; i < 3; i++) out3[i] = g_last_fs_counters[i]; }
 int kqo_get_targets(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, int hi,
                     const int32_t* flavor, const uint8_t* res_mode, int32_t cap, int32_t* tgt_adm, uint8_t* tgt_reason, int32_t* n_out) {
   Snap sn(*cfg, s);
@@ -1956,6 +1966,7 @@ int kqo_get_targets(const kq_config* cfg, const kq_snapshot* s, const kq_heads* 
   }
   std::vector<int64_t> before = sn.usage;
   std::vector<Target> t = sch.preemptor.GetTargets(wl, a);
+  g_last_fs_counters[0] = sn.st.fs_first_cq_evals; g_last_fs_counters[1] = sn.st.fs_second_evals; g_last_fs_counters[2] = sn.st.fs_skipped_queues;
   if (before != sn.usage) return KQ_EINVAL;  // snapshot-restoration invariant (preemption_test.go:4172)
   for (auto x : sn.removed) if (x) return KQ_EINVAL;
   std::sort(t.begin(), t.end(), [](const Target& x, const Target& y) { return x.row < y.row; });
@@ -2292,6 +2303,63 @@ int kqo_jacobi_probe(const kq_config* cfg, const kq_snapshot* s, const kq_heads*
     for (int pos = 0; pos < npos; pos++) { if (prevSeq[pos] != trueSeq[pos] || !prev[trueSeq[pos]].same(truth[trueSeq[pos]])) break; ok++; }
     per_entry[11] = ok;
   }
+  return KQ_OK;
+}
+
+// entryComparer.less (fair_sharing_iterator.go:176-221) with INJECTED DRS values, as TestEntryComparerLess (scheduler_test.go:8411-8683)
+// drives it: heads 0 / 1 of `h` are a / b (queue_ts, KQ_HEAD_IS_PREEMPTOR, priority). kind[i]: -1 no entry in drsValues (the map's
+// zero value DRS{}), 0 DRS{} stored explicitly, 1 schdcache.BorrowingDRS(fr 0) (fair_sharing_test_util.go:22), 2 schdcache.NegativeDRS()
+// (fair_sharing.go:58). req[i]: requestedFRs[entry][fr 0] (0 = no entry).
+int kqo_entry_less(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, const int32_t* kind, const int64_t* req) {
+  Snap sn(*cfg, s);
+  Scheduler sch(sn, h);
+  std::vector<Entry> entries(2);
+  for (int i = 0; i < 2; i++) entries[i].head = sch.loadHead(i);
+  const int cohort = sn.N;  // any key: the comparison only looks the two entries up under it
+  for (int i = 0; i < 2; i++) {
+    DRS d;
+    d.fairWeight = 0;                                   // Go zero value
+    if (kind[i] == 1) { d.fairWeight = 1.0; d.borrowing = true; d.borrowedFRs = {0}; }
+    if (kind[i] == 2) d = NegativeDRS();
+    if (kind[i] >= 0) sch.drsValues[{cohort, i}] = d;
+    if (req[i] > 0) sch.requestedFRs[i][0] = Amount(req[i]);
+  }
+  return sch.less(entries, 0, 1, cohort) ? 1 : 0;
+}
+// scheduler.fits (scheduler.go:771-777) as TestFitsDedupsOverlappingVictims (scheduler_test.go:9379-9450) calls it: the incoming usage of
+// ClusterQueue `cq` against the snapshot with `preempted` ∪ `targets` removed ONCE each. Returns the FitsCheckResult (0 Ok, 1 NoQuota).
+int kqo_fits_check(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, int32_t cq, int32_t n_use, const int32_t* fr, const int64_t* qty,
+                   int32_t n_pre, const int32_t* pre_rows, int32_t n_tgt, const int32_t* tgt_rows) {
+  Snap sn(*cfg, s);
+  Scheduler sch(sn, h);
+  Entry e;
+  FRQ usage;
+  for (int i = 0; i < n_use; i++) usage[fr[i]] = Amount(qty[i]);
+  std::set<int> preempted(pre_rows, pre_rows + n_pre);
+  std::vector<Target> targets;
+  for (int i = 0; i < n_tgt; i++) targets.push_back({tgt_rows[i], 0});
+  const std::vector<int64_t> before = sn.usage;
+  const int rc = sch.fitsCheck(e, cq, usage, preempted, targets);
+  if (before != sn.usage) return KQ_EINVAL;
+  return rc;
+}
+
+// Assignment.TotalRequestsFor (flavorassigner.go:267-296, with a replaced workload slice :265) as TestAssignment_TotalRequestsFor
+// (flavorassigner_test.go:4645) drives it: head `hi`, the assignment's per-podset counts and the flavor of every (podset, resource) cell
+// (-1: no flavor for that resource). usage_fr: dense [n_fr], 0 where absent.
+int kqo_total_requests_for(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, int32_t hi, const int32_t* counts, const int32_t* flavor, int64_t* usage_fr) {
+  Snap sn(*cfg, s);
+  Scheduler sch(sn, h);
+  Head wl = sch.loadHead(hi);
+  Assignment a;
+  for (size_t p = 0; p < wl.ps.size(); p++) {
+    PodSetAssignment psa; psa.count = counts[p];
+    for (int r = 0; r < sn.nR; r++) if (flavor[p * sn.nR + r] >= 0) { FlavorAssignment f; f.flavor = flavor[p * sn.nR + r]; f.mode = Fit; psa.flavors[r] = f; }
+    a.PodSets.push_back(psa);
+  }
+  FRQ u = sch.preemptor.TotalRequestsFor(wl, a);
+  for (int fr = 0; fr < sn.nfr; fr++) usage_fr[fr] = 0;
+  for (auto& kv : u) usage_fr[kv.first] = kv.second.v;
   return KQ_OK;
 }
 }  // extern "C"

@@ -5,7 +5,7 @@ from tests import fixture_cycles as FC
 from tests.conftest import load_golden
 
 PRE = load_golden("preemption.yaml")["cases"] + load_golden("preemption_manual.yaml")["cases"]
-FAIR = load_golden("preemption_fair.yaml")["cases"]
+FAIR = load_golden("preemption_fair.yaml")["cases"] + load_golden("preemption_fair_manual.yaml")["cases"]   # + TestFairPreemptionSkipsUnsatisfiableTournament
 ASG = load_golden("assign_flavors.yaml")["cases"] + load_golden("assign_flavors_hierarchical.yaml")["cases"] + load_golden("assign_flavors_reclaim.yaml")["cases"]
 
 # how many cases the bridge must carry all the way to the Go expectation (measured; a drop means the bridge or the engine regressed)

@@ -196,3 +196,94 @@ def test_tas_sorted_domains(oracle, case):
 def test_tas_sorted_domains_with_leader(oracle, case):
     """tas_flavor_snapshot_test.go:601 TestSortedDomainsWithLeader."""
     assert _sorted_domains(case, True) == case["want"]
+
+
+DRS_KIND = {"absent": -1, "zero": 0, "borrowing": 1, "negative": 2}
+
+
+@pytest.mark.parametrize("case", M["entryComparerLess"], ids=lambda c: c["name"][:70])
+def test_entry_comparer_less(oracle, case):
+    """scheduler_test.go:8411 TestEntryComparerLess — entryComparer.less with injected DRS values (hand transcription, each case cites its
+    line). The engine orders through the same comparison inside k_process_fair (a 4 x u64 key); its inputs there are real DRS values of a
+    snapshot, so this table pins the restatement, the whole-cycle fair-sharing tables (schedule_fair.yaml, schedule_recompute.yaml) the engine."""
+    import ctypes as C
+    import numpy as np
+    rg = [ResourceGroup([FlavorQuotas("default").Resource("cpu", "100")])]
+    cqs = [ClusterQueue("cq-a", cohort="test-cohort", resource_groups=rg), ClusterQueue("cq-b", cohort="test-cohort", resource_groups=rg)]
+    snap = Snapshot(cqs, [Cohort("test-cohort")], [])
+    oracle.derive(snap)
+    wls = [Workload(n, f"cq-{n}", priority=0, creation_ts=case[n]["queueTs"] * 1_000_000_000, pod_sets=[PodSet("main", count=1).Request("cpu", "1")]) for n in ("a", "b")]
+    heads = Heads(snap, wls)
+    for i, n in enumerate(("a", "b")):
+        if case[n].get("preemptor"):
+            heads.arrays["flags"][i] |= F.HEAD_IS_PREEMPTOR
+    heads._struct = None
+    cfg = make_config(fair_sharing=True, gates=gates_with(case.get("gates") or {}))
+    kind = np.array([DRS_KIND[case[n]["drs"]] for n in ("a", "b")], np.int32)
+    req = np.array([int(case[n].get("requested", 0)) for n in ("a", "b")], np.int64)
+    oracle.lib().kqo_entry_less.restype = C.c_int
+    got = oracle.lib().kqo_entry_less(C.byref(cfg), C.byref(snap.struct()), C.byref(heads.struct()), F.ptr(kind), F.ptr(req))
+    assert bool(got) == case["want"]
+
+
+@pytest.mark.parametrize("case", M["fitsDedupsOverlappingVictims"], ids=lambda c: c["name"][:70])
+def test_fits_dedups_overlapping_victims(oracle, case):
+    """scheduler_test.go:9379 TestFitsDedupsOverlappingVictims — scheduler.fits removes preemptedWorkloads ∪ targets, every workload once."""
+    import ctypes as C
+    import numpy as np
+    from kueue_amd.api import resource_value
+    rg = [ResourceGroup([FlavorQuotas("default").Resource("cpu", case["nominal"])])]
+    snap_adm = [Workload(n, "cq", priority=0, creation_ts=0, pod_sets=[PodSet("main", count=1, flavors={"cpu": "default"}).Request("cpu", q)], reserve_ts=1, uid=n)
+                for n, q in case["admitted"].items()]
+    snap = Snapshot([ClusterQueue("cq", resource_groups=rg)], [], snap_adm)
+    oracle.derive(snap)
+    heads = Heads(snap, [Workload("incoming", "cq", priority=0, creation_ts=1, pod_sets=[PodSet("main", count=1).Request("cpu", case["incoming"])])])
+    row = {w.name: i for i, w in enumerate(snap.admitted)}
+    fr = np.array([snap.flavor_index["default"] * snap.n_resource + snap.resource_index["cpu"]], np.int32)
+    qty = np.array([resource_value("cpu", case["incoming"])], np.int64)
+    pre = np.array([row[n] for n in case["preempted"]], np.int32)
+    tgt = np.array([row[n] for n in case["targets"]], np.int32)
+    cfg = make_config()
+    oracle.lib().kqo_fits_check.restype = C.c_int
+    got = oracle.lib().kqo_fits_check(C.byref(cfg), C.byref(snap.struct()), C.byref(heads.struct()), C.c_int32(0), 1, F.ptr(fr), F.ptr(qty),
+                                      len(pre), F.ptr(pre), len(tgt), F.ptr(tgt))
+    assert got == {"Ok": 0, "NoQuota": 1}[case["want"]]
+    # the engine's scheduler.fits (entry_fits over the np plane, kq_device.hpp) sees the same situation in a whole cycle: a head whose
+    # nominated target was preempted by an earlier entry of the cycle — tests/golden/schedule_recompute.yaml "legacy overlap skip"
+
+
+@pytest.mark.parametrize("case", M["totalRequestsFor"], ids=lambda c: c["name"][:70])
+def test_total_requests_for(oracle, case):
+    """flavorassigner_test.go:4645 TestAssignment_TotalRequestsFor — the usage GetTargets and processEntry charge for an assignment: scaled
+    to the assigned pod counts (partial admission), only the delta over a replaced workload slice (hand transcription)."""
+    import ctypes as C
+    import numpy as np
+    rg = [ResourceGroup([FlavorQuotas("default").Resource("cpu", "100").Resource("memory", "100Gi")])]
+    admitted = []
+    if case.get("slice"):
+        old = [PodSet(p["name"], count=p["count"], flavors={r: "default" for r in p["requests"]}) for p in case["slice"]]
+        for ps, p in zip(old, case["slice"]):
+            for r, q in p["requests"].items():
+                ps.Request(r, q)
+        admitted.append(Workload("old-slice", "cq", pod_sets=old, reserve_ts=1, uid="old-slice"))
+    extra = sorted({r for p in case["podsets"] for r in p["requests"]})
+    snap = Snapshot([ClusterQueue("cq", resource_groups=rg)], [], admitted, extra_resources=extra)
+    oracle.derive(snap)
+    pss = [PodSet(p["name"], count=p["count"]) for p in case["podsets"]]
+    for ps, p in zip(pss, case["podsets"]):
+        for r, q in p["requests"].items():
+            ps.Request(r, q)
+    heads = Heads(snap, [Workload("test", "cq", pod_sets=pss, replaces="old-slice" if case.get("slice") else None)])
+    nR = snap.n_resource
+    flavor = np.full(len(pss) * nR, -1, np.int32)
+    for pi in range(len(pss)):
+        for r in ("cpu", "memory"):
+            flavor[pi * nR + snap.resource_index[r]] = snap.flavor_index["default"]
+    counts = np.array(case["assigned"], np.int32)
+    usage = np.zeros(snap.n_fr, np.int64)
+    cfg = make_config()
+    oracle.lib().kqo_total_requests_for.restype = C.c_int
+    rc = oracle.lib().kqo_total_requests_for(C.byref(cfg), C.byref(snap.struct()), C.byref(heads.struct()), 0, F.ptr(counts), F.ptr(flavor), F.ptr(usage))
+    assert rc == 0
+    got = {snap.fr_name(fr): int(usage[fr]) for fr in range(snap.n_fr) if usage[fr] != 0}
+    assert got == {tuple(k.split("/", 1)): v for k, v in case["want"].items()}
