@@ -54,6 +54,7 @@ KQ_DEV void atomic_max_i32(int* p, int v) { if (v > *p) *p = v; }
 KQ_DEV void atomic_min_i32(int* p, int v) { if (v < *p) *p = v; }
 KQ_DEV void atomic_add_i64(long long* p, long long v) { *p = (long long)((unsigned long long)*p + (unsigned long long)v); }  // wraps like the device's atomic (bucket fingerprints rely on it)
 KQ_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
+KQ_DEV void atomic_and_u64(uint64_t* p, uint64_t v) { *p &= v; }
 KQ_DEV int64_t atomic_cas_i64(int64_t* p, int64_t expect, int64_t v) { int64_t o = *p; if (o == expect) *p = v; return o; }
 KQ_DEV int64_t wsum_i64(int64_t v) { return v; }
 KQ_DEV int wbcast_u(int v, int) { return v; }
@@ -128,6 +129,7 @@ KQ_DEV void atomic_max_i32(int* p, int v) { atomicMax(p, v); }
 KQ_DEV void atomic_min_i32(int* p, int v) { atomicMin(p, v); }
 KQ_DEV void atomic_add_i64(long long* p, long long v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
 KQ_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
+KQ_DEV void atomic_and_u64(uint64_t* p, uint64_t v) { atomicAnd((unsigned long long*)p, (unsigned long long)v); }
 KQ_DEV int64_t atomic_cas_i64(int64_t* p, int64_t expect, int64_t v) {
   return (int64_t)atomicCAS((unsigned long long*)p, (unsigned long long)expect, (unsigned long long)v);
 }
@@ -264,6 +266,7 @@ struct DCfg {
   int quota_check_strategy;
   int cs_on;                 // classical victim searches may take the scan formulation (kq_cs.hpp)
   int fs_on;                 // fair-sharing victim searches may take the LDS-resident formulation (kq_fs.hpp)
+  int fs_batch;              // ... and evaluate the candidates of a cohort's ClusterQueues as a batch (fs_batch; KQ_FS_BATCH=0 turns it off)
   int dbg_variant;           // KQ_PROF builds only: timing experiments (KQ_DEBUG_VARIANT; results are wrong when non-zero)
   int any_preempt;           // some ClusterQueue of the snapshot may preempt (Prep::any_preemption)
   int64_t cycle;

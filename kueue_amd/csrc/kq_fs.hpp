@@ -29,6 +29,8 @@ namespace kq {
 constexpr int FS_PCN = 64;      // (in-use slot, level) cells of the preemptor's context
 constexpr int FS_NCMAX = 16;    // usage columns cached per search
 constexpr int FS_RC = CS_RFR * FS_LV;
+constexpr int FS_BQ = 64;       // ClusterQueues of one cohort handled as a batch (fs_batch_first / fs_batch_second)
+constexpr int FS_BC = 256;      // candidates evaluated per batch
 
 struct Fs {
   const K* k; Wave* w; Search* s;
@@ -43,11 +45,30 @@ struct Fs {
   int64_t* td; int32_t* tp; double* tx; uint64_t* tout;   // staging of one row operation: borrowed-amount deltas / borrowed-cell count deltas per (flavor-resource, level), share terms per (level, resource), result
   int32_t* pc_ptr; int64_t *pc_lq, *pc_sq, *pc_sqb, *pc_bl, *pc_lend; double* pc_wt; int32_t* pc_u;
   int32_t* tpos;
+  // batch of one cohort's ClusterQueues (fs_batch_*): unsorted (child order) and sorted (visiting order) views, candidate list
+  int16_t *bq_c, *bq_ord; uint64_t *bq_k, *bq_h; uint8_t* bq_z;
+  int16_t *br_c, *br_ap, *br_at, *br_n, *br_off; uint8_t* br_fl; uint64_t *br_pk, *br_tk; int32_t *br_vc, *br_qc;
+  int32_t *cl_pos, *cl_cost; uint8_t* cl_rk;
   // fields of the Search (it lives in the caller's frame)
   int64_t* W; const int64_t* usage; const uint8_t* removed; int32_t* trow; uint8_t* treason;
 };
 struct FsRow { int64_t qty[CS_RFR]; int fr[CS_RFR]; int res[CS_RFR]; int lp[FS_LV]; int plen, row, cbytes, rowbytes; uint32_t hkey; };
 
+// every array of the search sits in the workgroup's LDS (fs_setup checks it): tell the compiler, so that the accesses are ds_* instead
+// of flat_* — in every function that receives the Fs by reference (the facts do not travel across a call)
+KQ_DEV void fs_assume_lds(const Fs& f) {
+#if !defined(KQ_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
+  #define FS_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))
+  FS_LDS(f.psum); FS_LDS(f.dval); FS_LDS(f.ppos); FS_LDS(f.nflag); FS_LDS(f.m1); FS_LDS(f.m2); FS_LDS(f.mq); FS_LDS(f.colslot); FS_LDS(f.col);
+  FS_LDS(f.posoff); FS_LDS(f.kid); FS_LDS(f.koff); FS_LDS(f.knc); FS_LDS(f.knh); FS_LDS(f.c0); FS_LDS(f.c1); FS_LDS(f.par); FS_LDS(f.plv);
+  FS_LDS(f.rc_ptr); FS_LDS(f.rc_lq); FS_LDS(f.rc_sqb); FS_LDS(f.rc_lend); FS_LDS(f.rc_wt); FS_LDS(f.td); FS_LDS(f.tp); FS_LDS(f.tx); FS_LDS(f.tout);
+  FS_LDS(f.pc_ptr); FS_LDS(f.pc_lq); FS_LDS(f.pc_sq); FS_LDS(f.pc_sqb); FS_LDS(f.pc_bl); FS_LDS(f.pc_lend); FS_LDS(f.pc_wt); FS_LDS(f.pc_u);
+  FS_LDS(f.bq_c); FS_LDS(f.bq_ord); FS_LDS(f.bq_k); FS_LDS(f.bq_h); FS_LDS(f.bq_z); FS_LDS(f.br_c); FS_LDS(f.br_ap); FS_LDS(f.br_at); FS_LDS(f.br_n); FS_LDS(f.br_off);
+  FS_LDS(f.br_fl); FS_LDS(f.br_pk); FS_LDS(f.br_tk); FS_LDS(f.br_vc); FS_LDS(f.br_qc); FS_LDS(f.cl_pos); FS_LDS(f.cl_cost); FS_LDS(f.cl_rk);
+  #undef FS_LDS
+#endif
+  (void)f;
+}
 #ifdef KQ_HOST_EMU
 static inline
 #else
@@ -65,6 +86,9 @@ size_t fs_bytes(int nn, int nqs, int nR, int nfr, int mw, int ncols) {
   b += al((size_t)(ncoh > 0 ? ncoh : 1) * 2) * 3 + al((size_t)(nqs + 1) * 4) + al(nfr);            // koff knc knh posoff colslot
   b += al((size_t)nn * nR * 8) + al((size_t)mw * 8) * 2;                                           // psum m1 m2
   b += al((size_t)nn * 8) * (size_t)ncols;
+  b += al(FS_BQ * 2) * 2 + al(FS_BQ * 8) * 2 + al(FS_BQ);                                          // bq_c bq_ord bq_k bq_h bq_z
+  b += al(FS_BQ * 2) * 4 + al((FS_BQ + 1) * 2) + al(FS_BQ) + al(FS_BQ * 8) * 2 + al(FS_BQ * 4) * 2;  // br_*
+  b += al(FS_BC * 4) * 2 + al(FS_BC);                                                              // cl_*
   return b + 256;
 }
 
@@ -576,15 +600,13 @@ KQ_DEV bool fs_setup(Search& s, Fs& f) {
   f.tpos = s.cand;
   f.W = s.W; f.usage = s.usage; f.removed = s.removed; f.trow = s.trow; f.treason = s.treason;
   f.col = (int64_t*)cv.take((size_t)f.nn * 8 * (size_t)(nc > 0 ? nc : 1));
-#if !defined(KQ_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
-  // every array sits in the workgroup's LDS (checked above): tell the compiler, so that the accesses are ds_* instead of flat_*
-  #define FS_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))
-  FS_LDS(f.psum); FS_LDS(f.dval); FS_LDS(f.ppos); FS_LDS(f.nflag); FS_LDS(f.m1); FS_LDS(f.m2); FS_LDS(f.mq); FS_LDS(f.colslot); FS_LDS(f.col);
-  FS_LDS(f.posoff); FS_LDS(f.kid); FS_LDS(f.koff); FS_LDS(f.knc); FS_LDS(f.knh); FS_LDS(f.c0); FS_LDS(f.c1); FS_LDS(f.par); FS_LDS(f.plv);
-  FS_LDS(f.rc_ptr); FS_LDS(f.rc_lq); FS_LDS(f.rc_sqb); FS_LDS(f.rc_lend); FS_LDS(f.rc_wt); FS_LDS(f.td); FS_LDS(f.tp); FS_LDS(f.tx); FS_LDS(f.tout);
-  FS_LDS(f.pc_ptr); FS_LDS(f.pc_lq); FS_LDS(f.pc_sq); FS_LDS(f.pc_sqb); FS_LDS(f.pc_bl); FS_LDS(f.pc_lend); FS_LDS(f.pc_wt); FS_LDS(f.pc_u);
-  #undef FS_LDS
-#endif
+  f.bq_c = (int16_t*)cv.take(FS_BQ * 2); f.bq_ord = (int16_t*)cv.take(FS_BQ * 2); f.bq_k = (uint64_t*)cv.take(FS_BQ * 8); f.bq_h = (uint64_t*)cv.take(FS_BQ * 8);
+  f.bq_z = (uint8_t*)cv.take(FS_BQ);
+  f.br_c = (int16_t*)cv.take(FS_BQ * 2); f.br_ap = (int16_t*)cv.take(FS_BQ * 2); f.br_at = (int16_t*)cv.take(FS_BQ * 2); f.br_n = (int16_t*)cv.take(FS_BQ * 2);
+  f.br_off = (int16_t*)cv.take((FS_BQ + 1) * 2); f.br_fl = (uint8_t*)cv.take(FS_BQ); f.br_pk = (uint64_t*)cv.take(FS_BQ * 8); f.br_tk = (uint64_t*)cv.take(FS_BQ * 8);
+  f.br_vc = (int32_t*)cv.take(FS_BQ * 4); f.br_qc = (int32_t*)cv.take(FS_BQ * 4);
+  f.cl_pos = (int32_t*)cv.take(FS_BC * 4); f.cl_cost = (int32_t*)cv.take(FS_BC * 4); f.cl_rk = (uint8_t*)cv.take(FS_BC);
+  fs_assume_lds(f);
   for (int i = lane; i < f.nfr; i += WAVE) f.colslot[i] = -1;
   wsync();
   #pragma unroll
@@ -645,6 +667,319 @@ KQ_DEV void fs_lcas(const Fs& f, int cand, int* ap, int* at) {
     prev = cur; cur = f.par[cur];
   }
   *ap = w.cs_pl[f.plen - 1]; *at = prev;
+}
+
+
+// ---- a cohort's ClusterQueues as a batch ------------------------------------------------------------------------------------------
+// Between two RemoveWorkload commits nothing the tournament reads changes: a candidate that fails the strategy goes to retryCandidates
+// and the state stays as it was (ComputeTargetShareAfterRemoval restores it, target.go:67-73). So after nextTarget has returned the
+// ClusterQueue `cand` of cohort X, the CALLS THAT FOLLOW are known in advance as long as candidates keep failing: X's non-pruned
+// ClusterQueues come back one after the other in descending share order (ordering.go:152-176: max DRS, zero-weight borrowers first,
+// ties by the queue heads' CandidatesOrdering), each has all its candidates popped, fails, and is pruned by the next call. Instead of
+// ~3000 dependent instructions per pop and ~1200 per call, the candidates of all those ClusterQueues are evaluated at once — one lane
+// each: the row's record, the quota constants of its cells, the removeUsage chain up to the target's almost-LCA, the share there — and
+// the first one that passes (in visiting order) is found with a ballot. Everything in front of it is moved to retryCandidates in bulk,
+// the ClusterQueues in front of its own are pruned, and the algorithmic bytes of the calls / visits / evaluations that did not
+// happen one by one are charged in closed form:
+//   call t (t = 2 ..) returns the ClusterQueue of rank t - 1; it reads every non-pruned child of the cohorts from the root down to X:
+//   above X those sets are what call 1 left (U_up), at X it is A' minus the ranks 0 .. t - 3 (rank t - 2 is exhausted but only this
+//   call notices and prunes it).
+// The batch ends in front of the preemptor's own ClusterQueue (an unconditional removal, preemption.go:399-410), in front of a
+// ClusterQueue whose share does not beat X's best child cohort (nextTarget descends there instead, ordering.go:219), and at FS_BC
+// candidates. Returns -1: not applicable, nothing was touched (the caller takes `cand` alone, the walk's way); 0: every candidate of
+// the batch failed; 1: *pos_out passed (it has been popped; the caller commits it).
+KQ_DEV uint64_t fs_range_bits(const uint64_t* m, int wi, int a, int b) {  // the bits of word wi of bitmap m inside [a, b)
+  if (a >= b) return 0;
+  const int wa = a >> 6, wb = (b - 1) >> 6;
+  if (wi < wa || wi > wb) return 0;
+  uint64_t x = m[wi];
+  if (wi == wa) x &= ~0ull << (a & 63);
+  if (wi == wb) { const int e = (b - 1) & 63; if (e < 63) x &= (2ull << e) - 1; }
+  return x;
+}
+KQ_DEV int fs_range_count(const uint64_t* m, int a, int b) {
+  int n = 0;
+  if (a >= b) return 0;
+  for (int wi = a >> 6; wi <= ((b - 1) >> 6); wi++) n += popc64(fs_range_bits(m, wi, a, b));
+  return n;
+}
+// the share of node `at` (on the row's path) after RemoveWorkload of the row at position p, nothing written: the one-lane form of
+// fs_row_apply(commit = false) + fs_nodes_update for that node. *flags = zero-weight-borrows | (borrowed cells > 0) << 1.
+KQ_DEV uint64_t fs_eval_removed(const Fs& f, int p, int at, int* flags) {
+  const DSnap& S = f.k->S;
+  const FsApply a = S.fs_apply[(size_t)f.row0 + p];
+  const int plen = a.plen;
+  int ia = 0;
+  #pragma unroll
+  for (int i = 0; i < FS_LV; i++) if (i < plen && (int)a.lp[i] == at) ia = i;
+  int64_t du[CS_RFR]; int dpu[CS_RFR];
+  #pragma unroll
+  for (int u = 0; u < CS_RFR; u++) {
+    du[u] = 0; dpu[u] = 0;
+    const int fr = a.fr[u];
+    if (fr < 0) continue;
+    int64_t val = a.qty[u];
+    bool go = true;
+    #pragma unroll
+    for (int i = 0; i < FS_LV; i++) {
+      if (!go || i >= plen || i > ia) continue;
+      const int li = a.lp[i];
+      const FsQ q = S.fs_q[(size_t)(f.n0 + li) * f.nfr + fr];
+      const int64_t lq = fs_cap(q.lq), sqb = fs_cap(q.sqb);
+      const int64_t uu = fs_ld(f, fs_cell(f, li, fr));
+      const int64_t stored = uu - lq, nv = uu - val;
+      if (i == ia) {
+        const int64_t ob = i64max(0, uu - sqb), nb = i64max(0, nv - sqb);
+        du[u] = nb - ob; dpu[u] = (nb > 0 ? 1 : 0) - (ob > 0 ? 1 : 0);
+      }
+      if (stored <= 0 || i + 1 >= plen) go = false; else val = i64min(val, stored);
+    }
+  }
+  double ratio = 0;
+  for (int rr = 0; rr < f.nR; rr++) {
+    int64_t d = 0;
+    #pragma unroll
+    for (int u = 0; u < CS_RFR; u++) if (a.fr[u] >= 0 && (int)a.res[u] == rr) d += du[u];
+    const int64_t sum = f.psum[(size_t)at * f.nR + rr] + d;
+    double x = 0;
+    if (sum > 0) { const int64_t lr = S.fs_lend[(size_t)(f.n0 + at) * f.nR + rr]; if (lr > 0) x = (double)sum * 1000.0 / (double)lr; }
+    if (x > ratio) ratio = x;
+  }
+  int np = f.ppos[at];
+  #pragma unroll
+  for (int u = 0; u < CS_RFR; u++) np += dpu[u];
+  const double weight = S.fs_weight[f.n0 + at];
+  const bool zwb = weight == 0 && ratio != 0;
+  double v = ratio;
+  if (!zwb) v = ratio == 0 ? 0.0 : (weight == 0 ? __builtin_inf() : ratio / weight);
+  *flags = (zwb ? 1 : 0) | (np > 0 ? 2 : 0);
+  return fs_okey(v);
+}
+// sum of fs_cost over the non-pruned children (ClusterQueues and cohorts) of tree-local cohort X: what one nextTarget level reads
+KQ_DEV int64_t fs_level_cost(const Fs& f, int X) {
+  const int xc = X - f.nqs;
+  const int k0 = f.koff[xc], nk = f.knc[xc] + f.knh[xc];
+  int64_t c = 0;
+  for (int j = lane_id(); j < nk; j += WAVE) { const int ch = f.kid[k0 + j]; if (!(f.nflag[ch] & 1)) c += fs_cost(f, ch); }
+  return wsum_i64(c);
+}
+// `second`: runSecondFsStrategy's form (preemption.go:501-534): no candidate simulation, one pop per ClusterQueue, DropQueue at once.
+KQ_NOINLINE int fs_batch(Fs& f, int cand, int strategy0, bool second, int* pos_out) {
+  const K& k = *f.k; Wave& w = *f.w; const DSnap& S = k.S;
+  const int lane = lane_id();
+  fs_assume_lds(f);
+  const int X = f.par[cand];
+  if (X < f.nqs) return -1;
+  const int xc = X - f.nqs;
+  const int k0 = f.koff[xc], nkc = f.knc[xc], nkh = f.knh[xc];
+  // ---- X's non-pruned ClusterQueues (all eligible: the call that returned `cand` has just pruned the others), child order ----
+  int nq = 0;
+  for (int base = 0; base < nkc; base += WAVE) {
+    const int j = base + lane;
+    const int c = j < nkc ? f.kid[k0 + j] : -1;
+    const bool in = c >= 0 && !(f.nflag[c] & 1);
+    const uint64_t m = wballot(in);
+    const int o = nq + popc64(m & ((1ull << lane) - 1));
+    if (in && o < FS_BQ) { f.bq_c[o] = (int16_t)c; f.bq_k[o] = fs_okey(f.dval[c]); f.bq_z[o] = (f.nflag[c] & 2) ? 1 : 0; }
+    nq += popc64(m);
+  }
+  if (nq > FS_BQ || nq < 1) return -1;
+  // X's best child cohort: a ClusterQueue is only returned while its share is strictly above it (ordering.go:219 `>= 0` descends)
+  int hz = 0; uint64_t hk2 = fs_okey(-1.0); bool has_co = false;
+  for (int base = 0; base < nkh; base += WAVE) {
+    const int j = base + lane;
+    const int ch = j < nkh ? f.kid[k0 + nkc + j] : -1;
+    const bool in = ch >= 0 && !(f.nflag[ch] & 1);
+    uint64_t m = wballot(in);
+    if (!m) continue;
+    const int z = in && (f.nflag[ch] & 2) ? 1 : 0;
+    const uint64_t mz = wballot(in && z);
+    if (mz) m = mz;
+    const bool cmpin = ((m >> lane) & 1) != 0;
+    const uint64_t mx = wmax_u64(cmpin ? fs_okey(f.dval[ch]) : 0);
+    const int zb = mz ? 1 : 0;
+    if (!has_co || fs_cmp(zb, mx, hz, hk2) >= 0) { hz = zb; hk2 = mx; }
+    has_co = true;
+  }
+  wsync_lds();
+  // ---- visiting order: zero-weight borrowers first, share descending, ties by the queue heads (ordering.go:158-166) ----
+  bool tie = false;
+  for (int i = lane; i < nq; i += WAVE)
+    for (int j = 0; j < nq; j++) if (j != i && f.bq_z[j] == f.bq_z[i] && f.bq_k[j] == f.bq_k[i]) tie = true;
+  if (wballot(tie)) {
+    for (int i = lane; i < nq; i += WAVE) f.bq_h[i] = fs_head_key(f, f.bq_c[i]);
+  } else {
+    for (int i = lane; i < nq; i += WAVE) f.bq_h[i] = 0;
+  }
+  wsync_lds();
+  for (int i = lane; i < nq; i += WAVE) {
+    const int zi = f.bq_z[i]; const uint64_t ki = f.bq_k[i], hi = f.bq_h[i];
+    int r = 0;
+    for (int j = 0; j < nq; j++) {
+      if (j == i) continue;
+      const int zj = f.bq_z[j]; const uint64_t kj = f.bq_k[j], hj = f.bq_h[j];
+      const bool before = zj != zi ? zj > zi : (kj != ki ? kj > ki : (hj != hi ? hj < hi : j < i));
+      if (before) r++;
+    }
+    f.bq_ord[r] = (int16_t)i;
+  }
+  wsync_lds();
+  if ((int)f.bq_c[f.bq_ord[0]] != cand) return -1;  // (cannot happen: rank 0 is what nextTarget has just returned)
+  // ---- per rank: the almost-LCAs and both shares (least_common_ancestor.go:27-58), fsStrategyUnsatisfiable, the candidates ----
+  const uint64_t* mq = second ? f.m2 : f.m1;
+  for (int r = lane; r < nq; r += WAVE) {
+    const int i = f.bq_ord[r], q = f.bq_c[i];
+    int ap = f.wli, at = q;
+    fs_lcas(f, q, &ap, &at);
+    const int pz = (f.nflag[ap] & 2) ? 1 : 0, tz = (f.nflag[at] & 2) ? 1 : 0;
+    const uint64_t pk = fs_okey(f.dval[ap]), tk = fs_okey(f.dval[at]);
+    const bool unsat = !second && fs_pos_inf(f, ap) && !fs_pos_inf(f, at);
+    // the batch stops in front of: the preemptor's own ClusterQueue (first strategy), a ClusterQueue that does not beat the best cohort
+    const bool stop = (!second && q == f.wli) || (has_co && fs_cmp(hz, hk2, f.bq_z[i], f.bq_k[i]) >= 0);
+    const bool passed2 = fs_cmp(pz, pk, tz, tk) < 0;  // second strategy: LessThanInitialShare on the shares as they are
+    f.br_c[r] = (int16_t)q; f.br_ap[r] = (int16_t)ap; f.br_at[r] = (int16_t)at;
+    f.br_pk[r] = pk; f.br_tk[r] = tk;
+    f.br_fl[r] = (uint8_t)((pz ? 1 : 0) | (tz ? 2 : 0) | (unsat ? 4 : 0) | (stop ? 8 : 0) | (passed2 ? 16 : 0));
+    f.br_vc[r] = (int32_t)(fs_cost(f, ap) + fs_cost(f, at));
+    f.br_qc[r] = (int32_t)fs_cost(f, q);
+    f.br_n[r] = (int16_t)fs_range_count(mq, f.posoff[q], f.posoff[q + 1]);
+  }
+  wsync_lds();
+  // how many ranks the batch takes (uniform, serial over <= 64 entries), and the offsets of their candidates
+  int kk = 0, T = 0;
+  for (int r = 0; r < nq; r++) {
+    if (f.br_fl[r] & 8) break;
+    const int n = second ? 0 : ((f.br_fl[r] & 4) ? 0 : (int)f.br_n[r]);
+    if (T + n > FS_BC) break;
+    if (lane == 0) f.br_off[r] = (int16_t)T;
+    T += n; kk++;
+  }
+  if (kk < 1) return -1;
+  if (lane == 0) f.br_off[kk] = (int16_t)T;
+  wsync_lds();
+  int pass_rank = -1, pass_idx = -1, pass_pos = -1;
+  int64_t eval_bytes = 0;
+  if (!second) {
+    // ---- candidate list in visiting order, then the evaluation, 64 (one in the emulation) at a time ----
+    bool miss = false;
+    for (int r = lane; r < kk; r += WAVE) {
+      if (f.br_fl[r] & 4) continue;
+      const int q = f.br_c[r], a0 = f.posoff[q], b0 = f.posoff[q + 1];
+      int o = f.br_off[r];
+      if (a0 < b0)
+        for (int wi = a0 >> 6; wi <= ((b0 - 1) >> 6); wi++) {
+          uint64_t x = fs_range_bits(f.m1, wi, a0, b0);
+          while (x) { const int b = ffs64(x); x &= x - 1; f.cl_pos[o] = wi * 64 + b; f.cl_rk[o] = (uint8_t)r; o++; }
+        }
+    }
+    wsync_lds();
+    for (int i = lane; i < T; i += WAVE) {
+      const FsApply a = S.fs_apply[(size_t)f.row0 + f.cl_pos[i]];
+      #pragma unroll
+      for (int e = 0; e < CS_RFR; e++) if (a.fr[e] >= 0 && f.colslot[a.fr[e]] < 0) miss = true;
+    }
+    if (wballot(miss)) fs_ensure_w(f);
+    for (int base = 0; base < T && pass_idx < 0; base += WAVE) {
+      const int i = base + lane;
+      bool pass = false;
+      int cost = 0;
+      if (i < T) {
+        const int r = f.cl_rk[i], at = f.br_at[r];
+        int fl = 0;
+        const uint64_t nk = fs_eval_removed(f, f.cl_pos[i], at, &fl);
+        cost = (int)f.c0[at] + ((fl & 2) ? (int)f.c1[at] : 0);
+        const int pz = f.br_fl[r] & 1, tz = (f.br_fl[r] >> 1) & 1;
+        pass = strategy0 == KQ_FS_LESS_THAN_OR_EQUAL_TO_FINAL_SHARE ? fs_cmp(pz, f.br_pk[r], fl & 1, nk) <= 0 : fs_cmp(pz, f.br_pk[r], tz, f.br_tk[r]) < 0;
+      }
+      const uint64_t pm = wballot(pass);
+      int upto = T - base < WAVE ? T - base : WAVE;   // evaluations of this chunk that the walk would have made
+      if (pm) { const int b = ffs64(pm); pass_idx = base + b; upto = b + 1; }
+      eval_bytes += wsum_i64(lane < upto ? (int64_t)cost : 0);
+    }
+    if (pass_idx >= 0) { pass_rank = f.cl_rk[pass_idx]; pass_pos = f.cl_pos[pass_idx]; }
+    CSTAT(13, pass_idx >= 0 ? pass_idx + 1 : T);
+  } else {
+    // second strategy: the first ClusterQueue in visiting order whose target share is above the preemptor's
+    for (int base = 0; base < kk && pass_rank < 0; base += WAVE) {
+      const int r = base + lane;
+      const uint64_t pm = wballot(r < kk && (f.br_fl[r] & 16));
+      if (pm) pass_rank = base + ffs64(pm);
+    }
+    if (pass_rank >= 0) pass_pos = fs_first(f.m2, f.posoff[f.br_c[pass_rank]], f.posoff[f.br_c[pass_rank] + 1]);
+    CSTAT(13, pass_rank >= 0 ? pass_rank + 1 : kk);
+  }
+  // ---- what the calls / visits that did not run one by one are charged ----
+  const int visited = pass_rank >= 0 ? pass_rank + 1 : kk;       // ClusterQueues nextTarget returned (the first by the real call)
+  const int R = visited - 1;                                     // virtual calls
+  int64_t bytes = eval_bytes;
+  {
+    int64_t vb = 0;
+    for (int r = lane; r < visited; r += WAVE) vb += f.br_vc[r];
+    bytes += wsum_i64(vb);
+  }
+  if (R > 0) {
+    int64_t up = 0;
+    for (int A = f.par[X]; A >= f.nqs; A = f.par[A]) up += fs_level_cost(f, A);
+    const int64_t Ap = fs_level_cost(f, X);
+    // first strategy: rank s is pruned by the call after the one that finds it exhausted; second: DropQueue prunes it at its own visit
+    int64_t sub = 0;
+    for (int s = lane; s < visited; s += WAVE) {
+      const int times = second ? (R - s) : (R - 1 - s);
+      if (times > 0) sub += (int64_t)f.br_qc[s] * times;
+    }
+    bytes += (int64_t)R * (up + Ap) - wsum_i64(sub);
+    CSTAT(11, R);
+  }
+  if (lane == 0) w.bytes += bytes;
+  CSTAT(27, 1); CSTAT(28, R); if (second) CSTAT(29, 1);
+  // ---- effects ----
+  if (!second) {
+    // candidates in front of the passing one (all of them if none passed) become retryCandidates
+    const int nmove = pass_idx >= 0 ? pass_idx : T;
+    for (int i = lane; i < nmove; i += WAVE) {
+      const int p = f.cl_pos[i];
+      atomic_and_u64(&f.m1[p >> 6], ~(1ull << (p & 63)));
+      atomic_or_u64(&f.m2[p >> 6], 1ull << (p & 63));
+    }
+    wsync_lds();
+    // fsStrategyUnsatisfiable :494-497: the whole queue goes over without a simulation
+    for (int r = 0; r < visited; r++) {
+      if (!(f.br_fl[r] & 4)) continue;
+      const int q = f.br_c[r], a0 = f.posoff[q], b0 = f.posoff[q + 1];
+      if (a0 < b0)
+        for (int wi = (a0 >> 6) + lane; wi <= ((b0 - 1) >> 6); wi += WAVE) {
+          const uint64_t mv = fs_range_bits(f.m1, wi, a0, b0);
+          CSTAT(13, popc64(mv));
+          atomic_or_u64(&f.m2[wi], mv); atomic_and_u64(&f.m1[wi], ~mv);
+        }
+      wsync_lds();
+    }
+    if (pass_idx >= 0 && lane == 0) f.m1[pass_pos >> 6] &= ~(1ull << (pass_pos & 63));  // PopWorkload of the one that passed
+    wsync_lds();
+    for (int r = lane; r < visited; r += WAVE) {
+      const int q = f.br_c[r];
+      if (r == pass_rank) {
+        const bool has = fs_first(f.m1, f.posoff[q], f.posoff[q + 1]) >= 0;
+        f.nflag[q] = (uint8_t)((f.nflag[q] & ~8) | (has ? 8 : 0));
+      } else {
+        // exhausted; the call that returned the next rank has pruned it — the last one of a batch without a pass is still unnoticed
+        const bool pruned = pass_rank >= 0 || r < visited - 1;
+        f.nflag[q] = (uint8_t)((f.nflag[q] & ~8) | (pruned ? 1 : 0));
+      }
+    }
+  } else {
+    // one pop per visited ClusterQueue (ordering.PopWorkload :84-90), then DropQueue :129-131
+    for (int r = lane; r < visited; r += WAVE) {
+      const int q = f.br_c[r];
+      const int p = fs_first(f.m2, f.posoff[q], f.posoff[q + 1]);
+      if (p >= 0) atomic_and_u64(&f.m2[p >> 6], ~(1ull << (p & 63)));
+      f.nflag[q] |= 1;
+    }
+  }
+  wsync_lds();
+  if (pass_rank < 0) return 0;
+  *pos_out = pass_pos;
+  return 1;
 }
 
 // fairPreemptions (preemption.go:536-597): same contract as fair_search. false: preconditions not met, nothing was done.
@@ -748,6 +1083,23 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
         if (fs_fits_fs(f)) fits = true;
         continue;
       }
+      if (k.C.fs_batch) {  // the ClusterQueues of cand's cohort as a batch: the first candidate that passes, found without walking to it
+        int bp = -1;
+        const int br = fs_batch(f, cand, strategy0, false, &bp);
+        KQ_LS(w, 1);
+        if (br == 0) continue;
+        if (br == 1) {
+          const FsRow r = fs_row_load(f, bp);
+          fs_row_ctx(f, r);
+          fs_row_apply(f, r, false, true, true);
+          KQ_LS(w, 4);
+          if (!fs_push_target(f, &nt, r.row, bp, KQ_REASON_IN_COHORT_FAIR_SHARING)) { w.ntgt = 0; return true; }
+          tbytes += r.rowbytes;
+          if (fs_fits_fs(f)) fits = true;
+          KQ_LS(w, 6);
+          continue;
+        }
+      }
       int ap = f.wli, at = cand;
       fs_lcas(f, cand, &ap, &at);
       const int pz = (f.nflag[ap] & 2) ? 1 : 0, tz = (f.nflag[at] & 2) ? 1 : 0;
@@ -806,6 +1158,20 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
     while (!fits) {
       const int cand = fs_ordering_next(f);
       if (cand < 0) break;
+      if (k.C.fs_batch) {
+        int bp = -1;
+        const int br = fs_batch(f, cand, strategy0, true, &bp);
+        if (br == 0) continue;
+        if (br == 1) {
+          const FsRow r = fs_row_load(f, bp);
+          fs_row_ctx(f, r);
+          fs_row_apply(f, r, false, true, true);
+          if (!fs_push_target(f, &nt, r.row, bp, KQ_REASON_IN_COHORT_FAIR_SHARING)) { w.ntgt = 0; return true; }
+          tbytes += r.rowbytes;
+          if (fs_fits_fs(f)) fits = true;
+          continue;
+        }
+      }
       int ap = f.wli, at = cand;
       fs_lcas(f, cand, &ap, &at);
       const bool passed = fs_cmp((f.nflag[ap] & 2) ? 1 : 0, fs_okey(f.dval[ap]), (f.nflag[at] & 2) ? 1 : 0, fs_okey(f.dval[at])) < 0;
