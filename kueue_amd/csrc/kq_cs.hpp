@@ -34,6 +34,7 @@ struct CsCtx {
   int64_t* dB[CS_NS];    // [Mp] per slot: what the candidate's removal takes out of the node one level up (level by level, in place)
   int64_t *sqT, *lqT;    // [ns][nn]  SubtreeQuota / localQuota of every node of the tree for the slots; null: read the planes
   uint16_t *tord, *tinv, *rb;  // [Mp] candidate at time t / time of candidate j (0xffff = never) / AdmRec::rowbytes
+  uint16_t* lst;               // [Mp] the level-order positions of the candidates inside a time prefix (cs_level_pass)
   uint8_t *alive, *cls, *att;  // [Mp] still removable / class byte (classical_search) / path level the candidate's branch hangs off
   uint8_t* cqi;          // [tree ClusterQueues] Search::cqinfo
   uint32_t needm, inum;
@@ -46,7 +47,7 @@ __host__ __device__ inline
 #endif
 size_t cs_bytes(int ns, int M, int nn, int nqs, bool tables) {  // everything a search with ns slots allocates
   const size_t Mp = ((size_t)M + 63) & ~(size_t)63;
-  return (size_t)ns * nn * 8 * (tables ? 3 : 1) + (size_t)ns * Mp * 8 + Mp * 2 * 3 + Mp * 3 + (((size_t)nqs + 15) & ~(size_t)15) + 512;
+  return (size_t)ns * nn * 8 * (tables ? 3 : 1) + (size_t)ns * Mp * 8 + Mp * 2 * 4 + Mp * 3 + (((size_t)nqs + 15) & ~(size_t)15) + 512;
 }
 // Arrays are placed in the workgroup's LDS region in order of heat while they fit, the rest in the wave slot's HBM spill space:
 // the byte arrays and the private usage first, then the quota tables, then the per-slot quantity arrays.
@@ -103,13 +104,32 @@ KQ_DEV void cs_level_pass(CsCtx& c, int dd, int limit_t, bool finalize) {
   int64_t carry[CS_NS];
   #pragma unroll
   for (int u = 0; u < CS_NS; u++) carry[u] = 0;
+  // A time prefix (limit_t in front of the last candidate: the lazy first rounds of cs_run, the finalising passes) only involves the
+  // candidates removed at or before limit_t: their level-order positions are gathered first — a light pass over the bucket (8 bytes per
+  // entry) — and the scan below runs over those alone. Segments (same node) stay contiguous and time-ordered in the gathered list.
+  const bool packed = limit_t + 1 < c.Mt;
+  int n = M;
+  if (packed) {
+    n = 0;
+    for (int base = 0; base < M; base += WAVE) {
+      const int q = base + lane;
+      bool act = false;
+      if (q < M) { const int jd = ents[q].jd, nd = ents[q].node; act = nd >= 0 && (int)c.tinv[jd & 0xffffff] <= limit_t; }
+      const uint64_t m = wballot(act);
+      if (act) c.lst[n + popc64(m & ((1ull << lane) - 1))] = (uint16_t)q;
+      n += popc64(m);
+    }
+    wsync();
+    if (n == 0) return;
+  }
+  auto pos_of = [&](int i) -> int { const int ii = i < n ? i : n - 1; return packed ? (int)c.lst[ii] : ii; };
   // the entries are static and read front to back: the next chunk's load is in flight while this one is processed
-  CsEnt e_next = ents[lane < M ? lane : M - 1];
-  for (int base = 0; base < M; base += WAVE) {
+  CsEnt e_next = ents[pos_of(lane)];
+  for (int base = 0; base < n; base += WAVE) {
     const int q = base + lane;
-    const bool in = q < M;
+    const bool in = q < n;
     const CsEnt e = e_next;
-    { const int qn = q + WAVE; e_next = ents[qn < M ? qn : M - 1]; }
+    e_next = ents[pos_of(q + WAVE)];
     const int node_prev = wshift_up_i32(e.node);
     const bool head = in && (lane == 0 ? e.node != carry_node : e.node != node_prev);
     const uint64_t H = wballot(head);
@@ -169,7 +189,7 @@ KQ_DEV void cs_level_pass(CsCtx& c, int dd, int limit_t, bool finalize) {
       const int nsh = wshift_down_i32(e.node);
       const int nfirst = wbcast_u(e_next.node, 0);  // first entry of the next chunk
       int nxt = -9;
-      if (q + 1 < M) nxt = lane == WAVE - 1 ? nfirst : nsh;
+      if (q + 1 < n) nxt = lane == WAVE - 1 ? nfirst : nsh;
       #pragma unroll
       for (int u = 0; u < CS_NS; u++) if (u < ns && part && nxt != e.node) c.W[(size_t)u * c.nn + e.node] = ua[u];
     }
@@ -209,6 +229,7 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
     CsCarve cv{w.cs_lds, w.cs_lds ? w.cs_lds + w.cs_lds_bytes : nullptr, k.X.cs + (size_t)s.slot * k.X.cs_bytes};
     c.alive = (uint8_t*)cv.take(c.Mp); c.cls = (uint8_t*)cv.take(c.Mp); c.att = (uint8_t*)cv.take(c.Mp);
     c.tord = (uint16_t*)cv.take((size_t)c.Mp * 2); c.tinv = (uint16_t*)cv.take((size_t)c.Mp * 2); c.rb = (uint16_t*)cv.take((size_t)c.Mp * 2);
+    c.lst = (uint16_t*)cv.take((size_t)c.Mp * 2);
     c.cqi = (uint8_t*)cv.take(nqs);
     c.W = (int64_t*)cv.take((size_t)ns * nn * 8);
     // the quota tables only pay off next to the arithmetic: in LDS or not at all (the planes are L2-resident anyway)
@@ -325,12 +346,20 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
   for (int at = 0; at < nattempt; at++) {
     const bool borrowing = attempts[at];
     CSTAT(3, 1);
-    for (int base = 0; base < M; base += WAVE) {
-      const int j = base + lane;
-      if (j < M) { const uint8_t cb = c.cls[j]; c.alive[j] = (cb != 0 && !(borrowing && (cb >> 3) == V_RECLAIM_NO_BORROW)) ? 1 : 0; }
+    // The walk stops at the first candidate whose removal makes the preemptor fit, and nothing behind that candidate has any influence
+    // on what happens in front of it: the death points and the first fit are computed for a PREFIX of the time order (128 candidates,
+    // then 4 x as many, ...) and the search stops at the first prefix that holds the stopping point. An overlap recomputation in
+    // processEntry typically needs a handful of victims out of thousands of candidates (profiles/r04a_cfg4c_jacobi_probe.txt).
+    int tstar = -1, nt = 0; int64_t rb_removed = 0;
+    int cN = 0; int64_t cRB = 0;
+    for (int T = k.C.cs_lazy ? (Mt < 128 ? Mt : 128) : Mt;; T = (T * 4 < Mt ? T * 4 : Mt)) {
+    CSTAT(30, 1); if (T < Mt) CSTAT(31, 1);
+    for (int base = 0; base < T; base += WAVE) {
+      const int t = base + lane;
+      if (t < T) { const int j = c.tord[t]; const uint8_t cb = c.cls[j]; c.alive[j] = (cb != 0 && !(borrowing && (cb >> 3) == V_RECLAIM_NO_BORROW)) ? 1 : 0; }
     }
     wsync();
-    for (int dd = c.levels; dd >= 1; dd--) cs_level_pass(c, dd, 0xffff, false);
+    for (int dd = c.levels; dd >= 1; dd--) cs_level_pass(c, dd, T - 1, false);
     if (c.levels == 0) {  // ClusterQueues without a cohort: only same-queue candidates, straight onto the path
       for (int base = 0; base < M; base += WAVE) {
         const int j = base + lane;
@@ -349,11 +378,11 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
       #pragma unroll
       for (int l = 0; l <= CS_LEVELS; l++) cA[u][l] = 0;
     }
-    int cN = 0; int64_t cRB = 0;
-    int tstar = -1, nt = 0; int64_t rb_removed = 0;
-    for (int base = 0; base < Mt && tstar < 0; base += WAVE) {
+    cN = 0; cRB = 0;
+    tstar = -1; nt = 0; rb_removed = 0;
+    for (int base = 0; base < T && tstar < 0; base += WAVE) {
       const int t = base + lane;
-      const bool in = t < Mt;
+      const bool in = t < T;
       const int j = in ? c.tord[t] : 0;
       const bool al = in && c.alive[j] != 0;
       const int L = c.att[j];
@@ -400,6 +429,8 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
       }
     }
     wsync();
+    if (tstar >= 0 || T >= Mt) break;
+    }  // next, longer prefix
     CSTAT(5, tstar >= 0 ? nt : cN);
     if (tstar < 0) {  // every candidate removed, never fit: restoreSnapshot adds them all back (preemption.go:333)
       if (lane == 0) w.bytes += 2 * cRB + (int64_t)cN * fits_bytes;

@@ -266,6 +266,7 @@ struct DCfg {
   int quota_check_strategy;
   int cs_on;                 // classical victim searches may take the scan formulation (kq_cs.hpp)
   int fs_on;                 // fair-sharing victim searches may take the LDS-resident formulation (kq_fs.hpp)
+  int cs_lazy;               // the scan search works on growing prefixes of the candidate time order (kq_cs.hpp; KQ_CS_LAZY=0 turns it off)
   int fs_batch;              // ... and evaluate the candidates of a cohort's ClusterQueues as a batch (fs_batch; KQ_FS_BATCH=0 turns it off)
   int dbg_variant;           // KQ_PROF builds only: timing experiments (KQ_DEBUG_VARIANT; results are wrong when non-zero)
   int any_preempt;           // some ClusterQueue of the snapshot may preempt (Prep::any_preemption)
@@ -3007,12 +3008,18 @@ KQ_NOINLINE void process_entry(const K& k, Wave& w, int e, int pos, int slot, in
   // up changing nothing
   if (w.rep_mode != M_NOFIT) cert_unverifiable(k, tree);
   const int32_t* trows = O.pool_row + O.tgt_pos[e];
-  auto has_any = [&]() { bool a = false; for (int t = 0; t < nt; t++) if (k.preempted[trows[t]]) a = true; return a; };
-  // updateAssignmentIfNeeded :707-769
-  bool fits_ok = entry_fits(k, w, trows, nt, quota_usage, tree);
+  // (lanes over the targets: the serial form was one dependent global load per target on every lane)
+  auto has_any = [&]() { bool a = false; for (int t = lane; t < nt; t += WAVE) if (k.preempted[trows[t]]) a = true; return wballot(a) != 0; };
+  // updateAssignmentIfNeeded :707-769. The reference evaluates fits() first and throws the result away when the targets overlap (the
+  // recomputation ends with its own fits(), :747): with up to several hundred nominated targets per entry that discarded evaluation was
+  // 95 of the 620 ms of k_process at cfg 4c (profiles/r04a_prof_cfg4c.txt) — only its algorithmic bytes are charged then.
+  const bool recompute = has_any() && gate(k, KQ_GATE_RECOMPUTE_ON_OVERLAP);
+  bool fits_ok = true;
+  if (!recompute) fits_ok = entry_fits(k, w, trows, nt, quota_usage, tree);
+  else if (quota_usage && w.nuse > 0 && lane == 0) w.bytes += (int64_t)w.nuse * 40 * w.plen;
   KQ_TS(k, 34);  // generic path: first fits
   int mode = w.rep_mode;
-  if (has_any() && gate(k, KQ_GATE_RECOMPUTE_ON_OVERLAP)) {
+  if (recompute) {
     // SimulateWorkloadRemoval(victimsOfOtherPreemptions) == evaluate on usage_np with those rows deleted.
     // The generic nominate code reads HBM planes: publish the LDS-resident cohort rows first.
     KQ_TS(k, 4);  // (KQ_PROF) everything of this entry before the recomputation

@@ -982,6 +982,91 @@ KQ_NOINLINE int fs_batch(Fs& f, int cand, int strategy0, bool second, int* pos_o
   return 1;
 }
 
+
+// fillBackWorkloads (preemption.go:341-354, allowBorrowing = true) without walking it: the reference adds the targets back newest-first,
+// keeps one out of the set when the preemptor still fits, removes it again otherwise. A probe that fails leaves the state as it was (on
+// plain amounts removeUsage undoes addUsage level by level), and usage only grows with every probe that is kept back — so the probes of
+// 64 targets are EVALUATED at once against the state as it is (one lane each: the addUsage chain of the row, Available on the
+// preemptor's path with the cells the chain reaches replaced), the lanes in front of the first one that fits have failed for good, that
+// one is committed (swap-delete, as the reference), and only the lanes behind it are evaluated again. Returns the new target count.
+KQ_DEV bool fs_probe_fits(const Fs& f, int p) {  // would the preemptor still fit with the row at position p added back? (one lane)
+  const DSnap& S = f.k->S; const Wave& w = *f.w;
+  const FsApply a = S.fs_apply[(size_t)f.row0 + p];
+  const int rplen = a.plen;
+  bool bad = false;
+  for (int j = 0; j < f.npc; j++) {
+    const int frj = w.s_fr[f.pc_u[j]];
+    int64_t add[FS_LV];
+    #pragma unroll
+    for (int i = 0; i < FS_LV; i++) add[i] = 0;
+    #pragma unroll
+    for (int e = 0; e < CS_RFR; e++) {
+      if ((int)a.fr[e] != frj) continue;
+      int64_t val = a.qty[e];
+      bool go = true;
+      #pragma unroll
+      for (int h = 0; h < FS_LV; h++) {  // addUsage resource_node.go:144-152
+        if (!go || h >= rplen) continue;
+        const int li = a.lp[h];
+        const int64_t uu = fs_ld(f, fs_cell(f, li, frj));
+        const int64_t lq = fs_cap(S.fs_q[(size_t)(f.n0 + li) * f.nfr + frj].lq);
+        const int pl = f.plv[li];
+        #pragma unroll
+        for (int i = 0; i < FS_LV; i++) if (i == pl) add[i] = val;
+        const int64_t la = i64max(0, lq - uu);
+        if (h + 1 < rplen && val > la) val = val - la; else go = false;
+      }
+    }
+    int64_t v[FS_LV];
+    #pragma unroll
+    for (int i = 0; i < FS_LV; i++) { v[i] = 0; if (i < f.plen) v[i] = fs_ld(f, f.pc_ptr[j * FS_LV + i]) + add[i]; }
+    if (w.s_qty[f.pc_u[j]] > i64max(0, fs_avail(v, f.pc_lq + j * FS_LV, f.pc_sq + j * FS_LV, f.pc_bl + j * FS_LV, f.plen))) bad = true;
+  }
+  return !bad;
+}
+KQ_NOINLINE int fs_fillback_batch(Fs& f, int nt, int64_t* tbytes) {
+  Wave& w = *f.w; const DSnap& S = f.k->S;
+  const int lane = lane_id();
+  fs_assume_lds(f);
+  const int64_t fits_bytes = 40 * (int64_t)f.plen * f.npc;
+  int64_t bytes = 0;
+  for (int hi = nt - 2; hi >= 0; hi -= WAVE) {
+    const int t = hi - lane;
+    const bool in = t >= 0;
+    const int p = in ? f.tpos[t] : f.tpos[0];
+    const FsApply a = S.fs_apply[(size_t)f.row0 + p];
+    const int64_t rowbytes = 16 * (int64_t)a.plen * (((int)a.cbytes - 32) / 12);
+    bool miss = false;
+    #pragma unroll
+    for (int e = 0; e < CS_RFR; e++) if (in && a.fr[e] >= 0 && f.colslot[a.fr[e]] < 0) miss = true;
+    if (wballot(miss)) fs_ensure_w(f);
+    uint64_t pending = wballot(in);
+    bool kept_out = false;   // this lane's target left the set (the preemptor fits without preempting it)
+    while (pending) {
+      const bool mine = in && ((pending >> lane) & 1);
+      const uint64_t fm = wballot(mine && fs_probe_fits(f, p)) & pending;
+      if (!fm) break;
+      const int b = ffs64(fm);             // lane 0 holds the newest target: the first probe that fits is the one the walk keeps back next
+      const int tb = hi - b;
+      {  // commit: AddWorkload of that row, then the reference's swap-delete (targets[i] = targets[last]; targets = targets[:last])
+        const FsRow r = fs_row_load(f, f.tpos[tb]);
+        fs_row_ctx(f, r);
+        fs_row_apply(f, r, true, true, false);
+        if (lane == 0) { f.trow[tb] = f.trow[nt - 1]; f.treason[tb] = f.treason[nt - 1]; f.tpos[tb] = f.tpos[nt - 1]; }
+        nt--;
+        wsync();
+      }
+      if (lane == b) kept_out = true;
+      pending &= b == 63 ? 0ull : ~((2ull << b) - 1);
+    }
+    // every target of the chunk was probed once: AddWorkload + the fit test, and RemoveWorkload again for the ones that stay targets
+    bytes += wsum_i64(in ? rowbytes + fits_bytes + (kept_out ? 0 : rowbytes) : 0);
+    *tbytes -= wsum_i64(in && kept_out ? rowbytes : 0);
+  }
+  if (lane == 0) w.bytes += bytes;
+  return nt;
+}
+
 // fairPreemptions (preemption.go:536-597): same contract as fair_search. false: preconditions not met, nothing was done.
 KQ_NOINLINE bool fair_search_lds(Search& s) {
   const K& k = *s.k; Wave& w = *s.w; const DSnap& S = k.S;
@@ -1017,30 +1102,58 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
   {
     int64_t cbytes = 0;
     const int policy_same = KQ_POL_WITHIN_CQ(w.pol), policy_other = KQ_POL_RECLAIM(w.pol);
-    for (int base = 0; base < f.nrows; base += 64) {
-      uint64_t word = 0;
-      for (int sub = 0; sub < 64; sub += WAVE) {  // one ballot per 64 positions (the emulation has one lane)
-        const int p = base + sub + lane;
-        bool bit = false;
-        if (p < f.nrows) {
-          const FsScan sc = fs_scan_load(S.fs_scan + (size_t)f.row0 + p);
-          if ((f.nflag[sc.cql] & 4) && !(f.removed && f.removed[sc.row])) {
-            cbytes += sc.cbytes;
-            const int policy = sc.cql == f.wli ? policy_same : policy_other;
-            const bool lower = w.prio > sc.prio;
-            bool ok = policy == KQ_POLICY_ANY;
-            if (policy == KQ_POLICY_LOWER_PRIORITY) ok = lower;
-            if (policy == KQ_POLICY_LOWER_OR_NEWER_EQUAL) ok = lower || (w.prio == sc.prio && w.ts < sc.qts);
-            bool uses = false;
-            #pragma unroll
-            for (int e = 0; e < CS_RFR; e++)
-              for (int u = 0; u < w.ns; u++) if (sc.fr[e] >= 0 && w.s_need[u] && w.s_fr[u] == sc.fr[e]) uses = true;
-            bit = ok && uses;
-          }
+    // a record's verdict once it is known whether its row still exists (findCandidatesForPolicy :599-627)
+    auto cand_bit = [&](const FsScan& sc, bool live) -> bool {
+      if (!live) return false;
+      cbytes += sc.cbytes;
+      const int policy = sc.cql == f.wli ? policy_same : policy_other;
+      const bool lower = w.prio > sc.prio;
+      bool ok = policy == KQ_POLICY_ANY;
+      if (policy == KQ_POLICY_LOWER_PRIORITY) ok = lower;
+      if (policy == KQ_POLICY_LOWER_OR_NEWER_EQUAL) ok = lower || (w.prio == sc.prio && w.ts < sc.qts);
+      bool uses = false;
+      #pragma unroll
+      for (int e = 0; e < CS_RFR; e++)
+        for (int u = 0; u < w.ns; u++) if (sc.fr[e] >= 0 && w.s_need[u] && w.s_fr[u] == sc.fr[e]) uses = true;
+      return ok && uses;
+    };
+    if constexpr (WAVE == 64) {
+      // four words per step: the four records of a lane are in flight together, then the four `removed` bytes that depend on them —
+      // two round trips per 256 positions instead of two per 64 (the scan was 5 % of a search, one dependent load after the other)
+      constexpr int UN = 4;
+      for (int base = 0; base < f.nrows; base += 64 * UN) {
+        FsScan sc[UN]; bool in[UN], live[UN];
+        #pragma unroll
+        for (int q = 0; q < UN; q++) {
+          const int p = base + q * 64 + lane;
+          in[q] = p < f.nrows;
+          sc[q] = fs_scan_load(S.fs_scan + (size_t)f.row0 + (in[q] ? p : f.nrows - 1));
         }
-        word |= wballot(bit) << sub;
+        #pragma unroll
+        for (int q = 0; q < UN; q++) {
+          live[q] = in[q] && (f.nflag[sc[q].cql] & 4);
+          if (live[q] && f.removed && f.removed[sc[q].row]) live[q] = false;
+        }
+        #pragma unroll
+        for (int q = 0; q < UN; q++) {
+          const uint64_t word = wballot(cand_bit(sc[q], live[q]));
+          if (lane == 0 && base + q * 64 < f.nrows) f.m1[(base >> 6) + q] = word;
+        }
       }
-      if (lane == 0) f.m1[base >> 6] = word;
+    } else {
+      for (int base = 0; base < f.nrows; base += 64) {
+        uint64_t word = 0;
+        for (int sub = 0; sub < 64; sub += WAVE) {  // one ballot per 64 positions (the emulation has one lane)
+          const int p = base + sub + lane;
+          bool bit = false;
+          if (p < f.nrows) {
+            const FsScan sc = fs_scan_load(S.fs_scan + (size_t)f.row0 + p);
+            bit = cand_bit(sc, (f.nflag[sc.cql] & 4) && !(f.removed && f.removed[sc.row]));
+          }
+          word |= wballot(bit) << sub;
+        }
+        if (lane == 0) f.m1[base >> 6] = word;
+      }
     }
     const int64_t tot = wsum_i64(cbytes);
     if (lane == 0) w.bytes += tot;
@@ -1191,15 +1304,20 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
   }
   fs_pc_apply(f, false);  // revertSimulation
   KQ_TS(k, 44);
+  bool as_started = false;
   if (!fits) {
     if (lane == 0) w.bytes += tbytes;
-    // restoreSnapshot :356 — the private copy is dropped, but callers read it: put the rows back
-    for (int t = 0; t < nt; t++) { const FsRow r = fs_row_load(f, f.tpos[t]); fs_row_ctx(f, r); fs_row_apply(f, r, true, true, false); }
+    // restoreSnapshot :356 — the private copy is dropped, but callers read it on the preemptor's path. With every row back the state is
+    // the one the search started from (plain amounts: usage is a function of the SET of rows present), so nothing is walked back.
+    if (k.C.fs_batch) as_started = true;
+    else for (int t = 0; t < nt; t++) { const FsRow r = fs_row_load(f, f.tpos[t]); fs_row_ctx(f, r); fs_row_apply(f, r, true, true, false); }
     w.ntgt = 0;
     KQ_TS(k, 45);
   } else {
     CSTAT(16, 1); CSTAT(17, nt);
     // fillBackWorkloads :341-354 with allowBorrowing = true
+    if (k.C.fs_batch) nt = fs_fillback_batch(f, nt, &tbytes);
+    else
     for (int t = nt - 2; t >= 0; t--) {
       const FsRow r = fs_row_load(f, f.tpos[t]);
       fs_row_ctx(f, r);
@@ -1222,7 +1340,8 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
   for (int c = lane; c < f.npc * FS_LV; c += WAVE) {
     const int j = c / FS_LV, i = c % FS_LV;
     if (i >= f.plen) continue;
-    f.W[(size_t)w.cs_pl[i] * f.nfr + w.s_fr[f.pc_u[j]]] = fs_ld(f, f.pc_ptr[c]);
+    const int fr = w.s_fr[f.pc_u[j]];
+    f.W[(size_t)w.cs_pl[i] * f.nfr + fr] = as_started ? f.usage[ix(S, w.path[i], fr)] : fs_ld(f, f.pc_ptr[c]);
   }
   wsync();
   return true;

@@ -45,6 +45,7 @@ template <class B> struct EngineT {
   bool force_exact_drs = false;  // tests: take the saturation-safe DRS loops even when the sums would be exact
   bool cs_disable = false;       // tests: classical victim searches always take the candidate-by-candidate walk
   bool fs_disable = false;       // tests: fair-sharing victim searches always take the walk
+  bool cs_lazy_on = [] { const char* e = getenv("KQ_CS_LAZY"); return !(e && e[0] == '0'); }();    // A/B switch of the prefix rounds of the scan search (kq_cs.hpp)
   bool fs_batch_on = [] { const char* e = getenv("KQ_FS_BATCH"); return !(e && e[0] == '0'); }();   // A/B switch of the batched candidate evaluation (kq_fs.hpp fs_batch)
   bool help_disable = false;     // tests: no helper workgroups
   Buf b_cs;
@@ -1191,6 +1192,7 @@ template <class B> struct EngineT {
     k.C.cs_on = (!cfg.fair_sharing && prep.any_preemption && prep.fs_plain && !cs_disable) ? 1 : 0;
     k.C.fs_on = (cfg.fair_sharing && prep.any_preemption && prep.fs_plain && !fs_disable) ? 1 : 0;
     k.C.fs_batch = fs_batch_on ? 1 : 0;
+    k.C.cs_lazy = cs_lazy_on ? 1 : 0;
     k.C.any_preempt = prep.any_preemption ? 1 : 0;
     k.C.gates = cfg.gates; k.C.fair_sharing = cfg.fair_sharing; k.C.quota_check_strategy = cfg.quota_check_strategy; k.C.cycle = hbch.cycle;
     k.H = hbch.H;
