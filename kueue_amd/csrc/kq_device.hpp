@@ -267,6 +267,7 @@ struct DCfg {
   int cs_on;                 // classical victim searches may take the scan formulation (kq_cs.hpp)
   int fs_on;                 // fair-sharing victim searches may take the LDS-resident formulation (kq_fs.hpp)
   int cs_lazy;               // the scan search works on growing prefixes of the candidate time order (kq_cs.hpp; KQ_CS_LAZY=0 turns it off)
+  int fs_lrun;               // the fair iterator's leader pops on its own while entries change no usage (KQ_FS_LRUN=0 turns it off)
   int fs_batch;              // ... and evaluate the candidates of a cohort's ClusterQueues as a batch (fs_batch; KQ_FS_BATCH=0 turns it off)
   int dbg_variant;           // KQ_PROF builds only: timing experiments (KQ_DEBUG_VARIANT; results are wrong when non-zero)
   int any_preempt;           // some ClusterQueue of the snapshot may preempt (Prep::any_preemption)
@@ -419,6 +420,7 @@ struct K {  // everything a kernel needs
                              // negative): the sum-based DRS shortcuts (C.fs_plain) are off from then on
   int32_t* defer_list;       // [H] heads the lean nominate pass handed to the full pass
   int32_t* defer_count;      // [1]
+  int32_t* nom_ticket;       // [1] next position of defer_list to hand out (k_nominate pulls heads: their costs differ by orders of magnitude)
   // speculative process kernel (kq_spec.hpp)
   int32_t* cq_heads;         // [nq] heads of the batch per ClusterQueue (k_records counts them; > 1: the entries take the serial kernel)
   int32_t* spec_resume;      // [n_tree] iterator position from which the serial kernel (process_tree) takes the tree over; >= H.n: nothing left
@@ -4132,7 +4134,10 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
     bsync();
     if (leader) KQ_TS(k, 17);
     // ---- leader: tournament, pop, processEntry ----
-    if (leader) {
+    // An entry that changes no usage (skipped, NoFit, no longer fits: nine out of ten pops at cfg 3f) leaves every DRS value as it is:
+    // the next pop needs no computeDRS pass and no barrier pair, only the tournaments on the popped entry's path — the leader keeps
+    // popping on its own until an entry does change usage (the other waves wait at the barrier below meanwhile).
+    if (leader) for (bool lrun = true; lrun;) {
       if (first) {
         for (int d = KQ_MAXD - 1; d >= 0; d--)
           for (int i = nqs; i < nn; i++) {
@@ -4207,6 +4212,8 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
       lpos++;
       if (lane == 0) { ctl[0] -= 1; ctl[1] = ec; ctl[2] = w.usage_dirty; }
       wsync();
+      first = false;
+      lrun = k.C.fs_lrun && ctl[0] > 0 && !w.usage_dirty;
     }
     bsync();
     if (ctl[0] == 0) break;

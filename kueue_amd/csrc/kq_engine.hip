@@ -46,7 +46,17 @@ __global__ __launch_bounds__(64) void k_nominate(const K* __restrict__ kp, int s
   __syncthreads();
   const int slot = blockIdx.x;
   const int nd = *k.defer_count;
-  for (int i = slot; i < nd; i += slots) nominate_head(k, w, k.defer_list[i], slot);
+  (void)slots;
+  // heads are pulled, not dealt: a head with victim searches costs 10^3 x one without, and the searches of two heads differ by 10 x
+  __shared__ int next;
+  for (;;) {
+    if (threadIdx.x == 0) next = atomicAdd(k.nom_ticket, 1);
+    __syncthreads();
+    const int i = next;
+    __syncthreads();
+    if (i >= nd) break;
+    nominate_head(k, w, k.defer_list[i], slot);
+  }
 }
 
 // Entry order (scheduler.go:1110-1163): rank(i) = number of entries that precede i. 2-D grid: block (bi, bj)

@@ -30,7 +30,7 @@ constexpr int FS_PCN = 64;      // (in-use slot, level) cells of the preemptor's
 constexpr int FS_NCMAX = 16;    // usage columns cached per search
 constexpr int FS_RC = CS_RFR * FS_LV;
 constexpr int FS_BQ = 64;       // ClusterQueues of one cohort handled as a batch (fs_batch_first / fs_batch_second)
-constexpr int FS_BC = 256;      // candidates evaluated per batch
+constexpr int FS_BC = 128;      // candidates evaluated per batch
 
 struct Fs {
   const K* k; Wave* w; Search* s;
@@ -47,8 +47,8 @@ struct Fs {
   int32_t* tpos;
   // batch of one cohort's ClusterQueues (fs_batch_*): unsorted (child order) and sorted (visiting order) views, candidate list
   int16_t *bq_c, *bq_ord; uint64_t *bq_k, *bq_h; uint8_t* bq_z;
-  int16_t *br_c, *br_ap, *br_at, *br_n, *br_off; uint8_t* br_fl; uint64_t *br_pk, *br_tk; int32_t *br_vc, *br_qc;
-  int32_t *cl_pos, *cl_cost; uint8_t* cl_rk;
+  int16_t *br_c, *br_ap, *br_at, *br_n, *br_off; uint8_t* br_fl;
+  int32_t* cl_pos; uint8_t* cl_rk;
   // fields of the Search (it lives in the caller's frame)
   int64_t* W; const int64_t* usage; const uint8_t* removed; int32_t* trow; uint8_t* treason;
 };
@@ -64,7 +64,7 @@ KQ_DEV void fs_assume_lds(const Fs& f) {
   FS_LDS(f.rc_ptr); FS_LDS(f.rc_lq); FS_LDS(f.rc_sqb); FS_LDS(f.rc_lend); FS_LDS(f.rc_wt); FS_LDS(f.td); FS_LDS(f.tp); FS_LDS(f.tx); FS_LDS(f.tout);
   FS_LDS(f.pc_ptr); FS_LDS(f.pc_lq); FS_LDS(f.pc_sq); FS_LDS(f.pc_sqb); FS_LDS(f.pc_bl); FS_LDS(f.pc_lend); FS_LDS(f.pc_wt); FS_LDS(f.pc_u);
   FS_LDS(f.bq_c); FS_LDS(f.bq_ord); FS_LDS(f.bq_k); FS_LDS(f.bq_h); FS_LDS(f.bq_z); FS_LDS(f.br_c); FS_LDS(f.br_ap); FS_LDS(f.br_at); FS_LDS(f.br_n); FS_LDS(f.br_off);
-  FS_LDS(f.br_fl); FS_LDS(f.br_pk); FS_LDS(f.br_tk); FS_LDS(f.br_vc); FS_LDS(f.br_qc); FS_LDS(f.cl_pos); FS_LDS(f.cl_cost); FS_LDS(f.cl_rk);
+  FS_LDS(f.br_fl); FS_LDS(f.cl_pos); FS_LDS(f.cl_rk);
   #undef FS_LDS
 #endif
   (void)f;
@@ -87,8 +87,8 @@ size_t fs_bytes(int nn, int nqs, int nR, int nfr, int mw, int ncols) {
   b += al((size_t)nn * nR * 8) + al((size_t)mw * 8) * 2;                                           // psum m1 m2
   b += al((size_t)nn * 8) * (size_t)ncols;
   b += al(FS_BQ * 2) * 2 + al(FS_BQ * 8) * 2 + al(FS_BQ);                                          // bq_c bq_ord bq_k bq_h bq_z
-  b += al(FS_BQ * 2) * 4 + al((FS_BQ + 1) * 2) + al(FS_BQ) + al(FS_BQ * 8) * 2 + al(FS_BQ * 4) * 2;  // br_*
-  b += al(FS_BC * 4) * 2 + al(FS_BC);                                                              // cl_*
+  b += al(FS_BQ * 2) * 4 + al((FS_BQ + 1) * 2) + al(FS_BQ);                                        // br_*
+  b += al(FS_BC * 4) + al(FS_BC);                                                                  // cl_*
   return b + 256;
 }
 
@@ -603,9 +603,8 @@ KQ_DEV bool fs_setup(Search& s, Fs& f) {
   f.bq_c = (int16_t*)cv.take(FS_BQ * 2); f.bq_ord = (int16_t*)cv.take(FS_BQ * 2); f.bq_k = (uint64_t*)cv.take(FS_BQ * 8); f.bq_h = (uint64_t*)cv.take(FS_BQ * 8);
   f.bq_z = (uint8_t*)cv.take(FS_BQ);
   f.br_c = (int16_t*)cv.take(FS_BQ * 2); f.br_ap = (int16_t*)cv.take(FS_BQ * 2); f.br_at = (int16_t*)cv.take(FS_BQ * 2); f.br_n = (int16_t*)cv.take(FS_BQ * 2);
-  f.br_off = (int16_t*)cv.take((FS_BQ + 1) * 2); f.br_fl = (uint8_t*)cv.take(FS_BQ); f.br_pk = (uint64_t*)cv.take(FS_BQ * 8); f.br_tk = (uint64_t*)cv.take(FS_BQ * 8);
-  f.br_vc = (int32_t*)cv.take(FS_BQ * 4); f.br_qc = (int32_t*)cv.take(FS_BQ * 4);
-  f.cl_pos = (int32_t*)cv.take(FS_BC * 4); f.cl_cost = (int32_t*)cv.take(FS_BC * 4); f.cl_rk = (uint8_t*)cv.take(FS_BC);
+  f.br_off = (int16_t*)cv.take((FS_BQ + 1) * 2); f.br_fl = (uint8_t*)cv.take(FS_BQ);
+  f.cl_pos = (int32_t*)cv.take(FS_BC * 4); f.cl_rk = (uint8_t*)cv.take(FS_BC);
   fs_assume_lds(f);
   for (int i = lane; i < f.nfr; i += WAVE) f.colslot[i] = -1;
   wsync();
@@ -838,10 +837,7 @@ KQ_NOINLINE int fs_batch(Fs& f, int cand, int strategy0, bool second, int* pos_o
     const bool stop = (!second && q == f.wli) || (has_co && fs_cmp(hz, hk2, f.bq_z[i], f.bq_k[i]) >= 0);
     const bool passed2 = fs_cmp(pz, pk, tz, tk) < 0;  // second strategy: LessThanInitialShare on the shares as they are
     f.br_c[r] = (int16_t)q; f.br_ap[r] = (int16_t)ap; f.br_at[r] = (int16_t)at;
-    f.br_pk[r] = pk; f.br_tk[r] = tk;
     f.br_fl[r] = (uint8_t)((pz ? 1 : 0) | (tz ? 2 : 0) | (unsat ? 4 : 0) | (stop ? 8 : 0) | (passed2 ? 16 : 0));
-    f.br_vc[r] = (int32_t)(fs_cost(f, ap) + fs_cost(f, at));
-    f.br_qc[r] = (int32_t)fs_cost(f, q);
     f.br_n[r] = (int16_t)fs_range_count(mq, f.posoff[q], f.posoff[q + 1]);
   }
   wsync_lds();
@@ -882,14 +878,15 @@ KQ_NOINLINE int fs_batch(Fs& f, int cand, int strategy0, bool second, int* pos_o
     for (int base = 0; base < T && pass_idx < 0; base += WAVE) {
       const int i = base + lane;
       bool pass = false;
-      int cost = 0;
+      int cost = 0;   // what the walk charges this evaluation (the cached share of `at`, fs_cost's two parts)
       if (i < T) {
         const int r = f.cl_rk[i], at = f.br_at[r];
         int fl = 0;
         const uint64_t nk = fs_eval_removed(f, f.cl_pos[i], at, &fl);
         cost = (int)f.c0[at] + ((fl & 2) ? (int)f.c1[at] : 0);
         const int pz = f.br_fl[r] & 1, tz = (f.br_fl[r] >> 1) & 1;
-        pass = strategy0 == KQ_FS_LESS_THAN_OR_EQUAL_TO_FINAL_SHARE ? fs_cmp(pz, f.br_pk[r], fl & 1, nk) <= 0 : fs_cmp(pz, f.br_pk[r], tz, f.br_tk[r]) < 0;
+        const uint64_t pk = fs_okey(f.dval[f.br_ap[r]]);
+        pass = strategy0 == KQ_FS_LESS_THAN_OR_EQUAL_TO_FINAL_SHARE ? fs_cmp(pz, pk, fl & 1, nk) <= 0 : fs_cmp(pz, pk, tz, fs_okey(f.dval[at])) < 0;
       }
       const uint64_t pm = wballot(pass);
       int upto = T - base < WAVE ? T - base : WAVE;   // evaluations of this chunk that the walk would have made
@@ -914,7 +911,7 @@ KQ_NOINLINE int fs_batch(Fs& f, int cand, int strategy0, bool second, int* pos_o
   int64_t bytes = eval_bytes;
   {
     int64_t vb = 0;
-    for (int r = lane; r < visited; r += WAVE) vb += f.br_vc[r];
+    for (int r = lane; r < visited; r += WAVE) vb += fs_cost(f, f.br_ap[r]) + fs_cost(f, f.br_at[r]);
     bytes += wsum_i64(vb);
   }
   if (R > 0) {
@@ -925,7 +922,7 @@ KQ_NOINLINE int fs_batch(Fs& f, int cand, int strategy0, bool second, int* pos_o
     int64_t sub = 0;
     for (int s = lane; s < visited; s += WAVE) {
       const int times = second ? (R - s) : (R - 1 - s);
-      if (times > 0) sub += (int64_t)f.br_qc[s] * times;
+      if (times > 0) sub += fs_cost(f, f.br_c[s]) * times;
     }
     bytes += (int64_t)R * (up + Ap) - wsum_i64(sub);
     CSTAT(11, R);

@@ -45,6 +45,7 @@ template <class B> struct EngineT {
   bool force_exact_drs = false;  // tests: take the saturation-safe DRS loops even when the sums would be exact
   bool cs_disable = false;       // tests: classical victim searches always take the candidate-by-candidate walk
   bool fs_disable = false;       // tests: fair-sharing victim searches always take the walk
+  bool fs_lrun_on = [] { const char* e = getenv("KQ_FS_LRUN"); return !(e && e[0] == '0'); }();    // A/B switch of the fair iterator's leader-only runs (process_tree_fair)
   bool cs_lazy_on = [] { const char* e = getenv("KQ_CS_LAZY"); return !(e && e[0] == '0'); }();    // A/B switch of the prefix rounds of the scan search (kq_cs.hpp)
   bool fs_batch_on = [] { const char* e = getenv("KQ_FS_BATCH"); return !(e && e[0] == '0'); }();   // A/B switch of the batched candidate evaluation (kq_fs.hpp fs_batch)
   bool help_disable = false;     // tests: no helper workgroups
@@ -1193,6 +1194,7 @@ template <class B> struct EngineT {
     k.C.fs_on = (cfg.fair_sharing && prep.any_preemption && prep.fs_plain && !fs_disable) ? 1 : 0;
     k.C.fs_batch = fs_batch_on ? 1 : 0;
     k.C.cs_lazy = cs_lazy_on ? 1 : 0;
+    k.C.fs_lrun = fs_lrun_on ? 1 : 0;
     k.C.any_preempt = prep.any_preemption ? 1 : 0;
     k.C.gates = cfg.gates; k.C.fair_sharing = cfg.fair_sharing; k.C.quota_check_strategy = cfg.quota_check_strategy; k.C.cycle = hbch.cycle;
     k.H = hbch.H;
@@ -1291,7 +1293,7 @@ template <class B> struct EngineT {
     k.prof = (long long*)grow<int64_t>(b_prof, 64);
     k.grec = grow<PRec>(b_grec, n);
     k.cq_dirty = grow<uint8_t>(b_cqd, std::max(prep.nq, 1));  // cleared per head by k_records
-    k.defer_list = grow<int32_t>(b_defer, (size_t)n + 1); k.defer_count = k.defer_list + n;
+    k.defer_list = grow<int32_t>(b_defer, (size_t)n + 2); k.defer_count = k.defer_list + n; k.nom_ticket = k.defer_list + n + 1;
     k.cq_heads = grow<int32_t>(b_cqh, (size_t)std::max(prep.nq, 1) + std::max(prep.n_tree, 1) + 8);
     k.spec_resume = k.cq_heads + std::max(prep.nq, 1); k.spec_stats = spec_stats_on ? k.spec_resume + std::max(prep.n_tree, 1) : nullptr;
     prep_fill(k.cq_heads, (size_t)std::max(prep.nq, 1) + std::max(prep.n_tree, 1) + 8, 0);  // resume 0: the serial kernel takes the whole tree
@@ -1302,7 +1304,7 @@ template <class B> struct EngineT {
       k.spec_hdr = grow<SpecHdr>(b_sphdr, (size_t)n);
       k.spec_K = a; k.spec_T = a + cells; k.spec_push = a + 2 * cells; k.spec_nv = a + 2 * cells + slots_; k.spec_o = (int32_t*)(a + 2 * cells + 2 * slots_);
     }
-    prep_fill(k.defer_count, 1, 0);
+    prep_fill(k.defer_count, 2, 0);
     k.help = nullptr; k.help_quit = nullptr; k.help_trees = 0;
     k.tc = d_tc;
     HelpBox* d_help = nullptr;

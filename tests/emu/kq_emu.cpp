@@ -20,10 +20,10 @@ struct EmuBackend {
   void free(void* p) { ::free(p); }
   void* alloc_host(size_t n) { return calloc(n, 1); }
   void free_host(void* p) { ::free(p); }
-  void h2d(void* d, const void* h, size_t n) { memcpy(d, h, n); }
-  void d2h(void* h, const void* d, size_t n) { memcpy(h, d, n); }
-  void d2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
-  void memset(void* d, int v, size_t n) { ::memset(d, v, n); }
+  void h2d(void* d, const void* h, size_t n) { if (n) memcpy(d, h, n); }   // (n == 0 may come with null pointers: empty tables)
+  void d2h(void* h, const void* d, size_t n) { if (n) memcpy(h, d, n); }
+  void d2d(void* d, const void* s, size_t n) { if (n) memcpy(d, s, n); }
+  void memset(void* d, int v, size_t n) { if (n) ::memset(d, v, n); }
   int sync() { return KQ_OK; }
   const char* error() { return ""; }
   int rot = 0, nom_rot = 0, spec_rot = 0, spec_fixed = -1;
