@@ -239,6 +239,7 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
     for (int u = 0; u < CS_NS; u++) c.dB[u] = u < ns ? (int64_t*)cv.take((size_t)c.Mp * 8) : nullptr;
   }
   CSTAT(20, 1);
+  KQ_T0();
   // ---- private copy of the tree's usage (and quotas) for the slots; constants of the preemptor's path ----
   for (int i = lane; i < nn * ns; i += WAVE) {
     const int u = i / nn, ln = i % nn;
@@ -261,6 +262,7 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
     if (u == 0) w.cs_pl[l] = S.node_local[n];
   }
   wsync();
+  KQ_TS(k, 35);  // scan search: private usage / quota tables / path constants
   // ---- classify the bucket once (hierarchical_preemption.go:81-113); class byte = 1 + list + 3 * not-evicted + 8 * variant ----
   const int32_t* rows = S.frbr + boff;
   const CsRec* recs = S.frec + boff;
@@ -327,6 +329,7 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
     }
   }
   wsync();
+  KQ_TS(k, 36);  // scan search: classification + time order
   const bool no_hier = cnt[0] + cnt[3] == 0, no_other = no_hier && (cnt[1] + cnt[4] == 0);
   const bool forbidden = KQ_POL_BORROW_WITHIN(w.pol) == 0;
   bool under_nominal;  // queueUnderNominalInResourcesNeedingPreemption preemption.go:700-707
@@ -371,6 +374,7 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
       }
       wsync();
     }
+    KQ_TS(k, 37);  // scan search: alive flags + level passes of the prefix
     // ---- first fit in time order ----
     int64_t cA[CS_NS][CS_LEVELS + 1];
     #pragma unroll
@@ -429,6 +433,7 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
       }
     }
     wsync();
+    KQ_TS(k, 38);  // scan search: first fit
     if (tstar >= 0 || T >= Mt) break;
     }  // next, longer prefix
     CSTAT(5, tstar >= 0 ? nt : cN);
@@ -459,6 +464,7 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
       }
     }
     wsync();
+    KQ_TS(k, 39);  // scan search: finalising passes + target list
     // ---- fillBackWorkloads (preemption.go:341-354): probes newest-first, 64 at a time ----
     uint8_t* keep = c.alive;  // per target: still removed
     for (int i = lane; i < nt; i += WAVE) keep[i] = 1;
@@ -564,6 +570,7 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
       if (lane == 0) w.bytes += fb_bytes + restore;
     }
     CSTAT(6, 1); CSTAT(7, w.ntgt);
+    KQ_TS(k, 63);  // scan search: fill-back + compaction of the targets
     // the private state with exactly the targets removed, for the caller (find_height reads the preemptor's path)
     for (int i = lane; i < ns * plen; i += WAVE) {
       const int u = i / plen, l = i % plen;

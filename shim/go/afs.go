@@ -175,3 +175,32 @@ func (e *Engine) SetConsumed(l *FlatLedger, lq []int32, rows []corev1.ResourceLi
 	}
 	return nil
 }
+
+// SetWorkloadPenalties = what PushPenalty would record for pending workloads that arrived after PutLedger (AddPending / UpdatePending):
+// rows[i] = afs.CalculateEntryPenalty(SumTotalRequests(wl[i]), cfg) (admission_fair_sharing.go:53-60), computed where the workload
+// controller computes it today.
+func (e *Engine) SetWorkloadPenalties(l *FlatLedger, wl []int32, rows []corev1.ResourceList) error {
+	var p runtime.Pinner
+	defer p.Unpin()
+	nr := len(l.Resources)
+	lo, hi, mask := make([]uint64, len(wl)*nr), make([]int64, len(wl)*nr), make([]uint64, len(wl))
+	for i, rl := range rows {
+		mask[i] = l.put(lo, hi, i, rl)
+	}
+	if rc := C.kq_pending_afs_wl_penalty(e.h, C.int32_t(len(wl)), (*C.int32_t)(pin(&p, wl)), (*C.uint64_t)(pin(&p, lo)), (*C.int64_t)(pin(&p, hi)),
+		(*C.uint64_t)(pin(&p, mask))); rc != 0 {
+		return e.err("kq_pending_afs_wl_penalty", rc)
+	}
+	return nil
+}
+
+// ReadLedgerUsage = afs.CalculateUsage of every LocalQueue as the next Heads() will see it (the visibility endpoint and the LocalQueue
+// status read the same number, admission_fair_sharing.go:86-103).
+func (e *Engine) ReadLedgerUsage(usage []float64) error {
+	var p runtime.Pinner
+	defer p.Unpin()
+	if rc := C.kq_pending_afs_read(e.h, (*C.double)(pin(&p, usage)), nil, nil, nil, nil, nil, nil); rc != 0 {
+		return e.err("kq_pending_afs_read", rc)
+	}
+	return nil
+}

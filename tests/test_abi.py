@@ -151,3 +151,16 @@ def test_no_exception_can_cross_the_c_abi():
     guarded = re.findall(r"KQ_TRY\((?:en|t), return (?:en|t)->e\.[a-z_0-9]+\(", body)
     assert len(calls) == len(guarded) and len(guarded) >= 50, (len(calls), len(guarded))
     assert "g_tmp" not in open(os.path.join(ROOT, "kueue_amd", "csrc", "kq_rows_kernel.hip")).read()   # per-engine rocPRIM scratch
+
+
+def test_every_export_has_a_go_caller_and_every_go_call_is_declared():
+    """shim/go cannot be compiled here (no Go toolchain): at least every entry point of the three headers is bound by a C.kq_* call
+    somewhere under shim/go (the kq_debug_* test hooks and kq_abi_version excepted), and no Go file calls a symbol the headers do not declare."""
+    hdr = set(declared_symbols()) | set(declared_symbols("kq_tas.h")) | set(declared_symbols("kq_cycle_tas.h"))
+    go = set()
+    for f in os.listdir(os.path.join(ROOT, "shim", "go")):
+        if f.endswith(".go"):
+            go |= set(re.findall(r"C\.(kq_[a-z_0-9]+)\(", open(os.path.join(ROOT, "shim", "go", f)).read()))
+    unbound = {s for s in hdr - go if not s.startswith("kq_debug_") and s != "kq_abi_version"}
+    assert not unbound, sorted(unbound)
+    assert not (go - hdr), sorted(go - hdr)

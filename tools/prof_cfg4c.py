@@ -26,6 +26,8 @@ lib.kq_debug_prof(eng._h, F.ptr(prof), 1)
 names = {8: "pc_load", 9: "pc_flush", 10: "chunk_prefetch", 11: "chunk serial core (incl. generic path)", 12: "chunk write results", 13: "leader waits for helpers", 14: "leader: whole tree", 27: "re-prefetch after a stopped chunk",
          0: "generic: load_head", 1: "generic: use list", 34: "generic: first fits (entry_fits with targets)", 4: "generic: has_any .. before recompute", 5: "recompute: row flush",
          6: "recompute: get_assignments", 7: "recompute: row reload", 32: "recompute: fits after", 33: "generic: tail (has_any, insert targets, add usage)", 2: "fast entry", 3: "fast entry: stat",
+         35: "scan search: private usage + tables", 36: "scan search: classification + time order", 37: "scan search: alive + level passes (prefix)",
+         38: "scan search: first fit", 39: "scan search: finalise + targets", 63: "scan search: fill-back",
          40: "search(fair): private plane copy", 41: "search(fair): sums + clears", 42: "search(fair): findCandidates", 43: "search(fair): first strategy",
          21: "nominate heads Fit (sum cycles)", 22: "nominate heads Preempt (sum cycles)", 23: "nominate heads NoFit (sum cycles)", 24: "n Fit", 25: "n Preempt", 26: "n NoFit", 30: "slowest head"}
 print(f"cfg4c n_cq {ncq} cycles {ncy} heads {n} wall {dt:.3f}s last kernel_ms {d.kernel_ms}")
