@@ -355,7 +355,10 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
     // processEntry typically needs a handful of victims out of thousands of candidates (profiles/r04a_cfg4c_jacobi_probe.txt).
     int tstar = -1, nt = 0; int64_t rb_removed = 0;
     int cN = 0; int64_t cRB = 0;
-    for (int T = k.C.cs_lazy ? (Mt < 128 ? Mt : 128) : Mt;; T = (T * 4 < Mt ? T * 4 : Mt)) {
+    // (only where few victims are expected: a recomputation inside processEntry, s.removed set. A nomination against an over-committed
+    // cycle-start snapshot removes hundreds of candidates before the first fit: growing prefixes would cost a third more than one pass.)
+    const bool lazy = k.C.cs_lazy == 2 || (k.C.cs_lazy == 1 && s.removed != nullptr);
+    for (int T = lazy ? (Mt < 128 ? Mt : 128) : Mt;; T = (T * 4 < Mt ? T * 4 : Mt)) {
     CSTAT(30, 1); if (T < Mt) CSTAT(31, 1);
     for (int base = 0; base < T; base += WAVE) {
       const int t = base + lane;

@@ -268,7 +268,7 @@ struct DCfg {
   int fs_on;                 // fair-sharing victim searches may take the LDS-resident formulation (kq_fs.hpp)
   int cs_lazy;               // the scan search works on growing prefixes of the candidate time order (kq_cs.hpp; KQ_CS_LAZY=0 turns it off)
   int fs_lrun;               // the fair iterator's leader pops on its own while entries change no usage (KQ_FS_LRUN=0 turns it off)
-  int fs_batch;              // ... and evaluate the candidates of a cohort's ClusterQueues as a batch (fs_batch; KQ_FS_BATCH=0 turns it off)
+  int fs_batch;              // ... and evaluate the candidates of a cohort's ClusterQueues as a batch (bits: kq_host.hpp fs_batch_bits; KQ_FS_BATCH=0 turns it off)
   int dbg_variant;           // KQ_PROF builds only: timing experiments (KQ_DEBUG_VARIANT; results are wrong when non-zero)
   int any_preempt;           // some ClusterQueue of the snapshot may preempt (Prep::any_preemption)
   int64_t cycle;

@@ -763,7 +763,10 @@ KQ_DEV int64_t fs_level_cost(const Fs& f, int X) {
   return wsum_i64(c);
 }
 // `second`: runSecondFsStrategy's form (preemption.go:501-534): no candidate simulation, one pop per ClusterQueue, DropQueue at once.
-KQ_NOINLINE int fs_batch(Fs& f, int cand, int strategy0, bool second, int* pos_out) {
+// (force-inlined: passing the Fs block by reference to a function that is not inlined sends the whole block to scratch memory in the
+// caller as well — every f.psum / f.dval / ... access of the search became a scratch load, 14.1 instead of 11.5 s per cfg 4f cycle in
+// k_process_fair with the batch switched OFF, profiles/r04c_bench_cfg4f_nobatch.json)
+KQ_DEV int fs_batch(Fs& f, int cand, int strategy0, bool second, int* pos_out) {
   const K& k = *f.k; Wave& w = *f.w; const DSnap& S = k.S;
   const int lane = lane_id();
   fs_assume_lds(f);
@@ -1021,7 +1024,7 @@ KQ_DEV bool fs_probe_fits(const Fs& f, int p) {  // would the preemptor still fi
   }
   return !bad;
 }
-KQ_NOINLINE int fs_fillback_batch(Fs& f, int nt, int64_t* tbytes) {
+KQ_DEV int fs_fillback_batch(Fs& f, int nt, int64_t* tbytes) {
   Wave& w = *f.w; const DSnap& S = f.k->S;
   const int lane = lane_id();
   fs_assume_lds(f);
@@ -1193,7 +1196,7 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
         if (fs_fits_fs(f)) fits = true;
         continue;
       }
-      if (k.C.fs_batch) {  // the ClusterQueues of cand's cohort as a batch: the first candidate that passes, found without walking to it
+      if (k.C.fs_batch & 1) {  // the ClusterQueues of cand's cohort as a batch: the first candidate that passes, found without walking to it
         int bp = -1;
         const int br = fs_batch(f, cand, strategy0, false, &bp);
         KQ_LS(w, 1);
@@ -1268,7 +1271,7 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
     while (!fits) {
       const int cand = fs_ordering_next(f);
       if (cand < 0) break;
-      if (k.C.fs_batch) {
+      if (k.C.fs_batch & 2) {
         int bp = -1;
         const int br = fs_batch(f, cand, strategy0, true, &bp);
         if (br == 0) continue;
@@ -1306,14 +1309,14 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
     if (lane == 0) w.bytes += tbytes;
     // restoreSnapshot :356 — the private copy is dropped, but callers read it on the preemptor's path. With every row back the state is
     // the one the search started from (plain amounts: usage is a function of the SET of rows present), so nothing is walked back.
-    if (k.C.fs_batch) as_started = true;
+    if (k.C.fs_batch & 8) as_started = true;
     else for (int t = 0; t < nt; t++) { const FsRow r = fs_row_load(f, f.tpos[t]); fs_row_ctx(f, r); fs_row_apply(f, r, true, true, false); }
     w.ntgt = 0;
     KQ_TS(k, 45);
   } else {
     CSTAT(16, 1); CSTAT(17, nt);
     // fillBackWorkloads :341-354 with allowBorrowing = true
-    if (k.C.fs_batch) nt = fs_fillback_batch(f, nt, &tbytes);
+    if (k.C.fs_batch & 4) nt = fs_fillback_batch(f, nt, &tbytes);
     else
     for (int t = nt - 2; t >= 0; t--) {
       const FsRow r = fs_row_load(f, f.tpos[t]);

@@ -46,8 +46,9 @@ template <class B> struct EngineT {
   bool cs_disable = false;       // tests: classical victim searches always take the candidate-by-candidate walk
   bool fs_disable = false;       // tests: fair-sharing victim searches always take the walk
   bool fs_lrun_on = [] { const char* e = getenv("KQ_FS_LRUN"); return !(e && e[0] == '0'); }();    // A/B switch of the fair iterator's leader-only runs (process_tree_fair)
-  bool cs_lazy_on = [] { const char* e = getenv("KQ_CS_LAZY"); return !(e && e[0] == '0'); }();    // A/B switch of the prefix rounds of the scan search (kq_cs.hpp)
-  bool fs_batch_on = [] { const char* e = getenv("KQ_FS_BATCH"); return !(e && e[0] == '0'); }();   // A/B switch of the batched candidate evaluation (kq_fs.hpp fs_batch)
+  int cs_lazy_mode = [] { const char* e = getenv("KQ_CS_LAZY"); return e ? atoi(e) : 1; }();   // prefix rounds of the scan search (kq_cs.hpp): 0 off, 1 in recomputations, 2 always
+  // A/B switches of the batched fair search (kq_fs.hpp): bit 0 first strategy, 1 second strategy, 2 fill-back, 3 no restore walk (KQ_FS_BATCH=<bits>)
+  int fs_batch_bits = [] { const char* e = getenv("KQ_FS_BATCH"); return e ? atoi(e) : 15; }();
   bool help_disable = false;     // tests: no helper workgroups
   Buf b_cs;
   struct HeadBatch { Buf hb[1]; DHeads H{}; int n = 0; size_t nps = 0; int slot_cap = 1; int64_t cycle = 0; bool valid = false; bool plain = true; int max_nps = KQ_MAXPS; bool partial = true; };
@@ -1192,8 +1193,8 @@ template <class B> struct EngineT {
     // scan-formulated classical search: usage and admitted quantities must be plain (its prefix sums are ordinary additions)
     k.C.cs_on = (!cfg.fair_sharing && prep.any_preemption && prep.fs_plain && !cs_disable) ? 1 : 0;
     k.C.fs_on = (cfg.fair_sharing && prep.any_preemption && prep.fs_plain && !fs_disable) ? 1 : 0;
-    k.C.fs_batch = fs_batch_on ? 1 : 0;
-    k.C.cs_lazy = cs_lazy_on ? 1 : 0;
+    k.C.fs_batch = fs_batch_bits;
+    k.C.cs_lazy = cs_lazy_mode;
     k.C.fs_lrun = fs_lrun_on ? 1 : 0;
     k.C.any_preempt = prep.any_preemption ? 1 : 0;
     k.C.gates = cfg.gates; k.C.fair_sharing = cfg.fair_sharing; k.C.quota_check_strategy = cfg.quota_check_strategy; k.C.cycle = hbch.cycle;
