@@ -4020,12 +4020,56 @@ KQ_DEV int tournament_cohort(const K& k, int slot, int x, const int32_t* win, co
   }
   return best;
 }
+// The iterator's per-tree state in LDS. A pop of the fair-sharing iterator is three tournaments on the popped entry's
+// path (fair_sharing_iterator.go:125-163); with the state in global memory each of them was a chain of seven dependent loads (children
+// offsets -> child id -> tree-local id -> winner -> its ClusterQueue -> that one's local id and depth -> the key): ~20 round trips per
+// pop, most of the 24 us a pop took at cfg 3f. Here the children lists (tree-local ids, kq_prep.hpp fs_kid / fs_koff / fs_knc / fs_knh),
+// the parent table, the depths, cqToEntry and the winners (entry + its ClusterQueue) live in the workgroup's LDS: a tournament is LDS
+// reads and ONE round of independent key loads.
+struct FIter { int32_t *ent, *win; int16_t *wcq, *kid, *koff, *knc, *knh, *par; int8_t* dep; bool on; };
+KQ_HD size_t fiter_bytes(int nn, int nqs) {
+  auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
+  const int ncoh = nn - nqs > 0 ? nn - nqs : 1;
+  return al((size_t)nqs * 4) + al((size_t)nn * 4) + al((size_t)nn * 2) * 3 + al((size_t)ncoh * 2) * 3 + al((size_t)nn) + 64;
+}
+struct FWin { int e, wc; };
+KQ_DEV FWin tournament_cohort_lds(const FIter& it, const uint64_t* fkeys, int xl, int nqs) {
+  const int lane = lane_id();
+  const int xc = xl - nqs;
+  const int k0 = it.koff[xc], nkc = it.knc[xc], nkh = it.knh[xc];
+  const int dx = it.dep[xl];
+  FWin best{-1, -1};
+  FsKey bk; bk.k1 = bk.k2 = bk.k3 = bk.k4 = 0;
+  for (int base = 0; base < nkh + nkc; base += WAVE) {
+    const int j = base + lane;
+    int cnd = -1, wc = 0;
+    if (j < nkh) { const int ch = it.kid[k0 + nkc + j]; cnd = it.win[ch]; wc = it.wcq[ch]; }          // winners of the child cohorts first (:129-137)
+    else if (j < nkh + nkc) { wc = it.kid[k0 + j - nkh]; cnd = it.ent[wc]; }                             // then the child ClusterQueues' entries (:138-144)
+    bool in = cnd >= 0;
+    FsKey key; key.k1 = key.k2 = key.k3 = key.k4 = 0;
+    if (in) { const uint64_t* p = fkeys + ((size_t)wc * KQ_MAXD + (it.dep[wc] - dx - 1)) * 4; key.k1 = p[0]; key.k2 = p[1]; key.k3 = p[2]; key.k4 = p[3]; }
+    if (wballot(in) == 0) continue;
+    uint64_t mn;
+    mn = wmin_u64(in ? key.k1 : ~0ull); in = in && key.k1 == mn;
+    mn = wmin_u64(in ? key.k2 : ~0ull); in = in && key.k2 == mn;
+    mn = wmin_u64(in ? key.k3 : ~0ull); in = in && key.k3 == mn;
+    mn = wmin_u64(in ? key.k4 : ~0ull); in = in && key.k4 == mn;
+    const int b = ffs64(wballot(in));  // ties keep the first candidate
+    FsKey wk;
+    wk.k1 = (uint64_t)wbcast_u((int64_t)key.k1, b); wk.k2 = (uint64_t)wbcast_u((int64_t)key.k2, b);
+    wk.k3 = (uint64_t)wbcast_u((int64_t)key.k3, b); wk.k4 = (uint64_t)wbcast_u((int64_t)key.k4, b);
+    const int we = wbcast_u(cnd, b), wwc = wbcast_u(wc, b);
+    if (best.e < 0 || fskey_less(wk, bk)) { best.e = we; best.wc = wwc; bk = wk; }  // an earlier chunk's winner keeps ties
+  }
+  return best;
+}
 // One workgroup per root-cohort tree. Wave 0 ("leader") runs the serial part — tournament on the path of the
 // last popped entry, processEntry on the winner — and every wave of the workgroup takes part in computeDRS.
 // computeDRS is incremental: DRS(path[l] of entry i, with i admitted) only reads usage rows of path[0..l], so it
 // is recomputed only for levels at or above the lowest ancestor shared with the entry processEntry just changed;
 // the algorithmic-byte counter is still charged for every (entry, level) the reference evaluates on each pop.
-KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* lds, size_t lds_bytes, int tid, int nthreads) {
+KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* lds, size_t lds_bytes, int tid, int nthreads,
+                              unsigned char* iter_mem = nullptr, size_t iter_bytes = 0) {
   const DSnap& S = k.S; const DOut& O = k.O; const DHeads& H = k.H;
   const int lane = lane_id();
   const bool leader = tid < WAVE;
@@ -4033,6 +4077,22 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
   const int n0 = S.tree_node_off[tree], nn = S.tree_node_off[tree + 1] - n0;
   int32_t* cq_ent = k.X.cq_ent + (size_t)slot * k.X.max_tree_cqs;
   int32_t* win = k.X.fs_win + (size_t)slot * k.X.max_tree_nodes;
+  FIter it{};
+  it.on = iter_mem != nullptr && nn > nqs && nn <= 32767 && iter_bytes >= fiter_bytes(nn, nqs);
+  if (it.on) {
+    auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    unsigned char* q = iter_mem;
+    const int ncoh = nn - nqs;
+    it.ent = (int32_t*)q; q += al((size_t)nqs * 4); it.win = (int32_t*)q; q += al((size_t)nn * 4);
+    it.wcq = (int16_t*)q; q += al((size_t)nn * 2); it.kid = (int16_t*)q; q += al((size_t)nn * 2); it.par = (int16_t*)q; q += al((size_t)nn * 2);
+    it.koff = (int16_t*)q; q += al((size_t)ncoh * 2); it.knc = (int16_t*)q; q += al((size_t)ncoh * 2); it.knh = (int16_t*)q; q += al((size_t)ncoh * 2);
+    it.dep = (int8_t*)q;
+    for (int i = tid; i < nn; i += nthreads) {
+      it.kid[i] = S.fs_kid[n0 + i]; it.par[i] = S.fs_par[n0 + i]; it.dep[i] = (int8_t)S.depth[S.tree_nodes[n0 + i]]; it.wcq[i] = 0;
+      if (i >= nqs) { it.koff[i - nqs] = S.fs_koff[n0 + i]; it.knc[i - nqs] = S.fs_knc[n0 + i]; it.knh[i - nqs] = S.fs_knh[n0 + i]; }
+    }
+    cq_ent = it.ent; win = it.win;
+  }
   int32_t* seq = k.X.fs_seq + (size_t)slot * k.X.max_tree_cqs;
   uint64_t* fkeys = k.X.fs_keys + (size_t)slot * k.X.max_tree_cqs * KQ_MAXD * 4;
   // lds layout: [2 planes of the tree's cohort rows, if they fit][one prefetched entry record]
@@ -4085,6 +4145,8 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
     return;
   }
   const int root = S.path[(size_t)S.tree_cqs[q0] * KQ_MAXD + S.plen[S.tree_cqs[q0]] - 1];
+  const int root_local = S.node_local[root];
+  int last_ei = 0;
   const bool want_bon = gate(k, KQ_GATE_FS_PRIORITIZE_NON_BORROWING);
   const bool fs_plain = fs_plain_now(k);
   int lpos = 0;
@@ -4138,7 +4200,23 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
     // the next pop needs no computeDRS pass and no barrier pair, only the tournaments on the popped entry's path — the leader keeps
     // popping on its own until an entry does change usage (the other waves wait at the barrier below meanwhile).
     if (leader) for (bool lrun = true; lrun;) {
-      if (first) {
+      if (it.on) {
+        if (first) {
+          for (int d = KQ_MAXD - 1; d >= 0; d--)
+            for (int i = nqs; i < nn; i++) {
+              if (it.dep[i] != d) continue;
+              const FWin b = tournament_cohort_lds(it, fkeys, i, nqs);
+              if (lane == 0) { it.win[i] = b.e; it.wcq[i] = (int16_t)(b.wc < 0 ? 0 : b.wc); }
+              wsync_lds();
+            }
+        } else {
+          for (int xl = it.par[last_ei]; xl >= 0; xl = it.par[xl]) {  // only the cohorts that nominated the popped entry can change
+            const FWin b = tournament_cohort_lds(it, fkeys, xl, nqs);
+            if (lane == 0) { it.win[xl] = b.e; it.wcq[xl] = (int16_t)(b.wc < 0 ? 0 : b.wc); }
+            wsync_lds();
+          }
+        }
+      } else if (first) {
         for (int d = KQ_MAXD - 1; d >= 0; d--)
           for (int i = nqs; i < nn; i++) {
             const int x = S.tree_nodes[n0 + i];
@@ -4157,8 +4235,10 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
         }
       }
       KQ_TS(k, 18);
-      const int e = win[S.node_local[root]];
-      const int ec = H.cq[e], ei = S.cq_local[ec];
+      const int e = win[root_local];
+      const int ei = it.on ? (int)it.wcq[root_local] : S.cq_local[H.cq[e]];
+      const int ec = it.on ? S.tree_cqs[q0 + ei] : H.cq[e];
+      last_ei = ei;
       if (lane == 0) {
         atomic_add_i64(O.stat_bytes, *sum);  // the reference evaluates every remaining (entry, level) on every pop
         long long mine = 0;

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(PROCESS_THREADS) void k_process(const K* __restrict
 // Fair sharing: the iterator pops interleave with processEntry (scheduler.go:358), so ordering and processing
 // are one kernel: one wave per root-cohort tree; the tree's cohort usage rows stay in LDS.
 constexpr int FAIR_THREADS = 512;  // wave 0 leads, all 8 waves recompute DRS values between pops
-__global__ __launch_bounds__(FAIR_THREADS) void k_process_fair(const K* __restrict__ kp, unsigned lds_bytes) {
+__global__ __launch_bounds__(FAIR_THREADS) void k_process_fair(const K* __restrict__ kp, unsigned lds_bytes, unsigned iter_bytes) {
   const K& k = *kp;
   __shared__ Wave w;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
@@ -158,7 +158,9 @@ __global__ __launch_bounds__(FAIR_THREADS) void k_process_fair(const K* __restri
     return;
   }
   if (threadIdx.x == 0) { w.cs_lds = nullptr; w.cs_lds_bytes = 0; w.help_on = 0; }
-  process_tree_fair(k, w, blockIdx.x, blockIdx.x, (int64_t*)dyn_lds, lds_bytes, (int)threadIdx.x, FAIR_THREADS);
+  // [region | one record][the iterator's state (FIter), when it fits]
+  process_tree_fair(k, w, blockIdx.x, blockIdx.x, (int64_t*)dyn_lds, lds_bytes - iter_bytes, (int)threadIdx.x, FAIR_THREADS,
+                    iter_bytes ? dyn_lds + (lds_bytes - iter_bytes) : nullptr, iter_bytes);
   if (k.help && threadIdx.x == 0) { ag_release(); ag_add_u32(k.help_quit, 1); }  // this tree needs no more help
 }
 // global iteration positions from the per-tree sequences (kq::fair_rank): 2-D grid like k_order
@@ -756,6 +758,12 @@ struct HipBackend {
     size_t region = cohort_rows_bytes + sizeof(PRec) <= budget ? cohort_rows_bytes : 0;
     region = std::max(region, std::min(search_bytes, budget - sizeof(PRec)));
     size_t lds = sizeof(PRec) + region;
+    lds = (lds + 15) & ~(size_t)15;
+    // the iterator's per-tree state next to it (kq_device.hpp FIter): only if the whole thing still fits the CU
+    size_t iter = (fiter_bytes(k.X.max_tree_nodes, k.X.max_tree_cqs) + 15) & ~(size_t)15;
+    if (getenv("KQ_FS_ITER_LDS") && getenv("KQ_FS_ITER_LDS")[0] == '0') iter = 0;
+    if (lds + iter > budget) iter = 0;
+    lds += iter;
     if (lds > 48 * 1024 && lds != lds_attr_fair) {
       chk(hipFuncSetAttribute((const void*)k_process_fair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
       lds_attr_fair = lds;
@@ -763,7 +771,7 @@ struct HipBackend {
     const K* d = put_k(k, 1);
     dproc = d;
     const int nblk = n_tree + (k.help ? help_blocks(n_tree) : 0);
-    hipLaunchKernelGGL(k_process_fair, dim3(nblk), dim3(FAIR_THREADS), lds, stream, d, (unsigned)lds);
+    hipLaunchKernelGGL(k_process_fair, dim3(nblk), dim3(FAIR_THREADS), lds, stream, d, (unsigned)lds, (unsigned)iter);
     const int nb = (k.H.n + 255) / 256;
     chk(hipMemsetAsync(rank, 0, (size_t)k.H.n * sizeof(int32_t), stream), "memset rank");
     hipLaunchKernelGGL(k_fair_rank, dim3(nb, nb), dim3(256), 0, stream, d, rank);

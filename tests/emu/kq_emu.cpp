@@ -201,7 +201,13 @@ struct EmuBackend {
     std::vector<int64_t> lds(160 * 1024 / 8);
     // (a recomputation's victim search borrows the region: whole state in "LDS" / almost none of it / no region at all)
     const size_t budgets[3] = {lds.size() * 8, sizeof(PRec) + 2048, 0};
-    for (int t = 0; t < n_tree; t++) { Wave w{}; process_tree_fair(k, w, t, t, lds.data(), budgets[(t + rot) % 3], 0, 1); }
+    // (the iterator's state in "LDS" for two launches out of three)
+    std::vector<unsigned char> iter(fiter_bytes(k.X.max_tree_nodes, k.X.max_tree_cqs) + 64);
+    for (int t = 0; t < n_tree; t++) {
+      Wave w{};
+      const bool lds_iter = (t + rot) % 3 != 1;
+      process_tree_fair(k, w, t, t, lds.data(), budgets[(t + rot) % 3], 0, 1, lds_iter ? iter.data() : nullptr, lds_iter ? iter.size() : 0);
+    }
     rot++;
     for (int i = 0; i < hn(k.H); i++) rank[i] = k.X.fs_key[i] >= 0 ? fair_rank(k, i, 0, hn(k.H)) : 0;
     for (int i = 0; i < hn(k.H); i++) if (k.X.fs_key[i] >= 0) k.O.order[i] = rank[i];
