@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3-batch", "cfg3-split", "cfg4c-split", "cfg4c", "cfg3f", "cfg4f", "cfg5", "cfg5-split", "cfg5-cycle"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3-batch", "cfg3-split", "cfg4c-split", "cfg4f-split", "cfg4c", "cfg3f", "cfg4f", "cfg5", "cfg5-split", "cfg5-cycle"],
                     help="cfg3 = BASELINE.json configs[2] (100k pending, 1k CQ, 16 flavors, 3-level cohorts); "
                          "cfg4c = configs[3] population under classical preemption; cfg4f = configs[3] as quoted "
                          "(fair sharing + preemption); cfg3f = configs[2] population under fair sharing; cfg5 = configs[4] "
@@ -78,7 +78,7 @@ def main():
         return bench_tas_cycle(args, torch, dist, world, rank, local_rank)
     if args.workload == "cfg3-batch":
         return bench_batch(args, torch, dist, world, rank, local_rank)
-    if args.workload in ("cfg3-split", "cfg4c-split"):
+    if args.workload in ("cfg3-split", "cfg4c-split", "cfg4f-split"):
         return bench_split(args, torch, dist, world, rank, local_rank)
     if args.workload in ("cfg2", "cfg3", "cfg3f") and not args.resident_batches and not args.open_loop:
         return bench_pending(args, torch, dist, world, rank, local_rank)
@@ -673,10 +673,11 @@ def bench_split(args, torch, dist, world, rank, local_rank):
     from kueue_amd.engine import Engine
     from kueue_amd.population import BASE_SEED, generate
     from kueue_amd.sharding import ShardedCycle
-    cfgn = 4 if args.workload.startswith("cfg4c") else 3
-    pop = generate(cfgn, seed=BASE_SEED, fill=args.fill) if cfgn == 3 else generate(cfgn, seed=BASE_SEED)
+    cfgn = 4 if args.workload.startswith("cfg4") else 3
+    fair = args.workload.startswith("cfg4f")   # BASELINE configs[3]: fair sharing + fair preemption; what shards is the victim searches of nominate
+    pop = generate(cfgn, seed=BASE_SEED, fill=args.fill) if cfgn == 3 else generate(cfgn, seed=BASE_SEED, fair_sharing=fair)
     snap = pop.snapshot
-    kcfg = make_config(device=local_rank)
+    kcfg = make_config(device=local_rank, fair_sharing=fair)
     tgt_cap = 4096 if cfgn == 3 else 4 * snap.n_adm
     per_cq = int((pop.cq_w_off[1:] - pop.cq_w_off[:-1]).max())
     n_batches = min(per_cq, args.steps + args.warmup)

@@ -4290,6 +4290,9 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
         wsync();
       }
       lpos++;
+#if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
+      if (lane == 0 && w.usage_dirty) atomic_add_i64((long long*)k.prof + 15, 1);   // pops that changed usage (each one costs a computeDRS pass)
+#endif
       if (lane == 0) { ctl[0] -= 1; ctl[1] = ec; ctl[2] = w.usage_dirty; }
       wsync();
       first = false;

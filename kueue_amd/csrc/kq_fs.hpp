@@ -1030,38 +1030,44 @@ KQ_DEV int fs_fillback_batch(Fs& f, int nt, int64_t* tbytes) {
   fs_assume_lds(f);
   const int64_t fits_bytes = 40 * (int64_t)f.plen * f.npc;
   int64_t bytes = 0;
-  for (int hi = nt - 2; hi >= 0; hi -= WAVE) {
-    const int t = hi - lane;
-    const bool in = t >= 0;
-    const int p = in ? f.tpos[t] : f.tpos[0];
-    const FsApply a = S.fs_apply[(size_t)f.row0 + p];
-    const int64_t rowbytes = 16 * (int64_t)a.plen * (((int)a.cbytes - 32) / 12);
-    bool miss = false;
-    #pragma unroll
-    for (int e = 0; e < CS_RFR; e++) if (in && a.fr[e] >= 0 && f.colslot[a.fr[e]] < 0) miss = true;
-    if (wballot(miss)) fs_ensure_w(f);
-    uint64_t pending = wballot(in);
-    bool kept_out = false;   // this lane's target left the set (the preemptor fits without preempting it)
-    while (pending) {
-      const bool mine = in && ((pending >> lane) & 1);
-      const uint64_t fm = wballot(mine && fs_probe_fits(f, p)) & pending;
-      if (!fm) break;
-      const int b = ffs64(fm);             // lane 0 holds the newest target: the first probe that fits is the one the walk keeps back next
-      const int tb = hi - b;
-      {  // commit: AddWorkload of that row, then the reference's swap-delete (targets[i] = targets[last]; targets = targets[:last])
-        const FsRow r = fs_row_load(f, f.tpos[tb]);
-        fs_row_ctx(f, r);
-        fs_row_apply(f, r, true, true, false);
-        if (lane == 0) { f.trow[tb] = f.trow[nt - 1]; f.treason[tb] = f.treason[nt - 1]; f.tpos[tb] = f.tpos[nt - 1]; }
+  int t = nt - 2;
+  while (t >= 0) {
+    // one probe the walk's way: where the fill-back keeps most targets back (a search that removed far more than it needed) the probes
+    // succeed one after the other and an evaluation round per success would cost more than it saves
+    {
+      const FsRow r = fs_row_load(f, f.tpos[t]);
+      fs_row_ctx(f, r);
+      fs_row_apply(f, r, true, true, true);
+      if (fs_fits(f, false)) {
+        if (lane == 0) { f.trow[t] = f.trow[nt - 1]; f.treason[t] = f.treason[nt - 1]; f.tpos[t] = f.tpos[nt - 1]; }
         nt--;
+        *tbytes -= r.rowbytes;
         wsync();
+        t--;
+        continue;
       }
-      if (lane == b) kept_out = true;
-      pending &= b == 63 ? 0ull : ~((2ull << b) - 1);
+      fs_row_apply(f, r, false, true, true);
+      t--;
     }
-    // every target of the chunk was probed once: AddWorkload + the fit test, and RemoveWorkload again for the ones that stay targets
-    bytes += wsum_i64(in ? rowbytes + fits_bytes + (kept_out ? 0 : rowbytes) : 0);
-    *tbytes -= wsum_i64(in && kept_out ? rowbytes : 0);
+    // it failed: skip over the failures that follow, 64 probes per round, up to the next probe that fits (the walk's step above takes it)
+    while (t >= 0) {
+      const int tt = t - lane;
+      const bool in = tt >= 0;
+      const int p = in ? f.tpos[tt] : f.tpos[0];
+      const FsApply a = S.fs_apply[(size_t)f.row0 + p];
+      bool miss = false;
+      #pragma unroll
+      for (int e = 0; e < CS_RFR; e++) if (in && a.fr[e] >= 0 && f.colslot[a.fr[e]] < 0) miss = true;
+      if (wballot(miss)) fs_ensure_w(f);
+      const uint64_t fm = wballot(in && fs_probe_fits(f, p));
+      const int span = t + 1 < WAVE ? t + 1 : WAVE;
+      const int nfail = fm ? ffs64(fm) : span;
+      // a failed probe: AddWorkload, the fit test, RemoveWorkload again
+      const int64_t rowbytes = 16 * (int64_t)a.plen * (((int)a.cbytes - 32) / 12);
+      bytes += wsum_i64(lane < nfail ? 2 * rowbytes + fits_bytes : 0);
+      t -= nfail;
+      if (fm) break;
+    }
   }
   if (lane == 0) w.bytes += bytes;
   return nt;
@@ -1181,6 +1187,7 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
       for (int u = 0; u < w.ns; u++)
         if (w.s_need[u] && S.nominal[ix(S, w.cq, w.s_fr[u])] < fs_ld(f, fs_cell(f, f.wli, w.s_fr[u]))) within_nominal = false;
     }
+    int streak = 0;   // ClusterQueues visited since the last victim
     while (!fits) {
       KQ_A0();
       const int cand = fs_ordering_next(f);
@@ -1194,14 +1201,20 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
         if (!fs_push_target(f, &nt, r.row, p, cand == f.wli ? KQ_REASON_IN_CLUSTER_QUEUE : KQ_REASON_IN_COHORT_RECLAMATION)) { w.ntgt = 0; return true; }
         tbytes += r.rowbytes;
         if (fs_fits_fs(f)) fits = true;
+        streak = 0;
         continue;
       }
-      if (k.C.fs_batch & 1) {  // the ClusterQueues of cand's cohort as a batch: the first candidate that passes, found without walking to it
+      // The batch pays when candidates FAIL (it skips over them); where most of them pass — a recomputation inside processEntry, whose
+      // snapshot is no longer over-committed — a batch per victim costs twice the walk's single evaluation (k_process_fair 15.7 s with the
+      // batch always on against 10.6 s without, profiles/r04e_*). So a visit takes the batch only while the walk is in a losing streak:
+      // the previous ClusterQueue was exhausted without a victim.
+      if ((k.C.fs_batch & 1) && (streak > 0 || (k.C.fs_batch & 16))) {
         int bp = -1;
         const int br = fs_batch(f, cand, strategy0, false, &bp);
         KQ_LS(w, 1);
         if (br == 0) continue;
         if (br == 1) {
+          streak = 0;
           const FsRow r = fs_row_load(f, bp);
           fs_row_ctx(f, r);
           fs_row_apply(f, r, false, true, true);
@@ -1231,9 +1244,11 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
         }
         if (lane == 0) f.nflag[cand] &= ~8;
         wsync();
+        streak++;
         continue;
       }
       KQ_LS(w, 7);
+      streak++;   // (reset below if this ClusterQueue yields a victim)
       while (fs_cq_has(f, cand)) {
         const int p = fs_pop(f, cand, f.m1, nullptr);
         KQ_LS(w, 1);
@@ -1255,6 +1270,7 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
           tbytes += r.rowbytes;
           if (fs_fits_fs(f)) fits = true;
           KQ_LS(w, 6);
+          streak = 0;
           break;
         }
         if (lane == 0) f.m2[p >> 6] |= 1ull << (p & 63);  // retryCandidates
@@ -1268,14 +1284,16 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
     f.mq = f.m2;
     for (int i = lane; i < f.nn; i += WAVE) { f.nflag[i] &= ~1; if (i < f.nqs) fs_has_update(f, i); }
     wsync();
+    int streak2 = 0;
     while (!fits) {
       const int cand = fs_ordering_next(f);
       if (cand < 0) break;
-      if (k.C.fs_batch & 2) {
+      if ((k.C.fs_batch & 2) && (streak2 > 0 || (k.C.fs_batch & 16))) {
         int bp = -1;
         const int br = fs_batch(f, cand, strategy0, true, &bp);
         if (br == 0) continue;
         if (br == 1) {
+          streak2 = 0;
           const FsRow r = fs_row_load(f, bp);
           fs_row_ctx(f, r);
           fs_row_apply(f, r, false, true, true);
@@ -1290,6 +1308,7 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
       const bool passed = fs_cmp((f.nflag[ap] & 2) ? 1 : 0, fs_okey(f.dval[ap]), (f.nflag[at] & 2) ? 1 : 0, fs_okey(f.dval[at])) < 0;
       if (lane == 0) w.bytes += fs_cost(f, ap) + fs_cost(f, at);
       const int p = fs_pop(f, cand, f.m2, nullptr);
+      streak2 = passed ? 0 : streak2 + 1;
       if (passed) {
         const FsRow r = fs_row_load(f, p);
         fs_row_ctx(f, r);

@@ -22,7 +22,7 @@ for c in range(3, 13):
 lib.kq_debug_prof(eng._h, F.ptr(prof), 1)
 names = {8: "pc_load", 9: "pc_flush", 10: "chunk_prefetch", 11: "chunk serial core",  12: "chunk write results", 13: "leader waits for helpers", 14: "leader: whole tree", 27: "re-prefetch after a stopped chunk",
          0: "slow: load_head", 1: "slow: use list", 4: "recompute: before (fits, np)", 5: "recompute: row flush", 6: "recompute: get_assignments", 7: "recompute: row reload",
-         16: "fair: computeDRS (leader wave)", 17: "fair: barrier wait", 18: "fair: tournament", 19: "fair: pop bookkeeping", 20: "fair: processEntry"}
+         15: "fair: pops that changed usage (COUNT, not cycles)", 16: "fair: computeDRS (leader wave)", 17: "fair: barrier wait", 18: "fair: tournament", 19: "fair: pop bookkeeping", 20: "fair: processEntry"}
 for i, nm in names.items():
     print(f"{nm:28s} {prof[i]/n:10.1f} cycles/entry   total {prof[i]}")
 for i, nm in enumerate(("Fit", "Preempt", "NoFit")):
