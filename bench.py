@@ -53,7 +53,9 @@ def main():
     ap.add_argument("--resident-batches", action="store_true",
                     help="cfg2 / cfg3 / cfg3f: the round-1 loop over pre-cut resident head batches (batch c = the c-th workload of every "
                          "ClusterQueue, no requeue) instead of the pending-side loop (Heads() and requeue on the device)")
-    ap.add_argument("--full-run", type=int, default=6000, help="pending loop: cycle cap of the untimed 'until every workload had a decision' leg (0 = skip)")
+    ap.add_argument("--full-run", type=int, default=20000, help="pending loop: cycle cap of the untimed 'until every workload had a decision' leg (0 = skip); "
+                                                              "the leg also stops when no NEW workload was decided for --full-run-idle cycles (the tail is starved, not stuck)")
+    ap.add_argument("--full-run-idle", type=int, default=1500)
     ap.add_argument("--fill", type=float, default=1.0, help="cfg3-split: scale of the admitted set's fill (1.0 = BASELINE population, whose root "
                     "cohort is the binding constraint; < 1 leaves headroom at the root)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive kq_cycle_run leg and the kq_snapshot_put timing")
@@ -365,6 +367,8 @@ class PendingLoop:
         rel = 0
         if self.live > self.hold:
             rel = self.hold + 1; self.live -= 1
+        self.t_issue = getattr(self, "t_issue", [])
+        self.t_issue.append(time.perf_counter())          # host call -> decisions readable (SURVEY 8d's cycle latency) starts here
         eng._check(lib.kq_pending_step(h, self.cycle, None, self.out.struct().tgt_cap, rel, 1 if want_heads else 0))
         self.in_flight = getattr(self, "in_flight", 0) + 1
 
@@ -372,6 +376,8 @@ class PendingLoop:
         C, lib, h, eng = self.C, self.lib, self.h, self.eng
         eng._check(lib.kq_pending_step_wait(h, C.byref(self.out.struct()), C.byref(self.n), C.byref(self.nps), F_ptr(self.hw) if want_heads else None))
         self.in_flight -= 1
+        self.latency_ms = getattr(self, "latency_ms", [])
+        self.latency_ms.append((time.perf_counter() - self.t_issue.pop(0)) * 1e3)   # (steps complete in issue order)
         return self.n.value
 
     def step_pipelined(self, want_heads=False):
@@ -519,6 +525,7 @@ def bench_pending(args, torch, dist, world, rank, local_rank):
     if world > 1:
         dist.barrier()
     cyc_ms, dec = [], 0
+    loop.latency_ms = []
     nom_ms = ord_ms = proc_ms = 0.0
     nom_by = proc_by = 0
 
@@ -574,6 +581,10 @@ def bench_pending(args, torch, dist, world, rank, local_rank):
                                + ("one enqueue per cycle (kq_pending_step), decisions of cycle i fetched while cycle i+1 runs; cycle_ms = interval between completions"
                                   if pipelined else "kq_pending_heads / kq_cycle_run_pending / commit / apply / release, two host round trips per cycle")},
             "p50_cycle_ms": float(np.percentile(cyc_ms, 50)), "p99_cycle_ms": float(np.percentile(cyc_ms, 99)),
+            # the pipelined loop's cycle_ms is the interval between two completions; SURVEY 8d's "host call -> decisions readable" is the
+            # time from kq_pending_step of a cycle to the return of its kq_pending_step_wait (about two intervals with two steps in flight)
+            "issue_to_readable_ms": ({"p50": float(np.percentile(loop.latency_ms, 50)), "p99": float(np.percentile(loop.latency_ms, 99))}
+                                     if pipelined and loop.latency_ms else None),
             "kernel_ms_per_cycle": {"k_nominate": nom_ms / args.steps, "k_order": ord_ms / args.steps, "k_process": proc_ms / args.steps},
             "roofline": {"bound": "hbm", "kernel": {"k_process": "k_process_fair" if fair else "k_process_spec + k_process", "k_nominate": "k_nominate_lean (+ k_nominate, k_records)"}[dom],
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
@@ -588,15 +599,26 @@ def bench_pending(args, torch, dist, world, rank, local_rank):
             decided = np.zeros(pop.n_pending, bool)
             ms, fdec, cyc = [], 0, 0
             parked = np.zeros(pop.n_pending, bool)
+            idle, ndec, stopped = 0, 0, "cycle cap"
             while cyc < args.full_run and not (decided | parked).all():
                 t1 = time.perf_counter()
                 n = loop.step(want_heads=True)
                 ms.append((time.perf_counter() - t1) * 1e3)
                 cyc += 1
                 if n == 0:
+                    stopped = "Heads() returned nothing"
                     break
                 decided[loop.hw[loop.hw >= 0]] = True
                 fdec += n
+                nd = int(decided.sum())
+                idle = idle + 1 if nd == ndec else 0
+                ndec = nd
+                if idle >= args.full_run_idle:
+                    # the heads of these cycles were all workloads that had been heads before (requeued NoFit heads pop again in front of the
+                    # lower-priority workloads behind them; admissions are bounded by the release of the 4-cycle-old ones): starvation, as in
+                    # the reference's queues, not progress that a longer run would finish
+                    stopped = f"no new workload decided in {args.full_run_idle} cycles"
+                    break
                 if cyc % 25 == 0:
                     # a workload whose equivalence class was bulk-moved with a NoFit head is parked among the inadmissible workloads
                     # without ever being a head (cluster_queue.go:592-597): the reference decides it "by class", so does the run
@@ -605,7 +627,7 @@ def bench_pending(args, torch, dist, world, rank, local_rank):
             st, counts = eng.pending_state()
             parked = (st == 2) & ~decided
             out["full_run"] = {"cycles": cyc, "decisions": fdec, "workloads_decided": int(decided.sum()), "parked_with_their_class": int(parked.sum()),
-                               "complete": bool((decided | parked).all()), "of": pop.n_pending,
+                               "complete": bool((decided | parked).all()), "stopped_by": "every workload decided" if (decided | parked).all() else stopped, "of": pop.n_pending,
                                "decisions_per_s": fdec / (sum(ms) * 1e-3), "p50_cycle_ms": float(np.percentile(ms, 50)), "p99_cycle_ms": float(np.percentile(ms, 99)),
                                "admitted": int(counts[3]), "still_active": int(counts[0]), "inadmissible": int(counts[2]),
                                "what": "fresh queue -> cycles until every pending workload had >= 1 decision or was parked with its equivalence class "

@@ -688,7 +688,12 @@ struct HipBackend {
       chk(hipFuncSetAttribute((const void*)k_nominate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
       lds_attr_nom = lds;
     }
-    const K* d = put_k(k, 0);
+    // (timing builds: KQ_PROF_SKIP_NOMINATE=1 sends the nominate kernels' segment counters to a sink, so that the shared search code's
+    //  timers show the process kernel alone)
+    static const bool prof_skip_nom = getenv("KQ_PROF_SKIP_NOMINATE") != nullptr;
+    K kk = k;
+    if (prof_skip_nom && kk.prof) kk.prof += 64;
+    const K* d = put_k(kk, 0);
     hipLaunchKernelGGL(k_nominate_lean, dim3(slots), dim3(64), 0, stream, d, slots);
     if (full_pass) hipLaunchKernelGGL(k_nominate, dim3(slots), dim3(64), lds, stream, d, slots, (unsigned)lds);
     chk(hipGetLastError(), "k_nominate");

@@ -1291,7 +1291,7 @@ template <class B> struct EngineT {
     k.usage_work = grow<int64_t>(b_usage_work, Nfr);
     k.usage_np = grow<int64_t>(b_usage_np, Nfr);
     k.preempted = grow<uint8_t>(b_preempted, ((size_t)std::max(prep.n_adm, 1) + 3) & ~(size_t)3);
-    k.prof = (long long*)grow<int64_t>(b_prof, 64);
+    k.prof = (long long*)grow<int64_t>(b_prof, 128);   // [64] segment counters + [64] a sink (KQ_PROF_SKIP_NOMINATE: the nominate kernels count there)
     k.grec = grow<PRec>(b_grec, n);
     k.cq_dirty = grow<uint8_t>(b_cqd, std::max(prep.nq, 1));  // cleared per head by k_records
     k.defer_list = grow<int32_t>(b_defer, (size_t)n + 2); k.defer_count = k.defer_list + n; k.nom_ticket = k.defer_list + n + 1;
