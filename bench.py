@@ -700,7 +700,7 @@ def bench_split(args, torch, dist, world, rank, local_rank):
     pop = generate(cfgn, seed=BASE_SEED, fill=args.fill) if cfgn == 3 else generate(cfgn, seed=BASE_SEED, fair_sharing=fair)
     snap = pop.snapshot
     kcfg = make_config(device=local_rank, fair_sharing=fair)
-    tgt_cap = 4096 if cfgn == 3 else 4 * snap.n_adm
+    tgt_cap = 4096 if cfgn == 3 else (32 if fair else 4) * snap.n_adm   # (fair: a nomination lists every victim of every head, as in bench_cycle)
     per_cq = int((pop.cq_w_off[1:] - pop.cq_w_off[:-1]).max())
     n_batches = min(per_cq, args.steps + args.warmup)
     batches = [pop.heads_for_cycle(c, cycle=c + 1) for c in range(n_batches)]

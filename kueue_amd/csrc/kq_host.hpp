@@ -1367,7 +1367,12 @@ template <class B> struct EngineT {
     if (sc.mode == 1) {
       be.launch_shard_export(k, nps, rsn_win);
       last_cycle_n = -1;
-      return be.sync();   // the caller's all-reduce reads the buffer next
+      int32_t derr = 0;   // this rank's own device-side error is reported here with its code (the merged error word only says "some rank failed")
+      be.d2h(&derr, k.O.error, sizeof(derr));
+      rc = be.sync();     // the caller's all-reduce reads the buffer next
+      if (rc != KQ_OK) return fail(rc, be.error());
+      if (derr != 0) return fail(derr, derr == KQ_ECAPACITY ? "device-side error: target pool too small for this rank's nominations (tgt_cap)" : "device-side error (capacity or unsupported input)");
+      return KQ_OK;
     }
     if (!nominate_only && !d_tc) be.launch_records(k);  // entry records (static part) for k_process; charged to the nominate interval
     be.timer_mark(1);

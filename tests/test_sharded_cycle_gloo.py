@@ -142,3 +142,21 @@ def test_sharded_cycle_world1_gpu(kind):
             assert np.array_equal(a.read_usage(), b.read_usage())
     finally:
         a.close(); b.close()
+
+
+def test_nominate_shard_reports_its_own_capacity_error():
+    """A rank whose nominations overflow the target pool fails in kq_cycle_nominate_shard with KQ_ECAPACITY (the merged error word of
+    kq_cycle_process_merged only says that some rank failed)."""
+    import torch
+    from kueue_amd.api import Decisions, make_config
+    from tests.emu import kqe
+    pop, fair = _population("cfg4f")
+    eng = kqe.EmuEngine(make_config(fair_sharing=fair))
+    eng.put(pop.snapshot)
+    heads = pop.heads_for_cycle(0, cycle=1)
+    d = Decisions(heads, tgt_cap=1)
+    x = torch.zeros(eng.shard_words(heads, d, 1), dtype=torch.int64)
+    with pytest.raises(AssertionError) as ei:
+        eng.nominate_shard(heads, None, 1, 0, x.data_ptr(), d)
+    assert ei.value.args[0][0] == -5 and b"tgt_cap" in ei.value.args[0][1]
+    eng.close()
