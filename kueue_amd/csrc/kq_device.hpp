@@ -3950,6 +3950,63 @@ KQ_DEV DRSv drs_entry_level(const K& k, const Wave& w, const int32_t* path, int 
   d.borrow_on = bon;
   return d;
 }
+// drs_entry_level for a path of at most four levels whose nodes are known (nd: global ids; row: the cohort's row in the LDS-resident
+// planes, -1 = read HBM). The walk above costs one dependent round trip per (usage entry, level) — ~40 k cycles for a ClusterQueue that
+// shares its cohort with the popped entry, and the leader waits for the slowest thread of the pass. Here every operand of four usage
+// entries is requested before the first one is used: one round trip per four entries. Same arithmetic, same order.
+KQ_DEV DRSv drs_entry_level_g(const K& k, const Wave& w, const int* nd, const int* row, int level, const int32_t* ufr, const int64_t* uqty, int nu,
+                              bool want_bon, int64_t* bytes) {
+  const DSnap& S = k.S;
+  const int nR = S.nR, n = fs_sel4(nd, level), rown = fs_sel4(row, level);
+  auto usage_of = [&](int node, int rw, int fr) -> int64_t {
+    return rw >= 0 ? w.pc_lds[(size_t)rw * S.nfr + fr] : k.usage_work[(size_t)node * S.nfr + fr];   // plane 0 of the resident rows = usage_work
+  };
+  int64_t sum[KQ_MAXR];
+  #pragma unroll
+  for (int r = 0; r < KQ_MAXR; r++) sum[r] = r < nR ? k.X.bs_sum[(size_t)n * nR + r] : 0;
+  int pos = k.X.bs_pos[n];
+  int bon = 0;
+  for (int q0 = 0; q0 < nu; q0 += 4) {
+    int fr[4]; int64_t qty[4], sqn[4], un[4], lq[4][3], ul[4][3]; uint8_t qf[4]; bool in[4];
+    #pragma unroll
+    for (int j = 0; j < 4; j++) { in[j] = q0 + j < nu; fr[j] = ufr[in[j] ? q0 + j : q0]; qty[j] = uqty[in[j] ? q0 + j : q0]; }
+    #pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const size_t o = ix(S, n, fr[j]);
+      qf[j] = S.qflags[o]; sqn[j] = S.sq[o]; un[j] = usage_of(n, rown, fr[j]);
+      #pragma unroll
+      for (int l = 0; l < 3; l++) {
+        lq[j][l] = 0; ul[j][l] = 0;
+        if (l < level) {
+          const size_t om = ix(S, nd[l], fr[j]);
+          const int64_t ll = S.ll[om], sqm = S.sq[om];
+          lq[j][l] = ll != KQ_NIL_LIMIT ? i64max(0, a_sub(sqm, ll)) : 0;   // local_quota
+          ul[j][l] = usage_of(nd[l], row[l], fr[j]);
+        }
+      }
+    }
+    #pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (!in[j] || !(qf[j] & KQ_QF_SUBTREE)) continue;
+      int64_t delta = qty[j];
+      #pragma unroll
+      for (int l = 0; l < 3; l++) {  // what AddUsage bubbles up to this level (resource_node.go:144-152)
+        if (l >= level || delta == 0) continue;
+        const int64_t la = i64max(0, a_sub(lq[j][l], ul[j][l]));
+        if (delta > la) delta = a_sub(delta, la); else delta = 0;
+      }
+      const int64_t ob = i64max(0, a_sub(un[j], sqn[j])), nb = i64max(0, a_sub(a_add(un[j], delta), sqn[j]));
+      const int r = fr[j] % nR;
+      #pragma unroll
+      for (int rr = 0; rr < KQ_MAXR; rr++) if (rr == r) sum[rr] += nb - ob;
+      pos += (nb > 0 ? 1 : 0) - (ob > 0 ? 1 : 0);
+      if (want_bon && nb > 0 && qty[j] > 0) bon = 1;
+    }
+  }
+  DRSv d = drs_from_sums(S, n, sum, pos, bytes);
+  d.borrow_on = bon;
+  return d;
+}
 // entryComparer.less (fair_sharing_iterator.go:176-221) as a lexicographic key: a wins over b inside
 // parentCohort <=> key(a) < key(b); ties keep the earlier tournament candidate.
 //   k1: [PrioritizePreemptors] non-preemptor, [FairSharingPrioritizeNonBorrowing] borrowing on a requested
@@ -4110,7 +4167,7 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
     w.pc_on = (w.pc_ncoh > 0 && have_rec && (size_t)w.pc_ncoh * S.nfr * 16 <= lds_bytes - sizeof(PRec)) ? 1 : 0;
     w.pc_region_bytes = have_rec ? (int)(lds_bytes - sizeof(PRec)) : 0;  // the rows (if resident) are flushed before a recomputation borrows the region
     w.help_on = k.help ? 1 : 0; w.help_tree = tree;
-    *sum = 0; ctl[0] = 0; ctl[1] = -1; ctl[2] = 0;
+    *sum = 0; ctl[0] = 0; ctl[1] = -1; ctl[2] = 0; ctl[3] = 0;
     w.np_broken = 0; w.n_pre = 0; w.broken[0] = w.broken[1] = w.broken[2] = w.broken[3] = 0; w.n_pre = 0; w.broken[0] = w.broken[1] = w.broken[2] = w.broken[3] = 0;
   }
   for (int i = tid; i < nqs; i += nthreads) { cq_ent[i] = -1; stale[i] = 0; }
@@ -4158,9 +4215,51 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
       const int xc = ctl[1];
       const bool changed = ctl[2] != 0;
       int64_t delta = 0;
+      const int xi = ctl[3];   // tree-local index of the ClusterQueue popped last
       for (int i = tid; i < nqs; i += nthreads) {
         const int en = cq_ent[i];
         if (en < 0) continue;
+        if (fs_plain && it.on && it.dep[i] <= 3 && (!changed || it.dep[xi] <= 3)) {
+          // The paths come from the iterator's LDS state (parents, depths): which levels are out of date is known without a global
+          // access, and a ClusterQueue that only shares the root with the popped one — nine out of ten — is done here.
+          const int plen = it.dep[i] + 1;
+          int lp[4];
+          lp[0] = i;
+          #pragma unroll
+          for (int l = 1; l < 4; l++) lp[l] = l < plen ? (int)it.par[lp[l - 1]] : -1;
+          int from = stale[i];
+          if (changed) {
+            const int xl = it.dep[xi] + 1;
+            int xp[4];
+            xp[0] = xi;
+            #pragma unroll
+            for (int l = 1; l < 4; l++) xp[l] = l < xl ? (int)it.par[xp[l - 1]] : -1;
+            int t = 0;
+            while (t < plen - 1 && t < xl - 1 && fs_sel4(lp, plen - 2 - t) == fs_sel4(xp, xl - 2 - t)) t++;
+            const int lvl = plen - 1 - t;
+            if (lvl < from) from = lvl;
+          }
+          if (from + 1 >= plen) { if (from != 255) stale[i] = 255; continue; }
+          int nd[4], row[4];
+          #pragma unroll
+          for (int l = 0; l < 4; l++) {
+            nd[l] = S.tree_nodes[n0 + (l < plen ? lp[l] : i)];
+            row[l] = (l >= 1 && l < plen && w.pc_on) ? lp[l] - nqs : -1;
+          }
+          const int32_t* ufr = O.use_fr + (size_t)en * KQ_MAXU; const int64_t* uqty = O.use_qty + (size_t)en * KQ_MAXU;
+          const int nu = (H.flags[en] & KQ_HEAD_HAS_QUOTA_RESERVATION) ? 0 : O.use_n[en];  // netUsage scheduler.go:785-794
+          for (int l = from; l + 1 < plen; l++) {
+            int64_t lb = 0;
+            const DRSv d = drs_entry_level_g(k, w, nd, row, l, ufr, uqty, nu, want_bon, &lb);
+            const size_t o = (size_t)i * KQ_MAXD + l;
+            const FsKey key = fs_make_key(k, en, d);
+            fkeys[o * 4 + 0] = key.k1; fkeys[o * 4 + 1] = key.k2; fkeys[o * 4 + 2] = key.k3; fkeys[o * 4 + 3] = key.k4;
+            delta += lb - cost[o];
+            cost[o] = (int32_t)lb;
+          }
+          stale[i] = 255;
+          continue;
+        }
         const int c = S.tree_cqs[q0 + i];
         const int32_t* path = S.path + (size_t)c * KQ_MAXD;
         const int plen = S.plen[c];
@@ -4293,7 +4392,7 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
 #if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
       if (lane == 0 && w.usage_dirty) atomic_add_i64((long long*)k.prof + 15, 1);   // pops that changed usage (each one costs a computeDRS pass)
 #endif
-      if (lane == 0) { ctl[0] -= 1; ctl[1] = ec; ctl[2] = w.usage_dirty; }
+      if (lane == 0) { ctl[0] -= 1; ctl[1] = ec; ctl[2] = w.usage_dirty; ctl[3] = ei; }
       wsync();
       first = false;
       lrun = k.C.fs_lrun && ctl[0] > 0 && !w.usage_dirty;

@@ -1031,9 +1031,81 @@ KQ_DEV int fs_fillback_batch(Fs& f, int nt, int64_t* tbytes) {
   const int64_t fits_bytes = 40 * (int64_t)f.plen * f.npc;
   int64_t bytes = 0;
   int t = nt - 2;
+  // Where the fill-back keeps most targets back (a recomputation inside processEntry removes ~750 rows and keeps ~24 of them,
+  // profiles/r04f_cfg4f_jacobi_probe.txt) the probes succeed one after the other, and a probe the walk's way is two dependent global
+  // round trips (the row's record, then the quota constants of its cells) plus the bookkeeping of shares nobody reads any more:
+  // 5.2 us per probe, 2.6 of the 10.5 s of k_process_fair (profiles/r04g_prof_fair_cfg4f_process_only.txt). So the operands of FS_FG
+  // probes are fetched together — a lane per (row, usage entry) — and parked in LDS; the probes then run one after the other on LDS
+  // alone: AddWorkload as the usage chains only (the borrowed sums and cached shares are dead once the strategies are over), the fit
+  // test, and RemoveWorkload again where it fails. Same cells written in the same order, same bytes charged.
+  constexpr int FS_FG = 16, FS_FC = FS_FG * CS_RFR;
+  static_assert(CS_RFR == 4 && FS_LV == 4, "fs_sel4 on the usage entries and the levels");
+  const size_t st_bytes = (size_t)FS_FC * FS_LV * 8 + (size_t)FS_FC * FS_LV * 4 + (size_t)FS_FC * 8 + (size_t)FS_FC * 4 + (size_t)FS_FG * 8;
+  const bool staged = (size_t)f.nn * f.nR * 8 >= st_bytes;   // the staging area lies over the borrowed sums
+  int64_t* st_lq = f.psum; int32_t* st_ptr = (int32_t*)(st_lq + FS_FC * FS_LV); int64_t* st_qty = (int64_t*)(st_ptr + FS_FC * FS_LV);
+  int32_t* st_fr = (int32_t*)(st_qty + FS_FC); int32_t* st_plen = st_fr + FS_FC; int32_t* st_rb = st_plen + FS_FG;
   while (t >= 0) {
-    // one probe the walk's way: where the fill-back keeps most targets back (a search that removed far more than it needed) the probes
-    // succeed one after the other and an evaluation round per success would cost more than it saves
+    if (staged) {
+      const int nb = t + 1 < FS_FG ? t + 1 : FS_FG;
+      {
+        bool miss = false;
+        for (int c = lane; c < FS_FC; c += WAVE) {
+          const int rr = c / CS_RFR, u = c % CS_RFR;
+          if (rr < nb) { const int fr = S.fs_apply[(size_t)f.row0 + f.tpos[t - rr]].fr[u]; if (fr >= 0 && f.colslot[fr] < 0) miss = true; }
+        }
+        if (wballot(miss)) fs_ensure_w(f);
+      }
+      for (int c = lane; c < FS_FC; c += WAVE) {
+        const int rr = c / CS_RFR, u = c % CS_RFR;
+        const bool in = rr < nb;
+        const FsApply a = S.fs_apply[(size_t)f.row0 + f.tpos[in ? t - rr : t]];
+        const int fr = in ? (int)fs_sel4(a.fr, u) : -1;
+        int64_t lqv[FS_LV];
+        #pragma unroll
+        for (int i = 0; i < FS_LV; i++) lqv[i] = (fr >= 0 && i < (int)a.plen) ? S.fs_q[(size_t)(f.n0 + a.lp[i]) * f.nfr + fr].lq : 0;
+        #pragma unroll
+        for (int i = 0; i < FS_LV; i++) {
+          st_lq[c * FS_LV + i] = fs_cap(lqv[i]);
+          st_ptr[c * FS_LV + i] = (fr >= 0 && i < (int)a.plen) ? fs_cell(f, a.lp[i], fr) : 0;
+        }
+        st_qty[c] = fr >= 0 ? fs_sel4(a.qty, u) : 0;
+        st_fr[c] = fr;
+        if (u == 0 && in) { st_plen[rr] = a.plen; st_rb[rr] = 16 * (int)a.plen * (((int)a.cbytes - 32) / 12); }
+      }
+      wsync();
+      CSTAT(18, 1);   // staged fill-back rounds
+      bool failed = false;
+      int done = 0;
+      for (int rr = 0; rr < nb; rr++) {
+        const int rplen = st_plen[rr], rb = st_rb[rr];
+        for (int u = lane; u < CS_RFR; u += WAVE) {
+          const int c = rr * CS_RFR + u;
+          if (st_fr[c] >= 0) (void)fs_chain(f, st_ptr + c * FS_LV, st_lq + c * FS_LV, st_lq + c * FS_LV, rplen, st_qty[c], true, true);
+        }
+        wsync();
+        if (lane == 0) w.bytes += rb;
+        done = rr + 1;
+        if (fs_fits(f, false)) {
+          const int tt = t - rr;
+          if (lane == 0) { f.trow[tt] = f.trow[nt - 1]; f.treason[tt] = f.treason[nt - 1]; f.tpos[tt] = f.tpos[nt - 1]; }
+          nt--;
+          *tbytes -= rb;
+          wsync();
+          continue;
+        }
+        for (int u = lane; u < CS_RFR; u += WAVE) {
+          const int c = rr * CS_RFR + u;
+          if (st_fr[c] >= 0) (void)fs_chain(f, st_ptr + c * FS_LV, st_lq + c * FS_LV, st_lq + c * FS_LV, rplen, st_qty[c], false, true);
+        }
+        wsync();
+        if (lane == 0) w.bytes += rb;
+        failed = true;
+        break;
+      }
+      t -= done;
+      if (!failed) continue;
+    } else
+    // one probe the walk's way
     {
       const FsRow r = fs_row_load(f, f.tpos[t]);
       fs_row_ctx(f, r);
