@@ -13,7 +13,10 @@
  * Host side, as for include/kq_tas.h: topology trees, node feasibility (leaf_ok), level-key resolution per TAS flavor,
  * checkPodSetAndFlavorMatchForTAS (tas_flavorassigner.go:164 -> folded into kq_heads.ps_flavor_ok like taints and affinity).
  * A failed placement leaves a KQ_RSN_TAS_FAILURE reason record (kq_engine.h) when out->rsn_cap > 0.
- * Outside (KQ_EUNSUPPORTED or left to the caller): fair sharing together with TAS, a workload whose podsets land on more than one TAS
+ * With fair sharing (kq_config.fair_sharing) the entries are walked in the fair-sharing iterator's order — one iterator over every root
+ * tree (fair_sharing_iterator.go:47-263), the lowest ClusterQueue index still waiting naming the tree that pops next — and fair
+ * preemption's victim search (preemption.go:381-631) carries the leaf usage with the victims.
+ * Outside (KQ_EUNSUPPORTED or left to the caller): a workload whose podsets land on more than one TAS
  * flavor (TASHandleOverlappingFlavors), balanced placement, node replacement, workloads that hold a previous admission (second pass).
  */
 #ifndef KQ_CYCLE_TAS_H
@@ -72,7 +75,7 @@ typedef struct kq_cycle_tas_out {
  * and, optionally, the leaf usage after the cycle. t->adm_* is indexed by the admitted rows of the resident snapshot, t->ps_* by the
  * podsets of `h`. stats (optional, int64[4]): [0] placements computed, [1] TAS recomputations inside processEntry, [2] 1 when the cycle met a
  * workload outside the path (two TAS flavors), [3] placements of processEntry that started from a resident request-class table.
- * KQ_EUNSUPPORTED: fair sharing, or a workload with TAS requests on more than one TAS flavor. */
+ * KQ_EUNSUPPORTED: a workload with TAS requests on more than one TAS flavor. */
 int kq_cycle_run_tas(kq_engine* e, const kq_heads* h, const kq_cycle_tas* t, kq_decisions* out, kq_cycle_tas_out* tout, int64_t* stats);
 
 #ifdef __cplusplus

@@ -1372,7 +1372,9 @@ struct PG {  // a global plane
 };
 
 // snapshot.RemoveWorkload / AddWorkload or plain Remove/AddUsage of the row's usage: one lane per usage entry
-KQ_DEV void f_apply_row(const Search& s, int row, bool add, bool count) {
+// tas: the row's leaf usage follows on the search's private TAS plane (kq_cycle_run_tas under fair sharing; snapshot.RemoveWorkload /
+// AddWorkload carry Usage.TAS). The remove/add pair around ComputeTargetShareAfterRemoval cancels and leaves it alone.
+KQ_DEV void f_apply_row(const Search& s, int row, bool add, bool count, bool tas) {
   const DSnap& S = s.k->S;
   KQ_A0();
   int c = S.adm_cq[row];
@@ -1392,6 +1394,11 @@ KQ_DEV void f_apply_row(const Search& s, int row, bool add, bool count) {
   }
   wsync();
   if (count && lane_id() == 0) s.w->bytes += 16 * (int64_t)cplen * (e1 - e0);
+#ifdef KQ_TAS_CYCLE
+  if (tas && s.k->tc) tc_search_row(*s.k, *s.w, s.slot, row, add);
+#else
+  (void)tas;
+#endif
   KQ_AS(*s.k, 49);
 }
 // cq.SimulateUsageAddition(workloadUsage) / its revert (preemption.go:557, :690-695)
@@ -1414,7 +1421,12 @@ KQ_DEV bool f_fits(const Search& s) {
     if (w.s_qty[u] > i64max(0, available_of(S, w.path, w.plen, w.s_fr[u], uf))) bad = true;
   }
   if (lane_id() == 0) { int nu = 0; for (int u = 0; u < w.ns; u++) nu += w.s_inu[u] ? 1 : 0; w.bytes += 40 * (int64_t)w.plen * nu; }
+#ifdef KQ_TAS_CYCLE
+  if (wballot(bad) != 0) return false;
+  return s.k->tc ? tc_search_fits(*s.k, w, s.slot) : true;   // preemption.go:676-684: the placement on the leaf usage without the victims so far
+#else
   return wballot(bad) == 0;
+#endif
 }
 KQ_DEV bool f_fits_fs(const Search& s) {  // workloadFitsForFairSharing :690-695
   KQ_A0();
@@ -1707,7 +1719,7 @@ KQ_DEV void fair_search_walk(Search& s) {
     for (int cand = f_ordering_next(s); cand >= 0 && !fits; cand = fits ? -1 : f_ordering_next(s)) {
       if (cand == w.cq || within_nominal) {
         int row = f_pop(s, cand, 1, 0);
-        f_apply_row(s, row, false, true);
+        f_apply_row(s, row, false, true, true);
         if (!f_push_target(s, &nt, row, cand == w.cq ? KQ_REASON_IN_CLUSTER_QUEUE : KQ_REASON_IN_COHORT_RECLAMATION)) { w.ntgt = 0; return; }
         if (f_fits_fs(s)) fits = true;
         continue;
@@ -1723,12 +1735,12 @@ KQ_DEV void fair_search_walk(Search& s) {
       while (s.qcnt[li] > 0) {
         int row = f_pop(s, cand, 1, 0);
         // ComputeTargetShareAfterRemoval target.go:67-73
-        f_apply_row(s, row, false, false);
+        f_apply_row(s, row, false, false, false);
         DRSv tn = f_drs_uniform(s, at);
-        f_apply_row(s, row, true, false);
+        f_apply_row(s, row, true, false, false);
         bool pass = strategy0 == KQ_FS_LESS_THAN_OR_EQUAL_TO_FINAL_SHARE ? compare_drs(pn, tn) <= 0 : compare_drs(pn, to) < 0;  // strategy.go:41,46
         if (pass) {
-          f_apply_row(s, row, false, true);
+          f_apply_row(s, row, false, true, true);
           if (!f_push_target(s, &nt, row, KQ_REASON_IN_COHORT_FAIR_SHARING)) { w.ntgt = 0; return; }
           if (f_fits_fs(s)) fits = true;
           break;
@@ -1760,7 +1772,7 @@ KQ_DEV void fair_search_walk(Search& s) {
       bool passed = compare_drs(pn, to) < 0;
       int row = f_pop(s, cand, 2, 0);
       if (passed) {
-        f_apply_row(s, row, false, true);
+        f_apply_row(s, row, false, true, true);
         if (!f_push_target(s, &nt, row, KQ_REASON_IN_COHORT_FAIR_SHARING)) { w.ntgt = 0; return; }
         if (f_fits_fs(s)) fits = true;
       }
@@ -1774,7 +1786,7 @@ KQ_DEV void fair_search_walk(Search& s) {
     if (lane == 0)
       for (int t = 0; t < nt; t++) { int r = s.trow[t]; w.bytes += 16 * (int64_t)S.plen[S.adm_cq[r]] * (S.adm_use_off[r + 1] - S.adm_use_off[r]); }
     // restoreSnapshot :356 — the private copy is dropped, but callers read it: put the rows back
-    for (int t = 0; t < nt; t++) f_apply_row(s, s.trow[t], true, false);
+    for (int t = 0; t < nt; t++) f_apply_row(s, s.trow[t], true, false, true);
     w.ntgt = 0;
     KQ_TS(k, 45);  // fair search: restore after a failed search
     return;
@@ -1783,13 +1795,13 @@ KQ_DEV void fair_search_walk(Search& s) {
   // fillBackWorkloads :341-354 with allowBorrowing = true
   for (int t = nt - 2; t >= 0; t--) {
     int r = s.trow[t];
-    f_apply_row(s, r, true, true);
+    f_apply_row(s, r, true, true, true);
     if (f_fits(s)) {
       if (lane == 0) { s.trow[t] = s.trow[nt - 1]; s.treason[t] = s.treason[nt - 1]; }
       nt--;
       wsync();
     } else {
-      f_apply_row(s, r, false, true);
+      f_apply_row(s, r, false, true, true);
     }
   }
   w.ntgt = nt;

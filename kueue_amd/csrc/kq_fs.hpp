@@ -45,6 +45,10 @@ struct Fs {
   int64_t* td; int32_t* tp; double* tx; uint64_t* tout;   // staging of one row operation: borrowed-amount deltas / borrowed-cell count deltas per (flavor-resource, level), share terms per (level, resource), result
   int32_t* pc_ptr; int64_t *pc_lq, *pc_sq, *pc_sqb, *pc_bl, *pc_lend; double* pc_wt; int32_t* pc_u;
   int32_t* tpos;
+  // the first tcap targets (row, reason, position) live in what LDS the state left over: a target pushed or moved is then no global
+  // store, and every fence of the walk waits for the wave's outstanding global stores (fs_tget / fs_tset; flushed to trow / treason /
+  // tpos when the search ends)
+  int tcap; int32_t *lt_row, *lt_pos; uint8_t* lt_rs;
   // batch of one cohort's ClusterQueues (fs_batch_*): unsorted (child order) and sorted (visiting order) views, candidate list
   int16_t *bq_c, *bq_ord; uint64_t *bq_k, *bq_h; uint8_t* bq_z;
   int16_t *br_c, *br_ap, *br_at, *br_n, *br_off; uint8_t* br_fl;
@@ -65,6 +69,7 @@ KQ_DEV void fs_assume_lds(const Fs& f) {
   FS_LDS(f.pc_ptr); FS_LDS(f.pc_lq); FS_LDS(f.pc_sq); FS_LDS(f.pc_sqb); FS_LDS(f.pc_bl); FS_LDS(f.pc_lend); FS_LDS(f.pc_wt); FS_LDS(f.pc_u);
   FS_LDS(f.bq_c); FS_LDS(f.bq_ord); FS_LDS(f.bq_k); FS_LDS(f.bq_h); FS_LDS(f.bq_z); FS_LDS(f.br_c); FS_LDS(f.br_ap); FS_LDS(f.br_at); FS_LDS(f.br_n); FS_LDS(f.br_off);
   FS_LDS(f.br_fl); FS_LDS(f.cl_pos); FS_LDS(f.cl_rk);
+  if (f.tcap > 0) { FS_LDS(f.lt_row); FS_LDS(f.lt_pos); FS_LDS(f.lt_rs); }
   #undef FS_LDS
 #endif
   (void)f;
@@ -143,6 +148,19 @@ KQ_DEV int fs_cell(const Fs& f, int li, int fr) {
 }
 KQ_DEV int64_t fs_ld(const Fs& f, int code) { return code >= 0 ? f.col[code] : f.W[~code]; }
 KQ_DEV void fs_st(const Fs& f, int code, int64_t v) { if (code >= 0) f.col[code] = v; else f.W[~code] = v; }
+struct FsTgt { int32_t row, pos; uint8_t reason; };
+KQ_DEV FsTgt fs_tget(const Fs& f, int i) { return i < f.tcap ? FsTgt{f.lt_row[i], f.lt_pos[i], f.lt_rs[i]} : FsTgt{f.trow[i], f.tpos[i], f.treason[i]}; }
+KQ_DEV int fs_tpos(const Fs& f, int i) { return i < f.tcap ? f.lt_pos[i] : f.tpos[i]; }
+KQ_DEV void fs_tset(const Fs& f, int i, const FsTgt& t) {
+  if (i < f.tcap) { f.lt_row[i] = t.row; f.lt_pos[i] = t.pos; f.lt_rs[i] = t.reason; }
+  else { f.trow[i] = t.row; f.tpos[i] = t.pos; f.treason[i] = t.reason; }
+}
+// the search is over: the nt targets it keeps, where the callers read them
+KQ_DEV void fs_tflush(const Fs& f, int nt) {
+  const int m = nt < f.tcap ? nt : f.tcap;
+  for (int i = lane_id(); i < m; i += WAVE) { f.trow[i] = f.lt_row[i]; f.treason[i] = f.lt_rs[i]; }
+  wsync();
+}
 // the private HBM plane serves the columns that are not cached: copied from the search's starting state on first use
 KQ_DEV void fs_ensure_w(Fs& f) {
   if (f.wcopied) return;
@@ -528,7 +546,7 @@ KQ_DEV int fs_pop(const Fs& f, int li, uint64_t* from, uint64_t* to) {
 }
 KQ_DEV bool fs_push_target(Fs& f, int* nt, int row, int p, int reason) {
   if (*nt >= f.k->X.tgt_cap) { set_error(*f.k, KQ_ECAPACITY); return false; }
-  if (lane_id() == 0) { f.trow[*nt] = row; f.treason[*nt] = (uint8_t)reason; f.tpos[*nt] = p; }  // read back after later fences only
+  if (lane_id() == 0) fs_tset(f, *nt, FsTgt{row, p, (uint8_t)reason});  // read back after later fences only
   (*nt)++;
   return true;
 }
@@ -605,6 +623,16 @@ KQ_DEV bool fs_setup(Search& s, Fs& f) {
   f.br_c = (int16_t*)cv.take(FS_BQ * 2); f.br_ap = (int16_t*)cv.take(FS_BQ * 2); f.br_at = (int16_t*)cv.take(FS_BQ * 2); f.br_n = (int16_t*)cv.take(FS_BQ * 2);
   f.br_off = (int16_t*)cv.take((FS_BQ + 1) * 2); f.br_fl = (uint8_t*)cv.take(FS_BQ);
   f.cl_pos = (int32_t*)cv.take(FS_BC * 4); f.cl_rk = (uint8_t*)cv.take(FS_BC);
+  f.tcap = 0; f.lt_row = nullptr; f.lt_pos = nullptr; f.lt_rs = nullptr;
+  if (all_lds) {
+    const size_t left = (size_t)(cv.ae - cv.a);
+    int cap = (int)(left / 9) & ~15;
+    if (cap > 4096) cap = 4096;
+#ifdef KQ_HOST_EMU
+    if ((w.h & 1) && cap > 64) cap = 64;   // (tests: lists that straddle the LDS part and the global part)
+#endif
+    if (cap >= 64) { f.tcap = cap; f.lt_row = (int32_t*)cv.take((size_t)cap * 4); f.lt_pos = (int32_t*)cv.take((size_t)cap * 4); f.lt_rs = (uint8_t*)cv.take(cap); }
+  }
   fs_assume_lds(f);
   for (int i = lane; i < f.nfr; i += WAVE) f.colslot[i] = -1;
   wsync();
@@ -1051,14 +1079,14 @@ KQ_DEV int fs_fillback_batch(Fs& f, int nt, int64_t* tbytes) {
         bool miss = false;
         for (int c = lane; c < FS_FC; c += WAVE) {
           const int rr = c / CS_RFR, u = c % CS_RFR;
-          if (rr < nb) { const int fr = S.fs_apply[(size_t)f.row0 + f.tpos[t - rr]].fr[u]; if (fr >= 0 && f.colslot[fr] < 0) miss = true; }
+          if (rr < nb) { const int fr = S.fs_apply[(size_t)f.row0 + fs_tpos(f, t - rr)].fr[u]; if (fr >= 0 && f.colslot[fr] < 0) miss = true; }
         }
         if (wballot(miss)) fs_ensure_w(f);
       }
       for (int c = lane; c < FS_FC; c += WAVE) {
         const int rr = c / CS_RFR, u = c % CS_RFR;
         const bool in = rr < nb;
-        const FsApply a = S.fs_apply[(size_t)f.row0 + f.tpos[in ? t - rr : t]];
+        const FsApply a = S.fs_apply[(size_t)f.row0 + fs_tpos(f, in ? t - rr : t)];
         const int fr = in ? (int)fs_sel4(a.fr, u) : -1;
         int64_t lqv[FS_LV];
         #pragma unroll
@@ -1087,7 +1115,7 @@ KQ_DEV int fs_fillback_batch(Fs& f, int nt, int64_t* tbytes) {
         done = rr + 1;
         if (fs_fits(f, false)) {
           const int tt = t - rr;
-          if (lane == 0) { f.trow[tt] = f.trow[nt - 1]; f.treason[tt] = f.treason[nt - 1]; f.tpos[tt] = f.tpos[nt - 1]; }
+          if (lane == 0) fs_tset(f, tt, fs_tget(f, nt - 1));
           nt--;
           *tbytes -= rb;
           wsync();
@@ -1107,11 +1135,11 @@ KQ_DEV int fs_fillback_batch(Fs& f, int nt, int64_t* tbytes) {
     } else
     // one probe the walk's way
     {
-      const FsRow r = fs_row_load(f, f.tpos[t]);
+      const FsRow r = fs_row_load(f, fs_tpos(f, t));
       fs_row_ctx(f, r);
       fs_row_apply(f, r, true, true, true);
       if (fs_fits(f, false)) {
-        if (lane == 0) { f.trow[t] = f.trow[nt - 1]; f.treason[t] = f.treason[nt - 1]; f.tpos[t] = f.tpos[nt - 1]; }
+        if (lane == 0) fs_tset(f, t, fs_tget(f, nt - 1));
         nt--;
         *tbytes -= r.rowbytes;
         wsync();
@@ -1125,7 +1153,7 @@ KQ_DEV int fs_fillback_batch(Fs& f, int nt, int64_t* tbytes) {
     while (t >= 0) {
       const int tt = t - lane;
       const bool in = tt >= 0;
-      const int p = in ? f.tpos[tt] : f.tpos[0];
+      const int p = fs_tpos(f, in ? tt : 0);
       const FsApply a = S.fs_apply[(size_t)f.row0 + p];
       bool miss = false;
       #pragma unroll
@@ -1401,7 +1429,7 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
     // restoreSnapshot :356 — the private copy is dropped, but callers read it on the preemptor's path. With every row back the state is
     // the one the search started from (plain amounts: usage is a function of the SET of rows present), so nothing is walked back.
     if (k.C.fs_batch & 8) as_started = true;
-    else for (int t = 0; t < nt; t++) { const FsRow r = fs_row_load(f, f.tpos[t]); fs_row_ctx(f, r); fs_row_apply(f, r, true, true, false); }
+    else for (int t = 0; t < nt; t++) { const FsRow r = fs_row_load(f, fs_tpos(f, t)); fs_row_ctx(f, r); fs_row_apply(f, r, true, true, false); }
     w.ntgt = 0;
     KQ_TS(k, 45);
   } else {
@@ -1410,11 +1438,11 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
     if (k.C.fs_batch & 4) nt = fs_fillback_batch(f, nt, &tbytes);
     else
     for (int t = nt - 2; t >= 0; t--) {
-      const FsRow r = fs_row_load(f, f.tpos[t]);
+      const FsRow r = fs_row_load(f, fs_tpos(f, t));
       fs_row_ctx(f, r);
       fs_row_apply(f, r, true, true, true);
       if (fs_fits(f, false)) {
-        if (lane == 0) { f.trow[t] = f.trow[nt - 1]; f.treason[t] = f.treason[nt - 1]; f.tpos[t] = f.tpos[nt - 1]; }
+        if (lane == 0) fs_tset(f, t, fs_tget(f, nt - 1));
         nt--;
         tbytes -= r.rowbytes;
         wsync();
@@ -1423,6 +1451,7 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
       }
     }
     w.ntgt = nt;
+    fs_tflush(f, nt);
     if (lane == 0) w.bytes += tbytes;
     KQ_TS(k, 46);
   }

@@ -922,7 +922,6 @@ template <class B> struct EngineT {
   int cycle_run_tas(const kq_heads* h, const kq_cycle_tas* t, kq_decisions* out, kq_cycle_tas_out* tout, int64_t* stats) {
     if (!have_snapshot) return fail(KQ_EINVAL, "kq_cycle_run_tas before kq_snapshot_put");
     if (!t || !tout || !tout->ps_tas || !tout->dom_off) return fail(KQ_EINVAL, "null kq_cycle_tas / kq_cycle_tas_out");
-    if (cfg.fair_sharing) return fail(KQ_EUNSUPPORTED, "TAS inside a fair-sharing cycle is outside this entry point");
     if (t->n_tas < 0) return fail(KQ_EINVAL, "negative n_tas");
     shard_heads_ok = false;
     int rc = heads_put(h, 0);
@@ -1192,7 +1191,7 @@ template <class B> struct EngineT {
     k.C.fs_plain = (prep.fs_plain && hbch.plain && prep.nR <= KQ_MAXR && !force_exact_drs) ? 1 : 0;
     // scan-formulated classical search: usage and admitted quantities must be plain (its prefix sums are ordinary additions)
     k.C.cs_on = (!cfg.fair_sharing && prep.any_preemption && prep.fs_plain && !cs_disable) ? 1 : 0;
-    k.C.fs_on = (cfg.fair_sharing && prep.any_preemption && prep.fs_plain && !fs_disable) ? 1 : 0;
+    k.C.fs_on = (cfg.fair_sharing && prep.any_preemption && prep.fs_plain && !fs_disable && !d_tc) ? 1 : 0;   // (a TAS cycle's searches carry leaf usage: the walk)
     k.C.fs_batch = fs_batch_bits;
     k.C.cs_lazy = cs_lazy_mode;
     k.C.fs_lrun = fs_lrun_on ? 1 : 0;
@@ -1380,11 +1379,11 @@ template <class B> struct EngineT {
     be.timer_mark(2);
     k.O.stat_bytes = (long long*)(misc + 2);
     if (nominate_only) {}
+    else if (d_tc) { if (tas_n_cls > 0) be.launch_tas_cycle_classes(d_tc, tas_n_cls); be.launch_process_tas(k); }   // one wave, every tree, entry order (fair sharing: the iterators of the trees interleaved): TAS leaves are shared across root cohorts
     else if (cfg.fair_sharing) {
       if (n_help > 0) { k.help = d_help; k.help_quit = (uint32_t*)(d_help + prep.n_tree); k.help_trees = prep.n_tree; }
       be.launch_process_fair(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16, fs_want, rank);
     }
-    else if (d_tc) { if (tas_n_cls > 0) be.launch_tas_cycle_classes(d_tc, tas_n_cls); be.launch_process_tas(k); }   // one wave, every tree, entry order: TAS leaves are shared across root cohorts
     else be.launch_process(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16);
     be.timer_mark(3);
     last_cycle_n = -1;  // set on the success path only: a failed cycle must not be committable

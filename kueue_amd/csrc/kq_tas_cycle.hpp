@@ -675,6 +675,151 @@ KQ_NOINLINE void process_entry_tas(const K& k, Wave& w, int e, int pos, int slot
   KQ_TS(k, 44);   // usage added, result written
 }
 
+// k_process_tas under fair sharing: ONE wave plays the fair-sharing iterator (fair_sharing_iterator.go:47-263) of every root tree,
+// interleaved the way the reference's single iterator does — with the canonical getCq the lowest ClusterQueue
+// index still in the map names the tree that pops next. TAS leaves are shared across root cohorts (snapshot.go:260), so the trees cannot
+// run side by side as they do in k_process_fair. Per-tree iterator state lives in the scratch rows of slot = tree, exactly as there:
+// cqToEntry, the cached tournament keys with their stale levels and costs, the cohort winners. Same pops, same byte count.
+KQ_DEV void process_all_fair_tas(const K& k, Wave& w, int slot) {
+  const DSnap& S = k.S; const DOut& O = k.O; const DHeads& H = k.H;
+  const int lane = lane_id();
+  const int n = hn(H);
+  const bool want_bon = gate(k, KQ_GATE_FS_PRIORITIZE_NON_BORROWING);
+  const bool fs_plain = fs_plain_now(k);
+  auto ents = [&](int t) { return k.X.cq_ent + (size_t)t * k.X.max_tree_cqs; };
+  for (int t = 0; t < S.n_tree; t++) {
+    const int nqs = S.tree_cq_off[t + 1] - S.tree_cq_off[t], nn = S.tree_node_off[t + 1] - S.tree_node_off[t];
+    int32_t* cq_ent = ents(t);
+    uint8_t* stale = k.X.fs_stale + (size_t)t * k.X.max_tree_cqs;
+    int32_t* cost = k.X.fs_cost + (size_t)t * k.X.max_tree_cqs * KQ_MAXD;
+    int32_t* win = k.X.fs_win + (size_t)t * k.X.max_tree_nodes;
+    for (int i = lane; i < nqs; i += WAVE) { cq_ent[i] = -1; stale[i] = 0; }
+    for (int i = lane; i < nqs * KQ_MAXD; i += WAVE) cost[i] = 0;
+    for (int i = lane; i < nn; i += WAVE) win[i] = -1;
+    if (lane == 0) { k.X.fs_sum[t] = 0; int32_t* ctl = k.X.fs_ctl + (size_t)t * 4; ctl[0] = 0; ctl[1] = -1; ctl[2] = 0; ctl[3] = 0; }
+  }
+  wsync();
+  // cqToEntry: the last head of a CQ wins (:58-60)
+  for (int h = lane; h < n; h += WAVE) { const int c = H.cq[h]; atomic_max_i32(&ents(S.tree_of[c])[S.cq_local[c]], h); }
+  wsync();
+  int cur = -1, pos = 0;
+  for (int c = 0; c < S.nq;) {
+    const int t = S.tree_of[c];
+    int32_t* cq_ent = ents(t);
+    if (cq_ent[S.cq_local[c]] < 0) { c++; continue; }   // getCq: the lowest ClusterQueue index still in the map
+    if (t != cur) { tc_tree_switch(k, w, cur, t); cur = t; }
+    const int q0 = S.tree_cq_off[t], nqs = S.tree_cq_off[t + 1] - q0;
+    const int n0 = S.tree_node_off[t], nn = S.tree_node_off[t + 1] - n0;
+    if (nn == 1) {  // ClusterQueue without Cohort: its workload is simply returned (:71-78)
+      const int e = cq_ent[0];
+      wsync();
+      if (lane == 0) cq_ent[0] = -1;
+      wsync();
+      process_entry_tas(k, w, e, pos++, slot, t);
+      continue;
+    }
+    int32_t* win = k.X.fs_win + (size_t)t * k.X.max_tree_nodes;
+    uint64_t* fkeys = k.X.fs_keys + (size_t)t * k.X.max_tree_cqs * KQ_MAXD * 4;
+    uint8_t* stale = k.X.fs_stale + (size_t)t * k.X.max_tree_cqs;
+    int32_t* cost = k.X.fs_cost + (size_t)t * k.X.max_tree_cqs * KQ_MAXD;
+    long long* sum = k.X.fs_sum + t;
+    int32_t* ctl = k.X.fs_ctl + (size_t)t * 4;
+    // ---- computeDRS (:227-263): the levels of every remaining entry that the tree's last pop made stale ----
+    {
+      const int xc = ctl[1];
+      const bool changed = ctl[2] != 0;
+      int64_t delta = 0;
+      for (int i = lane; i < nqs; i += WAVE) {
+        const int en = cq_ent[i];
+        if (en < 0) continue;
+        const int cq = S.tree_cqs[q0 + i];
+        const int32_t* path = S.path + (size_t)cq * KQ_MAXD;
+        const int plen = S.plen[cq];
+        int from = stale[i];
+        if (changed) {  // lowest level of this path that is also on the popped entry's path
+          const int32_t* xp = S.path + (size_t)xc * KQ_MAXD;
+          const int xl = S.plen[xc];
+          int tt = 0;
+          while (tt < plen - 1 && tt < xl - 1 && path[plen - 1 - tt - 1] == xp[xl - 1 - tt - 1]) tt++;
+          const int lvl = plen - 1 - tt;
+          if (lvl < from) from = lvl;
+        }
+        if (from + 1 >= plen) { if (from != 255) stale[i] = 255; continue; }
+        PE pe{&k, &w, path, 0, O.use_fr + (size_t)en * KQ_MAXU, O.use_qty + (size_t)en * KQ_MAXU,
+              (H.flags[en] & KQ_HEAD_HAS_QUOTA_RESERVATION) ? 0 : O.use_n[en]};  // netUsage scheduler.go:785-794
+        for (int l = from; l + 1 < plen; l++) {
+          pe.level = l;
+          int64_t lb = 0;
+          DRSv d = fs_plain ? drs_entry_level(k, w, path, l, pe.ufr, pe.uqty, pe.nu, want_bon, &lb)
+                            : drs_of(S, path[l], pe, &lb, pe.ufr, pe.uqty, want_bon ? pe.nu : 0);
+          const size_t o = (size_t)i * KQ_MAXD + l;
+          const FsKey key = fs_make_key(k, en, d);
+          fkeys[o * 4 + 0] = key.k1; fkeys[o * 4 + 1] = key.k2; fkeys[o * 4 + 2] = key.k3; fkeys[o * 4 + 3] = key.k4;
+          delta += lb - cost[o];
+          cost[o] = (int32_t)lb;
+        }
+        stale[i] = 255;
+      }
+      const int64_t tot = wsum_i64(delta);
+      if (lane == 0 && tot) *sum += tot;
+      wsync();
+    }
+    // ---- the tournaments (:125-163): all of them at the tree's first pop, afterwards the cohorts on the last popped entry's path ----
+    if (!ctl[3]) {
+      for (int d = KQ_MAXD - 1; d >= 0; d--)
+        for (int i = nqs; i < nn; i++) {
+          const int x = S.tree_nodes[n0 + i];
+          if (S.depth[x] != d) continue;
+          const int b = tournament_cohort(k, t, x, win, cq_ent);
+          if (lane == 0) win[i] = b;
+          wsync();
+        }
+    } else {
+      const int xc = ctl[1];
+      for (int l = 1; l < S.plen[xc]; l++) {
+        const int x = S.path[(size_t)xc * KQ_MAXD + l];
+        const int b = tournament_cohort(k, t, x, win, cq_ent);
+        if (lane == 0) win[S.node_local[x]] = b;
+        wsync();
+      }
+    }
+    const int root = S.path[(size_t)S.tree_cqs[q0] * KQ_MAXD + S.plen[S.tree_cqs[q0]] - 1];
+    const int e = win[S.node_local[root]];
+    const int ec = H.cq[e], ei = S.cq_local[ec];
+    wsync();
+    if (lane == 0) {
+      atomic_add_i64(O.stat_bytes, *sum);  // the reference evaluates every remaining (entry, level) on every pop
+      long long mine = 0;
+      for (int l = 0; l + 1 < S.plen[ec]; l++) mine += cost[(size_t)ei * KQ_MAXD + l];
+      *sum -= mine;
+      cq_ent[ei] = -1;
+      w.usage_dirty = 0;
+    }
+    wsync();
+    process_entry_tas(k, w, e, pos++, slot, t);
+    if (fs_plain && w.usage_dirty) {  // the rows of the popped entry's path changed: refresh their sums
+      const int pl = S.plen[ec];
+      PW pw{&k, &w};
+      for (int j = lane; j < pl * S.nR; j += WAVE) {
+        const int nd = S.path[(size_t)ec * KQ_MAXD + j / S.nR], r = j % S.nR;
+        int64_t sm; int ps;
+        node_sums(S, nd, pw, r, &sm, &ps);
+        k.X.bs_sum[(size_t)nd * S.nR + r] = sm;
+        w.cell_borrow[j] = ps;
+      }
+      wsync();
+      for (int j = lane; j < pl; j += WAVE) {
+        int ps = 0;
+        for (int r = 0; r < S.nR; r++) ps += w.cell_borrow[j * S.nR + r];
+        k.X.bs_pos[S.path[(size_t)ec * KQ_MAXD + j]] = ps;
+      }
+      wsync();
+    }
+    if (lane == 0) { ctl[1] = ec; ctl[2] = w.usage_dirty; ctl[3] = 1; }
+    wsync();
+  }
+}
+
 // k_process_tas: one wave walks every entry in iterator order
 KQ_DEV void process_all_tas(const K& k, Wave& w, int slot, TLeafJob* mail) {
   const int n = hn(k.H);
@@ -684,6 +829,7 @@ KQ_DEV void process_all_tas(const K& k, Wave& w, int slot, TLeafJob* mail) {
     w.cs_lds = nullptr; w.cs_lds_bytes = 0; w.help_on = 0; w.mono_break = 0; w.ta.plane = 1; w.ta.srch = 0;
   }
   wsync();
+  if (k.C.fair_sharing) { process_all_fair_tas(k, w, slot); return; }
   int cur = -1;
   for (int i = 0; i < n; i++) {
     const int e = k.order_idx[i];

@@ -125,24 +125,34 @@ def test_without_tas_flavors_it_is_the_plain_cycle_emulated(oracle, seed):
     assert (out.a["ps_tas"][:heads.n_ps] == -1).all()
 
 
-def test_fair_sharing_is_refused(oracle):
-    cfg, snap, heads, ct, _ = random_tas_cycle_case(4, fair=True, tight=False, preemption=False)
+def _random_fair(oracle, make, seed):
+    """TAS inside a fair-sharing cycle: the fair iterator over every root tree interleaved (kq_tas_cycle.hpp process_all_fair_tas), fair
+    preemption with the leaf usage following the victims (f_apply_row / f_fits hooks)."""
+    cfg, snap, heads, ct, _ = random_tas_cycle_case(seed, fair=True, tight=seed % 2 == 0, preemption=seed % 3 != 0, partial=seed % 7 == 0)
     oracle.derive(snap)
-    eng = _emu(cfg)
-    eng.put(snap)
-    got, _ = eng.run_tas(heads, ct)
-    eng.close()
-    assert got.rc == -4   # KQ_EUNSUPPORTED
+    return _same(oracle, make, cfg, snap, heads, ct, tgt_cap=max(16, snap.n_adm))
 
 
-def _population(oracle, make, n_cq, n_pending, **topo):
+@pytest.mark.parametrize("seed", range(900))
+def test_random_fair_tas_cycles_emulated(oracle, seed):
+    _random_fair(oracle, _emu, 5000 + seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", range(6))
+def test_random_fair_tas_cycles_gpu(oracle, block):
+    for seed in range(block * 100, block * 100 + 100):
+        _random_fair(oracle, _hip, 5000 + seed)
+
+
+def _population(oracle, make, n_cq, n_pending, fair=False, **topo):
     """BASELINE configs[4] as whole cycles (kueue_amd/tas_population.py generate_tas_cycle): one TAS flavor shared by every ClusterQueue, so
     most entries lose their leaves to an earlier entry and are recomputed inside processEntry — the path of the resident request-class
     tables (kq_tas_cycle.hpp) and of their incremental update after every AddUsage."""
     from kueue_amd.api import make_config
     from kueue_amd.tas_population import generate_tas_cycle
     snap, _, batch = generate_tas_cycle(n_cq=n_cq, n_pending=n_pending, **topo)
-    cfg = make_config()
+    cfg = make_config(fair_sharing=fair)
     oracle.derive(snap)
     rec = 0
     for c in range((n_pending + n_cq - 1) // n_cq):
@@ -171,6 +181,21 @@ def test_tas_cycle_population_gpu(oracle, classes_off, monkeypatch):
     rec, hits = _population(oracle, _hip, 400, 800)
     assert rec > 300
     assert (hits == 0) if classes_off else (hits >= rec)
+
+
+def test_fair_tas_cycle_population_emulated(oracle):
+    """The same population under fair sharing: ten root trees whose iterators are interleaved by the canonical getCq, the recomputation
+    chain over the shared leaves."""
+    _LAST.clear()
+    rec, _ = _population(oracle, _emu, 120, 360, fair=True, blocks=2, racks=4, hosts=16)
+    assert rec > 100
+
+
+@pytest.mark.gpu
+def test_fair_tas_cycle_population_gpu(oracle):
+    _LAST.clear()
+    rec, _ = _population(oracle, _hip, 400, 800, fair=True)
+    assert rec > 300
 
 
 def test_dom_cap_too_small_is_reported(oracle):
