@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3-batch", "cfg3-split", "cfg4c-split", "cfg4f-split", "cfg4c", "cfg3f", "cfg4f", "cfg5", "cfg5-split", "cfg5-cycle"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3-batch", "cfg3-split", "cfg4c-split", "cfg4f-split", "cfg4c", "cfg3f", "cfg4f", "cfg5", "cfg5-split", "cfg5-cycle", "cfg5f-cycle"],
                     help="cfg3 = BASELINE.json configs[2] (100k pending, 1k CQ, 16 flavors, 3-level cohorts); "
                          "cfg4c = configs[3] population under classical preemption; cfg4f = configs[3] as quoted "
                          "(fair sharing + preemption); cfg3f = configs[2] population under fair sharing; cfg5 = configs[4] "
@@ -76,7 +76,7 @@ def main():
         return bench_tas(args, torch, dist, world, rank, local_rank)
     if args.workload == "cfg5-split":
         return bench_tas_split(args, torch, dist, world, rank, local_rank)
-    if args.workload == "cfg5-cycle":
+    if args.workload in ("cfg5-cycle", "cfg5f-cycle"):
         return bench_tas_cycle(args, torch, dist, world, rank, local_rank)
     if args.workload == "cfg3-batch":
         return bench_batch(args, torch, dist, world, rank, local_rank)
@@ -197,7 +197,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(pop, kcfg, args.cpu_seconds, closed, args.hold)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 
@@ -641,7 +641,7 @@ def bench_pending(args, torch, dist, world, rank, local_rank):
             out["cpu_baseline"] = cpu_baseline_pending(pop, kcfg, args.cpu_seconds, args.hold)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 
@@ -780,7 +780,7 @@ def bench_split(args, torch, dist, world, rank, local_rank):
                     ok = np.array_equal(a[k][:m], b[k][:m]) if k in ("tgt_adm", "tgt_reason") else np.array_equal(a[k], b[k])
                     verified = verified and bool(ok)
         ref.close()
-        print(json.dumps({
+        emit({
             "metric": "admission-decisions/sec + p99 schedule-cycle ms @ 100k pending, 1k CQ",
             "value": dec / elapsed, "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -795,7 +795,7 @@ def bench_split(args, torch, dist, world, rank, local_rank):
                       "ratio_to_plain": (elapsed / args.steps * 1e3) / plain_ms if plain_ms else None},
             "parity_checked": verified,
             "parity": "every decision field of every cycle and the resident usage at the end equal a plain engine's kq_cycle_run loop" if verified is not None else "skipped",
-            "roofline": None, "cpu_baseline": None}))
+            "roofline": None, "cpu_baseline": None})
     eng.close()
     if world > 1:
         dist.destroy_process_group()
@@ -870,7 +870,7 @@ def bench_batch(args, torch, dist, world, rank, local_rank):
         res["cpu_baseline"] = None if args.no_cpu_baseline else {
             "value": heads.n / dt, "unit": "decisions/s", "cores": 1, "kind": "port",
             "sample": f"the same {heads.n} nominations, C++ restatement of the Go path, host nproc={os.cpu_count()}"}
-        print(json.dumps(res))
+        emit(res)
     if world > 1:
         dist.destroy_process_group()
 
@@ -946,7 +946,7 @@ def bench_tas_split(args, torch, dist, world, rank, local_rank):
         verified = bool(np.array_equal(ref.read_usage(), eng.read_usage()))
         ref.close()
     if rank == 0:
-        print(json.dumps({
+        emit({
             "metric": "admission-decisions/sec + p99 schedule-cycle ms @ 100k pending, 1k CQ",
             "value": dec / elapsed, "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -959,7 +959,7 @@ def bench_tas_split(args, torch, dist, world, rank, local_rank):
             "admitted_per_cycle": n_adm / max(args.steps, 1), "split_stats": sp.stats,
             "end_state_equals_single_engine": verified,
             "roofline": None, "cpu_baseline": None,
-        }))
+        })
     eng.close()
     if world > 1:
         dist.destroy_process_group()
@@ -1034,7 +1034,7 @@ def bench_tas(args, torch, dist, world, rank, local_rank):
                                    "sample": f"first {n_s} workloads of the same batch, C++ restatement of FindTopologyAssignmentsForFlavor, host nproc={os.cpu_count()}"}
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res))
+        emit(res)
     if world > 1:
         dist.destroy_process_group()
 
@@ -1050,29 +1050,34 @@ def bench_tas_cycle(args, torch, dist, world, rank, local_rank):
     from kueue_amd.engine import Engine
     from kueue_amd.tas_population import TAS_SEED, generate_tas_cycle
     n_cq = args.tas_cycle
-    n_pending = max(n_cq, min(args.tas_batch, n_cq * (args.steps + args.warmup)))
+    fair = args.workload == "cfg5f-cycle"   # the same population under fair sharing: the trees' fair iterators interleaved, fair preemption
+    n_pending = max(n_cq, args.tas_batch)   # configs[4]: 50k pending workloads (the cycles of a run take the first batches of them)
     snap, topos, batch = generate_tas_cycle(n_cq=n_cq, n_pending=n_pending, seed=TAS_SEED + 1000 * rank)
-    cfg = make_config()
+    cfg = make_config(fair_sharing=fair)
     snap.derive()   # SubtreeQuota / cohort usage on the host, as the Go cache holds them before Snapshot() (kueue_amd/api.py)
     eng = Engine(cfg)
     eng.put(snap)
-    nb = (n_pending + n_cq - 1) // n_cq
+    nb = min((n_pending + n_cq - 1) // n_cq, max(args.steps + args.warmup, 5))
     batches = [batch(c) for c in range(nb)]
     topo = topos["tas-flavor"]
     parity = None
     if rank == 0 and not args.no_parity_gate:
         from oracle import kqo   # the checker: parity gate here, cpu_baseline below — never inside the timed region
-        h0, c0 = batches[0]
-        want, wout = kqo.cycle_run_tas(cfg, snap, h0, c0)
-        got, gout = eng.run_tas(h0, c0)
-        bad = want.equal(got)
-        m = int(wout.a["dom_off"][h0.n_ps])
-        same = (not bad and np.array_equal(wout.a["ps_tas"][:h0.n_ps], gout.a["ps_tas"][:h0.n_ps]) and np.array_equal(wout.a["dom_off"], gout.a["dom_off"]) and
-                np.array_equal(wout.a["dom_leaf"][:m], gout.a["dom_leaf"][:m]) and np.array_equal(wout.a["dom_count"][:m], gout.a["dom_count"][:m]) and
-                np.array_equal(wout.a["tas_usage_after"], gout.a["tas_usage_after"]))
-        if not same:
-            raise SystemExit(f"cfg5-cycle: the engine's first cycle differs from the oracle's ({bad})")
-        parity = f"cycle 0: {h0.n} decisions, every TopologyAssignment and the leaf usage after the cycle equal the oracle's"
+        gated = min(nb, 5)
+        ndec = 0
+        for c in range(gated):
+            h0, c0 = batches[c]
+            want, wout = kqo.cycle_run_tas(cfg, snap, h0, c0)
+            got, gout = eng.run_tas(h0, c0)
+            bad = want.equal(got)
+            m = int(wout.a["dom_off"][h0.n_ps])
+            same = (not bad and np.array_equal(wout.a["ps_tas"][:h0.n_ps], gout.a["ps_tas"][:h0.n_ps]) and np.array_equal(wout.a["dom_off"], gout.a["dom_off"]) and
+                    np.array_equal(wout.a["dom_leaf"][:m], gout.a["dom_leaf"][:m]) and np.array_equal(wout.a["dom_count"][:m], gout.a["dom_count"][:m]) and
+                    np.array_equal(wout.a["tas_usage_after"], gout.a["tas_usage_after"]))
+            if not same:
+                raise SystemExit(f"{args.workload}: cycle {c} of the engine differs from the oracle's ({bad})")
+            ndec += h0.n
+        parity = f"cycles 0..{gated - 1}: {ndec} decisions, every TopologyAssignment and the leaf usage after each cycle equal the oracle's"
     phases = np.zeros(3, np.float64)
     import ctypes as C
 
@@ -1119,7 +1124,7 @@ def bench_tas_cycle(args, torch, dist, world, rank, local_rank):
             "value": decf / elapsed, "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
-            "config": {"workload": f"cfg5-cycle: TAS inside the scheduling cycle, {snap.n_cq} ClusterQueues in {snap.n_cohort} cohorts, one TAS flavor of {topo.n_leaves} leaves "
+            "config": {"workload": f"{args.workload}: TAS inside the scheduling cycle{' under fair sharing' if fair else ''}, {snap.n_cq} ClusterQueues in {snap.n_cohort} cohorts, one TAS flavor of {topo.n_leaves} leaves "
                                    f"(8 blocks x 8 racks x 64 hosts, {R} resources) shared by all of them + one ordinary flavor, {n_pending} pending workloads, one head per ClusterQueue per cycle",
                        "decision": "one head through flavor assignment, TAS placement, the entry-order walk (quota + leaf capacity) and its recomputation",
                        "loop": "open loop: the next batch of heads every step against the same cycle-start snapshot; heads and TAS side uploaded every step",
@@ -1128,7 +1133,7 @@ def bench_tas_cycle(args, torch, dist, world, rank, local_rank):
             "kernel_ms_per_cycle": {n: float(v) / args.steps for n, v in zip(names, ph)},
             "per_cycle": {"admitted": admitted / args.steps, "placements": finds / args.steps, "tas_recomputations": recomputes / args.steps},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "algorithmic_bytes_per_launch": abytes, "traffic": pmc_traffic("cfg5-cycle", names[dom]),
+                         "algorithmic_bytes_per_launch": abytes, "traffic": pmc_traffic(args.workload, names[dom]),
                          "note": "all three intervals of the cycle; the placements' bytes are the reference's phase-1 accounting per FindTopologyAssignmentsForFlavor call"},
             "parity_checked": parity is not None, "parity": parity,
         }
@@ -1147,7 +1152,7 @@ def bench_tas_cycle(args, torch, dist, world, rank, local_rank):
                                    "sample": f"the first {nd} heads of the same cycles, C++ restatement of the cycle with TAS (kqo_cycle_run_tas), host nproc={os.cpu_count()}"}
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res))
+        emit(res)
     eng.close()
     if world > 1:
         dist.destroy_process_group()
@@ -1156,6 +1161,16 @@ def bench_tas_cycle(args, torch, dist, world, rank, local_rank):
 def F_ptr(a):
     from kueue_amd import _ffi as F
     return F.ptr(a)
+
+
+def emit(res):
+    """The one JSON line. roofline.traffic is not measured inside this run (PMC counters need their own rocprofv3 passes): say where it
+    comes from."""
+    rf = res.get("roofline")
+    if isinstance(rf, dict):
+        rf["traffic_source"] = ("replayed from profiles/pmc_traffic_<workload>.json: separate rocprofv3 --pmc passes of this same command, not this run"
+                                if rf.get("traffic") is not None else "none committed for this workload")
+    print(json.dumps(res))
 
 
 def pmc_traffic(workload, kernel):

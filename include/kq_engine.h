@@ -426,8 +426,11 @@ int  kq_pending_set_lq_usage(kq_engine* e, int32_t n_lq, const double* usage);
  * and unpacks its decisions; at most two steps may be in flight, so the host enqueues cycle i+1 while the device runs cycle i
  * (schedule()'s own side effects — the API writes of admit / requeueAndUpdate — trail the cycle in the reference as well,
  * scheduler.go:362-377 runs them from the decisions, not the other way round).
- * `out` of kq_pending_step_wait is sized for the bound (kq_pending_bounds); reason records are not produced on this path
- * (out->rsn_cap is ignored: use kq_cycle_run_pending for a cycle whose messages are wanted). tgt_cap as in kq_decisions.
+ * `out` of kq_pending_step_wait is sized for the bound (kq_pending_bounds). Reason records (the operands of Status.reasons /
+ * the "couldn't assign flavors" messages) are produced by the steps issued after kq_pending_step_reasons(e, rsn_cap > 0): their
+ * windows are staged to the host with the decisions, and kq_pending_step_wait fills out->rsn_* exactly as kq_cycle_run does when
+ * out->rsn_cap > 0 (KQ_ECAPACITY when it is too small); rsn_cap = 0 switches them off again (the default: a step without them copies
+ * 32 B x the window of every head less). tgt_cap as in kq_decisions.
  * A step whose cycle fails on the device (KQ_ECAPACITY of the target pool, ...) commits nothing and puts its heads back into their
  * heaps; kq_pending_step_wait returns the error for that step. KQ_ECAPACITY from the unpack (out->tgt_cap too small for the target
  * CSR) leaves the step applied on the device.
@@ -435,6 +438,7 @@ int  kq_pending_set_lq_usage(kq_engine* e, int32_t n_lq, const double* usage);
 int  kq_pending_bounds(kq_engine* e, int32_t* max_heads, int32_t* max_podsets);
 int  kq_pending_step(kq_engine* e, int64_t cycle, const uint8_t* cq_active, int32_t tgt_cap, int32_t release_age, int32_t want_head_wl);
 int  kq_pending_step_wait(kq_engine* e, kq_decisions* out, int32_t* n_heads, int32_t* n_podsets, int32_t* head_wl);
+int  kq_pending_step_reasons(kq_engine* e, int32_t rsn_cap);
 
 /* ---- AdmissionFairSharing ledger on the device (pkg/cache/queue/afs/usage_ledger.go, entry_penalties.go) --------------------
  * With a ledger resident, the LocalQueues' fair-sharing usage that Heads() orders by is evaluated on the device from the ledger, and the

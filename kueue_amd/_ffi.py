@@ -263,7 +263,8 @@ def load_engine():
     lib.kq_pending_bounds.argtypes = [C.c_void_p, i32p, i32p]
     lib.kq_pending_step.argtypes = [C.c_void_p, C.c_int64, u8p, C.c_int32, C.c_int32, C.c_int32]
     lib.kq_pending_step_wait.argtypes = [C.c_void_p, C.POINTER(kq_decisions), i32p, i32p, i32p]
-    for f in ("kq_pending_bounds", "kq_pending_step", "kq_pending_step_wait"):
+    lib.kq_pending_step_reasons.argtypes = [C.c_void_p, C.c_int32]
+    for f in ("kq_pending_bounds", "kq_pending_step", "kq_pending_step_wait", "kq_pending_step_reasons"):
         getattr(lib, f).restype = C.c_int
     lib.kq_pending_afs_put.argtypes = [C.c_void_p, C.POINTER(kq_afs_ledger)]
     lib.kq_pending_afs_wl_penalty.argtypes = [C.c_void_p, C.c_int32, i32p, u64p, i64p, u64p]
@@ -311,7 +312,7 @@ ABI_SYMBOLS = [
     "kq_cycle_commit", "kq_cycle_release", "kq_snapshot_derive", "kq_snapshot_read_planes", "kq_strerror", "kq_last_error", "kq_abi_version",
     "kq_heads_put", "kq_cycle_run_resident", "kq_nominate_run_resident", "kq_last_cycle_phases",
     "kq_cycle_certificate", "kq_snapshot_usage_add", "kq_snapshot_patch", "kq_snapshot_patch_rows", "kq_cycle_shard_words", "kq_cycle_nominate_shard", "kq_cycle_process_merged",
-    "kq_pending_bounds", "kq_pending_step", "kq_pending_step_wait",
+    "kq_pending_bounds", "kq_pending_step", "kq_pending_step_wait", "kq_pending_step_reasons",
     "kq_pending_afs_put", "kq_pending_afs_wl_penalty", "kq_pending_afs_sub_penalty", "kq_pending_afs_set_consumed", "kq_pending_afs_read",
     "kq_pending_set_lq_usage", "kq_pending_add", "kq_pending_update", "kq_pending_delete", "kq_pending_set_clock", "kq_pending_set_requeue_at", "kq_pending_put", "kq_pending_heads", "kq_cycle_run_pending", "kq_pending_apply", "kq_pending_queue_inadmissible", "kq_pending_read_state",
     "kq_debug_read_usage_work", "kq_debug_force_exact_drs", "kq_debug_prof", "kq_debug_spec_stats", "kq_debug_disable_scan_search",

@@ -727,6 +727,11 @@ class Decisions:
         v.a["ps_count"] = self.a["ps_count"][:nps].copy()
         v.a["tgt_off"] = self.a["tgt_off"][:n + 1].copy()
         v.a["tgt_adm"], v.a["tgt_reason"] = self.a["tgt_adm"], self.a["tgt_reason"]
+        if "rsn_off" in self.a:   # reason records of a step issued after kq_pending_step_reasons
+            v.a["rsn_off"] = self.a["rsn_off"][:n + 1].copy()
+            for k in self.a:
+                if k.startswith("rsn_") and k != "rsn_off":
+                    v.a[k] = self.a[k]
         return v
 
     def targets(self, i: int) -> List[Tuple[int, int]]:

@@ -935,6 +935,7 @@ int kq_pending_step_wait(kq_engine* en, kq_decisions* out, int32_t* n_heads, int
   (void)hipSetDevice(en->e.be.device);
   KQ_TRY(en, return en->e.pending_step_wait(out, n_heads, n_podsets, head_wl));
 }
+int kq_pending_step_reasons(kq_engine* en, int32_t rsn_cap) { if (!en) return KQ_EINVAL; KQ_TRY(en, return en->e.pending_step_reasons(rsn_cap)); }
 int kq_pending_afs_put(kq_engine* en, const kq_afs_ledger* l) {
   if (!en || !l) return KQ_EINVAL;
   (void)hipSetDevice(en->e.be.device);

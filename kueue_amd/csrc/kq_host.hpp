@@ -1157,10 +1157,11 @@ template <class B> struct EngineT {
     uint8_t* host = nullptr; size_t cap = 0;
     bool busy = false;
     PackLayout lay; int n_bound = 0; size_t nps_bound = 0, nR = 0; int pool_cap = 0; bool with_pool = false, with_heads = false;
-    size_t o_counts = 0, o_prow = 0, o_preason = 0, o_headwl = 0;
+    size_t o_counts = 0, o_prow = 0, o_preason = 0, o_headwl = 0, o_rsn = 0;   // o_rsn: the reason windows (kq_pending_step_reasons), staged like the pool
     int tgt_cap = 0; int64_t cycle = 0;
   };
   StepStage steps[2];
+  int step_rsn_cap = 0;   // kq_pending_step_reasons: reason records of the steps issued from now on (0: none recorded)
   bool step_unfused = getenv("KQ_STEP_UNFUSED") != nullptr;   // (A/B switch: the step's commit / apply / release as the separate launches of the call-by-call API)
   int64_t steps_issued = 0, steps_waited = 0;
 
@@ -1398,11 +1399,14 @@ template <class B> struct EngineT {
       st->o_prow = so; so += st->with_pool ? (((size_t)O.pool_cap * 4 + 15) & ~(size_t)15) : 0;
       st->o_preason = so; so += st->with_pool ? (((size_t)O.pool_cap + 15) & ~(size_t)15) : 0;
       st->o_headwl = so; so += st->with_heads ? (size_t)pend.nq * 4 : 0;
+      so = (so + 15) & ~(size_t)15;
+      st->o_rsn = so; so += rsn_win ? (size_t)n * rsn_win * sizeof(RsnRec) : 0;
       if (st->cap < so) { if (st->host) be.free_host(st->host); st->cap = so + so / 4; st->host = (uint8_t*)be.alloc_host(st->cap); }
       be.side_fence();                           // the copies run next to the step's tail kernels, behind everything enqueued so far
       be.d2h_side(st->host, pack, pack_bytes);   // (the head / podset counts ride in the pack: pack_counts)
       if (st->with_pool) { be.d2h_side(st->host + st->o_prow, O.pool_row, (size_t)O.pool_cap * 4); be.d2h_side(st->host + st->o_preason, O.pool_reason, (size_t)O.pool_cap); }
       if (st->with_heads) be.d2h_side(st->host + st->o_headwl, pend.D.head_wl, (size_t)pend.nq * 4);
+      if (rsn_win) be.d2h_side(st->host + st->o_rsn, O.rsn, (size_t)n * rsn_win * sizeof(RsnRec));   // (a window per head of the bound: the next step rewrites them)
       be.side_done();
       last_O = k.O; last_slot = slot; pend.O = k.O; pend.H = k.H;
       return KQ_OK;
@@ -1422,7 +1426,8 @@ template <class B> struct EngineT {
   }
   // The packed region of a finished cycle (host copy `stg`) -> the caller's kq_decisions. n / nps: heads and podsets of the cycle.
   // prow / preason: the target pool when it is already on the host (asynchronous step), else it is fetched here.
-  int cycle_unpack(const PackLayout& L, const uint8_t* stg, int n, size_t nps, size_t nR, kq_decisions* out, const DOut& O, const int32_t* prow_h, const uint8_t* preason_h) {
+  int cycle_unpack(const PackLayout& L, const uint8_t* stg, int n, size_t nps, size_t nR, kq_decisions* out, const DOut& O, const int32_t* prow_h, const uint8_t* preason_h,
+                   const RsnRec* win_h = nullptr) {
     int rc = KQ_OK;
     const int rsn_win = L.rsn_win;
     if (out->tgt_off) out->tgt_off[0] = 0;
@@ -1447,8 +1452,9 @@ template <class B> struct EngineT {
       const int32_t* rn = (const int32_t*)(stg + L.o_rsn);
       size_t used_heads = 0;
       for (int i = 0; i < n; i++) if (rn[i] != 0) used_heads++;
-      std::vector<RsnRec> win;
-      if (used_heads) { win.resize((size_t)n * rsn_win); be.d2h(win.data(), O.rsn, win.size() * sizeof(RsnRec)); rc = be.sync(); if (rc != KQ_OK) return fail(rc, be.error()); }
+      std::vector<RsnRec> win_v;
+      if (used_heads && !win_h) { win_v.resize((size_t)n * rsn_win); be.d2h(win_v.data(), O.rsn, win_v.size() * sizeof(RsnRec)); rc = be.sync(); if (rc != KQ_OK) return fail(rc, be.error()); }
+      const RsnRec* win = win_h ? win_h : win_v.data();
       int tot = 0;
       for (int i = 0; i < n; i++) {
         if (out->rsn_off) out->rsn_off[i] = tot;
@@ -1652,7 +1658,7 @@ template <class B> struct EngineT {
     H.last_hash = G.last_hash; H.hash = G.hash;
     st.with_heads = want_head_wl != 0;
     kq_decisions caps{};
-    caps.tgt_cap = tgt_cap; caps.rsn_cap = 0;
+    caps.tgt_cap = tgt_cap; caps.rsn_cap = step_rsn_cap;
     int rc = cycle_exec(PEND_SLOT, &caps, false, ShardCall{}, &st);
     if (rc == KQ_OK && prep.usage_consistent && !step_unfused) {
       // commit + requeue policy in one launch, the release of the older commit in one more (+ the requeue of the freed trees): the
@@ -1695,6 +1701,11 @@ template <class B> struct EngineT {
     if (max_podsets) *max_podsets = (int32_t)std::max<size_t>(pend.gps, 1);
     return KQ_OK;
   }
+  int pending_step_reasons(int rsn_cap) {
+    if (rsn_cap < 0) return fail(KQ_EINVAL, "kq_pending_step_reasons: negative rsn_cap");
+    step_rsn_cap = rsn_cap;
+    return KQ_OK;
+  }
   int pending_step_wait(kq_decisions* out, int32_t* n_heads, int32_t* n_podsets, int32_t* head_wl) {
     if (steps_waited == steps_issued) return fail(KQ_EINVAL, "kq_pending_step_wait: no step in flight");
     StepStage& st = steps[steps_waited & 1];
@@ -1717,9 +1728,11 @@ template <class B> struct EngineT {
       if (((int32_t*)miscs)[0] != 0 && ((int32_t*)miscs)[1] == 0) return fail(KQ_EDEVICE, "kq_pending_step_wait: targets in a snapshot without preemption");
     }
     kq_decisions o = *out;
-    o.rsn_cap = 0; o.rsn_off = nullptr;   // reason records need the synchronous path (their windows are not staged)
-    return cycle_unpack(st.lay, st.host, n, nps, st.nR, &o, pend.O, st.with_pool ? (const int32_t*)(st.host + st.o_prow) : nullptr,
-                        st.with_pool ? st.host + st.o_preason : nullptr);
+    PackLayout lay = st.lay;
+    if (lay.rsn_win == 0) { o.rsn_cap = 0; o.rsn_off = nullptr; }   // the step was issued without reason records (kq_pending_step_reasons)
+    else if (o.rsn_cap <= 0) lay.rsn_win = 0;                          // ... or the caller does not want them this time
+    return cycle_unpack(lay, st.host, n, nps, st.nR, &o, pend.O, st.with_pool ? (const int32_t*)(st.host + st.o_prow) : nullptr,
+                        st.with_pool ? st.host + st.o_preason : nullptr, lay.rsn_win ? (const RsnRec*)(st.host + st.o_rsn) : nullptr);
   }
   // ---- AdmissionFairSharing ledger (kq_pending.hpp DAfs) ----
   int pending_afs_put(const kq_afs_ledger* l) {

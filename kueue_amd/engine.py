@@ -201,6 +201,10 @@ class Engine:
         act = None if cq_active is None else F.ptr(np.ascontiguousarray(cq_active, np.uint8))
         self._check(self._lib.kq_pending_step(self._h, C.c_int64(cycle), act, C.c_int32(tgt_cap), C.c_int32(release_age), C.c_int32(1 if want_heads else 0)))
 
+    def pending_step_reasons(self, rsn_cap: int):
+        """kq_pending_step_reasons: the steps issued from now on record reason windows (rsn_cap > 0) or not (0)."""
+        self._check(self._lib.kq_pending_step_reasons(self._h, C.c_int32(rsn_cap)))
+
     def pending_step_wait(self, out=None, want_heads=False):
         """kq_pending_step_wait for the oldest step in flight -> (n_heads, n_podsets, head_wl or None); `out` sized for pending_bounds()."""
         n, nps = C.c_int32(), C.c_int32()

@@ -47,6 +47,15 @@ func (e *Engine) Step(cycle int64, cqActive []uint8, tgtCap, releaseAge int32, w
 	return nil
 }
 
+// StepReasons switches the reason records of the steps issued from now on (rsnCap > 0: StepWait fills the Rsn* arrays of its
+// FlatDecisions, from which messages.go rebuilds the reference's "couldn't assign flavors" texts; 0: off, the default).
+func (e *Engine) StepReasons(rsnCap int) error {
+	if rc := C.kq_pending_step_reasons(e.h, C.int32_t(rsnCap)); rc != 0 {
+		return e.err("kq_pending_step_reasons", rc)
+	}
+	return nil
+}
+
 // StepWait blocks until the OLDEST step in flight is done and unpacks its decisions (out sized by PendingBounds; headWl optional, [n_cq]).
 // The caller then runs admit / IssuePreemptions / requeueAndUpdate from `out` (apply.go), exactly as after RunCycle.
 func (e *Engine) StepWait(out *FlatDecisions, headWl []int32) (nHeads, nPodsets int32, err error) {

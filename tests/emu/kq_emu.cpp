@@ -286,6 +286,7 @@ int kqe_pending_apply(void* e) { return ((EmuEngine*)e)->pending_apply(); }
 int kqe_pending_bounds(void* e, int32_t* a, int32_t* b) { return ((EmuEngine*)e)->pending_bounds(a, b); }
 int kqe_pending_step(void* e, int64_t cycle, const uint8_t* act, int32_t tgt_cap, int32_t release_age, int32_t want) { return ((EmuEngine*)e)->pending_step(cycle, act, tgt_cap, release_age, want); }
 int kqe_pending_step_wait(void* e, kq_decisions* out, int32_t* n, int32_t* nps, int32_t* hw) { return ((EmuEngine*)e)->pending_step_wait(out, n, nps, hw); }
+int kqe_pending_step_reasons(void* e, int32_t cap) { return ((EmuEngine*)e)->pending_step_reasons(cap); }
 int kqe_pending_afs_put(void* e, const kq_afs_ledger* l) { return ((EmuEngine*)e)->pending_afs_put(l); }
 int kqe_pending_afs_wl_penalty(void* e, int32_t n, const int32_t* wl, const uint64_t* lo, const int64_t* hi, const uint64_t* mask) { return ((EmuEngine*)e)->pending_afs_wl_penalty(n, wl, lo, hi, mask); }
 int kqe_pending_afs_sub_penalty(void* e, int32_t n, const int32_t* wl) { return ((EmuEngine*)e)->pending_afs_sub_penalty(n, wl); }

@@ -29,7 +29,7 @@ def _hip(cfg):
     return Engine(cfg)
 
 
-def _loop(oracle, eng_factory, kind, depth, cycles, hold=2):
+def _loop(oracle, eng_factory, kind, depth, cycles, hold=2, rsn_cap=0):
     kw, fair = KINDS[kind]
     pop = generate(**kw)
     snap = pop.snapshot
@@ -45,7 +45,9 @@ def _loop(oracle, eng_factory, kind, depth, cycles, hold=2):
         mh, mps = eng.pending_bounds()
         assert mh == snap.n_cq and mps >= int(pop.w_nps.max())
         any_heads = pop.heads_for_cycle(0)
-        outs = [Decisions(any_heads, tgt_cap=tgt_cap, n=mh, n_ps=mps) for _ in range(2)]
+        outs = [Decisions(any_heads, tgt_cap=tgt_cap, rsn_cap=rsn_cap, n=mh, n_ps=mps) for _ in range(2)]
+        if rsn_cap:
+            eng.pending_step_reasons(rsn_cap)
         osnap = copy.copy(snap); osnap.arrays = dict(snap.arrays)
         held, live, issued, waited = [], 0, 0, 0
         elive = 0
@@ -57,7 +59,7 @@ def _loop(oracle, eng_factory, kind, depth, cycles, hold=2):
             if hb.n == 0:
                 want_q.append((hb, ohw, None, q.state().copy()))
                 return
-            want = oracle.cycle_run(cfg, osnap, hb)
+            want = oracle.cycle_run(cfg, osnap, hb, rsn_cap=rsn_cap)
             usage, na, triples = oracle.cycle_commit(cfg, osnap, hb)
             osnap.arrays["usage"] = usage; osnap._struct = None
             q.apply(hb, want)
@@ -106,6 +108,18 @@ def _loop(oracle, eng_factory, kind, depth, cycles, hold=2):
         assert np.array_equal(eng.read_usage(), osnap.arrays["usage"]), kind
     finally:
         eng.close(); q.close()
+
+
+@pytest.mark.parametrize("kind", ["cfg3-120cq", "cfg4c-60cq", "cfg4f-40cq"])
+def test_step_loop_with_reason_records_emulated(oracle, kind):
+    """kq_pending_step_reasons: the steps stage their reason windows with the decisions; every record equals the oracle's."""
+    _loop(oracle, _emu, kind, 2, 6, rsn_cap=1 << 16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["cfg3-120cq", "cfg4c-60cq", "cfg4f-40cq"])
+def test_step_loop_with_reason_records_gpu(oracle, kind):
+    _loop(oracle, _hip, kind, 2, 6, rsn_cap=1 << 16)
 
 
 @pytest.mark.parametrize("depth", [1, 2])
