@@ -1625,6 +1625,8 @@ KQ_DEV void fair_search(Search& s) {
     if (same && nt1 > 0) { int q = 0; for (int l = 0; l < w.plen; l++) for (int u = 0; u < w.ns; u++) { const int64_t v = s.W[(size_t)S.node_local[w.path[l]] * S.nfr + w.s_fr[u]]; if (w.s_inu[u] && pw[q] != v) same = false; q++; } }
     if (!same) { CSTAT(24, 1); fprintf(stderr, "FS MISMATCH head %d: lds %d targets %lld bytes, walk %d targets %lld bytes\n", w.h, nt1, (long long)(b1 - bytes_entry), w.ntgt, (long long)(w.bytes - bytes_entry)); }
   }
+#elif defined(KQ_FAIR_WALK_ONLY)
+  fair_search_walk(s);
 #else
   if (!fair_search_lds(s)) fair_search_walk(s);
 #endif
@@ -1868,11 +1870,7 @@ KQ_DEV void simulate_preemption(const K& k, Wave& w, int slot, const int64_t* us
   if (lane_id() == 0) { w.ns = 1; w.s_fr[0] = fr; w.s_qty[0] = val; w.s_inu[0] = 1; w.s_need[0] = 1; }
   wsync();
   Search s = make_search(k, w, slot, usage, removed);
-#ifdef KQ_NO_FAIR
-  classical_search(s);
-#else
   if (k.C.fair_sharing) fair_search(s); else classical_search(s);
-#endif
   wsync();
   if (w.ntgt == 0) { *pm = PM_NOCAND; *borrow = base_borrow; return; }
   bool any_same = false;
@@ -2396,11 +2394,7 @@ KQ_DEV Search get_targets(const K& k, Wave& w, int slot, const int64_t* usage, c
 #ifdef KQ_TAS_CYCLE
   if (k.tc) tc_search_begin(k, w, slot);   // preemption.go:135-138: tasRequests of the assignment; the walk then carries the leaf usage
 #endif
-#ifdef KQ_NO_FAIR
-  classical_search(s);   // (kq_tas_cycle_kernel.hip: fair sharing is refused by the host, its searches are not compiled in)
-#else
   if (k.C.fair_sharing) fair_search(s); else classical_search(s);
-#endif
   wsync();
 #ifdef KQ_TAS_CYCLE
   if (k.tc) tc_search_end(w);

@@ -145,7 +145,10 @@ __global__ __launch_bounds__(PROCESS_THREADS) void k_process(const K* __restrict
 
 // Fair sharing: the iterator pops interleave with processEntry (scheduler.go:358), so ordering and processing
 // are one kernel: one wave per root-cohort tree; the tree's cohort usage rows stay in LDS.
-constexpr int FAIR_THREADS = 512;  // wave 0 leads, all 8 waves recompute DRS values between pops
+#ifndef KQ_FAIR_THREADS
+#define KQ_FAIR_THREADS 512
+#endif
+constexpr int FAIR_THREADS = KQ_FAIR_THREADS;  // wave 0 leads, all waves recompute DRS values between pops (A/B builds: -DKQ_FAIR_THREADS=256 gives the leader 512 registers)
 __global__ __launch_bounds__(FAIR_THREADS) void k_process_fair(const K* __restrict__ kp, unsigned lds_bytes, unsigned iter_bytes) {
   const K& k = *kp;
   __shared__ Wave w;

@@ -7,7 +7,7 @@
 //   k_process_tas   1 wave for the whole cycle: entries of every root cohort in iterator order (a TAS flavor's leaves are shared by
 //                   ClusterQueues of different root cohorts, snapshot.go:260), recomputation on overlap / on lost TAS capacity
 #define KQ_TAS_CYCLE 1
-#define KQ_NO_FAIR 1   // kq_cycle_run_tas refuses fair-sharing cycles: their victim searches stay out of these kernels
+#define KQ_FAIR_WALK_ONLY 1   // a fair-sharing TAS cycle's victim searches carry leaf usage: the candidate-by-candidate walk (kq_fs.hpp's LDS formulation stays out of these kernels)
 #include <hip/hip_runtime.h>
 
 #include "kq_device.hpp"

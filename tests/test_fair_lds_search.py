@@ -88,3 +88,29 @@ def test_walk_still_runs_when_the_lds_search_is_off(oracle):
         eng.close()
     assert not want.equal(got)
     assert _stats()[23] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fair", [True, False])
+def test_walks_on_the_gpu(oracle, fair):
+    """The candidate-by-candidate walks — what runs when a victim search is outside the preconditions of kq_fs.hpp / kq_cs.hpp, and in
+    every TAS cycle — through the C ABI on the HIP engine (kq_debug_disable_scan_search), against the oracle."""
+    from kueue_amd.engine import Engine
+    for seed in range(90_000, 90_090):
+        kw = dict(fair=fair, preemption=True)
+        if seed % 3 == 0:
+            kw.update(max_cq=10)
+        if seed % 3 == 1:
+            kw.update(partial=True)
+        cfg, snap, heads = random_case(seed, **kw)
+        oracle.derive(snap)
+        want = oracle.cycle_run(cfg, snap, heads)
+        eng = Engine(cfg)
+        try:
+            eng._lib.kq_debug_disable_scan_search(eng._h, 1)
+            eng.put(snap)
+            got = eng.run(heads)
+        finally:
+            eng.close()
+        assert not want.equal(got), (seed, fair, want.equal(got))
+        assert got.bytes == want.stats["total"], (seed, fair)
