@@ -3961,21 +3961,28 @@ KQ_DEV DRSv drs_entry_level(const K& k, const Wave& w, const int32_t* path, int 
 // shares its cohort with the popped entry, and the leader waits for the slowest thread of the pass. Here every operand of four usage
 // entries is requested before the first one is used: one round trip per four entries. Same arithmetic, same order.
 KQ_DEV DRSv drs_entry_level_g(const K& k, const Wave& w, const int* nd, const int* row, int level, const int32_t* ufr, const int64_t* uqty, int nu,
-                              bool want_bon, int64_t* bytes) {
+                              bool want_bon, int64_t* bytes, const int* fr0 = nullptr, const int64_t* qty0 = nullptr) {
   const DSnap& S = k.S;
   const int nR = S.nR, n = fs_sel4(nd, level), rown = fs_sel4(row, level);
   auto usage_of = [&](int node, int rw, int fr) -> int64_t {
     return rw >= 0 ? w.pc_lds[(size_t)rw * S.nfr + fr] : k.usage_work[(size_t)node * S.nfr + fr];   // plane 0 of the resident rows = usage_work
   };
-  int64_t sum[KQ_MAXR];
+  int64_t sum[KQ_MAXR], lend[KQ_MAXR];
   #pragma unroll
-  for (int r = 0; r < KQ_MAXR; r++) sum[r] = r < nR ? k.X.bs_sum[(size_t)n * nR + r] : 0;
+  for (int r = 0; r < KQ_MAXR; r++) { sum[r] = r < nR ? k.X.bs_sum[(size_t)n * nR + r] : 0; lend[r] = r < nR ? S.lendable[(size_t)n * nR + r] : 0; }
   int pos = k.X.bs_pos[n];
+  // (what drs_from_sums reads of the node: requested with the cells, not behind them)
+  const double weight = S.fair_weight[n];
+  const int frcount = S.frcount[n], depth = S.depth[n];
   int bon = 0;
   for (int q0 = 0; q0 < nu; q0 += 4) {
     int fr[4]; int64_t qty[4], sqn[4], un[4], lq[4][3], ul[4][3]; uint8_t qf[4]; bool in[4];
     #pragma unroll
-    for (int j = 0; j < 4; j++) { in[j] = q0 + j < nu; fr[j] = ufr[in[j] ? q0 + j : q0]; qty[j] = uqty[in[j] ? q0 + j : q0]; }
+    for (int j = 0; j < 4; j++) {
+      in[j] = q0 + j < nu;
+      if (q0 == 0 && fr0) { fr[j] = fr0[j]; qty[j] = qty0[j]; }   // the caller fetched the first four with its other operands
+      else { fr[j] = ufr[in[j] ? q0 + j : q0]; qty[j] = uqty[in[j] ? q0 + j : q0]; }
+    }
     #pragma unroll
     for (int j = 0; j < 4; j++) {
       const size_t o = ix(S, n, fr[j]);
@@ -4009,8 +4016,14 @@ KQ_DEV DRSv drs_entry_level_g(const K& k, const Wave& w, const int* nd, const in
       if (want_bon && nb > 0 && qty[j] > 0) bon = 1;
     }
   }
-  DRSv d = drs_from_sums(S, n, sum, pos, bytes);
-  d.borrow_on = bon;
+  // drs_from_sums on the operands gathered above
+  DRSv d; d.ratio = 0; d.weight = weight; d.borrowing = pos > 0; d.borrow_on = bon;
+  #pragma unroll
+  for (int r = 0; r < KQ_MAXR; r++) {
+    if (r >= nR || sum[r] <= 0) continue;
+    if (lend[r] > 0) { const double ratio = (double)sum[r] * 1000.0 / (double)lend[r]; if (ratio > d.ratio) d.ratio = ratio; }
+  }
+  *bytes += (int64_t)frcount * 24 + (d.borrowing ? (int64_t)frcount * 40 * (depth + 1) : 0);
   return d;
 }
 // entryComparer.less (fair_sharing_iterator.go:176-221) as a lexicographic key: a wins over b inside
@@ -4089,11 +4102,11 @@ KQ_DEV int tournament_cohort(const K& k, int slot, int x, const int32_t* win, co
 // pop, most of the 24 us a pop took at cfg 3f. Here the children lists (tree-local ids, kq_prep.hpp fs_kid / fs_koff / fs_knc / fs_knh),
 // the parent table, the depths, cqToEntry and the winners (entry + its ClusterQueue) live in the workgroup's LDS: a tournament is LDS
 // reads and ONE round of independent key loads.
-struct FIter { int32_t *ent, *win; int16_t *wcq, *kid, *koff, *knc, *knh, *par; int8_t* dep; bool on; };
+struct FIter { int32_t *ent, *win; int16_t *wcq, *kid, *koff, *knc, *knh, *par; int8_t* dep; uint8_t* stl; bool on; };   // stl: lowest path level whose cached DRS is out of date (255 = none)
 KQ_HD size_t fiter_bytes(int nn, int nqs) {
   auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
   const int ncoh = nn - nqs > 0 ? nn - nqs : 1;
-  return al((size_t)nqs * 4) + al((size_t)nn * 4) + al((size_t)nn * 2) * 3 + al((size_t)ncoh * 2) * 3 + al((size_t)nn) + 64;
+  return al((size_t)nqs * 4) + al((size_t)nn * 4) + al((size_t)nn * 2) * 3 + al((size_t)ncoh * 2) * 3 + al((size_t)nn) + al((size_t)nqs) + 64;
 }
 struct FWin { int e, wc; };
 KQ_DEV FWin tournament_cohort_lds(const FIter& it, const uint64_t* fkeys, int xl, int nqs) {
@@ -4149,7 +4162,7 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
     it.ent = (int32_t*)q; q += al((size_t)nqs * 4); it.win = (int32_t*)q; q += al((size_t)nn * 4);
     it.wcq = (int16_t*)q; q += al((size_t)nn * 2); it.kid = (int16_t*)q; q += al((size_t)nn * 2); it.par = (int16_t*)q; q += al((size_t)nn * 2);
     it.koff = (int16_t*)q; q += al((size_t)ncoh * 2); it.knc = (int16_t*)q; q += al((size_t)ncoh * 2); it.knh = (int16_t*)q; q += al((size_t)ncoh * 2);
-    it.dep = (int8_t*)q;
+    it.dep = (int8_t*)q; q += al((size_t)nn); it.stl = (uint8_t*)q;
     for (int i = tid; i < nn; i += nthreads) {
       it.kid[i] = S.fs_kid[n0 + i]; it.par[i] = S.fs_par[n0 + i]; it.dep[i] = (int8_t)S.depth[S.tree_nodes[n0 + i]]; it.wcq[i] = 0;
       if (i >= nqs) { it.koff[i - nqs] = S.fs_koff[n0 + i]; it.knc[i - nqs] = S.fs_knc[n0 + i]; it.knh[i - nqs] = S.fs_knh[n0 + i]; }
@@ -4162,7 +4175,7 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
   const bool have_rec = lds_bytes >= sizeof(PRec);
   PRec* rec = (PRec*)((unsigned char*)lds + (lds_bytes - (have_rec ? sizeof(PRec) : 0)));
   int64_t fast_bytes = 0;
-  uint8_t* stale = k.X.fs_stale + (size_t)slot * k.X.max_tree_cqs;
+  uint8_t* stale = it.on ? it.stl : k.X.fs_stale + (size_t)slot * k.X.max_tree_cqs;
   int32_t* cost = k.X.fs_cost + (size_t)slot * k.X.max_tree_cqs * KQ_MAXD;
   long long* sum = k.X.fs_sum + slot;
   int32_t* ctl = k.X.fs_ctl + (size_t)slot * 4;
@@ -4222,50 +4235,74 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
       const bool changed = ctl[2] != 0;
       int64_t delta = 0;
       const int xi = ctl[3];   // tree-local index of the ClusterQueue popped last
-      for (int i = tid; i < nqs; i += nthreads) {
-        const int en = cq_ent[i];
-        if (en < 0) continue;
-        if (fs_plain && it.on && it.dep[i] <= 3 && (!changed || it.dep[xi] <= 3)) {
-          // The paths come from the iterator's LDS state (parents, depths): which levels are out of date is known without a global
-          // access, and a ClusterQueue that only shares the root with the popped one — nine out of ten — is done here.
+      // The common case — plain amounts, the iterator's state in LDS, paths of at most four levels — as (ClusterQueue, level) items,
+      // four consecutive threads per ClusterQueue: which levels are out of date comes from LDS (parents, depths, the stale level), so a
+      // ClusterQueue that only shares the root with the popped one — nine out of ten — is done without a global access; an item with work
+      // makes two rounds of independent loads (what hangs on the entry and the path; what hangs on the nodes and flavor-resources) where
+      // the walk below makes one per operand, and a ClusterQueue's levels run side by side instead of one after the other.
+      const bool quick = fs_plain && it.on && (!changed || it.dep[xi] <= 3);
+      if (quick) {
+        for (int item = tid; item < nqs * 4; item += nthreads) {
+          const int i = item >> 2, l = item & 3;
+          const int en = cq_ent[i];
+          if (en < 0 || it.dep[i] > 3) continue;
           const int plen = it.dep[i] + 1;
           int lp[4];
           lp[0] = i;
           #pragma unroll
-          for (int l = 1; l < 4; l++) lp[l] = l < plen ? (int)it.par[lp[l - 1]] : -1;
+          for (int q = 1; q < 4; q++) lp[q] = q < plen ? (int)it.par[lp[q - 1]] : -1;
           int from = stale[i];
+          const int from0 = from;
           if (changed) {
             const int xl = it.dep[xi] + 1;
             int xp[4];
             xp[0] = xi;
             #pragma unroll
-            for (int l = 1; l < 4; l++) xp[l] = l < xl ? (int)it.par[xp[l - 1]] : -1;
+            for (int q = 1; q < 4; q++) xp[q] = q < xl ? (int)it.par[xp[q - 1]] : -1;
             int t = 0;
             while (t < plen - 1 && t < xl - 1 && fs_sel4(lp, plen - 2 - t) == fs_sel4(xp, xl - 2 - t)) t++;
             const int lvl = plen - 1 - t;
             if (lvl < from) from = lvl;
           }
-          if (from + 1 >= plen) { if (from != 255) stale[i] = 255; continue; }
+          wsync_lds();   // (the four items of a ClusterQueue sit in one wave: all of them have read its stale level)
+          if (l == 3 && from0 != 255) stale[i] = 255;   // (the last of the four: the emulation runs them one after the other)
+          if (l < from || l + 1 >= plen) continue;
+          // round 1: what hangs on the entry and on the path
           int nd[4], row[4];
           #pragma unroll
-          for (int l = 0; l < 4; l++) {
-            nd[l] = S.tree_nodes[n0 + (l < plen ? lp[l] : i)];
-            row[l] = (l >= 1 && l < plen && w.pc_on) ? lp[l] - nqs : -1;
+          for (int q = 0; q < 4; q++) {
+            nd[q] = S.tree_nodes[n0 + (q < plen ? lp[q] : i)];
+            row[q] = (q >= 1 && q < plen && w.pc_on) ? lp[q] - nqs : -1;
           }
           const int32_t* ufr = O.use_fr + (size_t)en * KQ_MAXU; const int64_t* uqty = O.use_qty + (size_t)en * KQ_MAXU;
-          const int nu = (H.flags[en] & KQ_HEAD_HAS_QUOTA_RESERVATION) ? 0 : O.use_n[en];  // netUsage scheduler.go:785-794
-          for (int l = from; l + 1 < plen; l++) {
-            int64_t lb = 0;
-            const DRSv d = drs_entry_level_g(k, w, nd, row, l, ufr, uqty, nu, want_bon, &lb);
-            const size_t o = (size_t)i * KQ_MAXD + l;
-            const FsKey key = fs_make_key(k, en, d);
-            fkeys[o * 4 + 0] = key.k1; fkeys[o * 4 + 1] = key.k2; fkeys[o * 4 + 2] = key.k3; fkeys[o * 4 + 3] = key.k4;
-            delta += lb - cost[o];
-            cost[o] = (int32_t)lb;
-          }
-          stale[i] = 255;
-          continue;
+          const uint32_t hfl = H.flags[en];
+          const int un = O.use_n[en];
+          const int64_t hprio = H.priority[en], hts = H.queue_ts[en];
+          const size_t o = (size_t)i * KQ_MAXD + l;
+          const int32_t cost0 = cost[o];
+          int fr0[4]; int64_t qty0[4];
+          #pragma unroll
+          for (int q = 0; q < 4; q++) { fr0[q] = ufr[q]; qty0[q] = uqty[q]; }   // (KQ_MAXU >= 4 entries per head are allocated)
+          const int nu = (hfl & KQ_HEAD_HAS_QUOTA_RESERVATION) ? 0 : un;  // netUsage scheduler.go:785-794
+          // round 2 (inside): what hangs on the nodes and the flavor-resources
+          int64_t lb = 0;
+          const DRSv d = drs_entry_level_g(k, w, nd, row, l, ufr, uqty, nu, want_bon, &lb, fr0, qty0);
+          const bool zwb = drs_zwb(d);
+          FsKey key;   // fs_make_key on the operands of round 1
+          key.k1 = (gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS) && !(hfl & KQ_HEAD_IS_PREEMPTOR) ? 4u : 0u) |
+                   (gate(k, KQ_GATE_FS_PRIORITIZE_NON_BORROWING) && d.borrow_on ? 2u : 0u) | (zwb ? 1u : 0u);
+          key.k2 = f64_bits(zwb ? d.ratio : drs_pws(d));
+          key.k3 = gate(k, KQ_GATE_PRIORITY_SORTING_IN_COHORT) ? ~((uint64_t)hprio ^ 0x8000000000000000ull) : 0;
+          key.k4 = (uint64_t)hts ^ 0x8000000000000000ull;
+          fkeys[o * 4 + 0] = key.k1; fkeys[o * 4 + 1] = key.k2; fkeys[o * 4 + 2] = key.k3; fkeys[o * 4 + 3] = key.k4;
+          delta += lb - cost0;
+          cost[o] = (int32_t)lb;
         }
+      }
+      for (int i = tid; i < nqs; i += nthreads) {
+        const int en = cq_ent[i];
+        if (en < 0) continue;
+        if (quick && it.dep[i] <= 3) continue;   // done above
         const int c = S.tree_cqs[q0 + i];
         const int32_t* path = S.path + (size_t)c * KQ_MAXD;
         const int plen = S.plen[c];
