@@ -723,7 +723,7 @@ struct HipBackend {
       lds_attr = lds;
     }
     // after launch_order the block of the nominate step is already what the process step needs (k_order_scatter moved its byte counter)
-    const K* d = stat_patched ? dcur0 : put_k(k, 1);
+    const K* d = (stat_patched && !getenv("KQ_PROF_SKIP_NOMINATE")) ? dcur0 : put_k(k, 1);   // (timing builds: the nominate step's block counts into the sink)
     dproc = d; stat_patched = false;
     if (!spec_off && k.spec_kt) chk(launch_process_spec(d, n_tree, stream), "k_process_spec");
     hipLaunchKernelGGL(k_process, dim3(n_tree), dim3(PROCESS_THREADS), lds, stream, d, (unsigned)lds);

@@ -42,7 +42,10 @@ struct Fs {
   int32_t* posoff; int16_t *kid, *koff, *knc, *knh, *c0, *c1, *par; int8_t* plv;   // plv: level of the node on the preemptor's path, -1 = not on it
   // context of the row being applied / of the preemptor
   int32_t* rc_ptr; int64_t *rc_lq, *rc_sqb, *rc_lend; double* rc_wt;   // rc_ptr / pc_ptr: cell codes, see fs_cell
-  int64_t* td; int32_t* tp; double* tx; uint64_t* tout;   // staging of one row operation: borrowed-amount deltas / borrowed-cell count deltas per (flavor-resource, level), share terms per (level, resource), result
+  int64_t* td; int32_t* tp; double* tx; uint64_t* tout;
+  // what an evaluation (commit = false) computed, kept for the commit that follows it when the candidate passes: new cell values and
+  // touched levels per chain, new borrowed sums per (level, resource), new borrowed-cell counts / shares / zero-weight flags per level
+  int64_t *ev_nv, *ev_sum; int32_t *ev_t, *ev_np; double* ev_v; uint8_t* ev_z;   // staging of one row operation: borrowed-amount deltas / borrowed-cell count deltas per (flavor-resource, level), share terms per (level, resource), result
   int32_t* pc_ptr; int64_t *pc_lq, *pc_sq, *pc_sqb, *pc_bl, *pc_lend; double* pc_wt; int32_t* pc_u;
   int32_t* tpos;
   // the first tcap targets (row, reason, position) live in what LDS the state left over: a target pushed or moved is then no global
@@ -66,6 +69,7 @@ KQ_DEV void fs_assume_lds(const Fs& f) {
   FS_LDS(f.psum); FS_LDS(f.dval); FS_LDS(f.ppos); FS_LDS(f.nflag); FS_LDS(f.m1); FS_LDS(f.m2); FS_LDS(f.mq); FS_LDS(f.colslot); FS_LDS(f.col);
   FS_LDS(f.posoff); FS_LDS(f.kid); FS_LDS(f.koff); FS_LDS(f.knc); FS_LDS(f.knh); FS_LDS(f.c0); FS_LDS(f.c1); FS_LDS(f.par); FS_LDS(f.plv);
   FS_LDS(f.rc_ptr); FS_LDS(f.rc_lq); FS_LDS(f.rc_sqb); FS_LDS(f.rc_lend); FS_LDS(f.rc_wt); FS_LDS(f.td); FS_LDS(f.tp); FS_LDS(f.tx); FS_LDS(f.tout);
+  FS_LDS(f.ev_nv); FS_LDS(f.ev_sum); FS_LDS(f.ev_t); FS_LDS(f.ev_np); FS_LDS(f.ev_v); FS_LDS(f.ev_z);
   FS_LDS(f.pc_ptr); FS_LDS(f.pc_lq); FS_LDS(f.pc_sq); FS_LDS(f.pc_sqb); FS_LDS(f.pc_bl); FS_LDS(f.pc_lend); FS_LDS(f.pc_wt); FS_LDS(f.pc_u);
   FS_LDS(f.bq_c); FS_LDS(f.bq_ord); FS_LDS(f.bq_k); FS_LDS(f.bq_h); FS_LDS(f.bq_z); FS_LDS(f.br_c); FS_LDS(f.br_ap); FS_LDS(f.br_at); FS_LDS(f.br_n); FS_LDS(f.br_off);
   FS_LDS(f.br_fl); FS_LDS(f.cl_pos); FS_LDS(f.cl_rk);
@@ -85,6 +89,7 @@ size_t fs_bytes(int nn, int nqs, int nR, int nfr, int mw, int ncols) {
   size_t b = 0;
   b += al(FS_RC * 8) * 3 + al(FS_LV * KQ_MAXR * 8) + al(FS_LV * 8);                               // row context
   b += al(FS_RC * 8) + al(FS_RC * 4) + al(FS_LV * KQ_MAXR * 8) + al(4 * 8);                        // staging of a row operation
+  b += al(FS_RC * 8) + al(FS_LV * KQ_MAXR * 8) + al(CS_RFR * 4) + al(FS_LV * 4) + al(FS_LV * 8) + al(FS_LV);   // an evaluation's results (ev_*)
   b += al(FS_PCN * 8) * 5 + al(FS_PCN * 4) + al(FS_LV * KQ_MAXR * 8) + al(FS_LV * 8);              // preemptor context
   b += al(FS_NCMAX * 8);                                                                            // column pointers
   b += al(nn) * 2 + al((size_t)nn * 8) + al((size_t)nn * 4) + al((size_t)nn * 2) * 4;              // nflag plv dval ppos c0 c1 kid par
@@ -244,7 +249,8 @@ KQ_DEV void fs_row_ctx(Fs& f, const FsRow& r) {
 // Outputs per level: the new value, what the node's borrowed amount (max(0, usage - SubtreeQuota)) and its count of borrowed
 // cells change by. `write`: store the new values.
 struct FsChainOut { int64_t d[FS_LV]; int dp[FS_LV]; };
-KQ_DEV FsChainOut fs_chain(const Fs& f, const int32_t* ptr, const int64_t* lq, const int64_t* sqb, int plen, int64_t val, bool add, bool write) {
+KQ_DEV FsChainOut fs_chain(const Fs& f, const int32_t* ptr, const int64_t* lq, const int64_t* sqb, int plen, int64_t val, bool add, bool write,
+                           int64_t* nv_out = nullptr, int32_t* t_out = nullptr) {
   int64_t v[FS_LV], nv[FS_LV];
   bool t[FS_LV];
   #pragma unroll
@@ -275,6 +281,12 @@ KQ_DEV FsChainOut fs_chain(const Fs& f, const int32_t* ptr, const int64_t* lq, c
     o.dp[i] = (nb > 0 ? 1 : 0) - (ob > 0 ? 1 : 0);
     if (write) fs_st(f, ptr[i], nv[i]);
   }
+  if (nv_out) {
+    int tm = 0;
+    #pragma unroll
+    for (int i = 0; i < FS_LV; i++) { nv_out[i] = nv[i]; if (t[i]) tm |= 1 << i; }
+    *t_out = tm;
+  }
   return o;
 }
 // The borrowed sums / cached shares of `plen` path nodes after the per-chain deltas staged in f.td / f.tp (nch chains, chain u
@@ -292,6 +304,7 @@ KQ_DEV int fs_nodes_update(const Fs& f, const int* lp, int plen, const int64_t* 
     for (int u = 0; u < nch; u++) if (res(u) == rr) d += f.td[u * FS_LV + i];
     const int64_t sum = f.psum[(size_t)li * f.nR + rr] + d;
     if (commit && d != 0) f.psum[(size_t)li * f.nR + rr] = sum;
+    if (!commit) f.ev_sum[j] = sum;
     double x = 0;
     if (sum > 0) { const int64_t lr = lend[i * KQ_MAXR + rr]; if (lr > 0) x = (double)sum * 1000.0 / (double)lr; }
     f.tx[i * KQ_MAXR + rr] = x;
@@ -312,7 +325,7 @@ KQ_DEV int fs_nodes_update(const Fs& f, const int* lp, int plen, const int64_t* 
       if (dp) f.ppos[li] = np;
       f.dval[li] = v;
       f.nflag[li] = (uint8_t)((f.nflag[li] & ~2) | (zwb ? 2 : 0));
-    }
+    } else { f.ev_np[i] = np; f.ev_v[i] = v; f.ev_z[i] = zwb ? 1 : 0; }
     if (li == at) { f.tout[0] = fs_okey(v); f.tout[1] = (uint64_t)((zwb ? 1 : 0) | (np > 0 ? 2 : 0)); }
   }
   wsync_lds();
@@ -328,7 +341,9 @@ KQ_DEV int fs_row_apply(const Fs& f, const FsRow& r, bool add, bool commit, bool
     FsChainOut o;
     #pragma unroll
     for (int i = 0; i < FS_LV; i++) { o.d[i] = 0; o.dp[i] = 0; }
-    if (fr >= 0) o = fs_chain(f, f.rc_ptr + u * FS_LV, f.rc_lq + u * FS_LV, f.rc_sqb + u * FS_LV, r.plen, fs_sel4(r.qty, u), add, commit);
+    if (fr >= 0) o = fs_chain(f, f.rc_ptr + u * FS_LV, f.rc_lq + u * FS_LV, f.rc_sqb + u * FS_LV, r.plen, fs_sel4(r.qty, u), add, commit,
+                              commit ? nullptr : f.ev_nv + u * FS_LV, commit ? nullptr : f.ev_t + u);
+    else if (!commit) f.ev_t[u] = 0;
     #pragma unroll
     for (int i = 0; i < FS_LV; i++) { f.td[u * FS_LV + i] = o.d[i]; f.tp[u * FS_LV + i] = o.dp[i]; }
   }
@@ -336,6 +351,31 @@ KQ_DEV int fs_row_apply(const Fs& f, const FsRow& r, bool add, bool commit, bool
   const int z = fs_nodes_update(f, r.lp, r.plen, f.rc_lend, f.rc_wt, CS_RFR, FsRowRes{r.res[0], r.res[1], r.res[2], r.res[3]}, commit, at, key);
   if (count && lane_id() == 0) f.w->bytes += r.rowbytes;
   return z;
+}
+
+// RemoveWorkload of the row whose removal has just been EVALUATED (fs_row_apply with commit = false, same row, nothing in between): the
+// evaluation computed every new value — cells, borrowed sums, counts, shares — and only kept the share it was asked for; the commit
+// writes what it left in ev_* instead of computing it a second time.
+KQ_DEV void fs_row_commit_evaluated(const Fs& f, const FsRow& r) {
+  const int lane = lane_id();
+  for (int u = lane; u < CS_RFR; u += WAVE) {
+    const int tm = f.ev_t[u];
+    #pragma unroll
+    for (int i = 0; i < FS_LV; i++) if (tm & (1 << i)) fs_st(f, f.rc_ptr[u * FS_LV + i], f.ev_nv[u * FS_LV + i]);
+  }
+  for (int j = lane; j < FS_LV * KQ_MAXR; j += WAVE) {
+    const int i = j / KQ_MAXR, rr = j % KQ_MAXR;
+    if (i >= r.plen || rr >= f.nR) continue;
+    f.psum[(size_t)fs_sel4(r.lp, i) * f.nR + rr] = f.ev_sum[j];   // (unchanged sums are written back as they were)
+  }
+  for (int i = lane; i < r.plen; i += WAVE) {
+    const int li = fs_sel4(r.lp, i);
+    f.ppos[li] = f.ev_np[i];
+    f.dval[li] = f.ev_v[i];
+    f.nflag[li] = (uint8_t)((f.nflag[li] & ~2) | (f.ev_z[i] ? 2 : 0));
+  }
+  if (lane == 0) f.w->bytes += r.rowbytes;
+  wsync();
 }
 
 // ---- the preemptor ----------------------------------------------------------------------------------------------------------
@@ -603,6 +643,8 @@ KQ_DEV bool fs_setup(Search& s, Fs& f) {
   f.rc_ptr = (int32_t*)cv.take(FS_RC * 8); f.rc_lq = (int64_t*)cv.take(FS_RC * 8); f.rc_sqb = (int64_t*)cv.take(FS_RC * 8);
   f.rc_lend = (int64_t*)cv.take(FS_LV * KQ_MAXR * 8); f.rc_wt = (double*)cv.take(FS_LV * 8);
   f.td = (int64_t*)cv.take(FS_RC * 8); f.tp = (int32_t*)cv.take(FS_RC * 4); f.tx = (double*)cv.take(FS_LV * KQ_MAXR * 8); f.tout = (uint64_t*)cv.take(4 * 8);
+  f.ev_nv = (int64_t*)cv.take(FS_RC * 8); f.ev_sum = (int64_t*)cv.take(FS_LV * KQ_MAXR * 8); f.ev_t = (int32_t*)cv.take(CS_RFR * 4); f.ev_np = (int32_t*)cv.take(FS_LV * 4);
+  f.ev_v = (double*)cv.take(FS_LV * 8); f.ev_z = (uint8_t*)cv.take(FS_LV);
   f.pc_ptr = (int32_t*)cv.take(FS_PCN * 8); f.pc_lq = (int64_t*)cv.take(FS_PCN * 8); f.pc_sq = (int64_t*)cv.take(FS_PCN * 8);
   f.pc_sqb = (int64_t*)cv.take(FS_PCN * 8); f.pc_bl = (int64_t*)cv.take(FS_PCN * 8); f.pc_u = (int32_t*)cv.take(FS_PCN * 4);
   f.pc_lend = (int64_t*)cv.take(FS_LV * KQ_MAXR * 8); f.pc_wt = (double*)cv.take(FS_LV * 8);
@@ -1364,7 +1406,7 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
         if (lane == 0) w.bytes += (int64_t)f.c0[at] + ((zb & 2) ? (int64_t)f.c1[at] : 0);
         const bool pass = strategy0 == KQ_FS_LESS_THAN_OR_EQUAL_TO_FINAL_SHARE ? fs_cmp(pz, pk, nz, nk) <= 0 : fs_cmp(pz, pk, tz, tk) < 0;  // strategy.go:41,46
         if (pass) {
-          fs_row_apply(f, r, false, true, true);
+          fs_row_commit_evaluated(f, r);
           KQ_LS(w, 4);
           if (!fs_push_target(f, &nt, r.row, p, KQ_REASON_IN_COHORT_FAIR_SHARING)) { w.ntgt = 0; return true; }
           tbytes += r.rowbytes;
