@@ -3980,7 +3980,7 @@ KQ_DEV DRSv drs_entry_level_g(const K& k, const Wave& w, const int* nd, const in
     #pragma unroll
     for (int j = 0; j < 4; j++) {
       in[j] = q0 + j < nu;
-      if (q0 == 0 && fr0) { fr[j] = fr0[j]; qty[j] = qty0[j]; }   // the caller fetched the first four with its other operands
+      if (q0 == 0 && fr0) { fr[j] = in[j] ? fr0[j] : fr0[0]; qty[j] = in[j] ? qty0[j] : qty0[0]; }   // the caller fetched the first four with its other operands (entries past nu hold anything)
       else { fr[j] = ufr[in[j] ? q0 + j : q0]; qty[j] = uqty[in[j] ? q0 + j : q0]; }
     }
     #pragma unroll
@@ -4235,74 +4235,50 @@ KQ_DEV void process_tree_fair(const K& k, Wave& w, int tree, int slot, int64_t* 
       const bool changed = ctl[2] != 0;
       int64_t delta = 0;
       const int xi = ctl[3];   // tree-local index of the ClusterQueue popped last
-      // The common case — plain amounts, the iterator's state in LDS, paths of at most four levels — as (ClusterQueue, level) items,
-      // four consecutive threads per ClusterQueue: which levels are out of date comes from LDS (parents, depths, the stale level), so a
-      // ClusterQueue that only shares the root with the popped one — nine out of ten — is done without a global access; an item with work
-      // makes two rounds of independent loads (what hangs on the entry and the path; what hangs on the nodes and flavor-resources) where
-      // the walk below makes one per operand, and a ClusterQueue's levels run side by side instead of one after the other.
-      const bool quick = fs_plain && it.on && (!changed || it.dep[xi] <= 3);
-      if (quick) {
-        for (int item = tid; item < nqs * 4; item += nthreads) {
-          const int i = item >> 2, l = item & 3;
-          const int en = cq_ent[i];
-          if (en < 0 || it.dep[i] > 3) continue;
+      for (int i = tid; i < nqs; i += nthreads) {
+        const int en = cq_ent[i];
+        if (en < 0) continue;
+        if (fs_plain && it.on && it.dep[i] <= 3 && (!changed || it.dep[xi] <= 3)) {
+          // The paths come from the iterator's LDS state (parents, depths): which levels are out of date is known without a global
+          // access, and a ClusterQueue that only shares the root with the popped one — nine out of ten — is done here.
           const int plen = it.dep[i] + 1;
           int lp[4];
           lp[0] = i;
           #pragma unroll
-          for (int q = 1; q < 4; q++) lp[q] = q < plen ? (int)it.par[lp[q - 1]] : -1;
+          for (int l = 1; l < 4; l++) lp[l] = l < plen ? (int)it.par[lp[l - 1]] : -1;
           int from = stale[i];
-          const int from0 = from;
           if (changed) {
             const int xl = it.dep[xi] + 1;
             int xp[4];
             xp[0] = xi;
             #pragma unroll
-            for (int q = 1; q < 4; q++) xp[q] = q < xl ? (int)it.par[xp[q - 1]] : -1;
+            for (int l = 1; l < 4; l++) xp[l] = l < xl ? (int)it.par[xp[l - 1]] : -1;
             int t = 0;
             while (t < plen - 1 && t < xl - 1 && fs_sel4(lp, plen - 2 - t) == fs_sel4(xp, xl - 2 - t)) t++;
             const int lvl = plen - 1 - t;
             if (lvl < from) from = lvl;
           }
-          wsync_lds();   // (the four items of a ClusterQueue sit in one wave: all of them have read its stale level)
-          if (l == 3 && from0 != 255) stale[i] = 255;   // (the last of the four: the emulation runs them one after the other)
-          if (l < from || l + 1 >= plen) continue;
-          // round 1: what hangs on the entry and on the path
+          if (from + 1 >= plen) { if (from != 255) stale[i] = 255; continue; }
           int nd[4], row[4];
           #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            nd[q] = S.tree_nodes[n0 + (q < plen ? lp[q] : i)];
-            row[q] = (q >= 1 && q < plen && w.pc_on) ? lp[q] - nqs : -1;
+          for (int l = 0; l < 4; l++) {
+            nd[l] = S.tree_nodes[n0 + (l < plen ? lp[l] : i)];
+            row[l] = (l >= 1 && l < plen && w.pc_on) ? lp[l] - nqs : -1;
           }
           const int32_t* ufr = O.use_fr + (size_t)en * KQ_MAXU; const int64_t* uqty = O.use_qty + (size_t)en * KQ_MAXU;
-          const uint32_t hfl = H.flags[en];
-          const int un = O.use_n[en];
-          const int64_t hprio = H.priority[en], hts = H.queue_ts[en];
-          const size_t o = (size_t)i * KQ_MAXD + l;
-          const int32_t cost0 = cost[o];
-          int fr0[4]; int64_t qty0[4];
-          #pragma unroll
-          for (int q = 0; q < 4; q++) { fr0[q] = ufr[q]; qty0[q] = uqty[q]; }   // (KQ_MAXU >= 4 entries per head are allocated)
-          const int nu = (hfl & KQ_HEAD_HAS_QUOTA_RESERVATION) ? 0 : un;  // netUsage scheduler.go:785-794
-          // round 2 (inside): what hangs on the nodes and the flavor-resources
-          int64_t lb = 0;
-          const DRSv d = drs_entry_level_g(k, w, nd, row, l, ufr, uqty, nu, want_bon, &lb, fr0, qty0);
-          const bool zwb = drs_zwb(d);
-          FsKey key;   // fs_make_key on the operands of round 1
-          key.k1 = (gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS) && !(hfl & KQ_HEAD_IS_PREEMPTOR) ? 4u : 0u) |
-                   (gate(k, KQ_GATE_FS_PRIORITIZE_NON_BORROWING) && d.borrow_on ? 2u : 0u) | (zwb ? 1u : 0u);
-          key.k2 = f64_bits(zwb ? d.ratio : drs_pws(d));
-          key.k3 = gate(k, KQ_GATE_PRIORITY_SORTING_IN_COHORT) ? ~((uint64_t)hprio ^ 0x8000000000000000ull) : 0;
-          key.k4 = (uint64_t)hts ^ 0x8000000000000000ull;
-          fkeys[o * 4 + 0] = key.k1; fkeys[o * 4 + 1] = key.k2; fkeys[o * 4 + 2] = key.k3; fkeys[o * 4 + 3] = key.k4;
-          delta += lb - cost0;
-          cost[o] = (int32_t)lb;
+          const int nu = (H.flags[en] & KQ_HEAD_HAS_QUOTA_RESERVATION) ? 0 : O.use_n[en];  // netUsage scheduler.go:785-794
+          for (int l = from; l + 1 < plen; l++) {
+            int64_t lb = 0;
+            const DRSv d = drs_entry_level_g(k, w, nd, row, l, ufr, uqty, nu, want_bon, &lb);
+            const size_t o = (size_t)i * KQ_MAXD + l;
+            const FsKey key = fs_make_key(k, en, d);
+            fkeys[o * 4 + 0] = key.k1; fkeys[o * 4 + 1] = key.k2; fkeys[o * 4 + 2] = key.k3; fkeys[o * 4 + 3] = key.k4;
+            delta += lb - cost[o];
+            cost[o] = (int32_t)lb;
+          }
+          stale[i] = 255;
+          continue;
         }
-      }
-      for (int i = tid; i < nqs; i += nthreads) {
-        const int en = cq_ent[i];
-        if (en < 0) continue;
-        if (quick && it.dep[i] <= 3) continue;   // done above
         const int c = S.tree_cqs[q0 + i];
         const int32_t* path = S.path + (size_t)c * KQ_MAXD;
         const int plen = S.plen[c];

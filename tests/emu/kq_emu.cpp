@@ -16,7 +16,15 @@
 
 namespace kq {
 struct EmuBackend {
-  void* alloc(size_t n) { return calloc(n, 1); }
+  // Device memory is not zeroed by hipMalloc: the emulation hands out POISONED memory (0xA5 bytes; KQE_ZERO_ALLOC=1 restores zeroes), so
+  // that code which only works on zero-initialised buffers fails here and not first on the GPU (round 4: the entries of DOut::use_fr past
+  // use_n are whatever the allocator left there; an address built from one of them faulted on the MI355X while every CPU test passed).
+  void* alloc(size_t n) {
+    static const bool zero = getenv("KQE_ZERO_ALLOC") != nullptr;
+    void* p = malloc(n ? n : 1);
+    if (p) memset(p, zero ? 0 : 0xA5, n);
+    return p;
+  }
   void free(void* p) { ::free(p); }
   void* alloc_host(size_t n) { return calloc(n, 1); }
   void free_host(void* p) { ::free(p); }

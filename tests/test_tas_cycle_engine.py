@@ -6,6 +6,8 @@
    implied TAS (TAS-only queues), slices, podset groups;
  * without TAS flavors the entry point is the ordinary cycle.
 CPU suite: the 1-lane emulation of the same device code (tests/emu). GPU suite (-m gpu): the HIP engine through the C ABI."""
+import copy
+
 import numpy as np
 import pytest
 
@@ -16,6 +18,7 @@ from tests.tasgen_cycle import random_tas_cycle_case
 from tests.test_oracle_schedule_tas import check_case
 
 CASES = load_golden("schedule_tas.yaml")["cases"]
+MANUAL = load_golden("schedule_tas_manual.yaml")   # flavorassigner_test.go tables transcribed as whole cycles (each case cites its line)
 _LAST = {}
 
 
@@ -92,6 +95,44 @@ def test_schedule_tas_emulated(oracle, case):
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"][:80])
 def test_schedule_tas_gpu(oracle, case):
     _golden(oracle, _hip, case)
+
+
+def _bookmark(oracle, make, case):
+    """TestFlavorScanRecordsLastTriedFlavorIdx / TestRecomputeRecordsLastTriedFlavorIdx: what LastState.LastTriedFlavorIdx holds for each
+    shape the flavor scan takes with TAS on — the quota scan writes the bookmark before the placement runs, and a recomputation under
+    the nomination mapping writes it again. The Go expectation first, then everything else against the oracle."""
+    cfg, snap, heads, ct = load_tas_case(case)
+    oracle.derive(snap)
+    want = _same(oracle, make, cfg, snap, heads, ct, tgt_cap=max(16, snap.n_adm))
+    eng = make(cfg)
+    try:
+        eng.put(snap)
+        got, gout = eng.run_tas(heads, ct, tgt_cap=max(16, snap.n_adm))
+    finally:
+        eng.close()
+    e = case["expectAssignment"]
+    i = [w["name"] for w in case["pending"]].index(e["head"])
+    hi = list(heads.names).index(e["head"]) if hasattr(heads, "names") else i
+    ps0 = int(heads.arrays["ps_off"][hi])
+    assert int(got.a["mode"][hi]) == MANUAL["modes"][e["mode"]], (case["name"], int(got.a["mode"][hi]))
+    nR = snap.n_resource
+    for res, idx in e["triedIdx"].items():
+        r = list(snap.resources).index(res)
+        assert int(got.a["tried_idx"][ps0 * nR + r]) == idx, (case["name"], res, got.a["tried_idx"].tolist())
+    if "plan" in e:
+        assert (int(gout.a["ps_tas"][ps0]) >= 0) == e["plan"], case["name"]
+    assert want is not None
+
+
+@pytest.mark.parametrize("case", MANUAL["cases"], ids=lambda c: c["name"][:80])
+def test_flavor_scan_bookmark_emulated(oracle, case):
+    _bookmark(oracle, _emu, case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", MANUAL["cases"], ids=lambda c: c["name"][:80])
+def test_flavor_scan_bookmark_gpu(oracle, case):
+    _bookmark(oracle, _hip, case)
 
 
 def _random(oracle, make, seed):
@@ -261,3 +302,67 @@ def test_full_assignment_keeps_the_pserror_get_targets_left(oracle, seed):
     eng.close()
     assert got.tas_stats["finds"] == want.tas_stats["finds"]
     _same(oracle, _emu, cfg, snap, heads, ct, tgt_cap=max(16, snap.n_adm))
+
+
+# ---- TestScheduleForPreserveFlavorScanProgress (pkg/scheduler/scheduler_preserve_flavor_scan_progress_test.go:82) --------------------
+# Four real scheduling cycles of a fair-sharing ClusterQueue with two TAS flavors: "blocker" fills flavor-1's only node, "pending" needs a
+# whole node, quota alone keeps selecting flavor-1 (4 cpu of quota, 2 cpu of node), TAS turns that into Preempt, nothing can be
+# preempted (equal priorities), and the bookmark of the quota scan is what may carry "pending" to flavor-2 in the next cycle — unless
+# AllocatableResourceGeneration advanced in between and FlavorFungibilityPreserveScanProgress is off. Between the cycles this driver does
+# what the scheduler and the cache do: an admitted workload joins the snapshot with its TopologyAssignment (cache.AssumeWorkload), a
+# requeued one keeps Assignment.LastState (scheduler.go:459-464), the churn bumps the ClusterQueue's generation.
+_PP_NODES = [{"name": f"node-f{i}", "labels": {"tas-node": "true", "tas-flavor": f"f{i}", "kubernetes.io/hostname": f"node-f{i}"},
+              "allocatable": {"cpu": "2", "pods": "10"}, "ready": True} for i in (1, 2)]
+
+
+def _preserve_progress(oracle, make, gate, churn, cycles=4):
+    from kueue_amd import _ffi as F
+    wl = {n: {"name": f"default/{n}", "cq": "tas-cq", "priority": 10, "created": created,
+              "podsets": [dict({"name": "one", "count": 1, "requests": {"cpu": "2"}, "topologyRequest": {"required": "kubernetes.io/hostname"}}, **extra)]}
+          for n, created, extra in (("blocker", -60_000_000_000, {"excludedFlavors": ["tas-flavor-2"]}), ("pending", 0, {}))}
+    admitted, waiting, gen, landed = [], ["blocker", "pending"], 0, {}
+    for cyc in range(1, cycles + 1):
+        if not waiting:
+            break
+        head = copy.deepcopy(wl[waiting[0]])   # one ClusterQueue: Heads() is its first workload (earlier creation first, equal priorities)
+        case = {"name": "preserve", "now": 1_000_000_000_000, "nodes": _PP_NODES, "topologies": {"tas-single-level": ["kubernetes.io/hostname"]},
+                "resourceFlavors": [{"name": f"tas-flavor-{i}", "nodeLabels": {"tas-flavor": f"f{i}"}, "topologyName": "tas-single-level"} for i in (1, 2)],
+                "clusterQueues": [{"name": "tas-cq", "generation": gen, "preemption": {"withinClusterQueue": "LowerPriority", "reclaimWithinCohort": "Any"},
+                                   "resourceGroups": [[{"flavor": "tas-flavor-1", "resources": {"cpu": ["4", "", ""]}},
+                                                       {"flavor": "tas-flavor-2", "resources": {"cpu": ["5" if churn and cyc % 2 == 0 else "4", "", ""]}}]]}],
+                "cohorts": [], "admitted": copy.deepcopy(admitted), "pending": [head], "notHeads": [], "expect": {}, "fairSharing": True,
+                "gates": {"FlavorFungibilityPreserveScanProgress": gate}, "gatesGo": {}}
+        cfg, snap, heads, ct = load_tas_case(case, cycle=cyc)
+        oracle.derive(snap)
+        want = _same(oracle, make, cfg, snap, heads, ct, tgt_cap=16)
+        assert want is not None
+        d, out = oracle.cycle_run_tas(cfg, snap, heads, ct, tgt_cap=16)
+        name = waiting[0]
+        if int(d.a["action"][0]) == F.ACT_ADMIT:
+            fl = d.flavors_of(0)[0]["cpu"][0]
+            ta = out.topology_assignment(0, 0)
+            w = copy.deepcopy(wl[name])
+            w["podsets"][0].update(flavors={"cpu": fl}, topologyAssignment={"levels": ["kubernetes.io/hostname"], "domains": [[list(v), c] for v, c in ta[1]]})
+            admitted.append(w)
+            landed[name] = fl
+            waiting.pop(0)
+        else:  # requeued with what the (recomputed) assignment recorded
+            wl[name]["lastAssignment"] = {"lastTriedFlavorIdx": [{"cpu": d.flavors_of(0)[0]["cpu"][2]}], "generation": gen, "cycle": cyc}
+        if churn:
+            gen += 1   # updateQuotasAndResourceGroups: flavor-2's quota really changes every cycle
+    return landed
+
+
+@pytest.mark.parametrize("gate,churn,want", [(False, True, None), (True, True, "tas-flavor-2"), (False, False, "tas-flavor-2"), (True, False, "tas-flavor-2")],
+                         ids=["gate disabled", "gate enabled", "no generation churn, gate disabled", "no generation churn, gate enabled"])
+def test_preserve_flavor_scan_progress_emulated(oracle, gate, churn, want):
+    landed = _preserve_progress(oracle, _emu, gate, churn)
+    assert landed.get("blocker") == "tas-flavor-1" and landed.get("pending") == want, landed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gate,churn,want", [(False, True, None), (True, True, "tas-flavor-2"), (False, False, "tas-flavor-2"), (True, False, "tas-flavor-2")],
+                         ids=["gate disabled", "gate enabled", "no generation churn, gate disabled", "no generation churn, gate enabled"])
+def test_preserve_flavor_scan_progress_gpu(oracle, gate, churn, want):
+    landed = _preserve_progress(oracle, _hip, gate, churn)
+    assert landed.get("blocker") == "tas-flavor-1" and landed.get("pending") == want, landed
