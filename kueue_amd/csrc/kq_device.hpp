@@ -697,6 +697,8 @@ struct TAW {
   int plane;                      // which leaf-usage plane "the snapshot" is: 0 cycle start, 1 work, 2 work minus preempted rows
   int srch;                       // a GetTargets walk with TAS requests is in flight: its private plane is live
   struct TLeafJob* mail;          // k_process_tas: phase 1 of a placement is shared with the workgroup's helper waves through this LDS block
+  unsigned char* lds;             // k_process_tas: room for a class-path placement's working state (kq_tas_device.hpp TLds), lds_bytes of it
+  int lds_bytes;
 };
 #define KQ_TAS_WALK(w) ((w).ta.srch != 0)
 #else

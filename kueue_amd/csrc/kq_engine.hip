@@ -131,7 +131,7 @@ namespace kq {
 hipError_t launch_tas_base_k(const TCyc* c, int n, hipStream_t stream);
 hipError_t launch_nominate_tas_k(const K* d, int slots, hipStream_t stream);
 hipError_t launch_tas_cycle_classes_k(const TCyc* c, int n, hipStream_t stream);
-hipError_t launch_process_tas_k(const K* d, hipStream_t stream);
+hipError_t launch_process_tas_k(const K* d, size_t want, size_t* attr, hipStream_t stream);
 }
 
 constexpr int PROCESS_THREADS = 256;   // wave 0 runs the serial core; all 4 waves prefetch the entry records of a chunk
@@ -741,11 +741,12 @@ struct HipBackend {
     const K* d = put_k(k, 0);
     chk(launch_nominate_tas_k(d, slots, stream), "k_nominate_tas");
   }
-  void launch_process_tas(const K& k) {
+  void launch_process_tas(const K& k, size_t lds_want) {
     const K* d = stat_patched ? dcur0 : put_k(k, 1);
     dproc = d; stat_patched = false;
-    chk(launch_process_tas_k(d, stream), "k_process_tas");
+    chk(launch_process_tas_k(d, lds_want, &lds_attr_tas, stream), "k_process_tas");
   }
+  size_t lds_attr_tas = 0;
   size_t lds_attr = 0, lds_attr_fair = 0;
   const K* dproc = nullptr;    // argument block of the last process launch (kq_cycle_commit reads the cycle's outputs through it)
   bool stat_patched = false;

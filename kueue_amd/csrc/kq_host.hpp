@@ -917,6 +917,7 @@ template <class B> struct EngineT {
   size_t tnext = 0;
   bool tas_classes_off = getenv("KQ_TAS_CLASSES_OFF") != nullptr;   // (A/B switch and tests: every placement of k_process_tas runs its own phase 1)
   int tas_n_cls = 0;       // (TAS flavor, request class) pairs of the cycle being enqueued
+  size_t tas_lds_want = 0; // LDS a class-path placement's working state takes on the largest TAS flavor (kq_tas_device.hpp TLds)
   template <class T> T* tgrow(size_t n) { if (tnext >= tbuf.size()) tbuf.resize(tnext + 16); return grow<T>(tbuf[tnext++], n); }
   template <class T> T* tstage(const T* host, size_t n) { T* d = tgrow<T>(n); if (n) be.h2d(d, host, n * sizeof(T)); return d; }
   int cycle_run_tas(const kq_heads* h, const kq_cycle_tas* t, kq_decisions* out, kq_cycle_tas_out* tout, int64_t* stats) {
@@ -1093,6 +1094,8 @@ template <class B> struct EngineT {
       be.sync();  // (locals)
     }
     tas_n_cls = nt * ncls;
+    tas_lds_want = 0;
+    if (ncls > 0) for (int i = 0; i < nt; i++) tas_lds_want = std::max(tas_lds_want, tas_lds_layout(tks[i].T.D, tks[i].X.max_set).total);
     TCyc* d_tc = tstage(&c, 1);
     if (n_ent > 0) be.launch_tas_base(d_tc, n_ent);   // base plane += workload.TASUsage() of every admitted row
     for (int i = 0; i < nt; i++) {
@@ -1380,7 +1383,7 @@ template <class B> struct EngineT {
     be.timer_mark(2);
     k.O.stat_bytes = (long long*)(misc + 2);
     if (nominate_only) {}
-    else if (d_tc) { if (tas_n_cls > 0) be.launch_tas_cycle_classes(d_tc, tas_n_cls); be.launch_process_tas(k); }   // one wave, every tree, entry order (fair sharing: the iterators of the trees interleaved): TAS leaves are shared across root cohorts
+    else if (d_tc) { if (tas_n_cls > 0) be.launch_tas_cycle_classes(d_tc, tas_n_cls); be.launch_process_tas(k, tas_lds_want); }   // one wave, every tree, entry order (fair sharing: the iterators of the trees interleaved): TAS leaves are shared across root cohorts
     else if (cfg.fair_sharing) {
       if (n_help > 0) { k.help = d_help; k.help_quit = (uint32_t*)(d_help + prep.n_tree); k.help_trees = prep.n_tree; }
       be.launch_process_fair(k, prep.n_tree, (size_t)prep.max_tree_cohorts * prep.nfr * 16, fs_want, rank);

@@ -166,6 +166,8 @@ KQ_DEV void tc_class_update(const K& k, const Wave& w) {
     T.tas_usage = c.work[t];
     const int32_t* par = c.par[t]; int32_t* flag = c.cflag[t];
     const int n = c.h_n[g], pos = c.h_pos[g], items = n * c.ncls;
+    // (a placement that keeps its working state in LDS fills it from the table every time: no working copies to maintain)
+    const bool copies = !(w.ta.lds && tas_lds_layout(T.D, c.tk[t].X.max_set).total <= (size_t)w.ta.lds_bytes);
     // A: leaves, podCount deltas up the tree (and the sliceCount deltas when the leaves are the slice level)
     for (int i = lane; i < items; i += WAVE) {
       const int cls = i / n, j = i % n;
@@ -207,7 +209,7 @@ KQ_DEV void tc_class_update(const K& k, const Wave& w) {
       for (int x = T.leaf_base + c.pool_leaf[pos + j]; x >= 0; x = par[x], lvl--) {
         const int32_t v0 = (int32_t)ag_load_u32((const uint32_t*)&a.pc[x]), v1 = (int32_t)ag_load_u32((const uint32_t*)&a.sc[x]);
         a.pc[x] = v0; a.pcwl[x] = v0; a.sc[x] = v1; a.scwl[x] = v1;
-        b.pc[x] = v0; b.pcwl[x] = v0; b.sc[x] = v1; b.scwl[x] = v1; b.lc[x] = 0;
+        if (copies) { b.pc[x] = v0; b.pcwl[x] = v0; b.sc[x] = v1; b.scwl[x] = v1; b.lc[x] = 0; }
         if (lvl == a.sliceLevelIdx) flag[(size_t)cls * T.D + x] = 0;
       }
     }
@@ -325,6 +327,7 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
   tk.O.pool_used = qi + TQ_MISC; tk.O.error = qi + TQ_MISC + 1; tk.O.bytes = (long long*)(qi + TQ_MISC + 2);
   tk.C.n = 0;
   tk.mail = w.ta.mail;
+  tk.lds = nullptr;
   int xslot = slot;
   if (which == 1 && !simulateEmpty && n == 1 && c.ncls > 0) {   // processEntry on the work plane: start from the class's resident phase 1
     const int g = w.ps_base + w.ta.req_ps[0];
@@ -336,6 +339,7 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
       tk.C.pc = tab; tk.C.sc = tab + nD; tk.C.pcwl = tab + 2 * nD; tk.C.scwl = tab + 3 * nD; tk.C.lc = tab + 4 * nD;
       tk.C.bytes = c.cls_bytes[t];
       xslot = c.slots + cls;
+      if (w.ta.lds && tas_lds_layout(tk.T.D, tk.X.max_set).total <= (size_t)w.ta.lds_bytes) tk.lds = w.ta.lds;   // the working state in LDS
       if (lane == 0 && c.stats) atomic_add_i64(c.stats + 3, 1);
     }
   }
@@ -664,8 +668,11 @@ KQ_NOINLINE void process_entry_tas(const K& k, Wave& w, int e, int pos, int slot
     np_apply_targets(k, w, trows, nt, false, false, tree);
     for (int t = lane; t < nt; t += WAVE) if (k.preempted[trows[t]] == 3) k.preempted[trows[t]] = 1;
     wsync();
+    KQ_TS(k, 59);   // (timing builds) preemptedWorkloads.Insert
     if (quota_usage) entry_add_usage(k, w, w.use_qty);
+    KQ_TS(k, 60);   // AddUsage on the quota planes
     tc_entry_add(k, w);
+    KQ_TS(k, 61);   // leaf usage + the class tables
     if (mode == M_PREEMPT) { action = KQ_ACT_PREEMPT; rq = KQ_RQ_PENDING_PREEMPTION; }
     else { status = KQ_ST_ASSUMED; action = KQ_ACT_ADMIT; }
   }
@@ -821,10 +828,10 @@ KQ_DEV void process_all_fair_tas(const K& k, Wave& w, int slot) {
 }
 
 // k_process_tas: one wave walks every entry in iterator order
-KQ_DEV void process_all_tas(const K& k, Wave& w, int slot, TLeafJob* mail) {
+KQ_DEV void process_all_tas(const K& k, Wave& w, int slot, TLeafJob* mail, unsigned char* lds, int lds_bytes) {
   const int n = hn(k.H);
   if (lane_id() == 0) {
-    w.ta.mail = mail;
+    w.ta.mail = mail; w.ta.lds = lds_bytes > 0 ? lds : nullptr; w.ta.lds_bytes = lds_bytes;
     w.pc_on = 0; w.pc_lds = nullptr; w.np_broken = 0; w.n_pre = 0; w.broken[0] = w.broken[1] = w.broken[2] = w.broken[3] = 0;
     w.cs_lds = nullptr; w.cs_lds_bytes = 0; w.help_on = 0; w.mono_break = 0; w.ta.plane = 1; w.ta.srch = 0;
   }

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64) void k_tas_cycle_classes(const TCyc* __restrict
 __global__ __launch_bounds__(64) void k_nominate_tas(const K* __restrict__ kp, int slots) {
   const K& k = *kp;
   __shared__ Wave w;
-  if (threadIdx.x == 0) { w.cs_lds = nullptr; w.cs_lds_bytes = 0; w.help_on = 0; w.ta.plane = 0; w.ta.srch = 0; w.ta.mail = nullptr; }
+  if (threadIdx.x == 0) { w.cs_lds = nullptr; w.cs_lds_bytes = 0; w.help_on = 0; w.ta.plane = 0; w.ta.srch = 0; w.ta.mail = nullptr; w.ta.lds = nullptr; w.ta.lds_bytes = 0; }
   __syncthreads();
   const int slot = blockIdx.x;
   for (int h = slot, n = hn(k.H); h < n; h += slots) nominate_head(k, w, h, slot);
@@ -34,13 +34,15 @@ __global__ __launch_bounds__(64) void k_nominate_tas(const K* __restrict__ kp, i
 // wave 0 walks the entries; waves 1..3 wait for the placements' phase-1 jobs (TLeafJob in LDS) and fill their stripes of the leaves.
 // 256 threads = one wave per SIMD: the leader keeps its 512 registers.
 constexpr int PROCESS_TAS_THREADS = 256;
-__global__ __launch_bounds__(PROCESS_TAS_THREADS) void k_process_tas(const K* __restrict__ kp) {
+// lds_bytes of dynamic LDS hold the working state of a class-path placement (kq_tas_device.hpp TLds); 0 = the slot's global rows
+__global__ __launch_bounds__(PROCESS_TAS_THREADS) void k_process_tas(const K* __restrict__ kp, unsigned lds_bytes, int coop_min) {
   __shared__ Wave w;
   __shared__ TLeafJob job;
-  if (threadIdx.x == 0) { job.cmd = 0; job.nw = PROCESS_TAS_THREADS / 64; job.bytes = 0; }
+  extern __shared__ __align__(16) unsigned char dyn_lds[];
+  if (threadIdx.x == 0) { job.cmd = 0; job.nw = PROCESS_TAS_THREADS / 64; job.bytes = 0; job.coop_min = coop_min; }
   __syncthreads();
   if (threadIdx.x < 64) {
-    process_all_tas(*kp, w, 0, &job);
+    process_all_tas(*kp, w, 0, &job, dyn_lds, (int)lds_bytes);
     if (threadIdx.x == 0) job.cmd = 2;
     __syncthreads();
   } else {
@@ -64,8 +66,21 @@ hipError_t launch_nominate_tas_k(const K* d, int slots, hipStream_t stream) {
   hipLaunchKernelGGL(k_nominate_tas, dim3(slots), dim3(64), 0, stream, d, slots);
   return hipGetLastError();
 }
-hipError_t launch_process_tas_k(const K* d, hipStream_t stream) {
-  hipLaunchKernelGGL(k_process_tas, dim3(1), dim3(PROCESS_TAS_THREADS), 0, stream, d);
+// want = bytes of LDS a placement's working state needs (0: none); granted when it fits next to the kernel's static LDS
+hipError_t launch_process_tas_k(const K* d, size_t want, size_t* attr_p, hipStream_t stream) {
+  size_t& attr = *attr_p;   // (per engine: the attribute is per device)
+  hipFuncAttributes fa{};
+  hipError_t e = hipFuncGetAttributes(&fa, (const void*)k_process_tas);
+  if (e != hipSuccess) return e;
+  const size_t room = (size_t)160 * 1024 - fa.sharedSizeBytes - 256;
+  const size_t lds = (want > 0 && want <= room && !getenv("KQ_TAS_LDS_OFF")) ? want : 0;
+  if (lds > attr) {
+    e = hipFuncSetAttribute((const void*)k_process_tas, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr = lds;
+  }
+  const char* cm = getenv("KQ_TAS_COOP_MIN");   // (tests: short slices shared as well)
+  hipLaunchKernelGGL(k_process_tas, dim3(1), dim3(PROCESS_TAS_THREADS), lds, stream, d, (unsigned)lds, cm ? atoi(cm) : 1024);
   return hipGetLastError();
 }
 }  // namespace kq

@@ -70,7 +70,24 @@ struct TClass {
   const int32_t* order;             // [n_wl] workloads sorted by class: a slot walks a contiguous piece
 };
 struct TLeafJob;
-struct TK { TTopo T; TReq Q; TOut O; TScratch X; TClass C; TLeafJob* mail; };  // mail: phase 1 shared with the helper waves of the workgroup (null: none)
+// k_process_tas only: the working state of a class-path placement in the workgroup's LDS instead of the slot's global rows. A lone wave
+// pays an L2 round trip (1 500-2 000 cycles) per dependent access to its scratch rows, and a placement is a chain of them: sweep, reduce,
+// write the winner, read it back. In LDS the same chain costs ~100 cycles a link. What lives there: the counts (podCount, sliceCount
+// of every domain: a class has no leader, so the ...WithLeader arrays ARE these arrays and there is no leaderCount array at all,
+// TState::nolead), the sort keys of the slice being walked, its materialised prefix, currFitDomain x2 and the meta words. The slice's
+// id list (set: written once, read by index) and the log stay in global memory. 148.5 KB for 4096 leaves, next to 8.8 KB of static LDS.
+struct TLdsLay { size_t k0, k1, pc, sc, arr, cur, nxt, meta, total; };
+KQ_HD TLdsLay tas_lds_layout(int D, int max_set) {
+  TLdsLay l{};
+  size_t o = 0;
+  auto take = [&](size_t b) { const size_t at = o; o += (b + 15) & ~(size_t)15; return at; };
+  l.k0 = take((size_t)max_set * 8); l.k1 = take((size_t)max_set * 8);
+  l.pc = take((size_t)D * 4); l.sc = take((size_t)D * 4);
+  l.arr = take(((size_t)max_set + 1) * 4); l.cur = take((size_t)max_set * 4); l.nxt = take((size_t)max_set * 4); l.meta = take(16);
+  l.total = o;
+  return l;
+}
+struct TK { TTopo T; TReq Q; TOut O; TScratch X; TClass C; TLeafJob* mail; unsigned char* lds; };  // mail: phase 1 shared with the helper waves of the workgroup (null: none); lds: see TLds (null: the slot's global rows)
 
 struct TState {  // per-slot pointers
   int32_t *pc, *sc, *pcwl, *scwl, *lc, *set, *arr, *cur, *nxt;
@@ -78,12 +95,18 @@ struct TState {  // per-slot pointers
   int64_t* assumed;
   int32_t *log, *meta;
   int logcap;
+  bool nolead;   // leaderCount is 0 everywhere and stays 0: no lc array
+  TLeafJob* coop;   // the state is in LDS and the workgroup has helper waves: long slices are swept together (null: alone)
+  int coop_min;
 };
 // lane 0 records a domain whose state it is about to change
 KQ_DEV void t_touch(const TState& s, int d) {
   const int n = s.meta[0];
   if (n < s.logcap) { s.log[n] = d; s.meta[0] = n + 1; } else s.meta[1] = 1;
 }
+// leaderCount of domain d: a state without leaders (TState::nolead: the LDS working copy of a request class) holds no such array
+KQ_DEV int32_t t_lc(const TState& s, int d) { return s.nolead ? 0 : s.lc[d]; }
+KQ_DEV void t_set_lc(const TState& s, int d, int32_t v) { if (!s.nolead) s.lc[d] = v; }
 KQ_DEV TState tas_state(const TK& k, int slot) {
   TState s;
   const size_t D = k.T.D, M = k.X.max_set;
@@ -92,6 +115,15 @@ KQ_DEV TState tas_state(const TK& k, int slot) {
   s.k0 = k.X.k0 + slot * M; s.k1 = k.X.k1 + slot * M;
   s.assumed = k.X.assumed + (size_t)slot * k.T.n_leaves * k.T.R;
   s.log = k.X.log + slot * M; s.meta = k.X.meta + (size_t)slot * 4; s.logcap = (int)M;
+  s.nolead = false; s.coop = nullptr; s.coop_min = 0;
+  if (k.lds) {
+    const TLdsLay l = tas_lds_layout(k.T.D, (int)M);
+    s.k0 = (uint64_t*)(k.lds + l.k0); s.k1 = (uint64_t*)(k.lds + l.k1);
+    s.pc = (int32_t*)(k.lds + l.pc); s.sc = (int32_t*)(k.lds + l.sc);
+    s.pcwl = s.pc; s.scwl = s.sc;   // no leader in a class: the placement never writes the ...WithLeader counts, and the table holds the same values
+    s.lc = nullptr; s.nolead = true;
+    s.arr = (int32_t*)(k.lds + l.arr); s.cur = (int32_t*)(k.lds + l.cur); s.nxt = (int32_t*)(k.lds + l.nxt); s.meta = (int32_t*)(k.lds + l.meta);
+  }
   return s;
 }
 
@@ -164,13 +196,51 @@ struct TLeafArgs {
   int simulateEmpty, hasAssumed, sliceLevelIdx;
   int32_t sliceSize;
 };
+// one sweep over a slice of domains (t_view_first_fit): what it is after, and what a wave found in its share of the elements
+struct TSweepArgs { int n, order, id0; bool lfc, by_order; int32_t needed, leaderCount; int which; };
+struct TSweepRes { uint64_t m0, m1, g, g0, g1; };   // slice order minimum; (count, slice order) minimum over the holders (g = ~0: none)
 struct TLeafJob {
   TTopo T;
   TLeafArgs a;
-  int cmd;            // 0 idle, 1 job posted, 2 quit
+  int cmd;            // 0 idle, 1 phase-1 job posted, 2 quit, 3 copy job posted (a.pc / a.sc = the class table's rows, cp_* = the LDS arrays)
   int nw;             // waves of the workgroup sharing the job (set once by the kernel that owns the helpers)
+  int coop_min;       // slices at least this long are swept by every wave of the workgroup (two barriers: ~1 us; set once, 1024 unless a test says otherwise)
   long long bytes;    // helpers add their share
+  int32_t *cp_pc, *cp_sc;
+  int cp_n;
+  // cmd 4: a fused sweep (t_sweep_part) / cmd 5: the arg-min over the keys not yet produced (t_get) — of a state in LDS, shared by the waves
+  TState sw_s;
+  TSweepArgs sw_a;
+  TSweepRes sw_r[8];
+  int ar_n, ar_started, ar_skip;
+  uint64_t ar_c0, ar_c1, ar_m0[8], ar_m1[8];
 };
+// A class's phase-1 rows (global memory, patched by L2 atomics: agent-scope loads, so that no stale line of this CU's vector cache is
+// read) into the LDS working copy; thread tid of nthreads. Eight 8-byte loads per array in flight per thread: 4168 domains are one round
+// trip for 256 threads.
+KQ_DEV void t_class_copy(const int32_t* spc, const int32_t* ssc, int32_t* dpc, int32_t* dsc, int n, int tid, int nthreads) {
+  const int32_t* src[2] = {spc, ssc};
+  int32_t* dst[2] = {dpc, dsc};
+  #pragma unroll
+  for (int a = 0; a < 2; a++) {
+    const int h = (int)(((uintptr_t)src[a] >> 2) & 1);   // one leading element up to 8-byte alignment
+    const int n2 = n > h ? (n - h) / 2 : 0;
+    if (tid == 0 && h && n > 0) dst[a][0] = (int32_t)ag_load_u32((const uint32_t*)src[a]);
+    if (tid == 0 && n > h && ((n - h) & 1)) dst[a][n - 1] = (int32_t)ag_load_u32((const uint32_t*)src[a] + n - 1);
+    const uint64_t* s2 = (const uint64_t*)(src[a] + h);
+    constexpr int U = 8;
+    for (int b = tid; b < n2; b += nthreads * U) {
+      uint64_t v[U];
+      #pragma unroll
+      for (int q = 0; q < U; q++) { const int i = b + q * nthreads; v[q] = i < n2 ? ag_load_u64(s2 + i) : 0; }
+      #pragma unroll
+      for (int q = 0; q < U; q++) {
+        const int i = b + q * nthreads;
+        if (i < n2) { dst[a][h + 2 * i] = (int32_t)(uint32_t)v[q]; dst[a][h + 2 * i + 1] = (int32_t)(uint32_t)(v[q] >> 32); }
+      }
+    }
+  }
+}
 // leaves first, first + stride, ...: U leaves per step so that the next one's rows are in flight while the first one divides.
 // RM = 4 keeps the per-pod requests (incl. the pod itself; 0 = not requested) in registers; the general case reads them per use.
 template <int RM, int U> KQ_DEV int64_t t_leaf_counts(const TTopo& T, const TLeafArgs& a, int first, int stride) {
@@ -236,13 +306,49 @@ KQ_DEV int64_t t_leaf_counts_any(const TTopo& T, const TLeafArgs& a, int first, 
   return T.R <= 4 ? t_leaf_counts<4, 2>(T, a, first, stride) : t_leaf_counts<KQ_TAS_MAXR, 1>(T, a, first, stride);
 }
 // helper waves of a workgroup whose wave 0 posts phase-1 jobs (k_process_tas): wave `wv` of `nw`
+KQ_DEV void t_sweep_help(TLeafJob& job, int wv, int nw);
+KQ_DEV void t_argmin_help(TLeafJob& job, int wv, int nw);
+// one posted job, wave wv's share of it
+KQ_DEV void t_helper_step(TLeafJob& job, int wv, int nw) {
+  if (job.cmd == 3) {
+    t_class_copy(job.a.pc, job.a.sc, job.cp_pc, job.cp_sc, job.cp_n, wv * WAVE + lane_id(), nw * WAVE);
+  } else if (job.cmd == 4) {
+    t_sweep_help(job, wv, nw);
+  } else if (job.cmd == 5) {
+    t_argmin_help(job, wv, nw);
+  } else {
+    const int64_t lb = wsum_i64(t_leaf_counts_any(job.T, job.a, wv * WAVE + lane_id(), nw * WAVE));
+    if (lane_id() == 0 && lb) atomic_add_i64(&job.bytes, (long long)lb);
+  }
+}
 KQ_DEV void t_leaf_helper(TLeafJob& job, int wv, int nw) {
   for (;;) {
     bsync();
     if (job.cmd == 2) break;
-    const int64_t lb = wsum_i64(t_leaf_counts_any(job.T, job.a, wv * WAVE + lane_id(), nw * WAVE));
-    if (lane_id() == 0 && lb) atomic_add_i64(&job.bytes, (long long)lb);
+    t_helper_step(job, wv, nw);
     bsync();
+  }
+}
+// the 1-lane emulation has no concurrent waves: the leader plays the helpers' shares itself, right after posting a job
+#ifdef KQ_HOST_EMU
+#define KQ_TAS_EMU_HELPERS(j) do { for (int _wv = 1; _wv < (j).nw; _wv++) t_helper_step((j), _wv, (j).nw); } while (0)
+#else
+#define KQ_TAS_EMU_HELPERS(j) do {} while (0)
+#endif
+// the leader's side of a copy job: with helper waves the rows are split over the workgroup, alone the wave copies them itself
+KQ_DEV void t_class_to_lds(const TK& k, const TState& s, int cls) {
+  const TTopo& T = k.T;
+  const int32_t* spc = k.C.pc + (size_t)cls * T.D; const int32_t* ssc = k.C.sc + (size_t)cls * T.D;
+  if (k.mail) {
+    TLeafJob& j = *k.mail;
+    if (lane_id() == 0) { j.a.pc = (int32_t*)spc; j.a.sc = (int32_t*)ssc; j.cp_pc = s.pc; j.cp_sc = s.sc; j.cp_n = T.D; j.cmd = 3; }
+    bsync();
+    KQ_TAS_EMU_HELPERS(j);
+    t_class_copy(spc, ssc, s.pc, s.sc, T.D, lane_id(), j.nw * WAVE);
+    bsync();
+  } else {
+    t_class_copy(spc, ssc, s.pc, s.sc, T.D, lane_id(), WAVE);
+    wsync();
   }
 }
 
@@ -250,7 +356,7 @@ KQ_DEV void t_leaf_helper(TLeafJob& job, int wv, int nw) {
 KQ_DEV void t_fill_in_counts(const TK& k, const TState& s, const TParams& p, long long* bytes_out) {
   const TTopo& T = k.T;
   const int lane = lane_id();
-  for (int d = lane; d < T.leaf_base; d += WAVE) { s.pc[d] = 0; s.sc[d] = 0; s.pcwl[d] = 0; s.scwl[d] = 0; s.lc[d] = 0; }
+  for (int d = lane; d < T.leaf_base; d += WAVE) { s.pc[d] = 0; s.sc[d] = 0; s.pcwl[d] = 0; s.scwl[d] = 0; t_set_lc(s, d, 0); }
   int64_t lb = 0;
   {
     const TLeafArgs a{s.pc, s.sc, s.pcwl, s.scwl, s.lc, s.assumed, p.req, p.leaderReq, p.leafOk, p.simulateEmpty ? 1 : 0, p.hasAssumed ? 1 : 0, p.sliceLevelIdx, p.sliceSize};
@@ -258,6 +364,7 @@ KQ_DEV void t_fill_in_counts(const TK& k, const TState& s, const TParams& p, lon
       TLeafJob& j = *k.mail;
       if (lane == 0) { j.T = T; j.a = a; j.bytes = 0; j.cmd = 1; }
       bsync();
+      KQ_TAS_EMU_HELPERS(j);
       lb = t_leaf_counts_any(j.T, j.a, lane, j.nw * WAVE);
       bsync();
       if (lane == 0) lb += j.bytes;
@@ -275,7 +382,7 @@ KQ_DEV void t_fill_in_counts(const TK& k, const TState& s, const TParams& p, lon
       const int32_t innerSize = t_size_at(p, level + 1);  // a child at a constrained level only contributes whole inner slices (:1950-1967)
       for (int c = c0; c < c0 + cn; c++) {
         int32_t cpc = s.pc[c], cpcwl = s.pcwl[c];
-        const int32_t csc = s.sc[c], cscwl = s.scwl[c], clc = s.lc[c];
+        const int32_t csc = s.sc[c], cscwl = s.scwl[c], clc = t_lc(s, c);
         if (innerSize > 0) { cpc = (cpc / innerSize) * innerSize; cpcwl = (cpcwl / innerSize) * innerSize; }
         childrenCapacity += cpc;
         sliceCapacity += csc;
@@ -289,7 +396,7 @@ KQ_DEV void t_fill_in_counts(const TK& k, const TState& s, const TParams& p, lon
       int32_t pcwl = 0, scwl = 0;
       if (contributor) { pcwl = childrenCapacity - minPodDiff; scwl = sliceCapacity - minSliceDiff; }
       if (level == p.sliceLevelIdx) { sliceCapacity = childrenCapacity / p.sliceSize; scwl = pcwl / p.sliceSize; }
-      s.pc[d] = childrenCapacity; s.pcwl[d] = pcwl; s.lc[d] = leaderCount; s.sc[d] = sliceCapacity; s.scwl[d] = scwl;
+      s.pc[d] = childrenCapacity; s.pcwl[d] = pcwl; t_set_lc(s, d, leaderCount); s.sc[d] = sliceCapacity; s.scwl[d] = scwl;
       lb += 24;
     }
     wsync();
@@ -315,7 +422,7 @@ KQ_DEV int t_dom(uint64_t k1) { return (int)(uint32_t)(k1 & 0xffffffffu); }
 KQ_DEV void t_key_of(const TState& s, int d, int pos, int order, bool lfc, uint64_t* k0, uint64_t* k1) {
   if (order == ORD_LIST) { *k0 = 0; *k1 = ((uint64_t)(uint32_t)pos << 32) | (uint32_t)d; return; }
   const bool wl = order == ORD_LEADER;
-  const uint32_t lcv = wl ? (uint32_t)s.lc[d] : 0u;
+  const uint32_t lcv = wl ? (uint32_t)t_lc(s, d) : 0u;
   const uint32_t scv = (uint32_t)(wl ? s.scwl[d] : s.sc[d]);
   const uint32_t pcv = (uint32_t)(wl ? s.pcwl[d] : s.pc[d]);
   // leaderCount descending, sliceCount descending (BestFit) / ascending (LeastFreeCapacity), podCount ascending, levelValues
@@ -323,7 +430,7 @@ KQ_DEV void t_key_of(const TState& s, int d, int pos, int order, bool lfc, uint6
   *k1 = ((uint64_t)pcv << 32) | (uint32_t)d;
 }
 KQ_DEV bool t_key_lt(uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1) { return a0 < b0 || (a0 == b0 && a1 < b1); }
-KQ_DEV bool t_all_zero(const TState& s, int d) { return (s.pc[d] | s.sc[d] | s.pcwl[d] | s.scwl[d] | s.lc[d]) == 0; }
+KQ_DEV bool t_all_zero(const TState& s, int d) { return (s.pc[d] | s.sc[d] | s.pcwl[d] | s.scwl[d] | t_lc(s, d)) == 0; }
 
 // s.set[0..n) must hold the slice. In the sorted orders, domains with an all-zero state are dropped: in every loop of
 // phase 2 they neither change a remaining count nor survive into the assignment (buildTopologyAssignmentForLevels :1690
@@ -343,21 +450,21 @@ KQ_DEV TView t_view(const TK& k, const TState& s, int n, int order, bool unconst
 }
 // wave arg-min over the elements accepted by `sel`, ranked by sel.rank (default: the slice order: the winner is
 // t_dom(*o1)); false if no element is accepted
-template <class SEL> KQ_DEV bool t_argmin(const TState& s, const TView& v, const SEL& sel, uint64_t* o0, uint64_t* o1, bool with_excluded = false) {
+template <class SEL> KQ_DEV void t_argmin_part(const TState& s, int n, const SEL& sel, bool with_excluded, int tid, int nth, uint64_t* m0o, uint64_t* m1o) {
   uint64_t b0 = ~0ull, b1 = ~0ull;
   // a lone wave is latency-bound: fetch the keys of UNR strided elements before looking at any of them
   constexpr int UNR = 8;
-  for (int base = lane_id(); base < v.n; base += WAVE * UNR) {
+  for (int base = tid; base < n; base += nth * UNR) {
     uint64_t k0v[UNR], k1v[UNR];
     #pragma unroll
     for (int q = 0; q < UNR; q++) {
-      const int i = base + q * WAVE;
-      k0v[q] = i < v.n ? s.k0[i] : KQ_TAS_EXCLUDED;
-      k1v[q] = i < v.n ? s.k1[i] : 0;
+      const int i = base + q * nth;
+      k0v[q] = i < n ? s.k0[i] : KQ_TAS_EXCLUDED;
+      k1v[q] = i < n ? s.k1[i] : 0;
     }
     #pragma unroll
     for (int q = 0; q < UNR; q++) {
-      if (base + q * WAVE >= v.n) continue;
+      if (base + q * nth >= n) continue;
       uint64_t a0 = k0v[q];
       const uint64_t a1 = k1v[q];
       if (a0 & KQ_TAS_EXCLUDED) { if (!with_excluded) continue; a0 &= ~KQ_TAS_EXCLUDED; }
@@ -368,7 +475,12 @@ template <class SEL> KQ_DEV bool t_argmin(const TState& s, const TView& v, const
     }
   }
   const uint64_t m0 = wmin_u64(b0);
-  const uint64_t m1 = wmin_u64(b0 == m0 ? b1 : ~0ull);
+  *m0o = m0;
+  *m1o = wmin_u64(b0 == m0 ? b1 : ~0ull);
+}
+template <class SEL> KQ_DEV bool t_argmin(const TState& s, const TView& v, const SEL& sel, uint64_t* o0, uint64_t* o1, bool with_excluded = false) {
+  uint64_t m0, m1;
+  t_argmin_part(s, v.n, sel, with_excluded, lane_id(), WAVE, &m0, &m1);
   if (m0 == ~0ull && m1 == ~0ull) return false;
   *o0 = m0; *o1 = m1;
   return true;
@@ -381,11 +493,12 @@ struct SelRest {
   KQ_MDEV void rank(uint64_t*, uint64_t*) const {}
 };
 // domains[i]: materialise the slice up to index i; -1 past the end
+KQ_DEV bool t_argmin_rest_coop(const TState& s, const TView& v, const SelRest& sel, uint64_t* o0, uint64_t* o1);
 KQ_DEV int t_get(const TState& s, TView& v, int i) {
   while (v.mat <= i) {
     SelRest sel{v.started, v.c0, v.c1, v.skip};
     uint64_t o0 = 0, o1 = 0;
-    if (!t_argmin(s, v, sel, &o0, &o1)) return -1;
+    if (!(s.coop && v.n >= s.coop_min ? t_argmin_rest_coop(s, v, sel, &o0, &o1) : t_argmin(s, v, sel, &o0, &o1))) return -1;
     const int d = t_dom(o1);
     v.started = true; v.c0 = o0; v.c1 = o1;
     if (lane_id() == 0) s.arr[v.mat] = d;
@@ -403,7 +516,7 @@ struct SelFitCount {  // rank = the count itself
   KQ_MDEV bool take(uint64_t a0, uint64_t a1) const {
     if (!r.rest(a0, a1)) return false;
     const int d = t_dom(a1);
-    if (s->lc[d] < leaderCount) return false;
+    if (t_lc(*s, d) < leaderCount) return false;
     const int32_t c = t_count_of(*s, d, which);
     return c >= needed && c < below;
   }
@@ -414,7 +527,7 @@ struct SelFitEq {  // the first element, in slice order, having exactly `want`
   KQ_MDEV bool take(uint64_t a0, uint64_t a1) const {
     if (!r.rest(a0, a1)) return false;
     const int d = t_dom(a1);
-    return s->lc[d] >= leaderCount && t_count_of(*s, d, which) == want;
+    return t_lc(*s, d) >= leaderCount && t_count_of(*s, d, which) == want;
   }
   KQ_MDEV void rank(uint64_t*, uint64_t*) const {}
 };
@@ -425,7 +538,7 @@ KQ_DEV int t_best_fit(const TState& s, TView& v, int from, int32_t needed, int w
   int best = -1; int32_t bestCount = 0x7fffffff;
   for (int i = from; i < v.mat; i++) {
     const int d = s.arr[i];
-    if (s.lc[d] < leaderCount) continue;
+    if (t_lc(s, d) < leaderCount) continue;
     const int32_t c = t_count_of(s, d, which);
     if (c >= needed && c < bestCount) { best = d; bestCount = c; }
   }
@@ -458,69 +571,122 @@ KQ_DEV int t_best_fit_slices(const TState& s, TView& v, int from, int32_t sliceC
 // The view comes back with domains[0] materialised, exactly as after t_view + t_get(.., 0).
 // id0 >= 0: the slice is the contiguous id range [id0, id0 + n) (a whole level, the children of one domain) — s.set holds the same
 // values but is not read here, so the caller needs no fence between writing it and this sweep.
-KQ_DEV TView t_view_first_fit(const TK& k, const TState& s, int n, int order, bool unconstrained, int32_t needed, int which, int32_t leaderCount,
-                              int* first, int* fit, int id0 = -1) {
-  TView v;
-  v.n = n; v.order = order; v.lfc = t_lfc(k, unconstrained); v.mat = 0; v.c0 = 0; v.c1 = 0; v.started = false; v.skip = -1;
+// elements tid, tid + nth, ... of the slice; the result is the wave's (every lane holds it)
+KQ_DEV TSweepRes t_sweep_part(const TState& s, const TSweepArgs& a, int tid, int nth) {
+  const int n = a.n, order = a.order, id0 = a.id0, which = a.which;
   uint64_t b0 = ~0ull, b1 = ~0ull;               // slice order
   uint64_t f0 = ~0ull, f1 = ~0ull, fc = ~0ull;   // (count, slice order) over the holders
   // a lone wave is latency-bound: the rows of UNR strided elements are in flight before any of them is looked at
   constexpr int UNR = 8;
-  for (int base = lane_id(); base < n; base += WAVE * UNR) {
+  for (int base = tid; base < n; base += nth * UNR) {
     int dv[UNR]; int32_t pcv[UNR], scv[UNR], pwv[UNR], swv[UNR], lcv[UNR];
     #pragma unroll
-    for (int q = 0; q < UNR; q++) { const int i = base + q * WAVE; dv[q] = i < n ? (id0 >= 0 ? id0 + i : s.set[i]) : -1; }
+    for (int q = 0; q < UNR; q++) { const int i = base + q * nth; dv[q] = i < n ? (id0 >= 0 ? id0 + i : s.set[i]) : -1; }
     #pragma unroll
     for (int q = 0; q < UNR; q++) {
       const int d = dv[q];
       if (d < 0) { pcv[q] = scv[q] = pwv[q] = swv[q] = lcv[q] = 0; continue; }
-      pcv[q] = s.pc[d]; scv[q] = s.sc[d]; pwv[q] = s.pcwl[d]; swv[q] = s.scwl[d]; lcv[q] = s.lc[d];
+      pcv[q] = s.pc[d]; scv[q] = s.sc[d];
+      if (s.nolead) { pwv[q] = pcv[q]; swv[q] = scv[q]; lcv[q] = 0; }   // (the ...WithLeader arrays are the same arrays)
+      else { pwv[q] = s.pcwl[d]; swv[q] = s.scwl[d]; lcv[q] = s.lc[d]; }
     }
     #pragma unroll
     for (int q = 0; q < UNR; q++) {
-      const int i = base + q * WAVE, d = dv[q];
+      const int i = base + q * nth, d = dv[q];
       if (d < 0) continue;
-      uint64_t a, b;
-      if (order == ORD_LIST) { a = 0; b = ((uint64_t)(uint32_t)i << 32) | (uint32_t)d; }
+      uint64_t ka, kb;
+      if (order == ORD_LIST) { ka = 0; kb = ((uint64_t)(uint32_t)i << 32) | (uint32_t)d; }
       else {
         const bool wl = order == ORD_LEADER;
         const uint32_t l = wl ? (uint32_t)lcv[q] : 0u, sc2 = (uint32_t)(wl ? swv[q] : scv[q]), pc2 = (uint32_t)(wl ? pwv[q] : pcv[q]);
-        a = ((uint64_t)(0x7fffffffu - l) << 32) | (uint64_t)(v.lfc ? sc2 : 0x7fffffffu - sc2);
-        b = ((uint64_t)pc2 << 32) | (uint32_t)d;
+        ka = ((uint64_t)(0x7fffffffu - l) << 32) | (uint64_t)(a.lfc ? sc2 : 0x7fffffffu - sc2);
+        kb = ((uint64_t)pc2 << 32) | (uint32_t)d;
       }
       const bool zero = order != ORD_LIST && (pcv[q] | scv[q] | pwv[q] | swv[q] | lcv[q]) == 0;
-      s.k0[i] = zero ? (a | KQ_TAS_EXCLUDED) : a; s.k1[i] = b;
+      s.k0[i] = zero ? (ka | KQ_TAS_EXCLUDED) : ka; s.k1[i] = kb;
       if (zero) continue;
-      if (t_key_lt(a, b, b0, b1)) { b0 = a; b1 = b; }
+      if (t_key_lt(ka, kb, b0, b1)) { b0 = ka; b1 = kb; }
       const int32_t c = which == 0 ? pcv[q] : which == 1 ? pwv[q] : which == 2 ? scv[q] : swv[q];
-      if (lcv[q] >= leaderCount && c >= needed) {
-        const uint64_t cu = (uint64_t)(uint32_t)c;
-        if (cu < fc || (cu == fc && t_key_lt(a, b, f0, f1))) { fc = cu; f0 = a; f1 = b; }
+      if (lcv[q] >= a.leaderCount && c >= a.needed) {
+        const uint64_t cu = a.by_order ? 0 : (uint64_t)(uint32_t)c;
+        if (cu < fc || (cu == fc && t_key_lt(ka, kb, f0, f1))) { fc = cu; f0 = ka; f1 = kb; }
       }
     }
   }
-  const uint64_t m0 = wmin_u64(b0);
-  const uint64_t m1 = wmin_u64(b0 == m0 ? b1 : ~0ull);
-  const uint64_t g = wmin_u64(fc);
-  *first = -1; *fit = -1;
-  if (g != ~0ull) {
-    const uint64_t g0 = wmin_u64(fc == g ? f0 : ~0ull);
-    const uint64_t g1 = wmin_u64(fc == g && f0 == g0 ? f1 : ~0ull);
-    *fit = t_dom(g1);
+  TSweepRes r;
+  r.m0 = wmin_u64(b0);
+  r.m1 = wmin_u64(b0 == r.m0 ? b1 : ~0ull);
+  r.g = wmin_u64(fc);
+  r.g0 = ~0ull; r.g1 = ~0ull;
+  if (r.g != ~0ull) {
+    r.g0 = wmin_u64(fc == r.g ? f0 : ~0ull);
+    r.g1 = wmin_u64(fc == r.g && f0 == r.g0 ? f1 : ~0ull);
   }
-  if (!(m0 == ~0ull && m1 == ~0ull)) {
-    *first = t_dom(m1);
-    v.started = true; v.c0 = m0; v.c1 = m1; v.mat = 1;
+  return r;
+}
+KQ_DEV void t_sweep_merge(TSweepRes& r, const TSweepRes& o) {
+  if (t_key_lt(o.m0, o.m1, r.m0, r.m1)) { r.m0 = o.m0; r.m1 = o.m1; }
+  if (o.g < r.g || (o.g == r.g && t_key_lt(o.g0, o.g1, r.g0, r.g1))) { r.g = o.g; r.g0 = o.g0; r.g1 = o.g1; }
+}
+KQ_DEV TSweepRes t_sweep_coop(const TState& s, const TSweepArgs& a);
+// by_order: the holders are ranked by the slice order alone — LeastFreeCapacity's "first domain, ascending, that holds everything"
+// (:1364-1376) instead of BestFit's smallest count.
+KQ_DEV TView t_view_first_fit(const TK& k, const TState& s, int n, int order, bool unconstrained, int32_t needed, int which, int32_t leaderCount,
+                              int* first, int* fit, int id0 = -1, bool by_order = false) {
+  TView v;
+  v.n = n; v.order = order; v.lfc = t_lfc(k, unconstrained); v.mat = 0; v.c0 = 0; v.c1 = 0; v.started = false; v.skip = -1;
+  const TSweepArgs a{n, order, id0, v.lfc, by_order, needed, leaderCount, which};
+  // a long slice of a state in LDS is shared with the workgroup's helper waves (k_process_tas): each wave a quarter of the elements
+  const TSweepRes r = (s.coop && n >= s.coop_min && id0 >= 0) ? t_sweep_coop(s, a) : t_sweep_part(s, a, lane_id(), WAVE);
+  *first = -1; *fit = -1;
+  if (r.g != ~0ull) *fit = t_dom(r.g1);
+  if (!(r.m0 == ~0ull && r.m1 == ~0ull)) {
+    *first = t_dom(r.m1);
+    v.started = true; v.c0 = r.m0; v.c1 = r.m1; v.mat = 1;
     if (lane_id() == 0) s.arr[0] = *first;
   }
   wsync();
   return v;
 }
+// ---- long slices of a state in LDS, shared with the helper waves (k_process_tas) ----
+KQ_DEV void t_sweep_help(TLeafJob& job, int wv, int nw) {
+  const TSweepRes r = t_sweep_part(job.sw_s, job.sw_a, wv * WAVE + lane_id(), nw * WAVE);
+  if (lane_id() == 0) job.sw_r[wv] = r;
+}
+KQ_DEV TSweepRes t_sweep_coop(const TState& s, const TSweepArgs& a) {
+  TLeafJob& j = *s.coop;
+  if (lane_id() == 0) { j.sw_s = s; j.sw_a = a; j.cmd = 4; }
+  bsync();
+  KQ_TAS_EMU_HELPERS(j);
+  TSweepRes r = t_sweep_part(s, a, lane_id(), j.nw * WAVE);
+  bsync();
+  for (int wv = 1; wv < j.nw; wv++) t_sweep_merge(r, j.sw_r[wv]);
+  return r;
+}
+KQ_DEV void t_argmin_help(TLeafJob& job, int wv, int nw) {
+  const SelRest sel{job.ar_started != 0, job.ar_c0, job.ar_c1, job.ar_skip};
+  uint64_t m0, m1;
+  t_argmin_part(job.sw_s, job.ar_n, sel, false, wv * WAVE + lane_id(), nw * WAVE, &m0, &m1);
+  if (lane_id() == 0) { job.ar_m0[wv] = m0; job.ar_m1[wv] = m1; }
+}
+KQ_DEV bool t_argmin_rest_coop(const TState& s, const TView& v, const SelRest& sel, uint64_t* o0, uint64_t* o1) {
+  TLeafJob& j = *s.coop;
+  if (lane_id() == 0) { j.sw_s = s; j.ar_n = v.n; j.ar_started = sel.started ? 1 : 0; j.ar_c0 = sel.c0; j.ar_c1 = sel.c1; j.ar_skip = sel.skip; j.cmd = 5; }
+  bsync();
+  KQ_TAS_EMU_HELPERS(j);
+  uint64_t m0, m1;
+  t_argmin_part(s, v.n, sel, false, lane_id(), j.nw * WAVE, &m0, &m1);
+  bsync();
+  for (int wv = 1; wv < j.nw; wv++) if (t_key_lt(j.ar_m0[wv], j.ar_m1[wv], m0, m1)) { m0 = j.ar_m0[wv]; m1 = j.ar_m1[wv]; }
+  if (m0 == ~0ull && m1 == ~0ull) return false;
+  *o0 = m0; *o1 = m1;
+  return true;
+}
 struct SelLeaderElig {
   const TState* s; int32_t leaderCount, availableCapacity, requiredCapacity; bool slices;
   KQ_MDEV bool take(uint64_t, uint64_t a1) const {
     const int d = t_dom(a1);
-    if (s->lc[d] < leaderCount) return false;
+    if (t_lc(*s, d) < leaderCount) return false;
     const int32_t pen = slices ? s->sc[d] - s->scwl[d] : s->pc[d] - s->pcwl[d];
     return availableCapacity - pen >= requiredCapacity;
   }
@@ -561,20 +727,20 @@ KQ_DEV bool t_consume_with_leaders(const TK& k, const TState& s, TView& v, int i
   int d = *domain;
   int32_t* withLeader = slices ? s.scwl : s.pcwl;
   int32_t* primary = slices ? s.sc : s.pc;
-  if (!t_lfc(k, unconstrained) && withLeader[d] >= *remainingPrimary && s.lc[d] >= *remainingLeaderCount)
+  if (!t_lfc(k, unconstrained) && withLeader[d] >= *remainingPrimary && t_lc(s, d) >= *remainingLeaderCount)
     d = slices ? t_best_fit_slices(s, v, i, *remainingPrimary, *remainingLeaderCount) : t_best_fit_pods(s, v, i, *remainingPrimary, *remainingLeaderCount);
   *domain = d;
   bool completed;
-  if (withLeader[d] >= *remainingPrimary && s.lc[d] >= *remainingLeaderCount) {
+  if (withLeader[d] >= *remainingPrimary && t_lc(s, d) >= *remainingLeaderCount) {
     wsync();
-    if (lane_id() == 0) { t_touch(s, d); primary[d] = *remainingPrimary; s.lc[d] = *remainingLeaderCount; s.pc[d] = *remainingPrimary * sliceSize; }
+    if (lane_id() == 0) { t_touch(s, d); primary[d] = *remainingPrimary; t_set_lc(s, d, *remainingLeaderCount); s.pc[d] = *remainingPrimary * sliceSize; }
     completed = true;
   } else {
-    int32_t wl = withLeader[d], lcv = s.lc[d];
+    int32_t wl = withLeader[d], lcv = t_lc(s, d);
     if (wl > *remainingPrimary) wl = *remainingPrimary;
     if (lcv > *remainingLeaderCount) lcv = *remainingLeaderCount;
     wsync();
-    if (lane_id() == 0) { t_touch(s, d); withLeader[d] = wl; s.lc[d] = lcv; primary[d] = wl; s.pc[d] = wl * sliceSize; }
+    if (lane_id() == 0) { t_touch(s, d); withLeader[d] = wl; t_set_lc(s, d, lcv); primary[d] = wl; s.pc[d] = wl * sliceSize; }
     *remainingLeaderCount -= lcv;
     *remainingPrimary -= wl;
     completed = false;
@@ -633,12 +799,12 @@ KQ_DEV int t_update_counts(const TK& k, const TState& s, int n, int order, int32
       const int32_t scv = s.sc[dom];
       wsync();
       if (scv >= remainingPrimary) {
-        if (lane_id() == 0) { t_touch(s, dom); s.lc[dom] = 0; s.pc[dom] = remainingPrimary * sliceSize; s.sc[dom] = remainingPrimary; out[out_n] = dom; }
+        if (lane_id() == 0) { t_touch(s, dom); t_set_lc(s, dom, 0); s.pc[dom] = remainingPrimary * sliceSize; s.sc[dom] = remainingPrimary; out[out_n] = dom; }
         out_n++;
         wsync();
         return out_n;
       }
-      if (lane_id() == 0) { t_touch(s, dom); s.lc[dom] = 0; s.pc[dom] = scv * sliceSize; out[out_n] = dom; }
+      if (lane_id() == 0) { t_touch(s, dom); t_set_lc(s, dom, 0); s.pc[dom] = scv * sliceSize; out[out_n] = dom; }
       remainingPrimary -= scv;
       out_n++;
       wsync();
@@ -648,12 +814,12 @@ KQ_DEV int t_update_counts(const TK& k, const TState& s, int n, int order, int32
     const int32_t pcv = s.pc[dom];
     wsync();
     if (pcv >= remainingPrimary) {
-      if (lane_id() == 0) { t_touch(s, dom); s.lc[dom] = 0; s.pc[dom] = remainingPrimary; out[out_n] = dom; }
+      if (lane_id() == 0) { t_touch(s, dom); t_set_lc(s, dom, 0); s.pc[dom] = remainingPrimary; out[out_n] = dom; }
       out_n++;
       wsync();
       return out_n;
     }
-    if (lane_id() == 0) { t_touch(s, dom); s.lc[dom] = 0; out[out_n] = dom; }
+    if (lane_id() == 0) { t_touch(s, dom); t_set_lc(s, dom, 0); out[out_n] = dom; }
     remainingPrimary -= pcv;
     out_n++;
     wsync();
@@ -664,15 +830,6 @@ KQ_DEV int t_update_counts(const TK& k, const TState& s, int n, int order, int32
 }
 
 struct TFail { int status; int32_t a, b; };
-struct SelHolds {  // LeastFreeCapacity: the first domain (ascending order) that holds everything (:1364-1376)
-  const TState* s; int32_t sliceCount, leaderCount;
-  KQ_MDEV bool take(uint64_t, uint64_t a1) const {
-    const int d = t_dom(a1);
-    if (leaderCount > 0) return s->lc[d] >= leaderCount && s->scwl[d] >= sliceCount;
-    return s->sc[d] >= sliceCount;
-  }
-  KQ_MDEV void rank(uint64_t*, uint64_t*) const {}
-};
 struct SelLast {  // the last element of the slice: arg-max by complementing the key (the caller un-complements the id)
   KQ_MDEV bool take(uint64_t, uint64_t) const { return true; }
   KQ_MDEV void rank(uint64_t* x0, uint64_t* x1) const { *x0 = ~*x0 - 1; *x1 = ~*x1; }
@@ -704,9 +861,10 @@ KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* 
     for (int i = lane_id(); i < n; i += WAVE) s.set[i] = T.level_off[searchLevelIdx] + i;
     int fitDomain = -1, topDomain = -1;
     TView v;
-    if (!lfc) v = t_view_first_fit(k, s, n, ORD_LEADER, st.unconstrained, sliceCount, st.leaderCount > 0 ? 3 : 2, st.leaderCount, &topDomain, &fitDomain,
-                                   T.level_off[searchLevelIdx]);   // (its closing fence publishes s.set as well)
-    else { wsync(); v = t_view(k, s, n, ORD_LEADER, st.unconstrained); topDomain = t_get(s, v, 0); }
+    // keys, sortedDomain[0] and the domain the level's search is after — BestFit: findBestFitDomainBy over the whole level;
+    // LeastFreeCapacity: the first domain in ascending order that holds everything — in one sweep (its closing fence publishes s.set as well)
+    v = t_view_first_fit(k, s, n, ORD_LEADER, st.unconstrained, sliceCount, st.leaderCount > 0 ? 3 : 2, st.leaderCount, &topDomain, &fitDomain,
+                         T.level_off[searchLevelIdx], lfc);
     if (topDomain < 0) {
       // every domain of the level has an all-zero state: whatever sortedDomain[0] is, it holds nothing
       if (sliceCount == 0 && st.leaderCount == 0) {
@@ -718,12 +876,10 @@ KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* 
       if (st.required || searchLevelIdx == 0 || st.unconstrained) return TFail{KQ_TAS_NOT_FIT, 0, sliceCount};
       continue;
     }
-    if (!lfc && s.scwl[topDomain] >= sliceCount && s.lc[topDomain] >= st.leaderCount && fitDomain >= 0) topDomain = fitDomain;   // findBestFitDomain :1293 over the whole level
+    if (!lfc && s.scwl[topDomain] >= sliceCount && t_lc(s, topDomain) >= st.leaderCount && fitDomain >= 0) topDomain = fitDomain;   // findBestFitDomain :1293 over the whole level
     if (lfc) {
-      SelHolds sh{&s, sliceCount, st.leaderCount};
-      uint64_t e0 = 0, e1 = 0;
-      if (t_argmin(s, v, sh, &e0, &e1)) {
-        if (lane_id() == 0) s.cur[0] = t_dom(e1);
+      if (fitDomain >= 0) {
+        if (lane_id() == 0) s.cur[0] = fitDomain;
         *fitLevel = searchLevelIdx; *nfit = 1;
         wsync();
         return TFail{KQ_TAS_OK, 0, 0};
@@ -733,7 +889,7 @@ KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* 
         return TFail{KQ_TAS_NOT_FIT, last >= 0 ? s.pc[last] : 0, sliceCount};
       }
     }
-    if (s.scwl[topDomain] < sliceCount || s.lc[topDomain] < st.leaderCount) {
+    if (s.scwl[topDomain] < sliceCount || t_lc(s, topDomain) < st.leaderCount) {
       if (st.required) return TFail{KQ_TAS_NOT_FIT, s.sc[t_true_first(s, v)], sliceCount};
       if (searchLevelIdx > 0 && !st.unconstrained) continue;
       int nres = 0;
@@ -742,11 +898,11 @@ KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* 
       int idx = 0;
       for (; remainingLeaderCount > 0; idx++) {
         int domain = t_get(s, v, idx);
-        if (domain < 0 || s.lc[domain] <= 0) break;
+        if (domain < 0 || t_lc(s, domain) <= 0) break;
         if (!lfc && s.scwl[domain] >= remainingSliceCount) domain = t_best_fit_slices(s, v, idx, remainingSliceCount, remainingLeaderCount);
         if (lane_id() == 0) s.cur[nres] = domain;
         nres++;
-        remainingLeaderCount -= s.lc[domain];
+        remainingLeaderCount -= t_lc(s, domain);
         remainingSliceCount -= s.scwl[domain];
       }
       if (remainingLeaderCount > 0) return TFail{KQ_TAS_NOT_FIT, st.leaderCount - remainingLeaderCount, sliceCount};
@@ -782,8 +938,9 @@ KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* 
           long long* bins = (long long*)s.nxt;
           for (int b = lane_id(); b < NB; b += WAVE) bins[b] = 0;
           wsync();
+          const int lvl0 = T.level_off[searchLevelIdx];   // (idx == 0: the slice is still the whole level, s.set[i] = lvl0 + i)
           for (int i = lane_id(); i < m; i += WAVE) {
-            const int32_t scv = s.sc[s.set[i]];
+            const int32_t scv = s.sc[lvl0 + i];
             if (scv > 0) atomic_add_i64(&bins[scv < NB - 1 ? scv : NB - 1], (long long)scv);
           }
           wsync();
@@ -800,7 +957,7 @@ KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* 
           for (int base = 0; base < m; base += WAVE) {
             const int i = base + lane_id();
             int d = 0, bin = -1;
-            if (i < m) { d = s.set[i]; const int32_t scv = s.sc[d]; bin = scv > 0 ? (scv < NB - 1 ? scv : NB - 1) : -1; }
+            if (i < m) { d = lvl0 + i; const int32_t scv = s.sc[d]; bin = scv > 0 ? (scv < NB - 1 ? scv : NB - 1) : -1; }
             const uint64_t lo = wballot(bin >= 0 && bin < tb), at = wballot(bin == tb);
             const uint64_t below_me = (lane_id() == 0) ? 0ull : (~0ull >> (64 - lane_id()));
             if (bin >= 0 && bin < tb) s.cur[nres + popc64(lo & below_me)] = d;
@@ -918,7 +1075,7 @@ KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, 
       const int d = s.cur[j], c0 = T.child_first[d], cn = T.child_cnt[d];
       for (int i = lane_id(); i < cn; i += WAVE) s.set[i] = c0 + i;
       wsync();
-      const int32_t dpc = s.pc[d], dlc = s.lc[d];
+      const int32_t dpc = s.pc[d], dlc = t_lc(s, d);
       nout = t_update_counts(k, s, cn, ORD_PLAIN, dpc, dlc, sliceSizeOnLevel, st.unconstrained, sliceSizeOnLevel > 1, s.nxt, nout, sliceSizeOnLevel);
       if (nout < 0) { *nfit = 0; return TFail{KQ_TAS_OK, 0, 0}; }
     }
@@ -939,7 +1096,7 @@ KQ_DEV void t_emit(const TK& k, const TState& s, int ncur, int which, int ps) {
   int total = 0;
   for (int base = 0; base < ncur; base += WAVE) {
     const int i = base + lane;
-    const bool in = i < ncur && (which == 0 ? s.pc[s.cur[i]] : s.lc[s.cur[i]]) > 0;
+    const bool in = i < ncur && (which == 0 ? s.pc[s.cur[i]] : t_lc(s, s.cur[i])) > 0;
     total += popc64(wballot(in));
   }
   int pos = 0;
@@ -955,12 +1112,12 @@ KQ_DEV void t_emit(const TK& k, const TState& s, int ncur, int which, int ps) {
   if (pos + total > O.pool_cap) return;
   for (int i = lane; i < ncur; i += WAVE) {
     const int d = s.cur[i];
-    const int32_t c = which == 0 ? s.pc[d] : s.lc[d];
+    const int32_t c = which == 0 ? s.pc[d] : t_lc(s, d);
     if (c <= 0) continue;
     int rank = 0;
     for (int j = 0; j < ncur; j++) {
       const int e = s.cur[j];
-      if ((which == 0 ? s.pc[e] : s.lc[e]) > 0 && e < d) rank++;
+      if ((which == 0 ? s.pc[e] : t_lc(s, e)) > 0 && e < d) rank++;
     }
     O.pool_leaf[pos + rank] = d - T.leaf_base;
     O.pool_count[pos + rank] = c;
@@ -971,7 +1128,9 @@ KQ_DEV void t_emit(const TK& k, const TState& s, int ncur, int which, int ps) {
 // FindTopologyAssignmentsForFlavor :578 for workload w
 KQ_DEV void t_workload(const TK& k, int slot, int w) {
   const TTopo& T = k.T; const TReq& Q = k.Q; const TOut& O = k.O;
-  const TState s = tas_state(k, slot);
+  TState s0 = tas_state(k, slot);
+  if (k.lds && k.mail) { s0.coop = k.mail; s0.coop_min = k.mail->coop_min; }
+  const TState s = s0;
   const int lane = lane_id();
   const int p0 = Q.wl_off[w], p1 = Q.wl_off[w + 1];
   // more than one group => later groups see the usage assumed for the earlier ones (:654-656)
@@ -1042,12 +1201,16 @@ KQ_DEV void t_workload(const TK& k, int slot, int w) {
       const int cls = k.C.n > 0 ? k.C.wl_class[w] : -1;
       bool have = false;
       if (cls >= 0) {
-        // start from the class's phase-1 table; the slot keeps it between workloads of the same class
-        if (s.meta[2] != cls || s.meta[1]) {
+        // start from the class's phase-1 table; the slot keeps it between workloads of the same class (the LDS copy is filled every
+        // time: the table moves with every AddUsage, and the copy is one round trip of the whole workgroup)
+        if (k.lds) {
+          t_class_to_lds(k, s, cls);
+          if (lane == 0) { s.meta[1] = 1; s.meta[2] = cls; }   // (nothing to put back afterwards)
+        } else if (s.meta[2] != cls || s.meta[1]) {
           wsync();
           for (int d = lane; d < T.D; d += WAVE) {
             const size_t o = (size_t)cls * T.D + d;
-            s.pc[d] = k.C.pc[o]; s.sc[d] = k.C.sc[o]; s.pcwl[d] = k.C.pcwl[o]; s.scwl[d] = k.C.scwl[o]; s.lc[d] = k.C.lc[o];
+            s.pc[d] = k.C.pc[o]; s.sc[d] = k.C.sc[o]; s.pcwl[d] = k.C.pcwl[o]; s.scwl[d] = k.C.scwl[o]; t_set_lc(s, d, k.C.lc[o]);
           }
           if (lane == 0) { s.meta[1] = 0; s.meta[2] = cls; }
         }
@@ -1072,7 +1235,7 @@ KQ_DEV void t_workload(const TK& k, int slot, int w) {
         const int d = s.cur[i], leaf = d - T.leaf_base;
         for (int r = 0; r < T.R; r++) {
           int64_t add = Q.spr[(size_t)workers * T.R + r] * (int64_t)s.pc[d] + (r == T.pods ? s.pc[d] : 0);
-          if (leader >= 0) add += Q.spr[(size_t)leader * T.R + r] * (int64_t)s.lc[d] + (r == T.pods ? s.lc[d] : 0);
+          if (leader >= 0) add += Q.spr[(size_t)leader * T.R + r] * (int64_t)t_lc(s, d) + (r == T.pods ? t_lc(s, d) : 0);
           s.assumed[(size_t)leaf * T.R + r] += add;
         }
       }
@@ -1090,7 +1253,7 @@ KQ_DEV void t_workload(const TK& k, int slot, int w) {
     for (int i = lane; i < nlog; i += WAVE) {
       const int d = s.log[i];
       const size_t o = (size_t)cls * T.D + d;
-      s.pc[d] = k.C.pc[o]; s.sc[d] = k.C.sc[o]; s.pcwl[d] = k.C.pcwl[o]; s.scwl[d] = k.C.scwl[o]; s.lc[d] = k.C.lc[o];
+      s.pc[d] = k.C.pc[o]; s.sc[d] = k.C.sc[o]; s.pcwl[d] = k.C.pcwl[o]; s.scwl[d] = k.C.scwl[o]; t_set_lc(s, d, k.C.lc[o]);
     }
     wsync();
   }

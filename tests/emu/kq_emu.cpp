@@ -204,7 +204,17 @@ struct EmuBackend {
   void launch_nominate_tas(const K& k, int slots) {
     for (int slot = 0; slot < slots; slot++) { Wave w{}; for (int h = slot; h < hn(k.H); h += slots) nominate_head(k, w, h, slot); }
   }
-  void launch_process_tas(const K& k) { Wave w{}; process_all_tas(k, w, 0, nullptr); last_k = k; }
+  // (the placement's working state in "LDS" unless KQ_TAS_LDS_OFF is set; poisoned, as a workgroup's LDS holds anything at launch)
+  void launch_process_tas(const K& k, size_t lds_want) {
+    Wave w{};
+    std::vector<unsigned char> lds(getenv("KQ_TAS_LDS_OFF") ? 0 : lds_want, 0xa5);
+    // (helper waves: the leader plays their shares itself, KQ_TAS_EMU_HELPERS; every other launch runs without them)
+    static int launches = 0;
+    TLeafJob job{};
+    job.nw = 4; job.coop_min = getenv("KQ_TAS_COOP_MIN") ? atoi(getenv("KQ_TAS_COOP_MIN")) : 8;
+    process_all_tas(k, w, 0, (launches++ & 1) ? nullptr : &job, lds.data(), (int)lds.size());
+    last_k = k;
+  }
   void launch_process_fair(const K& k, int n_tree, size_t, size_t, int32_t* rank) {
     std::vector<int64_t> lds(160 * 1024 / 8);
     // (a recomputation's victim search borrows the region: whole state in "LDS" / almost none of it / no region at all)
