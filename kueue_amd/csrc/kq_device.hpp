@@ -699,6 +699,11 @@ struct TAW {
   struct TLeafJob* mail;          // k_process_tas: phase 1 of a placement is shared with the workgroup's helper waves through this LDS block
   unsigned char* lds;             // k_process_tas: room for a class-path placement's working state (kq_tas_device.hpp TLds), lds_bytes of it
   int lds_bytes;
+  int pf_pos;                     // k_process_tas: iterator position whose header helper wave 1 should fetch once this entry's placement is done, -1 = none
+  // k_process_tas with the LDS block: the request block of a one-podset class-path find and the wave's two domain stores live behind the
+  // placement's working state (kq_tas_cycle.hpp TX_*); the TopologyAssignment the entry published is then still in store half 0
+  int q_lds, d_lds, pub_lds;
+  int pool_own, pool_next;        // k_process_tas (pool_own = 1): the wave is the only writer of the published pool, pool_next its next free position; else the atomic counter
 };
 #define KQ_TAS_WALK(w) ((w).ta.srch != 0)
 #else

@@ -1095,7 +1095,7 @@ template <class B> struct EngineT {
     }
     tas_n_cls = nt * ncls;
     tas_lds_want = 0;
-    if (ncls > 0) for (int i = 0; i < nt; i++) tas_lds_want = std::max(tas_lds_want, tas_lds_layout(tks[i].T.D, tks[i].X.max_set).total);
+    if (ncls > 0) for (int i = 0; i < nt; i++) tas_lds_want = std::max(tas_lds_want, TX_BYTES + tas_lds_layout(tks[i].T.D, tks[i].X.max_set).total);
     TCyc* d_tc = tstage(&c, 1);
     if (n_ent > 0) be.launch_tas_base(d_tc, n_ent);   // base plane += workload.TASUsage() of every admitted row
     for (int i = 0; i < nt; i++) {

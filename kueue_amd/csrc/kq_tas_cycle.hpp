@@ -28,6 +28,17 @@ enum {
   TQ_OPA = TQ_STATUS + TC_P, TQ_OPB = TQ_OPA + TC_P, TQ_DPOS = TQ_OPB + TC_P, TQ_DN = TQ_DPOS + TC_P, TQ_MISC = TQ_DN + TC_P, TQ_WORDS = TQ_MISC + 24   // misc: pool_used, error, bytes (64 bit), then the timing builds' cycle counters
 };
 static_assert(TQ_MISC % 2 == 0, "the misc words hold an aligned 64-bit byte counter");
+// where the fields of a request block start: the slot's block in global memory holds TC_P podsets, the block k_process_tas keeps in LDS one
+struct TQOff { int count, level, ssize, slevel, group, nlay, llevel, lsize, status, opa, opb, dpos, dn, misc; };
+KQ_DEV TQOff tq_full() { return TQOff{TQ_COUNT, TQ_LEVEL, TQ_SSIZE, TQ_SLEVEL, TQ_GROUP, TQ_NLAY, TQ_LLEVEL, TQ_LSIZE, TQ_STATUS, TQ_OPA, TQ_OPB, TQ_DPOS, TQ_DN, TQ_MISC}; }
+KQ_DEV TQOff tq_one() { return TQOff{2, 3, 4, 5, 6, 7, 8, 8 + TC_ML, 8 + 2 * TC_ML, 9 + 2 * TC_ML, 10 + 2 * TC_ML, 11 + 2 * TC_ML, 12 + 2 * TC_ML, 14 + 2 * TC_ML}; }
+// the LDS block of k_process_tas behind the placement's working state (tas_lds_layout): request block of one podset, its flags, its
+// per-pod requests, the wave's two domain stores of TX_DCAP entries each
+constexpr int TX_QWORDS = 14 + 2 * TC_ML + 24, TX_DCAP = 64;
+static_assert((14 + 2 * TC_ML) % 2 == 0, "the misc words hold an aligned 64-bit byte counter");
+constexpr size_t TX_Q = 0, TX_QU = TX_Q + (size_t)TX_QWORDS * 4, TX_QS = TX_QU + 16, TX_DL = TX_QS + (size_t)KQ_TAS_MAXR * 8, TX_DC = TX_DL + (size_t)2 * TX_DCAP * 4,
+                 TX_BYTES = (TX_DC + (size_t)2 * TX_DCAP * 4 + 15) & ~(size_t)15;
+static_assert(TX_QS % 8 == 0 && TX_Q % 8 == 0, "alignment of the LDS request block");
 
 struct TCyc {
   uint32_t flags;
@@ -155,19 +166,19 @@ KQ_DEV void tc_class_init(const TCyc& c, int t, int cls) {
 // lanes = (class, touched leaf): the leaf's counts are recomputed from the plane (CountIn), the difference of its podCount is added to
 // every ancestor; then the slice-level ancestors (one owner lane each) turn their new podCount into a sliceCount and send that
 // difference up. Bit-identical to running phase 1 again.
-KQ_DEV void tc_class_update(const K& k, const Wave& w) {
+KQ_DEV void tc_class_update(const K& k, int ps_base, int nps, bool lds_on, int lds_bytes) {
   const TCyc& c = *k.tc;
   if (c.ncls == 0) return;
   const int lane = lane_id();
-  for (int p = 0; p < w.nps; p++) {
-    const int g = w.ps_base + p, t = c.h_tas[g];
+  for (int p = 0; p < nps; p++) {
+    const int g = ps_base + p, t = c.h_tas[g];
     if (t < 0 || c.h_n[g] == 0) continue;
     TTopo T = c.tk[t].T;
     T.tas_usage = c.work[t];
     const int32_t* par = c.par[t]; int32_t* flag = c.cflag[t];
     const int n = c.h_n[g], pos = c.h_pos[g], items = n * c.ncls;
     // (a placement that keeps its working state in LDS fills it from the table every time: no working copies to maintain)
-    const bool copies = !(w.ta.lds && tas_lds_layout(T.D, c.tk[t].X.max_set).total <= (size_t)w.ta.lds_bytes);
+    const bool copies = !(lds_on && TX_BYTES + tas_lds_layout(T.D, c.tk[t].X.max_set).total <= (size_t)lds_bytes);
     // A: leaves, podCount deltas up the tree (and the sliceCount deltas when the leaves are the slice level)
     for (int i = lane; i < items; i += WAVE) {
       const int cls = i / n, j = i % n;
@@ -279,6 +290,17 @@ KQ_NOINLINE void tc_requests(const K& k, Wave& w) {
 struct TcFail { bool failed; int ps, status; int32_t a, b; };
 // ClusterQueueSnapshot.FindTopologyAssignmentsForWorkload clusterqueue_snapshot.go:204-237 for the requests in w.ta on plane `which`;
 // the domains land in half 1 of the slot's store. Failure = TASAssignmentsResult.Failure :411 (first failing podset).
+// the wave's domain stores: half 0 = the assignment it keeps, half 1 = output of the find in flight
+KQ_DEV void tc_dstore(const TCyc& c, const Wave& w, int slot, int half, int32_t** leaf, int32_t** count, int* cap) {
+  if (w.ta.d_lds) { *leaf = (int32_t*)(w.ta.lds + TX_DL) + half * TX_DCAP; *count = (int32_t*)(w.ta.lds + TX_DC) + half * TX_DCAP; *cap = TX_DCAP; }
+  else { *leaf = c.d_leaf + ((size_t)slot * 2 + half) * c.d_cap; *count = c.d_count + ((size_t)slot * 2 + half) * c.d_cap; *cap = c.d_cap; }
+}
+// the request / result block of the wave's last find
+KQ_DEV int32_t* tc_qblock(const TCyc& c, const Wave& w, int slot, TQOff* qo) {
+  if (w.ta.q_lds) { *qo = tq_one(); return (int32_t*)(w.ta.lds + TX_Q); }
+  *qo = tq_full();
+  return c.q_i32 + (size_t)slot * TQ_WORDS;
+}
 KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, int which) {
   const TCyc& c = *k.tc;
   TcFail f{false, -1, 0, 0, 0};
@@ -287,79 +309,99 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
   KQ_T0();
   const int t = w.ta.t;
   const int lane = lane_id();
-  int32_t* qi = c.q_i32 + (size_t)slot * TQ_WORDS;
-  uint8_t* qu = c.q_u8 + (size_t)slot * (TC_P + 8);
-  int64_t* qs = c.q_spr + (size_t)slot * TC_P * c.R;
+  // processEntry on the work plane, one podset of a request class: start from the class's resident phase 1, and (k_process_tas) keep the
+  // request block and the placement's working state in LDS
+  int cls = -1;
+  if (which == 1 && !simulateEmpty && n == 1 && c.ncls > 0) {
+    cls = c.ps_class[w.ps_base + w.ta.req_ps[0]];
+    if (cls >= 0 && !c.cls_ok[(size_t)t * c.ncls + cls]) cls = -1;
+  }
+  const TK& tk0 = c.tk[t];
+  const bool st_lds = cls >= 0 && w.ta.lds && TX_BYTES + tas_lds_layout(tk0.T.D, tk0.X.max_set).total <= (size_t)w.ta.lds_bytes;
+  wsync();
+  if (lane == 0) w.ta.q_lds = st_lds ? 1 : 0;
+  wsync();
+  TQOff qo;
+  int32_t* qi = tc_qblock(c, w, slot, &qo);
+  uint8_t* qu = st_lds ? (uint8_t*)(w.ta.lds + TX_QU) : c.q_u8 + (size_t)slot * (TC_P + 8);
+  int64_t* qs = st_lds ? (int64_t*)(w.ta.lds + TX_QS) : c.q_spr + (size_t)slot * TC_P * c.R;
+  uint8_t* qsim = st_lds ? qu + 8 : qu + TC_P;
   const bool layered = c.ps_n_layers != nullptr;
   if (lane == 0) {
     qi[TQ_WLOFF] = 0; qi[TQ_WLOFF + 1] = n;
     for (int i = 0; i < n; i++) {
       const int g = w.ps_base + w.ta.req_ps[i];
-      qi[TQ_COUNT + i] = k.O.ps_count[g];
-      qi[TQ_LEVEL + i] = c.ps_level[(size_t)g * c.n_tas + t];
-      qi[TQ_SSIZE + i] = c.ps_slice_size[g];
-      qi[TQ_SLEVEL + i] = c.ps_slice_level[(size_t)g * c.n_tas + t];
-      qi[TQ_GROUP + i] = c.ps_group[g];
+      qi[qo.count + i] = k.O.ps_count[g];
+      qi[qo.level + i] = c.ps_level[(size_t)g * c.n_tas + t];
+      qi[qo.ssize + i] = c.ps_slice_size[g];
+      qi[qo.slevel + i] = c.ps_slice_level[(size_t)g * c.n_tas + t];
+      qi[qo.group + i] = c.ps_group[g];
       qu[i] = c.ps_kind[g];
       for (int r = 0; r < c.R; r++) qs[(size_t)i * c.R + r] = c.ps_req[(size_t)g * c.R + r];
       if (layered) {
-        qi[TQ_NLAY + i] = c.ps_n_layers[g];
+        qi[qo.nlay + i] = c.ps_n_layers[g];
         for (int j = 0; j < TC_ML; j++) {
-          qi[TQ_LLEVEL + i * TC_ML + j] = c.ps_layer_level[((size_t)g * c.n_tas + t) * TC_ML + j];
-          qi[TQ_LSIZE + i * TC_ML + j] = c.ps_layer_size[(size_t)g * TC_ML + j];
+          qi[qo.llevel + i * TC_ML + j] = c.ps_layer_level[((size_t)g * c.n_tas + t) * TC_ML + j];
+          qi[qo.lsize + i * TC_ML + j] = c.ps_layer_size[(size_t)g * TC_ML + j];
         }
       }
     }
-    qu[TC_P] = simulateEmpty ? 1 : 0;
-    for (int i = 0; i < 24; i++) qi[TQ_MISC + i] = 0;
+    *qsim = simulateEmpty ? 1 : 0;
+    for (int i = 0; i < 24; i++) qi[qo.misc + i] = 0;
     if (c.stats) atomic_add_i64(c.stats, 1);
   }
   wsync();
   TK tk = c.tk[t];
   tk.T.tas_usage = tc_plane(c, t, which, slot);
-  tk.Q.n_wl = 1; tk.Q.wl_off = qi + TQ_WLOFF; tk.Q.sim_empty = qu + TC_P; tk.Q.spr = qs;
-  tk.Q.count = qi + TQ_COUNT; tk.Q.level = qi + TQ_LEVEL; tk.Q.kind = qu; tk.Q.slice_size = qi + TQ_SSIZE; tk.Q.slice_level = qi + TQ_SLEVEL;
-  tk.Q.group = qi + TQ_GROUP; tk.Q.leaf_ok = nullptr;
-  tk.Q.n_layers = layered ? qi + TQ_NLAY : nullptr; tk.Q.layer_level = layered ? qi + TQ_LLEVEL : nullptr; tk.Q.layer_size = layered ? qi + TQ_LSIZE : nullptr;
-  tk.O.status = qi + TQ_STATUS; tk.O.op_a = qi + TQ_OPA; tk.O.op_b = qi + TQ_OPB; tk.O.dom_pos = qi + TQ_DPOS; tk.O.dom_n = qi + TQ_DN;
+  tk.Q.n_wl = 1; tk.Q.wl_off = qi + TQ_WLOFF; tk.Q.sim_empty = qsim; tk.Q.spr = qs;
+  tk.Q.count = qi + qo.count; tk.Q.level = qi + qo.level; tk.Q.kind = qu; tk.Q.slice_size = qi + qo.ssize; tk.Q.slice_level = qi + qo.slevel;
+  tk.Q.group = qi + qo.group; tk.Q.leaf_ok = nullptr;
+  tk.Q.n_layers = layered ? qi + qo.nlay : nullptr; tk.Q.layer_level = layered ? qi + qo.llevel : nullptr; tk.Q.layer_size = layered ? qi + qo.lsize : nullptr;
+  tk.O.status = qi + qo.status; tk.O.op_a = qi + qo.opa; tk.O.op_b = qi + qo.opb; tk.O.dom_pos = qi + qo.dpos; tk.O.dom_n = qi + qo.dn;
   tk.O.layer_fit = nullptr;
-  tk.O.pool_leaf = c.d_leaf + ((size_t)slot * 2 + 1) * c.d_cap; tk.O.pool_count = c.d_count + ((size_t)slot * 2 + 1) * c.d_cap; tk.O.pool_cap = c.d_cap;
-  tk.O.pool_used = qi + TQ_MISC; tk.O.error = qi + TQ_MISC + 1; tk.O.bytes = (long long*)(qi + TQ_MISC + 2);
+  tc_dstore(c, w, slot, 1, &tk.O.pool_leaf, &tk.O.pool_count, &tk.O.pool_cap);
+  tk.O.pool_used = qi + qo.misc; tk.O.error = qi + qo.misc + 1; tk.O.bytes = (long long*)(qi + qo.misc + 2);
   tk.C.n = 0;
   tk.mail = w.ta.mail;
   tk.lds = nullptr;
   int xslot = slot;
-  if (which == 1 && !simulateEmpty && n == 1 && c.ncls > 0) {   // processEntry on the work plane: start from the class's resident phase 1
+  if (cls >= 0) {
     const int g = w.ps_base + w.ta.req_ps[0];
-    const int cls = c.ps_class[g];
-    if (cls >= 0 && c.cls_ok[(size_t)t * c.ncls + cls]) {
-      const size_t nD = (size_t)c.ncls * tk.T.D;
-      int32_t* tab = c.cls_tab[t];
-      tk.C.n = c.ncls; tk.C.wl_class = c.ps_class + g; tk.C.order = nullptr;
-      tk.C.pc = tab; tk.C.sc = tab + nD; tk.C.pcwl = tab + 2 * nD; tk.C.scwl = tab + 3 * nD; tk.C.lc = tab + 4 * nD;
-      tk.C.bytes = c.cls_bytes[t];
-      xslot = c.slots + cls;
-      if (w.ta.lds && tas_lds_layout(tk.T.D, tk.X.max_set).total <= (size_t)w.ta.lds_bytes) tk.lds = w.ta.lds;   // the working state in LDS
-      if (lane == 0 && c.stats) atomic_add_i64(c.stats + 3, 1);
-    }
+    const size_t nD = (size_t)c.ncls * tk.T.D;
+    int32_t* tab = c.cls_tab[t];
+    tk.C.n = c.ncls; tk.C.wl_class = c.ps_class + g; tk.C.order = nullptr;
+    tk.C.pc = tab; tk.C.sc = tab + nD; tk.C.pcwl = tab + 2 * nD; tk.C.scwl = tab + 3 * nD; tk.C.lc = tab + 4 * nD;
+    tk.C.bytes = c.cls_bytes[t];
+    xslot = c.slots + cls;
+    if (st_lds) tk.lds = w.ta.lds + TX_BYTES;   // the working state in LDS
+    if (lane == 0 && c.stats) atomic_add_i64(c.stats + 3, 1);
   }
   if (which != 0) KQ_TS(k, 47);   // request block + argument block of the placement
   t_workload(tk, xslot, 0);
   wsync();
+  if (w.ta.mail && w.ta.pf_pos >= 0) {
+    // nothing is posted to the helper waves for the rest of this entry: wave 1 fetches the next entry's header meanwhile
+    TLeafJob& j = *w.ta.mail;
+    if (lane == 0) { j.pf_next = w.ta.pf_pos; j.cmd = 6; w.ta.pf_pos = -1; }
+    bsync();
+#ifdef KQ_HOST_EMU
+    t_prefetch_entry(j);
+#endif
+  }
   if (which != 0) KQ_TS(k, 45);   // (timing builds, processEntry only) the placement; 46 = its phase 1
 #if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
   if (lane == 0 && which != 0) {
-    atomic_add_i64((long long*)k.prof + 46, *(long long*)(qi + TQ_MISC + 4));
-    for (int j = 0; j < 8; j++) atomic_add_i64((long long*)k.prof + 51 + j, *(long long*)(qi + TQ_MISC + 6 + 2 * j));   // TPROF segments of the placement
+    atomic_add_i64((long long*)k.prof + 46, *(long long*)(qi + qo.misc + 4));
+    for (int j = 0; j < 8; j++) atomic_add_i64((long long*)k.prof + 51 + j, *(long long*)(qi + qo.misc + 6 + 2 * j));   // TPROF segments of the placement
   }
 #endif
-  // (the placement's own algorithmic bytes, qi[TQ_MISC + 2], are not added to the cycle's counter: SURVEY 8d's accounting of the quota
+  // (the placement's own algorithmic bytes, qi[misc + 2], are not added to the cycle's counter: SURVEY 8d's accounting of the quota
   // cycle does not include them, and neither does the oracle's)
-  if (lane == 0 && qi[TQ_MISC + 1] != 0 && *k.O.error == 0) *k.O.error = qi[TQ_MISC + 1];
+  if (lane == 0 && qi[qo.misc + 1] != 0 && *k.O.error == 0) *k.O.error = qi[qo.misc + 1];
   wsync();
   for (int i = 0; i < n; i++) {
-    const int st = qi[TQ_STATUS + i];
-    if (st != KQ_TAS_OK && st != KQ_TAS_SKIPPED) { f.failed = true; f.ps = w.ta.req_ps[i]; f.status = st; f.a = qi[TQ_OPA + i]; f.b = qi[TQ_OPB + i]; break; }
+    const int st = qi[qo.status + i];
+    if (st != KQ_TAS_OK && st != KQ_TAS_SKIPPED) { f.failed = true; f.ps = w.ta.req_ps[i]; f.status = st; f.a = qi[qo.opa + i]; f.b = qi[qo.opb + i]; break; }
   }
   return f;
 }
@@ -367,15 +409,17 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
 // domains (copied into half 0 of the store), the others lose theirs
 KQ_NOINLINE void tc_keep_result(const K& k, Wave& w, int slot) {
   const TCyc& c = *k.tc;
-  const int32_t* qi = c.q_i32 + (size_t)slot * TQ_WORDS;
-  const int32_t* fl = c.d_leaf + ((size_t)slot * 2 + 1) * c.d_cap; const int32_t* fc = c.d_count + ((size_t)slot * 2 + 1) * c.d_cap;
-  int32_t* kl = c.d_leaf + (size_t)slot * 2 * c.d_cap; int32_t* kc = c.d_count + (size_t)slot * 2 * c.d_cap;
+  TQOff qo;
+  const int32_t* qi = tc_qblock(c, w, slot, &qo);
+  int32_t *fl, *fc, *kl, *kc; int dcap;
+  tc_dstore(c, w, slot, 1, &fl, &fc, &dcap);
+  tc_dstore(c, w, slot, 0, &kl, &kc, &dcap);
   for (int i = 0; i < w.ta.nreq; i++) {
     const int p = w.ta.req_ps[i];
-    const bool ok = qi[TQ_STATUS + i] == KQ_TAS_OK;
-    const int pos = qi[TQ_DPOS + i], n = ok ? qi[TQ_DN + i] : 0;
+    const bool ok = qi[qo.status + i] == KQ_TAS_OK;
+    const int pos = qi[qo.dpos + i], n = ok ? qi[qo.dn + i] : 0;
     const int at = w.ta.kept_used;
-    if (ok && at + n > c.d_cap) { set_error(k, KQ_ECAPACITY); return; }
+    if (ok && at + n > dcap) { set_error(k, KQ_ECAPACITY); return; }
     for (int j = lane_id(); j < n; j += WAVE) { kl[at + j] = fl[pos + j]; kc[at + j] = fc[pos + j]; }
     wsync();
     if (lane_id() == 0) {
@@ -456,14 +500,17 @@ KQ_DEV void tc_update_assignment(const K& k, Wave& w, int slot, const int32_t* t
 // the head's TopologyAssignments for processEntry and the host
 KQ_NOINLINE void tc_publish(const K& k, Wave& w, int slot) {
   const TCyc& c = *k.tc;
-  const int32_t* kl = c.d_leaf + (size_t)slot * 2 * c.d_cap; const int32_t* kc = c.d_count + (size_t)slot * 2 * c.d_cap;
+  int32_t *kl, *kc; int dcap;
+  tc_dstore(c, w, slot, 0, &kl, &kc, &dcap);
   int total = 0;
   for (int p = 0; p < w.nps && p < TC_P; p++) if ((w.ta.has_mask >> p) & 1) total += w.ta.n[p];
   int base = 0;
   if (lane_id() == 0) {
-    base = total > 0 ? atomic_add_i32(c.pool_used, total) : 0;
+    if (w.ta.pool_own) { base = total > 0 ? w.ta.pool_next : 0; w.ta.pool_next += total; *c.pool_used = w.ta.pool_next; }   // (k_process_tas: the only writer)
+    else base = total > 0 ? atomic_add_i32(c.pool_used, total) : 0;
     if (base + total > c.pool_cap) { if (*k.O.error == 0) *k.O.error = KQ_ECAPACITY; base = -1; }
     w.counts[0] = base;
+    w.ta.pub_lds = (w.ta.d_lds && base >= 0) ? 1 : 0;   // the published domains are still in store half 0 (tc_entry_fits / tc_entry_add)
   }
   wsync();
   base = w.counts[0];
@@ -484,17 +531,31 @@ KQ_NOINLINE void tc_publish(const K& k, Wave& w, int slot) {
 // ---- processEntry ------------------------------------------------------------------------------------------------------------------------
 // Usage.TAS of entry e (Assignment.ComputeTASNetUsage flavorassigner.go:106-155, pending workloads) against / onto plane `which`:
 // every (podset, domain) on its own (clusterqueue_snapshot.go:136-149)
+// the TopologyAssignment entry processing sees for podset p: what the head published (global memory), or — k_process_tas after a
+// recomputation of this very entry — the same domains where they still are, in store half 0 (LDS)
+struct TcPub { int t, n; const int32_t *leaf, *count; };
+KQ_DEV TcPub tc_pub(const TCyc& c, const Wave& w, int p) {
+  if (w.ta.pub_lds) {
+    const bool has = p < TC_P && ((w.ta.has_mask >> p) & 1);
+    int32_t *kl, *kc; int cap;
+    tc_dstore(c, w, 0, 0, &kl, &kc, &cap);
+    return TcPub{has ? w.ta.t : -1, has ? w.ta.n[p] : 0, kl + (has ? w.ta.pos[p] : 0), kc + (has ? w.ta.pos[p] : 0)};
+  }
+  const int g = w.ps_base + p, t = c.h_tas[g];
+  return TcPub{t, t >= 0 ? c.h_n[g] : 0, c.pool_leaf + c.h_pos[g], c.pool_count + c.h_pos[g]};
+}
 KQ_DEV bool tc_entry_fits(const K& k, const Wave& w, int which) {
   const TCyc& c = *k.tc;
   bool bad = false;
   for (int p = 0; p < w.nps; p++) {
-    const int g = w.ps_base + p, t = c.h_tas[g];
-    if (t < 0) continue;
-    const TTopo& T = c.tk[t].T;
-    const int64_t* pl = tc_plane(c, t, which, 0);
-    for (int j = lane_id(); j < c.h_n[g]; j += WAVE) {
-      const int32_t cnt = c.pool_count[c.h_pos[g] + j];
-      if (cnt > 0 && !tc_fits_dom(T, pl, c.pool_leaf[c.h_pos[g] + j], cnt, c.ps_req + (size_t)g * c.R)) bad = true;
+    const TcPub a = tc_pub(c, w, p);
+    if (a.t < 0) continue;
+    const int g = w.ps_base + p;
+    const TTopo& T = c.tk[a.t].T;
+    const int64_t* pl = tc_plane(c, a.t, which, 0);
+    for (int j = lane_id(); j < a.n; j += WAVE) {
+      const int32_t cnt = a.count[j];
+      if (cnt > 0 && !tc_fits_dom(T, pl, a.leaf[j], cnt, c.ps_req + (size_t)g * c.R)) bad = true;
     }
   }
   return wballot(bad) == 0;
@@ -502,12 +563,13 @@ KQ_DEV bool tc_entry_fits(const K& k, const Wave& w, int which) {
 KQ_DEV void tc_entry_add(const K& k, const Wave& w) {  // updateTASUsage :267 on the work plane and on the one without the preempted rows
   const TCyc& c = *k.tc;
   for (int p = 0; p < w.nps; p++) {
-    const int g = w.ps_base + p, t = c.h_tas[g];
+    const TcPub a = tc_pub(c, w, p);
+    const int g = w.ps_base + p, t = a.t;
     if (t < 0) continue;
     const TTopo& T = c.tk[t].T;
-    for (int j = lane_id(); j < c.h_n[g]; j += WAVE) {
-      const int64_t cnt = c.pool_count[c.h_pos[g] + j];
-      const int leaf = c.pool_leaf[c.h_pos[g] + j];
+    for (int j = lane_id(); j < a.n; j += WAVE) {
+      const int64_t cnt = a.count[j];
+      const int leaf = a.leaf[j];
       if (cnt <= 0) continue;
       for (int r = 0; r < T.R; r++) {
         const int64_t q = c.ps_req[(size_t)g * c.R + r];
@@ -519,14 +581,24 @@ KQ_DEV void tc_entry_add(const K& k, const Wave& w) {  // updateTASUsage :267 on
     }
     wsync();
   }
-  tc_class_update(k, w);
+  if (w.ta.mail && k.tc->ncls > 0) {
+    // The class tables are read next by the copy job of the next placement, a barrier away: helper wave 2 patches them while the leader
+    // goes on (one barrier to post, nobody waits). A later AddUsage that lands on the plane before wave 2 has read a leaf is simply seen
+    // by this patch already (a patch recomputes its leaves from the plane and sends the difference to the table's old values up).
+    TLeafJob& j = *w.ta.mail;
+    if (lane_id() == 0) { j.cu_ps_base = w.ps_base; j.cu_nps = w.nps; j.cu_lds_on = w.ta.lds != nullptr; j.cu_lds_bytes = w.ta.lds_bytes; j.cmd = 7; }
+    bsync();
+#ifdef KQ_HOST_EMU
+    t_class_update_job(j);
+#endif
+  } else tc_class_update(k, w.ps_base, w.nps, w.ta.lds != nullptr, w.ta.lds_bytes);
 }
 // scheduler.fits :771-777 -> ClusterQueueSnapshot.Fits :136-150: 0 = fits, 1 = no quota, 2 = no TAS capacity
 KQ_DEV int tc_fits_check(const K& k, Wave& w, const int32_t* trows, int nt, bool quota_usage, int tree) {
   const TCyc& c = *k.tc;
   if (!entry_fits(k, w, trows, nt, quota_usage, tree)) return 1;
   bool any = false;
-  for (int p = 0; p < w.nps; p++) if (c.h_tas[w.ps_base + p] >= 0 && c.h_n[w.ps_base + p] > 0) any = true;
+  for (int p = 0; p < w.nps; p++) { const TcPub a = tc_pub(c, w, p); if (a.t >= 0 && a.n > 0) any = true; }
   if (!any) return 0;
   for (int i = 0; i < nt; i++) if (!k.preempted[trows[i]]) tc_row_apply(c, trows[i], false, 2, 0);
   const bool ok = tc_entry_fits(k, w, 2);
@@ -555,31 +627,90 @@ KQ_DEV void tc_tree_switch(const K& k, Wave& w, int from, int to) {
   wsync();
 }
 
+// helper wave 2 of k_process_tas: the class tables follow the AddUsage the leader just made
+KQ_DEV void t_class_update_job(TLeafJob& job) {
+  tc_class_update(*(const K*)job.pf_k, job.cu_ps_base, job.cu_nps, job.cu_lds_on != 0, job.cu_lds_bytes);
+}
+// helper wave 1 of k_process_tas: the header of the entry at iterator position job.pf_next into job.pre[position & 1]
+KQ_DEV void t_prefetch_entry(TLeafJob& job) {
+  const K& k = *(const K*)job.pf_k;
+  const DSnap& S = k.S; const DOut& O = k.O; const DHeads& H = k.H;
+  const int pos = job.pf_next, lane = lane_id();
+  TPre& r = job.pre[pos & 1];
+  const int e = k.order_idx[pos];
+  const int cq = H.cq[e];
+  // what hangs on e and on cq, one item per lane (a loop over the items: the 1-lane emulation walks it)
+  for (int it = lane; it < 10 + KQ_MAXD; it += WAVE) {
+    switch (it) {
+      case 0: r.e = e; r.cq = cq; r.prio = H.priority[e]; r.ts = H.queue_ts[e]; break;
+      case 1: r.hflags = H.flags[e]; break;
+      case 2: { const int a = H.ps_off[e]; r.ps_base = a; r.nps = H.ps_off[e + 1] - a; break; }
+      case 3: r.slice_row = (H.slice_row && gate(k, KQ_GATE_ELASTIC_JOBS)) ? H.slice_row[e] : -1; break;
+      case 4: r.borrowing = O.borrowing[e]; break;
+      case 5: r.nominated_mode = O.nominated_mode[e]; break;
+      case 6: r.tgt_n = O.tgt_n[e]; r.tgt_pos = O.tgt_pos[e]; break;
+      case 7: r.pol = S.cq_policy[cq]; break;
+      case 8: r.plen = S.plen[cq]; break;
+      case 9: r.tree = S.tree_of[cq]; break;
+      default: {
+        const int i = it - 10;
+        const int nd = S.path[(size_t)cq * KQ_MAXD + i];
+        r.path[i] = nd;
+        r.node_local[i] = (i < S.plen[cq] && nd >= 0) ? S.node_local[nd] : 0;
+      }
+    }
+  }
+  const int nu = O.use_n[e];
+  if (lane == 0) r.nuse = nu;
+  for (int u = lane; u < nu; u += WAVE) { r.use_fr[u] = O.use_fr[(size_t)e * KQ_MAXU + u]; r.use_qty[u] = O.use_qty[(size_t)e * KQ_MAXU + u]; }
+  wsync();
+  if (lane == 0) *(volatile int*)&r.ready_for = pos;
+  wsync();
+}
+
 // scheduler.go:392-523 for entry e at iterator position pos; the generic path of process_entry with the TAS side of
 // updateAssignmentIfNeeded (:707-769), Fits and AddUsage
-KQ_NOINLINE void process_entry_tas(const K& k, Wave& w, int e, int pos, int slot, int tree) {
+KQ_NOINLINE void process_entry_tas(const K& k, Wave& w, int e, int pos, int slot, int tree, const TPre* pre = nullptr) {
   const DSnap& S = k.S; const DOut& O = k.O; const TCyc& c = *k.tc;
   const int lane = lane_id();
-  load_head(k, w, e);
-  auto load_nomination = [&]() {
+  int nt, tpos;
+  if (lane == 0) w.ta.pub_lds = 0;   // what the head published came from k_nominate_tas: global memory
+  if (pre) {
+    // the header came with helper wave 1 (LDS): load_head + the nomination without a global access
+    if (lane == 0) {
+      w.h = e; w.cq = pre->cq; w.prio = pre->prio; w.ts = pre->ts; w.hflags = pre->hflags; w.pol = pre->pol;
+      w.ps_base = pre->ps_base; w.nps = pre->nps; w.plen = pre->plen;
+      for (int i = 0; i < KQ_MAXD; i++) w.path[i] = pre->path[i];
+      w.has_last = (pre->hflags & KQ_HEAD_HAS_LAST_ASSIGNMENT) ? 1 : 0;
+      w.bytes = 0;
+      w.slice_row = pre->slice_row;
+      if (w.nps > KQ_MAXPS) *k.O.error = KQ_EUNSUPPORTED;
+      w.nuse = pre->nuse; w.borrowing = pre->borrowing; w.rep_mode = pre->nominated_mode;
+      O.order[e] = pos;
+      for (int i = 1; i < pre->plen; i++) w.path_coh[i] = pre->node_local[i] - w.pc_ncq;
+    }
+    for (int u = lane; u < pre->nuse; u += WAVE) { w.use_fr[u] = pre->use_fr[u]; w.use_qty[u] = pre->use_qty[u]; }
+    nt = pre->tgt_n; tpos = pre->tgt_pos;
+    wsync();
+  } else {
+    load_head(k, w, e);
     if (lane == 0) {
       w.nuse = O.use_n[e];
       for (int u = 0; u < w.nuse; u++) { w.use_fr[u] = O.use_fr[(size_t)e * KQ_MAXU + u]; w.use_qty[u] = O.use_qty[(size_t)e * KQ_MAXU + u]; }
       w.borrowing = O.borrowing[e];
     }
     wsync();
-  };
-  load_nomination();
-  if (lane == 0) {
-    w.rep_mode = O.nominated_mode[e];
-    O.order[e] = pos;
-    for (int i = 1; i < w.plen; i++) w.path_coh[i] = S.node_local[w.path[i]] - w.pc_ncq;
+    if (lane == 0) {
+      w.rep_mode = O.nominated_mode[e];
+      O.order[e] = pos;
+      for (int i = 1; i < w.plen; i++) w.path_coh[i] = S.node_local[w.path[i]] - w.pc_ncq;
+    }
+    wsync();
+    nt = O.tgt_n[e]; tpos = O.tgt_pos[e];
   }
-  wsync();
-  int nt = O.tgt_n[e];
   const bool quota_usage = !(w.hflags & KQ_HEAD_HAS_QUOTA_RESERVATION);
   if (w.rep_mode != M_NOFIT) cert_unverifiable(k, tree);
-  const int32_t* trows = O.pool_row + O.tgt_pos[e];
+  const int32_t* trows = O.pool_row + tpos;
   auto has_any = [&]() { bool a = false; for (int t = 0; t < nt; t++) if (k.preempted[trows[t]]) a = true; return a; };
   KQ_T0();
   int fc = tc_fits_check(k, w, trows, nt, quota_usage, tree);
@@ -831,7 +962,10 @@ KQ_DEV void process_all_fair_tas(const K& k, Wave& w, int slot) {
 KQ_DEV void process_all_tas(const K& k, Wave& w, int slot, TLeafJob* mail, unsigned char* lds, int lds_bytes) {
   const int n = hn(k.H);
   if (lane_id() == 0) {
-    w.ta.mail = mail; w.ta.lds = lds_bytes > 0 ? lds : nullptr; w.ta.lds_bytes = lds_bytes;
+    w.ta.mail = mail; w.ta.lds = lds_bytes > 0 ? lds : nullptr; w.ta.lds_bytes = lds_bytes; w.ta.pf_pos = -1;
+    w.ta.q_lds = 0; w.ta.pub_lds = 0; w.ta.d_lds = (lds_bytes >= (int)TX_BYTES && k.tc->d_cap <= TX_DCAP) ? 1 : 0;
+    w.ta.pool_own = 1; w.ta.pool_next = *k.tc->pool_used;
+    if (mail) { mail->pf_k = &k; mail->pf_next = -1; mail->pre[0].ready_for = -1; mail->pre[1].ready_for = -1; }
     w.pc_on = 0; w.pc_lds = nullptr; w.np_broken = 0; w.n_pre = 0; w.broken[0] = w.broken[1] = w.broken[2] = w.broken[3] = 0;
     w.cs_lds = nullptr; w.cs_lds_bytes = 0; w.help_on = 0; w.mono_break = 0; w.ta.plane = 1; w.ta.srch = 0;
   }
@@ -839,10 +973,18 @@ KQ_DEV void process_all_tas(const K& k, Wave& w, int slot, TLeafJob* mail, unsig
   if (k.C.fair_sharing) { process_all_fair_tas(k, w, slot); return; }
   int cur = -1;
   for (int i = 0; i < n; i++) {
-    const int e = k.order_idx[i];
-    const int tree = k.S.tree_of[k.H.cq[e]];
+    // the entry's header: from helper wave 1 if it was fetched while the previous entry finished, else from global memory
+    const TPre* pre = nullptr;
+    if (mail) {
+      const TPre* cand = &mail->pre[i & 1];
+      if (*(volatile const int*)&cand->ready_for == i) pre = cand;
+      wsync();
+    }
+    const int e = pre ? pre->e : k.order_idx[i];
+    const int tree = pre ? pre->tree : k.S.tree_of[k.H.cq[e]];
+    if (lane_id() == 0) w.ta.pf_pos = (mail && i + 1 < n) ? i + 1 : -1;
     if (tree != cur) { tc_tree_switch(k, w, cur, tree); cur = tree; }
-    process_entry_tas(k, w, e, i, slot, tree);
+    process_entry_tas(k, w, e, i, slot, tree, pre);
   }
 }
 

@@ -199,10 +199,23 @@ struct TLeafArgs {
 // one sweep over a slice of domains (t_view_first_fit): what it is after, and what a wave found in its share of the elements
 struct TSweepArgs { int n, order, id0; bool lfc, by_order; int32_t needed, leaderCount; int which; };
 struct TSweepRes { uint64_t m0, m1, g, g0, g1; };   // slice order minimum; (count, slice order) minimum over the holders (g = ~0: none)
+// k_process_tas, classical order: what the leader needs to start on the NEXT entry (its head, its nomination), fetched by helper wave 1
+// while the leader finishes the current one. None of it changes while the kernel runs: an entry's nomination outputs are only rewritten
+// by its own processEntry. (A dozen dependent global round trips per entry otherwise: 20 us between two entries at cfg 5.)
+struct TPre {
+  int ready_for;   // iterator position the record was made for, -1: none
+  int e, tree, cq, plen, ps_base, nps, slice_row, nuse, borrowing, nominated_mode, tgt_n, tgt_pos;
+  uint32_t hflags, pol;
+  int64_t prio, ts;
+  int32_t path[KQ_MAXD], node_local[KQ_MAXD];
+  int32_t use_fr[KQ_MAXU];
+  int64_t use_qty[KQ_MAXU];
+};
 struct TLeafJob {
   TTopo T;
   TLeafArgs a;
-  int cmd;            // 0 idle, 1 phase-1 job posted, 2 quit, 3 copy job posted (a.pc / a.sc = the class table's rows, cp_* = the LDS arrays)
+  int cmd;            // 0 idle, 1 phase-1 job posted, 2 quit, 3 copy job posted (a.pc / a.sc = the class table's rows, cp_* = the LDS arrays),
+                      // 6 wave 1 fetches the header of entry pf_next, 7 wave 2 patches the class tables (one barrier each, nobody waits for them)
   int nw;             // waves of the workgroup sharing the job (set once by the kernel that owns the helpers)
   int coop_min;       // slices at least this long are swept by every wave of the workgroup (two barriers: ~1 us; set once, 1024 unless a test says otherwise)
   long long bytes;    // helpers add their share
@@ -214,6 +227,10 @@ struct TLeafJob {
   TSweepRes sw_r[8];
   int ar_n, ar_started, ar_skip;
   uint64_t ar_c0, ar_c1, ar_m0[8], ar_m1[8];
+  const void* pf_k;   // the kernel's K block
+  int pf_next;        // iterator position to fetch next, -1: none
+  TPre pre[2];        // [position & 1]
+  int cu_ps_base, cu_nps, cu_lds_on, cu_lds_bytes;   // cmd 7: the podsets whose TopologyAssignments were just added to the work plane
 };
 // A class's phase-1 rows (global memory, patched by L2 atomics: agent-scope loads, so that no stale line of this CU's vector cache is
 // read) into the LDS working copy; thread tid of nthreads. Eight 8-byte loads per array in flight per thread: 4168 domains are one round
@@ -321,10 +338,24 @@ KQ_DEV void t_helper_step(TLeafJob& job, int wv, int nw) {
     if (lane_id() == 0 && lb) atomic_add_i64(&job.bytes, (long long)lb);
   }
 }
+KQ_DEV void t_prefetch_entry(TLeafJob& job);   // kq_tas_cycle.hpp
+KQ_DEV void t_class_update_job(TLeafJob& job);
 KQ_DEV void t_leaf_helper(TLeafJob& job, int wv, int nw) {
   for (;;) {
     bsync();
     if (job.cmd == 2) break;
+    if (job.cmd == 6) {
+#ifdef KQ_TAS_CYCLE
+      if (wv == 1) t_prefetch_entry(job);
+#endif
+      continue;
+    }
+    if (job.cmd == 7) {
+#ifdef KQ_TAS_CYCLE
+      if (wv == 2) t_class_update_job(job);
+#endif
+      continue;
+    }
     t_helper_step(job, wv, nw);
     bsync();
   }
