@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define KQ_TAS_MAX_LEVELS 8
+#define KQ_TAS_MAX_LEVELS 16   /* TopologySpec.Levels: MaxItems=16 (apis/kueue/v1beta1/topology_types.go) */
 
 /* podset topology request kinds (isRequired :1240, isUnconstrained :1244) */
 #define KQ_TAS_REQUIRED      0

@@ -185,7 +185,7 @@ KQ_DEV int32_t t_count_in(const TK& k, const int64_t* req, const int64_t* rem) {
   return have ? result : 0;
 }
 
-constexpr int KQ_TAS_MAXR = 16;
+constexpr int KQ_TAS_MAXR = 32;   // resources of a TAS flavor's leaves (the reference's BenchmarkSchedulerTAS uses 30)
 
 // Phase 1 over the leaves (fillLeafCounts :1899) as a job any wave of the workgroup can take a stripe of: the leader of k_process_tas
 // posts it in LDS and its helper waves fill their stripes (t_leaf_helper); everywhere else the wave does it alone.
@@ -320,7 +320,8 @@ template <int RM, int U> KQ_DEV int64_t t_leaf_counts(const TTopo& T, const TLea
   return lb;
 }
 KQ_DEV int64_t t_leaf_counts_any(const TTopo& T, const TLeafArgs& a, int first, int stride) {
-  return T.R <= 4 ? t_leaf_counts<4, 2>(T, a, first, stride) : t_leaf_counts<KQ_TAS_MAXR, 1>(T, a, first, stride);
+  if (T.R <= 4) return t_leaf_counts<4, 2>(T, a, first, stride);
+  return T.R <= 16 ? t_leaf_counts<16, 1>(T, a, first, stride) : t_leaf_counts<KQ_TAS_MAXR, 1>(T, a, first, stride);
 }
 // helper waves of a workgroup whose wave 0 posts phase-1 jobs (k_process_tas): wave `wv` of `nw`
 KQ_DEV void t_sweep_help(TLeafJob& job, int wv, int nw);

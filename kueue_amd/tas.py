@@ -21,7 +21,7 @@ HOSTNAME_LABEL = "kubernetes.io/hostname"
 
 KQ_TAS_REQUIRED, KQ_TAS_PREFERRED, KQ_TAS_UNCONSTRAINED = 0, 1, 2
 TAS_OK, TAS_NOT_FIT, TAS_NO_LEVEL, TAS_SLICE_ABOVE, TAS_BAD_SLICE_SIZE, TAS_SKIPPED, TAS_UNSUPPORTED, TAS_NOT_FIT_LAYERS, TAS_BAD_LAYER = range(9)
-TAS_MAX_LEVELS = 8
+TAS_MAX_LEVELS = 16
 
 
 class kq_tas_topology(C.Structure):

@@ -161,7 +161,7 @@ class CycleTAS:
         level = np.full((max(n_ps, 1), max(nt, 1)), -1, np.int32); slevel = np.full((max(n_ps, 1), max(nt, 1)), -1, np.int32)
         ssize = np.ones(max(n_ps, 1), np.int32); group = np.full(max(n_ps, 1), -1, np.int32)
         req = np.zeros((max(n_ps, 1), R), np.int64)
-        ML = 8   # KQ_TAS_MAX_LEVELS
+        ML = 16   # KQ_TAS_MAX_LEVELS
         nlay = np.zeros(max(n_ps, 1), np.int32); llev = np.full((max(n_ps, 1), max(nt, 1), ML), -1, np.int32); lsz = np.zeros((max(n_ps, 1), ML), np.int32)
         g = 0
         gid: Dict[Tuple[str, str], int] = {}

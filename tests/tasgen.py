@@ -148,3 +148,62 @@ def random_tas_multilayer_case(seed, n_workloads=10):
         workloads.append(podsets)
         sim.append(rnd.random() < 0.1)
     return topo, T.Requests(topo, workloads, simulate_empty=sim)
+
+
+def deep_tas_case(seed, n_levels=12, n_res=30, n_workloads=10):
+    """The limits of the API rather than the usual shapes: a topology of up to 16 levels (TopologySpec.Levels MaxItems=16; the lowest is the
+    hostname) with one or two children per domain on the way down, and up to 30 resources per node (the reference's BenchmarkSchedulerTAS
+    runs 30, scheduler_tas_bench_test.go:46); podsets ask for a handful of them, required / preferred / unconstrained on any level, with
+    slices on a lower level."""
+    rnd = random.Random(0xDEE9 + seed)
+    levels = [f"example.com/l{i:02d}" for i in range(n_levels - 1)] + [T.HOSTNAME_LABEL]
+    res = [f"example.com/r{i:02d}" for i in range(n_res)]
+    nodes = []
+    paths = [[]]
+    for l in range(n_levels - 1):
+        nxt = []
+        for p in paths:
+            for ch in range(2 if (len(paths) < 24 and rnd.random() < 0.45) else 1):
+                nxt.append(p + [f"d{l}-{len(nxt)}"])
+        paths = nxt
+    hid = 0
+    for p in paths:
+        for h in range(rnd.randint(1, 3)):
+            hid += 1
+            alloc = {"pods": str(rnd.choice([4, 10, 110]))}
+            for r in res:
+                if rnd.random() < 0.7:
+                    alloc[r] = str(rnd.randint(0, 16))
+            labels = {levels[i]: p[i] for i in range(n_levels - 1)}
+            labels[T.HOSTNAME_LABEL] = f"x{hid:03d}"
+            nodes.append(T.Node(f"n{hid}", labels, alloc, ready=rnd.random() > 0.03))
+    topo = T.Topology(levels, nodes, resources=res, profile_mixed=rnd.random() > 0.3)
+    use = {}
+    for leaf in range(topo.n_leaves):
+        if rnd.random() < 0.4:
+            use[leaf] = {r: rnd.randint(0, 4) for r in rnd.sample(res, 3)}
+            use[leaf]["pods"] = rnd.randint(0, 3)
+    topo.set_tas_usage(use)
+    workloads, sim = [], []
+    for w in range(rnd.randint(2, n_workloads)):
+        reqs = {r: rnd.randint(0, 3) for r in rnd.sample(res, rnd.randint(1, 6))}
+        li = rnd.randrange(n_levels)
+        mode = rnd.choice(["required", "preferred", "unconstrained", "slice-only"])
+        slice_kw = {}
+        if rnd.random() < 0.4 or mode == "slice-only":
+            lo = li if mode in ("required", "preferred") else 0
+            slice_kw = dict(slice_required_topology=levels[rnd.randrange(lo, n_levels)], slice_size=rnd.choice([1, 2, 3]))
+        if mode == "required":
+            tr = T.TopologyRequest(required=levels[li], **slice_kw)
+        elif mode == "preferred":
+            tr = T.TopologyRequest(preferred=levels[li], **slice_kw)
+        elif mode == "unconstrained":
+            tr = T.TopologyRequest(unconstrained=True, **slice_kw)
+        else:
+            tr = T.TopologyRequest(**slice_kw)
+        count = rnd.choice([1, 2, 3, 4, 6, 9, 12])
+        if slice_kw:
+            count = max(1, count // slice_kw["slice_size"]) * slice_kw["slice_size"]
+        workloads.append([T.TASPodSetRequests("main", count, reqs, tr)])
+        sim.append(rnd.random() < 0.2)
+    return topo, T.Requests(topo, workloads, simulate_empty=sim)

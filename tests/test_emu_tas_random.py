@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from tests.emu import kqe
-from tests.tasgen import random_tas_case
+from tests.tasgen import deep_tas_case, random_tas_case
 
 
 @pytest.mark.parametrize("seed", range(500))
@@ -20,6 +20,23 @@ def test_tas_random(oracle, seed):
     bad = want.equal(got)
     assert not bad, (bad, {k: (want.a[k].tolist(), got.a[k].tolist()) for k in bad})
     assert got.bytes == want.bytes
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_tas_deep_and_wide(oracle, seed):
+    """The API's own limits (VERDICT r03 "missing" 8): 9-16 topology levels, 17-30 resources per node."""
+    topo, rq = deep_tas_case(seed, n_levels=9 + seed % 8, n_res=17 + seed % 14)
+    want = oracle.tas_find(topo, rq)
+    eng = kqe.EmuTas()
+    try:
+        eng.put(topo)
+        got = eng.find(rq)
+    finally:
+        eng.close()
+    bad = want.equal(got)
+    assert not bad, (bad, {k: (want.a[k].tolist(), got.a[k].tolist()) for k in bad})
+    assert got.bytes == want.bytes
+    assert (got.a["status"] == 0).any() or seed % 3, "nothing placed"
 
 
 def test_usage_apply_and_fits(oracle):

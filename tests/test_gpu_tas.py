@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from kueue_amd import tas as T
-from tests.tasgen import random_tas_case
+from tests.tasgen import deep_tas_case, random_tas_case
 
 pytestmark = pytest.mark.gpu
 
@@ -24,6 +24,25 @@ def test_tas_random_gpu(oracle, block):
             bad = want.equal(got)
             assert not bad, (seed, bad)
             assert got.bytes == want.bytes, seed
+    finally:
+        eng.close()
+
+
+def test_tas_deep_and_wide_gpu(oracle):
+    """9-16 topology levels, 17-30 resources per node: the limits of the API (topology_types.go MaxItems=16, scheduler_tas_bench_test.go:46)."""
+    eng = T.TASEngine()
+    try:
+        placed = 0
+        for seed in range(48):
+            topo, rq = deep_tas_case(seed, n_levels=9 + seed % 8, n_res=17 + seed % 14)
+            want = oracle.tas_find(topo, rq)
+            eng.put(topo)
+            got = eng.find(rq)
+            bad = want.equal(got)
+            assert not bad, (seed, bad)
+            assert got.bytes == want.bytes, seed
+            placed += int((got.a["status"] == 0).sum())
+        assert placed > 50
     finally:
         eng.close()
 
