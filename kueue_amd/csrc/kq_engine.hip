@@ -256,7 +256,9 @@ __global__ __launch_bounds__(256) void k_derive_level(DSnap S, DDerive d, int de
 }
 
 // TAS: one wavefront per workload (FindTopologyAssignmentsForFlavor), grid-stride over the batch
-__global__ __launch_bounds__(64) void k_tas_find(const TK* __restrict__ kp, int slots) {
+// (two waves per SIMD: the wide-resource tiers of phase 1 — up to 32 resources per leaf in registers — spill rather than halve the occupancy
+// of the usual four-resource case: 182 registers before the tiers existed)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_tas_find(const TK* __restrict__ kp, int slots) {
   const TK& k = *kp;
   // workloads are sorted by request class; a slot walks a contiguous piece so that it rarely changes class
   const int per = (k.Q.n_wl + slots - 1) / slots;

@@ -379,6 +379,7 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
   if (which != 0) KQ_TS(k, 47);   // request block + argument block of the placement
   t_workload(tk, xslot, 0);
   wsync();
+#ifndef KQ_TAS_NO_PREFETCH
   if (w.ta.mail && w.ta.pf_pos >= 0) {
     // nothing is posted to the helper waves for the rest of this entry: wave 1 fetches the next entry's header meanwhile
     TLeafJob& j = *w.ta.mail;
@@ -388,6 +389,7 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
     t_prefetch_entry(j);
 #endif
   }
+#endif
   if (which != 0) KQ_TS(k, 45);   // (timing builds, processEntry only) the placement; 46 = its phase 1
 #if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
   if (lane == 0 && which != 0) {
@@ -581,7 +583,12 @@ KQ_DEV void tc_entry_add(const K& k, const Wave& w) {  // updateTASUsage :267 on
     }
     wsync();
   }
-  if (w.ta.mail && k.tc->ncls > 0) {
+#ifdef KQ_TAS_NO_ASYNC
+  const bool async_ok = false;
+#else
+  const bool async_ok = true;
+#endif
+  if (async_ok && w.ta.mail && k.tc->ncls > 0) {
     // The class tables are read next by the copy job of the next placement, a barrier away: helper wave 2 patches them while the leader
     // goes on (one barrier to post, nobody waits). A later AddUsage that lands on the plane before wave 2 has read a leaf is simply seen
     // by this patch already (a patch recomputes its leaves from the plane and sends the difference to the table's old values up).
@@ -596,20 +603,24 @@ KQ_DEV void tc_entry_add(const K& k, const Wave& w) {  // updateTASUsage :267 on
 // scheduler.fits :771-777 -> ClusterQueueSnapshot.Fits :136-150: 0 = fits, 1 = no quota, 2 = no TAS capacity
 KQ_DEV int tc_fits_check(const K& k, Wave& w, const int32_t* trows, int nt, bool quota_usage, int tree) {
   const TCyc& c = *k.tc;
-  if (!entry_fits(k, w, trows, nt, quota_usage, tree)) return 1;
+  KQ_T0();
+  const bool qfits = entry_fits(k, w, trows, nt, quota_usage, tree);
+  KQ_TS(k, 38);   // (timing builds) scheduler.fits: the quota half, both calls of an entry
+  if (!qfits) return 1;
   bool any = false;
   for (int p = 0; p < w.nps; p++) { const TcPub a = tc_pub(c, w, p); if (a.t >= 0 && a.n > 0) any = true; }
   if (!any) return 0;
   for (int i = 0; i < nt; i++) if (!k.preempted[trows[i]]) tc_row_apply(c, trows[i], false, 2, 0);
   const bool ok = tc_entry_fits(k, w, 2);
   for (int i = nt - 1; i >= 0; i--) if (!k.preempted[trows[i]]) tc_row_apply(c, trows[i], true, 2, 0);
+  KQ_TS(k, 39);   // scheduler.fits: the leaf half
   return ok ? 0 : 2;
 }
 
 // the per-tree state of processEntry (Wave::np_broken, n_pre, broken) while ONE wave walks the entries of every tree in entry order:
 // a TAS flavor's leaves are shared by ClusterQueues of different root cohorts (snapshot.go:260), so the trees cannot run side by side
-KQ_DEV void tc_tree_switch(const K& k, Wave& w, int from, int to) {
-  int32_t* st = k.tc->tree_state;
+KQ_DEV void tc_tree_switch(const K& k, Wave& w, int from, int to, const TPre* pre = nullptr) {
+  int32_t* st = (w.ta.mail && k.S.n_tree <= KQ_TAS_TS_TREES) ? w.ta.mail->tstate : k.tc->tree_state;   // (the job block's copy starts zeroed, as the host's does)
   if (lane_id() == 0) {
     if (from >= 0) {
       int32_t* a = st + (size_t)from * 12;
@@ -620,8 +631,8 @@ KQ_DEV void tc_tree_switch(const K& k, Wave& w, int from, int to) {
     w.np_broken = b[0]; w.n_pre = b[1];
     for (int i = 0; i < 4; i++) w.broken[i] = (uint64_t)(uint32_t)b[2 + 2 * i] | ((uint64_t)(uint32_t)b[3 + 2 * i] << 32);
     w.pc_on = 0;
-    w.pc_ncq = k.S.tree_cq_off[to + 1] - k.S.tree_cq_off[to];
-    w.pc_ncoh = (k.S.tree_node_off[to + 1] - k.S.tree_node_off[to]) - w.pc_ncq;
+    w.pc_ncq = pre ? pre->tree_ncq : k.S.tree_cq_off[to + 1] - k.S.tree_cq_off[to];
+    w.pc_ncoh = (pre ? pre->tree_nn : k.S.tree_node_off[to + 1] - k.S.tree_node_off[to]) - w.pc_ncq;
     w.pc_region_bytes = 0;
   }
   wsync();
@@ -651,7 +662,7 @@ KQ_DEV void t_prefetch_entry(TLeafJob& job) {
       case 6: r.tgt_n = O.tgt_n[e]; r.tgt_pos = O.tgt_pos[e]; break;
       case 7: r.pol = S.cq_policy[cq]; break;
       case 8: r.plen = S.plen[cq]; break;
-      case 9: r.tree = S.tree_of[cq]; break;
+      case 9: { const int tr = S.tree_of[cq]; r.tree = tr; r.tree_ncq = S.tree_cq_off[tr + 1] - S.tree_cq_off[tr]; r.tree_nn = S.tree_node_off[tr + 1] - S.tree_node_off[tr]; break; }
       default: {
         const int i = it - 10;
         const int nd = S.path[(size_t)cq * KQ_MAXD + i];
@@ -662,9 +673,9 @@ KQ_DEV void t_prefetch_entry(TLeafJob& job) {
   }
   const int nu = O.use_n[e];
   if (lane == 0) r.nuse = nu;
-  for (int u = lane; u < nu; u += WAVE) { r.use_fr[u] = O.use_fr[(size_t)e * KQ_MAXU + u]; r.use_qty[u] = O.use_qty[(size_t)e * KQ_MAXU + u]; }
+  for (int u = lane; u < nu && u < KQ_TAS_PF_MAXU; u += WAVE) { r.use_fr[u] = O.use_fr[(size_t)e * KQ_MAXU + u]; r.use_qty[u] = O.use_qty[(size_t)e * KQ_MAXU + u]; }
   wsync();
-  if (lane == 0) *(volatile int*)&r.ready_for = pos;
+  if (lane == 0) *(volatile int*)&r.ready_for = nu <= KQ_TAS_PF_MAXU ? pos : -1;
   wsync();
 }
 
@@ -673,6 +684,9 @@ KQ_DEV void t_prefetch_entry(TLeafJob& job) {
 KQ_NOINLINE void process_entry_tas(const K& k, Wave& w, int e, int pos, int slot, int tree, const TPre* pre = nullptr) {
   const DSnap& S = k.S; const DOut& O = k.O; const TCyc& c = *k.tc;
   const int lane = lane_id();
+#if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
+  const long long _h0 = clock64();
+#endif
   int nt, tpos;
   if (lane == 0) w.ta.pub_lds = 0;   // what the head published came from k_nominate_tas: global memory
   if (pre) {
@@ -711,6 +725,9 @@ KQ_NOINLINE void process_entry_tas(const K& k, Wave& w, int e, int pos, int slot
   const bool quota_usage = !(w.hflags & KQ_HEAD_HAS_QUOTA_RESERVATION);
   if (w.rep_mode != M_NOFIT) cert_unverifiable(k, tree);
   const int32_t* trows = O.pool_row + tpos;
+#if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
+  if (lane == 0) { atomic_add_i64((long long*)k.prof + 36, clock64() - _h0); if (pre) atomic_add_i64((long long*)k.prof + 34, 1); }   // the entry's header; headers that came prefetched
+#endif
   auto has_any = [&]() { bool a = false; for (int t = 0; t < nt; t++) if (k.preempted[trows[t]]) a = true; return a; };
   KQ_T0();
   int fc = tc_fits_check(k, w, trows, nt, quota_usage, tree);
@@ -731,6 +748,7 @@ KQ_NOINLINE void process_entry_tas(const K& k, Wave& w, int e, int pos, int slot
     Search s = get_assignments(k, w, slot, plane, removed, true);
     KQ_TS(k, 42);   // the recomputation (45 / 46 are inside it)
     publish_assignment(k, w, s, e);
+    KQ_TS(k, 37);   // publish
     trows = O.pool_row + O.tgt_pos[e];
     nt = O.tgt_n[e];
     mode = w.rep_mode;
@@ -965,13 +983,17 @@ KQ_DEV void process_all_tas(const K& k, Wave& w, int slot, TLeafJob* mail, unsig
     w.ta.mail = mail; w.ta.lds = lds_bytes > 0 ? lds : nullptr; w.ta.lds_bytes = lds_bytes; w.ta.pf_pos = -1;
     w.ta.q_lds = 0; w.ta.pub_lds = 0; w.ta.d_lds = (lds_bytes >= (int)TX_BYTES && k.tc->d_cap <= TX_DCAP) ? 1 : 0;
     w.ta.pool_own = 1; w.ta.pool_next = *k.tc->pool_used;
-    if (mail) { mail->pf_k = &k; mail->pf_next = -1; mail->pre[0].ready_for = -1; mail->pre[1].ready_for = -1; }
+    if (mail) {
+      mail->pf_k = &k; mail->pf_next = -1; mail->pre[0].ready_for = -1; mail->pre[1].ready_for = -1;
+      for (int i = 0; i < KQ_TAS_TS_TREES * 12; i++) mail->tstate[i] = 0;
+    }
     w.pc_on = 0; w.pc_lds = nullptr; w.np_broken = 0; w.n_pre = 0; w.broken[0] = w.broken[1] = w.broken[2] = w.broken[3] = 0;
     w.cs_lds = nullptr; w.cs_lds_bytes = 0; w.help_on = 0; w.mono_break = 0; w.ta.plane = 1; w.ta.srch = 0;
   }
   wsync();
   if (k.C.fair_sharing) { process_all_fair_tas(k, w, slot); return; }
   int cur = -1;
+  KQ_T0();
   for (int i = 0; i < n; i++) {
     // the entry's header: from helper wave 1 if it was fetched while the previous entry finished, else from global memory
     const TPre* pre = nullptr;
@@ -983,8 +1005,12 @@ KQ_DEV void process_all_tas(const K& k, Wave& w, int slot, TLeafJob* mail, unsig
     const int e = pre ? pre->e : k.order_idx[i];
     const int tree = pre ? pre->tree : k.S.tree_of[k.H.cq[e]];
     if (lane_id() == 0) w.ta.pf_pos = (mail && i + 1 < n) ? i + 1 : -1;
-    if (tree != cur) { tc_tree_switch(k, w, cur, tree); cur = tree; }
+    if (tree != cur) { tc_tree_switch(k, w, cur, tree, pre); cur = tree; }
+    KQ_TS(k, 35);   // (timing builds) position -> entry, tree switch
     process_entry_tas(k, w, e, i, slot, tree, pre);
+#if defined(KQ_PROF) && !defined(KQ_HOST_EMU)
+    _t0 = clock64();
+#endif
   }
 }
 

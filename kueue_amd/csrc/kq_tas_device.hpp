@@ -202,15 +202,18 @@ struct TSweepRes { uint64_t m0, m1, g, g0, g1; };   // slice order minimum; (cou
 // k_process_tas, classical order: what the leader needs to start on the NEXT entry (its head, its nomination), fetched by helper wave 1
 // while the leader finishes the current one. None of it changes while the kernel runs: an entry's nomination outputs are only rewritten
 // by its own processEntry. (A dozen dependent global round trips per entry otherwise: 20 us between two entries at cfg 5.)
+constexpr int KQ_TAS_PF_MAXU = 16;
 struct TPre {
   int ready_for;   // iterator position the record was made for, -1: none
   int e, tree, cq, plen, ps_base, nps, slice_row, nuse, borrowing, nominated_mode, tgt_n, tgt_pos;
+  int tree_ncq, tree_nn;   // ClusterQueues / nodes of the entry's tree (what a tree switch asks the snapshot for)
   uint32_t hflags, pol;
   int64_t prio, ts;
   int32_t path[KQ_MAXD], node_local[KQ_MAXD];
-  int32_t use_fr[KQ_MAXU];
-  int64_t use_qty[KQ_MAXU];
+  int32_t use_fr[KQ_TAS_PF_MAXU];   // (an assignment with more usage entries is not prefetched)
+  int64_t use_qty[KQ_TAS_PF_MAXU];
 };
+constexpr int KQ_TAS_TS_TREES = 16;   // processEntry's per-tree state of that many trees fits the job block (LDS); more: global memory
 struct TLeafJob {
   TTopo T;
   TLeafArgs a;
@@ -231,6 +234,7 @@ struct TLeafJob {
   int pf_next;        // iterator position to fetch next, -1: none
   TPre pre[2];        // [position & 1]
   int cu_ps_base, cu_nps, cu_lds_on, cu_lds_bytes;   // cmd 7: the podsets whose TopologyAssignments were just added to the work plane
+  int32_t tstate[KQ_TAS_TS_TREES * 12];              // TCyc::tree_state of a cycle with few trees
 };
 // A class's phase-1 rows (global memory, patched by L2 atomics: agent-scope loads, so that no stale line of this CU's vector cache is
 // read) into the LDS working copy; thread tid of nthreads. Eight 8-byte loads per array in flight per thread: 4168 domains are one round

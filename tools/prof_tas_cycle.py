@@ -21,13 +21,16 @@ n = rec = 0
 for h, ct in bs[1:]:
     d, _ = eng.run_tas(h, ct); n += h.n; rec += d.tas_stats["recomputes"]
 lib.kq_debug_prof(eng._h, F.ptr(prof), 1)
-names = {40: "head + first fits", 41: "before the recomputation", 42: "recomputation (get_assignments)", 43: "publish + second fits", 44: "usage added, result written (admit path: the result only)", 59: "  admit path: preemptedWorkloads.Insert", 60: "  admit path: AddUsage on the quota planes", 61: "  admit path: leaf usage + class tables",
+names = {35: "position -> entry, tree switch", 36: "the entry's header (load_head + nomination, or the prefetched record)",
+         38: "  scheduler.fits: quota half (both calls)", 39: "  scheduler.fits: leaf half (both calls)", 37: "  publish (inside 'publish + second fits')",
+         40: "head + first fits", 41: "before the recomputation", 42: "recomputation (get_assignments)", 43: "publish + second fits", 44: "usage added, result written (admit path: the result only)", 59: "  admit path: preemptedWorkloads.Insert", 60: "  admit path: AddUsage on the quota planes", 61: "  admit path: leaf usage + class tables",
          48: "  recomputation: WorkloadsTopologyRequests", 49: "  recomputation: the find (request block + placement)", 47: "    request / argument block", 45: "    placement (t_workload)",
          46: "      phase 1 of the placement", 55: "      before the search (state of the class, parameters)", 56: "      t_find_assignment", 51: "        findLevelWithFitDomains",
          52: "        the fit level's own domains", 53: "        levels down to the slice level", 54: "        levels below the slice level", 57: "      status + buildAssignment",
          58: "      consumed domains restored", 50: "  recomputation: keeping the result"}
 for i, nm in names.items():
     print(f"{nm:60s} {prof[i]/n:10.1f} cycles/entry  ({prof[i]/n/2400:.2f} us at 2.4 GHz)")
-tot = sum(prof[i] for i in (40, 41, 42, 43, 44, 59, 60, 61))
+tot = sum(prof[i] for i in (35, 36, 40, 41, 42, 43, 37, 44, 59, 60, 61))
+print(f"headers that came prefetched: {prof[34]} of {n}")
 print(f"sum of the entry segments {tot/n:10.1f} cycles/entry  ({tot/n/2400:.2f} us at 2.4 GHz)")
 print(f"{n} entries, {rec} recomputations; kernel ms last cycle {d.kernel_ms}")
