@@ -404,7 +404,11 @@ typedef struct kq_pending {
 } kq_pending;
 #define KQ_REQUEUE_NONE    INT64_MIN
 #define KQ_REQUEUE_BLOCKED INT64_MAX
-/* PushOrUpdate (cluster_queue.go:379) of every workload into its ClusterQueue's heap; replaces any previous pending set. */
+/* PushOrUpdate (cluster_queue.go:379) of every workload into its ClusterQueue's heap; replaces any previous pending set.
+ * Workload slices (ElasticJobsViaWorkloadSlices): p->w may carry the slice_* columns — here, in kq_pending_add and in kq_pending_update;
+ * they stay resident with the workloads, travel into every Heads() batch, and kq_snapshot_patch_rows moves the slice_row of every pending
+ * workload with the admitted table (the slice that left the table is simply gone: the head is then an ordinary workload,
+ * workloadslicing.go:371). */
 int  kq_pending_put(kq_engine* e, const kq_pending* p);
 /* Heads(): pops <= 1 workload per ClusterQueue (cq_active[c] == 0: ClusterQueue skipped, manager.go:926; NULL = all active)
  * and gathers them, in canonical head order (ClusterQueue index ascending), into the engine's resident pending batch.

@@ -672,6 +672,11 @@ class Pending:
         arr = {k: cat(k) for k in ("cq", "priority", "queue_ts", "flags", "ps_count", "ps_min_count", "req_res", "req_qty", "ps_flavor_ok",
                                    "ps_last_tried", "last_generation", "last_cycle", "last_hash", "hash")}
         arr["ps_off"] = off("ps_off"); arr["ps_req_off"] = off("ps_req_off")
+        if "slice_row" in a or "slice_row" in b:   # workload slices: a side without the columns replaces nothing
+            none = {"slice_row": (-1, np.int32, "cq"), "ps_slice_count": (0, np.int32, "ps_count"), "req_slice_flavor": (-1, np.int32, "req_res"),
+                    "req_slice_qty": (0, np.int64, "req_res"), "ps_slice_pods_flavor": (-1, np.int32, "ps_count"), "ps_slice_pods_qty": (0, np.int64, "ps_count")}
+            for k, (fill, dt, like) in none.items():
+                arr[k] = np.concatenate([x[k] if k in x else np.full(len(x[like]), fill, dt) for x in (a, b)]).astype(dt)
         h = Heads.from_arrays(self.snap, arr, cycle=self.heads.cycle)
         if self.heads.workloads is not None and more.heads.workloads is not None:
             h.workloads = list(self.heads.workloads) + list(more.heads.workloads)

@@ -151,7 +151,9 @@ template <class B> struct EngineT {
     DGather& G = P.G;
     for (const void* q : {(const void*)G.cq, (const void*)G.priority, (const void*)G.queue_ts, (const void*)G.flags, (const void*)G.ps_off, (const void*)G.ps_count,
                           (const void*)G.ps_min_count, (const void*)G.ps_req_off, (const void*)G.req_res, (const void*)G.req_qty, (const void*)G.ps_flavor_ok,
-                          (const void*)G.ps_last_tried, (const void*)G.last_generation, (const void*)G.last_cycle, (const void*)G.last_hash, (const void*)G.hash})
+                          (const void*)G.ps_last_tried, (const void*)G.last_generation, (const void*)G.last_cycle, (const void*)G.last_hash, (const void*)G.hash,
+                          (const void*)G.slice_row, (const void*)G.ps_slice_count, (const void*)G.req_slice_flavor, (const void*)G.ps_slice_pods_flavor,
+                          (const void*)G.req_slice_qty, (const void*)G.ps_slice_pods_qty})
       if (q) pend_release_ptr(q);
     G.cq = pend_alloc<int32_t>(nq); G.priority = pend_alloc<int64_t>(nq); G.queue_ts = pend_alloc<int64_t>(nq); G.flags = pend_alloc<uint32_t>(nq);
     G.ps_off = pend_alloc<int32_t>(nq + 1);
@@ -160,6 +162,17 @@ template <class B> struct EngineT {
     G.ps_flavor_ok = pend_alloc<uint64_t>(gps * nfw); G.ps_last_tried = pend_alloc<int32_t>(gps * nR);
     G.last_generation = pend_alloc<int64_t>(nq); G.last_cycle = pend_alloc<int64_t>(nq);
     G.last_hash = pend_alloc<uint64_t>(nq); G.hash = pend_alloc<uint64_t>(nq);
+    G.slice_row = nullptr; G.ps_slice_count = nullptr; G.req_slice_flavor = nullptr; G.ps_slice_pods_flavor = nullptr; G.req_slice_qty = nullptr; G.ps_slice_pods_qty = nullptr;
+    if (P.D.P.slice_row) {   // the resident set holds workload slices
+      G.slice_row = pend_alloc<int32_t>(nq); G.ps_slice_count = pend_alloc<int32_t>(gps); G.ps_slice_pods_flavor = pend_alloc<int32_t>(gps);
+      G.ps_slice_pods_qty = pend_alloc<int64_t>(gps); G.req_slice_flavor = pend_alloc<int32_t>(grq); G.req_slice_qty = pend_alloc<int64_t>(grq);
+    }
+  }
+  // the gathered slice columns of a batch of heads (kq_pending_heads / kq_pending_step)
+  void pend_wire_slices(DHeads& H) {
+    const DGather& G = pend.G;
+    H.slice_row = G.slice_row; H.ps_slice_count = G.ps_slice_count; H.req_slice_flavor = G.req_slice_flavor; H.req_slice_qty = G.req_slice_qty;
+    H.ps_slice_pods_flavor = G.ps_slice_pods_flavor; H.ps_slice_pods_qty = G.ps_slice_pods_qty;
   }
   template <class T> T* pend_alloc(size_t n, const T* host = nullptr, int fill = -2) {
     T* d = (T*)be.alloc(std::max<size_t>(n, 1) * sizeof(T));
@@ -619,6 +632,9 @@ template <class B> struct EngineT {
     last_cycle_n = -1;              // the last cycle's argument block names freed arrays
     // resident head batches that name admitted rows (slice_row) name the OLD indices: void them (kq_heads_put again)
     for (size_t b = 0; b < batches.size(); b++) if ((int)b != PEND_SLOT && batches[b].valid && batches[b].H.slice_row) batches[b].valid = false;
+    // the resident pending set follows the move: the slices its workloads replace keep their identity, a removed one is simply gone
+    // (the head is then an ordinary workload: ReplacedWorkloadSlice finds nothing, workloadslicing.go:371)
+    if (pend.valid && pend.D.P.slice_row && pend.W > 0) { R.remap = const_cast<int32_t*>(pend.D.P.slice_row); be.launch_rows(R, RO_REMAP, pend.W); }
     rc = rows_rebuild(n_new);
     // not atomic on failure: the new row table is resident but the structures derived from it are not — no cycle may run on that.
     // The caller re-puts (kq_snapshot_put); every entry point checks have_snapshot.
@@ -1515,13 +1531,22 @@ template <class B> struct EngineT {
   }
 
   // ---- pending side: host orchestration ----------------------------------------------------------------------------
+  // the slice columns of the resident set for its first W workloads / nps podsets / nreq requests (h: where they come from, null = none replace a slice)
+  void pend_slice_columns(int W, size_t nps, size_t nreq, const kq_heads* h) {
+    DHeads& S0 = pend.D.P;
+    S0.slice_row = pend_alloc<int32_t>(W, h ? h->slice_row : nullptr, 0xff);
+    S0.ps_slice_count = pend_alloc<int32_t>(nps, h ? h->ps_slice_count : nullptr, 0);
+    S0.req_slice_flavor = pend_alloc<int32_t>(nreq, h ? h->req_slice_flavor : nullptr, 0xff);
+    S0.req_slice_qty = pend_alloc<int64_t>(nreq, h ? h->req_slice_qty : nullptr, 0);
+    S0.ps_slice_pods_flavor = pend_alloc<int32_t>(nps, h ? h->ps_slice_pods_flavor : nullptr, 0xff);
+    S0.ps_slice_pods_qty = pend_alloc<int64_t>(nps, h ? h->ps_slice_pods_qty : nullptr, 0);
+  }
   int pending_put(const kq_pending* p) {
     if (!have_snapshot) return fail(KQ_EINVAL, "kq_pending_put before kq_snapshot_put");
     const kq_heads* h = &p->w;
     int slot_cap = 1, max_nps = 1; bool plain = true;
     int rc = validate_heads(h, &slot_cap, &plain, &max_nps);
     if (rc != KQ_OK) return rc;
-    if (h->slice_row) return fail(KQ_EUNSUPPORTED, "workload slices in the resident pending set: use kq_cycle_run for heads that replace a slice");
     pending_free();
     const int W = h->n, nq = prep.nq, nR = prep.nR;
     const size_t nfw = (prep.nF + 63) / 64;
@@ -1555,6 +1580,8 @@ template <class B> struct EngineT {
     S0.ps_flavor_ok = pend_alloc(nps * nfw, h->ps_flavor_ok);
     S0.ps_last_tried = nullptr; S0.last_generation = nullptr; S0.last_cycle = nullptr; S0.last_hash = nullptr;
     S0.hash = pend_alloc<uint64_t>(W, h->hash, 0);
+    S0.slice_row = nullptr; S0.ps_slice_count = nullptr; S0.req_slice_flavor = nullptr; S0.req_slice_qty = nullptr; S0.ps_slice_pods_flavor = nullptr; S0.ps_slice_pods_qty = nullptr;
+    if (h->slice_row) pend_slice_columns(W, nps, nreq, h);   // workload slices: absent columns read as "no flavor / nothing requested" (as heads_put)
     D.uid = pend_alloc<uint32_t>(W, P.h_uid.data());
     D.cq_off = pend_alloc(nq + 1, cq_off.data()); D.ord = pend_alloc(W, ord.data());
     D.state = pend_alloc<uint8_t>(W, nullptr, 0);  // WL_ACTIVE
@@ -1611,6 +1638,7 @@ template <class B> struct EngineT {
     H.ps_count = G.ps_count; H.ps_min_count = G.ps_min_count; H.ps_req_off = G.ps_req_off; H.req_res = G.req_res; H.req_qty = G.req_qty;
     H.ps_flavor_ok = G.ps_flavor_ok; H.ps_last_tried = G.ps_last_tried; H.last_generation = G.last_generation; H.last_cycle = G.last_cycle;
     H.last_hash = G.last_hash; H.hash = G.hash;
+    pend_wire_slices(H);
     if (n_heads) *n_heads = P.n_heads;
     if (n_podsets) *n_podsets = P.n_ps;
     return KQ_OK;
@@ -1659,6 +1687,7 @@ template <class B> struct EngineT {
     H.ps_count = G.ps_count; H.ps_min_count = G.ps_min_count; H.ps_req_off = G.ps_req_off; H.req_res = G.req_res; H.req_qty = G.req_qty;
     H.ps_flavor_ok = G.ps_flavor_ok; H.ps_last_tried = G.ps_last_tried; H.last_generation = G.last_generation; H.last_cycle = G.last_cycle;
     H.last_hash = G.last_hash; H.hash = G.hash;
+    pend_wire_slices(H);
     st.with_heads = want_head_wl != 0;
     kq_decisions caps{};
     caps.tgt_cap = tgt_cap; caps.rsn_cap = step_rsn_cap;
@@ -1904,7 +1933,7 @@ template <class B> struct EngineT {
     DPend& D = P.D;
     DHeads& S0 = D.P;
     AddStage a;
-    a.cap = (size_t)n * 96 + aps * (16 + 8 * nfw + 4 * (size_t)nR) + arq * 16 + (size_t)(n + nq + 2) * 8 + 64 * 16;
+    a.cap = (size_t)n * 104 + aps * (40 + 8 * nfw + 4 * (size_t)nR) + arq * 32 + (size_t)(n + nq + 2) * 8 + 96 * 16;
     if (hup_cap < a.cap) { if (hup) be.free_host(hup); hup_cap = a.cap + a.cap / 4; hup = (uint8_t*)be.alloc_host(hup_cap); }
     a.host = hup;
     a.dev = grow<uint8_t>(b_addstage, a.cap);
@@ -1920,6 +1949,15 @@ template <class B> struct EngineT {
     add_col(a, S0.req_res, nrq0, arq, h->req_res); add_col(a, S0.req_qty, nrq0, arq, h->req_qty);
     add_col(a, S0.ps_flavor_ok, nps0 * nfw, aps * nfw, h->ps_flavor_ok);
     add_col(a, S0.hash, W0, n, h->hash, 0);
+    if (h->slice_row && !S0.slice_row) { pend_slice_columns(W0, nps0, nrq0, nullptr); pend_alloc_gather(); }   // the first arrivals that replace a slice
+    if (S0.slice_row) {
+      add_col(a, S0.slice_row, W0, n, h->slice_row, 0xff);
+      add_col(a, S0.ps_slice_count, nps0, aps, h->slice_row ? h->ps_slice_count : nullptr, 0);
+      add_col(a, S0.req_slice_flavor, nrq0, arq, h->slice_row ? h->req_slice_flavor : nullptr, 0xff);
+      add_col(a, S0.req_slice_qty, nrq0, arq, h->slice_row ? h->req_slice_qty : nullptr, 0);
+      add_col(a, S0.ps_slice_pods_flavor, nps0, aps, h->slice_row ? h->ps_slice_pods_flavor : nullptr, 0xff);
+      add_col(a, S0.ps_slice_pods_qty, nps0, aps, h->slice_row ? h->ps_slice_pods_qty : nullptr, 0);
+    }
     std::vector<uint32_t> uid(n);
     for (int w = 0; w < n; w++) uid[w] = p->uid_rank ? p->uid_rank[w] : (uint32_t)(W0 + w);
     add_col(a, D.uid, W0, n, uid.data());

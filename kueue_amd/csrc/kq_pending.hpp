@@ -222,6 +222,8 @@ struct DGather {
   int32_t* cq; int64_t* priority; int64_t* queue_ts; uint32_t* flags; int32_t* ps_off;
   int32_t *ps_count, *ps_min_count, *ps_req_off, *req_res; int64_t* req_qty; uint64_t* ps_flavor_ok; int32_t* ps_last_tried;
   int64_t *last_generation, *last_cycle; uint64_t *last_hash, *hash;
+  // workload slices (null unless the resident set holds the columns): kq_heads slice_row ... ps_slice_pods_qty
+  int32_t *slice_row, *ps_slice_count, *req_slice_flavor, *ps_slice_pods_flavor; int64_t *req_slice_qty, *ps_slice_pods_qty;
 };
 
 // ClusterQueue.Pop (cluster_queue.go:657-672) for ClusterQueue c — one wave
@@ -329,6 +331,14 @@ KQ_DEV void pend_gather_head(const DPend& D, const DGather& G, int h) {
   for (int i = lane; i < nreq; i += WAVE) { G.req_res[gr0 + i] = D.P.req_res[r0 + i]; G.req_qty[gr0 + i] = D.P.req_qty[r0 + i]; }
   for (int i = lane; i < nps * D.nfw; i += WAVE) G.ps_flavor_ok[(size_t)gp0 * D.nfw + i] = D.P.ps_flavor_ok[(size_t)p0 * D.nfw + i];
   for (int i = lane; i < nps * D.nR; i += WAVE) G.ps_last_tried[(size_t)gp0 * D.nR + i] = D.last_tried[(size_t)p0 * D.nR + i];
+  if (G.slice_row) {   // ElasticJobsViaWorkloadSlices: the slice the head replaces and what that slice holds (workloadslicing.go:371)
+    if (lane == 0) G.slice_row[h] = D.P.slice_row[w];
+    for (int i = lane; i < nps; i += WAVE) {
+      G.ps_slice_count[gp0 + i] = D.P.ps_slice_count[p0 + i];
+      G.ps_slice_pods_flavor[gp0 + i] = D.P.ps_slice_pods_flavor[p0 + i]; G.ps_slice_pods_qty[gp0 + i] = D.P.ps_slice_pods_qty[p0 + i];
+    }
+    for (int i = lane; i < nreq; i += WAVE) { G.req_slice_flavor[gr0 + i] = D.P.req_slice_flavor[r0 + i]; G.req_slice_qty[gr0 + i] = D.P.req_slice_qty[r0 + i]; }
+  }
 }
 
 // Step 6 of schedule() for head h (scheduler.go:362-377): the queue side of requeueAndUpdate :1165 — or, for an admitted entry,

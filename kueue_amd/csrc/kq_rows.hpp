@@ -20,7 +20,7 @@ namespace kq {
 struct RowsScratch { void* p = nullptr; size_t cap = 0; };
 
 enum { RO_ROW_INIT = 0, RO_KEY_RTS, RO_KEY_PRIO, RO_KEY_TREE, RO_RANK, RO_KEY_ASC, RO_ASC, RO_ENT_FILL, RO_BOUNDS, RO_BUCKET_FILL, RO_BUCKET_SIZE,
-       RO_LKEY, RO_LFILL, RO_MOVE_ROW, RO_MOVE_ENT, RO_ADD_ROW, RO_KEY_FS, RO_FS_FILL, RO_EVICT };
+       RO_LKEY, RO_LFILL, RO_MOVE_ROW, RO_MOVE_ENT, RO_ADD_ROW, RO_KEY_FS, RO_FS_FILL, RO_EVICT, RO_REMAP };
 
 struct DRows {
   // the row table the structures are built from
@@ -57,6 +57,7 @@ struct DRows {
   const int32_t *o_use_off, *o_use_fr; const int64_t *o_prio, *o_qts, *o_rts, *o_use_qty; const uint32_t* o_uid; const uint8_t* o_flags; const int32_t* o_adm_cq;
   int32_t *n_use_off, *n_use_fr, *n_ucnt; int64_t *n_prio, *n_qts, *n_rts, *n_use_qty; uint32_t* n_uid; uint8_t* n_flags;
   int32_t* new_of_old;  // [old n] new index of an old row, -1 = removed
+  int32_t* remap;       // RO_REMAP: row indices held elsewhere (the resident pending set's slice_row column) follow the move; a removed row becomes -1
   const int32_t* ev_rows;   // old rows that get KQ_ADM_EVICTED
   int n_old, n_add;
   const int32_t *a_target, *a_use_off, *a_use_fr; const int64_t *a_prio, *a_qts, *a_rts, *a_use_qty; const uint32_t* a_uid; const uint8_t* a_flags;
@@ -239,6 +240,7 @@ KQ_DEV void ro_add_row(const DRows& R, int i) {    // i = added row: scalars and
   R.n_ucnt[nr] = R.a_use_off[i + 1] - R.a_use_off[i];
 }
 KQ_DEV void ro_evict(const DRows& R, int i) { const int nr = R.new_of_old[R.ev_rows[i]]; if (nr >= 0) R.n_flags[nr] |= KQ_ADM_EVICTED; }
+KQ_DEV void ro_remap(const DRows& R, int i) { const int r = R.remap[i]; if (r >= 0) R.remap[i] = r < R.n_old ? R.new_of_old[r] : -1; }
 KQ_DEV void ro_move_ent(const DRows& R, int r) {   // r < n_old: an old row's entries; r >= n_old: added row r - n_old (n_use_off scanned)
   if (r < R.n_old) {
     const int nr = R.new_of_old[r];
@@ -274,6 +276,7 @@ KQ_DEV void rows_cell(const DRows& R, int op, int i, bool active) {
     case RO_KEY_FS: ro_key_fs(R, i); break;
     case RO_FS_FILL: ro_fs_fill(R, i); break;
     case RO_EVICT: ro_evict(R, i); break;
+    case RO_REMAP: ro_remap(R, i); break;
     default: break;
   }
 }

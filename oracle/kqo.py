@@ -382,6 +382,18 @@ class PendingOracle:
         self.pending = self.pending.extended(more)
         return first
 
+    def remap_rows(self, new_index, snap):
+        """kq_snapshot_patch_rows moved the admitted rows: the slices the pending workloads replace follow (a removed one is gone)."""
+        a = self.pending.heads.arrays
+        if "slice_row" in a:
+            r = a["slice_row"]
+            a["slice_row"] = np.where(r >= 0, np.asarray(new_index, np.int32)[np.maximum(r, 0)], -1).astype(np.int32)
+            self.pending.heads._struct = None
+            self.pending._struct = None
+        self.snap = snap
+        self.pending.snap = snap
+        self.pending.heads.snap = snap
+
     def set_clock(self, now_ns: int):
         self.l.kqp_set_clock.restype = None
         self.l.kqp_set_clock(self.h, C.c_int64(int(now_ns)))

@@ -143,3 +143,77 @@ def test_slices_random_cycles_gpu(oracle, seed):
         assert np.array_equal(want.usage_after, eng.usage_after()), seed
     finally:
         eng.close()
+
+
+# ---- workload slices in the RESIDENT pending set (kq_pending_put / kq_pending_add; VERDICT r03 "missing" 7) -------------------------------
+def _pending_slices_loop(oracle, eng_factory, seed, patch=False, arrivals=False, late=False):
+    """The heads of a random slice case as the pending workloads of the queues: every cycle's Heads(), decisions and targets against the
+    oracle on the same batch; optionally rows leave the snapshot between two cycles (kq_snapshot_patch_rows: the slices the pending
+    workloads replace follow the move) and half of the workloads arrive later (kq_pending_add)."""
+    import copy
+    from kueue_amd.api import Decisions, Heads, Pending
+    cfg, snap, heads = random_case(seed, fair=False, preemption=(seed % 2 == 0), partial=False, slices=True)
+    if "slice_row" not in heads.arrays or heads.n < 2:
+        return 0
+    oracle.derive(snap)
+    n0 = heads.n // 2 if arrivals else heads.n
+    first = heads.subset(np.arange(n0)) if arrivals else heads
+    if arrivals and late:   # the resident set starts without the slice columns: the first arrivals that replace a slice bring them
+        first = Heads.from_arrays(snap, {k: v for k, v in first.arrays.items() if not k.startswith(("slice_", "ps_slice", "req_slice"))}, cycle=first.cycle)
+    eng = eng_factory(cfg)
+    q = oracle.PendingOracle(cfg, snap, Pending(heads))
+    if arrivals:
+        q.close(); q = oracle.PendingOracle(cfg, snap, Pending(first))
+    osnap = snap
+    checked = 0
+    try:
+        eng.put(snap)
+        eng.pending_put(Pending(first))
+        if arrivals:
+            more = Pending(heads.subset(np.arange(n0, heads.n)), uid_rank=np.arange(n0, heads.n))
+            assert eng.pending_add(more) == n0
+            q.add(more)
+        for cyc in range(1, 6):
+            n, nps, hw = eng.pending_heads(cyc)
+            hb, ohw = q.heads(cyc)
+            assert np.array_equal(hw, ohw), (seed, cyc)
+            if n == 0:
+                break
+            got = eng.run_pending(Decisions(hb, tgt_cap=max(64, osnap.n_adm)))
+            want = oracle.cycle_run(cfg, osnap, hb)
+            assert not want.equal(got), (seed, cyc, want.equal(got))
+            checked += int((hb.arrays["slice_row"] >= 0).sum()) if "slice_row" in hb.arrays else 0
+            eng.pending_apply()
+            q.apply(hb, want)
+            if patch and cyc == 1 and osnap.n_adm > 2:
+                # every third admitted row leaves (finished workloads): the rows behind them move up, a replaced slice that left is gone
+                gone = np.arange(0, osnap.n_adm, 3)
+                res = eng.patch_rows(remove_rows=gone)
+                if isinstance(res, tuple):   # (the emulated engine returns its rc as well)
+                    assert res[0] == 0
+                    res = res[1]
+                new_index = np.asarray(res)[:osnap.n_adm]
+                keep = np.setdiff1d(np.arange(osnap.n_adm), gone)
+                osnap = osnap.with_rows(keep)
+                oracle.derive(osnap)
+                q.remap_rows(new_index, osnap)
+    finally:
+        eng.close(); q.close()
+    return checked
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_pending_set_with_slices_emulated(oracle, seed):
+    from tests.emu import kqe
+    _pending_slices_loop(oracle, kqe.EmuEngine, seed, patch=seed % 3 == 0, arrivals=seed % 4 == 1, late=seed % 8 == 5)
+
+
+def test_pending_set_with_slices_sees_slices(oracle):
+    from tests.emu import kqe
+    assert sum(_pending_slices_loop(oracle, kqe.EmuEngine, s, patch=s % 3 == 0, arrivals=s % 4 == 1) for s in range(30)) > 20
+
+
+@pytest.mark.gpu
+def test_pending_set_with_slices_gpu(oracle):
+    from kueue_amd.engine import Engine
+    assert sum(_pending_slices_loop(oracle, Engine, 2000 + s, patch=s % 3 == 0, arrivals=s % 4 == 1, late=s % 8 == 5) for s in range(40)) > 20
