@@ -2853,8 +2853,16 @@ KQ_DEV bool entry_fits(const K& k, Wave& w, const int32_t* trows, int nt, bool q
   np_apply_targets(k, w, trows, nt, false, true, tree);
   bool bad = false;
   for (int u = lane_id(); u < w.nuse; u += WAVE) {
-    UP g = up_plane(k, w, 1, w.use_fr[u]);
-    if (i64max(0, available_of(S, w.path, w.plen, w.use_fr[u], g)) < w.use_qty[u]) bad = true;
+    int64_t avail;
+    if (!w.pc_on && w.plen <= GP_MAX) {   // the path's cells of every level in one round trip (available_of makes one per level)
+      GPath gp;
+      gpath_load(S, w.path, w.plen, w.use_fr[u], k.usage_np, gp);
+      avail = gpath_available(gp, w.plen);
+    } else {
+      UP g = up_plane(k, w, 1, w.use_fr[u]);
+      avail = available_of(S, w.path, w.plen, w.use_fr[u], g);
+    }
+    if (i64max(0, avail) < w.use_qty[u]) bad = true;
   }
   bool ok = wballot(bad) == 0;
   wsync();
@@ -2865,6 +2873,34 @@ KQ_DEV bool entry_fits(const K& k, Wave& w, const int32_t* trows, int nt, bool q
 // cq.AddUsage on both planes (clusterqueue_snapshot.go:107)
 KQ_DEV void entry_add_usage(const K& k, Wave& w, const int64_t* qty) {
   const DSnap& S = k.S;
+  if (!w.pc_on && w.plen <= GP_MAX) {
+    // planes in global memory, a short path: lanes = (usage entry, plane), and a lane fetches the cells of all its levels before it
+    // walks them (add_usage makes a round trip per level, and the two planes one after the other)
+    for (int it = lane_id(); it < 2 * w.nuse; it += WAVE) {
+      const int u = it >> 1, plane = it & 1, fr = w.use_fr[u];
+      int64_t* pl = plane == 0 ? k.usage_work : k.usage_np;
+      int64_t uu[GP_MAX], lq[GP_MAX];
+      #pragma unroll
+      for (int i = 0; i < GP_MAX; i++) {
+        const int n = w.path[i < w.plen ? i : 0];
+        uu[i] = pl[ix(S, n, fr)];
+        lq[i] = local_quota(S, n, fr);
+      }
+      int64_t val = qty[u];
+      #pragma unroll
+      for (int i = 0; i < GP_MAX; i++) {
+        if (i >= w.plen) break;
+        const int n = w.path[i];
+        const int64_t la = i64max(0, a_sub(lq[i], uu[i]));
+        pl[ix(S, n, fr)] = a_add(uu[i], val);
+        if (k.cq_dirty && n < S.nq) k.cq_dirty[n] = 1;
+        if (i + 1 < w.plen && val > la) val = a_sub(val, la); else break;
+      }
+    }
+    if (lane_id() == 0) { w.bytes += (int64_t)w.nuse * 8 * w.plen; w.usage_dirty = 1; }
+    wsync();
+    return;
+  }
   for (int u = lane_id(); u < w.nuse; u += WAVE) {
     int fr = w.use_fr[u];
     UP a = up_plane(k, w, 0, fr), b = up_plane(k, w, 1, fr);

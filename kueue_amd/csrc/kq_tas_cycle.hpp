@@ -107,6 +107,25 @@ KQ_NOINLINE void tc_row_apply(const TCyc& c, int row, bool add, int which, int s
 }
 // TASFlavorSnapshot.Fits :433 for one TopologyDomainRequests on `pl` (agent-scope loads: the cells are updated with L2 atomics)
 KQ_DEV bool tc_fits_dom(const TTopo& T, const int64_t* pl, int leaf, int32_t count, const int64_t* spr) {
+  if (T.R <= 4) {   // the usual width: every operand (requests, capacity, usage) is in flight before the first division
+    int64_t q[4], cap[4], used[4];
+    #pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const bool in = r < T.R;
+      q[r] = in ? spr[r] : 0;
+      cap[r] = in ? T.free_cap[(size_t)leaf * T.R + r] : 0;
+      used[r] = in ? (int64_t)ag_load_u64((const uint64_t*)(pl + (size_t)leaf * T.R + r)) : 0;
+    }
+    bool have = false; int32_t result = 0;
+    #pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if (q[r] == 0) continue;
+      int32_t cc = 0x7fffffff;
+      if (q[r] > 0) cc = (int32_t)i64max(0, i64min(t_div(cap[r] - used[r], q[r]), 0x7fffffff));
+      if (!have || cc < result) { result = cc; have = true; }
+    }
+    return (have ? result : 0) >= count;
+  }
   bool have = false; int32_t result = 0;
   for (int r = 0; r < T.R; r++) {
     if (spr[r] == 0) continue;

@@ -897,10 +897,12 @@ KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* 
     for (int i = lane_id(); i < n; i += WAVE) s.set[i] = T.level_off[searchLevelIdx] + i;
     int fitDomain = -1, topDomain = -1;
     TView v;
+    TPROF0();
     // keys, sortedDomain[0] and the domain the level's search is after — BestFit: findBestFitDomainBy over the whole level;
     // LeastFreeCapacity: the first domain in ascending order that holds everything — in one sweep (its closing fence publishes s.set as well)
     v = t_view_first_fit(k, s, n, ORD_LEADER, st.unconstrained, sliceCount, st.leaderCount > 0 ? 3 : 2, st.leaderCount, &topDomain, &fitDomain,
                          T.level_off[searchLevelIdx], lfc);
+    TPROF(k, 3);   // (timing builds) the level's sweep
     if (topDomain < 0) {
       // every domain of the level has an all-zero state: whatever sortedDomain[0] is, it holds nothing
       if (sliceCount == 0 && st.leaderCount == 0) {
@@ -1006,6 +1008,7 @@ KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* 
           wsync();
           remainingSliceCount -= (int32_t)cum;
           m = m2;
+          TPROF(k, 7);   // LeastFreeCapacity: the histogram threshold (everything of the level between the sweep and here)
         }
         TView r = t_view(k, s, m, ORD_PLAIN, st.unconstrained);
         for (int i = 0; remainingSliceCount > 0; i++) {
@@ -1119,7 +1122,6 @@ KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, 
     wsync();
     ncur = nout;
   }
-  TPROF(k, 3);   // levels below the slice level
   *nfit = ncur;
   return TFail{KQ_TAS_OK, 0, 0};
 }
@@ -1293,7 +1295,6 @@ KQ_DEV void t_workload(const TK& k, int slot, int w) {
     }
     wsync();
   }
-  TPROF(k, 7);   // the consumed domains restored from the class table
 }
 // phase 1 of request class c into the class tables
 KQ_DEV void t_class(const TK& k, int c) {

@@ -26,8 +26,8 @@ names = {35: "position -> entry, tree switch", 36: "the entry's header (load_hea
          40: "head + first fits", 41: "before the recomputation", 42: "recomputation (get_assignments)", 43: "publish + second fits", 44: "usage added, result written (admit path: the result only)", 59: "  admit path: preemptedWorkloads.Insert", 60: "  admit path: AddUsage on the quota planes", 61: "  admit path: leaf usage + class tables",
          48: "  recomputation: WorkloadsTopologyRequests", 49: "  recomputation: the find (request block + placement)", 47: "    request / argument block", 45: "    placement (t_workload)",
          46: "      phase 1 of the placement", 55: "      before the search (state of the class, parameters)", 56: "      t_find_assignment", 51: "        findLevelWithFitDomains",
-         52: "        the fit level's own domains", 53: "        levels down to the slice level", 54: "        levels below the slice level", 57: "      status + buildAssignment",
-         58: "      consumed domains restored", 50: "  recomputation: keeping the result"}
+         52: "        the fit level's own domains", 53: "        levels down to the slice level", 54: "          findLevel: the level's sweep", 58: "          findLevel: LeastFreeCapacity histogram threshold", 57: "      status + buildAssignment",
+         50: "  recomputation: keeping the result"}
 for i, nm in names.items():
     print(f"{nm:60s} {prof[i]/n:10.1f} cycles/entry  ({prof[i]/n/2400:.2f} us at 2.4 GHz)")
 tot = sum(prof[i] for i in (35, 36, 40, 41, 42, 43, 37, 44, 59, 60, 61))
