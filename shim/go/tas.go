@@ -63,7 +63,7 @@ type TASCycle struct {
 	PsLevel, PsSliceLevel         []int32 // [podsets][len(Topos)]
 	PsSliceSize, PsGroup          []int32
 	PsReq                         []int64 // [podsets][resources] SinglePodRequests (tas_flavorassigner.go:116)
-	PsNLayers, PsLayerLevel, PsLayerSize []int32 // TASMultiLayerTopology; nil = single layer everywhere
+	PsNLayers, PsLayerLevel, PsLayerSize []int32 // TASMultiLayerTopology; nil = single layer everywhere. Strides: [podsets][len(Topos)][C.KQ_TAS_MAX_LEVELS] / [podsets][C.KQ_TAS_MAX_LEVELS] (16, the API's MaxItems)
 }
 
 // TASCycleOut receives the TopologyAssignment of every podset that holds one (kq_cycle_tas_out).
@@ -221,7 +221,7 @@ type TASRequests struct {
 	Kind                                []uint8
 	Group                               []int32
 	LeafOK                              []uint8 // [n][leaves] or nil
-	NLayers, LayerLevel, LayerSize      []int32 // nil = single layer
+	NLayers, LayerLevel, LayerSize      []int32 // nil = single layer; [podsets][C.KQ_TAS_MAX_LEVELS]
 }
 
 // TASResult = the TopologyAssignment (or the failure operands, KQ_TAS_*) per podset request.
