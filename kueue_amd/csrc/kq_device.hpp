@@ -703,11 +703,14 @@ struct TAW {
   // k_process_tas with the LDS block: the request block of a one-podset class-path find and the wave's two domain stores live behind the
   // placement's working state (kq_tas_cycle.hpp TX_*); the TopologyAssignment the entry published is then still in store half 0
   int q_lds, d_lds, pub_lds;
+  const struct TPre* cur_pre;     // k_process_tas: the prefetched header of the entry being processed (null: it was loaded the ordinary way)
   int pool_own, pool_next;        // k_process_tas (pool_own = 1): the wave is the only writer of the published pool, pool_next its next free position; else the atomic counter
 };
 #define KQ_TAS_WALK(w) ((w).ta.srch != 0)
+#define KQ_TAS_PROCESS(k, w) ((k).tc != nullptr && (w).ta.plane != 0)   // (timing builds) assign_flavors inside k_process_tas's recomputation
 #else
 #define KQ_TAS_WALK(w) false
+#define KQ_TAS_PROCESS(k, w) false
 #endif
 struct Wave {
 #ifdef KQ_TAS_CYCLE
@@ -2101,7 +2104,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
     for (int r = lane; r < nR; r += WAVE) { O.flavor[(size_t)psg * nR + r] = -1; O.res_mode[(size_t)psg * nR + r] = M_NOFIT; O.tried_idx[(size_t)psg * nR + r] = -1; }
     if (lane == 0) O.ps_count[psg] = scale ? new_count : count;
     wsync();
-    if constexpr (LEAN) KQ_TS(k, 57);  // lean: requests of the podset in iterator order, output rows cleared
+    if (LEAN || KQ_TAS_PROCESS(k, w)) KQ_TS(k, 57);  // lean: requests of the podset in iterator order, output rows cleared
     bool group_failed = false;
     int ps_reasons = 0, ps_nflavors = 0, ps_mode = M_FIT;
     if (lane == 0) w.rsn_ps0 = w.nrsn;
@@ -2183,7 +2186,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
           w.cell_pm[c] = pm | (mismatch ? 0x40 : 0); w.cell_borrow[c] = borrow; w.cell_val[c] = val; w.cell_aux[c] = aux;
         }
         wsync();
-        if constexpr (LEAN) KQ_TS(k, 58);  // lean: the (flavor, resource) cells of the pass (fitsResourceQuota)
+        if (LEAN || KQ_TAS_PROCESS(k, w)) KQ_TS(k, 58);  // lean: the (flavor, resource) cells of the pass (fitsResourceQuota)
         // ---- recomputation inside k_process_fair: every cell of the pass that needs a SimulatePreemption is posted as one batch ----
         bool batched = false;
         HelpBox* hbox = nullptr;
@@ -2281,7 +2284,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
           }
         }
       }
-      if constexpr (LEAN) KQ_TS(k, 59);  // lean: the serial choice among the flavors
+      if (LEAN || KQ_TAS_PROCESS(k, w)) KQ_TS(k, 59);  // lean: the serial choice among the flavors
       int tried = -1;
       if (gate(k, KQ_GATE_FLAVOR_FUNGIBILITY)) tried = (attempted == nflv - 1) ? -1 : attempted;
       else tried = 0;
@@ -2353,7 +2356,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
       break;
     }
   }
-  if constexpr (LEAN) KQ_TS(k, 60);  // lean: usage list / outputs of the podsets
+  if (LEAN || KQ_TAS_PROCESS(k, w)) KQ_TS(k, 60);  // lean: usage list / outputs of the podsets
   if (!any_ps) rep = M_NOFIT;  // RepresentativeMode with no podsets :212-215
   if (lane == 0) {
     w.rep_mode = rep;

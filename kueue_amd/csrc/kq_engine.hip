@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
   // workloads are sorted by request class; a slot walks a contiguous piece so that it rarely changes class
   const int per = (k.Q.n_wl + slots - 1) / slots;
   const int lo = blockIdx.x * per, hi = (lo + per) < k.Q.n_wl ? (lo + per) : k.Q.n_wl;
-  for (int i = lo; i < hi; i++) t_workload(k, blockIdx.x, k.C.order[i]);
+  for (int i = lo; i < hi; i++) t_workload_t<false>(k, blockIdx.x, k.C.order[i]);   // (the batch kernel's state is in global memory)
 }
 __global__ __launch_bounds__(64) void k_tas_classes(const TK* __restrict__ kp) { t_class(*kp, blockIdx.x); }
 __global__ __launch_bounds__(64) void k_tas_usage(TTopo T, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int add) {

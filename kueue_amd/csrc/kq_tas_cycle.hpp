@@ -330,10 +330,15 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
   const int lane = lane_id();
   // processEntry on the work plane, one podset of a request class: start from the class's resident phase 1, and (k_process_tas) keep the
   // request block and the placement's working state in LDS
+  // (k_process_tas: the static half of the block came with the entry's prefetched header when it has one podset on the one TAS flavor)
+  const TPre* qp = (w.ta.cur_pre && w.ta.cur_pre->q_ok && n == 1 && w.ta.req_ps[0] == 0 && t == 0) ? w.ta.cur_pre : nullptr;
   int cls = -1;
   if (which == 1 && !simulateEmpty && n == 1 && c.ncls > 0) {
-    cls = c.ps_class[w.ps_base + w.ta.req_ps[0]];
-    if (cls >= 0 && !c.cls_ok[(size_t)t * c.ncls + cls]) cls = -1;
+    if (qp) cls = qp->q_cls_ok ? qp->q_cls : -1;
+    else {
+      cls = c.ps_class[w.ps_base + w.ta.req_ps[0]];
+      if (cls >= 0 && !c.cls_ok[(size_t)t * c.ncls + cls]) cls = -1;
+    }
   }
   const TK& tk0 = c.tk[t];
   const bool st_lds = cls >= 0 && w.ta.lds && TX_BYTES + tas_lds_layout(tk0.T.D, tk0.X.max_set).total <= (size_t)w.ta.lds_bytes;
@@ -348,6 +353,12 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
   const bool layered = c.ps_n_layers != nullptr;
   if (lane == 0) {
     qi[TQ_WLOFF] = 0; qi[TQ_WLOFF + 1] = n;
+    if (qp) {
+      qi[qo.count] = k.O.ps_count[w.ps_base];
+      qi[qo.level] = qp->q_level; qi[qo.ssize] = qp->q_ssize; qi[qo.slevel] = qp->q_slevel; qi[qo.group] = qp->q_group;
+      qu[0] = (uint8_t)qp->q_kind;
+      for (int r = 0; r < c.R; r++) qs[r] = qp->q_req[r];
+    } else
     for (int i = 0; i < n; i++) {
       const int g = w.ps_base + w.ta.req_ps[i];
       qi[qo.count + i] = k.O.ps_count[g];
@@ -402,6 +413,7 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
   if (w.ta.mail && w.ta.pf_pos >= 0) {
     // nothing is posted to the helper waves for the rest of this entry: wave 1 fetches the next entry's header meanwhile
     TLeafJob& j = *w.ta.mail;
+    t_post_begin(j);
     if (lane == 0) { j.pf_next = w.ta.pf_pos; j.cmd = 6; w.ta.pf_pos = -1; }
     bsync();
 #ifdef KQ_HOST_EMU
@@ -612,7 +624,8 @@ KQ_DEV void tc_entry_add(const K& k, const Wave& w) {  // updateTASUsage :267 on
     // goes on (one barrier to post, nobody waits). A later AddUsage that lands on the plane before wave 2 has read a leaf is simply seen
     // by this patch already (a patch recomputes its leaves from the plane and sends the difference to the table's old values up).
     TLeafJob& j = *w.ta.mail;
-    if (lane_id() == 0) { j.cu_ps_base = w.ps_base; j.cu_nps = w.nps; j.cu_lds_on = w.ta.lds != nullptr; j.cu_lds_bytes = w.ta.lds_bytes; j.cmd = 7; }
+    t_post_begin(j);
+    if (lane_id() == 0) { j.early_cls = -1; j.cu_ps_base = w.ps_base; j.cu_nps = w.nps; j.cu_lds_on = w.ta.lds != nullptr; j.cu_lds_bytes = w.ta.lds_bytes; j.cmd = 7; }   // (the tables move: whatever rows sit in LDS are stale)
     bsync();
 #ifdef KQ_HOST_EMU
     t_class_update_job(j);
@@ -690,12 +703,58 @@ KQ_DEV void t_prefetch_entry(TLeafJob& job) {
       }
     }
   }
+  {  // the request block's static half (tc_find), when there is one podset and one TAS flavor
+    const TCyc& c = *k.tc;
+    const int g = H.ps_off[e];
+    const bool one = c.n_tas == 1 && H.ps_off[e + 1] - g == 1 && c.R <= KQ_TAS_PF_R && c.ps_n_layers == nullptr;
+    if (lane == 0) r.q_ok = one ? 1 : 0;
+    if (one) {
+      for (int it = lane; it < 7 + c.R; it += WAVE) {
+        switch (it) {
+          case 0: { const int cls = c.ncls > 0 ? c.ps_class[g] : -1; r.q_cls = cls; r.q_cls_ok = cls >= 0 ? c.cls_ok[cls] : 0; break; }
+          case 1: r.q_level = c.ps_level[g]; break;
+          case 2: r.q_ssize = c.ps_slice_size[g]; break;
+          case 3: r.q_slevel = c.ps_slice_level[g]; break;
+          case 4: r.q_group = c.ps_group[g]; break;
+          case 5: r.q_kind = c.ps_kind[g]; break;
+          case 6: break;
+          default: r.q_req[it - 7] = c.ps_req[(size_t)g * c.R + (it - 7)];
+        }
+      }
+    }
+  }
   const int nu = O.use_n[e];
   if (lane == 0) r.nuse = nu;
   for (int u = lane; u < nu && u < KQ_TAS_PF_MAXU; u += WAVE) { r.use_fr[u] = O.use_fr[(size_t)e * KQ_MAXU + u]; r.use_qty[u] = O.use_qty[(size_t)e * KQ_MAXU + u]; }
   wsync();
   if (lane == 0) *(volatile int*)&r.ready_for = nu <= KQ_TAS_PF_MAXU ? pos : -1;
   wsync();
+}
+
+// A recomputation on the work plane that will place one podset of a request class (the usual entry of a TAS cycle): its class's rows
+// are copied into LDS by the helper waves while the leader runs the flavor assignment (cmd 8, split-phase; t_class_to_lds joins it).
+// One TAS flavor only: which flavor a podset lands on is the assignment's to decide.
+KQ_DEV void tc_early_copy(const K& k, Wave& w, bool overlap) {
+  const TCyc& c = *k.tc;
+  if (overlap || !w.ta.mail || !w.ta.lds || c.n_tas != 1 || c.ncls == 0 || w.nps != 1 || w.ta.mail->nw < 2) return;
+  const int cls = c.ps_class[w.ps_base];
+  if (cls < 0 || !c.cls_ok[cls]) return;
+  const TK& tk0 = c.tk[0];
+  const TLdsLay l = tas_lds_layout(tk0.T.D, tk0.X.max_set);
+  if (TX_BYTES + l.total > (size_t)w.ta.lds_bytes) return;
+  TLeafJob& j = *w.ta.mail;
+  t_post_begin(j);
+  unsigned char* base = w.ta.lds + TX_BYTES;
+  if (lane_id() == 0) {
+    const int32_t* tab = c.cls_tab[0];
+    j.a.pc = const_cast<int32_t*>(tab) + (size_t)cls * tk0.T.D; j.a.sc = const_cast<int32_t*>(tab) + (size_t)c.ncls * tk0.T.D + (size_t)cls * tk0.T.D;
+    j.cp_pc = (int32_t*)(base + l.pc); j.cp_sc = (int32_t*)(base + l.sc); j.cp_n = tk0.T.D;
+    j.early_cls = cls; j.early_pending = 1; j.cmd = 8;
+  }
+  bsync();
+#ifdef KQ_HOST_EMU
+  for (int wv = 1; wv < j.nw; wv++) t_helper_step(j, wv, j.nw);
+#endif
 }
 
 // scheduler.go:392-523 for entry e at iterator position pos; the generic path of process_entry with the TAS side of
@@ -707,7 +766,7 @@ KQ_NOINLINE void process_entry_tas(const K& k, Wave& w, int e, int pos, int slot
   const long long _h0 = clock64();
 #endif
   int nt, tpos;
-  if (lane == 0) w.ta.pub_lds = 0;   // what the head published came from k_nominate_tas: global memory
+  if (lane == 0) { w.ta.pub_lds = 0; w.ta.cur_pre = pre; }   // what the head published came from k_nominate_tas: global memory
   if (pre) {
     // the header came with helper wave 1 (LDS): load_head + the nomination without a global access
     if (lane == 0) {
@@ -758,6 +817,7 @@ KQ_NOINLINE void process_entry_tas(const K& k, Wave& w, int e, int pos, int slot
     if (overlap && np_exact_mode(w)) np_rebuild(k, w, tree, false);
     if (!overlap && lane == 0 && c.stats) atomic_add_i64(c.stats + 1, 1);
     if (lane == 0) { w.has_last = 0; w.ta.plane = overlap ? 2 : 1; }
+    tc_early_copy(k, w, overlap);
     for (int i = lane; i < w.nps * S.nR; i += WAVE) k.X.nom[(size_t)slot * KQ_MAXPS * S.nR + i] = O.flavor[(size_t)w.ps_base * S.nR + i];
     wsync();
     // overlap: SimulateWorkloadRemoval(victimsOfOtherPreemptions) = the planes without the preempted rows; TAS only: the snapshot as it is
@@ -836,9 +896,9 @@ KQ_NOINLINE void process_entry_tas(const K& k, Wave& w, int e, int pos, int slot
     np_apply_targets(k, w, trows, nt, false, false, tree);
     for (int t = lane; t < nt; t += WAVE) if (k.preempted[trows[t]] == 3) k.preempted[trows[t]] = 1;
     wsync();
-    KQ_TS(k, 59);   // (timing builds) preemptedWorkloads.Insert
+    KQ_TS(k, 62);   // (timing builds) preemptedWorkloads.Insert
     if (quota_usage) entry_add_usage(k, w, w.use_qty);
-    KQ_TS(k, 60);   // AddUsage on the quota planes
+    KQ_TS(k, 63);   // AddUsage on the quota planes
     tc_entry_add(k, w);
     KQ_TS(k, 61);   // leaf usage + the class tables
     if (mode == M_PREEMPT) { action = KQ_ACT_PREEMPT; rq = KQ_RQ_PENDING_PREEMPTION; }
@@ -1000,10 +1060,10 @@ KQ_DEV void process_all_tas(const K& k, Wave& w, int slot, TLeafJob* mail, unsig
   const int n = hn(k.H);
   if (lane_id() == 0) {
     w.ta.mail = mail; w.ta.lds = lds_bytes > 0 ? lds : nullptr; w.ta.lds_bytes = lds_bytes; w.ta.pf_pos = -1;
-    w.ta.q_lds = 0; w.ta.pub_lds = 0; w.ta.d_lds = (lds_bytes >= (int)TX_BYTES && k.tc->d_cap <= TX_DCAP) ? 1 : 0;
+    w.ta.cur_pre = nullptr; w.ta.q_lds = 0; w.ta.pub_lds = 0; w.ta.d_lds = (lds_bytes >= (int)TX_BYTES && k.tc->d_cap <= TX_DCAP) ? 1 : 0;
     w.ta.pool_own = 1; w.ta.pool_next = *k.tc->pool_used;
     if (mail) {
-      mail->pf_k = &k; mail->pf_next = -1; mail->pre[0].ready_for = -1; mail->pre[1].ready_for = -1;
+      mail->pf_k = &k; mail->pf_next = -1; mail->pre[0].ready_for = -1; mail->pre[1].ready_for = -1; mail->early_pending = 0; mail->early_cls = -1;
       for (int i = 0; i < KQ_TAS_TS_TREES * 12; i++) mail->tstate[i] = 0;
     }
     w.pc_on = 0; w.pc_lds = nullptr; w.np_broken = 0; w.n_pre = 0; w.broken[0] = w.broken[1] = w.broken[2] = w.broken[3] = 0;

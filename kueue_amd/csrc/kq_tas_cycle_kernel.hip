@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64) void k_tas_cycle_classes(const TCyc* __restrict
 __global__ __launch_bounds__(64) void k_nominate_tas(const K* __restrict__ kp, int slots) {
   const K& k = *kp;
   __shared__ Wave w;
-  if (threadIdx.x == 0) { w.cs_lds = nullptr; w.cs_lds_bytes = 0; w.help_on = 0; w.ta.plane = 0; w.ta.srch = 0; w.ta.mail = nullptr; w.ta.lds = nullptr; w.ta.lds_bytes = 0; w.ta.pf_pos = -1; w.ta.q_lds = 0; w.ta.d_lds = 0; w.ta.pub_lds = 0; w.ta.pool_own = 0; w.ta.pool_next = 0; }
+  if (threadIdx.x == 0) { w.cs_lds = nullptr; w.cs_lds_bytes = 0; w.help_on = 0; w.ta.plane = 0; w.ta.srch = 0; w.ta.mail = nullptr; w.ta.lds = nullptr; w.ta.lds_bytes = 0; w.ta.pf_pos = -1; w.ta.q_lds = 0; w.ta.d_lds = 0; w.ta.pub_lds = 0; w.ta.pool_own = 0; w.ta.pool_next = 0; w.ta.cur_pre = nullptr; }
   __syncthreads();
   const int slot = blockIdx.x;
   for (int h = slot, n = hn(k.H); h < n; h += slots) nominate_head(k, w, h, slot);
@@ -39,10 +39,11 @@ __global__ __launch_bounds__(PROCESS_TAS_THREADS) void k_process_tas(const K* __
   __shared__ Wave w;
   __shared__ TLeafJob job;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
-  if (threadIdx.x == 0) { job.cmd = 0; job.nw = PROCESS_TAS_THREADS / 64; job.bytes = 0; job.coop_min = coop_min; }
+  if (threadIdx.x == 0) { job.cmd = 0; job.nw = PROCESS_TAS_THREADS / 64; job.bytes = 0; job.coop_min = coop_min; job.early_pending = 0; job.early_cls = -1; }
   __syncthreads();
   if (threadIdx.x < 64) {
     process_all_tas(*kp, w, 0, &job, dyn_lds, (int)lds_bytes);
+    t_post_begin(job);   // (a split-phase copy nobody asked for any more)
     if (threadIdx.x == 0) job.cmd = 2;
     __syncthreads();
   } else {

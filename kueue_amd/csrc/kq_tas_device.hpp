@@ -104,6 +104,19 @@ KQ_DEV void t_touch(const TState& s, int d) {
   const int n = s.meta[0];
   if (n < s.logcap) { s.log[n] = d; s.meta[0] = n + 1; } else s.meta[1] = 1;
 }
+// The arrays of a state in LDS are reached through generic pointers: a `flat_*` access, which waits for the wave's outstanding GLOBAL
+// traffic as well (one counter pair) — the fire-and-forget stores of the id lists and the log would be back on the chain. Told that the
+// pointers are LDS, the compiler emits `ds_*`; that takes a second instantiation of the placement (LDS = true) next to the one every
+// other caller uses.
+#if !defined(KQ_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
+#define KQ_TAS_IS_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))
+#else
+#define KQ_TAS_IS_LDS(p) do {} while (0)   // (the emulation, and hipcc's host pass)
+#endif
+KQ_DEV void t_assume_lds(const TState& s) {
+  KQ_TAS_IS_LDS(s.pc); KQ_TAS_IS_LDS(s.sc); KQ_TAS_IS_LDS(s.pcwl); KQ_TAS_IS_LDS(s.scwl); KQ_TAS_IS_LDS(s.k0); KQ_TAS_IS_LDS(s.k1);
+  KQ_TAS_IS_LDS(s.arr); KQ_TAS_IS_LDS(s.cur); KQ_TAS_IS_LDS(s.nxt); KQ_TAS_IS_LDS(s.meta);
+}
 // leaderCount of domain d: a state without leaders (TState::nolead: the LDS working copy of a request class) holds no such array
 KQ_DEV int32_t t_lc(const TState& s, int d) { return s.nolead ? 0 : s.lc[d]; }
 KQ_DEV void t_set_lc(const TState& s, int d, int32_t v) { if (!s.nolead) s.lc[d] = v; }
@@ -202,11 +215,14 @@ struct TSweepRes { uint64_t m0, m1, g, g0, g1; };   // slice order minimum; (cou
 // k_process_tas, classical order: what the leader needs to start on the NEXT entry (its head, its nomination), fetched by helper wave 1
 // while the leader finishes the current one. None of it changes while the kernel runs: an entry's nomination outputs are only rewritten
 // by its own processEntry. (A dozen dependent global round trips per entry otherwise: 20 us between two entries at cfg 5.)
-constexpr int KQ_TAS_PF_MAXU = 16;
+constexpr int KQ_TAS_PF_MAXU = 16, KQ_TAS_PF_R = 8;
 struct TPre {
   int ready_for;   // iterator position the record was made for, -1: none
   int e, tree, cq, plen, ps_base, nps, slice_row, nuse, borrowing, nominated_mode, tgt_n, tgt_pos;
   int tree_ncq, tree_nn;   // ClusterQueues / nodes of the entry's tree (what a tree switch asks the snapshot for)
+  // the static half of the request block of a find for the entry's ONLY podset on the cycle's ONLY TAS flavor (q_ok = 0: anything else)
+  int q_ok, q_cls, q_cls_ok, q_level, q_ssize, q_slevel, q_group, q_kind;
+  int64_t q_req[KQ_TAS_PF_R];
   uint32_t hflags, pol;
   int64_t prio, ts;
   int32_t path[KQ_MAXD], node_local[KQ_MAXD];
@@ -218,7 +234,8 @@ struct TLeafJob {
   TTopo T;
   TLeafArgs a;
   int cmd;            // 0 idle, 1 phase-1 job posted, 2 quit, 3 copy job posted (a.pc / a.sc = the class table's rows, cp_* = the LDS arrays),
-                      // 6 wave 1 fetches the header of entry pf_next, 7 wave 2 patches the class tables (one barrier each, nobody waits for them)
+                      // 6 wave 1 fetches the header of entry pf_next, 7 wave 2 patches the class tables (one barrier each, nobody waits for them),
+                      // 8 the helper waves copy a class table into LDS and wait for the leader at the second barrier
   int nw;             // waves of the workgroup sharing the job (set once by the kernel that owns the helpers)
   int coop_min;       // slices at least this long are swept by every wave of the workgroup (two barriers: ~1 us; set once, 1024 unless a test says otherwise)
   long long bytes;    // helpers add their share
@@ -235,6 +252,10 @@ struct TLeafJob {
   TPre pre[2];        // [position & 1]
   int cu_ps_base, cu_nps, cu_lds_on, cu_lds_bytes;   // cmd 7: the podsets whose TopologyAssignments were just added to the work plane
   int32_t tstate[KQ_TAS_TS_TREES * 12];              // TCyc::tree_state of a cycle with few trees
+  // cmd 8: the copy job of the NEXT placement posted split-phase at the start of a recomputation — the helper waves copy the class's rows
+  // while the leader runs the flavor assignment, and wait at the job's second barrier; the leader joins it when the placement starts
+  // (t_class_to_lds), or before it posts anything else (t_post_begin). early_cls: the class whose rows the LDS arrays hold (-1: none)
+  int early_pending, early_cls;
 };
 // A class's phase-1 rows (global memory, patched by L2 atomics: agent-scope loads, so that no stale line of this CU's vector cache is
 // read) into the LDS working copy; thread tid of nthreads. Eight 8-byte loads per array in flight per thread: 4168 domains are one round
@@ -330,9 +351,19 @@ KQ_DEV int64_t t_leaf_counts_any(const TTopo& T, const TLeafArgs& a, int first, 
 // helper waves of a workgroup whose wave 0 posts phase-1 jobs (k_process_tas): wave `wv` of `nw`
 KQ_DEV void t_sweep_help(TLeafJob& job, int wv, int nw);
 KQ_DEV void t_argmin_help(TLeafJob& job, int wv, int nw);
+// before the leader posts a job: a split-phase copy still waiting at its second barrier is joined first
+KQ_DEV void t_post_begin(TLeafJob& j) {
+  if (j.early_pending) {
+    bsync();
+    if (lane_id() == 0) j.early_pending = 0;
+    wsync();
+  }
+}
 // one posted job, wave wv's share of it
 KQ_DEV void t_helper_step(TLeafJob& job, int wv, int nw) {
-  if (job.cmd == 3) {
+  if (job.cmd == 8) {
+    if (nw > 1) t_class_copy(job.a.pc, job.a.sc, job.cp_pc, job.cp_sc, job.cp_n, (wv - 1) * WAVE + lane_id(), (nw - 1) * WAVE);
+  } else if (job.cmd == 3) {
     t_class_copy(job.a.pc, job.a.sc, job.cp_pc, job.cp_sc, job.cp_n, wv * WAVE + lane_id(), nw * WAVE);
   } else if (job.cmd == 4) {
     t_sweep_help(job, wv, nw);
@@ -377,7 +408,15 @@ KQ_DEV void t_class_to_lds(const TK& k, const TState& s, int cls) {
   const int32_t* spc = k.C.pc + (size_t)cls * T.D; const int32_t* ssc = k.C.sc + (size_t)cls * T.D;
   if (k.mail) {
     TLeafJob& j = *k.mail;
-    if (lane_id() == 0) { j.a.pc = (int32_t*)spc; j.a.sc = (int32_t*)ssc; j.cp_pc = s.pc; j.cp_sc = s.sc; j.cp_n = T.D; j.cmd = 3; }
+    if (j.early_pending && j.early_cls == cls && j.cp_pc == s.pc) {
+      // the rows came while the flavor assignment ran: the helper waves are at the job's second barrier
+      bsync();
+      if (lane_id() == 0) { j.early_pending = 0; j.early_cls = -1; }   // (the placement consumes the copy)
+      wsync();
+      return;
+    }
+    t_post_begin(j);
+    if (lane_id() == 0) { j.early_cls = -1; j.a.pc = (int32_t*)spc; j.a.sc = (int32_t*)ssc; j.cp_pc = s.pc; j.cp_sc = s.sc; j.cp_n = T.D; j.cmd = 3; }
     bsync();
     KQ_TAS_EMU_HELPERS(j);
     t_class_copy(spc, ssc, s.pc, s.sc, T.D, lane_id(), j.nw * WAVE);
@@ -398,6 +437,7 @@ KQ_DEV void t_fill_in_counts(const TK& k, const TState& s, const TParams& p, lon
     const TLeafArgs a{s.pc, s.sc, s.pcwl, s.scwl, s.lc, s.assumed, p.req, p.leaderReq, p.leafOk, p.simulateEmpty ? 1 : 0, p.hasAssumed ? 1 : 0, p.sliceLevelIdx, p.sliceSize};
     if (k.mail) {
       TLeafJob& j = *k.mail;
+      t_post_begin(j);
       if (lane == 0) { j.T = T; j.a = a; j.bytes = 0; j.cmd = 1; }
       bsync();
       KQ_TAS_EMU_HELPERS(j);
@@ -686,11 +726,14 @@ KQ_DEV TView t_view_first_fit(const TK& k, const TState& s, int n, int order, bo
 }
 // ---- long slices of a state in LDS, shared with the helper waves (k_process_tas) ----
 KQ_DEV void t_sweep_help(TLeafJob& job, int wv, int nw) {
-  const TSweepRes r = t_sweep_part(job.sw_s, job.sw_a, wv * WAVE + lane_id(), nw * WAVE);
+  const TState s = job.sw_s;
+  t_assume_lds(s);
+  const TSweepRes r = t_sweep_part(s, job.sw_a, wv * WAVE + lane_id(), nw * WAVE);
   if (lane_id() == 0) job.sw_r[wv] = r;
 }
 KQ_DEV TSweepRes t_sweep_coop(const TState& s, const TSweepArgs& a) {
   TLeafJob& j = *s.coop;
+  t_post_begin(j);
   if (lane_id() == 0) { j.sw_s = s; j.sw_a = a; j.cmd = 4; }
   bsync();
   KQ_TAS_EMU_HELPERS(j);
@@ -702,11 +745,14 @@ KQ_DEV TSweepRes t_sweep_coop(const TState& s, const TSweepArgs& a) {
 KQ_DEV void t_argmin_help(TLeafJob& job, int wv, int nw) {
   const SelRest sel{job.ar_started != 0, job.ar_c0, job.ar_c1, job.ar_skip};
   uint64_t m0, m1;
-  t_argmin_part(job.sw_s, job.ar_n, sel, false, wv * WAVE + lane_id(), nw * WAVE, &m0, &m1);
+  const TState s = job.sw_s;
+  t_assume_lds(s);
+  t_argmin_part(s, job.ar_n, sel, false, wv * WAVE + lane_id(), nw * WAVE, &m0, &m1);
   if (lane_id() == 0) { job.ar_m0[wv] = m0; job.ar_m1[wv] = m1; }
 }
 KQ_DEV bool t_argmin_rest_coop(const TState& s, const TView& v, const SelRest& sel, uint64_t* o0, uint64_t* o1) {
   TLeafJob& j = *s.coop;
+  t_post_begin(j);
   if (lane_id() == 0) { j.sw_s = s; j.ar_n = v.n; j.ar_started = sel.started ? 1 : 0; j.ar_c0 = sel.c0; j.ar_c1 = sel.c1; j.ar_skip = sel.skip; j.cmd = 5; }
   bsync();
   KQ_TAS_EMU_HELPERS(j);
@@ -1164,10 +1210,11 @@ KQ_DEV void t_emit(const TK& k, const TState& s, int ncur, int which, int ps) {
 }
 
 // FindTopologyAssignmentsForFlavor :578 for workload w
-KQ_DEV void t_workload(const TK& k, int slot, int w) {
+template <bool LDS> KQ_DEV void t_workload_t(const TK& k, int slot, int w) {
   const TTopo& T = k.T; const TReq& Q = k.Q; const TOut& O = k.O;
   TState s0 = tas_state(k, slot);
-  if (k.lds && k.mail) { s0.coop = k.mail; s0.coop_min = k.mail->coop_min; }
+  if (LDS && k.mail) { s0.coop = k.mail; s0.coop_min = k.mail->coop_min; }
+  if (LDS) t_assume_lds(s0);
   const TState s = s0;
   const int lane = lane_id();
   const int p0 = Q.wl_off[w], p1 = Q.wl_off[w + 1];
@@ -1241,7 +1288,7 @@ KQ_DEV void t_workload(const TK& k, int slot, int w) {
       if (cls >= 0) {
         // start from the class's phase-1 table; the slot keeps it between workloads of the same class (the LDS copy is filled every
         // time: the table moves with every AddUsage, and the copy is one round trip of the whole workgroup)
-        if (k.lds) {
+        if (LDS) {
           t_class_to_lds(k, s, cls);
           if (lane == 0) { s.meta[1] = 1; s.meta[2] = cls; }   // (nothing to put back afterwards)
         } else if (s.meta[2] != cls || s.meta[1]) {
@@ -1295,6 +1342,9 @@ KQ_DEV void t_workload(const TK& k, int slot, int w) {
     }
     wsync();
   }
+}
+KQ_DEV void t_workload(const TK& k, int slot, int w) {
+  if (k.lds) t_workload_t<true>(k, slot, w); else t_workload_t<false>(k, slot, w);
 }
 // phase 1 of request class c into the class tables
 KQ_DEV void t_class(const TK& k, int c) {

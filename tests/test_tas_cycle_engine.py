@@ -224,6 +224,30 @@ def test_tas_cycle_population_gpu(oracle, classes_off, monkeypatch):
     assert (hits == 0) if classes_off else (hits >= rec)
 
 
+@pytest.mark.parametrize("mode", ["lds-off", "coop-1"])
+def test_tas_cycle_population_state_modes_emulated(oracle, mode, monkeypatch):
+    """k_process_tas keeps a class-path placement's working state in LDS and shares long sweeps with its helper waves: the same
+    population with the state in the slot's global rows (a topology that does not fit falls back to them) and with every slice
+    shared, however short."""
+    monkeypatch.setenv(*{"lds-off": ("KQ_TAS_LDS_OFF", "1"), "coop-1": ("KQ_TAS_COOP_MIN", "1")}[mode])
+    _LAST.clear()
+    rec, hits = _population(oracle, _emu, 120, 360, blocks=2, racks=4, hosts=16)
+    assert rec > 100 and hits >= rec
+    for seed in range(60):
+        _random(oracle, _emu, seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["lds-off", "coop-1"])
+def test_tas_cycle_population_state_modes_gpu(oracle, mode, monkeypatch):
+    monkeypatch.setenv(*{"lds-off": ("KQ_TAS_LDS_OFF", "1"), "coop-1": ("KQ_TAS_COOP_MIN", "1")}[mode])
+    _LAST.clear()
+    rec, hits = _population(oracle, _hip, 400, 800)
+    assert rec > 300 and hits >= rec
+    for seed in range(60):
+        _random(oracle, _hip, seed)
+
+
 def test_fair_tas_cycle_population_emulated(oracle):
     """The same population under fair sharing: ten root trees whose iterators are interleaved by the canonical getCq, the recomputation
     chain over the shared leaves."""

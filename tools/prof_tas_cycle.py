@@ -23,14 +23,15 @@ for h, ct in bs[1:]:
 lib.kq_debug_prof(eng._h, F.ptr(prof), 1)
 names = {35: "position -> entry, tree switch", 36: "the entry's header (load_head + nomination, or the prefetched record)",
          38: "  scheduler.fits: quota half (both calls)", 39: "  scheduler.fits: leaf half (both calls)", 37: "  publish (inside 'publish + second fits')",
-         40: "head + first fits", 41: "before the recomputation", 42: "recomputation (get_assignments)", 43: "publish + second fits", 44: "usage added, result written (admit path: the result only)", 59: "  admit path: preemptedWorkloads.Insert", 60: "  admit path: AddUsage on the quota planes", 61: "  admit path: leaf usage + class tables",
+         40: "head + first fits", 41: "before the recomputation", 42: "recomputation (get_assignments)", 43: "publish + second fits", 44: "usage added, result written (admit path: the result only)", 62: "  admit path: preemptedWorkloads.Insert", 63: "  admit path: AddUsage on the quota planes", 61: "  admit path: leaf usage + class tables",
+         57: "  recomputation: assign_flavors - requests of the podset, output rows cleared", 58: "  recomputation: assign_flavors - the (flavor, resource) cells", 59: "  recomputation: assign_flavors - the choice among the flavors", 60: "  recomputation: assign_flavors - usage list / outputs",
          48: "  recomputation: WorkloadsTopologyRequests", 49: "  recomputation: the find (request block + placement)", 47: "    request / argument block", 45: "    placement (t_workload)",
          46: "      phase 1 of the placement", 55: "      before the search (state of the class, parameters)", 56: "      t_find_assignment", 51: "        findLevelWithFitDomains",
          52: "        the fit level's own domains", 53: "        levels down to the slice level", 54: "          findLevel: the level's sweep", 58: "          findLevel: LeastFreeCapacity histogram threshold", 57: "      status + buildAssignment",
          50: "  recomputation: keeping the result"}
 for i, nm in names.items():
     print(f"{nm:60s} {prof[i]/n:10.1f} cycles/entry  ({prof[i]/n/2400:.2f} us at 2.4 GHz)")
-tot = sum(prof[i] for i in (35, 36, 40, 41, 42, 43, 37, 44, 59, 60, 61))
+tot = sum(prof[i] for i in (35, 36, 40, 41, 42, 43, 37, 44, 62, 63, 61))
 print(f"headers that came prefetched: {prof[34]} of {n}")
 print(f"sum of the entry segments {tot/n:10.1f} cycles/entry  ({tot/n/2400:.2f} us at 2.4 GHz)")
 print(f"{n} entries, {rec} recomputations; kernel ms last cycle {d.kernel_ms}")
