@@ -2551,7 +2551,11 @@ KQ_DEV void publish_assignment(const K& k, Wave& w, const Search& s, int h) {
     else { O.tgt_pos[h] = pos; O.tgt_n[h] = w.ntgt; }
     w.counts[0] = pos;  // broadcast through LDS
   }
+#ifdef KQ_TAS_CYCLE
+  if (k.tc && w.ta.pool_own) wsync_lds(); else wsync();   // (k_process_tas: the word travels through LDS; the fence below covers the global stores)
+#else
   wsync();
+#endif
   pos = w.counts[0];
   if (pos + w.ntgt <= O.pool_cap)
     for (int t = lane_id(); t < w.ntgt; t += WAVE) { O.pool_row[pos + t] = s.trow[t]; O.pool_reason[pos + t] = s.treason[t]; }

@@ -545,9 +545,13 @@ KQ_NOINLINE void tc_publish(const K& k, Wave& w, int slot) {
     w.counts[0] = base;
     w.ta.pub_lds = (w.ta.d_lds && base >= 0) ? 1 : 0;   // the published domains are still in store half 0 (tc_entry_fits / tc_entry_add)
   }
-  wsync();
+  // k_process_tas (the pool is the wave's own): only LDS words are exchanged here, and a full fence would wait for the acknowledgement
+  // of the global stores above — a round trip each
+  const bool own = w.ta.pool_own != 0;
+  if (own) wsync_lds(); else wsync();
   base = w.counts[0];
-  wsync();
+  const bool in_lds = w.ta.pub_lds != 0;
+  if (own) wsync_lds(); else wsync();
   int at = base;
   for (int p = 0; p < w.nps && p < TC_P; p++) {
     const int g = w.ps_base + p;
@@ -558,7 +562,9 @@ KQ_NOINLINE void tc_publish(const K& k, Wave& w, int slot) {
       at += w.ta.n[p];
     }
   }
-  wsync();
+  // what was just written to global memory (h_*, the pool) is read by this wave again only when the domains are NOT kept in LDS; its
+  // other readers — helper wave 2's class-table patch, the host — come behind the fences of AddUsage / the kernel's end
+  if (own && in_lds) wsync_lds(); else wsync();
 }
 
 // ---- processEntry ------------------------------------------------------------------------------------------------------------------------
