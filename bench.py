@@ -998,6 +998,19 @@ def bench_tas(args, torch, dist, world, rank, local_rank):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    parity = (None, "skipped")
+    if rank == 0 and not args.no_parity_gate:   # outside the timed region: a sample of the batch against the oracle, every output field
+        from oracle import kqo
+        if args.warmup == 0:
+            step()
+        idx = np.arange(0, rq.n, max(1, rq.n // 2000))
+        sub = rq.subset(idx)
+        want = kqo.tas_find(topo, sub)
+        got = eng.find(sub)
+        bad = want.equal(got)
+        assert not bad and got.bytes == want.bytes, f"cfg5 parity gate: the engine's placements differ from the oracle's in {bad}"
+        parity = (True, f"{len(idx)} workloads of the batch (every {max(1, rq.n // 2000)}th) placed again on their own: status, failure operands, "
+                        "domains, counts and the algorithmic byte counter equal the oracle's")
     if world > 1:
         dist.barrier()
     ms = np.zeros(1, np.float64); by = np.zeros(1, np.int64)
@@ -1031,6 +1044,7 @@ def bench_tas(args, torch, dist, world, rank, local_rank):
                        "sharding": "TAS flavor per GPU, no collective"},
             "p50_cycle_ms": float(np.percentile(st_ms, 50)), "p99_cycle_ms": float(np.percentile(st_ms, 99)),
             "kernel_ms_per_cycle": {"k_tas_find": kms / args.steps},
+            "parity_checked": parity[0], "parity": parity[1],
             "roofline": {"bound": "hbm", "kernel": "k_tas_find", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "algorithmic_bytes_per_launch": kby / args.steps, "traffic": pmc_traffic("cfg5", "k_tas_find"),
                          "note": "algorithmic bytes = phase 1 of every workload as the reference runs it; the kernel runs phase 1 once "
