@@ -13,8 +13,10 @@
  * (levelKeyWithImpliedFallback :1212 -> `level`), message formatting from (status, operands).
  * Multi-layer slice constraints (TASMultiLayerTopology, default on): buildSliceSizeAtLevel :1123, the rounding of fillInCountsHelper
  * :1955, the per-level slice size of the descent :1054, multiLayerNotFitMessage :2030 / countSlicesInSubtree :2019.
- * Not covered (status KQ_TAS_UNSUPPORTED): TASBalancedPlacement, TASRespectNodeAffinityPreferred (both default-off gates), node
- * replacement.
+ * Node replacement (the HasUnhealthyNodes branch :608-633): kq_tas_find_replacement — findReplacementAssignment :686,
+ * requiredReplacementDomain :759, findIncompleteSliceDomain :842, mergeTopologyAssignments :2072, the BelongsTo test of fillLeafCounts
+ * :1902. The node-exclusion statistics of notFitMessage :1997 (tasExclusionStats :470): kq_tas_exclusion_stats.
+ * Not covered (status KQ_TAS_UNSUPPORTED): TASBalancedPlacement, TASRespectNodeAffinityPreferred (both default-off gates).
  *
  * Canonical order: the domains of every level are numbered in the lexicographic order of their levelValues
  * (compareDomainLevelValues :1727), so every "levelValues ascending" tie-break is an integer compare.
@@ -46,6 +48,10 @@ extern "C" {
                                      level), b = that level; kq_tas_result.layer_fit = slices that fit in its subtree, per layer */
 #define KQ_TAS_BAD_LAYER       8  /* buildSliceSizeAtLevel :1123: operand a = the offending layer (index in the constraint list), b = 0
                                      level not found, 1 not below the previous layer's level, 2 size does not divide the previous size */
+
+#define KQ_TAS_STALE           9  /* findReplacementAssignment :695: the existing assignment names a domain that is not a leaf of the
+                                     snapshot; operand a = index of that domain in the podset's existing list */
+#define KQ_TAS_NO_REPLACEMENT 10  /* :727 "cannot find replacement assignment for unhealthy node" */
 
 typedef struct kq_tas_topology {
   int32_t n_levels;               /* len(levelKeys) */
@@ -130,6 +136,38 @@ int  kq_tas_admit(kq_tas*, const kq_tas_requests* r, const kq_tas_result* res, c
 int  kq_tas_usage_delta(kq_tas*, const kq_tas_requests* r, const kq_tas_result* res, const uint8_t* wl_sel, int64_t* plane_dev);
 int  kq_tas_usage_add(kq_tas*, const int64_t* plane_dev, int32_t sign);
 int  kq_tas_overflow(kq_tas*, const int64_t* plane_dev, uint8_t* leaf_over, int32_t* n_over);
+
+/* ---- node replacement: FindTopologyAssignmentsForFlavor for workloads with Status.UnhealthyNodes (:608-633) -------------------------
+ * A batch `r` whose podsets may hold an existing TopologyAssignment. The host (Go) side has done what is string work: deleteDomain
+ * :828 (the domain of UnhealthyNodes[0] is taken out of the list, r->count[i] = the pods it held), findPSA :747 (a podset without a
+ * PodSetAssignment / TopologyAssignment is not submitted at all, :612), SkipReassignmentForPodOwnedWorkloads (:615, the podset is not
+ * submitted: its result is the existing assignment), and the resolution of every remaining domain to a leaf index (-1 = no such leaf).
+ * For a podset with is_replacement[i] != 0 the library then does findReplacementAssignment :686 — the stale check :694
+ * (KQ_TAS_STALE), requiredReplacementDomain :759 / findIncompleteSliceDomain :842 (r->level / kind / slice_* / layer_* describe the
+ * podset's ORIGINAL topology request), the rewrite of the slice request :703-722, the placement of r->count[i] pods restricted to the
+ * leaves below the required domain (:1902) without a leader (the podsets of a group are placed one by one, :609, each seeing the
+ * assumed usage of the replacements before it, :633), KQ_TAS_NO_REPLACEMENT for an empty result (:727) and mergeTopologyAssignments
+ * :2072: out->dom_* of the podset is the merged assignment, leaves ascending. Podsets with is_replacement[i] == 0 take the ordinary
+ * path (a workload is one or the other as a whole in the reference; the library does not check). findIncompleteSliceDomain ranges over
+ * a Go map (:879): where several domains qualify the reference's answer is not determined; the library takes the first in the
+ * canonical domain order. */
+typedef struct kq_tas_replacement {
+  const uint8_t* is_replacement;  /* [n] */
+  const int32_t* ex_off;          /* [n+1] CSR into ex_leaf / ex_count: the existing TopologyAssignment after deleteDomain */
+  const int32_t* ex_leaf;         /* leaf index, -1 = IsTopologyAssignmentStale :818 */
+  const int32_t* ex_count;
+} kq_tas_replacement;
+int  kq_tas_find_replacement(kq_tas*, const kq_tas_requests* r, const kq_tas_replacement* x, kq_tas_result* out);
+/* tasExclusionStats :470 of the podsets `podsets[0..n_sel)` of a batch that kq_tas_find / kq_tas_find_replacement answered (`res`; x may
+ * be NULL) — normally the ones that failed with KQ_TAS_NOT_FIT*: notFitMessage :1997 appends "Total nodes: N; excluded: ..." from them.
+ * The library counts what the leaf state decides, against the same state the placement saw (the assumed usage of the workload's
+ * earlier podset groups rebuilt from `res`): topology_domain[s] = feasible leaves (r->leaf_ok) outside the required replacement domain
+ * (:1902-1905), resources[s][res] = leaves whose pod count is 0 with `res` the limiting resource (CountInWithLimitingResource
+ * pkg/resources/requests.go:195: the smallest count, ties by resource NAME — resource_rank[res] = rank of the name, NULL = index order).
+ * TotalNodes and the nodeSelector / affinity / taint counts are the simulator's (host side). The kernel runs on demand, after a
+ * failure: the counters are not part of the placement's hot loop. */
+int  kq_tas_exclusion_stats(kq_tas*, const kq_tas_requests* r, const kq_tas_replacement* x, const kq_tas_result* res, int32_t n_sel,
+                            const int32_t* podsets, const int32_t* resource_rank, int32_t* topology_domain, int32_t* resources);
 
 int  kq_tas_last_stats(kq_tas*, double* kernel_ms, int64_t* bytes);
 const char* kq_tas_last_error(kq_tas*);

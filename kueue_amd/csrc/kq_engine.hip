@@ -290,6 +290,11 @@ __global__ __launch_bounds__(256) void k_tas_overflow(TTopo T, const int64_t* pl
   const int leaf = blockIdx.x * 256 + threadIdx.x;
   if (leaf < T.n_leaves) t_overflow_cell(T, leaf, plane, over, n_over);
 }
+// tasExclusionStats (kq_tas_exclusion_stats): one thread per (selected podset, leaf); blockIdx.y = the podset
+__global__ __launch_bounds__(256) void k_tas_excl(TTopo T, TExcl E) {
+  const int leaf = blockIdx.x * 256 + threadIdx.x;
+  if (leaf < T.n_leaves) t_excl_cell(T, E, blockIdx.y, leaf);
+}
 
 // pending side on the device (kq_pending.hpp): Heads() = pop per ClusterQueue + compaction + gather; requeue from the decisions
 __global__ __launch_bounds__(64) void k_pend_pop(DPend D) { pend_pop(D, blockIdx.x); }
@@ -553,6 +558,10 @@ struct HipBackend {
   void launch_tas_overflow(const TTopo& T, const int64_t* plane, uint8_t* over, int32_t* n_over) {
     hipLaunchKernelGGL(k_tas_overflow, dim3((T.n_leaves + 255) / 256), dim3(256), 0, stream, T, plane, over, n_over);
     chk(hipGetLastError(), "k_tas_overflow");
+  }
+  void launch_tas_excl(const TTopo& T, const TExcl& E) {
+    hipLaunchKernelGGL(k_tas_excl, dim3((T.n_leaves + 255) / 256, E.n_sel), dim3(256), 0, stream, T, E);
+    chk(hipGetLastError(), "k_tas_excl");
   }
   void launch_commit_mask(int n, int32_t* use_n_out, int32_t* cq_out, int32_t* fr_out, int64_t* qty_out, int32_t* count) {  // uses the K block of the last cycle
     hipLaunchKernelGGL(k_commit_mask, dim3((n * KQ_MAXU + 255) / 256), dim3(256), 0, stream, dproc, use_n_out, cq_out, fr_out, qty_out, count);
@@ -1107,6 +1116,17 @@ int kq_tas_overflow(kq_tas* t, const int64_t* plane_dev, uint8_t* leaf_over, int
   if (!t) return KQ_EINVAL;
   (void)hipSetDevice(t->e.be.device);
   KQ_TRY(t, return t->e.overflow(plane_dev, leaf_over, n_over));
+}
+int kq_tas_find_replacement(kq_tas* t, const kq_tas_requests* r, const kq_tas_replacement* x, kq_tas_result* out) {
+  if (!t || !r || !x || !out) return KQ_EINVAL;
+  (void)hipSetDevice(t->e.be.device);
+  KQ_TRY(t, return t->e.find_replacement(r, x, out));
+}
+int kq_tas_exclusion_stats(kq_tas* t, const kq_tas_requests* r, const kq_tas_replacement* x, const kq_tas_result* res, int32_t n_sel, const int32_t* podsets,
+                           const int32_t* resource_rank, int32_t* topology_domain, int32_t* resources) {
+  if (!t || !r || !res) return KQ_EINVAL;
+  (void)hipSetDevice(t->e.be.device);
+  KQ_TRY(t, return t->e.exclusion_stats(r, x, res, n_sel, podsets, resource_rank, topology_domain, resources));
 }
 int kq_tas_read_usage(kq_tas* t, int64_t* u) { if (!t || !u) return KQ_EINVAL; (void)hipSetDevice(t->e.be.device); KQ_TRY(t, return t->e.read_usage(u)); }
 int kq_tas_last_stats(kq_tas* t, double* ms, int64_t* bytes) { if (!t) return KQ_EINVAL; if (ms) *ms = t->e.last_ms; if (bytes) *bytes = t->e.last_bytes; return KQ_OK; }

@@ -25,6 +25,22 @@ struct TAdmit {
   int32_t* n_admitted;       // [1]
 };
 
+// arguments of t_excl_cell (below): tasExclusionStats :470 for selected podsets of an answered batch
+struct TExcl {
+  int n_sel;
+  const int32_t* podset;      // [n_sel] request rows
+  const uint8_t* sim_empty;   // [n_sel]
+  const int32_t *lo, *hi;     // [n_sel] the leaves below the required replacement domain (all leaves without one)
+  const int64_t* spr;         // [n][R]
+  const uint8_t* leaf_ok;     // [n][n_leaves] or NULL
+  const int32_t* as_off;      // [n_sel+1] CSR: the podsets of the workload's earlier groups (their assignments are the assumed usage :586)
+  const int32_t* as_ps;
+  const int32_t *dom_off, *dom_leaf, *dom_count;  // the answered batch
+  const int32_t* rank;        // [R] rank of the resource's name (the tie-break of CountInWithLimitingResource), NULL = index order
+  int32_t* topo_dom;          // [n_sel]
+  int32_t* res;               // [n_sel][R]
+};
+
 template <class Backend> struct TasT {
   Backend be;
   std::string last_error;
@@ -34,6 +50,8 @@ template <class Backend> struct TasT {
   struct Buf { void* p = nullptr; size_t cap = 0; };
   Buf bq[16], bo[8], bx[15], bc[12];
   bool use_classes = true;  // tests can switch the shared phase 1 off
+  std::vector<int32_t> h_par, h_leaf_lo, h_leaf_hi;  // [D] host mirrors of the tree (topology_put)
+  Buf be_x[12];
   double last_ms = 0;
   int64_t last_bytes = 0;
 
@@ -66,6 +84,7 @@ template <class Backend> struct TasT {
     for (auto& b : bx) if (b.p) be.free(b.p);
     for (auto& b : bc) if (b.p) be.free(b.p);
     for (auto& b : ba) if (b.p) be.free(b.p);
+    for (auto& b : be_x) if (b.p) be.free(b.p);
   }
 
   int topology_put(const kq_tas_topology* t) {
@@ -90,6 +109,14 @@ template <class Backend> struct TasT {
         if (first[g] < 0) first[g] = d;
         cnt[g]++;
       }
+    }
+    // host mirrors for the node-replacement bookkeeping: global parent ids and the (contiguous) leaf range below every domain
+    h_par.assign(T.D, -1); h_leaf_lo.assign(T.D, 0); h_leaf_hi.assign(T.D, 0);
+    for (int l = 1; l < T.L; l++) for (int d = T.level_off[l]; d < T.level_off[l + 1]; d++) h_par[d] = T.level_off[l - 1] + t->parent[d];
+    for (int d = T.leaf_base; d < T.D; d++) { h_leaf_lo[d] = d - T.leaf_base; h_leaf_hi[d] = d - T.leaf_base + 1; }
+    for (int d = T.leaf_base - 1; d >= 0; d--) {
+      if (first[d] < 0) { h_leaf_lo[d] = h_leaf_hi[d] = 0; continue; }
+      h_leaf_lo[d] = h_leaf_lo[first[d]]; h_leaf_hi[d] = h_leaf_hi[first[d] + cnt[d] - 1];
     }
     T.child_first = upload(topo_allocs, first.data(), first.size());
     T.child_cnt = upload(topo_allocs, cnt.data(), cnt.size());
@@ -236,6 +263,201 @@ template <class Backend> struct TasT {
       out->dom_off[i + 1] = tot;
     }
     return KQ_OK;
+  }
+
+  // ---- node replacement (include/kq_tas.h kq_tas_find_replacement) --------------------------------------------------------------
+  // ancestor of leaf `leaf` at level `lv`
+  int ancestor_at(int leaf, int lv) const { int d = T.leaf_base + leaf; for (int i = T.L - 1; i > lv; i--) d = h_par[d]; return d; }
+  // findIncompleteSliceDomain :842 — the domain at `lv` whose pods of the existing assignment plus the missing ones fill whole slices.
+  // The reference ranges over a map (:879); the first qualifying domain in canonical order is taken here.
+  int incomplete_slice_domain(const kq_tas_replacement* x, int i, int32_t missing, int32_t size, int lv) const {
+    if (lv < 0 || lv >= T.L || size <= 0) return -1;
+    std::vector<std::pair<int, int64_t>> use;
+    for (int j = x->ex_off[i]; j < x->ex_off[i + 1]; j++) {
+      if (x->ex_leaf[j] < 0) continue;
+      const int d = ancestor_at(x->ex_leaf[j], lv);
+      bool found = false;
+      for (auto& u : use) if (u.first == d) { u.second += x->ex_count[j]; found = true; break; }
+      if (!found) use.push_back({d, x->ex_count[j]});
+    }
+    std::sort(use.begin(), use.end());
+    for (auto& u : use) if ((u.second + missing) % size == 0) return u.first;
+    return -1;
+  }
+  // the podset's constraint list, outermost first (utiltas.PodSetSliceRequiredTopologyConstraints); empty = no slices requested
+  static void constraints_of(const kq_tas_requests* r, int i, std::vector<std::pair<int, int32_t>>* out) {
+    out->clear();
+    const int nl = r->n_layers ? r->n_layers[i] : 0;
+    if (nl > 1) { for (int j = 0; j < nl; j++) out->push_back({r->layer_level[(size_t)i * KQ_TAS_MAX_LEVELS + j], r->layer_size[(size_t)i * KQ_TAS_MAX_LEVELS + j]}); return; }
+    if (r->slice_size[i] != 1) out->push_back({r->slice_level[i], r->slice_size[i]});
+  }
+  // requiredReplacementDomain :759 -> global domain id, -1 = none ("")
+  int required_replacement_domain(const kq_tas_requests* r, const kq_tas_replacement* x, int i) const {
+    const int lv = r->level[i];
+    if (lv < 0 || lv >= T.L) return -1;                                   // key == nil / level not found
+    if (x->ex_off[i + 1] == x->ex_off[i]) return -1;                      // the faulty node was the only one
+    const int32_t size = r->slice_size[i], count = r->count[i];
+    if (size <= 0) return -1;                                             // getSliceSizeWithSinglePodAsDefault's reason
+    if (size != 1 && count % size != 0) {                                 // slicesRequested && tr.Count % sliceSize != 0
+      std::vector<std::pair<int, int32_t>> cs;
+      constraints_of(r, i, &cs);
+      if (cs.size() > 1) for (size_t j = cs.size(); j-- > 0;) if (cs[j].second > 0 && count % cs[j].second != 0) return incomplete_slice_domain(x, i, count, cs[j].second, cs[j].first);
+      return incomplete_slice_domain(x, i, count, size, r->slice_level[i]);
+    }
+    if (r->kind[i] != KQ_TAS_REQUIRED) return -1;
+    const int leaf = x->ex_leaf[x->ex_off[i]];
+    if (leaf < 0) return -1;
+    return ancestor_at(leaf, lv);
+  }
+  int find_replacement(const kq_tas_requests* r, const kq_tas_replacement* x, kq_tas_result* out) {
+    if (!have_topo) return fail(KQ_EINVAL, "kq_tas_find_replacement before kq_tas_topology_put");
+    if (!x || !x->is_replacement || !x->ex_off) return fail(KQ_EINVAL, "null kq_tas_replacement");
+    const int nw = r->n_workloads;
+    if (nw < 0) return fail(KQ_EINVAL, "negative workload count");
+    const int n = nw > 0 ? r->wl_off[nw] : 0;
+    if (n == 0) return find(r, out);
+    if (!r->count || !r->level || !r->kind || !r->slice_size || !r->slice_level || !r->group) return fail(KQ_EINVAL, "null array in kq_tas_requests");
+    if (x->ex_off[0] != 0) return fail(KQ_EINVAL, "ex_off[0] must be 0");
+    for (int i = 0; i < n; i++) {
+      if (x->ex_off[i + 1] < x->ex_off[i]) return fail(KQ_EINVAL, "ex_off not monotone");
+      for (int j = x->ex_off[i]; j < x->ex_off[i + 1]; j++) if (x->ex_leaf[j] >= T.n_leaves || x->ex_count[j] < 0) return fail(KQ_EINVAL, "existing assignment out of range");
+    }
+    // the request as the placement sees it
+    std::vector<int32_t> slice_size(r->slice_size, r->slice_size + n), slice_level(r->slice_level, r->slice_level + n), group(r->group, r->group + n);
+    std::vector<int32_t> n_layers(n, 0), stale(n, -1), req_dom(n, -1);
+    if (r->n_layers) n_layers.assign(r->n_layers, r->n_layers + n);
+    bool any = false;
+    for (int i = 0; i < n; i++) {
+      if (!x->is_replacement[i]) continue;
+      any = true;
+      group[i] = -1;                                                      // placed on its own, without a leader (:723 leader = nil)
+      for (int j = x->ex_off[i]; j < x->ex_off[i + 1] && stale[i] < 0; j++) if (x->ex_leaf[j] < 0) stale[i] = j - x->ex_off[i];   // :694
+      if (stale[i] >= 0) continue;
+      req_dom[i] = required_replacement_domain(r, x, i);
+      const int32_t size = r->slice_size[i], count = r->count[i];
+      if (size > 0 && size != 1 && req_dom[i] >= 0 && count % size != 0) {  // :703-722: the innermost constraint whose size divides the count
+        std::vector<std::pair<int, int32_t>> cs;
+        constraints_of(r, i, &cs);
+        int32_t eff = 1; int eff_level = T.L - 1;                         // no slice topology: single pods (sliceLevelKeyWithDefault :1197)
+        for (size_t j = cs.size(); j-- > 0;) if (cs[j].second > 0 && count % cs[j].second == 0) { eff = cs[j].second; eff_level = cs[j].first; break; }
+        slice_size[i] = eff; slice_level[i] = eff_level; n_layers[i] = 0;
+      }
+    }
+    if (!any) return find(r, out);
+    std::vector<uint8_t> mask((size_t)n * T.n_leaves);
+    for (int i = 0; i < n; i++) {
+      uint8_t* m = mask.data() + (size_t)i * T.n_leaves;
+      if (r->leaf_ok) std::memcpy(m, r->leaf_ok + (size_t)i * T.n_leaves, T.n_leaves); else std::memset(m, 1, T.n_leaves);
+      if (req_dom[i] >= 0) for (int l = 0; l < T.n_leaves; l++) if (l < h_leaf_lo[req_dom[i]] || l >= h_leaf_hi[req_dom[i]]) m[l] = 0;   // :1902
+    }
+    kq_tas_requests q = *r;
+    q.slice_size = slice_size.data(); q.slice_level = slice_level.data(); q.group = group.data(); q.leaf_ok = mask.data();
+    q.n_layers = r->n_layers ? n_layers.data() : nullptr;
+    // a replacement is never placed with WithSimulateEmpty (:723 passes false)
+    std::vector<uint8_t> sim_empty;
+    if (r->simulate_empty) {
+      sim_empty.assign(r->simulate_empty, r->simulate_empty + nw);
+      for (int w = 0; w < nw; w++) for (int i = r->wl_off[w]; i < r->wl_off[w + 1]; i++) if (x->is_replacement[i]) sim_empty[w] = 0;
+      q.simulate_empty = sim_empty.data();
+    }
+    // the placement answers into scratch; the merged assignments go to `out`
+    const int cap = std::max(out->dom_cap, 1);
+    std::vector<int32_t> d_off(n + 1), d_leaf(cap), d_count(cap);
+    kq_tas_result tmp = *out;
+    tmp.dom_off = d_off.data(); tmp.dom_leaf = d_leaf.data(); tmp.dom_count = d_count.data(); tmp.dom_cap = cap;
+    int rc = find(&q, &tmp);
+    if (rc != KQ_OK) return rc;
+    int tot = 0;
+    out->dom_off[0] = 0;
+    for (int w = 0; w < nw; w++) {
+      bool failed = false, repl_wl = false;
+      for (int i = r->wl_off[w]; i < r->wl_off[w + 1]; i++) if (x->is_replacement[i]) repl_wl = true;
+      for (int i = r->wl_off[w]; i < r->wl_off[w + 1]; i++) {
+        int a0 = d_off[i], a1 = d_off[i + 1];
+        if (!repl_wl) {}   // an ordinary workload: the placement's own answer (a failed group fails together, the later ones are skipped)
+        else if (failed) { out->status[i] = KQ_TAS_SKIPPED; out->operand_a[i] = out->operand_b[i] = 0; a1 = a0; }
+        else if (x->is_replacement[i] && stale[i] >= 0) { out->status[i] = KQ_TAS_STALE; out->operand_a[i] = stale[i]; out->operand_b[i] = 0; a1 = a0; failed = true; }
+        else if (out->status[i] != KQ_TAS_OK) { failed = true; a1 = a0; }
+        else if (x->is_replacement[i] && a1 == a0) { out->status[i] = KQ_TAS_NO_REPLACEMENT; out->operand_a[i] = out->operand_b[i] = 0; failed = true; }   // :727
+        if (out->layer_fit && out->status[i] != KQ_TAS_NOT_FIT_LAYERS) std::memset(out->layer_fit + (size_t)i * KQ_TAS_MAX_LEVELS, 0, KQ_TAS_MAX_LEVELS * sizeof(int32_t));
+        // mergeTopologyAssignments :2072 (leaves are numbered in the order of their levelValues)
+        int e0 = x->is_replacement[i] && out->status[i] == KQ_TAS_OK ? x->ex_off[i] : 0, e1 = x->is_replacement[i] && out->status[i] == KQ_TAS_OK ? x->ex_off[i + 1] : 0;
+        std::vector<std::pair<int32_t, int32_t>> m;
+        for (int j = a0; j < a1; j++) m.push_back({d_leaf[j], d_count[j]});
+        for (int j = e0; j < e1; j++) m.push_back({x->ex_leaf[j], x->ex_count[j]});
+        std::stable_sort(m.begin(), m.end(), [](const std::pair<int32_t, int32_t>& a, const std::pair<int32_t, int32_t>& b) { return a.first < b.first; });
+        int last = -1;
+        for (auto& dm : m) {
+          if (last >= 0 && out->dom_leaf[last] == dm.first) { out->dom_count[last] += dm.second; continue; }
+          if (tot >= out->dom_cap) return fail(KQ_ECAPACITY, "dom_cap too small");
+          out->dom_leaf[tot] = dm.first; out->dom_count[tot] = dm.second; last = tot++;
+        }
+        out->dom_off[i + 1] = tot;
+      }
+    }
+    return KQ_OK;
+  }
+  // include/kq_tas.h kq_tas_exclusion_stats
+  int exclusion_stats(const kq_tas_requests* r, const kq_tas_replacement* x, const kq_tas_result* res, int n_sel, const int32_t* podsets,
+                      const int32_t* rank, int32_t* topology_domain, int32_t* resources) {
+    if (!have_topo) return fail(KQ_EINVAL, "no topology");
+    if (n_sel <= 0) return KQ_OK;
+    const int nw = r->n_workloads, n = nw > 0 ? r->wl_off[nw] : 0;
+    if (!podsets || !topology_domain || !resources || !res || !res->status || !res->dom_off) return fail(KQ_EINVAL, "null array");
+    std::vector<int32_t> wl_of(n, 0);
+    for (int w = 0; w < nw; w++) for (int i = r->wl_off[w]; i < r->wl_off[w + 1]; i++) wl_of[i] = w;
+    std::vector<int32_t> lo(n_sel, 0), hi(n_sel, T.n_leaves), as_off(n_sel + 1, 0), as_ps;
+    std::vector<uint8_t> sim(n_sel, 0);
+    std::vector<int32_t> src(n_sel, 0);
+    for (int s = 0; s < n_sel; s++) {
+      const int p = podsets[s];
+      if (p < 0 || p >= n) return fail(KQ_EINVAL, "podset out of range");
+      const int w = wl_of[p], p0 = r->wl_off[w], p1 = r->wl_off[w + 1];
+      sim[s] = r->simulate_empty ? r->simulate_empty[w] : 0;
+      const bool repl = x && x->is_replacement && x->is_replacement[p];
+      if (repl) {
+        sim[s] = 0;
+        bool st = false;
+        for (int j = x->ex_off[p]; j < x->ex_off[p + 1]; j++) if (x->ex_leaf[j] < 0) st = true;
+        const int d = st ? -1 : required_replacement_domain(r, x, p);
+        if (d >= 0) { lo[s] = h_leaf_lo[d]; hi[s] = h_leaf_hi[d]; }
+      }
+      // groups in the order of their first podset (:594-604); a replacement podset stands alone (:609)
+      auto gid = [&](int i) { return (x && x->is_replacement && x->is_replacement[i]) || r->group[i] < 0 ? -1 - i : r->group[i]; };
+      auto first_of = [&](int i) { for (int j = p0; j < i; j++) if (gid(j) == gid(i)) return j; return i; };
+      const int mine = first_of(p);
+      for (int i = p0; i < p1; i++)
+        if (gid(i) != gid(p) && first_of(i) < mine && res->status[i] == KQ_TAS_OK) as_ps.push_back(i);
+      as_off[s + 1] = (int32_t)as_ps.size();
+      // a leader / workers group is counted with the workers' requests (requirements.requests, findLeaderAndWorkers :668)
+      int second = -1;
+      for (int i = mine + 1; i < p1 && second < 0; i++) if (gid(i) == gid(p)) second = i;
+      src[s] = second < 0 ? p : (r->count[second] > r->count[mine] ? second : mine);
+    }
+    // a replacement's assumed usage is its replacement part only (:633): `res` holds the merged assignment, so take the existing one out
+    std::vector<int32_t> dcount(res->dom_count, res->dom_count + res->dom_off[n]);
+    if (x && x->is_replacement)
+      for (int i = 0; i < n; i++) if (x->is_replacement[i] && res->status[i] == KQ_TAS_OK)
+        for (int j = x->ex_off[i]; j < x->ex_off[i + 1]; j++)
+          for (int k2 = res->dom_off[i]; k2 < res->dom_off[i + 1]; k2++) if (res->dom_leaf[k2] == x->ex_leaf[j]) dcount[k2] -= x->ex_count[j];
+    TExcl E{};
+    E.n_sel = n_sel;
+    E.podset = stage(be_x[0], src.data(), n_sel); E.sim_empty = stage(be_x[1], sim.data(), n_sel);
+    E.lo = stage(be_x[2], lo.data(), n_sel); E.hi = stage(be_x[3], hi.data(), n_sel);
+    E.spr = stage(be_x[4], r->single_pod_requests, (size_t)n * T.R);
+    E.leaf_ok = r->leaf_ok ? stage(be_x[5], r->leaf_ok, (size_t)n * T.n_leaves) : nullptr;
+    E.as_off = stage(be_x[6], as_off.data(), (size_t)n_sel + 1); E.as_ps = stage(be_x[7], as_ps.data(), as_ps.size());
+    E.dom_off = stage(be_x[8], res->dom_off, (size_t)n + 1); E.dom_leaf = stage(be_x[9], res->dom_leaf, (size_t)res->dom_off[n]);
+    E.dom_count = stage(be_x[10], dcount.data(), dcount.size());
+    E.rank = rank ? stage(bq[15], rank, T.R) : nullptr;
+    int32_t* cnt = grow<int32_t>(be_x[11], (size_t)n_sel * (T.R + 1));
+    be.memset(cnt, 0, (size_t)n_sel * (T.R + 1) * sizeof(int32_t));
+    E.topo_dom = cnt; E.res = cnt + n_sel;
+    be.launch_tas_excl(T, E);
+    be.d2h(topology_domain, E.topo_dom, (size_t)n_sel * sizeof(int32_t));
+    be.d2h(resources, E.res, (size_t)n_sel * T.R * sizeof(int32_t));
+    int rc = be.sync();
+    return rc == KQ_OK ? KQ_OK : fail(rc, be.error());
   }
 
   int usage_apply(int n_dom, const int32_t* leaf, const int32_t* count, const int64_t* spr, int add) {
@@ -391,6 +613,31 @@ KQ_DEV void t_fits_cell(const TTopo& T, int i, const int32_t* leaf, const int32_
     if (!have || c < result) { result = c; have = true; }
   }
   if ((have ? result : 0) < count[i]) *flag = 0;
+}
+
+
+// tasExclusionStats :470 — what fillLeafCounts :1899 records for one (selected podset, leaf). Run on demand after a failed placement
+// (notFitMessage :1997 is the only reader), so the counters cost the placement's hot loop nothing. One thread per (podset, leaf).
+KQ_DEV void t_excl_cell(const TTopo& T, const TExcl& E, int s, int leaf) {
+  const int p = E.podset[s];
+  if (E.leaf_ok && !E.leaf_ok[(size_t)p * T.n_leaves + leaf]) return;                    // not a candidate: the simulator's own statistics
+  if (leaf < E.lo[s] || leaf >= E.hi[s]) { atomic_add_i32((int*)E.topo_dom + s, 1); return; }  // BelongsTo :1902-1905
+  bool have = false; int32_t result = 0; int best = -1;
+  for (int r = 0; r < T.R; r++) {
+    const int64_t q = E.spr[(size_t)p * T.R + r] + (r == T.pods ? 1 : 0);
+    if (q == 0) continue;
+    int64_t rem = T.free_cap[(size_t)leaf * T.R + r];
+    if (!E.sim_empty[s]) rem -= T.tas_usage[(size_t)leaf * T.R + r];                     // remainingCapacityForLeaf :1884
+    for (int j = E.as_off[s]; j < E.as_off[s + 1]; j++) {                                // requirements.assumedUsage[leaf.id] :1909
+      const int q2 = E.as_ps[j];
+      for (int i = E.dom_off[q2]; i < E.dom_off[q2 + 1]; i++)
+        if (E.dom_leaf[i] == leaf) rem -= E.spr[(size_t)q2 * T.R + r] * (int64_t)E.dom_count[i] + (r == T.pods ? E.dom_count[i] : 0);
+    }
+    const int32_t cnt = (int32_t)i64max(0, i64min(t_div(rem, q), 0x7fffffff));
+    const bool first = !have || cnt < result || (cnt == result && (E.rank ? E.rank[r] < E.rank[best] : false));
+    if (first) { result = cnt; best = r; have = true; }
+  }
+  if (have && result == 0) atomic_add_i32((int*)E.res + (size_t)s * T.R + best, 1);      // recordResourceExclusion :524
 }
 
 

@@ -20,7 +20,8 @@ from .api import amount_from_quantity
 HOSTNAME_LABEL = "kubernetes.io/hostname"
 
 KQ_TAS_REQUIRED, KQ_TAS_PREFERRED, KQ_TAS_UNCONSTRAINED = 0, 1, 2
-TAS_OK, TAS_NOT_FIT, TAS_NO_LEVEL, TAS_SLICE_ABOVE, TAS_BAD_SLICE_SIZE, TAS_SKIPPED, TAS_UNSUPPORTED, TAS_NOT_FIT_LAYERS, TAS_BAD_LAYER = range(9)
+TAS_OK, TAS_NOT_FIT, TAS_NO_LEVEL, TAS_SLICE_ABOVE, TAS_BAD_SLICE_SIZE, TAS_SKIPPED, TAS_UNSUPPORTED, TAS_NOT_FIT_LAYERS, TAS_BAD_LAYER, \
+    TAS_STALE, TAS_NO_REPLACEMENT = range(11)
 TAS_MAX_LEVELS = 16
 
 
@@ -48,6 +49,10 @@ class kq_tas_result(C.Structure):
         ("dom_off", F.i32p), ("dom_leaf", F.i32p), ("dom_count", F.i32p), ("dom_cap", C.c_int32),
         ("layer_fit", F.i32p),                                                   # optional, NULL = not wanted
     ]
+
+
+class kq_tas_replacement(C.Structure):
+    _fields_ = [("is_replacement", F.u8p), ("ex_off", F.i32p), ("ex_leaf", F.i32p), ("ex_count", F.i32p)]
 
 
 @dataclass
@@ -89,6 +94,9 @@ class TASPodSetRequests:
     topology_request: Optional[TopologyRequest] = None   # None => Implied (:8417 of the test harness / :1216)
     group: Optional[str] = None                           # PodSetGroupName
     leaf_ok: Optional[Sequence[bool]] = None              # node feasibility mask from the simulator, by leaf index
+    # the podset's PodSetAssignment.TopologyAssignment of the workload's admission (findPSA :747): [(domain Values, count)]; read when
+    # the workload has an unhealthy node (Requests(unhealthy_nodes=...)): the podset then takes findReplacementAssignment :686
+    existing: Optional[Sequence[Tuple[Sequence[str], int]]] = None
 
 
 class Topology:
@@ -192,6 +200,17 @@ class Topology:
                                                       pods_resource=self.resource_index["pods"], profile_mixed=1 if self.profile_mixed else 0))
         return self._struct
 
+    def leaf_of_values(self, values: Sequence[str]) -> int:
+        """Leaf index of a TopologyDomainAssignment's Values (hostname alone on a hostname-level topology), -1 = no such leaf
+        (IsTopologyAssignmentStale :818)."""
+        v = tuple(values)
+        if self.lowest_is_node and len(v) == 1 and len(self.levels) > 1:
+            for i, lv in enumerate(self.level_values[-1]):
+                if lv[-1] == v[0]:
+                    return i
+            return -1
+        return self.index[-1].get(v, -1)
+
     def leaf_values(self, leaf: int) -> List[str]:
         """TopologyDomainAssignment.Values of a leaf as buildAssignment emits them (:1701-1710)."""
         v = self.level_values[-1][leaf]
@@ -205,9 +224,40 @@ def _amount(r: str, q) -> int:
 class Requests:
     """FlavorTASRequests of a batch of workloads -> kq_tas_requests."""
 
-    def __init__(self, topo: Topology, workloads: Sequence[Sequence[TASPodSetRequests]], simulate_empty: Optional[Sequence[bool]] = None):
+    def __init__(self, topo: Topology, workloads: Sequence[Sequence[TASPodSetRequests]], simulate_empty: Optional[Sequence[bool]] = None,
+                 unhealthy_nodes: Optional[Sequence[Optional[str]]] = None):
+        """unhealthy_nodes[w] = Status.UnhealthyNodes[0].Name of workload w (None = healthy). For such a workload the podsets that carry
+        `existing` are replacement requests (kq_tas_find_replacement): deleteDomain :828 happens here — the domain of the unhealthy node
+        leaves the list and its pod count becomes the podset's count (:693) — the podsets without one are dropped (:612)."""
         self.topo = topo
         self.workloads = [list(w) for w in workloads]
+        self.unhealthy_nodes = list(unhealthy_nodes) if unhealthy_nodes is not None else None
+        self.replacement = None
+        if self.unhealthy_nodes is not None and any(u is not None for u in self.unhealthy_nodes):
+            is_repl, ex_off, ex_leaf, ex_count = [], [0], [], []
+            self.existing_values: List[List[Sequence[str]]] = []
+            for wi, w in enumerate(self.workloads):
+                bad = self.unhealthy_nodes[wi]
+                if bad is not None:
+                    w = [tr for tr in w if tr.existing is not None]
+                    kept = []
+                    for tr in w:
+                        affected, vals = 0, []
+                        for values, cnt in tr.existing:
+                            if values[-1] == bad:
+                                affected = int(cnt)
+                            else:
+                                ex_leaf.append(topo.leaf_of_values(values)); ex_count.append(int(cnt)); vals.append(list(values))
+                        ex_off.append(len(ex_leaf)); is_repl.append(1); self.existing_values.append(vals)
+                        kept.append(TASPodSetRequests(tr.name, affected, tr.single_pod_requests, tr.topology_request, tr.group, tr.leaf_ok, tr.existing))
+                    self.workloads[wi] = kept
+                else:
+                    for _ in w:
+                        ex_off.append(len(ex_leaf)); is_repl.append(0); self.existing_values.append([])
+            self.replacement = dict(is_replacement=np.array(is_repl, np.uint8), ex_off=np.array(ex_off, np.int32),
+                                    ex_leaf=np.array(ex_leaf + [0], np.int32), ex_count=np.array(ex_count + [0], np.int32))
+            self._repl_struct = kq_tas_replacement()
+            F.fill_struct(self._repl_struct, self.replacement, {})
         R = len(topo.resources)
         flat = [tr for w in self.workloads for tr in w]
         n = len(flat)
@@ -260,6 +310,9 @@ class Requests:
         F.fill_struct(self._struct, self.arrays, dict(n_workloads=len(self.arrays["wl_off"]) - 1))
         return self._struct
 
+    def replacement_struct(self) -> Optional[kq_tas_replacement]:
+        return self._repl_struct if self.replacement is not None else None
+
     @property
     def n_workloads(self) -> int:
         return len(self.arrays["wl_off"]) - 1
@@ -306,6 +359,9 @@ class Result:
         self.rq = rq
         n = rq.n
         cap = dom_cap if dom_cap is not None else max(64, int(rq.arrays["count"].sum()) + n)
+        if dom_cap is None and getattr(rq, "replacement", None) is not None:
+            cap += len(rq.replacement["ex_leaf"])
+        self.exclusions: Dict[int, Tuple[int, int, Dict[str, int]]] = {}   # podset -> (TotalNodes, topologyDomain, {resource: leaves})
         self.a = dict(status=np.zeros(n, np.int32), operand_a=np.zeros(n, np.int32), operand_b=np.zeros(n, np.int32),
                       dom_off=np.zeros(n + 1, np.int32), dom_leaf=np.zeros(cap, np.int32), dom_count=np.zeros(cap, np.int32),
                       layer_fit=np.zeros(n * TAS_MAX_LEVELS, np.int32))
@@ -354,6 +410,27 @@ class Result:
                     bad.append(k)
         return bad
 
+    def _exclusion_tail(self, i: int) -> str:
+        """tasExclusionStats.formatReasons :500 behind hasExclusions :496, when the statistics were fetched (TASEngine.exclusion_stats)."""
+        if i not in self.exclusions:
+            return ""
+        total, td, res = self.exclusions[i]
+        reasons = ([f"topologyDomain: {td}"] if td > 0 else []) + [f'resource "{r}": {n}' for r, n in sorted(res.items()) if n > 0]
+        return f". Total nodes: {total}; excluded: {', '.join(sorted(reasons))}" if reasons else ""
+
+    def effective_slice_size(self, i: int) -> int:
+        """Slice size of a replacement podset after the rewrite of findReplacementAssignment :703-722 (the unit notFitMessage names): the
+        innermost constraint whose size divides the replacement count when the count breaks the outermost one, 1 without any."""
+        cnt = int(self.rq.arrays["count"][i]); size = int(self.rq.arrays["slice_size"][i])
+        if size <= 1 or cnt % size == 0:
+            return size
+        nl = int(self.rq.arrays["n_layers"][i]) if "n_layers" in self.rq.arrays else 0
+        sizes = [int(self.rq.arrays["layer_size"][i * TAS_MAX_LEVELS + j]) for j in range(nl)] if nl > 1 else [size]
+        for sz in reversed(sizes):
+            if sz > 0 and cnt % sz == 0:
+                return sz
+        return 1
+
     def _prev_level_key(self, i: int, layer: int) -> str:
         # the previous layer that was accepted: its resolved level (layer 0 is the slice level)
         lv = int(self.rq.arrays["layer_level"][i * TAS_MAX_LEVELS + layer - 1]) if layer > 1 else int(self.rq.arrays["slice_level"][i])
@@ -366,9 +443,19 @@ class Result:
             return ""
         if st == TAS_NOT_FIT:
             unit = "pod" if int(self.rq.arrays["slice_size"][i]) == 1 else "slice"
+            if getattr(self.rq, "replacement", None) is not None and self.rq.replacement["is_replacement"][i]:
+                unit = "pod" if self.effective_slice_size(i) == 1 else "slice"
             if a == 0:
-                return f'topology "{topology_name}" doesn\'t allow to fit any of {b} {unit}(s)'
-            return f'topology "{topology_name}" allows to fit only {a} out of {b} {unit}(s)'
+                msg = f'topology "{topology_name}" doesn\'t allow to fit any of {b} {unit}(s)'
+            else:
+                msg = f'topology "{topology_name}" allows to fit only {a} out of {b} {unit}(s)'
+            return msg + self._exclusion_tail(i)
+        if st == TAS_STALE:
+            dom = self.rq.existing_values[i][a]
+            return f"Cannot replace the node, because the existing topologyAssignment is invalid, as it contains the stale domain {dom[0]}"
+        if st == TAS_NO_REPLACEMENT:
+            w = int(np.searchsorted(self.rq.arrays["wl_off"], i, side="right")) - 1
+            return f"cannot find replacement assignment for unhealthy node: {self.rq.unhealthy_nodes[w]}"
         if st == TAS_NOT_FIT_LAYERS:
             # multiLayerNotFitMessage :2030: "; fit/needed slice(s) fit on level <key>" per constraint, counted in the best domain
             msg = f'topology "{topology_name}" doesn\'t allow to fit'
@@ -381,7 +468,7 @@ class Result:
                 if lv < 0:
                     continue
                 msg += f"; {int(self.a['layer_fit'][i * TAS_MAX_LEVELS + j])}/{cnt // sz} slice(s) fit on level {self.rq.topo.levels[lv]}"
-            return msg
+            return msg + self._exclusion_tail(i)
         if st == TAS_BAD_LAYER:
             # buildSliceSizeAtLevel :1123
             key = lambda j: (self.rq.layer_keys[i][j] if getattr(self.rq, "layer_keys", None) else f"#{j}")
@@ -416,6 +503,9 @@ def load_tas():
         lib.kq_tas_usage_delta.argtypes = [C.c_void_p, C.POINTER(kq_tas_requests), C.POINTER(kq_tas_result), F.u8p, C.c_void_p]
         lib.kq_tas_usage_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         lib.kq_tas_overflow.argtypes = [C.c_void_p, C.c_void_p, F.u8p, F.i32p]
+        lib.kq_tas_find_replacement.argtypes = [C.c_void_p, C.POINTER(kq_tas_requests), C.POINTER(kq_tas_replacement), C.POINTER(kq_tas_result)]
+        lib.kq_tas_exclusion_stats.argtypes = [C.c_void_p, C.POINTER(kq_tas_requests), C.POINTER(kq_tas_replacement), C.POINTER(kq_tas_result), C.c_int32,
+                                               F.i32p, F.i32p, F.i32p, F.i32p]
         lib.kq_tas_last_stats.argtypes = [C.c_void_p, F.f64p, F.i64p]
         lib.kq_tas_last_error.argtypes = [C.c_void_p]
         lib.kq_tas_last_error.restype = C.c_char_p
@@ -425,7 +515,8 @@ def load_tas():
 
 TAS_ABI_SYMBOLS = ["kq_tas_create", "kq_tas_destroy", "kq_tas_topology_put", "kq_tas_find", "kq_tas_usage_apply", "kq_tas_fits",
                    "kq_tas_read_usage", "kq_tas_last_stats", "kq_tas_last_error",
-                   "kq_tas_admit", "kq_tas_usage_delta", "kq_tas_usage_add", "kq_tas_overflow"]
+                   "kq_tas_admit", "kq_tas_usage_delta", "kq_tas_usage_add", "kq_tas_overflow",
+                   "kq_tas_find_replacement", "kq_tas_exclusion_stats"]
 
 
 class TASEngine:
@@ -454,6 +545,32 @@ class TASEngine:
         self._lib.kq_tas_last_stats(self._h, F.ptr(ms), F.ptr(by))
         out.kernel_ms, out.bytes = float(ms[0]), int(by[0])
         return out
+
+    def find_replacement(self, rq: Requests, dom_cap: Optional[int] = None) -> Result:
+        """FindTopologyAssignmentsForFlavor for a batch built with unhealthy_nodes (kq_tas_find_replacement): the replacement podsets
+        come back with the merged assignment (mergeTopologyAssignments :2072)."""
+        if rq.replacement is None:
+            return self.find(rq, dom_cap)
+        out = Result(rq, dom_cap)
+        self._check(self._lib.kq_tas_find_replacement(self._h, C.byref(rq.struct()), C.byref(rq.replacement_struct()), C.byref(out.struct())))
+        return out
+
+    def exclusion_stats(self, rq: Requests, res: Result, podsets: Optional[Sequence[int]] = None) -> Result:
+        """tasExclusionStats of the given podsets (default: the ones that did not fit) into res.exclusions, which Result.message
+        appends the way notFitMessage :1997 does. TotalNodes is the leaf count (every test topology of the reference hands all its
+        Ready nodes to the simulator)."""
+        if podsets is None:
+            podsets = [i for i in range(rq.n) if int(res.a["status"][i]) in (TAS_NOT_FIT, TAS_NOT_FIT_LAYERS)]
+        if len(podsets) == 0:
+            return res
+        R = len(self.topo.resources)
+        ps = np.asarray(podsets, np.int32); td = np.zeros(len(ps), np.int32); rs = np.zeros(len(ps) * R, np.int32)
+        x = rq.replacement_struct()
+        self._check(self._lib.kq_tas_exclusion_stats(self._h, C.byref(rq.struct()), C.byref(x) if x is not None else None, C.byref(res.struct()),
+                                                     len(ps), F.ptr(ps), None, F.ptr(td), F.ptr(rs)))
+        for k, i in enumerate(ps):
+            res.exclusions[int(i)] = (self.topo.n_leaves, int(td[k]), {self.topo.resources[r]: int(rs[k * R + r]) for r in range(R) if rs[k * R + r]})
+        return res
 
     def usage_apply(self, assignment: Sequence[Tuple[int, int]], single_pod_requests: np.ndarray, add: bool = True):
         leaf = np.array([a for a, _ in assignment], np.int32); cnt = np.array([c for _, c in assignment], np.int32)

@@ -237,6 +237,24 @@ def tas_find(topo, rq, dom_cap=None):
     return out
 
 
+def tas_find_replacement(topo, rq, dom_cap=None):
+    """FindTopologyAssignmentsForFlavor incl. the HasUnhealthyNodes branch (findReplacementAssignment :686) and the exclusion
+    statistics of every podset (oracle/kq_tas_oracle.cpp kqo_tas_find_replacement) -> Result with .exclusions filled for all podsets."""
+    from kueue_amd import tas as T
+    out = T.Result(rq, dom_cap)
+    R = len(topo.resources)
+    td = np.zeros(rq.n, np.int32); rs = np.zeros(rq.n * R, np.int32)
+    x = rq.replacement_struct()
+    l = lib()
+    l.kqo_tas_find_replacement.restype = C.c_int
+    rc = l.kqo_tas_find_replacement(C.byref(topo.struct()), C.byref(rq.struct()), C.byref(x) if x is not None else None, None, C.byref(out.struct()),
+                                    F.ptr(td), F.ptr(rs))
+    assert rc == 0, rc
+    for i in range(rq.n):
+        out.exclusions[i] = (topo.n_leaves, int(td[i]), {topo.resources[r]: int(rs[i * R + r]) for r in range(R) if rs[i * R + r]})
+    return out
+
+
 def cycle_run_tas(cfg: F.kq_config, snap: Snapshot, heads: Heads, ct, tgt_cap=None, rsn_cap=0):
     """One scheduling cycle with Topology-Aware Scheduling inside it (include/kq_cycle_tas.h; ct = kueue_amd.tas_cycle.CycleTAS).
     -> (Decisions, CycleTASOut); Decisions.tas_stats = {finds, recomputes, unsupported}."""

@@ -63,6 +63,7 @@ struct EmuBackend {
   }
   void launch_tas_plane_add(const TTopo& T, const int64_t* plane, int sign) { for (size_t i = 0; i < (size_t)T.n_leaves * T.R; i++) t_plane_add_cell(T, i, plane, sign); }
   void launch_tas_overflow(const TTopo& T, const int64_t* plane, uint8_t* over, int32_t* n_over) { for (int l = 0; l < T.n_leaves; l++) t_overflow_cell(T, l, plane, over, n_over); }
+  void launch_tas_excl(const TTopo& T, const TExcl& E) { for (int s = 0; s < E.n_sel; s++) for (int l = 0; l < T.n_leaves; l++) t_excl_cell(T, E, s, l); }
   void launch_tas_fits(const TTopo& T, int n, const int32_t* leaf, const int32_t* count, const int64_t* spr, int32_t* flag) { for (int i = 0; i < n; i++) t_fits_cell(T, i, leaf, count, spr, flag); }
   K last_k{};
   void launch_commit_mask(int n, int32_t* use_n_out, int32_t* cq_out, int32_t* fr_out, int64_t* qty_out, int32_t* count) {
@@ -273,6 +274,8 @@ int kqe_tas_admit(void* t, const kq_tas_requests* r, const kq_tas_result* res, c
 int kqe_tas_usage_delta(void* t, const kq_tas_requests* r, const kq_tas_result* res, const uint8_t* wl_sel, int64_t* plane) { return ((EmuTas*)t)->usage_delta(r, res, wl_sel, plane); }
 int kqe_tas_usage_add(void* t, const int64_t* plane, int32_t sign) { return ((EmuTas*)t)->usage_add(plane, sign); }
 int kqe_tas_overflow(void* t, const int64_t* plane, uint8_t* leaf_over, int32_t* n_over) { return ((EmuTas*)t)->overflow(plane, leaf_over, n_over); }
+int kqe_tas_find_replacement(void* t, const kq_tas_requests* r, const kq_tas_replacement* x, kq_tas_result* out) { return ((EmuTas*)t)->find_replacement(r, x, out); }
+int kqe_tas_exclusion_stats(void* t, const kq_tas_requests* r, const kq_tas_replacement* x, const kq_tas_result* res, int32_t n_sel, const int32_t* podsets, const int32_t* rank, int32_t* td, int32_t* rs) { return ((EmuTas*)t)->exclusion_stats(r, x, res, n_sel, podsets, rank, td, rs); }
 int kqe_tas_read_usage(void* t, int64_t* u) { return ((EmuTas*)t)->read_usage(u); }
 int64_t kqe_tas_last_bytes(void* t) { return ((EmuTas*)t)->last_bytes; }
 const char* kqe_tas_last_error(void* t) { return ((EmuTas*)t)->last_error.c_str(); }

@@ -333,6 +333,31 @@ class EmuTas:
         out.bytes = int(lib().kqe_tas_last_bytes(self.h))
         return out
 
+    def find_replacement(self, rq, dom_cap=None):
+        from kueue_amd import tas as T
+        if rq.replacement is None:
+            return self.find(rq, dom_cap)
+        out = T.Result(rq, dom_cap)
+        rc = lib().kqe_tas_find_replacement(self.h, C.byref(rq.struct()), C.byref(rq.replacement_struct()), C.byref(out.struct()))
+        assert rc == 0, (rc, lib().kqe_tas_last_error(self.h))
+        return out
+
+    def exclusion_stats(self, rq, res, podsets=None):
+        from kueue_amd import tas as T
+        if podsets is None:
+            podsets = [i for i in range(rq.n) if int(res.a["status"][i]) in (T.TAS_NOT_FIT, T.TAS_NOT_FIT_LAYERS)]
+        if len(podsets) == 0:
+            return res
+        R = len(self.topo.resources)
+        ps = np.asarray(podsets, np.int32); td = np.zeros(len(ps), np.int32); rs = np.zeros(len(ps) * R, np.int32)
+        x = rq.replacement_struct()
+        rc = lib().kqe_tas_exclusion_stats(self.h, C.byref(rq.struct()), C.byref(x) if x is not None else None, C.byref(res.struct()), len(ps), F.ptr(ps), None,
+                                           F.ptr(td), F.ptr(rs))
+        assert rc == 0, (rc, lib().kqe_tas_last_error(self.h))
+        for k, i in enumerate(ps):
+            res.exclusions[int(i)] = (self.topo.n_leaves, int(td[k]), {self.topo.resources[r]: int(rs[k * R + r]) for r in range(R) if rs[k * R + r]})
+        return res
+
     def usage_apply(self, assignment, single_pod_requests, add=True):
         leaf = np.array([a for a, _ in assignment], np.int32); cnt = np.array([c for _, c in assignment], np.int32)
         req = np.ascontiguousarray(single_pod_requests, np.int64)
