@@ -292,8 +292,7 @@ __global__ __launch_bounds__(256) void k_tas_overflow(TTopo T, const int64_t* pl
 }
 // tasExclusionStats (kq_tas_exclusion_stats): one thread per (selected podset, leaf); blockIdx.y = the podset
 __global__ __launch_bounds__(256) void k_tas_excl(TTopo T, TExcl E) {
-  const int leaf = blockIdx.x * 256 + threadIdx.x;
-  if (leaf < T.n_leaves) t_excl_cell(T, E, blockIdx.y, leaf);
+  t_excl_cell(T, E, blockIdx.y, blockIdx.x * 256 + threadIdx.x);   // (all lanes: the cell ballots)
 }
 
 // pending side on the device (kq_pending.hpp): Heads() = pop per ClusterQueue + compaction + gather; requeue from the decisions

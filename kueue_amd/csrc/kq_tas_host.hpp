@@ -618,26 +618,36 @@ KQ_DEV void t_fits_cell(const TTopo& T, int i, const int32_t* leaf, const int32_
 
 // tasExclusionStats :470 — what fillLeafCounts :1899 records for one (selected podset, leaf). Run on demand after a failed placement
 // (notFitMessage :1997 is the only reader), so the counters cost the placement's hot loop nothing. One thread per (podset, leaf).
-KQ_DEV void t_excl_cell(const TTopo& T, const TExcl& E, int s, int leaf) {
+KQ_DEV void t_excl_cell(const TTopo& T, const TExcl& E, int s, int leaf) {   // every lane of a wave calls it, with leaf >= n_leaves past the end
   const int p = E.podset[s];
-  if (E.leaf_ok && !E.leaf_ok[(size_t)p * T.n_leaves + leaf]) return;                    // not a candidate: the simulator's own statistics
-  if (leaf < E.lo[s] || leaf >= E.hi[s]) { atomic_add_i32((int*)E.topo_dom + s, 1); return; }  // BelongsTo :1902-1905
+  const uint64_t below = ((uint64_t)1 << lane_id()) - 1;
+  const bool cand = leaf < T.n_leaves && (!E.leaf_ok || E.leaf_ok[(size_t)p * T.n_leaves + leaf]);   // else: the simulator's own statistics
+  const bool outside = cand && (leaf < E.lo[s] || leaf >= E.hi[s]);                                   // BelongsTo :1902-1905
+  // one atomic per wave and counter: with a required domain nearly every leaf of a podset lands on the same word
+  const uint64_t mo = wballot(outside);
+  if (outside && (mo & below) == 0) atomic_add_i32((int*)E.topo_dom + s, popc64(mo));
   bool have = false; int32_t result = 0; int best = -1;
-  for (int r = 0; r < T.R; r++) {
-    const int64_t q = E.spr[(size_t)p * T.R + r] + (r == T.pods ? 1 : 0);
-    if (q == 0) continue;
-    int64_t rem = T.free_cap[(size_t)leaf * T.R + r];
-    if (!E.sim_empty[s]) rem -= T.tas_usage[(size_t)leaf * T.R + r];                     // remainingCapacityForLeaf :1884
-    for (int j = E.as_off[s]; j < E.as_off[s + 1]; j++) {                                // requirements.assumedUsage[leaf.id] :1909
-      const int q2 = E.as_ps[j];
-      for (int i = E.dom_off[q2]; i < E.dom_off[q2 + 1]; i++)
-        if (E.dom_leaf[i] == leaf) rem -= E.spr[(size_t)q2 * T.R + r] * (int64_t)E.dom_count[i] + (r == T.pods ? E.dom_count[i] : 0);
+  if (cand && !outside) {
+    for (int r = 0; r < T.R; r++) {
+      const int64_t q = E.spr[(size_t)p * T.R + r] + (r == T.pods ? 1 : 0);
+      if (q == 0) continue;
+      int64_t rem = T.free_cap[(size_t)leaf * T.R + r];
+      if (!E.sim_empty[s]) rem -= T.tas_usage[(size_t)leaf * T.R + r];                     // remainingCapacityForLeaf :1884
+      for (int j = E.as_off[s]; j < E.as_off[s + 1]; j++) {                                // requirements.assumedUsage[leaf.id] :1909
+        const int q2 = E.as_ps[j];
+        for (int i = E.dom_off[q2]; i < E.dom_off[q2 + 1]; i++)
+          if (E.dom_leaf[i] == leaf) rem -= E.spr[(size_t)q2 * T.R + r] * (int64_t)E.dom_count[i] + (r == T.pods ? E.dom_count[i] : 0);
+      }
+      const int32_t cnt = (int32_t)i64max(0, i64min(t_div(rem, q), 0x7fffffff));
+      const bool first = !have || cnt < result || (cnt == result && (E.rank ? E.rank[r] < E.rank[best] : false));
+      if (first) { result = cnt; best = r; have = true; }
     }
-    const int32_t cnt = (int32_t)i64max(0, i64min(t_div(rem, q), 0x7fffffff));
-    const bool first = !have || cnt < result || (cnt == result && (E.rank ? E.rank[r] < E.rank[best] : false));
-    if (first) { result = cnt; best = r; have = true; }
   }
-  if (have && result == 0) atomic_add_i32((int*)E.res + (size_t)s * T.R + best, 1);      // recordResourceExclusion :524
+  const int lim = have && result == 0 ? best : -1;                                         // recordResourceExclusion :524
+  for (int r = 0; r < T.R; r++) {
+    const uint64_t m = wballot(lim == r);
+    if (lim == r && (m & below) == 0) atomic_add_i32((int*)E.res + (size_t)s * T.R + r, popc64(m));
+  }
 }
 
 
