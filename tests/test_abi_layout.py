@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STRUCTS = {
     "kq_config": F.kq_config, "kq_snapshot": F.kq_snapshot, "kq_heads": F.kq_heads, "kq_pending": F.kq_pending, "kq_decisions": F.kq_decisions,
     "kq_afs_ledger": F.kq_afs_ledger, "kq_row_patch": F.kq_row_patch,
-    "kq_tas_topology": T.kq_tas_topology, "kq_tas_requests": T.kq_tas_requests, "kq_tas_result": T.kq_tas_result,
+    "kq_tas_topology": T.kq_tas_topology, "kq_tas_requests": T.kq_tas_requests, "kq_tas_result": T.kq_tas_result, "kq_tas_replacement": T.kq_tas_replacement,
     "kq_cycle_tas": TC.kq_cycle_tas, "kq_cycle_tas_out": TC.kq_cycle_tas_out,
 }
 
