@@ -31,8 +31,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=None, help="default: 60 for the pending loops (cfg2 / cfg3 / cfg3f: past the runtime's one-time 6-12 ms at the 53rd cycle "
-                                                              "of a run, profiles/r04q_notes.txt), 5 for the workloads whose cycles take longer")
+    ap.add_argument("--warmup", type=int, default=None, help="default: 60 for the pending loops cfg3 / cfg3f (past the runtime's one-time 6-12 ms at the 53rd cycle "
+                                                              "of a run, profiles/r04q_notes.txt), 5 for the workloads whose cycles take longer and for cfg2, whose 10 k pending workloads "
+                                                              "are 78 cycles of full head batches: after a long warm-up the window would time a draining queue")
     ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3-batch", "cfg3-split", "cfg4c-split", "cfg4f-split", "cfg4c", "cfg3f", "cfg4f", "cfg5", "cfg5-split", "cfg5-cycle", "cfg5f-cycle"],
                     help="cfg3 = BASELINE.json configs[2] (100k pending, 1k CQ, 16 flavors, 3-level cohorts); "
                          "cfg4c = configs[3] population under classical preemption; cfg4f = configs[3] as quoted "
@@ -62,7 +63,7 @@ def main():
     ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive kq_cycle_run leg and the kq_snapshot_put timing")
     args = ap.parse_args()
     if args.warmup is None:
-        args.warmup = 60 if args.workload in ("cfg2", "cfg3", "cfg3f") else 5
+        args.warmup = 60 if args.workload in ("cfg3", "cfg3f") else 5
 
     import torch
     import torch.distributed as dist
