@@ -76,7 +76,7 @@ KQ_DEV int wshift_up_i32(int v) { return v; }
 KQ_DEV int wshift_down_i32(int v) { return v; }
 KQ_DEV int wshfl_i32(int v, int) { return v; }
 KQ_DEV int clz64(uint64_t m) { return __builtin_clzll(m); }
-static int g_emu_pipeline = 0;  // tests: emulate the helper waves of k_process prefetching one chunk ahead
+static thread_local int g_emu_pipeline = 0;  // tests: emulate the helper waves of k_process prefetching one chunk ahead
 }  // namespace kq
 #else
 #include <hip/hip_runtime.h>
@@ -825,9 +825,9 @@ KQ_DEV bool np_exact_mode(const Wave& w) { return w.np_broken && w.n_pre > 0; }
 #endif
 
 #ifdef KQ_HOST_EMU
-static long long g_cs[32];
+static thread_local long long g_cs[32];   // (thread_local: the emulated group of tests/test_group.py runs one engine per thread)
 #define CSTAT(i, v) (g_cs[i] += (v))
-static int g_cs_check = 0, g_cs_force_off = 0;  // tests: run every scan-formulated search a second time as a walk and compare
+static thread_local int g_cs_check = 0, g_cs_force_off = 0;  // tests: run every scan-formulated search a second time as a walk and compare
 #else
 #define CSTAT(i, v) do {} while (0)
 #endif
@@ -1608,7 +1608,7 @@ KQ_DEV bool f_push_target(Search& s, int* nt, int row, int reason) {
 #include "kq_fs.hpp"
 namespace kq {
 #ifdef KQ_HOST_EMU
-static int g_fs_check = 0, g_fs_force_off = 0;  // tests: run every LDS-formulated fair search a second time as the walk and compare
+static thread_local int g_fs_check = 0, g_fs_force_off = 0;  // tests: run every LDS-formulated fair search a second time as the walk and compare
 #endif
 KQ_DEV void fair_search_walk(Search& s);
 // fairPreemptions (preemption.go:536-597). On return w->ntgt targets are in s.trow/s.treason and the private

@@ -57,8 +57,8 @@ enum { SPC_DONE = 0, SPC_FIT = 1, SPC_FORCED = 2 };                 // entry cla
 enum { SPS_UNKNOWN = 0, SPS_ADMIT = 1, SPS_REJECT = 2, SPS_DROP = 3 };  // DROP: behind the truncation point, handed back
 
 #ifdef KQ_HOST_EMU
-static int g_spec_off = 0;       // tests: 1 = every tree goes to the serial kernel
-static int g_spec_maxe = SP_MAXE, g_spec_maxi = SP_MAXI, g_spec_pmax = SP_PMAX;  // tests: small windows / early truncation
+static thread_local int g_spec_off = 0;       // tests: 1 = every tree goes to the serial kernel
+static thread_local int g_spec_maxe = SP_MAXE, g_spec_maxi = SP_MAXI, g_spec_pmax = SP_PMAX;  // tests: small windows / early truncation
 #endif
 
 struct SpecLds {

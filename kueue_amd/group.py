@@ -12,12 +12,16 @@ from . import _ffi as F
 from .api import Decisions, Heads, Snapshot, make_config
 from .engine import EngineError
 
-GROUP_ABI_SYMBOLS = ["kq_group_create", "kq_group_destroy", "kq_group_size", "kq_group_snapshot_put", "kq_group_cycle_run",
+HOST_COLLECTIVE = 1   # KQ_GROUP_HOST_COLLECTIVE: the exchange through pinned host memory, no RCCL; a device ordinal may repeat
+FORCE_SHARDED = 2     # KQ_GROUP_FORCE_SHARDED: one device also takes the sharded path
+
+GROUP_ABI_SYMBOLS = ["kq_group_create", "kq_group_create_opts", "kq_group_destroy", "kq_group_size", "kq_group_snapshot_put", "kq_group_cycle_run",
                      "kq_group_cycle_commit", "kq_group_cycle_release", "kq_group_read_usage", "kq_group_last_error"]
 
 
 class Group:
-    def __init__(self, cfg: Optional[F.kq_config] = None, devices: Sequence[int] = (0,)):
+    def __init__(self, cfg: Optional[F.kq_config] = None, devices: Sequence[int] = (0,), flags: Optional[int] = None):
+        """flags None: kq_group_create (KQ_GROUP_COLLECTIVE / KQ_GROUP_FORCE_SHARDED from the environment); else kq_group_create_opts."""
         self._lib = F.load_engine()
         l = self._lib
         l.kq_group_create.restype = C.c_int
@@ -28,7 +32,11 @@ class Group:
         self.cfg = cfg if cfg is not None else make_config()
         self.devices = np.ascontiguousarray(devices, np.int32)
         self._h = C.c_void_p()
-        rc = l.kq_group_create(C.byref(self.cfg), C.c_int32(len(self.devices)), F.ptr(self.devices), C.byref(self._h))
+        if flags is None:
+            rc = l.kq_group_create(C.byref(self.cfg), C.c_int32(len(self.devices)), F.ptr(self.devices), C.byref(self._h))
+        else:
+            l.kq_group_create_opts.restype = C.c_int
+            rc = l.kq_group_create_opts(C.byref(self.cfg), C.c_int32(len(self.devices)), F.ptr(self.devices), C.c_uint32(flags), C.byref(self._h))
         if rc != 0:
             raise EngineError(rc, l.kq_strerror(rc).decode())
         self.snap: Optional[Snapshot] = None
@@ -46,7 +54,7 @@ class Group:
 
     def _check(self, rc: int):
         if rc != 0:
-            raise EngineError(rc, self._lib.kq_group_last_error(self._h).decode())
+            raise EngineError(rc, self._lib.kq_group_last_error(self._h).decode(errors="replace"))
 
     @property
     def size(self) -> int:

@@ -110,6 +110,22 @@ struct GranularMode {
 };
 static const int64_t MAXINT = I64MAX;  // math.MaxInt on 64-bit
 
+// ---- probe of runFirstFsStrategy (tools/fs_pop_probe.py; VERDICT r04 item 1 "measure first"): histograms over every victim search
+// of the calls made on this thread while it is enabled. Layout (int64 each):
+//   [0] searches  [1] pops  [2] failed pops (-> retryCandidates)  [3] victims  [4] ClusterQueue visits (nextTarget results)
+//   [5] visits ending with a victim  [6] visits exhausted without one  [7] visits skipped by fsStrategyUnsatisfiable
+//   [8] unconditional victims (own ClusterQueue / within nominal)
+//   [9] consecutive victims: same ClusterQueue  [10] same parent cohort  [11] same child of the root  [12] pairs counted
+//   [13] consecutive nextTarget results: same parent cohort  [14] same child of the root  [15] pairs counted
+//   [16] victims whose removal changes a usage cell on the preemptor's path  [17] victims that do not
+//   [18..21] victims by height of the LCA above the target ClusterQueue (1 = its parent .. 3; 0 = own ClusterQueue)
+//   [32..95]  failed pops in front of the victim of a visit (index = count, last bin = 63+)
+//   [96..159] failed pops of a visit that ended exhausted
+//   [160..223] length of a run of consecutive victims under the same child of the root (last bin 63+)
+//   [224..287] candidates left in the ClusterQueue at the moment it is visited
+static thread_local bool g_fs_probe_on = false;
+static thread_local int64_t g_fs_probe[288];
+
 // ---- bytes accounting (SURVEY §8d "algorithmic bytes") ------------------------------------------
 struct Stats {
   int64_t cells = 0;         // fitsResourceQuota evaluations
@@ -1169,22 +1185,61 @@ struct Preemptor {
     return -1;
   }
   // preemption.go:384-470
+  // (probe helpers: read-only)
+  int probeTopChild(int cq) const { int prev = cq; for (int a = sn.Parent(cq); a >= 0; a = sn.Parent(a)) { if (sn.Parent(a) < 0) return prev; prev = a; } return prev; }
+  std::vector<int64_t> probePathCells(const PreemptionCtx& ctx) const {
+    std::vector<int64_t> v;
+    for (int a = ctx.preemptorCQ; a >= 0; a = sn.Parent(a)) for (auto& kv : ctx.workloadUsage) v.push_back(sn.usage[(size_t)a * sn.nfr + kv.first]);
+    return v;
+  }
+  bool probeReachesPreemptor(const PreemptionCtx& ctx, const std::vector<int64_t>& before) const { return before != probePathCells(ctx); }
   bool runFirstFsStrategy(const PreemptionCtx& ctx, const std::vector<int>& candidates, int strategy, std::vector<Target>* targets, std::vector<int>* retryCandidates) {
     Ordering ordering = MakeClusterQueueOrdering(ctx.preemptorCQ, candidates);
     bool preemptorWithinNominal = sn.gate(KQ_GATE_FS_PREEMPT_WITHIN_NOMINAL) && queueWithinNominalInResourcesNeedingPreemption(ctx);
+    const bool P = g_fs_probe_on;
+    int64_t* H = g_fs_probe;
+    int lastVictimCq = -1, lastVisitCq = -1, run = 0;
+    auto bin = [](int64_t v) { return (int)(v > 63 ? 63 : v); };
+    auto victim = [&](int cq, const std::vector<int64_t>& before) {
+      H[3]++;
+      if (lastVictimCq >= 0) {
+        H[12]++;
+        if (cq == lastVictimCq) H[9]++;
+        if (sn.Parent(cq) == sn.Parent(lastVictimCq)) H[10]++;
+        if (probeTopChild(cq) == probeTopChild(lastVictimCq)) { H[11]++; run++; } else { H[160 + bin(run)]++; run = 1; }
+      } else run = 1;
+      lastVictimCq = cq;
+      H[probeReachesPreemptor(ctx, before) ? 16 : 17]++;
+      int h = 0;
+      if (cq != ctx.preemptorCQ) { auto al = getAlmostLCAs(ordering, cq); h = 1; for (int a = cq; a != al.second; a = sn.Parent(a)) h++; }
+      H[18 + (h > 3 ? 3 : h)]++;
+    };
+    if (P) H[0]++;
+    bool result = false;
     for (int candCQ = orderingNext(ordering); candCQ >= 0; candCQ = orderingNext(ordering)) {
+      if (P) {
+        H[4]++;
+        if (lastVisitCq >= 0) { H[15]++; if (sn.Parent(candCQ) == sn.Parent(lastVisitCq)) H[13]++; if (probeTopChild(candCQ) == probeTopChild(lastVisitCq)) H[14]++; }
+        lastVisitCq = candCQ;
+        H[224 + bin((int64_t)ordering.clusterQueueToTarget[candCQ].size())]++;
+      }
+      std::vector<int64_t> before;
       if (candCQ == ctx.preemptorCQ) {  // InClusterQueuePreemption
         int candWl = ordering.PopWorkload(candCQ);
+        if (P) before = probePathCells(ctx);
         sn.RemoveWorkload(candWl);
         targets->push_back({candWl, KQ_REASON_IN_CLUSTER_QUEUE});
-        if (workloadFitsForFairSharing(ctx)) return true;
+        if (P) { H[1]++; H[8]++; H[5]++; victim(candCQ, before); }
+        if (workloadFitsForFairSharing(ctx)) { result = true; break; }
         continue;
       }
       if (preemptorWithinNominal) {
         int candWl = ordering.PopWorkload(candCQ);
+        if (P) before = probePathCells(ctx);
         sn.RemoveWorkload(candWl);
         targets->push_back({candWl, KQ_REASON_IN_COHORT_RECLAMATION});
-        if (workloadFitsForFairSharing(ctx)) return true;
+        if (P) { H[1]++; H[8]++; H[5]++; victim(candCQ, before); }
+        if (workloadFitsForFairSharing(ctx)) { result = true; break; }
         continue;
       }
       auto al = getAlmostLCAs(ordering, candCQ);
@@ -1192,29 +1247,40 @@ struct Preemptor {
       // fsStrategyUnsatisfiable :494-497
       if (std::isinf(preemptorNewShare.PreciseWeightedShare()) && preemptorNewShare.PreciseWeightedShare() > 0 &&
           !(std::isinf(targetOldShare.PreciseWeightedShare()) && targetOldShare.PreciseWeightedShare() > 0)) {
-        while (ordering.hasWorkload(candCQ)) retryCandidates->push_back(ordering.PopWorkload(candCQ));
+        while (ordering.hasWorkload(candCQ)) { retryCandidates->push_back(ordering.PopWorkload(candCQ)); if (P) { H[1]++; H[2]++; } }
         sn.st.fs_skipped_queues++;
+        if (P) H[7]++;
         continue;
       }
       sn.st.fs_first_cq_evals++;
+      int fails = 0; bool got = false, fit = false;
       while (ordering.hasWorkload(candCQ)) {
         int candWl = ordering.PopWorkload(candCQ);
+        if (P) H[1]++;
         // ComputeTargetShareAfterRemoval target.go:67-73
         FRQ u = sn.admUsage(candWl);
         sn.RemoveUsage(candCQ, u);
         DRS targetNewShare = dominantResourceShare(sn, getAlmostLCAs(ordering, candCQ).second);
         sn.AddUsage(candCQ, u);
         if (strategyPass(strategy, preemptorNewShare, targetOldShare, targetNewShare)) {
+          if (P) before = probePathCells(ctx);
           sn.RemoveWorkload(candWl);
           targets->push_back({candWl, KQ_REASON_IN_COHORT_FAIR_SHARING});
-          if (workloadFitsForFairSharing(ctx)) return true;
+          got = true;
+          if (P) { H[5]++; H[32 + bin(fails)]++; victim(candCQ, before); }
+          if (workloadFitsForFairSharing(ctx)) fit = true;
           break;
         } else {
           retryCandidates->push_back(candWl);
+          fails++;
+          if (P) H[2]++;
         }
       }
+      if (P && !got) { H[6]++; H[96 + bin(fails)]++; }
+      if (fit) { result = true; break; }
     }
-    return false;
+    if (P && run > 0) H[160 + bin(run)]++;
+    return result;
   }
   // preemption.go:501-534
   bool runSecondFsStrategy(const std::vector<int>& retryCandidates, const PreemptionCtx& ctx, std::vector<Target>* targets) {
@@ -1950,6 +2016,12 @@ int kqo_assign(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, in
 
 // Preemptor.GetTargets for head `hi` given an explicit assignment (flavor + mode per (podset,resource)),
 // as TestPreemption drives it (preemption_test.go:4093-4170). Checks the snapshot is restored exactly.
+// probe of runFirstFsStrategy (see g_fs_probe): on != 0 clears and enables, on == 0 disables; out (may be null) receives the 288 counters
+void kqo_fs_probe(int on, int64_t* out288) {
+  if (out288) for (int i = 0; i < 288; i++) out288[i] = g_fs_probe[i];
+  if (on) for (int i = 0; i < 288; i++) g_fs_probe[i] = 0;
+  g_fs_probe_on = on != 0;
+}
 static thread_local int64_t g_last_fs_counters[3] = {0, 0, 0};
 // the three log-line counters of the last kqo_get_targets on this thread (see Stats::fs_first_cq_evals)
 void kqo_last_fs_counters(int64_t* out3) { for (int i = 0; i < 3; i++) out3[i] = g_last_fs_counters[i]; }

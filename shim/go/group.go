@@ -38,6 +38,33 @@ func NewGroup(cfg Config, devices []int32) (*Group, error) {
 	}
 	return g, nil
 }
+
+// Flags of NewGroupOpts (include/kq_group.h).
+const (
+	GroupHostCollective uint32 = 1 // the exchange through pinned host memory: no RCCL, a device ordinal may repeat
+	GroupForceSharded   uint32 = 2 // a group of one device also takes the sharded path
+)
+
+// NewGroupOpts is NewGroup with explicit flags (the environment is not read).
+func NewGroupOpts(cfg Config, devices []int32, flags uint32) (*Group, error) {
+	var p runtime.Pinner
+	defer p.Unpin()
+	c := C.kq_config{abi_version: C.KQ_ABI_VERSION, gates: C.uint32_t(cfg.Gates), quota_check_strategy: C.int32_t(cfg.QuotaCheckStrategy)}
+	if cfg.FairSharing {
+		c.fair_sharing = 1
+	}
+	c.n_fs_strategies = C.int32_t(len(cfg.FSStrategies))
+	for i, s := range cfg.FSStrategies {
+		if i < 2 {
+			c.fs_strategies[i] = C.int32_t(s)
+		}
+	}
+	g := &Group{}
+	if rc := C.kq_group_create_opts(&c, C.int32_t(len(devices)), (*C.int32_t)(pin(&p, devices)), C.uint32_t(flags), &g.h); rc != 0 {
+		return nil, fmt.Errorf("kq_group_create_opts: %s", C.GoString(C.kq_strerror(rc)))
+	}
+	return g, nil
+}
 func (g *Group) Close()     { C.kq_group_destroy(g.h); g.h = nil }
 func (g *Group) Size() int  { return int(C.kq_group_size(g.h)) }
 func (g *Group) err(what string, rc C.int) error {

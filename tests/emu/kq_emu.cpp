@@ -174,7 +174,7 @@ struct EmuBackend {
     // the speculative rounds first (kq_spec.hpp), with rotating window sizes / round limits so that multi-window trees, truncation
     // (the undecided tail goes back to the serial kernel) and "rounds off" are all exercised; then the serial kernel from K::spec_resume
     {
-      static SpecLds sl;
+      static thread_local SpecLds sl;
       const int variant = spec_fixed >= 0 ? spec_fixed : spec_rot++ % 5;
       g_spec_off = variant == 4;
       g_spec_maxe = variant == 1 ? 3 : (variant == 2 ? 17 : SP_MAXE);
@@ -210,7 +210,7 @@ struct EmuBackend {
     Wave w{};
     std::vector<unsigned char> lds(getenv("KQ_TAS_LDS_OFF") ? 0 : lds_want, 0xa5);
     // (helper waves: the leader plays their shares itself, KQ_TAS_EMU_HELPERS; every other launch runs without them)
-    static int launches = 0;
+    static thread_local int launches = 0;
     TLeafJob job{};
     job.nw = 4; job.coop_min = getenv("KQ_TAS_COOP_MIN") ? atoi(getenv("KQ_TAS_COOP_MIN")) : 8;
     process_all_tas(k, w, 0, (launches++ & 1) ? nullptr : &job, lds.data(), (int)lds.size());
@@ -346,4 +346,67 @@ int kqe_read_usage(void* e, int64_t* out) { return ((EmuEngine*)e)->read_usage_w
 int kqe_last_bytes(void* e, int64_t* out) { *out = ((EmuEngine*)e)->last_bytes; return KQ_OK; }
 int kqe_phase_bytes(void* e, int64_t* out) { out[0] = ((EmuEngine*)e)->last_phase_bytes[0]; out[1] = ((EmuEngine*)e)->last_phase_bytes[1]; return KQ_OK; }
 const char* kqe_last_error(void* e) { return ((EmuEngine*)e)->last_error.c_str(); }
+}
+
+// ---- include/kq_group.h over emulated engines (tests/test_group.py): the SAME driver as the device build (kq_group_core.hpp: persistent
+// rank workers, phase barriers, error containment, the host collective) with the kqe_* engines above and malloc'ed "device" buffers.
+// The device collective does not exist here: a group is always created with KQ_GROUP_HOST_COLLECTIVE. `inject`: a rank and a step
+// (1 nominate, 2 export copy, 3 import copy, 4 process) that fails once with KQ_EDEVICE — the other ranks must leave the cycle with it.
+#include "../../kueue_amd/csrc/kq_group_core.hpp"
+namespace {
+struct EmuGroupBackend {
+  int inject_rank = -1, inject_step = 0;
+  bool take(int rank, int step) { if (rank == inject_rank && step == inject_step) { inject_rank = -1; return true; } return false; }
+  bool set_device(int) { return true; }
+  int engine_create(const kq_config* c, void** e) { return kqe_engine_create(c, e); }
+  void engine_destroy(void* e) { kqe_engine_destroy(e); }
+  int rank_init(int, int) { return KQ_OK; }
+  void rank_fini(int) {}
+  int comm_init(int, const int*, std::string* err) { *err = "the emulation has no device collective"; return KQ_EUNSUPPORTED; }
+  void comm_destroy() {}
+  void* xalloc(size_t b) { void* p = malloc(b ? b : 1); if (p) memset(p, 0xA5, b); return p; }
+  void xfree(void* p) { free(p); }
+  void* host_alloc(size_t b) { return calloc(b ? b : 1, 1); }
+  void host_free(void* p) { free(p); }
+  std::vector<void*> xb;   // exchange buffer of each rank as seen by d2h / h2d (to find the rank for the injection)
+  int d2h(void* h, const void* d, size_t b) { for (size_t r = 0; r < xb.size(); r++) if (xb[r] == d && take((int)r, 2)) return KQ_EDEVICE; memcpy(h, d, b); return KQ_OK; }
+  int h2d(void* d, const void* h, size_t b) { for (size_t r = 0; r < xb.size(); r++) if (xb[r] == d && take((int)r, 3)) return KQ_EDEVICE; memcpy(d, h, b); return KQ_OK; }
+  int allreduce_all(int, const int*, void* const*, size_t, std::string* err) { *err = "the emulation has no device collective"; return KQ_EUNSUPPORTED; }
+  int comm_wait(int) { return KQ_OK; }
+  int snapshot_put(void* e, const kq_snapshot* s) { return kqe_snapshot_put(e, s); }
+  int cycle_run(void* e, const kq_heads* h, kq_decisions* o) { return kqe_cycle_run(e, h, o); }
+  int shard_words(void* e, const kq_heads* h, const kq_decisions* o, int world, int64_t* w) { return kqe_cycle_shard_words(e, h, o, world, w); }
+  int nominate_shard(void* e, const kq_heads* h, const uint8_t* mine, int world, int rank, void* x, kq_decisions* o) {
+    if ((int)xb.size() < world) xb.resize((size_t)world, nullptr);
+    xb[(size_t)rank] = x;
+    if (take(rank, 1)) return KQ_EDEVICE;
+    return kqe_cycle_nominate_shard(e, h, mine, world, rank, x, o);
+  }
+  int process_merged(void* e, int world, int rank, const void* x, kq_decisions* o) { if (take(rank, 4)) return KQ_EDEVICE; return kqe_cycle_process_merged(e, world, rank, x, o); }
+  int commit(void* e, int32_t* n) { return kqe_cycle_commit(e, n); }
+  int release(void* e, int32_t age) { return kqe_cycle_release(e, age); }
+  int read_usage(void* e, int64_t* u) { return kqe_read_planes(e, nullptr, u, nullptr); }
+  const char* last_error(void* e) { return kqe_last_error(e); }
+};
+typedef kqg::Group<EmuGroupBackend> EmuGroup;
+}  // namespace
+extern "C" {
+int kqe_group_create(const kq_config* cfg, int32_t n, uint32_t flags, void** out) {
+  if (!cfg || !out || n < 1 || n > 64) return KQ_EINVAL;
+  auto* g = new EmuGroup();
+  g->be.xb.assign((size_t)n, nullptr);   // (sized before the workers exist: nominate_shard only writes its own slot)
+  std::vector<int32_t> dev((size_t)n, 0);
+  const int rc = g->create(cfg, n, dev.data(), flags | KQ_GROUP_HOST_COLLECTIVE);
+  if (rc != KQ_OK) { g->destroy(); delete g; return rc; }
+  *out = g;
+  return KQ_OK;
+}
+void kqe_group_destroy(void* g) { if (g) { ((EmuGroup*)g)->destroy(); delete (EmuGroup*)g; } }
+int kqe_group_snapshot_put(void* g, const kq_snapshot* s) { return ((EmuGroup*)g)->snapshot_put(s); }
+int kqe_group_cycle_run(void* g, const kq_heads* h, kq_decisions* out) { return ((EmuGroup*)g)->cycle_run(h, out); }
+int kqe_group_cycle_commit(void* g, int32_t* n) { return ((EmuGroup*)g)->cycle_commit(n); }
+int kqe_group_cycle_release(void* g, int32_t age) { return ((EmuGroup*)g)->cycle_release(age); }
+int kqe_group_read_usage(void* g, int32_t rank, int64_t* u) { return ((EmuGroup*)g)->read_usage(rank, u); }
+const char* kqe_group_last_error(void* g) { return ((EmuGroup*)g)->last_error.c_str(); }
+void kqe_group_inject(void* g, int32_t rank, int32_t step) { ((EmuGroup*)g)->be.inject_rank = rank; ((EmuGroup*)g)->be.inject_step = step; }
 }

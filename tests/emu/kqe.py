@@ -403,3 +403,53 @@ class EmuTas:
         if self.h:
             lib().kqe_tas_destroy(self.h)
             self.h = None
+
+
+class EmuGroup:
+    """include/kq_group.h over emulated engines (kq_emu.cpp kqe_group_*): the device build's driver (kq_group_core.hpp) with the host collective."""
+    FORCE_SHARDED = 2
+
+    def __init__(self, cfg, n, flags=0):
+        self.h = C.c_void_p()
+        lib().kqe_group_last_error.restype = C.c_char_p
+        rc = lib().kqe_group_create(C.byref(cfg), C.c_int32(n), C.c_uint32(flags), C.byref(self.h))
+        assert rc == 0, rc
+        self.n = n
+
+    def put(self, snap):
+        rc = lib().kqe_group_snapshot_put(self.h, C.byref(snap.struct()))
+        assert rc == 0, (rc, lib().kqe_group_last_error(self.h))
+        self.snap = snap
+
+    def run(self, heads, tgt_cap=None, rsn_cap=0, check=True):
+        d = Decisions(heads, tgt_cap=tgt_cap, rsn_cap=rsn_cap)
+        rc = lib().kqe_group_cycle_run(self.h, C.byref(heads.struct()), C.byref(d.struct()))
+        if check:
+            assert rc == 0, (rc, lib().kqe_group_last_error(self.h))
+            return d
+        return rc
+
+    def commit(self):
+        n = C.c_int32()
+        rc = lib().kqe_group_cycle_commit(self.h, C.byref(n))
+        assert rc == 0, (rc, lib().kqe_group_last_error(self.h))
+        return n.value
+
+    def release(self, age=1):
+        assert lib().kqe_group_cycle_release(self.h, C.c_int32(age)) == 0
+
+    def usage(self, rank=0):
+        u = np.zeros(self.snap.N * self.snap.n_fr, np.int64)
+        assert lib().kqe_group_read_usage(self.h, C.c_int32(rank), F.ptr(u)) == 0
+        return u
+
+    def inject(self, rank, step):
+        lib().kqe_group_inject(self.h, C.c_int32(rank), C.c_int32(step))
+
+    def last_error(self):
+        return lib().kqe_group_last_error(self.h).decode()
+
+    def close(self):
+        if self.h:
+            lib().kqe_group_destroy(self.h)
+            self.h = None
