@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None, help="default: 60 for the pending loops cfg3 / cfg3f (past the runtime's one-time 6-12 ms at the 53rd cycle "
                                                               "of a run, profiles/r04q_notes.txt), 5 for the workloads whose cycles take longer and for cfg2, whose 10 k pending workloads "
                                                               "are 78 cycles of full head batches: after a long warm-up the window would time a draining queue")
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3-batch", "cfg3-split", "cfg4c-split", "cfg4f-split", "cfg4c", "cfg3f", "cfg4f", "cfg5", "cfg5-split", "cfg5-cycle", "cfg5f-cycle"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3-batch", "cfg3-group", "cfg4c-group", "cfg4f-group", "cfg3-split", "cfg4c-split", "cfg4f-split", "cfg4c", "cfg3f", "cfg4f", "cfg5", "cfg5-split", "cfg5-cycle", "cfg5f-cycle"],
                     help="cfg3 = BASELINE.json configs[2] (100k pending, 1k CQ, 16 flavors, 3-level cohorts); "
                          "cfg4c = configs[3] population under classical preemption; cfg4f = configs[3] as quoted "
                          "(fair sharing + preemption); cfg3f = configs[2] population under fair sharing; cfg5 = configs[4] "
@@ -76,6 +76,8 @@ def main():
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
+    if args.workload.endswith("-group"):
+        return bench_group(args, torch, dist, world, rank, local_rank)
     if args.workload == "cfg5":
         return bench_tas(args, torch, dist, world, rank, local_rank)
     if args.workload == "cfg5-split":
@@ -815,6 +817,75 @@ def bench_split(args, torch, dist, world, rank, local_rank):
         dist.destroy_process_group()
 
 
+def bench_group(args, torch, dist, world, rank, local_rank):
+    """cfg3-group / cfg4c-group / cfg4f-group: include/kq_group.h — the C++ multi-device driver — on ONE GPU: the same closed loop
+    (heads uploaded every cycle, kq_cycle_commit / kq_cycle_release) through (a) a plain engine (kq_cycle_run), (b) a group of ONE engine
+    forced through the sharded path (export -> import -> kq_cycle_process_merged: what the protocol costs by itself), (c) a group of
+    TWO engines on the same device with the host collective (the N > 1 code: rank worker, phase barriers, host sum). Every cycle of (b)
+    and (c) is compared with (a). One process, one device: a figure about the driver's overhead, not about scaling."""
+    from kueue_amd.api import Decisions, make_config
+    from kueue_amd.engine import Engine
+    from kueue_amd import group as G
+    from kueue_amd.population import BASE_SEED, generate
+    cfgn = 4 if args.workload.startswith("cfg4") else 3
+    fair = args.workload.startswith("cfg4f")
+    pop = generate(cfgn, seed=BASE_SEED) if cfgn == 3 else generate(cfgn, seed=BASE_SEED, fair_sharing=fair, n_cq=100 if fair else None)
+    snap = pop.snapshot
+    kcfg = make_config(device=local_rank, fair_sharing=fair)
+    tgt_cap = 4096 if cfgn == 3 else (32 if fair else 4) * snap.n_adm
+    per_cq = int((pop.cq_w_off[1:] - pop.cq_w_off[:-1]).max())
+    total = args.warmup + args.steps
+    n_batches = min(per_cq, total)
+    batches = [pop.heads_for_cycle(c, cycle=c + 1) for c in range(n_batches)]
+
+    def loop(x, run):
+        live, ms, outs = 0, [], []
+        for i in range(total):
+            h = batches[i % n_batches]
+            t1 = time.perf_counter()
+            d = run(h)
+            x.commit(); live += 1
+            if live > args.hold:
+                x.release(args.hold + 1); live -= 1
+            ms.append((time.perf_counter() - t1) * 1e3)
+            outs.append({k: v.copy() for k, v in d.a.items()})
+        return ms[args.warmup:], outs
+
+    def same(a, b):
+        for x, y in zip(a, b):
+            m = int(x["tgt_off"][-1])
+            for k in x:
+                if not (np.array_equal(x[k][:m], y[k][:m]) if k in ("tgt_adm", "tgt_reason") else np.array_equal(x[k], y[k])):
+                    return False
+        return True
+
+    eng = Engine(kcfg); eng.put(snap)
+    plain_ms, want = loop(eng, lambda h: eng.run(h, tgt_cap=tgt_cap))
+    want_usage = eng.read_usage(); eng.close()
+    legs = {}
+    for name, devices, flags in (("one engine through the sharded path", [local_rank], G.FORCE_SHARDED), ("two engines on this device, host collective", [local_rank, local_rank], G.HOST_COLLECTIVE)):
+        g = G.Group(kcfg, devices=devices, flags=flags)
+        g.put(snap)
+        ms, got = loop(g, lambda h: g.run(h, tgt_cap=tgt_cap))
+        ok = same(want, got) and all(np.array_equal(want_usage, g.usage(r)) for r in range(len(devices)))
+        g.close()
+        legs[name] = {"ms_per_cycle": float(np.mean(ms)), "p50_ms": float(np.percentile(ms, 50)), "p99_ms": float(np.percentile(ms, 99)),
+                      "ratio_to_plain": float(np.mean(ms)) / float(np.mean(plain_ms)), "equal_to_plain_engine": bool(ok)}
+    dec = sum(batches[i % n_batches].n for i in range(args.warmup, total))
+    two = legs["two engines on this device, host collective"]
+    emit({"metric": "admission-decisions/sec + p99 schedule-cycle ms @ 100k pending, 1k CQ",
+          "value": dec / (two["ms_per_cycle"] * args.steps * 1e-3), "unit": "decisions/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+          "ms_per_step": two["ms_per_cycle"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+          "config": {"workload": f"{args.workload}: kq_group (C++ driver of include/kq_group.h) on ONE device, {snap.n_cq} ClusterQueues, {snap.n_adm} admitted, {batches[0].n} heads per cycle uploaded every cycle",
+                     "loop": f"closed: commit every cycle, release after {args.hold} cycles", "value_is": "the two-engine group (both engines share the one GPU: not a scaling figure)"},
+          "plain_engine": {"ms_per_cycle": float(np.mean(plain_ms)), "p50_ms": float(np.percentile(plain_ms, 50)), "p99_ms": float(np.percentile(plain_ms, 99))},
+          "group": legs,
+          "parity_checked": True, "parity": "every decision field of every cycle and the resident usage of every rank equal the plain engine's: " + str(all(v["equal_to_plain_engine"] for v in legs.values())),
+          "roofline": None, "cpu_baseline": None})
+    if not all(v["equal_to_plain_engine"] for v in legs.values()):
+        raise SystemExit(f"{args.workload}: a group leg differs from the plain engine")
+
+
 def bench_batch(args, torch, dist, world, rank, local_rank):
     """cfg3-batch: one step = Scheduler.nominate (flavorassigner.Assign + GetTargets) for EVERY pending workload of cfg 3 in one
     k_nominate launch against the resident snapshot — the bandwidth-meaningful figure of SURVEY 8d; a 'decision' here is one
@@ -909,9 +980,14 @@ def bench_tas_split(args, torch, dist, world, rank, local_rank):
     R = len(topo.resources)
     held = []
 
+    adm_log = []   # the admitted set of every cycle since the put (compared with the oracle's replay after the timed region)
+    find_ms, find_by = [0.0], [0]
+
     def step(i):
         rq = batches[i % n_batches]
         merged, adm = sp.cycle(rq)
+        find_ms[0] += float(sp.last_find[0]); find_by[0] += int(sp.last_find[1])   # the shard's k_tas_find of this cycle: HIP-event interval, algorithmic bytes
+        adm_log.append(np.asarray(adm).astype(np.uint8).copy())
         # what the cycle added (for the release --hold cycles later): Usage.TAS of the admitted workloads
         plane = torch.zeros(topo.n_leaves * R, dtype=torch.int64, device=dev)
         torch.cuda.synchronize()
@@ -927,6 +1003,7 @@ def bench_tas_split(args, torch, dist, world, rank, local_rank):
     if world > 1:
         dist.barrier()
     sp.stats = dict(cycles=0, exact=0, contended=0, walked=0)
+    find_ms[0], find_by[0] = 0.0, 0
     cyc_ms, dec, n_adm = [], 0, 0
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -959,7 +1036,41 @@ def bench_tas_split(args, torch, dist, world, rank, local_rank):
                 ref.usage_add(h2.pop(0).data_ptr(), -1)
         verified = bool(np.array_equal(ref.read_usage(), eng.read_usage()))
         ref.close()
+    parity, cpu = None, None
+    if rank == 0 and not args.no_parity_gate:
+        # the ORACLE replays the first cycles of the same closed loop on the host (FindTopologyAssignmentsForFlavor for the whole batch
+        # against the evolving leaf usage, the entry-order admission walk, the release after --hold cycles): the admitted set of every
+        # one of those dependent cycles must equal what the split protocol admitted. The same replay is the cpu_baseline.
+        from oracle import kqo
+        gate = min(len(adm_log), 6)
+        usage0 = topo.arrays["tas_usage"].copy()
+        usage = usage0.copy()
+        hq, t_or, n_or = [], 0.0, 0
+        try:
+            for c in range(gate):
+                rq = batches[c % n_batches]
+                topo.arrays["tas_usage"][:] = usage
+                topo._struct = None
+                t1 = time.perf_counter()
+                res = kqo.tas_find(topo, rq)
+                adm, after = kqo.tas_admit(topo, rq, res)
+                t_or += time.perf_counter() - t1; n_or += per
+                if not np.array_equal(adm.astype(np.uint8), adm_log[c][:len(adm)]):
+                    raise SystemExit(f"cfg5-split: cycle {c}: the admitted set of the split protocol differs from the oracle's")
+                hq.append(after - usage)
+                usage = after.copy()
+                if len(hq) > args.hold:
+                    usage -= hq.pop(0)
+        finally:
+            topo.arrays["tas_usage"][:] = usage0
+            topo._struct = None
+        parity = f"cycles 0..{gate - 1} ({gate * per} decisions, dependent through the leaf usage and the releases): the admitted set of every cycle equals the oracle's find + entry-order walk"
+        cpu = {"value": n_or / t_or, "unit": "decisions/s", "cores": 1, "kind": "port",
+               "sample": f"the first {gate} cycles of the same loop ({n_or} workloads): C++ restatement of FindTopologyAssignmentsForFlavor + the admission walk, host nproc={os.cpu_count()}"}
     if rank == 0:
+        kms = find_ms[0] / max(args.steps, 1)
+        kby = find_by[0] / max(args.steps, 1)
+        achieved = kby / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         emit({
             "metric": "admission-decisions/sec + p99 schedule-cycle ms @ 100k pending, 1k CQ",
             "value": dec / elapsed, "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -972,7 +1083,13 @@ def bench_tas_split(args, torch, dist, world, rank, local_rank):
             "p50_cycle_ms": float(np.percentile(cyc_ms, 50)), "p99_cycle_ms": float(np.percentile(cyc_ms, 99)),
             "admitted_per_cycle": n_adm / max(args.steps, 1), "split_stats": sp.stats,
             "end_state_equals_single_engine": verified,
-            "roofline": None, "cpu_baseline": None,
+            "parity_checked": parity is not None, "parity": parity,
+            "kernel_ms_per_cycle": {"k_tas_find": kms},
+            "roofline": {"bound": "hbm", "kernel": "k_tas_find", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "algorithmic_bytes_per_launch": kby, "traffic": pmc_traffic("cfg5", "k_tas_find"),
+                         "note": "rank 0's placement launch of a cycle (its shard of the batch): algorithmic bytes = phase 1 of every workload as the reference runs it, "
+                                 "HIP-event interval of the launch; traffic is the cfg 5 batch launch's PMC figure, not this launch's"},
+            "cpu_baseline": cpu if world == 1 and not args.no_cpu_baseline else None,
         })
     eng.close()
     if world > 1:
@@ -1084,12 +1201,40 @@ def bench_tas_cycle(args, torch, dist, world, rank, local_rank):
     cfg = make_config(fair_sharing=fair)
     snap.derive()   # SubtreeQuota / cohort usage on the host, as the Go cache holds them before Snapshot() (kueue_amd/api.py)
     eng = Engine(cfg)
-    eng.put(snap)
-    nb = min((n_pending + n_cq - 1) // n_cq, max(args.steps + args.warmup, 5))
-    batches = [batch(c) for c in range(nb)]
     topo = topos["tas-flavor"]
     parity = None
-    if rank == 0 and not args.no_parity_gate:
+    closed = not args.open_loop
+    traj, oracle_s, oracle_dec = [], 0.0, 0
+    if closed:
+        # CLOSED loop, driven the reference's way (scheduler.go:308-386 with manager.go:903): every cycle starts from a fresh
+        # cache.Snapshot() that holds what the cycles before admitted — rows, quota usage, TopologyAssignments as leaf usage — and the
+        # workloads finish --hold cycles later (kueue_amd/tas_population.py TASClosedLoop). The trajectory is laid down by the oracle
+        # BEFORE the timed region (it is the parity reference and the cpu_baseline anyway); a step then is kq_snapshot_put of that
+        # cycle's snapshot + kq_cycle_run_tas, and every step's outcome is compared with the oracle's after the timed region.
+        from oracle import kqo
+        loop = batch.closed_loop(hold=args.hold)
+        nb = min(args.steps + args.warmup, 24)
+        for c in range(nb):
+            sn, h0, c0 = loop.cycle_input()
+            t1 = time.perf_counter()
+            want, wout = kqo.cycle_run_tas(cfg, sn, h0, c0)
+            oracle_s += time.perf_counter() - t1; oracle_dec += h0.n
+            traj.append((sn, h0, c0, want, wout))
+            loop.fold(h0, want, wout)
+        batches = [(t[1], t[2]) for t in traj]
+    else:
+        eng.put(snap)
+        nb = min((n_pending + n_cq - 1) // n_cq, max(args.steps + args.warmup, 5))
+        batches = [batch(c) for c in range(nb)]
+
+    def tas_same(want, wout, got, gout, h0):
+        bad = want.equal(got)
+        m = int(wout.a["dom_off"][h0.n_ps])
+        return (not bad and np.array_equal(wout.a["ps_tas"][:h0.n_ps], gout.a["ps_tas"][:h0.n_ps]) and np.array_equal(wout.a["dom_off"], gout.a["dom_off"]) and
+                np.array_equal(wout.a["dom_leaf"][:m], gout.a["dom_leaf"][:m]) and np.array_equal(wout.a["dom_count"][:m], gout.a["dom_count"][:m]) and
+                np.array_equal(wout.a["tas_usage_after"], gout.a["tas_usage_after"])), bad
+
+    if rank == 0 and not args.no_parity_gate and not closed:
         from oracle import kqo   # the checker: parity gate here, cpu_baseline below — never inside the timed region
         gated = min(nb, 5)
         ndec = 0
@@ -1097,11 +1242,7 @@ def bench_tas_cycle(args, torch, dist, world, rank, local_rank):
             h0, c0 = batches[c]
             want, wout = kqo.cycle_run_tas(cfg, snap, h0, c0)
             got, gout = eng.run_tas(h0, c0)
-            bad = want.equal(got)
-            m = int(wout.a["dom_off"][h0.n_ps])
-            same = (not bad and np.array_equal(wout.a["ps_tas"][:h0.n_ps], gout.a["ps_tas"][:h0.n_ps]) and np.array_equal(wout.a["dom_off"], gout.a["dom_off"]) and
-                    np.array_equal(wout.a["dom_leaf"][:m], gout.a["dom_leaf"][:m]) and np.array_equal(wout.a["dom_count"][:m], gout.a["dom_count"][:m]) and
-                    np.array_equal(wout.a["tas_usage_after"], gout.a["tas_usage_after"]))
+            same, bad = tas_same(want, wout, got, gout, h0)
             if not same:
                 raise SystemExit(f"{args.workload}: cycle {c} of the engine differs from the oracle's ({bad})")
             ndec += h0.n
@@ -1109,9 +1250,16 @@ def bench_tas_cycle(args, torch, dist, world, rank, local_rank):
     phases = np.zeros(3, np.float64)
     import ctypes as C
 
+    seen = {}
+
     def step(i):
         h, c = batches[i % nb]
-        return eng.run_tas(h, c)
+        if closed:
+            eng.put(traj[i % nb][0])     # the cycle's cache.Snapshot(): what the cycles before it admitted is in it
+        r = eng.run_tas(h, c)
+        if closed and (i % nb) not in seen:
+            seen[i % nb] = r             # (compared with the oracle's outcome after the timed region)
+        return r
 
     for i in range(args.warmup):
         step(i)
@@ -1155,7 +1303,10 @@ def bench_tas_cycle(args, torch, dist, world, rank, local_rank):
             "config": {"workload": f"{args.workload}: TAS inside the scheduling cycle{' under fair sharing' if fair else ''}, {snap.n_cq} ClusterQueues in {snap.n_cohort} cohorts, one TAS flavor of {topo.n_leaves} leaves "
                                    f"(8 blocks x 8 racks x 64 hosts, {R} resources) shared by all of them + one ordinary flavor, {n_pending} pending workloads, one head per ClusterQueue per cycle",
                        "decision": "one head through flavor assignment, TAS placement, the entry-order walk (quota + leaf capacity) and its recomputation",
-                       "loop": "open loop: the next batch of heads every step against the same cycle-start snapshot; heads and TAS side uploaded every step",
+                       "loop": (f"closed loop, host-driven as the reference drives it: step c = kq_snapshot_put of the cache.Snapshot() that holds what cycles 0..c-1 admitted "
+                                f"(rows, quota usage, TopologyAssignments as leaf usage; workloads finish after {args.hold} cycles) + kq_cycle_run_tas over the next head of every "
+                                f"ClusterQueue; a trajectory of {nb} dependent cycles laid down by the oracle before the timed region, repeated when steps + warmup exceed it"
+                                if closed else "open loop: the next batch of heads every step against the same cycle-start snapshot; heads and TAS side uploaded every step"),
                        "sharding": "population per GPU, no collective"},
             "p50_cycle_ms": float(np.percentile(st_ms, 50)), "p99_cycle_ms": float(np.percentile(st_ms, 99)),
             "kernel_ms_per_cycle": {n: float(v) / args.steps for n, v in zip(names, ph)},
@@ -1165,7 +1316,20 @@ def bench_tas_cycle(args, torch, dist, world, rank, local_rank):
                          "note": "all three intervals of the cycle; the placements' bytes are the reference's phase-1 accounting per FindTopologyAssignmentsForFlavor call"},
             "parity_checked": parity is not None, "parity": parity,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if closed and not args.no_parity_gate:
+            ndec = 0
+            for c in sorted(seen):
+                same, bad = tas_same(traj[c][3], traj[c][4], seen[c][0], seen[c][1], traj[c][1])
+                if not same:
+                    raise SystemExit(f"{args.workload}: closed-loop cycle {c} of the engine differs from the oracle's ({bad})")
+                ndec += traj[c][1].n
+            res["parity_checked"] = True
+            res["parity"] = (f"closed-loop cycles {min(seen)}..{max(seen)} ({len(seen)} dependent cycles, {ndec} decisions): decisions, every TopologyAssignment and the leaf usage "
+                             f"after each cycle equal the oracle's; rows in the snapshot grow to {max(t[0].n_adm for t in traj)}")
+        if closed and not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = {"value": oracle_dec / oracle_s, "unit": "decisions/s", "cores": 1, "kind": "port",
+                                   "sample": f"the same {nb} closed-loop cycles ({oracle_dec} heads), C++ restatement of the cycle with TAS (kqo_cycle_run_tas) without the snapshot build, host nproc={os.cpu_count()}"}
+        elif not args.no_cpu_baseline and world == 1:
             from oracle import kqo
             t1 = time.perf_counter()
             nd = 0

@@ -600,6 +600,10 @@ int  kq_debug_disable_scan_search(kq_engine* e, int on);  /* classical victim se
  * from the resident row table, and read back one by one (`which`: kueue_amd/csrc/kq_host.hpp read_rows; *bytes: capacity in, size out;
  * KQ_ECAPACITY with the size when too small): tests compare the device-built structures with the host-built ones byte for byte. */
 int  kq_debug_rows_rebuild(kq_engine* e);
+/* KQ_GUARD=1 in the environment when the engine is created: every device buffer lies between two 256-byte guard zones; this reads them
+ * all back. out3: [0] buffers checked, [1] buffers with a damaged guard (kq_last_error names them), [2] guard bytes read.
+ * KQ_EUNSUPPORTED without KQ_GUARD. */
+int  kq_debug_check_guards(kq_engine* e, int64_t* out3);
 int  kq_debug_read_rows(kq_engine* e, int32_t which, void* out, int64_t* bytes);
 int  kq_debug_prof(kq_engine* e, int64_t* out64, int reset);
 /* last cycle's speculative process rounds (kq_spec.hpp): [0] windows, [1] rounds, [2] entries they decided, [3] trees handed (partly)

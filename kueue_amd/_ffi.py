@@ -316,5 +316,5 @@ ABI_SYMBOLS = [
     "kq_pending_afs_put", "kq_pending_afs_wl_penalty", "kq_pending_afs_sub_penalty", "kq_pending_afs_set_consumed", "kq_pending_afs_read",
     "kq_pending_set_lq_usage", "kq_pending_add", "kq_pending_update", "kq_pending_delete", "kq_pending_set_clock", "kq_pending_set_requeue_at", "kq_pending_put", "kq_pending_heads", "kq_cycle_run_pending", "kq_pending_apply", "kq_pending_queue_inadmissible", "kq_pending_read_state",
     "kq_debug_read_usage_work", "kq_debug_force_exact_drs", "kq_debug_prof", "kq_debug_spec_stats", "kq_debug_disable_scan_search",
-    "kq_debug_rows_rebuild", "kq_debug_read_rows",
+    "kq_debug_rows_rebuild", "kq_debug_read_rows", "kq_debug_check_guards",
 ]

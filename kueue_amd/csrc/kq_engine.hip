@@ -434,8 +434,52 @@ struct HipBackend {
     if (rows_tmp.p) (void)hipFree(rows_tmp.p);
     if (stream) (void)hipStreamDestroy(stream);
   }
-  void* alloc(size_t n) { void* p = nullptr; chk(hipMalloc(&p, n), "hipMalloc"); return p; }
-  void free(void* p) { (void)hipFree(p); }
+  // KQ_GUARD=1 (tools/fuzz_put_guard.py): every device buffer of the engine sits between two 256-byte guard zones filled with 0xC7 — the
+  // tail zone starts at the first byte behind the requested size — and kq_debug_check_guards reads them all back. An out-of-bounds
+  // write of a kernel or a copy (the suspect behind the memory-access fault round 3 / 4 saw once inside kq_snapshot_put) lands in a
+  // guard instead of in a neighbouring allocation, on every box, whatever the allocator's layout.
+  static constexpr size_t GW = 256;
+  struct GuardRec { char* base; size_t n; };
+  std::vector<GuardRec> guards;
+  bool guard_on = getenv("KQ_GUARD") != nullptr;
+  void* alloc(size_t n) {
+    if (!guard_on) { void* p = nullptr; chk(hipMalloc(&p, n), "hipMalloc"); return p; }
+    char* p = nullptr;
+    const size_t body = (n + 255) & ~(size_t)255;
+    chk(hipMalloc((void**)&p, body + 2 * GW), "hipMalloc");
+    if (!p) return nullptr;
+    chk(hipMemset(p, 0xC7, GW), "guard fill");
+    chk(hipMemset(p + GW + n, 0xC7, body - n + GW), "guard fill");
+    guards.push_back(GuardRec{p, n});
+    return p + GW;
+  }
+  void free(void* p) {
+    if (!guard_on || !p) { (void)hipFree(p); return; }
+    for (size_t i = 0; i < guards.size(); i++)
+      if (guards[i].base + GW == (char*)p) { (void)hipFree(guards[i].base); guards[i] = guards.back(); guards.pop_back(); return; }
+    (void)hipFree(p);
+  }
+  // out3: buffers checked, buffers with a damaged guard, guard bytes read. The text names the first damaged buffers.
+  int check_guards(int64_t* out3, std::string* text) {
+    out3[0] = out3[1] = out3[2] = 0;
+    if (!guard_on) { *text = "KQ_GUARD is not set"; return KQ_EUNSUPPORTED; }
+    if (hipDeviceSynchronize() != hipSuccess) { *text = "device error before the guard check"; return KQ_EDEVICE; }
+    std::vector<unsigned char> h;
+    for (const GuardRec& g : guards) {
+      const size_t body = (g.n + 255) & ~(size_t)255, tail = body - g.n + GW;
+      h.resize(GW + tail);
+      if (hipMemcpy(h.data(), g.base, GW, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(h.data() + GW, g.base + GW + g.n, tail, hipMemcpyDeviceToHost) != hipSuccess) { *text = "guard read failed"; return KQ_EDEVICE; }
+      out3[0]++; out3[2] += (int64_t)h.size();
+      long first = -1; size_t bad = 0;
+      for (size_t i = 0; i < h.size(); i++) if (h[i] != 0xC7) { bad++; if (first < 0) first = (long)i; }
+      if (bad) {
+        out3[1]++;
+        if (text->size() < 600) *text += "buffer of " + std::to_string(g.n) + " B: " + std::to_string(bad) + " guard bytes overwritten, first at " +
+                                         (first < (long)GW ? std::to_string(first - (long)GW) : "+" + std::to_string(first - (long)GW)) + " from its " + (first < (long)GW ? "start" : "end") + "; ";
+      }
+    }
+    return KQ_OK;
+  }
   void* alloc_host(size_t n) { void* p = nullptr; chk(hipHostMalloc(&p, n, hipHostMallocDefault), "hipHostMalloc"); return p; }
   void free_host(void* p) { (void)hipHostFree(p); }
   void h2d(void* d, const void* h, size_t n) { chk(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, stream), "h2d"); }
@@ -1016,6 +1060,10 @@ int kq_cycle_certificate(kq_engine* en, int64_t* usage_delta_dev, int64_t* root_
 int kq_snapshot_patch_rows(kq_engine* en, const kq_row_patch* p, int32_t* new_index) {
   if (!en || !p) return KQ_EINVAL;
   KQ_TRY(en, return en->e.snapshot_patch_rows(p, new_index));
+}
+int kq_debug_check_guards(kq_engine* en, int64_t* out3) {
+  if (!en || !out3) return KQ_EINVAL;
+  KQ_TRY(en, { std::string t; const int rc = en->e.be.check_guards(out3, &t); if (rc != KQ_OK || out3[1]) en->e.last_error = t; return rc; });
 }
 int kq_debug_rows_rebuild(kq_engine* en) { if (!en) return KQ_EINVAL; KQ_TRY(en, return en->e.debug_rows_rebuild()); }
 int kq_debug_read_rows(kq_engine* en, int32_t which, void* out, int64_t* bytes) { if (!en || !bytes) return KQ_EINVAL; KQ_TRY(en, return en->e.read_rows(which, out, bytes)); }

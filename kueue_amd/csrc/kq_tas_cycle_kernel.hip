@@ -73,12 +73,19 @@ hipError_t launch_process_tas_k(const K* d, size_t want, size_t* attr_p, hipStre
   hipFuncAttributes fa{};
   hipError_t e = hipFuncGetAttributes(&fa, (const void*)k_process_tas);
   if (e != hipSuccess) return e;
-  const size_t room = (size_t)160 * 1024 - fa.sharedSizeBytes - 256;
-  const size_t lds = (want > 0 && want <= room && !getenv("KQ_TAS_LDS_OFF")) ? want : 0;
+  // what the device grants a workgroup (160 KB on gfx950): asked once, not assumed — on a part or a driver that grants less, or when the
+  // attribute is refused, the placement's state stays in global memory (lds = 0, the KQ_TAS_LDS_OFF path) instead of failing the cycle
+  static const size_t dev_lds = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) return (size_t)64 * 1024;
+    return (size_t)v;
+  }();
+  const size_t room = dev_lds > fa.sharedSizeBytes + 256 ? dev_lds - fa.sharedSizeBytes - 256 : 0;
+  size_t lds = (want > 0 && want <= room && !getenv("KQ_TAS_LDS_OFF")) ? want : 0;
   if (lds > attr) {
     e = hipFuncSetAttribute((const void*)k_process_tas, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr = lds;
+    if (e != hipSuccess) { (void)hipGetLastError(); lds = 0; }
+    else attr = lds;
   }
   const char* cm = getenv("KQ_TAS_COOP_MIN");   // (tests: short slices shared as well)
   hipLaunchKernelGGL(k_process_tas, dim3(1), dim3(PROCESS_TAS_THREADS), lds, stream, d, (unsigned)lds, cm ? atoi(cm) : 1024);

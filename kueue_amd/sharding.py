@@ -362,6 +362,7 @@ class SplitTAS:
         mine = order[self.rank::self.world]                      # round-robin over the entry order: balanced whatever the order is
         sub = rq.subset(mine)
         res = self.eng.find(sub)
+        self.last_find = (getattr(res, "kernel_ms", 0.0), getattr(res, "bytes", 0))   # this rank's placement launch: HIP-event ms, algorithmic bytes
         nd = int(res.a["dom_off"][-1])
         part = (mine, {k: (v[:nd] if k in ("dom_leaf", "dom_count") else v) for k, v in res.a.items()})
         off = sub.arrays["wl_off"]

@@ -76,7 +76,7 @@ def generate_tas_cycle(n_cq: int = 1000, n_pending: int = 50_000, seed: int = TA
     topologies = {"tas-flavor": topo}
     prio = rng.integers(0, 4, size=n_pending)
 
-    def batch(c: int):
+    def workloads_of(c: int):
         wls, pod_tas = [], {}
         for i in range(n_cq):
             w = c * n_cq + i
@@ -87,8 +87,69 @@ def generate_tas_cycle(n_cq: int = 1000, n_pending: int = 50_000, seed: int = TA
             name = f"ns/wl-{w:05d}"
             wls.append(Workload(name, f"cq-{i:04d}", priority=int(prio[w]), creation_ts=w, pod_sets=[PodSet("main", count=ps.count, requests=reqs)]))
             pod_tas[(name, 0)] = PodSetTAS(ps.topology_request, None, dict(ps.single_pod_requests))
+        return wls, pod_tas
+
+    def batch(c: int):
         from .api import Heads
+        wls, pod_tas = workloads_of(c)
         heads = Heads(snap, wls, cycle=c + 1)
         return heads, CycleTAS(snap, heads, topologies, pod_tas)
 
+    batch.closed_loop = lambda hold=0: TASClosedLoop(cqs, [Cohort(f"cohort-{j:02d}") for j in range(cohorts)], topologies, workloads_of, hold)
     return snap, topologies, batch
+
+
+class TASClosedLoop:
+    """BASELINE configs[4] as a CLOSED loop, driven the way the reference drives it (scheduler.go:308-386 with manager.go:903): every
+    cycle starts from a fresh cache.Snapshot() that holds what the cycles before it admitted — their rows, their quota usage and their
+    TopologyAssignments as TAS usage of the leaves (workload.TASUsage) — and takes the next head of every ClusterQueue. `cycle_input(c)`
+    -> (Snapshot [derived], Heads, CycleTAS); `fold(heads, decisions, tas_out)` turns the cycle's admissions into admitted workloads.
+    The same object feeds the engine and the oracle, so a parity gate over k cycles compares k dependent cycles."""
+
+    def __init__(self, cqs, cohorts, topologies, workloads_of, hold: int = 0):
+        """hold > 0: a workload finishes `hold` cycles after the cycle that admitted it (its row, quota and leaf usage leave the cache)."""
+        self.cqs, self.cohorts, self.topologies, self.workloads_of, self.hold = cqs, cohorts, topologies, workloads_of, hold
+        self.admitted = []          # api.Workload with PodSet.flavors
+        self.admitted_tas = {}      # name -> [AdmittedTAS]
+        self.cycle = 0
+
+    def cycle_input(self):
+        from .api import Heads, Snapshot
+        from .tas_cycle import CycleTAS
+        snap = Snapshot(self.cqs, self.cohorts, list(self.admitted), extra_resources=["pods"])
+        snap.derive()
+        wls, pod_tas = self.workloads_of(self.cycle)
+        heads = Heads(snap, wls, cycle=self.cycle + 1)
+        self._pod_tas = pod_tas
+        return snap, heads, CycleTAS(snap, heads, self.topologies, pod_tas, admitted_tas=self.admitted_tas)
+
+    def fold(self, heads, d, tout) -> int:
+        """The cycle's admissions -> admitted workloads (flavors from the decision, TAS usage from its TopologyAssignment). -> how many."""
+        import copy
+        from . import _ffi as F
+        from .tas_cycle import AdmittedTAS
+        n = 0
+        for i, w in enumerate(heads.workloads):
+            if int(d.a["action"][i]) != F.ACT_ADMIT:
+                continue
+            fl = d.flavors_of(i)
+            aw = copy.deepcopy(w)
+            aw.reserve_ts = 10 ** 12 + self.cycle * 10 ** 6 + i
+            tas = []
+            for pi, ps in enumerate(aw.pod_sets):
+                ps.flavors = {r: v[0] for r, v in fl[pi].items()}
+                ta = tout.topology_assignment(i, pi)
+                if ta is not None:
+                    tas.append(AdmittedTAS(ta[0], [(tuple(vals), cnt) for vals, cnt in ta[1]], dict(self._pod_tas[(w.name, pi)].single_pod_requests)))
+            aw._admitted_in = self.cycle
+            self.admitted.append(aw)
+            if tas:
+                self.admitted_tas[aw.name] = tas
+            n += 1
+        if self.hold > 0:
+            gone = [w for w in self.admitted if w._admitted_in <= self.cycle - self.hold]
+            for w in gone:
+                self.admitted_tas.pop(w.name, None)
+            self.admitted = [w for w in self.admitted if w._admitted_in > self.cycle - self.hold]
+        self.cycle += 1
+        return n

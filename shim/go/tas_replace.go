@@ -173,7 +173,11 @@ func (t *TAS) ExclusionStats(r *TASRequests, x *TASReplacement, res *TASResult, 
 }
 
 // ExclusionTail is what notFitMessage :1997 appends: ". Total nodes: N; excluded: ..." (formatReasons :500), "" without exclusions.
+// The gate is hasExclusions (:496), which does not look at SchedulerLibraryNoFit: a podset whose only exclusion is that count gets no tail.
 func (s *TASExclusions) ExclusionTail() string {
+	if !(s.NodeSelector > 0 || s.Affinity > 0 || len(s.Taints) > 0 || s.TopologyDomain > 0 || len(s.Resources) > 0) {
+		return ""
+	}
 	var reasons []string
 	if s.NodeSelector > 0 {
 		reasons = append(reasons, fmt.Sprintf("nodeSelector: %d", s.NodeSelector))
@@ -192,9 +196,6 @@ func (s *TASExclusions) ExclusionTail() string {
 	}
 	for k, v := range s.Resources {
 		reasons = append(reasons, fmt.Sprintf("resource %q: %d", k, v))
-	}
-	if len(reasons) == 0 {
-		return ""
 	}
 	sort.Strings(reasons)
 	return fmt.Sprintf(". Total nodes: %d; excluded: %s", s.TotalNodes, strings.Join(reasons, ", "))

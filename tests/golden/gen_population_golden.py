@@ -27,10 +27,49 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 # name -> (generate kwargs, fair sharing, cycles)
 CASES = {
-    "cfg4c": (dict(cfg=4), False, [0]),
-    "cfg4f": (dict(cfg=4, fair_sharing=True), True, [0]),
+    "cfg4c": (dict(cfg=4), False, [0, 1]),
+    "cfg4f": (dict(cfg=4, fair_sharing=True), True, [0, 1]),
     "cfg3f": (dict(cfg=3, fair_sharing=True), True, [0]),
 }
+
+
+def cycle_input(pop, name, c):
+    """(snapshot, heads) of cycle c. Cycle 0: the population as generated. Cycle 1 (configs[3] at full size was pinned on
+    one cycle only): the snapshot after kq_cycle_commit of cycle 0 — the usage of every workload the COMMITTED cycle-0 golden admitted
+    is added to its ClusterQueue (flavor per resource from the golden's decision, quantity from the head's requests, the pods
+    resource = the podset's count), cohort usage re-derived; rows stay (issued preemptions have not been carried out yet, and
+    kq_cycle_commit does not append rows) — and the SECOND workload of every ClusterQueue as heads: 1000 other preemptors on the
+    over-committed snapshot. The successor is built from the committed cycle-0 expectation, so the chain is pinned end to end."""
+    import copy
+    heads = pop.heads_for_cycle(c, cycle=c + 1)
+    if c == 0:
+        return pop.snapshot, heads
+    assert c == 1
+    g = np.load(path_of(name, 0))
+    base = pop.snapshot
+    h0 = pop.heads_for_cycle(0, cycle=1)
+    ha = h0.arrays
+    nR, nfr = base.n_resource, base.n_fr
+    usage = base.arrays["usage"].reshape(base.N, nfr).copy()
+    usage[base.n_cq:] = 0   # (cohort rows are re-derived below)
+    pods = base.resource_index.get("pods", -1)
+    for i in np.flatnonzero(g["action"] == 1):   # KQ_ACT_ADMIT
+        cq = int(ha["cq"][i])
+        for p in range(int(ha["ps_off"][i]), int(ha["ps_off"][i + 1])):
+            req = {int(ha["req_res"][k]): int(ha["req_qty"][k]) for k in range(int(ha["ps_req_off"][p]), int(ha["ps_req_off"][p + 1]))}
+            for r in range(nR):
+                fl = int(g["flavor"][p * nR + r])
+                if fl < 0:
+                    continue
+                q = int(g["ps_count"][p]) if r == pods else req.get(r, 0)
+                usage[cq, fl * nR + r] += q
+    snap = copy.copy(base)
+    snap.arrays = dict(base.arrays)
+    snap.arrays["usage"] = usage.reshape(-1)
+    snap._struct = None
+    snap.derived = False
+    snap.derive()
+    return snap, type(heads).from_arrays(snap, dict(heads.arrays), cycle=c + 1)
 
 
 def digest_inputs(snap, heads) -> str:
@@ -55,9 +94,12 @@ def main(names):
         pop = generate(**kw)
         cfg = make_config(fair_sharing=fair)
         for c in cycles:
-            heads = pop.heads_for_cycle(c, cycle=c + 1)
+            if os.path.exists(path_of(name, c)) and not os.environ.get("KQ_GOLDEN_FORCE"):
+                print(f"{name} cycle {c}: {path_of(name, c)} exists (KQ_GOLDEN_FORCE=1 rewrites it)", flush=True)
+                continue
+            snap, heads = cycle_input(pop, name, c)
             t0 = time.perf_counter()
-            want = kqo.cycle_run(cfg, pop.snapshot, heads, want_usage=True)
+            want = kqo.cycle_run(cfg, snap, heads, want_usage=True)
             dt = time.perf_counter() - t0
             m = int(want.a["tgt_off"][-1])
             out = {k: v for k, v in want.a.items() if k not in ("tgt_adm", "tgt_reason")}
@@ -65,7 +107,7 @@ def main(names):
             out["tgt_reason"] = want.a["tgt_reason"][:m]
             out["usage_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(want.usage_after).tobytes()).digest(), np.uint8)
             out["bytes_total"] = np.array([want.stats["total"]], np.int64)
-            out["inputs_sha256"] = np.frombuffer(bytes.fromhex(digest_inputs(pop.snapshot, heads)), np.uint8)
+            out["inputs_sha256"] = np.frombuffer(bytes.fromhex(digest_inputs(snap, heads)), np.uint8)
             out["oracle_seconds"] = np.array([dt])
             np.savez_compressed(path_of(name, c), **out)
             print(f"{name} cycle {c}: {heads.n} heads, {m} targets, oracle {dt:.1f} s -> {path_of(name, c)}", flush=True)

@@ -9,7 +9,7 @@ import pytest
 
 from kueue_amd.api import make_config
 from kueue_amd.population import generate
-from tests.golden.gen_population_golden import CASES, digest_inputs, path_of
+from tests.golden.gen_population_golden import CASES, cycle_input, digest_inputs, path_of
 
 PRESENT = [(n, c) for n, (_, _, cycles) in CASES.items() for c in cycles if os.path.exists(path_of(n, c))]
 _pops = {}
@@ -30,8 +30,8 @@ def test_golden_inputs_are_current(name, cycle):
     """The committed expectation belongs to the population the generator produces today (seeded, deterministic)."""
     g = np.load(path_of(name, cycle))
     pop = _pop(name)
-    heads = pop.heads_for_cycle(cycle, cycle=cycle + 1)
-    assert digest_inputs(pop.snapshot, heads) == bytes(g["inputs_sha256"]).hex()
+    snap, heads = cycle_input(pop, name, cycle)
+    assert digest_inputs(snap, heads) == bytes(g["inputs_sha256"]).hex()
     assert len(g["status"]) == heads.n
 
 
@@ -43,10 +43,10 @@ def test_engine_matches_offline_oracle(name, cycle):
     pop = _pop(name)
     fair = CASES[name][1]
     cfg = make_config(fair_sharing=fair)
-    heads = pop.heads_for_cycle(cycle, cycle=cycle + 1)
+    snap, heads = cycle_input(pop, name, cycle)
     eng = Engine(cfg)
     try:
-        eng.put(pop.snapshot)
+        eng.put(snap)
         m = int(g["tgt_off"][-1])
         got = eng.run(heads, tgt_cap=max(4096, (32 if fair else 4) * pop.snapshot.n_adm))
         for k in ("status", "action", "nominated_mode", "mode", "requeue_reason", "skip", "borrowing", "order", "flavor", "res_mode",
