@@ -16,7 +16,8 @@
  * Node replacement (the HasUnhealthyNodes branch :608-633): kq_tas_find_replacement — findReplacementAssignment :686,
  * requiredReplacementDomain :759, findIncompleteSliceDomain :842, mergeTopologyAssignments :2072, the BelongsTo test of fillLeafCounts
  * :1902. The node-exclusion statistics of notFitMessage :1997 (tasExclusionStats :470): kq_tas_exclusion_stats.
- * Not covered (status KQ_TAS_UNSUPPORTED): TASBalancedPlacement, TASRespectNodeAffinityPreferred (both default-off gates).
+ * Not covered: TASBalancedPlacement, TASRespectNodeAffinityPreferred (both default-off gates): a caller that runs with one of them ON says so
+ * in kq_tas_topology.profile_mixed (KQ_TAS_F_*) and gets KQ_EUNSUPPORTED from kq_tas_topology_put / kq_cycle_run_tas.
  *
  * Canonical order: the domains of every level are numbered in the lexicographic order of their levelValues
  * (compareDomainLevelValues :1727), so every "levelValues ascending" tie-break is an integer compare.
@@ -53,11 +54,18 @@ extern "C" {
                                      snapshot; operand a = index of that domain in the podset's existing list */
 #define KQ_TAS_NO_REPLACEMENT 10  /* :727 "cannot find replacement assignment for unhealthy node" */
 
+#define KQ_TAS_F_PROFILE_MIXED       1
+#define KQ_TAS_F_BALANCED_PLACEMENT  2   /* tas_balanced_placement.go (gate TASBalancedPlacement, kube_features.go:692): not implemented */
+#define KQ_TAS_F_AFFINITY_PREFERRED  4   /* TASRespectNodeAffinityPreferred: not implemented */
+
 typedef struct kq_tas_topology {
   int32_t n_levels;               /* len(levelKeys) */
   int32_t n_resources;
   int32_t pods_resource;          /* index of corev1.ResourcePods (resources.OnePodRequest is added to every request) */
-  int32_t profile_mixed;          /* features.TASProfileMixed: LeastFreeCapacity for unconstrained podsets (:1468) */
+  int32_t profile_mixed;          /* feature bits (the name is the first one's; 0 / 1 as before): KQ_TAS_F_PROFILE_MIXED = features.TASProfileMixed,
+                                     LeastFreeCapacity for unconstrained podsets (:1468). KQ_TAS_F_BALANCED_PLACEMENT / _AFFINITY_PREFERRED: the caller
+                                     runs with TASBalancedPlacement / TASRespectNodeAffinityPreferred ON (both alpha, default off) — paths this library
+                                     does not have: kq_tas_topology_put / kq_cycle_run_tas return KQ_EUNSUPPORTED and the caller keeps its Go path */
   const int32_t* level_off;       /* [n_levels+1] offsets of each level's domains in `parent` */
   const int32_t* parent;          /* [level_off[n_levels]] index (within the level above) of the parent domain; level 0: -1 */
   /* leaves = domains of the last level, n_leaves = level_off[n_levels] - level_off[n_levels-1] */

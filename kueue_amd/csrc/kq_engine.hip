@@ -450,6 +450,10 @@ struct HipBackend {
     if (!p) return nullptr;
     chk(hipMemset(p, 0xC7, GW), "guard fill");
     chk(hipMemset(p + GW + n, 0xC7, body - n + GW), "guard fill");
+    // ... and the buffer itself is POISONED (0xA5, as the emulation's allocator does): hipMalloc hands out whatever the previous owner of
+    // the pages left — zeroes in a fresh process, garbage in a long-lived one — so code that only works on zero-initialised memory
+    // passes every short test and faults in a controller that has been up for a day (or in the 400th test of a pytest worker)
+    if (n) chk(hipMemset(p + GW, 0xA5, n), "poison fill");
     guards.push_back(GuardRec{p, n});
     return p + GW;
   }

@@ -1000,7 +1000,8 @@ template <class B> struct EngineT {
       TK& tk = tks[i];
       tk = TK{};
       TTopo& T = tk.T;
-      T.L = tp.n_levels; T.R = R; T.pods = tp.pods_resource; T.profile_mixed = tp.profile_mixed;
+      if (tp.profile_mixed & ~KQ_TAS_F_PROFILE_MIXED) return fail(KQ_EUNSUPPORTED, "TASBalancedPlacement / TASRespectNodeAffinityPreferred are not implemented: keep the Go path while the gate is on");
+      T.L = tp.n_levels; T.R = R; T.pods = tp.pods_resource; T.profile_mixed = tp.profile_mixed & KQ_TAS_F_PROFILE_MIXED;
       for (int l = 0; l <= T.L; l++) T.level_off[l] = tp.level_off[l];
       T.D = T.level_off[T.L]; T.leaf_base = T.level_off[T.L - 1]; T.n_leaves = T.D - T.leaf_base;
       for (int l = 0; l < T.L; l++) if (T.level_off[l + 1] < T.level_off[l]) return fail(KQ_EINVAL, "level_off not monotone");

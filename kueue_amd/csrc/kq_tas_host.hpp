@@ -91,8 +91,9 @@ template <class Backend> struct TasT {
     free_topo();
     if (t->n_levels < 1 || t->n_levels > KQ_TAS_MAX_LEVELS) return fail(KQ_EUNSUPPORTED, "n_levels out of range");
     if (t->n_resources < 1 || t->n_resources > KQ_TAS_MAXR) return fail(KQ_EUNSUPPORTED, "n_resources out of range");
+    if (t->profile_mixed & ~KQ_TAS_F_PROFILE_MIXED) return fail(KQ_EUNSUPPORTED, "TASBalancedPlacement / TASRespectNodeAffinityPreferred are not implemented: keep the Go path while the gate is on");
     T = TTopo{};
-    T.L = t->n_levels; T.R = t->n_resources; T.pods = t->pods_resource; T.profile_mixed = t->profile_mixed;
+    T.L = t->n_levels; T.R = t->n_resources; T.pods = t->pods_resource; T.profile_mixed = t->profile_mixed & KQ_TAS_F_PROFILE_MIXED;
     for (int l = 0; l <= T.L; l++) T.level_off[l] = t->level_off[l];
     T.D = T.level_off[T.L]; T.leaf_base = T.level_off[T.L - 1]; T.n_leaves = T.D - T.leaf_base;
     for (int l = 0; l < T.L; l++) if (T.level_off[l + 1] < T.level_off[l]) return fail(KQ_EINVAL, "level_off not monotone");
@@ -326,6 +327,20 @@ template <class Backend> struct TasT {
     std::vector<int32_t> slice_size(r->slice_size, r->slice_size + n), slice_level(r->slice_level, r->slice_level + n), group(r->group, r->group + n);
     std::vector<int32_t> n_layers(n, 0), stale(n, -1), req_dom(n, -1);
     if (r->n_layers) n_layers.assign(r->n_layers, r->n_layers + n);
+    // A workload's replacement podsets are placed one by one in podset order here. The reference walks groupsOrder — the first appearance
+    // of each PodSetGroupName — and the podsets inside a group (:594-633): for a workload whose group names interleave ([A, B, A]) that is
+    // 0, 2, 1, and the assumed usage a later replacement sees differs when they compete for the same leaves. Not restated: such a
+    // workload is KQ_EUNSUPPORTED (the caller keeps the Go path for it) instead of being placed in the other order.
+    for (int w = 0; w < nw; w++) {
+      bool repl = false;
+      for (int i = r->wl_off[w]; i < r->wl_off[w + 1]; i++) if (x->is_replacement[i]) repl = true;
+      if (!repl) continue;
+      for (int i = r->wl_off[w]; i < r->wl_off[w + 1]; i++) {
+        if (r->group[i] < 0) continue;
+        int last = i;
+        for (int j = i + 1; j < r->wl_off[w + 1]; j++) if (r->group[j] == r->group[i]) { if (j != last + 1) return fail(KQ_EUNSUPPORTED, "node replacement of a workload whose podset groups interleave"); last = j; }
+      }
+    }
     bool any = false;
     for (int i = 0; i < n; i++) {
       if (!x->is_replacement[i]) continue;

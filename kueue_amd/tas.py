@@ -106,6 +106,7 @@ class Topology:
                  resources: Optional[Sequence[str]] = None, profile_mixed: bool = True):
         self.levels = list(levels)
         self.profile_mixed = profile_mixed
+        self.feature_bits = 0   # KQ_TAS_F_BALANCED_PLACEMENT (2) / KQ_TAS_F_AFFINITY_PREFERRED (4): gates the library does not implement -> KQ_EUNSUPPORTED
         L = len(self.levels)
         self.lowest_is_node = self.levels[-1] == HOSTNAME_LABEL
         res = set(resources or [])
@@ -197,7 +198,7 @@ class Topology:
         if self._struct is None:
             self._struct = kq_tas_topology()
         F.fill_struct(self._struct, self.arrays, dict(n_levels=len(self.levels), n_resources=len(self.resources),
-                                                      pods_resource=self.resource_index["pods"], profile_mixed=1 if self.profile_mixed else 0))
+                                                      pods_resource=self.resource_index["pods"], profile_mixed=(1 if self.profile_mixed else 0) | self.feature_bits))
         return self._struct
 
     def leaf_of_values(self, values: Sequence[str]) -> int:

@@ -44,7 +44,8 @@ func FlattenTAS(snap *schdcache.Snapshot, fs *FlatSnapshot, ix *Index, heads []*
 		tasIdx[n] = int32(i)
 		tc.TASFlavor = append(tc.TASFlavor, ix.Flavor[n])
 		tc.Topos = append(tc.Topos, FlatTopology{NLevels: int32(len(f.LevelKeys)), NResources: int32(nR), PodsResource: fs.PodsResource,
-			ProfileMixed: features.Enabled(features.TASProfileMixed), LevelOff: f.LevelOff, Parent: f.Parent,
+			ProfileMixed: features.Enabled(features.TASProfileMixed), BalancedPlacement: features.Enabled(features.TASBalancedPlacement),
+			AffinityPreferred: features.Enabled(features.TASRespectNodeAffinityPreferred), LevelOff: f.LevelOff, Parent: f.Parent,
 			FreeCapacity: f.FreeCapacity, TASUsage: slices.Clone(f.TASUsage), LeafValues: f.LeafValues})
 	}
 	// isTASOnly (clusterqueue.go:746)

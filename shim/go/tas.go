@@ -42,6 +42,7 @@ var ErrUnsupported = errors.New("kqengine: the cycle is outside the device path 
 // order (utiltas.DomainID order, tas_flavor_snapshot.go:1770 sorts by it last), leaves last.
 type FlatTopology struct {
 	NLevels, NResources, PodsResource int32
+	BalancedPlacement, AffinityPreferred bool // gates the library does not implement (-> KQ_EUNSUPPORTED)
 	ProfileMixed                      bool    // features.TASProfileMixed
 	LevelOff, Parent                  []int32 // Parent: index within the level above, -1 at level 0
 	FreeCapacity, TASUsage            []int64 // [leaves][resources]: leafCapacity.freeCapacity :88 / tasUsage
@@ -87,7 +88,15 @@ func fillTopology(p *runtime.Pinner, c *C.kq_tas_topology, t *FlatTopology) {
 	c.n_resources = C.int32_t(t.NResources)
 	c.pods_resource = C.int32_t(t.PodsResource)
 	if t.ProfileMixed {
-		c.profile_mixed = 1
+		c.profile_mixed = C.KQ_TAS_F_PROFILE_MIXED
+	}
+	// features.TASBalancedPlacement / TASRespectNodeAffinityPreferred (alpha, default off): paths the library does not have — it answers
+	// KQ_EUNSUPPORTED and the scheduler keeps its own FindTopologyAssignmentsForFlavor while one of them is on
+	if t.BalancedPlacement {
+		c.profile_mixed |= C.KQ_TAS_F_BALANCED_PLACEMENT
+	}
+	if t.AffinityPreferred {
+		c.profile_mixed |= C.KQ_TAS_F_AFFINITY_PREFERRED
 	}
 	c.level_off = (*C.int32_t)(pin(p, t.LevelOff))
 	c.parent = (*C.int32_t)(pin(p, t.Parent))
