@@ -48,10 +48,11 @@ struct Fs {
   int64_t *ev_nv, *ev_sum; int32_t *ev_t, *ev_np; double* ev_v; uint8_t* ev_z;   // staging of one row operation: borrowed-amount deltas / borrowed-cell count deltas per (flavor-resource, level), share terms per (level, resource), result
   int32_t* pc_ptr; int64_t *pc_lq, *pc_sq, *pc_sqb, *pc_bl, *pc_lend; double* pc_wt; int32_t* pc_u;
   int32_t* tpos;
-  // per ClusterQueue of the tree: its path (tree-local ids, 4 x int16) and the almost-LCAs with the preemptor (fs_lcas), filled once per
-  // search; the landing area of fs_row_fetch (the candidate's record + the quota constants of its path, one round trip) and the
-  // flavor-resource of every cached column
-  uint64_t* cq_path; int32_t* cq_lca; int16_t* colfr; int64_t* sp_rec; FsQ* sp_q;
+  // per ClusterQueue of the tree: the almost-LCAs with the preemptor (fs_lcas), filled once per search. (Round 5 also tried the candidate's
+  // record and the quota constants of its path in ONE round trip through an LDS landing area instead of fs_row_load + fs_row_ctx's two
+  // dependent ones: the staging cost more than the round trip it saved — "row load + context" 1 086 -> 1 329 ms of the cfg 4f process
+  // kernel, profiles/r05d_prof_fair_cfg4f_process_only.txt — and was taken out again.)
+  int32_t* cq_lca;
   // the first tcap targets (row, reason, position) live in what LDS the state left over: a target pushed or moved is then no global
   // store, and every fence of the walk waits for the wave's outstanding global stores (fs_tget / fs_tset; flushed to trow / treason /
   // tpos when the search ends)
@@ -77,7 +78,7 @@ KQ_DEV void fs_assume_lds(const Fs& f) {
   FS_LDS(f.pc_ptr); FS_LDS(f.pc_lq); FS_LDS(f.pc_sq); FS_LDS(f.pc_sqb); FS_LDS(f.pc_bl); FS_LDS(f.pc_lend); FS_LDS(f.pc_wt); FS_LDS(f.pc_u);
   FS_LDS(f.bq_c); FS_LDS(f.bq_ord); FS_LDS(f.bq_k); FS_LDS(f.bq_h); FS_LDS(f.bq_z); FS_LDS(f.br_c); FS_LDS(f.br_ap); FS_LDS(f.br_at); FS_LDS(f.br_n); FS_LDS(f.br_off);
   FS_LDS(f.br_fl); FS_LDS(f.cl_pos); FS_LDS(f.cl_rk);
-  FS_LDS(f.cq_path); FS_LDS(f.cq_lca); FS_LDS(f.colfr); FS_LDS(f.sp_rec); FS_LDS(f.sp_q);
+  FS_LDS(f.cq_lca);
   if (f.tcap > 0) { FS_LDS(f.lt_row); FS_LDS(f.lt_pos); FS_LDS(f.lt_rs); }
   #undef FS_LDS
 #endif
@@ -104,7 +105,7 @@ size_t fs_bytes(int nn, int nqs, int nR, int nfr, int mw, int ncols) {
   b += al(FS_BQ * 2) * 2 + al(FS_BQ * 8) * 2 + al(FS_BQ);                                          // bq_c bq_ord bq_k bq_h bq_z
   b += al(FS_BQ * 2) * 4 + al((FS_BQ + 1) * 2) + al(FS_BQ);                                        // br_*
   b += al(FS_BC * 4) + al(FS_BC);                                                                  // cl_*
-  b += al((size_t)nqs * 8) + al((size_t)nqs * 4) + al(FS_NCMAX * 2) + al(64) + al(FS_LV * FS_NCMAX * 16);   // cq_path cq_lca colfr sp_rec sp_q
+  b += al((size_t)nqs * 4);   // cq_lca
   return b + 256;
 }
 
@@ -671,8 +672,7 @@ KQ_DEV bool fs_setup(Search& s, Fs& f) {
   f.br_c = (int16_t*)cv.take(FS_BQ * 2); f.br_ap = (int16_t*)cv.take(FS_BQ * 2); f.br_at = (int16_t*)cv.take(FS_BQ * 2); f.br_n = (int16_t*)cv.take(FS_BQ * 2);
   f.br_off = (int16_t*)cv.take((FS_BQ + 1) * 2); f.br_fl = (uint8_t*)cv.take(FS_BQ);
   f.cl_pos = (int32_t*)cv.take(FS_BC * 4); f.cl_rk = (uint8_t*)cv.take(FS_BC);
-  f.cq_path = (uint64_t*)cv.take((size_t)f.nqs * 8); f.cq_lca = (int32_t*)cv.take((size_t)f.nqs * 4); f.colfr = (int16_t*)cv.take(FS_NCMAX * 2);
-  f.sp_rec = (int64_t*)cv.take(64); f.sp_q = (FsQ*)cv.take(FS_LV * FS_NCMAX * 16);
+  f.cq_lca = (int32_t*)cv.take((size_t)f.nqs * 4);
   f.tcap = 0; f.lt_row = nullptr; f.lt_pos = nullptr; f.lt_rs = nullptr;
   if (all_lds) {
     const size_t left = (size_t)(cv.ae - cv.a);
@@ -689,7 +689,7 @@ KQ_DEV bool fs_setup(Search& s, Fs& f) {
   #pragma unroll
   for (int q = 0; q < FS_NCMAX; q++) {
     if (q >= nc) continue;
-    if (lane == 0) { f.colslot[colfr[q]] = (int8_t)q; f.colfr[q] = (int16_t)colfr[q]; }
+    if (lane == 0) f.colslot[colfr[q]] = (int8_t)q;
   }
   // tree-local ids of the preemptor's path
   if (lane == 0) for (int i = 0; i < w.plen; i++) w.cs_pl[i] = S.node_local[w.path[i]];
@@ -731,14 +731,9 @@ KQ_DEV void fs_init(Fs& f) {
   }
   wsync();
   for (int i = lane; i < f.nn; i += WAVE) fs_refresh(f, i, S.fs_lend + (size_t)(f.n0 + i) * f.nR, S.fs_weight[f.n0 + i]);
-  // per ClusterQueue: its path and its almost-LCAs with the preemptor (least_common_ancestor.go:27-58) — a visit read them through three
-  // dependent LDS round trips each (0.6 of the 6.3 s the first strategy took at cfg 4f, profiles/r04k_prof_fair_cfg4f_process_only.txt)
+  // per ClusterQueue: its almost-LCAs with the preemptor (least_common_ancestor.go:27-58) — a visit read them through three dependent LDS
+  // round trips (602 -> 378 ms of the 6.3 s the first strategy takes at cfg 4f, profiles/r04k_* vs r05d_prof_fair_cfg4f_process_only.txt)
   for (int q = lane; q < f.nqs; q += WAVE) {
-    uint64_t pw = 0;
-    int cur = q;
-    #pragma unroll
-    for (int i = 0; i < FS_LV; i++) { pw |= (uint64_t)(uint16_t)(int16_t)cur << (16 * i); if (cur >= 0) cur = f.par[cur]; }
-    f.cq_path[q] = pw;
     int ap = f.wli, at = q;
     fs_lcas(f, q, &ap, &at);
     f.cq_lca[q] = (int32_t)(((uint32_t)(uint16_t)(int16_t)at << 16) | (uint32_t)(uint16_t)(int16_t)ap);
@@ -746,66 +741,6 @@ KQ_DEV void fs_init(Fs& f) {
   wsync();
 }
 KQ_DEV void fs_lca_get(const Fs& f, int q, int* ap, int* at) { const uint32_t v = (uint32_t)f.cq_lca[q]; *ap = (int16_t)(v & 0xffff); *at = (int16_t)(v >> 16); }
-
-// The record of the candidate at position p of ClusterQueue q AND the constants of its row operation — localQuota / SubtreeQuota of every
-// (path level, cached column), lendable and weight of the path nodes — in ONE round trip: the constants depend on the ClusterQueue's path
-// and on the row's flavor, and a candidate uses a flavor the preemptor needs, i.e. cached columns. fs_row_load + fs_row_ctx were two
-// dependent round trips (record, then the cells its fr[] name): 1.1 of the 6.3 s of the first strategy. Lanes 0-3 fetch the record's four
-// 16-byte quarters, the lanes behind them one (level, column) cell each, all through the same 16-byte load; the landing area is LDS. A row
-// that touches a column outside the cache (another flavor of a multi-flavor workload) takes fs_row_ctx's gather after all.
-KQ_DEV FsRow fs_row_fetch(Fs& f, int q, int p) {
-  const DSnap& S = f.k->S;
-  const int lane = lane_id();
-  const uint64_t pw = f.cq_path[q];
-  int lp[FS_LV];
-  int plen = 0;
-  #pragma unroll
-  for (int i = 0; i < FS_LV; i++) { lp[i] = (int16_t)(pw >> (16 * i)); if (lp[i] >= 0) plen = i + 1; }
-  const int ncell = plen * f.nc;
-  for (int L = lane; L < 4 + ncell; L += WAVE) {   // (FsQ doubles as the 16-byte carrier of a record quarter)
-    const FsQ* src; FsQ* dst;
-    if (L < 4) { src = (const FsQ*)(S.fs_apply + (size_t)f.row0 + p) + L; dst = (FsQ*)f.sp_rec + L; }
-    else {
-      const int i = (L - 4) / f.nc, c = (L - 4) % f.nc;
-      src = S.fs_q + (size_t)(f.n0 + fs_sel4(lp, i)) * f.nfr + f.colfr[c];
-      dst = f.sp_q + i * FS_NCMAX + c;
-    }
-    *dst = *src;
-  }
-  for (int j = lane; j < FS_LV * KQ_MAXR + FS_LV; j += WAVE) {
-    if (j < FS_LV * KQ_MAXR) {
-      const int i = j / KQ_MAXR, rr = j % KQ_MAXR;
-      if (i < plen && rr < f.nR) f.rc_lend[j] = S.fs_lend[(size_t)(f.n0 + fs_sel4(lp, i)) * f.nR + rr];
-    } else {
-      const int i = j - FS_LV * KQ_MAXR;
-      if (i < plen) f.rc_wt[i] = S.fs_weight[f.n0 + fs_sel4(lp, i)];
-    }
-  }
-  wsync();
-  const FsApply ap = *(const FsApply*)f.sp_rec;
-  FsRow r;
-  #pragma unroll
-  for (int e = 0; e < CS_RFR; e++) { r.qty[e] = ap.qty[e]; r.fr[e] = ap.fr[e]; r.res[e] = ap.fr[e] >= 0 ? (int)ap.res[e] : -1; }
-  #pragma unroll
-  for (int l = 0; l < FS_LV; l++) r.lp[l] = ap.lp[l];
-  r.plen = ap.plen; r.row = ap.row; r.cbytes = ap.cbytes; r.hkey = ap.hkey;
-  r.rowbytes = 16 * (int)ap.plen * (((int)ap.cbytes - 32) / 12);
-  bool miss = false;
-  #pragma unroll
-  for (int e = 0; e < CS_RFR; e++) if (r.fr[e] >= 0 && f.colslot[r.fr[e]] < 0) miss = true;
-  if (miss) { fs_row_ctx(f, r); return r; }
-  for (int c = lane; c < FS_RC; c += WAVE) {
-    const int u = c / FS_LV, i = c % FS_LV;
-    const int fr = fs_sel4(r.fr, u), li = fs_sel4(r.lp, i);
-    if (fr < 0 || i >= r.plen) continue;
-    const int sl = f.colslot[fr];
-    const FsQ qq = f.sp_q[i * FS_NCMAX + sl];
-    f.rc_lq[c] = fs_cap(qq.lq); f.rc_sqb[c] = fs_cap(qq.sqb);
-    f.rc_ptr[c] = sl * f.nn + li;
-  }
-  wsync();
-  return r;
-}
 
 // getAlmostLCAs (least_common_ancestor.go:27-58): the nodes just below the lowest common ancestor on the preemptor's and on the
 // target ClusterQueue's path (tree-local ids), from the tree's parent table
@@ -1419,7 +1354,8 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
       if (cand < 0) break;
       if (cand == f.wli || within_nominal) {
         const int p = fs_pop(f, cand, f.m1, nullptr);
-        const FsRow r = fs_row_fetch(f, cand, p);
+        const FsRow r = fs_row_load(f, p);
+        fs_row_ctx(f, r);
         fs_row_apply(f, r, false, true, true);
         if (!fs_push_target(f, &nt, r.row, p, cand == f.wli ? KQ_REASON_IN_CLUSTER_QUEUE : KQ_REASON_IN_COHORT_RECLAMATION)) { w.ntgt = 0; return true; }
         tbytes += r.rowbytes;
@@ -1475,7 +1411,8 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
       while (fs_cq_has(f, cand)) {
         const int p = fs_pop(f, cand, f.m1, nullptr);
         KQ_LS(w, 1);
-        const FsRow r = fs_row_fetch(f, cand, p);
+        const FsRow r = fs_row_load(f, p);
+        fs_row_ctx(f, r);
         KQ_LS(w, 2);
         // ComputeTargetShareAfterRemoval target.go:67-73: RemoveWorkload, share of the target's side, AddWorkload. The state after
         // the pair is the state before it (plain amounts, see fs_fits), so the removal is only evaluated.
