@@ -177,6 +177,21 @@ int  kq_tas_find_replacement(kq_tas*, const kq_tas_requests* r, const kq_tas_rep
 int  kq_tas_exclusion_stats(kq_tas*, const kq_tas_requests* r, const kq_tas_replacement* x, const kq_tas_result* res, int32_t n_sel,
                             const int32_t* podsets, const int32_t* resource_rank, int32_t* topology_domain, int32_t* resources);
 
+/* FindTopologyAssignmentsForFlavor for callers running with features.ElasticJobsViaWorkloadSlicesWithTAS (alpha, default off): a podset that
+ * carries TASPodSetRequests.PreviousAssignment (:388 — the TopologyAssignment of the workload slice it replaces, tas_flavorassigner.go:132)
+ * takes handleElasticWorkload (tas_elastic_workloads.go:37-165): the previous pods stay where they are —
+ *   count > previous: only the delta is placed (findTopologyAssignment for count - previous, the previous pods of workers and leader
+ *                     consuming capacity as assumed usage :97-106), and merged into the previous assignment (mergeTopologyAssignments
+ *                     :2072); a leader that has a previous assignment keeps it and is not part of the delta placement;
+ *   count < previous: TruncateAssignment (util/tas/tas_assignment.go:528) in the assignment's domain order; count == previous: reused;
+ *   a previous assignment (workers' or leader's) that names a domain the snapshot no longer holds (IsTopologyAssignmentStale :818,
+ *   ex_leaf = -1): fresh placement, as if there were none.
+ * `prev` has the layout of kq_tas_replacement: is_replacement[i] = 1 where podset i carries a PreviousAssignment, ex_* = its domains in the
+ * assignment's order. Podsets without one, and workloads none of whose podsets has one, are placed as by kq_tas_find. The assumed usage
+ * of the previous pods is seeded when the workload's placement starts, which is what the reference does for a workload of ONE podset
+ * group (the elastic jobs: workers, or leader + workers); an elastic workload with several podset groups is KQ_EUNSUPPORTED. */
+int  kq_tas_find_elastic(kq_tas*, const kq_tas_requests* r, const kq_tas_replacement* prev, kq_tas_result* out);
+
 int  kq_tas_last_stats(kq_tas*, double* kernel_ms, int64_t* bytes);
 const char* kq_tas_last_error(kq_tas*);
 

@@ -1168,6 +1168,11 @@ int kq_tas_overflow(kq_tas* t, const int64_t* plane_dev, uint8_t* leaf_over, int
   (void)hipSetDevice(t->e.be.device);
   KQ_TRY(t, return t->e.overflow(plane_dev, leaf_over, n_over));
 }
+int kq_tas_find_elastic(kq_tas* t, const kq_tas_requests* r, const kq_tas_replacement* prev, kq_tas_result* out) {
+  if (!t || !r || !prev || !out) return KQ_EINVAL;
+  (void)hipSetDevice(t->e.be.device);
+  KQ_TRY(t, return t->e.find_elastic(r, prev, out));
+}
 int kq_tas_find_replacement(kq_tas* t, const kq_tas_requests* r, const kq_tas_replacement* x, kq_tas_result* out) {
   if (!t || !r || !x || !out) return KQ_EINVAL;
   (void)hipSetDevice(t->e.be.device);

@@ -37,6 +37,9 @@ struct TReq {
   const int32_t *slice_size, *slice_level, *group;
   const uint8_t* leaf_ok;
   const int32_t *n_layers, *layer_level, *layer_size;  // TASMultiLayerTopology: NULL = single layer everywhere
+  // kq_tas_find_elastic: assumed usage a workload starts with — the previous pods of its elastic slice (handleScaleUp
+  // tas_elastic_workloads.go:97-106): CSR per workload of (leaf, count, podset whose SinglePodRequests the pods carry); NULL = none
+  const int32_t *seed_off, *seed_leaf, *seed_count, *seed_ps;
 };
 struct TOut {
   int32_t *status, *op_a, *op_b, *dom_pos, *dom_n;  // per podset request; dom_pos = offset into the pool
@@ -1225,11 +1228,21 @@ template <bool LDS> KQ_DEV void t_workload_t(const TK& k, int slot, int w) {
     if (Q.group[p] >= 0) for (int q = p0; q < p; q++) if (Q.group[q] == Q.group[p]) firstOfGroup = false;
     if (firstOfGroup) ngroups++;
   }
-  const bool track = ngroups > 1;
+  const int sd0 = Q.seed_off ? Q.seed_off[w] : 0, sd1 = Q.seed_off ? Q.seed_off[w + 1] : 0;
+  const bool seeded = sd1 > sd0;
+  const bool track = ngroups > 1 || seeded;
   TPROF0();
   if (lane == 0) s.meta[0] = 0;
   if (track) { for (int i = lane; i < T.n_leaves * T.R; i += WAVE) s.assumed[i] = 0; wsync(); }
-  bool failed = false, hasAssumed = false;
+  if (seeded) {   // addAssumedUsage :734 of the previous pods (one lane per resource: the entries of a workload may name a leaf twice)
+    for (int r = lane; r < T.R; r += WAVE)
+      for (int j = sd0; j < sd1; j++) {
+        const int64_t c = Q.seed_count[j];
+        s.assumed[(size_t)Q.seed_leaf[j] * T.R + r] += Q.spr[(size_t)Q.seed_ps[j] * T.R + r] * c + (r == T.pods ? c : 0);
+      }
+    wsync();
+  }
+  bool failed = false, hasAssumed = seeded;
   for (int p = p0; p < p1; p++) {
     bool firstOfGroup = true;
     if (Q.group[p] >= 0) for (int q = p0; q < p; q++) if (Q.group[q] == Q.group[p]) firstOfGroup = false;
@@ -1283,7 +1296,7 @@ template <bool LDS> KQ_DEV void t_workload_t(const TK& k, int slot, int w) {
       }
     }
     if (f.status == KQ_TAS_OK) {
-      const int cls = k.C.n > 0 ? k.C.wl_class[w] : -1;
+      const int cls = (k.C.n > 0 && !seeded) ? k.C.wl_class[w] : -1;   // (a seeded workload's phase 1 sees its own assumed usage: no shared table)
       bool have = false;
       if (cls >= 0) {
         // start from the class's phase-1 table; the slot keeps it between workloads of the same class (the LDS copy is filled every

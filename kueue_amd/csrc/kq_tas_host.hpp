@@ -2,6 +2,7 @@
 // HipBackend in kq_engine.hip, the 1-lane emulation in tests/emu).
 #pragma once
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <numeric>
 #include <unordered_map>
@@ -48,7 +49,7 @@ template <class Backend> struct TasT {
   TTopo T{};
   std::vector<void*> topo_allocs;
   struct Buf { void* p = nullptr; size_t cap = 0; };
-  Buf bq[16], bo[8], bx[15], bc[12];
+  Buf bq[20], bo[8], bx[15], bc[12];
   bool use_classes = true;  // tests can switch the shared phase 1 off
   std::vector<int32_t> h_par, h_leaf_lo, h_leaf_hi;  // [D] host mirrors of the tree (topology_put)
   Buf be_x[12];
@@ -129,7 +130,9 @@ template <class Backend> struct TasT {
     return KQ_OK;
   }
 
-  int find(const kq_tas_requests* r, kq_tas_result* out) {
+  // assumed usage the workloads of a batch start with (kq_tas_find_elastic): CSR per workload of (leaf, count, podset)
+  struct Seeds { std::vector<int32_t> off, leaf, count, ps; };
+  int find(const kq_tas_requests* r, kq_tas_result* out, const Seeds* seeds = nullptr) {
     if (!have_topo) return fail(KQ_EINVAL, "kq_tas_find before kq_tas_topology_put");
     const int nw = r->n_workloads;
     if (nw < 0) return fail(KQ_EINVAL, "negative workload count");
@@ -153,6 +156,11 @@ template <class Backend> struct TasT {
     Q.count = stage(bq[3], r->count, n); Q.level = stage(bq[4], r->level, n); Q.kind = stage(bq[5], r->kind, n);
     Q.slice_size = stage(bq[6], r->slice_size, n); Q.slice_level = stage(bq[7], r->slice_level, n); Q.group = stage(bq[8], r->group, n);
     Q.leaf_ok = r->leaf_ok ? stage(bq[9], r->leaf_ok, (size_t)n * T.n_leaves) : nullptr;
+    Q.seed_off = nullptr; Q.seed_leaf = nullptr; Q.seed_count = nullptr; Q.seed_ps = nullptr;
+    if (seeds && !seeds->leaf.empty()) {
+      Q.seed_off = stage(bq[15], seeds->off.data(), (size_t)nw + 1); Q.seed_leaf = stage(bq[16], seeds->leaf.data(), seeds->leaf.size());
+      Q.seed_count = stage(bq[17], seeds->count.data(), seeds->count.size()); Q.seed_ps = stage(bq[18], seeds->ps.data(), seeds->ps.size());
+    }
     // TASMultiLayerTopology: staged only when some podset carries more than one layer
     bool layered = false;
     if (r->n_layers) {
@@ -201,6 +209,7 @@ template <class Backend> struct TasT {
         const int p0 = r->wl_off[w], p1 = r->wl_off[w + 1];
         if (p1 - p0 < 1 || p1 - p0 > 2) continue;
         if (p1 - p0 == 2 && (r->group[p0] < 0 || r->group[p0] != r->group[p0 + 1])) continue;
+        if (seeds && !seeds->leaf.empty() && seeds->off[w + 1] > seeds->off[w]) continue;   // its phase 1 sees its own assumed usage
         int workers = p0, leader = -1;
         if (p1 - p0 == 2) { leader = p0 + 1; if (r->count[leader] > r->count[workers]) { leader = p0; workers = p0 + 1; } }
         if (layered && r->n_layers[workers] > 1) continue;  // inner layers change the roll-up: private phase 1
@@ -309,6 +318,174 @@ template <class Backend> struct TasT {
     const int leaf = x->ex_leaf[x->ex_off[i]];
     if (leaf < 0) return -1;
     return ancestor_at(leaf, lv);
+  }
+  // include/kq_tas.h kq_tas_find_elastic: handleElasticWorkload (tas_elastic_workloads.go:37-165) composed around the placement — the
+  // previous pods become the workload's starting assumed usage (Seeds), scale-up places the delta only, the merge / truncation /
+  // reuse of the previous assignment happen here on the host.
+  int find_elastic(const kq_tas_requests* r, const kq_tas_replacement* x, kq_tas_result* out) {
+    if (!have_topo) return fail(KQ_EINVAL, "kq_tas_find_elastic before kq_tas_topology_put");
+    if (!x || !x->is_replacement || !x->ex_off) return fail(KQ_EINVAL, "null previous-assignment table");
+    const int nw = r->n_workloads;
+    if (nw < 0) return fail(KQ_EINVAL, "negative workload count");
+    const int n = nw > 0 ? r->wl_off[nw] : 0;
+    if (n == 0) return find(r, out);
+    if (!r->count || !r->level || !r->kind || !r->slice_size || !r->slice_level || !r->group || !r->single_pod_requests) return fail(KQ_EINVAL, "null array in kq_tas_requests");
+    if (x->ex_off[0] != 0) return fail(KQ_EINVAL, "ex_off[0] must be 0");
+    for (int i = 0; i < n; i++) {
+      if (x->ex_off[i + 1] < x->ex_off[i]) return fail(KQ_EINVAL, "ex_off not monotone");
+      for (int j = x->ex_off[i]; j < x->ex_off[i + 1]; j++) if (x->ex_leaf[j] >= T.n_leaves || x->ex_count[j] < 0) return fail(KQ_EINVAL, "previous assignment out of range");
+    }
+    // what happens to every podset: 0 placed as it stands, 1 workers of a scale-up (delta placed, merged with the previous assignment),
+    // 2 answered from the previous assignment alone (truncated / reused: `fixed`), 3 a leader that keeps its previous assignment
+    std::vector<uint8_t> how(n, 0);
+    std::vector<int32_t> count(r->count, r->count + n), group(r->group, r->group + n);
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> fixed(n);
+    Seeds seeds; seeds.off.assign(nw + 1, 0);
+    std::vector<int> keep;          // podsets that go to the placement, old index
+    std::vector<int> new_of(n, -1);
+    bool any = false;
+    auto stale = [&](int i) { for (int j = x->ex_off[i]; j < x->ex_off[i + 1]; j++) if (x->ex_leaf[j] < 0) return true; return false; };
+    for (int w = 0; w < nw; w++) {
+      const int p0 = r->wl_off[w], p1 = r->wl_off[w + 1];
+      bool elastic = false;
+      for (int i = p0; i < p1; i++) if (x->is_replacement[i]) elastic = true;
+      std::vector<std::array<int32_t, 3>> sd;   // (leaf, count, OLD podset index) — renumbered below
+      if (elastic) {
+        // one podset group only: the previous pods are seeded when the workload's placement starts, which equals the reference's
+        // "before this group's placement" only if no other group is placed first
+        if (p1 - p0 > 2 || (p1 - p0 == 2 && (r->group[p0] < 0 || r->group[p0] != r->group[p0 + 1]))) return fail(KQ_EUNSUPPORTED, "elastic workload with more than one podset group");
+        int workers = p0, leader = -1;   // findLeaderAndWorkers :668
+        if (p1 - p0 == 2) { leader = p0 + 1; if (r->count[leader] > r->count[workers]) { leader = p0; workers = p0 + 1; } }
+        const bool leader_prev = leader >= 0 && x->is_replacement[leader];
+        if (x->is_replacement[workers] && !stale(workers) && !(leader_prev && stale(leader))) {   // :43-60, else fresh placement
+          any = true;
+          int32_t previous = 0;
+          for (int j = x->ex_off[workers]; j < x->ex_off[workers + 1]; j++) previous += x->ex_count[j];
+          if (r->count[workers] > previous) {                      // handleScaleUp :81
+            how[workers] = 1; count[workers] = r->count[workers] - previous;
+            // (the placement tells leader from workers by their counts, :668: a leader that stays in the placement must not outnumber the delta)
+            if (leader >= 0 && !leader_prev && r->count[leader] > count[workers]) return fail(KQ_EUNSUPPORTED, "elastic scale-up smaller than the leader podset");
+            for (int j = x->ex_off[workers]; j < x->ex_off[workers + 1]; j++) sd.push_back({x->ex_leaf[j], x->ex_count[j], workers});
+            if (leader_prev) {
+              how[leader] = 3; group[workers] = -1;                // placementLeader = nil :104
+              for (int j = x->ex_off[leader]; j < x->ex_off[leader + 1]; j++) { sd.push_back({x->ex_leaf[j], x->ex_count[j], leader}); fixed[leader].push_back({x->ex_leaf[j], x->ex_count[j]}); }
+            }
+          } else {                                                 // handleScaleDown :134 / same count :74 -> finalizeElasticAssignment :147
+            how[workers] = 2;
+            int32_t remaining = r->count[workers];
+            for (int j = x->ex_off[workers]; j < x->ex_off[workers + 1]; j++) {
+              if (r->count[workers] < previous) { if (remaining <= 0) break; const int32_t c = std::min(x->ex_count[j], remaining); fixed[workers].push_back({x->ex_leaf[j], c}); remaining -= c; }
+              else fixed[workers].push_back({x->ex_leaf[j], x->ex_count[j]});
+            }
+            if (leader >= 0) { how[leader] = 2; if (leader_prev) for (int j = x->ex_off[leader]; j < x->ex_off[leader + 1]; j++) fixed[leader].push_back({x->ex_leaf[j], x->ex_count[j]}); }
+          }
+        }
+      }
+      // (the placement tells leader from workers by position and count, :668 — trs[0] is the workers unless trs[1] is larger: the workers of a
+      // scale-up go first, so that a delta as small as the leader podset keeps its role)
+      for (int i = p0; i < p1; i++) if (how[i] == 1) { new_of[i] = (int)keep.size(); keep.push_back(i); }
+      for (int i = p0; i < p1; i++) if (how[i] == 0) { new_of[i] = (int)keep.size(); keep.push_back(i); }
+      // the seeds carry the per-pod requests of a podset: of one that is placed (its row is in the batch), else of ... itself, appended below
+      for (auto& e : sd) { seeds.leaf.push_back(e[0]); seeds.count.push_back(e[1]); seeds.ps.push_back(e[2]); }
+      seeds.off[w + 1] = (int32_t)seeds.leaf.size();
+    }
+    if (!any) return find(r, out);
+    // the batch the placement sees: the kept podsets, then one request-only row per leader that keeps its assignment (its per-pod requests
+    // price its seeds; it belongs to no workload)
+    std::vector<int> rows = keep;
+    for (size_t k = 0; k < seeds.ps.size(); k++) {
+      const int old = seeds.ps[k];
+      if (new_of[old] < 0) { new_of[old] = (int)rows.size(); rows.push_back(old); }
+      seeds.ps[k] = new_of[old];
+    }
+    const int m = (int)rows.size(), mk = (int)keep.size();
+    std::vector<int32_t> q_off(nw + 1, 0), q_count(m), q_level(m), q_ss(m), q_sl(m), q_group(m), q_nl, q_ll, q_ls;
+    std::vector<uint8_t> q_kind(m), q_leaf_ok;
+    std::vector<int64_t> q_spr((size_t)m * T.R);
+    for (int k = 0; k < m; k++) {
+      const int i = rows[k];
+      q_count[k] = count[i]; q_level[k] = r->level[i]; q_ss[k] = r->slice_size[i]; q_sl[k] = r->slice_level[i]; q_group[k] = group[i]; q_kind[k] = r->kind[i];
+      std::memcpy(q_spr.data() + (size_t)k * T.R, r->single_pod_requests + (size_t)i * T.R, (size_t)T.R * 8);
+    }
+    if (r->leaf_ok) { q_leaf_ok.resize((size_t)m * T.n_leaves); for (int k = 0; k < m; k++) std::memcpy(q_leaf_ok.data() + (size_t)k * T.n_leaves, r->leaf_ok + (size_t)rows[k] * T.n_leaves, T.n_leaves); }
+    if (r->n_layers) {
+      q_nl.resize(m); q_ll.resize((size_t)m * KQ_TAS_MAX_LEVELS); q_ls.resize((size_t)m * KQ_TAS_MAX_LEVELS);
+      for (int k = 0; k < m; k++) {
+        q_nl[k] = r->n_layers[rows[k]];
+        std::memcpy(q_ll.data() + (size_t)k * KQ_TAS_MAX_LEVELS, r->layer_level + (size_t)rows[k] * KQ_TAS_MAX_LEVELS, KQ_TAS_MAX_LEVELS * 4);
+        std::memcpy(q_ls.data() + (size_t)k * KQ_TAS_MAX_LEVELS, r->layer_size + (size_t)rows[k] * KQ_TAS_MAX_LEVELS, KQ_TAS_MAX_LEVELS * 4);
+      }
+    }
+    { int k = 0; for (int w = 0; w < nw; w++) { for (int i = r->wl_off[w]; i < r->wl_off[w + 1]; i++) if (how[i] == 0 || how[i] == 1) k++; q_off[w + 1] = k; } }
+    // (the request-only rows sit behind the last workload: wl_off never reaches them)
+    kq_tas_requests q = *r;
+    q.wl_off = q_off.data(); q.count = q_count.data(); q.level = q_level.data(); q.kind = q_kind.data(); q.slice_size = q_ss.data(); q.slice_level = q_sl.data();
+    q.group = q_group.data(); q.single_pod_requests = q_spr.data(); q.leaf_ok = r->leaf_ok ? q_leaf_ok.data() : nullptr;
+    q.n_layers = r->n_layers ? q_nl.data() : nullptr; q.layer_level = r->n_layers ? q_ll.data() : nullptr; q.layer_size = r->n_layers ? q_ls.data() : nullptr;
+    const int cap = std::max(out->dom_cap, 1);
+    std::vector<int32_t> st(std::max(m, 1)), oa(std::max(m, 1)), ob(std::max(m, 1)), d_off(mk + 1, 0), d_leaf(cap), d_count(cap), lfit;
+    kq_tas_result tmp = *out;
+    tmp.status = st.data(); tmp.operand_a = oa.data(); tmp.operand_b = ob.data(); tmp.dom_off = d_off.data(); tmp.dom_leaf = d_leaf.data(); tmp.dom_count = d_count.data(); tmp.dom_cap = cap;
+    if (out->layer_fit) { lfit.assign((size_t)std::max(m, 1) * KQ_TAS_MAX_LEVELS, 0); tmp.layer_fit = lfit.data(); }
+    int rc;
+    if (m > mk) {
+      // the request-only rows as one trailing workload of podsets that fail before phase 1 (slice size 0 -> KQ_TAS_BAD_SLICE_SIZE, no usage,
+      // no domains): their statuses are ignored, their per-pod requests are what the seeds read
+      std::vector<int32_t> q_off2(q_off); q_off2.push_back(m);
+      for (int k = mk; k < m; k++) { q_ss[k] = 0; q_group[k] = -1; }
+      std::vector<uint8_t> sim2;
+      if (r->simulate_empty) { sim2.assign(r->simulate_empty, r->simulate_empty + nw); sim2.push_back(0); q.simulate_empty = sim2.data(); }
+      q.n_workloads = nw + 1; q.wl_off = q_off2.data();
+      seeds.off.push_back(seeds.off.back());
+      d_off.assign(m + 1, 0); tmp.dom_off = d_off.data();
+      rc = find(&q, &tmp, &seeds);
+    } else rc = find(&q, &tmp, &seeds);
+    if (rc != KQ_OK) return rc;
+    // results in the caller's podset numbering
+    int tot = 0;
+    out->dom_off[0] = 0;
+    auto emit = [&](std::vector<std::pair<int32_t, int32_t>>& mlist, bool sort_merge) -> bool {
+      if (sort_merge) std::stable_sort(mlist.begin(), mlist.end(), [](const std::pair<int32_t, int32_t>& a, const std::pair<int32_t, int32_t>& b) { return a.first < b.first; });
+      int last = -1;
+      for (auto& dm : mlist) {
+        if (sort_merge && last >= 0 && out->dom_leaf[last] == dm.first) { out->dom_count[last] += dm.second; continue; }
+        if (tot >= out->dom_cap) return false;
+        out->dom_leaf[tot] = dm.first; out->dom_count[tot] = dm.second; last = tot++;
+      }
+      return true;
+    };
+    for (int w = 0; w < nw; w++) {
+      bool delta_failed = false;
+      for (int i = r->wl_off[w]; i < r->wl_off[w + 1]; i++) if (how[i] == 1 && st[new_of[i]] != KQ_TAS_OK) delta_failed = true;
+      for (int i = r->wl_off[w]; i < r->wl_off[w + 1]; i++) {
+        std::vector<std::pair<int32_t, int32_t>> mlist;
+        const int k = (how[i] == 0 || how[i] == 1) ? new_of[i] : -1;
+        if (out->layer_fit) std::memset(out->layer_fit + (size_t)i * KQ_TAS_MAX_LEVELS, 0, KQ_TAS_MAX_LEVELS * sizeof(int32_t));
+        if (how[i] == 0 && !delta_failed) {           // placed as it stands (also the leader of a scale-up that has no previous assignment)
+          out->status[i] = st[k]; out->operand_a[i] = oa[k]; out->operand_b[i] = ob[k];
+          if (out->layer_fit && st[k] == KQ_TAS_NOT_FIT_LAYERS) std::memcpy(out->layer_fit + (size_t)i * KQ_TAS_MAX_LEVELS, lfit.data() + (size_t)k * KQ_TAS_MAX_LEVELS, KQ_TAS_MAX_LEVELS * 4);
+          if (st[k] == KQ_TAS_OK) for (int j = d_off[k]; j < d_off[k + 1]; j++) mlist.push_back({d_leaf[j], d_count[j]});
+          if (!emit(mlist, false)) return fail(KQ_ECAPACITY, "dom_cap too small");
+        } else if (how[i] == 0) {                      // the delta placement of its group failed: only the workers carry the reason :109-112
+          out->status[i] = KQ_TAS_SKIPPED; out->operand_a[i] = out->operand_b[i] = 0;
+        } else if (how[i] == 1) {
+          out->status[i] = st[k]; out->operand_a[i] = oa[k]; out->operand_b[i] = ob[k];
+          if (out->layer_fit && st[k] == KQ_TAS_NOT_FIT_LAYERS) std::memcpy(out->layer_fit + (size_t)i * KQ_TAS_MAX_LEVELS, lfit.data() + (size_t)k * KQ_TAS_MAX_LEVELS, KQ_TAS_MAX_LEVELS * 4);
+          if (st[k] == KQ_TAS_OK) {                    // mergeTopologyAssignments :2072 of the delta and the previous assignment
+            for (int j = d_off[k]; j < d_off[k + 1]; j++) mlist.push_back({d_leaf[j], d_count[j]});
+            for (int j = x->ex_off[i]; j < x->ex_off[i + 1]; j++) mlist.push_back({x->ex_leaf[j], x->ex_count[j]});
+            if (!emit(mlist, true)) return fail(KQ_ECAPACITY, "dom_cap too small");
+          }
+        } else if (delta_failed) {                     // (a kept leader of a failed scale-up)
+          out->status[i] = KQ_TAS_SKIPPED; out->operand_a[i] = out->operand_b[i] = 0;
+        } else {                                       // truncated / reused / kept: the previous assignment's own order
+          out->status[i] = KQ_TAS_OK; out->operand_a[i] = out->operand_b[i] = 0;
+          if (!emit(fixed[i], false)) return fail(KQ_ECAPACITY, "dom_cap too small");
+        }
+        out->dom_off[i + 1] = tot;
+      }
+    }
+    return KQ_OK;
   }
   int find_replacement(const kq_tas_requests* r, const kq_tas_replacement* x, kq_tas_result* out) {
     if (!have_topo) return fail(KQ_EINVAL, "kq_tas_find_replacement before kq_tas_topology_put");

@@ -97,6 +97,9 @@ class TASPodSetRequests:
     # the podset's PodSetAssignment.TopologyAssignment of the workload's admission (findPSA :747): [(domain Values, count)]; read when
     # the workload has an unhealthy node (Requests(unhealthy_nodes=...)): the podset then takes findReplacementAssignment :686
     existing: Optional[Sequence[Tuple[Sequence[str], int]]] = None
+    # TASPodSetRequests.PreviousAssignment (:388): the TopologyAssignment of the workload slice this podset replaces
+    # (ElasticJobsViaWorkloadSlicesWithTAS, handleElasticWorkload tas_elastic_workloads.go:37) -> kq_tas_find_elastic
+    previous: Optional[Sequence[Tuple[Sequence[str], int]]] = None
 
 
 class Topology:
@@ -259,6 +262,23 @@ class Requests:
                                     ex_leaf=np.array(ex_leaf + [0], np.int32), ex_count=np.array(ex_count + [0], np.int32))
             self._repl_struct = kq_tas_replacement()
             F.fill_struct(self._repl_struct, self.replacement, {})
+        # previous assignments of elastic slices, in the layout of kq_tas_replacement (leaf -1: a domain the snapshot no longer holds)
+        self.previous = None
+        if any(tr.previous is not None for w in self.workloads for tr in w):
+            has, off, leaf, cnt = [], [0], [], []
+            for w in self.workloads:
+                for tr in w:
+                    for values, c in (tr.previous or []):
+                        try:
+                            lf = topo.leaf_of_values(values)
+                        except Exception:
+                            lf = None
+                        leaf.append(-1 if lf is None else int(lf)); cnt.append(int(c))
+                    off.append(len(leaf)); has.append(1 if tr.previous is not None else 0)
+            self.previous = dict(is_replacement=np.array(has, np.uint8), ex_off=np.array(off, np.int32),
+                                 ex_leaf=np.array(leaf + [0], np.int32), ex_count=np.array(cnt + [0], np.int32))
+            self._prev_struct = kq_tas_replacement()
+            F.fill_struct(self._prev_struct, self.previous, {})
         R = len(topo.resources)
         flat = [tr for w in self.workloads for tr in w]
         n = len(flat)
@@ -314,6 +334,9 @@ class Requests:
     def replacement_struct(self) -> Optional[kq_tas_replacement]:
         return self._repl_struct if self.replacement is not None else None
 
+    def previous_struct(self) -> Optional[kq_tas_replacement]:
+        return self._prev_struct if self.previous is not None else None
+
     @property
     def n_workloads(self) -> int:
         return len(self.arrays["wl_off"]) - 1
@@ -362,6 +385,8 @@ class Result:
         cap = dom_cap if dom_cap is not None else max(64, int(rq.arrays["count"].sum()) + n)
         if dom_cap is None and getattr(rq, "replacement", None) is not None:
             cap += len(rq.replacement["ex_leaf"])
+        if dom_cap is None and getattr(rq, "previous", None) is not None:
+            cap += len(rq.previous["ex_leaf"])
         self.exclusions: Dict[int, Tuple[int, int, Dict[str, int]]] = {}   # podset -> (TotalNodes, topologyDomain, {resource: leaves})
         self.a = dict(status=np.zeros(n, np.int32), operand_a=np.zeros(n, np.int32), operand_b=np.zeros(n, np.int32),
                       dom_off=np.zeros(n + 1, np.int32), dom_leaf=np.zeros(cap, np.int32), dom_count=np.zeros(cap, np.int32),
@@ -515,7 +540,7 @@ def load_tas():
 
 
 TAS_ABI_SYMBOLS = ["kq_tas_create", "kq_tas_destroy", "kq_tas_topology_put", "kq_tas_find", "kq_tas_usage_apply", "kq_tas_fits",
-                   "kq_tas_read_usage", "kq_tas_last_stats", "kq_tas_last_error",
+                   "kq_tas_read_usage", "kq_tas_last_stats", "kq_tas_last_error", "kq_tas_find_elastic",
                    "kq_tas_admit", "kq_tas_usage_delta", "kq_tas_usage_add", "kq_tas_overflow",
                    "kq_tas_find_replacement", "kq_tas_exclusion_stats"]
 
@@ -554,6 +579,16 @@ class TASEngine:
             return self.find(rq, dom_cap)
         out = Result(rq, dom_cap)
         self._check(self._lib.kq_tas_find_replacement(self._h, C.byref(rq.struct()), C.byref(rq.replacement_struct()), C.byref(out.struct())))
+        return out
+
+    def find_elastic(self, rq: Requests, dom_cap: Optional[int] = None) -> Result:
+        """FindTopologyAssignmentsForFlavor with ElasticJobsViaWorkloadSlicesWithTAS on (kq_tas_find_elastic): podsets that carry `previous`
+        keep their pods where they are — scale-up places the delta only, scale-down truncates, the same count reuses the assignment."""
+        if rq.previous is None:
+            return self.find(rq, dom_cap)
+        out = Result(rq, dom_cap)
+        self._lib.kq_tas_find_elastic.restype = C.c_int
+        self._check(self._lib.kq_tas_find_elastic(self._h, C.byref(rq.struct()), C.byref(rq.previous_struct()), C.byref(out.struct())))
         return out
 
     def exclusion_stats(self, rq: Requests, res: Result, podsets: Optional[Sequence[int]] = None) -> Result:

@@ -237,6 +237,19 @@ def tas_find(topo, rq, dom_cap=None):
     return out
 
 
+def tas_find_elastic(topo, rq, dom_cap=None):
+    """FindTopologyAssignmentsForFlavor with ElasticJobsViaWorkloadSlicesWithTAS on (oracle/kq_tas_oracle.cpp kqo_tas_find_elastic): the podsets
+    with a previous assignment take handleElasticWorkload (tas_elastic_workloads.go:37)."""
+    from kueue_amd import tas as T
+    out = T.Result(rq, dom_cap)
+    x = rq.previous_struct()
+    l = lib()
+    l.kqo_tas_find_elastic.restype = C.c_int
+    rc = l.kqo_tas_find_elastic(C.byref(topo.struct()), C.byref(rq.struct()), C.byref(x) if x is not None else None, C.byref(out.struct()))
+    assert rc == 0, rc
+    return out
+
+
 def tas_find_replacement(topo, rq, dom_cap=None):
     """FindTopologyAssignmentsForFlavor incl. the HasUnhealthyNodes branch (findReplacementAssignment :686) and the exclusion
     statistics of every podset (oracle/kq_tas_oracle.cpp kqo_tas_find_replacement) -> Result with .exclusions filled for all podsets."""

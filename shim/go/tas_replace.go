@@ -102,6 +102,29 @@ func (t *TAS) FindReplacementAssignments(r *TASRequests, x *TASReplacement, out 
 	return nil
 }
 
+// FindElasticAssignments = FindTopologyAssignmentsForFlavor with features.ElasticJobsViaWorkloadSlicesWithTAS on (kq_tas_find_elastic): `prev`
+// marks the podsets that carry TASPodSetRequests.PreviousAssignment (IsReplacement[i] = 1; Ex* = its domains in the assignment's order,
+// leaf -1 for a domain the snapshot no longer holds) — handleElasticWorkload (tas_elastic_workloads.go:37): scale-up places the delta
+// only and merges, scale-down truncates, the same count reuses. KQ_EUNSUPPORTED (an elastic workload of several podset groups): the
+// caller keeps s.handleElasticWorkload for that workload.
+func (t *TAS) FindElasticAssignments(r *TASRequests, prev *TASReplacement, out *TASResult) error {
+	var p runtime.Pinner
+	defer p.Unpin()
+	cr := (*C.kq_tas_requests)(C.calloc(1, C.sizeof_kq_tas_requests))
+	defer C.free(unsafe.Pointer(cr))
+	cx := (*C.kq_tas_replacement)(C.calloc(1, C.sizeof_kq_tas_replacement))
+	defer C.free(unsafe.Pointer(cx))
+	co := (*C.kq_tas_result)(C.calloc(1, C.sizeof_kq_tas_result))
+	defer C.free(unsafe.Pointer(co))
+	fillRequests(&p, cr, r)
+	fillReplacement(&p, cx, prev)
+	fillResult(&p, co, out)
+	if rc := C.kq_tas_find_elastic(t.h, cr, cx, co); rc != 0 {
+		return t.err("kq_tas_find_elastic", rc)
+	}
+	return nil
+}
+
 // ReplacementMessage is the failure reason of findReplacementAssignment for the two statuses the library adds (:696, :728).
 func (x *TASReplacement) ReplacementMessage(podset int, status, operandA int32) string {
 	switch status {

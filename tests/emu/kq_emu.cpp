@@ -274,6 +274,7 @@ int kqe_tas_admit(void* t, const kq_tas_requests* r, const kq_tas_result* res, c
 int kqe_tas_usage_delta(void* t, const kq_tas_requests* r, const kq_tas_result* res, const uint8_t* wl_sel, int64_t* plane) { return ((EmuTas*)t)->usage_delta(r, res, wl_sel, plane); }
 int kqe_tas_usage_add(void* t, const int64_t* plane, int32_t sign) { return ((EmuTas*)t)->usage_add(plane, sign); }
 int kqe_tas_overflow(void* t, const int64_t* plane, uint8_t* leaf_over, int32_t* n_over) { return ((EmuTas*)t)->overflow(plane, leaf_over, n_over); }
+int kqe_tas_find_elastic(void* t, const kq_tas_requests* r, const kq_tas_replacement* x, kq_tas_result* out) { return ((EmuTas*)t)->find_elastic(r, x, out); }
 int kqe_tas_find_replacement(void* t, const kq_tas_requests* r, const kq_tas_replacement* x, kq_tas_result* out) { return ((EmuTas*)t)->find_replacement(r, x, out); }
 int kqe_tas_exclusion_stats(void* t, const kq_tas_requests* r, const kq_tas_replacement* x, const kq_tas_result* res, int32_t n_sel, const int32_t* podsets, const int32_t* rank, int32_t* td, int32_t* rs) { return ((EmuTas*)t)->exclusion_stats(r, x, res, n_sel, podsets, rank, td, rs); }
 int kqe_tas_read_usage(void* t, int64_t* u) { return ((EmuTas*)t)->read_usage(u); }

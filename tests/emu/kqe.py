@@ -333,6 +333,17 @@ class EmuTas:
         out.bytes = int(lib().kqe_tas_last_bytes(self.h))
         return out
 
+    def find_elastic(self, rq, dom_cap=None, check=True):
+        from kueue_amd import tas as T
+        if rq.previous is None:
+            return self.find(rq, dom_cap)
+        out = T.Result(rq, dom_cap)
+        rc = lib().kqe_tas_find_elastic(self.h, C.byref(rq.struct()), C.byref(rq.previous_struct()), C.byref(out.struct()))
+        if not check:
+            return rc if rc != 0 else out
+        assert rc == 0, (rc, lib().kqe_tas_last_error(self.h))
+        return out
+
     def find_replacement(self, rq, dom_cap=None):
         from kueue_amd import tas as T
         if rq.replacement is None:
