@@ -51,7 +51,12 @@ struct Fs {
   // per ClusterQueue of the tree: the almost-LCAs with the preemptor (fs_lcas), filled once per search. (Round 5 also tried the candidate's
   // record and the quota constants of its path in ONE round trip through an LDS landing area instead of fs_row_load + fs_row_ctx's two
   // dependent ones: the staging cost more than the round trip it saved — "row load + context" 1 086 -> 1 329 ms of the cfg 4f process
-  // kernel, profiles/r05d_prof_fair_cfg4f_process_only.txt — and was taken out again.)
+  // kernel, profiles/r05d_prof_fair_cfg4f_process_only.txt — and was taken out again. So were two more attempts on the same visit, each
+  // measured with the segment timers of the -DKQ_PROF build: nextTarget's answer kept per cohort until something below it moves
+  // ("ordering.next" 1 637 -> 1 931 ms: the bookkeeping of the kept answers and their invalidation cost more than the scans it saved,
+  // profiles/r05e_prof_fair_cfg4f_nexttarget_cache.txt), and a per-row record of the quota constants so that the row's record and its
+  // constants leave in one round trip (A/B on one box: 1 208 vs 1 216 ms, profiles/r05g_prof_fair_cfg4f_rowc_{on,off}.txt — the two
+  // dependent loads were never the cost of that segment).)
   int32_t* cq_lca;
   // the first tcap targets (row, reason, position) live in what LDS the state left over: a target pushed or moved is then no global
   // store, and every fence of the walk waits for the wave's outstanding global stores (fs_tget / fs_tset; flushed to trow / treason /

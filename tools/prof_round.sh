@@ -20,8 +20,14 @@ if [[ $WHAT == *benches* ]]; then
   run cfg4c --workload cfg4c --steps 3 --warmup 1 --cpu-seconds 5
   run cfg5 --workload cfg5 --steps 5 --warmup 1
   run cfg5split --workload cfg5-split --steps 5 --warmup 1
-  run cfg5cycle --workload cfg5-cycle --steps 10 --warmup 2 --cpu-seconds 5
-  TMO=900 run cfg4f --workload cfg4f --steps 1 --warmup 0 --cpu-seconds 5 --no-host-leg
+  run cfg5cycle --workload cfg5-cycle --steps 20 --warmup 4
+  run cfg5cycle_open --workload cfg5-cycle --open-loop --steps 10 --warmup 2 --cpu-seconds 5
+  run cfg5fcycle --workload cfg5f-cycle --steps 10 --warmup 2
+  run cfg3group --workload cfg3-group --steps 20 --warmup 5
+  run cfg4cgroup --workload cfg4c-group --steps 5 --warmup 1
+  run cfg4fgroup --workload cfg4f-group --steps 10 --warmup 2
+  run default_driver --steps 20 --warmup 5
+  TMO=900 run cfg4f --workload cfg4f --steps 2 --warmup 1 --cpu-seconds 5 --no-host-leg
 fi
 if [[ $WHAT == *profiles* ]]; then
   cd /tmp && export TMPDIR=/tmp
