@@ -16,8 +16,10 @@
  * With fair sharing (kq_config.fair_sharing) the entries are walked in the fair-sharing iterator's order — one iterator over every root
  * tree (fair_sharing_iterator.go:47-263), the lowest ClusterQueue index still waiting naming the tree that pops next — and fair
  * preemption's victim search (preemption.go:381-631) carries the leaf usage with the victims.
+ * Heads that hold an admission (the second pass: a delayed topology request, or a node failure -> replacement) are part of the cycle:
+ * see ps_adm_flavor / ps_ex_* below.
  * Outside (KQ_EUNSUPPORTED or left to the caller): a workload whose podsets land on more than one TAS
- * flavor (TASHandleOverlappingFlavors), balanced placement, node replacement, workloads that hold a previous admission (second pass).
+ * flavor (TASHandleOverlappingFlavors), balanced placement.
  */
 #ifndef KQ_CYCLE_TAS_H
 #define KQ_CYCLE_TAS_H
@@ -31,6 +33,10 @@ extern "C" {
 #define KQ_PS_TAS_EXPLICIT 1u   /* workload.IsExplicitlyRequestingTAS(podSet) */
 
 #define KQ_CT_NO_RECOMPUTE 1u    /* features.TASRecomputeAssignmentWithinSchedulingCycle off (default on) */
+#define KQ_CT_NO_FAIL_FAST 2u    /* features.TASFailedNodeReplacementFailFast off (default on) */
+
+#define KQ_EX_UNHEALTHY 1u       /* the domain's node is one of Status.UnhealthyNodes (PodSetAssignment.HasUnhealthyNode tas_flavorassigner.go:85) */
+#define KQ_EX_FIRST     2u       /* ... and it is UnhealthyNodes[0]: the domain deleteDomain takes out (tas_flavor_snapshot.go:693, :828) */
 
 typedef struct kq_cycle_tas {
   uint32_t flags;                   /* KQ_CT_* */
@@ -59,6 +65,23 @@ typedef struct kq_cycle_tas {
   const int32_t* ps_n_layers;       /* [n_ps] */
   const int32_t* ps_layer_level;    /* [n_ps][n_tas][KQ_TAS_MAX_LEVELS] resolved against each TAS flavor, -1 = absent */
   const int32_t* ps_layer_size;     /* [n_ps][KQ_TAS_MAX_LEVELS] */
+  /* Second pass (workload.NeedsSecondPass workload.go:974; heads with KQ_HEAD_HAS_QUOTA_RESERVATION come first, manager.go:923,
+   * scheduler.go:1114): what Status.Admission holds for the head's podsets. All NULL = no head holds an admission.
+   *   ps_adm_flavor: PodSetAssignments[i].Flavors — Assign keeps them (flavorassigner.go:768-774: mode Fit, no flavor scan for those
+   *     resources); the head consumes no new quota (netUsage scheduler.go:785-794);
+   *   ps_ex_*: PodSetAssignments[i].TopologyAssignment, every domain in the assignment's order, resolved to a leaf of the podset's TAS
+   *     flavor (the TAS flavor among ps_adm_flavor; -1 = the snapshot has no such leaf, IsTopologyAssignmentStale :818). A podset that
+   *     holds one is placed again only when it names an unhealthy node (WorkloadsTopologyRequests tas_flavorassigner.go:50), and then
+   *     through findReplacementAssignment (tas_flavor_snapshot.go:608-633, :686): the pods of UnhealthyNodes[0]'s domain are placed below
+   *     the required replacement domain and merged into the rest; the entry's Usage.TAS is what the new assignment holds beyond the
+   *     admitted one, per domain (ComputeTASNetUsage flavorassigner.go:106-155). A replacement that fails evicts the workload
+   *     (KQ_ST_EVICTED / KQ_ACT_EVICT) unless KQ_CT_NO_FAIL_FAST. SkipReassignmentForPodOwnedWorkloads (:615) is the caller's: such a
+   *     workload is not submitted. */
+  const int32_t* ps_adm_flavor;     /* [n_ps][n_resource of the snapshot] flavor index, -1 = none */
+  const int32_t* ps_ex_off;         /* [n_ps+1] */
+  const int32_t* ps_ex_leaf;
+  const int32_t* ps_ex_count;
+  const uint8_t* ps_ex_flags;       /* KQ_EX_* */
 } kq_cycle_tas;
 
 typedef struct kq_cycle_tas_out {

@@ -177,6 +177,9 @@ typedef struct kq_snapshot {
 #define KQ_HEAD_HAS_QUOTA_RESERVATION 0x1  /* workload.HasQuotaReservation (second pass)          */
 #define KQ_HEAD_IS_PREEMPTOR          0x2  /* Head.IsPreemptor                                    */
 #define KQ_HEAD_HAS_LAST_ASSIGNMENT   0x4  /* Info.LastAssignment != nil                          */
+#define KQ_HEAD_HAS_UNHEALTHY_NODES   0x8  /* workload.HasUnhealthyNodes (kq_cycle_run_tas: the second pass after a node failure)      */
+#define KQ_HEAD_UNHEALTHY_ASSIGNMENT  0x10 /* workload.HasTopologyAssignmentWithUnhealthyNode workload.go:1392 (admitted, and a
+                                            * TopologyAssignment names one of Status.UnhealthyNodes)                                     */
 
 typedef struct kq_heads {
   int32_t n;                        /* number of heads; canonical order = as given (CQ name asc) */
@@ -223,6 +226,7 @@ typedef struct kq_heads {
 #define KQ_ST_NOT_NOMINATED  0
 #define KQ_ST_NOMINATED      1
 #define KQ_ST_SKIPPED        2
+#define KQ_ST_EVICTED        4  /* kq_cycle_run_tas: handleFailedTASReplacement scheduler.go:522 (TASFailedNodeReplacementFailFast) */
 #define KQ_ST_ASSUMED        5
 /* qcache.RequeueReason (cluster_queue.go:54-65) */
 #define KQ_RQ_GENERIC                  0
@@ -234,6 +238,7 @@ typedef struct kq_heads {
 #define KQ_ACT_NONE     0  /* requeueAndUpdate only */
 #define KQ_ACT_ADMIT    1  /* Scheduler.admit (scheduler.go:991) */
 #define KQ_ACT_PREEMPT  2  /* Scheduler.issuePreemptions (scheduler.go:563) on targets */
+#define KQ_ACT_EVICT    3  /* evictWorkloadAfterFailedTASReplacement (scheduler.go:926): no replacement for the unhealthy node */
 /* why an entry was skipped (inadmissibleMsg selector, scheduler.go:470-481) */
 #define KQ_SKIP_NONE            0
 #define KQ_SKIP_OVERLAP         1  /* "Workload has overlapping preemption targets with another workload" */

@@ -705,6 +705,11 @@ struct TAW {
   int q_lds, d_lds, pub_lds;
   const struct TPre* cur_pre;     // k_process_tas: the prefetched header of the entry being processed (null: it was loaded the ordinary way)
   int pool_own, pool_next;        // k_process_tas (pool_own = 1): the wave is the only writer of the published pool, pool_next its next free position; else the atomic counter
+  // the last tc_find of this wave was a simulate-empty placement of ONE podset that succeeded and nothing has overwritten its request
+  // block / store half since: (podset, TAS flavor, count) of it, -1 = none. updateAssignmentForTAS without targets (scheduler.go:966-975)
+  // asks for exactly the placement Assign's Preempt branch (flavorassigner.go:889-897) has just computed — an empty cluster looks the
+  // same to both — and takes it from there.
+  int em_ps, em_t, em_count;
 };
 #define KQ_TAS_WALK(w) ((w).ta.srch != 0)
 #define KQ_TAS_PROCESS(k, w) ((k).tc != nullptr && (w).ta.plane != 0)   // (timing builds) assign_flavors inside k_process_tas's recomputation

@@ -984,11 +984,11 @@ template <class B> struct EngineT {
       }
     }
     const int ncls = (int)cls_rep.size();
-    const int xslots = slots + ncls;
+    const int xslots = slots + 2 * ncls;   // wave slots, then the working copies of the request classes' tables, then those of their empty-cluster twins
     std::vector<int32_t> tas_of(prep.nF, -1);
     std::vector<TK> tks(nt);
     std::vector<int64_t*> work(nt), np(nt), priv(nt);
-    std::vector<int32_t*> cls_tab(nt), cflag(nt), par(nt);
+    std::vector<int32_t*> cls_tab(nt), cls_tab_e(nt), cflag(nt), par(nt);
     std::vector<long long*> cls_bytes(nt);
     int max_leaves = 1;
     for (int i = 0; i < nt; i++) {
@@ -1026,6 +1026,7 @@ template <class B> struct EngineT {
       par[i] = tstage(parent.data(), parent.size());
       be.sync();  // (first / cnt / parent are locals)
       cls_tab[i] = tgrow<int32_t>((size_t)5 * std::max(ncls, 1) * std::max(T.D, 1));
+      cls_tab_e[i] = tgrow<int32_t>((size_t)5 * std::max(ncls, 1) * std::max(T.D, 1));
       cls_bytes[i] = (long long*)tgrow<int64_t>(std::max(ncls, 1));
       cflag[i] = tgrow<int32_t>((size_t)std::max(ncls, 1) * std::max(T.D, 1));
       be.memset(cflag[i], 0, (size_t)std::max(ncls, 1) * std::max(T.D, 1) * 4);
@@ -1105,6 +1106,7 @@ template <class B> struct EngineT {
       }
       c.cls_req = tstage(creq.data(), creq.size()); c.cls_ssize = tstage(css.data(), css.size()); c.cls_slevel = tstage(csl.data(), csl.size());
       c.cls_tab = tstage(cls_tab.data(), cls_tab.size()); c.cls_bytes = tstage(cls_bytes.data(), cls_bytes.size());
+      c.cls_tab_e = getenv("KQ_TAS_EMPTY_TABLES_OFF") ? nullptr : tstage(cls_tab_e.data(), cls_tab_e.size());   // (A/B switch)
       c.par = (const int32_t* const*)tstage(par.data(), par.size()); c.cflag = tstage(cflag.data(), cflag.size());
       c.cls_ok = tgrow<uint8_t>((size_t)nt * std::max(ncls, 1));
       be.memset(c.cls_ok, 0, (size_t)nt * std::max(ncls, 1));

@@ -25,7 +25,8 @@ constexpr int TC_ML = KQ_TAS_MAX_LEVELS;
 enum {
   TQ_WLOFF = 0, TQ_COUNT = 2, TQ_LEVEL = TQ_COUNT + TC_P, TQ_SSIZE = TQ_LEVEL + TC_P, TQ_SLEVEL = TQ_SSIZE + TC_P, TQ_GROUP = TQ_SLEVEL + TC_P,
   TQ_NLAY = TQ_GROUP + TC_P, TQ_LLEVEL = TQ_NLAY + TC_P, TQ_LSIZE = TQ_LLEVEL + TC_P * TC_ML, TQ_STATUS = TQ_LSIZE + TC_P * TC_ML,
-  TQ_OPA = TQ_STATUS + TC_P, TQ_OPB = TQ_OPA + TC_P, TQ_DPOS = TQ_OPB + TC_P, TQ_DN = TQ_DPOS + TC_P, TQ_MISC = TQ_DN + TC_P, TQ_WORDS = TQ_MISC + 24   // misc: pool_used, error, bytes (64 bit), then the timing builds' cycle counters
+  TQ_OPA = TQ_STATUS + TC_P, TQ_OPB = TQ_OPA + TC_P, TQ_DPOS = TQ_OPB + TC_P, TQ_DN = TQ_DPOS + TC_P, TQ_MISC = TQ_DN + TC_P,   // misc: pool_used, error, bytes (64 bit), then the timing builds' cycle counters
+  TQ_LO = TQ_MISC + 24, TQ_HI = TQ_LO + TC_P, TQ_WORDS = TQ_HI + TC_P   // second pass: the leaf range of a replacement (global block only)
 };
 static_assert(TQ_MISC % 2 == 0, "the misc words hold an aligned 64-bit byte counter");
 // where the fields of a request block start: the slot's block in global memory holds TC_P podsets, the block k_process_tas keeps in LDS one
@@ -74,11 +75,28 @@ struct TCyc {
   const int32_t* cls_ssize;       // [ncls]
   const int32_t* cls_slevel;      // [ncls][n_tas]
   int32_t* const* cls_tab;        // [n_tas] -> [5][ncls][D]: podCount, sliceCount, podCountWithLeader, sliceCountWithLeader, leaderCount
+  // The same tables for an EMPTY cluster (WithSimulateEmpty :555: usage ignored): the placement a Preempt-mode assignment reserves with
+  // (flavorassigner.go:889-897, scheduler.go:966-975). They depend on the free capacity alone — computed once per cycle, never patched.
+  // In a saturated closed loop every recomputed entry runs two such placements, and each paid a full phase 1 over all leaves: 61 of the
+  // 233 us of an entry (profiles/r05j_prof_tas_closed.txt). Working copies: slots c.slots + c.ncls + cls.
+  int32_t* const* cls_tab_e;
   long long* const* cls_bytes;    // [n_tas] -> [ncls] algorithmic bytes of one phase 1 of the class
   uint8_t* cls_ok;                // [n_tas][ncls] the class's slice parameters are valid on this flavor
   const int32_t* const* par;      // [n_tas] -> [D] parent domain (global id), -1 at level 0
   int32_t* const* cflag;          // [n_tas] -> [ncls][D] owner marks of the incremental update (all zero between two updates)
+  // The second pass (kq_cycle_tas.ps_adm_flavor / ps_ex_*): heads that hold an admission. All null when no head does.
+  const int32_t* ps_adm_flavor;   // [n_ps][nR] Status.Admission's flavors: Assign keeps them (flavorassigner.go:768-774)
+  const uint8_t* sp_kind;         // [n_ps] SP_HAS_EX: the admission holds a TopologyAssignment for the podset; SP_UNHEALTHY: it names an unhealthy node
+  // what findReplacementAssignment :686 derives from the admission and the topology alone, done by the host (kq_host.hpp sp_prepare):
+  // [n_ps][SP_W] = {status (KQ_TAS_OK, or the failure known up front: KQ_TAS_STALE :695, KQ_TAS_BAD_SLICE_SIZE :701), operand a, operand b,
+  // tr.Count = the pods of the deleted domain :693, slice size and slice level after the rewrite :703-722, 1 when rewritten (no inner layers left),
+  // [lo, hi) = the leaves below requiredReplacementDomain :759, leaf of the deleted domain (-1 = not a leaf of the snapshot)}
+  const int32_t* sp_req;
+  int32_t* sp_del_out;            // [n_ps] pods the replacement put back on the deleted domain's leaf: the admission accounts for them
+                                  // already (ComputeTASNetUsage flavorassigner.go:131-141), so they are kept out of the wave's usage list
 };
+constexpr int SP_W = 12, SP_STATUS = 0, SP_OPA = 1, SP_OPB = 2, SP_COUNT = 3, SP_SSIZE = 4, SP_SLEVEL = 5, SP_NLAY = 6, SP_LO = 7, SP_HI = 8, SP_DEL = 9;
+constexpr uint8_t SP_HAS_EX = 1, SP_UNHEALTHY = 2;
 
 #ifdef KQ_TAS_CYCLE
 // ---- usage planes --------------------------------------------------------------------------------------------------------------------
@@ -177,6 +195,20 @@ KQ_DEV void tc_class_init(const TCyc& c, int t, int cls) {
   int32_t* meta = tk.X.meta + (size_t)(c.slots + cls) * 4;
   if (lane == 0) { meta[0] = 0; meta[1] = 0; meta[2] = cls; }
   wsync();
+  if (c.cls_tab_e) {   // the empty-cluster table and its working copy
+    const TLeafArgs ae = tc_class_args(c, t, cls, c.cls_tab_e[t]);
+    const size_t o = (size_t)(c.slots + c.ncls + cls) * T.D;
+    TState se{};
+    se.pc = ae.pc; se.sc = ae.sc; se.pcwl = ae.pcwl; se.scwl = ae.scwl; se.lc = ae.lc;
+    st.simulateEmpty = true;
+    long long scratch_bytes = 0;   // (a class's phase-1 bytes are charged from cls_bytes: the same whatever the usage)
+    t_fill_in_counts(tk, se, st, &scratch_bytes);
+    wsync();
+    for (int d = lane; d < T.D; d += WAVE) { tk.X.pc[o + d] = ae.pc[d]; tk.X.sc[o + d] = ae.sc[d]; tk.X.pcwl[o + d] = ae.pcwl[d]; tk.X.scwl[o + d] = ae.scwl[d]; tk.X.lc[o + d] = ae.lc[d]; }
+    int32_t* me = tk.X.meta + (size_t)(c.slots + c.ncls + cls) * 4;
+    if (lane == 0) { me[0] = 0; me[1] = 0; me[2] = cls; }
+    wsync();
+  }
 }
 // AddUsage changed the work plane on the leaves of entry e's TopologyAssignments: every class table (and its working copy) follows.
 // A class carries no leader and no inner layers, so in its table podCountWithLeader == podCount, sliceCountWithLeader == sliceCount,
@@ -254,7 +286,7 @@ KQ_DEV int tc_flavor_of(const TCyc& c, int nF, int t) {  // the ResourceFlavor o
 
 // ---- Assign's TAS step -------------------------------------------------------------------------------------------------------------------
 KQ_DEV void tc_reset(Wave& w) {
-  if (lane_id() == 0) { w.ta.t = -1; w.ta.nreq = 0; w.ta.af_early = 0; w.ta.err_mask = 0; w.ta.has_mask = 0; w.ta.kept_used = 0; w.ta.srch = 0; }
+  if (lane_id() == 0) { w.ta.t = -1; w.ta.nreq = 0; w.ta.af_early = 0; w.ta.err_mask = 0; w.ta.has_mask = 0; w.ta.kept_used = 0; w.ta.srch = 0; w.ta.em_ps = -1; }
 }
 // Assignment.updateMode flavorassigner.go:192-198 for podset p; the usage entries' modes (flavorResourcesNeedPreemption reads them)
 // are re-derived from the cells: an entry is as weak as the weakest (podset, resource) behind it
@@ -291,6 +323,12 @@ KQ_NOINLINE void tc_requests(const K& k, Wave& w) {
       if ((w.ta.err_mask >> p) & 1) continue;
       if (k.O.ps_count[g] == 0) continue;
       if ((w.ta.has_mask >> p) & 1) continue;
+      if (c.sp_kind) {
+        // second pass: a podset whose admission holds a TopologyAssignment is placed again only to replace a failed node (:50); in the
+        // replacement branch a podset without one gets no result at all (findPSA tas_flavor_snapshot.go:612)
+        const uint8_t sk = c.sp_kind[g];
+        if ((sk & SP_HAS_EX) && !((w.hflags & KQ_HEAD_HAS_UNHEALTHY_NODES) && (sk & SP_UNHEALTHY))) continue;
+      }
       int first = -1; bool many = false;
       for (int r = 0; r < nR; r++) {
         const int fl = k.O.flavor[(size_t)g * nR + r];
@@ -301,6 +339,7 @@ KQ_NOINLINE void tc_requests(const K& k, Wave& w) {
       if (first < 0 || many) { w.ta.err_mask |= 1u << p; w.rep_mode = M_NOFIT; continue; }  // psError :290 -> RepresentativeMode NoFit
       if (w.ta.t >= 0 && w.ta.t != first) { if (*k.O.error == 0) *k.O.error = KQ_EUNSUPPORTED; if (c.stats) c.stats[2] = 1; continue; }
       w.ta.t = first;
+      if (c.sp_kind && (w.hflags & KQ_HEAD_HAS_UNHEALTHY_NODES) && !(c.sp_kind[g] & SP_HAS_EX)) continue;   // requested, but the replacement branch has no result for it
       w.ta.req_ps[w.ta.nreq++] = (uint8_t)p;
     }
   }
@@ -328,12 +367,20 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
   KQ_T0();
   const int t = w.ta.t;
   const int lane = lane_id();
+  if (lane == 0) w.ta.em_ps = -1;   // (whatever the block and the store half held is about to be overwritten)
   // processEntry on the work plane, one podset of a request class: start from the class's resident phase 1, and (k_process_tas) keep the
   // request block and the placement's working state in LDS
   // (k_process_tas: the static half of the block came with the entry's prefetched header when it has one podset on the one TAS flavor)
-  const TPre* qp = (w.ta.cur_pre && w.ta.cur_pre->q_ok && n == 1 && w.ta.req_ps[0] == 0 && t == 0) ? w.ta.cur_pre : nullptr;
+  // second pass, a failed node to replace (tas_flavor_snapshot.go:608-633): every podset on its own through findReplacementAssignment :686
+  // — the request the host rewrote (TCyc::sp_req), never on an empty cluster (:723), no class table, no prefetched block
+  const bool repl = c.sp_kind != nullptr && (w.hflags & KQ_HEAD_HAS_UNHEALTHY_NODES) != 0;
+  if (repl) simulateEmpty = false;
+  int n_place = n;   // the requests in front of the first one whose failure is known up front (:694-702)
+  if (repl) for (int i = n - 1; i >= 0; i--) if (c.sp_req[(size_t)(w.ps_base + w.ta.req_ps[i]) * SP_W + SP_STATUS] != KQ_TAS_OK) n_place = i;
+  const TPre* qp = (!repl && w.ta.cur_pre && w.ta.cur_pre->q_ok && n == 1 && w.ta.req_ps[0] == 0 && t == 0) ? w.ta.cur_pre : nullptr;
   int cls = -1;
-  if (which == 1 && !simulateEmpty && n == 1 && c.ncls > 0) {
+  const bool empty_tab = simulateEmpty && c.cls_tab_e != nullptr;
+  if (!repl && which == 1 && (!simulateEmpty || empty_tab) && n == 1 && c.ncls > 0) {
     if (qp) cls = qp->q_cls_ok ? qp->q_cls : -1;
     else {
       cls = c.ps_class[w.ps_base + w.ta.req_ps[0]];
@@ -352,7 +399,7 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
   uint8_t* qsim = st_lds ? qu + 8 : qu + TC_P;
   const bool layered = c.ps_n_layers != nullptr;
   if (lane == 0) {
-    qi[TQ_WLOFF] = 0; qi[TQ_WLOFF + 1] = n;
+    qi[TQ_WLOFF] = 0; qi[TQ_WLOFF + 1] = n_place;
     if (qp) {
       qi[qo.count] = k.O.ps_count[w.ps_base];
       qi[qo.level] = qp->q_level; qi[qo.ssize] = qp->q_ssize; qi[qo.slevel] = qp->q_slevel; qi[qo.group] = qp->q_group;
@@ -375,6 +422,13 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
           qi[qo.lsize + i * TC_ML + j] = c.ps_layer_size[(size_t)g * TC_ML + j];
         }
       }
+      if (repl) {
+        const int32_t* sp = c.sp_req + (size_t)g * SP_W;
+        qi[qo.count + i] = sp[SP_COUNT]; qi[qo.ssize + i] = sp[SP_SSIZE]; qi[qo.slevel + i] = sp[SP_SLEVEL];
+        qi[qo.group + i] = -1;   // (:609: the podsets of a group one by one, none of them a leader)
+        if (layered && sp[SP_NLAY]) qi[qo.nlay + i] = 0;
+        qi[TQ_LO + i] = sp[SP_LO]; qi[TQ_HI + i] = sp[SP_HI];
+      }
     }
     *qsim = simulateEmpty ? 1 : 0;
     for (int i = 0; i < 24; i++) qi[qo.misc + i] = 0;
@@ -386,6 +440,7 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
   tk.Q.n_wl = 1; tk.Q.wl_off = qi + TQ_WLOFF; tk.Q.sim_empty = qsim; tk.Q.spr = qs;
   tk.Q.count = qi + qo.count; tk.Q.level = qi + qo.level; tk.Q.kind = qu; tk.Q.slice_size = qi + qo.ssize; tk.Q.slice_level = qi + qo.slevel;
   tk.Q.group = qi + qo.group; tk.Q.leaf_ok = nullptr;
+  tk.Q.leaf_lo = repl ? qi + TQ_LO : nullptr; tk.Q.leaf_hi = repl ? qi + TQ_HI : nullptr;
   tk.Q.n_layers = layered ? qi + qo.nlay : nullptr; tk.Q.layer_level = layered ? qi + qo.llevel : nullptr; tk.Q.layer_size = layered ? qi + qo.lsize : nullptr;
   tk.O.status = qi + qo.status; tk.O.op_a = qi + qo.opa; tk.O.op_b = qi + qo.opb; tk.O.dom_pos = qi + qo.dpos; tk.O.dom_n = qi + qo.dn;
   tk.O.layer_fit = nullptr;
@@ -398,16 +453,16 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
   if (cls >= 0) {
     const int g = w.ps_base + w.ta.req_ps[0];
     const size_t nD = (size_t)c.ncls * tk.T.D;
-    int32_t* tab = c.cls_tab[t];
+    int32_t* tab = simulateEmpty ? c.cls_tab_e[t] : c.cls_tab[t];
     tk.C.n = c.ncls; tk.C.wl_class = c.ps_class + g; tk.C.order = nullptr;
     tk.C.pc = tab; tk.C.sc = tab + nD; tk.C.pcwl = tab + 2 * nD; tk.C.scwl = tab + 3 * nD; tk.C.lc = tab + 4 * nD;
     tk.C.bytes = c.cls_bytes[t];
-    xslot = c.slots + cls;
+    xslot = c.slots + (simulateEmpty ? c.ncls : 0) + cls;
     if (st_lds) tk.lds = w.ta.lds + TX_BYTES;   // the working state in LDS
     if (lane == 0 && c.stats) atomic_add_i64(c.stats + 3, 1);
   }
   if (which != 0) KQ_TS(k, 47);   // request block + argument block of the placement
-  t_workload(tk, xslot, 0);
+  if (n_place > 0) t_workload(tk, xslot, 0);
   wsync();
 #ifndef KQ_TAS_NO_PREFETCH
   if (w.ta.mail && w.ta.pf_pos >= 0) {
@@ -432,10 +487,17 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
   // cycle does not include them, and neither does the oracle's)
   if (lane == 0 && qi[qo.misc + 1] != 0 && *k.O.error == 0) *k.O.error = qi[qo.misc + 1];
   wsync();
-  for (int i = 0; i < n; i++) {
+  for (int i = 0; i < n_place; i++) {
     const int st = qi[qo.status + i];
     if (st != KQ_TAS_OK && st != KQ_TAS_SKIPPED) { f.failed = true; f.ps = w.ta.req_ps[i]; f.status = st; f.a = qi[qo.opa + i]; f.b = qi[qo.opb + i]; break; }
+    if (repl && st == KQ_TAS_OK && qi[qo.dn + i] == 0) { f.failed = true; f.ps = w.ta.req_ps[i]; f.status = KQ_TAS_NO_REPLACEMENT; break; }   // :727
   }
+  if (!f.failed && n_place < n) {
+    const int32_t* sp = c.sp_req + (size_t)(w.ps_base + w.ta.req_ps[n_place]) * SP_W;
+    f.failed = true; f.ps = w.ta.req_ps[n_place]; f.status = sp[SP_STATUS]; f.a = sp[SP_OPA]; f.b = sp[SP_OPB];
+  }
+  if (lane == 0 && simulateEmpty && n == 1 && !f.failed && qi[qo.status] == KQ_TAS_OK) { w.ta.em_ps = w.ta.req_ps[0]; w.ta.em_t = t; w.ta.em_count = k.O.ps_count[w.ps_base + w.ta.req_ps[0]]; }
+  wsync();
   return f;
 }
 // Assignment.UpdateForTASResult flavorassigner.go:87-96 with the result of the last tc_find: a podset whose placement succeeded keeps its
@@ -453,10 +515,29 @@ KQ_NOINLINE void tc_keep_result(const K& k, Wave& w, int slot) {
     const int pos = qi[qo.dpos + i], n = ok ? qi[qo.dn + i] : 0;
     const int at = w.ta.kept_used;
     if (ok && at + n > dcap) { set_error(k, KQ_ECAPACITY); return; }
-    for (int j = lane_id(); j < n; j += WAVE) { kl[at + j] = fl[pos + j]; kc[at + j] = fc[pos + j]; }
-    wsync();
+    int kept = n;
+    if (c.sp_kind && (w.hflags & KQ_HEAD_HAS_UNHEALTHY_NODES)) {
+      // a replacement: the wave keeps the entry's net usage (ComputeTASNetUsage flavorassigner.go:106-155) — the replacement's pods,
+      // except those that went back onto the deleted domain's leaf, which the admission accounts for already (at most as many as it
+      // held there). The host merges the admission's other domains in for the caller (mergeTopologyAssignments :2072).
+      const int g = w.ps_base + p;
+      const int del = c.sp_req[(size_t)g * SP_W + SP_DEL];
+      int o = 0; int32_t back = 0;   // (every lane walks the few domains; lane 0 writes: Wave::counts is Assign's under partial admission)
+      for (int j = 0; j < n; j++) {
+        const int32_t lf = fl[pos + j], cn = fc[pos + j];
+        if (del >= 0 && lf == del) { back += cn; continue; }
+        if (lane_id() == 0) { kl[at + o] = lf; kc[at + o] = cn; }
+        o++;
+      }
+      if (lane_id() == 0) c.sp_del_out[g] = ok ? back : 0;
+      kept = o;
+      wsync();
+    } else {
+      for (int j = lane_id(); j < n; j += WAVE) { kl[at + j] = fl[pos + j]; kc[at + j] = fc[pos + j]; }
+      wsync();
+    }
     if (lane_id() == 0) {
-      if (ok) { w.ta.has_mask |= 1u << p; w.ta.pos[p] = at; w.ta.n[p] = n; w.ta.kept_used = at + n; }
+      if (ok) { w.ta.has_mask |= 1u << p; w.ta.pos[p] = at; w.ta.n[p] = kept; w.ta.kept_used = at + kept; }
       else w.ta.has_mask &= ~(1u << p);
     }
     wsync();
@@ -481,7 +562,7 @@ KQ_DEV void tc_assign_tas(const K& k, Wave& w, int slot) {
     } else tc_keep_result(k, w, slot);
     if (w.ta.plane != 0) KQ_TS(k, 50); // keep the result
   }
-  if (w.rep_mode == M_PREEMPT) {
+  if (w.rep_mode == M_PREEMPT && !(w.hflags & KQ_HEAD_HAS_UNHEALTHY_NODES)) {   // :879 "Don't preempt other workloads if looking for a failed node replacement"
     const TcFail f = tc_find(k, w, slot, true, w.ta.plane);
     if (f.failed) tc_update_mode(k, w, f.ps, M_NOFIT);
     else for (int i = 0; i < w.ta.nreq; i++) tc_update_mode(k, w, w.ta.req_ps[i], M_PREEMPT);  // updateModeForTASRequests :200
@@ -514,6 +595,7 @@ KQ_DEV bool tc_search_fits(const K& k, Wave& w, int slot) {  // preemption.go:67
 KQ_DEV void tc_update_assignment(const K& k, Wave& w, int slot, const int32_t* trow, int nt) {
   const TCyc& c = *k.tc;
   if (w.rep_mode != M_PREEMPT) return;
+  if (w.hflags & KQ_HEAD_UNHEALTHY_ASSIGNMENT) return;   // scheduler.go:952 !HasTopologyAssignmentWithUnhealthyNode
   bool any = c.cq_tas_only[w.cq] != 0;
   for (int p = 0; p < w.nps && !any; p++) if (c.ps_flags[w.ps_base + p] & KQ_PS_TAS_EXPLICIT) any = true;
   if (!any) return;
@@ -524,6 +606,11 @@ KQ_DEV void tc_update_assignment(const K& k, Wave& w, int slot, const int32_t* t
       for (int i = 0; i < nt; i++) tc_row_apply(c, trow[i], false, 3, slot);   // SimulateWorkloadUsageRemoval
     }
     tc_find(k, w, slot, false, 3);
+  } else if (w.ta.nreq == 1 && w.ta.em_ps == (int)w.ta.req_ps[0] && w.ta.em_t == w.ta.t && w.ta.em_count == k.O.ps_count[w.ps_base + w.ta.req_ps[0]]) {
+    // the simulate-empty placement of this very request is still in the request block and the store half (see TAW::em_ps): the call the
+    // reference makes here returns it again; it is counted, not computed
+    if (lane_id() == 0 && c.stats) atomic_add_i64(c.stats, 1);
+    wsync();
   } else {
     tc_find(k, w, slot, true, w.ta.plane);
   }
@@ -851,7 +938,11 @@ KQ_NOINLINE void process_entry_tas(const K& k, Wave& w, int e, int pos, int slot
   const bool fits_ok = fc == 0;
   int status = KQ_ST_NOT_NOMINATED, action = KQ_ACT_NONE, rq = KQ_RQ_GENERIC, skip = KQ_SKIP_NONE;
   bool done = false;
-  if (mode == M_NOFIT) { rq = KQ_RQ_NOFIT; done = true; }
+  if ((w.hflags & KQ_HEAD_UNHEALTHY_ASSIGNMENT) && !(c.flags & KQ_CT_NO_FAIL_FAST) && mode != M_FIT) {
+    // TASFailedNodeReplacementFailFast scheduler.go:425-428: no replacement for the failed node -> handleFailedTASReplacement :522
+    status = KQ_ST_EVICTED; action = KQ_ACT_EVICT; done = true;
+  }
+  if (!done && mode == M_NOFIT) { rq = KQ_RQ_NOFIT; done = true; }
   if (!done && mode == M_PREEMPT && nt == 0) {
     rq = KQ_RQ_PREEMPTION_NO_CANDIDATES;
     const bool can_always_reclaim = KQ_POL_RECLAIM(w.pol) == KQ_POLICY_ANY;

@@ -40,6 +40,9 @@ struct TReq {
   // kq_tas_find_elastic: assumed usage a workload starts with — the previous pods of its elastic slice (handleScaleUp
   // tas_elastic_workloads.go:97-106): CSR per workload of (leaf, count, podset whose SinglePodRequests the pods carry); NULL = none
   const int32_t *seed_off, *seed_leaf, *seed_count, *seed_ps;
+  // the leaves below a required replacement domain (tas_flavor_snapshot.go:1902-1905), per podset request: [leaf_lo, leaf_hi) in leaf
+  // indices; NULL = every leaf. (kq_cycle_run_tas's second pass; the batch entry point kq_tas_find_replacement passes a leaf_ok row.)
+  const int32_t *leaf_lo = nullptr, *leaf_hi = nullptr;
 };
 struct TOut {
   int32_t *status, *op_a, *op_b, *dom_pos, *dom_n;  // per podset request; dom_pos = offset into the pool
@@ -158,6 +161,7 @@ struct TParams {  // topologyAssignmentParameters :473 + requirements :461
   const int64_t* req;        // [R] SinglePodRequests of the workers (pods added on the fly)
   const int64_t* leaderReq;  // [R] or NULL
   const uint8_t* leafOk;
+  int leafLo = 0, leafHi = 0x7fffffff;   // the leaves below the required replacement domain (:1902), all of them by default
   // TASMultiLayerTopology: sliceSizeAtLevel :474 (0 = no entry), the constraint list for multiLayerNotFitMessage :2030
   int32_t sizeAt[KQ_TAS_MAX_LEVELS + 1];
   int nLayers;                // len(multiLayerConstraints) :482, 0 unless sliceSizeAtLevel has an entry
@@ -211,6 +215,7 @@ struct TLeafArgs {
   const uint8_t* leafOk;
   int simulateEmpty, hasAssumed, sliceLevelIdx;
   int32_t sliceSize;
+  int leafLo = 0, leafHi = 0x7fffffff;
 };
 // one sweep over a slice of domains (t_view_first_fit): what it is after, and what a wave found in its share of the elements
 struct TSweepArgs { int n, order, id0; bool lfc, by_order; int32_t needed, leaderCount; int which; };
@@ -312,7 +317,7 @@ template <int RM, int U> KQ_DEV int64_t t_leaf_counts(const TTopo& T, const TLea
     #pragma unroll
     for (int u = 0; u < U; u++) {
       const int leaf = leaf0 + u * stride;
-      ok[u] = leaf < T.n_leaves && (!a.leafOk || a.leafOk[leaf]);
+      ok[u] = leaf < T.n_leaves && leaf >= a.leafLo && leaf < a.leafHi && (!a.leafOk || a.leafOk[leaf]);
       #pragma unroll
       for (int r = 0; r < RM; r++) {
         rem[u][r] = 0;
@@ -411,7 +416,7 @@ KQ_DEV void t_class_to_lds(const TK& k, const TState& s, int cls) {
   const int32_t* spc = k.C.pc + (size_t)cls * T.D; const int32_t* ssc = k.C.sc + (size_t)cls * T.D;
   if (k.mail) {
     TLeafJob& j = *k.mail;
-    if (j.early_pending && j.early_cls == cls && j.cp_pc == s.pc) {
+    if (j.early_pending && j.early_cls == cls && j.cp_pc == s.pc && j.a.pc == spc) {   // (same class AND same table: the empty-cluster tables share the class numbers)
       // the rows came while the flavor assignment ran: the helper waves are at the job's second barrier
       bsync();
       if (lane_id() == 0) { j.early_pending = 0; j.early_cls = -1; }   // (the placement consumes the copy)
@@ -437,7 +442,7 @@ KQ_DEV void t_fill_in_counts(const TK& k, const TState& s, const TParams& p, lon
   for (int d = lane; d < T.leaf_base; d += WAVE) { s.pc[d] = 0; s.sc[d] = 0; s.pcwl[d] = 0; s.scwl[d] = 0; t_set_lc(s, d, 0); }
   int64_t lb = 0;
   {
-    const TLeafArgs a{s.pc, s.sc, s.pcwl, s.scwl, s.lc, s.assumed, p.req, p.leaderReq, p.leafOk, p.simulateEmpty ? 1 : 0, p.hasAssumed ? 1 : 0, p.sliceLevelIdx, p.sliceSize};
+    const TLeafArgs a{s.pc, s.sc, s.pcwl, s.scwl, s.lc, s.assumed, p.req, p.leaderReq, p.leafOk, p.simulateEmpty ? 1 : 0, p.hasAssumed ? 1 : 0, p.sliceLevelIdx, p.sliceSize, p.leafLo, p.leafHi};
     if (k.mail) {
       TLeafJob& j = *k.mail;
       t_post_begin(j);
@@ -1267,6 +1272,7 @@ template <bool LDS> KQ_DEV void t_workload_t(const TK& k, int slot, int w) {
     st.simulateEmpty = Q.sim_empty && Q.sim_empty[w]; st.hasLeader = leader >= 0; st.hasAssumed = hasAssumed;
     st.req = Q.spr + (size_t)workers * T.R; st.leaderReq = leader >= 0 ? Q.spr + (size_t)leader * T.R : nullptr;
     st.leafOk = Q.leaf_ok ? Q.leaf_ok + (size_t)workers * T.n_leaves : nullptr;
+    if (Q.leaf_lo) { st.leafLo = Q.leaf_lo[workers]; st.leafHi = Q.leaf_hi[workers]; }
     #pragma unroll
     for (int l = 0; l <= KQ_TAS_MAX_LEVELS; l++) st.sizeAt[l] = 0;
     st.nLayers = 0; st.layerLevel = nullptr; st.layerSize = nullptr;

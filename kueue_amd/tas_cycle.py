@@ -24,6 +24,8 @@ from .tas import KQ_TAS_UNCONSTRAINED, Node, TASPodSetRequests, Topology, Topolo
 CYCLE_TAS_ABI_SYMBOLS = ["kq_cycle_run_tas"]   # include/kq_cycle_tas.h
 PS_TAS_EXPLICIT = 1
 CT_NO_RECOMPUTE = 1
+CT_NO_FAIL_FAST = 2
+EX_UNHEALTHY, EX_FIRST = 1, 2
 
 
 class kq_cycle_tas(C.Structure):
@@ -33,6 +35,8 @@ class kq_cycle_tas(C.Structure):
         ("ps_flags", F.u8p), ("ps_kind", F.u8p), ("ps_level", F.i32p), ("ps_slice_size", F.i32p), ("ps_slice_level", F.i32p),
         ("ps_group", F.i32p), ("ps_req", F.i64p),
         ("ps_n_layers", F.i32p), ("ps_layer_level", F.i32p), ("ps_layer_size", F.i32p),   # TASMultiLayerTopology, NULL = single layer
+        # the second pass: what Status.Admission holds for the heads' podsets, NULL = no head holds an admission
+        ("ps_adm_flavor", F.i32p), ("ps_ex_off", F.i32p), ("ps_ex_leaf", F.i32p), ("ps_ex_count", F.i32p), ("ps_ex_flags", F.u8p),
     ]
 
 

@@ -467,6 +467,7 @@ struct PodSetAssignment {
   bool hasTopo = false;
   int tasIdx = -1;
   tas::Assignment topo;
+  std::vector<uint8_t> topoFlags;  // KQ_EX_* of topo's domains while it is still the admission's (second pass); empty afterwards
   // flavorassigner.go:386-404
   int RepresentativeMode() const {
     if (!err && nreasons == 0) return Fit;
@@ -521,8 +522,21 @@ struct TasResult {
   }
 };
 
-// tas_flavorassigner.go:37-83 (+ podSetTopologyRequest :92, onlyTASFlavor :142). MultiKueue / ProvisioningRequest delays, elastic
-// slices and unhealthy-node replacement are outside the boundary (the host keeps such workloads on the Go path).
+// PodSetAssignment.HasUnhealthyNode tas_flavorassigner.go:85: the names of Status.UnhealthyNodes are the leaves the admission's
+// domains flag (KQ_EX_UNHEALTHY), on any podset of the head
+static bool HasUnhealthyNode(Snap& sn, const Head& wl, const PodSetAssignment& psa) {
+  if (!(wl.flags & KQ_HEAD_HAS_UNHEALTHY_NODES) || !sn.T->ps_ex_off) return false;
+  for (size_t i = 0; i < psa.topo.size(); i++) {
+    if (i < psa.topoFlags.size()) { if (psa.topoFlags[i] & KQ_EX_UNHEALTHY) return true; continue; }
+    if (psa.topo[i].first < 0) continue;
+    for (size_t q = 0; q < wl.ps.size(); q++)
+      for (int j = sn.T->ps_ex_off[wl.ps_base + q]; j < sn.T->ps_ex_off[wl.ps_base + q + 1]; j++)
+        if ((sn.T->ps_ex_flags[j] & KQ_EX_UNHEALTHY) && sn.T->ps_ex_leaf[j] == psa.topo[i].first) return true;
+  }
+  return false;
+}
+// tas_flavorassigner.go:37-83 (+ podSetTopologyRequest :92, onlyTASFlavor :142). MultiKueue / ProvisioningRequest delays and elastic
+// slices are outside the boundary (the host keeps such workloads on the Go path).
 static TasRequests WorkloadsTopologyRequests(Snap& sn, const Head& wl, Assignment& a) {
   TasRequests out;
   if (!sn.T) return out;
@@ -534,7 +548,7 @@ static TasRequests WorkloadsTopologyRequests(Snap& sn, const Head& wl, Assignmen
     PodSetAssignment& psa = a.PodSets[p];
     if (psa.err) continue;
     if (psa.count == 0) continue;
-    if (psa.hasTopo) continue;
+    if (psa.hasTopo && !HasUnhealthyNode(sn, wl, psa)) continue;  // :50: already computed, and no failed node to replace
     std::set<int> flavors;  // onlyTASFlavor
     for (auto& kv : psa.flavors) if (sn.tasOfFlavor[kv.second.flavor] >= 0) flavors.insert(sn.tasOfFlavor[kv.second.flavor]);
     if (flavors.size() != 1) { psa.err = true; a.rep = -1; continue; }  // ErrNoTASFlavorAssigned / MultipleTASFlavorsAssignedError -> psError :290
@@ -579,6 +593,33 @@ static TasResult FindTopologyAssignmentsForWorkload(Snap& sn, const Head& wl, co
     rq.kind = kind.data(); rq.slice_size = slice_size.data(); rq.slice_level = slice_level.data(); rq.group = group.data();
     if (sn.T->ps_n_layers) { rq.n_layers = n_layers.data(); rq.layer_level = layer_level.data(); rq.layer_size = layer_size.data(); }
     std::vector<tas::PodSetResult> res;
+    if ((wl.flags & KQ_HEAD_HAS_UNHEALTHY_NODES) && sn.T->ps_ex_off) {
+      // tas_flavor_snapshot.go:608-633: every podset on its own through findReplacementAssignment :686, against Status.Admission's
+      // TopologyAssignment (findPSA :747, not the assignment under construction); deleteDomain :693 takes UnhealthyNodes[0]'s domain
+      // out and its pods are what is placed
+      std::vector<uint8_t> isr(n, 0);
+      std::vector<int32_t> xo(1, 0), xl, xc;
+      for (int i = 0; i < n; i++) {
+        const int g = wl.ps_base + pss[i];
+        const int e0 = sn.T->ps_ex_off[g], e1 = sn.T->ps_ex_off[g + 1];
+        isr[i] = e1 > e0;   // psa.TopologyAssignment != nil
+        int32_t affected = 0;
+        for (int j = e0; j < e1; j++) {
+          if (sn.T->ps_ex_flags[j] & KQ_EX_FIRST) affected = sn.T->ps_ex_count[j];
+          else { xl.push_back(sn.T->ps_ex_leaf[j]); xc.push_back(sn.T->ps_ex_count[j]); }
+        }
+        if (isr[i]) count[i] = affected;
+        xo.push_back((int32_t)xl.size());
+      }
+      kq_tas_replacement x;
+      x.is_replacement = isr.data(); x.ex_off = xo.data(); x.ex_leaf = xl.data(); x.ex_count = xc.data();
+      tas::find_workload_replacement(*sn.tasS[t], &rq, &x, 0, n, &res);
+      bool any = false;
+      for (int i = 0; i < n; i++) any = any || isr[i];
+      if (any) sn.tasFinds++;   // (the counter is a diagnostic: one per call that placed or refused something)
+      for (int i = 0; i < n; i++) if (isr[i]) out.byPodSet[pss[i]] = {t, res[i]};   // (no result for a podset without a TopologyAssignment :612)
+      continue;
+    }
     tas::find_workload(*sn.tasS[t], &rq, 0, n, simulateEmpty, &res);
     sn.tasFinds++;
     for (int i = 0; i < n; i++) out.byPodSet[pss[i]] = {t, res[i]};
@@ -586,25 +627,35 @@ static TasResult FindTopologyAssignmentsForWorkload(Snap& sn, const Head& wl, co
   return out;
 }
 
-// Assignment.ComputeTASNetUsage flavorassigner.go:106-155 (no previous admission: pending workloads only)
-static void ComputeTASNetUsage(Assignment& a) {
+// Assignment.ComputeTASNetUsage flavorassigner.go:106-155: per domain, what the assignment holds beyond admittedDomainCounts :157 of
+// Status.Admission (nothing for a pending workload)
+static void ComputeTASNetUsage(Snap& sn, const Head& wl, Assignment& a) {
   a.UsageTAS.clear();
   for (size_t p = 0; p < a.PodSets.size(); p++) {
     const PodSetAssignment& psa = a.PodSets[p];
     if (!psa.hasTopo) continue;
-    for (auto& dc : psa.topo) if (dc.second > 0) a.UsageTAS.push_back({psa.tasIdx, dc.first, dc.second, (int)p});
+    std::map<int, int32_t> accounted;
+    if (sn.T->ps_ex_off)
+      for (int j = sn.T->ps_ex_off[wl.ps_base + p]; j < sn.T->ps_ex_off[wl.ps_base + p + 1]; j++)
+        if (sn.T->ps_ex_leaf[j] >= 0) accounted[sn.T->ps_ex_leaf[j]] += sn.T->ps_ex_count[j];
+    for (auto& dc : psa.topo) {
+      if (dc.first < 0) continue;   // a domain the snapshot does not hold: it is the admission's own (stale), unchanged
+      const int32_t count = dc.second - (accounted.count(dc.first) ? accounted[dc.first] : 0);
+      if (count > 0) a.UsageTAS.push_back({psa.tasIdx, dc.first, count, (int)p});
+    }
   }
 }
 // Assignment.UpdateForTASResult flavorassigner.go:87-96
-static void UpdateForTASResult(Assignment& a, const TasResult& result) {
+static void UpdateForTASResult(Snap& sn, const Head& wl, Assignment& a, const TasResult& result) {
   for (auto& kv : result.byPodSet) {
     PodSetAssignment& psa = a.PodSets[kv.first];
     const tas::PodSetResult& r = kv.second.second;
     psa.hasTopo = r.status == KQ_TAS_OK;  // TopologyAssignment = psResult.TopologyAssignment (nil on failure)
     psa.tasIdx = kv.second.first;
     psa.topo = r.status == KQ_TAS_OK ? r.domains : tas::Assignment();
+    psa.topoFlags.clear();
   }
-  ComputeTASNetUsage(a);
+  ComputeTASNetUsage(sn, wl, a);
 }
 // Assignment.updateMode flavorassigner.go:192-198
 static void updateModePS(Assignment& a, int ps, int mode) {
@@ -816,6 +867,23 @@ struct FlavorAssigner {
       std::map<int, FlavorAssignment> groupFlavors;
       bool groupNil = false;
       int groupReasons = 0;
+      if (sn.T && sn.T->ps_adm_flavor) {
+        // :765-779 "Respect preexisting assignments. The PodSet assignments may be already set if this is the second pass of scheduler":
+        // mode Fit, TriedFlavorIdx 0, and the flavor scan skips the resource (:819); the admission's TopologyAssignment comes along
+        const int g = wl.ps_base + i;
+        for (int r = 0; r < sn.nR; r++) {
+          const int fl = sn.T->ps_adm_flavor[(size_t)g * sn.nR + r];
+          if (fl >= 0) { FlavorAssignment fa; fa.flavor = fl; fa.mode = Fit; fa.tried = 0; fa.borrow = 0; groupFlavors[r] = fa; }
+        }
+        if (sn.T->ps_ex_off && sn.T->ps_ex_off[g + 1] > sn.T->ps_ex_off[g]) {
+          psa.hasTopo = true;
+          for (auto& kv : groupFlavors) if (sn.tasOfFlavor[kv.second.flavor] >= 0) psa.tasIdx = sn.tasOfFlavor[kv.second.flavor];
+          for (int j = sn.T->ps_ex_off[g]; j < sn.T->ps_ex_off[g + 1]; j++) {
+            psa.topo.push_back({sn.T->ps_ex_leaf[j], sn.T->ps_ex_count[j]});
+            psa.topoFlags.push_back(sn.T->ps_ex_flags[j]);
+          }
+        }
+      }
       for (auto& rq : podSet.req) {
         int resName = rq.first; int64_t quantity = rq.second;
         if (sn.RGByResource(cq, resName) < 0) {  // :809-817
@@ -878,10 +946,10 @@ struct FlavorAssigner {
         psa.reasons.push_back({KQ_RSN_TAS_FAILURE, sn.T->tas_flavor[failure.tas], -1, failure.status, failure.a, failure.b});
         updateModePS(assignment, failure.ps, Preempt);
       } else {
-        UpdateForTASResult(assignment, result);
+        UpdateForTASResult(sn, wl, assignment, result);
       }
     }
-    if (assignment.RepresentativeMode() == Preempt) {
+    if (assignment.RepresentativeMode() == Preempt && !(wl.flags & KQ_HEAD_HAS_UNHEALTHY_NODES)) {  // :879 "Don't preempt other workloads if looking for a failed node replacement"
       TasResult result = FindTopologyAssignmentsForWorkload(sn, wl, assignment, tasRequests, true, &sn.tasUnsupported);
       TasFailure failure = result.Failure();
       if (failure.failed) updateModePS(assignment, failure.ps, NoFit);
@@ -1540,6 +1608,7 @@ struct Scheduler {
   // scheduler.go:941-985
   void updateAssignmentForTAS(const Head& wl, Assignment& assignment, const std::vector<Target>& targets) {
     if (assignment.RepresentativeMode() != Preempt) return;
+    if (wl.flags & KQ_HEAD_UNHEALTHY_ASSIGNMENT) return;  // :952 !HasTopologyAssignmentWithUnhealthyNode
     bool anyExplicit = false;
     for (size_t p = 0; p < wl.ps.size(); p++) if (sn.T->ps_flags[wl.ps_base + p] & KQ_PS_TAS_EXPLICIT) anyExplicit = true;
     if (!anyExplicit && !sn.T->cq_tas_only[wl.cq]) return;
@@ -1552,7 +1621,7 @@ struct Scheduler {
     } else {
       tasResult = FindTopologyAssignmentsForWorkload(sn, wl, assignment, tasRequests, true, &sn.tasUnsupported);
     }
-    UpdateForTASResult(assignment, tasResult);
+    UpdateForTASResult(sn, wl, assignment, tasResult);
   }
   // scheduler.go:647 assignmentUsage -> netUsage :785-794
   FRQ assignmentUsage(const Entry& e) const {
@@ -1638,6 +1707,10 @@ struct Scheduler {
     bool fitsOk = updateAssignmentIfNeeded(e, cq, preemptedWorkloads, &usage);
     int mode = e.assignment.RepresentativeMode();
     e.finalMode = mode;
+    if (sn.T && !(sn.T->flags & KQ_CT_NO_FAIL_FAST) && (e.head.flags & KQ_HEAD_UNHEALTHY_ASSIGNMENT) && mode != Fit) {  // :425-428 handleFailedTASReplacement :522
+      e.status = KQ_ST_EVICTED; e.action = KQ_ACT_EVICT;
+      return;
+    }
     if (mode == NoFit) { e.requeueReason = KQ_RQ_NOFIT; return; }
     if (mode == Preempt) {
       if (e.preemptionTargets.empty()) {

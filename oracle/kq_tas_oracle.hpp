@@ -30,6 +30,9 @@ int64_t snapshot_bytes(const Snapshot* s);
 
 // FindTopologyAssignmentsForFlavor :578 for the podset requests [p0, p1) of rq, all of ONE workload. out[i] belongs to p0 + i.
 void find_workload(Snapshot& s, const kq_tas_requests* rq, int p0, int p1, bool simulateEmpty, std::vector<PodSetResult>* out);
+// The HasUnhealthyNodes branch of FindTopologyAssignmentsForFlavor (:608-633) for the podsets [p0, p1) of ONE workload: x as in
+// kq_tas_find_replacement (include/kq_tas.h). A podset with is_replacement == 0 gets no result (status KQ_TAS_SKIPPED, findPSA :612).
+void find_workload_replacement(Snapshot& s, const kq_tas_requests* rq, const kq_tas_replacement* x, int p0, int p1, std::vector<PodSetResult>* out);
 // TASFlavorSnapshot.Fits :433 for one TopologyDomainRequests{leaf, SinglePodRequests, Count}; req in the dense convention of
 // kq_tas_fits (0 = absent, KQ_TAS_REQ_ZERO = present with quantity zero).
 bool fits_domain(const Snapshot& s, int leaf, int32_t count, const int64_t* req);
