@@ -36,7 +36,8 @@ extern "C" {
 #define KQ_CT_NO_FAIL_FAST 2u    /* features.TASFailedNodeReplacementFailFast off (default on) */
 
 #define KQ_EX_UNHEALTHY 1u       /* the domain's node is one of Status.UnhealthyNodes (PodSetAssignment.HasUnhealthyNode tas_flavorassigner.go:85) */
-#define KQ_EX_FIRST     2u       /* ... and it is UnhealthyNodes[0]: the domain deleteDomain takes out (tas_flavor_snapshot.go:693, :828) */
+#define KQ_EX_FIRST     2u       /* ... and it is UnhealthyNodes[0]: the domain deleteDomain takes out (tas_flavor_snapshot.go:693, :828);
+                                  * at most one domain per podset (a node's name is unique among the hostname-level domains) */
 
 typedef struct kq_cycle_tas {
   uint32_t flags;                   /* KQ_CT_* */

@@ -63,8 +63,10 @@ GATE_BY_NAME = {
 NoFit, Preempt, DeferredFit, Fit = 0, 1, 2, 3
 MODE_NAMES = {0: "NoFit", 1: "Preempt", 2: "DeferredFit", 3: "Fit"}
 ST_NOT_NOMINATED, ST_NOMINATED, ST_SKIPPED, ST_ASSUMED = 0, 1, 2, 5
+ST_EVICTED = 4   # kq_cycle_run_tas: handleFailedTASReplacement
 RQ_GENERIC, RQ_FAILED_AFTER_NOMINATION, RQ_PENDING_PREEMPTION, RQ_NOFIT, RQ_PREEMPTION_NO_CANDIDATES = 0, 1, 4, 7, 8
 ACT_NONE, ACT_ADMIT, ACT_PREEMPT = 0, 1, 2
+ACT_EVICT = 3
 SKIP_NONE, SKIP_OVERLAP, SKIP_NO_LONGER_FITS = 0, 1, 2
 REASONS = {
     0: "InClusterQueue",
@@ -77,6 +79,8 @@ REASON_BY_NAME = {v: k for k, v in REASONS.items()}
 
 HEAD_HAS_QUOTA_RESERVATION = 0x1
 HEAD_IS_PREEMPTOR = 0x2
+HEAD_HAS_UNHEALTHY_NODES = 0x8
+HEAD_UNHEALTHY_ASSIGNMENT = 0x10
 HEAD_HAS_LAST_ASSIGNMENT = 0x4
 ADM_EVICTED = 0x1
 

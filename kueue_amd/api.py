@@ -209,6 +209,9 @@ class Workload:
     # pending side
     has_quota_reservation: bool = False
     is_preemptor: bool = False
+    # the second pass after a node failure (kq_cycle_run_tas): workload.HasUnhealthyNodes, workload.HasTopologyAssignmentWithUnhealthyNode
+    has_unhealthy_nodes: bool = False
+    unhealthy_assignment: bool = False
     last_assignment: Optional[LastAssignment] = None
     scheduling_hash: int = 0
     # ElasticJobsViaWorkloadSlices: name of the ADMITTED workload (same ClusterQueue) this one replaces (workloadslicing.ReplacedWorkloadSlice,
@@ -519,6 +522,10 @@ class Heads:
                 f |= F.HEAD_HAS_QUOTA_RESERVATION
             if w.is_preemptor:
                 f |= F.HEAD_IS_PREEMPTOR
+            if w.has_unhealthy_nodes:
+                f |= F.HEAD_HAS_UNHEALTHY_NODES
+            if w.unhealthy_assignment:
+                f |= F.HEAD_UNHEALTHY_ASSIGNMENT
             if w.last_assignment is not None:
                 f |= F.HEAD_HAS_LAST_ASSIGNMENT
             flags.append(f)

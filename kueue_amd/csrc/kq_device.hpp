@@ -854,6 +854,8 @@ KQ_DEV void tc_search_row(const K& k, const Wave& w, int slot, int row, bool add
 KQ_DEV bool tc_search_fits(const K& k, Wave& w, int slot);
 KQ_DEV void tc_update_assignment(const K& k, Wave& w, int slot, const int32_t* trow, int nt);
 KQ_NOINLINE void tc_publish(const K& k, Wave& w, int slot);
+KQ_DEV int tc_adm_flavor(const K& k, int psg, int res);
+KQ_DEV void tc_sp_reset(const K& k, int psg);
 #endif
 KQ_DEV int64_t pref_key(int pm, int64_t borrow, uint32_t pol) {
   if (pm == PM_NOFIT) return -1;
@@ -2112,6 +2114,20 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
     if (LEAN || KQ_TAS_PROCESS(k, w)) KQ_TS(k, 57);  // lean: requests of the podset in iterator order, output rows cleared
     bool group_failed = false;
     int ps_reasons = 0, ps_nflavors = 0, ps_mode = M_FIT;
+#ifdef KQ_TAS_CYCLE
+    if constexpr (!LEAN) if (k.tc) {
+      // "Respect preexisting assignments. The PodSet assignments may be already set if this is the second pass of scheduler"
+      // (flavorassigner.go:765-779): the admission's flavor, mode Fit, TriedFlavorIdx 0, and no flavor scan for the resource (:819)
+      tc_sp_reset(k, psg);
+      for (int a = 0; a < w.nreq; a++) {
+        const int fl = tc_adm_flavor(k, psg, w.req_res[a]);
+        if (fl < 0) continue;
+        ps_nflavors++;
+        if (lane == 0) { w.req_done[a] = 1; w.req_flavor[a] = fl; w.req_mode[a] = M_FIT; w.req_borrow[a] = 0; w.req_tried[a] = 0; }
+      }
+      wsync();
+    }
+#endif
     if (lane == 0) w.rsn_ps0 = w.nrsn;
     for (int a = 0; a < w.nreq && !group_failed; a++) {
       const int res_name = w.req_res[a];

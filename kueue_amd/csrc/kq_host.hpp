@@ -9,6 +9,7 @@
 #pragma once
 #include <cstdlib>
 #include <algorithm>
+#include <map>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -969,8 +970,10 @@ template <class B> struct EngineT {
     std::vector<int32_t> ps_class(std::max<size_t>(nps, 1), -1), cls_rep;
     if (!tas_classes_off) {
       std::unordered_map<std::string, int> ids;
+      std::vector<uint8_t> repl_head(std::max<size_t>(nps, 1), 0);   // podsets of a head that looks for a failed node's replacement: rewritten requests
+      if (t->ps_adm_flavor) for (int i = 0; i < n; i++) if (h->flags[i] & KQ_HEAD_HAS_UNHEALTHY_NODES) for (int p = h->ps_off[i]; p < h->ps_off[i + 1]; p++) repl_head[p] = 1;
       for (size_t p = 0; p < nps; p++) {
-        if (t->ps_group[p] >= 0 || (t->ps_n_layers && t->ps_n_layers[p] > 1)) continue;
+        if (t->ps_group[p] >= 0 || (t->ps_n_layers && t->ps_n_layers[p] > 1) || repl_head[p]) continue;
         std::string key((const char*)(t->ps_req + p * R), (size_t)R * 8);
         key.append((const char*)&t->ps_slice_size[p], 4);
         key.append((const char*)(t->ps_slice_level + p * nt), (size_t)nt * 4);
@@ -990,6 +993,8 @@ template <class B> struct EngineT {
     std::vector<int64_t*> work(nt), np(nt), priv(nt);
     std::vector<int32_t*> cls_tab(nt), cls_tab_e(nt), cflag(nt), par(nt);
     std::vector<long long*> cls_bytes(nt);
+    const bool second = t->ps_adm_flavor != nullptr;   // heads that hold an admission (the second pass)
+    std::vector<std::vector<int32_t>> h_first(nt), h_cnt(nt), h_par(nt);   // host mirrors of the trees (second pass: requiredReplacementDomain)
     int max_leaves = 1;
     for (int i = 0; i < nt; i++) {
       const kq_tas_topology& tp = t->topo[i];
@@ -1025,6 +1030,7 @@ template <class B> struct EngineT {
       T.child_first = tstage(first.data(), first.size()); T.child_cnt = tstage(cnt.data(), cnt.size());
       par[i] = tstage(parent.data(), parent.size());
       be.sync();  // (first / cnt / parent are locals)
+      if (second) { h_first[i] = first; h_cnt[i] = cnt; h_par[i] = parent; }
       cls_tab[i] = tgrow<int32_t>((size_t)5 * std::max(ncls, 1) * std::max(T.D, 1));
       cls_tab_e[i] = tgrow<int32_t>((size_t)5 * std::max(ncls, 1) * std::max(T.D, 1));
       cls_bytes[i] = (long long*)tgrow<int64_t>(std::max(ncls, 1));
@@ -1073,6 +1079,114 @@ template <class B> struct EngineT {
     c.ps_n_layers = layered ? tstage(t->ps_n_layers, nps) : nullptr;
     c.ps_layer_level = layered ? tstage(t->ps_layer_level, nps * nt * KQ_TAS_MAX_LEVELS) : nullptr;
     c.ps_layer_size = layered ? tstage(t->ps_layer_size, nps * KQ_TAS_MAX_LEVELS) : nullptr;
+    // ---- the second pass (kq_cycle_tas.ps_adm_flavor / ps_ex_*) ----------------------------------------------------------------
+    std::vector<uint8_t> sp_kind;
+    std::vector<int32_t> sp_req, sp_tas;
+    if (second) {
+      const int nR = prep.nR;
+      if (t->ps_ex_off && t->ps_ex_off[nps] > 0 && (!t->ps_ex_leaf || !t->ps_ex_count || !t->ps_ex_flags)) return fail(KQ_EINVAL, "ps_ex_off without ps_ex_leaf / ps_ex_count / ps_ex_flags");
+      if (t->ps_ex_off && t->ps_ex_off[0] != 0) return fail(KQ_EINVAL, "ps_ex_off[0] must be 0");
+      sp_kind.assign(std::max<size_t>(nps, 1), 0); sp_req.assign(std::max<size_t>(nps, 1) * SP_W, 0); sp_tas.assign(std::max<size_t>(nps, 1), -1);
+      for (int i = 0; i < n; i++)
+        for (int g = h->ps_off[i]; g < h->ps_off[i + 1]; g++) {
+          int32_t* sp = sp_req.data() + (size_t)g * SP_W;
+          sp[SP_DEL] = -1;
+          int tt = -1;
+          for (int r = 0; r < nR; r++) {
+            const int fl = t->ps_adm_flavor[(size_t)g * nR + r];
+            if (fl < -1 || fl >= prep.nF) return fail(KQ_EINVAL, "ps_adm_flavor out of range");
+            if (fl >= 0 && !(h->flags[i] & KQ_HEAD_HAS_QUOTA_RESERVATION)) return fail(KQ_EINVAL, "ps_adm_flavor on a head without KQ_HEAD_HAS_QUOTA_RESERVATION");
+            if (fl >= 0 && tas_of[fl] >= 0) tt = tas_of[fl];
+          }
+          sp_tas[g] = tt;
+          const int e0 = t->ps_ex_off ? t->ps_ex_off[g] : 0, e1 = t->ps_ex_off ? t->ps_ex_off[g + 1] : 0;
+          if (e1 < e0) return fail(KQ_EINVAL, "ps_ex_off not monotone");
+          if (e1 == e0) continue;
+          if (tt < 0) return fail(KQ_EINVAL, "a podset holds a TopologyAssignment but none of its admitted flavors is a TAS flavor");
+          const TTopo& T = tks[tt].T;
+          sp_kind[g] |= SP_HAS_EX;
+          for (int j = e0; j < e1; j++) {
+            if (t->ps_ex_leaf[j] >= T.n_leaves || t->ps_ex_count[j] < 0) return fail(KQ_EINVAL, "existing assignment out of range");
+            if (t->ps_ex_flags[j] & KQ_EX_UNHEALTHY) sp_kind[g] |= SP_UNHEALTHY;
+          }
+          if (!(h->flags[i] & KQ_HEAD_HAS_UNHEALTHY_NODES) || !(sp_kind[g] & SP_UNHEALTHY)) continue;
+          // findReplacementAssignment :686 up to the placement: deleteDomain :693, the stale check :694, requiredReplacementDomain :759,
+          // the rewrite of the slice request :703-722
+          std::vector<std::pair<int, int32_t>> ex;   // the assignment after deleteDomain
+          int32_t affected = 0;
+          int n_first = 0;
+          for (int j = e0; j < e1; j++) if (t->ps_ex_flags[j] & KQ_EX_FIRST) n_first++;
+          if (n_first > 1) return fail(KQ_EINVAL, "more than one domain of a podset flagged KQ_EX_FIRST (a node holds one domain of an assignment)");
+          for (int j = e0; j < e1; j++) {
+            if (t->ps_ex_flags[j] & KQ_EX_FIRST) { affected = t->ps_ex_count[j]; sp[SP_DEL] = t->ps_ex_leaf[j]; }
+            else ex.push_back({t->ps_ex_leaf[j], t->ps_ex_count[j]});
+          }
+          sp[SP_COUNT] = affected;
+          sp[SP_SSIZE] = t->ps_slice_size[g]; sp[SP_SLEVEL] = t->ps_slice_level[(size_t)g * nt + tt];
+          sp[SP_LO] = 0; sp[SP_HI] = 0;   // (hi <= 0: every leaf)
+          int stale = -1;
+          for (size_t j = 0; j < ex.size() && stale < 0; j++) if (ex[j].first < 0) stale = (int)j;
+          if (stale >= 0) { sp[SP_STATUS] = KQ_TAS_STALE; sp[SP_OPA] = stale; continue; }
+          std::vector<std::pair<int, int32_t>> cons;   // PodSetSliceRequiredTopologyConstraints (level, size), outermost first
+          const int nl = t->ps_n_layers ? t->ps_n_layers[g] : 0;
+          if (nl > 1) for (int j = 0; j < nl; j++) cons.push_back({t->ps_layer_level[((size_t)g * nt + tt) * KQ_TAS_MAX_LEVELS + j], t->ps_layer_size[(size_t)g * KQ_TAS_MAX_LEVELS + j]});
+          else if (t->ps_slice_size[g] != 1) cons.push_back({t->ps_slice_level[(size_t)g * nt + tt], t->ps_slice_size[g]});
+          const std::vector<int32_t>& P = h_par[tt];
+          auto ancestor = [&](int leaf, int lv) { int d = T.leaf_base + leaf; for (int l = T.L - 1; l > lv; l--) d = P[d]; return d; };
+          auto incomplete = [&](int32_t missing, int32_t size, int lv) {   // findIncompleteSliceDomain :842 (the first in the canonical domain order)
+            if (lv < 0 || lv >= T.L || size <= 0) return -1;
+            std::map<int, int32_t> use;
+            for (auto& dc : ex) if (dc.first >= 0) use[ancestor(dc.first, lv)] += dc.second;
+            for (auto& kv : use) if ((kv.second + missing) % size == 0) return kv.first;
+            return -1;
+          };
+          const int level = t->ps_level[(size_t)g * nt + tt];
+          const int32_t size0 = cons.empty() ? 1 : cons[0].second;
+          int required = -1;   // requiredReplacementDomain :759
+          if (level >= 0 && level < T.L && !ex.empty() && size0 > 0) {
+            if (!cons.empty() && affected % size0 != 0) {
+              bool found = false;
+              if (cons.size() > 1)
+                for (size_t j = cons.size(); j-- > 0 && !found;)
+                  if (cons[j].second > 0 && affected % cons[j].second != 0) { required = incomplete(affected, cons[j].second, cons[j].first); found = true; }
+              if (!found) required = incomplete(affected, size0, cons[0].first);
+            } else if (t->ps_kind[g] == KQ_TAS_REQUIRED && ex[0].first >= 0) required = ancestor(ex[0].first, level);
+          }
+          if (size0 <= 0) { sp[SP_STATUS] = KQ_TAS_BAD_SLICE_SIZE; continue; }   // :699-702
+          if (!cons.empty() && required >= 0 && affected % size0 != 0) {   // :703-722
+            int32_t eff = 1; int eff_level = -1;
+            for (size_t j = cons.size(); j-- > 0;) if (cons[j].second > 0 && affected % cons[j].second == 0) { eff = cons[j].second; eff_level = cons[j].first; break; }
+            sp[SP_NLAY] = 1;
+            sp[SP_SSIZE] = eff_level >= 0 ? eff : 1; sp[SP_SLEVEL] = eff_level >= 0 ? eff_level : T.L - 1;
+          }
+          if (required >= 0) {   // the leaves below it (:1902-1905): the domains of a level are ordered by their parents, so a contiguous run
+            int lv = 0;
+            while (lv < T.L && !(required >= T.level_off[lv] && required < T.level_off[lv + 1])) lv++;
+            int lo = required, hi = required + 1;
+            for (int l = lv; l < T.L - 1 && hi > lo; l++) {
+              int nlo = -1, nhi = -1;
+              for (int d = lo; d < hi; d++) if (h_first[tt][d] >= 0) { if (nlo < 0) nlo = h_first[tt][d]; nhi = h_first[tt][d] + h_cnt[tt][d]; }
+              if (nlo < 0) { lo = hi = T.leaf_base + 1; break; }   // (a domain without leaves: the empty range [1, 1))
+              lo = nlo; hi = nhi;
+            }
+            sp[SP_LO] = lo - T.leaf_base; sp[SP_HI] = hi - T.leaf_base;
+          }
+        }
+      // (the podsets of a replacement are placed one by one in podset order; the reference walks groupsOrder :591-603)
+      for (int i = 0; i < n; i++) {
+        if (!(h->flags[i] & KQ_HEAD_HAS_UNHEALTHY_NODES)) continue;
+        for (int g = h->ps_off[i]; g < h->ps_off[i + 1]; g++) {
+          if (t->ps_group[g] < 0) continue;
+          int last = g;
+          for (int q = g + 1; q < h->ps_off[i + 1]; q++) if (t->ps_group[q] == t->ps_group[g]) { if (q != last + 1) return fail(KQ_EUNSUPPORTED, "node replacement of a workload whose podset groups interleave"); last = q; }
+        }
+      }
+      c.ps_adm_flavor = tstage(t->ps_adm_flavor, nps * nR);
+      c.sp_kind = tstage(sp_kind.data(), sp_kind.size()); c.sp_req = tstage(sp_req.data(), sp_req.size());
+      c.sp_del_out = tgrow<int32_t>(std::max<size_t>(nps, 1));
+      be.memset(c.sp_del_out, 0, std::max<size_t>(nps, 1) * 4);
+      be.sync();   // (sp_kind / sp_req are staged from locals that stay alive, but the copy must not outlive a later resize)
+    }
     c.q_i32 = tgrow<int32_t>((size_t)slots * TQ_WORDS); c.q_u8 = tgrow<uint8_t>((size_t)slots * (TC_P + 8)); c.q_spr = tgrow<int64_t>((size_t)slots * TC_P * R);
     // a head's TopologyAssignments hold at most min(pods, leaves) domains per podset
     int d_cap = 1;
@@ -1142,16 +1256,45 @@ template <class B> struct EngineT {
     rc = be.sync();
     if (rc != KQ_OK) return fail(rc, be.error());
     if (stats) { stats[0] = hm[0]; stats[1] = hm[1]; stats[2] = hm[2]; stats[3] = hm[3]; }
+    std::vector<int32_t> del_out;
+    if (second) { del_out.resize(std::max<size_t>(nps, 1)); be.d2h(del_out.data(), c.sp_del_out, nps * 4); rc = be.sync(); if (rc != KQ_OK) return fail(rc, be.error()); }
     int tot = 0;
+    auto put = [&](int leaf, int32_t count) {
+      if (tot >= tout->dom_cap) return false;
+      if (tout->dom_leaf) tout->dom_leaf[tot] = leaf;
+      if (tout->dom_count) tout->dom_count[tot] = count;
+      tot++;
+      return true;
+    };
     for (size_t p = 0; p < nps; p++) {
-      const int tt = ht[p], pos = ht[nps + p], cnt = tt >= 0 ? ht[2 * nps + p] : 0;
-      tout->ps_tas[p] = tt;
-      for (int j = 0; j < cnt; j++) {
-        if (tot >= tout->dom_cap) return fail(KQ_ECAPACITY, "dom_cap too small");
-        if (tout->dom_leaf) tout->dom_leaf[tot] = pl[pos + j];
-        if (tout->dom_count) tout->dom_count[tot] = pc[pos + j];
-        tot++;
+      int tt = ht[p]; const int pos = ht[nps + p], cnt = tt >= 0 ? ht[2 * nps + p] : 0;
+      if (second && (sp_kind[p] & SP_HAS_EX)) {
+        // a podset whose admission holds a TopologyAssignment: what the device published is the replacement's net usage — the caller gets
+        // mergeTopologyAssignments :2072 of it with the admission's other domains; a podset that was not placed again (no failed node
+        // in it, or no replacement found) keeps the admission's assignment as it is
+        const int e0 = t->ps_ex_off[p], e1 = t->ps_ex_off[p + 1];
+        if (tt >= 0) {
+          std::vector<std::pair<int, int32_t>> m;
+          for (int j = 0; j < cnt; j++) m.push_back({pl[pos + j], pc[pos + j]});
+          if (del_out[p] > 0) m.push_back({sp_req[p * SP_W + SP_DEL], del_out[p]});
+          for (int j = e0; j < e1; j++) if (!(t->ps_ex_flags[j] & KQ_EX_FIRST)) m.push_back({t->ps_ex_leaf[j], t->ps_ex_count[j]});
+          std::stable_sort(m.begin(), m.end(), [](const std::pair<int, int32_t>& a, const std::pair<int, int32_t>& b) { return a.first < b.first; });
+          int last = -1;
+          for (auto& d : m) {
+            if (last >= 0 && tout->dom_leaf && tout->dom_leaf[last] == d.first) { if (tout->dom_count) tout->dom_count[last] += d.second; continue; }
+            if (!put(d.first, d.second)) return fail(KQ_ECAPACITY, "dom_cap too small");
+            last = tot - 1;
+          }
+        } else if (del_out[p] >= 0) {   // (-1: a failed result took the assignment away, UpdateForTASResult flavorassigner.go:90)
+          tt = sp_tas[p];
+          for (int j = e0; j < e1; j++) if (!put(t->ps_ex_leaf[j], t->ps_ex_count[j])) return fail(KQ_ECAPACITY, "dom_cap too small");
+        }
+        tout->ps_tas[p] = tt;
+        tout->dom_off[p + 1] = tot;
+        continue;
       }
+      tout->ps_tas[p] = tt;
+      for (int j = 0; j < cnt; j++) if (!put(pl[pos + j], pc[pos + j])) return fail(KQ_ECAPACITY, "dom_cap too small");
       tout->dom_off[p + 1] = tot;
     }
     return KQ_OK;

@@ -93,7 +93,8 @@ struct TCyc {
   // [lo, hi) = the leaves below requiredReplacementDomain :759, leaf of the deleted domain (-1 = not a leaf of the snapshot)}
   const int32_t* sp_req;
   int32_t* sp_del_out;            // [n_ps] pods the replacement put back on the deleted domain's leaf: the admission accounts for them
-                                  // already (ComputeTASNetUsage flavorassigner.go:131-141), so they are kept out of the wave's usage list
+                                  // already (ComputeTASNetUsage flavorassigner.go:131-141), so they are kept out of the wave's usage list;
+                                  // -1 = the podset lost the admission's assignment to a failed result
 };
 constexpr int SP_W = 12, SP_STATUS = 0, SP_OPA = 1, SP_OPB = 2, SP_COUNT = 3, SP_SSIZE = 4, SP_SLEVEL = 5, SP_NLAY = 6, SP_LO = 7, SP_HI = 8, SP_DEL = 9;
 constexpr uint8_t SP_HAS_EX = 1, SP_UNHEALTHY = 2;
@@ -285,6 +286,12 @@ KQ_DEV int tc_flavor_of(const TCyc& c, int nF, int t) {  // the ResourceFlavor o
 }
 
 // ---- Assign's TAS step -------------------------------------------------------------------------------------------------------------------
+KQ_DEV int tc_adm_flavor(const K& k, int psg, int res) {
+  const TCyc& c = *k.tc;
+  return c.ps_adm_flavor ? c.ps_adm_flavor[(size_t)psg * k.S.nR + res] : -1;
+}
+// a fresh Assign starts from the admission's TopologyAssignment again (flavorassigner.go:777-779)
+KQ_DEV void tc_sp_reset(const K& k, int psg) { if (k.tc->sp_del_out && lane_id() == 0) k.tc->sp_del_out[psg] = 0; }
 KQ_DEV void tc_reset(Wave& w) {
   if (lane_id() == 0) { w.ta.t = -1; w.ta.nreq = 0; w.ta.af_early = 0; w.ta.err_mask = 0; w.ta.has_mask = 0; w.ta.kept_used = 0; w.ta.srch = 0; w.ta.em_ps = -1; }
 }
@@ -529,7 +536,7 @@ KQ_NOINLINE void tc_keep_result(const K& k, Wave& w, int slot) {
         if (lane_id() == 0) { kl[at + o] = lf; kc[at + o] = cn; }
         o++;
       }
-      if (lane_id() == 0) c.sp_del_out[g] = ok ? back : 0;
+      if (lane_id() == 0) c.sp_del_out[g] = ok ? back : -1;   // -1: UpdateForTASResult took the admission's assignment away (a failed result, flavorassigner.go:90)
       kept = o;
       wsync();
     } else {

@@ -42,7 +42,7 @@ struct TReq {
   const int32_t *seed_off, *seed_leaf, *seed_count, *seed_ps;
   // the leaves below a required replacement domain (tas_flavor_snapshot.go:1902-1905), per podset request: [leaf_lo, leaf_hi) in leaf
   // indices; NULL = every leaf. (kq_cycle_run_tas's second pass; the batch entry point kq_tas_find_replacement passes a leaf_ok row.)
-  const int32_t *leaf_lo = nullptr, *leaf_hi = nullptr;
+  const int32_t *leaf_lo, *leaf_hi;
 };
 struct TOut {
   int32_t *status, *op_a, *op_b, *dom_pos, *dom_n;  // per podset request; dom_pos = offset into the pool
@@ -161,7 +161,7 @@ struct TParams {  // topologyAssignmentParameters :473 + requirements :461
   const int64_t* req;        // [R] SinglePodRequests of the workers (pods added on the fly)
   const int64_t* leaderReq;  // [R] or NULL
   const uint8_t* leafOk;
-  int leafLo = 0, leafHi = 0x7fffffff;   // the leaves below the required replacement domain (:1902), all of them by default
+  int leafLo, leafHi;   // the leaves below the required replacement domain (:1902): [leafLo, leafHi); leafHi <= 0 = every leaf
   // TASMultiLayerTopology: sliceSizeAtLevel :474 (0 = no entry), the constraint list for multiLayerNotFitMessage :2030
   int32_t sizeAt[KQ_TAS_MAX_LEVELS + 1];
   int nLayers;                // len(multiLayerConstraints) :482, 0 unless sliceSizeAtLevel has an entry
@@ -215,7 +215,7 @@ struct TLeafArgs {
   const uint8_t* leafOk;
   int simulateEmpty, hasAssumed, sliceLevelIdx;
   int32_t sliceSize;
-  int leafLo = 0, leafHi = 0x7fffffff;
+  int leafLo, leafHi;   // [leafLo, leafHi) of the leaves, leafHi <= 0 (what a shorter initializer list leaves) = every leaf
 };
 // one sweep over a slice of domains (t_view_first_fit): what it is after, and what a wave found in its share of the elements
 struct TSweepArgs { int n, order, id0; bool lfc, by_order; int32_t needed, leaderCount; int which; };
@@ -317,7 +317,7 @@ template <int RM, int U> KQ_DEV int64_t t_leaf_counts(const TTopo& T, const TLea
     #pragma unroll
     for (int u = 0; u < U; u++) {
       const int leaf = leaf0 + u * stride;
-      ok[u] = leaf < T.n_leaves && leaf >= a.leafLo && leaf < a.leafHi && (!a.leafOk || a.leafOk[leaf]);
+      ok[u] = leaf < T.n_leaves && (a.leafHi <= 0 || (leaf >= a.leafLo && leaf < a.leafHi)) && (!a.leafOk || a.leafOk[leaf]);
       #pragma unroll
       for (int r = 0; r < RM; r++) {
         rem[u][r] = 0;
@@ -1272,7 +1272,7 @@ template <bool LDS> KQ_DEV void t_workload_t(const TK& k, int slot, int w) {
     st.simulateEmpty = Q.sim_empty && Q.sim_empty[w]; st.hasLeader = leader >= 0; st.hasAssumed = hasAssumed;
     st.req = Q.spr + (size_t)workers * T.R; st.leaderReq = leader >= 0 ? Q.spr + (size_t)leader * T.R : nullptr;
     st.leafOk = Q.leaf_ok ? Q.leaf_ok + (size_t)workers * T.n_leaves : nullptr;
-    if (Q.leaf_lo) { st.leafLo = Q.leaf_lo[workers]; st.leafHi = Q.leaf_hi[workers]; }
+    st.leafLo = Q.leaf_lo ? Q.leaf_lo[workers] : 0; st.leafHi = Q.leaf_lo ? Q.leaf_hi[workers] : 0;
     #pragma unroll
     for (int l = 0; l <= KQ_TAS_MAX_LEVELS; l++) st.sizeAt[l] = 0;
     st.nLayers = 0; st.layerLevel = nullptr; st.layerSize = nullptr;
@@ -1377,7 +1377,7 @@ KQ_DEV void t_class(const TK& k, int c) {
   st.sliceLevelIdx = Q.slice_level[workers]; st.requestedLevelIdx = Q.level[workers];
   st.simulateEmpty = k.C.sim_empty[c] != 0; st.hasAssumed = false;
   st.req = Q.spr + (size_t)workers * T.R; st.leaderReq = leader >= 0 ? Q.spr + (size_t)leader * T.R : nullptr;
-  st.leafOk = nullptr;
+  st.leafOk = nullptr; st.leafLo = 0; st.leafHi = 0;
   if (lane_id() == 0) k.C.bytes[c] = 0;
   wsync();
   if (st.sliceSize <= 0 || st.sliceLevelIdx < 0 || st.sliceLevelIdx >= T.L) return;  // the workloads of the class fail before phase 1

@@ -103,6 +103,9 @@ def _workload(d: dict) -> Workload:
         creation_ts=int(d.get("created", 0)), pod_sets=_podsets(d), uid=d.get("uid"),
         reserve_ts=d.get("reservedAt"), evicted=bool(d.get("evicted", False)),
         has_quota_reservation=bool(d.get("hasQuotaReservation", False)), is_preemptor=bool(d.get("isPreemptor", False)),
+        has_unhealthy_nodes=bool(d.get("unhealthyNodes")),
+        unhealthy_assignment=bool(d.get("unhealthyNodes")) and bool(d.get("isAdmitted", False)) and any(
+            dm[0][-1] in d["unhealthyNodes"] for ps in d.get("admission") or [] for dm in (ps.get("topologyAssignment") or {}).get("domains", [])),
         last_assignment=la, scheduling_hash=int(d.get("hash", 0)), replaces=d.get("replaces"),
     )
 

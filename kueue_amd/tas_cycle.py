@@ -75,6 +75,19 @@ class AdmittedTAS:
     single_pod_requests: Dict[str, object]
 
 
+@dataclass
+class HeadAdmission:
+    """Status.Admission + Status.UnhealthyNodes of a head on its second pass (workload.NeedsSecondPass workload.go:974): per podset the
+    admitted flavor of every resource and the TopologyAssignment (None: none yet — a delayed topology request)."""
+    flavors: List[Dict[str, str]]                                    # [podset] resource -> flavor
+    domains: List[Optional[List[Tuple[Tuple[str, ...], int]]]]       # [podset] (levelValues as stored, count) in the assignment's order
+    unhealthy_nodes: List[str] = field(default_factory=list)
+    admitted: bool = True                                            # workload.IsAdmitted
+
+    def names_unhealthy(self) -> bool:   # HasTopologyAssignmentWithUnhealthyNode workload.go:1392
+        return self.admitted and any(v[-1] in self.unhealthy_nodes for d in self.domains if d for v, _ in d)
+
+
 def tas_only(cq, tas_flavors) -> bool:
     return all(fq.name in tas_flavors for rg in cq.resource_groups for fq in rg.flavors)
 
@@ -126,7 +139,8 @@ class CycleTAS:
     """kq_cycle_tas for one (Snapshot, Heads)."""
 
     def __init__(self, snap: Snapshot, heads: Heads, topologies: Dict[str, Topology], pod_tas: Dict[Tuple[str, int], PodSetTAS],
-                 admitted_tas: Optional[Dict[str, List[AdmittedTAS]]] = None, recompute: bool = True):
+                 admitted_tas: Optional[Dict[str, List[AdmittedTAS]]] = None, recompute: bool = True,
+                 head_admission: Optional[Dict[str, HeadAdmission]] = None, fail_fast: bool = True):
         self.snap, self.heads = snap, heads
         names = sorted(topologies)                       # slices.Sorted(maps.Keys(...)) clusterqueue_snapshot.go:220
         self.names = names
@@ -194,13 +208,42 @@ class CycleTAS:
                  ps_group=group, ps_req=req.reshape(-1).copy())
         if (nlay > 1).any():
             a.update(ps_n_layers=nlay, ps_layer_level=llev.reshape(-1).copy(), ps_layer_size=lsz.reshape(-1).copy())
+        if head_admission:
+            # the second pass: Status.Admission of the heads that hold one (include/kq_cycle_tas.h ps_adm_flavor / ps_ex_*)
+            nR = snap.n_resource
+            adm = np.full((max(n_ps, 1), nR), -1, np.int32)
+            xo, xl, xc, xf = [0], [], [], []
+            self.ex_domains: Dict[int, list] = {}
+            g = 0
+            for w in heads.workloads:
+                ha = head_admission.get(w.name)
+                for pi, ps in enumerate(w.pod_sets):
+                    if ha is not None:
+                        assert w.has_quota_reservation, "a head that holds an admission has its quota reserved"
+                        for r, fl in ha.flavors[pi].items():
+                            adm[g, snap.resource_index[r]] = snap.flavor_index[fl]
+                        tas_fl = [fl for fl in set(ha.flavors[pi].values()) if fl in tix]
+                        for values, cnt in (ha.domains[pi] or []):
+                            assert len(tas_fl) == 1, "a TopologyAssignment belongs to the podset's one TAS flavor"
+                            leaf = _leaf_of(topologies[tas_fl[0]], tuple(values))
+                            f = 0
+                            if values[-1] in ha.unhealthy_nodes:
+                                f |= EX_UNHEALTHY
+                                if ha.unhealthy_nodes and values[-1] == ha.unhealthy_nodes[0]:
+                                    f |= EX_FIRST
+                            xl.append(-1 if leaf is None else leaf); xc.append(cnt); xf.append(f)
+                            self.ex_domains.setdefault(g, []).append((list(values), cnt))
+                    xo.append(len(xl))
+                    g += 1
+            a.update(ps_adm_flavor=adm.reshape(-1).copy(), ps_ex_off=np.array(xo, np.int32), ps_ex_leaf=np.array(xl or [0], np.int32),
+                     ps_ex_count=np.array(xc or [0], np.int32), ps_ex_flags=np.array(xf or [0], np.uint8))
         self.arrays = a
         self._topo_arr = (kq_tas_topology * max(nt, 1))()
         for i, t in enumerate(self.topos):
             st = t.struct()
             C.memmove(C.byref(self._topo_arr, i * C.sizeof(kq_tas_topology)), C.byref(st), C.sizeof(kq_tas_topology))
         self._struct = kq_cycle_tas()
-        F.fill_struct(self._struct, a, dict(n_tas=nt, flags=0 if recompute else CT_NO_RECOMPUTE))
+        F.fill_struct(self._struct, a, dict(n_tas=nt, flags=(0 if recompute else CT_NO_RECOMPUTE) | (0 if fail_fast else CT_NO_FAIL_FAST)))
         self._struct.topo = C.cast(self._topo_arr, C.POINTER(kq_tas_topology))
 
     def struct(self) -> kq_cycle_tas:
@@ -229,6 +272,11 @@ class CycleTASOut:
             return None
         topo = self.ct.topos[t]
         o = self.a["dom_off"]
+        if any(int(self.a["dom_leaf"][k]) < 0 for k in range(o[g], o[g + 1])):
+            # the admission's own assignment, untouched (it names a node the snapshot no longer holds): its values as the caller gave them
+            ex = getattr(self.ct, "ex_domains", {}).get(g, [])
+            assert [c for _, c in ex] == [int(self.a["dom_count"][k]) for k in range(o[g], o[g + 1])], (g, ex)
+            return self.ct.names[t], [(list(v), c) for v, c in ex]
         return self.ct.names[t], [(topo.leaf_values(int(self.a["dom_leaf"][k])), int(self.a["dom_count"][k])) for k in range(o[g], o[g + 1])]
 
 
@@ -275,7 +323,7 @@ def load_tas_case(case: dict, cycle: int = 1):
     extra = set()
     for w in case.get("pending", []) + case.get("admitted", []):
         for ps in w.get("podsets", []):
-            extra.update((ps.get("requests") or {}).keys())
+            extra.update((ps.get("requests") or {}).keys()); extra.update((ps.get("podRequests") or {}).keys())
     non_tas = {node: {r: (sum(_amount(r, q) for q in qs) if isinstance(qs, (list, tuple)) else _amount(r, qs)) for r, qs in d.items()}
                for node, d in (case.get("nonTASUsage") or {}).items()}
     topologies = build_topologies(list(flavors.values()), {k: list(v) for k, v in (case.get("topologies") or {}).items()}, nodes,
@@ -289,14 +337,14 @@ def load_tas_case(case: dict, cycle: int = 1):
             tr = TopologyRequest(required=t.get("required"), preferred=t.get("preferred"), unconstrained=bool(t.get("unconstrained", False)),
                                  slice_required_topology=t.get("sliceRequiredTopology"), slice_size=t.get("sliceSize"),
                                  slice_constraints=[(c["topology"], c["size"]) for c in t["sliceConstraints"]] if t.get("sliceConstraints") else None)
-        return PodSetTAS(tr, ps.get("group"), dict(ps.get("requests") or {}))
+        return PodSetTAS(tr, ps.get("group"), dict(ps.get("podRequests") or ps.get("requests") or {}))
 
     pod_tas: Dict[Tuple[str, int], PodSetTAS] = {}
     for w in case.get("pending", []):
         for pi, ps in enumerate(w.get("podsets", [])):
             pt = req_of(ps)
             pod_tas[(w["name"], pi)] = pt
-            ex = excluded_flavors_for_tas(cqs[w["cq"]], list((ps.get("requests") or {}).keys()), pt, topologies, flavors)
+            ex = excluded_flavors_for_tas(cqs[w["cq"]], list((ps.get("requests") or ps.get("totalRequests") or {}).keys()), pt, topologies, flavors)
             ps["excludedFlavors"] = sorted(set(ps.get("excludedFlavors") or []) | set(ex))
     admitted_tas: Dict[str, List[AdmittedTAS]] = {}
     for w in case.get("admitted", []):
@@ -313,4 +361,14 @@ def load_tas_case(case: dict, cycle: int = 1):
     case["flavors"] = sorted(set(case["flavors"]) | set(flavors))
     cfg, snap, heads = load_case(case, cycle)
     recompute = bool((case.get("gatesGo") or {}).get("TASRecomputeAssignmentWithinSchedulingCycle", True))
-    return cfg, snap, heads, CycleTAS(snap, heads, topologies, pod_tas, admitted_tas, recompute=recompute)
+    fail_fast = bool((case.get("gatesGo") or {}).get("TASFailedNodeReplacementFailFast", True))
+    head_adm = {}
+    for w in case.get("pending", []):
+        if w.get("admission") is None:
+            continue
+        head_adm[w["name"]] = HeadAdmission(
+            flavors=[dict(ps.get("flavors") or {}) for ps in w["admission"]],
+            domains=[[(tuple(d[0]), int(d[1])) for d in ps["topologyAssignment"]["domains"]] if ps.get("topologyAssignment") else None for ps in w["admission"]],
+            unhealthy_nodes=list(w.get("unhealthyNodes") or []), admitted=bool(w.get("isAdmitted", True)))
+    return cfg, snap, heads, CycleTAS(snap, heads, topologies, pod_tas, admitted_tas, recompute=recompute, head_admission=head_adm or None,
+                                      fail_fast=fail_fast)

@@ -16,7 +16,8 @@ import (
 // decision codes of include/kq_engine.h
 const (
 	stNotNominated, stNominated, stSkipped, stAssumed = 0, 1, 2, 5
-	actNone, actAdmit, actPreempt                     = 0, 1, 2
+	actNone, actAdmit, actPreempt, actEvict           = 0, 1, 2, 3
+	stEvicted                                         = 4 // KQ_ST_EVICTED (kq_cycle_run_tas)
 	modeNoFit, modePreempt, modeDeferredFit, modeFit  = 0, 1, 2, 3
 	skipNone, skipOverlap, skipNoLongerFits           = 0, 1, 2
 )
@@ -41,6 +42,7 @@ type Outcome struct {
 	Order           int // position in the entry iterator: side effects are issued in this order (scheduler.go:358)
 	Status          uint8
 	Admit, Preempt  bool
+	Evict           bool // KQ_ACT_EVICT: the second pass found no replacement for the failed node (TASFailedNodeReplacementFailFast): the caller runs evictWorkloadAfterFailedTASReplacement (scheduler.go:926) and markEvicted
 	RepMode         uint8
 	Borrowing       int
 	PodSets         []map[corev1.ResourceName]FlavorChoice // Assignment.PodSets[i].Flavors
@@ -59,7 +61,7 @@ func Outcomes(f *resources.ResourceFormatter, s *FlatSnapshot, h *FlatHeads, d *
 	n, nR := int(h.N), int(s.NResource)
 	out := make([]Outcome, n)
 	for i := 0; i < n; i++ {
-		o := Outcome{Head: i, Order: int(d.Order[i]), Status: d.Status[i], Admit: d.Action[i] == actAdmit, Preempt: d.Action[i] == actPreempt,
+		o := Outcome{Head: i, Order: int(d.Order[i]), Status: d.Status[i], Admit: d.Action[i] == actAdmit, Preempt: d.Action[i] == actPreempt, Evict: d.Action[i] == actEvict,
 			RepMode: d.Mode[i], Borrowing: int(d.Borrowing[i]), RequeueReason: requeueReasons[d.RequeueReason[i]]}
 		// LastAssignment for the next cycle: recordAssignment :281, cleared by markPreemptionOutcome :291, DeferredFit :459-464,
 		// markSkipped without FlavorFungibilityPreserveScanProgress :248-254

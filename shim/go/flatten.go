@@ -40,6 +40,8 @@ const (
 	qfSubtree  = uint8(0x2)       // KQ_QF_SUBTREE
 	headQuota  = uint32(0x1)      // KQ_HEAD_HAS_QUOTA_RESERVATION
 	headPre    = uint32(0x2)      // KQ_HEAD_IS_PREEMPTOR
+	headUnhealthy   = uint32(0x8)  // KQ_HEAD_HAS_UNHEALTHY_NODES: workload.HasUnhealthyNodes
+	headUnhealthyTA = uint32(0x10) // KQ_HEAD_UNHEALTHY_ASSIGNMENT: workload.HasTopologyAssignmentWithUnhealthyNode
 	headLast   = uint32(0x4)      // KQ_HEAD_HAS_LAST_ASSIGNMENT
 	admEvicted = uint8(0x1)       // KQ_ADM_EVICTED
 )
@@ -376,6 +378,12 @@ func FlattenHeads(log logr.Logger, s *FlatSnapshot, ix *Index, heads []*qcache.H
 		}
 		if hd.IsPreemptor {
 			fl |= headPre
+		}
+		if workload.HasUnhealthyNodes(wl.Obj) { // the second pass after a node failure (kq_cycle_run_tas; TASCycle.PsAdmFlavor / PsEx*)
+			fl |= headUnhealthy
+		}
+		if workload.HasTopologyAssignmentWithUnhealthyNode(wl.Obj) {
+			fl |= headUnhealthyTA
 		}
 		la := wl.LastAssignment
 		if la != nil {

@@ -10,6 +10,8 @@ import (
 
 	corev1 "k8s.io/api/core/v1"
 
+	kueue "sigs.k8s.io/kueue/apis/kueue/v1beta2"
+
 	qcache "sigs.k8s.io/kueue/pkg/cache/queue"
 	schdcache "sigs.k8s.io/kueue/pkg/cache/scheduler"
 	"sigs.k8s.io/kueue/pkg/features"
@@ -35,7 +37,8 @@ func FlattenTAS(snap *schdcache.Snapshot, fs *FlatSnapshot, ix *Index, heads []*
 		resNames[i] = corev1.ResourceName(n)
 	}
 	nR := len(resNames)
-	tc := &TASCycle{NoRecompute: !features.Enabled(features.TASRecomputeAssignmentWithinSchedulingCycle)}
+	tc := &TASCycle{NoRecompute: !features.Enabled(features.TASRecomputeAssignmentWithinSchedulingCycle),
+		NoFailFast: !features.Enabled(features.TASFailedNodeReplacementFailFast)}
 	flats := make([]*schdcache.FlatTAS, len(names))
 	tasIdx := map[string]int32{}
 	for i, n := range names {
@@ -141,7 +144,75 @@ func FlattenTAS(snap *schdcache.Snapshot, fs *FlatSnapshot, ix *Index, heads []*
 			p++
 		}
 	}
+	flattenSecondPass(tc, fs, ix, fh, heads, flats, tasIdx)
 	return tc
+}
+
+// flattenSecondPass fills TASCycle.PsAdmFlavor / PsEx* for the heads that hold an admission (workload.NeedsSecondPass workload.go:974):
+// PodSetResources.Flavors is what Assign keeps (flavorassigner.go:768-774), Status.Admission's TopologyAssignment what
+// WorkloadsTopologyRequests (:50) and findReplacementAssignment (tas_flavor_snapshot.go:686) read. Workloads owned by a single pod are the
+// caller's to keep off the engine while SkipReassignmentForPodOwnedWorkloads is on (tas_flavor_snapshot.go:615).
+func flattenSecondPass(tc *TASCycle, fs *FlatSnapshot, ix *Index, fh *FlatHeads, heads []*qcache.Head, flats []*schdcache.FlatTAS, tasIdx map[string]int32) {
+	any := false
+	for _, hd := range heads {
+		if workload.HasQuotaReservation(hd.Info.Obj) && hd.Info.Obj.Status.Admission != nil {
+			any = true
+		}
+	}
+	if !any {
+		return
+	}
+	nR := int(fs.NResource)
+	nps := int(fh.PsOff[fh.N])
+	tc.PsAdmFlavor = make([]int32, nps*nR)
+	for i := range tc.PsAdmFlavor {
+		tc.PsAdmFlavor[i] = -1
+	}
+	tc.PsExOff = make([]int32, 1, nps+1)
+	p := 0
+	for _, hd := range heads {
+		wl := hd.Info.Obj
+		second := workload.HasQuotaReservation(wl) && wl.Status.Admission != nil
+		for i := range hd.Info.TotalRequests {
+			if second {
+				psr := &hd.Info.TotalRequests[i]
+				ti := int32(-1)
+				for res, flv := range psr.Flavors {
+					tc.PsAdmFlavor[p*nR+int(ix.Resource[string(res)])] = ix.Flavor[string(flv)]
+					if t, ok := tasIdx[string(flv)]; ok {
+						ti = t
+					}
+				}
+				if psa := findPSA(wl, psr.Name); psa != nil && psa.TopologyAssignment != nil && ti >= 0 {
+					for _, d := range utiltas.InternalFrom(psa.TopologyAssignment).Domains {
+						leaf, ok := flats[ti].LeafOfID[utiltas.DomainID(d.Values)]
+						if !ok {
+							leaf = -1 // IsTopologyAssignmentStale :818
+						}
+						f := uint8(0)
+						if node := d.Values[len(d.Values)-1]; workload.HasUnhealthyNode(wl, node) {
+							f |= ExUnhealthy
+							if wl.Status.UnhealthyNodes[0].Name == node {
+								f |= ExFirst
+							}
+						}
+						tc.PsExLeaf, tc.PsExCount, tc.PsExFlags = append(tc.PsExLeaf, leaf), append(tc.PsExCount, d.Count), append(tc.PsExFlags, f)
+					}
+				}
+			}
+			tc.PsExOff = append(tc.PsExOff, int32(len(tc.PsExLeaf)))
+			p++
+		}
+	}
+}
+
+func findPSA(wl *kueue.Workload, name kueue.PodSetReference) *kueue.PodSetAssignment {
+	for i := range wl.Status.Admission.PodSetAssignments {
+		if wl.Status.Admission.PodSetAssignments[i].Name == name {
+			return &wl.Status.Admission.PodSetAssignments[i]
+		}
+	}
+	return nil
 }
 
 // admittedInfos lists the workload.Info of the admitted rows in FlatSnapshot row order (ClusterQueue name order, then the order Flatten

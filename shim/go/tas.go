@@ -53,6 +53,7 @@ type FlatTopology struct {
 // (slices.Sorted, clusterqueue_snapshot.go:220).
 type TASCycle struct {
 	NoRecompute bool    // !features.TASRecomputeAssignmentWithinSchedulingCycle
+	NoFailFast  bool    // !features.TASFailedNodeReplacementFailFast (kq_cycle_run_tas evicts a second-pass head whose node replacement fails)
 	TASFlavor   []int32 // index of every TAS flavor in FlatSnapshot.FlavorNames
 	Topos       []FlatTopology
 	CQTASOnly   []uint8
@@ -65,7 +66,17 @@ type TASCycle struct {
 	PsSliceSize, PsGroup          []int32
 	PsReq                         []int64 // [podsets][resources] SinglePodRequests (tas_flavorassigner.go:116)
 	PsNLayers, PsLayerLevel, PsLayerSize []int32 // TASMultiLayerTopology; nil = single layer everywhere. Strides: [podsets][len(Topos)][C.KQ_TAS_MAX_LEVELS] / [podsets][C.KQ_TAS_MAX_LEVELS] (16, the API's MaxItems)
+	// The second pass (workload.NeedsSecondPass; heads carry headQuota, and headUnhealthy / headUnhealthyTA in Heads.Flags): what
+	// Status.Admission holds for the heads' podsets. All nil = no head holds an admission.
+	PsAdmFlavor                  []int32 // [podsets][snapshot resources] PodSetAssignments[i].Flavors as flavor indices, -1 = none
+	PsExOff, PsExLeaf, PsExCount []int32 // CSR per podset: PodSetAssignments[i].TopologyAssignment, every domain, leaf index in the podset's TAS flavor (-1 = stale)
+	PsExFlags                    []uint8 // ExUnhealthy | ExFirst per domain
 }
+
+const (
+	ExUnhealthy = uint8(1) // KQ_EX_UNHEALTHY: the domain's node is one of Status.UnhealthyNodes
+	ExFirst     = uint8(2) // KQ_EX_FIRST: ... and it is UnhealthyNodes[0] (deleteDomain tas_flavor_snapshot.go:693)
+)
 
 // TASCycleOut receives the TopologyAssignment of every podset that holds one (kq_cycle_tas_out).
 type TASCycleOut struct {
@@ -130,6 +141,9 @@ func (e *Engine) RunCycleTAS(h *FlatHeads, t *TASCycle, out *FlatDecisions, tout
 	if t.NoRecompute {
 		ct.flags |= C.KQ_CT_NO_RECOMPUTE
 	}
+	if t.NoFailFast { // !features.Enabled(features.TASFailedNodeReplacementFailFast)
+		ct.flags |= C.KQ_CT_NO_FAIL_FAST
+	}
 	ct.n_tas = C.int32_t(nt)
 	ct.tas_flavor = (*C.int32_t)(pin(&p, t.TASFlavor))
 	ct.topo = topos
@@ -150,6 +164,15 @@ func (e *Engine) RunCycleTAS(h *FlatHeads, t *TASCycle, out *FlatDecisions, tout
 		ct.ps_n_layers = (*C.int32_t)(pin(&p, t.PsNLayers))
 		ct.ps_layer_level = (*C.int32_t)(pin(&p, t.PsLayerLevel))
 		ct.ps_layer_size = (*C.int32_t)(pin(&p, t.PsLayerSize))
+	}
+	if len(t.PsAdmFlavor) > 0 {
+		ct.ps_adm_flavor = (*C.int32_t)(pin(&p, t.PsAdmFlavor))
+		if len(t.PsExOff) > 0 {
+			ct.ps_ex_off = (*C.int32_t)(pin(&p, t.PsExOff))
+			ct.ps_ex_leaf = (*C.int32_t)(pin(&p, t.PsExLeaf))
+			ct.ps_ex_count = (*C.int32_t)(pin(&p, t.PsExCount))
+			ct.ps_ex_flags = (*C.uint8_t)(pin(&p, t.PsExFlags))
+		}
 	}
 	co.ps_tas = (*C.int32_t)(pin(&p, tout.PsTAS))
 	co.dom_off = (*C.int32_t)(pin(&p, tout.DomOff))

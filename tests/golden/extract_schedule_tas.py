@@ -269,7 +269,7 @@ def parse_podsets(args, sym):
 
 WL_OK = {"MakeWorkload", "Queue", "Priority", "Creation", "Request", "PodSets", "ReserveQuota", "ReserveQuotaAt", "Admission", "Condition",
          "ResourceRequests", "SchedulingStatsEviction", "Obj", "UID", "JobUID", "Generation", "Clone", "AdmittedAt", "Admitted", "PastAdmittedTime",
-         "ResourceVersion", "Label", "Labels", "Finalizers"}
+         "ResourceVersion", "Label", "Labels", "Finalizers", "UnhealthyNodes"}
 
 
 def parse_wl(text, start, sym):
@@ -293,6 +293,10 @@ def parse_wl(text, start, sym):
             parts = split_top(a)
             w["cq"], w["admission"] = parse_admission(parts[0], sym)
             w["reservedAt"] = parse_time(parts[1]) if len(parts) > 1 else NOW
+        elif m == "UnhealthyNodes":
+            w["unhealthyNodes"] = re.findall(r'"([^"]+)"', a)
+        elif m in ("AdmittedAt", "Admitted"):
+            w["isAdmitted"] = split_top(a)[0].strip() == "true"
         elif m == "Condition":
             typ = re.search(r"Type:\s*kueue\.(\w+)", a)
             status = re.search(r"Status:\s*metav1\.Condition(\w+)", a)
@@ -324,7 +328,7 @@ def parse_keymap(text):
     return out
 
 
-BAD = r"AdmissionCheck|Toleration|NodeSelector|Taint|PreemptionGate|WorkloadSlice|Annotation|UnhealthyNode|DelayedTopologyRequest|PodSetGroup|" \
+BAD = r"AdmissionCheck|Toleration|NodeSelector|Taint|PreemptionGate|WorkloadSlice|Annotation|DelayedTopologyRequest|PodSetGroup|" \
       r"resourceTransformations|patchStatusErr|RequiredDuringScheduling|PreferredDuringScheduling|PodSetUpdate|StopPolicy|" \
       r"MinimumCount|SetMinimumCount"
 
@@ -351,14 +355,18 @@ def extract(src, func, cases, skipped):
         name = m.group(1)
         line = line0 + body[:p + 1 + m.start()].count("\n") + 1
         try:
-            if re.search(BAD, block):
-                raise Skip("outside the boundary (" + re.search(BAD, block).group(0) + ")")
+            # (AdmissionCheck objects that exist in the cluster but that no ClusterQueue of the case lists do not reach the path: the
+            # ClusterQueues are checked one by one below)
+            scan = re.sub(r"(?m)^\t{3}admissionChecks:\s*\[\]kueue\.AdmissionCheck\{[^}]*\},?\n", "", block)
+            if re.search(BAD, scan):
+                raise Skip("outside the boundary (" + re.search(BAD, scan).group(0) + ")")
             gates = {}
             fg = field(block, "featureGates")
             if fg:
                 for g, v in re.findall(r"features\.(\w+):\s*(true|false)", fg):
                     gates[g] = v == "true"
                 allowed = {"TASMultiLayerTopology": True, "TASProfileMixed": True, "TASRecomputeAssignmentWithinSchedulingCycle": None, "VectorizedResourceRequests": None,
+                           "TASFailedNodeReplacementFailFast": None,
                            "TASCachingRemainingResources": None, "TASCacheNodeMatchResults": None}
                 for g, v in gates.items():
                     if g not in allowed or (allowed[g] is not None and allowed[g] != v):
@@ -383,7 +391,7 @@ def extract(src, func, cases, skipped):
             wf = field(block, "workloads") or ""
             wls = workloads_in(wf, sym)
             cq_names = {c["name"] for c in cqs}
-            admitted, pending = [], []
+            admitted, pending, second = [], [], []
             pod_requests = {}
             for w in wls:
                 key = f"{w['ns']}/{w['name']}"
@@ -400,6 +408,26 @@ def extract(src, func, cases, skipped):
                             e["podRequests"] = spec[ps["name"]]["requests"] if ps["name"] in spec else {}
                         d["podsets"].append(e)
                     admitted.append(d)
+                    # workload.NeedsSecondPass workload.go:974 after a node failure: quota reserved, admitted, and a TopologyAssignment
+                    # names one of Status.UnhealthyNodes -> the workload is ALSO a head of the cycle (manager.go:923)
+                    un = w.get("unhealthyNodes") or []
+                    names = [dm[0][-1] for ps in w["admission"] if "topologyAssignment" in ps for dm in ps["topologyAssignment"]["domains"]]
+                    if un and w.get("isAdmitted") and any(x in un for x in names):
+                        by = {ps["name"]: ps for ps in w["admission"]}
+                        if [ps["name"] for ps in w["podsets"]] != [ps["name"] for ps in w["admission"]]:
+                            raise Skip("admission podsets not aligned with the spec")
+                        # workload.Info of an admitted workload: count and total requests are the admission's (workload.go:866-900); the
+                        # placement reads the pod spec (tas_flavorassigner.go:116)
+                        sp_podsets = [{"name": ps["name"], "count": by[ps["name"]]["count"], "totalRequests": by[ps["name"]]["usage"],
+                                       "podRequests": ps["requests"], **({"topologyRequest": ps["topologyRequest"]} if "topologyRequest" in ps else {})}
+                                      for ps in w["podsets"]]
+                        second.append({"name": key, "cq": w["cq"], "priority": w["priority"], "created": w["created"], "podsets": sp_podsets,
+                                       "hasQuotaReservation": True, "isAdmitted": True, "unhealthyNodes": un,
+                                       "admission": [{"flavors": by[ps["name"]]["flavors"], "count": by[ps["name"]]["count"],
+                                                      **({"topologyAssignment": by[ps["name"]]["topologyAssignment"]} if "topologyAssignment" in by[ps["name"]] else {})}
+                                                     for ps in w["podsets"]]})
+                    elif un:
+                        raise Skip("unhealthy nodes without a second pass")
                 else:
                     cq = lqs.get((w["ns"], w.get("queue", "")))
                     if cq is None or cq not in cq_names:
@@ -411,6 +439,7 @@ def extract(src, func, cases, skipped):
                 if len(q) > 1 and (-q[0]["priority"], q[0]["created"]) == (-q[1]["priority"], q[1]["created"]):
                     raise Skip("head order decided by UID / name tie-break")
                 heads.append(q[0]); rest += q[1:]
+            heads = second + heads   # "second-pass heads first" (manager.go:923)
             want_adm = {}
             wa = field(block, "wantNewAssignments")
             if wa and "{" in wa:
@@ -432,6 +461,10 @@ def extract(src, func, cases, skipped):
             for k in want_adm:
                 if k not in expect:
                     raise Skip("admission of a workload that is not a head")
+            ev = field(block, "wantEvents") or ""
+            for ns_, nm_, reason in re.findall(r'MakeEventRecord\("([^"]+)",\s*"([^"]+)",\s*"([^"]+)"', ev):
+                if f"{ns_}/{nm_}" in expect:
+                    expect[f"{ns_}/{nm_}"].setdefault("events", []).append(reason)
             left = parse_keymap(field(block, "wantLeft"))
             inadm = parse_keymap(field(block, "wantInadmissibleLeft"))
             for keys in left.values():

@@ -70,3 +70,85 @@ def random_tas_cycle_case(seed, roomy=False, **kw):
             admitted_tas.setdefault(w.name, []).append(AdmittedTAS(tf[0], [(tuple(topo.leaf_values(leaf)), ps.count)], per_pod))
     ct = CycleTAS(snap, heads, topologies, pod_tas, admitted_tas, recompute=rnd.random() < 0.85)
     return cfg, snap, heads, ct, pod_tas
+
+
+def random_second_pass_case(seed, **kw):
+    """random_tas_cycle_case + heads on their SECOND pass after a node failure (workload.NeedsSecondPass workload.go:974): a few admitted TAS
+    workloads come back as heads that hold their admission; one node of it is unhealthy (a leaf of the snapshot, or a node the snapshot
+    no longer holds). The cycle mixes them with the first-pass heads (manager.go:923)."""
+    import copy
+
+    from kueue_amd.tas_cycle import HeadAdmission
+    cfg, snap, heads, ct, pod_tas = random_tas_cycle_case(seed, **kw)
+    rnd = random.Random(seed * 104729 + 5)
+    topologies = {n: t for n, t in zip(ct.names, ct.topos)}
+    admitted_tas, head_adm, second = {}, {}, []
+    levels = ct.topos[0].levels if ct.topos else [HOST]
+    for w in snap.admitted:
+        tas_ps = []
+        for pi, ps in enumerate(w.pod_sets):
+            tf = [f for f in set(ps.flavors.values()) if f in topologies]
+            tas_ps.append(tf[0] if len(tf) == 1 and ps.count > 0 and topologies[tf[0]].n_leaves > 0 else None)
+        if not any(tas_ps) or rnd.random() < 0.35:
+            continue
+        make_head = rnd.random() < 0.6 and len(second) < 3 and all(topologies[t].lowest_is_node for t in tas_ps if t)   # (an unhealthy NODE: hostname leaves)
+        gone = f"gone-{w.name}"
+        unhealthy = None
+        doms = []
+        for pi, ps in enumerate(w.pod_sets):
+            if tas_ps[pi] is None:
+                doms.append(None)
+                continue
+            topo = topologies[tas_ps[pi]]
+            left, d, used = ps.count, [], set()
+            while left > 0:
+                c = rnd.randint(1, left)
+                if make_head and rnd.random() < 0.25 and gone not in used:
+                    d.append(((gone,) if topo.lowest_is_node else tuple(["gone"] * (len(levels) - 1) + [gone]), c)); used.add(gone)
+                else:
+                    free = [l for l in range(topo.n_leaves) if l not in used]
+                    if len(free) <= 1:
+                        c = left   # the last free leaf takes the rest
+                    if not free:
+                        v, c0 = d[-1]; d[-1] = (v, c0 + left); break
+                    leaf = rnd.choice(free)
+                    used.add(leaf)
+                    d.append((tuple(topo.leaf_values(leaf)), c))
+                left -= c
+            doms.append(d)
+            per_pod = {r: q // ps.count for r, q in ps.requests.items() if r != "pods" and q // ps.count > 0}
+            admitted_tas.setdefault(w.name, []).append(AdmittedTAS(tas_ps[pi], [x for x in d if x[0][-1] != gone], per_pod))
+        if not make_head:
+            continue
+        names = [v[-1] for d in doms if d for v, _ in d]
+        k = rnd.random()
+        unhealthy = [gone] if (gone in names and k < 0.5) else [rnd.choice(names)]
+        if rnd.random() < 0.15:
+            unhealthy.append(rnd.choice(names))   # (a second unhealthy node: only UnhealthyNodes[0] is replaced, :693)
+        hw = copy.deepcopy(w)
+        hw.has_quota_reservation = True
+        hw.has_unhealthy_nodes = True
+        is_admitted = rnd.random() < 0.9
+        ha = HeadAdmission([dict(ps.flavors) for ps in w.pod_sets], doms, unhealthy, admitted=is_admitted)
+        hw.unhealthy_assignment = ha.names_unhealthy()
+        for pi, ps in enumerate(hw.pod_sets):
+            tr = None
+            k = rnd.random()
+            if k < 0.3:
+                tr = TopologyRequest(required=rnd.choice(levels))
+            elif k < 0.55:
+                tr = TopologyRequest(preferred=rnd.choice(levels))
+            elif k < 0.7:
+                tr = TopologyRequest(unconstrained=True)
+            elif k < 0.9 and ps.count > 1:
+                tr = TopologyRequest(required=levels[0], slice_required_topology=levels[-1], slice_size=rnd.choice([s for s in (1, 2, 3, 4) if ps.count % s == 0]))
+            per_pod = {r: (q // ps.count if ps.count else 0) for r, q in ps.requests.items() if r != "pods"}
+            pod_tas[(hw.name, pi)] = PodSetTAS(tr, None, per_pod)
+        head_adm[hw.name] = ha
+        second.append(hw)
+    # the rows that did not get a fresh assignment above keep the one random_tas_cycle_case drew
+    workloads = second + list(heads.workloads)
+    heads = Heads(snap, workloads, cycle=heads.cycle)
+    ct2 = CycleTAS(snap, heads, topologies, pod_tas, admitted_tas, recompute=rnd.random() < 0.85, head_admission=head_adm or None,
+                   fail_fast=rnd.random() < 0.7)
+    return cfg, snap, heads, ct2, len(second)

@@ -14,7 +14,7 @@ import pytest
 from kueue_amd.tas_cycle import CycleTAS, load_tas_case
 from tests.conftest import load_golden
 from tests.randgen import random_case
-from tests.tasgen_cycle import random_tas_cycle_case
+from tests.tasgen_cycle import random_second_pass_case, random_tas_cycle_case
 from tests.test_oracle_schedule_tas import check_case
 
 CASES = load_golden("schedule_tas.yaml")["cases"]
@@ -151,6 +151,42 @@ def test_random_tas_cycles_emulated(oracle, seed):
 def test_random_tas_cycles_gpu(oracle, block):
     for seed in range(block * 50, block * 50 + 50):
         _random(oracle, _hip, seed)
+
+
+def _second_pass(oracle, make, seed):
+    """Cycles that mix heads on their first pass with heads on their second pass after a node failure (scheduler.go:583, manager.go:923,
+    tas_flavor_snapshot.go:608-633): the admission's flavors kept, the failed node's pods placed below the required replacement domain and
+    merged in, net leaf usage, eviction when no replacement exists (TASFailedNodeReplacementFailFast) — everything equal to the oracle's."""
+    cfg, snap, heads, ct, n_second = random_second_pass_case(seed, fair=seed % 5 == 4)
+    oracle.derive(snap)
+    _same(oracle, make, cfg, snap, heads, ct, tgt_cap=max(16, snap.n_adm))
+
+
+@pytest.mark.parametrize("seed", range(400))
+def test_random_second_pass_cycles_emulated(oracle, seed):
+    _second_pass(oracle, _emu, seed)
+
+
+def test_random_second_pass_cycles_cover_every_outcome(oracle):
+    """what the 400 cycles above are made of: replacements admitted, evictions (fail fast), entries left pending, entries that stopped fitting"""
+    from kueue_amd import _ffi as F
+    seen = {}
+    for seed in range(200):
+        cfg, snap, heads, ct, n_second = random_second_pass_case(seed, fair=seed % 5 == 4)
+        oracle.derive(snap)
+        d, _ = oracle.cycle_run_tas(cfg, snap, heads, ct, tgt_cap=max(16, snap.n_adm))
+        for i in range(n_second):
+            k = (int(d.a["action"][i]), int(d.a["status"][i]))
+            seen[k] = seen.get(k, 0) + 1
+    for k in ((F.ACT_ADMIT, F.ST_ASSUMED), (F.ACT_EVICT, F.ST_EVICTED), (F.ACT_NONE, F.ST_NOT_NOMINATED), (F.ACT_NONE, F.ST_SKIPPED)):
+        assert seen.get(k, 0) >= 10, (k, seen)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", range(6))
+def test_random_second_pass_cycles_gpu(oracle, block):
+    for seed in range(block * 50, block * 50 + 50):
+        _second_pass(oracle, _hip, seed)
 
 
 @pytest.mark.parametrize("seed", range(40))
