@@ -356,6 +356,8 @@ def main():
                 for k, v in gates.items():
                     if k == "features.TASProfileMixed":
                         case["profileMixed"] = v.strip() == "true"
+                    elif k == "features.TASBalancedPlacement":
+                        case["balancedPlacement"] = v.strip() == "true"   # tas_balanced_placement.go: restated by the oracle; the library answers KQ_EUNSUPPORTED
                     elif k == "features.TASMultiLayerTopology" and v.strip() == "true":
                         pass  # the gate only lets the job parser populate the constraint list; the algorithm honours whatever is there
                     else:
