@@ -55,7 +55,8 @@ extern "C" {
 #define KQ_TAS_NO_REPLACEMENT 10  /* :727 "cannot find replacement assignment for unhealthy node" */
 
 #define KQ_TAS_F_PROFILE_MIXED       1
-#define KQ_TAS_F_BALANCED_PLACEMENT  2   /* tas_balanced_placement.go (gate TASBalancedPlacement, kube_features.go:692): not implemented */
+#define KQ_TAS_F_BALANCED_PLACEMENT  2   /* tas_balanced_placement.go (gate TASBalancedPlacement, kube_features.go:692): not implemented by the
+                                          * library (KQ_EUNSUPPORTED); the oracle restates it (oracle/kq_tas_oracle.cpp) */
 #define KQ_TAS_F_AFFINITY_PREFERRED  4   /* TASRespectNodeAffinityPreferred: not implemented */
 
 typedef struct kq_tas_topology {
