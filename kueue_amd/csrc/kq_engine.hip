@@ -442,7 +442,24 @@ struct HipBackend {
   struct GuardRec { char* base; size_t n; };
   std::vector<GuardRec> guards;
   bool guard_on = getenv("KQ_GUARD") != nullptr;
+  // KQ_EFENCE=1 (debugging only): every buffer gets a region of its own, a multiple of 2 MiB (the granularity the memory-access faults
+  // of r05l-r05n were reported at), and sits at the END of it, 16-byte aligned — a kernel that reads or writes more than the alignment
+  // slack past a buffer faults at once, on every box, instead of when the allocator happens to put the buffer last in a mapped chunk.
+  // The body is poisoned like KQ_GUARD's.
+  bool efence_on = getenv("KQ_EFENCE") != nullptr;
+  struct FenceRec { char* base; char* user; };
+  std::vector<FenceRec> fences;
   void* alloc(size_t n) {
+    if (efence_on) {
+      const size_t CH = (size_t)2 << 20, body = (n + 15) & ~(size_t)15, total = ((body + CH - 1) / CH) * CH + (body == 0 ? CH : 0);
+      char* p = nullptr;
+      chk(hipMalloc((void**)&p, total), "hipMalloc");
+      if (!p) return nullptr;
+      char* u = p + total - body;
+      if (n) chk(hipMemset(u, 0xA5, n), "poison fill");
+      fences.push_back(FenceRec{p, u});
+      return u;
+    }
     if (!guard_on) { void* p = nullptr; chk(hipMalloc(&p, n), "hipMalloc"); return p; }
     char* p = nullptr;
     const size_t body = (n + 255) & ~(size_t)255;
@@ -458,6 +475,12 @@ struct HipBackend {
     return p + GW;
   }
   void free(void* p) {
+    if (efence_on && p) {
+      for (size_t i = 0; i < fences.size(); i++)
+        if (fences[i].user == (char*)p) { (void)hipFree(fences[i].base); fences[i] = fences.back(); fences.pop_back(); return; }
+      (void)hipFree(p);
+      return;
+    }
     if (!guard_on || !p) { (void)hipFree(p); return; }
     for (size_t i = 0; i < guards.size(); i++)
       if (guards[i].base + GW == (char*)p) { (void)hipFree(guards[i].base); guards[i] = guards.back(); guards.pop_back(); return; }

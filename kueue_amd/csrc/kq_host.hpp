@@ -203,7 +203,10 @@ template <class B> struct EngineT {
     size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
     if (bytes > b.cap) {
       if (b.p) be.free(b.p);
-      size_t cap = bytes + bytes / 4;
+      // (KQ_EXACT_ALLOC=1, debugging: no head room, so that an overrun of the requested size meets the allocator's own end — ASan's red
+      // zone under the emulation, the fence of KQ_EFENCE on the device — instead of the 25 % nobody asked for)
+      static const bool exact = getenv("KQ_EXACT_ALLOC") != nullptr;
+      size_t cap = exact ? bytes : bytes + bytes / 4;
       b.p = be.alloc(cap);
       b.cap = cap;
     }
@@ -1463,7 +1466,12 @@ template <class B> struct EngineT {
     k.cq_heads = grow<int32_t>(b_cqh, (size_t)std::max(prep.nq, 1) + std::max(prep.n_tree, 1) + 8);
     k.spec_resume = k.cq_heads + std::max(prep.nq, 1); k.spec_stats = spec_stats_on ? k.spec_resume + std::max(prep.n_tree, 1) : nullptr;
     prep_fill(k.cq_heads, (size_t)std::max(prep.nq, 1) + std::max(prep.n_tree, 1) + 8, 0);  // resume 0: the serial kernel takes the whole tree
-    k.spec_kt = cfg.fair_sharing ? nullptr : grow<int64_t>(b_spkt, (size_t)std::min(std::max(prep.n_tree, 1), (int)SP_SLOTS) * SP_KT_WORDS);
+    // (not in a TAS cycle: k_process_tas runs no speculative rounds, and k_records — which writes the entry records k_order_scatter's
+    // spec_hdr_of reads — is not launched there. Until round 5 the pointers were set all the same, so k_order_scatter read nuse / plen of
+    // records nobody had written: nothing with fresh (zero) or poisoned memory, a walk of cbig[u][i] far past the record — a GPU memory
+    // access fault when the buffer happened to end a mapped region — with whatever an earlier engine of the process had left there.
+    // That was the "unexplained" abort inside kq_cycle_run_tas of rounds 3-5, found with AMD_SERIALIZE_KERNEL=3: profiles/r05p_*.)
+    k.spec_kt = (cfg.fair_sharing || d_tc) ? nullptr : grow<int64_t>(b_spkt, (size_t)std::min(std::max(prep.n_tree, 1), (int)SP_SLOTS) * SP_KT_WORDS);
     if (k.spec_kt) {  // per-cell constants of the rounds, written by k_records
       const size_t cells = (size_t)n * FU * FD, slots_ = (size_t)n * FU;
       int64_t* a = grow<int64_t>(b_spc, cells * 2 + slots_ * 2 + (cells + 1) / 2);

@@ -438,6 +438,9 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
       }
     }
     *qsim = simulateEmpty ? 1 : 0;
+#ifdef KQ_HOST_EMU
+    for (int i = 0; i < n; i++) { qi[qo.status + i] = 0x5a5a5a5a; qi[qo.dn + i] = 0x5a5a5a5a; qi[qo.dpos + i] = 0x5a5a5a5a; }   // (the emulation: nothing may be read from the block of the find before)
+#endif
     for (int i = 0; i < 24; i++) qi[qo.misc + i] = 0;
     if (c.stats) atomic_add_i64(c.stats, 1);
   }
@@ -502,6 +505,19 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
   if (!f.failed && n_place < n) {
     const int32_t* sp = c.sp_req + (size_t)(w.ps_base + w.ta.req_ps[n_place]) * SP_W;
     f.failed = true; f.ps = w.ta.req_ps[n_place]; f.status = sp[SP_STATUS]; f.a = sp[SP_OPA]; f.b = sp[SP_OPB];
+  }
+  if (repl && f.failed) {
+    // tc_keep_result reads the status words (updateAssignmentForTAS keeps the result of a failed find too: UpdateForTASResult takes the
+    // assignment away): the failures found here, and the requests behind the failing one, are written where the placement's are
+    wsync();
+    if (lane == 0) {
+      bool behind = false;
+      for (int i = 0; i < n; i++) {
+        if (behind) { qi[qo.status + i] = KQ_TAS_SKIPPED; qi[qo.dn + i] = 0; }
+        else if ((int)w.ta.req_ps[i] == f.ps) { qi[qo.status + i] = f.status; qi[qo.opa + i] = f.a; qi[qo.opb + i] = f.b; qi[qo.dn + i] = 0; behind = true; }
+      }
+    }
+    wsync();
   }
   if (lane == 0 && simulateEmpty && n == 1 && !f.failed && qi[qo.status] == KQ_TAS_OK) { w.ta.em_ps = w.ta.req_ps[0]; w.ta.em_t = t; w.ta.em_count = k.O.ps_count[w.ps_base + w.ta.req_ps[0]]; }
   wsync();

@@ -21,8 +21,9 @@ struct EmuBackend {
   // use_n are whatever the allocator left there; an address built from one of them faulted on the MI355X while every CPU test passed).
   void* alloc(size_t n) {
     static const bool zero = getenv("KQE_ZERO_ALLOC") != nullptr;
+    static const int poison = getenv("KQE_POISON") ? (int)strtol(getenv("KQE_POISON"), nullptr, 16) : 0xA5;   // (0xA5 words are negative: "absent" to most checks; 01 / 7f make them large valid-looking indices)
     void* p = malloc(n ? n : 1);
-    if (p) memset(p, zero ? 0 : 0xA5, n);
+    if (p) memset(p, zero ? 0 : poison, n);
     return p;
   }
   void free(void* p) { ::free(p); }
