@@ -850,7 +850,7 @@ KQ_NOINLINE void tc_requests(const K& k, Wave& w);
 KQ_DEV void tc_assign_tas(const K& k, Wave& w, int slot);
 KQ_DEV void tc_search_begin(const K& k, Wave& w, int slot);
 KQ_DEV void tc_search_end(Wave& w);
-KQ_DEV void tc_search_row(const K& k, const Wave& w, int slot, int row, bool add);
+KQ_DEV void tc_search_row(const K& k, Wave& w, int slot, int row, bool add);
 KQ_DEV bool tc_search_fits(const K& k, Wave& w, int slot);
 KQ_DEV void tc_update_assignment(const K& k, Wave& w, int slot, const int32_t* trow, int nt);
 KQ_NOINLINE void tc_publish(const K& k, Wave& w, int slot);
@@ -995,7 +995,7 @@ KQ_DEV void w_apply_row(const Search& s, int row, bool add) {
   wsync();
   if (lane_id() == 0) s.w->bytes += 16 * (int64_t)cplen * (S.adm_use_off[row + 1] - S.adm_use_off[row]);
 #ifdef KQ_TAS_CYCLE
-  if (s.k->tc) tc_search_row(*s.k, w, s.slot, row, add);
+  if (s.k->tc) tc_search_row(*s.k, *s.w, s.slot, row, add);
 #endif
 }
 // preemption.go:669-686 on the private state (quota part)

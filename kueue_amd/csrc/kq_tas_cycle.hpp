@@ -600,17 +600,26 @@ KQ_NOINLINE void tc_copy_plane(const TCyc& c, int t, int from, int slot) {
   for (int i = lane_id(); i < T.n_leaves * T.R; i += WAVE) dst[i] = (int64_t)ag_load_u64((const uint64_t*)(src + i));
   wsync();
 }
+// The private copy is made when the walk first touches it (srch == 2: asked for, not made yet): a search that finds no candidate —
+// every Preempt-mode entry of a ClusterQueue without a preemption policy, i.e. all of the closed loop of cfg5-cycle — never does, and
+// the copy (131 KB read + written by ONE wave at cfg 5) was most of what such an entry's GetTargets cost inside processEntry.
 KQ_DEV void tc_search_begin(const K& k, Wave& w, int slot) {
   tc_requests(k, w);
   if (w.ta.nreq == 0) return;
+  if (lane_id() == 0) w.ta.srch = 2;
+  wsync();
+}
+KQ_DEV void tc_search_copy(const K& k, Wave& w, int slot) {
+  if (w.ta.srch != 2) return;
   for (int t = 0; t < k.tc->n_tas; t++) tc_copy_plane(*k.tc, t, w.ta.plane, slot);
   if (lane_id() == 0) w.ta.srch = 1;
   wsync();
 }
 KQ_DEV void tc_search_end(Wave& w) { if (lane_id() == 0) w.ta.srch = 0; wsync(); }
-KQ_DEV void tc_search_row(const K& k, const Wave& w, int slot, int row, bool add) { if (w.ta.srch) tc_row_apply(*k.tc, row, add, 3, slot); }
+KQ_DEV void tc_search_row(const K& k, Wave& w, int slot, int row, bool add) { if (w.ta.srch) { tc_search_copy(k, w, slot); tc_row_apply(*k.tc, row, add, 3, slot); } }
 KQ_DEV bool tc_search_fits(const K& k, Wave& w, int slot) {  // preemption.go:676-684
   if (!w.ta.srch) return true;
+  tc_search_copy(k, w, slot);
   return !tc_find(k, w, slot, false, 3).failed;
 }
 
