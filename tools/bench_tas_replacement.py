@@ -61,7 +61,7 @@ def main():
                           parity=dict(equal=not diff and not bad_stats, fields=diff, stats_mismatch=len(bad_stats)),
                           statuses=dict(ok=int(st[T.TAS_OK]), not_fit=int(st[T.TAS_NOT_FIT]), no_replacement=int(st[T.TAS_NO_REPLACEMENT])),
                           find_replacement_ms=find_ms, replacements_per_s=n / find_ms * 1e3, failed_podsets=len(failed), exclusion_stats_ms=stats_ms,
-                          oracle_one_core_s=oracle_s, note="host wall time of the C call incl. the mask build, H2D and D2H")))
+                          oracle_one_core_s=oracle_s, note="host wall time of the C call incl. the request rewrite, H2D and D2H (round 5: the required domain travels as a leaf range, no n x leaves mask)")))
     eng.close()
 
 
