@@ -50,6 +50,9 @@ def main():
                          "call-by-call loop with two host round trips per cycle")
     ap.add_argument("--parity-cycles", type=int, default=0, help="pending loop: cycles of the parity gate (0 = 12, 6 with fair sharing)")
     ap.add_argument("--hold", type=int, default=4, help="closed loop: admitted workloads finish after this many cycles")
+    ap.add_argument("--node-failures", type=int, default=0,
+                    help="cfg5-cycle closed loop: this many nodes hosting admitted pods fail in every cycle; the workloads that lose pods come back as "
+                         "second-pass heads (replaced below the required domain, or evicted) next to the first-pass heads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true")
     ap.add_argument("--resident-batches", action="store_true",
@@ -1212,7 +1215,7 @@ def bench_tas_cycle(args, torch, dist, world, rank, local_rank):
         # BEFORE the timed region (it is the parity reference and the cpu_baseline anyway); a step then is kq_snapshot_put of that
         # cycle's snapshot + kq_cycle_run_tas, and every step's outcome is compared with the oracle's after the timed region.
         from oracle import kqo
-        loop = batch.closed_loop(hold=args.hold)
+        loop = batch.closed_loop(hold=args.hold, failures=args.node_failures)
         nb = min(args.steps + args.warmup, 24)
         for c in range(nb):
             sn, h0, c0 = loop.cycle_input()
@@ -1316,6 +1319,11 @@ def bench_tas_cycle(args, torch, dist, world, rank, local_rank):
                          "note": "all three intervals of the cycle; the placements' bytes are the reference's phase-1 accounting per FindTopologyAssignmentsForFlavor call"},
             "parity_checked": parity is not None, "parity": parity,
         }
+        if closed and args.node_failures:
+            res["config"]["node_failures"] = (f"{args.node_failures} nodes hosting admitted pods fail in every cycle: {loop.second_pass['heads']} second-pass heads over the {nb} "
+                                              f"cycles ({loop.second_pass['replaced']} replaced below the required domain and admitted again, {loop.second_pass['evicted']} evicted "
+                                              f"by TASFailedNodeReplacementFailFast, {loop.second_pass['pending']} left pending) next to the first-pass heads")
+            res["second_pass"] = dict(loop.second_pass)
         if closed and not args.no_parity_gate:
             ndec = 0
             for c in sorted(seen):

@@ -109,6 +109,7 @@ class Topology:
                  resources: Optional[Sequence[str]] = None, profile_mixed: bool = True):
         self.levels = list(levels)
         self.profile_mixed = profile_mixed
+        self.nodes, self._non_tas_usage = list(nodes), non_tas_usage   # (kept for without_nodes)
         self.feature_bits = 0   # KQ_TAS_F_BALANCED_PLACEMENT (2) / KQ_TAS_F_AFFINITY_PREFERRED (4): gates the library does not implement -> KQ_EUNSUPPORTED
         L = len(self.levels)
         self.lowest_is_node = self.levels[-1] == HOSTNAME_LABEL
@@ -150,6 +151,14 @@ class Topology:
         self.arrays = dict(level_off=np.array(level_off, np.int32), parent=np.array(parent, np.int32),
                            free_capacity=free.reshape(-1).copy(), tas_usage=np.zeros(self.n_leaves * R, np.int64))
         self._struct = None
+
+    def without_nodes(self, hostnames) -> "Topology":
+        """The flavor's snapshot after these nodes failed (NotReady nodes are not part of the tree, tas_flavor.go): a new Topology."""
+        gone = set(hostnames)
+        t = Topology(self.levels, [n for n in self.nodes if n.labels.get(HOSTNAME_LABEL, n.name) not in gone], self._non_tas_usage,
+                     resources=self.resources, profile_mixed=self.profile_mixed)
+        t.feature_bits = self.feature_bits
+        return t
 
     # -- level resolution: levelKey :1222, levelKeyWithImpliedFallback :1212, sliceLevelKeyWithDefault :1197 --
     def resolve(self, tr: TASPodSetRequests) -> Tuple[int, int, int, int]:

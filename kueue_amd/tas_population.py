@@ -95,7 +95,7 @@ def generate_tas_cycle(n_cq: int = 1000, n_pending: int = 50_000, seed: int = TA
         heads = Heads(snap, wls, cycle=c + 1)
         return heads, CycleTAS(snap, heads, topologies, pod_tas)
 
-    batch.closed_loop = lambda hold=0: TASClosedLoop(cqs, [Cohort(f"cohort-{j:02d}") for j in range(cohorts)], topologies, workloads_of, hold)
+    batch.closed_loop = lambda hold=0, failures=0: TASClosedLoop(cqs, [Cohort(f"cohort-{j:02d}") for j in range(cohorts)], topologies, workloads_of, hold, failures)
     return snap, topologies, batch
 
 
@@ -106,22 +106,51 @@ class TASClosedLoop:
     -> (Snapshot [derived], Heads, CycleTAS); `fold(heads, decisions, tas_out)` turns the cycle's admissions into admitted workloads.
     The same object feeds the engine and the oracle, so a parity gate over k cycles compares k dependent cycles."""
 
-    def __init__(self, cqs, cohorts, topologies, workloads_of, hold: int = 0):
-        """hold > 0: a workload finishes `hold` cycles after the cycle that admitted it (its row, quota and leaf usage leave the cache)."""
+    def __init__(self, cqs, cohorts, topologies, workloads_of, hold: int = 0, failures: int = 0, failure_seed: int = 4242):
+        """hold > 0: a workload finishes `hold` cycles after the cycle that admitted it (its row, quota and leaf usage leave the cache).
+        failures > 0: in every cycle that many nodes hosting admitted pods are gone from the snapshot (NotReady); every admitted workload
+        with pods on one of them comes back as a head on its SECOND pass (workload.NeedsSecondPass workload.go:974, manager.go:923) next
+        to the first-pass heads — the failed node's pods are re-placed (tas_flavor_snapshot.go:608-633) or, when that is impossible, the
+        workload is evicted (TASFailedNodeReplacementFailFast). The nodes are back in the next cycle."""
         self.cqs, self.cohorts, self.topologies, self.workloads_of, self.hold = cqs, cohorts, topologies, workloads_of, hold
+        self.failures, self.failure_seed = failures, failure_seed
         self.admitted = []          # api.Workload with PodSet.flavors
         self.admitted_tas = {}      # name -> [AdmittedTAS]
+        self.admitted_pod_tas = {}  # name -> [PodSetTAS] (the workload's topology requests: a second pass places by them)
         self.cycle = 0
+        self.second_pass = dict(heads=0, replaced=0, evicted=0, pending=0)
 
     def cycle_input(self):
+        import copy
         from .api import Heads, Snapshot
-        from .tas_cycle import CycleTAS
+        from .tas_cycle import CycleTAS, HeadAdmission
         snap = Snapshot(self.cqs, self.cohorts, list(self.admitted), extra_resources=["pods"])
         snap.derive()
         wls, pod_tas = self.workloads_of(self.cycle)
-        heads = Heads(snap, wls, cycle=self.cycle + 1)
+        topologies, second, head_adm = self.topologies, [], {}
+        if self.failures > 0 and self.admitted_tas:
+            rng = np.random.default_rng(self.failure_seed + self.cycle)
+            hosting = sorted({vals[-1] for tas in self.admitted_tas.values() for a in tas for vals, _ in a.domains})
+            failed = set(rng.choice(hosting, size=min(self.failures, len(hosting)), replace=False).tolist())
+            topologies = {name: t.without_nodes(failed) for name, t in self.topologies.items()}
+            for w in self.admitted:
+                tas = self.admitted_tas.get(w.name)
+                lost = sorted({vals[-1] for a in (tas or []) for vals, _ in a.domains if vals[-1] in failed})
+                if not lost:
+                    continue
+                hw = copy.deepcopy(w)
+                hw.has_quota_reservation = hw.has_unhealthy_nodes = hw.unhealthy_assignment = True
+                doms = [None] * len(w.pod_sets)
+                for pi, a in enumerate(tas):   # (one AdmittedTAS per podset, in podset order: fold() below)
+                    doms[pi] = [(tuple(v), int(c)) for v, c in a.domains]
+                head_adm[hw.name] = HeadAdmission([dict(ps.flavors) for ps in w.pod_sets], doms, lost, admitted=True)
+                for pi, pt in enumerate(self.admitted_pod_tas[w.name]):
+                    pod_tas[(hw.name, pi)] = pt
+                second.append(hw)
+        heads = Heads(snap, second + wls, cycle=self.cycle + 1)
         self._pod_tas = pod_tas
-        return snap, heads, CycleTAS(snap, heads, self.topologies, pod_tas, admitted_tas=self.admitted_tas)
+        self.second_pass["heads"] += len(second)
+        return snap, heads, CycleTAS(snap, heads, topologies, pod_tas, admitted_tas=self.admitted_tas, head_admission=head_adm or None)
 
     def fold(self, heads, d, tout) -> int:
         """The cycle's admissions -> admitted workloads (flavors from the decision, TAS usage from its TopologyAssignment). -> how many."""
@@ -130,7 +159,22 @@ class TASClosedLoop:
         from .tas_cycle import AdmittedTAS
         n = 0
         for i, w in enumerate(heads.workloads):
-            if int(d.a["action"][i]) != F.ACT_ADMIT:
+            act = int(d.a["action"][i])
+            if w.has_unhealthy_nodes:
+                # the second pass of an admitted workload: the replaced TopologyAssignment takes the place of the old one (Scheduler.admit
+                # scheduler.go:991-1011), an eviction takes the workload out of the cache, anything else leaves it as it was
+                if act == F.ACT_ADMIT:
+                    self.admitted_tas[w.name] = [AdmittedTAS(ta[0], [(tuple(vals), cnt) for vals, cnt in ta[1]], dict(self._pod_tas[(w.name, pi)].single_pod_requests))
+                                                 for pi in range(len(w.pod_sets)) for ta in [tout.topology_assignment(i, pi)] if ta is not None]
+                    self.second_pass["replaced"] += 1
+                elif act == F.ACT_EVICT:
+                    self.admitted = [a for a in self.admitted if a.name != w.name]
+                    self.admitted_tas.pop(w.name, None); self.admitted_pod_tas.pop(w.name, None)
+                    self.second_pass["evicted"] += 1
+                else:
+                    self.second_pass["pending"] += 1
+                continue
+            if act != F.ACT_ADMIT:
                 continue
             fl = d.flavors_of(i)
             aw = copy.deepcopy(w)
@@ -145,11 +189,12 @@ class TASClosedLoop:
             self.admitted.append(aw)
             if tas:
                 self.admitted_tas[aw.name] = tas
+                self.admitted_pod_tas[aw.name] = [self._pod_tas[(w.name, pi)] for pi in range(len(aw.pod_sets))]
             n += 1
         if self.hold > 0:
             gone = [w for w in self.admitted if w._admitted_in <= self.cycle - self.hold]
             for w in gone:
-                self.admitted_tas.pop(w.name, None)
+                self.admitted_tas.pop(w.name, None); self.admitted_pod_tas.pop(w.name, None)
             self.admitted = [w for w in self.admitted if w._admitted_in > self.cycle - self.hold]
         self.cycle += 1
         return n
