@@ -19,7 +19,7 @@
  * Heads that hold an admission (the second pass: a delayed topology request, or a node failure -> replacement) are part of the cycle:
  * see ps_adm_flavor / ps_ex_* below.
  * Outside (KQ_EUNSUPPORTED or left to the caller): a workload whose podsets land on more than one TAS
- * flavor (TASHandleOverlappingFlavors), balanced placement.
+ * flavor (TASHandleOverlappingFlavors), TASRespectNodeAffinityPreferred. (TASBalancedPlacement: kq_tas_topology.profile_mixed, include/kq_tas.h.)
  */
 #ifndef KQ_CYCLE_TAS_H
 #define KQ_CYCLE_TAS_H

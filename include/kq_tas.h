@@ -16,8 +16,13 @@
  * Node replacement (the HasUnhealthyNodes branch :608-633): kq_tas_find_replacement — findReplacementAssignment :686,
  * requiredReplacementDomain :759, findIncompleteSliceDomain :842, mergeTopologyAssignments :2072, the BelongsTo test of fillLeafCounts
  * :1902. The node-exclusion statistics of notFitMessage :1997 (tasExclusionStats :470): kq_tas_exclusion_stats.
- * Not covered: TASBalancedPlacement, TASRespectNodeAffinityPreferred (both default-off gates): a caller that runs with one of them ON says so
- * in kq_tas_topology.profile_mixed (KQ_TAS_F_*) and gets KQ_EUNSUPPORTED from kq_tas_topology_put / kq_cycle_run_tas.
+ * Balanced placement (tas_balanced_placement.go, gate TASBalancedPlacement, default off): a caller running with the gate ON sets
+ * KQ_TAS_F_BALANCED_PLACEMENT in kq_tas_topology.profile_mixed; preferred requests then go through findBestDomainsForBalancedPlacement :235
+ * / applyBalancedPlacementAlgorithm :296 (with the fall-back to BestFit, tas_flavor_snapshot.go:1012-1024) in kq_tas_find and in
+ * kq_cycle_run_tas. Limit: a request whose dynamic programme (selectOptimalDomainSetToFit :79) needs more than 2^20 (domains used,
+ * leaders left, pods left) states is KQ_EUNSUPPORTED for the batch.
+ * Not covered: TASRespectNodeAffinityPreferred (default-off gate): a caller that runs with it ON says so (KQ_TAS_F_AFFINITY_PREFERRED) and gets
+ * KQ_EUNSUPPORTED from kq_tas_topology_put / kq_cycle_run_tas.
  *
  * Canonical order: the domains of every level are numbered in the lexicographic order of their levelValues
  * (compareDomainLevelValues :1727), so every "levelValues ascending" tie-break is an integer compare.
@@ -55,8 +60,7 @@ extern "C" {
 #define KQ_TAS_NO_REPLACEMENT 10  /* :727 "cannot find replacement assignment for unhealthy node" */
 
 #define KQ_TAS_F_PROFILE_MIXED       1
-#define KQ_TAS_F_BALANCED_PLACEMENT  2   /* tas_balanced_placement.go (gate TASBalancedPlacement, kube_features.go:692): not implemented by the
-                                          * library (KQ_EUNSUPPORTED); the oracle restates it (oracle/kq_tas_oracle.cpp) */
+#define KQ_TAS_F_BALANCED_PLACEMENT  2   /* tas_balanced_placement.go (gate TASBalancedPlacement, kube_features.go:692): preferred requests are balanced */
 #define KQ_TAS_F_AFFINITY_PREFERRED  4   /* TASRespectNodeAffinityPreferred: not implemented */
 
 typedef struct kq_tas_topology {
@@ -64,9 +68,9 @@ typedef struct kq_tas_topology {
   int32_t n_resources;
   int32_t pods_resource;          /* index of corev1.ResourcePods (resources.OnePodRequest is added to every request) */
   int32_t profile_mixed;          /* feature bits (the name is the first one's; 0 / 1 as before): KQ_TAS_F_PROFILE_MIXED = features.TASProfileMixed,
-                                     LeastFreeCapacity for unconstrained podsets (:1468). KQ_TAS_F_BALANCED_PLACEMENT / _AFFINITY_PREFERRED: the caller
-                                     runs with TASBalancedPlacement / TASRespectNodeAffinityPreferred ON (both alpha, default off) — paths this library
-                                     does not have: kq_tas_topology_put / kq_cycle_run_tas return KQ_EUNSUPPORTED and the caller keeps its Go path */
+                                     LeastFreeCapacity for unconstrained podsets (:1468). KQ_TAS_F_BALANCED_PLACEMENT = features.TASBalancedPlacement.
+                                     KQ_TAS_F_AFFINITY_PREFERRED: the caller runs with TASRespectNodeAffinityPreferred ON (alpha, default off) — a path this
+                                     library does not have: kq_tas_topology_put / kq_cycle_run_tas return KQ_EUNSUPPORTED and the caller keeps its Go path */
   const int32_t* level_off;       /* [n_levels+1] offsets of each level's domains in `parent` */
   const int32_t* parent;          /* [level_off[n_levels]] index (within the level above) of the parent domain; level 0: -1 */
   /* leaves = domains of the last level, n_leaves = level_off[n_levels] - level_off[n_levels-1] */

@@ -966,12 +966,16 @@ template <class B> struct EngineT {
     if ((nt > 0 && (!t->tas_flavor || !t->topo)) || !t->cq_tas_only || !t->adm_off || !t->ps_flags || !t->ps_kind || !t->ps_level || !t->ps_slice_size ||
         !t->ps_slice_level || !t->ps_group || !t->ps_req) return fail(KQ_EINVAL, "null array in kq_cycle_tas");
     tnext = 0;
-    const int slots = std::max(1, std::min(n, be.max_slots()));
+    // TASBalancedPlacement (tas_balanced_placement.go): a preferred request's dynamic programme needs a table per wave slot (kq_tas_device.hpp
+    // TBal) and the full domain state (no request-class tables, no LDS copy of them): fewer slots, classes off for the cycle
+    bool balanced = false;
+    for (int i = 0; i < t->n_tas; i++) if (t->topo && (t->topo[i].profile_mixed & KQ_TAS_F_BALANCED_PLACEMENT)) balanced = true;
+    const int slots = std::max(1, std::min(n, balanced ? std::min(be.max_slots(), 64) : be.max_slots()));
     // request classes of the cycle's podsets (k_process_tas keeps their phase-1 tables resident, kq_tas_cycle.hpp): same per-pod requests,
     // slice size and slice level on every TAS flavor; podset groups and inner layers stay outside
     constexpr int TC_MAXCLS = 32;
     std::vector<int32_t> ps_class(std::max<size_t>(nps, 1), -1), cls_rep;
-    if (!tas_classes_off) {
+    if (!tas_classes_off && !balanced) {
       std::unordered_map<std::string, int> ids;
       std::vector<uint8_t> repl_head(std::max<size_t>(nps, 1), 0);   // podsets of a head that looks for a failed node's replacement: rewritten requests
       if (t->ps_adm_flavor) for (int i = 0; i < n; i++) if (h->flags[i] & KQ_HEAD_HAS_UNHEALTHY_NODES) for (int p = h->ps_off[i]; p < h->ps_off[i + 1]; p++) repl_head[p] = 1;
@@ -1008,8 +1012,9 @@ template <class B> struct EngineT {
       TK& tk = tks[i];
       tk = TK{};
       TTopo& T = tk.T;
-      if (tp.profile_mixed & ~KQ_TAS_F_PROFILE_MIXED) return fail(KQ_EUNSUPPORTED, "TASBalancedPlacement / TASRespectNodeAffinityPreferred are not implemented: keep the Go path while the gate is on");
+      if (tp.profile_mixed & ~(KQ_TAS_F_PROFILE_MIXED | KQ_TAS_F_BALANCED_PLACEMENT)) return fail(KQ_EUNSUPPORTED, "TASRespectNodeAffinityPreferred is not implemented: keep the Go path while the gate is on");
       T.L = tp.n_levels; T.R = R; T.pods = tp.pods_resource; T.profile_mixed = tp.profile_mixed & KQ_TAS_F_PROFILE_MIXED;
+      T.balanced = (tp.profile_mixed & KQ_TAS_F_BALANCED_PLACEMENT) ? 1 : 0;
       for (int l = 0; l <= T.L; l++) T.level_off[l] = tp.level_off[l];
       T.D = T.level_off[T.L]; T.leaf_base = T.level_off[T.L - 1]; T.n_leaves = T.D - T.leaf_base;
       for (int l = 0; l < T.L; l++) if (T.level_off[l + 1] < T.level_off[l]) return fail(KQ_EINVAL, "level_off not monotone");
@@ -1051,6 +1056,13 @@ template <class B> struct EngineT {
       X.k0 = (uint64_t*)tgrow<int64_t>(sm); X.k1 = (uint64_t*)tgrow<int64_t>(sm);
       X.assumed = tgrow<int64_t>((size_t)xslots * cells);
       X.log = tgrow<int32_t>(sm); X.meta = tgrow<int32_t>((size_t)xslots * 4);
+      if (T.balanced) {
+        int wd = 1;
+        for (int l = 0; l < T.L; l++) wd = std::max(wd, T.level_off[l + 1] - T.level_off[l]);
+        X.bal_w = wd; X.bal_dp = (long long)1 << 20;
+        X.bal_stride = 10ll * T.D + 4ll * wd + 2 * X.bal_dp;
+        X.bal = tgrow<int32_t>((size_t)xslots * (size_t)X.bal_stride);
+      }
       be.memset(X.meta, 0xff, (size_t)xslots * 4 * sizeof(int32_t));
     }
     const int n_adm = prep.n_adm;

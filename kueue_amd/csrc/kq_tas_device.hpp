@@ -16,11 +16,13 @@
 #pragma once
 #include "../../include/kq_tas.h"
 #include "kq_device.hpp"
+#include <cmath>   // (the entropy order of balanced placement: frexp / log on the host build; the device build has HIP's)
 
 namespace kq {
 
 struct TTopo {
   int L, R, pods, profile_mixed, D, n_leaves, leaf_base;
+  int balanced;                // features.TASBalancedPlacement (KQ_TAS_F_BALANCED_PLACEMENT): kq_tas_find only
   int level_off[KQ_TAS_MAX_LEVELS + 1];
   const int32_t* child_first;  // [D] global id of the first child (children are contiguous), -1 for leaves
   const int32_t* child_cnt;    // [D]
@@ -61,6 +63,9 @@ struct TScratch {  // per wave slot
   int32_t* log;                         // [slots][max_set] domains whose state phase 2 changed
   int32_t* meta;                        // [slots][4] log length, state no longer restorable, class the state was copied from
   int32_t max_set;
+  // balanced placement (tas_balanced_placement.go; T.balanced): per-slot scratch of bal_stride int32 words — two saved copies of the
+  // domain state, four domain lists of the widest level, the dynamic programme's table (bal_dp entries of two words)
+  int32_t* bal; long long bal_stride; long long bal_dp; int32_t bal_w;
 };
 // Phase 1 only depends on (requests, leader requests, simulate-empty, slice size / level) — not on the pod count, the
 // requested level or required / preferred / unconstrained. Workloads with one podset group and no feasibility mask are
@@ -104,6 +109,7 @@ struct TState {  // per-slot pointers
   bool nolead;   // leaderCount is 0 everywhere and stays 0: no lc array
   TLeafJob* coop;   // the state is in LDS and the workgroup has helper waves: long slices are swept together (null: alone)
   int coop_min;
+  int bal_slot;     // the slot's index (TScratch::bal)
 };
 // lane 0 records a domain whose state it is about to change
 KQ_DEV void t_touch(const TState& s, int d) {
@@ -134,7 +140,7 @@ KQ_DEV TState tas_state(const TK& k, int slot) {
   s.k0 = k.X.k0 + slot * M; s.k1 = k.X.k1 + slot * M;
   s.assumed = k.X.assumed + (size_t)slot * k.T.n_leaves * k.T.R;
   s.log = k.X.log + slot * M; s.meta = k.X.meta + (size_t)slot * 4; s.logcap = (int)M;
-  s.nolead = false; s.coop = nullptr; s.coop_min = 0;
+  s.nolead = false; s.coop = nullptr; s.coop_min = 0; s.bal_slot = slot;
   if (k.lds) {
     const TLdsLay l = tas_lds_layout(k.T.D, (int)M);
     s.k0 = (uint64_t*)(k.lds + l.k0); s.k1 = (uint64_t*)(k.lds + l.k1);
@@ -939,6 +945,7 @@ KQ_DEV int t_true_last(const TState& s, const TView& v) {
   return t_argmin(s, v, SelLast{}, &a, &b, true) ? t_dom(~b) : -1;
 }
 
+// (the balanced placement is defined behind t_find_level's helpers, see below)
 // findLevelWithFitDomains :1336 ; on success the fitting domains are in s.cur[0..*nfit)
 KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* fitLevel, int* nfit) {
   const TTopo& T = k.T;
@@ -1114,6 +1121,317 @@ KQ_DEV TFail t_not_fit_layers(const TK& k, const TState& s, const TParams& st, i
   return TFail{KQ_TAS_NOT_FIT_LAYERS, best, lvl};
 }
 
+// ---- tas_balanced_placement.go (features.TASBalancedPlacement; preferred requests only, tas_flavor_snapshot.go:1012) ------------------------
+// A gate that is off by default: the whole of it runs on lane 0 over the slot's own scratch (TScratch::bal) — plain loops, insertion
+// sorts, a dynamic programme over a table of back-pointers. The placement's other steps (phase 1 before it, updateCountsToMinimum and the
+// descent after it) are the wave-wide ones. Every candidate set of the reference works on cloneDomains :347 of the subtrees; here the
+// state arrays are saved / restored as a whole, which is the same for the subtrees a candidate touches.
+struct TBal {
+  int32_t *orig, *best;           // [5 * D] pc | sc | pcwl | scwl | lc
+  int32_t *la, *lb, *lc, *ld;     // [W] domain lists
+  int32_t* dp; long long dp_cap;  // [dp_cap][2]: (domain | -2 = the empty placement | -1 = unset, previous state's index)
+  long long bytes;                // algorithmic bytes of the roll-ups (fillInCountsHelper: 24 per inner domain)
+  bool overflow;                  // the table does not hold the request: KQ_EUNSUPPORTED
+};
+KQ_DEV TBal t_bal_of(const TK& k, int slot) {
+  TBal b;
+  int32_t* p = k.X.bal + (size_t)slot * k.X.bal_stride;
+  const size_t D = k.T.D, W = k.X.bal_w;
+  b.orig = p; b.best = p + 5 * D; b.la = p + 10 * D; b.lb = b.la + W; b.lc = b.lb + W; b.ld = b.lc + W; b.dp = b.ld + W;
+  b.dp_cap = k.X.bal_dp; b.bytes = 0; b.overflow = false;
+  return b;
+}
+KQ_DEV void t_bal_save(const TK& k, const TState& s, int32_t* dst) {
+  const int D = k.T.D;
+  for (int d = 0; d < D; d++) { dst[d] = s.pc[d]; dst[D + d] = s.sc[d]; dst[2 * D + d] = s.pcwl[d]; dst[3 * D + d] = s.scwl[d]; dst[4 * D + d] = t_lc(s, d); }
+}
+KQ_DEV void t_bal_load(const TK& k, const TState& s, const int32_t* src) {
+  const int D = k.T.D;
+  for (int d = 0; d < D; d++) { s.pc[d] = src[d]; s.sc[d] = src[D + d]; s.pcwl[d] = src[2 * D + d]; s.scwl[d] = src[3 * D + d]; t_set_lc(s, d, src[4 * D + d]); }
+}
+// sortedDomainsWithLeader :1731 / sortedDomains :1770 (BestFit: these callers pass unconstrained = false), in place
+KQ_DEV bool t_bal_before(const TState& s, int a, int b, bool withLeader) {
+  if (withLeader) {
+    if (t_lc(s, a) != t_lc(s, b)) return t_lc(s, b) < t_lc(s, a);
+    if (s.scwl[a] != s.scwl[b]) return s.scwl[b] < s.scwl[a];
+    if (s.pcwl[a] != s.pcwl[b]) return s.pcwl[a] < s.pcwl[b];
+    return a < b;
+  }
+  if (s.sc[a] != s.sc[b]) return s.sc[b] < s.sc[a];
+  if (s.pc[a] != s.pc[b]) return s.pc[a] < s.pc[b];
+  return a < b;
+}
+KQ_DEV void t_bal_sort(const TState& s, int32_t* l, int n, bool withLeader) {
+  for (int i = 1; i < n; i++) {
+    const int x = l[i];
+    int j = i - 1;
+    while (j >= 0 && t_bal_before(s, x, l[j], withLeader)) { l[j + 1] = l[j]; j--; }
+    l[j + 1] = x;
+  }
+}
+struct TGreedy { bool fits; int32_t selected; int lastWithLeader, last; };
+// evaluateGreedyAssignment :28 over the list l[0..n) (tmp: a list of the same length)
+KQ_DEV TGreedy t_bal_greedy(const TState& s, const int32_t* l, int n, int32_t* tmp, int32_t sliceCount, int32_t leaderCount) {
+  TGreedy g{false, 0, -1, -1};
+  for (int i = 0; i < n; i++) tmp[i] = l[i];
+  int32_t remainingSlice = sliceCount, remainingLeader = leaderCount;
+  int idx = 0;
+  if (leaderCount > 0) {
+    t_bal_sort(s, tmp, n, true);
+    for (; remainingLeader > 0 && idx < n && t_lc(s, tmp[idx]) > 0; idx++) {
+      g.selected++; g.lastWithLeader = tmp[idx];
+      remainingLeader -= t_lc(s, tmp[idx]);
+      remainingSlice -= s.scwl[tmp[idx]];
+    }
+  }
+  t_bal_sort(s, tmp + idx, n - idx, false);
+  if (remainingLeader > 0) return TGreedy{false, 0, -1, -1};
+  for (int i = idx; remainingSlice > 0 && i < n && s.sc[tmp[i]] > 0; i++) {
+    g.selected++; g.last = tmp[i];
+    remainingSlice -= s.sc[tmp[i]];
+  }
+  if (remainingSlice > 0) return TGreedy{false, 0, -1, -1};
+  g.fits = true;
+  return g;
+}
+KQ_DEV int32_t t_bal_threshold(const TState& s, int32_t sliceCount, const TGreedy& g) {   // balanceThresholdValue :64
+  int32_t t = sliceCount / g.selected;
+  if (g.lastWithLeader >= 0 && s.scwl[g.lastWithLeader] < t) t = s.scwl[g.lastWithLeader];
+  if (g.last >= 0 && s.sc[g.last] < t) t = s.sc[g.last];
+  return t;
+}
+// math.Log2 (log2.go): Frexp, then Log(frac) * (1 / Ln2) + exp
+KQ_DEV double t_bal_log2(double x) {
+  int e; const double frac = ::frexp(x, &e);
+  if (frac == 0.5) return (double)(e - 1);
+  return ::log(frac) * (1.0 / 0.693147180559945309417232121458176568) + (double)e;
+}
+KQ_DEV double t_bal_entropy(const TK& k, const TState& s, int d) {   // calculateDomainsEntropy :189 of d's children
+  const int c0 = k.T.child_first[d], cn = c0 >= 0 ? k.T.child_cnt[d] : 0;
+  if (cn == 0) return 0.0;
+  int32_t total = 0;
+  for (int c = c0; c < c0 + cn; c++) total += s.pc[c];
+  if (total == 0) return 0.0;
+  double e = 0.0; const double tf = (double)total;
+  for (int c = c0; c < c0 + cn; c++) if (s.pc[c] > 0) { const double pI = (double)s.pc[c] / tf; e += -pI * t_bal_log2(pI); }
+  return e;
+}
+KQ_DEV bool t_bal_before_entropy(const TK& k, const TState& s, int a, int b) {   // compareDomainCapacityAndEntropy :214 < 0
+  if (t_lc(s, a) != t_lc(s, b)) return t_lc(s, b) < t_lc(s, a);
+  if (s.scwl[a] != s.scwl[b]) return s.scwl[b] < s.scwl[a];
+  const double ae = t_bal_entropy(k, s, a), be = t_bal_entropy(k, s, b);
+  if (be > ae) return false;
+  if (be < ae) return true;
+  return a < b;
+}
+// selectOptimalDomainSetToFit :79: the result in out[0..return), -1 = nil. The Go maps keyed by (leaders left, pods left) are one table
+// of back-pointers here: "first writer wins" with the keys walked in ascending order, as slices.Sorted(maps.Keys(..)) does.
+KQ_DEV int t_bal_select(const TK& k, const TState& s, TBal& b, const int32_t* l, int n, int32_t* ord, int32_t* tmp, int32_t* out,
+                        int32_t sliceCount, int32_t leaderCount, int32_t sliceSize, bool byEntropy) {
+  const TGreedy g = t_bal_greedy(s, l, n, tmp, sliceCount, leaderCount);
+  if (!g.fits) return -1;
+  const int optimal = g.selected;
+  for (int i = 0; i < n; i++) ord[i] = l[i];
+  for (int i = 1; i < n; i++) {   // slices.SortFunc by the entropy order / by levelValues
+    const int x = ord[i];
+    int j = i - 1;
+    while (j >= 0 && (byEntropy ? t_bal_before_entropy(k, s, x, ord[j]) : x < ord[j])) { ord[j + 1] = ord[j]; j--; }
+    ord[j + 1] = x;
+  }
+  int32_t maxPc = 1;
+  for (int i = 0; i < n; i++) { if (s.pc[ord[i]] > maxPc) maxPc = s.pc[ord[i]]; if (s.pcwl[ord[i]] > maxPc) maxPc = s.pcwl[ord[i]]; }
+  // pods left: from P0 down. A state with nothing left (no leader, pods <= 0) is final, so without a leader the lowest key is
+  // 1 - maxPc; while a leader is still to be placed a state goes on below zero: at most `optimal` picks of maxPc each
+  const long long P0 = (long long)sliceCount * sliceSize, minP = leaderCount > 0 ? P0 - (long long)optimal * maxPc - 1 : 1 - (long long)maxPc,
+                  R = P0 - minP + 1, Lr = (long long)leaderCount + 1;
+  const long long cells = (long long)(optimal + 1) * Lr * R;
+  if (cells > b.dp_cap || P0 > 0x3fffffff) { b.overflow = true; return -1; }
+  for (long long c = 0; c < cells; c++) b.dp[2 * c] = -1;
+  auto at = [&](int i, long long ld, long long pods) { return ((long long)i * Lr + ld) * R + (pods - minP); };
+  b.dp[2 * at(0, leaderCount, P0)] = -2;
+  for (int q = 0; q < n; q++) {
+    const int d = ord[q];
+    const int32_t dlc = t_lc(s, d), dpc = s.pc[d], dpcwl = s.pcwl[d], dsc = s.sc[d];
+    for (int i = optimal; i > 0; i--)
+      for (long long bl = 0; bl < Lr; bl++)
+        for (long long bp = minP; bp <= P0; bp++) {
+          const long long from = at(i - 1, bl, bp);
+          if (b.dp[2 * from] == -1) continue;
+          if (bl <= 0 && bp <= 0) continue;
+          if (bl > 0 && dlc > 0) {   // pick this domain with leader
+            const long long al = bl - dlc, ap = bp - dpcwl;
+            if (al >= 0 && ap >= minP) { const long long to = at(i, al, ap); if (b.dp[2 * to] == -1) { b.dp[2 * to] = d; b.dp[2 * to + 1] = (int32_t)from; } }
+          }
+          if (dsc > 0) {             // pick this domain without leader
+            const long long ap = bp - dpc;
+            if (ap >= minP) { const long long to = at(i, bl, ap); if (b.dp[2 * to] == -1) { b.dp[2 * to] = d; b.dp[2 * to + 1] = (int32_t)from; } }
+          }
+        }
+  }
+  long long bestIdx = -1;
+  for (long long pods = 0; pods >= minP; pods--) { const long long c = at(optimal, 0, pods); if (b.dp[2 * c] != -1) { bestIdx = c; break; } }
+  if (bestIdx < 0) return -1;
+  int m = 0;
+  for (long long c = bestIdx; b.dp[2 * c] != -2; c = b.dp[2 * c + 1]) out[m++] = b.dp[2 * c];
+  for (int i = 0; i < m / 2; i++) { const int t = out[i]; out[i] = out[m - 1 - i]; out[m - 1 - i] = t; }
+  return m;
+}
+// placeSlicesOnDomainsBalanced :151 on the list l[0..n): the chosen domains, in sortedDomainsWithLeader order, in out; -1 = a failure reason
+KQ_DEV int t_bal_place(const TK& k, const TState& s, TBal& b, const int32_t* l, int n, int32_t* ord, int32_t* tmp, int32_t* out,
+                       int32_t sliceCount, int32_t leaderCount, int32_t sliceSize, int32_t threshold) {
+  const int m = t_bal_select(k, s, b, l, n, ord, tmp, out, sliceCount, leaderCount, sliceSize, false);
+  if (m < 0) return -1;
+  if (sliceCount < (int32_t)m * threshold) return -1;
+  t_bal_sort(s, out, m, true);
+  int32_t extraLeft = sliceCount - (int32_t)m * threshold, leadersLeft = leaderCount, take = 0;
+  for (int i = 0; i < m; i++) {
+    const int d = out[i];
+    if (leadersLeft > 0) { take = s.scwl[d] - threshold < extraLeft ? s.scwl[d] - threshold : extraLeft; t_set_lc(s, d, 1); leadersLeft--; }
+    else if (extraLeft > 0) { take = s.sc[d] - threshold < extraLeft ? s.sc[d] - threshold : extraLeft; t_set_lc(s, d, 0); }
+    else { t_set_lc(s, d, 0); take = 0; }
+    s.pc[d] = (threshold + take) * sliceSize;
+    s.sc[d] = threshold + take;
+    s.scwl[d] = s.sc[d];
+    s.pcwl[d] = s.pc[d] - t_lc(s, d);
+    extraLeft -= take;
+  }
+  if (extraLeft > 0 || leadersLeft > 0) return -1;
+  return m;
+}
+// the id range of d's subtree at depth `dep` below d's own level (children of consecutive domains are consecutive)
+KQ_DEV void t_bal_range(const TK& k, int d, int dep, int* lo, int* hi) {
+  int a = d, z = d + 1;
+  for (int i = 0; i < dep && z > a; i++) {
+    int na = -1, nz = -1;
+    for (int x = a; x < z; x++) if (k.T.child_first[x] >= 0 && k.T.child_cnt[x] > 0) { if (na < 0) na = k.T.child_first[x]; nz = k.T.child_first[x] + k.T.child_cnt[x]; }
+    if (na < 0) { a = z = 0; break; }
+    a = na; z = nz;
+  }
+  *lo = a; *hi = z;
+}
+KQ_DEV void t_bal_clear(const TK& k, const TState& s, int d, int level, bool leaderOnly) {   // clearState :324 / clearLeaderCapacity :332
+  for (int dep = 0; level + dep < k.T.L; dep++) {
+    int lo, hi;
+    t_bal_range(k, d, dep, &lo, &hi);
+    for (int x = lo; x < hi; x++) {
+      if (!leaderOnly) { s.pc[x] = 0; s.sc[x] = 0; }
+      s.pcwl[x] = 0; s.scwl[x] = 0; t_set_lc(s, x, 0);
+    }
+  }
+}
+KQ_DEV void t_bal_prune_node(const TK& k, const TState& s, int d, int level, int32_t threshold, bool leaderRequired) {   // :365
+  if (s.sc[d] < threshold) { t_bal_clear(k, s, d, level, false); return; }
+  if (leaderRequired && t_lc(s, d) > 0 && s.scwl[d] < threshold) t_bal_clear(k, s, d, level, true);
+}
+// fillInCountsHelper :1930 for the subtree of d (level `level`), without inner slice layers (pruneDomainsBelowThreshold passes nil)
+KQ_DEV void t_bal_rollup(const TK& k, const TState& s, TBal& b, int d, int level, int32_t sliceSize, int sliceLevelIdx, bool leaderRequired) {
+  for (int lv = k.T.L - 1; lv >= level; lv--) {
+    int lo, hi;
+    t_bal_range(k, d, lv - level, &lo, &hi);
+    for (int x = lo; x < hi; x++) {
+      const int c0 = k.T.child_first[x], cn = c0 >= 0 ? k.T.child_cnt[x] : 0;
+      if (cn == 0) {
+        if (lv == sliceLevelIdx) { s.sc[x] = s.pc[x] / sliceSize; s.scwl[x] = s.pcwl[x] / sliceSize; }
+        continue;
+      }
+      int32_t childrenCapacity = 0, sliceCapacity = 0, minPodDiff = 0x7fffffff, minSliceDiff = 0x7fffffff, leaderCount = 0;
+      bool contributor = false;
+      for (int c = c0; c < c0 + cn; c++) {
+        childrenCapacity += s.pc[c];
+        sliceCapacity += s.sc[c];
+        if (!leaderRequired || t_lc(s, c) > 0) {
+          contributor = true;
+          if (s.pc[c] - s.pcwl[c] < minPodDiff) minPodDiff = s.pc[c] - s.pcwl[c];
+          if (s.sc[c] - s.scwl[c] < minSliceDiff) minSliceDiff = s.sc[c] - s.scwl[c];
+        }
+        if (t_lc(s, c) > leaderCount) leaderCount = t_lc(s, c);
+      }
+      s.pc[x] = childrenCapacity;
+      int32_t scwl = 0;
+      if (contributor) { s.pcwl[x] = childrenCapacity - minPodDiff; scwl = sliceCapacity - minSliceDiff; } else s.pcwl[x] = 0;
+      t_set_lc(s, x, leaderCount);
+      if (lv == sliceLevelIdx) { sliceCapacity = s.pc[x] / sliceSize; scwl = s.pcwl[x] / sliceSize; }
+      s.sc[x] = sliceCapacity; s.scwl[x] = scwl;
+      b.bytes += 24;
+    }
+  }
+}
+// pruneDomainsBelowThreshold :377 over the sibling range [a, a + n) at `level`
+KQ_DEV void t_bal_prune(const TK& k, const TState& s, TBal& b, int a, int n, int32_t threshold, int32_t sliceSize, int sliceLevelIdx, int level, bool leaderRequired) {
+  for (int d = a; d < a + n; d++) {
+    const int c0 = k.T.child_first[d], cn = c0 >= 0 ? k.T.child_cnt[d] : 0;
+    for (int c = c0; c < c0 + cn; c++) t_bal_prune_node(k, s, c, level + 1, threshold, leaderRequired);
+  }
+  for (int d = a; d < a + n; d++) {
+    t_bal_rollup(k, s, b, d, level, sliceSize, sliceLevelIdx, leaderRequired);
+    t_bal_prune_node(k, s, d, level, threshold, leaderRequired);
+  }
+}
+// :1012-1024 of findTopologyAssignment: findBestDomainsForBalancedPlacement :235 + applyBalancedPlacementAlgorithm :296. Lane 0 only.
+// true: s.cur[0..*ncur) holds currFitDomain at *fitLevel and the state is the chosen candidate's; false: the state is the original
+// one and findLevelWithFitDomains takes over ("falling back to Best Fit").
+KQ_DEV bool t_balanced_lane0(const TK& k, const TState& s, const TParams& p, TBal& b, int* fitLevel, int* ncur) {
+  const TTopo& T = k.T;
+  const int32_t sliceCount = p.count / p.sliceSize;
+  const bool leaderRequired = p.leaderCount > 0;
+  const int req = p.requestedLevelIdx;
+  t_bal_save(k, s, b.orig);
+  int32_t bestThreshold = 0, bestDomainCount = 0;
+  int bestA = -1, bestN = 0;
+  const int nsets = req == 0 ? 1 : T.level_off[req] - T.level_off[req - 1];
+  for (int si = 0; si < nsets; si++) {
+    int a, n;
+    if (req == 0) { a = T.level_off[0]; n = T.level_off[1] - T.level_off[0]; }
+    else { const int h = T.level_off[req - 1] + si; a = T.child_first[h]; n = a >= 0 ? T.child_cnt[h] : 0; }
+    if (si > 0) t_bal_load(k, s, b.orig);   // cloneDomains: every candidate starts from the shared state
+    if (n <= 0) continue;
+    // getLowerLevelDomains :317
+    int la = a, ln = n;
+    if (req < p.sliceLevelIdx) { int lo, hi; lo = -1; hi = -1; for (int d = a; d < a + n; d++) if (T.child_first[d] >= 0 && T.child_cnt[d] > 0) { if (lo < 0) lo = T.child_first[d]; hi = T.child_first[d] + T.child_cnt[d]; } la = lo < 0 ? 0 : lo; ln = lo < 0 ? 0 : hi - lo; }
+    for (int i = 0; i < ln; i++) b.la[i] = la + i;
+    const TGreedy g = t_bal_greedy(s, b.la, ln, b.lb, sliceCount, p.leaderCount);
+    if (!g.fits || g.selected == 0) continue;   // (selected == 0: an empty request, which the reference never sends here)
+    int32_t threshold = t_bal_threshold(s, sliceCount, g);
+    int32_t withLeaderReservation = threshold;
+    if (p.leaderCount > 0 && g.last >= 0 && s.scwl[g.last] < withLeaderReservation) withLeaderReservation = s.scwl[g.last];
+    if (threshold < bestThreshold) continue;
+    t_bal_prune(k, s, b, a, n, threshold, p.sliceSize, p.sliceLevelIdx, req, leaderRequired);
+    for (int i = 0; i < n; i++) b.la[i] = a + i;
+    TGreedy after = t_bal_greedy(s, b.la, n, b.lb, sliceCount, p.leaderCount);
+    if (!after.fits && withLeaderReservation < threshold) {
+      if (withLeaderReservation <= 0 || withLeaderReservation < bestThreshold) continue;
+      threshold = withLeaderReservation;
+      t_bal_load(k, s, b.orig);
+      t_bal_prune(k, s, b, a, n, threshold, p.sliceSize, p.sliceLevelIdx, req, leaderRequired);
+      after = t_bal_greedy(s, b.la, n, b.lb, sliceCount, p.leaderCount);
+    }
+    if (!after.fits) continue;
+    if (threshold > bestThreshold || (threshold == bestThreshold && after.selected < bestDomainCount)) {
+      bestThreshold = threshold; bestDomainCount = after.selected; bestA = a; bestN = n;
+      t_bal_save(k, s, b.best);
+    }
+  }
+  if (bestThreshold <= 0) { t_bal_load(k, s, b.orig); return false; }
+  t_bal_load(k, s, b.best);
+  // applyBalancedPlacementAlgorithm :296
+  int n = bestN;
+  for (int i = 0; i < n; i++) b.la[i] = bestA + i;
+  int32_t* curr = b.la;
+  if (req < p.sliceLevelIdx) {
+    const int m = t_bal_select(k, s, b, b.la, n, b.lb, b.lc, b.ld, sliceCount, p.leaderCount, p.sliceSize, true);
+    if (m < 0) { t_bal_load(k, s, b.orig); return false; }
+    n = 0;
+    for (int i = 0; i < m; i++) { const int d = b.ld[i], c0 = T.child_first[d], cn = c0 >= 0 ? T.child_cnt[d] : 0; for (int c = c0; c < c0 + cn; c++) b.la[n++] = c; }   // lowerLevelDomains
+    *fitLevel = req + 1;
+  } else *fitLevel = req;
+  const int m = t_bal_place(k, s, b, curr, n, b.lb, b.lc, b.ld, sliceCount, p.leaderCount, p.sliceSize, bestThreshold);
+  if (m < 0) { t_bal_load(k, s, b.orig); return false; }
+  for (int i = 0; i < m; i++) s.cur[i] = b.ld[i];
+  *ncur = m;
+  return true;
+}
+
+
 // findTopologyAssignment :886. On success the leaves of the assignment are in s.cur[0..*nfit) with their pod / leader
 // counts in s.pc / s.lc.
 KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, int* nfit, bool have_counts) {
@@ -1127,7 +1445,27 @@ KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, 
 #endif
   int fitLevelIdx = 0, ncur = 0;
   TPROF0();
-  TFail f = t_find_level(k, s, st, &fitLevelIdx, &ncur);
+  bool balanced = false;
+  if (T.balanced && !st.required && !st.unconstrained && k.X.bal) {   // tas_flavor_snapshot.go:1012-1024
+    // (lane 0 alone; its verdict travels through the head of the slot's scratch. The class table's state, if the placement started from
+    // one, is no longer restorable by the log: the next workload copies it again)
+    TBal b = t_bal_of(k, s.bal_slot);
+    int32_t* verdict = b.dp;   // [4] behind the routine: used, fitLevel, ncur, error
+    wsync();
+    if (lane_id() == 0) {
+      int fl = 0, nc = 0;
+      const bool used = t_balanced_lane0(k, s, st, b, &fl, &nc);
+      s.meta[1] = 1;
+      atomic_add_i64(k.O.bytes, b.bytes);
+      verdict[0] = used ? 1 : 0; verdict[1] = fl; verdict[2] = nc; verdict[3] = b.overflow ? 1 : 0;
+      if (b.overflow && *k.O.error == 0) *k.O.error = KQ_EUNSUPPORTED;
+    }
+    wsync();
+    balanced = verdict[0] != 0; fitLevelIdx = verdict[1]; ncur = verdict[2];
+    wsync();
+  }
+  TFail f{KQ_TAS_OK, 0, 0};
+  if (!balanced) f = t_find_level(k, s, st, &fitLevelIdx, &ncur);
   TPROF(k, 0);   // findLevelWithFitDomains
   if (f.status == KQ_TAS_NOT_FIT && st.nLayers > 0) { *nfit = fitLevelIdx; return f; }  // the caller turns it into the per-layer form
   if (f.status != KQ_TAS_OK) return f;
@@ -1142,7 +1480,7 @@ KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, 
   ncur = nout;
   TPROF(k, 1);   // the fit level's own domains
   int level = fitLevelIdx;
-  const int stop = (T.L - 1) < st.sliceLevelIdx ? (T.L - 1) : st.sliceLevelIdx;
+  const int stop = balanced ? level : ((T.L - 1) < st.sliceLevelIdx ? (T.L - 1) : st.sliceLevelIdx);   // (:1034 "&& !useBalancedPlacement")
   for (; level < stop; level++) {
     // sortedDomains(lowerLevelDomains(currFitDomain))
     int m = 0, id0 = -1;

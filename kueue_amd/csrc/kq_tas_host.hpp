@@ -93,9 +93,9 @@ template <class Backend> struct TasT {
     free_topo();
     if (t->n_levels < 1 || t->n_levels > KQ_TAS_MAX_LEVELS) return fail(KQ_EUNSUPPORTED, "n_levels out of range");
     if (t->n_resources < 1 || t->n_resources > KQ_TAS_MAXR) return fail(KQ_EUNSUPPORTED, "n_resources out of range");
-    if (t->profile_mixed & ~KQ_TAS_F_PROFILE_MIXED) return fail(KQ_EUNSUPPORTED, "TASBalancedPlacement / TASRespectNodeAffinityPreferred are not implemented: keep the Go path while the gate is on");
+    if (t->profile_mixed & ~(KQ_TAS_F_PROFILE_MIXED | KQ_TAS_F_BALANCED_PLACEMENT)) return fail(KQ_EUNSUPPORTED, "TASRespectNodeAffinityPreferred is not implemented: keep the Go path while the gate is on");
     T = TTopo{};
-    T.L = t->n_levels; T.R = t->n_resources; T.pods = t->pods_resource; T.profile_mixed = t->profile_mixed & KQ_TAS_F_PROFILE_MIXED;
+    T.L = t->n_levels; T.R = t->n_resources; T.pods = t->pods_resource; T.profile_mixed = t->profile_mixed & KQ_TAS_F_PROFILE_MIXED; T.balanced = (t->profile_mixed & KQ_TAS_F_BALANCED_PLACEMENT) ? 1 : 0;
     for (int l = 0; l <= T.L; l++) T.level_off[l] = t->level_off[l];
     T.D = T.level_off[T.L]; T.leaf_base = T.level_off[T.L - 1]; T.n_leaves = T.D - T.leaf_base;
     for (int l = 0; l < T.L; l++) if (T.level_off[l + 1] < T.level_off[l]) return fail(KQ_EINVAL, "level_off not monotone");
@@ -190,7 +190,8 @@ template <class Backend> struct TasT {
       O.layer_fit = grow<int32_t>(bo[4], (size_t)n * KQ_TAS_MAX_LEVELS);
       be.memset(O.layer_fit, 0, (size_t)n * KQ_TAS_MAX_LEVELS * sizeof(int32_t));
     }
-    const int slots = std::min(nw, be.max_slots());
+    // TASBalancedPlacement: the dynamic programme of a preferred request needs a table per slot (kq_tas_device.hpp TBal): fewer, larger slots
+    const int slots = std::min(nw, T.balanced ? std::min(be.max_slots(), 64) : be.max_slots());
     TScratch& X = k.X;
     X.max_set = (std::max(T.n_leaves, T.D - T.n_leaves + 1) + 1 + 15) & ~15;  // per-slot lists start 64-byte aligned (s.nxt doubles as int64 bins)
     const size_t sd = (size_t)slots * T.D, sm = (size_t)slots * X.max_set;
@@ -199,6 +200,14 @@ template <class Backend> struct TasT {
     X.k0 = (uint64_t*)grow<int64_t>(bx[9], sm); X.k1 = (uint64_t*)grow<int64_t>(bx[10], sm);
     X.assumed = grow<int64_t>(bx[11], (size_t)slots * T.n_leaves * T.R);
     X.log = grow<int32_t>(bx[12], sm); X.meta = grow<int32_t>(bx[13], (size_t)slots * 4);
+    X.bal = nullptr; X.bal_stride = 0; X.bal_dp = 0; X.bal_w = 0;
+    if (T.balanced) {
+      int w = 1;
+      for (int l = 0; l < T.L; l++) w = std::max(w, T.level_off[l + 1] - T.level_off[l]);
+      X.bal_w = w; X.bal_dp = (long long)1 << 20;   // 1 Mi (leaders left, pods left) states per slot: a request beyond that is KQ_EUNSUPPORTED
+      X.bal_stride = 10ll * T.D + 4ll * w + 2 * X.bal_dp;
+      X.bal = grow<int32_t>(bx[14], (size_t)slots * (size_t)X.bal_stride);
+    }
     be.memset(X.meta, 0xff, (size_t)slots * 4 * sizeof(int32_t));
     // request classes: workloads with one podset group and no feasibility mask share phase 1 when their requests,
     // leader requests, simulate-empty flag and slice parameters are identical
@@ -262,7 +271,7 @@ template <class Backend> struct TasT {
     last_ms = be.timer_ms(0, 1);
     last_bytes = hm[1];
     const int32_t used = ((int32_t*)hm)[0], derr = ((int32_t*)hm)[1];
-    if (derr != 0) return fail(derr, "device-side error (dom_cap too small)");
+    if (derr != 0) return fail(derr, derr == KQ_EUNSUPPORTED ? "device-side error: a balanced placement's table exceeds the slot's scratch (TASBalancedPlacement: keep the Go path for this batch)" : "device-side error (dom_cap too small)");
     std::vector<int32_t> pl(std::max(used, 1)), pcnt(std::max(used, 1));
     if (used > 0) { be.d2h(pl.data(), O.pool_leaf, (size_t)used * 4); be.d2h(pcnt.data(), O.pool_count, (size_t)used * 4); rc = be.sync(); if (rc != KQ_OK) return fail(rc, be.error()); }
     int tot = 0;

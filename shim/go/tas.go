@@ -42,7 +42,8 @@ var ErrUnsupported = errors.New("kqengine: the cycle is outside the device path 
 // order (utiltas.DomainID order, tas_flavor_snapshot.go:1770 sorts by it last), leaves last.
 type FlatTopology struct {
 	NLevels, NResources, PodsResource int32
-	BalancedPlacement, AffinityPreferred bool // gates the library does not implement (-> KQ_EUNSUPPORTED)
+	BalancedPlacement bool // features.TASBalancedPlacement: preferred requests go through tas_balanced_placement.go
+	AffinityPreferred bool // features.TASRespectNodeAffinityPreferred: a gate the library does not implement (-> KQ_EUNSUPPORTED)
 	ProfileMixed                      bool    // features.TASProfileMixed
 	LevelOff, Parent                  []int32 // Parent: index within the level above, -1 at level 0
 	FreeCapacity, TASUsage            []int64 // [leaves][resources]: leafCapacity.freeCapacity :88 / tasUsage
@@ -101,8 +102,8 @@ func fillTopology(p *runtime.Pinner, c *C.kq_tas_topology, t *FlatTopology) {
 	if t.ProfileMixed {
 		c.profile_mixed = C.KQ_TAS_F_PROFILE_MIXED
 	}
-	// features.TASBalancedPlacement / TASRespectNodeAffinityPreferred (alpha, default off): paths the library does not have — it answers
-	// KQ_EUNSUPPORTED and the scheduler keeps its own FindTopologyAssignmentsForFlavor while one of them is on
+	// features.TASRespectNodeAffinityPreferred (alpha, default off): a path the library does not have — it answers KQ_EUNSUPPORTED and the
+	// scheduler keeps its own FindTopologyAssignmentsForFlavor while it is on. TASBalancedPlacement is implemented (kq_tas.h).
 	if t.BalancedPlacement {
 		c.profile_mixed |= C.KQ_TAS_F_BALANCED_PLACEMENT
 	}

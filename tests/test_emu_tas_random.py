@@ -22,6 +22,51 @@ def test_tas_random(oracle, seed):
     assert got.bytes == want.bytes
 
 
+def _balanced(oracle, make, seed):
+    """features.TASBalancedPlacement on: preferred requests go through tas_balanced_placement.go (the device: lane 0 over the slot's scratch,
+    kq_tas_device.hpp t_balanced_lane0), everything else — and every fall-back to BestFit — through the usual placement."""
+    topo, rq = random_tas_case(seed, max_blocks=3 + seed % 3, max_racks=4 + seed % 4, max_hosts=6 + seed % 5, n_workloads=12 + seed % 7)
+    topo.feature_bits |= 2   # KQ_TAS_F_BALANCED_PLACEMENT
+    want = oracle.tas_find(topo, rq)
+    eng = make()
+    try:
+        eng.put(topo)
+        got = eng.find(rq)
+    finally:
+        eng.close()
+    bad = want.equal(got)
+    assert not bad, (bad, {k: (want.a[k].tolist(), got.a[k].tolist()) for k in bad})
+    assert got.bytes == want.bytes
+    return want
+
+
+@pytest.mark.parametrize("seed", range(600))
+def test_tas_random_balanced_placement(oracle, seed):
+    _balanced(oracle, kqe.EmuTas, seed)
+
+
+def test_balanced_placement_changes_answers(oracle):
+    """(the gate is not a no-op on these populations: with it on, some preferred requests get another assignment than BestFit's)"""
+    changed = 0
+    for seed in range(120):
+        topo, rq = random_tas_case(seed, max_blocks=3 + seed % 3, max_racks=4 + seed % 4, max_hosts=6 + seed % 5, n_workloads=12 + seed % 7)
+        off = oracle.tas_find(topo, rq)
+        topo.feature_bits |= 2
+        topo._struct = None
+        on = oracle.tas_find(topo, rq)
+        if on.equal(off):
+            changed += 1
+    assert changed >= 10, changed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", range(4))
+def test_tas_random_balanced_placement_gpu(oracle, block):
+    from kueue_amd import tas as T
+    for seed in range(block * 100, block * 100 + 100):
+        _balanced(oracle, T.TASEngine, seed)
+
+
 @pytest.mark.parametrize("seed", range(60))
 def test_tas_deep_and_wide(oracle, seed):
     """The API's own limits (VERDICT r03 "missing" 8): 9-16 topology levels, 17-30 resources per node."""

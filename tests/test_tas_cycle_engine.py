@@ -153,6 +153,28 @@ def test_random_tas_cycles_gpu(oracle, block):
         _random(oracle, _hip, seed)
 
 
+def _random_balanced(oracle, make, seed):
+    """The whole cycle with features.TASBalancedPlacement on: every placement of a preferred request inside Assign, the victim search's
+    workloadFits and processEntry's recomputation goes through tas_balanced_placement.go (kq_tas_device.hpp t_balanced_lane0)."""
+    cfg, snap, heads, ct, _ = random_tas_cycle_case(seed, fair=seed % 6 == 5, tight=seed % 2 == 0, preemption=seed % 3 != 0)
+    for i in range(len(ct.topos)):
+        ct._topo_arr[i].profile_mixed |= 2   # KQ_TAS_F_BALANCED_PLACEMENT
+    oracle.derive(snap)
+    return _same(oracle, make, cfg, snap, heads, ct, tgt_cap=max(16, snap.n_adm))
+
+
+@pytest.mark.parametrize("seed", range(200))
+def test_random_tas_cycles_balanced_placement_emulated(oracle, seed):
+    _random_balanced(oracle, _emu, seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", range(3))
+def test_random_tas_cycles_balanced_placement_gpu(oracle, block):
+    for seed in range(block * 100, block * 100 + 100):
+        _random_balanced(oracle, _hip, seed)
+
+
 def _second_pass(oracle, make, seed):
     """Cycles that mix heads on their first pass with heads on their second pass after a node failure (scheduler.go:583, manager.go:923,
     tas_flavor_snapshot.go:608-633): the admission's flavors kept, the failed node's pods placed below the required replacement domain and
