@@ -1370,7 +1370,8 @@ KQ_DEV void t_bal_prune(const TK& k, const TState& s, TBal& b, int a, int n, int
 // :1012-1024 of findTopologyAssignment: findBestDomainsForBalancedPlacement :235 + applyBalancedPlacementAlgorithm :296. Lane 0 only.
 // true: s.cur[0..*ncur) holds currFitDomain at *fitLevel and the state is the chosen candidate's; false: the state is the original
 // one and findLevelWithFitDomains takes over ("falling back to Best Fit").
-KQ_DEV bool t_balanced_lane0(const TK& k, const TState& s, const TParams& p, TBal& b, int* fitLevel, int* ncur) {
+// (not inlined: a gate that is off by default must not grow the placement every kernel carries)
+KQ_NOINLINE bool t_balanced_lane0(const TK& k, const TState& s, const TParams& p, TBal& b, int* fitLevel, int* ncur) {
   const TTopo& T = k.T;
   const int32_t sliceCount = p.count / p.sliceSize;
   const bool leaderRequired = p.leaderCount > 0;
