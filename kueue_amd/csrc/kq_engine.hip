@@ -132,6 +132,10 @@ hipError_t launch_tas_base_k(const TCyc* c, int n, hipStream_t stream);
 hipError_t launch_nominate_tas_k(const K* d, int slots, hipStream_t stream);
 hipError_t launch_tas_cycle_classes_k(const TCyc* c, int n, hipStream_t stream);
 hipError_t launch_process_tas_k(const K* d, size_t want, size_t* attr, hipStream_t stream);
+// the same kernels with tas_balanced_placement.go inside the placement (features.TASBalancedPlacement): kq_tas_cycle_kernel_bal.hip, kq_tas_bal_kernel.hip
+hipError_t launch_nominate_tas_k_bal(const K* d, int slots, hipStream_t stream);
+hipError_t launch_process_tas_k_bal(const K* d, size_t want, size_t* attr, hipStream_t stream);
+hipError_t launch_tas_find_bal_k(const TK* d, int slots, hipStream_t stream);
 }
 
 constexpr int PROCESS_THREADS = 256;   // wave 0 runs the serial core; all 4 waves prefetch the entry records of a chunk
@@ -601,6 +605,7 @@ struct HipBackend {
   }
   void launch_tas_find(const TK& k, int slots) {
     put_tk(k);
+    if (k.T.balanced) { chk(launch_tas_find_bal_k((const TK*)dtk, slots, stream), "k_tas_find_bal"); return; }   // (the gate's own kernel)
     hipLaunchKernelGGL(k_tas_find, dim3(slots), dim3(64), 0, stream, (const TK*)dtk, slots);
     chk(hipGetLastError(), "k_tas_find");
   }
@@ -820,14 +825,15 @@ struct HipBackend {
   void launch_nominate_tas(const K& k, int slots) {
     stat_patched = false;
     const K* d = put_k(k, 0);
-    chk(launch_nominate_tas_k(d, slots, stream), "k_nominate_tas");
+    chk(tas_bal ? launch_nominate_tas_k_bal(d, slots, stream) : launch_nominate_tas_k(d, slots, stream), "k_nominate_tas");
   }
+  bool tas_bal = false;   // this cycle's TAS flavors carry KQ_TAS_F_BALANCED_PLACEMENT: the _bal kernels (set by cycle_run_tas)
   void launch_process_tas(const K& k, size_t lds_want) {
     const K* d = stat_patched ? dcur0 : put_k(k, 1);
     dproc = d; stat_patched = false;
-    chk(launch_process_tas_k(d, lds_want, &lds_attr_tas, stream), "k_process_tas");
+    chk(tas_bal ? launch_process_tas_k_bal(d, lds_want, &lds_attr_tas_bal, stream) : launch_process_tas_k(d, lds_want, &lds_attr_tas, stream), "k_process_tas");
   }
-  size_t lds_attr_tas = 0;
+  size_t lds_attr_tas = 0, lds_attr_tas_bal = 0;
   size_t lds_attr = 0, lds_attr_fair = 0;
   const K* dproc = nullptr;    // argument block of the last process launch (kq_cycle_commit reads the cycle's outputs through it)
   bool stat_patched = false;

@@ -971,6 +971,7 @@ template <class B> struct EngineT {
     bool balanced = false;
     for (int i = 0; i < t->n_tas; i++) if (t->topo && (t->topo[i].profile_mixed & KQ_TAS_F_BALANCED_PLACEMENT)) balanced = true;
     const int slots = std::max(1, std::min(n, balanced ? std::min(be.max_slots(), 64) : be.max_slots()));
+    be.tas_bal = balanced;   // (the kernels that carry the gate's code)
     // request classes of the cycle's podsets (k_process_tas keeps their phase-1 tables resident, kq_tas_cycle.hpp): same per-pod requests,
     // slice size and slice level on every TAS flavor; podset groups and inner layers stay outside
     constexpr int TC_MAXCLS = 32;

@@ -1121,6 +1121,10 @@ KQ_DEV TFail t_not_fit_layers(const TK& k, const TState& s, const TParams& st, i
   return TFail{KQ_TAS_NOT_FIT_LAYERS, best, lvl};
 }
 
+// The gate is off by default: its code is compiled into kernel variants of their own (KQ_TAS_BAL: k_tas_find_bal, k_nominate_tas_bal,
+// k_process_tas_bal — chosen by the host when a topology carries KQ_TAS_F_BALANCED_PLACEMENT), so that the kernels everybody runs keep their
+// registers and stay without scratch (k_tas_find: 0 B; with the routine as a callee it had 392 B and ran 7 % slower, profiles/r05t_*).
+#ifdef KQ_TAS_BAL
 // ---- tas_balanced_placement.go (features.TASBalancedPlacement; preferred requests only, tas_flavor_snapshot.go:1012) ------------------------
 // A gate that is off by default: the whole of it runs on lane 0 over the slot's own scratch (TScratch::bal) — plain loops, insertion
 // sorts, a dynamic programme over a table of back-pointers. The placement's other steps (phase 1 before it, updateCountsToMinimum and the
@@ -1431,7 +1435,7 @@ KQ_NOINLINE bool t_balanced_lane0(const TK& k, const TState& s, const TParams& p
   *ncur = m;
   return true;
 }
-
+#endif  // KQ_TAS_BAL
 
 // findTopologyAssignment :886. On success the leaves of the assignment are in s.cur[0..*nfit) with their pod / leader
 // counts in s.pc / s.lc.
@@ -1447,6 +1451,7 @@ KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, 
   int fitLevelIdx = 0, ncur = 0;
   TPROF0();
   bool balanced = false;
+#ifdef KQ_TAS_BAL
   if (T.balanced && !st.required && !st.unconstrained && k.X.bal) {   // tas_flavor_snapshot.go:1012-1024
     // (lane 0 alone; its verdict travels through the head of the slot's scratch. The class table's state, if the placement started from
     // one, is no longer restorable by the log: the next workload copies it again)
@@ -1465,6 +1470,7 @@ KQ_DEV TFail t_find_assignment(const TK& k, const TState& s, const TParams& st, 
     balanced = verdict[0] != 0; fitLevelIdx = verdict[1]; ncur = verdict[2];
     wsync();
   }
+#endif
   TFail f{KQ_TAS_OK, 0, 0};
   if (!balanced) f = t_find_level(k, s, st, &fitLevelIdx, &ncur);
   TPROF(k, 0);   // findLevelWithFitDomains

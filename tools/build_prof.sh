@@ -13,4 +13,4 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-valu
 /opt/rocm/bin/hipcc $F -c -o build/kq_tas_cycle_kernel_prof.o $S/kq_tas_cycle_kernel.hip &
 /opt/rocm/bin/hipcc $F -c -o build/kq_spec_kernel_prof2.o $S/kq_spec_kernel.hip
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o kueue_amd/libkq_engine_prof.so build/kq_engine_prof.o build/kq_spec_kernel_prof2.o build/kq_tas_cycle_kernel_prof.o build/kq_rows_kernel.o build/kq_group.o -ldl -lpthread  # (the row kernels carry no timers: the ordinary object)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o kueue_amd/libkq_engine_prof.so build/kq_engine_prof.o build/kq_spec_kernel_prof2.o build/kq_tas_cycle_kernel_prof.o build/kq_rows_kernel.o build/kq_group.o build/kq_tas_cycle_kernel_bal.o build/kq_tas_bal_kernel.o -ldl -lpthread  # (the row kernels carry no timers: the ordinary object)
