@@ -710,6 +710,7 @@ struct TAW {
   // asks for exactly the placement Assign's Preempt branch (flavorassigner.go:889-897) has just computed — an empty cluster looks the
   // same to both — and takes it from there.
   int em_ps, em_t, em_count;
+  int req_valid;   // tc_requests' answer (t, nreq, req_ps) is still the current one
 };
 #define KQ_TAS_WALK(w) ((w).ta.srch != 0)
 #define KQ_TAS_PROCESS(k, w) ((k).tc != nullptr && (w).ta.plane != 0)   // (timing builds) assign_flavors inside k_process_tas's recomputation

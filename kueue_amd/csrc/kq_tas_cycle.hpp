@@ -293,7 +293,7 @@ KQ_DEV int tc_adm_flavor(const K& k, int psg, int res) {
 // a fresh Assign starts from the admission's TopologyAssignment again (flavorassigner.go:777-779)
 KQ_DEV void tc_sp_reset(const K& k, int psg) { if (k.tc->sp_del_out && lane_id() == 0) k.tc->sp_del_out[psg] = 0; }
 KQ_DEV void tc_reset(Wave& w) {
-  if (lane_id() == 0) { w.ta.t = -1; w.ta.nreq = 0; w.ta.af_early = 0; w.ta.err_mask = 0; w.ta.has_mask = 0; w.ta.kept_used = 0; w.ta.srch = 0; w.ta.em_ps = -1; }
+  if (lane_id() == 0) { w.ta.t = -1; w.ta.nreq = 0; w.ta.af_early = 0; w.ta.err_mask = 0; w.ta.has_mask = 0; w.ta.kept_used = 0; w.ta.srch = 0; w.ta.em_ps = -1; w.ta.req_valid = 0; }
 }
 // Assignment.updateMode flavorassigner.go:192-198 for podset p; the usage entries' modes (flavorResourcesNeedPreemption reads them)
 // are re-derived from the cells: an entry is as weak as the weakest (podset, resource) behind it
@@ -302,24 +302,44 @@ KQ_NOINLINE void tc_update_mode(const K& k, Wave& w, int p, int mode) {
   const size_t o = (size_t)(w.ps_base + p) * nR;
   for (int r = lane_id(); r < nR; r += WAVE) if (k.O.flavor[o + r] >= 0) k.O.res_mode[o + r] = (uint8_t)mode;
   wsync();
-  if (lane_id() == 0) {
-    w.rep_mode = mode;
+  // (lanes = the head's (podset, resource) cells, one load each, a wave minimum per usage entry: this was nuse x nps x nR dependent loads
+  // on lane 0, twice per recomputed entry of a saturated cycle)
+  const int cells = w.nps * nR;
+  if (cells <= WAVE) {
+    const int i = lane_id();
+    int fr = -1, rm = M_FIT;
+    if (i < cells) {
+      const size_t c = (size_t)w.ps_base * nR + i;
+      const int fl = k.O.flavor[c];
+      if (fl >= 0) { fr = fl * nR + (i % nR); rm = k.O.res_mode[c]; }
+    }
+    for (int u = 0; u < w.nuse; u++) {
+      const int m = (int)wmin_u64((uint64_t)(fr == w.use_fr[u] ? rm : M_FIT));
+      if (lane_id() == 0) w.use_mode[u] = (uint8_t)m;
+    }
+  } else {
     for (int u = 0; u < w.nuse; u++) {
       int m = M_FIT;
-      for (int q = 0; q < w.nps; q++)
-        for (int r = 0; r < nR; r++) {
-          const size_t c = (size_t)(w.ps_base + q) * nR + r;
-          if (k.O.flavor[c] >= 0 && k.O.flavor[c] * nR + r == w.use_fr[u] && k.O.res_mode[c] < m) m = k.O.res_mode[c];
-        }
-      w.use_mode[u] = (uint8_t)m;
+      for (int i = lane_id(); i < cells; i += WAVE) {
+        const size_t c = (size_t)w.ps_base * nR + i;
+        const int fl = k.O.flavor[c];
+        if (fl >= 0 && fl * nR + (i % nR) == w.use_fr[u] && k.O.res_mode[c] < m) m = k.O.res_mode[c];
+      }
+      m = (int)wmin_u64((uint64_t)m);
+      if (lane_id() == 0) w.use_mode[u] = (uint8_t)m;
     }
   }
+  if (lane_id() == 0) w.rep_mode = mode;
   wsync();
 }
 // tas_flavorassigner.go:37-83 WorkloadsTopologyRequests (+ onlyTASFlavor :142) on the head's current flavor assignment
 KQ_NOINLINE void tc_requests(const K& k, Wave& w) {
   const TCyc& c = *k.tc;
+  // (Assign, GetTargets and updateAssignmentForTAS each ask — three times per recomputed entry; the answer only moves with the flavor
+  // assignment (tc_reset) and with the podsets that hold a TopologyAssignment (tc_keep_result))
+  if (w.ta.req_valid) return;
   if (lane_id() == 0) {
+    w.ta.req_valid = 1;
     const int nR = k.S.nR;
     w.ta.t = -1; w.ta.nreq = 0;
     for (int p = 0; p < w.nps && p < TC_P; p++) {
@@ -562,6 +582,7 @@ KQ_NOINLINE void tc_keep_result(const K& k, Wave& w, int slot) {
     if (lane_id() == 0) {
       if (ok) { w.ta.has_mask |= 1u << p; w.ta.pos[p] = at; w.ta.n[p] = kept; w.ta.kept_used = at + kept; }
       else w.ta.has_mask &= ~(1u << p);
+      w.ta.req_valid = 0;
     }
     wsync();
   }
@@ -1190,7 +1211,7 @@ KQ_DEV void process_all_tas(const K& k, Wave& w, int slot, TLeafJob* mail, unsig
   if (lane_id() == 0) {
     w.ta.mail = mail; w.ta.lds = lds_bytes > 0 ? lds : nullptr; w.ta.lds_bytes = lds_bytes; w.ta.pf_pos = -1;
     w.ta.cur_pre = nullptr; w.ta.q_lds = 0; w.ta.pub_lds = 0; w.ta.d_lds = (lds_bytes >= (int)TX_BYTES && k.tc->d_cap <= TX_DCAP) ? 1 : 0;
-    w.ta.pool_own = 1; w.ta.pool_next = *k.tc->pool_used;
+    w.ta.pool_own = 1; w.ta.pool_next = *k.tc->pool_used; w.ta.req_valid = 0; w.ta.em_ps = -1;
     if (mail) {
       mail->pf_k = &k; mail->pf_next = -1; mail->pre[0].ready_for = -1; mail->pre[1].ready_for = -1; mail->early_pending = 0; mail->early_cls = -1;
       for (int i = 0; i < KQ_TAS_TS_TREES * 12; i++) mail->tstate[i] = 0;

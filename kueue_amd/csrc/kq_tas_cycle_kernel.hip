@@ -35,7 +35,7 @@ __global__ __launch_bounds__(64) void k_tas_cycle_classes(const TCyc* __restrict
 __global__ __launch_bounds__(64) void KQ_TC_NAME(k_nominate_tas)(const K* __restrict__ kp, int slots) {
   const K& k = *kp;
   __shared__ Wave w;
-  if (threadIdx.x == 0) { w.cs_lds = nullptr; w.cs_lds_bytes = 0; w.help_on = 0; w.ta.plane = 0; w.ta.srch = 0; w.ta.mail = nullptr; w.ta.lds = nullptr; w.ta.lds_bytes = 0; w.ta.pf_pos = -1; w.ta.q_lds = 0; w.ta.d_lds = 0; w.ta.pub_lds = 0; w.ta.pool_own = 0; w.ta.pool_next = 0; w.ta.cur_pre = nullptr; }
+  if (threadIdx.x == 0) { w.cs_lds = nullptr; w.cs_lds_bytes = 0; w.help_on = 0; w.ta.plane = 0; w.ta.srch = 0; w.ta.mail = nullptr; w.ta.lds = nullptr; w.ta.lds_bytes = 0; w.ta.pf_pos = -1; w.ta.q_lds = 0; w.ta.d_lds = 0; w.ta.pub_lds = 0; w.ta.pool_own = 0; w.ta.pool_next = 0; w.ta.cur_pre = nullptr; w.ta.req_valid = 0; w.ta.em_ps = -1; }
   __syncthreads();
   const int slot = blockIdx.x;
   for (int h = slot, n = hn(k.H); h < n; h += slots) nominate_head(k, w, h, slot);
