@@ -525,6 +525,7 @@ struct HipBackend {
   }
   const char* error() { return msg.c_str(); }
   int max_slots() { return n_cu * 16; }  // 16 one-wave workgroups per CU (4 per SIMD)
+  long long bal_dp() { return (long long)1 << 20; }   // states of a balanced placement's dynamic programme per wave slot (8 MB)
   size_t lds_budget() { return 160 * 1024 - sizeof(Wave) - 256; }  // dynamic LDS a workgroup can get next to its static Wave
   // HIP events on the engine's own stream bracket each kernel (live per-kernel duration)
   void timer_mark(int i) { chk(hipEventRecord(ev[stage][i], stream), "hipEventRecord"); }

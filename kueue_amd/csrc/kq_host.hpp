@@ -1060,7 +1060,7 @@ template <class B> struct EngineT {
       if (T.balanced) {
         int wd = 1;
         for (int l = 0; l < T.L; l++) wd = std::max(wd, T.level_off[l + 1] - T.level_off[l]);
-        X.bal_w = wd; X.bal_dp = (long long)1 << 20;
+        X.bal_w = wd; X.bal_dp = be.bal_dp();
         X.bal_stride = 10ll * T.D + 4ll * wd + 2 * X.bal_dp;
         X.bal = tgrow<int32_t>((size_t)xslots * (size_t)X.bal_stride);
       }

@@ -204,7 +204,7 @@ template <class Backend> struct TasT {
     if (T.balanced) {
       int w = 1;
       for (int l = 0; l < T.L; l++) w = std::max(w, T.level_off[l + 1] - T.level_off[l]);
-      X.bal_w = w; X.bal_dp = (long long)1 << 20;   // 1 Mi (leaders left, pods left) states per slot: a request beyond that is KQ_EUNSUPPORTED
+      X.bal_w = w; X.bal_dp = be.bal_dp();   // (leaders left, pods left) states per slot — 1 Mi on the device: a request beyond that is KQ_EUNSUPPORTED
       X.bal_stride = 10ll * T.D + 4ll * w + 2 * X.bal_dp;
       X.bal = grow<int32_t>(bx[14], (size_t)slots * (size_t)X.bal_stride);
     }

@@ -37,6 +37,7 @@ struct EmuBackend {
   const char* error() { return ""; }
   int rot = 0, nom_rot = 0, spec_rot = 0, spec_fixed = -1;
   int max_slots() { return 7; }  // small on purpose: exercises the grid-stride loop over heads
+  long long bal_dp() { return (long long)1 << 16; }   // (small: the table is allocated and poisoned per call)
   bool tas_bal = false;          // (the HIP backend picks the _bal kernels by it; the emulation is compiled with KQ_TAS_BAL throughout)
   size_t lds_budget() { return 150 * 1024; }
   int help_blocks(int) { return 1; }  // no helper runs in the emulation, but the leader runs every other task the way one would
