@@ -450,6 +450,20 @@ struct HipBackend {
   // of r05l-r05n were reported at), and sits at the END of it, 16-byte aligned — a kernel that reads or writes more than the alignment
   // slack past a buffer faults at once, on every box, instead of when the allocator happens to put the buffer last in a mapped chunk.
   // The body is poisoned like KQ_GUARD's.
+  // What a fresh buffer holds under KQ_GUARD / KQ_EFENCE: 0xA5 bytes by default; KQ_POISON=small fills it with 32-bit words in [0, 300) —
+  // what the pages of a long-lived process typically hold (counts, indices of an earlier engine) and what made k_order_scatter walk off
+  // its records in round 5: garbage that LOOKS valid. KQ_POISON=<hex byte> for any other constant.
+  void poison(void* p, size_t n) {
+    if (!n) return;
+    const char* mode = getenv("KQ_POISON");
+    if (mode && !strcmp(mode, "small")) {
+      static std::vector<uint32_t> pat;
+      if (pat.empty()) { pat.resize(1 << 18); uint32_t x = 2463534242u; for (auto& v : pat) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; v = x % 300u; } }
+      for (size_t o = 0; o < n; o += pat.size() * 4) chk(hipMemcpy((char*)p + o, pat.data(), std::min(n - o, pat.size() * 4), hipMemcpyHostToDevice), "poison fill");
+      return;
+    }
+    chk(hipMemset(p, mode ? (int)strtol(mode, nullptr, 16) : 0xA5, n), "poison fill");
+  }
   bool efence_on = getenv("KQ_EFENCE") != nullptr;
   struct FenceRec { char* base; char* user; };
   std::vector<FenceRec> fences;
@@ -460,7 +474,7 @@ struct HipBackend {
       chk(hipMalloc((void**)&p, total), "hipMalloc");
       if (!p) return nullptr;
       char* u = p + total - body;
-      if (n) chk(hipMemset(u, 0xA5, n), "poison fill");
+      poison(u, n);
       fences.push_back(FenceRec{p, u});
       return u;
     }
@@ -474,7 +488,7 @@ struct HipBackend {
     // ... and the buffer itself is POISONED (0xA5, as the emulation's allocator does): hipMalloc hands out whatever the previous owner of
     // the pages left — zeroes in a fresh process, garbage in a long-lived one — so code that only works on zero-initialised memory
     // passes every short test and faults in a controller that has been up for a day (or in the 400th test of a pytest worker)
-    if (n) chk(hipMemset(p + GW, 0xA5, n), "poison fill");
+    poison(p + GW, n);
     guards.push_back(GuardRec{p, n});
     return p + GW;
   }
