@@ -164,3 +164,32 @@ def test_every_export_has_a_go_caller_and_every_go_call_is_declared():
     unbound = {s for s in hdr - go if not s.startswith("kq_debug_") and s != "kq_abi_version"}
     assert not unbound, sorted(unbound)
     assert not (go - hdr), sorted(go - hdr)
+
+
+def test_ctypes_mirrors_have_the_layout_of_the_c_structs(tmp_path):
+    """Every struct that crosses the C ABI from Python is declared twice — in include/*.h and as a ctypes.Structure. A field appended to
+    one and not the other is read past the end by the library (round 5 added five to kq_cycle_tas): sizes and the offset of every field
+    are compared against what gcc lays out."""
+    import ctypes as C
+    import subprocess
+    from kueue_amd import _ffi as F
+    from kueue_amd import tas as T
+    from kueue_amd import tas_cycle as TC
+    mirrors = {"kq_config": F.kq_config, "kq_snapshot": F.kq_snapshot, "kq_heads": F.kq_heads, "kq_pending": F.kq_pending, "kq_afs_ledger": F.kq_afs_ledger,
+               "kq_row_patch": F.kq_row_patch, "kq_decisions": F.kq_decisions, "kq_tas_topology": T.kq_tas_topology, "kq_tas_requests": T.kq_tas_requests,
+               "kq_tas_result": T.kq_tas_result, "kq_tas_replacement": T.kq_tas_replacement, "kq_cycle_tas": TC.kq_cycle_tas, "kq_cycle_tas_out": TC.kq_cycle_tas_out}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "kq_engine.h"', '#include "kq_tas.h"', '#include "kq_cycle_tas.h"', 'int main(void) {']
+    for name, cls in mirrors.items():
+        src.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+        for fname, _ in cls._fields_:
+            src.append(f'  printf("{name}.{fname} %zu\\n", offsetof({name}, {fname}));')
+    src += ['  return 0;', '}']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(c)])
+    want = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for name, cls in mirrors.items():
+        assert C.sizeof(cls) == int(want[name]), (name, C.sizeof(cls), want[name])
+        for fname, _ in cls._fields_:
+            assert getattr(cls, fname).offset == int(want[f"{name}.{fname}"]), (name, fname)
