@@ -219,6 +219,8 @@ def parse_admission(args, sym):
                         ps["count"] = int(a2)
                     elif n2 == "TopologyAssignment":
                         ps["topologyAssignment"] = parse_topology_assignment(a2, sym)
+                    elif n2 == "DelayedTopologyRequest":
+                        ps["delayed"] = re.search(r"DelayedTopologyRequestState(\w+)", a2).group(1)
                     elif n2 == "Obj":
                         pass
                     else:
@@ -269,7 +271,7 @@ def parse_podsets(args, sym):
 
 WL_OK = {"MakeWorkload", "Queue", "Priority", "Creation", "Request", "PodSets", "ReserveQuota", "ReserveQuotaAt", "Admission", "Condition",
          "ResourceRequests", "SchedulingStatsEviction", "Obj", "UID", "JobUID", "Generation", "Clone", "AdmittedAt", "Admitted", "PastAdmittedTime",
-         "ResourceVersion", "Label", "Labels", "Finalizers", "UnhealthyNodes"}
+         "ResourceVersion", "Label", "Labels", "Finalizers", "UnhealthyNodes", "AdmissionCheck"}
 
 
 def parse_wl(text, start, sym):
@@ -295,6 +297,8 @@ def parse_wl(text, start, sym):
             w["reservedAt"] = parse_time(parts[1]) if len(parts) > 1 else NOW
         elif m == "UnhealthyNodes":
             w["unhealthyNodes"] = re.findall(r'"([^"]+)"', a)
+        elif m == "AdmissionCheck":
+            w.setdefault("checks", []).append(re.search(r"State:\s*kueue\.CheckState(\w+)", a).group(1))
         elif m in ("AdmittedAt", "Admitted"):
             w["isAdmitted"] = split_top(a)[0].strip() == "true"
         elif m == "Condition":
@@ -328,7 +332,7 @@ def parse_keymap(text):
     return out
 
 
-BAD = r"AdmissionCheck|Toleration|NodeSelector|Taint|PreemptionGate|WorkloadSlice|Annotation|DelayedTopologyRequest|PodSetGroup|" \
+BAD = r"Toleration|NodeSelector|Taint|PreemptionGate|WorkloadSlice|Annotation|PodSetGroup|" \
       r"resourceTransformations|patchStatusErr|RequiredDuringScheduling|PreferredDuringScheduling|PodSetUpdate|StopPolicy|" \
       r"MinimumCount|SetMinimumCount"
 
@@ -360,6 +364,9 @@ def extract(src, func, cases, skipped):
             scan = re.sub(r"(?m)^\t{3}admissionChecks:\s*\[\]kueue\.AdmissionCheck\{[^}]*\},?\n", "", block)
             if re.search(BAD, scan):
                 raise Skip("outside the boundary (" + re.search(BAD, scan).group(0) + ")")
+            # AdmissionChecks on a ClusterQueue (ProvisioningRequest: the topology request of a FIRST pass is delayed, tas_flavorassigner.go:105)
+            # are the caller's: a case that has them is inside the boundary when every workload of it is on its second pass (decided below)
+            with_checks = re.search(r"AdmissionCheck|DelayedTopologyRequest", scan) is not None
             gates = {}
             fg = field(block, "featureGates")
             if fg:
@@ -428,7 +435,24 @@ def extract(src, func, cases, skipped):
                                                      for ps in w["podsets"]]})
                     elif un:
                         raise Skip("unhealthy nodes without a second pass")
+                    # ... or for a delayed topology request (needsSecondPassForDelayedAssignment workload.go:981): every admission check
+                    # Ready, a PodSetAssignment with DelayedTopologyRequest Pending and no TopologyAssignment, not admitted yet
+                    elif w.get("checks") and all(c == "Ready" for c in w["checks"]) and not w.get("isAdmitted") and \
+                            any(ps.get("delayed") == "Pending" and "topologyAssignment" not in ps for ps in w["admission"]):
+                        by = {ps["name"]: ps for ps in w["admission"]}
+                        if [ps["name"] for ps in w["podsets"]] != [ps["name"] for ps in w["admission"]]:
+                            raise Skip("admission podsets not aligned with the spec")
+                        sp_podsets = [{"name": ps["name"], "count": by[ps["name"]]["count"], "totalRequests": by[ps["name"]]["usage"],
+                                       "podRequests": ps["requests"], **({"topologyRequest": ps["topologyRequest"]} if "topologyRequest" in ps else {})}
+                                      for ps in w["podsets"]]
+                        second.append({"name": key, "cq": w["cq"], "priority": w["priority"], "created": w["created"], "podsets": sp_podsets,
+                                       "hasQuotaReservation": True, "isAdmitted": False,
+                                       "admission": [{"flavors": by[ps["name"]]["flavors"], "count": by[ps["name"]]["count"]} for ps in w["podsets"]]})
+                    elif with_checks:
+                        raise Skip("outside the boundary (AdmissionCheck)")
                 else:
+                    if with_checks:
+                        raise Skip("outside the boundary (AdmissionCheck)")   # a first pass in a case with admission checks: the caller's (delayed topology request)
                     cq = lqs.get((w["ns"], w.get("queue", "")))
                     if cq is None or cq not in cq_names:
                         raise Skip("pending workload in a missing LocalQueue/ClusterQueue")
@@ -439,6 +463,10 @@ def extract(src, func, cases, skipped):
                 if len(q) > 1 and (-q[0]["priority"], q[0]["created"]) == (-q[1]["priority"], q[1]["created"]):
                     raise Skip("head order decided by UID / name tie-break")
                 heads.append(q[0]); rest += q[1:]
+            tas_flavor_names = {f["name"] for f in flavors if f.get("topologyName")}
+            for h_ in second:   # (kq_cycle_tas.h: a workload whose podsets hold TAS flavors of their own is KQ_EUNSUPPORTED — TASHandleOverlappingFlavors)
+                if len({fl for ps in h_["admission"] for fl in ps["flavors"].values() if fl in tas_flavor_names}) > 1:
+                    raise Skip("a workload on two TAS flavors")
             heads = second + heads   # "second-pass heads first" (manager.go:923)
             want_adm = {}
             wa = field(block, "wantNewAssignments")

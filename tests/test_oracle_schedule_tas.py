@@ -23,7 +23,7 @@ def check_case(oracle, case):
     for i, w in enumerate(heads.workloads):
         exp = case["expect"][w.name]
         act = int(d.a["action"][i])
-        if w.has_unhealthy_nodes:
+        if w.has_unhealthy_nodes or w.has_quota_reservation:   # (a second pass: after a node failure, or for a delayed topology request — ProvisioningRequest)
             # the second pass after a node failure: wantNewAssignments is what the cache holds afterwards — the replaced assignment, or
             # the admission as it was when no replacement was found (then wantEvents tells which way it went: SecondPassFailed = the entry
             # stays pending with its reservation, EvictedDueToNodeFailures = TASFailedNodeReplacementFailFast evicted it)
