@@ -18,6 +18,8 @@ import sys
 
 import yaml
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # (kueue_amd.api: quantity parsing)
+
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from extract_assign_flavors import match_brace, parse_cq, res_name  # noqa: E402
 from extract_preemption import NOW, chain, parse_cohort, parse_time, split_top  # noqa: E402
@@ -232,7 +234,7 @@ def parse_admission(args, sym):
 
 
 PS_OK = {"MakePodSet", "Request", "Obj", "Image", "RequiredTopologyRequest", "PreferredTopologyRequest", "UnconstrainedTopologyRequest",
-         "SliceRequiredTopologyRequest", "SliceSizeTopologyRequest", "SliceRequiredTopologyConstraints", "Limit"}
+         "SliceRequiredTopologyRequest", "SliceSizeTopologyRequest", "SliceRequiredTopologyConstraints", "Limit", "SetMinimumCount"}
 
 
 def parse_podsets(args, sym):
@@ -250,6 +252,8 @@ def parse_podsets(args, sym):
             if m == "Request":
                 r, q = split_top(a)
                 ps["requests"][res_name(r) if not r.strip().startswith('"') else r.strip().strip('"')] = q.strip().strip('"')
+            elif m == "SetMinimumCount":
+                ps["minCount"] = int(a)   # partial admission (PodSet.MinCount)
             elif m == "RequiredTopologyRequest":
                 tr["required"] = label(a, sym)
             elif m == "PreferredTopologyRequest":
@@ -334,7 +338,7 @@ def parse_keymap(text):
 
 BAD = r"Toleration|NodeSelector|Taint|PreemptionGate|WorkloadSlice|Annotation|PodSetGroup|" \
       r"resourceTransformations|patchStatusErr|RequiredDuringScheduling|PreferredDuringScheduling|PodSetUpdate|StopPolicy|" \
-      r"MinimumCount|SetMinimumCount"
+      r"NOTHING_ELSE_HERE"
 
 
 def lqs_of(body):
@@ -410,6 +414,13 @@ def extract(src, func, cases, skipped):
                     spec = {ps["name"]: ps for ps in w["podsets"]}
                     for ps in w["admission"]:
                         e = {"count": ps["count"], "totalRequests": ps["usage"], "flavors": ps["flavors"]}
+                        # totalRequestsFromAdmission workload.go:758-766: a spec count below the admission's (reclaimable pods) scales the
+                        # quota usage down (Requests.Divide / Mul: integers in the resource's unit); the TopologyAssignment keeps its counts
+                        if ps["name"] in spec and spec[ps["name"]]["count"] < ps["count"]:
+                            from kueue_amd.api import amount_from_quantity
+                            c0, c1 = ps["count"], spec[ps["name"]]["count"]
+                            e["totalRequests"] = {r: (lambda v: f"{v}m" if r == "cpu" else str(v))(amount_from_quantity(r, q) // c0 * c1) for r, q in ps["usage"].items()}
+                            e["count"] = c1
                         if "topologyAssignment" in ps:
                             e["topologyAssignment"] = ps["topologyAssignment"]
                             e["podRequests"] = spec[ps["name"]]["requests"] if ps["name"] in spec else {}
