@@ -214,11 +214,16 @@ def int_expr(v):
 
 def parse_podset(body, named_levels):
     f = top_level_fields(body)
-    for bad in ("tolerations", "nodeSelector", "nodeAffinity", "previousAssignment"):
+    for bad in ("tolerations", "nodeAffinity", "previousAssignment"):
         if bad in f:
             raise Skip(bad)
     ps = dict(name=ident(f["podSetName"]) if "podSetName" in f else "", count=int(f.get("count", "0")))
     ps["requests"] = {}
+    if "nodeSelector" in f and f["nodeSelector"] != "nil":
+        # PodSpec.NodeSelector: the placement only counts the leaves (hostname level) whose node carries every label (the host's feasibility
+        # mask, kq_tas_requests.leaf_ok; tas_flavor_snapshot.go:963 with isLowestLevelNode)
+        ns = f["nodeSelector"]
+        ps["nodeSelector"] = {ident(k): ident(v) for k, v in top_level_fields_generic(ns[ns.index("{") + 1:ns.rindex("}")])}
     if "requests" in f:
         inner = f["requests"][f["requests"].index("{") + 1:f["requests"].rindex("}")]
         for k, v in top_level_fields_generic(inner):
