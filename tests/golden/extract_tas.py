@@ -154,6 +154,11 @@ def parse_nodes(text):
                 cf = top_level_fields(args[args.index("{") + 1:args.rindex("}")])
                 if cf.get("Type", "").strip() == "corev1.NodeReady":      # any other condition leaves readiness alone
                     node["ready"] = cf.get("Status", "").strip() == "corev1.ConditionTrue"
+            elif meth == "Taints":
+                for t in elements(args):
+                    tf = top_level_fields(t[t.index("{") + 1:t.rindex("}")])
+                    node.setdefault("taints", []).append(dict(key=ident(tf.get("Key", '""')), value=ident(tf.get("Value", '""')),
+                                                              effect=tf.get("Effect", "").strip().replace("corev1.TaintEffect", "")))
             elif meth == "Obj":
                 pass
             else:
@@ -214,7 +219,7 @@ def int_expr(v):
 
 def parse_podset(body, named_levels):
     f = top_level_fields(body)
-    for bad in ("tolerations", "nodeAffinity", "previousAssignment"):
+    for bad in ("nodeAffinity", "previousAssignment"):
         if bad in f:
             raise Skip(bad)
     ps = dict(name=ident(f["podSetName"]) if "podSetName" in f else "", count=int(f.get("count", "0")))
@@ -224,6 +229,14 @@ def parse_podset(body, named_levels):
         # mask, kq_tas_requests.leaf_ok; tas_flavor_snapshot.go:963 with isLowestLevelNode)
         ns = f["nodeSelector"]
         ps["nodeSelector"] = {ident(k): ident(v) for k, v in top_level_fields_generic(ns[ns.index("{") + 1:ns.rindex("}")])}
+    if "tolerations" in f and f["tolerations"] != "nil":
+        tl = f["tolerations"]
+        ps["tolerations"] = []
+        for t in elements(tl[tl.index("{") + 1:tl.rindex("}")]):
+            tf = top_level_fields(t[t.index("{") + 1:t.rindex("}")])
+            ps["tolerations"].append(dict(key=ident(tf.get("Key", '""')), value=ident(tf.get("Value", '""')),
+                                          operator=tf.get("Operator", "corev1.TolerationOpEqual").strip().replace("corev1.TolerationOp", ""),
+                                          effect=tf.get("Effect", "").strip().replace("corev1.TaintEffect", "")))
     if "requests" in f:
         inner = f["requests"][f["requests"].index("{") + 1:f["requests"].rindex("}")]
         for k, v in top_level_fields_generic(inner):
