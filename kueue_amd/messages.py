@@ -91,7 +91,16 @@ def amount_string(resource: str, a: int, binary_resources=()) -> str:
     return quantity_string(resource, a, binary_resources)
 
 
-def tas_failure_text(topology_name: str, status: int, a: int, b: int, slice_size: int = 1) -> str:
+def second_pass_names(adm, podset: int, a: int):
+    """(stale_domain, unhealthy_node) for tas_failure_text from a head's Status (kueue_amd/tas_cycle.py HeadAdmission): operand a of a
+    KQ_TAS_STALE record indexes the podset's TopologyAssignment AFTER deleteDomain dropped the unhealthy node's domain
+    (tas_flavor_snapshot.go:693, :828-840); IsTopologyAssignmentStale reports domain.Values[0] (:821)."""
+    node = adm.unhealthy_nodes[0] if adm.unhealthy_nodes else ""
+    doms = [v for v, _ in (adm.domains[podset] or []) if v[-1] != node]
+    return (doms[a][0] if 0 <= a < len(doms) else ""), node
+
+
+def tas_failure_text(topology_name: str, status: int, a: int, b: int, slice_size: int = 1, stale_domain: str = "", unhealthy_node: str = "") -> str:
     """TASAssignmentsResult.Failure().Reason from the operands of a KQ_RSN_TAS_FAILURE record: notFitMessage
     (tas_flavor_snapshot.go:1997) and the fixed strings of findTopologyAssignment (:886-947). The node-exclusion statistics the
     reference appends to the "doesn't allow to fit any" form ("Total nodes: N; excluded: ...") are not carried by the operands."""
@@ -103,6 +112,13 @@ def tas_failure_text(topology_name: str, status: int, a: int, b: int, slice_size
         return f'topology "{topology_name}" allows to fit only {a} out of {b} {unit}(s)'
     if status == T.TAS_NOT_FIT_LAYERS:
         return f'topology "{topology_name}" doesn\'t allow to fit'
+    # the second pass of kq_cycle_run_tas (findReplacementAssignment tas_flavor_snapshot.go:694-696, :727): the caller knows the names — operand
+    # a of KQ_TAS_STALE is the index of the stale domain in the admission's TopologyAssignment after deleteDomain (its first level value is
+    # what the reference prints), the unhealthy node is Status.UnhealthyNodes[0].Name
+    if status == T.TAS_STALE:
+        return f"Cannot replace the node, because the existing topologyAssignment is invalid, as it contains the stale domain {stale_domain or f'#{a}'}"
+    if status == T.TAS_NO_REPLACEMENT:
+        return f"cannot find replacement assignment for unhealthy node: {unhealthy_node}"
     return {T.TAS_NO_LEVEL: "no requested topology level", T.TAS_SLICE_ABOVE: "podset slice topology is above the podset topology",
             T.TAS_BAD_SLICE_SIZE: "slice topology requested, but slice size not provided"}.get(status, f"topology-aware placement failed (status {status})")
 

@@ -208,6 +208,7 @@ class CycleTAS:
                  ps_group=group, ps_req=req.reshape(-1).copy())
         if (nlay > 1).any():
             a.update(ps_n_layers=nlay, ps_layer_level=llev.reshape(-1).copy(), ps_layer_size=lsz.reshape(-1).copy())
+        self.head_admission: Dict[str, HeadAdmission] = dict(head_admission or {})   # by workload name: the message text needs its names
         if head_admission:
             # the second pass: Status.Admission of the heads that hold one (include/kq_cycle_tas.h ps_adm_flavor / ps_ex_*)
             nR = snap.n_resource

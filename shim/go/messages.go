@@ -100,6 +100,19 @@ func TASFailureText(topology string, status int, a, b int32, sliceSize int32) st
 	return fmt.Sprintf("topology %q doesn't allow to fit", topology)
 }
 
+// TASReplacementFailureText words the two failures only the second pass after a node failure produces (findReplacementAssignment
+// tas_flavor_snapshot.go:694-696, :727; KQ_TAS_STALE = 9 with operand a = index of the stale domain in the admission's TopologyAssignment after
+// deleteDomain, KQ_TAS_NO_REPLACEMENT = 10): the caller resolves the names from wl.Status. ok = false: not one of the two.
+func TASReplacementFailureText(status int, staleDomainFirstValue, unhealthyNode string) (string, bool) {
+	switch status {
+	case 9:
+		return fmt.Sprintf("Cannot replace the node, because the existing topologyAssignment is invalid, as it contains the stale domain %v", staleDomainFirstValue), true
+	case 10:
+		return fmt.Sprintf("cannot find replacement assignment for unhealthy node: %v", unhealthyNode), true
+	}
+	return "", false
+}
+
 // RsnTruncated = KQ_RSN_TRUNCATED (kq_engine.h): the head's reason window overflowed, its record list is incomplete.
 const RsnTruncated = 255
 

@@ -359,6 +359,39 @@ def test_tas_failure_message_of_the_reference(oracle):
     assert msg == 'couldn\'t assign flavors to pod set one: topology "tas-single-level" allows to fit only 1 out of 2 pod(s)'
 
 
+def test_second_pass_failure_messages():
+    """findReplacementAssignment's own two failures (tas_flavor_snapshot.go:695, :728) from the operands of the cycle's record: the names come
+    from the head's Status, which the caller holds (messages.second_pass_names)."""
+    from kueue_amd import messages as M
+    from kueue_amd import tas as T
+    from kueue_amd.tas_cycle import HeadAdmission
+    adm = HeadAdmission(flavors=[{"cpu": "tas"}], domains=[[(("b1", "r1", "x0"), 1), (("b1", "r1", "x1"), 2), (("b2", "r9", "gone"), 1)]], unhealthy_nodes=["x0"])
+    stale, node = M.second_pass_names(adm, 0, 1)
+    assert (stale, node) == ("b2", "x0")
+    assert M.tas_failure_text("t", T.TAS_STALE, 1, 0, stale_domain=stale, unhealthy_node=node) == \
+        "Cannot replace the node, because the existing topologyAssignment is invalid, as it contains the stale domain b2"
+    assert M.tas_failure_text("t", T.TAS_NO_REPLACEMENT, 0, 0, stale_domain=stale, unhealthy_node=node) == "cannot find replacement assignment for unhealthy node: x0"
+    # and on a cycle: the random campaign's seed 1 holds a head whose kept domains name a node the snapshot no longer has
+    cfg, snap, heads, ct, *_ = random_second_pass_case(1)
+    eng = _emu(cfg)
+    eng.put(snap)
+    d, _ = eng.run_tas(heads, ct, rsn_cap=4096, tgt_cap=max(16, snap.n_adm))
+    eng.close()
+    assert d.rc == 0
+    seen = 0
+    for h in range(heads.n):
+        for k in range(int(d.a["rsn_off"][h]), int(d.a["rsn_off"][h + 1])):
+            if int(d.a["rsn_code"][k]) == M.RSN_TAS_FAILURE and int(d.a["rsn_a"][k]) == T.TAS_STALE:
+                ps = int(d.a["rsn_podset"][k]) - int(heads.arrays["ps_off"][h])
+                adm = ct.head_admission[heads.workloads[h].name]
+                stale, node = M.second_pass_names(adm, ps, int(d.a["rsn_b"][k]))
+                kept = [v for v, _ in adm.domains[ps] if v[-1] != node]
+                assert stale and stale == kept[int(d.a["rsn_b"][k])][0]
+                assert M.tas_failure_text("t", T.TAS_STALE, int(d.a["rsn_b"][k]), 0, stale_domain=stale).endswith("the stale domain " + stale)
+                seen += 1
+    assert seen
+
+
 def test_tas_request_without_any_tas_flavor(oracle):
     """Found by the random campaign (seed 1607): a snapshot without TAS flavors but a podset that asks for TAS — WorkloadsTopologyRequests
     still runs and turns the assignment into NoFit (ErrNoTASFlavorAssigned, tas_flavorassigner.go:60-66); the entry point must not take
