@@ -456,7 +456,14 @@ struct Head {
 struct FlavorAssignment { int flavor = -1; int mode = NoFit; int tried = 0; int borrow = 0; };
 // one Status.reasons string as its operands (KQ_RSN_*, include/kq_engine.h): Status.appendf flavorassigner.go:349
 struct Reason { int code, flavor, resource; int64_t a, b, c; };
+// FlavorAssignmentAttempt (flavor_assigner_attempts.go:35-42) as far as Assignment.NoFitReason needs it: the flavor, the worst mode over the
+// resources it was tried for, and its NoFitReason as the severity rank of reasonSeverity (flavorassigner.go:306-327): 0 "", 1
+// TopologyPlacementFailed, 2 WaitingForQuota, 3 ExceedsMaxQuota, 4 NoMatchingFlavor — mostSevereReason is then max(). Collected only when
+// FlavorAssigner.observe is set (the UnadmittedWorkloadsObservability gate): kqo_assign_attempts, the checker of TestIsNoFitDueToCapacityAndLimits.
+enum { lblNone = 0, lblTopologyPlacementFailed = 1, lblWaitingForQuota = 2, lblExceedsMaxQuota = 3, lblNoMatchingFlavor = 4 };
+struct Attempt { int flavor; int mode; int label; };
 struct PodSetAssignment {
+  std::vector<Attempt> attempts;             // FlavorAssignmentAttempts (sorted by flavor name in the reference; an unordered set here)
   std::map<int, FlavorAssignment> flavors;  // resource -> assignment (ResourceAssignment)
   int nreasons = 0;                          // len(Status.reasons)
   std::vector<Reason> reasons;               // Status.reasons, in append order
@@ -481,6 +488,7 @@ struct PodSetAssignment {
 struct TasDomainUse { int tas, leaf; int32_t count; int ps; };  // workload.TopologyDomainRequests; SinglePodRequests = the podset's
 struct Assignment {
   std::vector<PodSetAssignment> PodSets;
+  int noFitLabel = lblNone;  // Assignment.NoFitReason (flavorassigner.go:82), set by resolveNoFitReason when observe is on
   int Borrowing = 0;
   FRQ Usage;  // Usage.Quota.Assigned
   std::vector<TasDomainUse> UsageTAS;  // Usage.TAS
@@ -713,6 +721,7 @@ struct FlavorAssigner {
   int cq;
   bool enableFairSharing;
   OracleFn oracle;
+  bool observe = false;  // features.UnadmittedWorkloadsObservability: keep the attempts and their NoFitReason
 
   bool flavorOk(int psGlobal, int flavor) const {
     int nw = (sn.nF + 63) / 64;
@@ -732,7 +741,7 @@ struct FlavorAssigner {
     return idx + 1;
   }
   // flavorassigner.go:1334-1384 ; returns (preemptionMode, borrow, hasStatus)
-  struct FitRes { int pm; int borrow; bool status; Reason why; };
+  struct FitRes { int pm; int borrow; bool status; Reason why; int label = lblNone; };  // label: Status.noFitReason (:1342-1343, :1361, :1378-1380)
   FitRes fitsResourceQuota(int fr, Amount assumedUsage, int64_t requestUsage) {
     sn.st.cells++;
     sn.st.cell_bytes += 40 * (sn.depth[cq] + 1);
@@ -740,19 +749,19 @@ struct FlavorAssigner {
     Amount maxCapacity = sn.PotentialAvailable(cq, fr);
     Amount val = assumedUsage.AddInt64(requestUsage);
     const int fl = fr / sn.nR, rs = fr % sn.nR;
-    if (val.Cmp(maxCapacity) > 0) return {pmNoFit, 0, true, {KQ_RSN_EXCEEDS_MAX_CAPACITY, fl, rs, assumedUsage.v, requestUsage, maxCapacity.v}};  // :1353
+    if (val.Cmp(maxCapacity) > 0) return {pmNoFit, 0, true, {KQ_RSN_EXCEEDS_MAX_CAPACITY, fl, rs, assumedUsage.v, requestUsage, maxCapacity.v}, lblExceedsMaxQuota};  // :1353
     auto hb = sn.FindHeightOfLowestSubtreeThatFits(cq, fr, val);
     int borrow = hb.first;
     bool mayReclaimInHierarchy = hb.second;
-    if (val.Cmp(available) <= 0) return {pmFit, borrow, false, {}};
+    if (val.Cmp(available) <= 0) return {pmFit, borrow, false, {}, lblNone};
     const Reason more = {KQ_RSN_INSUFFICIENT_UNUSED, fl, rs, val.Sub(available).v, 0, 0};  // :1372
     if (sn.Nominal(cq, fr).Cmp(val) >= 0 || mayReclaimInHierarchy || canPreemptWhileBorrowing()) {
       auto r = oracle(cq, wl, fr, val);
       int mode;
       switch (r.first) { case ppNoCandidates: mode = pmNoCandidates; break; case ppPreempt: mode = pmPreempt; break; default: mode = pmReclaim; }
-      return {mode, r.second, true, more};
+      return {mode, r.second, true, more, mode != pmNoFit ? lblNone : lblWaitingForQuota};
     }
-    return {pmNoFit, borrow, true, more};
+    return {pmNoFit, borrow, true, more, lblWaitingForQuota};
   }
   // flavorassigner.go:1408-1414 / :1422-1430
   bool shouldRespectNominationMapping() const {
@@ -764,9 +773,10 @@ struct FlavorAssigner {
   // returns assignments (empty => nil), nreasons; *statusNil true when Go returns a nil status
   std::map<int, FlavorAssignment> findFlavorForPodSets(int psi, const std::vector<std::pair<int, int64_t>>& requests,
                                                        int resName, const FRQ& assignmentUsage, int* nreasons, bool* statusNil,
-                                                       std::vector<Reason>* why) {
+                                                       std::vector<Reason>* why, std::vector<Attempt>* considered = nullptr) {
     *nreasons = 0; *statusNil = false;
     why->clear();
+    if (considered) considered->clear();
     int g = sn.RGByResource(cq, resName);
     if (g < 0) { *nreasons = 1; why->push_back({KQ_RSN_RESOURCE_UNAVAILABLE, -1, resName, 0, 0, 0}); return {}; }
     std::vector<std::pair<int, int64_t>> filtered;  // filterRequestedResources :1391
@@ -787,7 +797,12 @@ struct FlavorAssigner {
         bool keep = it != wl.nomination[psi].end() && it->second == fName;
         if (!keep) { (*nreasons)++; why->push_back({KQ_RSN_NOT_IN_NOMINATION, fName, resName, 0, 0, 0}); continue; }
       }
-      if (!flavorOk(wl.ps_base + psi, fName)) { (*nreasons)++; why->push_back({KQ_RSN_FLAVOR_INELIGIBLE, fName, -1, 0, 0, 0}); continue; }  // checkFlavorForPodSets :1212 (host-evaluated)
+      if (!flavorOk(wl.ps_base + psi, fName)) {  // checkFlavorForPodSets :1212 (host-evaluated)
+        (*nreasons)++; why->push_back({KQ_RSN_FLAVOR_INELIGIBLE, fName, -1, 0, 0, 0});
+        if (considered) considered->push_back({fName, NoFit, lblNoMatchingFlavor});  // :1106-1108 AddNoFitFlavorAttempt
+        continue;
+      }
+      int flavorNoFitReason = lblNone;
       std::map<int, FlavorAssignment> assignments;
       GranularMode representativeMode = {pmFit, 0};
       for (auto& rq : filtered) {
@@ -799,19 +814,21 @@ struct FlavorAssigner {
           if (originalFlavor != fName) {
             representativeMode = {pmNoFit, MAXINT};  // worstGranularMode(); the `break` only leaves the psIDs loop: fitsResourceQuota still runs
             (*nreasons)++; why->push_back({KQ_RSN_SLICE_FLAVOR_MISMATCH, fName, rq.first, originalFlavor, 0, 0});
+            flavorNoFitReason = std::max(flavorNoFitReason, (int)lblNoMatchingFlavor);  // :1136
           } else val -= it->second.second;
         }
         const bool discarded = representativeMode.pm == pmNoFit;
         const int64_t vb0 = sn.st.victim_bytes + sn.st.drs_bytes;
         FitRes r = fitsResourceQuota(fr, frq_get(assignmentUsage, fr), val);
         if (discarded) sn.st.discarded_bytes += sn.st.victim_bytes + sn.st.drs_bytes - vb0;
-        if (r.status) { (*nreasons)++; why->push_back(r.why); }
+        if (r.status) { (*nreasons)++; why->push_back(r.why); flavorNoFitReason = std::max(flavorNoFitReason, r.label); }  // :1155
         GranularMode mode = {r.pm, r.borrow};
         if (isPreferred(representativeMode, mode, pol)) representativeMode = mode;
         if (representativeMode.pm == pmNoFit) continue;  // closure "return" :1161
         FlavorAssignment fa; fa.flavor = fName; fa.mode = flavorAssignmentMode(r.pm); fa.borrow = r.borrow;
         assignments[rq.first] = fa;
       }
+      if (considered) considered->push_back({fName, flavorAssignmentMode(representativeMode.pm), flavorNoFitReason});  // :1174
       if (sn.gate(KQ_GATE_FLAVOR_FUNGIBILITY)) {
         if (!shouldTryNextFlavor(representativeMode, pol)) {
           bestAssignment = assignments; haveBest = true; bestMode = representativeMode;
@@ -893,7 +910,9 @@ struct FlavorAssigner {
         if (groupFlavors.count(resName)) continue;  // :819
         int nre; bool statusNil;
         std::vector<Reason> why;
-        auto flavors = findFlavorForPodSets(i, podSet.req, resName, a.Usage, &nre, &statusNil, &why);
+        std::vector<Attempt> considered;
+        auto flavors = findFlavorForPodSets(i, podSet.req, resName, a.Usage, &nre, &statusNil, &why, observe ? &considered : nullptr);
+        if (observe) mergeFlavorAttemptsForResource(psa.attempts, considered, resName);
         if (flavors.empty() && !podSet.req.empty()) {  // :826
           groupFlavors.clear(); groupNil = true; groupReasons = nre;
           psa.reasons = why;  // psAssignment.Status = status (:829)
@@ -927,11 +946,53 @@ struct FlavorAssigner {
       bool failed = !podSet.req.empty() && psa.flavors.empty();
       a.PodSets.push_back(psa);
       a.rep = -1;
-      if (failed) return a;  // atLeastOnePodsAssignmentFailed :848-853
+      if (failed) { resolveNoFitReason(a); return a; }  // atLeastOnePodsAssignmentFailed :848-853
     }
-    if (a.RepresentativeMode() == NoFit) return a;  // :857-862
+    if (a.RepresentativeMode() == NoFit) { resolveNoFitReason(a); return a; }  // :857-862
     if (sn.T) assignTAS(a);
+    resolveNoFitReason(a);  // :904-906
     return a;
+  }
+
+  // flavor_assigner_attempts.go:88-122 + mergeFlavorAttempts :124-166 (mode, NoFitReason only)
+  void mergeFlavorAttemptsForResource(std::vector<Attempt>& dst, const std::vector<Attempt>& src, int resName) {
+    for (const Attempt& at : src) {
+      bool found = false;
+      for (Attempt& e : dst) if (e.flavor == at.flavor) { e.mode = std::min(e.mode, at.mode); e.label = std::max(e.label, at.label); found = true; break; }
+      if (!found) dst.push_back(at);
+    }
+    if (src.empty()) return;
+    const int g = sn.RGByResource(cq, resName);
+    for (Attempt& e : dst) {
+      bool inRG = false, present = false;
+      for (int k = sn.s->rg_flavor_off[g]; k < sn.s->rg_flavor_off[g + 1]; k++) inRG |= sn.s->rg_flavor[k] == e.flavor;
+      for (const Attempt& at : src) present |= at.flavor == e.flavor;
+      if (inRG && !present) { e.mode = NoFit; e.label = lblNoMatchingFlavor; }  // "flavor %s does not provide resource %s"
+    }
+  }
+  // flavorassigner.go:947-994
+  void resolveNoFitReason(Assignment& a) {
+    if (!observe || a.RepresentativeMode() != NoFit) return;
+    int overall = lblNone;
+    for (PodSetAssignment& ps : a.PodSets) {
+      if (ps.RepresentativeMode() != NoFit) continue;
+      if (ps.attempts.empty()) { overall = std::max(overall, (int)lblNoMatchingFlavor); continue; }
+      std::map<int, int> rgMinReason;  // resource group -> the least severe blocker among its (alternative) flavors
+      for (const Attempt& att : ps.attempts) {
+        if (att.mode != NoFit) continue;
+        // findRGIndicesByFlavor: every resource group of the ClusterQueue that lists the flavor (a flavor of an attempt is always listed)
+        for (int g = sn.s->cq_rg_off[cq]; g < sn.s->cq_rg_off[cq + 1]; g++)
+          for (int k = sn.s->rg_flavor_off[g]; k < sn.s->rg_flavor_off[g + 1]; k++)
+            if (sn.s->rg_flavor[k] == att.flavor) {
+              auto it = rgMinReason.find(g);
+              if (it == rgMinReason.end() || att.label < it->second) rgMinReason[g] = att.label;
+            }
+      }
+      int podSetReason = lblNone;
+      for (auto& kv : rgMinReason) podSetReason = std::max(podSetReason, kv.second);  // across groups: co-requisites
+      overall = std::max(overall, podSetReason);
+    }
+    a.noFitLabel = overall;
   }
 
   // flavorassigner.go:864-903
@@ -952,7 +1013,12 @@ struct FlavorAssigner {
     if (assignment.RepresentativeMode() == Preempt && !(wl.flags & KQ_HEAD_HAS_UNHEALTHY_NODES)) {  // :879 "Don't preempt other workloads if looking for a failed node replacement"
       TasResult result = FindTopologyAssignmentsForWorkload(sn, wl, assignment, tasRequests, true, &sn.tasUnsupported);
       TasFailure failure = result.Failure();
-      if (failure.failed) updateModePS(assignment, failure.ps, NoFit);
+      if (failure.failed) {
+        if (observe)  // markFlavorAttempt :413-421
+          for (Attempt& at : assignment.PodSets[failure.ps].attempts)
+            if (at.flavor == sn.T->tas_flavor[failure.tas]) { at.mode = NoFit; at.label = lblTopologyPlacementFailed; break; }
+        updateModePS(assignment, failure.ps, NoFit);
+      }
       else for (auto& kv : tasRequests) for (int ps : kv.second) updateModePS(assignment, ps, Preempt);  // updateModeForTASRequests :200
     }
   }
@@ -2085,6 +2151,40 @@ int kqo_assign(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, in
     *rsn_n = n;
   }
   return KQ_OK;
+}
+
+// Assign with features.UnadmittedWorkloadsObservability on: the FlavorAssignmentAttempts of every podset — (podset, flavor, mode, label), label
+// = the severity rank of the attempt's NoFitReason (lbl* above) — and Assignment.NoFitReason, as TestIsNoFitDueToCapacityAndLimits reads them
+// (flavorassigner_test.go:5772-5793). t may be NULL (no TAS flavors); stub as in kqo_assign.
+int kqo_assign_attempts(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, const kq_cycle_tas* t, int hi,
+                        int n_stub, const int32_t* stub_fr, const int32_t* stub_poss, const int32_t* stub_borrow,
+                        int32_t att_cap, int32_t* att_n, int32_t* att_rec /* [att_cap][4] */, int32_t* no_fit_label, int32_t* rep_mode) {
+  Snap sn(*cfg, s);
+  if (t) sn.attachTAS(t);
+  Scheduler sch(sn, h);
+  Head wl = sch.loadHead(hi);
+  OracleFn orc;
+  if (n_stub >= 0) {
+    orc = [=](int, const Head&, int fr, Amount) -> std::pair<int, int> {
+      for (int k = 0; k < n_stub; k++) if (stub_fr[k] == fr) return {stub_poss[k], stub_borrow[k]};
+      return {ppPreempt, 0};
+    };
+  } else {
+    orc = sch.makeOracle();
+  }
+  FlavorAssigner fa{sn, h, wl, wl.cq, cfg->fair_sharing != 0, orc};
+  fa.observe = true;
+  Assignment a = fa.assignFlavors(nullptr);
+  int n = 0;
+  for (size_t p = 0; p < a.PodSets.size(); p++)
+    for (const Attempt& at : a.PodSets[p].attempts) {
+      if (n < att_cap) { att_rec[4 * n] = (int)p; att_rec[4 * n + 1] = at.flavor; att_rec[4 * n + 2] = at.mode; att_rec[4 * n + 3] = at.label; }
+      n++;
+    }
+  *att_n = n;
+  *no_fit_label = a.noFitLabel;
+  *rep_mode = a.RepresentativeMode();
+  return sn.tasUnsupported ? KQ_EUNSUPPORTED : KQ_OK;
 }
 
 // Preemptor.GetTargets for head `hi` given an explicit assignment (flavor + mode per (podset,resource)),

@@ -77,6 +77,34 @@ def nominate_run(cfg: F.kq_config, snap: Snapshot, heads: Heads, tgt_cap=None):
     return d
 
 
+NO_FIT_LABELS = ["", "TopologyPlacementFailed", "WaitingForQuota", "ExceedsMaxQuota", "NoMatchingFlavor"]   # reasonSeverity flavorassigner.go:306-327
+
+
+def assign_attempts(cfg, snap: Snapshot, heads: Heads, hi: int = 0, stub=None, tas=None):
+    """Assign with UnadmittedWorkloadsObservability on -> (Assignment.NoFitReason, representative mode, [per podset {flavor: (mode, NoFitReason)}]).
+    tas: a kueue_amd.tas_cycle.CycleTAS (or None: no TAS flavors)."""
+    P = int(heads.arrays["ps_off"][hi + 1] - heads.arrays["ps_off"][hi])
+    if stub is None:
+        n_stub, sf, sp, sb = -1, np.zeros(1, np.int32), np.zeros(1, np.int32), np.zeros(1, np.int32)
+    else:
+        n_stub = len(stub)
+        sf = np.array(list(stub.keys()) or [0], np.int32)
+        sp = np.array([v[0] for v in stub.values()] or [0], np.int32)
+        sb = np.array([v[1] for v in stub.values()] or [0], np.int32)
+    cap = 1024
+    n = C.c_int32(); rec = np.zeros(cap * 4, np.int32); label = C.c_int32(); rep = C.c_int32()
+    rc = lib().kqo_assign_attempts(C.byref(cfg), C.byref(snap.struct()), C.byref(heads.struct()), C.byref(tas.struct()) if tas is not None else None,
+                                   C.c_int(hi), C.c_int(n_stub), F.ptr(sf), F.ptr(sp), F.ptr(sb), C.c_int32(cap), C.byref(n), F.ptr(rec),
+                                   C.byref(label), C.byref(rep))
+    assert rc == 0, rc
+    assert n.value <= cap
+    out = [dict() for _ in range(P)]
+    for k in range(n.value):
+        p_, fl, mode, lb = (int(x) for x in rec[4 * k:4 * k + 4])
+        out[p_][snap.flavors[fl]] = (F.MODE_NAMES[mode], NO_FIT_LABELS[lb])
+    return NO_FIT_LABELS[label.value], F.MODE_NAMES[rep.value], out
+
+
 def assign(cfg, snap: Snapshot, heads: Heads, hi: int = 0, counts=None, stub=None, ineligible=None):
     """FlavorAssigner.Assign with an optional stub preemption oracle {fr: (possibility, borrow)}."""
     nR = snap.n_resource
