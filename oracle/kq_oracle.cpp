@@ -123,6 +123,12 @@ static const int64_t MAXINT = I64MAX;  // math.MaxInt on 64-bit
 //   [96..159] failed pops of a visit that ended exhausted
 //   [160..223] length of a run of consecutive victims under the same child of the root (last bin 63+)
 //   [224..287] candidates left in the ClusterQueue at the moment it is visited
+// assignFlavors over PodSetGroupName groups (flavorassigner.go:782-860): OFF by default — the engine's flavor scan runs per podset, and so does
+// this restatement's default path, which is what the parity suites compare it with. ON (kqo_set_grouped): the reference's grouping, pinned on the
+// leader-worker-set rows of TestAssignFlavors; DESIGN §7 "grouped flavor assignment" says where the two differ. groups: PodSetGroupName id per
+// podset of the heads batch (-1 none), or null = kq_cycle_tas.ps_group.
+static thread_local bool g_grouped = false;
+static thread_local const int32_t* g_groups = nullptr;
 static thread_local bool g_fs_probe_on = false;
 static thread_local int64_t g_fs_probe[288];
 
@@ -773,7 +779,8 @@ struct FlavorAssigner {
   // returns assignments (empty => nil), nreasons; *statusNil true when Go returns a nil status
   std::map<int, FlavorAssignment> findFlavorForPodSets(int psi, const std::vector<std::pair<int, int64_t>>& requests,
                                                        int resName, const FRQ& assignmentUsage, int* nreasons, bool* statusNil,
-                                                       std::vector<Reason>* why, std::vector<Attempt>* considered = nullptr) {
+                                                       std::vector<Reason>* why, std::vector<Attempt>* considered = nullptr,
+                                                       const std::vector<int>* psIDs = nullptr /* the podset group; null = {psi} */) {
     *nreasons = 0; *statusNil = false;
     why->clear();
     if (considered) considered->clear();
@@ -793,11 +800,16 @@ struct FlavorAssigner {
       attemptedFlavorIdx = idx;
       int fName = sn.s->rg_flavor[f0 + idx];
       if (respectNom) {  // shouldSkipBasedOnNominationMapping :1422
-        auto it = wl.nomination[psi].find(resName);
-        bool keep = it != wl.nomination[psi].end() && it->second == fName;
+        bool keep = false;
+        for (int q : (psIDs ? *psIDs : std::vector<int>{psi})) {
+          auto it = wl.nomination[q].find(resName);
+          keep |= it != wl.nomination[q].end() && it->second == fName;
+        }
         if (!keep) { (*nreasons)++; why->push_back({KQ_RSN_NOT_IN_NOMINATION, fName, resName, 0, 0, 0}); continue; }
       }
-      if (!flavorOk(wl.ps_base + psi, fName)) {  // checkFlavorForPodSets :1212 (host-evaluated)
+      bool eligible = flavorOk(wl.ps_base + psi, fName);
+      if (psIDs) for (int q : *psIDs) eligible &= flavorOk(wl.ps_base + q, fName);  // checkFlavorForPodSets walks every podset of the group (:1234)
+      if (!eligible) {  // checkFlavorForPodSets :1212 (host-evaluated)
         (*nreasons)++; why->push_back({KQ_RSN_FLAVOR_INELIGIBLE, fName, -1, 0, 0, 0});
         if (considered) considered->push_back({fName, NoFit, lblNoMatchingFlavor});  // :1106-1108 AddNoFitFlavorAttempt
         continue;
@@ -850,6 +862,7 @@ struct FlavorAssigner {
 
   // flavorassigner.go:708-908 (TAS branches excluded: out of scope for this path)
   Assignment assignFlavors(const std::vector<int>* counts) {
+    if (g_grouped) return assignFlavorsGrouped(counts);
     Assignment a;
     int P = (int)wl.ps.size();
     std::vector<PodSetReq> requests(P);
@@ -951,6 +964,124 @@ struct FlavorAssigner {
     if (a.RepresentativeMode() == NoFit) { resolveNoFitReason(a); return a; }  // :857-862
     if (sn.T) assignTAS(a);
     resolveNoFitReason(a);  // :904-906
+    return a;
+  }
+
+  // assignFlavors as the reference groups it (flavorassigner.go:782-860): the podsets of one PodSetGroupName are ONE flavor scan over the sum of
+  // their requests; every member then takes the group's flavors for the resources it requests itself (resolvePodSetFlavors :917-945; a member
+  // without requests keeps the group's TAS flavors) and the group's Status. Groups must be contiguous (orderedgroups appends PodSets in group
+  // order; this restatement indexes PodSets by podset): an interleaved workload raises tasUnsupported. Workload slices: single podsets only.
+  Assignment assignFlavorsGrouped(const std::vector<int>* counts) {
+    Assignment a;
+    const int P = (int)wl.ps.size();
+    std::vector<PodSetReq> requests(P);
+    std::vector<PodSetAssignment> psas(P);
+    for (int i = 0; i < P; i++) {
+      requests[i] = wl.ps[i];
+      if (counts && !counts->empty()) {
+        int nc2 = (*counts)[i];
+        if (wl.ps[i].count != 0 && wl.ps[i].count != nc2) {
+          for (auto& rq : requests[i].req) { rq.second = rq.second / (int64_t)wl.ps[i].count; rq.second = SaturatingMul(rq.second, (int64_t)nc2); }
+          requests[i].count = nc2;
+        }
+      }
+      PodSetReq& podSet = requests[i];
+      if (sn.s->pods_resource >= 0 && sn.RGByResource(cq, sn.s->pods_resource) >= 0) {
+        bool found = false;
+        for (auto& rq : podSet.req) if (rq.first == sn.s->pods_resource) { rq.second = podSet.count; found = true; }
+        if (!found) podSet.req.push_back({sn.s->pods_resource, (int64_t)podSet.count});
+      }
+      std::stable_sort(podSet.req.begin(), podSet.req.end(), [&](const std::pair<int, int64_t>& x, const std::pair<int, int64_t>& y) {
+        return sn.s->resource_order[x.first] < sn.s->resource_order[y.first];
+      });
+      psas[i].count = podSet.count;
+      psas[i].requests = podSet.req;
+      if (sn.T && sn.T->ps_adm_flavor) {  // :765-779, as in assignFlavors
+        const int g = wl.ps_base + i;
+        for (int r = 0; r < sn.nR; r++) {
+          const int fl = sn.T->ps_adm_flavor[(size_t)g * sn.nR + r];
+          if (fl >= 0) { FlavorAssignment fa; fa.flavor = fl; fa.mode = Fit; fa.tried = 0; fa.borrow = 0; psas[i].flavors[r] = fa; }
+        }
+        if (sn.T->ps_ex_off && sn.T->ps_ex_off[g + 1] > sn.T->ps_ex_off[g]) {
+          psas[i].hasTopo = true;
+          for (auto& kv : psas[i].flavors) if (sn.tasOfFlavor[kv.second.flavor] >= 0) psas[i].tasIdx = sn.tasOfFlavor[kv.second.flavor];
+          for (int j = sn.T->ps_ex_off[g]; j < sn.T->ps_ex_off[g + 1]; j++) { psas[i].topo.push_back({sn.T->ps_ex_leaf[j], sn.T->ps_ex_count[j]}); psas[i].topoFlags.push_back(sn.T->ps_ex_flags[j]); }
+        }
+      }
+    }
+    auto groupOf = [&](int i) { const int g = wl.ps_base + i; return g_groups ? g_groups[g] : (sn.T && sn.T->ps_group ? sn.T->ps_group[g] : -1); };
+    for (int i = 0; i < P;) {
+      std::vector<int> psIDs{i};
+      const int gid = groupOf(i);
+      int j = i + 1;
+      if (gid >= 0) {
+        while (j < P && groupOf(j) == gid) psIDs.push_back(j++);
+        for (int q = j; q < P; q++) if (groupOf(q) == gid) sn.tasUnsupported = true;  // interleaved group names
+      }
+      if (wl.slice_row >= 0 && psIDs.size() > 1) sn.tasUnsupported = true;
+      std::vector<std::pair<int, int64_t>> sum;  // requests.Add over the members, Requests.Iter order
+      for (int q : psIDs) for (auto& rq : requests[q].req) {
+        bool found = false;
+        for (auto& x : sum) if (x.first == rq.first) { x.second = SaturatingAdd(x.second, rq.second); found = true; }
+        if (!found) sum.push_back(rq);
+      }
+      std::stable_sort(sum.begin(), sum.end(), [&](const std::pair<int, int64_t>& x, const std::pair<int, int64_t>& y) {
+        return sn.s->resource_order[x.first] < sn.s->resource_order[y.first];
+      });
+      sn.st.head_io_bytes += (int64_t)sum.size() * 8;
+      std::map<int, FlavorAssignment> groupFlavors;
+      for (int q : psIDs) for (auto& kv : psas[q].flavors) groupFlavors[kv.first] = kv.second;  // every prior-pass assignment (:801-804)
+      bool groupNil = false;
+      int groupReasons = 0;
+      std::vector<Reason> groupWhy;
+      std::vector<Attempt> attempts;
+      for (auto& rq : sum) {
+        const int resName = rq.first; const int64_t quantity = rq.second;
+        if (sn.RGByResource(cq, resName) < 0) {
+          if (quantity == 0) continue;
+          if (sn.gate(KQ_GATE_QUOTA_CHECK_STRATEGY) && sn.cfg.quota_check_strategy == KQ_QUOTA_CHECK_IGNORE_UNDECLARED) continue;
+        }
+        if (groupFlavors.count(resName)) continue;
+        int nre; bool statusNil;
+        std::vector<Reason> why;
+        std::vector<Attempt> considered;
+        auto flavors = findFlavorForPodSets(psIDs[0], sum, resName, a.Usage, &nre, &statusNil, &why, observe ? &considered : nullptr, &psIDs);
+        if (observe) mergeFlavorAttemptsForResource(attempts, considered, resName);
+        if (flavors.empty() && !sum.empty()) { groupFlavors.clear(); groupNil = true; groupReasons = nre; groupWhy = why; break; }
+        for (auto& kv : flavors) groupFlavors[kv.first] = kv.second;
+        if (!statusNil) { groupReasons += nre; groupWhy.insert(groupWhy.end(), why.begin(), why.end()); }
+      }
+      bool failed = false;
+      for (int q : psIDs) {
+        PodSetAssignment& psa = psas[q];
+        psa.flavors.clear();
+        if (!groupNil) {  // resolvePodSetFlavors :917-945
+          if (!requests[q].req.empty()) {
+            for (auto& kv : groupFlavors) for (auto& rq : requests[q].req) if (rq.first == kv.first) { psa.flavors[kv.first] = kv.second; break; }
+          } else if (gid >= 0) {
+            for (auto& kv : groupFlavors) if (sn.T && sn.tasOfFlavor[kv.second.flavor] >= 0) psa.flavors[kv.first] = kv.second;  // tasFlavorsOnly :996
+          }
+        }
+        psa.nreasons = groupReasons; psa.reasons = groupWhy; psa.attempts = attempts;
+        for (auto& kv : psa.flavors) {  // Assignment.append :1017-1041
+          if (kv.second.borrow > a.Borrowing) a.Borrowing = kv.second.borrow;
+          const int fr = kv.second.flavor * sn.nR + kv.first;
+          int64_t requestAmount = 0;
+          for (auto& rq : requests[q].req) if (rq.first == kv.first) requestAmount = rq.second;
+          if (wl.slice_row >= 0) { auto it = wl.ps[q].slice.find(kv.first); if (it != wl.ps[q].slice.end()) requestAmount -= it->second.second; }
+          a.Usage[fr] = frq_get(a.Usage, fr).AddInt64(requestAmount);
+        }
+        sn.st.head_io_bytes += (int64_t)requests[q].req.size() * 8 + (int64_t)psa.flavors.size() * 16;
+        failed |= !requests[q].req.empty() && psa.flavors.empty();
+        a.PodSets.push_back(psa);
+        a.rep = -1;
+      }
+      if (failed) { resolveNoFitReason(a); return a; }
+      i = j;
+    }
+    if (a.RepresentativeMode() == NoFit) { resolveNoFitReason(a); return a; }
+    if (sn.T) assignTAS(a);
+    resolveNoFitReason(a);
     return a;
   }
 
@@ -2108,12 +2239,38 @@ int kqo_nominate_run(const kq_config* cfg, const kq_snapshot* s, const kq_heads*
 // TestAssignFlavors drives it (flavorassigner_test.go:159-176,3641-3652): stub_fr[k] ->
 // (stub_poss[k], stub_borrow[k]); any other fr -> (Preempt, 0). n_stub < 0 selects the real oracle.
 // counts: optional per-podset counts (partial admission).
+static int assignImpl(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, const kq_cycle_tas* t, int hi, const int32_t* counts,
+               int n_stub, const int32_t* stub_fr, const int32_t* stub_poss, const int32_t* stub_borrow,
+               int32_t* flavor, uint8_t* res_mode, int32_t* tried_idx, int32_t* res_borrow,
+               int32_t* rep_mode, int32_t* borrowing, int64_t* usage_fr, int32_t* ps_nreasons,
+               int32_t rsn_cap, int32_t* rsn_n, int32_t* rsn_rec, int64_t* rsn_abc, int32_t* ps_err);
+
 int kqo_assign(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, int hi, const int32_t* counts,
                int n_stub, const int32_t* stub_fr, const int32_t* stub_poss, const int32_t* stub_borrow,
                int32_t* flavor, uint8_t* res_mode, int32_t* tried_idx, int32_t* res_borrow,
                int32_t* rep_mode, int32_t* borrowing, int64_t* usage_fr /* [n_fr] dense, 0 if absent */, int32_t* ps_nreasons,
                int32_t rsn_cap, int32_t* rsn_n, int32_t* rsn_rec /* [rsn_cap][4]: podset, code, flavor, resource */, int64_t* rsn_abc /* [rsn_cap][3] */) {
+  return assignImpl(cfg, s, h, nullptr, hi, counts, n_stub, stub_fr, stub_poss, stub_borrow, flavor, res_mode, tried_idx, res_borrow, rep_mode, borrowing,
+                    usage_fr, ps_nreasons, rsn_cap, rsn_n, rsn_rec, rsn_abc, nullptr);
+}
+// kqo_assign with the TAS half of Assign (t != NULL: assignTAS runs — WorkloadsTopologyRequests, the placements) and PodSetAssignment.Status.err
+// per podset (ps_err, may be NULL): what TestAssignFlavors_LeaderWorkerSetTASFlavor reads (flavorassigner_test.go:6036-6050)
+int kqo_assign_tas(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, const kq_cycle_tas* t, int hi,
+                   int n_stub, const int32_t* stub_fr, const int32_t* stub_poss, const int32_t* stub_borrow,
+                   int32_t* flavor, uint8_t* res_mode, int32_t* tried_idx, int32_t* rep_mode, int64_t* usage_fr, int32_t* ps_nreasons, int32_t* ps_err,
+                   int32_t rsn_cap, int32_t* rsn_n, int32_t* rsn_rec, int64_t* rsn_abc) {
+  int32_t borrowing = 0;
+  return assignImpl(cfg, s, h, t, hi, nullptr, n_stub, stub_fr, stub_poss, stub_borrow, flavor, res_mode, tried_idx, nullptr, rep_mode, &borrowing,
+                    usage_fr, ps_nreasons, rsn_cap, rsn_n, rsn_rec, rsn_abc, ps_err);
+}
+} // extern "C"
+static int assignImpl(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, const kq_cycle_tas* t, int hi, const int32_t* counts,
+               int n_stub, const int32_t* stub_fr, const int32_t* stub_poss, const int32_t* stub_borrow,
+               int32_t* flavor, uint8_t* res_mode, int32_t* tried_idx, int32_t* res_borrow,
+               int32_t* rep_mode, int32_t* borrowing, int64_t* usage_fr, int32_t* ps_nreasons,
+               int32_t rsn_cap, int32_t* rsn_n, int32_t* rsn_rec, int64_t* rsn_abc, int32_t* ps_err) {
   Snap sn(*cfg, s);
+  if (t) sn.attachTAS(t);
   Scheduler sch(sn, h);
   Head wl = sch.loadHead(hi);
   OracleFn orc;
@@ -2150,8 +2307,13 @@ int kqo_assign(const kq_config* cfg, const kq_snapshot* s, const kq_heads* h, in
       }
     *rsn_n = n;
   }
+  if (ps_err) for (int p = 0; p < P; p++) ps_err[p] = p < (int)a.PodSets.size() && a.PodSets[p].err ? 1 : 0;
   return KQ_OK;
 }
+extern "C" {
+
+// the switch of g_grouped / g_groups above; groups (may be null) must stay valid until the switch is turned off
+void kqo_set_grouped(int on, const int32_t* groups) { g_grouped = on != 0; g_groups = on ? groups : nullptr; }
 
 // Assign with features.UnadmittedWorkloadsObservability on: the FlavorAssignmentAttempts of every podset — (podset, flavor, mode, label), label
 // = the severity rank of the attempt's NoFitReason (lbl* above) — and Assignment.NoFitReason, as TestIsNoFitDueToCapacityAndLimits reads them

@@ -77,6 +77,48 @@ def nominate_run(cfg: F.kq_config, snap: Snapshot, heads: Heads, tgt_cap=None):
     return d
 
 
+def set_grouped(on: bool, groups=None):
+    """The reference's grouping of assignFlavors by PodSetGroupName (flavorassigner.go:782-860) — OFF by default, see kq_oracle.cpp g_grouped.
+    groups: int32 PodSetGroupName id per podset of the heads batch (-1 none; kept alive here), None = kq_cycle_tas.ps_group."""
+    global _groups_keep
+    _groups_keep = None if groups is None else np.ascontiguousarray(groups, np.int32)
+    lib().kqo_set_grouped.restype = None
+    lib().kqo_set_grouped(C.c_int(1 if on else 0), F.ptr(_groups_keep) if (on and _groups_keep is not None) else None)
+
+
+_groups_keep = None
+
+
+def assign_tas(cfg, snap: Snapshot, heads: Heads, tas, hi: int = 0, stub=None, ineligible=None):
+    """kqo_assign_tas: Assign(nil) with its TAS half -> dict(rep_mode, podsets [{resource: (flavor, mode, tried)}], usage, reasons, err [bool per podset])."""
+    nR = snap.n_resource
+    P = int(heads.arrays["ps_off"][hi + 1] - heads.arrays["ps_off"][hi])
+    flavor = np.zeros(P * nR, np.int32); mode = np.zeros(P * nR, np.uint8); tried = np.zeros(P * nR, np.int32)
+    rep = C.c_int32(); usage = np.zeros(snap.n_fr, np.int64); nre = np.zeros(max(P, 1), np.int32); err = np.zeros(max(P, 1), np.int32)
+    stub = stub or {}
+    sf = np.array(list(stub.keys()) or [0], np.int32)
+    sp = np.array([v[0] for v in stub.values()] or [0], np.int32)
+    sb = np.array([v[1] for v in stub.values()] or [0], np.int32)
+    rcap = 4096
+    rsn_n = C.c_int32(); rsn_rec = np.zeros(rcap * 4, np.int32); rsn_abc = np.zeros(rcap * 3, np.int64)
+    rc = lib().kqo_assign_tas(C.byref(cfg), C.byref(snap.struct()), C.byref(heads.struct()), C.byref(tas.struct()) if tas is not None else None, C.c_int(hi),
+                              C.c_int(len(stub)), F.ptr(sf), F.ptr(sp), F.ptr(sb), F.ptr(flavor), F.ptr(mode), F.ptr(tried), C.byref(rep), F.ptr(usage),
+                              F.ptr(nre), F.ptr(err), C.c_int32(rcap), C.byref(rsn_n), F.ptr(rsn_rec), F.ptr(rsn_abc))
+    assert rc == 0, rc
+    from kueue_amd import messages as M
+    reasons = [[] for _ in range(P)]
+    for k in range(min(rsn_n.value, rcap)):
+        p_, code, fl, rs = (int(x) for x in rsn_rec[4 * k:4 * k + 4])
+        a_, b_, c_ = (int(x) for x in rsn_abc[3 * k:3 * k + 3])
+        reasons[p_].extend(M.reason_text(snap, code, fl, rs, a_, b_, c_, ineligible, p_))
+    podsets = []
+    for p in range(P):
+        podsets.append({snap.resources[r]: (snap.flavors[int(flavor[p * nR + r])], F.MODE_NAMES[int(mode[p * nR + r])], int(tried[p * nR + r]))
+                        for r in range(nR) if flavor[p * nR + r] >= 0})
+    return dict(rep_mode=F.MODE_NAMES[rep.value], podsets=podsets, usage={snap.fr_name(fr): int(usage[fr]) for fr in range(snap.n_fr) if usage[fr] != 0},
+                reasons=[sorted(x) for x in reasons], err=[bool(x) for x in err[:P]])
+
+
 NO_FIT_LABELS = ["", "TopologyPlacementFailed", "WaitingForQuota", "ExceedsMaxQuota", "NoMatchingFlavor"]   # reasonSeverity flavorassigner.go:306-327
 
 

@@ -166,7 +166,9 @@ def parse_podsets(text):
         ps = {"name": nm, "count": int(m.group(2)), "requests": {}}
         for r in re.finditer(r'\.\s*Request\(([^,]+),\s*"([^"]*)"\)', seg):
             ps["requests"][res_name(r.group(1))] = r.group(2)
-        if re.search(r"NodeSelector|RequiredDuringScheduling|Affinity|SetMinimumCount|TopologyRequest|PodSetGroup", seg):
+        if re.search(r"PodSetGroup", seg):
+            return "group"
+        if re.search(r"NodeSelector|RequiredDuringScheduling|Affinity|SetMinimumCount|TopologyRequest", seg):
             return None
         ps["tolerates_spot"] = bool(re.search(r"Toleration\(", seg))
         pods.append(ps)
@@ -224,6 +226,9 @@ def main():
         if re.search(r"preemptWorkloadSlice|topologies|TopologyRequest|wlReclaimablePods|tas-|DelayedTopology", block):
             skipped.append((name, "TAS / workload slices / reclaimable pods: outside the engine boundary")); continue
         pods = parse_podsets(field(block, "wlPods") or "")
+        if pods == "group":
+            skipped.append((name, "PodSetGroupName: one flavor scan per group (flavorassigner.go:782-860) - by hand in assign_flavors_groups_manual.yaml, "
+                                  "pinned on the oracle's grouped path; the engine scans per podset (DESIGN section 7)")); continue
         if pods is None:
             skipped.append((name, "node selector / affinity / minimum count (host-side eligibility, not transcribed)")); continue
         cq = parse_cq(field(block, "clusterQueue"))
