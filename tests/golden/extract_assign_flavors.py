@@ -156,6 +156,21 @@ def parse_cq(text):
 TAINTED = {"tainted"}  # flavors whose taint no test podset tolerates by itself
 
 
+_LABELS = None
+
+
+def flavor_labels(src):
+    """The ResourceFlavor objects of TestAssignFlavors (:179-207): flavor -> nodeLabels."""
+    global _LABELS
+    if _LABELS is None:
+        _LABELS = {}
+        head = src[src.index("func TestAssignFlavors("):]
+        head = head[:head.index("cases := map[string]struct")]
+        for m in re.finditer(r'MakeResourceFlavor\("([^"]+)"\)((?:\.\s*NodeLabel\("[^"]+",\s*"[^"]*"\))*)', head):
+            _LABELS[m.group(1)] = dict(re.findall(r'NodeLabel\("([^"]+)",\s*"([^"]*)"\)', m.group(2)))
+    return _LABELS
+
+
 def parse_podsets(text):
     pods = []
     for m in re.finditer(r"MakePodSet\(([^,]+),\s*(\d+)\)", text):
@@ -166,10 +181,16 @@ def parse_podsets(text):
         ps = {"name": nm, "count": int(m.group(2)), "requests": {}}
         for r in re.finditer(r'\.\s*Request\(([^,]+),\s*"([^"]*)"\)', seg):
             ps["requests"][res_name(r.group(1))] = r.group(2)
+        for c in re.finditer(r"SingleContainerForRequest\(map\[corev1\.ResourceName\]string\{([^}]*)\}", seg):   # Containers(...): the same requests, via the pod template
+            for r in re.finditer(r'([\w.]+|"[^"]+"):\s*"([^"]*)"', c.group(1)):
+                ps["requests"][res_name(r.group(1))] = r.group(2)
         if re.search(r"PodSetGroup", seg):
             return "group"
-        if re.search(r"NodeSelector|RequiredDuringScheduling|Affinity|SetMinimumCount|TopologyRequest", seg):
+        if re.search(r"RequiredDuringScheduling|Affinity|SetMinimumCount|TopologyRequest", seg):
             return None
+        sel = re.search(r"NodeSelector\(map\[string\]string\{([^}]*)\}\)", seg)
+        if sel:   # spec.nodeSelector: evaluated against each flavor's OWN label keys below (flavorSelector flavorassigner.go:1264-1298)
+            ps["node_selector"] = dict(re.findall(r'"([^"]+)":\s*"([^"]*)"', sel.group(1)))
         ps["tolerates_spot"] = bool(re.search(r"Toleration\(", seg))
         pods.append(ps)
     return pods
@@ -205,6 +226,9 @@ def parse_want(text):
             i = e + 1
     m = re.search(r"(?m)^\t{4}Borrowing:\s*(\d+)", text)
     want["borrowing"] = int(m.group(1)) if m else 0
+    m = re.search(r'(?m)^\t{4}NoFitReason:\s*"(\w*)"', text)   # Assignment.NoFitReason (the attempts' own labels sit deeper); compared when the gate is on
+    if m:
+        want["noFitReason"] = m.group(1)
     m = re.search(r"Usage:\s*workload\.Usage\{", text)
     want["usage"] = parse_frq(text[m.start():]) if m else {}
     return want
@@ -243,10 +267,19 @@ def main():
         all_flavors = {f["flavor"] for q in (cq, cq2) if q for rg in q["resourceGroups"] for f in rg}
         if "nonexistent-flavor" in all_flavors or "non-existent" in " ".join(all_flavors):
             skipped.append((name, "missing ResourceFlavor object")); continue
+        inel = {}
         for ps in pods:
             excl = [f for f in sorted(all_flavors) if f in TAINTED and not ps["tolerates_spot"]]
+            sel = ps.pop("node_selector", None)
+            if sel:
+                for f in sorted(all_flavors):
+                    labels = flavor_labels(src).get(f, {})
+                    if f not in excl and any(k in labels and labels[k] != v for k, v in sel.items()):
+                        excl.append(f)
+                        inel[f] = f"flavor {f} doesn't match node affinity"   # checkFlavorForPodSets :1256
+                ps["nodeSelector"] = sel
             if excl:
-                ps["excludedFlavors"] = excl
+                ps["excludedFlavors"] = sorted(excl)
             del ps["tolerates_spot"]
         sim = {}
         st = field(block, "simulationResult")
@@ -265,6 +298,8 @@ def main():
                 "pending": [{"name": "wl", "cq": cq["name"], "podsets": pods}], "want": want}
         if sim:
             case["simulationResult"] = sim
+        if inel:
+            case["ineligibleText"] = inel
         if gates:
             case["gates"] = gates
         efs = field(block, "enableFairSharing")

@@ -29,8 +29,9 @@ TAINT_TEXT = {"tainted": "untolerated taint {instance spot NoSchedule <nil>} in 
               "spot-tainted-2": "untolerated taint {key val2 NoSchedule <nil>} in flavor spot-tainted-2"}
 
 
-def _ineligible(snap):
-    return lambda ps, fl: [TAINT_TEXT[snap.flavors[fl]]]
+def _ineligible(snap, case=None):
+    text = dict(TAINT_TEXT, **((case or {}).get("ineligibleText") or {}))   # node-selector rows carry their own "doesn't match node affinity"
+    return lambda ps, fl: [text[snap.flavors[fl]]]
 
 
 def test_quantity_strings():
@@ -51,7 +52,7 @@ def test_assign_flavors_status_strings(oracle, case):
     """FlavorAssigner.Assign with the table's stub oracle -> Status.reasons per podset, regenerated from the operands."""
     cfg, snap, heads = load_case(case)
     oracle.derive(snap)
-    got = oracle.assign(cfg, snap, heads, 0, stub=_stub(snap, case), ineligible=_ineligible(snap))
+    got = oracle.assign(cfg, snap, heads, 0, stub=_stub(snap, case), ineligible=_ineligible(snap, case))
     for pi, ps in enumerate(case["want"]["podsets"]):
         assert got["reasons"][pi] == sorted(ps.get("status", [])), (case["name"], pi)
 

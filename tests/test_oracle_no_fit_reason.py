@@ -155,3 +155,33 @@ def test_regenerated_labels_equal_the_oracles_on_random_cycles(oracle, block):
         a, b = _compare_cycle(oracle, cfg, snap, heads, d)
         n += a; n_nofit += b
     assert n > 100 and n_nofit > 20, (n, n_nofit)
+
+
+ASG = load_golden("assign_flavors.yaml")["cases"]
+
+
+@pytest.mark.parametrize("case", ASG, ids=lambda c: c["name"][:60])
+def test_assign_flavors_table_no_fit_reason(oracle, case):
+    """TestAssignFlavors runs every row with the gate on as well (flavorassigner_test.go:3581) and then compares Assignment.NoFitReason
+    (:3658-3661): the row's `NoFitReason:` or "" — on the oracle with the table's stub, and regenerated from the emulated engine's records
+    (the label does not depend on what the preemption simulation answers, only on whether it is asked)."""
+    from kueue_amd.fixtures import load_case
+    from tests.emu import kqe
+    from kueue_amd import no_fit_reason as N
+    cfg, snap, heads = load_case(case)
+    oracle.derive(snap)
+    stub = {}
+    for k, (poss, borrow) in (case.get("simulationResult") or {}).items():
+        f, r = k.split("/", 1)
+        stub[snap.fr(f, r)] = (POSS[poss], borrow)
+    want = case["want"].get("noFitReason", "")
+    label, rep, _ = oracle.assign_attempts(cfg, snap, heads, 0, stub=stub)
+    assert label == want and rep == case["want"]["repMode"], (label, rep)
+    eng = kqe.EmuEngine(cfg)
+    try:
+        eng.put(snap)
+        d = eng.run(heads, rsn_cap=256)
+    finally:
+        eng.close()
+    got, _ = N.flavor_attempts(d, 0, bool(cfg.fair_sharing))
+    assert N.LABELS[got] == want
