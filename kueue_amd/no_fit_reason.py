@@ -187,3 +187,25 @@ def flavor_attempts(dec, i: int, fair_sharing: bool, tas_flavors: Optional[Set[i
                     rg_min[rg] = lb
         overall = max([overall] + list(rg_min.values()))
     return overall, out
+
+
+def quota_reserved_reason(dec, i: int, fair_sharing: bool, tas_flavors: Optional[Set[int]] = None, tree: Optional[QuotaTree] = None) -> str:
+    """entry.quotaReservedReason as processEntry leaves it (scheduler.go:424-513) — the Reason of the QuotaReserved=False condition
+    requeueAndUpdate patches (:1188, UnadmittedWorkloadReasonWithFallback; the gate is on by default) — for a head of a cycle. "" for a head that
+    was admitted. The reasons nominate sets before an entry reaches processEntry (Misconfigured / Suspended / PendingEvaluation :678-691:
+    inactive ClusterQueue, namespace mismatch, admission checks) belong to heads the host never sends across the boundary."""
+    a = dec.a
+    if int(a["status"][i]) == F.ST_ASSUMED:
+        return ""
+    if int(a["skip"][i]) in (F.SKIP_OVERLAP, F.SKIP_NO_LONGER_FITS):   # :471-484
+        return "WaitingForQuota"
+    mode = int(a["mode"][i])
+    if mode == NOFIT:                                                  # :430-435
+        return LABELS[flavor_attempts(dec, i, fair_sharing, tas_flavors, tree)[0]]
+    if mode == 2:                                                      # DeferredFit :455-468
+        return "WaitingForPreemptedWorkloads"
+    if int(a["action"][i]) == F.ACT_PREEMPT:                           # :495
+        return "WaitingForPreemptedWorkloads"
+    if mode == PREEMPT and int(a["tgt_off"][i + 1]) == int(a["tgt_off"][i]):   # :437-443
+        return "WaitingForQuota"
+    return ""

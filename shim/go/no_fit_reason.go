@@ -266,3 +266,26 @@ func NoFitReason(s *FlatSnapshot, h *FlatHeads, d *FlatDecisions, i int, fairSha
 	}
 	return noFitLabels[overall], named, nil
 }
+
+// QuotaReservedReason is entry.quotaReservedReason as processEntry leaves it (scheduler.go:424-513) for head i of a cycle — the Reason of the
+// QuotaReserved=False condition requeueAndUpdate patches (:1188; features.UnadmittedWorkloadsObservability is on by default). "" for a head that
+// was admitted. Twin of kueue_amd/no_fit_reason.py quota_reserved_reason, which the repository's tests run against the 110 condition Reasons
+// of TestSchedule / TestScheduleForFairSharing / TestScheduleRecomputePreemptionTargets / TestScheduleForTAS.
+func QuotaReservedReason(s *FlatSnapshot, h *FlatHeads, d *FlatDecisions, i int, fairSharing bool, isTASFlavor func(flavor int32) bool) (string, error) {
+	switch {
+	case d.Status[i] == stAssumed:
+		return "", nil
+	case d.Skip[i] == skipOverlap || d.Skip[i] == skipNoLongerFits: // :471-484
+		return kueue.WorkloadQuotaReservedReasonWaitingForQuota, nil
+	case d.Mode[i] == modeNoFit: // :430-435
+		r, _, err := NoFitReason(s, h, d, i, fairSharing, isTASFlavor)
+		return r, err
+	case d.Mode[i] == 2: // DeferredFit :455-468
+		return kueue.WorkloadQuotaReservedReasonWaitingForPreemptedWorkloads, nil
+	case d.Action[i] == actPreempt: // :495
+		return kueue.WorkloadQuotaReservedReasonWaitingForPreemptedWorkloads, nil
+	case d.Mode[i] == modePreempt && d.TgtOff[i+1] == d.TgtOff[i]: // :437-443
+		return kueue.WorkloadQuotaReservedReasonWaitingForQuota, nil
+	}
+	return "", nil
+}

@@ -128,6 +128,8 @@ def parse_wl(text, start):
                 mm = re.search(r'Message:\s*((?:"(?:[^"\\]|\\.)*"\s*\+?\s*)+)', a)
                 if mm:
                     w["pendingMessage"] = "".join(bytes(x, "utf-8").decode("unicode_escape") for x in re.findall(r'"((?:[^"\\]|\\.)*)"', mm.group(1)))
+                if reason:   # e.quotaReservedReason (scheduler.go:433-513) -> the condition's Reason with UnadmittedWorkloadsObservability on (the default)
+                    w["pendingReason"] = reason.group(1).replace("WorkloadQuotaReservedReason", "")
             if typ and status and status.group(1) == "True":
                 if typ.group(1) == "WorkloadPreempted":
                     w["preemptedReason"] = reason.group(1).replace("Reason", "") if reason else ""
@@ -343,6 +345,8 @@ def extract(fname, func, cases, skipped):
                 k = f"{w['ns']}/{w['name']}"
                 if "pendingMessage" in w and k in expect and not expect[k]["admitted"]:
                     expect[k]["message"] = w["pendingMessage"]
+                if "pendingReason" in w and k in expect and not expect[k]["admitted"]:
+                    expect[k]["reason"] = w["pendingReason"]
             preempted = sorted(f"{w['ns']}/{w['name']}:{w['preemptedReason']}" for w in want_wls if "preemptedReason" in w and f"{w['ns']}/{w['name']}" in adm_keys)
             for c in cqs:
                 c.pop("_bad", None)

@@ -312,6 +312,10 @@ def parse_wl(text, start, sym):
                 w["evicted"] = True
             if typ and status and status.group(1) == "True" and typ.group(1) == "WorkloadPreempted":
                 w["preempted"] = True
+            if typ and status and status.group(1) == "False" and typ.group(1) == "WorkloadQuotaReserved":
+                rs = re.search(r'Reason:\s*(?:kueue\.)?"?([\w\.]+)"?', a)   # e.quotaReservedReason scheduler.go:433-513
+                if rs:
+                    w["pendingReason"] = rs.group(1).replace("WorkloadQuotaReservedReason", "")
     if w["podsets"] is None:
         raise Skip("workload without PodSets")
     return w, end
@@ -516,6 +520,10 @@ def extract(src, func, cases, skipped):
                         expect[k]["left"] = "inadmissible"
             want_wls = workloads_in(field(block, "wantWorkloads") or "", sym)
             preempted = sorted(f"{w['ns']}/{w['name']}" for w in want_wls if w.get("preempted"))
+            for w in want_wls:
+                k = f"{w['ns']}/{w['name']}"
+                if "pendingReason" in w and k in expect and not expect[k]["admitted"]:
+                    expect[k]["reason"] = w["pendingReason"]
             case = {"name": name, "ref": f"pkg/scheduler/scheduler_tas_test.go:{line}", "func": func, "now": NOW, "nodes": nodes,
                     "topologies": topologies, "resourceFlavors": flavors, "clusterQueues": cqs, "cohorts": cohorts, "admitted": admitted,
                     "pending": heads, "notHeads": [r["name"] for r in rest], "expect": expect}

@@ -2,7 +2,7 @@
 TestAssignFlavors_LeaderWorkerSetTASFlavor (tests/golden/assign_flavors_groups_manual.yaml; flavorassigner.go:782-860, :917-945).
 
 The engine — and the oracle's default path the parity suites compare it with — scans flavors per podset. The two agree whenever a group's
-members end on the same flavors either way (every podset-group case of TestScheduleForTAS and the random TAS populations do); they differ when
+members end on the same flavors either way; they differ when
 the SUM of a group's requests changes the scan's outcome, or when a member requests none of the group's resources and inherits its TAS flavor.
 The `ungrouped` blocks pin what the per-podset scan yields on the reference's own rows; DESIGN §7 states the gap."""
 import numpy as np

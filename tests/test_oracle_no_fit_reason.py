@@ -185,3 +185,62 @@ def test_assign_flavors_table_no_fit_reason(oracle, case):
         eng.close()
     got, _ = N.flavor_attempts(d, 0, bool(cfg.fair_sharing))
     assert N.LABELS[got] == want
+
+
+SCHED = [c for f in ("schedule.yaml", "schedule_fair.yaml", "schedule_recompute.yaml") for c in load_golden(f)["cases"]
+         if any("reason" in e for e in c["expect"].values())]
+
+
+def _reasons(cfg, heads, d):
+    from kueue_amd import no_fit_reason as N
+    return {w.name: N.quota_reserved_reason(d, i, bool(cfg.fair_sharing)) for i, w in enumerate(heads.workloads)}
+
+
+@pytest.mark.parametrize("case", SCHED, ids=lambda c: c["name"][:70])
+def test_quota_reserved_reason_of_the_schedule_tables(oracle, case):
+    """TestSchedule / TestScheduleForFairSharing / TestScheduleRecomputePreemptionTargets pin the Reason of the QuotaReserved=False condition of
+    every workload that stays pending (wantWorkloads `Reason: kueue.WorkloadQuotaReservedReason…`, 77 of them in the transcribed rows;
+    tests/golden/extract_schedule.py `reason`): entry.quotaReservedReason (scheduler.go:433-513), regenerated from the decisions of the oracle's
+    cycle and of the emulated engine's."""
+    from kueue_amd.fixtures import load_case
+    from tests.emu import kqe
+    cfg, snap, heads = load_case(case)
+    oracle.derive(snap)
+    want = {k: e["reason"] for k, e in case["expect"].items() if "reason" in e}
+    d = oracle.cycle_run(cfg, snap, heads, rsn_cap=4096)
+    got = _reasons(cfg, heads, d)
+    assert {k: got[k] for k in want if k in got} == {k: v for k, v in want.items() if k in got}, got
+    assert any(k in got for k in want)
+    eng = kqe.EmuEngine(cfg)
+    try:
+        eng.put(snap)
+        d = eng.run(heads, rsn_cap=4096)
+    finally:
+        eng.close()
+    assert _reasons(cfg, heads, d) == got
+
+
+SCHED_TAS = [c for c in load_golden("schedule_tas.yaml")["cases"] if any("reason" in e for e in c["expect"].values())]
+
+
+@pytest.mark.parametrize("case", SCHED_TAS, ids=lambda c: c["name"][:70])
+def test_quota_reserved_reason_of_the_tas_schedule_table(oracle, case):
+    """The same column of TestScheduleForTAS (33 reasons, one of them TopologyPlacementFailed) through kq_cycle_run_tas: the oracle's cycle and
+    the emulated engine's."""
+    from kueue_amd import no_fit_reason as N
+    from tests.emu import kqe
+    cfg, snap, heads, ct = load_tas_case(case)
+    oracle.derive(snap)
+    tas_fl = {snap.flavor_index[n] for n in ct.names}
+    want = {k: e["reason"] for k, e in case["expect"].items() if "reason" in e}
+    d, _ = oracle.cycle_run_tas(cfg, snap, heads, ct, tgt_cap=max(16, snap.n_adm), rsn_cap=4096)
+    got = {w.name: N.quota_reserved_reason(d, i, bool(cfg.fair_sharing), tas_fl) for i, w in enumerate(heads.workloads)}
+    assert {k: got[k] for k in want if k in got} == {k: v for k, v in want.items() if k in got}, got
+    assert any(k in got for k in want)
+    eng = kqe.EmuEngine(cfg)
+    try:
+        eng.put(snap)
+        d, _ = eng.run_tas(heads, ct, tgt_cap=max(16, snap.n_adm), rsn_cap=4096)
+    finally:
+        eng.close()
+    assert {w.name: N.quota_reserved_reason(d, i, bool(cfg.fair_sharing), tas_fl) for i, w in enumerate(heads.workloads)} == got
