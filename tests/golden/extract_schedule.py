@@ -271,7 +271,8 @@ def extract(fname, func, cases, skipped):
             wls = workloads_in(field(block, "workloads") or "")
             want_wls = workloads_in(field(block, "wantWorkloads") or "")
             cq_names = {c["name"] for c in cqs}
-            flavors_known = {"default", "on-demand", "spot", "model-a"}
+            flavors_known = {"default", "on-demand", "spot", "model-a", "spot-tainted", "spot-tainted-2"}
+            tainted = {"spot-tainted", "spot-tainted-2"}   # scheduler_test.go:376-387 key=val / key=val2 NoSchedule; rows whose pods tolerate them are skipped above
             for c in cqs:
                 for rg in c["resourceGroups"]:
                     for f in rg:
@@ -300,6 +301,10 @@ def extract(fname, func, cases, skipped):
                     need = {"sales": "sales", "eng-alpha": "eng", "eng-beta": "eng", "lend-a": "lend", "lend-b": "lend"}.get(cq)
                     if need is not None and dep != need:
                         raise Skip("namespace selector mismatch (host-side gatekeeping)")
+                    excl = sorted({f["flavor"] for c in cqs if c["name"] == cq for rg in c["resourceGroups"] for f in rg} & tainted)
+                    if excl:   # checkFlavorForPodSets "untolerated taint" (flavorassigner.go:1243): the host-side eligibility mask
+                        for ps in w["podsets"]:
+                            ps["excludedFlavors"] = excl
                     pending.append({"name": f"{w['ns']}/{w['name']}", "cq": cq, "priority": w["priority"], "created": w["created"], "podsets": w["podsets"]})
             cqs = [c for c in cqs if not c.get("_bad")]
             # heads: one per ClusterQueue, priority desc then creation asc (cluster_queue.go:844)
