@@ -195,7 +195,7 @@ def quota_reserved_reason(dec, i: int, fair_sharing: bool, tas_flavors: Optional
     was admitted. The reasons nominate sets before an entry reaches processEntry (Misconfigured / Suspended / PendingEvaluation :678-691:
     inactive ClusterQueue, namespace mismatch, admission checks) belong to heads the host never sends across the boundary."""
     a = dec.a
-    if int(a["status"][i]) == F.ST_ASSUMED:
+    if int(a["status"][i]) in (F.ST_ASSUMED, F.ST_EVICTED):   # admitted; or evicted by handleFailedTASReplacement (:426-429), which sets no reason
         return ""
     if int(a["skip"][i]) in (F.SKIP_OVERLAP, F.SKIP_NO_LONGER_FITS):   # :471-484
         return "WaitingForQuota"

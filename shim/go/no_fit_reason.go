@@ -273,7 +273,7 @@ func NoFitReason(s *FlatSnapshot, h *FlatHeads, d *FlatDecisions, i int, fairSha
 // of TestSchedule / TestScheduleForFairSharing / TestScheduleRecomputePreemptionTargets / TestScheduleForTAS.
 func QuotaReservedReason(s *FlatSnapshot, h *FlatHeads, d *FlatDecisions, i int, fairSharing bool, isTASFlavor func(flavor int32) bool) (string, error) {
 	switch {
-	case d.Status[i] == stAssumed:
+	case d.Status[i] == stAssumed || d.Status[i] == stEvicted: // admitted; or evicted by handleFailedTASReplacement (:426-429), which sets no reason
 		return "", nil
 	case d.Skip[i] == skipOverlap || d.Skip[i] == skipNoLongerFits: // :471-484
 		return kueue.WorkloadQuotaReservedReasonWaitingForQuota, nil

@@ -244,3 +244,17 @@ def test_quota_reserved_reason_of_the_tas_schedule_table(oracle, case):
     finally:
         eng.close()
     assert {w.name: N.quota_reserved_reason(d, i, bool(cfg.fair_sharing), tas_fl) for i, w in enumerate(heads.workloads)} == got
+
+
+def test_an_evicted_second_pass_head_has_no_reason(oracle):
+    """handleFailedTASReplacement (scheduler.go:426-429, :525-531) returns before any quotaReservedReason is set: the workload is evicted, not
+    requeued with a condition."""
+    from kueue_amd import _ffi as F
+    from kueue_amd import no_fit_reason as N
+    case = next(c for c in load_golden("schedule_tas.yaml")["cases"]
+                if c["name"] == "workload with unhealthyNode annotation; second pass; preferred; no fit; FailFast")
+    cfg, snap, heads, ct = load_tas_case(case)
+    oracle.derive(snap)
+    d, _ = oracle.cycle_run_tas(cfg, snap, heads, ct, tgt_cap=16, rsn_cap=256)
+    assert int(d.a["status"][0]) == F.ST_EVICTED
+    assert N.quota_reserved_reason(d, 0, False, {snap.flavor_index[n] for n in ct.names}) == ""
