@@ -186,7 +186,19 @@ def parse_podsets(text):
                 ps["requests"][res_name(r.group(1))] = r.group(2)
         if re.search(r"PodSetGroup", seg):
             return "group"
-        if re.search(r"RequiredDuringScheduling|Affinity|SetMinimumCount|TopologyRequest", seg):
+        if re.search(r"SetMinimumCount|TopologyRequest", seg):
+            return None
+        aff = re.search(r"RequiredDuringSchedulingIgnoredDuringExecution\(", seg)
+        if aff:   # node affinity: terms ORed, expressions ANDed; only NodeSelectorOpIn appears in the table
+            body = re.sub(r"//[^\n]*", "", seg[aff.end(): match_brace(seg, aff.end() - 1, "(", ")")])
+            terms = []
+            for t in body.split("MatchExpressions:")[1:]:
+                exprs = re.findall(r'Key:\s*"([^"]+)",\s*Operator:\s*corev1\.NodeSelectorOp(\w+),\s*Values:\s*\[\]string\{([^}]*)\}', t)
+                if any(op != "In" for _, op, _ in exprs):
+                    return None
+                terms.append([(k, re.findall(r'"([^"]*)"', v)) for k, _, v in exprs])
+            ps["affinity_terms"] = terms
+        elif re.search(r"Affinity", seg):
             return None
         sel = re.search(r"NodeSelector\(map\[string\]string\{([^}]*)\}\)", seg)
         if sel:   # spec.nodeSelector: evaluated against each flavor's OWN label keys below (flavorSelector flavorassigner.go:1264-1298)
@@ -247,7 +259,7 @@ def main():
         block = table[m.end():j]
         name = m.group(1)
         line = src[: body_start + 1 + m.start()].count("\n") + 1
-        if re.search(r"preemptWorkloadSlice|topologies|TopologyRequest|wlReclaimablePods|tas-|DelayedTopology", block):
+        if re.search(r"preemptWorkloadSlice|topologies|TopologyRequest|tas-|DelayedTopology", block):
             skipped.append((name, "TAS / workload slices / reclaimable pods: outside the engine boundary")); continue
         pods = parse_podsets(field(block, "wlPods") or "")
         if pods == "group":
@@ -262,8 +274,18 @@ def main():
         if fg:
             for g, v in re.findall(r"features\.(\w+):\s*(true|false)", fg):
                 gates[g] = v == "true"
-            if any(g not in ("FlavorFungibility", "QuotaCheckStrategy") for g in gates):
+            if any(g not in ("FlavorFungibility", "QuotaCheckStrategy", "ReclaimablePods") for g in gates):
                 skipped.append((name, f"feature gate {list(gates)} not modelled")); continue
+        # Status.ReclaimablePods: workload.NewInfo subtracts them from the podset's count before Assign sees it (workload.go totalRequestsFromPodSets,
+        # gate ReclaimablePods) — the host side of the boundary; the row is transcribed with the count the scheduler is handed
+        rp = field(block, "wlReclaimablePods")
+        if rp and gates.pop("ReclaimablePods", True):
+            for r in re.finditer(r"Name:\s*([^,]+),\s*Count:\s*(\d+)", rp):
+                nm = "main" if r.group(1).strip() == "kueue.DefaultPodSetName" else r.group(1).strip().strip('"')
+                for ps in pods:
+                    if ps["name"] == nm:
+                        ps["count"] -= int(r.group(2)); ps["reclaimed"] = int(r.group(2))
+        gates.pop("ReclaimablePods", None)
         all_flavors = {f["flavor"] for q in (cq, cq2) if q for rg in q["resourceGroups"] for f in rg}
         if "nonexistent-flavor" in all_flavors or "non-existent" in " ".join(all_flavors):
             skipped.append((name, "missing ResourceFlavor object")); continue
@@ -271,13 +293,23 @@ def main():
         for ps in pods:
             excl = [f for f in sorted(all_flavors) if f in TAINTED and not ps["tolerates_spot"]]
             sel = ps.pop("node_selector", None)
-            if sel:
+            terms = ps.pop("affinity_terms", None)
+            if sel or terms:
                 for f in sorted(all_flavors):
                     labels = flavor_labels(src).get(f, {})
-                    if f not in excl and any(k in labels and labels[k] != v for k, v in sel.items()):
+                    ok = not any(k in labels and labels[k] != v for k, v in (sel or {}).items())
+                    # flavorSelector :1264-1298: every term keeps only the expressions on the flavor's OWN label keys; a term left empty matches
+                    # any flavor (terms are ORed) and the affinity reduces to spec.nodeSelector
+                    kept = [[(k, vs) for k, vs in t if k in labels] for t in (terms or [])]
+                    if kept and all(kept):
+                        ok = ok and any(all(labels[k] in vs for k, vs in t) for t in kept)
+                    if f not in excl and not ok:
                         excl.append(f)
                         inel[f] = f"flavor {f} doesn't match node affinity"   # checkFlavorForPodSets :1256
-                ps["nodeSelector"] = sel
+                if sel:
+                    ps["nodeSelector"] = sel
+                if terms:
+                    ps["nodeAffinityTerms"] = [{k: vs for k, vs in t} for t in terms]
             if excl:
                 ps["excludedFlavors"] = sorted(excl)
             del ps["tolerates_spot"]
