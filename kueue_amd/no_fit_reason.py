@@ -26,7 +26,7 @@ from . import messages as M
 
 LABELS = ["", "TopologyPlacementFailed", "WaitingForQuota", "ExceedsMaxQuota", "NoMatchingFlavor"]   # reasonSeverity flavorassigner.go:306-327
 NONE, TOPOLOGY, WAITING, EXCEEDS, NO_MATCH = range(5)
-NOFIT, PREEMPT, FIT = 0, 1, 3   # FlavorAssignmentMode as kq_decisions carries it (KQ_MODE_*; 2 = DeferredFit, set after Assign)
+NOFIT, PREEMPT, DEFERRED_FIT, FIT = 0, 1, 2, 3   # FlavorAssignmentMode as kq_decisions carries it (KQ_MODE_*; DeferredFit is set after Assign)
 U = (1 << 63) - 1
 MINI = -(1 << 63)
 
@@ -202,7 +202,7 @@ def quota_reserved_reason(dec, i: int, fair_sharing: bool, tas_flavors: Optional
     mode = int(a["mode"][i])
     if mode == NOFIT:                                                  # :430-435
         return LABELS[flavor_attempts(dec, i, fair_sharing, tas_flavors, tree)[0]]
-    if mode == 2:                                                      # DeferredFit :455-468
+    if mode == DEFERRED_FIT:                                           # :455-468
         return "WaitingForPreemptedWorkloads"
     if int(a["action"][i]) == F.ACT_PREEMPT:                           # :495
         return "WaitingForPreemptedWorkloads"

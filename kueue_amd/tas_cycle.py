@@ -297,6 +297,11 @@ class CycleTAS:
     def struct(self) -> kq_cycle_tas:
         return self._struct
 
+    def grouped_scan_risk(self) -> List[int]:
+        """Heads of this cycle whose flavor assignment may differ from the reference's one-scan-per-PodSetGroupName (grouped_scan_risk above);
+        [] proves that it cannot."""
+        return grouped_scan_risk(self.snap, self.heads, self.arrays["ps_group"])
+
 
 class CycleTASOut:
     def __init__(self, ct: CycleTAS, dom_cap: Optional[int] = None):
