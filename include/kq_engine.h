@@ -214,6 +214,12 @@ typedef struct kq_heads {
   const int64_t* req_slice_qty;     /* [n_req] the old slice's request for (podset, resource) */
   const int32_t* ps_slice_pods_flavor; /* [n_ps] the same two for the `pods` request the assigner injects (flavorassigner.go:743-749) */
   const int64_t* ps_slice_pods_qty; /* [n_ps] */
+  /* PodSet groups (PodSet.TopologyRequest.PodSetGroupName): assignFlavors runs ONE flavor scan per group over the sum of the members'
+   * requests (flavorassigner.go:782-860), every member then keeps the group's flavors for the resources it requests itself
+   * (resolvePodSetFlavors :917-945) and the group's Status. NULL: no podset of the batch is in a group (kq_cycle_run_tas: NULL = take
+   * kq_cycle_tas.ps_group). The members of a group must be consecutive podsets of their head (KQ_EUNSUPPORTED otherwise), and a head
+   * that replaces a workload slice holds no group of several podsets. */
+  const int32_t* ps_group;          /* [n_ps] group id (any value >= 0, equal inside a group), -1 = none */
 } kq_heads;
 
 /* ---- decisions -------------------------------------------------------------------------------- */

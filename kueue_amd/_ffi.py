@@ -146,6 +146,7 @@ class kq_heads(C.Structure):
         ("last_generation", i64p), ("last_cycle", i64p), ("last_hash", u64p), ("hash", u64p),
         ("slice_row", i32p), ("ps_slice_count", i32p), ("req_slice_flavor", i32p), ("req_slice_qty", i64p),
         ("ps_slice_pods_flavor", i32p), ("ps_slice_pods_qty", i64p),
+        ("ps_group", i32p),
     ]
 
 

@@ -180,6 +180,8 @@ class PodSet:
     flavors: Dict[str, str] = field(default_factory=dict)
     # pending workloads: flavors for which checkFlavorForPodSets fails (taints / affinity), host-evaluated
     excluded_flavors: List[str] = field(default_factory=list)
+    # PodSet.TopologyRequest.PodSetGroupName: the podsets of one group share ONE flavor scan (flavorassigner.go:782-790)
+    group: Optional[str] = None
 
     def Request(self, resource: str, per_pod) -> "PodSet":
         self.requests[resource] = sat(resource_value(resource, per_pod) * self.count) if self.count else 0
@@ -585,6 +587,12 @@ class Heads:
             a["slice_row"] = np.array(srow, np.int32); a["ps_slice_count"] = np.array(scnt, np.int32)
             a["req_slice_flavor"] = np.array(sfl, np.int32); a["req_slice_qty"] = np.array(sq, np.int64)
             a["ps_slice_pods_flavor"] = np.array(spf, np.int32); a["ps_slice_pods_qty"] = np.array(spq, np.int64)
+        if any(ps.group is not None for w in self.workloads for ps in w.pod_sets):
+            grp = []
+            for w in self.workloads:
+                ids: Dict[str, int] = {}
+                grp += [-1 if ps.group is None else ids.setdefault(ps.group, len(ids)) for ps in w.pod_sets]
+            a["ps_group"] = np.array(grp, np.int32)
         self.arrays = a
         self.n = n
         self.n_ps = len(ps_count)
@@ -629,6 +637,8 @@ class Heads:
         if "slice_row" in a:  # workload slices travel with their heads
             b.update(slice_row=a["slice_row"][idx], ps_slice_count=a["ps_slice_count"][ps_idx], req_slice_flavor=a["req_slice_flavor"][req_idx],
                      req_slice_qty=a["req_slice_qty"][req_idx], ps_slice_pods_flavor=a["ps_slice_pods_flavor"][ps_idx], ps_slice_pods_qty=a["ps_slice_pods_qty"][ps_idx])
+        if "ps_group" in a:
+            b["ps_group"] = a["ps_group"][ps_idx]
         h = Heads.from_arrays(self.snap, b, cycle=self.cycle if cycle is None else cycle)
         if self.workloads is not None:
             h.workloads = [self.workloads[int(i)] for i in idx]

@@ -291,6 +291,7 @@ struct DHeads {
   const int64_t* req_slice_qty;
   const int32_t* ps_slice_pods_flavor;
   const int64_t* ps_slice_pods_qty;
+  const int32_t* ps_group;   // [n_ps] PodSetGroupName id, -1 = none; null: no podset groups in the batch (kq_heads.ps_group)
 };
 
 KQ_DEV int hn(const DHeads& H) { return H.n_dev ? H.n_dev[0] : H.n; }
@@ -857,6 +858,7 @@ KQ_DEV void tc_update_assignment(const K& k, Wave& w, int slot, const int32_t* t
 KQ_NOINLINE void tc_publish(const K& k, Wave& w, int slot);
 KQ_DEV int tc_adm_flavor(const K& k, int psg, int res);
 KQ_DEV void tc_sp_reset(const K& k, int psg);
+KQ_DEV bool tc_is_tas_flavor(const K& k, int flavor);
 #endif
 KQ_DEV int64_t pref_key(int pm, int64_t borrow, uint32_t pol) {
   if (pm == PM_NOFIT) return -1;
@@ -2038,6 +2040,119 @@ KQ_DEV void slice_of(const K& k, const Wave& w, int psg, int a, int* flavor, int
   *qty = H.req_slice_qty ? H.req_slice_qty[e] : 0;
 }
 
+// ---- PodSetGroupName groups (flavorassigner.go:782-860) ---------------------------------------------------------------------------
+// The podsets of one group are ONE flavor scan over the sum of their requests (requests.Add over the members, :786-790), eligible where
+// EVERY member is (checkFlavorForPodSets walks psIDs, :1234), resumed from the FIRST member's bookmark (:1092), pinned to a flavor ANY
+// member was nominated on (:1422); each member then keeps the group's flavors for the resources it requests itself — a member that
+// requests nothing keeps the group's TAS flavors — (resolvePodSetFlavors :917-945) and the group's Status. Members are consecutive
+// podsets of their head (the host checks). A podset outside any group is a group of one and takes the code it always took.
+KQ_DEV int group_len(const K& k, const Wave& w, int pi) {
+  const int32_t* grp = k.H.ps_group;
+  if (!grp) return 1;
+  const int gid = grp[w.ps_base + pi];
+  if (gid < 0) return 1;
+  int gn = 1;
+  while (pi + gn < w.nps && grp[w.ps_base + pi + gn] == gid) gn++;
+  return gn;
+}
+// the effective requests of podset pi, one after the other (ScaledTo workload.go:317-340; the injected `pods`, flavorassigner.go:743-749):
+// fn(resource, quantity); returns how many there are (Requests.Len())
+template <class F> KQ_DEV int member_requests(const K& k, const Wave& w, int pi, const int* counts, bool pods_cov, F&& fn) {
+  const DHeads& H = k.H;
+  const int psg = w.ps_base + pi;
+  const int count = H.ps_count[psg], new_count = counts ? counts[pi] : count;
+  const bool scale = counts && count != 0 && count != new_count;
+  bool have_pods = false;
+  int n = 0;
+  for (int e = H.ps_req_off[psg]; e < H.ps_req_off[psg + 1]; e++) {
+    const int r = H.req_res[e];
+    int64_t q = H.req_qty[e];
+    if (scale) q = sat_mul(q / (int64_t)count, (int64_t)new_count);
+    if (pods_cov && r == k.S.pods_res) { q = scale ? new_count : count; have_pods = true; }
+    fn(r, q); n++;
+  }
+  if (pods_cov && !have_pods) { fn(k.S.pods_res, (int64_t)(scale ? new_count : count)); n++; }
+  return n;
+}
+// w.req_* = the sum of the members' requests, in arrival order (lane 0; the caller sorts them into Requests.Iter order)
+KQ_NOINLINE void group_requests(const K& k, Wave& w, int pi, int gn, const int* counts, bool pods_cov) {
+  if (lane_id() == 0) {
+    int n = 0;
+    for (int m = 0; m < gn; m++)
+      member_requests(k, w, pi + m, counts, pods_cov, [&](int r, int64_t q) {
+        for (int b = 0; b < n; b++) if (w.req_res[b] == r) { w.req_qty[b] = sat_add(w.req_qty[b], q); return; }   // SliceRequests.Add: SaturatingAdd
+        if (n >= KQ_MAXREQ) { *k.O.error = KQ_EUNSUPPORTED; return; }
+        w.req_res[n] = r; w.req_qty[n] = q; w.req_src[n] = 0; n++;
+      });
+    w.nreq = n;
+    if (w.slice_row >= 0) *k.O.error = KQ_EUNSUPPORTED;   // (a workload slice with a group of several podsets: the host refuses the batch)
+  }
+  wsync();
+}
+// one flavor of the assignment goes to podset psg / resource res: the output row, Assignment.append's usage entry (:1017-1041)
+KQ_DEV void group_take(const K& k, Wave& w, int psg, int a, int64_t amount) {
+  const DOut& O = k.O;
+  const int nR = k.S.nR, res = w.req_res[a];
+  const size_t o = (size_t)psg * nR + res;
+  O.flavor[o] = w.req_flavor[a]; O.res_mode[o] = w.req_mode[a]; O.tried_idx[o] = w.req_tried[a];
+  if (w.req_borrow[a] > w.borrowing) w.borrowing = w.req_borrow[a];
+  const int fr = w.req_flavor[a] * nR + res;
+  int e = -1;
+  for (int i = 0; i < w.nuse; i++) if (w.use_fr[i] == fr) e = i;
+  if (e < 0) {
+    if (w.nuse >= KQ_MAXU) { *O.error = KQ_EUNSUPPORTED; return; }
+    e = w.nuse++; w.use_fr[e] = fr; w.use_qty[e] = 0; w.use_mode[e] = M_FIT;
+  }
+  w.use_qty[e] = a_addi(w.use_qty[e], amount);
+  if (w.req_mode[a] < w.use_mode[e]) w.use_mode[e] = w.req_mode[a];
+  w.bytes += 16;
+}
+// the members of a group behind its scan: flavors, usage, Status and RepresentativeMode of each (flavorassigner.go:836-847). Returns the
+// weakest member's mode; *failed = atLeastOnePodsAssignmentFailed.
+KQ_NOINLINE int group_finish(const K& k, Wave& w, int pi, int gn, const int* counts, bool pods_cov, bool group_failed, int reasons, bool* failed) {
+  const int lane = lane_id();
+  int rep = M_FIT;
+  bool bad = false;
+  if (lane == 0 && k.O.rsn_win > 0) {   // podSetAssignment.Status = groupStatus for every member: the first member's records once more for each of the others
+    RsnRec* win = k.O.rsn + (size_t)w.h * k.O.rsn_win;
+    const int cnt = w.nrsn - w.rsn_ps0;
+    for (int m = 1; m < gn; m++)
+      for (int q = 0; q < cnt; q++) {
+        if (w.nrsn >= k.O.rsn_win) { w.rsn_over = 1; break; }
+        RsnRec r = win[w.rsn_ps0 + q]; r.podset = (uint8_t)(pi + m);
+        win[w.nrsn++] = r;
+      }
+  }
+  for (int m = 0; m < gn; m++) {
+    const int psg = w.ps_base + pi + m;
+    int nfl = 0, mode = M_FIT;
+    // (every lane walks the member's few requests; lane 0 writes)
+    const int mreq = member_requests(k, w, pi + m, counts, pods_cov, [&](int r, int64_t q) {
+      if (group_failed) return;
+      int a = -1;
+      for (int b = 0; b < w.nreq; b++) if (w.req_res[b] == r) a = b;
+      if (a < 0 || !w.req_done[a]) return;
+      nfl++; if (w.req_mode[a] < mode) mode = w.req_mode[a];
+      if (lane == 0) group_take(k, w, psg, a, q);
+    });
+#ifdef KQ_TAS_CYCLE
+    if (mreq == 0 && !group_failed && k.tc)   // tasFlavorsOnly :996: "a PodSet with no resource requests in a topology group (e.g. an LWS leader) still needs a resolved TAS flavor"
+      for (int a = 0; a < w.nreq; a++) {
+        if (!w.req_done[a] || !tc_is_tas_flavor(k, w.req_flavor[a])) continue;
+        nfl++; if (w.req_mode[a] < mode) mode = w.req_mode[a];
+        if (lane == 0) group_take(k, w, psg, a, 0);
+      }
+#endif
+    if (lane == 0) w.bytes += (int64_t)mreq * 8;
+    const int pmode = reasons == 0 ? M_FIT : (nfl == 0 ? M_NOFIT : mode);   // PodSetAssignment.RepresentativeMode :386-404
+    if (pmode < rep) rep = pmode;
+    bad |= mreq > 0 && nfl == 0;
+  }
+  wsync();
+  *failed = bad;
+  return rep;
+}
+
 template <bool LEAN>
 KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed,
                            const int* counts, bool nominate_map) {
@@ -2053,9 +2168,11 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
   int rep = M_FIT;
   bool any_ps = false;
   const bool pods_cov = S.pods_res >= 0 && rg_by_resource(S, w.cq, S.pods_res) >= 0;
-  for (int pi = 0; pi < w.nps; pi++) {
+  int gn = 1;
+  for (int pi = 0; pi < w.nps; pi += gn) {
     const int psg = w.ps_base + pi;
     any_ps = true;
+    gn = group_len(k, w, pi);   // the podsets [pi, pi + gn) share one flavor scan (PodSetGroupName); 1 = a podset on its own
     // ---- effective requests -------------------------------------------------------------
     int count = H.ps_count[psg];
     int new_count = counts ? counts[pi] : count;
@@ -2066,6 +2183,8 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
     const int ne = ne_raw < KQ_MAXREQ ? ne_raw : KQ_MAXREQ;
     if (ne_raw > KQ_MAXREQ && lane == 0) *O.error = KQ_EUNSUPPORTED;
     bool is_pods = false;
+    if (gn > 1) group_requests(k, w, pi, gn, counts, pods_cov);   // the sum of the members' requests (requests.Add :789)
+    else {
     for (int a = lane; a < ne; a += WAVE) {
       int64_t q = H.req_qty[e0 + a];
       if (scale) q = sat_mul(q / (int64_t)count, (int64_t)new_count);
@@ -2084,6 +2203,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
       w.nreq = n;
     }
     wsync();
+    }
     {  // Requests.Iter order (slice_requests.go:54-60)
       const int n = w.nreq;
 #ifdef KQ_HOST_EMU
@@ -2104,13 +2224,16 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
       wsync();
       if (lane < n) { w.req_res[rank] = r; w.req_qty[rank] = q; w.req_src[rank] = (uint8_t)sr; w.req_done[rank] = 0; w.req_rg[rank] = S.cq_res_rg[(size_t)w.cq * nR + r]; }
 #endif
-      if (lane == 0) w.bytes += (int64_t)n * 16;  // requests in + requests echoed in the PodSetAssignment
+      if (lane == 0) w.bytes += (int64_t)n * (gn > 1 ? 8 : 16);  // requests in + requests echoed in the PodSetAssignment (a group: its members echo theirs, group_finish)
     }
     wsync();
     // (the nomination mapping of a recomputation, X.nom, was taken before O.flavor is overwritten: process_entry)
     // clear the podset's output rows
-    for (int r = lane; r < nR; r += WAVE) { O.flavor[(size_t)psg * nR + r] = -1; O.res_mode[(size_t)psg * nR + r] = M_NOFIT; O.tried_idx[(size_t)psg * nR + r] = -1; }
-    if (lane == 0) O.ps_count[psg] = scale ? new_count : count;
+    for (int r = lane; r < gn * nR; r += WAVE) { O.flavor[(size_t)psg * nR + r] = -1; O.res_mode[(size_t)psg * nR + r] = M_NOFIT; O.tried_idx[(size_t)psg * nR + r] = -1; }
+    if (lane == 0) {
+      O.ps_count[psg] = scale ? new_count : count;
+      for (int m = 1; m < gn; m++) { const int c0 = H.ps_count[psg + m], c1 = counts ? counts[pi + m] : c0; O.ps_count[psg + m] = (counts && c0 != 0) ? c1 : c0; }
+    }
     wsync();
     if (LEAN || KQ_TAS_PROCESS(k, w)) KQ_TS(k, 57);  // lean: requests of the podset in iterator order, output rows cleared
     bool group_failed = false;
@@ -2119,12 +2242,14 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
     if constexpr (!LEAN) if (k.tc) {
       // "Respect preexisting assignments. The PodSet assignments may be already set if this is the second pass of scheduler"
       // (flavorassigner.go:765-779): the admission's flavor, mode Fit, TriedFlavorIdx 0, and no flavor scan for the resource (:819)
-      tc_sp_reset(k, psg);
-      for (int a = 0; a < w.nreq; a++) {
-        const int fl = tc_adm_flavor(k, psg, w.req_res[a]);
-        if (fl < 0) continue;
-        ps_nflavors++;
-        if (lane == 0) { w.req_done[a] = 1; w.req_flavor[a] = fl; w.req_mode[a] = M_FIT; w.req_borrow[a] = 0; w.req_tried[a] = 0; }
+      for (int m = 0; m < gn; m++) {   // (a group: "seed the dedup memo with every prior-pass assignment, not just one" :801-804 — maps.Copy in member order)
+        tc_sp_reset(k, psg + m);
+        for (int a = 0; a < w.nreq; a++) {
+          const int fl = tc_adm_flavor(k, psg + m, w.req_res[a]);
+          if (fl < 0) continue;
+          if (lane == 0) { w.req_done[a] = 1; w.req_flavor[a] = fl; w.req_mode[a] = M_FIT; w.req_borrow[a] = 0; w.req_tried[a] = 0; }
+          wsync();
+        }
       }
       wsync();
     }
@@ -2145,7 +2270,15 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
       // ---- findFlavorForPodSets :1065-1210 ---------------------------------------------
       if (lane == 0) {
         int nf = 0;
-        for (int b = 0; b < w.nreq; b++) if (w.req_rg[b] == gl) { w.f_res[nf] = w.req_res[b]; w.f_qty[nf] = w.req_qty[b]; w.f_slot[nf] = (uint8_t)b; nf++; }
+        // filterRequestedResources :1391: the requests group g covers. With overlapping groups (two groups of the ClusterQueue covering one
+        // resource — the webhook rejects the spec, the cache keeps it; flavorassigner_test.go:505) that is more than the requests whose
+        // RGByResource is g: the scan takes them all and its flavors overwrite what an earlier scan gave them (maps.Copy :831)
+        const bool overlap = (w.pol & KQ_POL_DEV_RG_OVERLAP) != 0;
+        for (int b = 0; b < w.nreq; b++) {
+          bool cov = w.req_rg[b] == gl;
+          if (!cov && overlap) for (int i = S.rg_res_off[g]; i < S.rg_res_off[g + 1]; i++) cov = cov || S.rg_res[i] == w.req_res[b];
+          if (cov) { w.f_res[nf] = w.req_res[b]; w.f_qty[nf] = w.req_qty[b]; w.f_slot[nf] = (uint8_t)b; nf++; }
+        }
         w.nf = nf;
         w.rsn_g0 = w.nrsn;
       }
@@ -2167,8 +2300,13 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
           int j = cs + c / nf, kk = c % nf;
           int f = S.rg_flavor[f0 + j];
           bool ok = (H.ps_flavor_ok[(size_t)psg * S.nfw + (f >> 6)] >> (f & 63)) & 1;  // checkFlavorForPodSets :1212 (host-evaluated)
+          for (int m = 1; m < gn; m++) ok = ok && ((H.ps_flavor_ok[(size_t)(psg + m) * S.nfw + (f >> 6)] >> (f & 63)) & 1);   // ... for every podset of the group (:1234)
           uint8_t pm = PM_SKIP; int32_t borrow = ok ? 0 : KQ_RSN_FLAVOR_INELIGIBLE; int64_t val = 0, aux = 0;  // a skipped cell keeps WHY in `borrow`
-          if (nominate_map && k.X.nom[((size_t)slot * KQ_MAXPS + pi) * nR + res_name] != f) { ok = false; borrow = KQ_RSN_NOT_IN_NOMINATION; }  // shouldSkipBasedOnNominationMapping :1422 (checked first, :1096)
+          if (nominate_map) {  // shouldSkipBasedOnNominationMapping :1422 (checked first, :1096): kept when ANY podset of the group was nominated on the flavor
+            bool keep = false;
+            for (int m = 0; m < gn; m++) keep = keep || k.X.nom[((size_t)slot * KQ_MAXPS + pi + m) * nR + res_name] == f;
+            if (!keep) { ok = false; borrow = KQ_RSN_NOT_IN_NOMINATION; }
+          }
           bool mismatch = false;
           if (ok) {
             int fr = f * nR + w.f_res[kk];
@@ -2332,12 +2470,17 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
         }
       }
       wsync();
-      for (int kk = 0; kk < nf; kk++) { ps_nflavors++; if (w.best_mode[kk] < ps_mode) ps_mode = w.best_mode[kk]; }
       if (!status_nil) ps_reasons += reasons;
     }
     // PodSetAssignment.RepresentativeMode :386-404 ; Assignment.append :1017-1041
     int pmode;
-    if (group_failed) {
+    // atLeastOnePodsAssignmentFailed :842-845: a podset that requests something and ends without any flavor — also when every request of
+    // it was skipped (:809-817) and no scan ran at all
+    ps_nflavors = 0;   // the flavors the podset (group) ends with: seeds of the second pass, the scans' (a later scan may have overwritten an earlier one's)
+    for (int a = 0; a < w.nreq; a++) if (w.req_done[a]) { ps_nflavors++; if (w.req_mode[a] < ps_mode) ps_mode = w.req_mode[a]; }
+    bool failed = w.nreq > 0 && (group_failed || ps_nflavors == 0);
+    if (gn > 1) pmode = group_finish(k, w, pi, gn, counts, pods_cov, group_failed, ps_reasons, &failed);
+    else if (group_failed) {
       // groupFlavors = nil: the podset keeps no flavor and contributes no usage
       pmode = ps_reasons == 0 ? M_FIT : M_NOFIT;
     } else {
@@ -2365,14 +2508,14 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
       wsync();
     }
     if (pmode < rep) rep = pmode;
-    if (group_failed && w.nreq > 0) {  // atLeastOnePodsAssignmentFailed :848-853: later podsets are never assigned
-      for (int i = lane + (pi + 1) * nR; i < w.nps * nR; i += WAVE) {
+    if (failed) {  // :848-853: later podsets are never assigned
+      for (int i = lane + (pi + gn) * nR; i < w.nps * nR; i += WAVE) {
         size_t o = (size_t)w.ps_base * nR + i;
         O.flavor[o] = -1; O.res_mode[o] = M_NOFIT; O.tried_idx[o] = -1;
       }
-      for (int q = pi + 1 + lane; q < w.nps; q += WAVE) O.ps_count[w.ps_base + q] = H.ps_count[w.ps_base + q];
+      for (int q = pi + gn + lane; q < w.nps; q += WAVE) O.ps_count[w.ps_base + q] = H.ps_count[w.ps_base + q];
 #ifdef KQ_TAS_CYCLE
-      if (k.tc && lane == 0) w.ta.af_early = pi + 1;
+      if (k.tc && lane == 0) w.ta.af_early = pi + gn;
 #endif
       wsync();
       break;

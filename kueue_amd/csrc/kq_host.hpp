@@ -264,7 +264,7 @@ template <class B> struct EngineT {
     S.rg_flavor = upload(s->rg_flavor, s->rg_flavor_off[prep.n_rg]);
     S.rg_res_off = upload(s->rg_res_off, prep.n_rg + 1);
     S.rg_res = upload(s->rg_res, s->rg_res_off[prep.n_rg]);
-    S.cq_policy = upload(s->cq_policy, nq);
+    S.cq_policy = upload(prep.cq_policy_dev.data(), nq);
     S.cq_thr = upload(s->cq_borrow_prio_threshold, nq);
     S.cq_gen = upload(s->cq_generation, nq);
     S.cq_adm_off = upload(s->cq_adm_off, nq + 1);
@@ -831,9 +831,35 @@ template <class B> struct EngineT {
         if (row < -1 || row >= prep.n_adm) return fail(KQ_EINVAL, "slice_row out of range");
         if (row >= 0 && h_adm_cq[row] != h->cq[i]) return fail(KQ_EINVAL, "slice_row: the replaced slice is not admitted in the head's ClusterQueue");
       }
+    // PodSetGroupName groups (kq_heads.ps_group): consecutive podsets of their head (the reference appends a group's podsets together,
+    // orderedgroups.InOrder, so an interleaved group would reorder Assignment.PodSets), their summed requests within KQ_MAXREQ, and no
+    // group of several podsets on a head that replaces a workload slice
+    if (h->ps_group)
+      for (int i = 0; i < h->n; i++)
+        for (int p = h->ps_off[i]; p < h->ps_off[i + 1]; p++) {
+          const int gid = h->ps_group[p];
+          if (gid < 0 || (p > h->ps_off[i] && h->ps_group[p - 1] == gid)) continue;   // not in a group / not the first member
+          int last = p;
+          std::vector<int32_t> res;
+          for (int q = p; q < h->ps_off[i + 1]; q++) {
+            if (h->ps_group[q] != gid) continue;
+            if (q > last + 1) return fail(KQ_EUNSUPPORTED, "the podsets of a PodSetGroupName group must be consecutive");
+            last = q;
+            for (int e = h->ps_req_off[q]; e < h->ps_req_off[q + 1]; e++) if (std::find(res.begin(), res.end(), h->req_res[e]) == res.end()) res.push_back(h->req_res[e]);
+          }
+          if (last > p && (int)res.size() + 1 > KQ_MAXREQ) return fail(KQ_EUNSUPPORTED, "more resources in a podset group than KQ_MAXREQ");
+          if (last > p && h->slice_row && h->slice_row[i] >= 0) return fail(KQ_EUNSUPPORTED, "a workload slice with a podset group of several podsets");
+        }
     *slot_cap = cap;
     if (max_nps) *max_nps = mnps;
     return KQ_OK;
+  }
+  // the pending side (kq_pending_*) keeps no PodSetGroupName column
+  bool heads_grouped(const kq_heads* h) const {
+    if (!h->ps_group) return false;
+    const size_t nps = h->n > 0 ? (size_t)h->ps_off[h->n] : 0;
+    for (size_t p = 0; p < nps; p++) if (h->ps_group[p] >= 0) return true;
+    return false;
   }
 
   // Make one batch of heads resident in HBM. slot 0 is the transient batch of kq_cycle_run.
@@ -863,6 +889,8 @@ template <class B> struct EngineT {
     const bool sl = h->slice_row != nullptr;
     const size_t o_srow = place(sl ? n * 4 : 0), o_scnt = place(sl ? nps * 4 : 0), o_sfl = place(sl ? nreqs * 4 : 0), o_sq = place(sl ? nreqs * 8 : 0),
                  o_spf = place(sl ? nps * 4 : 0), o_spq = place(sl ? nps * 8 : 0);
+    const bool grp = heads_grouped(h);
+    const size_t o_grp = place(grp ? nps * 4 : 0);
     const size_t total = off;
     if (hup_cap < total) { if (hup) be.free_host(hup); hup_cap = total + total / 4; hup = (uint8_t*)be.alloc_host(hup_cap); }
     if (!hup) { hup_cap = 0; return fail(KQ_EDEVICE, "pinned staging buffer for the heads could not be allocated"); }
@@ -886,10 +914,12 @@ template <class B> struct EngineT {
       if (h->ps_slice_pods_flavor) put(o_spf, h->ps_slice_pods_flavor, nps * 4); else fill(o_spf, 0xff, nps * 4);
       if (h->ps_slice_pods_qty) put(o_spq, h->ps_slice_pods_qty, nps * 8); else fill(o_spq, 0, nps * 8);
     }
+    if (grp) put(o_grp, h->ps_group, nps * 4);
     uint8_t* d = grow<uint8_t>(hbch.hb[0], total);
     be.h2d(d, hup, total);
     DHeads& H = hbch.H;
     H.n = n;
+    H.ps_group = grp ? (const int32_t*)(d + o_grp) : nullptr;
     H.cq = (const int32_t*)(d + o_cq); H.priority = (const int64_t*)(d + o_prio); H.queue_ts = (const int64_t*)(d + o_ts);
     H.flags = (const uint32_t*)(d + o_flags); H.ps_off = (const int32_t*)(d + o_psoff); H.ps_count = (const int32_t*)(d + o_pscnt);
     H.ps_min_count = (const int32_t*)(d + o_psmin); H.ps_req_off = (const int32_t*)(d + o_reqoff); H.req_res = (const int32_t*)(d + o_rres);
@@ -945,7 +975,9 @@ template <class B> struct EngineT {
     if (!t || !tout || !tout->ps_tas || !tout->dom_off) return fail(KQ_EINVAL, "null kq_cycle_tas / kq_cycle_tas_out");
     if (t->n_tas < 0) return fail(KQ_EINVAL, "negative n_tas");
     shard_heads_ok = false;
-    int rc = heads_put(h, 0);
+    kq_heads hg = *h;   // the flavor scan's podset groups: the heads' own column, else the TAS side's (one PodSetGroupName, two consumers)
+    if (!hg.ps_group) hg.ps_group = t->ps_group;
+    int rc = heads_put(&hg, 0);
     if (rc != KQ_OK) return rc;
     const int n = batches[0].n;
     const size_t nps = batches[0].nps;
@@ -1714,6 +1746,7 @@ template <class B> struct EngineT {
     int slot_cap = 1, max_nps = 1; bool plain = true;
     int rc = validate_heads(h, &slot_cap, &plain, &max_nps);
     if (rc != KQ_OK) return rc;
+    if (heads_grouped(h)) return fail(KQ_EUNSUPPORTED, "kq_pending_*: workloads with PodSetGroupName groups are not kept resident (kq_cycle_run / kq_cycle_run_tas take them)");
     pending_free();
     const int W = h->n, nq = prep.nq, nR = prep.nR;
     const size_t nfw = (prep.nF + 63) / 64;
@@ -2088,6 +2121,7 @@ template <class B> struct EngineT {
     int slot_cap = 1, max_nps = 1; bool plain = true;
     int rc = validate_heads(h, &slot_cap, &plain, &max_nps);
     if (rc != KQ_OK) return rc;
+    if (heads_grouped(h)) return fail(KQ_EUNSUPPORTED, "kq_pending_*: workloads with PodSetGroupName groups are not kept resident (kq_cycle_run / kq_cycle_run_tas take them)");
     Pending& P = pend;
     const int n = h->n, W0 = P.W, nq = prep.nq, nR = prep.nR;
     if (first_index) *first_index = W0;

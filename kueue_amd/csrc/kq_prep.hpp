@@ -21,6 +21,7 @@ constexpr int KQ_MAXD = 8;      // max nodes on a CQ->root path (CQ + 7 cohort l
 constexpr int KQ_MAXREQ = 16;   // max resources requested by one podset (incl. injected "pods")
 constexpr int KQ_MAXU = 56;     // max (flavor,resource) entries in one assignment's usage (18 podsets x (2 resources + pods))
 constexpr int KQ_MAXPS = 18;    // max podsets per workload = the API limit (apis/kueue/v1beta2/workload_types.go:36 MaxItems=18)
+constexpr uint32_t KQ_POL_DEV_RG_OVERLAP = 1u << 31;   // device copy of cq_policy only: two resource groups of the ClusterQueue cover one resource
 constexpr int KQ_MAXR = 8;      // max resources for the incremental (sum-based) DRS; more fall back to the exact loops
 
 // ---- static structures of the scan-formulated classical victim search (kq_cs.hpp) ----------------------------------
@@ -107,6 +108,7 @@ struct Prep {
   std::vector<int32_t> top_of;                     // [N] the ancestor-or-self that is a child of the root (-1 for roots)
   int max_tree_nodes = 0, max_tree_cqs = 0, max_tree_rows = 0, max_tree_cohorts = 0;
   std::vector<int8_t> cq_res_rg;                   // [nq * nR] RGByResource: index of the covering group inside the ClusterQueue's groups, -1 = none
+  std::vector<uint32_t> cq_policy_dev;             // [nq] kq_snapshot.cq_policy + the engine's own bits (KQ_POL_DEV_*)
   // kq_fs.hpp: per tree position (same offsets as tree_rows)
   std::vector<FsScan> fs_scan;
   std::vector<FsApply> fs_apply;
@@ -524,11 +526,18 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
     p.max_tree_cohorts = std::max(p.max_tree_cohorts, (p.tree_node_off[t + 1] - p.tree_node_off[t]) - (p.tree_cq_off[t + 1] - p.tree_cq_off[t]));
   }
   p.cq_res_rg.assign((size_t)p.nq * p.nR, -1);
+  p.cq_policy_dev.assign(std::max(p.nq, 1), 0);
   for (int c = 0; c < p.nq; c++) {
     if (s->cq_rg_off[c + 1] - s->cq_rg_off[c] > 127) { p.err = "more than 127 resource groups in a ClusterQueue"; return KQ_EUNSUPPORTED; }
+    bool overlap = false;   // a resource covered by two groups of the ClusterQueue (the webhook rejects such a spec, the cache keeps it)
     for (int g = s->cq_rg_off[c + 1] - 1; g >= s->cq_rg_off[c]; g--)  // the first group covering a resource wins (util/resourcegroups/resourcegroups.go:62)
       for (int i = s->rg_res_off[g]; i < s->rg_res_off[g + 1]; i++)
-        if (s->rg_res[i] >= 0 && s->rg_res[i] < p.nR) p.cq_res_rg[(size_t)c * p.nR + s->rg_res[i]] = (int8_t)(g - s->cq_rg_off[c]);
+        if (s->rg_res[i] >= 0 && s->rg_res[i] < p.nR) {
+          int8_t& cell = p.cq_res_rg[(size_t)c * p.nR + s->rg_res[i]];
+          if (cell >= 0 && cell != (int8_t)(g - s->cq_rg_off[c])) overlap = true;
+          cell = (int8_t)(g - s->cq_rg_off[c]);
+        }
+    p.cq_policy_dev[c] = (s->cq_policy[c] & 0xfffu) | (overlap ? KQ_POL_DEV_RG_OVERLAP : 0u);
   }
   p.max_rsn_per_podset = 1;
   for (int c = 0; c < p.nq; c++) {

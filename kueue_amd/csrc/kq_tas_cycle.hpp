@@ -290,6 +290,7 @@ KQ_DEV int tc_adm_flavor(const K& k, int psg, int res) {
   const TCyc& c = *k.tc;
   return c.ps_adm_flavor ? c.ps_adm_flavor[(size_t)psg * k.S.nR + res] : -1;
 }
+KQ_DEV bool tc_is_tas_flavor(const K& k, int flavor) { return k.tc->tas_of_flavor[flavor] >= 0; }   // a key of cq.TASFlavors (tasFlavorsOnly, flavorassigner.go:996)
 // a fresh Assign starts from the admission's TopologyAssignment again (flavorassigner.go:777-779)
 KQ_DEV void tc_sp_reset(const K& k, int psg) { if (k.tc->sp_del_out && lane_id() == 0) k.tc->sp_del_out[psg] = 0; }
 KQ_DEV void tc_reset(Wave& w) {
@@ -301,6 +302,16 @@ KQ_NOINLINE void tc_update_mode(const K& k, Wave& w, int p, int mode) {
   const int nR = k.S.nR;
   const size_t o = (size_t)(w.ps_base + p) * nR;
   for (int r = lane_id(); r < nR; r += WAVE) if (k.O.flavor[o + r] >= 0) k.O.res_mode[o + r] = (uint8_t)mode;
+  // ResourceAssignment holds *FlavorAssignment, and resolvePodSetFlavors (:917, FilterKeys) hands every member of a PodSetGroupName group the
+  // SAME pointers out of groupFlavors: the mode written through p's entry is the mode of the other members' entries for that resource
+  if (const int32_t* grp = k.H.ps_group) {
+    const int gid = grp[w.ps_base + p];
+    for (int q = 0; gid >= 0 && q < w.nps; q++) {
+      if (q == p || grp[w.ps_base + q] != gid) continue;
+      const size_t oq = (size_t)(w.ps_base + q) * nR;
+      for (int r = lane_id(); r < nR; r += WAVE) if (k.O.flavor[o + r] >= 0 && k.O.flavor[oq + r] >= 0) k.O.res_mode[oq + r] = (uint8_t)mode;
+    }
+  }
   wsync();
   // (lanes = the head's (podset, resource) cells, one load each, a wave minimum per usage entry: this was nuse x nps x nR dependent loads
   // on lane 0, twice per recomputed entry of a saturated cycle)
@@ -342,6 +353,7 @@ KQ_NOINLINE void tc_requests(const K& k, Wave& w) {
     w.ta.req_valid = 1;
     const int nR = k.S.nR;
     w.ta.t = -1; w.ta.nreq = 0;
+    bool two_flavors = false;
     for (int p = 0; p < w.nps && p < TC_P; p++) {
       const int g = w.ps_base + p;
       const bool explicitReq = (c.ps_flags[g] & KQ_PS_TAS_EXPLICIT) != 0;
@@ -364,11 +376,14 @@ KQ_NOINLINE void tc_requests(const K& k, Wave& w) {
         if (first < 0) first = t; else if (t != first) many = true;
       }
       if (first < 0 || many) { w.ta.err_mask |= 1u << p; w.rep_mode = M_NOFIT; continue; }  // psError :290 -> RepresentativeMode NoFit
-      if (w.ta.t >= 0 && w.ta.t != first) { if (*k.O.error == 0) *k.O.error = KQ_EUNSUPPORTED; if (c.stats) c.stats[2] = 1; continue; }
+      if (w.ta.t >= 0 && w.ta.t != first) { two_flavors = true; continue; }
       w.ta.t = first;
       if (c.sp_kind && (w.hflags & KQ_HEAD_HAS_UNHEALTHY_NODES) && !(c.sp_kind[g] & SP_HAS_EX)) continue;   // requested, but the replacement branch has no result for it
       w.ta.req_ps[w.ta.nreq++] = (uint8_t)p;
     }
+    // the podsets of one workload on two TAS flavors: the placement (one TAS flavor per wave) does not take them. With a psError on some podset
+    // the assignment is NoFit and no placement is ever asked for (flavorassigner.go:866, :879; scheduler.go:941): nothing to refuse then
+    if (two_flavors && !w.ta.err_mask) { if (*k.O.error == 0) *k.O.error = KQ_EUNSUPPORTED; if (c.stats) c.stats[2] = 1; }
   }
   wsync();
 }

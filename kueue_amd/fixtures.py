@@ -87,6 +87,7 @@ def _podsets(d: dict) -> List[PodSet]:
             ps.requests[r] = resource_value(r, q)
         ps.flavors = dict(p.get("flavors") or {})
         ps.excluded_flavors = list(p.get("excludedFlavors") or [])
+        ps.group = p.get("group")   # PodSet.TopologyRequest.PodSetGroupName
         out.append(ps)
     return out
 

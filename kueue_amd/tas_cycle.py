@@ -135,53 +135,6 @@ def excluded_flavors_for_tas(cq, ps_requests: Sequence[str], ptas: PodSetTAS, to
     return out
 
 
-def grouped_scan_risk(snap: Snapshot, heads: Heads, ps_group) -> List[int]:
-    """Heads whose flavor assignment MAY differ from the reference's because the engine scans flavors per podset while assignFlavors scans once per
-    PodSetGroupName group over the sum of its members' requests (flavorassigner.go:782-860, resolvePodSetFlavors :917; DESIGN §7 "grouped flavor
-    assignment"). A head is NOT listed — the two scans provably pick the same flavors — when, for every group of two or more of its podsets: every
-    member requests a resource the ClusterQueue covers, the head carries no LastAssignment bookmark, the members share one eligibility mask (kq_heads.ps_flavor_ok), and every resource a member requests lies in a
-    resource group of the ClusterQueue that lists a single flavor (both scans then try that one flavor against the same running total). A caller
-    that must match the reference exactly sends the cycles of the listed heads down the reference's own path."""
-    a, h = snap.arrays, heads.arrays
-    nR = snap.n_resource
-    out = []
-    for i in range(heads.n):
-        cq = int(h["cq"][i])
-        p0, p1 = int(h["ps_off"][i]), int(h["ps_off"][i + 1])
-        rg_of = {}
-        for rg in range(int(a["cq_rg_off"][cq]), int(a["cq_rg_off"][cq + 1])):
-            for k in range(int(a["rg_res_off"][rg]), int(a["rg_res_off"][rg + 1])):
-                rg_of.setdefault(int(a["rg_res"][k]), rg)
-        pods = snap.pods_resource if snap.pods_resource in rg_of else -1
-        members: Dict[int, List[int]] = {}
-        for p in range(p0, p1):
-            if int(ps_group[p]) >= 0:
-                members.setdefault(int(ps_group[p]), []).append(p)
-        risky = False
-        nw = h["ps_flavor_ok"].size // max(int(h["ps_off"][-1]), 1)
-        for ms in members.values():
-            if len(ms) < 2:
-                continue
-            if int(h["flags"][i]) & F.HEAD_HAS_LAST_ASSIGNMENT:   # the group's scan resumes from its FIRST member's bookmark (:1092 psIDs[0])
-                risky = True
-            masks = {bytes(h["ps_flavor_ok"][p * nw:(p + 1) * nw].tobytes()) for p in ms}
-            if len(masks) > 1:
-                risky = True
-            for p in ms:
-                res = [int(r) for r in h["req_res"][int(h["ps_req_off"][p]):int(h["ps_req_off"][p + 1])]]
-                if pods >= 0 and pods not in res:
-                    res.append(pods)
-                if not any(r in rg_of for r in res):   # requests none of the ClusterQueue's resources: takes the group's Status (and TAS flavors)
-                    risky = True
-                for r in res:
-                    rg = rg_of.get(r)
-                    if rg is not None and int(a["rg_flavor_off"][rg + 1]) - int(a["rg_flavor_off"][rg]) > 1:
-                        risky = True
-        if risky:
-            out.append(i)
-    return out
-
-
 class CycleTAS:
     """kq_cycle_tas for one (Snapshot, Heads)."""
 
@@ -297,10 +250,6 @@ class CycleTAS:
     def struct(self) -> kq_cycle_tas:
         return self._struct
 
-    def grouped_scan_risk(self) -> List[int]:
-        """Heads of this cycle whose flavor assignment may differ from the reference's one-scan-per-PodSetGroupName (grouped_scan_risk above);
-        [] proves that it cannot."""
-        return grouped_scan_risk(self.snap, self.heads, self.arrays["ps_group"])
 
 
 class CycleTASOut:

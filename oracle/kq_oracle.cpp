@@ -123,12 +123,6 @@ static const int64_t MAXINT = I64MAX;  // math.MaxInt on 64-bit
 //   [96..159] failed pops of a visit that ended exhausted
 //   [160..223] length of a run of consecutive victims under the same child of the root (last bin 63+)
 //   [224..287] candidates left in the ClusterQueue at the moment it is visited
-// assignFlavors over PodSetGroupName groups (flavorassigner.go:782-860): OFF by default — the engine's flavor scan runs per podset, and so does
-// this restatement's default path, which is what the parity suites compare it with. ON (kqo_set_grouped): the reference's grouping, pinned on the
-// leader-worker-set rows of TestAssignFlavors; DESIGN §7 "grouped flavor assignment" says where the two differ. groups: PodSetGroupName id per
-// podset of the heads batch (-1 none), or null = kq_cycle_tas.ps_group.
-static thread_local bool g_grouped = false;
-static thread_local const int32_t* g_groups = nullptr;
 static thread_local bool g_fs_probe_on = false;
 static thread_local int64_t g_fs_probe[288];
 
@@ -440,6 +434,7 @@ struct PodSetReq {
   // the podset of the replaced workload slice at the same index (replaceWorkloadSlice.TotalRequests[psID]): Count, Flavors, Requests
   int slice_count = 0;
   std::map<int, std::pair<int, int64_t>> slice;  // resource -> (flavor or -1, request)
+  int group = -1;                            // PodSetGroupName id (kq_heads.ps_group, else kq_cycle_tas.ps_group), -1 = none
 };
 struct Head {
   int idx, cq;
@@ -475,6 +470,7 @@ struct PodSetAssignment {
   std::vector<Reason> reasons;               // Status.reasons, in append order
   bool err = false;
   int count = 0;
+  int group = -1;                            // PodSetGroupName id of the podset (its Flavors entries are shared with the group's other members)
   std::vector<std::pair<int, int64_t>> requests;  // effective requests (incl. injected pods)
   // TopologyAssignment (flavorassigner.go:379): (leaf, count) on TAS flavor tasIdx
   bool hasTopo = false;
@@ -671,9 +667,16 @@ static void UpdateForTASResult(Snap& sn, const Head& wl, Assignment& a, const Ta
   }
   ComputeTASNetUsage(sn, wl, a);
 }
-// Assignment.updateMode flavorassigner.go:192-198
+// Assignment.updateMode flavorassigner.go:192-198. ResourceAssignment maps resources to *FlavorAssignment and resolvePodSetFlavors (:917, FilterKeys)
+// hands every member of a PodSetGroupName group the SAME pointers out of groupFlavors: the mode written through one member's entry is the mode of
+// the other members' entries for that resource too.
 static void updateModePS(Assignment& a, int ps, int mode) {
   for (auto& kv : a.PodSets[ps].flavors) kv.second.mode = mode;
+  const int grp = a.PodSets[ps].group;
+  if (grp >= 0)
+    for (size_t q = 0; q < a.PodSets.size(); q++)
+      if ((int)q != ps && a.PodSets[q].group == grp)
+        for (auto& kv : a.PodSets[q].flavors) if (a.PodSets[ps].flavors.count(kv.first)) kv.second.mode = mode;
   a.rep = mode;
 }
 // Usage.TAS applied to / checked against the flavor snapshots (clusterqueue_snapshot.go:121-149)
@@ -860,118 +863,12 @@ struct FlavorAssigner {
     return bestAssignment;
   }
 
-  // flavorassigner.go:708-908 (TAS branches excluded: out of scope for this path)
+  // flavorassigner.go:708-908. The podsets of one PodSetGroupName (:782-790) are ONE flavor scan over the sum of their requests; every member
+  // then takes the group's flavors for the resources it requests itself (resolvePodSetFlavors :917-945; a member without requests keeps the
+  // group's TAS flavors) and the group's Status. A podset outside any group is a group of one. Groups must be contiguous (orderedgroups
+  // appends PodSets in group order; this restatement indexes PodSets by podset): an interleaved workload raises tasUnsupported. Workload
+  // slices: single podsets only.
   Assignment assignFlavors(const std::vector<int>* counts) {
-    if (g_grouped) return assignFlavorsGrouped(counts);
-    Assignment a;
-    int P = (int)wl.ps.size();
-    std::vector<PodSetReq> requests(P);
-    for (int i = 0; i < P; i++) {
-      requests[i] = wl.ps[i];
-      if (counts && !counts->empty()) {  // ScaledTo workload.go:317-340
-        int nc2 = (*counts)[i];
-        if (wl.ps[i].count != 0 && wl.ps[i].count != nc2) {
-          for (auto& rq : requests[i].req) {
-            rq.second = rq.second / (int64_t)wl.ps[i].count;          // Divide slice_requests.go:192
-            rq.second = SaturatingMul(rq.second, (int64_t)nc2);       // Mul
-          }
-          requests[i].count = nc2;
-        }
-      }
-    }
-    for (int i = 0; i < P; i++) {
-      PodSetReq& podSet = requests[i];
-      if (sn.s->pods_resource >= 0 && sn.RGByResource(cq, sn.s->pods_resource) >= 0) {  // :743-749
-        bool found = false;
-        for (auto& rq : podSet.req) if (rq.first == sn.s->pods_resource) { rq.second = podSet.count; found = true; }
-        if (!found) podSet.req.push_back({sn.s->pods_resource, (int64_t)podSet.count});
-      }
-      // Requests.Iter order: FNV-1a64(name), name (slice_requests.go:54-60)
-      std::stable_sort(podSet.req.begin(), podSet.req.end(), [&](const std::pair<int, int64_t>& x, const std::pair<int, int64_t>& y) {
-        return sn.s->resource_order[x.first] < sn.s->resource_order[y.first];
-      });
-      sn.st.head_io_bytes += (int64_t)podSet.req.size() * 8;
-      PodSetAssignment psa;
-      psa.count = podSet.count;
-      psa.requests = podSet.req;
-      std::map<int, FlavorAssignment> groupFlavors;
-      bool groupNil = false;
-      int groupReasons = 0;
-      if (sn.T && sn.T->ps_adm_flavor) {
-        // :765-779 "Respect preexisting assignments. The PodSet assignments may be already set if this is the second pass of scheduler":
-        // mode Fit, TriedFlavorIdx 0, and the flavor scan skips the resource (:819); the admission's TopologyAssignment comes along
-        const int g = wl.ps_base + i;
-        for (int r = 0; r < sn.nR; r++) {
-          const int fl = sn.T->ps_adm_flavor[(size_t)g * sn.nR + r];
-          if (fl >= 0) { FlavorAssignment fa; fa.flavor = fl; fa.mode = Fit; fa.tried = 0; fa.borrow = 0; groupFlavors[r] = fa; }
-        }
-        if (sn.T->ps_ex_off && sn.T->ps_ex_off[g + 1] > sn.T->ps_ex_off[g]) {
-          psa.hasTopo = true;
-          for (auto& kv : groupFlavors) if (sn.tasOfFlavor[kv.second.flavor] >= 0) psa.tasIdx = sn.tasOfFlavor[kv.second.flavor];
-          for (int j = sn.T->ps_ex_off[g]; j < sn.T->ps_ex_off[g + 1]; j++) {
-            psa.topo.push_back({sn.T->ps_ex_leaf[j], sn.T->ps_ex_count[j]});
-            psa.topoFlags.push_back(sn.T->ps_ex_flags[j]);
-          }
-        }
-      }
-      for (auto& rq : podSet.req) {
-        int resName = rq.first; int64_t quantity = rq.second;
-        if (sn.RGByResource(cq, resName) < 0) {  // :809-817
-          if (quantity == 0) continue;
-          if (sn.gate(KQ_GATE_QUOTA_CHECK_STRATEGY) && sn.cfg.quota_check_strategy == KQ_QUOTA_CHECK_IGNORE_UNDECLARED) continue;
-        }
-        if (groupFlavors.count(resName)) continue;  // :819
-        int nre; bool statusNil;
-        std::vector<Reason> why;
-        std::vector<Attempt> considered;
-        auto flavors = findFlavorForPodSets(i, podSet.req, resName, a.Usage, &nre, &statusNil, &why, observe ? &considered : nullptr);
-        if (observe) mergeFlavorAttemptsForResource(psa.attempts, considered, resName);
-        if (flavors.empty() && !podSet.req.empty()) {  // :826
-          groupFlavors.clear(); groupNil = true; groupReasons = nre;
-          psa.reasons = why;  // psAssignment.Status = status (:829)
-          break;
-        }
-        for (auto& kv : flavors) groupFlavors[kv.first] = kv.second;
-        if (!statusNil) { groupReasons += nre; psa.reasons.insert(psa.reasons.end(), why.begin(), why.end()); }
-      }
-      // resolvePodSetFlavors :921-947 — keep flavors for resources this podset requests
-      if (!groupNil && !podSet.req.empty()) {
-        for (auto& kv : groupFlavors) {
-          bool req = false;
-          for (auto& rq : podSet.req) if (rq.first == kv.first) req = true;
-          if (req) psa.flavors[kv.first] = kv.second;
-        }
-      }
-      psa.nreasons = groupReasons;
-      // Assignment.append :1017-1041
-      for (auto& kv : psa.flavors) {
-        if (kv.second.borrow > a.Borrowing) a.Borrowing = kv.second.borrow;
-        int fr = kv.second.flavor * sn.nR + kv.first;
-        int64_t requestAmount = 0;
-        for (auto& rq : podSet.req) if (rq.first == kv.first) requestAmount = rq.second;
-        if (wl.slice_row >= 0) {  // :1032-1035 findOldPodSetRequest (by podset name: the host aligned the names to indices)
-          auto it = wl.ps[i].slice.find(kv.first);
-          if (it != wl.ps[i].slice.end()) requestAmount -= it->second.second;
-        }
-        a.Usage[fr] = frq_get(a.Usage, fr).AddInt64(requestAmount);
-      }
-      sn.st.head_io_bytes += (int64_t)podSet.req.size() * 8 + (int64_t)psa.flavors.size() * 16;
-      bool failed = !podSet.req.empty() && psa.flavors.empty();
-      a.PodSets.push_back(psa);
-      a.rep = -1;
-      if (failed) { resolveNoFitReason(a); return a; }  // atLeastOnePodsAssignmentFailed :848-853
-    }
-    if (a.RepresentativeMode() == NoFit) { resolveNoFitReason(a); return a; }  // :857-862
-    if (sn.T) assignTAS(a);
-    resolveNoFitReason(a);  // :904-906
-    return a;
-  }
-
-  // assignFlavors as the reference groups it (flavorassigner.go:782-860): the podsets of one PodSetGroupName are ONE flavor scan over the sum of
-  // their requests; every member then takes the group's flavors for the resources it requests itself (resolvePodSetFlavors :917-945; a member
-  // without requests keeps the group's TAS flavors) and the group's Status. Groups must be contiguous (orderedgroups appends PodSets in group
-  // order; this restatement indexes PodSets by podset): an interleaved workload raises tasUnsupported. Workload slices: single podsets only.
-  Assignment assignFlavorsGrouped(const std::vector<int>* counts) {
     Assignment a;
     const int P = (int)wl.ps.size();
     std::vector<PodSetReq> requests(P);
@@ -995,6 +892,7 @@ struct FlavorAssigner {
         return sn.s->resource_order[x.first] < sn.s->resource_order[y.first];
       });
       psas[i].count = podSet.count;
+      psas[i].group = wl.ps[i].group;
       psas[i].requests = podSet.req;
       if (sn.T && sn.T->ps_adm_flavor) {  // :765-779, as in assignFlavors
         const int g = wl.ps_base + i;
@@ -1009,7 +907,7 @@ struct FlavorAssigner {
         }
       }
     }
-    auto groupOf = [&](int i) { const int g = wl.ps_base + i; return g_groups ? g_groups[g] : (sn.T && sn.T->ps_group ? sn.T->ps_group[g] : -1); };
+    auto groupOf = [&](int i) { return wl.ps[i].group; };
     for (int i = 0; i < P;) {
       std::vector<int> psIDs{i};
       const int gid = groupOf(i);
@@ -1629,6 +1527,10 @@ struct Preemptor {
   FRQ TotalRequestsFor(const Head& wl, Assignment& a) const {
     FRQ usage;
     for (size_t i = 0; i < wl.ps.size(); i++) {
+      // (an assignment that stopped early — atLeastOnePodsAssignmentFailed :848 — holds fewer PodSets than the workload; with a Preempt
+      // RepresentativeMode the reference indexes past them here and panics. Only a stale bookmark past the last flavor gets there: a podset
+      // with requests, an empty scan and an empty Status. The restatement stops at the PodSets there are; the engine reads "no flavor".)
+      if (i >= a.PodSets.size()) break;
       const PodSetReq& ps = wl.ps[i];
       int newCount = a.PodSets[i].count;
       if (wl.slice_row >= 0) newCount = ps.count - ps.slice_count;  // :265-267
@@ -1718,6 +1620,7 @@ struct Scheduler {
         if (sn.s->pods_resource >= 0 && !ps.slice.count(sn.s->pods_resource))
           ps.slice[sn.s->pods_resource] = {H->ps_slice_pods_flavor ? H->ps_slice_pods_flavor[p] : -1, H->ps_slice_pods_qty ? H->ps_slice_pods_qty[p] : 0};
       }
+      ps.group = H->ps_group ? H->ps_group[p] : (sn.T && sn.T->ps_group ? sn.T->ps_group[p] : -1);
       h.ps.push_back(ps);
       std::vector<int> lt(sn.nR, -1);
       if (H->ps_last_tried) for (int r = 0; r < sn.nR; r++) lt[r] = H->ps_last_tried[(size_t)p * sn.nR + r];
@@ -2312,8 +2215,6 @@ static int assignImpl(const kq_config* cfg, const kq_snapshot* s, const kq_heads
 }
 extern "C" {
 
-// the switch of g_grouped / g_groups above; groups (may be null) must stay valid until the switch is turned off
-void kqo_set_grouped(int on, const int32_t* groups) { g_grouped = on != 0; g_groups = on ? groups : nullptr; }
 
 // Assign with features.UnadmittedWorkloadsObservability on: the FlavorAssignmentAttempts of every podset — (podset, flavor, mode, label), label
 // = the severity rank of the attempt's NoFitReason (lbl* above) — and Assignment.NoFitReason, as TestIsNoFitDueToCapacityAndLimits reads them

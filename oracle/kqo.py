@@ -77,18 +77,6 @@ def nominate_run(cfg: F.kq_config, snap: Snapshot, heads: Heads, tgt_cap=None):
     return d
 
 
-def set_grouped(on: bool, groups=None):
-    """The reference's grouping of assignFlavors by PodSetGroupName (flavorassigner.go:782-860) — OFF by default, see kq_oracle.cpp g_grouped.
-    groups: int32 PodSetGroupName id per podset of the heads batch (-1 none; kept alive here), None = kq_cycle_tas.ps_group."""
-    global _groups_keep
-    _groups_keep = None if groups is None else np.ascontiguousarray(groups, np.int32)
-    lib().kqo_set_grouped.restype = None
-    lib().kqo_set_grouped(C.c_int(1 if on else 0), F.ptr(_groups_keep) if (on and _groups_keep is not None) else None)
-
-
-_groups_keep = None
-
-
 def assign_tas(cfg, snap: Snapshot, heads: Heads, tas, hi: int = 0, stub=None, ineligible=None):
     """kqo_assign_tas: Assign(nil) with its TAS half -> dict(rep_mode, podsets [{resource: (flavor, mode, tried)}], usage, reasons, err [bool per podset])."""
     nR = snap.n_resource

@@ -429,7 +429,35 @@ func FlattenHeads(log logr.Logger, s *FlatSnapshot, ix *Index, heads []*qcache.H
 		h.PsOff = append(h.PsOff, int32(len(h.PsCount)))
 	}
 	flattenSlices(s, ix, heads, h)
+	flattenGroups(heads, h)
 	return h
+}
+
+// flattenGroups fills kq_heads.ps_group: the PodSetGroupName of every podset as an id inside its head (flavorassigner.go:782-790 groups
+// the podsets by that name whether or not the ClusterQueue holds a TAS flavor). Left nil when no podset of the batch names a group.
+func flattenGroups(heads []*qcache.Head, h *FlatHeads) {
+	var grp []int32
+	any := false
+	for _, hd := range heads {
+		ids := map[string]int32{}
+		for pi := range hd.Info.TotalRequests {
+			g := int32(-1)
+			if pi < len(hd.Info.Obj.Spec.PodSets) {
+				if tr := hd.Info.Obj.Spec.PodSets[pi].TopologyRequest; tr != nil && tr.PodSetGroupName != nil {
+					id, ok := ids[*tr.PodSetGroupName]
+					if !ok {
+						id = int32(len(ids))
+						ids[*tr.PodSetGroupName] = id
+					}
+					g, any = id, true
+				}
+			}
+			grp = append(grp, g)
+		}
+	}
+	if any {
+		h.PsGroup = grp
+	}
 }
 
 // flattenSlices fills the kq_heads.slice_* columns: for a head that replaces an admitted workload slice

@@ -117,6 +117,9 @@ type FlatHeads struct {
 	// workload slices (ElasticJobsViaWorkloadSlices): nil when no head replaces a slice
 	SliceRow, PsSliceCount, ReqSliceFlavor, PsSlicePodsFlavor []int32
 	ReqSliceQty, PsSlicePodsQty                               []int64
+	// PodSet.TopologyRequest.PodSetGroupName per podset (id inside the head, -1 none): assignFlavors scans flavors once per group
+	// (flavorassigner.go:782-860). nil when no podset of the batch is in a group.
+	PsGroup []int32
 }
 
 type FlatDecisions struct {
@@ -296,6 +299,9 @@ func fillHeads(p *runtime.Pinner, c *C.kq_heads, h *FlatHeads) {
 		c.req_slice_qty = (*C.int64_t)(pin(p, h.ReqSliceQty))
 		c.ps_slice_pods_flavor = (*C.int32_t)(pin(p, h.PsSlicePodsFlavor))
 		c.ps_slice_pods_qty = (*C.int64_t)(pin(p, h.PsSlicePodsQty))
+	}
+	if h.PsGroup != nil {
+		c.ps_group = (*C.int32_t)(pin(p, h.PsGroup))
 	}
 }
 

@@ -10,7 +10,7 @@ from tests.randgen import random_case
 BLOCK, RACK, HOST = "cloud.com/topology-block", "cloud.com/topology-rack", "kubernetes.io/hostname"
 
 
-def random_tas_cycle_case(seed, roomy=False, **kw):
+def random_tas_cycle_case(seed, roomy=False, rich_groups=False, **kw):
     cfg, snap, heads = random_case(seed, **kw)
     rnd = random.Random(seed * 7919 + 13)
     levels = rnd.choice([[HOST], [RACK, HOST], [BLOCK, RACK, HOST], [BLOCK, RACK]])
@@ -36,6 +36,25 @@ def random_tas_cycle_case(seed, roomy=False, **kw):
     rg = random.Random(seed * 31 + 7)   # (its own stream: the populations of the earlier seeds stay what they were)
     # leader + workers (PodSetGroupName): the API admits one leader pod per group, findLeaderAndWorkers :668 takes the smaller podset
     grouped = {w.name for w in pending if len(w.pod_sets) == 2 and min(ps.count for ps in w.pod_sets) == 1 and rg.random() < 0.7}
+    if rich_groups:
+        # LeaderWorkerSet shapes the flavor scan's grouping (flavorassigner.go:782-860) is sensitive to: a leader that requests nothing (it
+        # keeps the group's TAS flavors, resolvePodSetFlavors :931) or only some of the workers' resources; more 2-podset workloads in a group
+        rr = random.Random(seed * 53 + 29)
+        for w in pending:
+            if len(w.pod_sets) == 2 and w.name not in grouped and rr.random() < 0.6 and not getattr(w, "replaces", None):
+                w.pod_sets[rr.randrange(2)].count = 1
+                for ps in w.pod_sets:
+                    ps.min_count = None if ps.count == 1 else ps.min_count
+                grouped.add(w.name)
+            if w.name not in grouped:
+                continue
+            lead = min(w.pod_sets, key=lambda ps: ps.count)
+            k = rr.random()
+            if k < 0.35:
+                lead.requests = {}
+            elif k < 0.6 and len(lead.requests) > 1:
+                for r in rr.sample(sorted(lead.requests), rr.randint(1, len(lead.requests) - 1)):
+                    del lead.requests[r]
     for w in pending:
         for pi, ps in enumerate(w.pod_sets):
             tr = None
