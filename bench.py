@@ -49,7 +49,14 @@ def main():
                     help="pending workloads (cfg2 / cfg3 / cfg3f): one enqueue per cycle with the decisions fetched one cycle later (kq_pending_step), or the "
                          "call-by-call loop with two host round trips per cycle")
     ap.add_argument("--parity-cycles", type=int, default=0, help="pending loop: cycles of the parity gate (0 = 12, 6 with fair sharing)")
-    ap.add_argument("--hold", type=int, default=4, help="closed loop: admitted workloads finish after this many cycles")
+    ap.add_argument("--hold", type=int, default=None, help="closed loop: admitted workloads finish after this many cycles (default 4; the preemption loops "
+                                                            "cfg4c / cfg4f: 0 = never inside the run — workloads outlive scheduling cycles by orders of magnitude, "
+                                                            "and preemption is then the only way in once the tree is full)")
+    ap.add_argument("--start", default="spec", choices=["spec", "feasible"],
+                    help="cfg4c / cfg4f closed loop: the spec'd start (every ClusterQueue filled to 1.0-1.5 x nominal on every flavor: 40 of 64 root cells "
+                         "over-committed) or a state admission could have produced (kueue_amd/population.py generate(feasible=True))")
+    ap.add_argument("--series-cycles", type=int, default=0, help="cfg4c / cfg4f closed loop: cycles recorded in the per-cycle series in front of the timed "
+                                                                   "window (0 = --warmup); the timed window follows them")
     ap.add_argument("--node-failures", type=int, default=0,
                     help="cfg5-cycle closed loop: this many nodes hosting admitted pods fail in every cycle; the workloads that lose pods come back as "
                          "second-pass heads (replaced below the required domain, or evicted) next to the first-pass heads")
@@ -67,6 +74,9 @@ def main():
     args = ap.parse_args()
     if args.warmup is None:
         args.warmup = 60 if args.workload in ("cfg3", "cfg3f") else 5
+    preempt_loop = args.workload in ("cfg4c", "cfg4f") and not args.open_loop and not args.resident_batches
+    if args.hold is None:
+        args.hold = 0 if preempt_loop else 4
 
     import torch
     import torch.distributed as dist
@@ -93,6 +103,8 @@ def main():
         return bench_split(args, torch, dist, world, rank, local_rank)
     if args.workload in ("cfg2", "cfg3", "cfg3f") and not args.resident_batches and not args.open_loop:
         return bench_pending(args, torch, dist, world, rank, local_rank)
+    if preempt_loop:
+        return bench_preempt_loop(args, torch, dist, world, rank, local_rank)
     from kueue_amd.api import Decisions, make_config
     from kueue_amd.engine import Engine
     from kueue_amd.population import BASE_SEED, generate
@@ -209,6 +221,176 @@ def main():
         emit(out)
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_preempt_loop(args, torch, dist, world, rank, local_rank):
+    """BASELINE configs[3] as SURVEY 8d defines a run: the CLOSED loop of a population with preemption (kueue_amd/closed_loop.py) — Heads() and the
+    requeue policy on the device, one scheduling cycle, then ONE kq_snapshot_patch_rows(KQ_ROWS_FOLD_USAGE): the cycle's admissions appended as
+    admitted rows, its preemption targets marked Evicted (gone one cycle later), finished workloads removed, usage folded on the device. A step =
+    one such cycle, decisions readable on the host, the patch applied. The loop is not stationary (the spec'd start digs itself out of an
+    over-committed tree in its first cycles), so the line carries the per-cycle series from cycle 1 on; `value` is the timed window behind it."""
+    import ctypes as C
+    from kueue_amd import _ffi as F
+    from kueue_amd.api import make_config
+    from kueue_amd.closed_loop import PreemptionLoop
+    from kueue_amd.engine import Engine
+    from kueue_amd.population import BASE_SEED, generate
+    fair = args.workload == "cfg4f"
+    feasible = args.start == "feasible"
+    pop = generate(4, seed=BASE_SEED + 1000 * rank, fair_sharing=fair, feasible=feasible)
+    snap, pending = pop.snapshot, pop.pending()
+    kcfg = make_config(fair_sharing=fair, device=local_rank)
+    hold = args.hold if args.hold > 0 else 1 << 40
+    tgt_cap = max(4096, (32 if fair else 4) * snap.n_adm)
+    extra = {}
+    if rank == 0 and not args.no_parity_gate:
+        extra["parity_checked"], extra["parity"] = preempt_loop_gate(kcfg, pop, snap, pending, fair, feasible, tgt_cap)
+    eng = Engine(kcfg)
+    eng.put(snap); eng.pending_put(pending)
+    loop = PreemptionLoop(eng, snap, pending, hold=hold, tgt_cap=tgt_cap)
+    lib, h = eng._lib, eng._h
+    phase_ms = np.zeros(3, np.float64); phase_by = np.zeros(2, np.int64)
+    series = []
+
+    def cycle(c):
+        t1 = time.perf_counter()
+        d, ha, hw = loop.step(c)
+        ms = (time.perf_counter() - t1) * 1e3
+        lib.kq_last_cycle_phases(h, F.ptr(phase_ms), F.ptr(phase_by))
+        st = loop.stats[-1]
+        series.append(dict(cycle=c, ms=round(ms, 3), heads=st["heads"], admitted=st["admitted"], preempting=st["preempting"], targets=st["targets"],
+                           nominated_preempt=int((d.a["nominated_mode"] == 1).sum()) if d is not None else 0,
+                           rows=st["rows"], k_nominate_ms=round(float(phase_ms[0]), 3), k_process_ms=round(float(phase_ms[2]), 3)))
+        return (0 if d is None else d.n), ms, float(phase_ms[0]), float(phase_ms[2]), int(phase_by[0]), int(phase_by[1])
+
+    lead = args.series_cycles or args.warmup
+    for c in range(1, lead + 1):
+        cycle(c)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dec, cyc_ms, nom_ms, proc_ms, nom_by, proc_by = 0, [], 0.0, 0.0, 0, 0
+    t0 = time.perf_counter()
+    for c in range(lead + 1, lead + args.steps + 1):
+        n, ms, a, b, x, y = cycle(c)
+        dec += n; cyc_ms.append(ms); nom_ms += a; proc_ms += b; nom_by += x; proc_by += y
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed, float(dec)], dtype=torch.float64, device="cuda")
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed_all, dec_all = float(tmax[0]), float(tsum[1])
+    else:
+        elapsed_all, dec_all = elapsed, float(dec)
+    if rank == 0:
+        kernels = {"k_nominate": (nom_ms, nom_by), "k_process": (proc_ms, proc_by)}
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        dms, dby = kernels[dom]
+        achieved = (dby / args.steps) / (dms / args.steps * 1e-3) / 1e9 if dms > 0 else 0.0
+        timed = series[lead:]
+        whole_ms = sum(x["ms"] for x in series)
+        out = {
+            "metric": "admission-decisions/sec + p99 schedule-cycle ms @ 100k pending, 1k CQ",
+            "value": dec_all / elapsed_all, "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": lead,
+            "ms_per_step": elapsed_all / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {snap.n_cq} ClusterQueues, {snap.n_cohort} cohorts, {snap.n_flavor} flavors x {snap.n_resource} resources, "
+                                   f"{snap.n_adm} admitted at the start, {pop.n_pending} pending per GPU; one cycle = <= {snap.n_cq} heads",
+                       "pending_per_gpu": pop.n_pending, "sharding": "root cohort per GPU, no collective",
+                       "start": ("feasible: root usage <= SubtreeQuota in every cell, 80-100 % full" if feasible else
+                                 "spec'd: every ClusterQueue filled to 1.0-1.5 x nominal on every flavor (root over-committed in most cells)"),
+                       "loop": ("closed, preemptions applied: Heads() + requeue on the device, admissions appended as admitted rows, preemption targets marked "
+                                "Evicted and gone one cycle later, usage folded on the device (kq_snapshot_patch_rows KQ_ROWS_FOLD_USAGE); "
+                                + (f"workloads finish after {args.hold} cycles" if args.hold > 0 else "workloads do not finish inside the run"))},
+            "p50_cycle_ms": float(np.percentile(cyc_ms, 50)), "p99_cycle_ms": float(np.percentile(cyc_ms, 99)),
+            "kernel_ms_per_cycle": {"k_nominate": nom_ms / args.steps, "k_process": proc_ms / args.steps},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "algorithmic_bytes_per_launch": dby / args.steps, "traffic": pmc_traffic(args.workload, dom)},
+            "full_run": {"cycles": len(series), "decisions": int(sum(x["heads"] for x in series)), "decisions_per_s": sum(x["heads"] for x in series) / (whole_ms * 1e-3),
+                         "admitted": int(sum(x["admitted"] for x in series)), "preempting_heads": int(sum(x["preempting"] for x in series)),
+                         "targets": int(sum(x["targets"] for x in series)),
+                         "what": "every cycle from the start state on (the series), wall time per cycle with the decisions on the host and the patch applied"},
+            "window": {"heads_nominated_preempt_frac": float(sum(x["nominated_preempt"] for x in timed)) / max(1, sum(x["heads"] for x in timed)),
+                       "heads_issuing_preemption_frac": float(sum(x["preempting"] for x in timed)) / max(1, sum(x["heads"] for x in timed)),
+                       "targets_per_preempting_head": float(sum(x["targets"] for x in timed)) / max(1, sum(x["preempting"] for x in timed))},
+            "series": series,
+        }
+        out.update(extra)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline_preempt_loop(pop, kcfg, snap, pending, hold, loop.uid_base, args.cpu_seconds, fair, feasible)
+        else:
+            out["cpu_baseline"] = None
+        emit(out)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def preempt_loop_gate(kcfg, pop, snap, pending, fair, feasible, tgt_cap):
+    """The first cycles of this very loop on a fresh engine against what the oracle's loop produced offline for them
+    (tests/golden/loop_<name>.npz, tests/golden/gen_preemption_loop_golden.py: a full-size cycle costs the oracle up to tens of minutes). The
+    goldens were made with hold = 4; no workload admitted inside the loop finishes before cycle 5, so they hold for every hold >= 4."""
+    from kueue_amd.closed_loop import PreemptionLoop
+    from kueue_amd.engine import Engine
+    name = ("cfg4f" if fair else "cfg4c") + ("-feasible" if feasible else "")
+    path = os.path.join(ROOT, "tests", "golden", f"loop_{name}.npz")
+    if not os.path.exists(path):
+        return False, f"no committed expectation {path}"
+    g = np.load(path)
+    n = min(int(g["cycles"][0]), 4)
+    eng = Engine(kcfg)
+    try:
+        eng.put(snap); eng.pending_put(pending)
+        loop = PreemptionLoop(eng, snap, pending, hold=1 << 40, tgt_cap=tgt_cap)
+        checked = 0
+        for c in range(1, n + 1):
+            d, ha, hw = loop.step(c)
+            if not np.array_equal(hw, g[f"c{c}_head_wl"]):
+                return False, f"MISMATCH: Heads() of cycle {c}"
+            for k in ("status", "action", "nominated_mode", "mode", "requeue_reason", "skip", "borrowing", "order", "flavor", "res_mode", "tried_idx", "ps_count", "tgt_off"):
+                if not np.array_equal(d.a[k], g[f"c{c}_{k}"]):
+                    return False, f"MISMATCH in {k}, cycle {c}"
+            m = int(d.a["tgt_off"][-1])
+            if not (np.array_equal(d.a["tgt_adm"][:m], g[f"c{c}_tgt_adm"]) and np.array_equal(d.a["tgt_reason"][:m], g[f"c{c}_tgt_reason"])):
+                return False, f"MISMATCH in the targets of cycle {c}"
+            checked += d.n
+        return True, f"cycles 1-{n} of the loop ({checked} decisions, every field, all targets) equal to the oracle's offline run of the same loop ({os.path.basename(path)})"
+    finally:
+        eng.close()
+
+
+def cpu_baseline_preempt_loop(pop, kcfg, snap, pending, hold, uid_base, budget_s, fair, feasible):
+    """The same closed loop on the oracle (oracle/loop.py: its queues, its snapshot image, its patch), one thread, whole cycles from the start
+    state until the budget is spent — at least one. Where ONE cycle of the start state is beyond any budget (the spec'd start: minutes with
+    classical preemption, tens of minutes with fair sharing), the sample is an evenly spaced subset of the first cycle's heads instead."""
+    from oracle import kqo
+    from oracle.loop import OracleLoop
+    if not feasible:
+        limit, per_head = 4, None
+        t1 = time.perf_counter()
+        kqo.cycle_run(kcfg, snap, pop.heads_for_cycle(0, cycle=1, limit=limit))
+        per_head = (time.perf_counter() - t1) / limit
+        limit = int(max(4, min(1000, budget_s / max(per_head, 1e-6))))
+        hb = pop.heads_for_cycle(0, cycle=1, limit=limit)
+        t1 = time.perf_counter()
+        kqo.cycle_run(kcfg, snap, hb)
+        dt = time.perf_counter() - t1
+        return {"value": hb.n / dt, "unit": "decisions/s", "cores": 1, "kind": "port",
+                "sample": f"{hb.n} evenly spaced heads of cycle 1 of the same loop (the spec'd start; a whole cycle is beyond the budget), C++ restatement of the Go path, "
+                          f"host nproc={os.cpu_count()}"}
+    ol = OracleLoop(kqo, kcfg, snap, pending, hold, uid_base, int(getattr(snap, "now_ns", 0) or 0), 1_000_000)
+    dec, cyc, t0 = 0, 0, time.perf_counter()
+    try:
+        while time.perf_counter() - t0 < budget_s and cyc < 200:
+            hb, _, want = ol.step(cyc + 1)
+            cyc += 1
+            dec += hb.n
+    finally:
+        ol.close()
+    dt = time.perf_counter() - t0
+    return {"value": dec / dt, "unit": "decisions/s", "cores": 1, "kind": "port",
+            "sample": f"the first {cyc} cycles ({dec} decisions) of the same closed loop from the same start state, C++ restatement of the Go path + the loop's host-side "
+                      f"bookkeeping in Python on both sides, host nproc={os.cpu_count()}"}
 
 
 def parity_gate(eng, pop, kcfg, batches, outs, next_i, n_batches, fair):

@@ -340,7 +340,7 @@ int  kq_snapshot_patch(kq_engine* e, const kq_snapshot* s, uint32_t what);
  * kq_snapshot_put of the snapshot with that row table (tests/test_rows_device.py). Row indices of later calls (remove_rows,
  * kq_decisions.tgt_adm, kq_heads.slice_row) refer to the new table: kept rows keep their order, `new_index` (optional, [n rows before
  * the call]) receives the new index of every old row, -1 for a removed one.
- * Usage is NOT touched: fold it with kq_cycle_commit / kq_cycle_release or KQ_PATCH_USAGE as before. add_uid_rank must be comparable
+ * Usage is NOT touched (unless flags has KQ_ROWS_FOLD_USAGE): fold it with kq_cycle_commit / kq_cycle_release or KQ_PATCH_USAGE as before. add_uid_rank must be comparable
  * with the resident rows' adm_uid_rank (any order-preserving 32-bit key of Obj.UID works; dense ranks do not survive insertions).
  * KQ_EUNSUPPORTED (use kq_snapshot_patch): amounts outside the plain range, sizes beyond the sort keys' fields (2^20 rows, 2^21 nodes). */
 typedef struct kq_row_patch {
@@ -358,7 +358,17 @@ typedef struct kq_row_patch {
   const int64_t* add_use_qty;
   int32_t n_evict;                  /* rows (of the resident table, not among remove_rows) that get KQ_ADM_EVICTED: the targets of the last cycle's */
   const int32_t* evict_rows;        /* preemptions stay admitted until they terminate, marked Evicted (preemption.go IssuePreemptions)            */
+  uint32_t flags;                   /* KQ_ROWS_* */
 } kq_row_patch;
+/* clusterQueue.updateWorkloadUsage (clusterqueue.go:594) in full: the usage of the removed rows leaves the snapshot (removeUsage
+ * resource_node.go:156), the usage of the added rows enters it (addUsage :144) — on the device, from the rows' own usage entries; with a
+ * pending set resident, the removal is the event that sends the inadmissible workloads of the freed root cohorts back to their heaps
+ * (QueueAssociatedInadmissibleWorkloadsAfter, inadmissible_workloads.go:112-147), as kq_cycle_release does. The caller then does NOT
+ * kq_cycle_commit the cycle whose admissions it adds as rows. This is the closed loop of a population with preemption
+ * (kueue_amd/closed_loop.py, shim/go/closed_loop.go): add = the heads the cycle admitted, evict_rows = its preemption targets,
+ * remove_rows = the targets of the cycle before (terminated) + the workloads that finished. Rows of more than 56 usage entries:
+ * KQ_EUNSUPPORTED. */
+#define KQ_ROWS_FOLD_USAGE 0x1u
 int  kq_snapshot_patch_rows(kq_engine* e, const kq_row_patch* p, int32_t* new_index);
 
 /* One scheduling cycle: nominate + iterator + processEntry (scheduler.go:308-386, steps 3-5).

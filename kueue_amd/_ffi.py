@@ -169,7 +169,10 @@ PATCH_USAGE, PATCH_ADMITTED = 1, 2
 class kq_row_patch(C.Structure):
     _fields_ = [("n_remove", C.c_int32), ("remove_rows", i32p), ("n_add", C.c_int32), ("add_cq", i32p), ("add_priority", i64p), ("add_queue_ts", i64p),
                 ("add_reserve_ts", i64p), ("add_uid_rank", u32p), ("add_flags", u8p), ("add_use_off", i32p), ("add_use_fr", i32p), ("add_use_qty", i64p),
-                ("n_evict", C.c_int32), ("evict_rows", i32p)]
+                ("n_evict", C.c_int32), ("evict_rows", i32p), ("flags", C.c_uint32)]
+
+
+ROWS_FOLD_USAGE = 1
 
 
 class kq_decisions(C.Structure):

@@ -32,19 +32,26 @@ namespace kqg {
 // 0.4 ms), yield when the others are late.
 class Barrier {
  public:
-  void reset(int parties) { n_ = parties; count_.store(0); gen_.store(0); }
-  void wait() {
+  void reset(int parties) { n_ = parties; count_.store(0); gen_.store(0); abort_.store(0); }
+  // a rank that leaves its job any other way than through the barriers (an exception) calls abort(code): everybody waiting, or arriving
+  // later, returns that code instead of waiting for a rank that is gone. reset() (the next job) clears it.
+  void abort(int code) { abort_.store(code, std::memory_order_release); }
+  int wait() {
+    if (int a = abort_.load(std::memory_order_acquire)) return a;
     const uint64_t g = gen_.load(std::memory_order_acquire);
     if (count_.fetch_add(1, std::memory_order_acq_rel) + 1 == n_) {
       count_.store(0, std::memory_order_relaxed);
       gen_.store(g + 1, std::memory_order_release);
-      return;
+      return 0;
     }
-    for (int spins = 0; gen_.load(std::memory_order_acquire) == g; spins++)
+    for (int spins = 0; gen_.load(std::memory_order_acquire) == g; spins++) {
+      if (int a = abort_.load(std::memory_order_acquire)) return a;
       if (spins > 4000) std::this_thread::yield();
+    }
+    return 0;
   }
  private:
-  std::atomic<int> count_{0}; std::atomic<uint64_t> gen_{0}; int n_ = 1;
+  std::atomic<int> count_{0}; std::atomic<uint64_t> gen_{0}; std::atomic<int> abort_{0}; int n_ = 1;
 };
 
 // the decision buffers of the ranks other than 0: same capacities as the caller's
@@ -113,7 +120,7 @@ struct Group {
         f = job;
       }
       int rc;
-      try { rc = f(r); } catch (const std::bad_alloc&) { rc = KQ_ENOMEM; } catch (...) { rc = KQ_EINVAL; }
+      try { rc = f(r); } catch (const std::bad_alloc&) { rc = KQ_ENOMEM; bar.abort(rc); } catch (...) { rc = KQ_EINVAL; bar.abort(rc); }
       {
         std::lock_guard<std::mutex> lk(jm);
         job_rc[(size_t)r] = rc;
@@ -125,6 +132,8 @@ struct Group {
   // contains on every rank (see phase()).
   template <class F> int run(F f) {
     origin.store(-1);
+    bar.reset(n);   // (nobody is inside the barrier between two jobs) — also clears an abort and the phase parity a broken job left behind
+    std::fill(phase_no.begin(), phase_no.end(), 0);
     if (n > 1) {
       std::lock_guard<std::mutex> lk(jm);
       job = f; job_left = n - 1; job_gen++;
@@ -133,7 +142,7 @@ struct Group {
     }
     (void)be.set_device(dev[0]);
     int rc0;
-    try { rc0 = f(0); } catch (const std::bad_alloc&) { rc0 = KQ_ENOMEM; } catch (...) { rc0 = KQ_EINVAL; }
+    try { rc0 = f(0); } catch (const std::bad_alloc&) { rc0 = KQ_ENOMEM; bar.abort(rc0); } catch (...) { rc0 = KQ_EINVAL; bar.abort(rc0); }
     if (n > 1) {
       std::unique_lock<std::mutex> lk(jm);
       dcv.wait(lk, [&] { return job_left == 0; });
@@ -152,7 +161,7 @@ struct Group {
   int phase(int r, int rc) {
     std::vector<int>& pr = phase_rc[(size_t)(phase_no[(size_t)r]++ & 1)];
     pr[(size_t)r] = rc;
-    bar.wait();
+    if (const int gone = bar.wait()) return gone;   // a rank left through an exception: its code, nobody waits for it
     for (int q = 0; q < n; q++) if (pr[(size_t)q] != KQ_OK) { int none = -1; origin.compare_exchange_strong(none, q); return pr[(size_t)q]; }   // (every rank finds the same q; the first failing phase names the rank)
     return KQ_OK;
   }
@@ -161,7 +170,7 @@ struct Group {
     n = n_dev; flags = fl;
     dev.assign(devices, devices + n_dev);
     if (!host_collective())
-      for (int i = 0; i < n_dev; i++) for (int j = 0; j < i; j++) if (dev[(size_t)i] == dev[(size_t)j]) return KQ_EINVAL;   // RCCL: one rank per device
+      for (int i = 0; i < n_dev; i++) for (int j = 0; j < i; j++) if (dev[(size_t)i] == dev[(size_t)j]) { n = 0; return fail(KQ_EINVAL, "one rank per device: a device is listed twice (KQ_GROUP_HOST_COLLECTIVE lifts this)"); }   // RCCL: one rank per device; n = 0: nothing was created, destroy() has nothing to walk
     eng.assign((size_t)n_dev, nullptr); xbuf.assign((size_t)n_dev, nullptr); xwords.assign((size_t)n_dev, 0);
     hbuf.assign((size_t)n_dev, nullptr); scratch.resize((size_t)n_dev); job_rc.assign((size_t)n_dev, KQ_OK); phase_rc[0].assign((size_t)n_dev, KQ_OK); phase_rc[1].assign((size_t)n_dev, KQ_OK); phase_no.assign((size_t)n_dev, 0);
     bar.reset(n_dev);
@@ -190,7 +199,7 @@ struct Group {
     for (auto& t : workers) if (t.joinable()) t.join();
     workers.clear();
     be.comm_destroy();
-    for (int r = 0; r < n; r++) {
+    for (int r = 0; r < n && (size_t)r < eng.size(); r++) {   // (a create() that failed half-way leaves null entries, one that failed before sizing leaves none)
       (void)be.set_device(dev[(size_t)r]);
       if (xbuf[(size_t)r]) be.xfree(xbuf[(size_t)r]);
       if (hbuf[(size_t)r]) be.host_free(hbuf[(size_t)r]);

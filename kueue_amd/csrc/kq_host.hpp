@@ -604,6 +604,24 @@ template <class B> struct EngineT {
     R.n_ucnt = grow<int32_t>(rb[11], (size_t)n_new + 1);
     be.memset(R.n_ucnt, 0, ((size_t)n_new + 1) * 4);
     R.new_of_old = grow<int32_t>(rb[3], std::max(n_old, 1));   // (rb[3] = ent_cnt of the rebuild: free until then)
+    // KQ_ROWS_FOLD_USAGE: the usage rows of what leaves and what arrives, packed from the OLD table / the staged rows before anything moves
+    const bool fold = (p->flags & KQ_ROWS_FOLD_USAGE) != 0;
+    if (p->flags & ~KQ_ROWS_FOLD_USAGE) return fail(KQ_EINVAL, "unknown kq_row_patch.flags");
+    int32_t *f_cq = nullptr, *f_un = nullptr, *f_fr = nullptr; int64_t* f_qty = nullptr;
+    if (fold && n_rm + n_add > 0) {
+      const size_t nf = (size_t)n_rm + n_add;
+      f_cq = grow<int32_t>(fb[0], nf); f_un = grow<int32_t>(fb[1], nf); f_fr = grow<int32_t>(fb[2], nf * KQ_MAXU); f_qty = grow<int64_t>(fb[3], nf * KQ_MAXU);
+      int32_t* f_err = grow<int32_t>(fb[4], 4);
+      be.memset(f_err, 0, 16);
+      R.n_rm = n_rm; R.a_cq = (const int32_t*)stage(fb[5], p->add_cq, (size_t)n_add * 4);
+      R.f_cq = f_cq; R.f_use_n = f_un; R.f_use_fr = f_fr; R.f_use_qty = f_qty; R.f_err = f_err;
+      be.launch_rows(R, RO_FOLD_PACK, (int)nf);
+      int32_t err = 0;
+      be.d2h(&err, f_err, 4);
+      int rc0 = be.sync();
+      if (rc0 != KQ_OK) return fail(rc0, be.error());
+      if (err) return fail(KQ_EUNSUPPORTED, "KQ_ROWS_FOLD_USAGE: a row of more than KQ_MAXU usage entries");
+    }
     be.launch_rows(R, RO_MOVE_ROW, n_old);
     be.launch_rows(R, RO_ADD_ROW, n_add);
     if (p->n_evict > 0) {   // (two marks of one row write the same byte with the same bit: no ordering needed)
@@ -642,9 +660,25 @@ template <class B> struct EngineT {
     rc = rows_rebuild(n_new);
     // not atomic on failure: the new row table is resident but the structures derived from it are not — no cycle may run on that.
     // The caller re-puts (kq_snapshot_put); every entry point checks have_snapshot.
-    if (rc != KQ_OK) have_snapshot = false;
-    return rc;
+    if (rc != KQ_OK) { have_snapshot = false; return rc; }
+    if (fold) {
+      // removeUsage of what left, addUsage of what arrived (resource_node.go:144-165) through the commit's own cell functions; quota that was
+      // freed sends the inadmissible workloads of those root cohorts back to their heaps, as a release does
+      if (n_rm > 0) {
+        DCommit dc{n_rm, f_cq, f_un, f_fr, f_qty, d_usage, d_big};
+        apply_commit(dc, false);
+        if (pend.valid && pend.nq == prep.nq) be.launch_pend_release(pend.D, S, pend.d_tree_stamp, dc.cq, dc.use_n, n_rm, ++pend.release_seq);
+      }
+      if (n_add > 0) {
+        DCommit dc{n_add, f_cq + n_rm, f_un + n_rm, f_fr + (size_t)n_rm * KQ_MAXU, f_qty + (size_t)n_rm * KQ_MAXU, d_usage, d_big};
+        apply_commit(dc, true);
+      }
+      rc = be.sync();
+      if (rc != KQ_OK) return fail(rc, be.error());
+    }
+    return KQ_OK;
   }
+  Buf fb[6];   // KQ_ROWS_FOLD_USAGE: the packed usage rows
   // test hook: the resident admitted-row structures, one by one (which: 0 adm_cq, 1 tree_row_off, 2 tree_rows, 3 tree_rows_asc, 4 rank_pos,
   // 5 frb_off, 6 frb, 7 frbr, 8 cq_row_bytes, 9 adm_rec, 10 frec, 11-13 frl, 14 frb_sig, 15 cs_ok, 16 rec_ok, 17 cq_adm_off, 18 adm_use_off,
   // 19 adm_use_fr, 20 adm_use_qty, 21 adm_prio, 22 adm_qts, 23 adm_rts, 24 adm_uid, 25 adm_flags). *bytes: capacity in, size out.
@@ -1327,12 +1361,11 @@ template <class B> struct EngineT {
           if (del_out[p] > 0) m.push_back({sp_req[p * SP_W + SP_DEL], del_out[p]});
           for (int j = e0; j < e1; j++) if (!(t->ps_ex_flags[j] & KQ_EX_FIRST)) m.push_back({t->ps_ex_leaf[j], t->ps_ex_count[j]});
           std::stable_sort(m.begin(), m.end(), [](const std::pair<int, int32_t>& a, const std::pair<int, int32_t>& b) { return a.first < b.first; });
-          int last = -1;
-          for (auto& d : m) {
-            if (last >= 0 && tout->dom_leaf && tout->dom_leaf[last] == d.first) { if (tout->dom_count) tout->dom_count[last] += d.second; continue; }
-            if (!put(d.first, d.second)) return fail(KQ_ECAPACITY, "dom_cap too small");
-            last = tot - 1;
-          }
+          // (merged on the local list, not on the output arrays: dom_leaf / dom_count may be null for a caller that only wants the offsets)
+          size_t u = 0;
+          for (size_t j = 0; j < m.size(); j++) { if (u > 0 && m[u - 1].first == m[j].first) m[u - 1].second += m[j].second; else m[u++] = m[j]; }
+          m.resize(u);
+          for (auto& d : m) if (!put(d.first, d.second)) return fail(KQ_ECAPACITY, "dom_cap too small");
         } else if (del_out[p] >= 0) {   // (-1: a failed result took the assignment away, UpdateForTASResult flavorassigner.go:90)
           tt = sp_tas[p];
           for (int j = e0; j < e1; j++) if (!put(t->ps_ex_leaf[j], t->ps_ex_count[j])) return fail(KQ_ECAPACITY, "dom_cap too small");

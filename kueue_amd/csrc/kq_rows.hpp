@@ -20,7 +20,7 @@ namespace kq {
 struct RowsScratch { void* p = nullptr; size_t cap = 0; };
 
 enum { RO_ROW_INIT = 0, RO_KEY_RTS, RO_KEY_PRIO, RO_KEY_TREE, RO_RANK, RO_KEY_ASC, RO_ASC, RO_ENT_FILL, RO_BOUNDS, RO_BUCKET_FILL, RO_BUCKET_SIZE,
-       RO_LKEY, RO_LFILL, RO_MOVE_ROW, RO_MOVE_ENT, RO_ADD_ROW, RO_KEY_FS, RO_FS_FILL, RO_EVICT, RO_REMAP };
+       RO_LKEY, RO_LFILL, RO_MOVE_ROW, RO_MOVE_ENT, RO_ADD_ROW, RO_KEY_FS, RO_FS_FILL, RO_EVICT, RO_REMAP, RO_FOLD_PACK };
 
 struct DRows {
   // the row table the structures are built from
@@ -61,6 +61,9 @@ struct DRows {
   const int32_t* ev_rows;   // old rows that get KQ_ADM_EVICTED
   int n_old, n_add;
   const int32_t *a_target, *a_use_off, *a_use_fr; const int64_t *a_prio, *a_qts, *a_rts, *a_use_qty; const uint32_t* a_uid; const uint8_t* a_flags;
+  // KQ_ROWS_FOLD_USAGE: the removed rows [0, n_rm) and the added rows [n_rm, n_rm + n_add) as the usage rows of a commit (DCommit layout)
+  int n_rm; const int32_t* a_cq;
+  int32_t *f_cq, *f_use_n, *f_use_fr; int64_t* f_use_qty; int32_t* f_err;
 };
 
 KQ_DEV uint64_t ro_bias(int64_t v) { return (uint64_t)v ^ 0x8000000000000000ull; }
@@ -254,6 +257,16 @@ KQ_DEV void ro_move_ent(const DRows& R, int r) {   // r < n_old: an old row's en
   }
 }
 
+KQ_DEV void ro_fold_pack(const DRows& R, int i) {
+  int cq, e0, e1; const int32_t* fr; const int64_t* qty;
+  if (i < R.n_rm) { const int r = R.rm_rows[i]; cq = R.o_adm_cq[r]; e0 = R.o_use_off[r]; e1 = R.o_use_off[r + 1]; fr = R.o_use_fr; qty = R.o_use_qty; }
+  else { const int a = i - R.n_rm; cq = R.a_cq[a]; e0 = R.a_use_off[a]; e1 = R.a_use_off[a + 1]; fr = R.a_use_fr; qty = R.a_use_qty; }
+  int n = e1 - e0;
+  if (n > KQ_MAXU) { *R.f_err = 1; n = 0; }
+  R.f_cq[i] = cq; R.f_use_n[i] = n;
+  for (int q = 0; q < n; q++) { R.f_use_fr[(size_t)i * KQ_MAXU + q] = fr[e0 + q]; R.f_use_qty[(size_t)i * KQ_MAXU + q] = qty[e0 + q]; }
+}
+
 KQ_DEV void rows_cell(const DRows& R, int op, int i, bool active) {
   if (op == RO_BUCKET_FILL) { ro_bucket_fill(R, i, active); return; }   // (every lane of the wave takes part in its reduction)
   if (!active) return;
@@ -277,6 +290,7 @@ KQ_DEV void rows_cell(const DRows& R, int op, int i, bool active) {
     case RO_FS_FILL: ro_fs_fill(R, i); break;
     case RO_EVICT: ro_evict(R, i); break;
     case RO_REMAP: ro_remap(R, i); break;
+    case RO_FOLD_PACK: ro_fold_pack(R, i); break;
     default: break;
   }
 }

@@ -1204,11 +1204,28 @@ KQ_DEV int32_t t_bal_threshold(const TState& s, int32_t sliceCount, const TGreed
   if (g.last >= 0 && s.sc[g.last] < t) t = s.sc[g.last];
   return t;
 }
+// math.Log as Go computes it on amd64 (src/math/log.go: the pure-Go port of FreeBSD's e_log.c — there is no assembly stub outside s390x):
+// the libm of the host and HIP's device log are correctly rounded to < 1 ulp too, but not bit-identical to it, and a 1-ulp difference in
+// calculateDomainsEntropy can flip compareDomainCapacityAndEntropy between two near-equal domains. x is a finite positive fraction here
+// (frac of Frexp, in [0.5, 1)); no fused multiply-add (-ffp-contract=off; GOAMD64=v1 does not fuse either).
+KQ_DEV double t_go_log(double x) {
+  const double Ln2Hi = 6.93147180369123816490e-01, Ln2Lo = 1.90821492927058770002e-10,
+               L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01, L3 = 2.857142874366239149e-01, L4 = 2.222219843214978396e-01,
+               L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01, L7 = 1.479819860511658591e-01;
+  int ki; double f1 = ::frexp(x, &ki);
+  if (f1 < 0.70710678118654752440 /* Sqrt2 / 2 */) { f1 *= 2; ki--; }
+  const double f = f1 - 1, k = (double)ki;
+  const double s = f / (2 + f), s2 = s * s, s4 = s2 * s2;
+  const double t1 = s2 * (L1 + s4 * (L3 + s4 * (L5 + s4 * L7)));
+  const double t2 = s4 * (L2 + s4 * (L4 + s4 * L6));
+  const double R = t1 + t2, hfsq = 0.5 * f * f;
+  return k * Ln2Hi - ((hfsq - (s * (hfsq + R) + k * Ln2Lo)) - f);
+}
 // math.Log2 (log2.go): Frexp, then Log(frac) * (1 / Ln2) + exp
 KQ_DEV double t_bal_log2(double x) {
   int e; const double frac = ::frexp(x, &e);
   if (frac == 0.5) return (double)(e - 1);
-  return ::log(frac) * (1.0 / 0.693147180559945309417232121458176568) + (double)e;
+  return t_go_log(frac) * (1.0 / 0.693147180559945309417232121458176568) + (double)e;
 }
 KQ_DEV double t_bal_entropy(const TK& k, const TState& s, int d) {   // calculateDomainsEntropy :189 of d's children
   const int c0 = k.T.child_first[d], cn = c0 >= 0 ? k.T.child_cnt[d] : 0;

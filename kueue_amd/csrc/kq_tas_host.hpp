@@ -458,11 +458,16 @@ template <class Backend> struct TasT {
     out->dom_off[0] = 0;
     auto emit = [&](std::vector<std::pair<int32_t, int32_t>>& mlist, bool sort_merge) -> bool {
       if (sort_merge) std::stable_sort(mlist.begin(), mlist.end(), [](const std::pair<int32_t, int32_t>& a, const std::pair<int32_t, int32_t>& b) { return a.first < b.first; });
-      int last = -1;
+      if (sort_merge) {   // (equal leaves merged on the local list: dom_leaf / dom_count may be null for a caller that only wants the offsets)
+        size_t u = 0;
+        for (size_t j = 0; j < mlist.size(); j++) { if (u > 0 && mlist[u - 1].first == mlist[j].first) mlist[u - 1].second += mlist[j].second; else mlist[u++] = mlist[j]; }
+        mlist.resize(u);
+      }
       for (auto& dm : mlist) {
-        if (sort_merge && last >= 0 && out->dom_leaf[last] == dm.first) { out->dom_count[last] += dm.second; continue; }
         if (tot >= out->dom_cap) return false;
-        out->dom_leaf[tot] = dm.first; out->dom_count[tot] = dm.second; last = tot++;
+        if (out->dom_leaf) out->dom_leaf[tot] = dm.first;
+        if (out->dom_count) out->dom_count[tot] = dm.second;
+        tot++;
       }
       return true;
     };

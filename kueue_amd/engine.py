@@ -16,10 +16,11 @@ from . import _ffi as F
 from .api import Decisions, Heads, Snapshot, make_config
 
 
-def row_patch_struct(remove_rows, add, evict_rows=()):
+def row_patch_struct(remove_rows, add, evict_rows=(), fold_usage=False):
     """kq_row_patch from plain arrays -> (struct, the arrays it points into)."""
     keep = []
     p = F.kq_row_patch()
+    p.flags = F.ROWS_FOLD_USAGE if fold_usage else 0
     rm = np.ascontiguousarray(remove_rows, np.int32)
     keep.append(rm)
     p.n_remove = len(rm); p.remove_rows = F.ptr(rm) if len(rm) else None
@@ -82,10 +83,11 @@ class Engine:
         self._check(self._lib.kq_snapshot_patch(self._h, C.byref(snap.struct()), what))
         self.snap = snap
 
-    def patch_rows(self, remove_rows=(), add: Optional[dict] = None, evict_rows=()) -> np.ndarray:
+    def patch_rows(self, remove_rows=(), add: Optional[dict] = None, evict_rows=(), fold_usage=False) -> np.ndarray:
         """kq_snapshot_patch_rows: rows that left / rows that came (add: dict of arrays cq, priority, queue_ts, reserve_ts, uid_rank, flags,
-        use_off, use_fr, use_qty); the admitted table and everything derived from it are rebuilt on the device. -> new index of every old row."""
-        p, keep = row_patch_struct(remove_rows, add, evict_rows)
+        use_off, use_fr, use_qty); the admitted table and everything derived from it are rebuilt on the device. -> new index of every old row.
+        fold_usage (KQ_ROWS_FOLD_USAGE): the usage of the rows that left leaves the snapshot, the usage of the rows that came enters it."""
+        p, keep = row_patch_struct(remove_rows, add, evict_rows, fold_usage)
         new_index = np.zeros(max(self._n_adm(), 1), np.int32)
         self._check(self._lib.kq_snapshot_patch_rows(self._h, C.byref(p), F.ptr(new_index)))
         return new_index

@@ -120,9 +120,41 @@ def _quota(rng, unit, lo, hi, limits: bool, unlimited_p: float):
 
 
 def generate(cfg: int, seed: int = BASE_SEED, n_cq: int = None, per_cq: int = None, preemption: bool = None,
-             fair_sharing: bool = False, fill: float = 1.0) -> Population:
+             fair_sharing: bool = False, fill: float = 1.0, feasible: bool = False) -> Population:
     """Build population `cfg` (1..4). n_cq / per_cq override the sizes for parity-sized variants; fill scales how full the admitted
-    set leaves every flavor (1.0 = the BASELINE populations; < 1 leaves headroom at the root cohort)."""
+    set leaves every flavor (1.0 = the BASELINE populations; < 1 leaves headroom at the root cohort).
+    feasible (cfg 4): a start state admission could have produced — in no flavor-resource does the ROOT cohort's usage exceed its
+    SubtreeQuota, and every root cell is 80-100 % full (the spec'd cfg 4 fills every ClusterQueue to 1.0-1.5 x nominal on every flavor: 40 of 64 root cells over-committed, a
+    state fits() never admits into). ClusterQueues alternate, per flavor, between borrowers (above nominal, on what their siblings
+    lend) and lenders (80-95 % of it); per flavor-resource the fills are scaled until the root is 80-100 % full: pending heads meet a full tree."""
+    if feasible:
+        if cfg != 4:
+            raise ValueError("feasible: cfg 4 only")
+        fac = None
+        for it in range(16):
+            pop = _generate(cfg, seed, n_cq, per_cq, preemption, fair_sharing, fill, fac if fac is not None else 1.0)
+            sn = pop.snapshot
+            a = sn.arrays
+            u, sq = a["usage"].reshape(sn.N, sn.n_fr).astype(np.float64), a["subtree_quota"].reshape(sn.N, sn.n_fr).astype(np.float64)
+            roots = [n for n in range(sn.n_cq, sn.N) if a["parent"][n] < 0]
+            ur, sr = u[roots].sum(0), sq[roots].sum(0)
+            live = (sr > 0) & (sr < 2.0 ** 62)
+            if sn.pods_resource >= 0:   # (a row's `pods` usage is its pod count, not a fill: those cells stay nearly empty)
+                live[sn.pods_resource::sn.n_resource] = False
+            ratio = np.where(live, ur / np.maximum(sr, 1.0), 0.0)
+            over = all((u[r] <= sq[r]).all() for r in roots)
+            if over and (ratio[live] >= 0.78).all():   # (gpu cells move in whole devices: 0.8 is as close as the coarse ones get)
+                pop.name += "-feasible"
+                return pop
+            if fac is None:
+                fac = np.ones(sn.n_fr)
+            # every root cell towards 96 % full (usage above the guaranteed part bubbles up: not linear in the factor, hence the iteration)
+            fac = fac * np.where(live, np.clip((0.96 if it < 12 else 0.93) / np.maximum(ratio, 1e-9), 0.6, 1.6), 1.0)
+        raise RuntimeError("no feasible fill found")
+    return _generate(cfg, seed, n_cq, per_cq, preemption, fair_sharing, fill, None)
+
+
+def _generate(cfg, seed, n_cq, per_cq, preemption, fair_sharing, fill, feas):
     rng = np.random.default_rng(seed + cfg)
     if cfg == 1:
         nq, F, res, per, shape, strategy = 4, 2, ["cpu"], 25, "none", "StrictFIFO"
@@ -219,13 +251,17 @@ def generate(cfg: int, seed: int = BASE_SEED, n_cq: int = None, per_cq: int = No
                 continue
             fq = cq.resource_groups[0].flavors[fi]
             fill_f = rng.uniform(lo_f, hi_f) * fill
+            if feas is not None:   # borrowers above nominal, lenders below (one draw either way: the stream stays aligned)
+                fill_f = (1.02 + (fill_f - 1.0) * 0.5) if (i + fi) % 2 == 0 else (0.80 + (fill_f - 1.0) * 0.3)
             for j in range(k):
                 ps = PodSet("main", count=int(rng.integers(1, 5)))
                 for r in res:
                     nom = fq.resources[r].nominal
                     if nom == MAXI64:
                         nom = ranges[r][1] * units[r]
-                    ps.requests[r] = ps.count if r == "pods" else int(nom * fill_f / k / units[r]) * units[r]
+                    # (feas: a factor per flavor-resource, indexed as the snapshot does — fr = flavor * n_resource + resource, names ascending)
+                    ff = fill_f if feas is None or np.isscalar(feas) else fill_f * float(feas[fi * len(res) + sorted(res).index(r)])
+                    ps.requests[r] = ps.count if r == "pods" else int(nom * ff / k / units[r]) * units[r]
                     ps.flavors[r] = f
                 t += 1
                 admitted.append(Workload(f"{cq.name}-adm-{fi:02d}-{j}", cq.name, priority=int(rng.integers(0, 8 if preemption else 4)),

@@ -241,6 +241,9 @@ type RowPatch struct {
 	AddUseOff, AddUseFr                   []int32
 	AddUseQty                             []int64
 	EvictRows                             []int32 // rows that get the Evicted mark: the targets of the last cycle's preemptions
+	// KQ_ROWS_FOLD_USAGE: the usage of the removed rows leaves the resident snapshot, the usage of the added rows enters it
+	// (clusterQueue.updateWorkloadUsage in full); the cycle whose admissions are added as rows is then not committed with CommitCycle.
+	FoldUsage bool
 }
 
 // PatchRows = kq_snapshot_patch_rows: the O(changes) form of PatchSnapshot(KQ_PATCH_ADMITTED). newIndex (len = rows before the call)
@@ -265,6 +268,9 @@ func (e *Engine) PatchRows(p *RowPatch, newIndex []int32) error {
 	c.add_use_qty = (*C.int64_t)(pin(&pin_, p.AddUseQty))
 	c.n_evict = C.int32_t(len(p.EvictRows))
 	c.evict_rows = (*C.int32_t)(pin(&pin_, p.EvictRows))
+	if p.FoldUsage {
+		c.flags = C.KQ_ROWS_FOLD_USAGE
+	}
 	if rc := C.kq_snapshot_patch_rows(e.h, c, (*C.int32_t)(pin(&pin_, newIndex))); rc != 0 {
 		if rc == C.KQ_EUNSUPPORTED {
 			return ErrUnsupported

@@ -356,6 +356,7 @@ const char* kqe_last_error(void* e) { return ((EmuEngine*)e)->last_error.c_str()
 // rank workers, phase barriers, error containment, the host collective) with the kqe_* engines above and malloc'ed "device" buffers.
 // The device collective does not exist here: a group is always created with KQ_GROUP_HOST_COLLECTIVE. `inject`: a rank and a step
 // (1 nominate, 2 export copy, 3 import copy, 4 process) that fails once with KQ_EDEVICE — the other ranks must leave the cycle with it.
+#include <stdexcept>
 #include "../../kueue_amd/csrc/kq_group_core.hpp"
 namespace {
 struct EmuGroupBackend {
@@ -384,9 +385,10 @@ struct EmuGroupBackend {
     if ((int)xb.size() < world) xb.resize((size_t)world, nullptr);
     xb[(size_t)rank] = x;
     if (take(rank, 1)) return KQ_EDEVICE;
+    if (take(rank, 5)) throw std::runtime_error("injected");   // a rank that leaves its job through an exception (Barrier::abort)
     return kqe_cycle_nominate_shard(e, h, mine, world, rank, x, o);
   }
-  int process_merged(void* e, int world, int rank, const void* x, kq_decisions* o) { if (take(rank, 4)) return KQ_EDEVICE; return kqe_cycle_process_merged(e, world, rank, x, o); }
+  int process_merged(void* e, int world, int rank, const void* x, kq_decisions* o) { if (take(rank, 4)) return KQ_EDEVICE; if (take(rank, 6)) throw std::bad_alloc(); return kqe_cycle_process_merged(e, world, rank, x, o); }
   int commit(void* e, int32_t* n) { return kqe_cycle_commit(e, n); }
   int release(void* e, int32_t age) { return kqe_cycle_release(e, age); }
   int read_usage(void* e, int64_t* u) { return kqe_read_planes(e, nullptr, u, nullptr); }
@@ -400,7 +402,8 @@ int kqe_group_create(const kq_config* cfg, int32_t n, uint32_t flags, void** out
   auto* g = new EmuGroup();
   g->be.xb.assign((size_t)n, nullptr);   // (sized before the workers exist: nominate_shard only writes its own slot)
   std::vector<int32_t> dev((size_t)n, 0);
-  const int rc = g->create(cfg, n, dev.data(), flags | KQ_GROUP_HOST_COLLECTIVE);
+  // (bit 30: as given — the duplicate-device refusal of a group without the host collective, tests/test_group.py)
+  const int rc = g->create(cfg, n, dev.data(), (flags & (1u << 30)) ? (flags & ~(1u << 30)) : (flags | KQ_GROUP_HOST_COLLECTIVE));
   if (rc != KQ_OK) { g->destroy(); delete g; return rc; }
   *out = g;
   return KQ_OK;

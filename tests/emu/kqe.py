@@ -296,10 +296,10 @@ def _run_tas(self, heads, ct, tgt_cap=None, want_usage=False, dom_cap=None, rsn_
 EmuEngine.run_tas = _run_tas
 
 
-def _patch_rows(self, remove_rows=(), add=None, evict_rows=()):
+def _patch_rows(self, remove_rows=(), add=None, evict_rows=(), fold_usage=False):
     """kqe_snapshot_patch_rows on the emulated engine -> (rc, new index of every old row)."""
     from kueue_amd.engine import row_patch_struct
-    p, keep = row_patch_struct(remove_rows, add, evict_rows)
+    p, keep = row_patch_struct(remove_rows, add, evict_rows, fold_usage)
     cap = C.c_int64(0)
     lib().kqe_debug_read_rows(self.h, C.c_int32(0), None, C.byref(cap))
     new_index = np.zeros(max(int(cap.value) // 4, 1), np.int32)

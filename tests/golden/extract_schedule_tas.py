@@ -120,6 +120,12 @@ def items_of(expr, sym):
 
 
 def parse_node(text, sym):
+    if "MakeNode" not in text:
+        # `*singleNode.Clone().StatusAllocatable(...).Obj()`: a builder variable (a MakeNode chain without Obj) and the calls made on its copy —
+        # the variable's own chain first, then those (StatusAllocatable merges, testingjobs/node/wrappers.go:82)
+        m = re.match(r"^\s*\*?(\w+)\s*\.", text)
+        if m and m.group(1) in sym and "MakeNode" in sym[m.group(1)]:
+            text = sym[m.group(1)].rstrip() + text[m.end() - 1:]
     calls, _ = chain(text, text.index("MakeNode"))
     n = {"name": calls[0][1].strip().strip('"'), "labels": {}, "allocatable": {}, "ready": False}
     for m, a in calls[1:]:

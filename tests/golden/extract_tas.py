@@ -275,14 +275,28 @@ def parse_podset(body, named_levels):
         ps["wantReason"] = w[1:-1].replace('\\"', '"')
     if "wantAssignment" in f and f["wantAssignment"] != "nil":
         w = f["wantAssignment"]
-        wf = top_level_fields(w[w.index("{") + 1:w.rindex("}")])
-        doms = []
-        dtext = wf["Domains"]
-        for el in elements(dtext[dtext.index("{") + 1:dtext.rindex("}")]):
-            df = top_level_fields(el[el.index("{") + 1:el.rindex("}")])
+
+        def domain(body):
+            df = top_level_fields(body)
             vals = df["Values"]
-            doms.append(dict(count=int(df["Count"]), values=[ident(x) for x in elements(vals[vals.index("{") + 1:vals.rindex("}")])]))
-        ps["wantAssignment"] = dict(levels=parse_strings(wf["Levels"], named_levels), domains=doms)
+            return dict(count=int(df["Count"]), values=[ident(x) for x in elements(vals[vals.index("{") + 1:vals.rindex("}")])])
+
+        bm = re.search(r"MakeTopologyAssignment\(", w)
+        if bm:
+            # the builder form: utiltestingapi.MakeTopologyAssignment([]string{levels}).Domain(tas.TopologyDomainAssignment{Count, Values})....TopologyAssignment
+            close = match_brace(w, bm.end() - 1, "(", ")")
+            levels = parse_strings(w[bm.end():close], named_levels)
+            doms, i = [], close
+            for dm in re.finditer(r"\.\s*Domain\(", w[close:]):
+                o = close + dm.end() - 1
+                arg = w[o + 1:match_brace(w, o, "(", ")")]
+                doms.append(domain(arg[arg.index("{") + 1:arg.rindex("}")]))
+            ps["wantAssignment"] = dict(levels=levels, domains=doms)
+        else:
+            wf = top_level_fields(w[w.index("{") + 1:w.rindex("}")])
+            dtext = wf["Domains"]
+            doms = [domain(el[el.index("{") + 1:el.rindex("}")]) for el in elements(dtext[dtext.index("{") + 1:dtext.rindex("}")])]
+            ps["wantAssignment"] = dict(levels=parse_strings(wf["Levels"], named_levels), domains=doms)
     return ps
 
 

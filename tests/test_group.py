@@ -10,6 +10,8 @@ import os
 import re
 
 import numpy as np
+import ctypes as C
+
 import pytest
 
 from kueue_amd import _ffi as F
@@ -142,6 +144,41 @@ def test_a_failing_rank_takes_every_rank_out_of_the_cycle(rank, step):
         assert not want.equal(got), want.equal(got)
     finally:
         g.close(); eng.close()
+
+
+@pytest.mark.parametrize("rank,step,code", [(0, 5, -1), (1, 5, -1), (0, 6, -2), (1, 6, -2)])
+def test_a_rank_that_throws_takes_every_rank_out_of_the_cycle(rank, step, code):
+    """ADVICE r05: a rank whose job ends in a C++ exception (5: std::runtime_error inside nominate -> KQ_EINVAL, 6: std::bad_alloc inside
+    process -> KQ_ENOMEM) never reaches the remaining phase barriers; Barrier::abort lets the others out (the test would hang), and the next
+    cycle starts from a reset barrier / phase parity and equals one engine's."""
+    from kueue_amd.api import make_config
+    from tests.emu import kqe
+    pop, _ = _population("cfg4c")
+    cfg = make_config()
+    g = kqe.EmuGroup(cfg, 2)
+    eng = kqe.EmuEngine(cfg); eng.put(pop.snapshot)
+    try:
+        g.put(pop.snapshot)
+        heads = pop.heads_for_cycle(0, cycle=1)
+        g.inject(rank, step)
+        rc = g.run(heads, tgt_cap=4 * pop.snapshot.n_adm, check=False)
+        assert rc == code, rc
+        for _ in range(2):
+            got = g.run(heads, tgt_cap=4 * pop.snapshot.n_adm)
+            want = eng.run(heads, tgt_cap=4 * pop.snapshot.n_adm)
+            assert not want.equal(got), want.equal(got)
+    finally:
+        g.close(); eng.close()
+
+
+def test_duplicate_devices_without_the_host_collective_are_refused_not_crashed():
+    """kq_group_create(devices=[0, 0], flags=0) is KQ_EINVAL — create() returns before anything is sized and destroy() must not
+    walk vectors that were never filled."""
+    from kueue_amd.api import make_config
+    from tests.emu import kqe
+    h = C.c_void_p()
+    rc = kqe.lib().kqe_group_create(C.byref(make_config()), C.c_int32(2), C.c_uint32(1 << 30), C.byref(h))
+    assert rc == F.KQ_EINVAL and not h.value, rc
 
 
 def test_group_keeps_the_engines_error_code():
