@@ -88,6 +88,17 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # the rank count RCCL itself saw: a SUM all-reduce of ones on device tensors — fail loudly when it is not the launch's world size
+        ones = torch.ones(1, dtype=torch.int64, device="cuda")
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        if int(ones[0]) != world:
+            raise SystemExit(f"RCCL all-reduce saw {int(ones[0])} ranks, the launch has {world}")
+        _RANKS.update(world=world, backend=f"{dist.get_backend()} (RCCL)", rccl_allreduce_ranks_seen=int(ones[0]),
+                      data_path_collective=("none: whole root cohorts per rank, the collective only carries the timing (barrier, MAX / SUM of the window)"
+                                            if not args.workload.endswith(("-split", "-group")) else "see the workload's own fields"),
+                      expected_ceiling=("weak scaling with no exchange on the data path: N x the single-GPU value, minus launch skew between ranks"
+                                        if not args.workload.endswith(("-split", "-group")) else "see expected_ceiling / the split protocol's fallback rate"))
 
     if args.workload.endswith("-group"):
         return bench_group(args, torch, dist, world, rank, local_rank)
@@ -1044,29 +1055,63 @@ def bench_group(args, torch, dist, world, rank, local_rank):
                     return False
         return True
 
+    if world > 1 and rank != 0:
+        # kq_group is ONE process over several devices (ncclCommInitAll): under torchrun the other ranks only keep the rendezvous alive
+        dist.barrier(); dist.destroy_process_group()
+        return
     eng = Engine(kcfg); eng.put(snap)
-    plain_ms, want = loop(eng, lambda h: eng.run(h, tgt_cap=tgt_cap))
+    phase = np.zeros(3); pby = np.zeros(2, np.int64); nom = tot = 0.0
+    from kueue_amd import _ffi as F
+
+    def plain_run(h):
+        nonlocal nom, tot
+        d = eng.run(h, tgt_cap=tgt_cap)
+        eng._lib.kq_last_cycle_phases(eng._h, F.ptr(phase), F.ptr(pby))
+        nom += phase[0]; tot += phase.sum()
+        return d
+    plain_ms, want = loop(eng, plain_run)
     want_usage = eng.read_usage(); eng.close()
     legs = {}
-    for name, devices, flags in (("one engine through the sharded path", [local_rank], G.FORCE_SHARDED), ("two engines on this device, host collective", [local_rank, local_rank], G.HOST_COLLECTIVE)):
+    plan = [("one engine through the sharded path", [local_rank], G.FORCE_SHARDED), ("two engines on this device, host collective", [local_rank, local_rank], G.HOST_COLLECTIVE)]
+    n_dev = max(world, args.gpus)
+    if n_dev > 1:
+        if torch.cuda.device_count() < n_dev:
+            raise SystemExit(f"{args.workload} --gpus {n_dev}: only {torch.cuda.device_count()} devices visible to this process")
+        plan.append((f"{n_dev} devices, RCCL all-reduce over xGMI", list(range(n_dev)), 0))
+    rccl = None
+    for name, devices, flags in plan:
         g = G.Group(kcfg, devices=devices, flags=flags)
         g.put(snap)
         ms, got = loop(g, lambda h: g.run(h, tgt_cap=tgt_cap))
         ok = same(want, got) and all(np.array_equal(want_usage, g.usage(r)) for r in range(len(devices)))
+        if flags == 0 and len(devices) > 1:
+            rccl = g.collective_info()
+            # a scaling figure measured over the host seam, or without the collective having run, would be a lie: fail loudly
+            if rccl["rccl_ranks"] != len(devices) or rccl["allreduce_calls"] < total or rccl["host_sums"] != 0:
+                raise SystemExit(f"{args.workload}: the {len(devices)}-device group did not run on RCCL: {rccl}")
         g.close()
         legs[name] = {"ms_per_cycle": float(np.mean(ms)), "p50_ms": float(np.percentile(ms, 50)), "p99_ms": float(np.percentile(ms, 99)),
                       "ratio_to_plain": float(np.mean(ms)) / float(np.mean(plain_ms)), "equal_to_plain_engine": bool(ok)}
     dec = sum(batches[i % n_batches].n for i in range(args.warmup, total))
-    two = legs["two engines on this device, host collective"]
+    two = legs[plan[-1][0]]
+    # nomination is sharded, order + processEntry are replicated: the most N devices can give is T / (T_nominate / N + T_rest), minus the all-reduce
+    share = nom / tot if tot > 0 else 0.0
+    ceiling = {f"{k} devices": 1.0 / (share / k + (1.0 - share)) for k in (2, 4, 8)}
     emit({"metric": "admission-decisions/sec + p99 schedule-cycle ms @ 100k pending, 1k CQ",
-          "value": dec / (two["ms_per_cycle"] * args.steps * 1e-3), "unit": "decisions/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+          "value": dec / (two["ms_per_cycle"] * args.steps * 1e-3), "unit": "decisions/s", "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup,
+          "collective": {"rccl": rccl, "what": "kq_group_collective_info of the multi-device leg: communicators from ncclCommInitAll, ncclAllReduce groups issued, host-seam sums (must be 0)"} if rccl else
+                        {"rccl": None, "what": "one device: the N > 1 protocol runs over the host seam (two engines on this GPU); not a scaling figure"},
+          "expected_ceiling": {"nominate_share_of_device_time": share, "speedup_at_most": ceiling,
+                               "why": "kq_group shards nominate and replicates order + processEntry on every device (DESIGN.md section 5)"},
           "ms_per_step": two["ms_per_cycle"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
           "config": {"workload": f"{args.workload}: kq_group (C++ driver of include/kq_group.h) on ONE device, {snap.n_cq} ClusterQueues, {snap.n_adm} admitted, {batches[0].n} heads per cycle uploaded every cycle",
-                     "loop": f"closed: commit every cycle, release after {args.hold} cycles", "value_is": "the two-engine group (both engines share the one GPU: not a scaling figure)"},
+                     "loop": f"closed: commit every cycle, release after {args.hold} cycles", "value_is": plan[-1][0] + (" (both engines share the one GPU: not a scaling figure)" if n_dev == 1 else "")},
           "plain_engine": {"ms_per_cycle": float(np.mean(plain_ms)), "p50_ms": float(np.percentile(plain_ms, 50)), "p99_ms": float(np.percentile(plain_ms, 99))},
           "group": legs,
           "parity_checked": True, "parity": "every decision field of every cycle and the resident usage of every rank equal the plain engine's: " + str(all(v["equal_to_plain_engine"] for v in legs.values())),
           "roofline": None, "cpu_baseline": None})
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
     if not all(v["equal_to_plain_engine"] for v in legs.values()):
         raise SystemExit(f"{args.workload}: a group leg differs from the plain engine")
 
@@ -1545,6 +1590,9 @@ def F_ptr(a):
     return F.ptr(a)
 
 
+_RANKS = {}
+
+
 def emit(res):
     """The one JSON line. roofline.traffic is not measured inside this run (PMC counters need their own rocprofv3 passes): say where it
     comes from."""
@@ -1552,6 +1600,8 @@ def emit(res):
     if isinstance(rf, dict):
         rf["traffic_source"] = ("replayed from profiles/pmc_traffic_<workload>.json: separate rocprofv3 --pmc passes of this same command, not this run"
                                 if rf.get("traffic") is not None else "none committed for this workload")
+    if _RANKS:
+        res.setdefault("ranks", dict(_RANKS))
     print(json.dumps(res))
 
 

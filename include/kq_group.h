@@ -49,6 +49,10 @@ int  kq_group_cycle_release(kq_group* g, int32_t age);
 /* The resident usage plane of device `rank` ([N * n_fr]): equal on all ranks; tests compare them. */
 int  kq_group_read_usage(kq_group* g, int32_t rank, int64_t* usage);
 const char* kq_group_last_error(kq_group* g);
+/* What the group's exchange actually ran on — for a caller (bench.py --gpus N) that must not mistake the host seam for RCCL:
+ * *rccl_ranks = communicators ncclCommInitAll created (0: the host collective, or a group of one), *allreduce_calls = ncclAllReduce
+ * groups issued so far (one per cycle of a group of several devices), *host_sums = exchanges summed through host memory. */
+int  kq_group_collective_info(kq_group* g, int32_t* rccl_ranks, int64_t* allreduce_calls, int64_t* host_sums);
 
 #ifdef __cplusplus
 }

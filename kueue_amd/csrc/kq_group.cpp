@@ -43,6 +43,8 @@ struct HipBackend {
   Rccl rccl;
   std::vector<hipStream_t> stream;
   std::vector<ncclComm_t> comm;
+  int64_t n_allreduce = 0;   // ncclAllReduce groups issued (kq_group_collective_info)
+  int rccl_ranks() const { int k = 0; for (auto c : comm) if (c) k++; return k; }
   bool set_device(int d) { return hipSetDevice(d) == hipSuccess; }
   int engine_create(const kq_config* c, void** e) { return kq_engine_create(c, (kq_engine**)e); }
   void engine_destroy(void* e) { kq_engine_destroy((kq_engine*)e); }
@@ -71,6 +73,7 @@ struct HipBackend {
   // every rank's all-reduce from ONE thread inside one ncclGroup: an enqueue that fails cannot leave the other ranks waiting in theirs
   int allreduce_all(int n, const int* devs, void* const* xbuf, size_t words, std::string* err) {
     ncclResult_t bad = ncclSuccess;
+    n_allreduce++;
     (void)rccl.GroupStart();
     for (int r = 0; r < n; r++) {
       (void)hipSetDevice(devs[r]);
@@ -155,6 +158,13 @@ int kq_group_cycle_release(kq_group* g, int32_t age) {
 int kq_group_read_usage(kq_group* g, int32_t rank, int64_t* usage) {
   if (!g) return KQ_EINVAL;
   KQG_TRY(g->g.read_usage(rank, usage))
+}
+int kq_group_collective_info(kq_group* g, int32_t* rccl_ranks, int64_t* allreduce_calls, int64_t* host_sums) {
+  if (!g) return KQ_EINVAL;
+  if (rccl_ranks) *rccl_ranks = g->g.be.rccl_ranks();
+  if (allreduce_calls) *allreduce_calls = g->g.be.n_allreduce;
+  if (host_sums) *host_sums = g->g.host_sums;
+  return KQ_OK;
 }
 
 }  // extern "C"

@@ -92,6 +92,7 @@ struct Group {
   int64_t* hsum = nullptr;
   std::vector<Scratch> scratch;
   int nR = 0;
+  int64_t host_sums = 0;   // exchanges that went through the host seam (kq_group_collective_info)
   std::string last_error;
   // ---- workers ----
   std::vector<std::thread> workers;
@@ -286,6 +287,7 @@ struct Group {
       if (c != KQ_OK) return c;
       // (2) the one collective of the cycle: sum of buffers with disjoint supports = gather of the nominations
       if (n > 1) {
+        if (r == 0 && host_collective()) host_sums++;
         c = host_collective() ? exchange_host(r, words) : exchange_device(r, words, &issue_rc, &issue_err);
         c = phase(r, c);
         if (c != KQ_OK) return c;

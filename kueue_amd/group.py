@@ -16,7 +16,7 @@ HOST_COLLECTIVE = 1   # KQ_GROUP_HOST_COLLECTIVE: the exchange through pinned ho
 FORCE_SHARDED = 2     # KQ_GROUP_FORCE_SHARDED: one device also takes the sharded path
 
 GROUP_ABI_SYMBOLS = ["kq_group_create", "kq_group_create_opts", "kq_group_destroy", "kq_group_size", "kq_group_snapshot_put", "kq_group_cycle_run",
-                     "kq_group_cycle_commit", "kq_group_cycle_release", "kq_group_read_usage", "kq_group_last_error"]
+                     "kq_group_cycle_commit", "kq_group_cycle_release", "kq_group_read_usage", "kq_group_last_error", "kq_group_collective_info"]
 
 
 class Group:
@@ -81,3 +81,10 @@ class Group:
         u = np.zeros(self.snap.N * self.snap.n_fr, np.int64)
         self._check(self._lib.kq_group_read_usage(self._h, C.c_int32(rank), F.ptr(u)))
         return u
+
+    def collective_info(self) -> dict:
+        """kq_group_collective_info: what the exchange actually ran on — communicators ncclCommInitAll created, ncclAllReduce groups issued,
+        exchanges summed through host memory."""
+        r, a, hs = C.c_int32(0), C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.kq_group_collective_info(self._h, C.byref(r), C.byref(a), C.byref(hs)))
+        return dict(rccl_ranks=int(r.value), allreduce_calls=int(a.value), host_sums=int(hs.value))

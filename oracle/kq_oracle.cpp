@@ -799,6 +799,21 @@ struct FlavorAssigner {
     int attemptedFlavorIdx = -1;
     int idx = NextFlavorToTry(psi, resName);
     bool respectNom = shouldRespectNominationMapping();
+    // Accounting only (the decisions below are the reference's, simulation by simulation): the engine does not run the simulations whose
+    // results cannot be observed (kq_device.hpp assign_flavors "dead simulations") — those of the flavors in front of the flavor that ends
+    // the scan with every cell Fit, inside the engine's pass of 64 / |requests| flavors, when no flavor in front of it could have ended the
+    // scan (no FlavorFungibility, or WhenCanPreempt = TryNextFlavor). Their bytes are booked as discarded so that both byte counters agree.
+    const int idxFirst = idx;
+    std::vector<int64_t> flavorSim(std::max(nflv, 1), 0);
+    auto bookDead = [&](int S) {
+      if (sn.gate(KQ_GATE_FLAVOR_FUNGIBILITY) && !KQ_POL_PREEMPT_TRYNEXT(pol)) return;
+      if (KQ_POL_PREFERENCE(pol) == KQ_PREF_PREEMPTION_OVER_BORROWING) return;   // (the representative mode of a flavor with a simulated cell can be "Fit" there)
+      const int nf = (int)filtered.size();
+      if (nf == 0) return;
+      const int fpp = 64 / nf;
+      const int p0 = idxFirst + ((S - idxFirst) / fpp) * fpp;
+      for (int j = p0; j < S; j++) sn.st.discarded_bytes += flavorSim[j];
+    };
     for (; idx < nflv; idx++) {
       attemptedFlavorIdx = idx;
       int fName = sn.s->rg_flavor[f0 + idx];
@@ -836,6 +851,7 @@ struct FlavorAssigner {
         const int64_t vb0 = sn.st.victim_bytes + sn.st.drs_bytes;
         FitRes r = fitsResourceQuota(fr, frq_get(assignmentUsage, fr), val);
         if (discarded) sn.st.discarded_bytes += sn.st.victim_bytes + sn.st.drs_bytes - vb0;
+        else flavorSim[idx] += sn.st.victim_bytes + sn.st.drs_bytes - vb0;
         if (r.status) { (*nreasons)++; why->push_back(r.why); flavorNoFitReason = std::max(flavorNoFitReason, r.label); }  // :1155
         GranularMode mode = {r.pm, r.borrow};
         if (isPreferred(representativeMode, mode, pol)) representativeMode = mode;
@@ -847,12 +863,13 @@ struct FlavorAssigner {
       if (sn.gate(KQ_GATE_FLAVOR_FUNGIBILITY)) {
         if (!shouldTryNextFlavor(representativeMode, pol)) {
           bestAssignment = assignments; haveBest = true; bestMode = representativeMode;
+          if (representativeMode.pm == pmFit) bookDead(idx);
           break;
         }
         if (isPreferred(representativeMode, bestMode, pol)) { bestAssignment = assignments; haveBest = true; bestMode = representativeMode; }
       } else if (representativeMode.pm > bestMode.pm) {
         bestAssignment = assignments; haveBest = true; bestMode = representativeMode;
-        if (bestMode.pm == pmFit) { *statusNil = true; return bestAssignment; }
+        if (bestMode.pm == pmFit) { bookDead(idx); *statusNil = true; return bestAssignment; }
       }
     }
     if (sn.gate(KQ_GATE_FLAVOR_FUNGIBILITY)) {

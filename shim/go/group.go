@@ -120,3 +120,14 @@ func (g *Group) ReadUsage(rank int32, usage []int64) error {
 	}
 	return nil
 }
+
+// CollectiveInfo = kq_group_collective_info: communicators ncclCommInitAll created (0: host collective / group of one), ncclAllReduce
+// groups issued so far, exchanges summed through host memory.
+func (g *Group) CollectiveInfo() (rcclRanks int32, allreduceCalls, hostSums int64, err error) {
+	var r C.int32_t
+	var a, h C.int64_t
+	if rc := C.kq_group_collective_info(g.h, &r, &a, &h); rc != 0 {
+		return 0, 0, 0, g.err("kq_group_collective_info", rc)
+	}
+	return int32(r), int64(a), int64(h), nil
+}

@@ -68,10 +68,14 @@ def _engine_row(oracle, make, case):
     eng = make(cfg)
     try:
         eng.put(snap)
-        if case.get("topologies"):
-            got, _ = eng.run_tas(heads, ct, tgt_cap=max(16, snap.n_adm))
-        else:
-            got = eng.run(heads)
+        try:
+            if case.get("topologies"):
+                got, _ = eng.run_tas(heads, ct, tgt_cap=max(16, snap.n_adm))
+            else:
+                got = eng.run(heads)
+        except Exception as ex:   # (the HIP engine raises on a refused cycle, the emulation returns the code)
+            assert getattr(ex, "code", None) == -4, ex
+            got = type("Refused", (), {"rc": -4, "error": str(ex)})()
     finally:
         eng.close()
     if getattr(got, "rc", 0) == -4:
