@@ -28,10 +28,50 @@ NEVER = np.iinfo(np.int64).max
 
 def assignment_rows(snap, heads_arrays: dict, d: Decisions, sel: np.ndarray, reserve_ts: int, uid_rank: np.ndarray) -> dict:
     """The admitted-workload rows of the heads `sel` of a cycle (kq_row_patch.add_*): usage = Assignment.Usage (flavorassigner.go:1017-1041) —
-    per (podset, resource) that was given a flavor, the podset's request scaled to the admitted count (the injected `pods` request: the count)."""
+    per (podset, resource) that was given a flavor, the podset's request scaled to the admitted count (the injected `pods` request: the count).
+    A row's usage entries stand in the order Assignment.append meets them (podset by podset, resources ascending). Vectorised: the loop runs
+    once per cycle over up to a thousand heads."""
+    a = heads_arrays
+    nR, nfr, pods = snap.n_resource, snap.n_fr, snap.pods_resource
+    sel = np.asarray(sel, np.int64)
+    n = len(sel)
+    ps0, ps1 = a["ps_off"][sel].astype(np.int64), a["ps_off"][sel + 1].astype(np.int64)
+    nps = ps1 - ps0
+    ps = np.concatenate([np.arange(x, y) for x, y in zip(ps0, ps1)]).astype(np.int64) if n else np.zeros(0, np.int64)
+    owner = np.repeat(np.arange(n), nps)
+    # the requests of those podsets as a dense [podsets, resources] table
+    r0, r1 = a["ps_req_off"][ps].astype(np.int64), a["ps_req_off"][ps + 1].astype(np.int64)
+    e = np.concatenate([np.arange(x, y) for x, y in zip(r0, r1)]).astype(np.int64) if len(ps) else np.zeros(0, np.int64)
+    req = np.zeros((len(ps), nR), np.int64)
+    req[np.repeat(np.arange(len(ps)), r1 - r0), a["req_res"][e]] = a["req_qty"][e]
+    cnt0, cnt = a["ps_count"][ps].astype(np.int64), d.a["ps_count"][ps].astype(np.int64)
+    sc = (cnt0 != 0) & (cnt0 != cnt)
+    if sc.any():
+        req[sc] = (req[sc] // cnt0[sc, None]) * cnt[sc, None]       # ScaledTo workload.go:317-340
+    if pods >= 0:
+        cov = _pods_covered(snap)[a["cq"][sel]][owner]
+        req[cov, pods] = cnt[cov]                                   # flavorassigner.go:743-749
+    fl = d.a["flavor"].reshape(-1, nR)[ps].astype(np.int64)
+    pi, ri = np.nonzero(fl >= 0)                                    # row-major: podset by podset, resources ascending
+    fr = fl[pi, ri] * nR + ri
+    key = owner[pi] * nfr + fr
+    uk, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    qty = np.zeros(len(uk), np.int64)
+    np.add.at(qty, inv, req[pi, ri])
+    order = np.lexsort((first, uk // nfr))                          # per head, in the order of first appearance
+    uk, qty = uk[order], qty[order]
+    use_off = np.concatenate([[0], np.cumsum(np.bincount(uk // nfr, minlength=n))]).astype(np.int32)
+    return dict(cq=a["cq"][sel].astype(np.int32), priority=a["priority"][sel].astype(np.int64), queue_ts=a["queue_ts"][sel].astype(np.int64),
+                reserve_ts=np.full(n, reserve_ts, np.int64), uid_rank=np.asarray(uid_rank, np.uint32), flags=np.zeros(n, np.uint8),
+                use_off=use_off, use_fr=(uk % nfr).astype(np.int32), use_qty=qty)
+
+
+def assignment_rows_loop(snap, heads_arrays: dict, d: Decisions, sel: np.ndarray, reserve_ts: int, uid_rank: np.ndarray) -> dict:
+    """assignment_rows head by head (the readable form; tests hold the two against each other)."""
     a = heads_arrays
     nR = snap.n_resource
     pods = snap.pods_resource
+    cov = _pods_covered(snap) if pods >= 0 else None
     cq, prio, qts, uo, ufr, uq = [], [], [], [0], [], []
     for i in sel:
         i = int(i)
@@ -45,8 +85,8 @@ def assignment_rows(snap, heads_arrays: dict, d: Decisions, sel: np.ndarray, res
                     continue
                 q = req.get(r, 0)
                 if cnt0 != 0 and cnt0 != cnt:
-                    q = (q // cnt0) * cnt                      # ScaledTo workload.go:317-340
-                if r == pods and _pods_injected(snap, int(a["cq"][i]), pods):
+                    q = (q // cnt0) * cnt
+                if r == pods and cov[int(a["cq"][i])]:
                     q = cnt
                 fr = f * nR + r
                 use[fr] = use.get(fr, 0) + q
@@ -63,22 +103,19 @@ def assignment_rows(snap, heads_arrays: dict, d: Decisions, sel: np.ndarray, res
 _PODS_CACHE: dict = {}
 
 
-def _pods_injected(snap, cq: int, pods: int) -> bool:
-    """flavorassigner.go:743-749: the assigner sets requests[pods] = count when the ClusterQueue has a resource group covering `pods`."""
-    if pods < 0:
-        return False
-    key = id(snap)
-    cov = _PODS_CACHE.get(key)
+def _pods_covered(snap) -> np.ndarray:
+    """[n_cq] flavorassigner.go:743-749: the assigner sets requests[pods] = count when the ClusterQueue has a resource group covering `pods`."""
+    cov = _PODS_CACHE.get(id(snap))
     if cov is None or cov[0] is not snap:
-        a = snap.arrays
+        a, pods = snap.arrays, snap.pods_resource
         c = np.zeros(snap.n_cq, bool)
         for q in range(snap.n_cq):
             for g in range(int(a["cq_rg_off"][q]), int(a["cq_rg_off"][q + 1])):
                 if pods in a["rg_res"][int(a["rg_res_off"][g]):int(a["rg_res_off"][g + 1])]:
                     c[q] = True
         cov = (snap, c)
-        _PODS_CACHE.clear(); _PODS_CACHE[key] = cov
-    return bool(cov[1][cq])
+        _PODS_CACHE.clear(); _PODS_CACHE[id(snap)] = cov
+    return cov[1]
 
 
 class RowBook:
@@ -109,10 +146,12 @@ class RowBook:
         # kept rows: position inside the ClusterQueue = rank among the kept rows of it (the table is grouped by ClusterQueue already)
         kpos = off[kept_cq] + (np.arange(len(kept_cq)) - np.concatenate([[0], np.cumsum(k_cnt)])[kept_cq])
         cq[kpos] = kept_cq; fin[kpos] = self.finish[keep]; ev[kpos] = self.evicted_at[keep]
-        nxt = (off[:-1] + k_cnt).astype(np.int64)
-        apos = np.empty(len(add_cq), np.int64)
-        for i, c in enumerate(add_cq):
-            apos[i] = nxt[c]; nxt[c] += 1
+        # added rows: behind the kept rows of their ClusterQueue, in the order given (rank among the added rows of the same ClusterQueue)
+        add_cq = np.asarray(add_cq, np.int64)
+        o = np.argsort(add_cq, kind="stable")
+        rank = np.empty(len(add_cq), np.int64)
+        rank[o] = np.arange(len(add_cq)) - np.concatenate([[0], np.cumsum(a_cnt)])[add_cq[o]]
+        apos = (off[:-1] + k_cnt)[add_cq] + rank
         cq[apos] = add_cq; fin[apos] = add_finish; ev[apos] = NEVER
         if new_index is not None:   # (the engine's own answer, when it gave one: must agree)
             want = np.full(self.n, -1, np.int64); want[np.nonzero(keep)[0]] = kpos

@@ -2348,23 +2348,26 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
         wsync();
         if (LEAN || KQ_TAS_PROCESS(k, w)) KQ_TS(k, 58);  // lean: the (flavor, resource) cells of the pass (fitsResourceQuota)
         // ---- dead simulations -------------------------------------------------------------------------------------------------
-        // The first flavor of the pass that ENDS the scan without any simulation — every cell Fit and (no borrowing, or WhenCanBorrow =
-        // MayStopSearch; without FlavorFungibility: any Fit flavor) — becomes the assignment whatever the flavors in front of it gave
-        // (:1176-1180 `bestAssignment = assignments; break`, :1184-1190), with a nil Status (:1199-1207), provided none of THEM can end
-        // the scan first: a flavor whose cells need SimulatePreemption ends it only under WhenCanPreempt = MayStopSearch (:1271), a NoFit
-        // flavor never. Under WhenCanPreempt = TryNextFlavor (the API's default) the simulations of the flavors in front of that flavor
-        // are unobservable: they are not run. In a saturated tree that is every simulation of every head that still finds a flavor with
-        // room — at cfg 4 the whole k_nominate pass of a cycle without preemptions. (The oracle runs them, as the reference does, and
-        // books their bytes as discarded by the same rule: kq_oracle.cpp findFlavorForPodSets.)
-        // (Preference = PreemptionOverBorrowing orders modes by borrowing level first: the representative mode of a flavor with a cell that
-        // needs a simulation can then come out as "Fit, borrowing" and end the scan itself — no pruning under that preference.)
-        int dead_before = 0;
+        // A flavor whose cells are all Fit beats every flavor with a cell that needs SimulatePreemption (isPreferred compares the
+        // preemption mode first, :553-558), the scan's Status is nil once the best flavor is Fit (:1199-1207), and a flavor that needs a
+        // simulation cannot END the scan under WhenCanPreempt = TryNextFlavor (:1271; NoCandidates never does, :1267) — nor without
+        // FlavorFungibility, where only a Fit flavor ends it (:1184-1190). So once a Fit flavor is in hand, or stands anywhere in this
+        // pass, what the simulations of the pass would return cannot be observed — not in the assignment, not in the bookmark
+        // (attemptedFlavorIdx is where the scan ends: a Fit flavor that does not borrow, or borrows under WhenCanBorrow = MayStopSearch,
+        // or the last flavor), not in the reasons: they are not run. In a saturated tree that is every simulation of every head that still
+        // finds a flavor with room: at cfg 4 the whole k_nominate pass of a cycle without preemptions, and such heads finish in the lean
+        // pass. Not under Preference = PreemptionOverBorrowing (modes are ordered by borrowing level first there: a flavor with a simulated
+        // cell can come out as "Fit, borrowing" and win or end the scan) and not under WhenCanPreempt = MayStopSearch (a flavor that can
+        // preempt ends the scan). The oracle runs them all, as the reference does, and books their bytes as discarded by the same rule
+        // (kq_oracle.cpp findFlavorForPodSets).
+        bool dead_all = false;
         if ((!gate(k, KQ_GATE_FLAVOR_FUNGIBILITY) || KQ_POL_PREEMPT_TRYNEXT(w.pol)) && KQ_POL_PREFERENCE(w.pol) != KQ_PREF_PREEMPTION_OVER_BORROWING) {
-          for (int jj = 0; jj < nfl; jj++) {
+          dead_all = best_pm == PM_FIT;
+          for (int jj = 0; jj < nfl && !dead_all; jj++) {
             if (w.cell_pm[jj * nf] == PM_SKIP) continue;
-            bool all_fit = true, borrows = false;
-            for (int kk = 0; kk < nf; kk++) { all_fit = all_fit && w.cell_pm[jj * nf + kk] == PM_FIT; borrows = borrows || w.cell_borrow[jj * nf + kk] != 0; }
-            if (all_fit && (!gate(k, KQ_GATE_FLAVOR_FUNGIBILITY) || !borrows || !KQ_POL_BORROW_TRYNEXT(w.pol))) { dead_before = jj; break; }
+            bool all_fit = true;
+            for (int kk = 0; kk < nf; kk++) all_fit = all_fit && w.cell_pm[jj * nf + kk] == PM_FIT;
+            dead_all = all_fit;
           }
         }
         // ---- recomputation inside k_process_fair: every cell of the pass that needs a SimulatePreemption is posted as one batch ----
@@ -2380,7 +2383,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
                   const int c = jj * nf + kk;
                   w.cell_task[c] = 0xff;
                   if (w.cell_pm[jj * nf] == PM_SKIP) continue;
-                  if ((w.cell_pm[c] & 0x3f) == PM_NEEDS && jj >= dead_before) {
+                  if ((w.cell_pm[c] & 0x3f) == PM_NEEDS && !dead_all) {
                     hbox->task[nt] = HelpTask{S.rg_flavor[f0 + cs + jj] * nR + w.f_res[kk], w.cell_borrow[c], w.cell_val[c]};
                     w.cell_task[c] = (uint8_t)nt++;
                   }
@@ -2427,7 +2430,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
             if (rep_pm == PM_NOFIT) { if (had_status) reasons++; continue; }  // oracle result unused past a noFit (:1161)
             if (pm == PM_NEEDS) {
               int opm, ob;
-              if (jj < dead_before) { opm = PM_NOCAND; ob = borrow; }   // a dead simulation (above): whatever stands here is overwritten
+              if (dead_all) { opm = PM_NOCAND; ob = borrow; }   // a dead simulation (above): whatever stands here cannot be observed
               else if constexpr (LEAN) {
                 const bool can_search = KQ_POL_WITHIN_CQ(w.pol) != KQ_POLICY_NEVER || (w.plen > 1 && KQ_POL_RECLAIM(w.pol) != KQ_POLICY_NEVER);
                 if (can_search) { if (lane == 0) w.defer_head = 1; wsync(); return; }

@@ -800,19 +800,26 @@ struct FlavorAssigner {
     int idx = NextFlavorToTry(psi, resName);
     bool respectNom = shouldRespectNominationMapping();
     // Accounting only (the decisions below are the reference's, simulation by simulation): the engine does not run the simulations whose
-    // results cannot be observed (kq_device.hpp assign_flavors "dead simulations") — those of the flavors in front of the flavor that ends
-    // the scan with every cell Fit, inside the engine's pass of 64 / |requests| flavors, when no flavor in front of it could have ended the
-    // scan (no FlavorFungibility, or WhenCanPreempt = TryNextFlavor). Their bytes are booked as discarded so that both byte counters agree.
+    // results cannot be observed (kq_device.hpp assign_flavors "dead simulations") — inside one of its passes of 64 / |requests| flavors,
+    // every simulation once a flavor with all cells Fit is the best so far or stands anywhere in the pass (no FlavorFungibility, or
+    // WhenCanPreempt = TryNextFlavor; not under PreemptionOverBorrowing). Their bytes are booked as discarded so that both byte counters agree.
     const int idxFirst = idx;
     std::vector<int64_t> flavorSim(std::max(nflv, 1), 0);
-    auto bookDead = [&](int S) {
+    std::vector<char> flavorAllFit(std::max(nflv, 1), 0);
+    auto bookDead = [&](int scannedEnd) {   // flavors [idxFirst, scannedEnd) were looked at
       if (sn.gate(KQ_GATE_FLAVOR_FUNGIBILITY) && !KQ_POL_PREEMPT_TRYNEXT(pol)) return;
       if (KQ_POL_PREFERENCE(pol) == KQ_PREF_PREEMPTION_OVER_BORROWING) return;   // (the representative mode of a flavor with a simulated cell can be "Fit" there)
       const int nf = (int)filtered.size();
       if (nf == 0) return;
       const int fpp = 64 / nf;
-      const int p0 = idxFirst + ((S - idxFirst) / fpp) * fpp;
-      for (int j = p0; j < S; j++) sn.st.discarded_bytes += flavorSim[j];
+      bool fitSeen = false;
+      for (int p0 = idxFirst; p0 < scannedEnd; p0 += fpp) {
+        const int p1 = std::min(p0 + fpp, scannedEnd);
+        bool passFit = false;
+        for (int j = p0; j < p1; j++) passFit |= flavorAllFit[j] != 0;
+        if (fitSeen || passFit) for (int j = p0; j < p1; j++) sn.st.discarded_bytes += flavorSim[j];
+        fitSeen |= passFit;
+      }
     };
     for (; idx < nflv; idx++) {
       attemptedFlavorIdx = idx;
@@ -860,18 +867,19 @@ struct FlavorAssigner {
         assignments[rq.first] = fa;
       }
       if (considered) considered->push_back({fName, flavorAssignmentMode(representativeMode.pm), flavorNoFitReason});  // :1174
+      flavorAllFit[idx] = representativeMode.pm == pmFit;
       if (sn.gate(KQ_GATE_FLAVOR_FUNGIBILITY)) {
         if (!shouldTryNextFlavor(representativeMode, pol)) {
           bestAssignment = assignments; haveBest = true; bestMode = representativeMode;
-          if (representativeMode.pm == pmFit) bookDead(idx);
           break;
         }
         if (isPreferred(representativeMode, bestMode, pol)) { bestAssignment = assignments; haveBest = true; bestMode = representativeMode; }
       } else if (representativeMode.pm > bestMode.pm) {
         bestAssignment = assignments; haveBest = true; bestMode = representativeMode;
-        if (bestMode.pm == pmFit) { bookDead(idx); *statusNil = true; return bestAssignment; }
+        if (bestMode.pm == pmFit) { flavorAllFit[idx] = 1; bookDead(idx + 1); *statusNil = true; return bestAssignment; }
       }
     }
+    bookDead(std::min(idx + 1, nflv));
     if (sn.gate(KQ_GATE_FLAVOR_FUNGIBILITY)) {
       for (auto& kv : bestAssignment) kv.second.tried = (attemptedFlavorIdx == nflv - 1) ? -1 : attemptedFlavorIdx;
       if (bestMode.pm == pmFit) { *statusNil = true; return bestAssignment; }

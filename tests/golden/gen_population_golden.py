@@ -33,6 +33,11 @@ CASES = {
 }
 
 
+# version of the algorithmic-byte accounting: 2 = simulations whose results cannot be observed are booked as discarded (round 6,
+# kq_oracle.cpp findFlavorForPodSets "dead simulations"); files without the key follow rule 1 and their byte total is not compared
+ACCOUNTING = 2
+
+
 def cycle_input(pop, name, c):
     """(snapshot, heads) of cycle c. Cycle 0: the population as generated. Cycle 1 (configs[3] at full size was pinned on
     one cycle only): the snapshot after kq_cycle_commit of cycle 0 — the usage of every workload the COMMITTED cycle-0 golden admitted
@@ -107,6 +112,7 @@ def main(names):
             out["tgt_reason"] = want.a["tgt_reason"][:m]
             out["usage_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(want.usage_after).tobytes()).digest(), np.uint8)
             out["bytes_total"] = np.array([want.stats["total"]], np.int64)
+            out["accounting"] = np.array([ACCOUNTING])   # which rule the byte total follows (the decisions do not depend on it)
             out["inputs_sha256"] = np.frombuffer(bytes.fromhex(digest_inputs(snap, heads)), np.uint8)
             out["oracle_seconds"] = np.array([dt])
             np.savez_compressed(path_of(name, c), **out)

