@@ -368,6 +368,7 @@ struct DScratch {
 // for every flavor-resource cell that needs one, flavorassigner.go:1375-1384) are independent given the snapshot state. The
 // leader of a tree posts them as a batch; idle workgroups (and the leader itself) take them one by one.
 struct HelpTask { int32_t fr, base_borrow; int64_t val; };
+struct SimTask { int32_t head, fr, base_borrow, pad; int64_t val; };
 struct HelpRes { int32_t pm, borrow; int64_t bytes; };
 struct HelpBox {
   uint64_t hdr;      // batch sequence << 32 | tasks (0 tasks = closed)
@@ -441,6 +442,17 @@ struct K {  // everything a kernel needs
   long long* root_margin;    // [n_tree * nfr], start = CERT_INF
   int32_t* cert_flags;       // [n_tree]
   const struct TCyc* tc;     // Topology-Aware Scheduling inside the cycle (kq_tas_cycle.hpp; kq_cycle_run_tas), null in the ordinary cycle
+  // Simulations ahead of the full nominate pass (round 6, sim_emit / sim_worker below): the SimulatePreemption calls a deferred head's
+  // first flavor scan will make are independent given the cycle-start snapshot (preemption_oracle.go:43: a pure function of the
+  // snapshot, the head and the cell). The lean pass lists them, k_nominate_sim runs one per wave, the full pass reads the results where
+  // it would have searched. A cycle in which a handful of heads need victims no longer lasts as long as one head's ~50 searches in a row.
+  struct SimTask* sim_task;  // [sim_cap]
+  HelpRes* sim_res;          // [sim_cap]
+  int32_t* sim_ctl;          // [2] tasks listed, next task to hand out (zeroed per cycle, with defer_count)
+  int32_t* sim_first;        // [H] first task of the head, -1 = none listed (filled per cycle); null: the mechanism is off
+  int32_t* sim_scan;         // [H] the resource whose scan listed them (findFlavorForPodSets' resName)
+  int32_t* sim_cell;         // [H * CELLS] task of cell c of that scan's first pass, -1 = none (valid where sim_first[h] >= 0)
+  int32_t sim_cap;
   HelpBox* help;             // [n_tree] or null: no helper workgroups in this launch
   uint32_t* help_quit;       // [1] trees whose leader has finished
   int help_trees;            // n_tree of the launch (helper workgroups are the blocks after them)
@@ -2153,6 +2165,44 @@ KQ_NOINLINE int group_finish(const K& k, Wave& w, int pi, int gn, const int* cou
   return rep;
 }
 
+// ---- simulations ahead (K::sim_*) ---------------------------------------------------------------------------------------------------
+// Lean pass, a head about to be deferred because cell (jj, kk) of the pass needs a real SimulatePreemption: list every cell of the pass
+// the scan will simulate — per flavor the cells in front of the first one that is NoFit before any simulation (behind it the closure
+// returns early, :1161); flavors skipped by eligibility or the nomination pin have none. Under WhenCanPreempt = TryNextFlavor the scan
+// visits all of them (no flavor of this pass is Fit, or the pass would have no live cell); under MayStopSearch it may stop earlier and
+// some results go unused. Only the head's FIRST scan (podset 0, nothing assumed yet, the pass that starts at the bookmark) is listed.
+KQ_NOINLINE void sim_emit(const K& k, Wave& w, int res_name, int f0, int cs, int nfl, int nf) {
+  if (lane_id() == 0 && k.sim_first[w.h] < 0) {
+    int n = 0;
+    for (int pass = 0; pass < 2; pass++) {   // count, then write
+      int base = 0;
+      if (pass == 1) {
+        if (n == 0) break;
+        base = atomic_add_i32(&k.sim_ctl[0], n);
+        if (base + n > k.sim_cap) break;     // (no room: the full pass searches in place)
+      }
+      int t = 0;
+      for (int jj = 0; jj < nfl; jj++) {
+        bool live = w.cell_pm[jj * nf] != PM_SKIP;
+        for (int kk = 0; kk < nf; kk++) {
+          const int c = jj * nf + kk;
+          const uint8_t full = w.cell_pm[c];
+          const bool task = live && !(full & 0x40) && (full & 0x3f) == PM_NEEDS;
+          if (pass == 1) {
+            k.sim_cell[(size_t)w.h * CELLS + c] = task ? base + t : -1;
+            if (task) k.sim_task[base + t] = SimTask{w.h, k.S.rg_flavor[f0 + cs + jj] * k.S.nR + w.f_res[kk], w.cell_borrow[c], 0, w.cell_val[c]};
+          }
+          if (task) t++;
+          if ((full & 0x40) || (full & 0x3f) == PM_NOFIT) live = false;   // representativeMode is noFit from here on: no further oracle call for this flavor
+        }
+      }
+      n = t;
+      if (pass == 1) { k.sim_scan[w.h] = res_name; k.sim_first[w.h] = base; }
+    }
+  }
+  wsync();
+}
+
 template <bool LEAN>
 KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, const uint8_t* removed,
                            const int* counts, bool nominate_map) {
@@ -2370,6 +2420,10 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
             dead_all = all_fit;
           }
         }
+        // the simulations of this pass were listed by the lean pass and run by k_nominate_sim (sim_emit): the head's first scan only
+        bool sim_ahead = false;
+        if constexpr (!LEAN) sim_ahead = k.sim_first != nullptr && pi == 0 && !counts && !nominate_map && cs == idx0 && w.slice_row < 0 && gn == 1 &&
+                                         k.sim_first[w.h] >= 0 && k.sim_scan[w.h] == res_name;
         // ---- recomputation inside k_process_fair: every cell of the pass that needs a SimulatePreemption is posted as one batch ----
         bool batched = false;
         HelpBox* hbox = nullptr;
@@ -2433,11 +2487,20 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
               if (dead_all) { opm = PM_NOCAND; ob = borrow; }   // a dead simulation (above): whatever stands here cannot be observed
               else if constexpr (LEAN) {
                 const bool can_search = KQ_POL_WITHIN_CQ(w.pol) != KQ_POLICY_NEVER || (w.plen > 1 && KQ_POL_RECLAIM(w.pol) != KQ_POLICY_NEVER);
-                if (can_search) { if (lane == 0) w.defer_head = 1; wsync(); return; }
+                if (can_search) {
+                  if (k.sim_first && pi == 0 && !counts && !nominate_map && cs == idx0 && w.slice_row < 0 && gn == 1) sim_emit(k, w, res_name, f0, cs, nfl, nf);
+                  if (lane == 0) w.defer_head = 1;
+                  wsync();
+                  return;
+                }
                 opm = PM_NOCAND; ob = borrow;  // simulate_preemption with an empty target set
               } else {
                 if (batched && w.cell_task[c] != 0xff) {  // the batch evaluated it; only a consumed result is charged
                   const HelpRes hr = hbox->res[w.cell_task[c]];
+                  opm = hr.pm; ob = hr.borrow;
+                  if (lane == 0) w.bytes += hr.bytes;
+                } else if (sim_ahead && k.sim_cell[(size_t)w.h * CELLS + c] >= 0) {   // k_nominate_sim ran it (K::sim_*); charged when consumed
+                  const HelpRes hr = k.sim_res[k.sim_cell[(size_t)w.h * CELLS + c]];
                   opm = hr.pm; ob = hr.borrow;
                   if (lane == 0) w.bytes += hr.bytes;
                 } else {
@@ -2830,6 +2893,32 @@ KQ_DEV void nominate_head(const K& k, Wave& w, int h, int slot) {
 #endif
   }
   wsync();
+}
+
+// k_nominate_sim: one wave, tasks pulled by ticket (two searches differ by 10 x); the result of a task is a pure function of the
+// cycle-start snapshot, the head and the cell, so any wave may run it and any number of them at once. `first`: the first ticket is taken
+// by the caller (the emulation deals tasks to its serial "waves").
+KQ_DEV void sim_worker(const K& k, Wave& w, int slot) {
+  const int lane = lane_id();
+  int cur = -1;
+  int nt = k.sim_ctl[0];
+  if (nt > k.sim_cap) nt = k.sim_cap;
+  for (;;) {
+    int t = 0;
+    if (lane == 0) t = atomic_add_i32(&k.sim_ctl[1], 1);
+    t = wuniform_i32(t);
+    if (t >= nt) break;
+    const SimTask task = k.sim_task[t];
+    if (task.head != cur) { load_head(k, w, task.head); cur = task.head; }
+    wsync();
+    if (lane == 0) w.bytes = 0;
+    wsync();
+    int pm = 0, borrow = 0;
+    simulate_preemption(k, w, slot, k.usage, nullptr, task.fr, task.val, task.base_borrow, &pm, &borrow);
+    wsync();
+    if (lane == 0) { k.sim_res[t].pm = pm; k.sim_res[t].borrow = borrow; k.sim_res[t].bytes = w.bytes; }
+    wsync();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -59,6 +59,16 @@ __global__ __launch_bounds__(64) void k_nominate(const K* __restrict__ kp, int s
   }
 }
 
+// Between the two passes: the SimulatePreemption calls the deferred heads' first scans will make, one per wave (kq_device.hpp sim_worker).
+__global__ __launch_bounds__(64) void k_nominate_sim(const K* __restrict__ kp, unsigned lds_bytes) {
+  const K& k = *kp;
+  __shared__ Wave w;
+  extern __shared__ __align__(16) unsigned char dyn_lds[];
+  if (threadIdx.x == 0) { w.cs_lds = lds_bytes ? dyn_lds : nullptr; w.cs_lds_bytes = (int)lds_bytes; w.help_on = 0; }
+  __syncthreads();
+  sim_worker(k, w, blockIdx.x);
+}
+
 // Entry order (scheduler.go:1110-1163): rank(i) = number of entries that precede i. 2-D grid: block (bi, bj)
 // compares 256 entries i against a 64-key tile j staged in LDS and adds its partial count to rank[i];
 // k_order_scatter then writes order_idx[rank[i]] = i. H^2/16384 blocks keep more CUs busy than H/256.
@@ -799,6 +809,13 @@ struct HipBackend {
     if (prof_skip_nom && kk.prof) kk.prof += 64;
     const K* d = put_k(kk, 0);
     hipLaunchKernelGGL(k_nominate_lean, dim3(slots), dim3(64), 0, stream, d, slots);
+    if (full_pass && k.sim_first) {
+      if (lds > 48 * 1024 && lds != lds_attr_sim) {
+        chk(hipFuncSetAttribute((const void*)k_nominate_sim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
+        lds_attr_sim = lds;
+      }
+      hipLaunchKernelGGL(k_nominate_sim, dim3(slots), dim3(64), lds, stream, d, (unsigned)lds);
+    }
     if (full_pass) hipLaunchKernelGGL(k_nominate, dim3(slots), dim3(64), lds, stream, d, slots, (unsigned)lds);
     chk(hipGetLastError(), "k_nominate");
   }
@@ -849,7 +866,7 @@ struct HipBackend {
     chk(tas_bal ? launch_process_tas_k_bal(d, lds_want, &lds_attr_tas_bal, stream) : launch_process_tas_k(d, lds_want, &lds_attr_tas, stream), "k_process_tas");
   }
   size_t lds_attr_tas = 0, lds_attr_tas_bal = 0;
-  size_t lds_attr = 0, lds_attr_fair = 0;
+  size_t lds_attr = 0, lds_attr_fair = 0, lds_attr_sim = 0;
   const K* dproc = nullptr;    // argument block of the last process launch (kq_cycle_commit reads the cycle's outputs through it)
   bool stat_patched = false;
   bool spec_off = getenv("KQ_SPEC_OFF") != nullptr;  // KQ_SPEC_OFF: every tree goes to the serial kernel (A/B timing)

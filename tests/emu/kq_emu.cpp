@@ -138,6 +138,20 @@ struct EmuBackend {
     const bool lean = !full_pass || (nom_rot++ & 1) == 0;
     if (lean) { for (int slot = 0; slot < slots; slot++) { Wave w{}; for (int h = slot; h < hn(k.H); h += slots) nominate_head_lean(k, w, h); } }
     else { for (int h = 0; h < hn(k.H); h++) k.defer_list[h] = h; *k.defer_count = hn(k.H); }
+    // the simulations the lean pass listed (K::sim_*), dealt to serial "waves" with both placements of the search arrays
+    if (full_pass && k.sim_first && lean)
+      for (int wave = 0; wave < 3; wave++) {
+        const int slot = wave % std::max(slots, 1);
+        Wave w{};
+        if (lds && ((wave + rot) & 1)) { w.cs_lds = (unsigned char*)region.data(); w.cs_lds_bytes = (int)lds; }
+        if (wave == 2 || k.sim_ctl[0] < 4) sim_worker(k, w, slot);                       // the last "wave" drains the list
+        else {   // a third each (a wave's last, failing pull takes a ticket: handed back here — on the device the list is empty by then)
+          const int keep = k.sim_ctl[0];
+          k.sim_ctl[0] = std::min(keep, k.sim_ctl[1] + 1 + keep / 3);
+          sim_worker(k, w, slot);
+          k.sim_ctl[1] = k.sim_ctl[0]; k.sim_ctl[0] = keep;
+        }
+      }
     const int nd = *k.defer_count;
     if (!full_pass) { if (nd != 0) { fprintf(stderr, "kq_emu: the lean pass deferred %d heads but the host skipped the full pass\n", nd); abort(); } return; }
     for (int slot = 0; slot < slots; slot++) {
