@@ -59,10 +59,15 @@ struct CsCarve {
     void* p = b; b += bytes; if (in_lds) *in_lds = false; return p;
   }
 };
-KQ_DEV int64_t cs_rec_qty(const AdmRec& r, int fr) {
+KQ_DEV int64_t cs_rec_qty(const DSnap& S, const AdmRec& r, int row, int fr) {
   int64_t q = 0;
   #pragma unroll
   for (int e = 0; e < CS_RFR; e++) if (r.fr[e] == fr) q = r.qty[e];
+  if (r.flags & 2u) {   // a wide row (kq_prep.hpp AdmRecX): rare, one more record
+    const AdmRecX x = S.adm_recx[row];
+    #pragma unroll
+    for (int e = 0; e < CS_RFX; e++) if (x.fr[e] == fr) q = x.qty[e];
+  }
   return q;
 }
 KQ_DEV int64_t cs_B(int64_t u, int64_t lq) { return i64max(0, a_sub(u, lq)); }
@@ -146,7 +151,7 @@ KQ_DEV void cs_level_pass(CsCtx& c, int dd, int limit_t, bool finalize) {
       if (enters && al && ns > 1) r = S.adm_rec[e.row];  // the other slots' quantities; the bucket's own one travels with the entry
       #pragma unroll
       for (int u = 0; u < CS_NS; u++)
-        d[u] = (u < ns && al) ? (enters ? (u == c.ufirst ? e.qty : cs_rec_qty(r, w.s_fr[u])) : c.dB[u][j]) : 0;
+        d[u] = (u < ns && al) ? (enters ? (u == c.ufirst ? e.qty : cs_rec_qty(S, r, e.row, w.s_fr[u])) : c.dB[u][j]) : 0;
     }
     bool within = true;   // IsWithinNominalInResources on the state before this candidate (resource_node.go:247-254)
     int64_t ua[CS_NS], outv[CS_NS];
@@ -372,7 +377,7 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
         if (j < M) {
           const AdmRec r = S.adm_rec[rows[j]];
           #pragma unroll
-          for (int u = 0; u < CS_NS; u++) if (u < ns) c.dB[u][j] = cs_rec_qty(r, w.s_fr[u]);
+          for (int u = 0; u < CS_NS; u++) if (u < ns) c.dB[u][j] = cs_rec_qty(S, r, rows[j], w.s_fr[u]);
         }
       }
       wsync();
@@ -506,7 +511,7 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
           for (int u = 0; u < CS_NS; u++) {
             if (u >= ns) { nchg[u] = 0; continue; }
             // addUsage of the row (resource_node.go:144-152) on the private state, kept in registers
-            int64_t v = cs_rec_qty(r, w.s_fr[u]);
+            int64_t v = cs_rec_qty(S, r, row, w.s_fr[u]);
             int nc = 0;
             bool go = true;
             #pragma unroll

@@ -236,6 +236,7 @@ struct DSnap {
   const uint32_t* adm_uid;
   // scan-formulated classical victim search (kq_cs.hpp): static per-snapshot structures built by kq_prep.hpp
   const AdmRec* adm_rec;        // [n_adm]
+  const AdmRecX* adm_recx;      // [n_adm] flavor-resources 5 .. 8 of a wide row (AdmRec::flags bit 1)
   const CsEnt* frl[CS_LEVELS];  // level orders of the buckets (offsets = frb_off)
   const int32_t* frbr;          // admitted row of every bucket entry
   const CsRec* frec;            // rank order of every bucket (offsets = frb_off)
@@ -3006,7 +3007,7 @@ KQ_DEV void np_apply_targets(const K& k, Wave& w, const int32_t* trows, int nt, 
       row = trows[add ? nt - 1 - (base + lane) : base + lane];
       skip = restricted ? (k.preempted[row] != 0) : (k.preempted[row] != 1);  // Insert: rows this entry just marked (1); rows marked 3 were in the set already
       const AdmRec a = S.adm_rec[row];
-      plen = S.plen[a.cq];
+      plen = (a.flags & 2u) ? KQ_MAXD + 1 : S.plen[a.cq];   // a wide row (more flavor-resources than the gathered record): the row walk below
       #pragma unroll
       for (int e = 0; e < CS_RFR; e++) { rf[e] = a.fr[e]; rq[e] = a.qty[e]; }
       #pragma unroll
@@ -3015,7 +3016,7 @@ KQ_DEV void np_apply_targets(const K& k, Wave& w, const int32_t* trows, int nt, 
     for (int jj = 0; jj < cnt; jj++) {
       if (wbcast_u(skip, jj)) continue;
       const int pl = wbcast_u(plen, jj);
-      if (pl > 4) {  // deeper than the gathered path: the row walk
+      if (pl > 4) {  // deeper than the gathered path, or a wide row: the row walk
         const int rw = wbcast_u(row, jj);
         if (restricted) np_apply_row_restricted(k, w, rw, add);
         else {

@@ -305,6 +305,7 @@ template <class B> struct EngineT {
     S.adm_rts = upload(s->adm_reserve_ts, prep.n_adm);
     S.adm_uid = upload(s->adm_uid_rank, prep.n_adm);
     S.adm_rec = upload(prep.adm_rec.data(), prep.adm_rec.size());
+    S.adm_recx = upload(prep.adm_recx.data(), prep.adm_recx.size());
     for (int l = 0; l < CS_LEVELS; l++) S.frl[l] = upload(prep.frl[l].data(), prep.frl[l].size());
     S.frbr = upload(prep.frbr.data(), prep.frbr.size());
     S.frec = upload(prep.frec.data(), prep.frec.size());
@@ -375,6 +376,7 @@ template <class B> struct EngineT {
       reupload(S.frb_off, prep.frb_off.data(), prep.frb_off.size()); reupload(S.frb, prep.frb.data(), prep.frb.size());
       reupload(S.cq_row_bytes, prep.cq_row_bytes.data(), prep.cq_row_bytes.size());
       reupload(S.adm_rec, prep.adm_rec.data(), prep.adm_rec.size());
+      reupload(S.adm_recx, prep.adm_recx.data(), prep.adm_recx.size());
       for (int l = 0; l < CS_LEVELS; l++) reupload(S.frl[l], prep.frl[l].data(), prep.frl[l].size());
       reupload(S.frbr, prep.frbr.data(), prep.frbr.size()); reupload(S.frec, prep.frec.data(), prep.frec.size());
       reupload(S.frb_sig, prep.frb_sig.data(), prep.frb_sig.size()); reupload(S.cs_ok, prep.cs_ok.data(), prep.cs_ok.size());
@@ -395,7 +397,7 @@ template <class B> struct EngineT {
   Buf rb[12];
   Buf rk2, rv2;        // second (key, value) pair of the sorts
   Buf rfs;             // resident fs_ok
-  Buf rs[20];          // the rebuilt structures live in grow-only buffers (a hipMalloc / hipFree pair per array and call cost more than the sorts)
+  Buf rs[24];          // the rebuilt structures live in grow-only buffers (a hipMalloc / hipFree pair per array and call cost more than the sorts)
   Buf rt[2][10];       // the row table of kq_snapshot_patch_rows, double-buffered (the move reads the old table, writes the new one)
   int rt_cur = 0;
   // S.<field> now points into a persistent buffer: release the upload()ed array it pointed to before, if any
@@ -460,6 +462,7 @@ template <class B> struct EngineT {
     R.adm_cq = grow<int32_t>(rs[0], n); R.tree_row_off = grow<int32_t>(rs[1], (size_t)n_tree + 1); R.tree_rows = grow<int32_t>(rs[2], n);
     R.tree_rows_asc = grow<int32_t>(rs[3], n); R.rank_pos = grow<int32_t>(rs[4], n); R.frb_off = grow<int32_t>(rs[5], nb + 1);
     R.cq_row_bytes = grow<int32_t>(rs[6], nq); R.adm_rec = grow<AdmRec>(rs[7], n); R.frb_sig = (uint64_t*)grow<int64_t>(rs[8], nb);
+    R.adm_recx = grow<AdmRecX>(rs[20], n);
     be.memset(R.cq_row_bytes, 0, (size_t)std::max(nq, 1) * 4); be.memset(R.frb_sig, 0, std::max<size_t>(nb, 1) * 8);
     be.launch_rows(R, RO_ROW_INIT, n);
     be.sort_pairs(R.key, R.val, key2, val2, n, 32);
@@ -523,7 +526,7 @@ template <class B> struct EngineT {
     prep.tree_row_off = tro;
     adopt(S.adm_cq, R.adm_cq); adopt(S.tree_row_off, R.tree_row_off); adopt(S.tree_rows, R.tree_rows);
     adopt(S.tree_rows_asc, R.tree_rows_asc); adopt(S.rank_pos, R.rank_pos); adopt(S.frb_off, R.frb_off); adopt(S.frb, R.frb);
-    adopt(S.cq_row_bytes, R.cq_row_bytes); adopt(S.adm_rec, R.adm_rec); adopt(S.frbr, R.frbr); adopt(S.frec, R.frec);
+    adopt(S.cq_row_bytes, R.cq_row_bytes); adopt(S.adm_rec, R.adm_rec); adopt(S.adm_recx, R.adm_recx); adopt(S.frbr, R.frbr); adopt(S.frec, R.frec);
     for (int l = 0; l < CS_LEVELS; l++) adopt(S.frl[l], R.frl[l]);
     adopt(S.frb_sig, R.frb_sig); adopt(S.cs_ok, d_cs); adopt(S.rec_ok, d_rec);
     adopt(S.fs_ok, d_fs);
@@ -720,6 +723,7 @@ template <class B> struct EngineT {
       case 27: src = S.fs_posoff; sz = cfg.fair_sharing ? ((size_t)prep.nq + prep.n_tree) * 4 : 0; break;
       case 28: src = S.fs_scan; sz = cfg.fair_sharing ? n * sizeof(FsScan) : 0; break;
       case 29: src = S.fs_apply; sz = cfg.fair_sharing ? n * sizeof(FsApply) : 0; break;
+      case 30: src = S.adm_recx; sz = n * sizeof(AdmRecX); break;
       default: return fail(KQ_EINVAL, "unknown structure");
     }
     if ((int64_t)sz > *bytes) { *bytes = (int64_t)sz; return fail(KQ_ECAPACITY, "buffer too small"); }

@@ -28,7 +28,10 @@ constexpr int KQ_MAXR = 8;      // max resources for the incremental (sum-based)
 // One record per admitted row: its usage entries folded per flavor-resource (<= CS_RFR distinct ones), the policy operands and
 // the algorithmic cost of one snapshot.RemoveWorkload / AddWorkload of the row.
 constexpr int CS_NS = 4;       // flavor-resource slots of one search on the fast path
-constexpr int CS_RFR = 4;      // distinct flavor-resources of a row on the fast path
+constexpr int CS_RFR = 4;      // distinct flavor-resources of a row in its record
+constexpr int CS_RFX = 4;      // ... and as many again in the extension record of a WIDE row (AdmRec::flags bit 1): a workload whose podsets
+                               // landed on two flavors holds up to 8 — without it ONE such admission sent every victim search of its whole
+                               // root tree down the candidate-by-candidate walk (round 6: the closed loop admits one in its first cycle)
 constexpr int CS_LEVELS = 3;   // candidate ClusterQueues may sit up to this many levels below the LCA with the preemptor's path
 struct alignas(16) AdmRec {
   int64_t qty[CS_RFR];
@@ -36,9 +39,10 @@ struct alignas(16) AdmRec {
   int64_t prio, qts;
   int32_t cq;
   int32_t rowbytes;            // 16 * (depth + 1) * usage entries of the row (what the oracle charges per Remove/AddWorkload)
-  uint32_t flags;              // bit0 evicted
+  uint32_t flags;              // bit0 evicted, bit1 wide: the row's flavor-resources 5 .. 8 stand in AdmRecX[row]
   int32_t pad;
 };
+struct alignas(16) AdmRecX { int64_t qty[CS_RFX]; int32_t fr[CS_RFX]; };   // read only for wide rows
 // One entry of a (tree, flavor-resource) bucket in "level order" d (d = 1 .. CS_LEVELS, the depth below the root): grouped by the
 // node of depth d on the way from the row's ClusterQueue to the root (`node`, tree-local id; the ClusterQueue itself when it sits
 // at depth d; -1 when it is shallower), evicted rows first, then candidate rank — i.e. the order in which the reference's
@@ -65,6 +69,35 @@ static_assert(sizeof(FsScan) == 32 && sizeof(FsApply) == 64 && sizeof(FsQ) == 16
 #else
 #define KQ_PREP_HD static inline
 #endif
+// the fold of a row's usage entries into its record(s): -> number of distinct flavor-resources, or -1 when they do not fit
+template <class FR, class QTY> KQ_PREP_HD int adm_rec_fold(AdmRec& a, AdmRecX& x, int k0, int k1, FR fr_of, QTY qty_of) {
+  for (int e = 0; e < CS_RFR; e++) { a.fr[e] = -1; a.qty[e] = 0; }
+  for (int e = 0; e < CS_RFX; e++) { x.fr[e] = -1; x.qty[e] = 0; }
+  int nf = 0;
+  for (int e = k0; e < k1; e++) {
+    const int fr = fr_of(e);
+    int k = 0;
+    while (k < nf && (k < CS_RFR ? a.fr[k] : x.fr[k - CS_RFR]) != fr) k++;
+    if (k == nf) {
+      if (nf == CS_RFR + CS_RFX) return -1;
+      if (nf < CS_RFR) a.fr[nf] = fr; else x.fr[nf - CS_RFR] = fr;
+      nf++;
+    }
+    // plain sum (entries of a repeated flavor-resource are removed one after another by the reference; on plain amounts that
+    // is the removal of their sum). Non-plain rows switch the fast search off through fs_plain_adm.
+    int64_t& cell = k < CS_RFR ? a.qty[k] : x.qty[k - CS_RFR];
+    cell = (int64_t)((uint64_t)cell + (uint64_t)qty_of(e));
+  }
+  if (nf > CS_RFR) a.flags |= 2u;
+  return nf;
+}
+// the row's quantity of one flavor-resource from its record(s)
+KQ_PREP_HD int64_t adm_rec_qty(const AdmRec& a, const AdmRecX* xs, int row, int fr) {
+  int64_t q = 0;
+  for (int e = 0; e < CS_RFR; e++) if (a.fr[e] == fr) q = a.qty[e];
+  if (a.flags & 2u) { const AdmRecX& x = xs[row]; for (int e = 0; e < CS_RFX; e++) if (x.fr[e] == fr) q = x.qty[e]; }
+  return q;
+}
 KQ_PREP_HD uint64_t frb_sig_row(int row) { uint64_t h = (uint64_t)(uint32_t)(row + 1) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; return h * 0xBF58476D1CE4E5B9ull; }
 KQ_PREP_HD uint64_t frb_sig_size(int M) { return (uint64_t)(uint32_t)M * 0xD6E8FEB86659FD93ull; }
 
@@ -91,6 +124,7 @@ struct Prep {
   std::vector<int32_t> h_parent;                   // host copies kept for build_fair after a device derive
   std::vector<int64_t> h_ll, h_bl;
   std::vector<AdmRec> adm_rec;                     // [n_adm]
+  std::vector<AdmRecX> adm_recx;                   // [n_adm] (meaningful for wide rows)
   std::vector<CsEnt> frl[CS_LEVELS];               // level orders of every bucket (same offsets as frb)
   std::vector<CsRec> frec;                         // rank order of every bucket (same offsets as frb)
   std::vector<uint64_t> frb_sig;                   // [n_tree * nfr] hash of the bucket's row list (equal sets <=> equal buckets)
@@ -384,31 +418,20 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
     for (int t = 0; t < p.n_tree; t++)
       for (int i = p.frb_off[(size_t)t * p.nfr]; i < p.frb_off[(size_t)(t + 1) * p.nfr]; i++) p.frbr[i] = p.tree_rows[p.tree_row_off[t] + p.frb[i]];
     p.adm_rec.assign(p.skip_rows ? 0 : p.n_adm, AdmRec{});
+    p.adm_recx.assign(p.skip_rows ? 0 : p.n_adm, AdmRecX{});
     p.fs_ok.assign(p.n_tree, 1); p.rec_ok.assign(p.n_tree, 1);
     for (int c = 0; c < nq; c++) if (p.depth[c] > CS_LEVELS) p.cs_ok[p.tree_of[c]] = 0;
     for (int r = 0; r < p.n_adm && !p.skip_rows; r++) {
       AdmRec& a = p.adm_rec[r];
-      for (int e = 0; e < CS_RFR; e++) { a.fr[e] = -1; a.qty[e] = 0; }
       const int c = p.adm_cq[r];
       a.prio = s->adm_priority[r]; a.qts = s->adm_queue_ts[r]; a.cq = c; a.flags = (s->adm_flags[r] & KQ_ADM_EVICTED) ? 1u : 0u;
       a.rowbytes = 16 * (p.depth[c] + 1) * (s->adm_use_off[r + 1] - s->adm_use_off[r]);
-      int nf = 0;
-      for (int e = s->adm_use_off[r]; e < s->adm_use_off[r + 1]; e++) {
-        const int fr = s->adm_use_fr[e];
-        int k = 0;
-        while (k < nf && a.fr[k] != fr) k++;
-        if (k == nf) { if (nf == CS_RFR) { p.cs_ok[p.tree_of[c]] = 0; break; } a.fr[nf++] = fr; }
-        // plain sum (entries of a repeated flavor-resource are removed one after another by the reference; on plain amounts that
-        // is the removal of their sum). Non-plain rows switch the fast search off through fs_plain_adm.
-        a.qty[k] = (int64_t)((uint64_t)a.qty[k] + (uint64_t)s->adm_use_qty[e]);
-      }
-      if (nf == CS_RFR) {  // did the row have more distinct flavor-resources than a record holds?
-        for (int e = s->adm_use_off[r]; e < s->adm_use_off[r + 1]; e++) {
-          bool in = false;
-          for (int q = 0; q < CS_RFR; q++) if (a.fr[q] == s->adm_use_fr[e]) in = true;
-          if (!in) { p.fs_ok[p.tree_of[c]] = 0; p.rec_ok[p.tree_of[c]] = 0; }
-        }
-      }
+      const int nf = adm_rec_fold(a, p.adm_recx[r], s->adm_use_off[r], s->adm_use_off[r + 1],
+                                  [&](int e) { return s->adm_use_fr[e]; }, [&](int e) { return s->adm_use_qty[e]; });
+      // more flavor-resources than the two records hold: the scan-formulated search is off for the tree; more than the first holds:
+      // the fair-sharing formulation (its position records carry CS_RFR entries) is
+      if (nf < 0) { p.cs_ok[p.tree_of[c]] = 0; p.rec_ok[p.tree_of[c]] = 0; }
+      if (nf < 0 || nf > CS_RFR) p.fs_ok[p.tree_of[c]] = 0;
     }
     // ---- kq_fs.hpp: candidates in position order, children lists in tree-node order ----
     for (int c = 0; c < nq; c++) if (p.depth[c] + 1 > FS_LV) p.fs_ok[p.tree_of[c]] = 0;
@@ -512,8 +535,7 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
           for (int q = 0; q < M; q++) {
             const int j = idx[q];
             const int row = p.tree_rows[p.tree_row_off[t] + p.frb[o + j]];
-            int64_t qty = 0;
-            for (int e = 0; e < CS_RFR; e++) if (p.adm_rec[row].fr[e] == fr) qty = p.adm_rec[row].qty[e];
+            const int64_t qty = adm_rec_qty(p.adm_rec[row], p.adm_recx.data(), row, fr);
             p.frl[l][o + q] = CsEnt{j | (p.depth[p.adm_cq[row]] << 24), anc[j] >= 0 ? p.node_local[anc[j]] : -1, row, anc[j], qty};
           }
         }

@@ -41,7 +41,7 @@ struct DRows {
   int32_t* scal;        // [4] cs_max_bucket, max_tree_rows
   // outputs
   int32_t *adm_cq, *tree_row_off, *tree_rows, *tree_rows_asc, *rank_pos, *frb_off, *frb, *frbr, *cq_row_bytes;
-  AdmRec* adm_rec;
+  AdmRec* adm_rec; AdmRecX* adm_recx;
   CsRec* frec;
   CsEnt* frl[CS_LEVELS];
   uint64_t* frb_sig;
@@ -93,28 +93,15 @@ KQ_DEV void ro_row_init(const DRows& R, int r) {
   const int t = R.tree_of[c];   // (rows per tree: the host derives them from the CSR offsets — one counter per tree would serialise every row)
   const int k0 = R.adm_use_off[r], k1 = R.adm_use_off[r + 1];
   atomic_add_i32(&R.cq_row_bytes[c], 32 + 12 * (k1 - k0));
-  AdmRec a;
-  for (int e = 0; e < CS_RFR; e++) { a.fr[e] = -1; a.qty[e] = 0; }
+  AdmRec a; AdmRecX x;
   a.prio = R.adm_prio[r]; a.qts = R.adm_qts[r]; a.cq = c; a.flags = (R.adm_flags[r] & KQ_ADM_EVICTED) ? 1u : 0u;
   a.rowbytes = 16 * (R.depth[c] + 1) * (k1 - k0); a.pad = 0;
-  int nf = 0, distinct = 0;
-  bool broke = false;
-  for (int e = k0; e < k1; e++) {
-    const int fr = R.adm_use_fr[e];
-    if (ro_first_use(R, r, e)) distinct++;
-    if (broke) continue;
-    int k = 0;
-    while (k < nf && a.fr[k] != fr) k++;
-    if (k == nf) { if (nf == CS_RFR) { R.cs_ok[t] = 0; broke = true; continue; } a.fr[nf++] = fr; }
-    a.qty[k] = (int64_t)((uint64_t)a.qty[k] + (uint64_t)R.adm_use_qty[e]);
-  }
-  if (nf == CS_RFR)
-    for (int e = k0; e < k1; e++) {
-      bool in = false;
-      for (int q = 0; q < CS_RFR; q++) if (a.fr[q] == R.adm_use_fr[e]) in = true;
-      if (!in) { R.fs_ok[t] = 0; R.rec_ok[t] = 0; }
-    }
-  R.adm_rec[r] = a;
+  int distinct = 0;
+  for (int e = k0; e < k1; e++) if (ro_first_use(R, r, e)) distinct++;
+  const int nf = adm_rec_fold(a, x, k0, k1, [&](int e) { return R.adm_use_fr[e]; }, [&](int e) { return R.adm_use_qty[e]; });
+  if (nf < 0) { R.cs_ok[t] = 0; R.rec_ok[t] = 0; }
+  if (nf < 0 || nf > CS_RFR) R.fs_ok[t] = 0;
+  R.adm_rec[r] = a; R.adm_recx[r] = x;
   R.ent_cnt[r] = distinct;
   R.val[r] = r;
   R.key[r] = (uint64_t)R.adm_uid[r];
@@ -203,8 +190,7 @@ KQ_DEV void ro_lfill(const DRows& R, int x) {
   const int cq = R.adm_cq[row];
   const int anc = ro_anc(R, cq, l);
   const int fr = b % R.nfr;
-  int64_t qty = 0;
-  for (int e = 0; e < CS_RFR; e++) if (R.adm_rec[row].fr[e] == fr) qty = R.adm_rec[row].qty[e];
+  const int64_t qty = adm_rec_qty(R.adm_rec[row], R.adm_recx, row, fr);
   R.frl[l][q] = CsEnt{j | (R.depth[cq] << 24), anc >= 0 ? R.node_local[anc] : -1, row, anc, qty};
 }
 KQ_DEV uint32_t ro_hkey(const DRows& R, int row) { return ((R.adm_flags[row] & KQ_ADM_EVICTED) ? 0u : 0x80000000u) | (uint32_t)R.rank_pos[row]; }

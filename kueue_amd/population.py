@@ -12,6 +12,7 @@ Everything is emitted directly in the flat boundary schema (api.Snapshot / api.H
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List
 
@@ -280,6 +281,8 @@ def _generate(cfg, seed, n_cq, per_cq, preemption, fair_sharing, fill, feas):
         cpu = rng.choice([1000, 2000, 4000, 8000, 16000], size=W)
         prio = rng.integers(0, 8 if preemption else 4, size=W)
         w_nps = np.where(rng.random(W) < 0.1, 2, 1)
+        if os.environ.get("KQ_POP_ONE_PODSET"):   # (experiment: no admitted row ever holds more than one flavor's resources)
+            w_nps = np.ones(W, np.int64)
     n_ps = int(w_nps.sum())
     ps_owner = np.repeat(np.arange(W), w_nps)
     ps_count = rng.integers(1, 5, size=n_ps)

@@ -10,10 +10,10 @@ import pytest
 
 from tests.randgen import random_case
 
-N_STRUCT = 30
+N_STRUCT = 31
 NAMES = ["adm_cq", "tree_row_off", "tree_rows", "tree_rows_asc", "rank_pos", "frb_off", "frb", "frbr", "cq_row_bytes", "adm_rec", "frec", "frl0", "frl1", "frl2",
          "frb_sig", "cs_ok", "rec_ok", "cq_adm_off", "adm_use_off", "adm_use_fr", "adm_use_qty", "adm_prio", "adm_qts", "adm_rts", "adm_uid", "adm_flags",
-         "fs_ok", "fs_posoff", "fs_scan", "fs_apply"]
+         "fs_ok", "fs_posoff", "fs_scan", "fs_apply", "adm_recx"]
 
 
 class _Emu:
