@@ -20,7 +20,7 @@
 //
 // Same sequence of operations as fair_search, hence the same targets, the same private state where callers read it, and the
 // same algorithmic byte count (an "evaluation" of a cached share is charged what computing it costs the reference). Trees or
-// searches outside the preconditions (deeper than FS_LV levels, rows with more than CS_RFR flavor-resources, non-plain
+// searches outside the preconditions (deeper than FS_LV levels, rows with more than FS_RFR flavor-resources, non-plain
 // amounts, more than FS_PCN preemptor cells) return false and fair_search runs. Bit-exact: tests run both and compare.
 #pragma once
 
@@ -28,7 +28,7 @@ namespace kq {
 
 constexpr int FS_PCN = 64;      // (in-use slot, level) cells of the preemptor's context
 constexpr int FS_NCMAX = 16;    // usage columns cached per search
-constexpr int FS_RC = CS_RFR * FS_LV;
+constexpr int FS_RC = FS_RFR * FS_LV;
 constexpr int FS_BQ = 64;       // ClusterQueues of one cohort handled as a batch (fs_batch_first / fs_batch_second)
 constexpr int FS_BC = 128;      // candidates evaluated per batch
 
@@ -69,7 +69,7 @@ struct Fs {
   // fields of the Search (it lives in the caller's frame)
   int64_t* W; const int64_t* usage; const uint8_t* removed; int32_t* trow; uint8_t* treason;
 };
-struct FsRow { int64_t qty[CS_RFR]; int fr[CS_RFR]; int res[CS_RFR]; int lp[FS_LV]; int plen, row, cbytes, rowbytes; uint32_t hkey; };
+struct FsRow { int64_t qty[FS_RFR]; int fr[FS_RFR]; int res[FS_RFR]; int lp[FS_LV]; int plen, row, cbytes, rowbytes, nent; uint32_t hkey; };   // nent: entries to look at (CS_RFR, a wide row FS_RFR)
 
 // every array of the search sits in the workgroup's LDS (fs_setup checks it): tell the compiler, so that the accesses are ds_* instead
 // of flat_* — in every function that receives the Fs by reference (the facts do not travel across a call)
@@ -100,7 +100,7 @@ size_t fs_bytes(int nn, int nqs, int nR, int nfr, int mw, int ncols) {
   size_t b = 0;
   b += al(FS_RC * 8) * 3 + al(FS_LV * KQ_MAXR * 8) + al(FS_LV * 8);                               // row context
   b += al(FS_RC * 8) + al(FS_RC * 4) + al(FS_LV * KQ_MAXR * 8) + al(4 * 8);                        // staging of a row operation
-  b += al(FS_RC * 8) + al(FS_LV * KQ_MAXR * 8) + al(CS_RFR * 4) + al(FS_LV * 4) + al(FS_LV * 8) + al(FS_LV);   // an evaluation's results (ev_*)
+  b += al(FS_RC * 8) + al(FS_LV * KQ_MAXR * 8) + al(FS_RFR * 4) + al(FS_LV * 4) + al(FS_LV * 8) + al(FS_LV);   // an evaluation's results (ev_*)
   b += al(FS_PCN * 8) * 5 + al(FS_PCN * 4) + al(FS_LV * KQ_MAXR * 8) + al(FS_LV * 8);              // preemptor context
   b += al(FS_NCMAX * 8);                                                                            // column pointers
   b += al(nn) * 2 + al((size_t)nn * 8) + al((size_t)nn * 4) + al((size_t)nn * 2) * 4;              // nflag plv dval ppos c0 c1 kid par
@@ -136,6 +136,24 @@ KQ_DEV int fs_cmp(int za, uint64_t ka, int zb, uint64_t kb) {
 }
 KQ_DEV uint64_t wmax_u64(uint64_t v) { return ~wmin_u64(~v); }
 template <class T> KQ_DEV T fs_sel4(const T* a, int i) { T v = a[0]; if (i == 1) v = a[1]; if (i == 2) v = a[2]; if (i == 3) v = a[3]; return v; }
+template <class T> KQ_DEV T fs_sel8(const T* a, int i) { const T lo = fs_sel4(a, i & 3), hi = fs_sel4(a + 4, i & 3); return i < 4 ? lo : hi; }
+static_assert(CS_RFR == 4 && FS_RFR == 8 && FS_LV == 4, "fs_sel4 on the levels and on a record's entries, fs_sel8 on a row's entries");
+// the usage entries of the row of a position record, as the search sees them: the record's own, then a wide row's other ones
+struct FsEnt { int64_t qty[FS_RFR]; int fr[FS_RFR]; int res[FS_RFR]; };   // res = the entry's resource index (fr % nR), -1 = unused entry
+KQ_DEV FsEnt fs_entries(const DSnap& S, const FsApply& a) {
+  FsEnt e;
+  #pragma unroll
+  for (int u = 0; u < CS_RFR; u++) {
+    e.qty[u] = a.qty[u]; e.fr[u] = a.fr[u]; e.res[u] = a.fr[u] >= 0 ? (int)a.res[u] : -1;
+    e.qty[CS_RFR + u] = 0; e.fr[CS_RFR + u] = -1; e.res[CS_RFR + u] = -1;
+  }
+  if (a.wide) {
+    const AdmRecX x = S.adm_recx[a.row];
+    #pragma unroll
+    for (int u = 0; u < CS_RFX; u++) { e.qty[CS_RFR + u] = x.qty[u]; e.fr[CS_RFR + u] = x.fr[u]; e.res[CS_RFR + u] = x.fr[u] >= 0 ? x.fr[u] % S.nR : -1; }
+  }
+  return e;
+}
 
 // first set position of bitmap m inside [a, b), -1 if none
 KQ_DEV int fs_first(const uint64_t* m, int a, int b) {
@@ -226,8 +244,10 @@ KQ_DEV FsRow fs_row_load(const Fs& f, int p) {
   const DSnap& S = f.k->S;
   const FsApply ap = S.fs_apply[(size_t)f.row0 + p];
   FsRow r;
+  const FsEnt en = fs_entries(S, ap);
   #pragma unroll
-  for (int e = 0; e < CS_RFR; e++) { r.qty[e] = ap.qty[e]; r.fr[e] = ap.fr[e]; r.res[e] = ap.fr[e] >= 0 ? (int)ap.res[e] : -1; }
+  for (int e = 0; e < FS_RFR; e++) { r.qty[e] = en.qty[e]; r.fr[e] = en.fr[e]; r.res[e] = en.res[e]; }
+  r.nent = ap.wide ? FS_RFR : CS_RFR;
   #pragma unroll
   for (int l = 0; l < FS_LV; l++) r.lp[l] = ap.lp[l];
   r.plen = ap.plen; r.row = ap.row; r.cbytes = ap.cbytes; r.hkey = ap.hkey;
@@ -239,11 +259,11 @@ KQ_DEV void fs_row_ctx(Fs& f, const FsRow& r) {
   const DSnap& S = f.k->S;
   bool miss = false;
   #pragma unroll
-  for (int e = 0; e < CS_RFR; e++) if (r.fr[e] >= 0 && f.colslot[r.fr[e]] < 0) miss = true;
+  for (int e = 0; e < FS_RFR; e++) if (r.fr[e] >= 0 && f.colslot[r.fr[e]] < 0) miss = true;
   if (miss) fs_ensure_w(f);
-  for (int c = lane_id(); c < FS_RC; c += WAVE) {
+  for (int c = lane_id(); c < r.nent * FS_LV; c += WAVE) {
     const int u = c / FS_LV, i = c % FS_LV;
-    const int fr = fs_sel4(r.fr, u), li = fs_sel4(r.lp, i);
+    const int fr = fs_sel8(r.fr, u), li = fs_sel4(r.lp, i);
     if (fr < 0 || i >= r.plen) continue;
     const FsQ q = S.fs_q[(size_t)(f.n0 + li) * f.nfr + fr];
     f.rc_lq[c] = fs_cap(q.lq); f.rc_sqb[c] = fs_cap(q.sqb);
@@ -344,23 +364,23 @@ KQ_DEV int fs_nodes_update(const Fs& f, const int* lp, int plen, const int64_t* 
   if (at >= 0) { *key = f.tout[0]; return (int)f.tout[1]; }
   return 0;
 }
-struct FsRowRes { int r0, r1, r2, r3; KQ_MDEV int operator()(int u) const { return u == 0 ? r0 : (u == 1 ? r1 : (u == 2 ? r2 : r3)); } };
+struct FsRowRes { int r[FS_RFR]; KQ_MDEV int operator()(int u) const { return fs_sel8(r, u); } };
 // snapshot.RemoveWorkload / AddWorkload of the row whose context is loaded. commit = false evaluates the share of node `at`
 // after the operation without changing anything.
 KQ_DEV int fs_row_apply(const Fs& f, const FsRow& r, bool add, bool commit, bool count, int at = -1, uint64_t* key = nullptr) {
-  for (int u = lane_id(); u < CS_RFR; u += WAVE) {
-    const int fr = fs_sel4(r.fr, u);
+  for (int u = lane_id(); u < r.nent; u += WAVE) {
+    const int fr = fs_sel8(r.fr, u);
     FsChainOut o;
     #pragma unroll
     for (int i = 0; i < FS_LV; i++) { o.d[i] = 0; o.dp[i] = 0; }
-    if (fr >= 0) o = fs_chain(f, f.rc_ptr + u * FS_LV, f.rc_lq + u * FS_LV, f.rc_sqb + u * FS_LV, r.plen, fs_sel4(r.qty, u), add, commit,
+    if (fr >= 0) o = fs_chain(f, f.rc_ptr + u * FS_LV, f.rc_lq + u * FS_LV, f.rc_sqb + u * FS_LV, r.plen, fs_sel8(r.qty, u), add, commit,
                               commit ? nullptr : f.ev_nv + u * FS_LV, commit ? nullptr : f.ev_t + u);
     else if (!commit) f.ev_t[u] = 0;
     #pragma unroll
     for (int i = 0; i < FS_LV; i++) { f.td[u * FS_LV + i] = o.d[i]; f.tp[u * FS_LV + i] = o.dp[i]; }
   }
   wsync();
-  const int z = fs_nodes_update(f, r.lp, r.plen, f.rc_lend, f.rc_wt, CS_RFR, FsRowRes{r.res[0], r.res[1], r.res[2], r.res[3]}, commit, at, key);
+  const int z = fs_nodes_update(f, r.lp, r.plen, f.rc_lend, f.rc_wt, r.nent, FsRowRes{{r.res[0], r.res[1], r.res[2], r.res[3], r.res[4], r.res[5], r.res[6], r.res[7]}}, commit, at, key);
   if (count && lane_id() == 0) f.w->bytes += r.rowbytes;
   return z;
 }
@@ -370,7 +390,7 @@ KQ_DEV int fs_row_apply(const Fs& f, const FsRow& r, bool add, bool commit, bool
 // writes what it left in ev_* instead of computing it a second time.
 KQ_DEV void fs_row_commit_evaluated(const Fs& f, const FsRow& r) {
   const int lane = lane_id();
-  for (int u = lane; u < CS_RFR; u += WAVE) {
+  for (int u = lane; u < r.nent; u += WAVE) {
     const int tm = f.ev_t[u];
     #pragma unroll
     for (int i = 0; i < FS_LV; i++) if (tm & (1 << i)) fs_st(f, f.rc_ptr[u * FS_LV + i], f.ev_nv[u * FS_LV + i]);
@@ -420,7 +440,7 @@ KQ_DEV void fs_pc_apply(const Fs& f, bool add) {
   int lp[FS_LV];
   #pragma unroll
   for (int i = 0; i < FS_LV; i++) lp[i] = w.cs_pl[i];
-  // FS_RC staging cells serve CS_RFR chains at a time
+  // the staging cells serve CS_RFR chains at a time
   for (int base = 0; base < f.npc; base += CS_RFR) {
     const int nch = f.npc - base < CS_RFR ? f.npc - base : CS_RFR;
     for (int q = lane_id(); q < CS_RFR; q += WAVE) {
@@ -436,7 +456,7 @@ KQ_DEV void fs_pc_apply(const Fs& f, bool add) {
     int rs[CS_RFR];
     #pragma unroll
     for (int q = 0; q < CS_RFR; q++) rs[q] = q < nch ? w.s_fr[f.pc_u[base + q]] % f.nR : -1;
-    fs_nodes_update(f, lp, f.plen, f.pc_lend, f.pc_wt, nch, FsRowRes{rs[0], rs[1], rs[2], rs[3]}, true, -1, nullptr);
+    fs_nodes_update(f, lp, f.plen, f.pc_lend, f.pc_wt, nch, FsRowRes{{rs[0], rs[1], rs[2], rs[3], -1, -1, -1, -1}}, true, -1, nullptr);
   }
 }
 // Available (resource_node.go:106-122) of one in-use slot from its gathered path cells
@@ -655,7 +675,7 @@ KQ_DEV bool fs_setup(Search& s, Fs& f) {
   f.rc_ptr = (int32_t*)cv.take(FS_RC * 8); f.rc_lq = (int64_t*)cv.take(FS_RC * 8); f.rc_sqb = (int64_t*)cv.take(FS_RC * 8);
   f.rc_lend = (int64_t*)cv.take(FS_LV * KQ_MAXR * 8); f.rc_wt = (double*)cv.take(FS_LV * 8);
   f.td = (int64_t*)cv.take(FS_RC * 8); f.tp = (int32_t*)cv.take(FS_RC * 4); f.tx = (double*)cv.take(FS_LV * KQ_MAXR * 8); f.tout = (uint64_t*)cv.take(4 * 8);
-  f.ev_nv = (int64_t*)cv.take(FS_RC * 8); f.ev_sum = (int64_t*)cv.take(FS_LV * KQ_MAXR * 8); f.ev_t = (int32_t*)cv.take(CS_RFR * 4); f.ev_np = (int32_t*)cv.take(FS_LV * 4);
+  f.ev_nv = (int64_t*)cv.take(FS_RC * 8); f.ev_sum = (int64_t*)cv.take(FS_LV * KQ_MAXR * 8); f.ev_t = (int32_t*)cv.take(FS_RFR * 4); f.ev_np = (int32_t*)cv.take(FS_LV * 4);
   f.ev_v = (double*)cv.take(FS_LV * 8); f.ev_z = (uint8_t*)cv.take(FS_LV);
   f.pc_ptr = (int32_t*)cv.take(FS_PCN * 8); f.pc_lq = (int64_t*)cv.take(FS_PCN * 8); f.pc_sq = (int64_t*)cv.take(FS_PCN * 8);
   f.pc_sqb = (int64_t*)cv.take(FS_PCN * 8); f.pc_bl = (int64_t*)cv.take(FS_PCN * 8); f.pc_u = (int32_t*)cv.take(FS_PCN * 4);
@@ -803,13 +823,14 @@ KQ_DEV uint64_t fs_eval_removed(const Fs& f, int p, int at, int* flags) {
   int ia = 0;
   #pragma unroll
   for (int i = 0; i < FS_LV; i++) if (i < plen && (int)a.lp[i] == at) ia = i;
-  int64_t du[CS_RFR]; int dpu[CS_RFR];
+  const FsEnt en = fs_entries(S, a);
+  int64_t du[FS_RFR]; int dpu[FS_RFR];
   #pragma unroll
-  for (int u = 0; u < CS_RFR; u++) {
+  for (int u = 0; u < FS_RFR; u++) {
     du[u] = 0; dpu[u] = 0;
-    const int fr = a.fr[u];
+    const int fr = en.fr[u];
     if (fr < 0) continue;
-    int64_t val = a.qty[u];
+    int64_t val = en.qty[u];
     bool go = true;
     #pragma unroll
     for (int i = 0; i < FS_LV; i++) {
@@ -830,7 +851,7 @@ KQ_DEV uint64_t fs_eval_removed(const Fs& f, int p, int at, int* flags) {
   for (int rr = 0; rr < f.nR; rr++) {
     int64_t d = 0;
     #pragma unroll
-    for (int u = 0; u < CS_RFR; u++) if (a.fr[u] >= 0 && (int)a.res[u] == rr) d += du[u];
+    for (int u = 0; u < FS_RFR; u++) if (en.res[u] == rr) d += du[u];
     const int64_t sum = f.psum[(size_t)at * f.nR + rr] + d;
     double x = 0;
     if (sum > 0) { const int64_t lr = S.fs_lend[(size_t)(f.n0 + at) * f.nR + rr]; if (lr > 0) x = (double)sum * 1000.0 / (double)lr; }
@@ -838,7 +859,7 @@ KQ_DEV uint64_t fs_eval_removed(const Fs& f, int p, int at, int* flags) {
   }
   int np = f.ppos[at];
   #pragma unroll
-  for (int u = 0; u < CS_RFR; u++) np += dpu[u];
+  for (int u = 0; u < FS_RFR; u++) np += dpu[u];
   const double weight = S.fs_weight[f.n0 + at];
   const bool zwb = weight == 0 && ratio != 0;
   double v = ratio;
@@ -965,9 +986,9 @@ KQ_DEV int fs_batch(Fs& f, int cand, int strategy0, bool second, int* pos_out) {
     }
     wsync_lds();
     for (int i = lane; i < T; i += WAVE) {
-      const FsApply a = S.fs_apply[(size_t)f.row0 + f.cl_pos[i]];
+      const FsEnt en = fs_entries(S, S.fs_apply[(size_t)f.row0 + f.cl_pos[i]]);
       #pragma unroll
-      for (int e = 0; e < CS_RFR; e++) if (a.fr[e] >= 0 && f.colslot[a.fr[e]] < 0) miss = true;
+      for (int e = 0; e < FS_RFR; e++) if (en.fr[e] >= 0 && f.colslot[en.fr[e]] < 0) miss = true;
     }
     if (wballot(miss)) fs_ensure_w(f);
     for (int base = 0; base < T && pass_idx < 0; base += WAVE) {
@@ -1084,6 +1105,7 @@ KQ_DEV int fs_batch(Fs& f, int cand, int strategy0, bool second, int* pos_out) {
 KQ_DEV bool fs_probe_fits(const Fs& f, int p) {  // would the preemptor still fit with the row at position p added back? (one lane)
   const DSnap& S = f.k->S; const Wave& w = *f.w;
   const FsApply a = S.fs_apply[(size_t)f.row0 + p];
+  const FsEnt en = fs_entries(S, a);
   const int rplen = a.plen;
   bool bad = false;
   for (int j = 0; j < f.npc; j++) {
@@ -1092,9 +1114,9 @@ KQ_DEV bool fs_probe_fits(const Fs& f, int p) {  // would the preemptor still fi
     #pragma unroll
     for (int i = 0; i < FS_LV; i++) add[i] = 0;
     #pragma unroll
-    for (int e = 0; e < CS_RFR; e++) {
-      if ((int)a.fr[e] != frj) continue;
-      int64_t val = a.qty[e];
+    for (int e = 0; e < FS_RFR; e++) {
+      if (en.fr[e] != frj) continue;
+      int64_t val = en.qty[e];
       bool go = true;
       #pragma unroll
       for (int h = 0; h < FS_LV; h++) {  // addUsage resource_node.go:144-152
@@ -1130,8 +1152,7 @@ KQ_DEV int fs_fillback_batch(Fs& f, int nt, int64_t* tbytes) {
   // probes are fetched together — a lane per (row, usage entry) — and parked in LDS; the probes then run one after the other on LDS
   // alone: AddWorkload as the usage chains only (the borrowed sums and cached shares are dead once the strategies are over), the fit
   // test, and RemoveWorkload again where it fails. Same cells written in the same order, same bytes charged.
-  constexpr int FS_FG = 16, FS_FC = FS_FG * CS_RFR;
-  static_assert(CS_RFR == 4 && FS_LV == 4, "fs_sel4 on the usage entries and the levels");
+  constexpr int FS_FG = 16, FS_FC = FS_FG * FS_RFR;
   const size_t st_bytes = (size_t)FS_FC * FS_LV * 8 + (size_t)FS_FC * FS_LV * 4 + (size_t)FS_FC * 8 + (size_t)FS_FC * 4 + (size_t)FS_FG * 8;
   const bool staged = (size_t)f.nn * f.nR * 8 >= st_bytes;   // the staging area lies over the borrowed sums
   int64_t* st_lq = f.psum; int32_t* st_ptr = (int32_t*)(st_lq + FS_FC * FS_LV); int64_t* st_qty = (int64_t*)(st_ptr + FS_FC * FS_LV);
@@ -1142,16 +1163,17 @@ KQ_DEV int fs_fillback_batch(Fs& f, int nt, int64_t* tbytes) {
       {
         bool miss = false;
         for (int c = lane; c < FS_FC; c += WAVE) {
-          const int rr = c / CS_RFR, u = c % CS_RFR;
-          if (rr < nb) { const int fr = S.fs_apply[(size_t)f.row0 + fs_tpos(f, t - rr)].fr[u]; if (fr >= 0 && f.colslot[fr] < 0) miss = true; }
+          const int rr = c / FS_RFR, u = c % FS_RFR;
+          if (rr < nb) { const int fr = fs_sel8(fs_entries(S, S.fs_apply[(size_t)f.row0 + fs_tpos(f, t - rr)]).fr, u); if (fr >= 0 && f.colslot[fr] < 0) miss = true; }
         }
         if (wballot(miss)) fs_ensure_w(f);
       }
       for (int c = lane; c < FS_FC; c += WAVE) {
-        const int rr = c / CS_RFR, u = c % CS_RFR;
+        const int rr = c / FS_RFR, u = c % FS_RFR;
         const bool in = rr < nb;
         const FsApply a = S.fs_apply[(size_t)f.row0 + fs_tpos(f, in ? t - rr : t)];
-        const int fr = in ? (int)fs_sel4(a.fr, u) : -1;
+        const FsEnt en = fs_entries(S, a);
+        const int fr = in ? fs_sel8(en.fr, u) : -1;
         int64_t lqv[FS_LV];
         #pragma unroll
         for (int i = 0; i < FS_LV; i++) lqv[i] = (fr >= 0 && i < (int)a.plen) ? S.fs_q[(size_t)(f.n0 + a.lp[i]) * f.nfr + fr].lq : 0;
@@ -1160,7 +1182,7 @@ KQ_DEV int fs_fillback_batch(Fs& f, int nt, int64_t* tbytes) {
           st_lq[c * FS_LV + i] = fs_cap(lqv[i]);
           st_ptr[c * FS_LV + i] = (fr >= 0 && i < (int)a.plen) ? fs_cell(f, a.lp[i], fr) : 0;
         }
-        st_qty[c] = fr >= 0 ? fs_sel4(a.qty, u) : 0;
+        st_qty[c] = fr >= 0 ? fs_sel8(en.qty, u) : 0;
         st_fr[c] = fr;
         if (u == 0 && in) { st_plen[rr] = a.plen; st_rb[rr] = 16 * (int)a.plen * (((int)a.cbytes - 32) / 12); }
       }
@@ -1170,8 +1192,8 @@ KQ_DEV int fs_fillback_batch(Fs& f, int nt, int64_t* tbytes) {
       int done = 0;
       for (int rr = 0; rr < nb; rr++) {
         const int rplen = st_plen[rr], rb = st_rb[rr];
-        for (int u = lane; u < CS_RFR; u += WAVE) {
-          const int c = rr * CS_RFR + u;
+        for (int u = lane; u < FS_RFR; u += WAVE) {
+          const int c = rr * FS_RFR + u;
           if (st_fr[c] >= 0) (void)fs_chain(f, st_ptr + c * FS_LV, st_lq + c * FS_LV, st_lq + c * FS_LV, rplen, st_qty[c], true, true);
         }
         wsync();
@@ -1185,8 +1207,8 @@ KQ_DEV int fs_fillback_batch(Fs& f, int nt, int64_t* tbytes) {
           wsync();
           continue;
         }
-        for (int u = lane; u < CS_RFR; u += WAVE) {
-          const int c = rr * CS_RFR + u;
+        for (int u = lane; u < FS_RFR; u += WAVE) {
+          const int c = rr * FS_RFR + u;
           if (st_fr[c] >= 0) (void)fs_chain(f, st_ptr + c * FS_LV, st_lq + c * FS_LV, st_lq + c * FS_LV, rplen, st_qty[c], false, true);
         }
         wsync();
@@ -1219,9 +1241,10 @@ KQ_DEV int fs_fillback_batch(Fs& f, int nt, int64_t* tbytes) {
       const bool in = tt >= 0;
       const int p = fs_tpos(f, in ? tt : 0);
       const FsApply a = S.fs_apply[(size_t)f.row0 + p];
+      const FsEnt en = fs_entries(S, a);
       bool miss = false;
       #pragma unroll
-      for (int e = 0; e < CS_RFR; e++) if (in && a.fr[e] >= 0 && f.colslot[a.fr[e]] < 0) miss = true;
+      for (int e = 0; e < FS_RFR; e++) if (in && en.fr[e] >= 0 && f.colslot[en.fr[e]] < 0) miss = true;
       if (wballot(miss)) fs_ensure_w(f);
       const uint64_t fm = wballot(in && fs_probe_fits(f, p));
       const int span = t + 1 < WAVE ? t + 1 : WAVE;
@@ -1275,7 +1298,7 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
     // a record's verdict once it is known whether its row still exists (findCandidatesForPolicy :599-627)
     auto cand_bit = [&](const FsScan& sc, bool live) -> bool {
       if (!live) return false;
-      cbytes += sc.cbytes;
+      cbytes += sc.cbytes & ~FS_SCAN_WIDE;
       const int policy = sc.cql == f.wli ? policy_same : policy_other;
       const bool lower = w.prio > sc.prio;
       bool ok = policy == KQ_POLICY_ANY;
@@ -1285,6 +1308,12 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
       #pragma unroll
       for (int e = 0; e < CS_RFR; e++)
         for (int u = 0; u < w.ns; u++) if (sc.fr[e] >= 0 && w.s_need[u] && w.s_fr[u] == sc.fr[e]) uses = true;
+      if (ok && !uses && (sc.cbytes & FS_SCAN_WIDE)) {   // a wide row: its other entries
+        const AdmRecX x = S.adm_recx[sc.row];
+        #pragma unroll
+        for (int e = 0; e < CS_RFX; e++)
+          for (int u = 0; u < w.ns; u++) if (x.fr[e] >= 0 && w.s_need[u] && w.s_fr[u] == x.fr[e]) uses = true;
+      }
       return ok && uses;
     };
     if constexpr (WAVE == 64) {

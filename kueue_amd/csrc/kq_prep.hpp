@@ -58,8 +58,11 @@ struct alignas(8) CsRec { int64_t prio, qts; int32_t row, cql, rowbytes; uint32_
 // common/ordering.go:42-83). A search's candidate classes are bitmaps over these positions. Two records per position: what the
 // candidate scan reads, and what a pop / a snapshot.RemoveWorkload of the row reads (tree-local path of its ClusterQueue included).
 constexpr int FS_LV = 4;       // path levels (ClusterQueue + 3 cohort levels) of a tree the LDS search handles
+constexpr int FS_RFR = CS_RFR + CS_RFX;   // usage entries of a row in the search: the records below carry the first CS_RFR, a WIDE row's other
+                                          // entries are read from AdmRecX[row] (FsApply::wide; bit 15 of FsScan::cbytes, FS_SCAN_WIDE)
+constexpr uint16_t FS_SCAN_WIDE = 0x8000u;
 struct alignas(16) FsScan { int64_t prio, qts; int16_t fr[CS_RFR]; int32_t row; int16_t cql; uint16_t cbytes; };
-struct alignas(16) FsApply { int64_t qty[CS_RFR]; int16_t lp[FS_LV]; int16_t fr[CS_RFR]; int32_t row; uint32_t hkey; uint16_t cbytes; uint8_t plen; uint8_t res[CS_RFR]; uint8_t pad; };
+struct alignas(16) FsApply { int64_t qty[CS_RFR]; int16_t lp[FS_LV]; int16_t fr[CS_RFR]; int32_t row; uint32_t hkey; uint16_t cbytes; uint8_t plen; uint8_t res[CS_RFR]; uint8_t wide; };
 struct alignas(16) FsQ { int64_t lq, sqb; };  // localQuota, SubtreeQuota (INT64_MAX where the node has no entry) of one (node, flavor-resource)
 static_assert(sizeof(FsScan) == 32 && sizeof(FsApply) == 64 && sizeof(FsQ) == 16, "FsScan / FsApply / FsQ are read as 32 / 64 / 16 byte records");
 
@@ -428,10 +431,8 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
       a.rowbytes = 16 * (p.depth[c] + 1) * (s->adm_use_off[r + 1] - s->adm_use_off[r]);
       const int nf = adm_rec_fold(a, p.adm_recx[r], s->adm_use_off[r], s->adm_use_off[r + 1],
                                   [&](int e) { return s->adm_use_fr[e]; }, [&](int e) { return s->adm_use_qty[e]; });
-      // more flavor-resources than the two records hold: the scan-formulated search is off for the tree; more than the first holds:
-      // the fair-sharing formulation (its position records carry CS_RFR entries) is
-      if (nf < 0) { p.cs_ok[p.tree_of[c]] = 0; p.rec_ok[p.tree_of[c]] = 0; }
-      if (nf < 0 || nf > CS_RFR) p.fs_ok[p.tree_of[c]] = 0;
+      // more flavor-resources than the two records hold: the scan-formulated searches (classical and fair) are off for the tree
+      if (nf < 0) { p.cs_ok[p.tree_of[c]] = 0; p.rec_ok[p.tree_of[c]] = 0; p.fs_ok[p.tree_of[c]] = 0; }
     }
     // ---- kq_fs.hpp: candidates in position order, children lists in tree-node order ----
     for (int c = 0; c < nq; c++) if (p.depth[c] + 1 > FS_LV) p.fs_ok[p.tree_of[c]] = 0;
@@ -461,9 +462,11 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
           FsApply& ap = p.fs_apply[(size_t)r0 + pos];
           sc.prio = a.prio; sc.qts = a.qts; sc.row = r; sc.cql = (int16_t)i;
           sc.cbytes = (uint16_t)(32 + 12 * (s->adm_use_off[r + 1] - s->adm_use_off[r]));
+          ap.cbytes = sc.cbytes; ap.wide = (a.flags & 2u) ? 1 : 0;
+          if (ap.wide) sc.cbytes |= FS_SCAN_WIDE;
           for (int e = 0; e < CS_RFR; e++) { sc.fr[e] = ap.fr[e] = (int16_t)a.fr[e]; ap.qty[e] = a.qty[e]; ap.res[e] = (uint8_t)(a.fr[e] >= 0 ? a.fr[e] % p.nR : 255); }
           for (int l = 0; l < FS_LV; l++) ap.lp[l] = l < p.plen[c] ? (int16_t)p.node_local[p.path[(size_t)c * KQ_MAXD + l]] : (int16_t)-1;
-          ap.hkey = hkey(r); ap.row = r; ap.cbytes = sc.cbytes; ap.plen = (uint8_t)std::min(p.plen[c], 255);
+          ap.hkey = hkey(r); ap.row = r; ap.plen = (uint8_t)std::min(p.plen[c], 255);
           pos++;
         }
       }

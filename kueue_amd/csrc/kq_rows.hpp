@@ -99,8 +99,7 @@ KQ_DEV void ro_row_init(const DRows& R, int r) {
   int distinct = 0;
   for (int e = k0; e < k1; e++) if (ro_first_use(R, r, e)) distinct++;
   const int nf = adm_rec_fold(a, x, k0, k1, [&](int e) { return R.adm_use_fr[e]; }, [&](int e) { return R.adm_use_qty[e]; });
-  if (nf < 0) { R.cs_ok[t] = 0; R.rec_ok[t] = 0; }
-  if (nf < 0 || nf > CS_RFR) R.fs_ok[t] = 0;
+  if (nf < 0) { R.cs_ok[t] = 0; R.rec_ok[t] = 0; R.fs_ok[t] = 0; }
   R.adm_rec[r] = a; R.adm_recx[r] = x;
   R.ent_cnt[r] = distinct;
   R.val[r] = r;
@@ -206,9 +205,11 @@ KQ_DEV void ro_fs_fill(const DRows& R, int q) {   // q = global position = tree_
   FsScan sc{}; FsApply ap{};
   sc.prio = a.prio; sc.qts = a.qts; sc.row = r; sc.cql = (int16_t)R.cq_local[c];
   sc.cbytes = (uint16_t)(32 + 12 * (R.adm_use_off[r + 1] - R.adm_use_off[r]));
+  ap.cbytes = sc.cbytes; ap.wide = (a.flags & 2u) ? 1 : 0;
+  if (ap.wide) sc.cbytes |= FS_SCAN_WIDE;
   for (int e = 0; e < CS_RFR; e++) { sc.fr[e] = ap.fr[e] = (int16_t)a.fr[e]; ap.qty[e] = a.qty[e]; ap.res[e] = (uint8_t)(a.fr[e] >= 0 ? a.fr[e] % R.nR : 255); }
   for (int l = 0; l < FS_LV; l++) ap.lp[l] = l < R.plen[c] ? (int16_t)R.node_local[R.path[(size_t)c * KQ_MAXD + l]] : (int16_t)-1;
-  ap.hkey = ro_hkey(R, r); ap.row = r; ap.cbytes = sc.cbytes; ap.plen = (uint8_t)(R.plen[c] < 255 ? R.plen[c] : 255);
+  ap.hkey = ro_hkey(R, r); ap.row = r; ap.plen = (uint8_t)(R.plen[c] < 255 ? R.plen[c] : 255);
   R.fs_scan[q] = sc; R.fs_apply[q] = ap;
 }
 

@@ -9,7 +9,7 @@ POL_WCQ = ["Never", "LowerPriority", "LowerOrNewerEqualPriority"]
 POL_RWC = ["Never", "LowerPriority", "LowerOrNewerEqualPriority", "Any"]
 
 
-def random_case(seed, fair=False, preemption=True, max_cq=6, partial=False, fair_dups=False, tight=False, slices=False):
+def random_case(seed, fair=False, preemption=True, max_cq=6, partial=False, fair_dups=False, tight=False, slices=False, wide_rows=False):
     global _TIGHT
     _TIGHT = tight
     rnd = random.Random(seed)
@@ -71,9 +71,20 @@ def random_case(seed, fair=False, preemption=True, max_cq=6, partial=False, fair
             for r in fl.resources:
                 ps.requests[r] = (rnd.randint(0, 3) * 1000 if r == "cpu" else rnd.randint(0, 3))
                 ps.flavors[r] = fl.name
+            adm_pods = [ps]
+            if wide_rows and rnd.random() < 0.6:
+                # a second podset on another flavor (of any resource group): the row holds up to 8 distinct flavor-resources, the records
+                # of the scan-formulated searches hold 4 (AdmRecX, kq_prep.hpp)
+                ps2 = PodSet("second", count=rnd.randint(1, 3))
+                rg2 = rnd.choice(cq.resource_groups)
+                fl2 = rnd.choice(rg2.flavors)
+                for r in fl2.resources:
+                    ps2.requests[r] = (rnd.randint(0, 3) * 1000 if r == "cpu" else rnd.randint(0, 3))
+                    ps2.flavors[r] = fl2.name
+                adm_pods.append(ps2)
             t += 1
             admitted.append(Workload(f"{cq.name}-adm{j}", cq.name, priority=rnd.randint(-1, 3), creation_ts=rnd.randint(0, 50),
-                                     pod_sets=[ps], reserve_ts=rnd.choice([None, rnd.randint(0, 100)]), evicted=rnd.random() < 0.1,
+                                     pod_sets=adm_pods, reserve_ts=rnd.choice([None, rnd.randint(0, 100)]), evicted=rnd.random() < 0.1,
                                      uid=f"uid-{rnd.randint(0, 10**6)}-{t}"))
     # pending heads: one per CQ (most), in CQ-name order
     pending = []
