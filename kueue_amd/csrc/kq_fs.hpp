@@ -1293,65 +1293,46 @@ KQ_NOINLINE bool fair_search_lds(Search& s) {
   }
   wsync();
   {
+    // Round 6: the candidates come from the (tree, flavor-resource) buckets of the flavor-resources that need preemption (Prep::frb /
+    // frec: every row using that flavor-resource, the policy operands beside it) instead of a scan over every row of the tree — a
+    // candidate uses one of them by definition (:606, :618). At BASELINE configs[3] a bucket holds 1/16 of the 40 k rows; the scan was a
+    // third of a search (profiles/r06i_*). The candidate records the reference reads are those of every workload of a contributing
+    // ClusterQueue, whatever it uses: charged per ClusterQueue (cq_row_bytes minus the rows preempted so far), as the classical search does.
     int64_t cbytes = 0;
+    for (int i = lane; i < f.nqs; i += WAVE)
+      if (f.nflag[i] & 4) { const int c = S.tree_cqs[f.q0 + i]; cbytes += S.cq_row_bytes[c] - (f.removed ? k.cq_rm_bytes[c] : 0); }
     const int policy_same = KQ_POL_WITHIN_CQ(w.pol), policy_other = KQ_POL_RECLAIM(w.pol);
-    // a record's verdict once it is known whether its row still exists (findCandidatesForPolicy :599-627)
-    auto cand_bit = [&](const FsScan& sc, bool live) -> bool {
-      if (!live) return false;
-      cbytes += sc.cbytes & ~FS_SCAN_WIDE;
-      const int policy = sc.cql == f.wli ? policy_same : policy_other;
-      const bool lower = w.prio > sc.prio;
+    // a record's verdict (findCandidatesForPolicy :599-627)
+    auto cand_ok = [&](const CsRec& rc) -> bool {
+      if (!(f.nflag[rc.cql] & 4)) return false;
+      if (f.removed && f.removed[rc.row]) return false;
+      const int policy = rc.cql == f.wli ? policy_same : policy_other;
+      const bool lower = w.prio > rc.prio;
       bool ok = policy == KQ_POLICY_ANY;
       if (policy == KQ_POLICY_LOWER_PRIORITY) ok = lower;
-      if (policy == KQ_POLICY_LOWER_OR_NEWER_EQUAL) ok = lower || (w.prio == sc.prio && w.ts < sc.qts);
-      bool uses = false;
-      #pragma unroll
-      for (int e = 0; e < CS_RFR; e++)
-        for (int u = 0; u < w.ns; u++) if (sc.fr[e] >= 0 && w.s_need[u] && w.s_fr[u] == sc.fr[e]) uses = true;
-      if (ok && !uses && (sc.cbytes & FS_SCAN_WIDE)) {   // a wide row: its other entries
-        const AdmRecX x = S.adm_recx[sc.row];
-        #pragma unroll
-        for (int e = 0; e < CS_RFX; e++)
-          for (int u = 0; u < w.ns; u++) if (x.fr[e] >= 0 && w.s_need[u] && w.s_fr[u] == x.fr[e]) uses = true;
-      }
-      return ok && uses;
+      if (policy == KQ_POLICY_LOWER_OR_NEWER_EQUAL) ok = lower || (w.prio == rc.prio && w.ts < rc.qts);
+      return ok;
     };
-    if constexpr (WAVE == 64) {
-      // four words per step: the four records of a lane are in flight together, then the four `removed` bytes that depend on them —
-      // two round trips per 256 positions instead of two per 64 (the scan was 5 % of a search, one dependent load after the other)
+    for (int u = 0; u < w.ns; u++) {
+      if (!w.s_need[u]) continue;
+      bool dup = false;
+      for (int v = 0; v < u; v++) if (w.s_need[v] && w.s_fr[v] == w.s_fr[u]) dup = true;
+      if (dup) continue;
+      const size_t b = (size_t)f.tree * S.nfr + w.s_fr[u];
+      const int j0 = S.frb_off[b], j1 = S.frb_off[b + 1];
+      // four records of a lane in flight together, then the bytes / positions that depend on them
       constexpr int UN = 4;
-      for (int base = 0; base < f.nrows; base += 64 * UN) {
-        FsScan sc[UN]; bool in[UN], live[UN];
+      for (int base = j0; base < j1; base += WAVE * UN) {
+        CsRec rc[UN]; bool in[UN], ok[UN];
         #pragma unroll
-        for (int q = 0; q < UN; q++) {
-          const int p = base + q * 64 + lane;
-          in[q] = p < f.nrows;
-          sc[q] = fs_scan_load(S.fs_scan + (size_t)f.row0 + (in[q] ? p : f.nrows - 1));
-        }
+        for (int q = 0; q < UN; q++) { const int j = base + q * WAVE + lane; in[q] = j < j1; rc[q] = S.frec[in[q] ? j : j1 - 1]; }
         #pragma unroll
-        for (int q = 0; q < UN; q++) {
-          live[q] = in[q] && (f.nflag[sc[q].cql] & 4);
-          if (live[q] && f.removed && f.removed[sc[q].row]) live[q] = false;
-        }
+        for (int q = 0; q < UN; q++) ok[q] = in[q] && cand_ok(rc[q]);
+        int pos[UN];
         #pragma unroll
-        for (int q = 0; q < UN; q++) {
-          const uint64_t word = wballot(cand_bit(sc[q], live[q]));
-          if (lane == 0 && base + q * 64 < f.nrows) f.m1[(base >> 6) + q] = word;
-        }
-      }
-    } else {
-      for (int base = 0; base < f.nrows; base += 64) {
-        uint64_t word = 0;
-        for (int sub = 0; sub < 64; sub += WAVE) {  // one ballot per 64 positions (the emulation has one lane)
-          const int p = base + sub + lane;
-          bool bit = false;
-          if (p < f.nrows) {
-            const FsScan sc = fs_scan_load(S.fs_scan + (size_t)f.row0 + p);
-            bit = cand_bit(sc, (f.nflag[sc.cql] & 4) && !(f.removed && f.removed[sc.row]));
-          }
-          word |= wballot(bit) << sub;
-        }
-        if (lane == 0) f.m1[base >> 6] = word;
+        for (int q = 0; q < UN; q++) pos[q] = ok[q] ? S.adm_rec[rc[q].row].fs_pos : 0;
+        #pragma unroll
+        for (int q = 0; q < UN; q++) if (ok[q]) atomic_or_u64(&f.m1[pos[q] >> 6], 1ull << (pos[q] & 63));
       }
     }
     const int64_t tot = wsum_i64(cbytes);

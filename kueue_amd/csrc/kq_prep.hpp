@@ -40,7 +40,7 @@ struct alignas(16) AdmRec {
   int32_t cq;
   int32_t rowbytes;            // 16 * (depth + 1) * usage entries of the row (what the oracle charges per Remove/AddWorkload)
   uint32_t flags;              // bit0 evicted, bit1 wide: the row's flavor-resources 5 .. 8 stand in AdmRecX[row]
-  int32_t pad;
+  int32_t fs_pos;              // the row's position in its tree's fair-sharing position order (FsScan / FsApply below); 0 without fair sharing
 };
 struct alignas(16) AdmRecX { int64_t qty[CS_RFX]; int32_t fr[CS_RFX]; };   // read only for wide rows
 // One entry of a (tree, flavor-resource) bucket in "level order" d (d = 1 .. CS_LEVELS, the depth below the root): grouped by the
@@ -467,6 +467,7 @@ inline int build_prep(const kq_snapshot* s, Prep& p) {
           for (int e = 0; e < CS_RFR; e++) { sc.fr[e] = ap.fr[e] = (int16_t)a.fr[e]; ap.qty[e] = a.qty[e]; ap.res[e] = (uint8_t)(a.fr[e] >= 0 ? a.fr[e] % p.nR : 255); }
           for (int l = 0; l < FS_LV; l++) ap.lp[l] = l < p.plen[c] ? (int16_t)p.node_local[p.path[(size_t)c * KQ_MAXD + l]] : (int16_t)-1;
           ap.hkey = hkey(r); ap.row = r; ap.plen = (uint8_t)std::min(p.plen[c], 255);
+          p.adm_rec[r].fs_pos = pos;
           pos++;
         }
       }

@@ -95,7 +95,7 @@ KQ_DEV void ro_row_init(const DRows& R, int r) {
   atomic_add_i32(&R.cq_row_bytes[c], 32 + 12 * (k1 - k0));
   AdmRec a; AdmRecX x;
   a.prio = R.adm_prio[r]; a.qts = R.adm_qts[r]; a.cq = c; a.flags = (R.adm_flags[r] & KQ_ADM_EVICTED) ? 1u : 0u;
-  a.rowbytes = 16 * (R.depth[c] + 1) * (k1 - k0); a.pad = 0;
+  a.rowbytes = 16 * (R.depth[c] + 1) * (k1 - k0); a.fs_pos = 0;
   int distinct = 0;
   for (int e = k0; e < k1; e++) if (ro_first_use(R, r, e)) distinct++;
   const int nf = adm_rec_fold(a, x, k0, k1, [&](int e) { return R.adm_use_fr[e]; }, [&](int e) { return R.adm_use_qty[e]; });
@@ -211,6 +211,7 @@ KQ_DEV void ro_fs_fill(const DRows& R, int q) {   // q = global position = tree_
   for (int l = 0; l < FS_LV; l++) ap.lp[l] = l < R.plen[c] ? (int16_t)R.node_local[R.path[(size_t)c * KQ_MAXD + l]] : (int16_t)-1;
   ap.hkey = ro_hkey(R, r); ap.row = r; ap.plen = (uint8_t)(R.plen[c] < 255 ? R.plen[c] : 255);
   R.fs_scan[q] = sc; R.fs_apply[q] = ap;
+  R.adm_rec[r].fs_pos = q - R.tree_row_off[R.tree_of[c]];
 }
 
 // ---- kq_snapshot_patch_rows: kept rows move to their new index, added rows land behind the kept rows of their ClusterQueue ----------------

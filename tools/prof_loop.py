@@ -20,7 +20,10 @@ names = {14: "leader: whole tree", 11: "chunk serial core (incl. generic path)",
          33: "generic: tail (has_any, insert targets, add usage)", 0: "generic: load_head", 1: "generic: use list", 4: "generic: has_any .. before recompute", 2: "fast entry",
          35: "scan search: private usage + tables", 36: "scan search: classification + time order", 37: "scan search: alive + level passes (prefix)", 38: "scan search: first fit",
          39: "scan search: finalise + targets", 63: "scan search: fill-back", 40: "search(fair): private plane copy", 41: "search(fair): sums + clears", 42: "search(fair): findCandidates",
-         43: "search(fair): first strategy", 21: "nominate heads Fit (sum cycles)", 22: "nominate heads Preempt (sum cycles)", 24: "n Fit", 25: "n Preempt", 30: "slowest head"}
+         43: "search(fair): first strategy", 44: "search(fair): second strategy", 45: "search(fair): restore (no fit)", 46: "search(fair): fillBack",
+         47: "  lds search: ordering.next", 48: "  lds search: pop / batch", 49: "  lds search: row load + context", 50: "  lds search: share after removal (virtual)",
+         51: "  lds search: RemoveWorkload commit", 53: "  lds search: fits", 54: "  lds search: LCAs + shares of both sides", 5: "recompute: row flush", 7: "recompute: row reload",
+         16: "fair: computeDRS (leader wave)", 17: "fair: barrier wait", 18: "fair: tournament", 19: "fair: pop bookkeeping", 20: "fair: processEntry", 21: "nominate heads Fit (sum cycles)", 22: "nominate heads Preempt (sum cycles)", 24: "n Fit", 25: "n Preempt", 30: "slowest head"}
 rows = []
 prof = np.zeros(64, np.int64)
 lib.kq_debug_prof(eng._h, F.ptr(prof), 1)

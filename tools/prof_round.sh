@@ -17,7 +17,7 @@ if [[ $WHAT == *benches* ]]; then
   run cfg3b --workload cfg3-batch --steps 20 --warmup 2
   run cfg3split --workload cfg3-split --steps 50
   run cfg4csplit --workload cfg4c-split --steps 3 --warmup 1
-  run cfg4c --workload cfg4c --steps 3 --warmup 1 --cpu-seconds 5
+  run cfg4c_open --workload cfg4c --open-loop --steps 3 --warmup 1 --cpu-seconds 5
   run cfg5 --workload cfg5 --steps 5 --warmup 1
   run cfg5split --workload cfg5-split --steps 5 --warmup 1
   run cfg5cycle --workload cfg5-cycle --steps 20 --warmup 4
@@ -27,7 +27,12 @@ if [[ $WHAT == *benches* ]]; then
   run cfg4cgroup --workload cfg4c-group --steps 5 --warmup 1
   run cfg4fgroup --workload cfg4f-group --steps 10 --warmup 2
   run default_driver --steps 20 --warmup 5
-  TMO=900 run cfg4f --workload cfg4f --steps 2 --warmup 1 --cpu-seconds 5 --no-host-leg
+  TMO=900 run cfg4f_open --workload cfg4f --open-loop --steps 2 --warmup 1 --cpu-seconds 5 --no-host-leg
+  # BASELINE configs[3] as the closed loop (round 6): both start states, classical and fair
+  TMO=1500 run cfg4c_feasible --workload cfg4c --start feasible --steps 60 --series-cycles 20 --cpu-seconds 10
+  TMO=1500 run cfg4c --workload cfg4c --steps 40 --series-cycles 6 --cpu-seconds 10
+  TMO=1500 run cfg4f_feasible --workload cfg4f --start feasible --steps 40 --series-cycles 14 --cpu-seconds 10
+  TMO=1500 run cfg4f --workload cfg4f --steps 16 --series-cycles 6 --cpu-seconds 10
 fi
 if [[ $WHAT == *profiles* ]]; then
   cd /tmp && export TMPDIR=/tmp
@@ -35,8 +40,9 @@ if [[ $WHAT == *profiles* ]]; then
   declare -A CMD
   CMD[cfg3]="python $R/bench.py $Q"
   CMD[cfg3f]="python $R/bench.py --workload cfg3f --steps 20 $Q"
-  CMD[cfg4c]="python $R/bench.py --workload cfg4c --steps 2 --warmup 1 $Q"
-  CMD[cfg4f]="python $R/bench.py --workload cfg4f --steps 1 --warmup 0 $Q"
+  CMD[cfg4c]="python $R/bench.py --workload cfg4c --start feasible --steps 24 --warmup 4 --series-cycles 0 --no-cpu-baseline --no-parity-gate"
+  CMD[cfg4f]="python $R/bench.py --workload cfg4f --start feasible --steps 12 --warmup 4 --series-cycles 0 --no-cpu-baseline --no-parity-gate"
+  CMD[cfg2]="python $R/bench.py --workload cfg2 $Q"
   CMD[cfg5]="python $R/bench.py --workload cfg5 --steps 5 --warmup 1 --no-cpu-baseline"
   CMD[cfg5-cycle]="python $R/bench.py --workload cfg5-cycle --steps 5 --warmup 1 --no-cpu-baseline --no-parity-gate"
   for W in ${PROF_WORKLOADS:-cfg3 cfg3f cfg4c cfg5 cfg4f}; do
