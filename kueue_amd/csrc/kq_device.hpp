@@ -370,6 +370,8 @@ struct DScratch {
 // leader of a tree posts them as a batch; idle workgroups (and the leader itself) take them one by one.
 struct HelpTask { int32_t fr, base_borrow; int64_t val; };
 struct SimTask { int32_t head, fr, base_borrow, pad; int64_t val; };
+constexpr int SIM_KS = 4;       // scans of one head whose simulations can be listed ahead (K::sim_*); further ones are searched in place
+constexpr int SIM_ROUNDS = 2;   // k_nominate_emit rounds behind the lean pass: scans 2 .. SIM_ROUNDS + 1 of a head
 struct HelpRes { int32_t pm, borrow; int64_t bytes; };
 struct HelpBox {
   uint64_t hdr;      // batch sequence << 32 | tasks (0 tasks = closed)
@@ -443,16 +445,18 @@ struct K {  // everything a kernel needs
   long long* root_margin;    // [n_tree * nfr], start = CERT_INF
   int32_t* cert_flags;       // [n_tree]
   const struct TCyc* tc;     // Topology-Aware Scheduling inside the cycle (kq_tas_cycle.hpp; kq_cycle_run_tas), null in the ordinary cycle
-  // Simulations ahead of the full nominate pass (round 6, sim_emit / sim_worker below): the SimulatePreemption calls a deferred head's
-  // first flavor scan will make are independent given the cycle-start snapshot (preemption_oracle.go:43: a pure function of the
-  // snapshot, the head and the cell). The lean pass lists them, k_nominate_sim runs one per wave, the full pass reads the results where
-  // it would have searched. A cycle in which a handful of heads need victims no longer lasts as long as one head's ~50 searches in a row.
+  // Simulations ahead of the full nominate pass (round 6, sim_emit / sim_worker below): the SimulatePreemption calls of one flavor scan
+  // of a deferred head are independent given the cycle-start snapshot (preemption_oracle.go:43: a pure function of the snapshot, the
+  // head and the cell). The lean pass lists those of the head's first scan, k_nominate_sim runs one per wave; k_nominate_emit then walks
+  // the deferred heads again with those results in hand and lists the NEXT scan (a later podset, resource group or chunk of flavors:
+  // its cells depend on what the scans before it assigned), and so on for SIM_ROUNDS rounds; the full pass reads the results where it
+  // would have searched. A cycle in which a handful of heads need victims no longer lasts as long as one head's ~100 searches in a row.
   struct SimTask* sim_task;  // [sim_cap]
   HelpRes* sim_res;          // [sim_cap]
-  int32_t* sim_ctl;          // [2] tasks listed, next task to hand out (zeroed per cycle, with defer_count)
-  int32_t* sim_first;        // [H] first task of the head, -1 = none listed (filled per cycle); null: the mechanism is off
-  int32_t* sim_scan;         // [H] the resource whose scan listed them (findFlavorForPodSets' resName)
-  int32_t* sim_cell;         // [H * CELLS] task of cell c of that scan's first pass, -1 = none (valid where sim_first[h] >= 0)
+  int32_t* sim_ctl;          // [2 + SIM_ROUNDS] tasks listed, next task to hand out, next deferred head of emit round r (zeroed per cycle, with defer_count)
+  int32_t* sim_nscan;        // [H] scans listed for the head (zeroed per cycle); null: the mechanism is off
+  int32_t* sim_key;          // [H * SIM_KS] which scan: podset | resName << 8 | first flavor index of the chunk << 16
+  int32_t* sim_cell;         // [H * SIM_KS * CELLS] task of cell c of that scan, -1 = none
   int32_t sim_cap;
   HelpBox* help;             // [n_tree] or null: no helper workgroups in this launch
   uint32_t* help_quit;       // [1] trees whose leader has finished
@@ -2167,13 +2171,21 @@ KQ_NOINLINE int group_finish(const K& k, Wave& w, int pi, int gn, const int* cou
 }
 
 // ---- simulations ahead (K::sim_*) ---------------------------------------------------------------------------------------------------
-// Lean pass, a head about to be deferred because cell (jj, kk) of the pass needs a real SimulatePreemption: list every cell of the pass
-// the scan will simulate — per flavor the cells in front of the first one that is NoFit before any simulation (behind it the closure
-// returns early, :1161); flavors skipped by eligibility or the nomination pin have none. Under WhenCanPreempt = TryNextFlavor the scan
-// visits all of them (no flavor of this pass is Fit, or the pass would have no live cell); under MayStopSearch it may stop earlier and
-// some results go unused. Only the head's FIRST scan (podset 0, nothing assumed yet, the pass that starts at the bookmark) is listed.
-KQ_NOINLINE void sim_emit(const K& k, Wave& w, int res_name, int f0, int cs, int nfl, int nf) {
-  if (lane_id() == 0 && k.sim_first[w.h] < 0) {
+// Lean / emit pass, a head about to be deferred because cell (jj, kk) of the pass needs a real SimulatePreemption: list every cell of
+// the pass the scan will simulate — per flavor the cells in front of the first one that is NoFit before any simulation (behind it the
+// closure returns early, :1161); flavors skipped by eligibility or the nomination pin have none. Under WhenCanPreempt = TryNextFlavor
+// the scan visits all of them (no flavor of this pass is Fit, or the pass would have no live cell); under MayStopSearch it may stop
+// earlier and some results go unused. `key` names the scan (sim_find): the passes that follow reach it in the same state.
+KQ_DEV int sim_find(const K& k, int h, int key) {
+  int n = k.sim_nscan[h];
+  if (n > SIM_KS) n = SIM_KS;
+  for (int q = 0; q < n; q++) if (k.sim_key[(size_t)h * SIM_KS + q] == key) return q;
+  return -1;
+}
+KQ_NOINLINE void sim_emit(const K& k, Wave& w, int key, int f0, int cs, int nfl, int nf) {
+  if (lane_id() == 0 && k.sim_nscan[w.h] < SIM_KS) {
+    const int q = k.sim_nscan[w.h];
+    int32_t* cell = k.sim_cell + ((size_t)w.h * SIM_KS + q) * CELLS;
     int n = 0;
     for (int pass = 0; pass < 2; pass++) {   // count, then write
       int base = 0;
@@ -2190,7 +2202,7 @@ KQ_NOINLINE void sim_emit(const K& k, Wave& w, int res_name, int f0, int cs, int
           const uint8_t full = w.cell_pm[c];
           const bool task = live && !(full & 0x40) && (full & 0x3f) == PM_NEEDS;
           if (pass == 1) {
-            k.sim_cell[(size_t)w.h * CELLS + c] = task ? base + t : -1;
+            cell[c] = task ? base + t : -1;
             if (task) k.sim_task[base + t] = SimTask{w.h, k.S.rg_flavor[f0 + cs + jj] * k.S.nR + w.f_res[kk], w.cell_borrow[c], 0, w.cell_val[c]};
           }
           if (task) t++;
@@ -2198,7 +2210,7 @@ KQ_NOINLINE void sim_emit(const K& k, Wave& w, int res_name, int f0, int cs, int
         }
       }
       n = t;
-      if (pass == 1) { k.sim_scan[w.h] = res_name; k.sim_first[w.h] = base; }
+      if (pass == 1) { k.sim_key[(size_t)w.h * SIM_KS + q] = key; k.sim_nscan[w.h] = q + 1; if (q > 0) CSTAT(8, 1); }
     }
   }
   wsync();
@@ -2421,10 +2433,12 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
             dead_all = all_fit;
           }
         }
-        // the simulations of this pass were listed by the lean pass and run by k_nominate_sim (sim_emit): the head's first scan only
-        bool sim_ahead = false;
-        if constexpr (!LEAN) sim_ahead = k.sim_first != nullptr && pi == 0 && !counts && !nominate_map && cs == idx0 && w.slice_row < 0 && gn == 1 &&
-                                         k.sim_first[w.h] >= 0 && k.sim_scan[w.h] == res_name;
+        // the simulations of this pass may have been listed by an earlier pass over the head and run by k_nominate_sim (sim_emit)
+        const bool sim_elig = k.sim_nscan != nullptr && !counts && !nominate_map && w.slice_row < 0 && gn == 1 && pi < 256 && res_name < 256 && cs < 32768;
+        const int sim_key = pi | (res_name << 8) | (cs << 16);
+        const int32_t* sim_cells = nullptr;
+        int sim_q = -1;
+        if (sim_elig) { sim_q = sim_find(k, w.h, sim_key); if (sim_q >= 0) sim_cells = k.sim_cell + ((size_t)w.h * SIM_KS + sim_q) * CELLS; }
         // ---- recomputation inside k_process_fair: every cell of the pass that needs a SimulatePreemption is posted as one batch ----
         bool batched = false;
         HelpBox* hbox = nullptr;
@@ -2489,19 +2503,25 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
               else if constexpr (LEAN) {
                 const bool can_search = KQ_POL_WITHIN_CQ(w.pol) != KQ_POLICY_NEVER || (w.plen > 1 && KQ_POL_RECLAIM(w.pol) != KQ_POLICY_NEVER);
                 if (can_search) {
-                  if (k.sim_first && pi == 0 && !counts && !nominate_map && cs == idx0 && w.slice_row < 0 && gn == 1) sim_emit(k, w, res_name, f0, cs, nfl, nf);
-                  if (lane == 0) w.defer_head = 1;
-                  wsync();
-                  return;
-                }
-                opm = PM_NOCAND; ob = borrow;  // simulate_preemption with an empty target set
+                  if (sim_cells && sim_cells[c] >= 0) {   // listed by an earlier pass, run by k_nominate_sim: go on to the scans behind this one
+                    const HelpRes hr = k.sim_res[sim_cells[c]];
+                    opm = hr.pm; ob = hr.borrow;
+                    if (lane == 0) w.bytes += hr.bytes;
+                  } else {
+                    if (sim_elig && !sim_cells) sim_emit(k, w, sim_key, f0, cs, nfl, nf);
+                    if (lane == 0) w.defer_head = 1;
+                    wsync();
+                    return;
+                  }
+                } else { opm = PM_NOCAND; ob = borrow; }  // simulate_preemption with an empty target set
               } else {
                 if (batched && w.cell_task[c] != 0xff) {  // the batch evaluated it; only a consumed result is charged
                   const HelpRes hr = hbox->res[w.cell_task[c]];
                   opm = hr.pm; ob = hr.borrow;
                   if (lane == 0) w.bytes += hr.bytes;
-                } else if (sim_ahead && k.sim_cell[(size_t)w.h * CELLS + c] >= 0) {   // k_nominate_sim ran it (K::sim_*); charged when consumed
-                  const HelpRes hr = k.sim_res[k.sim_cell[(size_t)w.h * CELLS + c]];
+                } else if (sim_cells && sim_cells[c] >= 0) {   // k_nominate_sim ran it (K::sim_*); charged when consumed
+                  if (sim_q > 0) CSTAT(19, 1);
+                  const HelpRes hr = k.sim_res[sim_cells[c]];
                   opm = hr.pm; ob = hr.borrow;
                   if (lane == 0) w.bytes += hr.bytes;
                 } else {
@@ -2896,17 +2916,22 @@ KQ_DEV void nominate_head(const K& k, Wave& w, int h, int slot) {
   wsync();
 }
 
-// k_nominate_sim: one wave, tasks pulled by ticket (two searches differ by 10 x); the result of a task is a pure function of the
-// cycle-start snapshot, the head and the cell, so any wave may run it and any number of them at once. `first`: the first ticket is taken
-// by the caller (the emulation deals tasks to its serial "waves").
-KQ_DEV void sim_worker(const K& k, Wave& w, int slot) {
+// k_nominate_sim, round r (behind the lean pass: r = 0; behind emit round q: r = q + 1): one wave, the tasks listed since the previous
+// round pulled by ticket (two searches differ by 10 x); the result of a task is a pure function of the cycle-start snapshot, the head
+// and the cell, so any wave may run it and any number of them at once. sim_ctl: [0] tasks listed, [SIMC_TICKET + r] tickets of round
+// r, [SIMC_START + r] first task of round r (written by the round before it: nothing is listed while a sim round runs).
+constexpr int SIMC_TICKET = 1, SIMC_EMIT = SIMC_TICKET + SIM_ROUNDS + 1, SIMC_START = SIMC_EMIT + SIM_ROUNDS, SIMC_WORDS = SIMC_START + SIM_ROUNDS + 2;
+KQ_DEV void sim_worker(const K& k, Wave& w, int slot, int round) {
   const int lane = lane_id();
   int cur = -1;
   int nt = k.sim_ctl[0];
   if (nt > k.sim_cap) nt = k.sim_cap;
+  const int start = round == 0 ? 0 : k.sim_ctl[SIMC_START + round];
+  wsync();
+  if (lane == 0) k.sim_ctl[SIMC_START + round + 1] = nt;   // (every wave of the round writes the same value)
   for (;;) {
     int t = 0;
-    if (lane == 0) t = atomic_add_i32(&k.sim_ctl[1], 1);
+    if (lane == 0) t = start + atomic_add_i32(&k.sim_ctl[SIMC_TICKET + round], 1);
     t = wuniform_i32(t);
     if (t >= nt) break;
     const SimTask task = k.sim_task[t];
@@ -2920,6 +2945,18 @@ KQ_DEV void sim_worker(const K& k, Wave& w, int slot) {
     if (lane == 0) { k.sim_res[t].pm = pm; k.sim_res[t].borrow = borrow; k.sim_res[t].bytes = w.bytes; }
     wsync();
   }
+}
+// k_nominate_emit: a deferred head walked again by the lean code with the results of the scans listed so far in hand — it gets as far as
+// the next scan that needs simulations and lists them (assign_flavors<true> -> sim_emit). Its outputs are dropped: the full pass
+// recomputes the head, reading every listed result where it would have searched.
+KQ_DEV void nominate_head_emit(const K& k, Wave& w, int h) {
+  const int ns = k.sim_nscan[h];
+  if (ns == 0 || ns >= SIM_KS) return;   // nothing was listed for it (deferred for another reason, not eligible, no room), or its table is full
+  load_head(k, w, h);
+  if (lane_id() == 0) { if (w.has_last && last_assignment_outdated(k, h, w.cq)) w.has_last = 0; w.defer_head = 0; }
+  wsync();
+  assign_flavors<true>(k, w, 0, k.usage, nullptr, nullptr, false);
+  wsync();
 }
 
 // ------------------------------------------------------------------------------------------------

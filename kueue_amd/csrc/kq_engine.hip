@@ -59,14 +59,29 @@ __global__ __launch_bounds__(64) void k_nominate(const K* __restrict__ kp, int s
   }
 }
 
-// Between the two passes: the SimulatePreemption calls the deferred heads' first scans will make, one per wave (kq_device.hpp sim_worker).
-__global__ __launch_bounds__(64) void k_nominate_sim(const K* __restrict__ kp, unsigned lds_bytes) {
+// Between the two passes: the SimulatePreemption calls the deferred heads' flavor scans will make, one per wave (kq_device.hpp sim_worker),
+// scan by scan: k_nominate_emit walks the deferred heads again with the results so far and lists each head's next scan.
+__global__ __launch_bounds__(64) void k_nominate_emit(const K* __restrict__ kp, int round) {
+  const K& k = *kp;
+  __shared__ Wave w;
+  __shared__ int next;
+  const int nd = *k.defer_count;
+  for (;;) {
+    if (threadIdx.x == 0) next = atomicAdd(&k.sim_ctl[SIMC_EMIT + round], 1);
+    __syncthreads();
+    const int i = next;
+    __syncthreads();
+    if (i >= nd) break;
+    nominate_head_emit(k, w, k.defer_list[i]);
+  }
+}
+__global__ __launch_bounds__(64) void k_nominate_sim(const K* __restrict__ kp, unsigned lds_bytes, int round) {
   const K& k = *kp;
   __shared__ Wave w;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
   if (threadIdx.x == 0) { w.cs_lds = lds_bytes ? dyn_lds : nullptr; w.cs_lds_bytes = (int)lds_bytes; w.help_on = 0; }
   __syncthreads();
-  sim_worker(k, w, blockIdx.x);
+  sim_worker(k, w, blockIdx.x, round);
 }
 
 // Entry order (scheduler.go:1110-1163): rank(i) = number of entries that precede i. 2-D grid: block (bi, bj)
@@ -809,12 +824,16 @@ struct HipBackend {
     if (prof_skip_nom && kk.prof) kk.prof += 64;
     const K* d = put_k(kk, 0);
     hipLaunchKernelGGL(k_nominate_lean, dim3(slots), dim3(64), 0, stream, d, slots);
-    if (full_pass && k.sim_first) {
+    if (full_pass && k.sim_nscan) {
       if (lds > 48 * 1024 && lds != lds_attr_sim) {
         chk(hipFuncSetAttribute((const void*)k_nominate_sim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
         lds_attr_sim = lds;
       }
-      hipLaunchKernelGGL(k_nominate_sim, dim3(slots), dim3(64), lds, stream, d, (unsigned)lds);
+      hipLaunchKernelGGL(k_nominate_sim, dim3(slots), dim3(64), lds, stream, d, (unsigned)lds, 0);
+      for (int r = 0; r < SIM_ROUNDS; r++) {
+        hipLaunchKernelGGL(k_nominate_emit, dim3(slots), dim3(64), 0, stream, d, r);
+        hipLaunchKernelGGL(k_nominate_sim, dim3(slots), dim3(64), lds, stream, d, (unsigned)lds, r + 1);
+      }
     }
     if (full_pass) hipLaunchKernelGGL(k_nominate, dim3(slots), dim3(64), lds, stream, d, slots, (unsigned)lds);
     chk(hipGetLastError(), "k_nominate");

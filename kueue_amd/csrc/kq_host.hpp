@@ -1546,7 +1546,7 @@ template <class B> struct EngineT {
     k.prof = (long long*)grow<int64_t>(b_prof, 128);   // [64] segment counters + [64] a sink (KQ_PROF_SKIP_NOMINATE: the nominate kernels count there)
     k.grec = grow<PRec>(b_grec, n);
     k.cq_dirty = grow<uint8_t>(b_cqd, std::max(prep.nq, 1));  // cleared per head by k_records
-    k.defer_list = grow<int32_t>(b_defer, (size_t)n + 4); k.defer_count = k.defer_list + n; k.nom_ticket = k.defer_list + n + 1;
+    k.defer_list = grow<int32_t>(b_defer, (size_t)n + 2 + SIMC_WORDS); k.defer_count = k.defer_list + n; k.nom_ticket = k.defer_list + n + 1;
     k.sim_ctl = k.defer_list + n + 2;   // (zeroed with defer_count)
     k.cq_heads = grow<int32_t>(b_cqh, (size_t)std::max(prep.nq, 1) + std::max(prep.n_tree, 1) + 8);
     k.spec_resume = k.cq_heads + std::max(prep.nq, 1); k.spec_stats = spec_stats_on ? k.spec_resume + std::max(prep.n_tree, 1) : nullptr;
@@ -1563,17 +1563,17 @@ template <class B> struct EngineT {
       k.spec_hdr = grow<SpecHdr>(b_sphdr, (size_t)n);
       k.spec_K = a; k.spec_T = a + cells; k.spec_push = a + 2 * cells; k.spec_nv = a + 2 * cells + slots_; k.spec_o = (int32_t*)(a + 2 * cells + 2 * slots_);
     }
-    prep_fill(k.defer_count, 4, 0);
+    prep_fill(k.defer_count, 2 + SIMC_WORDS, 0);
     // simulations ahead of the full nominate pass (K::sim_*): only where a victim search can happen at all, not in a TAS cycle (every head
     // goes through the full code there) and not for the sharded nominate's masked batches (the lean pass still lists per head: fine)
-    k.sim_first = nullptr; k.sim_task = nullptr; k.sim_res = nullptr; k.sim_scan = nullptr; k.sim_cell = nullptr; k.sim_cap = 0;
+    k.sim_nscan = nullptr; k.sim_task = nullptr; k.sim_res = nullptr; k.sim_key = nullptr; k.sim_cell = nullptr; k.sim_cap = 0;
     if (prep.any_preemption && !d_tc && sim_ahead_on && n > 0) {
-      k.sim_cap = n * CELLS;
-      k.sim_first = grow<int32_t>(b_sim[0], (size_t)n * 2); k.sim_scan = k.sim_first + n;
-      k.sim_cell = grow<int32_t>(b_sim[1], (size_t)n * CELLS);
+      k.sim_cap = n * CELLS * 2;   // (two full scans per head; a scan that finds no room is searched in place by the full pass)
+      k.sim_nscan = grow<int32_t>(b_sim[0], (size_t)n * (1 + SIM_KS)); k.sim_key = k.sim_nscan + n;
+      k.sim_cell = grow<int32_t>(b_sim[1], (size_t)n * SIM_KS * CELLS);
       k.sim_task = grow<SimTask>(b_sim[2], (size_t)k.sim_cap);
       k.sim_res = grow<HelpRes>(b_sim[3], (size_t)k.sim_cap);
-      if (pp.n < 15) prep_fill(k.sim_first, (size_t)n, 0xffffffffu); else be.memset(k.sim_first, 0xff, (size_t)n * 4);
+      if (pp.n < 15) prep_fill(k.sim_nscan, (size_t)n, 0); else be.memset(k.sim_nscan, 0, (size_t)n * 4);
     }
     k.help = nullptr; k.help_quit = nullptr; k.help_trees = 0;
     k.tc = d_tc;

@@ -138,18 +138,21 @@ struct EmuBackend {
     const bool lean = !full_pass || (nom_rot++ & 1) == 0;
     if (lean) { for (int slot = 0; slot < slots; slot++) { Wave w{}; for (int h = slot; h < hn(k.H); h += slots) nominate_head_lean(k, w, h); } }
     else { for (int h = 0; h < hn(k.H); h++) k.defer_list[h] = h; *k.defer_count = hn(k.H); }
-    // the simulations the lean pass listed (K::sim_*), dealt to serial "waves" with both placements of the search arrays
-    if (full_pass && k.sim_first && lean)
-      for (int wave = 0; wave < 3; wave++) {
-        const int slot = wave % std::max(slots, 1);
-        Wave w{};
-        if (lds && ((wave + rot) & 1)) { w.cs_lds = (unsigned char*)region.data(); w.cs_lds_bytes = (int)lds; }
-        if (wave == 2 || k.sim_ctl[0] < 4) sim_worker(k, w, slot);                       // the last "wave" drains the list
-        else {   // a third each (a wave's last, failing pull takes a ticket: handed back here — on the device the list is empty by then)
-          const int keep = k.sim_ctl[0];
-          k.sim_ctl[0] = std::min(keep, k.sim_ctl[1] + 1 + keep / 3);
-          sim_worker(k, w, slot);
-          k.sim_ctl[1] = k.sim_ctl[0]; k.sim_ctl[0] = keep;
+    // the simulations the lean pass / the emit rounds listed (K::sim_*), dealt to two serial "waves" with both placements of the search arrays
+    if (full_pass && k.sim_nscan)
+      for (int round = 0; round <= SIM_ROUNDS; round++) {
+        if (round > 0) { Wave w{}; for (int i = 0; i < *k.defer_count; i++) nominate_head_emit(k, w, k.defer_list[i]); }
+        const int keep = k.sim_ctl[0];
+        const int start = round == 0 ? 0 : k.sim_ctl[SIMC_START + round];
+        for (int wave = 0; wave < 2; wave++) {
+          const int slot = wave % std::max(slots, 1);
+          Wave w{};
+          if (lds && ((wave + rot) & 1)) { w.cs_lds = (unsigned char*)region.data(); w.cs_lds_bytes = (int)lds; }
+          if (wave == 0 && keep - start >= 2) {   // the first half (a wave's last, failing pull takes a ticket: handed back here — on the device the list is empty by then)
+            k.sim_ctl[0] = start + (keep - start) / 2;
+            sim_worker(k, w, slot, round);
+            k.sim_ctl[SIMC_TICKET + round] -= 1; k.sim_ctl[0] = keep;
+          } else sim_worker(k, w, slot, round);   // the last "wave" drains the list (and leaves the next round's start behind)
         }
       }
     const int nd = *k.defer_count;

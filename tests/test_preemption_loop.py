@@ -166,3 +166,17 @@ def test_assignment_rows_vectorised_equals_the_loop(oracle):
             assert np.array_equal(x[k], y[k]), (seed, k, x[k], y[k])
         n += len(sel)
     assert n > 100
+
+
+def test_simulations_of_later_scans_are_listed_ahead(oracle):
+    """k_nominate_emit (kq_device.hpp sim_emit / nominate_head_emit): the SimulatePreemption calls of a head's SECOND flavor scan (its second
+    podset: the cells depend on what the first scan assigned) are listed by a walk over the deferred heads with the first scan's results in
+    hand, run by the task pool, and read by the full pass — the loop stays equal to the oracle's (run_loop) and the mechanism did run."""
+    import ctypes as C
+    from tests.emu import kqe
+    out = (C.c_longlong * 32)()
+    kqe.lib().kqe_cstat(out)
+    tot, stats = run_loop(oracle, _emu, "cfg4c-100cq-feasible", cycles=16, hold=1 << 40)
+    kqe.lib().kqe_cstat(out)
+    assert tot["targets"] > 0
+    assert out[8] > 0 and out[19] > 0, (out[8], out[19])

@@ -47,8 +47,9 @@ def main(tag, workload, kernels):
     cmd = {"cfg3": "python bench.py --no-cpu-baseline --no-parity-gate --full-run 0 --no-host-leg   (the default bench: workload cfg3, pending loop, 100 steps + 5 warm-up, 1 x MI355X)",
            "cfg3-batch": "python bench.py --workload cfg3-batch --steps 10 --warmup 1 --no-cpu-baseline   (nominate-all-pending, 100 000 heads per launch, 1 x MI355X)",
            "cfg3f": "python bench.py --workload cfg3f --steps 20 --no-cpu-baseline --no-parity-gate --full-run 0 --no-host-leg   (fair sharing, pending loop, 1 x MI355X)",
-           "cfg4c": "python bench.py --workload cfg4c --steps 2 --warmup 1 --no-cpu-baseline --no-parity-gate --full-run 0 --no-host-leg   (classical preemption, 1000 heads per cycle, 1 x MI355X)",
-           "cfg4f": "python bench.py --workload cfg4f --steps 1 --warmup 0 --no-cpu-baseline --no-parity-gate --full-run 0 --no-host-leg   (fair sharing + preemption, 1000 heads per cycle, 1 x MI355X)",
+           "cfg4c": "python bench.py --workload cfg4c --start feasible --steps 24 --warmup 4 --series-cycles 0 --no-cpu-baseline --no-parity-gate   (classical preemption as the CLOSED loop, feasible start, 1000 heads per cycle, 28 cycles, 1 x MI355X; round 6 - until round 5: one open-loop cycle)",
+           "cfg4f": "python bench.py --workload cfg4f --start feasible --steps 12 --warmup 4 --series-cycles 0 --no-cpu-baseline --no-parity-gate   (fair sharing + fair preemption as the CLOSED loop, feasible start, 1000 heads per cycle, 16 cycles, 1 x MI355X; round 6 - until round 5: one open-loop cycle)",
+           "cfg2": "python bench.py --workload cfg2 --no-cpu-baseline --no-parity-gate --full-run 0 --no-host-leg   (128 ClusterQueues, 110 heads per cycle, pending loop, 1 x MI355X)",
            "cfg5": "python bench.py --workload cfg5 --steps 5 --warmup 1 --no-cpu-baseline   (1 x MI355X)",
            "cfg5-cycle": "python bench.py --workload cfg5-cycle --steps 5 --warmup 1 --no-cpu-baseline --no-parity-gate   (TAS inside the cycle, 1000 heads per cycle, 1 x MI355X)"}.get(workload, workload)
     lines = [f"# rocprofv3 --kernel-trace --stats --output-format csv -- {cmd}"]
