@@ -2236,6 +2236,12 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
     const int psg = w.ps_base + pi;
     any_ps = true;
     gn = group_len(k, w, pi);   // the podsets [pi, pi + gn) share one flavor scan (PodSetGroupName); 1 = a podset on its own
+    if constexpr (LEAN) {
+      // a head with a multi-podset group goes to the full pass: the lean kernel keeps no function call (group_requests / group_finish are
+      // not inlined; with them the kernel carried a call frame — 52 B of scratch, 52 more SGPR spills — and every head paid for it:
+      // k_nominate_lean 110 -> 123 us at cfg 3, profiles/r06p_cfg3_timeline.txt). The host launches the full pass for batches with groups.
+      if (gn > 1) { if (lane == 0) w.defer_head = 1; wsync(); return; }
+    }
     // ---- effective requests -------------------------------------------------------------
     int count = H.ps_count[psg];
     int new_count = counts ? counts[pi] : count;
@@ -2246,8 +2252,9 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
     const int ne = ne_raw < KQ_MAXREQ ? ne_raw : KQ_MAXREQ;
     if (ne_raw > KQ_MAXREQ && lane == 0) *O.error = KQ_EUNSUPPORTED;
     bool is_pods = false;
-    if (gn > 1) group_requests(k, w, pi, gn, counts, pods_cov);   // the sum of the members' requests (requests.Add :789)
-    else {
+    bool grouped = false;
+    if constexpr (!LEAN) { if (gn > 1) { group_requests(k, w, pi, gn, counts, pods_cov); grouped = true; } }   // the sum of the members' requests (requests.Add :789)
+    if (!grouped) {
     for (int a = lane; a < ne; a += WAVE) {
       int64_t q = H.req_qty[e0 + a];
       if (scale) q = sat_mul(q / (int64_t)count, (int64_t)new_count);
@@ -2581,13 +2588,15 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
       if (!status_nil) ps_reasons += reasons;
     }
     // PodSetAssignment.RepresentativeMode :386-404 ; Assignment.append :1017-1041
-    int pmode;
+    int pmode = M_FIT;
     // atLeastOnePodsAssignmentFailed :842-845: a podset that requests something and ends without any flavor — also when every request of
     // it was skipped (:809-817) and no scan ran at all
     ps_nflavors = 0;   // the flavors the podset (group) ends with: seeds of the second pass, the scans' (a later scan may have overwritten an earlier one's)
     for (int a = 0; a < w.nreq; a++) if (w.req_done[a]) { ps_nflavors++; if (w.req_mode[a] < ps_mode) ps_mode = w.req_mode[a]; }
     bool failed = w.nreq > 0 && (group_failed || ps_nflavors == 0);
-    if (gn > 1) pmode = group_finish(k, w, pi, gn, counts, pods_cov, group_failed, ps_reasons, &failed);
+    bool finished = false;
+    if constexpr (!LEAN) { if (gn > 1) { pmode = group_finish(k, w, pi, gn, counts, pods_cov, group_failed, ps_reasons, &failed); finished = true; } }
+    if (finished) {}
     else if (group_failed) {
       // groupFlavors = nil: the podset keeps no flavor and contributes no usage
       pmode = ps_reasons == 0 ? M_FIT : M_NOFIT;

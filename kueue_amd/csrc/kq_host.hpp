@@ -1629,7 +1629,7 @@ template <class B> struct EngineT {
     else {
       // the full pass (victim searches, partial admission, replaced slices) only gets heads the lean pass defers; when nothing of the
       // kind exists in the snapshot and the batch, its launch is skipped
-      const bool full_pass = prep.any_preemption || hbch.partial || hbch.H.slice_row != nullptr || !lean_only_ok;
+      const bool full_pass = prep.any_preemption || hbch.partial || hbch.H.slice_row != nullptr || hbch.H.ps_group != nullptr || !lean_only_ok;   // (a head with a multi-podset group is deferred by the lean pass)
       if (d_tc) be.launch_nominate_tas(k, slots_nom);   // every head through the full nominate code with the TAS hooks (kq_tas_cycle.hpp)
       else be.launch_nominate(k, slots_nom, nom_lds, full_pass);
     }
