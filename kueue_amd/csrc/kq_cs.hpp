@@ -34,7 +34,8 @@ struct CsCtx {
   int64_t* dB[CS_NS];    // [Mp] per slot: what the candidate's removal takes out of the node one level up (level by level, in place)
   int64_t *sqT, *lqT;    // [ns][nn]  SubtreeQuota / localQuota of every node of the tree for the slots; null: read the planes
   uint16_t *tord, *tinv, *rb;  // [Mp] candidate at time t / time of candidate j (0xffff = never) / AdmRec::rowbytes
-  uint16_t* lst;               // [Mp] the level-order positions of the candidates inside a time prefix (cs_level_pass)
+  uint16_t* lstL[CS_LEVELS];   // [Mp] per level: the level-order positions of the candidates inside a time prefix (cs_gather)
+  int nL[CS_LEVELS]; int lst_T; // their lengths; the prefix they were gathered for (-1: none)
   uint8_t *alive, *cls, *att;  // [Mp] still removable / class byte (classical_search) / path level the candidate's branch hangs off
   uint8_t* cqi;          // [tree ClusterQueues] Search::cqinfo
   uint32_t needm, inum;
@@ -47,7 +48,7 @@ __host__ __device__ inline
 #endif
 size_t cs_bytes(int ns, int M, int nn, int nqs, bool tables) {  // everything a search with ns slots allocates
   const size_t Mp = ((size_t)M + 63) & ~(size_t)63;
-  return (size_t)ns * nn * 8 * (tables ? 3 : 1) + (size_t)ns * Mp * 8 + Mp * 2 * 4 + Mp * 3 + (((size_t)nqs + 15) & ~(size_t)15) + 512;
+  return (size_t)ns * nn * 8 * (tables ? 3 : 1) + (size_t)ns * Mp * 8 + Mp * 2 * (3 + CS_LEVELS) + Mp * 3 + (((size_t)nqs + 15) & ~(size_t)15) + 512;
 }
 // Arrays are placed in the workgroup's LDS region in order of heat while they fit, the rest in the wave slot's HBM spill space:
 // the byte arrays and the private usage first, then the quota tables, then the per-slot quantity arrays.
@@ -96,6 +97,40 @@ KQ_DEV int cs_path_level(const Wave& w, int plen, int node_local) {
   return r;
 }
 
+// A time prefix (limit_t in front of the last candidate: the lazy first rounds of cs_run, the finalising passes) only involves the
+// candidates removed at or before limit_t: their level-order positions, for every level at once — one light pass over the bucket (8 bytes
+// per entry and level, the levels' loads in flight together) instead of one per level and pass: the gathers were most of a
+// recomputation's level passes (profiles/r06l_prof_loop_cfg4c_feasible_process_only.txt). The lists serve every pass up to limit_t: the
+// finalising passes (limit = the stopping time) reuse the prefix round's. Segments (same node) stay contiguous and time-ordered.
+KQ_DEV void cs_gather(CsCtx& c, int limit_t) {
+  const DSnap& S = c.k->S;
+  const int lane = lane_id(), M = c.M;
+  int n[CS_LEVELS];
+  #pragma unroll
+  for (int l = 0; l < CS_LEVELS; l++) n[l] = 0;
+  for (int base = 0; base < M; base += WAVE) {
+    const int q = base + lane;
+    int jd[CS_LEVELS], nd[CS_LEVELS];
+    #pragma unroll
+    for (int l = 0; l < CS_LEVELS; l++) {
+      jd[l] = 0; nd[l] = -1;
+      if (l < c.levels && q < M) { const CsEnt* e = S.frl[l] + c.boff + q; jd[l] = e->jd; nd[l] = e->node; }
+    }
+    #pragma unroll
+    for (int l = 0; l < CS_LEVELS; l++) {
+      if (l >= c.levels) continue;
+      const bool act = nd[l] >= 0 && (int)c.tinv[jd[l] & 0xffffff] <= limit_t;
+      const uint64_t m = wballot(act);
+      if (act) c.lstL[l][n[l] + popc64(m & ((1ull << lane) - 1))] = (uint16_t)q;
+      n[l] += popc64(m);
+    }
+  }
+  #pragma unroll
+  for (int l = 0; l < CS_LEVELS; l++) c.nL[l] = n[l];
+  c.lst_T = limit_t;
+  wsync();
+}
+
 // One bottom-up level: the nodes at depth dd below the root (passes run from the deepest level up to 1; the root is on every
 // preemptor's path). limit_t: only candidates removed at or before that time count. finalize: leave every node's usage after
 // its last counted removal in W (second run, after the stopping time is known); otherwise mark the candidates that meet a dead
@@ -109,25 +144,17 @@ KQ_DEV void cs_level_pass(CsCtx& c, int dd, int limit_t, bool finalize) {
   int64_t carry[CS_NS];
   #pragma unroll
   for (int u = 0; u < CS_NS; u++) carry[u] = 0;
-  // A time prefix (limit_t in front of the last candidate: the lazy first rounds of cs_run, the finalising passes) only involves the
-  // candidates removed at or before limit_t: their level-order positions are gathered first — a light pass over the bucket (8 bytes per
-  // entry) — and the scan below runs over those alone. Segments (same node) stay contiguous and time-ordered in the gathered list.
+  // a time prefix runs over the gathered candidates alone (cs_gather); a list gathered for a longer prefix serves too: the entries
+  // behind limit_t take part with zero quantities (`al` below) and change nothing
   const bool packed = limit_t + 1 < c.Mt;
   int n = M;
+  const uint16_t* lst = nullptr;
   if (packed) {
-    n = 0;
-    for (int base = 0; base < M; base += WAVE) {
-      const int q = base + lane;
-      bool act = false;
-      if (q < M) { const int jd = ents[q].jd, nd = ents[q].node; act = nd >= 0 && (int)c.tinv[jd & 0xffffff] <= limit_t; }
-      const uint64_t m = wballot(act);
-      if (act) c.lst[n + popc64(m & ((1ull << lane) - 1))] = (uint16_t)q;
-      n += popc64(m);
-    }
-    wsync();
+    if (c.lst_T < limit_t) cs_gather(c, limit_t);
+    n = c.nL[dd - 1]; lst = c.lstL[dd - 1];
     if (n == 0) return;
   }
-  auto pos_of = [&](int i) -> int { const int ii = i < n ? i : n - 1; return packed ? (int)c.lst[ii] : ii; };
+  auto pos_of = [&](int i) -> int { const int ii = i < n ? i : n - 1; return packed ? (int)lst[ii] : ii; };
   // the entries are static and read front to back: the next chunk's load is in flight while this one is processed
   CsEnt e_next = ents[pos_of(lane)];
   for (int base = 0; base < n; base += WAVE) {
@@ -187,7 +214,7 @@ KQ_DEV void cs_level_pass(CsCtx& c, int dd, int limit_t, bool finalize) {
     for (int u = 0; u < CS_NS; u++) {
       if (u >= ns || !in) continue;
       if (part) { if (al && !dead) c.dB[u][j] = outv[u]; }
-      else if (enters) c.dB[u][j] = d[u];  // the preemptor's own ClusterQueue: straight onto the path
+      else if (enters && (!finalize || (int)c.tinv[j] <= limit_t)) c.dB[u][j] = d[u];  // the preemptor's own ClusterQueue: straight onto the path
     }
     if (finalize) {
       // the node's usage after its last counted removal: written by the last entry of the segment
@@ -234,7 +261,8 @@ KQ_DEV bool cs_run(Search& s, bool same_on, bool other_on) {
     CsCarve cv{w.cs_lds, w.cs_lds ? w.cs_lds + w.cs_lds_bytes : nullptr, k.X.cs + (size_t)s.slot * k.X.cs_bytes};
     c.alive = (uint8_t*)cv.take(c.Mp); c.cls = (uint8_t*)cv.take(c.Mp); c.att = (uint8_t*)cv.take(c.Mp);
     c.tord = (uint16_t*)cv.take((size_t)c.Mp * 2); c.tinv = (uint16_t*)cv.take((size_t)c.Mp * 2); c.rb = (uint16_t*)cv.take((size_t)c.Mp * 2);
-    c.lst = (uint16_t*)cv.take((size_t)c.Mp * 2);
+    for (int l = 0; l < CS_LEVELS; l++) c.lstL[l] = (uint16_t*)cv.take((size_t)c.Mp * 2);
+    c.lst_T = -1;
     c.cqi = (uint8_t*)cv.take(nqs);
     c.W = (int64_t*)cv.take((size_t)ns * nn * 8);
     // the quota tables only pay off next to the arithmetic: in LDS or not at all (the planes are L2-resident anyway)
