@@ -2227,7 +2227,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
   if (k.tc) tc_reset(w);
 #endif
   if (lane == 0) { w.nuse = 0; w.borrowing = 0; w.rep_mode = M_FIT; w.nrsn = 0; w.rsn_over = 0; }
-  wsync();
+  wsync_lds();
   int rep = M_FIT;
   bool any_ps = false;
   const bool pods_cov = S.pods_res >= 0 && rg_by_resource(S, w.cq, S.pods_res) >= 0;
@@ -2263,7 +2263,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
       w.req_res[a] = r; w.req_qty[a] = q; w.req_src[a] = (uint8_t)a;
     }
     const bool have_pods = wballot(is_pods) != 0;
-    wsync();
+    wsync_lds();
     if (lane == 0) {
       int n = ne;
       if (pods_cov && !have_pods) {
@@ -2272,7 +2272,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
       }
       w.nreq = n;
     }
-    wsync();
+    wsync_lds();
     }
     {  // Requests.Iter order (slice_requests.go:54-60)
       const int n = w.nreq;
@@ -2291,12 +2291,12 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
         const int ob = wshfl_i32(ord, b);
         if (lane < n && (ob < ord || (ob == ord && b < lane))) rank++;
       }
-      wsync();
+      wsync_lds();
       if (lane < n) { w.req_res[rank] = r; w.req_qty[rank] = q; w.req_src[rank] = (uint8_t)sr; w.req_done[rank] = 0; w.req_rg[rank] = S.cq_res_rg[(size_t)w.cq * nR + r]; }
 #endif
       if (lane == 0) w.bytes += (int64_t)n * (gn > 1 ? 8 : 16);  // requests in + requests echoed in the PodSetAssignment (a group: its members echo theirs, group_finish)
     }
-    wsync();
+    wsync_lds();
     // (the nomination mapping of a recomputation, X.nom, was taken before O.flavor is overwritten: process_entry)
     // clear the podset's output rows
     for (int r = lane; r < gn * nR; r += WAVE) { O.flavor[(size_t)psg * nR + r] = -1; O.res_mode[(size_t)psg * nR + r] = M_NOFIT; O.tried_idx[(size_t)psg * nR + r] = -1; }
@@ -2352,7 +2352,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
         w.nf = nf;
         w.rsn_g0 = w.nrsn;
       }
-      wsync();
+      wsync_lds();
       const int nf = w.nf;
       const int f0 = S.rg_flavor_off[g], nflv = S.rg_flavor_off[g + 1] - f0;
       const int fpp = CELLS / nf;  // flavors per pass (nf <= KQ_MAXREQ <= CELLS)
@@ -2415,7 +2415,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
           }
           w.cell_pm[c] = pm | (mismatch ? 0x40 : 0); w.cell_borrow[c] = borrow; w.cell_val[c] = val; w.cell_aux[c] = aux;
         }
-        wsync();
+        wsync_lds();
         if (LEAN || KQ_TAS_PROCESS(k, w)) KQ_TS(k, 58);  // lean: the (flavor, resource) cells of the pass (fitsResourceQuota)
         // ---- dead simulations -------------------------------------------------------------------------------------------------
         // A flavor whose cells are all Fit beats every flavor with a cell that needs SimulatePreemption (isPreferred compares the
@@ -2543,7 +2543,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
             if (rep_pm == PM_NOFIT) continue;
             if (lane == 0) { w.cur_mode[kk] = fa_mode(pm); w.cur_borrow[kk] = borrow; }
           }
-          wsync();
+          wsync_lds();
           bool take = false;
           if (gate(k, KQ_GATE_FLAVOR_FUNGIBILITY)) {
             if (!should_try_next(rep_pm, rep_borrow, w.pol)) { take = true; stop = true; }
@@ -2555,7 +2555,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
           if (take) {
             best = j; best_key = rep_key; best_pm = rep_pm;
             if (lane == 0) for (int kk = 0; kk < nf; kk++) { w.best_mode[kk] = w.cur_mode[kk]; w.best_borrow[kk] = w.cur_borrow[kk]; }
-            wsync();
+            wsync_lds();
           }
         }
       }
@@ -2584,7 +2584,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
           w.req_borrow[a2] = w.best_borrow[kk]; w.req_tried[a2] = tried;
         }
       }
-      wsync();
+      wsync_lds();
       if (!status_nil) ps_reasons += reasons;
     }
     // PodSetAssignment.RepresentativeMode :386-404 ; Assignment.append :1017-1041
@@ -2706,6 +2706,45 @@ KQ_DEV bool last_assignment_outdated(const K& k, int h, int cq) {
 
 KQ_DEV void load_head(const K& k, Wave& w, int h) {
   const DSnap& S = k.S; const DHeads& H = k.H;
+#if !defined(KQ_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
+  // Uniform code, every lane: the head's own chain (head -> ClusterQueue -> policy / path) and, riding with it, the request rows of EVERY
+  // podset of the head, touched once by the whole wave. A podset's turn in assign_flavors is a dependent chain of its own (count /
+  // request offsets -> requests -> resource order / resource group: ~4 round trips of a lone wave), and the chains of a head's podsets do
+  // not depend on each other: here they are one chain for all of them, in flight together with the head's, and the per-podset loads
+  // find their lines in the cache (tools/prof_lean.py: "requests in iterator order" was 23 % of k_nominate_lean). The touched values
+  // are dropped.
+  const int lane = lane_id();
+  const int cq = H.cq[h], pb = H.ps_off[h], pn = H.ps_off[h + 1] - pb;
+  const int64_t prio = H.priority[h], ts = H.queue_ts[h];
+  const uint32_t hfl = H.flags[h];
+  const int slice_row = (H.slice_row && gate(k, KQ_GATE_ELASTIC_JOBS)) ? H.slice_row[h] : -1;
+  // second round trip
+  const uint32_t pol = S.cq_policy[cq];
+  const int plen = S.plen[cq];
+  const int pth = lane < KQ_MAXD ? S.path[(size_t)cq * KQ_MAXD + lane] : 0;
+  const int pnc = pn < 0 ? 0 : (pn < KQ_MAXPS ? pn : KQ_MAXPS);
+  int o = 0, sink = 0;
+  if (lane <= pnc) { o = H.ps_req_off[pb + lane]; if (lane < pnc) { sink += H.ps_count[pb + lane]; if (H.ps_group) sink += H.ps_group[pb + lane]; } }
+  // third and fourth
+  const int e0 = __shfl(o, 0, 64), e1 = __shfl(o, pnc, 64);
+  if (e0 + lane < e1) {
+    const int r = H.req_res[e0 + lane];
+    sink += (int)H.req_qty[e0 + lane] + S.resource_order[r] + S.cq_res_rg[(size_t)cq * S.nR + r];
+  }
+  if (lane < KQ_MAXD) w.path[lane] = pth;
+  if (lane == 0) {
+    w.h = h; w.cq = cq; w.prio = prio; w.ts = ts; w.hflags = hfl;
+    w.pol = pol;
+    w.ps_base = pb; w.nps = pn;
+    w.plen = plen;
+    w.has_last = (hfl & KQ_HEAD_HAS_LAST_ASSIGNMENT) ? 1 : 0;
+    w.bytes = 0;
+    w.slice_row = slice_row;
+    if (pn > KQ_MAXPS) *k.O.error = KQ_EUNSUPPORTED;
+  }
+  asm volatile("" :: "v"(sink));
+  wsync();
+#else
   if (lane_id() == 0) {
     w.h = h; w.cq = H.cq[h]; w.prio = H.priority[h]; w.ts = H.queue_ts[h]; w.hflags = H.flags[h];
     w.pol = S.cq_policy[w.cq];
@@ -2718,6 +2757,7 @@ KQ_DEV void load_head(const K& k, Wave& w, int h) {
     if (w.nps > KQ_MAXPS) *k.O.error = KQ_EUNSUPPORTED;
   }
   wsync();
+#endif
 }
 
 // Scheduler.getAssignments + getInitialAssignments (scheduler.go:821-924). Leaves the chosen
@@ -4955,9 +4995,25 @@ KQ_DEV void derive_usage_cell(const DSnap& S, int64_t* usage, int cohort, int fr
   for (int pass = 0; pass < 2; pass++) {
     const int32_t* off = pass == 0 ? S.child_cohort_off : S.child_cq_off;
     const int32_t* lst = pass == 0 ? S.child_cohort : S.child_cq;
-    for (int i = off[kx]; i < off[kx + 1]; i++) {
-      const size_t co = ix(S, lst[i], fr);
-      u = a_add(u, i64max(0, a_sub(usage[co], local_quota(S, lst[i], fr))));
+    // children in chunks of 8: the ids first, then the three cells of every child — the loads of a chunk are in flight together (one child
+    // after the other was two dependent round trips per child: 10 children x 3 levels = most of k_usage_cols' 22 us at cfg 3); the sum
+    // keeps the children's order
+    constexpr int CH = 8;
+    for (int i0 = off[kx], i1 = off[kx + 1]; i0 < i1; i0 += CH) {
+      int ch[CH]; int64_t uv[CH], llv[CH], sqv[CH];
+      #pragma unroll
+      for (int q = 0; q < CH; q++) ch[q] = i0 + q < i1 ? lst[i0 + q] : -1;
+      #pragma unroll
+      for (int q = 0; q < CH; q++) {
+        uv[q] = 0; llv[q] = KQ_NIL_LIMIT; sqv[q] = 0;
+        if (ch[q] >= 0) { const size_t co = ix(S, ch[q], fr); uv[q] = usage[co]; llv[q] = S.ll[co]; sqv[q] = S.sq[co]; }
+      }
+      #pragma unroll
+      for (int q = 0; q < CH; q++) {
+        if (ch[q] < 0) continue;
+        const int64_t lq = llv[q] != KQ_NIL_LIMIT ? i64max(0, a_sub(sqv[q], llv[q])) : 0;   // local_quota
+        u = a_add(u, i64max(0, a_sub(uv[q], lq)));
+      }
     }
   }
   usage[ix(S, cohort, fr)] = u;

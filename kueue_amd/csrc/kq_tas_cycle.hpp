@@ -499,7 +499,7 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
     const int g = w.ps_base + w.ta.req_ps[0];
     const size_t nD = (size_t)c.ncls * tk.T.D;
     int32_t* tab = simulateEmpty ? c.cls_tab_e[t] : c.cls_tab[t];
-    tk.C.n = c.ncls; tk.C.wl_class = c.ps_class + g; tk.C.order = nullptr;
+    tk.C.n = c.ncls; tk.C.wl_class = c.ps_class + g; tk.C.order = nullptr; tk.C.leader = nullptr; tk.C.workers = nullptr;   // (leader == nullptr: t_workload keeps all five count arrays of a global-row state)
     tk.C.pc = tab; tk.C.sc = tab + nD; tk.C.pcwl = tab + 2 * nD; tk.C.scwl = tab + 3 * nD; tk.C.lc = tab + 4 * nD;
     tk.C.bytes = c.cls_bytes[t];
     xslot = c.slots + (simulateEmpty ? c.ncls : 0) + cls;

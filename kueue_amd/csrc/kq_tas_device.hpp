@@ -109,6 +109,7 @@ struct TState {  // per-slot pointers
   bool nolead;   // leaderCount is 0 everywhere and stays 0: no lc array
   TLeafJob* coop;   // the state is in LDS and the workgroup has helper waves: long slices are swept together (null: alone)
   int coop_min;
+  bool lazy_keys;   // the slot's rows are global memory: t_find_level writes a level's id list and sort keys only when something reads them
   int bal_slot;     // the slot's index (TScratch::bal)
 };
 // lane 0 records a domain whose state it is about to change
@@ -140,7 +141,7 @@ KQ_DEV TState tas_state(const TK& k, int slot) {
   s.k0 = k.X.k0 + slot * M; s.k1 = k.X.k1 + slot * M;
   s.assumed = k.X.assumed + (size_t)slot * k.T.n_leaves * k.T.R;
   s.log = k.X.log + slot * M; s.meta = k.X.meta + (size_t)slot * 4; s.logcap = (int)M;
-  s.nolead = false; s.coop = nullptr; s.coop_min = 0; s.bal_slot = slot;
+  s.nolead = false; s.coop = nullptr; s.coop_min = 0; s.bal_slot = slot; s.lazy_keys = k.lds == nullptr;
   if (k.lds) {
     const TLdsLay l = tas_lds_layout(k.T.D, (int)M);
     s.k0 = (uint64_t*)(k.lds + l.k0); s.k1 = (uint64_t*)(k.lds + l.k1);
@@ -224,7 +225,7 @@ struct TLeafArgs {
   int leafLo, leafHi;   // [leafLo, leafHi) of the leaves, leafHi <= 0 (what a shorter initializer list leaves) = every leaf
 };
 // one sweep over a slice of domains (t_view_first_fit): what it is after, and what a wave found in its share of the elements
-struct TSweepArgs { int n, order, id0; bool lfc, by_order; int32_t needed, leaderCount; int which; };
+struct TSweepArgs { int n, order, id0; bool lfc, by_order; int32_t needed, leaderCount; int which; bool store; };   // store: the keys of every element are written for the t_get calls that may follow
 struct TSweepRes { uint64_t m0, m1, g, g0, g1; };   // slice order minimum; (count, slice order) minimum over the holders (g = ~0: none)
 // k_process_tas, classical order: what the leader needs to start on the NEXT entry (its head, its nomination), fetched by helper wave 1
 // while the leader finishes the current one. None of it changes while the kernel runs: an entry's nomination outputs are only rewritten
@@ -507,6 +508,7 @@ struct TView {
   uint64_t c0, c1;       // key of the last element taken from the stream
   bool started;
   int skip;              // element moved to the front by prioritizeLeaderDomain (it sits in arr already), -1 none
+  bool virt;             // no stored keys: every look builds an element's key from the state (a slice nothing changes while it is walked)
 };
 KQ_DEV int t_dom(uint64_t k1) { return (int)(uint32_t)(k1 & 0xffffffffu); }
 KQ_DEV void t_key_of(const TState& s, int d, int pos, int order, bool lfc, uint64_t* k0, uint64_t* k1) {
@@ -527,7 +529,7 @@ KQ_DEV bool t_all_zero(const TState& s, int d) { return (s.pc[d] | s.sc[d] | s.p
 // drops podCount == 0), and they can never win a best-fit scan.
 KQ_DEV TView t_view(const TK& k, const TState& s, int n, int order, bool unconstrained) {
   TView v;
-  v.n = n; v.order = order; v.lfc = t_lfc(k, unconstrained); v.mat = 0; v.c0 = 0; v.c1 = 0; v.started = false; v.skip = -1;
+  v.n = n; v.order = order; v.lfc = t_lfc(k, unconstrained); v.mat = 0; v.c0 = 0; v.c1 = 0; v.started = false; v.skip = -1; v.virt = false;
   for (int i = lane_id(); i < n; i += WAVE) {
     const int d = s.set[i];
     uint64_t a, b;
@@ -540,17 +542,33 @@ KQ_DEV TView t_view(const TK& k, const TState& s, int n, int order, bool unconst
 }
 // wave arg-min over the elements accepted by `sel`, ranked by sel.rank (default: the slice order: the winner is
 // t_dom(*o1)); false if no element is accepted
-template <class SEL> KQ_DEV void t_argmin_part(const TState& s, int n, const SEL& sel, bool with_excluded, int tid, int nth, uint64_t* m0o, uint64_t* m1o) {
+template <class SEL> KQ_DEV void t_argmin_part(const TState& s, int n, const SEL& sel, bool with_excluded, int tid, int nth, uint64_t* m0o, uint64_t* m1o,
+                                               bool virt = false, int order = ORD_PLAIN, bool lfc = false) {
   uint64_t b0 = ~0ull, b1 = ~0ull;
   // a lone wave is latency-bound: fetch the keys of UNR strided elements before looking at any of them
   constexpr int UNR = 8;
   for (int base = tid; base < n; base += nth * UNR) {
     uint64_t k0v[UNR], k1v[UNR];
+    if (virt) {   // the keys t_view would have stored, from the (unchanged) state
+      int dv[UNR];
+      #pragma unroll
+      for (int q = 0; q < UNR; q++) { const int i = base + q * nth; dv[q] = i < n ? s.set[i] : -1; }
+      #pragma unroll
+      for (int q = 0; q < UNR; q++) {
+        k0v[q] = KQ_TAS_EXCLUDED; k1v[q] = 0;
+        if (dv[q] < 0) continue;
+        uint64_t a, b;
+        t_key_of(s, dv[q], base + q * nth, order, lfc, &a, &b);
+        if (order != ORD_LIST && t_all_zero(s, dv[q])) a |= KQ_TAS_EXCLUDED;
+        k0v[q] = a; k1v[q] = b;
+      }
+    } else {
     #pragma unroll
     for (int q = 0; q < UNR; q++) {
       const int i = base + q * nth;
       k0v[q] = i < n ? s.k0[i] : KQ_TAS_EXCLUDED;
       k1v[q] = i < n ? s.k1[i] : 0;
+    }
     }
     #pragma unroll
     for (int q = 0; q < UNR; q++) {
@@ -570,7 +588,7 @@ template <class SEL> KQ_DEV void t_argmin_part(const TState& s, int n, const SEL
 }
 template <class SEL> KQ_DEV bool t_argmin(const TState& s, const TView& v, const SEL& sel, uint64_t* o0, uint64_t* o1, bool with_excluded = false) {
   uint64_t m0, m1;
-  t_argmin_part(s, v.n, sel, with_excluded, lane_id(), WAVE, &m0, &m1);
+  t_argmin_part(s, v.n, sel, with_excluded, lane_id(), WAVE, &m0, &m1, v.virt, v.order, v.lfc);
   if (m0 == ~0ull && m1 == ~0ull) return false;
   *o0 = m0; *o1 = m1;
   return true;
@@ -693,7 +711,7 @@ KQ_DEV TSweepRes t_sweep_part(const TState& s, const TSweepArgs& a, int tid, int
         kb = ((uint64_t)pc2 << 32) | (uint32_t)d;
       }
       const bool zero = order != ORD_LIST && (pcv[q] | scv[q] | pwv[q] | swv[q] | lcv[q]) == 0;
-      s.k0[i] = zero ? (ka | KQ_TAS_EXCLUDED) : ka; s.k1[i] = kb;
+      if (a.store) { s.k0[i] = zero ? (ka | KQ_TAS_EXCLUDED) : ka; s.k1[i] = kb; }
       if (zero) continue;
       if (t_key_lt(ka, kb, b0, b1)) { b0 = ka; b1 = kb; }
       const int32_t c = which == 0 ? pcv[q] : which == 1 ? pwv[q] : which == 2 ? scv[q] : swv[q];
@@ -722,10 +740,10 @@ KQ_DEV TSweepRes t_sweep_coop(const TState& s, const TSweepArgs& a);
 // by_order: the holders are ranked by the slice order alone — LeastFreeCapacity's "first domain, ascending, that holds everything"
 // (:1364-1376) instead of BestFit's smallest count.
 KQ_DEV TView t_view_first_fit(const TK& k, const TState& s, int n, int order, bool unconstrained, int32_t needed, int which, int32_t leaderCount,
-                              int* first, int* fit, int id0 = -1, bool by_order = false) {
+                              int* first, int* fit, int id0 = -1, bool by_order = false, bool store = true) {
   TView v;
-  v.n = n; v.order = order; v.lfc = t_lfc(k, unconstrained); v.mat = 0; v.c0 = 0; v.c1 = 0; v.started = false; v.skip = -1;
-  const TSweepArgs a{n, order, id0, v.lfc, by_order, needed, leaderCount, which};
+  v.n = n; v.order = order; v.lfc = t_lfc(k, unconstrained); v.mat = 0; v.c0 = 0; v.c1 = 0; v.started = false; v.skip = -1; v.virt = false;
+  const TSweepArgs a{n, order, id0, v.lfc, by_order, needed, leaderCount, which, store};
   // a long slice of a state in LDS is shared with the workgroup's helper waves (k_process_tas): each wave a quarter of the elements
   const TSweepRes r = (s.coop && n >= s.coop_min && id0 >= 0) ? t_sweep_coop(s, a) : t_sweep_part(s, a, lane_id(), WAVE);
   *first = -1; *fit = -1;
@@ -955,14 +973,33 @@ KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* 
     *fitLevel = searchLevelIdx;  // also the level a KQ_TAS_NOT_FIT below refers to (notFitReason :1354)
     const int n = T.level_off[searchLevelIdx + 1] - T.level_off[searchLevelIdx];
     if (n == 0) return TFail{KQ_TAS_NO_LEVEL, 0, 0};
-    for (int i = lane_id(); i < n; i += WAVE) s.set[i] = T.level_off[searchLevelIdx] + i;
+    // A slot whose rows are global memory (k_tas_find) writes the level's id list and sort keys only when something is going to read them:
+    // a level search that ends with the sweep's own answer (one domain holds everything; nothing does and the level above is next) never
+    // does, and an unconstrained request sweeps every leaf — 20 B written per leaf and workload, 2.28 GB per 50 000-workload launch at
+    // 4096 leaves (profiles/r05w). Nothing changes the state between the sweep and need_keys(): the keys are the ones the sweep saw.
+    const bool lazy = s.lazy_keys;
+    const int lvl_id0 = T.level_off[searchLevelIdx];
+    if (!lazy) for (int i = lane_id(); i < n; i += WAVE) s.set[i] = lvl_id0 + i;
+    bool have_keys = !lazy;
+    auto need_keys = [&]() {
+      if (have_keys) return;
+      have_keys = true;
+      for (int i = lane_id(); i < n; i += WAVE) {
+        const int d = lvl_id0 + i;
+        uint64_t a, b;
+        t_key_of(s, d, i, ORD_LEADER, lfc, &a, &b);
+        if (t_all_zero(s, d)) a |= KQ_TAS_EXCLUDED;
+        s.set[i] = d; s.k0[i] = a; s.k1[i] = b;
+      }
+      wsync();
+    };
     int fitDomain = -1, topDomain = -1;
     TView v;
     TPROF0();
     // keys, sortedDomain[0] and the domain the level's search is after — BestFit: findBestFitDomainBy over the whole level;
     // LeastFreeCapacity: the first domain in ascending order that holds everything — in one sweep (its closing fence publishes s.set as well)
     v = t_view_first_fit(k, s, n, ORD_LEADER, st.unconstrained, sliceCount, st.leaderCount > 0 ? 3 : 2, st.leaderCount, &topDomain, &fitDomain,
-                         T.level_off[searchLevelIdx], lfc);
+                         lvl_id0, lfc, !lazy);
     TPROF(k, 3);   // (timing builds) the level's sweep
     if (topDomain < 0) {
       // every domain of the level has an all-zero state: whatever sortedDomain[0] is, it holds nothing
@@ -984,13 +1021,17 @@ KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* 
         return TFail{KQ_TAS_OK, 0, 0};
       }
       if (st.required) {
+        need_keys();
         const int last = t_true_last(s, v);
         return TFail{KQ_TAS_NOT_FIT, last >= 0 ? s.pc[last] : 0, sliceCount};
       }
     }
     if (s.scwl[topDomain] < sliceCount || t_lc(s, topDomain) < st.leaderCount) {
-      if (st.required) return TFail{KQ_TAS_NOT_FIT, s.sc[t_true_first(s, v)], sliceCount};
+      if (st.required) { need_keys(); return TFail{KQ_TAS_NOT_FIT, s.sc[t_true_first(s, v)], sliceCount}; }
       if (searchLevelIdx > 0 && !st.unconstrained) continue;
+      // the LeastFreeCapacity histogram below reads the counts alone and builds its own slice: no keys of the whole level either
+      const bool histo = lfc && st.leaderCount == 0 && n > 128 && k.X.max_set >= 128;
+      if (!histo) need_keys();
       int nres = 0;
       int32_t remainingSliceCount = sliceCount, remainingLeaderCount = st.leaderCount;
       t_prioritize_leader(k, s, v, st.count, st.leaderCount, st.sliceSize, true);
@@ -1071,7 +1112,11 @@ KQ_DEV TFail t_find_level(const TK& k, const TState& s, const TParams& st, int* 
           m = m2;
           TPROF(k, 7);   // LeastFreeCapacity: the histogram threshold (everything of the level between the sweep and here)
         }
-        TView r = t_view(k, s, m, ORD_PLAIN, st.unconstrained);
+        // (a global-row state, behind the histogram: the domains at the threshold value are often hundreds, a few of them are consumed, and
+        // nothing changes the state while they are walked — no keys are stored for them)
+        TView r;
+        if (lazy && histo) { r.n = m; r.order = ORD_PLAIN; r.lfc = lfc; r.mat = 0; r.c0 = 0; r.c1 = 0; r.started = false; r.skip = -1; r.virt = true; }
+        else r = t_view(k, s, m, ORD_PLAIN, st.unconstrained);
         for (int i = 0; remainingSliceCount > 0; i++) {
           int domain = t_get(s, r, i);
           if (domain < 0) break;
@@ -1585,7 +1630,7 @@ template <bool LDS> KQ_DEV void t_workload_t(const TK& k, int slot, int w) {
   TState s0 = tas_state(k, slot);
   if (LDS && k.mail) { s0.coop = k.mail; s0.coop_min = k.mail->coop_min; }
   if (LDS) t_assume_lds(s0);
-  const TState s = s0;
+  TState s = s0;   // (the global rows of k_tas_find: the ...WithLeader arrays alias the plain ones while a class without a leader is being placed, below)
   const int lane = lane_id();
   const int p0 = Q.wl_off[w], p1 = Q.wl_off[w + 1];
   // more than one group => later groups see the usage assumed for the earlier ones (:654-656)
@@ -1666,6 +1711,13 @@ template <bool LDS> KQ_DEV void t_workload_t(const TK& k, int slot, int w) {
     if (f.status == KQ_TAS_OK) {
       const int cls = (k.C.n > 0 && !seeded) ? k.C.wl_class[w] : -1;   // (a seeded workload's phase 1 sees its own assumed usage: no shared table)
       bool have = false;
+      if (!LDS) {
+        // a class without a leader: podCountWithLeader / sliceCountWithLeader hold the plain counts in its table, the placement never writes
+        // them apart and leaderCount is 0 everywhere — the slot keeps two arrays of the five (what the LDS state of k_process_tas does):
+        // 33 KB instead of 83 KB copied per class change at 4096 leaves, 8 B instead of 20 B read per domain and sweep
+        const bool nl = cls >= 0 && k.C.leader && k.C.leader[cls] < 0;   // (k_tas_find's classes; the cycle's per-class slots are patched in place by its class updates and keep every array)
+        s.nolead = nl; s.pcwl = nl ? s0.pc : s0.pcwl; s.scwl = nl ? s0.sc : s0.scwl; s.lc = nl ? nullptr : s0.lc;
+      }
       if (cls >= 0) {
         // start from the class's phase-1 table; the slot keeps it between workloads of the same class (the LDS copy is filled every
         // time: the table moves with every AddUsage, and the copy is one round trip of the whole workgroup)
@@ -1676,7 +1728,8 @@ template <bool LDS> KQ_DEV void t_workload_t(const TK& k, int slot, int w) {
           wsync();
           for (int d = lane; d < T.D; d += WAVE) {
             const size_t o = (size_t)cls * T.D + d;
-            s.pc[d] = k.C.pc[o]; s.sc[d] = k.C.sc[o]; s.pcwl[d] = k.C.pcwl[o]; s.scwl[d] = k.C.scwl[o]; t_set_lc(s, d, k.C.lc[o]);
+            s.pc[d] = k.C.pc[o]; s.sc[d] = k.C.sc[o];
+            if (!s.nolead) { s.pcwl[d] = k.C.pcwl[o]; s.scwl[d] = k.C.scwl[o]; s.lc[d] = k.C.lc[o]; }
           }
           if (lane == 0) { s.meta[1] = 0; s.meta[2] = cls; }
         }
@@ -1719,7 +1772,8 @@ template <bool LDS> KQ_DEV void t_workload_t(const TK& k, int slot, int w) {
     for (int i = lane; i < nlog; i += WAVE) {
       const int d = s.log[i];
       const size_t o = (size_t)cls * T.D + d;
-      s.pc[d] = k.C.pc[o]; s.sc[d] = k.C.sc[o]; s.pcwl[d] = k.C.pcwl[o]; s.scwl[d] = k.C.scwl[o]; t_set_lc(s, d, k.C.lc[o]);
+      s.pc[d] = k.C.pc[o]; s.sc[d] = k.C.sc[o];
+      if (!s.nolead) { s.pcwl[d] = k.C.pcwl[o]; s.scwl[d] = k.C.scwl[o]; s.lc[d] = k.C.lc[o]; }
     }
     wsync();
   }
