@@ -794,7 +794,9 @@ struct Wave {
   uint8_t win_off[256];           // ... and their positions in the order, relative to the window base
   int nwin2[2], chunk_done, chunk_stop;  // leader -> helper waves of the process workgroup
   // gathered cells of the entry under process: c = u * plen + i
-  int64_t g_uw[CELLS], g_un[CELLS];  // g_lq / g_sq / g_bl: see the unions above
+  // g_lq / g_sq / g_bl: see the unions above; flv_*: a pass of assign_flavors, per flavor of the pass (the same sharing rule)
+  union { int64_t g_uw[CELLS]; int64_t flv_key[CELLS]; };    // flv_key: pref_key of the flavor's representative mode
+  union { int64_t g_un[CELLS]; int64_t flv_pack[CELLS]; };   // flv_pack: representative mode | reasons of its cells << 8 | borrow level << 32
   union { uint8_t g_dirty[CELLS]; uint8_t cell_task[CELLS]; };  // cell_task (assign_flavors inside a recomputation): task index of a cell whose simulation was posted to K::help, 0xff = none
   int64_t bytes;                  // algorithmic bytes (lane 0 meaningful)
   int usage_dirty;                // set when processEntry added usage to the snapshot plane (fair-sharing DRS cache)
@@ -2470,8 +2472,72 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
             if (w.help_nt > 1) { CSTAT(25, 1); CSTAT(26, w.help_nt); help_exec(k, w, slot, hbox, w.help_nt); batched = true; }
           }
         }
+        // ---- the scan, flavor-parallel ----------------------------------------------------------------------------------------------
+        // When no reason records are kept, the head replaces no slice and no cell of the pass waits for a victim search (none needs one,
+        // or every simulation of the pass is dead, or the ClusterQueue cannot preempt at all), a flavor's representative mode is a function
+        // of its own cells: one lane per flavor folds them (the loop over kk below, cell by cell in order), and the ordered part of the
+        // scan — early exit, isPreferred against the best so far, the bookmark — walks one packed word per flavor instead of every cell.
+        // At cfg 3 a head that finds no room walks 16 flavors x 4 resources: 64 cells one after the other were 40 % of k_nominate_lean
+        // (tools/prof_lean.py). Written for any lane count: the 1-lane emulation runs the same code.
+        bool fast = false;
+        if (k.O.rsn_win <= 0 && w.slice_row < 0 && !batched) {
+          bool needs_ok = dead_all;
+          if constexpr (LEAN) needs_ok = needs_ok || !(KQ_POL_WITHIN_CQ(w.pol) != KQ_POLICY_NEVER || (w.plen > 1 && KQ_POL_RECLAIM(w.pol) != KQ_POLICY_NEVER));
+          bool mine = false;
+          if (!needs_ok) for (int c = lane; c < nfl * nf; c += WAVE) mine = mine || ((w.cell_pm[c] & 0x3f) == PM_NEEDS && w.cell_pm[(c / nf) * nf] != PM_SKIP);
+          fast = needs_ok || wballot(mine) == 0;
+        }
+        if (fast) {
+          for (int jj = lane; jj < nfl; jj += WAVE) {
+            int64_t pack = PM_SKIP, key = 0;
+            if (w.cell_pm[jj * nf] != PM_SKIP) {
+              int rep_pm = PM_FIT; int rep_borrow = 0, rs = 0; int64_t rep_key = pref_key(PM_FIT, 0, w.pol);
+              for (int kk = 0; kk < nf; kk++) {
+                const int c = jj * nf + kk;
+                int pm = w.cell_pm[c] & 0x3f; const int borrow = w.cell_borrow[c];
+                if ((w.cell_pm[c] & 0x80) || pm == PM_NOFIT || pm == PM_NEEDS) rs++;   // had_status: a reason either way
+                if (rep_pm == PM_NOFIT) continue;            // oracle result unused past a noFit (:1161)
+                if (pm == PM_NEEDS) pm = PM_NOCAND;          // a dead simulation / SimulatePreemption with an empty candidate set: borrow kept
+                const int64_t key2 = pref_key(pm, borrow, w.pol);
+                if (rep_key > key2) { rep_pm = pm; rep_borrow = borrow; rep_key = key2; }
+              }
+              pack = (int64_t)(((uint64_t)(uint32_t)rep_borrow << 32) | ((uint64_t)rs << 8) | (uint64_t)rep_pm); key = rep_key;
+            }
+            w.flv_key[jj] = key; w.flv_pack[jj] = pack;
+          }
+          wsync_lds();
+          int best_jj = -1, visited = 0;
+          for (int jj = 0; jj < nfl && !stop; jj++) {
+            const int j = cs + jj;
+            attempted = j;
+            const int64_t pack = w.flv_pack[jj];
+            const int rep_pm = (int)(pack & 0xff);
+            if (rep_pm == PM_SKIP) { reasons++; continue; }
+            visited++;
+            reasons += (int)((pack >> 8) & 0xff);
+            const int64_t rep_borrow = (int64_t)(int32_t)(uint32_t)((uint64_t)pack >> 32), rep_key = w.flv_key[jj];
+            bool take = false;
+            if (gate(k, KQ_GATE_FLAVOR_FUNGIBILITY)) {
+              if (!should_try_next(rep_pm, rep_borrow, w.pol)) { take = true; stop = true; }
+              else if (rep_key > best_key) take = true;
+            } else if (rep_pm > best_pm) {
+              take = true;
+              if (rep_pm == PM_FIT) stop = true;
+            }
+            if (take) { best = j; best_key = rep_key; best_pm = rep_pm; best_jj = jj; }
+          }
+          if (best_jj >= 0)
+            for (int kk = lane; kk < nf; kk += WAVE) {
+              const int c = best_jj * nf + kk;
+              int pm = w.cell_pm[c] & 0x3f;
+              if (pm == PM_NEEDS) pm = PM_NOCAND;
+              w.best_mode[kk] = fa_mode(pm); w.best_borrow[kk] = w.cell_borrow[c];
+            }
+          if (lane == 0) w.bytes += (int64_t)visited * nf * 40 * plen;  // nf fitsResourceQuota calls per flavor the scan reached, (D+1) x 5 planes x 8 B each
+          wsync_lds();
+        }
         // ---- ordered scan of the pass (uniform) ------------------------------------------
-        for (int jj = 0; jj < nfl && !stop; jj++) {
+        for (int jj = 0; jj < nfl && !stop && !fast; jj++) {
           const int j = cs + jj;
           attempted = j;
           const int f = S.rg_flavor[f0 + j];

@@ -221,6 +221,20 @@ __global__ __launch_bounds__(256) void k_prep(DPrep p) {
   const int o = blockIdx.y;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < p.op[o].words; i += gridDim.x * 256) prep_word(p, o, i);
 }
+// k_prep with the cycle's argument block riding along: the block arrives as a kernel argument and the first workgroup stores it into
+// the device copy the cycle's kernels read — instead of an H2D copy between k_prep and the nominate pass (a blit kernel of its own:
+// 3.6 us + 6 us of gaps per cycle at cfg 3, profiles/r06p_cfg3_timeline.txt)
+static_assert(sizeof(DPrep) + sizeof(K) + 16 <= 4096, "k_prep_k: the kernel argument segment holds 4 KB");
+static_assert(sizeof(K) % 4 == 0, "k_prep_k copies words");
+__global__ __launch_bounds__(256) void k_prep_k(DPrep p, K kb, K* dst) {
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    const uint32_t* s = (const uint32_t*)&kb;
+    uint32_t* d = (uint32_t*)dst;
+    for (unsigned i = threadIdx.x; i < sizeof(K) / 4; i += 256) d[i] = s[i];
+  }
+  const int o = blockIdx.y;
+  if (o < p.n) for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < p.op[o].words; i += gridDim.x * 256) prep_word(p, o, i);
+}
 // cohort usage re-derived from the ClusterQueue cells, every level in one launch (one workgroup; small populations)
 __global__ __launch_bounds__(1024) void k_usage_levels(DSnap S, int64_t* usage, int max_depth) {
   const int cells = S.nc * S.nfr;
@@ -713,6 +727,19 @@ struct HipBackend {
     hipLaunchKernelGGL(k_prep, dim3(gx, p.n), dim3(256), 0, stream, p);
     chk(hipGetLastError(), "k_prep");
   }
+  // launch_prep + the upload of the nominate step's argument block in one launch (launch_nominate takes the block from here)
+  static constexpr bool FUSE_PREP_K = true;
+  bool k0_ready = false;
+  void launch_prep_k(const DPrep& p, const K& k) {
+    if (in_step) { launch_prep(p); return; }   // (side streams: the block travels on the copy stream)
+    uint32_t mx = 0;
+    for (int o = 0; o < p.n; o++) mx = std::max(mx, p.op[o].words);
+    const unsigned gx = std::max(1u, std::min<unsigned>((mx + 1023) / 1024, 256));
+    if (!dk[0]) chk(hipMalloc((void**)&dk[0], sizeof(K)), "hipMalloc K");
+    hipLaunchKernelGGL(k_prep_k, dim3(gx, std::max(p.n, 1)), dim3(256), 0, stream, p, k, dk[0]);
+    chk(hipGetLastError(), "k_prep_k");
+    dcur0 = dk[0]; k0_ready = true;
+  }
   void launch_derive(const DSnap& S, const DDerive& d, int max_depth) {
     if (S.nq * S.nfr > 0) hipLaunchKernelGGL(k_derive_cq, dim3((S.nq * S.nfr + 255) / 256), dim3(256), 0, stream, S, d);
     if (S.nc * S.nfr > 0)
@@ -822,7 +849,8 @@ struct HipBackend {
     static const bool prof_skip_nom = getenv("KQ_PROF_SKIP_NOMINATE") != nullptr;
     K kk = k;
     if (prof_skip_nom && kk.prof) kk.prof += 64;
-    const K* d = put_k(kk, 0);
+    const K* d = (k0_ready && !prof_skip_nom) ? dcur0 : put_k(kk, 0);   // (k0_ready: launch_prep_k stored this block)
+    k0_ready = false;
     hipLaunchKernelGGL(k_nominate_lean, dim3(slots), dim3(64), 0, stream, d, slots);
     if (full_pass && k.sim_nscan) {
       if (lds > 48 * 1024 && lds != lds_attr_sim) {

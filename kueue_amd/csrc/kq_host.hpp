@@ -1597,7 +1597,9 @@ template <class B> struct EngineT {
     prep_copy(k.usage_np, d_usage, Nfr * 2);
     prep_fill(k.preempted, ((size_t)std::max(prep.n_adm, 1) + 3) / 4, 0);
     if (!cfg.fair_sharing) prep_fill(rank, (size_t)n, 0);  // k_order accumulates into it
-    be.launch_prep(pp);
+    // (the plain classical cycle: the fills and copies are launched in front of the nominate pass, with its argument block riding along)
+    const bool prep_with_k = B::FUSE_PREP_K && !cfg.fair_sharing && sc.mode == 0 && !d_tc;
+    if (!prep_with_k) be.launch_prep(pp);
 
     be.timer_mark(0);
     if (cfg.fair_sharing) {
@@ -1631,7 +1633,7 @@ template <class B> struct EngineT {
       // kind exists in the snapshot and the batch, its launch is skipped
       const bool full_pass = prep.any_preemption || hbch.partial || hbch.H.slice_row != nullptr || hbch.H.ps_group != nullptr || !lean_only_ok;   // (a head with a multi-podset group is deferred by the lean pass)
       if (d_tc) be.launch_nominate_tas(k, slots_nom);   // every head through the full nominate code with the TAS hooks (kq_tas_cycle.hpp)
-      else be.launch_nominate(k, slots_nom, nom_lds, full_pass);
+      else { if (prep_with_k) be.launch_prep_k(pp, k); be.launch_nominate(k, slots_nom, nom_lds, full_pass); }
     }
     if (sc.mode == 1) {
       be.launch_shard_export(k, nps, rsn_win);

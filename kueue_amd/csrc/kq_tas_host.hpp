@@ -191,7 +191,9 @@ template <class Backend> struct TasT {
       be.memset(O.layer_fit, 0, (size_t)n * KQ_TAS_MAX_LEVELS * sizeof(int32_t));
     }
     // TASBalancedPlacement: the dynamic programme of a preferred request needs a table per slot (kq_tas_device.hpp TBal): fewer, larger slots
-    const int slots = std::min(nw, T.balanced ? std::min(be.max_slots(), 64) : be.max_slots());
+    // (KQ_TAS_SLOTS: A/B knob — fewer resident waves keep the slots' count rows inside the XCDs' L2s, more of them hide more latency)
+    static const int slots_env = [] { const char* e = getenv("KQ_TAS_SLOTS"); return e ? atoi(e) : 0; }();
+    const int slots = std::min(nw, T.balanced ? std::min(be.max_slots(), 64) : (slots_env > 0 ? std::min(slots_env, be.max_slots()) : be.max_slots()));
     TScratch& X = k.X;
     X.max_set = (std::max(T.n_leaves, T.D - T.n_leaves + 1) + 1 + 15) & ~15;  // per-slot lists start 64-byte aligned (s.nxt doubles as int64 bins)
     const size_t sd = (size_t)slots * T.D, sm = (size_t)slots * X.max_set;

@@ -83,6 +83,8 @@ struct EmuBackend {
     for (int dep = max_depth; dep >= 0; dep--)
       for (int i = 0; i < S.nc * S.nfr; i++) if (S.depth[S.nq + i / S.nfr] == dep) derive_usage_cell(S, usage, S.nq + i / S.nfr, i % S.nfr);
   }
+  static constexpr bool FUSE_PREP_K = false;
+  void launch_prep_k(const DPrep& p, const K&) { launch_prep(p); }
   void launch_prep(const DPrep& p) { for (int o = 0; o < p.n; o++) for (uint32_t i = 0; i < p.op[o].words; i++) prep_word(p, o, i); }
   void launch_derive(const DSnap& S, const DDerive& d, int max_depth) {
     for (int i = 0; i < S.nq * S.nfr; i++) derive_cq_cell(S, d, i / S.nfr, i % S.nfr);
