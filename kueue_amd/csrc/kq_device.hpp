@@ -2480,7 +2480,7 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
         // At cfg 3 a head that finds no room walks 16 flavors x 4 resources: 64 cells one after the other were 40 % of k_nominate_lean
         // (tools/prof_lean.py). Written for any lane count: the 1-lane emulation runs the same code.
         bool fast = false;
-        if (k.O.rsn_win <= 0 && w.slice_row < 0 && !batched) {
+        if (w.slice_row < 0 && !batched) {
           bool needs_ok = dead_all;
           if constexpr (LEAN) needs_ok = needs_ok || !(KQ_POL_WITHIN_CQ(w.pol) != KQ_POLICY_NEVER || (w.plen > 1 && KQ_POL_RECLAIM(w.pol) != KQ_POLICY_NEVER));
           bool mine = false;
@@ -2507,14 +2507,18 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
           }
           wsync_lds();
           int best_jj = -1, visited = 0;
+          const int nrsn0 = w.nrsn;   // (uniform: lane 0 wrote it in front of a barrier)
+          int nrec = 0, jj_end = 0;   // reason records of the flavors the scan reaches, and how far it gets
           for (int jj = 0; jj < nfl && !stop; jj++) {
             const int j = cs + jj;
             attempted = j;
+            jj_end = jj + 1;
             const int64_t pack = w.flv_pack[jj];
             const int rep_pm = (int)(pack & 0xff);
-            if (rep_pm == PM_SKIP) { reasons++; continue; }
+            if (rep_pm == PM_SKIP) { reasons++; nrec++; continue; }
             visited++;
             reasons += (int)((pack >> 8) & 0xff);
+            nrec += (int)((pack >> 8) & 0xff);
             const int64_t rep_borrow = (int64_t)(int32_t)(uint32_t)((uint64_t)pack >> 32), rep_key = w.flv_key[jj];
             bool take = false;
             if (gate(k, KQ_GATE_FLAVOR_FUNGIBILITY)) {
@@ -2534,6 +2538,34 @@ KQ_DEV void assign_flavors(const K& k, Wave& w, int slot, const int64_t* usage, 
               w.best_mode[kk] = fa_mode(pm); w.best_borrow[kk] = w.cell_borrow[c];
             }
           if (lane == 0) w.bytes += (int64_t)visited * nf * 40 * plen;  // nf fitsResourceQuota calls per flavor the scan reached, (D+1) x 5 planes x 8 B each
+          if (k.O.rsn_win > 0 && nrec > 0) {
+            // the reason records of the flavors the scan reached (Status.appendf :349), in scan order: a skipped flavor has one, the others
+            // one per cell with a status (:1353-1373). One lane per flavor: its offset is the count of the flavors in front of it.
+            RsnRec* win = k.O.rsn + (size_t)w.h * k.O.rsn_win;
+            for (int jj = lane; jj < jj_end; jj += WAVE) {
+              int pos = nrsn0;
+              for (int q = 0; q < jj; q++) { const int64_t pq = w.flv_pack[q]; pos += (int)(pq & 0xff) == PM_SKIP ? 1 : (int)((pq >> 8) & 0xff); }
+              const int f = S.rg_flavor[f0 + cs + jj];
+              if (w.cell_pm[jj * nf] == PM_SKIP) {
+                const int why = w.cell_borrow[jj * nf];
+                if (pos < k.O.rsn_win) { RsnRec r; r.code = (uint8_t)why; r.podset = (uint8_t)pi; r.flavor = (int16_t)f; r.resource = (int16_t)(why == KQ_RSN_NOT_IN_NOMINATION ? res_name : -1); r.pad = 0; r.a = 0; r.b = 0; r.c = 0; win[pos] = r; }
+                continue;
+              }
+              for (int kk = 0; kk < nf; kk++) {
+                const int c = jj * nf + kk;
+                const int pm = w.cell_pm[c] & 0x3f;
+                if (!((w.cell_pm[c] & 0x80) || pm == PM_NOFIT || pm == PM_NEEDS)) continue;
+                if (pos < k.O.rsn_win) {
+                  RsnRec r; r.podset = (uint8_t)pi; r.flavor = (int16_t)f; r.resource = (int16_t)w.f_res[kk]; r.pad = 0;
+                  if (pm == PM_NOFIT && !(w.cell_pm[c] & 0x80)) { r.code = (uint8_t)KQ_RSN_EXCEEDS_MAX_CAPACITY; r.a = assumed_usage(w, f * nR + w.f_res[kk]); r.b = w.f_qty[kk]; r.c = w.cell_aux[c]; }
+                  else { r.code = (uint8_t)KQ_RSN_INSUFFICIENT_UNUSED; r.a = w.cell_aux[c]; r.b = 0; r.c = 0; }
+                  win[pos] = r;
+                }
+                pos++;
+              }
+            }
+            if (lane == 0) { if (nrsn0 + nrec > k.O.rsn_win) { w.nrsn = nrsn0 > k.O.rsn_win ? nrsn0 : k.O.rsn_win; w.rsn_over = 1; } else w.nrsn = nrsn0 + nrec; }
+          }
           wsync_lds();
         }
         // ---- ordered scan of the pass (uniform) ------------------------------------------
@@ -5061,10 +5093,10 @@ KQ_DEV void derive_usage_cell(const DSnap& S, int64_t* usage, int cohort, int fr
   for (int pass = 0; pass < 2; pass++) {
     const int32_t* off = pass == 0 ? S.child_cohort_off : S.child_cq_off;
     const int32_t* lst = pass == 0 ? S.child_cohort : S.child_cq;
-    // children in chunks of 8: the ids first, then the three cells of every child — the loads of a chunk are in flight together (one child
+    // children in chunks of 16: the ids first, then the three cells of every child — the loads of a chunk are in flight together (one child
     // after the other was two dependent round trips per child: 10 children x 3 levels = most of k_usage_cols' 22 us at cfg 3); the sum
     // keeps the children's order
-    constexpr int CH = 8;
+    constexpr int CH = 16;
     for (int i0 = off[kx], i1 = off[kx + 1]; i0 < i1; i0 += CH) {
       int ch[CH]; int64_t uv[CH], llv[CH], sqv[CH];
       #pragma unroll

@@ -101,12 +101,10 @@ __device__ __forceinline__ OrderKey order_key(const K& k, int h, bool pre, bool 
   o.c = (uint64_t)k.H.queue_ts[h] ^ 0x8000000000000000ull;
   return o;
 }
-__global__ __launch_bounds__(256) void k_order(const K* __restrict__ kp, int32_t* rank) {
-  const K& k = *kp;
-  __shared__ OrderKey tile[ORDER_TILE];
+__device__ __forceinline__ void order_block(const K& k, int32_t* rank, int bx, int by, OrderKey* tile) {
   const int n = hn(k.H);
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const int base = blockIdx.y * ORDER_TILE;
+  const int i = bx * 256 + threadIdx.x;
+  const int base = by * ORDER_TILE;
   const bool pre = gate(k, KQ_GATE_PRIORITIZE_PREEMPTORS), psort = gate(k, KQ_GATE_PRIORITY_SORTING_IN_COHORT);
   if ((int)threadIdx.x < ORDER_TILE && base + (int)threadIdx.x < n) tile[threadIdx.x] = order_key(k, base + threadIdx.x, pre, psort);
   __syncthreads();
@@ -123,6 +121,10 @@ __global__ __launch_bounds__(256) void k_order(const K* __restrict__ kp, int32_t
   }
   if (cnt) atomicAdd(&rank[i], cnt);
 }
+__global__ __launch_bounds__(256) void k_order(const K* __restrict__ kp, int32_t* rank) {
+  __shared__ OrderKey tile[ORDER_TILE];
+  order_block(*kp, rank, blockIdx.x, blockIdx.y, tile);
+}
 __global__ __launch_bounds__(256) void k_order_scatter(const K* __restrict__ kp, int n, const int32_t* rank, int32_t* order_idx, int patch_stat) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   // the process step charges its bytes to the next counter: the argument block is patched in place instead of being uploaded a second
@@ -138,6 +140,18 @@ __global__ __launch_bounds__(256) void k_order_scatter(const K* __restrict__ kp,
 __global__ __launch_bounds__(256) void k_records(const K* __restrict__ kp) {
   const K& k = *kp;
   const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx == 0) pack_counts(k);
+  if (idx < hn(k.H) * FU * FD) rec_fill_static(k, idx / (FU * FD), idx % (FU * FD));
+}
+
+// the entry order and the entry records in one launch: both only read what the nominate pass wrote, and neither reads the other's output
+// (k_order_scatter, which reads both, follows) — the first n_order workgroups rank, the others fill records
+__global__ __launch_bounds__(256) void k_order_records(const K* __restrict__ kp, int32_t* rank, int nbx, int n_order) {
+  __shared__ OrderKey tile[ORDER_TILE];
+  const K& k = *kp;
+  const int b = blockIdx.x;
+  if (b < n_order) { order_block(k, rank, b % nbx, b / nbx, tile); return; }
+  const int idx = (b - n_order) * 256 + threadIdx.x;
   if (idx == 0) pack_counts(k);
   if (idx < hn(k.H) * FU * FD) rec_fill_static(k, idx / (FU * FD), idx % (FU * FD));
 }
@@ -877,6 +891,16 @@ struct HipBackend {
     hipLaunchKernelGGL(k_order_scatter, dim3(nb), dim3(256), 0, stream, dcur0, k.H.n, (const int32_t*)rank, order_idx, 1);
     stat_patched = true;
     chk(hipGetLastError(), "k_order");
+  }
+  // launch_records + launch_order with the two independent kernels in one launch
+  static constexpr bool FUSE_RECORDS_ORDER = true;
+  void launch_records_order(const K& k, int32_t* order_idx, int32_t* rank) {
+    if (k.H.n == 0) return;
+    const int nb = (k.H.n + 255) / 256, ny = (k.H.n + ORDER_TILE - 1) / ORDER_TILE, nrec = (k.H.n * FU * FD + 255) / 256;
+    hipLaunchKernelGGL(k_order_records, dim3(nb * ny + nrec), dim3(256), 0, stream, dcur0, rank, nb, nb * ny);
+    hipLaunchKernelGGL(k_order_scatter, dim3(nb), dim3(256), 0, stream, dcur0, k.H.n, (const int32_t*)rank, order_idx, 1);
+    stat_patched = true;
+    chk(hipGetLastError(), "k_order_records");
   }
   // dynamic LDS = [cohort rows (2 planes) of the largest tree, if they fit][CH prefetched entry records]
   void launch_process(const K& k, int n_tree, size_t cohort_rows_bytes) {

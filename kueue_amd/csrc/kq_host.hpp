@@ -1645,9 +1645,11 @@ template <class B> struct EngineT {
       if (derr != 0) return fail(derr, derr == KQ_ECAPACITY ? "device-side error: target pool too small for this rank's nominations (tgt_cap)" : "device-side error (capacity or unsupported input)");
       return KQ_OK;
     }
-    if (!nominate_only && !d_tc) be.launch_records(k);  // entry records (static part) for k_process; charged to the nominate interval
+    const bool fuse_ro = B::FUSE_RECORDS_ORDER && !nominate_only && !d_tc && !cfg.fair_sharing;   // (one launch for the two: then charged to the order interval)
+    if (!nominate_only && !d_tc && !fuse_ro) be.launch_records(k);  // entry records (static part) for k_process; charged to the nominate interval
     be.timer_mark(1);
-    if (!cfg.fair_sharing && !nominate_only) be.launch_order(k, order_idx, rank);
+    if (fuse_ro) be.launch_records_order(k, order_idx, rank);
+    else if (!cfg.fair_sharing && !nominate_only) be.launch_order(k, order_idx, rank);
     be.timer_mark(2);
     k.O.stat_bytes = (long long*)(misc + 2);
     if (nominate_only) {}

@@ -38,8 +38,10 @@
 
 namespace kq {
 
+// 1024 threads: 5 items per thread. Measured at cfg 3 (round 6, gpurun_out/r07b/time_spec.txt): the process interval 0.152 ms with 512 threads
+// (10 items per thread, 256 VGPRs, 113 spilled), 0.142 ms with 1024 (128 VGPRs, 95 spilled).
 #ifndef KQ_SPEC_NT
-#define KQ_SPEC_NT 512
+#define KQ_SPEC_NT 1024
 #endif
 constexpr int SP_NT = KQ_SPEC_NT;          // threads of the workgroup
 constexpr int SP_IPT = 5120 / SP_NT;       // items per thread

@@ -176,6 +176,8 @@ struct EmuBackend {
     shard_import_misc(k, nps_total);
     for (int t = 0; t < k.shard.world * k.shard.pool_cap; t++) shard_import_pool(k, nps_total, rsn_win, t);
   }
+  static constexpr bool FUSE_RECORDS_ORDER = false;
+  void launch_records_order(const K& k, int32_t* order_idx, int32_t* rank) { launch_records(k); launch_order(k, order_idx, rank); }
   void launch_records(const K& k) {
     pack_counts(k);
     for (int e = 0; e < hn(k.H); e++) for (int c = 0; c < FU * FD; c++) rec_fill_static(k, e, c);
