@@ -284,11 +284,22 @@ def podset_reducer_search(counts, min_counts, count_limit):
     return oc.value, bool(of.value)
 
 
-def tas_find(topo, rq, dom_cap=None):
-    """FindTopologyAssignmentsForFlavor restatement (oracle/kq_tas_oracle.cpp) -> kueue_amd.tas.Result (+ .bytes)."""
+def tas_find(topo, rq, dom_cap=None, leaf_score=None):
+    """FindTopologyAssignmentsForFlavor restatement (oracle/kq_tas_oracle.cpp) -> kueue_amd.tas.Result (+ .bytes).
+    leaf_score ([podset requests][leaves] int64): features.TASRespectNodeAffinityPreferred on, with the PreferredSchedulingTerms score of every
+    leaf's node (kqo_tas_find_affinity; the library itself refuses the gate)."""
     from kueue_amd import tas as T
     out = T.Result(rq, dom_cap)
     stats = np.zeros(2, np.int64)
+    if leaf_score is not None:
+        ls = np.ascontiguousarray(leaf_score, np.int64)
+        assert ls.shape == (rq.n, topo.n_leaves), (ls.shape, rq.n, topo.n_leaves)
+        l = lib()
+        l.kqo_tas_find_affinity.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        rc = l.kqo_tas_find_affinity(C.byref(topo.struct()), C.byref(rq.struct()), ls.ctypes.data, C.byref(out.struct()), stats.ctypes.data)
+        assert rc == 0, rc
+        out.bytes = int(stats[0])
+        return out
     rc = lib().kqo_tas_find(C.byref(topo.struct()), C.byref(rq.struct()), C.byref(out.struct()), F.ptr(stats))
     assert rc == 0, rc
     out.bytes = int(stats[0])

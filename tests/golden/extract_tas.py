@@ -219,7 +219,7 @@ def int_expr(v):
 
 def parse_podset(body, named_levels):
     f = top_level_fields(body)
-    for bad in ("nodeAffinity", "previousAssignment"):
+    for bad in ("previousAssignment",):
         if bad in f:
             raise Skip(bad)
     ps = dict(name=ident(f["podSetName"]) if "podSetName" in f else "", count=int(f.get("count", "0")))
@@ -229,6 +229,34 @@ def parse_podset(body, named_levels):
         # mask, kq_tas_requests.leaf_ok; tas_flavor_snapshot.go:963 with isLowestLevelNode)
         ns = f["nodeSelector"]
         ps["nodeSelector"] = {ident(k): ident(v) for k, v in top_level_fields_generic(ns[ns.index("{") + 1:ns.rindex("}")])}
+    if "nodeAffinity" in f and f["nodeAffinity"] != "nil":
+        # corev1.NodeAffinity in the builder forms the table uses: MakeNodeSelectorTerms().Term(key, op, values...) (required: the terms are
+        # ORed, one expression each) and MakePreferredSchedulingTerms().Term(weight, key, op, values...) (features.TASRespectNodeAffinityPreferred)
+        na = f["nodeAffinity"]
+        aff = {}
+        def terms_of(text, with_weight):
+            out = []
+            for tm in re.finditer(r"\.\s*Term\(", text):
+                o = tm.end() - 1
+                args = [a.strip() for a in elements(text[o + 1:match_brace(text, o, "(", ")")])]
+                if with_weight:
+                    w, args = int(args[0]), args[1:]
+                t = dict(key=ident(args[0]), operator=args[1].replace("corev1.NodeSelectorOp", ""), values=[ident(a) for a in args[2:]])
+                if with_weight:
+                    t["weight"] = w
+                out.append(t)
+            return out
+        rm = re.search(r"MakeNodeSelectorTerms\(\)", na)
+        pm = re.search(r"MakePreferredSchedulingTerms\(\)", na)
+        if "RequiredDuringSchedulingIgnoredDuringExecution" in na and not rm:
+            raise Skip("nodeAffinity form")
+        if rm:
+            aff["required"] = terms_of(na[rm.end():pm.start() if pm and pm.start() > rm.end() else len(na)], False)
+        if pm:
+            aff["preferred"] = terms_of(na[pm.end():rm.start() if rm and rm.start() > pm.end() else len(na)], True)
+        if not aff:
+            raise Skip("nodeAffinity form")
+        ps["nodeAffinity"] = aff
     if "tolerations" in f and f["tolerations"] != "nil":
         tl = f["tolerations"]
         ps["tolerations"] = []
@@ -367,6 +395,7 @@ def main():
     close_cases = match_brace(body, open_cases)
     cases_text = body[open_cases + 1:close_cases]
     cases, skipped = [], collections.Counter()
+    aff_cases = []
     for el in elements(cases_text):
         nm = re.match(r'"((?:[^"\\]|\\.)*)"\s*:\s*\{', el)
         if not nm:
@@ -390,6 +419,8 @@ def main():
                         case["profileMixed"] = v.strip() == "true"
                     elif k == "features.TASBalancedPlacement":
                         case["balancedPlacement"] = v.strip() == "true"   # tas_balanced_placement.go: restated by the oracle; the library answers KQ_EUNSUPPORTED
+                    elif k == "features.TASRespectNodeAffinityPreferred" and v.strip() == "true":
+                        case["affinityPreferred"] = True   # alpha gate: restated by the oracle only (kqo_tas_find_affinity); written to tas_find_affinity.yaml
                     elif k == "features.TASMultiLayerTopology" and v.strip() == "true":
                         pass  # the gate only lets the job parser populate the constraint list; the algorithm honours whatever is there
                     else:
@@ -409,7 +440,9 @@ def main():
                 case["nonTASUsage"] = parse_pods(p[p.index("{") + 1:p.rindex("}")])
             ps_text = f["podSets"]
             case["podSets"] = [parse_podset(e[e.index("{") + 1:e.rindex("}")], named_levels) for e in elements(ps_text[ps_text.index("{") + 1:ps_text.rindex("}")])]
-            cases.append(case)
+            if not case.get("affinityPreferred") and any("nodeAffinity" in ps_ for ps_ in case["podSets"]):
+                raise Skip("nodeAffinity")
+            (aff_cases if case.get("affinityPreferred") else cases).append(case)
         except Skip as e:
             skipped[str(e).split(" ")[0] if str(e).startswith(("gate", "node", "pod")) else str(e)] += 1
         except (KeyError, ValueError, AttributeError) as e:
@@ -419,7 +452,11 @@ def main():
     with open(OUT, "w") as fh:
         fh.write(hdr)
         yaml.safe_dump(dict(cases=cases), fh, sort_keys=False, width=160)
-    print(len(cases), "cases;", dict(skipped))
+    with open(OUT.replace("tas_find.yaml", "tas_find_affinity.yaml"), "w") as fh:
+        fh.write("# Generated by tests/golden/extract_tas.py from pkg/cache/scheduler/tas_cache_test.go (TestFindTopologyAssignments): the rows that run\n"
+                 f"# with features.TASRespectNodeAffinityPreferred on ({len(aff_cases)} cases). Oracle only: the library refuses the gate (KQ_TAS_F_AFFINITY_PREFERRED).\n")
+        yaml.safe_dump(dict(cases=aff_cases), fh, sort_keys=False, width=160)
+    print(len(cases), "cases;", len(aff_cases), "affinity cases;", dict(skipped))
 
 
 if __name__ == "__main__":
