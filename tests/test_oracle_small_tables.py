@@ -180,19 +180,26 @@ def _sorted_domains(case, with_leader):
     order_in = np.asarray([idx_of[i] for i in range(len(doms))], np.int32)
     out = np.zeros(len(doms), np.int32)
     l = kqo.lib()
+    if case["affinityGate"]:   # features.TASRespectNodeAffinityPreferred on: the oracle's restatement of the gate (the library refuses it)
+        aff = np.zeros(len(doms), np.int64)
+        for orig, d in enumerate(doms):
+            aff[idx_of[orig]] = d.get("affinityScore", 0)
+        l.kqo_tas_sorted_domains_affinity.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        assert l.kqo_tas_sorted_domains_affinity(len(doms), state.ctypes.data, aff.ctypes.data, order_in.ctypes.data, int(case["unconstrained"]), 1, int(with_leader), out.ctypes.data) == 0
+        return [doms[by_level[r]]["id"] for r in out]
     l.kqo_tas_sorted_domains.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     # the reference test runs with the default (Mixed) profile: unconstrained => LeastFreeCapacity (tas_flavor_snapshot.go:1468)
     assert l.kqo_tas_sorted_domains(len(doms), state.ctypes.data, order_in.ctypes.data, int(case["unconstrained"]), 1, int(with_leader), out.ctypes.data) == 0
     return [doms[by_level[r]]["id"] for r in out]
 
 
-@pytest.mark.parametrize("case", [c for c in T["sortedDomains"] if not c["affinityGate"]], ids=lambda c: c["name"][:70])
+@pytest.mark.parametrize("case", T["sortedDomains"], ids=lambda c: c["name"][:70])
 def test_tas_sorted_domains(oracle, case):
-    """tas_flavor_snapshot_test.go:884 TestSortedDomains (the TASRespectNodeAffinityPreferred cases are outside the boundary)."""
+    """tas_flavor_snapshot_test.go:884 TestSortedDomains (the TASRespectNodeAffinityPreferred rows on the oracle's restatement of the gate)."""
     assert _sorted_domains(case, False) == case["want"]
 
 
-@pytest.mark.parametrize("case", [c for c in T["sortedDomainsWithLeader"] if not c["affinityGate"]], ids=lambda c: c["name"][:70])
+@pytest.mark.parametrize("case", T["sortedDomainsWithLeader"], ids=lambda c: c["name"][:70])
 def test_tas_sorted_domains_with_leader(oracle, case):
     """tas_flavor_snapshot_test.go:601 TestSortedDomainsWithLeader."""
     assert _sorted_domains(case, True) == case["want"]
