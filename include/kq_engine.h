@@ -218,7 +218,8 @@ typedef struct kq_heads {
    * requests (flavorassigner.go:782-860), every member then keeps the group's flavors for the resources it requests itself
    * (resolvePodSetFlavors :917-945) and the group's Status. NULL: no podset of the batch is in a group (kq_cycle_run_tas: NULL = take
    * kq_cycle_tas.ps_group). The members of a group must be consecutive podsets of their head (KQ_EUNSUPPORTED otherwise), and a head
-   * that replaces a workload slice holds no group of several podsets. */
+   * that replaces a workload slice holds no group of several podsets. The pending side keeps the column resident (kq_pending_put /
+   * kq_pending_add / kq_pending_update) and Heads() hands it to the cycle. */
   const int32_t* ps_group;          /* [n_ps] group id (any value >= 0, equal inside a group), -1 = none */
 } kq_heads;
 

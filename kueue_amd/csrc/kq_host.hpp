@@ -73,6 +73,7 @@ template <class B> struct EngineT {
     int W = 0, nq = 0, nR = 0, nF = 0, n_tree = 0, slot_cap = 1, max_nps = 1;
     bool plain = true;
     bool partial = false;      // some pending podset may be admitted partially
+    bool grouped = false;      // some resident workload has a PodSetGroupName group of several podsets (kq_heads.ps_group)
     std::vector<void*> allocs;
     DPend D{};
     DGather G{};
@@ -154,7 +155,7 @@ template <class B> struct EngineT {
                           (const void*)G.ps_min_count, (const void*)G.ps_req_off, (const void*)G.req_res, (const void*)G.req_qty, (const void*)G.ps_flavor_ok,
                           (const void*)G.ps_last_tried, (const void*)G.last_generation, (const void*)G.last_cycle, (const void*)G.last_hash, (const void*)G.hash,
                           (const void*)G.slice_row, (const void*)G.ps_slice_count, (const void*)G.req_slice_flavor, (const void*)G.ps_slice_pods_flavor,
-                          (const void*)G.req_slice_qty, (const void*)G.ps_slice_pods_qty})
+                          (const void*)G.req_slice_qty, (const void*)G.ps_slice_pods_qty, (const void*)G.ps_group})
       if (q) pend_release_ptr(q);
     G.cq = pend_alloc<int32_t>(nq); G.priority = pend_alloc<int64_t>(nq); G.queue_ts = pend_alloc<int64_t>(nq); G.flags = pend_alloc<uint32_t>(nq);
     G.ps_off = pend_alloc<int32_t>(nq + 1);
@@ -164,6 +165,7 @@ template <class B> struct EngineT {
     G.last_generation = pend_alloc<int64_t>(nq); G.last_cycle = pend_alloc<int64_t>(nq);
     G.last_hash = pend_alloc<uint64_t>(nq); G.hash = pend_alloc<uint64_t>(nq);
     G.slice_row = nullptr; G.ps_slice_count = nullptr; G.req_slice_flavor = nullptr; G.ps_slice_pods_flavor = nullptr; G.req_slice_qty = nullptr; G.ps_slice_pods_qty = nullptr;
+    G.ps_group = P.grouped ? pend_alloc<int32_t>(gps) : nullptr;   // PodSetGroupName groups among the resident workloads: the batch carries kq_heads.ps_group
     if (P.D.P.slice_row) {   // the resident set holds workload slices
       G.slice_row = pend_alloc<int32_t>(nq); G.ps_slice_count = pend_alloc<int32_t>(gps); G.ps_slice_pods_flavor = pend_alloc<int32_t>(gps);
       G.ps_slice_pods_qty = pend_alloc<int64_t>(gps); G.req_slice_flavor = pend_alloc<int32_t>(grq); G.req_slice_qty = pend_alloc<int64_t>(grq);
@@ -1801,7 +1803,6 @@ template <class B> struct EngineT {
     int slot_cap = 1, max_nps = 1; bool plain = true;
     int rc = validate_heads(h, &slot_cap, &plain, &max_nps);
     if (rc != KQ_OK) return rc;
-    if (heads_grouped(h)) return fail(KQ_EUNSUPPORTED, "kq_pending_*: workloads with PodSetGroupName groups are not kept resident (kq_cycle_run / kq_cycle_run_tas take them)");
     pending_free();
     const int W = h->n, nq = prep.nq, nR = prep.nR;
     const size_t nfw = (prep.nF + 63) / 64;
@@ -1830,6 +1831,8 @@ template <class B> struct EngineT {
     S0.flags = pend_alloc(W, h->flags); S0.ps_off = pend_alloc(W + 1, h->ps_off);
     S0.ps_count = pend_alloc(nps, h->ps_count);
     S0.ps_min_count = pend_alloc<int32_t>(nps, h->ps_min_count, 0xff);
+    S0.ps_group = pend_alloc<int32_t>(nps, h->ps_group, 0xff);   // (-1 everywhere when the caller has no column)
+    P.grouped = heads_grouped(h);
     S0.ps_req_off = pend_alloc(nps + 1, h->ps_req_off);
     S0.req_res = pend_alloc(nreq, h->req_res); S0.req_qty = pend_alloc(nreq, h->req_qty);
     S0.ps_flavor_ok = pend_alloc(nps * nfw, h->ps_flavor_ok);
@@ -1892,7 +1895,7 @@ template <class B> struct EngineT {
     H.n = P.n_heads; H.cq = G.cq; H.priority = G.priority; H.queue_ts = G.queue_ts; H.flags = G.flags; H.ps_off = G.ps_off;
     H.ps_count = G.ps_count; H.ps_min_count = G.ps_min_count; H.ps_req_off = G.ps_req_off; H.req_res = G.req_res; H.req_qty = G.req_qty;
     H.ps_flavor_ok = G.ps_flavor_ok; H.ps_last_tried = G.ps_last_tried; H.last_generation = G.last_generation; H.last_cycle = G.last_cycle;
-    H.last_hash = G.last_hash; H.hash = G.hash;
+    H.last_hash = G.last_hash; H.hash = G.hash; H.ps_group = G.ps_group;
     pend_wire_slices(H);
     if (n_heads) *n_heads = P.n_heads;
     if (n_podsets) *n_podsets = P.n_ps;
@@ -1941,7 +1944,7 @@ template <class B> struct EngineT {
     H.cq = G.cq; H.priority = G.priority; H.queue_ts = G.queue_ts; H.flags = G.flags; H.ps_off = G.ps_off;
     H.ps_count = G.ps_count; H.ps_min_count = G.ps_min_count; H.ps_req_off = G.ps_req_off; H.req_res = G.req_res; H.req_qty = G.req_qty;
     H.ps_flavor_ok = G.ps_flavor_ok; H.ps_last_tried = G.ps_last_tried; H.last_generation = G.last_generation; H.last_cycle = G.last_cycle;
-    H.last_hash = G.last_hash; H.hash = G.hash;
+    H.last_hash = G.last_hash; H.hash = G.hash; H.ps_group = G.ps_group;
     pend_wire_slices(H);
     st.with_heads = want_head_wl != 0;
     kq_decisions caps{};
@@ -2176,7 +2179,6 @@ template <class B> struct EngineT {
     int slot_cap = 1, max_nps = 1; bool plain = true;
     int rc = validate_heads(h, &slot_cap, &plain, &max_nps);
     if (rc != KQ_OK) return rc;
-    if (heads_grouped(h)) return fail(KQ_EUNSUPPORTED, "kq_pending_*: workloads with PodSetGroupName groups are not kept resident (kq_cycle_run / kq_cycle_run_tas take them)");
     Pending& P = pend;
     const int n = h->n, W0 = P.W, nq = prep.nq, nR = prep.nR;
     if (first_index) *first_index = W0;
@@ -2189,7 +2191,7 @@ template <class B> struct EngineT {
     DPend& D = P.D;
     DHeads& S0 = D.P;
     AddStage a;
-    a.cap = (size_t)n * 104 + aps * (40 + 8 * nfw + 4 * (size_t)nR) + arq * 32 + (size_t)(n + nq + 2) * 8 + 96 * 16;
+    a.cap = (size_t)n * 104 + aps * (48 + 8 * nfw + 4 * (size_t)nR) + arq * 32 + (size_t)(n + nq + 2) * 8 + 96 * 16;
     if (hup_cap < a.cap) { if (hup) be.free_host(hup); hup_cap = a.cap + a.cap / 4; hup = (uint8_t*)be.alloc_host(hup_cap); }
     a.host = hup;
     a.dev = grow<uint8_t>(b_addstage, a.cap);
@@ -2200,6 +2202,8 @@ template <class B> struct EngineT {
     add_col(a, S0.ps_off, (size_t)W0 + 1, n, t_ps.data());
     add_col(a, S0.ps_count, nps0, aps, h->ps_count);
     add_col(a, S0.ps_min_count, nps0, aps, h->ps_min_count, 0xff);
+    add_col(a, S0.ps_group, nps0, aps, h->ps_group, 0xff);
+    if (!P.grouped && heads_grouped(h)) { P.grouped = true; pend_alloc_gather(); }   // the first arrivals with a PodSetGroupName group
     for (size_t i = 0; i < aps; i++) t_rq[i] = (int32_t)(nrq0 + h->ps_req_off[i + 1]);
     add_col(a, S0.ps_req_off, nps0 + 1, aps, t_rq.data());
     add_col(a, S0.req_res, nrq0, arq, h->req_res); add_col(a, S0.req_qty, nrq0, arq, h->req_qty);

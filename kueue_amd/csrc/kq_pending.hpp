@@ -224,6 +224,7 @@ struct DGather {
   int64_t *last_generation, *last_cycle; uint64_t *last_hash, *hash;
   // workload slices (null unless the resident set holds the columns): kq_heads slice_row ... ps_slice_pods_qty
   int32_t *slice_row, *ps_slice_count, *req_slice_flavor, *ps_slice_pods_flavor; int64_t *req_slice_qty, *ps_slice_pods_qty;
+  int32_t* ps_group;   // kq_heads.ps_group of the batch (PodSetGroupName groups), null while no resident workload has one
 };
 
 // ClusterQueue.Pop (cluster_queue.go:657-672) for ClusterQueue c — one wave
@@ -326,6 +327,7 @@ KQ_DEV void pend_gather_head(const DPend& D, const DGather& G, int h) {
   }
   for (int i = lane; i < nps; i += WAVE) {
     G.ps_count[gp0 + i] = D.P.ps_count[p0 + i]; G.ps_min_count[gp0 + i] = D.P.ps_min_count[p0 + i];
+    if (G.ps_group) G.ps_group[gp0 + i] = D.P.ps_group[p0 + i];
     G.ps_req_off[gp0 + i] = gr0 + (D.P.ps_req_off[p0 + i] - r0);
   }
   for (int i = lane; i < nreq; i += WAVE) { G.req_res[gr0 + i] = D.P.req_res[r0 + i]; G.req_qty[gr0 + i] = D.P.req_qty[r0 + i]; }
