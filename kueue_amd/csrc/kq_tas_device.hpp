@@ -352,7 +352,7 @@ template <int RM, int U> KQ_DEV int64_t t_leaf_counts(const TTopo& T, const TLea
         pcwl = lc ? count(a.req, rem[u]) : pc;   // without a leader on the leaf the capacity is what it was
         lb += (int64_t)T.R * 16 + 24;
       }
-      a.pc[d] = pc; a.pcwl[d] = pcwl; a.lc[d] = lc;
+      a.pc[d] = pc; a.pcwl[d] = pcwl; if (a.lc) a.lc[d] = lc;   // (no leaderCount array: a state without leaders, TState::nolead)
       a.sc[d] = at ? pc / a.sliceSize : 0;
       a.scwl[d] = at ? pcwl / a.sliceSize : 0;
     }
@@ -1715,7 +1715,11 @@ template <bool LDS> KQ_DEV void t_workload_t(const TK& k, int slot, int w) {
         // a class without a leader: podCountWithLeader / sliceCountWithLeader hold the plain counts in its table, the placement never writes
         // them apart and leaderCount is 0 everywhere — the slot keeps two arrays of the five (what the LDS state of k_process_tas does):
         // 33 KB instead of 83 KB copied per class change at 4096 leaves, 8 B instead of 20 B read per domain and sweep
-        const bool nl = cls >= 0 && k.C.leader && k.C.leader[cls] < 0;   // (k_tas_find's classes; the cycle's per-class slots are patched in place by its class updates and keep every array)
+        // (k_tas_find's classes; the cycle's per-class slots are patched in place by its class updates and keep every array. A private
+        // phase 1 without a leader fills the same values into both pairs — leaf :352, roll-up with minPodDiff = 0 — and is used by this
+        // placement alone: two arrays there as well, 33 KB instead of 83 KB written per placement of k_nominate_tas at 4096 leaves. Not with
+        // the balanced placement, whose saved copies hold five arrays.)
+        const bool nl = cls >= 0 ? (k.C.leader && k.C.leader[cls] < 0) : (leader < 0 && !T.balanced);
         s.nolead = nl; s.pcwl = nl ? s0.pc : s0.pcwl; s.scwl = nl ? s0.sc : s0.scwl; s.lc = nl ? nullptr : s0.lc;
       }
       if (cls >= 0) {
