@@ -83,6 +83,17 @@ typedef struct kq_cycle_tas {
   const int32_t* ps_ex_leaf;
   const int32_t* ps_ex_count;
   const uint8_t* ps_ex_flags;       /* KQ_EX_* */
+  /* Node feasibility of a podset on a TAS flavor — the node's NoSchedule / NoExecute taints against the podset's and the flavor's
+   * tolerations, PodSpec.NodeSelector and the required node affinity against the node's labels (tas_flavor_snapshot.go:955-963,
+   * fillInCounts :1893-1905): string matching, evaluated by the host exactly as for kq_tas_requests.leaf_ok, and shared here as ROWS
+   * because most podsets of a cycle carry the same few tolerations. ps_mask NULL = every podset may use every leaf.
+   *   ps_mask:   [n_ps][n_tas] row of leaf_mask, -1 = every leaf of that flavor
+   *   leaf_mask: [n_masks][mask_stride] 1 = the leaf's node may host the podset; mask_stride >= the n_leaves of every topology a row is
+   *              used with. A masked podset starts from a phase 1 of its own (no request-class table). */
+  const int32_t* ps_mask;
+  const uint8_t* leaf_mask;
+  int32_t n_masks;
+  int32_t mask_stride;
 } kq_cycle_tas;
 
 typedef struct kq_cycle_tas_out {

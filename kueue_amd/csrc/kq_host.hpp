@@ -1056,6 +1056,7 @@ template <class B> struct EngineT {
       if (t->ps_adm_flavor) for (int i = 0; i < n; i++) if (h->flags[i] & KQ_HEAD_HAS_UNHEALTHY_NODES) for (int p = h->ps_off[i]; p < h->ps_off[i + 1]; p++) repl_head[p] = 1;
       for (size_t p = 0; p < nps; p++) {
         if (t->ps_group[p] >= 0 || (t->ps_n_layers && t->ps_n_layers[p] > 1) || repl_head[p]) continue;
+        if (t->ps_mask) { bool m = false; for (int i = 0; i < nt; i++) m = m || t->ps_mask[p * nt + i] >= 0; if (m) continue; }   // its phase 1 sees fewer leaves than the class's
         std::string key((const char*)(t->ps_req + p * R), (size_t)R * 8);
         key.append((const char*)&t->ps_slice_size[p], 4);
         key.append((const char*)(t->ps_slice_level + p * nt), (size_t)nt * 4);
@@ -1169,6 +1170,14 @@ template <class B> struct EngineT {
     c.ps_n_layers = layered ? tstage(t->ps_n_layers, nps) : nullptr;
     c.ps_layer_level = layered ? tstage(t->ps_layer_level, nps * nt * KQ_TAS_MAX_LEVELS) : nullptr;
     c.ps_layer_size = layered ? tstage(t->ps_layer_size, nps * KQ_TAS_MAX_LEVELS) : nullptr;
+    // node feasibility rows (kq_cycle_tas.ps_mask / leaf_mask)
+    c.ps_mask = nullptr; c.leaf_mask = nullptr; c.mask_stride = 0;
+    if (t->ps_mask) {
+      if (!t->leaf_mask || t->n_masks <= 0 || t->mask_stride <= 0) return fail(KQ_EINVAL, "ps_mask without leaf_mask rows");
+      for (int i = 0; i < nt; i++) if (tks[(size_t)i].T.n_leaves > t->mask_stride) return fail(KQ_EINVAL, "mask_stride below a topology's leaf count");
+      for (size_t p = 0; p < nps * (size_t)nt; p++) if (t->ps_mask[p] >= t->n_masks) return fail(KQ_EINVAL, "ps_mask names a row leaf_mask does not hold");
+      c.ps_mask = tstage(t->ps_mask, nps * nt); c.leaf_mask = tstage(t->leaf_mask, (size_t)t->n_masks * t->mask_stride); c.mask_stride = t->mask_stride;
+    }
     // ---- the second pass (kq_cycle_tas.ps_adm_flavor / ps_ex_*) ----------------------------------------------------------------
     std::vector<uint8_t> sp_kind;
     std::vector<int32_t> sp_req, sp_tas;

@@ -26,7 +26,8 @@ enum {
   TQ_WLOFF = 0, TQ_COUNT = 2, TQ_LEVEL = TQ_COUNT + TC_P, TQ_SSIZE = TQ_LEVEL + TC_P, TQ_SLEVEL = TQ_SSIZE + TC_P, TQ_GROUP = TQ_SLEVEL + TC_P,
   TQ_NLAY = TQ_GROUP + TC_P, TQ_LLEVEL = TQ_NLAY + TC_P, TQ_LSIZE = TQ_LLEVEL + TC_P * TC_ML, TQ_STATUS = TQ_LSIZE + TC_P * TC_ML,
   TQ_OPA = TQ_STATUS + TC_P, TQ_OPB = TQ_OPA + TC_P, TQ_DPOS = TQ_OPB + TC_P, TQ_DN = TQ_DPOS + TC_P, TQ_MISC = TQ_DN + TC_P,   // misc: pool_used, error, bytes (64 bit), then the timing builds' cycle counters
-  TQ_LO = TQ_MISC + 24, TQ_HI = TQ_LO + TC_P, TQ_WORDS = TQ_HI + TC_P   // second pass: the leaf range of a replacement (global block only)
+  TQ_LO = TQ_MISC + 24, TQ_HI = TQ_LO + TC_P,   // second pass: the leaf range of a replacement (global block only)
+  TQ_MASK = TQ_HI + TC_P, TQ_WORDS = TQ_MASK + TC_P   // node feasibility: the request's row of TCyc::leaf_mask, -1 = none (global block only)
 };
 static_assert(TQ_MISC % 2 == 0, "the misc words hold an aligned 64-bit byte counter");
 // where the fields of a request block start: the slot's block in global memory holds TC_P podsets, the block k_process_tas keeps in LDS one
@@ -92,6 +93,10 @@ struct TCyc {
   // tr.Count = the pods of the deleted domain :693, slice size and slice level after the rewrite :703-722, 1 when rewritten (no inner layers left),
   // [lo, hi) = the leaves below requiredReplacementDomain :759, leaf of the deleted domain (-1 = not a leaf of the snapshot)}
   const int32_t* sp_req;
+  // node feasibility rows (kq_cycle_tas.ps_mask / leaf_mask): null = every podset may use every leaf. A masked podset has no request class.
+  const int32_t* ps_mask;         // [n_ps][n_tas] row, -1 = every leaf
+  const uint8_t* leaf_mask;       // [n_masks][mask_stride]
+  int mask_stride;
   int32_t* sp_del_out;            // [n_ps] pods the replacement put back on the deleted domain's leaf: the admission accounts for them
                                   // already (ComputeTASNetUsage flavorassigner.go:131-141), so they are kept out of the wave's usage list;
                                   // -1 = the podset lost the admission's assignment to a failed result
@@ -436,6 +441,7 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
   wsync();
   TQOff qo;
   int32_t* qi = tc_qblock(c, w, slot, &qo);
+  const bool masks = c.ps_mask != nullptr && !st_lds;   // (a masked podset has no class: its block is the slot's global one)
   uint8_t* qu = st_lds ? (uint8_t*)(w.ta.lds + TX_QU) : c.q_u8 + (size_t)slot * (TC_P + 8);
   int64_t* qs = st_lds ? (int64_t*)(w.ta.lds + TX_QS) : c.q_spr + (size_t)slot * TC_P * c.R;
   uint8_t* qsim = st_lds ? qu + 8 : qu + TC_P;
@@ -472,6 +478,7 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
         qi[TQ_LO + i] = sp[SP_LO]; qi[TQ_HI + i] = sp[SP_HI];
       }
     }
+    if (masks) for (int i = 0; i < n; i++) qi[TQ_MASK + i] = c.ps_mask[(size_t)(w.ps_base + w.ta.req_ps[i]) * c.n_tas + t];
     *qsim = simulateEmpty ? 1 : 0;
 #ifdef KQ_HOST_EMU
     for (int i = 0; i < n; i++) { qi[qo.status + i] = 0x5a5a5a5a; qi[qo.dn + i] = 0x5a5a5a5a; qi[qo.dpos + i] = 0x5a5a5a5a; }   // (the emulation: nothing may be read from the block of the find before)
@@ -484,7 +491,8 @@ KQ_NOINLINE TcFail tc_find(const K& k, Wave& w, int slot, bool simulateEmpty, in
   tk.T.tas_usage = tc_plane(c, t, which, slot);
   tk.Q.n_wl = 1; tk.Q.wl_off = qi + TQ_WLOFF; tk.Q.sim_empty = qsim; tk.Q.spr = qs;
   tk.Q.count = qi + qo.count; tk.Q.level = qi + qo.level; tk.Q.kind = qu; tk.Q.slice_size = qi + qo.ssize; tk.Q.slice_level = qi + qo.slevel;
-  tk.Q.group = qi + qo.group; tk.Q.leaf_ok = nullptr;
+  tk.Q.group = qi + qo.group;
+  tk.Q.leaf_ok = masks ? c.leaf_mask : nullptr; tk.Q.leaf_ok_idx = masks ? qi + TQ_MASK : nullptr; tk.Q.leaf_ok_stride = c.mask_stride;
   tk.Q.leaf_lo = repl ? qi + TQ_LO : nullptr; tk.Q.leaf_hi = repl ? qi + TQ_HI : nullptr;
   tk.Q.n_layers = layered ? qi + qo.nlay : nullptr; tk.Q.layer_level = layered ? qi + qo.llevel : nullptr; tk.Q.layer_size = layered ? qi + qo.lsize : nullptr;
   tk.O.status = qi + qo.status; tk.O.op_a = qi + qo.opa; tk.O.op_b = qi + qo.opb; tk.O.dom_pos = qi + qo.dpos; tk.O.dom_n = qi + qo.dn;

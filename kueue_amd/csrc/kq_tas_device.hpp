@@ -38,6 +38,10 @@ struct TReq {
   const uint8_t* kind;
   const int32_t *slice_size, *slice_level, *group;
   const uint8_t* leaf_ok;
+  // kq_cycle_run_tas: the requests share mask ROWS — request i uses row leaf_ok_idx[i] of leaf_ok (stride leaf_ok_stride), -1 = every
+  // leaf; NULL = the batch layout, one row of n_leaves per request
+  const int32_t* leaf_ok_idx = nullptr;
+  int leaf_ok_stride = 0;
   const int32_t *n_layers, *layer_level, *layer_size;  // TASMultiLayerTopology: NULL = single layer everywhere
   // kq_tas_find_elastic: assumed usage a workload starts with — the previous pods of its elastic slice (handleScaleUp
   // tas_elastic_workloads.go:97-106): CSR per workload of (leaf, count, podset whose SinglePodRequests the pods carry); NULL = none
@@ -1678,7 +1682,8 @@ template <bool LDS> KQ_DEV void t_workload_t(const TK& k, int slot, int w) {
     st.required = Q.kind[workers] == KQ_TAS_REQUIRED; st.unconstrained = Q.kind[workers] == KQ_TAS_UNCONSTRAINED;
     st.simulateEmpty = Q.sim_empty && Q.sim_empty[w]; st.hasLeader = leader >= 0; st.hasAssumed = hasAssumed;
     st.req = Q.spr + (size_t)workers * T.R; st.leaderReq = leader >= 0 ? Q.spr + (size_t)leader * T.R : nullptr;
-    st.leafOk = Q.leaf_ok ? Q.leaf_ok + (size_t)workers * T.n_leaves : nullptr;
+    st.leafOk = !Q.leaf_ok ? nullptr : !Q.leaf_ok_idx ? Q.leaf_ok + (size_t)workers * T.n_leaves
+              : Q.leaf_ok_idx[workers] >= 0 ? Q.leaf_ok + (size_t)Q.leaf_ok_idx[workers] * Q.leaf_ok_stride : nullptr;
     st.leafLo = Q.leaf_lo ? Q.leaf_lo[workers] : 0; st.leafHi = Q.leaf_lo ? Q.leaf_hi[workers] : 0;
     #pragma unroll
     for (int l = 0; l <= KQ_TAS_MAX_LEVELS; l++) st.sizeAt[l] = 0;

@@ -152,6 +152,16 @@ class Topology:
                            free_capacity=free.reshape(-1).copy(), tas_usage=np.zeros(self.n_leaves * R, np.int64))
         self._struct = None
 
+    def leaf_nodes(self) -> List[Optional[Node]]:
+        """The node behind every leaf when the lowest level is the hostname (one node per leaf), else None per leaf: what the simulator
+        looks at (scheduling_simulator_default.go:77 — a leaf without a node object is always feasible)."""
+        out: List[Optional[Node]] = [None] * self.n_leaves
+        if self.lowest_is_node:
+            by_name = {n.name: n for n in self.nodes}
+            for name, leaf in self.node_leaf.items():
+                out[leaf] = by_name[name]
+        return out
+
     def without_nodes(self, hostnames) -> "Topology":
         """The flavor's snapshot after these nodes failed (NotReady nodes are not part of the tree, tas_flavor.go): a new Topology."""
         gone = set(hostnames)

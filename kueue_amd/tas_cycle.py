@@ -37,6 +37,8 @@ class kq_cycle_tas(C.Structure):
         ("ps_n_layers", F.i32p), ("ps_layer_level", F.i32p), ("ps_layer_size", F.i32p),   # TASMultiLayerTopology, NULL = single layer
         # the second pass: what Status.Admission holds for the heads' podsets, NULL = no head holds an admission
         ("ps_adm_flavor", F.i32p), ("ps_ex_off", F.i32p), ("ps_ex_leaf", F.i32p), ("ps_ex_count", F.i32p), ("ps_ex_flags", F.u8p),
+        # node feasibility rows (taints / tolerations, nodeSelector, required affinity), NULL = every leaf for every podset
+        ("ps_mask", F.i32p), ("leaf_mask", F.u8p), ("n_masks", C.c_int32), ("mask_stride", C.c_int32),
     ]
 
 
@@ -47,10 +49,13 @@ class kq_cycle_tas_out(C.Structure):
 
 @dataclass
 class ResourceFlavor:
-    """kueue.ResourceFlavor: nodeLabels select the nodes, topologyName makes it a TAS flavor."""
+    """kueue.ResourceFlavor: nodeLabels select the nodes, topologyName makes it a TAS flavor; nodeTaints / tolerations take part in the
+    host-side eligibility (kueue_amd/node_match.py)."""
     name: str
     node_labels: Dict[str, str] = field(default_factory=dict)
     topology_name: Optional[str] = None
+    node_taints: list = field(default_factory=list)     # node_match.Taint
+    tolerations: list = field(default_factory=list)     # node_match.Toleration
 
 
 @dataclass
@@ -59,6 +64,9 @@ class PodSetTAS:
     topology_request: Optional[TopologyRequest] = None
     group: Optional[str] = None
     single_pod_requests: Dict[str, object] = field(default_factory=dict)   # from the pod spec (resources.NewRequestsFromPodSpec)
+    # node feasibility per TAS flavor NAME, by leaf index (taints vs the podset's + the flavor's tolerations, PodSpec.NodeSelector,
+    # required node affinity: tas_flavor_snapshot.go:955-963, host-evaluated string matching); a flavor not named = every leaf
+    leaf_ok: Optional[Dict[str, Sequence[bool]]] = None
 
     @property
     def explicit(self) -> bool:  # workload.IsExplicitlyRequestingTAS workload.go:535-541
@@ -140,7 +148,11 @@ class CycleTAS:
 
     def __init__(self, snap: Snapshot, heads: Heads, topologies: Dict[str, Topology], pod_tas: Dict[Tuple[str, int], PodSetTAS],
                  admitted_tas: Optional[Dict[str, List[AdmittedTAS]]] = None, recompute: bool = True,
-                 head_admission: Optional[Dict[str, HeadAdmission]] = None, fail_fast: bool = True):
+                 head_admission: Optional[Dict[str, HeadAdmission]] = None, fail_fast: bool = True, overlapping: bool = True):
+        """overlapping = features.TASHandleOverlappingFlavors (beta, on): cache.Snapshot() hands a flavor whose lowest level is the
+        hostname the TAS usage EVERY such flavor holds on its nodes (snapshot.go:216-240 -> tas_flavor.go:209 addTASUsageForHeldDomains),
+        so two flavors over the same nodes see each other's pods. Inside the cycle usage moves per flavor (clusterqueue_snapshot.go:121),
+        so the other flavors' share is base usage of the snapshot: it goes into kq_tas_topology.tas_usage, not into the rows' CSR."""
         self.snap, self.heads = snap, heads
         names = sorted(topologies)                       # slices.Sorted(maps.Keys(...)) clusterqueue_snapshot.go:220
         self.names = names
@@ -158,6 +170,7 @@ class CycleTAS:
         a["cq_tas_only"] = np.array([1 if tas_only(cq, topologies) else 0 for cq in snap.cluster_queues], np.uint8)
         # admitted rows
         off, at, al, ac, ar = [0], [], [], [], []
+        others: Dict[int, np.ndarray] = {}   # TAS flavor -> [n_leaves][R] usage the OTHER hostname-level flavors hold on its nodes
         for w in snap.admitted:
             for u in (admitted_tas or {}).get(w.name, []):
                 topo = topologies[u.flavor]
@@ -165,6 +178,18 @@ class CycleTAS:
                 for r, q in u.single_pod_requests.items():
                     req[rix[r]] = _amount(r, q)
                 for values, cnt in u.domains:
+                    if overlapping and topo.lowest_is_node:
+                        # the cache keys a hostname-level flavor's usage by the hostname alone (utiltas.DomainID of the stored values): the
+                        # aggregate reaches every flavor that holds that node, whether this one still does or not (snapshot.go:271-285)
+                        for b, tb in enumerate(self.topos):
+                            if names[b] == u.flavor or not tb.lowest_is_node:
+                                continue
+                            lb = _leaf_of(tb, (values[-1],))
+                            if lb is None:
+                                continue
+                            o = others.setdefault(b, np.zeros((tb.n_leaves, R), np.int64))
+                            o[lb] += np.where(req > 0, req, 0) * cnt
+                            o[lb, rix["pods"]] += cnt
                     leaf = _leaf_of(topo, tuple(values))
                     if leaf is None:
                         continue  # a domain the flavor no longer holds: updateTASUsage ignores it (tas_flavor_snapshot.go:250)
@@ -208,6 +233,33 @@ class CycleTAS:
                  ps_group=group, ps_req=req.reshape(-1).copy())
         if (nlay > 1).any():
             a.update(ps_n_layers=nlay, ps_layer_level=llev.reshape(-1).copy(), ps_layer_size=lsz.reshape(-1).copy())
+        # node feasibility rows (kq_cycle_tas.ps_mask / leaf_mask): equal masks share a row
+        if nt and any(pod_tas.get((w.name, pi), PodSetTAS()).leaf_ok for w in heads.workloads for pi in range(len(w.pod_sets))):
+            stride = max(t.n_leaves for t in self.topos)
+            rows: Dict[bytes, int] = {}
+            mats: List[np.ndarray] = []
+            pm = np.full((max(n_ps, 1), nt), -1, np.int32)
+            g = 0
+            for w in heads.workloads:
+                for pi in range(len(w.pod_sets)):
+                    lo = pod_tas.get((w.name, pi), PodSetTAS()).leaf_ok or {}
+                    for name, m in lo.items():
+                        if name not in tix or m is None:
+                            continue
+                        row = np.zeros(stride, np.uint8)
+                        mm = np.asarray(m, np.uint8)
+                        assert mm.size == self.topos[tix[name]].n_leaves, "a leaf_ok mask has one entry per leaf of its TAS flavor"
+                        row[:mm.size] = mm
+                        if row[:mm.size].all():
+                            continue
+                        key = row.tobytes()
+                        if key not in rows:
+                            rows[key] = len(mats); mats.append(row)
+                        pm[g, tix[name]] = rows[key]
+                    g += 1
+            if mats:
+                a.update(ps_mask=pm.reshape(-1).copy(), leaf_mask=np.stack(mats).reshape(-1).copy())
+                self._mask_scalars = dict(n_masks=len(mats), mask_stride=stride)
         self.head_admission: Dict[str, HeadAdmission] = dict(head_admission or {})   # by workload name: the message text needs its names
         if head_admission:
             # the second pass: Status.Admission of the heads that hold one (include/kq_cycle_tas.h ps_adm_flavor / ps_ex_*)
@@ -243,8 +295,14 @@ class CycleTAS:
         for i, t in enumerate(self.topos):
             st = t.struct()
             C.memmove(C.byref(self._topo_arr, i * C.sizeof(kq_tas_topology)), C.byref(st), C.sizeof(kq_tas_topology))
+        self._base_usage = {}
+        for b, o in others.items():
+            if o.any():
+                self._base_usage[b] = (self.topos[b].arrays["tas_usage"].reshape(-1) + o.reshape(-1)).astype(np.int64)
+                self._topo_arr[b].tas_usage = F.ptr(self._base_usage[b])
         self._struct = kq_cycle_tas()
-        F.fill_struct(self._struct, a, dict(n_tas=nt, flags=(0 if recompute else CT_NO_RECOMPUTE) | (0 if fail_fast else CT_NO_FAIL_FAST)))
+        F.fill_struct(self._struct, a, dict(n_tas=nt, flags=(0 if recompute else CT_NO_RECOMPUTE) | (0 if fail_fast else CT_NO_FAIL_FAST),
+                                            **getattr(self, "_mask_scalars", {})))
         self._struct.topo = C.cast(self._topo_arr, C.POINTER(kq_tas_topology))
 
     def struct(self) -> kq_cycle_tas:
@@ -319,7 +377,21 @@ def load_tas_case(case: dict, cycle: int = 1):
     from .fixtures import _cq, load_case
 
     case = copy.deepcopy(case)
-    flavors = {f["name"]: ResourceFlavor(f["name"], dict(f.get("nodeLabels") or {}), f.get("topologyName")) for f in case.get("resourceFlavors", [])}
+    from . import node_match as NM
+
+    def _tols(l):
+        return [NM.Toleration(t.get("key", ""), t.get("operator") or "Equal", t.get("value", ""), t.get("effect", "")) for t in l or []]
+
+    def _taints(l):
+        return [NM.Taint(t["key"], t.get("value", ""), t.get("effect", "")) for t in l or []]
+
+    def _terms(l):
+        return None if l is None else [NM.NodeSelectorTerm([NM.NodeSelectorRequirement(e["key"], e["operator"], list(e.get("values") or []))
+                                                            for e in t.get("matchExpressions") or []]) for t in l]
+
+    flavors = {f["name"]: ResourceFlavor(f["name"], dict(f.get("nodeLabels") or {}), f.get("topologyName"), _taints(f.get("nodeTaints")), _tols(f.get("tolerations")))
+               for f in case.get("resourceFlavors", [])}
+    node_taints = {n["name"]: _taints(n.get("taints")) for n in case.get("nodes", []) if n.get("taints")}
     nodes = [Node(n["name"], dict(n.get("labels") or {}), dict(n.get("allocatable") or {}), bool(n.get("ready", True)), bool(n.get("unschedulable", False)))
              for n in case.get("nodes", [])]
     extra = set()
@@ -347,6 +419,21 @@ def load_tas_case(case: dict, cycle: int = 1):
             pt = req_of(ps)
             pod_tas[(w["name"], pi)] = pt
             ex = excluded_flavors_for_tas(cqs[w["cq"]], list((ps.get("requests") or ps.get("totalRequests") or {}).keys()), pt, topologies, flavors)
+            # taints / tolerations, nodeSelector, required affinity: the flavor half (checkFlavorForPodSets flavorassigner.go:1243-1260 ->
+            # excluded flavors) and the node half (FindFeasibleNodes -> the podset's feasible leaves on every TAS flavor, kq_cycle_tas.ps_mask)
+            tols, sel, terms = _tols(ps.get("tolerations")), dict(ps.get("nodeSelector") or {}), _terms(ps.get("requiredAffinity"))
+            if tols or sel or terms is not None or node_taints or any(rf.node_taints for rf in flavors.values()):
+                for rg in cqs[w["cq"]].resource_groups:
+                    for fq in rg.flavors:
+                        rf = flavors.get(fq.name)
+                        if rf is not None and NM.flavor_mismatch(sel, terms, tols, rf.node_labels, rf.node_taints, rf.tolerations) is not None:
+                            ex.append(fq.name)
+                masks = {}
+                for name, topo in topologies.items():
+                    m = NM.leaf_mask(topo.leaf_nodes(), topo.lowest_is_node, tols + flavors[name].tolerations, sel, terms, node_taints)
+                    if m is not None:
+                        masks[name] = m
+                pt.leaf_ok = masks or None
             ps["excludedFlavors"] = sorted(set(ps.get("excludedFlavors") or []) | set(ex))
     admitted_tas: Dict[str, List[AdmittedTAS]] = {}
     for w in case.get("admitted", []):

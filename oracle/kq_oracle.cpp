@@ -602,6 +602,23 @@ static TasResult FindTopologyAssignmentsForWorkload(Snap& sn, const Head& wl, co
     rq.n_workloads = 1; rq.wl_off = wl_off.data(); rq.single_pod_requests = req.data(); rq.count = count.data(); rq.level = level.data();
     rq.kind = kind.data(); rq.slice_size = slice_size.data(); rq.slice_level = slice_level.data(); rq.group = group.data();
     if (sn.T->ps_n_layers) { rq.n_layers = n_layers.data(); rq.layer_level = layer_level.data(); rq.layer_size = layer_size.data(); }
+    // node feasibility of the podsets on this flavor (kq_cycle_tas.ps_mask: taints / tolerations, nodeSelector, required affinity —
+    // the simulator's side of fillInCounts, tas_flavor_snapshot.go:955-963, :1893-1905), as the leaf_ok rows of the batch boundary
+    std::vector<uint8_t> leaf_ok;
+    if (sn.T->ps_mask) {
+      const kq_tas_topology& tp = sn.T->topo[t];
+      const int nL = tp.level_off[tp.n_levels] - tp.level_off[tp.n_levels - 1];
+      bool any = false;
+      for (int i = 0; i < n; i++) any = any || sn.T->ps_mask[(size_t)(wl.ps_base + pss[i]) * nt + t] >= 0;
+      if (any) {
+        leaf_ok.assign((size_t)n * nL, 1);
+        for (int i = 0; i < n; i++) {
+          const int row = sn.T->ps_mask[(size_t)(wl.ps_base + pss[i]) * nt + t];
+          if (row >= 0) memcpy(leaf_ok.data() + (size_t)i * nL, sn.T->leaf_mask + (size_t)row * sn.T->mask_stride, (size_t)nL);
+        }
+        rq.leaf_ok = leaf_ok.data();
+      }
+    }
     std::vector<tas::PodSetResult> res;
     if ((wl.flags & KQ_HEAD_HAS_UNHEALTHY_NODES) && sn.T->ps_ex_off) {
       // tas_flavor_snapshot.go:608-633: every podset on its own through findReplacementAssignment :686, against Status.Admission's

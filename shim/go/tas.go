@@ -72,6 +72,11 @@ type TASCycle struct {
 	PsAdmFlavor                  []int32 // [podsets][snapshot resources] PodSetAssignments[i].Flavors as flavor indices, -1 = none
 	PsExOff, PsExLeaf, PsExCount []int32 // CSR per podset: PodSetAssignments[i].TopologyAssignment, every domain, leaf index in the podset's TAS flavor (-1 = stale)
 	PsExFlags                    []uint8 // ExUnhealthy | ExFirst per domain
+	// Node feasibility of a podset on a TAS flavor (taints vs tolerations, PodSpec.NodeSelector, required node affinity:
+	// tas_flavor_snapshot.go:955-963), evaluated on the host and shared as rows. nil = every podset may use every leaf.
+	PsMask     []int32 // [podsets][len(Topos)] row of LeafMask, -1 = every leaf
+	LeafMask   []uint8 // [rows][MaskStride] 1 = the leaf's node may host the podset
+	MaskStride int32
 }
 
 const (
@@ -174,6 +179,12 @@ func (e *Engine) RunCycleTAS(h *FlatHeads, t *TASCycle, out *FlatDecisions, tout
 			ct.ps_ex_count = (*C.int32_t)(pin(&p, t.PsExCount))
 			ct.ps_ex_flags = (*C.uint8_t)(pin(&p, t.PsExFlags))
 		}
+	}
+	if len(t.PsMask) > 0 && t.MaskStride > 0 {
+		ct.ps_mask = (*C.int32_t)(pin(&p, t.PsMask))
+		ct.leaf_mask = (*C.uint8_t)(pin(&p, t.LeafMask))
+		ct.n_masks = C.int32_t(int32(len(t.LeafMask)) / t.MaskStride)
+		ct.mask_stride = C.int32_t(t.MaskStride)
 	}
 	co.ps_tas = (*C.int32_t)(pin(&p, tout.PsTAS))
 	co.dom_off = (*C.int32_t)(pin(&p, tout.DomOff))

@@ -119,6 +119,74 @@ def items_of(expr, sym):
     return [resolve(t, sym) for t in split_top(e[p + 1: match_brace(e, p)]) if t.strip()]
 
 
+def _kv(body):
+    """`Key: x, Operator: y, ...` of a Go struct literal -> {field: token} (top level only)"""
+    out = {}
+    for part in split_top(body):
+        if ":" in part:
+            k, v = part.split(":", 1)
+            out[k.strip()] = v.strip()
+    return out
+
+
+def _tok(t):
+    t = t.strip()
+    if t.startswith('"'):
+        return t.strip('"')
+    return {"corev1.TaintEffectNoSchedule": "NoSchedule", "corev1.TaintEffectNoExecute": "NoExecute", "corev1.TaintEffectPreferNoSchedule": "PreferNoSchedule",
+            "corev1.TolerationOpEqual": "Equal", "corev1.TolerationOpExists": "Exists", "corev1.NodeSelectorOpIn": "In", "corev1.NodeSelectorOpNotIn": "NotIn",
+            "corev1.NodeSelectorOpExists": "Exists", "corev1.NodeSelectorOpDoesNotExist": "DoesNotExist", "corev1.LabelHostname": HOST}.get(t) or _bad_tok(t)
+
+
+def _bad_tok(t):
+    raise Skip("not a literal: " + t[:40])
+
+
+def parse_taints(a):
+    """corev1.Taint{Key: .., Value: .., Effect: ..} literals of a Taints(...) / Taint(...) call"""
+    out = []
+    for m in re.finditer(r"corev1\.Taint\{", a):
+        j = match_brace(a, m.end() - 1)
+        f = _kv(a[m.end():j])
+        out.append(dict(key=_tok(f.get("Key", '""')), value=_tok(f.get("Value", '""')), effect=_tok(f.get("Effect", '""'))))
+    return out
+
+
+def parse_tolerations(a):
+    out = []
+    for m in re.finditer(r"corev1\.Toleration\{", a):
+        j = match_brace(a, m.end() - 1)
+        f = _kv(a[m.end():j])
+        out.append(dict(key=_tok(f.get("Key", '""')), operator=_tok(f.get("Operator", '"Equal"')), value=_tok(f.get("Value", '""')), effect=_tok(f.get("Effect", '""'))))
+    return out
+
+
+def parse_terms(a):
+    """[]corev1.NodeSelectorTerm{{MatchExpressions: []corev1.NodeSelectorRequirement{{Key:, Operator:, Values: []string{..}}}}}"""
+    p = a.index("{", a.index("NodeSelectorTerm"))
+    terms = []
+    for t in split_top(a[p + 1:match_brace(a, p)]):
+        t = t.strip()
+        if not t:
+            continue
+        f = _kv(t[t.index("{") + 1:match_brace(t, t.index("{"))])
+        if set(f) - {"MatchExpressions"}:
+            raise Skip("NodeSelectorTerm." + ",".join(sorted(set(f) - {"MatchExpressions"})))
+        exprs = []
+        me = f.get("MatchExpressions")
+        if me:
+            q = me.index("{")
+            for e in split_top(me[q + 1:match_brace(me, q)]):
+                e = e.strip()
+                if not e:
+                    continue
+                g = _kv(e[e.index("{") + 1:match_brace(e, e.index("{"))])
+                vals = re.findall(r'"([^"]*)"', g.get("Values", ""))
+                exprs.append(dict(key=_tok(g["Key"]), operator=_tok(g["Operator"]), values=vals))
+        terms.append(dict(matchExpressions=exprs))
+    return terms
+
+
 def parse_node(text, sym):
     if "MakeNode" not in text:
         # `*singleNode.Clone().StatusAllocatable(...).Obj()`: a builder variable (a MakeNode chain without Obj) and the calls made on its copy —
@@ -141,6 +209,8 @@ def parse_node(text, sym):
             n["ready"] = False
         elif m == "Unschedulable":
             n["unschedulable"] = True
+        elif m == "Taints":
+            n.setdefault("taints", []).extend(parse_taints(a))
         elif m in ("Obj", "DeepCopy", "Clone"):
             pass
         else:
@@ -197,6 +267,10 @@ def parse_flavor(text, sym):
             f["nodeLabels"][label(k, sym)] = label(v, sym)
         elif m == "TopologyName":
             f["topologyName"] = a.strip().strip('"')
+        elif m == "Toleration":
+            f.setdefault("tolerations", []).extend(parse_tolerations(a))
+        elif m == "Taint":
+            f.setdefault("nodeTaints", []).extend(parse_taints(a))
         elif m != "Obj":
             raise Skip("ResourceFlavor." + m)
     return f
@@ -240,7 +314,8 @@ def parse_admission(args, sym):
 
 
 PS_OK = {"MakePodSet", "Request", "Obj", "Image", "RequiredTopologyRequest", "PreferredTopologyRequest", "UnconstrainedTopologyRequest",
-         "SliceRequiredTopologyRequest", "SliceSizeTopologyRequest", "SliceRequiredTopologyConstraints", "Limit", "SetMinimumCount"}
+         "SliceRequiredTopologyRequest", "SliceSizeTopologyRequest", "SliceRequiredTopologyConstraints", "Limit", "SetMinimumCount",
+         "Toleration", "RequiredDuringSchedulingIgnoredDuringExecution"}
 
 
 def parse_podsets(args, sym):
@@ -260,6 +335,10 @@ def parse_podsets(args, sym):
                 ps["requests"][res_name(r) if not r.strip().startswith('"') else r.strip().strip('"')] = q.strip().strip('"')
             elif m == "SetMinimumCount":
                 ps["minCount"] = int(a)   # partial admission (PodSet.MinCount)
+            elif m == "Toleration":
+                ps.setdefault("tolerations", []).extend(parse_tolerations(a))
+            elif m == "RequiredDuringSchedulingIgnoredDuringExecution":
+                ps["requiredAffinity"] = parse_terms(a)
             elif m == "RequiredTopologyRequest":
                 tr["required"] = label(a, sym)
             elif m == "PreferredTopologyRequest":
@@ -346,8 +425,8 @@ def parse_keymap(text):
     return out
 
 
-BAD = r"Toleration|NodeSelector|Taint|PreemptionGate|WorkloadSlice|Annotation|PodSetGroup|" \
-      r"resourceTransformations|patchStatusErr|RequiredDuringScheduling|PreferredDuringScheduling|PodSetUpdate|StopPolicy|" \
+BAD = r"NodeSelector\(|PreemptionGate|WorkloadSlice|Annotation|PodSetGroup|" \
+      r"resourceTransformations|patchStatusErr|PreferredDuringScheduling|PodSetUpdate|StopPolicy|" \
       r"NOTHING_ELSE_HERE"
 
 
@@ -510,6 +589,8 @@ def extract(src, func, cases, skipped):
             for k in want_adm:
                 if k not in expect:
                     raise Skip("admission of a workload that is not a head")
+                if len({fl for ps in want_adm[k]["podsets"] for fl in ps["flavors"].values() if fl in tas_flavor_names}) > 1:
+                    raise Skip("a workload on two TAS flavors")   # (the expected admission spreads one workload over two TAS flavors: KQ_EUNSUPPORTED)
             ev = field(block, "wantEvents") or ""
             for ns_, nm_, reason in re.findall(r'MakeEventRecord\("([^"]+)",\s*"([^"]+)",\s*"([^"]+)"', ev):
                 if f"{ns_}/{nm_}" in expect:

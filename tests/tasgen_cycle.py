@@ -10,7 +10,29 @@ from tests.randgen import random_case
 BLOCK, RACK, HOST = "cloud.com/topology-block", "cloud.com/topology-rack", "kubernetes.io/hostname"
 
 
-def random_tas_cycle_case(seed, roomy=False, rich_groups=False, **kw):
+def add_node_masks(seed, heads, topologies, pod_tas, share=0.45):
+    """Node feasibility per (podset, TAS flavor) — what taints / tolerations / nodeSelector / required affinity leave of the leaves
+    (kq_cycle_tas.ps_mask): a few masks per topology, shared by the podsets that draw them (tolerations repeat across a queue's workloads),
+    now and then a mask that leaves nothing."""
+    rm = random.Random(seed * 101 + 3)
+    pool = {}
+    for name, topo in sorted(topologies.items()):
+        n = topo.n_leaves
+        ms = []
+        for _ in range(3):
+            keep = rm.choice([0.5, 0.7, 0.9])
+            ms.append([1 if rm.random() < keep else 0 for _ in range(n)])
+        ms.append([0] * n)
+        pool[name] = ms
+    for w in heads.workloads:
+        for pi in range(len(w.pod_sets)):
+            if rm.random() >= share:
+                continue
+            pt = pod_tas[(w.name, pi)]
+            pt.leaf_ok = {name: (ms[3] if rm.random() < 0.08 else rm.choice(ms[:3])) for name, ms in pool.items() if rm.random() < 0.8}
+
+
+def random_tas_cycle_case(seed, roomy=False, rich_groups=False, masks=False, **kw):
     cfg, snap, heads = random_case(seed, **kw)
     rnd = random.Random(seed * 7919 + 13)
     levels = rnd.choice([[HOST], [RACK, HOST], [BLOCK, RACK, HOST], [BLOCK, RACK]])
@@ -87,6 +109,8 @@ def random_tas_cycle_case(seed, roomy=False, rich_groups=False, **kw):
             leaf = rnd.randrange(topo.n_leaves)
             per_pod = {r: q // ps.count for r, q in ps.requests.items() if r != "pods" and q // ps.count > 0}
             admitted_tas.setdefault(w.name, []).append(AdmittedTAS(tf[0], [(tuple(topo.leaf_values(leaf)), ps.count)], per_pod))
+    if masks:
+        add_node_masks(seed, heads, topologies, pod_tas)
     ct = CycleTAS(snap, heads, topologies, pod_tas, admitted_tas, recompute=rnd.random() < 0.85)
     return cfg, snap, heads, ct, pod_tas
 
@@ -166,6 +190,9 @@ def random_second_pass_case(seed, **kw):
         head_adm[hw.name] = ha
         second.append(hw)
     # the rows that did not get a fresh assignment above keep the one random_tas_cycle_case drew
+    if kw.get("masks") and second:
+        import types
+        add_node_masks(seed + 977, types.SimpleNamespace(workloads=second), topologies, pod_tas, share=0.5)
     workloads = second + list(heads.workloads)
     heads = Heads(snap, workloads, cycle=heads.cycle)
     ct2 = CycleTAS(snap, heads, topologies, pod_tas, admitted_tas, recompute=rnd.random() < 0.85, head_admission=head_adm or None,

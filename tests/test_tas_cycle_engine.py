@@ -153,6 +153,84 @@ def test_random_tas_cycles_gpu(oracle, block):
         _random(oracle, _hip, seed)
 
 
+def _random_masked(oracle, make, seed):
+    """Node feasibility inside the cycle (kq_cycle_tas.ps_mask / leaf_mask: taints vs tolerations, nodeSelector, required affinity —
+    tas_flavor_snapshot.go:955-963): ~45 % of the podsets carry a mask per TAS flavor, rows shared; the masked placements of nominate,
+    of the victim search's workloadFits and of processEntry's recomputation start from a phase 1 of their own."""
+    cfg, snap, heads, ct, _ = random_tas_cycle_case(seed, fair=seed % 4 == 3, tight=seed % 2 == 0, preemption=seed % 3 != 0, partial=seed % 7 == 0, masks=True)
+    if seed % 5 == 4:
+        for i in range(len(ct.topos)):
+            ct._topo_arr[i].profile_mixed |= 2   # KQ_TAS_F_BALANCED_PLACEMENT
+    oracle.derive(snap)
+    return _same(oracle, make, cfg, snap, heads, ct, tgt_cap=max(16, snap.n_adm))
+
+
+@pytest.mark.parametrize("seed", range(400))
+def test_random_tas_cycles_with_node_masks_emulated(oracle, seed):
+    _random_masked(oracle, _emu, seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", range(4))
+def test_random_tas_cycles_with_node_masks_gpu(oracle, block):
+    for seed in range(block * 100, block * 100 + 100):
+        _random_masked(oracle, _hip, seed)
+
+
+def test_node_masks_change_the_outcome(oracle):
+    """... and the masks are seen: against the same cycles without them, decisions or TopologyAssignments differ in a good share of the seeds."""
+    differ = masked_ps = 0
+    for seed in range(240):
+        out = []
+        for masks in (False, True):
+            cfg, snap, heads, ct, _ = random_tas_cycle_case(seed, fair=False, tight=seed % 2 == 0, preemption=seed % 3 != 0, masks=masks)
+            oracle.derive(snap)
+            d, t = oracle.cycle_run_tas(cfg, snap, heads, ct, tgt_cap=max(16, snap.n_adm))
+            out.append((d.a["action"].tobytes(), t.a["dom_off"].tobytes(), t.a["dom_leaf"].tobytes()))
+            if masks and "ps_mask" in ct.arrays:
+                masked_ps += int((ct.arrays["ps_mask"] >= 0).sum())
+        differ += out[0] != out[1]
+    assert differ >= 20 and masked_ps >= 250, (differ, masked_ps)
+
+
+def _second_pass_masked(oracle, make, seed):
+    cfg, snap, heads, ct, n_second = random_second_pass_case(seed, fair=seed % 5 == 4, masks=True)
+    oracle.derive(snap)
+    _same(oracle, make, cfg, snap, heads, ct, tgt_cap=max(16, snap.n_adm))
+
+
+@pytest.mark.parametrize("seed", range(200))
+def test_random_second_pass_cycles_with_node_masks_emulated(oracle, seed):
+    """the failed node's replacement (findReplacementAssignment :686) looks at the podset's feasible nodes only"""
+    _second_pass_masked(oracle, _emu, seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", range(2))
+def test_random_second_pass_cycles_with_node_masks_gpu(oracle, block):
+    for seed in range(block * 100, block * 100 + 100):
+        _second_pass_masked(oracle, _hip, seed)
+
+
+def test_node_mask_arguments_are_checked(oracle):
+    """ps_mask without rows, a row index past n_masks, a stride below a topology's leaf count: KQ_EINVAL, not a read past the array"""
+    from kueue_amd import _ffi as F
+    for seed in range(40):
+        cfg, snap, heads, ct, _ = random_tas_cycle_case(seed, fair=False, masks=True)
+        if "ps_mask" in ct.arrays and max(t.n_leaves for t in ct.topos) > 1:
+            break
+    oracle.derive(snap)
+    for field, bad in (("n_masks", 0), ("mask_stride", 1), ("n_masks", int(ct.arrays["ps_mask"].max()))):
+        keep = getattr(ct._struct, field)
+        setattr(ct._struct, field, bad)
+        eng = _emu(cfg)
+        eng.put(snap)
+        d, _ = eng.run_tas(heads, ct, tgt_cap=max(16, snap.n_adm))
+        assert d.rc == F.KQ_EINVAL, (field, bad, d.rc, d.error)
+        eng.close()
+        setattr(ct._struct, field, keep)
+
+
 def _random_balanced(oracle, make, seed):
     """The whole cycle with features.TASBalancedPlacement on: every placement of a preferred request inside Assign, the victim search's
     workloadFits and processEntry's recomputation goes through tas_balanced_placement.go (kq_tas_device.hpp t_balanced_lane0)."""
