@@ -268,11 +268,15 @@ __global__ __launch_bounds__(256) void k_commit_cq(DSnap S, DCommit c, int add) 
 }
 // the same for larger trees in ONE launch: the levels of a flavor-resource column only depend on that column, so a workgroup takes a
 // few columns of every cohort through all levels (barrier between levels) — 1 launch instead of max_depth + 1 (4 x ~6 us at cfg 3)
-__global__ __launch_bounds__(256) void k_usage_cols(DSnap S, int64_t* usage, int max_depth, int cols) {
+// A cell is 8 bytes and a node's cells lie side by side (ix = node * nfr + fr): a workgroup that takes 2 columns uses 16 of the 64 bytes of
+// every line it touches, and at cfg 3 (111 cohorts, 64 columns) the kernel fetched 6.9 MB to read 1.6 MB (profiles/r07g_cfg3_rocprof_summary.txt).
+// Workgroups of up to 1024 threads take whole lines — 8 columns, the lanes of a cell group side by side in fr — still one cell per thread
+// and level.
+__global__ __launch_bounds__(1024) void k_usage_cols(DSnap S, int64_t* usage, int max_depth, int cols) {
   const int col0 = blockIdx.x * cols;
   const int ncol = (col0 + cols <= S.nfr) ? cols : S.nfr - col0;
   for (int dep = max_depth; dep >= 0; dep--) {
-    for (int i = threadIdx.x; i < S.nc * ncol; i += 256) {
+    for (int i = threadIdx.x; i < S.nc * ncol; i += blockDim.x) {
       const int cohort = S.nq + i / ncol;
       if (S.depth[cohort] == dep) derive_usage_cell(S, usage, cohort, col0 + i % ncol);
     }
@@ -726,8 +730,10 @@ struct HipBackend {
     // (many workgroups) is faster than the serial passes of one (measured: 75 us vs 4 x 6.5 us at 7104 cells)
     if (cells <= 1024) hipLaunchKernelGGL(k_usage_levels, dim3(1), dim3(1024), 0, stream, S, usage, max_depth);
     else if (S.nc <= 4096) {  // one launch: a workgroup per group of columns (as many as keep one cell per thread and level)
-      const int cols = std::max(1, std::min(S.nfr, 256 / std::max(S.nc, 1)));
-      hipLaunchKernelGGL(k_usage_cols, dim3((S.nfr + cols - 1) / cols), dim3(256), 0, stream, S, usage, max_depth, cols);
+      int nt = 256, cols = std::max(1, std::min(S.nfr, nt / std::max(S.nc, 1)));
+      if (cols < 8 && S.nfr >= 8 && S.nc * 8 <= 1024 * 2) { nt = std::min(1024, ((S.nc * 8 + 63) / 64) * 64); cols = 8; }   // whole 64-byte lines; at most two cells per thread and level
+      else if (cols > 8) cols &= ~7;
+      hipLaunchKernelGGL(k_usage_cols, dim3((S.nfr + cols - 1) / cols), dim3(nt), 0, stream, S, usage, max_depth, cols);
     }
     else for (int dep = max_depth; dep >= 0; dep--)
       hipLaunchKernelGGL(k_usage_level, dim3((cells + 255) / 256), dim3(256), 0, stream, S, usage, dep);
