@@ -408,14 +408,24 @@ def main():
             if "nodeLabels" in f:  # flavorInformation.NodeLabels: the flavor only selects nodes carrying these labels
                 nl = f["nodeLabels"]
                 case["nodeLabels"] = {ident(k): ident(v) for k, v in top_level_fields_generic(nl[nl.index("{") + 1:nl.rindex("}")])}
-            for bad in ("workload", "priorOwnUsage", "priorFlavorUsage", "aggregatedDomainUsages"):
+            for bad in ("workload", "aggregatedDomainUsages"):
                 if bad in f:
                     raise Skip(bad)
+            prior = {}
+            for key in ("priorOwnUsage", "priorFlavorUsage"):   # []workload.TopologyDomainRequests: TAS usage the flavor / a sibling flavor over the same nodes holds
+                if key in f:
+                    prior[key] = [dict(values=[ident(v) for v in re.findall(r'"[^"]*"|[\w\.]+', vals)],
+                                       requests={ident(r.strip()): int(q) for r, q in re.findall(r'([\w\.]+|"[^"]+")\s*:\s*(\d+)', reqs)}, count=int(cnt))
+                                  for vals, reqs, cnt in re.findall(r'Values:\s*\[\]string\{([^}]*)\},\s*SinglePodRequests:\s*resources\.NewRequestsFromMap\(map\[corev1\.ResourceName\]int64\{([^}]*)\}\),\s*Count:\s*(\d+)', f[key], re.S)]
+                    if not prior[key]:
+                        raise Skip(key)
             if "featureGates" in f:
                 g = f["featureGates"]
                 gates = dict(top_level_fields_generic(g[g.index("{") + 1:g.rindex("}")]))
                 for k, v in gates.items():
-                    if k == "features.TASProfileMixed":
+                    if k == "features.TASHandleOverlappingFlavors":
+                        case["overlappingFlavors"] = v.strip() == "true"
+                    elif k == "features.TASProfileMixed":
                         case["profileMixed"] = v.strip() == "true"
                     elif k == "features.TASBalancedPlacement":
                         case["balancedPlacement"] = v.strip() == "true"   # tas_balanced_placement.go: restated by the oracle; the library answers KQ_EUNSUPPORTED
@@ -435,6 +445,12 @@ def main():
             else:
                 case["nodes"] = []
             case["levels"] = parse_strings(f["levels"], named_levels)
+            if prior:
+                # what the harness hands the snapshot (tas_cache_test.go:8368-8395): with TASHandleOverlappingFlavors (beta, on) and a hostname
+                # lowest level the AGGREGATED usage — the sibling flavor's, aggregatedDomainUsagesForPriorFlavorUsage :8935 — replaces the
+                # flavor's own (tas_flavor.go:209); otherwise the flavor's own usage
+                overlapping = case.get("overlappingFlavors", True) and case["levels"][-1] == "kubernetes.io/hostname"
+                case["tasUsage"] = prior.get("priorFlavorUsage", []) if overlapping else prior.get("priorOwnUsage", [])
             if "pods" in f:
                 p = f["pods"]
                 case["nonTASUsage"] = parse_pods(p[p.index("{") + 1:p.rindex("}")])
