@@ -1435,11 +1435,19 @@ def bench_tas_cycle(args, torch, dist, world, rank, local_rank):
     parity = None
     closed = not args.open_loop
     traj, oracle_s, oracle_dec = [], 0.0, 0
+
+    def tas_same(want, wout, got, gout, h0):
+        bad = want.equal(got)
+        m = int(wout.a["dom_off"][h0.n_ps])
+        return (not bad and np.array_equal(wout.a["ps_tas"][:h0.n_ps], gout.a["ps_tas"][:h0.n_ps]) and np.array_equal(wout.a["dom_off"], gout.a["dom_off"]) and
+                np.array_equal(wout.a["dom_leaf"][:m], gout.a["dom_leaf"][:m]) and np.array_equal(wout.a["dom_count"][:m], gout.a["dom_count"][:m]) and
+                np.array_equal(wout.a["tas_usage_after"], gout.a["tas_usage_after"])), bad
+
     if closed:
         # CLOSED loop, driven the reference's way (scheduler.go:308-386 with manager.go:903): every cycle starts from a fresh
         # cache.Snapshot() that holds what the cycles before admitted — rows, quota usage, TopologyAssignments as leaf usage — and the
-        # workloads finish --hold cycles later (kueue_amd/tas_population.py TASClosedLoop). The trajectory is laid down by the oracle
-        # BEFORE the timed region (it is the parity reference and the cpu_baseline anyway); a step then is kq_snapshot_put of that
+        # workloads finish --hold cycles later (kueue_amd/tas_population.py TASClosedLoop). The trajectory is laid down by the ENGINE
+        # BEFORE the timed region, the oracle following cycle by cycle (it is the parity reference and the cpu_baseline anyway); a step then is kq_snapshot_put of that
         # cycle's snapshot + kq_cycle_run_tas, and every step's outcome is compared with the oracle's after the timed region.
         from oracle import kqo
         loop = batch.closed_loop(hold=args.hold, failures=args.node_failures)
@@ -1450,19 +1458,19 @@ def bench_tas_cycle(args, torch, dist, world, rank, local_rank):
             want, wout = kqo.cycle_run_tas(cfg, sn, h0, c0)
             oracle_s += time.perf_counter() - t1; oracle_dec += h0.n
             traj.append((sn, h0, c0, want, wout))
-            loop.fold(h0, want, wout)
+            # ENGINE-driven: the next cycle's cache.Snapshot() holds what the engine decided in this one (the oracle follows and is compared
+            # cycle by cycle, here and once more over the timed steps); VERDICT r05 "weak" 2b
+            eng.put(sn)
+            got0, gout0 = eng.run_tas(h0, c0)
+            same0, bad0 = tas_same(want, wout, got0, gout0, h0)
+            if not same0 and not args.no_parity_gate:
+                raise SystemExit(f"{args.workload}: closed-loop cycle {c} of the engine differs from the oracle's ({bad0})")
+            loop.fold(h0, got0, gout0)
         batches = [(t[1], t[2]) for t in traj]
     else:
         eng.put(snap)
         nb = min((n_pending + n_cq - 1) // n_cq, max(args.steps + args.warmup, 5))
         batches = [batch(c) for c in range(nb)]
-
-    def tas_same(want, wout, got, gout, h0):
-        bad = want.equal(got)
-        m = int(wout.a["dom_off"][h0.n_ps])
-        return (not bad and np.array_equal(wout.a["ps_tas"][:h0.n_ps], gout.a["ps_tas"][:h0.n_ps]) and np.array_equal(wout.a["dom_off"], gout.a["dom_off"]) and
-                np.array_equal(wout.a["dom_leaf"][:m], gout.a["dom_leaf"][:m]) and np.array_equal(wout.a["dom_count"][:m], gout.a["dom_count"][:m]) and
-                np.array_equal(wout.a["tas_usage_after"], gout.a["tas_usage_after"])), bad
 
     if rank == 0 and not args.no_parity_gate and not closed:
         from oracle import kqo   # the checker: parity gate here, cpu_baseline below — never inside the timed region
@@ -1535,7 +1543,7 @@ def bench_tas_cycle(args, torch, dist, world, rank, local_rank):
                        "decision": "one head through flavor assignment, TAS placement, the entry-order walk (quota + leaf capacity) and its recomputation",
                        "loop": (f"closed loop, host-driven as the reference drives it: step c = kq_snapshot_put of the cache.Snapshot() that holds what cycles 0..c-1 admitted "
                                 f"(rows, quota usage, TopologyAssignments as leaf usage; workloads finish after {args.hold} cycles) + kq_cycle_run_tas over the next head of every "
-                                f"ClusterQueue; a trajectory of {nb} dependent cycles laid down by the oracle before the timed region, repeated when steps + warmup exceed it"
+                                f"ClusterQueue; a trajectory of {nb} dependent cycles laid down by the ENGINE before the timed region (each cycle's snapshot folds the engine's own decisions; the oracle follows and is compared cycle by cycle), replayed in the timed region and repeated when steps + warmup exceed it"
                                 if closed else "open loop: the next batch of heads every step against the same cycle-start snapshot; heads and TAS side uploaded every step"),
                        "sharding": "population per GPU, no collective"},
             "p50_cycle_ms": float(np.percentile(st_ms, 50)), "p99_cycle_ms": float(np.percentile(st_ms, 99)),
