@@ -6,6 +6,7 @@
 package kqengine
 
 import (
+	"context"
 	"slices"
 
 	corev1 "k8s.io/api/core/v1"
@@ -20,7 +21,8 @@ import (
 )
 
 // FlattenTAS returns nil when the snapshot holds no TAS flavor (the cycle then goes through RunCycle).
-func FlattenTAS(snap *schdcache.Snapshot, fs *FlatSnapshot, ix *Index, heads []*qcache.Head, fh *FlatHeads) *TASCycle {
+func FlattenTAS(ctx context.Context, snap *schdcache.Snapshot, fs *FlatSnapshot, ix *Index, heads []*qcache.Head, fh *FlatHeads) *TASCycle {
+	maskRows := map[string]int32{} // leaf_mask rows by content
 	// every TAS flavor of the snapshot, name order; one TASFlavorSnapshot per flavor is shared by the ClusterQueues (snapshot.go:260)
 	flavors := map[string]*schdcache.TASFlavorSnapshot{}
 	for _, cq := range snap.ClusterQueues() {
@@ -135,6 +137,36 @@ func FlattenTAS(snap *schdcache.Snapshot, fs *FlatSnapshot, ix *Index, heads []*
 					sl = int32(slices.Index(keys, sliceKey))
 				}
 				tc.PsLevel[p*nt+t], tc.PsSliceLevel[p*nt+t] = lv, sl
+			}
+			// node feasibility (kq_cycle_tas.ps_mask / leaf_mask): the snapshot's own FindFeasibleNodes per TAS flavor; equal masks share a row
+			for t := range nt {
+				mask, err := flavors[names[t]].FeasibleLeafMask(ctx, ps, flats[t])
+				if err != nil {
+					tc.Unsupported = true // an unparsable selector / affinity: the reference fails the placement with its message (:958, :968) — that cycle stays in Go
+					continue
+				}
+				if mask == nil {
+					continue
+				}
+				if tc.PsMask == nil {
+					tc.PsMask = make([]int32, len(tc.PsKind)*nt)
+					for i := range tc.PsMask {
+						tc.PsMask[i] = -1
+					}
+					for _, f := range flats {
+						tc.MaskStride = max(tc.MaskStride, int32(len(f.LeafValues)))
+					}
+				}
+				row := make([]uint8, tc.MaskStride)
+				copy(row, mask)
+				key := string(row)
+				id, ok := maskRows[key]
+				if !ok {
+					id = int32(len(maskRows))
+					maskRows[key] = id
+					tc.LeafMask = append(tc.LeafMask, row...)
+				}
+				tc.PsMask[p*nt+t] = id
 			}
 			// SinglePodRequests = resources.NewRequestsFromPodSpec (tas_flavorassigner.go:116)
 			single := psr.SinglePodRequests()

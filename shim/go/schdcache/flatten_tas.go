@@ -10,10 +10,14 @@
 package scheduler
 
 import (
+	"context"
 	"slices"
 
 	corev1 "k8s.io/api/core/v1"
+	"k8s.io/apimachinery/pkg/labels"
+	"k8s.io/component-helpers/scheduling/corev1/nodeaffinity"
 
+	kueue "sigs.k8s.io/kueue/apis/kueue/v1beta2"
 	"sigs.k8s.io/kueue/pkg/resources"
 	utiltas "sigs.k8s.io/kueue/pkg/util/tas"
 )
@@ -93,4 +97,46 @@ func (c *ClusterQueueSnapshot) TASFlavorNames() []string {
 	}
 	slices.Sort(names)
 	return names
+}
+
+// FeasibleLeafMask is FindFeasibleNodes for one podset on this flavor as a 0/1 per leaf of `flat` (kq_cycle_tas.leaf_mask rows): the
+// requirements are built exactly as findTopologyAssignment builds them (tas_flavor_snapshot.go:955-985 — tolerations = the podset's + the
+// flavor's, PodSpec.NodeSelector only when the lowest level is the node, the required node affinity) and handed to the snapshot's own
+// getMatchingLeaves (:1845), so a custom simulator and the TASCacheNodeMatchResults cache keep working. nil = every leaf is feasible (no
+// row needed). A selector / affinity that does not parse is the placement's failure message in the reference (:958, :968): the caller
+// keeps such a head out of the engine's batch (err != nil).
+func (s *TASFlavorSnapshot) FeasibleLeafMask(ctx context.Context, ps *kueue.PodSet, flat *FlatTAS) ([]uint8, error) {
+	info := ps.Template.Spec
+	req := &topologyAssignmentPodRequirements{}
+	req.podRequirements.Tolerations = append(slices.Clone(info.Tolerations), s.tolerations...)
+	if s.isLowestLevelNode {
+		sel, err := labels.ValidatedSelectorFromSet(info.NodeSelector)
+		if err != nil {
+			return nil, err
+		}
+		req.podRequirements.Selector = sel
+	} else {
+		req.podRequirements.Selector = labels.Everything()
+	}
+	if a := info.Affinity; a != nil && a.NodeAffinity != nil && a.NodeAffinity.RequiredDuringSchedulingIgnoredDuringExecution != nil {
+		as, err := nodeaffinity.NewNodeSelector(a.NodeAffinity.RequiredDuringSchedulingIgnoredDuringExecution)
+		if err != nil {
+			return nil, err
+		}
+		req.podRequirements.AffinitySelector = as
+	}
+	matched, _, err := s.getMatchingLeaves(ctx, req)
+	if err != nil {
+		return nil, err
+	}
+	if len(matched) == len(flat.LeafValues) {
+		return nil, nil
+	}
+	mask := make([]uint8, len(flat.LeafValues))
+	for _, m := range matched {
+		if i, ok := flat.LeafOfID[m.GetID()]; ok {
+			mask[i] = 1
+		}
+	}
+	return mask, nil
 }

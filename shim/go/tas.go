@@ -77,6 +77,7 @@ type TASCycle struct {
 	PsMask     []int32 // [podsets][len(Topos)] row of LeafMask, -1 = every leaf
 	LeafMask   []uint8 // [rows][MaskStride] 1 = the leaf's node may host the podset
 	MaskStride int32
+	Unsupported bool // FlattenTAS met something the engine does not take (an unparsable selector / affinity): run this cycle in Go
 }
 
 const (
